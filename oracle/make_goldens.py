@@ -1,0 +1,317 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (build container only).
+
+Test infrastructure.  Runs only where `/root/reference` exists; the reference
+sources never travel -- only the captured input/output vectors do.
+
+Recipe: `src/model/__init__.py` drags in boto3, so `units.py`
+and `policy.py` are loaded as a synthetic package `refmodel` straight from
+their files.  All captures are float32, dropout OFF (module.eval()), except
+the Self-Monitor train-mode BatchNorm capture where the two Dropout layers are
+set to p=0 so batch statistics are exercised deterministically.
+
+    python oracle/make_goldens.py            # rewrites tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/tasks/R2R-judy/src/model"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def load_reference():
+    pkg = types.ModuleType("refmodel")
+    pkg.__path__ = [REF]
+    sys.modules["refmodel"] = pkg
+    mods = {}
+    for name in ("units", "policy"):
+        spec = importlib.util.spec_from_file_location(f"refmodel.{name}", os.path.join(REF, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"refmodel.{name}"] = m
+        spec.loader.exec_module(m)
+        setattr(pkg, name, m)
+        mods[name] = m
+    return mods["units"], mods["policy"]
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, **groups):
+    flat = {}
+    for g, d in groups.items():
+        for k, v in npify(d).items():
+            flat[f"{g}/{k}"] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} kB, {len(flat)} arrays")
+
+
+def grads_of(module, loss, extra=()):
+    params = [p for p in module.parameters() if p.requires_grad]
+    names = [n for n, p in module.named_parameters() if p.requires_grad]
+    gs = torch.autograd.grad(loss, params + list(extra), allow_unused=True)
+    out = {n: (g if g is not None else torch.zeros_like(p)) for n, g, p in zip(names, gs, params)}
+    return out, gs[len(params):]
+
+
+def feats(g, B, S, img, angle):
+    """Non-negative image part (post-ReLU ResNet pool5) + angle tail in [-1,1]."""
+    x = torch.randn(B, S, img + angle, generator=g)
+    x[..., :img] = x[..., :img].abs() * 0.5
+    x[..., img:] = torch.sin(x[..., img:] * 3)
+    return x
+
+
+def gen_encoder(U, name, g, *, vocab, E, H, bidir, layers, B=4, L=20, lengths=(20, 13, 7, 3)):
+    torch.manual_seed(int(torch.randint(0, 10000, (1,), generator=g)))
+    enc = U.EncoderLSTM(vocab, E, H, padding_idx=0, drop_ratio=0.5, bidirectional=bidir, num_layers=layers).eval()
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lengths):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    lens = torch.tensor(lengths)
+    ctx, h, c = enc(tokens, lens)
+    r1, r2, r3 = torch.randn(ctx.shape, generator=g), torch.randn(h.shape, generator=g), torch.randn(c.shape, generator=g)
+    loss = (ctx * r1).sum() + (h * r2).sum() + (c * r3).sum()
+    gp, _ = grads_of(enc, loss)
+    save(name, cfg=dict(vocab=vocab, E=E, H=H, bidir=int(bidir), layers=layers),
+         inp=dict(tokens=tokens, lengths=lens, r1=r1, r2=r2, r3=r3),
+         param=dict(enc.state_dict()), out=dict(ctx=ctx, h=h, c=c, loss=loss), grad=gp)
+
+
+def gen_attention(U, g):
+    B, S, Q, D = 4, 9, 32, 48
+    # (1) text attention, full (cat + linear_out + tanh), masked
+    for tag, ctx_only, cdim in (("full", False, None), ("ctxonly", True, None), ("visual", True, D)):
+        torch.manual_seed(7)
+        att = U.SoftDotAttention(Q, context_only=ctx_only, context_dim=cdim).eval()
+        d = Q if cdim is None else cdim
+        h = torch.randn(B, Q, generator=g, requires_grad=True)
+        ctx = torch.randn(B, S, d, generator=g, requires_grad=True)
+        mask = torch.zeros(B, S, dtype=torch.bool)
+        if tag != "visual":
+            for i, n in enumerate((9, 6, 4, 1)):
+                mask[i, n:] = True
+        out, attn = att(h, ctx, mask if tag != "visual" else None)
+        r = torch.randn(out.shape, generator=g)
+        ra = torch.randn(attn.shape, generator=g)
+        loss = (out * r).sum() + (attn * ra).sum()
+        gp, (gh, gc) = grads_of(att, loss, (h, ctx))
+        save(f"softdot_{tag}", inp=dict(h=h, ctx=ctx, mask=mask, r=r, ra=ra), param=dict(att.state_dict()),
+             out=dict(out=out, attn=attn, loss=loss), grad=dict(gp, h=gh, ctx=gc))
+    # (2) VisualSoftDot: follower (v-projection) and monitor (no projection, masked)
+    for tag, vdim, dot in (("follower", 40, 16), ("monitor", None, 24)):
+        torch.manual_seed(11)
+        att = U.VisualSoftDotAttention(Q, vdim, dot).eval()
+        vd = vdim if vdim is not None else dot
+        h = torch.randn(B, Q, generator=g, requires_grad=True)
+        v = torch.randn(B, S, vd, generator=g, requires_grad=True)
+        mask = None
+        if tag == "monitor":
+            mask = torch.zeros(B, S, dtype=torch.bool)
+            for i, n in enumerate((9, 5, 3, 2)):
+                mask[i, n:] = True
+        out, attn = att(h, v, mask)
+        r = torch.randn(out.shape, generator=g)
+        ra = torch.randn(attn.shape, generator=g)
+        loss = (out * r).sum() + (attn * ra).sum()
+        gp, (gh, gv) = grads_of(att, loss, (h, v))
+        save(f"visualdot_{tag}", inp=dict(h=h, v=v, mask=mask if mask is not None else torch.zeros(0), r=r, ra=ra),
+             param=dict(att.state_dict()), out=dict(out=out, attn=attn, loss=loss), grad=dict(gp, h=gh, v=gv))
+
+
+def gen_envdrop(P, g, steps, name):
+    B, L, V, C, H, IMG, ANG, AE = 4, 11, 36, 5, 64, 96, 32, 16
+    F = IMG + ANG
+    torch.manual_seed(21)
+    dec = P.EnvDropDecoder(H, 0.5, 0.3, action_embed_size=AE, angle_feat_size=ANG, feature_size=F).eval()
+    ctx = torch.randn(B, L, H, generator=g, requires_grad=True)
+    ctx_mask = torch.zeros(B, L, dtype=torch.bool)
+    for i, n in enumerate((11, 8, 5, 2)):
+        ctx_mask[i, n:] = True
+    h_tilde = torch.randn(B, H, generator=g, requires_grad=True)
+    c = torch.randn(B, H, generator=g, requires_grad=True)
+    h_t = torch.randn(B, H, generator=g)
+    ht0, c0 = h_tilde, c
+    inp, out = dict(ctx=ctx, ctx_mask=ctx_mask, h_tilde0=h_tilde, c0=c), {}
+    loss = 0.
+    cand_len = (5, 4, 3, 2)
+    for t in range(steps):
+        a = torch.sin(torch.randn(B, ANG, generator=g) * 3)
+        img = feats(g, B, V, IMG, ANG)
+        cand = feats(g, B, C, IMG, ANG)
+        for i, n in enumerate(cand_len):
+            cand[i, n - 1:] = 0                                # STOP slot + padding are zero rows
+        logit, (h_t, c), h_tilde = dec(a, img.clone(), cand.clone(), h_tilde, h_t, c, ctx, ctx_mask, False)
+        rl = torch.randn(logit.shape, generator=g)
+        rh = torch.randn(B, H, generator=g)
+        loss = loss + (logit * rl).sum() + (h_t * rh).sum() * 0.1
+        inp.update({f"a{t}": a, f"img{t}": img, f"cand{t}": cand, f"rl{t}": rl, f"rh{t}": rh})
+        out.update({f"logit{t}": logit, f"h1_{t}": h_t, f"c1_{t}": c, f"h_tilde{t}": h_tilde})
+    rf = torch.randn(B, H, generator=g)
+    rc = torch.randn(B, H, generator=g)
+    loss = loss + (h_tilde * rf).sum() + (c * rc).sum()
+    inp.update(rf=rf, rc=rc)
+    out["loss"] = loss
+    gp, (gctx, ght, gc0) = grads_of(dec, loss, (ctx, ht0, c0))
+    save(name, cfg=dict(steps=steps, H=H, IMG=IMG, ANG=ANG, AE=AE), inp=inp, param=dict(dec.state_dict()),
+         out=out, grad=dict(gp, ctx=gctx, h_tilde0=ght, c0=gc0))
+
+
+def gen_follower(P, g, steps, name):
+    B, L, V, C, H, IMG, ANG = 4, 11, 36, 5, 32, 64, 16
+    F = IMG + ANG
+    torch.manual_seed(22)
+    dec = P.AttnDecoderLSTM(H, 0.5, action_embed_size=F, feature_size=F).eval()
+    ctx = torch.randn(B, L, H, generator=g, requires_grad=True)
+    ctx_mask = torch.zeros(B, L, dtype=torch.bool)
+    for i, n in enumerate((11, 8, 5, 2)):
+        ctx_mask[i, n:] = True
+    h = torch.randn(B, H, generator=g, requires_grad=True)
+    c = torch.randn(B, H, generator=g, requires_grad=True)
+    h0, c0 = h, c
+    inp, out = dict(ctx=ctx, ctx_mask=ctx_mask, h0=h, c0=c), {}
+    loss = 0.
+    a_prev = torch.zeros(B, F)
+    for t in range(steps):
+        img = feats(g, B, V, IMG, ANG)
+        cand = feats(g, B, C, IMG, ANG)
+        for i, n in enumerate((5, 4, 3, 2)):
+            cand[i, n - 1:] = 0
+        logit, (h, c), (ac, av) = dec(img, a_prev, cand, h, c, ctx, ctx_mask)
+        rl = torch.randn(logit.shape, generator=g)
+        loss = loss + (logit * rl).sum()
+        inp.update({f"img{t}": img, f"cand{t}": cand, f"a_prev{t}": a_prev, f"rl{t}": rl})
+        out.update({f"logit{t}": logit, f"h1_{t}": h, f"c1_{t}": c, f"alpha_c{t}": ac, f"alpha_v{t}": av})
+        a_prev = cand[:, t % 2].detach()
+    rf = torch.randn(B, H, generator=g)
+    rc = torch.randn(B, H, generator=g)
+    loss = loss + (h * rf).sum() + (c * rc).sum()
+    inp.update(rf=rf, rc=rc)
+    out["loss"] = loss
+    gp, (gctx, gh0, gc0) = grads_of(dec, loss, (ctx, h0, c0))
+    save(name, cfg=dict(steps=steps, H=H, IMG=IMG, ANG=ANG), inp=inp, param=dict(dec.state_dict()),
+         out=out, grad=dict(gp, ctx=gctx, h0=gh0, c0=gc0))
+
+
+def gen_monitor(P, g, training, name):
+    B, L, C, H, IMG, ANG, M = 4, 12, 5, 32, 64, 16, 48
+    F = IMG + ANG
+    torch.manual_seed(23)
+    dec = P.MonitorDecoder(H, 0.5, L, mlp_dims=[M], action_embed_size=F, feature_size=F)
+    # non-trivial BN affine + running stats so eval mode is exercised
+    with torch.no_grad():
+        for k in ("0", "2"):
+            bn = dec.proj_navigable_mlp.mlp[int(k)]
+            bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.uniform_(-0.3, 0.3, generator=g)
+            bn.running_mean.uniform_(-0.2, 0.2, generator=g); bn.running_var.uniform_(0.5, 1.5, generator=g)
+    if training:
+        dec.train()
+        for m in dec.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    else:
+        dec.eval()
+    sd_before = {k: v.clone() for k, v in dec.state_dict().items()}
+    ctx = torch.randn(B, L, H, generator=g, requires_grad=True)
+    ctx_mask = torch.zeros(B, L, dtype=torch.bool)
+    for i, n in enumerate((12, 8, 5, 2)):
+        ctx_mask[i, n:] = True
+    h = torch.randn(B, H, generator=g, requires_grad=True)
+    c = torch.randn(B, H, generator=g, requires_grad=True)
+    a_prev = feats(g, B, 1, IMG, ANG)[:, 0]
+    cand = feats(g, B, C, IMG, ANG)
+    cand_len = (5, 4, 3, 2)
+    for i, n in enumerate(cand_len):
+        cand[i, n - 1:] = 0
+    cmask = torch.zeros(B, C, dtype=torch.bool)
+    for i, n in enumerate(cand_len):
+        cmask[i, n:] = True
+    (logit, prog), (h1, c1), (ctx_attn, cand_attn) = dec(None, a_prev, cand, h, c, ctx, ctx_mask, cmask)
+    rl, rp = torch.randn(logit.shape, generator=g), torch.randn(prog.shape, generator=g)
+    rh, rc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    loss = (logit * rl).sum() + (prog * rp).sum() + (h1 * rh).sum() + (c1 * rc).sum()
+    gp, (gctx, gh0, gc0) = grads_of(dec, loss, (ctx, h, c))
+    save(name, cfg=dict(H=H, IMG=IMG, ANG=ANG, M=M, L=L, training=int(training)),
+         inp=dict(ctx=ctx, ctx_mask=ctx_mask, h0=h, c0=c, a_prev=a_prev, cand=cand, cand_mask=cmask,
+                  rl=rl, rp=rp, rh=rh, rc=rc),
+         param=sd_before, param_after=dict(dec.state_dict()),
+         out=dict(logit=logit, prog=prog, h1=h1, c1=c1, ctx_attn=ctx_attn, cand_attn=cand_attn, loss=loss),
+         grad=dict(gp, ctx=gctx, h0=gh0, c0=gc0))
+
+
+def gen_critic(P, g):
+    torch.manual_seed(24)
+    cr = P.Critic(64, 0.5).eval()
+    s = torch.randn(5, 64, generator=g, requires_grad=True)
+    v = cr(s)
+    r = torch.randn(5, generator=g)
+    loss = (v * r).sum()
+    gp, (gs,) = grads_of(cr, loss, (s,))
+    save("critic", inp=dict(state=s, r=r), param=dict(cr.state_dict()), out=dict(value=v, loss=loss), grad=dict(gp, state=gs))
+
+
+def gen_losses(g):
+    """The torch ops the agents call inline for A9 (follower.py:62,123-128;
+    envdrop.py:70,173-195): CrossEntropyLoss(ignore_index=-1) on -inf-masked
+    logits, Categorical log_prob/entropy.  Captured from torch itself -- the
+    arithmetic the reference delegates to."""
+    B, C = 6, 5
+    logits = torch.randn(B, C, generator=g, requires_grad=True)
+    lens = (5, 4, 3, 2, 5, 1)
+    cmask = torch.zeros(B, C, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        cmask[i, n:] = True
+    target = torch.tensor([1, 3, -1, 0, 4, 0])
+    out, grad = {}, {}
+    for red in ("none", "sum", "mean"):
+        lg = logits.masked_fill(cmask, -float("inf"))
+        ce = torch.nn.CrossEntropyLoss(ignore_index=-1, reduction=red)(lg, target)
+        w = torch.arange(1, B + 1).float() if red == "none" else torch.tensor(1.0)
+        (gl,) = torch.autograd.grad((ce * w).sum(), logits)
+        out[f"ce_{red}"] = ce
+        grad[f"ce_{red}"] = gl
+    lg = logits.masked_fill(cmask, -float("inf"))
+    dist = torch.distributions.Categorical(torch.softmax(lg, 1))
+    act = torch.tensor([0, 2, 1, 1, 4, 0])
+    lp, ent = dist.log_prob(act), dist.entropy()
+    (gl,) = torch.autograd.grad((lp * torch.arange(1, B + 1).float()).sum() + (ent * 0.5).sum(), logits)
+    out.update(log_prob=lp, entropy=ent)
+    grad["cat"] = gl
+    save("losses", inp=dict(logits=logits, cand_mask=cmask, target=target, action=act), out=out, grad=grad)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    U, P = load_reference()
+    g = torch.Generator().manual_seed(2020)
+    gen_encoder(U, "encoder_envdrop", g, vocab=64, E=32, H=64, bidir=True, layers=1)
+    gen_encoder(U, "encoder_follower", g, vocab=64, E=24, H=32, bidir=True, layers=2)
+    gen_encoder(U, "encoder_monitor", g, vocab=64, E=32, H=48, bidir=False, layers=1)
+    gen_attention(U, g)
+    gen_envdrop(P, g, 1, "envdrop_step")
+    gen_envdrop(P, g, 3, "envdrop_chain3")
+    gen_follower(P, g, 1, "follower_step")
+    gen_follower(P, g, 3, "follower_chain3")
+    gen_monitor(P, g, True, "monitor_step_train")
+    gen_monitor(P, g, False, "monitor_step_eval")
+    gen_critic(P, g)
+    gen_losses(g)
+
+
+if __name__ == "__main__":
+    main()

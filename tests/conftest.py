@@ -1,0 +1,35 @@
+"""pytest config: registers the `gpu` marker, puts the repo root on sys.path and
+offers helpers to load the committed golden fixtures (tests/golden/*.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name, dtype=None):
+    """-> dict group -> dict key -> torch tensor."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    for k in z.files:
+        g, key = k.split("/", 1)
+        t = torch.from_numpy(z[k])
+        if dtype is not None and t.is_floating_point():
+            t = t.to(dtype)
+        out.setdefault(g, {})[key] = t
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
