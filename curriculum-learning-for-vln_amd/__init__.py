@@ -1,0 +1,11 @@
+"""MI355X-native training hot path for the R2R navigation agents of
+IMNearth/Curriculum-Learning-For-VLN (tasks/R2R-judy/src/model): hand-written
+gfx950 HIP kernels behind a C ABI (include/vln_hip.h), wrapped in nn.Modules
+that keep the reference's constructor / forward / state_dict surface.
+
+Import as `import vln_amd` (root shim) -- the directory name is not a Python
+identifier."""
+from . import _lib, ops  # noqa: F401
+from ._lib import VlnError, LIB_PATH  # noqa: F401
+
+__all__ = ["_lib", "ops", "VlnError", "LIB_PATH"]

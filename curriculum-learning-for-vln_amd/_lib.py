@@ -1,0 +1,96 @@
+"""ctypes binding of libvln_hip.so (C ABI: include/vln_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is
+absent, importing / calling fails loudly.  `python __graft_entry__.py` (or
+`make -C curriculum-learning-for-vln_amd/csrc`) builds the library in-tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvln_hip.so")
+
+i32, i64, u64, f32 = C.c_int, C.c_int64, C.c_uint64, C.c_float
+ptr = C.c_void_p
+
+
+class VlnError(RuntimeError):
+    pass
+
+
+class EnvDropDims(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "L", "V", "C", "H", "IMG", "ANG", "AE", "wtype", "ctype")]
+
+
+class EnvDropWeights(C.Structure):
+    _fields_ = [(n, ptr) for n in ("act_w", "act_b", "w_vin", "w_vin_t", "w_cat", "w_cat_t", "b_ih", "b_hh",
+                                   "w_tin", "w_tin_t", "w_tout", "w_tout_t", "w_c", "w_c_t")]
+
+
+class EnvDropStep(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("a_prev", "img", "cand", "img_lp", "cand_lp", "h_tilde_prev", "c0", "ctx",
+                                    "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
+                                    "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd")]
+                + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32),
+                   ("ws", ptr), ("ws_floats", i64)])
+
+
+class EnvDropGrads(C.Structure):
+    _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
+                                   "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de")]
+
+
+# symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
+SIGNATURES = {
+    "vln_abi_version": (i32, []),
+    "vln_last_error_string": (C.c_char_p, []),
+    "vln_linear_fwd": (i32, [ptr, i64, ptr, i32, i64, ptr, i64, i32, i32, i32, ptr, i32, ptr, i64, ptr]),
+    "vln_linear_wgrad": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
+    "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr]),
+    "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
+    "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
+    "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),
+    "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
+    "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
+    "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
+    "vln_lstm_pointwise_fwd": (i32, [ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32, i32, i32, ptr]),
+    "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
+    "vln_dropout_mask": (i32, [ptr, i64, u64, u64, f32, ptr]),
+    "vln_scale_dropout": (i32, [ptr, i64, ptr, i64, i32, i32, u64, u64, f32, ptr]),
+    "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
+    "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
+    "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),
+                                   C.POINTER(EnvDropGrads), ptr]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library; raises VlnError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VlnError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(or `make -C curriculum-learning-for-vln_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VlnError(f"libvln_hip.so lacks symbol {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().vln_last_error_string()
+        raise VlnError(f"{what} failed (status {status}): {msg.decode() if msg else '?'}")

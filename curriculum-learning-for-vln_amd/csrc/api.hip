@@ -1,0 +1,111 @@
+// C-ABI wrappers (include/vln_hip.h) around the internal launchers + error plumbing.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return VLN_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return VLN_ERR_HIP;
+}
+}  // namespace vln
+
+using namespace vln;
+
+extern "C" int vln_abi_version(void) { return 1; }
+extern "C" const char* vln_last_error_string(void) { return get_error(); }
+
+extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,
+                              int64_t ldy, int M, int N, int K, const float* bias, int act, float* ws,
+                              int64_t ws_floats, vln_stream_t s) {
+  if (!X || !W || !Y) { set_error("vln_linear_fwd: null pointer"); return VLN_ERR_ARG; }
+  return gemm_nt((hipStream_t)s, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, ws, ws_floats, nullptr);
+}
+extern "C" int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd,
+                                int Mt, int N, int K, int accumulate, vln_stream_t s) {
+  if (!A || !X || !D) { set_error("vln_linear_wgrad: null pointer"); return VLN_ERR_ARG; }
+  return gemm_tn((hipStream_t)s, A, lda, X, ldx, D, ldd, Mt, N, K, accumulate);
+}
+extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, vln_stream_t s) {
+  if (!A || !out || cols <= 0) { set_error("vln_colsum: bad args"); return VLN_ERR_ARG; }
+  return colsum((hipStream_t)s, A, lda, out, rows, cols, accumulate);
+}
+extern "C" int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K,
+                                  vln_stream_t s) {
+  if (!W || !Wt || N <= 0 || K <= 0) { set_error("vln_transpose_cast: bad args"); return VLN_ERR_ARG; }
+  return transpose_cast((hipStream_t)s, W, ldw, Wt, out_type, ldt, N, K);
+}
+extern "C" int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols,
+                             vln_stream_t s) {
+  if (!W || !out || rows <= 0 || cols <= 0) { set_error("vln_cast_copy: bad args"); return VLN_ERR_ARG; }
+  return cast_copy((hipStream_t)s, W, ldw, out, out_type, ldo, rows, cols);
+}
+extern "C" int vln_attn_dot(const void* ctx, int ctype, const float* vec, int64_t ldv, float* dots, int B, int S,
+                            int D, vln_stream_t s) {
+  if (!ctx || !vec || !dots) { set_error("vln_attn_dot: null pointer"); return VLN_ERR_ARG; }
+  return attn_dot((hipStream_t)s, ctx, ctype, vec, ldv, dots, B, S, D);
+}
+extern "C" int vln_attn_softmax_wsum(const void* ctx, int ctype, const float* logits, const uint8_t* mask,
+                                     float* attn, float* out, int64_t ldo, int B, int S, int D, vln_stream_t s) {
+  if (!ctx || !logits || !out) { set_error("vln_attn_softmax_wsum: null pointer"); return VLN_ERR_ARG; }
+  return attn_softmax_wsum((hipStream_t)s, ctx, ctype, logits, mask, attn, out, ldo, B, S, D);
+}
+extern "C" int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* out, int64_t ldo, int B, int S,
+                             int D, vln_stream_t s) {
+  if (!ctx || !w || !out) { set_error("vln_rows_wsum: null pointer"); return VLN_ERR_ARG; }
+  return rows_wsum((hipStream_t)s, ctx, ctype, w, out, ldo, B, S, D);
+}
+extern "C" int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha,
+                            const float* dattn_ext, const float* dwc, int64_t lddwc, const float* vec,
+                            int64_t ldvec, float* dvec, int64_t lddvec, float* dctx, float* dl_out, int B, int S,
+                            int D, vln_stream_t s) {
+  if (!ctx || !attn) { set_error("vln_attn_bwd: null pointer"); return VLN_ERR_ARG; }
+  return attn_bwd((hipStream_t)s, ctx, ctype, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx,
+                  dl_out, B, S, D);
+}
+extern "C" int vln_lstm_pointwise_fwd(const float* gates, int nsplit, int64_t slab_stride, const float* b_ih,
+                                      const float* b_hh, const float* c0, float* h1, float* c1, float* act,
+                                      float* tanh_c1, float* h1_drop, uint64_t seed, uint64_t offset, float p, int B,
+                                      int H, vln_stream_t s) {
+  if (!gates || !c0 || !h1 || !c1 || B <= 0 || H <= 0 || nsplit < 1) { set_error("vln_lstm_pointwise_fwd: bad args"); return VLN_ERR_ARG; }
+  LstmPwFwd a{};
+  a.gates = gates; a.nsplit = nsplit; a.slab_stride = slab_stride; a.bias_a = b_ih; a.bias_b = b_hh;
+  a.c0 = c0; a.ldc0 = H; a.h1 = h1; a.ldh1 = H; a.c1 = c1; a.ldc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
+  a.h1_drop = h1_drop; a.ldh1d = H; a.drop = DropSpec{seed, offset, p}; a.B = B; a.H = H;
+  return lstm_pointwise_fwd((hipStream_t)s, a);
+}
+extern "C" int vln_lstm_pointwise_bwd(const float* dh1, const float* dh1_drop, const float* dc1, uint64_t seed,
+                                      uint64_t offset, float p, const float* act, const float* tanh_c1,
+                                      const float* c0, float* dgates, float* dc0, int B, int H, vln_stream_t s) {
+  if (!act || !tanh_c1 || !c0 || !dgates || !dc0 || B <= 0 || H <= 0) { set_error("vln_lstm_pointwise_bwd: bad args"); return VLN_ERR_ARG; }
+  LstmPwBwd a{};
+  a.dh1_a = dh1; a.ld_a = H; a.dh1_b = dh1_drop; a.ld_b = H; a.dh1_b2 = nullptr; a.ld_b2 = 0;
+  a.drop = DropSpec{seed, offset, p}; a.dc1 = dc1; a.lddc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
+  a.c0 = c0; a.ldc0 = H; a.dgates = dgates; a.lddg = 4 * H; a.dc0 = dc0; a.lddc0 = H; a.B = B; a.H = H;
+  return lstm_pointwise_bwd((hipStream_t)s, a);
+}
+extern "C" int vln_dropout_mask(float* out, int64_t n, uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+  if (!out || n < 0) { set_error("vln_dropout_mask: bad args"); return VLN_ERR_ARG; }
+  return export_dropout_mask((hipStream_t)s, out, n, DropSpec{seed, offset, p});
+}
+extern "C" int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols,
+                                 uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+  if (!x || !y) { set_error("vln_scale_dropout: null pointer"); return VLN_ERR_ARG; }
+  return scale_dropout((hipStream_t)s, x, ldx, y, ldy, rows, cols, DropSpec{seed, offset, p});
+}
+extern "C" int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed,
+                                        uint64_t offset, float p, void* copy_bf16, vln_stream_t s) {
+  if (!x) { set_error("vln_feat_dropout_inplace: null pointer"); return VLN_ERR_ARG; }
+  return feat_dropout_inplace((hipStream_t)s, x, xtype, rows, img, angle, DropSpec{seed, offset, p}, copy_bf16);
+}

@@ -1,0 +1,271 @@
+// Batched dot-product attention over short sequences (36 panoramic views, <=80 instruction tokens,
+// <=16 candidates) of wide rows (2176 / 512 floats).  HBM-bound streaming of the [B,S,D] context:
+//   attn_dot          : one WAVE per (b,s) row, 16-byte loads, wave-shuffle reduction
+//   attn_softmax_wsum : grid (B, D-chunks); softmax over S recomputed per workgroup in one wave (S is tiny),
+//                       the 4 waves split the S rows, lanes own 16 bytes of the D-chunk, LDS cross-wave sum
+//   attn_bwd          : same geometry; softmax backward + d(query vector) and (text attention only) the
+//                       in-place dctx accumulation
+// Reference semantics: units.py:100-122 (SoftDotAttention), units.py:138-160 (VisualSoftDotAttention).
+#include "vln_internal.h"
+
+namespace vln {
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------
+template <typename TC>
+__global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, const float* vec, long ldv, float* dots,
+                                                       long rows, int S, int D, int vec_ok) {
+  constexpr int V = Elt<TC>::kVec;   // elements per 16-byte access
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / S);
+    const TC* c = ctx + r * (long)D;
+    const float* v = vec + (long)b * ldv;
+    float acc = 0.f;
+    if (vec_ok) {
+      for (int d = lane * V; d < D; d += 64 * V) {
+        float x[V];
+        Elt<TC>::ld16(c + d, x);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          float4 t = *reinterpret_cast<const float4*>(v + d + j);
+          acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
+        }
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(c + d) * v[d];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dots[r] = acc;
+  }
+}
+
+int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, float* dots, int B, int S,
+             int D) {
+  if (B <= 0 || S <= 0 || D <= 0) { set_error("attn_dot: bad dims"); return VLN_ERR_ARG; }
+  long rows = (long)B * S;
+  int blocks = (int)((rows + 3) / 4);
+  if (blocks > 8192) blocks = 8192;
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  int vec_ok = aligned16(ctx) && aligned16(vec) && (D % V == 0) && (ldv % 4 == 0);
+  if (ctype == W_BF16)
+    hipLaunchKernelGGL(attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+  else
+    hipLaunchKernelGGL(attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+  VLN_CHECK_LAUNCH("attn_dot");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kMaxS = 512;   // longest attended sequence supported (reference: <= 80)
+
+// softmax over S (<= kMaxS) with optional mask -> LDS, computed by wave 0
+__device__ __forceinline__ void softmax_to_lds(const float* logits, const uint8_t* mask, int S, float* sw) {
+  const int lane = threadIdx.x & 63;
+  if ((threadIdx.x >> 6) == 0) {
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      float v = (mask && mask[s]) ? -INFINITY : logits[s];
+      sw[s] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      float e = __expf(sw[s] - mx);
+      sw[s] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int s = lane; s < S; s += 64) sw[s] *= inv;
+  }
+}
+
+template <typename TC, bool kSoftmax>
+__global__ __launch_bounds__(256) void attn_wsum_kernel(const TC* ctx, const float* logits, const uint8_t* mask,
+                                                        float* attn, float* out, long ldo, int S, int D,
+                                                        int vec_ok) {
+  constexpr int V = Elt<TC>::kVec;
+  constexpr int DC = 64 * V;
+  __shared__ float sw[kMaxS];
+  __shared__ float red[4][DC];
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* lg = logits + (long)b * S;
+  if constexpr (kSoftmax) {
+    softmax_to_lds(lg, mask ? mask + (long)b * S : nullptr, S, sw);
+  } else {
+    for (int s = threadIdx.x; s < S; s += 256) sw[s] = lg[s];
+  }
+  __syncthreads();
+  if (kSoftmax && attn && chunk == 0)
+    for (int s = threadIdx.x; s < S; s += 256) attn[(long)b * S + s] = sw[s];
+
+  const int d0 = chunk * DC + lane * V;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const TC* base = ctx + (long)b * S * D;
+  if (vec_ok) {
+    if (d0 < D) {
+      for (int s = wave; s < S; s += 4) {
+        const float w = sw[s];
+        const TC* p = base + (long)s * D + d0;
+        float x[V];
+        Elt<TC>::ld16(p, x);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += w * x[j];
+      }
+    }
+  } else {
+    for (int s = wave; s < S; s += 4) {
+      const float w = sw[s];
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (d0 + j < D) acc[j] += w * Elt<TC>::ld(base + (long)s * D + d0 + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[wave][lane * V + j] = acc[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < DC; i += 256) {
+    const int d = chunk * DC + i;
+    if (d < D) out[(long)b * ldo + d] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
+}
+
+static int launch_wsum(hipStream_t st, const void* ctx, int ctype, const float* logits, const uint8_t* mask,
+                       float* attn, float* out, long ldo, int B, int S, int D, bool softmax) {
+  if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn wsum: bad dims B=%d S=%d D=%d", B, S, D); return VLN_ERR_ARG; }
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  const int DC = 64 * V;
+  int vec_ok = aligned16(ctx) && (D % V == 0);
+  dim3 grid(B, (D + DC - 1) / DC), block(256);
+  if (ctype == W_BF16) {
+    if (softmax) hipLaunchKernelGGL((attn_wsum_kernel<bf16_raw, true>), grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    else hipLaunchKernelGGL((attn_wsum_kernel<bf16_raw, false>), grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+  } else {
+    if (softmax) hipLaunchKernelGGL((attn_wsum_kernel<float, true>), grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    else hipLaunchKernelGGL((attn_wsum_kernel<float, false>), grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+  }
+  VLN_CHECK_LAUNCH("attn_wsum");
+  return VLN_OK;
+}
+
+int attn_softmax_wsum(hipStream_t st, const void* ctx, int ctype, const float* logits, const uint8_t* mask,
+                      float* attn, float* out, long ldo, int B, int S, int D) {
+  return launch_wsum(st, ctx, ctype, logits, mask, attn, out, ldo, B, S, D, true);
+}
+int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
+              int D) {
+  return launch_wsum(st, ctx, ctype, w, nullptr, nullptr, out, ldo, B, S, D, false);
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+template <typename TC>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const TC* ctx, const float* attn, const float* dalpha,
+                                                       const float* dattn_ext, const float* dwc, long lddwc,
+                                                       const float* vec, long ldvec, float* dvec, long lddvec,
+                                                       float* dctx, float* dl_out, int S, int D, int vec_ok) {
+  constexpr int V = Elt<TC>::kVec;
+  constexpr int DC = 64 * V;
+  __shared__ float sa[kMaxS];   // attn
+  __shared__ float sl[kMaxS];   // dlogits
+  __shared__ float red[4][DC];
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    float dot = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float a = attn[(long)b * S + s];
+      float g = dalpha ? dalpha[(long)b * S + s] : 0.f;
+      if (dattn_ext) g += dattn_ext[(long)b * S + s];
+      sa[s] = a;
+      sl[s] = g;
+      dot += a * g;
+    }
+    dot = wave_sum(dot);
+    for (int s = lane; s < S; s += 64) {
+      const float v = sa[s] * (sl[s] - dot);
+      sl[s] = v;
+      if (dl_out && chunk == 0) dl_out[(long)b * S + s] = v;
+    }
+  }
+  __syncthreads();
+  const int d0 = chunk * DC + lane * V;
+  float acc[V], gw[V], qv[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    acc[j] = 0.f;
+    gw[j] = (dctx && d0 + j < D) ? dwc[(long)b * lddwc + d0 + j] : 0.f;
+    qv[j] = (dctx && d0 + j < D) ? vec[(long)b * ldvec + d0 + j] : 0.f;
+  }
+  const TC* base = ctx + (long)b * S * D;
+  float* dbase = dctx ? dctx + (long)b * S * D : nullptr;
+  if (vec_ok) {
+    if (d0 < D) {
+      for (int s = wave; s < S; s += 4) {
+        const float dl = sl[s], a = sa[s];
+        const TC* p = base + (long)s * D + d0;
+        float x[V];
+        Elt<TC>::ld16(p, x);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += dl * x[j];
+        if (dbase) {
+          float* q = dbase + (long)s * D + d0;
+#pragma unroll
+          for (int j = 0; j < V; j += 4) {
+            float4 t = *reinterpret_cast<float4*>(q + j);
+            t.x += a * gw[j] + dl * qv[j];
+            t.y += a * gw[j + 1] + dl * qv[j + 1];
+            t.z += a * gw[j + 2] + dl * qv[j + 2];
+            t.w += a * gw[j + 3] + dl * qv[j + 3];
+            *reinterpret_cast<float4*>(q + j) = t;
+          }
+        }
+      }
+    }
+  } else {
+    for (int s = wave; s < S; s += 4) {
+      const float dl = sl[s], a = sa[s];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (d0 + j < D) {
+          acc[j] += dl * Elt<TC>::ld(base + (long)s * D + d0 + j);
+          if (dbase) dbase[(long)s * D + d0 + j] += a * gw[j] + dl * qv[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[wave][lane * V + j] = acc[j];
+  __syncthreads();
+  if (dvec)
+    for (int i = threadIdx.x; i < DC; i += 256) {
+      const int d = chunk * DC + i;
+      if (d < D) dvec[(long)b * lddvec + d] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dalpha,
+             const float* dattn_ext, const float* dwc, long lddwc, const float* vec, long ldvec, float* dvec,
+             long lddvec, float* dctx, float* dl_out, int B, int S, int D) {
+  if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_bwd: bad dims"); return VLN_ERR_ARG; }
+  if (dctx && (!dwc || !vec)) { set_error("attn_bwd: dctx needs dwc and vec"); return VLN_ERR_ARG; }
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  const int DC = 64 * V;
+  int vec_ok = aligned16(ctx) && (D % V == 0) && (!dctx || aligned16(dctx));
+  dim3 grid(B, (D + DC - 1) / DC), block(256);
+  if (ctype == W_BF16)
+    hipLaunchKernelGGL(attn_bwd_kernel<bf16_raw>, grid, block, 0, st, (const bf16_raw*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, 0, st, (const float*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
+  VLN_CHECK_LAUNCH("attn_bwd");
+  return VLN_OK;
+}
+
+}  // namespace vln

@@ -1,0 +1,126 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wavefront = 64 lanes everywhere; no warp-32 idioms, no multi-arch paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_raw;
+
+#define VLN_WAVE 64
+
+// status codes returned by every C-ABI entry point
+#define VLN_OK 0
+#define VLN_ERR_ARG 1
+#define VLN_ERR_HIP 2
+
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(bf16_raw, h);
+}
+
+// element loaders for the streamed operand type (float or bf16 bits)
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int kVec = 4;  // elements per 16-byte access
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __device__ static __forceinline__ void st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // one 16-byte access -> kVec floats
+  __device__ static __forceinline__ void ld16(const float* p, float* o) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+};
+template <> struct Elt<bf16_raw> {
+  static constexpr int kVec = 8;
+  __device__ static __forceinline__ float ld(const bf16_raw* p) { return bf16_bits_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_raw* p, float v) { *p = f32_to_bf16_bits(v); }
+  // 4 consecutive elements (8 bytes)
+  __device__ static __forceinline__ void ld4(const bf16_raw* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st4(bf16_raw* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)f32_to_bf16_bits(o[0]) | ((uint32_t)f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16_bits(o[2]) | ((uint32_t)f32_to_bf16_bits(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+  __device__ static __forceinline__ void ld16(const bf16_raw* p, float* o) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: dropout masks are a pure function of
+// (seed, stream offset, element index) so backward regenerates them instead
+// of storing them, and tests can export the exact mask the kernels used.
+// ---------------------------------------------------------------------------
+struct Philox4 { uint32_t x, y, z, w; };
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t offset, uint32_t idx) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = idx, c1 = 0u, c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// keep-mask (already scaled by 1/(1-p)) for 4 consecutive elements idx4*4 .. idx4*4+3
+__host__ __device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t offset, uint32_t idx4, float p,
+                                                        float (&m)[4]) {
+  Philox4 r = philox4x32_10(seed, offset, idx4);
+  const float inv = 1.0f / (1.0f - p);
+  const float u = 1.0f / 16777216.0f;
+  m[0] = ((r.x >> 8) * u >= p) ? inv : 0.0f;
+  m[1] = ((r.y >> 8) * u >= p) ? inv : 0.0f;
+  m[2] = ((r.z >> 8) * u >= p) ? inv : 0.0f;
+  m[3] = ((r.w >> 8) * u >= p) ? inv : 0.0f;
+}
+// single element (element e lives in word e&3 of call e>>2)
+__host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t offset, uint32_t e, float p) {
+  if (p <= 0.0f) return 1.0f;
+  float m[4];
+  dropout_scale4(seed, offset, e >> 2, p, m);
+  return m[e & 3];
+}
+
+struct DropSpec {      // one dropout site; p == 0 disables it
+  uint64_t seed;
+  uint64_t offset;
+  float p;
+};

@@ -1,0 +1,230 @@
+// EnvDropDecoder.forward (reference policy.py:208-246) and its hand-derived backward as ONE C call each:
+// the whole step is issued as a fixed chain of launches on the caller's stream with no host sync and a single
+// Python->C crossing.  Weight gradients are NOT formed here: backward only produces the dX chain and drops the
+// dY operand of every Linear into the rollout stash; the caller forms dW once per optimizer step with one
+// contraction over (steps x batch) per weight (vln_linear_wgrad).
+//
+// Dropout sites (Philox offset = step_offset*8 + site):
+//   0 act-embedding (policy.py:224)   1 h_tilde_prev (:234)   2 h_1 (:240)   3 h_tilde (:243)
+//   4 image features (:228)           5 candidate features (:230)
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+
+struct PrepArgs {
+  const float* a; const float* act_w; const float* act_b; const float* htp;
+  float* e; float* xcat; long ldx; float* hq;
+  int B, ANG, AE, F, H;
+  DropSpec d_act, d_h;
+};
+// e = tanh(a W_a^T + b); xcat[:, :AE] = drop(e); xcat[:, AE+F:] = h_tilde_prev; hq = drop(h_tilde_prev)
+__global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
+  const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh; i += (long)gridDim.x * blockDim.x) {
+    if (i < ne) {
+      const int b = (int)(i / p.AE), j = (int)(i % p.AE);
+      const float* a = p.a + (long)b * p.ANG;
+      const float* w = p.act_w + (long)j * p.ANG;
+      float acc = p.act_b[j];
+      for (int k = 0; k < p.ANG; ++k) acc += a[k] * w[k];
+      const float e = tanhf(acc);
+      p.e[i] = e;
+      p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.offset, (uint32_t)i, p.d_act.p);
+    } else {
+      const long k = i - ne;
+      const int b = (int)(k / p.H), j = (int)(k % p.H);
+      const float v = p.htp[k];
+      p.xcat[(long)b * p.ldx + p.AE + p.F + j] = v;
+      p.hq[k] = v * dropout_scale1(p.d_h.seed, p.d_h.offset, (uint32_t)k, p.d_h.p);
+    }
+  }
+}
+
+struct PrepBwdArgs {
+  const float* dxcat; long ldx; const float* e; const float* dhq;
+  float* s_de; float* dhtp;
+  int B, AE, F, H;
+  DropSpec d_act, d_h;
+};
+__global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
+  const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh; i += (long)gridDim.x * blockDim.x) {
+    if (i < ne) {
+      const int b = (int)(i / p.AE), j = (int)(i % p.AE);
+      const float e = p.e[i];
+      const float de = p.dxcat[(long)b * p.ldx + j] * dropout_scale1(p.d_act.seed, p.d_act.offset, (uint32_t)i, p.d_act.p);
+      p.s_de[i] = de * (1.f - e * e);
+    } else {
+      const long k = i - ne;
+      const int b = (int)(k / p.H), j = (int)(k % p.H);
+      p.dhtp[k] = p.dxcat[(long)b * p.ldx + p.AE + p.F + j] +
+                  p.dhq[k] * dropout_scale1(p.d_h.seed, p.d_h.offset, (uint32_t)k, p.d_h.p);
+    }
+  }
+}
+
+// dz = (dhtd * mask + dht_ext) * (1 - ht^2)
+__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(const float* dhtd, const float* dht_ext, const float* ht,
+                                                            float* dz, long n, DropSpec d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float g = dhtd[i] * dropout_scale1(d.seed, d.offset, (uint32_t)i, d.p);
+    if (dht_ext) g += dht_ext[i];
+    const float h = ht[i];
+    dz[i] = g * (1.f - h * h);
+  }
+}
+
+static inline int nblocks(long n, int cap = 2048) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+struct Ws {   // carve-up of the per-step scratch
+  float *slabs, *tv, *tc, *dots, *dtcat, *dhtd, *dxcat, *dhq, *dh1d;
+  long slab_floats;
+};
+static long ws_layout(const vln_envdrop_dims& d, float* base, Ws* w) {
+  const long B = d.B, F = d.IMG + d.ANG, XK = d.AE + F + d.H;
+  long maxn = 4L * d.H;
+  if (F > maxn) maxn = F;
+  if (XK > maxn) maxn = XK;
+  long off = 0;
+  auto take = [&](long n) { long o = off; off += (n + 63) & ~63L; return o; };
+  const long slab_floats = 16 * B * maxn;
+  long o_slabs = take(slab_floats), o_tv = take(B * F), o_tc = take(B * F);
+  long smax = d.V; if (d.L > smax) smax = d.L; if (d.C > smax) smax = d.C;
+  long o_dots = take(B * smax), o_dtcat = take(B * 2 * d.H), o_dhtd = take(B * d.H), o_dxcat = take(B * XK);
+  long o_dhq = take(B * d.H), o_dh1d = take(B * d.H);
+  if (w) {
+    w->slabs = base + o_slabs; w->tv = base + o_tv; w->tc = base + o_tc; w->dots = base + o_dots;
+    w->dtcat = base + o_dtcat; w->dhtd = base + o_dhtd; w->dxcat = base + o_dxcat; w->dhq = base + o_dhq;
+    w->dh1d = base + o_dh1d; w->slab_floats = slab_floats;
+  }
+  return off;
+}
+
+static inline DropSpec site(const vln_envdrop_step* io, int k, float p) {
+  return DropSpec{io->seed, io->offset * 8 + (uint64_t)k, p};
+}
+
+static int check_dims(const vln_envdrop_dims* d) {
+  if (!d || d->B <= 0 || d->L <= 0 || d->V <= 0 || d->C <= 0 || d->H <= 0 || d->IMG <= 0 || d->ANG <= 0 || d->AE <= 0) {
+    set_error("envdrop: bad dims");
+    return VLN_ERR_ARG;
+  }
+  if ((d->H & 3) || (d->IMG & 3) || (d->ANG & 3) || (d->AE & 3)) {
+    set_error("envdrop: H, IMG, ANG, AE must be multiples of 4");
+    return VLN_ERR_ARG;
+  }
+  return VLN_OK;
+}
+
+}  // namespace vln
+
+using namespace vln;
+
+#define RUN(x) do { int _s = (x); if (_s != VLN_OK) return _s; } while (0)
+
+extern "C" int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d) {
+  if (check_dims(d) != VLN_OK) return -1;
+  return ws_layout(*d, nullptr, nullptr);
+}
+
+extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
+                                    vln_stream_t s) {
+  RUN(check_dims(d));
+  hipStream_t st = (hipStream_t)s;
+  const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
+  if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop fwd: workspace too small"); return VLN_ERR_ARG; }
+  Ws ws; ws_layout(*d, io->ws, &ws);
+  const bool lp = (d->ctype == VLN_BF16);
+  if (lp && (!io->img_lp || !io->cand_lp || !io->ctx_lp)) { set_error("envdrop fwd: bf16 stream copies missing"); return VLN_ERR_ARG; }
+  const float pf = io->already_dropfeat ? 0.f : io->p_feat;
+
+  // (1) act embedding, h_tilde_prev copy + dropout            policy.py:224,234
+  PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
+              B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
+  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
+  VLN_CHECK_LAUNCH("envdrop_prep");
+  // (2) environmental feature dropout, in place                policy.py:226-231
+  RUN(feat_dropout_inplace(st, io->img, W_F32, (long)B * d->V, d->IMG, d->ANG, site(io, 4, pf), lp ? io->img_lp : nullptr));
+  RUN(feat_dropout_inplace(st, io->cand, W_F32, (long)B * d->C, d->IMG, d->ANG, site(io, 5, pf), lp ? io->cand_lp : nullptr));
+  const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
+  const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
+  const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
+  // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
+  RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, ws.tv, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(attn_dot(st, img, d->ctype, ws.tv, F, ws.dots, B, d->V, F));
+  RUN(attn_softmax_wsum(st, img, d->ctype, ws.dots, nullptr, io->alpha_v, io->xcat + AE, XK, B, d->V, F));
+  // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
+  int nsplit = 1;
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, &nsplit));
+  LstmPwFwd pw{};
+  pw.gates = ws.slabs; pw.nsplit = nsplit; pw.slab_stride = (long)B * 4 * H;
+  pw.bias_a = w->b_ih; pw.bias_b = w->b_hh; pw.c0 = io->c0; pw.ldc0 = H;
+  pw.h1 = io->h1; pw.ldh1 = H; pw.c1 = io->c1; pw.ldc1 = H; pw.act = io->gate_act; pw.tanh_c1 = io->tanh_c1;
+  pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
+  RUN(lstm_pointwise_fwd(st, pw));
+  // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
+  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, io->tt, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(attn_dot(st, ctx, d->ctype, io->tt, H, ws.dots, B, d->L, H));
+  RUN(attn_softmax_wsum(st, ctx, d->ctype, ws.dots, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, B, d->L, H));
+  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, nullptr, 0, B, H, 2 * H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, &nsplit));
+  RUN(reduce_epilogue(st, ws.slabs, nsplit, (long)B * H, H, io->h_tilde, H, B, H, nullptr, ACT_TANH, io->htd, H, site(io, 3, io->p_drop)));
+  // (6) candidate logits                                        policy.py:243-244,199-206
+  RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, ws.tc, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(attn_dot(st, cand, d->ctype, ws.tc, F, io->logit, B, d->C, F));
+  return VLN_OK;
+}
+
+extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
+                                    vln_envdrop_grads* g, vln_stream_t s) {
+  RUN(check_dims(d));
+  hipStream_t st = (hipStream_t)s;
+  const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
+  if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop bwd: workspace too small"); return VLN_ERR_ARG; }
+  Ws ws; ws_layout(*d, io->ws, &ws);
+  const bool lp = (d->ctype == VLN_BF16);
+  const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
+  const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
+  const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
+
+  // (6') logits -> d(cand query) -> d(drop(h_tilde))
+  if (g->dlogit) {
+    RUN(rows_wsum(st, cand, d->ctype, g->dlogit, g->s_dtc, F, B, d->C, F));
+    RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, d->wtype, F, ws.dhtd, H, B, H, F, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  } else {
+    RUN(fill_f32(st, g->s_dtc, (long)B * F, 0.f));
+    RUN(fill_f32(st, ws.dhtd, (long)B * H, 0.f));
+  }
+  // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
+  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ws.dhtd, g->dh_tilde,
+                     io->h_tilde, g->s_dz, (long)B * H, site(io, 3, io->p_drop));
+  VLN_CHECK_LAUNCH("tanh_drop_bwd");
+  // (5') linear_out -> [d weighted ctx | d drop(h1)]
+  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, ws.dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
+  RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, nullptr, B, d->L, H));
+  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, ws.dh1d, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  // (4') LSTM cell
+  LstmPwBwd pb{};
+  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = ws.dtcat + H; pb.ld_b = 2 * H; pb.dh1_b2 = ws.dh1d; pb.ld_b2 = H;
+  pb.drop = site(io, 2, io->p_drop); pb.dc1 = g->dc1; pb.lddc1 = H;
+  pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
+  pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
+  RUN(lstm_pointwise_bwd(st, pb));
+  RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, ws.dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  // (3') visual attention: features carry no gradient, only the query does
+  RUN(attn_dot(st, img, d->ctype, ws.dxcat + AE, XK, ws.dots, B, d->V, F));
+  RUN(attn_bwd(st, img, d->ctype, io->alpha_v, ws.dots, nullptr, nullptr, 0, nullptr, 0, g->s_dtv, F, nullptr, nullptr, B, d->V, F));
+  RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, ws.dhq, H, B, H, F, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  // (1') act embedding + the two uses of h_tilde_prev
+  PrepBwdArgs pa{ws.dxcat, XK, io->e, ws.dhq, g->s_de, g->dh_tilde_prev, B, AE, F, H,
+                 site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
+  hipLaunchKernelGGL(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
+  VLN_CHECK_LAUNCH("envdrop_prep_bwd");
+  return VLN_OK;
+}

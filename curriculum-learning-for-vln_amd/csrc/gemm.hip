@@ -1,0 +1,429 @@
+// Skinny-M MFMA GEMMs for the decoder/encoder linears (gfx950).
+//
+//   gemm_nt : Y[M,N] = X[M,K] * W[N,K]^T       forward linears and, with the transposed weight shadow,
+//                                               the dX products.  M is the episode batch (64..128) or
+//                                               batch*candidates; the WEIGHT stream is the HBM-bound operand.
+//   gemm_tn : D[N,K] (+)= A[Mt,N]^T * X[Mt,K]  deferred weight gradients, contraction over (steps x batch).
+//
+// Tiling (gemm_nt): one 256-thread workgroup = 4 waves computes a 64(M) x 64(N) tile over one K-chunk
+// (cross-workgroup split-K fills the 256 CUs; partial slabs are summed by the consumer / reduce pass, which
+// keeps results deterministic -- no float atomics).  Each wave owns 16 output columns: its W fragments go
+// global->VGPR directly (each lane reads 32 contiguous bytes of one weight row: 16 rows x 128 B per wave
+// instruction pair, whole cache lines), the X tile is shared by the 4 waves through LDS (144-B padded rows,
+// ds_read_b128).  fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32), bf16 uses v_mfma_f32_16x16x32_bf16 with
+// fp32 accumulate; lane group q = lane>>4 owns k = k0 + q*VK .. +VK so both operands read 32 B per lane.
+#include "vln_internal.h"
+
+namespace vln {
+
+template <typename TW> struct GemmCfg;
+template <> struct GemmCfg<float> { static constexpr int BK = 32, VK = 8; };
+template <> struct GemmCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; };
+
+constexpr int kLdsRow = 144;  // 128 B of data + 16 B pad per staged X row
+
+struct GemmNTArgs {
+  const float* X; long ldx;
+  const void* W; long ldw;
+  float* Y; long ldy; long slab_stride;
+  const float* bias; int act;
+  int M, N, K, kchunk;
+  int xvec, wvec;
+};
+
+template <typename TW>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
+  constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
+  constexpr bool kF32 = (sizeof(TW) == 4);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][64 * kLdsRow];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.K, kbeg + a.kchunk);
+  const int nsteps = (kend - kbeg + BK - 1) / BK;
+
+  // staging role: thread -> (row, 32-byte segment) of the X tile
+  const int srow = tid >> 2, sseg = tid & 3;
+  const bool srow_ok = (m0 + srow) < a.M;
+  const float* xrow = a.X + (long)(srow_ok ? (m0 + srow) : 0) * a.ldx;
+  // fragment role
+  const int fi = lane & 15, fq = lane >> 4;
+  const int wn = n0 + wave * 16 + fi;
+  const bool wn_ok = wn < a.N;
+  const TW* wrow = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok ? wn : 0) * a.ldw;
+  const int mrows = min(64, a.M - m0);
+  const int nrb = (mrows + 15) >> 4;
+
+  float xs[VK];
+  float wf32[kF32 ? 8 : 1];
+  bf16x8 wb16[kF32 ? 1 : 2];
+
+  auto load_x = [&](int kb) {
+    const int k = kb + sseg * VK;
+    if (srow_ok && a.xvec && k + VK <= kend) {
+#pragma unroll
+      for (int v = 0; v < VK / 4; ++v) {
+        float4 t = *reinterpret_cast<const float4*>(xrow + k + v * 4);
+        xs[v * 4 + 0] = t.x; xs[v * 4 + 1] = t.y; xs[v * 4 + 2] = t.z; xs[v * 4 + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VK; ++j) xs[j] = (srow_ok && (k + j) < kend) ? xrow[k + j] : 0.0f;
+    }
+  };
+  auto store_x = [&](int buf) {
+    unsigned char* dst = &smem[buf][srow * kLdsRow + sseg * 32];
+    if constexpr (kF32) {
+      *reinterpret_cast<float4*>(dst) = make_float4(xs[0], xs[1], xs[2], xs[3]);
+      *reinterpret_cast<float4*>(dst + 16) = make_float4(xs[4], xs[5], xs[6], xs[7]);
+    } else {
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { lo[j] = (__bf16)xs[j]; hi[j] = (__bf16)xs[8 + j]; }
+      *reinterpret_cast<bf16x8*>(dst) = lo;
+      *reinterpret_cast<bf16x8*>(dst + 16) = hi;
+    }
+  };
+  auto load_w = [&](int kb) {
+    const int k = kb + fq * VK;
+    if constexpr (kF32) {
+      if (wn_ok && a.wvec && k + VK <= kend) {
+        float4 t0 = *reinterpret_cast<const float4*>(wrow + k);
+        float4 t1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+        wf32[0] = t0.x; wf32[1] = t0.y; wf32[2] = t0.z; wf32[3] = t0.w;
+        wf32[4] = t1.x; wf32[5] = t1.y; wf32[6] = t1.z; wf32[7] = t1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf32[j] = (wn_ok && (k + j) < kend) ? wrow[k + j] : 0.0f;
+      }
+    } else {
+      if (wn_ok && a.wvec && k + VK <= kend) {
+        wb16[0] = *reinterpret_cast<const bf16x8*>(wrow + k);
+        wb16[1] = *reinterpret_cast<const bf16x8*>(wrow + k + 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16_raw r0 = (wn_ok && (k + j) < kend) ? wrow[k + j] : (bf16_raw)0;
+          bf16_raw r1 = (wn_ok && (k + 8 + j) < kend) ? wrow[k + 8 + j] : (bf16_raw)0;
+          wb16[0][j] = __builtin_bit_cast(__bf16, r0);
+          wb16[1][j] = __builtin_bit_cast(__bf16, r1);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nsteps > 0) {
+    load_x(kbeg);
+    load_w(kbeg);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    store_x(buf);
+    // current W fragment -> private copy before the prefetch overwrites the registers
+    float wc32[kF32 ? 8 : 1];
+    bf16x8 wc16[kF32 ? 1 : 2];
+    if constexpr (kF32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wc32[j] = wf32[j];
+    } else {
+      wc16[0] = wb16[0]; wc16[1] = wb16[1];
+    }
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      load_x(kbeg + (s + 1) * BK);
+      load_w(kbeg + (s + 1) * BK);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      if (rb < nrb) {
+        const unsigned char* src = &smem[buf][(rb * 16 + fi) * kLdsRow + fq * 32];
+        if constexpr (kF32) {
+          float4 a0 = *reinterpret_cast<const float4*>(src);
+          float4 a1 = *reinterpret_cast<const float4*>(src + 16);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc32[0], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc32[1], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc32[2], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc32[3], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wc32[4], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wc32[5], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wc32[6], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wc32[7], acc[rb], 0, 0, 0);
+        } else {
+          bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
+          bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[0], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[1], acc[rb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  if (wn_ok) {
+    float* y = a.Y + (long)blockIdx.y * a.slab_stride;
+    const bool fused = (a.slab_stride == 0);
+    const float bv = (fused && a.bias) ? a.bias[wn] : 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + rb * 16 + fq * 4 + r;
+        if (row < a.M) {
+          float v = acc[rb][r] + bv;
+          if (fused) {
+            if (a.act == ACT_TANH) v = tanhf(v);
+            else if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+          }
+          y[(long)row * a.ldy + wn] = v;
+        }
+      }
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
+            int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
+  if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }
+  const int BK = (wtype == W_BF16) ? 64 : 32;
+  const int nb = (N + 63) / 64, mb = (M + 63) / 64;
+  const int ksteps = (K + BK - 1) / BK;
+  // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk
+  int nsplit = 1;
+  if (ws != nullptr) {
+    const int target = 512;
+    nsplit = target / (nb * mb);
+    if (nsplit > ksteps / 2) nsplit = ksteps / 2;
+    if (nsplit < 1) nsplit = 1;
+    long per = (long)M * N;
+    if ((long)nsplit * per > ws_floats) nsplit = (int)(ws_floats / per);
+    if (nsplit < 1) nsplit = 1;
+  }
+  int steps_per = (ksteps + nsplit - 1) / nsplit;
+  nsplit = (ksteps + steps_per - 1) / steps_per;
+  GemmNTArgs a;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.kchunk = steps_per * BK;
+  a.bias = bias; a.act = act;
+  a.xvec = aligned16(X) && (ldx % 4 == 0);
+  a.wvec = aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0);
+  const bool to_slabs = (nsplit > 1) || (nsplit_out != nullptr);
+  if (to_slabs && ws == nullptr) { set_error("gemm_nt: slab output needs a workspace"); return VLN_ERR_ARG; }
+  if (to_slabs) { a.Y = ws; a.ldy = N; a.slab_stride = (long)M * N; }
+  else { a.Y = Y; a.ldy = ldy; a.slab_stride = 0; }
+  dim3 grid(nb, nsplit, mb), block(256);
+  if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, st, a);
+  VLN_CHECK_LAUNCH("gemm_nt");
+  if (nsplit_out) { *nsplit_out = nsplit; return VLN_OK; }   // caller consumes the slabs itself
+  if (to_slabs)
+    return reduce_epilogue(st, ws, nsplit, (long)M * N, N, Y, ldy, M, N, bias, act, nullptr, 0, DropSpec{0, 0, 0.f});
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reduce + epilogue
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* slabs, int nsplit, long slab_stride,
+                                                              long lds, float* out, long ldo, int M, int N,
+                                                              const float* bias, int act, float* out2, long ldo2,
+                                                              DropSpec drop) {
+  const long total = (long)M * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / N), c = (int)(e % N);
+    float v = bias ? bias[c] : 0.0f;
+    for (int s = 0; s < nsplit; ++s) v += slabs[(long)s * slab_stride + (long)r * lds + c];
+    if (act == ACT_TANH) v = tanhf(v);
+    else if (act == ACT_RELU) v = fmaxf(v, 0.0f);
+    out[(long)r * ldo + c] = v;
+    if (out2) out2[(long)r * ldo2 + c] = v * dropout_scale1(drop.seed, drop.offset, (uint32_t)e, drop.p);
+  }
+}
+
+int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_stride, long lds, float* out,
+                    long ldo, int M, int N, const float* bias, int act, float* out2, long ldo2, DropSpec drop) {
+  long total = (long)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, st, slabs, nsplit, slab_stride, lds, out,
+                     ldo, M, N, bias, act, out2, ldo2, drop);
+  VLN_CHECK_LAUNCH("reduce_epilogue");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gemm_tn: D[N,K] (+)= A[Mt,N]^T X[Mt,K]   (fp32 in, exact fp32 MFMA)
+// 64x64 output tile per workgroup; both operands are staged row-major through LDS (coalesced along their
+// contiguous dim) and read back as 4-byte fragments: the transposition costs no extra pass.
+// ---------------------------------------------------------------------------
+constexpr int kTnStride = 80;  // floats per staged row: 64 + 16 keeps the two k-slots of a half-wave on
+                               // disjoint banks for ds_read_b32
+struct GemmTNArgs {
+  const float* A; long lda; const float* X; long ldx; float* D; long ldd;
+  int Mt, N, K, accumulate, avec, xvec;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[2][32 * kTnStride];
+  __shared__ __attribute__((aligned(16))) float sX[2][32 * kTnStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int sm = tid >> 3, sc = (tid & 7) * 8;   // staging: row in the 32-row step, 8-float column segment
+  float ra[8], rx[8];
+
+  auto load_tile = [&](const float* P, long ld, int c0, int C, int vec, int mbase, float (&r)[8]) {
+    const int m = mbase + sm;
+    const bool ok = m < a.Mt;
+    const float* p = P + (long)(ok ? m : 0) * ld + c0 + sc;
+    if (ok && vec && (c0 + sc + 8) <= C) {
+      float4 t0 = *reinterpret_cast<const float4*>(p);
+      float4 t1 = *reinterpret_cast<const float4*>(p + 4);
+      r[0] = t0.x; r[1] = t0.y; r[2] = t0.z; r[3] = t0.w; r[4] = t1.x; r[5] = t1.y; r[6] = t1.z; r[7] = t1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (ok && (c0 + sc + j) < C) ? p[j] : 0.0f;
+    }
+  };
+  auto store_tile = [&](float* S, const float (&r)[8]) {
+    float* d = S + sm * kTnStride + sc;
+    *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(r[4], r[5], r[6], r[7]);
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (a.Mt + 31) / 32;
+  if (nsteps > 0) {
+    load_tile(a.A, a.lda, n0, a.N, a.avec, 0, ra);
+    load_tile(a.X, a.ldx, k0, a.K, a.xvec, 0, rx);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    store_tile(sA[buf], ra);
+    store_tile(sX[buf], rx);
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      load_tile(a.A, a.lda, n0, a.N, a.avec, (s + 1) * 32, ra);
+      load_tile(a.X, a.ldx, k0, a.K, a.xvec, (s + 1) * 32, rx);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int m = kk * 4 + fq;
+      const float av = sA[buf][m * kTnStride + wave * 16 + fi];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const float xv = sX[buf][m * kTnStride + kb * 16 + fi];
+        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv, acc[kb], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int col = k0 + kb * 16 + fi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = n0 + wave * 16 + fq * 4 + r;
+      if (row < a.N && col < a.K) {
+        float* d = a.D + (long)row * a.ldd + col;
+        *d = a.accumulate ? (*d + acc[kb][r]) : acc[kb][r];
+      }
+    }
+  }
+}
+
+int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
+            int N, int K, int accumulate) {
+  if (N <= 0 || K <= 0 || Mt < 0) { set_error("gemm_tn: bad dims"); return VLN_ERR_ARG; }
+  GemmTNArgs a{A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, 0, 0};
+  a.avec = aligned16(A) && (lda % 4 == 0);
+  a.xvec = aligned16(X) && (ldx % 4 == 0);
+  dim3 grid((K + 63) / 64, (N + 63) / 64), block(256);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, st, a);
+  VLN_CHECK_LAUNCH("gemm_tn");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// colsum: bias gradients
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* A, long lda, float* out, int rows, int cols,
+                                                     int accumulate) {
+  // block = 64 columns x 4 row-lanes; rows strided by 4
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = rl; r < rows; r += 4) s += A[(long)r * lda + c];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, A, lda, out, rows, cols, accumulate);
+  VLN_CHECK_LAUNCH("colsum");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight shadows: transposed / cast copies refreshed once per optimizer step
+// ---------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* W, long ldw, TO* Wt, long ldt, int N,
+                                                             int K) {
+  __shared__ float tile[64][65];
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, k = k0 + tx;
+    tile[r][tx] = (n < N && k < K) ? W[(long)n * ldw + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int k = k0 + r, n = n0 + tx;
+    if (k < K && n < N) Elt<TO>::st(Wt + (long)k * ldt + n, tile[tx][r]);
+  }
+}
+int transpose_cast(hipStream_t st, const float* W, long ldw, void* Wt, int out_type, long ldt, int N, int K) {
+  dim3 grid((K + 63) / 64, (N + 63) / 64), block(256);
+  if (out_type == W_BF16)
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16_raw>, grid, block, 0, st, W, ldw, (bf16_raw*)Wt, ldt, N, K);
+  else
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, st, W, ldw, (float*)Wt, ldt, N, K);
+  VLN_CHECK_LAUNCH("transpose_cast");
+  return VLN_OK;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_copy_kernel(const float* W, long ldw, TO* out, long ldo, int rows,
+                                                        int cols) {
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    Elt<TO>::st(out + (long)r * ldo + c, W[(long)r * ldw + c]);
+  }
+}
+int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type, long ldo, int rows, int cols) {
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (out_type == W_BF16)
+    hipLaunchKernelGGL(cast_copy_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, W, ldw, (bf16_raw*)out, ldo, rows, cols);
+  else
+    hipLaunchKernelGGL(cast_copy_kernel<float>, dim3(blocks), dim3(256), 0, st, W, ldw, (float*)out, ldo, rows, cols);
+  VLN_CHECK_LAUNCH("cast_copy");
+  return VLN_OK;
+}
+
+}  // namespace vln

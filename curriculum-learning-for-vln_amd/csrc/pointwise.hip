@@ -1,0 +1,193 @@
+// Fused elementwise stages: LSTM 4-gate cell epilogue (sums the split-K gate slabs, adds both biases,
+// applies the i,f,g,o nonlinearities and the state update in one pass), its backward, Philox dropout
+// helpers and the in-place environmental feature dropout (policy.py:226-231).
+#include "vln_internal.h"
+
+namespace vln {
+
+// ---------------------------------------------------------------------------
+// LSTM cell pointwise (torch.nn.LSTMCell semantics, gate order i,f,g,o)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
+  const long total = (long)a.B * a.H;
+  const int H = a.H;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / H), j = (int)(e % H);
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = q * H + j;
+      float v = 0.f;
+      if (a.bias_a) v += a.bias_a[col];
+      if (a.bias_b) v += a.bias_b[col];
+      for (int s = 0; s < a.nsplit; ++s) v += a.gates[(long)s * a.slab_stride + (long)b * 4 * H + col];
+      g[q] = v;
+    }
+    const float si = sigmoidf_(g[0]), sf = sigmoidf_(g[1]), tg = tanhf(g[2]), so = sigmoidf_(g[3]);
+    const float c0 = a.c0[(long)b * a.ldc0 + j];
+    const float c1 = sf * c0 + si * tg;
+    const float tc = tanhf(c1);
+    const float h1 = so * tc;
+    a.h1[(long)b * a.ldh1 + j] = h1;
+    a.c1[(long)b * a.ldc1 + j] = c1;
+    if (a.act) {
+      float* p = a.act + (long)b * 4 * H + j;
+      p[0] = si; p[H] = sf; p[2 * H] = tg; p[3 * H] = so;
+    }
+    if (a.tanh_c1) a.tanh_c1[e] = tc;
+    if (a.h1_drop) a.h1_drop[(long)b * a.ldh1d + j] = h1 * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)e, a.drop.p);
+  }
+}
+int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a) {
+  long total = (long)a.B * a.H;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  VLN_CHECK_LAUNCH("lstm_pointwise_fwd");
+  return VLN_OK;
+}
+
+__global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(LstmPwBwd a) {
+  const long total = (long)a.B * a.H;
+  const int H = a.H;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / H), j = (int)(e % H);
+    float dh = a.dh1_a ? a.dh1_a[(long)b * a.ld_a + j] : 0.f;
+    if (a.dh1_b) {
+      float v = a.dh1_b[(long)b * a.ld_b + j];
+      if (a.dh1_b2) v += a.dh1_b2[(long)b * a.ld_b2 + j];
+      dh += v * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)e, a.drop.p);
+    }
+    const float* act = a.act + (long)b * 4 * H + j;
+    const float si = act[0], sf = act[H], tg = act[2 * H], so = act[3 * H];
+    const float tc = a.tanh_c1[e];
+    const float c0 = a.c0[(long)b * a.ldc0 + j];
+    float dc = (a.dc1 ? a.dc1[(long)b * a.lddc1 + j] : 0.f) + dh * so * (1.f - tc * tc);
+    float* dg = a.dgates + (long)b * a.lddg + j;
+    dg[0] = dc * tg * si * (1.f - si);
+    dg[H] = dc * c0 * sf * (1.f - sf);
+    dg[2 * H] = dc * si * (1.f - tg * tg);
+    dg[3 * H] = dh * tc * so * (1.f - so);
+    a.dc0[(long)b * a.lddc0 + j] = dc * sf;
+  }
+}
+int lstm_pointwise_bwd(hipStream_t st, const LstmPwBwd& a) {
+  long total = (long)a.B * a.H;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  VLN_CHECK_LAUNCH("lstm_pointwise_bwd");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_dropout_kernel(const float* x, long ldx, float* y, long ldy,
+                                                            int rows, int cols, DropSpec d) {
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    y[(long)r * ldy + c] = x[(long)r * ldx + c] * dropout_scale1(d.seed, d.offset, (uint32_t)e, d.p);
+  }
+}
+int scale_dropout(hipStream_t st, const float* x, long ldx, float* y, long ldy, int rows, int cols, DropSpec d) {
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(scale_dropout_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, rows, cols, d);
+  VLN_CHECK_LAUNCH("scale_dropout");
+  return VLN_OK;
+}
+
+__global__ __launch_bounds__(256) void export_mask_kernel(float* out, long n, DropSpec d) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = dropout_scale1(d.seed, d.offset, (uint32_t)e, d.p);
+}
+int export_dropout_mask(hipStream_t st, float* out, long n, DropSpec d) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(export_mask_kernel, dim3(blocks), dim3(256), 0, st, out, n, d);
+  VLN_CHECK_LAUNCH("export_dropout_mask");
+  return VLN_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, long n, float v) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = v;
+}
+int fill_f32(hipStream_t st, float* p, long n, float v) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+  VLN_CHECK_LAUNCH("fill_f32");
+  return VLN_OK;
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* y, long ldy, const float* x, long ldx, int rows,
+                                                          int cols) {
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    y[(long)r * ldy + c] += x[(long)r * ldx + c];
+  }
+}
+int add_inplace(hipStream_t st, float* y, long ldy, const float* x, long ldx, int rows, int cols) {
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, y, ldy, x, ldx, rows, cols);
+  VLN_CHECK_LAUNCH("add_inplace");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Environmental feature dropout, in place on the image part of every [img | angle] row.
+// Element index for the mask = row*img + d (image part only); 4 elements per Philox call.
+// Optionally emits a bf16 copy of the WHOLE row (image part dropped, angle tail verbatim) that the
+// bf16 attention path streams instead of the fp32 tensor.
+// ---------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(256) void feat_dropout_kernel(TX* x, long rows, int img, int angle, DropSpec d,
+                                                           bf16_raw* copy) {
+  const int F = img + angle;
+  const int q4 = img >> 2;                       // img % 4 == 0 checked on the host
+  const long total4 = rows * (long)(F >> 2);     // F % 4 == 0 checked on the host
+  const int f4 = F >> 2;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / f4;
+    const int c4 = (int)(e % f4);
+    TX* p = x + r * F + c4 * 4;
+    float v[4];
+    Elt<TX>::ld4(p, v);
+    if (c4 < q4) {
+      if (d.p > 0.f) {
+        float m[4];
+        dropout_scale4(d.seed, d.offset, (uint32_t)(r * q4 + c4), d.p, m);
+        v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
+        Elt<TX>::st4(p, v);
+      }
+    }
+    if (copy) Elt<bf16_raw>::st4(copy + r * F + c4 * 4, v);
+  }
+}
+int feat_dropout_inplace(hipStream_t st, void* x, int xtype, long rows, int img, int angle, DropSpec d,
+                         void* copy_bf16) {
+  if ((img & 3) || (angle & 3)) { set_error("feat_dropout: img/angle sizes must be multiples of 4"); return VLN_ERR_ARG; }
+  if (rows <= 0) return VLN_OK;
+  if (d.p <= 0.f && !copy_bf16) return VLN_OK;
+  long total4 = rows * (long)((img + angle) >> 2);
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (xtype == W_BF16)
+    hipLaunchKernelGGL(feat_dropout_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (bf16_raw*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
+  else
+    hipLaunchKernelGGL(feat_dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
+  VLN_CHECK_LAUNCH("feat_dropout");
+  return VLN_OK;
+}
+
+}  // namespace vln

@@ -1,0 +1,98 @@
+// Internal C++ launcher interface shared by the .hip translation units.
+// Everything here is host-side glue; the public boundary is include/vln_hip.h.
+#pragma once
+#include "common.h"
+
+namespace vln {
+
+enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
+enum WType { W_F32 = 0, W_BF16 = 1 };
+
+// thread-local last error text (vln_last_error_string)
+void set_error(const char* fmt, ...);
+const char* get_error();
+int check_hip(hipError_t e, const char* what);
+
+#define VLN_CHECK_LAUNCH(what)                                   \
+  do {                                                           \
+    int _st = vln::check_hip(hipGetLastError(), what);           \
+    if (_st != VLN_OK) return _st;                               \
+  } while (0)
+
+// ---- gemm.hip -------------------------------------------------------------
+// Y[M,N] = act(X[M,K] * W[N,K]^T + bias).  W is the streamed operand (fp32 or
+// bf16 bits), X/Y fp32.  When the problem is split over K (nsplit > 1) partial
+// slabs go to `ws` (nsplit*M*N floats) and a reduce+epilogue pass finishes.
+// `ws_floats` bounds the split.  If `slabs_out`/`nsplit_out` are given the
+// reduce pass is skipped and the caller's consumer kernel sums the slabs
+// (slab s at ws + s*M*N, dense ld = N).
+int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
+            int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out);
+// (nsplit_out != nullptr  =>  raw partial sums ALWAYS go to ws, even for nsplit == 1; no bias/act applied)
+
+// D[N,K] (+)= A[Mt,N]^T * X[Mt,K]   (weight gradients; contraction over rows)
+int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
+            int N, int K, int accumulate);
+
+// out[c] (+)= sum_r A[r*lda + c]
+int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate);
+
+// out = act(sum_s slabs[s] + bias); optional second output out2 = out * dropout mask
+int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_stride, long lds, float* out,
+                    long ldo, int M, int N, const float* bias, int act, float* out2, long ldo2, DropSpec drop);
+
+// Wt[K,N] = W[N,K]^T (fp32 or bf16 out);  Wc = cast(W)
+int transpose_cast(hipStream_t st, const float* W, long ldw, void* Wt, int out_type, long ldt, int N, int K);
+int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type, long ldo, int rows, int cols);
+
+// ---- attention.hip --------------------------------------------------------
+// dots[b,s] = ctx[b,s,:] . vec[b,:]   (ctx streamed: fp32 or bf16)
+int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, float* dots, int B, int S,
+             int D);
+// Forward weighted sum: attn = softmax(mask(logits)); out[b,:] = sum_s attn[b,s] ctx[b,s,:]
+int attn_softmax_wsum(hipStream_t st, const void* ctx, int ctype, const float* logits, const uint8_t* mask,
+                      float* attn, float* out, long ldo, int B, int S, int D);
+// Backward: dl = attn*(dalpha - sum(attn*dalpha)) [+ attn*(dattn_ext - ...)]; dvec[b,:] = sum_s dl ctx;
+// if dctx != null: dctx[b,s,:] += attn[b,s]*dwc[b,:] + dl[b,s]*vec[b,:]
+int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dalpha,
+             const float* dattn_ext, const float* dwc, long lddwc, const float* vec, long ldvec, float* dvec,
+             long lddvec, float* dctx, float* dl_out, int B, int S, int D);
+// dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
+int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
+              int D);
+
+// ---- pointwise.hip --------------------------------------------------------
+struct LstmPwFwd {
+  const float* gates; int nsplit; long slab_stride;  // pre-activation slabs [nsplit][B,4H]
+  const float* bias_a; const float* bias_b;          // b_ih, b_hh (nullable)
+  const float* c0; long ldc0;
+  float* h1; long ldh1; float* c1; long ldc1;
+  float* act;          // [B,4H] saved sigma(i),sigma(f),tanh(g),sigma(o)
+  float* tanh_c1;      // [B,H] saved
+  float* h1_drop; long ldh1d; DropSpec drop;         // optional dropped copy of h1
+  int B, H;
+};
+int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a);
+struct LstmPwBwd {
+  const float* dh1_a; long ld_a;   // external grad on h1 (nullable)
+  const float* dh1_b; long ld_b;   // grad flowing from the dropped copy (nullable); multiplied by the mask
+  const float* dh1_b2; long ld_b2; // second contribution to the dropped copy's grad (nullable)
+  DropSpec drop;
+  const float* dc1; long lddc1;    // external grad on c1 (nullable)
+  const float* act; const float* tanh_c1; const float* c0; long ldc0;
+  float* dgates; long lddg;        // [B,4H]
+  float* dc0; long lddc0;
+  int B, H;
+};
+int lstm_pointwise_bwd(hipStream_t st, const LstmPwBwd& a);
+
+// y = x * dropout ; generic small elementwise helpers
+int scale_dropout(hipStream_t st, const float* x, long ldx, float* y, long ldy, int rows, int cols, DropSpec d);
+// feature dropout in place on x[..., :img] of rows of length img+angle (policy.py:228-231)
+int feat_dropout_inplace(hipStream_t st, void* x, int xtype, long rows, int img, int angle, DropSpec d,
+                         void* copy_bf16);
+int export_dropout_mask(hipStream_t st, float* out, long n, DropSpec d);
+int fill_f32(hipStream_t st, float* p, long n, float v);
+int add_inplace(hipStream_t st, float* y, long ldy, const float* x, long ldx, int rows, int cols);
+
+}  // namespace vln

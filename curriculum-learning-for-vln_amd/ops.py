@@ -1,0 +1,210 @@
+"""Tensor-level wrappers over the C ABI: PyTorch supplies device memory and the
+current HIP stream, nothing else.  All tensors must live on the GPU; fp32
+activations, fp32 or bf16 streamed operands."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.VlnError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dim must be contiguous")
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(device, floats: int) -> torch.Tensor:
+    """Per-device split-K scratch, grown on demand (stream-ordered reuse)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < floats:
+        w = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None):
+    """y = act(x @ w.T + bias); x [M,K] fp32 (row stride free), w [N,K] fp32|bf16."""
+    lib = _lib.load()
+    _req(x, "x"); _req(w, "w", None)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, 16 * M * N)
+    _lib.check(lib.vln_linear_fwd(_p(x), x.stride(0), _p(w), _dt(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                                  _p(bias), act, _p(ws), ws.numel(), _stream()), "vln_linear_fwd")
+    return out
+
+
+def linear_wgrad(dy, x, out=None, accumulate=False):
+    """dW[N,K] (+)= dy[Mt,N].T @ x[Mt,K]"""
+    lib = _lib.load()
+    _req(dy, "dy"); _req(x, "x")
+    Mt, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == Mt
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _lib.check(lib.vln_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), Mt, N, K,
+                                    int(accumulate), _stream()), "vln_linear_wgrad")
+    return out
+
+
+def colsum(a, out=None, accumulate=False):
+    lib = _lib.load()
+    _req(a, "a")
+    rows, cols = a.shape
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=a.device)
+        accumulate = False
+    _lib.check(lib.vln_colsum(_p(a), a.stride(0), _p(out), rows, cols, int(accumulate), _stream()), "vln_colsum")
+    return out
+
+
+def transpose_cast(w, dtype=torch.float32, out=None):
+    lib = _lib.load()
+    _req(w, "w")
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(K, N, dtype=dtype, device=w.device)
+    _lib.check(lib.vln_transpose_cast(_p(w), w.stride(0), _p(out), _dt(out), out.stride(0), N, K, _stream()),
+               "vln_transpose_cast")
+    return out
+
+
+def cast_copy(w, dtype=torch.bfloat16, out=None):
+    lib = _lib.load()
+    _req(w, "w")
+    w2 = w.reshape(-1, w.shape[-1])
+    if out is None:
+        out = torch.empty(w.shape, dtype=dtype, device=w.device)
+    o2 = out.reshape(-1, out.shape[-1])
+    _lib.check(lib.vln_cast_copy(_p(w2), w2.stride(0), _p(o2), _dt(o2), o2.stride(0), w2.shape[0], w2.shape[1],
+                                 _stream()), "vln_cast_copy")
+    return out
+
+
+def attn_dot(ctx, vec):
+    """dots[b,s] = ctx[b,s,:] . vec[b,:]"""
+    lib = _lib.load()
+    _req(ctx, "ctx", None); _req(vec, "vec")
+    B, S, D = ctx.shape
+    assert ctx.is_contiguous()
+    dots = torch.empty(B, S, dtype=torch.float32, device=ctx.device)
+    _lib.check(lib.vln_attn_dot(_p(ctx), _dt(ctx), _p(vec), vec.stride(0), _p(dots), B, S, D, _stream()),
+               "vln_attn_dot")
+    return dots
+
+
+def attn_softmax_wsum(ctx, logits, mask=None, out=None):
+    lib = _lib.load()
+    _req(ctx, "ctx", None); _req(logits, "logits")
+    B, S, D = ctx.shape
+    assert ctx.is_contiguous() and logits.is_contiguous()
+    attn = torch.empty(B, S, dtype=torch.float32, device=ctx.device)
+    if out is None:
+        out = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
+    m8 = None
+    if mask is not None:
+        m8 = mask.to(torch.uint8).contiguous()
+    _lib.check(lib.vln_attn_softmax_wsum(_p(ctx), _dt(ctx), _p(logits), _p(m8), _p(attn), _p(out), out.stride(0),
+                                         B, S, D, _stream()), "vln_attn_softmax_wsum")
+    return out, attn
+
+
+def rows_wsum(ctx, w, out=None):
+    lib = _lib.load()
+    _req(ctx, "ctx", None); _req(w, "w")
+    B, S, D = ctx.shape
+    assert ctx.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
+    _lib.check(lib.vln_rows_wsum(_p(ctx), _dt(ctx), _p(w), _p(out), out.stride(0), B, S, D, _stream()),
+               "vln_rows_wsum")
+    return out
+
+
+def attn_bwd(ctx, attn, dalpha, dattn_ext=None, dwc=None, vec=None, dctx=None, want_dl=False):
+    """Returns (dvec, dl).  If dctx is given it is accumulated in place."""
+    lib = _lib.load()
+    B, S, D = ctx.shape
+    dvec = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
+    dl = torch.empty(B, S, dtype=torch.float32, device=ctx.device) if want_dl else None
+    _lib.check(lib.vln_attn_bwd(_p(ctx), _dt(ctx), _p(attn), _p(dalpha), _p(dattn_ext), _p(dwc),
+                                dwc.stride(0) if dwc is not None else 0, _p(vec),
+                                vec.stride(0) if vec is not None else 0, _p(dvec), dvec.stride(0), _p(dctx), _p(dl),
+                                B, S, D, _stream()), "vln_attn_bwd")
+    return dvec, dl
+
+
+def dropout_mask(n: int, seed: int, offset: int, p: float, device) -> torch.Tensor:
+    """The exact pre-scaled keep mask (0 or 1/(1-p)) the kernels use for (seed, offset)."""
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    _lib.check(lib.vln_dropout_mask(_p(out), n, seed, offset, p, _stream()), "vln_dropout_mask")
+    return out
+
+
+def feat_dropout_inplace(x, img: int, angle: int, seed: int, offset: int, p: float, copy_bf16=None):
+    lib = _lib.load()
+    _req(x, "x", None)
+    assert x.is_contiguous() and x.shape[-1] == img + angle
+    rows = x.numel() // (img + angle)
+    _lib.check(lib.vln_feat_dropout_inplace(_p(x), _dt(x), rows, img, angle, seed, offset, p, _p(copy_bf16),
+                                            _stream()), "vln_feat_dropout_inplace")
+    return x
+
+
+def lstm_pointwise_fwd(gates, b_ih, b_hh, c0, seed=0, offset=0, p=0.0, want_drop=False):
+    """gates: [nsplit,B,4H] pre-activation slabs."""
+    lib = _lib.load()
+    ns, B, H4 = gates.shape
+    H = H4 // 4
+    dev = gates.device
+    h1 = torch.empty(B, H, device=dev); c1 = torch.empty(B, H, device=dev)
+    act = torch.empty(B, H4, device=dev); tc = torch.empty(B, H, device=dev)
+    hd = torch.empty(B, H, device=dev) if want_drop else None
+    _lib.check(lib.vln_lstm_pointwise_fwd(_p(gates), ns, B * H4, _p(b_ih), _p(b_hh), _p(c0), _p(h1), _p(c1), _p(act),
+                                          _p(tc), _p(hd), seed, offset, p, B, H, _stream()), "vln_lstm_pointwise_fwd")
+    return h1, c1, act, tc, hd
+
+
+def lstm_pointwise_bwd(dh1, dh1_drop, dc1, act, tanh_c1, c0, seed=0, offset=0, p=0.0):
+    lib = _lib.load()
+    B, H = c0.shape
+    dg = torch.empty(B, 4 * H, device=c0.device); dc0 = torch.empty(B, H, device=c0.device)
+    _lib.check(lib.vln_lstm_pointwise_bwd(_p(dh1), _p(dh1_drop), _p(dc1), seed, offset, p, _p(act), _p(tanh_c1),
+                                          _p(c0), _p(dg), _p(dc0), B, H, _stream()), "vln_lstm_pointwise_bwd")
+    return dg, dc0

@@ -1,0 +1,163 @@
+/* vln_hip.h -- C ABI of the MI355X (gfx950) training hot path for the R2R navigation agents.
+ *
+ * The reference (IMNearth/Curriculum-Learning-For-VLN, tasks/R2R-judy) has no FFI layer: its boundary for
+ * this path is the nn.Module surface of src/model/units.py and src/model/policy.py.  This library is what a
+ * torch.autograd.Function inside a drop-in nn.Module binds to (ctypes).  Every entry
+ * point takes raw DEVICE pointers, explicit sizes/strides and a hipStream_t, returns an int status
+ * (0 = VLN_OK), never allocates or frees caller memory and keeps no hidden global state (only a
+ * thread-local error string).  Tensors are row-major; "ld" = row stride in elements.
+ *
+ * dtype codes: 0 = fp32, 1 = bf16 (raw uint16 bits).  Activations/gradients are fp32; the streamed
+ * operands (weights, feature/context tensors) may be bf16 shadows with fp32 accumulation.
+ */
+#ifndef VLN_HIP_H
+#define VLN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vln_stream_t; /* hipStream_t */
+
+#define VLN_OK 0
+#define VLN_ERR_ARG 1
+#define VLN_ERR_HIP 2
+#define VLN_F32 0
+#define VLN_BF16 1
+#define VLN_ACT_NONE 0
+#define VLN_ACT_TANH 1
+#define VLN_ACT_RELU 2
+
+int vln_abi_version(void);
+const char* vln_last_error_string(void);
+
+/* ---- generic operators ---------------------------------------------------------------------------- */
+
+/* nn.Linear forward / dX product: Y[M,N] = act(X[M,K] W[N,K]^T + bias).  Replaces the F.linear calls inside
+ * units.py:69,106,120,144,146,181-184 and policy.py:115,124,189,204.  ws: split-K scratch (may be NULL). */
+int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y, int64_t ldy,
+                   int M, int N, int K, const float* bias, int act, float* ws, int64_t ws_floats, vln_stream_t s);
+/* weight gradient: D[N,K] (+)= A[Mt,N]^T X[Mt,K] (autograd of the same Linear layers, batched over steps) */
+int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd, int Mt,
+                     int N, int K, int accumulate, vln_stream_t s);
+int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, vln_stream_t s);
+/* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */
+int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K, vln_stream_t s);
+int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols, vln_stream_t s);
+
+/* SoftDotAttention / VisualSoftDotAttention pieces (units.py:100-122, 138-160):
+ *   dots[b,s] = ctx[b,s,:] . vec[b,:]                          torch.bmm(context, target)
+ *   attn = softmax(mask(logits)); out[b,:] = sum_s attn ctx     masked_fill_ + Softmax + torch.bmm(attn3, context)
+ *   backward of both, with optional in-place dctx accumulation */
+int vln_attn_dot(const void* ctx, int ctype, const float* vec, int64_t ldv, float* dots, int B, int S, int D, vln_stream_t s);
+int vln_attn_softmax_wsum(const void* ctx, int ctype, const float* logits, const uint8_t* mask, float* attn,
+                          float* out, int64_t ldo, int B, int S, int D, vln_stream_t s);
+int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* out, int64_t ldo, int B, int S, int D, vln_stream_t s);
+int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha, const float* dattn_ext,
+                 const float* dwc, int64_t lddwc, const float* vec, int64_t ldvec, float* dvec, int64_t lddvec,
+                 float* dctx, float* dl_out, int B, int S, int D, vln_stream_t s);
+
+/* nn.LSTMCell pointwise stage (policy.py:30,96,192): gates are nsplit pre-activation slabs [B,4H] */
+int vln_lstm_pointwise_fwd(const float* gates, int nsplit, int64_t slab_stride, const float* b_ih, const float* b_hh,
+                           const float* c0, float* h1, float* c1, float* act, float* tanh_c1, float* h1_drop,
+                           uint64_t seed, uint64_t offset, float p, int B, int H, vln_stream_t s);
+int vln_lstm_pointwise_bwd(const float* dh1, const float* dh1_drop, const float* dc1, uint64_t seed, uint64_t offset,
+                           float p, const float* act, const float* tanh_c1, const float* c0, float* dgates, float* dc0,
+                           int B, int H, vln_stream_t s);
+
+/* nn.Dropout replacements: Philox4x32-10 keyed by (seed, offset, element index) */
+int vln_dropout_mask(float* out_scaled_mask, int64_t n, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, uint64_t seed,
+                      uint64_t offset, float p, vln_stream_t s);
+/* EnvDropDecoder feature dropout, in place on x[..., :img] (policy.py:226-231); optional bf16 copy of x */
+int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
+                             float p, void* copy_bf16, vln_stream_t s);
+
+/* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
+
+typedef struct vln_envdrop_dims {
+  int B, L, V, C;        /* batch, instruction length, views (36), candidates (+STOP) */
+  int H, IMG, ANG, AE;   /* hidden, image feat (2048), angle feat (128), action embedding (64) */
+  int wtype;             /* dtype of the weight shadows (VLN_F32 / VLN_BF16) */
+  int ctype;             /* dtype of the streamed img/cand/ctx tensors the attention kernels read */
+} vln_envdrop_dims;
+
+typedef struct vln_envdrop_weights {
+  const float* act_w;    /* act_embed.0.weight [AE,ANG] */
+  const float* act_b;    /* act_embed.0.bias   [AE]     */
+  const void* w_vin;     /* visual_attn.linear_in.weight [F,H]           (wtype) */
+  const void* w_vin_t;   /* its transpose [H,F]                                    */
+  const void* w_cat;     /* [lstm.weight_ih | lstm.weight_hh]  [4H, AE+F+H]        */
+  const void* w_cat_t;   /* transpose [AE+F+H, 4H]                                 */
+  const float* b_ih;     /* lstm.bias_ih [4H] */
+  const float* b_hh;     /* lstm.bias_hh [4H] */
+  const void* w_tin;     /* text_attn.linear_in.weight [H,H]   */
+  const void* w_tin_t;
+  const void* w_tout;    /* text_attn.linear_out.weight [H,2H] */
+  const void* w_tout_t;  /* [2H,H] */
+  const void* w_c;       /* cand_attn.weight [F,H] */
+  const void* w_c_t;     /* [H,F] */
+} vln_envdrop_weights;
+
+typedef struct vln_envdrop_step {
+  /* inputs (forward) */
+  const float* a_prev;   /* [B,ANG] */
+  float* img;            /* [B,V,F] fp32, MUTATED in place by the feature dropout */
+  float* cand;           /* [B,C,F] fp32, MUTATED in place */
+  void* img_lp;          /* [B,V,F] bf16 copy written by fwd when ctype==BF16 (else NULL) */
+  void* cand_lp;         /* [B,C,F] bf16 copy */
+  const float* h_tilde_prev; /* [B,H] */
+  const float* c0;       /* [B,H] */
+  const float* ctx;      /* [B,L,H] fp32 */
+  const void* ctx_lp;    /* [B,L,H] bf16 copy when ctype==BF16 (else NULL) */
+  const uint8_t* ctx_mask; /* [B,L] 1 = masked, may be NULL */
+  /* outputs */
+  float* logit;          /* [B,C] */
+  float* h1;             /* [B,H] */
+  float* c1;             /* [B,H] */
+  float* h_tilde;        /* [B,H] */
+  /* saved for backward; e/xcat/hq/tcat/h1d/htd double as the X operands of the deferred weight-grad GEMMs */
+  float* e;              /* [B,AE]   tanh(act_embed) before dropout */
+  float* xcat;           /* [B,AE+F+H] LSTM input [drop(e) | visual | h_tilde_prev] */
+  float* hq;             /* [B,H]    drop(h_tilde_prev) */
+  float* alpha_v;        /* [B,V] */
+  float* gate_act;       /* [B,4H] */
+  float* tanh_c1;        /* [B,H] */
+  float* tcat;           /* [B,2H]  [weighted ctx | drop(h1)] */
+  float* tt;             /* [B,H]   text attention query */
+  float* alpha_t;        /* [B,L] */
+  float* htd;            /* [B,H]   drop(h_tilde) */
+  /* dropout */
+  uint64_t seed, offset; /* site k of this step uses Philox offset = offset*8 + k */
+  float p_drop, p_feat;
+  int already_dropfeat;
+  /* scratch */
+  float* ws; int64_t ws_floats;
+} vln_envdrop_step;
+
+typedef struct vln_envdrop_grads {
+  const float* dlogit;   /* [B,C] nullable */
+  const float* dh1;      /* [B,H] nullable */
+  const float* dc1;      /* [B,H] nullable */
+  const float* dh_tilde; /* [B,H] nullable */
+  float* dh_tilde_prev;  /* [B,H] out */
+  float* dc0;            /* [B,H] out */
+  float* dctx;           /* [B,L,H] accumulated in place (+=), nullable */
+  /* dY operands of the deferred weight-gradient GEMMs (row blocks of the rollout stash) */
+  float* s_dtc;          /* [B,F]  -> cand_attn.weight */
+  float* s_dz;           /* [B,H]  -> text_attn.linear_out.weight */
+  float* s_dtt;          /* [B,H]  -> text_attn.linear_in.weight */
+  float* s_dgates;       /* [B,4H] -> lstm.weight_ih / weight_hh / biases */
+  float* s_dtv;          /* [B,F]  -> visual_attn.linear_in.weight */
+  float* s_de;           /* [B,AE] -> act_embed.0.{weight,bias} */
+} vln_envdrop_grads;
+
+int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
+int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io, vln_stream_t s);
+int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
+                         vln_envdrop_grads* g, vln_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLN_HIP_H */
