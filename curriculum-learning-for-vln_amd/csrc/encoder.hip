@@ -1,0 +1,346 @@
+// Packed (bi)LSTM instruction encoder (reference units.py:48-74: embedding -> dropout ->
+// pack_padded_sequence -> nn.LSTM -> pad_packed_sequence -> dropout).
+//
+// The input projection of ALL time steps is one GEMM (gemm_nt, M = L*B, time-major rows); only the
+// h_{t-1} * W_hh^T recurrence is sequential.  One launch per time step handles BOTH directions:
+//   workgroup = 4 waves = the 4 gates (i,f,g,o) of 16 hidden units for 16 batch rows,
+//   grid = (Hd/16, dirs, B/16)  ->  128 workgroups at B=64, Hd=256, so the fp32 MFMA work of a step is spread
+//   over half the chip; W_hh fragments stream global->VGPR (L2-resident across steps), the gate
+//   pre-activations meet in LDS and each of the 256 threads finishes one (row, unit) of the fused cell.
+// Packed-sequence semantics: row b only advances while t < len[b]; outputs at padded steps are 0; the
+// reverse direction starts at each row's own last token because its state stays 0 until t < len[b].
+// Backward-through-time mirrors it: wave w contracts gate block w of the previous step's dgates with the
+// transposed W_hh shadow, LDS-reduce, then the pointwise cell backward.
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+
+template <typename TW> struct RecCfg;
+template <> struct RecCfg<float> { static constexpr int BK = 32, VK = 8; };
+template <> struct RecCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; };
+
+// acc += A[16 rows, kbeg:kend] * Wrow[16 cols, kbeg:kend]^T ; A fp32 row-major (lda), W rows K-contiguous.
+// Lane (fi = lane&15, fq = lane>>4) owns A row fi / W row fi and k-slots fq*VK..+VK of every K-step.
+template <typename TW>
+__device__ __forceinline__ void wave_tile_16x16(const float* arow, bool a_ok, const TW* wrow, bool w_ok, int kbeg,
+                                                int kend, int fq, bool vec, f32x4& acc) {
+  constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const int k = k0 + fq * VK;
+    float av[VK];
+    if (a_ok && vec && k + VK <= kend) {
+#pragma unroll
+      for (int v = 0; v < VK / 4; ++v) {
+        float4 t = *reinterpret_cast<const float4*>(arow + k + v * 4);
+        av[v * 4] = t.x; av[v * 4 + 1] = t.y; av[v * 4 + 2] = t.z; av[v * 4 + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VK; ++j) av[j] = (a_ok && (k + j) < kend) ? arow[k + j] : 0.f;
+    }
+    if constexpr (sizeof(TW) == 4) {
+      float wv[8];
+      if (w_ok && vec && k + 8 <= kend) {
+        float4 t0 = *reinterpret_cast<const float4*>(wrow + k);
+        float4 t1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+        wv[0] = t0.x; wv[1] = t0.y; wv[2] = t0.z; wv[3] = t0.w; wv[4] = t1.x; wv[5] = t1.y; wv[6] = t1.z; wv[7] = t1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = (w_ok && (k + j) < kend) ? wrow[k + j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);
+    } else {
+      bf16x8 a0, a1, l0, l1, w0, w1;   // activations split hi + lo: only the weight stream is quantised
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0[j] = (__bf16)av[j];
+        a1[j] = (__bf16)av[8 + j];
+        l0[j] = (__bf16)(av[j] - (float)a0[j]);
+        l1[j] = (__bf16)(av[8 + j] - (float)a1[j]);
+      }
+      if (w_ok && vec && k + 16 <= kend) {
+        w0 = *reinterpret_cast<const bf16x8*>(wrow + k);
+        w1 = *reinterpret_cast<const bf16x8*>(wrow + k + 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16_raw r0 = (w_ok && (k + j) < kend) ? wrow[k + j] : (bf16_raw)0;
+          bf16_raw r1 = (w_ok && (k + 8 + j) < kend) ? wrow[k + 8 + j] : (bf16_raw)0;
+          w0[j] = __builtin_bit_cast(__bf16, r0);
+          w1[j] = __builtin_bit_cast(__bf16, r1);
+        }
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, w0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, w1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc, 0, 0, 0);
+    }
+  }
+}
+
+struct RecFwdArgs {
+  const float* xproj;     // [L*B, dirs*4Hd] (biases already added)
+  const void* w_hh;       // [dirs][4Hd, Hd]
+  const int* lengths;     // [B]
+  float* hprev;           // [dirs][L][B][Hd]  state fed into the cell at time t
+  float* cprev;           // [dirs][L][B][Hd]
+  float* y;               // [L*B, dirs*Hd]
+  float* act;             // [L*B, dirs*4Hd]
+  float* tanh_c;          // [L*B, dirs*Hd]
+  float* hcat;            // [B, dirs*Hd] final h
+  float* ccat;            // [B, dirs*Hd] final c
+  int B, L, Hd, dirs, step, vec;
+};
+
+template <typename TW>
+__global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs a) {
+  __shared__ float sg[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int j0 = blockIdx.x * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const int Hd = a.Hd, B = a.B, L = a.L;
+  const int t = (d == 0) ? a.step : (L - 1 - a.step);
+  const long sbase = ((long)d * L + t) * B;          // row offset into hprev/cprev for (d, t)
+  // gate `wave` of units j0..j0+15 for rows b0..b0+15
+  {
+    const bool a_ok = (b0 + fi) < B, w_ok = (j0 + fi) < Hd;
+    const float* arow = a.hprev + (sbase + (a_ok ? b0 + fi : 0)) * Hd;
+    const TW* wrow = reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * Hd + (long)wave * Hd + (w_ok ? j0 + fi : 0)) * Hd;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    wave_tile_16x16<TW>(arow, a_ok, wrow, w_ok, 0, Hd, fq, a.vec, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sg[wave][fq * 4 + r][fi] = acc[r];
+  }
+  __syncthreads();
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  if (b >= B || j >= Hd) return;
+  const int G = a.dirs * 4 * Hd, Y = a.dirs * Hd;
+  const long row = (long)t * B + b;
+  const float* xp = a.xproj + row * G + (long)d * 4 * Hd + j;
+  const float pi = sg[0][bl][jl] + xp[0], pf = sg[1][bl][jl] + xp[Hd];
+  const float pg = sg[2][bl][jl] + xp[2 * Hd], po = sg[3][bl][jl] + xp[3 * Hd];
+  const float hp = a.hprev[(sbase + b) * Hd + j], cp = a.cprev[(sbase + b) * Hd + j];
+  const bool valid = t < a.lengths[b];
+  const float si = sigmoidf_(pi), sf = sigmoidf_(pf), tg = tanhf(pg), so = sigmoidf_(po);
+  const float cn = sf * cp + si * tg, tc = tanhf(cn), hn = so * tc;
+  float* ac = a.act + row * G + (long)d * 4 * Hd + j;
+  ac[0] = si; ac[Hd] = sf; ac[2 * Hd] = tg; ac[3 * Hd] = so;
+  a.tanh_c[row * Y + d * Hd + j] = tc;
+  a.y[row * Y + d * Hd + j] = valid ? hn : 0.f;
+  const float hs = valid ? hn : hp, cs = valid ? cn : cp;
+  const int tn = (d == 0) ? t + 1 : t - 1;
+  if (tn >= 0 && tn < L) {
+    const long nb = ((long)d * L + tn) * B + b;
+    a.hprev[nb * Hd + j] = hs;
+    a.cprev[nb * Hd + j] = cs;
+  } else {
+    a.hcat[(long)b * Y + d * Hd + j] = hs;
+    a.ccat[(long)b * Y + d * Hd + j] = cs;
+  }
+}
+
+struct RecBwdArgs {
+  const float* dy;        // [L*B, dirs*Hd] grad of the layer output (nullable)
+  const void* w_hh_t;     // [dirs][Hd, 4Hd] transposed shadow
+  const int* lengths;
+  const float* act; const float* tanh_c; const float* cprev;
+  float* dgates;          // [L*B, dirs*4Hd]
+  float* dh_pass;         // [dirs][B][Hd]  in: grad wrt the state after this step; out: before it (frozen rows)
+  float* dc_carry;        // [dirs][B][Hd]
+  int B, L, Hd, dirs, step, first, vec;
+};
+
+template <typename TW>
+__global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
+  __shared__ float sp[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int j0 = blockIdx.x * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const int Hd = a.Hd, B = a.B, L = a.L;
+  const int t = (d == 0) ? a.step : (L - 1 - a.step);     // a.step counts DOWN on the host side
+  const int G = a.dirs * 4 * Hd, Y = a.dirs * Hd;
+  if (!a.first) {
+    // dh_rec[b, j] = sum_k dgates[t_later][b, k] * W_hh[k, j]; wave w contracts gate block w
+    const int tl = (d == 0) ? t + 1 : t - 1;
+    const bool a_ok = (b0 + fi) < B, w_ok = (j0 + fi) < Hd;
+    const float* arow = a.dgates + ((long)tl * B + (a_ok ? b0 + fi : 0)) * G + (long)d * 4 * Hd;
+    const TW* wrow = reinterpret_cast<const TW*>(a.w_hh_t) + ((long)d * Hd + (w_ok ? j0 + fi : 0)) * 4 * Hd;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    wave_tile_16x16<TW>(arow, a_ok, wrow, w_ok, wave * Hd, (wave + 1) * Hd, fq, a.vec, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sp[wave][fq * 4 + r][fi] = acc[r];
+  }
+  __syncthreads();
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  if (b >= B || j >= Hd) return;
+  const long ci = ((long)d * B + b) * Hd + j;
+  float dh = a.dh_pass[ci];
+  if (!a.first) dh += sp[0][bl][jl] + sp[1][bl][jl] + sp[2][bl][jl] + sp[3][bl][jl];
+  const long row = (long)t * B + b;
+  float* dg = a.dgates + row * G + (long)d * 4 * Hd + j;
+  if (t < a.lengths[b]) {
+    if (a.dy) dh += a.dy[row * Y + d * Hd + j];
+    const float* ac = a.act + row * G + (long)d * 4 * Hd + j;
+    const float si = ac[0], sf = ac[Hd], tg = ac[2 * Hd], so = ac[3 * Hd];
+    const float tc = a.tanh_c[row * Y + d * Hd + j];
+    const float cp = a.cprev[(((long)d * L + t) * B + b) * Hd + j];
+    const float dc = a.dc_carry[ci] + dh * so * (1.f - tc * tc);
+    dg[0] = dc * tg * si * (1.f - si);
+    dg[Hd] = dc * cp * sf * (1.f - sf);
+    dg[2 * Hd] = dc * si * (1.f - tg * tg);
+    dg[3 * Hd] = dh * tc * so * (1.f - so);
+    a.dc_carry[ci] = dc * sf;
+    a.dh_pass[ci] = 0.f;
+  } else {
+    dg[0] = 0.f; dg[Hd] = 0.f; dg[2 * Hd] = 0.f; dg[3 * Hd] = 0.f;
+    a.dh_pass[ci] = dh;
+  }
+}
+
+// ---- embedding gather (+dropout) to time-major rows, and its scatter-add backward ----------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens, const float* E, float* out, int B,
+                                                        int L, int D, DropSpec dr) {
+  const long total = (long)L * B * D;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % D);
+    const long rb = e / D;
+    const int b = (int)(rb % B), t = (int)(rb / B);
+    const long tok = tokens[(long)b * L + t];
+    const long idx = ((long)b * L + t) * D + c;           // mask index follows the [B,L,D] layout
+    out[e] = E[tok * D + c] * dropout_scale1(dr.seed, dr.offset, (uint32_t)idx, dr.p);
+  }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* tokens, const int* lengths, const float* dx,
+                                                        float* dE, int B, int L, int D, long padding_idx,
+                                                        DropSpec dr) {
+  const long total = (long)L * B * D;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % D);
+    const long rb = e / D;
+    const int b = (int)(rb % B), t = (int)(rb / B);
+    if (t >= lengths[b]) continue;                        // padded steps carry no gradient
+    const long tok = tokens[(long)b * L + t];
+    if (tok == padding_idx) continue;
+    const long idx = ((long)b * L + t) * D + c;
+    const float g = dx[e] * dropout_scale1(dr.seed, dr.offset, (uint32_t)idx, dr.p);
+    atomicAdd(dE + tok * D + c, g);
+  }
+}
+
+// ---- layout changes with fused dropout: time-major [L,B,W] <-> batch-major [B,L,W] -------------------------
+__global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* bm, bf16_raw* bm_lp, int B, int L,
+                                                       int W, DropSpec dr) {
+  const long total = (long)B * L * W;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % W);
+    const long rb = e / W;
+    const int t = (int)(rb % L), b = (int)(rb / L);
+    const float v = tm[((long)t * B + b) * W + c] * dropout_scale1(dr.seed, dr.offset, (uint32_t)e, dr.p);
+    bm[e] = v;
+    if (bm_lp) bm_lp[e] = f32_to_bf16_bits(v);
+  }
+}
+__global__ __launch_bounds__(256) void bm_to_tm_kernel(const float* bm, float* tm, int B, int L, int W, DropSpec dr) {
+  const long total = (long)B * L * W;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % W);
+    const long rb = e / W;
+    const int t = (int)(rb % L), b = (int)(rb / L);
+    tm[((long)t * B + b) * W + c] = bm[e] * dropout_scale1(dr.seed, dr.offset, (uint32_t)e, dr.p);
+  }
+}
+
+static inline int nblk(long n, int cap = 4096) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace vln
+
+using namespace vln;
+
+extern "C" int vln_embed_fwd(const int64_t* tokens, const float* E, float* out_tm, int B, int L, int D,
+                             uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+  if (!tokens || !E || !out_tm || B <= 0 || L <= 0 || D <= 0) { set_error("vln_embed_fwd: bad args"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+                     (const long long*)tokens, E, out_tm, B, L, D, DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("embed_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE, int B,
+                             int L, int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p,
+                             vln_stream_t s) {
+  if (!tokens || !lengths || !dx_tm || !dE) { set_error("vln_embed_bwd: null pointer"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+                     (const long long*)tokens, lengths, dx_tm, dE, B, L, D, (long)padding_idx, DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("embed_bwd");
+  return VLN_OK;
+}
+extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, int L, int W, uint64_t seed,
+                            uint64_t offset, float p, vln_stream_t s) {
+  if (!tm || !bm) { set_error("vln_tm_to_bm: null pointer"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(tm_to_bm_kernel, dim3(nblk((long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
+                     (bf16_raw*)bm_bf16, B, L, W, DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("tm_to_bm");
+  return VLN_OK;
+}
+extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p,
+                            vln_stream_t s) {
+  if (!tm || !bm) { set_error("vln_bm_to_tm: null pointer"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(bm_to_tm_kernel, dim3(nblk((long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B, L, W,
+                     DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("bm_to_tm");
+  return VLN_OK;
+}
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
+                                float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
+                                int L, int Hd, int dirs, vln_stream_t s) {
+  if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
+      L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  // initial states: time 0 of the forward direction, time L-1 of the reverse direction
+  const long blk = (long)B * Hd;
+  for (int d = 0; d < dirs; ++d) {
+    const long off = ((long)d * L + (d == 0 ? 0 : L - 1)) * blk;
+    int r = fill_f32(st, hprev + off, blk, 0.f); if (r) return r;
+    r = fill_f32(st, cprev + off, blk, 0.f); if (r) return r;
+  }
+  RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 0};
+  a.vec = al16(w_hh) && al16(hprev) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
+  dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
+  for (int step = 0; step < L; ++step) {
+    a.step = step;
+    if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_fwd_kernel<bf16_raw>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(lstm_rec_fwd_kernel<float>, grid, block, 0, st, a);
+  }
+  VLN_CHECK_LAUNCH("lstm_rec_fwd");
+  return VLN_OK;
+}
+
+extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                                const float* act, const float* tanh_c, const float* cprev, float* dgates,
+                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, vln_stream_t s) {
+  if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
+      Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0};
+  a.vec = al16(w_hh_t) && al16(dgates) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
+  dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
+  for (int step = L - 1; step >= 0; --step) {
+    a.step = step;
+    a.first = (step == L - 1);
+    if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_bwd_kernel<bf16_raw>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(lstm_rec_bwd_kernel<float>, grid, block, 0, st, a);
+  }
+  VLN_CHECK_LAUNCH("lstm_rec_bwd");
+  return VLN_OK;
+}

@@ -35,7 +35,10 @@ template <typename TW>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
   constexpr bool kF32 = (sizeof(TW) == 4);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][64 * kLdsRow];
+  // bf16 path: the fp32 activations are split x = hi + lo (two bf16 planes) so only the STREAMED operand is
+  // quantised; the second MFMA pair is free in these weight-bandwidth-bound shapes.
+  constexpr int kPlanes = kF32 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][kPlanes][64 * kLdsRow];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
@@ -73,16 +76,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     }
   };
   auto store_x = [&](int buf) {
-    unsigned char* dst = &smem[buf][srow * kLdsRow + sseg * 32];
+    unsigned char* dst = &smem[buf][0][srow * kLdsRow + sseg * 32];
     if constexpr (kF32) {
       *reinterpret_cast<float4*>(dst) = make_float4(xs[0], xs[1], xs[2], xs[3]);
       *reinterpret_cast<float4*>(dst + 16) = make_float4(xs[4], xs[5], xs[6], xs[7]);
     } else {
-      bf16x8 lo, hi;
+      bf16x8 h0, h1, l0, l1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { lo[j] = (__bf16)xs[j]; hi[j] = (__bf16)xs[8 + j]; }
-      *reinterpret_cast<bf16x8*>(dst) = lo;
-      *reinterpret_cast<bf16x8*>(dst + 16) = hi;
+      for (int j = 0; j < 8; ++j) {
+        h0[j] = (__bf16)xs[j];
+        h1[j] = (__bf16)xs[8 + j];
+        l0[j] = (__bf16)(xs[j] - (float)h0[j]);
+        l1[j] = (__bf16)(xs[8 + j] - (float)h1[j]);
+      }
+      *reinterpret_cast<bf16x8*>(dst) = h0;
+      *reinterpret_cast<bf16x8*>(dst + 16) = h1;
+      unsigned char* dlo = &smem[buf][kPlanes - 1][srow * kLdsRow + sseg * 32];
+      *reinterpret_cast<bf16x8*>(dlo) = l0;
+      *reinterpret_cast<bf16x8*>(dlo + 16) = l1;
     }
   };
   auto load_w = [&](int kb) {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       if (rb < nrb) {
-        const unsigned char* src = &smem[buf][(rb * 16 + fi) * kLdsRow + fq * 32];
+        const unsigned char* src = &smem[buf][0][(rb * 16 + fi) * kLdsRow + fq * 32];
         if constexpr (kF32) {
           float4 a0 = *reinterpret_cast<const float4*>(src);
           float4 a1 = *reinterpret_cast<const float4*>(src + 16);
@@ -156,6 +167,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
         } else {
           bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
           bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
+          const unsigned char* slo = &smem[buf][kPlanes - 1][(rb * 16 + fi) * kLdsRow + fq * 32];
+          bf16x8 b0 = *reinterpret_cast<const bf16x8*>(slo);
+          bf16x8 b1 = *reinterpret_cast<const bf16x8*>(slo + 16);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[0], acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[1], acc[rb], 0, 0, 0);
           acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[0], acc[rb], 0, 0, 0);
           acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[1], acc[rb], 0, 0, 0);
         }

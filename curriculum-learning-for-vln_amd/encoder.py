@@ -1,0 +1,207 @@
+"""Drop-in `EncoderLSTM` (reference: src/model/units.py:12-74).
+
+Constructor, `forward(inputs, lengths, already_sorted=True) -> (ctx, decoder_init, c_t)` and the
+`state_dict` keys (`embedding.weight`, `lstm.weight_ih_l{k}[_reverse]`, ..., `enc2dec.{weight,bias}`)
+are the reference's; `nn.Embedding` / `nn.LSTM` / `nn.Linear` objects are kept only as parameter
+holders (default init identical to the reference) -- their forward is never called.
+
+Algorithm (see csrc/encoder.hip): time-major internal layout, one input-projection GEMM per layer for all
+time steps, L fused recurrence launches per layer (both directions each), one BPTT launch per step, and
+ONE weight-gradient contraction over (L x B) per weight.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .runtime import ShadowSet
+
+_p = ops._p
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, tokens, lens32, p_drop, offset, *params):
+        lib = _lib.load()
+        sh = mod._shadow.t
+        B, L = tokens.shape
+        dev = tokens.device
+        Hd, dirs, nl = mod.hidden_size, mod.num_directions, mod.num_layers
+        E = mod.embed_size
+        seed = mod.dropout_seed
+        f32 = dict(dtype=torch.float32, device=dev)
+        wtype = ops.BF16 if mod.compute_dtype == torch.bfloat16 else ops.F32
+        p_emb = 0.0 if mod.use_glove else p_drop
+        x = torch.empty(L * B, E, **f32)
+        _lib.check(lib.vln_embed_fwd(_p(tokens), _p(mod.embedding.weight), _p(x), B, L, E, seed, offset * 8 + 0,
+                                     p_emb, _stream()), "vln_embed_fwd")
+        saved = []
+        p_inter = p_drop if nl > 1 else 0.0
+        for k in range(nl):
+            xproj = ops.linear_fwd(x, sh[f"w_ih{k}"], sh[f"bsum{k}"])
+            hprev = torch.empty(dirs, L, B, Hd, **f32)
+            cprev = torch.empty(dirs, L, B, Hd, **f32)
+            y = torch.empty(L * B, dirs * Hd, **f32)
+            act = torch.empty(L * B, dirs * 4 * Hd, **f32)
+            tanh_c = torch.empty(L * B, dirs * Hd, **f32)
+            hcat = torch.empty(B, dirs * Hd, **f32)
+            ccat = torch.empty(B, dirs * Hd, **f32)
+            _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
+                                            _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs,
+                                            _stream()), "vln_lstm_seq_fwd")
+            saved.append((x, hprev, cprev, act, tanh_c))
+            if k < nl - 1:
+                if p_inter > 0:
+                    xn = torch.empty_like(y)
+                    _lib.check(lib.vln_scale_dropout(_p(y), y.stride(0), _p(xn), xn.stride(0), L * B, dirs * Hd, seed,
+                                                     offset * 8 + 2 + k, p_inter, _stream()), "vln_scale_dropout")
+                    x = xn
+                else:
+                    x = y
+        H = dirs * Hd
+        ctx_out = torch.empty(B, L, H, **f32)
+        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), None, B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
+                   "vln_tm_to_bm")
+        dec_init = ops.linear_fwd(hcat, sh["w_e2d"], mod.enc2dec.bias.detach(), ops.ACT_TANH)
+        ctx.mod, ctx.saved, ctx.misc = mod, saved, (tokens, lens32, p_drop, offset, hcat, dec_init, wtype)
+        ctx.set_materialize_grads(False)
+        return ctx_out, dec_init, ccat
+
+    @staticmethod
+    def backward(ctx, dctx, ddec, dct):
+        lib = _lib.load()
+        mod = ctx.mod
+        sh = mod._shadow.t
+        tokens, lens32, p_drop, offset, hcat, dec_init, wtype = ctx.misc
+        B, L = tokens.shape
+        dev = tokens.device
+        Hd, dirs, nl = mod.hidden_size, mod.num_directions, mod.num_layers
+        H = dirs * Hd
+        seed = mod.dropout_seed
+        f32 = dict(dtype=torch.float32, device=dev)
+        p_emb = 0.0 if mod.use_glove else p_drop
+        p_inter = p_drop if nl > 1 else 0.0
+        grads = {}
+        # decoder_init = tanh(enc2dec(h_t))                                       units.py:69
+        if ddec is not None:
+            dpre = (ddec * (1.0 - dec_init * dec_init)).contiguous()
+            grads["enc2dec.weight"] = ops.linear_wgrad(dpre, hcat)
+            grads["enc2dec.bias"] = ops.colsum(dpre)
+            dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])
+        else:
+            dhcat = torch.zeros(B, H, **f32)
+        dccat = dct.contiguous() if dct is not None else torch.zeros(B, H, **f32)
+        dy = None
+        if dctx is not None:
+            dy = torch.empty(L * B, H, **f32)
+            dctx = dctx.contiguous()
+            _lib.check(lib.vln_bm_to_tm(_p(dctx), _p(dy), B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
+                       "vln_bm_to_tm")
+        for k in range(nl - 1, -1, -1):
+            x, hprev, cprev, act, tanh_c = ctx.saved[k]
+            if k == nl - 1:   # only the last layer's final states are returned (units.py:63-67)
+                dh_pass = dhcat.view(B, dirs, Hd).transpose(0, 1).contiguous()
+                dc_carry = dccat.view(B, dirs, Hd).transpose(0, 1).contiguous()
+            else:
+                dh_pass = torch.zeros(dirs, B, Hd, **f32)
+                dc_carry = torch.zeros(dirs, B, Hd, **f32)
+            dgates = torch.empty(L * B, dirs * 4 * Hd, **f32)
+            _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
+                                            _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
+                                            _stream()), "vln_lstm_seq_bwd")
+            for d in range(dirs):
+                sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
+                dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
+                grads["lstm.weight_hh" + sfx] = ops.linear_wgrad(dg, hprev[d].view(L * B, Hd))
+                grads["lstm.weight_ih" + sfx] = ops.linear_wgrad(dg, x)
+                gb = ops.colsum(dg)
+                grads["lstm.bias_ih" + sfx] = gb
+                grads["lstm.bias_hh" + sfx] = gb.clone()
+            need_dx = (k > 0) or mod.embedding.weight.requires_grad
+            if need_dx:
+                dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])
+                if k > 0:
+                    if p_inter > 0:
+                        dy = torch.empty_like(dx)
+                        _lib.check(lib.vln_scale_dropout(_p(dx), dx.stride(0), _p(dy), dy.stride(0), L * B, dx.shape[1],
+                                                         seed, offset * 8 + 2 + (k - 1), p_inter, _stream()),
+                                   "vln_scale_dropout")
+                    else:
+                        dy = dx
+                else:
+                    dE = torch.zeros_like(mod.embedding.weight)
+                    pad = mod.embedding.padding_idx
+                    _lib.check(lib.vln_embed_bwd(_p(tokens), _p(lens32), _p(dx), _p(dE), B, L, mod.embed_size,
+                                                 -1 if pad is None else pad, seed, offset * 8 + 0, p_emb, _stream()),
+                               "vln_embed_bwd")
+                    grads["embedding.weight"] = dE
+        out = [grads.get(n) for n in mod._param_names]
+        return (None, None, None, None, None) + tuple(out)
+
+
+class EncoderLSTM(nn.Module):
+    def __init__(self, vocab_size, embed_size, hidden_size, padding_idx, drop_ratio=0.5, bidirectional=False,
+                 num_layers=1, glove=None, compute_dtype=torch.float32):
+        super().__init__()
+        self.embed_size = embed_size
+        self.vocab_size = vocab_size
+        self.num_directions = 2 if bidirectional else 1
+        self.hidden_size = hidden_size // self.num_directions
+        self.num_layers = num_layers
+        self.use_glove = glove is not None
+        self.drop_ratio = float(drop_ratio)
+        self.drop = nn.Dropout(p=drop_ratio)
+        if self.use_glove:
+            self.embedding = nn.Embedding.from_pretrained(torch.from_numpy(glove), freeze=True)
+        else:
+            self.embedding = nn.Embedding(vocab_size, embed_size, padding_idx=padding_idx)
+        self.lstm = nn.LSTM(self.embed_size, self.hidden_size, dropout=drop_ratio * (num_layers > 1),
+                            num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
+        self.enc2dec = nn.Linear(self.hidden_size * self.num_directions, self.hidden_size * self.num_directions)
+        self.compute_dtype = compute_dtype
+        self.dropout_seed = 0xE2C0DE
+        self._calls = 0
+        self._shadow = ShadowSet()
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    def _refresh_shadows(self):
+        dt = self.compute_dtype
+        t = self._shadow.t
+        t.clear()
+        for k in range(self.num_layers):
+            sfxs = [f"_l{k}"] + ([f"_l{k}_reverse"] if self.num_directions == 2 else [])
+            w_ih = torch.cat([getattr(self.lstm, "weight_ih" + s).detach() for s in sfxs], 0).contiguous()
+            t[f"w_ih{k}"] = w_ih if dt == torch.float32 else ops.cast_copy(w_ih, dt)
+            t[f"w_ih_t{k}"] = ops.transpose_cast(w_ih, dt)
+            t[f"bsum{k}"] = torch.cat([(getattr(self.lstm, "bias_ih" + s) + getattr(self.lstm, "bias_hh" + s)).detach()
+                                       for s in sfxs], 0).contiguous()
+            w_hh = torch.stack([getattr(self.lstm, "weight_hh" + s).detach() for s in sfxs], 0).contiguous()
+            t[f"w_hh{k}"] = w_hh if dt == torch.float32 else ops.cast_copy(w_hh, dt)
+            t[f"w_hh_t{k}"] = torch.stack([ops.transpose_cast(w_hh[d], dt) for d in range(w_hh.shape[0])], 0).contiguous()
+        w = self.enc2dec.weight.detach()
+        t["w_e2d"] = w if dt == torch.float32 else ops.cast_copy(w, dt)
+        t["w_e2d_t"] = ops.transpose_cast(w, dt)
+
+    def forward(self, inputs: torch.Tensor, lengths, already_sorted: bool = True):
+        """inputs [B, max_len] int64 on the GPU, lengths [B] (CPU or GPU, any int type).  Rows are processed
+        independently with packed-sequence semantics, so `already_sorted` needs no special handling."""
+        if not inputs.is_cuda:
+            raise _lib.VlnError("EncoderLSTM: inputs must be on the GPU; there is no CPU fallback")
+        params = [p for _, p in self.named_parameters()]
+        key = ShadowSet.key_of(params, self.compute_dtype)
+        if self._shadow.stale(key):
+            with torch.no_grad():
+                self._refresh_shadows()
+            self._shadow.commit(key)
+        self._calls += 1
+        tokens = inputs.contiguous()
+        if tokens.dtype != torch.int64:
+            tokens = tokens.long()
+        lens32 = torch.as_tensor(lengths).to(device=inputs.device, dtype=torch.int32)
+        p = self.drop_ratio if self.training else 0.0
+        return _EncoderFn.apply(self, tokens, lens32, p, self._calls, *params)

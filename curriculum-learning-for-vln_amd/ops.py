@@ -34,7 +34,7 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32):
         raise _lib.VlnError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
-    if t.stride(-1) != 1:
+    if t.shape[-1] > 1 and t.stride(-1) != 1:
         raise ValueError(f"{name}: innermost dim must be contiguous")
     return t
 
@@ -61,7 +61,7 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None):
     assert w.shape[1] == K
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    ws = workspace(x.device, 16 * M * N)
+    ws = workspace(x.device, min(16 * M * N, 1 << 24))
     _lib.check(lib.vln_linear_fwd(_p(x), x.stride(0), _p(w), _dt(w), w.stride(0), _p(out), out.stride(0), M, N, K,
                                   _p(bias), act, _p(ws), ws.numel(), _stream()), "vln_linear_fwd")
     return out

@@ -1,0 +1,264 @@
+"""Host-side runtime shared by the drop-in modules.
+
+* `ShadowSet`  -- compute-dtype / transposed copies of the fp32 master weights,
+  refreshed only when a parameter's version or storage changes (i.e. once per
+  optimizer step), so every GEMM (forward, dX) streams a K-contiguous operand.
+* `Stash`      -- the rollout arena.  Every Linear's X operand is written by the
+  forward kernels straight into row-block t of a per-site [rows, dim] buffer
+  and its dY operand by the backward kernels, so each weight gradient is ONE
+  contraction over (steps x batch) per optimizer step instead of a
+  read-modify-write of the whole dW per decoder step.
+* `WeightGate` / `CtxGate` -- identity autograd nodes.  Autograd runs a gate's
+  backward only after every decoder step that consumed its outputs has run
+  its own backward; that is where the deferred dW GEMMs / the in-place
+  accumulated dctx are handed to autograd.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class ShadowSet:
+    def __init__(self):
+        self._key = None
+        self.t: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def key_of(params: Sequence[torch.Tensor], dtype) -> tuple:
+        return (dtype,) + tuple((p._version, p.data_ptr()) for p in params)
+
+    def stale(self, key) -> bool:
+        return key != self._key
+
+    def commit(self, key):
+        self._key = key
+
+
+class StepSlot:
+    """Row block [r0, r0+rows) of one chunk, owned by one decoder step."""
+    __slots__ = ("chunk", "r0", "rows", "done")
+
+    def __init__(self, chunk, r0, rows):
+        self.chunk, self.r0, self.rows, self.done = chunk, r0, rows, False
+
+    def view(self, site: str) -> torch.Tensor:
+        return self.chunk.bufs[site][self.r0:self.r0 + self.rows]
+
+
+class Chunk:
+    __slots__ = ("bufs", "cap", "used", "slots", "owners")
+
+    def __init__(self, bufs, cap):
+        self.bufs, self.cap = bufs, cap
+        self.used, self.slots, self.owners = 0, [], []
+
+    def recyclable(self) -> bool:
+        # every rollout that wrote here is gone (its context tensor died => its autograd graph died)
+        return all(o() is None for o in self.owners) and not any(s.done for s in self.slots)
+
+    def clear(self):
+        self.used, self.slots, self.owners = 0, [], []
+
+
+class Stash:
+    """Row arena for the deferred weight-gradient operands of one module (`sites`: name -> width)."""
+    CHUNK_ROWS = 1024
+
+    def __init__(self, sites: Dict[str, int], device):
+        self.sites = dict(sites)
+        self.device = device
+        self.chunks: List[Chunk] = []
+        self._pool: List[Chunk] = []
+
+    def reset(self):
+        for c in self.chunks:
+            c.clear()
+        self._pool.extend(self.chunks)
+        self.chunks = []
+
+    def _new_chunk(self, rows: int) -> Chunk:
+        # reclaim chunks of dead rollouts first (bounds memory when graphs are built but never backpropagated,
+        # e.g. the reference's validation rollouts)
+        live = []
+        for c in self.chunks[:-1] if self.chunks else []:
+            if c.recyclable():
+                c.clear()
+                self._pool.append(c)
+            else:
+                live.append(c)
+        if self.chunks:
+            live.append(self.chunks[-1])
+        self.chunks = live
+        for i, c in enumerate(self._pool):
+            if c.cap >= rows:
+                ch = self._pool.pop(i)
+                break
+        else:
+            cap = max(rows, self.CHUNK_ROWS)
+            ch = Chunk({k: torch.empty(cap, w, dtype=torch.float32, device=self.device)
+                        for k, w in self.sites.items()}, cap)
+        self.chunks.append(ch)
+        return ch
+
+    def take(self, rows: int, owner_ref) -> StepSlot:
+        ch = self.chunks[-1] if self.chunks else None
+        if ch is None or ch.used + rows > ch.cap:
+            ch = self._new_chunk(rows)
+        slot = StepSlot(ch, ch.used, rows)
+        ch.used += rows
+        ch.slots.append(slot)
+        if not ch.owners or ch.owners[-1] is not owner_ref:
+            ch.owners.append(owner_ref)
+        return slot
+
+    def done_runs(self):
+        """Yield (bufs, r0, r1) for maximal runs of steps whose backward ran; consumes the flags."""
+        for c in self.chunks:
+            run = None
+            for st in c.slots:
+                if st.done:
+                    st.done = False
+                    if run is not None and run[1] == st.r0:
+                        run[1] = st.r0 + st.rows
+                        continue
+                    if run is not None:
+                        yield c.bufs, run[0], run[1]
+                    run = [st.r0, st.r0 + st.rows]
+                elif run is not None:
+                    yield c.bufs, run[0], run[1]
+                    run = None
+            if run is not None:
+                yield c.bufs, run[0], run[1]
+
+
+class WeightGate(torch.autograd.Function):
+    """outs = aliases of the parameters; backward = owner._deferred_wgrads()."""
+
+    @staticmethod
+    def forward(ctx, owner_ref, *params):
+        ctx.owner_ref = owner_ref
+        ctx.n = len(params)
+        ctx.set_materialize_grads(False)
+        return tuple(p.detach() for p in params)
+
+    @staticmethod
+    def backward(ctx, *unused):
+        owner = ctx.owner_ref()
+        if owner is None:
+            return (None,) + (None,) * ctx.n
+        grads = owner._deferred_wgrads()
+        return (None,) + tuple(grads)
+
+
+class CtxEntry:
+    """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
+    low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
+    __slots__ = ("ref", "dctx", "lp", "gated", "__weakref__")
+
+    def __init__(self, t):
+        self.ref = weakref.ref(t)
+        self.dctx = None
+        self.lp = None
+        self.gated = None
+
+
+class CtxGate(torch.autograd.Function):
+    """Identity on the encoder context; backward returns the dctx buffer the decoder steps accumulated
+    into in place (one [B,L,H] buffer per rollout instead of one per step)."""
+
+    @staticmethod
+    def forward(ctx, entry, x):
+        ctx.entry_ref = weakref.ref(entry)
+        ctx.set_materialize_grads(False)
+        return x.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        e = ctx.entry_ref()
+        d = None
+        if e is not None:
+            d, e.dctx, e.gated = e.dctx, None, None
+        if g is not None:
+            d = g if d is None else d + g
+        return None, d
+
+
+class GatedModuleMixin:
+    """Bookkeeping for modules whose per-step autograd nodes defer weight grads through a WeightGate."""
+
+    def _init_gating(self):
+        self._shadow = ShadowSet()
+        self._stash: Optional[Stash] = None
+        self._gate_outs = None
+        self._ctx_entries: Dict[int, CtxEntry] = {}
+        self._step_counter = 0
+        self.compute_dtype = torch.float32      # dtype of the streamed operands (weights / features / ctx)
+        self.dropout_seed = 0x5EED
+
+    # -- provided by the module -----------------------------------------------------------------------
+    def _gated_params(self) -> List[torch.Tensor]:
+        raise NotImplementedError
+
+    def _stash_sites(self) -> Dict[str, int]:
+        raise NotImplementedError
+
+    def _refresh_shadows(self):
+        raise NotImplementedError
+
+    def _deferred_wgrads(self) -> List[Optional[torch.Tensor]]:
+        raise NotImplementedError
+
+    # -------------------------------------------------------------------------------------------------
+    def _ensure_current(self, need_grad: bool):
+        params = self._gated_params()
+        key = ShadowSet.key_of(params, self.compute_dtype)
+        if self._shadow.stale(key):
+            with torch.no_grad():
+                self._refresh_shadows()
+            self._shadow.commit(key)
+            self._gate_outs = None
+        if need_grad and self._gate_outs is None:
+            dev = params[0].device
+            if self._stash is None or self._stash.device != dev:
+                self._stash = Stash(self._stash_sites(), dev)
+            else:
+                self._stash.reset()
+            self._ctx_entries = {}
+            self._gate_outs = WeightGate.apply(weakref.ref(self), *params)
+        return self._gate_outs
+
+    def _gate_consumed(self):
+        # called from _deferred_wgrads once the dW GEMMs are issued: the next forward opens a new gate
+        self._gate_outs = None
+
+    def _gated_ctx(self, ctx_t: torch.Tensor, need_grad: bool):
+        """-> (tensor to hand to the step Function, CtxEntry)."""
+        k = id(ctx_t)
+        e = self._ctx_entries.get(k)
+        if e is None or e.ref() is not ctx_t:
+            if len(self._ctx_entries) > 16:
+                self._ctx_entries = {i: x for i, x in self._ctx_entries.items() if x.ref() is not None}
+            e = CtxEntry(ctx_t)
+            self._ctx_entries[k] = e
+        if need_grad and ctx_t.requires_grad:
+            if e.gated is None:
+                e.gated = CtxGate.apply(e, ctx_t)
+            return e.gated, e
+        return ctx_t, e
+
+    def _next_offset(self) -> int:
+        self._step_counter += 1
+        return self._step_counter
+
+    @staticmethod
+    def _ctx_lp(entry: CtxEntry, ctx_t: torch.Tensor, dtype):
+        if dtype == torch.float32:
+            return None
+        if entry.lp is None:
+            entry.lp = ops.cast_copy(ctx_t.detach().contiguous(), dtype)
+        return entry.lp

@@ -73,6 +73,28 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
 
+/* ---- EncoderLSTM pieces (units.py:48-74) ------------------------------------------------------------
+ * Internal layout is TIME-major: row (t*B + b).  nn.Embedding + Dropout -> vln_embed_fwd; the input projection
+ * of all steps is one vln_linear_fwd (M = L*B, bias = b_ih + b_hh); the packed recurrence of one layer (both
+ * directions per launch, L launches) is vln_lstm_seq_fwd; pad_packed_sequence + Dropout -> vln_tm_to_bm. */
+int vln_embed_fwd(const int64_t* tokens /*[B,L]*/, const float* E, float* out_tm /*[L*B,D]*/, int B, int L, int D,
+                  uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE /* += */, int B, int L,
+                  int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_tm_to_bm(const float* tm /*[L,B,W]*/, float* bm /*[B,L,W]*/, void* bm_bf16 /*nullable*/, int B, int L, int W,
+                 uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+/* xproj [L*B, dirs*4Hd]; w_hh [dirs][4Hd,Hd] (wtype); hprev/cprev [dirs][L][B][Hd] (state fed into time t, written
+ * here); y_tm [L*B, dirs*Hd]; act [L*B, dirs*4Hd]; tanh_c [L*B, dirs*Hd]; hcat/ccat [B, dirs*Hd] final states */
+int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev, float* cprev,
+                     float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B, int L, int Hd, int dirs,
+                     vln_stream_t s);
+/* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
+ * in: grads of the final states, clobbered */
+int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
+                     const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry, int B, int L,
+                     int Hd, int dirs, vln_stream_t s);
+
 /* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
 
 typedef struct vln_envdrop_dims {

@@ -31,10 +31,9 @@ def test_linear_fwd(vln, M, N, K, wdt):
     x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
     wq = w.to(wdt)
     ref = torch.tanh(x.double() @ wq.double().t() + b.double())
-    if wdt == torch.bfloat16:   # the kernel also rounds x to bf16 for the MFMA
-        ref = torch.tanh(x.bfloat16().double() @ wq.double().t() + b.double())
+    # bf16 path: only the streamed weight is bf16; x is split hi+lo so it is exact to ~2^-17
     y = vln.ops.linear_fwd(x.to(dev()), wq.to(dev()), b.to(dev()), vln.ops.ACT_TANH)
-    tol = 1e-4 if wdt == torch.float32 else 2e-3
+    tol = 1e-4 if wdt == torch.float32 else 2e-4
     assert rel_err(y, ref) < tol
 
 
