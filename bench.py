@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""bench.py -- EnvDrop agent training steps/sec on MI355X (BASELINE.json metric, config 1).
+
+One "step" = one agent training iteration of the reference's EnvDrop IL path
+(trainer.py:411-427 with feedback="teacher"): instruction encoder forward, T teacher-forced decoder steps
+with the in-place candidate mask + cross-entropy (envdrop.py:151-179), `ml_loss * ML_WEIGHT / B`, full
+backward, gradient all-reduce (N > 1), clip-norm 40 on encoder and decoder, RMSprop step.  Batch 64 episodes
+per GPU, 36 x (2048+128) view features, <= 80 instruction tokens, synthetic data, inputs
+resident in HBM before the timed region; dropout ON (training mode).
+
+    python bench.py                       # N=1, prints ONE JSON line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+The `cpu_baseline` leg times the CPU oracle (oracle/torch_port.py, kind "port") on a bounded sample of the same
+workload on rank 0 at N=1 only.  The `roofline` leg replays the K timed steps with per-kernel HIP-event timers
+(vln_prof_*), and reports the kernel with the largest total time.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as Fn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ML_WEIGHT = 0.2            # configs/envdrop/envdrop_config.yaml:45
+CLIP = 40.0                # trainer.py:425-426
+LR = 1e-4                  # envdrop_config.yaml:19
+
+
+def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
+    """Synthetic episode batch (BASELINE.md §3 / SURVEY.md §8d), CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    F = IMG + ANG
+    lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values
+    lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, 0] = 3                                        # <BOS>
+        tokens[i, 1:n - 1] = torch.randint(4, vocab, (n - 2,), generator=g)
+        tokens[i, n - 1] = 2                                    # <EOS>
+    seq_mask = tokens == 0
+
+    def angle_feat(n):
+        h = torch.rand(n, generator=g) * 6.283 - 3.1415
+        e = (torch.rand(n, generator=g) - 0.5) * 1.04
+        return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], 1).repeat(1, ANG // 4)
+
+    def feats(n):
+        x = torch.empty(n, F)
+        x[:, :IMG] = torch.randn(n, IMG, generator=g).abs() * 0.5  # post-ReLU pool5: non-negative
+        x[:, IMG:] = angle_feat(n)
+        return x
+
+    T_i = torch.randint(4, T + 1, (B,), generator=g)
+    T_i[0] = T
+    steps = []
+    for t in range(T):
+        ncand = torch.randint(3, C_max + 1, (B,), generator=g)      # candidates incl. the STOP slot
+        Ct = int(ncand.max())
+        cand = feats(B * Ct).view(B, Ct, F)
+        cmask = torch.arange(Ct)[None, :] >= ncand[:, None]
+        for i in range(B):
+            cand[i, ncand[i] - 1:] = 0                              # STOP slot + padding are zero rows
+        ended = t >= T_i
+        tgt = torch.where(t == T_i - 1, ncand - 1, (torch.rand(B, generator=g) * (ncand - 1).float()).long())
+        tgt = torch.where(ended, torch.full_like(tgt, -1), tgt)
+        steps.append(dict(img=feats(B * V).view(B, V, F), cand=cand, cand_mask=cmask, angle=angle_feat(B), target=tgt))
+    return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
+
+
+def tape_to(tape, dev):
+    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k != "steps"}
+    out["lengths32"] = tape["lengths"].to(dev, torch.int32)
+    out["steps"] = [{k: v.to(dev) for k, v in s.items()} for s in tape["steps"]]
+    return out
+
+
+class GpuAgent:
+    """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
+
+    def __init__(self, vln, dev, dtype, world):
+        self.vln, self.world = vln, world
+        self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
+        self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
+        self.enc.train(); self.dec.train()
+        params = list(self.enc.parameters()) + list(self.dec.parameters())
+        self.bucket = vln.dp.GradBucket(params)
+        self.opt = torch.optim.RMSprop(params, lr=LR)
+
+    def iteration(self, tape):
+        B = tape["B"]
+        self.bucket.zero()
+        ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
+        h_tilde = h_t
+        ml = 0.
+        for s in tape["steps"]:
+            img, cand = s["img"].clone(), s["cand"].clone()      # fresh per-step feature buffers (mutated in place)
+            logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], False)
+            logits.masked_fill_(s["cand_mask"], -float("inf"))
+            ml = ml + Fn.cross_entropy(logits, s["target"], ignore_index=-1, reduction="none").sum()
+        loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
+        loss.backward()
+        self.bucket.allreduce()
+        torch.nn.utils.clip_grad_norm_(self.enc.parameters(), CLIP)
+        torch.nn.utils.clip_grad_norm_(self.dec.parameters(), CLIP)
+        self.opt.step()
+        return loss
+
+
+def cpu_baseline(tape, iters, P_enc, P_dec):
+    """The CPU oracle driven identically (dropout sampled with bernoulli_ like nn.Dropout)."""
+    from oracle import torch_port as O
+    B, ANG = tape["B"], tape["ANG"]
+    params = [p.requires_grad_(True) for p in list(P_enc.values()) + list(P_dec.values())]
+    opt = torch.optim.RMSprop(params, lr=LR)
+
+    def mask(shape, p):
+        return torch.empty(shape).bernoulli_(1 - p).div_(1 - p)
+
+    def one():
+        opt.zero_grad()
+        L = tape["L"]
+        ctx, h_t, c_t = O.encoder_forward(P_enc, tape["tokens"], tape["lengths"].tolist(), num_layers=1, bidirectional=True,
+                                          emb_mask=mask((B, L, 256), 0.5), ctx_mask_drop=mask((B, L, 512), 0.5))
+        h_tilde, ml = h_t, 0.
+        for s in tape["steps"]:
+            img = O.feature_dropout(s["img"], mask(s["img"][..., :-ANG].shape, 0.3), ANG)
+            cand = O.feature_dropout(s["cand"], mask(s["cand"][..., :-ANG].shape, 0.3), ANG)
+            drop = {"act": mask((B, 64), 0.5), "hprev": mask((B, 512), 0.5), "h1": mask((B, 512), 0.5), "htilde": mask((B, 512), 0.5)}
+            logit, (h_t, c_t), h_tilde, _ = O.envdrop_step(P_dec, s["angle"], img, cand, h_tilde, c_t, ctx, tape["seq_mask"], drop=drop)
+            ml = ml + O.masked_cross_entropy(logit, s["target"], s["cand_mask"], "sum")
+        (ml * ML_WEIGHT / B).backward()
+        torch.nn.utils.clip_grad_norm_(list(P_enc.values()), CLIP)
+        torch.nn.utils.clip_grad_norm_(list(P_dec.values()), CLIP)
+        opt.step()
+
+    t0 = time.perf_counter()
+    one()                                   # warm-up
+    warm = time.perf_counter() - t0
+    if warm > 20.0:                         # pathological host (e.g. CPU quota): keep the bench bounded
+        return warm, 1
+    t0 = time.perf_counter()
+    done = 0
+    while done < iters and (time.perf_counter() - t0) < 20.0:
+        one()
+        done += 1
+    return (time.perf_counter() - t0) / done, done
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def read_prof(lib, nk):
+    rows = []
+    for k in range(nk):
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        lib.vln_prof_read(k, C.byref(n), C.byref(ms), C.byref(by))
+        if n.value:
+            rows.append(dict(kernel=lib.vln_prof_kernel_name(k).decode(), launches=n.value, ms=ms.value, bytes=by.value))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--len", type=int, default=80, dest="L")
+    ap.add_argument("--T", type=int, default=7)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import vln_amd as vln
+    lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(2020)
+    agent = GpuAgent(vln, dev, dtype, world)
+    tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
+    tape = tape_to(tape_cpu, dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        agent.iteration(tape)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] warm-up {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.iteration(tape)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+    if rank == 0:
+        print(f"[bench] timed region: {ms_per_step:.3f} ms/step on {world} GPU(s)", file=sys.stderr, flush=True)
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        nk = 0
+        while lib.vln_prof_kernel_name(nk):
+            nk += 1
+        for k in range(nk):
+            lib.vln_prof_enable(k, 1)
+        read_prof(lib, nk)
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            agent.iteration(tape)
+        torch.cuda.synchronize()
+        rows = read_prof(lib, nk)
+        for k in range(nk):
+            lib.vln_prof_enable(k, 0)
+        if rows:
+            rows.sort(key=lambda r: -r["ms"])
+            top = rows[0]
+            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes/launch (rocprofv3 --pmc runs)
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get(args.dtype, {}).get(top["kernel"])
+            roofline = dict(bound="hbm", kernel=top["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                            avg_launch_us=round(top["ms"] * 1e3 / top["launches"], 2),
+                            algo_bytes_per_launch=round(top["bytes"] / top["launches"]),
+                            kernels=[dict(kernel=r["kernel"], launches_per_step=r["launches"] / args.steps,
+                                          us_per_step=round(r["ms"] * 1e3 / args.steps, 1),
+                                          GBps=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in rows])
+    if world > 1:
+        torch.distributed.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ncores = min(usable_cores(), 64)
+        torch.set_num_threads(ncores)
+        print(f"[bench] cpu baseline on {ncores} threads ...", file=sys.stderr, flush=True)
+        P_enc = {k: v.detach().float().cpu().clone() for k, v in agent.enc.state_dict().items()}
+        P_dec = {k: v.detach().float().cpu().clone() for k, v in agent.dec.state_dict().items()}
+        sec, done = cpu_baseline(tape_cpu, args.cpu_iters, P_enc, P_dec)
+        cpu = dict(value=round(1.0 / sec, 4), unit="steps/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"{done} iterations of the same tape (B={args.batch}, L={args.L}, T={args.T}), fp32, after 1 warm-up")
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "agent train steps/sec (EnvDrop IL, batch 64/GPU, 36x2048 feats)", "value": round(value, 3),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}",
+                       "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

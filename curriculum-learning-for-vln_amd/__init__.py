@@ -5,7 +5,7 @@ that keep the reference's constructor / forward / state_dict surface.
 
 Import as `import vln_amd` (root shim) -- the directory name is not a Python
 identifier."""
-from . import _lib, ops, runtime  # noqa: F401
+from . import _lib, ops, runtime, dp  # noqa: F401
 from ._lib import VlnError, LIB_PATH  # noqa: F401
 from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "vln_internal.h"
 #include "../../include/vln_hip.h"
 
@@ -19,9 +21,65 @@ int check_hip(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return VLN_ERR_HIP;
 }
+// ---- per-kernel event timers -------------------------------------------------------------------------
+unsigned g_prof_mask = 0;
+namespace {
+struct ProfSlot { hipEvent_t a, b; };
+struct ProfState {
+  std::vector<ProfSlot> pool;   // created lazily, reused across reads
+  size_t used = 0;
+  double bytes = 0.0;
+};
+ProfState g_prof[K_COUNT];
+const char* kKernelNames[K_COUNT] = {"gemm_nt", "gemm_tn", "attn_dot", "attn_wsum", "attn_bwd", "lstm_rec_fwd",
+                                     "lstm_rec_bwd", "feat_dropout", "lstm_pointwise", "reduce_epilogue"};
+}  // namespace
+void prof_begin(hipStream_t st, int kid, double algo_bytes) {
+  ProfState& p = g_prof[kid];
+  if (p.used == p.pool.size()) {
+    ProfSlot s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    p.pool.push_back(s);
+  }
+  p.bytes += algo_bytes;
+  (void)hipEventRecord(p.pool[p.used].a, st);
+}
+void prof_end(hipStream_t st, int kid) {
+  ProfState& p = g_prof[kid];
+  if (p.used < p.pool.size()) {
+    (void)hipEventRecord(p.pool[p.used].b, st);
+    p.used++;
+  }
+}
 }  // namespace vln
 
 using namespace vln;
+
+extern "C" int vln_prof_enable(int kernel_id, int on) {
+  if (kernel_id < 0 || kernel_id >= K_COUNT) { set_error("vln_prof_enable: bad kernel id"); return VLN_ERR_ARG; }
+  if (on) g_prof_mask |= (1u << kernel_id); else g_prof_mask &= ~(1u << kernel_id);
+  return VLN_OK;
+}
+extern "C" const char* vln_prof_kernel_name(int kernel_id) {
+  return (kernel_id >= 0 && kernel_id < K_COUNT) ? kKernelNames[kernel_id] : nullptr;
+}
+// Sums and clears the recorded event pairs of one kernel (synchronises on them).
+extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_bytes) {
+  if (kernel_id < 0 || kernel_id >= K_COUNT || !launches || !total_ms || !total_bytes) { set_error("vln_prof_read: bad args"); return VLN_ERR_ARG; }
+  ProfState& p = g_prof[kernel_id];
+  double ms = 0.0;
+  for (size_t i = 0; i < p.used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(p.pool[i].b) != hipSuccess || hipEventElapsedTime(&t, p.pool[i].a, p.pool[i].b) != hipSuccess) {
+      set_error("vln_prof_read: event query failed");
+      return VLN_ERR_HIP;
+    }
+    ms += t;
+  }
+  *launches = (int64_t)p.used; *total_ms = ms; *total_bytes = p.bytes;
+  p.used = 0; p.bytes = 0.0;
+  return VLN_OK;
+}
 
 extern "C" int vln_abi_version(void) { return 1; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }

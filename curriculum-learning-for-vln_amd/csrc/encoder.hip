@@ -317,8 +317,11 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
   RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 0};
   a.vec = al16(w_hh) && al16(hprev) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
   dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
+  // per-launch algorithmic bytes: W_hh once, h/c state in+out, xproj in, y/act/tanh_c out
+  const double step_bytes = (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1));
   for (int step = 0; step < L; ++step) {
     a.step = step;
+    ProfScope prof(st, K_LSTM_REC_FWD, step_bytes);
     if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_fwd_kernel<bf16_raw>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(lstm_rec_fwd_kernel<float>, grid, block, 0, st, a);
   }
@@ -338,6 +341,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
   for (int step = L - 1; step >= 0; --step) {
     a.step = step;
     a.first = (step == L - 1);
+    ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
     if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_bwd_kernel<bf16_raw>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(lstm_rec_bwd_kernel<float>, grid, block, 0, st, a);
   }

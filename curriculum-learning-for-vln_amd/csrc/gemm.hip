@@ -234,8 +234,12 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   if (to_slabs) { a.Y = ws; a.ldy = N; a.slab_stride = (long)M * N; }
   else { a.Y = Y; a.ldy = ldy; a.slab_stride = 0; }
   dim3 grid(nb, nsplit, mb), block(256);
-  if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, st, a);
+  {
+    // algorithmic bytes: the weight stream once + activations in + result out
+    ProfScope prof(st, K_GEMM_NT, (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N);
+    if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, st, a);
+  }
   VLN_CHECK_LAUNCH("gemm_nt");
   if (nsplit_out) { *nsplit_out = nsplit; return VLN_OK; }   // caller consumes the slabs itself
   if (to_slabs)
@@ -362,7 +366,10 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
   a.avec = aligned16(A) && (lda % 4 == 0);
   a.xvec = aligned16(X) && (ldx % 4 == 0);
   dim3 grid((K + 63) / 64, (N + 63) / 64), block(256);
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, st, a);
+  {
+    ProfScope prof(st, K_GEMM_TN, 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1)));
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, st, a);
+  }
   VLN_CHECK_LAUNCH("gemm_tn");
   return VLN_OK;
 }

@@ -13,7 +13,23 @@ void set_error(const char* fmt, ...);
 const char* get_error();
 int check_hip(hipError_t e, const char* what);
 
-#define VLN_CHECK_LAUNCH(what)                                   \
+// ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------
+enum KernelId {
+  K_GEMM_NT = 0, K_GEMM_TN, K_ATTN_DOT, K_ATTN_WSUM, K_ATTN_BWD, K_LSTM_REC_FWD, K_LSTM_REC_BWD, K_FEAT_DROPOUT,
+  K_LSTM_PW, K_REDUCE_EPI, K_COUNT
+};
+extern unsigned g_prof_mask;
+void prof_begin(hipStream_t st, int kid, double algo_bytes);
+void prof_end(hipStream_t st, int kid);
+struct ProfScope {   // brackets the launches issued in its scope with an event pair on the SAME stream
+  hipStream_t st; int kid; bool on;
+  ProfScope(hipStream_t s, int k, double bytes) : st(s), kid(k), on((g_prof_mask >> k) & 1u) {
+    if (on) prof_begin(st, kid, bytes);
+  }
+  ~ProfScope() { if (on) prof_end(st, kid); }
+};
+
+#define VLN_CHECK_LAUNCH(what)                                 \
   do {                                                           \
     int _st = vln::check_hip(hipGetLastError(), what);           \
     if (_st != VLN_OK) return _st;                               \

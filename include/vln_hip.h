@@ -31,6 +31,13 @@ typedef void* vln_stream_t; /* hipStream_t */
 int vln_abi_version(void);
 const char* vln_last_error_string(void);
 
+/* Optional per-kernel timers (measurement only; the reference has no counterpart): when enabled for a kernel id,
+ * every launch of that kernel is bracketed by a hipEvent pair on the launch stream.  vln_prof_read sums and clears
+ * them and returns the algorithmic bytes of those launches. */
+int vln_prof_enable(int kernel_id, int on);
+const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */
+int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_bytes);
+
 /* ---- generic operators ---------------------------------------------------------------------------- */
 
 /* nn.Linear forward / dX product: Y[M,N] = act(X[M,K] W[N,K]^T + bias).  Replaces the F.linear calls inside
