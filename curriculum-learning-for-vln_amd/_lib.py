@@ -46,12 +46,13 @@ class EnvDropGrads(C.Structure):
 SIGNATURES = {
     "vln_abi_version": (i32, []),
     "vln_last_error_string": (C.c_char_p, []),
+    "vln_set_graphs": (i32, [i32]),
     "vln_prof_enable": (i32, [i32, i32]),
     "vln_prof_kernel_name": (C.c_char_p, [i32]),
     "vln_prof_read": (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vln_linear_fwd": (i32, [ptr, i64, ptr, i32, i64, ptr, i64, i32, i32, i32, ptr, i32, ptr, i64, ptr]),
-    "vln_linear_wgrad": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr]),
-    "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr]),
+    "vln_linear_wgrad": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),

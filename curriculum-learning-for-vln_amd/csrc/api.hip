@@ -21,6 +21,7 @@ int check_hip(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return VLN_ERR_HIP;
 }
+int g_graphs_enabled = 1;
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {
@@ -55,6 +56,7 @@ void prof_end(hipStream_t st, int kid) {
 
 using namespace vln;
 
+extern "C" int vln_set_graphs(int on) { g_graphs_enabled = on ? 1 : 0; return VLN_OK; }
 extern "C" int vln_prof_enable(int kernel_id, int on) {
   if (kernel_id < 0 || kernel_id >= K_COUNT) { set_error("vln_prof_enable: bad kernel id"); return VLN_ERR_ARG; }
   if (on) g_prof_mask |= (1u << kernel_id); else g_prof_mask &= ~(1u << kernel_id);
@@ -91,13 +93,14 @@ extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wt
   return gemm_nt((hipStream_t)s, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, ws, ws_floats, nullptr);
 }
 extern "C" int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd,
-                                int Mt, int N, int K, int accumulate, vln_stream_t s) {
+                                int Mt, int N, int K, int accumulate, float* ws, int64_t ws_floats, vln_stream_t s) {
   if (!A || !X || !D) { set_error("vln_linear_wgrad: null pointer"); return VLN_ERR_ARG; }
-  return gemm_tn((hipStream_t)s, A, lda, X, ldx, D, ldd, Mt, N, K, accumulate);
+  return gemm_tn((hipStream_t)s, A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, ws, ws_floats);
 }
-extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, vln_stream_t s) {
+extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
+                          int64_t ws_floats, vln_stream_t s) {
   if (!A || !out || cols <= 0) { set_error("vln_colsum: bad args"); return VLN_ERR_ARG; }
-  return colsum((hipStream_t)s, A, lda, out, rows, cols, accumulate);
+  return colsum((hipStream_t)s, A, lda, out, rows, cols, accumulate, ws, ws_floats);
 }
 extern "C" int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K,
                                   vln_stream_t s) {

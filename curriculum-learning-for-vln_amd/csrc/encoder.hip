@@ -12,6 +12,7 @@
 // Backward-through-time mirrors it: wave w contracts gate block w of the previous step's dgates with the
 // transposed W_hh shadow, LDS-reduce, then the pointwise cell backward.
 #include "vln_internal.h"
+#include "graph_cache.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -20,12 +21,72 @@ template <typename TW> struct RecCfg;
 template <> struct RecCfg<float> { static constexpr int BK = 32, VK = 8; };
 template <> struct RecCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; };
 
+// Fast path: a K range of exactly NS K-steps, aligned, all rows valid: every load of the whole range is issued
+// before the first MFMA (one memory latency per launch instead of one per K-step).
+template <typename TW, int NS>
+__device__ __forceinline__ void wave_tile_16x16_fast(const float* arow, const TW* wrow, int kbeg, int fq, f32x4& acc) {
+  constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+  float4 av[NS][VK / 4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int v = 0; v < VK / 4; ++v) av[s][v] = *reinterpret_cast<const float4*>(arow + kbeg + s * BK + fq * VK + v * 4);
+  if constexpr (sizeof(TW) == 4) {
+    float4 wv[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      wv[s][0] = *reinterpret_cast<const float4*>(wrow + kbeg + s * BK + fq * VK);
+      wv[s][1] = *reinterpret_cast<const float4*>(wrow + kbeg + s * BK + fq * VK + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0].x, wv[s][0].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0].y, wv[s][0].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0].z, wv[s][0].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0].w, wv[s][0].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1].x, wv[s][1].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1].y, wv[s][1].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1].z, wv[s][1].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1].w, wv[s][1].w, acc, 0, 0, 0);
+    }
+  } else {
+    bf16x8 wv[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      wv[s][0] = *reinterpret_cast<const bf16x8*>(wrow + kbeg + s * BK + fq * VK);
+      wv[s][1] = *reinterpret_cast<const bf16x8*>(wrow + kbeg + s * BK + fq * VK + 8);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float x[16] = {av[s][0].x, av[s][0].y, av[s][0].z, av[s][0].w, av[s][1].x, av[s][1].y, av[s][1].z, av[s][1].w,
+                           av[s][2].x, av[s][2].y, av[s][2].z, av[s][2].w, av[s][3].x, av[s][3].y, av[s][3].z, av[s][3].w};
+      bf16x8 a0, a1, l0, l1;   // activations split hi + lo: only the weight stream is quantised
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0[j] = (__bf16)x[j];
+        a1[j] = (__bf16)x[8 + j];
+        l0[j] = (__bf16)(x[j] - (float)a0[j]);
+        l1[j] = (__bf16)(x[8 + j] - (float)a1[j]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, wv[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, wv[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[s][1], acc, 0, 0, 0);
+    }
+  }
+}
+
 // acc += A[16 rows, kbeg:kend] * Wrow[16 cols, kbeg:kend]^T ; A fp32 row-major (lda), W rows K-contiguous.
 // Lane (fi = lane&15, fq = lane>>4) owns A row fi / W row fi and k-slots fq*VK..+VK of every K-step.
 template <typename TW>
 __device__ __forceinline__ void wave_tile_16x16(const float* arow, bool a_ok, const TW* wrow, bool w_ok, int kbeg,
                                                 int kend, int fq, bool vec, f32x4& acc) {
+  if (vec && (kend - kbeg) == 256 && __all(a_ok && w_ok)) {   // the reference's 2x256 encoder (wave-uniform test)
+    wave_tile_16x16_fast<TW, 256 / RecCfg<TW>::BK>(arow, wrow, kbeg, fq, acc);
+    return;
+  }
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+#pragma unroll 4
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const int k = k0 + fq * VK;
     float av[VK];
@@ -103,6 +164,21 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs a) {
   const int Hd = a.Hd, B = a.B, L = a.L;
   const int t = (d == 0) ? a.step : (L - 1 - a.step);
   const long sbase = ((long)d * L + t) * B;          // row offset into hprev/cprev for (d, t)
+  // pointwise operands of this thread's (row, unit): issued first so their latency hides under the MFMAs
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool live = (b < B) && (j < Hd);
+  const int G = a.dirs * 4 * Hd, Y = a.dirs * Hd;
+  const long row = (long)t * B + (live ? b : 0);
+  float xi = 0.f, xf = 0.f, xg = 0.f, xo = 0.f, hp = 0.f, cp = 0.f;
+  int len = 0;
+  if (live) {
+    const float* xp = a.xproj + row * G + (long)d * 4 * Hd + j;
+    xi = xp[0]; xf = xp[Hd]; xg = xp[2 * Hd]; xo = xp[3 * Hd];
+    hp = a.hprev[(sbase + b) * Hd + j];
+    cp = a.cprev[(sbase + b) * Hd + j];
+    len = a.lengths[b];
+  }
   // gate `wave` of units j0..j0+15 for rows b0..b0+15
   {
     const bool a_ok = (b0 + fi) < B, w_ok = (j0 + fi) < Hd;
@@ -114,16 +190,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs a) {
     for (int r = 0; r < 4; ++r) sg[wave][fq * 4 + r][fi] = acc[r];
   }
   __syncthreads();
-  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
-  const int b = b0 + bl, j = j0 + jl;
-  if (b >= B || j >= Hd) return;
-  const int G = a.dirs * 4 * Hd, Y = a.dirs * Hd;
-  const long row = (long)t * B + b;
-  const float* xp = a.xproj + row * G + (long)d * 4 * Hd + j;
-  const float pi = sg[0][bl][jl] + xp[0], pf = sg[1][bl][jl] + xp[Hd];
-  const float pg = sg[2][bl][jl] + xp[2 * Hd], po = sg[3][bl][jl] + xp[3 * Hd];
-  const float hp = a.hprev[(sbase + b) * Hd + j], cp = a.cprev[(sbase + b) * Hd + j];
-  const bool valid = t < a.lengths[b];
+  if (!live) return;
+  const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf;
+  const float pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
+  const bool valid = t < len;
   const float si = sigmoidf_(pi), sf = sigmoidf_(pf), tg = tanhf(pg), so = sigmoidf_(po);
   const float cn = sf * cp + si * tg, tc = tanhf(cn), hn = so * tc;
   float* ac = a.act + row * G + (long)d * 4 * Hd + j;
@@ -162,6 +232,26 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
   const int Hd = a.Hd, B = a.B, L = a.L;
   const int t = (d == 0) ? a.step : (L - 1 - a.step);     // a.step counts DOWN on the host side
   const int G = a.dirs * 4 * Hd, Y = a.dirs * Hd;
+  // pointwise operands first (their loads overlap the recurrent product)
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool live = (b < B) && (j < Hd);
+  const long ci = ((long)d * B + (live ? b : 0)) * Hd + (live ? j : 0);
+  const long row = (long)t * B + (live ? b : 0);
+  float dh = 0.f, dyv = 0.f, si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, cp = 0.f, dcc = 0.f;
+  int len = 0;
+  if (live) {
+    dh = a.dh_pass[ci];
+    len = a.lengths[b];
+    if (t < len) {
+      if (a.dy) dyv = a.dy[row * Y + d * Hd + j];
+      const float* ac = a.act + row * G + (long)d * 4 * Hd + j;
+      si = ac[0]; sf = ac[Hd]; tg = ac[2 * Hd]; so = ac[3 * Hd];
+      tc = a.tanh_c[row * Y + d * Hd + j];
+      cp = a.cprev[(((long)d * L + t) * B + b) * Hd + j];
+      dcc = a.dc_carry[ci];
+    }
+  }
   if (!a.first) {
     // dh_rec[b, j] = sum_k dgates[t_later][b, k] * W_hh[k, j]; wave w contracts gate block w
     const int tl = (d == 0) ? t + 1 : t - 1;
@@ -174,21 +264,12 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
     for (int r = 0; r < 4; ++r) sp[wave][fq * 4 + r][fi] = acc[r];
   }
   __syncthreads();
-  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
-  const int b = b0 + bl, j = j0 + jl;
-  if (b >= B || j >= Hd) return;
-  const long ci = ((long)d * B + b) * Hd + j;
-  float dh = a.dh_pass[ci];
+  if (!live) return;
   if (!a.first) dh += sp[0][bl][jl] + sp[1][bl][jl] + sp[2][bl][jl] + sp[3][bl][jl];
-  const long row = (long)t * B + b;
   float* dg = a.dgates + row * G + (long)d * 4 * Hd + j;
-  if (t < a.lengths[b]) {
-    if (a.dy) dh += a.dy[row * Y + d * Hd + j];
-    const float* ac = a.act + row * G + (long)d * 4 * Hd + j;
-    const float si = ac[0], sf = ac[Hd], tg = ac[2 * Hd], so = ac[3 * Hd];
-    const float tc = a.tanh_c[row * Y + d * Hd + j];
-    const float cp = a.cprev[(((long)d * L + t) * B + b) * Hd + j];
-    const float dc = a.dc_carry[ci] + dh * so * (1.f - tc * tc);
+  if (t < len) {
+    dh += dyv;
+    const float dc = dcc + dh * so * (1.f - tc * tc);
     dg[0] = dc * tg * si * (1.f - si);
     dg[Hd] = dc * cp * sf * (1.f - sf);
     dg[2 * Hd] = dc * si * (1.f - tg * tg);
@@ -301,12 +382,9 @@ extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uin
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
-                                float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
-                                int L, int Hd, int dirs, vln_stream_t s) {
-  if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
-      L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
-  hipStream_t st = (hipStream_t)s;
+static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_hh, int wtype, const int32_t* lengths,
+                              float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
+                              float* ccat, int B, int L, int Hd, int dirs) {
   // initial states: time 0 of the forward direction, time L-1 of the reverse direction
   const long blk = (long)B * Hd;
   for (int d = 0; d < dirs; ++d) {
@@ -329,12 +407,23 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
   return VLN_OK;
 }
 
-extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
-                                const float* act, const float* tanh_c, const float* cprev, float* dgates,
-                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, vln_stream_t s) {
-  if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
-      Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
-  hipStream_t st = (hipStream_t)s;
+extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
+                                float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
+                                int L, int Hd, int dirs, vln_stream_t s) {
+  if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
+      L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
+  // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
+  struct { const void* p[10]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat},
+                                                 {wtype, B, L, Hd, dirs}};
+  static GraphCache cache;
+  return cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
+    return lstm_seq_fwd_issue(st, xproj, w_hh, wtype, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs);
+  });
+}
+
+static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                              const float* act, const float* tanh_c, const float* cprev, float* dgates, float* dh_pass,
+                              float* dc_carry, int B, int L, int Hd, int dirs) {
   RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0};
   a.vec = al16(w_hh_t) && al16(dgates) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
   dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
@@ -347,4 +436,17 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
   }
   VLN_CHECK_LAUNCH("lstm_rec_bwd");
   return VLN_OK;
+}
+
+extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                                const float* act, const float* tanh_c, const float* cprev, float* dgates,
+                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, vln_stream_t s) {
+  if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
+      Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
+  struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},
+                                                {wtype, B, L, Hd, dirs}};
+  static GraphCache cache;
+  return cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
+    return lstm_seq_bwd_issue(st, dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs);
+  });
 }

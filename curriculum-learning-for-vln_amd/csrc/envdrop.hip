@@ -26,8 +26,15 @@ __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
       const float* a = p.a + (long)b * p.ANG;
       const float* w = p.act_w + (long)j * p.ANG;
-      float acc = p.act_b[j];
-      for (int k = 0; k < p.ANG; ++k) acc += a[k] * w[k];
+      // 16-byte loads, 4 independent accumulators (ANG % 4 == 0 is checked on the host)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < p.ANG; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + k);
+        const float4 y = *reinterpret_cast<const float4*>(w + k);
+        a0 += x.x * y.x; a1 += x.y * y.y; a2 += x.z * y.z; a3 += x.w * y.w;
+      }
+      const float acc = p.act_b[j] + ((a0 + a1) + (a2 + a3));
       const float e = tanhf(acc);
       p.e[i] = e;
       p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.offset, (uint32_t)i, p.d_act.p);

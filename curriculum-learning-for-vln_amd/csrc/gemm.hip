@@ -210,7 +210,9 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   const int BK = (wtype == W_BF16) ? 64 : 32;
   const int nb = (N + 63) / 64, mb = (M + 63) / 64;
   const int ksteps = (K + BK - 1) / BK;
-  // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk
+  // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk.  (Measured on MI355X:
+  // many co-resident workgroups with one K-step of prefetch each beat one fat workgroup per CU with all of
+  // its loads in flight: 8.5 vs 12.5 us average per launch in the EnvDrop step, profiles/round1_notes.md.)
   int nsplit = 1;
   if (ws != nullptr) {
     const int target = 512;
@@ -258,7 +260,17 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* slabs
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int r = (int)(e / N), c = (int)(e % N);
     float v = bias ? bias[c] : 0.0f;
-    for (int s = 0; s < nsplit; ++s) v += slabs[(long)s * slab_stride + (long)r * lds + c];
+    const float* sp = slabs + (long)r * lds + c;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {   // 4 independent load streams
+      v += sp[(long)s * slab_stride];
+      v1 += sp[(long)(s + 1) * slab_stride];
+      v2 += sp[(long)(s + 2) * slab_stride];
+      v3 += sp[(long)(s + 3) * slab_stride];
+    }
+    for (; s < nsplit; ++s) v += sp[(long)s * slab_stride];
+    v += (v1 + v2) + v3;
     if (act == ACT_TANH) v = tanhf(v);
     else if (act == ACT_RELU) v = fmaxf(v, 0.0f);
     out[(long)r * ldo + c] = v;
@@ -287,6 +299,7 @@ constexpr int kTnStride = 80;  // floats per staged row: 64 + 16 keeps the two k
 struct GemmTNArgs {
   const float* A; long lda; const float* X; long ldx; float* D; long ldd;
   int Mt, N, K, accumulate, avec, xvec;
+  int mchunk; long slab_stride;   // split over the contraction rows: block z handles rows [z*mchunk, ...)
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
@@ -294,13 +307,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[2][32 * kTnStride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * a.mchunk;
+  const int mend = min(a.Mt, mbeg + a.mchunk);
   const int fi = lane & 15, fq = lane >> 4;
   const int sm = tid >> 3, sc = (tid & 7) * 8;   // staging: row in the 32-row step, 8-float column segment
   float ra[8], rx[8];
 
   auto load_tile = [&](const float* P, long ld, int c0, int C, int vec, int mbase, float (&r)[8]) {
     const int m = mbase + sm;
-    const bool ok = m < a.Mt;
+    const bool ok = m < mend;
     const float* p = P + (long)(ok ? m : 0) * ld + c0 + sc;
     if (ok && vec && (c0 + sc + 8) <= C) {
       float4 t0 = *reinterpret_cast<const float4*>(p);
@@ -320,10 +335,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   f32x4 acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nsteps = (a.Mt + 31) / 32;
+  const int nsteps = (mend - mbeg + 31) / 32;
   if (nsteps > 0) {
-    load_tile(a.A, a.lda, n0, a.N, a.avec, 0, ra);
-    load_tile(a.X, a.ldx, k0, a.K, a.xvec, 0, rx);
+    load_tile(a.A, a.lda, n0, a.N, a.avec, mbeg, ra);
+    load_tile(a.X, a.ldx, k0, a.K, a.xvec, mbeg, rx);
   }
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
@@ -331,8 +346,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     store_tile(sX[buf], rx);
     __syncthreads();
     if (s + 1 < nsteps) {
-      load_tile(a.A, a.lda, n0, a.N, a.avec, (s + 1) * 32, ra);
-      load_tile(a.X, a.ldx, k0, a.K, a.xvec, (s + 1) * 32, rx);
+      load_tile(a.A, a.lda, n0, a.N, a.avec, mbeg + (s + 1) * 32, ra);
+      load_tile(a.X, a.ldx, k0, a.K, a.xvec, mbeg + (s + 1) * 32, rx);
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -345,6 +360,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
       }
     }
   }
+  float* D = a.D + (long)blockIdx.z * a.slab_stride;
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     const int col = k0 + kb * 16 + fi;
@@ -352,48 +368,109 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int row = n0 + wave * 16 + fq * 4 + r;
       if (row < a.N && col < a.K) {
-        float* d = a.D + (long)row * a.ldd + col;
+        float* d = D + (long)row * a.ldd + col;
         *d = a.accumulate ? (*d + acc[kb][r]) : acc[kb][r];
       }
     }
   }
 }
 
+// D[r, c] (+)= sum_s slabs[s][r*cols + c]
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int nsplit, long slab_stride, float* D,
+                                                           long ldd, int rows, int cols, int accumulate) {
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += slabs[(long)s * slab_stride + e];
+    float* d = D + (long)r * ldd + c;
+    *d = accumulate ? (*d + v) : v;
+  }
+}
+static int reduce_slabs(hipStream_t st, const float* slabs, int nsplit, long slab_stride, float* D, long ldd, int rows,
+                        int cols, int accumulate) {
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, nsplit, slab_stride, D, ldd, rows, cols, accumulate);
+  VLN_CHECK_LAUNCH("reduce_slabs");
+  return VLN_OK;
+}
+
 int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
-            int N, int K, int accumulate) {
+            int N, int K, int accumulate, float* ws, long ws_floats) {
   if (N <= 0 || K <= 0 || Mt < 0) { set_error("gemm_tn: bad dims"); return VLN_ERR_ARG; }
-  GemmTNArgs a{A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, 0, 0};
+  GemmTNArgs a{A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, 0, 0, 0, 0};
   a.avec = aligned16(A) && (lda % 4 == 0);
   a.xvec = aligned16(X) && (ldx % 4 == 0);
-  dim3 grid((K + 63) / 64, (N + 63) / 64), block(256);
+  const int nbk = (K + 63) / 64, nbn = (N + 63) / 64;
+  // small outputs with a long contraction (encoder: Mt = L*B): split the rows over workgroups, slabs + reduce
+  int msplit = 1;
+  if (ws) {
+    msplit = 512 / (nbk * nbn);
+    const int max_by_rows = Mt / 128;
+    if (msplit > max_by_rows) msplit = max_by_rows;
+    const long per = (long)N * K;
+    if ((long)msplit * per > ws_floats) msplit = (int)(ws_floats / per);
+    if (msplit < 1) msplit = 1;
+  }
+  int mchunk = ((Mt + msplit - 1) / msplit + 31) / 32 * 32;
+  if (mchunk < 32) mchunk = 32;
+  msplit = (Mt + mchunk - 1) / mchunk;
+  if (msplit < 1) msplit = 1;
+  a.mchunk = mchunk;
+  if (msplit > 1) { a.D = ws; a.ldd = K; a.slab_stride = (long)N * K; a.accumulate = 0; }
+  dim3 grid(nbk, nbn, msplit), block(256);
   {
     ProfScope prof(st, K_GEMM_TN, 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1)));
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("gemm_tn");
+  if (msplit > 1) return reduce_slabs(st, ws, msplit, (long)N * K, D, ldd, N, K, accumulate);
   return VLN_OK;
 }
 
 // ---------------------------------------------------------------------------
-// colsum: bias gradients
+// colsum: bias gradients.  grid (cols/64, row chunks); chunks > 1 go through the workspace + reduce.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* A, long lda, float* out, int rows, int cols,
-                                                     int accumulate) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* A, long lda, float* out, long out_stride, int rows,
+                                                     int cols, int rchunk, int accumulate) {
   // block = 64 columns x 4 row-lanes; rows strided by 4
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * rchunk, rend = min(rows, rbeg + rchunk);
   float s = 0.f;
   if (c < cols)
-    for (int r = rl; r < rows; r += 4) s += A[(long)r * lda + c];
+    for (int r = rbeg + rl; r < rend; r += 4) s += A[(long)r * lda + c];
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
     float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    out[c] = accumulate ? out[c] + t : t;
+    float* o = out + (long)blockIdx.y * out_stride + c;
+    *o = accumulate ? *o + t : t;
   }
 }
-int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, A, lda, out, rows, cols, accumulate);
+int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,
+           long ws_floats) {
+  const int nbc = (cols + 63) / 64;
+  int rsplit = 1;
+  if (ws) {
+    rsplit = 256 / nbc;
+    if (rsplit > rows / 64) rsplit = rows / 64;
+    if ((long)rsplit * cols > ws_floats) rsplit = (int)(ws_floats / cols);
+    if (rsplit < 1) rsplit = 1;
+  }
+  int rchunk = (rows + rsplit - 1) / rsplit;
+  if (rchunk < 1) rchunk = 1;
+  rsplit = (rows + rchunk - 1) / rchunk;
+  if (rsplit < 1) rsplit = 1;
+  if (rsplit > 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(nbc, rsplit), dim3(256), 0, st, A, lda, ws, (long)cols, rows, cols, rchunk, 0);
+    VLN_CHECK_LAUNCH("colsum");
+    return reduce_slabs(st, ws, rsplit, cols, out, cols, 1, cols, accumulate);
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(nbc, 1), dim3(256), 0, st, A, lda, out, 0L, rows, cols, rchunk, accumulate);
   VLN_CHECK_LAUNCH("colsum");
   return VLN_OK;
 }

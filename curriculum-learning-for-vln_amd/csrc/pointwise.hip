@@ -8,21 +8,36 @@ namespace vln {
 // ---------------------------------------------------------------------------
 // LSTM cell pointwise (torch.nn.LSTMCell semantics, gate order i,f,g,o)
 // ---------------------------------------------------------------------------
+// 256 threads = 64 (row, unit) pairs x 4 gates: each thread sums the split-K slabs of ONE gate (4 independent
+// load streams per wave instead of 4*nsplit dependent loads per thread), the gates meet in LDS.
 __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
+  __shared__ float sg[4][64];
   const long total = (long)a.B * a.H;
   const int H = a.H;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(e / H), j = (int)(e % H);
-    float g[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+  const int pl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long e = base + pl;
+    const bool ok = e < total;
+    const int b = ok ? (int)(e / H) : 0, j = ok ? (int)(e % H) : 0;
+    {
       const int col = q * H + j;
-      float v = 0.f;
-      if (a.bias_a) v += a.bias_a[col];
-      if (a.bias_b) v += a.bias_b[col];
-      for (int s = 0; s < a.nsplit; ++s) v += a.gates[(long)s * a.slab_stride + (long)b * 4 * H + col];
-      g[q] = v;
+      float v0 = 0.f, v1 = 0.f;
+      if (ok) {
+        if (a.bias_a) v0 += a.bias_a[col];
+        if (a.bias_b) v1 += a.bias_b[col];
+        const float* gp = a.gates + (long)b * 4 * H + col;
+        int s = 0;
+        for (; s + 1 < a.nsplit; s += 2) {
+          v0 += gp[(long)s * a.slab_stride];
+          v1 += gp[(long)(s + 1) * a.slab_stride];
+        }
+        if (s < a.nsplit) v0 += gp[(long)s * a.slab_stride];
+      }
+      sg[q][pl] = v0 + v1;
     }
+    __syncthreads();
+    if (q != 0 || !ok) { __syncthreads(); continue; }
+    float g[4] = {sg[0][pl], sg[1][pl], sg[2][pl], sg[3][pl]};
     const float si = sigmoidf_(g[0]), sf = sigmoidf_(g[1]), tg = tanhf(g[2]), so = sigmoidf_(g[3]);
     const float c0 = a.c0[(long)b * a.ldc0 + j];
     const float c1 = sf * c0 + si * tg;
@@ -36,12 +51,13 @@ __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
     }
     if (a.tanh_c1) a.tanh_c1[e] = tc;
     if (a.h1_drop) a.h1_drop[(long)b * a.ldh1d + j] = h1 * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)e, a.drop.p);
+    __syncthreads();   // sg is rewritten by the next grid-stride iteration
   }
 }
 int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a) {
   long total = (long)a.B * a.H;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("lstm_pointwise_fwd");
   return VLN_OK;

@@ -48,10 +48,11 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
 
 // D[N,K] (+)= A[Mt,N]^T * X[Mt,K]   (weight gradients; contraction over rows)
 int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
-            int N, int K, int accumulate);
+            int N, int K, int accumulate, float* ws, long ws_floats);
 
 // out[c] (+)= sum_r A[r*lda + c]
-int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate);
+int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,
+           long ws_floats);
 
 // out = act(sum_s slabs[s] + bias); optional second output out2 = out * dropout mask
 int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_stride, long lds, float* out,

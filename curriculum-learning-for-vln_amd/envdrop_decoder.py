@@ -151,24 +151,25 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""
         H, F, AE = self.hidden_size, self.feature_size, self.action_embed_size
         P = self._gated_params()
-        grads = [torch.zeros_like(p) for p in P]
+        grads = [torch.empty_like(p) for p in P]
         (g_aw, g_ab, g_vin, g_ih, g_hh, g_bih, g_bhh, g_tin, g_tout, g_c) = grads
-        first = True
+        acc = False          # first run overwrites (no memset pass), later runs accumulate
         for bufs, r0, r1 in self._stash.done_runs():
-            acc = not first
             sl = slice(r0, r1)
-            ops.linear_wgrad(bufs["de"][sl], bufs["a"][sl], g_aw, acc or True)
-            ops.colsum(bufs["de"][sl], g_ab, True)
-            ops.linear_wgrad(bufs["dtv"][sl], bufs["hq"][sl], g_vin, True)
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, True)
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, True)
-            ops.colsum(bufs["dgates"][sl], g_bih, True)
-            ops.linear_wgrad(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, True)
-            ops.linear_wgrad(bufs["dz"][sl], bufs["tcat"][sl], g_tout, True)
-            ops.linear_wgrad(bufs["dtc"][sl], bufs["htd"][sl], g_c, True)
-            first = False
-        g_bhh.copy_(g_bih)
+            ops.linear_wgrad(bufs["de"][sl], bufs["a"][sl], g_aw, acc)
+            ops.colsum(bufs["de"][sl], g_ab, acc)
+            ops.linear_wgrad(bufs["dtv"][sl], bufs["hq"][sl], g_vin, acc)
+            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, acc)
+            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, acc)
+            ops.colsum(bufs["dgates"][sl], g_bih, acc)
+            ops.linear_wgrad(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, acc)
+            ops.linear_wgrad(bufs["dz"][sl], bufs["tcat"][sl], g_tout, acc)
+            ops.linear_wgrad(bufs["dtc"][sl], bufs["htd"][sl], g_c, acc)
+            acc = True
         self._gate_consumed()
+        if not acc:          # no decoder step took part in this backward
+            return [None] * len(P)
+        grads[6] = g_bih.clone()   # d b_hh == d b_ih (both biases are added to the same pre-activation)
         return grads
 
     # ---- forward -----------------------------------------------------------------------------------------

@@ -77,8 +77,9 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=x.device)
         accumulate = False
+    ws = workspace(x.device, 1 << 22)
     _lib.check(lib.vln_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), Mt, N, K,
-                                    int(accumulate), _stream()), "vln_linear_wgrad")
+                                    int(accumulate), _p(ws), ws.numel(), _stream()), "vln_linear_wgrad")
     return out
 
 
@@ -89,7 +90,9 @@ def colsum(a, out=None, accumulate=False):
     if out is None:
         out = torch.empty(cols, dtype=torch.float32, device=a.device)
         accumulate = False
-    _lib.check(lib.vln_colsum(_p(a), a.stride(0), _p(out), rows, cols, int(accumulate), _stream()), "vln_colsum")
+    ws = workspace(a.device, 1 << 22)
+    _lib.check(lib.vln_colsum(_p(a), a.stride(0), _p(out), rows, cols, int(accumulate), _p(ws), ws.numel(), _stream()),
+               "vln_colsum")
     return out
 
 

@@ -34,6 +34,9 @@ const char* vln_last_error_string(void);
 /* Optional per-kernel timers (measurement only; the reference has no counterpart): when enabled for a kernel id,
  * every launch of that kernel is bracketed by a hipEvent pair on the launch stream.  vln_prof_read sums and clears
  * them and returns the algorithmic bytes of those launches. */
+/* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
+ * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
+int vln_set_graphs(int on);
 int vln_prof_enable(int kernel_id, int on);
 const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */
 int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_bytes);
@@ -46,8 +49,10 @@ int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_
                    int M, int N, int K, const float* bias, int act, float* ws, int64_t ws_floats, vln_stream_t s);
 /* weight gradient: D[N,K] (+)= A[Mt,N]^T X[Mt,K] (autograd of the same Linear layers, batched over steps) */
 int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd, int Mt,
-                     int N, int K, int accumulate, vln_stream_t s);
-int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, vln_stream_t s);
+                     int N, int K, int accumulate, float* ws, int64_t ws_floats, vln_stream_t s);
+/* bias gradient: out[c] (+)= sum_r A[r, c]; ws (nullable) lets long contractions split over workgroups */
+int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
+               int64_t ws_floats, vln_stream_t s);
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */
 int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K, vln_stream_t s);
 int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols, vln_stream_t s);
