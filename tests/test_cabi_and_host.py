@@ -1,0 +1,148 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vln_hip.h declares (no compute calls -- there
+is no GPU here), the ctypes table covers exactly that set, and the host-side runtime logic (stash arena,
+shadow keys, synthetic tape) behaves."""
+import os
+import re
+import subprocess
+import weakref
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "vln_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vln_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def vln():
+    import vln_amd
+    if not os.path.exists(vln_amd.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return vln_amd
+
+
+def test_header_symbols_are_exported_and_typed(vln):
+    syms = declared_symbols()
+    assert len(syms) >= 25 and "vln_envdrop_step_fwd" in syms and "vln_lstm_seq_bwd" in syms
+    lib = vln._lib.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", vln.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vln_[a-z0-9_]+)", out))
+    missing = [s for s in syms if s not in exported]
+    assert not missing, f"declared in vln_hip.h but not exported: {missing}"
+    untyped = [s for s in syms if s not in vln._lib.SIGNATURES]
+    assert not untyped, f"declared but absent from the ctypes table: {untyped}"
+    stale = [s for s in vln._lib.SIGNATURES if s not in syms]
+    assert not stale, f"ctypes table lists undeclared symbols: {stale}"
+    assert lib.vln_abi_version() >= 1
+    assert lib.vln_prof_kernel_name(0) == b"gemm_nt"
+
+
+def test_struct_layouts_match_header(vln):
+    """The ctypes structs must list the header's fields in the header's order."""
+    txt = open(os.path.join(ROOT, "include", "vln_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+
+    def fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = re.sub(r"^(const\s+)?[a-z0-9_]+\s*\**", "", decl, count=1)
+            out += [n.strip().lstrip("*").strip() for n in names.split(",")]
+        return out
+
+    L = vln._lib
+    assert fields("vln_envdrop_dims") == [f for f, _ in L.EnvDropDims._fields_]
+    assert fields("vln_envdrop_weights") == [f for f, _ in L.EnvDropWeights._fields_]
+    assert fields("vln_envdrop_step") == [f for f, _ in L.EnvDropStep._fields_]
+    assert fields("vln_envdrop_grads") == [f for f, _ in L.EnvDropGrads._fields_]
+
+
+def test_modules_fail_loudly_without_gpu(vln):
+    dec = vln.EnvDropDecoder(64, 0.5, 0.3, 16, 32, 128)
+    B = 2
+    with pytest.raises(vln.VlnError):
+        dec(torch.zeros(B, 32), torch.zeros(B, 36, 128), torch.zeros(B, 3, 128), torch.zeros(B, 64), None,
+            torch.zeros(B, 64), torch.zeros(B, 5, 64))
+    enc = vln.EncoderLSTM(50, 16, 32, 0, 0.5, True, 1)
+    with pytest.raises(vln.VlnError):
+        enc(torch.zeros(B, 5, dtype=torch.long), torch.tensor([5, 3]))
+
+
+def test_state_dict_keys_match_reference_goldens(vln):
+    from conftest import load_golden
+    G = load_golden("envdrop_step")
+    dec = vln.EnvDropDecoder(int(G["cfg"]["H"]), 0.5, 0.3, int(G["cfg"]["AE"]), int(G["cfg"]["ANG"]),
+                             int(G["cfg"]["IMG"]) + int(G["cfg"]["ANG"]))
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == {k: tuple(v.shape) for k, v in G["param"].items()}
+    for name in ("encoder_envdrop", "encoder_follower", "encoder_monitor"):
+        G = load_golden(name)
+        c = G["cfg"]
+        enc = vln.EncoderLSTM(int(c["vocab"]), int(c["E"]), int(c["H"]), 0, 0.5, bool(c["bidir"]), int(c["layers"]))
+        assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == {k: tuple(v.shape) for k, v in G["param"].items()}
+    G = load_golden("critic")
+    assert set(vln.Critic(64, 0.5).state_dict()) == set(G["param"])
+
+
+class _Owner:
+    pass
+
+
+def test_stash_arena(vln):
+    from importlib import import_module
+    rt = vln.runtime
+    st = rt.Stash({"x": 4, "dy": 2}, torch.device("cpu"))
+    st.CHUNK_ROWS = 8
+    o1, o2 = _Owner(), _Owner()
+    r1, r2 = weakref.ref(o1), weakref.ref(o2)
+    a = st.take(3, r1); b = st.take(3, r1); c = st.take(3, r2)      # third block does not fit -> new chunk
+    assert a.chunk is b.chunk and c.chunk is not a.chunk and (a.r0, b.r0, c.r0) == (0, 3, 0)
+    a.view("x").fill_(1.0); b.view("x").fill_(2.0)
+    assert torch.equal(a.chunk.bufs["x"][:6, 0], torch.tensor([1., 1, 1, 2, 2, 2]))
+    # only steps whose backward ran are contracted; adjacent ones merge into one run
+    a.done = True; b.done = True
+    runs = list(st.done_runs())
+    assert [(r0, r1_) for _, r0, r1_ in runs] == [(0, 6)]
+    assert list(st.done_runs()) == []                                # flags are consumed
+    b.done = True; c.done = True
+    assert sorted((r0, r1_) for _, r0, r1_ in st.done_runs()) == [(0, 3), (3, 6)]
+    # chunks whose rollouts died are recycled instead of growing the arena (graphs built but never backpropagated)
+    first = a.chunk
+    del o1
+    d = st.take(8, r2)                                               # forces a new chunk -> reclaims `first`
+    e = st.take(8, r2)
+    assert d.chunk is first or e.chunk is first
+
+
+def test_shadow_key_tracks_optimizer_steps(vln):
+    p = torch.nn.Parameter(torch.zeros(3))
+    k0 = vln.runtime.ShadowSet.key_of([p], torch.float32)
+    with torch.no_grad():
+        p.add_(1.0)
+    assert vln.runtime.ShadowSet.key_of([p], torch.float32) != k0
+    assert vln.runtime.ShadowSet.key_of([p], torch.bfloat16) != vln.runtime.ShadowSet.key_of([p], torch.float32)
+
+
+def test_synthetic_tape_follows_the_obs_contract():
+    import bench
+    t = bench.make_tape(8, 20, 5, 6, seed=1)
+    assert t["tokens"].shape == (8, 20) and t["lengths"][0] == 20
+    assert (t["lengths"][:-1] >= t["lengths"][1:]).all()             # sorted descending (common_env.py:204-205)
+    assert ((t["tokens"] == 0) == t["seq_mask"]).all()
+    for s in t["steps"]:
+        B, C, F = s["cand"].shape
+        assert F == 2176 and s["img"].shape == (8, 36, 2176)
+        n = (~s["cand_mask"]).sum(1)                                 # candidates incl. STOP
+        for i in range(B):
+            assert s["cand"][i, n[i] - 1:].abs().sum() == 0          # STOP slot + padding are zero rows (base.py:152-153)
+            assert s["target"][i] == -1 or 0 <= s["target"][i] < n[i]
+        assert (s["img"][..., :2048] >= 0).all()
+    assert bench.usable_cores() >= 1

@@ -1,0 +1,108 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (stride-sharded episodes + ONE flat-bucket all-reduce +
+global-batch normalisation) must reproduce the single-process big-batch gradient.  The replica math is the CPU
+oracle (the HIP modules need a GPU); GradBucket / stride_shard are the shipped code."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    """A tiny EnvDrop IL batch on the oracle: returns (params, loss_fn(rows) -> summed CE over those rows)."""
+    sys.path.insert(0, ROOT)
+    from oracle import torch_port as O
+    g = torch.Generator().manual_seed(11)
+    B, L, V, C, H, IMG, ANG, AE = 6, 7, 4, 4, 16, 24, 8, 8
+    F = IMG + ANG
+    P = {"act_embed.0.weight": torch.randn(AE, ANG, generator=g) * 0.3, "act_embed.0.bias": torch.zeros(AE),
+         "lstm.weight_ih": torch.randn(4 * H, AE + F, generator=g) * 0.1, "lstm.weight_hh": torch.randn(4 * H, H, generator=g) * 0.1,
+         "lstm.bias_ih": torch.zeros(4 * H), "lstm.bias_hh": torch.zeros(4 * H),
+         "text_attn.linear_in.weight": torch.randn(H, H, generator=g) * 0.2,
+         "text_attn.linear_out.weight": torch.randn(H, 2 * H, generator=g) * 0.2,
+         "visual_attn.linear_in.weight": torch.randn(F, H, generator=g) * 0.2,
+         "cand_attn.weight": torch.randn(F, H, generator=g) * 0.2}
+    P = {k: v.double() for k, v in P.items()}
+    data = dict(a=torch.randn(B, ANG, generator=g).double(), img=torch.randn(B, V, F, generator=g).double().abs(),
+                cand=torch.randn(B, C, F, generator=g).double().abs(), h=torch.randn(B, H, generator=g).double(),
+                c=torch.randn(B, H, generator=g).double(), ctx=torch.randn(B, L, H, generator=g).double(),
+                tgt=torch.tensor([0, 1, 2, 3, 1, -1]))
+
+    def loss_rows(Pm, rows):
+        r = torch.tensor(rows)
+        lo, *_ = O.envdrop_step(Pm, data["a"][r], data["img"][r], data["cand"][r], data["h"][r], data["c"][r],
+                                data["ctx"][r], None)
+        return O.masked_cross_entropy(lo, data["tgt"][r], None, "sum")
+
+    return P, loss_rows, B
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, loss_rows, B = _problem()
+        params = [torch.nn.Parameter(v.clone()) for v in P.values()]
+        Pm = dict(zip(P.keys(), params))
+        bucket = vln.dp.GradBucket(params)
+        bucket.zero()
+        rows = vln.dp.stride_shard(B, rank, world)
+        loss = loss_rows(Pm, rows) * 0.2 / B                 # ML_WEIGHT / GLOBAL batch (envdrop.py:268)
+        loss.backward()
+        assert all(p.grad is v for p, v in zip(bucket.params, bucket.views)), "autograd must accumulate INTO the bucket views"
+        bucket.allreduce()
+        total = vln.dp.allreduce_scalar(torch.tensor([float(len(rows))]))
+        q.put((rank, bucket.flat.clone(), float(total), rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stride_shard_keeps_sorted_batches_sorted():
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    lens = [80, 71, 66, 52, 40, 33, 21, 9]
+    for w in (2, 4, 8):
+        shards = [vln.dp.stride_shard(len(lens), r, w) for r in range(w)]
+        assert sorted(sum(shards, [])) == list(range(len(lens)))
+        for s in shards:
+            ls = [lens[i] for i in s]
+            assert ls == sorted(ls, reverse=True)
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_bucket_allreduce_equals_big_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    P, loss_rows, B = _problem()
+    params = [v.clone().requires_grad_(True) for v in P.values()]
+    Pm = dict(zip(P.keys(), params))
+    (loss_rows(Pm, list(range(B))) * 0.2 / B).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in params])
+    for rank, flat, total, rows in got:
+        assert total == B
+        assert torch.allclose(flat, ref, rtol=1e-10, atol=1e-12), f"rank {rank}: DP gradient != big-batch gradient"
+    assert torch.equal(got[0][1], got[1][1])                 # replicas agree bit-for-bit after the all-reduce
