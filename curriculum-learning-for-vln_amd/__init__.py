@@ -9,5 +9,10 @@ from . import _lib, ops, runtime, dp  # noqa: F401
 from ._lib import VlnError, LIB_PATH  # noqa: F401
 from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401
+from . import functional  # noqa: F401
+from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401
+                       AttnDecoderLSTM, MonitorDecoder)
 
-__all__ = ["_lib", "ops", "runtime", "VlnError", "LIB_PATH", "EncoderLSTM", "EnvDropDecoder", "Critic"]
+__all__ = ["_lib", "ops", "runtime", "dp", "functional", "VlnError", "LIB_PATH", "EncoderLSTM", "EnvDropDecoder",
+           "Critic", "SoftDotAttention", "VisualSoftDotAttention", "ActionScoring", "PositionalEncoding", "MLPwithBN",
+           "AttnDecoderLSTM", "MonitorDecoder"]

@@ -1,0 +1,254 @@
+"""Drop-in attention units and the Speaker-Follower / Self-Monitoring decoders on the HIP operators.
+
+Reference surface reproduced (constructor args, forward signatures, return tuples, state_dict keys):
+  units.py:77-122  SoftDotAttention          units.py:125-160 VisualSoftDotAttention
+  units.py:163-185 ActionScoring             units.py:188-207 PositionalEncoding
+  units.py:210-242 MLPwithBN                 policy.py:15-60  AttnDecoderLSTM
+  policy.py:67-166 MonitorDecoder
+Every Linear / LSTMCell / attention contraction runs in the gfx950 kernels (functional.py); concatenations,
+BatchNorm statistics and a few [B,H]-sized elementwise ops are torch glue in this round.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from . import functional as Fh
+
+
+def _need_gpu(t, who):
+    if not t.is_cuda:
+        raise _lib.VlnError(f"{who}: tensors must be on the GPU; there is no CPU fallback")
+
+
+class _Seeded:
+    """Per-module Philox stream for the dropout sites (offset advances every forward)."""
+
+    def _init_seed(self, seed):
+        self.dropout_seed = seed
+        self._calls = 0
+        self.compute_dtype = torch.float32
+
+    def _next(self):
+        self._calls += 1
+        return self._calls * 16
+
+
+class SoftDotAttention(nn.Module):
+    def __init__(self, query_dim, context_only=False, context_dim=None):
+        super().__init__()
+        self.context_only = context_only
+        ctx_dim = query_dim if context_dim is None else context_dim
+        self.linear_in = nn.Linear(query_dim, ctx_dim, bias=False)
+        if not context_only:
+            self.linear_out = nn.Linear(query_dim + ctx_dim, query_dim, bias=False)
+        self.compute_dtype = torch.float32
+
+    def forward(self, h, context, mask=None):
+        _need_gpu(h, "SoftDotAttention")
+        target = Fh.linear(h, self.linear_in.weight, None, ops.ACT_NONE, self.compute_dtype)
+        wc, attn = Fh.soft_dot_core(target, context, context, mask)
+        if self.context_only:
+            return wc, attn
+        h_tilde = Fh.linear(torch.cat((wc, h), 1), self.linear_out.weight, None, ops.ACT_TANH, self.compute_dtype)
+        return h_tilde, attn
+
+
+class VisualSoftDotAttention(nn.Module):
+    def __init__(self, h_dim, v_dim=None, dot_dim=256):
+        super().__init__()
+        self.linear_in_h = nn.Linear(h_dim, dot_dim, bias=True)
+        self.use_v_linear = v_dim is not None
+        if self.use_v_linear:
+            self.linear_in_v = nn.Linear(v_dim, dot_dim, bias=True)
+        self.compute_dtype = torch.float32
+
+    def forward(self, h, visual_context, mask=None):
+        _need_gpu(h, "VisualSoftDotAttention")
+        target = Fh.linear(h, self.linear_in_h.weight, self.linear_in_h.bias, ops.ACT_NONE, self.compute_dtype)
+        if self.use_v_linear:
+            keys = Fh.linear(visual_context, self.linear_in_v.weight, self.linear_in_v.bias, ops.ACT_NONE, self.compute_dtype)
+        else:
+            keys = visual_context
+        assert keys.shape[-1] == target.shape[-1]
+        return Fh.soft_dot_core(target, keys, visual_context, mask)     # weighted sum over the UN-projected context
+
+
+class ActionScoring(nn.Module):
+    def __init__(self, action_size, hidden_size, dot_size=256):
+        super().__init__()
+        self.linear_act = nn.Linear(action_size, dot_size, bias=True)
+        self.linear_hid = nn.Linear(hidden_size, dot_size, bias=True)
+        self.linear_out = nn.Linear(dot_size, 1, bias=True)
+        self.compute_dtype = torch.float32
+
+    def forward(self, act_cands, h_tilde):
+        dt = self.compute_dtype
+        target = Fh.linear(h_tilde, self.linear_hid.weight, self.linear_hid.bias, ops.ACT_NONE, dt).unsqueeze(1)
+        context = Fh.linear(act_cands, self.linear_act.weight, self.linear_act.bias, ops.ACT_NONE, dt)
+        product = context * target
+        return Fh.linear(product, self.linear_out.weight, self.linear_out.bias, ops.ACT_NONE, torch.float32).squeeze(2)
+
+
+class AttnDecoderLSTM(nn.Module, _Seeded):
+    """policy.py:15-60."""
+
+    def __init__(self, hidden_size, drop_ratio, action_embed_size=2048 + 128, feature_size=2048 + 128,
+                 image_attn_layers=None, compute_dtype=torch.float32):
+        super().__init__()
+        self.action_embed_size, self.feature_size, self.hidden_size = action_embed_size, feature_size, hidden_size
+        self.drop_ratio = float(drop_ratio)
+        self.drop = nn.Dropout(p=drop_ratio)
+        self.lstm = nn.LSTMCell(action_embed_size + feature_size, hidden_size)
+        self.text_attn = SoftDotAttention(hidden_size)
+        self.visual_attn = VisualSoftDotAttention(hidden_size, feature_size)
+        self.decode_action = ActionScoring(action_embed_size, hidden_size)
+        self._init_seed(0xF0110)
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dt):
+        self.compute_dtype = dt
+        for m in (self.text_attn, self.visual_attn, self.decode_action):
+            m.compute_dtype = dt
+
+    def forward(self, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx, ctx_mask=None):
+        _need_gpu(img_feature, "AttnDecoderLSTM")
+        site = self._next()
+        p, tr, seed = self.drop_ratio, self.training, self.dropout_seed
+        # (1) look at the panorama with the previous hidden state: [B,36,F] -> [B,F]
+        pano, view_w = self.visual_attn(h_0, img_feature)
+        # (2) recurrent update on [previous action | attended view]
+        cell_in = Fh.dropout(torch.cat((a_t_prev, pano), 1), p, tr, seed, site)
+        h_new, c_new = Fh.LSTMCellFn.apply(cell_in, h_0, c_0, self.lstm.weight_ih, self.lstm.weight_hh,
+                                           self.lstm.bias_ih, self.lstm.bias_hh, self.compute_dtype)
+        # (3) ground in the instruction, (4) score every candidate against the grounded state
+        grounded, word_w = self.text_attn(Fh.dropout(h_new, p, tr, seed, site + 1), ctx, ctx_mask)
+        return self.decode_action(a_t_cands, grounded), (h_new, c_new), (word_w, view_w)
+
+
+class PositionalEncoding(nn.Module, _Seeded):
+    def __init__(self, d_model, dropout, max_len=80):
+        super().__init__()
+        self.p = float(dropout)
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len).float().unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+        self._init_seed(0x9E)
+
+    def forward(self, x):
+        x = x + self.pe[:, :x.size(1)]
+        return Fh.dropout(x, self.p, self.training, self.dropout_seed, self._next())
+
+
+class _HipLinear(nn.Linear):
+    compute_dtype = torch.float32
+
+    def forward(self, x):
+        return Fh.linear(x, self.weight, self.bias, ops.ACT_NONE, self.compute_dtype)
+
+
+class _PhiloxDropout(nn.Dropout, _Seeded):
+    def __init__(self, p):
+        super().__init__(p)
+        self._init_seed(0xD0)
+
+    def forward(self, x):
+        return Fh.dropout(x, self.p, self.training, self.dropout_seed, self._next())
+
+
+class MLPwithBN(nn.Module):
+    """units.py:210-242 (same Sequential layout -> same state_dict keys `mlp.{i}.*`)."""
+
+    def __init__(self, input_size, hidden_size, out_size=None, dropout=.0, use_bn=False, use_bias=True, relu=True):
+        super().__init__()
+        self.in_size = input_size
+        layers = []
+        if use_bn:
+            layers.append(nn.BatchNorm1d(input_size))
+        dims = [input_size] + list(hidden_size)
+        for i in range(len(dims) - 1):
+            layers.append(_HipLinear(dims[i], dims[i + 1], bias=use_bias))
+            if use_bn:
+                layers.append(nn.BatchNorm1d(dims[i + 1]))
+            if dropout > 0:
+                layers.append(_PhiloxDropout(dropout))
+            if relu:
+                layers.append(nn.ReLU(inplace=True))
+        self.out_size = hidden_size[-1]
+        if out_size:
+            layers.append(_HipLinear(dims[-1], out_size, bias=use_bias))
+            self.out_size = out_size
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class MonitorDecoder(nn.Module, _Seeded):
+    """policy.py:67-166 (co-grounding + progress monitor)."""
+
+    def __init__(self, rnn_hidden_size, drop_ratio, max_enc_len, mlp_dims=(128, 1024), action_embed_size=2048 + 128,
+                 feature_size=2048 + 128, compute_dtype=torch.float32):
+        super().__init__()
+        self.rnn_hidden_size, self.max_enc_len, self.mlp_dims = rnn_hidden_size, max_enc_len, list(mlp_dims)
+        self.feature_size, self.action_embed_size = feature_size, action_embed_size
+        self.img_hidden_size = self.mlp_dims[-1]
+        self.drop_ratio = float(drop_ratio)
+        self.proj_navigable_mlp = MLPwithBN(input_size=action_embed_size, hidden_size=self.mlp_dims, use_bn=True,
+                                            dropout=0.5, use_bias=True, relu=True)
+        self.position = PositionalEncoding(rnn_hidden_size, dropout=0.1, max_len=max_enc_len)
+        self.text_attn = SoftDotAttention(rnn_hidden_size, context_only=True)
+        self.visual_attn = VisualSoftDotAttention(rnn_hidden_size, None, self.img_hidden_size)
+        self.drop = nn.Dropout(p=drop_ratio)
+        self.lstm = nn.LSTMCell(self.img_hidden_size * 2 + rnn_hidden_size, rnn_hidden_size)
+        self.action_linear = nn.Linear(rnn_hidden_size * 2, self.img_hidden_size)
+        self.monitor_linear = nn.Linear(rnn_hidden_size + self.img_hidden_size, rnn_hidden_size, bias=True)
+        self.critic = nn.Sequential(nn.Linear(max_enc_len + rnn_hidden_size, 1), nn.Tanh())
+        self._init_seed(0x5E1F)
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dt):
+        self.compute_dtype = dt
+        for m in self.modules():
+            if m is not self and hasattr(m, "compute_dtype"):
+                m.compute_dtype = dt
+
+    def policy_net(self, weighted_ctx, hidden, cands_rep):
+        """logit[b,c] = cands_rep[b,c,:] . W_a [weighted_ctx ; hidden]      (policy.py:108-117)"""
+        query = Fh.linear(torch.cat((weighted_ctx, hidden), 1), self.action_linear.weight, self.action_linear.bias,
+                          ops.ACT_NONE, self.compute_dtype)
+        return Fh.AttnDotFn.apply(cands_rep, query)
+
+    def progress_monitor(self, h_0, c_1, weighted_cands, ctx_attn, site=None):
+        """tanh(W_c [ctx_attn ; drop(sigmoid(W_m [h_0 ; weighted_cands]) * tanh(c_1))])      (policy.py:119-130)"""
+        site = self._next() if site is None else site
+        gate = Fh.linear(torch.cat((h_0, weighted_cands), 1), self.monitor_linear.weight, self.monitor_linear.bias,
+                         ops.ACT_NONE, self.compute_dtype)
+        mem = Fh.dropout(torch.sigmoid(gate) * torch.tanh(c_1), self.drop_ratio, self.training, self.dropout_seed, site)
+        head = self.critic[0]
+        return Fh.linear(torch.cat((ctx_attn, mem), 1), head.weight, head.bias, ops.ACT_TANH, torch.float32).squeeze()
+
+    def forward(self, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx, ctx_mask=None, candidate_mask=None):
+        _need_gpu(a_t_prev, "MonitorDecoder")
+        site = self._next()
+        B, C, _ = a_t_cands.shape
+        # BN-MLP twice (previous action rows, then all B*C candidate rows incl. padded ones): two sets of batch
+        # statistics and two running-stat updates per step, as in the reference
+        prev_rep = self.proj_navigable_mlp(a_t_prev)
+        cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size)).view(B, C, -1)
+        cand_rep = cand_rep * (~candidate_mask).to(cand_rep.dtype).unsqueeze(2)        # padded slots -> 0
+        # co-grounding: words (position-encoded context) and candidates, both queried by h_0
+        words, word_w = self.text_attn(h_0, self.position(ctx), ctx_mask)
+        moves, move_w = self.visual_attn(h_0, cand_rep, candidate_mask)
+        h_new, c_new = Fh.LSTMCellFn.apply(torch.cat((prev_rep, moves, words), 1), h_0, c_0, self.lstm.weight_ih,
+                                           self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh, self.compute_dtype)
+        logit = self.policy_net(words, Fh.dropout(h_new, self.drop_ratio, self.training, self.dropout_seed, site), cand_rep)
+        progress = self.progress_monitor(h_0, c_new, moves, word_w, site + 1)
+        return (logit, progress), (h_new, c_new), (word_w, move_w)

@@ -87,11 +87,25 @@ class _EncoderFn(torch.autograd.Function):
         p_emb = 0.0 if mod.use_glove else p_drop
         p_inter = p_drop if nl > 1 else 0.0
         grads = {}
+        pmap = dict(mod.named_parameters())
+
+        def put(name, fn, *args):
+            """Form one gradient: straight into an existing contiguous .grad (e.g. a dp.GradBucket view, autograd
+            then gets None) or into a fresh tensor handed to autograd."""
+            p = pmap[name]
+            if not p.requires_grad:
+                return
+            g = p.grad
+            if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                fn(*args, g, True)
+            else:
+                grads[name] = fn(*args)
+
         # decoder_init = tanh(enc2dec(h_t))                                       units.py:69
         if ddec is not None:
             dpre = (ddec * (1.0 - dec_init * dec_init)).contiguous()
-            grads["enc2dec.weight"] = ops.linear_wgrad(dpre, hcat)
-            grads["enc2dec.bias"] = ops.colsum(dpre)
+            put("enc2dec.weight", ops.linear_wgrad, dpre, hcat)
+            put("enc2dec.bias", ops.colsum, dpre)
             dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])
         else:
             dhcat = torch.zeros(B, H, **f32)
@@ -117,11 +131,10 @@ class _EncoderFn(torch.autograd.Function):
             for d in range(dirs):
                 sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
                 dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
-                grads["lstm.weight_hh" + sfx] = ops.linear_wgrad(dg, hprev[d].view(L * B, Hd))
-                grads["lstm.weight_ih" + sfx] = ops.linear_wgrad(dg, x)
-                gb = ops.colsum(dg)
-                grads["lstm.bias_ih" + sfx] = gb
-                grads["lstm.bias_hh" + sfx] = gb.clone()
+                put("lstm.weight_hh" + sfx, ops.linear_wgrad, dg, hprev[d].view(L * B, Hd))
+                put("lstm.weight_ih" + sfx, ops.linear_wgrad, dg, x)
+                put("lstm.bias_ih" + sfx, ops.colsum, dg)
+                put("lstm.bias_hh" + sfx, ops.colsum, dg)     # both biases feed the same pre-activation
             need_dx = (k > 0) or mod.embedding.weight.requires_grad
             if need_dx:
                 dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])
@@ -134,12 +147,15 @@ class _EncoderFn(torch.autograd.Function):
                     else:
                         dy = dx
                 else:
-                    dE = torch.zeros_like(mod.embedding.weight)
+                    ge = mod.embedding.weight.grad
+                    inplace = ge is not None and ge.is_contiguous() and ge.dtype == torch.float32
+                    dE = ge if inplace else torch.zeros_like(mod.embedding.weight)
                     pad = mod.embedding.padding_idx
                     _lib.check(lib.vln_embed_bwd(_p(tokens), _p(lens32), _p(dx), _p(dE), B, L, mod.embed_size,
                                                  -1 if pad is None else pad, seed, offset * 8 + 0, p_emb, _stream()),
                                "vln_embed_bwd")
-                    grads["embedding.weight"] = dE
+                    if not inplace:
+                        grads["embedding.weight"] = dE
         out = [grads.get(n) for n in mod._param_names]
         return (None, None, None, None, None) + tuple(out)
 

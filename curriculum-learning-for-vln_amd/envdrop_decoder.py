@@ -151,26 +151,34 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""
         H, F, AE = self.hidden_size, self.feature_size, self.action_embed_size
         P = self._gated_params()
-        grads = [torch.empty_like(p) for p in P]
-        (g_aw, g_ab, g_vin, g_ih, g_hh, g_bih, g_bhh, g_tin, g_tout, g_c) = grads
-        acc = False          # first run overwrites (no memset pass), later runs accumulate
-        for bufs, r0, r1 in self._stash.done_runs():
-            sl = slice(r0, r1)
-            ops.linear_wgrad(bufs["de"][sl], bufs["a"][sl], g_aw, acc)
-            ops.colsum(bufs["de"][sl], g_ab, acc)
-            ops.linear_wgrad(bufs["dtv"][sl], bufs["hq"][sl], g_vin, acc)
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, acc)
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, acc)
-            ops.colsum(bufs["dgates"][sl], g_bih, acc)
-            ops.linear_wgrad(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, acc)
-            ops.linear_wgrad(bufs["dz"][sl], bufs["tcat"][sl], g_tout, acc)
-            ops.linear_wgrad(bufs["dtc"][sl], bufs["htd"][sl], g_c, acc)
-            acc = True
+        runs = list(self._stash.done_runs())
         self._gate_consumed()
-        if not acc:          # no decoder step took part in this backward
+        if not runs:         # no decoder step took part in this backward
             return [None] * len(P)
-        grads[6] = g_bih.clone()   # d b_hh == d b_ih (both biases are added to the same pre-activation)
-        return grads
+        # Where a parameter already has a (contiguous) .grad -- e.g. a dp.GradBucket view -- the contraction
+        # accumulates straight into it and autograd gets None: no temporary, no extra add pass.
+        tgt, ret, acc0 = [], [], []
+        for p in P:
+            if p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32:
+                tgt.append(p.grad); ret.append(None); acc0.append(True)
+            else:
+                t = torch.empty_like(p)
+                tgt.append(t); ret.append(t); acc0.append(False)
+        (g_aw, g_ab, g_vin, g_ih, g_hh, g_bih, g_bhh, g_tin, g_tout, g_c) = tgt
+        for i, (bufs, r0, r1) in enumerate(runs):
+            sl = slice(r0, r1)
+            a = [x or i > 0 for x in acc0]      # the first run overwrites fresh buffers, everything else accumulates
+            ops.linear_wgrad(bufs["de"][sl], bufs["a"][sl], g_aw, a[0])
+            ops.colsum(bufs["de"][sl], g_ab, a[1])
+            ops.linear_wgrad(bufs["dtv"][sl], bufs["hq"][sl], g_vin, a[2])
+            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, a[3])
+            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, a[4])
+            ops.colsum(bufs["dgates"][sl], g_bih, a[5])
+            ops.colsum(bufs["dgates"][sl], g_bhh, a[6])   # d b_hh == d b_ih (same pre-activation)
+            ops.linear_wgrad(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, a[7])
+            ops.linear_wgrad(bufs["dz"][sl], bufs["tcat"][sl], g_tout, a[8])
+            ops.linear_wgrad(bufs["dtc"][sl], bufs["htd"][sl], g_c, a[9])
+        return ret
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,

@@ -1,0 +1,204 @@
+"""Operator-level autograd bindings over the C ABI (used by the Follower / Self-Monitor decoders and usable on
+their own).  Each Function's forward/backward is a handful of HIP launches; weight shadows (transposed /
+bf16 copies) are cached per parameter version."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+
+
+class _ShadowCache:
+    """param -> {(kind, dtype): tensor}, invalidated when the parameter's version or storage changes."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, w: torch.Tensor, kind: str, dtype) -> torch.Tensor:
+        key = (id(w), kind, dtype)
+        ver = (w._version, w.data_ptr())
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        src = w.detach()
+        if kind == "t":
+            t = ops.transpose_cast(src.contiguous(), dtype)
+        elif dtype == torch.float32:
+            t = src.contiguous()
+        else:
+            t = ops.cast_copy(src.contiguous(), dtype)
+        if len(self._d) > 256:
+            self._d.clear()
+        self._d[key] = (ver, t)
+        return t
+
+
+SHADOWS = _ShadowCache()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) with x [M,K] fp32; act in {none,tanh,relu}.  Replaces F.linear (+ nn.Tanh/ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, dtype):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y = ops.linear_fwd(x2, SHADOWS.get(weight, "n", dtype), None if bias is None else bias.detach(), act)
+        ctx.save_for_backward(x2, weight, y if act != ops.ACT_NONE else None)
+        ctx.act, ctx.dtype, ctx.has_bias, ctx.xshape = act, dtype, bias is not None, x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if ctx.act == ops.ACT_TANH:
+            dy2 = dy2 * (1.0 - y * y)
+        elif ctx.act == ops.ACT_RELU:
+            dy2 = dy2 * (y > 0).to(dy2.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_fwd(dy2, SHADOWS.get(weight, "t", ctx.dtype)).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2)
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act=ops.ACT_NONE, dtype=torch.float32):
+    return LinearFn.apply(x, weight, bias, act, dtype)
+
+
+class AttnDotFn(torch.autograd.Function):
+    """dots[b,s] = keys[b,s,:] . vec[b,:]   (torch.bmm(context, target), units.py:109/150)"""
+
+    @staticmethod
+    def forward(ctx, keys, vec):
+        keys = keys.contiguous()
+        vec = vec.contiguous()
+        ctx.save_for_backward(keys, vec)
+        return ops.attn_dot(keys, vec)
+
+    @staticmethod
+    def backward(ctx, dd):
+        keys, vec = ctx.saved_tensors
+        dd = dd.contiguous()
+        dkeys = dvec = None
+        if ctx.needs_input_grad[1]:
+            dvec = ops.rows_wsum(keys, dd)
+        if ctx.needs_input_grad[0]:
+            dkeys = dd.unsqueeze(2) * vec.unsqueeze(1).to(dd.dtype)
+        return dkeys, dvec
+
+
+class SoftmaxWsumFn(torch.autograd.Function):
+    """attn = softmax(mask(logits)); out[b,:] = sum_s attn[b,s] values[b,s,:]   (units.py:111-117, 152-159)"""
+
+    @staticmethod
+    def forward(ctx, values, logits, mask):
+        values = values.contiguous()
+        out, attn = ops.attn_softmax_wsum(values, logits.contiguous(), mask)
+        ctx.save_for_backward(values, attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        values, attn = ctx.saved_tensors
+        B, S, D = values.shape
+        dalpha = None
+        if dout is not None:
+            dout = dout.contiguous()
+            dalpha = ops.attn_dot(values, dout)
+        dvalues = None
+        need_dv = ctx.needs_input_grad[0] and dout is not None
+        if need_dv:
+            dvalues = torch.zeros(B, S, D, dtype=torch.float32, device=values.device)
+            zero = torch.zeros(B, D, dtype=torch.float32, device=values.device)
+        dattn_c = None if dattn is None else dattn.contiguous()
+        _, dl = ops.attn_bwd(values, attn, dalpha, dattn_c, dout if need_dv else None, zero if need_dv else None,
+                             dvalues, want_dl=True)
+        return dvalues, dl, None
+
+
+def soft_dot_core(query_vec, keys, values, mask):
+    """-> (weighted values [B,Dv], attn [B,S]).  keys may be `values` itself."""
+    logits = AttnDotFn.apply(keys, query_vec)
+    return SoftmaxWsumFn.apply(values, logits, mask)
+
+
+class LSTMCellFn(torch.autograd.Function):
+    """nn.LSTMCell (policy.py:30,96): one fused-weight GEMM [x|h] [W_ih|W_hh]^T + fused 4-gate pointwise."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh, dtype):
+        B, H = h.shape
+        xc = torch.cat((x, h), 1).contiguous()
+        wcat = _fused_lstm_weight(w_ih, w_hh, dtype, False)
+        K = xc.shape[1]
+        ws = ops.workspace(x.device, 16 * B * 4 * H)
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        # slabs -> pointwise sums them
+        y = torch.empty(B, 4 * H, dtype=torch.float32, device=x.device)
+        _lib.check(lib.vln_linear_fwd(xc.data_ptr(), xc.stride(0), wcat.data_ptr(), ops._dt(wcat), wcat.stride(0),
+                                      y.data_ptr(), y.stride(0), B, 4 * H, K, None, 0, ws.data_ptr(), ws.numel(), st),
+                   "vln_linear_fwd")
+        h1, c1, act, tc, _ = ops.lstm_pointwise_fwd(y.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c.detach().contiguous())
+        ctx.save_for_backward(xc, c.detach().contiguous(), act, tc, w_ih, w_hh)
+        ctx.dtype, ctx.kx = dtype, x.shape[1]
+        return h1, c1
+
+    @staticmethod
+    def backward(ctx, dh1, dc1):
+        xc, c0, act, tc, w_ih, w_hh = ctx.saved_tensors
+        dg, dc0 = ops.lstm_pointwise_bwd(None if dh1 is None else dh1.contiguous(), None,
+                                         None if dc1 is None else dc1.contiguous(), act, tc, c0)
+        wcat_t = _fused_lstm_weight(w_ih, w_hh, ctx.dtype, True)
+        dxc = ops.linear_fwd(dg, wcat_t)
+        kx = ctx.kx
+        dwi = ops.linear_wgrad(dg, xc[:, :kx])
+        dwh = ops.linear_wgrad(dg, xc[:, kx:])
+        db = ops.colsum(dg)
+        return dxc[:, :kx], dxc[:, kx:], dc0, dwi, dwh, db, db.clone(), None
+
+
+_fused_cache = {}
+
+
+def _fused_lstm_weight(w_ih, w_hh, dtype, transposed):
+    key = (id(w_ih), id(w_hh), dtype, transposed)
+    ver = (w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr())
+    hit = _fused_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    wc = torch.cat((w_ih.detach(), w_hh.detach()), 1).contiguous()
+    t = ops.transpose_cast(wc, dtype) if transposed else (wc if dtype == torch.float32 else ops.cast_copy(wc, dtype))
+    if len(_fused_cache) > 64:
+        _fused_cache.clear()
+    _fused_cache[key] = (ver, t)
+    return t
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout with the kernels' Philox stream (seed, offset): mask regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        m = ops.dropout_mask(x.numel(), seed, offset, p, x.device).view_as(x)
+        ctx.save_for_backward(m)
+        return x * m
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        return dy * m, None, None, None
+
+
+def dropout(x, p: float, training: bool, seed: int, offset: int):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p, seed, offset)

@@ -1,0 +1,123 @@
+"""GPU: the Speaker-Follower and Self-Monitoring decoders and the attention units (HIP operators through the C ABI)
+against the golden vectors captured from the reference, state_dict loaded strict.  fp32 tolerance 1e-4 (grads 3e-4)."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vln():
+    import vln_amd
+    vln_amd._lib.load()
+    return vln_amd
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    # gradients that are analytically zero (e.g. the bias in front of a train-mode BatchNorm) are pure rounding
+    # noise ~1e-7 on both sides: floor the scale so they compare as absolute errors
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-2)).item()
+
+
+def check(a, b, tol, what):
+    e = rel_err(a, b)
+    assert e < tol, f"{what}: rel err {e:.3e} >= {tol}"
+
+
+def dev(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("tag", ["full", "ctxonly", "visual"])
+def test_softdot_units(vln, tag):
+    G = load_golden("softdot_" + tag)
+    I = dev(G["inp"])
+    Q = I["h"].shape[1]
+    D = I["ctx"].shape[2]
+    att = vln.SoftDotAttention(Q, context_only=(tag != "full"), context_dim=(D if tag == "visual" else None))
+    att.load_state_dict(G["param"], strict=True); att.to(DEV)
+    h = I["h"].clone().requires_grad_(True); ctx = I["ctx"].clone().requires_grad_(True)
+    out, attn = att(h, ctx, None if tag == "visual" else I["mask"])
+    check(out, G["out"]["out"], 1e-4, "out"); check(attn, G["out"]["attn"], 1e-4, "attn")
+    ((out * I["r"]).sum() + (attn * I["ra"]).sum()).backward()
+    for n, p in att.named_parameters():
+        check(p.grad, G["grad"][n], 3e-4, n)
+    check(h.grad, G["grad"]["h"], 3e-4, "dh"); check(ctx.grad, G["grad"]["ctx"], 3e-4, "dctx")
+
+
+@pytest.mark.parametrize("tag", ["follower", "monitor"])
+def test_visualdot_units(vln, tag):
+    G = load_golden("visualdot_" + tag)
+    I = dev(G["inp"])
+    vdim = I["v"].shape[2] if tag == "follower" else None
+    dot = G["param"]["linear_in_h.weight"].shape[0]
+    att = vln.VisualSoftDotAttention(I["h"].shape[1], vdim, dot)
+    att.load_state_dict(G["param"], strict=True); att.to(DEV)
+    h = I["h"].clone().requires_grad_(True); v = I["v"].clone().requires_grad_(True)
+    out, attn = att(h, v, I["mask"] if tag == "monitor" else None)
+    check(out, G["out"]["out"], 1e-4, "out"); check(attn, G["out"]["attn"], 1e-4, "attn")
+    ((out * I["r"]).sum() + (attn * I["ra"]).sum()).backward()
+    for n, p in att.named_parameters():
+        check(p.grad, G["grad"][n], 3e-4, n)
+    check(h.grad, G["grad"]["h"], 3e-4, "dh"); check(v.grad, G["grad"]["v"], 3e-4, "dv")
+
+
+@pytest.mark.parametrize("name", ["follower_step", "follower_chain3"])
+def test_follower_golden(vln, name):
+    G = load_golden(name)
+    cfg, I = G["cfg"], dev(G["inp"])
+    F = int(cfg["IMG"]) + int(cfg["ANG"])
+    dec = vln.AttnDecoderLSTM(int(cfg["H"]), 0.5, action_embed_size=F, feature_size=F)
+    dec.load_state_dict(G["param"], strict=True); dec.to(DEV).eval()
+    ctx = I["ctx"].clone().requires_grad_(True)
+    h = I["h0"].clone().requires_grad_(True); c = I["c0"].clone().requires_grad_(True)
+    h0, c0 = h, c
+    loss = 0.
+    for t in range(int(cfg["steps"])):
+        logit, (h, c), (ac, av) = dec(I[f"img{t}"], I[f"a_prev{t}"], I[f"cand{t}"], h, c, ctx, I["ctx_mask"])
+        check(logit, G["out"][f"logit{t}"], 1e-4, f"logit{t}")
+        check(h, G["out"][f"h1_{t}"], 1e-4, "h1"); check(c, G["out"][f"c1_{t}"], 1e-4, "c1")
+        check(ac, G["out"][f"alpha_c{t}"], 1e-4, "alpha_c"); check(av, G["out"][f"alpha_v{t}"], 1e-4, "alpha_v")
+        loss = loss + (logit * I[f"rl{t}"]).sum()
+    loss = loss + (h * I["rf"]).sum() + (c * I["rc"]).sum()
+    loss.backward()
+    for n, p in dec.named_parameters():
+        check(p.grad, G["grad"][n], 3e-4, f"grad[{n}]")
+    check(ctx.grad, G["grad"]["ctx"], 3e-4, "dctx"); check(h0.grad, G["grad"]["h0"], 3e-4, "dh0"); check(c0.grad, G["grad"]["c0"], 3e-4, "dc0")
+
+
+@pytest.mark.parametrize("name", ["monitor_step_train", "monitor_step_eval"])
+def test_monitor_golden(vln, name):
+    G = load_golden(name)
+    cfg, I = G["cfg"], dev(G["inp"])
+    F = int(cfg["IMG"]) + int(cfg["ANG"])
+    training = bool(cfg["training"])
+    dec = vln.MonitorDecoder(int(cfg["H"]), 0.5, int(cfg["L"]), mlp_dims=[int(cfg["M"])], action_embed_size=F, feature_size=F)
+    dec.load_state_dict(G["param"], strict=True); dec.to(DEV)
+    if training:            # the golden was captured in train mode with every Dropout at p = 0 (BatchNorm batch stats on)
+        dec.train()
+        dec.drop_ratio = 0.0; dec.position.p = 0.0
+        for m in dec.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    else:
+        dec.eval()
+    ctx = I["ctx"].clone().requires_grad_(True)
+    h = I["h0"].clone().requires_grad_(True); c = I["c0"].clone().requires_grad_(True)
+    (logit, prog), (h1, c1), (ca, va) = dec(None, I["a_prev"], I["cand"], h, c, ctx, I["ctx_mask"], I["cand_mask"])
+    for k, v in (("logit", logit), ("prog", prog), ("h1", h1), ("c1", c1), ("ctx_attn", ca), ("cand_attn", va)):
+        check(v, G["out"][k], 1e-4, k)
+    ((logit * I["rl"]).sum() + (prog * I["rp"]).sum() + (h1 * I["rh"]).sum() + (c1 * I["rc"]).sum()).backward()
+    for n, p in dec.named_parameters():
+        check(p.grad, G["grad"][n], 5e-4, f"grad[{n}]")
+    check(ctx.grad, G["grad"]["ctx"], 3e-4, "dctx"); check(h.grad, G["grad"]["h0"], 3e-4, "dh0"); check(c.grad, G["grad"]["c0"], 3e-4, "dc0")
+    if training:            # two running-stat updates per step (previous action rows, then B*C candidate rows)
+        sd = dec.state_dict()
+        for k in ("proj_navigable_mlp.mlp.0.running_mean", "proj_navigable_mlp.mlp.0.running_var",
+                  "proj_navigable_mlp.mlp.2.running_mean", "proj_navigable_mlp.mlp.2.running_var"):
+            check(sd[k], G["param_after"][k], 1e-4, k)
+        assert int(sd["proj_navigable_mlp.mlp.0.num_batches_tracked"]) == 2
