@@ -282,6 +282,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
   }
 }
 
+#include "encoder_persist.h"
+
 // ---- embedding gather (+dropout) to time-major rows, and its scatter-add backward ----------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens, const float* E, float* out, int B,
                                                         int L, int D, DropSpec dr) {
@@ -407,11 +409,78 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
   return VLN_OK;
 }
 
+// ---- persistent single-launch path (encoder_persist.h) ------------------------------------------------------
+int g_persist_enabled = 1;
+extern "C" int vln_set_persistent(int on) { g_persist_enabled = on ? 1 : 0; return VLN_OK; }
+
+static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
+  if (!g_persist_enabled || !sync_ws || g_prof_mask) return false;
+  if (Hd != 128 && Hd != 256 && Hd != 512) return false;
+  const long wgs = (long)(Hd / 16) * dirs * ((B + 15) / 16);
+  if (wgs > 256 || dirs * ((B + 15) / 16) > 32) return false;            // every workgroup must be co-resident
+  if ((long)L * B * dirs * 4 * Hd * 4 >= (1L << 32)) return false;       // 32-bit buffer offsets
+  return true;
+}
+
+template <typename TW>
+static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
+  constexpr int BK = RecCfg<TW>::BK;
+  switch (a.Hd / BK) {
+    case 2: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 2>), grid, dim3(256), 0, st, a, counters, status); break;
+    case 4: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 4>), grid, dim3(256), 0, st, a, counters, status); break;
+    case 8: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 8>), grid, dim3(256), 0, st, a, counters, status); break;
+    case 16: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 16>), grid, dim3(256), 0, st, a, counters, status); break;
+    default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
+  }
+  VLN_CHECK_LAUNCH("lstm_persist_fwd");
+  return VLN_OK;
+}
+
+template <typename TW, int NS>
+static int launch_persist_bwd_ns(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
+  constexpr int HD = NS * RecCfg<TW>::BK;
+  const size_t lds = (size_t)(16 * (4 * HD + 4) + 4 * 16 * 17 + 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel<TW, NS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("persistent lstm bwd: cannot reserve %zu bytes of LDS", lds);
+      return VLN_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NS>), grid, dim3(256), lds, st, a, counters, status);
+  VLN_CHECK_LAUNCH("lstm_persist_bwd");
+  return VLN_OK;
+}
+template <typename TW>
+static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
+  constexpr int BK = RecCfg<TW>::BK;
+  switch (a.Hd / BK) {
+    case 2: return launch_persist_bwd_ns<TW, 2>(st, a, counters, status, grid);
+    case 4: return launch_persist_bwd_ns<TW, 4>(st, a, counters, status, grid);
+    case 8: return launch_persist_bwd_ns<TW, 8>(st, a, counters, status, grid);
+    case 16: return launch_persist_bwd_ns<TW, 16>(st, a, counters, status, grid);
+    default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
+  }
+}
+
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
-                                int L, int Hd, int dirs, vln_stream_t s) {
+                                int L, int Hd, int dirs, void* sync_ws, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
+  if (persist_ok(B, L, Hd, dirs, sync_ws) && al16(w_hh) && al16(hprev)) {
+    hipStream_t st = (hipStream_t)s;
+    int r = fill_f32(st, (float*)sync_ws, 64, 0.f);     // counters [0..31], status word [32]
+    if (r) return r;
+    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1};
+    dim3 grid(Hd / 16, dirs, (B + 15) / 16);
+    unsigned* cw = (unsigned*)sync_ws;
+    return (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw, cw + 32, grid)
+                               : launch_persist_fwd<float>(st, a, cw, cw + 32, grid);
+  }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[10]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat},
                                                  {wtype, B, L, Hd, dirs}};
@@ -440,9 +509,20 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
 
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
-                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, vln_stream_t s) {
+                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, void* sync_ws,
+                                vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
+  if (persist_ok(B, L, Hd, dirs, sync_ws) && al16(w_hh_t) && al16(dgates)) {
+    hipStream_t st = (hipStream_t)s;
+    int r = fill_f32(st, (float*)sync_ws, 64, 0.f);
+    if (r) return r;
+    RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
+    dim3 grid(Hd / 16, dirs, (B + 15) / 16);
+    unsigned* cw = (unsigned*)sync_ws;
+    return (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw, cw + 32, grid)
+                               : launch_persist_bwd<float>(st, a, cw, cw + 32, grid);
+  }
   struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},
                                                 {wtype, B, L, Hd, dirs}};
   static GraphCache cache;

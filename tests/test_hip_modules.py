@@ -224,6 +224,40 @@ def _encoder_full(vln, compute_dtype, tol):
         check(prm.grad, P[n].grad, tol * 3, f"grad[{n}]")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
+    """The single-launch persistent bi-LSTM (in-kernel cross-workgroup hand-off) must reproduce the per-step
+    launch chain bit for bit, forward and backward, and report a clean status word."""
+    lib = vln._lib.load()
+    B, L, E, H, vocab = 64, 80, 256, 512, 992
+    g = torch.Generator().manual_seed(3)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=dtype).to(DEV).train()
+    lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    r = torch.randn(B, L, H, generator=g).to(DEV)
+    outs = []
+    for persistent in (1, 0):
+        lib.vln_set_persistent(persistent)
+        enc._calls = 0                                  # same dropout stream for both runs
+        enc.zero_grad(set_to_none=True)
+        ctx, h, c = enc(tokens.to(DEV), lens)
+        ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
+        torch.cuda.synchronize()
+        if persistent:
+            assert enc.persistent_status() == 0
+        outs.append([ctx.detach().clone(), h.detach().clone(), c.detach().clone()] +
+                    [p.grad.detach().clone() for p in enc.parameters()])
+    lib.vln_set_persistent(1)
+    names = ["ctx", "h", "c"] + [n for n, _ in enc.named_parameters()]
+    for n, a, b in zip(names, *outs):
+        if n in ("ctx", "h", "c"):       # same MFMA order, same pointwise expressions: bit-identical forward
+            assert torch.equal(a, b), n
+        else:                            # backward: the two kernels may contract a*b+c differently (last bit of
+            check(a, b, 2e-5, n)         # dgates) and the embedding scatter-add uses float atomics
+
+
 def test_missing_library_fails_loudly(vln, monkeypatch):
     monkeypatch.setattr(vln._lib, "_lib", None)
     monkeypatch.setattr(vln._lib, "LIB_PATH", "/nonexistent/libvln_hip.so")
