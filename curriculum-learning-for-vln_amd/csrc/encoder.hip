@@ -414,7 +414,7 @@ int g_persist_enabled = 1;
 extern "C" int vln_set_persistent(int on) { g_persist_enabled = on ? 1 : 0; return VLN_OK; }
 
 static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
-  if (!g_persist_enabled || !sync_ws || g_prof_mask) return false;
+  if (!g_persist_enabled || !sync_ws) return false;
   if (Hd != 128 && Hd != 256 && Hd != 512) return false;
   const long wgs = (long)(Hd / 16) * dirs * ((B + 15) / 16);
   if (wgs > 256 || dirs * ((B + 15) / 16) > 32) return false;            // every workgroup must be co-resident
@@ -478,6 +478,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
+    // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
+    ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
     return (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw, cw + 32, grid)
                                : launch_persist_fwd<float>(st, a, cw, cw + 32, grid);
   }
@@ -520,6 +522,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
+    ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
     return (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw, cw + 32, grid)
                                : launch_persist_bwd<float>(st, a, cw, cw + 32, grid);
   }

@@ -1,0 +1,114 @@
+// Per-step feature marshalling ON the device (reference: agent/base.py:141-157, environ/common_env.py:307-308,
+// utils/misc.py:285-317).  The reference gathers 36x2176 floats per episode on the host every step and ships
+// 20 MB (+ candidates) over PCIe; here the whole ResNet feature table (2.9 GB fp32 / 1.5 GB bf16 -- 1 % of the
+// MI355X's 288 GB) stays resident in HBM and a step ships only indices (B viewpoint rows + view indices + the
+// candidates' (row, view, heading, elevation)).  One pass gathers the rows, appends the angle features, applies
+// the environmental feature dropout (policy.py:226-231; same Philox indexing as feat_dropout_inplace) and
+// optionally emits the bf16 copy the attention kernels stream.  16-byte accesses, one workgroup per output row.
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const long long* rows, const int* view_index,
+                                                          const float* angle_table, float* out, bf16_raw* out_lp, int V,
+                                                          int IMG, int ANG, DropSpec dr) {
+  const int r = blockIdx.x;             // output row = b*V + v
+  const int b = r / V, v = r % V;
+  const int F = IMG + ANG;
+  const TT* src = table + ((long)rows[b] * V + v) * IMG;
+  const float* ang = angle_table + ((long)view_index[b] * V + v) * ANG;
+  float* dst = out + (long)r * F;
+  bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
+  for (int c = threadIdx.x * 4; c < F; c += 256 * 4) {
+    float x[4];
+    if (c < IMG) {
+      Elt<TT>::ld4(src + c, x);
+      if (dr.p > 0.f) {
+        float m[4];
+        dropout_scale4(dr.seed, dr.offset, (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
+        x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
+      }
+    } else {
+      Elt<float>::ld4(ang + (c - IMG), x);
+    }
+    Elt<float>::st4(dst + c, x);
+    if (dlp) Elt<bf16_raw>::st4(dlp + c, x);
+  }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, const long long* rows, const int* views,
+                                                           const float* heading, const float* elevation, float* out,
+                                                           bf16_raw* out_lp, int V, int IMG, int ANG, DropSpec dr) {
+  const int r = blockIdx.x;             // output row = b*C + c
+  const int F = IMG + ANG;
+  const long row = rows[r];
+  float* dst = out + (long)r * F;
+  bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
+  const bool empty = row < 0;           // STOP slot / padding: all-zero feature (base.py:152-153)
+  float sh = 0.f, ch = 0.f, se = 0.f, ce = 0.f;
+  if (!empty) { sh = sinf(heading[r]); ch = cosf(heading[r]); se = sinf(elevation[r]); ce = cosf(elevation[r]); }
+  const TT* src = empty ? table : table + (row * V + views[r]) * IMG;
+  const int q = ANG >> 2;               // [sin h]*q [cos h]*q [sin e]*q [cos e]*q   (misc.py:285-293)
+  for (int c = threadIdx.x * 4; c < F; c += 256 * 4) {
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!empty) {
+      if (c < IMG) {
+        Elt<TT>::ld4(src + c, x);
+        if (dr.p > 0.f) {
+          float m[4];
+          dropout_scale4(dr.seed, dr.offset, (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
+          x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int g = (c - IMG + j) / q;
+          x[j] = g == 0 ? sh : (g == 1 ? ch : (g == 2 ? se : ce));
+        }
+      }
+    }
+    Elt<float>::st4(dst + c, x);
+    if (dlp) Elt<bf16_raw>::st4(dlp + c, x);
+  }
+}
+
+}  // namespace vln
+
+using namespace vln;
+
+extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index,
+                               const float* angle_table, float* out, void* out_bf16, int B, int V, int IMG, int ANG,
+                               uint64_t seed, uint64_t offset, float p_feat, vln_stream_t s) {
+  if (!table || !rows || !view_index || !angle_table || !out || B <= 0 || V <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
+    set_error("vln_gather_pano: bad args (IMG and ANG must be multiples of 8)");
+    return VLN_ERR_ARG;
+  }
+  dim3 grid(B * V), block(256);
+  DropSpec dr{seed, offset, p_feat};
+  if (ttype == VLN_BF16)
+    hipLaunchKernelGGL(gather_pano_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+  else
+    hipLaunchKernelGGL(gather_pano_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+  VLN_CHECK_LAUNCH("gather_pano");
+  return VLN_OK;
+}
+
+extern "C" int vln_gather_cands(const void* table, int ttype, const int64_t* rows, const int32_t* views,
+                                const float* heading, const float* elevation, float* out, void* out_bf16, int BC,
+                                int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat, vln_stream_t s) {
+  if (!table || !rows || !views || !heading || !elevation || !out || BC <= 0 || V <= 0 || (IMG & 7) || (ANG & 7) || ANG <= 0 || IMG <= 0) {
+    set_error("vln_gather_cands: bad args (IMG and ANG must be multiples of 8)");
+    return VLN_ERR_ARG;
+  }
+  dim3 grid(BC), block(256);
+  DropSpec dr{seed, offset, p_feat};
+  if (ttype == VLN_BF16)
+    hipLaunchKernelGGL(gather_cands_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+  else
+    hipLaunchKernelGGL(gather_cands_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+  VLN_CHECK_LAUNCH("gather_cands");
+  return VLN_OK;
+}

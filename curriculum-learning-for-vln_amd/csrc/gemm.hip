@@ -451,9 +451,69 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* A, long lda, f
     *o = accumulate ? *o + t : t;
   }
 }
+// aligned fast path: 16 float4 column groups x 16 row lanes, 4 loads in flight per thread
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* A, long lda, float* out, long out_stride, int rows,
+                                                      int cols, int rchunk, int accumulate) {
+  __shared__ float4 part[16][16];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
+  const int rbeg = blockIdx.y * rchunk, rend = min(rows, rbeg + rchunk);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c < cols) {                       // cols % 4 == 0: a float4 never straddles the edge
+    const float* p = A + c;
+    int r = rbeg + rl;
+    for (; r + 48 < rend; r += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (long)r * lda);
+      const float4 b = *reinterpret_cast<const float4*>(p + (long)(r + 16) * lda);
+      const float4 d = *reinterpret_cast<const float4*>(p + (long)(r + 32) * lda);
+      const float4 e = *reinterpret_cast<const float4*>(p + (long)(r + 48) * lda);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += d.x; s2.y += d.y; s2.z += d.z; s2.w += d.w;
+      s3.x += e.x; s3.y += e.y; s3.z += e.z; s3.w += e.w;
+    }
+    for (; r < rend; r += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (long)r * lda);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+  }
+  part[rl][cg] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                             (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x >> 2, e = threadIdx.x & 3, cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += reinterpret_cast<const float*>(&part[k][g])[e];
+      float* o = out + (long)blockIdx.y * out_stride + cc;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
 int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,
            long ws_floats) {
   const int nbc = (cols + 63) / 64;
+  if (aligned16(A) && (lda % 4 == 0) && (cols % 4 == 0)) {
+    int rsplit = 1;
+    if (ws) {
+      rsplit = 512 / nbc;
+      if (rsplit > rows / 64) rsplit = rows / 64;
+      if ((long)rsplit * cols > ws_floats) rsplit = (int)(ws_floats / cols);
+      if (rsplit < 1) rsplit = 1;
+    }
+    int rchunk = ((rows + rsplit - 1) / rsplit + 15) / 16 * 16;
+    rsplit = (rows + rchunk - 1) / rchunk;
+    if (rsplit > 1) {
+      hipLaunchKernelGGL(colsum4_kernel, dim3(nbc, rsplit), dim3(256), 0, st, A, lda, ws, (long)cols, rows, cols, rchunk, 0);
+      VLN_CHECK_LAUNCH("colsum4");
+      return reduce_slabs(st, ws, rsplit, cols, out, cols, 1, cols, accumulate);
+    }
+    hipLaunchKernelGGL(colsum4_kernel, dim3(nbc, 1), dim3(256), 0, st, A, lda, out, 0L, rows, cols, rchunk, accumulate);
+    VLN_CHECK_LAUNCH("colsum4");
+    return VLN_OK;
+  }
   int rsplit = 1;
   if (ws) {
     rsplit = 256 / nbc;

@@ -3,6 +3,7 @@ their own).  Each Function's forward/backward is a handful of HIP launches; weig
 bf16 copies) are cached per parameter version."""
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -20,7 +21,7 @@ class _ShadowCache:
         key = (id(w), kind, dtype)
         ver = (w._version, w.data_ptr())
         hit = self._d.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and hit[2]() is w:      # id() can be recycled: check identity too
             return hit[1]
         src = w.detach()
         if kind == "t":
@@ -31,7 +32,7 @@ class _ShadowCache:
             t = ops.cast_copy(src.contiguous(), dtype)
         if len(self._d) > 256:
             self._d.clear()
-        self._d[key] = (ver, t)
+        self._d[key] = (ver, t, weakref.ref(w))
         return t
 
 
@@ -173,13 +174,13 @@ def _fused_lstm_weight(w_ih, w_hh, dtype, transposed):
     key = (id(w_ih), id(w_hh), dtype, transposed)
     ver = (w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr())
     hit = _fused_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and hit[2]() is w_ih and hit[3]() is w_hh:
         return hit[1]
     wc = torch.cat((w_ih.detach(), w_hh.detach()), 1).contiguous()
     t = ops.transpose_cast(wc, dtype) if transposed else (wc if dtype == torch.float32 else ops.cast_copy(wc, dtype))
     if len(_fused_cache) > 64:
         _fused_cache.clear()
-    _fused_cache[key] = (ver, t)
+    _fused_cache[key] = (ver, t, weakref.ref(w_ih), weakref.ref(w_hh))
     return t
 
 

@@ -1,0 +1,137 @@
+"""Getting per-step inputs into HBM (reference: agent/base.py:114-178 marshalling, `.to(device)` from pageable
+host memory every decoder step).
+
+* `DeviceFeatureStore` -- the MI355X-first layout: the precomputed ResNet table stays resident in HBM (fp32 2.9 GB
+  or bf16 1.5 GB for R2R's 10,567 viewpoints; 288 GB per GPU) and each step sends indices only; one HIP pass
+  gathers rows, appends angle features, applies the feature dropout and emits the bf16 stream copy
+  (`vln_gather_pano` / `vln_gather_cands`).
+* `PinnedStager` -- for callers that keep features on the host: a ring of pinned buffers and a dedicated copy
+  stream so `hipMemcpyAsync` of the next step's features overlaps compute; tensors become valid on the compute
+  stream through an event, the host never blocks on the copy.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+_p = ops._p
+
+
+def loc_embedding_table(angle_size: int = 128, views: int = 36) -> torch.Tensor:
+    """[viewIndex, absView, angle] static panorama angle features (utils/misc.py:296-317): 12 headings x 3
+    elevations 30 degrees apart, heading relative to the current view."""
+    inc = math.pi / 6.0
+    n = angle_size // 4
+    t = np.zeros((views, views, angle_size), np.float32)
+    for vi in range(views):
+        for av in range(views):
+            rel = (av - vi) % 12 + (av // 12) * 12
+            h, e = (rel % 12) * inc, (rel // 12 - 1) * inc
+            t[vi, av] = np.repeat(np.array([math.sin(h), math.cos(h), math.sin(e), math.cos(e)], np.float32), n)
+    return torch.from_numpy(t)
+
+
+class DeviceFeatureStore:
+    def __init__(self, table: torch.Tensor, ids: Optional[Sequence[str]] = None, device="cuda", dtype=torch.float32,
+                 angle_size: int = 128, seed: int = 0xFEA7):
+        """table [N, V, IMG] (host or device); ids[i] = the reference's long_id (scan_viewpoint) of row i."""
+        assert table.dim() == 3
+        self.device = torch.device(device)
+        self.table = table.to(self.device, dtype).contiguous()
+        self.N, self.V, self.IMG = self.table.shape
+        self.ANG = angle_size
+        self.row_of: Dict[str, int] = {k: i for i, k in enumerate(ids)} if ids is not None else {}
+        self.angle_table = loc_embedding_table(angle_size, self.V).to(self.device)
+        self.seed, self._calls = seed, 0
+
+    def _drop(self, p):
+        self._calls += 1
+        return self.seed, self._calls, float(p)
+
+    def gather_pano(self, rows: torch.Tensor, view_index: torch.Tensor, p_feat: float = 0.0, want_bf16: bool = False):
+        """rows int64 [B], view_index int32 [B] (device) -> img_feature [B, V, IMG+ANG] (+ bf16 copy)."""
+        lib = _lib.load()
+        B = rows.shape[0]
+        F = self.IMG + self.ANG
+        out = torch.empty(B, self.V, F, dtype=torch.float32, device=self.device)
+        lp = torch.empty(B, self.V, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        seed, off, p = self._drop(p_feat)
+        _lib.check(lib.vln_gather_pano(_p(self.table), ops._dt(self.table), _p(rows), _p(view_index), _p(self.angle_table),
+                                       _p(out), _p(lp), B, self.V, self.IMG, self.ANG, seed, off, p,
+                                       torch.cuda.current_stream().cuda_stream), "vln_gather_pano")
+        return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
+
+    def gather_cands(self, rows: torch.Tensor, views: torch.Tensor, heading: torch.Tensor, elevation: torch.Tensor,
+                     p_feat: float = 0.0, want_bf16: bool = False):
+        """rows int64 [B,C] (-1 = STOP slot / padding), views int32 [B,C], heading/elevation fp32 [B,C]."""
+        lib = _lib.load()
+        B, C = rows.shape
+        F = self.IMG + self.ANG
+        out = torch.empty(B, C, F, dtype=torch.float32, device=self.device)
+        lp = torch.empty(B, C, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        seed, off, p = self._drop(p_feat)
+        _lib.check(lib.vln_gather_cands(_p(self.table), ops._dt(self.table), _p(rows.contiguous()), _p(views.contiguous()),
+                                        _p(heading.contiguous()), _p(elevation.contiguous()), _p(out), _p(lp), B * C,
+                                        self.V, self.IMG, self.ANG, seed, off, p,
+                                        torch.cuda.current_stream().cuda_stream), "vln_gather_cands")
+        return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
+
+
+class PinnedStager:
+    """Ring of pinned host buffers + a copy stream.  `put(name->array)` returns device tensors that are ordered
+    after the async copy on the CURRENT stream; the slot is recycled `depth` calls later."""
+
+    def __init__(self, device="cuda", depth: int = 3):
+        self.device = torch.device(device)
+        self.depth = depth
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.slots = [dict(host={}, dev={}, free=None) for _ in range(depth)]
+        self.i = 0
+
+    @staticmethod
+    def _fits(t, shape, dtype):
+        return t is not None and t.dtype == dtype and t.numel() >= int(np.prod(shape))
+
+    def put(self, arrays: Dict[str, "np.ndarray | torch.Tensor"]) -> Dict[str, torch.Tensor]:
+        slot = self.slots[self.i]
+        self.i = (self.i + 1) % self.depth
+        cur = torch.cuda.current_stream(self.device)
+        if slot["free"] is not None:
+            if slot.get("released"):
+                slot["free"].synchronize()      # the consumer of this slot (depth calls ago) has finished
+            else:
+                cur.synchronize()               # consumer never called release(): be conservative
+        slot["released"] = False
+        self._last = slot
+        out = {}
+        with torch.cuda.stream(self.copy_stream):
+            for k, a in arrays.items():
+                t = torch.from_numpy(a) if isinstance(a, np.ndarray) else a
+                n = t.numel()
+                h = slot["host"].get(k)
+                if not self._fits(h, t.shape, t.dtype):
+                    h = torch.empty(max(n, 1), dtype=t.dtype).pin_memory()
+                    slot["host"][k] = h
+                    slot["dev"][k] = torch.empty(max(n, 1), dtype=t.dtype, device=self.device)
+                hv = h[:n].view(t.shape)
+                hv.copy_(t)                      # host memcpy into pinned memory
+                dv = slot["dev"][k][:n].view(t.shape)
+                dv.copy_(hv, non_blocking=True)  # hipMemcpyAsync on the copy stream
+                out[k] = dv
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        cur.wait_event(ready)
+        slot["free"] = torch.cuda.Event()
+        return out
+
+    def release(self):
+        """Mark the tensors of the last `put` as consumed at this point of the current stream."""
+        slot = getattr(self, "_last", None)
+        if slot is not None and slot["free"] is not None:
+            slot["free"].record(torch.cuda.current_stream(self.device))
+            slot["released"] = True

@@ -85,6 +85,20 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
 
+/* ---- per-step feature marshalling on the device (agent/base.py:141-157, common_env.py:307-308) -----------------
+ * The ResNet feature table [N_viewpoints, V, IMG] (fp32 or bf16) lives in HBM; a step ships indices only.
+ * vln_gather_pano : out[b,v,:] = [ table[rows[b], v, :] | angle_table[view_index[b], v, :] ]        (BasicR2RAgent._feature_variable)
+ * vln_gather_cands: out[r,:]   = [ table[rows[r], views[r], :] | make_angle_feat(heading[r], elevation[r]) ], rows[r] < 0 ->
+ *                   all-zero STOP/padding slot                                                       (BasicR2RAgent._candidate_variable)
+ * Both apply the EnvDrop feature dropout on the image part when p_feat > 0 (policy.py:226-231; call the decoder with
+ * already_dropfeat=True then) and optionally emit the bf16 copy of the row. */
+int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index, const float* angle_table,
+                    float* out, void* out_bf16, int B, int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat,
+                    vln_stream_t s);
+int vln_gather_cands(const void* table, int ttype, const int64_t* rows, const int32_t* views, const float* heading,
+                     const float* elevation, float* out, void* out_bf16, int BC, int V, int IMG, int ANG, uint64_t seed,
+                     uint64_t offset, float p_feat, vln_stream_t s);
+
 /* ---- EncoderLSTM pieces (units.py:48-74) ------------------------------------------------------------
  * Internal layout is TIME-major: row (t*B + b).  nn.Embedding + Dropout -> vln_embed_fwd; the input projection
  * of all steps is one vln_linear_fwd (M = L*B, bias = b_ih + b_hh); the packed recurrence of one layer (both

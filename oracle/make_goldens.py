@@ -294,6 +294,24 @@ def gen_losses(g):
     save("losses", inp=dict(logits=logits, cand_mask=cmask, target=target, action=act), out=out, grad=grad)
 
 
+def gen_angle_tables():
+    """utils/misc.py:285-317 (make_angle_feat, the 36 static panorama location embeddings) and misc.py:481-486
+    (length2mask).  misc.py imports MatterSim / prettytable at module level: stubbed, never called."""
+    for m in ("MatterSim", "prettytable"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["prettytable"].PrettyTable = object
+    spec = importlib.util.spec_from_file_location("refmisc", "/root/reference/tasks/R2R-judy/src/utils/misc.py")
+    misc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(misc)
+    table = np.stack(misc._static_loc_embeddings)                       # [36 viewIndex, 36 views, 128]
+    hs = np.linspace(-3.0, 3.0, 7).astype(np.float32)
+    es = np.linspace(-0.5, 0.5, 7).astype(np.float32)
+    samples = np.stack([misc.ImageFeatures.make_angle_feat(float(h), float(e)) for h, e in zip(hs, es)])
+    lens = [3, 1, 5, 2]
+    save("angle_feats", out=dict(table=table, samples=samples, mask=misc.length2mask(lens)),
+         inp=dict(headings=hs, elevations=es, lengths=np.array(lens)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -311,6 +329,7 @@ def main():
     gen_monitor(P, g, False, "monitor_step_eval")
     gen_critic(P, g)
     gen_losses(g)
+    gen_angle_tables()
 
 
 if __name__ == "__main__":

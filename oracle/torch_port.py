@@ -319,6 +319,50 @@ def length2mask(lengths: Sequence[int], size: Optional[int] = None) -> Tensor:
     return ar >= torch.as_tensor(list(lengths)).unsqueeze(1)
 
 
+# ---------------------------------------------------------------------------
+# A10  per-step marshalling (agent/base.py:141-157, environ/common_env.py:307-308,
+#      utils/misc.py:285-317): [36 x 2048 view features | 36 x 128 angle features]
+# ---------------------------------------------------------------------------
+def angle_feat(heading: float, elevation: float, feat_size: int = 128) -> Tensor:
+    """[sin h]*n, [cos h]*n, [sin e]*n, [cos e]*n with n = feat_size/4  (misc.py:285-293)."""
+    n = feat_size // 4
+    v = torch.tensor([math.sin(heading), math.cos(heading), math.sin(elevation), math.cos(elevation)], dtype=torch.float32)
+    return v.repeat_interleave(n)
+
+
+def loc_embedding_table(feat_size: int = 128) -> Tensor:
+    """table[viewIndex, absView] = angle feature of view absView seen from viewIndex (misc.py:296-317):
+    12 headings x 3 elevations, 30 degrees apart; heading is relative to the agent's view, elevation absolute."""
+    inc = math.pi / 6.0
+    t = torch.zeros(36, 36, feat_size)
+    for vi in range(36):
+        for av in range(36):
+            rel = (av - vi) % 12 + (av // 12) * 12
+            t[vi, av] = angle_feat((rel % 12) * inc, (rel // 12 - 1) * inc, feat_size)
+    return t
+
+
+def gather_pano(table: Tensor, rows: Tensor, view_index: Tensor, angle_table: Tensor) -> Tensor:
+    """img_feature [B,36,IMG+ANG] = [features of the viewpoint | angle features for the current viewIndex]
+    (common_env.py:307-308 + base.py:141-147)."""
+    return torch.cat((table[rows].float(), angle_table[view_index]), dim=-1)
+
+
+def gather_cands(table: Tensor, rows: Tensor, views: Tensor, heading: Tensor, elevation: Tensor, angle: int = 128) -> Tensor:
+    """cand_feature [B,C,IMG+ANG]; rows[b,c] < 0 marks the STOP slot / padding, which stay all-zero
+    (base.py:149-157; candidate feature = view feature | make_angle_feat(loc heading, loc elevation),
+    common_env.py:272,287-291)."""
+    B, C = rows.shape
+    IMG = table.shape[-1]
+    out = torch.zeros(B, C, IMG + angle)
+    for b in range(B):
+        for c in range(C):
+            if rows[b, c] >= 0:
+                out[b, c, :IMG] = table[rows[b, c], views[b, c]].float()
+                out[b, c, IMG:] = angle_feat(float(heading[b, c]), float(elevation[b, c]), angle)
+    return out
+
+
 def masked_cross_entropy(logits: Tensor, target: Tensor, cand_mask: Optional[Tensor],
                          reduction: str = "none", ignore_index: int = -1) -> Tensor:
     """logits.masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1).

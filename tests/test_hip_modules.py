@@ -137,6 +137,7 @@ def _full_size_envdrop(vln, compute_dtype, tol, T=3, train=True):
     B, L, V, C, H, IMG, ANG, AE = 64, 80, 36, 8, 512, 2048, 128, 64
     F = IMG + ANG
     g = torch.Generator().manual_seed(2020)
+    torch.manual_seed(2020)          # default parameter init comes from the global RNG: pin it (test-order independent)
     dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=compute_dtype).to(DEV)
     dec.train(train)
     P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()}
@@ -208,6 +209,7 @@ def _encoder_full(vln, compute_dtype, tol):
     from oracle import torch_port as O
     B, L, E, H, vocab = 64, 80, 256, 512, 992
     g = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
     enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=compute_dtype).to(DEV).eval()
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
     tokens = torch.zeros(B, L, dtype=torch.long)

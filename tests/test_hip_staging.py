@@ -1,0 +1,76 @@
+"""GPU: per-step input marshalling: the device-resident feature store must reproduce the
+host-side construction of img_feature / cand_feature bit for bit (it is a gather + table lookup), its fused
+feature dropout must use the same Philox stream the decoder would, and the pinned H2D ring must deliver the
+bytes it was given."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vln():
+    import vln_amd
+    vln_amd._lib.load()
+    return vln_amd
+
+
+def _problem(g, N=50, V=36, IMG=2048, B=16, C=7):
+    table = torch.randn(N, V, IMG, generator=g).abs()
+    rows = torch.randint(0, N, (B,), generator=g)
+    vidx = torch.randint(0, 36, (B,), generator=g).int()
+    crow = rows[:, None].repeat(1, C).clone()
+    ncand = torch.randint(1, C, (B,), generator=g)                  # real candidates; slot ncand = STOP, rest padding
+    for b in range(B):
+        crow[b, ncand[b]:] = -1
+    cview = torch.randint(0, 36, (B, C), generator=g).int()
+    head = (torch.rand(B, C, generator=g) - 0.5) * 6
+    elev = (torch.rand(B, C, generator=g) - 0.5)
+    return table, rows, vidx, crow, cview, head, elev
+
+
+@pytest.mark.parametrize("tdt", [torch.float32, torch.bfloat16])
+def test_device_feature_store_matches_host_marshalling(vln, tdt):
+    from oracle import torch_port as O
+    g = torch.Generator().manual_seed(5)
+    table, rows, vidx, crow, cview, head, elev = _problem(g)
+    store = vln.DeviceFeatureStore(table, device=DEV, dtype=tdt)
+    ref_table = table.to(tdt).float()
+    ang = O.loc_embedding_table(128)
+    img, _ = store.gather_pano(rows.to(DEV), vidx.to(DEV))
+    assert torch.equal(img.cpu(), O.gather_pano(ref_table, rows, vidx.long(), ang))
+    cand, lp, _ = store.gather_cands(crow.to(DEV), cview.to(DEV), head.to(DEV), elev.to(DEV), want_bf16=True)
+    ref = O.gather_cands(ref_table, crow, cview.long(), head, elev)
+    assert torch.equal(cand[..., :2048].cpu(), ref[..., :2048])
+    assert (cand[..., 2048:].cpu() - ref[..., 2048:]).abs().max() < 1e-6       # device sinf/cosf vs libm
+    assert torch.equal(lp, cand.bfloat16())
+    for b in range(crow.shape[0]):                                            # STOP slot + padding are all-zero rows
+        assert cand[b][crow[b] < 0].abs().sum().item() == 0.0
+
+
+def test_store_feature_dropout_uses_the_philox_stream(vln):
+    g = torch.Generator().manual_seed(6)
+    table, rows, vidx, *_ = _problem(g, N=20, B=8)
+    store = vln.DeviceFeatureStore(table, device=DEV)
+    clean, _ = store.gather_pano(rows.to(DEV), vidx.to(DEV))
+    dropped, (seed, off) = store.gather_pano(rows.to(DEV), vidx.to(DEV), p_feat=0.3)
+    m = vln.ops.dropout_mask(8 * 36 * 2048, seed, off, 0.3, DEV).view(8, 36, 2048)
+    assert torch.equal(dropped[..., :2048], clean[..., :2048] * m)
+    assert torch.equal(dropped[..., 2048:], clean[..., 2048:])                # angle tail never dropped
+    assert abs((m > 0).float().mean().item() - 0.7) < 0.01
+
+
+def test_pinned_stager_roundtrip_and_reuse(vln):
+    st = vln.PinnedStager(DEV, depth=2)
+    rng = np.random.default_rng(0)
+    for it in range(5):
+        a = rng.standard_normal((64, 36, 2176)).astype(np.float32)
+        t = rng.integers(0, 9, (64,)).astype(np.int64)
+        d = st.put({"img": a, "target": t})
+        s = d["img"].sum() + d["target"].sum()                                # consume on the compute stream
+        st.release()
+        assert torch.equal(d["img"].cpu(), torch.from_numpy(a)) and torch.equal(d["target"].cpu(), torch.from_numpy(t))
+        assert torch.isfinite(s)
+    assert st.slots[0]["host"]["img"].is_pinned()

@@ -160,6 +160,15 @@ def test_losses():
     close(g, G["grad"]["cat"], 1e-5, "dcat")
 
 
+def test_angle_features_and_masks():
+    G = load_golden("angle_feats")
+    table = O.loc_embedding_table(128)
+    close(table, G["out"]["table"], 1e-6, "static location embeddings")
+    for h, e, ref in zip(G["inp"]["headings"].tolist(), G["inp"]["elevations"].tolist(), G["out"]["samples"]):
+        close(O.angle_feat(h, e), ref, 1e-6, "make_angle_feat")
+    assert torch.equal(O.length2mask(G["inp"]["lengths"].tolist()), G["out"]["mask"])
+
+
 def test_length2mask():
     m = O.length2mask([3, 1, 2])
     assert m.tolist() == [[False, False, False], [False, True, True], [False, False, True]]
