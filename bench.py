@@ -106,8 +106,9 @@ class GpuAgent:
         for s in tape["steps"]:
             img, cand = s["img"].clone(), s["cand"].clone()      # fresh per-step feature buffers (mutated in place)
             logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], False)
-            logits.masked_fill_(s["cand_mask"], -float("inf"))
-            ml = ml + Fn.cross_entropy(logits, s["target"], ignore_index=-1, reduction="none").sum()
+            # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum(),
+            # as one fused HIP launch (losses.py)
+            ml = ml + self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "none").sum()
         loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
         loss.backward()
         self.bucket.allreduce()

@@ -1,0 +1,78 @@
+"""Loss / action-selection stage of the rollouts on the HIP path.
+
+The reference does this inline with torch ops every decoder step (follower.py:123-139, envdrop.py:173-195,
+monitor.py:146-176): `logits.masked_fill_(candidate_mask, -inf)`, `CrossEntropyLoss(ignore_index=-1)`,
+`softmax` -> `Categorical.log_prob / entropy`.  The drop-in modules leave that code untouched (it runs on
+PyTorch-ROCm); these functions are the fused alternative: ONE launch forward, ONE backward.
+The A2C sweep (envdrop.py:235-264) is [T,B]-sized arithmetic on these outputs and stays in torch.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+
+_p = ops._p
+
+
+def _mask8(cand_mask):
+    if cand_mask is None:
+        return None
+    m = cand_mask.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, cand_mask, ignore_index):
+        lib = _lib.load()
+        B, C = logits.shape
+        lg = logits.detach().contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+        probs = torch.empty(B, C, dtype=torch.float32, device=logits.device)
+        m8 = _mask8(cand_mask)
+        tgt = target.contiguous()
+        _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), _p(tgt), _p(m8), _p(loss), _p(probs), None, None, None, B, C,
+                                         ignore_index, 0, torch.cuda.current_stream().cuda_stream), "vln_masked_ce_fwd")
+        ctx.save_for_backward(probs, tgt)
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        probs, tgt = ctx.saved_tensors
+        B, C = probs.shape
+        dl = torch.empty_like(probs)
+        _lib.check(_lib.load().vln_masked_ce_bwd(_p(probs), _p(tgt), _p(dloss.contiguous()), _p(dl), B, C, ctx.ignore_index,
+                                                 torch.cuda.current_stream().cuda_stream), "vln_masked_ce_bwd")
+        return dl, None, None, None
+
+
+def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor] = None,
+                         reduction: str = "none", ignore_index: int = -1) -> torch.Tensor:
+    """== `CrossEntropyLoss(ignore_index, reduction)(logits.masked_fill(cand_mask, -inf), target)`.
+    reduction: 'none' ([B], 0 at ignored rows; what SELF-PACE consumes, curriculum.py:296), 'sum', 'mean' (mean over
+    the non-ignored rows, follower.py:62)."""
+    per = _MaskedCE.apply(logits, target, cand_mask, ignore_index)
+    if reduction == "none":
+        return per
+    if reduction == "sum":
+        return per.sum()
+    return per.sum() / (target != ignore_index).sum().to(per.dtype)
+
+
+def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
+    """(probs, log_prob(action), entropy) of Categorical(softmax(masked logits)) with torch.distributions' clamp
+    (envdrop.py:189-194) -- no autograd (sampling / logging); the differentiable A2C terms use torch ops."""
+    lib = _lib.load()
+    B, C = logits.shape
+    lg = logits.detach().contiguous()
+    probs = torch.empty(B, C, dtype=torch.float32, device=logits.device)
+    logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ent = torch.empty(B, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), None, _p(_mask8(cand_mask)), None, _p(probs), _p(action.contiguous()),
+                                     _p(logp), _p(ent), B, C, -1, 0, torch.cuda.current_stream().cuda_stream),
+               "vln_masked_ce_fwd")
+    return probs, logp, ent

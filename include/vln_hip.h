@@ -85,6 +85,17 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
 
+/* ---- loss / action-selection stage of the rollouts (follower.py:123-139, envdrop.py:173-195, monitor.py:146-176):
+ * logits.masked_fill_(cand_mask, -inf) [in place when write_mask], CrossEntropyLoss(ignore_index, reduction="none"),
+ * softmax probabilities and, for a given action, Categorical(probs).log_prob / .entropy() -- one wave per row.
+ * Backward of the CE: dlogits = dloss[b] * (probs - onehot(target)), 0 for ignored rows. */
+int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target /*nullable*/, const uint8_t* cand_mask /*nullable*/,
+                      float* loss /*[B] nullable*/, float* probs /*[B,C] nullable*/, const int64_t* action /*nullable*/,
+                      float* logp /*[B]*/, float* entropy /*[B] nullable*/, int B, int C, int64_t ignore_index, int write_mask,
+                      vln_stream_t s);
+int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, float* dlogits, int B, int C,
+                      int64_t ignore_index, vln_stream_t s);
+
 /* ---- per-step feature marshalling on the device (agent/base.py:141-157, common_env.py:307-308) -----------------
  * The ResNet feature table [N_viewpoints, V, IMG] (fp32 or bf16) lives in HBM; a step ships indices only.
  * vln_gather_pano : out[b,v,:] = [ table[rows[b], v, :] | angle_table[view_index[b], v, :] ]        (BasicR2RAgent._feature_variable)

@@ -62,6 +62,26 @@ def test_store_feature_dropout_uses_the_philox_stream(vln):
     assert abs((m > 0).float().mean().item() - 0.7) < 0.01
 
 
+def test_fused_masked_ce_and_action_stats_golden(vln):
+    """Row A9: the fused CE / Categorical kernel against the golden captured from torch's own ops (what the
+    reference agents call inline)."""
+    from conftest import load_golden
+    G = load_golden("losses")
+    I = {k: v.to(DEV) for k, v in G["inp"].items()}
+    B = I["logits"].shape[0]
+    w = torch.arange(1, B + 1, device=DEV).float()
+    for red in ("none", "sum", "mean"):
+        lg = I["logits"].clone().requires_grad_(True)
+        ce = vln.losses.masked_cross_entropy(lg, I["target"], I["cand_mask"], red)
+        assert torch.allclose(ce.cpu(), G["out"][f"ce_{red}"], rtol=1e-5, atol=1e-6), red
+        (ce * (w if red == "none" else 1.0)).sum().backward()
+        assert torch.allclose(lg.grad.cpu(), G["grad"][f"ce_{red}"], rtol=1e-5, atol=1e-6), red
+    probs, lp, ent = vln.losses.action_stats(I["logits"], I["action"], I["cand_mask"])
+    assert torch.allclose(lp.cpu(), G["out"]["log_prob"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ent.cpu(), G["out"]["entropy"], rtol=1e-5, atol=1e-6)
+    assert probs[I["cand_mask"]].abs().max().item() == 0.0
+
+
 def test_pinned_stager_roundtrip_and_reuse(vln):
     st = vln.PinnedStager(DEV, depth=2)
     rng = np.random.default_rng(0)
