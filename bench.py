@@ -61,7 +61,7 @@ def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
         x[:, IMG:] = angle_feat(n)
         return x
 
-    T_i = torch.randint(4, T + 1, (B,), generator=g)
+    T_i = torch.randint(min(4, T), T + 1, (B,), generator=g)
     T_i[0] = T
     steps = []
     for t in range(T):

@@ -43,8 +43,9 @@ _ws_cache = {}
 
 
 def workspace(device, floats: int) -> torch.Tensor:
-    """Per-device split-K scratch, grown on demand (stream-ordered reuse)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Per-(device, stream) split-K scratch, grown on demand.  Reuse is ordered by the stream it belongs to, so work
+    issued on a side stream never shares scratch with the main stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)

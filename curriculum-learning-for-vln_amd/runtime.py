@@ -214,7 +214,31 @@ class GatedModuleMixin:
         raise NotImplementedError
 
     # -------------------------------------------------------------------------------------------------
+    def prepare(self):
+        """Optional hint, call right after optimizer.step(): refresh the weight shadows NOW on a side stream so the
+        casts/transposes overlap whatever runs next on the main stream (e.g. the instruction encoder).  Forward
+        joins on an event; without this call the refresh happens lazily in forward -- same results either way."""
+        params = self._gated_params()
+        key = ShadowSet.key_of(params, self.compute_dtype)
+        if not params[0].is_cuda or not self._shadow.stale(key):
+            return
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_prep_stream", None)
+        if side is None or side.device != main.device:
+            side = self._prep_stream = torch.cuda.Stream(main.device)
+        side.wait_stream(main)                      # the optimizer updated the masters on the main stream
+        with torch.cuda.stream(side), torch.no_grad():
+            self._refresh_shadows()
+        self._shadow.commit(key)
+        self._gate_outs = None
+        self._shadow_ready = torch.cuda.Event()
+        self._shadow_ready.record(side)
+
     def _ensure_current(self, need_grad: bool):
+        ev = getattr(self, "_shadow_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._shadow_ready = None
         params = self._gated_params()
         key = ShadowSet.key_of(params, self.compute_dtype)
         if self._shadow.stale(key):

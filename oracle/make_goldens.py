@@ -312,6 +312,83 @@ def gen_angle_tables():
          inp=dict(headings=hs, elevations=es, lengths=np.array(lens)))
 
 
+def _import_reference_agents():
+    """`import src.agent` needs six absent third-party modules: stub them in sys.modules (never
+    called on this path) and put tasks/R2R-judy on sys.path.  Reference files are untouched."""
+    class _CN(dict):                       # attribute-style dict: enough for utils/config.py to build its defaults
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+        def clone(self):
+            return self
+
+    stubs = {"MatterSim": {}, "prettytable": {"PrettyTable": object}, "yacs": {}, "yacs.config": {"CfgNode": _CN},
+             "boto3": {}, "botocore": {}, "botocore.exceptions": {"ClientError": Exception},
+             "tensorboardX": {"SummaryWriter": object}}
+    for name, attrs in stubs.items():
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    root = "/root/reference/tasks/R2R-judy"
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import src.agent as A
+    return A
+
+
+class _Tok:
+    word_to_index = {"<PAD>": 0, "<UNK>": 1, "<EOS>": 2, "<BOS>": 3}
+
+    def __init__(self, n):
+        self.n = n
+
+    def vocab_size(self):
+        return self.n
+
+
+def gen_agent_tapes():
+    """Rollout-level goldens (SURVEY §8c last row): the reference's EnvDropAgent.rollout() driven by oracle/fake_env.py,
+    teacher-forced (IL) and sampled (IL + A2C), dropout off.  `torch.Tensor.cpu` is patched to return a clone while
+    capturing: on CPU the reference's `a_t.detach().cpu().numpy()` aliases the CE target and silently drops the
+    STOP rows' gradient; on a GPU `.cpu()` copies, which is the intended semantics."""
+    A = _import_reference_agents()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle.fake_env import FakeR2REnv
+    orig_cpu = torch.Tensor.cpu
+    torch.Tensor.cpu = lambda self, *a, **k: orig_cpu(self, *a, **k).clone()
+    try:
+        cfg = types.SimpleNamespace(ACT_EMB_SIZE=8, WORD_EMB_SIZE=16, HIDDEN_SIZE=32, DROP_RATE=0.5, FEAT_DROP_RATE=0.3,
+                                    ENC_BIDIRECTION=True, ENC_LAYERS=1, ML_WEIGHT=0.2, GAMMA=0.9, RL_NORMALIZE="total")
+        for mode in ("teacher", "sample"):
+            torch.manual_seed(2020)
+            env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+            agent = A.EnvDropAgent(cfg, 8, "/tmp", torch.device("cpu"), env, _Tok(40), episode_len=6)
+            agent.eval()                                               # dropout off; losses are still built
+            sd = {"enc." + k: v.clone() for k, v in agent.encoder.state_dict().items()}
+            sd.update({"dec." + k: v.clone() for k, v in agent.decoder.state_dict().items()})
+            sd.update({"cri." + k: v.clone() for k, v in agent.critic.state_dict().items()})
+            torch.manual_seed(99)
+            agent.rollout(train_ml=True, train_rl=(mode == "sample"), train_cl=False, reset=True, feedback=mode)
+            loss = agent.loss["ml_loss"] + agent.loss["rl_loss"]
+            params = dict([("enc." + n, p) for n, p in agent.encoder.named_parameters()] +
+                          [("dec." + n, p) for n, p in agent.decoder.named_parameters()] +
+                          [("cri." + n, p) for n, p in agent.critic.named_parameters()])
+            gs = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+            grads = {n: (g if g is not None else torch.zeros_like(p)) for (n, p), g in zip(params.items(), gs)}
+            small = {n: g for n, g in grads.items() if g.numel() <= 4096}
+            norms = {n: g.norm() for n, g in grads.items()}
+            out = dict(ml_loss=torch.as_tensor(float(agent.loss["ml_loss"])), rl_loss=torch.as_tensor(float(agent.loss["rl_loss"])),
+                       actions=np.stack(env.actions_log))
+            if mode == "sample":
+                out["total"] = np.array(agent.logs["total"][-1])
+            save(f"agent_envdrop_{mode}", cfg={k: (int(v) if isinstance(v, bool) else v) for k, v in vars(cfg).items()
+                                                if not isinstance(v, str)},
+                 param=sd, out=out, grad=small, gradnorm=norms)
+    finally:
+        torch.Tensor.cpu = orig_cpu
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -330,6 +407,7 @@ def main():
     gen_critic(P, g)
     gen_losses(g)
     gen_angle_tables()
+    gen_agent_tapes()
 
 
 if __name__ == "__main__":

@@ -401,7 +401,7 @@ def a2c_loss(log_probs: Sequence[Tensor], entropies: Sequence[Tensor], values: S
     T = len(rewards)
     B = rewards[0].shape[0]
     R = (~ended).to(last_value.dtype) * last_value.detach()
-    loss = torch.zeros(B, dtype=values[0].dtype)
+    loss = torch.zeros(B, dtype=values[0].dtype, device=values[0].device)
     total = 0.0
     for t in range(T - 1, -1, -1):
         R = R * gamma + rewards[t]

@@ -1,0 +1,66 @@
+"""Rollout-level parity (SURVEY §8c last row, rows A9/A10): the reference's own `EnvDropAgent.rollout()` was driven
+by `oracle/fake_env.py` (`oracle/make_goldens.py::gen_agent_tapes`); the same env + injected actions must give
+the same IL loss, A2C loss, `total` count, chosen actions and parameter gradients
+  * through the CPU oracle (pins oracle/rollout.py + the A2C / CE / marshalling restatements)   [CPU test]
+  * through the HIP drop-in modules on the GPU                                                   [-m gpu test]
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import rollout as R
+from oracle.fake_env import FakeR2REnv
+
+
+def split(P):
+    return ({k[4:]: v for k, v in P.items() if k.startswith("enc.")}, {k[4:]: v for k, v in P.items() if k.startswith("dec.")},
+            {k[4:]: v for k, v in P.items() if k.startswith("cri.")})
+
+
+def compare(res, grads, G, tol, gtol):
+    assert np.array_equal(res["actions"], G["out"]["actions"].numpy())
+    ml = float(torch.as_tensor(res["ml_loss"]).detach())
+    rl = float(torch.as_tensor(res["rl_loss"]).detach())
+    assert abs(ml - float(G["out"]["ml_loss"])) <= tol * max(1.0, abs(float(G["out"]["ml_loss"])))
+    assert abs(rl - float(G["out"]["rl_loss"])) <= tol * max(1.0, abs(float(G["out"]["rl_loss"])))
+    if "total" in G["out"]:
+        assert int(res["total"]) == int(G["out"]["total"])
+    for n, ref in G["gradnorm"].items():
+        got = grads[n].detach().double().cpu().norm().item()
+        assert abs(got - float(ref)) <= gtol * max(float(ref), 1e-3), f"grad norm {n}: {got} vs {float(ref)}"
+    for n, ref in G["grad"].items():
+        g = grads[n].detach().double().cpu()
+        err = (g - ref.double()).abs().max().item()
+        assert err <= gtol * max(ref.abs().max().item(), 1e-3), f"grad {n}: max err {err}"
+
+
+@pytest.mark.parametrize("mode", ["teacher", "sample"])
+def test_oracle_rollout_matches_reference_agent(mode):
+    G = load_golden("agent_envdrop_" + mode)
+    be = R.OracleBackend(*split(G["param"]))
+    env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+    res = R.envdrop_rollout(be, env, mode, 6, inject_actions=G["out"]["actions"].numpy(), train_rl=(mode == "sample"))
+    res["loss"].backward()
+    compare(res, be.named_grads(), G, 1e-5, 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["teacher", "sample"])
+def test_hip_rollout_matches_reference_agent(mode):
+    import vln_amd as vln
+    vln._lib.load()
+    dev = torch.device("cuda:0")
+    G = load_golden("agent_envdrop_" + mode)
+    Pe, Pd, Pc = split(G["param"])
+    enc = vln.EncoderLSTM(40, 16, 32, 0, 0.5, True, 1)
+    dec = vln.EnvDropDecoder(32, 0.5, 0.3, 8, 128, 2176)
+    cri = vln.Critic(32, 0.5)
+    enc.load_state_dict(Pe, strict=True); dec.load_state_dict(Pd, strict=True); cri.load_state_dict(Pc, strict=True)
+    for m in (enc, dec, cri):
+        m.to(dev).eval()
+    be = R.ModuleBackend(enc, dec, cri, dev)
+    env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+    res = R.envdrop_rollout(be, env, mode, 6, inject_actions=G["out"]["actions"].numpy(), train_rl=(mode == "sample"))
+    res["loss"].backward()
+    compare(res, be.named_grads(), G, 1e-4, 5e-4)
