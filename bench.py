@@ -190,8 +190,8 @@ def read_prof(lib, nk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--len", type=int, default=80, dest="L")
@@ -265,9 +265,10 @@ def main():
             top = rows[0]
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes/launch (rocprofv3 --pmc runs)
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived bytes/launch (scripts/pmc_traffic.py)
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(args.dtype, {}).get(top["kernel"])
+                t = json.load(open(tfile)).get(args.dtype, {}).get(top["kernel"])
+                traffic = t["bytes_per_launch"] if t else None
             roofline = dict(bound="hbm", kernel=top["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                             avg_launch_us=round(top["ms"] * 1e3 / top["launches"], 2),

@@ -118,6 +118,28 @@ def test_envdrop_inplace_logit_mask_and_stop(vln):
         check(p.grad, P[n].grad, 2e-4, f"grad[{n}]")
 
 
+def test_no_grad_inference_path_matches_training_graph_path(vln):
+    """Greedy evaluation (BaseAgent.test, feedback="argmax") runs the decoder under no_grad / without building the
+    stash: the plain C call must give the same numbers as the autograd-wrapped one."""
+    G = load_golden("envdrop_chain3")
+    cfg, I = G["cfg"], dev(G["inp"])
+    dec = vln.EnvDropDecoder(int(cfg["H"]), 0.5, 0.3, int(cfg["AE"]), int(cfg["ANG"]), int(cfg["IMG"]) + int(cfg["ANG"]))
+    dec.load_state_dict(G["param"], strict=True); dec.to(DEV).eval()
+    outs = []
+    for grad in (True, False):
+        with torch.set_grad_enabled(grad):
+            h_tilde, c = I["h_tilde0"], I["c0"]
+            seq = []
+            for t in range(3):
+                logit, (h1, c), h_tilde = dec(I[f"a{t}"], I[f"img{t}"].clone(), I[f"cand{t}"].clone(), h_tilde, None, c,
+                                              I["ctx"], I["ctx_mask"])
+                seq += [logit.detach().clone(), h1.detach().clone(), h_tilde.detach().clone()]
+            assert logit.requires_grad == grad
+        outs.append(seq)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_critic_golden(vln):
     G = load_golden("critic")
     I = dev(G["inp"])
