@@ -93,13 +93,13 @@ class GpuAgent:
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
         self.enc.train(); self.dec.train()
-        params = list(self.enc.parameters()) + list(self.dec.parameters())
-        self.bucket = vln.dp.GradBucket(params)
-        self.opt = torch.optim.RMSprop(params, lr=LR)
+        # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
+        # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
+        self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
 
     def iteration(self, tape):
         B = tape["B"]
-        self.bucket.zero()
+        self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
         ml = 0.
@@ -111,9 +111,7 @@ class GpuAgent:
             ml = ml + self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "none").sum()
         loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
         loss.backward()
-        self.bucket.allreduce()
-        torch.nn.utils.clip_grad_norm_(self.enc.parameters(), CLIP)
-        torch.nn.utils.clip_grad_norm_(self.dec.parameters(), CLIP)
+        self.opt.allreduce()
         self.opt.step()
         return loss
 

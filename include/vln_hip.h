@@ -85,6 +85,15 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
 
+/* ---- optimizer step over flat buffers (engine/trainer.py:380-381,423-427): per-group clip_grad_norm (max_norm, torch
+ * semantics, 0 = off) + torch.optim.RMSprop update (alpha, eps, no momentum, not centered).  group_begin: ngroups+1
+ * element offsets (multiples of 4); partial: vln_rmsprop_partial_floats() floats of scratch; norms_out[ngroups] nullable;
+ * grad_scale multiplies every gradient first (e.g. 1/world). */
+int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ngroups);
+int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin, int ngroups,
+                          float* partial, float* norms_out, float lr, float alpha, float eps, float max_norm, float grad_scale,
+                          vln_stream_t s);
+
 /* ---- loss / action-selection stage of the rollouts (follower.py:123-139, envdrop.py:173-195, monitor.py:146-176):
  * logits.masked_fill_(cand_mask, -inf) [in place when write_mask], CrossEntropyLoss(ignore_index, reduction="none"),
  * softmax probabilities and, for a given action, Categorical(probs).log_prob / .entropy() -- one wave per row.

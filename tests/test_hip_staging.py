@@ -82,6 +82,34 @@ def test_fused_masked_ce_and_action_stats_golden(vln):
     assert probs[I["cand_mask"]].abs().max().item() == 0.0
 
 
+def test_fused_rmsprop_clip_matches_torch(vln):
+    """Row N1: parameter trajectories of the fused clip+RMSprop step vs torch.optim.RMSprop + clip_grad_norm_ per
+    group (trainer.py:423-427), 4 steps, one group clipped hard, one not at all; odd sizes exercise the tails."""
+    torch.manual_seed(3)
+    shapes = [[(37, 5), (11,), (64, 33)], [(7,), (129, 3), (2, 2)]]
+    ref = [[torch.nn.Parameter(torch.randn(s, device=DEV)) for s in g] for g in shapes]
+    mine = [[torch.nn.Parameter(p.detach().clone()) for p in g] for g in ref]
+    opt_ref = torch.optim.RMSprop([p for g in ref for p in g], lr=1e-2)
+    opt = vln.optim.FusedRMSprop(mine, lr=1e-2, clip_norm=2.0)
+    for step in range(4):
+        scale = [10.0, 0.01]
+        opt.zero_grad(); opt_ref.zero_grad()
+        for gi, (gr, gm) in enumerate(zip(ref, mine)):
+            for pr, pm in zip(gr, gm):
+                gval = torch.randn_like(pr) * scale[gi]
+                pr.grad = gval.clone()
+                pm.grad.add_(gval)                     # accumulate INTO the flat-bucket view, like autograd does
+        norms = [torch.nn.utils.clip_grad_norm_(g, 2.0) for g in ref]
+        opt_ref.step(); opt.step()
+        assert torch.allclose(opt.norms, torch.stack(norms), rtol=1e-5)
+        for gr, gm in zip(ref, mine):
+            for pr, pm in zip(gr, gm):
+                assert torch.allclose(pm, pr, rtol=2e-5, atol=1e-6), step
+    v0 = mine[0][0]._version
+    opt.step()
+    assert mine[0][0]._version > v0                    # version-keyed weight shadows see the in-place update
+
+
 def test_pinned_stager_roundtrip_and_reuse(vln):
     st = vln.PinnedStager(DEV, depth=2)
     rng = np.random.default_rng(0)
