@@ -22,6 +22,7 @@ int check_hip(hipError_t e, const char* what) {
   return VLN_ERR_HIP;
 }
 int g_graphs_enabled = 1;
+int g_tunable[8] = {512, 1, 0, 0, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {
@@ -57,6 +58,11 @@ void prof_end(hipStream_t st, int kid) {
 using namespace vln;
 
 extern "C" int vln_set_graphs(int on) { g_graphs_enabled = on ? 1 : 0; return VLN_OK; }
+extern "C" int vln_set_tunable(int id, int value) {
+  if (id < 0 || id >= 8) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
+  g_tunable[id] = value;
+  return VLN_OK;
+}
 extern "C" int vln_prof_enable(int kernel_id, int on) {
   if (kernel_id < 0 || kernel_id >= K_COUNT) { set_error("vln_prof_enable: bad kernel id"); return VLN_ERR_ARG; }
   if (on) g_prof_mask |= (1u << kernel_id); else g_prof_mask &= ~(1u << kernel_id);

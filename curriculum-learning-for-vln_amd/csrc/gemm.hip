@@ -215,9 +215,12 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   // its loads in flight: 8.5 vs 12.5 us average per launch in the EnvDrop step, profiles/round1_notes.md.)
   int nsplit = 1;
   if (ws != nullptr) {
-    const int target = 512;
+    const int target = g_tunable[0];                 // workgroups wanted in flight (default 512)
     nsplit = target / (nb * mb);
     if (nsplit > ksteps / 2) nsplit = ksteps / 2;
+    // wide-and-shallow products (N >= 2048 columns, K <= 8 steps: the H->F query projections) already fill 32+
+    // workgroups; splitting them only buys a reduce launch
+    if (g_tunable[1] && nb * mb >= 32 && ksteps <= 8 && nsplit_out == nullptr) nsplit = 1;
     if (nsplit < 1) nsplit = 1;
     long per = (long)M * N;
     if ((long)nsplit * per > ws_floats) nsplit = (int)(ws_floats / per);

@@ -13,6 +13,9 @@ void set_error(const char* fmt, ...);
 const char* get_error();
 int check_hip(hipError_t e, const char* what);
 
+// run-time tunables (vln_set_tunable): [0] gemm_nt workgroups-in-flight target, [1] no-split rule for wide shallow GEMMs
+extern int g_tunable[8];
+
 // ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------
 enum KernelId {
   K_GEMM_NT = 0, K_GEMM_TN, K_ATTN_DOT, K_ATTN_WSUM, K_ATTN_BWD, K_LSTM_REC_FWD, K_LSTM_REC_BWD, K_FEAT_DROPOUT,

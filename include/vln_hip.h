@@ -37,6 +37,9 @@ const char* vln_last_error_string(void);
 /* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
  * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
 int vln_set_graphs(int on);
+/* performance tunables (never change results beyond summation order): 0 = gemm split-K workgroup target (512),
+ * 1 = keep wide shallow products unsplit (1) */
+int vln_set_tunable(int id, int value);
 int vln_prof_enable(int kernel_id, int on);
 const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */
 int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_bytes);

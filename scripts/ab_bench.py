@@ -1,5 +1,5 @@
 """Interleaved A/B timing of training-iteration variants in ONE process (cdna guide rule 24: separate invocations and
-separate boxes differ by >10 %).  Usage: python scripts/ab_bench.py [rounds]"""
+separate boxes differ by >10 %).  Usage: python scripts/ab_bench.py [rounds] [bf16|fp32]"""
 import statistics
 import sys
 import time
@@ -11,42 +11,43 @@ import vln_amd as vln
 
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
 tape = bench.tape_to(bench.make_tape(64, 80, 7, 8, 2020), dev)
 lib = vln._lib.load()
 
+# name -> (persistent, graphs, tunable0 (split target), tunable1 (no-split rule))
+VARIANTS = {
+    "base": (1, 1, 512, 1),
+    "split_rule_off": (1, 1, 512, 0),
+    "target256": (1, 1, 256, 1),
+    "target768": (1, 1, 768, 1),
+    "per_step_lstm": (0, 1, 512, 1),
+    "no_graphs_no_persist": (0, 0, 512, 1),
+}
+torch.manual_seed(0)
+agent = bench.GpuAgent(vln, dev, dtype, 1)
 
-def make(name):
-    torch.manual_seed(0)
-    ag = bench.GpuAgent(vln, dev, torch.bfloat16, 1)
-    it = ag.iteration
-    if name == "prepare":
-        def it2(t, _it=it, _ag=ag):
-            r = _it(t); _ag.dec.prepare(); return r
-        return ag, it2
-    if name == "overlap_wgrads":
-        ag.dec.overlap_wgrads = True
-    return ag, it
+
+def configure(cfg):
+    lib.vln_set_persistent(cfg[0]); lib.vln_set_graphs(cfg[1]); lib.vln_set_tunable(0, cfg[2]); lib.vln_set_tunable(1, cfg[3])
 
 
-variants = {n: make(n) for n in ("base", "prepare", "overlap_wgrads", "per_step_lstm", "no_graphs")}
-times = {n: [] for n in variants}
-for n, (ag, it) in variants.items():
+times = {n: [] for n in VARIANTS}
+for n, cfg in VARIANTS.items():
+    configure(cfg)
     for _ in range(3):
-        it(tape)
+        agent.iteration(tape)
 torch.cuda.synchronize()
 for r in range(rounds):
-    for n, (ag, it) in variants.items():
-        lib.vln_set_persistent(0 if n == "per_step_lstm" else 1)
-        lib.vln_set_graphs(0 if n == "no_graphs" else 1)
-        if n == "no_graphs":
-            lib.vln_set_persistent(0)
-        it(tape)
+    for n, cfg in VARIANTS.items():
+        configure(cfg)
+        agent.iteration(tape)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            it(tape)
+            agent.iteration(tape)
         torch.cuda.synchronize()
         times[n].append((time.perf_counter() - t0) / 10 * 1e3)
-lib.vln_set_persistent(1); lib.vln_set_graphs(1)
+configure(VARIANTS["base"])
 for n, v in times.items():
-    print(f"{n:16s} median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
+    print(f"{n:22s} median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
