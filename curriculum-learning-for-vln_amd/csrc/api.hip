@@ -22,7 +22,9 @@ int check_hip(hipError_t e, const char* what) {
   return VLN_ERR_HIP;
 }
 int g_graphs_enabled = 1;
-int g_tunable[8] = {512, 1, 0, 0, 0, 0, 0, 0};
+// [0] = 256: interleaved A/B (scripts/ab_bench.py) shows 256/512/768 within noise in time; 256 halves the split-K
+// slab traffic (PMC), so it wins on bytes
+int g_tunable[8] = {256, 1, 0, 0, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {

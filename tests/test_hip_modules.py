@@ -140,6 +140,50 @@ def test_no_grad_inference_path_matches_training_graph_path(vln):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ragged_and_unaligned_shapes(vln, dtype):
+    """Edge cases: batch not a multiple of the 16-row MFMA block, hidden size not a multiple of 16, a single
+    candidate (only the STOP slot), instructions longer than one wave (L > 64), length-1 instructions, unaligned
+    feature sizes -- every kernel's guarded / scalar path, encoder (2 layers, per-step recurrence) + EnvDrop step."""
+    from oracle import torch_port as O
+    B, L, V, C, H, IMG, ANG, AE, E, vocab = 5, 70, 7, 1, 40, 72, 24, 12, 20, 30
+    F = IMG + ANG
+    g = torch.Generator().manual_seed(17)
+    torch.manual_seed(17)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 2, compute_dtype=dtype).to(DEV).eval()
+    dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=dtype).to(DEV).eval()
+    lens = torch.tensor([70, 33, 9, 2, 1])
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    mask = tokens == 0
+    a = torch.sin(torch.randn(B, ANG, generator=g)); img = torch.randn(B, V, F, generator=g).abs()
+    cand = torch.zeros(B, C, F)                                      # the only candidate is STOP: an all-zero row
+    ctx, h, c = enc(tokens.to(DEV), lens)
+    logit, (h1, c1), ht = dec(a.to(DEV), img.to(DEV), cand.to(DEV), h, None, c, ctx, mask.to(DEV))
+    assert logit.shape == (B, 1) and logit.abs().max().item() == 0.0  # STOP logit is exactly 0
+    r = torch.randn(B, H, generator=g)
+    ((ht * r.to(DEV)).sum() + c1.sum() + (ctx ** 2).sum() * 0.01).backward()
+    Pe = {k: v.detach().cpu().double().requires_grad_(True) for k, v in enc.state_dict().items()}
+    Pd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()}
+    cx, ho, co = O.encoder_forward(Pe, tokens, lens.tolist(), num_layers=2, bidirectional=True)
+    imo = img.double() if dtype == torch.float32 else img.bfloat16().double()
+    lo, (h1o, c1o), hto, _ = O.envdrop_step(Pd, a.double(), imo, cand.double(), ho, co, cx, mask)
+    ((hto * r.double()).sum() + c1o.sum() + (cx ** 2).sum() * 0.01).backward()
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    check(ctx, cx, tol, "ctx"); check(ht, hto, tol, "h_tilde"); check(c1, c1o, tol, "c1")
+    for mod, src in ((enc, Pe), (dec, Pd)):
+        for n, p in mod.named_parameters():
+            if p.grad is None:                                        # cand_attn gets no gradient from this loss
+                assert src[n].grad is None or src[n].grad.abs().max().item() == 0.0, n
+                continue
+            ref = src[n].grad if src[n].grad is not None else torch.zeros_like(src[n])
+            if ref.abs().max().item() < 1e-12:
+                assert p.grad.abs().max().item() < 1e-6, n
+            else:
+                check(p.grad, ref, tol * 3, f"grad[{n}]")
+
+
 def test_critic_golden(vln):
     G = load_golden("critic")
     I = dev(G["inp"])
