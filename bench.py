@@ -38,7 +38,12 @@ LR = 1e-4                  # envdrop_config.yaml:19
 
 
 def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
-    """Synthetic episode batch (BASELINE.md §3 / SURVEY.md §8d), CPU tensors."""
+    """Synthetic episode batch (BASELINE.md §3 / SURVEY.md §8d), CPU tensors.  Features are defined the way the
+    reference's environment builds them (common_env.py:272,287-291,307-308): a per-viewpoint ResNet table
+    [T*B viewpoints, 36 views, 2048] (post-ReLU, non-negative), the agent's viewIndex selecting the static angle
+    table, and each candidate = (view of the current panorama, its relative heading/elevation).  The explicit
+    img/cand tensors of every step are materialised from those for the tensor path and the CPU baseline."""
+    import math
     g = torch.Generator().manual_seed(seed)
     F = IMG + ANG
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values
@@ -50,38 +55,49 @@ def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
         tokens[i, n - 1] = 2                                    # <EOS>
     seq_mask = tokens == 0
 
-    def angle_feat(n):
-        h = torch.rand(n, generator=g) * 6.283 - 3.1415
-        e = (torch.rand(n, generator=g) - 0.5) * 1.04
-        return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], 1).repeat(1, ANG // 4)
+    def angle_feat(h, e):                                       # utils/misc.py:285-293
+        return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], -1).repeat_interleave(ANG // 4, dim=-1)
 
-    def feats(n):
-        x = torch.empty(n, F)
-        x[:, :IMG] = torch.randn(n, IMG, generator=g).abs() * 0.5  # post-ReLU pool5: non-negative
-        x[:, IMG:] = angle_feat(n)
-        return x
+    import vln_amd
+    loc_table = vln_amd.staging.loc_embedding_table(ANG, V)    # static location embeddings [V, V, ANG], misc.py:296-317
 
+    table = torch.randn(T * B, V, IMG, generator=g).abs() * 0.5
     T_i = torch.randint(min(4, T), T + 1, (B,), generator=g)
     T_i[0] = T
     steps = []
     for t in range(T):
+        rows = torch.arange(B) + t * B
+        vidx = torch.randint(0, V, (B,), generator=g).int()
         ncand = torch.randint(3, C_max + 1, (B,), generator=g)      # candidates incl. the STOP slot
         Ct = int(ncand.max())
-        cand = feats(B * Ct).view(B, Ct, F)
         cmask = torch.arange(Ct)[None, :] >= ncand[:, None]
-        for i in range(B):
-            cand[i, ncand[i] - 1:] = 0                              # STOP slot + padding are zero rows
+        real = torch.arange(Ct)[None, :] < (ncand - 1)[:, None]     # STOP slot + padding are all-zero rows
+        crow = torch.where(real, rows[:, None].expand(B, Ct), torch.full((B, Ct), -1))
+        cview = torch.randint(0, V, (B, Ct), generator=g).int()
+        chead = (torch.rand(B, Ct, generator=g) - 0.5) * 6.0
+        celev = (torch.rand(B, Ct, generator=g) - 0.5) * 1.04
+        img = torch.cat((table[rows], loc_table[vidx.long()]), -1)
+        cand = torch.cat((table[rows[:, None].expand(B, Ct), cview.long()], angle_feat(chead, celev)), -1) * real[..., None]
         ended = t >= T_i
         tgt = torch.where(t == T_i - 1, ncand - 1, (torch.rand(B, generator=g) * (ncand - 1).float()).long())
         tgt = torch.where(ended, torch.full_like(tgt, -1), tgt)
-        steps.append(dict(img=feats(B * V).view(B, V, F), cand=cand, cand_mask=cmask, angle=angle_feat(B), target=tgt))
-    return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
+        ah = torch.rand(B, generator=g) * 6.283 - 3.1415
+        steps.append(dict(img=img, cand=cand, cand_mask=cmask, angle=angle_feat(ah, torch.zeros(B)), target=tgt, rows=rows,
+                          vidx=vidx, crow=crow, cview=cview, chead=chead, celev=celev))
+    return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, table=table, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
 
 
-def tape_to(tape, dev):
-    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k != "steps"}
+def tape_to(tape, dev, store_dtype=None):
+    """Device copy.  With `store_dtype` the ResNet table becomes a resident DeviceFeatureStore and the per-step img/cand
+    tensors are NOT uploaded (a step only needs its index vectors)."""
+    skip = ("steps", "table")
+    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k not in skip}
     out["lengths32"] = tape["lengths"].to(dev, torch.int32)
-    out["steps"] = [{k: v.to(dev) for k, v in s.items()} for s in tape["steps"]]
+    drop = ("img", "cand") if store_dtype is not None else ()
+    out["steps"] = [{k: v.to(dev) for k, v in s.items() if k not in drop} for s in tape["steps"]]
+    if store_dtype is not None:
+        import vln_amd
+        out["store"] = vln_amd.DeviceFeatureStore(tape["table"], device=dev, dtype=store_dtype, angle_size=tape["ANG"])
     return out
 
 
@@ -89,13 +105,29 @@ class GpuAgent:
     """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
 
     def __init__(self, vln, dev, dtype, world):
-        self.vln, self.world = vln, world
+        self.vln, self.world, self.dtype = vln, world, dtype
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
         self.enc.train(); self.dec.train()
         # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
         # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
         self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
+
+    def step_features(self, tape, s):
+        """Per-step marshalling (agent/base.py:141-157 + the EnvDrop feature dropout, policy.py:226-231).
+        store path: ONE gather pass per tensor from the HBM-resident table (indices in, dropped features + bf16 stream
+        copy out); tensor path: fresh copies of pre-built feature tensors, the decoder applies the dropout in place."""
+        store = tape.get("store")
+        if store is None:
+            return s["img"].clone(), s["cand"].clone(), {}
+        lp = self.dtype != torch.float32
+        pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
+        r1 = store.gather_pano(s["rows"], s["vidx"], pf, want_bf16=lp)
+        r2 = store.gather_cands(s["crow"], s["cview"], s["chead"], s["celev"], pf, want_bf16=lp)
+        kw = dict(already_dropfeat=True)
+        if lp:
+            kw.update(img_lp=r1[1], cand_lp=r2[1])
+        return r1[0], r2[0], kw
 
     def iteration(self, tape):
         B = tape["B"]
@@ -104,8 +136,8 @@ class GpuAgent:
         h_tilde = h_t
         ml = 0.
         for s in tape["steps"]:
-            img, cand = s["img"].clone(), s["cand"].clone()      # fresh per-step feature buffers (mutated in place)
-            logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], False)
+            img, cand, kw = self.step_features(tape, s)
+            logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], **kw)
             # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum(),
             # as one fused HIP launch (losses.py)
             ml = ml + self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "none").sum()
@@ -197,6 +229,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--features", default="store", choices=["store", "tensor"],
+                    help="store: ResNet table resident in HBM, a step ships indices (DeviceFeatureStore); "
+                         "tensor: pre-built per-step feature tensors, cloned each step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="(testing) map every rank to cuda:0")
@@ -221,7 +256,7 @@ def main():
     torch.manual_seed(2020)
     agent = GpuAgent(vln, dev, dtype, world)
     tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
-    tape = tape_to(tape_cpu, dev)
+    tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None))
 
     def barrier():
         if world > 1:
@@ -305,7 +340,7 @@ def main():
             "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}",
+            "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu}))

@@ -33,7 +33,7 @@ class EnvDropStep(C.Structure):
     _fields_ = ([(n, ptr) for n in ("a_prev", "img", "cand", "img_lp", "cand_lp", "h_tilde_prev", "c0", "ctx",
                                     "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
                                     "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd")]
-                + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32),
+                + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
                    ("ws", ptr), ("ws_floats", i64)])
 
 

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
   const int len = live ? a.lengths[b] : 0;
   float hreg = 0.f, creg = 0.f;
   __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, (unsigned)((long)a.dirs * L * B * HD * 4), 0x00020000);
+  __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();
 
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
   float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
   __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(a.dgates, 0, (unsigned)((long)L * B * G * 4), 0x00020000);
+  __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();
 

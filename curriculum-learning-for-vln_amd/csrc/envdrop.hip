@@ -157,8 +157,10 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep");
   // (2) environmental feature dropout, in place                policy.py:226-231
-  RUN(feat_dropout_inplace(st, io->img, W_F32, (long)B * d->V, d->IMG, d->ANG, site(io, 4, pf), lp ? io->img_lp : nullptr));
-  RUN(feat_dropout_inplace(st, io->cand, W_F32, (long)B * d->C, d->IMG, d->ANG, site(io, 5, pf), lp ? io->cand_lp : nullptr));
+  // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)
+  const bool need_copy = lp && !io->lp_ready;
+  RUN(feat_dropout_inplace(st, io->img, W_F32, (long)B * d->V, d->IMG, d->ANG, site(io, 4, pf), need_copy ? io->img_lp : nullptr));
+  RUN(feat_dropout_inplace(st, io->cand, W_F32, (long)B * d->C, d->IMG, d->ANG, site(io, 5, pf), need_copy ? io->cand_lp : nullptr));
   const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;

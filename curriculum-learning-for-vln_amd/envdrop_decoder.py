@@ -205,9 +205,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,
-                already_dropfeat=False):
+                already_dropfeat=False, img_lp=None, cand_lp=None):
         """Same contract as policy.py:208-246 (h_0 is unused there too).  img_feature / cand_feature are
-        overwritten in place by the feature dropout, like the reference."""
+        overwritten in place by the feature dropout, like the reference.  Extension (optional): `img_lp` / `cand_lp`
+        = bf16 copies of the two feature tensors already produced by `DeviceFeatureStore.gather_*` (together with
+        `already_dropfeat=True`): the decoder then skips its own dropout/copy pass over the features."""
         if not img_feature.is_cuda:
             raise _lib.VlnError("EnvDropDecoder: tensors must be on the GPU; there is no CPU fallback")
         B, V, F = img_feature.shape
@@ -262,8 +264,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         io = _lib.EnvDropStep()
         io.a_prev, io.img, io.cand = a_ptr, img.data_ptr(), cand.data_ptr()
         if lp:
-            keep["img_lp"] = torch.empty(B, V, F, dtype=dt, device=dev)
-            keep["cand_lp"] = torch.empty(B, Cn, F, dtype=dt, device=dev)
+            ready = already_dropfeat and img_lp is not None and cand_lp is not None and img_lp.dtype == dt and \
+                cand_lp.dtype == dt and img_lp.is_contiguous() and cand_lp.is_contiguous()
+            keep["img_lp"] = img_lp if ready else torch.empty(B, V, F, dtype=dt, device=dev)
+            keep["cand_lp"] = cand_lp if ready else torch.empty(B, Cn, F, dtype=dt, device=dev)
+            io.lp_ready = int(bool(ready))
             keep["ctx_lp"] = self._ctx_lp(entry, ctx, dt)
             io.img_lp, io.cand_lp, io.ctx_lp = keep["img_lp"].data_ptr(), keep["cand_lp"].data_ptr(), keep["ctx_lp"].data_ptr()
         io.h_tilde_prev, io.c0, io.ctx = htp.data_ptr(), c0.data_ptr(), ctxc.data_ptr()

@@ -207,6 +207,7 @@ typedef struct vln_envdrop_step {
   uint64_t seed, offset; /* site k of this step uses Philox offset = offset*8 + k */
   float p_drop, p_feat;
   int already_dropfeat;
+  int lp_ready;          /* 1: img_lp / cand_lp were filled by the caller (e.g. vln_gather_*): skip the copy pass */
   /* scratch */
   float* ws; int64_t ws_floats;
 } vln_envdrop_step;

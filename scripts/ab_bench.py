@@ -12,7 +12,9 @@ import vln_amd as vln
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
-tape = bench.tape_to(bench.make_tape(64, 80, 7, 8, 2020), dev)
+cpu_tape = bench.make_tape(64, 80, 7, 8, 2020)
+tape_t = bench.tape_to(cpu_tape, dev)
+tape_s = bench.tape_to(cpu_tape, dev, store_dtype=dtype)
 lib = vln._lib.load()
 
 # name -> (persistent, graphs, tunable0 (split target), tunable1 (no-split rule))
@@ -21,31 +23,33 @@ VARIANTS = {
     "split_rule_off": (1, 1, 512, 0),
     "target256": (1, 1, 256, 1),
     "target768": (1, 1, 768, 1),
+    "tensor_features": (1, 1, 512, 1),
+    "overlap_wgrads": (1, 1, 512, 1),
     "per_step_lstm": (0, 1, 512, 1),
-    "no_graphs_no_persist": (0, 0, 512, 1),
 }
 torch.manual_seed(0)
 agent = bench.GpuAgent(vln, dev, dtype, 1)
 
 
-def configure(cfg):
+def configure(cfg, name=""):
+    agent.dec.overlap_wgrads = (name == "overlap_wgrads")
     lib.vln_set_persistent(cfg[0]); lib.vln_set_graphs(cfg[1]); lib.vln_set_tunable(0, cfg[2]); lib.vln_set_tunable(1, cfg[3])
 
 
 times = {n: [] for n in VARIANTS}
 for n, cfg in VARIANTS.items():
-    configure(cfg)
+    configure(cfg, n)
     for _ in range(3):
-        agent.iteration(tape)
+        agent.iteration(tape_t if n == 'tensor_features' else tape_s)
 torch.cuda.synchronize()
 for r in range(rounds):
     for n, cfg in VARIANTS.items():
-        configure(cfg)
-        agent.iteration(tape)
+        configure(cfg, n)
+        agent.iteration(tape_t if n == 'tensor_features' else tape_s)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            agent.iteration(tape)
+            agent.iteration(tape_t if n == 'tensor_features' else tape_s)
         torch.cuda.synchronize()
         times[n].append((time.perf_counter() - t0) / 10 * 1e3)
 configure(VARIANTS["base"])
