@@ -24,7 +24,8 @@ int check_hip(hipError_t e, const char* what) {
 int g_graphs_enabled = 1;
 // [0] = 256: interleaved A/B (scripts/ab_bench.py) shows 256/512/768 within noise in time; 256 halves the split-K
 // slab traffic (PMC), so it wins on bytes
-int g_tunable[8] = {256, 1, 0, 0, 0, 0, 0, 0};
+// [2] = 1: narrow outputs (N <= 1024) use the 16-column kernel with the K split inside the workgroup
+int g_tunable[8] = {256, 1, 1, 0, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {

@@ -181,8 +181,8 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, io->tt, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   RUN(attn_dot(st, ctx, d->ctype, io->tt, H, ws.dots, B, d->L, H));
   RUN(attn_softmax_wsum(st, ctx, d->ctype, ws.dots, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, B, d->L, H));
-  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, nullptr, 0, B, H, 2 * H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, &nsplit));
-  RUN(reduce_epilogue(st, ws.slabs, nsplit, (long)B * H, H, io->h_tilde, H, B, H, nullptr, ACT_TANH, io->htd, H, site(io, 3, io->p_drop)));
+  RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
+                    site(io, 3, io->p_drop), ws.slabs, ws.slab_floats));
   // (6) candidate logits                                        policy.py:243-244,199-206
   RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, ws.tc, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   RUN(attn_dot(st, cand, d->ctype, ws.tc, F, io->logit, B, d->C, F));

@@ -204,9 +204,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#include "gemm_nt_n16.h"
+
+// narrow outputs: 16-column workgroups with the K split inside the workgroup (no slabs, no reduce launch)
+static bool n16_applies(int M, int N, int K) { return g_tunable[2] && N <= 1024 && M <= 256 && K >= 64; }
+
+static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
+                      int M, int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop) {
+  const int BK = (wtype == W_BF16) ? 64 : 32;
+  GemmN16Args a;
+  a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy; a.bias = bias; a.act = act;
+  a.Y2 = Y2; a.ldy2 = ldy2; a.drop = drop; a.M = M; a.N = N; a.K = K;
+  a.kq = ((K + 3) / 4 + BK - 1) / BK * BK;
+  a.xvec = aligned16(X) && (ldx % 4 == 0);
+  a.wvec = aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0);
+  dim3 grid((N + 15) / 16, 1, (M + 63) / 64), block(256);
+  ProfScope prof(st, K_GEMM_NT, (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N);
+  if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_n16_kernel<bf16_raw>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(gemm_nt_n16_kernel<float>, grid, block, 0, st, a);
+  VLN_CHECK_LAUNCH("gemm_nt_n16");
+  return VLN_OK;
+}
+
+// Y = act(X W^T + bias), Y2 = Y * dropout (optional): one launch for narrow outputs, else split-K slabs + reduce
+int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
+                  int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats) {
+  if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_fused: bad dims"); return VLN_ERR_ARG; }
+  if (n16_applies(M, N, K)) return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, Y2, ldy2, drop);
+  int nsplit = 1;
+  int r = gemm_nt(st, X, ldx, W, wtype, ldw, nullptr, 0, M, N, K, nullptr, ACT_NONE, ws, ws_floats, &nsplit);
+  if (r != VLN_OK) return r;
+  return reduce_epilogue(st, ws, nsplit, (long)M * N, N, Y, ldy, M, N, bias, act, Y2, ldy2, drop);
+}
+
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }
+  if (nsplit_out == nullptr && n16_applies(M, N, K))
+    return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, nullptr, 0, DropSpec{0, 0, 0.f});
   const int BK = (wtype == W_BF16) ? 64 : 32;
   const int nb = (N + 63) / 64, mb = (M + 63) / 64;
   const int ksteps = (K + BK - 1) / BK;

@@ -49,6 +49,10 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out);
 // (nsplit_out != nullptr  =>  raw partial sums ALWAYS go to ws, even for nsplit == 1; no bias/act applied)
 
+// Y = act(X W^T + bias) and optionally Y2 = Y * dropout mask, finished output in the fewest launches
+int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
+                  int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats);
+
 // D[N,K] (+)= A[Mt,N]^T * X[Mt,K]   (weight gradients; contraction over rows)
 int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
             int N, int K, int accumulate, float* ws, long ws_floats);
