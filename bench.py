@@ -134,13 +134,14 @@ class GpuAgent:
         self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
-        ml = 0.
+        terms = []
         for s in tape["steps"]:
             img, cand, kw = self.step_features(tape, s)
             logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], **kw)
             # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum(),
             # as one fused HIP launch (losses.py)
-            ml = ml + self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "none").sum()
+            terms.append(self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
+        ml = torch.stack(terms).sum()                            # ml_loss += ... over the steps (envdrop.py:179)
         loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
         loss.backward()
         self.opt.allreduce()

@@ -32,7 +32,7 @@ class EnvDropWeights(C.Structure):
 class EnvDropStep(C.Structure):
     _fields_ = ([(n, ptr) for n in ("a_prev", "img", "cand", "img_lp", "cand_lp", "h_tilde_prev", "c0", "ctx",
                                     "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
-                                    "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd")]
+                                    "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd", "a_stash")]
                 + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
                    ("ws", ptr), ("ws_floats", i64)])
 
@@ -67,8 +67,8 @@ SIGNATURES = {
     "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_rmsprop_partial_floats": (i64, [ptr, i32]),
     "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, f32, ptr]),
-    "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
-    "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
+    "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
+    "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_cands": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_embed_fwd": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
@@ -85,6 +85,11 @@ SIGNATURES = {
 }
 
 _lib = None
+try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()
+    import torch as _torch
+    _raw_stream, _get_device = _torch._C._cuda_getCurrentRawStream, _torch._C._cuda_getDevice
+except (ImportError, AttributeError):  # CPU-only torch builds: the modules fail loudly before they get here
+    _raw_stream = _get_device = None
 
 
 def load():
@@ -106,6 +111,12 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def raw_stream() -> int:
+    """hipStream_t of torch's current stream on the current device, without building a torch.cuda.Stream object
+    (the decoder path asks ~60 times per iteration; the object route costs ~3 us each)."""
+    return _raw_stream(_get_device())
 
 
 def check(status: int, what: str = ""):

@@ -49,6 +49,18 @@ void prof_begin(hipStream_t st, int kid, double algo_bytes) {
   p.bytes += algo_bytes;
   (void)hipEventRecord(p.pool[p.used].a, st);
 }
+bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b) {
+  ProfState& p = g_prof[kid];
+  if (p.used == p.pool.size()) {
+    ProfSlot s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return false;
+    p.pool.push_back(s);
+  }
+  p.bytes += algo_bytes;
+  *a = p.pool[p.used].a; *b = p.pool[p.used].b;
+  p.used++;
+  return true;
+}
 void prof_end(hipStream_t st, int kid) {
   ProfState& p = g_prof[kid];
   if (p.used < p.pool.size()) {

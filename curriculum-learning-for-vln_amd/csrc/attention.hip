@@ -49,11 +49,11 @@ int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long 
   if (blocks > 8192) blocks = 8192;
   const int V = (ctype == W_BF16) ? 8 : 4;
   int vec_ok = aligned16(ctx) && aligned16(vec) && (D % V == 0) && (ldv % 4 == 0);
-  ProfScope prof(st, K_ATTN_DOT, (double)rows * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 4.0 * rows);
+  const double bytes = (double)rows * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 4.0 * rows;
   if (ctype == W_BF16)
-    hipLaunchKernelGGL(attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
   else
-    hipLaunchKernelGGL(attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
   VLN_CHECK_LAUNCH("attn_dot");
   return VLN_OK;
 }
@@ -144,13 +144,13 @@ static int launch_wsum(hipStream_t st, const void* ctx, int ctype, const float* 
   const int DC = 64 * V;
   int vec_ok = aligned16(ctx) && (D % V == 0);
   dim3 grid(B, (D + DC - 1) / DC), block(256);
-  ProfScope prof(st, K_ATTN_WSUM, (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 8.0 * B * S);
+  const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 8.0 * B * S;
   if (ctype == W_BF16) {
-    if (softmax) hipLaunchKernelGGL((attn_wsum_kernel<bf16_raw, true>), grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
-    else hipLaunchKernelGGL((attn_wsum_kernel<bf16_raw, false>), grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    if (softmax) launch_timed(K_ATTN_WSUM, bytes, attn_wsum_kernel<bf16_raw, true>, grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    else launch_timed(K_ATTN_WSUM, bytes, attn_wsum_kernel<bf16_raw, false>, grid, block, 0, st, (const bf16_raw*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
   } else {
-    if (softmax) hipLaunchKernelGGL((attn_wsum_kernel<float, true>), grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
-    else hipLaunchKernelGGL((attn_wsum_kernel<float, false>), grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    if (softmax) launch_timed(K_ATTN_WSUM, bytes, attn_wsum_kernel<float, true>, grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
+    else launch_timed(K_ATTN_WSUM, bytes, attn_wsum_kernel<float, false>, grid, block, 0, st, (const float*)ctx, logits, mask, attn, out, ldo, S, D, vec_ok);
   }
   VLN_CHECK_LAUNCH("attn_wsum");
   return VLN_OK;
@@ -262,12 +262,12 @@ int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, cons
   const int DC = 64 * V;
   int vec_ok = aligned16(ctx) && (D % V == 0) && (!dctx || aligned16(dctx));
   dim3 grid(B, (D + DC - 1) / DC), block(256);
-  ProfScope prof(st, K_ATTN_BWD, (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + (dctx ? 8.0 * B * S * D : 0.0) +
-                                     4.0 * B * D * (dctx ? 3 : 1) + 12.0 * B * S);
+  const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + (dctx ? 8.0 * B * S * D : 0.0) +
+                       4.0 * B * D * (dctx ? 3 : 1) + 12.0 * B * S;
   if (ctype == W_BF16)
-    hipLaunchKernelGGL(attn_bwd_kernel<bf16_raw>, grid, block, 0, st, (const bf16_raw*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
+    launch_timed(K_ATTN_BWD, bytes, attn_bwd_kernel<bf16_raw>, grid, block, 0, st, (const bf16_raw*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
   else
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, 0, st, (const float*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
+    launch_timed(K_ATTN_BWD, bytes, attn_bwd_kernel<float>, grid, block, 0, st, (const float*)ctx, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx, dl_out, S, D, vec_ok);
   VLN_CHECK_LAUNCH("attn_bwd");
   return VLN_OK;
 }

@@ -17,12 +17,16 @@ struct PrepArgs {
   float* e; float* xcat; long ldx; float* hq;
   int B, ANG, AE, F, H;
   DropSpec d_act, d_h;
+  float* a_stash;   // nullable: copy of `a` kept for the deferred act_embed weight gradient
 };
 // e = tanh(a W_a^T + b); xcat[:, :AE] = drop(e); xcat[:, AE+F:] = h_tilde_prev; hq = drop(h_tilde_prev)
 __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
   const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh; i += (long)gridDim.x * blockDim.x) {
-    if (i < ne) {
+  const long na = p.a_stash ? (long)p.B * p.ANG : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh + na; i += (long)gridDim.x * blockDim.x) {
+    if (i >= ne + nh) {
+      p.a_stash[i - ne - nh] = p.a[i - ne - nh];
+    } else if (i < ne) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
       const float* a = p.a + (long)b * p.ANG;
       const float* w = p.act_w + (long)j * p.ANG;
@@ -153,8 +157,9 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
 
   // (1) act embedding, h_tilde_prev copy + dropout            policy.py:224,234
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
-              B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
-  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
+              B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
+              io->a_stash == io->a_prev ? nullptr : io->a_stash};
+  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * (AE + H + (pa.a_stash ? d->ANG : 0)))), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep");
   // (2) environmental feature dropout, in place                policy.py:226-231
   // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)

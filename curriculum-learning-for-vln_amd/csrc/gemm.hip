@@ -219,9 +219,9 @@ static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, i
   a.xvec = aligned16(X) && (ldx % 4 == 0);
   a.wvec = aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0);
   dim3 grid((N + 15) / 16, 1, (M + 63) / 64), block(256);
-  ProfScope prof(st, K_GEMM_NT, (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N);
-  if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_n16_kernel<bf16_raw>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(gemm_nt_n16_kernel<float>, grid, block, 0, st, a);
+  const double bytes = (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N;
+  if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_kernel<bf16_raw>, grid, block, 0, st, a);
+  else launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_kernel<float>, grid, block, 0, st, a);
   VLN_CHECK_LAUNCH("gemm_nt_n16");
   return VLN_OK;
 }
@@ -276,9 +276,9 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   dim3 grid(nb, nsplit, mb), block(256);
   {
     // algorithmic bytes: the weight stream once + activations in + result out
-    ProfScope prof(st, K_GEMM_NT, (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N);
-    if (wtype == W_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, st, a);
+    const double bytes = (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N;
+    if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
+    else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float>, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("gemm_nt");
   if (nsplit_out) { *nsplit_out = nsplit; return VLN_OK; }   // caller consumes the slabs itself
@@ -461,8 +461,8 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
   if (msplit > 1) { a.D = ws; a.ldd = K; a.slab_stride = (long)N * K; a.accumulate = 0; }
   dim3 grid(nbk, nbn, msplit), block(256);
   {
-    ProfScope prof(st, K_GEMM_TN, 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1)));
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, st, a);
+    launch_timed(K_GEMM_TN, 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1)),
+                 gemm_tn_kernel, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("gemm_tn");
   if (msplit > 1) return reduce_slabs(st, ws, msplit, (long)N * K, D, ldd, N, K, accumulate);

@@ -214,20 +214,21 @@ int feat_dropout_inplace(hipStream_t st, void* x, int xtype, long rows, int img,
 // per lane-slot, looped beyond).  Saves the masked softmax so backward is a single scaled subtraction.
 // ---------------------------------------------------------------------------
 namespace vln {
-__global__ __launch_bounds__(256) void masked_ce_fwd_kernel(float* logits, long ld, const long long* target,
-                                                            const unsigned char* mask, float* loss, float* probs,
-                                                            const long long* action, float* logp, float* entropy,
-                                                            int B, int C, long ignore_index, int write_mask) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
-  float* lg = logits + (long)b * ld;
+struct CeArgs {
+  float* logits; long ld; const long long* target; const unsigned char* mask; float* loss; float* probs;
+  const long long* action; float* logp; float* entropy; int B, C; long ignore_index; int write_mask;
+};
+// one wave per row; returns the row's CE term (wave-uniform)
+__device__ __forceinline__ float ce_row(const CeArgs& a, int b, int lane) {
+  const int C = a.C;
+  const unsigned char* mask = a.mask;
+  float* lg = a.logits + (long)b * a.ld;
   float mx = -INFINITY;
   for (int c = lane; c < C; c += 64) {
     float v = lg[c];
     if (mask && mask[(long)b * C + c]) {
       v = -INFINITY;
-      if (write_mask) lg[c] = v;                 // logits.masked_fill_(candidate_mask, -inf), in place like the caller
+      if (a.write_mask) lg[c] = v;               // logits.masked_fill_(candidate_mask, -inf), in place like the caller
     }
     mx = fmaxf(mx, v);
   }
@@ -239,54 +240,79 @@ __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(float* logits, long 
   }
   sum = wave_sum(sum);
   const float lse = mx + __logf(sum);
-  const long tgt = target ? target[b] : ignore_index;
+  const long tgt = a.target ? a.target[b] : a.ignore_index;
   const float eps = 1.1920928955078125e-07f;     // torch.distributions clamp_probs
   float ent = 0.f;
   for (int c = lane; c < C; c += 64) {
     const float v = (mask && mask[(long)b * C + c]) ? -INFINITY : lg[c];
     const float p = __expf(v - lse);
-    if (probs) probs[(long)b * C + c] = p;
+    if (a.probs) a.probs[(long)b * C + c] = p;
     const float pc = fminf(fmaxf(p, eps), 1.f - eps);
     ent -= p * __logf(pc);
-    if (action && logp && c == action[b]) logp[b] = __logf(pc);
+    if (a.action && a.logp && c == a.action[b]) a.logp[b] = __logf(pc);
   }
   ent = wave_sum(ent);
+  const float l = (tgt == a.ignore_index) ? 0.f : (lse - lg[tgt]);
   if (lane == 0) {
-    if (entropy) entropy[b] = ent;
-    if (loss) loss[b] = (tgt == ignore_index) ? 0.f : (lse - lg[tgt]);
+    if (a.entropy) a.entropy[b] = ent;
+    if (a.loss) a.loss[b] = l;
+  }
+  return l;
+}
+__global__ __launch_bounds__(256) void masked_ce_fwd_kernel(CeArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b < a.B) ce_row(a, b, lane);
+}
+// reduction="sum" in the same launch: ONE workgroup of 16 waves, rows strided over the waves, partial sums folded in a
+// fixed order (deterministic).  The batch is a few hundred rows of <= 16 candidates: nothing to parallelise further.
+__global__ __launch_bounds__(1024) void masked_ce_fwd_sum_kernel(CeArgs a, float* loss_sum) {
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wave; b < a.B; b += 16) acc += ce_row(a, b, lane);
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    loss_sum[0] = t;
   }
 }
 
 // dlogits[b,c] = dloss[b] * (p - onehot(target))   (0 for ignored rows; p = 0 at masked slots)
+// dloss_stride 0: one scalar upstream gradient for every row (the backward of the fused sum)
 __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* probs, const long long* target, const float* dloss,
-                                                            float* dlogits, int B, int C, long ignore_index) {
+                                                            long dloss_stride, float* dlogits, int B, int C,
+                                                            long ignore_index) {
   const long total = (long)B * C;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int b = (int)(e / C), c = (int)(e % C);
     const long t = target[b];
-    dlogits[e] = (t == ignore_index) ? 0.f : dloss[b] * (probs[e] - (c == t ? 1.f : 0.f));
+    dlogits[e] = (t == ignore_index) ? 0.f : dloss[b * dloss_stride] * (probs[e] - (c == t ? 1.f : 0.f));
   }
 }
 }  // namespace vln
 
 extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, float* loss,
-                                 float* probs, const int64_t* action, float* logp, float* entropy, int B, int C,
-                                 int64_t ignore_index, int write_mask, void* s) {
+                                 float* loss_sum, float* probs, const int64_t* action, float* logp, float* entropy, int B,
+                                 int C, int64_t ignore_index, int write_mask, void* s) {
   if (!logits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_fwd: bad args"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, (long)ld,
-                     (const long long*)target, cand_mask, loss, probs, (const long long*)action, logp, entropy, B, C,
-                     (long)ignore_index, write_mask);
+  vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, loss, probs, (const long long*)action, logp, entropy,
+                B, C, (long)ignore_index, write_mask};
+  if (loss_sum) hipLaunchKernelGGL(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, a, loss_sum);
+  else hipLaunchKernelGGL(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("masked_ce_fwd");
   return VLN_OK;
 }
-extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, float* dlogits, int B,
-                                 int C, int64_t ignore_index, void* s) {
+extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, int64_t dloss_stride,
+                                 float* dlogits, int B, int C, int64_t ignore_index, void* s) {
   if (!probs || !target || !dloss || !dlogits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_bwd: bad args"); return VLN_ERR_ARG; }
   long total = (long)B * C;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
-                     dloss, dlogits, B, C, (long)ignore_index);
+                     dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index);
   VLN_CHECK_LAUNCH("masked_ce_bwd");
   return VLN_OK;
 }

@@ -1,6 +1,8 @@
 // Internal C++ launcher interface shared by the .hip translation units.
 // Everything here is host-side glue; the public boundary is include/vln_hip.h.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace vln {
@@ -32,7 +34,21 @@ struct ProfScope {   // brackets the launches issued in its scope with an event 
   ~ProfScope() { if (on) prof_end(st, kid); }
 };
 
-#define VLN_CHECK_LAUNCH(what)                                 \
+// Single-kernel timing: the event pair rides on the dispatch itself (hipExtLaunchKernelGGL), so the elapsed time
+// is the kernel's own begin->end on the device, the figure rocprofv3 --kernel-trace reports, with no
+// launch gap or event-record packet inside the bracket.
+bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
+template <typename F, typename... A>
+inline void launch_timed(int kid, double algo_bytes, F kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t st,
+                         A... args) {
+  hipEvent_t ea, eb;
+  if (((g_prof_mask >> kid) & 1u) && prof_slot(kid, algo_bytes, &ea, &eb))
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ea, eb, 0u, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+
+#define VLN_CHECK_LAUNCH(what)                                \
   do {                                                           \
     int _st = vln::check_hip(hipGetLastError(), what);           \
     if (_st != VLN_OK) return _st;                               \

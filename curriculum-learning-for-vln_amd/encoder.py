@@ -21,7 +21,7 @@ _p = ops._p
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 class _EncoderFn(torch.autograd.Function):

@@ -32,16 +32,19 @@ class _SoftDotParams(nn.Module):
 
 
 class _StepRec:
-    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C")
+    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H")
+
+
+_NONES = (None,) * 64
 
 
 class _EnvDropStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, rec, h_tilde_prev, c0, ctx_t, *gated):
-        lib = _lib.load()
-        _lib.check(lib.vln_envdrop_step_fwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(rec.io),
-                                            torch.cuda.current_stream().cuda_stream), "vln_envdrop_step_fwd")
-        ctx.mod, ctx.rec = mod, rec
+        st = _lib.load().vln_envdrop_step_fwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(rec.io), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_envdrop_step_fwd")
+        ctx.mod, ctx.rec, ctx.n_gated = mod, rec, len(gated)
         ctx.set_materialize_grads(False)
         k = rec.keep
         return k["logit"], k["h1"], k["c1"], k["h_tilde"]
@@ -49,34 +52,45 @@ class _EnvDropStepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogit, dh1, dc1, dht):
         mod, rec = ctx.mod, ctx.rec
-        lib = _lib.load()
         dev = rec.keep["h1"].device
-        B, H = rec.dims.B, rec.dims.H
+        B, H = rec.B, rec.H
         g = _lib.EnvDropGrads()
-        hold = []
-        for name, t in (("dlogit", dlogit), ("dh1", dh1), ("dc1", dc1), ("dh_tilde", dht)):
-            if t is not None:
-                t = t.contiguous()
-                hold.append(t)
-                setattr(g, name, t.data_ptr())
+        hold = []          # keeps the contiguous copies alive until the launch is queued
+        if dlogit is not None:
+            if not dlogit.is_contiguous():
+                dlogit = dlogit.contiguous(); hold.append(dlogit)
+            g.dlogit = dlogit.data_ptr()
+        if dh1 is not None:
+            if not dh1.is_contiguous():
+                dh1 = dh1.contiguous(); hold.append(dh1)
+            g.dh1 = dh1.data_ptr()
+        if dc1 is not None:
+            if not dc1.is_contiguous():
+                dc1 = dc1.contiguous(); hold.append(dc1)
+            g.dc1 = dc1.data_ptr()
+        if dht is not None:
+            if not dht.is_contiguous():
+                dht = dht.contiguous(); hold.append(dht)
+            g.dh_tilde = dht.data_ptr()
         dhtp = torch.empty(B, H, dtype=torch.float32, device=dev)
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         g.dh_tilde_prev, g.dc0 = dhtp.data_ptr(), dc0.data_ptr()
-        e = rec.entry
         if ctx.needs_input_grad[4]:
+            e = rec.entry
             if e.dctx is None:
-                e.dctx = torch.zeros(rec.B, rec.L, H, dtype=torch.float32, device=dev)
+                e.dctx = torch.zeros(B, rec.L, H, dtype=torch.float32, device=dev)
             g.dctx = e.dctx.data_ptr()
         s = rec.slot
-        g.s_dtc, g.s_dz, g.s_dtt = s.view("dtc").data_ptr(), s.view("dz").data_ptr(), s.view("dtt").data_ptr()
-        g.s_dgates, g.s_dtv, g.s_de = s.view("dgates").data_ptr(), s.view("dtv").data_ptr(), s.view("de").data_ptr()
-        ws = ops.workspace(dev, rec.io.ws_floats)
-        rec.io.ws = ws.data_ptr()
-        _lib.check(lib.vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(rec.io), C.byref(g),
-                                            torch.cuda.current_stream().cuda_stream), "vln_envdrop_step_bwd")
+        g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
+        g.s_dgates, g.s_dtv, g.s_de = s.ptr("dgates"), s.ptr("dtv"), s.ptr("de")
+        io = rec.io
+        io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
+        st = _lib.load().vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(io), C.byref(g), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_envdrop_step_bwd")
         s.done = True
         ctx.rec = None
-        return (None, None, dhtp, dc0, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+        return (None, None, dhtp, dc0, None) + _NONES[:ctx.n_gated]
 
 
 class EnvDropDecoder(nn.Module, GatedModuleMixin):
@@ -108,12 +122,26 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # whose 128 co-resident workgroups then compete for CUs with the side stream's GEMM workgroups.
         self.overlap_wgrads = False
         self._side_stream = None
+        self._dims_cache = {}
 
     # ---- gating hooks ----------------------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
-        return [self.act_embed[0].weight, self.act_embed[0].bias, self.visual_attn.linear_in.weight,
-                self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,
-                self.text_attn.linear_in.weight, self.text_attn.linear_out.weight, self.cand_attn.weight]
+        # Called every step: read the Parameters through the owning submodules' `_parameters` dicts (resolved once)
+        # instead of ten nn.Module.__getattr__ chains; re-assigned parameters are still seen.
+        slots = self.__dict__.get("_pslots")
+        if slots is None:
+            a, l = self.act_embed[0]._parameters, self.lstm._parameters
+            slots = ((a, "weight"), (a, "bias"), (self.visual_attn.linear_in._parameters, "weight"),
+                     (l, "weight_ih"), (l, "weight_hh"), (l, "bias_ih"), (l, "bias_hh"),
+                     (self.text_attn.linear_in._parameters, "weight"), (self.text_attn.linear_out._parameters, "weight"),
+                     (self.cand_attn._parameters, "weight"))
+            object.__setattr__(self, "_pslots", slots)
+        return [d[k] for d, k in slots]
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Module):          # a replaced submodule invalidates the cached parameter slots
+            self.__dict__.pop("_pslots", None)
+        super().__setattr__(name, value)
 
     def _stash_sites(self) -> Dict[str, int]:
         H, F, AE, ANG = self.hidden_size, self.feature_size, self.action_embed_size, self.angle_feat_size
@@ -217,84 +245,111 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         L = ctx.shape[1]
         H, AE, ANG = self.hidden_size, self.action_embed_size, self.angle_feat_size
         dev = img_feature.device
+        P = self._gated_params()
         need_grad = torch.is_grad_enabled() and (
-            h_tilde_prev.requires_grad or c_0.requires_grad or ctx.requires_grad or self.lstm.weight_ih.requires_grad)
-        gated = self._ensure_current(need_grad)
+            h_tilde_prev.requires_grad or c_0.requires_grad or ctx.requires_grad or P[3].requires_grad)
+        gated = self._ensure_current(need_grad, P)
         ctx_in, entry = self._gated_ctx(ctx, need_grad)
         dt = self.compute_dtype
         lp = dt != torch.float32
 
         rec = _StepRec()
-        rec.B, rec.L, rec.C = B, L, Cn
+        rec.B, rec.L, rec.C, rec.H = B, L, Cn, H
         rec.ctx_owner, rec.entry = ctx, entry
-        d = _lib.EnvDropDims(B, L, V, Cn, H, F - ANG, ANG, AE, ops.BF16 if lp else ops.F32, ops.BF16 if lp else ops.F32)
+        # the dims block and its scratch size depend on the shapes only: built once per shape
+        dk = (B, L, V, Cn, lp)
+        cached = self._dims_cache.get(dk)
+        if cached is None:
+            d = _lib.EnvDropDims(B, L, V, Cn, H, F - ANG, ANG, AE, ops.BF16 if lp else ops.F32, ops.BF16 if lp else ops.F32)
+            nws = _lib.load().vln_envdrop_ws_floats(C.byref(d))
+            if nws < 0:
+                _lib.check(int(nws), "vln_envdrop_ws_floats")
+            if len(self._dims_cache) > 64:
+                self._dims_cache.clear()
+            cached = self._dims_cache[dk] = (d, nws)
+        d, nws = cached
         rec.dims = d
         img = img_feature if img_feature.is_contiguous() else img_feature.contiguous()
         cand = cand_feature if cand_feature.is_contiguous() else cand_feature.contiguous()
-        a = a_t_prev.contiguous()
-        htp = h_tilde_prev.detach().contiguous()
-        c0 = c_0.detach().contiguous()
+        a = a_t_prev if a_t_prev.is_contiguous() else a_t_prev.contiguous()
+        htp = h_tilde_prev.detach()
+        if not htp.is_contiguous():
+            htp = htp.contiguous()
+        c0 = c_0.detach()
+        if not c0.is_contiguous():
+            c0 = c0.contiguous()
         ctxc = ctx.detach()
         if not ctxc.is_contiguous():
             ctxc = ctxc.contiguous()
-        f32 = dict(dtype=torch.float32, device=dev)
-        keep = {"img": img, "cand": cand, "htp": htp, "c0": c0, "ctx": ctxc,
-                "logit": torch.empty(B, Cn, **f32), "h1": torch.empty(B, H, **f32), "c1": torch.empty(B, H, **f32),
-                "h_tilde": torch.empty(B, H, **f32)}
-        # per-step saved activations: one flat allocation carved into views
-        sizes = (("e", B * AE), ("alpha_v", B * V), ("gate_act", B * 4 * H), ("tanh_c1", B * H), ("tt", B * H),
-                 ("alpha_t", B * L))
-        flat = torch.empty(sum(n for _, n in sizes), **f32)
-        off = 0
-        for name, n in sizes:
-            keep[name] = flat[off:off + n]
-            off += n
+        logit = torch.empty(B, Cn, dtype=torch.float32, device=dev)
+        h1 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        c1 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        h_tilde = torch.empty(B, H, dtype=torch.float32, device=dev)
+        keep = {"img": img, "cand": cand, "a": a, "htp": htp, "c0": c0, "ctx": ctxc,
+                "logit": logit, "h1": h1, "c1": c1, "h_tilde": h_tilde}
+        io = _lib.EnvDropStep()
+        # per-step saved activations: ONE flat allocation, addressed by offset (no tensor views on this path)
+        n_e, n_av, n_g, n_h, n_at = B * AE, B * V, B * 4 * H, B * H, B * L
         if need_grad:
             slot = self._stash.take(B, entry.ref)
             rec.slot = slot
-            xa, hq, xcat, tcat, htd = (slot.view(k) for k in ("a", "hq", "xcat", "tcat", "htd"))
-            xa.copy_(a)
-            a_ptr = xa.data_ptr()
+            flat = torch.empty(n_e + n_av + n_g + 2 * n_h + n_at, dtype=torch.float32, device=dev)
+            io.a_stash, io.hq, io.xcat, io.tcat, io.htd = (slot.ptr("a"), slot.ptr("hq"), slot.ptr("xcat"), slot.ptr("tcat"),
+                                                           slot.ptr("htd"))
         else:
             rec.slot = None
-            hq, xcat, tcat, htd = (torch.empty(B, w, **f32) for w in (H, AE + F + H, 2 * H, H))
-            keep["tmp"] = (hq, xcat, tcat, htd)
-            a_ptr = a.data_ptr()
-            keep["a"] = a
-        io = _lib.EnvDropStep()
-        io.a_prev, io.img, io.cand = a_ptr, img.data_ptr(), cand.data_ptr()
+            XK = AE + F + H
+            flat = torch.empty(n_e + n_av + n_g + 2 * n_h + n_at + B * (H + XK + 2 * H + H), dtype=torch.float32, device=dev)
+            q = flat.data_ptr() + 4 * (n_e + n_av + n_g + 2 * n_h + n_at)
+            io.hq, io.xcat, io.tcat, io.htd = q, q + 4 * B * H, q + 4 * B * (H + XK), q + 4 * B * (H + XK + 2 * H)
+        keep["flat"] = flat
+        q = flat.data_ptr()
+        io.e = q; q += 4 * n_e
+        io.alpha_v = q; q += 4 * n_av
+        io.gate_act = q; q += 4 * n_g
+        io.tanh_c1 = q; q += 4 * n_h
+        io.tt = q; q += 4 * n_h
+        io.alpha_t = q
+        io.a_prev, io.img, io.cand = a.data_ptr(), img.data_ptr(), cand.data_ptr()
         if lp:
             ready = already_dropfeat and img_lp is not None and cand_lp is not None and img_lp.dtype == dt and \
                 cand_lp.dtype == dt and img_lp.is_contiguous() and cand_lp.is_contiguous()
-            keep["img_lp"] = img_lp if ready else torch.empty(B, V, F, dtype=dt, device=dev)
-            keep["cand_lp"] = cand_lp if ready else torch.empty(B, Cn, F, dtype=dt, device=dev)
-            io.lp_ready = int(bool(ready))
-            keep["ctx_lp"] = self._ctx_lp(entry, ctx, dt)
-            io.img_lp, io.cand_lp, io.ctx_lp = keep["img_lp"].data_ptr(), keep["cand_lp"].data_ptr(), keep["ctx_lp"].data_ptr()
+            if not ready:
+                img_lp = torch.empty(B, V, F, dtype=dt, device=dev)
+                cand_lp = torch.empty(B, Cn, F, dtype=dt, device=dev)
+            else:
+                io.lp_ready = 1
+            ctx_lp = entry.lp
+            if ctx_lp is None:
+                ctx_lp = self._ctx_lp(entry, ctx, dt)
+            keep["img_lp"], keep["cand_lp"], keep["ctx_lp"] = img_lp, cand_lp, ctx_lp
+            io.img_lp, io.cand_lp, io.ctx_lp = img_lp.data_ptr(), cand_lp.data_ptr(), ctx_lp.data_ptr()
         io.h_tilde_prev, io.c0, io.ctx = htp.data_ptr(), c0.data_ptr(), ctxc.data_ptr()
         if ctx_mask is not None:
-            m8 = ctx_mask.contiguous().view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8).contiguous()
+            m8 = entry.mask8 if entry.mask_src is ctx_mask else None
+            if m8 is None:
+                if ctx_mask.dtype == torch.bool and ctx_mask.is_contiguous():
+                    m8 = ctx_mask.view(torch.uint8)          # shares storage: remembered for the rollout's later steps
+                    entry.mask_src, entry.mask8 = ctx_mask, m8
+                else:
+                    m8 = ctx_mask.to(torch.uint8).contiguous()
             keep["mask"] = m8
             io.ctx_mask = m8.data_ptr()
-        io.logit, io.h1, io.c1, io.h_tilde = (keep[k].data_ptr() for k in ("logit", "h1", "c1", "h_tilde"))
-        io.e, io.xcat, io.hq = keep["e"].data_ptr(), xcat.data_ptr(), hq.data_ptr()
-        io.alpha_v, io.gate_act, io.tanh_c1 = keep["alpha_v"].data_ptr(), keep["gate_act"].data_ptr(), keep["tanh_c1"].data_ptr()
-        io.tcat, io.tt, io.alpha_t, io.htd = tcat.data_ptr(), keep["tt"].data_ptr(), keep["alpha_t"].data_ptr(), htd.data_ptr()
+        io.logit, io.h1, io.c1, io.h_tilde = logit.data_ptr(), h1.data_ptr(), c1.data_ptr(), h_tilde.data_ptr()
         io.seed, io.offset = self.dropout_seed, self._next_offset()
-        io.p_drop = self.drop_ratio if self.training else 0.0
-        io.p_feat = self.feat_drop_ratio if self.training else 0.0
-        io.already_dropfeat = int(bool(already_dropfeat))
-        nws = _lib.load().vln_envdrop_ws_floats(C.byref(d))
-        ws = ops.workspace(dev, nws)
-        io.ws, io.ws_floats = ws.data_ptr(), nws
+        if self.training:
+            io.p_drop, io.p_feat = self.drop_ratio, self.feat_drop_ratio
+        if already_dropfeat:
+            io.already_dropfeat = 1
+        io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
         rec.io, rec.keep = io, keep
 
         if need_grad:
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, *gated)
         else:
-            _lib.check(_lib.load().vln_envdrop_step_fwd(C.byref(d), C.byref(self._wstruct), C.byref(io),
-                                                        torch.cuda.current_stream().cuda_stream), "vln_envdrop_step_fwd")
-            logit, h1, c1, h_tilde = keep["logit"], keep["h1"], keep["c1"], keep["h_tilde"]
+            st = _lib.load().vln_envdrop_step_fwd(C.byref(d), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_envdrop_step_fwd")
         if img is not img_feature:
             img_feature.copy_(img)
         if cand is not cand_feature:

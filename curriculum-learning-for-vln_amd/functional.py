@@ -142,7 +142,7 @@ class LSTMCellFn(torch.autograd.Function):
         K = xc.shape[1]
         ws = ops.workspace(x.device, 16 * B * 4 * H)
         lib = _lib.load()
-        st = torch.cuda.current_stream().cuda_stream
+        st = _lib.raw_stream()
         # slabs -> pointwise sums them
         y = torch.empty(B, 4 * H, dtype=torch.float32, device=x.device)
         _lib.check(lib.vln_linear_fwd(xc.data_ptr(), xc.stride(0), wcat.data_ptr(), ops._dt(wcat), wcat.stride(0),

@@ -26,41 +26,58 @@ def _mask8(cand_mask):
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, cand_mask, ignore_index):
-        lib = _lib.load()
+    def forward(ctx, logits, target, cand_mask, ignore_index, fused_sum):
         B, C = logits.shape
-        lg = logits.detach().contiguous()
-        loss = torch.empty(B, dtype=torch.float32, device=logits.device)
-        probs = torch.empty(B, C, dtype=torch.float32, device=logits.device)
+        dev = logits.device
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        probs = torch.empty(B, C, dtype=torch.float32, device=dev)
         m8 = _mask8(cand_mask)
-        tgt = target.contiguous()
-        _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), _p(tgt), _p(m8), _p(loss), _p(probs), None, None, None, B, C,
-                                         ignore_index, 0, torch.cuda.current_stream().cuda_stream), "vln_masked_ce_fwd")
+        tgt = target if target.is_contiguous() else target.contiguous()
+        if fused_sum:        # reduction="sum" inside the same launch: a 0-dim result, no [B] vector round trip
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            loss_p, sum_p = None, out.data_ptr()
+        else:
+            out = torch.empty(B, dtype=torch.float32, device=dev)
+            loss_p, sum_p = out.data_ptr(), None
+        st = _lib.load().vln_masked_ce_fwd(lg.data_ptr(), lg.stride(0), tgt.data_ptr(), _p(m8), loss_p, sum_p, probs.data_ptr(),
+                                           None, None, None, B, C, ignore_index, 0, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_masked_ce_fwd")
         ctx.save_for_backward(probs, tgt)
-        ctx.ignore_index = ignore_index
-        return loss
+        ctx.ignore_index, ctx.fused_sum = ignore_index, fused_sum
+        return out
 
     @staticmethod
     def backward(ctx, dloss):
         probs, tgt = ctx.saved_tensors
         B, C = probs.shape
         dl = torch.empty_like(probs)
-        _lib.check(_lib.load().vln_masked_ce_bwd(_p(probs), _p(tgt), _p(dloss.contiguous()), _p(dl), B, C, ctx.ignore_index,
-                                                 torch.cuda.current_stream().cuda_stream), "vln_masked_ce_bwd")
-        return dl, None, None, None
+        if ctx.fused_sum or dloss.stride(0) == 0:
+            stride = 0                                  # one upstream scalar (also what .sum().backward() hands down)
+        else:
+            stride = 1
+            if not dloss.is_contiguous():
+                dloss = dloss.contiguous()
+        st = _lib.load().vln_masked_ce_bwd(probs.data_ptr(), tgt.data_ptr(), dloss.data_ptr(), stride, dl.data_ptr(), B, C,
+                                           ctx.ignore_index, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_masked_ce_bwd")
+        return dl, None, None, None, None
 
 
 def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor] = None,
                          reduction: str = "none", ignore_index: int = -1) -> torch.Tensor:
     """== `CrossEntropyLoss(ignore_index, reduction)(logits.masked_fill(cand_mask, -inf), target)`.
-    reduction: 'none' ([B], 0 at ignored rows; what SELF-PACE consumes, curriculum.py:296), 'sum', 'mean' (mean over
-    the non-ignored rows, follower.py:62)."""
-    per = _MaskedCE.apply(logits, target, cand_mask, ignore_index)
+    reduction: 'none' ([B], 0 at ignored rows; what SELF-PACE consumes, curriculum.py:296), 'sum' (0-dim, summed inside
+    the same launch), 'mean' (mean over the non-ignored rows, follower.py:62)."""
     if reduction == "none":
-        return per
+        return _MaskedCE.apply(logits, target, cand_mask, ignore_index, False)
+    total = _MaskedCE.apply(logits, target, cand_mask, ignore_index, True)
     if reduction == "sum":
-        return per.sum()
-    return per.sum() / (target != ignore_index).sum().to(per.dtype)
+        return total
+    return total / (target != ignore_index).sum().to(total.dtype)
 
 
 def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
@@ -72,7 +89,7 @@ def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional
     probs = torch.empty(B, C, dtype=torch.float32, device=logits.device)
     logp = torch.empty(B, dtype=torch.float32, device=logits.device)
     ent = torch.empty(B, dtype=torch.float32, device=logits.device)
-    _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), None, _p(_mask8(cand_mask)), None, _p(probs), _p(action.contiguous()),
-                                     _p(logp), _p(ent), B, C, -1, 0, torch.cuda.current_stream().cuda_stream),
+    _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), None, _p(_mask8(cand_mask)), None, None, _p(probs), _p(action.contiguous()),
+                                     _p(logp), _p(ent), B, C, -1, 0, _lib.raw_stream()),
                "vln_masked_ce_fwd")
     return probs, logp, ent

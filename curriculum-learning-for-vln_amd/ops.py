@@ -18,7 +18,7 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -45,7 +45,7 @@ _ws_cache = {}
 def workspace(device, floats: int) -> torch.Tensor:
     """Per-(device, stream) split-K scratch, grown on demand.  Reuse is ordered by the stream it belongs to, so work
     issued on a side stream never shares scratch with the main stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.raw_stream())
     w = _ws_cache.get(key)
     if w is None or w.numel() < floats:
         w = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)

@@ -72,6 +72,6 @@ class FusedRMSprop:
         _lib.check(lib.vln_rmsprop_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.sq.data_ptr(), self._begins,
                                              len(self.groups), self._partial.data_ptr(), self.norms.data_ptr(), self.lr,
                                              self.alpha, self.eps, self.clip_norm, grad_scale,
-                                             torch.cuda.current_stream().cuda_stream), "vln_rmsprop_clip_step")
+                                             _lib.raw_stream()), "vln_rmsprop_clip_step")
         for p in self.params:                       # in-place update outside autograd: tell version-keyed caches
             torch.autograd.graph.increment_version(p)

@@ -49,12 +49,18 @@ class StepSlot:
     def view(self, site: str) -> torch.Tensor:
         return self.chunk.bufs[site][self.r0:self.r0 + self.rows]
 
+    def ptr(self, site: str) -> int:
+        """Device address of the row block (no tensor view is built: the decoder asks ~15 times per step)."""
+        base, row_bytes = self.chunk.addr[site]
+        return base + self.r0 * row_bytes
+
 
 class Chunk:
-    __slots__ = ("bufs", "cap", "used", "slots", "owners")
+    __slots__ = ("bufs", "cap", "used", "slots", "owners", "addr")
 
     def __init__(self, bufs, cap):
         self.bufs, self.cap = bufs, cap
+        self.addr = {k: (t.data_ptr(), t.stride(0) * t.element_size()) for k, t in bufs.items()}
         self.used, self.slots, self.owners = 0, [], []
 
     def recyclable(self) -> bool:
@@ -158,13 +164,14 @@ class WeightGate(torch.autograd.Function):
 class CtxEntry:
     """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
     low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
-    __slots__ = ("ref", "dctx", "lp", "gated", "__weakref__")
+    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "__weakref__")
 
     def __init__(self, t):
         self.ref = weakref.ref(t)
         self.dctx = None
         self.lp = None
         self.gated = None
+        self.mask_src = self.mask8 = None     # the caller's ctx_mask and its uint8 form (converted once per rollout)
 
 
 class CtxGate(torch.autograd.Function):
@@ -199,6 +206,7 @@ class GatedModuleMixin:
         self._step_counter = 0
         self.compute_dtype = torch.float32      # dtype of the streamed operands (weights / features / ctx)
         self.dropout_seed = 0x5EED
+        self._shadow_ready = None               # event recorded by prepare() (side-stream shadow refresh)
 
     # -- provided by the module -----------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -234,12 +242,13 @@ class GatedModuleMixin:
         self._shadow_ready = torch.cuda.Event()
         self._shadow_ready.record(side)
 
-    def _ensure_current(self, need_grad: bool):
-        ev = getattr(self, "_shadow_ready", None)
+    def _ensure_current(self, need_grad: bool, params=None):
+        ev = self._shadow_ready
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self._shadow_ready = None
-        params = self._gated_params()
+        if params is None:
+            params = self._gated_params()
         key = ShadowSet.key_of(params, self.compute_dtype)
         if self._shadow.stale(key):
             with torch.no_grad():

@@ -63,7 +63,7 @@ class DeviceFeatureStore:
         seed, off, p = self._drop(p_feat)
         _lib.check(lib.vln_gather_pano(_p(self.table), ops._dt(self.table), _p(rows), _p(view_index), _p(self.angle_table),
                                        _p(out), _p(lp), B, self.V, self.IMG, self.ANG, seed, off, p,
-                                       torch.cuda.current_stream().cuda_stream), "vln_gather_pano")
+                                       _lib.raw_stream()), "vln_gather_pano")
         return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
 
     def gather_cands(self, rows: torch.Tensor, views: torch.Tensor, heading: torch.Tensor, elevation: torch.Tensor,
@@ -78,7 +78,7 @@ class DeviceFeatureStore:
         _lib.check(lib.vln_gather_cands(_p(self.table), ops._dt(self.table), _p(rows.contiguous()), _p(views.contiguous()),
                                         _p(heading.contiguous()), _p(elevation.contiguous()), _p(out), _p(lp), B * C,
                                         self.V, self.IMG, self.ANG, seed, off, p,
-                                        torch.cuda.current_stream().cuda_stream), "vln_gather_cands")
+                                        _lib.raw_stream()), "vln_gather_cands")
         return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
 
 

@@ -102,11 +102,13 @@ int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, 
  * softmax probabilities and, for a given action, Categorical(probs).log_prob / .entropy() -- one wave per row.
  * Backward of the CE: dlogits = dloss[b] * (probs - onehot(target)), 0 for ignored rows. */
 int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target /*nullable*/, const uint8_t* cand_mask /*nullable*/,
-                      float* loss /*[B] nullable*/, float* probs /*[B,C] nullable*/, const int64_t* action /*nullable*/,
+                      float* loss /*[B] nullable*/, float* loss_sum /*[1] nullable: sum over rows, same launch (reduction="sum")*/,
+                      float* probs /*[B,C] nullable*/, const int64_t* action /*nullable*/,
                       float* logp /*[B]*/, float* entropy /*[B] nullable*/, int B, int C, int64_t ignore_index, int write_mask,
                       vln_stream_t s);
-int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, float* dlogits, int B, int C,
-                      int64_t ignore_index, vln_stream_t s);
+/* dloss_stride: 1 = one upstream gradient per row, 0 = one scalar for all rows (backward of the fused sum) */
+int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, int64_t dloss_stride, float* dlogits,
+                      int B, int C, int64_t ignore_index, vln_stream_t s);
 
 /* ---- per-step feature marshalling on the device (agent/base.py:141-157, common_env.py:307-308) -----------------
  * The ResNet feature table [N_viewpoints, V, IMG] (fp32 or bf16) lives in HBM; a step ships indices only.
@@ -203,6 +205,7 @@ typedef struct vln_envdrop_step {
   float* tt;             /* [B,H]   text attention query */
   float* alpha_t;        /* [B,L] */
   float* htd;            /* [B,H]   drop(h_tilde) */
+  float* a_stash;        /* [B,ANG] nullable: fwd copies a_prev here (X operand of the deferred act_embed weight grad) */
   /* dropout */
   uint64_t seed, offset; /* site k of this step uses Philox offset = offset*8 + k */
   float p_drop, p_feat;

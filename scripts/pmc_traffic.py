@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "attn_dot_kernel": "attn_dot", "attn_wsum_kernel": "attn_wsum",
+NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "attn_dot_kernel": "attn_dot", "attn_wsum_kernel": "attn_wsum",
          "attn_bwd_kernel": "attn_bwd", "lstm_persist_fwd_kernel": "lstm_rec_fwd", "lstm_persist_bwd_kernel": "lstm_rec_bwd",
          "lstm_rec_fwd_kernel": "lstm_rec_fwd", "lstm_rec_bwd_kernel": "lstm_rec_bwd", "feat_dropout_kernel": "feat_dropout",
          "lstm_pw_fwd_kernel": "lstm_pointwise", "reduce_epilogue_kernel": "reduce_epilogue"}
