@@ -112,6 +112,8 @@ class GpuAgent:
         # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
         # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
         self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
+        if world > 1:   # the decoder's 34.7 MB of gradients are final before the encoder's BPTT starts: reduce them under it
+            self.dec.grads_ready_hook = lambda: self.opt.start_allreduce(1)
 
     def step_features(self, tape, s):
         """Per-step marshalling (agent/base.py:141-157 + the EnvDrop feature dropout, policy.py:226-231).

@@ -24,6 +24,43 @@ def stride_shard(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+def _dp_active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+class BucketReducer:
+    """Overlapped exchange of ONE flat gradient buffer.  `start(lo, hi)` hands a finished slice (e.g. the decoder's
+    gradients, complete before the encoder's BPTT begins) to an asynchronous all-reduce -- with nccl (= RCCL) it runs on
+    the process group's own stream behind an event on the caller's stream, so it overlaps the rest of backward;
+    `finish()` reduces whatever was not started early and waits for everything.  Every rank must call start/finish in
+    the same order with the same ranges (they are collectives)."""
+
+    def __init__(self, flat: torch.Tensor):
+        self.flat = flat
+        self.pending = []          # (lo, hi, work)
+
+    def start(self, lo: int, hi: int, group=None):
+        if hi <= lo or not _dp_active(group):
+            return
+        w = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        self.pending.append((lo, hi, w))
+
+    def finish(self, group=None):
+        if not _dp_active(group):
+            self.pending = []
+            return
+        pos, n = 0, self.flat.numel()
+        for lo, hi, _ in sorted(self.pending, key=lambda t: t[0]):
+            if lo > pos:
+                dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM, group=group)
+            pos = max(pos, hi)
+        if pos < n:
+            dist.all_reduce(self.flat[pos:n], op=dist.ReduceOp.SUM, group=group)
+        for _, _, w in self.pending:
+            w.wait()
+        self.pending = []
+
+
 class GradBucket:
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
@@ -33,12 +70,14 @@ class GradBucket:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         off = 0
-        self.views = []
+        self.views, self._span = [], {}
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             p.grad = v
             self.views.append(v)
+            self._span[id(p)] = (off, off + p.numel())
             off += p.numel()
+        self.reducer = BucketReducer(self.flat)
 
     def zero(self):
         """Replacement for optimizer.zero_grad(): keeps the .grad views alive."""
@@ -47,11 +86,27 @@ class GradBucket:
             if p.grad is not v:      # someone replaced .grad (e.g. zero_grad(set_to_none=True)): re-attach
                 p.grad = v
 
+    def span_of(self, params: Iterable[torch.nn.Parameter]):
+        """[lo, hi) of the bucket covering `params` (they must be adjacent in the bucket, e.g. one module's parameters)."""
+        spans = sorted(self._span[id(p)] for p in params if id(p) in self._span)
+        if not spans:
+            return 0, 0
+        for (_, h0), (l1, _) in zip(spans, spans[1:]):
+            if h0 != l1:
+                raise ValueError("GradBucket.span_of: parameters are not adjacent in the bucket")
+        return spans[0][0], spans[-1][1]
+
+    def start_allreduce(self, params: Iterable[torch.nn.Parameter], group=None):
+        """Begin reducing the gradients of `params` now (call when they are final, e.g. from the decoder's
+        `grads_ready_hook`); `allreduce()` later covers the rest and waits."""
+        lo, hi = self.span_of(params)
+        self.reducer.start(lo, hi, group)
+
     def allreduce(self, group=None, average: bool = False):
         """Sum (or mean) the bucket over all ranks.  No-op without an initialised process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not _dp_active(group):
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.reducer.finish(group)
         if average:
             self.flat.div_(dist.get_world_size(group))
 

@@ -123,6 +123,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self.overlap_wgrads = False
         self._side_stream = None
         self._dims_cache = {}
+        self.grads_ready_hook = None     # optional callable, see _deferred_wgrads
 
     # ---- gating hooks ----------------------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -212,6 +213,10 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             self._issue_wgrads(runs, acc0, tgt)
+        # Every decoder gradient is now final in its .grad (bucket view): a data-parallel caller starts their all-reduce
+        # here so it overlaps the encoder's BPTT (dp.BucketReducer / FusedRMSprop.start_allreduce).
+        if self.grads_ready_hook is not None and side is None and all(acc0):
+            self.grads_ready_hook()
         return ret
 
     def _issue_wgrads(self, runs, acc0, tgt):

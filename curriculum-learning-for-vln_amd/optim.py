@@ -12,9 +12,9 @@ import ctypes as C
 from typing import List, Sequence
 
 import torch
-import torch.distributed as dist
 
 from . import _lib
+from .dp import BucketReducer
 
 
 class FusedRMSprop:
@@ -55,6 +55,7 @@ class FusedRMSprop:
         nb = lib.vln_rmsprop_partial_floats(self._begins, len(self.groups))
         self._partial = torch.empty(max(int(nb), 1), dtype=torch.float32, device=dev)
         self.norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
+        self._reducer = BucketReducer(self.flat_g)
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
@@ -62,9 +63,14 @@ class FusedRMSprop:
             if p.grad is not v:
                 p.grad = v
 
+    def start_allreduce(self, group_index: int, group=None):
+        """Begin the RCCL all-reduce of clip group `group_index`'s gradients now, asynchronously (call when they are
+        final -- e.g. from `EnvDropDecoder.grads_ready_hook`, which fires before the encoder's BPTT starts);
+        `allreduce()` later reduces the remaining groups and waits."""
+        self._reducer.start(self._begins[group_index], self._begins[group_index + 1], group)
+
     def allreduce(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+        self._reducer.finish(group)
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):

@@ -50,7 +50,7 @@ def _problem():
     return P, loss_rows, B
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import vln_amd as vln
@@ -65,7 +65,11 @@ def _worker(rank, world, port, q):
         loss = loss_rows(Pm, rows) * 0.2 / B                 # ML_WEIGHT / GLOBAL batch (envdrop.py:268)
         loss.backward()
         assert all(p.grad is v for p, v in zip(bucket.params, bucket.views)), "autograd must accumulate INTO the bucket views"
+        if overlap:      # a finished slice goes out early (what the decoder's grads_ready_hook does), the rest at the end
+            bucket.start_allreduce(params[4:])
+            assert len(bucket.reducer.pending) == 1
         bucket.allreduce()
+        assert not bucket.reducer.pending
         total = vln.dp.allreduce_scalar(torch.tensor([float(len(rows))]))
         q.put((rank, bucket.flat.clone(), float(total), rows))
     finally:
@@ -85,11 +89,12 @@ def test_stride_shard_keeps_sorted_batches_sorted():
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_bucket_allreduce_equals_big_batch():
+@pytest.mark.parametrize("overlap", [False, True], ids=["one_allreduce", "early_slice_async"])
+def test_two_rank_bucket_allreduce_equals_big_batch(overlap):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=150) for _ in range(world)]
@@ -106,3 +111,15 @@ def test_two_rank_bucket_allreduce_equals_big_batch():
         assert total == B
         assert torch.allclose(flat, ref, rtol=1e-10, atol=1e-12), f"rank {rank}: DP gradient != big-batch gradient"
     assert torch.equal(got[0][1], got[1][1])                 # replicas agree bit-for-bit after the all-reduce
+
+
+def test_bucket_span_of_requires_adjacent_parameters():
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (3, 5, 7)]
+    b = vln.dp.GradBucket(ps)
+    assert b.span_of(ps[1:]) == (3, 15) and b.span_of([ps[0]]) == (0, 3)
+    with pytest.raises(ValueError):
+        b.span_of([ps[0], ps[2]])
+    b.start_allreduce(ps[1:]); b.allreduce()          # no process group: both are no-ops
+    assert not b.reducer.pending
