@@ -25,7 +25,7 @@ class FakeR2REnv:
     """B scripted episodes.  Episode i has a path of n_i moves then STOP; at node k the teacher's next viewpoint is
     candidate `teach[i][k]`; any move (teacher or not) advances one node.  Distance to goal = 2 m per remaining move."""
 
-    def __init__(self, batch_size=4, max_len=8, vocab=40, seed=0, max_cands=3, max_moves=3):
+    def __init__(self, batch_size=4, max_len=8, vocab=40, seed=0, max_cands=3, max_moves=3, img=IMG):
         self.batch_size = batch_size
         self.rng = np.random.default_rng(seed)
         r = self.rng
@@ -42,7 +42,8 @@ class FakeR2REnv:
         self.ncand = r.integers(1, max_cands + 1, (batch_size, n_nodes))
         self.teach = np.array([[r.integers(0, self.ncand[i, k]) for k in range(n_nodes)] for i in range(batch_size)])
         # low-entropy but distinct features: a few base vectors mixed per (episode, node, view)
-        self.base = np.abs(r.standard_normal((8, IMG))).astype(np.float32) * 0.5
+        self.img = img                                                 # width of the visual part (2048 in R2R)
+        self.base = np.abs(r.standard_normal((8, img))).astype(np.float32) * 0.5
         self.mix = r.random((batch_size, n_nodes, VIEWS, 8)).astype(np.float32)
         self.cmix = r.random((batch_size, n_nodes, max_cands, 8)).astype(np.float32)
         self.chead = ((r.random((batch_size, n_nodes, max_cands)) - 0.5) * 6).astype(np.float32)

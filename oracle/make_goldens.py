@@ -389,6 +389,72 @@ def gen_agent_tapes():
         torch.Tensor.cpu = orig_cpu
 
 
+def gen_agent_tapes_more():
+    """Rollout-level goldens for the other two agents and for the evaluation path (SURVEY §8c last row, §8f N4):
+    FollowerAgent / SelfMonitorAgent teacher-forced (training loss + grads) and all three agents with
+    feedback="argmax" in eval mode (what `BaseAgent.test` runs, base.py:63-82): actions, trajectories, loss."""
+    A = _import_reference_agents()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle.fake_env import FakeR2REnv
+    orig_cpu = torch.Tensor.cpu
+    torch.Tensor.cpu = lambda self, *a, **k: orig_cpu(self, *a, **k).clone()
+    # 64-wide visual features instead of 2048 keep the captured parameters small (the agents take the width from
+    # BasicR2RAgent's constructor default, base.py:95-104; changed on the imported class object only)
+    init = A.BasicR2RAgent.__init__
+    orig_defaults = init.__defaults__
+    init.__defaults__ = (64,) + tuple(orig_defaults[1:])
+    try:
+        base = dict(ACT_EMB_SIZE=8, WORD_EMB_SIZE=16, HIDDEN_SIZE=32, DROP_RATE=0.5, FEAT_DROP_RATE=0.3, ML_WEIGHT=0.2,
+                    GAMMA=0.9, RL_NORMALIZE="total")
+        kinds = {
+            "follower": (dict(base, ENC_BIDIRECTION=True, ENC_LAYERS=2),
+                         lambda cfg, env: A.FollowerAgent(cfg, "/tmp", torch.device("cpu"), env, _Tok(40), episode_len=6)),
+            "monitor": (dict(base, ENC_BIDIRECTION=False, ENC_LAYERS=1, MLP_HIDDEN=[24]),
+                        lambda cfg, env: A.SelfMonitorAgent(cfg, 8, "/tmp", torch.device("cpu"), env, _Tok(40), episode_len=6)),
+            "envdrop": (dict(base, ENC_BIDIRECTION=True, ENC_LAYERS=1),
+                        lambda cfg, env: A.EnvDropAgent(cfg, 8, "/tmp", torch.device("cpu"), env, _Tok(40), episode_len=6)),
+        }
+        for kind, (cfgd, make) in kinds.items():
+            for mode in ("teacher", "argmax"):
+                if kind == "envdrop" and mode == "teacher":
+                    continue                                        # already captured by gen_agent_tapes
+                cfg = types.SimpleNamespace(**cfgd)
+                torch.manual_seed(2021)
+                env = FakeR2REnv(batch_size=5, max_len=8, vocab=40, seed=11 if mode == "teacher" else 13, img=64)
+                agent = make(cfg, env)
+                assert agent.feature_size == 64 + 128
+                if hasattr(agent, "reset_loss"):
+                    agent.reset_loss()
+                agent.eval()                                        # dropout off, BatchNorm on running stats
+                mods = [("enc.", agent.encoder), ("dec.", agent.decoder)]
+                sd = {pre + k: v.clone() for pre, m in mods for k, v in m.state_dict().items()}
+                torch.manual_seed(99)
+                if kind == "envdrop":
+                    traj = agent.rollout(train_ml=True, train_rl=False, train_cl=False, reset=True, feedback=mode)
+                    ml = agent.loss["ml_loss"]
+                elif kind == "monitor":
+                    traj = agent.rollout(train_ml=True, train_cl=False, reset=True, lamb=0.5, feedback=mode)
+                    ml = agent.ml_loss
+                else:
+                    traj = agent.rollout(train_ml=True, train_rl=False, train_cl=False, reset=True, feedback=mode)
+                    ml = agent.ml_loss
+                params = dict((pre + n, p) for pre, m in mods for n, p in m.named_parameters())
+                gs = torch.autograd.grad(ml, list(params.values()), allow_unused=True)
+                grads = {n: (g if g is not None else torch.zeros_like(p)) for (n, p), g in zip(params.items(), gs)}
+                small = {n: g for n, g in grads.items() if g.numel() <= 4096}
+                norms = {n: g.norm() for n, g in grads.items()}
+                out = dict(ml_loss=torch.as_tensor(float(ml.detach())), actions=np.stack(env.actions_log),
+                           path_len=np.array([len(t["path"]) for t in traj]))
+                if kind == "monitor":
+                    out["progress_loss"] = torch.as_tensor(float(agent.progress_loss))
+                save(f"agent_{kind}_{mode}", cfg={k: (int(v) if isinstance(v, bool) else v) for k, v in cfgd.items()
+                                                   if not isinstance(v, (str, list))},
+                     param=sd, out=out, grad=small, gradnorm=norms)
+    finally:
+        torch.Tensor.cpu = orig_cpu
+        init.__defaults__ = orig_defaults
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -408,6 +474,7 @@ def main():
     gen_losses(g)
     gen_angle_tables()
     gen_agent_tapes()
+    gen_agent_tapes_more()
 
 
 if __name__ == "__main__":

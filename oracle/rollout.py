@@ -103,6 +103,8 @@ class ModuleBackend:
     def named_grads(self):
         out = {}
         for pre, m in (("enc.", self.enc), ("dec.", self.dec), ("cri.", self.cri)):
+            if m is None:
+                continue
             for k, p in m.named_parameters():
                 out[pre + k] = p.grad if p.grad is not None else torch.zeros_like(p)
         return out
@@ -116,6 +118,7 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
         train_rl = False
     obs = env.reset(restart=False)
     B = len(obs)
+    traj = [{"instr_id": ob["instr_id"], "path": [(ob["viewpointId"], ob["heading"], ob["elevation"])]} for ob in obs]
     tokens, seq_mask, lengths = marshal_instructions(obs, dev)
     ctx, h_t, c_t = be.encode(tokens, lengths)
     ended = np.zeros(B, bool)
@@ -133,6 +136,8 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
         ml = ml + O.masked_cross_entropy(logit, target, None, "sum")
         if feedback == "teacher":
             a_t = target
+        elif feedback == "argmax":                                  # envdrop.py:184-187 (student forcing; what test() runs)
+            a_t = logit.max(1)[1]
         else:
             a_t = torch.from_numpy(np.where(inject_actions[t] < 0, 0, inject_actions[t])).to(dev) if inject_actions is not None \
                 else torch.distributions.Categorical(torch.softmax(logit, 1)).sample()
@@ -147,7 +152,7 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
             if cpu_a[i] == len(obs[i]["candidates"]) or cpu_a[i] == -1 or ended[i]:
                 cpu_a[i] = -1
         acts.append(cpu_a.copy())
-        obs = env.step(cpu_a, obs, None)
+        obs = env.step(cpu_a, obs, traj)
         dist = np.array([ob["distance"] for ob in obs], np.float32)
         is_stop = cpu_a == -1
         reward = (is_stop * (2 * (dist < 3) - 1) * 2 + (1 - is_stop) * np.sign(last_dist - dist)) * (~ended)   # envdrop.py:209-212
@@ -168,4 +173,157 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
                                [torch.from_numpy(m).to(dev) for m in masks], last_v, torch.from_numpy(ended.copy()).to(dev),
                                gamma, "total")
     ml_loss = ml * ml_weight / B
-    return dict(ml_loss=ml_loss, rl_loss=rl, total=total, loss=ml_loss + rl, actions=np.stack(acts))
+    return dict(ml_loss=ml_loss, rl_loss=rl, total=total, loss=ml_loss + rl, actions=np.stack(acts), traj=traj)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FollowerAgent.rollout (follower.py:67-175) and SelfMonitorAgent.rollout (monitor.py:88-199), train_cl=False
+# ---------------------------------------------------------------------------------------------------------------------
+class FollowerOracle:
+    def __init__(self, P_enc, P_dec, layers=2, bidirectional=True, dtype=torch.float64):
+        cv = lambda P: {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point()) for k, v in P.items()}
+        self.Pe, self.Pd = cv(P_enc), cv(P_dec)
+        self.layers, self.bi, self.dtype, self.device = layers, bidirectional, dtype, torch.device("cpu")
+
+    def encode(self, tokens, lengths):
+        return O.encoder_forward(self.Pe, tokens, lengths.tolist(), num_layers=self.layers, bidirectional=self.bi)
+
+    def decode(self, img, a_prev, cand, h, c, ctx, mask):
+        d = self.dtype
+        logit, (h1, c1), _ = O.follower_step(self.Pd, img.to(d), a_prev.to(d), cand.to(d), h, c, ctx, mask)
+        return logit, h1, c1
+
+    def named_grads(self):
+        return {pre + k: (v.grad if v.grad is not None else torch.zeros_like(v)) for pre, P in (("enc.", self.Pe), ("dec.", self.Pd))
+                for k, v in P.items() if v.is_floating_point() and v.requires_grad}
+
+
+class MonitorOracle(FollowerOracle):
+    """eval-mode BatchNorm (running statistics), like the captured tapes (agent.eval())."""
+
+    def __init__(self, P_enc, P_dec, dtype=torch.float64):
+        super().__init__(P_enc, P_dec, layers=1, bidirectional=False, dtype=dtype)
+        for k, v in self.Pd.items():                 # buffers are not trained
+            if "running_" in k or k.endswith("position.pe"):
+                v.requires_grad_(False)
+
+    def decode(self, a_prev, cand, h, c, ctx, mask, cmask):
+        d = self.dtype
+        (logit, prog), (h1, c1), _, _ = O.monitor_step(self.Pd, a_prev.to(d), cand.to(d), h, c, ctx, mask, cmask, training=False)
+        return logit, prog, h1, c1
+
+
+class FollowerModules:
+    """nn.Modules with the reference's contracts (policy.py:37-60): the HIP drop-ins on the GPU."""
+
+    def __init__(self, enc, dec, device):
+        self.enc, self.dec, self.device = enc, dec, device
+
+    def encode(self, tokens, lengths):
+        return self.enc(tokens, lengths)
+
+    def decode(self, img, a_prev, cand, h, c, ctx, mask):
+        logit, (h1, c1), _ = self.dec(img, a_prev, cand, h, c, ctx, mask)
+        return logit, h1, c1
+
+    def named_grads(self):
+        return {pre + k: (p.grad if p.grad is not None else torch.zeros_like(p)) for pre, m in (("enc.", self.enc), ("dec.", self.dec))
+                for k, p in m.named_parameters()}
+
+
+class MonitorModules(FollowerModules):
+    def decode(self, a_prev, cand, h, c, ctx, mask, cmask):
+        (logit, prog), (h1, c1), _ = self.dec(None, a_prev, cand, h, c, ctx, mask, cmask)
+        return logit, prog, h1, c1
+
+
+def _select(feedback, logit, target, obs, inject, t, dev):
+    if feedback == "teacher":
+        return target
+    if inject is not None:                          # tape actions are post-processed (-1 = stop / ended)
+        stop_idx = torch.tensor([len(ob["candidates"]) for ob in obs], device=dev)
+        a = torch.from_numpy(np.where(inject[t] < 0, 0, inject[t])).to(dev)
+        return torch.where(torch.from_numpy(inject[t] < 0).to(dev), stop_idx, a)
+    if feedback == "argmax":
+        return logit.max(1)[1]
+    return torch.distributions.Categorical(torch.softmax(logit, 1)).sample()
+
+
+def _post(a_t, obs, ended):
+    cpu_a = a_t.detach().cpu().numpy().copy()       # a COPY (SURVEY §8c.3)
+    for i in range(len(obs)):
+        if cpu_a[i] == len(obs[i]["candidates"]) or cpu_a[i] == -1 or ended[i]:
+            cpu_a[i] = -1
+    return cpu_a
+
+
+def follower_rollout(be, env, feedback: str, episode_len: int, inject_actions: Optional[np.ndarray] = None):
+    """follower.py:67-175: ml_loss = sum_t CrossEntropy(mean over non-ended rows)."""
+    dev = be.device
+    obs = env.reset(restart=False)
+    B = len(obs)
+    traj = [{"instr_id": ob["instr_id"], "path": [(ob["viewpointId"], ob["heading"], ob["elevation"])]} for ob in obs]
+    tokens, seq_mask, lengths = marshal_instructions(obs, dev)
+    ctx, h_t, c_t = be.encode(tokens, lengths)
+    F = obs[0]["feature"].shape[-1]
+    a_prev = torch.zeros(B, F, device=dev)
+    ended = np.zeros(B, bool)
+    ml, acts = 0.0, []
+    for t in range(episode_len):
+        _, img, cand, cl = marshal_step(obs, dev)
+        logit, h_t, c_t = be.decode(img, a_prev, cand, h_t, c_t, ctx, seq_mask)
+        cmask = O.length2mask(cl).to(dev)
+        logit = logit.masked_fill(cmask, -float("inf"))                       # follower.py:123
+        target = torch.from_numpy(teacher_action(obs, ended)).to(dev)
+        ml = ml + O.masked_cross_entropy(logit, target, None, "mean")         # follower.py:62,127
+        a_t = _select(feedback, logit, target, obs, inject_actions, t, dev)
+        cpu_a = _post(a_t, obs, ended)
+        acts.append(cpu_a.copy())
+        obs = env.step(cpu_a, obs, traj)
+        a_prev = cand[torch.arange(B, device=dev), torch.from_numpy(np.maximum(cpu_a, 0)).to(dev)].detach()   # follower.py:164
+        ended[:] = np.logical_or(ended, cpu_a == -1)
+        if ended.all():
+            break
+    return dict(ml_loss=ml, actions=np.stack(acts), traj=traj)
+
+
+def monitor_rollout(be, env, feedback: str, episode_len: int, lamb: float = 0.5, inject_actions: Optional[np.ndarray] = None):
+    """monitor.py:88-199: co-grounding step + progress monitor; loss = CE at t=0, lamb*MSE + (1-lamb)*CE after."""
+    dev = be.device
+    obs = env.reset(restart=False)
+    B = len(obs)
+    traj = [{"instr_id": ob["instr_id"], "path": [(ob["viewpointId"], ob["heading"], ob["elevation"])]} for ob in obs]
+    seq = np.array([ob["instr_encoding"] for ob in obs])                      # monitor.py:68-86: NOT trimmed to the longest
+    tokens = torch.from_numpy(seq).long().to(dev)
+    seq_mask = tokens == 0
+    lengths = torch.from_numpy(np.array([ob["instr_length"] for ob in obs]))
+    ctx, h_t, c_t = be.encode(tokens, lengths)
+    F = obs[0]["feature"].shape[-1]
+    a_prev = torch.zeros(B, F, device=dev)
+    ended = np.zeros(B, bool)
+    start = np.array([ob["distance"] for ob in obs], np.float32)
+    cur = start.copy()
+    ml, prog_log, acts = 0.0, 0.0, []
+    for t in range(episode_len):
+        _, _, cand, cl = marshal_step(obs, dev)
+        cmask = O.length2mask(cl).to(dev)
+        logit, prog, h_t, c_t = be.decode(a_prev, cand, h_t, c_t, ctx, seq_mask, cmask)
+        logit = logit.masked_fill(cmask, -float("inf"))
+        target = torch.from_numpy(teacher_action(obs, ended)).to(dev)
+        pt = (start - cur) / start                                            # monitor.py:154-157
+        pt[cur <= 3.0] = 1.0
+        pt[ended] = prog.detach().cpu().numpy()[ended]
+        pt_t = torch.from_numpy(pt.astype(np.float32)).to(dev).to(prog.dtype)
+        if t > 0:
+            prog_log += float(torch.mean((prog.detach() - pt_t) ** 2))
+        ml = ml + O.monitor_mixed_loss(logit, target, None, prog, pt_t, t, lamb)
+        a_t = _select(feedback, logit, target, obs, inject_actions, t, dev)
+        cpu_a = _post(a_t, obs, ended)
+        acts.append(cpu_a.copy())
+        obs = env.step(cpu_a, obs, traj)
+        cur[:] = np.array([ob["distance"] for ob in obs], np.float32)
+        ended[:] = np.logical_or(ended, cpu_a == -1)
+        a_prev = cand[torch.arange(B, device=dev), torch.from_numpy(np.maximum(cpu_a, 0)).to(dev)].detach()
+        if ended.all():
+            break
+    return dict(ml_loss=ml, progress_loss=prog_log, actions=np.stack(acts), traj=traj)
