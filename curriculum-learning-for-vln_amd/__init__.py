@@ -9,7 +9,7 @@ from . import _lib, ops, runtime, dp  # noqa: F401
 from ._lib import VlnError, LIB_PATH  # noqa: F401
 from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401
-from . import functional, staging, losses, optim  # noqa: F401
+from . import functional, staging, losses, optim, metrics  # noqa: F401
 from .staging import DeviceFeatureStore, PinnedStager  # noqa: F401
 from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401
                        AttnDecoderLSTM, MonitorDecoder)

@@ -455,6 +455,46 @@ def gen_agent_tapes_more():
         init.__defaults__ = orig_defaults
 
 
+def gen_eval_scores():
+    """Evaluation-path golden: the reference's `Evaluation.score` (engine/evaluator.py:101-146) on a
+    synthetic weighted navigation graph with hand-made trajectories (success, overshoot, early stop, detour).  The
+    object is built without its constructor (which reads the R2R json files); only the fields score() touches are set."""
+    import json
+    from collections import defaultdict
+    import networkx as nx
+    _import_reference_agents()
+    from src.engine.evaluator import Evaluation
+    rng = np.random.default_rng(5)
+    G = nx.Graph()
+    W, H = 5, 4
+    edges = []
+    for x in range(W):
+        for y in range(H):
+            for dx, dy in ((1, 0), (0, 1)):
+                if x + dx < W and y + dy < H:
+                    w = float(np.round(1.0 + 2.0 * rng.random(), 3))
+                    edges.append((f"n{x}_{y}", f"n{x + dx}_{y + dy}", w))
+    G.add_weighted_edges_from(edges)
+    ev = object.__new__(Evaluation)
+    ev.error_margin, ev.splits, ev.dataset = 3.0, ["val_unseen"], "R2R"
+    ev.distances = {"s": dict(nx.all_pairs_dijkstra_path_length(G))}
+    paths = {1: ["n0_0", "n1_0", "n2_0", "n3_0"], 2: ["n0_3", "n1_3", "n1_2", "n2_2", "n3_2"], 3: ["n4_0", "n4_1", "n4_2"],
+             4: ["n2_1", "n2_2", "n2_3"]}
+    ev.gt = {pid: {"path_id": pid, "scan": "s", "path": p} for pid, p in paths.items()}
+    ev.instr_ids = {f"{pid}_0" for pid in paths}
+    traj = {"1_0": ["n0_0", "n1_0", "n2_0", "n3_0"],                      # exact
+            "2_0": ["n0_3", "n0_2", "n1_2", "n2_2", "n3_2", "n4_2"],      # detour + overshoot
+            "3_0": ["n4_0"],                                              # never moved
+            "4_0": ["n2_1", "n3_1", "n3_2", "n3_3", "n2_3"]}              # long way round
+    results = [{"instr_id": k, "trajectory": [(v, 0.0, 0.0) for v in p]} for k, p in traj.items()]
+    summary, scores = ev.score(results)
+    out = {"edges": edges, "gt": {f"{pid}_0": {"scan": "s", "path": p} for pid, p in paths.items()}, "results": results,
+           "summary": {k: float(v) for k, v in summary.items()}, "scores": {k: [float(x) for x in v] for k, v in scores.items()}}
+    with open(os.path.join(OUT, "eval_scores.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("eval_scores:", {k: round(v, 4) for k, v in out["summary"].items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -475,6 +515,7 @@ def main():
     gen_angle_tables()
     gen_agent_tapes()
     gen_agent_tapes_more()
+    gen_eval_scores()
 
 
 if __name__ == "__main__":
