@@ -1,9 +1,12 @@
-// Fused clip-grad-norm + RMSprop step over FLAT fp32 buffers.
-// Reference: engine/trainer.py:423-427 (EnvDrop): clip_grad_norm(encoder, 40); clip_grad_norm(decoder, 40);
-// torch.optim.RMSprop(lr=1e-4) with torch defaults (alpha 0.99, eps 1e-8, no momentum, not centered).
+// Fused clip-grad-norm + optimizer step over FLAT fp32 buffers.
+// Reference: engine/trainer.py:17-21 (optim_switcher adam / rms / sgd, torch defaults), :423-427 (EnvDrop):
+// clip_grad_norm(encoder, 40); clip_grad_norm(decoder, 40); RMSprop(lr=1e-4) (alpha 0.99, eps 1e-8, no momentum, not
+// centered); Follower :65-67 two Adam instances, Monitor :219-222 one Adam (betas 0.9/0.999, eps 1e-8).
 // torch issues ~10 multi-tensor launches for this; here: one partial-sum launch + one update launch over the
 // flat parameter / gradient / square-average buffers (the gradient buffer is dp.GradBucket's all-reduce bucket).
 // Clip groups are contiguous element ranges; group norms are reduced deterministically (per-block partials).
+#include <math.h>
+
 #include "vln_internal.h"
 #include "../../include/vln_hip.h"
 
@@ -51,9 +54,31 @@ __global__ __launch_bounds__(256) void opt_sumsq_kernel(const float* g, OptGroup
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void opt_rmsprop_kernel(float* p, const float* g, float* sq, OptGroups gr,
-                                                          const float* partial, float* norms_out, float lr, float alpha,
-                                                          float eps, float max_norm, float grad_scale) {
+enum OptMode { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_SGD = 2 };
+struct OptHyper {
+  float lr, a, b, eps;          // rmsprop: a = alpha; adam: a = beta1, b = beta2
+  float bc1, bc2_rsqrt;         // adam bias corrections: 1 - beta1^t, 1 / sqrt(1 - beta2^t)
+  float max_norm, grad_scale;
+};
+
+template <int MODE>
+__device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& s2, const OptHyper& h) {
+  if (MODE == OPT_RMSPROP) {            // torch.optim.RMSprop defaults: no momentum, not centered
+    s1 = h.a * s1 + (1.f - h.a) * g * g;
+    p -= h.lr * g / (sqrtf(s1) + h.eps);
+  } else if (MODE == OPT_ADAM) {        // torch.optim.Adam defaults: no weight decay, no amsgrad
+    s1 = h.a * s1 + (1.f - h.a) * g;
+    s2 = h.b * s2 + (1.f - h.b) * g * g;
+    const float denom = sqrtf(s2) * h.bc2_rsqrt + h.eps;
+    p -= (h.lr / h.bc1) * (s1 / denom);
+  } else {                              // torch.optim.SGD defaults: plain
+    p -= h.lr * g;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g, float* s1, float* s2, OptGroups gr,
+                                                       const float* partial, float* norms_out, OptHyper h) {
   __shared__ float sh[4];
   __shared__ float s_coef;
   int grp = 0;
@@ -63,9 +88,9 @@ __global__ __launch_bounds__(256) void opt_rmsprop_kernel(float* p, const float*
   for (int b = gr.blk0[grp] + threadIdx.x; b < gr.blk0[grp + 1]; b += kOptBlock) s += partial[b];
   s = block_sum(s, sh);
   if (threadIdx.x == 0) {
-    const float norm = sqrtf(s) * grad_scale;
-    float c = (max_norm > 0.f) ? max_norm / (norm + 1e-6f) : 1.f;       // torch.nn.utils.clip_grad_norm_
-    s_coef = grad_scale * (c < 1.f ? c : 1.f);
+    const float norm = sqrtf(s) * h.grad_scale;
+    float c = (h.max_norm > 0.f) ? h.max_norm / (norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
+    s_coef = h.grad_scale * (c < 1.f ? c : 1.f);
     if (norms_out && (int)blockIdx.x == gr.blk0[grp]) norms_out[grp] = norm;
   }
   __syncthreads();
@@ -76,28 +101,55 @@ __global__ __launch_bounds__(256) void opt_rmsprop_kernel(float* p, const float*
   for (int i = 0; i < kOptPerThread / 4; ++i) {
     const long e = base + ((long)i * kOptBlock + threadIdx.x) * 4;
     if (e + 3 < end) {
-      float4 gv = *reinterpret_cast<const float4*>(g + e);
-      float4 sv = *reinterpret_cast<const float4*>(sq + e);
+      const float4 gv = *reinterpret_cast<const float4*>(g + e);
       float4 pv = *reinterpret_cast<const float4*>(p + e);
-      float gg[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
-      float ss[4] = {sv.x, sv.y, sv.z, sv.w};
-      float pp[4] = {pv.x, pv.y, pv.z, pv.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ss[k] = alpha * ss[k] + (1.f - alpha) * gg[k] * gg[k];
-        pp[k] -= lr * gg[k] / (sqrtf(ss[k]) + eps);
-      }
-      *reinterpret_cast<float4*>(sq + e) = make_float4(ss[0], ss[1], ss[2], ss[3]);
-      *reinterpret_cast<float4*>(p + e) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      float4 av = (MODE != OPT_SGD) ? *reinterpret_cast<const float4*>(s1 + e) : make_float4(0, 0, 0, 0);
+      float4 bv = (MODE == OPT_ADAM) ? *reinterpret_cast<const float4*>(s2 + e) : make_float4(0, 0, 0, 0);
+      opt_update<MODE>(pv.x, gv.x * coef, av.x, bv.x, h);
+      opt_update<MODE>(pv.y, gv.y * coef, av.y, bv.y, h);
+      opt_update<MODE>(pv.z, gv.z * coef, av.z, bv.z, h);
+      opt_update<MODE>(pv.w, gv.w * coef, av.w, bv.w, h);
+      if (MODE != OPT_SGD) *reinterpret_cast<float4*>(s1 + e) = av;
+      if (MODE == OPT_ADAM) *reinterpret_cast<float4*>(s2 + e) = bv;
+      *reinterpret_cast<float4*>(p + e) = pv;
     } else {
       for (long k = e; k < end && k < e + 4; ++k) {
-        const float gk = g[k] * coef;
-        const float sk = alpha * sq[k] + (1.f - alpha) * gk * gk;
-        sq[k] = sk;
-        p[k] -= lr * gk / (sqrtf(sk) + eps);
+        float pk = p[k], ak = (MODE != OPT_SGD) ? s1[k] : 0.f, bk = (MODE == OPT_ADAM) ? s2[k] : 0.f;
+        opt_update<MODE>(pk, g[k] * coef, ak, bk, h);
+        if (MODE != OPT_SGD) s1[k] = ak;
+        if (MODE == OPT_ADAM) s2[k] = bk;
+        p[k] = pk;
       }
     }
   }
+}
+
+static int opt_launch(int mode, float* params, const float* grads, float* s1, float* s2, const int64_t* group_begin,
+                      int ngroups, float* partial, float* norms_out, OptHyper h, hipStream_t st, const char* what) {
+  if (!params || !grads || !group_begin || !partial || ngroups < 1 || ngroups > 8 || (mode != OPT_SGD && !s1) ||
+      (mode == OPT_ADAM && !s2)) {
+    set_error("%s: bad args", what);
+    return VLN_ERR_ARG;
+  }
+  OptGroups gr;
+  gr.ngroups = ngroups;
+  int blk = 0;
+  for (int g = 0; g <= ngroups; ++g) {
+    gr.begin[g] = group_begin[g];
+    if (group_begin[g] % 4) { set_error("%s: group offsets must be multiples of 4", what); return VLN_ERR_ARG; }
+    gr.blk0[g] = blk;
+    if (g < ngroups) blk += (int)((group_begin[g + 1] - group_begin[g] + kOptChunk - 1) / kOptChunk);
+  }
+  if (blk <= 0) return VLN_OK;
+  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(blk), dim3(kOptBlock), 0, st, grads, gr, partial);
+  if (mode == OPT_RMSPROP)
+    hipLaunchKernelGGL(opt_step_kernel<OPT_RMSPROP>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+  else if (mode == OPT_ADAM)
+    hipLaunchKernelGGL(opt_step_kernel<OPT_ADAM>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+  else
+    hipLaunchKernelGGL(opt_step_kernel<OPT_SGD>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+  VLN_CHECK_LAUNCH(what);
+  return VLN_OK;
 }
 
 }  // namespace vln
@@ -113,24 +165,23 @@ extern "C" int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ng
 extern "C" int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin,
                                      int ngroups, float* partial, float* norms_out, float lr, float alpha, float eps,
                                      float max_norm, float grad_scale, vln_stream_t s) {
-  if (!params || !grads || !square_avg || !group_begin || !partial || ngroups < 1 || ngroups > 8) {
-    set_error("vln_rmsprop_clip_step: bad args");
-    return VLN_ERR_ARG;
-  }
-  OptGroups gr;
-  gr.ngroups = ngroups;
-  int blk = 0;
-  for (int g = 0; g <= ngroups; ++g) {
-    gr.begin[g] = group_begin[g];
-    if (group_begin[g] % 4) { set_error("vln_rmsprop_clip_step: group offsets must be multiples of 4"); return VLN_ERR_ARG; }
-    gr.blk0[g] = blk;
-    if (g < ngroups) blk += (int)((group_begin[g + 1] - group_begin[g] + kOptChunk - 1) / kOptChunk);
-  }
-  if (blk <= 0) return VLN_OK;
-  hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(blk), dim3(kOptBlock), 0, st, grads, gr, partial);
-  hipLaunchKernelGGL(opt_rmsprop_kernel, dim3(blk), dim3(kOptBlock), 0, st, params, grads, square_avg, gr, partial, norms_out,
-                     lr, alpha, eps, max_norm, grad_scale);
-  VLN_CHECK_LAUNCH("rmsprop_clip_step");
-  return VLN_OK;
+  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, max_norm, grad_scale};
+  return opt_launch(OPT_RMSPROP, params, grads, square_avg, nullptr, group_begin, ngroups, partial, norms_out, h,
+                    (hipStream_t)s, "vln_rmsprop_clip_step");
+}
+extern "C" int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                  const int64_t* group_begin, int ngroups, float* partial, float* norms_out, float lr,
+                                  float beta1, float beta2, float eps, int64_t step, float max_norm, float grad_scale,
+                                  vln_stream_t s) {
+  if (step < 1) { set_error("vln_adam_clip_step: step counts from 1"); return VLN_ERR_ARG; }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), max_norm, grad_scale};
+  return opt_launch(OPT_ADAM, params, grads, exp_avg, exp_avg_sq, group_begin, ngroups, partial, norms_out, h,
+                    (hipStream_t)s, "vln_adam_clip_step");
+}
+extern "C" int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
+                                 float* norms_out, float lr, float max_norm, float grad_scale, vln_stream_t s) {
+  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, max_norm, grad_scale};
+  return opt_launch(OPT_SGD, params, grads, nullptr, nullptr, group_begin, ngroups, partial, norms_out, h, (hipStream_t)s,
+                    "vln_sgd_clip_step");
 }

@@ -1,10 +1,12 @@
-"""Fused clip-grad-norm + RMSprop over flat buffers.
+"""Fused clip-grad-norm + optimizer step over flat buffers.
 
-Reference semantics (engine/trainer.py:380-381,423-427): `torch.optim.RMSprop(params, lr)` with torch defaults and
-`clip_grad_norm(module.parameters(), 40.)` per module before the step.  Here parameters, gradients and the
-square-average state of all groups live in three flat fp32 buffers (each `p.data` / `p.grad` is a view), so
-`zero_grad` is one memset, the data-parallel exchange is one RCCL all-reduce of the gradient buffer, and
-clip + update are two launches (`vln_rmsprop_clip_step`) instead of ~10 multi-tensor launches.
+Reference semantics (engine/trainer.py): `optim_switcher` = {adam, rms, sgd} with torch defaults (:17-21); EnvDrop
+trains with one RMSprop over encoder+decoder+critic after `clip_grad_norm(module.parameters(), 40.)` per module
+(:380-381,423-427); Follower with two Adam instances (:65-67), Self-Monitor with one (:219-222).  Here parameters,
+gradients and the optimizer state of all groups live in flat fp32 buffers (each `p.data` / `p.grad` is a view), so
+`zero_grad` is one memset, the data-parallel exchange is one RCCL all-reduce of the gradient buffer (slices of it
+may start early, see `start_allreduce`), and clip + update are two launches (`vln_*_clip_step`) instead of ~10
+multi-tensor launches.
 """
 from __future__ import annotations
 
@@ -17,15 +19,17 @@ from . import _lib
 from .dp import BucketReducer
 
 
-class FusedRMSprop:
-    def __init__(self, groups: Sequence[Sequence[torch.nn.Parameter]], lr: float = 1e-2, alpha: float = 0.99,
-                 eps: float = 1e-8, clip_norm: float = 0.0):
+class _FusedFlat:
+    """Shared plumbing: flat parameter / gradient buffers, clip groups, overlapped all-reduce."""
+    n_state = 0
+
+    def __init__(self, groups: Sequence[Sequence[torch.nn.Parameter]], lr: float, clip_norm: float = 0.0):
         """groups: one parameter list per clip group (e.g. [encoder.parameters(), decoder.parameters()])."""
         self.groups: List[List[torch.nn.Parameter]] = [[p for p in g if p.requires_grad] for g in groups]
-        self.lr, self.alpha, self.eps, self.clip_norm = lr, alpha, eps, clip_norm
+        self.lr, self.clip_norm = lr, clip_norm
         first = self.groups[0][0]
         if not first.is_cuda:
-            raise _lib.VlnError("FusedRMSprop: parameters must be on the GPU")
+            raise _lib.VlnError(f"{type(self).__name__}: parameters must be on the GPU")
         begins, off = [], 0
         for g in self.groups:
             off = (off + 3) // 4 * 4
@@ -36,7 +40,7 @@ class FusedRMSprop:
         dev = first.device
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.state = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(self.n_state)]
         self._begins = (C.c_int64 * len(begins))(*begins)
         # group g covers [begins[g], begins[g+1]); the pad before the next group belongs to group g (zeros)
         self.params, self.views = [], []
@@ -56,6 +60,7 @@ class FusedRMSprop:
         self._partial = torch.empty(max(int(nb), 1), dtype=torch.float32, device=dev)
         self.norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
         self._reducer = BucketReducer(self.flat_g)
+        self.steps = 0
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
@@ -72,12 +77,62 @@ class FusedRMSprop:
     def allreduce(self, group=None):
         self._reducer.finish(group)
 
+    def _launch(self, lib, grad_scale: float) -> int:
+        raise NotImplementedError
+
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
-        lib = _lib.load()
-        _lib.check(lib.vln_rmsprop_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.sq.data_ptr(), self._begins,
-                                             len(self.groups), self._partial.data_ptr(), self.norms.data_ptr(), self.lr,
-                                             self.alpha, self.eps, self.clip_norm, grad_scale,
-                                             _lib.raw_stream()), "vln_rmsprop_clip_step")
+        self.steps += 1
+        st = self._launch(_lib.load(), grad_scale)
+        if st:
+            _lib.check(st, type(self).__name__ + ".step")
         for p in self.params:                       # in-place update outside autograd: tell version-keyed caches
             torch.autograd.graph.increment_version(p)
+
+
+class FusedRMSprop(_FusedFlat):
+    """torch.optim.RMSprop(params, lr) with torch defaults (alpha 0.99, eps 1e-8, no momentum, not centered)."""
+    n_state = 1
+
+    def __init__(self, groups, lr: float = 1e-2, alpha: float = 0.99, eps: float = 1e-8, clip_norm: float = 0.0):
+        super().__init__(groups, lr, clip_norm)
+        self.alpha, self.eps = alpha, eps
+        self.sq = self.state[0]
+
+    def _launch(self, lib, grad_scale):
+        return lib.vln_rmsprop_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.sq.data_ptr(), self._begins,
+                                         len(self.groups), self._partial.data_ptr(), self.norms.data_ptr(), self.lr, self.alpha,
+                                         self.eps, self.clip_norm, grad_scale, _lib.raw_stream())
+
+
+class FusedAdam(_FusedFlat):
+    """torch.optim.Adam(params, lr) with torch defaults (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad)."""
+    n_state = 2
+
+    def __init__(self, groups, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, clip_norm: float = 0.0):
+        super().__init__(groups, lr, clip_norm)
+        self.betas, self.eps = betas, eps
+        self.exp_avg, self.exp_avg_sq = self.state
+
+    def _launch(self, lib, grad_scale):
+        return lib.vln_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self._begins, len(self.groups), self._partial.data_ptr(),
+                                      self.norms.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
+                                      self.clip_norm, grad_scale, _lib.raw_stream())
+
+
+class FusedSGD(_FusedFlat):
+    """torch.optim.SGD(params, lr) with torch defaults (no momentum, no weight decay)."""
+    n_state = 0
+
+    def __init__(self, groups, lr: float = 1e-3, clip_norm: float = 0.0):
+        super().__init__(groups, lr, clip_norm)
+
+    def _launch(self, lib, grad_scale):
+        return lib.vln_sgd_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self._begins, len(self.groups),
+                                     self._partial.data_ptr(), self.norms.data_ptr(), self.lr, self.clip_norm, grad_scale,
+                                     _lib.raw_stream())
+
+
+# the reference's optim_switcher (engine/trainer.py:17-21)
+optim_switcher = {"adam": FusedAdam, "rms": FusedRMSprop, "sgd": FusedSGD}

@@ -96,6 +96,13 @@ int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ngroups);
 int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin, int ngroups,
                           float* partial, float* norms_out, float lr, float alpha, float eps, float max_norm, float grad_scale,
                           vln_stream_t s);
+/* Same contract for the other two entries of the reference's optim_switcher (trainer.py:17-21), torch defaults:
+ * Adam (betas, eps, bias correction with step = 1, 2, ...; no weight decay / amsgrad) and plain SGD. */
+int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* group_begin,
+                       int ngroups, float* partial, float* norms_out, float lr, float beta1, float beta2, float eps,
+                       int64_t step, float max_norm, float grad_scale, vln_stream_t s);
+int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
+                      float* norms_out, float lr, float max_norm, float grad_scale, vln_stream_t s);
 
 /* ---- loss / action-selection stage of the rollouts (follower.py:123-139, envdrop.py:173-195, monitor.py:146-176):
  * logits.masked_fill_(cand_mask, -inf) [in place when write_mask], CrossEntropyLoss(ignore_index, reduction="none"),

@@ -110,6 +110,35 @@ def test_fused_rmsprop_clip_matches_torch(vln):
     assert mine[0][0]._version > v0                    # version-keyed weight shadows see the in-place update
 
 
+@pytest.mark.parametrize("name", ["adam", "sgd"])
+def test_fused_adam_sgd_match_torch(vln, name):
+    """The other two entries of the reference's optim_switcher (trainer.py:17-21; Follower / Self-Monitor train with
+    Adam, :65-67,219-222): parameter trajectories over 10 steps vs torch.optim with torch defaults, no clipping in
+    one run and per-group clipping in the other."""
+    for clip in (0.0, 1.5):
+        torch.manual_seed(5)
+        shapes = [[(37, 5), (11,), (64, 33)], [(7,), (129, 3), (2, 2)]]
+        ref = [[torch.nn.Parameter(torch.randn(s, device=DEV)) for s in g] for g in shapes]
+        mine = [[torch.nn.Parameter(p.detach().clone()) for p in g] for g in ref]
+        flat_ref = [p for g in ref for p in g]
+        opt_ref = torch.optim.Adam(flat_ref, lr=1e-3) if name == "adam" else torch.optim.SGD(flat_ref, lr=1e-2)
+        opt = vln.optim.optim_switcher[name](mine, lr=1e-3 if name == "adam" else 1e-2, clip_norm=clip)
+        for step in range(10):
+            opt.zero_grad(); opt_ref.zero_grad()
+            for gr, gm in zip(ref, mine):
+                for pr, pm in zip(gr, gm):
+                    gval = torch.randn_like(pr) * (3.0 if step % 2 else 0.3)
+                    pr.grad = gval.clone()
+                    pm.grad.add_(gval)
+            if clip > 0:
+                for g in ref:
+                    torch.nn.utils.clip_grad_norm_(g, clip)
+            opt_ref.step(); opt.step()
+            for gr, gm in zip(ref, mine):
+                for pr, pm in zip(gr, gm):
+                    assert torch.allclose(pm, pr, rtol=2e-5, atol=2e-6), (name, clip, step)
+
+
 def test_pinned_stager_roundtrip_and_reuse(vln):
     st = vln.PinnedStager(DEV, depth=2)
     rng = np.random.default_rng(0)
