@@ -36,6 +36,30 @@ def loc_embedding_table(angle_size: int = 128, views: int = 36) -> torch.Tensor:
     return torch.from_numpy(t)
 
 
+def read_feature_tsv(path: str, views: int = 36, image_w: int = 640, image_h: int = 480, vfov: int = 60):
+    """The precomputed-feature file of the reference (`ImageFeatures.read_in`, utils/misc.py:253-279): one TSV row per
+    viewpoint, fields scanId, viewpointId, image_w, image_h, vfov, features = base64 of float32 [views, 2048].
+    Returns (table float32 [N, views, IMG] in file order, ids) with ids[i] = scanId + "_" + viewpointId -- the layout
+    `DeviceFeatureStore` keeps in HBM instead of the reference's dict of per-viewpoint arrays."""
+    import base64
+    import csv
+    import sys
+    csv.field_size_limit(sys.maxsize)
+    rows, ids = [], []
+    with open(path, "r") as f:
+        for item in csv.DictReader(f, delimiter="\t", fieldnames=["scanId", "viewpointId", "image_w", "image_h", "vfov", "features"]):
+            if int(item["image_h"]) != image_h or int(item["image_w"]) != image_w or int(item["vfov"]) != vfov:
+                raise ValueError(f"{path}: unexpected camera parameters in row {len(ids)}")
+            a = np.frombuffer(base64.b64decode(item["features"].encode("ascii")), dtype=np.float32)
+            if a.size % views:
+                raise ValueError(f"{path}: row {len(ids)} does not hold {views} views")
+            rows.append(a.reshape(views, -1))
+            ids.append(item["scanId"] + "_" + item["viewpointId"])
+    if not rows:
+        raise ValueError(f"{path}: no feature rows")
+    return torch.from_numpy(np.stack(rows)), ids
+
+
 class DeviceFeatureStore:
     def __init__(self, table: torch.Tensor, ids: Optional[Sequence[str]] = None, device="cuda", dtype=torch.float32,
                  angle_size: int = 128, seed: int = 0xFEA7):
@@ -48,6 +72,16 @@ class DeviceFeatureStore:
         self.row_of: Dict[str, int] = {k: i for i, k in enumerate(ids)} if ids is not None else {}
         self.angle_table = loc_embedding_table(angle_size, self.V).to(self.device)
         self.seed, self._calls = seed, 0
+
+    @classmethod
+    def from_tsv(cls, path: str, device="cuda", dtype=torch.float32, views: int = 36, **kw):
+        """Load the reference's feature TSV once and keep it resident (utils/misc.py:253-279)."""
+        table, ids = read_feature_tsv(path, views)
+        return cls(table, ids, device=device, dtype=dtype, **kw)
+
+    def rows_for(self, long_ids: Sequence[str]) -> torch.Tensor:
+        """int64 row indices (on the store's device) of `scanId_viewpointId` keys -- what a step ships instead of features."""
+        return torch.tensor([self.row_of[k] for k in long_ids], dtype=torch.int64, device=self.device)
 
     def _drop(self, p):
         self._calls += 1

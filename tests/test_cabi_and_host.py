@@ -146,3 +146,25 @@ def test_synthetic_tape_follows_the_obs_contract():
             assert s["target"][i] == -1 or 0 <= s["target"][i] < n[i]
         assert (s["img"][..., :2048] >= 0).all()
     assert bench.usable_cores() >= 1
+
+
+def test_feature_tsv_reader_matches_reference_format(tmp_path):
+    """Row N2: `ImageFeatures.read_in` file format (utils/misc.py:253-279): TSV, base64 float32 [36, 2048] per viewpoint."""
+    import base64
+    import numpy as np
+    from vln_amd import staging
+    rng = np.random.default_rng(0)
+    feats = {("scanA", "vp1"): rng.random((36, 2048), dtype=np.float32), ("scanA", "vp2"): rng.random((36, 2048), dtype=np.float32),
+             ("scanB", "vp9"): rng.random((36, 2048), dtype=np.float32)}
+    p = tmp_path / "feats.tsv"
+    with open(p, "w") as f:
+        for (scan, vp), a in feats.items():
+            f.write("\t".join([scan, vp, "640", "480", "60", base64.b64encode(a.tobytes()).decode("ascii")]) + "\n")
+    table, ids = staging.read_feature_tsv(str(p))
+    assert ids == ["scanA_vp1", "scanA_vp2", "scanB_vp9"] and table.shape == (3, 36, 2048)
+    for i, a in enumerate(feats.values()):
+        assert np.array_equal(table[i].numpy(), a)
+    with open(p, "a") as f:
+        f.write("\t".join(["scanB", "bad", "641", "480", "60", "AAAA"]) + "\n")
+    with pytest.raises(ValueError):
+        staging.read_feature_tsv(str(p))
