@@ -77,8 +77,9 @@ SIGNATURES = {
     "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr]),
     "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
-    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
-    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr]),
+    "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
+    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),

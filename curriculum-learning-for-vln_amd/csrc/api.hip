@@ -24,8 +24,10 @@ int check_hip(hipError_t e, const char* what) {
 int g_graphs_enabled = 1;
 // [0] = 256: interleaved A/B (scripts/ab_bench.py) shows 256/512/768 within noise in time; 256 halves the split-K
 // slab traffic (PMC), so it wins on bytes
-// [2] = 1: narrow outputs (N <= 1024) use the 16-column kernel with the K split inside the workgroup
-int g_tunable[8] = {256, 1, 1, 0, 0, 0, 0, 0};
+// [2] = 1, [3] = 512: narrow outputs (N <= 1024) with a SHORT contraction (K <= 512) use the 16-column kernel with the K
+// split inside the workgroup.  Interleaved A/B, GPU-bound iteration (scripts/ab_bench.py): all K 3.075 ms, K <= 1024
+// 2.890, K <= 512 2.861, off 2.878 -- every 16-column workgroup streams the whole X, which loses for K = 2176.
+int g_tunable[8] = {256, 1, 1, 512, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {

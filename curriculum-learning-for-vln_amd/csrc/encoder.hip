@@ -436,52 +436,41 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
   return VLN_OK;
 }
 
-template <typename TW, int NS>
-static int launch_persist_bwd_ns(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
-  constexpr int HD = NS * RecCfg<TW>::BK;
-  const size_t lds = (size_t)(16 * (4 * HD + 4) + 4 * 16 * 17 + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel<TW, NS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("persistent lstm bwd: cannot reserve %zu bytes of LDS", lds);
-      return VLN_ERR_HIP;
-    }
-    attr_set = true;
+template <typename TW>
+static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid) {
+  switch (a.Hd / 64) {
+    case 2: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 2>), grid, dim3(256), 0, st, a, counters, status, exch); break;
+    case 4: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 4>), grid, dim3(256), 0, st, a, counters, status, exch); break;
+    case 8: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 8>), grid, dim3(256), 0, st, a, counters, status, exch); break;
+    default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
   }
-  hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NS>), grid, dim3(256), lds, st, a, counters, status);
   VLN_CHECK_LAUNCH("lstm_persist_bwd");
   return VLN_OK;
 }
-template <typename TW>
-static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
-  constexpr int BK = RecCfg<TW>::BK;
-  switch (a.Hd / BK) {
-    case 2: return launch_persist_bwd_ns<TW, 2>(st, a, counters, status, grid);
-    case 4: return launch_persist_bwd_ns<TW, 4>(st, a, counters, status, grid);
-    case 8: return launch_persist_bwd_ns<TW, 8>(st, a, counters, status, grid);
-    case 16: return launch_persist_bwd_ns<TW, 16>(st, a, counters, status, grid);
-    default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
-  }
+
+// sync_ws layout: kSyncHeaderBytes of status word + arrival-flag lines (zeroed every call), then the backward's
+// partial-dh exchange buffer
+extern "C" int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs) {
+  if (B <= 0 || Hd <= 0 || dirs < 1) return kSyncHeaderBytes;
+  return kSyncHeaderBytes + persist_bwd_exchange_floats(B, Hd, dirs) * 4;
 }
 
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
-                                int L, int Hd, int dirs, void* sync_ws, vln_stream_t s) {
+                                int L, int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
-  if (persist_ok(B, L, Hd, dirs, sync_ws) && al16(w_hh) && al16(hprev)) {
+  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= kSyncHeaderBytes && al16(w_hh) && al16(hprev)) {
     hipStream_t st = (hipStream_t)s;
-    int r = fill_f32(st, (float*)sync_ws, 64, 0.f);     // counters [0..31], status word [32]
+    int r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);     // status word [32], flag lines from word 64
     if (r) return r;
     RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
     ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
-    return (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw, cw + 32, grid)
-                               : launch_persist_fwd<float>(st, a, cw, cw + 32, grid);
+    return (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
+                               : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
   }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[10]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat},
@@ -512,19 +501,21 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
                                 float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, void* sync_ws,
-                                vln_stream_t s) {
+                                int64_t sync_ws_bytes, vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
-  if (persist_ok(B, L, Hd, dirs, sync_ws) && al16(w_hh_t) && al16(dgates)) {
+  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
+      al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
-    int r = fill_f32(st, (float*)sync_ws, 64, 0.f);
+    int r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
     if (r) return r;
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
-    return (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw, cw + 32, grid)
-                               : launch_persist_bwd<float>(st, a, cw, cw + 32, grid);
+    float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
+    return (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
+                               : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
   }
   struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},
                                                 {wtype, B, L, Hd, dirs}};

@@ -7,39 +7,71 @@
 // Geometry: workgroup (jb, d, bb) = 16 hidden units x direction d x 16 batch rows, 4 waves = 4 gates.
 // Dependency group = the Hd/16 workgroups sharing (d, bb): step s needs the h slices all of them wrote in
 // step s-1.  Hand-off (cdna_hip_programming.md Guideline 16, recipe R1, counter form):
-//   producer: every h element is stored write-through (`global_store_dword sc1` via a relaxed agent-scope
-//             atomic store) -> every wave `s_waitcnt vmcnt(0)` -> workgroup barrier -> ONE lane adds 1 to the
-//             group's counter (agent-scope atomic);
-//   consumer: ONE lane polls the counter with sc1 loads (+ s_sleep) until it reaches njb*s -> workgroup barrier
+//   producer: every handed-off element is stored write-through (sc1) -> every wave `s_waitcnt vmcnt(0)` ->
+//             workgroup barrier -> ONE lane adds 1 to the group's counter (agent-scope atomic);
+//   consumer: wave 0 polls the counter with sc1 loads (+ s_sleep) until it reaches njb*s -> workgroup barrier
 //             -> EVERY load of handed-off bytes is a `buffer_load_dwordx4 ... sc1` (bypasses this CU's L1).
 // No fence is needed in this form; results do not depend on placement or timing.  All workgroups must be
 // co-resident (the host only takes this path when the grid fits the 256 CUs); every spin is bounded and a
 // timeout sets the status word and lets the kernel drain (wrong numbers, never a hang).
 #pragma once
 
+// A/B switch for scripts/lstm_probe.hip.  1 = the forward's bookkeeping stores are issued AFTER the arrival.  Measured
+// on MI355X (same box, interleaved): 572 us vs 515 us per 80-step launch -- LATE IS SLOWER: the poll's
+// `s_waitcnt vmcnt(0)` then also waits for those seven stores.  Default 0.
+#ifndef VLN_FWD_LATE_STORES
+#define VLN_FWD_LATE_STORES 0
+#endif
+#ifndef VLN_STAMP          // scripts/lstm_probe.hip defines it to record s_memrealtime at the stages of one workgroup
+#define VLN_STAMP(k)
+#endif
+
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 #define VLN_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define VLN_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-__device__ __forceinline__ void group_wait(unsigned* cnt, unsigned target, unsigned* status, int* s_abort) {
-  if (threadIdx.x == 0 && !*s_abort) {
+// Arrival signalling.  EACH dependency group owns a 128-byte line of the sync header.  That placement is what matters:
+// with the eight groups' counters packed in adjacent words (one line) every step sent 128 atomics and eight pollers
+// to the same line and a step cost 6.3 us (forward) / 8.7 us (backward); one line per group: 3.4 / 2.7 us
+// (scripts/lstm_probe.hip, MI355X, B=64, Hd=256, L=80).  Two forms, A/B-measured on one box:
+//   VLN_SYNC_FLAGS 0 (default): one counter per group -- arrive = agent-scope atomic add, wait = poll until njb*epoch;
+//   VLN_SYNC_FLAGS 1: one word per producer in the line -- arrive = write-through store of the epoch, wait = one load
+//                     of the line (lane p = producer p) until every word reached it.  ~4 % slower (289 vs 278 us).
+// Epochs count steps from 1; the header is zeroed before every launch.
+constexpr int kSyncHeaderBytes = 8192;    // status word at byte 128, flag lines (32 groups x 128 B) from byte 256
+#ifndef VLN_SYNC_FLAGS
+#define VLN_SYNC_FLAGS 0
+#endif
+__device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned epoch, unsigned* status, int* s_abort) {
+  if (threadIdx.x < 64 && !*s_abort) {
+    const int lane = threadIdx.x;
     unsigned spins = 0;
-    while (VLN_AGENT_LOAD(cnt) < target) {
+    for (;;) {
+#if VLN_SYNC_FLAGS
+      const unsigned v = (lane < njb) ? VLN_AGENT_LOAD(flags + lane) : epoch;
+      if (__all(v >= epoch)) break;
+#else
+      const unsigned v = VLN_AGENT_LOAD(flags);
+      if (v >= epoch * (unsigned)njb) break;
+#endif
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 24)) {            // ~1 s: a workgroup of the group is not resident / died
-        VLN_AGENT_STORE(status, 1u);
-        *s_abort = 1;
+        if (lane == 0) { VLN_AGENT_STORE(status, 1u); *s_abort = 1; }
         break;
       }
     }
   }
   __syncthreads();
 }
-__device__ __forceinline__ void group_arrive(unsigned* cnt) {
+__device__ __forceinline__ void group_arrive(unsigned* flags, int jb, unsigned epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if VLN_SYNC_FLAGS
+  if (threadIdx.x == 0) VLN_AGENT_STORE(flags + jb, epoch);
+#else
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // resident weight fragments of one wave: NS K-steps x 32 bytes per lane
@@ -116,9 +148,9 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
   const int fi = lane & 15, fq = lane >> 4;
   const int j0 = blockIdx.x * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
   const int B = a.B, L = a.L;
-  const unsigned njb = gridDim.x;
+  const int njb = (int)gridDim.x;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
-  unsigned* cnt = counters + d * gridDim.z + blockIdx.z;
+  unsigned* cnt = counters + (d * gridDim.z + blockIdx.z) * 32;      // this group's flag line
 
   WFrag<TW, NS> w;
   load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
@@ -142,8 +174,10 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       const float* xp = a.xproj + row * G + (long)d * 4 * HD + j;
       xi = xp[0]; xf = xp[HD]; xg = xp[2 * HD]; xo = xp[3 * HD];
     }
+    VLN_STAMP(0);
     if (step > 0) {
-      group_wait(cnt, njb * (unsigned)step, status, &s_abort);
+      group_wait(cnt, njb, (unsigned)step, status, &s_abort);
+      VLN_STAMP(1);
       // h tile [16 rows x HD] of time t, written by the group's workgroups in the previous step
 #pragma unroll
       for (int u = 0; u < HD / 64; ++u) {
@@ -157,6 +191,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       for (int i = threadIdx.x; i < 16 * LDH; i += 256) sh[i] = 0.f;
     }
     __syncthreads();
+    VLN_STAMP(2);
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       mfma_resident<TW, NS>(&sh[fi * LDH], w, fq, acc);
@@ -164,17 +199,16 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       for (int r = 0; r < 4; ++r) sg[wave][fq * 4 + r][fi] = acc[r];
     }
     __syncthreads();
+    VLN_STAMP(3);
+    float si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, yv = 0.f, c_in = creg;
     if (live) {
       const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf, pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
       const bool valid = t < len;
-      const float si = sigmoidf_(pi), sf = sigmoidf_(pf), tg = tanhf(pg), so = sigmoidf_(po);
-      const float cn = sf * creg + si * tg, tc = tanhf(cn), hn = so * tc;
-      float* ac = a.act + row * G + (long)d * 4 * HD + j;
-      ac[0] = si; ac[HD] = sf; ac[2 * HD] = tg; ac[3 * HD] = so;
-      a.tanh_c[row * Y + d * HD + j] = tc;
-      a.y[row * Y + d * HD + j] = valid ? hn : 0.f;
-      a.cprev[(sbase + b) * HD + j] = creg;                       // state fed into time t (for BPTT)
-      if (step == 0) a.hprev[(sbase + b) * HD + j] = 0.f;
+      si = sigmoidf_(pi); sf = sigmoidf_(pf); tg = tanhf(pg); so = sigmoidf_(po);
+      const float cn = sf * creg + si * tg;
+      tc = tanhf(cn);
+      const float hn = so * tc;
+      yv = valid ? hn : 0.f;
       const float hs = valid ? hn : hreg, cs = valid ? cn : creg;
       const int tn = (d == 0) ? t + 1 : t - 1;
       if (tn >= 0 && tn < L) {
@@ -185,32 +219,134 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       }
       hreg = hs; creg = cs;
     }
-    group_arrive(cnt);
+    VLN_STAMP(4);
+#if VLN_FWD_LATE_STORES
+    group_arrive(cnt, blockIdx.x, (unsigned)step + 1u);
+    VLN_STAMP(5);
+#endif
+    if (live) {   // saved for BPTT / the layer output: read only after this launch
+      float* ac = a.act + row * G + (long)d * 4 * HD + j;
+      ac[0] = si; ac[HD] = sf; ac[2 * HD] = tg; ac[3 * HD] = so;
+      a.tanh_c[row * Y + d * HD + j] = tc;
+      a.y[row * Y + d * HD + j] = yv;
+      a.cprev[(sbase + b) * HD + j] = c_in;                       // state fed into time t
+      if (step == 0) a.hprev[(sbase + b) * HD + j] = 0.f;
+    }
+#if !VLN_FWD_LATE_STORES
+    group_arrive(cnt, blockIdx.x, (unsigned)step + 1u);
+    VLN_STAMP(5);
+#endif
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward through time
+//
+// dh_t[b, j] = sum over the 4*Hd gate columns k of dgates_{t+1}[b, k] * W_hh[k, j].  Workgroup (jb, d, bb) has just
+// produced dgates_{t+1} for ITS 64 gate columns (4 gates x 16 units), so it contracts those 64 columns against its
+// resident [64, Hd] slice of W_hh and publishes a PARTIAL dh for all Hd units; the owner of units j0..j0+15 sums the
+// njb partials.  Per step a workgroup then reads njb x 1 KB = Hd*4 bytes (like the forward kernel) instead of the
+// full [16, 4*Hd] dgates rows (4x more: measured 4.5 us of an 8.7 us step, scripts/lstm_probe.hip).
+// Exchange buffer (sync_ws + kSyncHeaderBytes): [d][bb][parity][producer jb][unit Hd][row 16] fp32; a lane's MFMA result (4
+// consecutive rows of one unit) is ONE 16-byte write-through store, a consumer wave fetches one producer's
+// [16 units][16 rows] block with ONE 16-byte sc1 load per lane.  Two parities: a producer can run at most one step
+// ahead of the slowest consumer of its group (it needs everybody's arrival for step k before it may write step k+2).
+// Summation order is fixed (producers wave, wave+4, ... then waves 0..3): results do not depend on timing.
 // ---------------------------------------------------------------------------------------------------------
-template <typename TW, int NS>
-__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status) {
-  constexpr int HD = NS * RecCfg<TW>::BK;
-  constexpr int LDD = 4 * HD + 4;
-  // ALL LDS of this kernel is one dynamic array (base stays 16-byte aligned, Guideline 17):
-  //   sd [16][LDD] dgates tile of the later time step | sp [4][16][17] partial dh | abort flag
-  extern __shared__ __attribute__((aligned(16))) float sd[];
-  float (*sp)[16][17] = reinterpret_cast<float (*)[16][17]>(sd + 16 * LDD);
-  int& s_abort = *reinterpret_cast<int*>(sd + 16 * LDD + 4 * 16 * 17);
+template <typename TW, int NSK> struct AFrag;
+template <int NSK> struct AFrag<float, NSK> { float4 v[NSK][2]; };
+template <int NSK> struct AFrag<bf16_raw, NSK> { bf16x8 hi[NSK][2], lo[NSK][2]; };
+
+template <typename TW, int NSK>
+__device__ __forceinline__ void load_afrag(AFrag<TW, NSK>& f, const float* arow, int fq) {
+  constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+#pragma unroll
+  for (int s = 0; s < NSK; ++s) {
+    const float* p = arow + s * BK + fq * VK;
+    if constexpr (sizeof(TW) == 4) {
+      f.v[s][0] = *reinterpret_cast<const float4*>(p);
+      f.v[s][1] = *reinterpret_cast<const float4*>(p + 4);
+    } else {
+      float x[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(p + q * 4);
+        x[q * 4] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {     // activations split hi + lo: only the weight stream is quantised
+        f.hi[s][0][j] = (__bf16)x[j];
+        f.hi[s][1][j] = (__bf16)x[8 + j];
+        f.lo[s][0][j] = (__bf16)(x[j] - (float)f.hi[s][0][j]);
+        f.lo[s][1][j] = (__bf16)(x[8 + j] - (float)f.hi[s][1][j]);
+      }
+    }
+  }
+}
+template <typename TW, int NSK>
+__device__ __forceinline__ void mfma_frags(const AFrag<TW, NSK>& f, const WFrag<TW, NSK>& w, f32x4& acc) {
+#pragma unroll
+  for (int s = 0; s < NSK; ++s) {
+    if constexpr (sizeof(TW) == 4) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][0].x, w.v[s][0].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][0].y, w.v[s][0].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][0].z, w.v[s][0].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][0].w, w.v[s][0].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][1].x, w.v[s][1].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][1].y, w.v[s][1].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][1].z, w.v[s][1].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[s][1].w, w.v[s][1].w, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.lo[s][0], w.v[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.lo[s][1], w.v[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[s][0], w.v[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[s][1], w.v[s][1], acc, 0, 0, 0);
+    }
+  }
+}
+
+// floats of the exchange buffer behind the sync header
+__host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int dirs) {
+  return (long)dirs * ((B + 15) / 16) * 2 * (Hd / 16) * Hd * 16;
+}
+
+template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
+__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, float* exch) {
+  constexpr int HD = NT * 64;
+  constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+  constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
+  constexpr int NJB = HD / 16;                 // producers per dependency group
+  constexpr int LDT = 64 + 4;
+  __shared__ __attribute__((aligned(16))) float tile[16 * LDT];   // this step's dgates: [row][gate*16 + unit]
+  __shared__ __attribute__((aligned(16))) float red[4][64][4];    // per-wave sums of the incoming partial-dh blocks
+  __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const int j0 = blockIdx.x * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const int jb = blockIdx.x, j0 = jb * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
   const int B = a.B, L = a.L;
-  const unsigned njb = gridDim.x;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
-  unsigned* cnt = counters + d * gridDim.z + blockIdx.z;
+  unsigned* cnt = counters + (d * gridDim.z + blockIdx.z) * 32;      // this group's flag line
 
-  WFrag<TW, NS> w;   // rows j of W_hh^T, this wave's gate block of the contraction
-  load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh_t) + ((long)d * HD + j0 + fi) * 4 * HD + (long)wave * HD, fq);
+  // resident slice of W_hh: rows = this workgroup's 64 gate columns, all HD input units; read from the transposed
+  // shadow [unit n][4*HD] where each gate's 16 columns are contiguous
+  WFrag<TW, NSK> w[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (wave * NT + i) * 16 + fi;
+    const TW* wrow = reinterpret_cast<const TW*>(a.w_hh_t) + ((long)d * HD + n) * 4 * HD + j0;
+#pragma unroll
+    for (int s = 0; s < NSK; ++s) {
+      const int kk0 = s * BK + fq * VK;        // first of this lane's VK consecutive k (never straddles a gate)
+      const TW* p = wrow + (long)(kk0 / 16) * HD + (kk0 % 16);
+      if constexpr (sizeof(TW) == 4) {
+        w[i].v[s][0] = *reinterpret_cast<const float4*>(p);
+        w[i].v[s][1] = *reinterpret_cast<const float4*>(p + 4);
+      } else {
+        w[i].v[s][0] = *reinterpret_cast<const bf16x8*>(p);
+        w[i].v[s][1] = *reinterpret_cast<const bf16x8*>(p + 8);
+      }
+    }
+  }
 
   const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
   const int b = b0 + bl, j = j0 + jl;
@@ -218,14 +354,16 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   const int len = live ? a.lengths[b] : 0;
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
   float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
-  __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(a.dgates, 0, (unsigned)((long)L * B * G * 4), 0x00020000);
+  const long grp = (long)(d * gridDim.z + blockIdx.z) * 2;          // [grp + parity][producer][unit][row]
+  __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      exch, 0, (unsigned)(persist_bwd_exchange_floats(B, HD, a.dirs) * 4), 0x00020000);
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();
 
   for (int step = L - 1; step >= 0; --step) {
+    const int k = L - 1 - step;                // steps already processed
     const int t = (d == 0) ? step : (L - 1 - step);
-    const bool first = (step == L - 1);
     const long row = (long)t * B + (live ? b : 0);
     const bool valid = live && (t < len);
     float dyv = 0.f, si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, cp = 0.f;
@@ -236,46 +374,62 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
       tc = a.tanh_c[row * Y + d * HD + j];
       cp = a.cprev[(((long)d * L + t) * B + b) * HD + j];
     }
-    if (!first) {
-      group_wait(cnt, njb * (unsigned)(L - 1 - step), status, &s_abort);
-      const int tl = (d == 0) ? t + 1 : t - 1;
-#pragma unroll 4
-      for (int u = 0; u < HD / 16; ++u) {
-        const int unit = threadIdx.x + u * 256;
-        const int r = unit / HD, c4 = unit % HD;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (b0 + r < B)
-          v = __builtin_amdgcn_raw_buffer_load_b128(gres, (unsigned)((((long)tl * B + b0 + r) * G + (long)d * 4 * HD + c4 * 4) * 4), 0, 16);
-        *reinterpret_cast<u32x4_t*>(&sd[r * LDD + c4 * 4]) = v;
-      }
-    }
-    __syncthreads();
-    if (!first) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      mfma_resident<TW, NS>(&sd[fi * LDD + wave * HD], w, fq, acc);
+    VLN_STAMP(0);
+    float dh = dh_pass;
+    if (k > 0) {
+      group_wait(cnt, NJB, (unsigned)k, status, &s_abort);
+      VLN_STAMP(1);
+      const unsigned rbase = (unsigned)(((grp + ((k - 1) & 1)) * NJB * HD + j0) * 16 * 4) + (unsigned)lane * 16u;
+      float4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sp[wave][fq * 4 + r][fi] = acc[r];
-    }
-    __syncthreads();
-    if (live) {
-      float dh = dh_pass;
-      if (!first) dh += sp[0][bl][jl] + sp[1][bl][jl] + sp[2][bl][jl] + sp[3][bl][jl];
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-      if (valid) {
-        dh += dyv;
-        const float dc = dcc + dh * so * (1.f - tc * tc);
-        g0 = dc * tg * si * (1.f - si);
-        g1 = dc * cp * sf * (1.f - sf);
-        g2 = dc * si * (1.f - tg * tg);
-        g3 = dh * tc * so * (1.f - so);
-        dcc = dc * sf;
-        dh_pass = 0.f;
-      } else {
-        dh_pass = dh;
+      for (int i = 0; i < NJB / 4; ++i) {      // one producer's [16 units][16 rows] block per wave-wide load
+        const unsigned p = (unsigned)(wave + 4 * i);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xres, rbase + p * (unsigned)(HD * 16 * 4), 0, 16);
+        s4.x += __uint_as_float(v.x); s4.y += __uint_as_float(v.y); s4.z += __uint_as_float(v.z); s4.w += __uint_as_float(v.w);
       }
-      float* dg = a.dgates + row * G + (long)d * 4 * HD + j;      // write-through: the group reads it next step
-      VLN_AGENT_STORE(dg, g0); VLN_AGENT_STORE(dg + HD, g1); VLN_AGENT_STORE(dg + 2 * HD, g2); VLN_AGENT_STORE(dg + 3 * HD, g3);
+      *reinterpret_cast<float4*>(&red[wave][lane][0]) = s4;
+      __syncthreads();
+      const int q = jl * 4 + (bl >> 2), e = bl & 3;
+      dh += (red[0][q][e] + red[1][q][e]) + (red[2][q][e] + red[3][q][e]);
     }
-    group_arrive(cnt);
+    VLN_STAMP(2);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (valid) {
+      dh += dyv;
+      const float dc = dcc + dh * so * (1.f - tc * tc);
+      g0 = dc * tg * si * (1.f - si);
+      g1 = dc * cp * sf * (1.f - sf);
+      g2 = dc * si * (1.f - tg * tg);
+      g3 = dh * tc * so * (1.f - so);
+      dcc = dc * sf;
+      dh_pass = 0.f;
+    } else {
+      dh_pass = dh;
+    }
+    if (live) {    // consumed by the weight-gradient GEMMs after this launch: plain stores
+      float* dg = a.dgates + row * G + (long)d * 4 * HD + j;
+      dg[0] = g0; dg[HD] = g1; dg[2 * HD] = g2; dg[3 * HD] = g3;
+    }
+    if (step == 0) break;                      // nobody consumes a partial dh of the last processed step
+    float* tr = &tile[bl * LDT + jl];
+    tr[0] = g0; tr[16] = g1; tr[32] = g2; tr[48] = g3;
+    __syncthreads();
+    VLN_STAMP(3);
+    {
+      AFrag<TW, NSK> af;
+      load_afrag<TW, NSK>(af, &tile[fi * LDT], fq);
+      const unsigned wbase = (unsigned)(((grp + (k & 1)) * NJB + jb) * HD * 16 * 4);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mfma_frags<TW, NSK>(af, w[i], acc);
+        const int n = (wave * NT + i) * 16 + fi;
+        u32x4_t o = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, xres, wbase + (unsigned)((n * 16 + fq * 4) * 4), 0, 16);   // sc1
+      }
+    }
+    VLN_STAMP(4);
+    group_arrive(cnt, jb, (unsigned)k + 1u);
+    VLN_STAMP(5);
   }
 }

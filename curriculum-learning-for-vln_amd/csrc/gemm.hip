@@ -207,7 +207,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #include "gemm_nt_n16.h"
 
 // narrow outputs: 16-column workgroups with the K split inside the workgroup (no slabs, no reduce launch)
-static bool n16_applies(int M, int N, int K) { return g_tunable[2] && N <= 1024 && M <= 256 && K >= 64; }
+// tunable[3] = largest K it takes (every workgroup streams the WHOLE X once: long contractions belong to the split-K path)
+static bool n16_applies(int M, int N, int K) {
+  return g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
+}
 
 static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
                       int M, int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop) {

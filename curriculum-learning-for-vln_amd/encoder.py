@@ -53,7 +53,7 @@ class _EncoderFn(torch.autograd.Function):
             ccat = torch.empty(B, dirs * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
                                             _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs,
-                                            _p(mod._sync_ws(dev)), _stream()), "vln_lstm_seq_fwd")
+                                            *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:
                 if p_inter > 0:
@@ -127,7 +127,7 @@ class _EncoderFn(torch.autograd.Function):
             dgates = torch.empty(L * B, dirs * 4 * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
-                                            _p(mod._sync_ws(dev)), _stream()), "vln_lstm_seq_bwd")
+                                            *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
             for d in range(dirs):
                 sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
                 dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
@@ -185,13 +185,15 @@ class EncoderLSTM(nn.Module):
         self._shadow = ShadowSet()
         self._param_names = [n for n, _ in self.named_parameters()]
 
-    def _sync_ws(self, dev):
-        """256 bytes of device scratch for the persistent recurrence (group counters + status word)."""
+    def _sync_ws(self, dev, B, Hd, dirs):
+        """(pointer, bytes) of the device scratch of the persistent recurrence: group counters + status word, then the
+        backward's partial-dh exchange buffer (vln_lstm_sync_ws_bytes)."""
+        need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
         w = getattr(self, "_sync_buf", None)
-        if w is None or w.device != dev:
-            w = torch.zeros(64, dtype=torch.int32, device=dev)
+        if w is None or w.device != dev or w.numel() * 4 < need:
+            w = torch.zeros((need + 3) // 4, dtype=torch.int32, device=dev)
             self._sync_buf = w
-        return w
+        return w.data_ptr(), w.numel() * 4
 
     def persistent_status(self) -> int:
         """0 = every in-kernel wait of the last persistent launch completed; 1 = a bounded spin timed out."""

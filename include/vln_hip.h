@@ -144,19 +144,23 @@ int vln_tm_to_bm(const float* tm /*[L,B,W]*/, float* bm /*[B,L,W]*/, void* bm_bf
 int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
 /* xproj [L*B, dirs*4Hd]; w_hh [dirs][4Hd,Hd] (wtype); hprev/cprev [dirs][L][B][Hd] (state fed into time t, written
  * here); y_tm [L*B, dirs*Hd]; act [L*B, dirs*4Hd]; tanh_c [L*B, dirs*Hd]; hcat/ccat [B, dirs*Hd] final states */
-/* sync_ws (nullable): 256 bytes of device scratch.  When given and the grid of (Hd/16) x dirs x ceil(B/16) workgroups
- * is co-resident (<= 256) with Hd in {128,256,512}, the whole sequence runs as ONE persistent launch (W_hh slices
- * and cell state in registers, hidden slices exchanged with write-through stores + a per-group counter); word 32
- * of sync_ws is a status word (0 = ok, 1 = a bounded spin timed out).  Otherwise L launches (hipGraph-memoised). */
+/* sync_ws (nullable): device scratch of vln_lstm_sync_ws_bytes(B, Hd, dirs) bytes, 16-byte aligned: an 8 KB header
+ * (word 32 = status: 0 ok, 1 a bounded spin timed out; one 128-byte arrival line per dependency group from byte 256) followed by the backward's
+ * exchange buffer.
+ * When given (and large enough) and the grid of (Hd/16) x dirs x ceil(B/16) workgroups is co-resident (<= 256) with
+ * Hd in {128,256,512}, the whole sequence runs as ONE persistent launch: W_hh slices and cell state stay in registers;
+ * forward exchanges hidden slices, backward exchanges partial dh blocks, both with write-through stores + a
+ * per-group arrival counter.  Otherwise L launches (hipGraph-memoised).  The forward needs only the header. */
+int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs);
 int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev, float* cprev,
                      float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B, int L, int Hd, int dirs,
-                     void* sync_ws, vln_stream_t s);
+                     void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 forces the per-step path; results are identical */
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered */
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
                      const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry, int B, int L,
-                     int Hd, int dirs, void* sync_ws, vln_stream_t s);
+                     int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
 
 /* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
 
