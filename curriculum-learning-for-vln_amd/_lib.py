@@ -34,7 +34,7 @@ class EnvDropStep(C.Structure):
                                     "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
                                     "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd", "a_stash")]
                 + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
-                   ("ws", ptr), ("ws_floats", i64)])
+                   ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr)])
 
 
 class EnvDropGrads(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr]),
     "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
+    "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),

@@ -22,6 +22,7 @@ int check_hip(hipError_t e, const char* what) {
   return VLN_ERR_HIP;
 }
 int g_graphs_enabled = 1;
+long long g_graph_stats[3] = {0, 0, 0};
 // [0] = 256: interleaved A/B (scripts/ab_bench.py) shows 256/512/768 within noise in time; 256 halves the split-K
 // slab traffic (PMC), so it wins on bytes
 // [2] = 1, [3] = 512: narrow outputs (N <= 1024) with a SHORT contraction (K <= 512) use the 16-column kernel with the K
@@ -75,6 +76,11 @@ void prof_end(hipStream_t st, int kid) {
 using namespace vln;
 
 extern "C" int vln_set_graphs(int on) { g_graphs_enabled = on ? 1 : 0; return VLN_OK; }
+extern "C" int vln_graph_stats(int64_t out[3]) {
+  if (!out) { set_error("vln_graph_stats: null pointer"); return VLN_ERR_ARG; }
+  for (int i = 0; i < 3; ++i) out[i] = g_graph_stats[i];
+  return VLN_OK;
+}
 extern "C" int vln_set_tunable(int id, int value) {
   if (id < 0 || id >= 8) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
   g_tunable[id] = value;

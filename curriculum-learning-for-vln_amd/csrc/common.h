@@ -121,6 +121,10 @@ __host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t
 
 struct DropSpec {      // one dropout site; p == 0 disables it
   uint64_t seed;
-  uint64_t offset;
+  uint64_t offset;     // Philox offset of the site -- or, when `step` is set, the site index k of offset = *step * 8 + k
   float p;
+  // Optional: the per-step offset lives in DEVICE memory (written before the step's launches), so the launch
+  // arguments of a step do not change from call to call and the whole step can be replayed as one hipGraph.
+  const unsigned long long* step = nullptr;
+  __device__ __forceinline__ uint64_t off() const { return step ? (uint64_t)(*step) * 8ull + offset : offset; }
 };

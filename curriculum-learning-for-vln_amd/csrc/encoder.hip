@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens,
     const int b = (int)(rb % B), t = (int)(rb / B);
     const long tok = tokens[(long)b * L + t];
     const long idx = ((long)b * L + t) * D + c;           // mask index follows the [B,L,D] layout
-    out[e] = E[tok * D + c] * dropout_scale1(dr.seed, dr.offset, (uint32_t)idx, dr.p);
+    out[e] = E[tok * D + c] * dropout_scale1(dr.seed, dr.off(), (uint32_t)idx, dr.p);
   }
 }
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* tokens, const int* lengths, const float* dx,
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* tokens,
     const long tok = tokens[(long)b * L + t];
     if (tok == padding_idx) continue;
     const long idx = ((long)b * L + t) * D + c;
-    const float g = dx[e] * dropout_scale1(dr.seed, dr.offset, (uint32_t)idx, dr.p);
+    const float g = dx[e] * dropout_scale1(dr.seed, dr.off(), (uint32_t)idx, dr.p);
     atomicAdd(dE + tok * D + c, g);
   }
 }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* b
     const int c = (int)(e % W);
     const long rb = e / W;
     const int t = (int)(rb % L), b = (int)(rb / L);
-    const float v = tm[((long)t * B + b) * W + c] * dropout_scale1(dr.seed, dr.offset, (uint32_t)e, dr.p);
+    const float v = tm[((long)t * B + b) * W + c] * dropout_scale1(dr.seed, dr.off(), (uint32_t)e, dr.p);
     bm[e] = v;
     if (bm_lp) bm_lp[e] = f32_to_bf16_bits(v);
   }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void bm_to_tm_kernel(const float* bm, float* t
     const int c = (int)(e % W);
     const long rb = e / W;
     const int t = (int)(rb % L), b = (int)(rb / L);
-    tm[((long)t * B + b) * W + c] = bm[e] * dropout_scale1(dr.seed, dr.offset, (uint32_t)e, dr.p);
+    tm[((long)t * B + b) * W + c] = bm[e] * dropout_scale1(dr.seed, dr.off(), (uint32_t)e, dr.p);
   }
 }
 

@@ -7,7 +7,12 @@
 // Dropout sites (Philox offset = step_offset*8 + site):
 //   0 act-embedding (policy.py:224)   1 h_tilde_prev (:234)   2 h_1 (:240)   3 h_tilde (:243)
 //   4 image features (:228)           5 candidate features (:230)
+#include <string.h>
+
+#include <mutex>
+
 #include "vln_internal.h"
+#include "graph_cache.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -41,13 +46,13 @@ __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
       const float acc = p.act_b[j] + ((a0 + a1) + (a2 + a3));
       const float e = tanhf(acc);
       p.e[i] = e;
-      p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.offset, (uint32_t)i, p.d_act.p);
+      p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
     } else {
       const long k = i - ne;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
       const float v = p.htp[k];
       p.xcat[(long)b * p.ldx + p.AE + p.F + j] = v;
-      p.hq[k] = v * dropout_scale1(p.d_h.seed, p.d_h.offset, (uint32_t)k, p.d_h.p);
+      p.hq[k] = v * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
     }
   }
 }
@@ -64,13 +69,13 @@ __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
     if (i < ne) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
       const float e = p.e[i];
-      const float de = p.dxcat[(long)b * p.ldx + j] * dropout_scale1(p.d_act.seed, p.d_act.offset, (uint32_t)i, p.d_act.p);
+      const float de = p.dxcat[(long)b * p.ldx + j] * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
       p.s_de[i] = de * (1.f - e * e);
     } else {
       const long k = i - ne;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
       p.dhtp[k] = p.dxcat[(long)b * p.ldx + p.AE + p.F + j] +
-                  p.dhq[k] * dropout_scale1(p.d_h.seed, p.d_h.offset, (uint32_t)k, p.d_h.p);
+                  p.dhq[k] * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
     }
   }
 }
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
 __global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(const float* dhtd, const float* dht_ext, const float* ht,
                                                             float* dz, long n, DropSpec d) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float g = dhtd[i] * dropout_scale1(d.seed, d.offset, (uint32_t)i, d.p);
+    float g = dhtd[i] * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
     if (dht_ext) g += dht_ext[i];
     const float h = ht[i];
     dz[i] = g * (1.f - h * h);
@@ -117,9 +122,13 @@ static long ws_layout(const vln_envdrop_dims& d, float* base, Ws* w) {
   return off;
 }
 
+// Dropout site k of this step.  With io->offset_dev the step's offset is read from device memory by the kernels (the
+// launch arguments then repeat from call to call, which is what lets the step replay as a hipGraph).
 static inline DropSpec site(const vln_envdrop_step* io, int k, float p) {
+  if (io->offset_dev) return DropSpec{io->seed, (uint64_t)k, p, reinterpret_cast<const unsigned long long*>(io->offset_dev)};
   return DropSpec{io->seed, io->offset * 8 + (uint64_t)k, p};
 }
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 
 static int check_dims(const vln_envdrop_dims* d) {
   if (!d || d->B <= 0 || d->L <= 0 || d->V <= 0 || d->C <= 0 || d->H <= 0 || d->IMG <= 0 || d->ANG <= 0 || d->AE <= 0) {
@@ -144,10 +153,7 @@ extern "C" int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d) {
   return ws_layout(*d, nullptr, nullptr);
 }
 
-extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
-                                    vln_stream_t s) {
-  RUN(check_dims(d));
-  hipStream_t st = (hipStream_t)s;
+static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io) {
   const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop fwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
@@ -194,10 +200,8 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   return VLN_OK;
 }
 
-extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
-                                    vln_envdrop_grads* g, vln_stream_t s) {
-  RUN(check_dims(d));
-  hipStream_t st = (hipStream_t)s;
+static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io,
+                          const vln_envdrop_grads* g) {
   const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop bwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
@@ -241,4 +245,48 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   hipLaunchKernelGGL(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep_bwd");
   return VLN_OK;
+}
+
+
+// ---- C entry points: one call per decoder step ---------------------------------------------------------------------
+// With io->offset_dev the ~13 (forward) / ~15 (backward) launches of a step are a pure function of the argument block:
+// the first call with a given block is stream-captured, later calls replay it with ONE hipGraphLaunch (the host cost of
+// the launches, not their GPU time, bounds the rollout at B = 64).  Only the 8-byte offset changes per call; it is
+// written to device memory by a one-thread launch ahead of the graph.
+namespace {
+struct StepKey {
+  vln_envdrop_dims d; vln_envdrop_weights w; vln_envdrop_step io; vln_envdrop_grads g; int bwd;
+};
+}  // namespace
+
+extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
+                                    vln_stream_t s) {
+  RUN(check_dims(d));
+  if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  if (!io->offset_dev) return step_fwd_issue(st, d, w, io);
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
+                     (unsigned long long)io->offset);
+  VLN_CHECK_LAUNCH("envdrop step offset");
+  static StepKey key;                     // zero-initialised once: padding bytes stay zero, fields are overwritten
+  static std::mutex mu;
+  static GraphCache cache(64);
+  std::lock_guard<std::mutex> lock(mu);
+  key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.bwd = 0;
+  memset(&key.g, 0, sizeof(key.g));
+  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
+}
+
+extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
+                                    vln_envdrop_grads* g, vln_stream_t s) {
+  RUN(check_dims(d));
+  if (!w || !io || !g) { set_error("vln_envdrop_step_bwd: null pointer"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  if (!io->offset_dev) return step_bwd_issue(st, d, w, io, g);
+  static StepKey key;
+  static std::mutex mu;
+  static GraphCache cache(64);
+  std::lock_guard<std::mutex> lock(mu);
+  key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.g = *g; key.bwd = 1;
+  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
 }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const
       Elt<TT>::ld4(src + c, x);
       if (dr.p > 0.f) {
         float m[4];
-        dropout_scale4(dr.seed, dr.offset, (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
+        dropout_scale4(dr.seed, dr.off(), (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
         x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
       }
     } else {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, cons
         Elt<TT>::ld4(src + c, x);
         if (dr.p > 0.f) {
           float m[4];
-          dropout_scale4(dr.seed, dr.offset, (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
+          dropout_scale4(dr.seed, dr.off(), (uint32_t)(((long)r * IMG + c) >> 2), dr.p, m);
           x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
         }
       } else {

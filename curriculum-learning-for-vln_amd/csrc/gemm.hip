@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void reduce_epilogue_kernel(const float* slabs
     if (act == ACT_TANH) v = tanhf(v);
     else if (act == ACT_RELU) v = fmaxf(v, 0.0f);
     out[(long)r * ldo + c] = v;
-    if (out2) out2[(long)r * ldo2 + c] = v * dropout_scale1(drop.seed, drop.offset, (uint32_t)e, drop.p);
+    if (out2) out2[(long)r * ldo2 + c] = v * dropout_scale1(drop.seed, drop.off(), (uint32_t)e, drop.p);
   }
 }
 

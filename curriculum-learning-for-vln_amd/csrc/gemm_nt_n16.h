@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_nt_n16_kernel(GemmN16Args a) {
       if (a.act == ACT_TANH) v = tanhf(v);
       else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
       a.Y[(long)row * a.ldy + col] = v;
-      if (a.Y2) a.Y2[(long)row * a.ldy2 + col] = v * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)((long)row * a.N + col), a.drop.p);
+      if (a.Y2) a.Y2[(long)row * a.ldy2 + col] = v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)((long)row * a.N + col), a.drop.p);
     }
   }
 }

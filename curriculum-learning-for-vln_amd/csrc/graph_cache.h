@@ -22,6 +22,7 @@ namespace vln {
 
 extern int g_graphs_enabled;   // vln_set_graphs(); default on
 extern unsigned g_prof_mask;
+extern long long g_graph_stats[3];   // replays, captures, chains switched off (vln_graph_stats)
 
 class GraphCache {
  public:
@@ -39,21 +40,32 @@ class GraphCache {
     if (it != map_.end()) {
       lru_.splice(lru_.begin(), lru_, it->second.second);
       misses_in_a_row_ = 0;
+      ++g_graph_stats[0];
       if (hipGraphLaunch(it->second.first, st) == hipSuccess) return 0;
       (void)hipGetLastError();
       return issue(st);
     }
-    if (++misses_in_a_row_ > 64) {   // addresses never repeat: stop paying for captures
+    if (++misses_in_a_row_ > 24) {   // addresses never repeat: stop paying for captures
       disabled_ = true;
+      ++g_graph_stats[2];
       return issue(st);
     }
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    // Capture on a PRIVATE stream: the caller's stream is usually PyTorch's current stream = the legacy default
+    // stream, which cannot be captured.  The chain is only recorded there (nothing executes); the instantiated
+    // graph is then launched into the caller's stream.
+    if (cs_ == nullptr && hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      cs_ = nullptr;
+      return issue(st);
+    }
+    if (hipStreamBeginCapture(cs_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       (void)hipGetLastError();
       return issue(st);
     }
-    int rc = issue(st);
+    ++g_graph_stats[1];
+    int rc = issue(cs_);
     hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(st, &g);
+    hipError_t e = hipStreamEndCapture(cs_, &g);
     if (rc != 0 || e != hipSuccess || g == nullptr) {
       if (g) (void)hipGraphDestroy(g);
       (void)hipGetLastError();
@@ -87,6 +99,7 @@ class GraphCache {
  private:
   std::mutex mu_;
   size_t cap_;
+  hipStream_t cs_ = nullptr;   // capture-only stream
   bool disabled_ = false;
   int misses_in_a_row_ = 0;
   std::list<std::string> lru_;

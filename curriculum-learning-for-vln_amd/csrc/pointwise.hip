@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
       p[0] = si; p[H] = sf; p[2 * H] = tg; p[3 * H] = so;
     }
     if (a.tanh_c1) a.tanh_c1[e] = tc;
-    if (a.h1_drop) a.h1_drop[(long)b * a.ldh1d + j] = h1 * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)e, a.drop.p);
+    if (a.h1_drop) a.h1_drop[(long)b * a.ldh1d + j] = h1 * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
     __syncthreads();   // sg is rewritten by the next grid-stride iteration
   }
 }
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(LstmPwBwd a) {
     if (a.dh1_b) {
       float v = a.dh1_b[(long)b * a.ld_b + j];
       if (a.dh1_b2) v += a.dh1_b2[(long)b * a.ld_b2 + j];
-      dh += v * dropout_scale1(a.drop.seed, a.drop.offset, (uint32_t)e, a.drop.p);
+      dh += v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
     }
     const float* act = a.act + (long)b * 4 * H + j;
     const float si = act[0], sf = act[H], tg = act[2 * H], so = act[3 * H];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void scale_dropout_kernel(const float* x, long
   const long total = (long)rows * cols;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int r = (int)(e / cols), c = (int)(e % cols);
-    y[(long)r * ldy + c] = x[(long)r * ldx + c] * dropout_scale1(d.seed, d.offset, (uint32_t)e, d.p);
+    y[(long)r * ldy + c] = x[(long)r * ldx + c] * dropout_scale1(d.seed, d.off(), (uint32_t)e, d.p);
   }
 }
 int scale_dropout(hipStream_t st, const float* x, long ldx, float* y, long ldy, int rows, int cols, DropSpec d) {
@@ -119,7 +119,7 @@ int scale_dropout(hipStream_t st, const float* x, long ldx, float* y, long ldy, 
 
 __global__ __launch_bounds__(256) void export_mask_kernel(float* out, long n, DropSpec d) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-    out[e] = dropout_scale1(d.seed, d.offset, (uint32_t)e, d.p);
+    out[e] = dropout_scale1(d.seed, d.off(), (uint32_t)e, d.p);
 }
 int export_dropout_mask(hipStream_t st, float* out, long n, DropSpec d) {
   int blocks = (int)((n + 255) / 256);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void feat_dropout_kernel(TX* x, long rows, int
     if (c4 < q4) {
       if (d.p > 0.f) {
         float m[4];
-        dropout_scale4(d.seed, d.offset, (uint32_t)(r * q4 + c4), d.p, m);
+        dropout_scale4(d.seed, d.off(), (uint32_t)(r * q4 + c4), d.p, m);
         v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
         Elt<TX>::st4(p, v);
       }

@@ -124,6 +124,12 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self._side_stream = None
         self._dims_cache = {}
         self.grads_ready_hook = None     # optional callable, see _deferred_wgrads
+        # Replay each decoder step (forward: 13 launches, backward: 15) as ONE hipGraph.  A graph is keyed by the step's
+        # argument block, i.e. by device addresses; it only pays when the caller's tensors come back at the SAME
+        # addresses every iteration.  PyTorch's caching allocator does not guarantee that (measured: every step's
+        # block differs between consecutive iterations, 0 replays), so this is off unless the caller allocates from a
+        # fixed arena; results are identical either way.
+        self.step_graphs = False
 
     # ---- gating hooks ----------------------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -298,17 +304,20 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         if need_grad:
             slot = self._stash.take(B, entry.ref)
             rec.slot = slot
-            flat = torch.empty(n_e + n_av + n_g + 2 * n_h + n_at, dtype=torch.float32, device=dev)
+            flat = torch.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at, dtype=torch.float32, device=dev)
             io.a_stash, io.hq, io.xcat, io.tcat, io.htd = (slot.ptr("a"), slot.ptr("hq"), slot.ptr("xcat"), slot.ptr("tcat"),
                                                            slot.ptr("htd"))
         else:
             rec.slot = None
             XK = AE + F + H
-            flat = torch.empty(n_e + n_av + n_g + 2 * n_h + n_at + B * (H + XK + 2 * H + H), dtype=torch.float32, device=dev)
-            q = flat.data_ptr() + 4 * (n_e + n_av + n_g + 2 * n_h + n_at)
+            flat = torch.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at + B * (H + XK + 2 * H + H), dtype=torch.float32, device=dev)
+            q = flat.data_ptr() + 4 * (4 + n_e + n_av + n_g + 2 * n_h + n_at)
             io.hq, io.xcat, io.tcat, io.htd = q, q + 4 * B * H, q + 4 * B * (H + XK), q + 4 * B * (H + XK + 2 * H)
         keep["flat"] = flat
         q = flat.data_ptr()
+        if self.step_graphs:           # the step's dropout offset lives on the device: launch arguments repeat -> hipGraph replay
+            io.offset_dev = q
+        q += 16
         io.e = q; q += 4 * n_e
         io.alpha_v = q; q += 4 * n_av
         io.gate_act = q; q += 4 * n_g

@@ -37,6 +37,8 @@ const char* vln_last_error_string(void);
 /* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
  * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
 int vln_set_graphs(int on);
+/* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] chains switched off */
+int vln_graph_stats(int64_t out[3]);
 /* performance tunables (never change results beyond summation order): 0 = gemm split-K workgroup target (512),
  * 1 = keep wide shallow products unsplit (1) */
 int vln_set_tunable(int id, int value);
@@ -224,6 +226,10 @@ typedef struct vln_envdrop_step {
   int lp_ready;          /* 1: img_lp / cand_lp were filled by the caller (e.g. vln_gather_*): skip the copy pass */
   /* scratch */
   float* ws; int64_t ws_floats;
+  /* optional (nullable): 8 bytes of device memory owned by THIS step (kept until its backward has run).  When given,
+   * forward stores `offset` there and every kernel reads the step's dropout offset from it, so the launch arguments
+   * repeat from call to call and the step is replayed as one hipGraph (captured on first use per argument block). */
+  uint64_t* offset_dev;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {

@@ -23,6 +23,7 @@ VARIANTS = {   # (persistent, graphs, split target, no-split rule, n16 kernel, n
     "n16_all_K": (1, 1, 256, 1, 1, 0),
     "n16_off": (1, 1, 256, 1, 0, 0),
     "n16_off_target512": (1, 1, 512, 1, 0, 0),
+    "no_step_graphs": (1, 0, 256, 1, 1, 512),
     "per_step_lstm": (0, 1, 256, 1, 1, 512),
 }
 torch.manual_seed(0)
@@ -53,3 +54,7 @@ for r in range(rounds):
 configure(VARIANTS["base"])
 for n, v in times.items():
     print(f"{n:22s} median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
+import ctypes
+st = (ctypes.c_int64 * 3)()
+lib.vln_graph_stats(st)
+print(f"graphs: {st[0]} replays, {st[1]} captures, {st[2]} chains switched off")

@@ -358,6 +358,36 @@ def test_training_iteration_side_stream_overlap_is_transparent(vln):
     check(losses[0], losses[1], 1e-6, "store vs tensor loss")
 
 
+def test_step_graphs_with_device_side_dropout_offset_are_transparent(vln):
+    """`EnvDropDecoder.step_graphs`: the step's Philox offset is read from device memory and each step is captured /
+    replayed as a hipGraph (vln_envdrop_step.offset_dev).  Dropout ON: loss and every gradient must be bit-identical to
+    the plain-launch path, over two iterations (second one exercises re-capture or replay)."""
+    import ctypes
+    import bench
+    dev_ = torch.device(DEV)
+    tape = bench.tape_to(bench.make_tape(16, 24, 3, 6, seed=5), dev_)
+    res = []
+    for graphs in (True, False):
+        torch.manual_seed(13)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1)
+        ag.dec.step_graphs = graphs
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.opt.lr = 0.0
+        out = []
+        for _ in range(2):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in ag.dec.parameters()]))
+        res.append(out)
+    for (la, ga), (lb, gb) in zip(res[0], res[1]):
+        assert torch.equal(la, lb)
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+    st = (ctypes.c_int64 * 3)()
+    vln._lib.load().vln_graph_stats(st)
+    assert st[1] > 0                                  # steps were captured (replays need address-stable callers)
+
+
 def test_missing_library_fails_loudly(vln, monkeypatch):
     monkeypatch.setattr(vln._lib, "_lib", None)
     monkeypatch.setattr(vln._lib, "LIB_PATH", "/nonexistent/libvln_hip.so")
