@@ -104,7 +104,7 @@ def tape_to(tape, dev, store_dtype=None):
 class GpuAgent:
     """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
 
-    def __init__(self, vln, dev, dtype, world):
+    def __init__(self, vln, dev, dtype, world, arena=False):
         self.vln, self.world, self.dtype = vln, world, dtype
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
@@ -114,6 +114,14 @@ class GpuAgent:
         self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
         if world > 1:   # the decoder's 34.7 MB of gradients are final before the encoder's BPTT starts: reduce them under it
             self.dec.grads_ready_hook = lambda: self.opt.start_allreduce(1)
+        # A training loop allocates the same sequence of buffers every iteration: with the arena they come back at the
+        # same device addresses, so each decoder step (13 forward / 15 backward launches) replays as one hipGraph.
+        self.arena = None
+        self.use_arena(arena)
+
+    def use_arena(self, on: bool):
+        self.arena = self.vln.ops.RolloutArena() if on else None
+        self.dec.step_graphs = bool(on)
 
     def step_features(self, tape, s):
         """Per-step marshalling (agent/base.py:141-157 + the EnvDrop feature dropout, policy.py:226-231).
@@ -132,6 +140,15 @@ class GpuAgent:
         return r1[0], r2[0], kw
 
     def iteration(self, tape):
+        self.vln.ops.set_arena(self.arena)
+        if self.arena is not None:
+            self.arena.begin()
+        try:
+            return self._iteration(tape)
+        finally:
+            self.vln.ops.set_arena(None)
+
+    def _iteration(self, tape):
         B = tape["B"]
         self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
@@ -232,6 +249,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-arena", action="store_true", help="allocate per-iteration buffers with torch.empty (no address-stable "
+                                                           "arena, hence no decoder-step hipGraph replay)")
     ap.add_argument("--features", default="store", choices=["store", "tensor"],
                     help="store: ResNet table resident in HBM, a step ships indices (DeviceFeatureStore); "
                          "tensor: pre-built per-step feature tensors, cloned each step")
@@ -257,7 +276,7 @@ def main():
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(2020)
-    agent = GpuAgent(vln, dev, dtype, world)
+    agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena)
     tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
     tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None))
 
@@ -266,23 +285,38 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up runs like the timed loop: iterations back to back, no per-iteration sync (the first time the host gets
+    # many launches ahead of the GPU the runtime grows its in-flight pools: a one-time cost that belongs here).
+    tw = time.perf_counter()
     for i in range(args.warmup):
-        tw = time.perf_counter()
         agent.iteration(tape)
-        torch.cuda.synchronize()
-        if rank == 0:
-            print(f"[bench] warm-up {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+        if i == 0:
+            torch.cuda.synchronize()
+            if rank == 0:
+                print(f"[bench] first iteration (module init, captures): {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     barrier()
+    # Python's cyclic GC: a full pass over the (static) module/object graph costs tens of ms and would land in the
+    # timed region at random; collect now and move the survivors out of the collector's reach.
+    import gc
+    gc.collect()
+    gc.freeze()
     if agent.enc.persistent_status() != 0:       # a bounded in-kernel wait timed out during warm-up: fall back
         print("[bench] persistent recurrence reported a timeout; using per-step launches", file=sys.stderr, flush=True)
         lib.vln_set_persistent(0)
         agent.iteration(tape)
         barrier()
+    marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.iteration(tape)
+        marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and len(marks) >= 10:      # host submit time per block of iterations (diagnostic, stderr only)
+        q = max(1, len(marks) // 5)
+        blk = [(marks[min(i + q, len(marks)) - 1] - (marks[i - 1] if i else t0)) / (min(i + q, len(marks)) - i) * 1e3
+               for i in range(0, len(marks), q)]
+        print("[bench] host submit ms/iter by block: " + " ".join(f"{b:.2f}" for b in blk), file=sys.stderr, flush=True)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -37,38 +37,40 @@ class _EncoderFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         wtype = ops.BF16 if mod.compute_dtype == torch.bfloat16 else ops.F32
         p_emb = 0.0 if mod.use_glove else p_drop
-        x = torch.empty(L * B, E, **f32)
+        x = ops.empty(L * B, E, **f32)
         _lib.check(lib.vln_embed_fwd(_p(tokens), _p(mod.embedding.weight), _p(x), B, L, E, seed, offset * 8 + 0,
                                      p_emb, _stream()), "vln_embed_fwd")
         saved = []
         p_inter = p_drop if nl > 1 else 0.0
         for k in range(nl):
             xproj = ops.linear_fwd(x, sh[f"w_ih{k}"], sh[f"bsum{k}"])
-            hprev = torch.empty(dirs, L, B, Hd, **f32)
-            cprev = torch.empty(dirs, L, B, Hd, **f32)
-            y = torch.empty(L * B, dirs * Hd, **f32)
-            act = torch.empty(L * B, dirs * 4 * Hd, **f32)
-            tanh_c = torch.empty(L * B, dirs * Hd, **f32)
-            hcat = torch.empty(B, dirs * Hd, **f32)
-            ccat = torch.empty(B, dirs * Hd, **f32)
+            hprev = ops.empty(dirs, L, B, Hd, **f32)
+            cprev = ops.empty(dirs, L, B, Hd, **f32)
+            y = ops.empty(L * B, dirs * Hd, **f32)
+            act = ops.empty(L * B, dirs * 4 * Hd, **f32)
+            tanh_c = ops.empty(L * B, dirs * Hd, **f32)
+            hcat = ops.empty(B, dirs * Hd, **f32)
+            ccat = ops.empty(B, dirs * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
                                             _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:
                 if p_inter > 0:
-                    xn = torch.empty_like(y)
+                    xn = ops.empty_like(y)
                     _lib.check(lib.vln_scale_dropout(_p(y), y.stride(0), _p(xn), xn.stride(0), L * B, dirs * Hd, seed,
                                                      offset * 8 + 2 + k, p_inter, _stream()), "vln_scale_dropout")
                     x = xn
                 else:
                     x = y
         H = dirs * Hd
-        ctx_out = torch.empty(B, L, H, **f32)
+        ctx_out = ops.empty(B, L, H, **f32)
         _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), None, B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
                    "vln_tm_to_bm")
         dec_init = ops.linear_fwd(hcat, sh["w_e2d"], mod.enc2dec.bias.detach(), ops.ACT_TANH)
-        ctx.mod, ctx.saved, ctx.misc = mod, saved, (tokens, lens32, p_drop, offset, hcat, dec_init, wtype)
+        # dec_init is an OUTPUT: keeping the returned object on ctx would close a reference cycle through its grad_fn
+        # (tensor -> node -> ctx -> tensor) that only the cyclic GC can free -- ~85 MB of activations per iteration
+        ctx.mod, ctx.saved, ctx.misc = mod, saved, (tokens, lens32, p_drop, offset, hcat, dec_init.detach(), wtype)
         ctx.set_materialize_grads(False)
         return ctx_out, dec_init, ccat
 
@@ -108,11 +110,11 @@ class _EncoderFn(torch.autograd.Function):
             put("enc2dec.bias", ops.colsum, dpre)
             dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])
         else:
-            dhcat = torch.zeros(B, H, **f32)
-        dccat = dct.contiguous() if dct is not None else torch.zeros(B, H, **f32)
+            dhcat = ops.zeros(B, H, **f32)
+        dccat = dct.contiguous() if dct is not None else ops.zeros(B, H, **f32)
         dy = None
         if dctx is not None:
-            dy = torch.empty(L * B, H, **f32)
+            dy = ops.empty(L * B, H, **f32)
             dctx = dctx.contiguous()
             _lib.check(lib.vln_bm_to_tm(_p(dctx), _p(dy), B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
                        "vln_bm_to_tm")
@@ -122,9 +124,9 @@ class _EncoderFn(torch.autograd.Function):
                 dh_pass = dhcat.view(B, dirs, Hd).transpose(0, 1).contiguous()
                 dc_carry = dccat.view(B, dirs, Hd).transpose(0, 1).contiguous()
             else:
-                dh_pass = torch.zeros(dirs, B, Hd, **f32)
-                dc_carry = torch.zeros(dirs, B, Hd, **f32)
-            dgates = torch.empty(L * B, dirs * 4 * Hd, **f32)
+                dh_pass = ops.zeros(dirs, B, Hd, **f32)
+                dc_carry = ops.zeros(dirs, B, Hd, **f32)
+            dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
@@ -140,7 +142,7 @@ class _EncoderFn(torch.autograd.Function):
                 dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])
                 if k > 0:
                     if p_inter > 0:
-                        dy = torch.empty_like(dx)
+                        dy = ops.empty_like(dx)
                         _lib.check(lib.vln_scale_dropout(_p(dx), dx.stride(0), _p(dy), dy.stride(0), L * B, dx.shape[1],
                                                          seed, offset * 8 + 2 + (k - 1), p_inter, _stream()),
                                    "vln_scale_dropout")

@@ -47,7 +47,9 @@ class _EnvDropStepFn(torch.autograd.Function):
         ctx.mod, ctx.rec, ctx.n_gated = mod, rec, len(gated)
         ctx.set_materialize_grads(False)
         k = rec.keep
-        return k["logit"], k["h1"], k["c1"], k["h_tilde"]
+        # fresh aliases: the returned objects get this node as grad_fn, and rec (reachable from the node) must not hold
+        # them, or every step that never runs backward leaks until the cyclic GC passes
+        return k["logit"].detach(), k["h1"].detach(), k["c1"].detach(), k["h_tilde"].detach()
 
     @staticmethod
     def backward(ctx, dlogit, dh1, dc1, dht):
@@ -72,13 +74,13 @@ class _EnvDropStepFn(torch.autograd.Function):
             if not dht.is_contiguous():
                 dht = dht.contiguous(); hold.append(dht)
             g.dh_tilde = dht.data_ptr()
-        dhtp = torch.empty(B, H, dtype=torch.float32, device=dev)
-        dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        dhtp = ops.empty(B, H, dtype=torch.float32, device=dev)
+        dc0 = ops.empty(B, H, dtype=torch.float32, device=dev)
         g.dh_tilde_prev, g.dc0 = dhtp.data_ptr(), dc0.data_ptr()
         if ctx.needs_input_grad[4]:
             e = rec.entry
             if e.dctx is None:
-                e.dctx = torch.zeros(B, rec.L, H, dtype=torch.float32, device=dev)
+                e.dctx = ops.zeros(B, rec.L, H, dtype=torch.float32, device=dev)
             g.dctx = e.dctx.data_ptr()
         s = rec.slot
         g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
@@ -292,10 +294,10 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         ctxc = ctx.detach()
         if not ctxc.is_contiguous():
             ctxc = ctxc.contiguous()
-        logit = torch.empty(B, Cn, dtype=torch.float32, device=dev)
-        h1 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        c1 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        h_tilde = torch.empty(B, H, dtype=torch.float32, device=dev)
+        logit = ops.empty(B, Cn, dtype=torch.float32, device=dev)
+        h1 = ops.empty(B, H, dtype=torch.float32, device=dev)
+        c1 = ops.empty(B, H, dtype=torch.float32, device=dev)
+        h_tilde = ops.empty(B, H, dtype=torch.float32, device=dev)
         keep = {"img": img, "cand": cand, "a": a, "htp": htp, "c0": c0, "ctx": ctxc,
                 "logit": logit, "h1": h1, "c1": c1, "h_tilde": h_tilde}
         io = _lib.EnvDropStep()
@@ -304,13 +306,13 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         if need_grad:
             slot = self._stash.take(B, entry.ref)
             rec.slot = slot
-            flat = torch.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at, dtype=torch.float32, device=dev)
+            flat = ops.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at, dtype=torch.float32, device=dev)
             io.a_stash, io.hq, io.xcat, io.tcat, io.htd = (slot.ptr("a"), slot.ptr("hq"), slot.ptr("xcat"), slot.ptr("tcat"),
                                                            slot.ptr("htd"))
         else:
             rec.slot = None
             XK = AE + F + H
-            flat = torch.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at + B * (H + XK + 2 * H + H), dtype=torch.float32, device=dev)
+            flat = ops.empty(4 + n_e + n_av + n_g + 2 * n_h + n_at + B * (H + XK + 2 * H + H), dtype=torch.float32, device=dev)
             q = flat.data_ptr() + 4 * (4 + n_e + n_av + n_g + 2 * n_h + n_at)
             io.hq, io.xcat, io.tcat, io.htd = q, q + 4 * B * H, q + 4 * B * (H + XK), q + 4 * B * (H + XK + 2 * H)
         keep["flat"] = flat
@@ -329,8 +331,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             ready = already_dropfeat and img_lp is not None and cand_lp is not None and img_lp.dtype == dt and \
                 cand_lp.dtype == dt and img_lp.is_contiguous() and cand_lp.is_contiguous()
             if not ready:
-                img_lp = torch.empty(B, V, F, dtype=dt, device=dev)
-                cand_lp = torch.empty(B, Cn, F, dtype=dt, device=dev)
+                img_lp = ops.empty(B, V, F, dtype=dt, device=dev)
+                cand_lp = ops.empty(B, Cn, F, dtype=dt, device=dev)
             else:
                 io.lp_ready = 1
             ctx_lp = entry.lp

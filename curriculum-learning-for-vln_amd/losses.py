@@ -32,14 +32,14 @@ class _MaskedCE(torch.autograd.Function):
         lg = logits.detach()
         if not lg.is_contiguous():
             lg = lg.contiguous()
-        probs = torch.empty(B, C, dtype=torch.float32, device=dev)
+        probs = ops.empty(B, C, dtype=torch.float32, device=dev)
         m8 = _mask8(cand_mask)
         tgt = target if target.is_contiguous() else target.contiguous()
         if fused_sum:        # reduction="sum" inside the same launch: a 0-dim result, no [B] vector round trip
-            out = torch.empty((), dtype=torch.float32, device=dev)
+            out = ops.empty((), dtype=torch.float32, device=dev)
             loss_p, sum_p = None, out.data_ptr()
         else:
-            out = torch.empty(B, dtype=torch.float32, device=dev)
+            out = ops.empty(B, dtype=torch.float32, device=dev)
             loss_p, sum_p = out.data_ptr(), None
         st = _lib.load().vln_masked_ce_fwd(lg.data_ptr(), lg.stride(0), tgt.data_ptr(), _p(m8), loss_p, sum_p, probs.data_ptr(),
                                            None, None, None, B, C, ignore_index, 0, _lib.raw_stream())
@@ -53,7 +53,7 @@ class _MaskedCE(torch.autograd.Function):
     def backward(ctx, dloss):
         probs, tgt = ctx.saved_tensors
         B, C = probs.shape
-        dl = torch.empty_like(probs)
+        dl = ops.empty_like(probs)
         if ctx.fused_sum or dloss.stride(0) == 0:
             stride = 0                                  # one upstream scalar (also what .sum().backward() hands down)
         else:
@@ -86,9 +86,9 @@ def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional
     lib = _lib.load()
     B, C = logits.shape
     lg = logits.detach().contiguous()
-    probs = torch.empty(B, C, dtype=torch.float32, device=logits.device)
-    logp = torch.empty(B, dtype=torch.float32, device=logits.device)
-    ent = torch.empty(B, dtype=torch.float32, device=logits.device)
+    probs = ops.empty(B, C, dtype=torch.float32, device=logits.device)
+    logp = ops.empty(B, dtype=torch.float32, device=logits.device)
+    ent = ops.empty(B, dtype=torch.float32, device=logits.device)
     _lib.check(lib.vln_masked_ce_fwd(_p(lg), lg.stride(0), None, _p(_mask8(cand_mask)), None, None, _p(probs), _p(action.contiguous()),
                                      _p(logp), _p(ent), B, C, -1, 0, _lib.raw_stream()),
                "vln_masked_ce_fwd")

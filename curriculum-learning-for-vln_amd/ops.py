@@ -39,6 +39,86 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32):
     return t
 
 
+# ---- allocation ------------------------------------------------------------------------------------------------------
+# Every buffer the modules create on the per-iteration path goes through `empty` / `zeros` / `empty_like`.  Normally that
+# is torch.empty.  With a `RolloutArena` active the n-th request of an iteration returns the SAME memory as the n-th
+# request two iterations earlier, so the device addresses in a decoder step's argument block repeat and the step can be
+# replayed as a hipGraph (EnvDropDecoder.step_graphs) -- PyTorch's caching allocator gives no such guarantee.
+_arena = None
+
+
+class RolloutArena:
+    """Opt-in allocator for training loops with a fixed per-iteration allocation sequence.
+
+        arena = vln.ops.RolloutArena(); vln.ops.set_arena(arena)
+        for batch in loader:
+            arena.begin()          # top of every iteration
+            ... rollout, backward, optimizer step ...
+
+    Contract: a tensor produced by the modules during iteration i is overwritten during iteration i + `generations`
+    (default 2); copy (`.clone()` / `.item()`) anything that must live longer.  A request whose shape or dtype differs
+    from the recorded sequence simply gets fresh memory (correct, but that step's graph will not replay)."""
+
+    def __init__(self, generations: int = 2):
+        self.gens = [[] for _ in range(max(1, generations))]
+        self.g = 0
+        self.i = 0
+        self.misses = 0
+
+    def begin(self):
+        self.g = (self.g + 1) % len(self.gens)
+        self.i = 0
+
+    def get(self, shape, dtype, device, alias=True):
+        lst = self.gens[self.g]
+        i = self.i
+        self.i = i + 1
+        if i < len(lst):
+            t = lst[i]
+            if t.shape != shape or t.dtype != dtype or t.device != device:
+                self.misses += 1
+                t = lst[i] = torch.empty(shape, dtype=dtype, device=device)
+        else:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            lst.append(t)
+        # a fresh alias per request: autograd metadata (grad_fn) of an earlier iteration must not stick to the memory
+        return t.detach() if alias else t
+
+
+def set_arena(arena: Optional["RolloutArena"]):
+    global _arena
+    _arena = arena
+
+
+def empty(*size, dtype=torch.float32, device=None):
+    if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+        size = tuple(size[0])
+    a = _arena
+    if a is not None and device is not None:
+        return a.get(torch.Size(size), dtype, device if isinstance(device, torch.device) else torch.device(device))
+    return torch.empty(size, dtype=dtype, device=device)
+
+
+def zeros(*size, dtype=torch.float32, device=None):
+    if _arena is None:
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            size = tuple(size[0])
+        return torch.zeros(size, dtype=dtype, device=device)
+    return empty(*size, dtype=dtype, device=device).zero_()
+
+
+def zeros_like(t: torch.Tensor):
+    if _arena is None:
+        return torch.zeros_like(t)
+    return empty(t.shape, dtype=t.dtype, device=t.device).zero_()
+
+
+def empty_like(t: torch.Tensor):
+    if _arena is None:
+        return torch.empty_like(t)
+    return empty(t.shape, dtype=t.dtype, device=t.device)
+
+
 _ws_cache = {}
 
 
@@ -61,7 +141,7 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None):
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        out = empty(M, N, dtype=torch.float32, device=x.device)
     ws = workspace(x.device, min(16 * M * N, 1 << 24))
     _lib.check(lib.vln_linear_fwd(_p(x), x.stride(0), _p(w), _dt(w), w.stride(0), _p(out), out.stride(0), M, N, K,
                                   _p(bias), act, _p(ws), ws.numel(), _stream()), "vln_linear_fwd")
@@ -76,7 +156,7 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
     K = x.shape[1]
     assert x.shape[0] == Mt
     if out is None:
-        out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        out = torch.empty(N, K, dtype=torch.float32, device=x.device)   # a weight gradient: may become p.grad
         accumulate = False
     ws = workspace(x.device, 1 << 22)
     _lib.check(lib.vln_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), Mt, N, K,
@@ -89,7 +169,7 @@ def colsum(a, out=None, accumulate=False):
     _req(a, "a")
     rows, cols = a.shape
     if out is None:
-        out = torch.empty(cols, dtype=torch.float32, device=a.device)
+        out = torch.empty(cols, dtype=torch.float32, device=a.device)   # a bias gradient: may become p.grad
         accumulate = False
     ws = workspace(a.device, 1 << 22)
     _lib.check(lib.vln_colsum(_p(a), a.stride(0), _p(out), rows, cols, int(accumulate), _p(ws), ws.numel(), _stream()),
@@ -102,7 +182,7 @@ def transpose_cast(w, dtype=torch.float32, out=None):
     _req(w, "w")
     N, K = w.shape
     if out is None:
-        out = torch.empty(K, N, dtype=dtype, device=w.device)
+        out = torch.empty(K, N, dtype=dtype, device=w.device)           # a weight shadow: lives across iterations
     _lib.check(lib.vln_transpose_cast(_p(w), w.stride(0), _p(out), _dt(out), out.stride(0), N, K, _stream()),
                "vln_transpose_cast")
     return out
@@ -126,7 +206,7 @@ def attn_dot(ctx, vec):
     _req(ctx, "ctx", None); _req(vec, "vec")
     B, S, D = ctx.shape
     assert ctx.is_contiguous()
-    dots = torch.empty(B, S, dtype=torch.float32, device=ctx.device)
+    dots = empty(B, S, dtype=torch.float32, device=ctx.device)
     _lib.check(lib.vln_attn_dot(_p(ctx), _dt(ctx), _p(vec), vec.stride(0), _p(dots), B, S, D, _stream()),
                "vln_attn_dot")
     return dots
@@ -137,9 +217,9 @@ def attn_softmax_wsum(ctx, logits, mask=None, out=None):
     _req(ctx, "ctx", None); _req(logits, "logits")
     B, S, D = ctx.shape
     assert ctx.is_contiguous() and logits.is_contiguous()
-    attn = torch.empty(B, S, dtype=torch.float32, device=ctx.device)
+    attn = empty(B, S, dtype=torch.float32, device=ctx.device)
     if out is None:
-        out = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
+        out = empty(B, D, dtype=torch.float32, device=ctx.device)
     m8 = None
     if mask is not None:
         m8 = mask.to(torch.uint8).contiguous()
@@ -154,7 +234,7 @@ def rows_wsum(ctx, w, out=None):
     B, S, D = ctx.shape
     assert ctx.is_contiguous() and w.is_contiguous()
     if out is None:
-        out = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
+        out = empty(B, D, dtype=torch.float32, device=ctx.device)
     _lib.check(lib.vln_rows_wsum(_p(ctx), _dt(ctx), _p(w), _p(out), out.stride(0), B, S, D, _stream()),
                "vln_rows_wsum")
     return out
@@ -164,8 +244,8 @@ def attn_bwd(ctx, attn, dalpha, dattn_ext=None, dwc=None, vec=None, dctx=None, w
     """Returns (dvec, dl).  If dctx is given it is accumulated in place."""
     lib = _lib.load()
     B, S, D = ctx.shape
-    dvec = torch.empty(B, D, dtype=torch.float32, device=ctx.device)
-    dl = torch.empty(B, S, dtype=torch.float32, device=ctx.device) if want_dl else None
+    dvec = empty(B, D, dtype=torch.float32, device=ctx.device)
+    dl = empty(B, S, dtype=torch.float32, device=ctx.device) if want_dl else None
     _lib.check(lib.vln_attn_bwd(_p(ctx), _dt(ctx), _p(attn), _p(dalpha), _p(dattn_ext), _p(dwc),
                                 dwc.stride(0) if dwc is not None else 0, _p(vec),
                                 vec.stride(0) if vec is not None else 0, _p(dvec), dvec.stride(0), _p(dctx), _p(dl),
@@ -176,7 +256,7 @@ def attn_bwd(ctx, attn, dalpha, dattn_ext=None, dwc=None, vec=None, dctx=None, w
 def dropout_mask(n: int, seed: int, offset: int, p: float, device) -> torch.Tensor:
     """The exact pre-scaled keep mask (0 or 1/(1-p)) the kernels use for (seed, offset)."""
     lib = _lib.load()
-    out = torch.empty(n, dtype=torch.float32, device=device)
+    out = empty(n, dtype=torch.float32, device=device)
     _lib.check(lib.vln_dropout_mask(_p(out), n, seed, offset, p, _stream()), "vln_dropout_mask")
     return out
 
@@ -197,9 +277,9 @@ def lstm_pointwise_fwd(gates, b_ih, b_hh, c0, seed=0, offset=0, p=0.0, want_drop
     ns, B, H4 = gates.shape
     H = H4 // 4
     dev = gates.device
-    h1 = torch.empty(B, H, device=dev); c1 = torch.empty(B, H, device=dev)
-    act = torch.empty(B, H4, device=dev); tc = torch.empty(B, H, device=dev)
-    hd = torch.empty(B, H, device=dev) if want_drop else None
+    h1 = empty(B, H, device=dev); c1 = empty(B, H, device=dev)
+    act = empty(B, H4, device=dev); tc = empty(B, H, device=dev)
+    hd = empty(B, H, device=dev) if want_drop else None
     _lib.check(lib.vln_lstm_pointwise_fwd(_p(gates), ns, B * H4, _p(b_ih), _p(b_hh), _p(c0), _p(h1), _p(c1), _p(act),
                                           _p(tc), _p(hd), seed, offset, p, B, H, _stream()), "vln_lstm_pointwise_fwd")
     return h1, c1, act, tc, hd
@@ -208,7 +288,7 @@ def lstm_pointwise_fwd(gates, b_ih, b_hh, c0, seed=0, offset=0, p=0.0, want_drop
 def lstm_pointwise_bwd(dh1, dh1_drop, dc1, act, tanh_c1, c0, seed=0, offset=0, p=0.0):
     lib = _lib.load()
     B, H = c0.shape
-    dg = torch.empty(B, 4 * H, device=c0.device); dc0 = torch.empty(B, H, device=c0.device)
+    dg = empty(B, 4 * H, device=c0.device); dc0 = empty(B, H, device=c0.device)
     _lib.check(lib.vln_lstm_pointwise_bwd(_p(dh1), _p(dh1_drop), _p(dc1), seed, offset, p, _p(act), _p(tanh_c1),
                                           _p(c0), _p(dg), _p(dc0), B, H, _stream()), "vln_lstm_pointwise_bwd")
     return dg, dc0

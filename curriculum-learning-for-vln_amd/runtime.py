@@ -293,5 +293,6 @@ class GatedModuleMixin:
         if dtype == torch.float32:
             return None
         if entry.lp is None:
-            entry.lp = ops.cast_copy(ctx_t.detach().contiguous(), dtype)
+            src = ctx_t.detach().contiguous()
+            entry.lp = ops.cast_copy(src, dtype, ops.empty(src.shape, dtype=dtype, device=src.device))
         return entry.lp

@@ -92,8 +92,8 @@ class DeviceFeatureStore:
         lib = _lib.load()
         B = rows.shape[0]
         F = self.IMG + self.ANG
-        out = torch.empty(B, self.V, F, dtype=torch.float32, device=self.device)
-        lp = torch.empty(B, self.V, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        out = ops.empty(B, self.V, F, dtype=torch.float32, device=self.device)
+        lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         seed, off, p = self._drop(p_feat)
         _lib.check(lib.vln_gather_pano(_p(self.table), ops._dt(self.table), _p(rows), _p(view_index), _p(self.angle_table),
                                        _p(out), _p(lp), B, self.V, self.IMG, self.ANG, seed, off, p,
@@ -106,8 +106,8 @@ class DeviceFeatureStore:
         lib = _lib.load()
         B, C = rows.shape
         F = self.IMG + self.ANG
-        out = torch.empty(B, C, F, dtype=torch.float32, device=self.device)
-        lp = torch.empty(B, C, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        out = ops.empty(B, C, F, dtype=torch.float32, device=self.device)
+        lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         seed, off, p = self._drop(p_feat)
         _lib.check(lib.vln_gather_cands(_p(self.table), ops._dt(self.table), _p(rows.contiguous()), _p(views.contiguous()),
                                         _p(heading.contiguous()), _p(elevation.contiguous()), _p(out), _p(lp), B * C,

@@ -23,7 +23,8 @@ VARIANTS = {   # (persistent, graphs, split target, no-split rule, n16 kernel, n
     "n16_all_K": (1, 1, 256, 1, 1, 0),
     "n16_off": (1, 1, 256, 1, 0, 0),
     "n16_off_target512": (1, 1, 512, 1, 0, 0),
-    "no_step_graphs": (1, 0, 256, 1, 1, 512),
+    "arena_step_graphs": (1, 1, 256, 1, 1, 512),
+    "arena_no_graphs": (1, 0, 256, 1, 1, 512),
     "per_step_lstm": (0, 1, 256, 1, 1, 512),
 }
 torch.manual_seed(0)
@@ -32,6 +33,9 @@ agent = bench.GpuAgent(vln, dev, dtype, 1)
 
 def configure(cfg, name=""):
     agent.dec.overlap_wgrads = (name == "overlap_wgrads")
+    want = name.startswith("arena")
+    if want != (agent.arena is not None):
+        agent.use_arena(want)
     lib.vln_set_persistent(cfg[0]); lib.vln_set_graphs(cfg[1]); lib.vln_set_tunable(0, cfg[2]); lib.vln_set_tunable(1, cfg[3]); lib.vln_set_tunable(2, cfg[4]); lib.vln_set_tunable(3, cfg[5])
 
 
