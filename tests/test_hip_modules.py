@@ -388,6 +388,42 @@ def test_step_graphs_with_device_side_dropout_offset_are_transparent(vln):
     assert st[1] > 0                                  # steps were captured (replays need address-stable callers)
 
 
+def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
+    """ops.RolloutArena: per-iteration buffers come back at the same addresses, so from the third iteration on every
+    decoder step replays its hipGraph; losses and gradients equal the torch.empty / plain-launch configuration bit for
+    bit (dropout on), and the arena must not be left active after an iteration."""
+    import ctypes
+    import bench
+    dev_ = torch.device(DEV)
+    tape = bench.tape_to(bench.make_tape(16, 24, 3, 6, seed=6), dev_, store_dtype=torch.bfloat16)
+    lib = vln._lib.load()
+    st0, st1 = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
+    res = []
+    for arena in (True, False):
+        torch.manual_seed(17)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=arena)
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        tape["store"]._calls = 0                      # the store's feature-dropout stream restarts too
+        ag.opt.lr = 0.0
+        if arena:
+            lib.vln_graph_stats(st0)
+        out = []
+        for _ in range(5):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in ag.dec.parameters()]))
+        if arena:
+            lib.vln_graph_stats(st1)
+            assert ag.arena.misses == 0
+        assert vln.ops._arena is None
+        res.append(out)
+    assert st1[0] - st0[0] >= 3 * 6                  # iterations 3..5: 3 steps x (fwd + bwd) replays each
+    for (la, ga), (lb, gb) in zip(res[0], res[1]):
+        assert torch.equal(la, lb)
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+
+
 def test_missing_library_fails_loudly(vln, monkeypatch):
     monkeypatch.setattr(vln._lib, "_lib", None)
     monkeypatch.setattr(vln._lib, "LIB_PATH", "/nonexistent/libvln_hip.so")
