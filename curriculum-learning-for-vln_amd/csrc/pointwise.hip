@@ -264,20 +264,47 @@ __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(CeArgs a) {
   const int b = blockIdx.x * 4 + wave;
   if (b < a.B) ce_row(a, b, lane);
 }
-// reduction="sum" in the same launch: ONE workgroup of 16 waves, rows strided over the waves, partial sums folded in a
-// fixed order (deterministic).  The batch is a few hundred rows of <= 16 candidates: nothing to parallelise further.
-__global__ __launch_bounds__(1024) void masked_ce_fwd_sum_kernel(CeArgs a, float* loss_sum) {
-  __shared__ float part[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int b = wave; b < a.B; b += 16) acc += ce_row(a, b, lane);
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += part[w];
-    loss_sum[0] = t;
+// reduction="sum" in the same launch: ONE workgroup, one THREAD per row (a row is <= a few dozen candidates: three
+// short serial passes beat a wave's cross-lane reductions, and 64 rows then cost one wave), block sum in a fixed order.
+__device__ __forceinline__ float ce_row_serial(const CeArgs& a, int b) {
+  const int C = a.C;
+  const unsigned char* mk = a.mask ? a.mask + (long)b * C : nullptr;
+  float* lg = a.logits + (long)b * a.ld;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) {
+    float v = lg[c];
+    if (mk && mk[c]) {
+      v = -INFINITY;
+      if (a.write_mask) lg[c] = v;
+    }
+    mx = fmaxf(mx, v);
   }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx);
+  const float lse = mx + __logf(sum);
+  const long tgt = a.target ? a.target[b] : a.ignore_index;
+  const float eps = 1.1920928955078125e-07f;
+  float ent = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float p = __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - lse);
+    if (a.probs) a.probs[(long)b * C + c] = p;
+    const float pc = fminf(fmaxf(p, eps), 1.f - eps);
+    ent -= p * __logf(pc);
+    if (a.action && a.logp && c == a.action[b]) a.logp[b] = __logf(pc);
+  }
+  const float l = (tgt == a.ignore_index) ? 0.f : (lse - lg[tgt]);
+  if (a.entropy) a.entropy[b] = ent;
+  if (a.loss) a.loss[b] = l;
+  return l;
+}
+__global__ __launch_bounds__(256) void masked_ce_fwd_sum_kernel(CeArgs a, float* loss_sum) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) acc += ce_row_serial(a, b);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_sum[0] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // dlogits[b,c] = dloss[b] * (p - onehot(target))   (0 for ignored rows; p = 0 at masked slots)
@@ -300,7 +327,7 @@ extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* targe
   if (!logits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_fwd: bad args"); return VLN_ERR_ARG; }
   vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, loss, probs, (const long long*)action, logp, entropy,
                 B, C, (long)ignore_index, write_mask};
-  if (loss_sum) hipLaunchKernelGGL(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, a, loss_sum);
+  if (loss_sum) hipLaunchKernelGGL(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, loss_sum);
   else hipLaunchKernelGGL(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("masked_ce_fwd");
   return VLN_OK;
