@@ -79,7 +79,7 @@ SIGNATURES = {
     "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
-    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),

@@ -153,6 +153,7 @@ struct RecFwdArgs {
   float* hcat;            // [B, dirs*Hd] final h
   float* ccat;            // [B, dirs*Hd] final c
   int B, L, Hd, dirs, step, vec;
+  int init;               // 1: the first time slot of hprev/cprev holds a caller-given initial state (else zeros)
 };
 
 template <typename TW>
@@ -384,17 +385,36 @@ extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uin
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_hh, int wtype, const int32_t* lengths,
-                              float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
-                              float* ccat, int B, int L, int Hd, int dirs) {
-  // initial states: time 0 of the forward direction, time L-1 of the reverse direction
+// initial states: time 0 of the forward direction, time L-1 of the reverse direction; zeros unless h0/c0 [dirs][B][Hd]
+__global__ void copy_f32_kernel(const float* src, float* dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static int seed_initial_state(hipStream_t st, const float* h0, const float* c0, float* hprev, float* cprev, int B, int L,
+                              int Hd, int dirs) {
   const long blk = (long)B * Hd;
   for (int d = 0; d < dirs; ++d) {
     const long off = ((long)d * L + (d == 0 ? 0 : L - 1)) * blk;
-    int r = fill_f32(st, hprev + off, blk, 0.f); if (r) return r;
-    r = fill_f32(st, cprev + off, blk, 0.f); if (r) return r;
+    const float* src[2] = {h0 ? h0 + d * blk : nullptr, c0 ? c0 + d * blk : nullptr};
+    float* dst[2] = {hprev + off, cprev + off};
+    for (int k = 0; k < 2; ++k) {
+      if (src[k]) {
+        int nb = (int)((blk + 255) / 256); if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(copy_f32_kernel, dim3(nb), dim3(256), 0, st, src[k], dst[k], blk);
+      } else {
+        int r = fill_f32(st, dst[k], blk, 0.f); if (r) return r;
+      }
+    }
   }
-  RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 0};
+  VLN_CHECK_LAUNCH("lstm initial state");
+  return VLN_OK;
+}
+
+static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_hh, int wtype, const int32_t* lengths,
+                              float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
+                              float* ccat, int B, int L, int Hd, int dirs, const float* h0, const float* c0) {
+  int r0 = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs);
+  if (r0) return r0;
+  RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 0, 0};
   a.vec = al16(w_hh) && al16(hprev) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
   dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
   // per-launch algorithmic bytes: W_hh once, h/c state in+out, xproj in, y/act/tanh_c out
@@ -457,14 +477,17 @@ extern "C" int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs) {
 
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
-                                int L, int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s) {
+                                int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
+                                int64_t sync_ws_bytes, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= kSyncHeaderBytes && al16(w_hh) && al16(hprev)) {
     hipStream_t st = (hipStream_t)s;
     int r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);     // status word [32], flag lines from word 64
     if (r) return r;
-    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1};
+    const int init = (h0 || c0) ? 1 : 0;
+    if (init) { r = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs); if (r) return r; }
+    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
@@ -473,11 +496,11 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
                                : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
   }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
-  struct { const void* p[10]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat},
+  struct { const void* p[12]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, h0, c0},
                                                  {wtype, B, L, Hd, dirs}};
   static GraphCache cache;
   return cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
-    return lstm_seq_fwd_issue(st, xproj, w_hh, wtype, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs);
+    return lstm_seq_fwd_issue(st, xproj, w_hh, wtype, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, h0, c0);
   });
 }
 

@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
   const bool live = b < B;
   const int len = live ? a.lengths[b] : 0;
   float hreg = 0.f, creg = 0.f;
+  if (a.init && live) {      // caller-given initial state, already copied into the first time slot (plain loads)
+    const long s0 = (((long)d * L + (d == 0 ? 0 : L - 1)) * B + b) * HD + j;
+    hreg = a.hprev[s0]; creg = a.cprev[s0];
+  }
   __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, (unsigned)((long)a.dirs * L * B * HD * 4), 0x00020000);
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) s_abort = 0;
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       xi = xp[0]; xf = xp[HD]; xg = xp[2 * HD]; xo = xp[3 * HD];
     }
     VLN_STAMP(0);
-    if (step > 0) {
-      group_wait(cnt, njb, (unsigned)step, status, &s_abort);
+    if (step > 0 || a.init) {
+      if (step > 0) group_wait(cnt, njb, (unsigned)step, status, &s_abort);
       VLN_STAMP(1);
       // h tile [16 rows x HD] of time t, written by the group's workgroups in the previous step
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       a.tanh_c[row * Y + d * HD + j] = tc;
       a.y[row * Y + d * HD + j] = yv;
       a.cprev[(sbase + b) * HD + j] = c_in;                       // state fed into time t
-      if (step == 0) a.hprev[(sbase + b) * HD + j] = 0.f;
+      if (step == 0 && !a.init) a.hprev[(sbase + b) * HD + j] = 0.f;
     }
 #if !VLN_FWD_LATE_STORES
     group_arrive(cnt, blockIdx.x, (unsigned)step + 1u);

@@ -52,7 +52,7 @@ class _EncoderFn(torch.autograd.Function):
             hcat = ops.empty(B, dirs * Hd, **f32)
             ccat = ops.empty(B, dirs * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
-                                            _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs,
+                                            _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:

@@ -1,0 +1,227 @@
+"""Speaker modules for back-translation: drop-ins for the reference's `SpeakerEncoder` /
+`SpeakerDecoder` (src/model/units.py:286-395, themselves after github.com/airsplay/R2R-EnvDrop r2r_src/model.py).
+
+Same constructors, forward contracts and `state_dict` keys.  The math reuses the path's HIP kernels through the C ABI:
+the whole-sequence LSTMs run as one input-projection GEMM + the (persistent) recurrence of `vln_lstm_seq_fwd/bwd`
+(`_LSTMSeqFn`, unpacked: the reference calls `nn.LSTM` on the padded batch without lengths), the attention over the
+36 views / over the encoded path is `SoftDotAttention` on the attention kernels, the vocabulary projection is
+`vln_linear_fwd`.  An initial state (`h0`/`c0`, e.g. carried through word-by-word inference) is seeded into the
+recurrence's first time slot; only a DIFFERENTIABLE initial state takes the LSTM-cell path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from . import functional as Fh
+from .decoders import SoftDotAttention, _Seeded, _need_gpu
+
+_p = ops._p
+
+
+class _LSTMSeqFn(torch.autograd.Function):
+    """One (bi)LSTM layer over a full-length batch, zero initial state.  x_tm [L*B, I] time-major;
+    params = (w_ih, w_hh, b_ih, b_hh) per direction.  Returns y_tm [L*B, dirs*Hd], h_T, c_T [B, dirs*Hd]."""
+
+    @staticmethod
+    def forward(ctx, owner, x_tm, B, L, h0, c0, *params):
+        lib = _lib.load()
+        dirs = len(params) // 4
+        Hd = params[1].shape[1]
+        dev = x_tm.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        w_ih = torch.cat([params[4 * d].detach() for d in range(dirs)], 0).contiguous()
+        bsum = torch.cat([(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(dirs)], 0).contiguous()
+        w_hh = torch.stack([params[4 * d + 1].detach() for d in range(dirs)], 0).contiguous()
+        x_tm = x_tm.contiguous()
+        xproj = ops.linear_fwd(x_tm, w_ih, bsum)
+        hprev = ops.empty(dirs, L, B, Hd, **f32)
+        cprev = ops.empty(dirs, L, B, Hd, **f32)
+        y = ops.empty(L * B, dirs * Hd, **f32)
+        act = ops.empty(L * B, dirs * 4 * Hd, **f32)
+        tanh_c = ops.empty(L * B, dirs * Hd, **f32)
+        hcat = ops.empty(B, dirs * Hd, **f32)
+        ccat = ops.empty(B, dirs * Hd, **f32)
+        lens32 = torch.full((B,), L, dtype=torch.int32, device=dev)
+        _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), ops.F32, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
+                                        _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
+                                        *owner._sync_ws(dev, B, Hd, dirs), _lib.raw_stream()), "vln_lstm_seq_fwd")
+        ctx.owner, ctx.dims = owner, (B, L, Hd, dirs)
+        ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh)
+        ctx.set_materialize_grads(False)
+        return y, hcat, ccat
+
+    @staticmethod
+    def backward(ctx, dy, dh, dc):
+        lib = _lib.load()
+        x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh = ctx.saved_tensors
+        B, L, Hd, dirs = ctx.dims
+        dev = x_tm.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda t: t.reshape(B, dirs, Hd).transpose(0, 1).contiguous() if t is not None else ops.zeros(dirs, B, Hd, **f32)
+        dh_pass, dc_carry = z(dh), z(dc)
+        dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
+        w_hh_t = torch.stack([ops.transpose_cast(w_hh[d], torch.float32) for d in range(dirs)], 0).contiguous()
+        dyc = dy.contiguous() if dy is not None else None
+        _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), ops.F32, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
+                                        _p(dh_pass), _p(dc_carry), B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
+                                        _lib.raw_stream()), "vln_lstm_seq_bwd")
+        grads = []
+        for d in range(dirs):
+            dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
+            db = ops.colsum(dg)
+            grads += [ops.linear_wgrad(dg, x_tm), ops.linear_wgrad(dg, hprev[d].view(L * B, Hd)), db, db.clone()]
+        dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, torch.float32)) if ctx.needs_input_grad[1] else None
+        return (None, dx, None, None, None, None) + tuple(grads)
+
+
+class _SeqLSTM(nn.Module):
+    """Parameter holder with nn.LSTM's names (`weight_ih_l0[_reverse]`, ...) + the HIP forward."""
+
+    def __init__(self, input_size, hidden_size, bidirectional=False):
+        super().__init__()
+        # nn.LSTM registers the reference's parameter names and default init; its forward is never called
+        self.rnn = nn.LSTM(input_size, hidden_size, 1, batch_first=True, bidirectional=bidirectional)
+        self.hidden_size, self.dirs = hidden_size, 2 if bidirectional else 1
+
+    def _sync_ws(self, dev, B, Hd, dirs):
+        need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
+        w = self.__dict__.get("_sync_buf")
+        if w is None or w.device != dev or w.numel() * 4 < need:
+            w = torch.zeros((need + 3) // 4, dtype=torch.int32, device=dev)
+            object.__setattr__(self, "_sync_buf", w)
+        return w.data_ptr(), w.numel() * 4
+
+    def _params(self):
+        out = []
+        for sfx in ["_l0"] + (["_l0_reverse"] if self.dirs == 2 else []):
+            out += [getattr(self.rnn, n + sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return out
+
+    def forward(self, x, state=None):
+        """x [B, L, I] -> (y [B, L, dirs*H], (h_T, c_T) each [dirs, B, H]) like nn.LSTM(batch_first=True)."""
+        B, L, _ = x.shape
+        H = self.hidden_size
+        h0 = c0 = None
+        if state is not None:
+            h0, c0 = state
+            if h0.requires_grad or c0.requires_grad:   # gradient into the initial state: the LSTM-cell path, one direction
+                if self.dirs != 1:
+                    raise _lib.VlnError("speaker LSTM: a differentiable initial state needs a unidirectional layer")
+                w_ih, w_hh, b_ih, b_hh = self._params()
+                h, c = h0[0], c0[0]
+                ys = []
+                for t in range(L):
+                    h, c = Fh.LSTMCellFn.apply(x[:, t].contiguous(), h, c, w_ih, w_hh, b_ih, b_hh, torch.float32)
+                    ys.append(h)
+                return torch.stack(ys, 1), (h.unsqueeze(0), c.unsqueeze(0))
+            h0 = h0.detach().to(torch.float32).contiguous()
+            c0 = c0.detach().to(torch.float32).contiguous()
+        x_tm = x.transpose(0, 1).reshape(L * B, x.shape[-1])
+        y, hcat, ccat = _LSTMSeqFn.apply(self, x_tm, B, L, h0, c0, *self._params())
+        y = y.view(L, B, self.dirs * H).transpose(0, 1)
+        return y, (hcat.view(B, self.dirs, H).transpose(0, 1), ccat.view(B, self.dirs, H).transpose(0, 1))
+
+
+def _rename_lstm_keys(module: nn.Module, names):
+    """state_dict compatibility: the holder keeps nn.LSTM's parameters under `<name>.rnn.*`; the reference has them
+    directly under `<name>.*` (units.py:303,309,348)."""
+    def save_hook(mod, sd, prefix, local):
+        for n in names:
+            for k in [k for k in sd if k.startswith(prefix + n + ".rnn.")]:
+                sd[prefix + n + "." + k[len(prefix + n + ".rnn."):]] = sd.pop(k)
+
+    def load_hook(sd, prefix, *a):
+        for n in names:
+            for k in [k for k in sd if k.startswith(prefix + n + ".") and not k.startswith(prefix + n + ".rnn.")]:
+                sd[prefix + n + ".rnn." + k[len(prefix + n + "."):]] = sd.pop(k)
+
+    module._register_state_dict_hook(save_hook)
+    module._register_load_state_dict_pre_hook(load_hook)
+
+
+class SpeakerEncoder(nn.Module, _Seeded):
+    """units.py:286-341: LSTM over the path's action features -> attention over each step's 36 views -> post-LSTM."""
+
+    def __init__(self, feature_size, hidden_size, dropout_ratio, bidirectional, angle_feat_size, feat_dropout):
+        super().__init__()
+        self.num_directions = 2 if bidirectional else 1
+        self.hidden_size = hidden_size
+        self.num_layers = 1
+        self.feature_size = feature_size
+        self.angle_feat_size = angle_feat_size
+        self.drop_ratio, self.feat_drop_ratio = float(dropout_ratio), float(feat_dropout)
+        self.lstm = _SeqLSTM(feature_size, hidden_size // self.num_directions, bidirectional)
+        self.drop = nn.Dropout(p=dropout_ratio)
+        self.drop3 = nn.Dropout(p=feat_dropout)
+        self.attention_layer = SoftDotAttention(query_dim=hidden_size, context_dim=feature_size)
+        self.post_lstm = _SeqLSTM(hidden_size, hidden_size // self.num_directions, bidirectional)
+        self._init_seed(0x59EA)
+        _rename_lstm_keys(self, ("lstm", "post_lstm"))
+
+    def forward(self, action_embeds, feature, lengths=None, already_dropfeat=False):
+        """action_embeds [B, Lp, F], feature [B, Lp, 36, F] (both mutated in place by the feature dropout like the
+        reference, units.py:322,331) -> context [B, Lp, hidden]."""
+        _need_gpu(action_embeds, "SpeakerEncoder")
+        off = self._next()
+        p, pf = (self.drop_ratio, self.feat_drop_ratio) if self.training else (0.0, 0.0)
+        F, ANG = self.feature_size, self.angle_feat_size
+        B, Lp, _ = action_embeds.shape
+        x = action_embeds
+        if not already_dropfeat and pf > 0:
+            xc = x if x.is_contiguous() else x.contiguous()
+            ops.feat_dropout_inplace(xc, F - ANG, ANG, self.dropout_seed, off + 0, pf)
+            if xc is not x:
+                x.copy_(xc)
+            fc = feature if feature.is_contiguous() else feature.contiguous()
+            ops.feat_dropout_inplace(fc, F - ANG, ANG, self.dropout_seed, off + 1, pf)
+            if fc is not feature:
+                feature.copy_(fc)
+        ctx, _ = self.lstm(x)
+        ctx = Fh.dropout(ctx.contiguous(), p, self.training, self.dropout_seed, off + 2)
+        x, _ = self.attention_layer(ctx.view(B * Lp, self.hidden_size), feature.reshape(B * Lp, -1, F))
+        x = Fh.dropout(x.view(B, Lp, -1), p, self.training, self.dropout_seed, off + 3)
+        x, _ = self.post_lstm(x)
+        return Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 4)
+
+
+class SpeakerDecoder(nn.Module, _Seeded):
+    """units.py:344-395: word embedding -> LSTM -> attention over the encoded path -> vocabulary logits."""
+
+    def __init__(self, vocab_size, embedding_size, padding_idx, hidden_size, dropout_ratio):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.drop_ratio = float(dropout_ratio)
+        self.embedding = nn.Embedding(vocab_size, embedding_size, padding_idx)
+        self.lstm = _SeqLSTM(embedding_size, hidden_size, False)
+        self.drop = nn.Dropout(dropout_ratio)
+        self.attention_layer = SoftDotAttention(query_dim=hidden_size)
+        self.projection = nn.Linear(hidden_size, vocab_size)
+        self.baseline_projection = nn.Sequential(nn.Linear(hidden_size, 128), nn.ReLU(), nn.Dropout(dropout_ratio),
+                                                 nn.Linear(128, 1))
+        self._init_seed(0x5DEC)
+        _rename_lstm_keys(self, ("lstm",))
+
+    def forward(self, words, ctx, ctx_mask, h0, c0):
+        """words [Bw, Lw] int64, ctx [B, Lp, H], ctx_mask [B, Lp] (True = masked), h0/c0 [1, Bw, H]
+        -> (logit [Bw, Lw, vocab], h1, c1).  Bw may be a multiple of B (beam search), units.py:375-376."""
+        _need_gpu(ctx, "SpeakerDecoder")
+        off = self._next()
+        p = self.drop_ratio if self.training else 0.0
+        H = self.hidden_size
+        Bw, Lw = words.shape
+        emb = torch.nn.functional.embedding(words, self.embedding.weight, self.embedding.padding_idx)
+        emb = Fh.dropout(emb.contiguous(), p, self.training, self.dropout_seed, off + 0)
+        x, (h1, c1) = self.lstm(emb, (h0, c0))
+        x = Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 1)
+        n = Bw * Lw
+        mult = n // ctx.size(0)
+        ctx_e = ctx.unsqueeze(1).expand(-1, mult, -1, -1).contiguous().view(n, -1, H)
+        mask_e = ctx_mask.unsqueeze(1).expand(-1, mult, -1).contiguous().view(n, -1) if ctx_mask is not None else None
+        x, _ = self.attention_layer(x.view(n, H), ctx_e, mask=mask_e)
+        x = Fh.dropout(x.view(Bw, Lw, H), p, self.training, self.dropout_seed, off + 2)
+        logit = Fh.linear(x.view(n, H), self.projection.weight, self.projection.bias).view(Bw, Lw, -1)
+        return logit, h1, c1

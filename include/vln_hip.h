@@ -156,6 +156,8 @@ int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed,
 int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs);
 int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev, float* cprev,
                      float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B, int L, int Hd, int dirs,
+                     const float* h0, const float* c0 /* [dirs][B][Hd] initial state, nullable = zeros (no gradient flows
+                     back into it: vln_lstm_seq_bwd starts from the final states only) */,
                      void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 forces the per-step path; results are identical */
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]

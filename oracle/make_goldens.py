@@ -495,6 +495,42 @@ def gen_eval_scores():
     print("eval_scores:", {k: round(v, 4) for k, v in out["summary"].items()})
 
 
+def gen_speaker(U):
+    """Speaker modules (units.py:286-395), eval mode: encoder over a 5-step path with 36 views per step,
+    decoder teacher-forced over 7 words from a zero state and, separately, one word from a carried (non-zero) state."""
+    torch.manual_seed(31)
+    g = torch.Generator().manual_seed(3131)
+    B, Lp, V, IMG, ANG, H, E, VOC, Lw = 3, 5, 36, 24, 8, 32, 16, 40, 7
+    F = IMG + ANG
+    for bidir in (True, False):
+        enc = U.SpeakerEncoder(F, H, 0.5, bidir, ANG, 0.3).eval()
+        act = feats(g, B, Lp, IMG, ANG)
+        feat = torch.stack([feats(g, B, V, IMG, ANG) for _ in range(Lp)], 1)          # [B, Lp, 36, F]
+        r = torch.randn(B, Lp, H, generator=g)
+        ctx = enc(act.clone(), feat.clone(), None)
+        loss = (ctx * r).sum()
+        save(f"speaker_encoder_{'bi' if bidir else 'uni'}", cfg=dict(F=F, H=H, ANG=ANG, bidir=int(bidir)),
+             param=dict(enc.state_dict()), inp=dict(act=act, feat=feat, r=r), out=dict(ctx=ctx), grad=grads_of(enc, loss)[0])
+    dec = U.SpeakerDecoder(VOC, E, 0, H, 0.5).eval()
+    words = torch.randint(1, VOC, (B, Lw), generator=g)
+    words[1, 5:] = 0
+    ctx = torch.randn(B, Lp, H, generator=g).requires_grad_(True)
+    mask = torch.zeros(B, Lp, dtype=torch.bool)
+    mask[2, 3:] = True
+    h0 = torch.zeros(1, B, H); c0 = torch.zeros(1, B, H)
+    logit, h1, c1 = dec(words, ctx, mask, h0, c0)
+    r = torch.randn(B, Lw, VOC, generator=g)
+    loss = (logit * r).sum() + (h1 * 0.3).sum() + (c1 * 0.2).sum()
+    gr, (gctx,) = grads_of(dec, loss, extra=[ctx])
+    gr = dict(gr, ctx=gctx)
+    hs = torch.randn(1, B, H, generator=g) * 0.5; cs = torch.randn(1, B, H, generator=g) * 0.5
+    with torch.no_grad():
+        l2, h2, c2 = dec(words[:, :1], ctx, mask, hs, cs)                              # word-by-word inference step
+    save("speaker_decoder", cfg=dict(VOC=VOC, E=E, H=H), param=dict(dec.state_dict()),
+         inp=dict(words=words, ctx=ctx.detach(), mask=mask, r=r, hs=hs, cs=cs),
+         out=dict(logit=logit, h1=h1, c1=c1, step_logit=l2, step_h=h2, step_c=c2), grad=gr)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -512,6 +548,7 @@ def main():
     gen_monitor(P, g, False, "monitor_step_eval")
     gen_critic(P, g)
     gen_losses(g)
+    gen_speaker(U)
     gen_angle_tables()
     gen_agent_tapes()
     gen_agent_tapes_more()

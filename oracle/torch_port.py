@@ -432,3 +432,63 @@ def monitor_mixed_loss(logits: Tensor, target: Tensor, cand_mask: Tensor, progre
     if t == 0:
         return ce
     return lam * torch.mean((progress - progress_target) ** 2) + (1 - lam) * ce
+
+
+# ---------------------------------------------------------------------------
+# N3  Speaker modules (units.py:286-395): SpeakerEncoder / SpeakerDecoder
+# ---------------------------------------------------------------------------
+def _plain_lstm(P: Params, prefix: str, x: Tensor, bidirectional: bool, h0: Optional[Tensor] = None,
+                c0: Optional[Tensor] = None):
+    """nn.LSTM(batch_first=True, 1 layer) on an UNPACKED batch (every row runs all L steps, units.py:325,338,366)."""
+    B, L, _ = x.shape
+    outs, hs, cs = [], [], []
+    for d in range(2 if bidirectional else 1):
+        sfx = "_l0" + ("_reverse" if d == 1 else "")
+        w_ih, w_hh = P[prefix + "weight_ih" + sfx], P[prefix + "weight_hh" + sfx]
+        b_ih, b_hh = P[prefix + "bias_ih" + sfx], P[prefix + "bias_hh" + sfx]
+        H = w_hh.shape[1]
+        h = x.new_zeros(B, H) if h0 is None else h0[d]
+        c = x.new_zeros(B, H) if c0 is None else c0[d]
+        o = [None] * L
+        for t in (range(L - 1, -1, -1) if d == 1 else range(L)):
+            h, c = lstm_cell(x[:, t], h, c, w_ih, w_hh, b_ih, b_hh)
+            o[t] = h
+        outs.append(torch.stack(o, 1)); hs.append(h); cs.append(c)
+    return torch.cat(outs, 2), torch.stack(hs, 0), torch.stack(cs, 0)
+
+
+def speaker_encoder(P: Params, action_embeds: Tensor, feature: Tensor, bidirectional: bool, *,
+                    drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """SpeakerEncoder.forward (units.py:313-341); `action_embeds` / `feature` are the tensors AFTER the feature dropout.
+    Dropout sites: 'ctx' (:326), 'att' (:336), 'out' (:339)."""
+    drop = drop or {}
+    B, Lp, _ = action_embeds.shape
+    ctx, _, _ = _plain_lstm(P, "lstm.", action_embeds, bidirectional)
+    ctx = _mul(ctx, drop.get("ctx"))
+    H = ctx.shape[-1]
+    x, _ = softdot_attention(ctx.reshape(B * Lp, H), feature.reshape(B * Lp, feature.shape[2], feature.shape[3]), None,
+                             P["attention_layer.linear_in.weight"], P["attention_layer.linear_out.weight"])
+    x = _mul(x.reshape(B, Lp, -1), drop.get("att"))
+    x, _, _ = _plain_lstm(P, "post_lstm.", x, bidirectional)
+    return _mul(x, drop.get("out"))
+
+
+def speaker_decoder(P: Params, words: Tensor, ctx: Tensor, ctx_mask: Optional[Tensor], h0: Tensor, c0: Tensor, *,
+                    drop: Optional[Dict[str, Tensor]] = None, padding_idx: int = 0):
+    """SpeakerDecoder.forward (units.py:363-395).  Dropout sites: 'emb' (:365), 'lstm' (:368), 'att' (:392)."""
+    drop = drop or {}
+    Bw, Lw = words.shape
+    emb = torch.nn.functional.embedding(words, P["embedding.weight"], padding_idx)   # the pad row gets no gradient (:352)
+    emb = _mul(emb, drop.get("emb"))
+    x, h1, c1 = _plain_lstm(P, "lstm.", emb, False, h0, c0)
+    x = _mul(x, drop.get("lstm"))
+    H = x.shape[-1]
+    n = Bw * Lw
+    mult = n // ctx.shape[0]
+    ctx_e = ctx.unsqueeze(1).expand(-1, mult, -1, -1).reshape(n, ctx.shape[1], H)
+    mask_e = ctx_mask.unsqueeze(1).expand(-1, mult, -1).reshape(n, -1) if ctx_mask is not None else None
+    x, _ = softdot_attention(x.reshape(n, H), ctx_e, mask_e, P["attention_layer.linear_in.weight"],
+                             P["attention_layer.linear_out.weight"])
+    x = _mul(x.reshape(Bw, Lw, H), drop.get("att"))
+    logit = x @ P["projection.weight"].t() + P["projection.bias"]
+    return logit, h1, c1

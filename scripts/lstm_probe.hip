@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    int r = vln_lstm_seq_fwd(d_x, d_w, wtype, d_len, d_hp, d_cp, d_y, d_act, d_tc, d_hc, d_cc, B, L, Hd, dirs, d_sync, sync_bytes, nullptr);
+    int r = vln_lstm_seq_fwd(d_x, d_w, wtype, d_len, d_hp, d_cp, d_y, d_act, d_tc, d_hc, d_cc, B, L, Hd, dirs, nullptr, nullptr, d_sync, sync_bytes, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (r) { printf("fwd failed: %s\n", vln_last_error_string()); return 1; }

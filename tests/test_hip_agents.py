@@ -121,3 +121,56 @@ def test_monitor_golden(vln, name):
                   "proj_navigable_mlp.mlp.2.running_mean", "proj_navigable_mlp.mlp.2.running_var"):
             check(sd[k], G["param_after"][k], 1e-4, k)
         assert int(sd["proj_navigable_mlp.mlp.0.num_batches_tracked"]) == 2
+
+
+# ---- speaker modules (units.py:286-395) ------------------------------------------------------------------
+def _holder_name(n):
+    """reference parameter name -> attribute path here (the nn.LSTM parameter holder sits one level down)"""
+    for pre in ("post_lstm.", "lstm."):
+        if n.startswith(pre):
+            return pre + "rnn." + n[len(pre):]
+    return n
+
+
+@pytest.mark.parametrize("kind", ["bi", "uni"])
+def test_speaker_encoder_golden(vln, kind):
+    G = load_golden("speaker_encoder_" + kind)
+    cfg, I = G["cfg"], dev(G["inp"])
+    enc = vln.SpeakerEncoder(int(cfg["F"]), int(cfg["H"]), 0.5, bool(int(cfg["bidir"])), int(cfg["ANG"]), 0.3)
+    enc.load_state_dict(G["param"], strict=True)                       # the reference's key names
+    enc.to(DEV).eval()
+    ctx = enc(I["act"].clone(), I["feat"].clone(), None)
+    check(ctx, G["out"]["ctx"], 1e-4, "ctx")
+    (ctx * I["r"]).sum().backward()
+    names = dict(enc.named_parameters())
+    for n, g in G["grad"].items():
+        check(names[_holder_name(n)].grad, g, 3e-4, n)
+
+
+def test_speaker_decoder_golden(vln):
+    G = load_golden("speaker_decoder")
+    cfg, I = G["cfg"], dev(G["inp"])
+    dec = vln.SpeakerDecoder(int(cfg["VOC"]), int(cfg["E"]), 0, int(cfg["H"]), 0.5)
+    dec.load_state_dict(G["param"], strict=True)
+    dec.to(DEV).eval()
+    ctx = I["ctx"].clone().requires_grad_(True)
+    B, H = ctx.shape[0], ctx.shape[2]
+    z = torch.zeros(1, B, H, device=DEV)
+    logit, h1, c1 = dec(I["words"], ctx, I["mask"], z, z)
+    for a, k in ((logit, "logit"), (h1, "h1"), (c1, "c1")):
+        check(a, G["out"][k], 1e-4, k)
+    ((logit * I["r"]).sum() + (h1 * 0.3).sum() + (c1 * 0.2).sum()).backward()
+    names = dict(dec.named_parameters())
+    for n, g in G["grad"].items():
+        if n == "ctx":
+            check(ctx.grad, g, 3e-4, "dctx")
+            continue
+        p = names[_holder_name(n)]
+        if p.grad is None:                                             # baseline_projection is unused by forward
+            assert float(g.abs().max()) == 0.0, n
+        else:
+            check(p.grad, g, 3e-4, n)
+    with torch.no_grad():                                              # one word from a carried (non-zero) state
+        l2, h2, c2 = dec(I["words"][:, :1], ctx, I["mask"], I["hs"], I["cs"])
+    for a, k in ((l2, "step_logit"), (h2, "step_h"), (c2, "step_c")):
+        check(a, G["out"][k], 1e-4, k)

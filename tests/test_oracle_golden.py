@@ -172,3 +172,31 @@ def test_angle_features_and_masks():
 def test_length2mask():
     m = O.length2mask([3, 1, 2])
     assert m.tolist() == [[False, False, False], [False, True, True], [False, False, True]]
+
+
+@pytest.mark.parametrize("kind", ["bi", "uni"])
+def test_speaker_encoder(kind):
+    G = load_golden("speaker_encoder_" + kind)
+    I = G["inp"]
+    P = leafify(G["param"])
+    ctx = O.speaker_encoder(P, I["act"], I["feat"], bool(int(G["cfg"]["bidir"])))
+    close(ctx, G["out"]["ctx"], what="ctx")
+    check_grads((ctx * I["r"]).sum(), P, G["grad"])
+
+
+def test_speaker_decoder():
+    G = load_golden("speaker_decoder")
+    I = G["inp"]
+    P = leafify(G["param"])
+    ctx = I["ctx"].clone().requires_grad_(True)
+    B, H = ctx.shape[0], ctx.shape[2]
+    z = torch.zeros(1, B, H)
+    logit, h1, c1 = O.speaker_decoder(P, I["words"], ctx, I["mask"], z, z)
+    for a, k in ((logit, "logit"), (h1, "h1"), (c1, "c1")):
+        close(a, G["out"][k], what=k)
+    loss = (logit * I["r"]).sum() + (h1 * 0.3).sum() + (c1 * 0.2).sum()
+    check_grads(loss, P, G["grad"], extra={"ctx": ctx})
+    with torch.no_grad():                       # one word from a carried state (word-by-word inference)
+        l2, h2, c2 = O.speaker_decoder(P, I["words"][:, :1], ctx, I["mask"], I["hs"], I["cs"])
+    for a, k in ((l2, "step_logit"), (h2, "step_h"), (c2, "step_c")):
+        close(a, G["out"][k], what=k)
