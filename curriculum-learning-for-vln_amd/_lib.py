@@ -37,6 +37,11 @@ class EnvDropStep(C.Structure):
                    ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr)])
 
 
+class ShadowJob(C.Structure):
+    _fields_ = [("src", ptr), ("src2", ptr), ("dst", ptr), ("dst_t", ptr), ("ld_src", i64), ("ld_dst", i64), ("ld_dst_t", i64),
+                ("N", i32), ("K", i32), ("out_type", i32), ("pad_", i32)]
+
+
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
                                    "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de")]
@@ -78,6 +83,7 @@ SIGNATURES = {
     "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),
+    "vln_shadow_refresh": (i32, [ptr, i32, ptr]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),

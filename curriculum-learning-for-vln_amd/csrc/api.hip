@@ -199,3 +199,8 @@ extern "C" int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int im
   if (!x) { set_error("vln_feat_dropout_inplace: null pointer"); return VLN_ERR_ARG; }
   return feat_dropout_inplace((hipStream_t)s, x, xtype, rows, img, angle, DropSpec{seed, offset, p}, copy_bf16);
 }
+
+extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {
+  if (!jobs || n_jobs <= 0) { set_error("vln_shadow_refresh: bad args"); return VLN_ERR_ARG; }
+  return shadow_refresh((hipStream_t)s, jobs, n_jobs);
+}

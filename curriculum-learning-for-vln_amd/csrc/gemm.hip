@@ -13,6 +13,7 @@
 // ds_read_b128).  fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32), bf16 uses v_mfma_f32_16x16x32_bf16 with
 // fp32 accumulate; lane group q = lane>>4 owns k = k0 + q*VK .. +VK so both operands read 32 B per lane.
 #include "vln_internal.h"
+#include "../../include/vln_hip.h"
 
 namespace vln {
 
@@ -624,6 +625,64 @@ int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type,
   else
     hipLaunchKernelGGL(cast_copy_kernel<float>, dim3(blocks), dim3(256), 0, st, W, ldw, (float*)out, ldo, rows, cols);
   VLN_CHECK_LAUNCH("cast_copy");
+  return VLN_OK;
+}
+
+// ---- all shadows of a module in ONE launch ------------------------------------------------------------------------
+// job = one fp32 matrix [N,K] (optionally the sum of two: b_ih + b_hh) -> its compute-dtype copy and/or its transposed
+// copy.  64x64 tiles; a workgroup finds its job from the prefix sums of the jobs' tile counts.
+struct ShadowJobs {
+  vln_shadow_job j[VLN_SHADOW_MAX_JOBS];
+  int tile0[VLN_SHADOW_MAX_JOBS + 1];
+  int n;
+};
+template <typename TO>
+__device__ __forceinline__ void shadow_tile(const vln_shadow_job& q, int tile, float (*lds)[65]) {
+  const int tk = (q.K + 63) / 64;
+  const int n0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, k = k0 + tx;
+    float v = 0.f;
+    if (n < q.N && k < q.K) {
+      v = q.src[(long)n * q.ld_src + k];
+      if (q.src2) v += q.src2[(long)n * q.ld_src + k];
+      if (q.dst) Elt<TO>::st(reinterpret_cast<TO*>(q.dst) + (long)n * q.ld_dst + k, v);
+    }
+    lds[r][tx] = v;
+  }
+  if (!q.dst_t) return;
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int k = k0 + r, n = n0 + tx;
+    if (k < q.K && n < q.N) Elt<TO>::st(reinterpret_cast<TO*>(q.dst_t) + (long)k * q.ld_dst_t + n, lds[tx][r]);
+  }
+}
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(ShadowJobs a) {
+  __shared__ float lds[64][65];
+  int ji = 0;
+  while (ji + 1 < a.n && (int)blockIdx.x >= a.tile0[ji + 1]) ++ji;
+  const vln_shadow_job& q = a.j[ji];
+  const int tile = (int)blockIdx.x - a.tile0[ji];
+  if (q.out_type == W_BF16) shadow_tile<bf16_raw>(q, tile, lds);
+  else shadow_tile<float>(q, tile, lds);
+}
+int shadow_refresh(hipStream_t st, const vln_shadow_job* jobs, int n) {
+  for (int base = 0; base < n; base += VLN_SHADOW_MAX_JOBS) {
+    ShadowJobs a;
+    a.n = (n - base < VLN_SHADOW_MAX_JOBS) ? n - base : VLN_SHADOW_MAX_JOBS;
+    int t = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const vln_shadow_job& q = jobs[base + i];
+      if (!q.src || q.N <= 0 || q.K <= 0 || (!q.dst && !q.dst_t)) { set_error("shadow_refresh: bad job %d", base + i); return VLN_ERR_ARG; }
+      a.j[i] = q;
+      a.tile0[i] = t;
+      t += ((q.N + 63) / 64) * ((q.K + 63) / 64);
+    }
+    a.tile0[a.n] = t;
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3(t), dim3(256), 0, st, a);
+  }
+  VLN_CHECK_LAUNCH("shadow_refresh");
   return VLN_OK;
 }
 

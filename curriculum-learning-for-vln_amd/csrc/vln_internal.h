@@ -5,6 +5,8 @@
 
 #include "common.h"
 
+struct vln_shadow_job;   // include/vln_hip.h
+
 namespace vln {
 
 enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
@@ -84,6 +86,7 @@ int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_st
 // Wt[K,N] = W[N,K]^T (fp32 or bf16 out);  Wc = cast(W)
 int transpose_cast(hipStream_t st, const float* W, long ldw, void* Wt, int out_type, long ldt, int N, int K);
 int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type, long ldo, int rows, int cols);
+int shadow_refresh(hipStream_t st, const ::vln_shadow_job* jobs, int n);   // all shadows of a module in one launch
 
 // ---- attention.hip --------------------------------------------------------
 // dots[b,s] = ctx[b,s,:] . vec[b,:]   (ctx streamed: fp32 or bf16)

@@ -203,22 +203,35 @@ class EncoderLSTM(nn.Module):
         return 0 if w is None else int(w[32].item())
 
     def _refresh_shadows(self):
+        """Per layer: w_ih [dirs*4Hd, I] (+ transpose), bsum = b_ih + b_hh [dirs*4Hd], w_hh [dirs][4Hd,Hd] (+ per-direction
+        transposes), and enc2dec -- all written by ONE launch (ops.ShadowBatch), straight into their stacked layouts."""
         dt = self.compute_dtype
         t = self._shadow.t
-        t.clear()
+        dev = self.enc2dec.weight.device
+        Hd, dirs = self.hidden_size, self.num_directions
+        sb = ops.ShadowBatch()
+
+        def buf(name, shape, dtype=dt):
+            x = t.get(name)
+            if x is None or x.dtype != dtype or x.device != dev or x.shape != shape:
+                x = t[name] = torch.empty(shape, dtype=dtype, device=dev)
+            return x
+
         for k in range(self.num_layers):
-            sfxs = [f"_l{k}"] + ([f"_l{k}_reverse"] if self.num_directions == 2 else [])
-            w_ih = torch.cat([getattr(self.lstm, "weight_ih" + s).detach() for s in sfxs], 0).contiguous()
-            t[f"w_ih{k}"] = w_ih if dt == torch.float32 else ops.cast_copy(w_ih, dt)
-            t[f"w_ih_t{k}"] = ops.transpose_cast(w_ih, dt)
-            t[f"bsum{k}"] = torch.cat([(getattr(self.lstm, "bias_ih" + s) + getattr(self.lstm, "bias_hh" + s)).detach()
-                                       for s in sfxs], 0).contiguous()
-            w_hh = torch.stack([getattr(self.lstm, "weight_hh" + s).detach() for s in sfxs], 0).contiguous()
-            t[f"w_hh{k}"] = w_hh if dt == torch.float32 else ops.cast_copy(w_hh, dt)
-            t[f"w_hh_t{k}"] = torch.stack([ops.transpose_cast(w_hh[d], dt) for d in range(w_hh.shape[0])], 0).contiguous()
+            sfxs = [f"_l{k}"] + ([f"_l{k}_reverse"] if dirs == 2 else [])
+            I = getattr(self.lstm, "weight_ih" + sfxs[0]).shape[1]
+            w_ih, w_ih_t = buf(f"w_ih{k}", (dirs * 4 * Hd, I)), buf(f"w_ih_t{k}", (I, dirs * 4 * Hd))
+            w_hh, w_hh_t = buf(f"w_hh{k}", (dirs, 4 * Hd, Hd)), buf(f"w_hh_t{k}", (dirs, Hd, 4 * Hd))
+            bsum = buf(f"bsum{k}", (dirs * 4 * Hd,), torch.float32)
+            for d, s in enumerate(sfxs):
+                r0, r1 = d * 4 * Hd, (d + 1) * 4 * Hd
+                sb.add(getattr(self.lstm, "weight_ih" + s).detach(), w_ih[r0:r1], w_ih_t[:, r0:r1])
+                sb.add(getattr(self.lstm, "weight_hh" + s).detach(), w_hh[d], w_hh_t[d])
+                sb.add(getattr(self.lstm, "bias_ih" + s).detach().view(1, -1), bsum[r0:r1].view(1, -1), None,
+                       src2=getattr(self.lstm, "bias_hh" + s).detach().view(1, -1))
         w = self.enc2dec.weight.detach()
-        t["w_e2d"] = w if dt == torch.float32 else ops.cast_copy(w, dt)
-        t["w_e2d_t"] = ops.transpose_cast(w, dt)
+        sb.add(w, buf("w_e2d", tuple(w.shape)), buf("w_e2d_t", (w.shape[1], w.shape[0])))
+        sb.run()
 
     def forward(self, inputs: torch.Tensor, lengths, already_sorted: bool = True):
         """inputs [B, max_len] int64 on the GPU, lengths [B] (CPU or GPU, any int type).  Rows are processed

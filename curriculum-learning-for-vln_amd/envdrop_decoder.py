@@ -164,25 +164,32 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         XK = AE + F + H
         dev = self.lstm.weight_ih.device
 
+        sb = ops.ShadowBatch()          # every cast / transpose below goes out as ONE launch
+
+        def buf(name, shape):
+            x = t.get(name)
+            if x is None or x.dtype != dt or x.device != dev or x.shape != shape:
+                x = t[name] = torch.empty(shape, dtype=dt, device=dev)
+            return x
+
         def both(name, w):
             wf = w.detach()
-            t[name] = wf if dt == torch.float32 else ops.cast_copy(wf, dt, t.get(name))
-            t[name + "_t"] = ops.transpose_cast(wf, dt, t.get(name + "_t"))
+            N, K = wf.shape
+            if dt == torch.float32:
+                t[name] = wf
+                sb.add(wf, None, buf(name + "_t", (K, N)))
+            else:
+                sb.add(wf, buf(name, (N, K)), buf(name + "_t", (K, N)))
 
         both("w_vin", self.visual_attn.linear_in.weight)
         both("w_tin", self.text_attn.linear_in.weight)
         both("w_tout", self.text_attn.linear_out.weight)
         both("w_c", self.cand_attn.weight)
         # fused LSTM weight [W_ih | W_hh] and its transpose
-        wc = t.get("w_cat")
-        if wc is None or wc.dtype != dt or wc.device != dev:
-            wc = torch.empty(4 * H, XK, dtype=dt, device=dev)
-            t["w_cat_t"] = torch.empty(XK, 4 * H, dtype=dt, device=dev)
-        ops.cast_copy(self.lstm.weight_ih.detach(), dt, wc[:, :AE + F])
-        ops.cast_copy(self.lstm.weight_hh.detach(), dt, wc[:, AE + F:])
-        ops.transpose_cast(self.lstm.weight_ih.detach(), dt, t["w_cat_t"][:AE + F])
-        ops.transpose_cast(self.lstm.weight_hh.detach(), dt, t["w_cat_t"][AE + F:])
-        t["w_cat"] = wc
+        wc, wct = buf("w_cat", (4 * H, XK)), buf("w_cat_t", (XK, 4 * H))
+        sb.add(self.lstm.weight_ih.detach(), wc[:, :AE + F], wct[:AE + F])
+        sb.add(self.lstm.weight_hh.detach(), wc[:, AE + F:], wct[AE + F:])
+        sb.run()
         w = self._wstruct
         w.act_w, w.act_b = self.act_embed[0].weight.data_ptr(), self.act_embed[0].bias.data_ptr()
         w.b_ih, w.b_hh = self.lstm.bias_ih.data_ptr(), self.lstm.bias_hh.data_ptr()

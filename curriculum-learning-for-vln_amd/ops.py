@@ -200,6 +200,31 @@ def cast_copy(w, dtype=torch.bfloat16, out=None):
     return out
 
 
+class ShadowBatch:
+    """Collects (matrix -> compute-dtype copy / transposed copy) jobs and issues them as ONE launch
+    (`vln_shadow_refresh`): a module's weight shadows are refreshed once per optimizer step."""
+
+    def __init__(self):
+        self.jobs = []
+        self.keep = []
+
+    def add(self, src, dst=None, dst_t=None, src2=None):
+        """src [N,K] fp32 (row stride free); dst [N,K] / dst_t [K,N] preallocated (fp32 or bf16, same dtype)."""
+        N, K = src.shape
+        ref = dst if dst is not None else dst_t
+        j = _lib.ShadowJob(src.data_ptr(), _p(src2), _p(dst), _p(dst_t), src.stride(0), 0 if dst is None else dst.stride(0),
+                           0 if dst_t is None else dst_t.stride(0), N, K, _dt(ref), 0)
+        self.jobs.append(j)
+        self.keep += [src, src2, dst, dst_t]
+
+    def run(self):
+        if not self.jobs:
+            return
+        arr = (_lib.ShadowJob * len(self.jobs))(*self.jobs)
+        _lib.check(_lib.load().vln_shadow_refresh(arr, len(self.jobs), _stream()), "vln_shadow_refresh")
+        self.jobs, self.keep = [], []
+
+
 def attn_dot(ctx, vec):
     """dots[b,s] = ctx[b,s,:] . vec[b,:]"""
     lib = _lib.load()

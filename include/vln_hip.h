@@ -61,6 +61,16 @@ int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int 
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */
 int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K, vln_stream_t s);
 int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols, vln_stream_t s);
+/* All weight shadows of a module in ONE launch (they are refreshed once per optimizer step): job = fp32 matrix src
+ * [N,K] (+ src2, same layout, nullable: the two LSTM biases are summed) -> dst [N,K] (nullable) and/or dst_t [K,N]
+ * (nullable) in out_type (VLN_F32 / VLN_BF16); ld_* in elements. */
+#define VLN_SHADOW_MAX_JOBS 24
+typedef struct vln_shadow_job {
+  const float* src; const float* src2; void* dst; void* dst_t;
+  int64_t ld_src, ld_dst, ld_dst_t;
+  int N, K, out_type, pad_;
+} vln_shadow_job;
+int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
 
 /* SoftDotAttention / VisualSoftDotAttention pieces (units.py:100-122, 138-160):
  *   dots[b,s] = ctx[b,s,:] . vec[b,:]                          torch.bmm(context, target)
