@@ -132,12 +132,11 @@ class GpuAgent:
             return s["img"].clone(), s["cand"].clone(), {}
         lp = self.dtype != torch.float32
         pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-        r1 = store.gather_pano(s["rows"], s["vidx"], pf, want_bf16=lp)
-        r2 = store.gather_cands(s["crow"], s["cview"], s["chead"], s["celev"], pf, want_bf16=lp)
+        # bf16 decoder: only the bf16 rows exist (nothing on this path reads fp32 features)
+        r1 = store.gather_pano(s["rows"], s["vidx"], pf, want_bf16=lp, want_f32=not lp)
+        r2 = store.gather_cands(s["crow"], s["cview"], s["chead"], s["celev"], pf, want_bf16=lp, want_f32=not lp)
         kw = dict(already_dropfeat=True)
-        if lp:
-            kw.update(img_lp=r1[1], cand_lp=r2[1])
-        return r1[0], r2[0], kw
+        return (r1[1], r2[1], kw) if lp else (r1[0], r2[0], kw)
 
     def iteration(self, tape):
         self.vln.ops.set_arena(self.arena)

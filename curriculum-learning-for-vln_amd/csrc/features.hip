@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const
   const int F = IMG + ANG;
   const TT* src = table + ((long)rows[b] * V + v) * IMG;
   const float* ang = angle_table + ((long)view_index[b] * V + v) * ANG;
-  float* dst = out + (long)r * F;
+  float* dst = out ? out + (long)r * F : nullptr;
   bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
   for (int c = threadIdx.x * 4; c < F; c += 256 * 4) {
     float x[4];
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const
     } else {
       Elt<float>::ld4(ang + (c - IMG), x);
     }
-    Elt<float>::st4(dst + c, x);
+    if (dst) Elt<float>::st4(dst + c, x);
     if (dlp) Elt<bf16_raw>::st4(dlp + c, x);
   }
 }
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, cons
   const int r = blockIdx.x;             // output row = b*C + c
   const int F = IMG + ANG;
   const long row = rows[r];
-  float* dst = out + (long)r * F;
+  float* dst = out ? out + (long)r * F : nullptr;
   bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
   const bool empty = row < 0;           // STOP slot / padding: all-zero feature (base.py:152-153)
   float sh = 0.f, ch = 0.f, se = 0.f, ce = 0.f;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, cons
         }
       }
     }
-    Elt<float>::st4(dst + c, x);
+    if (dst) Elt<float>::st4(dst + c, x);
     if (dlp) Elt<bf16_raw>::st4(dlp + c, x);
   }
 }
@@ -82,7 +82,7 @@ using namespace vln;
 extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index,
                                const float* angle_table, float* out, void* out_bf16, int B, int V, int IMG, int ANG,
                                uint64_t seed, uint64_t offset, float p_feat, vln_stream_t s) {
-  if (!table || !rows || !view_index || !angle_table || !out || B <= 0 || V <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
+  if (!table || !rows || !view_index || !angle_table || (!out && !out_bf16) || B <= 0 || V <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
     set_error("vln_gather_pano: bad args (IMG and ANG must be multiples of 8)");
     return VLN_ERR_ARG;
   }
@@ -99,7 +99,7 @@ extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows
 extern "C" int vln_gather_cands(const void* table, int ttype, const int64_t* rows, const int32_t* views,
                                 const float* heading, const float* elevation, float* out, void* out_bf16, int BC,
                                 int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat, vln_stream_t s) {
-  if (!table || !rows || !views || !heading || !elevation || !out || BC <= 0 || V <= 0 || (IMG & 7) || (ANG & 7) || ANG <= 0 || IMG <= 0) {
+  if (!table || !rows || !views || !heading || !elevation || (!out && !out_bf16) || BC <= 0 || V <= 0 || (IMG & 7) || (ANG & 7) || ANG <= 0 || IMG <= 0) {
     set_error("vln_gather_cands: bad args (IMG and ANG must be multiples of 8)");
     return VLN_ERR_ARG;
   }

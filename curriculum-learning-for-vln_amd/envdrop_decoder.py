@@ -260,6 +260,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         `already_dropfeat=True`): the decoder then skips its own dropout/copy pass over the features."""
         if not img_feature.is_cuda:
             raise _lib.VlnError("EnvDropDecoder: tensors must be on the GPU; there is no CPU fallback")
+        if img_feature.dtype != torch.float32 or cand_feature.dtype != torch.float32:
+            # bf16 feature tensors (DeviceFeatureStore.gather_*(want_f32=False)): they ARE the stream copies
+            if not (already_dropfeat and img_feature.dtype == self.compute_dtype == cand_feature.dtype):
+                raise TypeError("EnvDropDecoder: non-fp32 features need compute_dtype of that type and already_dropfeat=True")
+            img_lp, cand_lp = img_feature, cand_feature
         B, V, F = img_feature.shape
         Cn = cand_feature.shape[1]
         L = ctx.shape[1]

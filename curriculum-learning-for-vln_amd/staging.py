@@ -87,12 +87,15 @@ class DeviceFeatureStore:
         self._calls += 1
         return self.seed, self._calls, float(p)
 
-    def gather_pano(self, rows: torch.Tensor, view_index: torch.Tensor, p_feat: float = 0.0, want_bf16: bool = False):
-        """rows int64 [B], view_index int32 [B] (device) -> img_feature [B, V, IMG+ANG] (+ bf16 copy)."""
+    def gather_pano(self, rows: torch.Tensor, view_index: torch.Tensor, p_feat: float = 0.0, want_bf16: bool = False,
+                    want_f32: bool = True):
+        """rows int64 [B], view_index int32 [B] (device) -> img_feature [B, V, IMG+ANG] (+ bf16 copy).
+        want_f32=False (with want_bf16): only the bf16 rows are written; a bf16 EnvDropDecoder accepts them as its
+        `img_feature` (it streams nothing else), which halves this pass's HBM writes."""
         lib = _lib.load()
         B = rows.shape[0]
         F = self.IMG + self.ANG
-        out = ops.empty(B, self.V, F, dtype=torch.float32, device=self.device)
+        out = ops.empty(B, self.V, F, dtype=torch.float32, device=self.device) if (want_f32 or not want_bf16) else None
         lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         seed, off, p = self._drop(p_feat)
         _lib.check(lib.vln_gather_pano(_p(self.table), ops._dt(self.table), _p(rows), _p(view_index), _p(self.angle_table),
@@ -101,12 +104,12 @@ class DeviceFeatureStore:
         return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
 
     def gather_cands(self, rows: torch.Tensor, views: torch.Tensor, heading: torch.Tensor, elevation: torch.Tensor,
-                     p_feat: float = 0.0, want_bf16: bool = False):
+                     p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True):
         """rows int64 [B,C] (-1 = STOP slot / padding), views int32 [B,C], heading/elevation fp32 [B,C]."""
         lib = _lib.load()
         B, C = rows.shape
         F = self.IMG + self.ANG
-        out = ops.empty(B, C, F, dtype=torch.float32, device=self.device)
+        out = ops.empty(B, C, F, dtype=torch.float32, device=self.device) if (want_f32 or not want_bf16) else None
         lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         seed, off, p = self._drop(p_feat)
         _lib.check(lib.vln_gather_cands(_p(self.table), ops._dt(self.table), _p(rows.contiguous()), _p(views.contiguous()),

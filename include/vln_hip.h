@@ -135,7 +135,8 @@ int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dl
  * vln_gather_cands: out[r,:]   = [ table[rows[r], views[r], :] | make_angle_feat(heading[r], elevation[r]) ], rows[r] < 0 ->
  *                   all-zero STOP/padding slot                                                       (BasicR2RAgent._candidate_variable)
  * Both apply the EnvDrop feature dropout on the image part when p_feat > 0 (policy.py:226-231; call the decoder with
- * already_dropfeat=True then) and optionally emit the bf16 copy of the row. */
+ * already_dropfeat=True then) and optionally emit the bf16 copy of the row; `out` (fp32) may be NULL when only the bf16
+ * copy is wanted (a bf16 decoder never reads the fp32 rows: that halves the pass's HBM writes). */
 int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index, const float* angle_table,
                     float* out, void* out_bf16, int B, int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat,
                     vln_stream_t s);

@@ -62,6 +62,34 @@ def test_store_feature_dropout_uses_the_philox_stream(vln):
     assert abs((m > 0).float().mean().item() - 0.7) < 0.01
 
 
+def test_bf16_only_gather_feeds_the_decoder_like_fp32_rows_plus_copy(vln):
+    """gather_*(want_f32=False): the bf16 rows alone, bit-identical to the bf16 copy of the full gather, and a bf16
+    EnvDropDecoder given them as `img_feature` / `cand_feature` computes exactly what it computes from fp32 rows + copies."""
+    g = torch.Generator().manual_seed(9)
+    table, rows, vidx, crow, cview, head, elev = _problem(g, IMG=256)
+    store = vln.DeviceFeatureStore(table, device=DEV, dtype=torch.bfloat16)
+    d = lambda t: t.to(DEV)
+    full = store.gather_pano(d(rows), d(vidx), 0.3, want_bf16=True)
+    store._calls -= 1                                               # same Philox stream position for the second pass
+    only = store.gather_pano(d(rows), d(vidx), 0.3, want_bf16=True, want_f32=False)
+    assert only[0] is None and torch.equal(full[1], only[1])
+    cfull = store.gather_cands(d(crow), d(cview), d(head), d(elev), 0.0, want_bf16=True)
+    conly = store.gather_cands(d(crow), d(cview), d(head), d(elev), 0.0, want_bf16=True, want_f32=False)
+    assert conly[0] is None and torch.equal(cfull[1], conly[1])
+    torch.manual_seed(3)
+    B, H, L = rows.shape[0], 64, 9
+    dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, 256 + 128, compute_dtype=torch.bfloat16).to(DEV).eval()
+    a = torch.randn(B, 128, device=DEV); h = torch.randn(B, H, device=DEV); c = torch.randn(B, H, device=DEV)
+    ctx = torch.randn(B, L, H, device=DEV)
+    with torch.no_grad():
+        o1 = dec(a, full[0].clone(), cfull[0].clone(), h, h, c, ctx, None, True, img_lp=full[1], cand_lp=cfull[1])
+        o2 = dec(a, only[1], conly[1], h, h, c, ctx, None, True)
+    for x, y in zip((o1[0], o1[1][0], o1[1][1], o1[2]), (o2[0], o2[1][0], o2[1][1], o2[2])):
+        assert torch.equal(x, y)
+    with pytest.raises(TypeError):
+        dec(a, only[1], conly[1], h, h, c, ctx, None, False)        # bf16 rows that were not produced by the store pass
+
+
 def test_fused_masked_ce_and_action_stats_golden(vln):
     """Row A9: the fused CE / Categorical kernel against the golden captured from torch's own ops (what the
     reference agents call inline)."""
