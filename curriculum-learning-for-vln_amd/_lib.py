@@ -44,7 +44,7 @@ class ShadowJob(C.Structure):
 
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
-                                   "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de")]
+                                   "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat")]
 
 
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
@@ -65,6 +65,9 @@ SIGNATURES = {
     "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
+    "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr]),
+    "vln_attn_bwd_rows": (i32, [ptr, i32, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
+    "vln_attn_dctx_deferred": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr]),
     "vln_lstm_pointwise_fwd": (i32, [ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32, i32, i32, ptr]),
     "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_dropout_mask": (i32, [ptr, i64, u64, u64, f32, ptr]),

@@ -112,7 +112,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 1; }
+extern "C" int vln_abi_version(void) { return 2; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,
@@ -163,6 +163,23 @@ extern "C" int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const
   if (!ctx || !attn) { set_error("vln_attn_bwd: null pointer"); return VLN_ERR_ARG; }
   return attn_bwd((hipStream_t)s, ctx, ctype, attn, dalpha, dattn_ext, dwc, lddwc, vec, ldvec, dvec, lddvec, dctx,
                   dl_out, B, S, D);
+}
+extern "C" int vln_attn_fwd_rows(const void* ctx, int ctype, const float* vec, int64_t ldv, const uint8_t* mask, float* attn,
+                                 float* out, int64_t ldo, float* dots_scratch, int B, int S, int D, vln_stream_t s) {
+  if (!ctx || !vec || !out) { set_error("vln_attn_fwd_rows: null pointer"); return VLN_ERR_ARG; }
+  return attn_fwd_rows((hipStream_t)s, ctx, ctype, vec, ldv, mask, attn, out, ldo, dots_scratch, B, S, D);
+}
+extern "C" int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float* dwc, int64_t lddwc,
+                                 const float* dattn_ext, float* dvec, int64_t lddvec, float* dl_out, float* dots_scratch,
+                                 int B, int S, int D, vln_stream_t s) {
+  if (!ctx || !attn || !dwc || !dvec) { set_error("vln_attn_bwd_rows: null pointer"); return VLN_ERR_ARG; }
+  return attn_bwd_rows((hipStream_t)s, ctx, ctype, attn, dwc, lddwc, dattn_ext, dvec, lddvec, dl_out, dots_scratch, B, S, D);
+}
+extern "C" int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
+                                      const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,
+                                      int accumulate, vln_stream_t s) {
+  if (!alpha || !dl || !g || !q || !dctx) { set_error("vln_attn_dctx_deferred: null pointer"); return VLN_ERR_ARG; }
+  return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate);
 }
 extern "C" int vln_lstm_pointwise_fwd(const float* gates, int nsplit, int64_t slab_stride, const float* b_ih,
                                       const float* b_hh, const float* c0, float* h1, float* c1, float* act,

@@ -272,4 +272,58 @@ int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, cons
   return VLN_OK;
 }
 
+
+#include "attention_fused.h"
+
+// dots + softmax + weighted sum in one launch when a register-resident configuration fits, else the two-kernel path
+// (`dots_scratch` [B,S] is only touched by the fallback).
+int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, const uint8_t* mask, float* attn,
+                  float* out, long ldo, float* dots_scratch, int B, int S, int D) {
+  if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_fwd_rows: bad dims B=%d S=%d D=%d", B, S, D); return VLN_ERR_ARG; }
+  AttnFusedArgs a{ctx, vec, ldv, mask, attn, nullptr, nullptr, out, ldo, S, D};
+  if (attn_fused_try(st, ctype, a, B, false)) { VLN_CHECK_LAUNCH("attn_fused_fwd"); return VLN_OK; }
+  if (!dots_scratch) { set_error("attn_fwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
+  int r = attn_dot(st, ctx, ctype, vec, ldv, dots_scratch, B, S, D);
+  if (r != VLN_OK) return r;
+  return attn_softmax_wsum(st, ctx, ctype, dots_scratch, mask, attn, out, ldo, B, S, D);
+}
+
+// d alpha = ctx . dwc, softmax backward, d query = sum_s dl ctx; dl_out (nullable) feeds attn_dctx_deferred
+int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
+                  const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D) {
+  if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_bwd_rows: bad dims"); return VLN_ERR_ARG; }
+  AttnFusedArgs a{ctx, dwc, lddwc, nullptr, const_cast<float*>(attn), dattn_ext, dl_out, dvec, lddvec, S, D};
+  if (attn_fused_try(st, ctype, a, B, true)) { VLN_CHECK_LAUNCH("attn_fused_bwd"); return VLN_OK; }
+  if (!dots_scratch) { set_error("attn_bwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
+  int r = attn_dot(st, ctx, ctype, dwc, lddwc, dots_scratch, B, S, D);
+  if (r != VLN_OK) return r;
+  return attn_bwd(st, ctx, ctype, attn, dots_scratch, dattn_ext, nullptr, 0, nullptr, 0, dvec, lddvec, nullptr, dl_out, B, S, D);
+}
+
+int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
+                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate) {
+  if (T <= 0 || B <= 0 || S <= 0 || D <= 0 || (D & 3) || !aligned16(dctx)) {
+    set_error("attn_dctx_deferred: bad args (T=%d B=%d S=%d D=%d)", T, B, S, D);
+    return VLN_ERR_ARG;
+  }
+  int tmax = (int)((60 * 1024) / (2 * (D + 16) * sizeof(float)));
+  if (tmax > kDctxMaxSteps) tmax = kDctxMaxSteps;
+  if (tmax < 1) { set_error("attn_dctx_deferred: D=%d too wide", D); return VLN_ERR_ARG; }
+  for (int t0 = 0; t0 < T; t0 += tmax) {
+    DctxArgs a{};
+    a.T = (T - t0 < tmax) ? T - t0 : tmax;
+    a.vec_ok = ((ldg & 3) == 0 && (ldq & 3) == 0) ? 1 : 0;
+    for (int t = 0; t < a.T; ++t) {
+      a.alpha[t] = alpha[t0 + t]; a.dl[t] = dl[t0 + t]; a.g[t] = g[t0 + t]; a.q[t] = q[t0 + t];
+      if (!a.alpha[t] || !a.dl[t] || !a.g[t] || !a.q[t]) { set_error("attn_dctx_deferred: null step pointer"); return VLN_ERR_ARG; }
+      if (!aligned16(a.g[t]) || !aligned16(a.q[t])) a.vec_ok = 0;
+    }
+    a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0;
+    const unsigned lds = (unsigned)(2 * a.T * (D + 16) * sizeof(float));
+    hipLaunchKernelGGL(attn_dctx_deferred_kernel, dim3(B, (S + 15) / 16), dim3(256), lds, st, a);
+    VLN_CHECK_LAUNCH("attn_dctx_deferred");
+  }
+  return VLN_OK;
+}
+
 }  // namespace vln

@@ -177,8 +177,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
   // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
   RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, ws.tv, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_dot(st, img, d->ctype, ws.tv, F, ws.dots, B, d->V, F));
-  RUN(attn_softmax_wsum(st, img, d->ctype, ws.dots, nullptr, io->alpha_v, io->xcat + AE, XK, B, d->V, F));
+  RUN(attn_fwd_rows(st, img, d->ctype, ws.tv, F, nullptr, io->alpha_v, io->xcat + AE, XK, ws.dots, B, d->V, F));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
   int nsplit = 1;
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, &nsplit));
@@ -190,8 +189,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   RUN(lstm_pointwise_fwd(st, pw));
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, io->tt, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_dot(st, ctx, d->ctype, io->tt, H, ws.dots, B, d->L, H));
-  RUN(attn_softmax_wsum(st, ctx, d->ctype, ws.dots, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, B, d->L, H));
+  RUN(attn_fwd_rows(st, ctx, d->ctype, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, ws.dots, B, d->L, H));
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.slabs, ws.slab_floats));
   // (6) candidate logits                                        policy.py:243-244,199-206
@@ -223,21 +221,28 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
                      io->h_tilde, g->s_dz, (long)B * H, site(io, 3, io->p_drop));
   VLN_CHECK_LAUNCH("tanh_drop_bwd");
   // (5') linear_out -> [d weighted ctx | d drop(h1)]
-  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, ws.dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
-  RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, nullptr, B, d->L, H));
+  // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
+  // deferred: this step only leaves d logits (g->s_dl) and [d weighted ctx | .] (g->s_dtcat) behind and the caller
+  // forms dctx once per rollout with vln_attn_dctx_deferred.
+  float* dtcat = g->s_dtcat ? g->s_dtcat : ws.dtcat;
+  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  if (g->dctx) {
+    RUN(attn_dot(st, ctx, d->ctype, dtcat, 2 * H, ws.dots, B, d->L, H));
+    RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
+  } else {
+    RUN(attn_bwd_rows(st, ctx, d->ctype, io->alpha_t, dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
+  }
   RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, ws.dh1d, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   // (4') LSTM cell
   LstmPwBwd pb{};
-  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = ws.dtcat + H; pb.ld_b = 2 * H; pb.dh1_b2 = ws.dh1d; pb.ld_b2 = H;
+  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = dtcat + H; pb.ld_b = 2 * H; pb.dh1_b2 = ws.dh1d; pb.ld_b2 = H;
   pb.drop = site(io, 2, io->p_drop); pb.dc1 = g->dc1; pb.lddc1 = H;
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
   RUN(lstm_pointwise_bwd(st, pb));
   RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, ws.dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   // (3') visual attention: features carry no gradient, only the query does
-  RUN(attn_dot(st, img, d->ctype, ws.dxcat + AE, XK, ws.dots, B, d->V, F));
-  RUN(attn_bwd(st, img, d->ctype, io->alpha_v, ws.dots, nullptr, nullptr, 0, nullptr, 0, g->s_dtv, F, nullptr, nullptr, B, d->V, F));
+  RUN(attn_bwd_rows(st, img, d->ctype, io->alpha_v, ws.dxcat + AE, XK, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
   RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, ws.dhq, H, B, H, F, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   // (1') act embedding + the two uses of h_tilde_prev
   PrepBwdArgs pa{ws.dxcat, XK, io->e, ws.dhq, g->s_de, g->dh_tilde_prev, B, AE, F, H,

@@ -17,7 +17,8 @@ void set_error(const char* fmt, ...);
 const char* get_error();
 int check_hip(hipError_t e, const char* what);
 
-// run-time tunables (vln_set_tunable): [0] gemm_nt workgroups-in-flight target, [1] no-split rule for wide shallow GEMMs
+// run-time tunables (vln_set_tunable): [0] gemm_nt workgroups-in-flight target, [1] no-split rule for wide shallow GEMMs,
+// [2]/[3] 16-column GEMM on / its largest K, [4] = 1 forces the two-kernel attention path
 extern int g_tunable[8];
 
 // ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------
@@ -100,6 +101,15 @@ int attn_softmax_wsum(hipStream_t st, const void* ctx, int ctype, const float* l
 int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dalpha,
              const float* dattn_ext, const float* dwc, long lddwc, const float* vec, long ldvec, float* dvec,
              long lddvec, float* dctx, float* dl_out, int B, int S, int D);
+// One launch per attention row block (attention_fused.h) with the two-kernel path as the fallback for shapes that
+// do not fit the register-resident configurations; `dots_scratch` [B,S] is used by the fallback only.
+int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, const uint8_t* mask, float* attn,
+                  float* out, long ldo, float* dots_scratch, int B, int S, int D);
+int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
+                  const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
+// dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
+int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
+                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate);
 // dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);

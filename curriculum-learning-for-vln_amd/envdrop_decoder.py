@@ -78,10 +78,16 @@ class _EnvDropStepFn(torch.autograd.Function):
         dc0 = ops.empty(B, H, dtype=torch.float32, device=dev)
         g.dh_tilde_prev, g.dc0 = dhtp.data_ptr(), dc0.data_ptr()
         if ctx.needs_input_grad[4]:
-            e = rec.entry
-            if e.dctx is None:
-                e.dctx = ops.zeros(B, rec.L, H, dtype=torch.float32, device=dev)
-            g.dctx = e.dctx.data_ptr()
+            # context gradient deferred: this step leaves d(text logits) and d(weighted ctx) behind; CtxGate forms
+            # dctx once per rollout from all steps (one write of [B,L,H] instead of T read-modify-write sweeps)
+            L = rec.L
+            n_dl = (B * L + 3) & ~3                      # keeps the [B,2H] block 16-byte aligned
+            t = ops.empty(n_dl + B * 2 * H, dtype=torch.float32, device=dev)
+            q = t.data_ptr()
+            g.s_dl, g.s_dtcat = q, q + 4 * n_dl
+            io0 = rec.io
+            rec.entry.terms.append((io0.alpha_t, q, q + 4 * n_dl, io0.tt, t, rec.keep["flat"]))
+            rec.entry.shape = (B, L, H)
         s = rec.slot
         g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
         g.s_dgates, g.s_dtv, g.s_de = s.ptr("dgates"), s.ptr("dtv"), s.ptr("de")

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -262,6 +264,53 @@ def rows_wsum(ctx, w, out=None):
         out = empty(B, D, dtype=torch.float32, device=ctx.device)
     _lib.check(lib.vln_rows_wsum(_p(ctx), _dt(ctx), _p(w), _p(out), out.stride(0), B, S, D, _stream()),
                "vln_rows_wsum")
+    return out
+
+
+def attn_fwd_rows(ctx, vec, mask=None, out=None, want_attn=True):
+    """softmax(mask(ctx . vec)) and the weighted sum of the context rows in ONE launch (units.py:106-118)."""
+    lib = _lib.load()
+    _req(ctx, "ctx", None); _req(vec, "vec")
+    B, S, D = ctx.shape
+    assert ctx.is_contiguous()
+    attn = empty(B, S, dtype=torch.float32, device=ctx.device) if want_attn else None
+    if out is None:
+        out = empty(B, D, dtype=torch.float32, device=ctx.device)
+    m8 = None
+    if mask is not None:
+        m8 = mask.view(torch.uint8) if (mask.dtype == torch.bool and mask.is_contiguous()) else mask.to(torch.uint8).contiguous()
+    scratch = empty(B, S, dtype=torch.float32, device=ctx.device)
+    _lib.check(lib.vln_attn_fwd_rows(_p(ctx), _dt(ctx), _p(vec), vec.stride(0), _p(m8), _p(attn), _p(out), out.stride(0),
+                                     _p(scratch), B, S, D, _stream()), "vln_attn_fwd_rows")
+    return out, attn
+
+
+def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None):
+    """Backward of attn_fwd_rows w.r.t. the query: returns (dvec [B,D], dl [B,S] or None)."""
+    lib = _lib.load()
+    _req(ctx, "ctx", None); _req(attn, "attn"); _req(dwc, "dwc")
+    B, S, D = ctx.shape
+    assert ctx.is_contiguous() and attn.is_contiguous()
+    dvec = out if out is not None else empty(B, D, dtype=torch.float32, device=ctx.device)
+    dl = empty(B, S, dtype=torch.float32, device=ctx.device) if want_dl else None
+    if dattn_ext is not None:
+        dattn_ext = dattn_ext.contiguous()
+    scratch = empty(B, S, dtype=torch.float32, device=ctx.device)
+    _lib.check(lib.vln_attn_bwd_rows(_p(ctx), _dt(ctx), _p(attn), _p(dwc), dwc.stride(0), _p(dattn_ext), _p(dvec),
+                                     dvec.stride(0), _p(dl), _p(scratch), B, S, D, _stream()), "vln_attn_bwd_rows")
+    return dvec, dl
+
+
+def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accumulate=False):
+    """out[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]; the four lists hold T device addresses."""
+    lib = _lib.load()
+    T = len(alpha_ptrs)
+    B, S, D = out.shape
+    assert out.is_contiguous() and len(dl_ptrs) == T and len(g_ptrs) == T and len(q_ptrs) == T
+    arr = (C.c_void_p * (4 * T))(*alpha_ptrs, *dl_ptrs, *g_ptrs, *q_ptrs)
+    base = C.addressof(arr)
+    _lib.check(lib.vln_attn_dctx_deferred(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
+                                          1 if accumulate else 0, _stream()), "vln_attn_dctx_deferred")
     return out
 
 

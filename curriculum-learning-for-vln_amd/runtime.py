@@ -164,11 +164,14 @@ class WeightGate(torch.autograd.Function):
 class CtxEntry:
     """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
     low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
-    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "__weakref__")
+    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "__weakref__")
 
     def __init__(self, t):
         self.ref = weakref.ref(t)
         self.dctx = None
+        # deferred context gradient: per decoder step (alpha_t ptr, dl ptr, [dwc|.] ptr, query ptr, keep-alive tensors...)
+        self.terms = []
+        self.shape = None
         self.lp = None
         self.gated = None
         self.mask_src = self.mask8 = None     # the caller's ctx_mask and its uint8 form (converted once per rollout)
@@ -190,6 +193,14 @@ class CtxGate(torch.autograd.Function):
         d = None
         if e is not None:
             d, e.dctx, e.gated = e.dctx, None, None
+            if e.terms:
+                terms, e.terms = e.terms, []
+                B, L, H = e.shape
+                acc = d is not None
+                if d is None:
+                    d = ops.empty(B, L, H, dtype=torch.float32, device=terms[0][4].device)
+                ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
+                                       [t[3] for t in terms], H, d, accumulate=acc)
         if g is not None:
             d = g if d is None else d + g
         return None, d

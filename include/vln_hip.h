@@ -80,6 +80,21 @@ int vln_attn_dot(const void* ctx, int ctype, const float* vec, int64_t ldv, floa
 int vln_attn_softmax_wsum(const void* ctx, int ctype, const float* logits, const uint8_t* mask, float* attn,
                           float* out, int64_t ldo, int B, int S, int D, vln_stream_t s);
 int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* out, int64_t ldo, int B, int S, int D, vln_stream_t s);
+/* One launch per attention (dots -> softmax -> weighted sum with the [S,D] block of a batch row resident in the
+ * workgroup's registers); shapes that do not fit fall back to the two launches above and need dots_scratch [B,S].
+ * Forward = SoftDotAttention / VisualSoftDotAttention core (units.py:106-118,150-158); backward returns d(query) and
+ * optionally d(logits) (dl_out), the in-place dctx update being replaced by vln_attn_dctx_deferred. */
+int vln_attn_fwd_rows(const void* ctx, int ctype, const float* vec, int64_t ldv, const uint8_t* mask /*nullable*/,
+                      float* attn /*nullable*/, float* out, int64_t ldo, float* dots_scratch /*nullable*/, int B, int S, int D,
+                      vln_stream_t s);
+int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float* dwc, int64_t lddwc,
+                      const float* dattn_ext /*nullable*/, float* dvec, int64_t lddvec, float* dl_out /*nullable*/,
+                      float* dots_scratch /*nullable*/, int B, int S, int D, vln_stream_t s);
+/* dctx[b,s,:] (+)= sum_t alpha[t][b,s] * g[t][b,:] + dl[t][b,s] * q[t][b,:]  -- the context gradient of a whole rollout
+ * (T decoder steps) in one pass; alpha/dl/g/q are HOST arrays of T device pointers. */
+int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
+                           const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D, int accumulate,
+                           vln_stream_t s);
 int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha, const float* dattn_ext,
                  const float* dwc, int64_t lddwc, const float* vec, int64_t ldvec, float* dvec, int64_t lddvec,
                  float* dctx, float* dl_out, int B, int S, int D, vln_stream_t s);
@@ -260,6 +275,10 @@ typedef struct vln_envdrop_grads {
   float* s_dgates;       /* [B,4H] -> lstm.weight_ih / weight_hh / biases */
   float* s_dtv;          /* [B,F]  -> visual_attn.linear_in.weight */
   float* s_de;           /* [B,AE] -> act_embed.0.{weight,bias} */
+  /* deferred context gradient (ABI v2; both nullable).  With dctx == NULL the step leaves these behind instead of
+   * sweeping [B,L,H]; the caller forms dctx once per rollout: vln_attn_dctx_deferred(alpha_t, s_dl, s_dtcat, tt). */
+  float* s_dl;           /* [B,L]  d(text attention logits) of this step */
+  float* s_dtcat;        /* [B,2H] [d weighted ctx | d drop(h1)]: kept by the caller instead of the step scratch */
 } vln_envdrop_grads;
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);

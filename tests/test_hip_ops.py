@@ -107,6 +107,74 @@ def test_attention_fwd_bwd(vln, B, S, D, cdt):
     assert rel_err(vln.ops.rows_wsum(cd, w.to(dev())), torch.einsum("bs,bsd->bd", w.double(), ctx.double())) < tol
 
 
+@pytest.mark.parametrize("B,S,D", [(64, 36, 2176), (64, 80, 512), (64, 8, 2176), (16, 12, 1024), (5, 33, 520), (4, 9, 48),
+                                   (3, 5, 50), (2, 100, 512), (7, 1, 64)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_attention_rows_one_launch(vln, B, S, D, cdt):
+    """vln_attn_fwd_rows / vln_attn_bwd_rows (register-resident context block, one launch; shapes outside the
+    configurations fall back to two launches) and the once-per-rollout context gradient vln_attn_dctx_deferred."""
+    if cdt == torch.bfloat16 and D % 8:
+        pytest.skip("bf16 path wants D % 8 == 0 for the vector loads; scalar path covered by fp32")
+    g = torch.Generator().manual_seed(B * S + D + 1)
+    ctx = (torch.randn(B, S, D, generator=g) * 0.5).to(cdt)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        mask[b, max(1, S - (b % S)):] = True
+    T = 3
+    c64 = ctx.double().requires_grad_(True)
+    tol = 1e-4 if cdt == torch.float32 else 1e-2
+    cd = ctx.to(dev())
+    terms, keep, total = [], [], 0.0
+    big = torch.zeros(B, 2 * D + 8, device=dev())           # strided query / gradient rows
+    for t in range(T):
+        vec = torch.randn(B, D, generator=g) / D ** 0.5
+        v64 = vec.double().requires_grad_(True)
+        logits = torch.einsum("bsd,bd->bs", c64, v64)
+        attn = torch.softmax(logits.masked_fill(mask, -float("inf")), 1)
+        wc = torch.einsum("bs,bsd->bd", attn, c64)
+        r = torch.randn(B, D, generator=g).double(); ra = torch.randn(B, S, generator=g).double()
+        loss = (wc * r).sum() + (attn * ra).sum()
+        gv, = torch.autograd.grad(loss, v64, retain_graph=True)
+        total = total + loss
+        vd = big[:, 4:4 + D]; vd.copy_(vec.to(dev()))
+        out, at = vln.ops.attn_fwd_rows(cd, vd, mask.to(dev()))
+        assert rel_err(at, attn.detach()) < tol and rel_err(out, wc.detach()) < tol
+        assert (at * mask.to(dev())).abs().max().item() == 0.0
+        dwc = torch.zeros(B, 2 * D, device=dev())[:, :D]; dwc.copy_(r.float().to(dev()))
+        dvec, dl = vln.ops.attn_bwd_rows(cd, at, dwc, ra.float().to(dev()), want_dl=True)
+        assert rel_err(dvec, gv) < tol * 5
+        # same numbers from the two-launch kernels
+        dalpha = vln.ops.attn_dot(cd, dwc)
+        dvec2, dl2 = vln.ops.attn_bwd(cd, at, dalpha, ra.float().to(dev()), want_dl=True)
+        assert rel_err(dvec, dvec2) < 1e-5 and rel_err(dl, dl2) < 1e-5
+        q = vd.clone()
+        keep += [at, dl, dwc, q]
+        terms.append((at.data_ptr(), dl.data_ptr(), dwc.data_ptr(), q.data_ptr()))
+    if D % 4:
+        return                                              # the deferred kernel needs 16-byte rows
+    total.backward()
+    dctx = torch.empty(B, S, D, device=dev())
+    vln.ops.attn_dctx_deferred([x[0] for x in terms], [x[1] for x in terms], [x[2] for x in terms], 2 * D,
+                               [x[3] for x in terms], D, dctx)
+    assert rel_err(dctx, c64.grad) < tol * 5
+    vln.ops.attn_dctx_deferred([x[0] for x in terms], [x[1] for x in terms], [x[2] for x in terms], 2 * D,
+                               [x[3] for x in terms], D, dctx, accumulate=True)
+    assert rel_err(dctx, 2 * c64.grad) < tol * 5
+
+
+def test_attention_dctx_deferred_many_steps(vln):
+    """More steps than one launch stages in LDS (chunks of <= 14 at D = 512): RL rollouts run up to 35 steps."""
+    B, S, D, T = 8, 20, 512, 35
+    g = torch.Generator().manual_seed(9)
+    al = torch.rand(T, B, S, generator=g).to(dev()); dl = torch.randn(T, B, S, generator=g).to(dev())
+    gw = torch.randn(T, B, 2 * D, generator=g).to(dev()); q = torch.randn(T, B, D, generator=g).to(dev())
+    ref = torch.einsum("tbs,tbd->bsd", al.double(), gw[:, :, :D].double()) + torch.einsum("tbs,tbd->bsd", dl.double(), q.double())
+    out = torch.empty(B, S, D, device=dev())
+    vln.ops.attn_dctx_deferred([al[t].data_ptr() for t in range(T)], [dl[t].data_ptr() for t in range(T)],
+                               [gw[t].data_ptr() for t in range(T)], 2 * D, [q[t].data_ptr() for t in range(T)], D, out)
+    assert rel_err(out, ref) < 1e-5
+
+
 def test_lstm_pointwise(vln):
     B, H = 64, 512
     g = torch.Generator().manual_seed(3)
