@@ -197,7 +197,7 @@ extern "C" int vln_lstm_pointwise_bwd(const float* dh1, const float* dh1_drop, c
                                       const float* c0, float* dgates, float* dc0, int B, int H, vln_stream_t s) {
   if (!act || !tanh_c1 || !c0 || !dgates || !dc0 || B <= 0 || H <= 0) { set_error("vln_lstm_pointwise_bwd: bad args"); return VLN_ERR_ARG; }
   LstmPwBwd a{};
-  a.dh1_a = dh1; a.ld_a = H; a.dh1_b = dh1_drop; a.ld_b = H; a.dh1_b2 = nullptr; a.ld_b2 = 0;
+  a.dh1_a = dh1; a.ld_a = H; a.dh1_b = plain_vec(dh1_drop, H); a.dh1_b2 = plain_vec(nullptr, 0);
   a.drop = DropSpec{seed, offset, p}; a.dc1 = dc1; a.lddc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
   a.c0 = c0; a.ldc0 = H; a.dgates = dgates; a.lddg = 4 * H; a.dc0 = dc0; a.lddc0 = H; a.B = B; a.H = H;
   return lstm_pointwise_bwd((hipStream_t)s, a);

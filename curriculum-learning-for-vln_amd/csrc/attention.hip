@@ -14,14 +14,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // ---------------------------------------------------------------------------
 template <typename TC>
-__global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, const float* vec, long ldv, float* dots,
+__global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec vec, float* dots,
                                                        long rows, int S, int D, int vec_ok) {
   constexpr int V = Elt<TC>::kVec;   // elements per 16-byte access
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const int b = (int)(r / S);
     const TC* c = ctx + r * (long)D;
-    const float* v = vec + (long)b * ldv;
     float acc = 0.f;
     if (vec_ok) {
       for (int d = lane * V; d < D; d += 64 * V) {
@@ -29,12 +28,12 @@ __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, const floa
         Elt<TC>::ld16(c + d, x);
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
-          float4 t = *reinterpret_cast<const float4*>(v + d + j);
+          const float4 t = vec.at4(b, d + j);
           acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
         }
       }
     } else {
-      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(c + d) * v[d];
+      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(c + d) * vec.at(b, d);
     }
     acc = wave_sum(acc);
     if (lane == 0) dots[r] = acc;
@@ -43,17 +42,21 @@ __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, const floa
 
 int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, float* dots, int B, int S,
              int D) {
+  return attn_dot_sv(st, ctx, ctype, plain_vec(vec, ldv), dots, B, S, D);
+}
+int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D) {
   if (B <= 0 || S <= 0 || D <= 0) { set_error("attn_dot: bad dims"); return VLN_ERR_ARG; }
+  const long ldv = vec.ld;
   long rows = (long)B * S;
   int blocks = (int)((rows + 3) / 4);
   if (blocks > 8192) blocks = 8192;
   const int V = (ctype == W_BF16) ? 8 : 4;
-  int vec_ok = aligned16(ctx) && aligned16(vec) && (D % V == 0) && (ldv % 4 == 0);
+  int vec_ok = aligned16(ctx) && aligned16(vec.p) && (D % V == 0) && (ldv % 4 == 0) && (vec.stride % 4 == 0);
   const double bytes = (double)rows * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 4.0 * rows;
   if (ctype == W_BF16)
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, dots, rows, S, D, vec_ok);
   else
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, ldv, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, dots, rows, S, D, vec_ok);
   VLN_CHECK_LAUNCH("attn_dot");
   return VLN_OK;
 }
@@ -279,11 +282,22 @@ int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, cons
 // (`dots_scratch` [B,S] is only touched by the fallback).
 int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, long ldv, const uint8_t* mask, float* attn,
                   float* out, long ldo, float* dots_scratch, int B, int S, int D) {
+  return attn_fwd_rows_sv(st, ctx, ctype, plain_vec(vec, ldv), nullptr, 0, mask, attn, out, ldo, dots_scratch, B, S, D);
+}
+// `vec` may still lie in split-K slabs; vec_out (nullable) receives the summed vector
+int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,
+                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D) {
   if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_fwd_rows: bad dims B=%d S=%d D=%d", B, S, D); return VLN_ERR_ARG; }
-  AttnFusedArgs a{ctx, vec, ldv, mask, attn, nullptr, nullptr, out, ldo, S, D};
+  AttnFusedArgs a{ctx, vec, vec_out, ldvo, mask, attn, nullptr, nullptr, out, ldo, S, D};
   if (attn_fused_try(st, ctype, a, B, false)) { VLN_CHECK_LAUNCH("attn_fused_fwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_fwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
-  int r = attn_dot(st, ctx, ctype, vec, ldv, dots_scratch, B, S, D);
+  if (vec.n > 1 || vec_out) {           // the two-kernel path wants a finished vector
+    if (!vec_out) { set_error("attn_fwd_rows: slab input on the two-kernel path needs vec_out"); return VLN_ERR_ARG; }
+    int r0 = reduce_epilogue(st, vec.p, vec.n, vec.stride, vec.ld, vec_out, ldvo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
+    if (r0 != VLN_OK) return r0;
+    vec = plain_vec(vec_out, ldvo);
+  }
+  int r = attn_dot_sv(st, ctx, ctype, vec, dots_scratch, B, S, D);
   if (r != VLN_OK) return r;
   return attn_softmax_wsum(st, ctx, ctype, dots_scratch, mask, attn, out, ldo, B, S, D);
 }
@@ -291,11 +305,21 @@ int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, 
 // d alpha = ctx . dwc, softmax backward, d query = sum_s dl ctx; dl_out (nullable) feeds attn_dctx_deferred
 int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
                   const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D) {
+  return attn_bwd_rows_sv(st, ctx, ctype, attn, plain_vec(dwc, lddwc), nullptr, 0, dattn_ext, dvec, lddvec, dl_out, dots_scratch, B, S, D);
+}
+int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* attn, SlabVec dwc, float* dwc_out, long lddo,
+                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D) {
   if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_bwd_rows: bad dims"); return VLN_ERR_ARG; }
-  AttnFusedArgs a{ctx, dwc, lddwc, nullptr, const_cast<float*>(attn), dattn_ext, dl_out, dvec, lddvec, S, D};
+  AttnFusedArgs a{ctx, dwc, dwc_out, lddo, nullptr, const_cast<float*>(attn), dattn_ext, dl_out, dvec, lddvec, S, D};
   if (attn_fused_try(st, ctype, a, B, true)) { VLN_CHECK_LAUNCH("attn_fused_bwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_bwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
-  int r = attn_dot(st, ctx, ctype, dwc, lddwc, dots_scratch, B, S, D);
+  if (dwc.n > 1 || dwc_out) {
+    if (!dwc_out) { set_error("attn_bwd_rows: slab input on the two-kernel path needs dwc_out"); return VLN_ERR_ARG; }
+    int r0 = reduce_epilogue(st, dwc.p, dwc.n, dwc.stride, dwc.ld, dwc_out, lddo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
+    if (r0 != VLN_OK) return r0;
+    dwc = plain_vec(dwc_out, lddo);
+  }
+  int r = attn_dot_sv(st, ctx, ctype, dwc, dots_scratch, B, S, D);
   if (r != VLN_OK) return r;
   return attn_bwd(st, ctx, ctype, attn, dots_scratch, dattn_ext, nullptr, 0, nullptr, 0, dvec, lddvec, nullptr, dl_out, B, S, D);
 }

@@ -20,8 +20,8 @@ constexpr int kFusedWaves = 8;
 
 struct AttnFusedArgs {
   const void* ctx;        // [B,S,D] streamed (fp32 or bf16)
-  const float* vec;       // [B,D] query (fwd) / d(weighted context) (bwd)
-  long ldv;
+  SlabVec vec;            // [B,D] query (fwd) / d(weighted context) (bwd), possibly still in split-K slabs
+  float* vec_out; long ldvo;   // nullable: the summed vector is written back (kept for backward / the deferred dctx)
   const uint8_t* mask;    // fwd: [B,S] 1 = masked, nullable
   float* alpha;           // fwd: out [B,S] (nullable); bwd: in [B,S]
   const float* ext;       // bwd: external gradient on alpha [B,S], nullable
@@ -56,14 +56,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(AttnFusedA
       else data[r][j] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
-  const float* q = a.vec + (long)b * a.ldv;
-  for (int i = threadIdx.x * 4; i < DP; i += NW * 64 * 4) {
+  for (int i = threadIdx.x * 4; i < DP; i += NW * 64 * 4) {      // D % 4 == 0 (host check)
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i + 3 < D) t = *reinterpret_cast<const float4*>(q + i);
-    else {
-      if (i < D) t.x = q[i];
-      if (i + 1 < D) t.y = q[i + 1];
-      if (i + 2 < D) t.z = q[i + 2];
+    if (i < D) {
+      t = a.vec.at4(b, i);
+      if (a.vec_out) *reinterpret_cast<float4*>(a.vec_out + (long)b * a.ldvo + i) = t;
     }
     *reinterpret_cast<float4*>(&sq[i]) = t;
   }
@@ -206,7 +203,8 @@ static bool attn_fused_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
   if (g_tunable[4]) return false;                               // tunable[4] = 1 forces the two-kernel path (A/B, tests)
   const int V = (ctype == W_BF16) ? 8 : 4;
   const int S = a.S, D = a.D;
-  if (D % V != 0 || !aligned16(a.ctx) || !aligned16(a.vec) || !aligned16(a.out) || (a.ldv & 3) || (a.ldo & 3) || (D & 3)) return false;
+  if (D % V != 0 || !aligned16(a.ctx) || !aligned16(a.vec.p) || !aligned16(a.out) || (a.vec.ld & 3) || (a.vec.stride & 3) ||
+      (a.ldo & 3) || (D & 3) || (a.vec_out && (!aligned16(a.vec_out) || (a.ldvo & 3)))) return false;
   const int nseg = D / V;
   const int sl = (nseg + 63) / 64, rw = (S + kFusedWaves - 1) / kFusedWaves;
   const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 8.0 * B * D + 8.0 * B * S;

@@ -119,6 +119,48 @@ __host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t
   return m[e & 3];
 }
 
+// A matrix that still lies in `n` split-K partial slabs: value(r, c) = sum_{s < n} p[s*stride + r*ld + c], summed in
+// the fixed order s = 0 .. n-1.  The consumer of a GEMM result adds the partials while it loads them, so a skinny
+// product can be split over all 256 CUs without a reduce launch in the dependent chain (n == 1: a plain matrix).
+struct SlabVec {
+  const float* p; long ld; int n; long stride;
+  // Partials are fetched four at a time (independent loads in flight) and added in slab order.
+  __device__ __forceinline__ float at(long r, long c) const {
+    const float* q = p + r * ld + c;
+    float v = q[0];
+    int s = 1;
+    for (; s + 3 < n; s += 4) {
+      const float t0 = q[(long)s * stride], t1 = q[(long)(s + 1) * stride], t2 = q[(long)(s + 2) * stride], t3 = q[(long)(s + 3) * stride];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    if (s + 1 < n) {
+      const float t0 = q[(long)s * stride], t1 = q[(long)(s + 1) * stride];
+      v += t0; v += t1; s += 2;
+    }
+    if (s < n) v += q[(long)s * stride];
+    return v;
+  }
+  __device__ __forceinline__ float4 at4(long r, long c) const {      // 16-byte aligned column group
+    const float* q = p + r * ld + c;
+    float4 v = *reinterpret_cast<const float4*>(q);
+    auto ld4 = [&](int s) { return *reinterpret_cast<const float4*>(q + (long)s * stride); };
+    auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int s = 1;
+    for (; s + 3 < n; s += 4) {
+      const float4 t0 = ld4(s), t1 = ld4(s + 1), t2 = ld4(s + 2), t3 = ld4(s + 3);
+      add(v, t0); add(v, t1); add(v, t2); add(v, t3);
+    }
+    if (s + 1 < n) {
+      const float4 t0 = ld4(s), t1 = ld4(s + 1);
+      add(v, t0); add(v, t1); s += 2;
+    }
+    if (s < n) add(v, ld4(s));
+    return v;
+  }
+  __host__ __device__ SlabVec shifted(long cols) const { return SlabVec{p + cols, ld, n, stride}; }
+};
+static inline SlabVec plain_vec(const float* p, long ld) { return SlabVec{p, ld, 1, 0}; }
+
 struct DropSpec {      // one dropout site; p == 0 disables it
   uint64_t seed;
   uint64_t offset;     // Philox offset of the site -- or, when `step` is set, the site index k of offset = *step * 8 + k

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
 }
 
 struct PrepBwdArgs {
-  const float* dxcat; long ldx; const float* e; const float* dhq;
+  SlabVec dxcat; const float* e; SlabVec dhq;      // dxcat [B, AE+F+H] and dhq [B,H] may still lie in split-K slabs
   float* s_de; float* dhtp;
   int B, AE, F, H;
   DropSpec d_act, d_h;
@@ -69,22 +69,23 @@ __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
     if (i < ne) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
       const float e = p.e[i];
-      const float de = p.dxcat[(long)b * p.ldx + j] * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
+      const float de = p.dxcat.at(b, j) * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
       p.s_de[i] = de * (1.f - e * e);
     } else {
       const long k = i - ne;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
-      p.dhtp[k] = p.dxcat[(long)b * p.ldx + p.AE + p.F + j] +
-                  p.dhq[k] * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
+      p.dhtp[k] = p.dxcat.at(b, p.AE + p.F + j) +
+                  p.dhq.at(b, j) * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
     }
   }
 }
 
-// dz = (dhtd * mask + dht_ext) * (1 - ht^2)
-__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(const float* dhtd, const float* dht_ext, const float* ht,
-                                                            float* dz, long n, DropSpec d) {
+// dz = (dhtd * mask + dht_ext) * (1 - ht^2)      (dhtd [B,H] may still lie in split-K slabs)
+__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(SlabVec dhtd, const float* dht_ext, const float* ht,
+                                                            float* dz, int B, int H, DropSpec d) {
+  const long n = (long)B * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float g = dhtd[i] * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
+    float g = dhtd.at(i / H, i % H) * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
     if (dht_ext) g += dht_ext[i];
     const float h = ht[i];
     dz[i] = g * (1.f - h * h);
@@ -98,26 +99,30 @@ static inline int nblocks(long n, int cap = 2048) {
   return (int)b;
 }
 
-struct Ws {   // carve-up of the per-step scratch
-  float *slabs, *tv, *tc, *dots, *dtcat, *dhtd, *dxcat, *dhq, *dh1d;
-  long slab_floats;
+// Per-step scratch.  Every skinny product of the step is split over K until ~256 workgroups are in flight and leaves
+// its partial slabs in one of four regions; the kernel that consumes the result adds the partials while loading
+// (SlabVec), so no reduce launch sits in the dependent chain.  Regions are reused once their consumer has run:
+//   s1 [S][B,F]        fwd: visual query, then linear_out scratch, then candidate query      bwd: -
+//   s2 [S][B,max(4H,XK)]  fwd: LSTM gate pre-activations                                     bwd: d xcat
+//   s3 [S][B,H]        fwd: text query                                                       bwd: d drop(h_tilde), d drop(h1) part 2, d hq
+//   s4 [S][B,2H]       fwd: -                                                                bwd: [d weighted ctx | d drop(h1)]
+constexpr int kMaxSlabs = 16;
+struct Ws {
+  float *s1, *s2, *s3, *s4, *dots, *dtcat, *tt;
+  long n1, n2, n3, n4;
 };
 static long ws_layout(const vln_envdrop_dims& d, float* base, Ws* w) {
-  const long B = d.B, F = d.IMG + d.ANG, XK = d.AE + F + d.H;
-  long maxn = 4L * d.H;
-  if (F > maxn) maxn = F;
-  if (XK > maxn) maxn = XK;
+  const long B = d.B, F = d.IMG + d.ANG, XK = d.AE + F + d.H, H = d.H;
   long off = 0;
   auto take = [&](long n) { long o = off; off += (n + 63) & ~63L; return o; };
-  const long slab_floats = 16 * B * maxn;
-  long o_slabs = take(slab_floats), o_tv = take(B * F), o_tc = take(B * F);
+  const long n1 = kMaxSlabs * B * F, n2 = kMaxSlabs * B * (4 * H > XK ? 4 * H : XK), n3 = 2 * kMaxSlabs * B * H, n4 = kMaxSlabs * B * 2 * H;
+  long o1 = take(n1), o2 = take(n2), o3 = take(n3), o4 = take(n4);
   long smax = d.V; if (d.L > smax) smax = d.L; if (d.C > smax) smax = d.C;
-  long o_dots = take(B * smax), o_dtcat = take(B * 2 * d.H), o_dhtd = take(B * d.H), o_dxcat = take(B * XK);
-  long o_dhq = take(B * d.H), o_dh1d = take(B * d.H);
+  long o_dots = take(B * smax), o_dtcat = take(B * 2 * H), o_tt = take(B * H);
   if (w) {
-    w->slabs = base + o_slabs; w->tv = base + o_tv; w->tc = base + o_tc; w->dots = base + o_dots;
-    w->dtcat = base + o_dtcat; w->dhtd = base + o_dhtd; w->dxcat = base + o_dxcat; w->dhq = base + o_dhq;
-    w->dh1d = base + o_dh1d; w->slab_floats = slab_floats;
+    w->s1 = base + o1; w->s2 = base + o2; w->s3 = base + o3; w->s4 = base + o4;
+    w->dots = base + o_dots; w->dtcat = base + o_dtcat; w->tt = base + o_tt;
+    w->n1 = n1; w->n2 = n2; w->n3 = n3; w->n4 = n4;
   }
   return off;
 }
@@ -176,25 +181,27 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
   // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
-  RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, ws.tv, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_fwd_rows(st, img, d->ctype, ws.tv, F, nullptr, io->alpha_v, io->xcat + AE, XK, ws.dots, B, d->V, F));
+  int n1 = 1, n2 = 1, n3 = 1;
+  RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  RUN(attn_fwd_rows_sv(st, img, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, nullptr, 0, nullptr, io->alpha_v, io->xcat + AE, XK,
+                       ws.dots, B, d->V, F));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
-  int nsplit = 1;
-  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, &nsplit));
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   LstmPwFwd pw{};
-  pw.gates = ws.slabs; pw.nsplit = nsplit; pw.slab_stride = (long)B * 4 * H;
+  pw.gates = ws.s2; pw.nsplit = n2; pw.slab_stride = (long)B * 4 * H;
   pw.bias_a = w->b_ih; pw.bias_b = w->b_hh; pw.c0 = io->c0; pw.ldc0 = H;
   pw.h1 = io->h1; pw.ldh1 = H; pw.c1 = io->c1; pw.ldc1 = H; pw.act = io->gate_act; pw.tanh_c1 = io->tanh_c1;
   pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
   RUN(lstm_pointwise_fwd(st, pw));
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
-  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, io->tt, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_fwd_rows(st, ctx, d->ctype, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, ws.dots, B, d->L, H));
+  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+  RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
+                       ws.dots, B, d->L, H));
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
-                    site(io, 3, io->p_drop), ws.slabs, ws.slab_floats));
+                    site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
-  RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, ws.tc, F, B, F, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
-  RUN(attn_dot(st, cand, d->ctype, ws.tc, F, io->logit, B, d->C, F));
+  RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
   return VLN_OK;
 }
 
@@ -209,43 +216,48 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
 
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
+  int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
+  SlabVec dhtd{ws.s3, H, 1, (long)B * H};
   if (g->dlogit) {
     RUN(rows_wsum(st, cand, d->ctype, g->dlogit, g->s_dtc, F, B, d->C, F));
-    RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, d->wtype, F, ws.dhtd, H, B, H, F, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+    RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+    dhtd.n = n3;
   } else {
     RUN(fill_f32(st, g->s_dtc, (long)B * F, 0.f));
-    RUN(fill_f32(st, ws.dhtd, (long)B * H, 0.f));
+    RUN(fill_f32(st, ws.s3, (long)B * H, 0.f));
   }
   // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
-  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ws.dhtd, g->dh_tilde,
-                     io->h_tilde, g->s_dz, (long)B * H, site(io, 3, io->p_drop));
+  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, dhtd, g->dh_tilde,
+                     io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop));
   VLN_CHECK_LAUNCH("tanh_drop_bwd");
-  // (5') linear_out -> [d weighted ctx | d drop(h1)]
+  // (5') linear_out -> [d weighted ctx | d drop(h1)], still in slabs (s4)
+  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, nullptr, 0, B, 2 * H, H, nullptr, ACT_NONE, ws.s4, ws.n4, &n4));
+  const SlabVec dtcat{ws.s4, 2 * H, n4, (long)B * 2 * H};
   // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
-  // deferred: this step only leaves d logits (g->s_dl) and [d weighted ctx | .] (g->s_dtcat) behind and the caller
+  // deferred: this step only leaves d logits (g->s_dl) and d weighted ctx (g->s_dtcat[:, :H]) behind and the caller
   // forms dctx once per rollout with vln_attn_dctx_deferred.
-  float* dtcat = g->s_dtcat ? g->s_dtcat : ws.dtcat;
-  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
   if (g->dctx) {
-    RUN(attn_dot(st, ctx, d->ctype, dtcat, 2 * H, ws.dots, B, d->L, H));
-    RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
+    RUN(reduce_epilogue(st, ws.s4, n4, (long)B * 2 * H, 2 * H, ws.dtcat, 2 * H, B, 2 * H, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f}));
+    RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
+    RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
   } else {
-    RUN(attn_bwd_rows(st, ctx, d->ctype, io->alpha_t, dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
+    RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
   }
-  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, ws.dh1d, H, B, H, H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
   // (4') LSTM cell
   LstmPwBwd pb{};
-  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = dtcat + H; pb.ld_b = 2 * H; pb.dh1_b2 = ws.dh1d; pb.ld_b2 = H;
+  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = dtcat.shifted(H); pb.dh1_b2 = SlabVec{ws.s3, H, n3b, (long)B * H};
   pb.drop = site(io, 2, io->p_drop); pb.dc1 = g->dc1; pb.lddc1 = H;
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
   RUN(lstm_pointwise_bwd(st, pb));
-  RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, ws.dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
+  const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does
-  RUN(attn_bwd_rows(st, img, d->ctype, io->alpha_v, ws.dxcat + AE, XK, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
-  RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, ws.dhq, H, B, H, F, nullptr, ACT_NONE, ws.slabs, ws.slab_floats, nullptr));
+  RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
+  RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
-  PrepBwdArgs pa{ws.dxcat, XK, io->e, ws.dhq, g->s_de, g->dh_tilde_prev, B, AE, F, H,
+  PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
   hipLaunchKernelGGL(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep_bwd");
@@ -261,6 +273,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
 namespace {
 struct StepKey {
   vln_envdrop_dims d; vln_envdrop_weights w; vln_envdrop_step io; vln_envdrop_grads g; int bwd;
+  int tun[8];          // the launch plan depends on the run-time tunables: a changed tunable never replays an old graph
 };
 }  // namespace
 
@@ -279,6 +292,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.bwd = 0;
   memset(&key.g, 0, sizeof(key.g));
+  memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
 }
 
@@ -293,5 +307,6 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   static GraphCache cache(64);
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.g = *g; key.bwd = 1;
+  memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
 }

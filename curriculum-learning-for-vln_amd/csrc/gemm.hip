@@ -32,7 +32,15 @@ struct GemmNTArgs {
   int xvec, wvec;
 };
 
-template <typename TW>
+// PD = register prefetch depth: the loads of K-steps s+1 .. s+PD are in flight while step s is multiplied.  Every
+// first-touch load in these launches crosses the fabric (~1.3 us: the operands were written by another XCD or come
+// from the MALL / HBM), and with PD = 1 a workgroup's K-steps are a chain of such round trips (13.4 us for the 8 steps
+// of an un-split H->F projection, 10.9 us for 6 steps of the LSTM gate product); PD = 4 overlaps them.
+// kFast: every load is unconditional (rows clamped to the last valid one, K a multiple of BK per chunk, 16-byte
+// aligned operands -- checked on the host).  The bounds-checked form branches per thread between a vector and a
+// scalar load, and the compiler closes every such divergent region with `s_waitcnt vmcnt(0)`: the prefetch never
+// overlaps anything.  Without branches the waits become vmcnt(N) and PD loads really are in flight.
+template <typename TW, int PD, bool kFast>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
   constexpr bool kF32 = (sizeof(TW) == 4);
@@ -50,45 +58,87 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   // staging role: thread -> (row, 32-byte segment) of the X tile
   const int srow = tid >> 2, sseg = tid & 3;
   const bool srow_ok = (m0 + srow) < a.M;
-  const float* xrow = a.X + (long)(srow_ok ? (m0 + srow) : 0) * a.ldx;
+  const float* xrow = a.X + (long)(srow_ok ? (m0 + srow) : (kFast ? a.M - 1 : 0)) * a.ldx;
   // fragment role
   const int fi = lane & 15, fq = lane >> 4;
   const int wn = n0 + wave * 16 + fi;
   const bool wn_ok = wn < a.N;
-  const TW* wrow = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok ? wn : 0) * a.ldw;
+  const TW* wrow = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok ? wn : (kFast ? a.N - 1 : 0)) * a.ldw;
   const int mrows = min(64, a.M - m0);
   const int nrb = (mrows + 15) >> 4;
 
-  float xs[VK];
-  float wf32[kF32 ? 8 : 1];
-  bf16x8 wb16[kF32 ? 1 : 2];
+  float xs[PD][VK];
+  float wf32[PD][kF32 ? 8 : 1];
+  bf16x8 wb16[PD][kF32 ? 1 : 2];
 
-  auto load_x = [&](int kb) {
+  // kFast staging role: each 16-lane group reads 256 contiguous bytes of ONE row (two cache lines) per instruction.
+  // (The bounds-checked role above gives every lane its own 64-byte run: a wave instruction then touches 32 lines for
+  // 1 KiB, and the CU's address path, not the fabric, sets the pace -- scripts/stream_probe.hip, "fragment shape".)
+  constexpr int NXI = VK / 4;                        // float4 loads per thread per K-step
+  constexpr int XLPR = BK / 4;                       // lanes per row: 16 (BK = 64) or 8 (BK = 32)
+  const int xpiece = lane % XLPR;
+  const float* xrow_i[NXI];
+  int xr_i[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    xr_i[i] = wave * 16 + i * (64 / XLPR) + lane / XLPR;
+    const int gr = min(m0 + xr_i[i], a.M - 1);
+    xrow_i[i] = a.X + (long)gr * a.ldx + xpiece * 4;
+  }
+  auto load_x = [&](float (&x)[VK], int kb) {
+    if constexpr (kFast) {
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(xrow_i[i] + kb);
+        x[i * 4 + 0] = t.x; x[i * 4 + 1] = t.y; x[i * 4 + 2] = t.z; x[i * 4 + 3] = t.w;
+      }
+      return;
+    }
     const int k = kb + sseg * VK;
     if (srow_ok && a.xvec && k + VK <= kend) {
 #pragma unroll
       for (int v = 0; v < VK / 4; ++v) {
         float4 t = *reinterpret_cast<const float4*>(xrow + k + v * 4);
-        xs[v * 4 + 0] = t.x; xs[v * 4 + 1] = t.y; xs[v * 4 + 2] = t.z; xs[v * 4 + 3] = t.w;
+        x[v * 4 + 0] = t.x; x[v * 4 + 1] = t.y; x[v * 4 + 2] = t.z; x[v * 4 + 3] = t.w;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < VK; ++j) xs[j] = (srow_ok && (k + j) < kend) ? xrow[k + j] : 0.0f;
+      for (int j = 0; j < VK; ++j) x[j] = (srow_ok && (k + j) < kend) ? xrow[k + j] : 0.0f;
     }
   };
-  auto store_x = [&](int buf) {
+  auto store_x = [&](const float (&x)[VK], int buf) {
+    if constexpr (kFast) {
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        if constexpr (kF32) {
+          *reinterpret_cast<float4*>(&smem[buf][0][xr_i[i] * kLdsRow + xpiece * 16]) =
+              make_float4(x[i * 4], x[i * 4 + 1], x[i * 4 + 2], x[i * 4 + 3]);
+        } else {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)x[i * 4 + j];
+            l[j] = (__bf16)(x[i * 4 + j] - (float)h[j]);
+          }
+          *reinterpret_cast<bf16x4*>(&smem[buf][0][xr_i[i] * kLdsRow + xpiece * 8]) = h;
+          *reinterpret_cast<bf16x4*>(&smem[buf][kPlanes - 1][xr_i[i] * kLdsRow + xpiece * 8]) = l;
+        }
+      }
+      return;
+    }
     unsigned char* dst = &smem[buf][0][srow * kLdsRow + sseg * 32];
     if constexpr (kF32) {
-      *reinterpret_cast<float4*>(dst) = make_float4(xs[0], xs[1], xs[2], xs[3]);
-      *reinterpret_cast<float4*>(dst + 16) = make_float4(xs[4], xs[5], xs[6], xs[7]);
+      *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4*>(dst + 16) = make_float4(x[4], x[5], x[6], x[7]);
     } else {
       bf16x8 h0, h1, l0, l1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        h0[j] = (__bf16)xs[j];
-        h1[j] = (__bf16)xs[8 + j];
-        l0[j] = (__bf16)(xs[j] - (float)h0[j]);
-        l1[j] = (__bf16)(xs[8 + j] - (float)h1[j]);
+        h0[j] = (__bf16)x[j];
+        h1[j] = (__bf16)x[8 + j];
+        l0[j] = (__bf16)(x[j] - (float)h0[j]);
+        l1[j] = (__bf16)(x[8 + j] - (float)h1[j]);
       }
       *reinterpret_cast<bf16x8*>(dst) = h0;
       *reinterpret_cast<bf16x8*>(dst + 16) = h1;
@@ -97,29 +147,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
       *reinterpret_cast<bf16x8*>(dlo + 16) = l1;
     }
   };
-  auto load_w = [&](int kb) {
+  auto load_w = [&](float (&w32)[kF32 ? 8 : 1], bf16x8 (&w16)[kF32 ? 1 : 2], int kb) {
     const int k = kb + fq * VK;
     if constexpr (kF32) {
-      if (wn_ok && a.wvec && k + VK <= kend) {
+      if (kFast || (wn_ok && a.wvec && k + VK <= kend)) {
         float4 t0 = *reinterpret_cast<const float4*>(wrow + k);
         float4 t1 = *reinterpret_cast<const float4*>(wrow + k + 4);
-        wf32[0] = t0.x; wf32[1] = t0.y; wf32[2] = t0.z; wf32[3] = t0.w;
-        wf32[4] = t1.x; wf32[5] = t1.y; wf32[6] = t1.z; wf32[7] = t1.w;
+        w32[0] = t0.x; w32[1] = t0.y; w32[2] = t0.z; w32[3] = t0.w;
+        w32[4] = t1.x; w32[5] = t1.y; w32[6] = t1.z; w32[7] = t1.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf32[j] = (wn_ok && (k + j) < kend) ? wrow[k + j] : 0.0f;
+        for (int j = 0; j < 8; ++j) w32[j] = (wn_ok && (k + j) < kend) ? wrow[k + j] : 0.0f;
       }
     } else {
-      if (wn_ok && a.wvec && k + VK <= kend) {
-        wb16[0] = *reinterpret_cast<const bf16x8*>(wrow + k);
-        wb16[1] = *reinterpret_cast<const bf16x8*>(wrow + k + 8);
+      if (kFast || (wn_ok && a.wvec && k + VK <= kend)) {
+        w16[0] = *reinterpret_cast<const bf16x8*>(wrow + k);
+        w16[1] = *reinterpret_cast<const bf16x8*>(wrow + k + 8);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           bf16_raw r0 = (wn_ok && (k + j) < kend) ? wrow[k + j] : (bf16_raw)0;
           bf16_raw r1 = (wn_ok && (k + 8 + j) < kend) ? wrow[k + 8 + j] : (bf16_raw)0;
-          wb16[0][j] = __builtin_bit_cast(__bf16, r0);
-          wb16[1][j] = __builtin_bit_cast(__bf16, r1);
+          w16[0][j] = __builtin_bit_cast(__bf16, r0);
+          w16[1][j] = __builtin_bit_cast(__bf16, r1);
         }
       }
     }
@@ -129,52 +179,66 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nsteps > 0) {
-    load_x(kbeg);
-    load_w(kbeg);
+#pragma unroll
+  for (int p = 0; p < PD; ++p) {
+    if (p < nsteps) {
+      load_x(xs[p], kbeg + p * BK);
+      load_w(wf32[p], wb16[p], kbeg + p * BK);
+    }
   }
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    store_x(buf);
-    // current W fragment -> private copy before the prefetch overwrites the registers
-    float wc32[kF32 ? 8 : 1];
-    bf16x8 wc16[kF32 ? 1 : 2];
-    if constexpr (kF32) {
+  for (int s0 = 0; s0 < nsteps; s0 += PD) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wc32[j] = wf32[j];
-    } else {
-      wc16[0] = wb16[0]; wc16[1] = wb16[1];
-    }
-    __syncthreads();
-    if (s + 1 < nsteps) {
-      load_x(kbeg + (s + 1) * BK);
-      load_w(kbeg + (s + 1) * BK);
-    }
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      if (rb < nrb) {
-        const unsigned char* src = &smem[buf][0][(rb * 16 + fi) * kLdsRow + fq * 32];
+    for (int p = 0; p < PD; ++p) {
+      const int s = s0 + p;
+      if (s < nsteps) {
+        const int buf = s & 1;
+        store_x(xs[p], buf);
+        // current W fragment -> private copy before the prefetch overwrites the registers
+        float wc32[kF32 ? 8 : 1];
+        bf16x8 wc16[kF32 ? 1 : 2];
         if constexpr (kF32) {
-          float4 a0 = *reinterpret_cast<const float4*>(src);
-          float4 a1 = *reinterpret_cast<const float4*>(src + 16);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc32[0], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc32[1], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc32[2], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc32[3], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wc32[4], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wc32[5], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wc32[6], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wc32[7], acc[rb], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wc32[j] = wf32[p][j];
         } else {
-          bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
-          bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
-          const unsigned char* slo = &smem[buf][kPlanes - 1][(rb * 16 + fi) * kLdsRow + fq * 32];
-          bf16x8 b0 = *reinterpret_cast<const bf16x8*>(slo);
-          bf16x8 b1 = *reinterpret_cast<const bf16x8*>(slo + 16);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[0], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[1], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[0], acc[rb], 0, 0, 0);
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[1], acc[rb], 0, 0, 0);
+          wc16[0] = wb16[p][0]; wc16[1] = wb16[p][1];
+        }
+        __syncthreads();
+        if (s + PD < nsteps) {
+          load_x(xs[p], kbeg + (s + PD) * BK);
+          load_w(wf32[p], wb16[p], kbeg + (s + PD) * BK);
+        }
+#ifdef VLN_PROBE_NO_MFMA       // scripts/gemm_probe.hip: what the K-step costs without the LDS reads and MFMAs
+        if constexpr (!kF32) { acc[0][0] += (float)wc16[0][0] + (float)wc16[1][7]; acc[1][0] += smem[buf][0][tid]; }
+        else { acc[0][0] += wc32[0] + wc32[7]; acc[1][0] += smem[buf][0][tid]; }
+        continue;
+#endif
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          if (rb < nrb) {
+            const unsigned char* src = &smem[buf][0][(rb * 16 + fi) * kLdsRow + fq * 32];
+            if constexpr (kF32) {
+              float4 a0 = *reinterpret_cast<const float4*>(src);
+              float4 a1 = *reinterpret_cast<const float4*>(src + 16);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc32[0], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc32[1], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc32[2], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc32[3], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wc32[4], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wc32[5], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wc32[6], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wc32[7], acc[rb], 0, 0, 0);
+            } else {
+              bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
+              bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
+              const unsigned char* slo = &smem[buf][kPlanes - 1][(rb * 16 + fi) * kLdsRow + fq * 32];
+              bf16x8 b0 = *reinterpret_cast<const bf16x8*>(slo);
+              bf16x8 b1 = *reinterpret_cast<const bf16x8*>(slo + 16);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[0], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[1], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[0], acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[1], acc[rb], 0, 0, 0);
+            }
+          }
         }
       }
     }
@@ -281,8 +345,20 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   {
     // algorithmic bytes: the weight stream once + activations in + result out
     const double bytes = (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N;
-    if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw>, grid, block, 0, st, a);
-    else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float>, grid, block, 0, st, a);
+    // fast form: aligned operands and every K-chunk a whole number of BK steps
+    const bool fast = a.xvec && a.wvec && (K % BK == 0) && g_tunable[5] != 2;      // tunable[5] = 2: bounds-checked kernel (A/B)
+    // Depth 4 was measured slower than depth 2 on every decoder shape (scripts/gemm_probe.hip: LSTM gates 13.0 vs 11.7 us;
+    // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
+    const bool deep = g_tunable[5] == 4 && steps_per > 2;
+#define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
+    if (wtype == W_BF16) {
+      if (fast) { if (deep) VLN_NT_LAUNCH(bf16_raw, 4, true); else VLN_NT_LAUNCH(bf16_raw, 2, true); }
+      else VLN_NT_LAUNCH(bf16_raw, 1, false);
+    } else {
+      if (fast) { if (deep) VLN_NT_LAUNCH(float, 4, true); else VLN_NT_LAUNCH(float, 2, true); }
+      else VLN_NT_LAUNCH(float, 1, false);
+    }
+#undef VLN_NT_LAUNCH
   }
   VLN_CHECK_LAUNCH("gemm_nt");
   if (nsplit_out) { *nsplit_out = nsplit; return VLN_OK; }   // caller consumes the slabs itself

@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(LstmPwBwd a) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int b = (int)(e / H), j = (int)(e % H);
     float dh = a.dh1_a ? a.dh1_a[(long)b * a.ld_a + j] : 0.f;
-    if (a.dh1_b) {
-      float v = a.dh1_b[(long)b * a.ld_b + j];
-      if (a.dh1_b2) v += a.dh1_b2[(long)b * a.ld_b2 + j];
+    if (a.dh1_b.p) {
+      float v = a.dh1_b.at(b, j);
+      if (a.dh1_b2.p) v += a.dh1_b2.at(b, j);
       dh += v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
     }
     const float* act = a.act + (long)b * 4 * H + j;

@@ -107,6 +107,12 @@ int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, 
                   float* out, long ldo, float* dots_scratch, int B, int S, int D);
 int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
                   const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
+// same, with the vector operand still in split-K slabs (SlabVec) and an optional write-back of the summed vector
+int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D);
+int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,
+                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D);
+int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* attn, SlabVec dwc, float* dwc_out, long lddo,
+                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate);
@@ -128,8 +134,8 @@ struct LstmPwFwd {
 int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a);
 struct LstmPwBwd {
   const float* dh1_a; long ld_a;   // external grad on h1 (nullable)
-  const float* dh1_b; long ld_b;   // grad flowing from the dropped copy (nullable); multiplied by the mask
-  const float* dh1_b2; long ld_b2; // second contribution to the dropped copy's grad (nullable)
+  SlabVec dh1_b;                   // grad flowing from the dropped copy (p nullable); multiplied by the mask
+  SlabVec dh1_b2;                  // second contribution to the dropped copy's grad (p nullable)
   DropSpec drop;
   const float* dc1; long lddc1;    // external grad on c1 (nullable)
   const float* act; const float* tanh_c1; const float* c0; long ldc0;

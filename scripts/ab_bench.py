@@ -17,15 +17,13 @@ tape_t = bench.tape_to(cpu_tape, dev)
 tape_s = bench.tape_to(cpu_tape, dev, store_dtype=dtype)
 lib = vln._lib.load()
 
-VARIANTS = {   # (persistent, graphs, split target, no-split rule, n16 kernel, n16 max K)
-    "base": (1, 1, 256, 1, 1, 512),
-    "n16_K<=1024": (1, 1, 256, 1, 1, 1024),
-    "n16_all_K": (1, 1, 256, 1, 1, 0),
-    "n16_off": (1, 1, 256, 1, 0, 0),
-    "n16_off_target512": (1, 1, 512, 1, 0, 0),
-    "arena_step_graphs": (1, 1, 256, 1, 1, 512),
-    "arena_no_graphs": (1, 0, 256, 1, 1, 512),
-    "per_step_lstm": (0, 1, 256, 1, 1, 512),
+VARIANTS = {   # (persistent, graphs, split target, no-split rule, n16 kernel, n16 max K, two-kernel attention, gemm prefetch depth 1)
+    "base": (1, 1, 256, 1, 1, 512, 0, 0),
+    "gemm_pd1": (1, 1, 256, 1, 1, 512, 0, 1),
+    "attn_two_kernels": (1, 1, 256, 1, 1, 512, 1, 0),
+    "n16_off": (1, 1, 256, 1, 0, 0, 0, 0),
+    "target512": (1, 1, 512, 1, 1, 512, 0, 0),
+    "n16_off_target512": (1, 1, 512, 1, 0, 0, 0, 0),
 }
 torch.manual_seed(0)
 agent = bench.GpuAgent(vln, dev, dtype, 1)
@@ -33,10 +31,11 @@ agent = bench.GpuAgent(vln, dev, dtype, 1)
 
 def configure(cfg, name=""):
     agent.dec.overlap_wgrads = (name == "overlap_wgrads")
-    want = name.startswith("arena")
+    want = not name.startswith("noarena")
     if want != (agent.arena is not None):
         agent.use_arena(want)
     lib.vln_set_persistent(cfg[0]); lib.vln_set_graphs(cfg[1]); lib.vln_set_tunable(0, cfg[2]); lib.vln_set_tunable(1, cfg[3]); lib.vln_set_tunable(2, cfg[4]); lib.vln_set_tunable(3, cfg[5])
+    lib.vln_set_tunable(4, cfg[6]); lib.vln_set_tunable(5, cfg[7])
 
 
 times = {n: [] for n in VARIANTS}
