@@ -42,6 +42,11 @@ class ShadowJob(C.Structure):
                 ("N", i32), ("K", i32), ("out_type", i32), ("pad_", i32)]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("dy", ptr), ("x", ptr), ("dw", ptr), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
+                ("N", i32), ("K", i32), ("accumulate", i32), ("pad_", i32)]
+
+
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
                                    "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat")]
@@ -58,6 +63,8 @@ SIGNATURES = {
     "vln_prof_read": (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vln_linear_fwd": (i32, [ptr, i64, ptr, i32, i64, ptr, i64, i32, i32, i32, ptr, i32, ptr, i64, ptr]),
     "vln_linear_wgrad": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_linear_wgrad_p": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_wgrad_grouped": (i32, [ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),

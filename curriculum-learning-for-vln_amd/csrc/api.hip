@@ -126,6 +126,19 @@ extern "C" int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int
   if (!A || !X || !D) { set_error("vln_linear_wgrad: null pointer"); return VLN_ERR_ARG; }
   return gemm_tn((hipStream_t)s, A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, ws, ws_floats);
 }
+extern "C" int vln_linear_wgrad_p(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd,
+                                  int Mt, int N, int K, int accumulate, int precision, float* ws, int64_t ws_floats,
+                                  vln_stream_t s) {
+  if (!A || !X || !D) { set_error("vln_linear_wgrad_p: null pointer"); return VLN_ERR_ARG; }
+  if (precision != 0 && precision != 1) { set_error("vln_linear_wgrad_p: precision must be 0 (fp32) or 1 (split bf16)"); return VLN_ERR_ARG; }
+  return gemm_tn((hipStream_t)s, A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, ws, ws_floats, precision);
+}
+extern "C" int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precision, float* ws, int64_t ws_floats,
+                                 vln_stream_t s) {
+  if (!jobs || n_jobs <= 0) { set_error("vln_wgrad_grouped: bad args"); return VLN_ERR_ARG; }
+  if (precision != 0 && precision != 1) { set_error("vln_wgrad_grouped: precision must be 0 (fp32) or 1 (split bf16)"); return VLN_ERR_ARG; }
+  return wgrad_grouped((hipStream_t)s, jobs, n_jobs, Mt, precision, ws, ws_floats);
+}
 extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                           int64_t ws_floats, vln_stream_t s) {
   if (!A || !out || cols <= 0) { set_error("vln_colsum: bad args"); return VLN_ERR_ARG; }

@@ -479,18 +479,170 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
     }
   }
   float* D = a.D + (long)blockIdx.z * a.slab_stride;
+  float old[4][4];                 // all 16 old values in flight at once, from clamped addresses (see gemm_tn_x3_kernel)
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = min(k0 + kb * 16 + fi, a.K - 1), row = min(n0 + wave * 16 + fq * 4 + r, a.N - 1);
+      old[kb][r] = a.accumulate ? D[(long)row * a.ldd + col] : 0.f;
+    }
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     const int col = k0 + kb * 16 + fi;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = n0 + wave * 16 + fq * 4 + r;
-      if (row < a.N && col < a.K) {
-        float* d = D + (long)row * a.ldd + col;
-        *d = a.accumulate ? (*d + acc[kb][r]) : acc[kb][r];
+      if (row < a.N && col < a.K) D[(long)row * a.ldd + col] = acc[kb][r] + old[kb][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gemm_tn, split-bf16 form (the bf16 compute mode's weight gradients): both fp32 operands are split x = hi + lo into
+// bf16 planes and D += Ah^T Xh + Ah^T Xl + Al^T Xh on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the dropped
+// lo*lo term is 2^-16 relative): 3 x 16 cycles per 32 contraction rows instead of 8 x 32 on the f32 MFMA.
+// 128(N) x 128(K) output tile per workgroup (operand re-reads halve against 64 x 64), 32 contraction rows per step.
+// Staging: threads 0-127 own the dY operand, 128-255 the X operand; a thread loads a 4-column x 8-row block with eight
+// coalesced float4 loads (32 lanes x 16 B = 512 contiguous bytes per row), so its registers already hold, per column,
+// the 8 consecutive contraction rows one MFMA lane supplies -- the transposition costs no shuffle.  LDS image per
+// operand and plane: [column][row group of 8] x 16 B, 80-byte rows (conflict-free ds_read_b128 / ds_write_b128).
+// ---------------------------------------------------------------------------
+// LDS image per operand and plane: [row group of 8 (4)][column slot (4 sections x 36)] x 16 B.  Column c of the tile
+// lives at slot (c % 4) * 36 + c / 4: the 32 lanes of a staging store (columns 4*cg + c, cg = lane) hit consecutive
+// 16-byte slots, and the 16 lanes of an MFMA fragment read (columns 16*t + fi) hit 16 distinct 4-bank groups.
+constexpr int kX3Plane = 4 * 144 * 16;      // bytes
+struct TnTile {           // one 128 x 128 output tile of D[N,K] (+)= A[Mt,N]^T X[Mt,K] over rows [mbeg, mend)
+  const float* A; long lda; const float* X; long ldx; float* D; long ldd;
+  int N, K, accumulate, n0, k0, mbeg, mend;
+};
+__device__ __forceinline__ int x3_slot(int c) { return (c & 3) * 36 + (c >> 2); }
+
+__device__ __forceinline__ void tn_x3_tile(const TnTile& a, unsigned char (*sm)[2][kX3Plane]) {
+  constexpr int PD = 2;                              // row steps in flight besides the one being multiplied
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  // staging role
+  const int op = tid >> 7, t = tid & 127, cg = t & 31, mq = t >> 5;
+  const float* P = op ? a.X : a.A;
+  const long ld = op ? a.ldx : a.lda;
+  const int C = op ? a.K : a.N;
+  const int col = (op ? a.k0 : a.n0) + cg * 4;
+  const bool col_ok = col < C;                       // C % 4 == 0 (host check): a float4 never straddles the edge
+  const float* pc = P + (col_ok ? col : 0);
+  float4 r[PD][8];
+  auto load = [&](float4 (&q)[8], int mbase) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = mbase + mq * 8 + i;
+      const float4 v = *reinterpret_cast<const float4*>(pc + (long)min(m, a.mend - 1) * ld);
+      const bool ok = col_ok && m < a.mend;          // select, not a branch: the loads stay unconditional
+      q[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+  };
+  auto store = [&](const float4 (&q)[8]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8 h, l;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (c == 0) ? q[i].x : (c == 1) ? q[i].y : (c == 2) ? q[i].z : q[i].w;
+        h[i] = (__bf16)v;
+        l[i] = (__bf16)(v - (float)h[i]);
+      }
+      const int off = (mq * 144 + c * 36 + cg) * 16;
+      *reinterpret_cast<bf16x8*>(&sm[op][0][off]) = h;
+      *reinterpret_cast<bf16x8*>(&sm[op][1][off]) = l;
+    }
+  };
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (a.mend - a.mbeg + 31) / 32;
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (p < nsteps) load(r[p], a.mbeg + p * 32);
+  for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int s = s0 + p;
+      if (s < nsteps) {
+        store(r[p]);
+        __syncthreads();
+        if (s + PD < nsteps) load(r[p], a.mbeg + (s + PD) * 32);
+        bf16x8 ah[4], al[4], xh[4], xl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int oa = (fq * 144 + x3_slot(wn + i * 16 + fi)) * 16, ox = (fq * 144 + x3_slot(wk + i * 16 + fi)) * 16;
+          ah[i] = *reinterpret_cast<const bf16x8*>(&sm[0][0][oa]);
+          al[i] = *reinterpret_cast<const bf16x8*>(&sm[0][1][oa]);
+          xh[i] = *reinterpret_cast<const bf16x8*>(&sm[1][0][ox]);
+          xl[i] = *reinterpret_cast<const bf16x8*>(&sm[1][1][ox]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], xh[j], acc[i][j], 0, 0, 0);
+          }
+        __syncthreads();
       }
     }
   }
+  // Epilogue.  With `accumulate` the old values are fetched 16 at a time from clamped addresses (no branch around a
+  // load: a bounds-checked read-modify-write per element makes every one of the 64 a separate round trip to memory).
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float old[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kcol = min(a.k0 + wk + j * 16 + fi, a.K - 1), nrow = min(a.n0 + wn + i * 16 + fq * 4 + q, a.N - 1);
+        old[j][q] = a.accumulate ? a.D[(long)nrow * a.ldd + kcol] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kcol = a.k0 + wk + j * 16 + fi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nrow = a.n0 + wn + i * 16 + fq * 4 + q;
+        if (nrow < a.N && kcol < a.K) a.D[(long)nrow * a.ldd + kcol] = acc[i][j][q] + old[j][q];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][kX3Plane];
+  const int mbeg = blockIdx.z * a.mchunk;
+  TnTile t{a.A, a.lda, a.X, a.ldx, a.D + (long)blockIdx.z * a.slab_stride, a.ldd, a.N, a.K, a.accumulate,
+           (int)blockIdx.y * 128, (int)blockIdx.x * 128, mbeg, min(a.Mt, mbeg + a.mchunk)};
+  tn_x3_tile(t, sm);
+}
+
+// Every weight gradient of a module in ONE launch: a workgroup finds its job from the prefix sums of the jobs' tile
+// counts (all jobs contract over the same Mt rows: the decoder's (steps x batch) stash rows).  The small products no
+// longer pay a launch + a row-split + a slab reduce each (7 launches of 14-21 us and 13 reduce launches per iteration).
+struct WgradJobs {
+  vln_wgrad_job j[VLN_WGRAD_MAX_JOBS];
+  int tile0[VLN_WGRAD_MAX_JOBS + 1];
+  int n, Mt;
+};
+__global__ __launch_bounds__(256) void wgrad_grouped_x3_kernel(WgradJobs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][kX3Plane];
+  int ji = 0;
+  while (ji + 1 < a.n && (int)blockIdx.x >= a.tile0[ji + 1]) ++ji;
+  const vln_wgrad_job& q = a.j[ji];
+  const int tile = (int)blockIdx.x - a.tile0[ji];
+  const int nbk = (q.K + 127) / 128;
+  TnTile t{q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.N, q.K, q.accumulate, (tile / nbk) * 128, (tile % nbk) * 128, 0, a.Mt};
+  tn_x3_tile(t, sm);
 }
 
 // D[r, c] (+)= sum_s slabs[s][r*cols + c]
@@ -517,35 +669,75 @@ static int reduce_slabs(hipStream_t st, const float* slabs, int nsplit, long sla
 }
 
 int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
-            int N, int K, int accumulate, float* ws, long ws_floats) {
+            int N, int K, int accumulate, float* ws, long ws_floats, int precision) {
   if (N <= 0 || K <= 0 || Mt < 0) { set_error("gemm_tn: bad dims"); return VLN_ERR_ARG; }
   GemmTNArgs a{A, lda, X, ldx, D, ldd, Mt, N, K, accumulate, 0, 0, 0, 0};
   a.avec = aligned16(A) && (lda % 4 == 0);
   a.xvec = aligned16(X) && (ldx % 4 == 0);
-  const int nbk = (K + 63) / 64, nbn = (N + 63) / 64;
-  // small outputs with a long contraction (encoder: Mt = L*B): split the rows over workgroups, slabs + reduce
+  // precision 1 (bf16 compute mode): split-bf16 MFMA form on 128 x 128 tiles, when the operands allow float4 columns
+  const bool x3 = precision == 1 && a.avec && a.xvec && (N % 4 == 0) && (K % 4 == 0) && Mt > 0 && g_tunable[6] != 1;
+  const int T = x3 ? 128 : 64, MS = x3 ? 32 : 32;
+  const int nbk = (K + T - 1) / T, nbn = (N + T - 1) / T;
+  // outputs with few tiles and a long contraction (encoder: Mt = L*B): split the rows over workgroups, slabs + reduce
   int msplit = 1;
   if (ws) {
-    msplit = 512 / (nbk * nbn);
+    msplit = (x3 ? 256 : 512) / (nbk * nbn);
     const int max_by_rows = Mt / 128;
     if (msplit > max_by_rows) msplit = max_by_rows;
     const long per = (long)N * K;
     if ((long)msplit * per > ws_floats) msplit = (int)(ws_floats / per);
     if (msplit < 1) msplit = 1;
   }
-  int mchunk = ((Mt + msplit - 1) / msplit + 31) / 32 * 32;
-  if (mchunk < 32) mchunk = 32;
+  int mchunk = ((Mt + msplit - 1) / msplit + MS - 1) / MS * MS;
+  if (mchunk < MS) mchunk = MS;
   msplit = (Mt + mchunk - 1) / mchunk;
   if (msplit < 1) msplit = 1;
   a.mchunk = mchunk;
   if (msplit > 1) { a.D = ws; a.ldd = K; a.slab_stride = (long)N * K; a.accumulate = 0; }
   dim3 grid(nbk, nbn, msplit), block(256);
   {
-    launch_timed(K_GEMM_TN, 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1)),
-                 gemm_tn_kernel, grid, block, 0, st, a);
+    const double bytes = 4.0 * ((double)Mt * N + (double)Mt * K + (double)N * K * (accumulate ? 2 : 1));
+    if (x3) launch_timed(K_GEMM_TN, bytes, gemm_tn_x3_kernel, grid, block, 0, st, a);
+    else launch_timed(K_GEMM_TN, bytes, gemm_tn_kernel, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("gemm_tn");
   if (msplit > 1) return reduce_slabs(st, ws, msplit, (long)N * K, D, ldd, N, K, accumulate);
+  return VLN_OK;
+}
+
+int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats) {
+  if (n <= 0 || Mt <= 0) { set_error("wgrad_grouped: bad args"); return VLN_ERR_ARG; }
+  bool ok = precision == 1 && g_tunable[6] != 1;
+  for (int i = 0; i < n && ok; ++i) {
+    const vln_wgrad_job& q = jobs[i];
+    ok = aligned16(q.dy) && aligned16(q.x) && (q.ld_dy % 4 == 0) && (q.ld_x % 4 == 0) && (q.N % 4 == 0) && (q.K % 4 == 0);
+  }
+  if (!ok) {       // exact fp32 form (or operands the grouped kernel does not take): one launch per product
+    for (int i = 0; i < n; ++i) {
+      const vln_wgrad_job& q = jobs[i];
+      int r = gemm_tn(st, q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, Mt, q.N, q.K, q.accumulate, ws, ws_floats, precision);
+      if (r != VLN_OK) return r;
+    }
+    return VLN_OK;
+  }
+  for (int base = 0; base < n; base += VLN_WGRAD_MAX_JOBS) {
+    WgradJobs a;
+    a.n = (n - base < VLN_WGRAD_MAX_JOBS) ? n - base : VLN_WGRAD_MAX_JOBS;
+    a.Mt = Mt;
+    int t = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < a.n; ++i) {
+      const vln_wgrad_job& q = jobs[base + i];
+      if (!q.dy || !q.x || !q.dw || q.N <= 0 || q.K <= 0) { set_error("wgrad_grouped: bad job %d", base + i); return VLN_ERR_ARG; }
+      a.j[i] = q;
+      a.tile0[i] = t;
+      t += ((q.N + 127) / 128) * ((q.K + 127) / 128);
+      bytes += 4.0 * ((double)Mt * q.N + (double)Mt * q.K + (double)q.N * q.K * (q.accumulate ? 2 : 1));
+    }
+    a.tile0[a.n] = t;
+    launch_timed(K_GEMM_TN, bytes, wgrad_grouped_x3_kernel, dim3(t), dim3(256), 0, st, a);
+  }
+  VLN_CHECK_LAUNCH("wgrad_grouped");
   return VLN_OK;
 }
 

@@ -6,6 +6,7 @@
 #include "common.h"
 
 struct vln_shadow_job;   // include/vln_hip.h
+struct vln_wgrad_job;
 
 namespace vln {
 
@@ -73,8 +74,12 @@ int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int w
                   int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats);
 
 // D[N,K] (+)= A[Mt,N]^T * X[Mt,K]   (weight gradients; contraction over rows)
+// precision 0: exact fp32 MFMA; 1: both operands split into bf16 hi + lo planes, three bf16 MFMAs, fp32 accumulation
 int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, float* D, long ldd, int Mt,
-            int N, int K, int accumulate, float* ws, long ws_floats);
+            int N, int K, int accumulate, float* ws, long ws_floats, int precision = 0);
+
+// every job's dW[N,K] (+)= dy[Mt,N]^T x[Mt,K] in one launch (precision 1) or one launch each (precision 0)
+int wgrad_grouped(hipStream_t st, const ::vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats);
 
 // out[c] (+)= sum_r A[r*lda + c]
 int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,

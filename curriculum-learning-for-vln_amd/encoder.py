@@ -91,12 +91,19 @@ class _EncoderFn(torch.autograd.Function):
         grads = {}
         pmap = dict(mod.named_parameters())
 
+        sb = mod.compute_dtype != torch.float32     # bf16 mode: weight gradients on the split-bf16 MFMA form
+
+        def wgrad(dy_, x_, out=None, accumulate=False):
+            return ops.linear_wgrad(dy_, x_, out, accumulate, sb)
+
         def put(name, fn, *args):
             """Form one gradient: straight into an existing contiguous .grad (e.g. a dp.GradBucket view, autograd
             then gets None) or into a fresh tensor handed to autograd."""
             p = pmap[name]
             if not p.requires_grad:
                 return
+            if fn is ops.linear_wgrad:
+                fn = wgrad
             g = p.grad
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 fn(*args, g, True)

@@ -243,19 +243,22 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
     def _issue_wgrads(self, runs, acc0, tgt):
         H, F, AE = self.hidden_size, self.feature_size, self.action_embed_size
         (g_aw, g_ab, g_vin, g_ih, g_hh, g_bih, g_bhh, g_tin, g_tout, g_c) = tgt
+        sb = self.compute_dtype != torch.float32       # bf16 mode: split-bf16 contractions (fp32 accumulation)
         for i, (bufs, r0, r1) in enumerate(runs):
             sl = slice(r0, r1)
             a = [x or i > 0 for x in acc0]      # the first run overwrites fresh buffers, everything else accumulates
-            ops.linear_wgrad(bufs["de"][sl], bufs["a"][sl], g_aw, a[0])
+            wb = ops.WgradBatch(sb)             # the seven products of a run: ONE launch in bf16 mode
+            wb.add(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, a[3])
+            wb.add(bufs["dtv"][sl], bufs["hq"][sl], g_vin, a[2])
+            wb.add(bufs["dtc"][sl], bufs["htd"][sl], g_c, a[9])
+            wb.add(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, a[4])
+            wb.add(bufs["dz"][sl], bufs["tcat"][sl], g_tout, a[8])
+            wb.add(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, a[7])
+            wb.add(bufs["de"][sl], bufs["a"][sl], g_aw, a[0])
+            wb.run()
             ops.colsum(bufs["de"][sl], g_ab, a[1])
-            ops.linear_wgrad(bufs["dtv"][sl], bufs["hq"][sl], g_vin, a[2])
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, :AE + F], g_ih, a[3])
-            ops.linear_wgrad(bufs["dgates"][sl], bufs["xcat"][sl][:, AE + F:], g_hh, a[4])
             ops.colsum(bufs["dgates"][sl], g_bih, a[5])
             ops.colsum(bufs["dgates"][sl], g_bhh, a[6])   # d b_hh == d b_ih (same pre-activation)
-            ops.linear_wgrad(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, a[7])
-            ops.linear_wgrad(bufs["dz"][sl], bufs["tcat"][sl], g_tout, a[8])
-            ops.linear_wgrad(bufs["dtc"][sl], bufs["htd"][sl], g_c, a[9])
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,

@@ -150,8 +150,9 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None):
     return out
 
 
-def linear_wgrad(dy, x, out=None, accumulate=False):
-    """dW[N,K] (+)= dy[Mt,N].T @ x[Mt,K]"""
+def linear_wgrad(dy, x, out=None, accumulate=False, split_bf16=False):
+    """dW[N,K] (+)= dy[Mt,N].T @ x[Mt,K].  split_bf16: both operands as bf16 hi + lo planes on the bf16 MFMA (three
+    products, fp32 accumulation) instead of the exact fp32 MFMA -- the bf16 compute mode's weight gradients."""
     lib = _lib.load()
     _req(dy, "dy"); _req(x, "x")
     Mt, N = dy.shape
@@ -161,8 +162,8 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
         out = torch.empty(N, K, dtype=torch.float32, device=x.device)   # a weight gradient: may become p.grad
         accumulate = False
     ws = workspace(x.device, 1 << 22)
-    _lib.check(lib.vln_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), Mt, N, K,
-                                    int(accumulate), _p(ws), ws.numel(), _stream()), "vln_linear_wgrad")
+    _lib.check(lib.vln_linear_wgrad_p(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), Mt, N, K,
+                                      int(accumulate), 1 if split_bf16 else 0, _p(ws), ws.numel(), _stream()), "vln_linear_wgrad_p")
     return out
 
 
@@ -225,6 +226,32 @@ class ShadowBatch:
         arr = (_lib.ShadowJob * len(self.jobs))(*self.jobs)
         _lib.check(_lib.load().vln_shadow_refresh(arr, len(self.jobs), _stream()), "vln_shadow_refresh")
         self.jobs, self.keep = [], []
+
+
+class WgradBatch:
+    """Collects dW (+)= dy.T @ x products over the SAME rows and issues them as one launch (`vln_wgrad_grouped`)."""
+
+    def __init__(self, split_bf16=False):
+        self.jobs, self.keep, self.Mt, self.split = [], [], None, split_bf16
+
+    def add(self, dy, x, out, accumulate=False):
+        _req(dy, "dy"); _req(x, "x"); _req(out, "out")
+        Mt, N = dy.shape
+        K = x.shape[1]
+        assert x.shape[0] == Mt and out.shape == (N, K) and (self.Mt is None or self.Mt == Mt)
+        self.Mt = Mt
+        self.jobs.append(_lib.WgradJob(dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.stride(0), x.stride(0), out.stride(0),
+                                       N, K, int(accumulate), 0))
+        self.keep += [dy, x, out]
+
+    def run(self):
+        if not self.jobs:
+            return
+        arr = (_lib.WgradJob * len(self.jobs))(*self.jobs)
+        ws = workspace(self.keep[0].device, 1 << 22)
+        _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, 1 if self.split else 0, _p(ws), ws.numel(),
+                                                 _stream()), "vln_wgrad_grouped")
+        self.jobs, self.keep, self.Mt = [], [], None
 
 
 def attn_dot(ctx, vec):

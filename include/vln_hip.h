@@ -56,6 +56,21 @@ int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_
 int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd, int Mt,
                      int N, int K, int accumulate, float* ws, int64_t ws_floats, vln_stream_t s);
 /* bias gradient: out[c] (+)= sum_r A[r, c]; ws (nullable) lets long contractions split over workgroups */
+/* Same contraction with a choice of arithmetic: precision 0 = exact fp32 MFMA (what vln_linear_wgrad does),
+ * 1 = both operands split into bf16 hi + lo planes, three bf16 MFMAs per product with fp32 accumulation
+ * (relative error 2^-16 per product; the bf16 compute mode's weight gradients). */
+int vln_linear_wgrad_p(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd, int Mt,
+                       int N, int K, int accumulate, int precision, float* ws, int64_t ws_floats, vln_stream_t s);
+/* All weight gradients of a module in one launch: job i forms dw[N,K] (+)= dy[Mt,N]^T x[Mt,K]; every job contracts
+ * over the same Mt rows (the rollout stash: steps x batch).  precision as in vln_linear_wgrad_p; with precision 0, or
+ * operands the grouped kernel does not take, it is one vln_linear_wgrad_p launch per job. */
+#define VLN_WGRAD_MAX_JOBS 16
+typedef struct vln_wgrad_job {
+  const float* dy; const float* x; float* dw;
+  int64_t ld_dy, ld_x, ld_dw;
+  int N, K, accumulate, pad_;
+} vln_wgrad_job;
+int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precision, float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */

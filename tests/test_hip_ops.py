@@ -46,7 +46,8 @@ def test_linear_fwd_strided_x(vln):
     assert rel_err(y, x.double() @ w.double().t()) < 1e-4
 
 
-@pytest.mark.parametrize("Mt,N,K", [(384, 2048, 2752), (64, 512, 512), (100, 48, 40), (5120, 96, 72), (3, 1, 5)])
+@pytest.mark.parametrize("Mt,N,K", [(384, 2048, 2752), (64, 512, 512), (100, 48, 40), (5120, 96, 72), (3, 1, 5), (448, 2176, 512),
+                                    (5120, 1024, 256), (77, 132, 260)])
 def test_linear_wgrad(vln, Mt, N, K):
     g = torch.Generator().manual_seed(Mt + N + K)
     dy = torch.randn(Mt, N, generator=g); x = torch.randn(Mt, K, generator=g)
@@ -57,6 +58,33 @@ def test_linear_wgrad(vln, Mt, N, K):
     assert rel_err(out2, 2 * ref) < 1e-4
     cs = vln.ops.colsum(dy.to(dev()))
     assert rel_err(cs, dy.double().sum(0)) < 1e-4
+    # split-bf16 form (bf16 compute mode): hi + lo planes of both operands, 2^-16 relative per product
+    o3 = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()), split_bf16=True)
+    assert rel_err(o3, ref) < 5e-5
+    o3b = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=o3, accumulate=True, split_bf16=True)
+    assert rel_err(o3b, 2 * ref) < 5e-5
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_wgrad_grouped(vln, split):
+    """All weight gradients of a module from one call (one launch in the split-bf16 form): the decoder's seven
+    products over the same (steps x batch) rows, strided operands, accumulate and overwrite mixed."""
+    g = torch.Generator().manual_seed(11)
+    Mt = 448
+    shapes = [(2048, 2240), (2176, 512), (2048, 512), (512, 1024), (512, 512), (64, 128), (132, 260)]
+    wb = vln.ops.WgradBatch(split)
+    refs, outs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = torch.randn(Mt, N + 4, generator=g).to(dev())[:, :N]
+        x = torch.randn(Mt, K + 8, generator=g).to(dev())[:, 4:4 + K]
+        acc = bool(i % 2)
+        out = torch.randn(N, K, generator=g).to(dev()) if acc else torch.empty(N, K, device=dev())
+        ref = dy.double().t() @ x.double() + (out.double() if acc else 0)
+        wb.add(dy, x, out, acc)
+        refs.append(ref); outs.append(out)
+    wb.run()
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < (5e-5 if split else 1e-5)
 
 
 @pytest.mark.parametrize("N,K", [(2048, 2752), (48, 40), (1, 7)])
