@@ -25,34 +25,46 @@ struct PrepArgs {
   float* a_stash;   // nullable: copy of `a` kept for the deferred act_embed weight gradient
 };
 // e = tanh(a W_a^T + b); xcat[:, :AE] = drop(e); xcat[:, AE+F:] = h_tilde_prev; hq = drop(h_tilde_prev)
+// Work items: B*AE dot products of length ANG, 8 lanes each (a lane group reads 128 contiguous bytes of the weight row
+// per step: whole cache lines, where one thread per output walked 64 rows x 16 B per wave instruction), then B*H/4
+// float4 copies of h_tilde_prev and B*ANG/4 of a_prev.
 __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
-  const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
-  const long na = p.a_stash ? (long)p.B * p.ANG : 0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh + na; i += (long)gridDim.x * blockDim.x) {
-    if (i >= ne + nh) {
-      p.a_stash[i - ne - nh] = p.a[i - ne - nh];
-    } else if (i < ne) {
-      const int b = (int)(i / p.AE), j = (int)(i % p.AE);
+  const long ne = (long)p.B * p.AE, nh4 = (long)p.B * p.H / 4;
+  const long na4 = p.a_stash ? (long)p.B * p.ANG / 4 : 0;
+  const long nitems = ne * 8 + nh4 + na4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
+    if (i < ne * 8) {                                  // ne*8 is a multiple of 64: a wave never straddles this branch
+      const long o = i >> 3;
+      const int sub = (int)(i & 7);
+      const int b = (int)(o / p.AE), j = (int)(o % p.AE);
       const float* a = p.a + (long)b * p.ANG;
       const float* w = p.act_w + (long)j * p.ANG;
-      // 16-byte loads, 4 independent accumulators (ANG % 4 == 0 is checked on the host)
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < p.ANG; k += 4) {
+      float acc = 0.f;
+      for (int k = sub * 4; k < p.ANG; k += 32) {
         const float4 x = *reinterpret_cast<const float4*>(a + k);
         const float4 y = *reinterpret_cast<const float4*>(w + k);
-        a0 += x.x * y.x; a1 += x.y * y.y; a2 += x.z * y.z; a3 += x.w * y.w;
+        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
       }
-      const float acc = p.act_b[j] + ((a0 + a1) + (a2 + a3));
-      const float e = tanhf(acc);
-      p.e[i] = e;
-      p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
-    } else {
-      const long k = i - ne;
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (sub == 0) {
+        const float e = tanhf(acc + p.act_b[j]);
+        p.e[o] = e;
+        p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)o, p.d_act.p);
+      }
+    } else if (i < ne * 8 + nh4) {
+      const long k4 = i - ne * 8;
+      const long k = k4 * 4;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
-      const float v = p.htp[k];
-      p.xcat[(long)b * p.ldx + p.AE + p.F + j] = v;
-      p.hq[k] = v * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
+      const float4 v = *reinterpret_cast<const float4*>(p.htp + k);
+      *reinterpret_cast<float4*>(p.xcat + (long)b * p.ldx + p.AE + p.F + j) = v;
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.d_h.p > 0.f) dropout_scale4(p.d_h.seed, p.d_h.off(), (uint32_t)k4, p.d_h.p, m);
+      *reinterpret_cast<float4*>(p.hq + k) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+    } else {
+      const long k = (i - ne * 8 - nh4) * 4;
+      *reinterpret_cast<float4*>(p.a_stash + k) = *reinterpret_cast<const float4*>(p.a + k);
     }
   }
 }
@@ -166,11 +178,16 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   if (lp && (!io->img_lp || !io->cand_lp || !io->ctx_lp)) { set_error("envdrop fwd: bf16 stream copies missing"); return VLN_ERR_ARG; }
   const float pf = io->already_dropfeat ? 0.f : io->p_feat;
 
+  {
+    const uintptr_t al = (uintptr_t)io->a_prev | (uintptr_t)io->h_tilde_prev | (uintptr_t)io->hq | (uintptr_t)io->xcat |
+                         (uintptr_t)io->a_stash | (uintptr_t)w->act_w;
+    if (al & 15) { set_error("envdrop fwd: a_prev, h_tilde_prev, hq, xcat, a_stash and act_w must be 16-byte aligned"); return VLN_ERR_ARG; }
+  }
   // (1) act embedding, h_tilde_prev copy + dropout            policy.py:224,234
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
               B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
               io->a_stash == io->a_prev ? nullptr : io->a_stash};
-  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * (AE + H + (pa.a_stash ? d->ANG : 0)))), dim3(256), 0, st, pa);
+  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep");
   // (2) environmental feature dropout, in place                policy.py:226-231
   // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)

@@ -632,17 +632,46 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(GemmTNArgs a) {
 struct WgradJobs {
   vln_wgrad_job j[VLN_WGRAD_MAX_JOBS];
   int tile0[VLN_WGRAD_MAX_JOBS + 1];
-  int n, Mt;
+  long slab0[VLN_WGRAD_MAX_JOBS];     // msplit > 1: offset of the job's first slab in ws (floats)
+  float* ws;
+  int n, Mt, msplit, mchunk, ntiles, per_xcd;
 };
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Tiles
+// that share an operand block (a row of tiles shares its dY columns) are numbered consecutively, so giving XCD x the
+// contiguous range [x*per_xcd, (x+1)*per_xcd) lets those re-reads hit that XCD's L2 instead of the fabric.
 __global__ __launch_bounds__(256) void wgrad_grouped_x3_kernel(WgradJobs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][kX3Plane];
+  const int lt = ((int)blockIdx.x & 7) * a.per_xcd + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= a.per_xcd || lt >= a.ntiles) return;
   int ji = 0;
-  while (ji + 1 < a.n && (int)blockIdx.x >= a.tile0[ji + 1]) ++ji;
+  while (ji + 1 < a.n && lt >= a.tile0[ji + 1]) ++ji;
   const vln_wgrad_job& q = a.j[ji];
-  const int tile = (int)blockIdx.x - a.tile0[ji];
+  const int tile = lt - a.tile0[ji];
   const int nbk = (q.K + 127) / 128;
-  TnTile t{q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.N, q.K, q.accumulate, (tile / nbk) * 128, (tile % nbk) * 128, 0, a.Mt};
+  const int mbeg = (int)blockIdx.y * a.mchunk;
+  TnTile t{q.dy, q.ld_dy, q.x, q.ld_x, q.dw, q.ld_dw, q.N, q.K, q.accumulate, (tile / nbk) * 128, (tile % nbk) * 128, mbeg,
+           min(a.Mt, mbeg + a.mchunk)};
+  if (a.msplit > 1) { t.D = a.ws + a.slab0[ji] + (long)blockIdx.y * q.N * q.K; t.ldd = q.K; t.accumulate = 0; }
   tn_x3_tile(t, sm);
+}
+// dw (+)= sum of the job's msplit slabs, every job in one launch (float4 columns: K % 4 == 0)
+__global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgradJobs a) {
+  for (int ji = 0; ji < a.n; ++ji) {
+    const vln_wgrad_job& q = a.j[ji];
+    const long total4 = (long)q.N * q.K / 4, per = (long)q.N * q.K;
+    const float* sl = a.ws + a.slab0[ji];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+      const long r = (e * 4) / q.K, c = (e * 4) % q.K;
+      float4 v = *reinterpret_cast<const float4*>(sl + e * 4);
+      for (int s = 1; s < a.msplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(sl + (long)s * per + e * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      float* d = q.dw + r * q.ld_dw + c;
+      if (q.accumulate) { v.x += d[0]; v.y += d[1]; v.z += d[2]; v.w += d[3]; }
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
 }
 
 // D[r, c] (+)= sum_s slabs[s][r*cols + c]
@@ -723,8 +752,9 @@ int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int 
   for (int base = 0; base < n; base += VLN_WGRAD_MAX_JOBS) {
     WgradJobs a;
     a.n = (n - base < VLN_WGRAD_MAX_JOBS) ? n - base : VLN_WGRAD_MAX_JOBS;
-    a.Mt = Mt;
+    a.Mt = Mt; a.ws = ws;
     int t = 0;
+    long elems = 0;
     double bytes = 0.0;
     for (int i = 0; i < a.n; ++i) {
       const vln_wgrad_job& q = jobs[base + i];
@@ -732,10 +762,32 @@ int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int 
       a.j[i] = q;
       a.tile0[i] = t;
       t += ((q.N + 127) / 128) * ((q.K + 127) / 128);
+      elems += (long)q.N * q.K;
       bytes += 4.0 * ((double)Mt * q.N + (double)Mt * q.K + (double)q.N * q.K * (q.accumulate ? 2 : 1));
     }
     a.tile0[a.n] = t;
-    launch_timed(K_GEMM_TN, bytes, wgrad_grouped_x3_kernel, dim3(t), dim3(256), 0, st, a);
+    a.ntiles = t;
+    a.per_xcd = (t + 7) / 8;
+    // few tiles, long contraction (the encoder: Mt = L*B rows): split the rows too, slabs in ws + one grouped reduce
+    int msplit = 1;
+    if (ws && t < 256) {
+      msplit = 256 / t;
+      if (msplit > Mt / 128) msplit = Mt / 128;
+      if ((long)msplit * elems > ws_floats) msplit = (int)(ws_floats / elems);
+      if (msplit < 1) msplit = 1;
+    }
+    int mchunk = ((Mt + msplit - 1) / msplit + 31) / 32 * 32;
+    msplit = (Mt + mchunk - 1) / mchunk;
+    a.msplit = msplit; a.mchunk = mchunk;
+    long off = 0;
+    for (int i = 0; i < a.n; ++i) { a.slab0[i] = off; off += (long)msplit * a.j[i].N * a.j[i].K; }
+    launch_timed(K_GEMM_TN, bytes, wgrad_grouped_x3_kernel, dim3(a.per_xcd * 8, msplit), dim3(256), 0, st, a);
+    if (msplit > 1) {
+      long b = (elems / 4 / a.n + 255) / 256;
+      if (b > 1024) b = 1024;
+      if (b < 1) b = 1;
+      hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+    }
   }
   VLN_CHECK_LAUNCH("wgrad_grouped");
   return VLN_OK;

@@ -137,13 +137,23 @@ class _EncoderFn(torch.autograd.Function):
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
+            wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode
             for d in range(dirs):
                 sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
                 dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
-                put("lstm.weight_hh" + sfx, ops.linear_wgrad, dg, hprev[d].view(L * B, Hd))
-                put("lstm.weight_ih" + sfx, ops.linear_wgrad, dg, x)
+                for name, xop in (("lstm.weight_hh" + sfx, hprev[d].view(L * B, Hd)), ("lstm.weight_ih" + sfx, x)):
+                    p = pmap[name]
+                    if not p.requires_grad:
+                        continue
+                    g = p.grad
+                    if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                        wb.add(dg, xop, g, True)
+                    else:
+                        grads[name] = torch.empty_like(p)
+                        wb.add(dg, xop, grads[name], False)
                 put("lstm.bias_ih" + sfx, ops.colsum, dg)
                 put("lstm.bias_hh" + sfx, ops.colsum, dg)     # both biases feed the same pre-activation
+            wb.run()
             need_dx = (k > 0) or mod.embedding.weight.requires_grad
             if need_dx:
                 dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])

@@ -248,7 +248,10 @@ class WgradBatch:
         if not self.jobs:
             return
         arr = (_lib.WgradJob * len(self.jobs))(*self.jobs)
-        ws = workspace(self.keep[0].device, 1 << 22)
+        # few output tiles + many rows (the encoder's L*B): the kernel also splits the rows and wants slab space
+        tiles = sum(((j.N + 127) // 128) * ((j.K + 127) // 128) for j in self.jobs)
+        msplit = max(1, min(256 // max(tiles, 1), self.Mt // 128))
+        ws = workspace(self.keep[0].device, max(1 << 22, msplit * sum(j.N * j.K for j in self.jobs)))
         _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, 1 if self.split else 0, _p(ws), ws.numel(),
                                                  _stream()), "vln_wgrad_grouped")
         self.jobs, self.keep, self.Mt = [], [], None

@@ -8,7 +8,7 @@ import torch, bench
 import vln_amd as vln
 dev = torch.device('cuda:0')
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
-agent = bench.GpuAgent(vln, dev, dtype, 1)
+agent = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
 tape = bench.tape_to(bench.make_tape(64, 80, 7, 8, 2020), dev, store_dtype=dtype)
 for _ in range(5): agent.iteration(tape)
 torch.cuda.synchronize()
