@@ -291,8 +291,7 @@ int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, fl
   AttnFusedArgs a{ctx, vec, vec_out, ldvo, mask, attn, nullptr, nullptr, out, ldo, S, D};
   if (attn_fused_try(st, ctype, a, B, false)) { VLN_CHECK_LAUNCH("attn_fused_fwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_fwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
-  if (vec.n > 1 || vec_out) {           // the two-kernel path wants a finished vector
-    if (!vec_out) { set_error("attn_fwd_rows: slab input on the two-kernel path needs vec_out"); return VLN_ERR_ARG; }
+  if (vec_out) {                        // the caller wants the finished vector: sum the slabs into it first
     int r0 = reduce_epilogue(st, vec.p, vec.n, vec.stride, vec.ld, vec_out, ldvo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
     if (r0 != VLN_OK) return r0;
     vec = plain_vec(vec_out, ldvo);
@@ -313,8 +312,7 @@ int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* at
   AttnFusedArgs a{ctx, dwc, dwc_out, lddo, nullptr, const_cast<float*>(attn), dattn_ext, dl_out, dvec, lddvec, S, D};
   if (attn_fused_try(st, ctype, a, B, true)) { VLN_CHECK_LAUNCH("attn_fused_bwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_bwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
-  if (dwc.n > 1 || dwc_out) {
-    if (!dwc_out) { set_error("attn_bwd_rows: slab input on the two-kernel path needs dwc_out"); return VLN_ERR_ARG; }
+  if (dwc_out) {
     int r0 = reduce_epilogue(st, dwc.p, dwc.n, dwc.stride, dwc.ld, dwc_out, lddo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
     if (r0 != VLN_OK) return r0;
     dwc = plain_vec(dwc_out, lddo);

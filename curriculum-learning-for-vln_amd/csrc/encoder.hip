@@ -444,12 +444,14 @@ static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
 
 template <typename TW>
 static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
+  const dim3 g1(grid.x * grid.y * grid.z);          // one-dimensional: the kernel decodes (slice, direction, row block)
+  const int xm = g_tunable[7] != 1;                 // tunable[7] = 1: dispatch-order mapping (A/B)
   constexpr int BK = RecCfg<TW>::BK;
   switch (a.Hd / BK) {
-    case 2: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 2>), grid, dim3(256), 0, st, a, counters, status); break;
-    case 4: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 4>), grid, dim3(256), 0, st, a, counters, status); break;
-    case 8: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 8>), grid, dim3(256), 0, st, a, counters, status); break;
-    case 16: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 16>), grid, dim3(256), 0, st, a, counters, status); break;
+    case 2: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 2>), g1, dim3(256), 0, st, a, counters, status, xm); break;
+    case 4: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 4>), g1, dim3(256), 0, st, a, counters, status, xm); break;
+    case 8: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 8>), g1, dim3(256), 0, st, a, counters, status, xm); break;
+    case 16: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 16>), g1, dim3(256), 0, st, a, counters, status, xm); break;
     default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
   }
   VLN_CHECK_LAUNCH("lstm_persist_fwd");
@@ -458,10 +460,12 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
 
 template <typename TW>
 static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid) {
+  const dim3 g1(grid.x * grid.y * grid.z);
+  const int xm = g_tunable[7] != 1;
   switch (a.Hd / 64) {
-    case 2: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 2>), grid, dim3(256), 0, st, a, counters, status, exch); break;
-    case 4: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 4>), grid, dim3(256), 0, st, a, counters, status, exch); break;
-    case 8: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 8>), grid, dim3(256), 0, st, a, counters, status, exch); break;
+    case 2: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 2>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
+    case 4: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 4>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
+    case 8: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 8>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
     default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
   }
   VLN_CHECK_LAUNCH("lstm_persist_bwd");

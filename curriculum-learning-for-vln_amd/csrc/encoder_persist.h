@@ -43,6 +43,19 @@ constexpr int kSyncHeaderBytes = 8192;    // status word at byte 128, flag lines
 #ifndef VLN_SYNC_FLAGS
 #define VLN_SYNC_FLAGS 0
 #endif
+// Workgroup -> (hidden slice jb, direction d, row block bb).  The grid is one-dimensional; workgroups are dealt to the 8
+// XCDs round-robin, so with xcd_map the 16 workgroups of one dependency group (same d, bb: they exchange hidden state
+// every step) get ids congruent mod (number of groups) and land on ONE XCD when there are 8 groups: their hand-off
+// loads then meet the producer's write-through stores in that XCD's L2 instead of crossing the fabric.  Placement is a
+// speed matter only -- the protocol (sc1 stores, counters, sc1 loads) does not assume it.
+struct PersistIdx { int jb, d, bb, nbb; };
+__device__ __forceinline__ PersistIdx persist_index(int njb, int dirs, int nbb, int xcd_map) {
+  const int id = (int)blockIdx.x, ngrp = dirs * nbb;
+  int g, jb;
+  if (xcd_map) { g = id % ngrp; jb = id / ngrp; } else { jb = id % njb; g = id / njb; }
+  return PersistIdx{jb, g % dirs, g / dirs, nbb};
+}
+
 __device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned epoch, unsigned* status, int* s_abort) {
   if (threadIdx.x < 64 && !*s_abort) {
     const int lane = threadIdx.x;
@@ -138,7 +151,7 @@ __device__ __forceinline__ void mfma_resident(const float* arow, const WFrag<TW,
 // forward: NS = Hd / BK
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NS>
-__global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, unsigned* counters, unsigned* status) {
+__global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, unsigned* counters, unsigned* status, int xcd_map) {
   constexpr int HD = NS * RecCfg<TW>::BK;
   constexpr int LDH = HD + 4;
   __shared__ __attribute__((aligned(16))) float sh[16 * LDH];
@@ -146,11 +159,12 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const int j0 = blockIdx.x * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const int j0 = ix.jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
-  const int njb = (int)gridDim.x;
+  const int njb = HD / 16;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
-  unsigned* cnt = counters + (d * gridDim.z + blockIdx.z) * 32;      // this group's flag line
+  unsigned* cnt = counters + (d * ix.nbb + ix.bb) * 32;      // this group's flag line
 
   WFrag<TW, NS> w;
   load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
     }
     VLN_STAMP(4);
 #if VLN_FWD_LATE_STORES
-    group_arrive(cnt, blockIdx.x, (unsigned)step + 1u);
+    group_arrive(cnt, ix.jb, (unsigned)step + 1u);
     VLN_STAMP(5);
 #endif
     if (live) {   // saved for BPTT / the layer output: read only after this launch
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
       if (step == 0 && !a.init) a.hprev[(sbase + b) * HD + j] = 0.f;
     }
 #if !VLN_FWD_LATE_STORES
-    group_arrive(cnt, blockIdx.x, (unsigned)step + 1u);
+    group_arrive(cnt, ix.jb, (unsigned)step + 1u);
     VLN_STAMP(5);
 #endif
   }
@@ -315,7 +329,7 @@ __host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int d
 }
 
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
-__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, float* exch) {
+__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, float* exch, int xcd_map) {
   constexpr int HD = NT * 64;
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
   constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
@@ -326,10 +340,11 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const int jb = blockIdx.x, j0 = jb * 16, d = blockIdx.y, b0 = blockIdx.z * 16;
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
-  unsigned* cnt = counters + (d * gridDim.z + blockIdx.z) * 32;      // this group's flag line
+  unsigned* cnt = counters + (d * ix.nbb + ix.bb) * 32;      // this group's flag line
 
   // resident slice of W_hh: rows = this workgroup's 64 gate columns, all HD input units; read from the transposed
   // shadow [unit n][4*HD] where each gate's 16 columns are contiguous
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   const int len = live ? a.lengths[b] : 0;
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
   float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
-  const long grp = (long)(d * gridDim.z + blockIdx.z) * 2;          // [grp + parity][producer][unit][row]
+  const long grp = (long)(d * ix.nbb + ix.bb) * 2;          // [grp + parity][producer][unit][row]
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       exch, 0, (unsigned)(persist_bwd_exchange_floats(B, HD, a.dirs) * 4), 0x00020000);
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work

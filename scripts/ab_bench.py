@@ -17,13 +17,14 @@ tape_t = bench.tape_to(cpu_tape, dev)
 tape_s = bench.tape_to(cpu_tape, dev, store_dtype=dtype)
 lib = vln._lib.load()
 
-VARIANTS = {   # (persistent, graphs, split target, no-split rule, n16 kernel, n16 max K, two-kernel attention, gemm prefetch depth 1)
-    "base": (1, 1, 256, 1, 1, 512, 0, 0),
-    "gemm_pd1": (1, 1, 256, 1, 1, 512, 0, 1),
-    "attn_two_kernels": (1, 1, 256, 1, 1, 512, 1, 0),
-    "n16_off": (1, 1, 256, 1, 0, 0, 0, 0),
-    "target512": (1, 1, 512, 1, 1, 512, 0, 0),
-    "n16_off_target512": (1, 1, 512, 1, 0, 0, 0, 0),
+# variant -> {tunable id: value} on top of the defaults (vln_set_tunable; see csrc/vln_internal.h)
+DEFAULT_TUN = {0: 256, 1: 1, 2: 1, 3: 512, 4: 0, 5: 0, 6: 0, 7: 0}
+VARIANTS = {
+    "base": {},
+    "lstm_dispatch_order_map": {7: 1},
+    "attn_two_kernels": {4: 1},
+    "wgrad_fp32_exact": {6: 1},
+    "gemm_split_target512": {0: 512},
 }
 torch.manual_seed(0)
 agent = bench.GpuAgent(vln, dev, dtype, 1)
@@ -34,8 +35,11 @@ def configure(cfg, name=""):
     want = not name.startswith("noarena")
     if want != (agent.arena is not None):
         agent.use_arena(want)
-    lib.vln_set_persistent(cfg[0]); lib.vln_set_graphs(cfg[1]); lib.vln_set_tunable(0, cfg[2]); lib.vln_set_tunable(1, cfg[3]); lib.vln_set_tunable(2, cfg[4]); lib.vln_set_tunable(3, cfg[5])
-    lib.vln_set_tunable(4, cfg[6]); lib.vln_set_tunable(5, cfg[7])
+    lib.vln_set_persistent(0 if name == "per_step_lstm" else 1)
+    lib.vln_set_graphs(0 if name == "no_graphs" else 1)
+    tun = dict(DEFAULT_TUN); tun.update(cfg)
+    for k, v in tun.items():
+        lib.vln_set_tunable(k, v)
 
 
 times = {n: [] for n in VARIANTS}
@@ -54,7 +58,7 @@ for r in range(rounds):
             agent.iteration(tape_t if n == 'tensor_features' else tape_s)
         torch.cuda.synchronize()
         times[n].append((time.perf_counter() - t0) / 10 * 1e3)
-configure(VARIANTS["base"])
+configure(VARIANTS["base"], "base")
 for n, v in times.items():
     print(f"{n:22s} median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
 import ctypes
