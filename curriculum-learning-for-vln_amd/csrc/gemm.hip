@@ -734,6 +734,229 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
   return VLN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Packed form of the grouped weight gradients (the default for precision 1).
+//   pass 1  wgrad_pack_kernel: every operand matrix [Mt, C] fp32 -> two bf16 planes (hi, lo) in MFMA-FRAGMENT order:
+//           block (column tile ct of 16, row step ms of 32) = 64 lanes x 16 B, lane (fi, fq) = column 16 ct + fi, rows
+//           32 ms + 8 fq .. +8.  Blocks of one column tile are consecutive over ms.  Each element is converted ONCE
+//           (the LDS-staged kernel converts it again in every tile that re-reads it: 18x for the LSTM's dgates).
+//   pass 2  wgrad_packed_kernel: a wave's fragment for (tile, step) is ONE coalesced 1 KiB load straight into the
+//           registers the MFMA reads -- no LDS, no barrier, no conversion; waves run independently with the next
+//           step's 16 loads in flight behind the current step's 48 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+struct PackJob { const float* src; long ld; int C; long dst; };       // dst: byte offset of the hi plane in the pack area
+struct PackJobs {
+  PackJob j[2 * VLN_WGRAD_MAX_JOBS];
+  int blk0[2 * VLN_WGRAD_MAX_JOBS + 1];
+  unsigned char* area; int n, Mt, MS;
+};
+__device__ __forceinline__ long pack_plane_bytes(int C, int MS) { return (long)((C + 15) / 16) * MS * 1024; }
+__global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
+  int ji = 0;
+  while (ji + 1 < a.n && (int)blockIdx.x >= a.blk0[ji + 1]) ++ji;
+  const PackJob q = a.j[ji];
+  const int blk = (int)blockIdx.x - a.blk0[ji];
+  const int ncb = (q.C + 127) / 128;
+  const int cb = blk % ncb, rb = blk / ncb;                       // 128 columns x 64 rows per workgroup
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127, cg = t & 31, mq = t >> 5;
+  const int ms = rb * 2 + half;
+  if (ms >= a.MS) return;
+  const int col = cb * 128 + cg * 4;
+  if (col >= ((q.C + 15) & ~15)) return;                          // beyond the last (zero-padded) column tile
+  const bool col_ok = col < q.C;                                  // C % 4 == 0
+  const float* pc = q.src + (col_ok ? col : 0);
+  float4 r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = ms * 32 + mq * 8 + i;
+    const float4 v = *reinterpret_cast<const float4*>(pc + (long)min(m, a.Mt - 1) * q.ld);
+    const bool ok = col_ok && m < a.Mt;
+    r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  }
+  unsigned char* hi = a.area + q.dst;
+  unsigned char* lo = hi + pack_plane_bytes(q.C, a.MS);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = (c == 0) ? r[i].x : (c == 1) ? r[i].y : (c == 2) ? r[i].z : r[i].w;
+      h[i] = (__bf16)v;
+      l[i] = (__bf16)(v - (float)h[i]);
+    }
+    const int column = col + c;
+    const long off = (((long)(column >> 4) * a.MS + ms) * 64 + (mq * 16 + (column & 15))) * 16;
+    *reinterpret_cast<bf16x8*>(hi + off) = h;
+    *reinterpret_cast<bf16x8*>(lo + off) = l;
+  }
+}
+
+#ifndef VLN_WGRAD_PACKED_BUFS
+#define VLN_WGRAD_PACKED_BUFS 2
+#endif
+struct PackedJobs {
+  vln_wgrad_job j[VLN_WGRAD_MAX_JOBS];
+  long pa[VLN_WGRAD_MAX_JOBS], px[VLN_WGRAD_MAX_JOBS];   // byte offsets of the packed dy / x operands (hi plane)
+  int tile0[VLN_WGRAD_MAX_JOBS + 1];
+  long slab0[VLN_WGRAD_MAX_JOBS];
+  unsigned char* area; float* ws;
+  int n, Mt, MS, msplit, schunk, ntiles, per_xcd;          // schunk: row steps per split
+};
+__global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) {
+  const int lt = ((int)blockIdx.x & 7) * a.per_xcd + ((int)blockIdx.x >> 3);       // XCD-aware tile order
+  if (((int)blockIdx.x >> 3) >= a.per_xcd || lt >= a.ntiles) return;
+  int ji = 0;
+  while (ji + 1 < a.n && lt >= a.tile0[ji + 1]) ++ji;
+  const vln_wgrad_job& q = a.j[ji];
+  const int tile = lt - a.tile0[ji];
+  const int nbk = (q.K + 127) / 128;
+  const int n0 = (tile / nbk) * 128, k0 = (tile % nbk) * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fi = lane & 15, fq = lane >> 4;
+  const int wn = n0 + (wave >> 1) * 64, wk = k0 + (wave & 1) * 64;
+  const int s_beg = (int)blockIdx.y * a.schunk, s_end = min(a.MS, s_beg + a.schunk);
+  const int nct = (q.N + 15) / 16, kct = (q.K + 15) / 16;
+  const unsigned char* Ah = a.area + a.pa[ji];
+  const unsigned char* Al = Ah + pack_plane_bytes(q.N, a.MS);
+  const unsigned char* Xh = a.area + a.px[ji];
+  const unsigned char* Xl = Xh + pack_plane_bytes(q.K, a.MS);
+  long oa[4], ox[4];                       // per-fragment base offsets (column tiles past the edge are clamped: their
+#pragma unroll                             // products land in rows / columns the epilogue does not write)
+  for (int i = 0; i < 4; ++i) {
+    oa[i] = ((long)min(wn / 16 + i, nct - 1) * a.MS * 64 + lane) * 16;
+    ox[i] = ((long)min(wk / 16 + i, kct - 1) * a.MS * 64 + lane) * 16;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NB = VLN_WGRAD_PACKED_BUFS;      // 2: next step's fragments load behind this step's MFMAs (256 VGPRs, one
+                                                 // workgroup per CU); 1: half the registers, co-resident workgroups overlap instead
+  bf16x8 ah[NB][4], al[NB][4], xh[NB][4], xl[NB][4];
+  auto load = [&](int buf, int ms) {
+    const long so = (long)ms * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[buf][i] = *reinterpret_cast<const bf16x8*>(Ah + oa[i] + so);
+      al[buf][i] = *reinterpret_cast<const bf16x8*>(Al + oa[i] + so);
+      xh[buf][i] = *reinterpret_cast<const bf16x8*>(Xh + ox[i] + so);
+      xl[buf][i] = *reinterpret_cast<const bf16x8*>(Xl + ox[i] + so);
+    }
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xl[buf][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
+      }
+  };
+  if constexpr (NB == 2) {
+    if (s_beg < s_end) load(0, s_beg);
+    for (int ms = s_beg; ms < s_end; ms += 2) {
+      if (ms + 1 < s_end) load(NB - 1, ms + 1);
+      mma(0);
+      if (ms + 1 < s_end) {
+        if (ms + 2 < s_end) load(0, ms + 2);
+        mma(NB - 1);
+      }
+    }
+  } else {
+    for (int ms = s_beg; ms < s_end; ++ms) { load(0, ms); mma(0); }
+  }
+  float* D = q.dw; long ldd = q.ld_dw; int accumulate = q.accumulate;
+  if (a.msplit > 1) { D = a.ws + a.slab0[ji] + (long)blockIdx.y * q.N * q.K; ldd = q.K; accumulate = 0; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float old[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kcol = min(wk + j * 16 + fi, q.K - 1), nrow = min(wn + i * 16 + fq * 4 + r, q.N - 1);
+        old[j][r] = accumulate ? D[(long)nrow * ldd + kcol] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kcol = wk + j * 16 + fi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nrow = wn + i * 16 + fq * 4 + r;
+        if (nrow < q.N && kcol < q.K) D[(long)nrow * ldd + kcol] = acc[i][j][r] + old[j][r];
+      }
+    }
+  }
+}
+
+// bytes of workspace the packed path wants for these jobs (pack area + row-split slabs)
+static long wgrad_packed_ws_floats(const vln_wgrad_job* jobs, int n, int Mt, int* msplit_out, long* area_floats_out) {
+  const int MS = (Mt + 31) / 32;
+  long area = 0, elems = 0;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    area += 2L * (((jobs[i].N + 15) / 16) + ((jobs[i].K + 15) / 16)) * MS * 1024;
+    elems += (long)jobs[i].N * jobs[i].K;
+    tiles += ((jobs[i].N + 127) / 128) * ((jobs[i].K + 127) / 128);
+  }
+  int msplit = 1;
+  if (tiles < 256) { msplit = 256 / tiles; if (msplit > MS / 4) msplit = MS / 4; if (msplit < 1) msplit = 1; }
+  if (msplit_out) *msplit_out = msplit;
+  if (area_floats_out) *area_floats_out = area / 4;
+  return area / 4 + (msplit > 1 ? (long)msplit * elems : 0);
+}
+
+static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats) {
+  const int MS = (Mt + 31) / 32;
+  int msplit = 1; long area_floats = 0;
+  const long need = wgrad_packed_ws_floats(jobs, n, Mt, &msplit, &area_floats);
+  if (need > ws_floats || !aligned16(ws)) return -1;                 // caller falls back to the LDS-staged kernel
+  PackJobs pk; PackedJobs g;
+  pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0;
+  g.area = pk.area; g.ws = ws + area_floats; g.Mt = Mt; g.MS = MS; g.n = n;
+  long off = 0; int blk = 0, t = 0; long slab = 0;
+  double bytes = 0.0;
+  const int rblocks = (MS + 1) / 2;
+  auto add_pack = [&](const float* src, long ld, int C) -> long {
+    for (int i = 0; i < pk.n; ++i)                                    // an operand shared by two products is packed once
+      if (pk.j[i].src == src && pk.j[i].ld == ld && pk.j[i].C == C) return pk.j[i].dst;
+    PackJob& q = pk.j[pk.n];
+    q.src = src; q.ld = ld; q.C = C; q.dst = off;
+    pk.blk0[pk.n] = blk;
+    blk += ((C + 127) / 128) * rblocks;
+    off += 2L * ((C + 15) / 16) * MS * 1024;
+    pk.n++;
+    return q.dst;
+  };
+  for (int i = 0; i < n; ++i) {
+    g.j[i] = jobs[i];
+    g.pa[i] = add_pack(jobs[i].dy, jobs[i].ld_dy, jobs[i].N);
+    g.px[i] = add_pack(jobs[i].x, jobs[i].ld_x, jobs[i].K);
+    g.tile0[i] = t;
+    t += ((jobs[i].N + 127) / 128) * ((jobs[i].K + 127) / 128);
+    g.slab0[i] = slab; slab += (long)msplit * jobs[i].N * jobs[i].K;
+    bytes += 4.0 * ((double)Mt * jobs[i].N + (double)Mt * jobs[i].K + (double)jobs[i].N * jobs[i].K * (jobs[i].accumulate ? 2 : 1));
+  }
+  pk.blk0[pk.n] = blk;
+  g.tile0[n] = t; g.ntiles = t; g.per_xcd = (t + 7) / 8;
+  g.schunk = (MS + msplit - 1) / msplit;
+  g.msplit = (MS + g.schunk - 1) / g.schunk;
+  hipLaunchKernelGGL(wgrad_pack_kernel, dim3(blk), dim3(256), 0, st, pk);
+  launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
+  if (g.msplit > 1) {
+    WgradJobs r;
+    r.n = n; r.Mt = Mt; r.ws = g.ws; r.msplit = g.msplit;
+    long elems = 0;
+    for (int i = 0; i < n; ++i) { r.j[i] = jobs[i]; r.slab0[i] = g.slab0[i]; elems += (long)jobs[i].N * jobs[i].K; }
+    long b = (elems / 4 / n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, r);
+  }
+  return (int)check_hip(hipGetLastError(), "wgrad_grouped_packed");
+}
+
 int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats) {
   if (n <= 0 || Mt <= 0) { set_error("wgrad_grouped: bad args"); return VLN_ERR_ARG; }
   bool ok = precision == 1 && g_tunable[6] != 1;
@@ -748,6 +971,10 @@ int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int 
       if (r != VLN_OK) return r;
     }
     return VLN_OK;
+  }
+  if (n <= VLN_WGRAD_MAX_JOBS && g_tunable[6] != 2) {      // tunable[6] = 2: LDS-staged grouped kernel (A/B)
+    const int r = wgrad_grouped_packed(st, jobs, n, Mt, ws, ws_floats);
+    if (r >= 0) return r;
   }
   for (int base = 0; base < n; base += VLN_WGRAD_MAX_JOBS) {
     WgradJobs a;

@@ -248,10 +248,13 @@ class WgradBatch:
         if not self.jobs:
             return
         arr = (_lib.WgradJob * len(self.jobs))(*self.jobs)
-        # few output tiles + many rows (the encoder's L*B): the kernel also splits the rows and wants slab space
+        # workspace of the packed form: both bf16 planes of every operand in fragment order + (few output tiles, many
+        # rows: the encoder's L*B) the slabs of a row split
+        MS = (self.Mt + 31) // 32
         tiles = sum(((j.N + 127) // 128) * ((j.K + 127) // 128) for j in self.jobs)
-        msplit = max(1, min(256 // max(tiles, 1), self.Mt // 128))
-        ws = workspace(self.keep[0].device, max(1 << 22, msplit * sum(j.N * j.K for j in self.jobs)))
+        msplit = max(1, min(256 // max(tiles, 1), MS // 4)) if tiles < 256 else 1
+        area = sum(2 * ((j.N + 15) // 16 + (j.K + 15) // 16) * MS * 1024 for j in self.jobs) // 4
+        ws = workspace(self.keep[0].device, max(1 << 22, area + (msplit * sum(j.N * j.K for j in self.jobs) if msplit > 1 else 0)))
         _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, 1 if self.split else 0, _p(ws), ws.numel(),
                                                  _stream()), "vln_wgrad_grouped")
         self.jobs, self.keep, self.Mt = [], [], None
