@@ -133,10 +133,10 @@ class GpuAgent:
         lp = self.dtype != torch.float32
         pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
         # bf16 decoder: only the bf16 rows exist (nothing on this path reads fp32 features)
-        r1 = store.gather_pano(s["rows"], s["vidx"], pf, want_bf16=lp, want_f32=not lp)
-        r2 = store.gather_cands(s["crow"], s["cview"], s["chead"], s["celev"], pf, want_bf16=lp, want_f32=not lp)
+        (img, img_lp), (cand, cand_lp), _ = store.gather_step(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"],
+                                                              pf, want_bf16=lp, want_f32=not lp)
         kw = dict(already_dropfeat=True)
-        return (r1[1], r2[1], kw) if lp else (r1[0], r2[0], kw)
+        return (img_lp, cand_lp, kw) if lp else (img, cand, kw)
 
     def iteration(self, tape):
         self.vln.ops.set_arena(self.arena)

@@ -88,6 +88,8 @@ SIGNATURES = {
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_cands": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
+    "vln_gather_step": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, u64, u64, u64,
+                              f32, ptr]),
     "vln_embed_fwd": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr]),
     "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),

@@ -119,6 +119,28 @@ class DeviceFeatureStore:
         return (out, lp, (seed, off)) if want_bf16 else (out, (seed, off))
 
 
+    def gather_step(self, rows, view_index, crows, cviews, heading, elevation, p_feat: float = 0.0,
+                    want_bf16: bool = False, want_f32: bool = True):
+        """gather_pano + gather_cands of one decoder step as ONE launch -> ((img, img_bf16), (cand, cand_bf16),
+        ((seed, off_pano), (seed, off_cand))); entries not asked for are None."""
+        lib = _lib.load()
+        B, C = crows.shape
+        F = self.IMG + self.ANG
+        f32 = want_f32 or not want_bf16
+        dev = self.device
+        img = ops.empty(B, self.V, F, dtype=torch.float32, device=dev) if f32 else None
+        cand = ops.empty(B, C, F, dtype=torch.float32, device=dev) if f32 else None
+        img_lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+        cand_lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+        seed, off1, p = self._drop(p_feat)
+        _, off2, _ = self._drop(p_feat)
+        _lib.check(lib.vln_gather_step(_p(self.table), ops._dt(self.table), _p(self.angle_table), _p(rows), _p(view_index),
+                                       _p(crows.contiguous()), _p(cviews.contiguous()), _p(heading.contiguous()),
+                                       _p(elevation.contiguous()), _p(img), _p(img_lp), _p(cand), _p(cand_lp), B, self.V, C,
+                                       self.IMG, self.ANG, seed, off1, off2, p, _lib.raw_stream()), "vln_gather_step")
+        return (img, img_lp), (cand, cand_lp), ((seed, off1), (seed, off2))
+
+
 class PinnedStager:
     """Ring of pinned host buffers + a copy stream.  `put(name->array)` returns device tensors that are ordered
     after the async copy on the CURRENT stream; the slot is recycled `depth` calls later."""

@@ -173,6 +173,12 @@ int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int
 int vln_gather_cands(const void* table, int ttype, const int64_t* rows, const int32_t* views, const float* heading,
                      const float* elevation, float* out, void* out_bf16, int BC, int V, int IMG, int ANG, uint64_t seed,
                      uint64_t offset, float p_feat, vln_stream_t s);
+/* Both gathers of a decoder step in ONE launch (same outputs, same dropout indexing: site offsets offset_pano /
+ * offset_cand are what vln_gather_pano / vln_gather_cands would have been given). */
+int vln_gather_step(const void* table, int ttype, const float* angle_table, const int64_t* rows, const int32_t* view_index,
+                    const int64_t* crows, const int32_t* cviews, const float* heading, const float* elevation, float* out,
+                    void* out_bf16, float* cout, void* cout_bf16, int B, int V, int C, int IMG, int ANG, uint64_t seed,
+                    uint64_t offset_pano, uint64_t offset_cand, float p_feat, vln_stream_t s);
 
 /* ---- EncoderLSTM pieces (units.py:48-74) ------------------------------------------------------------
  * Internal layout is TIME-major: row (t*B + b).  nn.Embedding + Dropout -> vln_embed_fwd; the input projection

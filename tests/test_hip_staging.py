@@ -62,6 +62,27 @@ def test_store_feature_dropout_uses_the_philox_stream(vln):
     assert abs((m > 0).float().mean().item() - 0.7) < 0.01
 
 
+@pytest.mark.parametrize("tdt", [torch.float32, torch.bfloat16])
+def test_gather_step_is_both_gathers_in_one_launch(vln, tdt):
+    """vln_gather_step == vln_gather_pano + vln_gather_cands with the same Philox positions, bit for bit (fp32 rows,
+    bf16 rows, dropped elements, STOP / padding rows)."""
+    g = torch.Generator().manual_seed(12)
+    table, rows, vidx, crow, cview, head, elev = _problem(g)
+    store = vln.DeviceFeatureStore(table, device=DEV, dtype=tdt)
+    d = lambda t: t.to(DEV)
+    a = store.gather_pano(d(rows), d(vidx), 0.3, want_bf16=True)
+    b = store.gather_cands(d(crow), d(cview), d(head), d(elev), 0.3, want_bf16=True)
+    store._calls -= 2
+    (img, img_lp), (cand, cand_lp), (k1, k2) = store.gather_step(d(rows), d(vidx), d(crow), d(cview), d(head), d(elev), 0.3,
+                                                                want_bf16=True)
+    assert k1 == a[2] and k2 == b[2]
+    assert torch.equal(img, a[0]) and torch.equal(img_lp, a[1]) and torch.equal(cand, b[0]) and torch.equal(cand_lp, b[1])
+    store._calls -= 2
+    (i2, i2lp), (c2, c2lp), _ = store.gather_step(d(rows), d(vidx), d(crow), d(cview), d(head), d(elev), 0.3, want_bf16=True,
+                                                  want_f32=False)
+    assert i2 is None and c2 is None and torch.equal(i2lp, a[1]) and torch.equal(c2lp, b[1])
+
+
 def test_bf16_only_gather_feeds_the_decoder_like_fp32_rows_plus_copy(vln):
     """gather_*(want_f32=False): the bf16 rows alone, bit-identical to the bf16 copy of the full gather, and a bf16
     EnvDropDecoder given them as `img_feature` / `cand_feature` computes exactly what it computes from fp32 rows + copies."""
