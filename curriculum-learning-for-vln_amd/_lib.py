@@ -47,6 +47,10 @@ class WgradJob(C.Structure):
                 ("N", i32), ("K", i32), ("accumulate", i32), ("pad_", i32)]
 
 
+class ColsumJob(C.Structure):
+    _fields_ = [("A", ptr), ("out1", ptr), ("out2", ptr), ("lda", i64), ("cols", i32), ("accumulate", i32)]
+
+
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
                                    "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat")]
@@ -66,6 +70,7 @@ SIGNATURES = {
     "vln_linear_wgrad_p": (i32, [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_wgrad_grouped": (i32, [ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
+    "vln_colsum_grouped": (i32, [ptr, i32, i32, ptr, i64, ptr]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),

@@ -144,6 +144,10 @@ extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int
   if (!A || !out || cols <= 0) { set_error("vln_colsum: bad args"); return VLN_ERR_ARG; }
   return colsum((hipStream_t)s, A, lda, out, rows, cols, accumulate, ws, ws_floats);
 }
+extern "C" int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* ws, int64_t ws_floats, vln_stream_t s) {
+  if (!jobs) { set_error("vln_colsum_grouped: null pointer"); return VLN_ERR_ARG; }
+  return colsum_grouped((hipStream_t)s, jobs, n_jobs, rows, ws, ws_floats);
+}
 extern "C" int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K,
                                   vln_stream_t s) {
   if (!W || !Wt || N <= 0 || K <= 0) { set_error("vln_transpose_cast: bad args"); return VLN_ERR_ARG; }

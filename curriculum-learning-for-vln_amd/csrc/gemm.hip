@@ -1124,6 +1124,98 @@ int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int c
   return VLN_OK;
 }
 
+// ---- every bias gradient of a module in one launch ---------------------------------------------------------------
+// job: out1[c] (and out2[c]: the LSTM's b_ih and b_hh receive the same sum) (+)= sum_r A[r*lda + c] over the SAME
+// `rows` for all jobs.  A workgroup owns 16 columns (4 float4 groups) x 64 row lanes and a row chunk; with one chunk
+// the sums go straight to the outputs, else partials go to ws and one second launch finishes every job.
+struct ColsumJobs {
+  vln_colsum_job j[VLN_COLSUM_MAX_JOBS];
+  int blk0[VLN_COLSUM_MAX_JOBS + 1];
+  int col0[VLN_COLSUM_MAX_JOBS + 1];      // first column of the job in the partial buffer
+  float* ws; int n, rows, rsplit, rchunk, total_cols;
+};
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(ColsumJobs a) {
+  __shared__ float4 part[64][4];
+  int ji = 0;
+  while (ji + 1 < a.n && (int)blockIdx.x >= a.blk0[ji + 1]) ++ji;
+  const vln_colsum_job& q = a.j[ji];
+  const int cb = (int)blockIdx.x - a.blk0[ji];
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = cb * 16 + cg * 4;
+  const int rbeg = (int)blockIdx.y * a.rchunk, rend = min(a.rows, rbeg + a.rchunk);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (c < q.cols) {                                   // cols % 4 == 0
+    const float* p = q.A + c;
+    int r = rbeg + rl;
+    for (; r + 64 < rend; r += 128) {
+      const float4 x = *reinterpret_cast<const float4*>(p + (long)r * q.lda);
+      const float4 y = *reinterpret_cast<const float4*>(p + (long)(r + 64) * q.lda);
+      s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+      s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
+    }
+    if (r < rend) {
+      const float4 x = *reinterpret_cast<const float4*>(p + (long)r * q.lda);
+      s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+    }
+  }
+  part[rl][cg] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int g = threadIdx.x >> 2, e = threadIdx.x & 3, cc = cb * 16 + threadIdx.x;
+    if (cc < q.cols) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) t += reinterpret_cast<const float*>(&part[k][g])[e];
+      if (a.rsplit > 1) a.ws[(long)blockIdx.y * a.total_cols + a.col0[ji] + cc] = t;
+      else {
+        if (q.out1) q.out1[cc] = q.accumulate ? q.out1[cc] + t : t;
+        if (q.out2) q.out2[cc] = q.accumulate ? q.out2[cc] + t : t;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void colsum_grouped_finish_kernel(ColsumJobs a) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.total_cols; i += gridDim.x * blockDim.x) {
+    int ji = 0;
+    while (ji + 1 < a.n && i >= a.col0[ji + 1]) ++ji;
+    const vln_colsum_job& q = a.j[ji];
+    const int cc = i - a.col0[ji];
+    float t = 0.f;
+    for (int s = 0; s < a.rsplit; ++s) t += a.ws[(long)s * a.total_cols + i];
+    if (q.out1) q.out1[cc] = q.accumulate ? q.out1[cc] + t : t;
+    if (q.out2) q.out2[cc] = q.accumulate ? q.out2[cc] + t : t;
+  }
+}
+int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats) {
+  if (n <= 0 || n > VLN_COLSUM_MAX_JOBS || rows <= 0) { set_error("colsum_grouped: bad args (n = %d)", n); return VLN_ERR_ARG; }
+  ColsumJobs a;
+  a.n = n; a.rows = rows; a.ws = ws;
+  int blk = 0, col = 0;
+  for (int i = 0; i < n; ++i) {
+    const vln_colsum_job& q = jobs[i];
+    if (!q.A || q.cols <= 0 || (q.cols & 3) || (q.lda & 3) || !aligned16(q.A) || (!q.out1 && !q.out2)) {
+      set_error("colsum_grouped: job %d needs 16-byte aligned rows and cols %% 4 == 0", i);
+      return VLN_ERR_ARG;
+    }
+    a.j[i] = q; a.blk0[i] = blk; a.col0[i] = col;
+    blk += (q.cols + 15) / 16; col += q.cols;
+  }
+  a.blk0[n] = blk; a.col0[n] = col; a.total_cols = col;
+  int rsplit = 1;
+  if (ws && rows > 1024) {
+    rsplit = 1024 / blk;
+    if (rsplit > rows / 512) rsplit = rows / 512;
+    if ((long)rsplit * col > ws_floats) rsplit = (int)(ws_floats / col);
+    if (rsplit < 1) rsplit = 1;
+  }
+  a.rchunk = ((rows + rsplit - 1) / rsplit + 63) / 64 * 64;
+  a.rsplit = (rows + a.rchunk - 1) / a.rchunk;
+  hipLaunchKernelGGL(colsum_grouped_kernel, dim3(blk, a.rsplit), dim3(256), 0, st, a);
+  if (a.rsplit > 1) hipLaunchKernelGGL(colsum_grouped_finish_kernel, dim3((col + 255) / 256), dim3(256), 0, st, a);
+  VLN_CHECK_LAUNCH("colsum_grouped");
+  return VLN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // weight shadows: transposed / cast copies refreshed once per optimizer step
 // ---------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 
 struct vln_shadow_job;   // include/vln_hip.h
 struct vln_wgrad_job;
+struct vln_colsum_job;
 
 namespace vln {
 
@@ -84,6 +85,9 @@ int wgrad_grouped(hipStream_t st, const ::vln_wgrad_job* jobs, int n, int Mt, in
 // out[c] (+)= sum_r A[r*lda + c]
 int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,
            long ws_floats);
+
+// every bias gradient of a module in one launch (two when the rows are split)
+int colsum_grouped(hipStream_t st, const ::vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats);
 
 // out = act(sum_s slabs[s] + bias); optional second output out2 = out * dropout mask
 int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_stride, long lds, float* out,

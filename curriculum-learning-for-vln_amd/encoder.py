@@ -137,6 +137,7 @@ class _EncoderFn(torch.autograd.Function):
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
+            cbt = ops.ColsumBatch()       # ... and its bias gradients
             wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode
             for d in range(dirs):
                 sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
@@ -151,9 +152,24 @@ class _EncoderFn(torch.autograd.Function):
                     else:
                         grads[name] = torch.empty_like(p)
                         wb.add(dg, xop, grads[name], False)
-                put("lstm.bias_ih" + sfx, ops.colsum, dg)
-                put("lstm.bias_hh" + sfx, ops.colsum, dg)     # both biases feed the same pre-activation
+                outs = []                                                     # both biases feed the same pre-activation
+                for name in ("lstm.bias_ih" + sfx, "lstm.bias_hh" + sfx):
+                    p = pmap[name]
+                    if not p.requires_grad:
+                        continue
+                    g = p.grad
+                    if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                        outs.append((g, True))
+                    else:
+                        grads[name] = torch.empty_like(p)
+                        outs.append((grads[name], False))
+                if len(outs) == 2 and outs[0][1] == outs[1][1]:
+                    cbt.add(dg, outs[0][0], outs[1][0], outs[0][1])           # one pass over dgates, two destinations
+                else:
+                    for o, acc in outs:
+                        cbt.add(dg, o, None, acc)
             wb.run()
+            cbt.run()
             need_dx = (k > 0) or mod.embedding.weight.requires_grad
             if need_dx:
                 dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])

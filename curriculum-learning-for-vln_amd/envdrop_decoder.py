@@ -256,9 +256,14 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             wb.add(bufs["dtt"][sl], bufs["tcat"][sl][:, H:], g_tin, a[7])
             wb.add(bufs["de"][sl], bufs["a"][sl], g_aw, a[0])
             wb.run()
-            ops.colsum(bufs["de"][sl], g_ab, a[1])
-            ops.colsum(bufs["dgates"][sl], g_bih, a[5])
-            ops.colsum(bufs["dgates"][sl], g_bhh, a[6])   # d b_hh == d b_ih (same pre-activation)
+            cb = ops.ColsumBatch()              # the three bias gradients: one launch (b_ih and b_hh share their sum)
+            cb.add(bufs["de"][sl], g_ab, None, a[1])
+            if a[5] == a[6]:
+                cb.add(bufs["dgates"][sl], g_bih, g_bhh, a[5])
+            else:
+                cb.add(bufs["dgates"][sl], g_bih, None, a[5])
+                cb.add(bufs["dgates"][sl], g_bhh, None, a[6])
+            cb.run()
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,

@@ -228,6 +228,35 @@ class ShadowBatch:
         self.jobs, self.keep = [], []
 
 
+class ColsumBatch:
+    """Bias gradients over the SAME rows as one launch (`vln_colsum_grouped`): add(a, out1, out2=None, accumulate)."""
+
+    def __init__(self):
+        self.jobs, self.keep, self.rows = [], [], None
+
+    def add(self, a, out1, out2=None, accumulate=False):
+        _req(a, "a")
+        rows, cols = a.shape
+        assert self.rows is None or self.rows == rows
+        self.rows = rows
+        if cols % 4 or a.stride(0) % 4 or a.data_ptr() % 16:          # odd shapes: the single-matrix kernel
+            colsum(a, out1, accumulate)
+            if out2 is not None:
+                colsum(a, out2, accumulate)
+            return
+        self.jobs.append(_lib.ColsumJob(a.data_ptr(), _p(out1), _p(out2), a.stride(0), cols, int(accumulate)))
+        self.keep += [a, out1, out2]
+
+    def run(self):
+        lib = _lib.load()
+        for i in range(0, len(self.jobs), 12):
+            chunk = self.jobs[i:i + 12]
+            arr = (_lib.ColsumJob * len(chunk))(*chunk)
+            ws = workspace(self.keep[0].device, 1 << 22)
+            _lib.check(lib.vln_colsum_grouped(arr, len(chunk), self.rows, _p(ws), ws.numel(), _stream()), "vln_colsum_grouped")
+        self.jobs, self.keep, self.rows = [], [], None
+
+
 class WgradBatch:
     """Collects dW (+)= dy.T @ x products over the SAME rows and issues them as one launch (`vln_wgrad_grouped`)."""
 

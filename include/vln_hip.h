@@ -74,6 +74,15 @@ int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precisi
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */
+/* All bias gradients of a module in one launch: out1[c] (and out2[c], nullable: an LSTM's b_ih and b_hh receive the
+ * same sum) (+)= sum_r A[r*lda + c], every job over the same `rows`.  cols and lda multiples of 4, A 16-byte aligned. */
+#define VLN_COLSUM_MAX_JOBS 12
+typedef struct vln_colsum_job {
+  const float* A; float* out1; float* out2;
+  int64_t lda;
+  int cols, accumulate;
+} vln_colsum_job;
+int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K, vln_stream_t s);
 int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols, vln_stream_t s);
 /* All weight shadows of a module in ONE launch (they are refreshed once per optimizer step): job = fp32 matrix src

@@ -87,6 +87,26 @@ def test_wgrad_grouped(vln, split):
         assert rel_err(o, r) < (5e-5 if split else 1e-5)
 
 
+@pytest.mark.parametrize("rows", [448, 5120, 7])
+def test_colsum_grouped(vln, rows):
+    """All bias gradients of a module in one launch (two when the rows are split): strided inputs, a shared sum written
+    to two destinations, accumulate and overwrite mixed, an odd shape through the single-matrix kernel."""
+    g = torch.Generator().manual_seed(rows)
+    big = torch.randn(rows, 2048 + 64 + 8, generator=g).to(dev())
+    a1, a2 = big[:, :2048], big[:, 2048:2112]
+    a3 = torch.randn(rows, 50, generator=g).to(dev())
+    o1 = torch.randn(2048, generator=g).to(dev()); o1b = o1.clone()
+    o2 = torch.empty(64, device=dev()); o3 = torch.empty(50, device=dev())
+    r1 = a1.double().sum(0) + o1.double()
+    cb = vln.ops.ColsumBatch()
+    cb.add(a1, o1, o1b, True)
+    cb.add(a2, o2, None, False)
+    cb.add(a3, o3, None, False)
+    cb.run()
+    assert rel_err(o1, r1) < 1e-5 and torch.equal(o1, o1b)
+    assert rel_err(o2, a2.double().sum(0)) < 1e-5 and rel_err(o3, a3.double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("N,K", [(2048, 2752), (48, 40), (1, 7)])
 def test_transpose_and_cast(vln, N, K):
     w = torch.randn(N, K).to(dev())
