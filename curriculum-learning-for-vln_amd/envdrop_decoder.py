@@ -31,6 +31,18 @@ class _SoftDotParams(nn.Module):
             self.linear_out = nn.Linear(query_dim + ctx_dim, query_dim, bias=False)
 
 
+class _StepPlan:
+    """What a decoder step needs again when the same argument block comes back (see EnvDropDecoder.forward)."""
+    __slots__ = ("io", "dims", "nws", "keep", "i0", "n_alloc", "xcat_ptr", "ctx_lp_ptr", "mask_ptr", "logit_ptr")
+
+    def __init__(self, io, dims, nws, keep, i0, n_alloc, xcat_ptr, ctx_lp_ptr, mask_ptr, logit_ptr):
+        self.io = _lib.EnvDropStep.from_buffer_copy(io)
+        own = ("logit", "h1", "c1", "h_tilde", "flat", "img_lp", "cand_lp")      # the module's buffers only: the caller's
+        self.dims, self.nws, self.i0, self.n_alloc = dims, nws, i0, n_alloc        # tensors are taken afresh every call
+        self.keep = {k: keep[k] for k in own if k in keep}
+        self.xcat_ptr, self.ctx_lp_ptr, self.mask_ptr, self.logit_ptr = xcat_ptr, ctx_lp_ptr, mask_ptr, logit_ptr
+
+
 class _StepRec:
     __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H")
 
@@ -40,11 +52,11 @@ _NONES = (None,) * 64
 
 class _EnvDropStepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, rec, h_tilde_prev, c0, ctx_t, *gated):
+    def forward(ctx, mod, rec, h_tilde_prev, c0, ctx_t, gate_token):
         st = _lib.load().vln_envdrop_step_fwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(rec.io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_envdrop_step_fwd")
-        ctx.mod, ctx.rec, ctx.n_gated = mod, rec, len(gated)
+        ctx.mod, ctx.rec = mod, rec
         ctx.set_materialize_grads(False)
         k = rec.keep
         # fresh aliases: the returned objects get this node as grad_fn, and rec (reachable from the node) must not hold
@@ -98,7 +110,7 @@ class _EnvDropStepFn(torch.autograd.Function):
             _lib.check(st, "vln_envdrop_step_bwd")
         s.done = True
         ctx.rec = None
-        return (None, None, dhtp, dc0, None) + _NONES[:ctx.n_gated]
+        return None, None, dhtp, dc0, None, None
 
 
 class EnvDropDecoder(nn.Module, GatedModuleMixin):
@@ -131,6 +143,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self.overlap_wgrads = False
         self._side_stream = None
         self._dims_cache = {}
+        self._plans = {}                 # step plans of the arena mode (see forward)
+        self.plan_hits = 0
         self.grads_ready_hook = None     # optional callable, see _deferred_wgrads
         # Replay each decoder step (forward: 13 launches, backward: 15) as ONE hipGraph.  A graph is keyed by the step's
         # argument block, i.e. by device addresses; it only pays when the caller's tensors come back at the SAME
@@ -265,6 +279,60 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 cb.add(bufs["dgates"][sl], g_bhh, None, a[6])
             cb.run()
 
+    def _forward_planned(self, plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
+                         h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp):
+        """The fast path of forward(): returns None (and leaves no trace) when anything the plan relies on moved."""
+        if not arena.reserve(plan.i0, plan.n_alloc, plan.logit_ptr):
+            return None
+        B, H = a_t_prev.shape[0], self.hidden_size
+        lp = self.compute_dtype != torch.float32
+        slot = None
+        ok = True
+        ctx_lp = entry.lp
+        if lp:
+            ok = ctx_lp is not None and ctx_lp.data_ptr() == plan.ctx_lp_ptr
+        m8 = None
+        if ok and ctx_mask is not None:
+            m8 = entry.mask8 if entry.mask_src is ctx_mask else None
+            if m8 is None and ctx_mask.dtype == torch.bool and ctx_mask.is_contiguous():
+                m8 = ctx_mask.view(torch.uint8)
+                entry.mask_src, entry.mask8 = ctx_mask, m8
+            ok = m8 is not None and m8.data_ptr() == plan.mask_ptr
+        if ok and need_grad:
+            slot = self._stash.take(B, entry.ref)
+            ok = slot.ptr("xcat") == plan.xcat_ptr
+        if not ok:                    # fall back to the full path from a clean state
+            arena.i = plan.i0
+            if slot is not None:
+                self._stash.untake(slot)
+            return None
+        arena.i = plan.i0 + plan.n_alloc
+        self.plan_hits += 1
+        io = _lib.EnvDropStep.from_buffer_copy(plan.io)
+        io.offset = self._next_offset()
+        io.ws = ops.workspace(img_feature.device, plan.nws).data_ptr()
+        keep = dict(plan.keep)
+        keep["img"], keep["cand"], keep["a"], keep["ctx"] = img_feature, cand_feature, a_t_prev, ctx
+        if lp:
+            keep["ctx_lp"] = ctx_lp
+            if img_lp is not None:
+                keep["img_lp"], keep["cand_lp"] = img_lp, cand_lp
+        if m8 is not None:
+            keep["mask"] = m8
+        rec = _StepRec()
+        rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], cand_feature.shape[1], H
+        rec.ctx_owner, rec.entry, rec.dims, rec.slot, rec.io, rec.keep = ctx, entry, plan.dims, slot, io, keep
+        if need_grad:
+            keep["htp"], keep["c0"] = h_tilde_prev.detach(), c_0.detach()
+            logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
+        else:
+            keep["htp"], keep["c0"] = h_tilde_prev, c_0
+            st = _lib.load().vln_envdrop_step_fwd(C.byref(plan.dims), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_envdrop_step_fwd")
+            logit, h1, c1, h_tilde = keep["logit"], keep["h1"], keep["c1"], keep["h_tilde"]
+        return logit, (h1, c1), h_tilde
+
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,
                 already_dropfeat=False, img_lp=None, cand_lp=None):
@@ -291,6 +359,31 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         ctx_in, entry = self._gated_ctx(ctx, need_grad)
         dt = self.compute_dtype
         lp = dt != torch.float32
+
+        # Step plans (arena mode): with address-stable buffers, the n-th step of an iteration sees the argument block of
+        # the n-th step two iterations earlier.  The filled C struct, the output tensors and the saved-activation
+        # block are then reused as they are (only the dropout offset and the per-rollout objects change) instead of
+        # being rebuilt: ~40 us of Python per step, on a path where the host, not the GPU, sets the pace at B = 64.
+        arena = ops.current_arena() if self.step_graphs else None
+        pkey = None
+        if arena is not None:
+            pkey = (arena.g, arena.i, a_t_prev.data_ptr(), img_feature.data_ptr(), cand_feature.data_ptr(), h_tilde_prev.data_ptr(),
+                    c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
+                    self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
+                    0 if cand_lp is None else cand_lp.data_ptr(), dt)
+        ctx_lp = None
+        if lp:                         # once per rollout; BEFORE the step's own buffers so the arena order is the same on
+            ctx_lp = entry.lp          # the planned and on the full path
+            if ctx_lp is None:
+                ctx_lp = self._ctx_lp(entry, ctx, dt)
+        if pkey is not None:
+            plan = self._plans.get(pkey)
+            if plan is not None:
+                out = self._forward_planned(plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
+                                            h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp)
+                if out is not None:
+                    return out
+        arena_i0 = arena.i if arena is not None else 0
 
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, L, Cn, H
@@ -361,9 +454,6 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 cand_lp = ops.empty(B, Cn, F, dtype=dt, device=dev)
             else:
                 io.lp_ready = 1
-            ctx_lp = entry.lp
-            if ctx_lp is None:
-                ctx_lp = self._ctx_lp(entry, ctx, dt)
             keep["img_lp"], keep["cand_lp"], keep["ctx_lp"] = img_lp, cand_lp, ctx_lp
             io.img_lp, io.cand_lp, io.ctx_lp = img_lp.data_ptr(), cand_lp.data_ptr(), ctx_lp.data_ptr()
         io.h_tilde_prev, io.c0, io.ctx = htp.data_ptr(), c0.data_ptr(), ctxc.data_ptr()
@@ -385,9 +475,16 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.already_dropfeat = 1
         io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
         rec.io, rec.keep = io, keep
+        if (pkey is not None and img is img_feature and cand is cand_feature and a is a_t_prev and htp.is_contiguous()
+                and h_tilde_prev.is_contiguous() and c_0.is_contiguous() and ctx.is_contiguous()):
+            if len(self._plans) > 256:
+                self._plans.clear()
+            self._plans[pkey] = _StepPlan(io, d, nws, keep, arena_i0, arena.i - arena_i0,
+                                          slot.ptr("xcat") if need_grad else 0, keep["ctx_lp"].data_ptr() if lp else 0,
+                                          io.ctx_mask, logit.data_ptr())
 
         if need_grad:
-            logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, *gated)
+            logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
         else:
             st = _lib.load().vln_envdrop_step_fwd(C.byref(d), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
             if st:

@@ -86,10 +86,20 @@ class RolloutArena:
         # a fresh alias per request: autograd metadata (grad_fn) of an earlier iteration must not stick to the memory
         return t.detach() if alias else t
 
+    def reserve(self, i0: int, n: int, first_ptr: int) -> bool:
+        """True if the next `n` requests of this generation are the recorded buffers starting at index i0 (the caller
+        then reuses its own aliases of them and advances `i` by n itself)."""
+        lst = self.gens[self.g]
+        return self.i == i0 and i0 + n <= len(lst) and n > 0 and lst[i0].data_ptr() == first_ptr
+
 
 def set_arena(arena: Optional["RolloutArena"]):
     global _arena
     _arena = arena
+
+
+def current_arena() -> Optional["RolloutArena"]:
+    return _arena
 
 
 def empty(*size, dtype=torch.float32, device=None):

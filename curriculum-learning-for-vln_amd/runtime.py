@@ -122,6 +122,13 @@ class Stash:
             ch.owners.append(owner_ref)
         return slot
 
+    def untake(self, slot: StepSlot):
+        """Give back the most recent take() (a caller that found its cached plan stale re-takes on the full path)."""
+        ch = slot.chunk
+        if ch.slots and ch.slots[-1] is slot:
+            ch.slots.pop()
+            ch.used -= slot.rows
+
     def done_runs(self):
         """Yield (bufs, r0, r1) for maximal runs of steps whose backward ran; consumes the flags."""
         for c in self.chunks:
@@ -143,14 +150,16 @@ class Stash:
 
 
 class WeightGate(torch.autograd.Function):
-    """outs = aliases of the parameters; backward = owner._deferred_wgrads()."""
+    """out = ONE token tensor that every decoder step takes as an input (the dependency edge is all autograd needs: a
+    step Function fed the ten parameter aliases paid ~40 us of argument handling per call); backward =
+    owner._deferred_wgrads(), run once every step that consumed the token has run its own backward."""
 
     @staticmethod
     def forward(ctx, owner_ref, *params):
         ctx.owner_ref = owner_ref
         ctx.n = len(params)
         ctx.set_materialize_grads(False)
-        return tuple(p.detach() for p in params)
+        return params[0].detach().view(-1)[:1]
 
     @staticmethod
     def backward(ctx, *unused):
@@ -218,6 +227,7 @@ class GatedModuleMixin:
         self.compute_dtype = torch.float32      # dtype of the streamed operands (weights / features / ctx)
         self.dropout_seed = 0x5EED
         self._shadow_ready = None               # event recorded by prepare() (side-stream shadow refresh)
+        self._open_versions = None              # parameter versions when the current gate opened
 
     # -- provided by the module -----------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -260,6 +270,10 @@ class GatedModuleMixin:
             self._shadow_ready = None
         if params is None:
             params = self._gated_params()
+        # A gate is open (a rollout is being recorded): only an in-place update could have staled the shadows since it
+        # opened, and that bumps `_version` -- ten attribute reads instead of the full (version, address) key per step.
+        if need_grad and self._gate_outs is not None and self._open_versions == [p._version for p in params]:
+            return self._gate_outs
         key = ShadowSet.key_of(params, self.compute_dtype)
         if self._shadow.stale(key):
             with torch.no_grad():
@@ -274,6 +288,7 @@ class GatedModuleMixin:
                 self._stash.reset()
             self._ctx_entries = {}
             self._gate_outs = WeightGate.apply(weakref.ref(self), *params)
+            self._open_versions = [p._version for p in params]
         return self._gate_outs
 
     def _gate_consumed(self):

@@ -11,7 +11,7 @@ from vln_amd import _lib
 
 dev = torch.device('cuda:0')
 dtype = torch.bfloat16
-agent = bench.GpuAgent(vln, dev, dtype, 1)
+agent = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
 tape = bench.tape_to(bench.make_tape(64, 80, 7, 8, 2020), dev, store_dtype=dtype)
 for _ in range(5): agent.iteration(tape)
 torch.cuda.synchronize()
@@ -30,7 +30,7 @@ def wrap(name):
     setattr(lib, name, g)
 
 
-for n in ("vln_envdrop_step_fwd", "vln_envdrop_step_bwd", "vln_gather_pano", "vln_gather_cands", "vln_masked_ce_fwd",
+for n in ("vln_envdrop_step_fwd", "vln_envdrop_step_bwd", "vln_gather_step", "vln_wgrad_grouped", "vln_colsum_grouped", "vln_attn_dctx_deferred", "vln_masked_ce_fwd",
           "vln_masked_ce_bwd", "vln_lstm_seq_fwd", "vln_lstm_seq_bwd", "vln_linear_wgrad", "vln_colsum", "vln_linear_fwd",
           "vln_transpose_cast", "vln_cast_copy", "vln_rmsprop_clip_step", "vln_embed_fwd", "vln_embed_bwd"):
     if hasattr(lib, n):

@@ -415,6 +415,7 @@ def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
         if arena:
             lib.vln_graph_stats(st1)
             assert ag.arena.misses == 0
+            assert ag.dec.plan_hits >= 3 * 3          # iterations 3..5 reuse the recorded step plans (host fast path)
         assert vln.ops._arena is None
         res.append(out)
     assert st1[0] - st0[0] >= 3 * 6                  # iterations 3..5: 3 steps x (fwd + bwd) replays each
