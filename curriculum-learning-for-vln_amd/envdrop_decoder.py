@@ -68,6 +68,35 @@ class _EnvDropStepFn(torch.autograd.Function):
         mod, rec = ctx.mod, ctx.rec
         dev = rec.keep["h1"].device
         B, H = rec.B, rec.H
+        s = rec.slot
+        want_ctx = ctx.needs_input_grad[4]
+        # backward plans (arena mode): same idea as the forward step plans -- the gradient block of this step two
+        # iterations ago is reused when every address in it repeats
+        arena = ops.current_arena() if mod.step_graphs else None
+        bkey = None
+        if arena is not None:
+            bkey = (arena.g, arena.i, 0 if dlogit is None else dlogit.data_ptr(), 0 if dh1 is None else dh1.data_ptr(),
+                    0 if dc1 is None else dc1.data_ptr(), 0 if dht is None else dht.data_ptr(), want_ctx, s.ptr("dtc"), B, rec.L)
+            bp = mod._bplans.get(bkey)
+            if (bp is not None and arena.reserve(bp[1], bp[2], bp[3]) and (dlogit is None or dlogit.is_contiguous())
+                    and (dh1 is None or dh1.is_contiguous()) and (dc1 is None or dc1.is_contiguous())
+                    and (dht is None or dht.is_contiguous())):
+                arena.i = bp[1] + bp[2]
+                g = _lib.EnvDropGrads.from_buffer_copy(bp[0])
+                dhtp, dc0, t = bp[4], bp[5], bp[6]
+                if want_ctx:
+                    io0 = rec.io
+                    rec.entry.terms.append((io0.alpha_t, g.s_dl, g.s_dtcat, io0.tt, t, rec.keep["flat"]))
+                    rec.entry.shape = (B, rec.L, H)
+                io = rec.io
+                io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
+                st = _lib.load().vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(io), C.byref(g), _lib.raw_stream())
+                if st:
+                    _lib.check(st, "vln_envdrop_step_bwd")
+                s.done = True
+                ctx.rec = None
+                return None, None, dhtp, dc0, None, None
+        arena_i0 = arena.i if arena is not None else 0
         g = _lib.EnvDropGrads()
         hold = []          # keeps the contiguous copies alive until the launch is queued
         if dlogit is not None:
@@ -89,7 +118,8 @@ class _EnvDropStepFn(torch.autograd.Function):
         dhtp = ops.empty(B, H, dtype=torch.float32, device=dev)
         dc0 = ops.empty(B, H, dtype=torch.float32, device=dev)
         g.dh_tilde_prev, g.dc0 = dhtp.data_ptr(), dc0.data_ptr()
-        if ctx.needs_input_grad[4]:
+        t = None
+        if want_ctx:
             # context gradient deferred: this step leaves d(text logits) and d(weighted ctx) behind; CtxGate forms
             # dctx once per rollout from all steps (one write of [B,L,H] instead of T read-modify-write sweeps)
             L = rec.L
@@ -100,9 +130,12 @@ class _EnvDropStepFn(torch.autograd.Function):
             io0 = rec.io
             rec.entry.terms.append((io0.alpha_t, q, q + 4 * n_dl, io0.tt, t, rec.keep["flat"]))
             rec.entry.shape = (B, L, H)
-        s = rec.slot
         g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
         g.s_dgates, g.s_dtv, g.s_de = s.ptr("dgates"), s.ptr("dtv"), s.ptr("de")
+        if bkey is not None and not hold:
+            if len(mod._bplans) > 256:
+                mod._bplans.clear()
+            mod._bplans[bkey] = (_lib.EnvDropGrads.from_buffer_copy(g), arena_i0, arena.i - arena_i0, dhtp.data_ptr(), dhtp, dc0, t)
         io = rec.io
         io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
         st = _lib.load().vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(io), C.byref(g), _lib.raw_stream())
@@ -144,6 +177,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self._side_stream = None
         self._dims_cache = {}
         self._plans = {}                 # step plans of the arena mode (see forward)
+        self._bplans = {}                # ... and of the step backward
         self.plan_hits = 0
         self.grads_ready_hook = None     # optional callable, see _deferred_wgrads
         # Replay each decoder step (forward: 13 launches, backward: 15) as ONE hipGraph.  A graph is keyed by the step's
