@@ -14,20 +14,32 @@ import json
 import re
 import sys
 
-NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "attn_dot_kernel": "attn_dot", "attn_wsum_kernel": "attn_wsum",
-         "attn_bwd_kernel": "attn_bwd", "lstm_persist_fwd_kernel": "lstm_rec_fwd", "lstm_persist_bwd_kernel": "lstm_rec_bwd",
-         "lstm_rec_fwd_kernel": "lstm_rec_fwd", "lstm_rec_bwd_kernel": "lstm_rec_bwd", "feat_dropout_kernel": "feat_dropout",
-         "lstm_pw_fwd_kernel": "lstm_pointwise", "reduce_epilogue_kernel": "reduce_epilogue"}
+NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "gemm_tn_x3_kernel": "gemm_tn",
+         "wgrad_packed_kernel": "gemm_tn", "wgrad_grouped_x3_kernel": "gemm_tn", "attn_dot_kernel": "attn_dot",
+         "attn_wsum_kernel": "attn_wsum", "attn_bwd_kernel": "attn_bwd", "lstm_persist_fwd_kernel": "lstm_rec_fwd",
+         "lstm_persist_bwd_kernel": "lstm_rec_bwd", "lstm_rec_fwd_kernel": "lstm_rec_fwd", "lstm_rec_bwd_kernel": "lstm_rec_bwd",
+         "feat_dropout_kernel": "feat_dropout", "lstm_pw_fwd_kernel": "lstm_pointwise", "reduce_epilogue_kernel": "reduce_epilogue",
+         "wgrad_pack_kernel": "wgrad_pack", "gather_step_kernel": "gather_step"}
+
+
+def kernel_key(name):
+    m = re.search(r"vln::(\w+)", name)
+    if not m:
+        return None
+    k = m.group(1)
+    if k == "attn_fused_kernel":          # one-launch attention rows: forward counts as attn_wsum, backward as attn_bwd
+        return "attn_bwd" if re.search(r",\s*true\s*>", name) else "attn_wsum"
+    return NAMES.get(k)
 
 
 def load(d):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"vln::(\w+)", r["Kernel_Name"])
-            if not m or m.group(1) not in NAMES:
+            key = kernel_key(r["Kernel_Name"])
+            if key is None:
                 continue
-            a = acc[NAMES[m.group(1)]]
+            a = acc[key]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     return acc
 
