@@ -367,6 +367,82 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* probs, 
 }
 }  // namespace vln
 
+// ---------------------------------------------------------------------------------------------------------------
+// A2C sweep of the EnvDrop rollout (envdrop.py:235-264) in one launch: one thread per episode walks the steps backwards,
+//   R_t = gamma R_{t+1} + r_t  (R_T = last_value where the episode has not ended),  A_t = R_t - V_t (a constant),
+//   loss_b = sum_t m_t ( -logp_t A_t + 1/2 (R_t - V_t)^2 - c H_t ),
+// and leaves the partial derivatives behind (d/dlogp = -A m, d/dV = -(R - V) m, d/dH = -c m) so that backward is one
+// elementwise launch.  total = sum of the masks (the reference's normaliser) is counted in the same pass.
+// ---------------------------------------------------------------------------------------------------------------
+namespace vln {
+__global__ __launch_bounds__(256) void a2c_fwd_kernel(const float* logp, const float* ent, const float* val, const float* reward,
+                                                      const uint8_t* mask, const float* last_value, const uint8_t* ended, int T, int B,
+                                                      float gamma, float ent_coef, float* loss_b, float* dlogp, float* dval,
+                                                      float* dent, float* total) {
+  __shared__ float part[4];
+  float cnt = 0.f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    float R = ended[b] ? 0.f : last_value[b];
+    float acc = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+      const long i = (long)t * B + b;
+      R = R * gamma + reward[i];
+      const float m = mask[i] ? 1.f : 0.f;
+      const float adv = R - val[i];
+      const float h = ent ? ent[i] : 0.f;
+      acc += -logp[i] * adv * m;               // same order of accumulation as the reference's three += per step
+      acc += 0.5f * (adv * adv) * m;
+      if (ent) acc += -ent_coef * h * m;
+      dlogp[i] = -adv * m;
+      dval[i] = -adv * m;
+      if (dent) dent[i] = -ent_coef * m;
+      cnt += m;
+    }
+    loss_b[b] = acc;
+  }
+  if (total) {                                 // single workgroup when total is requested (host sizes the grid)
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) total[0] = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+}
+__global__ __launch_bounds__(256) void a2c_bwd_kernel(const float* dloss_b, long stride, const float* dlogp, const float* dval,
+                                                      const float* dent, int T, int B, float* glogp, float* gval, float* gent) {
+  const long n = (long)T * B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = dloss_b[(i % B) * stride];
+    if (glogp) glogp[i] = g * dlogp[i];
+    if (gval) gval[i] = g * dval[i];
+    if (gent && dent) gent[i] = g * dent[i];
+  }
+}
+}  // namespace vln
+
+extern "C" int vln_a2c_loss_fwd(const float* logp, const float* ent, const float* val, const float* reward, const uint8_t* mask,
+                                const float* last_value, const uint8_t* ended, int T, int B, float gamma, float ent_coef,
+                                float* loss_b, float* dlogp, float* dval, float* dent, float* total, void* s) {
+  if (!logp || !val || !reward || !mask || !last_value || !ended || !loss_b || !dlogp || !dval || T <= 0 || B <= 0 || (ent && !dent)) {
+    vln::set_error("vln_a2c_loss_fwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  hipLaunchKernelGGL(vln::a2c_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logp, ent, val, reward, mask, last_value, ended, T, B,
+                     gamma, ent_coef, loss_b, dlogp, dval, dent, total);
+  VLN_CHECK_LAUNCH("a2c_loss_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_a2c_loss_bwd(const float* dloss_b, int64_t dloss_stride, const float* dlogp, const float* dval, const float* dent,
+                                int T, int B, float* glogp, float* gval, float* gent, void* s) {
+  if (!dloss_b || !dlogp || !dval || T <= 0 || B <= 0) { vln::set_error("vln_a2c_loss_bwd: bad args"); return VLN_ERR_ARG; }
+  long n = (long)T * B;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(vln::a2c_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dloss_b, (long)dloss_stride, dlogp, dval, dent, T,
+                     B, glogp, gval, gent);
+  VLN_CHECK_LAUNCH("a2c_loss_bwd");
+  return VLN_OK;
+}
+
 extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, float* loss,
                                  float* loss_sum, float* probs, const int64_t* action, float* logp, float* entropy, int B,
                                  int C, int64_t ignore_index, int write_mask, void* s) {

@@ -4,7 +4,7 @@ The reference does this inline with torch ops every decoder step (follower.py:12
 monitor.py:146-176): `logits.masked_fill_(candidate_mask, -inf)`, `CrossEntropyLoss(ignore_index=-1)`,
 `softmax` -> `Categorical.log_prob / entropy`.  The drop-in modules leave that code untouched (it runs on
 PyTorch-ROCm); these functions are the fused alternative: ONE launch forward, ONE backward.
-The A2C sweep (envdrop.py:235-264) is [T,B]-sized arithmetic on these outputs and stays in torch.
+`a2c_loss` is the A2C sweep (envdrop.py:235-264) as one launch forward, one backward.
 """
 from __future__ import annotations
 
@@ -93,3 +93,74 @@ def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional
                                      _p(logp), _p(ent), B, C, -1, 0, _lib.raw_stream()),
                "vln_masked_ce_fwd")
     return probs, logp, ent
+
+
+class _A2C(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, ent, val, reward, mask8, last_value, ended8, gamma, ent_coef):
+        T, B = val.shape
+        dev = val.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        loss_b, total = ops.empty(B, **f32), ops.empty((), **f32)
+        dlogp, dval = ops.empty(T, B, **f32), ops.empty(T, B, **f32)
+        dent = ops.empty(T, B, **f32) if ent is not None else None
+        lg, vl = logp.detach().contiguous(), val.detach().contiguous()
+        en = ent.detach().contiguous() if ent is not None else None
+        st = _lib.load().vln_a2c_loss_fwd(_p(lg), _p(en), _p(vl), _p(reward), _p(mask8), _p(last_value), _p(ended8), T, B, gamma,
+                                          ent_coef, _p(loss_b), _p(dlogp), _p(dval), _p(dent), _p(total), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_a2c_loss_fwd")
+        ctx.save_for_backward(dlogp, dval, *( [dent] if dent is not None else []))
+        ctx.has_ent = dent is not None
+        ctx.mark_non_differentiable(total)
+        return loss_b, total
+
+    @staticmethod
+    def backward(ctx, dloss_b, _dtotal):
+        saved = ctx.saved_tensors
+        dlogp, dval = saved[0], saved[1]
+        dent = saved[2] if ctx.has_ent else None
+        T, B = dval.shape
+        if dloss_b.stride(0) == 0:
+            stride = 0
+        else:
+            stride = 1
+            dloss_b = dloss_b.contiguous()
+        glogp = ops.empty_like(dlogp) if ctx.needs_input_grad[0] else None
+        gval = ops.empty_like(dval) if ctx.needs_input_grad[2] else None
+        gent = ops.empty_like(dent) if (dent is not None and ctx.needs_input_grad[1]) else None
+        st = _lib.load().vln_a2c_loss_bwd(_p(dloss_b), stride, _p(dlogp), _p(dval), _p(dent), T, B, _p(glogp), _p(gval), _p(gent),
+                                          _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_a2c_loss_bwd")
+        return glogp, gent, gval, None, None, None, None, None, None
+
+
+def _stack(x, dtype=None):
+    t = torch.stack(list(x)) if isinstance(x, (list, tuple)) else x
+    return t if dtype is None or t.dtype == dtype else t.to(dtype)
+
+
+def a2c_loss(log_probs, entropies, values, rewards, masks, last_value, ended, gamma: float, normalize: str = "total",
+             per_sample: bool = False, entropy_coef: float = 0.01):
+    """The A2C part of EnvDropAgent.rollout (envdrop.py:235-264) as ONE launch (+ one in backward).
+    log_probs / entropies / values / rewards / masks: lists of T tensors [B] or stacked [T,B] on the GPU (entropies None
+    when feedback != "sample"); last_value [B] (used detached), ended [B] bool.  Returns (loss, total): loss is [B] when
+    per_sample (SELF-PACE, curriculum.py:296) else 0-dim; total = number of (step, episode) pairs that were running, a
+    0-dim tensor -- the 'total' normaliser is applied on the device, nothing synchronises."""
+    lp, vl = _stack(log_probs), _stack(values)
+    en = _stack(entropies) if entropies is not None else None
+    rw = _stack(rewards, torch.float32).contiguous()
+    mk = _stack(masks)
+    mk8 = (mk.contiguous().view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)).contiguous()
+    en8 = ended.contiguous().view(torch.uint8) if ended.dtype == torch.bool else ended.to(torch.uint8).contiguous()
+    lv = last_value.detach().to(torch.float32).contiguous()
+    loss_b, total = _A2C.apply(lp, en, vl, rw, mk8, lv, en8, float(gamma), float(entropy_coef))
+    loss = loss_b if per_sample else loss_b.sum()
+    if normalize == "total":
+        loss = loss / total
+    elif normalize == "batch":
+        loss = loss / lp.shape[1]
+    elif normalize != "none":
+        raise ValueError("normalize must be 'total', 'batch' or 'none'")
+    return loss, total

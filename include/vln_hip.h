@@ -168,6 +168,18 @@ int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target /*nullabl
 int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, int64_t dloss_stride, float* dlogits,
                       int B, int C, int64_t ignore_index, vln_stream_t s);
 
+/* A2C sweep of the EnvDrop rollout (envdrop.py:235-264) as one launch.  All step tensors are stacked [T,B]:
+ * logp = log pi(a_t), ent = entropies (NULL with ent_coef unused: feedback != "sample"), val = critic values (with
+ * grad), reward, mask (1 = episode still running at t), last_value [B] (detached), ended [B].
+ *   R_t = gamma R_{t+1} + r_t,  R_T = ended ? 0 : last_value;   loss_b[b] = sum_t m (-logp (R-V) + (R-V)^2 / 2 - c ent)
+ * with (R-V) a constant in the first term.  dlogp / dval / dent [T,B] receive the partial derivatives, total (nullable)
+ * the sum of the masks (the reference's RL_NORMALIZE == 'total' divisor).  Backward: g* = dloss_b[b] * d*. */
+int vln_a2c_loss_fwd(const float* logp, const float* ent, const float* val, const float* reward, const uint8_t* mask,
+                     const float* last_value, const uint8_t* ended, int T, int B, float gamma, float ent_coef, float* loss_b,
+                     float* dlogp, float* dval, float* dent, float* total, vln_stream_t s);
+int vln_a2c_loss_bwd(const float* dloss_b, int64_t dloss_stride, const float* dlogp, const float* dval, const float* dent, int T,
+                     int B, float* glogp, float* gval, float* gent, vln_stream_t s);
+
 /* ---- per-step feature marshalling on the device (agent/base.py:141-157, common_env.py:307-308) -----------------
  * The ResNet feature table [N_viewpoints, V, IMG] (fp32 or bf16) lives in HBM; a step ships indices only.
  * vln_gather_pano : out[b,v,:] = [ table[rows[b], v, :] | angle_table[view_index[b], v, :] ]        (BasicR2RAgent._feature_variable)

@@ -87,8 +87,9 @@ class OracleBackend:
 class ModuleBackend:
     """nn.Modules with the reference's forward contracts (the HIP drop-ins, or the reference's own modules)."""
 
-    def __init__(self, enc, dec, cri, device):
+    def __init__(self, enc, dec, cri, device, a2c_loss=None):
         self.enc, self.dec, self.cri, self.device = enc, dec, cri, device
+        self.a2c_loss = a2c_loss          # optional replacement of torch_port.a2c_loss (losses.a2c_loss on the HIP path)
 
     def encode(self, tokens, lengths):
         return self.enc(tokens, lengths)
@@ -169,9 +170,11 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
             last_v = be.critic(last_h).detach()
         vals = [be.critic(h) for h in hidden]
         dt = vals[0].dtype
-        rl, total = O.a2c_loss(logps, ents, vals, [torch.from_numpy(r).to(dev).to(dt) for r in rewards],
-                               [torch.from_numpy(m).to(dev) for m in masks], last_v, torch.from_numpy(ended.copy()).to(dev),
-                               gamma, "total")
+        a2c = getattr(be, "a2c_loss", None) or O.a2c_loss          # a backend may bring its own (the fused HIP sweep)
+        rl, total = a2c(logps, ents, vals, [torch.from_numpy(r).to(dev).to(dt) for r in rewards],
+                        [torch.from_numpy(m).to(dev) for m in masks], last_v, torch.from_numpy(ended.copy()).to(dev),
+                        gamma, "total")
+        total = float(total)
     ml_loss = ml * ml_weight / B
     return dict(ml_loss=ml_loss, rl_loss=rl, total=total, loss=ml_loss + rl, actions=np.stack(acts), traj=traj)
 

@@ -87,6 +87,42 @@ def test_wgrad_grouped(vln, split):
         assert rel_err(o, r) < (5e-5 if split else 1e-5)
 
 
+@pytest.mark.parametrize("T,B,with_ent", [(7, 64, True), (35, 64, True), (5, 3, False), (1, 130, True)])
+def test_a2c_loss_kernel_matches_the_restated_sweep(vln, T, B, with_ent):
+    """vln_a2c_loss_fwd/bwd vs oracle/torch_port.py::a2c_loss (the restatement of envdrop.py:235-264, pinned by the
+    reference's own rollout tape): loss, `total`, and the gradients w.r.t. log-probs, values and entropies."""
+    from oracle import torch_port as O
+    g = torch.Generator().manual_seed(T * 100 + B)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    masks = [(t < lens) for t in range(T)]
+    ended = torch.rand(B, generator=g) < 0.7
+    rewards = [torch.randn(B, generator=g).sign() * m for m in masks]
+    mk = lambda: [torch.randn(B, generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(T)]
+    lp, en, vl = mk(), mk(), mk()
+    last_v = torch.randn(B, generator=g, dtype=torch.float64)
+    for norm, per in (("total", False), ("batch", True), ("none", False)):
+        ref_en = en if with_ent else [torch.zeros(B, dtype=torch.float64) for _ in range(T)]
+        ref, total = O.a2c_loss(lp, ref_en, vl, [r.double() for r in rewards], masks, last_v, ended, 0.9, norm, per)
+        w = torch.randn(B, generator=g, dtype=torch.float64) if per else None
+        for x in lp + en + vl:
+            x.grad = None
+        ((ref * w).sum() if per else ref).backward()
+        d = dev()
+        dlp = [x.detach().float().to(d).requires_grad_(True) for x in lp]
+        den = [x.detach().float().to(d).requires_grad_(True) for x in en] if with_ent else None
+        dvl = [x.detach().float().to(d).requires_grad_(True) for x in vl]
+        out, tot = vln.losses.a2c_loss(dlp, den, dvl, [r.to(d) for r in rewards], [m.to(d) for m in masks], last_v.float().to(d),
+                                       ended.to(d), 0.9, norm, per)
+        assert abs(float(tot) - total) < 1e-6
+        assert rel_err(out, ref.detach()) < 1e-5
+        ((out * w.float().to(d)).sum() if per else out).backward()
+        for a, b in zip(dlp + dvl + (den or []), lp + vl + (en if with_ent else [])):
+            if b.grad is None:
+                assert a.grad is None or a.grad.abs().max().item() == 0.0
+            else:
+                assert rel_err(a.grad, b.grad) < 1e-5
+
+
 @pytest.mark.parametrize("rows", [448, 5120, 7])
 def test_colsum_grouped(vln, rows):
     """All bias gradients of a module in one launch (two when the rows are split): strided inputs, a shared sum written

@@ -64,7 +64,8 @@ def test_hip_rollout_matches_reference_agent(mode):
     enc.load_state_dict(Pe, strict=True); dec.load_state_dict(Pd, strict=True); cri.load_state_dict(Pc, strict=True)
     for m in (enc, dec, cri):
         m.to(dev).eval()
-    be = R.ModuleBackend(enc, dec, cri, dev)
+    # the sample tape also runs the A2C sweep as the fused HIP launch (losses.a2c_loss) instead of torch arithmetic
+    be = R.ModuleBackend(enc, dec, cri, dev, a2c_loss=vln.losses.a2c_loss)
     env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
     res = R.envdrop_rollout(be, env, mode, 6, inject_actions=G["out"]["actions"].numpy(), train_rl=(mode == "sample"))
     res["loss"].backward()
