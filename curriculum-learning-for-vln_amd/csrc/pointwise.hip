@@ -443,6 +443,192 @@ extern "C" int vln_a2c_loss_bwd(const float* dloss_b, int64_t dloss_stride, cons
   return VLN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm1d (+ optional ReLU) of the Self-Monitor agent's BN-MLP (units.py:210-242, policy.py:148-149) in ONE launch
+// forward and ONE backward.  A workgroup owns a strip of 16 columns and ALL rows (64 row lanes), so the batch statistics
+// need no second kernel: mean, then the centred second moment (second pass over the strip, L2-resident: 64 B per row),
+// reduced through LDS; the normalised rows are written and the running statistics updated (momentum, unbiased
+// variance, num_batches_tracked) as torch.nn.BatchNorm1d does.
+// Backward, training mode:  dx = g rstd / R * (R dy - sum dy - xhat sum(dy xhat)),  dgamma = sum dy xhat, dbeta = sum dy
+// (dy masked by y > 0 when the ReLU is fused); eval mode: dx = dy g rstd with the running statistics.
+// ---------------------------------------------------------------------------------------------------------------
+namespace vln {
+struct BnArgs {
+  const float* x; long ldx; float* y; long ldy;
+  const float* gamma; const float* beta; float* run_mean; float* run_var; long long* nbt;
+  float* save_mean; float* save_rstd;
+  int R, D; float eps, momentum; int training, relu;
+};
+__device__ __forceinline__ float4 bn_strip_sum(float4 v, float4 (*part)[4], int rl, int cg) {
+  part[rl][cg] = v;
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int k = 0; k < 64; ++k) { const float4 q = part[k][cg]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+  __syncthreads();
+  return t;
+}
+__global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
+  __shared__ float4 part[64][4];
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + cg * 4;
+  const bool c_ok = c < a.D;                                   // D % 4 == 0
+  const int cc = c_ok ? c : 0;
+  const float* xp = a.x + cc;
+  float4 mean, rstd;
+  if (a.training) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c_ok)
+      for (int r = rl; r < a.R; r += 64) {
+        const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    s = bn_strip_sum(s, part, rl, cg);
+    const float inv = 1.f / (float)a.R;
+    mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c_ok)
+      for (int r = rl; r < a.R; r += 64) {                      // second pass over the strip: L2-resident by now
+        const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
+        const float dx = t.x - mean.x, dy = t.y - mean.y, dz = t.z - mean.z, dw = t.w - mean.w;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+      }
+    q = bn_strip_sum(q, part, rl, cg);
+    const float4 var = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    rstd = make_float4(rsqrtf(var.x + a.eps), rsqrtf(var.y + a.eps), rsqrtf(var.z + a.eps), rsqrtf(var.w + a.eps));
+    if (rl == 0 && c_ok) {
+      if (a.save_mean) *reinterpret_cast<float4*>(a.save_mean + c) = mean;
+      if (a.save_rstd) *reinterpret_cast<float4*>(a.save_rstd + c) = rstd;
+      if (a.run_mean) {
+        const float m = a.momentum, ub = (a.R > 1) ? (float)a.R / (float)(a.R - 1) : 1.f;
+        float4 rm = *reinterpret_cast<float4*>(a.run_mean + c), rv = *reinterpret_cast<float4*>(a.run_var + c);
+        rm.x = (1.f - m) * rm.x + m * mean.x; rm.y = (1.f - m) * rm.y + m * mean.y;
+        rm.z = (1.f - m) * rm.z + m * mean.z; rm.w = (1.f - m) * rm.w + m * mean.w;
+        rv.x = (1.f - m) * rv.x + m * var.x * ub; rv.y = (1.f - m) * rv.y + m * var.y * ub;
+        rv.z = (1.f - m) * rv.z + m * var.z * ub; rv.w = (1.f - m) * rv.w + m * var.w * ub;
+        *reinterpret_cast<float4*>(a.run_mean + c) = rm;
+        *reinterpret_cast<float4*>(a.run_var + c) = rv;
+      }
+    }
+    if (a.nbt && blockIdx.x == 0 && threadIdx.x == 0) *a.nbt += 1;
+  } else {
+    const float4 rm = *reinterpret_cast<const float4*>(a.run_mean + cc), rv = *reinterpret_cast<const float4*>(a.run_var + cc);
+    mean = rm;
+    rstd = make_float4(rsqrtf(rv.x + a.eps), rsqrtf(rv.y + a.eps), rsqrtf(rv.z + a.eps), rsqrtf(rv.w + a.eps));
+  }
+  if (!c_ok) return;
+  const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 bt = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = rl; r < a.R; r += 64) {
+    const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
+    float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
+                           (t.z - mean.z) * rstd.z * g.z + bt.z, (t.w - mean.w) * rstd.w * g.w + bt.w);
+    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(a.y + (long)r * a.ldy + c) = o;
+  }
+}
+
+struct BnBwdArgs {
+  const float* x; long ldx; const float* dy; long lddy; const float* y; long ldy;   // y only for the fused ReLU mask
+  const float* gamma; const float* mean; const float* rstd;     // training: saved batch stats; eval: running mean, var
+  float* dx; long lddx; float* dgamma; float* dbeta;
+  int R, D; float eps; int training, relu, accumulate;
+};
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
+  __shared__ float4 part[64][4];
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + cg * 4;
+  const bool c_ok = c < a.D;
+  const int cc = c_ok ? c : 0;
+  const float4 mean = *reinterpret_cast<const float4*>(a.mean + cc);
+  float4 rstd = *reinterpret_cast<const float4*>(a.rstd + cc);
+  if (!a.training) rstd = make_float4(rsqrtf(rstd.x + a.eps), rsqrtf(rstd.y + a.eps), rsqrtf(rstd.z + a.eps), rsqrtf(rstd.w + a.eps));
+  const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + cc) : make_float4(1.f, 1.f, 1.f, 1.f);
+  auto grad_at = [&](int r) {                // dy of row r with the fused ReLU's mask applied
+    float4 dv = *reinterpret_cast<const float4*>(a.dy + (long)r * a.lddy + cc);
+    if (a.relu) {
+      const float4 yv = *reinterpret_cast<const float4*>(a.y + (long)r * a.ldy + cc);
+      dv.x = yv.x > 0.f ? dv.x : 0.f; dv.y = yv.y > 0.f ? dv.y : 0.f; dv.z = yv.z > 0.f ? dv.z : 0.f; dv.w = yv.w > 0.f ? dv.w : 0.f;
+    }
+    return dv;
+  };
+  auto xhat_at = [&](int r) {
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + cc);
+    return make_float4((xv.x - mean.x) * rstd.x, (xv.y - mean.y) * rstd.y, (xv.z - mean.z) * rstd.z, (xv.w - mean.w) * rstd.w);
+  };
+  float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), sdx = sd;
+  if (c_ok)
+    for (int r = rl; r < a.R; r += 64) {
+      const float4 dv = grad_at(r), xh = xhat_at(r);
+      sd.x += dv.x; sd.y += dv.y; sd.z += dv.z; sd.w += dv.w;
+      sdx.x += dv.x * xh.x; sdx.y += dv.y * xh.y; sdx.z += dv.z * xh.z; sdx.w += dv.w * xh.w;
+    }
+  sd = bn_strip_sum(sd, part, rl, cg);
+  sdx = bn_strip_sum(sdx, part, rl, cg);
+  if (!c_ok) return;
+  if (rl == 0) {
+    if (a.dgamma) {
+      float4 o = sdx;
+      if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dgamma + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *reinterpret_cast<float4*>(a.dgamma + c) = o;
+    }
+    if (a.dbeta) {
+      float4 o = sd;
+      if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dbeta + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *reinterpret_cast<float4*>(a.dbeta + c) = o;
+    }
+  }
+  if (!a.dx) return;
+  const float inv = 1.f / (float)a.R;
+  for (int r = rl; r < a.R; r += 64) {       // second pass: the strip is L2-resident
+    const float4 dv = grad_at(r);
+    float4 o;
+    if (a.training) {
+      const float4 xh = xhat_at(r);
+      o.x = g.x * rstd.x * (dv.x - inv * (sd.x + xh.x * sdx.x));
+      o.y = g.y * rstd.y * (dv.y - inv * (sd.y + xh.y * sdx.y));
+      o.z = g.z * rstd.z * (dv.z - inv * (sd.z + xh.z * sdx.z));
+      o.w = g.w * rstd.w * (dv.w - inv * (sd.w + xh.w * sdx.w));
+    } else {
+      o = make_float4(dv.x * g.x * rstd.x, dv.y * g.y * rstd.y, dv.z * g.z * rstd.z, dv.w * g.w * rstd.w);
+    }
+    *reinterpret_cast<float4*>(a.dx + (long)r * a.lddx + c) = o;
+  }
+}
+static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace vln
+
+extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
+                          int R, int D, float eps, float momentum, int training, int relu, void* s) {
+  using namespace vln;
+  if (!x || !y || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3) || !al16p(x) || !al16p(y) ||
+      (!training && (!running_mean || !running_var)) || (training && (!save_mean || !save_rstd))) {
+    set_error("vln_bn_fwd: bad args (D %% 4 == 0, 16-byte aligned rows)");
+    return VLN_ERR_ARG;
+  }
+  BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
+           R, D, eps, momentum, training, relu};
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("bn_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
+                          const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R,
+                          int D, float eps, int training, int relu, int accumulate, void* s) {
+  using namespace vln;
+  if (!x || !dy || !mean || !rstd_or_var || (relu && !y) || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) ||
+      (relu && (ldy & 3)) || !al16p(x) || !al16p(dy) || (dx && !al16p(dx)) ) {
+    set_error("vln_bn_bwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
+              training, relu, accumulate};
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("bn_bwd");
+  return VLN_OK;
+}
+
 extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, float* loss,
                                  float* loss_sum, float* probs, const int64_t* action, float* logp, float* entropy, int B,
                                  int C, int64_t ignore_index, int write_mask, void* s) {

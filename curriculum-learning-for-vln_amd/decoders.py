@@ -6,7 +6,7 @@ Reference surface reproduced (constructor args, forward signatures, return tuple
   units.py:210-242 MLPwithBN                 policy.py:15-60  AttnDecoderLSTM
   policy.py:67-166 MonitorDecoder
 Every Linear / LSTMCell / attention contraction runs in the gfx950 kernels (functional.py); concatenations,
-BatchNorm statistics and a few [B,H]-sized elementwise ops are torch glue in this round.
+BatchNorm (+ReLU) of the BN-MLP runs on vln_bn_fwd/bwd; a few [B,H]-sized elementwise ops are torch glue.
 """
 from __future__ import annotations
 
@@ -163,6 +163,20 @@ class _PhiloxDropout(nn.Dropout, _Seeded):
         return Fh.dropout(x, self.p, self.training, self.dropout_seed, self._next())
 
 
+class _HipBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict keys) on the fused HIP kernel; `relu=True` also applies the
+    ReLU that follows it in the BN-MLP."""
+
+    def forward(self, x, relu=False):
+        if x.dim() != 2 or x.dtype != torch.float32 or (x.shape[1] & 3) or self.momentum is None:
+            y = super().forward(x)                 # shapes the kernel does not take (never on the agents' path)
+            return torch.relu(y) if relu else y
+        return Fh.batch_norm(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                             self.running_var if self.track_running_stats else None,
+                             self.num_batches_tracked if self.track_running_stats else None, self.training, self.momentum,
+                             self.eps, relu)
+
+
 class MLPwithBN(nn.Module):
     """units.py:210-242 (same Sequential layout -> same state_dict keys `mlp.{i}.*`)."""
 
@@ -171,12 +185,12 @@ class MLPwithBN(nn.Module):
         self.in_size = input_size
         layers = []
         if use_bn:
-            layers.append(nn.BatchNorm1d(input_size))
+            layers.append(_HipBatchNorm1d(input_size))
         dims = [input_size] + list(hidden_size)
         for i in range(len(dims) - 1):
             layers.append(_HipLinear(dims[i], dims[i + 1], bias=use_bias))
             if use_bn:
-                layers.append(nn.BatchNorm1d(dims[i + 1]))
+                layers.append(_HipBatchNorm1d(dims[i + 1]))
             if dropout > 0:
                 layers.append(_PhiloxDropout(dropout))
             if relu:
@@ -188,7 +202,17 @@ class MLPwithBN(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.mlp(x)
+        layers = list(self.mlp)
+        i = 0
+        while i < len(layers):                    # BatchNorm followed by ReLU (no dropout between) is one launch
+            m = layers[i]
+            if isinstance(m, _HipBatchNorm1d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                x = m(x, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class MonitorDecoder(nn.Module, _Seeded):

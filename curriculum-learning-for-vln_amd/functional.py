@@ -10,6 +10,8 @@ import torch
 
 from . import _lib, ops
 
+_p = ops._p
+
 
 class _ShadowCache:
     """param -> {(kind, dtype): tensor}, invalidated when the parameter's version or storage changes."""
@@ -203,3 +205,52 @@ def dropout(x, p: float, training: bool, seed: int, offset: int):
     if not training or p <= 0.0:
         return x
     return DropoutFn.apply(x, p, seed, offset)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm1d (+ optionally the ReLU that follows it) as ONE HIP launch forward and ONE backward
+    (vln_bn_fwd / vln_bn_bwd); running statistics and num_batches_tracked are updated in place like torch's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, training, momentum, eps, relu):
+        R, D = x.shape
+        xc = x.detach()
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
+        dev = x.device
+        y = ops.empty(R, D, dtype=torch.float32, device=dev)
+        stats = ops.empty(2, D, dtype=torch.float32, device=dev) if training else None
+        use_batch = bool(training or running_mean is None)
+        st = _lib.load().vln_bn_fwd(_p(xc), xc.stride(0), _p(y), y.stride(0), _p(weight), _p(bias), _p(running_mean), _p(running_var),
+                                    _p(nbt) if training else None, _p(stats), None if stats is None else stats.data_ptr() + 4 * D,
+                                    R, D, eps, momentum, 1 if use_batch else 0, 1 if relu else 0, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_bn_fwd")
+        ctx.save_for_backward(xc, y if relu else None, weight, stats, None if use_batch else running_mean, None if use_batch else running_var)
+        ctx.cfg = (use_batch, eps, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, y, weight, stats, rmean, rvar = ctx.saved_tensors
+        use_batch, eps, relu = ctx.cfg
+        R, D = xc.shape
+        dy = dy.contiguous()
+        dev = xc.device
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        dx = ops.empty(R, D, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dgb = torch.empty(2, D, dtype=torch.float32, device=dev) if need_w else None        # parameter gradients: not arena memory
+        mean_p = stats.data_ptr() if use_batch else rmean.data_ptr()
+        rstd_p = stats.data_ptr() + 4 * D if use_batch else rvar.data_ptr()
+        st = _lib.load().vln_bn_bwd(_p(xc), xc.stride(0), _p(dy), dy.stride(0), _p(y), 0 if y is None else y.stride(0), _p(weight),
+                                    mean_p, rstd_p, _p(dx), 0 if dx is None else dx.stride(0), None if dgb is None else dgb.data_ptr(),
+                                    None if dgb is None else dgb.data_ptr() + 4 * D, R, D, eps, 1 if use_batch else 0,
+                                    1 if relu else 0, 0, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_bn_bwd")
+        return dx, (dgb[0] if need_w else None), (dgb[1] if need_w else None), None, None, None, None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum=0.1, eps=1e-5, relu=False):
+    return BatchNormFn.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
+                             float(eps), bool(relu))

@@ -87,6 +87,36 @@ def test_wgrad_grouped(vln, split):
         assert rel_err(o, r) < (5e-5 if split else 1e-5)
 
 
+@pytest.mark.parametrize("R,D", [(128, 2176), (1024, 1024), (1792, 1024), (5, 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batch_norm_kernel(vln, R, D, relu):
+    """vln_bn_fwd / vln_bn_bwd vs torch.nn.functional.batch_norm (+ relu) in fp64: training mode (batch statistics,
+    running statistics and num_batches_tracked updated in place) and eval mode, outputs and all three gradients."""
+    from vln_amd import functional as Fh
+    g = torch.Generator().manual_seed(R + D)
+    x = (torch.randn(R, D, generator=g) * 0.7 + 0.3)
+    w, b = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    rm0, rv0 = torch.randn(D, generator=g) * 0.1, torch.rand(D, generator=g) + 0.5
+    r = torch.randn(R, D, generator=g)
+    for training in (True, False):
+        x64 = x.double().requires_grad_(True); w64 = w.double().requires_grad_(True); b64 = b.double().requires_grad_(True)
+        rm, rv = rm0.double().clone(), rv0.double().clone()
+        ref = torch.nn.functional.batch_norm(x64, rm, rv, w64, b64, training, 0.1, 1e-5)
+        if relu:
+            ref = torch.relu(ref)
+        (ref * r.double()).sum().backward()
+        d = dev()
+        xd = x.to(d).requires_grad_(True); wd = w.to(d).requires_grad_(True); bd = b.to(d).requires_grad_(True)
+        rmd, rvd = rm0.to(d).clone(), rv0.to(d).clone()
+        nbt = torch.zeros((), dtype=torch.int64, device=d)
+        y = Fh.batch_norm(xd, wd, bd, rmd, rvd, nbt, training, 0.1, 1e-5, relu)
+        (y * r.to(d)).sum().backward()
+        assert rel_err(y, ref.detach()) < 1e-5
+        assert rel_err(xd.grad, x64.grad) < 1e-4 and rel_err(wd.grad, w64.grad) < 1e-4 and rel_err(bd.grad, b64.grad) < 1e-4
+        assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+        assert int(nbt) == (1 if training else 0)
+
+
 @pytest.mark.parametrize("T,B,with_ent", [(7, 64, True), (35, 64, True), (5, 3, False), (1, 130, True)])
 def test_a2c_loss_kernel_matches_the_restated_sweep(vln, T, B, with_ent):
     """vln_a2c_loss_fwd/bwd vs oracle/torch_port.py::a2c_loss (the restatement of envdrop.py:235-264, pinned by the
