@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Timing of the OTHER configured workloads of BASELINE.json on one MI355X (not the headline metric: `bench.py` is):
+
+  monitor  (config 2)  Self-Monitoring agent + progress-monitor head, B=128, L=80 (uni-directional encoder, H=512,
+                       MLP 1024), T teacher-forced steps, loss = CE at t=0 then 0.5*MSE + 0.5*CE (monitor.py:146-165),
+                       one Adam over encoder+decoder (trainer.py:219-222)
+  a2c      (config 3, one rank)  EnvDrop IL (teacher, T=7) + RL (sampled actions, T=10, A2C with the critic) mixed loss
+                       at B=64 per GPU, clip 40 + RMSprop over encoder / decoder / critic
+
+Synthetic data of BASELINE.md's shapes, features resident in HBM; prints one JSON line per workload.
+    python scripts/bench_agents.py [monitor|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32]
+"""
+import argparse, json, sys, time
+sys.path.insert(0, '.')
+import torch
+import bench
+import vln_amd as vln
+
+ap = argparse.ArgumentParser()
+ap.add_argument("which", nargs="?", default="all")
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--warmup", type=int, default=8)
+ap.add_argument("--dtype", default="bf16")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+F = 2176
+
+
+def timed(fn):
+    for _ in range(args.warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / args.steps * 1e3
+
+
+def run_monitor(B=128, L=80, T=7, C=8):
+    g = torch.Generator().manual_seed(2020)
+    enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, False, 1, compute_dtype=dt).to(dev).train()
+    dec = vln.MonitorDecoder(512, 0.5, L, (128, 1024), F, F, compute_dtype=dt).to(dev).train()
+    opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-4)
+    tokens = torch.randint(4, 992, (B, L), generator=g)
+    lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, n:] = 0
+    tokens, lens32 = tokens.to(dev), lens.to(dev, torch.int32)
+    seq_mask = tokens == 0
+    steps = []
+    for t in range(T):
+        ncand = torch.randint(3, C + 1, (B,), generator=g)
+        cand = (torch.randn(B, C, F, generator=g).abs() * 0.5)
+        cmask = torch.arange(C)[None, :] >= ncand[:, None]
+        cand = cand * (~cmask)[..., None]
+        tgt = (torch.rand(B, generator=g) * ncand.float()).long()
+        prog_t = torch.rand(B, generator=g)
+        steps.append(dict(cand=cand.to(dev), cmask=cmask.to(dev), target=tgt.to(dev), prog=prog_t.to(dev)))
+
+    def it():
+        opt.zero_grad()
+        ctx, h, c = enc(tokens, lens32)
+        a_prev = torch.zeros(B, F, device=dev)
+        loss = 0.0
+        for t, s in enumerate(steps):
+            (logit, prog), (h, c), _ = dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
+            ce = vln.losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
+            loss = loss + (ce if t == 0 else 0.5 * torch.mean((prog - s["prog"]) ** 2) + 0.5 * ce)
+            a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
+        loss.backward()
+        opt.step()
+
+    ms = timed(it)
+    return dict(workload=f"self_monitor_il_B{B}_L{L}_T{T}_adam", ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
+                dtype=args.dtype)
+
+
+def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
+    cpu_tape = bench.make_tape(B, L, T_rl, C, 2020)
+    tape = bench.tape_to(cpu_tape, dev, store_dtype=dt)
+    enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dt).to(dev).train()
+    dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, F, compute_dtype=dt).to(dev).train()
+    cri = vln.Critic(512, 0.5).to(dev).train()
+    opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters()), list(cri.parameters())], lr=1e-4, clip_norm=40.0)
+    store = tape["store"]
+    lp = dt != torch.float32
+    g = torch.Generator().manual_seed(7)
+    rewards = [torch.randn(B, generator=g).sign().to(dev) for _ in range(T_rl)]
+    lens_rl = torch.randint(4, T_rl + 1, (B,), generator=g)
+    masks = [(t < lens_rl).to(dev) for t in range(T_rl)]
+    ended = (lens_rl < T_rl).to(dev)
+
+    def feats(s):
+        (img, img_lp), (cand, cand_lp), _ = store.gather_step(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"],
+                                                              0.3, want_bf16=lp, want_f32=not lp)
+        return (img_lp, cand_lp) if lp else (img, cand)
+
+    def rollout(T, sample):
+        ctx, h, c = enc(tape["tokens"], tape["lengths32"])
+        ht = h
+        ml, hidden, logps, ents = 0.0, [], [], []
+        for s in tape["steps"][:T]:
+            img, cand = feats(s)
+            logit, (h, c), ht = dec(s["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
+            hidden.append(h)
+            if not sample:
+                ml = ml + vln.losses.masked_cross_entropy(logit, s["target"], s["cand_mask"], "sum")
+            else:
+                masked = logit.masked_fill(s["cand_mask"], -float("inf"))
+                p = torch.softmax(masked, 1)
+                a = torch.multinomial(p.detach(), 1).squeeze(1)                 # envdrop.py:186-195
+                lpz = torch.log(p.clamp(1.1920928955078125e-07, 1 - 1.1920928955078125e-07))
+                logps.append(lpz.gather(1, a[:, None]).squeeze(1)); ents.append(-(p * lpz).sum(1))
+        if not sample:
+            return ml * 0.2 / B
+        img, cand = feats(tape["steps"][T - 1])
+        _, (last_h, _), _ = dec(tape["steps"][T - 1]["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
+        with torch.no_grad():
+            last_v = cri(last_h).detach()
+        vals = [cri(x) for x in hidden]
+        rl, _ = vln.losses.a2c_loss(logps, ents, vals, rewards[:T], masks[:T], last_v, ended, 0.9, "total")
+        return rl
+
+    def it():
+        opt.zero_grad()
+        (rollout(T_il, False) + rollout(T_rl, True)).backward()
+        opt.step()
+
+    ms = timed(it)
+    return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop", ms_per_iteration=round(ms, 3),
+                iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
+
+
+if args.which in ("monitor", "all"):
+    print(json.dumps(run_monitor()), flush=True)
+if args.which in ("a2c", "all"):
+    print(json.dumps(run_a2c()), flush=True)
