@@ -34,7 +34,7 @@ class EnvDropStep(C.Structure):
                                     "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
                                     "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd", "a_stash")]
                 + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
-                   ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr)])
+                   ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr)])
 
 
 class ShadowJob(C.Structure):

@@ -142,6 +142,8 @@ static long ws_layout(const vln_envdrop_dims& d, float* base, Ws* w) {
 // Dropout site k of this step.  With io->offset_dev the step's offset is read from device memory by the kernels (the
 // launch arguments then repeat from call to call, which is what lets the step replay as a hipGraph).
 static inline DropSpec site(const vln_envdrop_step* io, int k, float p) {
+  if (io->offset_base_dev)      // (*base + offset) * 8 + k
+    return DropSpec{io->seed, (uint64_t)k + io->offset * 8, p, reinterpret_cast<const unsigned long long*>(io->offset_base_dev)};
   if (io->offset_dev) return DropSpec{io->seed, (uint64_t)k, p, reinterpret_cast<const unsigned long long*>(io->offset_dev)};
   return DropSpec{io->seed, io->offset * 8 + (uint64_t)k, p};
 }
@@ -299,15 +301,18 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  if (!io->offset_dev) return step_fwd_issue(st, d, w, io);
-  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
-                     (unsigned long long)io->offset);
-  VLN_CHECK_LAUNCH("envdrop step offset");
+  if (!io->offset_dev && !io->offset_base_dev) return step_fwd_issue(st, d, w, io);
+  if (!io->offset_base_dev) {
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
+                       (unsigned long long)io->offset);
+    VLN_CHECK_LAUNCH("envdrop step offset");
+  }
   static StepKey key;                     // zero-initialised once: padding bytes stay zero, fields are overwritten
   static std::mutex mu;
   static GraphCache cache(64);
   std::lock_guard<std::mutex> lock(mu);
-  key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.bwd = 0;
+  key.d = *d; key.w = *w; key.io = *io; key.bwd = 0;
+  if (!io->offset_base_dev) key.io.offset = 0;      // per-step word: the value is not a launch argument
   memset(&key.g, 0, sizeof(key.g));
   memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
@@ -318,12 +323,13 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io || !g) { set_error("vln_envdrop_step_bwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  if (!io->offset_dev) return step_bwd_issue(st, d, w, io, g);
+  if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g);
   static StepKey key;
   static std::mutex mu;
   static GraphCache cache(64);
   std::lock_guard<std::mutex> lock(mu);
-  key.d = *d; key.w = *w; key.io = *io; key.io.offset = 0; key.g = *g; key.bwd = 1;
+  key.d = *d; key.w = *w; key.io = *io; key.g = *g; key.bwd = 1;
+  if (!io->offset_base_dev) key.io.offset = 0;
   memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
 }

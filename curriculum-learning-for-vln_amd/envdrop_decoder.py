@@ -344,6 +344,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self.plan_hits += 1
         io = _lib.EnvDropStep.from_buffer_copy(plan.io)
         io.offset = self._next_offset()
+        if io.offset_base_dev:
+            io.offset -= self._base_value
+            io.offset_base_dev = self._base_ptr
         io.ws = ops.workspace(img_feature.device, plan.nws).data_ptr()
         keep = dict(plan.keep)
         keep["img"], keep["cand"], keep["a"], keep["ctx"] = img_feature, cand_feature, a_t_prev, ctx
@@ -470,7 +473,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.hq, io.xcat, io.tcat, io.htd = q, q + 4 * B * H, q + 4 * B * (H + XK), q + 4 * B * (H + XK + 2 * H)
         keep["flat"] = flat
         q = flat.data_ptr()
-        if self.step_graphs:           # the step's dropout offset lives on the device: launch arguments repeat -> hipGraph replay
+        base_mode = self.step_graphs and need_grad
+        if self.step_graphs and not base_mode:     # the step's dropout offset lives on the device: launch arguments repeat
             io.offset_dev = q
         q += 16
         io.e = q; q += 4 * n_e
@@ -503,6 +507,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.ctx_mask = m8.data_ptr()
         io.logit, io.h1, io.c1, io.h_tilde = logit.data_ptr(), h1.data_ptr(), c1.data_ptr(), h_tilde.data_ptr()
         io.seed, io.offset = self.dropout_seed, self._next_offset()
+        if base_mode:                  # offsets relative to the gate's base word: no per-step device write (runtime._rebase_offsets)
+            io.offset -= self._base_value
+            io.offset_base_dev = self._base_ptr
         if self.training:
             io.p_drop, io.p_feat = self.drop_ratio, self.feat_drop_ratio
         if already_dropfeat:

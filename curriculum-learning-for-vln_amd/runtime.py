@@ -289,6 +289,7 @@ class GatedModuleMixin:
             self._ctx_entries = {}
             self._gate_outs = WeightGate.apply(weakref.ref(self), *params)
             self._open_versions = [p._version for p in params]
+            self._rebase_offsets(params[0].device)
         return self._gate_outs
 
     def _gate_consumed(self):
@@ -313,6 +314,20 @@ class GatedModuleMixin:
     def _next_offset(self) -> int:
         self._step_counter += 1
         return self._step_counter
+
+    def _rebase_offsets(self, device):
+        """Dropout offsets of the rollouts recorded under the gate that just opened are counted from a base value held
+        in a device word (one of two, alternating per gate: the previous gate's backward may still read the other one).
+        Written once here; the steps then carry only their small relative offset (see vln_envdrop_step.offset_base_dev)."""
+        b = self.__dict__.get("_offset_bases")
+        if b is None or b.device != device:
+            b = self._offset_bases = torch.zeros(2, dtype=torch.int64, device=device)
+            self._base_epoch = 0
+        self._base_epoch += 1
+        slot = self._base_epoch & 1
+        self._base_value = self._step_counter
+        b[slot].fill_(self._base_value)
+        self._base_ptr = b.data_ptr() + 8 * slot
 
     @staticmethod
     def _ctx_lp(entry: CtxEntry, ctx_t: torch.Tensor, dtype):

@@ -312,6 +312,12 @@ typedef struct vln_envdrop_step {
    * forward stores `offset` there and every kernel reads the step's dropout offset from it, so the launch arguments
    * repeat from call to call and the step is replayed as one hipGraph (captured on first use per argument block). */
   uint64_t* offset_dev;
+  /* optional (nullable, ABI v3): a device word the CALLER wrote, holding a base offset shared by many steps; the step's
+   * offset is then *offset_base_dev + offset (offset = the step's position relative to the base).  Nothing but that
+   * small relative number varies between the steps of a rollout, no per-step write is launched, and the n-th step of
+   * every iteration has the same argument block (replayed as one hipGraph).  The word must stay unchanged until the
+   * step's backward has run.  Takes precedence over offset_dev. */
+  const uint64_t* offset_base_dev;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {

@@ -123,13 +123,21 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
         rl, _ = vln.losses.a2c_loss(logps, ents, vals, rewards[:T], masks[:T], last_v, ended, 0.9, "total")
         return rl
 
+    arena = vln.ops.RolloutArena()
+    dec.step_graphs = True
+
     def it():
-        opt.zero_grad()
-        (rollout(T_il, False) + rollout(T_rl, True)).backward()
-        opt.step()
+        vln.ops.set_arena(arena); arena.begin()
+        try:
+            opt.zero_grad()
+            (rollout(T_il, False) + rollout(T_rl, True)).backward()
+            opt.step()
+        finally:
+            vln.ops.set_arena(None)
 
     ms = timed(it)
-    return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop", ms_per_iteration=round(ms, 3),
+    return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3),
+                plan_hits=dec.plan_hits, arena_misses=arena.misses,
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
