@@ -127,8 +127,43 @@ class SoftmaxWsumFn(torch.autograd.Function):
         return dvalues, dl, None
 
 
+class SoftDotRowsFn(torch.autograd.Function):
+    """softmax(mask(values . q)) and the weighted sum of `values` when the keys ARE the values (units.py:106-118): one
+    launch forward (vln_attn_fwd_rows); backward = one launch for d(query) and d(logits) (vln_attn_bwd_rows) plus, when
+    the attended tensor needs a gradient, one for d(values) = attn (x) dout + dl (x) q (vln_attn_dctx_deferred, T = 1)."""
+
+    @staticmethod
+    def forward(ctx, values, query, mask):
+        values = values.contiguous()
+        query = query.contiguous()
+        out, attn = ops.attn_fwd_rows(values, query, mask)
+        ctx.save_for_backward(values, query, attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        values, query, attn = ctx.saved_tensors
+        B, S, D = values.shape
+        if dout is None:
+            dout = torch.zeros(B, D, dtype=torch.float32, device=values.device)
+        dout = dout.contiguous()
+        need_dv = ctx.needs_input_grad[0]
+        dq, dl = ops.attn_bwd_rows(values, attn, dout, dattn, want_dl=need_dv)
+        dvalues = None
+        if need_dv:
+            if D % 4 == 0:
+                dvalues = torch.empty(B, S, D, dtype=torch.float32, device=values.device)
+                ops.attn_dctx_deferred([attn.data_ptr()], [dl.data_ptr()], [dout.data_ptr()], dout.stride(0),
+                                       [query.data_ptr()], query.stride(0), dvalues)
+            else:
+                dvalues = attn.unsqueeze(2) * dout.unsqueeze(1) + dl.unsqueeze(2) * query.unsqueeze(1)
+        return dvalues, (dq if ctx.needs_input_grad[1] else None), None
+
+
 def soft_dot_core(query_vec, keys, values, mask):
     """-> (weighted values [B,Dv], attn [B,S]).  keys may be `values` itself."""
+    if keys is values and values.dtype in (torch.float32, torch.bfloat16):
+        return SoftDotRowsFn.apply(values, query_vec, mask)
     logits = AttnDotFn.apply(keys, query_vec)
     return SoftmaxWsumFn.apply(values, logits, mask)
 
