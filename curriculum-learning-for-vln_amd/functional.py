@@ -226,14 +226,27 @@ class DropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, p, seed, offset):
-        m = ops.dropout_mask(x.numel(), seed, offset, p, x.device).view_as(x)
-        ctx.save_for_backward(m)
-        return x * m
+        ctx.cfg = (p, seed, offset)
+        return _scale_dropout(x, p, seed, offset)
 
     @staticmethod
     def backward(ctx, dy):
-        (m,) = ctx.saved_tensors
-        return dy * m, None, None, None
+        p, seed, offset = ctx.cfg
+        return _scale_dropout(dy, p, seed, offset), None, None, None
+
+
+def _scale_dropout(x, p, seed, offset):
+    """y = x * mask(seed, offset) in ONE launch (vln_scale_dropout); the mask is a function of the flat element index."""
+    xc = x.contiguous()
+    if xc.dtype != torch.float32:
+        xc = xc.float()
+    y = ops.empty(xc.shape, dtype=torch.float32, device=xc.device)
+    cols = xc.shape[-1] if xc.dim() > 0 else 1
+    rows = xc.numel() // max(cols, 1)
+    st = _lib.load().vln_scale_dropout(_p(xc), cols, _p(y), cols, rows, cols, seed, offset, p, _lib.raw_stream())
+    if st:
+        _lib.check(st, "vln_scale_dropout")
+    return y
 
 
 def dropout(x, p: float, training: bool, seed: int, offset: int):
