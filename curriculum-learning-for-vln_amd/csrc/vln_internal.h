@@ -19,8 +19,14 @@ void set_error(const char* fmt, ...);
 const char* get_error();
 int check_hip(hipError_t e, const char* what);
 
-// run-time tunables (vln_set_tunable): [0] gemm_nt workgroups-in-flight target, [1] no-split rule for wide shallow GEMMs,
-// [2]/[3] 16-column GEMM on / its largest K, [4] = 1 forces the two-kernel attention path
+// run-time tunables (vln_set_tunable; defaults in api.hip) -- A/B switches, every setting computes the same results:
+//   [0] gemm_nt split-K target (workgroups in flight, 256)       [1] no-split rule for wide shallow products with a fused epilogue
+//   [2] 16-column GEMM for narrow outputs on/off, [3] its largest K
+//   [4] 1: two-kernel attention path instead of the one-launch rows
+//   [5] gemm_nt: 0 fast form with depth-2 prefetch, 1 same, 2 bounds-checked form, 4 depth-4 prefetch
+//   [6] weight gradients of precision 1: 0 packed grouped form, 1 exact fp32 form, 2 LDS-staged grouped form
+//   [7] 1: persistent LSTM workgroups in dispatch order instead of one XCD per dependency group
+// The EnvDrop step's graph key includes all eight, so a changed tunable never replays a stale graph.
 extern int g_tunable[8];
 
 // ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------

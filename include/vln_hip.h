@@ -39,8 +39,10 @@ const char* vln_last_error_string(void);
 int vln_set_graphs(int on);
 /* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] chains switched off */
 int vln_graph_stats(int64_t out[3]);
-/* performance tunables (never change results beyond summation order): 0 = gemm split-K workgroup target (512),
- * 1 = keep wide shallow products unsplit (1) */
+/* performance / A-B tunables, ids 0..7 (never change results beyond summation order; documented in
+ * csrc/vln_internal.h): 0 = gemm split-K workgroup target (256), 1 = keep wide shallow fused-epilogue products unsplit,
+ * 2/3 = 16-column GEMM on / its largest K, 4 = two-kernel attention, 5 = gemm_nt form, 6 = weight-gradient form,
+ * 7 = persistent-LSTM workgroup order */
 int vln_set_tunable(int id, int value);
 int vln_prof_enable(int kernel_id, int on);
 const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */
@@ -338,7 +340,7 @@ typedef struct vln_envdrop_grads {
   /* deferred context gradient (ABI v2; both nullable).  With dctx == NULL the step leaves these behind instead of
    * sweeping [B,L,H]; the caller forms dctx once per rollout: vln_attn_dctx_deferred(alpha_t, s_dl, s_dtcat, tt). */
   float* s_dl;           /* [B,L]  d(text attention logits) of this step */
-  float* s_dtcat;        /* [B,2H] [d weighted ctx | d drop(h1)]: kept by the caller instead of the step scratch */
+  float* s_dtcat;        /* [B,2H] rows; the step writes d(weighted ctx) into columns [0,H) (ld 2H): the g operand of the deferred dctx */
 } vln_envdrop_grads;
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
