@@ -218,6 +218,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         XK = AE + F + H
         dev = self.lstm.weight_ih.device
 
+        ck = (dt, tuple(p.data_ptr() for p in self._gated_params()))
+        c = self.__dict__.get("_sb_handle")
+        if c is not None and c[0] == ck:          # same addresses, new values (an optimizer step): replay the recorded jobs
+            ops.ShadowBatch.replay(c[1])
+            return
         sb = ops.ShadowBatch()          # every cast / transpose below goes out as ONE launch
 
         def buf(name, shape):
@@ -243,13 +248,14 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         wc, wct = buf("w_cat", (4 * H, XK)), buf("w_cat_t", (XK, 4 * H))
         sb.add(self.lstm.weight_ih.detach(), wc[:, :AE + F], wct[:AE + F])
         sb.add(self.lstm.weight_hh.detach(), wc[:, AE + F:], wct[AE + F:])
-        sb.run()
+        handle = sb.run()
         w = self._wstruct
         w.act_w, w.act_b = self.act_embed[0].weight.data_ptr(), self.act_embed[0].bias.data_ptr()
         w.b_ih, w.b_hh = self.lstm.bias_ih.data_ptr(), self.lstm.bias_hh.data_ptr()
         for k in ("w_vin", "w_cat", "w_tin", "w_tout", "w_c"):
             setattr(w, k, t[k].data_ptr())
             setattr(w, k + "_t", t[k + "_t"].data_ptr())
+        object.__setattr__(self, "_sb_handle", (ck, handle))
 
     def _deferred_wgrads(self):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""

@@ -231,11 +231,20 @@ class ShadowBatch:
         self.keep += [src, src2, dst, dst_t]
 
     def run(self):
+        """Issues the launch; returns a replayable handle (the job array is valid as long as the sources and destinations
+        keep their addresses: `ShadowBatch.replay(handle)` refreshes again without rebuilding the jobs)."""
         if not self.jobs:
-            return
+            return None
         arr = (_lib.ShadowJob * len(self.jobs))(*self.jobs)
         _lib.check(_lib.load().vln_shadow_refresh(arr, len(self.jobs), _stream()), "vln_shadow_refresh")
+        handle = (arr, len(self.jobs), self.keep)
         self.jobs, self.keep = [], []
+        return handle
+
+    @staticmethod
+    def replay(handle):
+        arr, n, _keep = handle
+        _lib.check(_lib.load().vln_shadow_refresh(arr, n, _stream()), "vln_shadow_refresh")
 
 
 class ColsumBatch:
