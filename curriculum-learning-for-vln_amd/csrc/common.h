@@ -124,37 +124,29 @@ __host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t
 // product can be split over all 256 CUs without a reduce launch in the dependent chain (n == 1: a plain matrix).
 struct SlabVec {
   const float* p; long ld; int n; long stride;
-  // Partials are fetched four at a time (independent loads in flight) and added in slab order.
+  // Partials are fetched four at a time (independent loads in flight, no branch between them) and added in slab order.
   __device__ __forceinline__ float at(long r, long c) const {
     const float* q = p + r * ld + c;
-    float v = q[0];
-    int s = 1;
+    float v = 0.f;
+    int s = 0;
     for (; s + 3 < n; s += 4) {
       const float t0 = q[(long)s * stride], t1 = q[(long)(s + 1) * stride], t2 = q[(long)(s + 2) * stride], t3 = q[(long)(s + 3) * stride];
       v += t0; v += t1; v += t2; v += t3;
     }
-    if (s + 1 < n) {
-      const float t0 = q[(long)s * stride], t1 = q[(long)(s + 1) * stride];
-      v += t0; v += t1; s += 2;
-    }
-    if (s < n) v += q[(long)s * stride];
+    for (; s < n; ++s) v += q[(long)s * stride];
     return v;
   }
   __device__ __forceinline__ float4 at4(long r, long c) const {      // 16-byte aligned column group
     const float* q = p + r * ld + c;
-    float4 v = *reinterpret_cast<const float4*>(q);
     auto ld4 = [&](int s) { return *reinterpret_cast<const float4*>(q + (long)s * stride); };
     auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    int s = 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
     for (; s + 3 < n; s += 4) {
       const float4 t0 = ld4(s), t1 = ld4(s + 1), t2 = ld4(s + 2), t3 = ld4(s + 3);
       add(v, t0); add(v, t1); add(v, t2); add(v, t3);
     }
-    if (s + 1 < n) {
-      const float4 t0 = ld4(s), t1 = ld4(s + 1);
-      add(v, t0); add(v, t1); s += 2;
-    }
-    if (s < n) add(v, ld4(s));
+    for (; s < n; ++s) add(v, ld4(s));
     return v;
   }
   __host__ __device__ SlabVec shifted(long cols) const { return SlabVec{p + cols, ld, n, stride}; }
