@@ -27,6 +27,11 @@ __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
         if (a.bias_b) v1 += a.bias_b[col];
         const float* gp = a.gates + (long)b * 4 * H + col;
         int s = 0;
+        for (; s + 3 < a.nsplit; s += 4) {        // four partials in flight, two accumulation chains
+          const float t0 = gp[(long)s * a.slab_stride], t1 = gp[(long)(s + 1) * a.slab_stride];
+          const float t2 = gp[(long)(s + 2) * a.slab_stride], t3 = gp[(long)(s + 3) * a.slab_stride];
+          v0 += t0; v1 += t1; v0 += t2; v1 += t3;
+        }
         for (; s + 1 < a.nsplit; s += 2) {
           v0 += gp[(long)s * a.slab_stride];
           v1 += gp[(long)(s + 1) * a.slab_stride];
