@@ -40,7 +40,9 @@ struct GemmNTArgs {
 // aligned operands -- checked on the host).  The bounds-checked form branches per thread between a vector and a
 // scalar load, and the compiler closes every such divergent region with `s_waitcnt vmcnt(0)`: the prefetch never
 // overlaps anything.  Without branches the waits become vmcnt(N) and PD loads really are in flight.
-template <typename TW, int PD, bool kFast>
+// NT = 16-column tiles per wave: the workgroup's tile is 64 rows x 64*NT columns.  NT = 2 halves the re-reads of X (every
+// column tile streams the whole activation slice: 2x the weight bytes at NT = 1) for the wide products (LSTM gates, d xcat).
+template <typename TW, int PD, bool kFast, int NT = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
   constexpr bool kF32 = (sizeof(TW) == 4);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][kPlanes][64 * kLdsRow];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
+  const int n0 = blockIdx.x * 64 * NT, m0 = blockIdx.z * 64;
   const int kbeg = blockIdx.y * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nsteps = (kend - kbeg + BK - 1) / BK;
@@ -61,15 +63,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   const float* xrow = a.X + (long)(srow_ok ? (m0 + srow) : (kFast ? a.M - 1 : 0)) * a.ldx;
   // fragment role
   const int fi = lane & 15, fq = lane >> 4;
-  const int wn = n0 + wave * 16 + fi;
-  const bool wn_ok = wn < a.N;
-  const TW* wrow = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok ? wn : (kFast ? a.N - 1 : 0)) * a.ldw;
+  int wn[NT]; bool wn_ok[NT]; const TW* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    wn[t] = n0 + (wave * NT + t) * 16 + fi;
+    wn_ok[t] = wn[t] < a.N;
+    wrow[t] = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok[t] ? wn[t] : (kFast ? a.N - 1 : 0)) * a.ldw;
+  }
   const int mrows = min(64, a.M - m0);
   const int nrb = (mrows + 15) >> 4;
 
   float xs[PD][VK];
-  float wf32[PD][kF32 ? 8 : 1];
-  bf16x8 wb16[PD][kF32 ? 1 : 2];
+  float wf32[PD][NT][kF32 ? 8 : 1];
+  bf16x8 wb16[PD][NT][kF32 ? 1 : 2];
 
   // kFast staging role: each 16-lane group reads 256 contiguous bytes of ONE row (two cache lines) per instruction.
   // (The bounds-checked role above gives every lane its own 64-byte run: a wave instruction then touches 32 lines for
@@ -147,27 +153,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
       *reinterpret_cast<bf16x8*>(dlo + 16) = l1;
     }
   };
-  auto load_w = [&](float (&w32)[kF32 ? 8 : 1], bf16x8 (&w16)[kF32 ? 1 : 2], int kb) {
+  auto load_w = [&](float (&w32)[kF32 ? 8 : 1], bf16x8 (&w16)[kF32 ? 1 : 2], int kb, int t) {
+    const TW* wrow_t = wrow[t]; const bool wn_ok_t = wn_ok[t];
     const int k = kb + fq * VK;
     if constexpr (kF32) {
-      if (kFast || (wn_ok && a.wvec && k + VK <= kend)) {
-        float4 t0 = *reinterpret_cast<const float4*>(wrow + k);
-        float4 t1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+      if (kFast || (wn_ok_t && a.wvec && k + VK <= kend)) {
+        float4 t0 = *reinterpret_cast<const float4*>(wrow_t + k);
+        float4 t1 = *reinterpret_cast<const float4*>(wrow_t + k + 4);
         w32[0] = t0.x; w32[1] = t0.y; w32[2] = t0.z; w32[3] = t0.w;
         w32[4] = t1.x; w32[5] = t1.y; w32[6] = t1.z; w32[7] = t1.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w32[j] = (wn_ok && (k + j) < kend) ? wrow[k + j] : 0.0f;
+        for (int j = 0; j < 8; ++j) w32[j] = (wn_ok_t && (k + j) < kend) ? wrow_t[k + j] : 0.0f;
       }
     } else {
-      if (kFast || (wn_ok && a.wvec && k + VK <= kend)) {
-        w16[0] = *reinterpret_cast<const bf16x8*>(wrow + k);
-        w16[1] = *reinterpret_cast<const bf16x8*>(wrow + k + 8);
+      if (kFast || (wn_ok_t && a.wvec && k + VK <= kend)) {
+        w16[0] = *reinterpret_cast<const bf16x8*>(wrow_t + k);
+        w16[1] = *reinterpret_cast<const bf16x8*>(wrow_t + k + 8);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          bf16_raw r0 = (wn_ok && (k + j) < kend) ? wrow[k + j] : (bf16_raw)0;
-          bf16_raw r1 = (wn_ok && (k + 8 + j) < kend) ? wrow[k + 8 + j] : (bf16_raw)0;
+          bf16_raw r0 = (wn_ok_t && (k + j) < kend) ? wrow_t[k + j] : (bf16_raw)0;
+          bf16_raw r1 = (wn_ok_t && (k + 8 + j) < kend) ? wrow_t[k + 8 + j] : (bf16_raw)0;
           w16[0][j] = __builtin_bit_cast(__bf16, r0);
           w16[1][j] = __builtin_bit_cast(__bf16, r1);
         }
@@ -175,15 +182,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
     }
   };
 
-  f32x4 acc[4];
+  f32x4 acc[NT][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int p = 0; p < PD; ++p) {
     if (p < nsteps) {
       load_x(xs[p], kbeg + p * BK);
-      load_w(wf32[p], wb16[p], kbeg + p * BK);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_w(wf32[p][t], wb16[p][t], kbeg + p * BK, t);
     }
   }
   for (int s0 = 0; s0 < nsteps; s0 += PD) {
@@ -194,22 +204,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
         const int buf = s & 1;
         store_x(xs[p], buf);
         // current W fragment -> private copy before the prefetch overwrites the registers
-        float wc32[kF32 ? 8 : 1];
-        bf16x8 wc16[kF32 ? 1 : 2];
-        if constexpr (kF32) {
+        float wc32[NT][kF32 ? 8 : 1];
+        bf16x8 wc16[NT][kF32 ? 1 : 2];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) wc32[j] = wf32[p][j];
-        } else {
-          wc16[0] = wb16[p][0]; wc16[1] = wb16[p][1];
+        for (int t = 0; t < NT; ++t) {
+          if constexpr (kF32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wc32[t][j] = wf32[p][t][j];
+          } else {
+            wc16[t][0] = wb16[p][t][0]; wc16[t][1] = wb16[p][t][1];
+          }
         }
         __syncthreads();
         if (s + PD < nsteps) {
           load_x(xs[p], kbeg + (s + PD) * BK);
-          load_w(wf32[p], wb16[p], kbeg + (s + PD) * BK);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) load_w(wf32[p][t], wb16[p][t], kbeg + (s + PD) * BK, t);
         }
 #ifdef VLN_PROBE_NO_MFMA       // scripts/gemm_probe.hip: what the K-step costs without the LDS reads and MFMAs
-        if constexpr (!kF32) { acc[0][0] += (float)wc16[0][0] + (float)wc16[1][7]; acc[1][0] += smem[buf][0][tid]; }
-        else { acc[0][0] += wc32[0] + wc32[7]; acc[1][0] += smem[buf][0][tid]; }
+        if constexpr (!kF32) { acc[0][0][0] += (float)wc16[0][0][0] + (float)wc16[NT - 1][1][7]; acc[0][1][0] += smem[buf][0][tid]; }
+        else { acc[0][0][0] += wc32[0][0] + wc32[NT - 1][7]; acc[0][1][0] += smem[buf][0][tid]; }
         continue;
 #endif
 #pragma unroll
@@ -219,24 +233,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
             if constexpr (kF32) {
               float4 a0 = *reinterpret_cast<const float4*>(src);
               float4 a1 = *reinterpret_cast<const float4*>(src + 16);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc32[0], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc32[1], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc32[2], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc32[3], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wc32[4], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wc32[5], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wc32[6], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wc32[7], acc[rb], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc32[t][0], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc32[t][1], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc32[t][2], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc32[t][3], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wc32[t][4], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wc32[t][5], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wc32[t][6], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wc32[t][7], acc[t][rb], 0, 0, 0);
+              }
             } else {
               bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
               bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
               const unsigned char* slo = &smem[buf][kPlanes - 1][(rb * 16 + fi) * kLdsRow + fq * 32];
               bf16x8 b0 = *reinterpret_cast<const bf16x8*>(slo);
               bf16x8 b1 = *reinterpret_cast<const bf16x8*>(slo + 16);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[0], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[1], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[0], acc[rb], 0, 0, 0);
-              acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[1], acc[rb], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[t][0], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[t][1], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[t][0], acc[t][rb], 0, 0, 0);
+                acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[t][1], acc[t][rb], 0, 0, 0);
+              }
             }
           }
         }
@@ -245,22 +265,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   }
 
   // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-  if (wn_ok) {
-    float* y = a.Y + (long)blockIdx.y * a.slab_stride;
-    const bool fused = (a.slab_stride == 0);
-    const float bv = (fused && a.bias) ? a.bias[wn] : 0.0f;
+  float* y = a.Y + (long)blockIdx.y * a.slab_stride;
+  const bool fused = (a.slab_stride == 0);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (!wn_ok[t]) continue;
+    const float bv = (fused && a.bias) ? a.bias[wn[t]] : 0.0f;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + rb * 16 + fq * 4 + r;
         if (row < a.M) {
-          float v = acc[rb][r] + bv;
+          float v = acc[t][rb][r] + bv;
           if (fused) {
             if (a.act == ACT_TANH) v = tanhf(v);
             else if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
           }
-          y[(long)row * a.ldy + wn] = v;
+          y[(long)row * a.ldy + wn[t]] = v;
         }
       }
     }
@@ -311,7 +333,14 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   if (nsplit_out == nullptr && n16_applies(M, N, K))
     return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, nullptr, 0, DropSpec{0, 0, 0.f});
   const int BK = (wtype == W_BF16) ? 64 : 32;
-  const int nb = (N + 63) / 64, mb = (M + 63) / 64;
+  // 128-column tiles for the wide AND deep products consumed from slabs (LSTM gates, d xcat: N, K >= 2048): measured
+  // NO faster than 64-column tiles (11.3 vs 10.3 us and 11.2 vs 11.1 us; the pointwise consumer then reads 15 slabs
+  // instead of 8) -- the X re-reads hit L2 and are not what bounds these launches.  Opt-in only: tunable[1] bit 1.
+  const bool fast_ok = aligned16(X) && (ldx % 4 == 0) && aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0) && (K % BK == 0) &&
+                       g_tunable[5] != 2;
+  const bool wide = nsplit_out != nullptr && N >= 2048 && K >= 2048 && M <= 64 && fast_ok && (g_tunable[1] & 2);
+  const int TNW = wide ? 128 : 64;
+  const int nb = (N + TNW - 1) / TNW, mb = (M + 63) / 64;
   const int ksteps = (K + BK - 1) / BK;
   // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk.  (Measured on MI355X:
   // many co-resident workgroups with one K-step of prefetch each beat one fat workgroup per CU with all of
@@ -351,7 +380,10 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
     // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
     const bool deep = g_tunable[5] == 4 && steps_per > 2;
 #define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
-    if (wtype == W_BF16) {
+    if (wide && fast) {
+      if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw, 2, true, 2>, grid, block, 0, st, a);
+      else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float, 2, true, 2>, grid, block, 0, st, a);
+    } else if (wtype == W_BF16) {
       if (fast) { if (deep) VLN_NT_LAUNCH(bf16_raw, 4, true); else VLN_NT_LAUNCH(bf16_raw, 2, true); }
       else VLN_NT_LAUNCH(bf16_raw, 1, false);
     } else {
