@@ -316,8 +316,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* tokens,
 }
 
 // ---- layout changes with fused dropout: time-major [L,B,W] <-> batch-major [B,L,W] -------------------------
+// [L,B,W] <-> [B,L,W] with the context dropout (units.py:71-72): four consecutive columns per thread (one Philox call,
+// 16-byte accesses) when W % 4 == 0 and the pointers are aligned (`vec`), else one element per thread.
 __global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* bm, bf16_raw* bm_lp, int B, int L,
-                                                       int W, DropSpec dr) {
+                                                       int W, DropSpec dr, int vec) {
+  if (vec) {
+    const int W4 = W >> 2;
+    const long total4 = (long)B * L * W4;
+    for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+      const int c4 = (int)(e4 % W4);
+      const long rb = e4 / W4;
+      const int t = (int)(rb % L), b = (int)(rb / L);
+      const float4 x = *reinterpret_cast<const float4*>(tm + ((long)t * B + b) * W + c4 * 4);
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale4(dr.seed, dr.off(), (uint32_t)e4, dr.p, m);
+      const float v[4] = {x.x * m[0], x.y * m[1], x.z * m[2], x.w * m[3]};
+      *reinterpret_cast<float4*>(bm + e4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      if (bm_lp) Elt<bf16_raw>::st4(bm_lp + e4 * 4, v);
+    }
+    return;
+  }
   const long total = (long)B * L * W;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % W);
@@ -328,7 +346,21 @@ __global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* b
     if (bm_lp) bm_lp[e] = f32_to_bf16_bits(v);
   }
 }
-__global__ __launch_bounds__(256) void bm_to_tm_kernel(const float* bm, float* tm, int B, int L, int W, DropSpec dr) {
+__global__ __launch_bounds__(256) void bm_to_tm_kernel(const float* bm, float* tm, int B, int L, int W, DropSpec dr, int vec) {
+  if (vec) {
+    const int W4 = W >> 2;
+    const long total4 = (long)B * L * W4;
+    for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+      const int c4 = (int)(e4 % W4);
+      const long rb = e4 / W4;
+      const int t = (int)(rb % L), b = (int)(rb / L);
+      const float4 x = *reinterpret_cast<const float4*>(bm + e4 * 4);
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale4(dr.seed, dr.off(), (uint32_t)e4, dr.p, m);
+      *reinterpret_cast<float4*>(tm + ((long)t * B + b) * W + c4 * 4) = make_float4(x.x * m[0], x.y * m[1], x.z * m[2], x.w * m[3]);
+    }
+    return;
+  }
   const long total = (long)B * L * W;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % W);
@@ -369,16 +401,18 @@ extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, cons
 extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, int L, int W, uint64_t seed,
                             uint64_t offset, float p, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_tm_to_bm: null pointer"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(tm_to_bm_kernel, dim3(nblk((long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
-                     (bf16_raw*)bm_bf16, B, L, W, DropSpec{seed, offset, p});
+  const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm) | reinterpret_cast<uintptr_t>(bm_bf16)) & 15) == 0;
+  hipLaunchKernelGGL(tm_to_bm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
+                     (bf16_raw*)bm_bf16, B, L, W, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("tm_to_bm");
   return VLN_OK;
 }
 extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p,
                             vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_bm_to_tm: null pointer"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(bm_to_tm_kernel, dim3(nblk((long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B, L, W,
-                     DropSpec{seed, offset, p});
+  const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm)) & 15) == 0;
+  hipLaunchKernelGGL(bm_to_tm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
+                     L, W, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("bm_to_tm");
   return VLN_OK;
 }

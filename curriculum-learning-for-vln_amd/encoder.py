@@ -65,8 +65,11 @@ class _EncoderFn(torch.autograd.Function):
                     x = y
         H = dirs * Hd
         ctx_out = ops.empty(B, L, H, **f32)
-        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), None, B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
+        # bf16 mode: the stream copy of the context the decoders' attention reads comes out of the same pass
+        ctx_lp = ops.empty(B, L, H, dtype=torch.bfloat16, device=dev) if wtype == ops.BF16 else None
+        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
                    "vln_tm_to_bm")
+        mod._last_ctx_lp = ctx_lp
         dec_init = ops.linear_fwd(hcat, sh["w_e2d"], mod.enc2dec.bias.detach(), ops.ACT_TANH)
         # dec_init is an OUTPUT: keeping the returned object on ctx would close a reference cycle through its grad_fn
         # (tensor -> node -> ctx -> tensor) that only the cyclic GC can free -- ~85 MB of activations per iteration
@@ -306,4 +309,8 @@ class EncoderLSTM(nn.Module):
             tokens = tokens.long()
         lens32 = torch.as_tensor(lengths).to(device=inputs.device, dtype=torch.int32)
         p = self.drop_ratio if self.training else 0.0
-        return _EncoderFn.apply(self, tokens, lens32, p, self._calls, *params)
+        ctx, dec_init, c_t = _EncoderFn.apply(self, tokens, lens32, p, self._calls, *params)
+        lp, self._last_ctx_lp = self.__dict__.get("_last_ctx_lp"), None
+        if lp is not None:
+            ctx._vln_lp = lp          # picked up by the decoders instead of casting the context again (runtime._ctx_lp)
+        return ctx, dec_init, c_t

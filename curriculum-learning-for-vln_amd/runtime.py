@@ -334,6 +334,10 @@ class GatedModuleMixin:
         if dtype == torch.float32:
             return None
         if entry.lp is None:
+            lp = getattr(ctx_t, "_vln_lp", None)      # EncoderLSTM (bf16 mode) already wrote the copy
+            if lp is not None and lp.dtype == dtype and lp.shape == ctx_t.shape and lp.device == ctx_t.device:
+                entry.lp = lp
+                return lp
             src = ctx_t.detach().contiguous()
             entry.lp = ops.cast_copy(src, dtype, ops.empty(src.shape, dtype=dtype, device=src.device))
         return entry.lp
