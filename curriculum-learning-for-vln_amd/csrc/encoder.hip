@@ -287,7 +287,22 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
 
 // ---- embedding gather (+dropout) to time-major rows, and its scatter-add backward ----------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens, const float* E, float* out, int B,
-                                                        int L, int D, DropSpec dr) {
+                                                        int L, int D, DropSpec dr, int vec) {
+  if (vec) {                                             // D % 4 == 0, aligned: float4 rows, one Philox call per four
+    const int D4 = D >> 2;
+    const long total4 = (long)L * B * D4;
+    for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+      const int c4 = (int)(e4 % D4);
+      const long rb = e4 / D4;
+      const int b = (int)(rb % B), t = (int)(rb / B);
+      const long tok = tokens[(long)b * L + t];
+      const float4 x = *reinterpret_cast<const float4*>(E + tok * D + c4 * 4);
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale4(dr.seed, dr.off(), (uint32_t)(((long)b * L + t) * D4 + c4), dr.p, m);
+      *reinterpret_cast<float4*>(out + e4 * 4) = make_float4(x.x * m[0], x.y * m[1], x.z * m[2], x.w * m[3]);
+    }
+    return;
+  }
   const long total = (long)L * B * D;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % D);
@@ -384,8 +399,9 @@ using namespace vln;
 extern "C" int vln_embed_fwd(const int64_t* tokens, const float* E, float* out_tm, int B, int L, int D,
                              uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
   if (!tokens || !E || !out_tm || B <= 0 || L <= 0 || D <= 0) { set_error("vln_embed_fwd: bad args"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
-                     (const long long*)tokens, E, out_tm, B, L, D, DropSpec{seed, offset, p});
+  const int vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out_tm)) & 15) == 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk(vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+                     (const long long*)tokens, E, out_tm, B, L, D, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("embed_fwd");
   return VLN_OK;
 }
