@@ -101,6 +101,7 @@ SIGNATURES = {
                               f32, ptr]),
     "vln_embed_fwd": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr]),
+    "vln_embed_bwd_det": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i64, u64, u64, f32, ptr]),
     "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),

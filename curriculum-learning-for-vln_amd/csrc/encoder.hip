@@ -330,6 +330,54 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* tokens,
   }
 }
 
+// Deterministic form (no float atomics; opt-in, ~5x the time of the atomic kernel): one workgroup per vocabulary row
+// scans the B*L tokens through a ballot compaction and adds the matching positions' gradient rows in (t, b) order --
+// with it a training iteration is reproducible bit for bit from run to run (every other reduction on the path already
+// has a fixed order).
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const long long* tokens, const int* lengths, const float* dx,
+                                                            float* dE, int B, int L, int D, long padding_idx, DropSpec dr) {
+  __shared__ int s_hit[256];
+  __shared__ int s_wcnt[4];
+  const long v = blockIdx.x;
+  if (v == padding_idx) return;
+  const int P = L * B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};               // columns threadIdx.x + k*256 (D <= 1024)
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    const int p = p0 + threadIdx.x;                  // time-major position p = t*B + b
+    bool hit = false;
+    if (p < P) {
+      const int t = p / B, b = p % B;
+      hit = t < lengths[b] && tokens[(long)b * L + t] == v;
+    }
+    const unsigned long long bal = __ballot(hit);
+    __syncthreads();                                 // the previous chunk's hits are consumed
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+    if (hit) s_hit[base + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+    const int n = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const int q = s_hit[i], t = q / B, b = q % B;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < D) {
+          const long idx = ((long)b * L + t) * D + c;
+          acc[k] += dx[(long)q * D + c] * dropout_scale1(dr.seed, dr.off(), (uint32_t)idx, dr.p);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = threadIdx.x + k * 256;
+    if (c < D) dE[v * D + c] += acc[k];
+  }
+}
+
 // ---- layout changes with fused dropout: time-major [L,B,W] <-> batch-major [B,L,W] -------------------------
 // [L,B,W] <-> [B,L,W] with the context dropout (units.py:71-72): four consecutive columns per thread (one Philox call,
 // 16-byte accesses) when W % 4 == 0 and the pointers are aligned (`vec`), else one element per thread.
@@ -412,6 +460,14 @@ extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, cons
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
                      (const long long*)tokens, lengths, dx_tm, dE, B, L, D, (long)padding_idx, DropSpec{seed, offset, p});
   VLN_CHECK_LAUNCH("embed_bwd");
+  return VLN_OK;
+}
+extern "C" int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE, int B, int L,
+                                 int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+  if (!tokens || !lengths || !dx_tm || !dE || V <= 0 || D <= 0 || D > 1024) { set_error("vln_embed_bwd_det: bad args (D <= 1024)"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(V), dim3(256), 0, (hipStream_t)s, (const long long*)tokens, lengths, dx_tm, dE, B, L,
+                     D, (long)padding_idx, DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("embed_bwd_det");
   return VLN_OK;
 }
 extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, int L, int W, uint64_t seed,

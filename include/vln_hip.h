@@ -223,6 +223,10 @@ int vln_embed_fwd(const int64_t* tokens /*[B,L]*/, const float* E, float* out_tm
                   uint64_t seed, uint64_t offset, float p, vln_stream_t s);
 int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE /* += */, int B, int L,
                   int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+/* Same gradient without float atomics (opt-in: ~5x the time): one workgroup per vocabulary row V adds its tokens'
+ * gradient rows in a fixed (t, b) order, so the result is reproducible bit for bit (D <= 1024). */
+int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE /* += */, int B, int L,
+                      int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
 int vln_tm_to_bm(const float* tm /*[L,B,W]*/, float* bm /*[B,L,W]*/, void* bm_bf16 /*nullable*/, int B, int L, int W,
                  uint64_t seed, uint64_t offset, float p, vln_stream_t s);
 int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p, vln_stream_t s);

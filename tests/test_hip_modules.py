@@ -340,6 +340,7 @@ def test_training_iteration_side_stream_overlap_is_transparent(vln):
         ag = bench.GpuAgent(vln, dev_, torch.float32, 1)
         ag.dec.overlap_wgrads = overlap
         ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
         ag.opt.lr = 0.0                                   # keep the weights: RMSprop's g/sqrt(g^2) amplifies last-bit noise
         loss = ag.iteration(tape)
         torch.cuda.synchronize()
@@ -372,12 +373,14 @@ def test_step_graphs_with_device_side_dropout_offset_are_transparent(vln):
         ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1)
         ag.dec.step_graphs = graphs
         ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
         ag.opt.lr = 0.0
         out = []
         for _ in range(2):
             loss = ag.iteration(tape)
             torch.cuda.synchronize()
-            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in ag.dec.parameters()]))
+            # every gradient of both modules: all reductions on the path (incl. the embedding's) have a fixed order
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
         res.append(out)
     for (la, ga), (lb, gb) in zip(res[0], res[1]):
         assert torch.equal(la, lb)
@@ -403,6 +406,7 @@ def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
         torch.manual_seed(17)
         ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=arena)
         ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
         tape["store"]._calls = 0                      # the store's feature-dropout stream restarts too
         ag.opt.lr = 0.0
         if arena:
@@ -411,7 +415,8 @@ def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
         for _ in range(5):
             loss = ag.iteration(tape)
             torch.cuda.synchronize()
-            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in ag.dec.parameters()]))
+            # every gradient of both modules: all reductions on the path (incl. the embedding's) have a fixed order
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
         if arena:
             lib.vln_graph_stats(st1)
             assert ag.arena.misses == 0
