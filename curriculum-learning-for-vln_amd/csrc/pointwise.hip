@@ -603,6 +603,104 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
 static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace vln
 
+// ---------------------------------------------------------------------------------------------------------------
+// The sampled-action branch of the rollouts (envdrop.py:186-195) in ONE launch: probs = softmax(mask(logits)),
+// a ~ Categorical(probs) (drawn with the kernels' Philox stream when no action is given), log pi(a) and the entropy with
+// torch.distributions' clamp, one thread per episode (<= 64 candidates).  Backward (one launch):
+//   d logits_j = dlogp (1[j = a] - p_j) - dent p_j (log p_j + H)        (clamped / masked slots carry no gradient)
+// ---------------------------------------------------------------------------------------------------------------
+namespace vln {
+__global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* logits, long ld, const unsigned char* mask,
+                                                              const long long* action_in, long long* action_out, float* probs,
+                                                              float* logp, float* ent, int B, int C, uint64_t seed, uint64_t offset) {
+  const float eps = 1.1920928955078125e-07f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const float* lg = logits + (long)b * ld;
+    const unsigned char* mk = mask ? mask + (long)b * C : nullptr;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, (mk && mk[c]) ? -INFINITY : lg[c]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx);
+    const float inv = 1.f / sum;
+    long a;
+    if (action_in) a = action_in[b];
+    else {                                          // inverse-CDF draw from the row's own Philox word
+      const Philox4 r = philox4x32_10(seed, offset, (uint32_t)b);
+      const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+      float cum = 0.f;
+      a = -1;
+      long last = 0;
+      for (int c = 0; c < C; ++c) {
+        const float pc = __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx) * inv;
+        if (pc > 0.f) last = c;
+        cum += pc;
+        if (a < 0 && u < cum) a = c;
+      }
+      if (a < 0) a = last;
+    }
+    float H = 0.f, la = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float pc = __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx) * inv;
+      probs[(long)b * C + c] = pc;
+      const float lc = __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+      H -= pc * lc;
+      if (c == a) la = lc;
+    }
+    if (action_out) action_out[b] = a;
+    logp[b] = la;
+    ent[b] = H;
+  }
+}
+__global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* probs, const long long* action, const float* dlogp,
+                                                              const float* dent, float* dlogits, int B, int C) {
+  const float eps = 1.1920928955078125e-07f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const float* p = probs + (long)b * C;
+    const long a = action[b];
+    const float gl = dlogp ? dlogp[b] : 0.f, ge = dent ? dent[b] : 0.f;
+    // clamp_probs passes no gradient where it clamps: only slots with eps <= p <= 1 - eps count in the p-gradients
+    float gp_dot = 0.f;                              // sum_j (dL/dp_j) p_j over the live slots
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[c];
+      const bool live = pc >= eps && pc <= 1.f - eps;
+      float gp = 0.f;                                // dL/dp_c
+      if (live) gp = ((c == a) ? gl / pc : 0.f) - ge * (__logf(pc) + 1.f);
+      else gp = -ge * __logf(fminf(fmaxf(pc, eps), 1.f - eps));      // H = -sum p log(clamp p): the p factor still differentiates
+      gp_dot += gp * pc;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[c];
+      const bool live = pc >= eps && pc <= 1.f - eps;
+      float gp = 0.f;
+      if (live) gp = ((c == a) ? gl / pc : 0.f) - ge * (__logf(pc) + 1.f);
+      else gp = -ge * __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+      dlogits[(long)b * C + c] = pc * (gp - gp_dot);   // softmax backward; masked slots have p = 0 -> 0
+    }
+  }
+}
+}  // namespace vln
+
+extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mask, const int64_t* action_in,
+                                   int64_t* action_out, float* probs, float* logp, float* entropy, int B, int C, uint64_t seed,
+                                   uint64_t offset, void* s) {
+  if (!logits || !probs || !logp || !entropy || B <= 0 || C <= 0 || (!action_in && !action_out)) {
+    vln::set_error("vln_categorical_fwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  hipLaunchKernelGGL(vln::categorical_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
+                     (const long long*)action_in, (long long*)action_out, probs, logp, entropy, B, C, seed, offset);
+  VLN_CHECK_LAUNCH("categorical_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp, const float* dent, float* dlogits,
+                                   int B, int C, void* s) {
+  if (!probs || !action || !dlogits || B <= 0 || C <= 0) { vln::set_error("vln_categorical_bwd: bad args"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(vln::categorical_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, probs,
+                     (const long long*)action, dlogp, dent, dlogits, B, C);
+  VLN_CHECK_LAUNCH("categorical_bwd");
+  return VLN_OK;
+}
+
 extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
                           int R, int D, float eps, float momentum, int training, int relu, void* s) {

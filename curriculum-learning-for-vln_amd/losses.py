@@ -164,3 +164,53 @@ def a2c_loss(log_probs, entropies, values, rewards, masks, last_value, ended, ga
     elif normalize != "none":
         raise ValueError("normalize must be 'total', 'batch' or 'none'")
     return loss, total
+
+
+class _Categorical(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, cand_mask, action, seed, offset):
+        B, C = logits.shape
+        dev = logits.device
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        probs = ops.empty(B, C, dtype=torch.float32, device=dev)
+        logp = ops.empty(B, dtype=torch.float32, device=dev)
+        ent = ops.empty(B, dtype=torch.float32, device=dev)
+        act = action.contiguous() if action is not None else ops.empty(B, dtype=torch.int64, device=dev)
+        st = _lib.load().vln_categorical_fwd(_p(lg), lg.stride(0), _p(_mask8(cand_mask)), _p(action if action is None else act),
+                                             None if action is not None else act.data_ptr(), _p(probs), _p(logp), _p(ent), B, C,
+                                             seed, offset, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_categorical_fwd")
+        ctx.save_for_backward(probs, act)
+        ctx.mark_non_differentiable(act)
+        return act, logp, ent
+
+    @staticmethod
+    def backward(ctx, _da, dlogp, dent):
+        probs, act = ctx.saved_tensors
+        B, C = probs.shape
+        dl = ops.empty_like(probs)
+        gl = dlogp.contiguous() if dlogp is not None else None
+        ge = dent.contiguous() if dent is not None else None
+        st = _lib.load().vln_categorical_bwd(_p(probs), _p(act), _p(gl), _p(ge), _p(dl), B, C, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_categorical_bwd")
+        return dl, None, None, None, None
+
+
+_sample_calls = [0]
+
+
+def sample_action(logits: torch.Tensor, cand_mask: Optional[torch.Tensor] = None, action: Optional[torch.Tensor] = None,
+                  seed: int = 0x5A3B1E, offset: Optional[int] = None):
+    """The sampled-action branch of a rollout step (envdrop.py:186-195) as ONE launch, differentiable:
+    `probs = softmax(logits.masked_fill(cand_mask, -inf)); c = Categorical(probs); a = c.sample();
+    policy_log_probs.append(c.log_prob(a)); entropys.append(c.entropy())`  ->  (a, log_prob [B], entropy [B]).
+    `action` given: its log-prob / entropy instead of a draw (teacher or injected actions).  Draws come from the kernels'
+    Philox stream (seed, offset; offset defaults to a running counter), not from torch's generator."""
+    if offset is None:
+        _sample_calls[0] += 1
+        offset = _sample_calls[0]
+    return _Categorical.apply(logits, cand_mask, action, int(seed), int(offset))

@@ -170,6 +170,16 @@ int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target /*nullabl
 int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, int64_t dloss_stride, float* dlogits,
                       int B, int C, int64_t ignore_index, vln_stream_t s);
 
+/* The sampled-action branch of a rollout step (envdrop.py:186-195) as one launch: probs = softmax(logits masked with
+ * -inf where cand_mask), action ~ Categorical(probs) unless action_in is given (then action_out may be NULL), logp =
+ * log pi(action) and the entropy with torch.distributions' clamp_probs.  The draw uses the Philox word (seed, offset, b).
+ * Backward: dlogits from the upstream gradients on logp and entropy (either may be NULL). */
+int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mask /*nullable*/, const int64_t* action_in /*nullable*/,
+                        int64_t* action_out /*nullable*/, float* probs, float* logp, float* entropy, int B, int C, uint64_t seed,
+                        uint64_t offset, vln_stream_t s);
+int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp /*nullable*/, const float* dent /*nullable*/,
+                        float* dlogits, int B, int C, vln_stream_t s);
+
 /* BatchNorm1d (+ fused ReLU): the BN-MLP of the Self-Monitor agent (units.py:210-242; `bn_mlp` =
  * vln_bn_fwd / vln_linear_fwd / vln_bn_fwd(relu)).  Training: batch statistics, running statistics updated in place with
  * `momentum` and the unbiased variance, *num_batches_tracked += 1, save_mean / save_rstd [D] kept for backward.  Eval:

@@ -108,11 +108,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
             if not sample:
                 ml = ml + vln.losses.masked_cross_entropy(logit, s["target"], s["cand_mask"], "sum")
             else:
-                masked = logit.masked_fill(s["cand_mask"], -float("inf"))
-                p = torch.softmax(masked, 1)
-                a = torch.multinomial(p.detach(), 1).squeeze(1)                 # envdrop.py:186-195
-                lpz = torch.log(p.clamp(1.1920928955078125e-07, 1 - 1.1920928955078125e-07))
-                logps.append(lpz.gather(1, a[:, None]).squeeze(1)); ents.append(-(p * lpz).sum(1))
+                a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])     # envdrop.py:186-195 as one launch
+                logps.append(lp_a); ents.append(en_a)
         if not sample:
             return ml * 0.2 / B
         img, cand = feats(tape["steps"][T - 1])

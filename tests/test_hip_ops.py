@@ -117,6 +117,38 @@ def test_batch_norm_kernel(vln, R, D, relu):
         assert int(nbt) == (1 if training else 0)
 
 
+@pytest.mark.parametrize("B,C", [(64, 8), (300, 15), (5, 1)])
+def test_sample_action_kernel(vln, B, C):
+    """losses.sample_action vs torch.distributions.Categorical on the masked softmax: log-prob and entropy of a given
+    action, their gradients w.r.t. the logits, and the empirical distribution of the kernel's own draws."""
+    g = torch.Generator().manual_seed(B + C)
+    logits = torch.randn(B, C, generator=g) * 2
+    ncand = torch.randint(1, C + 1, (B,), generator=g)
+    mask = torch.arange(C)[None, :] >= ncand[:, None]
+    act = (torch.rand(B, generator=g) * ncand.float()).long()
+    l64 = logits.clone().requires_grad_(True)          # fp32 reference: clamp_probs' eps is the dtype's (1.19e-7 here)
+    dist = torch.distributions.Categorical(torch.softmax(l64.masked_fill(mask, -float("inf")), 1))
+    lp_ref, en_ref = dist.log_prob(act), dist.entropy()
+    w1, w2 = torch.randn(B, generator=g), torch.randn(B, generator=g)
+    ((lp_ref * w1).sum() + (en_ref * w2).sum()).backward()
+    d = dev()
+    ld = logits.to(d).requires_grad_(True)
+    a, lp, en = vln.losses.sample_action(ld, mask.to(d), act.to(d))
+    assert torch.equal(a.cpu(), act)
+    assert (lp.cpu() - lp_ref.detach()).abs().max() < 1e-5 and (en.cpu() - en_ref.detach()).abs().max() < 1e-5
+    ((lp * w1.to(d)).sum() + (en * w2.to(d)).sum()).backward()
+    assert (ld.grad.cpu() - l64.grad).abs().max() < 1e-4 * max(1.0, l64.grad.abs().max().item())
+    # draws: never a masked slot, frequencies follow the probabilities
+    row = torch.tensor([[1.0, 0.0, -1.0, 2.0] + [0.0] * 4]).repeat(4096, 1).to(d)
+    rmask = torch.tensor([[False, False, False, False] + [True] * 4]).repeat(4096, 1).to(d)
+    draws, lpd, _ = vln.losses.sample_action(row, rmask)
+    assert int(draws.max()) <= 3
+    freq = torch.bincount(draws.cpu(), minlength=4).float() / 4096
+    p = torch.softmax(torch.tensor([1.0, 0.0, -1.0, 2.0]), 0)
+    assert (freq[:4] - p).abs().max().item() < 0.03
+    assert rel_err(lpd, torch.log(p)[draws.cpu()]) < 1e-5
+
+
 @pytest.mark.parametrize("T,B,with_ent", [(7, 64, True), (35, 64, True), (5, 3, False), (1, 130, True)])
 def test_a2c_loss_kernel_matches_the_restated_sweep(vln, T, B, with_ent):
     """vln_a2c_loss_fwd/bwd vs oracle/torch_port.py::a2c_loss (the restatement of envdrop.py:235-264, pinned by the
