@@ -93,8 +93,9 @@ SIGNATURES = {
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
-    "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, ptr]),
-    "vln_bn_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, ptr, i32, i32, f32, i32, i32, i32, ptr]),
+    "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_bn_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, ptr, i32, i32, f32, i32, i32, i32, u64, u64, f32,
+                         ptr, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),

@@ -463,6 +463,8 @@ struct BnArgs {
   const float* gamma; const float* beta; float* run_mean; float* run_var; long long* nbt;
   float* save_mean; float* save_rstd;
   int R, D; float eps, momentum; int training, relu;
+  DropSpec drop;                    // optional dropout between the normalisation and the ReLU (MLPwithBN: BN, Dropout, ReLU)
+  const unsigned char* row_zero;    // optional [R]: rows whose output is forced to 0 (padded candidate slots, policy.py:148-149)
 };
 __device__ __forceinline__ float4 bn_strip_sum(float4 v, float4 (*part)[4], int rl, int cg) {
   part[rl][cg] = v;
@@ -528,7 +530,13 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
     const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
     float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
                            (t.z - mean.z) * rstd.z * g.z + bt.z, (t.w - mean.w) * rstd.w * g.w + bt.w);
+    if (a.drop.p > 0.f) {
+      float m[4];
+      dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + c) >> 2), a.drop.p, m);
+      o.x *= m[0]; o.y *= m[1]; o.z *= m[2]; o.w *= m[3];
+    }
     if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (a.row_zero && a.row_zero[r]) o = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(a.y + (long)r * a.ldy + c) = o;
   }
 }
@@ -538,6 +546,7 @@ struct BnBwdArgs {
   const float* gamma; const float* mean; const float* rstd;     // training: saved batch stats; eval: running mean, var
   float* dx; long lddx; float* dgamma; float* dbeta;
   int R, D; float eps; int training, relu, accumulate;
+  DropSpec drop; const unsigned char* row_zero;     // as in the forward
 };
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   __shared__ float4 part[64][4];
@@ -551,6 +560,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + cc) : make_float4(1.f, 1.f, 1.f, 1.f);
   auto grad_at = [&](int r) {                // dy of row r with the fused ReLU's mask applied
     float4 dv = *reinterpret_cast<const float4*>(a.dy + (long)r * a.lddy + cc);
+    if (a.row_zero && a.row_zero[r]) dv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.drop.p > 0.f) {
+      float m[4];
+      dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + cc) >> 2), a.drop.p, m);
+      dv.x *= m[0]; dv.y *= m[1]; dv.z *= m[2]; dv.w *= m[3];
+    }
     if (a.relu) {
       const float4 yv = *reinterpret_cast<const float4*>(a.y + (long)r * a.ldy + cc);
       dv.x = yv.x > 0.f ? dv.x : 0.f; dv.y = yv.y > 0.f ? dv.y : 0.f; dv.z = yv.z > 0.f ? dv.z : 0.f; dv.w = yv.w > 0.f ? dv.w : 0.f;
@@ -703,7 +718,8 @@ extern "C" int vln_categorical_bwd(const float* probs, const int64_t* action, co
 
 extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
-                          int R, int D, float eps, float momentum, int training, int relu, void* s) {
+                          int R, int D, float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset,
+                          float p_drop, const uint8_t* row_zero, void* s) {
   using namespace vln;
   if (!x || !y || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3) || !al16p(x) || !al16p(y) ||
       (!training && (!running_mean || !running_var)) || (training && (!save_mean || !save_rstd))) {
@@ -711,14 +727,15 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
     return VLN_ERR_ARG;
   }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
-           R, D, eps, momentum, training, relu};
+           R, D, eps, momentum, training, relu, DropSpec{seed, offset, p_drop}, row_zero};
   hipLaunchKernelGGL(bn_fwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_fwd");
   return VLN_OK;
 }
 extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
                           const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R,
-                          int D, float eps, int training, int relu, int accumulate, void* s) {
+                          int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, float p_drop,
+                          const uint8_t* row_zero, void* s) {
   using namespace vln;
   if (!x || !dy || !mean || !rstd_or_var || (relu && !y) || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) ||
       (relu && (ldy & 3)) || !al16p(x) || !al16p(dy) || (dx && !al16p(dx)) ) {
@@ -726,7 +743,7 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
     return VLN_ERR_ARG;
   }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
-              training, relu, accumulate};
+              training, relu, accumulate, DropSpec{seed, offset, p_drop}, row_zero};
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_bwd");
   return VLN_OK;

@@ -201,7 +201,55 @@ class MLPwithBN(nn.Module):
             self.out_size = out_size
         self.mlp = nn.Sequential(*layers)
 
-    def forward(self, x):
+    def _fused_plan(self):
+        """(bn0, [(linear, bn, dropout or None)]) when the Sequential is exactly BatchNorm, (Linear, BatchNorm, [Dropout],
+        ReLU)* -- the layout the Self-Monitor agent builds -- else None."""
+        plan = self.__dict__.get("_plan", False)
+        if plan is not False:
+            return plan
+        layers = list(self.mlp)
+        plan = None
+        if layers and isinstance(layers[0], _HipBatchNorm1d):
+            i, seq, ok = 1, [], True
+            while i < len(layers) and ok:
+                if not (isinstance(layers[i], _HipLinear) and i + 1 < len(layers) and isinstance(layers[i + 1], _HipBatchNorm1d)):
+                    ok = False
+                    break
+                lin, bnl = layers[i], layers[i + 1]
+                i += 2
+                dr = None
+                if i < len(layers) and isinstance(layers[i], _PhiloxDropout):
+                    dr = layers[i]; i += 1
+                if i < len(layers) and isinstance(layers[i], nn.ReLU):
+                    i += 1
+                else:
+                    ok = False
+                seq.append((lin, bnl, dr))
+            if ok and seq and all(m.track_running_stats and m.momentum is not None and m.affine for m in [layers[0]] + [t[1] for t in seq]):
+                plan = (layers[0], seq)
+        object.__setattr__(self, "_plan", plan)
+        return plan
+
+    def forward(self, x, row_zero=None):
+        """`row_zero` [rows] (bool): output rows forced to 0 (the padded candidate slots, policy.py:148-149)."""
+        plan = self._fused_plan()
+        if plan is not None and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda and x.shape[1] % 4 == 0 and \
+                all(t[0].out_features % 4 == 0 for t in plan[1]):
+            bn0, seq = plan
+            training = self.training
+            drops, bufs, tensors = [], [(bn0.running_mean, bn0.running_var, bn0.num_batches_tracked)], [bn0.weight, bn0.bias]
+            for lin, bnl, dr in seq:
+                p = dr.p if (dr is not None and training) else 0.0
+                drops.append((float(p), dr.dropout_seed if dr is not None else 0, dr._next() if (dr is not None and p > 0) else 0))
+                bufs.append((bnl.running_mean, bnl.running_var, bnl.num_batches_tracked))
+                tensors += [lin.weight, lin.bias, bnl.weight, bnl.bias]
+            return Fh.bn_mlp(x, row_zero, training, bn0.eps, bn0.momentum, seq[0][0].compute_dtype, drops, bufs, tensors)
+        y = self._forward_layers(x)
+        if row_zero is not None:
+            y = y * (~row_zero).to(y.dtype).unsqueeze(1)
+        return y
+
+    def _forward_layers(self, x):
         layers = list(self.mlp)
         i = 0
         while i < len(layers):                    # BatchNorm followed by ReLU (no dropout between) is one launch
@@ -266,8 +314,9 @@ class MonitorDecoder(nn.Module, _Seeded):
         # BN-MLP twice (previous action rows, then all B*C candidate rows incl. padded ones): two sets of batch
         # statistics and two running-stat updates per step, as in the reference
         prev_rep = self.proj_navigable_mlp(a_t_prev)
-        cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size)).view(B, C, -1)
-        cand_rep = cand_rep * (~candidate_mask).to(cand_rep.dtype).unsqueeze(2)        # padded slots -> 0
+        # the BN-MLP zeroes the padded candidate slots itself (row_zero): one autograd node per call
+        cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size),
+                                           row_zero=candidate_mask.reshape(B * C)).view(B, C, -1)
         # co-grounding: words (position-encoded context) and candidates, both queried by h_0
         words, word_w = self.text_attn(h_0, self.position(ctx), ctx_mask)
         moves, move_w = self.visual_attn(h_0, cand_rep, candidate_mask)

@@ -271,7 +271,7 @@ class BatchNormFn(torch.autograd.Function):
         use_batch = bool(training or running_mean is None)
         st = _lib.load().vln_bn_fwd(_p(xc), xc.stride(0), _p(y), y.stride(0), _p(weight), _p(bias), _p(running_mean), _p(running_var),
                                     _p(nbt) if training else None, _p(stats), None if stats is None else stats.data_ptr() + 4 * D,
-                                    R, D, eps, momentum, 1 if use_batch else 0, 1 if relu else 0, _lib.raw_stream())
+                                    R, D, eps, momentum, 1 if use_batch else 0, 1 if relu else 0, 0, 0, 0.0, None, _lib.raw_stream())
         if st:
             _lib.check(st, "vln_bn_fwd")
         ctx.save_for_backward(xc, y if relu else None, weight, stats, None if use_batch else running_mean, None if use_batch else running_var)
@@ -293,7 +293,7 @@ class BatchNormFn(torch.autograd.Function):
         st = _lib.load().vln_bn_bwd(_p(xc), xc.stride(0), _p(dy), dy.stride(0), _p(y), 0 if y is None else y.stride(0), _p(weight),
                                     mean_p, rstd_p, _p(dx), 0 if dx is None else dx.stride(0), None if dgb is None else dgb.data_ptr(),
                                     None if dgb is None else dgb.data_ptr() + 4 * D, R, D, eps, 1 if use_batch else 0,
-                                    1 if relu else 0, 0, _lib.raw_stream())
+                                    1 if relu else 0, 0, 0, 0, 0.0, None, _lib.raw_stream())
         if st:
             _lib.check(st, "vln_bn_bwd")
         return dx, (dgb[0] if need_w else None), (dgb[1] if need_w else None), None, None, None, None, None, None, None
@@ -302,3 +302,112 @@ class BatchNormFn(torch.autograd.Function):
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum=0.1, eps=1e-5, relu=False):
     return BatchNormFn.apply(x, weight, bias, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
                              float(eps), bool(relu))
+
+
+class BnMlpFn(torch.autograd.Function):
+    """MLPwithBN (units.py:210-242) with use_bn and relu -- BatchNorm, then per hidden layer Linear, BatchNorm, Dropout,
+    ReLU -- as ONE autograd node: forward = one BatchNorm launch per layer (statistics, normalisation, dropout, ReLU and
+    the zeroing of padded rows fused, vln_bn_fwd) + one GEMM per layer; backward = the mirrored chain with every weight
+    gradient of the call in one grouped launch and every bias gradient in another.  `cfg` = (training, eps, momentum,
+    dtype, [(p_drop, seed, offset) per hidden layer]); `row_zero` [R] uint8/bool or None zeroes output rows
+    (policy.py:148-149).  tensors = bn0.w, bn0.b, then per layer W, b, bn.w, bn.b; buffers (running stats, counters)
+    ride in `bufs` and are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, row_zero, cfg, bufs, *tensors):
+        training, eps, momentum, dtype, drops = cfg
+        lib = _lib.load()
+        st_ = _lib.raw_stream()
+        x = x.detach()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        R = x.shape[0]
+        dev = x.device
+        nl = (len(tensors) - 2) // 4
+        rz = None
+        if row_zero is not None:
+            rz = row_zero.contiguous()
+            rz = rz.view(torch.uint8) if rz.dtype == torch.bool else rz.to(torch.uint8)
+
+        def bn(inp, w, b, buf, relu, drop, rzp):
+            D = inp.shape[1]
+            out = ops.empty(R, D, dtype=torch.float32, device=dev)
+            stats = ops.empty(2, D, dtype=torch.float32, device=dev) if training else None
+            rm, rv, nbt = buf
+            p_, seed_, off_ = drop
+            rc = lib.vln_bn_fwd(_p(inp), inp.stride(0), _p(out), out.stride(0), _p(w), _p(b), _p(rm), _p(rv), _p(nbt) if training else None,
+                                _p(stats), None if stats is None else stats.data_ptr() + 4 * D, R, D, eps, momentum,
+                                1 if training else 0, 1 if relu else 0, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
+            if rc:
+                _lib.check(rc, "vln_bn_fwd")
+            return out, stats
+
+        saved = []
+        y, s0 = bn(x, tensors[0], tensors[1], bufs[0], False, (0.0, 0, 0), None)
+        saved += [x, s0, y]
+        for i in range(nl):
+            W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
+            z = ops.linear_fwd(y, SHADOWS.get(W, "n", dtype), None if b is None else b.detach())
+            last = i == nl - 1
+            y, si = bn(z, gw, gb, bufs[1 + i], True, drops[i], rz if last else None)
+            saved += [z, si, y]
+        ctx.cfg, ctx.bufs, ctx.nl, ctx.rz = cfg, bufs, nl, rz
+        ctx.save_for_backward(*[t for t in saved if t is not None], *tensors)
+        ctx.layout = [t is not None for t in saved]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, eps, momentum, dtype, drops = ctx.cfg
+        lib = _lib.load()
+        st_ = _lib.raw_stream()
+        nl, rz, bufs = ctx.nl, ctx.rz, ctx.bufs
+        it = iter(ctx.saved_tensors)
+        saved = [next(it) if present else None for present in ctx.layout]
+        tensors = list(it)
+        x, s0, y0 = saved[0], saved[1], saved[2]
+        R = x.shape[0]
+        dev = x.device
+        grads = [None] * len(tensors)
+        wb = ops.WgradBatch(dtype != torch.float32)
+        cb = ops.ColsumBatch()
+
+        def bn_bwd(inp, dyy, yy, w, stats, buf, relu, drop, rzp, want_dx, gi):
+            D = inp.shape[1]
+            dx = ops.empty(R, D, dtype=torch.float32, device=dev) if want_dx else None
+            dgb = torch.empty(2, D, dtype=torch.float32, device=dev)
+            p_, seed_, off_ = drop
+            mean_p = stats.data_ptr() if training else buf[0].data_ptr()
+            rstd_p = stats.data_ptr() + 4 * D if training else buf[1].data_ptr()
+            rc = lib.vln_bn_bwd(_p(inp), inp.stride(0), _p(dyy), dyy.stride(0), _p(yy), 0 if yy is None else yy.stride(0), _p(w), mean_p,
+                                rstd_p, _p(dx), 0 if dx is None else dx.stride(0), dgb.data_ptr(), dgb.data_ptr() + 4 * D, R, D, eps,
+                                1 if training else 0, 1 if relu else 0, 0, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
+            if rc:
+                _lib.check(rc, "vln_bn_bwd")
+            grads[gi], grads[gi + 1] = dgb[0], dgb[1]
+            return dx
+
+        g = dy.contiguous()
+        for i in range(nl - 1, -1, -1):
+            W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
+            z, si, y = saved[3 + 3 * i], saved[4 + 3 * i], saved[5 + 3 * i]
+            y_prev = saved[2 + 3 * i]                    # input of this layer's Linear (y0 for i = 0)
+            dz = bn_bwd(z, g, y, gw, si, bufs[1 + i], True, drops[i], rz if i == nl - 1 else None, True, 4 + 4 * i)
+            dW = torch.empty_like(W)
+            wb.add(dz, y_prev, dW, False)
+            grads[2 + 4 * i] = dW
+            if b is not None:
+                db = torch.empty_like(b)
+                cb.add(dz, db, None, False)
+                grads[3 + 4 * i] = db
+            g = ops.linear_fwd(dz, SHADOWS.get(W, "t", dtype))
+            if i > 0 or True:
+                pass
+        # Mt is the same for every product of the call: one grouped launch each for weights and biases
+        wb.run(); cb.run()
+        dx = bn_bwd(x, g, None, tensors[0], s0, bufs[0], False, (0.0, 0, 0), None, ctx.needs_input_grad[0], 0)
+        return (dx, None, None, None) + tuple(grads)
+
+
+def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors):
+    return BnMlpFn.apply(x, row_zero, (bool(training), float(eps), float(momentum), dtype, tuple(drops)), tuple(bufs), *tensors)

@@ -183,14 +183,17 @@ int vln_categorical_bwd(const float* probs, const int64_t* action, const float* 
 /* BatchNorm1d (+ fused ReLU): the BN-MLP of the Self-Monitor agent (units.py:210-242; `bn_mlp` =
  * vln_bn_fwd / vln_linear_fwd / vln_bn_fwd(relu)).  Training: batch statistics, running statistics updated in place with
  * `momentum` and the unbiased variance, *num_batches_tracked += 1, save_mean / save_rstd [D] kept for backward.  Eval:
- * running statistics.  Backward: training form with the saved statistics, eval form with (running_mean, running_var). */
+ * running statistics.  Backward: training form with the saved statistics, eval form with (running_mean, running_var).
+ * Optional epilogue in the BN-MLP's layer order (BatchNorm, Dropout, ReLU): a Philox dropout (seed, offset, p_drop) between
+ * the normalisation and the ReLU, and row_zero[r] != 0 forcing output row r to 0 (padded candidate slots). */
 int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
                float* running_var, int64_t* num_batches_tracked /*nullable*/, float* save_mean, float* save_rstd, int R, int D,
-               float eps, float momentum, int training, int relu, vln_stream_t s);
+               float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, float p_drop /*0: none*/,
+               const uint8_t* row_zero /*nullable [R]*/, vln_stream_t s);
 int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y /*relu only*/, int64_t ldy,
                const float* gamma, const float* mean, const float* rstd_or_var, float* dx /*nullable*/, int64_t lddx,
                float* dgamma /*nullable*/, float* dbeta /*nullable*/, int R, int D, float eps, int training, int relu,
-               int accumulate, vln_stream_t s);
+               int accumulate, uint64_t seed, uint64_t offset, float p_drop, const uint8_t* row_zero, vln_stream_t s);
 
 /* A2C sweep of the EnvDrop rollout (envdrop.py:235-264) as one launch.  All step tensors are stacked [T,B]:
  * logp = log pi(a_t), ent = entropies (NULL with ent_coef unused: feedback != "sample"), val = critic values (with
