@@ -198,6 +198,13 @@ extern "C" int vln_attn_dctx_deferred(const float* const* alpha, const float* co
   if (!alpha || !dl || !g || !q || !dctx) { set_error("vln_attn_dctx_deferred: null pointer"); return VLN_ERR_ARG; }
   return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate);
 }
+extern "C" int vln_attn_dctx_deferred_drop(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
+                                           const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,
+                                           int accumulate, const uint64_t* drop_seed, const uint64_t* drop_off,
+                                           const float* drop_p, vln_stream_t s) {
+  if (!alpha || !dl || !g || !q || !dctx) { set_error("vln_attn_dctx_deferred_drop: null pointer"); return VLN_ERR_ARG; }
+  return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate, drop_seed, drop_off, drop_p);
+}
 extern "C" int vln_lstm_pointwise_fwd(const float* gates, int nsplit, int64_t slab_stride, const float* b_ih,
                                       const float* b_hh, const float* c0, float* h1, float* c1, float* act,
                                       float* tanh_c1, float* h1_drop, uint64_t seed, uint64_t offset, float p, int B,

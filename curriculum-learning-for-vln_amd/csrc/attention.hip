@@ -323,7 +323,8 @@ int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* at
 }
 
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
-                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate) {
+                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,
+                       const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p) {
   if (T <= 0 || B <= 0 || S <= 0 || D <= 0 || (D & 3) || !aligned16(dctx)) {
     set_error("attn_dctx_deferred: bad args (T=%d B=%d S=%d D=%d)", T, B, S, D);
     return VLN_ERR_ARG;
@@ -337,8 +338,10 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
     a.vec_ok = ((ldg & 3) == 0 && (ldq & 3) == 0) ? 1 : 0;
     for (int t = 0; t < a.T; ++t) {
       a.alpha[t] = alpha[t0 + t]; a.dl[t] = dl[t0 + t]; a.g[t] = g[t0 + t]; a.q[t] = q[t0 + t];
-      if (!a.alpha[t] || !a.dl[t] || !a.g[t] || !a.q[t]) { set_error("attn_dctx_deferred: null step pointer"); return VLN_ERR_ARG; }
-      if (!aligned16(a.g[t]) || !aligned16(a.q[t])) a.vec_ok = 0;
+      if (!a.alpha[t] || !a.g[t] || (!a.dl[t]) != (!a.q[t])) { set_error("attn_dctx_deferred: null step pointer"); return VLN_ERR_ARG; }
+      if (!aligned16(a.g[t]) || (a.q[t] && !aligned16(a.q[t]))) a.vec_ok = 0;
+      a.drop_seed[t] = drop_seed ? drop_seed[t0 + t] : 0; a.drop_off[t] = drop_off ? drop_off[t0 + t] : 0;
+      a.drop_p[t] = drop_p ? drop_p[t0 + t] : 0.f;
     }
     a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0;
     const unsigned lds = (unsigned)(2 * a.T * (D + 16) * sizeof(float));

@@ -240,6 +240,9 @@ struct DctxArgs {
   long ldg, ldq;
   float* dctx;                         // [B,S,D]
   int T, S, D, accumulate, vec_ok;
+  // optional: step t's contribution passed through a dropout mask of the attended tensor (the Self-Monitor agent attends
+  // dropout(ctx + pe) with a fresh mask every step: units.py:188-207); p == 0: none.  Mask index = flat [B,S,D] index.
+  unsigned long long drop_seed[kDctxMaxSteps], drop_off[kDctxMaxSteps]; float drop_p[kDctxMaxSteps];
 };
 __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [2T][D] vectors, then [2T][16] row weights
@@ -249,17 +252,21 @@ __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
   float* swt = sm + (long)2 * T * D;
   for (int i = threadIdx.x; i < 2 * T * (D / 4); i += 256) {
     const int v = i / (D / 4), d4 = i % (D / 4);
-    const float* src = ((v < T) ? a.g[v] + (long)b * a.ldg : a.q[v - T] + (long)b * a.ldq) + d4 * 4;
-    float4 t;
-    if (a.vec_ok) t = *reinterpret_cast<const float4*>(src);
-    else t = make_float4(src[0], src[1], src[2], src[3]);
+    const float* base = (v < T) ? a.g[v] : a.q[v - T];
+    const float* src = base ? base + (long)b * ((v < T) ? a.ldg : a.ldq) + d4 * 4 : nullptr;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src) {
+      if (a.vec_ok) t = *reinterpret_cast<const float4*>(src);
+      else t = make_float4(src[0], src[1], src[2], src[3]);
+    }
     *reinterpret_cast<float4*>(&sv[(long)v * D + d4 * 4]) = t;
   }
   for (int i = threadIdx.x; i < 2 * T * 16; i += 256) {
     const int v = i / 16, r = i % 16;
     const int s = s0 + r;
     float w = 0.f;
-    if (s < S) w = (v < T) ? a.alpha[v][(long)b * S + s] : a.dl[v - T][(long)b * S + s];
+    const float* wp = (v < T) ? a.alpha[v] : a.dl[v - T];
+    if (s < S && wp) w = wp[(long)b * S + s];
     swt[i] = w;
   }
   __syncthreads();
@@ -268,12 +275,26 @@ __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
   const int s = s0 + r;
   if (s >= S) return;
   float* out = a.dctx + ((long)b * S + s) * D;
+  bool any_drop = false;
+  for (int t = 0; t < T; ++t) any_drop |= a.drop_p[t] > 0.f;
   for (int c = c0; c < D / 4; c += 16) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int v = 0; v < 2 * T; ++v) {
-      const float w = swt[v * 16 + r];
-      const float4 x = *reinterpret_cast<const float4*>(&sv[(long)v * D + c * 4]);
-      acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+    if (!any_drop) {
+      for (int v = 0; v < 2 * T; ++v) {
+        const float w = swt[v * 16 + r];
+        const float4 x = *reinterpret_cast<const float4*>(&sv[(long)v * D + c * 4]);
+        acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+      }
+    } else {
+      for (int t = 0; t < T; ++t) {          // per step: (alpha_t g_t + dl_t q_t) * mask_t
+        const float w0 = swt[t * 16 + r], w1 = swt[(T + t) * 16 + r];
+        const float4 x0 = *reinterpret_cast<const float4*>(&sv[(long)t * D + c * 4]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&sv[(long)(T + t) * D + c * 4]);
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.drop_p[t] > 0.f) dropout_scale4(a.drop_seed[t], a.drop_off[t], (uint32_t)((((long)b * S + s) * D + c * 4) >> 2), a.drop_p[t], m);
+        acc.x += (w0 * x0.x + w1 * x1.x) * m[0]; acc.y += (w0 * x0.y + w1 * x1.y) * m[1];
+        acc.z += (w0 * x0.z + w1 * x1.z) * m[2]; acc.w += (w0 * x0.w + w1 * x1.w) * m[3];
+      }
     }
     float4* o = reinterpret_cast<float4*>(out + c * 4);
     if (a.accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }

@@ -716,6 +716,134 @@ extern "C" int vln_categorical_bwd(const float* probs, const int64_t* action, co
   return VLN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pieces of the Self-Monitor decoder step (policy.py:119-166) that are not GEMMs or attention rows:
+//   pe_dropout      : positioned context = dropout(ctx + pe[:L])                       (units.py:188-207)
+//   monitor_head    : h_pm = dropout(sigmoid(W_m[h_0; w_cands]) * tanh(c_1)); progress = tanh(w_c . [ctx_attn; h_pm] + b_c)
+//                     forward and backward, one workgroup per episode                  (policy.py:119-130)
+//   add_n           : out (+)= sum of up to four strided matrices (gradient contributions of one tensor)
+// ---------------------------------------------------------------------------------------------------------------
+namespace vln {
+__global__ __launch_bounds__(256) void pe_dropout_kernel(const float* ctx, const float* pe, float* out, int B, int L, int H, DropSpec dr) {
+  const long total4 = (long)B * L * H / 4;                // H % 4 == 0
+  const long lh4 = (long)L * H / 4;
+  for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+    const float4 x = *reinterpret_cast<const float4*>(ctx + e4 * 4);
+    const float4 q = *reinterpret_cast<const float4*>(pe + (e4 % lh4) * 4);
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (dr.p > 0.f) dropout_scale4(dr.seed, dr.off(), (uint32_t)e4, dr.p, m);
+    *reinterpret_cast<float4*>(out + e4 * 4) = make_float4((x.x + q.x) * m[0], (x.y + q.y) * m[1], (x.z + q.z) * m[2], (x.w + q.w) * m[3]);
+  }
+}
+
+struct MonHeadArgs {
+  const float* mg; const float* c1; const float* word_w; const float* wc; const float* bc;   // wc [L+H], bc [1]
+  float* mem; float* prog;                        // fwd out: mem [B,H] (dropped gate product), prog [B]
+  int B, L, H; DropSpec dr;
+  // backward
+  const float* dprog; const float* dc1_ext; const float* dww_ext;      // [B], [B,H] nullable, [B,L] nullable
+  float* dmg; float* dc1; float* dww; float* Z; float* dpre;           // [B,H], [B,H], [B,L], [B,L+H] (rows dpre*[word_w|mem]), [B]
+};
+__global__ __launch_bounds__(256) void monitor_head_fwd_kernel(MonHeadArgs a) {
+  __shared__ float part[4];
+  const int b = blockIdx.x, H = a.H, L = a.L;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const long i = (long)b * H + j;
+    const float m = sigmoidf_(a.mg[i]) * tanhf(a.c1[i]) * dropout_scale1(a.dr.seed, a.dr.off(), (uint32_t)i, a.dr.p);
+    a.mem[i] = m;
+    acc += a.wc[L + j] * m;
+  }
+  for (int l = threadIdx.x; l < L; l += 256) acc += a.wc[l] * a.word_w[(long)b * L + l];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.prog[b] = tanhf((part[0] + part[1]) + (part[2] + part[3]) + a.bc[0]);
+}
+__global__ __launch_bounds__(256) void monitor_head_bwd_kernel(MonHeadArgs a) {
+  const int b = blockIdx.x, H = a.H, L = a.L;
+  const float pv = a.prog[b];
+  const float dpre = (a.dprog ? a.dprog[b] : 0.f) * (1.f - pv * pv);
+  if (threadIdx.x == 0) a.dpre[b] = dpre;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const long i = (long)b * H + j;
+    const float sg = sigmoidf_(a.mg[i]), tc = tanhf(a.c1[i]);
+    const float dm = dpre * a.wc[L + j] * dropout_scale1(a.dr.seed, a.dr.off(), (uint32_t)i, a.dr.p);
+    a.dmg[i] = dm * tc * sg * (1.f - sg);
+    a.dc1[i] = dm * sg * (1.f - tc * tc) + (a.dc1_ext ? a.dc1_ext[i] : 0.f);
+    a.Z[(long)b * (L + H) + L + j] = dpre * a.mem[i];
+  }
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const long i = (long)b * L + l;
+    a.dww[i] = dpre * a.wc[l] + (a.dww_ext ? a.dww_ext[i] : 0.f);
+    a.Z[(long)b * (L + H) + l] = dpre * a.word_w[i];
+  }
+}
+
+struct AddNArgs { const float* src[4]; long ld[4]; int n; float* out; long ldo; int rows, cols, accumulate; };
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) {
+  const long total = (long)a.rows * a.cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / a.cols, c = e % a.cols;
+    float v = a.accumulate ? a.out[r * a.ldo + c] : 0.f;
+    for (int i = 0; i < a.n; ++i) v += a.src[i][r * a.ld[i] + c];
+    a.out[r * a.ldo + c] = v;
+  }
+}
+}  // namespace vln
+
+extern "C" int vln_pe_dropout(const float* ctx, const float* pe, float* out, int B, int L, int H, uint64_t seed, uint64_t offset,
+                              float p, void* s) {
+  if (!ctx || !pe || !out || B <= 0 || L <= 0 || H <= 0 || (H & 3)) { vln::set_error("vln_pe_dropout: bad args (H %% 4 == 0)"); return VLN_ERR_ARG; }
+  long t4 = (long)B * L * H / 4;
+  int blocks = (int)((t4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vln::pe_dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, ctx, pe, out, B, L, H, DropSpec{seed, offset, p});
+  VLN_CHECK_LAUNCH("pe_dropout");
+  return VLN_OK;
+}
+extern "C" int vln_monitor_head_fwd(const float* mg, const float* c1, const float* word_w, const float* wc, const float* bc, float* mem,
+                                    float* prog, int B, int L, int H, uint64_t seed, uint64_t offset, float p, void* s) {
+  if (!mg || !c1 || !word_w || !wc || !bc || !mem || !prog || B <= 0) { vln::set_error("vln_monitor_head_fwd: bad args"); return VLN_ERR_ARG; }
+  vln::MonHeadArgs a{};
+  a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.bc = bc; a.mem = mem; a.prog = prog; a.B = B; a.L = L; a.H = H;
+  a.dr = DropSpec{seed, offset, p};
+  hipLaunchKernelGGL(vln::monitor_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("monitor_head_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_monitor_head_bwd(const float* mg, const float* c1, const float* word_w, const float* wc, const float* mem,
+                                    const float* prog, const float* dprog, const float* dc1_ext, const float* dww_ext, float* dmg,
+                                    float* dc1, float* dww, float* Z, float* dpre, int B, int L, int H, uint64_t seed, uint64_t offset,
+                                    float p, void* s) {
+  if (!mg || !c1 || !word_w || !wc || !mem || !prog || !dmg || !dc1 || !dww || !Z || !dpre || B <= 0) {
+    vln::set_error("vln_monitor_head_bwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  vln::MonHeadArgs a{};
+  a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.mem = const_cast<float*>(mem); a.prog = const_cast<float*>(prog);
+  a.B = B; a.L = L; a.H = H; a.dr = DropSpec{seed, offset, p};
+  a.dprog = dprog; a.dc1_ext = dc1_ext; a.dww_ext = dww_ext; a.dmg = dmg; a.dc1 = dc1; a.dww = dww; a.Z = Z; a.dpre = dpre;
+  hipLaunchKernelGGL(vln::monitor_head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("monitor_head_bwd");
+  return VLN_OK;
+}
+extern "C" int vln_add_n(float* out, int64_t ldo, int rows, int cols, const float* s0, int64_t ld0, const float* s1, int64_t ld1,
+                         const float* s2, int64_t ld2, const float* s3, int64_t ld3, int accumulate, void* s) {
+  if (!out || rows <= 0 || cols <= 0 || !s0) { vln::set_error("vln_add_n: bad args"); return VLN_ERR_ARG; }
+  vln::AddNArgs a{};
+  const float* src[4] = {s0, s1, s2, s3}; const int64_t ld[4] = {ld0, ld1, ld2, ld3};
+  a.n = 0;
+  for (int i = 0; i < 4; ++i) if (src[i]) { a.src[a.n] = src[i]; a.ld[a.n] = (long)ld[i]; a.n++; }
+  a.out = out; a.ldo = (long)ldo; a.rows = rows; a.cols = cols; a.accumulate = accumulate;
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vln::add_n_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("add_n");
+  return VLN_OK;
+}
+
 extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
                           int R, int D, float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset,

@@ -130,7 +130,8 @@ int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* at
                      const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
-                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate);
+                       const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,
+                       const uint64_t* drop_seed = nullptr, const uint64_t* drop_off = nullptr, const float* drop_p = nullptr);
 // dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);

@@ -284,6 +284,7 @@ class MonitorDecoder(nn.Module, _Seeded):
         self.monitor_linear = nn.Linear(rnn_hidden_size + self.img_hidden_size, rnn_hidden_size, bias=True)
         self.critic = nn.Sequential(nn.Linear(max_enc_len + rnn_hidden_size, 1), nn.Tanh())
         self._init_seed(0x5E1F)
+        self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
@@ -317,6 +318,21 @@ class MonitorDecoder(nn.Module, _Seeded):
         # the BN-MLP zeroes the padded candidate slots itself (row_zero): one autograd node per call
         cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size),
                                            row_zero=candidate_mask.reshape(B * C)).view(B, C, -1)
+        if self.fused_step and ctx.dtype == torch.float32 and cand_rep.shape[2] % 4 == 0 and self.rnn_hidden_size % 4 == 0 \
+                and ctx_mask is not None and candidate_mask is not None:
+            # everything after the BN-MLP as ONE autograd node (functional.MonitorCoreFn)
+            pos = self.position
+            cfg = (self.training, self.compute_dtype, pos.p, (pos.dropout_seed, pos._next()), self.drop_ratio, self.dropout_seed,
+                   site, site + 1)
+            head = self.critic[0]
+            logit, progress, h_new, c_new, word_w, move_w = Fh.MonitorCoreFn.apply(
+                cfg, pos.pe[0, :ctx.shape[1]], ctx_mask, candidate_mask, prev_rep, cand_rep, h_0, c_0, ctx,
+                self.text_attn.linear_in.weight, self.visual_attn.linear_in_h.weight, self.visual_attn.linear_in_h.bias,
+                self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,
+                self.action_linear.weight, self.action_linear.bias, self.monitor_linear.weight, self.monitor_linear.bias,
+                head.weight, head.bias)
+            return (logit, progress), (h_new, c_new), (word_w, move_w)
+        # operator-by-operator path (shapes the fused node does not take)
         # co-grounding: words (position-encoded context) and candidates, both queried by h_0
         words, word_w = self.text_attn(h_0, self.position(ctx), ctx_mask)
         moves, move_w = self.visual_attn(h_0, cand_rep, candidate_mask)

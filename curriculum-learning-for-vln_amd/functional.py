@@ -411,3 +411,142 @@ class BnMlpFn(torch.autograd.Function):
 
 def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors):
     return BnMlpFn.apply(x, row_zero, (bool(training), float(eps), float(momentum), dtype, tuple(drops)), tuple(bufs), *tensors)
+
+
+def _add_n(out, srcs):
+    """out = sum of up to four [rows, cols] matrices (row strides free)."""
+    rows, cols = out.shape
+    a = [(None, 0)] * 4
+    for i, t in enumerate(srcs):
+        a[i] = (t.data_ptr(), t.stride(0))
+    rc = _lib.load().vln_add_n(out.data_ptr(), out.stride(0), rows, cols, a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1],
+                               a[3][0], a[3][1], 0, _lib.raw_stream())
+    if rc:
+        _lib.check(rc, "vln_add_n")
+    return out
+
+
+class MonitorCoreFn(torch.autograd.Function):
+    """Everything of MonitorDecoder.forward (policy.py:132-166) after the BN-MLP, as ONE autograd node: positional encoding
+    + dropout, the two attentions, the LSTM cell, the action logits and the progress monitor -- forward ~20 launches,
+    backward ~25 (hand-derived chain; all six weight gradients in one grouped launch, all bias gradients in another)
+    instead of ~35 operator nodes each way.  cfg = (training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem).
+    params = W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c."""
+
+    @staticmethod
+    def forward(ctx, cfg, pe, ctx_mask, cand_mask, prev_rep, cand_rep, h0, c0, ctxt, *params):
+        training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = cfg
+        W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c = params
+        lib = _lib.load()
+        st_ = _lib.raw_stream()
+        f32 = torch.float32
+        prev_rep, cand_rep = prev_rep.detach().contiguous(), cand_rep.detach().contiguous()
+        h0, c0, ctxt = h0.detach().contiguous(), c0.detach().contiguous(), ctxt.detach().contiguous()
+        B, C, M = cand_rep.shape
+        H = h0.shape[1]
+        L = ctxt.shape[1]
+        dev = h0.device
+        XK = 2 * M + 2 * H
+        pp = p_pe if training else 0.0
+        pd = p_drop if training else 0.0
+        # positioned context (fresh dropout mask per step, units.py:205-207)
+        pctx = ops.empty(B, L, H, dtype=f32, device=dev)
+        rc = lib.vln_pe_dropout(_p(ctxt), _p(pe), _p(pctx), B, L, H, seed_pe, off_pe, pp, st_)
+        if rc:
+            _lib.check(rc, "vln_pe_dropout")
+        xcat = ops.empty(B, XK, dtype=f32, device=dev)          # [prev_rep | moves | words | h0]: the LSTM input row
+        tq = ops.linear_fwd(h0, SHADOWS.get(W_tin, "n", dtype))
+        _, word_w = ops.attn_fwd_rows(pctx, tq, ctx_mask, out=xcat[:, 2 * M:2 * M + H])
+        vq = ops.linear_fwd(h0, SHADOWS.get(W_vh, "n", dtype), b_vh.detach())
+        _, move_w = ops.attn_fwd_rows(cand_rep, vq, cand_mask, out=xcat[:, M:2 * M])
+        xcat[:, :M].copy_(prev_rep)
+        xcat[:, 2 * M + H:].copy_(h0)
+        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, dtype, False))
+        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off_h1, pd, True)
+        tcat = ops.empty(B, 2 * H, dtype=f32, device=dev)        # [words | drop(h1)]
+        tcat[:, :H].copy_(xcat[:, 2 * M:2 * M + H])
+        tcat[:, H:].copy_(hd)
+        aq = ops.linear_fwd(tcat, SHADOWS.get(W_a, "n", dtype), b_a.detach())
+        logit = ops.attn_dot(cand_rep, aq)
+        hm = ops.empty(B, H + M, dtype=f32, device=dev)          # [h0 | moves]
+        hm[:, :H].copy_(h0)
+        hm[:, H:].copy_(xcat[:, M:2 * M])
+        mg = ops.linear_fwd(hm, SHADOWS.get(W_m, "n", dtype), b_m.detach())
+        mem = ops.empty(B, H, dtype=f32, device=dev)
+        prog = ops.empty(B, dtype=f32, device=dev)
+        wc = W_c.detach().reshape(-1)
+        rc = lib.vln_monitor_head_fwd(_p(mg), _p(c1), _p(word_w), _p(wc), _p(b_c.detach()), _p(mem), _p(prog), B, L, H, seed, off_mem,
+                                      pd, st_)
+        if rc:
+            _lib.check(rc, "vln_monitor_head_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(pctx, tq, vq, xcat, tcat, aq, hm, mg, mem, prog, word_w, move_w, act, tc, c0, c1, cand_rep, h0, *params)
+        ctx.set_materialize_grads(False)
+        return logit, prog, h1, c1, word_w, move_w
+
+    @staticmethod
+    def backward(ctx, dlogit, dprog, dh1, dc1, dww_ext, dmw_ext):
+        training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = ctx.cfg
+        (pctx, tq, vq, xcat, tcat, aq, hm, mg, mem, prog, word_w, move_w, act, tc, c0, c1, cand_rep, h0,
+         W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c) = ctx.saved_tensors
+        lib = _lib.load()
+        st_ = _lib.raw_stream()
+        f32 = torch.float32
+        B, C, M = cand_rep.shape
+        H, L = h0.shape[1], pctx.shape[1]
+        dev = h0.device
+        pp = p_pe if training else 0.0
+        pd = p_drop if training else 0.0
+        cz = lambda t: None if t is None else t.contiguous()
+        dlogit, dprog, dh1, dc1, dww_ext, dmw_ext = cz(dlogit), cz(dprog), cz(dh1), cz(dc1), cz(dww_ext), cz(dmw_ext)
+        E = lambda *sh: ops.empty(*sh, dtype=f32, device=dev)
+        # progress head (policy.py:126-130)
+        dmg, dc1_t, dww, Z, dpre = E(B, H), E(B, H), E(B, L), E(B, L + H), E(B, 1)
+        wc = W_c.detach().reshape(-1)
+        rc = lib.vln_monitor_head_bwd(_p(mg), _p(c1), _p(word_w), _p(wc), _p(mem), _p(prog), _p(dprog), _p(dc1), _p(dww_ext), _p(dmg),
+                                      _p(dc1_t), _p(dww), _p(Z), _p(dpre), B, L, H, seed, off_mem, pd, st_)
+        if rc:
+            _lib.check(rc, "vln_monitor_head_bwd")
+        dhm = ops.linear_fwd(dmg, SHADOWS.get(W_m, "t", dtype))                          # [B, H+M] -> h0 | moves
+        # action logits (policy.py:108-117): logit = cand_rep . aq
+        if dlogit is None:
+            dlogit = torch.zeros(B, C, dtype=f32, device=dev)
+        daq = ops.rows_wsum(cand_rep, dlogit)
+        dtcat = ops.linear_fwd(daq, SHADOWS.get(W_a, "t", dtype))                        # [B, 2H] -> words | drop(h1)
+        # LSTM cell
+        dg, dc0 = ops.lstm_pointwise_bwd(dh1, dtcat[:, H:].contiguous(), dc1_t, act, tc, c0, seed, off_h1, pd)
+        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, dtype, True))          # [B, 2M+2H] -> prev | moves | words | h0
+        dmoves = _add_n(E(B, M), [dhm[:, H:], dxcat[:, M:2 * M]])
+        dwords = _add_n(E(B, H), [dtcat[:, :H], dxcat[:, 2 * M:2 * M + H]])
+        # visual attention over the projected candidates; d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
+        dvq, dl_v = ops.attn_bwd_rows(cand_rep, move_w, dmoves, dmw_ext, want_dl=True)
+        dcand = None
+        if ctx.needs_input_grad[5]:
+            dcand = torch.empty(B, C, M, dtype=f32, device=dev)
+            ops.attn_dctx_deferred([move_w.data_ptr(), dlogit.data_ptr()], [dl_v.data_ptr(), None], [dmoves.data_ptr(), aq.data_ptr()], M,
+                                   [vq.data_ptr(), None], M, dcand)
+        dh0_v = ops.linear_fwd(dvq, SHADOWS.get(W_vh, "t", dtype))
+        # text attention over dropout(ctx + pe): d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's mask
+        dtq, dl_t = ops.attn_bwd_rows(pctx, word_w, dwords, dww, want_dl=True)
+        dctx = None
+        if ctx.needs_input_grad[8]:
+            dctx = torch.empty(B, L, H, dtype=f32, device=dev)
+            ops.attn_dctx_deferred([word_w.data_ptr()], [dl_t.data_ptr()], [dwords.data_ptr()], H, [tq.data_ptr()], H, dctx,
+                                   drop=[(seed_pe, off_pe, pp)])
+        dh0_t = ops.linear_fwd(dtq, SHADOWS.get(W_tin, "t", dtype))
+        dh0 = _add_n(E(B, H), [dhm[:, :H], dxcat[:, 2 * M + H:], dh0_v, dh0_t])
+        # parameter gradients: six products over the same B rows -> one grouped launch; biases -> another
+        gW = [torch.empty_like(w) for w in (W_tin, W_vh, W_ih, W_hh, W_a, W_m)]
+        wb = ops.WgradBatch(dtype != f32)
+        wb.add(dtq, h0, gW[0]); wb.add(dvq, h0, gW[1])
+        wb.add(dg, xcat[:, :2 * M + H], gW[2]); wb.add(dg, xcat[:, 2 * M + H:], gW[3])
+        wb.add(daq, tcat, gW[4]); wb.add(dmg, hm, gW[5])
+        wb.run()
+        gb_vh, gb_ih, gb_hh, gb_a, gb_m = (torch.empty_like(b) for b in (b_vh, b_ih, b_hh, b_a, b_m))
+        gWc = torch.empty(L + H, dtype=f32, device=dev)
+        cb = ops.ColsumBatch()
+        cb.add(dvq, gb_vh); cb.add(dg, gb_ih, gb_hh); cb.add(daq, gb_a); cb.add(dmg, gb_m); cb.add(Z, gWc)
+        cb.run()
+        gbc = dpre.sum(0)
+        return (None, None, None, None, dxcat[:, :M], dcand, dh0, dc0, dctx,
+                gW[0], gW[1], gb_vh, gW[2], gW[3], gb_ih, gb_hh, gW[4], gb_a, gW[5], gb_m, gWc.view_as(W_c), gbc.view_as(b_c))

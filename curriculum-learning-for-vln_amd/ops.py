@@ -382,16 +382,26 @@ def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None):
     return dvec, dl
 
 
-def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accumulate=False):
-    """out[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]; the four lists hold T device addresses."""
+def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accumulate=False, drop=None):
+    """out[b,s,:] (+)= sum_t (alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]) [* mask_t]; the four lists hold T device
+    addresses ((dl_t, q_t) may both be None: a pure outer product); drop = [(seed, offset, p)] per step multiplies step
+    t's term by that dropout mask over the flat [B,S,D] index (the attended tensor's own per-step dropout)."""
     lib = _lib.load()
     T = len(alpha_ptrs)
     B, S, D = out.shape
     assert out.is_contiguous() and len(dl_ptrs) == T and len(g_ptrs) == T and len(q_ptrs) == T
     arr = (C.c_void_p * (4 * T))(*alpha_ptrs, *dl_ptrs, *g_ptrs, *q_ptrs)
     base = C.addressof(arr)
-    _lib.check(lib.vln_attn_dctx_deferred(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
-                                          1 if accumulate else 0, _stream()), "vln_attn_dctx_deferred")
+    if drop is None and None not in dl_ptrs:
+        _lib.check(lib.vln_attn_dctx_deferred(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
+                                              1 if accumulate else 0, _stream()), "vln_attn_dctx_deferred")
+        return out
+    drop = drop or [(0, 0, 0.0)] * T
+    seeds = (C.c_uint64 * T)(*[d[0] for d in drop]); offs = (C.c_uint64 * T)(*[d[1] for d in drop])
+    ps = (C.c_float * T)(*[d[2] for d in drop])
+    _lib.check(lib.vln_attn_dctx_deferred_drop(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
+                                               1 if accumulate else 0, C.addressof(seeds), C.addressof(offs), C.addressof(ps), _stream()),
+               "vln_attn_dctx_deferred_drop")
     return out
 
 

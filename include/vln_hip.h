@@ -121,6 +121,12 @@ int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float
 int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                            const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D, int accumulate,
                            vln_stream_t s);
+/* Same, with step t's contribution multiplied by the dropout mask (drop_seed[t], drop_off[t], drop_p[t]; mask index = flat
+ * [B,S,D] index) the attended tensor went through in that step, and with (dl[t], q[t]) allowed to be NULL together
+ * (a pure outer-product term).  HOST arrays of T entries.  The Self-Monitor agent's context and candidate gradients. */
+int vln_attn_dctx_deferred_drop(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
+                                const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D, int accumulate,
+                                const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p, vln_stream_t s);
 int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha, const float* dattn_ext,
                  const float* dwc, int64_t lddwc, const float* vec, int64_t ldvec, float* dvec, int64_t lddvec,
                  float* dctx, float* dl_out, int B, int S, int D, vln_stream_t s);
@@ -179,6 +185,22 @@ int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mas
                         uint64_t offset, vln_stream_t s);
 int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp /*nullable*/, const float* dent /*nullable*/,
                         float* dlogits, int B, int C, vln_stream_t s);
+
+/* Pieces of the Self-Monitor decoder step (policy.py:119-166) besides GEMMs, attention rows and the BN-MLP:
+ *   vln_pe_dropout        out = dropout(ctx + pe[:L])  [B,L,H]                               (units.py:188-207)
+ *   vln_monitor_head_fwd  mem = dropout(sigmoid(mg) * tanh(c1)); prog = tanh(wc . [word_w ; mem] + bc)   (policy.py:126-130)
+ *   vln_monitor_head_bwd  from dprog: dmg, dc1 (= dc1_ext + its own), dww (= dww_ext + its own), Z[b,:] = dpre[b] * [word_w ; mem]
+ *                         (colsum(Z) = d wc, colsum(dpre) = d bc)
+ *   vln_add_n             out (+)= s0 + s1 + s2 + s3 (NULL sources skipped): the gradient contributions of one tensor */
+int vln_pe_dropout(const float* ctx, const float* pe, float* out, int B, int L, int H, uint64_t seed, uint64_t offset, float p,
+                   vln_stream_t s);
+int vln_monitor_head_fwd(const float* mg, const float* c1, const float* word_w, const float* wc, const float* bc, float* mem,
+                         float* prog, int B, int L, int H, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_monitor_head_bwd(const float* mg, const float* c1, const float* word_w, const float* wc, const float* mem, const float* prog,
+                         const float* dprog, const float* dc1_ext, const float* dww_ext, float* dmg, float* dc1, float* dww, float* Z,
+                         float* dpre, int B, int L, int H, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+int vln_add_n(float* out, int64_t ldo, int rows, int cols, const float* s0, int64_t ld0, const float* s1, int64_t ld1,
+              const float* s2, int64_t ld2, const float* s3, int64_t ld3, int accumulate, vln_stream_t s);
 
 /* BatchNorm1d (+ fused ReLU): the BN-MLP of the Self-Monitor agent (units.py:210-242; `bn_mlp` =
  * vln_bn_fwd / vln_linear_fwd / vln_bn_fwd(relu)).  Training: batch statistics, running statistics updated in place with

@@ -123,6 +123,53 @@ def test_monitor_golden(vln, name):
         assert int(sd["proj_navigable_mlp.mlp.0.num_batches_tracked"]) == 2
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_monitor_fused_step_equals_operator_path(vln, cdt):
+    """MonitorDecoder with the one-node core (functional.MonitorCoreFn) against the operator-by-operator path it replaces,
+    in TRAINING mode with every dropout on (both draw the same Philox masks): outputs, state, attention weights, all
+    parameter gradients and the gradients of ctx / h0 / c0, over a two-step chain."""
+    B, C, L, H, M, F = 24, 7, 20, 64, 128, 256
+    g = torch.Generator().manual_seed(77)
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    a_prev = torch.randn(B, F, generator=g).abs(); cands = [torch.randn(B, C, F, generator=g).abs() for _ in range(2)]
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
+    nc = torch.randint(2, C + 1, (B,), generator=g); cmask = torch.arange(C)[None, :] >= nc[:, None]
+    r = [torch.randn(B, C, generator=g), torch.randn(B, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g),
+         torch.randn(B, L, generator=g)]
+    res = []
+    torch.manual_seed(5)
+    ref = vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F, compute_dtype=cdt)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    for fused in (True, False):
+        dec = vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F, compute_dtype=cdt)
+        dec.load_state_dict(sd); dec.to(DEV).train()
+        dec.fused_step = fused
+        ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+        hh, cc, ap, total, outs = h, c, a_prev.to(DEV), 0.0, []
+        for t in range(2):
+            (logit, prog), (hh, cc), (ww, mw) = dec(None, ap, cands[t].to(DEV), hh, cc, ctx, ctx_mask.to(DEV), cmask.to(DEV))
+            total = total + (logit.masked_fill(cmask.to(DEV), 0.0) * r[0].to(DEV)).sum() + (prog * r[1].to(DEV)).sum() + (ww * r[4].to(DEV)).sum()
+            outs += [logit, prog, ww, mw]
+            ap = cands[t][:, 0].to(DEV)
+        total = total + (hh * r[2].to(DEV)).sum() + (cc * r[3].to(DEV)).sum()
+        total.backward()
+        res.append((outs + [hh, cc], {n: p.grad.clone() for n, p in dec.named_parameters()}, [ctx.grad, h.grad, c.grad],
+                    {k: v.clone() for k, v in dec.state_dict().items() if "running" in k}))
+    tol = 2e-4 if cdt == torch.float32 else 2e-2
+    gscale = max(v.abs().max().item() for v in res[1][1].values())
+    def close(a, b, what, floor=1e-6):
+        err = (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), floor)
+        assert err < tol, (what, err)
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        close(a, b, f"out{i}")
+    for n in res[0][1]:      # gradients that are zero in exact arithmetic (a bias in front of a BatchNorm) are fp32 noise:
+        close(res[0][1][n], res[1][1][n], "grad " + n, floor=1e-2 * gscale)      # judged on the scale of the real gradients
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        close(a, b, f"input grad {i}")
+    for k in res[0][3]:
+        close(res[0][3][k], res[1][3][k], k)
+
+
 # ---- speaker modules (SURVEY §8f N3; units.py:286-395) ------------------------------------------------------------------
 def _holder_name(n):
     """reference parameter name -> attribute path here (the nn.LSTM parameter holder sits one level down)"""
