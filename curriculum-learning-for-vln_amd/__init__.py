@@ -11,10 +11,11 @@ from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401
 from . import functional, staging, losses, optim, metrics  # noqa: F401
 from .staging import DeviceFeatureStore, PinnedStager  # noqa: F401
-from .speaker import SpeakerEncoder, SpeakerDecoder  # noqa: F401
+from .speaker import SpeakerEncoder, SpeakerDecoder, Speaker, back_translate, env_drop_mask  # noqa: F401
 from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401
                        AttnDecoderLSTM, MonitorDecoder)
 
 __all__ = ["_lib", "ops", "runtime", "dp", "functional", "VlnError", "LIB_PATH", "EncoderLSTM", "EnvDropDecoder",
            "Critic", "SoftDotAttention", "VisualSoftDotAttention", "ActionScoring", "PositionalEncoding", "MLPwithBN",
-           "AttnDecoderLSTM", "MonitorDecoder", "SpeakerEncoder", "SpeakerDecoder"]
+           "AttnDecoderLSTM", "MonitorDecoder", "SpeakerEncoder", "SpeakerDecoder", "Speaker", "back_translate",
+           "env_drop_mask"]

@@ -225,3 +225,152 @@ class SpeakerDecoder(nn.Module, _Seeded):
         x = Fh.dropout(x.view(Bw, Lw, H), p, self.training, self.dropout_seed, off + 2)
         logit = Fh.linear(x.view(n, H), self.projection.weight, self.projection.bias).view(Bw, Lw, -1)
         return logit, h1, c1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The loop around the two modules: teacher-forced training loss, word-by-word inference and the back-translation
+# hook of the EnvDrop rollout (agent/speaker.py:235-376, agent/envdrop.py:105-121,155-157).  The reference's Speaker
+# object is tied to the simulator (`from_shortest_path`, speaker.py:191-226, walks the environment) and does not run as
+# shipped (`np.bool`, `self.decoder.drop_env`); what is reproduced here is its arithmetic on tensors:
+# the caller hands over the path features `(can_feats [B,Lp,F], img_feats [B,Lp,36,F], lengths [B])` that
+# `from_shortest_path` would have produced.
+# ---------------------------------------------------------------------------------------------------------------
+PAD, UNK, EOS, BOS = 0, 1, 2, 3            # utils/misc.py:21-25 (base vocabulary of the Tokenizer)
+
+
+def length2mask(lengths, device, size: Optional[int] = None) -> torch.Tensor:
+    """utils/misc.py:481-486: True where the position is past the row's length."""
+    lengths = torch.as_tensor(lengths, dtype=torch.int64)
+    size = int(lengths.max()) if size is None else size
+    return (torch.arange(size, dtype=torch.int64)[None, :] >= lengths[:, None]).to(device)
+
+
+class Speaker:
+    """speaker.py:16-376 without the simulator: `teacher_forcing` (the speaker's training / scoring loss) and
+    `infer_batch` (greedy or sampled instruction generation) on the HIP modules."""
+
+    def __init__(self, encoder: "SpeakerEncoder", decoder: "SpeakerDecoder", max_decode: int = 120,
+                 pad: int = PAD, unk: int = UNK, eos: int = EOS, bos: int = BOS, seed: int = 0x5BEA):
+        self.encoder, self.decoder = encoder, decoder
+        self.max_decode = max_decode                      # config.py:118 MAX_DECODE
+        self.pad, self.unk, self.eos, self.bos = pad, unk, eos, bos
+        self.rnn_dim = decoder.hidden_size
+        self.angle_feat_size = encoder.angle_feat_size
+        self.seed, self._draws = seed, 0
+
+    def _mode(self, train: bool):
+        self.encoder.train(train)
+        self.decoder.train(train)
+
+    def _zero_state(self, B, dev):
+        return (torch.zeros(1, B, self.rnn_dim, device=dev), torch.zeros(1, B, self.rnn_dim, device=dev))
+
+    def teacher_forcing(self, can_feats, img_feats, lengths, insts, train: bool = True, for_listener: bool = False):
+        """speaker.py:235-290.  insts [B, Lw] int64 (<BOS> w1 .. <EOS> <PAD>..).  train -> mean CE over the non-pad
+        targets; for_listener -> the un-reduced [B, Lw-1] losses (beam-search scoring); eval -> (loss, word_accu,
+        sent_accu)."""
+        from . import losses
+        self._mode(train)
+        dev = can_feats.device
+        B = can_feats.shape[0]
+        ctx = self.encoder(can_feats, img_feats, lengths)
+        h_t, c_t = self._zero_state(B, dev)
+        ctx_mask = length2mask(lengths, dev, ctx.shape[1])
+        logits, _, _ = self.decoder(insts, ctx, ctx_mask, h_t, c_t)                   # [B, Lw, vocab]
+        Lw, V = logits.shape[1], logits.shape[2]
+        flat = logits[:, :-1].reshape(B * (Lw - 1), V)                                # -1 for aligning (speaker.py:270)
+        tgt = insts[:, 1:].reshape(-1)                                                # "1:" ignores <BOS> (speaker.py:271)
+        per_word = losses.masked_cross_entropy(flat, tgt, None, "none", ignore_index=self.pad)
+        if for_listener:
+            return per_word.view(B, Lw - 1)
+        n_words = (tgt != self.pad).sum()
+        loss = per_word.sum() / n_words.to(per_word.dtype)
+        if train:
+            return loss
+        predict = logits.detach().argmax(dim=2)                                       # [B, Lw]
+        gt_mask = insts != self.pad
+        correct = (predict[:, :-1] == insts[:, 1:]) & gt_mask[:, 1:]
+        n_gt = gt_mask[:, 1:].sum(dim=1)
+        word_accu = correct.sum().item() / max(1, int(n_gt.sum().item()))
+        sent_accu = (correct.sum(dim=1) == n_gt).sum().item() / B
+        return loss.item(), word_accu, sent_accu
+
+    def infer_batch(self, can_feats, img_feats, lengths, sampling: bool = False, train: bool = False, featdropmask=None):
+        """speaker.py:292-376.  Greedy (or sampled) decoding from <BOS> until every row has produced <EOS> or
+        `max_decode` words; words after a row's <EOS> are <PAD>.  `featdropmask` [F-angle]: the environment-dropout
+        mask shared with the follower (applied in place to the image part of both feature tensors, speaker.py:313-315).
+        Returns words [B, n] (numpy int64); with sampling and train also (log_probs, hiddens, entropies) as tensors
+        that carry gradients."""
+        import numpy as np
+        from . import losses
+        self._mode(train)
+        dev = can_feats.device
+        B = can_feats.shape[0]
+        if featdropmask is not None:
+            a = self.angle_feat_size
+            img_feats[..., :-a] *= featdropmask
+            can_feats[..., :-a] *= featdropmask
+        ctx = self.encoder(can_feats, img_feats, lengths, already_dropfeat=featdropmask is not None)
+        ctx_mask = length2mask(lengths, dev, ctx.shape[1])
+        h_t, c_t = self._zero_state(B, dev)
+        ended = np.zeros(B, dtype=bool)
+        word = torch.full((B, 1), self.bos, dtype=torch.int64, device=dev)
+        unk_mask = torch.zeros(B, self.decoder.projection.out_features, dtype=torch.bool, device=dev)
+        unk_mask[:, self.unk] = True                                                  # no <UNK> in inference (speaker.py:336)
+        words, log_probs, hiddens, entropies = [], [], [], []
+        grad = torch.enable_grad() if (train and sampling) else torch.no_grad()
+        with grad:
+            for _ in range(self.max_decode):
+                logits, h_t, c_t = self.decoder(word, ctx, ctx_mask, h_t, c_t)        # [B, 1, vocab]
+                logits = logits.view(B, -1)
+                if sampling:
+                    self._draws += 1
+                    w, lp, ent = losses.sample_action(logits, unk_mask, seed=self.seed, offset=self._draws)
+                    log_probs.append(lp if train else lp.detach())
+                    hiddens.append(h_t.squeeze(0) if train else h_t.squeeze(0).detach())
+                    entropies.append(ent if train else ent.detach())
+                else:
+                    w = logits.masked_fill(unk_mask, float("-inf")).argmax(dim=1)
+                cpu_word = w.cpu().numpy().copy()          # a COPY: the word fed back below keeps the model's choice
+                cpu_word[ended] = self.pad
+                words.append(cpu_word)
+                word = w.view(B, 1)
+                ended = np.logical_or(ended, cpu_word == self.eos)
+                if ended.all():
+                    break
+        out = np.stack(words, 1)
+        if train and sampling:
+            return out, torch.stack(log_probs, 1), torch.stack(hiddens, 1), torch.stack(entropies, 1)
+        return out
+
+
+def env_drop_mask(decoder, n: Optional[int] = None, device=None) -> torch.Tensor:
+    """The per-batch environment-dropout mask of back-translation (envdrop.py:106: `self.decoder.drop_env(torch.ones(
+    img_feat_size))`, i.e. the follower's feature-dropout module applied to a vector of ones): [n] values in
+    {0, 1/(1-p)}, ONE mask shared by every view / candidate / step of the batch and by the speaker.  Drawn from the
+    decoder's Philox stream."""
+    n = (decoder.feature_size - decoder.angle_feat_size) if n is None else n
+    device = next(decoder.parameters()).device if device is None else device
+    p = decoder.feat_drop_ratio if decoder.training else 0.0
+    if p <= 0.0:
+        return torch.ones(n, device=device)
+    draws = getattr(decoder, "_env_mask_draws", 0) + 1      # its own counter: the step offsets of the rollouts are untouched
+    decoder._env_mask_draws = draws
+    return ops.dropout_mask(n, decoder.dropout_seed ^ 0xE17D, draws, p, device)
+
+
+def back_translate(speaker: Speaker, decoder, can_feats, img_feats, lengths):
+    """The self-training branch at the top of `EnvDropAgent.rollout` (envdrop.py:105-121): draw the shared environment
+    mask, let the speaker describe the (masked) shortest path greedily, prepend <BOS> and close unfinished sentences
+    with <EOS>.  Returns (instr_encoding [B, 1+n] numpy int64, noise [F-angle]); the caller rebuilds the batch with
+    these instructions and multiplies the image part of every step's features by `noise`, passing
+    `already_dropfeat=True` to the decoder (envdrop.py:155-160)."""
+    import numpy as np
+    noise = env_drop_mask(decoder, device=can_feats.device)
+    insts = speaker.infer_batch(can_feats, img_feats, lengths, featdropmask=noise)
+    boss = np.full((insts.shape[0], 1), speaker.bos, np.int64)
+    insts = np.concatenate((boss, insts), 1)
+    for inst in insts:
+        if inst[-1] != speaker.pad:            # the instruction has not ended (envdrop.py:113-114)
+            inst[-1] = speaker.eos
+    return insts, noise

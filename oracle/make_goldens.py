@@ -531,6 +531,57 @@ def gen_speaker(U):
          out=dict(logit=logit, h1=h1, c1=c1, step_logit=l2, step_h=h2, step_c=c2), grad=gr)
 
 
+def gen_speaker_loop(U):
+    """The speaker LOOP (agent/speaker.py:235-376 + the back-translation hook envdrop.py:105-121) on the reference's
+    own SpeakerEncoder / SpeakerDecoder, eval mode, driven by oracle/rollout.py's restated loop (the reference's Speaker
+    object needs the simulator and does not run as shipped): teacher-forcing loss (mean + un-reduced) with gradients,
+    greedy inference with a shared environment-dropout mask, instructions as the follower receives them."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import rollout as R
+    torch.manual_seed(int(os.environ.get('SPK_SEED', '75')))
+    g = torch.Generator().manual_seed(7707)
+    B, Lp, V, IMG, ANG, H, E, VOC, Lw, MAXD = 4, 5, 36, 24, 8, 32, 16, 40, 9, 10
+    F = IMG + ANG
+    EOS_BIAS = float(os.environ.get('EOS_BIAS', '1.0'))
+    ATT_SCALE = float(os.environ.get('ATT_SCALE', '1.5'))
+    enc = U.SpeakerEncoder(F, H, 0.5, True, ANG, 0.3).eval()
+    dec = U.SpeakerDecoder(VOC, E, 0, H, 0.5).eval()
+    with torch.no_grad():
+        dec.projection.weight *= 12.0                      # random-init logits barely depend on the input: spread them
+        dec.embedding.weight *= 4.0
+        dec.attention_layer.linear_out.weight[:, :H] *= ATT_SCALE   # ... and make them depend on the encoded path
+        for n_, p_ in enc.named_parameters():
+            if 'weight' in n_:
+                p_ *= 3.0
+        dec.projection.bias[2] += EOS_BIAS                 # make <EOS> likely enough that some rows end early
+    can = feats(g, B, Lp, IMG, ANG)
+    img = torch.stack([feats(g, B, V, IMG, ANG) for _ in range(Lp)], 1)
+    lengths = [5, 4, 4, 2]
+    insts = torch.randint(4, VOC, (B, Lw), generator=g)
+    insts[:, 0] = 3
+    for i, n in enumerate((9, 7, 5, 4)):
+        insts[i, n - 1] = 2
+        insts[i, n:] = 0
+    encode = lambda c, f, l, dropped: enc(c.clone(), f.clone(), l, already_dropfeat=dropped)
+    decode = lambda w, ctx, m, h, c: dec(w, ctx, m, h, c)
+    loss, per_word, predict = R.speaker_teacher_forcing(encode, decode, can, img, lengths, insts, H)
+    gr_e, _ = grads_of(enc, loss)
+    loss2, _, _ = R.speaker_teacher_forcing(encode, decode, can, img, lengths, insts, H)
+    gr_d, _ = grads_of(dec, loss2)
+    noise = (torch.rand(IMG, generator=g) > 0.3).float() / 0.7
+    with torch.no_grad():
+        words, step_logits = R.speaker_infer_batch(encode, decode, can, img, lengths, H, MAXD, featdropmask=noise, angle=ANG)
+        words_plain, _ = R.speaker_infer_batch(encode, decode, can, img, lengths, H, MAXD, angle=ANG)
+    bt = R.back_translate_instructions(words)
+    print("speaker_loop greedy words:\n", words, "\nback-translated:\n", bt)
+    save("speaker_loop", cfg=dict(F=F, H=H, ANG=ANG, VOC=VOC, E=E, MAXD=MAXD),
+         enc=dict(enc.state_dict()), dec=dict(dec.state_dict()),
+         inp=dict(can=can, img=img, lengths=np.array(lengths), insts=insts, noise=noise),
+         out=dict(loss=loss, per_word=per_word, predict=predict, words=words, words_plain=words_plain,
+                  step_logits=step_logits, instr_encoding=bt),
+         grad_enc=gr_e, grad_dec=gr_d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -549,6 +600,7 @@ def main():
     gen_critic(P, g)
     gen_losses(g)
     gen_speaker(U)
+    gen_speaker_loop(U)
     gen_angle_tables()
     gen_agent_tapes()
     gen_agent_tapes_more()

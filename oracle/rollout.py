@@ -67,8 +67,8 @@ class OracleBackend:
     def encode(self, tokens, lengths):
         return O.encoder_forward(self.Pe, tokens, lengths.tolist(), num_layers=1, bidirectional=True)
 
-    def decode(self, a, img, cand, h_tilde, h, c, ctx, mask):
-        d = self.dtype
+    def decode(self, a, img, cand, h_tilde, h, c, ctx, mask, dropped=False):
+        d = self.dtype                     # no dropout masks are injected here: `dropped` (already_dropfeat) changes nothing
         logit, (h1, c1), ht, _ = O.envdrop_step(self.Pd, a.to(d), img.to(d), cand.to(d), h_tilde, c, ctx, mask)
         return logit, h1, c1, ht
 
@@ -94,8 +94,8 @@ class ModuleBackend:
     def encode(self, tokens, lengths):
         return self.enc(tokens, lengths)
 
-    def decode(self, a, img, cand, h_tilde, h, c, ctx, mask):
-        logit, (h1, c1), ht = self.dec(a, img, cand, h_tilde, h, c, ctx, mask, False)
+    def decode(self, a, img, cand, h_tilde, h, c, ctx, mask, dropped=False):
+        logit, (h1, c1), ht = self.dec(a, img, cand, h_tilde, h, c, ctx, mask, dropped)
         return logit, h1, c1, ht
 
     def critic(self, h):
@@ -112,14 +112,31 @@ class ModuleBackend:
 
 
 def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Optional[np.ndarray] = None,
-                    train_rl: bool = False, ml_weight=0.2, gamma=0.9):
-    """Returns dict(ml_loss, rl_loss, total, loss, actions).  envdrop.py:86-278 with train_cl=False, speaker=None."""
+                    train_rl: bool = False, ml_weight=0.2, gamma=0.9, insts: Optional[np.ndarray] = None,
+                    noise: Optional[torch.Tensor] = None):
+    """Returns dict(ml_loss, rl_loss, total, loss, actions).  envdrop.py:86-278 with train_cl=False.
+    Back translation (envdrop.py:105-121,155-157; `speaker is not None` there): `insts` [B, n] = the generated
+    instructions (<BOS> .. <EOS> <PAD>..) that replace the batch's own, `noise` = the shared environment-dropout mask
+    multiplied into the image part of every step's features, the decoder then being told `already_dropfeat`.  The
+    reference leaves the stale `instr_length` in the batch and does not re-sort it (its `reset(batch=...)` path,
+    common_env.py:332-343, skips the sort of `_next_minibatch`), which the packed encoder cannot take; as in the upstream
+    EnvDrop agent the lengths are recomputed from the tokens and the batch is put in descending-length order by a
+    permutation that is undone when the actions go back to the environment."""
     dev = be.device
     if feedback != "sample":
         train_rl = False
-    obs = env.reset(restart=False)
-    B = len(obs)
-    traj = [{"instr_id": ob["instr_id"], "path": [(ob["viewpointId"], ob["heading"], ob["elevation"])]} for ob in obs]
+    env_obs = env.reset(restart=False)
+    B = len(env_obs)
+    perm = np.arange(B)
+    if insts is not None:
+        lens = np.array([int(np.argmax(r == 0)) if (r == 0).any() else len(r) for r in insts])
+        perm = np.argsort(-lens, kind="stable")
+        for ob, r, n in zip(env_obs, insts, lens):          # what reset(batch=...) hands back after the hook edited the batch
+            ob["instr_encoding"], ob["instr_length"] = r, int(n)
+    inv = np.argsort(perm)
+    P = lambda o: [o[i] for i in perm]
+    obs = P(env_obs)
+    traj = [{"instr_id": ob["instr_id"], "path": [(ob["viewpointId"], ob["heading"], ob["elevation"])]} for ob in env_obs]
     tokens, seq_mask, lengths = marshal_instructions(obs, dev)
     ctx, h_t, c_t = be.encode(tokens, lengths)
     ended = np.zeros(B, bool)
@@ -129,7 +146,10 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
     h_tilde = h_t
     for t in range(episode_len):
         a_in, img, cand, cl = marshal_step(obs, dev)
-        logit, h_t, c_t, h_tilde = be.decode(a_in, img, cand, h_tilde, h_t, c_t, ctx, seq_mask)
+        if noise is not None:                                       # envdrop.py:155-157
+            img[..., :-ANG] *= noise.to(img.dtype)
+            cand[..., :-ANG] *= noise.to(cand.dtype)
+        logit, h_t, c_t, h_tilde = be.decode(a_in, img, cand, h_tilde, h_t, c_t, ctx, seq_mask, noise is not None)
         hidden.append(h_t)
         cmask = O.length2mask(cl).to(dev)
         logit = logit.masked_fill(cmask, -float("inf"))            # envdrop.py:173 (in place there)
@@ -153,7 +173,8 @@ def envdrop_rollout(be, env, feedback: str, episode_len: int, inject_actions: Op
             if cpu_a[i] == len(obs[i]["candidates"]) or cpu_a[i] == -1 or ended[i]:
                 cpu_a[i] = -1
         acts.append(cpu_a.copy())
-        obs = env.step(cpu_a, obs, traj)
+        env_obs = env.step(cpu_a[inv], env_obs, traj)               # actions back in the environment's order
+        obs = P(env_obs)
         dist = np.array([ob["distance"] for ob in obs], np.float32)
         is_stop = cpu_a == -1
         reward = (is_stop * (2 * (dist < 3) - 1) * 2 + (1 - is_stop) * np.sign(last_dist - dist)) * (~ended)   # envdrop.py:209-212
@@ -330,3 +351,116 @@ def monitor_rollout(be, env, feedback: str, episode_len: int, lamb: float = 0.5,
         if ended.all():
             break
     return dict(ml_loss=ml, progress_loss=prog_log, actions=np.stack(acts), traj=traj)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N3  Speaker loop (reference src/agent/speaker.py:235-376, hook src/agent/envdrop.py:105-121) -- TEST INFRASTRUCTURE.
+# Written over two callables so the SAME loop drives the reference's own modules (oracle/make_goldens.py, which is
+# how tests/golden/speaker_loop.npz was captured: the reference's Speaker object is tied to the simulator and does
+# not run as shipped) and the CPU restatement (`SpeakerOracle`).
+#   encode(can_feats, img_feats, lengths, already_dropfeat) -> ctx [B, Lp, H]
+#   decode(words [B, Lw], ctx, ctx_mask, h [1,B,H], c [1,B,H]) -> (logit [B, Lw, V], h1, c1)
+# ---------------------------------------------------------------------------------------------------------------
+class SpeakerOracle:
+    def __init__(self, P_enc, P_dec, bidirectional: bool, dtype=torch.float64):
+        self.Pe = {k: v.detach().to(dtype).requires_grad_(v.is_floating_point()) for k, v in P_enc.items()}
+        self.Pd = {k: v.detach().to(dtype).requires_grad_(v.is_floating_point()) for k, v in P_dec.items()}
+        self.bidir, self.dtype = bidirectional, dtype
+
+    def encode(self, can_feats, img_feats, lengths, already_dropfeat=False):
+        return O.speaker_encoder(self.Pe, can_feats.to(self.dtype), img_feats.to(self.dtype), self.bidir)
+
+    def decode(self, words, ctx, ctx_mask, h, c):
+        return O.speaker_decoder(self.Pd, words, ctx, ctx_mask, h.to(self.dtype), c.to(self.dtype))
+
+    def named_grads(self):
+        out = {}
+        for pre, P in (("encoder.", self.Pe), ("decoder.", self.Pd)):
+            for k, v in P.items():
+                if v.requires_grad and v.grad is not None:
+                    out[pre + k] = v.grad
+        return out
+
+
+def speaker_teacher_forcing(encode, decode, can_feats, img_feats, lengths, insts, rnn_dim, pad=0):
+    """speaker.py:235-290 -> (mean CE over the non-pad targets, un-reduced [B, Lw-1] losses, argmax predictions)."""
+    B = can_feats.shape[0]
+    ctx = encode(can_feats, img_feats, lengths, False)
+    h = torch.zeros(1, B, rnn_dim, dtype=ctx.dtype)
+    c = torch.zeros(1, B, rnn_dim, dtype=ctx.dtype)
+    ctx_mask = O.length2mask(lengths, ctx.shape[1])
+    logits, _, _ = decode(insts, ctx, ctx_mask, h, c)
+    lg = logits.permute(0, 2, 1)[:, :, :-1]                      # (B, vocab, Lw-1), speaker.py:268-271
+    tgt = insts[:, 1:]
+    per_word = torch.nn.functional.cross_entropy(lg, tgt, ignore_index=pad, reduction="none")
+    loss = per_word.sum() / (tgt != pad).sum()
+    return loss, per_word, logits.argmax(dim=2)
+
+
+def speaker_infer_batch(encode, decode, can_feats, img_feats, lengths, rnn_dim, max_decode, featdropmask=None, angle=ANG,
+                        pad=0, unk=1, eos=2, bos=3, inject_words=None):
+    """speaker.py:292-376, greedy (or `inject_words` [B, n] in place of sampled words) -> (words [B, n] numpy, the
+    per-step masked logits).  The word fed back is the model's choice even for rows that already ended (the reference
+    pads only the CPU copy, speaker.py:355-360)."""
+    B = can_feats.shape[0]
+    if featdropmask is not None:
+        img_feats = img_feats.clone(); can_feats = can_feats.clone()
+        img_feats[..., :-angle] *= featdropmask
+        can_feats[..., :-angle] *= featdropmask
+    ctx = encode(can_feats, img_feats, lengths, featdropmask is not None)
+    ctx_mask = O.length2mask(lengths, ctx.shape[1])
+    h = torch.zeros(1, B, rnn_dim, dtype=ctx.dtype)
+    c = torch.zeros(1, B, rnn_dim, dtype=ctx.dtype)
+    ended = np.zeros(B, dtype=bool)
+    word = torch.full((B, 1), bos, dtype=torch.int64)
+    words, step_logits = [], []
+    for i in range(max_decode):
+        logits, h, c = decode(word, ctx, ctx_mask, h, c)
+        logits = logits.reshape(B, -1).clone()
+        logits[:, unk] = -float("inf")
+        step_logits.append(logits.detach())
+        w = logits.max(1)[1] if inject_words is None else torch.as_tensor(inject_words[:, i])
+        cpu_word = w.numpy().copy()
+        cpu_word[ended] = pad
+        words.append(cpu_word)
+        word = w.view(-1, 1)
+        ended = np.logical_or(ended, cpu_word == eos)
+        if ended.all():
+            break
+    return np.stack(words, 1), torch.stack(step_logits, 1)
+
+
+def shortest_path_features(env, device="cpu"):
+    """speaker.py:191-226 `from_shortest_path` over the (fake) environment: follow the teacher from the start of every
+    episode; per step the 36 view features and the feature of the candidate the teacher takes (zeros for STOP / ended).
+    -> (can_feats [B, Lp, F], img_feats [B, Lp, 36, F], lengths [B])."""
+    obs = env.reset(restart=False)
+    B = len(obs)
+    ended = np.zeros(B, bool)
+    length = np.zeros(B, np.int64)
+    img_feats, can_feats = [], []
+    while not ended.all():
+        img_feats.append(np.stack([ob["feature"] for ob in obs]).astype(np.float32))
+        a = teacher_action(obs, ended)
+        for i, act in enumerate(a):
+            if act < 0 or act == len(obs[i]["candidates"]):
+                a[i] = -1
+        cf = np.zeros((B, obs[0]["feature"].shape[-1]), np.float32)
+        for i, (ob, act) in enumerate(zip(obs, a)):
+            if act != -1:
+                cf[i] = ob["candidates"][act]["feature"]
+        can_feats.append(cf)
+        obs = env.step(a, obs, None)
+        length += (1 - ended)
+        ended[:] = np.logical_or(ended, a == -1)
+    t = lambda x: torch.from_numpy(np.stack(x, 1)).contiguous().to(device)
+    return t(can_feats), t(img_feats), length.tolist()
+
+
+def back_translate_instructions(insts, pad=0, eos=2, bos=3):
+    """envdrop.py:109-114: prepend <BOS>, close sentences that did not end with <EOS>."""
+    insts = np.concatenate((np.full((insts.shape[0], 1), bos, np.int64), insts), 1)
+    for inst in insts:
+        if inst[-1] != pad:
+            inst[-1] = eos
+    return insts

@@ -1,5 +1,6 @@
 """GPU: the Speaker-Follower and Self-Monitoring decoders and the attention units (HIP operators through the C ABI)
 against the golden vectors captured from the reference, state_dict loaded strict.  fp32 tolerance 1e-4 (grads 3e-4)."""
+import numpy as np
 import pytest
 import torch
 
@@ -221,3 +222,94 @@ def test_speaker_decoder_golden(vln):
         l2, h2, c2 = dec(I["words"][:, :1], ctx, I["mask"], I["hs"], I["cs"])
     for a, k in ((l2, "step_logit"), (h2, "step_h"), (c2, "step_c")):
         check(a, G["out"][k], 1e-4, k)
+
+
+# ---- speaker loop: teacher forcing, greedy / sampled inference, back-translation hook (speaker.py:235-376) ------------
+def _speaker_from_golden(vln, G):
+    cfg = G["cfg"]
+    F, H, ANG, VOC, E = (int(cfg[k]) for k in ("F", "H", "ANG", "VOC", "E"))
+    enc = vln.SpeakerEncoder(F, H, 0.5, True, ANG, 0.3)
+    dec = vln.SpeakerDecoder(VOC, E, 0, H, 0.5)
+    enc.load_state_dict(G["enc"], strict=True)
+    dec.load_state_dict(G["dec"], strict=True)
+    return vln.Speaker(enc.to(DEV), dec.to(DEV), max_decode=int(cfg["MAXD"]))
+
+
+def test_speaker_loop_golden(vln):
+    G = load_golden("speaker_loop")
+    I, out = dev(G["inp"]), G["out"]
+    spk = _speaker_from_golden(vln, G)
+    lengths = G["inp"]["lengths"].tolist()
+    # eval-mode numbers are what the golden holds: run the "train" entry with the modules' dropout probabilities at 0
+    spk.encoder.drop_ratio = spk.encoder.feat_drop_ratio = spk.decoder.drop_ratio = 0.0
+    loss = spk.teacher_forcing(I["can"].clone(), I["img"].clone(), lengths, I["insts"], train=True)
+    check(loss, out["loss"], 1e-4, "teacher-forcing loss")
+    loss.backward()
+    ne, nd = dict(spk.encoder.named_parameters()), dict(spk.decoder.named_parameters())
+    for n, g in G["grad_enc"].items():
+        check(ne[_holder_name(n)].grad, g, 5e-4, "grad encoder." + n)
+    for n, g in G["grad_dec"].items():
+        p = nd[_holder_name(n)]
+        check(p.grad if p.grad is not None else torch.zeros_like(p), g, 5e-4, "grad decoder." + n)
+    per_word = spk.teacher_forcing(I["can"].clone(), I["img"].clone(), lengths, I["insts"], train=False, for_listener=True)
+    check(per_word, out["per_word"], 1e-4, "un-reduced losses")
+    l, word_accu, sent_accu = spk.teacher_forcing(I["can"].clone(), I["img"].clone(), lengths, I["insts"], train=False)
+    assert abs(l - out["loss"].item()) < 1e-4 * max(1.0, abs(l))
+    gt = G["inp"]["insts"][:, 1:]
+    ok = (out["predict"][:, :-1] == gt) & (gt != 0)
+    assert abs(word_accu - ok.sum().item() / (gt != 0).sum().item()) < 1e-9
+    assert abs(sent_accu - (ok.sum(1) == (gt != 0).sum(1)).sum().item() / gt.shape[0]) < 1e-9
+    # greedy inference under a shared environment-dropout mask: the same words as the reference's modules chose
+    words = spk.infer_batch(I["can"].clone(), I["img"].clone(), lengths, featdropmask=I["noise"])
+    assert (words == out["words"].numpy()).all(), (words, out["words"])
+    # the back-translation hook; eval-mode follower -> the mask is all ones -> the unmasked greedy words
+    fol = vln.EnvDropDecoder(32, 0.5, 0.3, 16, int(G["cfg"]["ANG"]), int(G["cfg"]["F"])).to(DEV).eval()
+    insts, noise = vln.back_translate(spk, fol, I["can"].clone(), I["img"].clone(), lengths)
+    assert torch.equal(noise.cpu(), torch.ones(int(G["cfg"]["F"]) - int(G["cfg"]["ANG"])))
+    plain = out["words_plain"].numpy()
+    assert (insts[:, 1:1 + plain.shape[1]] [:, :-1] == plain[:, :-1]).all() and (insts[:, 0] == 3).all()
+    assert all(2 in row for row in insts)
+    fol.train()
+    m = vln.env_drop_mask(fol)
+    vals = set(m.unique().cpu().tolist())
+    assert vals <= {0.0, float(torch.tensor(1.0 / 0.7, dtype=torch.float32))} and len(vals) == 2
+    assert not torch.equal(m, vln.env_drop_mask(fol))                   # a fresh mask per batch
+
+
+def test_speaker_loop_sampling_vs_oracle(vln):
+    """Sampled inference in train mode (the speaker's own RL path, speaker.py:337-345): the returned log-probs /
+    entropies carry gradients and equal the oracle's for the SAME words (dropout off; draws cannot be RNG-matched)."""
+    from oracle import rollout as R
+    G = load_golden("speaker_loop")
+    I = dev(G["inp"])
+    spk = _speaker_from_golden(vln, G)
+    spk.encoder.drop_ratio = spk.encoder.feat_drop_ratio = spk.decoder.drop_ratio = 0.0
+    lengths = G["inp"]["lengths"].tolist()
+    H, ANG, MAXD = int(G["cfg"]["H"]), int(G["cfg"]["ANG"]), int(G["cfg"]["MAXD"])
+    words, logp, hid, ent = spk.infer_batch(I["can"].clone(), I["img"].clone(), lengths, sampling=True, train=True)
+    n = words.shape[1]
+    assert logp.shape == (4, n) and hid.shape == (4, n, H) and ent.shape == (4, n) and logp.requires_grad
+    assert (words != 1).all()                                           # <UNK> masked out
+    # what the model fed back: the sampled word, also for rows that had already ended -> rebuild from the pad pattern
+    ora = R.SpeakerOracle(G["enc"], G["dec"], True)
+    fed = words.copy()
+    # rows that ended were padded on the CPU copy only; their fed-back words are unknown to the caller, so compare the
+    # steps up to and including each row's <EOS>
+    live = np.ones_like(words, dtype=bool)
+    for b in range(words.shape[0]):
+        e = np.where(words[b] == 2)[0]
+        if len(e):
+            live[b, e[0] + 1:] = False
+    # replay the oracle with the same words while they are live (after the end any word keeps the state finite)
+    fed[~live] = 4
+    ow, step_logits = R.speaker_infer_batch(ora.encode, ora.decode, G["inp"]["can"], G["inp"]["img"], lengths, H, n, angle=ANG,
+                                            inject_words=fed)
+    lp_ref = torch.log_softmax(step_logits, dim=2).gather(2, torch.as_tensor(fed)[:, :, None]).squeeze(2)
+    p = torch.softmax(step_logits, dim=2)
+    ent_ref = -(p * torch.log(p.clamp(1.1920929e-07, 1 - 1.1920929e-07))).sum(2)
+    sel = torch.as_tensor(live)
+    check(logp.detach().cpu()[sel], lp_ref[sel], 2e-4, "log-probs of the sampled words")
+    check(ent.detach().cpu()[sel], ent_ref[sel], 2e-4, "entropies")
+    (-(logp * 0.5).sum() - 0.01 * ent.sum() + hid.sum() * 1e-3).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in spk.decoder.projection.parameters())
+    assert spk.encoder.lstm.rnn.weight_ih_l0.grad.abs().sum() > 0

@@ -200,3 +200,36 @@ def test_speaker_decoder():
         l2, h2, c2 = O.speaker_decoder(P, I["words"][:, :1], ctx, I["mask"], I["hs"], I["cs"])
     for a, k in ((l2, "step_logit"), (h2, "step_h"), (c2, "step_c")):
         close(a, G["out"][k], what=k)
+
+
+def test_speaker_loop():
+    """N3 loop (agent/speaker.py:235-376, envdrop.py:105-121): the CPU restatement of the speaker modules driven by the
+    restated loop reproduces what the reference's own modules produced under the same loop (tests/golden/speaker_loop.npz)."""
+    from oracle import rollout as R
+    G = load_golden("speaker_loop")
+    I, out, cfg = G["inp"], G["out"], G["cfg"]
+    H, ANG, MAXD = int(cfg["H"]), int(cfg["ANG"]), int(cfg["MAXD"])
+    spk = R.SpeakerOracle(G["enc"], G["dec"], True)
+    lengths = I["lengths"].tolist()
+    loss, per_word, predict = R.speaker_teacher_forcing(spk.encode, spk.decode, I["can"], I["img"], lengths, I["insts"], H)
+    close(loss, out["loss"], what="loss")
+    close(per_word, out["per_word"], what="per_word")
+    assert torch.equal(predict, out["predict"])
+    assert (per_word[I["insts"][:, 1:] == 0] == 0).all()              # pad targets carry no loss
+    loss.backward()
+    g = spk.named_grads()
+    for n, ref in G["grad_enc"].items():
+        close(g["encoder." + n], ref, 1e-4, "grad encoder." + n)
+    for n, ref in G["grad_dec"].items():
+        close(g.get("decoder." + n, torch.zeros_like(ref)), ref, 1e-4, "grad decoder." + n)
+    with torch.no_grad():
+        words, step_logits = R.speaker_infer_batch(spk.encode, spk.decode, I["can"], I["img"], lengths, H, MAXD,
+                                                   featdropmask=I["noise"].double(), angle=ANG)
+        plain, _ = R.speaker_infer_batch(spk.encode, spk.decode, I["can"], I["img"], lengths, H, MAXD, angle=ANG)
+    assert (words == out["words"].numpy()).all() and (plain == out["words_plain"].numpy()).all()
+    fin = torch.isfinite(out["step_logits"])
+    close(step_logits[fin], out["step_logits"][fin], 1e-4, "step logits")
+    assert (step_logits[:, :, 1] == -float("inf")).all()                # <UNK> is never produced
+    bt = R.back_translate_instructions(words)
+    assert (bt == out["instr_encoding"].numpy()).all()
+    assert (bt[:, 0] == 3).all() and all(2 in row for row in bt)        # <BOS> first, every sentence closed by <EOS>

@@ -136,3 +136,92 @@ def test_hip_rollouts_match_reference_agents(kind, mode):
     res = _run(kind, be, mode)
     res["ml_loss"].backward()
     compare(res, be.named_grads(), G, 1e-4, 5e-4)
+
+
+# ---- back translation (envdrop.py:105-121,155-157 + speaker.py:292-376) ----------------------------------
+# No tape of the reference exists for this branch: its hook calls attributes that do not exist (`decoder.drop_env`) and
+# leaves the batch unsorted with stale lengths (oracle/rollout.py::envdrop_rollout).  The CPU oracle -- itself pinned
+# module by module and loop by loop (tests/golden/speaker_*.npz) -- is the reference here.
+def _speaker_modules(make_enc, make_dec):
+    torch.manual_seed(91)
+    enc, dec = make_enc(), make_dec()
+    with torch.no_grad():                       # spread the random-init logits so that greedy decoding is not a tie-break
+        dec.projection.weight *= 12.0
+        dec.embedding.weight *= 4.0
+        dec.projection.bias[2] += 1.0
+    return enc, dec
+
+
+def test_shortest_path_features():
+    env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+    can, img, lengths = R.shortest_path_features(env)
+    assert lengths == [int(n) + 1 for n in env.n_moves]                    # n moves + the STOP step
+    assert can.shape == (4, max(lengths), 2176) and img.shape == (4, max(lengths), 36, 2176)
+    for i, n in enumerate(lengths):
+        assert can[i, n - 1:].abs().sum() == 0                             # STOP and the steps after it: zero features
+        assert can[i, :n - 1].abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_hip_back_translation_rollout():
+    import vln_amd as vln
+    vln._lib.load()
+    dev = torch.device("cuda:0")
+    G = load_golden("agent_envdrop_teacher")
+    Pe, Pd, Pc = split(G["param"])
+    enc = vln.EncoderLSTM(40, 16, 32, 0, 0.5, True, 1)
+    dec = vln.EnvDropDecoder(32, 0.5, 0.3, 8, 128, 2176)
+    enc.load_state_dict(Pe, strict=True); dec.load_state_dict(Pd, strict=True)
+    enc.to(dev).eval()
+    dec.to(dev).train()                         # the environment mask is a training-mode draw; the other dropouts off
+    dec.drop_ratio = 0.0
+    senc, sdec = _speaker_modules(lambda: vln.SpeakerEncoder(2176, 32, 0.5, True, 128, 0.3),
+                                  lambda: vln.SpeakerDecoder(40, 16, 0, 32, 0.5))
+    spk = vln.Speaker(senc.to(dev), sdec.to(dev), max_decode=7)
+    env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+    can, img, lengths = R.shortest_path_features(env)
+    insts, noise = vln.back_translate(spk, dec, can.to(dev), img.to(dev), lengths)
+    assert set(noise.unique().cpu().tolist()) <= {0.0, float(torch.tensor(1 / 0.7, dtype=torch.float32))}
+    # the oracle speaker, same weights, same mask -> the same instructions
+    ora = R.SpeakerOracle({k.replace(".rnn.", "."): v.cpu() for k, v in senc.state_dict().items()},
+                          {k.replace(".rnn.", "."): v.cpu() for k, v in sdec.state_dict().items()}, True)
+    with torch.no_grad():
+        words, _ = R.speaker_infer_batch(ora.encode, ora.decode, can, img, lengths, 32, 7, featdropmask=noise.cpu().double())
+    assert np.array_equal(R.back_translate_instructions(words), insts), (words, insts)
+    assert len({int(np.argmax(r == 0)) if (r == 0).any() else len(r) for r in insts}) > 1     # the re-sort is exercised
+    # the follower trained on the generated instructions under the shared mask: HIP modules == CPU oracle
+    be = R.ModuleBackend(enc, dec, None, dev)
+    res = R.envdrop_rollout(be, FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7), "teacher", 6, insts=insts, noise=noise)
+    res["loss"].backward()
+    bo = R.OracleBackend(Pe, Pd, Pc)
+    ref = R.envdrop_rollout(bo, FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7), "teacher", 6, insts=insts,
+                            noise=noise.cpu().double())
+    ref["loss"].backward()
+    assert np.array_equal(res["actions"], ref["actions"])
+    assert abs(float(res["ml_loss"].detach()) - float(ref["ml_loss"].detach())) <= 1e-4 * max(1.0, abs(float(ref["ml_loss"].detach())))
+    g, go = be.named_grads(), bo.named_grads()
+    for n, r in go.items():
+        if n.startswith("cri."):
+            continue
+        err = (g[n].detach().double().cpu() - r).abs().max().item()
+        assert err <= 5e-4 * max(r.abs().max().item(), 1e-3), f"grad {n}: max err {err}"
+
+
+def test_oracle_rollout_instruction_override_is_consistent():
+    """The back-translation plumbing of the harness (re-sort by recomputed length, actions mapped back to the environment's
+    order): feeding the batch's OWN instructions in a shuffled-length order must give the loss of the plain rollout."""
+    G = load_golden("agent_envdrop_teacher")
+    env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
+    own = np.stack([b["instr_encoding"] for b in env.batch])
+    be = R.OracleBackend(*split(G["param"]))
+    res = R.envdrop_rollout(be, env, "teacher", 6, insts=own)
+    assert abs(float(res["ml_loss"].detach()) - float(G["out"]["ml_loss"])) <= 1e-5 * max(1.0, abs(float(G["out"]["ml_loss"])))
+    assert np.array_equal(res["actions"], G["out"]["actions"].numpy())
+    # rows swapped so that the lengths are no longer sorted: same episodes, other instructions -> still runs, finite, and
+    # the actions (teacher forcing) are the environment's own
+    swapped = own[[3, 2, 1, 0]]
+    res2 = R.envdrop_rollout(R.OracleBackend(*split(G["param"])), FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7),
+                             "teacher", 6, insts=swapped)
+    assert np.isfinite(float(res2["ml_loss"]))
+    perm = np.argsort(-np.array([int(np.argmax(r == 0)) if (r == 0).any() else len(r) for r in swapped]), kind="stable")
+    assert np.array_equal(res2["actions"], G["out"]["actions"].numpy()[:, perm])
