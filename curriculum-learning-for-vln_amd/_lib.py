@@ -95,6 +95,7 @@ SIGNATURES = {
     "vln_pe_dropout": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
+    "vln_ew": (i32, [i32, ptr, i64, ptr, i64, i32, ptr, i64, i32, i32, ptr]),
     "vln_add_n": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i32, ptr]),
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),

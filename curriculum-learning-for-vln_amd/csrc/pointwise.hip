@@ -844,6 +844,52 @@ extern "C" int vln_add_n(float* out, int64_t ldo, int rows, int cols, const floa
   return VLN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small row-wise elementwise forms of the Speaker-Follower step (ActionScoring, units.py:163-185; tanh backward):
+//   VLN_EW_MUL         y[r,c] = a[r,c] * b[r*ldb + c]            (ldb = 0: b is one row vector, e.g. linear_out.weight)
+//   VLN_EW_ADD_SCALAR  y[r,c] = a[r,c] + b[0]                    (linear_out.bias)
+//   VLN_EW_TANH_GRAD   y[r,c] = a[r,c] * (1 - b[r,c]^2)          (b = tanh output)
+//   VLN_EW_MUL_ROWSUM  y[r,c] = a[r,c] * sum_{j<nb} b[r*ldb + j] (a = NULL: 1, i.e. the row sums themselves)
+// One workgroup per row (rows <= a few hundred, cols <= a few thousand): the row sum is a block reduction in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+namespace vln {
+struct EwArgs { const float* a; long lda; const float* b; long ldb; int nb; float* y; long ldy; int rows, cols, op; };
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs e) {
+  const int r = blockIdx.x;
+  __shared__ float part[4];
+  float rs = 0.f;
+  if (e.op == 3) {
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < e.nb; j += 256) acc += e.b[(long)r * e.ldb + j];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    rs = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+  const float b0 = (e.op == 1) ? e.b[0] : 0.f;
+  for (int c = threadIdx.x; c < e.cols; c += 256) {
+    const float av = e.a ? e.a[(long)r * e.lda + c] : 1.f;
+    float v;
+    if (e.op == 0) v = av * e.b[(long)r * e.ldb + c];
+    else if (e.op == 1) v = av + b0;
+    else if (e.op == 2) { const float t = e.b[(long)r * e.ldb + c]; v = av * (1.f - t * t); }
+    else v = av * rs;
+    e.y[(long)r * e.ldy + c] = v;
+  }
+}
+}  // namespace vln
+extern "C" int vln_ew(int op, const float* a, int64_t lda, const float* b, int64_t ldb, int nb, float* y, int64_t ldy, int rows,
+                      int cols, void* s) {
+  if (!y || !b || rows <= 0 || cols <= 0 || op < 0 || op > 3 || (!a && op != 3) || (op == 3 && nb <= 0)) {
+    vln::set_error("vln_ew: bad args");
+    return VLN_ERR_ARG;
+  }
+  vln::EwArgs e{a, (long)lda, b, (long)ldb, nb, y, (long)ldy, rows, cols, op};
+  hipLaunchKernelGGL(vln::ew_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, e);
+  VLN_CHECK_LAUNCH("ew");
+  return VLN_OK;
+}
+
 extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
                           int R, int D, float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset,

@@ -107,6 +107,7 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
         self.visual_attn = VisualSoftDotAttention(hidden_size, feature_size)
         self.decode_action = ActionScoring(action_embed_size, hidden_size)
         self._init_seed(0xF0110)
+        self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
@@ -118,6 +119,17 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
         _need_gpu(img_feature, "AttnDecoderLSTM")
         site = self._next()
         p, tr, seed = self.drop_ratio, self.training, self.dropout_seed
+        if self.fused_step and ctx.dtype == torch.float32 and img_feature.shape[2] % 4 == 0 and self.hidden_size % 4 == 0 \
+                and a_t_cands.shape[2] % 4 == 0 and not img_feature.requires_grad and not a_t_cands.requires_grad:
+            va, ds = self.visual_attn, self.decode_action            # the whole step as ONE autograd node
+            logit, h_new, c_new, word_w, view_w = Fh.FollowerCoreFn.apply(
+                (tr, self.compute_dtype, p, seed, site), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
+                va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
+                self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,
+                self.text_attn.linear_in.weight, self.text_attn.linear_out.weight,
+                ds.linear_act.weight, ds.linear_act.bias, ds.linear_hid.weight, ds.linear_hid.bias, ds.linear_out.weight, ds.linear_out.bias)
+            return logit, (h_new, c_new), (word_w, view_w)
+        # operator-by-operator path (shapes the fused node does not take; the reference for it in the tests)
         # (1) look at the panorama with the previous hidden state: [B,36,F] -> [B,F]
         pano, view_w = self.visual_attn(h_0, img_feature)
         # (2) recurrent update on [previous action | attended view]

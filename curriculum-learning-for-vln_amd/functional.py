@@ -550,3 +550,134 @@ class MonitorCoreFn(torch.autograd.Function):
         gbc = dpre.sum(0)
         return (None, None, None, None, dxcat[:, :M], dcand, dh0, dc0, dctx,
                 gW[0], gW[1], gb_vh, gW[2], gW[3], gb_ih, gb_hh, gW[4], gb_a, gW[5], gb_m, gWc.view_as(W_c), gbc.view_as(b_c))
+
+
+class FollowerCoreFn(torch.autograd.Function):
+    """AttnDecoderLSTM.forward (policy.py:37-60) + ActionScoring (units.py:163-185) as ONE autograd node: the v-projected
+    visual attention, dropout, the LSTM cell, the text attention with its tanh output layer and the candidate scores --
+    no torch glue (concatenations are row blocks of one buffer, `context * target` is folded into the score query:
+    logit = context . (target (.) w_out) + b_out), every weight gradient of the step in one grouped launch over the B
+    rows, every bias gradient in another.  The two projections over many rows (36 views, C candidates) never form their
+    [B*S, dot] gradient: dW_v = tq^T (sum_v dl_v img_v), dW_act = q^T (sum_c dlogit_c cand_c).
+    cfg = (training, dtype, p_drop, seed, off)   (dropout sites off, off + 1 as on the operator path).
+    params = W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out."""
+
+    @staticmethod
+    def forward(ctx, cfg, ctx_mask, img, a_prev, cands, h0, c0, ctxt, *params):
+        training, dtype, p_drop, seed, off = cfg
+        W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out = params
+        f32 = torch.float32
+        img, cands = img.detach().contiguous(), cands.detach().contiguous()
+        a_prev, h0, c0, ctxt = a_prev.detach().contiguous(), h0.detach().contiguous(), c0.detach().contiguous(), ctxt.detach().contiguous()
+        B, V, F = img.shape
+        C, A = cands.shape[1], cands.shape[2]
+        H = h0.shape[1]
+        D = W_h.shape[0]
+        dev = h0.device
+        pd = p_drop if training else 0.0
+        E = lambda *sh: ops.empty(*sh, dtype=f32, device=dev)
+        # (1) panorama attention: keys = W_v img + b_v, query = W_h h0 + b_h, weighted sum over the UN-projected views
+        tq = ops.linear_fwd(h0, SHADOWS.get(W_h, "n", dtype), b_h.detach())
+        keys = ops.linear_fwd(img.view(B * V, F), SHADOWS.get(W_v, "n", dtype), b_v.detach())
+        vlog = ops.attn_dot(keys.view(B, V, D), tq)
+        xcat = E(B, A + F + H)                                   # [a_prev | pano | h0]: the LSTM input row
+        _, view_w = ops.attn_softmax_wsum(img, vlog, None, out=xcat[:, A:A + F])
+        xcat[:, :A].copy_(a_prev)
+        xcat[:, A + F:].copy_(h0)
+        if pd > 0:                                               # dropout over cat(a_prev, pano) (policy.py:49), in place
+            st = _lib.load().vln_scale_dropout(xcat.data_ptr(), xcat.stride(0), xcat.data_ptr(), xcat.stride(0), B, A + F, seed, off, pd,
+                                               _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_scale_dropout")
+        # (2) LSTM cell
+        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, dtype, False))
+        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off + 1, pd, True)
+        # (3) text attention + tanh(W_out [wc ; drop(h1)])
+        tq2 = ops.linear_fwd(hd, SHADOWS.get(W_tin, "n", dtype))
+        tcat = E(B, 2 * H)
+        _, word_w = ops.attn_fwd_rows(ctxt, tq2, ctx_mask, out=tcat[:, :H])
+        tcat[:, H:].copy_(hd)
+        grounded = ops.linear_fwd(tcat, SHADOWS.get(W_tout, "n", dtype), None, ops.ACT_TANH)
+        # (4) candidate scores
+        target = ops.linear_fwd(grounded, SHADOWS.get(W_hid, "n", dtype), b_hid.detach())
+        wo = w_out.detach().reshape(-1)
+        q = ops.ew(ops.EW_MUL, target, wo, bcast=True)
+        context = ops.linear_fwd(cands.view(B * C, A), SHADOWS.get(W_act, "n", dtype), b_act.detach())
+        raw = ops.attn_dot(context.view(B, C, D), q)
+        logit = ops.ew(ops.EW_ADD_SCALAR, raw, b_out.detach(), bcast=True)
+        ctx.cfg = cfg
+        ctx.save_for_backward(img, cands, h0, c0, ctxt, tq, keys, view_w, xcat, act, tc, hd, tq2, tcat, word_w, grounded, target, q,
+                              context, *params)
+        ctx.set_materialize_grads(False)
+        return logit, h1, c1, word_w, view_w
+
+    @staticmethod
+    def backward(ctx, dlogit, dh1, dc1, dww_ext, dvw_ext):
+        training, dtype, p_drop, seed, off = ctx.cfg
+        (img, cands, h0, c0, ctxt, tq, keys, view_w, xcat, act, tc, hd, tq2, tcat, word_w, grounded, target, q, context,
+         W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out) = ctx.saved_tensors
+        f32 = torch.float32
+        B, V, F = img.shape
+        C, A = cands.shape[1], cands.shape[2]
+        H, D = h0.shape[1], W_h.shape[0]
+        dev = h0.device
+        pd = p_drop if training else 0.0
+        cz = lambda t: None if t is None else t.contiguous()
+        dlogit, dh1, dc1, dww_ext, dvw_ext = cz(dlogit), cz(dh1), cz(dc1), cz(dww_ext), cz(dvw_ext)
+        E = lambda *sh: ops.empty(*sh, dtype=f32, device=dev)
+        if dlogit is None:
+            dlogit = torch.zeros(B, C, dtype=f32, device=dev)
+        wo = w_out.detach().reshape(-1)
+        # (4) scores: logit = context . q + b_out, q = target (.) w_out, context = W_act cands + b_act
+        dq = ops.rows_wsum(context.view(B, C, D), dlogit)
+        dtarget = ops.ew(ops.EW_MUL, dq, wo, bcast=True)
+        Zo = ops.ew(ops.EW_MUL, dq, target)                                      # colsum -> d w_out
+        rc = ops.rows_wsum(cands, dlogit)                                        # [B, A]: sum_c dlogit_c cand_c -> d W_act = q^T rc
+        qs = ops.ew(ops.EW_MUL_ROWSUM, q, dlogit, nb=C)                          # colsum -> d b_act
+        sl = ops.ew(ops.EW_MUL_ROWSUM, None, dlogit, nb=C)                       # [B,1] row sums; colsum -> d b_out
+        dgr = ops.linear_fwd(dtarget, SHADOWS.get(W_hid, "t", dtype))
+        # (3) grounded = tanh(W_out tcat)
+        dz = ops.ew(ops.EW_TANH_GRAD, dgr, grounded)
+        dtcat = ops.linear_fwd(dz, SHADOWS.get(W_tout, "t", dtype))              # [B, 2H] -> wc | drop(h1)
+        need_dctx = ctx.needs_input_grad[7]
+        dtq2, dl_t = ops.attn_bwd_rows(ctxt, word_w, dtcat[:, :H], dww_ext, want_dl=need_dctx)
+        dctx = None
+        if need_dctx:
+            dctx = torch.empty_like(ctxt)
+            ops.attn_dctx_deferred([word_w.data_ptr()], [dl_t.data_ptr()], [dtcat.data_ptr()], dtcat.stride(0), [tq2.data_ptr()], H, dctx)
+        dhd = _add_n(E(B, H), [dtcat[:, H:], ops.linear_fwd(dtq2, SHADOWS.get(W_tin, "t", dtype))])
+        # (2) LSTM cell
+        dg, dc0 = ops.lstm_pointwise_bwd(dh1, dhd, dc1, act, tc, c0, seed, off + 1, pd)
+        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, dtype, True))  # [B, A+F+H] -> a_prev | pano | h0
+        if pd > 0:
+            st = _lib.load().vln_scale_dropout(dxcat.data_ptr(), dxcat.stride(0), dxcat.data_ptr(), dxcat.stride(0), B, A + F, seed, off, pd,
+                                               _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_scale_dropout")
+        # (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq)
+        dpano = dxcat[:, A:A + F]
+        dalpha = ops.attn_dot(img, dpano)
+        _, dl_v = ops.attn_bwd(img, view_w, dalpha, dvw_ext, None, None, None, want_dl=True)
+        dtq = ops.rows_wsum(keys.view(B, V, D), dl_v)
+        rv = ops.rows_wsum(img, dl_v)                                            # [B, F]: sum_v dl_v img_v -> d W_v = tq^T rv
+        tqs = ops.ew(ops.EW_MUL_ROWSUM, tq, dl_v, nb=V)                          # colsum -> d b_v (analytically 0: softmax rows)
+        dh0 = _add_n(E(B, H), [dxcat[:, A + F:], ops.linear_fwd(dtq, SHADOWS.get(W_h, "t", dtype))])
+        # parameter gradients: eight products over the same B rows -> one grouped launch; the biases -> another
+        gW = [torch.empty_like(w) for w in (W_h, W_v, W_ih, W_hh, W_tin, W_tout, W_act, W_hid)]
+        wb = ops.WgradBatch(dtype != f32)
+        wb.add(dtq, h0, gW[0]); wb.add(tq, rv, gW[1])
+        wb.add(dg, xcat[:, :A + F], gW[2]); wb.add(dg, xcat[:, A + F:], gW[3])
+        wb.add(dtq2, hd, gW[4]); wb.add(dz, tcat, gW[5])
+        wb.add(q, rc, gW[6]); wb.add(dtarget, grounded, gW[7])
+        wb.run()
+        gb_h, gb_v, gb_ih, gb_hh, gb_act, gb_hid = (torch.empty_like(b) for b in (b_h, b_v, b_ih, b_hh, b_act, b_hid))
+        gwo = torch.empty(D, dtype=f32, device=dev)
+        gbo = torch.empty(1, dtype=f32, device=dev)
+        cb = ops.ColsumBatch()
+        cb.add(dtq, gb_h); cb.add(tqs, gb_v); cb.add(dg, gb_ih, gb_hh); cb.add(qs, gb_act); cb.add(dtarget, gb_hid); cb.add(Zo, gwo)
+        cb.add(sl, gbo)
+        cb.run()
+        da = dxcat[:, :A] if ctx.needs_input_grad[3] else None
+        return (None, None, None, da, None, dh0, dc0, dctx,
+                gW[0], gb_h, gW[1], gb_v, gW[2], gW[3], gb_ih, gb_hh, gW[4], gW[5], gW[6], gb_act, gW[7], gb_hid,
+                gwo.view_as(w_out), gbo.view_as(b_out))

@@ -418,6 +418,25 @@ def attn_bwd(ctx, attn, dalpha, dattn_ext=None, dwc=None, vec=None, dctx=None, w
     return dvec, dl
 
 
+EW_MUL, EW_ADD_SCALAR, EW_TANH_GRAD, EW_MUL_ROWSUM = 0, 1, 2, 3
+
+
+def ew(op: int, a, b, out=None, nb: int = 0, bcast: bool = False):
+    """Row-wise elementwise forms (vln_ew): a [R,C] (row stride free; None for the plain row sums of op 3), b [R,C] /
+    [R,nb] or, with `bcast`, one row vector / scalar."""
+    lib = _lib.load()
+    if a is not None:
+        R, Cn = a.shape
+    else:
+        R, Cn = b.shape[0], 1
+    if out is None:
+        out = empty(R, Cn, dtype=torch.float32, device=b.device)
+    ldb = 0 if bcast else (b.stride(0) if b.dim() == 2 else 0)
+    _lib.check(lib.vln_ew(op, _p(a), a.stride(0) if a is not None else 0, _p(b), ldb, nb, _p(out), out.stride(0), R, Cn, _stream()),
+               "vln_ew")
+    return out
+
+
 def dropout_mask(n: int, seed: int, offset: int, p: float, device) -> torch.Tensor:
     """The exact pre-scaled keep mask (0 or 1/(1-p)) the kernels use for (seed, offset)."""
     lib = _lib.load()

@@ -186,6 +186,15 @@ int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mas
 int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp /*nullable*/, const float* dent /*nullable*/,
                         float* dlogits, int B, int C, vln_stream_t s);
 
+/* Row-wise elementwise forms of the Speaker-Follower step: ActionScoring's `context * target` folded into the query
+ * (units.py:180-184: logit = linear_out(context * target) = context . (target (.) w_out) + b_out) and the tanh backward.
+ *   op 0 VLN_EW_MUL        y[r,c] = a[r,c] * b[r*ldb + c]      (ldb = 0: b is one row vector)
+ *   op 1 VLN_EW_ADD_SCALAR y[r,c] = a[r,c] + b[0]
+ *   op 2 VLN_EW_TANH_GRAD  y[r,c] = a[r,c] * (1 - b[r,c]^2)
+ *   op 3 VLN_EW_MUL_ROWSUM y[r,c] = a[r,c] * sum_{j<nb} b[r*ldb + j]   (a NULL: the row sums themselves) */
+int vln_ew(int op, const float* a, int64_t lda, const float* b, int64_t ldb, int nb, float* y, int64_t ldy, int rows, int cols,
+           vln_stream_t s);
+
 /* Pieces of the Self-Monitor decoder step (policy.py:119-166) besides GEMMs, attention rows and the BN-MLP:
  *   vln_pe_dropout        out = dropout(ctx + pe[:L])  [B,L,H]                               (units.py:188-207)
  *   vln_monitor_head_fwd  mem = dropout(sigmoid(mg) * tanh(c1)); prog = tanh(wc . [word_w ; mem] + bc)   (policy.py:126-130)

@@ -4,11 +4,12 @@
   monitor  (config 2)  Self-Monitoring agent + progress-monitor head, B=128, L=80 (uni-directional encoder, H=512,
                        MLP 1024), T teacher-forced steps, loss = CE at t=0 then 0.5*MSE + 0.5*CE (monitor.py:146-165),
                        one Adam over encoder+decoder (trainer.py:219-222)
+  follower (config 0's model, GPU batch)  Speaker-Follower agent, B=64, L=80, T teacher-forced steps, CE mean, two Adam
   a2c      (config 3, one rank)  EnvDrop IL (teacher, T=7) + RL (sampled actions, T=10, A2C with the critic) mixed loss
                        at B=64 per GPU, clip 40 + RMSprop over encoder / decoder / critic
 
 Synthetic data of BASELINE.md's shapes, features resident in HBM; prints one JSON line per workload.
-    python scripts/bench_agents.py [monitor|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32]
+    python scripts/bench_agents.py [monitor|follower|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32]
 """
 import argparse, json, sys, time
 sys.path.insert(0, '.')
@@ -77,6 +78,47 @@ def run_monitor(B=128, L=80, T=7, C=8):
                 dtype=args.dtype)
 
 
+def run_follower(B=64, L=80, T=7, C=8, fused=True):
+    """Speaker-Follower agent (BASELINE config 0's model at a GPU batch): 2-layer bi-directional encoder (E=300, H=256),
+    AttnDecoderLSTM over 36 x 2176 views, CE mean per step (follower.py:62,123-139), two Adam instances (trainer.py:65-67)."""
+    g = torch.Generator().manual_seed(2020)
+    enc = vln.EncoderLSTM(992, 300, 256, 0, 0.5, True, 2, compute_dtype=dt).to(dev).train()
+    dec = vln.AttnDecoderLSTM(256, 0.5, F, F, compute_dtype=dt).to(dev).train()
+    dec.fused_step = fused
+    opt_e = vln.optim.FusedAdam([list(enc.parameters())], lr=1e-4)
+    opt_d = vln.optim.FusedAdam([list(dec.parameters())], lr=1e-4)
+    tokens = torch.randint(4, 992, (B, L), generator=g)
+    lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, n:] = 0
+    tokens, lens32 = tokens.to(dev), lens.to(dev, torch.int32)
+    seq_mask = tokens == 0
+    steps = []
+    for t in range(T):
+        ncand = torch.randint(3, C + 1, (B,), generator=g)
+        cmask = torch.arange(C)[None, :] >= ncand[:, None]
+        cand = torch.randn(B, C, F, generator=g).abs() * 0.5 * (~cmask)[..., None]
+        img = torch.randn(B, 36, F, generator=g).abs() * 0.5
+        tgt = (torch.rand(B, generator=g) * ncand.float()).long()
+        steps.append(dict(img=img.to(dev), cand=cand.to(dev), cmask=cmask.to(dev), target=tgt.to(dev)))
+
+    def it():
+        opt_e.zero_grad(); opt_d.zero_grad()
+        ctx, h, c = enc(tokens, lens32)
+        a_prev = torch.zeros(B, F, device=dev)
+        loss = 0.0
+        for s in steps:
+            logit, (h, c), _ = dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask)
+            loss = loss + vln.losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
+            a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
+        loss.backward()
+        opt_e.step(); opt_d.step()
+
+    ms = timed(it)
+    return dict(workload=f"follower_il_B{B}_L{L}_T{T}_adam" + ("" if fused else "_operator_path"), ms_per_iteration=round(ms, 3),
+                iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
+
+
 def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
     cpu_tape = bench.make_tape(B, L, T_rl, C, 2020)
     tape = bench.tape_to(cpu_tape, dev, store_dtype=dt)
@@ -140,5 +182,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
 
 if args.which in ("monitor", "all"):
     print(json.dumps(run_monitor()), flush=True)
+if args.which in ("follower", "all"):
+    print(json.dumps(run_follower()), flush=True)
+    print(json.dumps(run_follower(fused=False)), flush=True)
 if args.which in ("a2c", "all"):
     print(json.dumps(run_a2c()), flush=True)

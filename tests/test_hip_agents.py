@@ -171,6 +171,53 @@ def test_monitor_fused_step_equals_operator_path(vln, cdt):
         close(res[0][3][k], res[1][3][k], k)
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_follower_fused_step_equals_operator_path(vln, cdt):
+    """AttnDecoderLSTM as one autograd node (functional.FollowerCoreFn) against the operator-by-operator path it replaces,
+    in TRAINING mode with both dropouts on (same Philox masks): logits, state, both attention maps, every parameter
+    gradient (incl. the factorised d linear_in_v / d linear_act) and the gradients of ctx / h0 / c0, over a two-step chain
+    with ragged candidate counts and attention-map gradients flowing in."""
+    B, V, C, L, H, F = 12, 36, 6, 17, 64, 96
+    g = torch.Generator().manual_seed(99)
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    imgs = [torch.randn(B, V, F, generator=g).abs() for _ in range(2)]
+    cands = [torch.randn(B, C, F, generator=g).abs() for _ in range(2)]
+    a_prev = torch.randn(B, F, generator=g).abs()
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
+    r = [torch.randn(B, C, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g), torch.randn(B, L, generator=g),
+         torch.randn(B, V, generator=g)]
+    torch.manual_seed(6)
+    ref = vln.AttnDecoderLSTM(H, 0.5, F, F, compute_dtype=cdt)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    res = []
+    for fused in (True, False):
+        dec = vln.AttnDecoderLSTM(H, 0.5, F, F, compute_dtype=cdt)
+        dec.load_state_dict(sd); dec.to(DEV).train()
+        dec.fused_step = fused
+        ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+        hh, cc, ap, total, outs = h, c, a_prev.to(DEV), 0.0, []
+        for t in range(2):
+            logit, (hh, cc), (ww, vw) = dec(imgs[t].to(DEV), ap, cands[t].to(DEV), hh, cc, ctx, ctx_mask.to(DEV))
+            total = total + (logit * r[0].to(DEV)).sum() + (ww * r[3].to(DEV)).sum() + (vw * r[4].to(DEV)).sum()
+            outs += [logit, ww, vw]
+            ap = cands[t][:, 0].to(DEV)
+        total = total + (hh * r[1].to(DEV)).sum() + (cc * r[2].to(DEV)).sum()
+        total.backward()
+        res.append((outs + [hh, cc], {n: p.grad.clone() for n, p in dec.named_parameters()}, [ctx.grad, h.grad, c.grad]))
+    tol = 2e-4 if cdt == torch.float32 else 2e-2
+    gscale = max(v.abs().max().item() for v in res[1][1].values())
+
+    def close(a, b, what, floor=1e-6):
+        err = (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), floor)
+        assert err < tol, (what, err)
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        close(a, b, f"out{i}")
+    for n in res[0][1]:      # d linear_in_v.bias is zero in exact arithmetic (softmax rows): judged on the scale of real gradients
+        close(res[0][1][n], res[1][1][n], "grad " + n, floor=1e-2 * gscale)
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        close(a, b, f"input grad {i}")
+
+
 # ---- speaker modules (SURVEY §8f N3; units.py:286-395) ------------------------------------------------------------------
 def _holder_name(n):
     """reference parameter name -> attribute path here (the nn.LSTM parameter holder sits one level down)"""
