@@ -41,6 +41,34 @@ class _ShadowCache:
 SHADOWS = _ShadowCache()
 
 
+# ---- parameter gradients of the fused nodes: returned to autograd (default) or added straight into p.grad ---------------
+_GRAD_IN_PLACE = [False]
+GRAD_IN_PLACE_STATS = [0, 0]            # [gradients added in place, gradients returned to autograd] (diagnostic)
+
+
+def set_grad_in_place(on: bool):
+    """With this on, the fused decoder nodes (BnMlpFn, MonitorCoreFn, FollowerCoreFn) ADD their Linear weight / bias
+    gradients into an existing `p.grad` inside the grouped launches and hand autograd `None` for those parameters: the
+    ~250 AccumulateGrad `add_` launches per Self-Monitor iteration (one per parameter per decoder step) disappear.
+    Same numbers in `p.grad` after `backward()`; NOT for `torch.autograd.grad(...)` callers (they would see None), hence
+    opt-in.  Parameters whose `.grad` is None (first backward after `zero_grad(set_to_none=True)`) take the normal route."""
+    _GRAD_IN_PLACE[0] = bool(on)
+
+
+def _gsink(p):
+    """-> (tensor the launch writes, accumulate flag, value to return to autograd is None)."""
+    g = p.grad
+    if _GRAD_IN_PLACE[0] and g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous():
+        GRAD_IN_PLACE_STATS[0] += 1
+        return g, True
+    GRAD_IN_PLACE_STATS[1] += 1
+    return torch.empty_like(p), False
+
+
+def _gret(t, acc):
+    return None if acc else t
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) with x [M,K] fp32; act in {none,tanh,relu}.  Replaces F.linear (+ nn.Tanh/ReLU)."""
 
@@ -393,13 +421,13 @@ class BnMlpFn(torch.autograd.Function):
             z, si, y = saved[3 + 3 * i], saved[4 + 3 * i], saved[5 + 3 * i]
             y_prev = saved[2 + 3 * i]                    # input of this layer's Linear (y0 for i = 0)
             dz = bn_bwd(z, g, y, gw, si, bufs[1 + i], True, drops[i], rz if i == nl - 1 else None, True, 4 + 4 * i)
-            dW = torch.empty_like(W)
-            wb.add(dz, y_prev, dW, False)
-            grads[2 + 4 * i] = dW
+            dW, accW = _gsink(W)
+            wb.add(dz, y_prev, dW, accW)
+            grads[2 + 4 * i] = _gret(dW, accW)
             if b is not None:
-                db = torch.empty_like(b)
-                cb.add(dz, db, None, False)
-                grads[3 + 4 * i] = db
+                db, accb = _gsink(b)
+                cb.add(dz, db, None, accb)
+                grads[3 + 4 * i] = _gret(db, accb)
             g = ops.linear_fwd(dz, SHADOWS.get(W, "t", dtype))
             if i > 0 or True:
                 pass
@@ -536,20 +564,28 @@ class MonitorCoreFn(torch.autograd.Function):
         dh0_t = ops.linear_fwd(dtq, SHADOWS.get(W_tin, "t", dtype))
         dh0 = _add_n(E(B, H), [dhm[:, :H], dxcat[:, 2 * M + H:], dh0_v, dh0_t])
         # parameter gradients: six products over the same B rows -> one grouped launch; biases -> another
-        gW = [torch.empty_like(w) for w in (W_tin, W_vh, W_ih, W_hh, W_a, W_m)]
+        sk = [_gsink(w) for w in (W_tin, W_vh, W_ih, W_hh, W_a, W_m)]
+        gW = [t for t, _ in sk]
         wb = ops.WgradBatch(dtype != f32)
-        wb.add(dtq, h0, gW[0]); wb.add(dvq, h0, gW[1])
-        wb.add(dg, xcat[:, :2 * M + H], gW[2]); wb.add(dg, xcat[:, 2 * M + H:], gW[3])
-        wb.add(daq, tcat, gW[4]); wb.add(dmg, hm, gW[5])
+        wb.add(dtq, h0, gW[0], sk[0][1]); wb.add(dvq, h0, gW[1], sk[1][1])
+        wb.add(dg, xcat[:, :2 * M + H], gW[2], sk[2][1]); wb.add(dg, xcat[:, 2 * M + H:], gW[3], sk[3][1])
+        wb.add(daq, tcat, gW[4], sk[4][1]); wb.add(dmg, hm, gW[5], sk[5][1])
         wb.run()
-        gb_vh, gb_ih, gb_hh, gb_a, gb_m = (torch.empty_like(b) for b in (b_vh, b_ih, b_hh, b_a, b_m))
+        (gb_vh, a_vh), (gb_a, a_a), (gb_m, a_m) = _gsink(b_vh), _gsink(b_a), _gsink(b_m)
+        (gb_ih, a_ih), (gb_hh, a_hh) = _gsink(b_ih), _gsink(b_hh)
         gWc = torch.empty(L + H, dtype=f32, device=dev)
         cb = ops.ColsumBatch()
-        cb.add(dvq, gb_vh); cb.add(dg, gb_ih, gb_hh); cb.add(daq, gb_a); cb.add(dmg, gb_m); cb.add(Z, gWc)
+        cb.add(dvq, gb_vh, None, a_vh); cb.add(daq, gb_a, None, a_a); cb.add(dmg, gb_m, None, a_m); cb.add(Z, gWc)
+        if a_ih == a_hh:
+            cb.add(dg, gb_ih, gb_hh, a_ih)
+        else:
+            cb.add(dg, gb_ih, None, a_ih); cb.add(dg, gb_hh, None, a_hh)
         cb.run()
         gbc = dpre.sum(0)
         return (None, None, None, None, dxcat[:, :M], dcand, dh0, dc0, dctx,
-                gW[0], gW[1], gb_vh, gW[2], gW[3], gb_ih, gb_hh, gW[4], gb_a, gW[5], gb_m, gWc.view_as(W_c), gbc.view_as(b_c))
+                _gret(gW[0], sk[0][1]), _gret(gW[1], sk[1][1]), _gret(gb_vh, a_vh), _gret(gW[2], sk[2][1]), _gret(gW[3], sk[3][1]),
+                _gret(gb_ih, a_ih), _gret(gb_hh, a_hh), _gret(gW[4], sk[4][1]), _gret(gb_a, a_a), _gret(gW[5], sk[5][1]), _gret(gb_m, a_m),
+                gWc.view_as(W_c), gbc.view_as(b_c))
 
 
 class FollowerCoreFn(torch.autograd.Function):
@@ -663,21 +699,30 @@ class FollowerCoreFn(torch.autograd.Function):
         tqs = ops.ew(ops.EW_MUL_ROWSUM, tq, dl_v, nb=V)                          # colsum -> d b_v (analytically 0: softmax rows)
         dh0 = _add_n(E(B, H), [dxcat[:, A + F:], ops.linear_fwd(dtq, SHADOWS.get(W_h, "t", dtype))])
         # parameter gradients: eight products over the same B rows -> one grouped launch; the biases -> another
-        gW = [torch.empty_like(w) for w in (W_h, W_v, W_ih, W_hh, W_tin, W_tout, W_act, W_hid)]
+        sk = [_gsink(w) for w in (W_h, W_v, W_ih, W_hh, W_tin, W_tout, W_act, W_hid)]
+        gW = [t for t, _ in sk]
         wb = ops.WgradBatch(dtype != f32)
-        wb.add(dtq, h0, gW[0]); wb.add(tq, rv, gW[1])
-        wb.add(dg, xcat[:, :A + F], gW[2]); wb.add(dg, xcat[:, A + F:], gW[3])
-        wb.add(dtq2, hd, gW[4]); wb.add(dz, tcat, gW[5])
-        wb.add(q, rc, gW[6]); wb.add(dtarget, grounded, gW[7])
+        wb.add(dtq, h0, gW[0], sk[0][1]); wb.add(tq, rv, gW[1], sk[1][1])
+        wb.add(dg, xcat[:, :A + F], gW[2], sk[2][1]); wb.add(dg, xcat[:, A + F:], gW[3], sk[3][1])
+        wb.add(dtq2, hd, gW[4], sk[4][1]); wb.add(dz, tcat, gW[5], sk[5][1])
+        wb.add(q, rc, gW[6], sk[6][1]); wb.add(dtarget, grounded, gW[7], sk[7][1])
         wb.run()
-        gb_h, gb_v, gb_ih, gb_hh, gb_act, gb_hid = (torch.empty_like(b) for b in (b_h, b_v, b_ih, b_hh, b_act, b_hid))
+        bk = [_gsink(b) for b in (b_h, b_v, b_ih, b_hh, b_act, b_hid)]
+        gb_h, gb_v, gb_ih, gb_hh, gb_act, gb_hid = (t for t, _ in bk)
         gwo = torch.empty(D, dtype=f32, device=dev)
         gbo = torch.empty(1, dtype=f32, device=dev)
         cb = ops.ColsumBatch()
-        cb.add(dtq, gb_h); cb.add(tqs, gb_v); cb.add(dg, gb_ih, gb_hh); cb.add(qs, gb_act); cb.add(dtarget, gb_hid); cb.add(Zo, gwo)
+        cb.add(dtq, gb_h, None, bk[0][1]); cb.add(tqs, gb_v, None, bk[1][1]); cb.add(qs, gb_act, None, bk[4][1])
+        cb.add(dtarget, gb_hid, None, bk[5][1]); cb.add(Zo, gwo)
+        if bk[2][1] == bk[3][1]:
+            cb.add(dg, gb_ih, gb_hh, bk[2][1])
+        else:
+            cb.add(dg, gb_ih, None, bk[2][1]); cb.add(dg, gb_hh, None, bk[3][1])
         cb.add(sl, gbo)
         cb.run()
         da = dxcat[:, :A] if ctx.needs_input_grad[3] else None
         return (None, None, None, da, None, dh0, dc0, dctx,
-                gW[0], gb_h, gW[1], gb_v, gW[2], gW[3], gb_ih, gb_hh, gW[4], gW[5], gW[6], gb_act, gW[7], gb_hid,
+                _gret(gW[0], sk[0][1]), _gret(gb_h, bk[0][1]), _gret(gW[1], sk[1][1]), _gret(gb_v, bk[1][1]), _gret(gW[2], sk[2][1]),
+                _gret(gW[3], sk[3][1]), _gret(gb_ih, bk[2][1]), _gret(gb_hh, bk[3][1]), _gret(gW[4], sk[4][1]), _gret(gW[5], sk[5][1]),
+                _gret(gW[6], sk[6][1]), _gret(gb_act, bk[4][1]), _gret(gW[7], sk[7][1]), _gret(gb_hid, bk[5][1]),
                 gwo.view_as(w_out), gbo.view_as(b_out))

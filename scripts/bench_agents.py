@@ -22,7 +22,9 @@ ap.add_argument("which", nargs="?", default="all")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
 args = ap.parse_args()
+vln.functional.set_grad_in_place(not args.no_grad_in_place)
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 F = 2176
@@ -182,6 +184,7 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
 
 if args.which in ("monitor", "all"):
     print(json.dumps(run_monitor()), flush=True)
+    print("grad sinks [in place, via autograd]:", vln.functional.GRAD_IN_PLACE_STATS, file=sys.stderr)
 if args.which in ("follower", "all"):
     print(json.dumps(run_follower()), flush=True)
     print(json.dumps(run_follower(fused=False)), flush=True)

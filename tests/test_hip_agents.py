@@ -218,6 +218,45 @@ def test_follower_fused_step_equals_operator_path(vln, cdt):
         close(a, b, f"input grad {i}")
 
 
+@pytest.mark.parametrize("kind", ["follower", "monitor"])
+def test_fused_nodes_grad_in_place(vln, kind):
+    """functional.set_grad_in_place: the fused nodes add their Linear gradients into an existing p.grad (no AccumulateGrad
+    launches) -- after two backward passes p.grad equals the default route's, bit for bit where the launches are the same
+    and to rounding where accumulation order differs."""
+    B, V, C, L, H, F = 8, 36, 5, 12, 64, 96
+    g = torch.Generator().manual_seed(123)
+    ctx0 = torch.randn(B, L, H, generator=g); h0 = torch.randn(B, H, generator=g) * 0.5; c0 = torch.randn(B, H, generator=g) * 0.5
+    img = torch.randn(B, V, F, generator=g).abs(); cand = torch.randn(B, C, F, generator=g).abs(); ap = torch.randn(B, F, generator=g).abs()
+    lens = torch.randint(4, L + 1, (B,), generator=g); ctx_mask = (torch.arange(L)[None, :] >= lens[:, None]).to(DEV)
+    cmask = (torch.arange(C)[None, :] >= torch.randint(2, C + 1, (B,), generator=g)[:, None]).to(DEV)
+    r = torch.randn(B, C, generator=g).to(DEV)
+    torch.manual_seed(8)
+    make = (lambda: vln.AttnDecoderLSTM(H, 0.5, F, F)) if kind == "follower" else \
+        (lambda: vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, 128], action_embed_size=F, feature_size=F))
+    sd = {k: v.clone() for k, v in make().state_dict().items()}
+    out = []
+    try:
+        for inplace in (False, True):
+            vln.functional.set_grad_in_place(inplace)
+            dec = make(); dec.load_state_dict(sd); dec.to(DEV).train()
+            for p in dec.parameters():
+                p.grad = torch.zeros_like(p)
+            for _ in range(2):                                      # two backward passes: the second one accumulates either way
+                if kind == "follower":
+                    logit, (hh, cc), _ = dec(img.to(DEV), ap.to(DEV), cand.to(DEV), h0.to(DEV), c0.to(DEV), ctx0.to(DEV), ctx_mask)
+                else:
+                    (logit, prog), (hh, cc), _ = dec(None, ap.to(DEV), cand.to(DEV), h0.to(DEV), c0.to(DEV), ctx0.to(DEV), ctx_mask, cmask)
+                    logit = logit.masked_fill(cmask, 0.0) + prog[:, None]
+                ((logit * r).sum() + hh.sum() * 0.3 + cc.sum() * 0.2).backward()
+            out.append({n: p.grad.clone() for n, p in dec.named_parameters()})
+    finally:
+        vln.functional.set_grad_in_place(False)
+    scale = max(v.abs().max().item() for v in out[0].values())
+    for n in out[0]:
+        err = (out[0][n].double() - out[1][n].double()).abs().max().item()
+        assert err <= 2e-5 * max(out[0][n].abs().max().item(), 1e-2 * scale), (n, err)
+
+
 # ---- speaker modules (SURVEY §8f N3; units.py:286-395) ------------------------------------------------------------------
 def _holder_name(n):
     """reference parameter name -> attribute path here (the nn.LSTM parameter holder sits one level down)"""
