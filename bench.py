@@ -104,8 +104,12 @@ def tape_to(tape, dev, store_dtype=None):
 class GpuAgent:
     """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
 
-    def __init__(self, vln, dev, dtype, world, arena=False):
+    def __init__(self, vln, dev, dtype, world, arena=False, rollout_ce=True, side_gather=False):
         self.vln, self.world, self.dtype = vln, world, dtype
+        # (A/B option, off by default: measured slower) the step's feature gather reads only the resident table + index
+        # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
+        self.side = torch.cuda.Stream(device=dev) if side_gather else None
+        self.rollout_ce = rollout_ce
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
         self.enc.train(); self.dec.train()
@@ -134,7 +138,7 @@ class GpuAgent:
         pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
         # bf16 decoder: only the bf16 rows exist (nothing on this path reads fp32 features)
         (img, img_lp), (cand, cand_lp), _ = store.gather_step(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"],
-                                                              pf, want_bf16=lp, want_f32=not lp)
+                                                              pf, want_bf16=lp, want_f32=not lp, stream=self.side)
         kw = dict(already_dropfeat=True)
         return (img_lp, cand_lp, kw) if lp else (img, cand, kw)
 
@@ -149,17 +153,24 @@ class GpuAgent:
 
     def _iteration(self, tape):
         B = tape["B"]
+        if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
+            self.side.wait_stream(torch.cuda.current_stream())
         self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
         terms = []
+        ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
         for s in tape["steps"]:
             img, cand, kw = self.step_features(tape, s)
             logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], **kw)
-            # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum(),
-            # as one fused HIP launch (losses.py)
-            terms.append(self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
-        ml = torch.stack(terms).sum()                            # ml_loss += ... over the steps (envdrop.py:179)
+            # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum() (SURVEY §8 row
+            # A9): recorded per step, evaluated for the whole rollout in ONE launch (losses.RolloutCE) -- or, --ce per-step,
+            # one fused launch per step
+            if ce is not None:
+                ce.add(logits, s["target"], s["cand_mask"])
+            else:
+                terms.append(self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
+        ml = ce.sum() if ce is not None else torch.stack(terms).sum()     # ml_loss += ... over the steps (envdrop.py:179)
         loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
         loss.backward()
         self.opt.allreduce()
@@ -253,6 +264,13 @@ def main():
     ap.add_argument("--features", default="store", choices=["store", "tensor"],
                     help="store: ResNet table resident in HBM, a step ships indices (DeviceFeatureStore); "
                          "tensor: pre-built per-step feature tensors, cloned each step")
+    ap.add_argument("--ce", default="rollout", choices=["rollout", "per-step"],
+                    help="rollout: the IL loss of all T steps in one launch after the last step (losses.RolloutCE); per-step: one "
+                         "fused CE launch per decoder step")
+    ap.add_argument("--gather-stream", default="main", choices=["side", "main"],
+                    help="main: the per-step feature gather in line on the compute stream; side: on a side stream (it depends on "
+                         "no decoder output) -- measured SLOWER (2.28 vs 2.11 ms/iteration: the gathers land beside the persistent "
+                         "recurrence and slow its hand-offs, and the per-step event pair costs host time), kept for A/B")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="(testing) map every rank to cuda:0")
@@ -275,7 +293,8 @@ def main():
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(2020)
-    agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena)
+    agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
+                     side_gather=args.gather_stream == "side" and args.features == "store")
     tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
     tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None))
 

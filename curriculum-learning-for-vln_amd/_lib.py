@@ -24,6 +24,13 @@ class EnvDropDims(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "L", "V", "C", "H", "IMG", "ANG", "AE", "wtype", "ctype")]
 
 
+class CeStep(C.Structure):           # vln_ce_step
+    _fields_ = [("logits", ptr), ("ld", i64), ("target", ptr), ("cand_mask", ptr), ("probs", ptr), ("dlogits", ptr), ("C", i32)]
+
+
+CE_MAX_STEPS = 40                     # VLN_CE_MAX_STEPS
+
+
 class EnvDropWeights(C.Structure):
     _fields_ = [(n, ptr) for n in ("act_w", "act_b", "w_vin", "w_vin_t", "w_cat", "w_cat_t", "b_ih", "b_hh",
                                    "w_tin", "w_tin_t", "w_tout", "w_tout_t", "w_c", "w_c_t")]
@@ -91,6 +98,8 @@ SIGNATURES = {
     "vln_sgd_clip_step": (i32, [ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr]),
     "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
+    "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, ptr, i32, ptr]),
+    "vln_masked_ce_multi_bwd": (i32, [C.POINTER(CeStep), i32, i32, i64, ptr, ptr]),
     "vln_attn_dctx_deferred_drop": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr, ptr, ptr, ptr]),
     "vln_pe_dropout": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),

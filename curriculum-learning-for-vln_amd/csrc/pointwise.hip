@@ -2,6 +2,7 @@
 // applies the i,f,g,o nonlinearities and the state update in one pass), its backward, Philox dropout
 // helpers and the in-place environmental feature dropout (policy.py:226-231).
 #include "vln_internal.h"
+#include "../../include/vln_hip.h"
 
 namespace vln {
 
@@ -368,6 +369,48 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* probs, 
     const int b = (int)(e / C), c = (int)(e % C);
     const long t = target[b];
     dlogits[e] = (t == ignore_index) ? 0.f : dloss[b * dloss_stride] * (probs[e] - (c == t ? 1.f : 0.f));
+  }
+}
+
+// The IL loss of a whole rollout, ml_loss = sum_t CE_t (envdrop.py:178-179), in ONE launch after the last decoder step
+// instead of one per step: nothing on the rollout's dependent chain needs the loss, so the T small launches (and the T
+// backward ones) only lengthen it.  One workgroup; thread per (step, episode) row; rows of <= 16 candidates in registers.
+// Same per-row arithmetic as masked_ce_fwd_sum_kernel; the total is summed in a fixed order (rows strided by 256 per
+// thread, then the block tree).  Backward: one workgroup per step.
+struct CeMultiArgs {
+  float* logits[VLN_CE_MAX_STEPS]; const long long* target[VLN_CE_MAX_STEPS]; const unsigned char* mask[VLN_CE_MAX_STEPS];
+  float* probs[VLN_CE_MAX_STEPS]; float* dlogits[VLN_CE_MAX_STEPS]; int C[VLN_CE_MAX_STEPS]; int ld[VLN_CE_MAX_STEPS];
+  int T, B; long ignore_index;
+};
+__global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  const int rows = m.T * m.B;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int t = r / m.B, b = r - t * m.B;
+    CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
+             m.ignore_index, 0};
+    acc += (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (part[0] + part[1]) + (part[2] + part[3]);
+    loss_sum[0] = accumulate ? loss_sum[0] + v : v;
+  }
+}
+__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss) {
+  const int t = blockIdx.x;
+  const int C = m.C[t];
+  const float g = dloss[0];
+  const float* probs = m.probs[t];
+  const long long* target = m.target[t];
+  float* dl = m.dlogits[t];
+  for (int e = threadIdx.x; e < m.B * C; e += 256) {
+    const int b = e / C, c = e - b * C;
+    const long tg = target[b];
+    dl[e] = (tg == m.ignore_index) ? 0.f : g * (probs[e] - (c == tg ? 1.f : 0.f));
   }
 }
 }  // namespace vln
@@ -943,5 +986,36 @@ extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, cons
   hipLaunchKernelGGL(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
                      dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index);
   VLN_CHECK_LAUNCH("masked_ce_bwd");
+  return VLN_OK;
+}
+
+static int ce_multi_fill(vln::CeMultiArgs& m, const vln_ce_step* steps, int T, int B, int64_t ignore_index, bool bwd, const char* who) {
+  if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0) { vln::set_error(who); return VLN_ERR_ARG; }
+  m.T = T; m.B = B; m.ignore_index = (long)ignore_index;
+  for (int t = 0; t < T; ++t) {
+    const vln_ce_step& q = steps[t];
+    if (!q.logits || !q.target || !q.probs || q.C <= 0 || q.ld < q.C || (bwd && !q.dlogits)) { vln::set_error(who); return VLN_ERR_ARG; }
+    m.logits[t] = q.logits; m.target[t] = (const long long*)q.target; m.mask[t] = q.cand_mask; m.probs[t] = q.probs;
+    m.dlogits[t] = q.dlogits; m.C[t] = q.C; m.ld[t] = (int)q.ld;
+  }
+  return VLN_OK;
+}
+extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float* loss_sum, int accumulate,
+                                       void* s) {
+  vln::CeMultiArgs m{};
+  if (!loss_sum) { vln::set_error("vln_masked_ce_multi_fwd: bad args"); return VLN_ERR_ARG; }
+  const int rc = ce_multi_fill(m, steps, T, B, ignore_index, false, "vln_masked_ce_multi_fwd: bad args");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate);
+  VLN_CHECK_LAUNCH("masked_ce_multi_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, const float* dloss, void* s) {
+  vln::CeMultiArgs m{};
+  if (!dloss) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
+  const int rc = ce_multi_fill(m, steps, T, B, ignore_index, true, "vln_masked_ce_multi_bwd: bad args");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss);
+  VLN_CHECK_LAUNCH("masked_ce_multi_bwd");
   return VLN_OK;
 }

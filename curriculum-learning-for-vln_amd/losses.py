@@ -80,6 +80,80 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
     return total / (target != ignore_index).sum().to(total.dtype)
 
 
+class _RolloutCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, *logits):
+        targets, masks, ignore_index = meta
+        T, B = len(logits), logits[0].shape[0]
+        dev = logits[0].device
+        lib = _lib.load()
+        out = ops.empty((), dtype=torch.float32, device=dev)
+        keep, steps = [], []
+        for lg, tg, mk in zip(logits, targets, masks):
+            lg = lg.detach()
+            if not lg.is_contiguous():
+                lg = lg.contiguous()
+            C_ = lg.shape[1]
+            probs = ops.empty(B, C_, dtype=torch.float32, device=dev)
+            tg = tg if tg.is_contiguous() else tg.contiguous()
+            m8 = _mask8(mk)
+            keep.append((lg, tg, m8, probs))
+            steps.append(_lib.CeStep(lg.data_ptr(), lg.stride(0), tg.data_ptr(), _p(m8), probs.data_ptr(), None, C_))
+        for i in range(0, T, _lib.CE_MAX_STEPS):
+            chunk = steps[i:i + _lib.CE_MAX_STEPS]
+            arr = (_lib.CeStep * len(chunk))(*chunk)
+            st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, out.data_ptr(), 1 if i else 0, _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_masked_ce_multi_fwd")
+        ctx.keep, ctx.ignore_index = keep, ignore_index
+        return out
+
+    @staticmethod
+    def backward(ctx, dloss):
+        keep = ctx.keep
+        T = len(keep)
+        B = keep[0][0].shape[0]
+        lib = _lib.load()
+        dloss = dloss.contiguous()
+        steps, outs = [], []
+        for lg, tg, m8, probs in keep:
+            dl = ops.empty_like(probs)
+            outs.append(dl)
+            steps.append(_lib.CeStep(lg.data_ptr(), lg.stride(0), tg.data_ptr(), _p(m8), probs.data_ptr(), dl.data_ptr(), probs.shape[1]))
+        for i in range(0, T, _lib.CE_MAX_STEPS):
+            chunk = steps[i:i + _lib.CE_MAX_STEPS]
+            arr = (_lib.CeStep * len(chunk))(*chunk)
+            st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, dloss.data_ptr(), _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_masked_ce_multi_bwd")
+        ctx.keep = None
+        return (None, *outs)
+
+
+class RolloutCE:
+    """The imitation loss of a whole rollout, `ml_loss = sum_t CrossEntropyLoss(ignore_index, reduction="sum")(
+    logits_t.masked_fill(cand_mask_t, -inf), target_t)` (envdrop.py:173-179 accumulated over the steps), evaluated ONCE
+    after the last decoder step: `add(...)` per step only records the operands, `sum()` is one launch forward and one
+    backward for all T steps (nothing in the rollout depends on the loss value, so the per-step launches only lengthen the
+    stream).  Same numbers as summing `masked_cross_entropy(..., "sum")` over the steps; steps may differ in C."""
+
+    def __init__(self, ignore_index: int = -1):
+        self.ignore_index = ignore_index
+        self.logits, self.targets, self.masks = [], [], []
+
+    def add(self, logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
+        if logits.dim() != 2 or (self.logits and logits.shape[0] != self.logits[0].shape[0]):
+            raise ValueError("RolloutCE.add: logits must be [B, C] with the same B every step")
+        self.logits.append(logits); self.targets.append(target); self.masks.append(cand_mask)
+
+    def sum(self) -> torch.Tensor:
+        if not self.logits:
+            raise ValueError("RolloutCE.sum: no steps recorded")
+        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index), *self.logits)
+        self.logits, self.targets, self.masks = [], [], []
+        return out
+
+
 def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
     """(probs, log_prob(action), entropy) of Categorical(softmax(masked logits)) with torch.distributions' clamp
     (envdrop.py:189-194) -- no autograd (sampling / logging); the differentiable A2C terms use torch ops."""

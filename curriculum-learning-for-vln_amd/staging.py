@@ -72,6 +72,7 @@ class DeviceFeatureStore:
         self.row_of: Dict[str, int] = {k: i for i, k in enumerate(ids)} if ids is not None else {}
         self.angle_table = loc_embedding_table(angle_size, self.V).to(self.device)
         self.seed, self._calls = seed, 0
+        self._side_event = None
 
     @classmethod
     def from_tsv(cls, path: str, device="cuda", dtype=torch.float32, views: int = 36, **kw):
@@ -120,10 +121,21 @@ class DeviceFeatureStore:
 
 
     def gather_step(self, rows, view_index, crows, cviews, heading, elevation, p_feat: float = 0.0,
-                    want_bf16: bool = False, want_f32: bool = True):
+                    want_bf16: bool = False, want_f32: bool = True, stream: Optional["torch.cuda.Stream"] = None):
         """gather_pano + gather_cands of one decoder step as ONE launch -> ((img, img_bf16), (cand, cand_bf16),
-        ((seed, off_pano), (seed, off_cand))); entries not asked for are None."""
+        ((seed, off_pano), (seed, off_cand))); entries not asked for are None.
+        `stream`: issue the gather on this side stream.  It reads only the resident table and index vectors -- nothing a
+        decoder step produced (with teacher forcing not even the path depends on the logits) -- so it runs beside the
+        encoder / the previous step's kernels instead of in line with them; the current stream is made to wait for it.
+        With a RolloutArena the caller fences the side stream once per iteration (`stream.wait_stream(current)` before the
+        first gather: the buffers it writes were last read two iterations earlier); without one the fence is taken here,
+        per call, because the caching allocator may hand out memory whose last use is still in flight."""
         lib = _lib.load()
+        raw = _lib.raw_stream()
+        if stream is not None:
+            if ops.current_arena() is None:
+                stream.wait_stream(torch.cuda.current_stream(self.device))
+            raw = stream.cuda_stream
         B, C = crows.shape
         F = self.IMG + self.ANG
         f32 = want_f32 or not want_bf16
@@ -137,7 +149,13 @@ class DeviceFeatureStore:
         _lib.check(lib.vln_gather_step(_p(self.table), ops._dt(self.table), _p(self.angle_table), _p(rows), _p(view_index),
                                        _p(crows.contiguous()), _p(cviews.contiguous()), _p(heading.contiguous()),
                                        _p(elevation.contiguous()), _p(img), _p(img_lp), _p(cand), _p(cand_lp), B, self.V, C,
-                                       self.IMG, self.ANG, seed, off1, off2, p, _lib.raw_stream()), "vln_gather_step")
+                                       self.IMG, self.ANG, seed, off1, off2, p, raw), "vln_gather_step")
+        if stream is not None:
+            ev = self._side_event
+            if ev is None:
+                ev = self._side_event = torch.cuda.Event()
+            ev.record(stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
         return (img, img_lp), (cand, cand_lp), ((seed, off1), (seed, off2))
 
 

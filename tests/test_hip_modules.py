@@ -435,3 +435,32 @@ def test_missing_library_fails_loudly(vln, monkeypatch):
     monkeypatch.setattr(vln._lib, "LIB_PATH", "/nonexistent/libvln_hip.so")
     with pytest.raises(vln.VlnError):
         vln._lib.load()
+
+
+def test_side_stream_gather_and_rollout_ce_are_transparent(vln):
+    """bench.GpuAgent's two scheduling choices -- the per-step feature gather on a side stream and the IL loss of the whole
+    rollout in one launch (losses.RolloutCE) -- change WHEN work is issued, not what is computed: gradients of every
+    parameter equal the in-line / per-step configuration bit for bit over four arena iterations (dropout on); the loss
+    value differs only by the summation order of the per-step terms."""
+    import bench
+    dev_ = torch.device(DEV)
+    tape = bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=8), dev_, store_dtype=torch.bfloat16)
+    res = []
+    for side, rce in ((True, True), (False, False), (True, False), (False, True)):
+        torch.manual_seed(19)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side)
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        tape["store"]._calls = 0
+        ag.opt.lr = 0.0
+        out = []
+        for _ in range(4):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
+        res.append(out)
+    for other in res[1:]:
+        for (la, ga), (lb, gb) in zip(res[0], other):
+            assert abs(la.item() - lb.item()) <= 1e-6 * abs(lb.item())
+            for a, b in zip(ga, gb):
+                assert torch.equal(a, b)

@@ -131,6 +131,60 @@ def test_fused_masked_ce_and_action_stats_golden(vln):
     assert probs[I["cand_mask"]].abs().max().item() == 0.0
 
 
+def test_rollout_ce_equals_per_step_ce(vln):
+    """losses.RolloutCE: the IL loss of a whole rollout in one launch == the sum of the per-step fused CE launches, value and
+    every d logits bit for bit; steps with different candidate counts, ignored rows (-1), masked slots, a wide (>16) step;
+    and against torch's CrossEntropyLoss on the masked logits."""
+    from conftest import load_golden
+    G = load_golden("losses")
+    I = {k: v.to(DEV) for k, v in G["inp"].items()}
+    g = torch.Generator().manual_seed(5)
+    B = 37
+    steps = []
+    for C_ in (3, 8, 8, 5, 14, 20, 1):
+        n = torch.randint(1, C_ + 1, (B,), generator=g)
+        mask = torch.arange(C_)[None, :] >= n[:, None]
+        tgt = (torch.rand(B, generator=g) * n.float()).long()
+        tgt[torch.rand(B, generator=g) < 0.25] = -1
+        steps.append((torch.randn(B, C_, generator=g) * 3, tgt, mask if C_ != 5 else None))
+    res = []
+    for mode in ("rollout", "per_step", "torch"):
+        lgs = [s[0].to(DEV).clone().requires_grad_(True) for s in steps]
+        if mode == "rollout":
+            ce = vln.losses.RolloutCE()
+            for lg, s in zip(lgs, steps):
+                ce.add(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV))
+            total = ce.sum()
+        elif mode == "per_step":
+            total = sum(vln.losses.masked_cross_entropy(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV), "sum") for lg, s in zip(lgs, steps))
+        else:
+            total = sum(torch.nn.functional.cross_entropy(lg if s[2] is None else lg.masked_fill(s[2].to(DEV), float("-inf")), s[1].to(DEV),
+                                                          ignore_index=-1, reduction="sum") for lg, s in zip(lgs, steps))
+        (total * 0.37).backward()
+        res.append((total.detach().cpu(), [lg.grad.cpu() for lg in lgs]))
+    assert abs(res[0][0].item() - res[1][0].item()) <= 1e-5 * abs(res[1][0].item())     # same rows, another summation order
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert torch.allclose(res[0][0], res[2][0], rtol=1e-5)
+    for a, b in zip(res[0][1], res[2][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    # the golden rows (captured from torch's ops on the reference's shapes) as a one-step rollout
+    lg = I["logits"].clone().requires_grad_(True)
+    ce = vln.losses.RolloutCE(); ce.add(lg, I["target"], I["cand_mask"])
+    tot = ce.sum(); tot.backward()
+    assert torch.allclose(tot.cpu(), G["out"]["ce_sum"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lg.grad.cpu(), G["grad"]["ce_sum"], rtol=1e-5, atol=1e-6)
+    # more steps than one launch takes (VLN_CE_MAX_STEPS = 40)
+    many = [torch.randn(4, 6, generator=g).to(DEV).requires_grad_(True) for _ in range(45)]
+    tg = torch.randint(0, 6, (4,), generator=g).to(DEV)
+    ce = vln.losses.RolloutCE()
+    for lg in many:
+        ce.add(lg, tg)
+    tot = ce.sum(); tot.backward()
+    ref = sum(torch.nn.functional.cross_entropy(lg.detach(), tg, reduction="sum") for lg in many)
+    assert torch.allclose(tot, ref, rtol=1e-5) and all(lg.grad is not None for lg in many)
+
+
 def test_fused_rmsprop_clip_matches_torch(vln):
     """Row N1: parameter trajectories of the fused clip+RMSprop step vs torch.optim.RMSprop + clip_grad_norm_ per
     group (trainer.py:423-427), 4 steps, one group clipped hard, one not at all; odd sizes exercise the tails."""
