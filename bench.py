@@ -170,8 +170,11 @@ class GpuAgent:
                 ce.add(logits, s["target"], s["cand_mask"])
             else:
                 terms.append(self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
-        ml = ce.sum() if ce is not None else torch.stack(terms).sum()     # ml_loss += ... over the steps (envdrop.py:179)
-        loss = ml * ML_WEIGHT / (B * self.world)                 # global batch normalisation under DP
+        w = ML_WEIGHT / (B * self.world)                         # envdrop.py:268; global batch normalisation under DP
+        if ce is not None:
+            loss = ce.sum(scale=w)                               # ml_loss summed over the steps (envdrop.py:179), scaled in the launch
+        else:
+            loss = torch.stack(terms).sum() * w
         loss.backward()
         self.opt.allreduce()
         self.opt.step()
@@ -374,8 +377,12 @@ def main():
             if os.path.exists(tfile):
                 t = json.load(open(tfile)).get(args.dtype, {}).get(top["kernel"])
                 traffic = t["bytes_per_launch"] if t else None
+            mfma = None                                               # MFMA issue slots busy, SQ_VALU_MFMA_BUSY_CYCLES pass
+            mfile = os.path.join(ROOT, "profiles", "round1_mfma_util.json")      # (scripts/pmc_mfma.py), bf16 run
+            if os.path.exists(mfile) and args.dtype == "bf16":
+                mfma = json.load(open(mfile)).get(top["kernel"] + "_kernel", {}).get("mfma_util")
             roofline = dict(bound="hbm", kernel=top["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, mfma_util=mfma,
                             avg_launch_us=round(top["ms"] * 1e3 / top["launches"], 2),
                             algo_bytes_per_launch=round(top["bytes"] / top["launches"]),
                             kernels=[dict(kernel=r["kernel"], launches_per_step=r["launches"] / args.steps,

@@ -382,7 +382,7 @@ struct CeMultiArgs {
   float* probs[VLN_CE_MAX_STEPS]; float* dlogits[VLN_CE_MAX_STEPS]; int C[VLN_CE_MAX_STEPS]; int ld[VLN_CE_MAX_STEPS];
   int T, B; long ignore_index;
 };
-__global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate) {
+__global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale) {
   __shared__ float part[4];
   float acc = 0.f;
   const int rows = m.T * m.B;
@@ -396,14 +396,14 @@ __global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float v = (part[0] + part[1]) + (part[2] + part[3]);
+    const float v = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
     loss_sum[0] = accumulate ? loss_sum[0] + v : v;
   }
 }
-__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss) {
+__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss, float scale) {
   const int t = blockIdx.x;
   const int C = m.C[t];
-  const float g = dloss[0];
+  const float g = dloss[0] * scale;
   const float* probs = m.probs[t];
   const long long* target = m.target[t];
   float* dl = m.dlogits[t];
@@ -1000,22 +1000,23 @@ static int ce_multi_fill(vln::CeMultiArgs& m, const vln_ce_step* steps, int T, i
   }
   return VLN_OK;
 }
-extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float* loss_sum, int accumulate,
-                                       void* s) {
+extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, float* loss_sum,
+                                       int accumulate, void* s) {
   vln::CeMultiArgs m{};
   if (!loss_sum) { vln::set_error("vln_masked_ce_multi_fwd: bad args"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, false, "vln_masked_ce_multi_fwd: bad args");
   if (rc) return rc;
-  hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate);
+  hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_fwd");
   return VLN_OK;
 }
-extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, const float* dloss, void* s) {
+extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
+                                       void* s) {
   vln::CeMultiArgs m{};
   if (!dloss) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, true, "vln_masked_ce_multi_bwd: bad args");
   if (rc) return rc;
-  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss);
+  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_bwd");
   return VLN_OK;
 }

@@ -83,7 +83,7 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
 class _RolloutCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *logits):
-        targets, masks, ignore_index = meta
+        targets, masks, ignore_index, scale = meta
         T, B = len(logits), logits[0].shape[0]
         dev = logits[0].device
         lib = _lib.load()
@@ -102,10 +102,10 @@ class _RolloutCE(torch.autograd.Function):
         for i in range(0, T, _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
-            st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, out.data_ptr(), 1 if i else 0, _lib.raw_stream())
+            st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, scale, out.data_ptr(), 1 if i else 0, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_fwd")
-        ctx.keep, ctx.ignore_index = keep, ignore_index
+        ctx.keep, ctx.ignore_index, ctx.scale = keep, ignore_index, scale
         return out
 
     @staticmethod
@@ -123,7 +123,7 @@ class _RolloutCE(torch.autograd.Function):
         for i in range(0, T, _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
-            st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, dloss.data_ptr(), _lib.raw_stream())
+            st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, ctx.scale, dloss.data_ptr(), _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
@@ -146,10 +146,11 @@ class RolloutCE:
             raise ValueError("RolloutCE.add: logits must be [B, C] with the same B every step")
         self.logits.append(logits); self.targets.append(target); self.masks.append(cand_mask)
 
-    def sum(self) -> torch.Tensor:
+    def sum(self, scale: float = 1.0) -> torch.Tensor:
+        """`scale` multiplies the total inside the launch (the agents' `* ML_WEIGHT / batch_size`, envdrop.py:268)."""
         if not self.logits:
             raise ValueError("RolloutCE.sum: no steps recorded")
-        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index), *self.logits)
+        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index, float(scale)), *self.logits)
         self.logits, self.targets, self.masks = [], [], []
         return out
 

@@ -180,15 +180,17 @@ int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dl
  * the steps), in one launch after the last decoder step, and all the d logits_t in one launch at the start of backward:
  * the loss is on nobody's dependent chain, the 2T per-step launches only lengthen the stream.  Steps may differ in C.
  * probs_t [B,C_t] is written forward and read backward; dlogits_t [B,C_t] dense.  T <= VLN_CE_MAX_STEPS per call
- * (`accumulate` adds to *loss_sum for longer rollouts). */
+ * (`accumulate` adds to *loss_sum for longer rollouts).  `scale` multiplies the sum (and the gradients): the agents'
+ * `ml_loss * ML_WEIGHT / batch_size` (envdrop.py:268) without two more elementwise launches each way. */
 #define VLN_CE_MAX_STEPS 40
 typedef struct vln_ce_step {
   float* logits; int64_t ld; const int64_t* target; const uint8_t* cand_mask /*nullable*/; float* probs; float* dlogits /*bwd only*/;
   int C;
 } vln_ce_step;
-int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float* loss_sum, int accumulate,
+int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, float* loss_sum,
+                            int accumulate, vln_stream_t s);
+int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
                             vln_stream_t s);
-int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, const float* dloss, vln_stream_t s);
 
 /* The sampled-action branch of a rollout step (envdrop.py:186-195) as one launch: probs = softmax(logits masked with
  * -inf where cand_mask), action ~ Categorical(probs) unless action_in is given (then action_out may be NULL), logp =

@@ -154,7 +154,7 @@ def test_rollout_ce_equals_per_step_ce(vln):
             ce = vln.losses.RolloutCE()
             for lg, s in zip(lgs, steps):
                 ce.add(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV))
-            total = ce.sum()
+            total = ce.sum(scale=0.5) * 2.0                      # the in-launch scale, undone exactly (powers of two)
         elif mode == "per_step":
             total = sum(vln.losses.masked_cross_entropy(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV), "sum") for lg, s in zip(lgs, steps))
         else:
