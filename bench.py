@@ -327,7 +327,12 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    if agent.enc.persistent_status() != 0:       # a bounded in-kernel wait timed out during warm-up: fall back
+    timed_out = int(agent.enc.persistent_status() != 0)
+    if world > 1:                                 # the fallback below contains collectives: every rank takes it or none does
+        flag = torch.tensor([timed_out], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        timed_out = int(flag.item())
+    if timed_out:                                 # a bounded in-kernel wait timed out during warm-up: fall back
         print("[bench] persistent recurrence reported a timeout; using per-step launches", file=sys.stderr, flush=True)
         lib.vln_set_persistent(0)
         agent.iteration(tape)
@@ -354,20 +359,24 @@ def main():
         print(f"[bench] timed region: {ms_per_step:.3f} ms/step on {world} GPU(s)", file=sys.stderr, flush=True)
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # EVERY rank replays the K steps (an iteration contains the gradient all-reduce: a collective only rank 0 entered
+        # would never complete); the per-kernel timers are switched on and read on rank 0 only
         nk = 0
         while lib.vln_prof_kernel_name(nk):
             nk += 1
-        for k in range(nk):
-            lib.vln_prof_enable(k, 1)
-        read_prof(lib, nk)
+        if rank == 0:
+            for k in range(nk):
+                lib.vln_prof_enable(k, 1)
+            read_prof(lib, nk)
         torch.cuda.synchronize()
         for _ in range(args.steps):
             agent.iteration(tape)
         torch.cuda.synchronize()
-        rows = read_prof(lib, nk)
-        for k in range(nk):
-            lib.vln_prof_enable(k, 0)
+        rows = read_prof(lib, nk) if rank == 0 else []
+        if rank == 0:
+            for k in range(nk):
+                lib.vln_prof_enable(k, 0)
         if rows:
             rows.sort(key=lambda r: -r["ms"])
             top = rows[0]
