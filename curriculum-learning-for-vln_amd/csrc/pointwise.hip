@@ -400,17 +400,39 @@ __global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m,
     loss_sum[0] = accumulate ? loss_sum[0] + v : v;
   }
 }
-__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss, float scale) {
+// Per-episode form (SELF-PACE consumes the loss VECTOR, envdrop.py:70,178-179 with reduction="none"; curriculum.py:296):
+// loss_rows[b] = scale * sum_t CE_t[b].  Block = 64 episodes x 4 step groups (group g takes steps g, g+4, ...); the four
+// partials of an episode are added in a fixed order.
+__global__ __launch_bounds__(256) void masked_ce_multi_rows_kernel(CeMultiArgs m, float* loss_rows, int accumulate, float scale) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (b < m.B) {
+    for (int t = grp; t < m.T; t += 4) {
+      CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
+               m.ignore_index, 0};
+      acc += (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+    }
+  }
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && b < m.B) {
+    const float v = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * scale;
+    loss_rows[b] = accumulate ? loss_rows[b] + v : v;
+  }
+}
+// dloss_stride 0: one upstream scalar (the summed form); 1: one per episode (the per-episode form)
+__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss, int dloss_stride, float scale) {
   const int t = blockIdx.x;
   const int C = m.C[t];
-  const float g = dloss[0] * scale;
   const float* probs = m.probs[t];
   const long long* target = m.target[t];
   float* dl = m.dlogits[t];
   for (int e = threadIdx.x; e < m.B * C; e += 256) {
     const int b = e / C, c = e - b * C;
     const long tg = target[b];
-    dl[e] = (tg == m.ignore_index) ? 0.f : g * (probs[e] - (c == tg ? 1.f : 0.f));
+    dl[e] = (tg == m.ignore_index) ? 0.f : dloss[b * dloss_stride] * scale * (probs[e] - (c == tg ? 1.f : 0.f));
   }
 }
 }  // namespace vln
@@ -1001,22 +1023,26 @@ static int ce_multi_fill(vln::CeMultiArgs& m, const vln_ce_step* steps, int T, i
   return VLN_OK;
 }
 extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, float* loss_sum,
-                                       int accumulate, void* s) {
+                                       float* loss_rows, int accumulate, void* s) {
   vln::CeMultiArgs m{};
-  if (!loss_sum) { vln::set_error("vln_masked_ce_multi_fwd: bad args"); return VLN_ERR_ARG; }
+  if (!loss_sum == !loss_rows) { vln::set_error("vln_masked_ce_multi_fwd: exactly one of loss_sum / loss_rows"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, false, "vln_masked_ce_multi_fwd: bad args");
   if (rc) return rc;
-  hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
+  if (loss_sum)
+    hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
+  else
+    hipLaunchKernelGGL(vln::masked_ce_multi_rows_kernel, dim3((B + 63) / 64), dim3(256), 0, (hipStream_t)s, m, loss_rows, accumulate,
+                       scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_fwd");
   return VLN_OK;
 }
 extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
-                                       void* s) {
+                                       int64_t dloss_stride, void* s) {
   vln::CeMultiArgs m{};
-  if (!dloss) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
+  if (!dloss || (dloss_stride != 0 && dloss_stride != 1)) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, true, "vln_masked_ce_multi_bwd: bad args");
   if (rc) return rc;
-  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, scale);
+  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, (int)dloss_stride, scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_bwd");
   return VLN_OK;
 }

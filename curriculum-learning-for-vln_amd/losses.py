@@ -83,11 +83,11 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
 class _RolloutCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *logits):
-        targets, masks, ignore_index, scale = meta
+        targets, masks, ignore_index, scale, per_sample = meta
         T, B = len(logits), logits[0].shape[0]
         dev = logits[0].device
         lib = _lib.load()
-        out = ops.empty((), dtype=torch.float32, device=dev)
+        out = ops.empty(B if per_sample else (), dtype=torch.float32, device=dev)
         keep, steps = [], []
         for lg, tg, mk in zip(logits, targets, masks):
             lg = lg.detach()
@@ -102,10 +102,11 @@ class _RolloutCE(torch.autograd.Function):
         for i in range(0, T, _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
-            st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, scale, out.data_ptr(), 1 if i else 0, _lib.raw_stream())
+            st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, scale, None if per_sample else out.data_ptr(),
+                                             out.data_ptr() if per_sample else None, 1 if i else 0, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_fwd")
-        ctx.keep, ctx.ignore_index, ctx.scale = keep, ignore_index, scale
+        ctx.keep, ctx.ignore_index, ctx.scale, ctx.per_sample = keep, ignore_index, scale, per_sample
         return out
 
     @staticmethod
@@ -123,7 +124,8 @@ class _RolloutCE(torch.autograd.Function):
         for i in range(0, T, _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
-            st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, ctx.scale, dloss.data_ptr(), _lib.raw_stream())
+            st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, ctx.scale, dloss.data_ptr(), 1 if ctx.per_sample else 0,
+                                             _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
@@ -150,7 +152,17 @@ class RolloutCE:
         """`scale` multiplies the total inside the launch (the agents' `* ML_WEIGHT / batch_size`, envdrop.py:268)."""
         if not self.logits:
             raise ValueError("RolloutCE.sum: no steps recorded")
-        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index, float(scale)), *self.logits)
+        return self._run(scale, False)
+
+    def per_sample(self, scale: float = 1.0) -> torch.Tensor:
+        """[B]: every episode's own loss summed over the steps -- the vector SELF-PACE multiplies by its weights
+        (`reduction="none"` criterion, envdrop.py:70,178-179; curriculum.py:296) -- same single launch each way."""
+        if not self.logits:
+            raise ValueError("RolloutCE.per_sample: no steps recorded")
+        return self._run(scale, True)
+
+    def _run(self, scale, per_sample):
+        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index, float(scale), bool(per_sample)), *self.logits)
         self.logits, self.targets, self.masks = [], [], []
         return out
 

@@ -187,10 +187,14 @@ typedef struct vln_ce_step {
   float* logits; int64_t ld; const int64_t* target; const uint8_t* cand_mask /*nullable*/; float* probs; float* dlogits /*bwd only*/;
   int C;
 } vln_ce_step;
-int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, float* loss_sum,
+int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale,
+                            float* loss_sum /*[1]: total over steps and episodes*/,
+                            float* loss_rows /*[B]: per episode (reduction="none" summed over the steps, what SELF-PACE weighs,
+                                               curriculum.py:296); exactly one of the two*/,
                             int accumulate, vln_stream_t s);
+/* dloss_stride 0: one upstream scalar; 1: one per episode */
 int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
-                            vln_stream_t s);
+                            int64_t dloss_stride, vln_stream_t s);
 
 /* The sampled-action branch of a rollout step (envdrop.py:186-195) as one launch: probs = softmax(logits masked with
  * -inf where cand_mask), action ~ Categorical(probs) unless action_in is given (then action_out may be NULL), logp =

@@ -22,12 +22,26 @@ ap.add_argument("which", nargs="?", default="all")
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
 ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
 args = ap.parse_args()
 vln.functional.set_grad_in_place(not args.no_grad_in_place)
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 F = 2176
+
+
+def with_arena(fn):
+    """Per-iteration buffers from an address-stable arena (ops.RolloutArena) instead of torch.empty."""
+    arena = vln.ops.RolloutArena()
+
+    def run():
+        vln.ops.set_arena(arena); arena.begin()
+        try:
+            fn()
+        finally:
+            vln.ops.set_arena(None)
+    return run
 
 
 def timed(fn):
@@ -75,8 +89,10 @@ def run_monitor(B=128, L=80, T=7, C=8):
         loss.backward()
         opt.step()
 
+    if args.arena:
+        it = with_arena(it)
     ms = timed(it)
-    return dict(workload=f"self_monitor_il_B{B}_L{L}_T{T}_adam", ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
+    return dict(workload=f"self_monitor_il_B{B}_L{L}_T{T}_adam" + ("_arena" if args.arena else ""), ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
                 dtype=args.dtype)
 
 
@@ -116,6 +132,8 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
         loss.backward()
         opt_e.step(); opt_d.step()
 
+    if args.arena:
+        it = with_arena(it)
     ms = timed(it)
     return dict(workload=f"follower_il_B{B}_L{L}_T{T}_adam" + ("" if fused else "_operator_path"), ms_per_iteration=round(ms, 3),
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)

@@ -174,6 +174,24 @@ def test_rollout_ce_equals_per_step_ce(vln):
     tot = ce.sum(); tot.backward()
     assert torch.allclose(tot.cpu(), G["out"]["ce_sum"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(lg.grad.cpu(), G["grad"]["ce_sum"], rtol=1e-5, atol=1e-6)
+    # per-episode form (SELF-PACE): [B] vector == sum over steps of the reduction="none" launches, gradients to rounding
+    wrow = torch.rand(B, generator=g).to(DEV)
+    pv = []
+    for mode in ("rollout", "per_step"):
+        lgs = [s[0].to(DEV).clone().requires_grad_(True) for s in steps]
+        if mode == "rollout":
+            ce = vln.losses.RolloutCE()
+            for lg, s in zip(lgs, steps):
+                ce.add(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV))
+            vec = ce.per_sample()
+        else:
+            vec = sum(vln.losses.masked_cross_entropy(lg, s[1].to(DEV), None if s[2] is None else s[2].to(DEV), "none") for lg, s in zip(lgs, steps))
+        assert vec.shape == (B,)
+        (vec * wrow).sum().backward()
+        pv.append((vec.detach().cpu(), [lg.grad.cpu() for lg in lgs]))
+    assert torch.allclose(pv[0][0], pv[1][0], rtol=1e-6, atol=1e-6)
+    for a, b in zip(pv[0][1], pv[1][1]):      # the "none" launch is the wave-per-row kernel: same maths, other rounding
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     # more steps than one launch takes (VLN_CE_MAX_STEPS = 40)
     many = [torch.randn(4, 6, generator=g).to(DEV).requires_grad_(True) for _ in range(45)]
     tg = torch.randint(0, 6, (4,), generator=g).to(DEV)
