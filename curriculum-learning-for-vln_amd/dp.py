@@ -118,6 +118,28 @@ def allreduce_scalar(x: torch.Tensor, group=None) -> torch.Tensor:
     return x
 
 
+def gather_item_losses(item_index: torch.Tensor, item_loss: torch.Tensor, group=None):
+    """SELF-PACE bookkeeping under data parallelism (curriculum.py:311-314: `loss_for_item[cur_batch_idx] = ...`): every rank
+    holds the per-episode losses of ITS shard; the curriculum's weight update (curriculum.py:428-448) needs all of them on
+    every replica.  -> (index [B_global] int64, loss [B_global]) in rank order; shards must have equal sizes (stride
+    sharding of a batch divisible by the world size).  Two tiny all-gathers per iteration; identity without a group."""
+    if not _dp_active(group):
+        return item_index, item_loss
+    world = dist.get_world_size(group)
+    idx = [torch.empty_like(item_index) for _ in range(world)]
+    los = [torch.empty_like(item_loss) for _ in range(world)]
+    dist.all_gather(idx, item_index.contiguous(), group=group)
+    dist.all_gather(los, item_loss.detach().contiguous(), group=group)
+    return torch.cat(idx), torch.cat(los)
+
+
+def self_pace_batch_loss(weight_rows: torch.Tensor, per_sample_loss: torch.Tensor) -> torch.Tensor:
+    """`torch.dot(self.weight[cur_batch_idx], cur_loss)` (curriculum.py:296) on this rank's shard: the all-reduce of the
+    gradients sums the shards' terms, so no extra normalisation is needed for the EnvDrop form (the non-EnvDrop form divides
+    by the GLOBAL weight sum, curriculum.py:301 -> `allreduce_scalar(weight_rows.sum())`)."""
+    return torch.dot(weight_rows.to(per_sample_loss.dtype), per_sample_loss)
+
+
 def clip_grad_norm_groups(groups: Sequence[Sequence[torch.nn.Parameter]], max_norm: float) -> List[torch.Tensor]:
     """trainer.py:425-426 clips encoder and decoder separately (norm 40 each); applied AFTER the all-reduce
     so every replica computes the same scale."""

@@ -71,6 +71,9 @@ def _worker(rank, world, port, q, overlap=False):
         bucket.allreduce()
         assert not bucket.reducer.pending
         total = vln.dp.allreduce_scalar(torch.tensor([float(len(rows))]))
+        # SELF-PACE bookkeeping: every replica ends up with every episode's (index, loss)
+        gi, gl = vln.dp.gather_item_losses(torch.tensor(rows), torch.tensor([10.0 * r for r in rows], dtype=torch.float64))
+        assert sorted(gi.tolist()) == list(range(B)) and torch.equal(gl, gi.double() * 10.0)
         q.put((rank, bucket.flat.clone(), float(total), rows))
     finally:
         dist.destroy_process_group()
@@ -111,6 +114,18 @@ def test_two_rank_bucket_allreduce_equals_big_batch(overlap):
         assert total == B
         assert torch.allclose(flat, ref, rtol=1e-10, atol=1e-12), f"rank {rank}: DP gradient != big-batch gradient"
     assert torch.equal(got[0][1], got[1][1])                 # replicas agree bit-for-bit after the all-reduce
+
+
+def test_self_pace_helpers_without_a_group():
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    idx, loss = torch.tensor([3, 1]), torch.tensor([0.5, 2.0], requires_grad=True)
+    gi, gl = vln.dp.gather_item_losses(idx, loss)
+    assert gi is idx and gl is loss                                     # identity on one process
+    w = torch.tensor([0.2, 1.0, 0.7, 0.9])
+    bl = vln.dp.self_pace_batch_loss(w[idx], loss)                      # curriculum.py:296
+    bl.backward()
+    assert torch.allclose(bl, torch.tensor(0.9 * 0.5 + 1.0 * 2.0)) and torch.equal(loss.grad, w[idx])
 
 
 def test_bucket_span_of_requires_adjacent_parameters():
