@@ -213,6 +213,42 @@ def test_transpose_and_cast(vln, N, K):
     assert torch.equal(vln.ops.cast_copy(w), w.bfloat16())
 
 
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_shadow_refresh_grouped(vln, odt):
+    """vln_shadow_refresh: all shadows of a module in one launch -- plain / transposed / both, a summed pair (b_ih + b_hh),
+    shapes that take the 16-byte path (everything a multiple of 4), ragged ones that take the scalar path, partial 64x64
+    tiles and a strided source (a row block of a wider matrix); every element equals torch's cast of the fp32 value."""
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    sb = vln.ops.ShadowBatch()
+    exp = []
+    for N, K, kind in ((2048, 2752, "both"), (2176, 512, "t"), (64, 128, "n"), (100, 36, "both"), (130, 67, "both"), (1, 2048, "n"),
+                       (4, 4, "both")):
+        src = torch.randn(N, K, generator=g).to(d)
+        dst = torch.empty(N, K, dtype=odt, device=d) if kind in ("n", "both") else None
+        dst_t = torch.empty(K, N, dtype=odt, device=d) if kind in ("t", "both") else None
+        sb.add(src, dst, dst_t)
+        exp.append((src, dst, dst_t))
+    a, b = torch.randn(1, 2048, generator=g).to(d), torch.randn(1, 2048, generator=g).to(d)
+    dsum = torch.empty(1, 2048, dtype=odt, device=d)
+    sb.add(a, dsum, None, src2=b)
+    wide = torch.randn(96, 512, generator=g).to(d)
+    blk = wide[:, 128:384]                                   # strided source rows
+    dblk, dblk_t = torch.empty(96, 256, dtype=odt, device=d), torch.empty(256, 96, dtype=odt, device=d)
+    sb.add(blk, dblk, dblk_t)
+    h = sb.run()
+    torch.cuda.synchronize()
+    for src, dst, dst_t in exp + [(blk, dblk, dblk_t)]:
+        if dst is not None:
+            assert torch.equal(dst, src.to(odt))
+        if dst_t is not None:
+            assert torch.equal(dst_t, src.t().contiguous().to(odt))
+    assert torch.equal(dsum, (a + b).to(odt))
+    exp[0][0].mul_(2.0)                                      # replay refreshes from the same addresses
+    vln.ops.ShadowBatch.replay(h)
+    assert torch.equal(exp[0][1], exp[0][0].to(odt)) and torch.equal(exp[0][2], exp[0][0].t().contiguous().to(odt))
+
+
 @pytest.mark.parametrize("B,S,D", [(64, 36, 2176), (64, 80, 512), (64, 8, 2176), (4, 9, 48), (3, 5, 50)])
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_attention_fwd_bwd(vln, B, S, D, cdt):
