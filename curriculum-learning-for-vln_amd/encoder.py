@@ -116,7 +116,7 @@ class _EncoderFn(torch.autograd.Function):
 
         # decoder_init = tanh(enc2dec(h_t))                                       units.py:69
         if ddec is not None:
-            dpre = (ddec * (1.0 - dec_init * dec_init)).contiguous()
+            dpre = ops.ew(ops.EW_TANH_GRAD, ddec if ddec.stride(-1) == 1 else ddec.contiguous(), dec_init)      # one launch
             put("enc2dec.weight", ops.linear_wgrad, dpre, hcat)
             put("enc2dec.bias", ops.colsum, dpre)
             dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])

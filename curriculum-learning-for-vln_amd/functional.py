@@ -87,7 +87,7 @@ class LinearFn(torch.autograd.Function):
         x2, weight, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         if ctx.act == ops.ACT_TANH:
-            dy2 = dy2 * (1.0 - y * y)
+            dy2 = ops.ew(ops.EW_TANH_GRAD, dy2, y)
         elif ctx.act == ops.ACT_RELU:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = dw = db = None
@@ -429,8 +429,6 @@ class BnMlpFn(torch.autograd.Function):
                 cb.add(dz, db, None, accb)
                 grads[3 + 4 * i] = _gret(db, accb)
             g = ops.linear_fwd(dz, SHADOWS.get(W, "t", dtype))
-            if i > 0 or True:
-                pass
         # Mt is the same for every product of the call: one grouped launch each for weights and biases
         wb.run(); cb.run()
         dx = bn_bwd(x, g, None, tensors[0], s0, bufs[0], False, (0.0, 0, 0), None, ctx.needs_input_grad[0], 0)
