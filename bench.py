@@ -87,14 +87,20 @@ def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
     return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, table=table, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
 
 
-def tape_to(tape, dev, store_dtype=None):
+def tape_to(tape, dev, store_dtype=None, host_dtype=None):
     """Device copy.  With `store_dtype` the ResNet table becomes a resident DeviceFeatureStore and the per-step img/cand
-    tensors are NOT uploaded (a step only needs its index vectors)."""
+    tensors are NOT uploaded (a step only needs its index vectors).  With `host_dtype` the per-step img/cand tensors stay on
+    the HOST, pinned, in that dtype (fp32 = what the reference's ImageFeatures holds, utils/misc.py:253-279; bf16 = converted
+    once at load time): every step then pays its H2D copy (PCIe-inclusive mode, never the headline value)."""
     skip = ("steps", "table")
     out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k not in skip}
     out["lengths32"] = tape["lengths"].to(dev, torch.int32)
-    drop = ("img", "cand") if store_dtype is not None else ()
+    drop = ("img", "cand") if (store_dtype is not None or host_dtype is not None) else ()
     out["steps"] = [{k: v.to(dev) for k, v in s.items() if k not in drop} for s in tape["steps"]]
+    if host_dtype is not None:
+        for so, si in zip(out["steps"], tape["steps"]):
+            so["img_host"] = si["img"].to(host_dtype).contiguous().pin_memory()
+            so["cand_host"] = si["cand"].to(host_dtype).contiguous().pin_memory()
     if store_dtype is not None:
         import vln_amd
         out["store"] = vln_amd.DeviceFeatureStore(tape["table"], device=dev, dtype=store_dtype, angle_size=tape["ANG"])
@@ -109,6 +115,7 @@ class GpuAgent:
         # (A/B option, off by default: measured slower) the step's feature gather reads only the resident table + index
         # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
         self.side = torch.cuda.Stream(device=dev) if side_gather else None
+        self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
         self.rollout_ce = rollout_ce
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
@@ -132,6 +139,8 @@ class GpuAgent:
         store path: ONE gather pass per tensor from the HBM-resident table (indices in, dropped features + bf16 stream
         copy out); tensor path: fresh copies of pre-built feature tensors, the decoder applies the dropout in place."""
         store = tape.get("store")
+        if "img_host" in s:
+            return self.stage_from_host(s)
         if store is None:
             return s["img"].clone(), s["cand"].clone(), {}
         lp = self.dtype != torch.float32
@@ -142,7 +151,42 @@ class GpuAgent:
         kw = dict(already_dropfeat=True)
         return (img_lp, cand_lp, kw) if lp else (img, cand, kw)
 
+    def stage_from_host(self, s):
+        """Host-resident (pinned) features: hipMemcpyAsync on a copy stream into per-step device buffers, the compute stream
+        waits for the step's copy only -- the copies of later steps run under the encoder / earlier steps (north star:
+        'pinned and hipMemcpyAsync-streamed to HBM overlapped').  bf16 host features get the feature dropout here (the
+        decoder only takes non-fp32 features that are already dropped)."""
+        ops = self.vln.ops
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream()
+            self.copy_events = {}
+        main = torch.cuda.current_stream()
+        if ops.current_arena() is None or not self._copy_fenced:   # buffers may still be in use by earlier work on `main`
+            self.copy_stream.wait_stream(main)
+            self._copy_fenced = True
+        ih, ch = s["img_host"], s["cand_host"]
+        img = ops.empty(ih.shape, dtype=ih.dtype, device=main.device)
+        cand = ops.empty(ch.shape, dtype=ch.dtype, device=main.device)
+        with torch.cuda.stream(self.copy_stream):
+            img.copy_(ih, non_blocking=True)
+            cand.copy_(ch, non_blocking=True)
+        ev = self.copy_events.get(id(s))
+        if ev is None:
+            ev = self.copy_events[id(s)] = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        main.wait_event(ev)
+        if ih.dtype == torch.float32:
+            return img, cand, {}                                   # the decoder drops in place + writes its bf16 stream copies
+        pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
+        if pf > 0:
+            F, ANG = self.dec.feature_size, self.dec.angle_feat_size
+            self._host_drop += 2
+            ops.feat_dropout_inplace(img, F - ANG, ANG, 0x51A6E, self._host_drop, pf)
+            ops.feat_dropout_inplace(cand, F - ANG, ANG, 0x51A6E, self._host_drop + 1, pf)
+        return img, cand, dict(already_dropfeat=True)
+
     def iteration(self, tape):
+        self._copy_fenced = False
         self.vln.ops.set_arena(self.arena)
         if self.arena is not None:
             self.arena.begin()
@@ -155,6 +199,9 @@ class GpuAgent:
         B = tape["B"]
         if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
             self.side.wait_stream(torch.cuda.current_stream())
+        if self.copy_stream is not None and self.arena is not None:     # same fence for the H2D copy stream (host features)
+            self.copy_stream.wait_stream(torch.cuda.current_stream())
+            self._copy_fenced = True
         self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
@@ -264,9 +311,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-arena", action="store_true", help="allocate per-iteration buffers with torch.empty (no address-stable "
                                                            "arena, hence no decoder-step hipGraph replay)")
-    ap.add_argument("--features", default="store", choices=["store", "tensor"],
+    ap.add_argument("--features", default="store", choices=["store", "tensor", "host", "host-bf16"],
                     help="store: ResNet table resident in HBM, a step ships indices (DeviceFeatureStore); "
-                         "tensor: pre-built per-step feature tensors, cloned each step")
+                         "tensor: pre-built per-step feature tensors, cloned each step; host / host-bf16: per-step features in "
+                         "pinned HOST memory (fp32 like the reference / bf16 converted once), hipMemcpyAsync per step on a copy "
+                         "stream -- the PCIe-inclusive rate (DESIGN.md §6), never the headline value")
     ap.add_argument("--ce", default="rollout", choices=["rollout", "per-step"],
                     help="rollout: the IL loss of all T steps in one launch after the last step (losses.RolloutCE); per-step: one "
                          "fused CE launch per decoder step")
@@ -299,7 +348,10 @@ def main():
     agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
                      side_gather=args.gather_stream == "side" and args.features == "store")
     tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
-    tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None))
+    tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None),
+                   host_dtype={"host": torch.float32, "host-bf16": torch.bfloat16}.get(args.features))
+    if args.features == "host-bf16" and dtype != torch.bfloat16:
+        raise SystemExit("--features host-bf16 needs --dtype bf16")
 
     def barrier():
         if world > 1:

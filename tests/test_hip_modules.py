@@ -464,3 +464,27 @@ def test_side_stream_gather_and_rollout_ce_are_transparent(vln):
             assert abs(la.item() - lb.item()) <= 1e-6 * abs(lb.item())
             for a, b in zip(ga, gb):
                 assert torch.equal(a, b)
+
+
+def test_host_feature_staging_matches_resident_tensors(vln):
+    """bench.py --features host / host-bf16: per-step features in pinned host memory, copied on a copy stream into per-step
+    device buffers; dropout off -> the same loss and gradients as the device-resident tensors (fp32 host: bit for bit; bf16
+    host: the features are rounded once at load time, so to bf16 tolerance), over three arena iterations (buffer reuse)."""
+    import bench
+    dev_ = torch.device(DEV)
+    cpu_tape = bench.make_tape(16, 24, 3, 6, seed=9)
+    res = {}
+    for mode, hd in (("tensor", None), ("host", torch.float32), ("host-bf16", torch.bfloat16)):
+        tape = bench.tape_to(cpu_tape, dev_, host_dtype=hd)
+        torch.manual_seed(23)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+        ag.enc.eval(); ag.dec.eval(); ag.opt.lr = 0.0
+        ag.enc.deterministic_embedding_grad = True
+        for _ in range(3):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+        res[mode] = (loss.detach().clone(), [p.grad.detach().clone() for p in ag.dec.parameters()])
+    assert torch.equal(res["tensor"][0], res["host"][0])
+    for a, b in zip(res["tensor"][1], res["host"][1]):
+        assert torch.equal(a, b)
+    check(res["host-bf16"][0], res["tensor"][0], 1e-2, "bf16 host features: loss")
