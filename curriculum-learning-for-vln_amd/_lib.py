@@ -24,6 +24,10 @@ class EnvDropDims(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "L", "V", "C", "H", "IMG", "ANG", "AE", "wtype", "ctype")]
 
 
+class WsumStep(C.Structure):         # vln_wsum_step
+    _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32)]
+
+
 class CeStep(C.Structure):           # vln_ce_step
     _fields_ = [("logits", ptr), ("ld", i64), ("target", ptr), ("cand_mask", ptr), ("probs", ptr), ("dlogits", ptr), ("C", i32)]
 
@@ -60,7 +64,7 @@ class ColsumJob(C.Structure):
 
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
-                                   "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat")]
+                                   "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat", "dhtd_ext")]
 
 
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
@@ -82,6 +86,7 @@ SIGNATURES = {
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),
     "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
+    "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
     "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr]),

@@ -112,7 +112,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 3; }
+extern "C" int vln_abi_version(void) { return 4; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,
@@ -172,6 +172,9 @@ extern "C" int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* 
                              int D, vln_stream_t s) {
   if (!ctx || !w || !out) { set_error("vln_rows_wsum: null pointer"); return VLN_ERR_ARG; }
   return rows_wsum((hipStream_t)s, ctx, ctype, w, out, ldo, B, S, D);
+}
+extern "C" int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s) {
+  return rows_wsum_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldo);
 }
 extern "C" int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha,
                             const float* dattn_ext, const float* dwc, int64_t lddwc, const float* vec,

@@ -7,6 +7,7 @@
 //                       in-place dctx accumulation
 // Reference semantics: units.py:100-122 (SoftDotAttention), units.py:138-160 (VisualSoftDotAttention).
 #include "vln_internal.h"
+#include "../../include/vln_hip.h"
 
 namespace vln {
 
@@ -166,6 +167,75 @@ int attn_softmax_wsum(hipStream_t st, const void* ctx, int ctype, const float* l
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D) {
   return launch_wsum(st, ctx, ctype, w, nullptr, nullptr, out, ldo, B, S, D, false);
+}
+
+// The candidate-logit branch of a WHOLE rollout's backward: out_t[b,:] = sum_c w_t[b,c] ctx_t[b,c,:] for every step t in one
+// launch (steps differ in S = candidate count).  Same arithmetic and summation order as attn_wsum_kernel<TC,false>.
+struct WsumMulti {
+  const void* ctx[VLN_CE_MAX_STEPS]; const float* w[VLN_CE_MAX_STEPS]; float* out[VLN_CE_MAX_STEPS]; int S[VLN_CE_MAX_STEPS];
+  int T, B, D; long ldo;
+};
+template <typename TC>
+__global__ __launch_bounds__(256) void rows_wsum_multi_kernel(WsumMulti m, int vec_ok) {
+  constexpr int V = Elt<TC>::kVec;
+  constexpr int DC = 64 * V;
+  __shared__ float sw[kMaxS];
+  __shared__ float red[4][DC];
+  const int t = blockIdx.x / m.B, b = blockIdx.x - t * m.B, chunk = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = m.S[t], D = m.D;
+  const float* lg = m.w[t] + (long)b * S;
+  for (int s = threadIdx.x; s < S; s += 256) sw[s] = lg[s];
+  __syncthreads();
+  const int d0 = chunk * DC + lane * V;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const TC* base = reinterpret_cast<const TC*>(m.ctx[t]) + (long)b * S * D;
+  if (vec_ok) {
+    if (d0 < D) {
+      for (int s = wave; s < S; s += 4) {
+        const float w = sw[s];
+        float x[V];
+        Elt<TC>::ld16(base + (long)s * D + d0, x);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += w * x[j];
+      }
+    }
+  } else {
+    for (int s = wave; s < S; s += 4) {
+      const float w = sw[s];
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (d0 + j < D) acc[j] += w * Elt<TC>::ld(base + (long)s * D + d0 + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[wave][lane * V + j] = acc[j];
+  __syncthreads();
+  float* out = m.out[t];
+  for (int i = threadIdx.x; i < DC; i += 256) {
+    const int d = chunk * DC + i;
+    if (d < D) out[(long)b * m.ldo + d] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
+}
+int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo) {
+  if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0 || D <= 0) { set_error("rows_wsum_multi: bad dims"); return VLN_ERR_ARG; }
+  WsumMulti m{};
+  m.T = T; m.B = B; m.D = D; m.ldo = ldo;
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  int vec_ok = (D % V == 0);
+  for (int t = 0; t < T; ++t) {
+    if (!steps[t].ctx || !steps[t].w || !steps[t].out || steps[t].S <= 0 || steps[t].S > kMaxS) { set_error("rows_wsum_multi: bad step %d", t); return VLN_ERR_ARG; }
+    m.ctx[t] = steps[t].ctx; m.w[t] = steps[t].w; m.out[t] = steps[t].out; m.S[t] = steps[t].S;
+    vec_ok = vec_ok && aligned16(steps[t].ctx);
+  }
+  const int DC = 64 * V;
+  dim3 grid(T * B, (D + DC - 1) / DC), block(256);
+  if (ctype == W_BF16) hipLaunchKernelGGL(rows_wsum_multi_kernel<bf16_raw>, grid, block, 0, st, m, vec_ok);
+  else hipLaunchKernelGGL(rows_wsum_multi_kernel<float>, grid, block, 0, st, m, vec_ok);
+  VLN_CHECK_LAUNCH("rows_wsum_multi");
+  return VLN_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -237,7 +237,9 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
   SlabVec dhtd{ws.s3, H, 1, (long)B * H};
-  if (g->dlogit) {
+  if (g->dhtd_ext) {            // the logit branch of the whole rollout was formed up front (vln_rows_wsum_multi + one GEMM)
+    dhtd = SlabVec{g->dhtd_ext, H, 1, (long)B * H};
+  } else if (g->dlogit) {
     RUN(rows_wsum(st, cand, d->ctype, g->dlogit, g->s_dtc, F, B, d->C, F));
     RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
     dhtd.n = n3;

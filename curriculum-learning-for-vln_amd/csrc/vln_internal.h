@@ -6,6 +6,7 @@
 #include "common.h"
 
 struct vln_shadow_job;   // include/vln_hip.h
+struct vln_wsum_step;    // include/vln_hip.h
 struct vln_wgrad_job;
 struct vln_colsum_job;
 
@@ -135,6 +136,7 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
 // dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);
+int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo);
 
 // ---- pointwise.hip --------------------------------------------------------
 struct LstmPwFwd {

@@ -44,7 +44,7 @@ class _StepPlan:
 
 
 class _StepRec:
-    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H")
+    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H", "mod", "dhtd_ext", "dhtd_keep")
 
 
 _NONES = (None,) * 64
@@ -83,6 +83,7 @@ class _EnvDropStepFn(torch.autograd.Function):
                     and (dht is None or dht.is_contiguous())):
                 arena.i = bp[1] + bp[2]
                 g = _lib.EnvDropGrads.from_buffer_copy(bp[0])
+                g.dhtd_ext = rec.dhtd_ext          # the rollout-wide logit branch (EnvDropDecoder.logit_branch_backward), if it ran
                 dhtp, dc0, t = bp[4], bp[5], bp[6]
                 if want_ctx:
                     io0 = rec.io
@@ -94,6 +95,7 @@ class _EnvDropStepFn(torch.autograd.Function):
                 if st:
                     _lib.check(st, "vln_envdrop_step_bwd")
                 s.done = True
+                rec.dhtd_keep = None
                 ctx.rec = None
                 return None, None, dhtp, dc0, None, None
         arena_i0 = arena.i if arena is not None else 0
@@ -132,6 +134,7 @@ class _EnvDropStepFn(torch.autograd.Function):
             rec.entry.shape = (B, L, H)
         g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
         g.s_dgates, g.s_dtv, g.s_de = s.ptr("dgates"), s.ptr("dtv"), s.ptr("de")
+        g.dhtd_ext = rec.dhtd_ext
         if bkey is not None and not hold:
             if len(mod._bplans) > 256:
                 mod._bplans.clear()
@@ -142,6 +145,7 @@ class _EnvDropStepFn(torch.autograd.Function):
         if st:
             _lib.check(st, "vln_envdrop_step_bwd")
         s.done = True
+        rec.dhtd_keep = None
         ctx.rec = None
         return None, None, dhtp, dc0, None, None
 
@@ -163,6 +167,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self.act_embed = nn.Sequential(nn.Linear(angle_feat_size, action_embed_size), nn.Tanh())
         self.drop = nn.Dropout(p=drop_ratio)
         self.env_drop = nn.Dropout(p=feat_drop_ratio)
+        self.batch_logit_backward = True      # losses.RolloutCE hands all d logits of a rollout over at once (logit_branch_backward)
         self.lstm = nn.LSTMCell(action_embed_size + feature_size, hidden_size)
         self.text_attn = _SoftDotParams(hidden_size)
         self.visual_attn = _SoftDotParams(hidden_size, context_dim=feature_size, context_only=True)
@@ -256,6 +261,43 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             setattr(w, k, t[k].data_ptr())
             setattr(w, k + "_t", t[k + "_t"].data_ptr())
         object.__setattr__(self, "_sb_handle", (ck, handle))
+
+    def logit_branch_backward(self, pairs):
+        """The candidate-logit branch of the backward, logit_t = cand_t . (W_c drop(h_tilde_t)) (policy.py:199-206,243-244), for
+        ALL steps of a rollout at once: it depends on the d logits only -- which `losses.RolloutCE` produces for every step
+        in one launch at the root of the backward -- and on no other step's backward, so 2 T skinny launches on the
+        dependent chain (rows_wsum + an M = B GEMM per step) become ONE multi-step weighted sum, written straight into the
+        steps' `dtc` stash rows (the dY operand of d cand_attn.weight), and ONE GEMM over (steps x batch) rows per contiguous
+        stash run.  pairs: [(step record, d logits [B, C_t])] in rollout order.  Each step's backward then finds its [B,H] block
+        (`vln_envdrop_grads.dhtd_ext`) and skips the branch."""
+        lib = _lib.load()
+        lp = self.compute_dtype != torch.float32
+        F, H = self.feature_size, self.hidden_size
+        B = pairs[0][0].B
+        steps, runs = [], []
+        for rec, dl in pairs:
+            cand = rec.keep["cand_lp"] if lp else rec.keep["cand"]
+            steps.append(_lib.WsumStep(cand.data_ptr(), dl.data_ptr(), rec.slot.ptr("dtc"), rec.C))
+            sl = rec.slot
+            if runs and runs[-1][0] is sl.chunk and runs[-1][2] == sl.r0:
+                runs[-1][2] = sl.r0 + sl.rows
+                runs[-1][3].append(rec)
+            else:
+                runs.append([sl.chunk, sl.r0, sl.r0 + sl.rows, [rec]])
+        ctype = ops.BF16 if lp else ops.F32
+        for i in range(0, len(steps), _lib.CE_MAX_STEPS):
+            chunk = steps[i:i + _lib.CE_MAX_STEPS]
+            arr = (_lib.WsumStep * len(chunk))(*chunk)
+            st = lib.vln_rows_wsum_multi(arr, len(chunk), ctype, B, F, F, _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_rows_wsum_multi")
+        w_c_t = self._shadow.t["w_c_t"]
+        for chunk, r0, r1, recs in runs:
+            dh = ops.linear_fwd(chunk.bufs["dtc"][r0:r1], w_c_t)                    # [(steps x B), H]
+            base = dh.data_ptr()
+            for rec in recs:
+                rec.dhtd_ext = base + (rec.slot.r0 - r0) * H * 4
+                rec.dhtd_keep = dh
 
     def _deferred_wgrads(self):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""
@@ -365,9 +407,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], cand_feature.shape[1], H
         rec.ctx_owner, rec.entry, rec.dims, rec.slot, rec.io, rec.keep = ctx, entry, plan.dims, slot, io, keep
+        rec.mod, rec.dhtd_ext, rec.dhtd_keep = self, None, None
         if need_grad:
             keep["htp"], keep["c0"] = h_tilde_prev.detach(), c_0.detach()
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
+            logit._vln_rec = rec                  # lets losses.RolloutCE batch the logit branch of the backward
         else:
             keep["htp"], keep["c0"] = h_tilde_prev, c_0
             st = _lib.load().vln_envdrop_step_fwd(C.byref(plan.dims), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
@@ -431,6 +475,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, L, Cn, H
         rec.ctx_owner, rec.entry = ctx, entry
+        rec.mod, rec.dhtd_ext, rec.dhtd_keep = self, None, None
         # the dims block and its scratch size depend on the shapes only: built once per shape
         dk = (B, L, V, Cn, lp)
         cached = self._dims_cache.get(dk)
@@ -532,6 +577,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
 
         if need_grad:
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
+            logit._vln_rec = rec                      # lets losses.RolloutCE batch the logit branch of the backward
         else:
             st = _lib.load().vln_envdrop_step_fwd(C.byref(d), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
             if st:

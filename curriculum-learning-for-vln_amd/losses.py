@@ -107,6 +107,7 @@ class _RolloutCE(torch.autograd.Function):
             if st:
                 _lib.check(st, "vln_masked_ce_multi_fwd")
         ctx.keep, ctx.ignore_index, ctx.scale, ctx.per_sample = keep, ignore_index, scale, per_sample
+        ctx.recs = [getattr(lg, "_vln_rec", None) for lg in logits]      # EnvDropDecoder steps: their logit branch can be batched
         return out
 
     @staticmethod
@@ -129,6 +130,12 @@ class _RolloutCE(torch.autograd.Function):
             if st:
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
+        recs = ctx.recs
+        ctx.recs = None
+        if recs and all(r is not None and r.slot is not None for r in recs):
+            mod = recs[0].mod
+            if getattr(mod, "batch_logit_backward", False) and all(r.mod is mod and r.B == B for r in recs):
+                mod.logit_branch_backward(list(zip(recs, outs)))
         return (None, *outs)
 
 

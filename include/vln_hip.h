@@ -98,6 +98,11 @@ typedef struct vln_shadow_job {
 } vln_shadow_job;
 int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
 
+/* out_t[b,:] = sum_s w_t[b,s] ctx_t[b,s,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, w_t [B,S_t], out_t rows of
+ * leading dimension ldo): the d(query) of the candidate logits of a whole rollout (policy.py:199-206 backward). */
+typedef struct vln_wsum_step { const void* ctx; const float* w; float* out; int S; } vln_wsum_step;
+int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s);
+
 /* SoftDotAttention / VisualSoftDotAttention pieces (units.py:100-122, 138-160):
  *   dots[b,s] = ctx[b,s,:] . vec[b,:]                          torch.bmm(context, target)
  *   attn = softmax(mask(logits)); out[b,:] = sum_s attn ctx     masked_fill_ + Softmax + torch.bmm(attn3, context)
@@ -409,6 +414,11 @@ typedef struct vln_envdrop_grads {
    * sweeping [B,L,H]; the caller forms dctx once per rollout: vln_attn_dctx_deferred(alpha_t, s_dl, s_dtcat, tt). */
   float* s_dl;           /* [B,L]  d(text attention logits) of this step */
   float* s_dtcat;        /* [B,2H] rows; the step writes d(weighted ctx) into columns [0,H) (ld 2H): the g operand of the deferred dctx */
+  /* ABI v4: the candidate-logit branch of the backward (logit = cand . (W_c drop(h_tilde)), policy.py:199-206,243-244) precomputed
+   * for ALL steps of a rollout -- vln_rows_wsum_multi fills every step's s_dtc, one GEMM over (steps x batch) rows maps them
+   * through W_c -- because it depends on no other step's backward.  Given (non-NULL), dlogit is ignored, s_dtc is left as the
+   * caller filled it, and this [B,H] block is used as d drop(h_tilde) from the logits. */
+  const float* dhtd_ext;
 } vln_envdrop_grads;
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);

@@ -449,6 +449,7 @@ def test_side_stream_gather_and_rollout_ce_are_transparent(vln):
     for side, rce in ((True, True), (False, False), (True, False), (False, True)):
         torch.manual_seed(19)
         ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side)
+        ag.dec.batch_logit_backward = False           # (the batched logit branch sums in another order: its own test below)
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True
         tape["store"]._calls = 0
@@ -488,3 +489,37 @@ def test_host_feature_staging_matches_resident_tensors(vln):
     for a, b in zip(res["tensor"][1], res["host"][1]):
         assert torch.equal(a, b)
     check(res["host-bf16"][0], res["tensor"][0], 1e-2, "bf16 host features: loss")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_logit_branch_backward_equals_per_step(vln, dtype):
+    """EnvDropDecoder.logit_branch_backward (losses.RolloutCE hands over every step's d logits at once: one multi-step
+    weighted sum into the stash + one GEMM over (steps x batch) rows) against the per-step branch inside each step's
+    backward: same loss bit for bit, every gradient to summation-order rounding; over four arena iterations with dropout
+    on (plans and graph replays included), steps with different candidate counts."""
+    import bench
+    dev_ = torch.device(DEV)
+    tape = bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=10), dev_, store_dtype=dtype)
+    res = []
+    for batched in (True, False):
+        torch.manual_seed(29)
+        ag = bench.GpuAgent(vln, dev_, dtype, 1, arena=True)
+        ag.dec.batch_logit_backward = batched
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        tape["store"]._calls = 0
+        ag.opt.lr = 0.0
+        out = []
+        for _ in range(4):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in list(ag.dec.named_parameters()) + list(ag.enc.named_parameters())}))
+        res.append(out)
+        if batched:
+            assert ag.dec.plan_hits > 0
+    for (la, ga), (lb, gb) in zip(res[0], res[1]):
+        assert torch.equal(la, lb)
+        scale = max(v.abs().max().item() for v in gb.values())
+        for n in ga:
+            err = (ga[n].double() - gb[n].double()).abs().max().item()
+            assert err <= 2e-5 * max(gb[n].abs().max().item(), 1e-3 * scale), (n, err)
