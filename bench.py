@@ -120,6 +120,10 @@ class GpuAgent:
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
         self.enc.train(); self.dec.train()
+        # teacher forcing: nothing reads the logits before the loss, so the decoder leaves them to be formed for the whole
+        # rollout at once when losses.RolloutCE evaluates (one GEMM over steps x batch + one dot launch instead of two
+        # launches on every step's dependent chain)
+        self.dec.defer_logits = bool(rollout_ce)
         # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
         # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
         self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)

@@ -24,6 +24,10 @@ class EnvDropDims(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "L", "V", "C", "H", "IMG", "ANG", "AE", "wtype", "ctype")]
 
 
+class DotStep(C.Structure):          # vln_dot_step
+    _fields_ = [("ctx", ptr), ("vec", ptr), ("dots", ptr), ("S", i32)]
+
+
 class WsumStep(C.Structure):         # vln_wsum_step
     _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32)]
 
@@ -45,7 +49,8 @@ class EnvDropStep(C.Structure):
                                     "ctx_lp", "ctx_mask", "logit", "h1", "c1", "h_tilde", "e", "xcat", "hq",
                                     "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd", "a_stash")]
                 + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
-                   ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr)])
+                   ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr), ("defer_logits", i32),
+                   ("pad_", i32)])
 
 
 class ShadowJob(C.Structure):
@@ -86,6 +91,7 @@ SIGNATURES = {
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),
     "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
+    "vln_attn_dot_multi": (i32, [C.POINTER(DotStep), i32, i32, i32, i32, i64, ptr]),
     "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),

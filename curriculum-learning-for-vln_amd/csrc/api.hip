@@ -173,6 +173,9 @@ extern "C" int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* 
   if (!ctx || !w || !out) { set_error("vln_rows_wsum: null pointer"); return VLN_ERR_ARG; }
   return rows_wsum((hipStream_t)s, ctx, ctype, w, out, ldo, B, S, D);
 }
+extern "C" int vln_attn_dot_multi(const vln_dot_step* steps, int T, int ctype, int B, int D, int64_t ldv, vln_stream_t s) {
+  return attn_dot_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldv);
+}
 extern "C" int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s) {
   return rows_wsum_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldo);
 }

@@ -238,6 +238,64 @@ int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype
   return VLN_OK;
 }
 
+// The candidate logits of a WHOLE rollout in one launch: dots_t[b,s] = ctx_t[b,s,:] . vec_t[b,:] (steps differ in S).  One wave
+// per (step, episode, candidate) row; same arithmetic as attn_dot_kernel with a one-slab vector.
+struct DotMulti {
+  const void* ctx[VLN_CE_MAX_STEPS]; const float* vec[VLN_CE_MAX_STEPS]; float* dots[VLN_CE_MAX_STEPS]; int S[VLN_CE_MAX_STEPS];
+  int row0[VLN_CE_MAX_STEPS + 1];      // prefix sums of B * S_t
+  int T, B, D; long ldv;
+};
+template <typename TC>
+__global__ __launch_bounds__(256) void attn_dot_multi_kernel(DotMulti m, int vec_ok) {
+  constexpr int V = Elt<TC>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = m.D, total = m.row0[m.T];
+  for (int r = (int)blockIdx.x * 4 + wave; r < total; r += (int)gridDim.x * 4) {
+    int t = 0;
+    while (t + 1 < m.T && r >= m.row0[t + 1]) ++t;
+    const int q = r - m.row0[t], b = q / m.S[t];
+    const TC* c = reinterpret_cast<const TC*>(m.ctx[t]) + (long)q * D;
+    const float* v = m.vec[t] + (long)b * m.ldv;
+    float acc = 0.f;
+    if (vec_ok) {
+      for (int d = lane * V; d < D; d += 64 * V) {
+        float x[V];
+        Elt<TC>::ld16(c + d, x);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(v + d + j);
+          acc += x[j] * w.x + x[j + 1] * w.y + x[j + 2] * w.z + x[j + 3] * w.w;
+        }
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(c + d) * v[d];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) m.dots[t][q] = acc;
+  }
+}
+int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, int B, int D, long ldv) {
+  if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0 || D <= 0) { set_error("attn_dot_multi: bad dims"); return VLN_ERR_ARG; }
+  DotMulti m{};
+  m.T = T; m.B = B; m.D = D; m.ldv = ldv;
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  int vec_ok = (D % V == 0) && (ldv % 4 == 0);
+  int rows = 0;
+  for (int t = 0; t < T; ++t) {
+    if (!steps[t].ctx || !steps[t].vec || !steps[t].dots || steps[t].S <= 0) { set_error("attn_dot_multi: bad step %d", t); return VLN_ERR_ARG; }
+    m.ctx[t] = steps[t].ctx; m.vec[t] = steps[t].vec; m.dots[t] = steps[t].dots; m.S[t] = steps[t].S;
+    m.row0[t] = rows; rows += B * steps[t].S;
+    vec_ok = vec_ok && aligned16(steps[t].ctx) && aligned16(steps[t].vec);
+  }
+  m.row0[T] = rows;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (ctype == W_BF16) hipLaunchKernelGGL(attn_dot_multi_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
+  else hipLaunchKernelGGL(attn_dot_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
+  VLN_CHECK_LAUNCH("attn_dot_multi");
+  return VLN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------

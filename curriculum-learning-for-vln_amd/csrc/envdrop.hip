@@ -219,6 +219,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
+  if (io->defer_logits) return VLN_OK;      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
   RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
   return VLN_OK;

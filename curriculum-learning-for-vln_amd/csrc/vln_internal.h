@@ -7,6 +7,7 @@
 
 struct vln_shadow_job;   // include/vln_hip.h
 struct vln_wsum_step;    // include/vln_hip.h
+struct vln_dot_step;     // include/vln_hip.h
 struct vln_wgrad_job;
 struct vln_colsum_job;
 
@@ -137,6 +138,7 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);
 int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo);
+int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, int B, int D, long ldv);
 
 // ---- pointwise.hip --------------------------------------------------------
 struct LstmPwFwd {

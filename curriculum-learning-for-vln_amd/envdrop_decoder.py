@@ -168,6 +168,10 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self.drop = nn.Dropout(p=drop_ratio)
         self.env_drop = nn.Dropout(p=feat_drop_ratio)
         self.batch_logit_backward = True      # losses.RolloutCE hands all d logits of a rollout over at once (logit_branch_backward)
+        # Opt-in, TEACHER FORCING ONLY: forward() returns `logit` tensors that are filled later -- for all steps of the
+        # rollout at once (one GEMM over steps x batch + one multi-step dot launch, logit_branch_forward) when
+        # losses.RolloutCE evaluates the loss.  Nothing may read the logits before that (a sampled / greedy rollout does).
+        self.defer_logits = False
         self.lstm = nn.LSTMCell(action_embed_size + feature_size, hidden_size)
         self.text_attn = _SoftDotParams(hidden_size)
         self.visual_attn = _SoftDotParams(hidden_size, context_dim=feature_size, context_only=True)
@@ -261,6 +265,39 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             setattr(w, k, t[k].data_ptr())
             setattr(w, k + "_t", t[k + "_t"].data_ptr())
         object.__setattr__(self, "_sb_handle", (ck, handle))
+
+    def logit_branch_forward(self, recs):
+        """`defer_logits`: the candidate logits of every recorded step, logit_t = cand_t . (W_c drop(h_tilde_t))
+        (policy.py:199-206,243-244), formed now: ONE GEMM over (steps x batch) rows of the `htd` stash per contiguous run
+        and ONE multi-step dot launch writing into the tensors forward() already returned."""
+        lib = _lib.load()
+        lp = self.compute_dtype != torch.float32
+        F = self.feature_size
+        B = recs[0].B
+        runs = []
+        for rec in recs:
+            sl = rec.slot
+            if runs and runs[-1][0] is sl.chunk and runs[-1][2] == sl.r0:
+                runs[-1][2] = sl.r0 + sl.rows
+                runs[-1][3].append(rec)
+            else:
+                runs.append([sl.chunk, sl.r0, sl.r0 + sl.rows, [rec]])
+        w_c = self._shadow.t["w_c"]
+        steps, hold = [], []
+        for chunk, r0, r1, rs in runs:
+            q = ops.linear_fwd(chunk.bufs["htd"][r0:r1], w_c)                       # [(steps x B), F]
+            hold.append(q)
+            base = q.data_ptr()
+            for rec in rs:
+                cand = rec.keep["cand_lp"] if lp else rec.keep["cand"]
+                steps.append(_lib.DotStep(cand.data_ptr(), base + (rec.slot.r0 - r0) * F * 4, rec.keep["logit"].data_ptr(), rec.C))
+        ctype = ops.BF16 if lp else ops.F32
+        for i in range(0, len(steps), _lib.CE_MAX_STEPS):
+            chunk = steps[i:i + _lib.CE_MAX_STEPS]
+            arr = (_lib.DotStep * len(chunk))(*chunk)
+            st = lib.vln_attn_dot_multi(arr, len(chunk), ctype, B, F, F, _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_attn_dot_multi")
 
     def logit_branch_backward(self, pairs):
         """The candidate-logit branch of the backward, logit_t = cand_t . (W_c drop(h_tilde_t)) (policy.py:199-206,243-244), for
@@ -457,7 +494,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             pkey = (arena.g, arena.i, a_t_prev.data_ptr(), img_feature.data_ptr(), cand_feature.data_ptr(), h_tilde_prev.data_ptr(),
                     c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
                     self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
-                    0 if cand_lp is None else cand_lp.data_ptr(), dt)
+                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits))
         ctx_lp = None
         if lp:                         # once per rollout; BEFORE the step's own buffers so the arena order is the same on
             ctx_lp = entry.lp          # the planned and on the full path
@@ -565,6 +602,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.p_drop, io.p_feat = self.drop_ratio, self.feat_drop_ratio
         if already_dropfeat:
             io.already_dropfeat = 1
+        if self.defer_logits and need_grad:
+            io.defer_logits = 1
         io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
         rec.io, rec.keep = io, keep
         if (pkey is not None and img is img_feature and cand is cand_feature and a is a_t_prev and htp.is_contiguous()

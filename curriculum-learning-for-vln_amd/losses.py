@@ -87,6 +87,11 @@ class _RolloutCE(torch.autograd.Function):
         T, B = len(logits), logits[0].shape[0]
         dev = logits[0].device
         lib = _lib.load()
+        recs = [getattr(lg, "_vln_rec", None) for lg in logits]          # EnvDropDecoder steps (None for other producers)
+        pending = [r for r in recs if r is not None and r.slot is not None and r.io.defer_logits]
+        if pending:                                                       # EnvDropDecoder.defer_logits: form the logits now, all steps
+            for mod in {id(r.mod): r.mod for r in pending}.values():      # at once per decoder
+                mod.logit_branch_forward([r for r in pending if r.mod is mod])
         out = ops.empty(B if per_sample else (), dtype=torch.float32, device=dev)
         keep, steps = [], []
         for lg, tg, mk in zip(logits, targets, masks):
@@ -107,7 +112,7 @@ class _RolloutCE(torch.autograd.Function):
             if st:
                 _lib.check(st, "vln_masked_ce_multi_fwd")
         ctx.keep, ctx.ignore_index, ctx.scale, ctx.per_sample = keep, ignore_index, scale, per_sample
-        ctx.recs = [getattr(lg, "_vln_rec", None) for lg in logits]      # EnvDropDecoder steps: their logit branch can be batched
+        ctx.recs = recs                                                   # their logit branch of the backward can be batched too
         return out
 
     @staticmethod

@@ -103,6 +103,12 @@ int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
 typedef struct vln_wsum_step { const void* ctx; const float* w; float* out; int S; } vln_wsum_step;
 int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s);
 
+/* dots_t[b,s] = ctx_t[b,s,:] . vec_t[b,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, vec_t rows of leading
+ * dimension ldv, dots_t [B,S_t] dense): the candidate logits of a whole teacher-forced rollout (policy.py:199-206), whose
+ * queries W_c drop(h_tilde_t) come from ONE GEMM over (steps x batch) rows -- see vln_envdrop_step.defer_logits. */
+typedef struct vln_dot_step { const void* ctx; const float* vec; float* dots; int S; } vln_dot_step;
+int vln_attn_dot_multi(const vln_dot_step* steps, int T, int ctype, int B, int D, int64_t ldv, vln_stream_t s);
+
 /* SoftDotAttention / VisualSoftDotAttention pieces (units.py:100-122, 138-160):
  *   dots[b,s] = ctx[b,s,:] . vec[b,:]                          torch.bmm(context, target)
  *   attn = softmax(mask(logits)); out[b,:] = sum_s attn ctx     masked_fill_ + Softmax + torch.bmm(attn3, context)
@@ -393,6 +399,11 @@ typedef struct vln_envdrop_step {
    * every iteration has the same argument block (replayed as one hipGraph).  The word must stay unchanged until the
    * step's backward has run.  Takes precedence over offset_dev. */
   const uint64_t* offset_base_dev;
+  /* ABI v4.  1: forward leaves `logit` UNWRITTEN (step (6), the cand_attn projection + candidate dots, is skipped): with
+   * teacher forcing nothing reads the logits before the loss, so the caller forms them for all steps of the rollout at
+   * once -- one GEMM over (steps x batch) rows of the `htd` stash + vln_attn_dot_multi -- right before the rollout's loss
+   * launch (EnvDropDecoder.defer_logits + losses.RolloutCE).  Sampling / greedy rollouts need the logits per step: 0. */
+  int defer_logits; int pad_;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {
