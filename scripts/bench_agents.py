@@ -162,18 +162,20 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
     def rollout(T, sample):
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
         ht = h
-        ml, hidden, logps, ents = 0.0, [], [], []
+        hidden, logps, ents = [], [], []
+        dec.defer_logits = not sample           # teacher forcing: the logits are only needed by the loss (formed once per rollout)
+        ce = vln.losses.RolloutCE()
         for s in tape["steps"][:T]:
             img, cand = feats(s)
             logit, (h, c), ht = dec(s["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
             hidden.append(h)
             if not sample:
-                ml = ml + vln.losses.masked_cross_entropy(logit, s["target"], s["cand_mask"], "sum")
+                ce.add(logit, s["target"], s["cand_mask"])
             else:
                 a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])     # envdrop.py:186-195 as one launch
                 logps.append(lp_a); ents.append(en_a)
         if not sample:
-            return ml * 0.2 / B
+            return ce.sum(scale=0.2 / B)
         img, cand = feats(tape["steps"][T - 1])
         _, (last_h, _), _ = dec(tape["steps"][T - 1]["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
         with torch.no_grad():
