@@ -222,6 +222,6 @@ def test_oracle_rollout_instruction_override_is_consistent():
     swapped = own[[3, 2, 1, 0]]
     res2 = R.envdrop_rollout(R.OracleBackend(*split(G["param"])), FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7),
                              "teacher", 6, insts=swapped)
-    assert np.isfinite(float(res2["ml_loss"]))
+    assert np.isfinite(float(res2["ml_loss"].detach()))
     perm = np.argsort(-np.array([int(np.argmax(r == 0)) if (r == 0).any() else len(r) for r in swapped]), kind="stable")
     assert np.array_equal(res2["actions"], G["out"]["actions"].numpy()[:, perm])
