@@ -44,7 +44,7 @@ class _StepPlan:
 
 
 class _StepRec:
-    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H", "mod", "dhtd_ext", "dhtd_keep")
+    __slots__ = ("io", "dims", "slot", "keep", "ctx_owner", "entry", "B", "L", "C", "H", "mod", "dhtd_ext", "dhtd_keep", "flushed")
 
 
 _NONES = (None,) * 64
@@ -291,6 +291,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             for rec in rs:
                 cand = rec.keep["cand_lp"] if lp else rec.keep["cand"]
                 steps.append(_lib.DotStep(cand.data_ptr(), base + (rec.slot.r0 - r0) * F * 4, rec.keep["logit"].data_ptr(), rec.C))
+                rec.flushed = True
         ctype = ops.BF16 if lp else ops.F32
         for i in range(0, len(steps), _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
@@ -444,7 +445,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], cand_feature.shape[1], H
         rec.ctx_owner, rec.entry, rec.dims, rec.slot, rec.io, rec.keep = ctx, entry, plan.dims, slot, io, keep
-        rec.mod, rec.dhtd_ext, rec.dhtd_keep = self, None, None
+        rec.mod, rec.dhtd_ext, rec.dhtd_keep, rec.flushed = self, None, None, False
         if need_grad:
             keep["htp"], keep["c0"] = h_tilde_prev.detach(), c_0.detach()
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
@@ -512,7 +513,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, L, Cn, H
         rec.ctx_owner, rec.entry = ctx, entry
-        rec.mod, rec.dhtd_ext, rec.dhtd_keep = self, None, None
+        rec.mod, rec.dhtd_ext, rec.dhtd_keep, rec.flushed = self, None, None, False
         # the dims block and its scratch size depend on the shapes only: built once per shape
         dk = (B, L, V, Cn, lp)
         cached = self._dims_cache.get(dk)

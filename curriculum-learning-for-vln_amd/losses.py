@@ -17,6 +17,15 @@ from . import _lib, ops
 _p = ops._p
 
 
+def _not_deferred(logits, who):
+    """EnvDropDecoder.defer_logits leaves the logits unwritten until losses.RolloutCE forms them: anything of this module that
+    would read them earlier says so instead of computing on uninitialised memory."""
+    rec = getattr(logits, "_vln_rec", None)
+    if rec is not None and rec.io is not None and rec.io.defer_logits and not rec.flushed:
+        raise _lib.VlnError(f"{who}: these logits come from a decoder with defer_logits=True and have not been formed yet; "
+                            "use losses.RolloutCE for the rollout's loss, or defer_logits=False when the logits are read per step")
+
+
 def _mask8(cand_mask):
     if cand_mask is None:
         return None
@@ -72,6 +81,7 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
     """== `CrossEntropyLoss(ignore_index, reduction)(logits.masked_fill(cand_mask, -inf), target)`.
     reduction: 'none' ([B], 0 at ignored rows; what SELF-PACE consumes, curriculum.py:296), 'sum' (0-dim, summed inside
     the same launch), 'mean' (mean over the non-ignored rows, follower.py:62)."""
+    _not_deferred(logits, "masked_cross_entropy")
     if reduction == "none":
         return _MaskedCE.apply(logits, target, cand_mask, ignore_index, False)
     total = _MaskedCE.apply(logits, target, cand_mask, ignore_index, True)
@@ -88,7 +98,7 @@ class _RolloutCE(torch.autograd.Function):
         dev = logits[0].device
         lib = _lib.load()
         recs = [getattr(lg, "_vln_rec", None) for lg in logits]          # EnvDropDecoder steps (None for other producers)
-        pending = [r for r in recs if r is not None and r.slot is not None and r.io.defer_logits]
+        pending = [r for r in recs if r is not None and r.slot is not None and r.io.defer_logits and not r.flushed]
         if pending:                                                       # EnvDropDecoder.defer_logits: form the logits now, all steps
             for mod in {id(r.mod): r.mod for r in pending}.values():      # at once per decoder
                 mod.logit_branch_forward([r for r in pending if r.mod is mod])
@@ -182,6 +192,7 @@ class RolloutCE:
 def action_stats(logits: torch.Tensor, action: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
     """(probs, log_prob(action), entropy) of Categorical(softmax(masked logits)) with torch.distributions' clamp
     (envdrop.py:189-194) -- no autograd (sampling / logging); the differentiable A2C terms use torch ops."""
+    _not_deferred(logits, "action_stats")
     lib = _lib.load()
     B, C = logits.shape
     lg = logits.detach().contiguous()
@@ -309,6 +320,7 @@ def sample_action(logits: torch.Tensor, cand_mask: Optional[torch.Tensor] = None
     policy_log_probs.append(c.log_prob(a)); entropys.append(c.entropy())`  ->  (a, log_prob [B], entropy [B]).
     `action` given: its log-prob / entropy instead of a draw (teacher or injected actions).  Draws come from the kernels'
     Philox stream (seed, offset; offset defaults to a running counter), not from torch's generator."""
+    _not_deferred(logits, "sample_action")
     if offset is None:
         _sample_calls[0] += 1
         offset = _sample_calls[0]

@@ -561,3 +561,12 @@ def test_deferred_logits_are_filled_by_the_rollout_loss(vln):
     for x, y in zip(outs[0][1], outs[1][1]):
         check(x, y, 1e-5, "deferred logits")
         assert x[:, -1].abs().max().item() == 0.0
+    # a per-step consumer of deferred logits is told so instead of reading uninitialised memory
+    dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+    dec.defer_logits = True
+    img, cand, tgt = steps[0]
+    lg, _, _ = dec(a, img.clone(), cand.clone(), h.clone().requires_grad_(True), h, c, ctx)
+    for fn in (lambda: vln.losses.masked_cross_entropy(lg, tgt, None, "sum"), lambda: vln.losses.sample_action(lg),
+               lambda: vln.losses.action_stats(lg, tgt)):
+        with pytest.raises(vln.VlnError):
+            fn()
