@@ -25,6 +25,9 @@ VARIANTS = {
     "attn_two_kernels": {4: 1},
     "wgrad_fp32_exact": {6: 1},
     "gemm_split_target512": {0: 512},
+    "gemm_split_target384": {0: 384},
+    "gemm_split_target192": {0: 192},
+    "per_step_logits_and_loss_branch": {},
 }
 torch.manual_seed(0)
 agent = bench.GpuAgent(vln, dev, dtype, 1)
@@ -32,6 +35,7 @@ agent = bench.GpuAgent(vln, dev, dtype, 1)
 
 def configure(cfg, name=""):
     agent.dec.overlap_wgrads = (name == "overlap_wgrads")
+    agent.dec.defer_logits = agent.dec.batch_logit_backward = (name != "per_step_logits_and_loss_branch")
     want = not name.startswith("noarena")
     if want != (agent.arena is not None):
         agent.use_arena(want)
