@@ -29,7 +29,7 @@ class DotStep(C.Structure):          # vln_dot_step
 
 
 class WsumStep(C.Structure):         # vln_wsum_step
-    _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32)]
+    _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32), ("probs", ptr), ("target", ptr)]
 
 
 class CeStep(C.Structure):           # vln_ce_step
@@ -92,7 +92,7 @@ SIGNATURES = {
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),
     "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_dot_multi": (i32, [C.POINTER(DotStep), i32, i32, i32, i32, i64, ptr]),
-    "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, ptr]),
+    "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, f32, ptr, i64, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
     "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr]),

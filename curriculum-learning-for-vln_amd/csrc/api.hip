@@ -176,8 +176,9 @@ extern "C" int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* 
 extern "C" int vln_attn_dot_multi(const vln_dot_step* steps, int T, int ctype, int B, int D, int64_t ldv, vln_stream_t s) {
   return attn_dot_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldv);
 }
-extern "C" int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s) {
-  return rows_wsum_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldo);
+extern "C" int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, float ce_scale,
+                                   const float* ce_dloss, int64_t ignore_index, vln_stream_t s) {
+  return rows_wsum_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldo, ce_scale, ce_dloss, (long)ignore_index);
 }
 extern "C" int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha,
                             const float* dattn_ext, const float* dwc, int64_t lddwc, const float* vec,

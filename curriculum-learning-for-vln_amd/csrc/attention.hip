@@ -173,7 +173,8 @@ int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float*
 // launch (steps differ in S = candidate count).  Same arithmetic and summation order as attn_wsum_kernel<TC,false>.
 struct WsumMulti {
   const void* ctx[VLN_CE_MAX_STEPS]; const float* w[VLN_CE_MAX_STEPS]; float* out[VLN_CE_MAX_STEPS]; int S[VLN_CE_MAX_STEPS];
-  int T, B, D; long ldo;
+  const float* probs[VLN_CE_MAX_STEPS]; const long long* target[VLN_CE_MAX_STEPS];
+  int T, B, D; long ldo; float ce_scale; const float* ce_dloss; long ignore_index;
 };
 template <typename TC>
 __global__ __launch_bounds__(256) void rows_wsum_multi_kernel(WsumMulti m, int vec_ok) {
@@ -184,8 +185,15 @@ __global__ __launch_bounds__(256) void rows_wsum_multi_kernel(WsumMulti m, int v
   const int t = blockIdx.x / m.B, b = blockIdx.x - t * m.B, chunk = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = m.S[t], D = m.D;
-  const float* lg = m.w[t] + (long)b * S;
-  for (int s = threadIdx.x; s < S; s += 256) sw[s] = lg[s];
+  if (m.w[t]) {
+    const float* lg = m.w[t] + (long)b * S;
+    for (int s = threadIdx.x; s < S; s += 256) sw[s] = lg[s];
+  } else {                                   // d logits of the rollout's cross-entropy, formed here (masked_ce_multi_bwd_kernel's formula)
+    const long tg = m.target[t][b];
+    const float g = m.ce_dloss[0] * m.ce_scale;
+    const float* pr = m.probs[t] + (long)b * S;
+    for (int s = threadIdx.x; s < S; s += 256) sw[s] = (tg == m.ignore_index) ? 0.f : g * (pr[s] - (s == tg ? 1.f : 0.f));
+  }
   __syncthreads();
   const int d0 = chunk * DC + lane * V;
   float acc[V];
@@ -219,15 +227,18 @@ __global__ __launch_bounds__(256) void rows_wsum_multi_kernel(WsumMulti m, int v
     if (d < D) out[(long)b * m.ldo + d] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
-int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo) {
+int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo, float ce_scale,
+                    const float* ce_dloss, long ignore_index) {
   if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0 || D <= 0) { set_error("rows_wsum_multi: bad dims"); return VLN_ERR_ARG; }
   WsumMulti m{};
-  m.T = T; m.B = B; m.D = D; m.ldo = ldo;
+  m.T = T; m.B = B; m.D = D; m.ldo = ldo; m.ce_scale = ce_scale; m.ce_dloss = ce_dloss; m.ignore_index = ignore_index;
   const int V = (ctype == W_BF16) ? 8 : 4;
   int vec_ok = (D % V == 0);
   for (int t = 0; t < T; ++t) {
-    if (!steps[t].ctx || !steps[t].w || !steps[t].out || steps[t].S <= 0 || steps[t].S > kMaxS) { set_error("rows_wsum_multi: bad step %d", t); return VLN_ERR_ARG; }
+    const bool ce = !steps[t].w && steps[t].probs && steps[t].target && ce_dloss;
+    if (!steps[t].ctx || (!steps[t].w && !ce) || !steps[t].out || steps[t].S <= 0 || steps[t].S > kMaxS) { set_error("rows_wsum_multi: bad step %d", t); return VLN_ERR_ARG; }
     m.ctx[t] = steps[t].ctx; m.w[t] = steps[t].w; m.out[t] = steps[t].out; m.S[t] = steps[t].S;
+    m.probs[t] = steps[t].probs; m.target[t] = (const long long*)steps[t].target;
     vec_ok = vec_ok && aligned16(steps[t].ctx);
   }
   const int DC = 64 * V;

@@ -137,7 +137,8 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
 // dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);
-int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo);
+int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo, float ce_scale,
+                    const float* ce_dloss, long ignore_index);
 int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, int B, int D, long ldv);
 
 // ---- pointwise.hip --------------------------------------------------------

@@ -300,22 +300,31 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             if st:
                 _lib.check(st, "vln_attn_dot_multi")
 
-    def logit_branch_backward(self, pairs):
+    def logit_branch_backward(self, pairs, ce=None):
         """The candidate-logit branch of the backward, logit_t = cand_t . (W_c drop(h_tilde_t)) (policy.py:199-206,243-244), for
         ALL steps of a rollout at once: it depends on the d logits only -- which `losses.RolloutCE` produces for every step
         in one launch at the root of the backward -- and on no other step's backward, so 2 T skinny launches on the
         dependent chain (rows_wsum + an M = B GEMM per step) become ONE multi-step weighted sum, written straight into the
         steps' `dtc` stash rows (the dY operand of d cand_attn.weight), and ONE GEMM over (steps x batch) rows per contiguous
         stash run.  pairs: [(step record, d logits [B, C_t])] in rollout order.  Each step's backward then finds its [B,H] block
-        (`vln_envdrop_grads.dhtd_ext`) and skips the branch."""
+        (`vln_envdrop_grads.dhtd_ext`) and skips the branch.  With `ce` = (per-step (probs, target) list, d loss scalar tensor,
+        scale, ignore_index) the d logits are never materialised: the weighted-sum launch forms them from the loss's saved
+        probabilities on the fly (pairs then carry None in their place)."""
         lib = _lib.load()
         lp = self.compute_dtype != torch.float32
         F, H = self.feature_size, self.hidden_size
         B = pairs[0][0].B
         steps, runs = [], []
-        for rec, dl in pairs:
+        ce_scale, ce_dloss, ce_ignore = 1.0, None, -1
+        if ce is not None:
+            ce_pt, dloss, ce_scale, ce_ignore = ce
+            ce_dloss = dloss.data_ptr()
+        for i, (rec, dl) in enumerate(pairs):
             cand = rec.keep["cand_lp"] if lp else rec.keep["cand"]
-            steps.append(_lib.WsumStep(cand.data_ptr(), dl.data_ptr(), rec.slot.ptr("dtc"), rec.C))
+            if dl is not None:
+                steps.append(_lib.WsumStep(cand.data_ptr(), dl.data_ptr(), rec.slot.ptr("dtc"), rec.C, None, None))
+            else:
+                steps.append(_lib.WsumStep(cand.data_ptr(), None, rec.slot.ptr("dtc"), rec.C, ce_pt[i][0].data_ptr(), ce_pt[i][1].data_ptr()))
             sl = rec.slot
             if runs and runs[-1][0] is sl.chunk and runs[-1][2] == sl.r0:
                 runs[-1][2] = sl.r0 + sl.rows
@@ -326,7 +335,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         for i in range(0, len(steps), _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.WsumStep * len(chunk))(*chunk)
-            st = lib.vln_rows_wsum_multi(arr, len(chunk), ctype, B, F, F, _lib.raw_stream())
+            st = lib.vln_rows_wsum_multi(arr, len(chunk), ctype, B, F, F, ce_scale, ce_dloss, ce_ignore, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_rows_wsum_multi")
         w_c_t = self._shadow.t["w_c_t"]

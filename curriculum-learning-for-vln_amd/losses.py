@@ -132,6 +132,19 @@ class _RolloutCE(torch.autograd.Function):
         B = keep[0][0].shape[0]
         lib = _lib.load()
         dloss = dloss.contiguous()
+        recs = ctx.recs
+        ctx.recs = None
+        batched = bool(recs) and all(r is not None and r.slot is not None for r in recs)
+        if batched:
+            mod = recs[0].mod
+            batched = bool(getattr(mod, "batch_logit_backward", False)) and all(r.mod is mod and r.B == B for r in recs)
+        if batched and not ctx.per_sample:
+            # every consumer of these d logits is the decoder's rollout-wide logit branch: it forms them on the fly from the
+            # saved probabilities (no d logits tensors, no launch of its own here)
+            mod.logit_branch_backward([(r, None) for r in recs],
+                                      ce=([(k[3], k[1]) for k in keep], dloss, ctx.scale, ctx.ignore_index))
+            ctx.keep = None
+            return (None,) * (T + 1)
         steps, outs = [], []
         for lg, tg, m8, probs in keep:
             dl = ops.empty_like(probs)
@@ -145,12 +158,8 @@ class _RolloutCE(torch.autograd.Function):
             if st:
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
-        recs = ctx.recs
-        ctx.recs = None
-        if recs and all(r is not None and r.slot is not None for r in recs):
-            mod = recs[0].mod
-            if getattr(mod, "batch_logit_backward", False) and all(r.mod is mod and r.B == B for r in recs):
-                mod.logit_branch_backward(list(zip(recs, outs)))
+        if batched:
+            mod.logit_branch_backward(list(zip(recs, outs)))
         return (None, *outs)
 
 

@@ -100,8 +100,15 @@ int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
 
 /* out_t[b,:] = sum_s w_t[b,s] ctx_t[b,s,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, w_t [B,S_t], out_t rows of
  * leading dimension ldo): the d(query) of the candidate logits of a whole rollout (policy.py:199-206 backward). */
-typedef struct vln_wsum_step { const void* ctx; const float* w; float* out; int S; } vln_wsum_step;
-int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, vln_stream_t s);
+typedef struct vln_wsum_step {
+  const void* ctx; const float* w; float* out; int S;
+  /* optional (w == NULL): the weights are the cross-entropy gradient formed on the fly, w[b,s] = g * (probs[b,s] - 1[s ==
+   * target[b]]) (0 for rows whose target is ignore_index) -- the d logits of vln_masked_ce_multi_fwd without materialising them */
+  const float* probs; const int64_t* target;
+} vln_wsum_step;
+/* ce_scale / ce_dloss ([1] device scalar) / ignore_index: only read for steps given as (probs, target); g = *ce_dloss * ce_scale */
+int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, float ce_scale,
+                        const float* ce_dloss, int64_t ignore_index, vln_stream_t s);
 
 /* dots_t[b,s] = ctx_t[b,s,:] . vec_t[b,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, vec_t rows of leading
  * dimension ldv, dots_t [B,S_t] dense): the candidate logits of a whole teacher-forced rollout (policy.py:199-206), whose
