@@ -570,3 +570,42 @@ def test_deferred_logits_are_filled_by_the_rollout_loss(vln):
                lambda: vln.losses.action_stats(lg, tgt)):
         with pytest.raises(vln.VlnError):
             fn()
+
+
+def test_per_sample_rollout_loss_through_the_decoder(vln):
+    """SELF-PACE form (curriculum.py:296): `dot(weight, RolloutCE.per_sample())` through EnvDropDecoder steps -- the per-episode
+    upstream gradients take the materialised-d-logits route of the rollout-wide logit branch; deferred logits + batched branch
+    against the per-step configuration: loss vector and every gradient to rounding."""
+    B, L, V, Cn, H, F = 10, 9, 36, 6, 64, 256 + 128
+    g = torch.Generator().manual_seed(43)
+    ctx0 = torch.randn(B, L, H, generator=g).to(DEV)
+    h = torch.randn(B, H, generator=g).to(DEV); c = torch.randn(B, H, generator=g).to(DEV)
+    a = torch.randn(B, 128, generator=g).to(DEV)
+    w = torch.rand(B, generator=g).to(DEV)
+    steps = []
+    for t in range(3):
+        n = torch.randint(2, Cn + 1, (B,), generator=g)
+        cand = torch.randn(B, Cn, F, generator=g).abs() * (torch.arange(Cn)[None, :] < n[:, None])[..., None]
+        tgt = (torch.rand(B, generator=g) * n.float()).long()
+        tgt[torch.rand(B, generator=g) < 0.2] = -1
+        steps.append((torch.randn(B, V, F, generator=g).abs().to(DEV), cand.to(DEV), tgt.to(DEV), (torch.arange(Cn)[None, :] >= n[:, None]).to(DEV)))
+    res = []
+    for fast in (True, False):
+        torch.manual_seed(4)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+        dec.defer_logits = dec.batch_logit_backward = fast
+        ctx = ctx0.clone().requires_grad_(True)
+        hh, cc, ht = h.clone().requires_grad_(True), c.clone(), h.clone()
+        ce = vln.losses.RolloutCE()
+        for img, cand, tgt, cm in steps:
+            lg, (hh, cc), ht = dec(a, img.clone(), cand.clone(), ht, hh, cc, ctx)
+            ce.add(lg, tgt, cm)
+        vec = ce.per_sample(scale=0.5)
+        torch.dot(w, vec).backward()
+        res.append((vec.detach().clone(), {n: p.grad.detach().clone() for n, p in dec.named_parameters()}, ctx.grad.clone()))
+    check(res[0][0], res[1][0], 1e-5, "per-episode losses")
+    check(res[0][2], res[1][2], 2e-4, "d ctx")
+    scale = max(v.abs().max().item() for v in res[1][1].values())
+    for n in res[0][1]:
+        err = (res[0][1][n].double() - res[1][1][n].double()).abs().max().item()
+        assert err <= 2e-5 * max(res[1][1][n].abs().max().item(), 1e-3 * scale), (n, err)
