@@ -301,6 +301,20 @@ def read_prof(lib, nk):
     return rows
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run (one process per GPU) and return its exit code.  Called
+    before anything in this process has initialised the GPU; the children are ordinary subprocesses (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,11 +344,34 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="(testing) map every rank to cuda:0")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="(testing, runs without a GPU) launch / join the N ranks, all-reduce one scalar over --backend, rank 0 "
+                         "prints {n_gpus, world_size, backend} and every rank leaves: checks the launch path of --gpus N")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous
+        # on 127.0.0.1) BEFORE this process touches the GPU, and leave with the launcher's exit code -- rank 0 of the
+        # children prints the one JSON line.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group(args.backend)
+            one = torch.ones(1)
+            dist.all_reduce(one)
+            assert int(one.item()) == world == dist.get_world_size()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rendezvous_only": True,
+                              "config": {"world_size": world, "backend": args.backend if world > 1 else None}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -342,6 +379,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == args.backend, (dist.get_world_size(), dist.get_backend())
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -475,7 +513,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "world_size": world,
+                       "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -104,9 +104,9 @@ SIGNATURES = {
     "vln_scale_dropout": (i32, [ptr, i64, ptr, i64, i32, i32, u64, u64, f32, ptr]),
     "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_rmsprop_partial_floats": (i64, [ptr, i32]),
-    "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, f32, ptr]),
-    "vln_adam_clip_step": (i32, [ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, i64, f32, f32, ptr]),
-    "vln_sgd_clip_step": (i32, [ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr]),
+    "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr, f32, ptr]),
+    "vln_adam_clip_step": (i32, [ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, i64, ptr, f32, ptr]),
+    "vln_sgd_clip_step": (i32, [ptr, ptr, ptr, i32, ptr, ptr, f32, ptr, f32, ptr]),
     "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, ptr, i32, ptr]),
@@ -139,6 +139,7 @@ SIGNATURES = {
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
+    "vln_persistent_check": (i32, []),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),

@@ -539,11 +539,72 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
 int g_persist_enabled = 1;
 extern "C" int vln_set_persistent(int on) { g_persist_enabled = on ? 1 : 0; return VLN_OK; }
 
+// Co-residency: every workgroup of the persistent grid spins on its neighbours, so the WHOLE grid must be resident at once.
+// The kernels keep their W_hh slice in registers (about one workgroup per CU), so the capacity is the device's CU count --
+// queried, not assumed: a partitioned (CPX) or smaller device takes the per-step chain instead of spinning into a timeout.
+static int device_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+template <typename K>
+static bool kernel_fits_one_per_cu(K kernel) {      // the occupancy API's answer for this instantiation, cached by the caller
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return n >= 1;
+}
+
+// A bounded spin that timed out leaves wrong numbers behind.  The per-launch status word is zeroed by the next launch, so
+// the kernels also count timeouts in a STICKY word (header word 0); every persistent launch is followed by a 4-byte copy of
+// it into pinned host memory, and the next entry into the library (sequence forward / backward, optimizer step:
+// vln_persistent_check) reports it ONCE as an error and switches this process to the per-step chain.
+static unsigned* g_sticky_host = nullptr;       // pinned, one word per device
+static unsigned* sticky_host() {
+  if (!g_sticky_host) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&g_sticky_host), 16 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      g_sticky_host = nullptr;
+      return nullptr;
+    }
+    for (int i = 0; i < 16; ++i) g_sticky_host[i] = 0u;
+  }
+  return g_sticky_host;
+}
+static void sticky_publish(hipStream_t st, const void* sync_ws) {
+  unsigned* h = sticky_host();
+  int dev = 0;
+  if (!h || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return; }
+  if (hipMemcpyAsync(h + dev, sync_ws, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) (void)hipGetLastError();
+}
+extern "C" int vln_persistent_check(void) {
+  unsigned* h = g_sticky_host;
+  if (!h) return VLN_OK;
+  for (int d = 0; d < 16; ++d) {
+    if (h[d]) {
+      const unsigned n = h[d];
+      h[d] = 0u;
+      g_persist_enabled = 0;
+      set_error("persistent LSTM recurrence: %u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (its "
+                "workgroups were not co-resident); that iteration's numbers are invalid.  The persistent path is now off for "
+                "this process (per-step launches)", n, d);
+      return VLN_ERR_HIP;
+    }
+  }
+  return VLN_OK;
+}
+
 static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
   if (!g_persist_enabled || !sync_ws) return false;
   if (Hd != 128 && Hd != 256 && Hd != 512) return false;
   const long wgs = (long)(Hd / 16) * dirs * ((B + 15) / 16);
-  if (wgs > 256 || dirs * ((B + 15) / 16) > 32) return false;            // every workgroup must be co-resident
+  const int cus = device_cus();
+  if (cus <= 0 || wgs > cus || dirs * ((B + 15) / 16) > 32) return false;   // every workgroup must be co-resident
   if ((long)L * B * dirs * 4 * Hd * 4 >= (1L << 32)) return false;       // 32-bit buffer offsets
   return true;
 }
@@ -553,13 +614,21 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
   const dim3 g1(grid.x * grid.y * grid.z);          // one-dimensional: the kernel decodes (slice, direction, row block)
   const int xm = g_tunable[7] != 1;                 // tunable[7] = 1: dispatch-order mapping (A/B)
   constexpr int BK = RecCfg<TW>::BK;
+#define VLN_PERSIST_FWD(NS_)                                                                                              \
+  {                                                                                                                       \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_fwd_kernel<TW, NS_>);                                    \
+    if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
+    hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, counters, status, xm);                 \
+  }                                                                                                                       \
+  break
   switch (a.Hd / BK) {
-    case 2: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 2>), g1, dim3(256), 0, st, a, counters, status, xm); break;
-    case 4: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 4>), g1, dim3(256), 0, st, a, counters, status, xm); break;
-    case 8: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 8>), g1, dim3(256), 0, st, a, counters, status, xm); break;
-    case 16: hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, 16>), g1, dim3(256), 0, st, a, counters, status, xm); break;
+    case 2: VLN_PERSIST_FWD(2);
+    case 4: VLN_PERSIST_FWD(4);
+    case 8: VLN_PERSIST_FWD(8);
+    case 16: VLN_PERSIST_FWD(16);
     default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
   }
+#undef VLN_PERSIST_FWD
   VLN_CHECK_LAUNCH("lstm_persist_fwd");
   return VLN_OK;
 }
@@ -568,12 +637,20 @@ template <typename TW>
 static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid) {
   const dim3 g1(grid.x * grid.y * grid.z);
   const int xm = g_tunable[7] != 1;
+#define VLN_PERSIST_BWD(NT_)                                                                                              \
+  {                                                                                                                       \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_>);                                    \
+    if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
+    hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, exch, xm);           \
+  }                                                                                                                       \
+  break
   switch (a.Hd / 64) {
-    case 2: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 2>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
-    case 4: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 4>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
-    case 8: hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, 8>), g1, dim3(256), 0, st, a, counters, status, exch, xm); break;
+    case 2: VLN_PERSIST_BWD(2);
+    case 4: VLN_PERSIST_BWD(4);
+    case 8: VLN_PERSIST_BWD(8);
     default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
   }
+#undef VLN_PERSIST_BWD
   VLN_CHECK_LAUNCH("lstm_persist_bwd");
   return VLN_OK;
 }
@@ -593,7 +670,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= kSyncHeaderBytes && al16(w_hh) && al16(hprev)) {
     hipStream_t st = (hipStream_t)s;
-    int r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);     // status word [32], flag lines from word 64
+    int r = vln_persistent_check(); if (r) return r;
+    r = fill_f32(st, (float*)sync_ws + kSyncKeepWords, kSyncHeaderBytes / 4 - kSyncKeepWords, 0.f);     // status word [32], flag lines from word 64
     if (r) return r;
     const int init = (h0 || c0) ? 1 : 0;
     if (init) { r = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs); if (r) return r; }
@@ -601,9 +679,13 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
-    ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
-    return (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
-                               : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
+    {
+      ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
+      r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
+                              : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
+    }
+    sticky_publish(st, sync_ws);
+    return r;
   }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[12]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, h0, c0},
@@ -640,15 +722,20 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
-    int r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
+    int r = vln_persistent_check(); if (r) return r;
+    r = fill_f32(st, (float*)sync_ws + kSyncKeepWords, kSyncHeaderBytes / 4 - kSyncKeepWords, 0.f);
     if (r) return r;
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
-    ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
-    return (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
-                               : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
+    {
+      ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
+      r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
+                              : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
+    }
+    sticky_publish(st, sync_ws);
+    return r;
   }
   struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},
                                                 {wtype, B, L, Hd, dirs}};

@@ -39,7 +39,9 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 //   VLN_SYNC_FLAGS 1: one word per producer in the line -- arrive = write-through store of the epoch, wait = one load
 //                     of the line (lane p = producer p) until every word reached it.  ~4 % slower (289 vs 278 us).
 // Epochs count steps from 1; the header is zeroed before every launch.
-constexpr int kSyncHeaderBytes = 8192;    // status word at byte 128, flag lines (32 groups x 128 B) from byte 256
+constexpr int kSyncHeaderBytes = 8192;    // sticky timeout count at byte 0, status word at byte 128, flag lines (32 groups x 128 B) from byte 256
+constexpr int kStickyBack = 32;           // words from the status word back to the sticky counter
+constexpr int kSyncKeepWords = 16;        // the first 64 bytes of the header survive the per-launch zeroing
 #ifndef VLN_SYNC_FLAGS
 #define VLN_SYNC_FLAGS 0
 #endif
@@ -70,7 +72,11 @@ __device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned ep
 #endif
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 24)) {            // ~1 s: a workgroup of the group is not resident / died
-        if (lane == 0) { VLN_AGENT_STORE(status, 1u); *s_abort = 1; }
+        if (lane == 0) {
+          VLN_AGENT_STORE(status, 1u);           // this launch (zeroed with the header before the next one)
+          __hip_atomic_fetch_add(status - kStickyBack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: never zeroed by a launch
+          *s_abort = 1;
+        }
         break;
       }
     }

@@ -92,12 +92,15 @@ __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
   }
 }
 
-// dz = (dhtd * mask + dht_ext) * (1 - ht^2)      (dhtd [B,H] may still lie in split-K slabs)
-__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(SlabVec dhtd, const float* dht_ext, const float* ht,
+// dz = ((dhtd + dhtd2) * mask + dht_ext) * (1 - ht^2)      (dhtd [B,H] may still lie in split-K slabs; dhtd2 nullable:
+// the second consumer of the logits when the rollout-wide logit branch already covered the first)
+__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(SlabVec dhtd, const float* dhtd2, const float* dht_ext, const float* ht,
                                                             float* dz, int B, int H, DropSpec d) {
   const long n = (long)B * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float g = dhtd.at(i / H, i % H) * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
+    float gs = dhtd.at(i / H, i % H);
+    if (dhtd2) gs += dhtd2[i];
+    float g = gs * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
     if (dht_ext) g += dht_ext[i];
     const float h = ht[i];
     dz[i] = g * (1.f - h * h);
@@ -238,7 +241,17 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
   SlabVec dhtd{ws.s3, H, 1, (long)B * H};
-  if (g->dhtd_ext) {            // the logit branch of the whole rollout was formed up front (vln_rows_wsum_multi + one GEMM)
+  const float* dhtd2 = nullptr;
+  if (g->dhtd_ext && g->dlogit) {
+    // The rollout-wide logit branch (losses.RolloutCE -> logit_branch_backward) covered ITS d logits; `dlogit` is what the
+    // OTHER consumers of the same logits sent (sampled log-probs / entropy, a per-step loss, envdrop.py:173-195): their
+    // branch runs here and is added -- to the d(cand query) rows of the stash (d cand_attn.weight) and to d drop(h_tilde).
+    RUN(rows_wsum(st, cand, d->ctype, g->dlogit, ws.s1, F, B, d->C, F));
+    RUN(add_inplace(st, g->s_dtc, F, ws.s1, F, B, F));
+    RUN(gemm_nt(st, ws.s1, F, w->w_c_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+    dhtd.n = n3;
+    dhtd2 = g->dhtd_ext;
+  } else if (g->dhtd_ext) {     // the logit branch of the whole rollout was formed up front (vln_rows_wsum_multi + one GEMM)
     dhtd = SlabVec{g->dhtd_ext, H, 1, (long)B * H};
   } else if (g->dlogit) {
     RUN(rows_wsum(st, cand, d->ctype, g->dlogit, g->s_dtc, F, B, d->C, F));
@@ -249,7 +262,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(fill_f32(st, ws.s3, (long)B * H, 0.f));
   }
   // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
-  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, dhtd, g->dh_tilde,
+  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, dhtd, dhtd2, g->dh_tilde,
                      io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop));
   VLN_CHECK_LAUNCH("tanh_drop_bwd");
   // (5') linear_out -> [d weighted ctx | d drop(h1)], still in slabs (s4)
@@ -312,7 +325,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   }
   static StepKey key;                     // zero-initialised once: padding bytes stay zero, fields are overwritten
   static std::mutex mu;
-  static GraphCache cache(64);
+  static GraphCache cache;
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.bwd = 0;
   if (!io->offset_base_dev) key.io.offset = 0;      // per-step word: the value is not a launch argument
@@ -329,7 +342,7 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g);
   static StepKey key;
   static std::mutex mu;
-  static GraphCache cache(64);
+  static GraphCache cache;
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.g = *g; key.bwd = 1;
   if (!io->offset_base_dev) key.io.offset = 0;

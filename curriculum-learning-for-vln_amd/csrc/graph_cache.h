@@ -6,11 +6,12 @@
 // into a hipGraph and later calls with the SAME block replay it with one hipGraphLaunch (~10-16 us).  PyTorch's
 // caching allocator hands back the same addresses every training iteration, so the steady state always hits.
 // Anything that varies per call but is not an address (dropout offsets) must live in device memory, not in the
-// key.  If a chain keeps missing (addresses never repeat) graphs are switched off for that chain and it
-// falls back to plain launches -- results are identical either way.
+// key.  If a chain never hits (2 x cap captures without one replay) capturing is PAUSED for that chain for a while and it
+// runs as plain launches -- results are identical either way; vln_graph_stats()[2] counts the pauses.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <list>
 #include <mutex>
@@ -26,46 +27,67 @@ extern long long g_graph_stats[3];   // replays, captures, chains switched off (
 
 class GraphCache {
  public:
-  explicit GraphCache(size_t cap = 48) : cap_(cap) {}
+  // cap: graphs kept (LRU).  A rollout keeps 2 arena generations x steps x (forward + backward) blocks alive: the reference's
+  // sampled rollouts run up to MAX_EPISODE_LEN = 35 steps beside a 7-step teacher rollout (2 x 42 x 2 = 168), hence 512.
+  explicit GraphCache(size_t cap = 512) : cap_(cap) {}
 
   // key: raw bytes of the argument block.  issue(stream) enqueues the chain and returns a VLN status.
   template <typename F>
   int run(hipStream_t st, const void* key, size_t key_bytes, F&& issue) {
-    if (!g_graphs_enabled || g_prof_mask || disabled_) return issue(st);
+    if (!g_graphs_enabled || g_prof_mask) return issue(st);
     std::lock_guard<std::mutex> lock(mu_);
+    ++calls_;
+    if (calls_ < paused_until_) return issue(st);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return issue(st);
-    std::string k(reinterpret_cast<const char*>(key), key_bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return issue(st); }
+    std::string k(reinterpret_cast<const char*>(&dev), sizeof(dev));   // an argument block is only meaningful on its device
+    k.append(reinterpret_cast<const char*>(key), key_bytes);
     auto it = map_.find(k);
     if (it != map_.end()) {
       lru_.splice(lru_.begin(), lru_, it->second.second);
-      misses_in_a_row_ = 0;
+      captures_since_hit_ = 0;
+      pause_ = kPause;
       ++g_graph_stats[0];
       if (hipGraphLaunch(it->second.first, st) == hipSuccess) return 0;
       (void)hipGetLastError();
       return issue(st);
     }
-    if (++misses_in_a_row_ > 24) {   // addresses never repeat: stop paying for captures
-      disabled_ = true;
+    // Giving up needs EVIDENCE that argument blocks never come back: two arena generations of any rollout length are all
+    // misses by construction, so "a few misses in a row" proves nothing (the old rule switched a 13-step rollout's graphs
+    // off for good before their first possible hit).  Only after 2 x cap captures without a single replay -- every entry
+    // of the LRU was evicted unused, twice over -- does the chain run un-captured, and only for a while: the pause ends
+    // after a number of calls (kPause, x4 per failed retry) and the cache tries again (a caller may have switched to address-stable buffers meanwhile).
+    if (++captures_since_hit_ > 2 * cap_) {
+      paused_until_ = calls_ + pause_;
+      if (pause_ < (1ull << 22)) pause_ *= 4;        // back off: a chain that keeps failing the retry pays for it ever less often
+      captures_since_hit_ = 0;
       ++g_graph_stats[2];
+      if (!warned_) {
+        warned_ = true;
+        fprintf(stderr, "[vln] hipGraph replay paused for a launch chain: %zu captures without one replay (argument blocks do not "
+                        "repeat -- per-iteration buffers need stable addresses, see ops.RolloutArena); retrying later\n", 2 * cap_);
+      }
       return issue(st);
     }
     // Capture on a PRIVATE stream: the caller's stream is usually PyTorch's current stream = the legacy default
     // stream, which cannot be captured.  The chain is only recorded there (nothing executes); the instantiated
     // graph is then launched into the caller's stream.
-    if (cs_ == nullptr && hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) {
+    hipStream_t& cst = cs_[dev];
+    if (cst == nullptr && hipStreamCreateWithFlags(&cst, hipStreamNonBlocking) != hipSuccess) {
       (void)hipGetLastError();
-      cs_ = nullptr;
+      cst = nullptr;
       return issue(st);
     }
-    if (hipStreamBeginCapture(cs_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (hipStreamBeginCapture(cst, hipStreamCaptureModeThreadLocal) != hipSuccess) {
       (void)hipGetLastError();
       return issue(st);
     }
     ++g_graph_stats[1];
-    int rc = issue(cs_);
+    int rc = issue(cst);
     hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(cs_, &g);
+    hipError_t e = hipStreamEndCapture(cst, &g);
     if (rc != 0 || e != hipSuccess || g == nullptr) {
       if (g) (void)hipGraphDestroy(g);
       (void)hipGetLastError();
@@ -97,11 +119,14 @@ class GraphCache {
   }
 
  private:
+  static constexpr int kMaxDev = 16;
+  static constexpr unsigned long long kPause = 4096;
   std::mutex mu_;
   size_t cap_;
-  hipStream_t cs_ = nullptr;   // capture-only stream
-  bool disabled_ = false;
-  int misses_in_a_row_ = 0;
+  hipStream_t cs_[kMaxDev] = {};   // capture-only streams, one per device
+  unsigned long long calls_ = 0, paused_until_ = 0, pause_ = kPause;
+  size_t captures_since_hit_ = 0;
+  bool warned_ = false;
   std::list<std::string> lru_;
   std::unordered_map<std::string, std::pair<hipGraphExec_t, std::list<std::string>::iterator>> map_;
 };

@@ -58,7 +58,8 @@ enum OptMode { OPT_RMSPROP = 0, OPT_ADAM = 1, OPT_SGD = 2 };
 struct OptHyper {
   float lr, a, b, eps;          // rmsprop: a = alpha; adam: a = beta1, b = beta2
   float bc1, bc2_rsqrt;         // adam bias corrections: 1 - beta1^t, 1 / sqrt(1 - beta2^t)
-  float max_norm, grad_scale;
+  float grad_scale;
+  float max_norm[8];              // per clip group; 0 = that group is not clipped (trainer.py:425-426 clips encoder and decoder, not the critic)
 };
 
 template <int MODE>
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g,
   s = block_sum(s, sh);
   if (threadIdx.x == 0) {
     const float norm = sqrtf(s) * h.grad_scale;
-    float c = (h.max_norm > 0.f) ? h.max_norm / (norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
+    float c = (h.max_norm[grp] > 0.f) ? h.max_norm[grp] / (norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
     s_coef = h.grad_scale * (c < 1.f ? c : 1.f);
     if (norms_out && (int)blockIdx.x == gr.blk0[grp]) norms_out[grp] = norm;
   }
@@ -125,12 +126,14 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g,
 }
 
 static int opt_launch(int mode, float* params, const float* grads, float* s1, float* s2, const int64_t* group_begin,
-                      int ngroups, float* partial, float* norms_out, OptHyper h, hipStream_t st, const char* what) {
+                      int ngroups, float* partial, float* norms_out, OptHyper h, const float* max_norms, hipStream_t st,
+                      const char* what) {
   if (!params || !grads || !group_begin || !partial || ngroups < 1 || ngroups > 8 || (mode != OPT_SGD && !s1) ||
       (mode == OPT_ADAM && !s2)) {
     set_error("%s: bad args", what);
     return VLN_ERR_ARG;
   }
+  for (int g = 0; g < 8; ++g) h.max_norm[g] = (max_norms && g < ngroups) ? max_norms[g] : 0.f;
   OptGroups gr;
   gr.ngroups = ngroups;
   int blk = 0;
@@ -156,7 +159,8 @@ static int opt_launch(int mode, float* params, const float* grads, float* s1, fl
 
 using namespace vln;
 
-// group_begin: ngroups+1 element offsets (multiples of 4) into the flat buffers; partial: >= total blocks floats
+// group_begin: ngroups+1 element offsets (multiples of 4) into the flat buffers; partial: >= total blocks floats;
+// max_norms: HOST array of ngroups clip norms (0 = group not clipped) or NULL (no clipping)
 extern "C" int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ngroups) {
   long blocks = 0;
   for (int g = 0; g < ngroups; ++g) blocks += (group_begin[g + 1] - group_begin[g] + kOptChunk - 1) / kOptChunk;
@@ -164,24 +168,24 @@ extern "C" int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ng
 }
 extern "C" int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin,
                                      int ngroups, float* partial, float* norms_out, float lr, float alpha, float eps,
-                                     float max_norm, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, max_norm, grad_scale};
+                                     const float* max_norms, float grad_scale, vln_stream_t s) {
+  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, grad_scale, {}};
   return opt_launch(OPT_RMSPROP, params, grads, square_avg, nullptr, group_begin, ngroups, partial, norms_out, h,
-                    (hipStream_t)s, "vln_rmsprop_clip_step");
+                    max_norms, (hipStream_t)s, "vln_rmsprop_clip_step");
 }
 extern "C" int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                   const int64_t* group_begin, int ngroups, float* partial, float* norms_out, float lr,
-                                  float beta1, float beta2, float eps, int64_t step, float max_norm, float grad_scale,
+                                  float beta1, float beta2, float eps, int64_t step, const float* max_norms, float grad_scale,
                                   vln_stream_t s) {
   if (step < 1) { set_error("vln_adam_clip_step: step counts from 1"); return VLN_ERR_ARG; }
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), max_norm, grad_scale};
+  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, {}};
   return opt_launch(OPT_ADAM, params, grads, exp_avg, exp_avg_sq, group_begin, ngroups, partial, norms_out, h,
-                    (hipStream_t)s, "vln_adam_clip_step");
+                    max_norms, (hipStream_t)s, "vln_adam_clip_step");
 }
 extern "C" int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
-                                 float* norms_out, float lr, float max_norm, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, max_norm, grad_scale};
-  return opt_launch(OPT_SGD, params, grads, nullptr, nullptr, group_begin, ngroups, partial, norms_out, h, (hipStream_t)s,
-                    "vln_sgd_clip_step");
+                                 float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s) {
+  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, {}};
+  return opt_launch(OPT_SGD, params, grads, nullptr, nullptr, group_begin, ngroups, partial, norms_out, h, max_norms,
+                    (hipStream_t)s, "vln_sgd_clip_step");
 }

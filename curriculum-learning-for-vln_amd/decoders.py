@@ -180,9 +180,11 @@ class _HipBatchNorm1d(nn.BatchNorm1d):
     ReLU that follows it in the BN-MLP."""
 
     def forward(self, x, relu=False):
+        _need_gpu(x, "BatchNorm1d")
         if x.dim() != 2 or x.dtype != torch.float32 or (x.shape[1] & 3) or self.momentum is None:
-            y = super().forward(x)                 # shapes the kernel does not take (never on the agents' path)
-            return torch.relu(y) if relu else y
+            # no torch fallback in the product path: the agents' BN-MLP only ever sees [rows, 4k] fp32 matrices
+            raise _lib.VlnError(f"BatchNorm1d: vln_bn_fwd takes fp32 [rows, features % 4 == 0] with a fixed momentum; got "
+                                f"{tuple(x.shape)} {x.dtype}, momentum={self.momentum}")
         return Fh.batch_norm(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                              self.running_var if self.track_running_stats else None,
                              self.num_batches_tracked if self.track_running_stats else None, self.training, self.momentum,

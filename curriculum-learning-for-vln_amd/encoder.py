@@ -322,4 +322,5 @@ class EncoderLSTM(nn.Module):
         lp, self._last_ctx_lp = self.__dict__.get("_last_ctx_lp"), None
         if lp is not None:
             ctx._vln_lp = lp          # picked up by the decoders instead of casting the context again (runtime._ctx_lp)
+        ops.stamp(ctx, dec_init, c_t)
         return ctx, dec_init, c_t

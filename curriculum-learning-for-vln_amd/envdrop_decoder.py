@@ -481,6 +481,15 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             if not (already_dropfeat and img_feature.dtype == self.compute_dtype == cand_feature.dtype):
                 raise TypeError("EnvDropDecoder: non-fp32 features need compute_dtype of that type and already_dropfeat=True")
             img_lp, cand_lp = img_feature, cand_feature
+        out = self._forward(a_t_prev, img_feature, cand_feature, h_tilde_prev, c_0, ctx, ctx_mask, already_dropfeat, img_lp, cand_lp)
+        if ops._arena is not None:         # generation stamps: a later module call refuses these once their memory is reused
+            ops.stamp(out[0], out[1][0], out[1][1], out[2])
+        return out
+
+    def _forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, c_0, ctx, ctx_mask, already_dropfeat, img_lp, cand_lp):
+        if ops._arena is not None:
+            ops.check_live(h_tilde_prev, "EnvDropDecoder(h_tilde_prev)"); ops.check_live(c_0, "EnvDropDecoder(c_0)")
+            ops.check_live(ctx, "EnvDropDecoder(ctx)")
         B, V, F = img_feature.shape
         Cn = cand_feature.shape[1]
         L = ctx.shape[1]
@@ -652,6 +661,7 @@ class Critic(nn.Module):
 
     def forward(self, state):
         self._calls += 1
+        ops.check_live(state, "Critic(state)")
         p = self.drop_ratio if self.training else 0.0
         l0, l3 = self.state2value[0], self.state2value[3]
         return _CriticFn.apply(state, l0.weight, l0.bias, l3.weight, l3.bias, p, self.dropout_seed, self._calls).squeeze()

@@ -18,6 +18,11 @@ _p = ops._p
 
 
 def _not_deferred(logits, who):
+    ops.check_live(logits, who)
+    return _not_deferred_(logits, who)
+
+
+def _not_deferred_(logits, who):
     """EnvDropDecoder.defer_logits leaves the logits unwritten until losses.RolloutCE forms them: anything of this module that
     would read them earlier says so instead of computing on uninitialised memory."""
     rec = getattr(logits, "_vln_rec", None)
@@ -159,7 +164,11 @@ class _RolloutCE(torch.autograd.Function):
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
         if batched:
+            # the decoder's rollout-wide branch consumes these d logits here and now: autograd gets None for them, so whatever
+            # still reaches a step's backward as `dlogit` comes from OTHER consumers of the same logits (sampled log-probs,
+            # entropy, a per-step loss) and is added there (envdrop.hip step_bwd_issue) -- nothing is dropped or counted twice
             mod.logit_branch_backward(list(zip(recs, outs)))
+            return (None,) * (T + 1)
         return (None, *outs)
 
 
@@ -177,6 +186,7 @@ class RolloutCE:
     def add(self, logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor] = None):
         if logits.dim() != 2 or (self.logits and logits.shape[0] != self.logits[0].shape[0]):
             raise ValueError("RolloutCE.add: logits must be [B, C] with the same B every step")
+        ops.check_live(logits, "RolloutCE.add")
         self.logits.append(logits); self.targets.append(target); self.masks.append(cand_mask)
 
     def sum(self, scale: float = 1.0) -> torch.Tensor:

@@ -57,19 +57,31 @@ class RolloutArena:
             arena.begin()          # top of every iteration
             ... rollout, backward, optimizer step ...
 
-    Contract: a tensor produced by the modules during iteration i is overwritten during iteration i + `generations`
-    (default 2); copy (`.clone()` / `.item()`) anything that must live longer.  A request whose shape or dtype differs
-    from the recorded sequence simply gets fresh memory (correct, but that step's graph will not replay)."""
+    Lifetime: a tensor produced by the modules during iteration i shares its memory with iteration i + `generations`
+    (default 2); copy (`.clone()` / `.item()`) anything that must live longer.  This is CHECKED, not only documented: every
+    tensor a module returns carries a generation stamp (`stamp`), and every module entry point that receives a tensor
+    (`check_live`: decoder states / ctx, critic input, loss logits) raises VlnError when the stamp says the memory has been
+    handed out again since -- e.g. a trainer that keeps `hidden_states` (envdrop.py:163) across iterations.  Tensors derived
+    by torch ops lose the stamp; `RolloutArena(poison=True)` (debugging) additionally fills every buffer with NaN right
+    before it is handed out again, so ANY late read shows.  A request whose shape or dtype differs from the recorded
+    sequence simply gets fresh memory (correct, but that step's graph will not replay)."""
 
-    def __init__(self, generations: int = 2):
+    def __init__(self, generations: int = 2, poison: bool = False):
         self.gens = [[] for _ in range(max(1, generations))]
         self.g = 0
         self.i = 0
         self.misses = 0
+        self.epoch = 0             # iterations begun: the generation stamp of everything handed out since
+        self.poison = bool(poison)
 
     def begin(self):
         self.g = (self.g + 1) % len(self.gens)
         self.i = 0
+        self.epoch += 1
+        if self.poison:
+            for t in self.gens[self.g]:
+                if t.is_floating_point():
+                    t.fill_(float("nan"))
 
     def get(self, shape, dtype, device, alias=True):
         lst = self.gens[self.g]
@@ -91,6 +103,27 @@ class RolloutArena:
         then reuses its own aliases of them and advances `i` by n itself)."""
         lst = self.gens[self.g]
         return self.i == i0 and i0 + n <= len(lst) and n > 0 and lst[i0].data_ptr() == first_ptr
+
+
+def stamp(*tensors):
+    """Mark module outputs that live in arena memory with the arena's current generation (no-op without an arena)."""
+    a = _arena
+    if a is not None:
+        mark = (a, a.epoch)
+        for t in tensors:
+            if t is not None:
+                t._vln_born = mark
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def check_live(t, who: str):
+    """Raise if `t` was produced under a RolloutArena whose memory has been handed out again since (see RolloutArena)."""
+    mark = getattr(t, "_vln_born", None)
+    if mark is not None:
+        a, born = mark
+        if a.epoch - born >= len(a.gens):
+            raise _lib.VlnError(f"{who}: this tensor was produced {a.epoch - born} iterations ago under ops.RolloutArena(generations="
+                                f"{len(a.gens)}); its memory has been handed out again -- clone() what must outlive an iteration")
 
 
 def set_arena(arena: Optional["RolloutArena"]):

@@ -23,13 +23,19 @@ class _FusedFlat:
     """Shared plumbing: flat parameter / gradient buffers, clip groups, overlapped all-reduce."""
     n_state = 0
 
-    def __init__(self, groups: Sequence[Sequence[torch.nn.Parameter]], lr: float, clip_norm: float = 0.0):
-        """groups: one parameter list per clip group (e.g. [encoder.parameters(), decoder.parameters()])."""
+    def __init__(self, groups: Sequence[Sequence[torch.nn.Parameter]], lr: float, clip_norm=0.0):
+        """groups: one parameter list per clip group (e.g. [encoder.parameters(), decoder.parameters()]).
+        clip_norm: one max-norm for every group, or one per group with 0 = that group is not clipped -- the reference clips
+        encoder and decoder at 40 and leaves the critic alone although all three share one RMSprop (trainer.py:380-381,
+        425-427): `FusedRMSprop([enc, dec, critic], clip_norm=[40, 40, 0])`.
+        The flat-buffer plumbing (views, zero_grad, the overlapped all-reduce) is device-agnostic -- the world-size-2 gloo
+        test drives it on CPU -- but `step()` is the HIP kernel: it raises on CPU parameters, there is no CPU update."""
         self.groups: List[List[torch.nn.Parameter]] = [[p for p in g if p.requires_grad] for g in groups]
-        self.lr, self.clip_norm = lr, clip_norm
+        if not 1 <= len(self.groups) <= 8:
+            raise ValueError("1..8 clip groups")
+        self.lr = lr
+        self.clip_norm = clip_norm
         first = self.groups[0][0]
-        if not first.is_cuda:
-            raise _lib.VlnError(f"{type(self).__name__}: parameters must be on the GPU")
         begins, off = [], 0
         for g in self.groups:
             off = (off + 3) // 4 * 4
@@ -55,8 +61,7 @@ class _FusedFlat:
                     p.grad = v
                     self.params.append(p); self.views.append(v)
                     o += n
-        lib = _lib.load()
-        nb = lib.vln_rmsprop_partial_floats(self._begins, len(self.groups))
+        nb = sum((begins[i + 1] - begins[i] + 4095) // 4096 for i in range(len(self.groups)))   # = vln_rmsprop_partial_floats
         self._partial = torch.empty(max(int(nb), 1), dtype=torch.float32, device=dev)
         self.norms = torch.zeros(len(self.groups), dtype=torch.float32, device=dev)
         self._reducer = BucketReducer(self.flat_g)
@@ -80,10 +85,28 @@ class _FusedFlat:
     def _launch(self, lib, grad_scale: float) -> int:
         raise NotImplementedError
 
+    @property
+    def clip_norm(self):
+        return self._clip
+
+    @clip_norm.setter
+    def clip_norm(self, v):
+        vals = [float(x) for x in v] if isinstance(v, (list, tuple)) else [float(v)] * len(self.groups)
+        if len(vals) != len(self.groups):
+            raise ValueError(f"clip_norm: {len(vals)} values for {len(self.groups)} groups")
+        self._clip = vals
+        self._clip_c = (C.c_float * len(vals))(*vals)
+
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
+        if not self.flat_p.is_cuda:
+            raise _lib.VlnError(f"{type(self).__name__}.step: parameters must be on the GPU; there is no CPU update")
         self.steps += 1
-        st = self._launch(_lib.load(), grad_scale)
+        lib = _lib.load()
+        st = lib.vln_persistent_check()         # a timed-out persistent recurrence in this iteration: do not train on its numbers
+        if st:
+            _lib.check(st, "vln_persistent_check")
+        st = self._launch(lib, grad_scale)
         if st:
             _lib.check(st, type(self).__name__ + ".step")
         for p in self.params:                       # in-place update outside autograd: tell version-keyed caches
@@ -94,7 +117,7 @@ class FusedRMSprop(_FusedFlat):
     """torch.optim.RMSprop(params, lr) with torch defaults (alpha 0.99, eps 1e-8, no momentum, not centered)."""
     n_state = 1
 
-    def __init__(self, groups, lr: float = 1e-2, alpha: float = 0.99, eps: float = 1e-8, clip_norm: float = 0.0):
+    def __init__(self, groups, lr: float = 1e-2, alpha: float = 0.99, eps: float = 1e-8, clip_norm=0.0):
         super().__init__(groups, lr, clip_norm)
         self.alpha, self.eps = alpha, eps
         self.sq = self.state[0]
@@ -102,14 +125,14 @@ class FusedRMSprop(_FusedFlat):
     def _launch(self, lib, grad_scale):
         return lib.vln_rmsprop_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.sq.data_ptr(), self._begins,
                                          len(self.groups), self._partial.data_ptr(), self.norms.data_ptr(), self.lr, self.alpha,
-                                         self.eps, self.clip_norm, grad_scale, _lib.raw_stream())
+                                         self.eps, self._clip_c, grad_scale, _lib.raw_stream())
 
 
 class FusedAdam(_FusedFlat):
     """torch.optim.Adam(params, lr) with torch defaults (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad)."""
     n_state = 2
 
-    def __init__(self, groups, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, clip_norm: float = 0.0):
+    def __init__(self, groups, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, clip_norm=0.0):
         super().__init__(groups, lr, clip_norm)
         self.betas, self.eps = betas, eps
         self.exp_avg, self.exp_avg_sq = self.state
@@ -118,19 +141,19 @@ class FusedAdam(_FusedFlat):
         return lib.vln_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), self._begins, len(self.groups), self._partial.data_ptr(),
                                       self.norms.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
-                                      self.clip_norm, grad_scale, _lib.raw_stream())
+                                      self._clip_c, grad_scale, _lib.raw_stream())
 
 
 class FusedSGD(_FusedFlat):
     """torch.optim.SGD(params, lr) with torch defaults (no momentum, no weight decay)."""
     n_state = 0
 
-    def __init__(self, groups, lr: float = 1e-3, clip_norm: float = 0.0):
+    def __init__(self, groups, lr: float = 1e-3, clip_norm=0.0):
         super().__init__(groups, lr, clip_norm)
 
     def _launch(self, lib, grad_scale):
         return lib.vln_sgd_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self._begins, len(self.groups),
-                                     self._partial.data_ptr(), self.norms.data_ptr(), self.lr, self.clip_norm, grad_scale,
+                                     self._partial.data_ptr(), self.norms.data_ptr(), self.lr, self._clip_c, grad_scale,
                                      _lib.raw_stream())
 
 

@@ -37,7 +37,7 @@ const char* vln_last_error_string(void);
 /* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
  * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
 int vln_set_graphs(int on);
-/* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] chains switched off */
+/* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] times a chain's capturing was paused (2 x capacity captures without one replay) */
 int vln_graph_stats(int64_t out[3]);
 /* performance / A-B tunables, ids 0..7 (never change results beyond summation order; documented in
  * csrc/vln_internal.h): 0 = gemm split-K workgroup target (256), 1 = keep wide shallow fused-epilogue products unsplit,
@@ -165,21 +165,22 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
 
-/* ---- optimizer step over flat buffers (engine/trainer.py:380-381,423-427): per-group clip_grad_norm (max_norm, torch
- * semantics, 0 = off) + torch.optim.RMSprop update (alpha, eps, no momentum, not centered).  group_begin: ngroups+1
+/* ---- optimizer step over flat buffers (engine/trainer.py:380-381,423-427): per-group clip_grad_norm (max_norms: HOST array
+ * of ngroups norms, torch semantics, 0 = that group is not clipped -- the reference clips encoder and decoder at 40 and leaves
+ * the critic alone, trainer.py:425-426; NULL = no clipping) + torch.optim.RMSprop update (alpha, eps, no momentum, not centered).  group_begin: ngroups+1
  * element offsets (multiples of 4); partial: vln_rmsprop_partial_floats() floats of scratch; norms_out[ngroups] nullable;
  * grad_scale multiplies every gradient first (e.g. 1/world). */
 int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ngroups);
 int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin, int ngroups,
-                          float* partial, float* norms_out, float lr, float alpha, float eps, float max_norm, float grad_scale,
-                          vln_stream_t s);
+                          float* partial, float* norms_out, float lr, float alpha, float eps, const float* max_norms,
+                          float grad_scale, vln_stream_t s);
 /* Same contract for the other two entries of the reference's optim_switcher (trainer.py:17-21), torch defaults:
  * Adam (betas, eps, bias correction with step = 1, 2, ...; no weight decay / amsgrad) and plain SGD. */
 int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* group_begin,
                        int ngroups, float* partial, float* norms_out, float lr, float beta1, float beta2, float eps,
-                       int64_t step, float max_norm, float grad_scale, vln_stream_t s);
+                       int64_t step, const float* max_norms, float grad_scale, vln_stream_t s);
 int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
-                      float* norms_out, float lr, float max_norm, float grad_scale, vln_stream_t s);
+                      float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s);
 
 /* ---- loss / action-selection stage of the rollouts (follower.py:123-139, envdrop.py:173-195, monitor.py:146-176):
  * logits.masked_fill_(cand_mask, -inf) [in place when write_mask], CrossEntropyLoss(ignore_index, reduction="none"),
@@ -328,6 +329,11 @@ int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int3
                      back into it: vln_lstm_seq_bwd starts from the final states only) */,
                      void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 forces the per-step path; results are identical */
+/* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the
+ * device's CU count (queried).  If a wait still times out the kernels count it in a sticky word that every launch copies to
+ * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as
+ * VLN_ERR_HIP (the affected iteration's numbers are invalid) and switches the process to per-step launches. */
+int vln_persistent_check(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered */
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,

@@ -9,6 +9,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -33,3 +36,15 @@ def load_golden(name, dtype=None):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Achieved parity errors (worst tensor per test) go into the test log and into gpurun_out/parity_report.json."""
+    import parity
+    if not parity.RECORDS:
+        return
+    terminalreporter.section("achieved parity errors (max-abs relative to the tensor's max; tests/parity.py)")
+    for line in parity.summary_lines():
+        terminalreporter.write_line(line)
+    path = parity.write_report(ROOT)
+    terminalreporter.write_line(f"{len(parity.RECORDS)} comparisons -> {path}")

@@ -3,11 +3,13 @@
       reference state_dict with strict=True (checks key/shape compatibility),
   (b) the CPU oracle at BASELINE sizes with dropout ON, injecting the exact
       Philox masks the kernels used.
-Tolerances (north_star): fp32 1e-4, bf16 1e-2 (relative to the tensor's max)."""
+Tolerances (north_star): fp32 1e-4, bf16 1e-2 for outputs AND gradients (max-abs error relative to the tensor's
+max, tests/parity.py); the achieved errors are printed at the end of the run."""
 import pytest
 import torch
 
 from conftest import load_golden
+from parity import check, check_grads, rel_err, bf16_weights, bf16_round_st, FP32, BF16, SAME_BF16
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -18,28 +20,6 @@ def vln():
     import vln_amd
     vln_amd._lib.load()
     return vln_amd
-
-
-def rel_err(a, b):
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
-
-
-def rel_l2(a, b):
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
-
-
-def check(a, b, tol, what):
-    """fp32 (tol <= 1e-3): max-abs error relative to the tensor's max-abs.
-    bf16 (tol 1e-2): the parameters themselves are quantised to 8 mantissa bits, so the 1e-2 bound is on the
-    relative L2 error; the max-abs error (a 4-sigma event over ~1e5 elements) is bounded at 3x that."""
-    e = rel_err(a, b)
-    if tol >= 5e-3:
-        l2 = rel_l2(a, b)
-        assert l2 < tol and e < 3 * tol, f"{what}: rel L2 {l2:.3e} (tol {tol}), max-abs rel {e:.3e} (tol {3 * tol})"
-    else:
-        assert e < tol, f"{what}: rel err {e:.3e} >= {tol}"
 
 
 def dev(d):
@@ -61,7 +41,7 @@ def test_encoder_golden(vln, name):
     loss = (ctx * I["r1"]).sum() + (h * I["r2"]).sum() + (c * I["r3"]).sum()
     loss.backward()
     for n, p in enc.named_parameters():
-        check(p.grad, G["grad"][n], 2e-4, f"grad[{n}]")
+        check(p.grad, G["grad"][n], 1e-4, f"grad[{n}]")
 
 
 @pytest.mark.parametrize("name", ["envdrop_step", "envdrop_chain3"])
@@ -87,9 +67,9 @@ def test_envdrop_golden(vln, name):
     check(loss, G["out"]["loss"], 1e-4, "loss")
     loss.backward()
     for n, p in dec.named_parameters():
-        check(p.grad, G["grad"][n], 2e-4, f"grad[{n}]")
-    check(ctx.grad, G["grad"]["ctx"], 2e-4, "dctx")
-    check(ht0.grad, G["grad"]["h_tilde0"], 2e-4, "dh_tilde0"); check(c0.grad, G["grad"]["c0"], 2e-4, "dc0")
+        check(p.grad, G["grad"][n], 1e-4, f"grad[{n}]")
+    check(ctx.grad, G["grad"]["ctx"], 1e-4, "dctx")
+    check(ht0.grad, G["grad"]["h_tilde0"], 1e-4, "dh_tilde0"); check(c0.grad, G["grad"]["c0"], 1e-4, "dc0")
 
 
 def test_envdrop_inplace_logit_mask_and_stop(vln):
@@ -115,7 +95,7 @@ def test_envdrop_inplace_logit_mask_and_stop(vln):
     check(loss, ref, 1e-4, "ce loss")
     ref.backward()
     for n, p in dec.named_parameters():
-        check(p.grad, P[n].grad, 2e-4, f"grad[{n}]")
+        check(p.grad, P[n].grad, 1e-4, f"grad[{n}]")
 
 
 def test_no_grad_inference_path_matches_training_graph_path(vln):
@@ -181,7 +161,7 @@ def test_ragged_and_unaligned_shapes(vln, dtype):
             if ref.abs().max().item() < 1e-12:
                 assert p.grad.abs().max().item() < 1e-6, n
             else:
-                check(p.grad, ref, tol * 3, f"grad[{n}]")
+                check(p.grad, ref, tol, f"grad[{n}]")
 
 
 def test_critic_golden(vln):
@@ -194,11 +174,35 @@ def test_critic_golden(vln):
     check(v, G["out"]["value"], 1e-4, "value")
     (v * I["r"]).sum().backward()
     for n, p in cr.named_parameters():
-        check(p.grad, G["grad"][n], 2e-4, n)
-    check(s.grad, G["grad"]["state"], 2e-4, "dstate")
+        check(p.grad, G["grad"][n], 1e-4, n)
+    check(s.grad, G["grad"]["state"], 1e-4, "dstate")
 
 
-def _full_size_envdrop(vln, compute_dtype, tol, T=3, train=True):
+# bf16 vs the UNROUNDED fp64 oracle (north_star's 1e-2): what exceeds it, measured (gpurun_out/parity_report.json), and why --
+# every weight carries a 2^-9 relative rounding; the visual attention's logits (K = 2176 products of magnitude ~1 each, then a
+# softmax over 36 views) and the LSTM gates (K = 2752) turn that into ~1e-2 of the state's range after one step.  The
+# same-weights oracle (the kernels' arithmetic itself) is met at 1e-4 for every tensor.
+ENVDROP_BF16_EXC = {"h1_": 3e-2, "h_tilde": 2e-2, "logit": 2e-2, "dh_tilde0": 5e-2, "dc0": 3e-2, "dctx": 2e-2,
+                    "grad[visual_attn.linear_in.weight]": 4e-2, "grad[": 2e-2}
+ENCODER_BF16_EXC = {"grad[": 2e-2}
+
+
+def _tol_for(exc, tol, what):
+    for k, v in (exc or {}).items():
+        if what == k or what.startswith(k):
+            return v
+    return tol
+
+
+def _variants(compute_dtype, exc):
+    """[(name, tolerance, same-weights?, exceptions)]: fp32 = one oracle at 1e-4; bf16 = the oracle on the bf16-rounded
+    weights the kernels stream at SAME_BF16, and the oracle on the unrounded masters at north_star's 1e-2 (tests/parity.py)."""
+    if compute_dtype == torch.float32:
+        return [("fp32", FP32, False, None)]
+    return [("bf16 same-weights", SAME_BF16, True, None), ("bf16 unrounded", BF16, False, exc)]
+
+
+def _full_size_envdrop(vln, compute_dtype, T=3, train=True):
     from oracle import torch_port as O
     B, L, V, C, H, IMG, ANG, AE = 64, 80, 36, 8, 512, 2048, 128, 64
     F = IMG + ANG
@@ -206,15 +210,19 @@ def _full_size_envdrop(vln, compute_dtype, tol, T=3, train=True):
     torch.manual_seed(2020)          # default parameter init comes from the global RNG: pin it (test-order independent)
     dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=compute_dtype).to(DEV)
     dec.train(train)
-    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()}
     ctx = (torch.randn(B, L, H, generator=g) * 0.5)
     lens = torch.randint(8, L + 1, (B,), generator=g); lens[0] = L
     ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
     ht = torch.tanh(torch.randn(B, H, generator=g)); c = torch.randn(B, H, generator=g) * 0.5
     ctx_d = ctx.to(DEV).requires_grad_(True); ht_d = ht.to(DEV).requires_grad_(True); c_d = c.to(DEV).requires_grad_(True)
-    ctx_o = ctx.double().requires_grad_(True); ht_o = ht.double().requires_grad_(True); c_o = c.double().requires_grad_(True)
-    hd, cd, ho, co = ht_d, c_d, ht_o, c_o
-    loss_d, loss_o = 0., 0.
+    V_ = []
+    for name, tol, same, exc in _variants(compute_dtype, ENVDROP_BF16_EXC):
+        V_.append(dict(name=name, tol=tol, same=same, exc=exc, loss=0.,
+                       P={k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()},
+                       ctx=ctx.double().requires_grad_(True), ht=ht.double().requires_grad_(True), c=c.double().requires_grad_(True)))
+        V_[-1]["state"] = (V_[-1]["ht"], V_[-1]["c"])
+    hd, cd = ht_d, c_d
+    loss_d = 0.
     p, pf = (0.5, 0.3) if train else (0.0, 0.0)
     for t in range(T):
         a = torch.sin(torch.randn(B, ANG, generator=g) * 3)
@@ -233,45 +241,54 @@ def _full_size_envdrop(vln, compute_dtype, tol, T=3, train=True):
         cand_o = O.feature_dropout(cand.double(), m(5, B * C * IMG, pf).view(B, C, IMG), ANG)
         # in-place contract: the caller's tensors now hold the dropped features
         check(img_d, img_o, 1e-6, "img in place"); check(cand_d, cand_o, 1e-6, "cand in place")
-        if compute_dtype == torch.bfloat16:
+        if compute_dtype == torch.bfloat16:       # the features are DATA: both bf16 oracles see the rounded rows the kernels stream
             img_o = img_o.float().bfloat16().double(); cand_o = cand_o.float().bfloat16().double()
-        lo, (h1o, co), ho, _ = O.envdrop_step(P, a.double(), img_o, cand_o, ho, co, ctx_o, ctx_mask, drop=drop)
-        check(logit, lo, tol, f"logit{t}"); check(h1, h1o, tol, f"h1_{t}"); check(hd, ho, tol, f"h_tilde{t}")
         rl = torch.randn(B, C, generator=g)
         loss_d = loss_d + (logit * rl.to(DEV)).sum() + h1.sum() * 0.01
-        loss_o = loss_o + (lo * rl.double()).sum() + h1o.sum() * 0.01
+        for v in V_:
+            ho, co = v["state"]
+            Pv = bf16_weights(v["P"], skip=("act_embed.0.weight",)) if v["same"] else v["P"]   # the 128 -> 64 embedding runs in fp32
+            cx = bf16_round_st(v["ctx"]) if v["same"] else v["ctx"]          # the text attention streams a bf16 copy of ctx
+            lo, (h1o, co), ho, _ = O.envdrop_step(Pv, a.double(), img_o, cand_o, ho, co, cx, ctx_mask, drop=drop)
+            v["state"] = (ho, co)
+            for got, ref, what in ((logit, lo, f"logit{t}"), (h1, h1o, f"h1_{t}"), (hd, ho, f"h_tilde{t}")):
+                check(got, ref, _tol_for(v["exc"], v["tol"], what), f"{v['name']}: {what}")
+            v["loss"] = v["loss"] + (lo * rl.double()).sum() + h1o.sum() * 0.01
     loss_d = loss_d + hd.sum() * 0.1 + cd.sum() * 0.1
-    loss_o = loss_o + ho.sum() * 0.1 + co.sum() * 0.1
-    loss_d.backward(); loss_o.backward()
-    gt = tol * 3
-    for n, prm in dec.named_parameters():
-        check(prm.grad, P[n].grad, gt, f"grad[{n}]")
-    check(ctx_d.grad, ctx_o.grad, gt, "dctx"); check(ht_d.grad, ht_o.grad, gt, "dh_tilde0"); check(c_d.grad, c_o.grad, gt, "dc0")
+    loss_d.backward()
+    for v in V_:
+        ho, co = v["state"]
+        (v["loss"] + ho.sum() * 0.1 + co.sum() * 0.1).backward()
+        gmax = max(float(q.grad.abs().max()) for q in v["P"].values() if q.grad is not None)
+        for n, prm in dec.named_parameters():
+            check(prm.grad, v["P"][n].grad, _tol_for(v["exc"], v["tol"], f"grad[{n}]"), f"{v['name']}: grad[{n}]", floor=1e-2 * gmax)
+        for got, ref, what in ((ctx_d.grad, v["ctx"].grad, "dctx"), (ht_d.grad, v["ht"].grad, "dh_tilde0"), (c_d.grad, v["c"].grad, "dc0")):
+            check(got, ref, _tol_for(v["exc"], v["tol"], what), f"{v['name']}: {what}")
 
 
 def test_envdrop_full_size_fp32_dropout_on(vln):
-    _full_size_envdrop(vln, torch.float32, 1e-4)
+    _full_size_envdrop(vln, torch.float32)
 
 
 def test_envdrop_full_size_fp32_eval(vln):
-    _full_size_envdrop(vln, torch.float32, 1e-4, train=False)
+    _full_size_envdrop(vln, torch.float32, train=False)
 
 
 def test_envdrop_full_size_bf16(vln):
-    """bf16-streamed weights/features/context, fp32 accumulate, vs the fp64 oracle on the UNROUNDED
-    parameters: north_star's 1e-2."""
-    _full_size_envdrop(vln, torch.bfloat16, 1e-2)
+    """bf16-streamed weights / features / context, fp32 accumulate, dropout on: vs the fp64 oracle on the SAME rounded weights
+    (1e-4) and vs the fp64 oracle on the UNROUNDED parameters (north_star's 1e-2, exceptions listed in ENVDROP_BF16_EXC)."""
+    _full_size_envdrop(vln, torch.bfloat16)
 
 
 def test_encoder_full_size_bf16(vln):
-    _encoder_full(vln, torch.bfloat16, 1e-2)
+    _encoder_full(vln, torch.bfloat16)
 
 
 def test_encoder_full_size(vln):
-    _encoder_full(vln, torch.float32, 1e-4)
+    _encoder_full(vln, torch.float32)
 
 
-def _encoder_full(vln, compute_dtype, tol):
+def _encoder_full(vln, compute_dtype):
     from oracle import torch_port as O
     B, L, E, H, vocab = 64, 80, 256, 512, 992
     g = torch.Generator().manual_seed(7)
@@ -282,14 +299,18 @@ def _encoder_full(vln, compute_dtype, tol):
     for i, n in enumerate(lens.tolist()):
         tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
     ctx, h, c = enc(tokens.to(DEV), lens)
-    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in enc.state_dict().items()}
-    co, ho, cco = O.encoder_forward(P, tokens, lens.tolist(), num_layers=1, bidirectional=True)
-    check(ctx, co, tol, "ctx"); check(h, ho, tol, "h"); check(c, cco, tol, "c")
     r1, r2 = torch.randn(B, L, H, generator=g), torch.randn(B, H, generator=g)
     ((ctx * r1.to(DEV)).sum() + (h * r2.to(DEV)).sum() + c.sum()).backward()
-    ((co * r1.double()).sum() + (ho * r2.double()).sum() + cco.sum()).backward()
-    for n, prm in enc.named_parameters():
-        check(prm.grad, P[n].grad, tol * 3, f"grad[{n}]")
+    for name, tol, same, exc in _variants(compute_dtype, ENCODER_BF16_EXC):
+        P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in enc.state_dict().items()}
+        Pv = bf16_weights(P, skip=("embedding.weight",)) if same else P        # embedding rows are gathered in fp32
+        co, ho, cco = O.encoder_forward(Pv, tokens, lens.tolist(), num_layers=1, bidirectional=True)
+        for got, ref, what in ((ctx, co, "ctx"), (h, ho, "h"), (c, cco, "c")):
+            check(got, ref, _tol_for(exc, tol, what), f"{name}: {what}")
+        ((co * r1.double()).sum() + (ho * r2.double()).sum() + cco.sum()).backward()
+        gmax = max(float(q.grad.abs().max()) for q in P.values() if q.grad is not None)
+        for n, prm in enc.named_parameters():
+            check(prm.grad, P[n].grad, _tol_for(exc, tol, f"grad[{n}]"), f"{name}: grad[{n}]", floor=1e-2 * gmax)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -604,8 +625,103 @@ def test_per_sample_rollout_loss_through_the_decoder(vln):
         torch.dot(w, vec).backward()
         res.append((vec.detach().clone(), {n: p.grad.detach().clone() for n, p in dec.named_parameters()}, ctx.grad.clone()))
     check(res[0][0], res[1][0], 1e-5, "per-episode losses")
-    check(res[0][2], res[1][2], 2e-4, "d ctx")
+    check(res[0][2], res[1][2], 1e-4, "d ctx")
     scale = max(v.abs().max().item() for v in res[1][1].values())
     for n in res[0][1]:
         err = (res[0][1][n].double() - res[1][1][n].double()).abs().max().item()
         assert err <= 2e-5 * max(res[1][1][n].abs().max().item(), 1e-3 * scale), (n, err)
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_rollout_ce_and_sampled_log_probs_share_the_logits(vln, per_sample):
+    """Two differentiable consumers of the SAME logits (the ML loss and the sampled actions' log-probs / entropies,
+    envdrop.py:173-195): with the rollout-wide logit branch (batch_logit_backward, the default) the second consumer's gradient
+    used to be dropped silently (round-1 advisor finding).  Every gradient must equal the per-step configuration."""
+    B, L, V, Cn, H, F = 12, 9, 36, 5, 64, 256 + 128
+    g = torch.Generator().manual_seed(51)
+    ctx0 = torch.randn(B, L, H, generator=g).to(DEV)
+    h = torch.randn(B, H, generator=g).to(DEV); c = torch.randn(B, H, generator=g).to(DEV)
+    a = torch.randn(B, 128, generator=g).to(DEV)
+    steps = []
+    for t in range(3):
+        cand = torch.randn(B, Cn, F, generator=g).abs(); cand[:, -1] = 0
+        steps.append((torch.randn(B, V, F, generator=g).abs().to(DEV), cand.to(DEV), torch.randint(0, Cn, (B,), generator=g).to(DEV),
+                      torch.randint(0, Cn, (B,), generator=g).to(DEV)))
+    w = torch.rand(B, generator=g).to(DEV)
+    res = []
+    for batched in (True, False):
+        torch.manual_seed(6)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+        dec.batch_logit_backward = batched
+        ctx = ctx0.clone().requires_grad_(True)
+        hh, cc, ht = h.clone().requires_grad_(True), c.clone(), h.clone()
+        ce = vln.losses.RolloutCE()
+        rl = 0.0
+        for img, cand, tgt, act in steps:
+            lg, (hh, cc), ht = dec(a, img.clone(), cand.clone(), ht, hh, cc, ctx)
+            ce.add(lg, tgt)
+            _, logp, ent = vln.losses.sample_action(lg, None, action=act)
+            rl = rl + (-(logp * 0.7).sum() - 0.01 * ent.sum())
+        ml = torch.dot(w, ce.per_sample(scale=0.2)) if per_sample else ce.sum(scale=0.2)
+        (ml + rl).backward()
+        res.append(({n: p.grad.detach().clone() for n, p in dec.named_parameters()}, ctx.grad.clone()))
+    check(res[0][1], res[1][1], 1e-5, "d ctx")
+    scale = max(v.abs().max().item() for v in res[1][0].values())
+    for n in res[0][0]:
+        check(res[0][0][n], res[1][0][n], 2e-5, f"grad[{n}]", floor=1e-3 * scale)
+
+
+def test_long_rollouts_replay_their_step_graphs(vln):
+    """T = 20 decoder steps per iteration (the reference's sampled rollouts run up to MAX_EPISODE_LEN = 35): the graph cache
+    used to switch itself off for good after 24 misses in a row -- i.e. inside the first two (all-miss by construction)
+    arena generations -- before the first possible hit.  Iterations 3.. must replay every step, forward and backward."""
+    import ctypes
+    import bench
+    dev_ = torch.device(DEV)
+    T = 20
+    tape = bench.tape_to(bench.make_tape(8, 12, T, 5, seed=12), dev_, store_dtype=torch.bfloat16)
+    lib = vln._lib.load()
+    ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+    st = [(ctypes.c_int64 * 3)() for _ in range(3)]
+    lib.vln_graph_stats(st[0])
+    for _ in range(2):
+        ag.iteration(tape)
+    torch.cuda.synchronize()
+    lib.vln_graph_stats(st[1])
+    for _ in range(3):
+        ag.iteration(tape)
+    torch.cuda.synchronize()
+    lib.vln_graph_stats(st[2])
+    assert st[2][0] - st[1][0] >= 3 * 2 * T, (list(st[1]), list(st[2]))      # replays: 3 iterations x (fwd + bwd) x T steps
+    assert st[2][1] == st[1][1]                                                # no further captures
+    assert st[2][2] == st[0][2]                                                # capturing was never paused
+
+
+def test_arena_refuses_tensors_whose_memory_was_recycled(vln):
+    """ops.RolloutArena lifetime (a tensor of iteration i shares memory with iteration i + 2) is enforced, not only documented:
+    a module that is handed a stamped tensor from 2+ iterations ago raises; within the window it works."""
+    B, L, V, Cn, H, F = 4, 6, 36, 3, 64, 256 + 128
+    g = torch.Generator().manual_seed(61)
+    dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+    cri = vln.Critic(H, 0.5).to(DEV).eval()
+    ctx = torch.randn(B, L, H, generator=g).to(DEV); h = torch.randn(B, H, generator=g).to(DEV); c = torch.randn(B, H, generator=g).to(DEV)
+    a = torch.randn(B, 128, generator=g).to(DEV)
+    img = torch.randn(B, V, F, generator=g).abs().to(DEV); cand = torch.randn(B, Cn, F, generator=g).abs().to(DEV)
+    arena = vln.ops.RolloutArena()
+    vln.ops.set_arena(arena)
+    try:
+        kept = []
+        for it in range(3):
+            arena.begin()
+            with torch.no_grad():
+                lg, (h1, c1), ht = dec(a, img.clone(), cand.clone(), h, h, c, ctx)
+            kept.append(h1)
+            cri(kept[-1])                                  # same iteration: fine
+            if it >= 1:
+                cri(kept[-2])                              # previous iteration: still its own memory
+        with pytest.raises(vln.VlnError):
+            cri(kept[0])                                   # two iterations old: recycled
+        with pytest.raises(vln.VlnError):
+            dec(a, img.clone(), cand.clone(), kept[0], h, c, ctx)
+    finally:
+        vln.ops.set_arena(None)

@@ -18,9 +18,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def rel_err(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
-    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+from parity import check, rel_err
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 2048, 2752), (64, 2176, 512), (64, 512, 1024), (4, 48, 40), (7, 1, 64),
@@ -34,7 +32,7 @@ def test_linear_fwd(vln, M, N, K, wdt):
     # bf16 path: only the streamed weight is bf16; x is split hi+lo so it is exact to ~2^-17
     y = vln.ops.linear_fwd(x.to(dev()), wq.to(dev()), b.to(dev()), vln.ops.ACT_TANH)
     tol = 1e-4 if wdt == torch.float32 else 2e-4
-    assert rel_err(y, ref) < tol
+    check(y, ref, tol, "y")
 
 
 def test_linear_fwd_strided_x(vln):
@@ -43,7 +41,7 @@ def test_linear_fwd_strided_x(vln):
     x = big[:, 44:44 + 128]
     w = torch.randn(96, 128, generator=g).to(dev())
     y = vln.ops.linear_fwd(x, w)
-    assert rel_err(y, x.double() @ w.double().t()) < 1e-4
+    check(y, x.double() @ w.double().t(), 1e-4, "y")
 
 
 @pytest.mark.parametrize("Mt,N,K", [(384, 2048, 2752), (64, 512, 512), (100, 48, 40), (5120, 96, 72), (3, 1, 5), (448, 2176, 512),
@@ -53,16 +51,16 @@ def test_linear_wgrad(vln, Mt, N, K):
     dy = torch.randn(Mt, N, generator=g); x = torch.randn(Mt, K, generator=g)
     ref = dy.double().t() @ x.double()
     out = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()))
-    assert rel_err(out, ref) < 1e-4
+    check(out, ref, 1e-4, "out")
     out2 = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=out, accumulate=True)
-    assert rel_err(out2, 2 * ref) < 1e-4
+    check(out2, 2 * ref, 1e-4, "out2")
     cs = vln.ops.colsum(dy.to(dev()))
-    assert rel_err(cs, dy.double().sum(0)) < 1e-4
+    check(cs, dy.double().sum(0), 1e-4, "cs")
     # split-bf16 form (bf16 compute mode): hi + lo planes of both operands, 2^-16 relative per product
     o3 = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()), split_bf16=True)
-    assert rel_err(o3, ref) < 5e-5
+    check(o3, ref, 5e-5, "o3")
     o3b = vln.ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=o3, accumulate=True, split_bf16=True)
-    assert rel_err(o3b, 2 * ref) < 5e-5
+    check(o3b, 2 * ref, 5e-5, "o3b")
 
 
 @pytest.mark.parametrize("split", [False, True])
@@ -84,7 +82,7 @@ def test_wgrad_grouped(vln, split):
         refs.append(ref); outs.append(out)
     wb.run()
     for o, r in zip(outs, refs):
-        assert rel_err(o, r) < (5e-5 if split else 1e-5)
+        check(o, r, (5e-5 if split else 1e-5), "o")
 
 
 @pytest.mark.parametrize("R,D", [(128, 2176), (1024, 1024), (1792, 1024), (5, 8)])
@@ -111,9 +109,9 @@ def test_batch_norm_kernel(vln, R, D, relu):
         nbt = torch.zeros((), dtype=torch.int64, device=d)
         y = Fh.batch_norm(xd, wd, bd, rmd, rvd, nbt, training, 0.1, 1e-5, relu)
         (y * r.to(d)).sum().backward()
-        assert rel_err(y, ref.detach()) < 1e-5
-        assert rel_err(xd.grad, x64.grad) < 1e-4 and rel_err(wd.grad, w64.grad) < 1e-4 and rel_err(bd.grad, b64.grad) < 1e-4
-        assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+        check(y, ref.detach(), 1e-5, "y")
+        check(xd.grad, x64.grad, 1e-4, "xd.grad"); check(wd.grad, w64.grad, 1e-4, "wd.grad"); check(bd.grad, b64.grad, 1e-4, "bd.grad")
+        check(rmd, rm, 1e-5, "rmd"); check(rvd, rv, 1e-5, "rvd")
         assert int(nbt) == (1 if training else 0)
 
 
@@ -146,7 +144,7 @@ def test_sample_action_kernel(vln, B, C):
     freq = torch.bincount(draws.cpu(), minlength=4).float() / 4096
     p = torch.softmax(torch.tensor([1.0, 0.0, -1.0, 2.0]), 0)
     assert (freq[:4] - p).abs().max().item() < 0.03
-    assert rel_err(lpd, torch.log(p)[draws.cpu()]) < 1e-5
+    check(lpd, torch.log(p)[draws.cpu()], 1e-5, "lpd")
 
 
 @pytest.mark.parametrize("T,B,with_ent", [(7, 64, True), (35, 64, True), (5, 3, False), (1, 130, True)])
@@ -176,13 +174,13 @@ def test_a2c_loss_kernel_matches_the_restated_sweep(vln, T, B, with_ent):
         out, tot = vln.losses.a2c_loss(dlp, den, dvl, [r.to(d) for r in rewards], [m.to(d) for m in masks], last_v.float().to(d),
                                        ended.to(d), 0.9, norm, per)
         assert abs(float(tot) - total) < 1e-6
-        assert rel_err(out, ref.detach()) < 1e-5
+        check(out, ref.detach(), 1e-5, "out")
         ((out * w.float().to(d)).sum() if per else out).backward()
         for a, b in zip(dlp + dvl + (den or []), lp + vl + (en if with_ent else [])):
             if b.grad is None:
                 assert a.grad is None or a.grad.abs().max().item() == 0.0
             else:
-                assert rel_err(a.grad, b.grad) < 1e-5
+                check(a.grad, b.grad, 1e-5, "a.grad")
 
 
 @pytest.mark.parametrize("rows", [448, 5120, 7])
@@ -202,7 +200,7 @@ def test_colsum_grouped(vln, rows):
     cb.add(a3, o3, None, False)
     cb.run()
     assert rel_err(o1, r1) < 1e-5 and torch.equal(o1, o1b)
-    assert rel_err(o2, a2.double().sum(0)) < 1e-5 and rel_err(o3, a3.double().sum(0)) < 1e-5
+    check(o2, a2.double().sum(0), 1e-5, "o2"); check(o3, a3.double().sum(0), 1e-5, "o3")
 
 
 @pytest.mark.parametrize("N,K", [(2048, 2752), (48, 40), (1, 7)])
@@ -270,23 +268,23 @@ def test_attention_fwd_bwd(vln, B, S, D, cdt):
     cd, vd = ctx.to(dev()), vec.to(dev())
     dots = vln.ops.attn_dot(cd, vd)
     tol = 1e-4 if cdt == torch.float32 else 1e-2
-    assert rel_err(dots, logits.detach()) < tol
+    check(dots, logits.detach(), tol, "dots")
     out, at = vln.ops.attn_softmax_wsum(cd, dots, mask.to(dev()))
-    assert rel_err(at, attn.detach()) < tol and rel_err(out, wc.detach()) < tol
+    check(at, attn.detach(), tol, "at"); check(out, wc.detach(), tol, "out")
     assert at[mask.to(dev())].abs().max().item() == 0.0
     # backward: dalpha = ctx . dwc ; dvec, dctx
     dwc = r.float().to(dev())
     dalpha = vln.ops.attn_dot(cd, dwc)
     dctx = torch.zeros(B, S, D, device=dev())
     dvec, dl = vln.ops.attn_bwd(cd, at, dalpha, ra.float().to(dev()), dwc, vd, dctx, want_dl=True)
-    assert rel_err(dvec, v64.grad) < tol * 5
-    assert rel_err(dctx, c64.grad) < tol * 5
+    check(dvec, v64.grad, tol, "dvec")
+    check(dctx, c64.grad, tol, "dctx")
     # accumulate semantics
     vln.ops.attn_bwd(cd, at, dalpha, ra.float().to(dev()), dwc, vd, dctx)
-    assert rel_err(dctx, 2 * c64.grad) < tol * 5
+    check(dctx, 2 * c64.grad, tol, "dctx")
     # plain weighted sum
     w = torch.randn(B, S, generator=g)
-    assert rel_err(vln.ops.rows_wsum(cd, w.to(dev())), torch.einsum("bs,bsd->bd", w.double(), ctx.double())) < tol
+    check(vln.ops.rows_wsum(cd, w.to(dev())), torch.einsum("bs,bsd->bd", w.double(), ctx.double()), tol, "vln.ops.rows_wsum(cd, w.to(dev()))")
 
 
 @pytest.mark.parametrize("B,S,D", [(64, 36, 2176), (64, 80, 512), (64, 8, 2176), (16, 12, 1024), (5, 33, 520), (4, 9, 48),
@@ -320,15 +318,15 @@ def test_attention_rows_one_launch(vln, B, S, D, cdt):
         total = total + loss
         vd = big[:, 4:4 + D]; vd.copy_(vec.to(dev()))
         out, at = vln.ops.attn_fwd_rows(cd, vd, mask.to(dev()))
-        assert rel_err(at, attn.detach()) < tol and rel_err(out, wc.detach()) < tol
+        check(at, attn.detach(), tol, "at"); check(out, wc.detach(), tol, "out")
         assert (at * mask.to(dev())).abs().max().item() == 0.0
         dwc = torch.zeros(B, 2 * D, device=dev())[:, :D]; dwc.copy_(r.float().to(dev()))
         dvec, dl = vln.ops.attn_bwd_rows(cd, at, dwc, ra.float().to(dev()), want_dl=True)
-        assert rel_err(dvec, gv) < tol * 5
+        check(dvec, gv, tol, "dvec")
         # same numbers from the two-launch kernels
         dalpha = vln.ops.attn_dot(cd, dwc)
         dvec2, dl2 = vln.ops.attn_bwd(cd, at, dalpha, ra.float().to(dev()), want_dl=True)
-        assert rel_err(dvec, dvec2) < 1e-5 and rel_err(dl, dl2) < 1e-5
+        check(dvec, dvec2, 1e-5, "dvec"); check(dl, dl2, 1e-5, "dl")
         q = vd.clone()
         keep += [at, dl, dwc, q]
         terms.append((at.data_ptr(), dl.data_ptr(), dwc.data_ptr(), q.data_ptr()))
@@ -338,10 +336,10 @@ def test_attention_rows_one_launch(vln, B, S, D, cdt):
     dctx = torch.empty(B, S, D, device=dev())
     vln.ops.attn_dctx_deferred([x[0] for x in terms], [x[1] for x in terms], [x[2] for x in terms], 2 * D,
                                [x[3] for x in terms], D, dctx)
-    assert rel_err(dctx, c64.grad) < tol * 5
+    check(dctx, c64.grad, tol, "dctx")
     vln.ops.attn_dctx_deferred([x[0] for x in terms], [x[1] for x in terms], [x[2] for x in terms], 2 * D,
                                [x[3] for x in terms], D, dctx, accumulate=True)
-    assert rel_err(dctx, 2 * c64.grad) < tol * 5
+    check(dctx, 2 * c64.grad, tol, "dctx")
 
 
 def test_attention_dctx_deferred_many_steps(vln):
@@ -354,7 +352,7 @@ def test_attention_dctx_deferred_many_steps(vln):
     out = torch.empty(B, S, D, device=dev())
     vln.ops.attn_dctx_deferred([al[t].data_ptr() for t in range(T)], [dl[t].data_ptr() for t in range(T)],
                                [gw[t].data_ptr() for t in range(T)], 2 * D, [q[t].data_ptr() for t in range(T)], D, out)
-    assert rel_err(out, ref) < 1e-5
+    check(out, ref, 1e-5, "out")
 
 
 def test_lstm_pointwise(vln):
@@ -375,10 +373,10 @@ def test_lstm_pointwise(vln):
     ((h1 * r1).sum() + (c1 * r2).sum() + (h1 * mask.cpu().double() * r3).sum()).backward()
     d = dev()
     oh1, oc1, act, tc, hd = vln.ops.lstm_pointwise_fwd(slabs.to(d), bi.to(d), bh.to(d), c0.to(d), seed, off, p, True)
-    assert rel_err(oh1, h1.detach()) < 1e-5 and rel_err(oc1, c1.detach()) < 1e-5
-    assert rel_err(hd, (h1.detach() * mask.cpu().double())) < 1e-5
+    check(oh1, h1.detach(), 1e-5, "oh1"); check(oc1, c1.detach(), 1e-5, "oc1")
+    check(hd, (h1.detach() * mask.cpu().double()), 1e-5, "hd")
     dg, dc0 = vln.ops.lstm_pointwise_bwd(r1.float().to(d), r3.float().to(d), r2.float().to(d), act, tc, c0.to(d), seed, off, p)
-    assert rel_err(dg, gates.grad) < 1e-4 and rel_err(dc0, c064.grad) < 1e-4
+    check(dg, gates.grad, 1e-4, "dg"); check(dc0, c064.grad, 1e-4, "dc0")
 
 
 def test_feature_dropout(vln):

@@ -272,3 +272,28 @@ def test_pinned_stager_roundtrip_and_reuse(vln):
         assert torch.equal(d["img"].cpu(), torch.from_numpy(a)) and torch.equal(d["target"].cpu(), torch.from_numpy(t))
         assert torch.isfinite(s)
     assert st.slots[0]["host"]["img"].is_pinned()
+
+
+def test_fused_rmsprop_per_group_clip_like_the_reference_trainer(vln):
+    """trainer.py:380-381,423-427: ONE RMSprop over encoder + decoder + critic, but clip_grad_norm(40) on encoder and decoder
+    only -- `clip_norm=[c, c, 0]`: the third group's (large) gradients must pass unclipped, the first two are clipped."""
+    torch.manual_seed(9)
+    shapes = [[(40, 8), (13,)], [(9, 9)], [(33, 3), (5,)]]
+    ref = [[torch.nn.Parameter(torch.randn(s, device=DEV)) for s in g] for g in shapes]
+    mine = [[torch.nn.Parameter(p.detach().clone()) for p in g] for g in ref]
+    opt_ref = torch.optim.RMSprop([p for g in ref for p in g], lr=1e-2)
+    opt = vln.optim.FusedRMSprop(mine, lr=1e-2, clip_norm=[1.5, 1.5, 0.0])
+    for step in range(3):
+        opt.zero_grad(); opt_ref.zero_grad()
+        for gr, gm in zip(ref, mine):
+            for pr, pm in zip(gr, gm):
+                gval = torch.randn_like(pr) * 5.0
+                pr.grad = gval.clone(); pm.grad.add_(gval)
+        for g in ref[:2]:
+            torch.nn.utils.clip_grad_norm_(g, 1.5)
+        opt_ref.step(); opt.step()
+        for gr, gm in zip(ref, mine):
+            for pr, pm in zip(gr, gm):
+                assert torch.allclose(pm, pr, rtol=2e-5, atol=1e-6), step
+    with pytest.raises(ValueError):
+        vln.optim.FusedRMSprop(mine, lr=1e-2, clip_norm=[1.0, 2.0])

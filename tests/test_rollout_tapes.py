@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from parity import check
 from oracle import rollout as R
 from oracle.fake_env import FakeR2REnv
 
@@ -31,13 +32,16 @@ def compare(res, grads, G, tol, gtol):
         assert [len(t["path"]) for t in res["traj"]] == G["out"]["path_len"].numpy().tolist()
     if "total" in G["out"]:
         assert int(res["total"]) == int(G["out"]["total"])
+    gmax = max([float(r.abs().max()) for r in G["grad"].values()] + [1e-30])
     for n, ref in G["gradnorm"].items():
         got = grads[n].detach().double().cpu().norm().item()
         assert abs(got - float(ref)) <= gtol * max(float(ref), 1e-3), f"grad norm {n}: {got} vs {float(ref)}"
     for n, ref in G["grad"].items():
-        g = grads[n].detach().double().cpu()
-        err = (g - ref.double()).abs().max().item()
-        assert err <= gtol * max(ref.abs().max().item(), 1e-3), f"grad {n}: max err {err}"
+        # ActionScoring's output bias receives sum_{b,c} d logit: zero in exact arithmetic for a CE loss (softmax rows sum to
+        # their one-hot), so BOTH sides hold fp32 rounding noise of O(1e-7) x the O(1) summands (the reference's own value is
+        # 8.9e-8): it is compared on the scale of the summands, not of the (vanishing) result
+        zero_sum = n.endswith("decode_action.linear_out.bias")
+        check(grads[n], ref, gtol, f"grad[{n}]", floor=max(1e-2 * gmax, 1e-1 if zero_sum else 0.0))
 
 
 @pytest.mark.parametrize("mode", ["teacher", "sample"])
@@ -47,7 +51,7 @@ def test_oracle_rollout_matches_reference_agent(mode):
     env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
     res = R.envdrop_rollout(be, env, mode, 6, inject_actions=G["out"]["actions"].numpy(), train_rl=(mode == "sample"))
     res["loss"].backward()
-    compare(res, be.named_grads(), G, 1e-5, 2e-4)
+    compare(res, be.named_grads(), G, 1e-5, 1e-4)
 
 
 @pytest.mark.gpu
@@ -69,7 +73,7 @@ def test_hip_rollout_matches_reference_agent(mode):
     env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
     res = R.envdrop_rollout(be, env, mode, 6, inject_actions=G["out"]["actions"].numpy(), train_rl=(mode == "sample"))
     res["loss"].backward()
-    compare(res, be.named_grads(), G, 1e-4, 5e-4)
+    compare(res, be.named_grads(), G, 1e-4, 1e-4)
 
 
 # ---- the other two agents + the evaluation (argmax) path: tapes from gen_agent_tapes_more -------------------------------
@@ -103,7 +107,7 @@ def test_oracle_rollouts_match_reference_agents(kind, mode):
         be = R.OracleBackend(Pe, Pd, {})
     res = _run(kind, be, mode)                       # argmax: the rollout's OWN greedy actions must equal the tape's
     res["ml_loss"].backward()
-    compare(res, be.named_grads(), G, 1e-5, 2e-4)
+    compare(res, be.named_grads(), G, 1e-5, 1e-4)
 
 
 @pytest.mark.gpu
@@ -135,7 +139,7 @@ def test_hip_rollouts_match_reference_agents(kind, mode):
         be = R.ModuleBackend(enc, dec, None, dev)
     res = _run(kind, be, mode)
     res["ml_loss"].backward()
-    compare(res, be.named_grads(), G, 1e-4, 5e-4)
+    compare(res, be.named_grads(), G, 1e-4, 1e-4)
 
 
 # ---- back translation (envdrop.py:105-121,155-157 + speaker.py:292-376) ----------------------------------
@@ -200,11 +204,11 @@ def test_hip_back_translation_rollout():
     assert np.array_equal(res["actions"], ref["actions"])
     assert abs(float(res["ml_loss"].detach()) - float(ref["ml_loss"].detach())) <= 1e-4 * max(1.0, abs(float(ref["ml_loss"].detach())))
     g, go = be.named_grads(), bo.named_grads()
+    gmax = max(float(r.abs().max()) for n, r in go.items() if not n.startswith("cri."))
     for n, r in go.items():
         if n.startswith("cri."):
             continue
-        err = (g[n].detach().double().cpu() - r).abs().max().item()
-        assert err <= 5e-4 * max(r.abs().max().item(), 1e-3), f"grad {n}: max err {err}"
+        check(g[n], r, 1e-4, f"grad[{n}]", floor=1e-2 * gmax)
 
 
 def test_oracle_rollout_instruction_override_is_consistent():
