@@ -5,16 +5,22 @@ One "step" = one agent training iteration of the reference's EnvDrop IL path
 (trainer.py:411-427 with feedback="teacher"): instruction encoder forward, T teacher-forced decoder steps
 with the in-place candidate mask + cross-entropy (envdrop.py:151-179), `ml_loss * ML_WEIGHT / B`, full
 backward, gradient all-reduce (N > 1), clip-norm 40 on encoder and decoder, RMSprop step.  Batch 64 episodes
-per GPU, 36 x (2048+128) view features, <= 80 instruction tokens, synthetic data, inputs
-resident in HBM before the timed region; dropout ON (training mode).
+per GPU, 36 x (2048+128) view features, <= 80 instruction tokens, synthetic data, dropout ON.
+Inputs are resident in HBM before the timed region: the FULL-size ResNet table (10,567 viewpoints x 36 x 2048, 1.56 GB in
+bf16) and 8 different episode batches (tokens, viewpoint / candidate indices, targets) that the timed loop rotates through,
+so every iteration gathers rows it has not touched for 8 iterations from a table six times the Infinity Cache.
 
     python bench.py                       # N=1, prints ONE JSON line
+    python bench.py --gpus N              # starts N ranks itself (torch.distributed.run, RCCL, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-The `cpu_baseline` leg times the CPU oracle (oracle/torch_port.py, kind "port") on a bounded sample of the same
-workload on rank 0 at N=1 only.  The `roofline` leg replays the K timed steps with per-kernel HIP-event timers
-(vln_prof_*), and reports the kernel with the largest total time.
+`roofline`: the K timed steps replayed with per-kernel HIP-event timers (vln_prof_*); the kernel with the largest total time;
+`traffic` / `mfma_util` from the committed rocprofv3 --pmc passes IF they were taken on these kernel sources (hash-checked).
+`cpu_baseline`: the CPU oracle (oracle/torch_port.py, kind "port") on tape 0 of the same workload, on rank 0 at N=1 only:
+all usable cores (2 warm-ups, median of 10) and 1 thread.  `secondary` (N=1): ms per iteration of the fp32 path, of the
+PCIe-inclusive path (pinned fp32 host features), of EnvDrop IL + A2C at the reference's episode cap 35 and of the Self-Monitor
+agent at B=128 -- driver-timed side numbers, never `value`.
 """
 from __future__ import annotations
 
@@ -37,15 +43,20 @@ CLIP = 40.0                # trainer.py:425-426
 LR = 1e-4                  # envdrop_config.yaml:19
 
 
-def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
+N_VIEWPOINTS = 10567      # panoramas in the R2R ResNet-152 feature TSV (ImageFeatures.read_in, utils/misc.py:253-279)
+N_TAPES = 8               # distinct episode batches rotated through the timed loop
+
+
+def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128, n_rows=None):
     """Synthetic episode batch (BASELINE.md §3 / SURVEY.md §8d), CPU tensors.  Features are defined the way the
     reference's environment builds them (common_env.py:272,287-291,307-308): a per-viewpoint ResNet table
-    [T*B viewpoints, 36 views, 2048] (post-ReLU, non-negative), the agent's viewIndex selecting the static angle
-    table, and each candidate = (view of the current panorama, its relative heading/elevation).  The explicit
-    img/cand tensors of every step are materialised from those for the tensor path and the CPU baseline."""
-    import math
+    [viewpoints, 36 views, 2048] (post-ReLU, non-negative), the agent's viewIndex selecting the static angle
+    table, and each candidate = (view of the current panorama, its relative heading/elevation).
+    n_rows=None: the tape brings its own compact table (T*B viewpoints) and the explicit img/cand tensors of every step
+    (tensor path, CPU baseline, tests).  n_rows=N: INDEX-ONLY tape over a resident table of N viewpoints (the bench's
+    DeviceFeatureStore): every step visits B random viewpoints, one row of every step has all C_max candidate slots in use
+    so the padded candidate width is the same for every tape."""
     g = torch.Generator().manual_seed(seed)
-    F = IMG + ANG
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values
     lens[0] = L
     tokens = torch.zeros(B, L, dtype=torch.long)
@@ -54,21 +65,16 @@ def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
         tokens[i, 1:n - 1] = torch.randint(4, vocab, (n - 2,), generator=g)
         tokens[i, n - 1] = 2                                    # <EOS>
     seq_mask = tokens == 0
-
-    def angle_feat(h, e):                                       # utils/misc.py:285-293
-        return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], -1).repeat_interleave(ANG // 4, dim=-1)
-
-    import vln_amd
-    loc_table = vln_amd.staging.loc_embedding_table(ANG, V)    # static location embeddings [V, V, ANG], misc.py:296-317
-
-    table = torch.randn(T * B, V, IMG, generator=g).abs() * 0.5
+    table = None if n_rows is not None else torch.randn(T * B, V, IMG, generator=g).abs() * 0.5
     T_i = torch.randint(min(4, T), T + 1, (B,), generator=g)
     T_i[0] = T
     steps = []
     for t in range(T):
-        rows = torch.arange(B) + t * B
+        rows = torch.arange(B) + t * B if n_rows is None else torch.randint(0, n_rows, (B,), generator=g)
         vidx = torch.randint(0, V, (B,), generator=g).int()
         ncand = torch.randint(3, C_max + 1, (B,), generator=g)      # candidates incl. the STOP slot
+        if n_rows is not None:
+            ncand[int(torch.randint(0, B, (1,), generator=g))] = C_max
         Ct = int(ncand.max())
         cmask = torch.arange(Ct)[None, :] >= ncand[:, None]
         real = torch.arange(Ct)[None, :] < (ncand - 1)[:, None]     # STOP slot + padding are all-zero rows
@@ -76,35 +82,113 @@ def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128):
         cview = torch.randint(0, V, (B, Ct), generator=g).int()
         chead = (torch.rand(B, Ct, generator=g) - 0.5) * 6.0
         celev = (torch.rand(B, Ct, generator=g) - 0.5) * 1.04
-        img = torch.cat((table[rows], loc_table[vidx.long()]), -1)
-        cand = torch.cat((table[rows[:, None].expand(B, Ct), cview.long()], angle_feat(chead, celev)), -1) * real[..., None]
         ended = t >= T_i
         tgt = torch.where(t == T_i - 1, ncand - 1, (torch.rand(B, generator=g) * (ncand - 1).float()).long())
         tgt = torch.where(ended, torch.full_like(tgt, -1), tgt)
         ah = torch.rand(B, generator=g) * 6.283 - 3.1415
-        steps.append(dict(img=img, cand=cand, cand_mask=cmask, angle=angle_feat(ah, torch.zeros(B)), target=tgt, rows=rows,
-                          vidx=vidx, crow=crow, cview=cview, chead=chead, celev=celev))
+        st = dict(cand_mask=cmask, angle=angle_feat(ah, torch.zeros(B), ANG), target=tgt, rows=rows,
+                  vidx=vidx, crow=crow, cview=cview, chead=chead, celev=celev)
+        if table is not None:
+            st.update(materialize_step(st, table, ANG))
+        steps.append(st)
     return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, table=table, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
 
 
-def tape_to(tape, dev, store_dtype=None, host_dtype=None):
-    """Device copy.  With `store_dtype` the ResNet table becomes a resident DeviceFeatureStore and the per-step img/cand
-    tensors are NOT uploaded (a step only needs its index vectors).  With `host_dtype` the per-step img/cand tensors stay on
-    the HOST, pinned, in that dtype (fp32 = what the reference's ImageFeatures holds, utils/misc.py:253-279; bf16 = converted
-    once at load time): every step then pays its H2D copy (PCIe-inclusive mode, never the headline value)."""
+def angle_feat(h, e, ANG=128):                                  # utils/misc.py:285-293
+    return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], -1).repeat_interleave(ANG // 4, dim=-1)
+
+
+def materialize_step(st, table, ANG=128):
+    """The explicit img [B,36,F] / cand [B,C,F] tensors of a step from the ResNet table (any device), built the way the
+    reference's marshalling does (agent/base.py:141-157): what the tensor / host feature modes and the CPU baseline consume."""
+    import vln_amd
+    dev = table.device
+    V = table.shape[1]
+    loc_table = vln_amd.staging.loc_embedding_table(ANG, V).to(dev)            # [V, V, ANG], misc.py:296-317
+    rows, crow = st["rows"].to(dev), st["crow"].to(dev)
+    real = (crow >= 0)
+    img = torch.cat((table[rows].float(), loc_table[st["vidx"].to(dev).long()]), -1)
+    cand = torch.cat((table[crow.clamp_min(0), st["cview"].to(dev).long()].float(),
+                      angle_feat(st["chead"].to(dev), st["celev"].to(dev), ANG)), -1) * real[..., None]
+    return dict(img=img, cand=cand)
+
+
+def tape_to(tape, dev, store_dtype=None, host_dtype=None, store=None):
+    """Device copy.  With `store_dtype` the tape's own ResNet table becomes a resident DeviceFeatureStore (or `store` = an
+    existing one, for index-only tapes) and the per-step img/cand tensors are NOT uploaded (a step only needs its index
+    vectors).  With `host_dtype` the per-step img/cand tensors stay on the HOST, pinned, in that dtype (fp32 = what the
+    reference's ImageFeatures holds, utils/misc.py:253-279; bf16 = converted once at load time): every step then pays its
+    H2D copy (PCIe-inclusive mode, never the headline value)."""
     skip = ("steps", "table")
     out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k not in skip}
     out["lengths32"] = tape["lengths"].to(dev, torch.int32)
-    drop = ("img", "cand") if (store_dtype is not None or host_dtype is not None) else ()
+    drop = ("img", "cand") if (store_dtype is not None or host_dtype is not None or store is not None) else ()
     out["steps"] = [{k: v.to(dev) for k, v in s.items() if k not in drop} for s in tape["steps"]]
     if host_dtype is not None:
         for so, si in zip(out["steps"], tape["steps"]):
-            so["img_host"] = si["img"].to(host_dtype).contiguous().pin_memory()
-            so["cand_host"] = si["cand"].to(host_dtype).contiguous().pin_memory()
-    if store_dtype is not None:
+            so["img_host"] = si["img"].to("cpu", host_dtype).contiguous().pin_memory()
+            so["cand_host"] = si["cand"].to("cpu", host_dtype).contiguous().pin_memory()
+    if store is not None:
+        out["store"] = store
+    elif store_dtype is not None:
         import vln_amd
         out["store"] = vln_amd.DeviceFeatureStore(tape["table"], device=dev, dtype=store_dtype, angle_size=tape["ANG"])
     return out
+
+
+def build_store(vln, dev, dtype, n_rows=N_VIEWPOINTS, V=36, IMG=2048, ANG=128, seed=2020):
+    """The full-size resident feature table: n_rows x 36 x 2048 (1.56 GB in bf16, 3.1 GB in fp32 -- the reference keeps 2.9 GB
+    of fp32 on the host), generated on the device chunk by chunk.  Post-ReLU statistics: |N(0,1)| * 0.5."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    table = torch.empty(n_rows, V, IMG, dtype=dtype, device=dev)
+    for r0 in range(0, n_rows, 512):
+        r1 = min(n_rows, r0 + 512)
+        table[r0:r1] = (torch.randn(r1 - r0, V, IMG, generator=g, device=dev).abs_() * 0.5).to(dtype)
+    return vln.DeviceFeatureStore(table, device=dev, dtype=dtype, angle_size=ANG)
+
+
+class LiveBatch:
+    """The small per-batch tensors of the CURRENT episode batch (tokens, lengths, masks, per-step index vectors, targets,
+    angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (one copy
+    per iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA
+    changes every iteration.  `load(k)` = one device-to-device copy of batch k's packed blob into the live blob."""
+    TOP = ("tokens", "lengths32", "seq_mask")
+    STEP = ("rows", "vidx", "crow", "cview", "chead", "celev", "cand_mask", "angle", "target")
+
+    def __init__(self, tapes):
+        t0 = tapes[0]
+        self.layout, off = [], 0
+        for name, t in self._items(t0):
+            n = t.numel() * t.element_size()
+            self.layout.append((name, off, n, t.dtype, tuple(t.shape)))
+            off = (off + n + 15) & ~15
+        self.nbytes = off
+        dev = t0["tokens"].device
+        self.blobs = []
+        for tp in tapes:
+            blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+            for (name, o, n, dt, shape), (name2, t) in zip(self.layout, self._items(tp)):
+                if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
+                    raise ValueError(f"LiveBatch: tape layouts differ at {name}: {tuple(t.shape)} vs {shape}")
+                blob[o:o + n] = t.contiguous().view(-1).view(torch.uint8)
+            self.blobs.append(blob)
+        self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+        views = {name: self.live_blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.layout}
+        self.live = {k: v for k, v in t0.items() if k not in self.TOP + ("steps",)}
+        for k in self.TOP:
+            self.live[k] = views[k]
+        self.live["steps"] = [{k: views[f"{i}.{k}"] for k in self.STEP} for i in range(len(t0["steps"]))]
+
+    def _items(self, tp):
+        for k in self.TOP:
+            yield k, tp[k]
+        for i, s in enumerate(tp["steps"]):
+            for k in self.STEP:
+                yield f"{i}.{k}", s[k]
+
+    def load(self, k):
+        self.live_blob.copy_(self.blobs[k % len(self.blobs)], non_blocking=True)
+        return self.live
 
 
 class GpuAgent:
@@ -232,8 +316,9 @@ class GpuAgent:
         return loss
 
 
-def cpu_baseline(tape, iters, P_enc, P_dec):
-    """The CPU oracle driven identically (dropout sampled with bernoulli_ like nn.Dropout)."""
+def cpu_baseline(tape, P_enc, P_dec):
+    """The CPU oracle driven identically (dropout sampled with bernoulli_ like nn.Dropout).  Returns run(warm, iters, budget_s)
+    -> (median seconds per iteration, iterations timed)   (2 warm-ups, median)."""
     from oracle import torch_port as O
     B, ANG = tape["B"], tape["ANG"]
     params = [p.requires_grad_(True) for p in list(P_enc.values()) + list(P_dec.values())]
@@ -259,17 +344,22 @@ def cpu_baseline(tape, iters, P_enc, P_dec):
         torch.nn.utils.clip_grad_norm_(list(P_dec.values()), CLIP)
         opt.step()
 
-    t0 = time.perf_counter()
-    one()                                   # warm-up
-    warm = time.perf_counter() - t0
-    if warm > 20.0:                         # pathological host (e.g. CPU quota): keep the bench bounded
-        return warm, 1
-    t0 = time.perf_counter()
-    done = 0
-    while done < iters and (time.perf_counter() - t0) < 20.0:
-        one()
-        done += 1
-    return (time.perf_counter() - t0) / done, done
+    def run(warm, iters, budget):
+        t0 = time.perf_counter()
+        for _ in range(warm):
+            one()
+            if time.perf_counter() - t0 > budget:           # pathological host (e.g. CPU quota): keep the bench bounded
+                return time.perf_counter() - t0, 0
+        ts = []
+        t0 = time.perf_counter()
+        while len(ts) < iters and (time.perf_counter() - t0) < budget:
+            t1 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    return run
 
 
 def usable_cores() -> int:
@@ -326,6 +416,9 @@ def main():
     ap.add_argument("--T", type=int, default=7)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary numbers (fp32, host features, IL+A2C, Self-Monitor)")
+    ap.add_argument("--viewpoints", type=int, default=N_VIEWPOINTS, help="rows of the resident ResNet table (R2R: 10,567)")
+    ap.add_argument("--tapes", type=int, default=N_TAPES, help="distinct episode batches rotated through the timed loop")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-arena", action="store_true", help="allocate per-iteration buffers with torch.empty (no address-stable "
                                                            "arena, hence no decoder-step hipGraph replay)")
@@ -386,14 +479,39 @@ def main():
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.features == "host-bf16" and dtype != torch.bfloat16:
+        raise SystemExit("--features host-bf16 needs --dtype bf16")
     torch.manual_seed(2020)
     agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
                      side_gather=args.gather_stream == "side" and args.features == "store")
-    tape_cpu = make_tape(args.batch, args.L, args.T, 8, seed=2020 + rank)   # weak scaling: 64 episodes per rank
-    tape = tape_to(tape_cpu, dev, store_dtype=(dtype if args.features == "store" else None),
-                   host_dtype={"host": torch.float32, "host-bf16": torch.bfloat16}.get(args.features))
-    if args.features == "host-bf16" and dtype != torch.bfloat16:
-        raise SystemExit("--features host-bf16 needs --dtype bf16")
+    # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
+    # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
+    # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.
+    t_setup = time.perf_counter()
+    store = build_store(vln, dev, dtype, args.viewpoints)
+    cpu_tapes = [make_tape(args.batch, args.L, args.T, 8, seed=2020 + 97 * rank + k, n_rows=store.N) for k in range(args.tapes)]
+    if args.features == "store":
+        tapes = [tape_to(t, dev, store=store) for t in cpu_tapes]
+    else:                          # explicit per-step feature tensors, built from the same table rows
+        hd = {"host": torch.float32, "host-bf16": torch.bfloat16}.get(args.features)
+        tapes = []
+        for t in cpu_tapes:
+            for s in t["steps"]:
+                s.update(materialize_step(s, store.table))
+            tapes.append(tape_to(t, dev, host_dtype=hd))
+            if hd is not None:
+                for s in t["steps"]:
+                    del s["img"], s["cand"]
+    live = LiveBatch(tapes) if args.features == "store" else None
+    if rank == 0:
+        print(f"[bench] setup: {store.N}-viewpoint table ({store.table.numel() * store.table.element_size() / 2**30:.2f} GiB {args.dtype}), "
+              f"{len(tapes)} tapes, {time.perf_counter() - t_setup:.1f} s", file=sys.stderr, flush=True)
+    it_no = [0]
+
+    def iterate():
+        k = it_no[0]
+        it_no[0] = k + 1
+        return agent.iteration(live.load(k) if live is not None else tapes[k % len(tapes)])
 
     def barrier():
         if world > 1:
@@ -407,14 +525,14 @@ def main():
     # generation.  Like a JIT compile this happens once per process, whatever W is.
     tw = time.perf_counter()
     for i in range(4):
-        agent.iteration(tape)
+        iterate()
         if i == 0:
             torch.cuda.synchronize()
             if rank == 0:
                 print(f"[bench] first iteration (module init, captures): {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     for i in range(args.warmup):
-        agent.iteration(tape)
+        iterate()
     barrier()
     # Python's cyclic GC: a full pass over the (static) module/object graph costs tens of ms and would land in the
     # timed region at random; collect now and move the survivors out of the collector's reach.
@@ -429,12 +547,12 @@ def main():
     if timed_out:                                 # a bounded in-kernel wait timed out during warm-up: fall back
         print("[bench] persistent recurrence reported a timeout; using per-step launches", file=sys.stderr, flush=True)
         lib.vln_set_persistent(0)
-        agent.iteration(tape)
+        iterate()
         barrier()
     marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        agent.iteration(tape)
+        iterate()
         marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
@@ -465,7 +583,7 @@ def main():
             read_prof(lib, nk)
         torch.cuda.synchronize()
         for _ in range(args.steps):
-            agent.iteration(tape)
+            iterate()
         torch.cuda.synchronize()
         rows = read_prof(lib, nk) if rank == 0 else []
         if rank == 0:
@@ -475,17 +593,9 @@ def main():
             rows.sort(key=lambda r: -r["ms"])
             top = rows[0]
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived bytes/launch (scripts/pmc_traffic.py)
-            if os.path.exists(tfile):
-                t = json.load(open(tfile)).get(args.dtype, {}).get(top["kernel"])
-                traffic = t["bytes_per_launch"] if t else None
-            mfma = None                                               # MFMA issue slots busy, SQ_VALU_MFMA_BUSY_CYCLES pass
-            mfile = os.path.join(ROOT, "profiles", "round1_mfma_util.json")      # (scripts/pmc_mfma.py), bf16 run
-            if os.path.exists(mfile) and args.dtype == "bf16":
-                mfma = json.load(open(mfile)).get(top["kernel"] + "_kernel", {}).get("mfma_util")
+            traffic, mfma, pmc_note = pmc_figures(top["kernel"], args.dtype)
             roofline = dict(bound="hbm", kernel=top["kernel"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, mfma_util=mfma,
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, mfma_util=mfma, pmc=pmc_note,
                             avg_launch_us=round(top["ms"] * 1e3 / top["launches"], 2),
                             algo_bytes_per_launch=round(top["bytes"] / top["launches"]),
                             kernels=[dict(kernel=r["kernel"], launches_per_step=r["launches"] / args.steps,
@@ -494,16 +604,43 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    # Secondary, driver-timed numbers in the same line (never `value`): the fp32 path, the PCIe-inclusive path, and the two
+    # other single-GPU workloads BASELINE.json configures (IL + A2C at the reference's episode cap 35; Self-Monitor B=128).
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = {}
+        gc.unfreeze()
+        for name, fn in (("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args)),
+                         ("features_host_fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "host", args)),
+                         ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
+                         ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store))):
+            t1 = time.perf_counter()
+            try:
+                secondary[name] = fn()
+            except Exception as e:          # a secondary number never takes the headline line down
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] secondary {name}: {secondary[name]} ({time.perf_counter() - t1:.1f} s)", file=sys.stderr, flush=True)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = min(usable_cores(), 64)
-        torch.set_num_threads(ncores)
-        print(f"[bench] cpu baseline on {ncores} threads ...", file=sys.stderr, flush=True)
+        print(f"[bench] cpu baseline on {ncores} threads, then 1 ...", file=sys.stderr, flush=True)
         P_enc = {k: v.detach().float().cpu().clone() for k, v in agent.enc.state_dict().items()}
         P_dec = {k: v.detach().float().cpu().clone() for k, v in agent.dec.state_dict().items()}
-        sec, done = cpu_baseline(tape_cpu, args.cpu_iters, P_enc, P_dec)
-        cpu = dict(value=round(1.0 / sec, 4), unit="steps/s", cores=torch.get_num_threads(), kind="port",
-                   sample=f"{done} iterations of the same tape (B={args.batch}, L={args.L}, T={args.T}), fp32, after 1 warm-up")
+        t_cpu = cpu_tapes[0]
+        for s_ in t_cpu["steps"]:           # tape 0 with its explicit feature tensors, gathered from the same table rows
+            m = s_ if "img" in s_ else materialize_step(s_, store.table)
+            s_["img"], s_["cand"] = m["img"].float().cpu(), m["cand"].float().cpu()
+        run = cpu_baseline(t_cpu, P_enc, P_dec)
+        torch.set_num_threads(ncores)
+        sec_n, done_n = run(2, args.cpu_iters, 14.0)
+        torch.set_num_threads(1)
+        sec_1, done_1 = run(1, 3, 14.0)
+        torch.set_num_threads(ncores)
+        cpu = dict(value=round(1.0 / sec_n, 4), unit="steps/s", cores=ncores, kind="port",
+                   value_1thread=round(1.0 / sec_1, 4),
+                   sample=f"tape 0 of the same workload (B={args.batch}, L={args.L}, T={args.T}), fp32, dropout on: {ncores} threads = "
+                          f"median of {done_n} iterations after 2 warm-ups; 1 thread = median of {done_1} after 1 warm-up")
 
     if rank == 0:
         print(json.dumps({
@@ -512,12 +649,79 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
+                       "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if world > 1 else None},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def csrc_sha():
+    """Hash of the kernel sources: PMC figures are only quoted for the code they were measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "curriculum-learning-for-vln_amd", "csrc", "*.h*"))):
+        if f.endswith((".hip", ".h")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_figures(kernel, dtype):
+    """(HBM-side bytes per launch, MFMA issue-slot utilisation, note) of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/round2_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
+    same command).  The file carries the hash of the kernel sources it was taken on: a mismatch means the numbers describe
+    OTHER code, and they are refused (null) rather than quoted stale."""
+    f = os.path.join(ROOT, "profiles", "round2_pmc.json")
+    if not os.path.exists(f):
+        return None, None, "no PMC passes committed for this round yet"
+    d = json.load(open(f))
+    if d.get("csrc_sha") != csrc_sha():
+        return None, None, f"profiles/round2_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
+    t = d.get("traffic", {}).get(dtype, {}).get(kernel)
+    m = d.get("mfma_util", {}).get(dtype, {}).get(kernel)
+    return (t["bytes_per_launch"] if t else None), m, f"profiles/round2_pmc.json, kernel sources {d['csrc_sha']}"
+
+
+def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6):
+    """ms per iteration of the headline workload under another precision / feature path (own agent, own arena)."""
+    torch.manual_seed(2020)
+    ag = GpuAgent(vln, dev, dtype, 1, arena=True)
+    if features == "store":
+        st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
+        tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
+        live = LiveBatch(tapes)
+        get = live.load
+    else:                                   # pinned host fp32 features (what the reference's ImageFeatures holds): two batches
+        tapes = []
+        for t in cpu_tapes[:2]:
+            t = dict(t, steps=[dict(s) for s in t["steps"]])
+            for s in t["steps"]:
+                s.update(materialize_step(s, store.table))
+            tapes.append(tape_to(t, dev, host_dtype=torch.float32))
+        get = lambda k: tapes[k % len(tapes)]
+    for k in range(4 + warmup):
+        ag.iteration(get(k))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ag.iteration(get(k))
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / steps * 1e3, 3)
+
+
+def secondary_agents(dev, args, which, store):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_agents as W
+    W.configure(steps=12, warmup=5, dtype=args.dtype, arena=False, device=dev)
+    W.vln.functional.set_grad_in_place(True)
+    try:
+        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else W.run_monitor()
+    finally:
+        W.vln.functional.set_grad_in_place(False)
+    return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"]}
 
 
 if __name__ == "__main__":

@@ -9,26 +9,32 @@
                        at B=64 per GPU, clip 40 + RMSprop over encoder / decoder / critic
 
 Synthetic data of BASELINE.md's shapes, features resident in HBM; prints one JSON line per workload.
-    python scripts/bench_agents.py [monitor|follower|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32]
+    python scripts/bench_agents.py [monitor|follower|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32] [--T-rl 35]
+(bench.py imports run_monitor / run_a2c for the secondary numbers of its JSON line)
 """
-import argparse, json, sys, time
-sys.path.insert(0, '.')
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 import vln_amd as vln
 
-ap = argparse.ArgumentParser()
-ap.add_argument("which", nargs="?", default="all")
-ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--warmup", type=int, default=8)
-ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
-ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
-args = ap.parse_args()
-vln.functional.set_grad_in_place(not args.no_grad_in_place)
+
+class _Args:          # defaults when imported (bench.py's secondary numbers); overwritten by the command line below
+    steps, warmup, dtype, arena = 30, 8, "bf16", False
+
+
+args = _Args()
 dev = torch.device("cuda:0")
-dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+dt = torch.bfloat16
 F = 2176
+
+
+def configure(steps=30, warmup=8, dtype="bf16", arena=False, device=None):
+    global dt, dev
+    args.steps, args.warmup, args.dtype, args.arena = steps, warmup, dtype, arena
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    if device is not None:
+        dev = device
 
 
 def with_arena(fn):
@@ -139,18 +145,26 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
-def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
-    cpu_tape = bench.make_tape(B, L, T_rl, C, 2020)
-    tape = bench.tape_to(cpu_tape, dev, store_dtype=dt)
+def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
+    """EnvDrop IL (teacher-forced rollout, T_il steps) + RL (sampled rollout up to T_rl steps -- the reference caps episodes at
+    MAX_EPISODE_LEN = 35, configs/envdrop/envdrop_config.yaml:31 -- A2C with the critic, envdrop.py:186-264) per optimizer step
+    (trainer.py:411-427); one RMSprop over encoder / decoder / critic, clip 40 on encoder and decoder only (:425-426)."""
+    if store is None:
+        cpu_tape = bench.make_tape(B, L, T_rl, C, 2020)
+        tape = bench.tape_to(cpu_tape, dev, store_dtype=dt)
+    else:
+        tape = bench.tape_to(bench.make_tape(B, L, T_rl, C, 2020, n_rows=store.N), dev, store=store)
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dt).to(dev).train()
     dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, F, compute_dtype=dt).to(dev).train()
     cri = vln.Critic(512, 0.5).to(dev).train()
-    opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters()), list(cri.parameters())], lr=1e-4, clip_norm=40.0)
+    opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters()), list(cri.parameters())], lr=1e-4,
+                                 clip_norm=[40.0, 40.0, 0.0])
     store = tape["store"]
     lp = dt != torch.float32
     g = torch.Generator().manual_seed(7)
     rewards = [torch.randn(B, generator=g).sign().to(dev) for _ in range(T_rl)]
     lens_rl = torch.randint(4, T_rl + 1, (B,), generator=g)
+    lens_rl[0] = T_rl
     masks = [(t < lens_rl).to(dev) for t in range(T_rl)]
     ended = (lens_rl < T_rl).to(dev)
 
@@ -202,11 +216,27 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8):
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
-if args.which in ("monitor", "all"):
-    print(json.dumps(run_monitor()), flush=True)
-    print("grad sinks [in place, via autograd]:", vln.functional.GRAD_IN_PLACE_STATS, file=sys.stderr)
-if args.which in ("follower", "all"):
-    print(json.dumps(run_follower()), flush=True)
-    print(json.dumps(run_follower(fused=False)), flush=True)
-if args.which in ("a2c", "all"):
-    print(json.dumps(run_a2c()), flush=True)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="all")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--T-rl", type=int, default=35, help="cap of the sampled rollout (reference: MAX_EPISODE_LEN 35)")
+    ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
+    ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
+    a = ap.parse_args()
+    configure(a.steps, a.warmup, a.dtype, a.arena)
+    vln.functional.set_grad_in_place(not a.no_grad_in_place)
+    if a.which in ("monitor", "all"):
+        print(json.dumps(run_monitor()), flush=True)
+        print("grad sinks [in place, via autograd]:", vln.functional.GRAD_IN_PLACE_STATS, file=sys.stderr)
+    if a.which in ("follower", "all"):
+        print(json.dumps(run_follower()), flush=True)
+        print(json.dumps(run_follower(fused=False)), flush=True)
+    if a.which in ("a2c", "all"):
+        print(json.dumps(run_a2c(T_rl=a.T_rl)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
