@@ -78,6 +78,18 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// The fused LSTM cell's pointwise part with the roundings spelled out (no compiler-chosen FMA contraction): the per-step,
+// the counter-protocol and the granule-protocol recurrence kernels must produce bit-identical states.
+struct LstmCellPw { float si, sf, tg, so, cn, tc, hn; };
+__device__ __forceinline__ LstmCellPw lstm_cell_pw(float pi, float pf, float pg, float po, float c_prev) {
+  LstmCellPw o;
+  o.si = sigmoidf_(pi); o.sf = sigmoidf_(pf); o.tg = tanhf(pg); o.so = sigmoidf_(po);
+  o.cn = __fmaf_rn(o.sf, c_prev, __fmul_rn(o.si, o.tg));
+  o.tc = tanhf(o.cn);
+  o.hn = __fmul_rn(o.so, o.tc);
+  return o;
+}
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 counter RNG: dropout masks are a pure function of
 // (seed, stream offset, element index) so backward regenerates them instead

@@ -11,6 +11,9 @@
 // reverse direction starts at each row's own last token because its state stays 0 until t < len[b].
 // Backward-through-time mirrors it: wave w contracts gate block w of the previous step's dgates with the
 // transposed W_hh shadow, LDS-reduce, then the pointwise cell backward.
+#include <mutex>
+#include <unordered_map>
+
 #include "vln_internal.h"
 #include "graph_cache.h"
 #include "../../include/vln_hip.h"
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs a) {
   const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf;
   const float pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
   const bool valid = t < len;
-  const float si = sigmoidf_(pi), sf = sigmoidf_(pf), tg = tanhf(pg), so = sigmoidf_(po);
-  const float cn = sf * cp + si * tg, tc = tanhf(cn), hn = so * tc;
+  const LstmCellPw cw = lstm_cell_pw(pi, pf, pg, po, cp);
+  const float si = cw.si, sf = cw.sf, tg = cw.tg, so = cw.so, cn = cw.cn, tc = cw.tc, hn = cw.hn;
   float* ac = a.act + row * G + (long)d * 4 * Hd + j;
   ac[0] = si; ac[Hd] = sf; ac[2 * Hd] = tg; ac[3 * Hd] = so;
   a.tanh_c[row * Y + d * Hd + j] = tc;
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
 }
 
 #include "encoder_persist.h"
+#include "encoder_persist_g.h"
 
 // ---- embedding gather (+dropout) to time-major rows, and its scatter-add backward ----------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens, const float* E, float* out, int B,
@@ -536,8 +540,16 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
 }
 
 // ---- persistent single-launch path (encoder_persist.h) ------------------------------------------------------
+// 0 = per-step launch chain; 1 (default) = persistent kernels, forward with data-tagged granule hand-offs
+// (encoder_persist_g.h), backward with the counter + payload hand-off (encoder_persist.h); 2 = both on the counter protocol
+// (round 1); 3 = both on granules.  Measured on MI355X (scripts/lstm_probe, B=64, Hd=256, L=80, bf16, interleaved on one box,
+// profiles/round2_lstm_probe.txt): forward 259 us (counter) -> 193 us (granules); backward 196 us (counter) vs 291 us
+// (granules) -- its hand-off is a PARTIAL-SUM exchange of 32 KB per workgroup per step, and doubling those bytes with tags
+// costs more than the removed drain + barrier + atomic.  All variants produce identical bits.
 int g_persist_enabled = 1;
-extern "C" int vln_set_persistent(int on) { g_persist_enabled = on ? 1 : 0; return VLN_OK; }
+extern "C" int vln_set_persistent(int on) { g_persist_enabled = (on >= 0 && on <= 3) ? on : 1; return VLN_OK; }
+static inline bool fwd_granules() { return g_persist_enabled == 1 || g_persist_enabled == 3; }
+static inline bool bwd_granules() { return g_persist_enabled == 3; }
 
 // Co-residency: every workgroup of the persistent grid spins on its neighbours, so the WHOLE grid must be resident at once.
 // The kernels keep their W_hh slice in registers (about one workgroup per CU), so the capacity is the device's CU count --
@@ -606,6 +618,7 @@ static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
   const int cus = device_cus();
   if (cus <= 0 || wgs > cus || dirs * ((B + 15) / 16) > 32) return false;   // every workgroup must be co-resident
   if ((long)L * B * dirs * 4 * Hd * 4 >= (1L << 32)) return false;       // 32-bit buffer offsets
+  if ((fwd_granules() || bwd_granules()) && L > 255) return false;      // granule tags hold the step in 8 bits
   return true;
 }
 
@@ -655,11 +668,81 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
   return VLN_OK;
 }
 
-// sync_ws layout: kSyncHeaderBytes of status word + arrival-flag lines (zeroed every call), then the backward's
-// partial-dh exchange buffer
+// sync_ws layout: kSyncHeaderBytes (sticky word, status word, arrival-flag lines of the counter protocol; zeroed from word
+// kSyncKeepWords on every call) | counter protocol: the backward's partial-dh exchange floats | granule protocol: forward
+// exchange | granule protocol: backward exchange.  Granule regions are never cleared between launches: their tags carry a
+// per-buffer launch sequence (persist_tag_base).
+static long sync_off_gfwd(int B, int Hd, int dirs) { return kSyncHeaderBytes + persist_bwd_exchange_floats(B, Hd, dirs) * 4; }
+static long sync_off_gbwd(int B, int Hd, int dirs) { return sync_off_gfwd(B, Hd, dirs) + persist_g_fwd_bytes(B, Hd, dirs); }
 extern "C" int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs) {
   if (B <= 0 || Hd <= 0 || dirs < 1) return kSyncHeaderBytes;
-  return kSyncHeaderBytes + persist_bwd_exchange_floats(B, Hd, dirs) * 4;
+  return sync_off_gbwd(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs);
+}
+
+// Tag base of the next granule-protocol launch on this buffer: (sequence << 8), sequence = 1, 2, ... per buffer address.
+// A buffer starts zeroed (tags 0 never match a base >= 256); when the 24-bit sequence wraps the granule regions are cleared
+// once, so no stale granule can carry a live tag.
+static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long gran_bytes, unsigned* base_out) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, unsigned> seq;
+  std::lock_guard<std::mutex> lock(mu);
+  unsigned& q = seq[sync_ws];
+  if (++q >= (1u << 24)) {
+    if (hipMemsetAsync(static_cast<char*>(sync_ws) + gran_off, 0, (size_t)gran_bytes, st) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("persistent lstm: clearing the granule exchange on sequence wrap failed");
+      return VLN_ERR_HIP;
+    }
+    q = 1;
+  }
+  *base_out = q << 8;
+  return VLN_OK;
+}
+
+template <typename TW>
+static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+  const dim3 g1(grid.x * grid.y * grid.z);
+  const int xm = g_tunable[7] != 1;
+  constexpr int BK = RecCfg<TW>::BK;
+#define VLN_PERSIST_GF(NS_)                                                                                               \
+  {                                                                                                                       \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
+    if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
+    hipLaunchKernelGGL((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, exch, tag_base, xm);         \
+  }                                                                                                                       \
+  break
+  switch (a.Hd / BK) {
+    case 2: VLN_PERSIST_GF(2);
+    case 4: VLN_PERSIST_GF(4);
+    case 8: VLN_PERSIST_GF(8);
+    case 16: VLN_PERSIST_GF(16);
+    default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
+  }
+#undef VLN_PERSIST_GF
+  VLN_CHECK_LAUNCH("lstm_persist_g_fwd");
+  return VLN_OK;
+}
+
+template <typename TW>
+static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+  const dim3 g1(grid.x * grid.y * grid.z);
+  const int xm = g_tunable[7] != 1;
+#define VLN_PERSIST_GB(NT_)                                                                                               \
+  {                                                                                                                       \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_bwd_kernel<TW, NT_>);                                  \
+    if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
+    hipLaunchKernelGGL((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, exch, tag_base, xm);         \
+  }                                                                                                                       \
+  break
+  switch (a.Hd / 64) {
+    case 2: VLN_PERSIST_GB(2);
+    case 4: VLN_PERSIST_GB(4);
+    case 8: VLN_PERSIST_GB(8);
+    default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
+  }
+#undef VLN_PERSIST_GB
+  VLN_CHECK_LAUNCH("lstm_persist_g_bwd");
+  return VLN_OK;
 }
 
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
@@ -668,7 +751,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
                                 int64_t sync_ws_bytes, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
-  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= kSyncHeaderBytes && al16(w_hh) && al16(hprev)) {
+  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
+      al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
     r = fill_f32(st, (float*)sync_ws + kSyncKeepWords, kSyncHeaderBytes / 4 - kSyncKeepWords, 0.f);     // status word [32], flag lines from word 64
@@ -679,10 +763,20 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
+    unsigned tag_base = 0;
+    unsigned char* gex = static_cast<unsigned char*>(sync_ws) + sync_off_gfwd(B, Hd, dirs);
+    if (fwd_granules()) {
+      r = persist_tag_base(st, sync_ws, sync_off_gfwd(B, Hd, dirs), persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs), &tag_base);
+      if (r) return r;
+    }
     {
       ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
-      r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
-                              : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
+      if (fwd_granules())
+        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid)
+                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid);
+      else
+        r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
+                                : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
     }
     sticky_publish(st, sync_ws);
     return r;
@@ -729,10 +823,20 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
+    unsigned tag_base = 0;
+    unsigned char* gex = static_cast<unsigned char*>(sync_ws) + sync_off_gbwd(B, Hd, dirs);
+    if (bwd_granules()) {
+      r = persist_tag_base(st, sync_ws, sync_off_gfwd(B, Hd, dirs), persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs), &tag_base);
+      if (r) return r;
+    }
     {
       ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
-      r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
-                              : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
+      if (bwd_granules())
+        r = (wtype == VLN_BF16) ? launch_persist_g_bwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid)
+                                : launch_persist_g_bwd<float>(st, a, cw + 32, gex, tag_base, grid);
+      else
+        r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
+                                : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
     }
     sticky_publish(st, sync_ws);
     return r;

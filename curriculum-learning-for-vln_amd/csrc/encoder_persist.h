@@ -228,10 +228,9 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
     if (live) {
       const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf, pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
       const bool valid = t < len;
-      si = sigmoidf_(pi); sf = sigmoidf_(pf); tg = tanhf(pg); so = sigmoidf_(po);
-      const float cn = sf * creg + si * tg;
-      tc = tanhf(cn);
-      const float hn = so * tc;
+      const LstmCellPw cw = lstm_cell_pw(pi, pf, pg, po, creg);
+      si = cw.si; sf = cw.sf; tg = cw.tg; so = cw.so; tc = cw.tc;
+      const float cn = cw.cn, hn = cw.hn;
       yv = valid ? hn : 0.f;
       const float hs = valid ? hn : hreg, cs = valid ? cn : creg;
       const int tn = (d == 0) ? t + 1 : t - 1;

@@ -1,0 +1,368 @@
+// Persistent packed-(bi)LSTM recurrence, hand-off by DATA-TAGGED GRANULES (included by encoder.hip after encoder_persist.h,
+// whose geometry, resident-weight fragments and MFMA helpers it shares).
+//
+// Round 1's protocol (encoder_persist.h: write-through payload -> every wave's vmcnt(0) -> workgroup barrier -> one atomic add on
+// the group's counter; consumer: poll the counter -> barrier -> sc1 reload of the payload) cost 3.3 us (forward) / 2.7 us
+// (backward) per time step: a hand-off with a separate flag is two dependent fabric round trips plus two workgroup barriers.
+// Here every handed-off value travels as ONE naturally aligned 8-byte granule {fp32 value, 32-bit tag} (MI355X_MICROARCH.md,
+// "handoff-1to1" / Guideline 16 form R2): the tag says which launch and which time step the value belongs to, so
+//   producer:  two granules per lane-pair as ONE 16-byte write-through (sc1) store -- a 128-byte line per row is written
+//              whole by one store instruction of one wave; NO vmcnt drain, NO barrier, NO counter;
+//   consumer:  every wave sweeps ITS share of the tile with 16-byte sc1 loads (buffer_load_dwordx4: bypasses this CU's L1) and
+//              repeats the sweep until every tag carries this step's value; the data it needs arrived with the tag.
+// An 8-byte granule is written by one store and read by one load, so a reader sees either the old or the new {value, tag} --
+// no ordering between granules is needed.  Two parity slots per group: a producer can only be one step ahead of the slowest
+// consumer of its group (it needs every member's step-s data before it can publish step s+1, which reuses the slot of s-1).
+// Tags: (per-buffer launch sequence << 8) | (step + 1); the host hands every launch of a buffer a new sequence number and
+// clears the buffer when the 24-bit sequence wraps, so a stale granule can never carry a live tag.  L <= 255 on this path.
+// Spins are bounded; a timeout sets the status words (encoder.hip: vln_persistent_check) and lets the kernel drain.
+// Summation orders equal the counter-protocol kernels': results are bit-identical to theirs.
+#pragma once
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kGranSpinLimit = 1u << 20;     // sweeps of ~1 us: ~1 s
+
+// bytes of the two exchange regions behind the sync header (granules: 8 bytes per handed-off value)
+__host__ __device__ inline long persist_g_fwd_bytes(int B, int Hd, int dirs) {
+  return (long)dirs * ((B + 15) / 16) * 2 * 16 * Hd * 8;
+}
+__host__ __device__ inline long persist_g_bwd_bytes(int B, int Hd, int dirs) {
+  return (long)dirs * ((B + 15) / 16) * 2 * (Hd / 16) * Hd * 16 * 8;
+}
+
+// bf16 weights: the h tile is split hi + lo ONCE by the thread that receives it (two bf16 planes in LDS); the four gate waves
+// then read ready-made fragments.  The counter-protocol kernel converts inside every wave's MFMA loop: 4x the conversions, on
+// the step's critical path.  Same values, same MFMA order -> same bits.
+template <int NS>
+__device__ __forceinline__ void mfma_resident_planes(const bf16_raw* hi_row, const bf16_raw* lo_row, const WFrag<bf16_raw, NS>& w,
+                                                     int fq, f32x4& acc) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = s * 64 + fq * 16;
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hi_row + k), a1 = *reinterpret_cast<const bf16x8*>(hi_row + k + 8);
+    const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(lo_row + k), l1 = *reinterpret_cast<const bf16x8*>(lo_row + k + 8);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, w.v[s][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, w.v[s][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w.v[s][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w.v[s][1], acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void split_store2(bf16_raw* hi, bf16_raw* lo, float x0, float x1) {
+  const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+  const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
+  *reinterpret_cast<uint32_t*>(hi) = (uint32_t)__builtin_bit_cast(bf16_raw, h0) | ((uint32_t)__builtin_bit_cast(bf16_raw, h1) << 16);
+  *reinterpret_cast<uint32_t*>(lo) = (uint32_t)__builtin_bit_cast(bf16_raw, l0) | ((uint32_t)__builtin_bit_cast(bf16_raw, l1) << 16);
+}
+
+__device__ __forceinline__ void gran_timeout(unsigned* status, int* s_abort) {
+  VLN_AGENT_STORE(status, 1u);
+  __hip_atomic_fetch_add(status - kStickyBack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *s_abort = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: NS = Hd / BK.  Exchange layout: [group][parity][row 16][unit HD] granules.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TW, int NS>
+__global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned char* exch, unsigned tag_base,
+                                                                 int xcd_map) {
+  constexpr int HD = NS * RecCfg<TW>::BK;
+  constexpr int LDH = HD + 4;
+  constexpr int NLD = HD / 32;                 // 16-byte loads per thread per sweep: 16 rows x HD granules x 8 B / (256 x 16 B)
+  constexpr bool kPlanes = sizeof(TW) == 2;    // bf16 weights: the tile lives in LDS as two bf16 planes (hi, lo)
+  constexpr int LDP = HD + 8;                  // plane row stride in bf16: 2 HD + 16 bytes, conflict-free 16-byte fragment reads
+  constexpr int kTileBytes = kPlanes ? 2 * 16 * LDP * 2 : 16 * LDH * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char tile_raw[kTileBytes];
+  float* const sh = reinterpret_cast<float*>(tile_raw);
+  bf16_raw* const ph = reinterpret_cast<bf16_raw*>(tile_raw);           // hi plane; lo plane follows
+  bf16_raw* const pl = ph + 16 * LDP;
+  __shared__ float sg[4][16][17];
+  __shared__ int s_abort;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const int j0 = ix.jb * 16, d = ix.d, b0 = ix.bb * 16;
+  const int B = a.B, L = a.L;
+  const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
+
+  WFrag<TW, NS> w;
+  load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
+
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool live = b < B;
+  const int len = live ? a.lengths[b] : 0;
+  float hreg = 0.f, creg = 0.f;
+  if (a.init && live) {      // caller-given initial state, already copied into the first time slot (plain loads)
+    const long s0 = (((long)d * L + (d == 0 ? 0 : L - 1)) * B + b) * HD + j;
+    hreg = a.hprev[s0]; creg = a.cprev[s0];
+  }
+  const unsigned grp_bytes = 2u * 16u * HD * 8u;
+  __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(exch, 0, (unsigned)persist_g_fwd_bytes(B, HD, a.dirs), 0x00020000);
+  const unsigned gbase = (unsigned)(d * ix.nbb + ix.bb) * grp_bytes;
+  __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+
+  for (int step = 0; step < L; ++step) {
+    const int t = (d == 0) ? step : (L - 1 - step);
+    const long sbase = ((long)d * L + t) * B;
+    const long row = (long)t * B + (live ? b : 0);
+    float xi = 0.f, xf = 0.f, xg = 0.f, xo = 0.f;
+    if (live) {   // plain loads: written by the projection GEMM before this launch
+      const float* xp = a.xproj + row * G + (long)d * 4 * HD + j;
+      xi = xp[0]; xf = xp[HD]; xg = xp[2 * HD]; xo = xp[3 * HD];
+    }
+    VLN_STAMP(0);
+    if (step > 0) {
+      // sweep this thread's NLD x 2 granules of the group's h tile (time t), published in step - 1
+      const unsigned expect = tag_base + (unsigned)step;
+      const unsigned pbase = gbase + (unsigned)((step - 1) & 1) * (16u * HD * 8u);
+      u32x4_t v[NLD];
+      unsigned spins = 0;
+      const bool dead = s_abort != 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xres, pbase + (unsigned)(threadIdx.x + u * 256) * 16u, 0, 16);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) ok = ok && (v[u].y == expect) && (v[u].w == expect);
+        if (__all(ok) || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kGranSpinLimit) {          // a workgroup of the group is not resident / died
+          if (lane == 0) gran_timeout(status, &s_abort);
+          break;
+        }
+      }
+      VLN_STAMP(1);
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int unit = threadIdx.x + u * 256;                 // pair index within the tile: row r, units 2*c2, 2*c2 + 1
+        const int r = unit / (HD / 2), c2 = unit % (HD / 2);
+        if constexpr (kPlanes) split_store2(ph + r * LDP + c2 * 2, pl + r * LDP + c2 * 2, __uint_as_float(v[u].x), __uint_as_float(v[u].z));
+        else *reinterpret_cast<float2*>(&sh[r * LDH + c2 * 2]) = make_float2(__uint_as_float(v[u].x), __uint_as_float(v[u].z));
+      }
+    } else if (a.init) {
+      VLN_STAMP(1);
+      // caller-given initial state: plain rows of the first time slot
+#pragma unroll
+      for (int u = 0; u < HD / 64; ++u) {
+        const int unit = threadIdx.x + u * 256;
+        const int r = unit / (HD / 4), c4 = unit % (HD / 4);
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + r < B) v4 = *reinterpret_cast<const float4*>(a.hprev + (sbase + b0 + r) * HD + c4 * 4);
+        if constexpr (kPlanes) {
+          split_store2(ph + r * LDP + c4 * 4, pl + r * LDP + c4 * 4, v4.x, v4.y);
+          split_store2(ph + r * LDP + c4 * 4 + 2, pl + r * LDP + c4 * 4 + 2, v4.z, v4.w);
+        } else {
+          *reinterpret_cast<float4*>(&sh[r * LDH + c4 * 4]) = v4;
+        }
+      }
+    } else {
+      VLN_STAMP(1);
+      for (int i = threadIdx.x; i < kTileBytes / 4; i += 256) reinterpret_cast<uint32_t*>(tile_raw)[i] = 0u;
+    }
+    __syncthreads();
+    VLN_STAMP(2);
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (kPlanes) mfma_resident_planes<NS>(ph + fi * LDP, pl + fi * LDP, w, fq, acc);
+      else mfma_resident<TW, NS>(&sh[fi * LDH], w, fq, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sg[wave][fq * 4 + r][fi] = acc[r];
+    }
+    __syncthreads();
+    VLN_STAMP(3);
+    float si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, yv = 0.f, c_in = creg, hs = 0.f, cs = 0.f;
+    if (live) {
+      const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf, pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
+      const bool valid = t < len;
+      const LstmCellPw cw = lstm_cell_pw(pi, pf, pg, po, creg);
+      si = cw.si; sf = cw.sf; tg = cw.tg; so = cw.so; tc = cw.tc;
+      const float cn = cw.cn, hn = cw.hn;
+      yv = valid ? hn : 0.f;
+      hs = valid ? hn : hreg; cs = valid ? cn : creg;
+      hreg = hs; creg = cs;
+    }
+    const int tn = (d == 0) ? t + 1 : t - 1;
+    if (tn >= 0 && tn < L) {
+      // publish: lanes (jl even) store {h_j, tag, h_j+1, tag} = 16 bytes; the 8 stores of a row fill one 128-byte line
+      const float hnb = __shfl_down(hs, 1, 64);
+      if ((jl & 1) == 0) {
+        const unsigned tg_ = tag_base + (unsigned)step + 1u;
+        const u32x4_t o = {__float_as_uint(hs), tg_, __float_as_uint(hnb), tg_};
+        __builtin_amdgcn_raw_buffer_store_b128(o, xres, gbase + (unsigned)(step & 1) * (16u * HD * 8u) + (unsigned)(bl * HD + j) * 8u, 0, 16);   // sc1
+      }
+      if (live) a.hprev[(((long)d * L + tn) * B + b) * HD + j] = hs;     // history for BPTT / the weight gradients: plain
+    } else if (live) {
+      a.hcat[(long)b * Y + d * HD + j] = hs;
+      a.ccat[(long)b * Y + d * HD + j] = cs;
+    }
+    VLN_STAMP(4);
+    if (live) {   // saved for BPTT / the layer output: read only after this launch
+      float* ac = a.act + row * G + (long)d * 4 * HD + j;
+      ac[0] = si; ac[HD] = sf; ac[2 * HD] = tg; ac[3 * HD] = so;
+      a.tanh_c[row * Y + d * HD + j] = tc;
+      a.y[row * Y + d * HD + j] = yv;
+      a.cprev[(sbase + b) * HD + j] = c_in;                       // state fed into time t
+      if (step == 0 && !a.init) a.hprev[(sbase + b) * HD + j] = 0.f;
+    }
+    VLN_STAMP(5);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward through time (partial-dh exchange as in encoder_persist.h, granules instead of counter + payload).
+// Exchange layout: [group][parity][producer jb][unit HD][row 16] granules; a lane's MFMA result (4 consecutive rows of one
+// unit) is TWO 16-byte write-through stores; the owner of 16 units fetches each producer's [16 units][16 rows] block with two
+// 16-byte sc1 loads per lane.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
+__global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, unsigned* status, unsigned char* exch, unsigned tag_base,
+                                                                 int xcd_map) {
+  constexpr int HD = NT * 64;
+  constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
+  constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
+  constexpr int NJB = HD / 16;                 // producers per dependency group
+  constexpr int LDT = 64 + 4;
+  constexpr int NPW = NJB / 4;                 // producers summed per wave
+  __shared__ __attribute__((aligned(16))) float tile[16 * LDT];   // this step's dgates: [row][gate*16 + unit]
+  __shared__ __attribute__((aligned(16))) float red[4][64][4];    // per-wave sums of the incoming partial-dh blocks
+  __shared__ int s_abort;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
+  const int B = a.B, L = a.L;
+  const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
+
+  WFrag<TW, NSK> w[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = (wave * NT + i) * 16 + fi;
+    const TW* wrow = reinterpret_cast<const TW*>(a.w_hh_t) + ((long)d * HD + n) * 4 * HD + j0;
+#pragma unroll
+    for (int s = 0; s < NSK; ++s) {
+      const int kk0 = s * BK + fq * VK;        // first of this lane's VK consecutive k (never straddles a gate)
+      const TW* p = wrow + (long)(kk0 / 16) * HD + (kk0 % 16);
+      if constexpr (sizeof(TW) == 4) {
+        w[i].v[s][0] = *reinterpret_cast<const float4*>(p);
+        w[i].v[s][1] = *reinterpret_cast<const float4*>(p + 4);
+      } else {
+        w[i].v[s][0] = *reinterpret_cast<const bf16x8*>(p);
+        w[i].v[s][1] = *reinterpret_cast<const bf16x8*>(p + 8);
+      }
+    }
+  }
+
+  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool live = b < B;
+  const int len = live ? a.lengths[b] : 0;
+  const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
+  float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
+  const unsigned par_bytes = (unsigned)NJB * HD * 16u * 8u;                 // one parity slot of one group
+  __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(exch, 0, (unsigned)persist_g_bwd_bytes(B, HD, a.dirs), 0x00020000);
+  const unsigned gbase = (unsigned)(d * ix.nbb + ix.bb) * 2u * par_bytes;
+  __builtin_amdgcn_s_setprio(3);
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+
+  for (int step = L - 1; step >= 0; --step) {
+    const int k = L - 1 - step;                // steps already processed
+    const int t = (d == 0) ? step : (L - 1 - step);
+    const long row = (long)t * B + (live ? b : 0);
+    const bool valid = live && (t < len);
+    float dyv = 0.f, si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, cp = 0.f;
+    if (valid) {   // plain loads: produced by the forward pass / upstream gradient before this launch
+      if (a.dy) dyv = a.dy[row * Y + d * HD + j];
+      const float* ac = a.act + row * G + (long)d * 4 * HD + j;
+      si = ac[0]; sf = ac[HD]; tg = ac[2 * HD]; so = ac[3 * HD];
+      tc = a.tanh_c[row * Y + d * HD + j];
+      cp = a.cprev[(((long)d * L + t) * B + b) * HD + j];
+    }
+    VLN_STAMP(0);
+    float dh = dh_pass;
+    if (k > 0) {
+      // producer p's block for OUR 16 units: [unit j0 .. j0+15][row 16] granules = 2 KB; lane: unit lane/4, rows (lane&3)*4 .. +3
+      const unsigned expect = tag_base + (unsigned)k;
+      const unsigned rbase = gbase + (unsigned)((k - 1) & 1) * par_bytes + (unsigned)(j0 * 16) * 8u + (unsigned)lane * 32u;
+      u32x4_t v[NPW][2];
+      unsigned spins = 0;
+      const bool dead = s_abort != 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          const unsigned po = rbase + (unsigned)(wave + 4 * i) * (unsigned)(HD * 16 * 8);
+          v[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xres, po, 0, 16);
+          v[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xres, po + 16u, 0, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          ok = ok && (v[i][0].y == expect) && (v[i][0].w == expect) && (v[i][1].y == expect) && (v[i][1].w == expect);
+        if (__all(ok) || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kGranSpinLimit) {
+          if (lane == 0) gran_timeout(status, &s_abort);
+          break;
+        }
+      }
+      VLN_STAMP(1);
+      float4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {          // fixed order: producers wave, wave + 4, ...
+        s4.x += __uint_as_float(v[i][0].x); s4.y += __uint_as_float(v[i][0].z);
+        s4.z += __uint_as_float(v[i][1].x); s4.w += __uint_as_float(v[i][1].z);
+      }
+      *reinterpret_cast<float4*>(&red[wave][lane][0]) = s4;
+      __syncthreads();
+      const int q = jl * 4 + (bl >> 2), e = bl & 3;
+      dh += (red[0][q][e] + red[1][q][e]) + (red[2][q][e] + red[3][q][e]);
+    }
+    VLN_STAMP(2);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (valid) {
+      dh += dyv;
+      const float dc = dcc + dh * so * (1.f - tc * tc);
+      g0 = dc * tg * si * (1.f - si);
+      g1 = dc * cp * sf * (1.f - sf);
+      g2 = dc * si * (1.f - tg * tg);
+      g3 = dh * tc * so * (1.f - so);
+      dcc = dc * sf;
+      dh_pass = 0.f;
+    } else {
+      dh_pass = dh;
+    }
+    if (step > 0) {                            // nobody consumes a partial dh of the last processed step
+      float* tr = &tile[bl * LDT + jl];
+      tr[0] = g0; tr[16] = g1; tr[32] = g2; tr[48] = g3;
+    }
+    __syncthreads();                           // tile complete; every wave is past its reads of `red`
+    VLN_STAMP(3);
+    if (step > 0) {
+      AFrag<TW, NSK> af;
+      load_afrag<TW, NSK>(af, &tile[fi * LDT], fq);
+      const unsigned tg_ = tag_base + (unsigned)k + 1u;
+      const unsigned wbase = gbase + (unsigned)(k & 1) * par_bytes + (unsigned)jb * (unsigned)(HD * 16 * 8);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mfma_frags<TW, NSK>(af, w[i], acc);
+        const int n = (wave * NT + i) * 16 + fi;
+        const unsigned o = wbase + (unsigned)(n * 16 + fq * 4) * 8u;
+        const u32x4_t o0 = {__float_as_uint(acc[0]), tg_, __float_as_uint(acc[1]), tg_};
+        const u32x4_t o1 = {__float_as_uint(acc[2]), tg_, __float_as_uint(acc[3]), tg_};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, xres, o, 0, 16);          // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(o1, xres, o + 16u, 0, 16);    // sc1
+      }
+    }
+    VLN_STAMP(4);
+    if (live) {    // consumed by the weight-gradient GEMMs after this launch: plain stores, off the hand-off path
+      float* dg = a.dgates + row * G + (long)d * 4 * HD + j;
+      dg[0] = g0; dg[HD] = g1; dg[2 * HD] = g2; dg[3 * HD] = g3;
+    }
+    VLN_STAMP(5);
+  }
+}

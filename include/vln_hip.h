@@ -328,7 +328,8 @@ int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int3
                      const float* h0, const float* c0 /* [dirs][B][Hd] initial state, nullable = zeros (no gradient flows
                      back into it: vln_lstm_seq_bwd starts from the final states only) */,
                      void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
-int vln_set_persistent(int on);   /* 0 forces the per-step path; results are identical */
+int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = persistent kernels, granule hand-off forward, counter
+                                   * hand-off backward; 2 = counter both ways (round 1); 3 = granules both ways; identical results */
 /* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the
  * device's CU count (queried).  If a wait still times out the kernels count it in a sticky word that every launch copies to
  * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as

@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   hipMalloc(&d_len, B * 4);
   const long sync_bytes = vln_lstm_sync_ws_bytes(B, Hd, dirs);
   hipMalloc(&d_sync, sync_bytes);
+  hipMemset(d_sync, 0, sync_bytes);
   const size_t wel = whh.size();
   hipMalloc(&d_w, wel * 4); hipMalloc(&d_wt, wel * 4);
   std::vector<float> wt(wel);                                         // [dirs][Hd][4Hd] transpose for the backward
@@ -69,13 +70,18 @@ int main(int argc, char** argv) {
   hipMemcpy(d_len, len.data(), B * 4, hipMemcpyHostToDevice);
   hipMemset(d_dh, 0, dirs * B * Hd * 4); hipMemset(d_dc, 0, dirs * B * Hd * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  // protocol 2 = counter + payload hand-off (round 1), 1 = data-tagged granules; interleaved on the same box
+  for (int round = 0; round < 6; ++round) {
+  const int proto = (round % 3 == 0) ? 2 : (round % 3 == 1 ? 1 : 3);
+  vln_set_persistent(proto);
+  printf("---- protocol %s\n", proto == 2 ? "counter (fwd + bwd)" : proto == 1 ? "default: granules fwd, counter bwd" : "granules (fwd + bwd)");
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
     int r = vln_lstm_seq_fwd(d_x, d_w, wtype, d_len, d_hp, d_cp, d_y, d_act, d_tc, d_hc, d_cc, B, L, Hd, dirs, nullptr, nullptr, d_sync, sync_bytes, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (r) { printf("fwd failed: %s\n", vln_last_error_string()); return 1; }
-    if (rep == 3) { printf("fwd launch %.1f us  ", ms * 1e3); { const char* lab[] = {"", "wait", "load->LDS", "mfma", "pointwise+handoff store", "drain+arrive"}; report("fwd", L, 6, lab); } }
+    if (rep == 3) { printf("fwd launch %.1f us  ", ms * 1e3); { const char* lab[] = {"", "wait/sweep", "load->LDS", "mfma", "pointwise+handoff store", "drain+arrive / bookkeeping"}; report("fwd", L, 6, lab); } }
   }
   for (int rep = 0; rep < 4; ++rep) {
     hipMemset(d_dh, 0, dirs * B * Hd * 4); hipMemset(d_dc, 0, dirs * B * Hd * 4);
@@ -104,5 +110,6 @@ int main(int argc, char** argv) {
   }
   float chk[4]; hipMemcpy(chk, d_hc, 16, hipMemcpyDeviceToHost);
   printf("hcat[0..3] = %g %g %g %g\n", chk[0], chk[1], chk[2], chk[3]);
+  }
   return 0;
 }
