@@ -312,7 +312,7 @@ class GpuAgent:
             loss = torch.stack(terms).sum() * w
         loss.backward()
         self.opt.allreduce()
-        self.opt.step()
+        self.opt.step(zero_grads=True)       # the update clears the gradients it consumed: the next zero_grad() is free
         return loss
 
 

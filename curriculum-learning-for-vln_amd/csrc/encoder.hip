@@ -573,34 +573,32 @@ static bool kernel_fits_one_per_cu(K kernel) {      // the occupancy API's answe
 }
 
 // A bounded spin that timed out leaves wrong numbers behind.  The per-launch status word is zeroed by the next launch, so
-// the kernels also count timeouts in a STICKY word (header word 0); every persistent launch is followed by a 4-byte copy of
-// it into pinned host memory, and the next entry into the library (sequence forward / backward, optimizer step:
-// vln_persistent_check) reports it ONCE as an error and switches this process to the per-step chain.
-static unsigned* g_sticky_host = nullptr;       // pinned, one word per device
-static unsigned* sticky_host() {
+// the kernels also count timeouts in a STICKY word that lives in host-mapped pinned memory (one per device; a system-scope
+// atomic from the timeout path, i.e. no traffic at all in a healthy run); the next entry into the library (sequence
+// forward / backward, optimizer step: vln_persistent_check) reports it ONCE as an error and switches this process to the
+// per-step chain.
+static unsigned* g_sticky_host = nullptr;       // pinned + mapped, one word per device (16 words apart)
+static unsigned* g_sticky_dev = nullptr;        // the same memory as the device sees it
+static unsigned* sticky_dev_word() {
   if (!g_sticky_host) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&g_sticky_host), 16 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&g_sticky_host), 16 * 16 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&g_sticky_dev), g_sticky_host, 0) != hipSuccess) {
       (void)hipGetLastError();
-      g_sticky_host = nullptr;
+      g_sticky_host = nullptr; g_sticky_dev = nullptr;
       return nullptr;
     }
-    for (int i = 0; i < 16; ++i) g_sticky_host[i] = 0u;
+    for (int i = 0; i < 16 * 16; ++i) g_sticky_host[i] = 0u;
   }
-  return g_sticky_host;
-}
-static void sticky_publish(hipStream_t st, const void* sync_ws) {
-  unsigned* h = sticky_host();
   int dev = 0;
-  if (!h || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return; }
-  if (hipMemcpyAsync(h + dev, sync_ws, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) (void)hipGetLastError();
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+  return g_sticky_dev + dev * 16;
 }
 extern "C" int vln_persistent_check(void) {
   unsigned* h = g_sticky_host;
   if (!h) return VLN_OK;
   for (int d = 0; d < 16; ++d) {
-    if (h[d]) {
-      const unsigned n = h[d];
-      h[d] = 0u;
+    if (__atomic_load_n(&h[d * 16], __ATOMIC_RELAXED)) {
+      const unsigned n = __atomic_exchange_n(&h[d * 16], 0u, __ATOMIC_RELAXED);
       g_persist_enabled = 0;
       set_error("persistent LSTM recurrence: %u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (its "
                 "workgroups were not co-resident); that iteration's numbers are invalid.  The persistent path is now off for "
@@ -624,6 +622,8 @@ static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
 
 template <typename TW>
 static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* counters, unsigned* status, dim3 grid) {
+  unsigned* sticky = sticky_dev_word();
+  if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);          // one-dimensional: the kernel decodes (slice, direction, row block)
   const int xm = g_tunable[7] != 1;                 // tunable[7] = 1: dispatch-order mapping (A/B)
   constexpr int BK = RecCfg<TW>::BK;
@@ -631,7 +631,7 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_fwd_kernel<TW, NS_>);                                    \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, counters, status, xm);                 \
+    hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, counters, status, sticky, xm);                 \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -648,13 +648,15 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
 
 template <typename TW>
 static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid) {
+  unsigned* sticky = sticky_dev_word();
+  if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);
   const int xm = g_tunable[7] != 1;
 #define VLN_PERSIST_BWD(NT_)                                                                                              \
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_>);                                    \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, exch, xm);           \
+    hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, sticky, exch, xm);           \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -668,8 +670,8 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
   return VLN_OK;
 }
 
-// sync_ws layout: kSyncHeaderBytes (sticky word, status word, arrival-flag lines of the counter protocol; zeroed from word
-// kSyncKeepWords on every call) | counter protocol: the backward's partial-dh exchange floats | granule protocol: forward
+// sync_ws layout: kSyncHeaderBytes (status word, arrival-flag lines of the counter protocol; zeroed before every
+// counter-protocol launch) | counter protocol: the backward's partial-dh exchange floats | granule protocol: forward
 // exchange | granule protocol: backward exchange.  Granule regions are never cleared between launches: their tags carry a
 // per-buffer launch sequence (persist_tag_base).
 static long sync_off_gfwd(int B, int Hd, int dirs) { return kSyncHeaderBytes + persist_bwd_exchange_floats(B, Hd, dirs) * 4; }
@@ -701,6 +703,8 @@ static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long g
 
 template <typename TW>
 static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+  unsigned* sticky = sticky_dev_word();
+  if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);
   const int xm = g_tunable[7] != 1;
   constexpr int BK = RecCfg<TW>::BK;
@@ -708,7 +712,7 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, exch, tag_base, xm);         \
+    hipLaunchKernelGGL((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -725,13 +729,15 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
 
 template <typename TW>
 static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+  unsigned* sticky = sticky_dev_word();
+  if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);
   const int xm = g_tunable[7] != 1;
 #define VLN_PERSIST_GB(NT_)                                                                                               \
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_bwd_kernel<TW, NT_>);                                  \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, exch, tag_base, xm);         \
+    hipLaunchKernelGGL((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -755,8 +761,10 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
-    r = fill_f32(st, (float*)sync_ws + kSyncKeepWords, kSyncHeaderBytes / 4 - kSyncKeepWords, 0.f);     // status word [32], flag lines from word 64
-    if (r) return r;
+    if (!fwd_granules()) {    // counter protocol: status word [32] + flag lines from word 64 start at zero (the granule kernel
+      r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);        // clears its own status word and has no counters)
+      if (r) return r;
+    }
     const int init = (h0 || c0) ? 1 : 0;
     if (init) { r = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs); if (r) return r; }
     RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init};
@@ -778,7 +786,6 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
     }
-    sticky_publish(st, sync_ws);
     return r;
   }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
@@ -817,7 +824,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
-    r = fill_f32(st, (float*)sync_ws + kSyncKeepWords, kSyncHeaderBytes / 4 - kSyncKeepWords, 0.f);
+    r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
     if (r) return r;
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
@@ -838,7 +845,6 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
         r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
                                 : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
     }
-    sticky_publish(st, sync_ws);
     return r;
   }
   struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},

@@ -39,9 +39,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 //   VLN_SYNC_FLAGS 1: one word per producer in the line -- arrive = write-through store of the epoch, wait = one load
 //                     of the line (lane p = producer p) until every word reached it.  ~4 % slower (289 vs 278 us).
 // Epochs count steps from 1; the header is zeroed before every launch.
-constexpr int kSyncHeaderBytes = 8192;    // sticky timeout count at byte 0, status word at byte 128, flag lines (32 groups x 128 B) from byte 256
-constexpr int kStickyBack = 32;           // words from the status word back to the sticky counter
-constexpr int kSyncKeepWords = 16;        // the first 64 bytes of the header survive the per-launch zeroing
+constexpr int kSyncHeaderBytes = 8192;    // status word at byte 128, flag lines (32 groups x 128 B) from byte 256
 #ifndef VLN_SYNC_FLAGS
 #define VLN_SYNC_FLAGS 0
 #endif
@@ -58,7 +56,7 @@ __device__ __forceinline__ PersistIdx persist_index(int njb, int dirs, int nbb, 
   return PersistIdx{jb, g % dirs, g / dirs, nbb};
 }
 
-__device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned epoch, unsigned* status, int* s_abort) {
+__device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned epoch, unsigned* status, unsigned* sticky, int* s_abort) {
   if (threadIdx.x < 64 && !*s_abort) {
     const int lane = threadIdx.x;
     unsigned spins = 0;
@@ -74,7 +72,7 @@ __device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned ep
       if (++spins > (1u << 24)) {            // ~1 s: a workgroup of the group is not resident / died
         if (lane == 0) {
           VLN_AGENT_STORE(status, 1u);           // this launch (zeroed with the header before the next one)
-          __hip_atomic_fetch_add(status - kStickyBack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: never zeroed by a launch
+          __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sticky: host-mapped, never zeroed by a launch
           *s_abort = 1;
         }
         break;
@@ -157,7 +155,7 @@ __device__ __forceinline__ void mfma_resident(const float* arow, const WFrag<TW,
 // forward: NS = Hd / BK
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NS>
-__global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, unsigned* counters, unsigned* status, int xcd_map) {
+__global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, int xcd_map) {
   constexpr int HD = NS * RecCfg<TW>::BK;
   constexpr int LDH = HD + 4;
   __shared__ __attribute__((aligned(16))) float sh[16 * LDH];
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
     }
     VLN_STAMP(0);
     if (step > 0 || a.init) {
-      if (step > 0) group_wait(cnt, njb, (unsigned)step, status, &s_abort);
+      if (step > 0) group_wait(cnt, njb, (unsigned)step, status, sticky, &s_abort);
       VLN_STAMP(1);
       // h tile [16 rows x HD] of time t, written by the group's workgroups in the previous step
 #pragma unroll
@@ -334,7 +332,7 @@ __host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int d
 }
 
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
-__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, float* exch, int xcd_map) {
+__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map) {
   constexpr int HD = NT * 64;
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
   constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     VLN_STAMP(0);
     float dh = dh_pass;
     if (k > 0) {
-      group_wait(cnt, NJB, (unsigned)k, status, &s_abort);
+      group_wait(cnt, NJB, (unsigned)k, status, sticky, &s_abort);
       VLN_STAMP(1);
       const unsigned rbase = (unsigned)(((grp + ((k - 1) & 1)) * NJB * HD + j0) * 16 * 4) + (unsigned)lane * 16u;
       float4 s4 = {0.f, 0.f, 0.f, 0.f};

@@ -55,9 +55,9 @@ __device__ __forceinline__ void split_store2(bf16_raw* hi, bf16_raw* lo, float x
   *reinterpret_cast<uint32_t*>(lo) = (uint32_t)__builtin_bit_cast(bf16_raw, l0) | ((uint32_t)__builtin_bit_cast(bf16_raw, l1) << 16);
 }
 
-__device__ __forceinline__ void gran_timeout(unsigned* status, int* s_abort) {
+__device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky, int* s_abort) {
   VLN_AGENT_STORE(status, 1u);
-  __hip_atomic_fetch_add(status - kStickyBack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // host-mapped word (encoder.hip)
   *s_abort = 1;
 }
 
@@ -65,8 +65,8 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, int* s_abort) {
 // forward: NS = Hd / BK.  Exchange layout: [group][parity][row 16][unit HD] granules.
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NS>
-__global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned char* exch, unsigned tag_base,
-                                                                 int xcd_map) {
+__global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
+                                                                 unsigned tag_base, int xcd_map) {
   constexpr int HD = NS * RecCfg<TW>::BK;
   constexpr int LDH = HD + 4;
   constexpr int NLD = HD / 32;                 // 16-byte loads per thread per sweep: 16 rows x HD granules x 8 B / (256 x 16 B)
@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(exch, 0, (unsigned)persist_g_fwd_bytes(B, HD, a.dirs), 0x00020000);
   const unsigned gbase = (unsigned)(d * ix.nbb + ix.bb) * grp_bytes;
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
-  if (threadIdx.x == 0) s_abort = 0;
+  if (threadIdx.x == 0) {
+    s_abort = 0;
+    if (blockIdx.x == 0) VLN_AGENT_STORE(status, 0u);   // this launch's status (a timeout is >= 1 s away): no fill launch in front
+  }
   __syncthreads();
 
   for (int step = 0; step < L; ++step) {
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
         if (__all(ok) || dead) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kGranSpinLimit) {          // a workgroup of the group is not resident / died
-          if (lane == 0) gran_timeout(status, &s_abort);
+          if (lane == 0) gran_timeout(status, sticky, &s_abort);
           break;
         }
       }
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
 // 16-byte sc1 loads per lane.
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
-__global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, unsigned* status, unsigned char* exch, unsigned tag_base,
-                                                                 int xcd_map) {
+__global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
+                                                                 unsigned tag_base, int xcd_map) {
   constexpr int HD = NT * 64;
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
   constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, u
         if (__all(ok) || dead) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kGranSpinLimit) {
-          if (lane == 0) gran_timeout(status, &s_abort);
+          if (lane == 0) gran_timeout(status, sticky, &s_abort);
           break;
         }
       }

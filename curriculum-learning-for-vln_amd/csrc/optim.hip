@@ -59,6 +59,7 @@ struct OptHyper {
   float lr, a, b, eps;          // rmsprop: a = alpha; adam: a = beta1, b = beta2
   float bc1, bc2_rsqrt;         // adam bias corrections: 1 - beta1^t, 1 / sqrt(1 - beta2^t)
   float grad_scale;
+  int zero_grads;               // 1: the update also clears the gradient buffer it has just consumed (the next zero_grad() is free)
   float max_norm[8];              // per clip group; 0 = that group is not clipped (trainer.py:425-426 clips encoder and decoder, not the critic)
 };
 
@@ -78,7 +79,7 @@ __device__ __forceinline__ void opt_update(float& p, float g, float& s1, float& 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g, float* s1, float* s2, OptGroups gr,
+__global__ __launch_bounds__(256) void opt_step_kernel(float* p, float* g, float* s1, float* s2, OptGroups gr,
                                                        const float* partial, float* norms_out, OptHyper h) {
   __shared__ float sh[4];
   __shared__ float s_coef;
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g,
       if (MODE != OPT_SGD) *reinterpret_cast<float4*>(s1 + e) = av;
       if (MODE == OPT_ADAM) *reinterpret_cast<float4*>(s2 + e) = bv;
       *reinterpret_cast<float4*>(p + e) = pv;
+      if (h.zero_grads) *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       for (long k = e; k < end && k < e + 4; ++k) {
         float pk = p[k], ak = (MODE != OPT_SGD) ? s1[k] : 0.f, bk = (MODE == OPT_ADAM) ? s2[k] : 0.f;
@@ -120,12 +122,13 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* p, const float* g,
         if (MODE != OPT_SGD) s1[k] = ak;
         if (MODE == OPT_ADAM) s2[k] = bk;
         p[k] = pk;
+        if (h.zero_grads) g[k] = 0.f;
       }
     }
   }
 }
 
-static int opt_launch(int mode, float* params, const float* grads, float* s1, float* s2, const int64_t* group_begin,
+static int opt_launch(int mode, float* params, float* grads, float* s1, float* s2, const int64_t* group_begin,
                       int ngroups, float* partial, float* norms_out, OptHyper h, const float* max_norms, hipStream_t st,
                       const char* what) {
   if (!params || !grads || !group_begin || !partial || ngroups < 1 || ngroups > 8 || (mode != OPT_SGD && !s1) ||
@@ -134,6 +137,8 @@ static int opt_launch(int mode, float* params, const float* grads, float* s1, fl
     return VLN_ERR_ARG;
   }
   for (int g = 0; g < 8; ++g) h.max_norm[g] = (max_norms && g < ngroups) ? max_norms[g] : 0.f;
+  h.zero_grads = h.grad_scale < 0.f ? 1 : 0;       // grad_scale < 0: scale by |grad_scale| and clear the gradients afterwards
+  h.grad_scale = fabsf(h.grad_scale);
   OptGroups gr;
   gr.ngroups = ngroups;
   int blk = 0;
@@ -166,26 +171,26 @@ extern "C" int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ng
   for (int g = 0; g < ngroups; ++g) blocks += (group_begin[g + 1] - group_begin[g] + kOptChunk - 1) / kOptChunk;
   return blocks;
 }
-extern "C" int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin,
+extern "C" int vln_rmsprop_clip_step(float* params, float* grads, float* square_avg, const int64_t* group_begin,
                                      int ngroups, float* partial, float* norms_out, float lr, float alpha, float eps,
                                      const float* max_norms, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, grad_scale, {}};
+  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, grad_scale, 0, {}};
   return opt_launch(OPT_RMSPROP, params, grads, square_avg, nullptr, group_begin, ngroups, partial, norms_out, h,
                     max_norms, (hipStream_t)s, "vln_rmsprop_clip_step");
 }
-extern "C" int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+extern "C" int vln_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                                   const int64_t* group_begin, int ngroups, float* partial, float* norms_out, float lr,
                                   float beta1, float beta2, float eps, int64_t step, const float* max_norms, float grad_scale,
                                   vln_stream_t s) {
   if (step < 1) { set_error("vln_adam_clip_step: step counts from 1"); return VLN_ERR_ARG; }
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, {}};
+  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, 0, {}};
   return opt_launch(OPT_ADAM, params, grads, exp_avg, exp_avg_sq, group_begin, ngroups, partial, norms_out, h,
                     max_norms, (hipStream_t)s, "vln_adam_clip_step");
 }
-extern "C" int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
+extern "C" int vln_sgd_clip_step(float* params, float* grads, const int64_t* group_begin, int ngroups, float* partial,
                                  float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, {}};
+  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, 0, {}};
   return opt_launch(OPT_SGD, params, grads, nullptr, nullptr, group_begin, ngroups, partial, norms_out, h, max_norms,
                     (hipStream_t)s, "vln_sgd_clip_step");
 }

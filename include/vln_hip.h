@@ -169,17 +169,18 @@ int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angl
  * of ngroups norms, torch semantics, 0 = that group is not clipped -- the reference clips encoder and decoder at 40 and leaves
  * the critic alone, trainer.py:425-426; NULL = no clipping) + torch.optim.RMSprop update (alpha, eps, no momentum, not centered).  group_begin: ngroups+1
  * element offsets (multiples of 4); partial: vln_rmsprop_partial_floats() floats of scratch; norms_out[ngroups] nullable;
- * grad_scale multiplies every gradient first (e.g. 1/world). */
+ * grad_scale multiplies every gradient first (e.g. 1/world); grad_scale < 0: scale by |grad_scale| and CLEAR the gradient
+ * buffer in the same pass (the update is its last reader: the next iteration's zero_grad costs nothing). */
 int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ngroups);
-int vln_rmsprop_clip_step(float* params, const float* grads, float* square_avg, const int64_t* group_begin, int ngroups,
+int vln_rmsprop_clip_step(float* params, float* grads, float* square_avg, const int64_t* group_begin, int ngroups,
                           float* partial, float* norms_out, float lr, float alpha, float eps, const float* max_norms,
                           float grad_scale, vln_stream_t s);
 /* Same contract for the other two entries of the reference's optim_switcher (trainer.py:17-21), torch defaults:
  * Adam (betas, eps, bias correction with step = 1, 2, ...; no weight decay / amsgrad) and plain SGD. */
-int vln_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* group_begin,
+int vln_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* group_begin,
                        int ngroups, float* partial, float* norms_out, float lr, float beta1, float beta2, float eps,
                        int64_t step, const float* max_norms, float grad_scale, vln_stream_t s);
-int vln_sgd_clip_step(float* params, const float* grads, const int64_t* group_begin, int ngroups, float* partial,
+int vln_sgd_clip_step(float* params, float* grads, const int64_t* group_begin, int ngroups, float* partial,
                       float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s);
 
 /* ---- loss / action-selection stage of the rollouts (follower.py:123-139, envdrop.py:173-195, monitor.py:146-176):

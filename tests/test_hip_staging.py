@@ -297,3 +297,26 @@ def test_fused_rmsprop_per_group_clip_like_the_reference_trainer(vln):
                 assert torch.allclose(pm, pr, rtol=2e-5, atol=1e-6), step
     with pytest.raises(ValueError):
         vln.optim.FusedRMSprop(mine, lr=1e-2, clip_norm=[1.0, 2.0])
+
+
+def test_fused_step_can_clear_the_gradients_it_consumed(vln):
+    """step(zero_grads=True): same parameter trajectory as a separate memset, the flat gradient buffer is zero afterwards and
+    the next zero_grad() does not launch anything it does not need to."""
+    torch.manual_seed(21)
+    shapes = [[(40, 8), (13,)], [(9, 9), (5,)]]
+    a = [[torch.nn.Parameter(torch.randn(s, device=DEV)) for s in g] for g in shapes]
+    b = [[torch.nn.Parameter(p.detach().clone()) for p in g] for g in a]
+    oa = vln.optim.FusedRMSprop(a, lr=1e-2, clip_norm=1.0)
+    ob = vln.optim.FusedRMSprop(b, lr=1e-2, clip_norm=1.0)
+    for step in range(3):
+        oa.zero_grad(); ob.zero_grad()
+        assert float(ob.flat_g.abs().max()) == 0.0
+        for ga, gb in zip(a, b):
+            for pa, pb in zip(ga, gb):
+                gval = torch.randn_like(pa) * 3.0
+                pa.grad.add_(gval); pb.grad.add_(gval)
+        oa.step(); ob.step(zero_grads=True)
+        assert float(ob.flat_g.abs().max()) == 0.0 and float(oa.flat_g.abs().max()) > 0.0
+        for ga, gb in zip(a, b):
+            for pa, pb in zip(ga, gb):
+                assert torch.equal(pa, pb), step
