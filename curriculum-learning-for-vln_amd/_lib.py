@@ -72,6 +72,30 @@ class EnvDropGrads(C.Structure):
                                    "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat", "dhtd_ext")]
 
 
+class MonitorDims(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "L", "C", "H", "M", "wtype")]
+
+
+class MonitorWeights(C.Structure):
+    _fields_ = [(n, ptr) for n in ("w_tin", "w_tin_t", "w_vh", "w_vh_t", "b_vh", "w_cat", "w_cat_t", "b_ih", "b_hh", "w_a", "w_a_t",
+                                   "b_a", "w_m", "w_m_t", "b_m", "w_c", "b_c", "pe")]
+
+
+class MonitorStep(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("prev_rep", "cand_rep", "h0", "c0", "ctx", "ctx_mask", "cand_mask", "logit", "prog", "h1", "c1",
+                                    "word_w", "move_w", "pctx", "tq", "vq", "xcat", "tcat", "aq", "hm", "mg", "mem", "act", "tanh_c1",
+                                    "gates", "dots", "ws")]
+                + [("ws_floats", i64), ("seed_pe", u64), ("off_pe", u64), ("p_pe", f32), ("seed", u64), ("off_h1", u64),
+                   ("off_mem", u64), ("p_drop", f32)])
+
+
+class MonitorGrads(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("dlogit", "dprog", "dh1", "dc1", "dww_ext", "dmw_ext", "dprev_rep", "dcand_rep", "dh0", "dc0", "dctx")]
+                + [("dctx_accumulate", i32)]
+                + [(n, ptr) for n in ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")]
+                + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
+
+
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
 SIGNATURES = {
     "vln_abi_version": (i32, []),
@@ -140,6 +164,9 @@ SIGNATURES = {
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
+    "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
+    "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
+    "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),

@@ -1,0 +1,219 @@
+// MonitorDecoder.forward (reference policy.py:132-166: co-grounding step + progress monitor) after its BN-MLP, and the
+// hand-derived backward, as ONE C call each: a fixed chain of launches on the caller's stream, no host sync, a single
+// Python->C crossing (round 1 drove the same ~20 + ~25 launches from Python, one ctypes call each: the Self-Monitor agent at
+// B = 128 was bound by that Python, 9.2 ms per iteration for 6.9 ms of kernels).
+//
+//   forward   positioned context pctx = dropout(ctx + pe)                       units.py:188-207, policy.py:152
+//             words, word_w = SoftDot_ctx_only(h0, pctx, ctx_mask)              policy.py:153, units.py:106-118
+//             moves, move_w = VisualSoftDot(h0, cand_rep, cand_mask)            policy.py:155, units.py:144-159
+//             h1, c1 = LSTMCell([prev_rep | moves | words], (h0, c0))           policy.py:157-158
+//             logit = cand_rep . (W_a [words ; drop(h1)] + b_a)                 policy.py:108-117,160
+//             prog = tanh(w_c . [word_w ; drop(sigmoid(W_m [h0 ; moves] + b_m) * tanh(c1))] + b_c)   policy.py:119-130,162
+//   backward  the mirrored chain; the six weight gradients of the step in ONE grouped launch (B rows each), the bias / head
+//             gradients in another, accumulated into the caller's gradient buffers.
+// Dropout sites: pe (seed_pe, off_pe), h1 (seed, off_h1), progress-monitor memory (seed, off_mem).
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+
+struct CopyJobs { const float* src[4]; float* dst[4]; long lds[4], ldd[4]; int cols[4]; int n, rows; };
+// up to four [rows, cols] row-block copies in one launch (the concatenated operands of the step: [prev | moves | words | h0] ...)
+__global__ __launch_bounds__(256) void copy_blocks_kernel(CopyJobs j) {
+  for (int k = 0; k < j.n; ++k) {
+    const int c4 = j.cols[k] >> 2;
+    const long total = (long)j.rows * c4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+      const long r = e / c4, c = (e % c4) * 4;
+      *reinterpret_cast<float4*>(j.dst[k] + r * j.ldd[k] + c) = *reinterpret_cast<const float4*>(j.src[k] + r * j.lds[k] + c);
+    }
+  }
+}
+static int copy_blocks(hipStream_t st, const CopyJobs& j) {
+  long most = 0;
+  for (int k = 0; k < j.n; ++k) {
+    if ((j.cols[k] & 3) || (j.lds[k] & 3) || (j.ldd[k] & 3) || ((uintptr_t)j.src[k] & 15) || ((uintptr_t)j.dst[k] & 15)) {
+      set_error("monitor step: row blocks must be 16-byte aligned with widths that are multiples of 4");
+      return VLN_ERR_ARG;
+    }
+    const long t = (long)j.rows * (j.cols[k] >> 2);
+    if (t > most) most = t;
+  }
+  int blocks = (int)((most + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(blocks), dim3(256), 0, st, j);
+  VLN_CHECK_LAUNCH("copy_blocks");
+  return VLN_OK;
+}
+
+static int check_monitor_dims(const vln_monitor_dims* d) {
+  if (!d || d->B <= 0 || d->L <= 0 || d->C <= 0 || d->H <= 0 || d->M <= 0) { set_error("monitor step: bad dims"); return VLN_ERR_ARG; }
+  if ((d->H & 3) || (d->M & 3) || (d->L & 3)) { set_error("monitor step: H, M and L must be multiples of 4"); return VLN_ERR_ARG; }
+  return VLN_OK;
+}
+
+}  // namespace vln
+
+using namespace vln;
+
+#define RUN(x) do { int _s = (x); if (_s != VLN_OK) return _s; } while (0)
+
+// floats of the backward's temporaries (vln_monitor_grads.scratch)
+extern "C" int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d) {
+  if (check_monitor_dims(d) != VLN_OK) return -1;
+  const long B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H;
+  long n = 0;
+  auto take = [&](long k) { n += (k + 63) & ~63L; };
+  take(B * H); take(B * H); take(B * L); take(B * (L + H)); take(B);          // dmg, dc1_t, dww, Z, dpre
+  take(B * (H + M)); take(B * M); take(B * 2 * H); take(B * 4 * H); take(B * XK);   // dhm, daq, dtcat, dg, dxcat
+  take(B * M); take(B * H); take(B * M); take(B * C); take(B * H);            // dmoves, dwords, dvq, dl_v, dh0_v
+  take(B * H); take(B * L); take(B * H); take(B * C);                        // dtq, dl_t, dh0_t, zero d logits
+  return n;
+}
+
+extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w, vln_monitor_step* io, vln_stream_t s) {
+  RUN(check_monitor_dims(d));
+  if (!w || !io || !io->prev_rep || !io->cand_rep || !io->h0 || !io->c0 || !io->ctx || !io->ctx_mask || !io->cand_mask || !io->ws) {
+    set_error("vln_monitor_step_fwd: null pointer");
+    return VLN_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)s;
+  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
+  // (1) positioned, dropped context (fresh mask per step, units.py:205-207)
+  RUN(vln_pe_dropout(io->ctx, w->pe, io->pctx, B, L, H, io->seed_pe, io->off_pe, io->p_pe, s));
+  // (2) the row blocks that need no computing: xcat = [prev_rep | . | . | h0], hm = [h0 | .]
+  {
+    CopyJobs j{};
+    j.n = 3; j.rows = B;
+    j.src[0] = io->prev_rep; j.lds[0] = M; j.dst[0] = io->xcat; j.ldd[0] = XK; j.cols[0] = M;
+    j.src[1] = io->h0; j.lds[1] = H; j.dst[1] = io->xcat + 2 * M + H; j.ldd[1] = XK; j.cols[1] = H;
+    j.src[2] = io->h0; j.lds[2] = H; j.dst[2] = io->hm; j.ldd[2] = H + M; j.cols[2] = H;
+    RUN(copy_blocks(st, j));
+  }
+  // (3) text attention over the positioned context, weighted context straight into its xcat block
+  RUN(gemm_nt(st, io->h0, H, w->w_tin, wt, H, io->tq, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(attn_fwd_rows(st, io->pctx, W_F32, io->tq, H, io->ctx_mask, io->word_w, io->xcat + 2 * M, XK, io->dots, B, L, H));
+  // (4) attention over the projected candidates (padded slots masked)
+  RUN(gemm_nt(st, io->h0, H, w->w_vh, wt, H, io->vq, M, B, M, H, w->b_vh, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(attn_fwd_rows(st, io->cand_rep, W_F32, io->vq, M, io->cand_mask, io->move_w, io->xcat + M, XK, io->dots, B, C, M));
+  // (5) LSTM cell on [prev_rep | moves | words | h0]; drop(h1) lands in its tcat block
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  {
+    LstmPwFwd a{};
+    a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
+    a.c0 = io->c0; a.ldc0 = H; a.h1 = io->h1; a.ldh1 = H; a.c1 = io->c1; a.ldc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
+    a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = DropSpec{io->seed, io->off_h1, io->p_drop}; a.B = B; a.H = H;
+    RUN(lstm_pointwise_fwd(st, a));
+  }
+  {
+    CopyJobs j{};
+    j.n = 2; j.rows = B;
+    j.src[0] = io->xcat + 2 * M; j.lds[0] = XK; j.dst[0] = io->tcat; j.ldd[0] = 2 * H; j.cols[0] = H;          // words
+    j.src[1] = io->xcat + M; j.lds[1] = XK; j.dst[1] = io->hm + H; j.ldd[1] = H + M; j.cols[1] = M;            // moves
+    RUN(copy_blocks(st, j));
+  }
+  // (6) action logits
+  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_a, wt, 2 * H, io->aq, M, B, M, 2 * H, w->b_a, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(attn_dot(st, io->cand_rep, W_F32, io->aq, M, io->logit, B, C, M));
+  // (7) progress monitor
+  RUN(gemm_nt(st, io->hm, H + M, w->w_m, wt, H + M, io->mg, H, B, H, H + M, w->b_m, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(vln_monitor_head_fwd(io->mg, io->c1, io->word_w, w->w_c, w->b_c, io->mem, io->prog, B, L, H, io->seed, io->off_mem, io->p_drop, s));
+  return VLN_OK;
+}
+
+extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor_weights* w, const vln_monitor_step* io,
+                                    const vln_monitor_grads* g, vln_stream_t s) {
+  RUN(check_monitor_dims(d));
+  if (!w || !io || !g || !g->scratch || !g->dh0 || !g->dc0 || !g->dprev_rep) { set_error("vln_monitor_step_bwd: null pointer"); return VLN_ERR_ARG; }
+  if (g->scratch_floats < vln_monitor_bwd_scratch_floats(d)) { set_error("vln_monitor_step_bwd: scratch too small"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
+  float* q = g->scratch;
+  auto take = [&](long k) { float* p = q; q += (k + 63) & ~63L; return p; };
+  float *dmg = take((long)B * H), *dc1_t = take((long)B * H), *dww = take((long)B * L), *Z = take((long)B * (L + H)), *dpre = take(B);
+  float *dhm = take((long)B * (H + M)), *daq = take((long)B * M), *dtcat = take((long)B * 2 * H), *dg = take((long)B * 4 * H);
+  float *dxcat = take((long)B * XK), *dmoves = take((long)B * M), *dwords = take((long)B * H), *dvq = take((long)B * M);
+  float *dl_v = take((long)B * C), *dh0_v = take((long)B * H), *dtq = take((long)B * H), *dl_t = take((long)B * L);
+  float *dh0_t = take((long)B * H), *zlogit = take((long)B * C);
+  // progress head (policy.py:126-130)
+  RUN(vln_monitor_head_bwd(io->mg, io->c1, io->word_w, w->w_c, io->mem, io->prog, g->dprog, g->dc1, g->dww_ext, dmg, dc1_t, dww, Z,
+                           dpre, B, L, H, io->seed, io->off_mem, io->p_drop, s));
+  RUN(gemm_nt(st, dmg, H, w->w_m_t, wt, H, dhm, H + M, B, H + M, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> h0 | moves
+  // action logits (policy.py:108-117): logit = cand_rep . aq
+  const float* dlogit = g->dlogit;
+  if (!dlogit) { RUN(fill_f32(st, zlogit, (long)B * C, 0.f)); dlogit = zlogit; }
+  RUN(rows_wsum(st, io->cand_rep, W_F32, dlogit, daq, M, B, C, M));
+  RUN(gemm_nt(st, daq, M, w->w_a_t, wt, M, dtcat, 2 * H, B, 2 * H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));  // -> words | drop(h1)
+  // LSTM cell
+  {
+    LstmPwBwd a{};
+    a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dtcat + H, 2 * H); a.dh1_b2 = plain_vec(nullptr, 0);
+    a.drop = DropSpec{io->seed, io->off_h1, io->p_drop}; a.dc1 = dc1_t; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
+    a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
+    RUN(lstm_pointwise_bwd(st, a));
+  }
+  RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> prev | moves | words | h0
+  RUN(vln_add_n(dmoves, M, B, M, dhm + H, H + M, dxcat + M, XK, nullptr, 0, nullptr, 0, 0, s));
+  RUN(vln_add_n(dwords, H, B, H, dtcat, 2 * H, dxcat + 2 * M, XK, nullptr, 0, nullptr, 0, 0, s));
+  // candidates: d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
+  RUN(attn_bwd_rows(st, io->cand_rep, W_F32, io->move_w, dmoves, M, g->dmw_ext, dvq, M, dl_v, io->dots, B, C, M));
+  if (g->dcand_rep) {
+    const float* al[2] = {io->move_w, dlogit};
+    const float* dl[2] = {dl_v, nullptr};
+    const float* gg[2] = {dmoves, io->aq};
+    const float* qq[2] = {io->vq, nullptr};
+    RUN(attn_dctx_deferred(st, al, dl, gg, M, qq, M, 2, g->dcand_rep, B, C, M, 0));
+  }
+  RUN(gemm_nt(st, dvq, M, w->w_vh_t, wt, M, dh0_v, H, B, H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  // words: d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's pe-dropout mask
+  RUN(attn_bwd_rows(st, io->pctx, W_F32, io->word_w, dwords, H, dww, dtq, H, dl_t, io->dots, B, L, H));
+  if (g->dctx) {
+    const float* al[1] = {io->word_w};
+    const float* dl[1] = {dl_t};
+    const float* gg[1] = {dwords};
+    const float* qq[1] = {io->tq};
+    const uint64_t ds[1] = {io->seed_pe}, dof[1] = {io->off_pe};
+    const float dp[1] = {io->p_pe};
+    RUN(attn_dctx_deferred(st, al, dl, gg, H, qq, H, 1, g->dctx, B, L, H, g->dctx_accumulate, ds, dof, dp));
+  }
+  RUN(gemm_nt(st, dtq, H, w->w_tin_t, wt, H, dh0_t, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(vln_add_n(g->dh0, H, B, H, dhm, H + M, dxcat + 2 * M + H, XK, dh0_v, H, dh0_t, H, 0, s));
+  {
+    CopyJobs j{};
+    j.n = 1; j.rows = B;
+    j.src[0] = dxcat; j.lds[0] = XK; j.dst[0] = g->dprev_rep; j.ldd[0] = M; j.cols[0] = M;
+    RUN(copy_blocks(st, j));
+  }
+  // parameter gradients: six products over the same B rows -> one grouped launch; biases and the head -> another
+  {
+    vln_wgrad_job jobs[6];
+    int n = 0;
+    auto add = [&](const float* dy, long ldy, const float* x, long ldx, float* dw, long ldw, int N, int K, int acc) {
+      if (dw) jobs[n++] = vln_wgrad_job{dy, x, dw, ldy, ldx, ldw, N, K, acc, 0};
+    };
+    add(dtq, H, io->h0, H, g->g_tin, H, H, H, g->acc[0]);
+    add(dvq, M, io->h0, H, g->g_vh, H, M, H, g->acc[1]);
+    add(dg, 4 * H, io->xcat, XK, g->g_ih, 2 * M + H, 4 * H, 2 * M + H, g->acc[3]);
+    add(dg, 4 * H, io->xcat + 2 * M + H, XK, g->g_hh, H, 4 * H, H, g->acc[4]);
+    add(daq, M, io->tcat, 2 * H, g->g_a, 2 * H, M, 2 * H, g->acc[7]);
+    add(dmg, H, io->hm, H + M, g->g_m, H + M, H, H + M, g->acc[9]);
+    if (n) RUN(wgrad_grouped(st, jobs, n, B, g->precision, io->ws, io->ws_floats));
+  }
+  {
+    vln_colsum_job jobs[6];
+    int n = 0;
+    auto add = [&](const float* A, long lda, float* o1, float* o2, int cols, int acc) {
+      if (o1) jobs[n++] = vln_colsum_job{A, o1, o2, lda, cols, acc};
+    };
+    add(dvq, M, g->g_bvh, nullptr, M, g->acc[2]);
+    add(daq, M, g->g_ba, nullptr, M, g->acc[8]);
+    add(dmg, H, g->g_bm, nullptr, H, g->acc[10]);
+    add(Z, L + H, g->g_wc, nullptr, L + H, g->acc[11]);
+    if (g->g_bih && g->g_bhh && g->acc[5] == g->acc[6]) add(dg, 4 * H, g->g_bih, g->g_bhh, 4 * H, g->acc[5]);
+    else { add(dg, 4 * H, g->g_bih, nullptr, 4 * H, g->acc[5]); add(dg, 4 * H, g->g_bhh, nullptr, 4 * H, g->acc[6]); }
+    if (n) RUN(colsum_grouped(st, jobs, n, B, io->ws, io->ws_floats));
+    if (g->g_bc) RUN(colsum(st, dpre, 1, g->g_bc, B, 1, g->acc[12], io->ws, io->ws_floats));
+  }
+  return VLN_OK;
+}

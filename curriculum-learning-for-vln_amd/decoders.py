@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from . import functional as Fh
+from .monitor_step import MonitorStepFn
 
 
 def _need_gpu(t, who):
@@ -299,6 +300,7 @@ class MonitorDecoder(nn.Module, _Seeded):
         self.critic = nn.Sequential(nn.Linear(max_enc_len + rnn_hidden_size, 1), nn.Tanh())
         self._init_seed(0x5E1F)
         self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
+        self.c_step = True                # the fused node as ONE C call each way (csrc/monitor.hip); False: launches driven from Python
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
@@ -339,7 +341,8 @@ class MonitorDecoder(nn.Module, _Seeded):
             cfg = (self.training, self.compute_dtype, pos.p, (pos.dropout_seed, pos._next()), self.drop_ratio, self.dropout_seed,
                    site, site + 1)
             head = self.critic[0]
-            logit, progress, h_new, c_new, word_w, move_w = Fh.MonitorCoreFn.apply(
+            core = MonitorStepFn if self.c_step else Fh.MonitorCoreFn       # one C call per direction / Python-driven launches
+            logit, progress, h_new, c_new, word_w, move_w = core.apply(
                 cfg, pos.pe[0, :ctx.shape[1]], ctx_mask, candidate_mask, prev_rep, cand_rep, h_0, c_0, ctx,
                 self.text_attn.linear_in.weight, self.visual_attn.linear_in_h.weight, self.visual_attn.linear_in_h.bias,
                 self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,

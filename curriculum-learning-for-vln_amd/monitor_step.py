@@ -1,0 +1,134 @@
+"""The Self-Monitor decoder step after its BN-MLP (reference policy.py:132-166) as ONE C call each way
+(`vln_monitor_step_fwd` / `vln_monitor_step_bwd`, csrc/monitor.hip): the ~20 forward and ~25 backward launches that
+`functional.MonitorCoreFn` drives from Python, one ctypes call each, are issued by the library here.  Same numbers (it is the
+same launch sequence); at B = 128 the agent is bound by the GPU instead of by the Python of its steps.
+
+`MonitorStepFn.apply` takes MonitorCoreFn's arguments.  Parameter gradients follow `functional.set_grad_in_place`: added into an
+existing contiguous `p.grad` inside the grouped launches (autograd gets None), or returned to autograd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from .functional import SHADOWS, _fused_lstm_weight, _gret, _gsink
+
+_p = ops._p
+
+
+def _m8(mask):
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
+def _r64(n):
+    return (n + 63) & ~63
+
+
+class MonitorStepFn(torch.autograd.Function):
+    """cfg = (training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem);
+    params = W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c."""
+
+    @staticmethod
+    def forward(ctx, cfg, pe, ctx_mask, cand_mask, prev_rep, cand_rep, h0, c0, ctxt, *params):
+        training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = cfg
+        W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c = params
+        lib = _lib.load()
+        f32 = torch.float32
+        prev_rep, cand_rep = prev_rep.detach().contiguous(), cand_rep.detach().contiguous()
+        h0, c0, ctxt = h0.detach().contiguous(), c0.detach().contiguous(), ctxt.detach().contiguous()
+        B, Cn, M = cand_rep.shape
+        H, L = h0.shape[1], ctxt.shape[1]
+        dev = h0.device
+        XK = 2 * M + 2 * H
+        wt = ops.F32 if dtype == f32 else ops.BF16
+        d = _lib.MonitorDims(B, L, Cn, H, M, wt)
+        w = _lib.MonitorWeights()
+        hold = []                                    # streamed weight copies: kept alive until the launches are queued
+
+        def sh(W, kind):
+            t = SHADOWS.get(W, kind, dtype)
+            hold.append(t)
+            return t.data_ptr()
+
+        w.w_tin, w.w_tin_t = sh(W_tin, "n"), sh(W_tin, "t")
+        w.w_vh, w.w_vh_t, w.b_vh = sh(W_vh, "n"), sh(W_vh, "t"), b_vh.data_ptr()
+        wc_n, wc_t = _fused_lstm_weight(W_ih, W_hh, dtype, False), _fused_lstm_weight(W_ih, W_hh, dtype, True)
+        hold += [wc_n, wc_t]
+        w.w_cat, w.w_cat_t, w.b_ih, w.b_hh = wc_n.data_ptr(), wc_t.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr()
+        w.w_a, w.w_a_t, w.b_a = sh(W_a, "n"), sh(W_a, "t"), b_a.data_ptr()
+        w.w_m, w.w_m_t, w.b_m = sh(W_m, "n"), sh(W_m, "t"), b_m.data_ptr()
+        wcf = W_c.detach().reshape(-1)
+        pe_c = pe if pe.is_contiguous() else pe.contiguous()
+        hold += [wcf, pe_c]
+        w.w_c, w.b_c, w.pe = wcf.data_ptr(), b_c.data_ptr(), pe_c.data_ptr()
+        # outputs (returned) and the step's saved activations (one flat allocation)
+        logit = ops.empty(B, Cn, dtype=f32, device=dev); prog = ops.empty(B, dtype=f32, device=dev)
+        h1 = ops.empty(B, H, dtype=f32, device=dev); c1 = ops.empty(B, H, dtype=f32, device=dev)
+        word_w = ops.empty(B, L, dtype=f32, device=dev); move_w = ops.empty(B, Cn, dtype=f32, device=dev)
+        sizes = (("pctx", B * L * H), ("tq", B * H), ("vq", B * M), ("xcat", B * XK), ("tcat", B * 2 * H), ("aq", B * M),
+                 ("hm", B * (H + M)), ("mg", B * H), ("mem", B * H), ("act", B * 4 * H), ("tanh_c1", B * H),
+                 ("gates", B * 4 * H), ("dots", B * max(L, Cn)))
+        flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
+        io = _lib.MonitorStep()
+        q = flat.data_ptr()
+        for name, n in sizes:
+            setattr(io, name, q)
+            q += 4 * _r64(n)
+        m_ctx, m_cand = _m8(ctx_mask), _m8(cand_mask)
+        io.prev_rep, io.cand_rep, io.h0, io.c0, io.ctx = prev_rep.data_ptr(), cand_rep.data_ptr(), h0.data_ptr(), c0.data_ptr(), ctxt.data_ptr()
+        io.ctx_mask, io.cand_mask = m_ctx.data_ptr(), m_cand.data_ptr()
+        io.logit, io.prog, io.h1, io.c1 = logit.data_ptr(), prog.data_ptr(), h1.data_ptr(), c1.data_ptr()
+        io.word_w, io.move_w = word_w.data_ptr(), move_w.data_ptr()
+        ws = ops.workspace(dev, 1 << 22)
+        io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
+        io.seed_pe, io.off_pe, io.p_pe = seed_pe, off_pe, (p_pe if training else 0.0)
+        io.seed, io.off_h1, io.off_mem, io.p_drop = seed, off_h1, off_mem, (p_drop if training else 0.0)
+        st = lib.vln_monitor_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_monitor_step_fwd")
+        ctx.cfg = cfg
+        ctx.pack = (d, w, io, hold, (m_ctx, m_cand), (logit, prog, h1, c1, word_w, move_w))
+        ctx.save_for_backward(flat, prev_rep, cand_rep, h0, c0, ctxt, *params)
+        ctx.set_materialize_grads(False)
+        return logit, prog, h1, c1, word_w, move_w
+
+    @staticmethod
+    def backward(ctx, dlogit, dprog, dh1, dc1, dww_ext, dmw_ext):
+        d, w, io, hold, masks, outs = ctx.pack
+        flat, prev_rep, cand_rep, h0, c0, ctxt, *params = ctx.saved_tensors
+        W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c = params
+        dtype = ctx.cfg[1]
+        lib = _lib.load()
+        f32 = torch.float32
+        B, Cn, M = cand_rep.shape
+        H, L = h0.shape[1], ctxt.shape[1]
+        dev = h0.device
+        cz = lambda t: None if t is None else t.contiguous()
+        ups = [cz(t) for t in (dlogit, dprog, dh1, dc1, dww_ext, dmw_ext)]
+        g = _lib.MonitorGrads()
+        g.dlogit, g.dprog, g.dh1, g.dc1, g.dww_ext, g.dmw_ext = (_p(t) for t in ups)
+        dprev = ops.empty(B, M, dtype=f32, device=dev)
+        dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
+        dcand = torch.empty(B, Cn, M, dtype=f32, device=dev) if ctx.needs_input_grad[5] else None
+        dctx = torch.empty(B, L, H, dtype=f32, device=dev) if ctx.needs_input_grad[8] else None
+        g.dprev_rep, g.dcand_rep, g.dh0, g.dc0, g.dctx = dprev.data_ptr(), _p(dcand), dh0.data_ptr(), dc0.data_ptr(), _p(dctx)
+        sinks = [_gsink(p) for p in params]
+        names = ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")
+        for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
+            setattr(g, n, t.data_ptr())
+            g.acc[i] = 1 if acc else 0
+        g.precision = 0 if dtype == f32 else 1
+        ns = int(lib.vln_monitor_bwd_scratch_floats(C.byref(d)))
+        scratch = ops.empty(ns, dtype=f32, device=dev)
+        g.scratch, g.scratch_floats = scratch.data_ptr(), ns
+        ws = ops.workspace(dev, 1 << 22)             # (the forward's pointer may belong to another stream's workspace)
+        io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
+        st = lib.vln_monitor_step_bwd(C.byref(d), C.byref(w), C.byref(io), C.byref(g), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_monitor_step_bwd")
+        ctx.pack = None
+        return (None, None, None, None, dprev, dcand, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)

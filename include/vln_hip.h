@@ -251,6 +251,47 @@ int vln_monitor_head_bwd(const float* mg, const float* c1, const float* word_w, 
 int vln_add_n(float* out, int64_t ldo, int rows, int cols, const float* s0, int64_t ld0, const float* s1, int64_t ld1,
               const float* s2, int64_t ld2, const float* s3, int64_t ld3, int accumulate, vln_stream_t s);
 
+/* MonitorDecoder.forward after its BN-MLP (policy.py:132-166) and the backward of that, ONE call each (csrc/monitor.hip).
+ * All tensors fp32 row-major and dense unless a leading dimension is named; weights are the streamed copies in `wtype`
+ * ([N,K] and the transposed [K,N]); every buffer is caller-owned; the step's saved activations (pctx .. tanh_c1) must stay
+ * alive until vln_monitor_step_bwd has been issued.  M = width of the projected candidates (mlp_dims[-1]). */
+typedef struct vln_monitor_dims { int B, L, C, H, M, wtype; } vln_monitor_dims;
+typedef struct vln_monitor_weights {
+  const void *w_tin, *w_tin_t;                       /* text_attn.linear_in.weight        [H, H]            */
+  const void *w_vh, *w_vh_t; const float* b_vh;      /* visual_attn.linear_in_h           [M, H], [M]       */
+  const void *w_cat, *w_cat_t; const float *b_ih, *b_hh; /* [lstm.weight_ih | weight_hh]  [4H, 2M+H+H]      */
+  const void *w_a, *w_a_t; const float* b_a;         /* action_linear                     [M, 2H], [M]      */
+  const void *w_m, *w_m_t; const float* b_m;         /* monitor_linear                    [H, H+M], [H]     */
+  const float *w_c, *b_c;                            /* critic.0 (progress head), fp32    [L+H], [1]        */
+  const float* pe;                                   /* position.pe                       [L, H]            */
+} vln_monitor_weights;
+typedef struct vln_monitor_step {
+  const float *prev_rep /*[B,M]*/, *cand_rep /*[B,C,M]*/, *h0, *c0 /*[B,H]*/, *ctx /*[B,L,H]*/;
+  const uint8_t *ctx_mask /*[B,L]*/, *cand_mask /*[B,C]*/;                                  /* 1 = masked */
+  float *logit /*[B,C]*/, *prog /*[B]*/, *h1, *c1 /*[B,H]*/, *word_w /*[B,L]*/, *move_w /*[B,C]*/;      /* outputs */
+  float *pctx /*[B,L,H]*/, *tq /*[B,H]*/, *vq /*[B,M]*/, *xcat /*[B,2M+2H]*/, *tcat /*[B,2H]*/, *aq /*[B,M]*/, *hm /*[B,H+M]*/,
+        *mg /*[B,H]*/, *mem /*[B,H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/;                 /* saved for the backward */
+  float *gates /*[B,4H]*/, *dots /*[B,max(L,C)]*/;                                          /* scratch of the call */
+  float* ws; int64_t ws_floats;                                                             /* split-K / grouped-launch scratch */
+  uint64_t seed_pe, off_pe; float p_pe;              /* dropout on the positioned context (units.py:207) */
+  uint64_t seed, off_h1, off_mem; float p_drop;      /* dropout on h_1 (policy.py:160) and on the monitor memory (:128) */
+} vln_monitor_step;
+typedef struct vln_monitor_grads {
+  const float *dlogit, *dprog, *dh1, *dc1, *dww_ext, *dmw_ext;        /* upstream gradients, each nullable */
+  float *dprev_rep /*[B,M]*/, *dcand_rep /*[B,C,M], nullable*/, *dh0, *dc0 /*[B,H]*/, *dctx /*[B,L,H], nullable*/;
+  int dctx_accumulate;                               /* 1: add this step's term to dctx (one buffer for the rollout) */
+  /* parameter gradients in the order W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, w_c, b_c; each
+   * nullable; acc[i] = 1 adds to the buffer's contents (e.g. the optimizer's flat gradient views) */
+  float *g_tin, *g_vh, *g_bvh, *g_ih, *g_hh, *g_bih, *g_bhh, *g_a, *g_ba, *g_m, *g_bm, *g_wc, *g_bc;
+  int acc[13];
+  int precision;                                     /* weight gradients: 0 exact fp32 MFMA, 1 split-bf16 (three bf16 MFMAs) */
+  float* scratch; int64_t scratch_floats;            /* >= vln_monitor_bwd_scratch_floats(dims) */
+} vln_monitor_grads;
+int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d);
+int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w, vln_monitor_step* io, vln_stream_t s);
+int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor_weights* w, const vln_monitor_step* io,
+                         const vln_monitor_grads* g, vln_stream_t s);
+
 /* BatchNorm1d (+ fused ReLU): the BN-MLP of the Self-Monitor agent (units.py:210-242; `bn_mlp` =
  * vln_bn_fwd / vln_linear_fwd / vln_bn_fwd(relu)).  Training: batch statistics, running statistics updated in place with
  * `momentum` and the unbiased variance, *num_batches_tracked += 1, save_mean / save_rstd [D] kept for backward.  Eval:

@@ -65,6 +65,7 @@ def run_monitor(B=128, L=80, T=7, C=8):
     g = torch.Generator().manual_seed(2020)
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, False, 1, compute_dtype=dt).to(dev).train()
     dec = vln.MonitorDecoder(512, 0.5, L, (128, 1024), F, F, compute_dtype=dt).to(dev).train()
+    dec.c_step = not getattr(args, "python_step", False)
     opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-4)
     tokens = torch.randint(4, 992, (B, L), generator=g)
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
@@ -224,9 +225,12 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--T-rl", type=int, default=35, help="cap of the sampled rollout (reference: MAX_EPISODE_LEN 35)")
     ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
+    ap.add_argument("--python-step", action="store_true", help="monitor: the step's launches driven from Python (functional.MonitorCoreFn) "
+                                                               "instead of one C call each way")
     ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
     a = ap.parse_args()
     configure(a.steps, a.warmup, a.dtype, a.arena)
+    args.python_step = a.python_step
     vln.functional.set_grad_in_place(not a.no_grad_in_place)
     if a.which in ("monitor", "all"):
         print(json.dumps(run_monitor()), flush=True)

@@ -56,7 +56,7 @@ def test_struct_layouts_match_header(vln):
             if not decl:
                 continue
             names = re.sub(r"^(const\s+)?[a-z0-9_]+\s*\**", "", decl, count=1)
-            out += [n.strip().lstrip("*").strip() for n in names.split(",")]
+            out += [re.sub(r"\[\d+\]$", "", n.strip().lstrip("*").strip()) for n in names.split(",")]
         return out
 
     L = vln._lib
@@ -64,6 +64,10 @@ def test_struct_layouts_match_header(vln):
     assert fields("vln_envdrop_weights") == [f for f, _ in L.EnvDropWeights._fields_]
     assert fields("vln_envdrop_step") == [f for f, _ in L.EnvDropStep._fields_]
     assert fields("vln_envdrop_grads") == [f for f, _ in L.EnvDropGrads._fields_]
+    assert fields("vln_monitor_dims") == [f for f, _ in L.MonitorDims._fields_]
+    assert fields("vln_monitor_weights") == [f for f, _ in L.MonitorWeights._fields_]
+    assert fields("vln_monitor_step") == [f for f, _ in L.MonitorStep._fields_]
+    assert fields("vln_monitor_grads") == [f for f, _ in L.MonitorGrads._fields_]
 
 
 def test_modules_fail_loudly_without_gpu(vln):

@@ -157,6 +157,46 @@ def test_monitor_fused_step_equals_operator_path(vln, cdt):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_monitor_c_call_step_equals_python_driven_node(vln, cdt):
+    """`vln_monitor_step_fwd/bwd` (the step after the BN-MLP as ONE C call each way, csrc/monitor.hip) issues the launch sequence
+    that functional.MonitorCoreFn drives from Python: outputs bit-identical, gradients to summation-order rounding, in training
+    mode with every dropout on, over a two-step chain with attention-map gradients flowing in."""
+    B, C, L, H, M, F = 24, 7, 20, 64, 128, 256
+    g = torch.Generator().manual_seed(78)
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    a_prev = torch.randn(B, F, generator=g).abs(); cands = [torch.randn(B, C, F, generator=g).abs() for _ in range(2)]
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
+    nc = torch.randint(2, C + 1, (B,), generator=g); cmask = torch.arange(C)[None, :] >= nc[:, None]
+    r = [torch.randn(B, C, generator=g), torch.randn(B, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g),
+         torch.randn(B, L, generator=g), torch.randn(B, C, generator=g)]
+    torch.manual_seed(5)
+    sd = {k: v.clone() for k, v in vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F).state_dict().items()}
+    res = []
+    for c_step in (True, False):
+        dec = vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F, compute_dtype=cdt)
+        dec.load_state_dict(sd); dec.to(DEV).train()
+        dec.c_step = c_step
+        ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+        hh, cc, ap, total, outs = h, c, a_prev.to(DEV), 0.0, []
+        for t in range(2):
+            (logit, prog), (hh, cc), (ww, mw) = dec(None, ap, cands[t].to(DEV), hh, cc, ctx, ctx_mask.to(DEV), cmask.to(DEV))
+            total = total + (logit.masked_fill(cmask.to(DEV), 0.0) * r[0].to(DEV)).sum() + (prog * r[1].to(DEV)).sum() \
+                + (ww * r[4].to(DEV)).sum() + (mw * r[5].to(DEV)).sum()
+            outs += [logit, prog, ww, mw]
+            ap = cands[t][:, 0].to(DEV)
+        total = total + (hh * r[2].to(DEV)).sum() + (cc * r[3].to(DEV)).sum()
+        total.backward()
+        res.append((outs + [hh, cc], {n: p.grad.clone() for n, p in dec.named_parameters()}, [ctx.grad, h.grad, c.grad]))
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(a, b), f"output {i}"
+    gscale = max(v.abs().max().item() for v in res[1][1].values())
+    for n in res[0][1]:
+        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        check(a, b, 2e-5, f"input grad {i}")
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_follower_fused_step_equals_operator_path(vln, cdt):
     """AttnDecoderLSTM as one autograd node (functional.FollowerCoreFn) against the operator-by-operator path it replaces,
     in TRAINING mode with both dropouts on (same Philox masks): logits, state, both attention maps, every parameter
