@@ -690,45 +690,45 @@ static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 //   d logits_j = dlogp (1[j = a] - p_j) - dent p_j (log p_j + H)        (clamped / masked slots carry no gradient)
 // ---------------------------------------------------------------------------------------------------------------
 namespace vln {
+// One WAVE per episode, lane c = candidate c (C <= 64): the row is read once, max / sum / entropy are wave reductions, the
+// inverse-CDF draw is a 6-step inclusive scan + ballot.  (One thread per episode walked the row four times: ~32 dependent
+// loads, 9.6 us per launch on a sampled rollout's critical path.)
 __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* logits, long ld, const unsigned char* mask,
                                                               const long long* action_in, long long* action_out, float* probs,
                                                               float* logp, float* ent, int B, int C, uint64_t seed, uint64_t offset) {
   const float eps = 1.1920928955078125e-07f;
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
-    const float* lg = logits + (long)b * ld;
-    const unsigned char* mk = mask ? mask + (long)b * C : nullptr;
-    float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmaxf(mx, (mk && mk[c]) ? -INFINITY : lg[c]);
-    float sum = 0.f;
-    for (int c = 0; c < C; ++c) sum += __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx);
-    const float inv = 1.f / sum;
+  const int lane = threadIdx.x & 63;
+  for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += gridDim.x * 4) {
+    const bool in = lane < C;
+    const bool masked = in && mask && mask[(long)b * C + lane];
+    const float l = (in && !masked) ? logits[(long)b * ld + lane] : -INFINITY;
+    const float mx = wave_max(l);
+    const float e = (in && !masked) ? __expf(l - mx) : 0.f;
+    const float inv = 1.f / wave_sum(e);
+    const float pc = e * inv;
     long a;
     if (action_in) a = action_in[b];
     else {                                          // inverse-CDF draw from the row's own Philox word
       const Philox4 r = philox4x32_10(seed, offset, (uint32_t)b);
       const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
-      float cum = 0.f;
-      a = -1;
-      long last = 0;
-      for (int c = 0; c < C; ++c) {
-        const float pc = __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx) * inv;
-        if (pc > 0.f) last = c;
-        cum += pc;
-        if (a < 0 && u < cum) a = c;
+      float cum = pc;                               // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(cum, o, 64);
+        if (lane >= o) cum += t;
       }
-      if (a < 0) a = last;
+      const unsigned long long hit = __ballot(in && u < cum), live = __ballot(in && pc > 0.f);
+      a = hit ? (long)(__ffsll((long long)hit) - 1) : (live ? (long)(63 - __clzll((long long)live)) : 0);
     }
-    float H = 0.f, la = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float pc = __expf(((mk && mk[c]) ? -INFINITY : lg[c]) - mx) * inv;
-      probs[(long)b * C + c] = pc;
-      const float lc = __logf(fminf(fmaxf(pc, eps), 1.f - eps));
-      H -= pc * lc;
-      if (c == a) la = lc;
+    const float lc = __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+    const float H = -wave_sum(in ? pc * lc : 0.f);
+    const float la = (a >= 0 && a < C) ? __shfl(lc, (int)a, 64) : 0.f;      // wave-uniform `a`
+    if (in) probs[(long)b * C + lane] = pc;
+    if (lane == 0) {
+      if (action_out) action_out[b] = a;
+      logp[b] = la;
+      ent[b] = H;
     }
-    if (action_out) action_out[b] = a;
-    logp[b] = la;
-    ent[b] = H;
   }
 }
 __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* probs, const long long* action, const float* dlogp,
@@ -767,7 +767,8 @@ extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_
     vln::set_error("vln_categorical_fwd: bad args");
     return VLN_ERR_ARG;
   }
-  hipLaunchKernelGGL(vln::categorical_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
+  if (C > 64) { vln::set_error("vln_categorical_fwd: at most 64 candidates"); return VLN_ERR_ARG; }
+  hipLaunchKernelGGL(vln::categorical_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
                      (const long long*)action_in, (long long*)action_out, probs, logp, entropy, B, C, seed, offset);
   VLN_CHECK_LAUNCH("categorical_fwd");
   return VLN_OK;

@@ -195,7 +195,9 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
         _, (last_h, _), _ = dec(tape["steps"][T - 1]["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
         with torch.no_grad():
             last_v = cri(last_h).detach()
-        vals = [cri(x) for x in hidden]
+        # the critic is row-wise: V of all T steps in ONE call over (steps x batch) rows instead of T calls (the reference
+        # loops `self.critic(hidden_states[t])`, envdrop.py:246 -- same function of the same rows)
+        vals = list(cri(torch.cat(hidden, 0)).view(len(hidden), B).unbind(0))
         rl, _ = vln.losses.a2c_loss(logps, ents, vals, rewards[:T], masks[:T], last_v, ended, 0.9, "total")
         return rl
 
