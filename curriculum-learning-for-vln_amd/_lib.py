@@ -96,6 +96,30 @@ class MonitorGrads(C.Structure):
                 + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
 
 
+class FollowerDims(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "L", "V", "C", "H", "F", "A", "D", "wtype")]
+
+
+class FollowerWeights(C.Structure):
+    _fields_ = [(n, ptr) for n in ("w_h", "w_h_t", "b_h", "w_v", "b_v", "w_cat", "w_cat_t", "b_ih", "b_hh", "w_tin", "w_tin_t", "w_tout",
+                                   "w_tout_t", "w_act", "b_act", "w_hid", "w_hid_t", "b_hid", "w_out", "b_out")]
+
+
+class FollowerStep(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("img", "a_prev", "cands", "h0", "c0", "ctx", "ctx_mask", "logit", "h1", "c1", "word_w", "view_w",
+                                    "tq", "keys", "vlog", "xcat", "act", "tanh_c1", "tq2", "tcat", "grounded", "target", "q", "context",
+                                    "gates", "dots", "ws")]
+                + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32)])
+
+
+class FollowerGrads(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("dlogit", "dh1", "dc1", "dww_ext", "dvw_ext", "da_prev", "dh0", "dc0", "dctx")]
+                + [("dctx_accumulate", i32)]
+                + [(n, ptr) for n in ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact",
+                                      "g_whid", "g_bhid", "g_wout", "g_bout")]
+                + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
+
+
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
 SIGNATURES = {
     "vln_abi_version": (i32, []),
@@ -164,6 +188,9 @@ SIGNATURES = {
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
+    "vln_follower_bwd_scratch_floats": (i64, [ptr]),
+    "vln_follower_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
+    "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),

@@ -47,6 +47,16 @@ static int copy_blocks(hipStream_t st, const CopyJobs& j) {
   return VLN_OK;
 }
 
+// two row-block copies (the second optional) -- shared with follower.hip
+int copy_blocks2(hipStream_t st, int rows, const float* s0, long lds0, float* d0, long ldd0, int cols0, const float* s1, long lds1,
+                 float* d1, long ldd1, int cols1) {
+  CopyJobs j{};
+  j.rows = rows; j.n = s1 ? 2 : 1;
+  j.src[0] = s0; j.lds[0] = lds0; j.dst[0] = d0; j.ldd[0] = ldd0; j.cols[0] = cols0;
+  j.src[1] = s1; j.lds[1] = lds1; j.dst[1] = d1; j.ldd[1] = ldd1; j.cols[1] = cols1;
+  return copy_blocks(st, j);
+}
+
 static int check_monitor_dims(const vln_monitor_dims* d) {
   if (!d || d->B <= 0 || d->L <= 0 || d->C <= 0 || d->H <= 0 || d->M <= 0) { set_error("monitor step: bad dims"); return VLN_ERR_ARG; }
   if ((d->H & 3) || (d->M & 3) || (d->L & 3)) { set_error("monitor step: H, M and L must be multiples of 4"); return VLN_ERR_ARG; }

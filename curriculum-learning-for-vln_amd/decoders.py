@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from . import functional as Fh
-from .monitor_step import MonitorStepFn
+from .monitor_step import FollowerStepFn, MonitorStepFn
 
 
 def _need_gpu(t, who):
@@ -109,6 +109,7 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
         self.decode_action = ActionScoring(action_embed_size, hidden_size)
         self._init_seed(0xF0110)
         self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
+        self.c_step = True                # the fused node as ONE C call each way (csrc/follower.hip); False: launches driven from Python
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
@@ -123,7 +124,8 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
         if self.fused_step and ctx.dtype == torch.float32 and img_feature.shape[2] % 4 == 0 and self.hidden_size % 4 == 0 \
                 and a_t_cands.shape[2] % 4 == 0 and not img_feature.requires_grad and not a_t_cands.requires_grad:
             va, ds = self.visual_attn, self.decode_action            # the whole step as ONE autograd node
-            logit, h_new, c_new, word_w, view_w = Fh.FollowerCoreFn.apply(
+            core = FollowerStepFn if self.c_step else Fh.FollowerCoreFn      # one C call per direction / Python-driven launches
+            logit, h_new, c_new, word_w, view_w = core.apply(
                 (tr, self.compute_dtype, p, seed, site), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
                 self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,

@@ -91,10 +91,12 @@ class MonitorStepFn(torch.autograd.Function):
         if st:
             _lib.check(st, "vln_monitor_step_fwd")
         ctx.cfg = cfg
-        ctx.pack = (d, w, io, hold, (m_ctx, m_cand), (logit, prog, h1, c1, word_w, move_w))
+        # the backward reads c1, prog and the two attention maps: their memory is kept alive HERE, and the caller gets fresh
+        # aliases -- the returned objects carry this node as grad_fn, holding THEM on ctx would be a reference cycle
+        ctx.pack = (d, w, io, hold, (m_ctx, m_cand), (prog, c1, word_w, move_w))
         ctx.save_for_backward(flat, prev_rep, cand_rep, h0, c0, ctxt, *params)
         ctx.set_materialize_grads(False)
-        return logit, prog, h1, c1, word_w, move_w
+        return logit, prog.detach(), h1, c1.detach(), word_w.detach(), move_w.detach()
 
     @staticmethod
     def backward(ctx, dlogit, dprog, dh1, dc1, dww_ext, dmw_ext):
@@ -132,3 +134,110 @@ class MonitorStepFn(torch.autograd.Function):
             _lib.check(st, "vln_monitor_step_bwd")
         ctx.pack = None
         return (None, None, None, None, dprev, dcand, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)
+
+
+class FollowerStepFn(torch.autograd.Function):
+    """AttnDecoderLSTM.forward + ActionScoring (policy.py:37-60, units.py:163-185) as ONE C call each way
+    (`vln_follower_step_fwd/bwd`, csrc/follower.hip); arguments of functional.FollowerCoreFn:
+    cfg = (training, dtype, p_drop, seed, off); params = W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act,
+    W_hid, b_hid, w_out, b_out."""
+
+    @staticmethod
+    def forward(ctx, cfg, ctx_mask, img, a_prev, cands, h0, c0, ctxt, *params):
+        training, dtype, p_drop, seed, off = cfg
+        W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out = params
+        lib = _lib.load()
+        f32 = torch.float32
+        img, cands = img.detach().contiguous(), cands.detach().contiguous()
+        a_prev, h0, c0, ctxt = a_prev.detach().contiguous(), h0.detach().contiguous(), c0.detach().contiguous(), ctxt.detach().contiguous()
+        B, V, F = img.shape
+        Cn, A = cands.shape[1], cands.shape[2]
+        H, L, D = h0.shape[1], ctxt.shape[1], W_h.shape[0]
+        dev = h0.device
+        XK = A + F + H
+        wt = ops.F32 if dtype == f32 else ops.BF16
+        d = _lib.FollowerDims(B, L, V, Cn, H, F, A, D, wt)
+        w = _lib.FollowerWeights()
+        hold = []
+
+        def sh(W, kind):
+            t = SHADOWS.get(W, kind, dtype)
+            hold.append(t)
+            return t.data_ptr()
+
+        w.w_h, w.w_h_t, w.b_h = sh(W_h, "n"), sh(W_h, "t"), b_h.data_ptr()
+        w.w_v, w.b_v = sh(W_v, "n"), b_v.data_ptr()
+        wc_n, wc_t = _fused_lstm_weight(W_ih, W_hh, dtype, False), _fused_lstm_weight(W_ih, W_hh, dtype, True)
+        wo = w_out.detach().reshape(-1)
+        hold += [wc_n, wc_t, wo]
+        w.w_cat, w.w_cat_t, w.b_ih, w.b_hh = wc_n.data_ptr(), wc_t.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr()
+        w.w_tin, w.w_tin_t = sh(W_tin, "n"), sh(W_tin, "t")
+        w.w_tout, w.w_tout_t = sh(W_tout, "n"), sh(W_tout, "t")
+        w.w_act, w.b_act = sh(W_act, "n"), b_act.data_ptr()
+        w.w_hid, w.w_hid_t, w.b_hid = sh(W_hid, "n"), sh(W_hid, "t"), b_hid.data_ptr()
+        w.w_out, w.b_out = wo.data_ptr(), b_out.data_ptr()
+        logit = ops.empty(B, Cn, dtype=f32, device=dev)
+        h1 = ops.empty(B, H, dtype=f32, device=dev); c1 = ops.empty(B, H, dtype=f32, device=dev)
+        word_w = ops.empty(B, L, dtype=f32, device=dev); view_w = ops.empty(B, V, dtype=f32, device=dev)
+        sizes = (("tq", B * D), ("keys", B * V * D), ("vlog", B * V), ("xcat", B * XK), ("act", B * 4 * H), ("tanh_c1", B * H),
+                 ("tq2", B * H), ("tcat", B * 2 * H), ("grounded", B * H), ("target", B * D), ("q", B * D), ("context", B * Cn * D),
+                 ("gates", B * 4 * H), ("dots", B * max(L, V, Cn)))
+        flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
+        io = _lib.FollowerStep()
+        q = flat.data_ptr()
+        for name, n in sizes:
+            setattr(io, name, q)
+            q += 4 * _r64(n)
+        m_ctx = _m8(ctx_mask) if ctx_mask is not None else None
+        io.img, io.a_prev, io.cands, io.h0, io.c0, io.ctx = (img.data_ptr(), a_prev.data_ptr(), cands.data_ptr(), h0.data_ptr(),
+                                                           c0.data_ptr(), ctxt.data_ptr())
+        io.ctx_mask = _p(m_ctx)
+        io.logit, io.h1, io.c1, io.word_w, io.view_w = logit.data_ptr(), h1.data_ptr(), c1.data_ptr(), word_w.data_ptr(), view_w.data_ptr()
+        ws = ops.workspace(dev, 1 << 22)
+        io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
+        io.seed, io.off, io.p_drop = seed, off, (p_drop if training else 0.0)
+        st = lib.vln_follower_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_follower_step_fwd")
+        ctx.cfg = cfg
+        # the backward reads both attention maps: memory kept alive here, fresh aliases returned (no ctx <-> output cycle)
+        ctx.pack = (d, w, io, hold, m_ctx, (word_w, view_w))
+        ctx.save_for_backward(flat, img, cands, a_prev, h0, c0, ctxt, *params)
+        ctx.set_materialize_grads(False)
+        return logit, h1, c1, word_w.detach(), view_w.detach()
+
+    @staticmethod
+    def backward(ctx, dlogit, dh1, dc1, dww_ext, dvw_ext):
+        d, w, io, hold, m_ctx, _alive = ctx.pack
+        flat, img, cands, a_prev, h0, c0, ctxt, *params = ctx.saved_tensors
+        dtype = ctx.cfg[1]
+        lib = _lib.load()
+        f32 = torch.float32
+        B, A = a_prev.shape
+        H, L = h0.shape[1], ctxt.shape[1]
+        dev = h0.device
+        cz = lambda t: None if t is None else t.contiguous()
+        ups = [cz(t) for t in (dlogit, dh1, dc1, dww_ext, dvw_ext)]
+        g = _lib.FollowerGrads()
+        g.dlogit, g.dh1, g.dc1, g.dww_ext, g.dvw_ext = (_p(t) for t in ups)
+        da = ops.empty(B, A, dtype=f32, device=dev) if ctx.needs_input_grad[3] else None
+        dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
+        dctx = torch.empty(B, L, H, dtype=f32, device=dev) if ctx.needs_input_grad[7] else None
+        g.da_prev, g.dh0, g.dc0, g.dctx = _p(da), dh0.data_ptr(), dc0.data_ptr(), _p(dctx)
+        sinks = [_gsink(p) for p in params]
+        names = ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact", "g_whid", "g_bhid",
+                 "g_wout", "g_bout")
+        for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
+            setattr(g, n, t.data_ptr())
+            g.acc[i] = 1 if acc else 0
+        g.precision = 0 if dtype == f32 else 1
+        ns = int(lib.vln_follower_bwd_scratch_floats(C.byref(d)))
+        scratch = ops.empty(ns, dtype=f32, device=dev)
+        g.scratch, g.scratch_floats = scratch.data_ptr(), ns
+        ws = ops.workspace(dev, 1 << 22)
+        io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
+        st = lib.vln_follower_step_bwd(C.byref(d), C.byref(w), C.byref(io), C.byref(g), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_follower_step_bwd")
+        ctx.pack = None
+        return (None, None, None, da, None, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)

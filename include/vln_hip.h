@@ -292,6 +292,46 @@ int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w
 int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor_weights* w, const vln_monitor_step* io,
                          const vln_monitor_grads* g, vln_stream_t s);
 
+/* AttnDecoderLSTM.forward + ActionScoring (policy.py:37-60, units.py:163-185) and the backward of that, ONE call each
+ * (csrc/follower.hip).  Same conventions as the Self-Monitor step above.  F = view feature size, A = candidate / previous-action
+ * feature size, D = dot size of the panorama attention and of ActionScoring (256). */
+typedef struct vln_follower_dims { int B, L, V, C, H, F, A, D, wtype; } vln_follower_dims;
+typedef struct vln_follower_weights {
+  const void *w_h, *w_h_t; const float* b_h;         /* visual_attn.linear_in_h           [D, H], [D]       */
+  const void* w_v; const float* b_v;                 /* visual_attn.linear_in_v           [D, F], [D]       */
+  const void *w_cat, *w_cat_t; const float *b_ih, *b_hh; /* [lstm.weight_ih | weight_hh]  [4H, A+F+H]       */
+  const void *w_tin, *w_tin_t;                       /* text_attn.linear_in.weight        [H, H]            */
+  const void *w_tout, *w_tout_t;                     /* text_attn.linear_out.weight       [H, 2H]           */
+  const void* w_act; const float* b_act;             /* decode_action.linear_act          [D, A], [D]       */
+  const void *w_hid, *w_hid_t; const float* b_hid;   /* decode_action.linear_hid          [D, H], [D]       */
+  const float *w_out, *b_out;                        /* decode_action.linear_out, fp32    [D], [1]          */
+} vln_follower_weights;
+typedef struct vln_follower_step {
+  const float *img /*[B,V,F]*/, *a_prev /*[B,A]*/, *cands /*[B,C,A]*/, *h0, *c0 /*[B,H]*/, *ctx /*[B,L,H]*/;
+  const uint8_t* ctx_mask;                           /* [B,L], 1 = masked; nullable */
+  float *logit /*[B,C]*/, *h1, *c1 /*[B,H]*/, *word_w /*[B,L]*/, *view_w /*[B,V]*/;                         /* outputs */
+  float *tq /*[B,D]*/, *keys /*[B*V,D]*/, *vlog /*[B,V]*/, *xcat /*[B,A+F+H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/, *tq2 /*[B,H]*/,
+        *tcat /*[B,2H]*/, *grounded /*[B,H]*/, *target /*[B,D]*/, *q /*[B,D]*/, *context /*[B*C,D]*/;      /* saved for the backward */
+  float *gates /*[B,4H]*/, *dots /*[B,max(L,V,C)]*/;                                          /* scratch of the call */
+  float* ws; int64_t ws_floats;
+  uint64_t seed, off; float p_drop;                  /* dropout sites `off` (LSTM input row, policy.py:49) and `off + 1` (h_1, :54) */
+} vln_follower_step;
+typedef struct vln_follower_grads {
+  const float *dlogit, *dh1, *dc1, *dww_ext, *dvw_ext;                /* upstream gradients, each nullable */
+  float *da_prev /*[B,A], nullable*/, *dh0, *dc0 /*[B,H]*/, *dctx /*[B,L,H], nullable*/;
+  int dctx_accumulate;
+  /* parameter gradients in the order W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid,
+   * w_out, b_out; each nullable; acc[i] = 1 adds to the buffer's contents */
+  float *g_wh, *g_bh, *g_wv, *g_bv, *g_ih, *g_hh, *g_bih, *g_bhh, *g_tin, *g_tout, *g_wact, *g_bact, *g_whid, *g_bhid, *g_wout, *g_bout;
+  int acc[16];
+  int precision;
+  float* scratch; int64_t scratch_floats;            /* >= vln_follower_bwd_scratch_floats(dims) */
+} vln_follower_grads;
+int64_t vln_follower_bwd_scratch_floats(const vln_follower_dims* d);
+int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follower_weights* w, vln_follower_step* io, vln_stream_t s);
+int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follower_weights* w, const vln_follower_step* io,
+                          const vln_follower_grads* g, vln_stream_t s);
+
 /* BatchNorm1d (+ fused ReLU): the BN-MLP of the Self-Monitor agent (units.py:210-242; `bn_mlp` =
  * vln_bn_fwd / vln_linear_fwd / vln_bn_fwd(relu)).  Training: batch statistics, running statistics updated in place with
  * `momentum` and the unbiased variance, *num_batches_tracked += 1, save_mean / save_rstd [D] kept for backward.  Eval:

@@ -110,6 +110,7 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
     enc = vln.EncoderLSTM(992, 300, 256, 0, 0.5, True, 2, compute_dtype=dt).to(dev).train()
     dec = vln.AttnDecoderLSTM(256, 0.5, F, F, compute_dtype=dt).to(dev).train()
     dec.fused_step = fused
+    dec.c_step = not getattr(args, "python_step", False)
     opt_e = vln.optim.FusedAdam([list(enc.parameters())], lr=1e-4)
     opt_d = vln.optim.FusedAdam([list(dec.parameters())], lr=1e-4)
     tokens = torch.randint(4, 992, (B, L), generator=g)

@@ -68,6 +68,10 @@ def test_struct_layouts_match_header(vln):
     assert fields("vln_monitor_weights") == [f for f, _ in L.MonitorWeights._fields_]
     assert fields("vln_monitor_step") == [f for f, _ in L.MonitorStep._fields_]
     assert fields("vln_monitor_grads") == [f for f, _ in L.MonitorGrads._fields_]
+    assert fields("vln_follower_dims") == [f for f, _ in L.FollowerDims._fields_]
+    assert fields("vln_follower_weights") == [f for f, _ in L.FollowerWeights._fields_]
+    assert fields("vln_follower_step") == [f for f, _ in L.FollowerStep._fields_]
+    assert fields("vln_follower_grads") == [f for f, _ in L.FollowerGrads._fields_]
 
 
 def test_modules_fail_loudly_without_gpu(vln):

@@ -243,6 +243,46 @@ def test_follower_fused_step_equals_operator_path(vln, cdt):
         close(a, b, f"input grad {i}")
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_follower_c_call_step_equals_python_driven_node(vln, cdt):
+    """`vln_follower_step_fwd/bwd` (csrc/follower.hip) against functional.FollowerCoreFn: the same launch sequence issued by the
+    library -- outputs bit-identical; gradients to summation-order rounding (d linear_in_v takes sum_v dl_v img_v from the
+    attention backward's own pass instead of a second sweep over the panorama)."""
+    B, V, C, L, H, F = 12, 36, 6, 17, 64, 96
+    g = torch.Generator().manual_seed(98)
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    imgs = [torch.randn(B, V, F, generator=g).abs() for _ in range(2)]
+    cands = [torch.randn(B, C, F, generator=g).abs() for _ in range(2)]
+    a_prev = torch.randn(B, F, generator=g).abs()
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
+    r = [torch.randn(B, C, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g), torch.randn(B, L, generator=g),
+         torch.randn(B, V, generator=g)]
+    torch.manual_seed(6)
+    sd = {k: v.clone() for k, v in vln.AttnDecoderLSTM(H, 0.5, F, F).state_dict().items()}
+    res = []
+    for c_step in (True, False):
+        dec = vln.AttnDecoderLSTM(H, 0.5, F, F, compute_dtype=cdt)
+        dec.load_state_dict(sd); dec.to(DEV).train()
+        dec.c_step = c_step
+        ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+        hh, cc, ap, total, outs = h, c, a_prev.to(DEV), 0.0, []
+        for t in range(2):
+            logit, (hh, cc), (ww, vw) = dec(imgs[t].to(DEV), ap, cands[t].to(DEV), hh, cc, ctx, ctx_mask.to(DEV))
+            total = total + (logit * r[0].to(DEV)).sum() + (ww * r[3].to(DEV)).sum() + (vw * r[4].to(DEV)).sum()
+            outs += [logit, ww, vw]
+            ap = cands[t][:, 0].to(DEV)
+        total = total + (hh * r[1].to(DEV)).sum() + (cc * r[2].to(DEV)).sum()
+        total.backward()
+        res.append((outs + [hh, cc], {n: p.grad.clone() for n, p in dec.named_parameters()}, [ctx.grad, h.grad, c.grad]))
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(a, b), f"output {i}"
+    gscale = max(v.abs().max().item() for v in res[1][1].values())
+    for n in res[0][1]:
+        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        check(a, b, 2e-5, f"input grad {i}")
+
+
 @pytest.mark.parametrize("kind", ["follower", "monitor"])
 def test_fused_nodes_grad_in_place(vln, kind):
     """functional.set_grad_in_place: the fused nodes add their Linear gradients into an existing p.grad (no AccumulateGrad
