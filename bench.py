@@ -194,12 +194,16 @@ class LiveBatch:
 class GpuAgent:
     """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
 
-    def __init__(self, vln, dev, dtype, world, arena=False, rollout_ce=True, side_gather=False):
+    def __init__(self, vln, dev, dtype, world, arena=False, rollout_ce=True, side_gather=False, fused_gather=True):
         self.vln, self.world, self.dtype = vln, world, dtype
         # (A/B option, off by default: measured slower) the step's feature gather reads only the resident table + index
         # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
         self.side = torch.cuda.Stream(device=dev) if side_gather else None
         self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
+        # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
+        # instead of a separate store.gather_step launch in front of every step
+        self.fused_gather = bool(fused_gather) and not side_gather
+        self.clear_grads_in_step = False
         self.rollout_ce = rollout_ce
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
         self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
@@ -231,6 +235,8 @@ class GpuAgent:
             return self.stage_from_host(s)
         if store is None:
             return s["img"].clone(), s["cand"].clone(), {}
+        if self.fused_gather:
+            return None, None, dict(gather=(store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
         lp = self.dtype != torch.float32
         pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
         # bf16 decoder: only the bf16 rows exist (nothing on this path reads fp32 features)
@@ -312,7 +318,8 @@ class GpuAgent:
             loss = torch.stack(terms).sum() * w
         loss.backward()
         self.opt.allreduce()
-        self.opt.step(zero_grads=True)       # the update clears the gradients it consumed: the next zero_grad() is free
+        # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
+        self.opt.step(zero_grads=self.clear_grads_in_step)
         return loss
 
 
@@ -434,6 +441,9 @@ def main():
                     help="main: the per-step feature gather in line on the compute stream; side: on a side stream (it depends on "
                          "no decoder output) -- measured SLOWER (2.28 vs 2.11 ms/iteration: the gathers land beside the persistent "
                          "recurrence and slow its hand-offs, and the per-step event pair costs host time), kept for A/B")
+    ap.add_argument("--separate-gather", action="store_true",
+                    help="store features: one store.gather_step launch in front of every decoder step (A/B) instead of the gather "
+                         "inside the step's first launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="(testing) map every rank to cuda:0")
@@ -483,7 +493,8 @@ def main():
         raise SystemExit("--features host-bf16 needs --dtype bf16")
     torch.manual_seed(2020)
     agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
-                     side_gather=args.gather_stream == "side" and args.features == "store")
+                     side_gather=args.gather_stream == "side" and args.features == "store", fused_gather=not args.separate_gather)
+    agent.clear_grads_in_step = True
     # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
     # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
     # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.
@@ -689,6 +700,7 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
     """ms per iteration of the headline workload under another precision / feature path (own agent, own arena)."""
     torch.manual_seed(2020)
     ag = GpuAgent(vln, dev, dtype, 1, arena=True)
+    ag.clear_grads_in_step = True
     if features == "store":
         st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
         tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]

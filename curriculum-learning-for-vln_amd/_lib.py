@@ -50,7 +50,9 @@ class EnvDropStep(C.Structure):
                                     "alpha_v", "gate_act", "tanh_c1", "tcat", "tt", "alpha_t", "htd", "a_stash")]
                 + [("seed", u64), ("offset", u64), ("p_drop", f32), ("p_feat", f32), ("already_dropfeat", i32), ("lp_ready", i32),
                    ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr), ("defer_logits", i32),
-                   ("pad_", i32)])
+                   ("pad_", i32)]
+                + [(n, ptr) for n in ("g_table", "g_angle_table", "g_rows", "g_vidx", "g_crows", "g_cviews", "g_chead", "g_celev")]
+                + [("g_ttype", i32), ("pad2_", i32)])
 
 
 class ShadowJob(C.Structure):

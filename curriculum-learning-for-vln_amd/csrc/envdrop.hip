@@ -13,60 +13,13 @@
 
 #include "vln_internal.h"
 #include "graph_cache.h"
+#include "envdrop_prep.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
 
-struct PrepArgs {
-  const float* a; const float* act_w; const float* act_b; const float* htp;
-  float* e; float* xcat; long ldx; float* hq;
-  int B, ANG, AE, F, H;
-  DropSpec d_act, d_h;
-  float* a_stash;   // nullable: copy of `a` kept for the deferred act_embed weight gradient
-};
-// e = tanh(a W_a^T + b); xcat[:, :AE] = drop(e); xcat[:, AE+F:] = h_tilde_prev; hq = drop(h_tilde_prev)
-// Work items: B*AE dot products of length ANG, 8 lanes each (a lane group reads 128 contiguous bytes of the weight row
-// per step: whole cache lines, where one thread per output walked 64 rows x 16 B per wave instruction), then B*H/4
-// float4 copies of h_tilde_prev and B*ANG/4 of a_prev.
 __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
-  const long ne = (long)p.B * p.AE, nh4 = (long)p.B * p.H / 4;
-  const long na4 = p.a_stash ? (long)p.B * p.ANG / 4 : 0;
-  const long nitems = ne * 8 + nh4 + na4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (long)gridDim.x * blockDim.x) {
-    if (i < ne * 8) {                                  // ne*8 is a multiple of 64: a wave never straddles this branch
-      const long o = i >> 3;
-      const int sub = (int)(i & 7);
-      const int b = (int)(o / p.AE), j = (int)(o % p.AE);
-      const float* a = p.a + (long)b * p.ANG;
-      const float* w = p.act_w + (long)j * p.ANG;
-      float acc = 0.f;
-      for (int k = sub * 4; k < p.ANG; k += 32) {
-        const float4 x = *reinterpret_cast<const float4*>(a + k);
-        const float4 y = *reinterpret_cast<const float4*>(w + k);
-        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-      }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      if (sub == 0) {
-        const float e = tanhf(acc + p.act_b[j]);
-        p.e[o] = e;
-        p.xcat[(long)b * p.ldx + j] = e * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)o, p.d_act.p);
-      }
-    } else if (i < ne * 8 + nh4) {
-      const long k4 = i - ne * 8;
-      const long k = k4 * 4;
-      const int b = (int)(k / p.H), j = (int)(k % p.H);
-      const float4 v = *reinterpret_cast<const float4*>(p.htp + k);
-      *reinterpret_cast<float4*>(p.xcat + (long)b * p.ldx + p.AE + p.F + j) = v;
-      float m[4] = {1.f, 1.f, 1.f, 1.f};
-      if (p.d_h.p > 0.f) dropout_scale4(p.d_h.seed, p.d_h.off(), (uint32_t)k4, p.d_h.p, m);
-      *reinterpret_cast<float4*>(p.hq + k) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
-    } else {
-      const long k = (i - ne * 8 - nh4) * 4;
-      *reinterpret_cast<float4*>(p.a_stash + k) = *reinterpret_cast<const float4*>(p.a + k);
-    }
-  }
+  envdrop_prep_body(p, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 struct PrepBwdArgs {
@@ -192,13 +145,24 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
               B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
               io->a_stash == io->a_prev ? nullptr : io->a_stash};
-  hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
-  VLN_CHECK_LAUNCH("envdrop_prep");
-  // (2) environmental feature dropout, in place                policy.py:226-231
-  // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)
-  const bool need_copy = lp && !io->lp_ready;
-  RUN(feat_dropout_inplace(st, io->img, W_F32, (long)B * d->V, d->IMG, d->ANG, site(io, 4, pf), need_copy ? io->img_lp : nullptr));
-  RUN(feat_dropout_inplace(st, io->cand, W_F32, (long)B * d->C, d->IMG, d->ANG, site(io, 5, pf), need_copy ? io->cand_lp : nullptr));
+  if (io->g_table) {
+    // (1)+(2) in ONE launch: the step gathers its own feature rows from the resident table (dropout sites 4 / 5 on the way)
+    // and the prep work rides along as extra workgroups (features.hip)
+    GatherStepArgs ga{io->g_table, io->g_angle_table, (const long long*)io->g_rows, io->g_vidx, (const long long*)io->g_crows,
+                      io->g_cviews, io->g_chead, io->g_celev, lp ? nullptr : io->img, lp ? (bf16_raw*)io->img_lp : nullptr,
+                      lp ? nullptr : io->cand, lp ? (bf16_raw*)io->cand_lp : nullptr, B, d->V, d->C, d->IMG, d->ANG,
+                      site(io, 4, pf), site(io, 5, pf)};
+    if (!lp && (!io->img || !io->cand)) { set_error("envdrop fwd: gathered features need img / cand buffers"); return VLN_ERR_ARG; }
+    RUN(gather_step_prep(st, ga, io->g_ttype, pa));
+  } else {
+    hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
+    VLN_CHECK_LAUNCH("envdrop_prep");
+    // (2) environmental feature dropout, in place                policy.py:226-231
+    // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)
+    const bool need_copy = lp && !io->lp_ready;
+    RUN(feat_dropout_inplace(st, io->img, W_F32, (long)B * d->V, d->IMG, d->ANG, site(io, 4, pf), need_copy ? io->img_lp : nullptr));
+    RUN(feat_dropout_inplace(st, io->cand, W_F32, (long)B * d->C, d->IMG, d->ANG, site(io, 5, pf), need_copy ? io->cand_lp : nullptr));
+  }
   const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;

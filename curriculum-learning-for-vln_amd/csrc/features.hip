@@ -6,6 +6,7 @@
 // the environmental feature dropout (policy.py:226-231; same Philox indexing as feat_dropout_inplace) and
 // optionally emits the bf16 copy the attention kernels stream.  16-byte accesses, one workgroup per output row.
 #include "vln_internal.h"
+#include "envdrop_prep.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -78,19 +79,10 @@ __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, cons
 // ---- one launch per decoder step: panorama rows + candidate rows ------------------------------------------------
 // Same outputs, same Philox indexing as the two kernels above (so vln_dropout_mask exports the same masks); a thread
 // handles 8 consecutive elements (one 16-byte load from a bf16 table), a row of 2176 is one pass of 272 threads.
-struct GatherStepArgs {
-  const void* table; const float* angle_table;
-  const long long* rows; const int* view_index;                                     // panorama: [B], [B]
-  const long long* crows; const int* cviews; const float* heading; const float* elevation;   // candidates: [B*C]
-  float* out; bf16_raw* out_lp; float* cout; bf16_raw* cout_lp;
-  int B, V, C, IMG, ANG;
-  DropSpec dr_pano, dr_cand;
-};
 template <typename TT>
-__global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) {
+__device__ __forceinline__ void gather_step_row(const GatherStepArgs& a, int r) {
   const int F = a.IMG + a.ANG, IMG = a.IMG;
   const TT* table = reinterpret_cast<const TT*>(a.table);
-  int r = blockIdx.x;
   const bool pano = r < a.B * a.V;
   const TT* src; float* dst; bf16_raw* dlp; DropSpec dr;
   const float* ang = nullptr;
@@ -155,6 +147,34 @@ __global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) {
       *reinterpret_cast<uint4*>(dlp + c) = v;
     }
   }
+}
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) { gather_step_row<TT>(a, (int)blockIdx.x); }
+
+// The same gather + the decoder step's prep work (act embedding, h_tilde_prev copy / dropout: envdrop_prep.h) as the LAST
+// `nprep` workgroups of the launch: both only depend on what the previous step left behind, and as two launches the second
+// one was ~6.5 us of pure dependent-launch latency per decoder step.
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_step_prep_kernel(GatherStepArgs a, PrepArgs p, int nrows, int nprep) {
+  if ((int)blockIdx.x < nrows) gather_step_row<TT>(a, (int)blockIdx.x);
+  else envdrop_prep_body(p, (long)((int)blockIdx.x - nrows) * 256 + threadIdx.x, (long)nprep * 256);
+}
+
+int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const PrepArgs& p) {
+  if (!a.table || !a.angle_table || !a.rows || !a.view_index || !a.crows || !a.cviews || !a.heading || !a.elevation ||
+      (!a.out && !a.out_lp) || (!a.cout && !a.cout_lp) || a.B <= 0 || a.V <= 0 || a.C <= 0 || (a.IMG & 7) || (a.ANG & 7)) {
+    set_error("gather_step_prep: bad args (IMG and ANG must be multiples of 8)");
+    return VLN_ERR_ARG;
+  }
+  const int nrows = a.B * a.V + a.B * a.C;
+  long nb = (envdrop_prep_items(p) + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  const int nprep = (int)nb;
+  if (ttype == VLN_BF16) hipLaunchKernelGGL(gather_step_prep_kernel<bf16_raw>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  else hipLaunchKernelGGL(gather_step_prep_kernel<float>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  VLN_CHECK_LAUNCH("gather_step_prep");
+  return VLN_OK;
 }
 
 }  // namespace vln

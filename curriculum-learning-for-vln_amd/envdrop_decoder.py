@@ -33,14 +33,16 @@ class _SoftDotParams(nn.Module):
 
 class _StepPlan:
     """What a decoder step needs again when the same argument block comes back (see EnvDropDecoder.forward)."""
-    __slots__ = ("io", "dims", "nws", "keep", "i0", "n_alloc", "xcat_ptr", "ctx_lp_ptr", "mask_ptr", "logit_ptr")
+    __slots__ = ("io", "dims", "nws", "keep", "i0", "n_alloc", "xcat_ptr", "ctx_lp_ptr", "mask_ptr", "first_ptr")
 
-    def __init__(self, io, dims, nws, keep, i0, n_alloc, xcat_ptr, ctx_lp_ptr, mask_ptr, logit_ptr):
+    def __init__(self, io, dims, nws, keep, i0, n_alloc, xcat_ptr, ctx_lp_ptr, mask_ptr, first_ptr, gathered=False):
         self.io = _lib.EnvDropStep.from_buffer_copy(io)
         own = ("logit", "h1", "c1", "h_tilde", "flat", "img_lp", "cand_lp")      # the module's buffers only: the caller's
-        self.dims, self.nws, self.i0, self.n_alloc = dims, nws, i0, n_alloc        # tensors are taken afresh every call
+        if gathered:                                                              # tensors are taken afresh every call
+            own = own + ("img", "cand")
+        self.dims, self.nws, self.i0, self.n_alloc = dims, nws, i0, n_alloc
         self.keep = {k: keep[k] for k in own if k in keep}
-        self.xcat_ptr, self.ctx_lp_ptr, self.mask_ptr, self.logit_ptr = xcat_ptr, ctx_lp_ptr, mask_ptr, logit_ptr
+        self.xcat_ptr, self.ctx_lp_ptr, self.mask_ptr, self.first_ptr = xcat_ptr, ctx_lp_ptr, mask_ptr, first_ptr
 
 
 class _StepRec:
@@ -48,6 +50,10 @@ class _StepRec:
 
 
 _NONES = (None,) * 64
+
+
+def _tp(t):
+    return 0 if t is None else t.data_ptr()
 
 
 class _EnvDropStepFn(torch.autograd.Function):
@@ -409,9 +415,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             cb.run()
 
     def _forward_planned(self, plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
-                         h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp):
+                         h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather=None):
         """The fast path of forward(): returns None (and leaves no trace) when anything the plan relies on moved."""
-        if not arena.reserve(plan.i0, plan.n_alloc, plan.logit_ptr):
+        if not arena.reserve(plan.i0, plan.n_alloc, plan.first_ptr):
             return None
         B, H = a_t_prev.shape[0], self.hidden_size
         lp = self.compute_dtype != torch.float32
@@ -442,9 +448,13 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         if io.offset_base_dev:
             io.offset -= self._base_value
             io.offset_base_dev = self._base_ptr
-        io.ws = ops.workspace(img_feature.device, plan.nws).data_ptr()
+        io.ws = ops.workspace(a_t_prev.device, plan.nws).data_ptr()
         keep = dict(plan.keep)
-        keep["img"], keep["cand"], keep["a"], keep["ctx"] = img_feature, cand_feature, a_t_prev, ctx
+        keep["a"], keep["ctx"] = a_t_prev, ctx
+        if gather is None:
+            keep["img"], keep["cand"] = img_feature, cand_feature
+        else:
+            keep["gather"] = gather
         if lp:
             keep["ctx_lp"] = ctx_lp
             if img_lp is not None:
@@ -452,7 +462,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         if m8 is not None:
             keep["mask"] = m8
         rec = _StepRec()
-        rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], cand_feature.shape[1], H
+        rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], plan.dims.C, H
         rec.ctx_owner, rec.entry, rec.dims, rec.slot, rec.io, rec.keep = ctx, entry, plan.dims, slot, io, keep
         rec.mod, rec.dhtd_ext, rec.dhtd_keep, rec.flushed = self, None, None, False
         if need_grad:
@@ -469,11 +479,25 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,
-                already_dropfeat=False, img_lp=None, cand_lp=None):
+                already_dropfeat=False, img_lp=None, cand_lp=None, gather=None):
         """Same contract as policy.py:208-246 (h_0 is unused there too).  img_feature / cand_feature are
         overwritten in place by the feature dropout, like the reference.  Extension (optional): `img_lp` / `cand_lp`
         = bf16 copies of the two feature tensors already produced by `DeviceFeatureStore.gather_*` (together with
-        `already_dropfeat=True`): the decoder then skips its own dropout/copy pass over the features."""
+        `already_dropfeat=True`): the decoder then skips its own dropout/copy pass over the features.
+        Extension (optional): `gather=(store, rows, view_index, cand_rows, cand_views, cand_heading, cand_elevation)` with
+        `img_feature = cand_feature = None`: the step reads its features from the HBM-resident table of a
+        staging.DeviceFeatureStore itself (index vectors as for `store.gather_step`), applies the feature dropout of
+        policy.py:226-231 on the way (its own Philox sites, exactly as on caller-given tensors) and does so in the SAME launch as
+        its act-embedding / state prep -- one dependent launch less per step than `store.gather_step` + forward."""
+        if gather is not None:
+            if img_feature is not None or cand_feature is not None or already_dropfeat:
+                raise TypeError("EnvDropDecoder: with gather=(store, ...) pass img_feature=None, cand_feature=None")
+            if not a_t_prev.is_cuda:
+                raise _lib.VlnError("EnvDropDecoder: tensors must be on the GPU; there is no CPU fallback")
+            out = self._forward(a_t_prev, None, None, h_tilde_prev, c_0, ctx, ctx_mask, False, None, None, gather)
+            if ops._arena is not None:
+                ops.stamp(out[0], out[1][0], out[1][1], out[2])
+            return out
         if not img_feature.is_cuda:
             raise _lib.VlnError("EnvDropDecoder: tensors must be on the GPU; there is no CPU fallback")
         if img_feature.dtype != torch.float32 or cand_feature.dtype != torch.float32:
@@ -486,15 +510,24 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             ops.stamp(out[0], out[1][0], out[1][1], out[2])
         return out
 
-    def _forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, c_0, ctx, ctx_mask, already_dropfeat, img_lp, cand_lp):
+    def _forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, c_0, ctx, ctx_mask, already_dropfeat, img_lp, cand_lp,
+                 gather=None):
         if ops._arena is not None:
             ops.check_live(h_tilde_prev, "EnvDropDecoder(h_tilde_prev)"); ops.check_live(c_0, "EnvDropDecoder(c_0)")
             ops.check_live(ctx, "EnvDropDecoder(ctx)")
-        B, V, F = img_feature.shape
-        Cn = cand_feature.shape[1]
+        if gather is not None:
+            store, g_rows, g_vidx, g_crows, g_cviews, g_chead, g_celev = gather
+            B, V, F = g_rows.shape[0], store.V, store.IMG + store.ANG
+            Cn = g_crows.shape[1]
+            dev = a_t_prev.device
+            if F != self.feature_size or store.ANG != self.angle_feat_size:
+                raise ValueError("EnvDropDecoder: the feature store's row layout does not match the decoder's feature_size / angle_feat_size")
+        else:
+            B, V, F = img_feature.shape
+            Cn = cand_feature.shape[1]
+            dev = img_feature.device
         L = ctx.shape[1]
         H, AE, ANG = self.hidden_size, self.action_embed_size, self.angle_feat_size
-        dev = img_feature.device
         P = self._gated_params()
         need_grad = torch.is_grad_enabled() and (
             h_tilde_prev.requires_grad or c_0.requires_grad or ctx.requires_grad or P[3].requires_grad)
@@ -510,7 +543,12 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         arena = ops.current_arena() if self.step_graphs else None
         pkey = None
         if arena is not None:
-            pkey = (arena.g, arena.i, a_t_prev.data_ptr(), img_feature.data_ptr(), cand_feature.data_ptr(), h_tilde_prev.data_ptr(),
+            if gather is not None:      # the index vectors stand in for the feature tensors
+                fk = (g_rows.data_ptr(), g_crows.data_ptr(), g_vidx.data_ptr(), g_cviews.data_ptr(), g_chead.data_ptr(),
+                      g_celev.data_ptr(), store.table.data_ptr())
+            else:
+                fk = (img_feature.data_ptr(), cand_feature.data_ptr())
+            pkey = (arena.g, arena.i, a_t_prev.data_ptr(), fk, h_tilde_prev.data_ptr(),
                     c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
                     self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
                     0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits))
@@ -523,7 +561,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             plan = self._plans.get(pkey)
             if plan is not None:
                 out = self._forward_planned(plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
-                                            h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp)
+                                            h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather)
                 if out is not None:
                     return out
         arena_i0 = arena.i if arena is not None else 0
@@ -545,8 +583,12 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             cached = self._dims_cache[dk] = (d, nws)
         d, nws = cached
         rec.dims = d
-        img = img_feature if img_feature.is_contiguous() else img_feature.contiguous()
-        cand = cand_feature if cand_feature.is_contiguous() else cand_feature.contiguous()
+        if gather is not None:          # the step's own feature buffers: fp32 rows (fp32 compute) or only the bf16 stream rows
+            img = None if lp else ops.empty(B, V, F, dtype=torch.float32, device=dev)
+            cand = None if lp else ops.empty(B, Cn, F, dtype=torch.float32, device=dev)
+        else:
+            img = img_feature if img_feature.is_contiguous() else img_feature.contiguous()
+            cand = cand_feature if cand_feature.is_contiguous() else cand_feature.contiguous()
         a = a_t_prev if a_t_prev.is_contiguous() else a_t_prev.contiguous()
         htp = h_tilde_prev.detach()
         if not htp.is_contiguous():
@@ -590,7 +632,19 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         io.tanh_c1 = q; q += 4 * n_h
         io.tt = q; q += 4 * n_h
         io.alpha_t = q
-        io.a_prev, io.img, io.cand = a.data_ptr(), img.data_ptr(), cand.data_ptr()
+        io.a_prev, io.img, io.cand = a.data_ptr(), _tp(img), _tp(cand)
+        if gather is not None:
+            for t_, nm in ((g_rows, "rows"), (g_vidx, "view_index"), (g_crows, "cand_rows"), (g_cviews, "cand_views"),
+                           (g_chead, "cand_heading"), (g_celev, "cand_elevation")):
+                if not (t_.is_cuda and t_.is_contiguous()):
+                    raise ValueError(f"EnvDropDecoder gather: {nm} must be a contiguous device tensor")
+            if g_rows.dtype != torch.int64 or g_crows.dtype != torch.int64 or g_vidx.dtype != torch.int32 or g_cviews.dtype != torch.int32:
+                raise TypeError("EnvDropDecoder gather: rows int64, view indices int32")
+            io.g_table, io.g_angle_table = store.table.data_ptr(), store.angle_table.data_ptr()
+            io.g_rows, io.g_vidx, io.g_crows, io.g_cviews = g_rows.data_ptr(), g_vidx.data_ptr(), g_crows.data_ptr(), g_cviews.data_ptr()
+            io.g_chead, io.g_celev = g_chead.data_ptr(), g_celev.data_ptr()
+            io.g_ttype = ops._dt(store.table)
+            keep["gather"] = gather
         if lp:
             ready = already_dropfeat and img_lp is not None and cand_lp is not None and img_lp.dtype == dt and \
                 cand_lp.dtype == dt and img_lp.is_contiguous() and cand_lp.is_contiguous()
@@ -625,13 +679,14 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.defer_logits = 1
         io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
         rec.io, rec.keep = io, keep
-        if (pkey is not None and img is img_feature and cand is cand_feature and a is a_t_prev and htp.is_contiguous()
+        if (pkey is not None and (gather is not None or (img is img_feature and cand is cand_feature)) and a is a_t_prev and htp.is_contiguous()
                 and h_tilde_prev.is_contiguous() and c_0.is_contiguous() and ctx.is_contiguous()):
             if len(self._plans) > 256:
                 self._plans.clear()
+            first = img if (gather is not None and not lp) else logit          # the first buffer the step took from the arena
             self._plans[pkey] = _StepPlan(io, d, nws, keep, arena_i0, arena.i - arena_i0,
                                           slot.ptr("xcat") if need_grad else 0, keep["ctx_lp"].data_ptr() if lp else 0,
-                                          io.ctx_mask, logit.data_ptr())
+                                          io.ctx_mask, first.data_ptr(), gathered=gather is not None)
 
         if need_grad:
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
@@ -640,10 +695,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             st = _lib.load().vln_envdrop_step_fwd(C.byref(d), C.byref(self._wstruct), C.byref(io), _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_envdrop_step_fwd")
-        if img is not img_feature:
-            img_feature.copy_(img)
-        if cand is not cand_feature:
-            cand_feature.copy_(cand)
+        if gather is None:
+            if img is not img_feature:
+                img_feature.copy_(img)
+            if cand is not cand_feature:
+                cand_feature.copy_(cand)
         return logit, (h1, c1), h_tilde
 
 

@@ -500,6 +500,17 @@ typedef struct vln_envdrop_step {
    * once -- one GEMM over (steps x batch) rows of the `htd` stash + vln_attn_dot_multi -- right before the rollout's loss
    * launch (EnvDropDecoder.defer_logits + losses.RolloutCE).  Sampling / greedy rollouts need the logits per step: 0. */
   int defer_logits; int pad_;
+  /* ABI v6, optional (g_table nullable).  When given, the step reads its features from the HBM-resident ResNet table itself
+   * (staging.DeviceFeatureStore; reference marshalling agent/base.py:141-157): panorama rows table[g_rows[b], v, :] ++ the
+   * static angle embedding of (g_vidx[b], v), candidate rows table[g_crows[b,c], g_cviews[b,c], :] ++ the angle features of
+   * (g_chead, g_celev); rows with g_crows < 0 (STOP slot, padding) are zero.  The feature dropout of policy.py:226-231 is
+   * applied on the way (the step's own Philox sites 4 / 5, as when it drops caller-given tensors in place) and the rows
+   * land in img / cand (fp32 compute) or img_lp / cand_lp (bf16 compute).  The gather and the step's first launch (act
+   * embedding, h_tilde_prev copy / dropout) are ONE launch. */
+  const void* g_table; const float* g_angle_table;
+  const int64_t* g_rows; const int32_t* g_vidx;                       /* [B], [B] */
+  const int64_t* g_crows; const int32_t* g_cviews; const float* g_chead; const float* g_celev;   /* [B,C] each */
+  int g_ttype; int pad2_;                                             /* table element type: VLN_F32 / VLN_BF16 */
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {

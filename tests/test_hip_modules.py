@@ -469,7 +469,7 @@ def test_side_stream_gather_and_rollout_ce_are_transparent(vln):
     res = []
     for side, rce in ((True, True), (False, False), (True, False), (False, True)):
         torch.manual_seed(19)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side, fused_gather=False)
         ag.dec.batch_logit_backward = False           # (the batched logit branch sums in another order: its own test below)
         ag.dec.defer_logits = False
         ag.enc._calls = 0; ag.dec._step_counter = 0
@@ -725,3 +725,46 @@ def test_arena_refuses_tensors_whose_memory_was_recycled(vln):
             dec(a, img.clone(), cand.clone(), kept[0], h, c, ctx)
     finally:
         vln.ops.set_arena(None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_gathers_its_own_features_like_caller_given_tensors(vln, dtype):
+    """EnvDropDecoder.forward(gather=(store, indices)): the step reads its rows from the resident table inside its first launch
+    and applies the feature dropout with its own Philox sites -- the very masks it uses on caller-given tensors.  Against the
+    tensor path (explicit img / cand tensors, dropped in place) on the same episode data: loss and every gradient bit for
+    bit, dropout ON, over four arena iterations (plans + graph replays)."""
+    import bench
+    dev_ = torch.device(DEV)
+    cpu_tape = bench.make_tape(16, 24, 4, 6, seed=31)
+    cpu_tape["table"] = cpu_tape["table"].bfloat16().float()          # values both table dtypes hold exactly
+    for s_ in cpu_tape["steps"]:
+        s_.update(bench.materialize_step(s_, cpu_tape["table"]))
+    res = []
+    for gathered in (True, False):
+        tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype) if gathered else bench.tape_to(cpu_tape, dev_)
+        torch.manual_seed(37)
+        ag = bench.GpuAgent(vln, dev_, dtype, 1, arena=True, fused_gather=gathered)
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        ag.opt.lr = 0.0
+        out = []
+        for _ in range(4):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
+        if gathered:
+            assert ag.dec.plan_hits >= 2 * 4
+        res.append(out)
+    # bf16: bit for bit.  fp32: the candidates' angle features come from the device's sinf / cosf in the gather and from
+    # libm in the materialised tensors (last-bit differences, test_hip_staging.py): to rounding.
+    for (la, ga), (lb, gb) in zip(res[0], res[1]):
+        if dtype == torch.bfloat16:
+            assert torch.equal(la, lb)
+        else:
+            check(la, lb, 1e-6, "loss")
+        gmax = max(float(b.abs().max()) for b in gb)
+        for i, (a, b) in enumerate(zip(ga, gb)):
+            if dtype == torch.bfloat16:
+                assert torch.equal(a, b)
+            else:
+                check(a, b, 1e-5, f"grad {i}", floor=1e-2 * gmax)
