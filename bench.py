@@ -441,6 +441,9 @@ def main():
                     help="main: the per-step feature gather in line on the compute stream; side: on a side stream (it depends on "
                          "no decoder output) -- measured SLOWER (2.28 vs 2.11 ms/iteration: the gathers land beside the persistent "
                          "recurrence and slow its hand-offs, and the per-step event pair costs host time), kept for A/B")
+    ap.add_argument("--wgrad", default="bf16", choices=["split", "bf16"],
+                    help="bf16 mode: weight gradients from split-bf16 operands (three MFMAs per product, fp32-grade) or from plain "
+                         "bf16 operands (one MFMA, mixed-precision standard)")
     ap.add_argument("--separate-gather", action="store_true",
                     help="store features: one store.gather_step launch in front of every decoder step (A/B) instead of the gather "
                          "inside the step's first launch")
@@ -488,6 +491,7 @@ def main():
 
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
+    vln.ops.set_wgrad_precision(args.wgrad)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.features == "host-bf16" and dtype != torch.bfloat16:
         raise SystemExit("--features host-bf16 needs --dtype bf16")

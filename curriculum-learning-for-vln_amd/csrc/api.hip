@@ -136,7 +136,7 @@ extern "C" int vln_linear_wgrad_p(const float* A, int64_t lda, const float* X, i
 extern "C" int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precision, float* ws, int64_t ws_floats,
                                  vln_stream_t s) {
   if (!jobs || n_jobs <= 0) { set_error("vln_wgrad_grouped: bad args"); return VLN_ERR_ARG; }
-  if (precision != 0 && precision != 1) { set_error("vln_wgrad_grouped: precision must be 0 (fp32) or 1 (split bf16)"); return VLN_ERR_ARG; }
+  if (precision < 0 || precision > 2) { set_error("vln_wgrad_grouped: precision must be 0 (fp32), 1 (split bf16) or 2 (plain bf16)"); return VLN_ERR_ARG; }
   return wgrad_grouped((hipStream_t)s, jobs, n_jobs, Mt, precision, ws, ws_floats);
 }
 extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,

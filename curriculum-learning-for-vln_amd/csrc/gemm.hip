@@ -781,6 +781,7 @@ struct PackJobs {
   PackJob j[2 * VLN_WGRAD_MAX_JOBS];
   int blk0[2 * VLN_WGRAD_MAX_JOBS + 1];
   unsigned char* area; int n, Mt, MS;
+  int lo;                 // 1: hi + lo planes (split-bf16 contraction); 0: hi plane only (plain bf16 operands)
 };
 __device__ __forceinline__ long pack_plane_bytes(int C, int MS) { return (long)((C + 15) / 16) * MS * 1024; }
 __global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
     const int column = col + c;
     const long off = (((long)(column >> 4) * a.MS + ms) * 64 + (mq * 16 + (column & 15))) * 16;
     *reinterpret_cast<bf16x8*>(hi + off) = h;
-    *reinterpret_cast<bf16x8*>(lo + off) = l;
+    if (a.lo) *reinterpret_cast<bf16x8*>(lo + off) = l;
   }
 }
 
@@ -834,6 +835,9 @@ struct PackedJobs {
   unsigned char* area; float* ws;
   int n, Mt, MS, msplit, schunk, ntiles, per_xcd;          // schunk: row steps per split
 };
+// TERMS = 3: D = Ah Xh + Ah Xl + Al Xh (split bf16: fp32-grade products, error 2^-16); TERMS = 1: D = Ah Xh (plain bf16 operands,
+// fp32 accumulation: what mixed-precision training computes; a third of the MFMAs, half the fragment loads)
+template <int TERMS>
 __global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) {
   const int lt = ((int)blockIdx.x & 7) * a.per_xcd + ((int)blockIdx.x >> 3);       // XCD-aware tile order
   if (((int)blockIdx.x >> 3) >= a.per_xcd || lt >= a.ntiles) return;
@@ -870,9 +874,11 @@ __global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ah[buf][i] = *reinterpret_cast<const bf16x8*>(Ah + oa[i] + so);
-      al[buf][i] = *reinterpret_cast<const bf16x8*>(Al + oa[i] + so);
       xh[buf][i] = *reinterpret_cast<const bf16x8*>(Xh + ox[i] + so);
-      xl[buf][i] = *reinterpret_cast<const bf16x8*>(Xl + ox[i] + so);
+      if constexpr (TERMS == 3) {
+        al[buf][i] = *reinterpret_cast<const bf16x8*>(Al + oa[i] + so);
+        xl[buf][i] = *reinterpret_cast<const bf16x8*>(Xl + ox[i] + so);
+      }
     }
   };
   auto mma = [&](int buf) {
@@ -880,8 +886,10 @@ __global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xl[buf][j], acc[i][j], 0, 0, 0);
+        if constexpr (TERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xl[buf][j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
       }
   };
@@ -939,13 +947,13 @@ static long wgrad_packed_ws_floats(const vln_wgrad_job* jobs, int n, int Mt, int
   return area / 4 + (msplit > 1 ? (long)msplit * elems : 0);
 }
 
-static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats) {
+static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms) {
   const int MS = (Mt + 31) / 32;
   int msplit = 1; long area_floats = 0;
   const long need = wgrad_packed_ws_floats(jobs, n, Mt, &msplit, &area_floats);
   if (need > ws_floats || !aligned16(ws)) return -1;                 // caller falls back to the LDS-staged kernel
   PackJobs pk; PackedJobs g;
-  pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0;
+  pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0; pk.lo = terms == 3 ? 1 : 0;
   g.area = pk.area; g.ws = ws + area_floats; g.Mt = Mt; g.MS = MS; g.n = n;
   long off = 0; int blk = 0, t = 0; long slab = 0;
   double bytes = 0.0;
@@ -975,7 +983,8 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
   g.schunk = (MS + msplit - 1) / msplit;
   g.msplit = (MS + g.schunk - 1) / g.schunk;
   hipLaunchKernelGGL(wgrad_pack_kernel, dim3(blk), dim3(256), 0, st, pk);
-  launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
+  if (terms == 3) launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<3>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
+  else launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<1>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
   if (g.msplit > 1) {
     WgradJobs r;
     r.n = n; r.Mt = Mt; r.ws = g.ws; r.msplit = g.msplit;
@@ -991,6 +1000,10 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
 
 int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats) {
   if (n <= 0 || Mt <= 0) { set_error("wgrad_grouped: bad args"); return VLN_ERR_ARG; }
+  // precision 2 = plain bf16 operands on the packed grouped kernel; where that kernel cannot be used it degrades to the
+  // (more accurate) split form
+  const int terms = precision == 2 ? 1 : 3;
+  if (precision == 2) precision = 1;
   bool ok = precision == 1 && g_tunable[6] != 1;
   for (int i = 0; i < n && ok; ++i) {
     const vln_wgrad_job& q = jobs[i];
@@ -1005,7 +1018,7 @@ int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int 
     return VLN_OK;
   }
   if (n <= VLN_WGRAD_MAX_JOBS && g_tunable[6] != 2) {      // tunable[6] = 2: LDS-staged grouped kernel (A/B)
-    const int r = wgrad_grouped_packed(st, jobs, n, Mt, ws, ws_floats);
+    const int r = wgrad_grouped_packed(st, jobs, n, Mt, ws, ws_floats, terms);
     if (r >= 0) return r;
   }
   for (int base = 0; base < n; base += VLN_WGRAD_MAX_JOBS) {

@@ -123,7 +123,7 @@ class MonitorStepFn(torch.autograd.Function):
         for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
             setattr(g, n, t.data_ptr())
             g.acc[i] = 1 if acc else 0
-        g.precision = 0 if dtype == f32 else 1
+        g.precision = ops.wgrad_precision(dtype != f32)
         ns = int(lib.vln_monitor_bwd_scratch_floats(C.byref(d)))
         scratch = ops.empty(ns, dtype=f32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), ns
@@ -230,7 +230,7 @@ class FollowerStepFn(torch.autograd.Function):
         for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
             setattr(g, n, t.data_ptr())
             g.acc[i] = 1 if acc else 0
-        g.precision = 0 if dtype == f32 else 1
+        g.precision = ops.wgrad_precision(dtype != f32)
         ns = int(lib.vln_follower_bwd_scratch_floats(C.byref(d)))
         scratch = ops.empty(ns, dtype=f32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), ns

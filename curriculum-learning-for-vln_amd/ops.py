@@ -309,6 +309,30 @@ class ColsumBatch:
         self.jobs, self.keep, self.rows = [], [], None
 
 
+# Weight gradients in bf16 compute mode (fp32 compute mode always uses the exact fp32 MFMA):
+#   "bf16"  (default) plain bf16 operands, fp32 accumulation -- ONE MFMA per product, what mixed-precision training computes;
+#           gradients within 2-5e-3 of the fp64 result on the same weights (measured, tests/parity.py SAME_BF16_GRAD), inside
+#           north_star's 1e-2 bound for bf16;
+#   "split" both operands as hi + lo bf16 planes, three MFMAs per product: fp32-grade gradients (5e-5 of the fp64 result) for
+#           +50 us per EnvDrop iteration (1.80 -> 1.85 ms, profiles/round2_notes.md).
+_WGRAD_BF16 = [1 if __import__('os').environ.get('VLN_WGRAD') == 'split' else 2]      # VLN_WGRAD=split: process-wide default
+
+
+def set_wgrad_precision(mode: str):
+    """"bf16" (default) or "split": the form of the weight-gradient contractions in bf16 compute mode (see above)."""
+    if mode not in ("split", "bf16"):
+        raise ValueError("wgrad precision: 'split' or 'bf16'")
+    _WGRAD_BF16[0] = 1 if mode == "split" else 2
+
+
+def get_wgrad_precision() -> str:
+    return "split" if _WGRAD_BF16[0] == 1 else "bf16"
+
+
+def wgrad_precision(lp: bool) -> int:
+    return _WGRAD_BF16[0] if lp else 0
+
+
 class WgradBatch:
     """Collects dW (+)= dy.T @ x products over the SAME rows and issues them as one launch (`vln_wgrad_grouped`)."""
 
@@ -336,7 +360,7 @@ class WgradBatch:
         msplit = max(1, min(256 // max(tiles, 1), MS // 4)) if tiles < 256 else 1
         area = sum(2 * ((j.N + 15) // 16 + (j.K + 15) // 16) * MS * 1024 for j in self.jobs) // 4
         ws = workspace(self.keep[0].device, max(1 << 22, area + (msplit * sum(j.N * j.K for j in self.jobs) if msplit > 1 else 0)))
-        _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, 1 if self.split else 0, _p(ws), ws.numel(),
+        _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, wgrad_precision(self.split), _p(ws), ws.numel(),
                                                  _stream()), "vln_wgrad_grouped")
         self.jobs, self.keep, self.Mt = [], [], None
 

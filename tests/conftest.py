@@ -48,3 +48,14 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         terminalreporter.write_line(line)
     path = parity.write_report(ROOT)
     terminalreporter.write_line(f"{len(parity.RECORDS)} comparisons -> {path}")
+
+
+@pytest.fixture
+def split_wgrads():
+    """Tests that compare two schedules of the SAME computation to rounding (1e-5) run the bf16 mode's weight gradients in their
+    fp32-grade "split" form: with plain bf16 operands a last-bit difference of an operand can flip its bf16 rounding."""
+    import vln_amd
+    before = vln_amd.ops.get_wgrad_precision()
+    vln_amd.ops.set_wgrad_precision("split")
+    yield
+    vln_amd.ops.set_wgrad_precision(before)

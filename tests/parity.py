@@ -101,6 +101,15 @@ def write_report(root):
 #     weights themselves (2^-9 relative per weight), amplified by softmax / recurrence / ReLU switches; tensors that cannot meet
 #     1e-2 carry an explicit tolerance and a row in DESIGN.md section 2.
 SAME_BF16 = 1e-4
+# ... and for PARAMETER gradients under the default weight-gradient form of the bf16 mode (ops.set_wgrad_precision("bf16"): both
+# operands of dW = dY^T X enter the MFMA as plain bf16, 2^-9 relative rounding each): measured 2-5e-3 on the full-size tests;
+# with "split" operands (hi + lo planes, three MFMAs) the gradients meet SAME_BF16 like everything else.
+SAME_BF16_GRAD = 8e-3
+
+
+def same_bf16_grad_tol():
+    import vln_amd
+    return SAME_BF16 if vln_amd.ops.get_wgrad_precision() == "split" else SAME_BF16_GRAD
 
 
 def bf16_round_st(t):

@@ -110,6 +110,7 @@ def test_monitor_golden(vln, name):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_monitor_fused_step_equals_operator_path(vln, cdt):
     """MonitorDecoder with the one-node core (functional.MonitorCoreFn) against the operator-by-operator path it replaces,
     in TRAINING mode with every dropout on (both draw the same Philox masks): outputs, state, attention weights, all
@@ -157,6 +158,7 @@ def test_monitor_fused_step_equals_operator_path(vln, cdt):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_monitor_c_call_step_equals_python_driven_node(vln, cdt):
     """`vln_monitor_step_fwd/bwd` (the step after the BN-MLP as ONE C call each way, csrc/monitor.hip) issues the launch sequence
     that functional.MonitorCoreFn drives from Python: outputs bit-identical, gradients to summation-order rounding, in training
@@ -197,6 +199,7 @@ def test_monitor_c_call_step_equals_python_driven_node(vln, cdt):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_follower_fused_step_equals_operator_path(vln, cdt):
     """AttnDecoderLSTM as one autograd node (functional.FollowerCoreFn) against the operator-by-operator path it replaces,
     in TRAINING mode with both dropouts on (same Philox masks): logits, state, both attention maps, every parameter
@@ -244,6 +247,7 @@ def test_follower_fused_step_equals_operator_path(vln, cdt):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_follower_c_call_step_equals_python_driven_node(vln, cdt):
     """`vln_follower_step_fwd/bwd` (csrc/follower.hip) against functional.FollowerCoreFn: the same launch sequence issued by the
     library -- outputs bit-identical; gradients to summation-order rounding (d linear_in_v takes sum_v dl_v img_v from the
@@ -284,6 +288,7 @@ def test_follower_c_call_step_equals_python_driven_node(vln, cdt):
 
 
 @pytest.mark.parametrize("kind", ["follower", "monitor"])
+@pytest.mark.usefixtures("split_wgrads")
 def test_fused_nodes_grad_in_place(vln, kind):
     """functional.set_grad_in_place: the fused nodes add their Linear gradients into an existing p.grad (no AccumulateGrad
     launches) -- after two backward passes p.grad equals the default route's, bit for bit where the launches are the same

@@ -10,7 +10,7 @@ the UNROUNDED fp64 parameters).  north_star tolerances: 1e-4 (fp32) / 1e-2 (bf16
 import pytest
 import torch
 
-from parity import check, bf16_weights, FP32, BF16, SAME_BF16
+from parity import check, bf16_weights, same_bf16_grad_tol, FP32, BF16, SAME_BF16
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -66,7 +66,7 @@ class _Oracle:
 def _oracles(cdt, sd, leaves, skip, bf16_exceptions):
     if cdt == torch.float32:
         return [_Oracle("fp32", sd, leaves, FP32, False, skip)]
-    return [_Oracle("bf16 same-weights", sd, leaves, SAME_BF16, True, skip),
+    return [_Oracle("bf16 same-weights", sd, leaves, SAME_BF16, True, skip, {"grad[": same_bf16_grad_tol()}),
             _Oracle("bf16 unrounded", sd, leaves, BF16, False, skip, bf16_exceptions)]
 
 

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from parity import check, check_grads, rel_err, bf16_weights, bf16_round_st, FP32, BF16, SAME_BF16
+from parity import check, check_grads, rel_err, bf16_weights, bf16_round_st, same_bf16_grad_tol, FP32, BF16, SAME_BF16
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -199,7 +199,7 @@ def _variants(compute_dtype, exc):
     weights the kernels stream at SAME_BF16, and the oracle on the unrounded masters at north_star's 1e-2 (tests/parity.py)."""
     if compute_dtype == torch.float32:
         return [("fp32", FP32, False, None)]
-    return [("bf16 same-weights", SAME_BF16, True, None), ("bf16 unrounded", BF16, False, exc)]
+    return [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, exc)]
 
 
 def _full_size_envdrop(vln, compute_dtype, T=3, train=True):
@@ -314,6 +314,7 @@ def _encoder_full(vln, compute_dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
     """The single-launch persistent bi-LSTM (in-kernel cross-workgroup hand-off) must reproduce the per-step
     launch chain bit for bit, forward and backward, and report a clean status word."""
@@ -514,6 +515,7 @@ def test_host_feature_staging_matches_resident_tensors(vln):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_batched_logit_branch_backward_equals_per_step(vln, dtype):
     """EnvDropDecoder.logit_branch_backward (losses.RolloutCE hands over every step's d logits at once: one multi-step
     weighted sum into the stash + one GEMM over (steps x batch) rows) against the per-step branch inside each step's
@@ -593,6 +595,7 @@ def test_deferred_logits_are_filled_by_the_rollout_loss(vln):
             fn()
 
 
+@pytest.mark.usefixtures("split_wgrads")
 def test_per_sample_rollout_loss_through_the_decoder(vln):
     """SELF-PACE form (curriculum.py:296): `dot(weight, RolloutCE.per_sample())` through EnvDropDecoder steps -- the per-episode
     upstream gradients take the materialised-d-logits route of the rollout-wide logit branch; deferred logits + batched branch
@@ -633,6 +636,7 @@ def test_per_sample_rollout_loss_through_the_decoder(vln):
 
 
 @pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.usefixtures("split_wgrads")
 def test_rollout_ce_and_sampled_log_probs_share_the_logits(vln, per_sample):
     """Two differentiable consumers of the SAME logits (the ML loss and the sampled actions' log-probs / entropies,
     envdrop.py:173-195): with the rollout-wide logit branch (batch_logit_backward, the default) the second consumer's gradient
@@ -728,6 +732,7 @@ def test_arena_refuses_tensors_whose_memory_was_recycled(vln):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
 def test_step_gathers_its_own_features_like_caller_given_tensors(vln, dtype):
     """EnvDropDecoder.forward(gather=(store, indices)): the step reads its rows from the resident table inside its first launch
     and applies the feature dropout with its own Philox sites -- the very masks it uses on caller-given tensors.  Against the
@@ -768,3 +773,11 @@ def test_step_gathers_its_own_features_like_caller_given_tensors(vln, dtype):
                 assert torch.equal(a, b)
             else:
                 check(a, b, 1e-5, f"grad {i}", floor=1e-2 * gmax)
+
+
+@pytest.mark.usefixtures("split_wgrads")
+def test_envdrop_full_size_bf16_split_weight_gradients(vln):
+    """The fp32-grade form of the bf16 mode's weight gradients (ops.set_wgrad_precision("split")): every gradient meets the
+    same-weights bound of the outputs (1e-4)."""
+    assert same_bf16_grad_tol() == SAME_BF16
+    _full_size_envdrop(vln, torch.bfloat16)

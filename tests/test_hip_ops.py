@@ -63,10 +63,22 @@ def test_linear_wgrad(vln, Mt, N, K):
     check(o3b, 2 * ref, 5e-5, "o3b")
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "bf16"])
 def test_wgrad_grouped(vln, split):
-    """All weight gradients of a module from one call (one launch in the split-bf16 form): the decoder's seven
-    products over the same (steps x batch) rows, strided operands, accumulate and overwrite mixed."""
+    """All weight gradients of a module from one call (one launch in the bf16 forms): the decoder's seven
+    products over the same (steps x batch) rows, strided operands, accumulate and overwrite mixed.  False: exact fp32 MFMA;
+    True: split-bf16 operands (three MFMAs, 5e-5); "bf16": plain bf16 operands, fp32 accumulation (one MFMA, 2^-9 per operand)."""
+    before = vln.ops.get_wgrad_precision()
+    vln.ops.set_wgrad_precision("bf16" if split == "bf16" else "split")
+    try:
+        _wgrad_grouped(vln, split)
+    finally:
+        vln.ops.set_wgrad_precision(before)
+
+
+def _wgrad_grouped(vln, split):
+    tol = {False: 1e-5, True: 5e-5, "bf16": 6e-3}[split]
+    split = bool(split)
     g = torch.Generator().manual_seed(11)
     Mt = 448
     shapes = [(2048, 2240), (2176, 512), (2048, 512), (512, 1024), (512, 512), (64, 128), (132, 260)]
@@ -82,7 +94,7 @@ def test_wgrad_grouped(vln, split):
         refs.append(ref); outs.append(out)
     wb.run()
     for o, r in zip(outs, refs):
-        check(o, r, (5e-5 if split else 1e-5), "o")
+        check(o, r, tol, "o")
 
 
 @pytest.mark.parametrize("R,D", [(128, 2176), (1024, 1024), (1792, 1024), (5, 8)])
