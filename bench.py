@@ -444,6 +444,8 @@ def main():
     ap.add_argument("--wgrad", default="bf16", choices=["split", "bf16"],
                     help="bf16 mode: weight gradients from split-bf16 operands (three MFMAs per product, fp32-grade) or from plain "
                          "bf16 operands (one MFMA, mixed-precision standard)")
+    ap.add_argument("--chain", action="store_true",
+                    help="A/B: the decoder steps as chained kernels (csrc/chain.h: measured slower, 2.64 vs 1.80 ms) instead of one launch per stage")
     ap.add_argument("--separate-gather", action="store_true",
                     help="store features: one store.gather_step launch in front of every decoder step (A/B) instead of the gather "
                          "inside the step's first launch")
@@ -492,6 +494,7 @@ def main():
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     vln.ops.set_wgrad_precision(args.wgrad)
+    lib.vln_set_chain(1 if args.chain else 0)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.features == "host-bf16" and dtype != torch.bfloat16:
         raise SystemExit("--features host-bf16 needs --dtype bf16")

@@ -190,6 +190,8 @@ SIGNATURES = {
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
+    "vln_set_chain": (i32, [i32]),
+    "vln_get_chain": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),
     "vln_follower_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),

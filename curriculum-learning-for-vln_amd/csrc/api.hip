@@ -40,7 +40,7 @@ struct ProfState {
 };
 ProfState g_prof[K_COUNT];
 const char* kKernelNames[K_COUNT] = {"gemm_nt", "gemm_tn", "attn_dot", "attn_wsum", "attn_bwd", "lstm_rec_fwd",
-                                     "lstm_rec_bwd", "feat_dropout", "lstm_pointwise", "reduce_epilogue"};
+                                     "lstm_rec_bwd", "feat_dropout", "lstm_pointwise", "reduce_epilogue", "step_chain"};
 }  // namespace
 void prof_begin(hipStream_t st, int kid, double algo_bytes) {
   ProfState& p = g_prof[kid];

@@ -7,6 +7,7 @@
 //                       in-place dctx accumulation
 // Reference semantics: units.py:100-122 (SoftDotAttention), units.py:138-160 (VisualSoftDotAttention).
 #include "vln_internal.h"
+#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -243,8 +244,8 @@ int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype
   }
   const int DC = 64 * V;
   dim3 grid(T * B, (D + DC - 1) / DC), block(256);
-  if (ctype == W_BF16) hipLaunchKernelGGL(rows_wsum_multi_kernel<bf16_raw>, grid, block, 0, st, m, vec_ok);
-  else hipLaunchKernelGGL(rows_wsum_multi_kernel<float>, grid, block, 0, st, m, vec_ok);
+  if (ctype == W_BF16) VLN_LAUNCH(rows_wsum_multi_kernel<bf16_raw>, grid, block, 0, st, m, vec_ok);
+  else VLN_LAUNCH(rows_wsum_multi_kernel<float>, grid, block, 0, st, m, vec_ok);
   VLN_CHECK_LAUNCH("rows_wsum_multi");
   return VLN_OK;
 }
@@ -301,8 +302,8 @@ int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, 
   m.row0[T] = rows;
   int blocks = (rows + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  if (ctype == W_BF16) hipLaunchKernelGGL(attn_dot_multi_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
-  else hipLaunchKernelGGL(attn_dot_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
+  if (ctype == W_BF16) VLN_LAUNCH(attn_dot_multi_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
+  else VLN_LAUNCH(attn_dot_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, m, vec_ok);
   VLN_CHECK_LAUNCH("attn_dot_multi");
   return VLN_OK;
 }
@@ -484,7 +485,7 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
     }
     a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0;
     const unsigned lds = (unsigned)(2 * a.T * (D + 16) * sizeof(float));
-    hipLaunchKernelGGL(attn_dctx_deferred_kernel, dim3(B, (S + 15) / 16), dim3(256), lds, st, a);
+    VLN_LAUNCH(attn_dctx_deferred_kernel, dim3(B, (S + 15) / 16), dim3(256), lds, st, a);
     VLN_CHECK_LAUNCH("attn_dctx_deferred");
   }
   return VLN_OK;

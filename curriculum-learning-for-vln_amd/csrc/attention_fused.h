@@ -31,19 +31,28 @@ struct AttnFusedArgs {
   int S, D;
 };
 
-template <typename TC, int RW, int SL, bool kBwd>
-__global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(AttnFusedArgs a) {
+template <typename TC, int SL> constexpr int attn_fused_dp() { return 64 * SL * Elt<TC>::kVec; }
+template <typename TC, int RW, int SL> constexpr int attn_fused_smem_bytes() {
+  return (attn_fused_dp<TC, SL>() * (1 + kFusedWaves / 2) + kFusedWaves * RW) * (int)sizeof(float);
+}
+
+// One workgroup (8 waves) = one batch row `b`; `smem` = attn_fused_smem_bytes() of 16-byte aligned LDS.
+// `pre()` runs after the block's context loads have been issued and before the query vector (the producer's output) is
+// read: the chained step kernel (chain.hip) waits for the previous stage there.  `ctx_ready()` runs before the context
+// loads (the chained kernel waits there for the stage that produced the context, if one did).
+template <typename TC, int RW, int SL, bool kBwd, typename CtxReady, typename Pre>
+__device__ __forceinline__ void attn_fused_body(const AttnFusedArgs& a, int b, unsigned char* smem, CtxReady ctx_ready, Pre pre) {
   constexpr int V = Elt<TC>::kVec;
   constexpr int NW = kFusedWaves;
   constexpr int DP = 64 * SL * V;                   // padded row length covered by the lanes
-  __shared__ __attribute__((aligned(16))) float sq[DP];
-  __shared__ float sdots[NW * RW];
-  __shared__ __attribute__((aligned(16))) float red[NW / 2][DP];
-  const int b = blockIdx.x;
+  float* sq = reinterpret_cast<float*>(smem);                                  // [DP]
+  float (*red)[DP] = reinterpret_cast<float (*)[DP]>(smem + DP * sizeof(float));   // [NW / 2][DP]
+  float* sdots = reinterpret_cast<float*>(smem + (size_t)DP * (1 + NW / 2) * sizeof(float));   // [NW * RW]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.S, D = a.D, nseg = D / V;
   const TC* base = reinterpret_cast<const TC*>(a.ctx) + (long)b * S * D;
 
+  ctx_ready();
   // (1) every load of the block in flight at once
   uint4 data[RW][SL];
 #pragma unroll
@@ -56,6 +65,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(AttnFusedA
       else data[r][j] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  pre();
   for (int i = threadIdx.x * 4; i < DP; i += NW * 64 * 4) {      // D % 4 == 0 (host check)
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < D) {
@@ -191,6 +201,13 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(AttnFusedA
   }
 }
 
+template <typename TC, int RW, int SL, bool kBwd>
+__global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(AttnFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[attn_fused_smem_bytes<TC, RW, SL>()];
+  attn_fused_body<TC, RW, SL, kBwd>(a, (int)blockIdx.x, smem, [] {}, [] {});
+}
+
+#ifndef VLN_ATTN_FUSED_BODY_ONLY
 template <typename TC, int RW, int SL>
 static void attn_fused_launch(hipStream_t st, const AttnFusedArgs& a, int B, bool bwd, double bytes) {
   dim3 grid(B), block(kFusedWaves * 64);
@@ -208,18 +225,21 @@ static bool attn_fused_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
   const int nseg = D / V;
   const int sl = (nseg + 63) / 64, rw = (S + kFusedWaves - 1) / kFusedWaves;
   const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 8.0 * B * D + 8.0 * B * S;
-#define VLN_FUSED_CASE(TC, RWv, SLv) \
-  if (rw <= RWv && sl <= SLv) { attn_fused_launch<TC, RWv, SLv>(st, a, B, bwd, bytes); return true; }
+  // configuration k of a dtype is chain kind CK_ATTN_{FWD,BWD}_k (chain.hip instantiates the same four per dtype)
+#define VLN_FUSED_CASE(TC, RWv, SLv, k) \
+  if (rw <= RWv && sl <= SLv) { \
+    if (chain_add(st, (bwd ? CK_ATTN_BWD_0 : CK_ATTN_FWD_0) + k, B, 1, 1, &a, sizeof(a), bytes, ctype)) return true; \
+    attn_fused_launch<TC, RWv, SLv>(st, a, B, bwd, bytes); return true; }
   if (ctype == W_BF16) {
-    VLN_FUSED_CASE(bf16_raw, 10, 1)       // instruction context: S <= 80, D <= 512
-    VLN_FUSED_CASE(bf16_raw, 2, 2)        // projected candidates (Self-Monitor): S <= 16, D <= 1024
-    VLN_FUSED_CASE(bf16_raw, 2, 5)        // candidate features: S <= 16, D <= 2560
-    VLN_FUSED_CASE(bf16_raw, 5, 5)        // panorama: S <= 40, D <= 2560
+    VLN_FUSED_CASE(bf16_raw, 10, 1, 0)       // instruction context: S <= 80, D <= 512
+    VLN_FUSED_CASE(bf16_raw, 2, 2, 1)        // projected candidates (Self-Monitor): S <= 16, D <= 1024
+    VLN_FUSED_CASE(bf16_raw, 2, 5, 2)        // candidate features: S <= 16, D <= 2560
+    VLN_FUSED_CASE(bf16_raw, 5, 5, 3)        // panorama: S <= 40, D <= 2560
   } else {
-    VLN_FUSED_CASE(float, 10, 2)          // S <= 80, D <= 512
-    VLN_FUSED_CASE(float, 2, 4)           // S <= 16, D <= 1024
-    VLN_FUSED_CASE(float, 2, 9)           // S <= 16, D <= 2304
-    VLN_FUSED_CASE(float, 5, 9)           // S <= 40, D <= 2304
+    VLN_FUSED_CASE(float, 10, 2, 0)          // S <= 80, D <= 512
+    VLN_FUSED_CASE(float, 2, 4, 1)           // S <= 16, D <= 1024
+    VLN_FUSED_CASE(float, 2, 9, 2)           // S <= 16, D <= 2304
+    VLN_FUSED_CASE(float, 5, 9, 3)           // S <= 40, D <= 2304
   }
 #undef VLN_FUSED_CASE
   return false;
@@ -301,3 +321,4 @@ __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
     *o = acc;
   }
 }
+#endif  // VLN_ATTN_FUSED_BODY_ONLY

@@ -16,6 +16,7 @@
 
 #include "vln_internal.h"
 #include "graph_cache.h"
+#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -452,7 +453,7 @@ extern "C" int vln_embed_fwd(const int64_t* tokens, const float* E, float* out_t
                              uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
   if (!tokens || !E || !out_tm || B <= 0 || L <= 0 || D <= 0) { set_error("vln_embed_fwd: bad args"); return VLN_ERR_ARG; }
   const int vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out_tm)) & 15) == 0;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(nblk(vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+  VLN_LAUNCH(embed_fwd_kernel, dim3(nblk(vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
                      (const long long*)tokens, E, out_tm, B, L, D, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("embed_fwd");
   return VLN_OK;
@@ -461,7 +462,7 @@ extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, cons
                              int L, int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p,
                              vln_stream_t s) {
   if (!tokens || !lengths || !dx_tm || !dE) { set_error("vln_embed_bwd: null pointer"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+  VLN_LAUNCH(embed_bwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
                      (const long long*)tokens, lengths, dx_tm, dE, B, L, D, (long)padding_idx, DropSpec{seed, offset, p});
   VLN_CHECK_LAUNCH("embed_bwd");
   return VLN_OK;
@@ -469,7 +470,7 @@ extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, cons
 extern "C" int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE, int B, int L,
                                  int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
   if (!tokens || !lengths || !dx_tm || !dE || V <= 0 || D <= 0 || D > 1024) { set_error("vln_embed_bwd_det: bad args (D <= 1024)"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(V), dim3(256), 0, (hipStream_t)s, (const long long*)tokens, lengths, dx_tm, dE, B, L,
+  VLN_LAUNCH(embed_bwd_det_kernel, dim3(V), dim3(256), 0, (hipStream_t)s, (const long long*)tokens, lengths, dx_tm, dE, B, L,
                      D, (long)padding_idx, DropSpec{seed, offset, p});
   VLN_CHECK_LAUNCH("embed_bwd_det");
   return VLN_OK;
@@ -478,7 +479,7 @@ extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, in
                             uint64_t offset, float p, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_tm_to_bm: null pointer"); return VLN_ERR_ARG; }
   const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm) | reinterpret_cast<uintptr_t>(bm_bf16)) & 15) == 0;
-  hipLaunchKernelGGL(tm_to_bm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
+  VLN_LAUNCH(tm_to_bm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
                      (bf16_raw*)bm_bf16, B, L, W, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("tm_to_bm");
   return VLN_OK;
@@ -487,7 +488,7 @@ extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uin
                             vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_bm_to_tm: null pointer"); return VLN_ERR_ARG; }
   const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm)) & 15) == 0;
-  hipLaunchKernelGGL(bm_to_tm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
+  VLN_LAUNCH(bm_to_tm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
                      L, W, DropSpec{seed, offset, p}, vec);
   VLN_CHECK_LAUNCH("bm_to_tm");
   return VLN_OK;
@@ -509,7 +510,7 @@ static int seed_initial_state(hipStream_t st, const float* h0, const float* c0, 
     for (int k = 0; k < 2; ++k) {
       if (src[k]) {
         int nb = (int)((blk + 255) / 256); if (nb > 1024) nb = 1024;
-        hipLaunchKernelGGL(copy_f32_kernel, dim3(nb), dim3(256), 0, st, src[k], dst[k], blk);
+        VLN_LAUNCH(copy_f32_kernel, dim3(nb), dim3(256), 0, st, src[k], dst[k], blk);
       } else {
         int r = fill_f32(st, dst[k], blk, 0.f); if (r) return r;
       }
@@ -532,8 +533,8 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
   for (int step = 0; step < L; ++step) {
     a.step = step;
     ProfScope prof(st, K_LSTM_REC_FWD, step_bytes);
-    if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_fwd_kernel<bf16_raw>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(lstm_rec_fwd_kernel<float>, grid, block, 0, st, a);
+    if (wtype == VLN_BF16) VLN_LAUNCH(lstm_rec_fwd_kernel<bf16_raw>, grid, block, 0, st, a);
+    else VLN_LAUNCH(lstm_rec_fwd_kernel<float>, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("lstm_rec_fwd");
   return VLN_OK;
@@ -579,7 +580,7 @@ static bool kernel_fits_one_per_cu(K kernel) {      // the occupancy API's answe
 // per-step chain.
 static unsigned* g_sticky_host = nullptr;       // pinned + mapped, one word per device (16 words apart)
 static unsigned* g_sticky_dev = nullptr;        // the same memory as the device sees it
-static unsigned* sticky_dev_word() {
+unsigned* vln::sticky_dev_word() {
   if (!g_sticky_host) {
     if (hipHostMalloc(reinterpret_cast<void**>(&g_sticky_host), 16 * 16 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&g_sticky_dev), g_sticky_host, 0) != hipSuccess) {
@@ -600,9 +601,11 @@ extern "C" int vln_persistent_check(void) {
     if (__atomic_load_n(&h[d * 16], __ATOMIC_RELAXED)) {
       const unsigned n = __atomic_exchange_n(&h[d * 16], 0u, __ATOMIC_RELAXED);
       g_persist_enabled = 0;
-      set_error("persistent LSTM recurrence: %u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (its "
-                "workgroups were not co-resident); that iteration's numbers are invalid.  The persistent path is now off for "
-                "this process (per-step launches)", n, d);
+      g_chain_mode = 0;
+      set_error("%u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (persistent LSTM recurrence: its "
+                "workgroups were not co-resident; or a chained step kernel: a producer stage never ran); that iteration's "
+                "numbers are invalid.  The persistent recurrence and the chained steps are now off for this process "
+                "(per-step / per-stage launches)", n, d);
       return VLN_ERR_HIP;
     }
   }
@@ -631,7 +634,7 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_fwd_kernel<TW, NS_>);                                    \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, counters, status, sticky, xm);                 \
+    VLN_LAUNCH((lstm_persist_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, counters, status, sticky, xm);                 \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -656,7 +659,7 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_>);                                    \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, sticky, exch, xm);           \
+    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, sticky, exch, xm);           \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -712,7 +715,7 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -737,7 +740,7 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_bwd_kernel<TW, NT_>);                                  \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    hipLaunchKernelGGL((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
+    VLN_LAUNCH((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -807,8 +810,8 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
     a.step = step;
     a.first = (step == L - 1);
     ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
-    if (wtype == VLN_BF16) hipLaunchKernelGGL(lstm_rec_bwd_kernel<bf16_raw>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(lstm_rec_bwd_kernel<float>, grid, block, 0, st, a);
+    if (wtype == VLN_BF16) VLN_LAUNCH(lstm_rec_bwd_kernel<bf16_raw>, grid, block, 0, st, a);
+    else VLN_LAUNCH(lstm_rec_bwd_kernel<float>, grid, block, 0, st, a);
   }
   VLN_CHECK_LAUNCH("lstm_rec_bwd");
   return VLN_OK;

@@ -14,6 +14,8 @@
 #include "vln_internal.h"
 #include "graph_cache.h"
 #include "envdrop_prep.h"
+#include "step_bodies.h"
+#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -22,42 +24,11 @@ __global__ __launch_bounds__(256) void envdrop_prep_kernel(PrepArgs p) {
   envdrop_prep_body(p, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
-struct PrepBwdArgs {
-  SlabVec dxcat; const float* e; SlabVec dhq;      // dxcat [B, AE+F+H] and dhq [B,H] may still lie in split-K slabs
-  float* s_de; float* dhtp;
-  int B, AE, F, H;
-  DropSpec d_act, d_h;
-};
 __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
-  const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ne + nh; i += (long)gridDim.x * blockDim.x) {
-    if (i < ne) {
-      const int b = (int)(i / p.AE), j = (int)(i % p.AE);
-      const float e = p.e[i];
-      const float de = p.dxcat.at(b, j) * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
-      p.s_de[i] = de * (1.f - e * e);
-    } else {
-      const long k = i - ne;
-      const int b = (int)(k / p.H), j = (int)(k % p.H);
-      p.dhtp[k] = p.dxcat.at(b, p.AE + p.F + j) +
-                  p.dhq.at(b, j) * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
-    }
-  }
+  envdrop_prep_bwd_body(p, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
-
-// dz = ((dhtd + dhtd2) * mask + dht_ext) * (1 - ht^2)      (dhtd [B,H] may still lie in split-K slabs; dhtd2 nullable:
-// the second consumer of the logits when the rollout-wide logit branch already covered the first)
-__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(SlabVec dhtd, const float* dhtd2, const float* dht_ext, const float* ht,
-                                                            float* dz, int B, int H, DropSpec d) {
-  const long n = (long)B * H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float gs = dhtd.at(i / H, i % H);
-    if (dhtd2) gs += dhtd2[i];
-    float g = gs * dropout_scale1(d.seed, d.off(), (uint32_t)i, d.p);
-    if (dht_ext) g += dht_ext[i];
-    const float h = ht[i];
-    dz[i] = g * (1.f - h * h);
-  }
+__global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(TanhDropBwdArgs a) {
+  tanh_drop_bwd_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 static inline int nblocks(long n, int cap = 2048) {
@@ -145,17 +116,29 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
               B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
               io->a_stash == io->a_prev ? nullptr : io->a_stash};
+  // Chained form (chain.h): the step's launches below are recorded as stages of ONE kernel.  Stage order = dispatch order;
+  // the gather is a stage nothing waits for until the visual attention needs its rows, so the query projection runs beside it.
+  ChainScope chain(st, g_chain_mode != 0);
+  const bool chained = chain_recording();
+  int gather_stage = kDepNone;
+  bool gather_pending = false;
+  GatherStepArgs ga{};
   if (io->g_table) {
     // (1)+(2) in ONE launch: the step gathers its own feature rows from the resident table (dropout sites 4 / 5 on the way)
     // and the prep work rides along as extra workgroups (features.hip)
-    GatherStepArgs ga{io->g_table, io->g_angle_table, (const long long*)io->g_rows, io->g_vidx, (const long long*)io->g_crows,
-                      io->g_cviews, io->g_chead, io->g_celev, lp ? nullptr : io->img, lp ? (bf16_raw*)io->img_lp : nullptr,
-                      lp ? nullptr : io->cand, lp ? (bf16_raw*)io->cand_lp : nullptr, B, d->V, d->C, d->IMG, d->ANG,
-                      site(io, 4, pf), site(io, 5, pf)};
+    ga = GatherStepArgs{io->g_table, io->g_angle_table, (const long long*)io->g_rows, io->g_vidx, (const long long*)io->g_crows,
+                        io->g_cviews, io->g_chead, io->g_celev, lp ? nullptr : io->img, lp ? (bf16_raw*)io->img_lp : nullptr,
+                        lp ? nullptr : io->cand, lp ? (bf16_raw*)io->cand_lp : nullptr, B, d->V, d->C, d->IMG, d->ANG,
+                        site(io, 4, pf), site(io, 5, pf)};
     if (!lp && (!io->img || !io->cand)) { set_error("envdrop fwd: gathered features need img / cand buffers"); return VLN_ERR_ARG; }
-    RUN(gather_step_prep(st, ga, io->g_ttype, pa));
+    const int ttype_w = io->g_ttype == VLN_BF16 ? W_BF16 : W_F32;
+    if (chained && ttype_w == d->wtype && ttype_w == d->ctype) {
+      chain_next(kDepNone, kDepNone, 0);
+      gather_pending = chain_prep(st, pa);
+    }
+    if (!gather_pending) RUN(gather_step_prep(st, ga, io->g_ttype, pa));
   } else {
-    hipLaunchKernelGGL(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
+    VLN_LAUNCH(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
     VLN_CHECK_LAUNCH("envdrop_prep");
     // (2) environmental feature dropout, in place                policy.py:226-231
     // (skipped entirely when the caller already dropped the features and filled the bf16 copies: vln_gather_*)
@@ -167,11 +150,23 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
   // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
+  // chain_next(main, pre, early): weights and the rollout-constant contexts are requested before the stage waits
   int n1 = 1, n2 = 1, n3 = 1;
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  const int vin_stage = chain_last();
+  if (gather_pending) {
+    chain_next(kDepNone, kDepNone, 0);
+    if (!chain_gather_step(st, ga, io->g_ttype)) { set_error("envdrop fwd: chained gather refused"); return VLN_ERR_ARG; }
+    gather_stage = chain_last();
+    chain_next(vin_stage, gather_stage, 1);
+  } else {
+    chain_next(kDepPrev, kDepNone, 1);
+  }
   RUN(attn_fwd_rows_sv(st, img, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, nullptr, 0, nullptr, io->alpha_v, io->xcat + AE, XK,
                        ws.dots, B, d->V, F));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   LstmPwFwd pw{};
   pw.gates = ws.s2; pw.nsplit = n2; pw.slab_stride = (long)B * 4 * H;
@@ -180,16 +175,20 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
   RUN(lstm_pointwise_fwd(st, pw));
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
                        ws.dots, B, d->L, H));
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
-  if (io->defer_logits) return VLN_OK;      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
+  if (io->defer_logits) return chain.finish();      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
-  return VLN_OK;
+  return chain.finish();
 }
 
 static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io,
@@ -202,6 +201,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
 
+  ChainScope chain(st, g_chain_mode != 0);
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
   SlabVec dhtd{ws.s3, H, 1, (long)B * H};
@@ -226,10 +226,15 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(fill_f32(st, ws.s3, (long)B * H, 0.f));
   }
   // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
-  hipLaunchKernelGGL(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, dhtd, dhtd2, g->dh_tilde,
-                     io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop));
-  VLN_CHECK_LAUNCH("tanh_drop_bwd");
+  {
+    const TanhDropBwdArgs ta{dhtd, dhtd2, g->dh_tilde, io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop)};
+    if (!chain_add(st, CK_TANH_DROP_BWD, nblocks((long)B * H), 1, 1, &ta, sizeof(ta), 0.0, -1)) {
+      VLN_LAUNCH(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ta);
+      VLN_CHECK_LAUNCH("tanh_drop_bwd");
+    }
+  }
   // (5') linear_out -> [d weighted ctx | d drop(h1)], still in slabs (s4)
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, nullptr, 0, B, 2 * H, H, nullptr, ACT_NONE, ws.s4, ws.n4, &n4));
   const SlabVec dtcat{ws.s4, 2 * H, n4, (long)B * 2 * H};
   // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
@@ -240,8 +245,10 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
     RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
   } else {
+    chain_next(kDepPrev, kDepNone, 1);
     RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
   }
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
   // (4') LSTM cell
   LstmPwBwd pb{};
@@ -250,17 +257,22 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
   RUN(lstm_pointwise_bwd(st, pb));
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
+  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
   PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
-  hipLaunchKernelGGL(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
-  VLN_CHECK_LAUNCH("envdrop_prep_bwd");
-  return VLN_OK;
+  if (!chain_add(st, CK_PREP_BWD, nblocks((long)B * (AE + H)), 1, 1, &pa, sizeof(pa), 0.0, -1)) {
+    VLN_LAUNCH(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
+    VLN_CHECK_LAUNCH("envdrop_prep_bwd");
+  }
+  return chain.finish();
 }
 
 
@@ -273,6 +285,7 @@ namespace {
 struct StepKey {
   vln_envdrop_dims d; vln_envdrop_weights w; vln_envdrop_step io; vln_envdrop_grads g; int bwd;
   int tun[8];          // the launch plan depends on the run-time tunables: a changed tunable never replays an old graph
+  int chain;           // ... and on whether the step is one chained kernel
 };
 }  // namespace
 
@@ -281,9 +294,10 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
+  RUN(chain_prime());
   if (!io->offset_dev && !io->offset_base_dev) return step_fwd_issue(st, d, w, io);
   if (!io->offset_base_dev) {
-    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
+    VLN_LAUNCH(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
                        (unsigned long long)io->offset);
     VLN_CHECK_LAUNCH("envdrop step offset");
   }
@@ -294,7 +308,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   key.d = *d; key.w = *w; key.io = *io; key.bwd = 0;
   if (!io->offset_base_dev) key.io.offset = 0;      // per-step word: the value is not a launch argument
   memset(&key.g, 0, sizeof(key.g));
-  memcpy(key.tun, g_tunable, sizeof(key.tun));
+  memcpy(key.tun, g_tunable, sizeof(key.tun)); key.chain = g_chain_mode;
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
 }
 
@@ -303,6 +317,7 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io || !g) { set_error("vln_envdrop_step_bwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
+  RUN(chain_prime());
   if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g);
   static StepKey key;
   static std::mutex mu;
@@ -310,6 +325,6 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.g = *g; key.bwd = 1;
   if (!io->offset_base_dev) key.io.offset = 0;
-  memcpy(key.tun, g_tunable, sizeof(key.tun));
+  memcpy(key.tun, g_tunable, sizeof(key.tun)); key.chain = g_chain_mode;
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
 }

@@ -7,6 +7,8 @@
 // optionally emits the bf16 copy the attention kernels stream.  16-byte accesses, one workgroup per output row.
 #include "vln_internal.h"
 #include "envdrop_prep.h"
+#include "gather_body.h"
+#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -76,88 +78,31 @@ __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, cons
   }
 }
 
-// ---- one launch per decoder step: panorama rows + candidate rows ------------------------------------------------
-// Same outputs, same Philox indexing as the two kernels above (so vln_dropout_mask exports the same masks); a thread
-// handles 8 consecutive elements (one 16-byte load from a bf16 table), a row of 2176 is one pass of 272 threads.
 template <typename TT>
-__device__ __forceinline__ void gather_step_row(const GatherStepArgs& a, int r) {
-  const int F = a.IMG + a.ANG, IMG = a.IMG;
-  const TT* table = reinterpret_cast<const TT*>(a.table);
-  const bool pano = r < a.B * a.V;
-  const TT* src; float* dst; bf16_raw* dlp; DropSpec dr;
-  const float* ang = nullptr;
-  float sh = 0.f, ch = 0.f, se = 0.f, ce = 0.f;
-  bool empty = false;
-  if (pano) {
-    const int b = r / a.V, v = r % a.V;
-    src = table + ((long)a.rows[b] * a.V + v) * IMG;
-    ang = a.angle_table + ((long)a.view_index[b] * a.V + v) * a.ANG;
-    dst = a.out ? a.out + (long)r * F : nullptr;
-    dlp = a.out_lp ? a.out_lp + (long)r * F : nullptr;
-    dr = a.dr_pano;
-  } else {
-    r -= a.B * a.V;
-    const long row = a.crows[r];
-    empty = row < 0;                      // STOP slot / padding: all-zero feature (base.py:152-153)
-    if (!empty) { sh = sinf(a.heading[r]); ch = cosf(a.heading[r]); se = sinf(a.elevation[r]); ce = cosf(a.elevation[r]); }
-    src = empty ? table : table + (row * a.V + a.cviews[r]) * IMG;
-    dst = a.cout ? a.cout + (long)r * F : nullptr;
-    dlp = a.cout_lp ? a.cout_lp + (long)r * F : nullptr;
-    dr = a.dr_cand;
-  }
-  const int q = a.ANG >> 2;
-  for (int c = threadIdx.x * 8; c < F; c += 256 * 8) {       // IMG % 8 == 0, ANG % 8 == 0: a group never straddles
-    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!empty) {
-      if (c < IMG) {
-        if constexpr (sizeof(TT) == 2) Elt<bf16_raw>::ld16(reinterpret_cast<const bf16_raw*>(src) + c, x);
-        else {
-          const float4 t0 = *reinterpret_cast<const float4*>(src + c), t1 = *reinterpret_cast<const float4*>(src + c + 4);
-          x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-        }
-        if (dr.p > 0.f) {
-          float m[4];
-          const uint32_t i4 = (uint32_t)(((long)r * IMG + c) >> 2);
-          dropout_scale4(dr.seed, dr.off(), i4, dr.p, m);
-          x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
-          dropout_scale4(dr.seed, dr.off(), i4 + 1, dr.p, m);
-          x[4] *= m[0]; x[5] *= m[1]; x[6] *= m[2]; x[7] *= m[3];
-        }
-      } else if (pano) {
-        const float4 t0 = *reinterpret_cast<const float4*>(ang + (c - IMG)), t1 = *reinterpret_cast<const float4*>(ang + (c - IMG) + 4);
-        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int g = (c - IMG + j) / q;
-          x[j] = g == 0 ? sh : (g == 1 ? ch : (g == 2 ? se : ce));
-        }
-      }
-    }
-    if (dst) {
-      *reinterpret_cast<float4*>(dst + c) = make_float4(x[0], x[1], x[2], x[3]);
-      *reinterpret_cast<float4*>(dst + c + 4) = make_float4(x[4], x[5], x[6], x[7]);
-    }
-    if (dlp) {
-      uint4 v;
-      v.x = (uint32_t)f32_to_bf16_bits(x[0]) | ((uint32_t)f32_to_bf16_bits(x[1]) << 16);
-      v.y = (uint32_t)f32_to_bf16_bits(x[2]) | ((uint32_t)f32_to_bf16_bits(x[3]) << 16);
-      v.z = (uint32_t)f32_to_bf16_bits(x[4]) | ((uint32_t)f32_to_bf16_bits(x[5]) << 16);
-      v.w = (uint32_t)f32_to_bf16_bits(x[6]) | ((uint32_t)f32_to_bf16_bits(x[7]) << 16);
-      *reinterpret_cast<uint4*>(dlp + c) = v;
-    }
-  }
-}
-template <typename TT>
-__global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) { gather_step_row<TT>(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) { gather_step_row<TT>(a, (int)blockIdx.x, (int)threadIdx.x); }
 
 // The same gather + the decoder step's prep work (act embedding, h_tilde_prev copy / dropout: envdrop_prep.h) as the LAST
 // `nprep` workgroups of the launch: both only depend on what the previous step left behind, and as two launches the second
 // one was ~6.5 us of pure dependent-launch latency per decoder step.
 template <typename TT>
 __global__ __launch_bounds__(256) void gather_step_prep_kernel(GatherStepArgs a, PrepArgs p, int nrows, int nprep) {
-  if ((int)blockIdx.x < nrows) gather_step_row<TT>(a, (int)blockIdx.x);
+  if ((int)blockIdx.x < nrows) gather_step_row<TT>(a, (int)blockIdx.x, (int)threadIdx.x);
   else envdrop_prep_body(p, (long)((int)blockIdx.x - nrows) * 256 + threadIdx.x, (long)nprep * 256);
+}
+
+// chained forms (chain.hip): false when no chain is being recorded
+bool chain_prep(hipStream_t st, const PrepArgs& p) {
+  long nb = (envdrop_prep_items(p) + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return chain_add(st, CK_PREP, (int)nb, 1, 1, &p, sizeof(p), 0.0, -1);
+}
+bool chain_gather_step(hipStream_t st, const GatherStepArgs& a, int ttype) {
+  if (!a.table || !a.angle_table || !a.rows || !a.view_index || !a.crows || !a.cviews || !a.heading || !a.elevation ||
+      (!a.out && !a.out_lp) || (!a.cout && !a.cout_lp) || a.B <= 0 || a.V <= 0 || a.C <= 0 || (a.IMG & 7) || (a.ANG & 7)) return false;
+  const int nrows = a.B * a.V + a.B * a.C;
+  const double bytes = (double)nrows * (a.IMG * (ttype == VLN_BF16 ? 2.0 : 4.0) + (a.IMG + a.ANG) * ((a.out ? 4.0 : 0.0) + (a.out_lp ? 2.0 : 0.0)));
+  return chain_add(st, CK_GATHER_STEP, nrows, 1, 1, &a, sizeof(a), bytes, ttype == VLN_BF16 ? W_BF16 : W_F32);
 }
 
 int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const PrepArgs& p) {
@@ -171,8 +116,10 @@ int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const P
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   const int nprep = (int)nb;
-  if (ttype == VLN_BF16) hipLaunchKernelGGL(gather_step_prep_kernel<bf16_raw>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
-  else hipLaunchKernelGGL(gather_step_prep_kernel<float>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  // chained step: the prep work is its own (first) stage and the gather a stage NOTHING waits for until the visual
+  // attention needs the rows -- the caller orders the stages (envdrop.hip)
+  if (ttype == VLN_BF16) VLN_LAUNCH(gather_step_prep_kernel<bf16_raw>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  else VLN_LAUNCH(gather_step_prep_kernel<float>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
   VLN_CHECK_LAUNCH("gather_step_prep");
   return VLN_OK;
 }
@@ -195,8 +142,8 @@ extern "C" int vln_gather_step(const void* table, int ttype, const float* angle_
                    out, (bf16_raw*)out_bf16, cout, (bf16_raw*)cout_bf16, B, V, C, IMG, ANG,
                    DropSpec{seed, offset_pano, p_feat}, DropSpec{seed, offset_cand, p_feat}};
   dim3 grid(B * V + B * C), block(256);
-  if (ttype == VLN_BF16) hipLaunchKernelGGL(gather_step_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
-  else hipLaunchKernelGGL(gather_step_kernel<float>, grid, block, 0, (hipStream_t)s, a);
+  if (ttype == VLN_BF16) VLN_LAUNCH(gather_step_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
+  else VLN_LAUNCH(gather_step_kernel<float>, grid, block, 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("gather_step");
   return VLN_OK;
 }
@@ -211,9 +158,9 @@ extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows
   dim3 grid(B * V), block(256);
   DropSpec dr{seed, offset, p_feat};
   if (ttype == VLN_BF16)
-    hipLaunchKernelGGL(gather_pano_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_pano_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
   else
-    hipLaunchKernelGGL(gather_pano_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_pano_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
   VLN_CHECK_LAUNCH("gather_pano");
   return VLN_OK;
 }
@@ -228,9 +175,9 @@ extern "C" int vln_gather_cands(const void* table, int ttype, const int64_t* row
   dim3 grid(BC), block(256);
   DropSpec dr{seed, offset, p_feat};
   if (ttype == VLN_BF16)
-    hipLaunchKernelGGL(gather_cands_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_cands_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
   else
-    hipLaunchKernelGGL(gather_cands_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_cands_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
   VLN_CHECK_LAUNCH("gather_cands");
   return VLN_OK;
 }

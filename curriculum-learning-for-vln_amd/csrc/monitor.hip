@@ -42,7 +42,7 @@ static int copy_blocks(hipStream_t st, const CopyJobs& j) {
   int blocks = (int)((most + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(copy_blocks_kernel, dim3(blocks), dim3(256), 0, st, j);
+  VLN_LAUNCH(copy_blocks_kernel, dim3(blocks), dim3(256), 0, st, j);
   VLN_CHECK_LAUNCH("copy_blocks");
   return VLN_OK;
 }

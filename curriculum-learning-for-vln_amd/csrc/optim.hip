@@ -149,13 +149,13 @@ static int opt_launch(int mode, float* params, float* grads, float* s1, float* s
     if (g < ngroups) blk += (int)((group_begin[g + 1] - group_begin[g] + kOptChunk - 1) / kOptChunk);
   }
   if (blk <= 0) return VLN_OK;
-  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(blk), dim3(kOptBlock), 0, st, grads, gr, partial);
+  VLN_LAUNCH(opt_sumsq_kernel, dim3(blk), dim3(kOptBlock), 0, st, grads, gr, partial);
   if (mode == OPT_RMSPROP)
-    hipLaunchKernelGGL(opt_step_kernel<OPT_RMSPROP>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+    VLN_LAUNCH(opt_step_kernel<OPT_RMSPROP>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
   else if (mode == OPT_ADAM)
-    hipLaunchKernelGGL(opt_step_kernel<OPT_ADAM>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+    VLN_LAUNCH(opt_step_kernel<OPT_ADAM>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
   else
-    hipLaunchKernelGGL(opt_step_kernel<OPT_SGD>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
+    VLN_LAUNCH(opt_step_kernel<OPT_SGD>, dim3(blk), dim3(kOptBlock), 0, st, params, grads, s1, s2, gr, partial, norms_out, h);
   VLN_CHECK_LAUNCH(what);
   return VLN_OK;
 }

@@ -2,6 +2,8 @@
 // applies the i,f,g,o nonlinearities and the state update in one pass), its backward, Philox dropout
 // helpers and the in-place environmental feature dropout (policy.py:226-231).
 #include "vln_internal.h"
+#include "step_bodies.h"
+#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -9,95 +11,31 @@ namespace vln {
 // ---------------------------------------------------------------------------
 // LSTM cell pointwise (torch.nn.LSTMCell semantics, gate order i,f,g,o)
 // ---------------------------------------------------------------------------
-// 256 threads = 64 (row, unit) pairs x 4 gates: each thread sums the split-K slabs of ONE gate (4 independent
-// load streams per wave instead of 4*nsplit dependent loads per thread), the gates meet in LDS.
-__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a) {
+__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(LstmPwFwd a, int iters) {
   __shared__ float sg[4][64];
-  const long total = (long)a.B * a.H;
-  const int H = a.H;
-  const int pl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
-    const long e = base + pl;
-    const bool ok = e < total;
-    const int b = ok ? (int)(e / H) : 0, j = ok ? (int)(e % H) : 0;
-    {
-      const int col = q * H + j;
-      float v0 = 0.f, v1 = 0.f;
-      if (ok) {
-        if (a.bias_a) v0 += a.bias_a[col];
-        if (a.bias_b) v1 += a.bias_b[col];
-        const float* gp = a.gates + (long)b * 4 * H + col;
-        int s = 0;
-        for (; s + 3 < a.nsplit; s += 4) {        // four partials in flight, two accumulation chains
-          const float t0 = gp[(long)s * a.slab_stride], t1 = gp[(long)(s + 1) * a.slab_stride];
-          const float t2 = gp[(long)(s + 2) * a.slab_stride], t3 = gp[(long)(s + 3) * a.slab_stride];
-          v0 += t0; v1 += t1; v0 += t2; v1 += t3;
-        }
-        for (; s + 1 < a.nsplit; s += 2) {
-          v0 += gp[(long)s * a.slab_stride];
-          v1 += gp[(long)(s + 1) * a.slab_stride];
-        }
-        if (s < a.nsplit) v0 += gp[(long)s * a.slab_stride];
-      }
-      sg[q][pl] = v0 + v1;
-    }
-    __syncthreads();
-    if (q != 0 || !ok) { __syncthreads(); continue; }
-    float g[4] = {sg[0][pl], sg[1][pl], sg[2][pl], sg[3][pl]};
-    const float si = sigmoidf_(g[0]), sf = sigmoidf_(g[1]), tg = tanhf(g[2]), so = sigmoidf_(g[3]);
-    const float c0 = a.c0[(long)b * a.ldc0 + j];
-    const float c1 = sf * c0 + si * tg;
-    const float tc = tanhf(c1);
-    const float h1 = so * tc;
-    a.h1[(long)b * a.ldh1 + j] = h1;
-    a.c1[(long)b * a.ldc1 + j] = c1;
-    if (a.act) {
-      float* p = a.act + (long)b * 4 * H + j;
-      p[0] = si; p[H] = sf; p[2 * H] = tg; p[3 * H] = so;
-    }
-    if (a.tanh_c1) a.tanh_c1[e] = tc;
-    if (a.h1_drop) a.h1_drop[(long)b * a.ldh1d + j] = h1 * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
-    __syncthreads();   // sg is rewritten by the next grid-stride iteration
-  }
+  lstm_pw_fwd_body(a, (int)blockIdx.x, (int)gridDim.x, iters, (int)threadIdx.x, sg);
 }
 int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a) {
   long total = (long)a.B * a.H;
-  int blocks = (int)((total + 63) / 64);
+  const long groups = (total + 63) / 64;
+  int blocks = (int)groups;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  const int iters = (int)((groups + blocks - 1) / blocks);
+  if (chain_add(st, CK_LSTM_PW_FWD, blocks, iters, 1, &a, sizeof(a), 0.0, -1)) return VLN_OK;
+  VLN_LAUNCH(lstm_pw_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, iters);
   VLN_CHECK_LAUNCH("lstm_pointwise_fwd");
   return VLN_OK;
 }
 
 __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(LstmPwBwd a) {
-  const long total = (long)a.B * a.H;
-  const int H = a.H;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(e / H), j = (int)(e % H);
-    float dh = a.dh1_a ? a.dh1_a[(long)b * a.ld_a + j] : 0.f;
-    if (a.dh1_b.p) {
-      float v = a.dh1_b.at(b, j);
-      if (a.dh1_b2.p) v += a.dh1_b2.at(b, j);
-      dh += v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
-    }
-    const float* act = a.act + (long)b * 4 * H + j;
-    const float si = act[0], sf = act[H], tg = act[2 * H], so = act[3 * H];
-    const float tc = a.tanh_c1[e];
-    const float c0 = a.c0[(long)b * a.ldc0 + j];
-    float dc = (a.dc1 ? a.dc1[(long)b * a.lddc1 + j] : 0.f) + dh * so * (1.f - tc * tc);
-    float* dg = a.dgates + (long)b * a.lddg + j;
-    dg[0] = dc * tg * si * (1.f - si);
-    dg[H] = dc * c0 * sf * (1.f - sf);
-    dg[2 * H] = dc * si * (1.f - tg * tg);
-    dg[3 * H] = dh * tc * so * (1.f - so);
-    a.dc0[(long)b * a.lddc0 + j] = dc * sf;
-  }
+  lstm_pw_bwd_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 int lstm_pointwise_bwd(hipStream_t st, const LstmPwBwd& a) {
   long total = (long)a.B * a.H;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (chain_add(st, CK_LSTM_PW_BWD, blocks, 1, 1, &a, sizeof(a), 0.0, -1)) return VLN_OK;
+  VLN_LAUNCH(lstm_pw_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("lstm_pointwise_bwd");
   return VLN_OK;
 }
@@ -118,7 +56,7 @@ int scale_dropout(hipStream_t st, const float* x, long ldx, float* y, long ldy, 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(scale_dropout_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, rows, cols, d);
+  VLN_LAUNCH(scale_dropout_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, rows, cols, d);
   VLN_CHECK_LAUNCH("scale_dropout");
   return VLN_OK;
 }
@@ -131,7 +69,7 @@ int export_dropout_mask(hipStream_t st, float* out, long n, DropSpec d) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(export_mask_kernel, dim3(blocks), dim3(256), 0, st, out, n, d);
+  VLN_LAUNCH(export_mask_kernel, dim3(blocks), dim3(256), 0, st, out, n, d);
   VLN_CHECK_LAUNCH("export_dropout_mask");
   return VLN_OK;
 }
@@ -143,7 +81,7 @@ int fill_f32(hipStream_t st, float* p, long n, float v) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+  VLN_LAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
   VLN_CHECK_LAUNCH("fill_f32");
   return VLN_OK;
 }
@@ -161,7 +99,7 @@ int add_inplace(hipStream_t st, float* y, long ldy, const float* x, long ldx, in
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, y, ldy, x, ldx, rows, cols);
+  VLN_LAUNCH(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, y, ldy, x, ldx, rows, cols);
   VLN_CHECK_LAUNCH("add_inplace");
   return VLN_OK;
 }
@@ -205,9 +143,9 @@ int feat_dropout_inplace(hipStream_t st, void* x, int xtype, long rows, int img,
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (xtype == W_BF16)
-    hipLaunchKernelGGL(feat_dropout_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (bf16_raw*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
+    VLN_LAUNCH(feat_dropout_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (bf16_raw*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
   else
-    hipLaunchKernelGGL(feat_dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
+    VLN_LAUNCH(feat_dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)x, rows, img, angle, d, (bf16_raw*)copy_bf16);
   VLN_CHECK_LAUNCH("feat_dropout");
   return VLN_OK;
 }
@@ -496,7 +434,7 @@ extern "C" int vln_a2c_loss_fwd(const float* logp, const float* ent, const float
     vln::set_error("vln_a2c_loss_fwd: bad args");
     return VLN_ERR_ARG;
   }
-  hipLaunchKernelGGL(vln::a2c_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logp, ent, val, reward, mask, last_value, ended, T, B,
+  VLN_LAUNCH(vln::a2c_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, logp, ent, val, reward, mask, last_value, ended, T, B,
                      gamma, ent_coef, loss_b, dlogp, dval, dent, total);
   VLN_CHECK_LAUNCH("a2c_loss_fwd");
   return VLN_OK;
@@ -507,7 +445,7 @@ extern "C" int vln_a2c_loss_bwd(const float* dloss_b, int64_t dloss_stride, cons
   long n = (long)T * B;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(vln::a2c_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dloss_b, (long)dloss_stride, dlogp, dval, dent, T,
+  VLN_LAUNCH(vln::a2c_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, dloss_b, (long)dloss_stride, dlogp, dval, dent, T,
                      B, glogp, gval, gent);
   VLN_CHECK_LAUNCH("a2c_loss_bwd");
   return VLN_OK;
@@ -768,7 +706,7 @@ extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_
     return VLN_ERR_ARG;
   }
   if (C > 64) { vln::set_error("vln_categorical_fwd: at most 64 candidates"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(vln::categorical_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
+  VLN_LAUNCH(vln::categorical_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
                      (const long long*)action_in, (long long*)action_out, probs, logp, entropy, B, C, seed, offset);
   VLN_CHECK_LAUNCH("categorical_fwd");
   return VLN_OK;
@@ -776,7 +714,7 @@ extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_
 extern "C" int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp, const float* dent, float* dlogits,
                                    int B, int C, void* s) {
   if (!probs || !action || !dlogits || B <= 0 || C <= 0) { vln::set_error("vln_categorical_bwd: bad args"); return VLN_ERR_ARG; }
-  hipLaunchKernelGGL(vln::categorical_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, probs,
+  VLN_LAUNCH(vln::categorical_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, probs,
                      (const long long*)action, dlogp, dent, dlogits, B, C);
   VLN_CHECK_LAUNCH("categorical_bwd");
   return VLN_OK;
@@ -864,7 +802,7 @@ extern "C" int vln_pe_dropout(const float* ctx, const float* pe, float* out, int
   long t4 = (long)B * L * H / 4;
   int blocks = (int)((t4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(vln::pe_dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, ctx, pe, out, B, L, H, DropSpec{seed, offset, p});
+  VLN_LAUNCH(vln::pe_dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, ctx, pe, out, B, L, H, DropSpec{seed, offset, p});
   VLN_CHECK_LAUNCH("pe_dropout");
   return VLN_OK;
 }
@@ -874,7 +812,7 @@ extern "C" int vln_monitor_head_fwd(const float* mg, const float* c1, const floa
   vln::MonHeadArgs a{};
   a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.bc = bc; a.mem = mem; a.prog = prog; a.B = B; a.L = L; a.H = H;
   a.dr = DropSpec{seed, offset, p};
-  hipLaunchKernelGGL(vln::monitor_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  VLN_LAUNCH(vln::monitor_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("monitor_head_fwd");
   return VLN_OK;
 }
@@ -890,7 +828,7 @@ extern "C" int vln_monitor_head_bwd(const float* mg, const float* c1, const floa
   a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.mem = const_cast<float*>(mem); a.prog = const_cast<float*>(prog);
   a.B = B; a.L = L; a.H = H; a.dr = DropSpec{seed, offset, p};
   a.dprog = dprog; a.dc1_ext = dc1_ext; a.dww_ext = dww_ext; a.dmg = dmg; a.dc1 = dc1; a.dww = dww; a.Z = Z; a.dpre = dpre;
-  hipLaunchKernelGGL(vln::monitor_head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  VLN_LAUNCH(vln::monitor_head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("monitor_head_bwd");
   return VLN_OK;
 }
@@ -905,7 +843,7 @@ extern "C" int vln_add_n(float* out, int64_t ldo, int rows, int cols, const floa
   long total = (long)rows * cols;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(vln::add_n_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, a);
+  VLN_LAUNCH(vln::add_n_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("add_n");
   return VLN_OK;
 }
@@ -951,7 +889,7 @@ extern "C" int vln_ew(int op, const float* a, int64_t lda, const float* b, int64
     return VLN_ERR_ARG;
   }
   vln::EwArgs e{a, (long)lda, b, (long)ldb, nb, y, (long)ldy, rows, cols, op};
-  hipLaunchKernelGGL(vln::ew_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, e);
+  VLN_LAUNCH(vln::ew_kernel, dim3(rows), dim3(256), 0, (hipStream_t)s, e);
   VLN_CHECK_LAUNCH("ew");
   return VLN_OK;
 }
@@ -968,7 +906,7 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
   }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
            R, D, eps, momentum, training, relu, DropSpec{seed, offset, p_drop}, row_zero};
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
+  VLN_LAUNCH(bn_fwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_fwd");
   return VLN_OK;
 }
@@ -984,7 +922,7 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
   }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
               training, relu, accumulate, DropSpec{seed, offset, p_drop}, row_zero};
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
+  VLN_LAUNCH(bn_bwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_bwd");
   return VLN_OK;
 }
@@ -995,8 +933,8 @@ extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* targe
   if (!logits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_fwd: bad args"); return VLN_ERR_ARG; }
   vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, loss, probs, (const long long*)action, logp, entropy,
                 B, C, (long)ignore_index, write_mask};
-  if (loss_sum) hipLaunchKernelGGL(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, loss_sum);
-  else hipLaunchKernelGGL(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
+  if (loss_sum) VLN_LAUNCH(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, loss_sum);
+  else VLN_LAUNCH(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("masked_ce_fwd");
   return VLN_OK;
 }
@@ -1006,7 +944,7 @@ extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, cons
   long total = (long)B * C;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
+  VLN_LAUNCH(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
                      dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index);
   VLN_CHECK_LAUNCH("masked_ce_bwd");
   return VLN_OK;
@@ -1030,9 +968,9 @@ extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, i
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, false, "vln_masked_ce_multi_fwd: bad args");
   if (rc) return rc;
   if (loss_sum)
-    hipLaunchKernelGGL(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
+    VLN_LAUNCH(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
   else
-    hipLaunchKernelGGL(vln::masked_ce_multi_rows_kernel, dim3((B + 63) / 64), dim3(256), 0, (hipStream_t)s, m, loss_rows, accumulate,
+    VLN_LAUNCH(vln::masked_ce_multi_rows_kernel, dim3((B + 63) / 64), dim3(256), 0, (hipStream_t)s, m, loss_rows, accumulate,
                        scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_fwd");
   return VLN_OK;
@@ -1043,7 +981,7 @@ extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, i
   if (!dloss || (dloss_stride != 0 && dloss_stride != 1)) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, true, "vln_masked_ce_multi_bwd: bad args");
   if (rc) return rc;
-  hipLaunchKernelGGL(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, (int)dloss_stride, scale);
+  VLN_LAUNCH(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, (int)dloss_stride, scale);
   VLN_CHECK_LAUNCH("masked_ce_multi_bwd");
   return VLN_OK;
 }

@@ -417,6 +417,13 @@ int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = pe
  * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as
  * VLN_ERR_HIP (the affected iteration's numbers are invalid) and switches the process to per-step launches. */
 int vln_persistent_check(void);
+/* Chained decoder steps (csrc/chain.h), an A/B switch: 1 = the dependent launches of a decoder step (EnvDrop: policy.py:208-246
+ * and its backward) are issued as ONE kernel whose stages hand over through agent-scope completion flags; 0 (default) = one
+ * launch per stage, which is the faster form on MI355X (csrc/chain.h has the measurements).  Identical results (the stages
+ * run the same workgroup bodies).  A bounded wait that times out is reported by vln_persistent_check and switches the
+ * process to mode 0. */
+int vln_set_chain(int mode);
+int vln_get_chain(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered */
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
