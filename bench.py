@@ -200,6 +200,7 @@ class GpuAgent:
         # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
         self.side = torch.cuda.Stream(device=dev) if side_gather else None
         self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
+        self._gen_done, self._iter_no, self.prefetch_under_backward = [None, None], 0, True
         # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
         # instead of a separate store.gather_step launch in front of every step
         self.fused_gather = bool(fused_gather) and not side_gather
@@ -293,8 +294,16 @@ class GpuAgent:
         B = tape["B"]
         if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
             self.side.wait_stream(torch.cuda.current_stream())
-        if self.copy_stream is not None and self.arena is not None:     # same fence for the H2D copy stream (host features)
-            self.copy_stream.wait_stream(torch.cuda.current_stream())
+        if self.copy_stream is not None and self.arena is not None:
+            # Fence for the H2D copy stream (host features).  The arena alternates between two buffer generations, so this
+            # iteration's staging buffers were last read TWO iterations ago: the copies only wait for the end of that
+            # iteration and run under the previous iteration's backward (the link is busy for the whole iteration instead
+            # of the forward only: 'streamed to HBM overlapped with backward', north star / base.py:141-157).
+            ev = self._gen_done[self._iter_no & 1]
+            if ev is not None and self.prefetch_under_backward:
+                self.copy_stream.wait_event(ev)
+            else:
+                self.copy_stream.wait_stream(torch.cuda.current_stream())
             self._copy_fenced = True
         self.opt.zero_grad()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
@@ -320,6 +329,12 @@ class GpuAgent:
         self.opt.allreduce()
         # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
         self.opt.step(zero_grads=self.clear_grads_in_step)
+        if self.copy_stream is not None and self.arena is not None:
+            g = self._iter_no & 1
+            if self._gen_done[g] is None:
+                self._gen_done[g] = torch.cuda.Event()
+            self._gen_done[g].record()                          # this generation's buffers are free again from here
+        self._iter_no += 1
         return loss
 
 
@@ -444,6 +459,9 @@ def main():
     ap.add_argument("--wgrad", default="bf16", choices=["split", "bf16"],
                     help="bf16 mode: weight gradients from split-bf16 operands (three MFMAs per product, fp32-grade) or from plain "
                          "bf16 operands (one MFMA, mixed-precision standard)")
+    ap.add_argument("--no-backward-prefetch", action="store_true",
+                    help="host features A/B: the H2D copies of an iteration wait for the END of the previous iteration (forward-only "
+                         "overlap, round 1) instead of the end of the one before it (they then run under the previous backward)")
     ap.add_argument("--chain", action="store_true",
                     help="A/B: the decoder steps as chained kernels (csrc/chain.h: measured slower, 2.64 vs 1.80 ms) instead of one launch per stage")
     ap.add_argument("--separate-gather", action="store_true",
@@ -502,6 +520,7 @@ def main():
     agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
                      side_gather=args.gather_stream == "side" and args.features == "store", fused_gather=not args.separate_gather)
     agent.clear_grads_in_step = True
+    agent.prefetch_under_backward = not args.no_backward_prefetch
     # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
     # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
     # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.

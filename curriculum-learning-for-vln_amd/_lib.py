@@ -167,6 +167,8 @@ SIGNATURES = {
     "vln_monitor_head_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_ew": (i32, [i32, ptr, i64, ptr, i64, i32, ptr, i64, i32, i32, ptr]),
     "vln_add_n": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i32, ptr]),
+    "vln_monitor_loss_fwd": (i32, [ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, f32, i32, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
+    "vln_monitor_loss_bwd": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, f32, i32, ptr, ptr, i32, i32, i64, ptr]),
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr]),

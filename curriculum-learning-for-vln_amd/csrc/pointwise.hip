@@ -310,6 +310,77 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* probs, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Self-Monitor step loss (monitor.py:146-165) in one launch each way: the action CE, the progress target built from the
+// distances (monitor.py:155-157: (start - cur) / start, 1 within 3 m of the goal, the prediction itself for ended
+// episodes -- read on the device, the reference pulls cur_prog_val to the host every step for this), the MSE and the mix
+//   t == 0: CE          t > 0: lam * MSE + (1 - lam) * CE
+// with nn.CrossEntropyLoss(ignore_index) / nn.MSELoss() means (non-curriculum) or per-episode terms (reduction="none",
+// the curriculum criteria).  One workgroup, one thread per episode, fixed-order block sums.
+// ---------------------------------------------------------------------------
+struct MonLossArgs {
+  CeArgs ce;                                   // logits / target / mask / probs (loss, action, logp, entropy unused)
+  const float* progress; long ldp;             // [B] cur_prog_val
+  const float* start_dist; const float* cur_dist; const unsigned char* ended;
+  float* prog_target;                          // [B] out, kept for backward
+  float* out;                                  // per_sample: [B], else [1]
+  float* stats;                                // [2]: mean progress MSE (the agent's progress_loss record), #rows with a target
+  int t; float lam; int per_sample;
+};
+__global__ __launch_bounds__(256) void monitor_loss_fwd_kernel(MonLossArgs m) {
+  __shared__ float p_ce[4], p_sq[4], p_n[4];
+  const int B = m.ce.B;
+  float ce_acc = 0.f, sq_acc = 0.f, n_acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float l = (m.ce.C <= 16) ? ce_row_regs(m.ce, b) : ce_row_serial(m.ce, b);
+    const float p = m.progress[(long)b * m.ldp];
+    const float sd = m.start_dist[b], cd = m.cur_dist[b];
+    float pt = (sd - cd) / sd;
+    if (cd <= 3.0f) pt = 1.0f;
+    if (m.ended[b]) pt = p;
+    m.prog_target[b] = pt;
+    const float sq = (p - pt) * (p - pt);
+    if (m.per_sample) m.out[b] = (m.t == 0) ? l : m.lam * sq + (1.f - m.lam) * l;
+    ce_acc += l; sq_acc += sq;
+    n_acc += (m.ce.target[b] != m.ce.ignore_index) ? 1.f : 0.f;
+  }
+  ce_acc = wave_sum(ce_acc); sq_acc = wave_sum(sq_acc); n_acc = wave_sum(n_acc);
+  if ((threadIdx.x & 63) == 0) { p_ce[threadIdx.x >> 6] = ce_acc; p_sq[threadIdx.x >> 6] = sq_acc; p_n[threadIdx.x >> 6] = n_acc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float ce = (p_ce[0] + p_ce[1]) + (p_ce[2] + p_ce[3]);
+    const float sq = (p_sq[0] + p_sq[1]) + (p_sq[2] + p_sq[3]);
+    const float n = (p_n[0] + p_n[1]) + (p_n[2] + p_n[3]);
+    const float mse = sq / (float)B;
+    m.stats[0] = mse; m.stats[1] = n;
+    if (!m.per_sample) {
+      const float cem = ce / n;                          // mean over the rows that have a target (0/0 = nan like torch)
+      m.out[0] = (m.t == 0) ? cem : m.lam * mse + (1.f - m.lam) * cem;
+    }
+  }
+}
+struct MonLossBwdArgs {
+  const float* probs; const long long* target; const float* progress; long ldp; const float* prog_target; const float* stats;
+  const float* dloss; long dloss_stride;       // [1] (stride 0) or [B]
+  float* dlogits; float* dprogress;            // [B,C], [B]
+  int B, C, t; float lam; int per_sample; long ignore_index;
+};
+__global__ __launch_bounds__(256) void monitor_loss_bwd_kernel(MonLossBwdArgs m) {
+  const long total = (long)m.B * m.C;
+  const float wce = (m.t == 0 ? 1.f : 1.f - m.lam) * (m.per_sample ? 1.f : 1.f / m.stats[1]);
+  const float wsq = (m.t == 0 ? 0.f : m.lam * 2.f) * (m.per_sample ? 1.f : 1.f / (float)m.B);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + m.B; e += (long)gridDim.x * blockDim.x) {
+    if (e < total) {
+      const int b = (int)(e / m.C), c = (int)(e % m.C);
+      const long tg = m.target[b];
+      m.dlogits[e] = (tg == m.ignore_index) ? 0.f : m.dloss[b * m.dloss_stride] * wce * (m.probs[e] - (c == tg ? 1.f : 0.f));
+    } else {
+      const int b = (int)(e - total);
+      m.dprogress[b] = m.dloss[b * m.dloss_stride] * wsq * (m.progress[(long)b * m.ldp] - m.prog_target[b]);
+    }
+  }
+}
+
 // The IL loss of a whole rollout, ml_loss = sum_t CE_t (envdrop.py:178-179), in ONE launch after the last decoder step
 // instead of one per step: nothing on the rollout's dependent chain needs the loss, so the T small launches (and the T
 // backward ones) only lengthen it.  One workgroup; thread per (step, episode) row; rows of <= 16 candidates in registers.
@@ -947,6 +1018,41 @@ extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, cons
   VLN_LAUNCH(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
                      dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index);
   VLN_CHECK_LAUNCH("masked_ce_bwd");
+  return VLN_OK;
+}
+
+extern "C" int vln_monitor_loss_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, const float* progress,
+                                    int64_t ldp, const float* start_dist, const float* cur_dist, const uint8_t* ended, int t,
+                                    float lam, int per_sample, float* probs, float* prog_target, float* out, float* stats, int B,
+                                    int C, int64_t ignore_index, void* s) {
+  if (!logits || !target || !progress || !start_dist || !cur_dist || !ended || !probs || !prog_target || !out || !stats || B <= 0 ||
+      C <= 0 || ld < C || t < 0) {
+    vln::set_error("vln_monitor_loss_fwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  vln::MonLossArgs m{};
+  m.ce = vln::CeArgs{logits, (long)ld, (const long long*)target, cand_mask, nullptr, probs, nullptr, nullptr, nullptr, B, C,
+                     (long)ignore_index, 0};
+  m.progress = progress; m.ldp = (long)ldp; m.start_dist = start_dist; m.cur_dist = cur_dist; m.ended = ended;
+  m.prog_target = prog_target; m.out = out; m.stats = stats; m.t = t; m.lam = lam; m.per_sample = per_sample;
+  VLN_LAUNCH(vln::monitor_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("monitor_loss_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_monitor_loss_bwd(const float* probs, const int64_t* target, const float* progress, int64_t ldp,
+                                    const float* prog_target, const float* stats, const float* dloss, int64_t dloss_stride, int t,
+                                    float lam, int per_sample, float* dlogits, float* dprogress, int B, int C,
+                                    int64_t ignore_index, void* s) {
+  if (!probs || !target || !progress || !prog_target || !stats || !dloss || !dlogits || !dprogress || B <= 0 || C <= 0) {
+    vln::set_error("vln_monitor_loss_bwd: bad args");
+    return VLN_ERR_ARG;
+  }
+  vln::MonLossBwdArgs m{probs, (const long long*)target, progress, (long)ldp, prog_target, stats, dloss, (long)dloss_stride,
+                        dlogits, dprogress, B, C, t, lam, per_sample, (long)ignore_index};
+  int blocks = (int)(((long)B * (C + 1) + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  VLN_LAUNCH(vln::monitor_loss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("monitor_loss_bwd");
   return VLN_OK;
 }
 

@@ -95,6 +95,75 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
     return total / (target != ignore_index).sum().to(total.dtype)
 
 
+class _MonitorLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, progress, target, cand_mask, start_dist, cur_dist, ended, t, lam, per_sample, ignore_index):
+        B, C = logits.shape
+        dev = logits.device
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        pr = progress.detach().reshape(B)
+        if not pr.is_contiguous():
+            pr = pr.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        probs = ops.empty(B, C, **f32)
+        pt = ops.empty(B, **f32)
+        out = ops.empty(B, **f32) if per_sample else ops.empty((), **f32)
+        stats = ops.empty(2, **f32)
+        tgt = target if target.is_contiguous() else target.contiguous()
+        st = _lib.load().vln_monitor_loss_fwd(lg.data_ptr(), lg.stride(0), tgt.data_ptr(), _p(_mask8(cand_mask)), pr.data_ptr(), 1,
+                                              start_dist.data_ptr(), cur_dist.data_ptr(), _mask8(ended).data_ptr(), int(t), float(lam),
+                                              int(per_sample), probs.data_ptr(), pt.data_ptr(), out.data_ptr(), stats.data_ptr(), B, C,
+                                              ignore_index, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_monitor_loss_fwd")
+        ctx.save_for_backward(probs, tgt, pr, pt, stats)
+        ctx.meta = (int(t), float(lam), int(per_sample), ignore_index, progress.shape)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        probs, tgt, pr, pt, stats = ctx.saved_tensors
+        t, lam, per_sample, ignore_index, pshape = ctx.meta
+        B, C = probs.shape
+        dl = ops.empty_like(probs)
+        dp = ops.empty(B, dtype=torch.float32, device=probs.device)
+        if per_sample and dloss.dim() > 0 and dloss.stride(0) != 0:
+            stride = 1
+            if not dloss.is_contiguous():
+                dloss = dloss.contiguous()
+        else:
+            stride = 0
+        st = _lib.load().vln_monitor_loss_bwd(probs.data_ptr(), tgt.data_ptr(), pr.data_ptr(), 1, pt.data_ptr(), stats.data_ptr(),
+                                              dloss.data_ptr(), stride, t, lam, per_sample, dl.data_ptr(), dp.data_ptr(), B, C,
+                                              ignore_index, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_monitor_loss_bwd")
+        return dl, dp.view(pshape), None, None, None, None, None, None, None, None, None
+
+
+def monitor_mixed_loss(logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor], progress: torch.Tensor,
+                       start_dist: torch.Tensor, cur_dist: torch.Tensor, ended: torch.Tensor, t: int, lam: float,
+                       per_sample: bool = False, ignore_index: int = -1):
+    """The Self-Monitor agent's step loss (monitor.py:146-165) as ONE launch each way:
+
+        cur_action_loss = CrossEntropyLoss(ignore_index)(logits.masked_fill(cand_mask, -inf), target)
+        prog_target = (start_dist - cur_dist) / start_dist;  = 1 where cur_dist <= 3;  = cur_prog_val (detached) where ended
+        cur_loss = cur_action_loss                                         (t == 0)
+                 = lam * MSELoss()(cur_prog_val, prog_target) + (1 - lam) * cur_action_loss      (t > 0)
+
+    `per_sample` = the curriculum criteria (reduction="none", monitor.py:151,162): a [B] loss.  start_dist / cur_dist are [B]
+    float32 DEVICE tensors and `ended` a [B] bool/uint8 device tensor: the progress target is formed on the device, where the
+    reference copies cur_prog_val to the host every step (monitor.py:157) to build it in numpy.
+    Returns (loss, progress_mse): progress_mse = the mean MSE the agent logs as `progress_loss` (0-dim, no gradient;
+    meaningless at t == 0, where the reference does not compute it)."""
+    _not_deferred(logits, "monitor_mixed_loss")
+    loss, stats = _MonitorLoss.apply(logits, progress, target, cand_mask, start_dist, cur_dist, ended, t, lam, per_sample, ignore_index)
+    return loss, stats[0]
+
+
 class _RolloutCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *logits):

@@ -216,6 +216,21 @@ int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t igno
 int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
                             int64_t dloss_stride, vln_stream_t s);
 
+/* The Self-Monitor agent's step loss (monitor.py:146-165) in one launch each way, no host round trip: action CE on the masked
+ * logits, the progress target from the distances (monitor.py:155-157: (start_dist - cur_dist) / start_dist, 1 where
+ * cur_dist <= 3, the prediction itself where `ended`), MSE(progress, target), and the mix: t == 0 -> CE, t > 0 ->
+ * lam * MSE + (1 - lam) * CE.  per_sample 0: nn.CrossEntropyLoss(ignore_index) / nn.MSELoss() means, out [1];
+ * per_sample 1: reduction="none" terms (the curriculum criteria, monitor.py:151,162), out [B].
+ * stats [2] = {mean progress MSE (what the agent logs as progress_loss), number of rows with a target}. */
+int vln_monitor_loss_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask /*nullable*/,
+                         const float* progress, int64_t ldp, const float* start_dist, const float* cur_dist, const uint8_t* ended,
+                         int t, float lam, int per_sample, float* probs /*[B,C] out*/, float* prog_target /*[B] out*/,
+                         float* out, float* stats, int B, int C, int64_t ignore_index, vln_stream_t s);
+int vln_monitor_loss_bwd(const float* probs, const int64_t* target, const float* progress, int64_t ldp, const float* prog_target,
+                         const float* stats, const float* dloss, int64_t dloss_stride /*0: one scalar, 1: per episode*/, int t,
+                         float lam, int per_sample, float* dlogits /*[B,C]*/, float* dprogress /*[B]*/, int B, int C,
+                         int64_t ignore_index, vln_stream_t s);
+
 /* The sampled-action branch of a rollout step (envdrop.py:186-195) as one launch: probs = softmax(logits masked with
  * -inf where cand_mask), action ~ Categorical(probs) unless action_in is given (then action_out may be NULL), logp =
  * log pi(action) and the entropy with torch.distributions' clamp_probs.  The draw uses the Philox word (seed, offset, b).

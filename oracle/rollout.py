@@ -256,6 +256,11 @@ class FollowerModules:
 
 
 class MonitorModules(FollowerModules):
+    def __init__(self, enc, dec, device, mixed_loss=None):
+        super().__init__(enc, dec, device)
+        if mixed_loss is not None:
+            self.mixed_loss = mixed_loss      # optional replacement of the step-loss sequence (losses.monitor_mixed_loss on the HIP path)
+
     def decode(self, a_prev, cand, h, c, ctx, mask, cmask):
         (logit, prog), (h1, c1), _ = self.dec(None, a_prev, cand, h, c, ctx, mask, cmask)
         return logit, prog, h1, c1
@@ -331,16 +336,26 @@ def monitor_rollout(be, env, feedback: str, episode_len: int, lamb: float = 0.5,
     for t in range(episode_len):
         _, _, cand, cl = marshal_step(obs, dev)
         cmask = O.length2mask(cl).to(dev)
-        logit, prog, h_t, c_t = be.decode(a_prev, cand, h_t, c_t, ctx, seq_mask, cmask)
-        logit = logit.masked_fill(cmask, -float("inf"))
+        raw_logit, prog, h_t, c_t = be.decode(a_prev, cand, h_t, c_t, ctx, seq_mask, cmask)
+        logit = raw_logit.masked_fill(cmask, -float("inf"))
         target = torch.from_numpy(teacher_action(obs, ended)).to(dev)
-        pt = (start - cur) / start                                            # monitor.py:154-157
-        pt[cur <= 3.0] = 1.0
-        pt[ended] = prog.detach().cpu().numpy()[ended]
-        pt_t = torch.from_numpy(pt.astype(np.float32)).to(dev).to(prog.dtype)
-        if t > 0:
-            prog_log += float(torch.mean((prog.detach() - pt_t) ** 2))
-        ml = ml + O.monitor_mixed_loss(logit, target, None, prog, pt_t, t, lamb)
+        fused = getattr(be, "mixed_loss", None)
+        if fused is not None:
+            # the backend's own step loss (losses.monitor_mixed_loss on the HIP path): raw logits + mask + distances in, the
+            # progress target is built on the device
+            loss_t, pmse = fused(raw_logit, target, cmask, prog, torch.from_numpy(start).to(dev), torch.from_numpy(cur.copy()).to(dev),
+                                 torch.from_numpy(ended.copy()).to(dev), t, lamb)
+            if t > 0:
+                prog_log += float(pmse)
+            ml = ml + loss_t
+        else:
+            pt = (start - cur) / start                                            # monitor.py:154-157
+            pt[cur <= 3.0] = 1.0
+            pt[ended] = prog.detach().cpu().numpy()[ended]
+            pt_t = torch.from_numpy(pt.astype(np.float32)).to(dev).to(prog.dtype)
+            if t > 0:
+                prog_log += float(torch.mean((prog.detach() - pt_t) ** 2))
+            ml = ml + O.monitor_mixed_loss(logit, target, None, prog, pt_t, t, lamb)
         a_t = _select(feedback, logit, target, obs, inject_actions, t, dev)
         cpu_a = _post(a_t, obs, ended)
         acts.append(cpu_a.copy())

@@ -80,8 +80,10 @@ def run_monitor(B=128, L=80, T=7, C=8):
         cmask = torch.arange(C)[None, :] >= ncand[:, None]
         cand = cand * (~cmask)[..., None]
         tgt = (torch.rand(B, generator=g) * ncand.float()).long()
-        prog_t = torch.rand(B, generator=g)
-        steps.append(dict(cand=cand.to(dev), cmask=cmask.to(dev), target=tgt.to(dev), prog=prog_t.to(dev)))
+        start = torch.rand(B, generator=g) * 15 + 4
+        cur = (start - torch.rand(B, generator=g) * start).clamp_min(0.2)
+        steps.append(dict(cand=cand.to(dev), cmask=cmask.to(dev), target=tgt.to(dev), start=start.to(dev), cur=cur.to(dev),
+                          ended=(torch.rand(B, generator=g) < 0.1 * t).to(dev)))
 
     def it():
         opt.zero_grad()
@@ -90,8 +92,9 @@ def run_monitor(B=128, L=80, T=7, C=8):
         loss = 0.0
         for t, s in enumerate(steps):
             (logit, prog), (h, c), _ = dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
-            ce = vln.losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
-            loss = loss + (ce if t == 0 else 0.5 * torch.mean((prog - s["prog"]) ** 2) + 0.5 * ce)
+            # monitor.py:146-165 in one launch each way (CE + progress target + MSE + the lambda mix)
+            loss_t, _ = vln.losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, 0.5)
+            loss = loss + loss_t
             a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
         loss.backward()
         opt.step()

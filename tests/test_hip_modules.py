@@ -514,6 +514,32 @@ def test_host_feature_staging_matches_resident_tensors(vln):
     check(res["host-bf16"][0], res["tensor"][0], 1e-2, "bf16 host features: loss")
 
 
+def test_host_feature_copies_under_the_previous_backward(vln):
+    """Host-resident features with the arena: an iteration's H2D copies wait for the end of the iteration TWO back (the last
+    reader of its buffer generation) and so run under the previous iteration's backward.  Three different episode batches
+    rotating, six iterations back to back with no host sync in between, dropout ON: every iteration's loss and the final
+    gradients equal the forward-only overlap (copies wait for the previous iteration's end) bit for bit."""
+    import bench
+    dev_ = torch.device(DEV)
+    cpu_tapes = [bench.make_tape(16, 24, 3, 6, seed=90 + k) for k in range(3)]
+    res = []
+    for prefetch in (True, False):
+        tapes = [bench.tape_to(t, dev_, host_dtype=torch.float32) for t in cpu_tapes]
+        torch.manual_seed(29)
+        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+        ag.prefetch_under_backward = prefetch
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        ag.opt.lr = 0.0
+        losses = [ag.iteration(tapes[k % 3]).detach().clone() for k in range(6)]
+        torch.cuda.synchronize()
+        res.append((losses, [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.usefixtures("split_wgrads")
 def test_batched_logit_branch_backward_equals_per_step(vln, dtype):

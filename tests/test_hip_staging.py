@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import check
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -129,6 +131,54 @@ def test_fused_masked_ce_and_action_stats_golden(vln):
     assert torch.allclose(lp.cpu(), G["out"]["log_prob"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(ent.cpu(), G["out"]["entropy"], rtol=1e-5, atol=1e-6)
     assert probs[I["cand_mask"]].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("t", [0, 3])
+def test_fused_monitor_step_loss_equals_reference_sequence(vln, t, per_sample):
+    """Row A9 / monitor.py:146-165: losses.monitor_mixed_loss (ONE launch each way, the progress target built on the device)
+    against the reference's sequence restated by the oracle -- CE(ignore_index) on the masked logits, prog_target from the
+    distances in numpy with the `cur_dist <= 3` and `ended` rules, MSE, the t == 0 rule and the lambda mix -- value, d logits,
+    d progress and the logged progress MSE; means and the curriculum (reduction="none") form; ignored rows, masked slots, a
+    wide (> 16) row block."""
+    import numpy as np
+    from oracle import torch_port as O
+    g = torch.Generator().manual_seed(11 + t)
+    for B, C_ in ((37, 9), (128, 15), (5, 20)):
+        n = torch.randint(1, C_ + 1, (B,), generator=g)
+        mask = torch.arange(C_)[None, :] >= n[:, None]
+        tgt = (torch.rand(B, generator=g) * n.float()).long()
+        tgt[torch.rand(B, generator=g) < 0.2] = -1
+        tgt[0] = 0
+        logits = torch.randn(B, C_, generator=g) * 3
+        prog = torch.tanh(torch.randn(B, generator=g))
+        start = torch.rand(B, generator=g) * 15 + 4
+        cur = start - torch.rand(B, generator=g) * start * 1.2
+        cur = cur.clamp_min(0.2)
+        ended = torch.rand(B, generator=g) < 0.3
+        lam = 0.5 if B != 5 else 0.3
+        w = torch.arange(1, B + 1).float() / B
+        # reference sequence (monitor.py:155-158), numpy on the host
+        pt = (start.numpy() - cur.numpy()) / start.numpy()
+        pt[cur.numpy() <= 3.0] = 1.0
+        pt[ended.numpy()] = prog.numpy()[ended.numpy()]
+        lg0 = logits.clone().double().requires_grad_(True); pr0 = prog.clone().double().requires_grad_(True)
+        ref = O.monitor_mixed_loss(lg0, tgt, mask, pr0, torch.from_numpy(pt).double(), t, lam, per_sample)
+        ((ref * w.double()).sum() if per_sample else ref).backward()
+        lg = logits.to(DEV).requires_grad_(True); pr = prog.to(DEV).requires_grad_(True)
+        loss, pmse = vln.losses.monitor_mixed_loss(lg, tgt.to(DEV), mask.to(DEV), pr, start.to(DEV), cur.to(DEV), ended.to(DEV), t, lam,
+                                                   per_sample)
+        ((loss * w.to(DEV)).sum() if per_sample else loss).backward()
+        assert loss.shape == ref.shape
+        check(loss, ref.detach(), 1e-5, f"monitor loss B={B}")                 # fp32 kernel vs the fp64 restatement
+        check(lg.grad, lg0.grad, 1e-5, f"d logits B={B}")
+        if t > 0:
+            check(pr.grad, pr0.grad, 1e-5, f"d progress B={B}")
+            assert pr.grad[ended.to(DEV)].abs().max().item() == 0.0            # ended episodes: target = prediction (detached)
+            mse = float(((prog.double() - torch.from_numpy(pt).double()) ** 2).mean())
+            assert abs(float(pmse) - mse) <= 1e-5 * max(1.0, mse)
+        else:
+            assert pr.grad is None or pr.grad.abs().max().item() == 0.0
 
 
 def test_rollout_ce_equals_per_step_ce(vln):

@@ -142,6 +142,29 @@ def test_hip_rollouts_match_reference_agents(kind, mode):
     compare(res, be.named_grads(), G, 1e-4, 1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["teacher", "argmax"])
+def test_hip_monitor_rollout_with_the_fused_step_loss(mode):
+    """The reference Self-Monitor agent's tapes again, with the step loss of monitor.py:146-165 taken by
+    losses.monitor_mixed_loss (one launch each way, progress target built on the device, no per-step copy of cur_prog_val
+    to the host): same ml_loss, progress_loss, actions and gradients as the reference's own run."""
+    import vln_amd as vln
+    vln._lib.load()
+    dev = torch.device("cuda:0")
+    G = load_golden(f"agent_monitor_{mode}")
+    Pe, Pd, _ = split(G["param"])
+    F = 64 + 128
+    enc = vln.EncoderLSTM(40, 16, 32, 0, 0.5, False, 1)
+    dec = vln.MonitorDecoder(32, 0.5, 8, [24], F, F)
+    enc.load_state_dict(Pe, strict=True); dec.load_state_dict(Pd, strict=True)
+    for m in (enc, dec):
+        m.to(dev).eval()
+    be = R.MonitorModules(enc, dec, dev, mixed_loss=vln.losses.monitor_mixed_loss)
+    res = _run("monitor", be, mode)
+    res["ml_loss"].backward()
+    compare(res, be.named_grads(), G, 1e-4, 1e-4)
+
+
 # ---- back translation (SURVEY §8f N3; envdrop.py:105-121,155-157 + speaker.py:292-376) ----------------------------------
 # No tape of the reference exists for this branch: its hook calls attributes that do not exist (`decoder.drop_env`) and
 # leaves the batch unsorted with stale lengths (oracle/rollout.py::envdrop_rollout).  The CPU oracle -- itself pinned
