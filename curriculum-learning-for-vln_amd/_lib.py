@@ -32,6 +32,10 @@ class WsumStep(C.Structure):         # vln_wsum_step
     _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32), ("probs", ptr), ("target", ptr)]
 
 
+class CatStep(C.Structure):
+    _fields_ = [("probs", ptr), ("action", ptr), ("dlogits", ptr), ("C", i32)]
+
+
 class CeStep(C.Structure):           # vln_ce_step
     _fields_ = [("logits", ptr), ("ld", i64), ("target", ptr), ("cand_mask", ptr), ("probs", ptr), ("dlogits", ptr), ("C", i32)]
 
@@ -171,6 +175,7 @@ SIGNATURES = {
     "vln_monitor_loss_bwd": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, f32, i32, ptr, ptr, i32, i32, i64, ptr]),
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
+    "vln_categorical_multi_bwd": (i32, [C.POINTER(CatStep), i32, i32, ptr, ptr, ptr]),
     "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_bn_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, ptr, i32, i32, f32, i32, i32, i32, u64, u64, f32,
                          ptr, ptr]),

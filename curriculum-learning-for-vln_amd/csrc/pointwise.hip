@@ -767,7 +767,53 @@ __global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* probs
     }
   }
 }
+// every step of a sampled rollout in one launch: blockIdx.y = step, upstream gradients [T,B] (row t = step t)
+struct CatMultiArgs {
+  const float* probs[VLN_CE_MAX_STEPS]; const long long* action[VLN_CE_MAX_STEPS]; float* dlogits[VLN_CE_MAX_STEPS];
+  int C[VLN_CE_MAX_STEPS]; int T, B; const float* dlogp; const float* dent;
+};
+__global__ __launch_bounds__(256) void categorical_multi_bwd_kernel(CatMultiArgs m) {
+  const int t = blockIdx.y;
+  const int C = m.C[t];
+  const float eps = 1.1920928955078125e-07f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < m.B; b += gridDim.x * blockDim.x) {
+    const float* p = m.probs[t] + (long)b * C;
+    const long a = m.action[t][b];
+    const float gl = m.dlogp ? m.dlogp[(long)t * m.B + b] : 0.f, ge = m.dent ? m.dent[(long)t * m.B + b] : 0.f;
+    float gp_dot = 0.f;                              // same arithmetic, same order as categorical_bwd_kernel
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[c];
+      const bool live = pc >= eps && pc <= 1.f - eps;
+      float gp = 0.f;
+      if (live) gp = ((c == a) ? gl / pc : 0.f) - ge * (__logf(pc) + 1.f);
+      else gp = -ge * __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+      gp_dot += gp * pc;
+    }
+    float* dl = m.dlogits[t] + (long)b * C;
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[c];
+      const bool live = pc >= eps && pc <= 1.f - eps;
+      float gp = 0.f;
+      if (live) gp = ((c == a) ? gl / pc : 0.f) - ge * (__logf(pc) + 1.f);
+      else gp = -ge * __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+      dl[c] = pc * (gp - gp_dot);
+    }
+  }
+}
 }  // namespace vln
+
+extern "C" int vln_categorical_multi_bwd(const vln_cat_step* steps, int T, int B, const float* dlogp, const float* dent, void* s) {
+  if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0 || (!dlogp && !dent)) { vln::set_error("vln_categorical_multi_bwd: bad args"); return VLN_ERR_ARG; }
+  vln::CatMultiArgs m{};
+  m.T = T; m.B = B; m.dlogp = dlogp; m.dent = dent;
+  for (int t = 0; t < T; ++t) {
+    if (!steps[t].probs || !steps[t].action || !steps[t].dlogits || steps[t].C <= 0) { vln::set_error("vln_categorical_multi_bwd: null step pointer"); return VLN_ERR_ARG; }
+    m.probs[t] = steps[t].probs; m.action[t] = (const long long*)steps[t].action; m.dlogits[t] = steps[t].dlogits; m.C[t] = steps[t].C;
+  }
+  VLN_LAUNCH(vln::categorical_multi_bwd_kernel, dim3((B + 255) / 256, T), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("categorical_multi_bwd");
+  return VLN_OK;
+}
 
 extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mask, const int64_t* action_in,
                                    int64_t* action_out, float* probs, float* logp, float* entropy, int B, int C, uint64_t seed,

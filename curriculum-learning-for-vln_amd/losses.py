@@ -413,3 +413,99 @@ def sample_action(logits: torch.Tensor, cand_mask: Optional[torch.Tensor] = None
         _sample_calls[0] += 1
         offset = _sample_calls[0]
     return _Categorical.apply(logits, cand_mask, action, int(seed), int(offset))
+
+
+class _RolloutStats(torch.autograd.Function):
+    """logp / entropy [T,B] of a sampled rollout as ONE autograd node over the T steps' logits (RolloutSampler.stats)."""
+
+    @staticmethod
+    def forward(ctx, meta, *logits):
+        keep, logp, ent = meta
+        ctx.keep = keep
+        ctx.recs = [getattr(lg, "_vln_rec", None) for lg in logits]
+        return logp, ent
+
+    @staticmethod
+    def backward(ctx, dlogp, dent):
+        keep, recs = ctx.keep, ctx.recs
+        ctx.keep = ctx.recs = None
+        T = len(keep)
+        B = keep[0][0].shape[0]
+        gl = dlogp.contiguous() if dlogp is not None else None
+        ge = dent.contiguous() if dent is not None else None
+        outs, steps = [], []
+        for probs, act in keep:
+            dl = ops.empty_like(probs)
+            outs.append(dl)
+            steps.append(_lib.CatStep(probs.data_ptr(), act.data_ptr(), dl.data_ptr(), probs.shape[1]))
+        lib = _lib.load()
+        for i in range(0, T, _lib.CE_MAX_STEPS):
+            chunk = steps[i:i + _lib.CE_MAX_STEPS]
+            arr = (_lib.CatStep * len(chunk))(*chunk)
+            st = lib.vln_categorical_multi_bwd(arr, len(chunk), B, None if gl is None else gl[i:].data_ptr(),
+                                               None if ge is None else ge[i:].data_ptr(), _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_categorical_multi_bwd")
+        batched = all(r is not None and r.slot is not None for r in recs)
+        if batched:
+            mod = recs[0].mod
+            batched = bool(getattr(mod, "batch_logit_backward", False)) and all(r.mod is mod and r.B == B for r in recs)
+        if batched:
+            # the decoder's rollout-wide logit branch takes these d logits here and now (one multi-step weighted sum + one GEMM
+            # for all steps); autograd gets None, so a step's backward only sees what OTHER consumers of its logits sent
+            mod.logit_branch_backward(list(zip(recs, outs)))
+            return (None,) * (T + 1)
+        return (None, *outs)
+
+
+class RolloutSampler:
+    """The sampled-action branch of a WHOLE rollout (envdrop.py:186-195 every step, :235-264 afterwards):
+
+        s = RolloutSampler()
+        for t in range(T):  a_t = s.step(logits_t, cand_mask_t)      # one launch: mask, softmax, draw, log-prob, entropy
+        logp, ent = s.stats()                                        # [T,B] each, ONE autograd node for all steps
+
+    Same draws and numbers as calling `sample_action` every step; the difference is the backward: the d logits of all T
+    steps come from one launch at the root of the backward and -- with an EnvDropDecoder -- go through the decoder's
+    rollout-wide logit branch (one multi-step weighted sum, one GEMM) instead of three launches on every step's chain."""
+
+    def __init__(self, seed: int = 0x5A3B1E, capacity: int = _lib.CE_MAX_STEPS):
+        self.seed, self.cap = int(seed), int(capacity)
+        self.logits, self.keep = [], []
+        self.logp = self.ent = None
+
+    def step(self, logits: torch.Tensor, cand_mask: Optional[torch.Tensor] = None, action: Optional[torch.Tensor] = None,
+             offset: Optional[int] = None) -> torch.Tensor:
+        _not_deferred(logits, "RolloutSampler.step")
+        B, C = logits.shape
+        dev = logits.device
+        t = len(self.logits)
+        if self.logp is None:
+            self.logp = ops.empty(self.cap, B, dtype=torch.float32, device=dev)
+            self.ent = ops.empty(self.cap, B, dtype=torch.float32, device=dev)
+        if t >= self.cap or B != self.logp.shape[1]:
+            raise ValueError(f"RolloutSampler.step: more than {self.cap} steps, or the batch size changed")
+        if offset is None:
+            _sample_calls[0] += 1
+            offset = _sample_calls[0]
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        probs = ops.empty(B, C, dtype=torch.float32, device=dev)
+        act = action.contiguous() if action is not None else ops.empty(B, dtype=torch.int64, device=dev)
+        st = _lib.load().vln_categorical_fwd(_p(lg), lg.stride(0), _p(_mask8(cand_mask)), _p(action if action is None else act),
+                                             None if action is not None else act.data_ptr(), _p(probs), self.logp[t].data_ptr(),
+                                             self.ent[t].data_ptr(), B, C, self.seed, int(offset), _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_categorical_fwd")
+        self.logits.append(logits); self.keep.append((probs, act))
+        return act
+
+    def stats(self):
+        """(log_prob [T,B], entropy [T,B]) of the recorded steps, differentiable w.r.t. every step's logits."""
+        T = len(self.logits)
+        if T == 0:
+            raise ValueError("RolloutSampler.stats: no steps recorded")
+        out = _RolloutStats.apply((self.keep, self.logp[:T], self.ent[:T]), *self.logits)
+        self.logits, self.keep, self.logp, self.ent = [], [], None, None
+        return out

@@ -240,6 +240,10 @@ int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mas
                         uint64_t offset, vln_stream_t s);
 int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp /*nullable*/, const float* dent /*nullable*/,
                         float* dlogits, int B, int C, vln_stream_t s);
+/* The backward of EVERY step of a sampled rollout in one launch (losses.RolloutSampler): dlogp / dent [T,B], row t = step t. */
+typedef struct vln_cat_step { const float* probs; const int64_t* action; float* dlogits; int C; } vln_cat_step;
+int vln_categorical_multi_bwd(const vln_cat_step* steps, int T /* <= VLN_CE_MAX_STEPS */, int B, const float* dlogp /*nullable*/,
+                              const float* dent /*nullable*/, vln_stream_t s);
 
 /* Row-wise elementwise forms of the Speaker-Follower step: ActionScoring's `context * target` folded into the query
  * (units.py:180-184: logit = linear_out(context * target) = context . (target (.) w_out) + b_out) and the tanh backward.

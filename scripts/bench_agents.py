@@ -184,17 +184,22 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
         hidden, logps, ents = [], [], []
         dec.defer_logits = not sample           # teacher forcing: the logits are only needed by the loss (formed once per rollout)
         ce = vln.losses.RolloutCE()
+        sampler = vln.losses.RolloutSampler() if (sample and not getattr(args, "per_step_sampler", False)) else None
         for s in tape["steps"][:T]:
             img, cand = feats(s)
             logit, (h, c), ht = dec(s["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
             hidden.append(h)
             if not sample:
                 ce.add(logit, s["target"], s["cand_mask"])
+            elif sampler is not None:
+                sampler.step(logit, s["cand_mask"])                                 # envdrop.py:186-195 as one launch per step ...
             else:
-                a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])     # envdrop.py:186-195 as one launch
+                a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])
                 logps.append(lp_a); ents.append(en_a)
         if not sample:
             return ce.sum(scale=0.2 / B)
+        if sampler is not None:
+            logps, ents = sampler.stats()                                           # ... and ONE backward node for all steps
         img, cand = feats(tape["steps"][T - 1])
         _, (last_h, _), _ = dec(tape["steps"][T - 1]["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
         with torch.no_grad():
@@ -233,10 +238,12 @@ def main():
     ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
     ap.add_argument("--python-step", action="store_true", help="monitor: the step's launches driven from Python (functional.MonitorCoreFn) "
                                                                "instead of one C call each way")
+    ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
     a = ap.parse_args()
     configure(a.steps, a.warmup, a.dtype, a.arena)
     args.python_step = a.python_step
+    args.per_step_sampler = a.per_step_sampler
     vln.functional.set_grad_in_place(not a.no_grad_in_place)
     if a.which in ("monitor", "all"):
         print(json.dumps(run_monitor()), flush=True)

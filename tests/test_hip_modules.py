@@ -701,6 +701,71 @@ def test_rollout_ce_and_sampled_log_probs_share_the_logits(vln, per_sample):
         check(res[0][0][n], res[1][0][n], 2e-5, f"grad[{n}]", floor=1e-3 * scale)
 
 
+@pytest.mark.parametrize("given_actions", [False, True])
+@pytest.mark.usefixtures("split_wgrads")
+def test_rollout_sampler_equals_per_step_sample_action(vln, given_actions):
+    """losses.RolloutSampler: the sampled branch of every step (envdrop.py:186-195) with ONE backward node for the whole
+    rollout (all d logits in one launch, then the decoder's rollout-wide logit branch) against `sample_action` per step with
+    the same Philox offsets: identical draws, log-probs and entropies bit for bit; A2C loss (losses.a2c_loss) and every
+    gradient to rounding (the batched branch contracts over steps x batch rows)."""
+    B, L, V, Cn, H, F, T = 12, 9, 36, 6, 64, 256 + 128, 5
+    g = torch.Generator().manual_seed(61)
+    ctx0 = torch.randn(B, L, H, generator=g).to(DEV)
+    h = torch.randn(B, H, generator=g).to(DEV); c = torch.randn(B, H, generator=g).to(DEV)
+    a = torch.randn(B, 128, generator=g).to(DEV)
+    steps = []
+    for t in range(T):
+        n = torch.randint(2, Cn + 1, (B,), generator=g)
+        cmask = torch.arange(Cn)[None, :] >= n[:, None]
+        cand = torch.randn(B, Cn, F, generator=g).abs() * (~cmask)[..., None]
+        act = (torch.rand(B, generator=g) * n.float()).long()
+        steps.append((torch.randn(B, V, F, generator=g).abs().to(DEV), cand.to(DEV), cmask.to(DEV), act.to(DEV)))
+    rewards = [torch.randn(B, generator=g).sign().to(DEV) for _ in range(T)]
+    lens = torch.randint(2, T + 1, (B,), generator=g); lens[0] = T
+    masks = [(t < lens).to(DEV) for t in range(T)]
+    ended = (lens < T).to(DEV)
+    res = []
+    for rollout_wide in (True, False):
+        torch.manual_seed(6)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+        cri = vln.Critic(H, 0.5).to(DEV).eval()
+        ctx = ctx0.clone().requires_grad_(True)
+        hh, cc, ht = h.clone().requires_grad_(True), c.clone(), h.clone()
+        sampler = vln.losses.RolloutSampler(seed=77)
+        logps, ents, acts, hidden = [], [], [], []
+        for t, (img, cand, cmask, act) in enumerate(steps):
+            lg, (hh, cc), ht = dec(a, img.clone(), cand.clone(), ht, hh, cc, ctx)
+            hidden.append(hh)
+            given = act if given_actions else None
+            if rollout_wide:
+                acts.append(sampler.step(lg, cmask, action=given, offset=100 + t))
+            else:
+                a_t, lp_t, en_t = vln.losses.sample_action(lg, cmask, action=given, seed=77, offset=100 + t)
+                acts.append(a_t); logps.append(lp_t); ents.append(en_t)
+        if rollout_wide:
+            logps, ents = sampler.stats()
+            assert logps.shape == (T, B) and ents.shape == (T, B)
+        vals = [cri(x) for x in hidden]
+        with torch.no_grad():
+            last_v = cri(hh).detach()
+        loss, total = vln.losses.a2c_loss(logps, ents, vals, rewards, masks, last_v, ended, 0.9, "total")
+        loss.backward()
+        lp_all = logps.detach().clone() if rollout_wide else torch.stack([x.detach() for x in logps])
+        en_all = ents.detach().clone() if rollout_wide else torch.stack([x.detach() for x in ents])
+        res.append((torch.stack(acts).clone(), lp_all, en_all, loss.detach().clone(),
+                    {n: p.grad.detach().clone() for n, p in dec.named_parameters()}, ctx.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])                                # the same draws
+    if not given_actions:
+        for t, (_, _, cmask, _) in enumerate(steps):
+            assert not cmask[torch.arange(B), res[0][0][t]].any()             # never a masked slot
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    check(res[0][3], res[1][3], 1e-6, "a2c loss")
+    check(res[0][5], res[1][5], 1e-5, "d ctx")
+    scale = max(v.abs().max().item() for v in res[1][4].values())
+    for n in res[0][4]:
+        check(res[0][4][n], res[1][4][n], 2e-5, f"grad[{n}]", floor=1e-3 * scale)
+
+
 def test_long_rollouts_replay_their_step_graphs(vln):
     """T = 20 decoder steps per iteration (the reference's sampled rollouts run up to MAX_EPISODE_LEN = 35): the graph cache
     used to switch itself off for good after 24 misses in a row -- i.e. inside the first two (all-miss by construction)
