@@ -173,10 +173,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
     masks = [(t < lens_rl).to(dev) for t in range(T_rl)]
     ended = (lens_rl < T_rl).to(dev)
 
-    def feats(s):
-        (img, img_lp), (cand, cand_lp), _ = store.gather_step(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"],
-                                                              0.3, want_bf16=lp, want_f32=not lp)
-        return (img_lp, cand_lp) if lp else (img, cand)
+    def gather_of(s):
+        return (store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"])
 
     def rollout(T, sample):
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
@@ -186,8 +184,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
         ce = vln.losses.RolloutCE()
         sampler = vln.losses.RolloutSampler() if (sample and not getattr(args, "per_step_sampler", False)) else None
         for s in tape["steps"][:T]:
-            img, cand = feats(s)
-            logit, (h, c), ht = dec(s["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
+            # the step gathers its own feature rows from the resident table inside its first launch (forward(gather=...))
+            logit, (h, c), ht = dec(s["angle"], None, None, ht, h, c, ctx, tape["seq_mask"], gather=gather_of(s))
             hidden.append(h)
             if not sample:
                 ce.add(logit, s["target"], s["cand_mask"])
@@ -200,8 +198,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
             return ce.sum(scale=0.2 / B)
         if sampler is not None:
             logps, ents = sampler.stats()                                           # ... and ONE backward node for all steps
-        img, cand = feats(tape["steps"][T - 1])
-        _, (last_h, _), _ = dec(tape["steps"][T - 1]["angle"], img, cand, ht, h, c, ctx, tape["seq_mask"], True)
+        sl = tape["steps"][T - 1]
+        _, (last_h, _), _ = dec(sl["angle"], None, None, ht, h, c, ctx, tape["seq_mask"], gather=gather_of(sl))
         with torch.no_grad():
             last_v = cri(last_h).detach()
         # the critic is row-wise: V of all T steps in ONE call over (steps x batch) rows instead of T calls (the reference
