@@ -549,10 +549,18 @@ __device__ __forceinline__ float4 bn_strip_sum(float4 v, float4 (*part)[4], int 
   __syncthreads();
   return t;
 }
+// Workgroups are dealt to the 8 XCDs round-robin by block index.  A workgroup owns a 64-byte column strip, i.e. HALF of every
+// 128-byte line it touches: with the identity mapping the two halves of a line are fetched by two different XCDs' L2s (twice
+// the HBM traffic).  This mapping gives each XCD a CONTIGUOUS range of strips instead.
+__device__ __forceinline__ int xcd_chunked_block(int b, int nblk) {
+  const int x = b & 7, j = b >> 3;
+  const int q = nblk >> 3, rem = nblk & 7;          // XCD y owns q + (y < rem) blocks
+  return x * q + min(x, rem) + j;
+}
 __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
   __shared__ float4 part[64][4];
   const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 16 + cg * 4;
+  const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
   const bool c_ok = c < a.D;                                   // D % 4 == 0
   const int cc = c_ok ? c : 0;
   const float* xp = a.x + cc;
@@ -560,6 +568,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
   if (a.training) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c_ok)
+#pragma unroll 4
       for (int r = rl; r < a.R; r += 64) {
         const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
@@ -569,6 +578,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
     mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c_ok)
+#pragma unroll 4
       for (int r = rl; r < a.R; r += 64) {                      // second pass over the strip: L2-resident by now
         const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
         const float dx = t.x - mean.x, dy = t.y - mean.y, dz = t.z - mean.z, dw = t.w - mean.w;
@@ -600,6 +610,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(BnArgs a) {
   if (!c_ok) return;
   const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 bt = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
   for (int r = rl; r < a.R; r += 64) {
     const float4 t = *reinterpret_cast<const float4*>(xp + (long)r * a.ldx);
     float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
@@ -625,7 +636,7 @@ struct BnBwdArgs {
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   __shared__ float4 part[64][4];
   const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 16 + cg * 4;
+  const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
   const bool c_ok = c < a.D;
   const int cc = c_ok ? c : 0;
   const float4 mean = *reinterpret_cast<const float4*>(a.mean + cc);
@@ -652,6 +663,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   };
   float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), sdx = sd;
   if (c_ok)
+#pragma unroll 4
     for (int r = rl; r < a.R; r += 64) {
       const float4 dv = grad_at(r), xh = xhat_at(r);
       sd.x += dv.x; sd.y += dv.y; sd.z += dv.z; sd.w += dv.w;
@@ -674,6 +686,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   }
   if (!a.dx) return;
   const float inv = 1.f / (float)a.R;
+#pragma unroll 4
   for (int r = rl; r < a.R; r += 64) {       // second pass: the strip is L2-resident
     const float4 dv = grad_at(r);
     float4 o;

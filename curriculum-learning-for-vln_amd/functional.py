@@ -403,16 +403,24 @@ class BnMlpFn(torch.autograd.Function):
         def bn_bwd(inp, dyy, yy, w, stats, buf, relu, drop, rzp, want_dx, gi):
             D = inp.shape[1]
             dx = ops.empty(R, D, dtype=torch.float32, device=dev) if want_dx else None
-            dgb = torch.empty(2, D, dtype=torch.float32, device=dev)
+            # d gamma / d beta: straight into existing .grad tensors when grad-in-place is on (the kernel accumulates), else
+            # fresh tensors for autograd's AccumulateGrad (two `add_` launches per BatchNorm per step)
+            (gg, acc_g), (gbt, acc_b) = _gsink(tensors[gi]), _gsink(tensors[gi + 1])
+            if acc_g and acc_b:
+                pg, pb, acc = gg.data_ptr(), gbt.data_ptr(), 1
+            else:
+                dgb = torch.empty(2, D, dtype=torch.float32, device=dev)
+                pg, pb, acc = dgb.data_ptr(), dgb.data_ptr() + 4 * D, 0
             p_, seed_, off_ = drop
             mean_p = stats.data_ptr() if training else buf[0].data_ptr()
             rstd_p = stats.data_ptr() + 4 * D if training else buf[1].data_ptr()
             rc = lib.vln_bn_bwd(_p(inp), inp.stride(0), _p(dyy), dyy.stride(0), _p(yy), 0 if yy is None else yy.stride(0), _p(w), mean_p,
-                                rstd_p, _p(dx), 0 if dx is None else dx.stride(0), dgb.data_ptr(), dgb.data_ptr() + 4 * D, R, D, eps,
-                                1 if training else 0, 1 if relu else 0, 0, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
+                                rstd_p, _p(dx), 0 if dx is None else dx.stride(0), pg, pb, R, D, eps,
+                                1 if training else 0, 1 if relu else 0, acc, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
             if rc:
                 _lib.check(rc, "vln_bn_bwd")
-            grads[gi], grads[gi + 1] = dgb[0], dgb[1]
+            if not acc:
+                grads[gi], grads[gi + 1] = dgb[0], dgb[1]
             return dx
 
         g = dy.contiguous()

@@ -1,13 +1,12 @@
-import sys, subprocess
-sys.argv = ["bench_agents.py", "none"]
+"""torch.profiler view of the Self-Monitor workload (which aten ops the Python glue adds around the C calls)."""
+import sys
 sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
 import torch
-exec(open("scripts/bench_agents.py").read().split("if args.which in")[0])
+import bench_agents as W
 from torch.profiler import profile, ProfilerActivity
-args.steps, args.warmup = 3, 3
-def go():
-    run_monitor()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    go()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
-print(vln.functional.GRAD_IN_PLACE_STATS)
+
+W.configure(steps=3, warmup=3, dtype="bf16", arena=False)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    W.run_monitor()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=60))
+print(W.vln.functional.GRAD_IN_PLACE_STATS)
