@@ -176,9 +176,9 @@ SIGNATURES = {
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_categorical_multi_bwd": (i32, [C.POINTER(CatStep), i32, i32, ptr, ptr, ptr]),
-    "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr, i64, ptr]),
     "vln_bn_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, ptr, i32, i32, f32, i32, i32, i32, u64, u64, f32,
-                         ptr, ptr]),
+                         ptr, ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),

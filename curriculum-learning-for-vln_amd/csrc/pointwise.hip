@@ -702,6 +702,198 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
     *reinterpret_cast<float4*>(a.dx + (long)r * a.lddx + c) = o;
   }
 }
+// ---- row-chunked forms for tall inputs (R >= 512: the candidates' BN-MLP runs on B * C = 1024 rows) ----------------------
+// One workgroup per 16-column strip walks ALL rows two or three times: D / 16 workgroups (8 for the 128-wide layer) and
+// R / 64 dependent loop trips each -- 20-40 us for 0.5-16 MB.  Here the rows are cut into chunks of 128 (two rows per
+// thread, kept in registers between the passes) and the grid is (strips, chunks):
+//   phase A  per-chunk statistics into `ws`  (forward: mean and M2 of the chunk; backward: sum dy and sum dy * xhat)
+//   phase B  every workgroup merges the chunks' statistics for its strip in a fixed order (forward: Chan's parallel
+//            mean / M2 merge -- no E[x^2] - E[x]^2 cancellation) and finishes its own rows; chunk 0 writes the per-feature
+//            outputs (saved / running statistics; d gamma, d beta).
+// Two launches of ~6 us each instead of one of 20-40.
+constexpr int kBnChunk = 128;
+struct BnChunkWs { float* part; int nchunk; };       // part [nchunk][2][D]
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+
+__global__ __launch_bounds__(256) void bn_fwd_stats_kernel(BnArgs a, BnChunkWs w) {
+  __shared__ float4 part[64][4];
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
+  const bool c_ok = c < a.D;
+  const int cc = c_ok ? c : 0;
+  const int ch = blockIdx.y, r0 = ch * kBnChunk;
+  const int n = min(kBnChunk, a.R - r0);
+  const int ra = r0 + rl, rb = r0 + 64 + rl;
+  const bool oka = c_ok && rl < n, okb = c_ok && 64 + rl < n;
+  const float4 z = f4(0.f);
+  const float4 ta = oka ? *reinterpret_cast<const float4*>(a.x + (long)ra * a.ldx + cc) : z;
+  const float4 tb = okb ? *reinterpret_cast<const float4*>(a.x + (long)rb * a.ldx + cc) : z;
+  float4 s = make_float4(ta.x + tb.x, ta.y + tb.y, ta.z + tb.z, ta.w + tb.w);
+  s = bn_strip_sum(s, part, rl, cg);
+  const float inv = 1.f / (float)n;
+  const float4 mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  float4 q = z;
+  if (oka) { const float dx = ta.x - mean.x, dy = ta.y - mean.y, dz = ta.z - mean.z, dw = ta.w - mean.w; q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw; }
+  if (okb) { const float dx = tb.x - mean.x, dy = tb.y - mean.y, dz = tb.z - mean.z, dw = tb.w - mean.w; q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw; }
+  q = bn_strip_sum(q, part, rl, cg);
+  if (rl == 0 && c_ok) {
+    *reinterpret_cast<float4*>(w.part + ((long)ch * 2 + 0) * a.D + c) = mean;
+    *reinterpret_cast<float4*>(w.part + ((long)ch * 2 + 1) * a.D + c) = q;
+  }
+}
+__global__ __launch_bounds__(256) void bn_fwd_apply_kernel(BnArgs a, BnChunkWs w) {
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
+  if (c >= a.D) return;
+  const int ch = blockIdx.y, r0 = ch * kBnChunk;
+  float4 mean, rstd;
+  if (a.training) {
+    float4 ms = f4(0.f);
+    for (int i = 0; i < w.nchunk; ++i) {
+      const float ni = (float)min(kBnChunk, a.R - i * kBnChunk);
+      const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
+      ms.x += ni * mi.x; ms.y += ni * mi.y; ms.z += ni * mi.z; ms.w += ni * mi.w;
+    }
+    const float inv = 1.f / (float)a.R;
+    mean = make_float4(ms.x * inv, ms.y * inv, ms.z * inv, ms.w * inv);
+    float4 m2 = f4(0.f);
+    for (int i = 0; i < w.nchunk; ++i) {
+      const float ni = (float)min(kBnChunk, a.R - i * kBnChunk);
+      const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
+      const float4 qi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2 + 1) * a.D + c);
+      const float dx = mi.x - mean.x, dy = mi.y - mean.y, dz = mi.z - mean.z, dw = mi.w - mean.w;
+      m2.x += qi.x + ni * dx * dx; m2.y += qi.y + ni * dy * dy; m2.z += qi.z + ni * dz * dz; m2.w += qi.w + ni * dw * dw;
+    }
+    const float4 var = make_float4(m2.x * inv, m2.y * inv, m2.z * inv, m2.w * inv);
+    rstd = make_float4(rsqrtf(var.x + a.eps), rsqrtf(var.y + a.eps), rsqrtf(var.z + a.eps), rsqrtf(var.w + a.eps));
+    if (ch == 0 && rl == 0) {
+      if (a.save_mean) *reinterpret_cast<float4*>(a.save_mean + c) = mean;
+      if (a.save_rstd) *reinterpret_cast<float4*>(a.save_rstd + c) = rstd;
+      if (a.run_mean) {
+        const float m = a.momentum, ub = (a.R > 1) ? (float)a.R / (float)(a.R - 1) : 1.f;
+        float4 rm = *reinterpret_cast<float4*>(a.run_mean + c), rv = *reinterpret_cast<float4*>(a.run_var + c);
+        rm.x = (1.f - m) * rm.x + m * mean.x; rm.y = (1.f - m) * rm.y + m * mean.y;
+        rm.z = (1.f - m) * rm.z + m * mean.z; rm.w = (1.f - m) * rm.w + m * mean.w;
+        rv.x = (1.f - m) * rv.x + m * var.x * ub; rv.y = (1.f - m) * rv.y + m * var.y * ub;
+        rv.z = (1.f - m) * rv.z + m * var.z * ub; rv.w = (1.f - m) * rv.w + m * var.w * ub;
+        *reinterpret_cast<float4*>(a.run_mean + c) = rm;
+        *reinterpret_cast<float4*>(a.run_var + c) = rv;
+      }
+      if (a.nbt && blockIdx.x == 0 && cg == 0) *a.nbt += 1;
+    }
+  } else {
+    mean = *reinterpret_cast<const float4*>(a.run_mean + c);
+    const float4 rv = *reinterpret_cast<const float4*>(a.run_var + c);
+    rstd = make_float4(rsqrtf(rv.x + a.eps), rsqrtf(rv.y + a.eps), rsqrtf(rv.z + a.eps), rsqrtf(rv.w + a.eps));
+  }
+  const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : f4(1.f);
+  const float4 bt = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : f4(0.f);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = r0 + k * 64 + rl;
+    if (r >= a.R || k * 64 + rl >= kBnChunk) continue;
+    const float4 t = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + c);
+    float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
+                           (t.z - mean.z) * rstd.z * g.z + bt.z, (t.w - mean.w) * rstd.w * g.w + bt.w);
+    if (a.drop.p > 0.f) {
+      float m[4];
+      dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + c) >> 2), a.drop.p, m);
+      o.x *= m[0]; o.y *= m[1]; o.z *= m[2]; o.w *= m[3];
+    }
+    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (a.row_zero && a.row_zero[r]) o = f4(0.f);
+    *reinterpret_cast<float4*>(a.y + (long)r * a.ldy + c) = o;
+  }
+}
+
+// backward: `phase` 0 = per-chunk sums of dy and dy * xhat into ws; 1 = merge + d gamma / d beta (chunk 0) + dx of the chunk
+template <int kPhase>
+__global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(BnBwdArgs a, BnChunkWs w) {
+  __shared__ float4 part[64][4];
+  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
+  const bool c_ok = c < a.D;
+  const int cc = c_ok ? c : 0;
+  const int ch = blockIdx.y, r0 = ch * kBnChunk;
+  const float4 mean = *reinterpret_cast<const float4*>(a.mean + cc);
+  float4 rstd = *reinterpret_cast<const float4*>(a.rstd + cc);
+  if (!a.training) rstd = make_float4(rsqrtf(rstd.x + a.eps), rsqrtf(rstd.y + a.eps), rsqrtf(rstd.z + a.eps), rsqrtf(rstd.w + a.eps));
+  float4 dv[2], xh[2];
+  bool ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = r0 + k * 64 + rl;
+    ok[k] = c_ok && r < a.R;
+    dv[k] = f4(0.f); xh[k] = f4(0.f);
+    if (ok[k]) {
+      float4 d = *reinterpret_cast<const float4*>(a.dy + (long)r * a.lddy + cc);
+      if (a.row_zero && a.row_zero[r]) d = f4(0.f);
+      if (a.drop.p > 0.f) {
+        float m[4];
+        dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + cc) >> 2), a.drop.p, m);
+        d.x *= m[0]; d.y *= m[1]; d.z *= m[2]; d.w *= m[3];
+      }
+      if (a.relu) {
+        const float4 yv = *reinterpret_cast<const float4*>(a.y + (long)r * a.ldy + cc);
+        d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f; d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+      }
+      dv[k] = d;
+      const float4 xv = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + cc);
+      xh[k] = make_float4((xv.x - mean.x) * rstd.x, (xv.y - mean.y) * rstd.y, (xv.z - mean.z) * rstd.z, (xv.w - mean.w) * rstd.w);
+    }
+  }
+  if constexpr (kPhase == 0) {
+    float4 sd = make_float4(dv[0].x + dv[1].x, dv[0].y + dv[1].y, dv[0].z + dv[1].z, dv[0].w + dv[1].w);
+    float4 sdx = make_float4(dv[0].x * xh[0].x + dv[1].x * xh[1].x, dv[0].y * xh[0].y + dv[1].y * xh[1].y,
+                             dv[0].z * xh[0].z + dv[1].z * xh[1].z, dv[0].w * xh[0].w + dv[1].w * xh[1].w);
+    sd = bn_strip_sum(sd, part, rl, cg);
+    sdx = bn_strip_sum(sdx, part, rl, cg);
+    if (rl == 0 && c_ok) {
+      *reinterpret_cast<float4*>(w.part + ((long)ch * 2 + 0) * a.D + c) = sd;
+      *reinterpret_cast<float4*>(w.part + ((long)ch * 2 + 1) * a.D + c) = sdx;
+    }
+  } else {
+    if (!c_ok) return;
+    float4 sd = f4(0.f), sdx = f4(0.f);
+    for (int i = 0; i < w.nchunk; ++i) {
+      const float4 p0 = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
+      const float4 p1 = *reinterpret_cast<const float4*>(w.part + ((long)i * 2 + 1) * a.D + c);
+      sd.x += p0.x; sd.y += p0.y; sd.z += p0.z; sd.w += p0.w;
+      sdx.x += p1.x; sdx.y += p1.y; sdx.z += p1.z; sdx.w += p1.w;
+    }
+    if (ch == 0 && rl == 0) {
+      if (a.dgamma) {
+        float4 o = sdx;
+        if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dgamma + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        *reinterpret_cast<float4*>(a.dgamma + c) = o;
+      }
+      if (a.dbeta) {
+        float4 o = sd;
+        if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dbeta + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        *reinterpret_cast<float4*>(a.dbeta + c) = o;
+      }
+    }
+    if (!a.dx) return;
+    const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : f4(1.f);
+    const float inv = 1.f / (float)a.R;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!ok[k]) continue;
+      const int r = r0 + k * 64 + rl;
+      float4 o;
+      if (a.training) {
+        o.x = g.x * rstd.x * (dv[k].x - inv * (sd.x + xh[k].x * sdx.x));
+        o.y = g.y * rstd.y * (dv[k].y - inv * (sd.y + xh[k].y * sdx.y));
+        o.z = g.z * rstd.z * (dv[k].z - inv * (sd.z + xh[k].z * sdx.z));
+        o.w = g.w * rstd.w * (dv[k].w - inv * (sd.w + xh[k].w * sdx.w));
+      } else {
+        o = make_float4(dv[k].x * g.x * rstd.x, dv[k].y * g.y * rstd.y, dv[k].z * g.z * rstd.z, dv[k].w * g.w * rstd.w);
+      }
+      *reinterpret_cast<float4*>(a.dx + (long)r * a.lddx + c) = o;
+    }
+  }
+}
 static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace vln
 
@@ -1027,7 +1219,7 @@ extern "C" int vln_ew(int op, const float* a, int64_t lda, const float* b, int64
 extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
                           int R, int D, float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset,
-                          float p_drop, const uint8_t* row_zero, void* s) {
+                          float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
   using namespace vln;
   if (!x || !y || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3) || !al16p(x) || !al16p(y) ||
       (!training && (!running_mean || !running_var)) || (training && (!save_mean || !save_rstd))) {
@@ -1036,6 +1228,15 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
   }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
            R, D, eps, momentum, training, relu, DropSpec{seed, offset, p_drop}, row_zero};
+  const int nchunk = (R + kBnChunk - 1) / kBnChunk;
+  if (R >= 512 && ((!training) || (ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D))) {     // tall input: row-chunked form
+    BnChunkWs w{ws, nchunk};
+    dim3 grid((D + 15) / 16, nchunk);
+    if (training) VLN_LAUNCH(bn_fwd_stats_kernel, grid, dim3(256), 0, (hipStream_t)s, a, w);
+    VLN_LAUNCH(bn_fwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)s, a, w);
+    VLN_CHECK_LAUNCH("bn_fwd (chunked)");
+    return VLN_OK;
+  }
   VLN_LAUNCH(bn_fwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_fwd");
   return VLN_OK;
@@ -1043,7 +1244,7 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
 extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
                           const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R,
                           int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, float p_drop,
-                          const uint8_t* row_zero, void* s) {
+                          const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
   using namespace vln;
   if (!x || !dy || !mean || !rstd_or_var || (relu && !y) || R <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) ||
       (relu && (ldy & 3)) || !al16p(x) || !al16p(dy) || (dx && !al16p(dx)) ) {
@@ -1052,6 +1253,14 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
   }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
               training, relu, accumulate, DropSpec{seed, offset, p_drop}, row_zero};
+  const int nchunk = (R + kBnChunk - 1) / kBnChunk;
+  if (R >= 512 && ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D) {       // tall input: row-chunked form
+    BnChunkWs w{ws, nchunk};
+    VLN_LAUNCH(bn_bwd_chunk_kernel<0>, dim3((D + 15) / 16, nchunk), dim3(256), 0, (hipStream_t)s, a, w);
+    VLN_LAUNCH(bn_bwd_chunk_kernel<1>, dim3((D + 15) / 16, dx ? nchunk : 1), dim3(256), 0, (hipStream_t)s, a, w);
+    VLN_CHECK_LAUNCH("bn_bwd (chunked)");
+    return VLN_OK;
+  }
   VLN_LAUNCH(bn_bwd_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("bn_bwd");
   return VLN_OK;

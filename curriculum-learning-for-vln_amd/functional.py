@@ -55,6 +55,15 @@ def set_grad_in_place(on: bool):
     _GRAD_IN_PLACE[0] = bool(on)
 
 
+def _bn_ws(R, D, dev):
+    """Scratch of the row-chunked BatchNorm form (vln_bn_fwd / vln_bn_bwd, inputs of >= 512 rows): (tensor, ptr, floats)."""
+    if R < 512:
+        return None, None, 0
+    n = -(-R // 128) * 2 * D
+    t = ops.empty(n, dtype=torch.float32, device=dev)
+    return t, t.data_ptr(), n
+
+
 def _gsink(p):
     """-> (tensor the launch writes, accumulate flag, value to return to autograd is None)."""
     g = p.grad
@@ -297,9 +306,11 @@ class BatchNormFn(torch.autograd.Function):
         y = ops.empty(R, D, dtype=torch.float32, device=dev)
         stats = ops.empty(2, D, dtype=torch.float32, device=dev) if training else None
         use_batch = bool(training or running_mean is None)
+        _wst, wsp, wsn = _bn_ws(R, D, dev)
         st = _lib.load().vln_bn_fwd(_p(xc), xc.stride(0), _p(y), y.stride(0), _p(weight), _p(bias), _p(running_mean), _p(running_var),
                                     _p(nbt) if training else None, _p(stats), None if stats is None else stats.data_ptr() + 4 * D,
-                                    R, D, eps, momentum, 1 if use_batch else 0, 1 if relu else 0, 0, 0, 0.0, None, _lib.raw_stream())
+                                    R, D, eps, momentum, 1 if use_batch else 0, 1 if relu else 0, 0, 0, 0.0, None, wsp, wsn,
+                                    _lib.raw_stream())
         if st:
             _lib.check(st, "vln_bn_fwd")
         ctx.save_for_backward(xc, y if relu else None, weight, stats, None if use_batch else running_mean, None if use_batch else running_var)
@@ -318,10 +329,11 @@ class BatchNormFn(torch.autograd.Function):
         dgb = torch.empty(2, D, dtype=torch.float32, device=dev) if need_w else None        # parameter gradients: not arena memory
         mean_p = stats.data_ptr() if use_batch else rmean.data_ptr()
         rstd_p = stats.data_ptr() + 4 * D if use_batch else rvar.data_ptr()
+        _wst, wsp, wsn = _bn_ws(R, D, dev)
         st = _lib.load().vln_bn_bwd(_p(xc), xc.stride(0), _p(dy), dy.stride(0), _p(y), 0 if y is None else y.stride(0), _p(weight),
                                     mean_p, rstd_p, _p(dx), 0 if dx is None else dx.stride(0), None if dgb is None else dgb.data_ptr(),
                                     None if dgb is None else dgb.data_ptr() + 4 * D, R, D, eps, 1 if use_batch else 0,
-                                    1 if relu else 0, 0, 0, 0, 0.0, None, _lib.raw_stream())
+                                    1 if relu else 0, 0, 0, 0, 0.0, None, wsp, wsn, _lib.raw_stream())
         if st:
             _lib.check(st, "vln_bn_bwd")
         return dx, (dgb[0] if need_w else None), (dgb[1] if need_w else None), None, None, None, None, None, None, None
@@ -363,9 +375,10 @@ class BnMlpFn(torch.autograd.Function):
             stats = ops.empty(2, D, dtype=torch.float32, device=dev) if training else None
             rm, rv, nbt = buf
             p_, seed_, off_ = drop
+            _wst, wsp, wsn = _bn_ws(R, D, dev)
             rc = lib.vln_bn_fwd(_p(inp), inp.stride(0), _p(out), out.stride(0), _p(w), _p(b), _p(rm), _p(rv), _p(nbt) if training else None,
                                 _p(stats), None if stats is None else stats.data_ptr() + 4 * D, R, D, eps, momentum,
-                                1 if training else 0, 1 if relu else 0, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
+                                1 if training else 0, 1 if relu else 0, seed_, off_, p_ if training else 0.0, _p(rzp), wsp, wsn, st_)
             if rc:
                 _lib.check(rc, "vln_bn_fwd")
             return out, stats
@@ -414,9 +427,10 @@ class BnMlpFn(torch.autograd.Function):
             p_, seed_, off_ = drop
             mean_p = stats.data_ptr() if training else buf[0].data_ptr()
             rstd_p = stats.data_ptr() + 4 * D if training else buf[1].data_ptr()
+            _wst, wsp, wsn = _bn_ws(R, D, dev)
             rc = lib.vln_bn_bwd(_p(inp), inp.stride(0), _p(dyy), dyy.stride(0), _p(yy), 0 if yy is None else yy.stride(0), _p(w), mean_p,
                                 rstd_p, _p(dx), 0 if dx is None else dx.stride(0), pg, pb, R, D, eps,
-                                1 if training else 0, 1 if relu else 0, acc, seed_, off_, p_ if training else 0.0, _p(rzp), st_)
+                                1 if training else 0, 1 if relu else 0, acc, seed_, off_, p_ if training else 0.0, _p(rzp), wsp, wsn, st_)
             if rc:
                 _lib.check(rc, "vln_bn_bwd")
             if not acc:

@@ -360,11 +360,14 @@ int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follower_weights
 int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
                float* running_var, int64_t* num_batches_tracked /*nullable*/, float* save_mean, float* save_rstd, int R, int D,
                float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, float p_drop /*0: none*/,
-               const uint8_t* row_zero /*nullable [R]*/, vln_stream_t s);
+               const uint8_t* row_zero /*nullable [R]*/,
+               float* ws /*nullable: ceil(R/128) * 2 * D floats; with it, inputs of R >= 512 rows take the row-chunked two-launch form*/,
+               int64_t ws_floats, vln_stream_t s);
 int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y /*relu only*/, int64_t ldy,
                const float* gamma, const float* mean, const float* rstd_or_var, float* dx /*nullable*/, int64_t lddx,
                float* dgamma /*nullable*/, float* dbeta /*nullable*/, int R, int D, float eps, int training, int relu,
-               int accumulate, uint64_t seed, uint64_t offset, float p_drop, const uint8_t* row_zero, vln_stream_t s);
+               int accumulate, uint64_t seed, uint64_t offset, float p_drop, const uint8_t* row_zero,
+               float* ws /*nullable, as in vln_bn_fwd*/, int64_t ws_floats, vln_stream_t s);
 
 /* A2C sweep of the EnvDrop rollout (envdrop.py:235-264) as one launch.  All step tensors are stacked [T,B]:
  * logp = log pi(a_t), ent = entropies (NULL with ent_coef unused: feedback != "sample"), val = critic values (with

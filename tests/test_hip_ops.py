@@ -97,7 +97,7 @@ def _wgrad_grouped(vln, split):
         check(o, r, tol, "o")
 
 
-@pytest.mark.parametrize("R,D", [(128, 2176), (1024, 1024), (1792, 1024), (5, 8)])
+@pytest.mark.parametrize("R,D", [(128, 2176), (1024, 1024), (1792, 1024), (5, 8), (1000, 128), (601, 2176)])   # >= 512 rows: the row-chunked form
 @pytest.mark.parametrize("relu", [False, True])
 def test_batch_norm_kernel(vln, R, D, relu):
     """vln_bn_fwd / vln_bn_bwd vs torch.nn.functional.batch_norm (+ relu) in fp64: training mode (batch statistics,
