@@ -126,6 +126,32 @@ class FollowerGrads(C.Structure):
                 + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
 
 
+BN_MLP_MAX_LAYERS = 4                 # VLN_BN_MLP_MAX_LAYERS
+
+
+class BnAffine(C.Structure):
+    _fields_ = [(n, ptr) for n in ("gamma", "beta", "run_mean", "run_var", "nbt")]
+
+
+class BnMlpLayer(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("w", "w_t", "w_f32", "b")] + [("bn", BnAffine), ("out", i32), ("pad_", i32), ("p_drop", f32),
+                ("padf_", f32), ("seed", u64), ("offset", u64)])
+
+
+class BnMlp(C.Structure):
+    _fields_ = [("R", i32), ("D0", i32), ("nl", i32), ("wtype", i32), ("training", i32), ("pad_", i32), ("eps", f32), ("momentum", f32),
+                ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr)]
+
+
+class BnMlpGradLayer(C.Structure):
+    _fields_ = [("g_w", ptr), ("g_b", ptr), ("g_gamma", ptr), ("g_beta", ptr), ("acc_w", i32), ("acc_b", i32), ("acc_bn", i32), ("pad_", i32)]
+
+
+class BnMlpGrads(C.Structure):
+    _fields_ = [("g_gamma0", ptr), ("g_beta0", ptr), ("acc0", i32), ("pad0_", i32), ("layer", BnMlpGradLayer * BN_MLP_MAX_LAYERS),
+                ("precision", i32), ("pad_", i32), ("scratch", ptr), ("scratch_floats", i64)]
+
+
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
 SIGNATURES = {
     "vln_abi_version": (i32, []),
@@ -179,6 +205,12 @@ SIGNATURES = {
     "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr, i64, ptr]),
     "vln_bn_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, ptr, i32, i32, f32, i32, i32, i32, u64, u64, f32,
                          ptr, ptr, i64, ptr]),
+    "vln_bn_mlp_saved_floats": (i64, [C.POINTER(BnMlp)]),
+    "vln_bn_mlp_out_offset": (i64, [C.POINTER(BnMlp)]),
+    "vln_bn_mlp_ws_floats": (i64, [C.POINTER(BnMlp)]),
+    "vln_bn_mlp_bwd_scratch_floats": (i64, [C.POINTER(BnMlp)]),
+    "vln_bn_mlp_fwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr]),
+    "vln_bn_mlp_bwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr, i64, C.POINTER(BnMlpGrads), ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),

@@ -1,0 +1,151 @@
+// MLPwithBN (reference units.py:210-242) forward and backward as ONE C call each: BatchNorm1d, then per hidden layer Linear,
+// BatchNorm1d, Dropout, ReLU.  The Self-Monitor agent runs it twice per decoder step (previous action [B, F], candidates
+// [B*C, F]: policy.py:146-149).  The launches are the ones `functional.BnMlpFn` used to drive from Python -- vln_bn_fwd / bwd
+// (row-chunked for the tall candidate input), the skinny GEMMs, one grouped weight-gradient and one grouped bias-gradient
+// launch -- issued here back to back with a single Python -> C crossing.
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+namespace {
+
+inline long r64(long n) { return (n + 63) & ~63L; }
+inline long lin_ws(long ws_floats, long M, long N) {
+  long cap = 16 * M * N;
+  if (cap > (1L << 24)) cap = 1L << 24;
+  return ws_floats < cap ? ws_floats : cap;
+}
+
+int check_mlp(const vln_bn_mlp* m) {
+  if (!m || m->R <= 0 || m->D0 <= 0 || m->nl <= 0 || m->nl > VLN_BN_MLP_MAX_LAYERS || (m->D0 & 3)) { set_error("bn_mlp: bad dims"); return VLN_ERR_ARG; }
+  for (int i = 0; i < m->nl; ++i)
+    if (m->layer[i].out <= 0 || (m->layer[i].out & 3) || !m->layer[i].w || !m->layer[i].w_t) { set_error("bn_mlp: bad layer %d", i); return VLN_ERR_ARG; }
+  return VLN_OK;
+}
+
+struct SavedLayout { long y0, s0, z[VLN_BN_MLP_MAX_LAYERS], s[VLN_BN_MLP_MAX_LAYERS], y[VLN_BN_MLP_MAX_LAYERS], total; };
+SavedLayout saved_layout(const vln_bn_mlp* m) {
+  SavedLayout L{};
+  long off = 0;
+  auto take = [&](long n) { long o = off; off += r64(n); return o; };
+  const long R = m->R;
+  L.y0 = take(R * m->D0); L.s0 = take(2L * m->D0);
+  for (int i = 0; i < m->nl; ++i) {
+    const long D = m->layer[i].out;
+    L.z[i] = take(R * D); L.s[i] = take(2 * D); L.y[i] = take(R * D);
+  }
+  L.total = off;
+  return L;
+}
+
+}  // namespace
+}  // namespace vln
+
+using namespace vln;
+#define RUN(x) do { int _s = (x); if (_s != VLN_OK) return _s; } while (0)
+
+extern "C" int64_t vln_bn_mlp_saved_floats(const vln_bn_mlp* m) { return check_mlp(m) == VLN_OK ? saved_layout(m).total : -1; }
+extern "C" int64_t vln_bn_mlp_out_offset(const vln_bn_mlp* m) { return check_mlp(m) == VLN_OK ? saved_layout(m).y[m->nl - 1] : -1; }
+extern "C" int64_t vln_bn_mlp_ws_floats(const vln_bn_mlp* m) {
+  if (check_mlp(m) != VLN_OK) return -1;
+  // the grouped weight-gradient launch's packed operands (both bf16 planes of dy and x in fragment order) + the slabs of its
+  // row split (gemm.hip; the same sizing as ops.WgradBatch)
+  const long MS = (m->R + 31) / 32;
+  long area = 0, dmax = m->D0, in = m->D0, tiles = 0, nk = 0;
+  for (int i = 0; i < m->nl; ++i) {
+    const long out = m->layer[i].out;
+    area += 2 * ((out + 15) / 16 + (in + 15) / 16) * MS * 1024 / 4;
+    tiles += ((out + 127) / 128) * ((in + 127) / 128);
+    nk += out * in;
+    if (out > dmax) dmax = out;
+    in = out;
+  }
+  long msplit = 1;
+  if (tiles < 256) { msplit = 256 / (tiles > 0 ? tiles : 1); if (msplit > MS / 4) msplit = MS / 4; if (msplit < 1) msplit = 1; }
+  if (msplit > 1) area += msplit * nk;
+  long n = area;
+  const long bn_part = (long)((m->R + 127) / 128) * 2 * dmax;      // chunked BatchNorm partials
+  const long slabs = 16L * m->R * dmax;                            // split-K slabs of the skinny products
+  if (bn_part > n) n = bn_part;
+  if (slabs > n) n = slabs;
+  if (n < (1L << 22)) n = 1L << 22;
+  return n;
+}
+extern "C" int64_t vln_bn_mlp_bwd_scratch_floats(const vln_bn_mlp* m) {
+  if (check_mlp(m) != VLN_OK) return -1;
+  long n = 0, in = m->D0;
+  for (int i = 0; i < m->nl; ++i) { n += r64((long)m->R * m->layer[i].out) + r64((long)m->R * in); in = m->layer[i].out; }
+  return n;
+}
+
+extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, float* saved, float* ws, int64_t ws_floats, vln_stream_t s) {
+  RUN(check_mlp(m));
+  if (!x || !saved || !ws) { set_error("vln_bn_mlp_fwd: null pointer"); return VLN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)s;
+  const SavedLayout L = saved_layout(m);
+  const int R = m->R, tr = m->training;
+  float* y = saved + L.y0;
+  float* st0 = saved + L.s0;
+  RUN(vln_bn_fwd(x, ldx, y, m->D0, m->bn0.gamma, m->bn0.beta, m->bn0.run_mean, m->bn0.run_var, tr ? m->bn0.nbt : nullptr,
+                 tr ? st0 : nullptr, tr ? st0 + m->D0 : nullptr, R, m->D0, m->eps, m->momentum, tr, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
+  int in = m->D0;
+  for (int i = 0; i < m->nl; ++i) {
+    const vln_bn_mlp_layer& l = m->layer[i];
+    float* z = saved + L.z[i];
+    float* si = saved + L.s[i];
+    float* yi = saved + L.y[i];
+    // split-K scratch bounded like ops.linear_fwd bounds it: the same K split, hence the same bits, as the operator path
+    RUN(gemm_nt(st, y, in, l.w, m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
+    const bool last = (i == m->nl - 1);
+    RUN(vln_bn_fwd(z, l.out, yi, l.out, l.bn.gamma, l.bn.beta, l.bn.run_mean, l.bn.run_var, tr ? l.bn.nbt : nullptr, tr ? si : nullptr,
+                   tr ? si + l.out : nullptr, R, l.out, m->eps, m->momentum, tr, 1, l.seed, l.offset, tr ? l.p_drop : 0.f,
+                   last ? m->row_zero : nullptr, ws, ws_floats, s));
+    y = yi; in = l.out;
+  }
+  return VLN_OK;
+}
+
+extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, const float* saved, const float* dy, int64_t lddy,
+                              float* dx, int64_t lddx, const vln_bn_mlp_grads* g, float* ws, int64_t ws_floats, vln_stream_t s) {
+  RUN(check_mlp(m));
+  if (!x || !saved || !dy || !g || !ws || !g->scratch || g->scratch_floats < vln_bn_mlp_bwd_scratch_floats(m)) {
+    set_error("vln_bn_mlp_bwd: null pointer or scratch too small");
+    return VLN_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)s;
+  const SavedLayout L = saved_layout(m);
+  const int R = m->R, tr = m->training, nl = m->nl;
+  float* sc = g->scratch;
+  long so = 0;
+  auto take = [&](long n) { float* p = sc + so; so += r64(n); return p; };
+  vln_wgrad_job wj[VLN_BN_MLP_MAX_LAYERS];
+  vln_colsum_job cj[VLN_BN_MLP_MAX_LAYERS];
+  int nw = 0, nc = 0;
+  const float* gcur = dy;
+  long ldg = lddy;
+  for (int i = nl - 1; i >= 0; --i) {
+    const vln_bn_mlp_layer& l = m->layer[i];
+    const int in = (i == 0) ? m->D0 : m->layer[i - 1].out;
+    const float* z = saved + L.z[i];
+    const float* si = saved + L.s[i];
+    const float* yi = saved + L.y[i];
+    const float* yprev = (i == 0) ? saved + L.y0 : saved + L.y[i - 1];
+    float* dz = take((long)R * l.out);
+    const bool last = (i == nl - 1);
+    RUN(vln_bn_bwd(z, l.out, gcur, ldg, yi, l.out, l.bn.gamma, tr ? si : l.bn.run_mean, tr ? si + l.out : l.bn.run_var, dz, l.out,
+                   g->layer[i].g_gamma, g->layer[i].g_beta, R, l.out, m->eps, tr, 1, g->layer[i].acc_bn, l.seed, l.offset,
+                   tr ? l.p_drop : 0.f, last ? m->row_zero : nullptr, ws, ws_floats, s));
+    if (g->layer[i].g_w) wj[nw++] = vln_wgrad_job{dz, yprev, g->layer[i].g_w, l.out, in, in, l.out, in, g->layer[i].acc_w, 0};
+    if (g->layer[i].g_b && l.b) cj[nc++] = vln_colsum_job{dz, g->layer[i].g_b, nullptr, l.out, l.out, g->layer[i].acc_b};
+    float* gi = take((long)R * in);
+    RUN(gemm_nt(st, dz, l.out, l.w_t, m->wtype, l.out, gi, in, R, in, l.out, nullptr, ACT_NONE, ws, lin_ws(ws_floats, R, in), nullptr));
+    gcur = gi; ldg = in;
+  }
+  // Mt is the same for every product of the call: one grouped launch each for weights and biases
+  if (nw) RUN(wgrad_grouped(st, wj, nw, R, g->precision, ws, ws_floats));
+  if (nc) RUN(colsum_grouped(st, cj, nc, R, ws, ws_floats));
+  const float* s0 = saved + L.s0;
+  RUN(vln_bn_bwd(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
+                 g->g_gamma0, g->g_beta0, R, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
+  return VLN_OK;
+}

@@ -354,6 +354,95 @@ class BnMlpFn(torch.autograd.Function):
     ride in `bufs` and are updated in place."""
 
     @staticmethod
+    def _c_desc(x, rz, cfg, bufs, tensors):
+        """vln_bn_mlp filled from the module's tensors (+ the objects that keep its pointers alive)."""
+        training, eps, momentum, dtype, drops = cfg
+        nl = (len(tensors) - 2) // 4
+        m = _lib.BnMlp()
+        m.R, m.D0, m.nl = x.shape[0], x.shape[1], nl
+        m.wtype = ops.F32 if dtype == torch.float32 else ops.BF16
+        m.training, m.eps, m.momentum = int(training), eps, momentum
+        keep = []
+
+        def affine(a, w, b, buf):
+            a.gamma, a.beta = _p(w), _p(b)
+            a.run_mean, a.run_var, a.nbt = _p(buf[0]), _p(buf[1]), _p(buf[2])
+        affine(m.bn0, tensors[0], tensors[1], bufs[0])
+        for i in range(nl):
+            W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
+            wn, wt = SHADOWS.get(W, "n", dtype), SHADOWS.get(W, "t", dtype)
+            keep += [wn, wt]
+            l = m.layer[i]
+            l.w, l.w_t, l.w_f32, l.b = wn.data_ptr(), wt.data_ptr(), W.data_ptr(), _p(b)
+            affine(l.bn, gw, gb, bufs[1 + i])
+            l.out = W.shape[0]
+            l.p_drop, l.seed, l.offset = drops[i]
+        m.row_zero = _p(rz)
+        return m, keep
+
+    @staticmethod
+    def _forward_c(ctx, x, rz, cfg, bufs, tensors):
+        lib = _lib.load()
+        m, keep = BnMlpFn._c_desc(x, rz, cfg, bufs, tensors)
+        dev = x.device
+        saved = ops.empty(lib.vln_bn_mlp_saved_floats(m), dtype=torch.float32, device=dev)
+        ws = ops.workspace(dev, lib.vln_bn_mlp_ws_floats(m))
+        rc = lib.vln_bn_mlp_fwd(m, x.data_ptr(), x.stride(0), saved.data_ptr(), ws.data_ptr(), ws.numel(), _lib.raw_stream())
+        if rc:
+            _lib.check(rc, "vln_bn_mlp_fwd")
+        nl = m.nl
+        off = lib.vln_bn_mlp_out_offset(m)
+        out_dim = m.layer[nl - 1].out
+        ctx.cfg, ctx.bufs, ctx.nl, ctx.rz, ctx.c_call = cfg, bufs, nl, rz, True
+        ctx.save_for_backward(x, saved, *tensors)
+        # the output is the last block of `saved` (which the backward reads): the caller gets an alias, the ctx keeps the base
+        return saved[off:off + x.shape[0] * out_dim].view(x.shape[0], out_dim).detach()
+
+    @staticmethod
+    def _backward_c(ctx, dy):
+        lib = _lib.load()
+        x, saved = ctx.saved_tensors[:2]
+        tensors = list(ctx.saved_tensors[2:])
+        cfg = ctx.cfg
+        dtype = cfg[3]
+        m, keep = BnMlpFn._c_desc(x, ctx.rz, cfg, ctx.bufs, tensors)
+        dev = x.device
+        dy = dy.contiguous()
+        g = _lib.BnMlpGrads()
+        grads = [None] * len(tensors)
+
+        def sink(i):
+            t, acc = _gsink(tensors[i])
+            grads[i] = _gret(t, acc)
+            return t, acc
+        (g0, a0), (b0, ab0) = sink(0), sink(1)
+        if a0 != ab0:                                         # one accumulate flag per BatchNorm: both in place or neither
+            g0, b0 = torch.empty_like(tensors[0]), torch.empty_like(tensors[1]); grads[0], grads[1] = g0, b0; a0 = False
+        g.g_gamma0, g.g_beta0, g.acc0 = g0.data_ptr(), b0.data_ptr(), int(a0)
+        keepg = [g0, b0]
+        for i in range(ctx.nl):
+            W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
+            gl = g.layer[i]
+            t, acc = sink(2 + 4 * i); gl.g_w, gl.acc_w = t.data_ptr(), int(acc); keepg.append(t)
+            if b is not None:
+                t, acc = sink(3 + 4 * i); gl.g_b, gl.acc_b = t.data_ptr(), int(acc); keepg.append(t)
+            (tg, ag), (tb, ab) = sink(4 + 4 * i), sink(5 + 4 * i)
+            if ag != ab:
+                tg, tb = torch.empty_like(gw), torch.empty_like(gb); grads[4 + 4 * i], grads[5 + 4 * i] = tg, tb; ag = False
+            gl.g_gamma, gl.g_beta, gl.acc_bn = tg.data_ptr(), tb.data_ptr(), int(ag)
+            keepg += [tg, tb]
+        g.precision = ops.wgrad_precision(dtype != torch.float32)
+        scratch = ops.empty(lib.vln_bn_mlp_bwd_scratch_floats(m), dtype=torch.float32, device=dev)
+        g.scratch, g.scratch_floats = scratch.data_ptr(), scratch.numel()
+        dx = ops.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws = ops.workspace(dev, lib.vln_bn_mlp_ws_floats(m))
+        rc = lib.vln_bn_mlp_bwd(m, x.data_ptr(), x.stride(0), saved.data_ptr(), dy.data_ptr(), dy.stride(0), _p(dx),
+                                0 if dx is None else dx.stride(0), g, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+        if rc:
+            _lib.check(rc, "vln_bn_mlp_bwd")
+        return (dx, None, None, None) + tuple(grads)
+
+    @staticmethod
     def forward(ctx, x, row_zero, cfg, bufs, *tensors):
         training, eps, momentum, dtype, drops = cfg
         lib = _lib.load()
@@ -368,6 +457,9 @@ class BnMlpFn(torch.autograd.Function):
         if row_zero is not None:
             rz = row_zero.contiguous()
             rz = rz.view(torch.uint8) if rz.dtype == torch.bool else rz.to(torch.uint8)
+        ctx.c_call = False
+        if _BN_MLP_C_CALL[0] and nl <= _lib.BN_MLP_MAX_LAYERS and all(tensors[3 + 4 * i] is not None for i in range(nl)):
+            return BnMlpFn._forward_c(ctx, x, rz, cfg, bufs, tensors)
 
         def bn(inp, w, b, buf, relu, drop, rzp):
             D = inp.shape[1]
@@ -399,6 +491,8 @@ class BnMlpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.c_call:
+            return BnMlpFn._backward_c(ctx, dy)
         training, eps, momentum, dtype, drops = ctx.cfg
         lib = _lib.load()
         st_ = _lib.raw_stream()
@@ -455,6 +549,14 @@ class BnMlpFn(torch.autograd.Function):
         wb.run(); cb.run()
         dx = bn_bwd(x, g, None, tensors[0], s0, bufs[0], False, (0.0, 0, 0), None, ctx.needs_input_grad[0], 0)
         return (dx, None, None, None) + tuple(grads)
+
+
+_BN_MLP_C_CALL = [True]
+
+
+def set_bn_mlp_c_call(on: bool):
+    """A/B: BnMlpFn as one C call each way (vln_bn_mlp_fwd / bwd, the default) or its launches driven from Python."""
+    _BN_MLP_C_CALL[0] = bool(on)
 
 
 def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors):

@@ -369,6 +369,42 @@ int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const
                int accumulate, uint64_t seed, uint64_t offset, float p_drop, const uint8_t* row_zero,
                float* ws /*nullable, as in vln_bn_fwd*/, int64_t ws_floats, vln_stream_t s);
 
+/* MLPwithBN (units.py:210-242: BatchNorm1d, then per hidden layer Linear, BatchNorm1d, Dropout, ReLU -- the Self-Monitor agent's
+ * proj_navigable_mlp, applied to the previous action [B, F] and to the candidates [B*C, F] every step, policy.py:146-149) as ONE
+ * C call each way (the 5 forward / 7 backward launcher calls of a two-layer MLP used to be one ctypes call each, ~24 per decoder
+ * step: the Self-Monitor iteration was bound by that Python).  Same launches, same numbers as the vln_bn_* / vln_linear_*
+ * sequence.  `saved` (vln_bn_mlp_saved_floats) receives every intermediate the backward reads; the output y [R, out of the last
+ * layer] is the LAST block of `saved` (vln_bn_mlp_out_offset).  row_zero [R] (nullable) zeroes output rows (padded
+ * candidate slots, policy.py:148-149).  Backward: dx nullable (features carry no gradient); parameter gradients are written to
+ * (acc = 0) or accumulated into (acc = 1) the given buffers; all weight gradients in one grouped launch, all bias gradients in
+ * another. */
+#define VLN_BN_MLP_MAX_LAYERS 4
+typedef struct vln_bn_affine { const float* gamma; const float* beta; float* run_mean; float* run_var; int64_t* nbt; } vln_bn_affine;
+typedef struct vln_bn_mlp_layer {
+  const void* w; const void* w_t; const float* w_f32; const float* b;   /* Linear [out, in]: streamed shadow, its transpose, fp32 master (unused), bias (nullable) */
+  vln_bn_affine bn; int32_t out, pad_; float p_drop, padf_; uint64_t seed, offset;
+} vln_bn_mlp_layer;
+typedef struct vln_bn_mlp {
+  int32_t R, D0, nl, wtype, training, pad_; float eps, momentum;
+  vln_bn_affine bn0;
+  vln_bn_mlp_layer layer[VLN_BN_MLP_MAX_LAYERS];
+  const uint8_t* row_zero;
+} vln_bn_mlp;
+typedef struct vln_bn_mlp_grad_layer { float* g_w; float* g_b; float* g_gamma; float* g_beta; int32_t acc_w, acc_b, acc_bn, pad_; } vln_bn_mlp_grad_layer;
+typedef struct vln_bn_mlp_grads {
+  float* g_gamma0; float* g_beta0; int32_t acc0, pad0_;
+  vln_bn_mlp_grad_layer layer[VLN_BN_MLP_MAX_LAYERS];
+  int32_t precision, pad_;          /* weight gradients: 0 fp32, 1 split bf16, 2 plain bf16 (vln_wgrad_grouped) */
+  float* scratch; int64_t scratch_floats;     /* vln_bn_mlp_bwd_scratch_floats */
+} vln_bn_mlp_grads;
+int64_t vln_bn_mlp_saved_floats(const vln_bn_mlp* m);
+int64_t vln_bn_mlp_out_offset(const vln_bn_mlp* m);
+int64_t vln_bn_mlp_ws_floats(const vln_bn_mlp* m);            /* forward and backward workspace (split-K slabs, chunked-BN partials) */
+int64_t vln_bn_mlp_bwd_scratch_floats(const vln_bn_mlp* m);
+int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, float* saved, float* ws, int64_t ws_floats, vln_stream_t s);
+int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, const float* saved, const float* dy, int64_t lddy,
+                   float* dx /*nullable*/, int64_t lddx, const vln_bn_mlp_grads* g, float* ws, int64_t ws_floats, vln_stream_t s);
+
 /* A2C sweep of the EnvDrop rollout (envdrop.py:235-264) as one launch.  All step tensors are stacked [T,B]:
  * logp = log pi(a_t), ent = entropies (NULL with ent_coef unused: feedback != "sample"), val = critic values (with
  * grad), reward, mask (1 = episode still running at t), last_value [B] (detached), ended [B].

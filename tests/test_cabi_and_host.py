@@ -56,7 +56,7 @@ def test_struct_layouts_match_header(vln):
             if not decl:
                 continue
             names = re.sub(r"^(const\s+)?[a-z0-9_]+\s*\**", "", decl, count=1)
-            out += [re.sub(r"\[\d+\]$", "", n.strip().lstrip("*").strip()) for n in names.split(",")]
+            out += [re.sub(r"\[\w+\]$", "", n.strip().lstrip("*").strip()) for n in names.split(",")]
         return out
 
     L = vln._lib
@@ -72,6 +72,12 @@ def test_struct_layouts_match_header(vln):
     assert fields("vln_follower_weights") == [f for f, _ in L.FollowerWeights._fields_]
     assert fields("vln_follower_step") == [f for f, _ in L.FollowerStep._fields_]
     assert fields("vln_follower_grads") == [f for f, _ in L.FollowerGrads._fields_]
+    assert fields("vln_bn_affine") == [f for f, _ in L.BnAffine._fields_]
+    assert fields("vln_bn_mlp_layer") == [f for f, _ in L.BnMlpLayer._fields_]
+    assert fields("vln_bn_mlp") == [f for f, _ in L.BnMlp._fields_]
+    assert fields("vln_bn_mlp_grad_layer") == [f for f, _ in L.BnMlpGradLayer._fields_]
+    assert fields("vln_bn_mlp_grads") == [f for f, _ in L.BnMlpGrads._fields_]
+    assert fields("vln_cat_step") == [f for f, _ in L.CatStep._fields_]
 
 
 def test_modules_fail_loudly_without_gpu(vln):

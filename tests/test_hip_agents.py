@@ -469,3 +469,47 @@ def test_speaker_loop_sampling_vs_oracle(vln):
     (-(logp * 0.5).sum() - 0.01 * ent.sum() + hid.sum() * 1e-3).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in spk.decoder.projection.parameters())
     assert spk.encoder.lstm.rnn.weight_ih_l0.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,train", [(1024, True), (128, True), (1000, False)])
+def test_bn_mlp_c_call_equals_python_driven_launches(vln, dtype, R, train):
+    """MLPwithBN (units.py:210-242) as ONE C call each way (vln_bn_mlp_fwd / bwd) against the same launches driven from Python
+    (functional.set_bn_mlp_c_call(False)): output, running statistics, counters, input gradient and every parameter gradient,
+    with dropout and padded-row zeroing on, tall (row-chunked BatchNorm) and short inputs, training and eval."""
+    from vln_amd import functional as Fh
+    from vln_amd.decoders import MLPwithBN
+    g = torch.Generator().manual_seed(R)
+    F = 64 + 128
+    x0 = (torch.randn(R, F, generator=g).abs() * 0.5).to(DEV)
+    rz = (torch.rand(R, generator=g) < 0.2).to(DEV)
+    r = torch.randn(R, 256, generator=g).to(DEV)
+    res = []
+    try:
+        for c_call in (True, False):
+            Fh.set_bn_mlp_c_call(c_call)
+            torch.manual_seed(3)
+            mlp = MLPwithBN(F, (32, 256), dropout=0.5, use_bn=True, relu=True).to(DEV)
+            for m in mlp.modules():
+                if hasattr(m, "compute_dtype"):
+                    m.compute_dtype = dtype
+            mlp.train(train)
+            out = []
+            for it in range(2):                      # second pass: gradients accumulate, running statistics move again
+                x = x0.clone().requires_grad_(True)
+                y = mlp(x, row_zero=rz)
+                (y * r).sum().backward()
+                out.append((y.detach().clone(), x.grad.clone()))
+            res.append((out, {n: p.grad.clone() for n, p in mlp.named_parameters()},
+                        {n: b.clone() for n, b in mlp.named_buffers()}))
+    finally:
+        Fh.set_bn_mlp_c_call(True)
+    for (ya, dxa), (yb, dxb) in zip(res[0][0], res[1][0]):
+        check(ya, yb, 1e-6, "y"); check(dxa, dxb, 2e-5, "dx")
+    for n in res[0][1]:
+        check(res[0][1][n], res[1][1][n], 2e-5 if dtype == torch.float32 else 8e-3, f"grad[{n}]")
+    for n in res[0][2]:
+        if res[0][2][n].dtype.is_floating_point:
+            check(res[0][2][n], res[1][2][n], 1e-6, f"buffer[{n}]")
+        else:
+            assert torch.equal(res[0][2][n], res[1][2][n])
