@@ -189,6 +189,95 @@ def test_two_rank_bucket_allreduce_equals_big_batch(overlap):
     assert torch.equal(got[0][1], got[1][1])                 # replicas agree bit-for-bit after the all-reduce
 
 
+def _mixed_problem():
+    """BASELINE config 3 in miniature: EnvDrop IL + A2C mixed loss (envdrop.py:173-195,235-268) on the oracle.  Returns
+    (params, parts(rows) -> (summed CE, summed A2C terms, running (step, episode) pairs) over those episodes)."""
+    from oracle import torch_port as O
+    P, _, B = _problem()
+    g = torch.Generator().manual_seed(12)
+    H = 16
+    P = dict(P, **{"critic.w": torch.randn(H, generator=g).double() * 0.3})
+    g2 = torch.Generator().manual_seed(13)
+    ANG, V, C, L, IMG = 8, 4, 4, 7, 24
+    F = IMG + ANG
+    T = 3
+    data = dict(a=torch.randn(B, ANG, generator=g2).double(), img=torch.randn(T, B, V, F, generator=g2).double().abs(),
+                cand=torch.randn(T, B, C, F, generator=g2).double().abs(), h=torch.randn(B, H, generator=g2).double(),
+                c=torch.randn(B, H, generator=g2).double(), ctx=torch.randn(B, L, H, generator=g2).double(),
+                tgt=torch.tensor([[0, 1, 2, 3, 1, -1], [1, 1, 0, 2, 3, 0], [2, -1, 1, 0, 0, 3]]),
+                act=torch.tensor([[1, 0, 3, 2, 1, 0], [0, 2, 2, 1, 3, 3], [3, 1, 0, 0, 2, 1]]),
+                rew=torch.randn(T, B, generator=g2).sign().double(),
+                lens=torch.tensor([3, 2, 3, 1, 2, 3]))
+
+    def parts(Pm, rows):
+        r = torch.tensor(rows)
+        Pd = {k: v for k, v in Pm.items() if k != "critic.w"}
+        ht, c = data["h"][r], data["c"][r]
+        ce, lps, ens, vals = 0.0, [], [], []
+        for t in range(T):
+            lo, (h1, c), ht, _ = O.envdrop_step(Pd, data["a"][r], data["img"][t][r], data["cand"][t][r], ht, c, data["ctx"][r], None)
+            ce = ce + O.masked_cross_entropy(lo, data["tgt"][t][r], None, "sum")
+            dist_ = torch.distributions.Categorical(logits=lo)
+            lps.append(dist_.log_prob(data["act"][t][r])); ens.append(dist_.entropy())
+            vals.append(h1 @ Pm["critic.w"])
+        masks = [(t < data["lens"][r]) for t in range(T)]
+        ended = data["lens"][r] < T
+        a2c, total = O.a2c_loss(lps, ens, vals, [data["rew"][t][r] for t in range(T)], masks, vals[-1].detach(), ended, 0.9, "none")
+        return ce, a2c, total
+
+    return P, parts, B
+
+
+def _worker_mixed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, parts, B = _mixed_problem()
+        params = [torch.nn.Parameter(v.clone()) for v in P.values()]
+        Pm = dict(zip(P.keys(), params))
+        bucket = vln.dp.GradBucket(params)
+        bucket.zero()
+        rows = vln.dp.stride_shard(B, rank, world)
+        ce, a2c, total = parts(Pm, rows)
+        # the 'total' normaliser of the RL loss counts running (step, episode) pairs of the WHOLE batch (envdrop.py:262-264):
+        # every rank divides its own sum by the global count, the IL term by the global batch (envdrop.py:268)
+        total_g = vln.dp.allreduce_scalar(torch.tensor([float(total)], dtype=torch.float64))
+        loss = ce * 0.2 / B + a2c / total_g
+        loss.backward()
+        bucket.allreduce()
+        q.put((rank, bucket.flat.clone(), float(total_g), rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_il_plus_a2c_equals_big_batch():
+    """BASELINE config 3 (EnvDrop IL + RL mixed loss, data-parallel): per-rank sums normalised by the GLOBAL batch and the
+    GLOBAL running-pair count + one flat all-reduce == the single-process big-batch gradient (critic included)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_mixed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    P, parts, B = _mixed_problem()
+    params = [v.clone().requires_grad_(True) for v in P.values()]
+    Pm = dict(zip(P.keys(), params))
+    ce, a2c, total = parts(Pm, list(range(B)))
+    (ce * 0.2 / B + a2c / total).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in params])
+    for rank, flat, total_g, rows in got:
+        assert total_g == total
+        assert torch.allclose(flat, ref, rtol=1e-10, atol=1e-12), f"rank {rank}: DP gradient != big-batch gradient"
+    assert torch.equal(got[0][1], got[1][1])
+
+
 def test_self_pace_helpers_without_a_group():
     sys.path.insert(0, ROOT)
     import vln_amd as vln
