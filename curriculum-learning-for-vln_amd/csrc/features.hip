@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void gather_step_kernel(GatherStepArgs a) { ga
 // The same gather + the decoder step's prep work (act embedding, h_tilde_prev copy / dropout: envdrop_prep.h) as the LAST
 // `nprep` workgroups of the launch: both only depend on what the previous step left behind, and as two launches the second
 // one was ~6.5 us of pure dependent-launch latency per decoder step.
-template <typename TT>
+template <typename TT, int kGatherRows>
 __global__ __launch_bounds__(256) void gather_step_prep_kernel(GatherStepArgs a, PrepArgs p, int nrows, int nprep) {
-  if ((int)blockIdx.x < nrows) gather_step_row<TT>(a, (int)blockIdx.x, (int)threadIdx.x);
-  else envdrop_prep_body(p, (long)((int)blockIdx.x - nrows) * 256 + threadIdx.x, (long)nprep * 256);
+  const int nrb = (nrows + kGatherRows - 1) / kGatherRows;
+  if ((int)blockIdx.x < nrb) gather_step_rows<TT, kGatherRows>(a, (int)blockIdx.x * kGatherRows, nrows, (int)threadIdx.x);
+  else envdrop_prep_body(p, (long)((int)blockIdx.x - nrb) * 256 + threadIdx.x, (long)nprep * 256);
 }
 
 // chained forms (chain.hip): false when no chain is being recorded
@@ -118,8 +119,10 @@ int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const P
   const int nprep = (int)nb;
   // chained step: the prep work is its own (first) stage and the gather a stage NOTHING waits for until the visual
   // attention needs the rows -- the caller orders the stages (envdrop.hip)
-  if (ttype == VLN_BF16) VLN_LAUNCH(gather_step_prep_kernel<bf16_raw>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
-  else VLN_LAUNCH(gather_step_prep_kernel<float>, dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  // one table row per block: 2 / 4 rows per block with their loads in flight together measured SLOWER (1.815 / 1.855 vs 1.796 ms
+  // per iteration, profiles/round2_notes.md) -- thousands of small workgroups hide the cold HBM accesses better than fat ones
+  if (ttype == VLN_BF16) VLN_LAUNCH((gather_step_prep_kernel<bf16_raw, 1>), dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
+  else VLN_LAUNCH((gather_step_prep_kernel<float, 1>), dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);
   VLN_CHECK_LAUNCH("gather_step_prep");
   return VLN_OK;
 }

@@ -6,75 +6,113 @@
 namespace vln {
 
 // ---- one launch per decoder step: panorama rows + candidate rows ------------------------------------------------
-// Same outputs, same Philox indexing as the two kernels above (so vln_dropout_mask exports the same masks); a thread
-// handles 8 consecutive elements (one 16-byte load from a bf16 table), a row of 2176 is one pass of 272 threads.
-template <typename TT>
-__device__ __forceinline__ void gather_step_row(const GatherStepArgs& a, int r, int tid) {
+// Same outputs, same Philox indexing as the two kernels above (so vln_dropout_mask exports the same masks).  A 256-thread
+// block takes RPB consecutive output rows; a thread handles 8 consecutive image elements of each (one 16-byte load from a
+// bf16 table: 2048 elements = exactly one pass of the block) with the loads of all RPB rows in flight together -- the
+// rows are scattered over a 1.5 GB table, every one is a cold HBM access behind an index lookup -- and the first ANG / 8
+// threads also write the row's angle columns (a copy for panorama rows, sin / cos of the heading for candidates).
+template <typename TT, int RPB>
+__device__ __forceinline__ void gather_step_rows(const GatherStepArgs& a, int r0, int nrows, int tid) {
   const int F = a.IMG + a.ANG, IMG = a.IMG;
   const TT* table = reinterpret_cast<const TT*>(a.table);
-  const bool pano = r < a.B * a.V;
-  const TT* src; float* dst; bf16_raw* dlp; DropSpec dr;
-  const float* ang = nullptr;
-  float sh = 0.f, ch = 0.f, se = 0.f, ce = 0.f;
-  bool empty = false;
-  if (pano) {
-    const int b = r / a.V, v = r % a.V;
-    src = table + ((long)a.rows[b] * a.V + v) * IMG;
-    ang = a.angle_table + ((long)a.view_index[b] * a.V + v) * a.ANG;
-    dst = a.out ? a.out + (long)r * F : nullptr;
-    dlp = a.out_lp ? a.out_lp + (long)r * F : nullptr;
-    dr = a.dr_pano;
-  } else {
-    r -= a.B * a.V;
-    const long row = a.crows[r];
-    empty = row < 0;                      // STOP slot / padding: all-zero feature (base.py:152-153)
-    if (!empty) { sh = sinf(a.heading[r]); ch = cosf(a.heading[r]); se = sinf(a.elevation[r]); ce = cosf(a.elevation[r]); }
-    src = empty ? table : table + (row * a.V + a.cviews[r]) * IMG;
-    dst = a.cout ? a.cout + (long)r * F : nullptr;
-    dlp = a.cout_lp ? a.cout_lp + (long)r * F : nullptr;
-    dr = a.dr_cand;
-  }
-  const int q = a.ANG >> 2;
-  for (int c = tid * 8; c < F; c += 256 * 8) {       // IMG % 8 == 0, ANG % 8 == 0: a group never straddles
-    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!empty) {
-      if (c < IMG) {
-        if constexpr (sizeof(TT) == 2) Elt<bf16_raw>::ld16(reinterpret_cast<const bf16_raw*>(src) + c, x);
-        else {
-          const float4 t0 = *reinterpret_cast<const float4*>(src + c), t1 = *reinterpret_cast<const float4*>(src + c + 4);
-          x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-        }
-        if (dr.p > 0.f) {
-          float m[4];
-          const uint32_t i4 = (uint32_t)(((long)r * IMG + c) >> 2);
-          dropout_scale4(dr.seed, dr.off(), i4, dr.p, m);
-          x[0] *= m[0]; x[1] *= m[1]; x[2] *= m[2]; x[3] *= m[3];
-          dropout_scale4(dr.seed, dr.off(), i4 + 1, dr.p, m);
-          x[4] *= m[0]; x[5] *= m[1]; x[6] *= m[2]; x[7] *= m[3];
-        }
-      } else if (pano) {
-        const float4 t0 = *reinterpret_cast<const float4*>(ang + (c - IMG)), t1 = *reinterpret_cast<const float4*>(ang + (c - IMG) + 4);
-        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-      } else {
+  const int npano = a.B * a.V;
+  const TT* src[RPB]; float* dst[RPB]; bf16_raw* dlp[RPB]; bool pano[RPB], empty[RPB], live[RPB]; int rr[RPB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int g = (c - IMG + j) / q;
-          x[j] = g == 0 ? sh : (g == 1 ? ch : (g == 2 ? se : ce));
-        }
-      }
+  for (int k = 0; k < RPB; ++k) {
+    int r = r0 + k;
+    live[k] = r < nrows;
+    if (!live[k]) r = nrows - 1;
+    pano[k] = r < npano;
+    if (pano[k]) {
+      const int b = r / a.V, v = r % a.V;
+      src[k] = table + ((long)a.rows[b] * a.V + v) * IMG;
+      dst[k] = a.out ? a.out + (long)r * F : nullptr;
+      dlp[k] = a.out_lp ? a.out_lp + (long)r * F : nullptr;
+      empty[k] = false;
+      rr[k] = r;
+    } else {
+      const int rc = r - npano;
+      const long row = a.crows[rc];
+      empty[k] = row < 0;                      // STOP slot / padding: all-zero feature (base.py:152-153)
+      src[k] = empty[k] ? table : table + (row * a.V + a.cviews[rc]) * IMG;
+      dst[k] = a.cout ? a.cout + (long)rc * F : nullptr;
+      dlp[k] = a.cout_lp ? a.cout_lp + (long)rc * F : nullptr;
+      rr[k] = rc;
     }
-    if (dst) {
-      *reinterpret_cast<float4*>(dst + c) = make_float4(x[0], x[1], x[2], x[3]);
-      *reinterpret_cast<float4*>(dst + c + 4) = make_float4(x[4], x[5], x[6], x[7]);
+  }
+  auto store8 = [&](int k, int c, const float (&x)[8]) {
+    if (dst[k]) {
+      *reinterpret_cast<float4*>(dst[k] + c) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4*>(dst[k] + c + 4) = make_float4(x[4], x[5], x[6], x[7]);
     }
-    if (dlp) {
+    if (dlp[k]) {
       uint4 v;
       v.x = (uint32_t)f32_to_bf16_bits(x[0]) | ((uint32_t)f32_to_bf16_bits(x[1]) << 16);
       v.y = (uint32_t)f32_to_bf16_bits(x[2]) | ((uint32_t)f32_to_bf16_bits(x[3]) << 16);
       v.z = (uint32_t)f32_to_bf16_bits(x[4]) | ((uint32_t)f32_to_bf16_bits(x[5]) << 16);
       v.w = (uint32_t)f32_to_bf16_bits(x[6]) | ((uint32_t)f32_to_bf16_bits(x[7]) << 16);
-      *reinterpret_cast<uint4*>(dlp + c) = v;
+      *reinterpret_cast<uint4*>(dlp[k] + c) = v;
+    }
+  };
+  // image columns
+  for (int c = tid * 8; c < IMG; c += 256 * 8) {                 // IMG % 8 == 0
+    float x[RPB][8];
+#pragma unroll
+    for (int k = 0; k < RPB; ++k) {       // every row's load goes out before any is used: unconditional (an empty slot reads table row 0)
+      if constexpr (sizeof(TT) == 2) {
+        Elt<bf16_raw>::ld16(reinterpret_cast<const bf16_raw*>(src[k]) + c, x[k]);
+      } else {
+        const float4 t0 = *reinterpret_cast<const float4*>(src[k] + c), t1 = *reinterpret_cast<const float4*>(src[k] + c + 4);
+        x[k][0] = t0.x; x[k][1] = t0.y; x[k][2] = t0.z; x[k][3] = t0.w; x[k][4] = t1.x; x[k][5] = t1.y; x[k][6] = t1.z; x[k][7] = t1.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPB; ++k)
+      if (empty[k]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[k][j] = 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < RPB; ++k) {
+      if (!live[k]) continue;
+      const DropSpec& dr = pano[k] ? a.dr_pano : a.dr_cand;
+      if (!empty[k] && dr.p > 0.f) {
+        float m[4];
+        const uint32_t i4 = (uint32_t)(((long)rr[k] * IMG + c) >> 2);
+        dropout_scale4(dr.seed, dr.off(), i4, dr.p, m);
+        x[k][0] *= m[0]; x[k][1] *= m[1]; x[k][2] *= m[2]; x[k][3] *= m[3];
+        dropout_scale4(dr.seed, dr.off(), i4 + 1, dr.p, m);
+        x[k][4] *= m[0]; x[k][5] *= m[1]; x[k][6] *= m[2]; x[k][7] *= m[3];
+      }
+      store8(k, c, x[k]);
     }
   }
+  // angle columns (ANG % 8 == 0): a handful of threads per row
+  const int q = a.ANG >> 2;
+  for (int ca = tid * 8; ca < a.ANG; ca += 256 * 8) {
+#pragma unroll
+    for (int k = 0; k < RPB; ++k) {
+      if (!live[k]) continue;
+      float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (pano[k]) {
+        const int b = rr[k] / a.V, v = rr[k] % a.V;
+        const float* ang = a.angle_table + ((long)a.view_index[b] * a.V + v) * a.ANG;
+        const float4 t0 = *reinterpret_cast<const float4*>(ang + ca), t1 = *reinterpret_cast<const float4*>(ang + ca + 4);
+        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+      } else if (!empty[k]) {
+        const float sh = sinf(a.heading[rr[k]]), ch = cosf(a.heading[rr[k]]), se = sinf(a.elevation[rr[k]]), ce = cosf(a.elevation[rr[k]]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int g = (ca + j) / q;
+          x[j] = g == 0 ? sh : (g == 1 ? ch : (g == 2 ? se : ce));
+        }
+      }
+      store8(k, IMG + ca, x);
+    }
+  }
+}
+template <typename TT>
+__device__ __forceinline__ void gather_step_row(const GatherStepArgs& a, int r, int tid) {
+  gather_step_rows<TT, 1>(a, r, a.B * a.V + a.B * a.C, tid);
 }
 }  // namespace vln
