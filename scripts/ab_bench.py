@@ -24,7 +24,7 @@ VARIANTS = {
     "lstm_dispatch_order_map": {7: 1},
     "attn_two_kernels": {4: 1},
     "wgrad_fp32_exact": {6: 1},
-    "n16_upto_k1024": {3: 1024},
+    "overlap_wgrads": {},
     "gemm_split_target512": {0: 512},
     "gemm_split_target384": {0: 384},
     "gemm_split_target192": {0: 192},
