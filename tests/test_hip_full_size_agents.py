@@ -230,6 +230,13 @@ def test_follower_operator_path_full_size(vln, cdt):
     _follower_full(vln, cdt, train=True, B=16, fused=False)
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_follower_cfg0_size(vln, cdt):
+    """BASELINE config 0 (the reference's own CPU-runnable case): Follower step forward + backward at batch 4, 36 x (2048 + 128)
+    view features, 20-token instructions -- a batch that is a quarter of the 16-row MFMA block."""
+    _follower_full(vln, cdt, B=4, L=20, C=5, T=2)
+
+
 def test_batchnorm_refuses_shapes_the_kernel_does_not_take(vln):
     """No silent torch fallback in the product path (round-1 verdict): the BatchNorm layer raises instead."""
     from vln_amd.decoders import _HipBatchNorm1d
