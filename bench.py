@@ -642,7 +642,8 @@ def main():
         torch.distributed.barrier()
 
     # Secondary, driver-timed numbers in the same line (never `value`): the fp32 path, the PCIe-inclusive path, and the two
-    # other single-GPU workloads BASELINE.json configures (IL + A2C at the reference's episode cap 35; Self-Monitor B=128).
+    # other single-GPU workloads BASELINE.json configures (IL + A2C at the reference's episode cap 35; Self-Monitor B=128;
+    # the Speaker-Follower agent of config 0 at a GPU batch).
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = {}
@@ -650,7 +651,8 @@ def main():
         for name, fn in (("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args)),
                          ("features_host_fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "host", args)),
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
-                         ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store))):
+                         ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store)),
+                         ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store))):
             t1 = time.perf_counter()
             try:
                 secondary[name] = fn()
@@ -756,7 +758,7 @@ def secondary_agents(dev, args, which, store):
     W.configure(steps=12, warmup=5, dtype=args.dtype, arena=False, device=dev)
     W.vln.functional.set_grad_in_place(True)
     try:
-        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else W.run_monitor()
+        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else (W.run_follower() if which == "follower" else W.run_monitor())
     finally:
         W.vln.functional.set_grad_in_place(False)
     return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"]}
