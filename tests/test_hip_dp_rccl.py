@@ -1,0 +1,57 @@
+"""GPU: the data-parallel exchange on the real backend.  A one-GPU box cannot run two RCCL ranks (one device per rank), so this
+runs the product's collective path -- `dp.BucketReducer` through `optim.FusedRMSprop.start_allreduce / allreduce`,
+`dp.allreduce_scalar`, `dp.gather_item_losses` -- on a ONE-rank `nccl` (= RCCL) group in a child process: library load,
+communicator creation with `device_id`, asynchronous work objects and their stream ordering, with the world-size gate forced
+open.  The two-rank numerics are covered over gloo (tests/test_dp_gloo.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["VLN_ROOT"])
+import torch, torch.distributed as dist
+import vln_amd as vln
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+vln.dp._dp_active = lambda group=None: True          # a one-rank group: run the collectives anyway
+torch.manual_seed(0)
+enc = torch.nn.Linear(64, 32).to(dev); dec = torch.nn.Linear(32, 16).to(dev)
+opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters())], lr=1e-3, clip_norm=[40.0, 40.0])
+x = torch.randn(8, 64, device=dev)
+opt.zero_grad()
+dec(enc(x)).pow(2).sum().backward()
+ref = [p.grad.clone() for p in list(enc.parameters()) + list(dec.parameters())]
+opt.start_allreduce(1)                                 # the decoder's slice goes out early, asynchronously
+assert len(opt._reducer.pending) == 1
+opt.allreduce()                                        # the rest + wait
+assert not opt._reducer.pending
+torch.cuda.synchronize()
+for p, r in zip(list(enc.parameters()) + list(dec.parameters()), ref):
+    assert torch.equal(p.grad, r)                      # sum over one rank = identity
+before = [p.detach().clone() for p in enc.parameters()]
+opt.step()
+torch.cuda.synchronize()
+assert any(not torch.equal(a, b) for a, b in zip(before, enc.parameters()))
+t = vln.dp.allreduce_scalar(torch.tensor([5.0], device=dev))
+assert float(t) == 5.0
+gi, gl = vln.dp.gather_item_losses(torch.arange(4, device=dev), torch.arange(4, device=dev).float() * 2)
+assert gi.tolist() == [0, 1, 2, 3] and gl.tolist() == [0.0, 2.0, 4.0, 6.0]
+dist.destroy_process_group()
+print("RCCL-PATH-OK")
+'''
+
+
+def test_collective_path_on_a_one_rank_rccl_group():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL-PATH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
