@@ -641,7 +641,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
-    # Secondary, driver-timed numbers in the same line (never `value`): the fp32 path, the PCIe-inclusive path, and the two
+    # Secondary, driver-timed numbers in the same line (never `value`): the fp32 path, the PCIe-inclusive path, the same
+    # workload at 128 episodes per GPU (the iteration is bound by its dependent chain, not by bytes: twice the episodes cost
+    # about a third more), and the two
     # other single-GPU workloads BASELINE.json configures (IL + A2C at the reference's episode cap 35; Self-Monitor B=128;
     # the Speaker-Follower agent of config 0 at a GPU batch).
     secondary = None
@@ -650,6 +652,9 @@ def main():
         gc.unfreeze()
         for name, fn in (("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args)),
                          ("features_host_fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "host", args)),
+                         ("batch128_ms_per_step", lambda: secondary_envdrop(
+                             vln, dev, store, [make_tape(128, args.L, args.T, 8, seed=4040 + k, n_rows=store.N) for k in range(4)],
+                             dtype, "store", args)),
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
                          ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store)),
                          ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store))):
