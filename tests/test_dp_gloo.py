@@ -278,6 +278,97 @@ def test_two_rank_il_plus_a2c_equals_big_batch():
     assert torch.equal(got[0][1], got[1][1])
 
 
+def _worker_self_pace(rank, world, port, q, envdrop_form):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    from oracle import torch_port as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, parts, B = _mixed_problem()
+        params = [torch.nn.Parameter(v.clone()) for v in P.values()]
+        Pm = dict(zip(P.keys(), params))
+        bucket = vln.dp.GradBucket(params)
+        bucket.zero()
+        rows = vln.dp.stride_shard(B, rank, world)
+        weight = torch.linspace(0.1, 1.0, 40, dtype=torch.float64)            # the curriculum's per-item weights (curriculum.py:428-448)
+        item_idx = torch.tensor([3, 17, 8, 29, 11, 35])                       # dataset indices of the batch's episodes (cur_batch_index)
+        per_sample = _per_sample_losses(Pm, rows, envdrop_form)
+        w_rows = weight[item_idx[torch.tensor(rows)]]
+        loss = vln.dp.self_pace_batch_loss(w_rows, per_sample)                # torch.dot(self.weight[cur_batch_idx], cur_loss), curriculum.py:296
+        if not envdrop_form:                                                  # curriculum.py:301: / the batch's weight sum -- GLOBAL under DP
+            loss = loss / vln.dp.allreduce_scalar(w_rows.sum().reshape(1))
+        loss.backward()
+        bucket.allreduce()
+        gi, gl = vln.dp.gather_item_losses(item_idx[torch.tensor(rows)], per_sample.detach())   # loss_for_item[cur_batch_idx] = ...
+        q.put((rank, bucket.flat.clone(), gi.clone(), gl.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _per_sample_losses(Pm, rows, envdrop_form):
+    """Per-episode losses of the SELF-PACE curriculum: EnvDrop form = (IL + A2C per episode) * ML_WEIGHT / B-style scaling folded
+    in by the agent (reduction="none" criteria, envdrop.py:70,178-179); other agents = the per-episode CE."""
+    from oracle import torch_port as O
+    P, parts, B = _mixed_problem()
+    del P
+    # re-run the step chain of _mixed_problem with per-episode reductions
+    import types
+    r = torch.tensor(rows)
+    g2 = torch.Generator().manual_seed(13)
+    H, ANG, V, C, L, IMG, T = 16, 8, 4, 4, 7, 24, 3
+    F = IMG + ANG
+    data = dict(a=torch.randn(B, ANG, generator=g2).double(), img=torch.randn(T, B, V, F, generator=g2).double().abs(),
+                cand=torch.randn(T, B, C, F, generator=g2).double().abs(), h=torch.randn(B, H, generator=g2).double(),
+                c=torch.randn(B, H, generator=g2).double(), ctx=torch.randn(B, L, H, generator=g2).double(),
+                tgt=torch.tensor([[0, 1, 2, 3, 1, -1], [1, 1, 0, 2, 3, 0], [2, -1, 1, 0, 0, 3]]))
+    Pd = {k: v for k, v in Pm.items() if k != "critic.w"}
+    ht, c = data["h"][r], data["c"][r]
+    loss = 0.0
+    for t in range(T):
+        lo, (h1, c), ht, _ = O.envdrop_step(Pd, data["a"][r], data["img"][t][r], data["cand"][t][r], ht, c, data["ctx"][r], None)
+        loss = loss + O.masked_cross_entropy(lo, data["tgt"][t][r], None, "none")
+        if envdrop_form:
+            loss = loss + 0.05 * (h1 @ Pm["critic.w"]) ** 2             # a per-episode RL-style term through the critic
+    return loss
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("envdrop_form", [True, False], ids=["dot", "dot_over_weight_sum"])
+def test_two_rank_self_pace_weighted_loss_equals_big_batch(envdrop_form):
+    """BASELINE config 4's loss in miniature (SELF-PACE, curriculum.py:286-314): per-episode losses weighted by the curriculum's
+    item weights -- `torch.dot(weight[idx], cur_loss)` (EnvDrop) or the same over the batch's weight sum (other agents) --
+    sharded over two ranks == the single-process gradient, and every replica ends up with every episode's (index, loss) for
+    the weight update."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_self_pace, args=(r, world, port, q, envdrop_form)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    P, parts, B = _mixed_problem()
+    params = [v.clone().requires_grad_(True) for v in P.values()]
+    Pm = dict(zip(P.keys(), params))
+    weight = torch.linspace(0.1, 1.0, 40, dtype=torch.float64)
+    item_idx = torch.tensor([3, 17, 8, 29, 11, 35])
+    per_sample = _per_sample_losses(Pm, list(range(B)), envdrop_form)
+    loss = torch.dot(weight[item_idx], per_sample)
+    if not envdrop_form:
+        loss = loss / weight[item_idx].sum()
+    loss.backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])   # the critic is unused in the CE-only form
+    for rank, flat, gi, gl in got:
+        assert torch.allclose(flat, ref, rtol=1e-10, atol=1e-12), f"rank {rank}: DP gradient != big-batch gradient"
+        order = torch.argsort(gi)
+        assert torch.equal(gi[order], torch.sort(item_idx).values)
+        assert torch.allclose(gl[order], per_sample.detach()[torch.argsort(item_idx)], rtol=1e-12, atol=0)
+    assert torch.equal(got[0][1], got[1][1])
+
+
 def test_self_pace_helpers_without_a_group():
     sys.path.insert(0, ROOT)
     import vln_amd as vln
