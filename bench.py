@@ -204,6 +204,8 @@ class GpuAgent:
         # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
         # instead of a separate store.gather_step launch in front of every step
         self.fused_gather = bool(fused_gather) and not side_gather
+        # teacher forcing: every step's rows are known up front -> ONE gather launch per rollout (store.gather_rollout), A/B option
+        self.rollout_gather = False
         self.clear_grads_in_step = False
         self.rollout_ce = rollout_ce
         self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
@@ -310,8 +312,18 @@ class GpuAgent:
         h_tilde = h_t
         terms = []
         ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
-        for s in tape["steps"]:
-            img, cand, kw = self.step_features(tape, s)
+        pre = None
+        if self.rollout_gather and tape.get("store") is not None:
+            lp = self.dtype != torch.float32
+            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
+            pre = tape["store"].gather_rollout([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
+                                               pf, want_bf16=lp, want_f32=not lp)
+        for t, s in enumerate(tape["steps"]):
+            if pre is not None:
+                (im, im_lp), (cd, cd_lp) = pre[t]
+                img, cand, kw = (im_lp, cd_lp, dict(already_dropfeat=True)) if im_lp is not None else (im, cd, dict(already_dropfeat=True))
+            else:
+                img, cand, kw = self.step_features(tape, s)
             logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], **kw)
             # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum() (SURVEY §8 row
             # A9): recorded per step, evaluated for the whole rollout in ONE launch (losses.RolloutCE) -- or, --ce per-step,
@@ -464,6 +476,9 @@ def main():
                          "overlap, round 1) instead of the end of the one before it (they then run under the previous backward)")
     ap.add_argument("--chain", action="store_true",
                     help="A/B: the decoder steps as chained kernels (csrc/chain.h: measured slower, 2.64 vs 1.80 ms) instead of one launch per stage")
+    ap.add_argument("--rollout-gather", action="store_true",
+                    help="store features: ONE gather launch for all T steps ahead of the rollout (teacher forcing: the path is known), "
+                         "A/B against the gather inside every step's first launch")
     ap.add_argument("--separate-gather", action="store_true",
                     help="store features: one store.gather_step launch in front of every decoder step (A/B) instead of the gather "
                          "inside the step's first launch")
@@ -521,6 +536,7 @@ def main():
                      side_gather=args.gather_stream == "side" and args.features == "store", fused_gather=not args.separate_gather)
     agent.clear_grads_in_step = True
     agent.prefetch_under_backward = not args.no_backward_prefetch
+    agent.rollout_gather = bool(args.rollout_gather)
     # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
     # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
     # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.

@@ -32,6 +32,11 @@ class WsumStep(C.Structure):         # vln_wsum_step
     _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32), ("probs", ptr), ("target", ptr)]
 
 
+class GatherRolloutStep(C.Structure):
+    _fields_ = ([(n, ptr) for n in ("rows", "view_index", "crows", "cviews", "heading", "elevation", "out", "out_bf16", "cout", "cout_bf16")]
+                + [("offset_pano", u64), ("offset_cand", u64)])
+
+
 class CatStep(C.Structure):
     _fields_ = [("probs", ptr), ("action", ptr), ("dlogits", ptr), ("C", i32)]
 
@@ -213,6 +218,7 @@ SIGNATURES = {
     "vln_bn_mlp_bwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr, i64, C.POINTER(BnMlpGrads), ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
+    "vln_gather_rollout": (i32, [ptr, i32, ptr, C.POINTER(GatherRolloutStep), i32, i32, i32, i32, i32, i32, u64, f32, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_cands": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_step": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, u64, u64, u64,

@@ -106,6 +106,18 @@ bool chain_gather_step(hipStream_t st, const GatherStepArgs& a, int ttype) {
   return chain_add(st, CK_GATHER_STEP, nrows, 1, 1, &a, sizeof(a), bytes, ttype == VLN_BF16 ? W_BF16 : W_F32);
 }
 
+// ---- every step of a teacher-forced rollout in one launch ---------------------------------------------------------
+// With teacher forcing the path -- hence every step's viewpoint and candidate rows -- is known when the rollout starts
+// (the reference steps its simulator along the ground-truth actions, base.py:141-157 + follower.py:140): T gather launches of
+// ~15 us on the steps' dependent chains become one launch of T * (B*V + B*C) row blocks ahead of the first step.
+constexpr int kGatherMaxSteps = 12;
+struct GatherRolloutArgs { GatherStepArgs step[kGatherMaxSteps]; int T, nrows; };
+template <typename TT>
+__global__ __launch_bounds__(256) void gather_rollout_kernel(GatherRolloutArgs a) {
+  const int t = (int)blockIdx.x / a.nrows, r = (int)blockIdx.x % a.nrows;
+  gather_step_rows<TT, 1>(a.step[t], r, a.nrows, (int)threadIdx.x);
+}
+
 int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const PrepArgs& p) {
   if (!a.table || !a.angle_table || !a.rows || !a.view_index || !a.crows || !a.cviews || !a.heading || !a.elevation ||
       (!a.out && !a.out_lp) || (!a.cout && !a.cout_lp) || a.B <= 0 || a.V <= 0 || a.C <= 0 || (a.IMG & 7) || (a.ANG & 7)) {
@@ -148,6 +160,35 @@ extern "C" int vln_gather_step(const void* table, int ttype, const float* angle_
   if (ttype == VLN_BF16) VLN_LAUNCH(gather_step_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
   else VLN_LAUNCH(gather_step_kernel<float>, grid, block, 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("gather_step");
+  return VLN_OK;
+}
+
+extern "C" int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T,
+                                  int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, vln_stream_t s) {
+  if (!table || !angle_table || !steps || T <= 0 || B <= 0 || V <= 0 || C <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
+    set_error("vln_gather_rollout: bad args (IMG and ANG must be multiples of 8)");
+    return VLN_ERR_ARG;
+  }
+  const int nrows = B * V + B * C;
+  for (int t0 = 0; t0 < T; t0 += kGatherMaxSteps) {
+    GatherRolloutArgs a{};
+    a.T = (T - t0 < kGatherMaxSteps) ? T - t0 : kGatherMaxSteps;
+    a.nrows = nrows;
+    for (int t = 0; t < a.T; ++t) {
+      const vln_gather_rollout_step& q = steps[t0 + t];
+      if (!q.rows || !q.view_index || !q.crows || !q.cviews || !q.heading || !q.elevation || (!q.out && !q.out_bf16) || (!q.cout && !q.cout_bf16)) {
+        set_error("vln_gather_rollout: null pointer in step %d", t0 + t);
+        return VLN_ERR_ARG;
+      }
+      a.step[t] = GatherStepArgs{table, angle_table, (const long long*)q.rows, q.view_index, (const long long*)q.crows, q.cviews,
+                                 q.heading, q.elevation, q.out, (bf16_raw*)q.out_bf16, q.cout, (bf16_raw*)q.cout_bf16, B, V, C, IMG, ANG,
+                                 DropSpec{seed, q.offset_pano, p_feat}, DropSpec{seed, q.offset_cand, p_feat}};
+    }
+    dim3 grid((unsigned)(a.T * nrows)), block(256);
+    if (ttype == VLN_BF16) VLN_LAUNCH(gather_rollout_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
+    else VLN_LAUNCH(gather_rollout_kernel<float>, grid, block, 0, (hipStream_t)s, a);
+    VLN_CHECK_LAUNCH("gather_rollout");
+  }
   return VLN_OK;
 }
 

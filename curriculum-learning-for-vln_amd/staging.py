@@ -159,6 +159,41 @@ class DeviceFeatureStore:
         return (img, img_lp), (cand, cand_lp), ((seed, off1), (seed, off2))
 
 
+    def gather_rollout(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True):
+        """`gather_step` for EVERY step of a teacher-forced rollout in ONE launch (the path is known when the rollout starts:
+        base.py:141-157 driven by the ground-truth actions).  steps: sequence of (rows, view_index, crows, cviews, heading,
+        elevation); returns a list of ((img, img_bf16), (cand, cand_bf16)) like gather_step.  Same Philox stream as calling
+        gather_step for the steps in order (two offsets per step), so the results are bit-identical."""
+        lib = _lib.load()
+        dev = self.device
+        F = self.IMG + self.ANG
+        f32 = want_f32 or not want_bf16
+        arr = (_lib.GatherRolloutStep * len(steps))()
+        out, keep = [], []
+        seed, p = 0, 0.0
+        for t, (rows, view_index, crows, cviews, heading, elevation) in enumerate(steps):
+            B, C = crows.shape
+            img = ops.empty(B, self.V, F, dtype=torch.float32, device=dev) if f32 else None
+            cand = ops.empty(B, C, F, dtype=torch.float32, device=dev) if f32 else None
+            img_lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+            cand_lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+            seed, off1, p = self._drop(p_feat)
+            _, off2, _ = self._drop(p_feat)
+            cr, cv, hd, el = crows.contiguous(), cviews.contiguous(), heading.contiguous(), elevation.contiguous()
+            keep += [cr, cv, hd, el]
+            q = arr[t]
+            q.rows, q.view_index, q.crows, q.cviews, q.heading, q.elevation = _p(rows), _p(view_index), _p(cr), _p(cv), _p(hd), _p(el)
+            q.out, q.out_bf16, q.cout, q.cout_bf16 = _p(img), _p(img_lp), _p(cand), _p(cand_lp)
+            q.offset_pano, q.offset_cand = off1, off2
+            out.append(((img, img_lp), (cand, cand_lp)))
+            if t and (B, C) != tuple(steps[0][2].shape):
+                raise ValueError("gather_rollout: every step must have the same [B, C] candidate layout")
+        B, C = steps[0][2].shape
+        _lib.check(lib.vln_gather_rollout(_p(self.table), ops._dt(self.table), _p(self.angle_table), arr, len(steps), B, self.V, C,
+                                          self.IMG, self.ANG, seed, p, _lib.raw_stream()), "vln_gather_rollout")
+        return out
+
+
 class PinnedStager:
     """Ring of pinned host buffers + a copy stream.  `put(name->array)` returns device tensors that are ordered
     after the async copy on the CURRENT stream; the slot is recycled `depth` calls later."""

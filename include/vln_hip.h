@@ -425,6 +425,15 @@ int vln_a2c_loss_bwd(const float* dloss_b, int64_t dloss_stride, const float* dl
  * Both apply the EnvDrop feature dropout on the image part when p_feat > 0 (policy.py:226-231; call the decoder with
  * already_dropfeat=True then) and optionally emit the bf16 copy of the row; `out` (fp32) may be NULL when only the bf16
  * copy is wanted (a bf16 decoder never reads the fp32 rows: that halves the pass's HBM writes). */
+/* Every step of a TEACHER-FORCED rollout in one launch (the path, hence every step's viewpoint / candidate rows, is known when
+ * the rollout starts: base.py:141-157 driven by the ground-truth actions): per step the operands of vln_gather_step. */
+typedef struct vln_gather_rollout_step {
+  const int64_t* rows; const int32_t* view_index; const int64_t* crows; const int32_t* cviews; const float* heading; const float* elevation;
+  float* out; void* out_bf16; float* cout; void* cout_bf16;
+  uint64_t offset_pano, offset_cand;
+} vln_gather_rollout_step;
+int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T, int B, int V,
+                       int C, int IMG, int ANG, uint64_t seed, float p_feat, vln_stream_t s);
 int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index, const float* angle_table,
                     float* out, void* out_bf16, int B, int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat,
                     vln_stream_t s);

@@ -370,3 +370,29 @@ def test_fused_step_can_clear_the_gradients_it_consumed(vln):
         for ga, gb in zip(a, b):
             for pa, pb in zip(ga, gb):
                 assert torch.equal(pa, pb), step
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rollout_gather_equals_per_step_gathers(vln, dtype):
+    """DeviceFeatureStore.gather_rollout: every step of a teacher-forced rollout gathered in ONE launch == gather_step called
+    for the steps in order (same Philox offsets): bit for bit, feature dropout on, both output precisions."""
+    import bench
+    dev_ = torch.device(DEV)
+    cpu_tape = bench.make_tape(16, 24, 14, 6, seed=77)          # 14 steps: more than one chunk of the launch's argument block
+    tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
+    lp = dtype != torch.float32
+    res = []
+    for rollout in (True, False):
+        store = vln.DeviceFeatureStore(tape["store"].table, device=dev_, dtype=dtype)
+        steps = [(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]]
+        if rollout:
+            out = store.gather_rollout(steps, 0.3, want_bf16=lp, want_f32=True)
+        else:
+            out = [store.gather_step(*st, 0.3, want_bf16=lp, want_f32=True)[:2] for st in steps]
+        res.append(out)
+    for (ia, ca), (ib, cb) in zip(*res):
+        for x, y in zip(ia + ca, ib + cb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
+                assert x.float().abs().sum() > 0
