@@ -396,3 +396,36 @@ def test_rollout_gather_equals_per_step_gathers(vln, dtype):
             if x is not None:
                 assert torch.equal(x, y)
                 assert x.float().abs().sum() > 0
+
+
+def test_rollout_sampler_long_rollout_chunks(vln):
+    """losses.RolloutSampler beyond one launch's argument block (VLN_CE_MAX_STEPS = 40 steps per vln_categorical_multi_bwd call):
+    45 steps with differing candidate counts == sample_action per step, draws / log-probs / entropies bit for bit and the
+    d logits of every step (plain tensors as logits: the materialised-gradient route)."""
+    g = torch.Generator().manual_seed(3)
+    B, T = 9, 45
+    steps = []
+    for t in range(T):
+        C_ = 2 + (t % 13)
+        n = torch.randint(1, C_ + 1, (B,), generator=g)
+        steps.append((torch.randn(B, C_, generator=g) * 2, torch.arange(C_)[None, :] >= n[:, None]))
+    wl, we = torch.randn(T, B, generator=g).to(DEV), torch.randn(T, B, generator=g).to(DEV)
+    res = []
+    for wide in (True, False):
+        lgs = [lg.to(DEV).requires_grad_(True) for lg, _ in steps]
+        if wide:
+            s = vln.losses.RolloutSampler(seed=5, capacity=64)
+            acts = [s.step(lg, m.to(DEV), offset=10 + t) for t, (lg, (_, m)) in enumerate(zip(lgs, steps))]
+            lp, en = s.stats()
+        else:
+            outs = [vln.losses.sample_action(lg, m.to(DEV), seed=5, offset=10 + t) for t, (lg, (_, m)) in enumerate(zip(lgs, steps))]
+            acts = [o[0] for o in outs]; lp = torch.stack([o[1] for o in outs]); en = torch.stack([o[2] for o in outs])
+        ((lp * wl).sum() + (en * we).sum()).backward()
+        res.append((torch.stack(acts), lp.detach().clone(), en.detach().clone(), [lg.grad.clone() for lg in lgs]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        s = vln.losses.RolloutSampler(capacity=2)
+        for t in range(3):
+            s.step(steps[0][0].to(DEV))
