@@ -28,7 +28,7 @@ long long g_graph_stats[3] = {0, 0, 0};
 // [2] = 1, [3] = 512: narrow outputs (N <= 1024) with a SHORT contraction (K <= 512) use the 16-column kernel with the K
 // split inside the workgroup.  Interleaved A/B, GPU-bound iteration (scripts/ab_bench.py): all K 3.075 ms, K <= 1024
 // 2.890, K <= 512 2.861, off 2.878 -- every 16-column workgroup streams the whole X, which loses for K = 2176.
-int g_tunable[8] = {256, 1, 1, 512, 0, 0, 0, 0};
+int g_tunable[8] = {384, 1, 1, 512, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {

@@ -86,7 +86,7 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   // its loads in flight: 8.5 vs 12.5 us average per launch in the EnvDrop step, profiles/round1_notes.md.)
   int nsplit = 1;
   if (ws != nullptr) {
-    const int target = g_tunable[0];                 // workgroups wanted in flight (default 512)
+    const int target = g_tunable[0];                 // workgroups wanted in flight (default 384)
     nsplit = target / (nb * mb);
     if (nsplit > ksteps / 2) nsplit = ksteps / 2;
     // wide-and-shallow products (N >= 2048 columns, K <= 8 steps: the H->F query projections) already fill 32+

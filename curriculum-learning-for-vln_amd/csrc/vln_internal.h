@@ -22,7 +22,7 @@ const char* get_error();
 int check_hip(hipError_t e, const char* what);
 
 // run-time tunables (vln_set_tunable; defaults in api.hip) -- A/B switches, every setting computes the same results:
-//   [0] gemm_nt split-K target (workgroups in flight, 256)       [1] no-split rule for wide shallow products with a fused epilogue
+//   [0] gemm_nt split-K target (workgroups in flight, 384: 24-round A/B 1.794 vs 1.802 ms at 256)       [1] no-split rule for wide shallow products with a fused epilogue
 //   [2] 16-column GEMM for narrow outputs on/off, [3] its largest K
 //   [4] 1: two-kernel attention path instead of the one-launch rows
 //   [5] gemm_nt: 0 fast form with depth-2 prefetch, 1 same, 2 bounds-checked form, 4 depth-4 prefetch

@@ -18,16 +18,17 @@ tape_s = bench.tape_to(cpu_tape, dev, store_dtype=dtype)
 lib = vln._lib.load()
 
 # variant -> {tunable id: value} on top of the defaults (vln_set_tunable; see csrc/vln_internal.h)
-DEFAULT_TUN = {0: 256, 1: 1, 2: 1, 3: 512, 4: 0, 5: 0, 6: 0, 7: 0}
+DEFAULT_TUN = {0: 384, 1: 1, 2: 1, 3: 512, 4: 0, 5: 0, 6: 0, 7: 0}
 VARIANTS = {
     "base": {},
+    "gemm_split_target256": {0: 256},
+    "gemm_split_target384": {0: 384},
+    "gemm_split_target448": {0: 448},
+    "gemm_split_target512": {0: 512},
     "lstm_dispatch_order_map": {7: 1},
     "attn_two_kernels": {4: 1},
     "wgrad_fp32_exact": {6: 1},
     "overlap_wgrads": {},
-    "gemm_split_target512": {0: 512},
-    "gemm_split_target384": {0: 384},
-    "gemm_split_target192": {0: 192},
     "per_step_logits_and_loss_branch": {},
 }
 torch.manual_seed(0)
