@@ -21,6 +21,34 @@ def _free_port():
     return p
 
 
+def _run_world(target, extra=(), world=2, attempts=2):
+    """Spawn `world` ranks of `target(rank, world, port, queue, *extra)` and collect one result per rank.  The rendezvous port is
+    picked by binding port 0 and closing it again, so another process can take it in between (or the previous test's listener
+    may still be shutting down): a world that fails to come up is started once more on a fresh port before the test fails."""
+    last = None
+    for attempt in range(attempts):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = []
+        try:
+            got = [q.get(timeout=150) for _ in range(world)]
+        except Exception as e:             # queue.Empty: a rank died or hung before reporting
+            last = e
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+        if len(got) == world and all(p.exitcode == 0 for p in procs):
+            return got
+        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
+    raise AssertionError(f"the {world}-rank gloo world failed {attempts} times: {last!r}")
+
+
 def _problem():
     """A tiny EnvDrop IL batch on the oracle: returns (params, loss_fn(rows) -> summed CE over those rows)."""
     sys.path.insert(0, ROOT)
@@ -113,16 +141,7 @@ def _worker_fused(rank, world, port, q):
 
 @pytest.mark.timeout(180)
 def test_two_rank_fused_optimizer_bucket_equals_big_batch():
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_fused, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
+    got = _run_world(_worker_fused)
     P, loss_rows, B = _problem()
     params = [v.clone().requires_grad_(True) for v in P.values()]
     (loss_rows(dict(zip(P.keys(), params)), list(range(B))) * 0.2 / B).backward()
@@ -139,9 +158,12 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     no-op) -- checked without a GPU through --rendezvous-only over gloo: rank 0 reports n_gpus 2."""
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rendezvous-only"],
-                         capture_output=True, text=True, timeout=200,
-                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    for attempt in range(2):            # the launcher picks its rendezvous port by bind-and-close: retry once if it was taken meanwhile
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rendezvous-only"],
+                             capture_output=True, text=True, timeout=200,
+                             env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rep = json.loads(line)
@@ -167,16 +189,7 @@ def test_stride_shard_keeps_sorted_batches_sorted():
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("overlap", [False, True], ids=["one_allreduce", "early_slice_async"])
 def test_two_rank_bucket_allreduce_equals_big_batch(overlap):
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
+    got = _run_world(_worker, (overlap,))
     # single-process reference on the full batch
     P, loss_rows, B = _problem()
     params = [v.clone().requires_grad_(True) for v in P.values()]
@@ -256,16 +269,7 @@ def _worker_mixed(rank, world, port, q):
 def test_two_rank_il_plus_a2c_equals_big_batch():
     """BASELINE config 3 (EnvDrop IL + RL mixed loss, data-parallel): per-rank sums normalised by the GLOBAL batch and the
     GLOBAL running-pair count + one flat all-reduce == the single-process big-batch gradient (critic included)."""
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_mixed, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
+    got = _run_world(_worker_mixed)
     P, parts, B = _mixed_problem()
     params = [v.clone().requires_grad_(True) for v in P.values()]
     Pm = dict(zip(P.keys(), params))
@@ -340,16 +344,7 @@ def test_two_rank_self_pace_weighted_loss_equals_big_batch(envdrop_form):
     item weights -- `torch.dot(weight[idx], cur_loss)` (EnvDrop) or the same over the batch's weight sum (other agents) --
     sharded over two ranks == the single-process gradient, and every replica ends up with every episode's (index, loss) for
     the weight update."""
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_self_pace, args=(r, world, port, q, envdrop_form)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
+    got = _run_world(_worker_self_pace, (envdrop_form,))
     P, parts, B = _mixed_problem()
     params = [v.clone().requires_grad_(True) for v in P.values()]
     Pm = dict(zip(P.keys(), params))
