@@ -139,7 +139,7 @@ def _worker_fused(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(420)
 def test_two_rank_fused_optimizer_bucket_equals_big_batch():
     got = _run_world(_worker_fused)
     P, loss_rows, B = _problem()
@@ -152,7 +152,7 @@ def test_two_rank_fused_optimizer_bucket_equals_big_batch():
     assert torch.equal(got[0][1], got[1][1])
 
 
-@pytest.mark.timeout(240)
+@pytest.mark.timeout(480)
 def test_bench_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (round-1 verdict: the flag was a
     no-op) -- checked without a GPU through --rendezvous-only over gloo: rank 0 reports n_gpus 2."""
@@ -186,7 +186,7 @@ def test_stride_shard_keeps_sorted_batches_sorted():
             assert ls == sorted(ls, reverse=True)
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(420)
 @pytest.mark.parametrize("overlap", [False, True], ids=["one_allreduce", "early_slice_async"])
 def test_two_rank_bucket_allreduce_equals_big_batch(overlap):
     got = _run_world(_worker, (overlap,))
@@ -265,7 +265,7 @@ def _worker_mixed(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(420)
 def test_two_rank_il_plus_a2c_equals_big_batch():
     """BASELINE config 3 (EnvDrop IL + RL mixed loss, data-parallel): per-rank sums normalised by the GLOBAL batch and the
     GLOBAL running-pair count + one flat all-reduce == the single-process big-batch gradient (critic included)."""
@@ -337,7 +337,7 @@ def _per_sample_losses(Pm, rows, envdrop_form):
     return loss
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(420)
 @pytest.mark.parametrize("envdrop_form", [True, False], ids=["dot", "dot_over_weight_sum"])
 def test_two_rank_self_pace_weighted_loss_equals_big_batch(envdrop_form):
     """BASELINE config 4's loss in miniature (SELF-PACE, curriculum.py:286-314): per-episode losses weighted by the curriculum's
