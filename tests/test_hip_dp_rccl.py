@@ -51,7 +51,10 @@ print("RCCL-PATH-OK")
 
 
 def test_collective_path_on_a_one_rank_rccl_group():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    for attempt in range(2):            # the rendezvous port is picked by bind-and-close: one retry if it was taken meanwhile
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode == 0 or "address already in use" not in r.stderr.lower():
+            break
     assert r.returncode == 0 and "RCCL-PATH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
