@@ -212,6 +212,11 @@ class _RolloutCE(torch.autograd.Function):
         if batched:
             mod = recs[0].mod
             batched = bool(getattr(mod, "batch_logit_backward", False)) and all(r.mod is mod and r.B == B for r in recs)
+        # The decoder's rollout-wide logit branch runs ONCE per step record: if another rollout-wide consumer of the same logits
+        # (losses.RolloutSampler) took it already, these d logits go back to autograd and reach the steps as `dlogit`, which
+        # the step backward ADDS to the branch's result (envdrop.hip) -- nothing is dropped or counted twice.
+        if batched and any(r.dhtd_ext for r in recs):
+            batched = False
         if batched and not ctx.per_sample:
             # every consumer of these d logits is the decoder's rollout-wide logit branch: it forms them on the fly from the
             # saved probabilities (no d logits tensors, no launch of its own here)
@@ -450,6 +455,8 @@ class _RolloutStats(torch.autograd.Function):
         if batched:
             mod = recs[0].mod
             batched = bool(getattr(mod, "batch_logit_backward", False)) and all(r.mod is mod and r.B == B for r in recs)
+        if batched and any(r.dhtd_ext for r in recs):      # the branch ran for another consumer (losses.RolloutCE): see there
+            batched = False
         if batched:
             # the decoder's rollout-wide logit branch takes these d logits here and now (one multi-step weighted sum + one GEMM
             # for all steps); autograd gets None, so a step's backward only sees what OTHER consumers of its logits sent

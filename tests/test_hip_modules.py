@@ -766,6 +766,57 @@ def test_rollout_sampler_equals_per_step_sample_action(vln, given_actions):
         check(res[0][4][n], res[1][4][n], 2e-5, f"grad[{n}]", floor=1e-3 * scale)
 
 
+@pytest.mark.parametrize("ce_first", [True, False])
+@pytest.mark.usefixtures("split_wgrads")
+def test_rollout_ce_and_rollout_sampler_share_the_logits(vln, ce_first):
+    """BOTH rollout-wide consumers on the same logits (envdrop.py:173-195 with train_ml and train_rl in one rollout): the
+    decoder's rollout-wide logit branch can run only once per step, so whichever backward comes second must send its d logits
+    through autograd to the steps (added there).  Either order == the per-step configuration, every gradient."""
+    B, L, V, Cn, H, F, T = 12, 9, 36, 5, 64, 256 + 128, 3
+    g = torch.Generator().manual_seed(71)
+    ctx0 = torch.randn(B, L, H, generator=g).to(DEV)
+    h = torch.randn(B, H, generator=g).to(DEV); c = torch.randn(B, H, generator=g).to(DEV)
+    a = torch.randn(B, 128, generator=g).to(DEV)
+    steps = []
+    for t in range(T):
+        cand = torch.randn(B, Cn, F, generator=g).abs(); cand[:, -1] = 0
+        steps.append((torch.randn(B, V, F, generator=g).abs().to(DEV), cand.to(DEV), torch.randint(0, Cn, (B,), generator=g).to(DEV),
+                      torch.randint(0, Cn, (B,), generator=g).to(DEV)))
+    wl = torch.rand(T, B, generator=g).to(DEV)
+    res = []
+    for rollout_wide in (True, False):
+        torch.manual_seed(6)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, 16, 128, F).to(DEV).eval()
+        dec.batch_logit_backward = rollout_wide
+        ctx = ctx0.clone().requires_grad_(True)
+        hh, cc, ht = h.clone().requires_grad_(True), c.clone(), h.clone()
+        ce = vln.losses.RolloutCE()
+        sampler = vln.losses.RolloutSampler(seed=9)
+        lps, ens = [], []
+        for t, (img, cand, tgt, act) in enumerate(steps):
+            lg, (hh, cc), ht = dec(a, img.clone(), cand.clone(), ht, hh, cc, ctx)
+            ce.add(lg, tgt)
+            if rollout_wide:
+                sampler.step(lg, None, action=act, offset=50 + t)
+            else:
+                _, lp_t, en_t = vln.losses.sample_action(lg, None, action=act, seed=9, offset=50 + t)
+                lps.append(lp_t); ens.append(en_t)
+        if rollout_wide:
+            lp, en = sampler.stats()
+        else:
+            lp, en = torch.stack(lps), torch.stack(ens)
+        ml = ce.sum(scale=0.2)
+        rl = -(lp * wl).sum() - 0.01 * en.sum()
+        # autograd runs the node created LAST first: the order of the two sums decides which consumer takes the branch
+        loss = (rl + ml) if ce_first else (ml + rl)
+        loss.backward()
+        res.append(({n: p.grad.detach().clone() for n, p in dec.named_parameters()}, ctx.grad.clone()))
+    check(res[0][1], res[1][1], 1e-5, "d ctx")
+    scale = max(v.abs().max().item() for v in res[1][0].values())
+    for n in res[0][0]:
+        check(res[0][0][n], res[1][0][n], 2e-5, f"grad[{n}]", floor=1e-3 * scale)
+
+
 def test_long_rollouts_replay_their_step_graphs(vln):
     """T = 20 decoder steps per iteration (the reference's sampled rollouts run up to MAX_EPISODE_LEN = 35): the graph cache
     used to switch itself off for good after 24 misses in a row -- i.e. inside the first two (all-miss by construction)
