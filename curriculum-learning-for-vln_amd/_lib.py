@@ -232,7 +232,7 @@ SIGNATURES = {
     "vln_shadow_refresh": (i32, [ptr, i32, ptr]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, ptr]),
-    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
     "vln_set_chain": (i32, [i32]),

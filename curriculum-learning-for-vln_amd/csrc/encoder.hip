@@ -226,7 +226,20 @@ struct RecBwdArgs {
   float* dh_pass;         // [dirs][B][Hd]  in: grad wrt the state after this step; out: before it (frozen rows)
   float* dc_carry;        // [dirs][B][Hd]
   int B, L, Hd, dirs, step, first, vec;
+  // optional: the gradients of the FINAL states as the caller has them, [B, dirs*Hd] (hcat / ccat layout).  The persistent
+  // kernels read their initial dh / dc from these instead of dh_pass / dc_carry (which are then pure scratch): the caller's
+  // two transposing copies (two launches of ~5 us in front of the recurrence) disappear.
+  const float* dh_bm; const float* dc_bm;
 };
+__global__ __launch_bounds__(256) void state_bm_to_db_kernel(const float* dh_bm, const float* dc_bm, float* dh, float* dc, int B, int dirs, int Hd) {
+  const long n = (long)B * dirs * Hd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Hd), b = (int)((i / Hd) % B), d = (int)(i / ((long)Hd * B));
+    const long src = ((long)b * dirs + d) * Hd + j;
+    dh[i] = dh_bm[src];
+    dc[i] = dc_bm[src];
+  }
+}
 
 template <typename TW>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
@@ -802,8 +815,12 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
 
 static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                               const float* act, const float* tanh_c, const float* cprev, float* dgates, float* dh_pass,
-                              float* dc_carry, int B, int L, int Hd, int dirs) {
-  RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0};
+                              float* dc_carry, int B, int L, int Hd, int dirs, const float* dh_bm, const float* dc_bm) {
+  RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0, nullptr, nullptr};
+  if (dh_bm) {          // per-step launches keep their running state in dh_pass / dc_carry: bring the initial values into that layout
+    long nb = ((long)B * dirs * Hd + 255) / 256;
+    VLN_LAUNCH(state_bm_to_db_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, st, dh_bm, dc_bm, dh_pass, dc_carry, B, dirs, Hd);
+  }
   a.vec = al16(w_hh_t) && al16(dgates) && (Hd % (wtype == VLN_BF16 ? 8 : 4) == 0) && (Hd % 4 == 0);
   dim3 grid((Hd + 15) / 16, dirs, (B + 15) / 16), block(256);
   for (int step = L - 1; step >= 0; --step) {
@@ -819,17 +836,22 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
 
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
-                                float* dh_pass, float* dc_carry, int B, int L, int Hd, int dirs, void* sync_ws,
-                                int64_t sync_ws_bytes, vln_stream_t s) {
+                                float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
+                                int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
-      Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
+      Hd <= 0 || dirs < 1 || dirs > 2 || ((dh_init_bm == nullptr) != (dc_init_bm == nullptr))) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
+  const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
-    r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
-    if (r) return r;
-    RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1};
+    // The counter-protocol backward kernel resets its group counters itself and clears its status word; the header only
+    // needs a fill when another kernel left counters behind (the counter-protocol FORWARD of mode 2) or in the flag variant.
+    if (VLN_SYNC_FLAGS || !fwd_granules() || bwd_granules()) {
+      r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
+      if (r) return r;
+    }
+    RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1, dh_bm, dc_bm};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
@@ -850,10 +872,10 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     }
     return r;
   }
-  struct { const void* p[9]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry},
-                                                {wtype, B, L, Hd, dirs}};
+  struct { const void* p[11]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_bm, dc_bm},
+                                                 {wtype, B, L, Hd, dirs}};
   static GraphCache cache;
   return cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
-    return lstm_seq_bwd_issue(st, dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs);
+    return lstm_seq_bwd_issue(st, dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, dh_bm, dc_bm);
   });
 }

@@ -375,12 +375,23 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   const bool live = b < B;
   const int len = live ? a.lengths[b] : 0;
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
-  float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
+  float dh_pass = 0.f, dcc = 0.f;
+  if (live) {
+    if (a.dh_bm) {                       // the caller's [B, dirs*Hd] layout
+      const long cb = ((long)b * a.dirs + d) * HD + j;
+      dh_pass = a.dh_bm[cb]; dcc = a.dc_bm[cb];
+    } else {
+      dh_pass = a.dh_pass[ci]; dcc = a.dc_carry[ci];
+    }
+  }
   const long grp = (long)(d * ix.nbb + ix.bb) * 2;          // [grp + parity][producer][unit][row]
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       exch, 0, (unsigned)(persist_bwd_exchange_floats(B, HD, a.dirs) * 4), 0x00020000);
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
-  if (threadIdx.x == 0) s_abort = 0;
+  if (threadIdx.x == 0) {
+    s_abort = 0;
+    if (blockIdx.x == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status word (a timeout sets it long after this store)
+  }
   __syncthreads();
 
   for (int step = L - 1; step >= 0; --step) {
@@ -454,4 +465,17 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     group_arrive(cnt, jb, (unsigned)k + 1u);
     VLN_STAMP(5);
   }
+#if !VLN_SYNC_FLAGS
+  // Leave the group's counter as the launch found it (zero): every workgroup of the group has passed its LAST wait on it by
+  // the time it gets here, so the last one through resets it -- the host's fill launch in front of every backward
+  // recurrence (4 us on the dependent chain) is not needed.  (A launch that timed out leaves garbage: it also raises the
+  // sticky error, after which the library stops using these kernels.)
+  if (threadIdx.x == 0) {
+    const unsigned through = __hip_atomic_fetch_add(cnt + 24, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (through + 1u == (unsigned)NJB) {
+      VLN_AGENT_STORE(cnt, 0u);
+      VLN_AGENT_STORE(cnt + 24, 0u);
+    }
+  }
+#endif
 }

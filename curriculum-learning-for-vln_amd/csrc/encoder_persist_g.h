@@ -264,7 +264,15 @@ __global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, u
   const bool live = b < B;
   const int len = live ? a.lengths[b] : 0;
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
-  float dh_pass = live ? a.dh_pass[ci] : 0.f, dcc = live ? a.dc_carry[ci] : 0.f;
+  float dh_pass = 0.f, dcc = 0.f;
+  if (live) {
+    if (a.dh_bm) {                       // the caller's [B, dirs*Hd] layout
+      const long cb = ((long)b * a.dirs + d) * HD + j;
+      dh_pass = a.dh_bm[cb]; dcc = a.dc_bm[cb];
+    } else {
+      dh_pass = a.dh_pass[ci]; dcc = a.dc_carry[ci];
+    }
+  }
   const unsigned par_bytes = (unsigned)NJB * HD * 16u * 8u;                 // one parity slot of one group
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(exch, 0, (unsigned)persist_g_bwd_bytes(B, HD, a.dirs), 0x00020000);
   const unsigned gbase = (unsigned)(d * ix.nbb + ix.bb) * 2u * par_bytes;

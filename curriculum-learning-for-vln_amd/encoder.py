@@ -131,15 +131,18 @@ class _EncoderFn(torch.autograd.Function):
                        "vln_bm_to_tm")
         for k in range(nl - 1, -1, -1):
             x, hprev, cprev, act, tanh_c = ctx.saved[k]
-            if k == nl - 1:   # only the last layer's final states are returned (units.py:63-67)
-                dh_pass = dhcat.view(B, dirs, Hd).transpose(0, 1).contiguous()
-                dc_carry = dccat.view(B, dirs, Hd).transpose(0, 1).contiguous()
+            if k == nl - 1:   # only the last layer's final states are returned (units.py:63-67): their gradients go in as
+                # they are ([B, dirs*Hd]); the recurrence reads them in that layout, dh_pass / dc_carry are scratch
+                dh_pass = ops.empty(dirs, B, Hd, **f32)
+                dc_carry = ops.empty(dirs, B, Hd, **f32)
+                init = (dhcat if dhcat.is_contiguous() else dhcat.contiguous(), dccat)
             else:
                 dh_pass = ops.zeros(dirs, B, Hd, **f32)
                 dc_carry = ops.zeros(dirs, B, Hd, **f32)
+                init = (None, None)
             dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
-                                            _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), B, L, Hd, dirs,
+                                            _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs,
                                             *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
             cbt = ops.ColsumBatch()       # ... and its bias gradients
             wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode

@@ -67,7 +67,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         w_hh_t = torch.stack([ops.transpose_cast(w_hh[d], torch.float32) for d in range(dirs)], 0).contiguous()
         dyc = dy.contiguous() if dy is not None else None
         _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), ops.F32, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
-                                        _p(dh_pass), _p(dc_carry), B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
+                                        _p(dh_pass), _p(dc_carry), None, None, B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
                                         _lib.raw_stream()), "vln_lstm_seq_bwd")
         grads = []
         for d in range(dirs):

@@ -492,9 +492,12 @@ int vln_persistent_check(void);
 int vln_set_chain(int mode);
 int vln_get_chain(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
- * in: grads of the final states, clobbered */
+ * in: grads of the final states, clobbered.  dh_init_bm / dc_init_bm (both or neither): the same initial gradients in the
+ * caller's [B, dirs*Hd] layout (hcat / ccat, units.py:63-67) -- dh_pass / dc_carry are then scratch only and the caller's two
+ * transposing copies are not needed. */
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
-                     const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry, int B, int L,
+                     const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry,
+                     const float* dh_init_bm /*nullable*/, const float* dc_init_bm /*nullable*/, int B, int L,
                      int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
 
 /* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
