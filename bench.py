@@ -201,6 +201,7 @@ class GpuAgent:
         self.side = torch.cuda.Stream(device=dev) if side_gather else None
         self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
         self._gen_done, self._iter_no, self.prefetch_under_backward = [None, None], 0, True
+        self._one = None
         # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
         # instead of a separate store.gather_step launch in front of every step
         self.fused_gather = bool(fused_gather) and not side_gather
@@ -337,7 +338,9 @@ class GpuAgent:
             loss = ce.sum(scale=w)                               # ml_loss summed over the steps (envdrop.py:179), scaled in the launch
         else:
             loss = torch.stack(terms).sum() * w
-        loss.backward()
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(self._one)                                 # the root gradient is a constant: no ones_like fill per iteration
         self.opt.allreduce()
         # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
         self.opt.step(zero_grads=self.clear_grads_in_step)
