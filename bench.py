@@ -477,8 +477,6 @@ def main():
     ap.add_argument("--no-backward-prefetch", action="store_true",
                     help="host features A/B: the H2D copies of an iteration wait for the END of the previous iteration (forward-only "
                          "overlap, round 1) instead of the end of the one before it (they then run under the previous backward)")
-    ap.add_argument("--chain", action="store_true",
-                    help="A/B: the decoder steps as chained kernels (csrc/chain.h: measured slower, 2.64 vs 1.80 ms) instead of one launch per stage")
     ap.add_argument("--rollout-gather", action="store_true",
                     help="store features: ONE gather launch for all T steps ahead of the rollout (teacher forcing: the path is known), "
                          "A/B against the gather inside every step's first launch")
@@ -530,7 +528,6 @@ def main():
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     vln.ops.set_wgrad_precision(args.wgrad)
-    lib.vln_set_chain(1 if args.chain else 0)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.features == "host-bf16" and dtype != torch.bfloat16:
         raise SystemExit("--features host-bf16 needs --dtype bf16")

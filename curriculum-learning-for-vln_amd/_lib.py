@@ -235,8 +235,6 @@ SIGNATURES = {
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
-    "vln_set_chain": (i32, [i32]),
-    "vln_get_chain": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),
     "vln_follower_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
@@ -248,6 +246,10 @@ SIGNATURES = {
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),
                                    C.POINTER(EnvDropGrads), ptr]),
 }
+
+# The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
+# between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
+EXPECTED_ABI = 9
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()
@@ -274,6 +276,10 @@ def load():
             raise VlnError(f"libvln_hip.so lacks symbol {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    got = lib.vln_abi_version()
+    if got != EXPECTED_ABI:
+        raise VlnError(f"{LIB_PATH} has ABI version {got}, this package binds version {EXPECTED_ABI}: the library is stale "
+                       "(or half-built); rebuild it with `python __graft_entry__.py`")
     _lib = lib
     return lib
 

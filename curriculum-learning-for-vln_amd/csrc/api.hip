@@ -40,7 +40,7 @@ struct ProfState {
 };
 ProfState g_prof[K_COUNT];
 const char* kKernelNames[K_COUNT] = {"gemm_nt", "gemm_tn", "attn_dot", "attn_wsum", "attn_bwd", "lstm_rec_fwd",
-                                     "lstm_rec_bwd", "feat_dropout", "lstm_pointwise", "reduce_epilogue", "step_chain"};
+                                     "lstm_rec_bwd", "feat_dropout", "lstm_pointwise", "reduce_epilogue"};
 }  // namespace
 void prof_begin(hipStream_t st, int kid, double algo_bytes) {
   ProfState& p = g_prof[kid];
@@ -112,7 +112,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 8; }
+extern "C" int vln_abi_version(void) { return 9; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,

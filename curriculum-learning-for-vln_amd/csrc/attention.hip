@@ -7,7 +7,6 @@
 //                       in-place dctx accumulation
 // Reference semantics: units.py:100-122 (SoftDotAttention), units.py:138-160 (VisualSoftDotAttention).
 #include "vln_internal.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {

@@ -225,10 +225,8 @@ static bool attn_fused_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
   const int nseg = D / V;
   const int sl = (nseg + 63) / 64, rw = (S + kFusedWaves - 1) / kFusedWaves;
   const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 8.0 * B * D + 8.0 * B * S;
-  // configuration k of a dtype is chain kind CK_ATTN_{FWD,BWD}_k (chain.hip instantiates the same four per dtype)
 #define VLN_FUSED_CASE(TC, RWv, SLv, k) \
   if (rw <= RWv && sl <= SLv) { \
-    if (chain_add(st, (bwd ? CK_ATTN_BWD_0 : CK_ATTN_FWD_0) + k, B, 1, 1, &a, sizeof(a), bytes, ctype)) return true; \
     attn_fused_launch<TC, RWv, SLv>(st, a, B, bwd, bytes); return true; }
   if (ctype == W_BF16) {
     VLN_FUSED_CASE(bf16_raw, 10, 1, 0)       // instruction context: S <= 80, D <= 512

@@ -16,7 +16,6 @@
 
 #include "vln_internal.h"
 #include "graph_cache.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -614,11 +613,9 @@ extern "C" int vln_persistent_check(void) {
     if (__atomic_load_n(&h[d * 16], __ATOMIC_RELAXED)) {
       const unsigned n = __atomic_exchange_n(&h[d * 16], 0u, __ATOMIC_RELAXED);
       g_persist_enabled = 0;
-      g_chain_mode = 0;
       set_error("%u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (persistent LSTM recurrence: its "
-                "workgroups were not co-resident; or a chained step kernel: a producer stage never ran); that iteration's "
-                "numbers are invalid.  The persistent recurrence and the chained steps are now off for this process "
-                "(per-step / per-stage launches)", n, d);
+                "workgroups were not co-resident); that iteration's numbers are invalid.  The persistent recurrence is now off "
+                "for this process (per-step launches)", n, d);
       return VLN_ERR_HIP;
     }
   }

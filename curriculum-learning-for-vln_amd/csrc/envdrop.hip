@@ -15,7 +15,6 @@
 #include "graph_cache.h"
 #include "envdrop_prep.h"
 #include "step_bodies.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -116,12 +115,6 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
               B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
               io->a_stash == io->a_prev ? nullptr : io->a_stash};
-  // Chained form (chain.h): the step's launches below are recorded as stages of ONE kernel.  Stage order = dispatch order;
-  // the gather is a stage nothing waits for until the visual attention needs its rows, so the query projection runs beside it.
-  ChainScope chain(st, g_chain_mode != 0);
-  const bool chained = chain_recording();
-  int gather_stage = kDepNone;
-  bool gather_pending = false;
   GatherStepArgs ga{};
   if (io->g_table) {
     // (1)+(2) in ONE launch: the step gathers its own feature rows from the resident table (dropout sites 4 / 5 on the way)
@@ -131,12 +124,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
                         lp ? nullptr : io->cand, lp ? (bf16_raw*)io->cand_lp : nullptr, B, d->V, d->C, d->IMG, d->ANG,
                         site(io, 4, pf), site(io, 5, pf)};
     if (!lp && (!io->img || !io->cand)) { set_error("envdrop fwd: gathered features need img / cand buffers"); return VLN_ERR_ARG; }
-    const int ttype_w = io->g_ttype == VLN_BF16 ? W_BF16 : W_F32;
-    if (chained && ttype_w == d->wtype && ttype_w == d->ctype) {
-      chain_next(kDepNone, kDepNone, 0);
-      gather_pending = chain_prep(st, pa);
-    }
-    if (!gather_pending) RUN(gather_step_prep(st, ga, io->g_ttype, pa));
+    RUN(gather_step_prep(st, ga, io->g_ttype, pa));
   } else {
     VLN_LAUNCH(envdrop_prep_kernel, dim3(nblocks((long)B * AE * 8 + (long)B * (H + (pa.a_stash ? d->ANG : 0)) / 4)), dim3(256), 0, st, pa);
     VLN_CHECK_LAUNCH("envdrop_prep");
@@ -150,23 +138,11 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
   // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
-  // chain_next(main, pre, early): weights and the rollout-constant contexts are requested before the stage waits
   int n1 = 1, n2 = 1, n3 = 1;
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
-  const int vin_stage = chain_last();
-  if (gather_pending) {
-    chain_next(kDepNone, kDepNone, 0);
-    if (!chain_gather_step(st, ga, io->g_ttype)) { set_error("envdrop fwd: chained gather refused"); return VLN_ERR_ARG; }
-    gather_stage = chain_last();
-    chain_next(vin_stage, gather_stage, 1);
-  } else {
-    chain_next(kDepPrev, kDepNone, 1);
-  }
   RUN(attn_fwd_rows_sv(st, img, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, nullptr, 0, nullptr, io->alpha_v, io->xcat + AE, XK,
                        ws.dots, B, d->V, F));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   LstmPwFwd pw{};
   pw.gates = ws.s2; pw.nsplit = n2; pw.slab_stride = (long)B * 4 * H;
@@ -175,20 +151,16 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
   RUN(lstm_pointwise_fwd(st, pw));
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
                        ws.dots, B, d->L, H));
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
-  if (io->defer_logits) return chain.finish();      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
-  chain_next(kDepPrev, kDepNone, 1);
+  if (io->defer_logits) return VLN_OK;      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
   RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
-  return chain.finish();
+  return VLN_OK;
 }
 
 static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io,
@@ -201,7 +173,6 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
 
-  ChainScope chain(st, g_chain_mode != 0);
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
   SlabVec dhtd{ws.s3, H, 1, (long)B * H};
@@ -228,13 +199,10 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
   {
     const TanhDropBwdArgs ta{dhtd, dhtd2, g->dh_tilde, io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop)};
-    if (!chain_add(st, CK_TANH_DROP_BWD, nblocks((long)B * H), 1, 1, &ta, sizeof(ta), 0.0, -1)) {
-      VLN_LAUNCH(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ta);
-      VLN_CHECK_LAUNCH("tanh_drop_bwd");
-    }
+    VLN_LAUNCH(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ta);
+    VLN_CHECK_LAUNCH("tanh_drop_bwd");
   }
   // (5') linear_out -> [d weighted ctx | d drop(h1)], still in slabs (s4)
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, nullptr, 0, B, 2 * H, H, nullptr, ACT_NONE, ws.s4, ws.n4, &n4));
   const SlabVec dtcat{ws.s4, 2 * H, n4, (long)B * 2 * H};
   // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
@@ -245,10 +213,8 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
     RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
   } else {
-    chain_next(kDepPrev, kDepNone, 1);
-    RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
+      RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
   }
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
   // (4') LSTM cell
   LstmPwBwd pb{};
@@ -257,22 +223,17 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
   RUN(lstm_pointwise_bwd(st, pb));
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
-  chain_next(kDepPrev, kDepNone, 1);
   RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
   PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
-  if (!chain_add(st, CK_PREP_BWD, nblocks((long)B * (AE + H)), 1, 1, &pa, sizeof(pa), 0.0, -1)) {
-    VLN_LAUNCH(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
-    VLN_CHECK_LAUNCH("envdrop_prep_bwd");
-  }
-  return chain.finish();
+  VLN_LAUNCH(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
+  VLN_CHECK_LAUNCH("envdrop_prep_bwd");
+  return VLN_OK;
 }
 
 
@@ -285,7 +246,6 @@ namespace {
 struct StepKey {
   vln_envdrop_dims d; vln_envdrop_weights w; vln_envdrop_step io; vln_envdrop_grads g; int bwd;
   int tun[8];          // the launch plan depends on the run-time tunables: a changed tunable never replays an old graph
-  int chain;           // ... and on whether the step is one chained kernel
 };
 }  // namespace
 
@@ -294,7 +254,6 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  RUN(chain_prime());
   if (!io->offset_dev && !io->offset_base_dev) return step_fwd_issue(st, d, w, io);
   if (!io->offset_base_dev) {
     VLN_LAUNCH(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
@@ -308,7 +267,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   key.d = *d; key.w = *w; key.io = *io; key.bwd = 0;
   if (!io->offset_base_dev) key.io.offset = 0;      // per-step word: the value is not a launch argument
   memset(&key.g, 0, sizeof(key.g));
-  memcpy(key.tun, g_tunable, sizeof(key.tun)); key.chain = g_chain_mode;
+  memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
 }
 
@@ -317,7 +276,6 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io || !g) { set_error("vln_envdrop_step_bwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  RUN(chain_prime());
   if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g);
   static StepKey key;
   static std::mutex mu;
@@ -325,6 +283,6 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   std::lock_guard<std::mutex> lock(mu);
   key.d = *d; key.w = *w; key.io = *io; key.g = *g; key.bwd = 1;
   if (!io->offset_base_dev) key.io.offset = 0;
-  memcpy(key.tun, g_tunable, sizeof(key.tun)); key.chain = g_chain_mode;
+  memcpy(key.tun, g_tunable, sizeof(key.tun));
   return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
 }

@@ -72,8 +72,5 @@ struct GatherStepArgs {
 };
 // gather of a step + the step's prep work as extra workgroups of the same launch (features.hip)
 int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const PrepArgs& p);
-// the two as stages of a chained step (chain.h); false: no chain is being recorded
-bool chain_prep(hipStream_t st, const PrepArgs& p);
-bool chain_gather_step(hipStream_t st, const GatherStepArgs& a, int ttype);
 
 }  // namespace vln

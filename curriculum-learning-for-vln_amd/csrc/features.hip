@@ -8,7 +8,6 @@
 #include "vln_internal.h"
 #include "envdrop_prep.h"
 #include "gather_body.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -91,21 +90,6 @@ __global__ __launch_bounds__(256) void gather_step_prep_kernel(GatherStepArgs a,
   else envdrop_prep_body(p, (long)((int)blockIdx.x - nrb) * 256 + threadIdx.x, (long)nprep * 256);
 }
 
-// chained forms (chain.hip): false when no chain is being recorded
-bool chain_prep(hipStream_t st, const PrepArgs& p) {
-  long nb = (envdrop_prep_items(p) + 255) / 256;
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
-  return chain_add(st, CK_PREP, (int)nb, 1, 1, &p, sizeof(p), 0.0, -1);
-}
-bool chain_gather_step(hipStream_t st, const GatherStepArgs& a, int ttype) {
-  if (!a.table || !a.angle_table || !a.rows || !a.view_index || !a.crows || !a.cviews || !a.heading || !a.elevation ||
-      (!a.out && !a.out_lp) || (!a.cout && !a.cout_lp) || a.B <= 0 || a.V <= 0 || a.C <= 0 || (a.IMG & 7) || (a.ANG & 7)) return false;
-  const int nrows = a.B * a.V + a.B * a.C;
-  const double bytes = (double)nrows * (a.IMG * (ttype == VLN_BF16 ? 2.0 : 4.0) + (a.IMG + a.ANG) * ((a.out ? 4.0 : 0.0) + (a.out_lp ? 2.0 : 0.0)));
-  return chain_add(st, CK_GATHER_STEP, nrows, 1, 1, &a, sizeof(a), bytes, ttype == VLN_BF16 ? W_BF16 : W_F32);
-}
-
 // ---- every step of a teacher-forced rollout in one launch ---------------------------------------------------------
 // With teacher forcing the path -- hence every step's viewpoint and candidate rows -- is known when the rollout starts
 // (the reference steps its simulator along the ground-truth actions, base.py:141-157 + follower.py:140): T gather launches of
@@ -129,8 +113,6 @@ int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const P
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   const int nprep = (int)nb;
-  // chained step: the prep work is its own (first) stage and the gather a stage NOTHING waits for until the visual
-  // attention needs the rows -- the caller orders the stages (envdrop.hip)
   // one table row per block: 2 / 4 rows per block with their loads in flight together measured SLOWER (1.815 / 1.855 vs 1.796 ms
   // per iteration, profiles/round2_notes.md) -- thousands of small workgroups hide the cold HBM accesses better than fat ones
   if (ttype == VLN_BF16) VLN_LAUNCH((gather_step_prep_kernel<bf16_raw, 1>), dim3(nrows + nprep), dim3(256), 0, st, a, p, nrows, nprep);

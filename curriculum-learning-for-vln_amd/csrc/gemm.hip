@@ -14,7 +14,6 @@
 // fp32 accumulate; lane group q = lane>>4 owns k = k0 + q*VK .. +VK so both operands read 32 B per lane.
 #include "vln_internal.h"
 #include "step_bodies.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -119,9 +118,7 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
     // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
     const bool deep = g_tunable[5] == 4 && steps_per > 2;
 #define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
-    if (fast && !deep && !wide && chain_add(st, CK_GEMM_NT, nb, nsplit, mb, &a, sizeof(a), bytes, wtype)) {
-      // recorded as a stage of the chained step kernel (chain.hip runs gemm_nt_body<TW, 2, true, 1>)
-    } else if (wide && fast) {
+    if (wide && fast) {
       if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw, 2, true, 2>, grid, block, 0, st, a);
       else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float, 2, true, 2>, grid, block, 0, st, a);
     } else if (wtype == W_BF16) {
@@ -153,7 +150,6 @@ int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_st
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   const ReduceEpiArgs a{slabs, nsplit, slab_stride, lds, out, ldo, M, N, bias, act, out2, ldo2, drop};
-  if (chain_add(st, CK_REDUCE_EPI, blocks, 1, 1, &a, sizeof(a), 0.0, -1)) return VLN_OK;
   VLN_LAUNCH(reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("reduce_epilogue");
   return VLN_OK;

@@ -3,7 +3,6 @@
 // helpers and the in-place environmental feature dropout (policy.py:226-231).
 #include "vln_internal.h"
 #include "step_bodies.h"
-#include "chain.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -21,7 +20,6 @@ int lstm_pointwise_fwd(hipStream_t st, const LstmPwFwd& a) {
   int blocks = (int)groups;
   if (blocks > 4096) blocks = 4096;
   const int iters = (int)((groups + blocks - 1) / blocks);
-  if (chain_add(st, CK_LSTM_PW_FWD, blocks, iters, 1, &a, sizeof(a), 0.0, -1)) return VLN_OK;
   VLN_LAUNCH(lstm_pw_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, iters);
   VLN_CHECK_LAUNCH("lstm_pointwise_fwd");
   return VLN_OK;
@@ -34,7 +32,6 @@ int lstm_pointwise_bwd(hipStream_t st, const LstmPwBwd& a) {
   long total = (long)a.B * a.H;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (chain_add(st, CK_LSTM_PW_BWD, blocks, 1, 1, &a, sizeof(a), 0.0, -1)) return VLN_OK;
   VLN_LAUNCH(lstm_pw_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("lstm_pointwise_bwd");
   return VLN_OK;

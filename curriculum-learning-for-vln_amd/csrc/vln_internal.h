@@ -34,7 +34,7 @@ extern int g_tunable[8];
 // ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------
 enum KernelId {
   K_GEMM_NT = 0, K_GEMM_TN, K_ATTN_DOT, K_ATTN_WSUM, K_ATTN_BWD, K_LSTM_REC_FWD, K_LSTM_REC_BWD, K_FEAT_DROPOUT,
-  K_LSTM_PW, K_REDUCE_EPI, K_CHAIN, K_COUNT
+  K_LSTM_PW, K_REDUCE_EPI, K_COUNT
 };
 extern unsigned g_prof_mask;
 void prof_begin(hipStream_t st, int kid, double algo_bytes);
@@ -51,20 +51,13 @@ struct ProfScope {   // brackets the launches issued in its scope with an event 
 // is the kernel's own begin->end on the device, the figure rocprofv3 --kernel-trace reports, with no
 // launch gap or event-record packet inside the bracket.
 bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
-// Stages recorded for a chained step launch (chain.h) are submitted before ANY other launch of the calling thread: every
-// launch in the library goes through launch_timed or VLN_LAUNCH.
-int chain_flush();
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout
-#define VLN_LAUNCH(kernel, grid, block, lds, st, ...)                      \
-  do {                                                                        \
-    vln::chain_flush();                                                        \
-    hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);             \
-  } while (0)
+// every launch in the library goes through launch_timed or VLN_LAUNCH
+#define VLN_LAUNCH(kernel, grid, block, lds, st, ...) hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__)
 
 template <typename F, typename... A>
 inline void launch_timed(int kid, double algo_bytes, F kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t st,
                          A... args) {
-  chain_flush();
   hipEvent_t ea, eb;
   if (((g_prof_mask >> kid) & 1u) && prof_slot(kid, algo_bytes, &ea, &eb))
     hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ea, eb, 0u, args...);

@@ -4,8 +4,12 @@
  * this path is the nn.Module surface of src/model/units.py and src/model/policy.py.  This library is what a
  * torch.autograd.Function inside a drop-in nn.Module binds to (ctypes).  Every entry
  * point takes raw DEVICE pointers, explicit sizes/strides and a hipStream_t, returns an int status
- * (0 = VLN_OK), never allocates or frees caller memory and keeps no hidden global state (only a
- * thread-local error string).  Tensors are row-major; "ld" = row stride in elements.
+ * (0 = VLN_OK) and never allocates or frees CALLER memory.  State the library keeps on its own behalf (all of it
+ * process-wide, none of it changes results): a thread-local error string; the hipGraph caches of memoised launch chains
+ * (vln_set_graphs / vln_graph_stats); the A/B tunables and mode switches (vln_set_tunable, vln_set_persistent); the optional
+ * per-kernel timers (vln_prof_*); a per-buffer launch sequence for the recurrence's data-tagged hand-offs; one host-mapped
+ * status word per device that a timed-out bounded wait raises (vln_persistent_check).  Tensors are row-major; "ld" = row
+ * stride in elements.
  *
  * dtype codes: 0 = fp32, 1 = bf16 (raw uint16 bits).  Activations/gradients are fp32; the streamed
  * operands (weights, feature/context tensors) may be bf16 shadows with fp32 accumulation.
@@ -484,13 +488,6 @@ int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = pe
  * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as
  * VLN_ERR_HIP (the affected iteration's numbers are invalid) and switches the process to per-step launches. */
 int vln_persistent_check(void);
-/* Chained decoder steps (csrc/chain.h), an A/B switch: 1 = the dependent launches of a decoder step (EnvDrop: policy.py:208-246
- * and its backward) are issued as ONE kernel whose stages hand over through agent-scope completion flags; 0 (default) = one
- * launch per stage, which is the faster form on MI355X (csrc/chain.h has the measurements).  Identical results (the stages
- * run the same workgroup bodies).  A bounded wait that times out is reported by vln_persistent_check and switches the
- * process to mode 0. */
-int vln_set_chain(int mode);
-int vln_get_chain(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered.  dh_init_bm / dc_init_bm (both or neither): the same initial gradients in the
  * caller's [B, dirs*Hd] layout (hcat / ccat, units.py:63-67) -- dh_pass / dc_carry are then scratch only and the caller's two

@@ -1,0 +1,231 @@
+"""GPU: BASELINE configs 3 and 4 -- ONE RANK's workload at its full size against the fp64 CPU oracle.
+
+  cfg3  EnvDrop IL + A2C (trainer.py:412-416): a teacher-forced rollout (T = 7) whose IL loss is `ml_loss * ML_WEIGHT / B`
+        (envdrop.py:173-179,268) PLUS a sampled rollout up to the reference's episode cap (MAX_EPISODE_LEN 35,
+        configs/envdrop/envdrop_config.yaml:31) with the A2C loss of envdrop.py:222-264 (critic bootstrap from one more
+        decoder step, gamma 0.9, RL_NORMALIZE total), B = 64 episodes, L = 80 tokens, H = 512, 36 x 2176 views, C <= 8.
+  cfg4  the same iteration with the SELF-PACE curriculum's per-episode weights: both rollouts keep their losses as [B]
+        vectors (train_cl, envdrop.py:70,178-179,251-253) and the batch loss is `dot(weight[idx], loss)` (curriculum.py:296),
+        also in the weight-normalised form of curriculum.py:301.
+
+Through the product path of the sampled rollout: `forward(gather=...)` from a resident feature table, `losses.RolloutCE`,
+`losses.RolloutSampler` with the actions INJECTED (as the reference tapes do: sampled actions cannot be RNG-matched),
+`Critic` over (steps x batch) rows, `losses.a2c_loss`.  Training mode, every dropout ON: the kernels' Philox masks are exported
+(`vln_dropout_mask`) and injected into the oracle (encoder embedding / context, the six sites of every decoder step, the
+critic), so the comparison is exact, not statistical.  Compared: both losses, `total`, the log-probs / entropies / values of
+all 35 steps, and EVERY parameter gradient of encoder, decoder and critic.  fp32: 1e-4.  bf16: the oracle on the rounded
+weights the kernels stream (1e-4 outputs, same_bf16_grad_tol() gradients) and the oracle on the unrounded masters (1e-2;
+tensors that cannot meet it carry the measured bound below).
+"""
+import pytest
+import torch
+
+from parity import check, bf16_weights, bf16_round_st, same_bf16_grad_tol, FP32, BF16, SAME_BF16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ML_WEIGHT, GAMMA = 0.2, 0.9          # configs/envdrop/envdrop_config.yaml:45,42
+
+# bf16 vs the UNROUNDED fp64 oracle over a 35-step sampled rollout: every streamed weight carries a 2^-9 relative rounding that
+# the recurrence (35 LSTM steps, each behind two softmaxes) compounds; measured (gpurun_out/parity_report.json) and asserted:
+CFG3_BF16_EXC = {"logp": 3e-2, "entropy": 3e-2, "values": 3e-2, "rl_loss": 5e-2, "loss": 5e-2,
+                 "grad[dec.visual_attn.linear_in.weight]": 6e-2, "grad[dec.": 4e-2, "grad[enc.": 4e-2, "grad[cri.": 4e-2}
+
+
+def _tol(exc, tol, what):
+    for k, v in (exc or {}).items():
+        if what == k or what.startswith(k):
+            return v
+    return tol
+
+
+@pytest.fixture(scope="module")
+def vln():
+    import vln_amd
+    vln_amd._lib.load()
+    return vln_amd
+
+
+def _mask(vln, n, seed, offset, p, shape):
+    return vln.ops.dropout_mask(n, seed, offset, p, DEV).cpu().double().view(shape)
+
+
+def _rl_tape(B, T, ncands, g):
+    """Injected actions of the sampled rollout + what the environment answers (rewards, running masks): episode b runs for
+    len_b steps, takes a random non-STOP candidate each step and STOP (the last real slot) at its last one."""
+    lens = torch.randint(4, T + 1, (B,), generator=g)
+    lens[0] = T
+    lens[1] = T + 5                                    # an episode the cap cuts off: never ends, bootstraps from the critic
+    acts, masks, rewards = [], [], []
+    for t in range(T):
+        nc = ncands[t]
+        a = (torch.rand(B, generator=g) * (nc - 1).float()).long()
+        a = torch.where(t == lens - 1, nc - 1, a)
+        running = t < lens
+        a = torch.where(running, a, torch.zeros_like(a))            # ended episodes: any valid index (their terms are masked)
+        r = torch.where(t == lens - 1, torch.where(torch.rand(B, generator=g) < 0.5, 2.0, -2.0), torch.randn(B, generator=g).sign())
+        acts.append(a); masks.append(running); rewards.append((r * running).float())
+    return acts, masks, rewards, lens <= T
+
+
+def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False):
+    """mode 'sum' = cfg3, 'self_pace' = cfg4."""
+    import bench
+    from oracle import torch_port as O
+    H, E, AE, ANG, IMG, V = 512, 256, 64, 128, 2048, 36
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(3030)
+    torch.manual_seed(3030)
+    enc = vln.EncoderLSTM(992, E, H, 0, 0.5, True, 1, compute_dtype=cdt).to(dev).train()
+    dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, IMG + ANG, compute_dtype=cdt).to(dev).train()
+    cri = vln.Critic(H, 0.5).to(dev).train()
+    table = (torch.randn(N, V, IMG, generator=g).abs() * 0.5).to(cdt)
+    store = vln.DeviceFeatureStore(table, device=dev, dtype=cdt, angle_size=ANG)
+    cpu_tape = bench.make_tape(B, L, T_rl + 1, 8, seed=3031, n_rows=N)
+    tape = bench.tape_to(cpu_tape, dev, store=store)
+    ncands = [(~s["cand_mask"]).sum(1) for s in cpu_tape["steps"]]
+    acts, masks, rewards, ended = _rl_tape(B, T_rl, ncands, g)
+    weight = (torch.rand(B, generator=g) * 0.99 + 0.01) if mode == "self_pace" else None      # uniform [0.01, 1]
+    lp = cdt != torch.float32
+
+    # ---- the HIP path, recording the Philox offsets every module used ------------------------------------------------
+    offs = {"enc": [], "dec": [], "cri": []}
+
+    def gpu_rollout(T, sample):
+        offs["enc"].append(enc._calls + 1)
+        ctx, h, c = enc(tape["tokens"], tape["lengths32"])
+        ht = h
+        hidden = []
+        dec.defer_logits = not sample
+        ce = vln.losses.RolloutCE()
+        sampler = vln.losses.RolloutSampler()
+        for t, s in enumerate(tape["steps"][:T]):
+            offs["dec"].append(dec._step_counter + 1)
+            logit, (h, c), ht = dec(s["angle"], None, None, ht, h, c, ctx, tape["seq_mask"],
+                                    gather=(store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
+            hidden.append(h)
+            if sample:
+                sampler.step(logit, s["cand_mask"], action=acts[t].to(dev))
+            else:
+                ce.add(logit, s["target"], s["cand_mask"])
+        if not sample:
+            return dict(ml=ce.per_sample(scale=ML_WEIGHT / B) if weight is not None else ce.sum(scale=ML_WEIGHT / B))
+        logps, ents = sampler.stats()
+        sl = tape["steps"][T]                                               # envdrop.py:224-230: one more step for the bootstrap
+        offs["dec"].append(dec._step_counter + 1)
+        _, (last_h, _), _ = dec(sl["angle"], None, None, ht, h, c, ctx, tape["seq_mask"],
+                                gather=(store, sl["rows"], sl["vidx"], sl["crow"], sl["cview"], sl["chead"], sl["celev"]))
+        offs["cri"].append(cri._calls + 1)
+        with torch.no_grad():
+            last_v = cri(last_h).detach()
+        offs["cri"].append(cri._calls + 1)
+        vals = cri(torch.cat(hidden, 0)).view(T, B)
+        rl, total = vln.losses.a2c_loss(logps, ents, vals, [r.to(dev) for r in rewards], [m.to(dev) for m in masks], last_v,
+                                        ended.to(dev), GAMMA, "total", per_sample=weight is not None)
+        return dict(rl=rl, total=total, logp=logps, ent=ents, vals=vals)
+
+    def batch_loss(ml, rl, w):
+        if w is None:
+            return ml + rl
+        bl = torch.dot(w.to(ml.dtype), ml + rl)                              # curriculum.py:296
+        return bl / w.sum().to(ml.dtype) if normalised else bl               # curriculum.py:301
+
+    il = gpu_rollout(T_il, False)
+    rlr = gpu_rollout(T_rl, True)
+    loss = batch_loss(il["ml"], rlr["rl"], None if weight is None else weight.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # ---- the oracle(s) ---------------------------------------------------------------------------------------------------
+    variants = [("fp32", FP32, False, None)] if not lp else \
+        [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, CFG3_BF16_EXC)]
+    sd = {"enc": enc.state_dict(), "dec": dec.state_dict(), "cri": cri.state_dict()}
+    seq_mask = cpu_tape["seq_mask"]
+    lengths = cpu_tape["lengths"].tolist()
+    p, pf = 0.5, 0.3
+    for name, tol, same, exc in variants:
+        P = {k: {n: v.detach().cpu().double().requires_grad_(True) for n, v in d.items()} for k, d in sd.items()}
+        Pe = bf16_weights(P["enc"], skip=("embedding.weight",)) if same else P["enc"]       # embedding rows are gathered in fp32
+        Pd = bf16_weights(P["dec"], skip=("act_embed.0.weight",)) if same else P["dec"]     # the 128 -> 64 embedding runs in fp32
+        Pc = P["cri"]                                                                       # the critic computes in fp32
+        it = {k: iter(v) for k, v in offs.items()}
+
+        def ora_rollout(T, sample):
+            oe = next(it["enc"])
+            cx, h, c = O.encoder_forward(Pe, cpu_tape["tokens"], lengths, num_layers=1, bidirectional=True,
+                                         emb_mask=_mask(vln, B * L * E, enc.dropout_seed, oe * 8 + 0, p, (B, L, E)),
+                                         ctx_mask_drop=_mask(vln, B * L * H, enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
+            cxs = bf16_round_st(cx) if same else cx              # the text attention streams a bf16 copy of the context
+            ht = h
+            hidden, logps, ents, ml = [], [], [], 0.0
+
+            def step(s, ht, c):
+                od = next(it["dec"])
+                m = lambda site, n, pp, shape: _mask(vln, n, dec.dropout_seed, od * 8 + site, pp, shape)
+                f = bench.materialize_step(s, table.float(), ANG)
+                Ct = s["cand_mask"].shape[1]
+                img = O.feature_dropout(f["img"].double(), m(4, B * V * IMG, pf, (B, V, IMG)), ANG)
+                cand = O.feature_dropout(f["cand"].double(), m(5, B * Ct * IMG, pf, (B, Ct, IMG)), ANG)
+                if lp:                                           # the features are DATA: the kernels stream bf16 rows
+                    img, cand = img.float().bfloat16().double(), cand.float().bfloat16().double()
+                drop = {"act": m(0, B * AE, p, (B, AE)), "hprev": m(1, B * H, p, (B, H)), "h1": m(2, B * H, p, (B, H)),
+                        "htilde": m(3, B * H, p, (B, H))}
+                lo, (h1, c1), ht1, _ = O.envdrop_step(Pd, s["angle"].double(), img, cand, ht, c, cxs, seq_mask, drop=drop)
+                return lo, h1, c1, ht1
+
+            for t, s in enumerate(cpu_tape["steps"][:T]):
+                lo, h, c, ht = step(s, ht, c)
+                hidden.append(h)
+                lo = lo.masked_fill(s["cand_mask"], -float("inf"))                           # envdrop.py:173
+                if sample:
+                    l_, e_ = O.categorical_logprob_entropy(lo, acts[t])
+                    logps.append(l_); ents.append(e_)
+                else:
+                    ml = ml + O.masked_cross_entropy(lo, s["target"], None, "none" if weight is not None else "sum")
+            if not sample:
+                return dict(ml=ml * ML_WEIGHT / B)
+            _, last_h, _, _ = step(cpu_tape["steps"][T], ht, c)
+            oc = next(it["cri"])
+            with torch.no_grad():
+                last_v = O.critic(Pc, last_h, _mask(vln, B * H, cri.dropout_seed, oc, p, (B, H)))
+            oc = next(it["cri"])
+            vals = O.critic(Pc, torch.cat(hidden, 0), _mask(vln, T * B * H, cri.dropout_seed, oc, p, (T * B, H))).view(T, B)
+            rl, total = O.a2c_loss(logps, ents, list(vals.unbind(0)), [r.double() for r in rewards], masks, last_v, ended, GAMMA,
+                                   "total", per_sample=weight is not None)
+            return dict(rl=rl, total=total, logp=torch.stack(logps), ent=torch.stack(ents), vals=vals)
+
+        oil = ora_rollout(T_il, False)
+        orl = ora_rollout(T_rl, True)
+        oloss = batch_loss(oil["ml"], orl["rl"], None if weight is None else weight.double())
+        oloss.backward()
+        t = lambda what: _tol(exc, tol, what)
+        assert int(round(float(rlr["total"]))) == int(round(float(orl["total"]))) == int(sum(int(m.sum()) for m in masks))
+        check(il["ml"], oil["ml"], t("ml_loss"), f"{name}: ml_loss")
+        check(rlr["rl"], orl["rl"], t("rl_loss"), f"{name}: rl_loss")
+        check(loss, oloss, t("loss"), f"{name}: loss")
+        check(rlr["logp"], orl["logp"], t("logp"), f"{name}: logp [T,B]")
+        check(rlr["ent"], orl["ent"], t("entropy"), f"{name}: entropy [T,B]")
+        check(rlr["vals"], orl["vals"], t("values"), f"{name}: values [T,B]")
+        for key, mod in (("enc", enc), ("dec", dec), ("cri", cri)):
+            refs = {n: P[key][n].grad for n, _ in mod.named_parameters()}
+            gmax = max(float(r.abs().max()) for r in refs.values() if r is not None)
+            for n, prm in mod.named_parameters():
+                r = refs[n] if refs[n] is not None else torch.zeros_like(P[key][n])
+                got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+                check(got, r, t(f"grad[{key}.{n}]"), f"{name}: grad[{key}.{n}]", floor=1e-2 * gmax)
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_cfg3_il_plus_a2c_full_size(vln, cdt):
+    _iteration(vln, cdt, "sum")
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_cfg4_self_pace_weighted_full_size(vln, cdt):
+    _iteration(vln, cdt, "self_pace")
+
+
+def test_cfg4_self_pace_weight_normalised_form(vln):
+    """curriculum.py:301 (`dot(w, loss) / w.sum()`, the form the other agents' per-episode losses take) on the same per-episode
+    vector, with a shorter sampled rollout."""
+    _iteration(vln, torch.float32, "self_pace", T_rl=12, normalised=True)

@@ -923,46 +923,3 @@ def test_envdrop_full_size_bf16_split_weight_gradients(vln):
     same-weights bound of the outputs (1e-4)."""
     assert same_bf16_grad_tol() == SAME_BF16
     _full_size_envdrop(vln, torch.bfloat16)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("gathered", [True, False])
-def test_chained_step_kernel_equals_stage_launches(vln, dtype, gathered):
-    """vln_set_chain(1): the dependent launches of a decoder step run as the stages of ONE kernel (csrc/chain.h) -- the same
-    workgroup bodies, so loss and every gradient must equal the one-launch-per-stage form bit for bit, dropout ON, over four
-    arena iterations (step plans + graph replays), with the step gathering its own features and with caller-given tensors;
-    and no bounded wait may have timed out."""
-    import bench
-    from vln_amd import _lib
-    lib = _lib.load()
-    dev_ = torch.device(DEV)
-    cpu_tape = bench.make_tape(16, 24, 4, 6, seed=41)
-    cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
-    for s_ in cpu_tape["steps"]:
-        s_.update(bench.materialize_step(s_, cpu_tape["table"]))
-    res = []
-    try:
-        for chain in (1, 0):
-            lib.vln_set_chain(chain)
-            assert lib.vln_get_chain() == chain
-            tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype) if gathered else bench.tape_to(cpu_tape, dev_)
-            torch.manual_seed(43)
-            ag = bench.GpuAgent(vln, dev_, dtype, 1, arena=True, fused_gather=gathered)
-            ag.enc._calls = 0; ag.dec._step_counter = 0
-            ag.enc.deterministic_embedding_grad = True
-            ag.opt.lr = 0.0
-            out = []
-            for _ in range(4):
-                loss = ag.iteration(tape)
-                torch.cuda.synchronize()
-                out.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
-            res.append(out)
-            _lib.check(lib.vln_persistent_check(), "vln_persistent_check")
-    finally:
-        lib.vln_set_chain(1)
-    for (la, ga), (lb, gb) in zip(res[0], res[1]):
-        assert torch.isfinite(la).all()
-        assert torch.equal(la, lb)
-        for a, b in zip(ga, gb):
-            assert torch.equal(a, b)
