@@ -200,6 +200,7 @@ class GpuAgent:
         # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
         self.side = torch.cuda.Stream(device=dev) if side_gather else None
         self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
+        self._branch_stream = None
         self._gen_done, self._iter_no, self.prefetch_under_backward = [None, None], 0, True
         self._one = None
         # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
@@ -225,6 +226,29 @@ class GpuAgent:
         # same device addresses, so each decoder step (13 forward / 15 backward launches) replays as one hipGraph.
         self.arena = None
         self.use_arena(arena)
+        # runtime.DeviceClock: dropout offsets and the recurrence's launch sequence come from device words that one tick
+        # launch bumps per iteration -> the iteration's launch arguments repeat and it can be captured whole (graphs.IterationGraph)
+        self.clock = None
+        self.graph = None
+        self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
+
+    def use_clock(self, store=None):
+        self.clock = self.vln.DeviceClock(next(self.enc.parameters()).device)
+        self.clock.attach(self.enc, self.dec)
+        if store is not None:
+            self.clock.attach(store)
+        return self.clock
+
+    def capture(self, tape):
+        """Record one iteration over `tape` (buffers at fixed addresses: LiveBatch.live) as ONE hipGraph; `replay()` then runs
+        an iteration on whatever those buffers hold."""
+        if self.clock is None:
+            raise RuntimeError("GpuAgent.capture: use_clock() first (a captured iteration reads its dropout offsets from device words)")
+        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture()
+        return self.graph
+
+    def replay(self):
+        return self.graph.replay()
 
     def use_arena(self, on: bool):
         self.arena = self.vln.ops.RolloutArena() if on else None
@@ -295,6 +319,8 @@ class GpuAgent:
 
     def _iteration(self, tape):
         B = tape["B"]
+        if self.clock is not None:
+            self.clock.tick()          # one launch: this iteration's dropout offsets / launch sequence (device words)
         if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
             self.side.wait_stream(torch.cuda.current_stream())
         if self.copy_stream is not None and self.arena is not None:
@@ -309,16 +335,32 @@ class GpuAgent:
                 self.copy_stream.wait_stream(torch.cuda.current_stream())
             self._copy_fenced = True
         self.opt.zero_grad()
+        pre, branch = None, None
+
+        def gather_all():
+            lp = self.dtype != torch.float32
+            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
+            return tape["store"].gather_rollout([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
+                                                pf, want_bf16=lp, want_f32=not lp)
+
+        if self.rollout_gather and self.gather_branch and tape.get("store") is not None:
+            # the gather reads only the resident table + index vectors: as a branch of the captured graph it runs beside the
+            # instruction encoder (whose 0.2 ms recurrence keeps half of the CUs idle) and joins before the first decoder step
+            main = torch.cuda.current_stream()
+            if self._branch_stream is None:
+                self._branch_stream = torch.cuda.Stream()
+            branch = self._branch_stream
+            branch.wait_stream(main)
+            with torch.cuda.stream(branch):
+                pre = gather_all()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
         terms = []
         ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
-        pre = None
-        if self.rollout_gather and tape.get("store") is not None:
-            lp = self.dtype != torch.float32
-            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-            pre = tape["store"].gather_rollout([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
-                                               pf, want_bf16=lp, want_f32=not lp)
+        if branch is not None:
+            torch.cuda.current_stream().wait_stream(branch)
+        elif self.rollout_gather and tape.get("store") is not None:
+            pre = gather_all()
         for t, s in enumerate(tape["steps"]):
             if pre is not None:
                 (im, im_lp), (cd, cd_lp) = pre[t]
@@ -477,6 +519,13 @@ def main():
     ap.add_argument("--no-backward-prefetch", action="store_true",
                     help="host features A/B: the H2D copies of an iteration wait for the END of the previous iteration (forward-only "
                          "overlap, round 1) instead of the end of the one before it (they then run under the previous backward)")
+    ap.add_argument("--iteration-graph", default="auto", choices=["auto", "on", "off"],
+                    help="the WHOLE iteration (encoder, decoder steps, loss, backward, clip + RMSprop) captured as one hipGraph and "
+                         "replayed (graphs.IterationGraph; dropout offsets and the recurrence's launch sequence come from device words, "
+                         "runtime.DeviceClock).  auto: on for one GPU with the resident feature store, off otherwise (the gradient "
+                         "all-reduce of N > 1 stays a stream operation between launches)")
+    ap.add_argument("--gather-branch", action="store_true",
+                    help="with --rollout-gather and the iteration graph: the rollout-wide gather as a captured BRANCH beside the encoder")
     ap.add_argument("--rollout-gather", action="store_true",
                     help="store features: ONE gather launch for all T steps ahead of the rollout (teacher forcing: the path is known), "
                          "A/B against the gather inside every step's first launch")
@@ -537,6 +586,11 @@ def main():
     agent.clear_grads_in_step = True
     agent.prefetch_under_backward = not args.no_backward_prefetch
     agent.rollout_gather = bool(args.rollout_gather)
+    agent.gather_branch = bool(args.gather_branch)
+    use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and world == 1 and args.features == "store"
+                                                 and not args.no_arena)
+    if use_graph and (args.features != "store" or args.ce != "rollout"):
+        raise SystemExit("--iteration-graph on needs --features store and --ce rollout (inputs at fixed addresses, no host sync)")
     # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
     # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
     # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.
@@ -560,11 +614,21 @@ def main():
         print(f"[bench] setup: {store.N}-viewpoint table ({store.table.numel() * store.table.element_size() / 2**30:.2f} GiB {args.dtype}), "
               f"{len(tapes)} tapes, {time.perf_counter() - t_setup:.1f} s", file=sys.stderr, flush=True)
     it_no = [0]
+    if use_graph:
+        agent.use_clock(store)
 
-    def iterate():
+    def iterate_eager():
         k = it_no[0]
         it_no[0] = k + 1
         return agent.iteration(live.load(k) if live is not None else tapes[k % len(tapes)])
+
+    def iterate():
+        if agent.graph is None:
+            return iterate_eager()
+        k = it_no[0]
+        it_no[0] = k + 1
+        live.load(k)                  # the new batch into the fixed buffers (one 0.4 MB device copy), then ONE graph launch
+        return agent.replay()
 
     def barrier():
         if world > 1:
@@ -584,6 +648,14 @@ def main():
             if rank == 0:
                 print(f"[bench] first iteration (module init, captures): {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
+    if use_graph:
+        tg = time.perf_counter()
+        agent.capture(live.live)
+        for _ in range(2):
+            iterate()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] iteration captured as one hipGraph: {(time.perf_counter() - tg) * 1e3:.0f} ms", file=sys.stderr, flush=True)
     # Python's cyclic GC: a full pass over the (static) module/object graph costs tens of ms and would land in the
     # timed region at random; collect now and move the survivors out of the collector's reach.  (Before the warm-up
     # iterations, not after them: tens of ms of idle GPU right in front of the timed region let the clocks fall back, and
@@ -602,6 +674,8 @@ def main():
     if timed_out:                                 # a bounded in-kernel wait timed out during warm-up: fall back
         print("[bench] persistent recurrence reported a timeout; using per-step launches", file=sys.stderr, flush=True)
         lib.vln_set_persistent(0)
+        if agent.graph is not None:               # the recorded iteration contains the persistent launches: record it again
+            agent.capture(live.live)
         iterate()
         barrier()
     marks = []
@@ -638,7 +712,7 @@ def main():
             read_prof(lib, nk)
         torch.cuda.synchronize()
         for _ in range(args.steps):
-            iterate()
+            iterate_eager()           # per-kernel event pairs ride on plain launches (a captured graph has none)
         torch.cuda.synchronize()
         rows = read_prof(lib, nk) if rank == 0 else []
         if rank == 0:
@@ -713,7 +787,8 @@ def main():
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
-                       "parallelism": f"dp{world}", "world_size": world,
+                       "parallelism": f"dp{world}", "world_size": world, "iteration_graph": bool(use_graph),
+                       "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
     if world > 1:

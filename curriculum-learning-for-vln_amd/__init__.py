@@ -9,7 +9,9 @@ from . import _lib, ops, runtime, dp  # noqa: F401
 from ._lib import VlnError, LIB_PATH  # noqa: F401
 from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401
-from . import functional, staging, losses, optim, metrics  # noqa: F401
+from . import functional, staging, losses, optim, metrics, graphs  # noqa: F401
+from .runtime import DeviceClock  # noqa: F401
+from .graphs import IterationGraph  # noqa: F401
 from .staging import DeviceFeatureStore, PinnedStager  # noqa: F401
 from .speaker import SpeakerEncoder, SpeakerDecoder, Speaker, back_translate, env_drop_mask  # noqa: F401
 from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401

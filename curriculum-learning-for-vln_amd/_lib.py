@@ -64,6 +64,10 @@ class EnvDropStep(C.Structure):
                 + [("g_ttype", i32), ("pad2_", i32)])
 
 
+class TickItem(C.Structure):          # vln_tick_item
+    _fields_ = [("word", ptr), ("inc", u64), ("width", i32), ("pad_", i32)]
+
+
 class ShadowJob(C.Structure):
     _fields_ = [("src", ptr), ("src2", ptr), ("dst", ptr), ("dst_t", ptr), ("ld_src", i64), ("ld_dst", i64), ("ld_dst_t", i64),
                 ("N", i32), ("K", i32), ("out_type", i32), ("pad_", i32)]
@@ -186,7 +190,7 @@ SIGNATURES = {
     "vln_lstm_pointwise_fwd": (i32, [ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32, i32, i32, ptr]),
     "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_dropout_mask": (i32, [ptr, i64, u64, u64, f32, ptr]),
-    "vln_scale_dropout": (i32, [ptr, i64, ptr, i64, i32, i32, u64, u64, f32, ptr]),
+    "vln_scale_dropout": (i32, [ptr, i64, ptr, i64, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_rmsprop_partial_floats": (i64, [ptr, i32]),
     "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr, f32, ptr]),
@@ -218,21 +222,24 @@ SIGNATURES = {
     "vln_bn_mlp_bwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr, i64, C.POINTER(BnMlpGrads), ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
-    "vln_gather_rollout": (i32, [ptr, i32, ptr, C.POINTER(GatherRolloutStep), i32, i32, i32, i32, i32, i32, u64, f32, ptr]),
+    "vln_gather_rollout": (i32, [ptr, i32, ptr, C.POINTER(GatherRolloutStep), i32, i32, i32, i32, i32, i32, u64, f32, ptr, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_cands": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_step": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, u64, u64, u64,
                               f32, ptr]),
-    "vln_embed_fwd": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
-    "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr]),
-    "vln_embed_bwd_det": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i64, u64, u64, f32, ptr]),
-    "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
-    "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
+    "vln_embed_fwd": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_embed_bwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i64, u64, u64, f32, ptr, ptr]),
+    "vln_embed_bwd_det": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, i32, i64, u64, u64, f32, ptr, ptr]),
+    "vln_tm_to_bm": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_bm_to_tm": (i32, [ptr, ptr, i32, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),
     "vln_shadow_refresh": (i32, [ptr, i32, ptr]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
-    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, ptr]),
-    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_lstm_sync_seq_offset": (i64, [i32, i32, i32]),
+    "vln_lstm_sync_granule_range": (i32, [i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr]),
+    "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr]),
+    "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),

@@ -238,14 +238,40 @@ extern "C" int vln_dropout_mask(float* out, int64_t n, uint64_t seed, uint64_t o
   return export_dropout_mask((hipStream_t)s, out, n, DropSpec{seed, offset, p});
 }
 extern "C" int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols,
-                                 uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+                                 uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!x || !y) { set_error("vln_scale_dropout: null pointer"); return VLN_ERR_ARG; }
-  return scale_dropout((hipStream_t)s, x, ldx, y, ldy, rows, cols, DropSpec{seed, offset, p});
+  return scale_dropout((hipStream_t)s, x, ldx, y, ldy, rows, cols, drop_spec(seed, offset, p, offset_base_dev));
 }
 extern "C" int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed,
                                         uint64_t offset, float p, void* copy_bf16, vln_stream_t s) {
   if (!x) { set_error("vln_feat_dropout_inplace: null pointer"); return VLN_ERR_ARG; }
   return feat_dropout_inplace((hipStream_t)s, x, xtype, rows, img, angle, DropSpec{seed, offset, p}, copy_bf16);
+}
+
+// ---- device-resident counters (runtime.DeviceClock) ----------------------------------------------------------------
+namespace vln {
+struct TickArgs { unsigned long long* w64[VLN_TICK_MAX]; unsigned long long inc64[VLN_TICK_MAX]; unsigned* w32[VLN_TICK_MAX];
+                  unsigned inc32[VLN_TICK_MAX]; int n; };
+__global__ void tick_kernel(TickArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n) {
+    if (a.w64[i]) *a.w64[i] += a.inc64[i];
+    if (a.w32[i]) *a.w32[i] += a.inc32[i];
+  }
+}
+}  // namespace vln
+extern "C" int vln_tick(const vln_tick_item* items, int n, vln_stream_t s) {
+  if (!items || n <= 0 || n > VLN_TICK_MAX) { set_error("vln_tick: 1..%d items", VLN_TICK_MAX); return VLN_ERR_ARG; }
+  TickArgs a{};
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].word || (items[i].width != 4 && items[i].width != 8)) { set_error("vln_tick: item %d: null word or width not 4 / 8", i); return VLN_ERR_ARG; }
+    if (items[i].width == 8) { a.w64[i] = (unsigned long long*)items[i].word; a.inc64[i] = items[i].inc; }
+    else { a.w32[i] = (unsigned*)items[i].word; a.inc32[i] = (unsigned)items[i].inc; }
+  }
+  VLN_LAUNCH(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("tick");
+  return VLN_OK;
 }
 
 extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {

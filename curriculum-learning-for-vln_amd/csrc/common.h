@@ -174,3 +174,8 @@ struct DropSpec {      // one dropout site; p == 0 disables it
   const unsigned long long* step = nullptr;
   __device__ __forceinline__ uint64_t off() const { return step ? (uint64_t)(*step) * 8ull + offset : offset; }
 };
+// C-ABI form: `offset_base_dev` (nullable) = a device word; the site's Philox offset is then (*offset_base_dev) * 8 + offset,
+// read on the device, so the launch arguments repeat from iteration to iteration (whole-iteration graphs, runtime.DeviceClock)
+static inline DropSpec drop_spec(uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev) {
+  return DropSpec{seed, offset, p, reinterpret_cast<const unsigned long long*>(offset_base_dev)};
+}

@@ -462,46 +462,47 @@ static inline int nblk(long n, int cap = 4096) {
 using namespace vln;
 
 extern "C" int vln_embed_fwd(const int64_t* tokens, const float* E, float* out_tm, int B, int L, int D,
-                             uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+                             uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tokens || !E || !out_tm || B <= 0 || L <= 0 || D <= 0) { set_error("vln_embed_fwd: bad args"); return VLN_ERR_ARG; }
   const int vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out_tm)) & 15) == 0;
   VLN_LAUNCH(embed_fwd_kernel, dim3(nblk(vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
-                     (const long long*)tokens, E, out_tm, B, L, D, DropSpec{seed, offset, p}, vec);
+                     (const long long*)tokens, E, out_tm, B, L, D, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("embed_fwd");
   return VLN_OK;
 }
 extern "C" int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE, int B,
                              int L, int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p,
-                             vln_stream_t s) {
+                             const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tokens || !lengths || !dx_tm || !dE) { set_error("vln_embed_bwd: null pointer"); return VLN_ERR_ARG; }
   VLN_LAUNCH(embed_bwd_kernel, dim3(nblk((long)B * L * D)), dim3(256), 0, (hipStream_t)s,
-                     (const long long*)tokens, lengths, dx_tm, dE, B, L, D, (long)padding_idx, DropSpec{seed, offset, p});
+                     (const long long*)tokens, lengths, dx_tm, dE, B, L, D, (long)padding_idx, drop_spec(seed, offset, p, offset_base_dev));
   VLN_CHECK_LAUNCH("embed_bwd");
   return VLN_OK;
 }
 extern "C" int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE, int B, int L,
-                                 int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
+                                 int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p,
+                                 const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tokens || !lengths || !dx_tm || !dE || V <= 0 || D <= 0 || D > 1024) { set_error("vln_embed_bwd_det: bad args (D <= 1024)"); return VLN_ERR_ARG; }
   VLN_LAUNCH(embed_bwd_det_kernel, dim3(V), dim3(256), 0, (hipStream_t)s, (const long long*)tokens, lengths, dx_tm, dE, B, L,
-                     D, (long)padding_idx, DropSpec{seed, offset, p});
+                     D, (long)padding_idx, drop_spec(seed, offset, p, offset_base_dev));
   VLN_CHECK_LAUNCH("embed_bwd_det");
   return VLN_OK;
 }
 extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, int L, int W, uint64_t seed,
-                            uint64_t offset, float p, vln_stream_t s) {
+                            uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_tm_to_bm: null pointer"); return VLN_ERR_ARG; }
   const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm) | reinterpret_cast<uintptr_t>(bm_bf16)) & 15) == 0;
   VLN_LAUNCH(tm_to_bm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
-                     (bf16_raw*)bm_bf16, B, L, W, DropSpec{seed, offset, p}, vec);
+                     (bf16_raw*)bm_bf16, B, L, W, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("tm_to_bm");
   return VLN_OK;
 }
 extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p,
-                            vln_stream_t s) {
+                            const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_bm_to_tm: null pointer"); return VLN_ERR_ARG; }
   const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm)) & 15) == 0;
   VLN_LAUNCH(bm_to_tm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
-                     L, W, DropSpec{seed, offset, p}, vec);
+                     L, W, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("bm_to_tm");
   return VLN_OK;
 }
@@ -689,9 +690,21 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
 // per-buffer launch sequence (persist_tag_base).
 static long sync_off_gfwd(int B, int Hd, int dirs) { return kSyncHeaderBytes + persist_bwd_exchange_floats(B, Hd, dirs) * 4; }
 static long sync_off_gbwd(int B, int Hd, int dirs) { return sync_off_gfwd(B, Hd, dirs) + persist_g_fwd_bytes(B, Hd, dirs); }
+// ... | one 128-byte line: word 0 = the device-resident launch sequence of the granule protocol (device_seq form)
+static long sync_off_seq(int B, int Hd, int dirs) { return sync_off_gbwd(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs); }
 extern "C" int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs) {
-  if (B <= 0 || Hd <= 0 || dirs < 1) return kSyncHeaderBytes;
-  return sync_off_gbwd(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs);
+  if (B <= 0 || Hd <= 0 || dirs < 1) return kSyncHeaderBytes + 128;
+  return sync_off_seq(B, Hd, dirs) + 128;
+}
+extern "C" int64_t vln_lstm_sync_seq_offset(int B, int Hd, int dirs) {
+  if (B <= 0 || Hd <= 0 || dirs < 1) return -1;
+  return sync_off_seq(B, Hd, dirs);
+}
+extern "C" int vln_lstm_sync_granule_range(int B, int Hd, int dirs, int64_t* offset, int64_t* bytes) {
+  if (B <= 0 || Hd <= 0 || dirs < 1 || !offset || !bytes) { set_error("vln_lstm_sync_granule_range: bad args"); return VLN_ERR_ARG; }
+  *offset = sync_off_gfwd(B, Hd, dirs);
+  *bytes = persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs);
+  return VLN_OK;
 }
 
 // Tag base of the next granule-protocol launch on this buffer: (sequence << 8), sequence = 1, 2, ... per buffer address.
@@ -715,7 +728,8 @@ static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long g
 }
 
 template <typename TW>
-static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
+                                const unsigned* seq_dev, unsigned seq_rel) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);
@@ -725,7 +739,7 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel); \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -741,7 +755,8 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
 }
 
 template <typename TW>
-static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid) {
+static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
+                                const unsigned* seq_dev, unsigned seq_rel) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   const dim3 g1(grid.x * grid.y * grid.z);
@@ -750,7 +765,7 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_bwd_kernel<TW, NT_>);                                  \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    VLN_LAUNCH((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm);         \
+    VLN_LAUNCH((lstm_persist_g_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel); \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -767,7 +782,7 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
                                 int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
-                                int64_t sync_ws_bytes, vln_stream_t s) {
+                                int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
@@ -786,15 +801,16 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
     unsigned tag_base = 0;
     unsigned char* gex = static_cast<unsigned char*>(sync_ws) + sync_off_gfwd(B, Hd, dirs);
-    if (fwd_granules()) {
+    const unsigned* seq_dev = device_seq >= 0 ? reinterpret_cast<const unsigned*>(static_cast<char*>(sync_ws) + sync_off_seq(B, Hd, dirs)) : nullptr;
+    if (fwd_granules() && !seq_dev) {
       r = persist_tag_base(st, sync_ws, sync_off_gfwd(B, Hd, dirs), persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs), &tag_base);
       if (r) return r;
     }
     {
       ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
       if (fwd_granules())
-        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid)
-                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid);
+        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq)
+                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq);
       else
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
@@ -834,7 +850,7 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
                                 float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
-                                int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s) {
+                                int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2 || ((dh_init_bm == nullptr) != (dc_init_bm == nullptr))) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
   const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
@@ -854,15 +870,16 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
     unsigned tag_base = 0;
     unsigned char* gex = static_cast<unsigned char*>(sync_ws) + sync_off_gbwd(B, Hd, dirs);
-    if (bwd_granules()) {
+    const unsigned* seq_dev = device_seq >= 0 ? reinterpret_cast<const unsigned*>(static_cast<char*>(sync_ws) + sync_off_seq(B, Hd, dirs)) : nullptr;
+    if (bwd_granules() && !seq_dev) {
       r = persist_tag_base(st, sync_ws, sync_off_gfwd(B, Hd, dirs), persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs), &tag_base);
       if (r) return r;
     }
     {
       ProfScope prof(st, K_LSTM_REC_BWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 4 + 1 + 1 + 1 + 4)));
       if (bwd_granules())
-        r = (wtype == VLN_BF16) ? launch_persist_g_bwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid)
-                                : launch_persist_g_bwd<float>(st, a, cw + 32, gex, tag_base, grid);
+        r = (wtype == VLN_BF16) ? launch_persist_g_bwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq)
+                                : launch_persist_g_bwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq);
       else
         r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
                                 : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);

@@ -15,6 +15,9 @@
 // consumer of its group (it needs every member's step-s data before it can publish step s+1, which reuses the slot of s-1).
 // Tags: (per-buffer launch sequence << 8) | (step + 1); the host hands every launch of a buffer a new sequence number and
 // clears the buffer when the 24-bit sequence wraps, so a stale granule can never carry a live tag.  L <= 255 on this path.
+// Device-sequence form (vln_lstm_seq_fwd(device_seq >= 0)): the sequence is a 32-bit word at the end of sync_ws + the
+// launch's small relative index; the caller bumps the word between iterations (vln_tick) and clears the granule regions
+// before the 24-bit value wraps (runtime.DeviceClock does both).
 // Spins are bounded; a timeout sets the status words (encoder.hip: vln_persistent_check) and lets the kernel drain.
 // Summation orders equal the counter-protocol kernels': results are bit-identical to theirs.
 #pragma once
@@ -66,7 +69,11 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NS>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
-                                                                 unsigned tag_base, int xcd_map) {
+                                                                 unsigned tag_base, int xcd_map, const unsigned* seq_dev = nullptr,
+                                                                 unsigned seq_rel = 0) {
+  // launch sequence in DEVICE memory (whole-iteration graphs: the launch arguments must repeat): the word is bumped by a
+  // stream-ordered tick launch between iterations (vln_tick), never while a launch that reads it is in flight
+  if (seq_dev) tag_base = ((*seq_dev + seq_rel) & 0xFFFFFFu) << 8;
   constexpr int HD = NS * RecCfg<TW>::BK;
   constexpr int LDH = HD + 4;
   constexpr int NLD = HD / 32;                 // 16-byte loads per thread per sweep: 16 rows x HD granules x 8 B / (256 x 16 B)
@@ -223,7 +230,9 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
 // ---------------------------------------------------------------------------------------------------------
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
 __global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
-                                                                 unsigned tag_base, int xcd_map) {
+                                                                 unsigned tag_base, int xcd_map, const unsigned* seq_dev = nullptr,
+                                                                 unsigned seq_rel = 0) {
+  if (seq_dev) tag_base = ((*seq_dev + seq_rel) & 0xFFFFFFu) << 8;
   constexpr int HD = NT * 64;
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
   constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns

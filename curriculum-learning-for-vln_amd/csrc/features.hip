@@ -146,7 +146,8 @@ extern "C" int vln_gather_step(const void* table, int ttype, const float* angle_
 }
 
 extern "C" int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T,
-                                  int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, vln_stream_t s) {
+                                  int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev,
+                                  vln_stream_t s) {
   if (!table || !angle_table || !steps || T <= 0 || B <= 0 || V <= 0 || C <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
     set_error("vln_gather_rollout: bad args (IMG and ANG must be multiples of 8)");
     return VLN_ERR_ARG;
@@ -164,7 +165,7 @@ extern "C" int vln_gather_rollout(const void* table, int ttype, const float* ang
       }
       a.step[t] = GatherStepArgs{table, angle_table, (const long long*)q.rows, q.view_index, (const long long*)q.crows, q.cviews,
                                  q.heading, q.elevation, q.out, (bf16_raw*)q.out_bf16, q.cout, (bf16_raw*)q.cout_bf16, B, V, C, IMG, ANG,
-                                 DropSpec{seed, q.offset_pano, p_feat}, DropSpec{seed, q.offset_cand, p_feat}};
+                                 drop_spec(seed, q.offset_pano, p_feat, offset_base_dev), drop_spec(seed, q.offset_cand, p_feat, offset_base_dev)};
     }
     dim3 grid((unsigned)(a.T * nrows)), block(256);
     if (ttype == VLN_BF16) VLN_LAUNCH(gather_rollout_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);

@@ -11,6 +11,8 @@ ONE weight-gradient contraction over (L x B) per weight.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -22,6 +24,20 @@ _p = ops._p
 
 def _stream():
     return _lib.raw_stream()
+
+
+class _Off:
+    """Where a call's dropout offsets and launch sequence come from.  Host form: `v` = the module's call counter, the site
+    offset is v * 8 + k, the recurrence counts its launches on the host.  Clock form (runtime.DeviceClock): `v` = the call's
+    small index since the last tick, `base` = the clock's device word (the kernels form (word + v) * 8 + k), `seq` = the
+    launch's index into the device-resident launch sequence (forward 2v, backward 2v + 1)."""
+    __slots__ = ("v", "base", "seq")
+
+    def __init__(self, v, base=None, seq=-1):
+        self.v, self.base, self.seq = int(v), base, int(seq)
+
+    def site(self, k):
+        return self.v * 8 + k
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -38,8 +54,8 @@ class _EncoderFn(torch.autograd.Function):
         wtype = ops.BF16 if mod.compute_dtype == torch.bfloat16 else ops.F32
         p_emb = 0.0 if mod.use_glove else p_drop
         x = ops.empty(L * B, E, **f32)
-        _lib.check(lib.vln_embed_fwd(_p(tokens), _p(mod.embedding.weight), _p(x), B, L, E, seed, offset * 8 + 0,
-                                     p_emb, _stream()), "vln_embed_fwd")
+        _lib.check(lib.vln_embed_fwd(_p(tokens), _p(mod.embedding.weight), _p(x), B, L, E, seed, offset.site(0),
+                                     p_emb, offset.base, _stream()), "vln_embed_fwd")
         saved = []
         p_inter = p_drop if nl > 1 else 0.0
         for k in range(nl):
@@ -53,13 +69,13 @@ class _EncoderFn(torch.autograd.Function):
             ccat = ops.empty(B, dirs * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
                                             _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
-                                            *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_fwd")
+                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq, _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:
                 if p_inter > 0:
                     xn = ops.empty_like(y)
                     _lib.check(lib.vln_scale_dropout(_p(y), y.stride(0), _p(xn), xn.stride(0), L * B, dirs * Hd, seed,
-                                                     offset * 8 + 2 + k, p_inter, _stream()), "vln_scale_dropout")
+                                                     offset.site(2 + k), p_inter, offset.base, _stream()), "vln_scale_dropout")
                     x = xn
                 else:
                     x = y
@@ -67,7 +83,7 @@ class _EncoderFn(torch.autograd.Function):
         ctx_out = ops.empty(B, L, H, **f32)
         # bf16 mode: the stream copy of the context the decoders' attention reads comes out of the same pass
         ctx_lp = ops.empty(B, L, H, dtype=torch.bfloat16, device=dev) if wtype == ops.BF16 else None
-        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
+        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset.site(1), p_drop, offset.base, _stream()),
                    "vln_tm_to_bm")
         mod._last_ctx_lp = ctx_lp
         dec_init = ops.linear_fwd(hcat, sh["w_e2d"], mod.enc2dec.bias.detach(), ops.ACT_TANH)
@@ -127,7 +143,7 @@ class _EncoderFn(torch.autograd.Function):
         if dctx is not None:
             dy = ops.empty(L * B, H, **f32)
             dctx = dctx.contiguous()
-            _lib.check(lib.vln_bm_to_tm(_p(dctx), _p(dy), B, L, H, seed, offset * 8 + 1, p_drop, _stream()),
+            _lib.check(lib.vln_bm_to_tm(_p(dctx), _p(dy), B, L, H, seed, offset.site(1), p_drop, offset.base, _stream()),
                        "vln_bm_to_tm")
         for k in range(nl - 1, -1, -1):
             x, hprev, cprev, act, tanh_c = ctx.saved[k]
@@ -143,7 +159,8 @@ class _EncoderFn(torch.autograd.Function):
             dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs,
-                                            *mod._sync_ws(dev, B, Hd, dirs), _stream()), "vln_lstm_seq_bwd")
+                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq + 1 if offset.seq >= 0 else -1, _stream()),
+                       "vln_lstm_seq_bwd")
             cbt = ops.ColsumBatch()       # ... and its bias gradients
             wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode
             for d in range(dirs):
@@ -184,7 +201,7 @@ class _EncoderFn(torch.autograd.Function):
                     if p_inter > 0:
                         dy = ops.empty_like(dx)
                         _lib.check(lib.vln_scale_dropout(_p(dx), dx.stride(0), _p(dy), dy.stride(0), L * B, dx.shape[1],
-                                                         seed, offset * 8 + 2 + (k - 1), p_inter, _stream()),
+                                                         seed, offset.site(2 + (k - 1)), p_inter, offset.base, _stream()),
                                    "vln_scale_dropout")
                     else:
                         dy = dx
@@ -196,10 +213,10 @@ class _EncoderFn(torch.autograd.Function):
                     if mod.deterministic_embedding_grad and mod.embed_size <= 1024:      # fixed summation order, no float atomics
                         _lib.check(lib.vln_embed_bwd_det(_p(tokens), _p(lens32), _p(dx), _p(dE), B, L, mod.embed_size,
                                                          mod.embedding.num_embeddings, -1 if pad is None else pad, seed,
-                                                         offset * 8 + 0, p_emb, _stream()), "vln_embed_bwd_det")
+                                                         offset.site(0), p_emb, offset.base, _stream()), "vln_embed_bwd_det")
                     else:
                         _lib.check(lib.vln_embed_bwd(_p(tokens), _p(lens32), _p(dx), _p(dE), B, L, mod.embed_size,
-                                                     -1 if pad is None else pad, seed, offset * 8 + 0, p_emb, _stream()),
+                                                     -1 if pad is None else pad, seed, offset.site(0), p_emb, offset.base, _stream()),
                                    "vln_embed_bwd")
                     if not inplace:
                         grads["embedding.weight"] = dE
@@ -255,11 +272,25 @@ class EncoderLSTM(nn.Module):
     def _sync_ws(self, dev, B, Hd, dirs):
         """(pointer, bytes) of the device scratch of the persistent recurrence: group counters + status word, then the
         backward's partial-dh exchange buffer (vln_lstm_sync_ws_bytes)."""
-        need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
+        lib = _lib.load()
+        need = int(lib.vln_lstm_sync_ws_bytes(B, Hd, dirs))
         w = getattr(self, "_sync_buf", None)
         if w is None or w.device != dev or w.numel() * 4 < need:
             w = torch.zeros((need + 3) // 4, dtype=torch.int32, device=dev)
             self._sync_buf = w
+            self._sync_mode = None
+        clock = self.__dict__.get("clock")
+        mode = (None if clock is None else id(clock), B, Hd, dirs)
+        if self.__dict__.get("_sync_mode") != mode:
+            # The exchange's tags count launches: by the library on the host, or from the clock's device word.  When the
+            # counting changes hands (or the layout changes) old tags mean nothing: clear the exchange once.
+            go, gb = _lib.i64(), _lib.i64()
+            _lib.check(lib.vln_lstm_sync_granule_range(B, Hd, dirs, C.byref(go), C.byref(gb)), "vln_lstm_sync_granule_range")
+            if self.__dict__.get("_sync_mode") is not None or clock is not None:
+                w[go.value // 4:(go.value + gb.value) // 4].zero_()
+            if clock is not None:
+                clock.register_sequence(w, int(lib.vln_lstm_sync_seq_offset(B, Hd, dirs)), go.value, gb.value)
+            self._sync_mode = mode
         return w.data_ptr(), w.numel() * 4
 
     def persistent_status(self) -> int:
@@ -315,13 +346,20 @@ class EncoderLSTM(nn.Module):
             with torch.no_grad():
                 self._refresh_shadows()
             self._shadow.commit(key)
-        self._calls += 1
+        clock = self.__dict__.get("clock")
+        if clock is not None:          # runtime.DeviceClock: offsets / launch sequence relative to device words (graph-capturable)
+            r = clock.rel(id(self))
+            self._calls = clock.value(r)            # what a host counter would hold: the offset the tests export masks with
+            off = _Off(r, clock.ptr, 2 * (r - 1))
+        else:
+            self._calls += 1
+            off = _Off(self._calls)
         tokens = inputs.contiguous()
         if tokens.dtype != torch.int64:
             tokens = tokens.long()
         lens32 = torch.as_tensor(lengths).to(device=inputs.device, dtype=torch.int32)
         p = self.drop_ratio if self.training else 0.0
-        ctx, dec_init, c_t = _EncoderFn.apply(self, tokens, lens32, p, self._calls, *params)
+        ctx, dec_init, c_t = _EncoderFn.apply(self, tokens, lens32, p, off, *params)
         lp, self._last_ctx_lp = self.__dict__.get("_last_ctx_lp"), None
         if lp is not None:
             ctx._vln_lp = lp          # picked up by the decoders instead of casting the context again (runtime._ctx_lp)

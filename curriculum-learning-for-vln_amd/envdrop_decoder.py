@@ -622,7 +622,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.hq, io.xcat, io.tcat, io.htd = q, q + 4 * B * H, q + 4 * B * (H + XK), q + 4 * B * (H + XK + 2 * H)
         keep["flat"] = flat
         q = flat.data_ptr()
-        base_mode = self.step_graphs and need_grad
+        # offsets relative to a device word: per-step graphs (arena) and runtime.DeviceClock (whole-iteration graphs)
+        base_mode = (self.step_graphs or self.__dict__.get("clock") is not None) and need_grad
         if self.step_graphs and not base_mode:     # the step's dropout offset lives on the device: launch arguments repeat
             io.offset_dev = q
         q += 16

@@ -280,7 +280,7 @@ def _scale_dropout(x, p, seed, offset):
     y = ops.empty(xc.shape, dtype=torch.float32, device=xc.device)
     cols = xc.shape[-1] if xc.dim() > 0 else 1
     rows = xc.numel() // max(cols, 1)
-    st = _lib.load().vln_scale_dropout(_p(xc), cols, _p(y), cols, rows, cols, seed, offset, p, _lib.raw_stream())
+    st = _lib.load().vln_scale_dropout(_p(xc), cols, _p(y), cols, rows, cols, seed, offset, p, None, _lib.raw_stream())
     if st:
         _lib.check(st, "vln_scale_dropout")
     return y
@@ -744,7 +744,7 @@ class FollowerCoreFn(torch.autograd.Function):
         xcat[:, A + F:].copy_(h0)
         if pd > 0:                                               # dropout over cat(a_prev, pano) (policy.py:49), in place
             st = _lib.load().vln_scale_dropout(xcat.data_ptr(), xcat.stride(0), xcat.data_ptr(), xcat.stride(0), B, A + F, seed, off, pd,
-                                               _lib.raw_stream())
+                                               None, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_scale_dropout")
         # (2) LSTM cell
@@ -809,7 +809,7 @@ class FollowerCoreFn(torch.autograd.Function):
         dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, dtype, True))  # [B, A+F+H] -> a_prev | pano | h0
         if pd > 0:
             st = _lib.load().vln_scale_dropout(dxcat.data_ptr(), dxcat.stride(0), dxcat.data_ptr(), dxcat.stride(0), B, A + F, seed, off, pd,
-                                               _lib.raw_stream())
+                                               None, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_scale_dropout")
         # (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq)

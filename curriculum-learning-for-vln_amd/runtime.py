@@ -23,6 +23,107 @@ import torch
 from . import ops
 
 
+class DeviceClock:
+    """Device-resident counters for everything a training iteration used to take from the HOST per launch: the Philox offset
+    base of every dropout site and the launch sequence of the persistent recurrence's data-tagged hand-offs.  With a clock
+    attached (`clock.attach(encoder, decoder, ...)`) the modules hand the kernels a DEVICE word plus a small per-call index
+    instead of an absolute value, so the launch arguments of an iteration repeat and the WHOLE iteration -- encoder, decoder
+    steps, loss, backward, optimizer -- can be captured as one hipGraph (`graphs.IterationGraph`) whose replays still draw
+    fresh dropout masks.  `tick()` = one 1-thread launch at the top of every iteration (inside the graph when captured).
+
+    Offsets: word[0] after k ticks = k * STRIDE; call number r (1, 2, ...) of a module since the last tick uses Philox offset
+    (word + r) * 8 + site -- exactly what a host counter that stood at `host` would have produced (`value(r)`), which is how
+    the tests export the masks.  Launch sequences: every registered recurrence buffer's 32-bit word is bumped by the same
+    launch; before its low 24 bits wrap the exchange is cleared (between replays, on the stream)."""
+    STRIDE = 64
+
+    def __init__(self, device):
+        from . import _lib
+        self.device = torch.device(device)
+        self.word = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.ptr = self.word.data_ptr()
+        self.host = 0                # value of the device word once every tick issued so far has run
+        self.epoch = 0
+        self._rel: Dict[object, int] = {}
+        self._seqs = []              # [sync buffer (int32 tensor), seq word index, granule slice (int32 view), host mirror]
+        self._items = None
+
+    def attach(self, *modules):
+        for m in modules:
+            m.clock = self
+        return self
+
+    def rel(self, key, limit: Optional[int] = None) -> int:
+        r = self._rel.get(key, 0) + 1
+        if r > (self.STRIDE - 1 if limit is None else limit):
+            raise RuntimeError(f"DeviceClock: more than {self.STRIDE - 1 if limit is None else limit} calls of one module between two ticks")
+        self._rel[key] = r
+        return r
+
+    def value(self, rel: int) -> int:
+        """The absolute Philox offset (in the host-counter convention) of call `rel` since the last tick."""
+        return self.host + rel
+
+    def register_sequence(self, buf: torch.Tensor, seq_byte_offset: int, gran_byte_offset: int, gran_bytes: int):
+        """A recurrence scratch buffer (EncoderLSTM._sync_ws) joins: its exchange is cleared once (tags of the host-counted
+        form may be anything), its sequence word starts at 0 and is bumped by every tick from now on."""
+        for s in self._seqs:
+            if s[0] is buf:
+                return
+        gran = buf[gran_byte_offset // 4:(gran_byte_offset + gran_bytes) // 4]
+        gran.zero_()
+        buf[seq_byte_offset // 4].zero_()
+        self._seqs.append([buf, seq_byte_offset // 4, gran, 0])
+        self._items = None
+
+    def _tick_items(self):
+        from . import _lib
+        if self._items is None:
+            rows = [(self.ptr, self.STRIDE, 8)] + [(s[0].data_ptr() + 4 * s[1], self.STRIDE, 4) for s in self._seqs]
+            if len(rows) > 8:
+                raise RuntimeError("DeviceClock: at most 7 recurrence buffers per clock")
+            self._items = ((_lib.TickItem * len(rows))(*[_lib.TickItem(p, inc, w, 0) for p, inc, w in rows]), len(rows))
+        return self._items
+
+    def _maintain(self):
+        """Host mirror of the bump + the wrap guard of the 24-bit launch sequences (runs OUTSIDE a captured graph)."""
+        self.host += self.STRIDE
+        self.epoch += 1
+        self._rel.clear()
+        for s in self._seqs:
+            s[3] += self.STRIDE
+            if s[3] + 2 * self.STRIDE >= (1 << 24):      # clear the exchange and restart the sequence, stream-ordered
+                s[2].zero_()
+                s[0][s[1]].zero_()
+                s[3] = 0
+
+    def restart_sequences(self):
+        """Clear every registered exchange and restart its launch sequence (called right before a graph capture, so that the
+        wrap guard cannot fire INSIDE the captured iteration)."""
+        for s in self._seqs:
+            s[2].zero_()
+            s[0][s[1]].zero_()
+            s[3] = 0
+
+    def tick(self):
+        """Top of an iteration: bump the device words (one launch on the current stream) and the host mirror."""
+        from . import _lib
+        self._maintain()        # the clear (if due) is ordered BEFORE the bump: after it the word holds STRIDE, like the mirror
+        items, n = self._tick_items()
+        _lib.check(_lib.load().vln_tick(items, n, _lib.raw_stream()), "vln_tick")
+
+    def uncount(self):
+        """Undo the host side of one tick(): a tick that was CAPTURED did not run, the device words are unchanged."""
+        self.host -= self.STRIDE
+        self.epoch -= 1
+        for s in self._seqs:
+            s[3] = max(0, s[3] - self.STRIDE)
+
+    def replayed(self):
+        """A captured graph that contains this clock's tick launch is about to be replayed: advance the host side only."""
+        self._maintain()
+
+
 class ShadowSet:
     def __init__(self):
         self._key = None
@@ -312,6 +413,10 @@ class GatedModuleMixin:
         return ctx_t, e
 
     def _next_offset(self) -> int:
+        clock = self.__dict__.get("clock")
+        if clock is not None:        # DeviceClock: call r since the tick -> the offset a host counter at clock.host would give
+            self._step_counter = clock.value(clock.rel(id(self)))
+            return self._step_counter
         self._step_counter += 1
         return self._step_counter
 
@@ -319,6 +424,10 @@ class GatedModuleMixin:
         """Dropout offsets of the rollouts recorded under the gate that just opened are counted from a base value held
         in a device word (one of two, alternating per gate: the previous gate's backward may still read the other one).
         Written once here; the steps then carry only their small relative offset (see vln_envdrop_step.offset_base_dev)."""
+        clock = self.__dict__.get("clock")
+        if clock is not None:        # the clock's word IS the base: nothing to write, the tick launch bumps it
+            self._base_value, self._base_ptr = clock.host, clock.ptr
+            return
         b = self.__dict__.get("_offset_bases")
         if b is None or b.device != device:
             b = self._offset_bases = torch.zeros(2, dtype=torch.int64, device=device)

@@ -48,7 +48,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         lens32 = torch.full((B,), L, dtype=torch.int32, device=dev)
         _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), ops.F32, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
-                                        *owner._sync_ws(dev, B, Hd, dirs), _lib.raw_stream()), "vln_lstm_seq_fwd")
+                                        *owner._sync_ws(dev, B, Hd, dirs), -1, _lib.raw_stream()), "vln_lstm_seq_fwd")
         ctx.owner, ctx.dims = owner, (B, L, Hd, dirs)
         ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh)
         ctx.set_materialize_grads(False)
@@ -68,7 +68,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         dyc = dy.contiguous() if dy is not None else None
         _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), ops.F32, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
                                         _p(dh_pass), _p(dc_carry), None, None, B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
-                                        _lib.raw_stream()), "vln_lstm_seq_bwd")
+                                        -1, _lib.raw_stream()), "vln_lstm_seq_bwd")
         grads = []
         for d in range(dirs):
             dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]

@@ -171,14 +171,20 @@ class DeviceFeatureStore:
         arr = (_lib.GatherRolloutStep * len(steps))()
         out, keep = [], []
         seed, p = 0, 0.0
+        clock = self.__dict__.get("clock")        # runtime.DeviceClock (whole-iteration graphs)
         for t, (rows, view_index, crows, cviews, heading, elevation) in enumerate(steps):
             B, C = crows.shape
             img = ops.empty(B, self.V, F, dtype=torch.float32, device=dev) if f32 else None
             cand = ops.empty(B, C, F, dtype=torch.float32, device=dev) if f32 else None
             img_lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
             cand_lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
-            seed, off1, p = self._drop(p_feat)
-            _, off2, _ = self._drop(p_feat)
+            if clock is not None:      # offsets relative to the clock's device word: (word * 8 + r), r < 8 * STRIDE
+                seed, p = self.seed, float(p_feat)
+                off1 = clock.rel(id(self), 8 * clock.STRIDE - 1)
+                off2 = clock.rel(id(self), 8 * clock.STRIDE - 1)
+            else:
+                seed, off1, p = self._drop(p_feat)
+                _, off2, _ = self._drop(p_feat)
             cr, cv, hd, el = crows.contiguous(), cviews.contiguous(), heading.contiguous(), elevation.contiguous()
             keep += [cr, cv, hd, el]
             q = arr[t]
@@ -190,7 +196,8 @@ class DeviceFeatureStore:
                 raise ValueError("gather_rollout: every step must have the same [B, C] candidate layout")
         B, C = steps[0][2].shape
         _lib.check(lib.vln_gather_rollout(_p(self.table), ops._dt(self.table), _p(self.angle_table), arr, len(steps), B, self.V, C,
-                                          self.IMG, self.ANG, seed, p, _lib.raw_stream()), "vln_gather_rollout")
+                                          self.IMG, self.ANG, seed, p, None if clock is None else clock.ptr, _lib.raw_stream()),
+                   "vln_gather_rollout")
         return out
 
 

@@ -41,6 +41,11 @@ const char* vln_last_error_string(void);
 /* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
  * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
 int vln_set_graphs(int on);
+/* Device-resident counters: ONE tiny launch adds inc to every listed word (width 8: uint64, width 4: uint32) -- the dropout
+ * clock (`offset_base_dev`) and the recurrence's launch sequence (vln_lstm_sync_seq_offset) of a whole-iteration graph. */
+#define VLN_TICK_MAX 8
+typedef struct vln_tick_item { void* word; uint64_t inc; int32_t width; int32_t pad_; } vln_tick_item;
+int vln_tick(const vln_tick_item* items, int n /* 1..VLN_TICK_MAX */, vln_stream_t s);
 /* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] times a chain's capturing was paused (2 x capacity captures without one replay) */
 int vln_graph_stats(int64_t out[3]);
 /* performance / A-B tunables, ids 0..7 (never change results beyond summation order; documented in
@@ -164,7 +169,7 @@ int vln_lstm_pointwise_bwd(const float* dh1, const float* dh1_drop, const float*
 /* nn.Dropout replacements: Philox4x32-10 keyed by (seed, offset, element index) */
 int vln_dropout_mask(float* out_scaled_mask, int64_t n, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
 int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, uint64_t seed,
-                      uint64_t offset, float p, vln_stream_t s);
+                      uint64_t offset, float p, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/, vln_stream_t s);
 /* EnvDropDecoder feature dropout, in place on x[..., :img] (policy.py:226-231); optional bf16 copy of x */
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
                              float p, void* copy_bf16, vln_stream_t s);
@@ -437,7 +442,8 @@ typedef struct vln_gather_rollout_step {
   uint64_t offset_pano, offset_cand;
 } vln_gather_rollout_step;
 int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T, int B, int V,
-                       int C, int IMG, int ANG, uint64_t seed, float p_feat, vln_stream_t s);
+                       int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/,
+                       vln_stream_t s);
 int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index, const float* angle_table,
                     float* out, void* out_bf16, int B, int V, int IMG, int ANG, uint64_t seed, uint64_t offset, float p_feat,
                     vln_stream_t s);
@@ -455,17 +461,23 @@ int vln_gather_step(const void* table, int ttype, const float* angle_table, cons
  * Internal layout is TIME-major: row (t*B + b).  nn.Embedding + Dropout -> vln_embed_fwd; the input projection
  * of all steps is one vln_linear_fwd (M = L*B, bias = b_ih + b_hh); the packed recurrence of one layer (both
  * directions per launch, L launches) is vln_lstm_seq_fwd; pad_packed_sequence + Dropout -> vln_tm_to_bm. */
+/* `offset_base_dev` (nullable, here and wherever it appears): a DEVICE word; the site's Philox offset is then
+ * (*offset_base_dev) * 8 + offset, read by the kernel, so the launch arguments repeat from iteration to iteration and the
+ * launch can be captured into a whole-iteration hipGraph (the word is bumped between iterations: vln_tick).  NULL: `offset`
+ * is the Philox offset itself. */
 int vln_embed_fwd(const int64_t* tokens /*[B,L]*/, const float* E, float* out_tm /*[L*B,D]*/, int B, int L, int D,
-                  uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+                  uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s);
 int vln_embed_bwd(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE /* += */, int B, int L,
-                  int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+                  int D, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s);
 /* Same gradient without float atomics (opt-in: ~5x the time): one workgroup per vocabulary row V adds its tokens'
  * gradient rows in a fixed (t, b) order, so the result is reproducible bit for bit (D <= 1024). */
 int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, const float* dx_tm, float* dE /* += */, int B, int L,
-                      int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+                      int D, int V, int64_t padding_idx, uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev,
+                      vln_stream_t s);
 int vln_tm_to_bm(const float* tm /*[L,B,W]*/, float* bm /*[B,L,W]*/, void* bm_bf16 /*nullable*/, int B, int L, int W,
-                 uint64_t seed, uint64_t offset, float p, vln_stream_t s);
-int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p, vln_stream_t s);
+                 uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s);
+int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p,
+                 const uint64_t* offset_base_dev, vln_stream_t s);
 /* xproj [L*B, dirs*4Hd]; w_hh [dirs][4Hd,Hd] (wtype); hprev/cprev [dirs][L][B][Hd] (state fed into time t, written
  * here); y_tm [L*B, dirs*Hd]; act [L*B, dirs*4Hd]; tanh_c [L*B, dirs*Hd]; hcat/ccat [B, dirs*Hd] final states */
 /* sync_ws (nullable): device scratch of vln_lstm_sync_ws_bytes(B, Hd, dirs) bytes, 16-byte aligned: an 8 KB header
@@ -476,11 +488,19 @@ int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed,
  * forward exchanges hidden slices, backward exchanges partial dh blocks, both with write-through stores + a
  * per-group arrival counter.  Otherwise L launches (hipGraph-memoised).  The forward needs only the header. */
 int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs);
+/* The granule hand-off tags every exchanged value with a per-buffer LAUNCH SEQUENCE.  device_seq < 0: the library counts the
+ * launches of a sync_ws on the host (and clears the exchange when the 24-bit count wraps).  device_seq >= 0: the sequence is
+ * the 32-bit device word at byte vln_lstm_sync_seq_offset() of sync_ws PLUS device_seq, read by the kernel -- the launch
+ * arguments then repeat from iteration to iteration (whole-iteration hipGraphs); the caller gives every launch between two
+ * bumps a different device_seq, bumps the word between iterations by more than the largest one (vln_tick) and zeroes the
+ * byte range vln_lstm_sync_granule_range() before the low 24 bits of the word wrap (runtime.DeviceClock does all three). */
+int64_t vln_lstm_sync_seq_offset(int B, int Hd, int dirs);
+int vln_lstm_sync_granule_range(int B, int Hd, int dirs, int64_t* offset, int64_t* bytes);
 int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev, float* cprev,
                      float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B, int L, int Hd, int dirs,
                      const float* h0, const float* c0 /* [dirs][B][Hd] initial state, nullable = zeros (no gradient flows
                      back into it: vln_lstm_seq_bwd starts from the final states only) */,
-                     void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
+                     void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = persistent kernels, granule hand-off forward, counter
                                    * hand-off backward; 2 = counter both ways (round 1); 3 = granules both ways; identical results */
 /* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the
@@ -495,7 +515,7 @@ int vln_persistent_check(void);
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
                      const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry,
                      const float* dh_init_bm /*nullable*/, const float* dc_init_bm /*nullable*/, int B, int L,
-                     int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, vln_stream_t s);
+                     int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s);
 
 /* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
 

@@ -26,10 +26,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ML_WEIGHT, GAMMA = 0.2, 0.9          # configs/envdrop/envdrop_config.yaml:45,42
 
-# bf16 vs the UNROUNDED fp64 oracle over a 35-step sampled rollout: every streamed weight carries a 2^-9 relative rounding that
-# the recurrence (35 LSTM steps, each behind two softmaxes) compounds; measured (gpurun_out/parity_report.json) and asserted:
-CFG3_BF16_EXC = {"logp": 3e-2, "entropy": 3e-2, "values": 3e-2, "rl_loss": 5e-2, "loss": 5e-2,
-                 "grad[dec.visual_attn.linear_in.weight]": 6e-2, "grad[dec.": 4e-2, "grad[enc.": 4e-2, "grad[cri.": 4e-2}
+# bf16 vs the UNROUNDED fp64 oracle (north_star's 1e-2): met by both losses, the log-probs / entropies / values of all 35
+# steps and every encoder / decoder gradient (measured 2e-3 .. 7e-3, gpurun_out/parity_report.json).  The one exception is the
+# critic's hidden layer: its input h_1 differs by ~5e-3 from the oracle's (the rounding of the streamed weights), which flips
+# the ReLU of the units whose pre-activation is near zero -- each flip changes a gradient term by its full size (measured
+# 6e-2 max-abs, 3e-2 in L2; the same-weights oracle, where nothing flips, is met at 6e-3).
+CFG3_BF16_EXC = {"grad[cri.state2value.0": 0.12}
+# bf16 on the SAME rounded weights: activations enter the MFMAs as hi + lo bf16 planes (2^-17 relative, against 2^-24 in fp32
+# mode), and 35 recurrent steps compound that: the entropies of the last steps reach 1.2e-4 (single steps: <= 5e-5)
+CFG3_SAME_EXC = {"entropy": 3e-4, "logp": 3e-4, "values": 3e-4}
 
 
 def _tol(exc, tol, what):
@@ -68,8 +73,8 @@ def _rl_tape(B, T, ncands, g):
     return acts, masks, rewards, lens <= T
 
 
-def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False):
-    """mode 'sum' = cfg3, 'self_pace' = cfg4."""
+def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False, only=None):
+    """mode 'sum' = cfg3, 'self_pace' = cfg4.  `only`: run just the bf16 oracle of that name."""
     import bench
     from oracle import torch_port as O
     H, E, AE, ANG, IMG, V = 512, 256, 64, 128, 2048, 36
@@ -138,7 +143,10 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
 
     # ---- the oracle(s) ---------------------------------------------------------------------------------------------------
     variants = [("fp32", FP32, False, None)] if not lp else \
-        [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, CFG3_BF16_EXC)]
+        [("bf16 same-weights", SAME_BF16, True, dict(CFG3_SAME_EXC, **{"grad[": same_bf16_grad_tol()})),
+         ("bf16 unrounded", BF16, False, CFG3_BF16_EXC)]
+    if only is not None:
+        variants = [v for v in variants if v[0] == only]
     sd = {"enc": enc.state_dict(), "dec": dec.state_dict(), "cri": cri.state_dict()}
     seq_mask = cpu_tape["seq_mask"]
     lengths = cpu_tape["lengths"].tolist()
@@ -222,7 +230,9 @@ def test_cfg3_il_plus_a2c_full_size(vln, cdt):
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_cfg4_self_pace_weighted_full_size(vln, cdt):
-    _iteration(vln, cdt, "self_pace")
+    # bf16: north_star's comparison (the unrounded oracle); the kernels' own arithmetic is pinned by cfg3's same-weights run --
+    # the two configs differ in the loss weighting only
+    _iteration(vln, cdt, "self_pace", only=None if cdt == torch.float32 else "bf16 unrounded")
 
 
 def test_cfg4_self_pace_weight_normalised_form(vln):
