@@ -232,6 +232,15 @@ class GpuAgent:
         self.graph = None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
 
+    def _probe(self):
+        n = getattr(self, "probe_trivial", 0)
+        if n:
+            if getattr(self, "_probe_buf", None) is None:
+                self._probe_buf = torch.zeros(2, 64 * 512, device=next(self.enc.parameters()).device)
+            lib = self.vln._lib.load()
+            self.vln._lib.check(lib.vln_debug_trivial_chain(self._probe_buf[0].data_ptr(), self._probe_buf[1].data_ptr(), 64 * 512, n, 256,
+                                                            self.vln._lib.raw_stream()), "vln_debug_trivial_chain")
+
     def use_clock(self, store=None):
         self.clock = self.vln.DeviceClock(next(self.enc.parameters()).device)
         self.clock.attach(self.enc, self.dec)
@@ -321,6 +330,7 @@ class GpuAgent:
         B = tape["B"]
         if self.clock is not None:
             self.clock.tick()          # one launch: this iteration's dropout offsets / launch sequence (device words)
+        self._probe()
         if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
             self.side.wait_stream(torch.cuda.current_stream())
         if self.copy_stream is not None and self.arena is not None:
@@ -382,6 +392,7 @@ class GpuAgent:
             loss = torch.stack(terms).sum() * w
         if self._one is None or self._one.device != loss.device:
             self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        self._probe()
         loss.backward(self._one)                                 # the root gradient is a constant: no ones_like fill per iteration
         self.opt.allreduce()
         # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
@@ -524,6 +535,10 @@ def main():
                          "replayed (graphs.IterationGraph; dropout offsets and the recurrence's launch sequence come from device words, "
                          "runtime.DeviceClock).  auto: on for one GPU with the resident feature store, off otherwise (the gradient "
                          "all-reduce of N > 1 stays a stream operation between launches)")
+    ap.add_argument("--probe-trivial", type=int, default=0,
+                    help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
+                         "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
+                         "boundary inside this very graph (rocprofv3 reports a ~4.7 us floor for ANY short kernel; unprofiled: 1.95 us)")
     ap.add_argument("--gather-branch", action="store_true",
                     help="with --rollout-gather and the iteration graph: the rollout-wide gather as a captured BRANCH beside the encoder")
     ap.add_argument("--rollout-gather", action="store_true",
@@ -587,6 +602,7 @@ def main():
     agent.prefetch_under_backward = not args.no_backward_prefetch
     agent.rollout_gather = bool(args.rollout_gather)
     agent.gather_branch = bool(args.gather_branch)
+    agent.probe_trivial = int(args.probe_trivial)
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and world == 1 and args.features == "store"
                                                  and not args.no_arena)
     if use_graph and (args.features != "store" or args.ce != "rollout"):

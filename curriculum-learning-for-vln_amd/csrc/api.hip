@@ -274,6 +274,27 @@ extern "C" int vln_tick(const vln_tick_item* items, int n, vln_stream_t s) {
   return VLN_OK;
 }
 
+// ---- measurement only: a chain of trivial DEPENDENT launches (what does a kernel boundary cost inside THIS process / graph?) ----
+namespace vln {
+__global__ __launch_bounds__(256) void debug_trivial_kernel(const float4* in, float4* out, int n4, int shift) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n4) return;
+  int jr = j + shift; if (jr >= n4) jr -= n4;
+  const float4 v = in[jr];
+  out[j] = make_float4(v.x * .5f, v.y * .5f, v.z * .5f, v.w * .5f + 1.f);
+}
+}  // namespace vln
+extern "C" int vln_debug_trivial_chain(float* a, float* b, int n_floats, int launches, int shift, vln_stream_t s) {
+  if (!a || !b || n_floats < 4 || (n_floats & 3) || launches < 1) { set_error("vln_debug_trivial_chain: bad args"); return VLN_ERR_ARG; }
+  const int n4 = n_floats / 4;
+  for (int k = 0; k < launches; ++k) {
+    VLN_LAUNCH(debug_trivial_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float4*)((k & 1) ? b : a),
+               (float4*)((k & 1) ? a : b), n4, shift);
+  }
+  VLN_CHECK_LAUNCH("debug_trivial_chain");
+  return VLN_OK;
+}
+
 extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {
   if (!jobs || n_jobs <= 0) { set_error("vln_shadow_refresh: bad args"); return VLN_ERR_ARG; }
   return shadow_refresh((hipStream_t)s, jobs, n_jobs);

@@ -159,25 +159,34 @@ class DeviceFeatureStore:
         return (img, img_lp), (cand, cand_lp), ((seed, off1), (seed, off2))
 
 
-    def gather_rollout(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True):
+    def gather_rollout(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True, out=None):
         """`gather_step` for EVERY step of a teacher-forced rollout in ONE launch (the path is known when the rollout starts:
         base.py:141-157 driven by the ground-truth actions).  steps: sequence of (rows, view_index, crows, cviews, heading,
         elevation); returns a list of ((img, img_bf16), (cand, cand_bf16)) like gather_step.  Same Philox stream as calling
-        gather_step for the steps in order (two offsets per step), so the results are bit-identical."""
+        gather_step for the steps in order (two offsets per step), so the results are bit-identical.
+        `out`: a previous result of this call with the same shapes -- the rows are written into those buffers again
+        (address-stable destinations for captured graphs)."""
         lib = _lib.load()
         dev = self.device
         F = self.IMG + self.ANG
         f32 = want_f32 or not want_bf16
         arr = (_lib.GatherRolloutStep * len(steps))()
-        out, keep = [], []
+        res, keep = [], []
         seed, p = 0, 0.0
         clock = self.__dict__.get("clock")        # runtime.DeviceClock (whole-iteration graphs)
         for t, (rows, view_index, crows, cviews, heading, elevation) in enumerate(steps):
             B, C = crows.shape
-            img = ops.empty(B, self.V, F, dtype=torch.float32, device=dev) if f32 else None
-            cand = ops.empty(B, C, F, dtype=torch.float32, device=dev) if f32 else None
-            img_lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
-            cand_lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+            if out is not None:
+                (img, img_lp), (cand, cand_lp) = out[t]
+                ok = lambda x, n, dt: (x is None) == (dt is None) and (x is None or (tuple(x.shape) == (B, n, F) and x.dtype == dt))
+                if not (ok(img, self.V, torch.float32 if f32 else None) and ok(cand, C, torch.float32 if f32 else None) and
+                        ok(img_lp, self.V, torch.bfloat16 if want_bf16 else None) and ok(cand_lp, C, torch.bfloat16 if want_bf16 else None)):
+                    raise ValueError("gather_rollout: `out` buffers do not match this rollout's shapes / dtypes")
+            else:
+                img = ops.empty(B, self.V, F, dtype=torch.float32, device=dev) if f32 else None
+                cand = ops.empty(B, C, F, dtype=torch.float32, device=dev) if f32 else None
+                img_lp = ops.empty(B, self.V, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+                cand_lp = ops.empty(B, C, F, dtype=torch.bfloat16, device=dev) if want_bf16 else None
             if clock is not None:      # offsets relative to the clock's device word: (word * 8 + r), r < 8 * STRIDE
                 seed, p = self.seed, float(p_feat)
                 off1 = clock.rel(id(self), 8 * clock.STRIDE - 1)
@@ -191,14 +200,14 @@ class DeviceFeatureStore:
             q.rows, q.view_index, q.crows, q.cviews, q.heading, q.elevation = _p(rows), _p(view_index), _p(cr), _p(cv), _p(hd), _p(el)
             q.out, q.out_bf16, q.cout, q.cout_bf16 = _p(img), _p(img_lp), _p(cand), _p(cand_lp)
             q.offset_pano, q.offset_cand = off1, off2
-            out.append(((img, img_lp), (cand, cand_lp)))
+            res.append(((img, img_lp), (cand, cand_lp)))
             if t and (B, C) != tuple(steps[0][2].shape):
                 raise ValueError("gather_rollout: every step must have the same [B, C] candidate layout")
         B, C = steps[0][2].shape
         _lib.check(lib.vln_gather_rollout(_p(self.table), ops._dt(self.table), _p(self.angle_table), arr, len(steps), B, self.V, C,
                                           self.IMG, self.ANG, seed, p, None if clock is None else clock.ptr, _lib.raw_stream()),
                    "vln_gather_rollout")
-        return out
+        return res
 
 
 class PinnedStager:

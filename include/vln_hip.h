@@ -53,6 +53,10 @@ int vln_graph_stats(int64_t out[3]);
  * 2/3 = 16-column GEMM on / its largest K, 4 = two-kernel attention, 5 = gemm_nt form, 6 = weight-gradient form,
  * 7 = persistent-LSTM workgroup order */
 int vln_set_tunable(int id, int value);
+/* Measurement only: `launches` dependent launches of a trivial kernel (each reads what the one before wrote, rotated by `shift`
+ * float4 elements so the bytes come from another XCD) ping-ponging between a and b [n_floats]: the price of a kernel boundary
+ * inside the caller's own stream / captured graph (scripts/boundary_probe.hip is the stand-alone form). */
+int vln_debug_trivial_chain(float* a, float* b, int n_floats, int launches, int shift, vln_stream_t s);
 int vln_prof_enable(int kernel_id, int on);
 const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */
 int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_bytes);

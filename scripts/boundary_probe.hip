@@ -148,6 +148,15 @@ static double run(Api api, Str str, int kind /*0 small 1 big 2 vec 3 vec cross-X
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 400;
   const bool only_graph = argc > 2;      // any second argument: only the graph-of-48 table (short run for rocprofv3)
+  // third argument: process conditions of a framework process -- h = a host-mapped pinned allocation exists, s = 40 more streams
+  // exist, m = 4 GiB of device memory allocated
+  if (argc > 3) {
+    for (const char* c = argv[3]; *c; ++c) {
+      if (*c == 'h') { void* hp; CK(hipHostMalloc(&hp, 1 << 20, hipHostMallocMapped)); printf("# host-mapped pinned allocation made\n"); }
+      if (*c == 's') { for (int i = 0; i < 40; ++i) { hipStream_t t; CK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); hipLaunchKernelGGL(stage_small, dim3(1), dim3(256), 0, t, (const float*)nullptr, (float*)nullptr, 0, 0); } CK(hipDeviceSynchronize()); printf("# 40 extra streams created and used\n"); }
+      if (*c == 'm') { void* dp; CK(hipMalloc(&dp, 4ull << 30)); CK(hipMemset(dp, 1, 4ull << 30)); printf("# 4 GiB allocated\n"); }
+    }
+  }
   const char* env = getenv("HIP_FORCE_DEV_KERNARG");
   printf("# boundary_probe: us per dependent launch (wall / launches), chain of 12, %d repetitions; HIP_FORCE_DEV_KERNARG=%s\n", reps, env ? env : "(unset)");
   const char* apin[] = {"hipLaunchKernelGGL", "hipExtLaunchKernelGGL", "hipGraph(12)"};
