@@ -112,18 +112,37 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_
   }
   return Philox4{c0, c1, c2, c3};
 }
-// keep-mask (already scaled by 1/(1-p)) for 4 consecutive elements idx4*4 .. idx4*4+3
+// Keep-masks (already scaled by 1/(1-p)).  Element e of a site draws the 16-bit lane (e & 7) of Philox call (e >> 3): word
+// (e & 7) >> 1 of the call's four 32-bit outputs, low half for even e, high half for odd e; kept iff u16 / 65536 >= p (the
+// keep probability is exact to 2^-16).  ONE call serves 8 consecutive elements: the 32-bit integer multiplies of Philox run
+// at a quarter of the vector rate on gfx950, and with a call per 4 elements the feature gather (5.8 M elements per decoder
+// step), the context dropout and the embedding kernels were bound by them, not by memory (round 3: gather 14.2 -> see
+// profiles/round3_notes.md).  dropout_scale8 / 4 / 1 all follow this one mapping, so vln_dropout_mask exports what every
+// kernel uses.
+__host__ __device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t offset, uint32_t idx8, float p, float (&m)[8]) {
+  const Philox4 r = philox4x32_10(seed, offset, idx8);
+  const float inv = 1.0f / (1.0f - p);
+  const float u = 1.0f / 65536.0f;
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[2 * k] = ((float)(w[k] & 0xFFFFu) * u >= p) ? inv : 0.0f;
+    m[2 * k + 1] = ((float)(w[k] >> 16) * u >= p) ? inv : 0.0f;
+  }
+}
+// 4 consecutive elements idx4*4 .. idx4*4+3 (half of call idx4 >> 1)
 __host__ __device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t offset, uint32_t idx4, float p,
                                                         float (&m)[4]) {
-  Philox4 r = philox4x32_10(seed, offset, idx4);
+  const Philox4 r = philox4x32_10(seed, offset, idx4 >> 1);
   const float inv = 1.0f / (1.0f - p);
-  const float u = 1.0f / 16777216.0f;
-  m[0] = ((r.x >> 8) * u >= p) ? inv : 0.0f;
-  m[1] = ((r.y >> 8) * u >= p) ? inv : 0.0f;
-  m[2] = ((r.z >> 8) * u >= p) ? inv : 0.0f;
-  m[3] = ((r.w >> 8) * u >= p) ? inv : 0.0f;
+  const float u = 1.0f / 65536.0f;
+  const uint32_t w0 = (idx4 & 1u) ? r.z : r.x, w1 = (idx4 & 1u) ? r.w : r.y;
+  m[0] = ((float)(w0 & 0xFFFFu) * u >= p) ? inv : 0.0f;
+  m[1] = ((float)(w0 >> 16) * u >= p) ? inv : 0.0f;
+  m[2] = ((float)(w1 & 0xFFFFu) * u >= p) ? inv : 0.0f;
+  m[3] = ((float)(w1 >> 16) * u >= p) ? inv : 0.0f;
 }
-// single element (element e lives in word e&3 of call e>>2)
+// single element
 __host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t offset, uint32_t e, float p) {
   if (p <= 0.0f) return 1.0f;
   float m[4];

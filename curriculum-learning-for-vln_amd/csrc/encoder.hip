@@ -305,7 +305,23 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
 // ---- embedding gather (+dropout) to time-major rows, and its scatter-add backward ----------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* tokens, const float* E, float* out, int B,
                                                         int L, int D, DropSpec dr, int vec) {
-  if (vec) {                                             // D % 4 == 0, aligned: float4 rows, one Philox call per four
+  if (vec == 2) {                                        // D % 8 == 0, aligned: 8 columns per thread = ONE Philox call
+    const int D8 = D >> 3;
+    const long total8 = (long)L * B * D8;
+    for (long e8 = (long)blockIdx.x * blockDim.x + threadIdx.x; e8 < total8; e8 += (long)gridDim.x * blockDim.x) {
+      const int c8 = (int)(e8 % D8);
+      const long rb = e8 / D8;
+      const int b = (int)(rb % B), t = (int)(rb / B);
+      const long tok = tokens[(long)b * L + t];
+      const float4 x0 = *reinterpret_cast<const float4*>(E + tok * D + c8 * 8), x1 = *reinterpret_cast<const float4*>(E + tok * D + c8 * 8 + 4);
+      float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale8(dr.seed, dr.off(), (uint32_t)(((long)b * L + t) * D8 + c8), dr.p, m);
+      *reinterpret_cast<float4*>(out + e8 * 8) = make_float4(x0.x * m[0], x0.y * m[1], x0.z * m[2], x0.w * m[3]);
+      *reinterpret_cast<float4*>(out + e8 * 8 + 4) = make_float4(x1.x * m[4], x1.y * m[5], x1.z * m[6], x1.w * m[7]);
+    }
+    return;
+  }
+  if (vec) {                                             // D % 4 == 0, aligned: float4 rows, half a Philox call per four
     const int D4 = D >> 2;
     const long total4 = (long)L * B * D4;
     for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
@@ -400,6 +416,24 @@ __global__ __launch_bounds__(256) void embed_bwd_det_kernel(const long long* tok
 // 16-byte accesses) when W % 4 == 0 and the pointers are aligned (`vec`), else one element per thread.
 __global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* bm, bf16_raw* bm_lp, int B, int L,
                                                        int W, DropSpec dr, int vec) {
+  if (vec == 2) {                                        // W % 8 == 0: 8 columns per thread = ONE Philox call
+    const int W8 = W >> 3;
+    const long total8 = (long)B * L * W8;
+    for (long e8 = (long)blockIdx.x * blockDim.x + threadIdx.x; e8 < total8; e8 += (long)gridDim.x * blockDim.x) {
+      const int c8 = (int)(e8 % W8);
+      const long rb = e8 / W8;
+      const int t = (int)(rb % L), b = (int)(rb / L);
+      const float* src = tm + ((long)t * B + b) * W + c8 * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+      float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale8(dr.seed, dr.off(), (uint32_t)e8, dr.p, m);
+      const float v0[4] = {x0.x * m[0], x0.y * m[1], x0.z * m[2], x0.w * m[3]}, v1[4] = {x1.x * m[4], x1.y * m[5], x1.z * m[6], x1.w * m[7]};
+      *reinterpret_cast<float4*>(bm + e8 * 8) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+      *reinterpret_cast<float4*>(bm + e8 * 8 + 4) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+      if (bm_lp) { Elt<bf16_raw>::st4(bm_lp + e8 * 8, v0); Elt<bf16_raw>::st4(bm_lp + e8 * 8 + 4, v1); }
+    }
+    return;
+  }
   if (vec) {
     const int W4 = W >> 2;
     const long total4 = (long)B * L * W4;
@@ -427,6 +461,22 @@ __global__ __launch_bounds__(256) void tm_to_bm_kernel(const float* tm, float* b
   }
 }
 __global__ __launch_bounds__(256) void bm_to_tm_kernel(const float* bm, float* tm, int B, int L, int W, DropSpec dr, int vec) {
+  if (vec == 2) {
+    const int W8 = W >> 3;
+    const long total8 = (long)B * L * W8;
+    for (long e8 = (long)blockIdx.x * blockDim.x + threadIdx.x; e8 < total8; e8 += (long)gridDim.x * blockDim.x) {
+      const int c8 = (int)(e8 % W8);
+      const long rb = e8 / W8;
+      const int t = (int)(rb % L), b = (int)(rb / L);
+      const float4 x0 = *reinterpret_cast<const float4*>(bm + e8 * 8), x1 = *reinterpret_cast<const float4*>(bm + e8 * 8 + 4);
+      float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (dr.p > 0.f) dropout_scale8(dr.seed, dr.off(), (uint32_t)e8, dr.p, m);
+      float* dst = tm + ((long)t * B + b) * W + c8 * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(x0.x * m[0], x0.y * m[1], x0.z * m[2], x0.w * m[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(x1.x * m[4], x1.y * m[5], x1.z * m[6], x1.w * m[7]);
+    }
+    return;
+  }
   if (vec) {
     const int W4 = W >> 2;
     const long total4 = (long)B * L * W4;
@@ -464,8 +514,9 @@ using namespace vln;
 extern "C" int vln_embed_fwd(const int64_t* tokens, const float* E, float* out_tm, int B, int L, int D,
                              uint64_t seed, uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tokens || !E || !out_tm || B <= 0 || L <= 0 || D <= 0) { set_error("vln_embed_fwd: bad args"); return VLN_ERR_ARG; }
-  const int vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out_tm)) & 15) == 0;
-  VLN_LAUNCH(embed_fwd_kernel, dim3(nblk(vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
+  int vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out_tm)) & 15) == 0;
+  if (vec && D % 8 == 0) vec = 2;
+  VLN_LAUNCH(embed_fwd_kernel, dim3(nblk(vec == 2 ? (long)B * L * D / 8 : vec ? (long)B * L * D / 4 : (long)B * L * D)), dim3(256), 0, (hipStream_t)s,
                      (const long long*)tokens, E, out_tm, B, L, D, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("embed_fwd");
   return VLN_OK;
@@ -491,8 +542,9 @@ extern "C" int vln_embed_bwd_det(const int64_t* tokens, const int32_t* lengths, 
 extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, int L, int W, uint64_t seed,
                             uint64_t offset, float p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_tm_to_bm: null pointer"); return VLN_ERR_ARG; }
-  const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm) | reinterpret_cast<uintptr_t>(bm_bf16)) & 15) == 0;
-  VLN_LAUNCH(tm_to_bm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
+  int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm) | reinterpret_cast<uintptr_t>(bm_bf16)) & 15) == 0;
+  if (vec && W % 8 == 0) vec = 2;
+  VLN_LAUNCH(tm_to_bm_kernel, dim3(nblk(vec == 2 ? (long)B * L * W / 8 : vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, tm, bm,
                      (bf16_raw*)bm_bf16, B, L, W, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("tm_to_bm");
   return VLN_OK;
@@ -500,8 +552,9 @@ extern "C" int vln_tm_to_bm(const float* tm, float* bm, void* bm_bf16, int B, in
 extern "C" int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed, uint64_t offset, float p,
                             const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!tm || !bm) { set_error("vln_bm_to_tm: null pointer"); return VLN_ERR_ARG; }
-  const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm)) & 15) == 0;
-  VLN_LAUNCH(bm_to_tm_kernel, dim3(nblk(vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
+  int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(tm) | reinterpret_cast<uintptr_t>(bm)) & 15) == 0;
+  if (vec && W % 8 == 0) vec = 2;
+  VLN_LAUNCH(bm_to_tm_kernel, dim3(nblk(vec == 2 ? (long)B * L * W / 8 : vec ? (long)B * L * W / 4 : (long)B * L * W)), dim3(256), 0, (hipStream_t)s, bm, tm, B,
                      L, W, drop_spec(seed, offset, p, offset_base_dev), vec);
   VLN_CHECK_LAUNCH("bm_to_tm");
   return VLN_OK;

@@ -77,12 +77,10 @@ __device__ __forceinline__ void gather_step_rows(const GatherStepArgs& a, int r0
       if (!live[k]) continue;
       const DropSpec& dr = pano[k] ? a.dr_pano : a.dr_cand;
       if (!empty[k] && dr.p > 0.f) {
-        float m[4];
-        const uint32_t i4 = (uint32_t)(((long)rr[k] * IMG + c) >> 2);
-        dropout_scale4(dr.seed, dr.off(), i4, dr.p, m);
-        x[k][0] *= m[0]; x[k][1] *= m[1]; x[k][2] *= m[2]; x[k][3] *= m[3];
-        dropout_scale4(dr.seed, dr.off(), i4 + 1, dr.p, m);
-        x[k][4] *= m[0]; x[k][5] *= m[1]; x[k][6] *= m[2]; x[k][7] *= m[3];
+        float m[8];                    // IMG % 8 == 0 and c % 8 == 0: the thread's 8 elements are exactly one Philox call
+        dropout_scale8(dr.seed, dr.off(), (uint32_t)(((long)rr[k] * IMG + c) >> 3), dr.p, m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[k][j] *= m[j];
       }
       store8(k, c, x[k]);
     }

@@ -60,13 +60,26 @@ class _Oracle:
         gmax = max(float(r.abs().max()) for r in refs.values() if r is not None)
         for n, p in named_params:
             r = refs[n] if refs[n] is not None else torch.zeros_like(self.P[n])
-            check(p.grad if p.grad is not None else torch.zeros_like(p), r, self.t(f"grad[{n}]"), f"{self.name}: grad[{n}]", floor=1e-2 * gmax)
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            check(g, r, self.t(f"grad[{n}]"), f"{self.name}: grad[{n}]", floor=1e-2 * gmax)
+            # a loosened max-abs bound keeps its L2 bound (gradients that vanish in exact arithmetic -- a bias in front of a
+            # train-mode BatchNorm -- are rounding noise on both sides: no relative L2)
+            if self.same and self.t(f"grad[{n}]") > same_bf16_grad_tol() and float(r.abs().max()) > 1e-2 * gmax:
+                from parity import rel_l2
+                assert rel_l2(g, r) < same_bf16_grad_tol(), f"{self.name}: grad[{n}] L2 error {rel_l2(g, r):.2e}"
 
 
 def _oracles(cdt, sd, leaves, skip, bf16_exceptions):
     if cdt == torch.float32:
         return [_Oracle("fp32", sd, leaves, FP32, False, skip)]
-    return [_Oracle("bf16 same-weights", sd, leaves, SAME_BF16, True, skip, {"grad[": same_bf16_grad_tol()}),
+    # Same-weights oracle, gradients of the BN-MLP (Linear -> BatchNorm -> ReLU): a unit whose pre-activation is within rounding
+    # distance of zero has its ReLU on one side and off on the other (fp32 accumulation order differs between the kernels and
+    # the oracle) and then a WHOLE row term of its gradients differs; plain-bf16 weight-gradient operands add cancelling sums
+    # whose absolute error stays while the value shrinks.  Which elements are hit depends on the dropout draw, so single
+    # elements reach a few 1e-2 of the tensor's maximum (measured 1.5e-2 / 3.0e-2) while every tensor stays below the gradient
+    # tolerance in L2 -- asserted below for each loosened tensor.
+    same_exc = {"grad[proj_navigable_mlp": 6e-2, "grad[": same_bf16_grad_tol()}
+    return [_Oracle("bf16 same-weights", sd, leaves, SAME_BF16, True, skip, same_exc),
             _Oracle("bf16 unrounded", sd, leaves, BF16, False, skip, bf16_exceptions)]
 
 

@@ -207,7 +207,11 @@ def test_hip_back_translation_rollout():
     spk = vln.Speaker(senc.to(dev), sdec.to(dev), max_decode=7)
     env = FakeR2REnv(batch_size=4, max_len=8, vocab=40, seed=7)
     can, img, lengths = R.shortest_path_features(env)
-    insts, noise = vln.back_translate(spk, dec, can.to(dev), img.to(dev), lengths)
+    nlen = lambda ins: len({int(np.argmax(r == 0)) if (r == 0).any() else len(r) for r in ins})
+    for _ in range(8):          # every call draws a new environment mask; take one under which the sentences differ in length
+        insts, noise = vln.back_translate(spk, dec, can.to(dev), img.to(dev), lengths)      # (the re-sort below is then exercised)
+        if nlen(insts) > 1:
+            break
     assert set(noise.unique().cpu().tolist()) <= {0.0, float(torch.tensor(1 / 0.7, dtype=torch.float32))}
     # the oracle speaker, same weights, same mask -> the same instructions
     ora = R.SpeakerOracle({k.replace(".rnn.", "."): v.cpu() for k, v in senc.state_dict().items()},
