@@ -61,7 +61,7 @@ class EnvDropStep(C.Structure):
                    ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr), ("defer_logits", i32),
                    ("pad_", i32)]
                 + [(n, ptr) for n in ("g_table", "g_angle_table", "g_rows", "g_vidx", "g_crows", "g_cviews", "g_chead", "g_celev")]
-                + [("g_ttype", i32), ("pad2_", i32)])
+                + [("g_ttype", i32), ("pad2_", i32), ("attn_sync", ptr), ("attn_sync_bytes", i64)])
 
 
 class TickItem(C.Structure):          # vln_tick_item
@@ -185,8 +185,8 @@ SIGNATURES = {
     "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, f32, ptr, i64, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
-    "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr]),
-    "vln_attn_bwd_rows": (i32, [ptr, i32, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
+    "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
+    "vln_attn_bwd_rows": (i32, [ptr, i32, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_attn_dctx_deferred": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr]),
     "vln_lstm_pointwise_fwd": (i32, [ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32, i32, i32, ptr]),
     "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
@@ -250,6 +250,7 @@ SIGNATURES = {
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
+    "vln_attn_sync_bytes": (i64, [i32]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),
                                    C.POINTER(EnvDropGrads), ptr]),

@@ -189,15 +189,17 @@ extern "C" int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const
                   dl_out, B, S, D);
 }
 extern "C" int vln_attn_fwd_rows(const void* ctx, int ctype, const float* vec, int64_t ldv, const uint8_t* mask, float* attn,
-                                 float* out, int64_t ldo, float* dots_scratch, int B, int S, int D, vln_stream_t s) {
+                                 float* out, int64_t ldo, float* dots_scratch, int B, int S, int D, void* sync,
+                                 int64_t sync_bytes, vln_stream_t s) {
   if (!ctx || !vec || !out) { set_error("vln_attn_fwd_rows: null pointer"); return VLN_ERR_ARG; }
-  return attn_fwd_rows((hipStream_t)s, ctx, ctype, vec, ldv, mask, attn, out, ldo, dots_scratch, B, S, D);
+  return attn_fwd_rows_sv((hipStream_t)s, ctx, ctype, plain_vec(vec, ldv), nullptr, 0, mask, attn, out, ldo, dots_scratch, B, S, D, sync, sync_bytes);
 }
 extern "C" int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float* dwc, int64_t lddwc,
                                  const float* dattn_ext, float* dvec, int64_t lddvec, float* dl_out, float* dots_scratch,
-                                 int B, int S, int D, vln_stream_t s) {
+                                 int B, int S, int D, void* sync, int64_t sync_bytes, vln_stream_t s) {
   if (!ctx || !attn || !dwc || !dvec) { set_error("vln_attn_bwd_rows: null pointer"); return VLN_ERR_ARG; }
-  return attn_bwd_rows((hipStream_t)s, ctx, ctype, attn, dwc, lddwc, dattn_ext, dvec, lddvec, dl_out, dots_scratch, B, S, D);
+  return attn_bwd_rows_sv((hipStream_t)s, ctx, ctype, attn, plain_vec(dwc, lddwc), nullptr, 0, dattn_ext, dvec, lddvec, dl_out, dots_scratch, B, S, D,
+                          sync, sync_bytes);
 }
 extern "C" int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                                       const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,

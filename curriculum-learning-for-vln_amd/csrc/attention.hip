@@ -416,6 +416,7 @@ int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, cons
 
 
 #include "attention_fused.h"
+#include "attention_split.h"
 
 // dots + softmax + weighted sum in one launch when a register-resident configuration fits, else the two-kernel path
 // (`dots_scratch` [B,S] is only touched by the fallback).
@@ -425,9 +426,10 @@ int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, 
 }
 // `vec` may still lie in split-K slabs; vec_out (nullable) receives the summed vector
 int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,
-                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D) {
+                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D, void* sync, long sync_bytes) {
   if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_fwd_rows: bad dims B=%d S=%d D=%d", B, S, D); return VLN_ERR_ARG; }
   AttnFusedArgs a{ctx, vec, vec_out, ldvo, mask, attn, nullptr, nullptr, out, ldo, S, D};
+  if (attn_split_try(st, ctype, a, B, false, sync, sync_bytes, device_cus())) { VLN_CHECK_LAUNCH("attn_split_fwd"); return VLN_OK; }
   if (attn_fused_try(st, ctype, a, B, false)) { VLN_CHECK_LAUNCH("attn_fused_fwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_fwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
   if (vec_out) {                        // the caller wants the finished vector: sum the slabs into it first
@@ -446,9 +448,11 @@ int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn,
   return attn_bwd_rows_sv(st, ctx, ctype, attn, plain_vec(dwc, lddwc), nullptr, 0, dattn_ext, dvec, lddvec, dl_out, dots_scratch, B, S, D);
 }
 int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* attn, SlabVec dwc, float* dwc_out, long lddo,
-                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D) {
+                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D,
+                     void* sync, long sync_bytes) {
   if (B <= 0 || S <= 0 || D <= 0 || S > kMaxS) { set_error("attn_bwd_rows: bad dims"); return VLN_ERR_ARG; }
   AttnFusedArgs a{ctx, dwc, dwc_out, lddo, nullptr, const_cast<float*>(attn), dattn_ext, dl_out, dvec, lddvec, S, D};
+  if (attn_split_try(st, ctype, a, B, true, sync, sync_bytes, device_cus())) { VLN_CHECK_LAUNCH("attn_split_bwd"); return VLN_OK; }
   if (attn_fused_try(st, ctype, a, B, true)) { VLN_CHECK_LAUNCH("attn_fused_bwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_bwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
   if (dwc_out) {
@@ -491,3 +495,5 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
 }
 
 }  // namespace vln
+
+extern "C" int64_t vln_attn_sync_bytes(int B) { return B > 0 ? vln::attn_split_sync_bytes(B) : -1; }

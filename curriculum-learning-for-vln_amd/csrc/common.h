@@ -10,6 +10,11 @@ typedef unsigned short bf16_raw;
 
 #define VLN_WAVE 64
 
+// cross-workgroup hand-offs (persistent recurrence, split attention): relaxed agent-scope accesses = `sc1` loads / stores
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define VLN_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define VLN_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
 // status codes returned by every C-ABI entry point
 #define VLN_OK 0
 #define VLN_ERR_ARG 1

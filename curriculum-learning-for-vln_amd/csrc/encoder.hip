@@ -621,7 +621,7 @@ static inline bool bwd_granules() { return g_persist_enabled == 3; }
 // Co-residency: every workgroup of the persistent grid spins on its neighbours, so the WHOLE grid must be resident at once.
 // The kernels keep their W_hh slice in registers (about one workgroup per CU), so the capacity is the device's CU count --
 // queried, not assumed: a partitioned (CPX) or smaller device takes the per-step chain instead of spinning into a timeout.
-static int device_cus() {
+int vln::device_cus() {
   static int cus[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 0; }

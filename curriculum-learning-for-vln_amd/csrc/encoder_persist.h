@@ -26,10 +26,7 @@
 #define VLN_STAMP(k)
 #endif
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-#define VLN_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define VLN_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// u32x4_t, VLN_AGENT_LOAD / VLN_AGENT_STORE: common.h
 
 // Arrival signalling.  EACH dependency group owns a 128-byte line of the sync header.  That placement is what matters:
 // with the eight groups' counters packed in adjacent words (one line) every step sent 128 atomics and eight pollers

@@ -141,7 +141,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   int n1 = 1, n2 = 1, n3 = 1;
   RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_fwd_rows_sv(st, img, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, nullptr, 0, nullptr, io->alpha_v, io->xcat + AE, XK,
-                       ws.dots, B, d->V, F));
+                       ws.dots, B, d->V, F, io->attn_sync, io->attn_sync_bytes));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   LstmPwFwd pw{};
@@ -153,7 +153,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
-                       ws.dots, B, d->L, H));
+                       ws.dots, B, d->L, H, io->attn_sync, io->attn_sync_bytes));
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
@@ -213,7 +213,8 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
     RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
   } else {
-      RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H));
+      RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H,
+                         io->attn_sync, io->attn_sync_bytes));
   }
   RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
   // (4') LSTM cell
@@ -226,7 +227,8 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does
-  RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F));
+  RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F,
+                       io->attn_sync, io->attn_sync_bytes));
   RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
   PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,

@@ -52,6 +52,7 @@ struct ProfScope {   // brackets the launches issued in its scope with an event 
 // launch gap or event-record packet inside the bracket.
 bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout
+int device_cus();                 // encoder.hip: CU count of the current device (queried once), 0 if unknown
 // every launch in the library goes through launch_timed or VLN_LAUNCH
 #define VLN_LAUNCH(kernel, grid, block, lds, st, ...) hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__)
 
@@ -130,10 +131,13 @@ int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn,
                   const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
 // same, with the vector operand still in split-K slabs (SlabVec) and an optional write-back of the summed vector
 int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D);
+// `sync` / `sync_bytes` (nullable): the caller's zero-initialised exchange buffer of attn_split_sync_floats(B) floats; with it
+// (and B * 4 <= the device's CU count) a row's block is split over FOUR workgroups (attention_split.h)
 int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,
-                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D);
+                     float* attn, float* out, long ldo, float* dots_scratch, int B, int S, int D, void* sync = nullptr, long sync_bytes = 0);
 int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* attn, SlabVec dwc, float* dwc_out, long lddo,
-                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
+                     const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D,
+                     void* sync = nullptr, long sync_bytes = 0);
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,

@@ -201,6 +201,18 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # block differs between consecutive iterations, 0 replays), so this is off unless the caller allocates from a
         # fixed arena; results are identical either way.
         self.step_graphs = False
+        # The step's two attentions on FOUR workgroups per episode (csrc/attention_split.h) instead of one: 256 workgroups at
+        # B = 64.  Needs a zero-initialised exchange buffer that lives as long as the module (allocated on first use) and
+        # B * 4 <= the device's CU count (the library checks; larger batches take the one-workgroup kernels).
+        self.split_attention = True
+        self._attn_sync = None
+
+    def _attn_sync_buf(self, dev, B):
+        w = self._attn_sync
+        if w is None or w[0].device != dev or w[1] < B:
+            n = int(_lib.load().vln_attn_sync_bytes(B))
+            w = self._attn_sync = (torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev), B)
+        return w[0]
 
     # ---- gating hooks ----------------------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -656,6 +668,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 io.lp_ready = 1
             keep["img_lp"], keep["cand_lp"], keep["ctx_lp"] = img_lp, cand_lp, ctx_lp
             io.img_lp, io.cand_lp, io.ctx_lp = img_lp.data_ptr(), cand_lp.data_ptr(), ctx_lp.data_ptr()
+        if self.split_attention:
+            sy = self._attn_sync_buf(dev, B)
+            io.attn_sync, io.attn_sync_bytes = sy.data_ptr(), sy.numel() * 4
         io.h_tilde_prev, io.c0, io.ctx = htp.data_ptr(), c0.data_ptr(), ctxc.data_ptr()
         if ctx_mask is not None:
             m8 = entry.mask8 if entry.mask_src is ctx_mask else None

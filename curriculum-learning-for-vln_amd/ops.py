@@ -405,8 +405,15 @@ def rows_wsum(ctx, w, out=None):
     return out
 
 
-def attn_fwd_rows(ctx, vec, mask=None, out=None, want_attn=True):
-    """softmax(mask(ctx . vec)) and the weighted sum of the context rows in ONE launch (units.py:106-118)."""
+def attn_sync_buffer(B, device):
+    """Zero-initialised exchange scratch for the four-workgroups-per-row attention (csrc/attention_split.h): keep it for the
+    attention calls alone, for as long as they are issued."""
+    return torch.zeros((int(_lib.load().vln_attn_sync_bytes(B)) + 3) // 4, dtype=torch.int32, device=device)
+
+
+def attn_fwd_rows(ctx, vec, mask=None, out=None, want_attn=True, sync=None):
+    """softmax(mask(ctx . vec)) and the weighted sum of the context rows in ONE launch (units.py:106-118).
+    sync = attn_sync_buffer(B, device): four workgroups per row instead of one."""
     lib = _lib.load()
     _req(ctx, "ctx", None); _req(vec, "vec")
     B, S, D = ctx.shape
@@ -419,11 +426,12 @@ def attn_fwd_rows(ctx, vec, mask=None, out=None, want_attn=True):
         m8 = mask.view(torch.uint8) if (mask.dtype == torch.bool and mask.is_contiguous()) else mask.to(torch.uint8).contiguous()
     scratch = empty(B, S, dtype=torch.float32, device=ctx.device)
     _lib.check(lib.vln_attn_fwd_rows(_p(ctx), _dt(ctx), _p(vec), vec.stride(0), _p(m8), _p(attn), _p(out), out.stride(0),
-                                     _p(scratch), B, S, D, _stream()), "vln_attn_fwd_rows")
+                                     _p(scratch), B, S, D, _p(sync), 0 if sync is None else sync.numel() * sync.element_size(), _stream()),
+               "vln_attn_fwd_rows")
     return out, attn
 
 
-def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None):
+def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None, sync=None):
     """Backward of attn_fwd_rows w.r.t. the query: returns (dvec [B,D], dl [B,S] or None)."""
     lib = _lib.load()
     _req(ctx, "ctx", None); _req(attn, "attn"); _req(dwc, "dwc")
@@ -435,7 +443,8 @@ def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None):
         dattn_ext = dattn_ext.contiguous()
     scratch = empty(B, S, dtype=torch.float32, device=ctx.device)
     _lib.check(lib.vln_attn_bwd_rows(_p(ctx), _dt(ctx), _p(attn), _p(dwc), dwc.stride(0), _p(dattn_ext), _p(dvec),
-                                     dvec.stride(0), _p(dl), _p(scratch), B, S, D, _stream()), "vln_attn_bwd_rows")
+                                     dvec.stride(0), _p(dl), _p(scratch), B, S, D, _p(sync),
+                                     0 if sync is None else sync.numel() * sync.element_size(), _stream()), "vln_attn_bwd_rows")
     return dvec, dl
 
 

@@ -140,13 +140,16 @@ int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* out, int64_
 /* One launch per attention (dots -> softmax -> weighted sum with the [S,D] block of a batch row resident in the
  * workgroup's registers); shapes that do not fit fall back to the two launches above and need dots_scratch [B,S].
  * Forward = SoftDotAttention / VisualSoftDotAttention core (units.py:106-118,150-158); backward returns d(query) and
- * optionally d(logits) (dl_out), the in-place dctx update being replaced by vln_attn_dctx_deferred. */
+ * optionally d(logits) (dl_out), the in-place dctx update being replaced by vln_attn_dctx_deferred.
+ * sync / sync_bytes (nullable): a zero-initialised scratch of vln_attn_sync_bytes(B) bytes that the caller keeps for these
+ * calls alone -- a row's block is then split over FOUR workgroups (see vln_envdrop_step.attn_sync). */
 int vln_attn_fwd_rows(const void* ctx, int ctype, const float* vec, int64_t ldv, const uint8_t* mask /*nullable*/,
                       float* attn /*nullable*/, float* out, int64_t ldo, float* dots_scratch /*nullable*/, int B, int S, int D,
-                      vln_stream_t s);
+                      void* sync /*nullable*/, int64_t sync_bytes, vln_stream_t s);
 int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float* dwc, int64_t lddwc,
                       const float* dattn_ext /*nullable*/, float* dvec, int64_t lddvec, float* dl_out /*nullable*/,
-                      float* dots_scratch /*nullable*/, int B, int S, int D, vln_stream_t s);
+                      float* dots_scratch /*nullable*/, int B, int S, int D, void* sync /*nullable*/, int64_t sync_bytes,
+                      vln_stream_t s);
 /* dctx[b,s,:] (+)= sum_t alpha[t][b,s] * g[t][b,:] + dl[t][b,s] * q[t][b,:]  -- the context gradient of a whole rollout
  * (T decoder steps) in one pass; alpha/dl/g/q are HOST arrays of T device pointers. */
 int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
@@ -609,6 +612,12 @@ typedef struct vln_envdrop_step {
   const int64_t* g_rows; const int32_t* g_vidx;                       /* [B], [B] */
   const int64_t* g_crows; const int32_t* g_cviews; const float* g_chead; const float* g_celev;   /* [B,C] each */
   int g_ttype; int pad2_;                                             /* table element type: VLN_F32 / VLN_BF16 */
+  /* Optional: zero-initialised device scratch of vln_attn_sync_bytes(B) bytes, 16-byte aligned, owned by the caller for the
+   * life of the module and touched by nothing else.  With it (and B * 4 <= the device's CU count) the step's two attentions
+   * -- 36 x 2176 panorama, <= 80 x 512 instruction context -- run on FOUR workgroups per episode (csrc/attention_split.h: the
+   * block's columns are split, the partial row dots exchanged once as data-tagged granules), forward and backward.  NULL:
+   * one workgroup per episode. */
+  void* attn_sync; int64_t attn_sync_bytes;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {
@@ -638,6 +647,7 @@ typedef struct vln_envdrop_grads {
 } vln_envdrop_grads;
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
+int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
 int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io, vln_stream_t s);
 int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
                          vln_envdrop_grads* g, vln_stream_t s);

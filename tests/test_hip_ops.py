@@ -354,6 +354,42 @@ def test_attention_rows_one_launch(vln, B, S, D, cdt):
     check(dctx, 2 * c64.grad, tol, "dctx")
 
 
+@pytest.mark.parametrize("B,S,D", [(64, 36, 2176), (64, 80, 512), (48, 17, 2176), (9, 80, 512), (64, 33, 544)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_attention_rows_four_workgroups_per_row(vln, B, S, D, cdt):
+    """csrc/attention_split.h: a row's [S, D] block on FOUR workgroups (columns split, the partial row dots exchanged once as
+    data-tagged granules) against fp64 and against the one-workgroup kernel, forward and backward -- twelve launches in a row
+    on ONE exchange buffer (tags = a per-row launch count that every launch bumps), odd S, B not a multiple of 8, masked rows."""
+    g = torch.Generator().manual_seed(B + S + D)
+    ctx = (torch.randn(B, S, D, generator=g) * 0.5).to(cdt)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        mask[b, max(1, S - (b % S)):] = True
+    tol = 1e-4 if cdt == torch.float32 else 1e-2
+    cd, md = ctx.to(dev()), mask.to(dev())
+    sync = vln.ops.attn_sync_buffer(B, dev())
+    c64 = ctx.double()
+    for t in range(6):
+        vec = torch.randn(B, D, generator=g) / D ** 0.5
+        r = torch.randn(B, D, generator=g); ra = torch.randn(B, S, generator=g)
+        v64 = vec.double().requires_grad_(True)
+        attn = torch.softmax(torch.einsum("bsd,bd->bs", c64, v64).masked_fill(mask, -float("inf")), 1)
+        wc = torch.einsum("bs,bsd->bd", attn, c64)
+        gv, = torch.autograd.grad((wc * r.double()).sum() + (attn * ra.double()).sum(), v64)
+        out, at = vln.ops.attn_fwd_rows(cd, vec.to(dev()), md, sync=sync)
+        out1, at1 = vln.ops.attn_fwd_rows(cd, vec.to(dev()), md)
+        check(at, attn.detach(), tol, "attn (split)"); check(out, wc.detach(), tol, "out (split)")
+        check(at, at1, 1e-5, "attn split vs one workgroup"); check(out, out1, 1e-5, "out split vs one workgroup")
+        assert (at * md).abs().max().item() == 0.0
+        dvec, dl = vln.ops.attn_bwd_rows(cd, at, r.to(dev()), ra.to(dev()), want_dl=True, sync=sync)
+        dvec1, dl1 = vln.ops.attn_bwd_rows(cd, at, r.to(dev()), ra.to(dev()), want_dl=True)
+        check(dvec, gv, tol, "dvec (split)")
+        check(dvec, dvec1, 1e-5, "dvec split vs one workgroup"); check(dl, dl1, 1e-5, "dl split vs one workgroup")
+    torch.cuda.synchronize()
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")      # no bounded wait timed out
+    assert int(sync[0].item()) == 12                                                   # row 0's launch count
+
+
 def test_attention_dctx_deferred_many_steps(vln):
     """More steps than one launch stages in LDS (chunks of <= 14 at D = 512): RL rollouts run up to 35 steps."""
     B, S, D, T = 8, 20, 512, 35
