@@ -758,11 +758,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = {}
         gc.unfreeze()
-        for name, fn in (("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args)),
+        short = [make_tape(args.batch, args.L, 3, 8, seed=5050 + k, n_rows=store.N) for k in range(4)]
+
+        def per_step():      # marginal cost of one decoder step (forward + backward + its share of the weight gradients)
+            if args.T <= 3:
+                return {"error": "needs --T > 3"}
+            a = secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph)
+            b = secondary_envdrop(vln, dev, store, short, dtype, "store", args, graph=use_graph)
+            return {"us": round((a - b) / (args.T - 3) * 1e3, 1), "how": f"(ms at T={args.T} - ms at T=3) / {args.T - 3}, same path as the headline"}
+
+        for name, fn in (("eager_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args)),
+                         ("dropin_unchanged_caller_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "tensor", args, dropin=True)),
+                         ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
+                         ("decoder_step_fwd_bwd", per_step),
+                         ("phases", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, phases=True)),
+                         ("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args, graph=use_graph)),
                          ("features_host_fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "host", args)),
                          ("batch128_ms_per_step", lambda: secondary_envdrop(
                              vln, dev, store, [make_tape(128, args.L, args.T, 8, seed=4040 + k, n_rows=store.N) for k in range(4)],
-                             dtype, "store", args)),
+                             dtype, "store", args, graph=use_graph)),
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
                          ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store)),
                          ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store))):
@@ -838,32 +852,106 @@ def pmc_figures(kernel, dtype):
     return (t["bytes_per_launch"] if t else None), m, f"profiles/round2_pmc.json, kernel sources {d['csrc_sha']}"
 
 
-def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6):
-    """ms per iteration of the headline workload under another precision / feature path (own agent, own arena)."""
+def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,
+                      wgrad=None, phases=False):
+    """ms per iteration of the headline workload under another precision / feature path / caller (own agent, own arena).
+    graph: the whole iteration as one hipGraph (store features only).  dropin: the reference's UNCHANGED caller -- feature
+    tensors handed in every step, `logits.masked_fill_` + per-step cross entropy (envdrop.py:173-179), no arena, no deferred
+    logits; only the fused clip + RMSprop is kept.  phases: instead of the ms, GPU microseconds per phase of an eager iteration
+    (hip events on the stream: encoder forward, the decoder steps' forward, loss, backward, clip + optimizer)."""
     torch.manual_seed(2020)
-    ag = GpuAgent(vln, dev, dtype, 1, arena=True)
-    ag.clear_grads_in_step = True
-    if features == "store":
-        st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
-        tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
-        live = LiveBatch(tapes)
-        get = live.load
-    else:                                   # pinned host fp32 features (what the reference's ImageFeatures holds): two batches
-        tapes = []
-        for t in cpu_tapes[:2]:
-            t = dict(t, steps=[dict(s) for s in t["steps"]])
-            for s in t["steps"]:
-                s.update(materialize_step(s, store.table))
-            tapes.append(tape_to(t, dev, host_dtype=torch.float32))
-        get = lambda k: tapes[k % len(tapes)]
-    for k in range(4 + warmup):
-        ag.iteration(get(k))
+    prev_w = vln.ops.get_wgrad_precision()
+    if wgrad is not None:
+        vln.ops.set_wgrad_precision(wgrad)
+    try:
+        ag = GpuAgent(vln, dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
+        ag.clear_grads_in_step = True
+        if features == "store":
+            st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
+            tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
+            live = LiveBatch(tapes)
+            get = live.load
+        else:                    # host: pinned host fp32 features (what the reference's ImageFeatures holds); tensor: device tensors
+            tapes = []
+            for t in cpu_tapes[:2]:
+                t = dict(t, steps=[dict(s) for s in t["steps"]])
+                for s in t["steps"]:
+                    s.update(materialize_step(s, store.table))
+                tapes.append(tape_to(t, dev, host_dtype=torch.float32) if features == "host" else tape_to(t, dev))
+            get = lambda k: tapes[k % len(tapes)]
+        if graph:
+            ag.use_clock(st)
+        for k in range(4):
+            ag.iteration(get(k))
+        torch.cuda.synchronize()
+        if phases:
+            return _phase_times(ag, get, steps)
+        if graph:
+            ag.capture(live.live)
+            run = lambda k: (live.load(k), ag.replay())
+        else:
+            run = lambda k: ag.iteration(get(k))
+        for k in range(warmup):
+            run(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            run(k)
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / steps * 1e3, 3)
+    finally:
+        vln.ops.set_wgrad_precision(prev_w)
+
+
+def _phase_times(ag, get, steps):
+    """GPU time per phase of an eager iteration (per-decoder-step fwd / bwd and the optimizer reported apart): hip
+    events recorded on the stream between the phases; the host runs ahead, so the differences are device time."""
+    marks = {}
+
+    def mark(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.setdefault(name, []).append(ev)
+
+    enc_fwd, dec_call, opt_step, opt_zero = ag.enc.forward, ag.dec.forward, ag.opt.step, ag.opt.zero_grad
+    state = {"t": 0}
+    T = len(get(0)["steps"])
+
+    def enc_w(*a, **k):
+        mark("start")
+        out = enc_fwd(*a, **k)
+        mark("enc_done")
+        state["t"] = 0
+        return out
+
+    def dec_w(*a, **k):
+        out = dec_call(*a, **k)
+        state["t"] += 1
+        if state["t"] == T:
+            mark("dec_done")
+        return out
+
+    def opt_w(*a, **k):
+        mark("bwd_done")
+        out = opt_step(*a, **k)
+        mark("opt_done")
+        return out
+
+    ag.enc.forward, ag.dec.forward, ag.opt.step = enc_w, dec_w, opt_w
+    try:
+        for k in range(steps + 3):
+            ag.iteration(get(k))
+    finally:
+        ag.enc.forward, ag.dec.forward, ag.opt.step = enc_fwd, dec_call, opt_step
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        ag.iteration(get(k))
-    torch.cuda.synchronize()
-    return round((time.perf_counter() - t0) / steps * 1e3, 3)
+
+    def span(a, b):
+        v = sorted(x.elapsed_time(y) * 1e3 for x, y in list(zip(marks[a], marks[b]))[3:])
+        return round(v[len(v) // 2], 1)
+
+    return {"encoder_fwd_us": span("start", "enc_done"), "decoder_fwd_us_per_step": round(span("enc_done", "dec_done") / T, 1),
+            "loss_and_backward_us": span("dec_done", "bwd_done"), "clip_and_optimizer_us": span("bwd_done", "opt_done"),
+            "decoder_steps": T, "note": "eager launches; backward = loss + decoder steps + encoder BPTT + weight gradients"}
 
 
 def secondary_agents(dev, args, which, store):
