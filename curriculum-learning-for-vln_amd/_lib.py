@@ -168,6 +168,7 @@ SIGNATURES = {
     "vln_set_graphs": (i32, [i32]),
     "vln_set_tunable": (i32, [i32, i32]),
     "vln_debug_trivial_chain": (i32, [ptr, ptr, i32, i32, i32, ptr]),
+    "vln_debug_occupy": (i32, [i32, i32, i32, ptr]),
     "vln_prof_enable": (i32, [i32, i32]),
     "vln_prof_kernel_name": (C.c_char_p, [i32]),
     "vln_prof_read": (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -286,6 +286,32 @@ __global__ __launch_bounds__(256) void debug_trivial_kernel(const float4* in, fl
   out[j] = make_float4(v.x * .5f, v.y * .5f, v.z * .5f, v.w * .5f + 1.f);
 }
 }  // namespace vln
+// A kernel that only OCCUPIES compute units for a while: `workgroups` x 1024 threads, `lds_bytes` of LDS each, resident for
+// `micros` microseconds (wall clock) -- the stand-in for a communication kernel (RCCL) that is resident on another stream while
+// the persistent recurrence needs its own workgroups co-resident (tests/test_hip_dp_rccl.py).
+namespace vln {
+__global__ __launch_bounds__(1024) void debug_occupy_kernel(unsigned long long ticks, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char occ_lds[];
+  occ_lds[threadIdx.x] = (unsigned char)threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (sink && occ_lds[(threadIdx.x * 7) & 1023] == 255 && ticks == 0) *sink = 1;     // keeps the LDS allocation alive
+}
+}  // namespace vln
+extern "C" int vln_debug_occupy(int workgroups, int lds_bytes, int micros, vln_stream_t s) {
+  if (workgroups < 1 || workgroups > 1024 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || micros < 0 || micros > 100000) {
+    set_error("vln_debug_occupy: 1..1024 workgroups, 1 KB..160 KB of LDS, <= 100 ms");
+    return VLN_ERR_ARG;
+  }
+  if (lds_bytes > 64 * 1024 &&
+      check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(debug_occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
+                "vln_debug_occupy: hipFuncSetAttribute") != VLN_OK) return VLN_ERR_HIP;
+  VLN_LAUNCH(debug_occupy_kernel, dim3(workgroups), dim3(1024), (unsigned)lds_bytes, (hipStream_t)s, (unsigned long long)micros * 100ull, (int*)nullptr);
+  VLN_CHECK_LAUNCH("debug_occupy");
+  return VLN_OK;
+}
+
 extern "C" int vln_debug_trivial_chain(float* a, float* b, int n_floats, int launches, int shift, vln_stream_t s) {
   if (!a || !b || n_floats < 4 || (n_floats & 3) || launches < 1) { set_error("vln_debug_trivial_chain: bad args"); return VLN_ERR_ARG; }
   const int n4 = n_floats / 4;

@@ -56,6 +56,9 @@ int vln_set_tunable(int id, int value);
 /* Measurement only: `launches` dependent launches of a trivial kernel (each reads what the one before wrote, rotated by `shift`
  * float4 elements so the bytes come from another XCD) ping-ponging between a and b [n_floats]: the price of a kernel boundary
  * inside the caller's own stream / captured graph (scripts/boundary_probe.hip is the stand-alone form). */
+/* Test only: `workgroups` x 1024 threads that hold `lds_bytes` of LDS each and stay resident for `micros` microseconds -- a
+ * stand-in for a communication kernel resident on another stream while the persistent recurrence runs. */
+int vln_debug_occupy(int workgroups, int lds_bytes, int micros, vln_stream_t s);
 int vln_debug_trivial_chain(float* a, float* b, int n_floats, int launches, int shift, vln_stream_t s);
 int vln_prof_enable(int kernel_id, int on);
 const char* vln_prof_kernel_name(int kernel_id);   /* NULL past the last id */

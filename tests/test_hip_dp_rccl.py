@@ -58,3 +58,57 @@ def test_collective_path_on_a_one_rank_rccl_group():
         if r.returncode == 0 or "address already in use" not in r.stderr.lower():
             break
     assert r.returncode == 0 and "RCCL-PATH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("wgs", [32, 64, 160])
+def test_persistent_recurrence_beside_a_resident_kernel(wgs):
+    """The data-parallel design starts the decoder slice's all-reduce right before the encoder's BPTT, so a communication kernel
+    is RESIDENT while the persistent recurrence -- whose workgroups spin on each other -- is launched.  Stand-in: a kernel on
+    a second stream that holds `wgs` compute units (1024 threads + 160 KB of LDS each: nothing else fits beside it) for 3 ms.
+    32 / 64 held CUs leave room for the recurrence's 128 workgroups; 160 do not: part of its grid can only start when the other
+    kernel leaves.  In every case the instruction encoder's forward + backward must equal the undisturbed run bit for bit and no
+    bounded wait may time out (a communication kernel finishes on its own: RCCL kernels of the ranks wait for each other, never
+    for the recurrence)."""
+    import time
+    import torch
+    import vln_amd as vln
+    lib = vln._lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, L = 64, 80
+    enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=torch.bfloat16).to(dev).train()
+    enc.deterministic_embedding_grad = True
+    g = torch.Generator().manual_seed(6)
+    lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, 992, (n,), generator=g)
+    tokens = tokens.to(dev)
+    r = torch.randn(B, L, 512, generator=g).to(dev)
+    side = torch.cuda.Stream()
+
+    def run(occupy):
+        enc._calls = 0
+        for p in enc.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        if occupy:
+            with torch.cuda.stream(side):
+                vln._lib.check(lib.vln_debug_occupy(wgs, 160 * 1024, 3000, side.cuda_stream), "vln_debug_occupy")
+        t0 = time.perf_counter()
+        ctx, h, c = enc(tokens, lens)
+        ((ctx * r).sum() + h.sum() + c.sum()).backward()
+        torch.cuda.current_stream().synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+        return ctx.detach().clone(), [p.grad.clone() for p in enc.parameters()], dt
+
+    run(False)
+    ref_ctx, ref_g, t_alone = run(False)
+    ctx, grads, t_beside = run(True)
+    assert enc.persistent_status() == 0
+    assert torch.equal(ctx, ref_ctx)
+    for a, b in zip(grads, ref_g):
+        assert torch.equal(a, b)
+    print(f"\n[recurrence beside a resident kernel on {wgs} CUs] encoder fwd+bwd {t_alone:.3f} ms alone, {t_beside:.3f} ms beside it")
