@@ -535,6 +535,8 @@ def main():
                          "replayed (graphs.IterationGraph; dropout offsets and the recurrence's launch sequence come from device words, "
                          "runtime.DeviceClock).  auto: on for one GPU with the resident feature store, off otherwise (the gradient "
                          "all-reduce of N > 1 stays a stream operation between launches)")
+    ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE",
+                    help="(A/B) vln_set_tunable(ID, VALUE) before anything runs, e.g. --tunable 0=256 (csrc/vln_internal.h lists them)")
     ap.add_argument("--probe-trivial", type=int, default=0,
                     help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
                          "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
@@ -592,6 +594,9 @@ def main():
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     vln.ops.set_wgrad_precision(args.wgrad)
+    for tv in args.tunable:
+        tid, val = tv.split("=")
+        vln._lib.check(lib.vln_set_tunable(int(tid), int(val)), "vln_set_tunable")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.features == "host-bf16" and dtype != torch.bfloat16:
         raise SystemExit("--features host-bf16 needs --dtype bf16")
@@ -770,6 +775,8 @@ def main():
         for name, fn in (("eager_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args)),
                          ("dropin_unchanged_caller_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "tensor", args, dropin=True)),
                          ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
+                         ("fp32_query_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
+                                                                                      fp32_weights=("w_vin", "w_tin"))),
                          ("decoder_step_fwd_bwd", per_step),
                          ("phases", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, phases=True)),
                          ("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args, graph=use_graph)),
@@ -853,7 +860,7 @@ def pmc_figures(kernel, dtype):
 
 
 def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,
-                      wgrad=None, phases=False):
+                      wgrad=None, phases=False, fp32_weights=()):
     """ms per iteration of the headline workload under another precision / feature path / caller (own agent, own arena).
     graph: the whole iteration as one hipGraph (store features only).  dropin: the reference's UNCHANGED caller -- feature
     tensors handed in every step, `logits.masked_fill_` + per-step cross entropy (envdrop.py:173-179), no arena, no deferred
@@ -866,6 +873,8 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
     try:
         ag = GpuAgent(vln, dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
         ag.clear_grads_in_step = True
+        if fp32_weights:
+            ag.dec.fp32_weights = frozenset(fp32_weights)
         if features == "store":
             st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
             tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]

@@ -50,7 +50,7 @@ CE_MAX_STEPS = 40                     # VLN_CE_MAX_STEPS
 
 class EnvDropWeights(C.Structure):
     _fields_ = [(n, ptr) for n in ("act_w", "act_b", "w_vin", "w_vin_t", "w_cat", "w_cat_t", "b_ih", "b_hh",
-                                   "w_tin", "w_tin_t", "w_tout", "w_tout_t", "w_c", "w_c_t")]
+                                   "w_tin", "w_tin_t", "w_tout", "w_tout_t", "w_c", "w_c_t")] + [("f32_mask", i32), ("pad_", i32)]
 
 
 class EnvDropStep(C.Structure):
@@ -101,7 +101,7 @@ class MonitorStep(C.Structure):
                                     "word_w", "move_w", "pctx", "tq", "vq", "xcat", "tcat", "aq", "hm", "mg", "mem", "act", "tanh_c1",
                                     "gates", "dots", "ws")]
                 + [("ws_floats", i64), ("seed_pe", u64), ("off_pe", u64), ("p_pe", f32), ("seed", u64), ("off_h1", u64),
-                   ("off_mem", u64), ("p_drop", f32)])
+                   ("off_mem", u64), ("p_drop", f32), ("offset_base_dev", ptr)])
 
 
 class MonitorGrads(C.Structure):
@@ -124,7 +124,7 @@ class FollowerStep(C.Structure):
     _fields_ = ([(n, ptr) for n in ("img", "a_prev", "cands", "h0", "c0", "ctx", "ctx_mask", "logit", "h1", "c1", "word_w", "view_w",
                                     "tq", "keys", "vlog", "xcat", "act", "tanh_c1", "tq2", "tcat", "grounded", "target", "q", "context",
                                     "gates", "dots", "ws")]
-                + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32)])
+                + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32), ("offset_base_dev", ptr)])
 
 
 class FollowerGrads(C.Structure):
@@ -149,7 +149,7 @@ class BnMlpLayer(C.Structure):
 
 class BnMlp(C.Structure):
     _fields_ = [("R", i32), ("D0", i32), ("nl", i32), ("wtype", i32), ("training", i32), ("pad_", i32), ("eps", f32), ("momentum", f32),
-                ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr)]
+                ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr), ("offset_base_dev", ptr)]
 
 
 class BnMlpGradLayer(C.Structure):
@@ -196,13 +196,13 @@ SIGNATURES = {
     "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
     "vln_rmsprop_partial_floats": (i64, [ptr, i32]),
     "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr, f32, ptr]),
-    "vln_adam_clip_step": (i32, [ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, i64, ptr, f32, ptr]),
+    "vln_adam_clip_step": (i32, [ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, i64, ptr, ptr, f32, ptr]),
     "vln_sgd_clip_step": (i32, [ptr, ptr, ptr, i32, ptr, ptr, f32, ptr, f32, ptr]),
     "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, ptr, i32, ptr]),
     "vln_masked_ce_multi_bwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, i64, ptr]),
-    "vln_attn_dctx_deferred_drop": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr, ptr, ptr, ptr]),
+    "vln_attn_dctx_deferred_drop": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
     "vln_pe_dropout": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),

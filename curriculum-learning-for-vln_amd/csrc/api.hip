@@ -28,6 +28,10 @@ long long g_graph_stats[3] = {0, 0, 0};
 // [2] = 1, [3] = 512: narrow outputs (N <= 1024) with a SHORT contraction (K <= 512) use the 16-column kernel with the K
 // split inside the workgroup.  Interleaved A/B, GPU-bound iteration (scripts/ab_bench.py): all K 3.075 ms, K <= 1024
 // 2.890, K <= 512 2.861, off 2.878 -- every 16-column workgroup streams the whole X, which loses for K = 2176.
+const unsigned long long*& drop_base_tls() {
+  static thread_local const unsigned long long* base = nullptr;
+  return base;
+}
 int g_tunable[8] = {384, 1, 1, 512, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
@@ -210,8 +214,9 @@ extern "C" int vln_attn_dctx_deferred(const float* const* alpha, const float* co
 extern "C" int vln_attn_dctx_deferred_drop(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                                            const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,
                                            int accumulate, const uint64_t* drop_seed, const uint64_t* drop_off,
-                                           const float* drop_p, vln_stream_t s) {
+                                           const float* drop_p, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!alpha || !dl || !g || !q || !dctx) { set_error("vln_attn_dctx_deferred_drop: null pointer"); return VLN_ERR_ARG; }
+  DropBaseScope drop_scope(offset_base_dev);
   return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate, drop_seed, drop_off, drop_p);
 }
 extern "C" int vln_lstm_pointwise_fwd(const float* gates, int nsplit, int64_t slab_stride, const float* b_ih,

@@ -486,6 +486,7 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
       a.drop_seed[t] = drop_seed ? drop_seed[t0 + t] : 0; a.drop_off[t] = drop_off ? drop_off[t0 + t] : 0;
       a.drop_p[t] = drop_p ? drop_p[t0 + t] : 0.f;
     }
+    a.drop_base = drop_base_tls();
     a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0;
     const unsigned lds = (unsigned)(2 * a.T * (D + 16) * sizeof(float));
     VLN_LAUNCH(attn_dctx_deferred_kernel, dim3(B, (S + 15) / 16), dim3(256), lds, st, a);

@@ -261,6 +261,7 @@ struct DctxArgs {
   // optional: step t's contribution passed through a dropout mask of the attended tensor (the Self-Monitor agent attends
   // dropout(ctx + pe) with a fresh mask every step: units.py:188-207); p == 0: none.  Mask index = flat [B,S,D] index.
   unsigned long long drop_seed[kDctxMaxSteps], drop_off[kDctxMaxSteps]; float drop_p[kDctxMaxSteps];
+  const unsigned long long* drop_base;   // nullable: offsets relative to a device word, (*drop_base) * 8 + drop_off[t]
 };
 __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [2T][D] vectors, then [2T][16] row weights
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
         const float4 x0 = *reinterpret_cast<const float4*>(&sv[(long)t * D + c * 4]);
         const float4 x1 = *reinterpret_cast<const float4*>(&sv[(long)(T + t) * D + c * 4]);
         float m[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.drop_p[t] > 0.f) dropout_scale4(a.drop_seed[t], a.drop_off[t], (uint32_t)((((long)b * S + s) * D + c * 4) >> 2), a.drop_p[t], m);
+        if (a.drop_p[t] > 0.f) dropout_scale4(a.drop_seed[t], (a.drop_base ? *a.drop_base * 8ull : 0ull) + a.drop_off[t], (uint32_t)((((long)b * S + s) * D + c * 4) >> 2), a.drop_p[t], m);
         acc.x += (w0 * x0.x + w1 * x1.x) * m[0]; acc.y += (w0 * x0.y + w1 * x1.y) * m[1];
         acc.z += (w0 * x0.z + w1 * x1.z) * m[2]; acc.w += (w0 * x0.w + w1 * x1.w) * m[3];
       }

@@ -81,6 +81,7 @@ extern "C" int64_t vln_bn_mlp_bwd_scratch_floats(const vln_bn_mlp* m) {
 extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, float* saved, float* ws, int64_t ws_floats, vln_stream_t s) {
   RUN(check_mlp(m));
   if (!x || !saved || !ws) { set_error("vln_bn_mlp_fwd: null pointer"); return VLN_ERR_ARG; }
+  DropBaseScope drop_scope(m->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const SavedLayout L = saved_layout(m);
   const int R = m->R, tr = m->training;
@@ -112,6 +113,7 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     set_error("vln_bn_mlp_bwd: null pointer or scratch too small");
     return VLN_ERR_ARG;
   }
+  DropBaseScope drop_scope(m->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const SavedLayout L = saved_layout(m);
   const int R = m->R, tr = m->training, nl = m->nl;

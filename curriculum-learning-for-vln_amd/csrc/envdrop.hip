@@ -103,6 +103,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop fwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
   const bool lp = (d->ctype == VLN_BF16);
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };     // per-matrix fp32 override
   if (lp && (!io->img_lp || !io->cand_lp || !io->ctx_lp)) { set_error("envdrop fwd: bf16 stream copies missing"); return VLN_ERR_ARG; }
   const float pf = io->already_dropfeat ? 0.f : io->p_feat;
 
@@ -139,11 +140,11 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
   // (3) visual attention (context-only SoftDot)                policy.py:235, units.py:106-118
   int n1 = 1, n2 = 1, n3 = 1;
-  RUN(gemm_nt(st, io->hq, H, w->w_vin, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  RUN(gemm_nt(st, io->hq, H, w->w_vin, wt(0), H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_fwd_rows_sv(st, img, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, nullptr, 0, nullptr, io->alpha_v, io->xcat + AE, XK,
                        ws.dots, B, d->V, F, io->attn_sync, io->attn_sync_bytes));
   // (4) LSTM cell on [drop(e) | visual | h_tilde_prev]         policy.py:237-238
-  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, d->wtype, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt(1), XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   LstmPwFwd pw{};
   pw.gates = ws.s2; pw.nsplit = n2; pw.slab_stride = (long)B * 4 * H;
   pw.bias_a = w->b_ih; pw.bias_b = w->b_hh; pw.c0 = io->c0; pw.ldc0 = H;
@@ -151,14 +152,14 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
   RUN(lstm_pointwise_fwd(st, pw));
   // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
-  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
                        ws.dots, B, d->L, H, io->attn_sync, io->attn_sync_bytes));
-  RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, d->wtype, 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
+  RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, wt(3), 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
   if (io->defer_logits) return VLN_OK;      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
-  RUN(gemm_nt(st, io->htd, H, w->w_c, d->wtype, H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  RUN(gemm_nt(st, io->htd, H, w->w_c, wt(4), H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
   RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
   return VLN_OK;
 }
@@ -172,6 +173,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };
 
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;
@@ -183,14 +185,14 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     // branch runs here and is added -- to the d(cand query) rows of the stash (d cand_attn.weight) and to d drop(h_tilde).
     RUN(rows_wsum(st, cand, d->ctype, g->dlogit, ws.s1, F, B, d->C, F));
     RUN(add_inplace(st, g->s_dtc, F, ws.s1, F, B, F));
-    RUN(gemm_nt(st, ws.s1, F, w->w_c_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+    RUN(gemm_nt(st, ws.s1, F, w->w_c_t, wt(4), F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
     dhtd.n = n3;
     dhtd2 = g->dhtd_ext;
   } else if (g->dhtd_ext) {     // the logit branch of the whole rollout was formed up front (vln_rows_wsum_multi + one GEMM)
     dhtd = SlabVec{g->dhtd_ext, H, 1, (long)B * H};
   } else if (g->dlogit) {
     RUN(rows_wsum(st, cand, d->ctype, g->dlogit, g->s_dtc, F, B, d->C, F));
-    RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+    RUN(gemm_nt(st, g->s_dtc, F, w->w_c_t, wt(4), F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
     dhtd.n = n3;
   } else {
     RUN(fill_f32(st, g->s_dtc, (long)B * F, 0.f));
@@ -203,7 +205,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     VLN_CHECK_LAUNCH("tanh_drop_bwd");
   }
   // (5') linear_out -> [d weighted ctx | d drop(h1)], still in slabs (s4)
-  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, d->wtype, H, nullptr, 0, B, 2 * H, H, nullptr, ACT_NONE, ws.s4, ws.n4, &n4));
+  RUN(gemm_nt(st, g->s_dz, H, w->w_tout_t, wt(3), H, nullptr, 0, B, 2 * H, H, nullptr, ACT_NONE, ws.s4, ws.n4, &n4));
   const SlabVec dtcat{ws.s4, 2 * H, n4, (long)B * 2 * H};
   // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
   // deferred: this step only leaves d logits (g->s_dl) and d weighted ctx (g->s_dtcat[:, :H]) behind and the caller
@@ -216,7 +218,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
       RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H,
                          io->attn_sync, io->attn_sync_bytes));
   }
-  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, d->wtype, H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
+  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
   // (4') LSTM cell
   LstmPwBwd pb{};
   pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = dtcat.shifted(H); pb.dh1_b2 = SlabVec{ws.s3, H, n3b, (long)B * H};
@@ -224,12 +226,12 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
   RUN(lstm_pointwise_bwd(st, pb));
-  RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, d->wtype, 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
+  RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, wt(1), 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does
   RUN(attn_bwd_rows_sv(st, img, d->ctype, io->alpha_v, dxcat.shifted(AE), nullptr, 0, nullptr, g->s_dtv, F, nullptr, ws.dots, B, d->V, F,
                        io->attn_sync, io->attn_sync_bytes));
-  RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, d->wtype, F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+  RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, wt(0), F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
   PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)};

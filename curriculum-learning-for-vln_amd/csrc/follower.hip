@@ -49,6 +49,7 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
     set_error("vln_follower_step_fwd: null pointer");
     return VLN_ERR_ARG;
   }
+  DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, V = d->V, C = d->C, H = d->H, F = d->F, A = d->A, D = d->D, XK = A + F + H, wt = d->wtype;
   // (1) panorama attention: keys = W_v img + b_v, query = W_h h0 + b_h, weighted sum over the UN-projected views
@@ -58,14 +59,14 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   RUN(attn_softmax_wsum(st, io->img, W_F32, io->vlog, nullptr, io->view_w, io->xcat + A, XK, B, V, F));
   RUN(copy_blocks2(st, B, io->a_prev, A, io->xcat, XK, A, io->h0, H, io->xcat + A + F, XK, H));
   if (io->p_drop > 0.f)      // dropout over cat(a_prev, pano) (policy.py:49-51), in place
-    RUN(scale_dropout(st, io->xcat, XK, io->xcat, XK, B, A + F, DropSpec{io->seed, io->off, io->p_drop}));
+    RUN(scale_dropout(st, io->xcat, XK, io->xcat, XK, B, A + F, tls_drop(io->seed, io->off, io->p_drop)));
   // (2) LSTM cell; drop(h1) lands in its tcat block
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   {
     LstmPwFwd a{};
     a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
     a.c0 = io->c0; a.ldc0 = H; a.h1 = io->h1; a.ldh1 = H; a.c1 = io->c1; a.ldc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
-    a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = DropSpec{io->seed, io->off + 1, io->p_drop}; a.B = B; a.H = H;
+    a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = tls_drop(io->seed, io->off + 1, io->p_drop); a.B = B; a.H = H;
     RUN(lstm_pointwise_fwd(st, a));
   }
   // (3) text attention + tanh(W_out [wc ; drop(h1)])
@@ -86,6 +87,7 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   RUN(check_follower_dims(d));
   if (!w || !io || !g || !g->scratch || !g->dh0 || !g->dc0) { set_error("vln_follower_step_bwd: null pointer"); return VLN_ERR_ARG; }
   if (g->scratch_floats < vln_follower_bwd_scratch_floats(d)) { set_error("vln_follower_step_bwd: scratch too small"); return VLN_ERR_ARG; }
+  DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, V = d->V, C = d->C, H = d->H, F = d->F, A = d->A, D = d->D, XK = A + F + H, wt = d->wtype;
   float* p = g->scratch;
@@ -122,13 +124,13 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   {
     LstmPwBwd a{};
     a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dhd, H); a.dh1_b2 = plain_vec(nullptr, 0);
-    a.drop = DropSpec{io->seed, io->off + 1, io->p_drop}; a.dc1 = g->dc1; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
+    a.drop = tls_drop(io->seed, io->off + 1, io->p_drop); a.dc1 = g->dc1; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));
   }
   RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> a_prev | pano | h0
   if (io->p_drop > 0.f)
-    RUN(scale_dropout(st, dxcat, XK, dxcat, XK, B, A + F, DropSpec{io->seed, io->off, io->p_drop}));
+    RUN(scale_dropout(st, dxcat, XK, dxcat, XK, B, A + F, tls_drop(io->seed, io->off, io->p_drop)));
   // (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq); rv = sum_v dl_v img_v comes out of the same pass
   RUN(attn_dot(st, io->img, W_F32, dxcat + A, XK, dalpha, B, V, F));
   RUN(attn_bwd(st, io->img, W_F32, io->view_w, dalpha, g->dvw_ext, nullptr, 0, nullptr, 0, rv, F, nullptr, dl_v, B, V, F));

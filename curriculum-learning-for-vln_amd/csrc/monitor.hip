@@ -88,6 +88,7 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     set_error("vln_monitor_step_fwd: null pointer");
     return VLN_ERR_ARG;
   }
+  DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
   // (1) positioned, dropped context (fresh mask per step, units.py:205-207)
@@ -113,7 +114,7 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     LstmPwFwd a{};
     a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
     a.c0 = io->c0; a.ldc0 = H; a.h1 = io->h1; a.ldh1 = H; a.c1 = io->c1; a.ldc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
-    a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = DropSpec{io->seed, io->off_h1, io->p_drop}; a.B = B; a.H = H;
+    a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = tls_drop(io->seed, io->off_h1, io->p_drop); a.B = B; a.H = H;
     RUN(lstm_pointwise_fwd(st, a));
   }
   {
@@ -137,6 +138,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   RUN(check_monitor_dims(d));
   if (!w || !io || !g || !g->scratch || !g->dh0 || !g->dc0 || !g->dprev_rep) { set_error("vln_monitor_step_bwd: null pointer"); return VLN_ERR_ARG; }
   if (g->scratch_floats < vln_monitor_bwd_scratch_floats(d)) { set_error("vln_monitor_step_bwd: scratch too small"); return VLN_ERR_ARG; }
+  DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
   float* q = g->scratch;
@@ -159,7 +161,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   {
     LstmPwBwd a{};
     a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dtcat + H, 2 * H); a.dh1_b2 = plain_vec(nullptr, 0);
-    a.drop = DropSpec{io->seed, io->off_h1, io->p_drop}; a.dc1 = dc1_t; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
+    a.drop = tls_drop(io->seed, io->off_h1, io->p_drop); a.dc1 = dc1_t; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));
   }

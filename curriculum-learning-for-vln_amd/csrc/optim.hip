@@ -61,6 +61,9 @@ struct OptHyper {
   float grad_scale;
   int zero_grads;               // 1: the update also clears the gradient buffer it has just consumed (the next zero_grad() is free)
   float max_norm[8];              // per clip group; 0 = that group is not clipped (trainer.py:425-426 clips encoder and decoder, not the critic)
+  // adam, optional: the step count t = *step_dev + step_add lives on the device (whole-iteration graphs: the launch arguments
+  // must repeat); the bias corrections are then formed by the kernel instead of the host
+  const long long* step_dev; long long step_add;
 };
 
 template <int MODE>
@@ -82,7 +85,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void opt_step_kernel(float* p, float* g, float* s1, float* s2, OptGroups gr,
                                                        const float* partial, float* norms_out, OptHyper h) {
   __shared__ float sh[4];
-  __shared__ float s_coef;
+  __shared__ float s_coef, s_bc1, s_bc2r;
   int grp = 0;
   while (grp + 1 < gr.ngroups && (int)blockIdx.x >= gr.blk0[grp + 1]) ++grp;
   // total norm of this block's group (every block re-reduces its group's partials: a few hundred floats)
@@ -93,10 +96,16 @@ __global__ __launch_bounds__(256) void opt_step_kernel(float* p, float* g, float
     const float norm = sqrtf(s) * h.grad_scale;
     float c = (h.max_norm[grp] > 0.f) ? h.max_norm[grp] / (norm + 1e-6f) : 1.f;   // torch.nn.utils.clip_grad_norm_
     s_coef = h.grad_scale * (c < 1.f ? c : 1.f);
+    if (MODE == OPT_ADAM && h.step_dev) {
+      const double t = (double)(*h.step_dev + h.step_add);
+      s_bc1 = (float)(1.0 - pow((double)h.a, t));
+      s_bc2r = (float)(1.0 / sqrt(1.0 - pow((double)h.b, t)));
+    }
     if (norms_out && (int)blockIdx.x == gr.blk0[grp]) norms_out[grp] = norm;
   }
   __syncthreads();
   const float coef = s_coef;
+  if (MODE == OPT_ADAM && h.step_dev) { h.bc1 = s_bc1; h.bc2_rsqrt = s_bc2r; }
   const long base = gr.begin[grp] + (long)((int)blockIdx.x - gr.blk0[grp]) * kOptChunk;
   const long end = gr.begin[grp + 1];
 #pragma unroll
@@ -174,23 +183,24 @@ extern "C" int64_t vln_rmsprop_partial_floats(const int64_t* group_begin, int ng
 extern "C" int vln_rmsprop_clip_step(float* params, float* grads, float* square_avg, const int64_t* group_begin,
                                      int ngroups, float* partial, float* norms_out, float lr, float alpha, float eps,
                                      const float* max_norms, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, grad_scale, 0, {}};
+  OptHyper h{lr, alpha, 0.f, eps, 1.f, 1.f, grad_scale, 0, {}, nullptr, 0};
   return opt_launch(OPT_RMSPROP, params, grads, square_avg, nullptr, group_begin, ngroups, partial, norms_out, h,
                     max_norms, (hipStream_t)s, "vln_rmsprop_clip_step");
 }
 extern "C" int vln_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                                   const int64_t* group_begin, int ngroups, float* partial, float* norms_out, float lr,
-                                  float beta1, float beta2, float eps, int64_t step, const float* max_norms, float grad_scale,
-                                  vln_stream_t s) {
-  if (step < 1) { set_error("vln_adam_clip_step: step counts from 1"); return VLN_ERR_ARG; }
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, 0, {}};
+                                  float beta1, float beta2, float eps, int64_t step, const int64_t* step_dev, const float* max_norms,
+                                  float grad_scale, vln_stream_t s) {
+  if (!step_dev && step < 1) { set_error("vln_adam_clip_step: step counts from 1"); return VLN_ERR_ARG; }
+  const double st = step_dev ? 1.0 : (double)step;
+  const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+  OptHyper h{lr, beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, 0, {}, reinterpret_cast<const long long*>(step_dev), (long long)step};
   return opt_launch(OPT_ADAM, params, grads, exp_avg, exp_avg_sq, group_begin, ngroups, partial, norms_out, h,
                     max_norms, (hipStream_t)s, "vln_adam_clip_step");
 }
 extern "C" int vln_sgd_clip_step(float* params, float* grads, const int64_t* group_begin, int ngroups, float* partial,
                                  float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s) {
-  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, 0, {}};
+  OptHyper h{lr, 0.f, 0.f, 0.f, 1.f, 1.f, grad_scale, 0, {}, nullptr, 0};
   return opt_launch(OPT_SGD, params, grads, nullptr, nullptr, group_begin, ngroups, partial, norms_out, h, max_norms,
                     (hipStream_t)s, "vln_sgd_clip_step");
 }

@@ -1121,7 +1121,7 @@ extern "C" int vln_pe_dropout(const float* ctx, const float* pe, float* out, int
   long t4 = (long)B * L * H / 4;
   int blocks = (int)((t4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  VLN_LAUNCH(vln::pe_dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, ctx, pe, out, B, L, H, DropSpec{seed, offset, p});
+  VLN_LAUNCH(vln::pe_dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, ctx, pe, out, B, L, H, vln::tls_drop(seed, offset, p));
   VLN_CHECK_LAUNCH("pe_dropout");
   return VLN_OK;
 }
@@ -1130,7 +1130,7 @@ extern "C" int vln_monitor_head_fwd(const float* mg, const float* c1, const floa
   if (!mg || !c1 || !word_w || !wc || !bc || !mem || !prog || B <= 0) { vln::set_error("vln_monitor_head_fwd: bad args"); return VLN_ERR_ARG; }
   vln::MonHeadArgs a{};
   a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.bc = bc; a.mem = mem; a.prog = prog; a.B = B; a.L = L; a.H = H;
-  a.dr = DropSpec{seed, offset, p};
+  a.dr = vln::tls_drop(seed, offset, p);
   VLN_LAUNCH(vln::monitor_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("monitor_head_fwd");
   return VLN_OK;
@@ -1145,7 +1145,7 @@ extern "C" int vln_monitor_head_bwd(const float* mg, const float* c1, const floa
   }
   vln::MonHeadArgs a{};
   a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.mem = const_cast<float*>(mem); a.prog = const_cast<float*>(prog);
-  a.B = B; a.L = L; a.H = H; a.dr = DropSpec{seed, offset, p};
+  a.B = B; a.L = L; a.H = H; a.dr = vln::tls_drop(seed, offset, p);
   a.dprog = dprog; a.dc1_ext = dc1_ext; a.dww_ext = dww_ext; a.dmg = dmg; a.dc1 = dc1; a.dww = dww; a.Z = Z; a.dpre = dpre;
   VLN_LAUNCH(vln::monitor_head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("monitor_head_bwd");
@@ -1224,7 +1224,7 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
     return VLN_ERR_ARG;
   }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
-           R, D, eps, momentum, training, relu, DropSpec{seed, offset, p_drop}, row_zero};
+           R, D, eps, momentum, training, relu, tls_drop(seed, offset, p_drop), row_zero};
   const int nchunk = (R + kBnChunk - 1) / kBnChunk;
   if (R >= 512 && ((!training) || (ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D))) {     // tall input: row-chunked form
     BnChunkWs w{ws, nchunk};
@@ -1249,7 +1249,7 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
     return VLN_ERR_ARG;
   }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
-              training, relu, accumulate, DropSpec{seed, offset, p_drop}, row_zero};
+              training, relu, accumulate, tls_drop(seed, offset, p_drop), row_zero};
   const int nchunk = (R + kBnChunk - 1) / kBnChunk;
   if (R >= 512 && ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D) {       // tall input: row-chunked form
     BnChunkWs w{ws, nchunk};

@@ -31,6 +31,19 @@ int check_hip(hipError_t e, const char* what);
 // The EnvDrop step's graph key includes all eight, so a changed tunable never replays a stale graph.
 extern int g_tunable[8];
 
+// ---- device-resident dropout offsets of the struct-driven steps -----------------------------------------------------------------
+// vln_monitor_step / vln_follower_step / vln_bn_mlp carry `offset_base_dev`: while such a call issues its launches, every dropout
+// site it builds (also inside the entry points it calls: vln_pe_dropout, vln_monitor_head_*, vln_bn_fwd / vln_bn_bwd) takes the
+// device word as its base -- offset = (*base) * 8 + the struct's offset field (runtime.DeviceClock; see vln_embed_fwd).  The scope
+// lives on the calling thread for the duration of the call only.
+const unsigned long long*& drop_base_tls();
+struct DropBaseScope {
+  const unsigned long long* prev;
+  explicit DropBaseScope(const void* base) : prev(drop_base_tls()) { drop_base_tls() = static_cast<const unsigned long long*>(base); }
+  ~DropBaseScope() { drop_base_tls() = prev; }
+};
+inline DropSpec tls_drop(uint64_t seed, uint64_t offset, float p) { return DropSpec{seed, offset, p, drop_base_tls()}; }
+
 // ---- optional per-kernel HIP-event timers (bench.py roofline leg; zero cost when disabled) -----------
 enum KernelId {
   K_GEMM_NT = 0, K_GEMM_TN, K_ATTN_DOT, K_ATTN_WSUM, K_ATTN_BWD, K_LSTM_REC_FWD, K_LSTM_REC_BWD, K_FEAT_DROPOUT,

@@ -34,8 +34,18 @@ class _Seeded:
         self.compute_dtype = torch.float32
 
     def _next(self):
+        clock = self.__dict__.get("clock")
+        if clock is not None:          # runtime.DeviceClock: an offset relative to the clock's device word (see _drop_base)
+            r = clock.rel(id(self), 31)
+            self._calls = clock.value(r)
+            return r * 16
         self._calls += 1
         return self._calls * 16
+
+    def _drop_base(self):
+        """Device word the kernels add (x 8) to this module's dropout offsets, or None (absolute host offsets)."""
+        clock = self.__dict__.get("clock")
+        return None if clock is None else clock.ptr
 
 
 class SoftDotAttention(nn.Module):
@@ -125,8 +135,10 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
                 and a_t_cands.shape[2] % 4 == 0 and not img_feature.requires_grad and not a_t_cands.requires_grad:
             va, ds = self.visual_attn, self.decode_action            # the whole step as ONE autograd node
             core = FollowerStepFn if self.c_step else Fh.FollowerCoreFn      # one C call per direction / Python-driven launches
+            if self._drop_base() is not None and not self.c_step:
+                raise _lib.VlnError("AttnDecoderLSTM: a DeviceClock needs the C-call step (c_step=True)")
             logit, h_new, c_new, word_w, view_w = core.apply(
-                (tr, self.compute_dtype, p, seed, site), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
+                (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ()), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
                 self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,
                 self.text_attn.linear_in.weight, self.text_attn.linear_out.weight,
@@ -257,7 +269,8 @@ class MLPwithBN(nn.Module):
             drops, bufs, tensors = [], [(bn0.running_mean, bn0.running_var, bn0.num_batches_tracked)], [bn0.weight, bn0.bias]
             for lin, bnl, dr in seq:
                 p = dr.p if (dr is not None and training) else 0.0
-                drops.append((float(p), dr.dropout_seed if dr is not None else 0, dr._next() if (dr is not None and p > 0) else 0))
+                drops.append((float(p), dr.dropout_seed if dr is not None else 0, dr._next() if (dr is not None and p > 0) else 0) +
+                             ((dr._drop_base(),) if (dr is not None and dr._drop_base() is not None) else ()))
                 bufs.append((bnl.running_mean, bnl.running_var, bnl.num_batches_tracked))
                 tensors += [lin.weight, lin.bias, bnl.weight, bnl.bias]
             return Fh.bn_mlp(x, row_zero, training, bn0.eps, bn0.momentum, seq[0][0].compute_dtype, drops, bufs, tensors)
@@ -342,6 +355,10 @@ class MonitorDecoder(nn.Module, _Seeded):
             pos = self.position
             cfg = (self.training, self.compute_dtype, pos.p, (pos.dropout_seed, pos._next()), self.drop_ratio, self.dropout_seed,
                    site, site + 1)
+            if self._drop_base() is not None:
+                if not self.c_step:
+                    raise _lib.VlnError("MonitorDecoder: a DeviceClock needs the C-call step (c_step=True)")
+                cfg = cfg + (self._drop_base(),)
             head = self.critic[0]
             core = MonitorStepFn if self.c_step else Fh.MonitorCoreFn       # one C call per direction / Python-driven launches
             logit, progress, h_new, c_new, word_w, move_w = core.apply(

@@ -159,6 +159,7 @@ class _EnvDropStepFn(torch.autograd.Function):
 class EnvDropDecoder(nn.Module, GatedModuleMixin):
     """policy.py:173-246.  `compute_dtype=torch.bfloat16` streams bf16 weight shadows / features / context
     with fp32 accumulation (BASELINE config 1); fp32 is bit-for-bit fp32 math on the f32 MFMA."""
+    default_fp32_weights = frozenset()      # class-wide default of `fp32_weights` (A/B scripts, tests)
 
     def __init__(self, hidden_size, drop_ratio, feat_drop_ratio, action_embed_size: int = 64,
                  angle_feat_size: int = 128, feature_size: int = 2048 + 128, compute_dtype=torch.float32):
@@ -206,6 +207,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # B * 4 <= the device's CU count (the library checks; larger batches take the one-workgroup kernels).
         self.split_attention = True
         self._attn_sync = None
+        # bf16 compute: weight matrices that are streamed in fp32 all the same (names: w_vin, w_cat, w_tin, w_tout, w_c).  Set it
+        # before the first forward (the shadows are rebuilt when a parameter changes).
+        self.fp32_weights = frozenset(type(self).default_fp32_weights)
 
     def _attn_sync_buf(self, dev, B):
         w = self._attn_sync
@@ -245,25 +249,28 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         XK = AE + F + H
         dev = self.lstm.weight_ih.device
 
-        ck = (dt, tuple(p.data_ptr() for p in self._gated_params()))
+        ck = (dt, self.fp32_weights, tuple(p.data_ptr() for p in self._gated_params()))
         c = self.__dict__.get("_sb_handle")
         if c is not None and c[0] == ck:          # same addresses, new values (an optimizer step): replay the recorded jobs
             ops.ShadowBatch.replay(c[1])
             return
         sb = ops.ShadowBatch()          # every cast / transpose below goes out as ONE launch
 
-        def buf(name, shape):
+        f32 = self.fp32_weights
+
+        def buf(name, shape, d=None):
+            d = d or dt
             x = t.get(name)
-            if x is None or x.dtype != dt or x.device != dev or x.shape != shape:
-                x = t[name] = torch.empty(shape, dtype=dt, device=dev)
+            if x is None or x.dtype != d or x.device != dev or x.shape != shape:
+                x = t[name] = torch.empty(shape, dtype=d, device=dev)
             return x
 
         def both(name, w):
             wf = w.detach()
             N, K = wf.shape
-            if dt == torch.float32:
+            if dt == torch.float32 or name in f32:
                 t[name] = wf
-                sb.add(wf, None, buf(name + "_t", (K, N)))
+                sb.add(wf, None, buf(name + "_t", (K, N), torch.float32))
             else:
                 sb.add(wf, buf(name, (N, K)), buf(name + "_t", (K, N)))
 
@@ -272,16 +279,20 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         both("w_tout", self.text_attn.linear_out.weight)
         both("w_c", self.cand_attn.weight)
         # fused LSTM weight [W_ih | W_hh] and its transpose
-        wc, wct = buf("w_cat", (4 * H, XK)), buf("w_cat_t", (XK, 4 * H))
+        dc = torch.float32 if "w_cat" in f32 else dt
+        wc, wct = buf("w_cat", (4 * H, XK), dc), buf("w_cat_t", (XK, 4 * H), dc)
         sb.add(self.lstm.weight_ih.detach(), wc[:, :AE + F], wct[:AE + F])
         sb.add(self.lstm.weight_hh.detach(), wc[:, AE + F:], wct[AE + F:])
         handle = sb.run()
         w = self._wstruct
         w.act_w, w.act_b = self.act_embed[0].weight.data_ptr(), self.act_embed[0].bias.data_ptr()
         w.b_ih, w.b_hh = self.lstm.bias_ih.data_ptr(), self.lstm.bias_hh.data_ptr()
-        for k in ("w_vin", "w_cat", "w_tin", "w_tout", "w_c"):
+        w.f32_mask = 0
+        for i, k in enumerate(("w_vin", "w_cat", "w_tin", "w_tout", "w_c")):
             setattr(w, k, t[k].data_ptr())
             setattr(w, k + "_t", t[k + "_t"].data_ptr())
+            if dt != torch.float32 and k in f32:
+                w.f32_mask |= 1 << i
         object.__setattr__(self, "_sb_handle", (ck, handle))
 
     def logit_branch_forward(self, recs):

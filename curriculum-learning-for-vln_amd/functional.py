@@ -376,7 +376,9 @@ class BnMlpFn(torch.autograd.Function):
             l.w, l.w_t, l.w_f32, l.b = wn.data_ptr(), wt.data_ptr(), W.data_ptr(), _p(b)
             affine(l.bn, gw, gb, bufs[1 + i])
             l.out = W.shape[0]
-            l.p_drop, l.seed, l.offset = drops[i]
+            l.p_drop, l.seed, l.offset = drops[i][:3]
+            if len(drops[i]) > 3:
+                m.offset_base_dev = drops[i][3]                     # runtime.DeviceClock word: every layer's offset is relative to it
         m.row_zero = _p(rz)
         return m, keep
 
@@ -458,6 +460,8 @@ class BnMlpFn(torch.autograd.Function):
             rz = row_zero.contiguous()
             rz = rz.view(torch.uint8) if rz.dtype == torch.bool else rz.to(torch.uint8)
         ctx.c_call = False
+        if any(len(dr) > 3 for dr in drops) and not (_BN_MLP_C_CALL[0] and nl <= _lib.BN_MLP_MAX_LAYERS):
+            raise _lib.VlnError("MLPwithBN: a DeviceClock needs the C-call form of the BN-MLP")
         if _BN_MLP_C_CALL[0] and nl <= _lib.BN_MLP_MAX_LAYERS and all(tensors[3 + 4 * i] is not None for i in range(nl)):
             return BnMlpFn._forward_c(ctx, x, rz, cfg, bufs, tensors)
 

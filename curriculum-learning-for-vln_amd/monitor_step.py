@@ -34,7 +34,7 @@ class MonitorStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, pe, ctx_mask, cand_mask, prev_rep, cand_rep, h0, c0, ctxt, *params):
-        training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = cfg
+        training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = cfg[:8]
         W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c = params
         lib = _lib.load()
         f32 = torch.float32
@@ -87,6 +87,7 @@ class MonitorStepFn(torch.autograd.Function):
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         io.seed_pe, io.off_pe, io.p_pe = seed_pe, off_pe, (p_pe if training else 0.0)
         io.seed, io.off_h1, io.off_mem, io.p_drop = seed, off_h1, off_mem, (p_drop if training else 0.0)
+        io.offset_base_dev = cfg[8] if len(cfg) > 8 else None        # runtime.DeviceClock word (offsets relative to it)
         st = lib.vln_monitor_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_monitor_step_fwd")
@@ -144,7 +145,7 @@ class FollowerStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, ctx_mask, img, a_prev, cands, h0, c0, ctxt, *params):
-        training, dtype, p_drop, seed, off = cfg
+        training, dtype, p_drop, seed, off = cfg[:5]
         W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out = params
         lib = _lib.load()
         f32 = torch.float32
@@ -196,6 +197,7 @@ class FollowerStepFn(torch.autograd.Function):
         ws = ops.workspace(dev, 1 << 22)
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         io.seed, io.off, io.p_drop = seed, off, (p_drop if training else 0.0)
+        io.offset_base_dev = cfg[5] if len(cfg) > 5 else None
         st = lib.vln_follower_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_follower_step_fwd")

@@ -147,10 +147,19 @@ class FusedAdam(_FusedFlat):
         self.betas, self.eps = betas, eps
         self.exp_avg, self.exp_avg_sq = self.state
 
+    def use_clock(self, clock):
+        """The step count (Adam's bias corrections) in a DEVICE word that `clock.tick()` bumps once per iteration, so that
+        `step()` can be captured into a whole-iteration graph (graphs.IterationGraph).  Call before the next iteration's tick."""
+        self._step_word = torch.full((1,), self.steps, dtype=torch.int64, device=self.flat_p.device)
+        clock.register_counter(self._step_word, 1)
+        return self
+
     def _launch(self, lib, grad_scale):
+        word = self.__dict__.get("_step_word")
         return lib.vln_adam_clip_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), self._begins, len(self.groups), self._partial.data_ptr(),
-                                      self.norms.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
+                                      self.norms.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                      0 if word is not None else self.steps, None if word is None else word.data_ptr(),
                                       self._clip_c, grad_scale, _lib.raw_stream())
 
 

@@ -46,12 +46,23 @@ class DeviceClock:
         self.epoch = 0
         self._rel: Dict[object, int] = {}
         self._seqs = []              # [sync buffer (int32 tensor), seq word index, granule slice (int32 view), host mirror]
+        self._counters = []          # [(int64 word tensor, increment per tick)]  e.g. FusedAdam's step count
         self._items = None
 
     def attach(self, *modules):
+        """Every module (and every submodule that owns dropout sites) reads its offsets from this clock from now on."""
         for m in modules:
-            m.clock = self
+            if isinstance(m, torch.nn.Module):
+                for sub in m.modules():
+                    object.__setattr__(sub, "clock", self)
+            else:
+                m.clock = self
         return self
+
+    def register_counter(self, word: torch.Tensor, inc: int = 1):
+        """An int64 device word bumped by `inc` on every tick (an optimizer's step count)."""
+        self._counters.append((word, int(inc)))
+        self._items = None
 
     def rel(self, key, limit: Optional[int] = None) -> int:
         r = self._rel.get(key, 0) + 1
@@ -79,9 +90,10 @@ class DeviceClock:
     def _tick_items(self):
         from . import _lib
         if self._items is None:
-            rows = [(self.ptr, self.STRIDE, 8)] + [(s[0].data_ptr() + 4 * s[1], self.STRIDE, 4) for s in self._seqs]
+            rows = [(self.ptr, self.STRIDE, 8)] + [(s[0].data_ptr() + 4 * s[1], self.STRIDE, 4) for s in self._seqs] + \
+                [(w.data_ptr(), inc, 8) for w, inc in self._counters]
             if len(rows) > 8:
-                raise RuntimeError("DeviceClock: at most 7 recurrence buffers per clock")
+                raise RuntimeError("DeviceClock: at most 7 recurrence buffers / counters per clock")
             self._items = ((_lib.TickItem * len(rows))(*[_lib.TickItem(p, inc, w, 0) for p, inc, w in rows]), len(rows))
         return self._items
 

@@ -163,7 +163,8 @@ int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, co
  * (a pure outer-product term).  HOST arrays of T entries.  The Self-Monitor agent's context and candidate gradients. */
 int vln_attn_dctx_deferred_drop(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                                 const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D, int accumulate,
-                                const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p, vln_stream_t s);
+                                const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p,
+                                const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/, vln_stream_t s);
 int vln_attn_bwd(const void* ctx, int ctype, const float* attn, const float* dalpha, const float* dattn_ext,
                  const float* dwc, int64_t lddwc, const float* vec, int64_t ldvec, float* dvec, int64_t lddvec,
                  float* dctx, float* dl_out, int B, int S, int D, vln_stream_t s);
@@ -198,7 +199,9 @@ int vln_rmsprop_clip_step(float* params, float* grads, float* square_avg, const 
  * Adam (betas, eps, bias correction with step = 1, 2, ...; no weight decay / amsgrad) and plain SGD. */
 int vln_adam_clip_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* group_begin,
                        int ngroups, float* partial, float* norms_out, float lr, float beta1, float beta2, float eps,
-                       int64_t step, const float* max_norms, float grad_scale, vln_stream_t s);
+                       int64_t step, const int64_t* step_dev /* nullable: the step count lives in a DEVICE word (bumped by vln_tick
+                       between iterations) and `step` is added to it -- bias corrections then form on the device and the launch can be
+                       replayed from a graph */, const float* max_norms, float grad_scale, vln_stream_t s);
 int vln_sgd_clip_step(float* params, float* grads, const int64_t* group_begin, int ngroups, float* partial,
                       float* norms_out, float lr, const float* max_norms, float grad_scale, vln_stream_t s);
 
@@ -313,6 +316,7 @@ typedef struct vln_monitor_step {
   float* ws; int64_t ws_floats;                                                             /* split-K / grouped-launch scratch */
   uint64_t seed_pe, off_pe; float p_pe;              /* dropout on the positioned context (units.py:207) */
   uint64_t seed, off_h1, off_mem; float p_drop;      /* dropout on h_1 (policy.py:160) and on the monitor memory (:128) */
+  const uint64_t* offset_base_dev;                   /* nullable: every site's offset is (*offset_base_dev) * 8 + its field (see vln_embed_fwd) */
 } vln_monitor_step;
 typedef struct vln_monitor_grads {
   const float *dlogit, *dprog, *dh1, *dc1, *dww_ext, *dmw_ext;        /* upstream gradients, each nullable */
@@ -353,6 +357,7 @@ typedef struct vln_follower_step {
   float *gates /*[B,4H]*/, *dots /*[B,max(L,V,C)]*/;                                          /* scratch of the call */
   float* ws; int64_t ws_floats;
   uint64_t seed, off; float p_drop;                  /* dropout sites `off` (LSTM input row, policy.py:49) and `off + 1` (h_1, :54) */
+  const uint64_t* offset_base_dev;                   /* nullable: offsets relative to a device word (see vln_embed_fwd) */
 } vln_follower_step;
 typedef struct vln_follower_grads {
   const float *dlogit, *dh1, *dc1, *dww_ext, *dvw_ext;                /* upstream gradients, each nullable */
@@ -408,6 +413,7 @@ typedef struct vln_bn_mlp {
   vln_bn_affine bn0;
   vln_bn_mlp_layer layer[VLN_BN_MLP_MAX_LAYERS];
   const uint8_t* row_zero;
+  const uint64_t* offset_base_dev;                   /* nullable: the layers' dropout offsets relative to a device word (see vln_embed_fwd) */
 } vln_bn_mlp;
 typedef struct vln_bn_mlp_grad_layer { float* g_w; float* g_b; float* g_gamma; float* g_beta; int32_t acc_w, acc_b, acc_bn, pad_; } vln_bn_mlp_grad_layer;
 typedef struct vln_bn_mlp_grads {
@@ -551,6 +557,10 @@ typedef struct vln_envdrop_weights {
   const void* w_tout_t;  /* [2H,H] */
   const void* w_c;       /* cand_attn.weight [F,H] */
   const void* w_c_t;     /* [H,F] */
+  /* Per-matrix override of dims.wtype: bit k set = that matrix AND its transpose are fp32 although the step streams bf16
+   * (bit 0 w_vin, 1 w_cat, 2 w_tin, 3 w_tout, 4 w_c) -- the matrices whose 2^-9 rounding a caller does not want in front of a
+   * softmax (EnvDropDecoder.fp32_weights; the measured trade is in profiles/round3_notes.md). */
+  int32_t f32_mask; int32_t pad_;
 } vln_envdrop_weights;
 
 typedef struct vln_envdrop_step {

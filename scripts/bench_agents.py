@@ -20,7 +20,7 @@ import vln_amd as vln
 
 
 class _Args:          # defaults when imported (bench.py's secondary numbers); overwritten by the command line below
-    steps, warmup, dtype, arena = 30, 8, "bf16", False
+    steps, warmup, dtype, arena, graph = 30, 8, "bf16", False, True
 
 
 args = _Args()
@@ -29,9 +29,9 @@ dt = torch.bfloat16
 F = 2176
 
 
-def configure(steps=30, warmup=8, dtype="bf16", arena=False, device=None):
+def configure(steps=30, warmup=8, dtype="bf16", arena=False, device=None, graph=True):
     global dt, dev
-    args.steps, args.warmup, args.dtype, args.arena = steps, warmup, dtype, arena
+    args.steps, args.warmup, args.dtype, args.arena, args.graph = steps, warmup, dtype, arena, graph
     dt = torch.bfloat16 if dtype == "bf16" else torch.float32
     if device is not None:
         dev = device
@@ -48,6 +48,15 @@ def with_arena(fn):
         finally:
             vln.ops.set_arena(None)
     return run
+
+
+def graphed(fn, clock):
+    """The whole iteration (forward, losses, backward, optimizer) as ONE hipGraph (graphs.IterationGraph): `fn` ticks `clock`
+    first; the teacher-forced batch sits at fixed addresses."""
+    for _ in range(3):
+        fn()
+    g = vln.IterationGraph(fn, clock).capture()
+    return g.replay
 
 
 def timed(fn):
@@ -67,6 +76,10 @@ def run_monitor(B=128, L=80, T=7, C=8):
     dec = vln.MonitorDecoder(512, 0.5, L, (128, 1024), F, F, compute_dtype=dt).to(dev).train()
     dec.c_step = not getattr(args, "python_step", False)
     opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-4)
+    clock = None
+    if args.graph and dec.c_step and not args.arena:
+        clock = vln.DeviceClock(dev).attach(enc, dec)
+        opt.use_clock(clock)
     tokens = torch.randint(4, 992, (B, L), generator=g)
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
     for i, n in enumerate(lens.tolist()):
@@ -86,6 +99,8 @@ def run_monitor(B=128, L=80, T=7, C=8):
                           ended=(torch.rand(B, generator=g) < 0.1 * t).to(dev)))
 
     def it():
+        if clock is not None:
+            clock.tick()
         opt.zero_grad()
         ctx, h, c = enc(tokens, lens32)
         a_prev = torch.zeros(B, F, device=dev)
@@ -101,9 +116,11 @@ def run_monitor(B=128, L=80, T=7, C=8):
 
     if args.arena:
         it = with_arena(it)
+    if clock is not None:
+        it = graphed(it, clock)
     ms = timed(it)
-    return dict(workload=f"self_monitor_il_B{B}_L{L}_T{T}_adam" + ("_arena" if args.arena else ""), ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
-                dtype=args.dtype)
+    return dict(workload=f"self_monitor_il_B{B}_L{L}_T{T}_adam" + ("_arena" if args.arena else "") + ("_graph" if clock is not None else ""),
+                ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
 def run_follower(B=64, L=80, T=7, C=8, fused=True):
@@ -116,6 +133,10 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
     dec.c_step = not getattr(args, "python_step", False)
     opt_e = vln.optim.FusedAdam([list(enc.parameters())], lr=1e-4)
     opt_d = vln.optim.FusedAdam([list(dec.parameters())], lr=1e-4)
+    clock = None
+    if args.graph and fused and dec.c_step and not args.arena:
+        clock = vln.DeviceClock(dev).attach(enc, dec)
+        opt_e.use_clock(clock); opt_d.use_clock(clock)
     tokens = torch.randint(4, 992, (B, L), generator=g)
     lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
     for i, n in enumerate(lens.tolist()):
@@ -132,6 +153,8 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
         steps.append(dict(img=img.to(dev), cand=cand.to(dev), cmask=cmask.to(dev), target=tgt.to(dev)))
 
     def it():
+        if clock is not None:
+            clock.tick()
         opt_e.zero_grad(); opt_d.zero_grad()
         ctx, h, c = enc(tokens, lens32)
         a_prev = torch.zeros(B, F, device=dev)
@@ -145,8 +168,10 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
 
     if args.arena:
         it = with_arena(it)
+    if clock is not None:
+        it = graphed(it, clock)
     ms = timed(it)
-    return dict(workload=f"follower_il_B{B}_L{L}_T{T}_adam" + ("" if fused else "_operator_path"), ms_per_iteration=round(ms, 3),
+    return dict(workload=f"follower_il_B{B}_L{L}_T{T}_adam" + ("" if fused else "_operator_path") + ("_graph" if clock is not None else ""), ms_per_iteration=round(ms, 3),
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
@@ -237,9 +262,10 @@ def main():
     ap.add_argument("--python-step", action="store_true", help="monitor: the step's launches driven from Python (functional.MonitorCoreFn) "
                                                                "instead of one C call each way")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
+    ap.add_argument("--no-graph", action="store_true", help="monitor / follower: eager launches instead of one hipGraph per iteration")
     ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
     a = ap.parse_args()
-    configure(a.steps, a.warmup, a.dtype, a.arena)
+    configure(a.steps, a.warmup, a.dtype, a.arena, graph=not a.no_graph)
     args.python_step = a.python_step
     args.per_step_sampler = a.per_step_sampler
     vln.functional.set_grad_in_place(not a.no_grad_in_place)

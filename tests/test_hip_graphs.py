@@ -77,3 +77,98 @@ def test_clock_offsets_are_the_host_counter_offsets(vln):
     enc._calls = 2 * clock.STRIDE
     b = enc(tokens, lens)[0]
     assert torch.equal(a, b)
+
+
+def _small_agent(vln, kind, dev, seed):
+    """A miniature Self-Monitor / Speaker-Follower training iteration (scripts/bench_agents.py in small): encoder, T decoder
+    steps with their losses, backward, fused Adam -- with a DeviceClock attached to everything that owns dropout sites."""
+    torch.manual_seed(seed)
+    B, L, T, C, F = 16, 24, 3, 6, 192
+    g = torch.Generator().manual_seed(seed + 1)
+    if kind == "monitor":
+        enc = vln.EncoderLSTM(60, 32, 64, 0, 0.5, False, 1).to(dev).train()
+        dec = vln.MonitorDecoder(64, 0.5, L, (32, 128), F, F).to(dev).train()
+        opts = [vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-3)]
+    else:
+        enc = vln.EncoderLSTM(60, 32, 64, 0, 0.5, True, 2).to(dev).train()
+        dec = vln.AttnDecoderLSTM(64, 0.5, F, F).to(dev).train()
+        opts = [vln.optim.FusedAdam([list(enc.parameters())], lr=1e-3), vln.optim.FusedAdam([list(dec.parameters())], lr=1e-3)]
+    enc.deterministic_embedding_grad = True
+    clock = vln.DeviceClock(dev).attach(enc, dec)
+    for o in opts:
+        o.use_clock(clock)
+    batches = []
+    for k in range(4):
+        tokens = torch.randint(4, 60, (B, L), generator=g)
+        lens = torch.sort(torch.randint(4, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+        for i, n in enumerate(lens.tolist()):
+            tokens[i, n:] = 0
+        steps = []
+        for t in range(T):
+            ncand = torch.randint(2, C + 1, (B,), generator=g)
+            cmask = torch.arange(C)[None, :] >= ncand[:, None]
+            steps.append(dict(cand=(torch.randn(B, C, F, generator=g).abs() * 0.5 * (~cmask)[..., None]).to(dev), cmask=cmask.to(dev),
+                              img=(torch.randn(B, 36, F, generator=g).abs() * 0.5).to(dev),
+                              target=(torch.rand(B, generator=g) * ncand.float()).long().to(dev),
+                              start=(torch.rand(B, generator=g) * 15 + 4).to(dev), cur=(torch.rand(B, generator=g) * 10 + 0.2).to(dev),
+                              ended=(torch.rand(B, generator=g) < 0.1 * t).to(dev)))
+        batches.append(dict(tokens=tokens.to(dev), lens=lens.to(dev, torch.int32), steps=steps))
+    live = {k: (v.clone() if torch.is_tensor(v) else [{kk: vv.clone() for kk, vv in s.items()} for s in v]) for k, v in batches[0].items()}
+
+    def load(k):                       # the batch into the fixed buffers the (captured) iteration reads
+        b = batches[k % len(batches)]
+        live["tokens"].copy_(b["tokens"]); live["lens"].copy_(b["lens"])
+        for ls, bs in zip(live["steps"], b["steps"]):
+            for kk in ls:
+                ls[kk].copy_(bs[kk])
+
+    def it():
+        clock.tick()
+        for o in opts:
+            o.zero_grad()
+        ctx, h, c = enc(live["tokens"], live["lens"])
+        seq_mask = live["tokens"] == 0
+        a_prev = torch.zeros(B, F, device=dev)
+        loss = 0.0
+        for t, s in enumerate(live["steps"]):
+            if kind == "monitor":
+                (logit, prog), (h, c), _ = dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
+                lt, _ = vln.losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, 0.5)
+            else:
+                logit, (h, c), _ = dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask)
+                lt = vln.losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
+            loss = loss + lt
+            a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
+        loss.backward()
+        for o in opts:
+            o.step()
+        return loss
+
+    return it, load, opts, clock, dec
+
+
+@pytest.mark.parametrize("kind", ["monitor", "follower"])
+def test_other_agents_iteration_graph_equals_eager(vln, kind):
+    """The Self-Monitor and Speaker-Follower iterations (one C call per decoder step each way, BN-MLP, fused step loss, fused
+    Adam whose step count lives in a device word) captured whole and replayed: equal to the eager iterations bit for bit."""
+    dev = torch.device(DEV)
+    runs = []
+    for graph in (False, True):
+        it, load, opts, clock, dec = _small_agent(vln, kind, dev, 31)
+        out = []
+        for k in range(2):
+            load(k)
+            out.append((it().detach().clone(), [o.flat_p.clone() for o in opts]))
+        torch.cuda.synchronize()
+        g = vln.IterationGraph(it, clock).capture() if graph else None
+        for k in range(2, 6):
+            load(k)
+            loss = g.replay() if graph else it()
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), [o.flat_p.clone() for o in opts]))
+        runs.append(out)
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], b[0]), f"iteration {i}: loss {float(a[0])} vs {float(b[0])}"
+        for x, y in zip(a[1], b[1]):
+            assert torch.equal(x, y), f"iteration {i}: parameters differ"

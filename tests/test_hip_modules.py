@@ -182,8 +182,13 @@ def test_critic_golden(vln):
 # every weight carries a 2^-9 relative rounding; the visual attention's logits (K = 2176 products of magnitude ~1 each, then a
 # softmax over 36 views) and the LSTM gates (K = 2752) turn that into ~1e-2 of the state's range after one step.  The
 # same-weights oracle (the kernels' arithmetic itself) is met at 1e-4 for every tensor.
-ENVDROP_BF16_EXC = {"h1_": 3e-2, "h_tilde": 2e-2, "logit": 2e-2, "dh_tilde0": 5e-2, "dc0": 3e-2, "dctx": 2e-2,
-                    "grad[visual_attn.linear_in.weight]": 4e-2, "grad[": 2e-2}
+# Round 3, decided by measurement (scripts/bf16_exceptions_ab.py, profiles/round3_notes.md): of the 22 comparisons of this test TWO
+# exceed 1e-2 (d h_tilde_0 and d visual_attn.linear_in.weight, 1.4e-2 each); h1 / the text query's weight gradient / logits sit
+# at 0.8-1.0e-2 and move by +-30 % with the dropout draw (round 2's draw had h1 at 1.3e-2), hence the margins.  Streaming the two
+# attention QUERY projections (visual_attn.linear_in 512 x 2176, text_attn.linear_in 512 x 512) in fp32 brings EVERY comparison
+# to <= 6.5e-3 for +2.6 % time (EnvDropDecoder.fp32_weights; test_envdrop_full_size_bf16_meets_1e2_with_fp32_query_weights).
+ENVDROP_BF16_EXC = {"dh_tilde0": 3e-2, "grad[visual_attn.linear_in.weight]": 3e-2, "h1_": 2e-2, "dc0": 2e-2, "logit": 1.5e-2,
+                    "h_tilde": 1.5e-2, "dctx": 1.5e-2, "grad[": 1.5e-2}
 ENCODER_BF16_EXC = {"grad[": 2e-2}
 
 
@@ -202,7 +207,7 @@ def _variants(compute_dtype, exc):
     return [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, exc)]
 
 
-def _full_size_envdrop(vln, compute_dtype, T=3, train=True):
+def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=(), bf16_exc=None):
     from oracle import torch_port as O
     B, L, V, C, H, IMG, ANG, AE = 64, 80, 36, 8, 512, 2048, 128, 64
     F = IMG + ANG
@@ -210,13 +215,19 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True):
     torch.manual_seed(2020)          # default parameter init comes from the global RNG: pin it (test-order independent)
     dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=compute_dtype).to(DEV)
     dec.train(train)
+    if fp32_weights:
+        dec.fp32_weights = frozenset(fp32_weights)
+    fp32_names = {"w_vin": "visual_attn.linear_in.weight", "w_tin": "text_attn.linear_in.weight", "w_tout": "text_attn.linear_out.weight",
+                  "w_c": "cand_attn.weight", "w_cat": None}
+    skip_round = ("act_embed.0.weight",) + tuple(fp32_names[k] for k in fp32_weights if fp32_names[k]) + \
+        (("lstm.weight_ih", "lstm.weight_hh") if "w_cat" in fp32_weights else ())
     ctx = (torch.randn(B, L, H, generator=g) * 0.5)
     lens = torch.randint(8, L + 1, (B,), generator=g); lens[0] = L
     ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
     ht = torch.tanh(torch.randn(B, H, generator=g)); c = torch.randn(B, H, generator=g) * 0.5
     ctx_d = ctx.to(DEV).requires_grad_(True); ht_d = ht.to(DEV).requires_grad_(True); c_d = c.to(DEV).requires_grad_(True)
     V_ = []
-    for name, tol, same, exc in _variants(compute_dtype, ENVDROP_BF16_EXC):
+    for name, tol, same, exc in _variants(compute_dtype, ENVDROP_BF16_EXC if bf16_exc is None else bf16_exc):
         V_.append(dict(name=name, tol=tol, same=same, exc=exc, loss=0.,
                        P={k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()},
                        ctx=ctx.double().requires_grad_(True), ht=ht.double().requires_grad_(True), c=c.double().requires_grad_(True)))
@@ -247,7 +258,7 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True):
         loss_d = loss_d + (logit * rl.to(DEV)).sum() + h1.sum() * 0.01
         for v in V_:
             ho, co = v["state"]
-            Pv = bf16_weights(v["P"], skip=("act_embed.0.weight",)) if v["same"] else v["P"]   # the 128 -> 64 embedding runs in fp32
+            Pv = bf16_weights(v["P"], skip=skip_round) if v["same"] else v["P"]   # the 128 -> 64 embedding (and fp32_weights) run in fp32
             cx = bf16_round_st(v["ctx"]) if v["same"] else v["ctx"]          # the text attention streams a bf16 copy of ctx
             lo, (h1o, co), ho, _ = O.envdrop_step(Pv, a.double(), img_o, cand_o, ho, co, cx, ctx_mask, drop=drop)
             v["state"] = (ho, co)
@@ -278,6 +289,13 @@ def test_envdrop_full_size_bf16(vln):
     """bf16-streamed weights / features / context, fp32 accumulate, dropout on: vs the fp64 oracle on the SAME rounded weights
     (1e-4) and vs the fp64 oracle on the UNROUNDED parameters (north_star's 1e-2, exceptions listed in ENVDROP_BF16_EXC)."""
     _full_size_envdrop(vln, torch.bfloat16)
+
+
+def test_envdrop_full_size_bf16_meets_1e2_with_fp32_query_weights(vln):
+    """north_star's bf16 bound (1e-2 against the reference's fp32 arithmetic) for EVERY output and gradient, no exceptions: the
+    two attention query projections streamed in fp32 (their 2^-9 weight rounding sits in front of a softmax), everything else
+    bf16.  +2.6 % time per iteration (bench.py secondary `fp32_query_weights_ms_per_step`)."""
+    _full_size_envdrop(vln, torch.bfloat16, fp32_weights=("w_vin", "w_tin"), bf16_exc={})
 
 
 def test_encoder_full_size_bf16(vln):
