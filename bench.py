@@ -231,6 +231,7 @@ class GpuAgent:
         self.clock = None
         self.graph = None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
+        self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
 
     def _probe(self):
         n = getattr(self, "probe_trivial", 0)
@@ -353,7 +354,15 @@ class GpuAgent:
             return tape["store"].gather_rollout([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
                                                 pf, want_bf16=lp, want_f32=not lp)
 
-        if self.rollout_gather and self.gather_branch and tape.get("store") is not None:
+        ride = None
+        if self.ride_gather and tape.get("store") is not None:
+            # the rollout's gather rides in the encoder's persistent recurrence launch (passenger workgroups on its idle CUs)
+            lp = self.dtype != torch.float32
+            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
+            ride = tape["store"].rollout_ride([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
+                                              pf, want_bf16=lp, want_f32=not lp)
+            pre = ride.outputs
+        elif self.rollout_gather and self.gather_branch and tape.get("store") is not None:
             # the gather reads only the resident table + index vectors: as a branch of the captured graph it runs beside the
             # instruction encoder (whose 0.2 ms recurrence keeps half of the CUs idle) and joins before the first decoder step
             main = torch.cuda.current_stream()
@@ -363,13 +372,13 @@ class GpuAgent:
             branch.wait_stream(main)
             with torch.cuda.stream(branch):
                 pre = gather_all()
-        ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"])
+        ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"], ride=ride) if ride is not None else self.enc(tape["tokens"], tape["lengths32"])
         h_tilde = h_t
         terms = []
         ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
         if branch is not None:
             torch.cuda.current_stream().wait_stream(branch)
-        elif self.rollout_gather and tape.get("store") is not None:
+        elif pre is None and self.rollout_gather and tape.get("store") is not None:
             pre = gather_all()
         for t, s in enumerate(tape["steps"]):
             if pre is not None:
@@ -541,6 +550,10 @@ def main():
                     help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
                          "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
                          "boundary inside this very graph (rocprofv3 reports a ~4.7 us floor for ANY short kernel; unprofiled: 1.95 us)")
+    ap.add_argument("--ride-gather", default="auto", choices=["auto", "on", "off"],
+                    help="store features, teacher forcing: the rollout's feature gather as PASSENGER workgroups of the encoder's "
+                         "persistent recurrence launch (the 128 CUs that launch leaves idle at B = 64); the decoder steps then "
+                         "start with their prep launch only.  auto = on (profiles/round3_notes.md: 1.661 vs 1.687 ms)")
     ap.add_argument("--gather-branch", action="store_true",
                     help="with --rollout-gather and the iteration graph: the rollout-wide gather as a captured BRANCH beside the encoder")
     ap.add_argument("--rollout-gather", action="store_true",
@@ -607,6 +620,7 @@ def main():
     agent.prefetch_under_backward = not args.no_backward_prefetch
     agent.rollout_gather = bool(args.rollout_gather)
     agent.gather_branch = bool(args.gather_branch)
+    agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
     agent.probe_trivial = int(args.probe_trivial)
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and world == 1 and args.features == "store"
                                                  and not args.no_arena)
@@ -824,7 +838,7 @@ def main():
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
-                       "parallelism": f"dp{world}", "world_size": world, "iteration_graph": bool(use_graph),
+                       "parallelism": f"dp{world}", "world_size": world, "iteration_graph": bool(use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
@@ -873,6 +887,7 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
     try:
         ag = GpuAgent(vln, dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
         ag.clear_grads_in_step = True
+        ag.ride_gather = features == "store" and args.ride_gather != "off" and not args.rollout_gather
         if fp32_weights:
             ag.dec.fp32_weights = frozenset(fp32_weights)
         if features == "store":

@@ -37,6 +37,11 @@ class GatherRolloutStep(C.Structure):
                 + [("offset_pano", u64), ("offset_cand", u64)])
 
 
+class GatherRide(C.Structure):         # vln_gather_ride
+    _fields_ = ([("table", ptr), ("angle_table", ptr), ("steps", ptr)] + [(n, i32) for n in ("ttype", "T", "B", "V", "C", "IMG", "ANG", "pad_")]
+                + [("seed", u64), ("p_feat", f32), ("padf_", f32), ("offset_base_dev", ptr)])
+
+
 class CatStep(C.Structure):
     _fields_ = [("probs", ptr), ("action", ptr), ("dlogits", ptr), ("C", i32)]
 
@@ -239,7 +244,7 @@ SIGNATURES = {
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
     "vln_lstm_sync_seq_offset": (i64, [i32, i32, i32]),
     "vln_lstm_sync_granule_range": (i32, [i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
-    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr]),
+    "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr]),
     "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),
     "vln_set_persistent": (i32, [i32]),

@@ -16,6 +16,7 @@
 
 #include "vln_internal.h"
 #include "graph_cache.h"
+#include "gather_ride.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -782,17 +783,30 @@ static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long g
 
 template <typename TW>
 static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
-                                const unsigned* seq_dev, unsigned seq_rel) {
+                                const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
-  const dim3 g1(grid.x * grid.y * grid.z);
+  dim3 g1(grid.x * grid.y * grid.z);
+  const int nrec = (int)g1.x;
   const int xm = g_tunable[7] != 1;
   constexpr int BK = RecCfg<TW>::BK;
+  static const GatherRolloutArgs no_ride{};
+  unsigned lds_claim = 0;
+  if (ride) {
+    // passengers on the CUs the recurrence leaves idle (at most as many as it has workgroups); 96 KB of dynamic LDS on top of
+    // the kernel's own ~20 KB: ONE workgroup per compute unit, so the two kinds never share a CU
+    int np = device_cus() - nrec;
+    if (np > nrec) np = nrec;
+    if (np >= 8) { g1.x += (unsigned)np; lds_claim = 96u * 1024u; }
+    else ride = nullptr;
+  }
+  const GatherRolloutArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_GF(NS_)                                                                                               \
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), 0, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel); \
+    if (lds_claim) { static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess; (void)ok; } \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd); \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -835,7 +849,7 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
                                 int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
-                                int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s) {
+                                int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
@@ -854,6 +868,17 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
     unsigned tag_base = 0;
     unsigned char* gex = static_cast<unsigned char*>(sync_ws) + sync_off_gfwd(B, Hd, dirs);
+    // the ride: as passengers of the granule-protocol launch when it fits one argument block, else its own launch(es) first
+    GatherRolloutArgs ride_args{};
+    const GatherRolloutArgs* riders = nullptr;
+    if (ride) {
+      if (fwd_granules() && ride->T <= kGatherMaxSteps && g_tunable[6] != 3) {      // tunable[6] = 3: never as passengers (A/B)
+        r = gather_ride_args(*ride, 0, &ride_args); if (r) return r;
+        riders = &ride_args;
+      } else {
+        r = gather_ride_launch(st, *ride); if (r) return r;
+      }
+    }
     const unsigned* seq_dev = device_seq >= 0 ? reinterpret_cast<const unsigned*>(static_cast<char*>(sync_ws) + sync_off_seq(B, Hd, dirs)) : nullptr;
     if (fwd_granules() && !seq_dev) {
       r = persist_tag_base(st, sync_ws, sync_off_gfwd(B, Hd, dirs), persist_g_fwd_bytes(B, Hd, dirs) + persist_g_bwd_bytes(B, Hd, dirs), &tag_base);
@@ -862,14 +887,15 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     {
       ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
       if (fwd_granules())
-        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq)
-                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq);
+        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders)
+                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders);
       else
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
     }
     return r;
   }
+  if (ride) { int rr = gather_ride_launch((hipStream_t)s, *ride); if (rr) return rr; }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[12]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, h0, c0},
                                                  {wtype, B, L, Hd, dirs}};

@@ -70,6 +70,10 @@ struct GatherStepArgs {
   int B, V, C, IMG, ANG;
   DropSpec dr_pano, dr_cand;
 };
+// every step of a teacher-forced rollout (features.hip: one launch; encoder_persist_g.h: as PASSENGER workgroups of the
+// instruction encoder's persistent recurrence launch, on the compute units that launch leaves idle)
+constexpr int kGatherMaxSteps = 12;
+struct GatherRolloutArgs { GatherStepArgs step[kGatherMaxSteps]; int T, nrows, ttype, pipe; };   // pipe: gather_ride.h
 // gather of a step + the step's prep work as extra workgroups of the same launch (features.hip)
 int gather_step_prep(hipStream_t st, const GatherStepArgs& a, int ttype, const PrepArgs& p);
 

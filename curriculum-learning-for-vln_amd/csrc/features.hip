@@ -94,8 +94,6 @@ __global__ __launch_bounds__(256) void gather_step_prep_kernel(GatherStepArgs a,
 // With teacher forcing the path -- hence every step's viewpoint and candidate rows -- is known when the rollout starts
 // (the reference steps its simulator along the ground-truth actions, base.py:141-157 + follower.py:140): T gather launches of
 // ~15 us on the steps' dependent chains become one launch of T * (B*V + B*C) row blocks ahead of the first step.
-constexpr int kGatherMaxSteps = 12;
-struct GatherRolloutArgs { GatherStepArgs step[kGatherMaxSteps]; int T, nrows; };
 template <typename TT>
 __global__ __launch_bounds__(256) void gather_rollout_kernel(GatherRolloutArgs a) {
   const int t = (int)blockIdx.x / a.nrows, r = (int)blockIdx.x % a.nrows;
@@ -145,34 +143,53 @@ extern "C" int vln_gather_step(const void* table, int ttype, const float* angle_
   return VLN_OK;
 }
 
-extern "C" int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T,
-                                  int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev,
-                                  vln_stream_t s) {
-  if (!table || !angle_table || !steps || T <= 0 || B <= 0 || V <= 0 || C <= 0 || IMG <= 0 || ANG <= 0 || (IMG & 7) || (ANG & 7)) {
-    set_error("vln_gather_rollout: bad args (IMG and ANG must be multiples of 8)");
+namespace vln {
+// steps [t0, t0 + a->T) of a ride as the kernels' argument block
+int gather_ride_args(const ::vln_gather_ride& r, int t0, GatherRolloutArgs* a) {
+  if (!r.table || !r.angle_table || !r.steps || r.T <= 0 || r.B <= 0 || r.V <= 0 || r.C <= 0 || r.IMG <= 0 || r.ANG <= 0 || (r.IMG & 7) || (r.ANG & 7)) {
+    set_error("gather ride: bad args (IMG and ANG must be multiples of 8)");
     return VLN_ERR_ARG;
   }
-  const int nrows = B * V + B * C;
-  for (int t0 = 0; t0 < T; t0 += kGatherMaxSteps) {
-    GatherRolloutArgs a{};
-    a.T = (T - t0 < kGatherMaxSteps) ? T - t0 : kGatherMaxSteps;
-    a.nrows = nrows;
-    for (int t = 0; t < a.T; ++t) {
-      const vln_gather_rollout_step& q = steps[t0 + t];
-      if (!q.rows || !q.view_index || !q.crows || !q.cviews || !q.heading || !q.elevation || (!q.out && !q.out_bf16) || (!q.cout && !q.cout_bf16)) {
-        set_error("vln_gather_rollout: null pointer in step %d", t0 + t);
-        return VLN_ERR_ARG;
-      }
-      a.step[t] = GatherStepArgs{table, angle_table, (const long long*)q.rows, q.view_index, (const long long*)q.crows, q.cviews,
-                                 q.heading, q.elevation, q.out, (bf16_raw*)q.out_bf16, q.cout, (bf16_raw*)q.cout_bf16, B, V, C, IMG, ANG,
-                                 drop_spec(seed, q.offset_pano, p_feat, offset_base_dev), drop_spec(seed, q.offset_cand, p_feat, offset_base_dev)};
+  a->T = (r.T - t0 < kGatherMaxSteps) ? r.T - t0 : kGatherMaxSteps;
+  a->nrows = r.B * r.V + r.B * r.C;
+  a->ttype = r.ttype;
+  // the pipelined passenger loop (gather_ride.h): one 8-element chunk per thread per row, one float4 of angle columns per
+  // lane of a half-wave, ONE output precision, the same in every step
+  int pipe = (r.IMG == 2048 && r.ANG == 128) ? 3 : 0;
+  for (int t = 0; t < a->T; ++t) {
+    const vln_gather_rollout_step& q = r.steps[t0 + t];
+    if (!q.rows || !q.view_index || !q.crows || !q.cviews || !q.heading || !q.elevation || (!q.out && !q.out_bf16) || (!q.cout && !q.cout_bf16)) {
+      set_error("gather ride: null pointer in step %d", t0 + t);
+      return VLN_ERR_ARG;
     }
-    dim3 grid((unsigned)(a.T * nrows)), block(256);
-    if (ttype == VLN_BF16) VLN_LAUNCH(gather_rollout_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
-    else VLN_LAUNCH(gather_rollout_kernel<float>, grid, block, 0, (hipStream_t)s, a);
+    a->step[t] = GatherStepArgs{r.table, r.angle_table, (const long long*)q.rows, q.view_index, (const long long*)q.crows, q.cviews,
+                                q.heading, q.elevation, q.out, (bf16_raw*)q.out_bf16, q.cout, (bf16_raw*)q.cout_bf16, r.B, r.V, r.C, r.IMG, r.ANG,
+                                drop_spec(r.seed, q.offset_pano, r.p_feat, r.offset_base_dev), drop_spec(r.seed, q.offset_cand, r.p_feat, r.offset_base_dev)};
+    const int lp = (q.out_bf16 && q.cout_bf16 && !q.out && !q.cout) ? 1 : 0, f32 = (q.out && q.cout && !q.out_bf16 && !q.cout_bf16) ? 2 : 0;
+    pipe &= (lp | f32);
+  }
+  a->pipe = (pipe == 1 && r.ttype == VLN_BF16) || (pipe == 2 && r.ttype != VLN_BF16) ? pipe : 0;
+  return VLN_OK;
+}
+int gather_ride_launch(hipStream_t st, const ::vln_gather_ride& r) {
+  for (int t0 = 0; t0 < r.T; t0 += kGatherMaxSteps) {
+    GatherRolloutArgs a{};
+    int rc = gather_ride_args(r, t0, &a);
+    if (rc != VLN_OK) return rc;
+    dim3 grid((unsigned)(a.T * a.nrows)), block(256);
+    if (r.ttype == VLN_BF16) VLN_LAUNCH(gather_rollout_kernel<bf16_raw>, grid, block, 0, st, a);
+    else VLN_LAUNCH(gather_rollout_kernel<float>, grid, block, 0, st, a);
     VLN_CHECK_LAUNCH("gather_rollout");
   }
   return VLN_OK;
+}
+}  // namespace vln
+
+extern "C" int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T,
+                                  int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev,
+                                  vln_stream_t s) {
+  const vln_gather_ride r{table, angle_table, steps, ttype, T, B, V, C, IMG, ANG, 0, seed, p_feat, 0.f, offset_base_dev};
+  return gather_ride_launch((hipStream_t)s, r);
 }
 
 extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows, const int32_t* view_index,

@@ -6,6 +6,7 @@
 #include "common.h"
 
 struct vln_shadow_job;   // include/vln_hip.h
+struct vln_gather_ride;
 struct vln_wsum_step;    // include/vln_hip.h
 struct vln_dot_step;     // include/vln_hip.h
 struct vln_wgrad_job;
@@ -161,6 +162,11 @@ int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float*
 int rows_wsum_multi(hipStream_t st, const vln_wsum_step* steps, int T, int ctype, int B, int D, long ldo, float ce_scale,
                     const float* ce_dloss, long ignore_index);
 int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, int B, int D, long ldv);
+
+// ---- features.hip ---------------------------------------------------------
+struct GatherRolloutArgs;
+int gather_ride_args(const ::vln_gather_ride& r, int t0, GatherRolloutArgs* a);      // steps [t0, t0 + 12) as a kernel argument block
+int gather_ride_launch(hipStream_t st, const ::vln_gather_ride& r);                  // the ride as its own launch(es)
 
 // ---- pointwise.hip --------------------------------------------------------
 struct LstmPwFwd {

@@ -44,6 +44,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, tokens, lens32, p_drop, offset, *params):
         lib = _lib.load()
+        ride, mod._ride = mod.__dict__.get("_ride"), None
         sh = mod._shadow.t
         B, L = tokens.shape
         dev = tokens.device
@@ -69,7 +70,8 @@ class _EncoderFn(torch.autograd.Function):
             ccat = ops.empty(B, dirs * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
                                             _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
-                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq, _stream()), "vln_lstm_seq_fwd")
+                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq,
+                                            C.byref(ride.struct) if (ride is not None and k == nl - 1) else None, _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:
                 if p_inter > 0:
@@ -335,9 +337,11 @@ class EncoderLSTM(nn.Module):
         sb.add(w, buf("w_e2d", tuple(w.shape)), buf("w_e2d_t", (w.shape[1], w.shape[0])))
         object.__setattr__(self, "_sb_handle", (ck, sb.run()))
 
-    def forward(self, inputs: torch.Tensor, lengths, already_sorted: bool = True):
+    def forward(self, inputs: torch.Tensor, lengths, already_sorted: bool = True, ride=None):
         """inputs [B, max_len] int64 on the GPU, lengths [B] (CPU or GPU, any int type).  Rows are processed
-        independently with packed-sequence semantics, so `already_sorted` needs no special handling."""
+        independently with packed-sequence semantics, so `already_sorted` needs no special handling.
+        ride (optional, staging.DeviceFeatureStore.rollout_ride): a rollout's feature gather that this call carries -- as
+        passenger workgroups of the last layer's persistent recurrence launch (half of the CUs are idle there at B = 64)."""
         if not inputs.is_cuda:
             raise _lib.VlnError("EncoderLSTM: inputs must be on the GPU; there is no CPU fallback")
         params = self._params_cached()
@@ -359,6 +363,7 @@ class EncoderLSTM(nn.Module):
             tokens = tokens.long()
         lens32 = torch.as_tensor(lengths).to(device=inputs.device, dtype=torch.int32)
         p = self.drop_ratio if self.training else 0.0
+        object.__setattr__(self, "_ride", ride)
         ctx, dec_init, c_t = _EncoderFn.apply(self, tokens, lens32, p, off, *params)
         lp, self._last_ctx_lp = self.__dict__.get("_last_ctx_lp"), None
         if lp is not None:

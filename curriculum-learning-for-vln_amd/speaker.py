@@ -48,7 +48,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         lens32 = torch.full((B,), L, dtype=torch.int32, device=dev)
         _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), ops.F32, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
-                                        *owner._sync_ws(dev, B, Hd, dirs), -1, _lib.raw_stream()), "vln_lstm_seq_fwd")
+                                        *owner._sync_ws(dev, B, Hd, dirs), -1, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
         ctx.owner, ctx.dims = owner, (B, L, Hd, dirs)
         ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh)
         ctx.set_materialize_grads(False)

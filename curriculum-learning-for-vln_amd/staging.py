@@ -15,6 +15,8 @@ import math
 from typing import Dict, Optional, Sequence
 
 import numpy as np
+import ctypes as C_
+
 import torch
 
 from . import _lib, ops
@@ -159,7 +161,13 @@ class DeviceFeatureStore:
         return (img, img_lp), (cand, cand_lp), ((seed, off1), (seed, off2))
 
 
-    def gather_rollout(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True, out=None):
+    def rollout_ride(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True, out=None):
+        """`gather_rollout` as a DESCRIPTION instead of a launch: hand it to `EncoderLSTM.forward(..., ride=...)` and the gather
+        runs as passenger workgroups of the encoder's persistent recurrence launch (on the compute units that launch leaves
+        idle); `ride.outputs` is what gather_rollout would have returned, valid once the encoder's forward has been issued."""
+        return self.gather_rollout(steps, p_feat, want_bf16, want_f32, out, _ride=True)
+
+    def gather_rollout(self, steps, p_feat: float = 0.0, want_bf16: bool = False, want_f32: bool = True, out=None, _ride=False):
         """`gather_step` for EVERY step of a teacher-forced rollout in ONE launch (the path is known when the rollout starts:
         base.py:141-157 driven by the ground-truth actions).  steps: sequence of (rows, view_index, crows, cviews, heading,
         elevation); returns a list of ((img, img_bf16), (cand, cand_bf16)) like gather_step.  Same Philox stream as calling
@@ -204,10 +212,24 @@ class DeviceFeatureStore:
             if t and (B, C) != tuple(steps[0][2].shape):
                 raise ValueError("gather_rollout: every step must have the same [B, C] candidate layout")
         B, C = steps[0][2].shape
+        if _ride:
+            r = _lib.GatherRide()
+            r.table, r.angle_table, r.steps = _p(self.table), _p(self.angle_table), C_.addressof(arr)
+            r.ttype, r.T, r.B, r.V, r.C, r.IMG, r.ANG = ops._dt(self.table), len(steps), B, self.V, C, self.IMG, self.ANG
+            r.seed, r.p_feat, r.offset_base_dev = seed, p, None if clock is None else clock.ptr
+            return RolloutRide(r, res, (arr, keep, [s_[0] for s_ in steps], [s_[1] for s_ in steps]))
         _lib.check(lib.vln_gather_rollout(_p(self.table), ops._dt(self.table), _p(self.angle_table), arr, len(steps), B, self.V, C,
                                           self.IMG, self.ANG, seed, p, None if clock is None else clock.ptr, _lib.raw_stream()),
                    "vln_gather_rollout")
         return res
+
+
+class RolloutRide:
+    """A rollout's feature gather waiting for a carrier launch (DeviceFeatureStore.rollout_ride)."""
+    __slots__ = ("struct", "outputs", "_keep")
+
+    def __init__(self, struct, outputs, keep):
+        self.struct, self.outputs, self._keep = struct, outputs, keep
 
 
 class PinnedStager:

@@ -457,6 +457,15 @@ typedef struct vln_gather_rollout_step {
   float* out; void* out_bf16; float* cout; void* cout_bf16;
   uint64_t offset_pano, offset_cand;
 } vln_gather_rollout_step;
+/* The same rollout-wide gather as a description (vln_gather_rollout's arguments), for entry points that run it beside their own
+ * work: vln_lstm_seq_fwd(ride = ...) executes it as PASSENGER workgroups of the persistent recurrence launch, on the compute
+ * units that launch leaves idle (at B = 64 the recurrence holds 128 of 256 CUs for ~180 us). */
+typedef struct vln_gather_ride {
+  const void* table; const float* angle_table; const vln_gather_rollout_step* steps /* HOST array of T */;
+  int32_t ttype, T, B, V, C, IMG, ANG, pad_;
+  uint64_t seed; float p_feat; float padf_;
+  const uint64_t* offset_base_dev;     /* nullable, see vln_embed_fwd */
+} vln_gather_ride;
 int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T, int B, int V,
                        int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/,
                        vln_stream_t s);
@@ -516,7 +525,10 @@ int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int3
                      float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B, int L, int Hd, int dirs,
                      const float* h0, const float* c0 /* [dirs][B][Hd] initial state, nullable = zeros (no gradient flows
                      back into it: vln_lstm_seq_bwd starts from the final states only) */,
-                     void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s);
+                     void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq,
+                     const vln_gather_ride* ride /* nullable: a rollout's feature gather done by this call -- as passenger
+                     workgroups of the persistent launch when that path is taken (T <= 12), else as its own launch first */,
+                     vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = persistent kernels, granule hand-off forward, counter
                                    * hand-off backward; 2 = counter both ways (round 1); 3 = granules both ways; identical results */
 /* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the

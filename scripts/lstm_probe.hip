@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
   printf("---- protocol %s\n", proto == 2 ? "counter (fwd + bwd)" : proto == 1 ? "default: granules fwd, counter bwd" : "granules (fwd + bwd)");
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    int r = vln_lstm_seq_fwd(d_x, d_w, wtype, d_len, d_hp, d_cp, d_y, d_act, d_tc, d_hc, d_cc, B, L, Hd, dirs, nullptr, nullptr, d_sync, sync_bytes, -1, nullptr);
+    int r = vln_lstm_seq_fwd(d_x, d_w, wtype, d_len, d_hp, d_cp, d_y, d_act, d_tc, d_hc, d_cc, B, L, Hd, dirs, nullptr, nullptr, d_sync, sync_bytes, -1, nullptr, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (r) { printf("fwd failed: %s\n", vln_last_error_string()); return 1; }

@@ -27,7 +27,8 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4):
     ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
-    ag.rollout_gather = ag.gather_branch = branch
+    ag.rollout_gather = ag.gather_branch = branch == "branch"
+    ag.ride_gather = branch == "ride"            # the gather as passengers of the encoder's recurrence launch
     ag.use_clock(store)
     out = []
 
@@ -48,7 +49,7 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("branch", [False, True])
+@pytest.mark.parametrize("branch", ["steps", "branch", "ride"])
 def test_iteration_graph_equals_eager(vln, dtype, branch):
     eager, word_e, host_e = _run(vln, dtype, False, branch)
     graph, word_g, host_g = _run(vln, dtype, True, branch)

@@ -429,3 +429,34 @@ def test_rollout_sampler_long_rollout_chunks(vln):
         s = vln.losses.RolloutSampler(capacity=2)
         for t in range(3):
             s.step(steps[0][0].to(DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, dtype):
+    """EncoderLSTM.forward(ride=store.rollout_ride(...)): the rollout's feature rows gathered by PASSENGER workgroups of the
+    persistent recurrence launch are the rows of gather_rollout bit for bit (same Philox offsets), and the encoder's own
+    outputs are untouched by the passengers."""
+    import bench
+    dev_ = torch.device(DEV)
+    torch.manual_seed(11)
+    cpu_tape = bench.make_tape(64, 80, 7, 8, seed=77)
+    cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
+    tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
+    store = tape["store"]
+    enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev_).train()
+    steps = [(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]]
+    lp = dtype != torch.float32
+    store._calls = 0; enc._calls = 0
+    ref = store.gather_rollout(steps, 0.3, want_bf16=lp, want_f32=not lp)
+    ctx0, h0, c0 = enc(tape["tokens"], tape["lengths32"])
+    store._calls = 0; enc._calls = 0
+    ride = store.rollout_ride(steps, 0.3, want_bf16=lp, want_f32=not lp)
+    ctx1, h1, c1 = enc(tape["tokens"], tape["lengths32"], ride=ride)
+    torch.cuda.synchronize()
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    assert torch.equal(ctx0, ctx1) and torch.equal(h0, h1) and torch.equal(c0, c1)
+    for (a_img, a_cand), (b_img, b_cand) in zip(ref, ride.outputs):
+        for x, y in list(zip(a_img, b_img)) + list(zip(a_cand, b_cand)):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
