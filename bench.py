@@ -550,6 +550,9 @@ def main():
                     help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
                          "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
                          "boundary inside this very graph (rocprofv3 reports a ~4.7 us floor for ANY short kernel; unprofiled: 1.95 us)")
+    ap.add_argument("--inject-timeout", type=int, default=0, metavar="K",
+                    help="(test) raise the sticky timeout word before untimed iteration K, as a persistent recurrence whose "
+                         "workgroups were not co-resident would: exercises the fallback to per-step launches")
     ap.add_argument("--ride-gather", default="auto", choices=["auto", "on", "off"],
                     help="store features, teacher forcing: the rollout's feature gather as PASSENGER workgroups of the encoder's "
                          "persistent recurrence launch (the 128 CUs that launch leaves idle at B = 64); the decoder steps then "
@@ -670,6 +673,26 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    raised = [0]
+
+    def warm_iterate():
+        """`iterate()` of the untimed phases.  A bounded in-kernel wait that timed out (the persistent recurrence's workgroups
+        were not co-resident) surfaces as VlnError from the NEXT library entry on this rank only -- the library has already
+        switched this process to per-step launches, whose results are the same.  The rank completes the iteration's gradient
+        exchange (the other ranks are inside it), remembers, and goes on; at the end of the phase every rank learns of it
+        through one all-reduced flag and takes the fallback together."""
+        try:
+            if args.inject_timeout and it_no[0] == args.inject_timeout:
+                vln._lib.check(lib.vln_debug_raise_sticky(0), "vln_debug_raise_sticky")
+            return iterate()
+        except vln.VlnError as e:
+            if "timed out" not in str(e):
+                raise
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+            raised[0] = 1
+            agent.opt.abandon_iteration(early_groups=(1,))
+            return None
+
     # Warm-up runs like the timed loop: iterations back to back, no per-iteration sync (the first time the host gets
     # many launches ahead of the GPU the runtime grows its in-flight pools: a one-time cost that belongs here).
     # Initialisation (not warm-up): the first four iterations build what later iterations only replay -- library load,
@@ -677,7 +700,7 @@ def main():
     # generation.  Like a JIT compile this happens once per process, whatever W is.
     tw = time.perf_counter()
     for i in range(4):
-        iterate()
+        warm_iterate()
         if i == 0:
             torch.cuda.synchronize()
             if rank == 0:
@@ -685,9 +708,14 @@ def main():
     torch.cuda.synchronize()
     if use_graph:
         tg = time.perf_counter()
-        agent.capture(live.live)
+        try:
+            agent.capture(live.live)
+        except vln.VlnError as e:                  # a timeout in the four iterations above: recorded after the fallback below
+            if "timed out" not in str(e):
+                raise
+            raised[0] = 1
         for _ in range(2):
-            iterate()
+            warm_iterate()
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] iteration captured as one hipGraph: {(time.perf_counter() - tg) * 1e3:.0f} ms", file=sys.stderr, flush=True)
@@ -699,9 +727,9 @@ def main():
     gc.collect()
     gc.freeze()
     for i in range(args.warmup):
-        iterate()
+        warm_iterate()
     barrier()
-    timed_out = int(agent.enc.persistent_status() != 0)
+    timed_out = int(agent.enc.persistent_status() != 0 or raised[0] or lib.vln_persistent_check() != 0)
     if world > 1:                                 # the fallback below contains collectives: every rank takes it or none does
         flag = torch.tensor([timed_out], device=dev, dtype=torch.int32)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
@@ -709,9 +737,10 @@ def main():
     if timed_out:                                 # a bounded in-kernel wait timed out during warm-up: fall back
         print("[bench] persistent recurrence reported a timeout; using per-step launches", file=sys.stderr, flush=True)
         lib.vln_set_persistent(0)
-        if agent.graph is not None:               # the recorded iteration contains the persistent launches: record it again
+        if use_graph:                             # the recorded iteration contains the persistent launches: record it again
             agent.capture(live.live)
-        iterate()
+        for i in range(max(1, args.warmup)):      # the warm-up again, on the path that will be timed
+            iterate()
         barrier()
     marks = []
     t0 = time.perf_counter()

@@ -229,6 +229,8 @@ SIGNATURES = {
     "vln_bn_mlp_bwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr, i64, C.POINTER(BnMlpGrads), ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
+    "vln_feature_table_extent": (i32, [ptr, i64, i32]),
+    "vln_debug_raise_sticky": (i32, [i32]),
     "vln_gather_rollout": (i32, [ptr, i32, ptr, C.POINTER(GatherRolloutStep), i32, i32, i32, i32, i32, i32, u64, f32, ptr, ptr]),
     "vln_gather_pano": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_gather_cands": (i32, [ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, u64, u64, f32, ptr]),
@@ -264,7 +266,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 9
+EXPECTED_ABI = 10
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()

@@ -116,7 +116,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 9; }
+extern "C" int vln_abi_version(void) { return 10; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,

@@ -615,7 +615,26 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
 // (granules) -- its hand-off is a PARTIAL-SUM exchange of 32 KB per workgroup per step, and doubling those bytes with tags
 // costs more than the removed drain + barrier + atomic.  All variants produce identical bits.
 int g_persist_enabled = 1;
-extern "C" int vln_set_persistent(int on) { g_persist_enabled = (on >= 0 && on <= 3) ? on : 1; return VLN_OK; }
+// Which sync workspaces hold a header that the counter-protocol backward left CLEAN (group counters zero: it resets them
+// itself).  Anything else -- a buffer this process has not launched on yet (the caller may not have zeroed it), a header the
+// counter-protocol FORWARD or a mode switch touched -- gets the fill launch in front of the next counter-protocol backward.
+static std::mutex g_hdr_mu;
+static std::unordered_map<const void*, bool> g_hdr_clean;
+static bool header_clean(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_hdr_mu);
+  auto it = g_hdr_clean.find(ws);
+  return it != g_hdr_clean.end() && it->second;
+}
+static void header_mark(const void* ws, bool clean) {
+  std::lock_guard<std::mutex> lock(g_hdr_mu);
+  g_hdr_clean[ws] = clean;
+}
+extern "C" int vln_set_persistent(int on) {
+  g_persist_enabled = (on >= 0 && on <= 3) ? on : 1;
+  std::lock_guard<std::mutex> lock(g_hdr_mu);
+  g_hdr_clean.clear();              // another protocol may run on the same buffers next: every header is dirty
+  return VLN_OK;
+}
 static inline bool fwd_granules() { return g_persist_enabled == 1 || g_persist_enabled == 3; }
 static inline bool bwd_granules() { return g_persist_enabled == 3; }
 
@@ -661,6 +680,13 @@ unsigned* vln::sticky_dev_word() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
   return g_sticky_dev + dev * 16;
 }
+extern "C" int vln_debug_raise_sticky(int word) {      // test hook: what a timed-out wait (0) / a bad gather index (1) leaves behind
+  if (word < 0 || word > 1 || !sticky_dev_word()) { set_error("vln_debug_raise_sticky: bad word / no host-mapped status line"); return VLN_ERR_ARG; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return VLN_ERR_HIP; }
+  __atomic_fetch_add(&g_sticky_host[dev * 16 + word], 1u, __ATOMIC_RELAXED);
+  return VLN_OK;
+}
 extern "C" int vln_persistent_check(void) {
   unsigned* h = g_sticky_host;
   if (!h) return VLN_OK;
@@ -672,6 +698,13 @@ extern "C" int vln_persistent_check(void) {
                 "workgroups were not co-resident); that iteration's numbers are invalid.  The persistent recurrence is now off "
                 "for this process (per-step launches)", n, d);
       return VLN_ERR_HIP;
+    }
+    if (__atomic_load_n(&h[d * 16 + 1], __ATOMIC_RELAXED)) {
+      const unsigned n = __atomic_exchange_n(&h[d * 16 + 1], 0u, __ATOMIC_RELAXED);
+      set_error("%u feature-gather index(es) were out of range of the registered table on device %d in an EARLIER launch "
+                "(viewpoint row, view index or candidate view): those rows were gathered as zeros; that iteration's numbers "
+                "are invalid", n, d);
+      return VLN_ERR_ARG;
     }
   }
   return VLN_OK;
@@ -893,6 +926,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
     }
+    if (!fwd_granules()) header_mark(sync_ws, false);       // the counter-protocol forward leaves its counters behind
     return r;
   }
   if (ride) { int rr = gather_ride_launch((hipStream_t)s, *ride); if (rr) return rr; }
@@ -939,7 +973,10 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     int r = vln_persistent_check(); if (r) return r;
     // The counter-protocol backward kernel resets its group counters itself and clears its status word; the header only
     // needs a fill when another kernel left counters behind (the counter-protocol FORWARD of mode 2) or in the flag variant.
-    if (VLN_SYNC_FLAGS || !fwd_granules() || bwd_granules()) {
+    // The self-reset only holds for a header this protocol left behind itself: a first launch on a buffer, or one after a mode
+    // switch / a counter-protocol forward, gets the fill (header_clean).
+    const bool self_cleaning = !VLN_SYNC_FLAGS && fwd_granules() && !bwd_granules();
+    if (!self_cleaning || !header_clean(sync_ws)) {
       r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
       if (r) return r;
     }
@@ -963,6 +1000,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
         r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
                                 : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
     }
+    header_mark(sync_ws, r == VLN_OK && self_cleaning);
     return r;
   }
   struct { const void* p[11]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_bm, dc_bm},

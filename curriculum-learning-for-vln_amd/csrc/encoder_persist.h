@@ -468,10 +468,12 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   // recurrence (4 us on the dependent chain) is not needed.  (A launch that timed out leaves garbage: it also raises the
   // sticky error, after which the library stops using these kernels.)
   if (threadIdx.x == 0) {
-    const unsigned through = __hip_atomic_fetch_add(cnt + 24, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acq_rel: this workgroup's last arrival on `cnt` is ordered before its pass through here, and the last one through
+    // sees every other workgroup's; the resets are release stores at agent scope (once per launch: off the step chain)
+    const unsigned through = __hip_atomic_fetch_add(cnt + 24, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (through + 1u == (unsigned)NJB) {
-      VLN_AGENT_STORE(cnt, 0u);
-      VLN_AGENT_STORE(cnt + 24, 0u);
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 24, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #endif

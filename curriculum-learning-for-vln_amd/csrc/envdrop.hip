@@ -123,7 +123,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     ga = GatherStepArgs{io->g_table, io->g_angle_table, (const long long*)io->g_rows, io->g_vidx, (const long long*)io->g_crows,
                         io->g_cviews, io->g_chead, io->g_celev, lp ? nullptr : io->img, lp ? (bf16_raw*)io->img_lp : nullptr,
                         lp ? nullptr : io->cand, lp ? (bf16_raw*)io->cand_lp : nullptr, B, d->V, d->C, d->IMG, d->ANG,
-                        site(io, 4, pf), site(io, 5, pf)};
+                        site(io, 4, pf), site(io, 5, pf), gather_check(io->g_table)};
     if (!lp && (!io->img || !io->cand)) { set_error("envdrop fwd: gathered features need img / cand buffers"); return VLN_ERR_ARG; }
     RUN(gather_step_prep(st, ga, io->g_ttype, pa));
   } else {

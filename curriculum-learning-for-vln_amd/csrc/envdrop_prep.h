@@ -62,6 +62,10 @@ static inline long envdrop_prep_items(const PrepArgs& p) {
 }
 
 // one launch per decoder step: panorama rows + candidate rows from the resident table (features.hip)
+// Range check of the gather's indices: a viewpoint row outside [0, n_rows) (candidates: >= n_rows; < 0 is the empty slot), a
+// panorama view index outside [0, n_aviews) or a candidate view outside [0, V) reads NOTHING -- the output row is all zeros --
+// and is counted in a host-mapped sticky word that the next vln_persistent_check() reports (features.hip).
+struct GatherCheck { long n_rows; int n_aviews; unsigned* bad; };
 struct GatherStepArgs {
   const void* table; const float* angle_table;
   const long long* rows; const int* view_index;                                     // panorama: [B], [B]
@@ -69,6 +73,7 @@ struct GatherStepArgs {
   float* out; bf16_raw* out_lp; float* cout; bf16_raw* cout_lp;
   int B, V, C, IMG, ANG;
   DropSpec dr_pano, dr_cand;
+  GatherCheck chk;          // the table's registered extent (vln_feature_table_extent); n_rows == 0: indices are not checked
 };
 // every step of a teacher-forced rollout (features.hip: one launch; encoder_persist_g.h: as PASSENGER workgroups of the
 // instruction encoder's persistent recurrence launch, on the compute units that launch leaves idle)

@@ -5,6 +5,8 @@
 // candidates' (row, view, heading, elevation)).  One pass gathers the rows, appends the angle features, applies
 // the environmental feature dropout (policy.py:226-231; same Philox indexing as feat_dropout_inplace) and
 // optionally emits the bf16 copy the attention kernels stream.  16-byte accesses, one workgroup per output row.
+#include <mutex>
+#include <unordered_map>
 #include "vln_internal.h"
 #include "envdrop_prep.h"
 #include "gather_body.h"
@@ -12,15 +14,32 @@
 
 namespace vln {
 
+// ---- registered table extents: every gather entry point range-checks its indices against them -----------------------
+namespace {
+struct Extent { long rows; int aviews; };
+std::mutex g_ext_mu;
+std::unordered_map<const void*, Extent> g_ext;
+}  // namespace
+GatherCheck gather_check(const void* table) {
+  std::lock_guard<std::mutex> lock(g_ext_mu);
+  auto it = g_ext.find(table);
+  if (it == g_ext.end()) return GatherCheck{0, 0, nullptr};
+  unsigned* w = sticky_dev_word();
+  if (!w) return GatherCheck{0, 0, nullptr};
+  return GatherCheck{it->second.rows, it->second.aviews, w + 1};       // sticky word 1 of the device: bad gather indices
+}
+
 template <typename TT>
 __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const long long* rows, const int* view_index,
                                                           const float* angle_table, float* out, bf16_raw* out_lp, int V,
-                                                          int IMG, int ANG, DropSpec dr) {
+                                                          int IMG, int ANG, DropSpec dr, GatherCheck chk) {
   const int r = blockIdx.x;             // output row = b*V + v
   const int b = r / V, v = r % V;
   const int F = IMG + ANG;
-  const TT* src = table + ((long)rows[b] * V + v) * IMG;
-  const float* ang = angle_table + ((long)view_index[b] * V + v) * ANG;
+  const bool bad = chk.n_rows && (rows[b] < 0 || rows[b] >= chk.n_rows || view_index[b] < 0 || view_index[b] >= chk.n_aviews);
+  if (bad && threadIdx.x == 0) __hip_atomic_fetch_add(chk.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const TT* src = table + (bad ? 0 : ((long)rows[b] * V + v) * IMG);
+  const float* ang = angle_table + (bad ? 0 : ((long)view_index[b] * V + v) * ANG);
   float* dst = out ? out + (long)r * F : nullptr;
   bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
   for (int c = threadIdx.x * 4; c < F; c += 256 * 4) {
@@ -35,6 +54,7 @@ __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const
     } else {
       Elt<float>::ld4(ang + (c - IMG), x);
     }
+    if (bad) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; }      // an out-of-range index reads nothing (GatherCheck)
     if (dst) Elt<float>::st4(dst + c, x);
     if (dlp) Elt<bf16_raw>::st4(dlp + c, x);
   }
@@ -43,13 +63,15 @@ __global__ __launch_bounds__(256) void gather_pano_kernel(const TT* table, const
 template <typename TT>
 __global__ __launch_bounds__(256) void gather_cands_kernel(const TT* table, const long long* rows, const int* views,
                                                            const float* heading, const float* elevation, float* out,
-                                                           bf16_raw* out_lp, int V, int IMG, int ANG, DropSpec dr) {
+                                                           bf16_raw* out_lp, int V, int IMG, int ANG, DropSpec dr, GatherCheck chk) {
   const int r = blockIdx.x;             // output row = b*C + c
   const int F = IMG + ANG;
   const long row = rows[r];
   float* dst = out ? out + (long)r * F : nullptr;
   bf16_raw* dlp = out_lp ? out_lp + (long)r * F : nullptr;
-  const bool empty = row < 0;           // STOP slot / padding: all-zero feature (base.py:152-153)
+  const bool bad = chk.n_rows && row >= 0 && (row >= chk.n_rows || views[r] < 0 || views[r] >= V);
+  if (bad && threadIdx.x == 0) __hip_atomic_fetch_add(chk.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool empty = row < 0 || bad;    // STOP slot / padding: all-zero feature (base.py:152-153); out-of-range: the same, counted
   float sh = 0.f, ch = 0.f, se = 0.f, ce = 0.f;
   if (!empty) { sh = sinf(heading[r]); ch = cosf(heading[r]); se = sinf(elevation[r]); ce = cosf(elevation[r]); }
   const TT* src = empty ? table : table + (row * V + views[r]) * IMG;
@@ -135,7 +157,7 @@ extern "C" int vln_gather_step(const void* table, int ttype, const float* angle_
   }
   GatherStepArgs a{table, angle_table, (const long long*)rows, view_index, (const long long*)crows, cviews, heading, elevation,
                    out, (bf16_raw*)out_bf16, cout, (bf16_raw*)cout_bf16, B, V, C, IMG, ANG,
-                   DropSpec{seed, offset_pano, p_feat}, DropSpec{seed, offset_cand, p_feat}};
+                   DropSpec{seed, offset_pano, p_feat}, DropSpec{seed, offset_cand, p_feat}, gather_check(table)};
   dim3 grid(B * V + B * C), block(256);
   if (ttype == VLN_BF16) VLN_LAUNCH(gather_step_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, a);
   else VLN_LAUNCH(gather_step_kernel<float>, grid, block, 0, (hipStream_t)s, a);
@@ -156,6 +178,7 @@ int gather_ride_args(const ::vln_gather_ride& r, int t0, GatherRolloutArgs* a) {
   // the pipelined passenger loop (gather_ride.h): one 8-element chunk per thread per row, one float4 of angle columns per
   // lane of a half-wave, ONE output precision, the same in every step
   int pipe = (r.IMG == 2048 && r.ANG == 128) ? 3 : 0;
+  const GatherCheck chk = gather_check(r.table);
   for (int t = 0; t < a->T; ++t) {
     const vln_gather_rollout_step& q = r.steps[t0 + t];
     if (!q.rows || !q.view_index || !q.crows || !q.cviews || !q.heading || !q.elevation || (!q.out && !q.out_bf16) || (!q.cout && !q.cout_bf16)) {
@@ -164,7 +187,7 @@ int gather_ride_args(const ::vln_gather_ride& r, int t0, GatherRolloutArgs* a) {
     }
     a->step[t] = GatherStepArgs{r.table, r.angle_table, (const long long*)q.rows, q.view_index, (const long long*)q.crows, q.cviews,
                                 q.heading, q.elevation, q.out, (bf16_raw*)q.out_bf16, q.cout, (bf16_raw*)q.cout_bf16, r.B, r.V, r.C, r.IMG, r.ANG,
-                                drop_spec(r.seed, q.offset_pano, r.p_feat, r.offset_base_dev), drop_spec(r.seed, q.offset_cand, r.p_feat, r.offset_base_dev)};
+                                drop_spec(r.seed, q.offset_pano, r.p_feat, r.offset_base_dev), drop_spec(r.seed, q.offset_cand, r.p_feat, r.offset_base_dev), chk};
     const int lp = (q.out_bf16 && q.cout_bf16 && !q.out && !q.cout) ? 1 : 0, f32 = (q.out && q.cout && !q.out_bf16 && !q.cout_bf16) ? 2 : 0;
     pipe &= (lp | f32);
   }
@@ -185,6 +208,14 @@ int gather_ride_launch(hipStream_t st, const ::vln_gather_ride& r) {
 }
 }  // namespace vln
 
+extern "C" int vln_feature_table_extent(const void* table, int64_t n_rows, int n_angle_views) {
+  if (!table || n_rows < 0 || (n_rows > 0 && n_angle_views <= 0)) { set_error("vln_feature_table_extent: bad args"); return VLN_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(g_ext_mu);
+  if (n_rows == 0) g_ext.erase(table);
+  else g_ext[table] = Extent{(long)n_rows, n_angle_views};
+  return VLN_OK;
+}
+
 extern "C" int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T,
                                   int B, int V, int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev,
                                   vln_stream_t s) {
@@ -201,10 +232,11 @@ extern "C" int vln_gather_pano(const void* table, int ttype, const int64_t* rows
   }
   dim3 grid(B * V), block(256);
   DropSpec dr{seed, offset, p_feat};
+  const GatherCheck chk = gather_check(table);
   if (ttype == VLN_BF16)
-    VLN_LAUNCH(gather_pano_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_pano_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr, chk);
   else
-    VLN_LAUNCH(gather_pano_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_pano_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, view_index, angle_table, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr, chk);
   VLN_CHECK_LAUNCH("gather_pano");
   return VLN_OK;
 }
@@ -218,10 +250,11 @@ extern "C" int vln_gather_cands(const void* table, int ttype, const int64_t* row
   }
   dim3 grid(BC), block(256);
   DropSpec dr{seed, offset, p_feat};
+  const GatherCheck chk = gather_check(table);
   if (ttype == VLN_BF16)
-    VLN_LAUNCH(gather_cands_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_cands_kernel<bf16_raw>, grid, block, 0, (hipStream_t)s, (const bf16_raw*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr, chk);
   else
-    VLN_LAUNCH(gather_cands_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr);
+    VLN_LAUNCH(gather_cands_kernel<float>, grid, block, 0, (hipStream_t)s, (const float*)table, (const long long*)rows, views, heading, elevation, out, (bf16_raw*)out_bf16, V, IMG, ANG, dr, chk);
   VLN_CHECK_LAUNCH("gather_cands");
   return VLN_OK;
 }

@@ -25,16 +25,22 @@ __device__ __forceinline__ void gather_step_rows(const GatherStepArgs& a, int r0
     pano[k] = r < npano;
     if (pano[k]) {
       const int b = r / a.V, v = r % a.V;
-      src[k] = table + ((long)a.rows[b] * a.V + v) * IMG;
+      const long row = a.rows[b];
+      const bool bad = a.chk.n_rows && (row < 0 || row >= a.chk.n_rows || a.view_index[b] < 0 || a.view_index[b] >= a.chk.n_aviews);
+      if (bad && live[k] && tid == 0) __hip_atomic_fetch_add(a.chk.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      src[k] = bad ? table : table + (row * a.V + v) * IMG;
       dst[k] = a.out ? a.out + (long)r * F : nullptr;
       dlp[k] = a.out_lp ? a.out_lp + (long)r * F : nullptr;
-      empty[k] = false;
+      empty[k] = bad;                          // an out-of-range index reads nothing: zeros, counted (GatherCheck)
       rr[k] = r;
     } else {
       const int rc = r - npano;
       const long row = a.crows[rc];
-      empty[k] = row < 0;                      // STOP slot / padding: all-zero feature (base.py:152-153)
-      src[k] = empty[k] ? table : table + (row * a.V + a.cviews[rc]) * IMG;
+      const int cv = a.cviews[rc];
+      const bool bad = a.chk.n_rows && row >= 0 && (row >= a.chk.n_rows || cv < 0 || cv >= a.V);
+      if (bad && live[k] && tid == 0) __hip_atomic_fetch_add(a.chk.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      empty[k] = row < 0 || bad;               // STOP slot / padding: all-zero feature (base.py:152-153)
+      src[k] = empty[k] ? table : table + (row * a.V + cv) * IMG;
       dst[k] = a.cout ? a.cout + (long)rc * F : nullptr;
       dlp[k] = a.cout_lp ? a.cout_lp + (long)rc * F : nullptr;
       rr[k] = rc;
@@ -92,12 +98,12 @@ __device__ __forceinline__ void gather_step_rows(const GatherStepArgs& a, int r0
     for (int k = 0; k < RPB; ++k) {
       if (!live[k]) continue;
       float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pano[k]) {
+      if (pano[k] && !empty[k]) {
         const int b = rr[k] / a.V, v = rr[k] % a.V;
         const float* ang = a.angle_table + ((long)a.view_index[b] * a.V + v) * a.ANG;
         const float4 t0 = *reinterpret_cast<const float4*>(ang + ca), t1 = *reinterpret_cast<const float4*>(ang + ca + 4);
         x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-      } else if (!empty[k]) {
+      } else if (!pano[k] && !empty[k]) {
         const float sh = sinf(a.heading[rr[k]]), ch = cosf(a.heading[rr[k]]), se = sinf(a.elevation[rr[k]]), ce = cosf(a.elevation[rr[k]]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

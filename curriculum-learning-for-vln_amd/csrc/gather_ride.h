@@ -44,7 +44,8 @@ struct RideIdx {            // stage A of one group: wave-uniform except the ang
   long src[kRideRows];      // table row (x V + view) of each output row, -1 = empty candidate slot
   // the thread's angle item: output row r0 + (tid >> 5), columns IMG + (tid & 31) * 4 ..
   long ang_src;             // panorama row: element offset into the angle table
-  bool ang_empty;           // candidate row of an empty slot: zeros
+  bool ang_empty;           // empty candidate slot, or an out-of-range index: zeros
+  int nbad;                 // out-of-range indices among the group's rows (GatherCheck)
   float theta;              // candidate row: the heading (lanes 0-15 of the half-wave) or the elevation (16-31)
 };
 
@@ -61,21 +62,33 @@ __device__ __forceinline__ void gather_ride_pipelined(const GatherRolloutArgs& r
     g.t = i / groups; g.r0 = (i % groups) * kRideRows;
     const GatherStepArgs& a = ride.step[g.t];
     const int npano = a.B * a.V;
+    const long nr = a.chk.n_rows;
+    g.nbad = 0;
 #pragma unroll
     for (int k = 0; k < kRideRows; ++k) {
       const int r = row_of(g.r0, k);
       const int rp = r < npano ? r : npano - 1, rc = r < npano ? 0 : r - npano;
-      const long prow = a.rows[rp / a.V] * a.V + rp % a.V;
+      const long prow = a.rows[rp / a.V];
+      const int pvi = a.view_index[rp / a.V];
+      const bool pbad = nr && (prow < 0 || prow >= nr || pvi < 0 || pvi >= a.chk.n_aviews);
       const long crow = a.crows[rc];
-      const long cidx = crow < 0 ? -1 : crow * a.V + a.cviews[rc];
-      g.src[k] = r < npano ? prow : cidx;
+      const int cv = a.cviews[rc];
+      const bool cbad = nr && crow >= 0 && (crow >= nr || cv < 0 || cv >= a.V);
+      const long cidx = (crow < 0 || cbad) ? -1 : crow * a.V + cv;
+      g.src[k] = r < npano ? (pbad ? -1 : prow * a.V + rp % a.V) : cidx;
+      g.nbad += (g.r0 + k < nrows && (r < npano ? pbad : cbad)) ? 1 : 0;
     }
     const int r = row_of(g.r0, ka);
     const int rp = r < npano ? r : npano - 1, rc = r < npano ? 0 : r - npano;
-    g.ang_src = ((long)a.view_index[rp / a.V] * a.V + rp % a.V) * ANG + ja * 4;
+    const long prow = a.rows[rp / a.V];
+    const int pvi = a.view_index[rp / a.V];
+    const bool pbad = nr && (prow < 0 || prow >= nr || pvi < 0 || pvi >= a.chk.n_aviews);
+    g.ang_src = pbad ? 0 : ((long)pvi * a.V + rp % a.V) * ANG + ja * 4;
     const float h = a.heading[rc], e = a.elevation[rc];
     g.theta = ja < 16 ? h : e;
-    g.ang_empty = r >= npano && a.crows[rc] < 0;
+    const long crow = a.crows[rc];
+    const int cv = a.cviews[rc];
+    g.ang_empty = r < npano ? pbad : (crow < 0 || (nr && (crow >= nr || cv < 0 || cv >= a.V)));
   };
   auto stage_b = [&](const RideIdx& g, RideRaw<TT> (&raw)[kRideRows], float4& ang) {
     const GatherStepArgs& a = ride.step[g.t];
@@ -128,7 +141,7 @@ __device__ __forceinline__ void gather_ride_pipelined(const GatherRolloutArgs& r
       const bool empty = g.ang_empty;
       const float s = sinf(g.theta), c = cosf(g.theta);
       const float cv = empty ? 0.f : (((ja >> 3) & 1) ? c : s);       // ANG / 4 = 32 columns each of sin h, cos h, sin e, cos e
-      const float4 x = pano ? ang : make_float4(cv, cv, cv, cv);
+      const float4 x = pano ? (empty ? make_float4(0.f, 0.f, 0.f, 0.f) : ang) : make_float4(cv, cv, cv, cv);
       if constexpr (LP) {
         bf16_raw* d = (pano ? a.out_lp : a.cout_lp) + (long)rr * F + IMG + ja * 4;
         uint2 v;
@@ -148,15 +161,18 @@ __device__ __forceinline__ void gather_ride_pipelined(const GatherRolloutArgs& r
   stage_a(first, g0);
   stage_b(g0, raw0, ang0);
   stage_a(first + np, g1);
+  int nbad = 0;
   for (int i = first; i < total; i += np) {
     stage_b(g1, raw1, ang1);
     stage_a(i + 2 * np, g2);
     stage_c(g0, raw0, ang0);
+    nbad += g0.nbad;
     g0 = g1; g1 = g2;
 #pragma unroll
     for (int k = 0; k < kRideRows; ++k) raw0[k] = raw1[k];
     ang0 = ang1;
   }
+  if (nbad && tid == 0) __hip_atomic_fetch_add(ride.step[0].chk.bad, (unsigned)nbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the passenger workgroup `first` of `np`

@@ -65,6 +65,8 @@ struct ProfScope {   // brackets the launches issued in its scope with an event 
 // is the kernel's own begin->end on the device, the figure rocprofv3 --kernel-trace reports, with no
 // launch gap or event-record packet inside the bracket.
 bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
+struct GatherCheck;
+GatherCheck gather_check(const void* table);   // features.hip: the registered extent of a feature table (vln_feature_table_extent)
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout
 int device_cus();                 // encoder.hip: CU count of the current device (queried once), 0 if unknown
 // every launch in the library goes through launch_timed or VLN_LAUNCH

@@ -51,9 +51,16 @@ class IterationGraph:
             self.out = self.fn()
         self.clock.uncount()           # the captured tick did not run: the device words still hold the pre-capture values
         self.graph = g
+        self._check = lib.vln_persistent_check
         return self
 
     def replay(self):
+        # A replay has no host code between its launches: what an EARLIER replay raised on the device (a timed-out bounded
+        # wait, an out-of-range gather index -- host-mapped words, no synchronisation to read them) is reported here, loudly;
+        # that replay's update has already been applied, the caller restores from its last good state.
+        st = self._check()
+        if st:
+            _lib.check(st, "vln_persistent_check (raised by an earlier replay)")
         self.clock.replayed()          # host mirror of the tick launch inside the graph (+ the launch-sequence wrap guard)
         self.graph.replay()
         self.replays += 1

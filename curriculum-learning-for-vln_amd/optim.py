@@ -67,6 +67,7 @@ class _FusedFlat:
         self._reducer = BucketReducer(self.flat_g)
         self.steps = 0
         self._cleared_by_step = False
+        self._started, self._exchanged = [], False      # this iteration's early all-reduce slices / its exchange is complete
 
     def zero_grad(self, set_to_none: bool = False):
         if self._cleared_by_step:          # step(zero_grads=True) cleared the buffer while it read it
@@ -82,9 +83,24 @@ class _FusedFlat:
         final -- e.g. from `EnvDropDecoder.grads_ready_hook`, which fires before the encoder's BPTT starts);
         `allreduce()` later reduces the remaining groups and waits."""
         self._reducer.start(self._begins[group_index], self._begins[group_index + 1], group)
+        self._started.append(group_index)
 
     def allreduce(self, group=None):
         self._reducer.finish(group)
+        self._exchanged = True
+
+    def abandon_iteration(self, early_groups=(), group=None):
+        """Error path of a data-parallel loop: this rank's iteration raised (e.g. VlnError from vln_persistent_check) somewhere
+        between its backward and its update while the OTHER ranks run the iteration to the end.  Issue exactly the collectives a
+        normal iteration issues -- the early slices `early_groups` that were not started yet, then the rest -- so that the
+        ranks' collective sequences stay matched; the reduced numbers are garbage and the caller discards the iteration on
+        every rank (it all-reduces a flag at its next synchronisation point).  A no-op when the exchange had completed."""
+        if not self._exchanged:
+            for gi in early_groups:
+                if gi not in self._started:
+                    self.start_allreduce(gi, group)
+            self._reducer.finish(group)
+        self._started, self._exchanged = [], False
 
     def _launch(self, lib, grad_scale: float) -> int:
         raise NotImplementedError
@@ -117,6 +133,7 @@ class _FusedFlat:
             raise ValueError("grad_scale must be positive")
         st = self._launch(lib, -grad_scale if zero_grads else grad_scale)
         self._cleared_by_step = bool(zero_grads)
+        self._started, self._exchanged = [], False
         if st:
             _lib.check(st, type(self).__name__ + ".step")
         for p in self.params:                       # in-place update outside autograd: tell version-keyed caches

@@ -75,6 +75,40 @@ class DeviceFeatureStore:
         self.angle_table = loc_embedding_table(angle_size, self.V).to(self.device)
         self.seed, self._calls = seed, 0
         self._side_event = None
+        # every gather of this table is range-checked on the device from here on (out-of-range index -> zero row + a sticky
+        # error that the next vln_persistent_check raises); the angle table holds one row block per view index
+        if self.table.is_cuda:
+            _lib.check(_lib.load().vln_feature_table_extent(self.table.data_ptr(), self.N, self.angle_table.shape[0]),
+                       "vln_feature_table_extent")
+
+    def __del__(self):
+        try:
+            if self.table.is_cuda:
+                _lib.load().vln_feature_table_extent(self.table.data_ptr(), 0, 0)       # the address may be reused by another tensor
+        except Exception:
+            pass
+
+    def validate_indices(self, rows=None, view_index=None, cand_rows=None, cand_views=None):
+        """Host-side check of a batch's (or a whole tape's) index tensors when it is REGISTERED -- one synchronising reduction
+        per tensor, not something to call per step (the device kernels check every index they use anyway and zero the row):
+        rows in [0, N), view_index in [0, angle views), cand_rows < N (negative = empty slot), cand_views in [0, V) where the
+        slot is not empty.  Raises ValueError naming the first offending tensor."""
+        def bad(name, t, lo, hi, where=None):
+            if t is None:
+                return
+            t = torch.as_tensor(t)
+            ok = (t >= lo) & (t < hi)
+            if where is not None:
+                ok = ok | ~where
+            if not bool(ok.all()):
+                i = int((~ok).reshape(-1).nonzero()[0])
+                raise ValueError(f"DeviceFeatureStore: {name}[{i}] = {int(t.reshape(-1)[i])} is outside [{lo}, {hi})")
+        bad("rows", rows, 0, self.N)
+        bad("view_index", view_index, 0, int(self.angle_table.shape[0]))
+        if cand_rows is not None:
+            cr = torch.as_tensor(cand_rows)
+            bad("cand_rows", cr, -(1 << 62), self.N)
+            bad("cand_views", cand_views, 0, self.V, where=(cr >= 0) if cand_views is not None else None)
 
     @classmethod
     def from_tsv(cls, path: str, device="cuda", dtype=torch.float32, views: int = 36, **kw):
@@ -184,6 +218,11 @@ class DeviceFeatureStore:
         clock = self.__dict__.get("clock")        # runtime.DeviceClock (whole-iteration graphs)
         for t, (rows, view_index, crows, cviews, heading, elevation) in enumerate(steps):
             B, C = crows.shape
+            if (rows.dtype != torch.int64 or crows.dtype != torch.int64 or view_index.dtype != torch.int32 or cviews.dtype != torch.int32
+                    or heading.dtype != torch.float32 or elevation.dtype != torch.float32):
+                raise TypeError("gather_rollout: rows / cand rows int64, view_index / cand views int32, heading / elevation float32")
+            if rows.shape != (B,) or view_index.shape != (B,) or cviews.shape != (B, C) or heading.shape != (B, C) or elevation.shape != (B, C):
+                raise ValueError("gather_rollout: step %d: index tensors do not share one [B] / [B, C] layout" % t)
             if out is not None:
                 (img, img_lp), (cand, cand_lp) = out[t]
                 ok = lambda x, n, dt: (x is None) == (dt is None) and (x is None or (tuple(x.shape) == (B, n, F) and x.dtype == dt))
@@ -202,10 +241,11 @@ class DeviceFeatureStore:
             else:
                 seed, off1, p = self._drop(p_feat)
                 _, off2, _ = self._drop(p_feat)
+            rw_, vi_ = rows.contiguous(), view_index.contiguous()
             cr, cv, hd, el = crows.contiguous(), cviews.contiguous(), heading.contiguous(), elevation.contiguous()
-            keep += [cr, cv, hd, el]
+            keep += [rw_, vi_, cr, cv, hd, el]
             q = arr[t]
-            q.rows, q.view_index, q.crows, q.cviews, q.heading, q.elevation = _p(rows), _p(view_index), _p(cr), _p(cv), _p(hd), _p(el)
+            q.rows, q.view_index, q.crows, q.cviews, q.heading, q.elevation = _p(rw_), _p(vi_), _p(cr), _p(cv), _p(hd), _p(el)
             q.out, q.out_bf16, q.cout, q.cout_bf16 = _p(img), _p(img_lp), _p(cand), _p(cand_lp)
             q.offset_pano, q.offset_cand = off1, off2
             res.append(((img, img_lp), (cand, cand_lp)))

@@ -8,7 +8,8 @@
  * process-wide, none of it changes results): a thread-local error string; the hipGraph caches of memoised launch chains
  * (vln_set_graphs / vln_graph_stats); the A/B tunables and mode switches (vln_set_tunable, vln_set_persistent); the optional
  * per-kernel timers (vln_prof_*); a per-buffer launch sequence for the recurrence's data-tagged hand-offs; one host-mapped
- * status word per device that a timed-out bounded wait raises (vln_persistent_check).  Tensors are row-major; "ld" = row
+ * status line per device that a timed-out bounded wait or an out-of-range gather index raises (vln_persistent_check); the
+ * registered extents of feature tables (vln_feature_table_extent).  Tensors are row-major; "ld" = row
  * stride in elements.
  *
  * dtype codes: 0 = fp32, 1 = bf16 (raw uint16 bits).  Activations/gradients are fp32; the streamed
@@ -466,6 +467,14 @@ typedef struct vln_gather_ride {
   uint64_t seed; float p_feat; float padf_;
   const uint64_t* offset_base_dev;     /* nullable, see vln_embed_fwd */
 } vln_gather_ride;
+/* Index range checks (ABI v10).  A caller that registers its table's extent -- N viewpoint rows, and the number of view
+ * indices the angle table holds (36) -- gets every gather of that table (all entry points below, the in-step gather of
+ * vln_envdrop_step_fwd, the passengers of vln_lstm_seq_fwd) range-checked on the device: a viewpoint row outside [0, N), a
+ * panorama view index outside [0, n_angle_views) or a candidate view outside [0, V) reads NOTHING (the output row is all
+ * zeros, like an empty candidate slot) and is counted in the device's host-mapped sticky word; the next
+ * vln_persistent_check() -- every later vln_lstm_seq_*, the optimizer step, graphs.IterationGraph.replay -- reports the count
+ * ONCE as VLN_ERR_ARG.  Candidate rows < 0 stay the legitimate empty slot.  n_rows = 0 removes the registration (unchecked). */
+int vln_feature_table_extent(const void* table, int64_t n_rows, int n_angle_views);
 int vln_gather_rollout(const void* table, int ttype, const float* angle_table, const vln_gather_rollout_step* steps, int T, int B, int V,
                        int C, int IMG, int ANG, uint64_t seed, float p_feat, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/,
                        vln_stream_t s);
@@ -511,7 +520,11 @@ int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed,
  * When given (and large enough) and the grid of (Hd/16) x dirs x ceil(B/16) workgroups is co-resident (<= 256) with
  * Hd in {128,256,512}, the whole sequence runs as ONE persistent launch: W_hh slices and cell state stay in registers;
  * forward exchanges hidden slices, backward exchanges partial dh blocks, both with write-through stores + a
- * per-group arrival counter.  Otherwise L launches (hipGraph-memoised).  The forward needs only the header. */
+ * per-group arrival counter.  Otherwise L launches (hipGraph-memoised).  The forward needs only the header.
+ * INITIAL CONTENTS: the caller zero-fills sync_ws once, when it allocates it.  The granule exchange (data-tagged values) reads
+ * stale tags as "not yet written" only if they are older launches' or zero; the arrival counters of the header are zeroed by
+ * the library in front of the first counter-protocol launch on a buffer and whenever another protocol (vln_set_persistent)
+ * or the counter-protocol forward touched it since -- afterwards the backward kernel leaves them zero itself. */
 int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs);
 /* The granule hand-off tags every exchanged value with a per-buffer LAUNCH SEQUENCE.  device_seq < 0: the library counts the
  * launches of a sync_ws on the host (and clears the exchange when the 24-bit count wraps).  device_seq >= 0: the sequence is
@@ -536,6 +549,9 @@ int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = pe
  * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as
  * VLN_ERR_HIP (the affected iteration's numbers are invalid) and switches the process to per-step launches. */
 int vln_persistent_check(void);
+/* Test hook: raise the current device's sticky word from the host as a timed-out wait (word 0) or an out-of-range gather index
+ * (word 1) would -- so that callers' fallback paths can be exercised on a healthy device. */
+int vln_debug_raise_sticky(int word);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered.  dh_init_bm / dc_init_bm (both or neither): the same initial gradients in the
  * caller's [B, dirs*Hd] layout (hcat / ccat, units.py:63-67) -- dh_pass / dc_carry are then scratch only and the caller's two

@@ -173,3 +173,19 @@ def test_other_agents_iteration_graph_equals_eager(vln, kind):
         assert torch.equal(a[0], b[0]), f"iteration {i}: loss {float(a[0])} vs {float(b[0])}"
         for x, y in zip(a[1], b[1]):
             assert torch.equal(x, y), f"iteration {i}: parameters differ"
+
+
+@pytest.mark.parametrize("graph", ["on", "off"])
+def test_bench_falls_back_to_per_step_launches_after_a_timeout(graph):
+    """the sticky timeout raises VlnError from the next library entry, which bench.py did not catch -- the
+    fallback branch was dead.  `--inject-timeout K` raises the sticky word as a timed-out wait would: the run must catch it,
+    switch to per-step launches, warm up again (re-recording the iteration graph) and still print its JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--no-secondary", "--no-roofline",
+                          "--no-cpu-baseline", "--viewpoints", "400", "--iteration-graph", graph, "--inject-timeout", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "timed out" in out.stderr and "using per-step launches" in out.stderr
+    rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ms_per_step"] > 0 and rep["steps"] == 3

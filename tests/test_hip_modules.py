@@ -366,6 +366,55 @@ def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
             check(a, b, 2e-5, n)         # dgates) and the embedding scatter-add uses float atomics
 
 
+def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
+    """the counter-protocol backward leaves its group counters zero itself and skips the fill launch -- which
+    only holds for a header it left behind.  (a) a caller-supplied workspace whose header was never zeroed, (b) a header the
+    counter-protocol FORWARD of another mode wrote: both must get the fill (encoder.hip header_clean), i.e. no timeout and the
+    same gradients as on a clean workspace."""
+    lib = vln._lib.load()
+    B, L, E, H, vocab = 32, 12, 64, 512, 200
+    g = torch.Generator().manual_seed(5)
+    lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    r = torch.randn(B, L, H, generator=g).to(DEV)
+    torch.manual_seed(9)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.0, True, 1).to(DEV).train()
+    enc.deterministic_embedding_grad = True
+
+    def run():
+        enc.zero_grad(set_to_none=True)
+        ctx, h, c = enc(tokens.to(DEV), lens)
+        ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
+        torch.cuda.synchronize()
+        vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+        assert enc.persistent_status() == 0
+        return [p.grad.detach().clone() for p in enc.parameters()]
+
+    ref = run()
+    # (a) a fresh, larger workspace the library has never seen, header full of garbage (granule area zero as documented)
+    need = int(lib.vln_lstm_sync_ws_bytes(B, H // 2, 2))
+    w = torch.zeros((need + 3) // 4 + 64, dtype=torch.int32, device=DEV)
+    w[:2048] = 0x01010101
+    w[32] = 0
+    enc._sync_buf, enc._sync_mode = w, None
+    for a, b in zip(ref, run()):
+        assert torch.equal(a, b)
+    # (b) mode 2 (counter forward + counter backward): a forward WITHOUT its backward leaves counters behind, then mode 1
+    try:
+        lib.vln_set_persistent(2)
+        with torch.no_grad():
+            enc(tokens.to(DEV), lens)
+        torch.cuda.synchronize()
+    finally:
+        lib.vln_set_persistent(1)
+    for a, b in zip(ref, run()):
+        assert torch.equal(a, b)
+    for a, b in zip(ref, run()):                   # and the header it left itself needs no fill
+        assert torch.equal(a, b)
+
+
 def test_training_iteration_side_stream_overlap_is_transparent(vln):
     """bench.GpuAgent.iteration with the deferred weight-gradient GEMMs on a side stream (gradients accumulate into the
     flat bucket views) must give exactly the gradients of the serial configuration; store- and tensor-fed features

@@ -460,3 +460,66 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
             assert (x is None) == (y is None)
             if x is not None:
                 assert torch.equal(x, y)
+
+
+def test_out_of_range_gather_indices_give_zero_rows_and_a_sticky_error(vln):
+    """a bad viewpoint row / view index must not become a silent out-of-bounds read of the 1.5 GB table.  The
+    store registers its extent (vln_feature_table_extent); every gather -- stand-alone, per step, rollout-wide, riding in the
+    recurrence launch -- zeroes the offending output row and raises the device's sticky word, which the next
+    vln_persistent_check() reports once."""
+    dev_ = torch.device(DEV)
+    lib = vln._lib.load()
+    vln._lib.check(lib.vln_persistent_check(), "clean start")
+    g = torch.Generator().manual_seed(3)
+    N, V, IMG, B, C = 40, 36, 2048, 16, 6
+    table = torch.rand(N, V, IMG, generator=g)
+    store = vln.DeviceFeatureStore(table, device=dev_, dtype=torch.float32)
+    rows = torch.randint(0, N, (B,), generator=g).to(dev_)
+    vidx = torch.randint(0, 36, (B,), generator=g, dtype=torch.int32).to(dev_)
+    crows = torch.randint(0, N, (B, C), generator=g).to(dev_)
+    crows[:, -1] = -1                                                   # legitimate empty slots: not an error
+    cviews = torch.randint(0, V, (B, C), generator=g, dtype=torch.int32).to(dev_)
+    head = torch.rand(B, C, generator=g).to(dev_); elev = torch.rand(B, C, generator=g).to(dev_)
+    store.validate_indices(rows, vidx, crows, cviews)
+    (img0, _), (cand0, _), _ = store.gather_step(rows, vidx, crows, cviews, head, elev)
+    torch.cuda.synchronize()
+    vln._lib.check(lib.vln_persistent_check(), "in-range indices")
+    assert float(img0.abs().sum()) > 0 and float(cand0[:, -1].abs().sum()) == 0.0
+
+    bad_rows = rows.clone(); bad_rows[3] = N + 5                        # past the table
+    bad_vidx = vidx.clone(); bad_vidx[5] = 36                           # past the angle table
+    bad_crows = crows.clone(); bad_crows[2, 1] = 10 ** 9
+    bad_cviews = cviews.clone(); bad_cviews[7, 0] = -2
+    with pytest.raises(ValueError, match="rows"):
+        store.validate_indices(bad_rows, vidx, crows, cviews)
+    with pytest.raises(ValueError, match="cand_views"):
+        store.validate_indices(rows, vidx, crows, bad_cviews)
+
+    def expect(img, cand):
+        torch.cuda.synchronize()
+        assert float(img[3].abs().sum()) == 0.0 and float(img[5].abs().sum()) == 0.0
+        assert float(cand[2, 1].abs().sum()) == 0.0 and float(cand[7, 0].abs().sum()) == 0.0
+        keep = torch.ones(B, dtype=torch.bool, device=dev_); keep[3] = keep[5] = False
+        assert torch.equal(img[keep], img0[keep])
+        ck = torch.ones(B, C, dtype=torch.bool, device=dev_); ck[2, 1] = ck[7, 0] = False
+        assert torch.equal(cand[ck], cand0[ck])
+        with pytest.raises(vln.VlnError, match="out of range"):
+            vln._lib.check(lib.vln_persistent_check(), "bad indices")
+        vln._lib.check(lib.vln_persistent_check(), "reported once")
+
+    (img, _), (cand, _), _ = store.gather_step(bad_rows, bad_vidx, bad_crows, bad_cviews, head, elev)
+    expect(img, cand)
+    img, _ = store.gather_pano(bad_rows, bad_vidx)
+    cand, _ = store.gather_cands(bad_crows, bad_cviews, head, elev)
+    expect(img, cand)
+    steps = [(bad_rows, bad_vidx, bad_crows, bad_cviews, head, elev)] * 2
+    out = store.gather_rollout(steps)
+    expect(out[1][0][0], out[1][1][0])
+    # ... and as passengers of the recurrence launch (the pipelined loop: IMG 2048, ANG 128, one output precision)
+    enc = vln.EncoderLSTM(50, 32, 512, 0, 0.0, True, 1).to(dev_).eval()
+    tokens = torch.randint(1, 50, (64, 12), generator=g).to(dev_)
+    lengths = torch.full((64,), 12, dtype=torch.int32, device=dev_)
+    ride = store.rollout_ride(steps)
+    with torch.no_grad():
+        enc(tokens, lengths, ride=ride)
+    expect(ride.outputs[0][0][0], ride.outputs[0][1][0])
