@@ -465,8 +465,12 @@ def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accum
     drop = drop or [(0, 0, 0.0)] * T
     seeds = (C.c_uint64 * T)(*[d[0] for d in drop]); offs = (C.c_uint64 * T)(*[d[1] for d in drop])
     ps = (C.c_float * T)(*[d[2] for d in drop])
+    bases = {d[3] for d in drop if len(d) > 3}            # (seed, offset, p[, device offset base]): one clock for all steps
+    if len(bases) > 1:
+        raise ValueError("attn_dctx_deferred: the steps' dropout offsets must share one device base")
     _lib.check(lib.vln_attn_dctx_deferred_drop(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
-                                               1 if accumulate else 0, C.addressof(seeds), C.addressof(offs), C.addressof(ps), _stream()),
+                                               1 if accumulate else 0, C.addressof(seeds), C.addressof(offs), C.addressof(ps),
+                                               bases.pop() if bases else None, _stream()),
                "vln_attn_dctx_deferred_drop")
     return out
 
