@@ -1014,12 +1014,14 @@ def secondary_agents(dev, args, which, store):
     # with 8 of them the Self-Monitor number read 5.7 ms against 5.05 ms for a second run in the same process
     W.configure(steps=20, warmup=30, dtype=args.dtype, arena=False, device=dev)
     W.vln.functional.set_grad_in_place(True)
+    W.vln.functional.set_rollout_wgrads(which in ("monitor", "follower"))     # parameter gradients once per rollout (functional.RolloutWgrads)
     import gc
     gc.collect()
     gc.freeze()                         # the bench's own objects (agent, tapes, store) out of the cyclic collector's way, as in the timed loop
     try:
         r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else (W.run_follower() if which == "follower" else W.run_monitor())
     finally:
+        W.vln.functional.set_rollout_wgrads(False)
         W.vln.functional.set_grad_in_place(False)
         gc.unfreeze()
     return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"]}

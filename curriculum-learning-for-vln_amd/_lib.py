@@ -87,6 +87,14 @@ class ColsumJob(C.Structure):
     _fields_ = [("A", ptr), ("out1", ptr), ("out2", ptr), ("lda", i64), ("cols", i32), ("accumulate", i32)]
 
 
+PARAM_JOBS_MAX = 8                    # VLN_PARAM_JOBS_MAX
+
+
+class ParamJobs(C.Structure):
+    _fields_ = [("w", WgradJob * PARAM_JOBS_MAX), ("c", ColsumJob * PARAM_JOBS_MAX), ("nw", i32), ("nc", i32), ("rows", i32),
+                ("precision", i32)]
+
+
 class EnvDropGrads(C.Structure):
     _fields_ = [(n, ptr) for n in ("dlogit", "dh1", "dc1", "dh_tilde", "dh_tilde_prev", "dc0", "dctx", "s_dtc",
                                    "s_dz", "s_dtt", "s_dgates", "s_dtv", "s_de", "s_dl", "s_dtcat", "dhtd_ext")]
@@ -113,7 +121,7 @@ class MonitorGrads(C.Structure):
     _fields_ = ([(n, ptr) for n in ("dlogit", "dprog", "dh1", "dc1", "dww_ext", "dmw_ext", "dprev_rep", "dcand_rep", "dh0", "dc0", "dctx")]
                 + [("dctx_accumulate", i32)]
                 + [(n, ptr) for n in ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")]
-                + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
+                + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))])
 
 
 class FollowerDims(C.Structure):
@@ -137,7 +145,7 @@ class FollowerGrads(C.Structure):
                 + [("dctx_accumulate", i32)]
                 + [(n, ptr) for n in ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact",
                                       "g_whid", "g_bhid", "g_wout", "g_bout")]
-                + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64)])
+                + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))])
 
 
 BN_MLP_MAX_LAYERS = 4                 # VLN_BN_MLP_MAX_LAYERS
@@ -163,7 +171,7 @@ class BnMlpGradLayer(C.Structure):
 
 class BnMlpGrads(C.Structure):
     _fields_ = [("g_gamma0", ptr), ("g_beta0", ptr), ("acc0", i32), ("pad0_", i32), ("layer", BnMlpGradLayer * BN_MLP_MAX_LAYERS),
-                ("precision", i32), ("pad_", i32), ("scratch", ptr), ("scratch_floats", i64)]
+                ("precision", i32), ("pad_", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))]
 
 
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
@@ -229,6 +237,9 @@ SIGNATURES = {
     "vln_bn_mlp_bwd": (i32, [C.POINTER(BnMlp), ptr, i64, ptr, ptr, i64, ptr, i64, C.POINTER(BnMlpGrads), ptr, i64, ptr]),
     "vln_a2c_loss_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, ptr, ptr, ptr, ptr, ptr, ptr]),
     "vln_a2c_loss_bwd": (i32, [ptr, i64, ptr, ptr, ptr, i32, i32, ptr, ptr, ptr, ptr]),
+    "vln_wgrad_grouped_seg": (i32, [C.POINTER(WgradJob), C.POINTER(i64), C.POINTER(i64), i32, i32, i32, i32, ptr, i64, ptr]),
+    "vln_colsum_grouped_seg": (i32, [C.POINTER(ColsumJob), C.POINTER(i64), i32, i32, i32, ptr, i64, ptr]),
+    "vln_wgrad_grouped_ws_floats": (i64, [C.POINTER(WgradJob), i32, i32]),
     "vln_feature_table_extent": (i32, [ptr, i64, i32]),
     "vln_debug_raise_sticky": (i32, [i32]),
     "vln_gather_rollout": (i32, [ptr, i32, ptr, C.POINTER(GatherRolloutStep), i32, i32, i32, i32, i32, i32, u64, f32, ptr, ptr]),
@@ -266,7 +277,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 10
+EXPECTED_ABI = 11
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()

@@ -116,7 +116,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 10; }
+extern "C" int vln_abi_version(void) { return 11; }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,
@@ -142,6 +142,23 @@ extern "C" int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, 
   if (!jobs || n_jobs <= 0) { set_error("vln_wgrad_grouped: bad args"); return VLN_ERR_ARG; }
   if (precision < 0 || precision > 2) { set_error("vln_wgrad_grouped: precision must be 0 (fp32), 1 (split bf16) or 2 (plain bf16)"); return VLN_ERR_ARG; }
   return wgrad_grouped((hipStream_t)s, jobs, n_jobs, Mt, precision, ws, ws_floats);
+}
+extern "C" int vln_wgrad_grouped_seg(const vln_wgrad_job* jobs, const int64_t* dy_seg_stride, const int64_t* x_seg_stride, int n_jobs,
+                                     int seg_rows, int n_seg, int precision, float* ws, int64_t ws_floats, vln_stream_t s) {
+  if (!jobs || n_jobs <= 0) { set_error("vln_wgrad_grouped_seg: bad args"); return VLN_ERR_ARG; }
+  if (precision < 0 || precision > 2) { set_error("vln_wgrad_grouped_seg: precision must be 0 (fp32), 1 (split bf16) or 2 (plain bf16)"); return VLN_ERR_ARG; }
+  return wgrad_grouped_seg((hipStream_t)s, jobs, n_jobs, seg_rows, n_seg, dy_seg_stride, x_seg_stride, precision, ws, ws_floats);
+}
+extern "C" int vln_colsum_grouped_seg(const vln_colsum_job* jobs, const int64_t* seg_stride, int n_jobs, int seg_rows, int n_seg,
+                                      float* ws, int64_t ws_floats, vln_stream_t s) {
+  if (!jobs || !seg_stride || n_jobs <= 0 || seg_rows <= 0 || n_seg <= 0) { set_error("vln_colsum_grouped_seg: bad args"); return VLN_ERR_ARG; }
+  for (int i = 0; i < n_jobs; ++i)
+    if (seg_stride[i] & 3) { set_error("vln_colsum_grouped_seg: segment strides must be multiples of 4 floats"); return VLN_ERR_ARG; }
+  return colsum_grouped((hipStream_t)s, jobs, n_jobs, seg_rows * n_seg, ws, ws_floats, seg_rows, seg_stride);
+}
+extern "C" int64_t vln_wgrad_grouped_ws_floats(const vln_wgrad_job* jobs, int n_jobs, int Mt) {
+  if (!jobs || n_jobs <= 0 || Mt <= 0) return -1;
+  return wgrad_grouped_ws_floats(jobs, n_jobs, Mt);
 }
 extern "C" int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                           int64_t ws_floats, vln_stream_t s) {

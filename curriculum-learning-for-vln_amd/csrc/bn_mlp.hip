@@ -144,8 +144,14 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     gcur = gi; ldg = in;
   }
   // Mt is the same for every product of the call: one grouped launch each for weights and biases
-  if (nw) RUN(wgrad_grouped(st, wj, nw, R, g->precision, ws, ws_floats));
-  if (nc) RUN(colsum_grouped(st, cj, nc, R, ws, ws_floats));
+  if (g->defer) {        // the caller forms them once per rollout (vln_param_jobs)
+    for (int i = 0; i < nw; ++i) g->defer->w[i] = wj[i];
+    for (int i = 0; i < nc; ++i) g->defer->c[i] = cj[i];
+    g->defer->nw = nw; g->defer->nc = nc; g->defer->rows = R; g->defer->precision = g->precision;
+  } else {
+    if (nw) RUN(wgrad_grouped(st, wj, nw, R, g->precision, ws, ws_floats));
+    if (nc) RUN(colsum_grouped(st, cj, nc, R, ws, ws_floats));
+  }
   const float* s0 = saved + L.s0;
   RUN(vln_bn_bwd(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
                  g->g_gamma0, g->g_beta0, R, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0.f, nullptr, ws, ws_floats, s));

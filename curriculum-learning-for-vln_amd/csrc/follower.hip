@@ -146,7 +146,7 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     auto add = [&](const float* dy, long ldy, const float* x, long ldx, float* dw, long ldw, int N, int K, int acc) {
       if (dw) jobs[n++] = vln_wgrad_job{dy, x, dw, ldy, ldx, ldw, N, K, acc, 0};
     };
-    add(dtq, D, io->h0, H, g->g_wh, H, D, H, g->acc[0]);
+    add(dtq, D, io->xcat + A + F, XK, g->g_wh, H, D, H, g->acc[0]);      // X = h0, from its copy inside xcat (see vln_param_jobs)
     add(io->tq, D, rv, F, g->g_wv, F, D, F, g->acc[2]);
     add(dg, 4 * H, io->xcat, XK, g->g_ih, A + F, 4 * H, A + F, g->acc[4]);
     add(dg, 4 * H, io->xcat + A + F, XK, g->g_hh, H, 4 * H, H, g->acc[5]);
@@ -154,7 +154,8 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     add(dz, H, io->tcat, 2 * H, g->g_tout, 2 * H, H, 2 * H, g->acc[9]);
     add(io->q, D, rc, A, g->g_wact, A, D, A, g->acc[10]);
     add(dtarget, D, io->grounded, H, g->g_whid, H, D, H, g->acc[12]);
-    if (n) RUN(wgrad_grouped(st, jobs, n, B, g->precision, io->ws, io->ws_floats));
+    if (g->defer) { for (int i = 0; i < n; ++i) g->defer->w[i] = jobs[i]; g->defer->nw = n; g->defer->rows = B; g->defer->precision = g->precision; }
+    else if (n) RUN(wgrad_grouped(st, jobs, n, B, g->precision, io->ws, io->ws_floats));
   }
   {
     vln_colsum_job jobs[8];
@@ -169,7 +170,8 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     add(Zo, D, g->g_wout, nullptr, D, g->acc[14]);
     if (g->g_bih && g->g_bhh && g->acc[6] == g->acc[7]) add(dg, 4 * H, g->g_bih, g->g_bhh, 4 * H, g->acc[6]);
     else { add(dg, 4 * H, g->g_bih, nullptr, 4 * H, g->acc[6]); add(dg, 4 * H, g->g_bhh, nullptr, 4 * H, g->acc[7]); }
-    if (n) RUN(colsum_grouped(st, jobs, n, B, io->ws, io->ws_floats));
+    if (g->defer) { for (int i = 0; i < n; ++i) g->defer->c[i] = jobs[i]; g->defer->nc = n; }
+    else if (n) RUN(colsum_grouped(st, jobs, n, B, io->ws, io->ws_floats));
     if (g->g_bout) RUN(colsum(st, sl, 1, g->g_bout, B, 1, g->acc[15], io->ws, io->ws_floats));
   }
   return VLN_OK;

@@ -492,12 +492,16 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
 //           registers the MFMA reads -- no LDS, no barrier, no conversion; waves run independently with the next
 //           step's 16 loads in flight behind the current step's 48 MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-struct PackJob { const float* src; long ld; int C; long dst; };       // dst: byte offset of the hi plane in the pack area
+struct PackJob { const float* src; long ld; int C; long dst; long seg_stride; };       // dst: byte offset of the hi plane in the pack area
+// SEGMENTED rows (rollout-level weight gradients of per-step C calls): row m of an operand lives at
+// src + (m / seg_rows) * seg_stride + (m % seg_rows) * ld -- step t's [seg_rows, C] block sits seg_stride floats after step
+// t-1's (the steps' saved-activation / scratch blocks are slots of one arena).  seg_rows == 0: plain rows, m * ld.
 struct PackJobs {
   PackJob j[2 * VLN_WGRAD_MAX_JOBS];
   int blk0[2 * VLN_WGRAD_MAX_JOBS + 1];
   unsigned char* area; int n, Mt, MS;
   int lo;                 // 1: hi + lo planes (split-bf16 contraction); 0: hi plane only (plain bf16 operands)
+  int seg_rows;
 };
 __device__ __forceinline__ long pack_plane_bytes(int C, int MS) { return (long)((C + 15) / 16) * MS * 1024; }
 __global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
@@ -518,7 +522,9 @@ __global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = ms * 32 + mq * 8 + i;
-    const float4 v = *reinterpret_cast<const float4*>(pc + (long)min(m, a.Mt - 1) * q.ld);
+    const int mc = min(m, a.Mt - 1);
+    const long roff = a.seg_rows ? (long)(mc / a.seg_rows) * q.seg_stride + (long)(mc % a.seg_rows) * q.ld : (long)mc * q.ld;
+    const float4 v = *reinterpret_cast<const float4*>(pc + roff);
     const bool ok = col_ok && m < a.Mt;
     r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
@@ -663,22 +669,23 @@ static long wgrad_packed_ws_floats(const vln_wgrad_job* jobs, int n, int Mt, int
   return area / 4 + (msplit > 1 ? (long)msplit * elems : 0);
 }
 
-static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms) {
+static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms,
+                                int seg_rows = 0, const int64_t* dy_seg = nullptr, const int64_t* x_seg = nullptr) {
   const int MS = (Mt + 31) / 32;
   int msplit = 1; long area_floats = 0;
   const long need = wgrad_packed_ws_floats(jobs, n, Mt, &msplit, &area_floats);
   if (need > ws_floats || !aligned16(ws)) return -1;                 // caller falls back to the LDS-staged kernel
   PackJobs pk; PackedJobs g;
-  pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0; pk.lo = terms == 3 ? 1 : 0;
+  pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0; pk.lo = terms == 3 ? 1 : 0; pk.seg_rows = seg_rows;
   g.area = pk.area; g.ws = ws + area_floats; g.Mt = Mt; g.MS = MS; g.n = n;
   long off = 0; int blk = 0, t = 0; long slab = 0;
   double bytes = 0.0;
   const int rblocks = (MS + 1) / 2;
-  auto add_pack = [&](const float* src, long ld, int C) -> long {
+  auto add_pack = [&](const float* src, long ld, int C, long seg) -> long {
     for (int i = 0; i < pk.n; ++i)                                    // an operand shared by two products is packed once
-      if (pk.j[i].src == src && pk.j[i].ld == ld && pk.j[i].C == C) return pk.j[i].dst;
+      if (pk.j[i].src == src && pk.j[i].ld == ld && pk.j[i].C == C && pk.j[i].seg_stride == seg) return pk.j[i].dst;
     PackJob& q = pk.j[pk.n];
-    q.src = src; q.ld = ld; q.C = C; q.dst = off;
+    q.src = src; q.ld = ld; q.C = C; q.dst = off; q.seg_stride = seg;
     pk.blk0[pk.n] = blk;
     blk += ((C + 127) / 128) * rblocks;
     off += 2L * ((C + 15) / 16) * MS * 1024;
@@ -687,8 +694,8 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
   };
   for (int i = 0; i < n; ++i) {
     g.j[i] = jobs[i];
-    g.pa[i] = add_pack(jobs[i].dy, jobs[i].ld_dy, jobs[i].N);
-    g.px[i] = add_pack(jobs[i].x, jobs[i].ld_x, jobs[i].K);
+    g.pa[i] = add_pack(jobs[i].dy, jobs[i].ld_dy, jobs[i].N, dy_seg ? (long)dy_seg[i] : 0);
+    g.px[i] = add_pack(jobs[i].x, jobs[i].ld_x, jobs[i].K, x_seg ? (long)x_seg[i] : 0);
     g.tile0[i] = t;
     t += ((jobs[i].N + 127) / 128) * ((jobs[i].K + 127) / 128);
     g.slab0[i] = slab; slab += (long)msplit * jobs[i].N * jobs[i].K;
@@ -713,6 +720,38 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
   }
   return (int)check_hip(hipGetLastError(), "wgrad_grouped_packed");
 }
+
+// Rollout-level form for per-step C calls: every operand is n_seg blocks of [seg_rows, C], block t at base + t * stride.  One
+// pack + one contraction over Mt = n_seg * seg_rows rows when the packed kernel takes the operands; otherwise one grouped call
+// per segment, accumulating.
+int wgrad_grouped_seg(hipStream_t st, const vln_wgrad_job* jobs, int n, int seg_rows, int n_seg, const int64_t* dy_seg,
+                      const int64_t* x_seg, int precision, float* ws, long ws_floats) {
+  if (n <= 0 || n > VLN_WGRAD_MAX_JOBS || seg_rows <= 0 || n_seg <= 0 || !dy_seg || !x_seg) { set_error("wgrad_grouped_seg: bad args"); return VLN_ERR_ARG; }
+  if (n_seg == 1) return wgrad_grouped(st, jobs, n, seg_rows, precision, ws, ws_floats);
+  bool ok = precision != 0 && g_tunable[6] != 1 && g_tunable[6] != 2;
+  for (int i = 0; i < n && ok; ++i) {
+    const vln_wgrad_job& q = jobs[i];
+    ok = q.dy && q.x && q.dw && aligned16(q.dy) && aligned16(q.x) && (q.ld_dy % 4 == 0) && (q.ld_x % 4 == 0) && (q.N % 4 == 0) &&
+         (q.K % 4 == 0) && (dy_seg[i] % 4 == 0) && (x_seg[i] % 4 == 0);
+  }
+  if (ok) {
+    const int r = wgrad_grouped_packed(st, jobs, n, seg_rows * n_seg, ws, ws_floats, precision == 2 ? 1 : 3, seg_rows, dy_seg, x_seg);
+    if (r >= 0) return r;
+  }
+  vln_wgrad_job seg[VLN_WGRAD_MAX_JOBS];
+  for (int t = 0; t < n_seg; ++t) {
+    for (int i = 0; i < n; ++i) {
+      seg[i] = jobs[i];
+      seg[i].dy = jobs[i].dy + (long)t * dy_seg[i];
+      seg[i].x = jobs[i].x + (long)t * x_seg[i];
+      if (t) seg[i].accumulate = 1;
+    }
+    const int r = wgrad_grouped(st, seg, n, seg_rows, precision, ws, ws_floats);
+    if (r != VLN_OK) return r;
+  }
+  return VLN_OK;
+}
+int64_t wgrad_grouped_ws_floats(const vln_wgrad_job* jobs, int n, int Mt) { return wgrad_packed_ws_floats(jobs, n, Mt, nullptr, nullptr); }
 
 int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats) {
   if (n <= 0 || Mt <= 0) { set_error("wgrad_grouped: bad args"); return VLN_ERR_ARG; }
@@ -894,6 +933,7 @@ struct ColsumJobs {
   int blk0[VLN_COLSUM_MAX_JOBS + 1];
   int col0[VLN_COLSUM_MAX_JOBS + 1];      // first column of the job in the partial buffer
   float* ws; int n, rows, rsplit, rchunk, total_cols;
+  int seg_rows; long seg_stride[VLN_COLSUM_MAX_JOBS];      // segmented rows as in PackJobs (seg_rows == 0: plain)
 };
 __global__ __launch_bounds__(256) void colsum_grouped_kernel(ColsumJobs a) {
   __shared__ float4 part[64][4];
@@ -907,15 +947,17 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(ColsumJobs a) {
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
   if (c < q.cols) {                                   // cols % 4 == 0
     const float* p = q.A + c;
+    const long sst = a.seg_stride[ji];
+    auto roff = [&](int r) { return a.seg_rows ? (long)(r / a.seg_rows) * sst + (long)(r % a.seg_rows) * q.lda : (long)r * q.lda; };
     int r = rbeg + rl;
     for (; r + 64 < rend; r += 128) {
-      const float4 x = *reinterpret_cast<const float4*>(p + (long)r * q.lda);
-      const float4 y = *reinterpret_cast<const float4*>(p + (long)(r + 64) * q.lda);
+      const float4 x = *reinterpret_cast<const float4*>(p + roff(r));
+      const float4 y = *reinterpret_cast<const float4*>(p + roff(r + 64));
       s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
       s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
     }
     if (r < rend) {
-      const float4 x = *reinterpret_cast<const float4*>(p + (long)r * q.lda);
+      const float4 x = *reinterpret_cast<const float4*>(p + roff(r));
       s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
     }
   }
@@ -947,10 +989,12 @@ __global__ __launch_bounds__(256) void colsum_grouped_finish_kernel(ColsumJobs a
     if (q.out2) q.out2[cc] = q.accumulate ? q.out2[cc] + t : t;
   }
 }
-int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats) {
+int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows,
+                   const int64_t* seg_stride) {
   if (n <= 0 || n > VLN_COLSUM_MAX_JOBS || rows <= 0) { set_error("colsum_grouped: bad args (n = %d)", n); return VLN_ERR_ARG; }
   ColsumJobs a;
-  a.n = n; a.rows = rows; a.ws = ws;
+  a.n = n; a.rows = rows; a.ws = ws; a.seg_rows = seg_stride ? seg_rows : 0;
+  for (int i = 0; i < n; ++i) a.seg_stride[i] = seg_stride ? (long)seg_stride[i] : 0;
   int blk = 0, col = 0;
   for (int i = 0; i < n; ++i) {
     const vln_colsum_job& q = jobs[i];

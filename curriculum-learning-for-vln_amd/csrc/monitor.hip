@@ -199,21 +199,23 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   }
   // parameter gradients: six products over the same B rows -> one grouped launch; biases and the head -> another
   {
-    vln_wgrad_job jobs[6];
+    vln_wgrad_job jobs[VLN_PARAM_JOBS_MAX];
     int n = 0;
     auto add = [&](const float* dy, long ldy, const float* x, long ldx, float* dw, long ldw, int N, int K, int acc) {
       if (dw) jobs[n++] = vln_wgrad_job{dy, x, dw, ldy, ldx, ldw, N, K, acc, 0};
     };
-    add(dtq, H, io->h0, H, g->g_tin, H, H, H, g->acc[0]);
-    add(dvq, M, io->h0, H, g->g_vh, H, M, H, g->acc[1]);
+    // X = h0: read from its copy inside xcat (a slot of the step's saved block, so the rollout-level form finds every step's)
+    add(dtq, H, io->xcat + 2 * M + H, XK, g->g_tin, H, H, H, g->acc[0]);
+    add(dvq, M, io->xcat + 2 * M + H, XK, g->g_vh, H, M, H, g->acc[1]);
     add(dg, 4 * H, io->xcat, XK, g->g_ih, 2 * M + H, 4 * H, 2 * M + H, g->acc[3]);
     add(dg, 4 * H, io->xcat + 2 * M + H, XK, g->g_hh, H, 4 * H, H, g->acc[4]);
     add(daq, M, io->tcat, 2 * H, g->g_a, 2 * H, M, 2 * H, g->acc[7]);
     add(dmg, H, io->hm, H + M, g->g_m, H + M, H, H + M, g->acc[9]);
-    if (n) RUN(wgrad_grouped(st, jobs, n, B, g->precision, io->ws, io->ws_floats));
+    if (g->defer) { for (int i = 0; i < n; ++i) g->defer->w[i] = jobs[i]; g->defer->nw = n; g->defer->rows = B; g->defer->precision = g->precision; }
+    else if (n) RUN(wgrad_grouped(st, jobs, n, B, g->precision, io->ws, io->ws_floats));
   }
   {
-    vln_colsum_job jobs[6];
+    vln_colsum_job jobs[VLN_PARAM_JOBS_MAX];
     int n = 0;
     auto add = [&](const float* A, long lda, float* o1, float* o2, int cols, int acc) {
       if (o1) jobs[n++] = vln_colsum_job{A, o1, o2, lda, cols, acc};
@@ -224,7 +226,8 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     add(Z, L + H, g->g_wc, nullptr, L + H, g->acc[11]);
     if (g->g_bih && g->g_bhh && g->acc[5] == g->acc[6]) add(dg, 4 * H, g->g_bih, g->g_bhh, 4 * H, g->acc[5]);
     else { add(dg, 4 * H, g->g_bih, nullptr, 4 * H, g->acc[5]); add(dg, 4 * H, g->g_bhh, nullptr, 4 * H, g->acc[6]); }
-    if (n) RUN(colsum_grouped(st, jobs, n, B, io->ws, io->ws_floats));
+    if (g->defer) { for (int i = 0; i < n; ++i) g->defer->c[i] = jobs[i]; g->defer->nc = n; }
+    else if (n) RUN(colsum_grouped(st, jobs, n, B, io->ws, io->ws_floats));
     if (g->g_bc) RUN(colsum(st, dpre, 1, g->g_bc, B, 1, g->acc[12], io->ws, io->ws_floats));
   }
   return VLN_OK;

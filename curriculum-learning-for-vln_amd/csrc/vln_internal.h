@@ -110,13 +110,17 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
 
 // every job's dW[N,K] (+)= dy[Mt,N]^T x[Mt,K] in one launch (precision 1) or one launch each (precision 0)
 int wgrad_grouped(hipStream_t st, const ::vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats);
+int wgrad_grouped_seg(hipStream_t st, const ::vln_wgrad_job* jobs, int n, int seg_rows, int n_seg, const int64_t* dy_seg,
+                      const int64_t* x_seg, int precision, float* ws, long ws_floats);
+int64_t wgrad_grouped_ws_floats(const ::vln_wgrad_job* jobs, int n, int Mt);
 
 // out[c] (+)= sum_r A[r*lda + c]
 int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int cols, int accumulate, float* ws,
            long ws_floats);
 
 // every bias gradient of a module in one launch (two when the rows are split)
-int colsum_grouped(hipStream_t st, const ::vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats);
+int colsum_grouped(hipStream_t st, const ::vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows = 0,
+                   const int64_t* seg_stride = nullptr);
 
 // out = act(sum_s slabs[s] + bias); optional second output out2 = out * dropout mask
 int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_stride, long lds, float* out,

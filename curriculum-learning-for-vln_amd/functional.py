@@ -3,6 +3,7 @@ their own).  Each Function's forward/backward is a handful of HIP launches; weig
 bf16 copies) are cached per parameter version."""
 from __future__ import annotations
 
+import ctypes as C
 import weakref
 from typing import Optional
 
@@ -53,6 +54,131 @@ def set_grad_in_place(on: bool):
     Same numbers in `p.grad` after `backward()`; NOT for `torch.autograd.grad(...)` callers (they would see None), hence
     opt-in.  Parameters whose `.grad` is None (first backward after `zero_grad(set_to_none=True)`) take the normal route."""
     _GRAD_IN_PLACE[0] = bool(on)
+
+
+class RolloutWgrads:
+    """Parameter gradients of the per-step C calls (MonitorStepFn, FollowerStepFn, BnMlpFn) formed ONCE PER ROLLOUT.
+
+    A per-step call that adds into `p.grad` reads and rewrites every weight gradient of its module at every decoder step: 22
+    pack + 22 contraction + 22 bias launches per Self-Monitor iteration (0.7 ms of 5.05).  With this on (and
+    `set_grad_in_place(True)`, every `p.grad` present) a step's backward skips those launches and records the jobs it would
+    have run (`vln_param_jobs`); the operands stay where they are -- the step's saved-activation block and its backward
+    scratch are SLOTS of two arenas owned by this object, so operand i of steps 0..T-1 is one segmented matrix -- and when
+    autograd's backward pass ends (`queue_callback`) every group of steps is contracted in one `vln_wgrad_grouped_seg` + one
+    `vln_colsum_grouped_seg`.  Same gradients up to the summation order over steps (tests/test_hip_agents.py).
+
+    Lifetime: a slot is reused by the same step index of the NEXT rollout; BnMlpFn's output aliases its slot, like every module
+    output under ops.RolloutArena it must be consumed within the iteration.  A group = (kind, rows, first weight)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.groups = {}
+        self._queued = False
+        self.stats = [0, 0]          # [steps deferred, segmented launches issued]
+
+    class _Group:
+        __slots__ = ("fwd", "fwd_n", "bwd", "bwd_n", "nf", "pending")
+
+        def __init__(self):
+            self.fwd = self.bwd = None
+            self.fwd_n = self.bwd_n = 0
+            self.nf, self.pending = 0, []
+
+    def active(self, ctx):
+        # (inside Function.forward grad mode is off: whether a backward can follow is what needs_input_grad says)
+        return self.enabled and _GRAD_IN_PLACE[0] and any(ctx.needs_input_grad)
+
+    def reset(self):
+        """Forget half-finished rollouts (forwards whose backward never ran)."""
+        for g in self.groups.values():
+            g.nf, g.pending = 0, []
+        self._queued = False
+
+    @staticmethod
+    def _slot(buf, n, slot, floats, dev):
+        floats = (floats + 63) & ~63
+        if buf is None or n != floats or buf.shape[0] <= slot or buf.device != dev:
+            cap = 8
+            while cap <= slot:
+                cap *= 2
+            buf, n = torch.empty(cap, floats, dtype=torch.float32, device=dev), floats     # the old arena lives on in its steps' ctx
+        return buf, n, buf[slot]
+
+    def saved(self, key, floats, dev):
+        """forward: (this step's saved-activation block, its slot)."""
+        g = self.groups.get(key)
+        if g is None:
+            g = self.groups[key] = RolloutWgrads._Group()
+        slot = g.nf
+        if slot >= 4096:
+            raise _lib.VlnError("RolloutWgrads: 4096 forward steps without a backward pass; call functional.ROLLOUT_WGRADS.reset()")
+        g.nf += 1
+        g.fwd, g.fwd_n, t = self._slot(g.fwd, g.fwd_n, slot, floats, dev)
+        return t, slot
+
+    def scratch(self, key, slot, floats, dev):
+        g = self.groups[key]
+        g.bwd, g.bwd_n, t = self._slot(g.bwd, g.bwd_n, slot, floats, dev)
+        return t
+
+    def defer(self, key, slot, jobs, keep):
+        self.groups[key].pending.append((slot, jobs, keep))
+        self.stats[0] += 1
+        if not self._queued:
+            self._queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        """Issue the deferred gradients of every group (runs at the end of the backward pass; callable by hand)."""
+        self._queued = False
+        lib = _lib.load()
+        st = _lib.raw_stream()
+        for g in self.groups.values():
+            pend, g.pending, g.nf = sorted(g.pending, key=lambda t: t[0]), [], 0
+            i = 0
+            while i < len(pend):
+                base = pend[i][1]
+                nw, nc = base.nw, base.nc
+                ptrs = lambda pj: ([pj.w[k].dy or 0 for k in range(nw)], [pj.w[k].x or 0 for k in range(nw)], [pj.c[k].A or 0 for k in range(nc)])
+                p0 = ptrs(base)
+                # the longest run of consecutive slots whose operands all sit at one constant distance
+                j, stride = i + 1, None
+                while j < len(pend) and pend[j][0] == pend[j - 1][0] + 1 and pend[j][1].nw == nw and pend[j][1].nc == nc:
+                    a, b = ptrs(pend[j - 1][1]), ptrs(pend[j][1])
+                    d = tuple(tuple(y - x for x, y in zip(u, v)) for u, v in zip(a, b))
+                    if any(v % 16 for u in d for v in u) or (stride is not None and d != stride):
+                        break
+                    stride = d
+                    j += 1
+                n_seg = j - i
+                if stride is None:
+                    stride = tuple(tuple(0 for _ in u) for u in p0)
+                dev = pend[i][2][0].device
+                if nw:
+                    dy_s = (_lib.i64 * nw)(*[v // 4 for v in stride[0]]); x_s = (_lib.i64 * nw)(*[v // 4 for v in stride[1]])
+                    need = max(int(lib.vln_wgrad_grouped_ws_floats(base.w, nw, base.rows * n_seg)), 1 << 22)
+                    ws = ops.workspace(dev, need)
+                    _lib.check(lib.vln_wgrad_grouped_seg(base.w, dy_s, x_s, nw, base.rows, n_seg, base.precision, ws.data_ptr(), ws.numel(), st),
+                               "vln_wgrad_grouped_seg")
+                if nc:
+                    c_s = (_lib.i64 * nc)(*[v // 4 for v in stride[2]])
+                    ws = ops.workspace(dev, 1 << 22)
+                    _lib.check(lib.vln_colsum_grouped_seg(base.c, c_s, nc, base.rows, n_seg, ws.data_ptr(), ws.numel(), st),
+                               "vln_colsum_grouped_seg")
+                self.stats[1] += 1
+                i = j
+
+
+ROLLOUT_WGRADS = RolloutWgrads()
+
+
+def set_rollout_wgrads(on: bool):
+    """Per-step C calls (Self-Monitor step, Follower step, BN-MLP) form their parameter gradients once per rollout instead
+    of once per decoder step (RolloutWgrads).  Needs `set_grad_in_place(True)`; steps whose gradients are returned to autograd
+    keep the per-step launches."""
+    ROLLOUT_WGRADS.enabled = bool(on)
+    if not on:
+        ROLLOUT_WGRADS.reset()
 
 
 def _bn_ws(R, D, dev):
@@ -387,7 +513,13 @@ class BnMlpFn(torch.autograd.Function):
         lib = _lib.load()
         m, keep = BnMlpFn._c_desc(x, rz, cfg, bufs, tensors)
         dev = x.device
-        saved = ops.empty(lib.vln_bn_mlp_saved_floats(m), dtype=torch.float32, device=dev)
+        ctx.rw = None
+        if ROLLOUT_WGRADS.active(ctx) and cfg[0]:
+            key = ("bn_mlp", x.shape[0], id(tensors[2]))
+            saved, slot = ROLLOUT_WGRADS.saved(key, lib.vln_bn_mlp_saved_floats(m), dev)
+            ctx.rw = (key, slot)
+        else:
+            saved = ops.empty(lib.vln_bn_mlp_saved_floats(m), dtype=torch.float32, device=dev)
         ws = ops.workspace(dev, lib.vln_bn_mlp_ws_floats(m))
         rc = lib.vln_bn_mlp_fwd(m, x.data_ptr(), x.stride(0), saved.data_ptr(), ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if rc:
@@ -434,7 +566,14 @@ class BnMlpFn(torch.autograd.Function):
             gl.g_gamma, gl.g_beta, gl.acc_bn = tg.data_ptr(), tb.data_ptr(), int(ag)
             keepg += [tg, tb]
         g.precision = ops.wgrad_precision(dtype != torch.float32)
-        scratch = ops.empty(lib.vln_bn_mlp_bwd_scratch_floats(m), dtype=torch.float32, device=dev)
+        pj = None
+        in_place = all(g.layer[i].acc_w and (tensors[3 + 4 * i] is None or g.layer[i].acc_b) for i in range(ctx.nl))
+        if ctx.rw is not None and ROLLOUT_WGRADS.enabled and in_place:
+            scratch = ROLLOUT_WGRADS.scratch(ctx.rw[0], ctx.rw[1], lib.vln_bn_mlp_bwd_scratch_floats(m), dev)
+            pj = _lib.ParamJobs()
+            g.defer = C.pointer(pj)
+        else:
+            scratch = ops.empty(lib.vln_bn_mlp_bwd_scratch_floats(m), dtype=torch.float32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), scratch.numel()
         dx = ops.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         ws = ops.workspace(dev, lib.vln_bn_mlp_ws_floats(m))
@@ -442,6 +581,8 @@ class BnMlpFn(torch.autograd.Function):
                                 0 if dx is None else dx.stride(0), g, ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if rc:
             _lib.check(rc, "vln_bn_mlp_bwd")
+        if pj is not None:
+            ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (saved, scratch, keep, keepg))
         return (dx, None, None, None) + tuple(grads)
 
     @staticmethod

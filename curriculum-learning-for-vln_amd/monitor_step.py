@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from .functional import SHADOWS, _fused_lstm_weight, _gret, _gsink
+from .functional import ROLLOUT_WGRADS, SHADOWS, _fused_lstm_weight, _gret, _gsink
 
 _p = ops._p
 
@@ -72,7 +72,13 @@ class MonitorStepFn(torch.autograd.Function):
         sizes = (("pctx", B * L * H), ("tq", B * H), ("vq", B * M), ("xcat", B * XK), ("tcat", B * 2 * H), ("aq", B * M),
                  ("hm", B * (H + M)), ("mg", B * H), ("mem", B * H), ("act", B * 4 * H), ("tanh_c1", B * H),
                  ("gates", B * 4 * H), ("dots", B * max(L, Cn)))
-        flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
+        ctx.rw = None
+        if ROLLOUT_WGRADS.active(ctx) and training:          # the saved block as a slot of the rollout's arena (functional.RolloutWgrads)
+            key = ("monitor", B, id(W_ih))
+            flat, slot = ROLLOUT_WGRADS.saved(key, sum(_r64(n) for _, n in sizes), dev)
+            ctx.rw = (key, slot)
+        else:
+            flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
         io = _lib.MonitorStep()
         q = flat.data_ptr()
         for name, n in sizes:
@@ -126,13 +132,21 @@ class MonitorStepFn(torch.autograd.Function):
             g.acc[i] = 1 if acc else 0
         g.precision = ops.wgrad_precision(dtype != f32)
         ns = int(lib.vln_monitor_bwd_scratch_floats(C.byref(d)))
-        scratch = ops.empty(ns, dtype=f32, device=dev)
+        pj = None
+        if ctx.rw is not None and ROLLOUT_WGRADS.enabled and all(acc for _, acc in sinks):
+            scratch = ROLLOUT_WGRADS.scratch(ctx.rw[0], ctx.rw[1], ns, dev)
+            pj = _lib.ParamJobs()
+            g.defer = C.pointer(pj)
+        else:
+            scratch = ops.empty(ns, dtype=f32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), ns
         ws = ops.workspace(dev, 1 << 22)             # (the forward's pointer may belong to another stream's workspace)
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         st = lib.vln_monitor_step_bwd(C.byref(d), C.byref(w), C.byref(io), C.byref(g), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_monitor_step_bwd")
+        if pj is not None:
+            ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (flat, scratch, hold, [t for t, _ in sinks]))
         ctx.pack = None
         return (None, None, None, None, dprev, dcand, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)
 
@@ -183,7 +197,13 @@ class FollowerStepFn(torch.autograd.Function):
         sizes = (("tq", B * D), ("keys", B * V * D), ("vlog", B * V), ("xcat", B * XK), ("act", B * 4 * H), ("tanh_c1", B * H),
                  ("tq2", B * H), ("tcat", B * 2 * H), ("grounded", B * H), ("target", B * D), ("q", B * D), ("context", B * Cn * D),
                  ("gates", B * 4 * H), ("dots", B * max(L, V, Cn)))
-        flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
+        ctx.rw = None
+        if ROLLOUT_WGRADS.active(ctx) and training:
+            key = ("follower", B, id(W_ih))
+            flat, slot = ROLLOUT_WGRADS.saved(key, sum(_r64(n) for _, n in sizes), dev)
+            ctx.rw = (key, slot)
+        else:
+            flat = ops.empty(sum(_r64(n) for _, n in sizes), dtype=f32, device=dev)
         io = _lib.FollowerStep()
         q = flat.data_ptr()
         for name, n in sizes:
@@ -234,12 +254,20 @@ class FollowerStepFn(torch.autograd.Function):
             g.acc[i] = 1 if acc else 0
         g.precision = ops.wgrad_precision(dtype != f32)
         ns = int(lib.vln_follower_bwd_scratch_floats(C.byref(d)))
-        scratch = ops.empty(ns, dtype=f32, device=dev)
+        pj = None
+        if ctx.rw is not None and ROLLOUT_WGRADS.enabled and all(acc for _, acc in sinks):
+            scratch = ROLLOUT_WGRADS.scratch(ctx.rw[0], ctx.rw[1], ns, dev)
+            pj = _lib.ParamJobs()
+            g.defer = C.pointer(pj)
+        else:
+            scratch = ops.empty(ns, dtype=f32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), ns
         ws = ops.workspace(dev, 1 << 22)
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         st = lib.vln_follower_step_bwd(C.byref(d), C.byref(w), C.byref(io), C.byref(g), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_follower_step_bwd")
+        if pj is not None:
+            ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (flat, scratch, hold, [t for t, _ in sinks]))
         ctx.pack = None
         return (None, None, None, da, None, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)

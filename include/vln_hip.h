@@ -102,6 +102,25 @@ typedef struct vln_colsum_job {
   int cols, accumulate;
 } vln_colsum_job;
 int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* ws, int64_t ws_floats, vln_stream_t s);
+/* Parameter gradients of the per-step C calls (vln_monitor_step_bwd, vln_follower_step_bwd, vln_bn_mlp_bwd) once per ROLLOUT
+ * (ABI v11).  A per-step call that accumulates into p.grad reads and rewrites every weight gradient of the module per decoder
+ * step (Self-Monitor: 22 pack + 22 contraction + 22 bias launches per iteration, 0.7 ms).  With `defer` set in its grads
+ * struct the call SKIPS those launches and instead writes the jobs it would have run -- this step's operand pointers -- into
+ * the caller's vln_param_jobs.  When every step's saved-activation block and backward scratch are slots of two arenas
+ * (constant distance between consecutive steps), operand i of all T steps is ONE segmented matrix: rows
+ * [t * seg_rows, (t + 1) * seg_rows) at base_i + t * seg_stride_i.  The *_seg calls contract / sum over all T * seg_rows rows
+ * in one pack + one contraction (+ one reduce) / one launch; operands the packed kernel does not take are handled segment by
+ * segment.  functional.RolloutWgrads drives this from the end of autograd's backward pass. */
+#define VLN_PARAM_JOBS_MAX 8
+typedef struct vln_param_jobs {
+  vln_wgrad_job w[VLN_PARAM_JOBS_MAX]; vln_colsum_job c[VLN_PARAM_JOBS_MAX];
+  int32_t nw, nc, rows, precision;
+} vln_param_jobs;
+int vln_wgrad_grouped_seg(const vln_wgrad_job* jobs, const int64_t* dy_seg_stride, const int64_t* x_seg_stride, int n_jobs,
+                          int seg_rows, int n_seg, int precision, float* ws, int64_t ws_floats, vln_stream_t s);
+int vln_colsum_grouped_seg(const vln_colsum_job* jobs, const int64_t* seg_stride, int n_jobs, int seg_rows, int n_seg, float* ws,
+                           int64_t ws_floats, vln_stream_t s);
+int64_t vln_wgrad_grouped_ws_floats(const vln_wgrad_job* jobs, int n_jobs, int Mt);   /* workspace the one-contraction form wants */
 int vln_transpose_cast(const float* W, int64_t ldw, void* Wt, int out_type, int64_t ldt, int N, int K, vln_stream_t s);
 int vln_cast_copy(const float* W, int64_t ldw, void* out, int out_type, int64_t ldo, int rows, int cols, vln_stream_t s);
 /* All weight shadows of a module in ONE launch (they are refreshed once per optimizer step): job = fp32 matrix src
@@ -329,6 +348,7 @@ typedef struct vln_monitor_grads {
   int acc[13];
   int precision;                                     /* weight gradients: 0 exact fp32 MFMA, 1 split-bf16 (three bf16 MFMAs) */
   float* scratch; int64_t scratch_floats;            /* >= vln_monitor_bwd_scratch_floats(dims) */
+  vln_param_jobs* defer;                             /* nullable (ABI v11): see vln_param_jobs; b_c keeps its own one-column launch */
 } vln_monitor_grads;
 int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d);
 int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w, vln_monitor_step* io, vln_stream_t s);
@@ -370,6 +390,7 @@ typedef struct vln_follower_grads {
   int acc[16];
   int precision;
   float* scratch; int64_t scratch_floats;            /* >= vln_follower_bwd_scratch_floats(dims) */
+  vln_param_jobs* defer;                             /* nullable (ABI v11): see vln_param_jobs; b_out keeps its own one-column launch */
 } vln_follower_grads;
 int64_t vln_follower_bwd_scratch_floats(const vln_follower_dims* d);
 int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follower_weights* w, vln_follower_step* io, vln_stream_t s);
@@ -422,6 +443,7 @@ typedef struct vln_bn_mlp_grads {
   vln_bn_mlp_grad_layer layer[VLN_BN_MLP_MAX_LAYERS];
   int32_t precision, pad_;          /* weight gradients: 0 fp32, 1 split bf16, 2 plain bf16 (vln_wgrad_grouped) */
   float* scratch; int64_t scratch_floats;     /* vln_bn_mlp_bwd_scratch_floats */
+  vln_param_jobs* defer;                      /* nullable (ABI v11): the Linear weight / bias gradients as jobs, see vln_param_jobs */
 } vln_bn_mlp_grads;
 int64_t vln_bn_mlp_saved_floats(const vln_bn_mlp* m);
 int64_t vln_bn_mlp_out_offset(const vln_bn_mlp* m);

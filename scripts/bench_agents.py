@@ -263,12 +263,15 @@ def main():
                                                                "instead of one C call each way")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower: eager launches instead of one hipGraph per iteration")
+    ap.add_argument("--per-step-wgrads", action="store_true", help="monitor / follower: parameter gradients in every step's backward "
+                                                                   "(A/B) instead of once per rollout (functional.RolloutWgrads)")
     ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
     a = ap.parse_args()
     configure(a.steps, a.warmup, a.dtype, a.arena, graph=not a.no_graph)
     args.python_step = a.python_step
     args.per_step_sampler = a.per_step_sampler
     vln.functional.set_grad_in_place(not a.no_grad_in_place)
+    vln.functional.set_rollout_wgrads(not a.per_step_wgrads and not a.no_grad_in_place)
     if a.which in ("monitor", "all"):
         print(json.dumps(run_monitor()), flush=True)
         print("grad sinks [in place, via autograd]:", vln.functional.GRAD_IN_PLACE_STATS, file=sys.stderr)

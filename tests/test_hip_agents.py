@@ -513,3 +513,82 @@ def test_bn_mlp_c_call_equals_python_driven_launches(vln, dtype, R, train):
             check(res[0][2][n], res[1][2][n], 1e-6, f"buffer[{n}]")
         else:
             assert torch.equal(res[0][2][n], res[1][2][n])
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("agent", ["monitor", "follower"])
+@pytest.mark.usefixtures("split_wgrads")
+def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
+    """functional.RolloutWgrads: the per-step C calls skip their weight / bias gradient launches, the operands of all steps
+    sit in arena slots, and ONE segmented pack + contraction + column sum per group runs when the backward pass ends.  Same
+    outputs (bit for bit) and the same gradients as the per-step launches up to the summation order over steps -- over a
+    three-step chain in training mode, twice in a row (the second rollout reuses the slots)."""
+    T = 3
+    g = torch.Generator().manual_seed(123)
+    if agent == "monitor":
+        B, C, L, H, M, F = 24, 7, 20, 64, 128, 256
+        make = lambda: vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F, compute_dtype=cdt)
+    else:
+        B, V, C, L, H, F = 12, 36, 6, 17, 64, 96
+        make = lambda: vln.AttnDecoderLSTM(H, 0.5, F, F, compute_dtype=cdt)
+        imgs = [torch.randn(B, V, F, generator=g).abs().to(DEV) for _ in range(T)]
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    a_prev = torch.randn(B, F, generator=g).abs().to(DEV); cands = [torch.randn(B, C, F, generator=g).abs().to(DEV) for _ in range(T)]
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = (torch.arange(L)[None, :] >= lens[:, None]).to(DEV)
+    nc = torch.randint(2, C + 1, (B,), generator=g); cmask = (torch.arange(C)[None, :] >= nc[:, None]).to(DEV)
+    rl = torch.randn(B, C, generator=g).to(DEV); rh = torch.randn(B, H, generator=g).to(DEV); rp = torch.randn(B, generator=g).to(DEV)
+    torch.manual_seed(7)
+    sd = {k: v.clone() for k, v in make().state_dict().items()}
+    F_ = vln.functional
+    res = []
+    try:
+        F_.set_grad_in_place(True)
+        for deferred in (False, True):
+            F_.set_rollout_wgrads(deferred)
+            F_.ROLLOUT_WGRADS.stats[:] = [0, 0]
+            dec = make(); dec.load_state_dict(sd); dec.to(DEV).train()
+            per_rollout = []
+            for rollout in range(2):
+                dec._calls = 0                                  # the same dropout masks in both rollouts and both modes
+                for m_ in dec.modules():
+                    if hasattr(m_, "_calls"):
+                        m_._calls = 0
+                for p in dec.parameters():
+                    p.grad = torch.zeros_like(p)
+                ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+                hh, cc, ap, total, outs = h, c, a_prev, 0.0, []
+                for t in range(T):
+                    if agent == "monitor":
+                        (logit, prog), (hh, cc), _ = dec(None, ap, cands[t], hh, cc, ctx, ctx_mask, cmask)
+                        total = total + (logit.masked_fill(cmask, 0.0) * rl).sum() + (prog * rp).sum()
+                        outs += [logit, prog]
+                    else:
+                        logit, (hh, cc), _ = dec(imgs[t], ap, cands[t], hh, cc, ctx, ctx_mask)
+                        total = total + (logit * rl).sum()
+                        outs += [logit]
+                    ap = cands[t][:, 0]
+                total = total + (hh * rh).sum() + (cc * rh).sum()
+                total.backward()
+                torch.cuda.synchronize()
+                per_rollout.append(([o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in dec.named_parameters()},
+                                    [ctx.grad.clone(), h.grad.clone(), c.grad.clone()]))
+            res.append(per_rollout)
+            if deferred:
+                groups = 3 if agent == "monitor" else 1          # the step + the BN-MLP's two calls per step (B and B*C rows)
+                assert F_.ROLLOUT_WGRADS.stats == [2 * T * groups, 2 * groups], F_.ROLLOUT_WGRADS.stats
+            else:
+                assert F_.ROLLOUT_WGRADS.stats == [0, 0]
+    finally:
+        F_.set_rollout_wgrads(False)
+        F_.set_grad_in_place(False)
+    for rollout in range(2):
+        a, b = res[1][rollout], res[0][rollout]
+        for i, (x, y) in enumerate(zip(a[0], b[0])):
+            assert torch.equal(x, y), f"rollout {rollout} output {i}"
+        gscale = max(v.abs().max().item() for v in b[1].values())
+        for n in b[1]:
+            check(a[1][n], b[1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+        for i, (x, y) in enumerate(zip(a[2], b[2])):
+            assert torch.equal(x, y), f"rollout {rollout} input grad {i}"
+    for n in res[1][0][1]:                                      # the second rollout reproduces the first (slots reused correctly)
+        assert torch.equal(res[1][0][1][n], res[1][1][1][n]), n

@@ -148,26 +148,38 @@ def _small_agent(vln, kind, dev, seed):
     return it, load, opts, clock, dec
 
 
+@pytest.mark.parametrize("rollout_wgrads", [False, True], ids=["per_step_wgrads", "rollout_wgrads"])
 @pytest.mark.parametrize("kind", ["monitor", "follower"])
-def test_other_agents_iteration_graph_equals_eager(vln, kind):
+def test_other_agents_iteration_graph_equals_eager(vln, kind, rollout_wgrads):
     """The Self-Monitor and Speaker-Follower iterations (one C call per decoder step each way, BN-MLP, fused step loss, fused
-    Adam whose step count lives in a device word) captured whole and replayed: equal to the eager iterations bit for bit."""
+    Adam whose step count lives in a device word) captured whole and replayed: equal to the eager iterations bit for bit --
+    also with the parameter gradients formed once per rollout from autograd's end-of-backward callback
+    (functional.RolloutWgrads: the callback's launches are captured like any other)."""
     dev = torch.device(DEV)
     runs = []
-    for graph in (False, True):
-        it, load, opts, clock, dec = _small_agent(vln, kind, dev, 31)
-        out = []
-        for k in range(2):
-            load(k)
-            out.append((it().detach().clone(), [o.flat_p.clone() for o in opts]))
-        torch.cuda.synchronize()
-        g = vln.IterationGraph(it, clock).capture() if graph else None
-        for k in range(2, 6):
-            load(k)
-            loss = g.replay() if graph else it()
+    F_ = vln.functional
+    try:
+        F_.set_grad_in_place(rollout_wgrads)
+        F_.set_rollout_wgrads(rollout_wgrads)
+        for graph in (False, True):
+            F_.ROLLOUT_WGRADS.stats[:] = [0, 0]
+            it, load, opts, clock, dec = _small_agent(vln, kind, dev, 31)
+            out = []
+            for k in range(2):
+                load(k)
+                out.append((it().detach().clone(), [o.flat_p.clone() for o in opts]))
             torch.cuda.synchronize()
-            out.append((loss.detach().clone(), [o.flat_p.clone() for o in opts]))
-        runs.append(out)
+            g = vln.IterationGraph(it, clock).capture() if graph else None
+            for k in range(2, 6):
+                load(k)
+                loss = g.replay() if graph else it()
+                torch.cuda.synchronize()
+                out.append((loss.detach().clone(), [o.flat_p.clone() for o in opts]))
+            runs.append(out)
+            assert (F_.ROLLOUT_WGRADS.stats[0] > 0) == rollout_wgrads
+    finally:
+        F_.set_rollout_wgrads(False)
+        F_.set_grad_in_place(False)
     for i, (a, b) in enumerate(zip(*runs)):
         assert torch.isfinite(a[0]).all()
         assert torch.equal(a[0], b[0]), f"iteration {i}: loss {float(a[0])} vs {float(b[0])}"
