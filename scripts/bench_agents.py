@@ -263,6 +263,7 @@ def main():
                                                                "instead of one C call each way")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower: eager launches instead of one hipGraph per iteration")
+    ap.add_argument("--fused-only", action="store_true", help="follower: skip the operator-by-operator A/B run")
     ap.add_argument("--per-step-wgrads", action="store_true", help="monitor / follower: parameter gradients in every step's backward "
                                                                    "(A/B) instead of once per rollout (functional.RolloutWgrads)")
     ap.add_argument("--no-grad-in-place", action="store_true", help="parameter gradients of the fused nodes through autograd's AccumulateGrad")
@@ -277,7 +278,8 @@ def main():
         print("grad sinks [in place, via autograd]:", vln.functional.GRAD_IN_PLACE_STATS, file=sys.stderr)
     if a.which in ("follower", "all"):
         print(json.dumps(run_follower()), flush=True)
-        print(json.dumps(run_follower(fused=False)), flush=True)
+        if not a.fused_only:
+            print(json.dumps(run_follower(fused=False)), flush=True)
     if a.which in ("a2c", "all"):
         print(json.dumps(run_a2c(T_rl=a.T_rl)), flush=True)
 
