@@ -16,7 +16,7 @@ def vln():
     return vln_amd
 
 
-def _run(vln, dtype, graph, branch, n_eager=2, n_more=4):
+def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -41,6 +41,14 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4):
     if graph:
         ag.capture(live.live)
         assert ag.clock.host == n_eager * ag.clock.STRIDE           # the captured tick was not counted
+    if near_wrap:
+        # the recurrence's 24-bit launch sequence about to wrap (in a real run after ~260,000 iterations = minutes): two
+        # iterations with tags at the top of the range, then the guard clears the exchange and restarts the sequence
+        assert ag.clock._seqs
+        for s in ag.clock._seqs:
+            v = (1 << 24) - 5 * ag.clock.STRIDE
+            s[0][s[1]] = v
+            s[3] = v
     for k in range(n_eager, n_eager + n_more):
         live.load(k)
         record(ag.replay() if graph else ag.iteration(live.live))
@@ -60,6 +68,20 @@ def test_iteration_graph_equals_eager(vln, dtype, branch):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the replayed iteration"
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_launch_sequence_wrap_is_transparent(vln, graph):
+    """DeviceClock's wrap guard: the recurrence's granule tags carry a 24-bit launch sequence that the device clock bumps by 64
+    per iteration -- it wraps after 262,144 iterations.  Forced to the top of its range, the iterations before, across and after
+    the wrap (exchange cleared, sequence restarted, stream-ordered between replays) give the same bits as a run far from it,
+    and no wait times out."""
+    far, word_f, host_f = _run(vln, torch.bfloat16, graph, "ride", n_more=6)
+    near, word_n, host_n = _run(vln, torch.bfloat16, graph, "ride", n_more=6, near_wrap=True)
+    assert word_f == word_n == host_f == host_n
+    for i, (a, b) in enumerate(zip(far, near)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ across the sequence wrap"
 
 
 def test_clock_offsets_are_the_host_counter_offsets(vln):
