@@ -223,3 +223,40 @@ def test_bench_falls_back_to_per_step_launches_after_a_timeout(graph):
     assert "timed out" in out.stderr and "using per-step launches" in out.stderr
     rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ms_per_step"] > 0 and rep["steps"] == 3
+
+
+def test_replay_reports_what_an_earlier_replay_raised_on_the_device(vln):
+    """A replayed iteration has no host code between its launches.  What a launch of an EARLIER replay raised on the device -- a
+    timed-out bounded wait, an out-of-range gather index: host-mapped sticky words -- must surface as VlnError at the next
+    replay, once, and the graph keeps working afterwards."""
+    import bench
+    dev = torch.device(DEV)
+    lib = vln._lib.load()
+    store = bench.build_store(vln, dev, torch.bfloat16, n_rows=300, seed=5)
+    tapes = [bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=900 + k, n_rows=store.N), dev, store=store) for k in range(3)]
+    live = bench.LiveBatch(tapes)
+    ag = bench.GpuAgent(vln, dev, torch.bfloat16, 1, arena=True)
+    ag.clear_grads_in_step = True
+    ag.ride_gather = True
+    ag.use_clock(store)
+    for k in range(2):
+        ag.iteration(live.load(k))
+    ag.capture(live.live)
+    live.load(2); ag.replay()
+    torch.cuda.synchronize()
+    # (a) a REAL bad index inside a replay: the passengers' gather zeroes the row and raises the word
+    live.live["steps"][1]["rows"][3] = store.N + 7
+    ag.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(vln.VlnError, match="out of range"):
+        ag.replay()
+    live.load(0)                                     # a good batch again: the graph is intact
+    loss = ag.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all()
+    # (b) a timeout, injected through the test hook
+    vln._lib.check(lib.vln_debug_raise_sticky(0), "vln_debug_raise_sticky")
+    with pytest.raises(vln.VlnError, match="timed out"):
+        ag.replay()
+    lib.vln_set_persistent(1)                        # (the report switched this process to per-step launches)
+    vln._lib.check(lib.vln_persistent_check(), "clean again")
