@@ -174,9 +174,22 @@ class BnMlpGrads(C.Structure):
                 ("precision", i32), ("pad_", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))]
 
 
+# C struct name -> ctypes mirror: load() compares sizeof on both sides (vln_struct_size)
+STRUCT_MIRRORS = {
+    "vln_tick_item": TickItem, "vln_wgrad_job": WgradJob, "vln_colsum_job": ColsumJob, "vln_param_jobs": ParamJobs,
+    "vln_shadow_job": ShadowJob, "vln_wsum_step": WsumStep, "vln_dot_step": DotStep, "vln_ce_step": CeStep, "vln_cat_step": CatStep,
+    "vln_monitor_dims": MonitorDims, "vln_monitor_weights": MonitorWeights, "vln_monitor_step": MonitorStep, "vln_monitor_grads": MonitorGrads,
+    "vln_follower_dims": FollowerDims, "vln_follower_weights": FollowerWeights, "vln_follower_step": FollowerStep,
+    "vln_follower_grads": FollowerGrads, "vln_bn_affine": BnAffine, "vln_bn_mlp_layer": BnMlpLayer, "vln_bn_mlp": BnMlp,
+    "vln_bn_mlp_grad_layer": BnMlpGradLayer, "vln_bn_mlp_grads": BnMlpGrads, "vln_gather_rollout_step": GatherRolloutStep,
+    "vln_gather_ride": GatherRide, "vln_envdrop_dims": EnvDropDims, "vln_envdrop_weights": EnvDropWeights, "vln_envdrop_step": EnvDropStep,
+    "vln_envdrop_grads": EnvDropGrads,
+}
+
 # symbol -> (restype, argtypes); must list EVERY function declared in include/vln_hip.h
 SIGNATURES = {
     "vln_abi_version": (i32, []),
+    "vln_struct_size": (i64, [C.c_char_p]),
     "vln_last_error_string": (C.c_char_p, []),
     "vln_set_graphs": (i32, [i32]),
     "vln_set_tunable": (i32, [i32, i32]),
@@ -308,6 +321,11 @@ def load():
     if got != EXPECTED_ABI:
         raise VlnError(f"{LIB_PATH} has ABI version {got}, this package binds version {EXPECTED_ABI}: the library is stale "
                        "(or half-built); rebuild it with `python __graft_entry__.py`")
+    for cname, mirror in STRUCT_MIRRORS.items():
+        want = lib.vln_struct_size(cname.encode())
+        if want != C.sizeof(mirror):
+            raise VlnError(f"struct {cname}: the library has {want} bytes, the ctypes mirror {mirror.__name__} has {C.sizeof(mirror)}: "
+                           "_lib.py and include/vln_hip.h disagree (stale library or a binding bug)")
     _lib = lib
     return lib
 

@@ -4,6 +4,7 @@
 
 #include <vector>
 
+#include <cstring>
 #include "vln_internal.h"
 #include "../../include/vln_hip.h"
 
@@ -117,6 +118,40 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
 }
 
 extern "C" int vln_abi_version(void) { return 11; }
+extern "C" int64_t vln_struct_size(const char* name) {
+  if (!name) return -1;
+#define VLN_SZ(T) if (std::strcmp(name, #T) == 0) return (int64_t)sizeof(T)
+  VLN_SZ(vln_tick_item);
+  VLN_SZ(vln_wgrad_job);
+  VLN_SZ(vln_colsum_job);
+  VLN_SZ(vln_param_jobs);
+  VLN_SZ(vln_shadow_job);
+  VLN_SZ(vln_wsum_step);
+  VLN_SZ(vln_dot_step);
+  VLN_SZ(vln_ce_step);
+  VLN_SZ(vln_cat_step);
+  VLN_SZ(vln_monitor_dims);
+  VLN_SZ(vln_monitor_weights);
+  VLN_SZ(vln_monitor_step);
+  VLN_SZ(vln_monitor_grads);
+  VLN_SZ(vln_follower_dims);
+  VLN_SZ(vln_follower_weights);
+  VLN_SZ(vln_follower_step);
+  VLN_SZ(vln_follower_grads);
+  VLN_SZ(vln_bn_affine);
+  VLN_SZ(vln_bn_mlp_layer);
+  VLN_SZ(vln_bn_mlp);
+  VLN_SZ(vln_bn_mlp_grad_layer);
+  VLN_SZ(vln_bn_mlp_grads);
+  VLN_SZ(vln_gather_rollout_step);
+  VLN_SZ(vln_gather_ride);
+  VLN_SZ(vln_envdrop_dims);
+  VLN_SZ(vln_envdrop_weights);
+  VLN_SZ(vln_envdrop_step);
+  VLN_SZ(vln_envdrop_grads);
+#undef VLN_SZ
+  return -1;
+}
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,

@@ -34,6 +34,9 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_RELU 2
 
 int vln_abi_version(void);
+/* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
+ * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
+int64_t vln_struct_size(const char* name);
 const char* vln_last_error_string(void);
 
 /* Optional per-kernel timers (measurement only; the reference has no counterpart): when enabled for a kernel id,

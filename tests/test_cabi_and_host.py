@@ -194,3 +194,33 @@ def test_stale_library_is_refused(vln, monkeypatch):
     monkeypatch.setattr(lib_mod, "EXPECTED_ABI", lib_mod.EXPECTED_ABI + 1)
     with pytest.raises(lib_mod.VlnError, match="ABI version"):
         lib_mod.load()
+
+
+def test_every_public_struct_has_a_size_checked_mirror():
+    """include/vln_hip.h's structs against the ctypes mirrors: every `typedef struct vln_*` is listed in _lib.STRUCT_MIRRORS,
+    the library reports its own sizeof for each (vln_struct_size), load() compares them -- and refuses a mirror that is a field
+    short (a silent mismatch would make the kernels read wild pointers)."""
+    import ctypes as C
+    import re
+    import vln_amd
+    L = vln_amd._lib
+    header = open(os.path.join(ROOT, "include", "vln_hip.h")).read()
+    declared = set(re.findall(r"typedef\s+struct\s+(vln_[a-z0-9_]+)\s*\{", header))
+    assert declared == set(L.STRUCT_MIRRORS), declared ^ set(L.STRUCT_MIRRORS)
+    lib = L.load()
+    for name, mirror in L.STRUCT_MIRRORS.items():
+        assert lib.vln_struct_size(name.encode()) == C.sizeof(mirror), name
+    assert lib.vln_struct_size(b"vln_no_such_struct") == -1
+
+    class Short(C.Structure):
+        _fields_ = L.MonitorGrads._fields_[:-1]
+    good = L.STRUCT_MIRRORS["vln_monitor_grads"]
+    try:
+        L.STRUCT_MIRRORS["vln_monitor_grads"] = Short
+        L._lib = None
+        with pytest.raises(L.VlnError, match="vln_monitor_grads"):
+            L.load()
+    finally:
+        L.STRUCT_MIRRORS["vln_monitor_grads"] = good
+        L._lib = None
+        L.load()
