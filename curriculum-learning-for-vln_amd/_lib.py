@@ -157,11 +157,11 @@ class BnAffine(C.Structure):
 
 class BnMlpLayer(C.Structure):
     _fields_ = ([(n, ptr) for n in ("w", "w_t", "w_f32", "b")] + [("bn", BnAffine), ("out", i32), ("pad_", i32), ("p_drop", f32),
-                ("padf_", f32), ("seed", u64), ("offset", u64)])
+                ("padf_", f32), ("seed", u64), ("offset", u64), ("offset2", u64)])
 
 
 class BnMlp(C.Structure):
-    _fields_ = [("R", i32), ("D0", i32), ("nl", i32), ("wtype", i32), ("training", i32), ("pad_", i32), ("eps", f32), ("momentum", f32),
+    _fields_ = [("R", i32), ("D0", i32), ("nl", i32), ("wtype", i32), ("training", i32), ("R1", i32), ("eps", f32), ("momentum", f32),
                 ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr), ("offset_base_dev", ptr)]
 
 
@@ -290,7 +290,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 11
+EXPECTED_ABI = 12
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()

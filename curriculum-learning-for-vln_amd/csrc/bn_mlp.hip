@@ -17,7 +17,7 @@ inline long lin_ws(long ws_floats, long M, long N) {
 }
 
 int check_mlp(const vln_bn_mlp* m) {
-  if (!m || m->R <= 0 || m->D0 <= 0 || m->nl <= 0 || m->nl > VLN_BN_MLP_MAX_LAYERS || (m->D0 & 3)) { set_error("bn_mlp: bad dims"); return VLN_ERR_ARG; }
+  if (!m || m->R <= 0 || m->D0 <= 0 || m->nl <= 0 || m->nl > VLN_BN_MLP_MAX_LAYERS || (m->D0 & 3) || m->R1 < 0 || m->R1 >= m->R) { set_error("bn_mlp: bad dims"); return VLN_ERR_ARG; }
   for (int i = 0; i < m->nl; ++i)
     if (m->layer[i].out <= 0 || (m->layer[i].out & 3) || !m->layer[i].w || !m->layer[i].w_t) { set_error("bn_mlp: bad layer %d", i); return VLN_ERR_ARG; }
   return VLN_OK;
@@ -29,10 +29,11 @@ SavedLayout saved_layout(const vln_bn_mlp* m) {
   long off = 0;
   auto take = [&](long n) { long o = off; off += r64(n); return o; };
   const long R = m->R;
-  L.y0 = take(R * m->D0); L.s0 = take(2L * m->D0);
+  const long ns = m->R1 > 0 ? 4 : 2;                 // per BatchNorm: (mean, rstd) per segment
+  L.y0 = take(R * m->D0); L.s0 = take(ns * m->D0);
   for (int i = 0; i < m->nl; ++i) {
     const long D = m->layer[i].out;
-    L.z[i] = take(R * D); L.s[i] = take(2 * D); L.y[i] = take(R * D);
+    L.z[i] = take(R * D); L.s[i] = take(ns * D); L.y[i] = take(R * D);
   }
   L.total = off;
   return L;
@@ -64,7 +65,7 @@ extern "C" int64_t vln_bn_mlp_ws_floats(const vln_bn_mlp* m) {
   if (tiles < 256) { msplit = 256 / (tiles > 0 ? tiles : 1); if (msplit > MS / 4) msplit = MS / 4; if (msplit < 1) msplit = 1; }
   if (msplit > 1) area += msplit * nk;
   long n = area;
-  const long bn_part = (long)((m->R + 127) / 128) * 2 * dmax;      // chunked BatchNorm partials
+  const long bn_part = (long)((m->R + 127) / 128 + 1) * 2 * dmax;  // chunked BatchNorm partials (+1: two segments round up separately)
   const long slabs = 16L * m->R * dmax;                            // split-K slabs of the skinny products
   if (bn_part > n) n = bn_part;
   if (slabs > n) n = slabs;
@@ -87,8 +88,10 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
   const int R = m->R, tr = m->training;
   float* y = saved + L.y0;
   float* st0 = saved + L.s0;
-  RUN(vln_bn_fwd(x, ldx, y, m->D0, m->bn0.gamma, m->bn0.beta, m->bn0.run_mean, m->bn0.run_var, tr ? m->bn0.nbt : nullptr,
-                 tr ? st0 : nullptr, tr ? st0 + m->D0 : nullptr, R, m->D0, m->eps, m->momentum, tr, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
+  const int R1 = m->R1;
+  RUN(bn_fwd_seg(x, ldx, y, m->D0, m->bn0.gamma, m->bn0.beta, m->bn0.run_mean, m->bn0.run_var, tr ? m->bn0.nbt : nullptr,
+                 tr ? st0 : nullptr, tr ? st0 + m->D0 : nullptr, R, R1, 2L * m->D0, m->D0, m->eps, m->momentum, tr, 0, 0, 0, 0, 0.f, nullptr,
+                 ws, ws_floats, s));
   int in = m->D0;
   for (int i = 0; i < m->nl; ++i) {
     const vln_bn_mlp_layer& l = m->layer[i];
@@ -98,9 +101,9 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     // split-K scratch bounded like ops.linear_fwd bounds it: the same K split, hence the same bits, as the operator path
     RUN(gemm_nt(st, y, in, l.w, m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
     const bool last = (i == m->nl - 1);
-    RUN(vln_bn_fwd(z, l.out, yi, l.out, l.bn.gamma, l.bn.beta, l.bn.run_mean, l.bn.run_var, tr ? l.bn.nbt : nullptr, tr ? si : nullptr,
-                   tr ? si + l.out : nullptr, R, l.out, m->eps, m->momentum, tr, 1, l.seed, l.offset, tr ? l.p_drop : 0.f,
-                   last ? m->row_zero : nullptr, ws, ws_floats, s));
+    RUN(bn_fwd_seg(z, l.out, yi, l.out, l.bn.gamma, l.bn.beta, l.bn.run_mean, l.bn.run_var, tr ? l.bn.nbt : nullptr, tr ? si : nullptr,
+                   tr ? si + l.out : nullptr, R, R1, 2L * l.out, l.out, m->eps, m->momentum, tr, 1, l.seed, l.offset, l.offset2,
+                   tr ? l.p_drop : 0.f, last ? m->row_zero : nullptr, ws, ws_floats, s));
     y = yi; in = l.out;
   }
   return VLN_OK;
@@ -134,9 +137,9 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     const float* yprev = (i == 0) ? saved + L.y0 : saved + L.y[i - 1];
     float* dz = take((long)R * l.out);
     const bool last = (i == nl - 1);
-    RUN(vln_bn_bwd(z, l.out, gcur, ldg, yi, l.out, l.bn.gamma, tr ? si : l.bn.run_mean, tr ? si + l.out : l.bn.run_var, dz, l.out,
-                   g->layer[i].g_gamma, g->layer[i].g_beta, R, l.out, m->eps, tr, 1, g->layer[i].acc_bn, l.seed, l.offset,
-                   tr ? l.p_drop : 0.f, last ? m->row_zero : nullptr, ws, ws_floats, s));
+    RUN(bn_bwd_seg(z, l.out, gcur, ldg, yi, l.out, l.bn.gamma, tr ? si : l.bn.run_mean, tr ? si + l.out : l.bn.run_var, dz, l.out,
+                   g->layer[i].g_gamma, g->layer[i].g_beta, R, m->R1, 2L * l.out, l.out, m->eps, tr, 1, g->layer[i].acc_bn, l.seed, l.offset,
+                   l.offset2, tr ? l.p_drop : 0.f, last ? m->row_zero : nullptr, ws, ws_floats, s));
     if (g->layer[i].g_w) wj[nw++] = vln_wgrad_job{dz, yprev, g->layer[i].g_w, l.out, in, in, l.out, in, g->layer[i].acc_w, 0};
     if (g->layer[i].g_b && l.b) cj[nc++] = vln_colsum_job{dz, g->layer[i].g_b, nullptr, l.out, l.out, g->layer[i].acc_b};
     float* gi = take((long)R * in);
@@ -153,7 +156,7 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     if (nc) RUN(colsum_grouped(st, cj, nc, R, ws, ws_floats));
   }
   const float* s0 = saved + L.s0;
-  RUN(vln_bn_bwd(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
-                 g->g_gamma0, g->g_beta0, R, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
+  RUN(bn_bwd_seg(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
+                 g->g_gamma0, g->g_beta0, R, m->R1, 2L * m->D0, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
   return VLN_OK;
 }

@@ -536,7 +536,15 @@ struct BnArgs {
   int R, D; float eps, momentum; int training, relu;
   DropSpec drop;                    // optional dropout between the normalisation and the ReLU (MLPwithBN: BN, Dropout, ReLU)
   const unsigned char* row_zero;    // optional [R]: rows whose output is forced to 0 (padded candidate slots, policy.py:148-149)
+  // TWO SEGMENTS (row-chunked form only): rows [0, R1) and [R1, R) are two independent batches -- the Self-Monitor's BN-MLP runs
+  // on the previous action (B rows) and on the candidates (B*C rows) with the same weights, policy.py:140-149 -- normalised with
+  // their OWN statistics in one launch pair.  Segment 1 uses drop2, indexes its Philox elements and row_zero from ITS first row
+  // (exactly what a second call would do), keeps its saved statistics `stat2` floats after segment 0's, and the running
+  // statistics take both updates in order (num_batches_tracked += 2).  R1 == 0: one segment.
+  int R1; long stat2; DropSpec drop2;
 };
+// chunk -> (segment, first row, rows in the chunk, rows of the segment, the segment's first chunk and chunk count)
+struct BnSegChunk { int seg, r0, n, seg_rows, seg_r0, first, count; };
 __device__ __forceinline__ float4 bn_strip_sum(float4 v, float4 (*part)[4], int rl, int cg) {
   part[rl][cg] = v;
   __syncthreads();
@@ -629,6 +637,7 @@ struct BnBwdArgs {
   float* dx; long lddx; float* dgamma; float* dbeta;
   int R, D; float eps; int training, relu, accumulate;
   DropSpec drop; const unsigned char* row_zero;     // as in the forward
+  int R1; long stat2; DropSpec drop2;               // two segments, as in the forward (row-chunked form only)
 };
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   __shared__ float4 part[64][4];
@@ -710,6 +719,16 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
 // Two launches of ~6 us each instead of one of 20-40.
 constexpr int kBnChunk = 128;
 struct BnChunkWs { float* part; int nchunk; };       // part [nchunk][2][D]
+__host__ __device__ __forceinline__ int bn_nchunk(int R, int R1) {
+  return R1 > 0 ? (R1 + kBnChunk - 1) / kBnChunk + (R - R1 + kBnChunk - 1) / kBnChunk : (R + kBnChunk - 1) / kBnChunk;
+}
+__device__ __forceinline__ BnSegChunk bn_chunk(int ch, int R, int R1) {
+  if (R1 <= 0) return BnSegChunk{0, ch * kBnChunk, min(kBnChunk, R - ch * kBnChunk), R, 0, 0, (R + kBnChunk - 1) / kBnChunk};
+  const int n0 = (R1 + kBnChunk - 1) / kBnChunk;
+  if (ch < n0) return BnSegChunk{0, ch * kBnChunk, min(kBnChunk, R1 - ch * kBnChunk), R1, 0, 0, n0};
+  const int c = ch - n0, R2 = R - R1;
+  return BnSegChunk{1, R1 + c * kBnChunk, min(kBnChunk, R2 - c * kBnChunk), R2, R1, n0, (R2 + kBnChunk - 1) / kBnChunk};
+}
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 
@@ -719,8 +738,9 @@ __global__ __launch_bounds__(256) void bn_fwd_stats_kernel(BnArgs a, BnChunkWs w
   const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
   const bool c_ok = c < a.D;
   const int cc = c_ok ? c : 0;
-  const int ch = blockIdx.y, r0 = ch * kBnChunk;
-  const int n = min(kBnChunk, a.R - r0);
+  const int ch = blockIdx.y;
+  const BnSegChunk sc = bn_chunk(ch, a.R, a.R1);
+  const int r0 = sc.r0, n = sc.n;
   const int ra = r0 + rl, rb = r0 + 64 + rl;
   const bool oka = c_ok && rl < n, okb = c_ok && 64 + rl < n;
   const float4 z = f4(0.f);
@@ -743,41 +763,60 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(BnArgs a, BnChunkWs w
   const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
   if (c >= a.D) return;
-  const int ch = blockIdx.y, r0 = ch * kBnChunk;
+  const int ch = blockIdx.y;
+  const BnSegChunk sc = bn_chunk(ch, a.R, a.R1);
+  const int r0 = sc.r0;
   float4 mean, rstd;
   if (a.training) {
-    float4 ms = f4(0.f);
-    for (int i = 0; i < w.nchunk; ++i) {
-      const float ni = (float)min(kBnChunk, a.R - i * kBnChunk);
-      const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
-      ms.x += ni * mi.x; ms.y += ni * mi.y; ms.z += ni * mi.z; ms.w += ni * mi.w;
-    }
-    const float inv = 1.f / (float)a.R;
-    mean = make_float4(ms.x * inv, ms.y * inv, ms.z * inv, ms.w * inv);
-    float4 m2 = f4(0.f);
-    for (int i = 0; i < w.nchunk; ++i) {
-      const float ni = (float)min(kBnChunk, a.R - i * kBnChunk);
-      const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
-      const float4 qi = *reinterpret_cast<const float4*>(w.part + ((long)i * 2 + 1) * a.D + c);
-      const float dx = mi.x - mean.x, dy = mi.y - mean.y, dz = mi.z - mean.z, dw = mi.w - mean.w;
-      m2.x += qi.x + ni * dx * dx; m2.y += qi.y + ni * dy * dy; m2.z += qi.z + ni * dz * dz; m2.w += qi.w + ni * dw * dw;
-    }
-    const float4 var = make_float4(m2.x * inv, m2.y * inv, m2.z * inv, m2.w * inv);
+    // a segment's batch statistics from its chunks' (mean, M2), merged in chunk order (Chan)
+    auto merged = [&](const BnSegChunk& g, float4& mean_o, float4& var_o) {
+      float4 ms = f4(0.f);
+      for (int i = 0; i < g.count; ++i) {
+        const float ni = (float)min(kBnChunk, g.seg_rows - i * kBnChunk);
+        const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)(g.first + i) * 2) * a.D + c);
+        ms.x += ni * mi.x; ms.y += ni * mi.y; ms.z += ni * mi.z; ms.w += ni * mi.w;
+      }
+      const float inv = 1.f / (float)g.seg_rows;
+      mean_o = make_float4(ms.x * inv, ms.y * inv, ms.z * inv, ms.w * inv);
+      float4 m2 = f4(0.f);
+      for (int i = 0; i < g.count; ++i) {
+        const float ni = (float)min(kBnChunk, g.seg_rows - i * kBnChunk);
+        const float4 mi = *reinterpret_cast<const float4*>(w.part + ((long)(g.first + i) * 2) * a.D + c);
+        const float4 qi = *reinterpret_cast<const float4*>(w.part + ((long)(g.first + i) * 2 + 1) * a.D + c);
+        const float dx = mi.x - mean_o.x, dy = mi.y - mean_o.y, dz = mi.z - mean_o.z, dw = mi.w - mean_o.w;
+        m2.x += qi.x + ni * dx * dx; m2.y += qi.y + ni * dy * dy; m2.z += qi.z + ni * dz * dz; m2.w += qi.w + ni * dw * dw;
+      }
+      var_o = make_float4(m2.x * inv, m2.y * inv, m2.z * inv, m2.w * inv);
+    };
+    float4 var;
+    merged(sc, mean, var);
     rstd = make_float4(rsqrtf(var.x + a.eps), rsqrtf(var.y + a.eps), rsqrtf(var.z + a.eps), rsqrtf(var.w + a.eps));
-    if (ch == 0 && rl == 0) {
-      if (a.save_mean) *reinterpret_cast<float4*>(a.save_mean + c) = mean;
-      if (a.save_rstd) *reinterpret_cast<float4*>(a.save_rstd + c) = rstd;
+    if (ch == sc.first && rl == 0) {          // the segment's first chunk saves the segment's statistics
+      if (a.save_mean) *reinterpret_cast<float4*>(a.save_mean + sc.seg * a.stat2 + c) = mean;
+      if (a.save_rstd) *reinterpret_cast<float4*>(a.save_rstd + sc.seg * a.stat2 + c) = rstd;
+    }
+    if (ch == 0 && rl == 0) {                 // ONE workgroup per strip updates the running statistics: segment 0, then segment 1
       if (a.run_mean) {
-        const float m = a.momentum, ub = (a.R > 1) ? (float)a.R / (float)(a.R - 1) : 1.f;
         float4 rm = *reinterpret_cast<float4*>(a.run_mean + c), rv = *reinterpret_cast<float4*>(a.run_var + c);
-        rm.x = (1.f - m) * rm.x + m * mean.x; rm.y = (1.f - m) * rm.y + m * mean.y;
-        rm.z = (1.f - m) * rm.z + m * mean.z; rm.w = (1.f - m) * rm.w + m * mean.w;
-        rv.x = (1.f - m) * rv.x + m * var.x * ub; rv.y = (1.f - m) * rv.y + m * var.y * ub;
-        rv.z = (1.f - m) * rv.z + m * var.z * ub; rv.w = (1.f - m) * rv.w + m * var.w * ub;
+        const int nseg = a.R1 > 0 ? 2 : 1;
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+          float4 mu = mean, vr = var;
+          int rows = sc.seg_rows;
+          if (sgi == 1) {
+            const BnSegChunk g1 = bn_chunk((a.R1 + kBnChunk - 1) / kBnChunk, a.R, a.R1);
+            merged(g1, mu, vr);
+            rows = g1.seg_rows;
+          }
+          const float m = a.momentum, ub = (rows > 1) ? (float)rows / (float)(rows - 1) : 1.f;
+          rm.x = (1.f - m) * rm.x + m * mu.x; rm.y = (1.f - m) * rm.y + m * mu.y;
+          rm.z = (1.f - m) * rm.z + m * mu.z; rm.w = (1.f - m) * rm.w + m * mu.w;
+          rv.x = (1.f - m) * rv.x + m * vr.x * ub; rv.y = (1.f - m) * rv.y + m * vr.y * ub;
+          rv.z = (1.f - m) * rv.z + m * vr.z * ub; rv.w = (1.f - m) * rv.w + m * vr.w * ub;
+        }
         *reinterpret_cast<float4*>(a.run_mean + c) = rm;
         *reinterpret_cast<float4*>(a.run_var + c) = rv;
       }
-      if (a.nbt && blockIdx.x == 0 && cg == 0) *a.nbt += 1;
+      if (a.nbt && blockIdx.x == 0 && cg == 0) *a.nbt += (a.R1 > 0 ? 2 : 1);
     }
   } else {
     mean = *reinterpret_cast<const float4*>(a.run_mean + c);
@@ -786,20 +825,22 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(BnArgs a, BnChunkWs w
   }
   const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : f4(1.f);
   const float4 bt = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : f4(0.f);
+  const DropSpec& dsp = sc.seg ? a.drop2 : a.drop;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int r = r0 + k * 64 + rl;
-    if (r >= a.R || k * 64 + rl >= kBnChunk) continue;
+    if (k * 64 + rl >= sc.n) continue;
+    const int rs = r - sc.seg_r0;                     // row within its segment: what a call on the segment alone would index
     const float4 t = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + c);
     float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
                            (t.z - mean.z) * rstd.z * g.z + bt.z, (t.w - mean.w) * rstd.w * g.w + bt.w);
-    if (a.drop.p > 0.f) {
+    if (dsp.p > 0.f) {
       float m[4];
-      dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + c) >> 2), a.drop.p, m);
+      dropout_scale4(dsp.seed, dsp.off(), (uint32_t)(((long)rs * a.D + c) >> 2), dsp.p, m);
       o.x *= m[0]; o.y *= m[1]; o.z *= m[2]; o.w *= m[3];
     }
     if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    if (a.row_zero && a.row_zero[r]) o = f4(0.f);
+    if (a.row_zero && (a.R1 <= 0 || sc.seg == 1) && a.row_zero[rs]) o = f4(0.f);
     *reinterpret_cast<float4*>(a.y + (long)r * a.ldy + c) = o;
   }
 }
@@ -812,23 +853,28 @@ __global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(BnBwdArgs a, BnChunkW
   const int c = xcd_chunked_block(blockIdx.x, gridDim.x) * 16 + cg * 4;
   const bool c_ok = c < a.D;
   const int cc = c_ok ? c : 0;
-  const int ch = blockIdx.y, r0 = ch * kBnChunk;
-  const float4 mean = *reinterpret_cast<const float4*>(a.mean + cc);
-  float4 rstd = *reinterpret_cast<const float4*>(a.rstd + cc);
+  const int ch = blockIdx.y;
+  const BnSegChunk sc = bn_chunk(ch, a.R, a.R1);
+  const int r0 = sc.r0;
+  const long so = a.training ? sc.seg * a.stat2 : 0;          // eval mode: both segments use the running statistics
+  const float4 mean = *reinterpret_cast<const float4*>(a.mean + so + cc);
+  float4 rstd = *reinterpret_cast<const float4*>(a.rstd + so + cc);
+  const DropSpec& dsp = sc.seg ? a.drop2 : a.drop;
   if (!a.training) rstd = make_float4(rsqrtf(rstd.x + a.eps), rsqrtf(rstd.y + a.eps), rsqrtf(rstd.z + a.eps), rsqrtf(rstd.w + a.eps));
   float4 dv[2], xh[2];
   bool ok[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int r = r0 + k * 64 + rl;
-    ok[k] = c_ok && r < a.R;
+    const int rs = r - sc.seg_r0;
+    ok[k] = c_ok && k * 64 + rl < sc.n;
     dv[k] = f4(0.f); xh[k] = f4(0.f);
     if (ok[k]) {
       float4 d = *reinterpret_cast<const float4*>(a.dy + (long)r * a.lddy + cc);
-      if (a.row_zero && a.row_zero[r]) d = f4(0.f);
-      if (a.drop.p > 0.f) {
+      if (a.row_zero && (a.R1 <= 0 || sc.seg == 1) && a.row_zero[rs]) d = f4(0.f);
+      if (dsp.p > 0.f) {
         float m[4];
-        dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)(((long)r * a.D + cc) >> 2), a.drop.p, m);
+        dropout_scale4(dsp.seed, dsp.off(), (uint32_t)(((long)rs * a.D + cc) >> 2), dsp.p, m);
         d.x *= m[0]; d.y *= m[1]; d.z *= m[2]; d.w *= m[3];
       }
       if (a.relu) {
@@ -852,28 +898,34 @@ __global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(BnBwdArgs a, BnChunkW
     }
   } else {
     if (!c_ok) return;
-    float4 sd = f4(0.f), sdx = f4(0.f);
+    // this segment's sums (for its rows' dx); d gamma / d beta take every chunk of BOTH segments (chunk 0's workgroup)
+    float4 sd = f4(0.f), sdx = f4(0.f), td = f4(0.f), tdx = f4(0.f);
     for (int i = 0; i < w.nchunk; ++i) {
       const float4 p0 = *reinterpret_cast<const float4*>(w.part + ((long)i * 2) * a.D + c);
       const float4 p1 = *reinterpret_cast<const float4*>(w.part + ((long)i * 2 + 1) * a.D + c);
-      sd.x += p0.x; sd.y += p0.y; sd.z += p0.z; sd.w += p0.w;
-      sdx.x += p1.x; sdx.y += p1.y; sdx.z += p1.z; sdx.w += p1.w;
+      td.x += p0.x; td.y += p0.y; td.z += p0.z; td.w += p0.w;
+      tdx.x += p1.x; tdx.y += p1.y; tdx.z += p1.z; tdx.w += p1.w;
+      if (i >= sc.first && i < sc.first + sc.count) {
+        sd.x += p0.x; sd.y += p0.y; sd.z += p0.z; sd.w += p0.w;
+        sdx.x += p1.x; sdx.y += p1.y; sdx.z += p1.z; sdx.w += p1.w;
+      }
     }
     if (ch == 0 && rl == 0) {
+      const float4 sd_all = td, sdx_all = tdx;
       if (a.dgamma) {
-        float4 o = sdx;
+        float4 o = sdx_all;
         if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dgamma + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         *reinterpret_cast<float4*>(a.dgamma + c) = o;
       }
       if (a.dbeta) {
-        float4 o = sd;
+        float4 o = sd_all;
         if (a.accumulate) { const float4 p = *reinterpret_cast<float4*>(a.dbeta + c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         *reinterpret_cast<float4*>(a.dbeta + c) = o;
       }
     }
     if (!a.dx) return;
     const float4 g = a.gamma ? *reinterpret_cast<const float4*>(a.gamma + c) : f4(1.f);
-    const float inv = 1.f / (float)a.R;
+    const float inv = 1.f / (float)sc.seg_rows;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (!ok[k]) continue;
@@ -1223,10 +1275,19 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
     set_error("vln_bn_fwd: bad args (D %% 4 == 0, 16-byte aligned rows)");
     return VLN_ERR_ARG;
   }
+  return bn_fwd_seg(x, ldx, y, ldy, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, R, 0, 0, D, eps,
+                    momentum, training, relu, seed, offset, 0, p_drop, row_zero, ws, ws_floats, s);
+}
+int vln::bn_fwd_seg(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, int R, int R1, int64_t stat2, int D,
+                    float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, uint64_t offset2, float p_drop,
+                    const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
+  if (R1 < 0 || R1 >= R) { set_error("bn_fwd: bad segment split"); return VLN_ERR_ARG; }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
-           R, D, eps, momentum, training, relu, tls_drop(seed, offset, p_drop), row_zero};
-  const int nchunk = (R + kBnChunk - 1) / kBnChunk;
-  if (R >= 512 && ((!training) || (ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D))) {     // tall input: row-chunked form
+           R, D, eps, momentum, training, relu, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop)};
+  const int nchunk = bn_nchunk(R, R1);
+  if (R1 > 0 && !(ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D)) { set_error("bn_fwd: the two-segment form needs its workspace"); return VLN_ERR_ARG; }
+  if ((R1 > 0 || R >= 512) && ((!training) || (ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D))) {     // tall input: row-chunked form
     BnChunkWs w{ws, nchunk};
     dim3 grid((D + 15) / 16, nchunk);
     if (training) VLN_LAUNCH(bn_fwd_stats_kernel, grid, dim3(256), 0, (hipStream_t)s, a, w);
@@ -1248,10 +1309,19 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
     set_error("vln_bn_bwd: bad args");
     return VLN_ERR_ARG;
   }
+  return bn_bwd_seg(x, ldx, dy, lddy, y, ldy, gamma, mean, rstd_or_var, dx, lddx, dgamma, dbeta, R, 0, 0, D, eps, training, relu, accumulate,
+                    seed, offset, 0, p_drop, row_zero, ws, ws_floats, s);
+}
+int vln::bn_bwd_seg(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
+                    const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int R1,
+                    int64_t stat2, int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, uint64_t offset2,
+                    float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
+  if (R1 < 0 || R1 >= R) { set_error("bn_bwd: bad segment split"); return VLN_ERR_ARG; }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
-              training, relu, accumulate, tls_drop(seed, offset, p_drop), row_zero};
-  const int nchunk = (R + kBnChunk - 1) / kBnChunk;
-  if (R >= 512 && ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D) {       // tall input: row-chunked form
+              training, relu, accumulate, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop)};
+  const int nchunk = bn_nchunk(R, R1);
+  if (R1 > 0 && !(ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D)) { set_error("bn_bwd: the two-segment form needs its workspace"); return VLN_ERR_ARG; }
+  if ((R1 > 0 || R >= 512) && ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D) {       // tall input: row-chunked form
     BnChunkWs w{ws, nchunk};
     VLN_LAUNCH(bn_bwd_chunk_kernel<0>, dim3((D + 15) / 16, nchunk), dim3(256), 0, (hipStream_t)s, a, w);
     VLN_LAUNCH(bn_bwd_chunk_kernel<1>, dim3((D + 15) / 16, dx ? nchunk : 1), dim3(256), 0, (hipStream_t)s, a, w);

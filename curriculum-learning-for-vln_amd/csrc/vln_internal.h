@@ -65,6 +65,15 @@ struct ProfScope {   // brackets the launches issued in its scope with an event 
 // is the kernel's own begin->end on the device, the figure rocprofv3 --kernel-trace reports, with no
 // launch gap or event-record packet inside the bracket.
 bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
+// BatchNorm of two independent row segments in one launch pair (pointwise.hip; R1 == 0: one segment = vln_bn_fwd / vln_bn_bwd)
+int bn_fwd_seg(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
+               float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, int R, int R1, int64_t stat2, int D,
+               float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, uint64_t offset2, float p_drop,
+               const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s);
+int bn_bwd_seg(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
+               const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int R1,
+               int64_t stat2, int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, uint64_t offset2,
+               float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s);
 struct GatherCheck;
 GatherCheck gather_check(const void* table);   // features.hip: the registered extent of a feature table (vln_feature_table_extent)
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout

@@ -279,6 +279,38 @@ class MLPwithBN(nn.Module):
             y = y * (~row_zero).to(y.dtype).unsqueeze(1)
         return y
 
+    def forward_pair(self, x1, x2, row_zero2=None):
+        """(forward(x1), forward(x2, row_zero=row_zero2)) -- the reference's two calls with the same MLP on the previous action and
+        on the candidates (policy.py:140-149) -- as ONE fused call: every BatchNorm normalises each batch with its own statistics
+        and updates the running statistics twice, in that order; the Linear layers, their gradients and their weight gradients
+        run once over all rows.  Equal to the two calls up to summation order (the dropout offsets are consumed in the same
+        order, masks indexed per batch).  Falls back to the two calls when the fused path does not apply."""
+        plan = self._fused_plan()
+        ok = plan is not None and x1.dim() == 2 and x2.dim() == 2 and x1.dtype == torch.float32 and x2.dtype == torch.float32 and \
+            x1.is_cuda and x1.shape[1] % 4 == 0 and x1.shape[1] == x2.shape[1] and all(t[0].out_features % 4 == 0 for t in plan[1]) and \
+            len(plan[1]) <= Fh._lib.BN_MLP_MAX_LAYERS and all(t[0].bias is not None for t in plan[1]) and Fh._BN_MLP_C_CALL[0]
+        if not ok:
+            return self.forward(x1), self.forward(x2, row_zero=row_zero2)
+        bn0, seq = plan
+        training = self.training
+        bufs, tensors = [(bn0.running_mean, bn0.running_var, bn0.num_batches_tracked)], [bn0.weight, bn0.bias]
+        for lin, bnl, dr in seq:
+            bufs.append((bnl.running_mean, bnl.running_var, bnl.num_batches_tracked))
+            tensors += [lin.weight, lin.bias, bnl.weight, bnl.bias]
+
+        def offsets():                     # one call's worth of dropout offsets, layer by layer (what forward() consumes)
+            out = []
+            for lin, bnl, dr in seq:
+                p = dr.p if (dr is not None and training) else 0.0
+                out.append((float(p), dr.dropout_seed if dr is not None else 0, dr._next() if (dr is not None and p > 0) else 0) +
+                           ((dr._drop_base(),) if (dr is not None and dr._drop_base() is not None) else ()))
+            return out
+        drops = offsets()
+        offs2 = [d[2] for d in offsets()]
+        x = torch.cat([x1, x2], 0)
+        return Fh.bn_mlp(x, row_zero2, training, bn0.eps, bn0.momentum, seq[0][0].compute_dtype, drops, bufs, tensors,
+                         seg=(x1.shape[0], offs2))
+
     def _forward_layers(self, x):
         layers = list(self.mlp)
         i = 0
@@ -316,6 +348,7 @@ class MonitorDecoder(nn.Module, _Seeded):
         self._init_seed(0x5E1F)
         self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
         self.c_step = True                # the fused node as ONE C call each way (csrc/monitor.hip); False: launches driven from Python
+        self.merge_projections = False    # True: the BN-MLP's two calls per step as one two-batch call (MLPwithBN.forward_pair)
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
@@ -345,10 +378,16 @@ class MonitorDecoder(nn.Module, _Seeded):
         B, C, _ = a_t_cands.shape
         # BN-MLP twice (previous action rows, then all B*C candidate rows incl. padded ones): two sets of batch
         # statistics and two running-stat updates per step, as in the reference
-        prev_rep = self.proj_navigable_mlp(a_t_prev)
-        # the BN-MLP zeroes the padded candidate slots itself (row_zero): one autograd node per call
-        cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size),
-                                           row_zero=candidate_mask.reshape(B * C)).view(B, C, -1)
+        if self.merge_projections:
+            # both projections in ONE BN-MLP call (two batches, per-batch statistics): half the launches of this part of the step
+            prev_rep, cand_rep = self.proj_navigable_mlp.forward_pair(a_t_prev, a_t_cands.reshape(B * C, self.action_embed_size),
+                                                                      row_zero2=candidate_mask.reshape(B * C))
+            cand_rep = cand_rep.view(B, C, -1)
+        else:
+            prev_rep = self.proj_navigable_mlp(a_t_prev)
+            # the BN-MLP zeroes the padded candidate slots itself (row_zero): one autograd node per call
+            cand_rep = self.proj_navigable_mlp(a_t_cands.reshape(B * C, self.action_embed_size),
+                                               row_zero=candidate_mask.reshape(B * C)).view(B, C, -1)
         if self.fused_step and ctx.dtype == torch.float32 and cand_rep.shape[2] % 4 == 0 and self.rnn_hidden_size % 4 == 0 \
                 and ctx_mask is not None and candidate_mask is not None:
             # everything after the BN-MLP as ONE autograd node (functional.MonitorCoreFn)

@@ -482,10 +482,12 @@ class BnMlpFn(torch.autograd.Function):
     @staticmethod
     def _c_desc(x, rz, cfg, bufs, tensors):
         """vln_bn_mlp filled from the module's tensors (+ the objects that keep its pointers alive)."""
-        training, eps, momentum, dtype, drops = cfg
+        training, eps, momentum, dtype, drops = cfg[:5]
+        seg = cfg[5] if len(cfg) > 5 else None          # (R1, [segment 1's dropout offset per layer]): two batches in one call
         nl = (len(tensors) - 2) // 4
         m = _lib.BnMlp()
         m.R, m.D0, m.nl = x.shape[0], x.shape[1], nl
+        m.R1 = seg[0] if seg else 0
         m.wtype = ops.F32 if dtype == torch.float32 else ops.BF16
         m.training, m.eps, m.momentum = int(training), eps, momentum
         keep = []
@@ -503,6 +505,7 @@ class BnMlpFn(torch.autograd.Function):
             affine(l.bn, gw, gb, bufs[1 + i])
             l.out = W.shape[0]
             l.p_drop, l.seed, l.offset = drops[i][:3]
+            l.offset2 = seg[1][i] if seg else 0
             if len(drops[i]) > 3:
                 m.offset_base_dev = drops[i][3]                     # runtime.DeviceClock word: every layer's offset is relative to it
         m.row_zero = _p(rz)
@@ -530,10 +533,13 @@ class BnMlpFn(torch.autograd.Function):
         ctx.cfg, ctx.bufs, ctx.nl, ctx.rz, ctx.c_call = cfg, bufs, nl, rz, True
         ctx.save_for_backward(x, saved, *tensors)
         # the output is the last block of `saved` (which the backward reads): the caller gets an alias, the ctx keeps the base
-        return saved[off:off + x.shape[0] * out_dim].view(x.shape[0], out_dim).detach()
+        out = saved[off:off + x.shape[0] * out_dim].view(x.shape[0], out_dim).detach()
+        if m.R1 > 0:                                   # two batches: one output (and one incoming gradient) per segment
+            return out[:m.R1], out[m.R1:]
+        return out
 
     @staticmethod
-    def _backward_c(ctx, dy):
+    def _backward_c(ctx, *dys):
         lib = _lib.load()
         x, saved = ctx.saved_tensors[:2]
         tensors = list(ctx.saved_tensors[2:])
@@ -541,7 +547,13 @@ class BnMlpFn(torch.autograd.Function):
         dtype = cfg[3]
         m, keep = BnMlpFn._c_desc(x, ctx.rz, cfg, ctx.bufs, tensors)
         dev = x.device
-        dy = dy.contiguous()
+        if m.R1 > 0:                                   # the two segments' gradients -> the rows of one [R, out] operand (one launch)
+            od = m.layer[m.nl - 1].out
+            g1 = dys[0] if dys[0] is not None else torch.zeros(m.R1, od, dtype=torch.float32, device=dev)
+            g2 = dys[1] if dys[1] is not None else torch.zeros(m.R - m.R1, od, dtype=torch.float32, device=dev)
+            dy = torch.cat([g1.reshape(m.R1, od), g2.reshape(m.R - m.R1, od)], 0)
+        else:
+            dy = dys[0].contiguous()
         g = _lib.BnMlpGrads()
         grads = [None] * len(tensors)
 
@@ -587,7 +599,9 @@ class BnMlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, row_zero, cfg, bufs, *tensors):
-        training, eps, momentum, dtype, drops = cfg
+        training, eps, momentum, dtype, drops = cfg[:5]
+        if len(cfg) > 5 and cfg[5] is not None and not (_BN_MLP_C_CALL[0] and (len(tensors) - 2) // 4 <= _lib.BN_MLP_MAX_LAYERS):
+            raise _lib.VlnError("MLPwithBN: the two-segment form needs the C-call form of the BN-MLP")
         lib = _lib.load()
         st_ = _lib.raw_stream()
         x = x.detach()
@@ -635,10 +649,11 @@ class BnMlpFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         if ctx.c_call:
-            return BnMlpFn._backward_c(ctx, dy)
-        training, eps, momentum, dtype, drops = ctx.cfg
+            return BnMlpFn._backward_c(ctx, *dys)
+        dy = dys[0]
+        training, eps, momentum, dtype, drops = ctx.cfg[:5]
         lib = _lib.load()
         st_ = _lib.raw_stream()
         nl, rz, bufs = ctx.nl, ctx.rz, ctx.bufs
@@ -704,8 +719,11 @@ def set_bn_mlp_c_call(on: bool):
     _BN_MLP_C_CALL[0] = bool(on)
 
 
-def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors):
-    return BnMlpFn.apply(x, row_zero, (bool(training), float(eps), float(momentum), dtype, tuple(drops)), tuple(bufs), *tensors)
+def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors, seg=None):
+    """seg = (R1, [dropout offset of segment 1 per layer]): rows [0, R1) and [R1, R) are two independent batches (vln_bn_mlp.R1);
+    `row_zero` then covers segment 1's rows and the result is a pair (one output per segment)."""
+    cfg = (bool(training), float(eps), float(momentum), dtype, tuple(drops)) + (((int(seg[0]), tuple(seg[1])),) if seg else ())
+    return BnMlpFn.apply(x, row_zero, cfg, tuple(bufs), *tensors)
 
 
 def _add_n(out, srcs):

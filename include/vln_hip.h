@@ -33,7 +33,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2
 
-int vln_abi_version(void);
+int vln_abi_version(void);     /* 12 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -432,9 +432,16 @@ typedef struct vln_bn_affine { const float* gamma; const float* beta; float* run
 typedef struct vln_bn_mlp_layer {
   const void* w; const void* w_t; const float* w_f32; const float* b;   /* Linear [out, in]: streamed shadow, its transpose, fp32 master (unused), bias (nullable) */
   vln_bn_affine bn; int32_t out, pad_; float p_drop, padf_; uint64_t seed, offset;
+  uint64_t offset2;                                  /* ABI v12: the dropout offset of the SECOND segment's rows (vln_bn_mlp.R1 > 0) */
 } vln_bn_mlp_layer;
 typedef struct vln_bn_mlp {
-  int32_t R, D0, nl, wtype, training, pad_; float eps, momentum;
+  int32_t R, D0, nl, wtype, training;
+  int32_t R1;     /* ABI v12.  > 0: rows [0, R1) and [R1, R) are TWO independent batches (the Self-Monitor projects the previous action, B rows,
+                   * and the candidates, B*C rows, with the same MLP: policy.py:140-149) -- one call: every BatchNorm normalises each
+                   * segment with its own statistics (running statistics updated twice, in order), the Linear layers run over all R rows;
+                   * row_zero then has R - R1 entries (segment 1's rows), each layer's `offset2` is segment 1's dropout offset, and the
+                   * saved statistics hold segment 1's after segment 0's.  Same results as two calls up to summation order. */
+  float eps, momentum;
   vln_bn_affine bn0;
   vln_bn_mlp_layer layer[VLN_BN_MLP_MAX_LAYERS];
   const uint8_t* row_zero;

@@ -75,6 +75,7 @@ def run_monitor(B=128, L=80, T=7, C=8):
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, False, 1, compute_dtype=dt).to(dev).train()
     dec = vln.MonitorDecoder(512, 0.5, L, (128, 1024), F, F, compute_dtype=dt).to(dev).train()
     dec.c_step = not getattr(args, "python_step", False)
+    dec.merge_projections = not getattr(args, "two_bn_mlp_calls", False)
     opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-4)
     clock = None
     if args.graph and dec.c_step and not args.arena:
@@ -263,6 +264,9 @@ def main():
                                                                "instead of one C call each way")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower: eager launches instead of one hipGraph per iteration")
+    ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE", help="(A/B) vln_set_tunable(ID, VALUE) before anything runs")
+    ap.add_argument("--two-bn-mlp-calls", action="store_true", help="monitor: the BN-MLP called twice per step like the reference (A/B) "
+                                                                    "instead of once on both batches (MonitorDecoder.merge_projections)")
     ap.add_argument("--fused-only", action="store_true", help="follower: skip the operator-by-operator A/B run")
     ap.add_argument("--per-step-wgrads", action="store_true", help="monitor / follower: parameter gradients in every step's backward "
                                                                    "(A/B) instead of once per rollout (functional.RolloutWgrads)")
@@ -271,6 +275,10 @@ def main():
     configure(a.steps, a.warmup, a.dtype, a.arena, graph=not a.no_graph)
     args.python_step = a.python_step
     args.per_step_sampler = a.per_step_sampler
+    args.two_bn_mlp_calls = a.two_bn_mlp_calls
+    for tv in a.tunable:
+        tid, val = tv.split("=")
+        vln._lib.check(vln._lib.load().vln_set_tunable(int(tid), int(val)), "vln_set_tunable")
     vln.functional.set_grad_in_place(not a.no_grad_in_place)
     vln.functional.set_rollout_wgrads(not a.per_step_wgrads and not a.no_grad_in_place)
     if a.which in ("monitor", "all"):

@@ -592,3 +592,117 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             assert torch.equal(x, y), f"rollout {rollout} input grad {i}"
     for n in res[1][0][1]:                                      # the second rollout reproduces the first (slots reused correctly)
         assert torch.equal(res[1][0][1][n], res[1][1][1][n]), n
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(128, 1024), (24, 168), (40, 300)], ids=["B128xC8", "one_chunk_each", "ragged_chunks"])
+@pytest.mark.usefixtures("split_wgrads")
+def test_bn_mlp_two_batches_in_one_call_equal_two_calls(vln, cdt, shape):
+    """MLPwithBN.forward_pair (vln_bn_mlp.R1 > 0): the reference projects the previous action (B rows) and the candidates
+    (B*C rows) with the same BN-MLP in two calls (policy.py:140-149); the fused call normalises each batch with its OWN
+    statistics, updates the running statistics twice in that order, and runs the Linear layers once over all rows.  Against
+    the two calls: outputs, running statistics and counters, input-side nothing (features carry no gradient), every parameter
+    gradient -- in training mode with the MLP's dropout on (same masks: offsets consumed in the same order, indexed per batch)
+    and in eval mode."""
+    R1, R2 = shape
+    F, dims = 256, [32, 128]
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.randn(R1, F, generator=g).abs().to(DEV); x2 = torch.randn(R2, F, generator=g).abs().to(DEV)
+    rz = (torch.rand(R2, generator=g) < 0.2).to(DEV)
+    r1 = torch.randn(R1, dims[-1], generator=g).to(DEV); r2 = torch.randn(R2, dims[-1], generator=g).to(DEV)
+    torch.manual_seed(3)
+    from vln_amd.decoders import MLPwithBN
+    make = lambda: MLPwithBN(F, dims, use_bn=True, dropout=0.3, relu=True)
+    sd = {k: v.clone() for k, v in make().state_dict().items()}
+    res = {}
+    for mode in ("two", "pair"):
+        mlp = make(); mlp.load_state_dict(sd); mlp.to(DEV)
+        n_set = 0
+        for m_ in mlp.modules():
+            if hasattr(m_, "compute_dtype"):
+                m_.compute_dtype = cdt; n_set += 1
+        assert n_set >= len(dims)                                 # every Linear streams its weights in `cdt`
+        out = []
+        for training in (True, True, False):                     # two training calls (running statistics move twice), one eval
+            mlp.train(training)
+            for p in mlp.parameters():
+                p.grad = None
+            if mode == "two":
+                y1 = mlp(x1); y2 = mlp(x2, row_zero=rz)
+            else:
+                y1, y2 = mlp.forward_pair(x1, x2, row_zero2=rz)
+            if training:
+                ((y1 * r1).sum() + (y2 * r2).sum()).backward()
+            torch.cuda.synchronize()
+            out.append((y1.detach().clone(), y2.detach().clone(), {n: b.clone() for n, b in mlp.named_buffers()},
+                        {n: p.grad.clone() for n, p in mlp.named_parameters()} if training else {}))
+        res[mode] = out
+    for i, (a, b) in enumerate(zip(res["pair"], res["two"])):
+        check(a[0], b[0], 2e-5, f"call {i} y1"); check(a[1], b[1], 2e-5, f"call {i} y2")
+        assert float(a[1][rz].abs().sum()) == 0.0
+        for n in b[2]:
+            if "num_batches_tracked" in n:
+                assert torch.equal(a[2][n], b[2][n]), n
+            else:
+                check(a[2][n], b[2][n], 2e-5, f"call {i} buffer {n}")
+        gscale = max([v.abs().max().item() for v in b[3].values()] + [1e-30])
+        for n in b[3]:
+            check(a[3][n], b[3][n], 5e-5, f"call {i} grad[{n}]", floor=1e-2 * gscale)
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.usefixtures("split_wgrads")
+def test_monitor_merged_projections_equal_two_bn_mlp_calls(vln, cdt):
+    """MonitorDecoder.merge_projections: the step's two BN-MLP calls as one two-batch call -- logits, progress, state, attention
+    maps, BatchNorm running statistics and every gradient of a three-step chain against the reference's two calls per step
+    (same dropout masks), also with the parameter gradients formed once per rollout (RolloutWgrads: one group less)."""
+    T, B, C, L, H, M, F = 3, 24, 7, 20, 64, 128, 256
+    g = torch.Generator().manual_seed(321)
+    ctx0 = torch.randn(B, L, H, generator=g); h00 = torch.randn(B, H, generator=g) * 0.5; c00 = torch.randn(B, H, generator=g) * 0.5
+    a_prev = torch.randn(B, F, generator=g).abs().to(DEV); cands = [torch.randn(B, C, F, generator=g).abs().to(DEV) for _ in range(T)]
+    lens = torch.randint(5, L + 1, (B,), generator=g); ctx_mask = (torch.arange(L)[None, :] >= lens[:, None]).to(DEV)
+    nc = torch.randint(2, C + 1, (B,), generator=g); cmask = (torch.arange(C)[None, :] >= nc[:, None]).to(DEV)
+    rl = torch.randn(B, C, generator=g).to(DEV); rh = torch.randn(B, H, generator=g).to(DEV); rp = torch.randn(B, generator=g).to(DEV)
+    torch.manual_seed(7)
+    make = lambda: vln.MonitorDecoder(H, 0.5, L, mlp_dims=[32, M], action_embed_size=F, feature_size=F, compute_dtype=cdt)
+    sd = {k: v.clone() for k, v in make().state_dict().items()}
+    F_ = vln.functional
+    res = []
+    try:
+        for merged, rollout_wgrads in ((False, False), (True, False), (True, True)):
+            F_.set_grad_in_place(rollout_wgrads); F_.set_rollout_wgrads(rollout_wgrads)
+            F_.ROLLOUT_WGRADS.stats[:] = [0, 0]
+            dec = make(); dec.load_state_dict(sd); dec.to(DEV).train()
+            dec.merge_projections = merged
+            for p in dec.parameters():
+                p.grad = torch.zeros_like(p)
+            ctx = ctx0.to(DEV).requires_grad_(True); h = h00.to(DEV).requires_grad_(True); c = c00.to(DEV).requires_grad_(True)
+            hh, cc, ap, total, outs = h, c, a_prev, 0.0, []
+            for t in range(T):
+                (logit, prog), (hh, cc), (ww, mw) = dec(None, ap, cands[t], hh, cc, ctx, ctx_mask, cmask)
+                total = total + (logit.masked_fill(cmask, 0.0) * rl).sum() + (prog * rp).sum()
+                outs += [logit, prog, ww, mw]
+                ap = cands[t][:, 0]
+            total = total + (hh * rh).sum() + (cc * rh).sum()
+            total.backward()
+            torch.cuda.synchronize()
+            if rollout_wgrads:
+                assert F_.ROLLOUT_WGRADS.stats == [2 * T, 2], F_.ROLLOUT_WGRADS.stats      # two groups: the step, the ONE BN-MLP call
+            res.append(([o.detach().clone() for o in outs + [hh, cc]], {n: p.grad.clone() for n, p in dec.named_parameters()},
+                        [ctx.grad.clone(), h.grad.clone(), c.grad.clone()], {n: b.clone() for n, b in dec.named_buffers()}))
+    finally:
+        F_.set_rollout_wgrads(False); F_.set_grad_in_place(False)
+    ref = res[0]
+    gscale = max(v.abs().max().item() for v in ref[1].values())
+    for k, got in enumerate(res[1:]):
+        for i, (a, b) in enumerate(zip(got[0], ref[0])):
+            check(a, b, 5e-5, f"variant {k} output {i}")
+        for n in ref[1]:
+            check(got[1][n], ref[1][n], 1e-4, f"variant {k} grad[{n}]", floor=1e-2 * gscale)
+        for i, (a, b) in enumerate(zip(got[2], ref[2])):
+            check(a, b, 1e-4, f"variant {k} input grad {i}")
+        for n in ref[3]:
+            if "num_batches_tracked" in n:
+                assert torch.equal(got[3][n], ref[3][n]), n
+            elif ref[3][n].is_floating_point():
+                check(got[3][n], ref[3][n], 2e-5, f"variant {k} buffer {n}")

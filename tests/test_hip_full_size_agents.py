@@ -94,13 +94,14 @@ MONITOR_BF16_EXC = {"grad[proj_navigable_mlp": 0.6, "grad[visual_attn": 6e-2, "g
 FOLLOWER_BF16_EXC = {"loss": 2e-2}
 
 
-def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176, T=2, fused=True):
+def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176, T=2, fused=True, merged=False):
     from oracle import torch_port as O
     g = torch.Generator().manual_seed(2021)
     torch.manual_seed(2021)
     dec = vln.MonitorDecoder(H, 0.5, L, mlp_dims=[M], action_embed_size=F, feature_size=F, compute_dtype=cdt).to(DEV)
     dec.train(train)
     dec.fused_step = fused
+    dec.merge_projections = merged          # the BN-MLP's two calls per step as ONE two-batch call (MLPwithBN.forward_pair)
     ctx = torch.randn(B, L, H, generator=g) * 0.5
     lens = torch.randint(8, L + 1, (B,), generator=g); lens[0] = L
     ctx_mask = torch.arange(L)[None, :] >= lens[:, None]
@@ -161,13 +162,15 @@ def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176,
         assert int(sd["proj_navigable_mlp.mlp.0.num_batches_tracked"]) == 2 * T
 
 
+@pytest.mark.parametrize("merged", [False, True], ids=["two_bn_mlp_calls", "merged_projections"])
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_monitor_cfg2_full_size_dropout_on(vln, cdt):
-    _monitor_full(vln, cdt, train=True)
+def test_monitor_cfg2_full_size_dropout_on(vln, cdt, merged):
+    _monitor_full(vln, cdt, train=True, merged=merged)
 
 
-def test_monitor_cfg2_full_size_eval(vln):
-    _monitor_full(vln, torch.float32, train=False)
+@pytest.mark.parametrize("merged", [False, True], ids=["two_bn_mlp_calls", "merged_projections"])
+def test_monitor_cfg2_full_size_eval(vln, merged):
+    _monitor_full(vln, torch.float32, train=False, merged=merged)
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])

@@ -111,6 +111,7 @@ def _small_agent(vln, kind, dev, seed):
     if kind == "monitor":
         enc = vln.EncoderLSTM(60, 32, 64, 0, 0.5, False, 1).to(dev).train()
         dec = vln.MonitorDecoder(64, 0.5, L, (32, 128), F, F).to(dev).train()
+        dec.merge_projections = True              # the BN-MLP's two calls per step as one two-batch call
         opts = [vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-3)]
     else:
         enc = vln.EncoderLSTM(60, 32, 64, 0, 0.5, True, 2).to(dev).train()
