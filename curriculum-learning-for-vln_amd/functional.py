@@ -179,6 +179,7 @@ def set_rollout_wgrads(on: bool):
     ROLLOUT_WGRADS.enabled = bool(on)
     if not on:
         ROLLOUT_WGRADS.reset()
+        ROLLOUT_WGRADS.groups.clear()            # give the arenas back
 
 
 def _bn_ws(R, D, dev):
