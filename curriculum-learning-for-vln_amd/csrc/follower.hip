@@ -101,11 +101,14 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   if (!dlogit) { RUN(fill_f32(st, zlogit, (long)B * C, 0.f)); dlogit = zlogit; }
   // (4) scores: logit = context . q + b_out, q = target (.) w_out, context = W_act cands + b_act
   RUN(rows_wsum(st, io->context, W_F32, dlogit, dq, D, B, C, D));
-  RUN(vln_ew(0, dq, D, w->w_out, 0, 0, dtarget, D, B, D, s));
-  RUN(vln_ew(0, dq, D, io->target, D, 0, Zo, D, B, D, s));                          // colsum -> d w_out
+  {   // four independent row-wise forms of dq / d logits in ONE launch (they were four)
+    const EwJob ej[4] = {{0, dq, D, w->w_out, 0, 0, dtarget, D, B, D},
+                         {0, dq, D, io->target, D, 0, Zo, D, B, D},                  // colsum -> d w_out
+                         {3, io->q, D, dlogit, C, C, qs, D, B, D},                   // colsum -> d b_act
+                         {3, nullptr, 0, dlogit, C, C, sl, 1, B, 1}};                // row sums; colsum -> d b_out
+    RUN(ew_multi(st, ej, 4));
+  }
   RUN(rows_wsum(st, io->cands, W_F32, dlogit, rc, A, B, C, A));                     // sum_c dlogit_c cand_c -> d W_act = q^T rc
-  RUN(vln_ew(3, io->q, D, dlogit, C, C, qs, D, B, D, s));                           // colsum -> d b_act
-  RUN(vln_ew(3, nullptr, 0, dlogit, C, C, sl, 1, B, 1, s));                         // row sums; colsum -> d b_out
   RUN(gemm_nt(st, dtarget, D, w->w_hid_t, wt, D, dgr, H, B, H, D, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   // (3) grounded = tanh(W_out tcat)
   RUN(vln_ew(2, dgr, H, io->grounded, H, 0, dz, H, B, H, s));
@@ -137,8 +140,11 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   RUN(rows_wsum(st, io->keys, W_F32, dl_v, dtq, D, B, V, D));
   RUN(vln_ew(3, io->tq, D, dl_v, V, V, tqs, D, B, D, s));                           // colsum -> d b_v (analytically 0: softmax rows)
   RUN(gemm_nt(st, dtq, D, w->w_h_t, wt, D, t2, H, B, H, D, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(vln_add_n(g->dh0, H, B, H, dxcat + A + F, XK, t2, H, nullptr, 0, nullptr, 0, 0, s));
-  if (g->da_prev) RUN(copy_blocks2(st, B, dxcat, XK, g->da_prev, A, A, nullptr, 0, nullptr, 0, 0));
+  {   // d h0 and (optionally) d a_prev, one launch
+    const AddNJob aj[2] = {{g->dh0, H, B, H, 2, {dxcat + A + F, t2, nullptr, nullptr}, {XK, H, 0, 0}},
+                           {g->da_prev, A, B, A, 1, {dxcat, nullptr, nullptr, nullptr}, {XK, 0, 0, 0}}};
+    RUN(add_n_multi(st, aj, g->da_prev ? 2 : 1));
+  }
   // parameter gradients: eight products over the same B rows -> one grouped launch; the biases and the head -> another
   {
     vln_wgrad_job jobs[8];

@@ -166,8 +166,11 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     RUN(lstm_pointwise_bwd(st, a));
   }
   RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> prev | moves | words | h0
-  RUN(vln_add_n(dmoves, M, B, M, dhm + H, H + M, dxcat + M, XK, nullptr, 0, nullptr, 0, 0, s));
-  RUN(vln_add_n(dwords, H, B, H, dtcat, 2 * H, dxcat + 2 * M, XK, nullptr, 0, nullptr, 0, 0, s));
+  {   // d moves and d words: two sums of the same producers, one launch
+    const AddNJob aj[2] = {{dmoves, M, B, M, 2, {dhm + H, dxcat + M, nullptr, nullptr}, {H + M, XK, 0, 0}},
+                           {dwords, H, B, H, 2, {dtcat, dxcat + 2 * M, nullptr, nullptr}, {2 * H, XK, 0, 0}}};
+    RUN(add_n_multi(st, aj, 2));
+  }
   // candidates: d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
   RUN(attn_bwd_rows(st, io->cand_rep, W_F32, io->move_w, dmoves, M, g->dmw_ext, dvq, M, dl_v, io->dots, B, C, M));
   if (g->dcand_rep) {
@@ -190,12 +193,10 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     RUN(attn_dctx_deferred(st, al, dl, gg, H, qq, H, 1, g->dctx, B, L, H, g->dctx_accumulate, ds, dof, dp));
   }
   RUN(gemm_nt(st, dtq, H, w->w_tin_t, wt, H, dh0_t, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(vln_add_n(g->dh0, H, B, H, dhm, H + M, dxcat + 2 * M + H, XK, dh0_v, H, dh0_t, H, 0, s));
-  {
-    CopyJobs j{};
-    j.n = 1; j.rows = B;
-    j.src[0] = dxcat; j.lds[0] = XK; j.dst[0] = g->dprev_rep; j.ldd[0] = M; j.cols[0] = M;
-    RUN(copy_blocks(st, j));
+  {   // d h0 (four contributions) and d prev_rep (a column block of d xcat), one launch
+    const AddNJob aj[2] = {{g->dh0, H, B, H, 4, {dhm, dxcat + 2 * M + H, dh0_v, dh0_t}, {H + M, XK, H, H}},
+                           {g->dprev_rep, M, B, M, 1, {dxcat, nullptr, nullptr, nullptr}, {XK, 0, 0, 0}}};
+    RUN(add_n_multi(st, aj, 2));
   }
   // parameter gradients: six products over the same B rows -> one grouped launch; biases and the head -> another
   {

@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256) void monitor_head_bwd_kernel(MonHeadArgs a) {
 }
 
 struct AddNArgs { const float* src[4]; long ld[4]; int n; float* out; long ldo; int rows, cols, accumulate; };
-__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) {
+__device__ __forceinline__ void add_n_body(const AddNArgs& a) {
   const long total = (long)a.rows * a.cols;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long r = e / a.cols, c = e % a.cols;
@@ -1165,7 +1165,30 @@ __global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) {
     a.out[r * a.ldo + c] = v;
   }
 }
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) { add_n_body(a); }
+// up to 4 independent sums in ONE launch (blockIdx.y = the job; a one-source job is a strided copy): same bits as 4 launches
+struct AddNMulti { AddNArgs j[4]; };
+__global__ __launch_bounds__(256) void add_n_multi_kernel(AddNMulti m) { add_n_body(m.j[blockIdx.y]); }
 }  // namespace vln
+int vln::add_n_multi(hipStream_t st, const AddNJob* jobs, int n) {
+  if (!jobs || n < 1 || n > 4) { set_error("add_n_multi: 1..4 jobs"); return VLN_ERR_ARG; }
+  AddNMulti m{};
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const AddNJob& q = jobs[i];
+    if (!q.out || q.rows <= 0 || q.cols <= 0 || q.n < 1 || q.n > 4) { set_error("add_n_multi: bad job %d", i); return VLN_ERR_ARG; }
+    AddNArgs& a = m.j[i];
+    for (int k = 0; k < 4; ++k) { a.src[k] = k < q.n ? q.src[k] : nullptr; a.ld[k] = k < q.n ? q.ld[k] : 0; if (k < q.n && !q.src[k]) { set_error("add_n_multi: null source"); return VLN_ERR_ARG; } }
+    a.n = q.n; a.out = q.out; a.ldo = q.ldo; a.rows = q.rows; a.cols = q.cols; a.accumulate = 0;
+    const long t = (long)q.rows * q.cols;
+    if (t > most) most = t;
+  }
+  int blocks = (int)((most + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  VLN_LAUNCH(add_n_multi_kernel, dim3(blocks, n), dim3(256), 0, st, m);
+  VLN_CHECK_LAUNCH("add_n_multi");
+  return VLN_OK;
+}
 
 extern "C" int vln_pe_dropout(const float* ctx, const float* pe, float* out, int B, int L, int H, uint64_t seed, uint64_t offset,
                               float p, void* s) {
@@ -1229,8 +1252,15 @@ extern "C" int vln_add_n(float* out, int64_t ldo, int rows, int cols, const floa
 // ---------------------------------------------------------------------------------------------------------------
 namespace vln {
 struct EwArgs { const float* a; long lda; const float* b; long ldb; int nb; float* y; long ldy; int rows, cols, op; };
-__global__ __launch_bounds__(256) void ew_kernel(EwArgs e) {
-  const int r = blockIdx.x;
+__device__ __forceinline__ void ew_row(const EwArgs& e, int r);
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs e) { ew_row(e, (int)blockIdx.x); }
+// up to 4 independent row-wise forms in ONE launch (blockIdx.y = the job): same bits as 4 launches
+struct EwMulti { EwArgs j[4]; };
+__global__ __launch_bounds__(256) void ew_multi_kernel(EwMulti m) {
+  const EwArgs& e = m.j[blockIdx.y];
+  if ((int)blockIdx.x < e.rows) ew_row(e, (int)blockIdx.x);
+}
+__device__ __forceinline__ void ew_row(const EwArgs& e, int r) {
   __shared__ float part[4];
   float rs = 0.f;
   if (e.op == 3) {
@@ -1253,6 +1283,23 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs e) {
   }
 }
 }  // namespace vln
+int vln::ew_multi(hipStream_t st, const EwJob* jobs, int n) {
+  if (!jobs || n < 1 || n > 4) { set_error("ew_multi: 1..4 jobs"); return VLN_ERR_ARG; }
+  EwMulti m{};
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    const EwJob& q = jobs[i];
+    if (!q.y || !q.b || q.rows <= 0 || q.cols <= 0 || q.op < 0 || q.op > 3 || (!q.a && q.op != 3) || (q.op == 3 && q.nb <= 0)) {
+      set_error("ew_multi: bad job %d", i);
+      return VLN_ERR_ARG;
+    }
+    m.j[i] = EwArgs{q.a, q.lda, q.b, q.ldb, q.nb, q.y, q.ldy, q.rows, q.cols, q.op};
+    if (q.rows > rows) rows = q.rows;
+  }
+  VLN_LAUNCH(ew_multi_kernel, dim3(rows, n), dim3(256), 0, st, m);
+  VLN_CHECK_LAUNCH("ew_multi");
+  return VLN_OK;
+}
 extern "C" int vln_ew(int op, const float* a, int64_t lda, const float* b, int64_t ldb, int nb, float* y, int64_t ldy, int rows,
                       int cols, void* s) {
   if (!y || !b || rows <= 0 || cols <= 0 || op < 0 || op > 3 || (!a && op != 3) || (op == 3 && nb <= 0)) {

@@ -74,6 +74,12 @@ int bn_bwd_seg(const float* x, int64_t ldx, const float* dy, int64_t lddy, const
                const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int R1,
                int64_t stat2, int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, uint64_t offset2,
                float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s);
+// up to four row-wise elementwise forms (the ops of vln_ew) in one launch (pointwise.hip)
+struct EwJob { int op; const float* a; long lda; const float* b; long ldb; int nb; float* y; long ldy; int rows, cols; };
+int ew_multi(hipStream_t st, const EwJob* jobs, int n);
+// up to four independent `out = sum of <= 4 strided matrices` in one launch (pointwise.hip)
+struct AddNJob { float* out; long ldo; int rows, cols, n; const float* src[4]; long ld[4]; };
+int add_n_multi(hipStream_t st, const AddNJob* jobs, int n);
 struct GatherCheck;
 GatherCheck gather_check(const void* table);   // features.hip: the registered extent of a feature table (vln_feature_table_extent)
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout
