@@ -990,12 +990,19 @@ def _phase_times(ag, get, steps):
         mark("opt_done")
         return out
 
-    ag.enc.forward, ag.dec.forward, ag.opt.step = enc_w, dec_w, opt_w
+    hook = ag.dec.grads_ready_hook
+
+    def hook_w():                        # fires when the decoder's weight gradients have been issued, before the encoder's backward
+        mark("dec_bwd_done")
+        if hook is not None:
+            hook()
+
+    ag.enc.forward, ag.dec.forward, ag.opt.step, ag.dec.grads_ready_hook = enc_w, dec_w, opt_w, hook_w
     try:
         for k in range(steps + 3):
             ag.iteration(get(k))
     finally:
-        ag.enc.forward, ag.dec.forward, ag.opt.step = enc_fwd, dec_call, opt_step
+        ag.enc.forward, ag.dec.forward, ag.opt.step, ag.dec.grads_ready_hook = enc_fwd, dec_call, opt_step, hook
     torch.cuda.synchronize()
 
     def span(a, b):
@@ -1004,7 +1011,10 @@ def _phase_times(ag, get, steps):
 
     return {"encoder_fwd_us": span("start", "enc_done"), "decoder_fwd_us_per_step": round(span("enc_done", "dec_done") / T, 1),
             "loss_and_backward_us": span("dec_done", "bwd_done"), "clip_and_optimizer_us": span("bwd_done", "opt_done"),
-            "decoder_steps": T, "note": "eager launches; backward = loss + decoder steps + encoder BPTT + weight gradients"}
+            "decoder_bwd_us_per_step": round(span("dec_done", "dec_bwd_done") / T, 1),
+            "encoder_bwd_us": span("dec_bwd_done", "bwd_done"),
+            "decoder_steps": T, "note": "eager launches; backward = loss + decoder steps + encoder BPTT + weight gradients; "
+                                        "decoder_bwd per step includes 1/T of the rollout loss, the logit branch and the decoder's weight gradients"}
 
 
 def secondary_agents(dev, args, which, store):
