@@ -431,30 +431,42 @@ def test_rollout_sampler_long_rollout_chunks(vln):
             s.step(steps[0][0].to(DEV))
 
 
+@pytest.mark.parametrize("variant", ["pipelined", "both_outputs", "thirteen_steps", "per_step_recurrence"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, dtype):
+def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, dtype, variant):
     """EncoderLSTM.forward(ride=store.rollout_ride(...)): the rollout's feature rows gathered by PASSENGER workgroups of the
     persistent recurrence launch are the rows of gather_rollout bit for bit (same Philox offsets), and the encoder's own
-    outputs are untouched by the passengers."""
+    outputs are untouched by the passengers.  Variants: the software-pipelined passenger loop (one output precision); both
+    precisions at once (the plain 8-rows-per-pass passenger loop); 13 steps (more than one argument block holds: the ride runs
+    as its own launch in front of the recurrence); the per-step recurrence (no persistent launch to ride in: the same)."""
     import bench
     dev_ = torch.device(DEV)
+    lib = vln._lib.load()
     torch.manual_seed(11)
-    cpu_tape = bench.make_tape(64, 80, 7, 8, seed=77)
+    T = 13 if variant == "thirteen_steps" else 7
+    cpu_tape = bench.make_tape(64, 80, T, 8, seed=77)
     cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
     tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
     store = tape["store"]
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev_).train()
     steps = [(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]]
     lp = dtype != torch.float32
-    store._calls = 0; enc._calls = 0
-    ref = store.gather_rollout(steps, 0.3, want_bf16=lp, want_f32=not lp)
-    ctx0, h0, c0 = enc(tape["tokens"], tape["lengths32"])
-    store._calls = 0; enc._calls = 0
-    ride = store.rollout_ride(steps, 0.3, want_bf16=lp, want_f32=not lp)
-    ctx1, h1, c1 = enc(tape["tokens"], tape["lengths32"], ride=ride)
-    torch.cuda.synchronize()
-    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    want = dict(want_bf16=True, want_f32=True) if variant == "both_outputs" else dict(want_bf16=lp, want_f32=not lp)
+    try:
+        if variant == "per_step_recurrence":
+            lib.vln_set_persistent(0)
+        store._calls = 0; enc._calls = 0
+        ref = store.gather_rollout(steps, 0.3, **want)
+        ctx0, h0, c0 = enc(tape["tokens"], tape["lengths32"])
+        store._calls = 0; enc._calls = 0
+        ride = store.rollout_ride(steps, 0.3, **want)
+        ctx1, h1, c1 = enc(tape["tokens"], tape["lengths32"], ride=ride)
+        torch.cuda.synchronize()
+    finally:
+        lib.vln_set_persistent(1)
+    vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
     assert torch.equal(ctx0, ctx1) and torch.equal(h0, h1) and torch.equal(c0, c1)
+    assert len(ride.outputs) == T
     for (a_img, a_cand), (b_img, b_cand) in zip(ref, ride.outputs):
         for x, y in list(zip(a_img, b_img)) + list(zip(a_cand, b_cand)):
             assert (x is None) == (y is None)
