@@ -550,6 +550,8 @@ def main():
                     help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
                          "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
                          "boundary inside this very graph (rocprofv3 reports a ~4.7 us floor for ANY short kernel; unprofiled: 1.95 us)")
+    ap.add_argument("--inject-capture-failure", action="store_true",
+                    help="(test) make the whole-iteration graph capture fail: the run must fall back to eager launches and say so")
     ap.add_argument("--inject-timeout", type=int, default=0, metavar="K",
                     help="(test) raise the sticky timeout word before untimed iteration K, as a persistent recurrence whose "
                          "workgroups were not co-resident would: exercises the fallback to per-step launches")
@@ -709,15 +711,25 @@ def main():
     if use_graph:
         tg = time.perf_counter()
         try:
+            if args.inject_capture_failure:
+                raise RuntimeError("injected capture failure (--inject-capture-failure)")
             agent.capture(live.live)
         except vln.VlnError as e:                  # a timeout in the four iterations above: recorded after the fallback below
             if "timed out" not in str(e):
                 raise
             raised[0] = 1
+        except Exception as e:                     # noqa: BLE001 -- stream capture itself failed on this box / runtime: the bench
+            # line is still owed.  The eager path (per-step graphs, same kernels, same results) is what runs instead, and the
+            # JSON line says so (config.iteration_graph false).
+            print(f"[bench] the iteration could not be captured as a hipGraph ({type(e).__name__}: {e}); eager launches instead",
+                  file=sys.stderr, flush=True)
+            agent.graph = None
+            use_graph = False
+            torch.cuda.synchronize()
         for _ in range(2):
             warm_iterate()
         torch.cuda.synchronize()
-        if rank == 0:
+        if rank == 0 and use_graph:
             print(f"[bench] iteration captured as one hipGraph: {(time.perf_counter() - tg) * 1e3:.0f} ms", file=sys.stderr, flush=True)
     # Python's cyclic GC: a full pass over the (static) module/object graph costs tens of ms and would land in the
     # timed region at random; collect now and move the survivors out of the collector's reach.  (Before the warm-up

@@ -261,3 +261,17 @@ def test_replay_reports_what_an_earlier_replay_raised_on_the_device(vln):
         ag.replay()
     lib.vln_set_persistent(1)                        # (the report switched this process to per-step launches)
     vln._lib.check(lib.vln_persistent_check(), "clean again")
+
+
+def test_bench_survives_a_failed_graph_capture():
+    """If stream capture of the iteration fails on some box or runtime, the bench line is still owed: eager launches (per-step
+    graphs, the same kernels) run instead and the JSON says so."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--no-secondary", "--no-roofline",
+                          "--no-cpu-baseline", "--viewpoints", "400", "--inject-capture-failure"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "could not be captured" in out.stderr
+    rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["config"]["iteration_graph"] is False and rep["ms_per_step"] > 0
