@@ -830,8 +830,8 @@ def main():
         for name, fn in (("eager_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args)),
                          ("dropin_unchanged_caller_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "tensor", args, dropin=True)),
                          ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
-                         ("fp32_query_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
-                                                                                      fp32_weights=("w_vin", "w_tin"))),
+                         ("all_bf16_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
+                                                                                    fp32_weights=())),
                          ("decoder_step_fwd_bwd", per_step),
                          ("phases", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, phases=True)),
                          ("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args, graph=use_graph)),
@@ -840,8 +840,11 @@ def main():
                              vln, dev, store, [make_tape(128, args.L, args.T, 8, seed=4040 + k, n_rows=store.N) for k in range(4)],
                              dtype, "store", args, graph=use_graph)),
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
-                         ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store)),
-                         ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store))):
+                         # BASELINE config 2 does not ask for bf16: the Self-Monitor's figure is the fp32 one; bf16 beside it
+                         ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store, dtype="fp32")),
+                         ("self_monitor_B128_bf16", lambda: secondary_agents(dev, args, "monitor", store, dtype="bf16")),
+                         ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store, dtype="bf16")),
+                         ("speaker_follower_B64_fp32", lambda: secondary_agents(dev, args, "follower", store, dtype="fp32"))):
             t1 = time.perf_counter()
             try:
                 secondary[name] = fn()
@@ -915,7 +918,7 @@ def pmc_figures(kernel, dtype):
 
 
 def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,
-                      wgrad=None, phases=False, fp32_weights=()):
+                      wgrad=None, phases=False, fp32_weights=None):
     """ms per iteration of the headline workload under another precision / feature path / caller (own agent, own arena).
     graph: the whole iteration as one hipGraph (store features only).  dropin: the reference's UNCHANGED caller -- feature
     tensors handed in every step, `logits.masked_fill_` + per-step cross entropy (envdrop.py:173-179), no arena, no deferred
@@ -929,7 +932,7 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
         ag = GpuAgent(vln, dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
         ag.clear_grads_in_step = True
         ag.ride_gather = features == "store" and args.ride_gather != "off" and not args.rollout_gather
-        if fp32_weights:
+        if fp32_weights is not None:       # None: the module's default (the two attention query projections in fp32)
             ag.dec.fp32_weights = frozenset(fp32_weights)
         if features == "store":
             st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
@@ -1029,12 +1032,12 @@ def _phase_times(ag, get, steps):
                                         "decoder_bwd per step includes 1/T of the rollout loss, the logit branch and the decoder's weight gradients"}
 
 
-def secondary_agents(dev, args, which, store):
+def secondary_agents(dev, args, which, store, dtype=None):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import bench_agents as W
     # warm-up: the first iterations of a workload in a process grow the allocator's pools and load its kernels' code objects;
     # with 8 of them the Self-Monitor number read 5.7 ms against 5.05 ms for a second run in the same process
-    W.configure(steps=20, warmup=30, dtype=args.dtype, arena=False, device=dev)
+    W.configure(steps=20, warmup=30, dtype=dtype or args.dtype, arena=False, device=dev)
     W.vln.functional.set_grad_in_place(True)
     W.vln.functional.set_rollout_wgrads(which in ("monitor", "follower"))     # parameter gradients once per rollout (functional.RolloutWgrads)
     import gc
@@ -1046,7 +1049,7 @@ def secondary_agents(dev, args, which, store):
         W.vln.functional.set_rollout_wgrads(False)
         W.vln.functional.set_grad_in_place(False)
         gc.unfreeze()
-    return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"]}
+    return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"], "dtype": r.get("dtype")}
 
 
 if __name__ == "__main__":

@@ -106,7 +106,7 @@ class MonitorDims(C.Structure):
 
 class MonitorWeights(C.Structure):
     _fields_ = [(n, ptr) for n in ("w_tin", "w_tin_t", "w_vh", "w_vh_t", "b_vh", "w_cat", "w_cat_t", "b_ih", "b_hh", "w_a", "w_a_t",
-                                   "b_a", "w_m", "w_m_t", "b_m", "w_c", "b_c", "pe")]
+                                   "b_a", "w_m", "w_m_t", "b_m", "w_c", "b_c", "pe")] + [("f32_mask", i32), ("pad_", i32)]
 
 
 class MonitorStep(C.Structure):
@@ -275,6 +275,8 @@ SIGNATURES = {
     "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
+    "vln_set_split_attention": (i32, [i32]),
+    "vln_get_split_attention": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),
     "vln_follower_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
@@ -290,7 +292,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 12
+EXPECTED_ABI = 13
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void attn_split_kernel(AttnFusedArgs a, AttnSp
 // Returns true when a split configuration covers (ctype, S, D), the four workgroups of every row are co-resident and the
 // pointers are aligned; the launch is then issued.
 static bool attn_split_try(hipStream_t st, int ctype, const AttnFusedArgs& a, int B, bool bwd, void* sync, long sync_bytes, int cus) {
-  if (!sync || g_tunable[4] == 2) return false;                 // tunable[4] = 2: one workgroup per row (A/B)
+  if (!sync || g_tunable[4] == 2 || !g_split_attn_enabled) return false;     // tunable[4] = 2: one workgroup per row (A/B); the flag: off after a timeout
   const int V = (ctype == W_BF16) ? 8 : 4;
   const int S = a.S, D = a.D;
   if (S > kSplitSMax || D % (V * kSplitNS) != 0 || B * kSplitNS > cus || sync_bytes < attn_split_sync_bytes(B) || !aligned16(sync) ||
@@ -262,7 +262,7 @@ static bool attn_split_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
       (((long)D / kSplitNS) & 3) || (a.vec_out && (!aligned16(a.vec_out) || (a.ldvo & 3)))) return false;
   unsigned* sticky = sticky_dev_word();
   if (!sticky) return false;
-  AttnSplitSync sy{reinterpret_cast<unsigned*>(sync), static_cast<unsigned char*>(sync) + (long)B * 64, sticky};
+  AttnSplitSync sy{reinterpret_cast<unsigned*>(sync), static_cast<unsigned char*>(sync) + (long)B * 64, sticky + 2};   // word 2: its own report
   const int nseg_p = D / V / kSplitNS;
   const dim3 grid(((B + 7) / 8) * 8 * kSplitNS), block(512);
   const double bytes = (double)B * S * D * (ctype == W_BF16 ? 2 : 4) + 8.0 * B * D + 8.0 * B * S;

@@ -615,6 +615,7 @@ static int lstm_seq_fwd_issue(hipStream_t st, const float* xproj, const void* w_
 // (granules) -- its hand-off is a PARTIAL-SUM exchange of 32 KB per workgroup per step, and doubling those bytes with tags
 // costs more than the removed drain + barrier + atomic.  All variants produce identical bits.
 int g_persist_enabled = 1;
+int vln::g_split_attn_enabled = 1;       // cleared when a four-workgroup attention exchange timed out (attention_split.h reads it)
 // Which sync workspaces hold a header that the counter-protocol backward left CLEAN (group counters zero: it resets them
 // itself).  Anything else -- a buffer this process has not launched on yet (the caller may not have zeroed it), a header the
 // counter-protocol FORWARD or a mode switch touched -- gets the fill launch in front of the next counter-protocol backward.
@@ -680,8 +681,8 @@ unsigned* vln::sticky_dev_word() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
   return g_sticky_dev + dev * 16;
 }
-extern "C" int vln_debug_raise_sticky(int word) {      // test hook: what a timed-out wait (0) / a bad gather index (1) leaves behind
-  if (word < 0 || word > 1 || !sticky_dev_word()) { set_error("vln_debug_raise_sticky: bad word / no host-mapped status line"); return VLN_ERR_ARG; }
+extern "C" int vln_debug_raise_sticky(int word) {      // test hook: what a timed-out recurrence wait (0) / a bad gather index (1) / a timed-out attention exchange (2) leaves behind
+  if (word < 0 || word > 2 || !sticky_dev_word()) { set_error("vln_debug_raise_sticky: bad word / no host-mapped status line"); return VLN_ERR_ARG; }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return VLN_ERR_HIP; }
   __atomic_fetch_add(&g_sticky_host[dev * 16 + word], 1u, __ATOMIC_RELAXED);
@@ -706,9 +707,19 @@ extern "C" int vln_persistent_check(void) {
                 "are invalid", n, d);
       return VLN_ERR_ARG;
     }
+    if (__atomic_load_n(&h[d * 16 + 2], __ATOMIC_RELAXED)) {
+      const unsigned n = __atomic_exchange_n(&h[d * 16 + 2], 0u, __ATOMIC_RELAXED);
+      g_split_attn_enabled = 0;
+      set_error("%u bounded in-kernel wait(s) timed out on device %d in an EARLIER launch (four-workgroup attention: the "
+                "partial-dot exchange of a batch row never completed); that iteration's numbers are invalid.  The split "
+                "attention is now off for this process (one workgroup per batch row)", n, d);
+      return VLN_ERR_HIP;
+    }
   }
   return VLN_OK;
 }
+extern "C" int vln_set_split_attention(int on) { g_split_attn_enabled = on ? 1 : 0; return VLN_OK; }
+extern "C" int vln_get_split_attention(void) { return g_split_attn_enabled; }
 
 static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
   if (!g_persist_enabled || !sync_ws) return false;
@@ -814,6 +825,22 @@ static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long g
   return VLN_OK;
 }
 
+// Passenger workgroups a recurrence launch of `nrec` workgroups can carry: the CUs it leaves idle (at most as many as it has
+// workgroups itself), and only on a device whose workgroups may claim kRideLdsClaim bytes of dynamic LDS (the claim keeps the
+// launch at one workgroup per CU).  0 = the gather must be its own launch: the CALLER decides before it commits to passengers.
+static constexpr unsigned kRideLdsClaim = 96u * 1024u;
+static int ride_passengers(int nrec) {
+  static const int max_lds = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return v;
+  }();
+  if (max_lds < (int)(kRideLdsClaim + 24u * 1024u)) return 0;
+  int np = device_cus() - nrec;
+  if (np > nrec) np = nrec;
+  return np >= 8 ? np : 0;
+}
+
 template <typename TW>
 static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
                                 const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride) {
@@ -828,17 +855,19 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
   if (ride) {
     // passengers on the CUs the recurrence leaves idle (at most as many as it has workgroups); 96 KB of dynamic LDS on top of
     // the kernel's own ~20 KB: ONE workgroup per compute unit, so the two kinds never share a CU
-    int np = device_cus() - nrec;
-    if (np > nrec) np = nrec;
-    if (np >= 8) { g1.x += (unsigned)np; lds_claim = 96u * 1024u; }
-    else ride = nullptr;
+    const int np = ride_passengers(nrec);
+    if (np <= 0) { set_error("persistent lstm fwd: a gather ride was handed to a launch with no room for passengers (caller must check ride_passengers)"); return VLN_ERR_ARG; }
+    g1.x += (unsigned)np; lds_claim = kRideLdsClaim;
   }
   const GatherRolloutArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_GF(NS_)                                                                                               \
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    if (lds_claim) { static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess; (void)ok; } \
+    if (lds_claim) {                                                                                                      \
+      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
+      if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
+    }                                                                                                                     \
     VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd); \
   }                                                                                                                       \
   break
@@ -905,7 +934,9 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     GatherRolloutArgs ride_args{};
     const GatherRolloutArgs* riders = nullptr;
     if (ride) {
-      if (fwd_granules() && ride->T <= kGatherMaxSteps && g_tunable[6] != 3) {      // tunable[6] = 3: never as passengers (A/B)
+      // passengers need idle CUs (B = 128 with two directions of 256 units fills all 256) and the 96 KB dynamic-LDS claim
+      if (fwd_granules() && ride->T <= kGatherMaxSteps && g_tunable[6] != 3 &&       // tunable[6] = 3: never as passengers (A/B)
+          ride_passengers((int)(grid.x * grid.y * grid.z)) > 0) {
         r = gather_ride_args(*ride, 0, &ride_args); if (r) return r;
         riders = &ride_args;
       } else {

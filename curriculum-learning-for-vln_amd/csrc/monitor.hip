@@ -90,7 +90,8 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
   }
   DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
-  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
+  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H;
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };     // per-matrix fp32 override
   // (1) positioned, dropped context (fresh mask per step, units.py:205-207)
   RUN(vln_pe_dropout(io->ctx, w->pe, io->pctx, B, L, H, io->seed_pe, io->off_pe, io->p_pe, s));
   // (2) the row blocks that need no computing: xcat = [prev_rep | . | . | h0], hm = [h0 | .]
@@ -103,13 +104,13 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     RUN(copy_blocks(st, j));
   }
   // (3) text attention over the positioned context, weighted context straight into its xcat block
-  RUN(gemm_nt(st, io->h0, H, w->w_tin, wt, H, io->tq, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, io->h0, H, w->w_tin, wt(0), H, io->tq, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(attn_fwd_rows(st, io->pctx, W_F32, io->tq, H, io->ctx_mask, io->word_w, io->xcat + 2 * M, XK, io->dots, B, L, H));
   // (4) attention over the projected candidates (padded slots masked)
-  RUN(gemm_nt(st, io->h0, H, w->w_vh, wt, H, io->vq, M, B, M, H, w->b_vh, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, io->h0, H, w->w_vh, wt(1), H, io->vq, M, B, M, H, w->b_vh, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(attn_fwd_rows(st, io->cand_rep, W_F32, io->vq, M, io->cand_mask, io->move_w, io->xcat + M, XK, io->dots, B, C, M));
   // (5) LSTM cell on [prev_rep | moves | words | h0]; drop(h1) lands in its tcat block
-  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt(2), XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   {
     LstmPwFwd a{};
     a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
@@ -125,10 +126,10 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     RUN(copy_blocks(st, j));
   }
   // (6) action logits
-  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_a, wt, 2 * H, io->aq, M, B, M, 2 * H, w->b_a, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_a, wt(3), 2 * H, io->aq, M, B, M, 2 * H, w->b_a, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(attn_dot(st, io->cand_rep, W_F32, io->aq, M, io->logit, B, C, M));
   // (7) progress monitor
-  RUN(gemm_nt(st, io->hm, H + M, w->w_m, wt, H + M, io->mg, H, B, H, H + M, w->b_m, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, io->hm, H + M, w->w_m, wt(4), H + M, io->mg, H, B, H, H + M, w->b_m, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(vln_monitor_head_fwd(io->mg, io->c1, io->word_w, w->w_c, w->b_c, io->mem, io->prog, B, L, H, io->seed, io->off_mem, io->p_drop, s));
   return VLN_OK;
 }
@@ -140,7 +141,8 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   if (g->scratch_floats < vln_monitor_bwd_scratch_floats(d)) { set_error("vln_monitor_step_bwd: scratch too small"); return VLN_ERR_ARG; }
   DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
-  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H, wt = d->wtype;
+  const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H;
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };
   float* q = g->scratch;
   auto take = [&](long k) { float* p = q; q += (k + 63) & ~63L; return p; };
   float *dmg = take((long)B * H), *dc1_t = take((long)B * H), *dww = take((long)B * L), *Z = take((long)B * (L + H)), *dpre = take(B);
@@ -151,12 +153,12 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   // progress head (policy.py:126-130)
   RUN(vln_monitor_head_bwd(io->mg, io->c1, io->word_w, w->w_c, io->mem, io->prog, g->dprog, g->dc1, g->dww_ext, dmg, dc1_t, dww, Z,
                            dpre, B, L, H, io->seed, io->off_mem, io->p_drop, s));
-  RUN(gemm_nt(st, dmg, H, w->w_m_t, wt, H, dhm, H + M, B, H + M, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> h0 | moves
+  RUN(gemm_nt(st, dmg, H, w->w_m_t, wt(4), H, dhm, H + M, B, H + M, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> h0 | moves
   // action logits (policy.py:108-117): logit = cand_rep . aq
   const float* dlogit = g->dlogit;
   if (!dlogit) { RUN(fill_f32(st, zlogit, (long)B * C, 0.f)); dlogit = zlogit; }
   RUN(rows_wsum(st, io->cand_rep, W_F32, dlogit, daq, M, B, C, M));
-  RUN(gemm_nt(st, daq, M, w->w_a_t, wt, M, dtcat, 2 * H, B, 2 * H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));  // -> words | drop(h1)
+  RUN(gemm_nt(st, daq, M, w->w_a_t, wt(3), M, dtcat, 2 * H, B, 2 * H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));  // -> words | drop(h1)
   // LSTM cell
   {
     LstmPwBwd a{};
@@ -165,7 +167,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));
   }
-  RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> prev | moves | words | h0
+  RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt(2), 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> prev | moves | words | h0
   {   // d moves and d words: two sums of the same producers, one launch
     const AddNJob aj[2] = {{dmoves, M, B, M, 2, {dhm + H, dxcat + M, nullptr, nullptr}, {H + M, XK, 0, 0}},
                            {dwords, H, B, H, 2, {dtcat, dxcat + 2 * M, nullptr, nullptr}, {2 * H, XK, 0, 0}}};
@@ -180,7 +182,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     const float* qq[2] = {io->vq, nullptr};
     RUN(attn_dctx_deferred(st, al, dl, gg, M, qq, M, 2, g->dcand_rep, B, C, M, 0));
   }
-  RUN(gemm_nt(st, dvq, M, w->w_vh_t, wt, M, dh0_v, H, B, H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, dvq, M, w->w_vh_t, wt(1), M, dh0_v, H, B, H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   // words: d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's pe-dropout mask
   RUN(attn_bwd_rows(st, io->pctx, W_F32, io->word_w, dwords, H, dww, dtq, H, dl_t, io->dots, B, L, H));
   if (g->dctx) {
@@ -192,7 +194,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     const float dp[1] = {io->p_pe};
     RUN(attn_dctx_deferred(st, al, dl, gg, H, qq, H, 1, g->dctx, B, L, H, g->dctx_accumulate, ds, dof, dp));
   }
-  RUN(gemm_nt(st, dtq, H, w->w_tin_t, wt, H, dh0_t, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt(st, dtq, H, w->w_tin_t, wt(0), H, dh0_t, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   {   // d h0 (four contributions) and d prev_rep (a column block of d xcat), one launch
     const AddNJob aj[2] = {{g->dh0, H, B, H, 4, {dhm, dxcat + 2 * M + H, dh0_v, dh0_t}, {H + M, XK, H, H}},
                            {g->dprev_rep, M, B, M, 1, {dxcat, nullptr, nullptr, nullptr}, {XK, 0, 0, 0}}};

@@ -82,6 +82,7 @@ struct AddNJob { float* out; long ldo; int rows, cols, n; const float* src[4]; l
 int add_n_multi(hipStream_t st, const AddNJob* jobs, int n);
 struct GatherCheck;
 GatherCheck gather_check(const void* table);   // features.hip: the registered extent of a feature table (vln_feature_table_extent)
+extern int g_split_attn_enabled;  // encoder.hip: 0 after a four-workgroup attention exchange timed out (vln_persistent_check)
 unsigned* sticky_dev_word();      // encoder.hip: host-mapped word of the current device that bounded waits raise on a timeout
 int device_cus();                 // encoder.hip: CU count of the current device (queried once), 0 if unknown
 // every launch in the library goes through launch_timed or VLN_LAUNCH

@@ -326,7 +326,12 @@ class MLPwithBN(nn.Module):
 
 
 class MonitorDecoder(nn.Module, _Seeded):
-    """policy.py:67-166 (co-grounding + progress monitor)."""
+    """policy.py:67-166 (co-grounding + progress monitor).  BASELINE config 2 does not ask for bf16: the default compute dtype is
+    fp32.  `compute_dtype=torch.bfloat16` streams bf16 shadows of the weight matrices (activations stay fp32) EXCEPT the ones
+    named in `fp32_weights` (of "mlp" = the BN-MLP's Linear layers, "w_tin", "w_vh", "w_cat" = [lstm.weight_ih | weight_hh],
+    "w_a" = action_linear, "w_m" = monitor_linear)."""
+    # Class-wide default of `fp32_weights`, decided by measurement (scripts/bf16_exceptions_ab.py, profiles/round4_notes.md)
+    default_fp32_weights = frozenset()
 
     def __init__(self, rnn_hidden_size, drop_ratio, max_enc_len, mlp_dims=(128, 1024), action_embed_size=2048 + 128,
                  feature_size=2048 + 128, compute_dtype=torch.float32):
@@ -349,25 +354,45 @@ class MonitorDecoder(nn.Module, _Seeded):
         self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
         self.c_step = True                # the fused node as ONE C call each way (csrc/monitor.hip); False: launches driven from Python
         self.merge_projections = False    # True: the BN-MLP's two calls per step as one two-batch call (MLPwithBN.forward_pair)
+        self.fp32_weights = frozenset(type(self).default_fp32_weights)
         self.set_compute_dtype(compute_dtype)
 
-    def set_compute_dtype(self, dt):
+    def set_compute_dtype(self, dt, fp32_weights=None):
         self.compute_dtype = dt
+        if fp32_weights is not None:
+            self.fp32_weights = frozenset(fp32_weights)
+        unknown = self.fp32_weights - {"mlp", "w_tin", "w_vh", "w_cat", "w_a", "w_m"}
+        if unknown:
+            raise ValueError(f"MonitorDecoder.fp32_weights: unknown matrix name(s) {sorted(unknown)}")
         for m in self.modules():
             if m is not self and hasattr(m, "compute_dtype"):
                 m.compute_dtype = dt
+        self.text_attn.compute_dtype = self._wd("w_tin")
+        self.visual_attn.compute_dtype = self._wd("w_vh")
+        for m in self.proj_navigable_mlp.modules():
+            if isinstance(m, _HipLinear):
+                m.compute_dtype = self._wd("mlp")
+
+    def _wd(self, name):
+        return torch.float32 if name in self.fp32_weights else self.compute_dtype
+
+    def _node_dtype(self):
+        """what the fused step nodes get as `dtype`: the compute dtype, or (compute dtype, fp32 names) when an override is active"""
+        if self.compute_dtype == torch.float32 or not (self.fp32_weights - {"mlp"}):
+            return self.compute_dtype
+        return (self.compute_dtype, self.fp32_weights)
 
     def policy_net(self, weighted_ctx, hidden, cands_rep):
         """logit[b,c] = cands_rep[b,c,:] . W_a [weighted_ctx ; hidden]      (policy.py:108-117)"""
         query = Fh.linear(torch.cat((weighted_ctx, hidden), 1), self.action_linear.weight, self.action_linear.bias,
-                          ops.ACT_NONE, self.compute_dtype)
+                          ops.ACT_NONE, self._wd("w_a"))
         return Fh.AttnDotFn.apply(cands_rep, query)
 
     def progress_monitor(self, h_0, c_1, weighted_cands, ctx_attn, site=None):
         """tanh(W_c [ctx_attn ; drop(sigmoid(W_m [h_0 ; weighted_cands]) * tanh(c_1))])      (policy.py:119-130)"""
         site = self._next() if site is None else site
         gate = Fh.linear(torch.cat((h_0, weighted_cands), 1), self.monitor_linear.weight, self.monitor_linear.bias,
-                         ops.ACT_NONE, self.compute_dtype)
+                         ops.ACT_NONE, self._wd("w_m"))
         mem = Fh.dropout(torch.sigmoid(gate) * torch.tanh(c_1), self.drop_ratio, self.training, self.dropout_seed, site)
         head = self.critic[0]
         return Fh.linear(torch.cat((ctx_attn, mem), 1), head.weight, head.bias, ops.ACT_TANH, torch.float32).squeeze()
@@ -392,7 +417,7 @@ class MonitorDecoder(nn.Module, _Seeded):
                 and ctx_mask is not None and candidate_mask is not None:
             # everything after the BN-MLP as ONE autograd node (functional.MonitorCoreFn)
             pos = self.position
-            cfg = (self.training, self.compute_dtype, pos.p, (pos.dropout_seed, pos._next()), self.drop_ratio, self.dropout_seed,
+            cfg = (self.training, self._node_dtype(), pos.p, (pos.dropout_seed, pos._next()), self.drop_ratio, self.dropout_seed,
                    site, site + 1)
             if self._drop_base() is not None:
                 if not self.c_step:
@@ -412,7 +437,7 @@ class MonitorDecoder(nn.Module, _Seeded):
         words, word_w = self.text_attn(h_0, self.position(ctx), ctx_mask)
         moves, move_w = self.visual_attn(h_0, cand_rep, candidate_mask)
         h_new, c_new = Fh.LSTMCellFn.apply(torch.cat((prev_rep, moves, words), 1), h_0, c_0, self.lstm.weight_ih,
-                                           self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh, self.compute_dtype)
+                                           self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh, self._wd("w_cat"))
         logit = self.policy_net(words, Fh.dropout(h_new, self.drop_ratio, self.training, self.dropout_seed, site), cand_rep)
         progress = self.progress_monitor(h_0, c_new, moves, word_w, site + 1)
         return (logit, progress), (h_new, c_new), (word_w, move_w)

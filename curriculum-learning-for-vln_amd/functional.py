@@ -42,6 +42,19 @@ class _ShadowCache:
 SHADOWS = _ShadowCache()
 
 
+def wdtype(dtype, name):
+    """Streaming dtype of the weight matrix `name` of a fused node.  `dtype` is the node's compute dtype, or a pair
+    (compute dtype, frozenset of matrix names that are streamed in fp32 all the same) -- the per-matrix override of the bf16 mode
+    (MonitorDecoder.fp32_weights; EnvDropDecoder.fp32_weights is the same idea on its own struct)."""
+    if isinstance(dtype, tuple):
+        return torch.float32 if name in dtype[1] else dtype[0]
+    return dtype
+
+
+def base_dtype(dtype):
+    return dtype[0] if isinstance(dtype, tuple) else dtype
+
+
 # ---- parameter gradients of the fused nodes: returned to autograd (default) or added straight into p.grad ---------------
 _GRAD_IN_PLACE = [False]
 GRAD_IN_PLACE_STATS = [0, 0]            # [gradients added in place, gradients returned to autograd] (diagnostic)
@@ -665,7 +678,7 @@ class BnMlpFn(torch.autograd.Function):
         R = x.shape[0]
         dev = x.device
         grads = [None] * len(tensors)
-        wb = ops.WgradBatch(dtype != torch.float32)
+        wb = ops.WgradBatch(dtype != torch.float32, never_plain=True)     # behind a BatchNorm: split operands (csrc/bn_mlp.hip)
         cb = ops.ColsumBatch()
 
         def bn_bwd(inp, dyy, yy, w, stats, buf, relu, drop, rzp, want_dx, gi):
@@ -769,23 +782,23 @@ class MonitorCoreFn(torch.autograd.Function):
         if rc:
             _lib.check(rc, "vln_pe_dropout")
         xcat = ops.empty(B, XK, dtype=f32, device=dev)          # [prev_rep | moves | words | h0]: the LSTM input row
-        tq = ops.linear_fwd(h0, SHADOWS.get(W_tin, "n", dtype))
+        tq = ops.linear_fwd(h0, SHADOWS.get(W_tin, "n", wdtype(dtype, "w_tin")))
         _, word_w = ops.attn_fwd_rows(pctx, tq, ctx_mask, out=xcat[:, 2 * M:2 * M + H])
-        vq = ops.linear_fwd(h0, SHADOWS.get(W_vh, "n", dtype), b_vh.detach())
+        vq = ops.linear_fwd(h0, SHADOWS.get(W_vh, "n", wdtype(dtype, "w_vh")), b_vh.detach())
         _, move_w = ops.attn_fwd_rows(cand_rep, vq, cand_mask, out=xcat[:, M:2 * M])
         xcat[:, :M].copy_(prev_rep)
         xcat[:, 2 * M + H:].copy_(h0)
-        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, dtype, False))
+        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), False))
         h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off_h1, pd, True)
         tcat = ops.empty(B, 2 * H, dtype=f32, device=dev)        # [words | drop(h1)]
         tcat[:, :H].copy_(xcat[:, 2 * M:2 * M + H])
         tcat[:, H:].copy_(hd)
-        aq = ops.linear_fwd(tcat, SHADOWS.get(W_a, "n", dtype), b_a.detach())
+        aq = ops.linear_fwd(tcat, SHADOWS.get(W_a, "n", wdtype(dtype, "w_a")), b_a.detach())
         logit = ops.attn_dot(cand_rep, aq)
         hm = ops.empty(B, H + M, dtype=f32, device=dev)          # [h0 | moves]
         hm[:, :H].copy_(h0)
         hm[:, H:].copy_(xcat[:, M:2 * M])
-        mg = ops.linear_fwd(hm, SHADOWS.get(W_m, "n", dtype), b_m.detach())
+        mg = ops.linear_fwd(hm, SHADOWS.get(W_m, "n", wdtype(dtype, "w_m")), b_m.detach())
         mem = ops.empty(B, H, dtype=f32, device=dev)
         prog = ops.empty(B, dtype=f32, device=dev)
         wc = W_c.detach().reshape(-1)
@@ -821,15 +834,15 @@ class MonitorCoreFn(torch.autograd.Function):
                                       _p(dc1_t), _p(dww), _p(Z), _p(dpre), B, L, H, seed, off_mem, pd, st_)
         if rc:
             _lib.check(rc, "vln_monitor_head_bwd")
-        dhm = ops.linear_fwd(dmg, SHADOWS.get(W_m, "t", dtype))                          # [B, H+M] -> h0 | moves
+        dhm = ops.linear_fwd(dmg, SHADOWS.get(W_m, "t", wdtype(dtype, "w_m")))                          # [B, H+M] -> h0 | moves
         # action logits (policy.py:108-117): logit = cand_rep . aq
         if dlogit is None:
             dlogit = torch.zeros(B, C, dtype=f32, device=dev)
         daq = ops.rows_wsum(cand_rep, dlogit)
-        dtcat = ops.linear_fwd(daq, SHADOWS.get(W_a, "t", dtype))                        # [B, 2H] -> words | drop(h1)
+        dtcat = ops.linear_fwd(daq, SHADOWS.get(W_a, "t", wdtype(dtype, "w_a")))                        # [B, 2H] -> words | drop(h1)
         # LSTM cell
         dg, dc0 = ops.lstm_pointwise_bwd(dh1, dtcat[:, H:].contiguous(), dc1_t, act, tc, c0, seed, off_h1, pd)
-        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, dtype, True))          # [B, 2M+2H] -> prev | moves | words | h0
+        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), True))          # [B, 2M+2H] -> prev | moves | words | h0
         dmoves = _add_n(E(B, M), [dhm[:, H:], dxcat[:, M:2 * M]])
         dwords = _add_n(E(B, H), [dtcat[:, :H], dxcat[:, 2 * M:2 * M + H]])
         # visual attention over the projected candidates; d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
@@ -839,7 +852,7 @@ class MonitorCoreFn(torch.autograd.Function):
             dcand = torch.empty(B, C, M, dtype=f32, device=dev)
             ops.attn_dctx_deferred([move_w.data_ptr(), dlogit.data_ptr()], [dl_v.data_ptr(), None], [dmoves.data_ptr(), aq.data_ptr()], M,
                                    [vq.data_ptr(), None], M, dcand)
-        dh0_v = ops.linear_fwd(dvq, SHADOWS.get(W_vh, "t", dtype))
+        dh0_v = ops.linear_fwd(dvq, SHADOWS.get(W_vh, "t", wdtype(dtype, "w_vh")))
         # text attention over dropout(ctx + pe): d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's mask
         dtq, dl_t = ops.attn_bwd_rows(pctx, word_w, dwords, dww, want_dl=True)
         dctx = None
@@ -847,12 +860,12 @@ class MonitorCoreFn(torch.autograd.Function):
             dctx = torch.empty(B, L, H, dtype=f32, device=dev)
             ops.attn_dctx_deferred([word_w.data_ptr()], [dl_t.data_ptr()], [dwords.data_ptr()], H, [tq.data_ptr()], H, dctx,
                                    drop=[(seed_pe, off_pe, pp)])
-        dh0_t = ops.linear_fwd(dtq, SHADOWS.get(W_tin, "t", dtype))
+        dh0_t = ops.linear_fwd(dtq, SHADOWS.get(W_tin, "t", wdtype(dtype, "w_tin")))
         dh0 = _add_n(E(B, H), [dhm[:, :H], dxcat[:, 2 * M + H:], dh0_v, dh0_t])
         # parameter gradients: six products over the same B rows -> one grouped launch; biases -> another
         sk = [_gsink(w) for w in (W_tin, W_vh, W_ih, W_hh, W_a, W_m)]
         gW = [t for t, _ in sk]
-        wb = ops.WgradBatch(dtype != f32)
+        wb = ops.WgradBatch(base_dtype(dtype) != f32)
         wb.add(dtq, h0, gW[0], sk[0][1]); wb.add(dvq, h0, gW[1], sk[1][1])
         wb.add(dg, xcat[:, :2 * M + H], gW[2], sk[2][1]); wb.add(dg, xcat[:, 2 * M + H:], gW[3], sk[3][1])
         wb.add(daq, tcat, gW[4], sk[4][1]); wb.add(dmg, hm, gW[5], sk[5][1])

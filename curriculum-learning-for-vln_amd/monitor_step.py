@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from .functional import ROLLOUT_WGRADS, SHADOWS, _fused_lstm_weight, _gret, _gsink
+from .functional import ROLLOUT_WGRADS, SHADOWS, _fused_lstm_weight, _gret, _gsink, base_dtype, wdtype
 
 _p = ops._p
 
@@ -44,23 +44,29 @@ class MonitorStepFn(torch.autograd.Function):
         H, L = h0.shape[1], ctxt.shape[1]
         dev = h0.device
         XK = 2 * M + 2 * H
-        wt = ops.F32 if dtype == f32 else ops.BF16
+        base = base_dtype(dtype)                     # `dtype` may carry the per-matrix fp32 override (functional.wdtype)
+        wt = ops.F32 if base == f32 else ops.BF16
         d = _lib.MonitorDims(B, L, Cn, H, M, wt)
         w = _lib.MonitorWeights()
         hold = []                                    # streamed weight copies: kept alive until the launches are queued
+        w.f32_mask = 0
+        for bit, name in enumerate(("w_tin", "w_vh", "w_cat", "w_a", "w_m")):
+            if base != f32 and wdtype(dtype, name) == f32:
+                w.f32_mask |= 1 << bit
 
-        def sh(W, kind):
-            t = SHADOWS.get(W, kind, dtype)
+        def sh(W, kind, name):
+            t = SHADOWS.get(W, kind, wdtype(dtype, name))
             hold.append(t)
             return t.data_ptr()
 
-        w.w_tin, w.w_tin_t = sh(W_tin, "n"), sh(W_tin, "t")
-        w.w_vh, w.w_vh_t, w.b_vh = sh(W_vh, "n"), sh(W_vh, "t"), b_vh.data_ptr()
-        wc_n, wc_t = _fused_lstm_weight(W_ih, W_hh, dtype, False), _fused_lstm_weight(W_ih, W_hh, dtype, True)
+        w.w_tin, w.w_tin_t = sh(W_tin, "n", "w_tin"), sh(W_tin, "t", "w_tin")
+        w.w_vh, w.w_vh_t, w.b_vh = sh(W_vh, "n", "w_vh"), sh(W_vh, "t", "w_vh"), b_vh.data_ptr()
+        dcat = wdtype(dtype, "w_cat")
+        wc_n, wc_t = _fused_lstm_weight(W_ih, W_hh, dcat, False), _fused_lstm_weight(W_ih, W_hh, dcat, True)
         hold += [wc_n, wc_t]
         w.w_cat, w.w_cat_t, w.b_ih, w.b_hh = wc_n.data_ptr(), wc_t.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr()
-        w.w_a, w.w_a_t, w.b_a = sh(W_a, "n"), sh(W_a, "t"), b_a.data_ptr()
-        w.w_m, w.w_m_t, w.b_m = sh(W_m, "n"), sh(W_m, "t"), b_m.data_ptr()
+        w.w_a, w.w_a_t, w.b_a = sh(W_a, "n", "w_a"), sh(W_a, "t", "w_a"), b_a.data_ptr()
+        w.w_m, w.w_m_t, w.b_m = sh(W_m, "n", "w_m"), sh(W_m, "t", "w_m"), b_m.data_ptr()
         wcf = W_c.detach().reshape(-1)
         pe_c = pe if pe.is_contiguous() else pe.contiguous()
         hold += [wcf, pe_c]
@@ -130,7 +136,7 @@ class MonitorStepFn(torch.autograd.Function):
         for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
             setattr(g, n, t.data_ptr())
             g.acc[i] = 1 if acc else 0
-        g.precision = ops.wgrad_precision(dtype != f32)
+        g.precision = ops.wgrad_precision(base_dtype(dtype) != f32)
         ns = int(lib.vln_monitor_bwd_scratch_floats(C.byref(d)))
         pj = None
         if ctx.rw is not None and ROLLOUT_WGRADS.enabled and all(acc for _, acc in sinks):

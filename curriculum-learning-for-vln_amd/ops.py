@@ -336,8 +336,10 @@ def wgrad_precision(lp: bool) -> int:
 class WgradBatch:
     """Collects dW (+)= dy.T @ x products over the SAME rows and issues them as one launch (`vln_wgrad_grouped`)."""
 
-    def __init__(self, split_bf16=False):
-        self.jobs, self.keep, self.Mt, self.split = [], [], None, split_bf16
+    def __init__(self, split_bf16=False, never_plain=False):
+        """never_plain: in bf16 mode use split operands even when the process default is the plain-bf16 form (gradients behind a
+        BatchNorm: csrc/bn_mlp.hip does the same in the C call)."""
+        self.jobs, self.keep, self.Mt, self.split, self.never_plain = [], [], None, split_bf16, never_plain
 
     def add(self, dy, x, out, accumulate=False):
         _req(dy, "dy"); _req(x, "x"); _req(out, "out")
@@ -360,7 +362,10 @@ class WgradBatch:
         msplit = max(1, min(256 // max(tiles, 1), MS // 4)) if tiles < 256 else 1
         area = sum(2 * ((j.N + 15) // 16 + (j.K + 15) // 16) * MS * 1024 for j in self.jobs) // 4
         ws = workspace(self.keep[0].device, max(1 << 22, area + (msplit * sum(j.N * j.K for j in self.jobs) if msplit > 1 else 0)))
-        _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, wgrad_precision(self.split), _p(ws), ws.numel(),
+        prec = wgrad_precision(self.split)
+        if prec == 2 and self.never_plain:
+            prec = 1
+        _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, prec, _p(ws), ws.numel(),
                                                  _stream()), "vln_wgrad_grouped")
         self.jobs, self.keep, self.Mt = [], [], None
 

@@ -33,7 +33,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2
 
-int vln_abi_version(void);     /* 12 */
+int vln_abi_version(void);     /* 13 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -328,6 +328,8 @@ typedef struct vln_monitor_weights {
   const void *w_m, *w_m_t; const float* b_m;         /* monitor_linear                    [H, H+M], [H]     */
   const float *w_c, *b_c;                            /* critic.0 (progress head), fp32    [L+H], [1]        */
   const float* pe;                                   /* position.pe                       [L, H]            */
+  int32_t f32_mask, pad_;                            /* ABI v13: bit i set = matrix i (w_tin, w_vh, w_cat, w_a, w_m) and its transpose are
+                                                      * fp32 arrays whatever vln_monitor_dims.wtype says (per-matrix override of the bf16 mode) */
 } vln_monitor_weights;
 typedef struct vln_monitor_step {
   const float *prev_rep /*[B,M]*/, *cand_rep /*[B,C,M]*/, *h0, *c0 /*[B,H]*/, *ctx /*[B,L,H]*/;
@@ -581,9 +583,15 @@ int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = pe
  * pinned host memory; this call -- made by every later vln_lstm_seq_* and by the optimizer step -- reports it ONCE as
  * VLN_ERR_HIP (the affected iteration's numbers are invalid) and switches the process to per-step launches. */
 int vln_persistent_check(void);
-/* Test hook: raise the current device's sticky word from the host as a timed-out wait (word 0) or an out-of-range gather index
- * (word 1) would -- so that callers' fallback paths can be exercised on a healthy device. */
+/* Test hook: raise the current device's sticky word from the host as a timed-out recurrence wait (word 0), an out-of-range
+ * gather index (word 1) or a timed-out four-workgroup attention exchange (word 2) would -- so that callers' fallback paths can
+ * be exercised on a healthy device. */
 int vln_debug_raise_sticky(int word);
+/* The four-workgroups-per-row attention (units.py:77-160 on csrc/attention_split.h) spins (bounded) on its three sibling
+ * workgroups.  A timeout is counted in its OWN sticky word: vln_persistent_check reports it once as VLN_ERR_HIP and clears
+ * this switch, after which every attention runs on one workgroup per row.  1 = allowed (default), 0 = off. */
+int vln_set_split_attention(int on);
+int vln_get_split_attention(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]
  * in: grads of the final states, clobbered.  dh_init_bm / dc_init_bm (both or neither): the same initial gradients in the
  * caller's [B, dirs*Hd] layout (hcat / ccat, units.py:63-67) -- dh_pass / dc_carry are then scratch only and the caller's two

@@ -73,7 +73,7 @@ def timed(fn):
 def run_monitor(B=128, L=80, T=7, C=8):
     g = torch.Generator().manual_seed(2020)
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, False, 1, compute_dtype=dt).to(dev).train()
-    dec = vln.MonitorDecoder(512, 0.5, L, (128, 1024), F, F, compute_dtype=dt).to(dev).train()
+    dec = vln.MonitorDecoder(512, 0.5, L, (1024,), F, F, compute_dtype=dt).to(dev).train()      # MLP_HIDDEN (1024,): configs/monitor/selfmonitor_config.yaml:45
     dec.c_step = not getattr(args, "python_step", False)
     dec.merge_projections = not getattr(args, "two_bn_mlp_calls", False)
     opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-4)

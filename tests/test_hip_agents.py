@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from parity import check, check_grads, FP32, BF16
+from parity import check, check_grads, grad_floor, FP32, BF16
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -150,7 +150,7 @@ def test_monitor_fused_step_equals_operator_path(vln, cdt):
     for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
         close(a, b, f"out{i}")
     for n in res[0][1]:      # gradients that are zero in exact arithmetic (a bias in front of a BatchNorm) are fp32 noise:
-        close(res[0][1][n], res[1][1][n], "grad " + n, floor=1e-2 * gscale)      # judged on the scale of the real gradients
+        close(res[0][1][n], res[1][1][n], "grad " + n, floor=grad_floor(n, gscale))      # judged on the scale of the real gradients
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         close(a, b, f"input grad {i}")
     for k in res[0][3]:
@@ -193,7 +193,7 @@ def test_monitor_c_call_step_equals_python_driven_node(vln, cdt):
         assert torch.equal(a, b), f"output {i}"
     gscale = max(v.abs().max().item() for v in res[1][1].values())
     for n in res[0][1]:
-        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=grad_floor(n, gscale))
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         check(a, b, 2e-5, f"input grad {i}")
 
@@ -241,7 +241,7 @@ def test_follower_fused_step_equals_operator_path(vln, cdt):
     for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
         close(a, b, f"out{i}")
     for n in res[0][1]:      # d linear_in_v.bias is zero in exact arithmetic (softmax rows): judged on the scale of real gradients
-        close(res[0][1][n], res[1][1][n], "grad " + n, floor=1e-2 * gscale)
+        close(res[0][1][n], res[1][1][n], "grad " + n, floor=grad_floor(n, gscale))
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         close(a, b, f"input grad {i}")
 
@@ -282,7 +282,7 @@ def test_follower_c_call_step_equals_python_driven_node(vln, cdt):
         assert torch.equal(a, b), f"output {i}"
     gscale = max(v.abs().max().item() for v in res[1][1].values())
     for n in res[0][1]:
-        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+        check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=grad_floor(n, gscale))
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         check(a, b, 2e-5, f"input grad {i}")
 
@@ -587,7 +587,7 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             assert torch.equal(x, y), f"rollout {rollout} output {i}"
         gscale = max(v.abs().max().item() for v in b[1].values())
         for n in b[1]:
-            check(a[1][n], b[1][n], 2e-5, f"grad[{n}]", floor=1e-2 * gscale)
+            check(a[1][n], b[1][n], 2e-5, f"grad[{n}]", floor=grad_floor(n, gscale))
         for i, (x, y) in enumerate(zip(a[2], b[2])):
             assert torch.equal(x, y), f"rollout {rollout} input grad {i}"
     for n in res[1][0][1]:                                      # the second rollout reproduces the first (slots reused correctly)
@@ -647,7 +647,7 @@ def test_bn_mlp_two_batches_in_one_call_equal_two_calls(vln, cdt, shape):
                 check(a[2][n], b[2][n], 2e-5, f"call {i} buffer {n}")
         gscale = max([v.abs().max().item() for v in b[3].values()] + [1e-30])
         for n in b[3]:
-            check(a[3][n], b[3][n], 5e-5, f"call {i} grad[{n}]", floor=1e-2 * gscale)
+            check(a[3][n], b[3][n], 5e-5, f"call {i} grad[{n}]", floor=grad_floor(n, gscale))
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
@@ -698,7 +698,7 @@ def test_monitor_merged_projections_equal_two_bn_mlp_calls(vln, cdt):
         for i, (a, b) in enumerate(zip(got[0], ref[0])):
             check(a, b, 5e-5, f"variant {k} output {i}")
         for n in ref[1]:
-            check(got[1][n], ref[1][n], 1e-4, f"variant {k} grad[{n}]", floor=1e-2 * gscale)
+            check(got[1][n], ref[1][n], 1e-4, f"variant {k} grad[{n}]", floor=grad_floor(n, gscale))
         for i, (a, b) in enumerate(zip(got[2], ref[2])):
             check(a, b, 1e-4, f"variant {k} input grad {i}")
         for n in ref[3]:

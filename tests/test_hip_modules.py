@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from parity import check, check_grads, rel_err, bf16_weights, bf16_round_st, same_bf16_grad_tol, FP32, BF16, SAME_BF16
+from parity import check, check_grads, rel_err, bf16_weights, bf16_round_st, same_bf16_grad_tol, grad_floor, FP32, BF16, SAME_BF16
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -178,18 +178,16 @@ def test_critic_golden(vln):
     check(s.grad, G["grad"]["state"], 1e-4, "dstate")
 
 
-# bf16 vs the UNROUNDED fp64 oracle (north_star's 1e-2): what exceeds it, measured (gpurun_out/parity_report.json), and why --
-# every weight carries a 2^-9 relative rounding; the visual attention's logits (K = 2176 products of magnitude ~1 each, then a
-# softmax over 36 views) and the LSTM gates (K = 2752) turn that into ~1e-2 of the state's range after one step.  The
-# same-weights oracle (the kernels' arithmetic itself) is met at 1e-4 for every tensor.
-# Round 3, decided by measurement (scripts/bf16_exceptions_ab.py, profiles/round3_notes.md): of the 22 comparisons of this test TWO
-# exceed 1e-2 (d h_tilde_0 and d visual_attn.linear_in.weight, 1.4e-2 each); h1 / the text query's weight gradient / logits sit
-# at 0.8-1.0e-2 and move by +-30 % with the dropout draw (round 2's draw had h1 at 1.3e-2), hence the margins.  Streaming the two
-# attention QUERY projections (visual_attn.linear_in 512 x 2176, text_attn.linear_in 512 x 512) in fp32 brings EVERY comparison
-# to <= 6.5e-3 for +2.6 % time (EnvDropDecoder.fp32_weights; test_envdrop_full_size_bf16_meets_1e2_with_fp32_query_weights).
-ENVDROP_BF16_EXC = {"dh_tilde0": 3e-2, "grad[visual_attn.linear_in.weight]": 3e-2, "h1_": 2e-2, "dc0": 2e-2, "logit": 1.5e-2,
-                    "h_tilde": 1.5e-2, "dctx": 1.5e-2, "grad[": 1.5e-2}
-ENCODER_BF16_EXC = {"grad[": 2e-2}
+# bf16 vs the UNROUNDED fp64 oracle = north_star's bound (1e-2) for every logit, state and gradient.  Every streamed weight carries
+# a 2^-9 relative rounding; the two attention QUERY projections (visual_attn.linear_in: K = 2176 products in front of a softmax
+# over 36 views; text_attn.linear_in) turn theirs into 1.4e-2 of d h_tilde / d visual_attn.linear_in, so the module streams those
+# two matrices in fp32 BY DEFAULT (EnvDropDecoder.default_fp32_weights, round 4; +2.5 % time) and the default mode is held to
+# 1e-2 with NO exception (measured worst 6.5e-3, profiles/round3_notes.md section 7).  The all-bf16 mode (round 3's default) stays
+# available as `fp32_weights = frozenset()`: its two tensors over the bound are listed here and asserted at their measured size in
+# test_envdrop_full_size_all_bf16_weights -- a documented NON-default mode, timed as bench.py's `all_bf16_weights_ms_per_step`.
+ENVDROP_ALL_BF16_EXC = {"dh_tilde0": 3e-2, "grad[visual_attn.linear_in.weight]": 3e-2, "h1_": 2e-2, "dc0": 2e-2, "logit": 1.5e-2,
+                        "h_tilde": 1.5e-2, "dctx": 1.5e-2, "grad[": 1.5e-2}
+ENCODER_BF16_EXC = {}          # round 3 measured <= 2.6e-3 on every tensor: north_star's 1e-2 without exceptions
 
 
 def _tol_for(exc, tol, what):
@@ -207,7 +205,7 @@ def _variants(compute_dtype, exc):
     return [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, exc)]
 
 
-def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=(), bf16_exc=None):
+def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=None, bf16_exc=None):
     from oracle import torch_port as O
     B, L, V, C, H, IMG, ANG, AE = 64, 80, 36, 8, 512, 2048, 128, 64
     F = IMG + ANG
@@ -215,7 +213,9 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=(), bf1
     torch.manual_seed(2020)          # default parameter init comes from the global RNG: pin it (test-order independent)
     dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=compute_dtype).to(DEV)
     dec.train(train)
-    if fp32_weights:
+    if fp32_weights is None:             # the module's default: the two attention query projections streamed in fp32
+        fp32_weights = tuple(sorted(dec.fp32_weights))
+    else:
         dec.fp32_weights = frozenset(fp32_weights)
     fp32_names = {"w_vin": "visual_attn.linear_in.weight", "w_tin": "text_attn.linear_in.weight", "w_tout": "text_attn.linear_out.weight",
                   "w_c": "cand_attn.weight", "w_cat": None}
@@ -227,7 +227,7 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=(), bf1
     ht = torch.tanh(torch.randn(B, H, generator=g)); c = torch.randn(B, H, generator=g) * 0.5
     ctx_d = ctx.to(DEV).requires_grad_(True); ht_d = ht.to(DEV).requires_grad_(True); c_d = c.to(DEV).requires_grad_(True)
     V_ = []
-    for name, tol, same, exc in _variants(compute_dtype, ENVDROP_BF16_EXC if bf16_exc is None else bf16_exc):
+    for name, tol, same, exc in _variants(compute_dtype, {} if bf16_exc is None else bf16_exc):
         V_.append(dict(name=name, tol=tol, same=same, exc=exc, loss=0.,
                        P={k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()},
                        ctx=ctx.double().requires_grad_(True), ht=ht.double().requires_grad_(True), c=c.double().requires_grad_(True)))
@@ -272,7 +272,7 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=(), bf1
         (v["loss"] + ho.sum() * 0.1 + co.sum() * 0.1).backward()
         gmax = max(float(q.grad.abs().max()) for q in v["P"].values() if q.grad is not None)
         for n, prm in dec.named_parameters():
-            check(prm.grad, v["P"][n].grad, _tol_for(v["exc"], v["tol"], f"grad[{n}]"), f"{v['name']}: grad[{n}]", floor=1e-2 * gmax)
+            check(prm.grad, v["P"][n].grad, _tol_for(v["exc"], v["tol"], f"grad[{n}]"), f"{v['name']}: grad[{n}]", floor=grad_floor(n, gmax))
         for got, ref, what in ((ctx_d.grad, v["ctx"].grad, "dctx"), (ht_d.grad, v["ht"].grad, "dh_tilde0"), (c_d.grad, v["c"].grad, "dc0")):
             check(got, ref, _tol_for(v["exc"], v["tol"], what), f"{v['name']}: {what}")
 
@@ -286,16 +286,16 @@ def test_envdrop_full_size_fp32_eval(vln):
 
 
 def test_envdrop_full_size_bf16(vln):
-    """bf16-streamed weights / features / context, fp32 accumulate, dropout on: vs the fp64 oracle on the SAME rounded weights
-    (1e-4) and vs the fp64 oracle on the UNROUNDED parameters (north_star's 1e-2, exceptions listed in ENVDROP_BF16_EXC)."""
+    """BASELINE config 1 in the DEFAULT bf16 mode (bf16-streamed features / context / weights except the two attention query
+    projections, fp32 accumulate, dropout on): vs the fp64 oracle on the SAME rounded weights (1e-4) and vs the fp64 oracle on the
+    UNROUNDED parameters at north_star's 1e-2 for every logit, state and gradient -- no exceptions."""
     _full_size_envdrop(vln, torch.bfloat16)
 
 
-def test_envdrop_full_size_bf16_meets_1e2_with_fp32_query_weights(vln):
-    """north_star's bf16 bound (1e-2 against the reference's fp32 arithmetic) for EVERY output and gradient, no exceptions: the
-    two attention query projections streamed in fp32 (their 2^-9 weight rounding sits in front of a softmax), everything else
-    bf16.  +2.6 % time per iteration (bench.py secondary `fp32_query_weights_ms_per_step`)."""
-    _full_size_envdrop(vln, torch.bfloat16, fp32_weights=("w_vin", "w_tin"), bf16_exc={})
+def test_envdrop_full_size_all_bf16_weights(vln):
+    """The NON-default all-bf16 mode (`fp32_weights = frozenset()`): same-weights oracle at 1e-4; against the unrounded oracle
+    two tensors sit at 1.4e-2 (ENVDROP_ALL_BF16_EXC) -- why the default streams the query projections in fp32."""
+    _full_size_envdrop(vln, torch.bfloat16, fp32_weights=(), bf16_exc=ENVDROP_ALL_BF16_EXC)
 
 
 def test_encoder_full_size_bf16(vln):
@@ -328,7 +328,7 @@ def _encoder_full(vln, compute_dtype):
         ((co * r1.double()).sum() + (ho * r2.double()).sum() + cco.sum()).backward()
         gmax = max(float(q.grad.abs().max()) for q in P.values() if q.grad is not None)
         for n, prm in enc.named_parameters():
-            check(prm.grad, P[n].grad, _tol_for(exc, tol, f"grad[{n}]"), f"{name}: grad[{n}]", floor=1e-2 * gmax)
+            check(prm.grad, P[n].grad, _tol_for(exc, tol, f"grad[{n}]"), f"{name}: grad[{n}]", floor=grad_floor(n, gmax))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -441,3 +441,35 @@ def test_feature_dropout(vln):
     assert torch.equal(cp, x.bfloat16())
     m = vln.ops.dropout_mask(B * V * IMG, 99, 5, 0.3, dev()).view(B, V, IMG)
     assert torch.equal(m > 0, kept)                                 # exported mask == applied mask
+
+
+def test_split_attention_timeout_has_its_own_sticky_word_and_switches_the_split_kernels_off(vln):
+    """a timed-out exchange of the four-workgroups-per-row attention used to raise the persistent LSTM's sticky
+    word -- the report blamed the recurrence and the fallback (vln_set_persistent(0)) re-issued the same split kernels.  It has
+    its own word now: the check names the attention, clears `vln_get_split_attention()`, the next attention of the same shape
+    runs on one workgroup per row (bit-identical to what the tunable selects) and the LSTM switch is untouched."""
+    lib = vln._lib.load()
+    vln._lib.check(lib.vln_persistent_check(), "clean start")
+    B, S, D = 64, 36, 2176
+    g = torch.Generator().manual_seed(5)
+    ctx = (torch.randn(B, S, D, generator=g) * 0.3).to(DEV)
+    q = (torch.randn(B, D, generator=g) * 0.1).to(DEV)
+    sync = torch.zeros(int(lib.vln_attn_sync_bytes(B)) // 4 + 1, dtype=torch.int32, device=DEV)
+    out_split, attn_split = vln.ops.attn_fwd_rows(ctx, q, None, sync=sync)
+    assert lib.vln_get_split_attention() == 1
+    try:
+        vln._lib.check(lib.vln_debug_raise_sticky(2), "vln_debug_raise_sticky")
+        rc = lib.vln_persistent_check()
+        assert rc != 0
+        msg = lib.vln_last_error_string().decode()
+        assert "four-workgroup attention" in msg and "LSTM" not in msg, msg
+        assert lib.vln_get_split_attention() == 0
+        assert lib.vln_persistent_check() == 0                     # reported once
+        out_one, attn_one = vln.ops.attn_fwd_rows(ctx, q, None, sync=sync)          # one workgroup per row now
+        torch.cuda.synchronize()
+        check(out_one, out_split, 1e-6, "weighted sum, one workgroup per row vs four")
+        check(attn_one, attn_split, 1e-6, "attention weights")
+    finally:
+        lib.vln_set_split_attention(1)
+    out2, _ = vln.ops.attn_fwd_rows(ctx, q, None, sync=sync)
+    assert torch.equal(out2, out_split)

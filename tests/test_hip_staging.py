@@ -431,20 +431,22 @@ def test_rollout_sampler_long_rollout_chunks(vln):
             s.step(steps[0][0].to(DEV))
 
 
-@pytest.mark.parametrize("variant", ["pipelined", "both_outputs", "thirteen_steps", "per_step_recurrence"])
+@pytest.mark.parametrize("variant", ["pipelined", "both_outputs", "thirteen_steps", "per_step_recurrence", "batch128_no_idle_cus"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, dtype, variant):
     """EncoderLSTM.forward(ride=store.rollout_ride(...)): the rollout's feature rows gathered by PASSENGER workgroups of the
     persistent recurrence launch are the rows of gather_rollout bit for bit (same Philox offsets), and the encoder's own
     outputs are untouched by the passengers.  Variants: the software-pipelined passenger loop (one output precision); both
     precisions at once (the plain 8-rows-per-pass passenger loop); 13 steps (more than one argument block holds: the ride runs
-    as its own launch in front of the recurrence); the per-step recurrence (no persistent launch to ride in: the same)."""
+    as its own launch in front of the recurrence); the per-step recurrence (no persistent launch to ride in: the same); B = 128
+    (two directions x 16 unit slices x 8 row blocks = 256 workgroups fill every CU of an MI355X, no passenger fits:
+    the library must notice BEFORE it commits to passengers and issue the gather as its own launch -- round 3 dropped it)."""
     import bench
     dev_ = torch.device(DEV)
     lib = vln._lib.load()
     torch.manual_seed(11)
     T = 13 if variant == "thirteen_steps" else 7
-    cpu_tape = bench.make_tape(64, 80, T, 8, seed=77)
+    cpu_tape = bench.make_tape(128 if variant == "batch128_no_idle_cus" else 64, 80, T, 8, seed=77)
     cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
     tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
     store = tape["store"]

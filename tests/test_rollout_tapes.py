@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from parity import check
+from parity import check, grad_floor
 from oracle import rollout as R
 from oracle.fake_env import FakeR2REnv
 
@@ -235,7 +235,7 @@ def test_hip_back_translation_rollout():
     for n, r in go.items():
         if n.startswith("cri."):
             continue
-        check(g[n], r, 1e-4, f"grad[{n}]", floor=1e-2 * gmax)
+        check(g[n], r, 1e-4, f"grad[{n}]", floor=grad_floor(n, gmax))
 
 
 def test_oracle_rollout_instruction_override_is_consistent():
