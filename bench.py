@@ -151,11 +151,15 @@ class LiveBatch:
     """The small per-batch tensors of the CURRENT episode batch (tokens, lengths, masks, per-step index vectors, targets,
     angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (one copy
     per iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA
-    changes every iteration.  `load(k)` = one device-to-device copy of batch k's packed blob into the live blob."""
+    changes every iteration.  The packed batches wait in PINNED HOST memory (`host=True`, the bench's default since round 4: what
+    a trainer's data loader hands over -- base.py:114-178 marshals every batch on the host) and `load(k)` is ONE asynchronous
+    host-to-device copy of batch k's blob into the live blob, stream-ordered in front of the iteration; `host=False` keeps the
+    batches on the device (a device-to-device copy: round 3's form, kept for A/B)."""
     TOP = ("tokens", "lengths32", "seq_mask")
     STEP = ("rows", "vidx", "crow", "cview", "chead", "celev", "cand_mask", "angle", "target")
 
-    def __init__(self, tapes):
+    def __init__(self, tapes, host=False):
+        self.host = bool(host)
         t0 = tapes[0]
         self.layout, off = [], 0
         for name, t in self._items(t0):
@@ -171,6 +175,8 @@ class LiveBatch:
                 if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
                     raise ValueError(f"LiveBatch: tape layouts differ at {name}: {tuple(t.shape)} vs {shape}")
                 blob[o:o + n] = t.contiguous().view(-1).view(torch.uint8)
+            if self.host:
+                blob = blob.cpu().pin_memory()
             self.blobs.append(blob)
         self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
         views = {name: self.live_blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.layout}
@@ -230,6 +236,10 @@ class GpuAgent:
         # launch bumps per iteration -> the iteration's launch arguments repeat and it can be captured whole (graphs.IterationGraph)
         self.clock = None
         self.graph = None
+        # Segmented form of the iteration (graphs.SegmentedIterationGraph): the backward is cut at the encoder's outputs so that
+        # the host can start the decoder slice's all-reduce between the two halves -- the data-parallel path (N > 1, --dp-path)
+        self.segmented = False
+        self._cut = None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
         self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
 
@@ -254,7 +264,10 @@ class GpuAgent:
         an iteration on whatever those buffers hold."""
         if self.clock is None:
             raise RuntimeError("GpuAgent.capture: use_clock() first (a captured iteration reads its dropout offsets from device words)")
-        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture()
+        if self.segmented:
+            self.graph = self.vln.SegmentedIterationGraph(self.segments(tape), self.clock).capture()
+            return self.graph
+        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture(debug_dump=getattr(self, "dump_graph", None))
         return self.graph
 
     def replay(self):
@@ -318,6 +331,12 @@ class GpuAgent:
         return img, cand, dict(already_dropfeat=True)
 
     def iteration(self, tape):
+        if self.segmented:             # the same five pieces a SegmentedIterationGraph captures / replays, issued eagerly
+            out = None
+            for _, fn in self.segments(tape):
+                r = fn()
+                out = r if r is not None else out
+            return out
         self._copy_fenced = False
         self.vln.ops.set_arena(self.arena)
         if self.arena is not None:
@@ -326,6 +345,35 @@ class GpuAgent:
             return self._iteration(tape)
         finally:
             self.vln.ops.set_arena(None)
+
+    def segments(self, tape):
+        """The iteration cut at its two exchange points (trainer.py:421-427 with the gradient all-reduce in it):
+        [graph A: forward, loss, the decoder's backward] [host: start the decoder slice's all-reduce] [graph B: the encoder's
+        backward] [host: reduce the rest, wait] [graph C: clip + update]."""
+        def in_arena(fn, begin=False):
+            def run():
+                self.vln.ops.set_arena(self.arena)
+                if begin and self.arena is not None:
+                    self.arena.begin()
+                try:
+                    return fn()
+                finally:
+                    self.vln.ops.set_arena(None)
+            return run
+
+        def part_a():
+            self._copy_fenced = False
+            return self._iteration(tape)
+
+        def part_b():
+            self._cut.resume()
+
+        def part_c():
+            self.opt.step(zero_grads=self.clear_grads_in_step)
+            self._iter_no += 1
+
+        return [("graph", in_arena(part_a, begin=True)), ("host", lambda: self.opt.start_allreduce(1)),
+                ("graph", in_arena(part_b)), ("host", lambda: self.opt.allreduce()), ("graph", in_arena(part_c))]
 
     def _iteration(self, tape):
         B = tape["B"]
@@ -373,6 +421,10 @@ class GpuAgent:
             with torch.cuda.stream(branch):
                 pre = gather_all()
         ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"], ride=ride) if ride is not None else self.enc(tape["tokens"], tape["lengths32"])
+        if self.segmented:
+            # the decoder's backward ends at these leaves; the encoder's backward starts from their .grad (segments(): part_b)
+            self._cut = self.vln.dp.BackwardCut()
+            ctx, h_t, c_t = self._cut.at(ctx, h_t, c_t)
         h_tilde = h_t
         terms = []
         ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
@@ -403,6 +455,8 @@ class GpuAgent:
             self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
         self._probe()
         loss.backward(self._one)                                 # the root gradient is a constant: no ones_like fill per iteration
+        if self.segmented:
+            return loss
         self.opt.allreduce()
         # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
         self.opt.step(zero_grads=self.clear_grads_in_step)
@@ -546,6 +600,8 @@ def main():
                          "all-reduce of N > 1 stays a stream operation between launches)")
     ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE",
                     help="(A/B) vln_set_tunable(ID, VALUE) before anything runs, e.g. --tunable 0=256 (csrc/vln_internal.h lists them)")
+    ap.add_argument("--dump-graph", default=None, metavar="PATH",
+                    help="write the captured iteration graph's nodes (kernel names, memcpy / memset nodes, edges) as graphviz text")
     ap.add_argument("--probe-trivial", type=int, default=0,
                     help="(measurement) N trivial dependent launches (vln_debug_trivial_chain) at the top of every iteration and "
                          "N more between the forward and the backward: (ms with N - ms without) / 2N = the price of a kernel "
@@ -569,6 +625,14 @@ def main():
                          "inside the step's first launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
+    ap.add_argument("--batch-source", default="host", choices=["host", "device"],
+                    help="where the packed episode batches (tokens, masks, per-step index vectors, targets: ~0.4 MB each) wait: "
+                         "pinned HOST memory, one hipMemcpyAsync H2D per iteration (default: what a data loader hands over), or "
+                         "device memory, one device-to-device copy (round 3's form, A/B)")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
+                         "exchange issued between them (graphs.SegmentedIterationGraph) on a ONE-rank RCCL group, collectives "
+                         "forced on -- so that the path the N > 1 runs take is timed against the single graph on one GPU")
     ap.add_argument("--one-device", action="store_true", help="(testing) map every rank to cuda:0")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="(testing, runs without a GPU) launch / join the N ranks, all-reduce one scalar over --backend, rank 0 "
@@ -611,6 +675,16 @@ def main():
 
     import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
+    if args.dp_path:
+        if world != 1:
+            raise SystemExit("--dp-path is the one-GPU rehearsal of the N > 1 path: use it with --gpus 1")
+        import socket
+        import torch.distributed as dist
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        vln.dp._dp_active = lambda group=None: True              # a one-rank group: issue the collectives anyway
     vln.ops.set_wgrad_precision(args.wgrad)
     for tv in args.tunable:
         tid, val = tv.split("=")
@@ -627,8 +701,13 @@ def main():
     agent.gather_branch = bool(args.gather_branch)
     agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
     agent.probe_trivial = int(args.probe_trivial)
-    use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and world == 1 and args.features == "store"
-                                                 and not args.no_arena)
+    agent.dump_graph = args.dump_graph
+    use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and args.features == "store" and not args.no_arena)
+    # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
+    # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
+    agent.segmented = bool(use_graph and (world > 1 or args.dp_path))
+    if agent.segmented:
+        agent.dec.grads_ready_hook = None                        # the early slice goes out between segments A and B instead
     if use_graph and (args.features != "store" or args.ce != "rollout"):
         raise SystemExit("--iteration-graph on needs --features store and --ce rollout (inputs at fixed addresses, no host sync)")
     # The resident feature table is the FULL-size one (10,567 viewpoints x 36 x 2048: 1.56 GB bf16 / 3.1 GB fp32), and the
@@ -649,7 +728,7 @@ def main():
             if hd is not None:
                 for s in t["steps"]:
                     del s["img"], s["cand"]
-    live = LiveBatch(tapes) if args.features == "store" else None
+    live = LiveBatch(tapes, host=args.batch_source == "host") if args.features == "store" else None
     if rank == 0:
         print(f"[bench] setup: {store.N}-viewpoint table ({store.table.numel() * store.table.element_size() / 2**30:.2f} GiB {args.dtype}), "
               f"{len(tapes)} tapes, {time.perf_counter() - t_setup:.1f} s", file=sys.stderr, flush=True)
@@ -881,12 +960,15 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
+                       "batch_source": (("pinned host, one H2D copy per iteration" if args.batch_source == "host" else "device, one D2D copy per iteration") if live is not None else "per-step tensors"),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
-                       "parallelism": f"dp{world}", "world_size": world, "iteration_graph": bool(use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "parallelism": f"dp{world}", "world_size": world,
+                       "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
-                       "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if world > 1 else None},
+                       "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
-    if world > 1:
+    if world > 1 or args.dp_path:
         torch.distributed.destroy_process_group()
 
 
@@ -903,18 +985,18 @@ def csrc_sha():
 
 def pmc_figures(kernel, dtype):
     """(HBM-side bytes per launch, MFMA issue-slot utilisation, note) of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/round3_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
+    (profiles/round4_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
     same command).  The file carries the hash of the kernel sources it was taken on: a mismatch means the numbers describe
     OTHER code, and they are refused (null) rather than quoted stale."""
-    f = os.path.join(ROOT, "profiles", "round3_pmc.json")
+    f = os.path.join(ROOT, "profiles", "round4_pmc.json")
     if not os.path.exists(f):
         return None, None, "no PMC passes committed for this round yet"
     d = json.load(open(f))
     if d.get("csrc_sha") != csrc_sha():
-        return None, None, f"profiles/round3_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
+        return None, None, f"profiles/round4_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
     t = d.get("traffic", {}).get(dtype, {}).get(kernel)
     m = d.get("mfma_util", {}).get(dtype, {}).get(kernel)
-    return (t["bytes_per_launch"] if t else None), m, f"profiles/round3_pmc.json, kernel sources {d['csrc_sha']}"
+    return (t["bytes_per_launch"] if t else None), m, f"profiles/round4_pmc.json, kernel sources {d['csrc_sha']}"
 
 
 def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,

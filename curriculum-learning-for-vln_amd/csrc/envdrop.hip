@@ -103,7 +103,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop fwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
   const bool lp = (d->ctype == VLN_BF16);
-  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };     // per-matrix fp32 override
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32S : d->wtype; };     // per-matrix fp32 override
   if (lp && (!io->img_lp || !io->cand_lp || !io->ctx_lp)) { set_error("envdrop fwd: bf16 stream copies missing"); return VLN_ERR_ARG; }
   const float pf = io->already_dropfeat ? 0.f : io->p_feat;
 
@@ -173,7 +173,7 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   const void* img = lp ? (const void*)io->img_lp : (const void*)io->img;
   const void* cand = lp ? (const void*)io->cand_lp : (const void*)io->cand;
   const void* ctx = lp ? io->ctx_lp : (const void*)io->ctx;
-  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32S : d->wtype; };
 
   // (6') logits -> d(cand query) -> d(drop(h_tilde))
   int n2 = 1, n3 = 1, n3b = 1, n4 = 1;

@@ -12,6 +12,8 @@
 // instruction pair, whole cache lines), the X tile is shared by the 4 waves through LDS (144-B padded rows,
 // ds_read_b128).  fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32), bf16 uses v_mfma_f32_16x16x32_bf16 with
 // fp32 accumulate; lane group q = lane>>4 owns k = k0 + q*VK .. +VK so both operands read 32 B per lane.
+#include <type_traits>
+
 #include "vln_internal.h"
 #include "step_bodies.h"
 #include "../../include/vln_hip.h"
@@ -22,7 +24,7 @@ namespace vln {
 
 template <typename TW, int PD, bool kFast, int NT = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(sizeof(TW) == 4)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kF32)];
   const VBlock vb{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, smem};
   gemm_nt_body<TW, PD, kFast, NT>(a, vb, true, gemm_nt_nsteps(a, vb.by, GemmCfg<TW>::BK), [] {});
 }
@@ -33,8 +35,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // narrow outputs: 16-column workgroups with the K split inside the workgroup (no slabs, no reduce launch)
 // tunable[3] = largest K it takes (every workgroup streams the WHOLE X once: long contractions belong to the split-K path)
-static bool n16_applies(int M, int N, int K) {
-  return g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
+static bool n16_applies(int M, int N, int K, int wtype) {     // (W_F32S operands take the 64-column kernel)
+  return wtype != W_F32S && g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
 }
 
 static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
@@ -58,7 +60,7 @@ static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, i
 int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
                   int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_fused: bad dims"); return VLN_ERR_ARG; }
-  if (n16_applies(M, N, K)) return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, Y2, ldy2, drop);
+  if (n16_applies(M, N, K, wtype)) return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, Y2, ldy2, drop);
   int nsplit = 1;
   int r = gemm_nt(st, X, ldx, W, wtype, ldw, nullptr, 0, M, N, K, nullptr, ACT_NONE, ws, ws_floats, &nsplit);
   if (r != VLN_OK) return r;
@@ -68,9 +70,9 @@ int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int w
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }
-  if (nsplit_out == nullptr && n16_applies(M, N, K))
+  if (nsplit_out == nullptr && n16_applies(M, N, K, wtype))
     return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, nullptr, 0, DropSpec{0, 0, 0.f});
-  const int BK = (wtype == W_BF16) ? 64 : 32;
+  const int BK = (wtype == W_F32) ? 32 : 64;
   // 128-column tiles for the wide AND deep products consumed from slabs (LSTM gates, d xcat: N, K >= 2048): measured
   // NO faster than 64-column tiles (11.3 vs 10.3 us and 11.2 vs 11.1 us; the pointwise consumer then reads 15 slabs
   // instead of 8) -- the X re-reads hit L2 and are not what bounds these launches.  Opt-in only: tunable[1] bit 1.
@@ -118,9 +120,13 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
     // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
     const bool deep = g_tunable[5] == 4 && steps_per > 2;
 #define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
-    if (wide && fast) {
+    if (wtype != W_F32 && wtype != W_BF16 && wtype != W_F32S) { set_error("gemm_nt: unknown weight type %d", wtype); return VLN_ERR_ARG; }
+    if (wide && fast && wtype != W_F32S) {
       if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw, 2, true, 2>, grid, block, 0, st, a);
       else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float, 2, true, 2>, grid, block, 0, st, a);
+    } else if (wtype == W_F32S) {
+      if (fast) VLN_NT_LAUNCH(f32s_raw, 2, true);
+      else VLN_NT_LAUNCH(f32s_raw, 1, false);
     } else if (wtype == W_BF16) {
       if (fast) { if (deep) VLN_NT_LAUNCH(bf16_raw, 4, true); else VLN_NT_LAUNCH(bf16_raw, 2, true); }
       else VLN_NT_LAUNCH(bf16_raw, 1, false);

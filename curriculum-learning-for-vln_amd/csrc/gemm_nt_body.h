@@ -1,9 +1,11 @@
-// gemm_nt: the workgroup body of Y[M,N] = X[M,K] W[N,K]^T (included by gemm.hip and chain.hip inside namespace vln).
+// gemm_nt: the workgroup body of Y[M,N] = X[M,K] W[N,K]^T (included by gemm.hip inside namespace vln).
 #pragma once
 
+// kF32: exact fp32 MFMA on fp32 weights.  kWS: fp32 weights in memory, split into hi + lo bf16 planes in registers (W_F32S).
 template <typename TW> struct GemmCfg;
-template <> struct GemmCfg<float> { static constexpr int BK = 32, VK = 8; };
-template <> struct GemmCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; };
+template <> struct GemmCfg<float> { static constexpr int BK = 32, VK = 8; static constexpr bool kF32 = true, kWS = false; };
+template <> struct GemmCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; static constexpr bool kF32 = false, kWS = false; };
+template <> struct GemmCfg<f32s_raw> { static constexpr int BK = 64, VK = 16; static constexpr bool kF32 = false, kWS = true; };
 
 constexpr int kLdsRow = 144;  // 128 B of data + 16 B pad per staged X row
 
@@ -26,9 +28,7 @@ struct GemmNTArgs {
 // overlaps anything.  Without branches the waits become vmcnt(N) and PD loads really are in flight.
 // NT = 16-column tiles per wave: the workgroup's tile is 64 rows x 64*NT columns.  NT = 2 halves the re-reads of X (every
 // column tile streams the whole activation slice: 2x the weight bytes at NT = 1) for the wide products (LSTM gates, d xcat).
-// Virtual block of a launch: the same body runs as a kernel of its own (one 256-thread workgroup per block) and as a stage
-// of the chained step kernel (chain.hip: two virtual blocks per 512-thread workgroup; `nbar` = the K-step count both halves
-// walk through so that the workgroup barriers inside the loop stay uniform).
+// Virtual block of a launch (`nbar` = the K-step count the workgroup's barriers walk through).
 struct VBlock { int bx, by, bz; int tid; unsigned char* smem; };
 
 constexpr int gemm_nt_smem_bytes(bool f32) { return 2 * (f32 ? 1 : 2) * 64 * kLdsRow; }
@@ -44,7 +44,8 @@ __device__ __forceinline__ int gemm_nt_nsteps(const GemmNTArgs& a, int by, int B
 template <typename TW, int PD, bool kFast, int NT, typename Pre>
 __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& vb, bool active, int nbar, Pre pre) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
-  constexpr bool kF32 = (sizeof(TW) == 4);
+  constexpr bool kF32 = GemmCfg<TW>::kF32, kWS = GemmCfg<TW>::kWS;
+  typedef typename std::conditional<kWS, float, TW>::type TM;       // the weights' element type IN MEMORY
   // bf16 path: the fp32 activations are split x = hi + lo (two bf16 planes) so only the STREAMED operand is
   // quantised; the second MFMA pair is free in these weight-bandwidth-bound shapes.
   constexpr int kPlanes = kF32 ? 1 : 2;
@@ -63,19 +64,19 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
   const float* xrow = a.X + (long)(srow_ok ? (m0 + srow) : (kFast ? a.M - 1 : 0)) * a.ldx;
   // fragment role
   const int fi = lane & 15, fq = lane >> 4;
-  int wn[NT]; bool wn_ok[NT]; const TW* wrow[NT];
+  int wn[NT]; bool wn_ok[NT]; const TM* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     wn[t] = n0 + (wave * NT + t) * 16 + fi;
     wn_ok[t] = wn[t] < a.N;
-    wrow[t] = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok[t] ? wn[t] : (kFast ? a.N - 1 : 0)) * a.ldw;
+    wrow[t] = reinterpret_cast<const TM*>(a.W) + (long)(wn_ok[t] ? wn[t] : (kFast ? a.N - 1 : 0)) * a.ldw;
   }
   const int mrows = min(64, a.M - m0);
   const int nrb = (mrows + 15) >> 4;
 
   float xs[PD][VK];
-  float wf32[PD][NT][kF32 ? 8 : 1];
-  bf16x8 wb16[PD][NT][kF32 ? 1 : 2];
+  float wf32[PD][NT][kF32 ? 8 : (kWS ? 16 : 1)];
+  bf16x8 wb16[PD][NT][(kF32 || kWS) ? 1 : 2];
 
   // kFast staging role: each 16-lane group reads 256 contiguous bytes of ONE row (two cache lines) per instruction.
   // (The bounds-checked role above gives every lane its own 64-byte run: a wave instruction then touches 32 lines for
@@ -153,18 +154,20 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
       *reinterpret_cast<bf16x8*>(dlo + 16) = l1;
     }
   };
-  auto load_w = [&](float (&w32)[kF32 ? 8 : 1], bf16x8 (&w16)[kF32 ? 1 : 2], int kb, int t) {
-    const TW* wrow_t = wrow[t]; const bool wn_ok_t = wn_ok[t];
+  auto load_w = [&](float (&w32)[kF32 ? 8 : (kWS ? 16 : 1)], bf16x8 (&w16)[(kF32 || kWS) ? 1 : 2], int kb, int t) {
+    const TM* wrow_t = wrow[t]; const bool wn_ok_t = wn_ok[t];
     const int k = kb + fq * VK;
-    if constexpr (kF32) {
+    if constexpr (kF32 || kWS) {
+      constexpr int NW = kF32 ? 8 : 16;
       if (kFast || (wn_ok_t && a.wvec && k + VK <= kend)) {
-        float4 t0 = *reinterpret_cast<const float4*>(wrow_t + k);
-        float4 t1 = *reinterpret_cast<const float4*>(wrow_t + k + 4);
-        w32[0] = t0.x; w32[1] = t0.y; w32[2] = t0.z; w32[3] = t0.w;
-        w32[4] = t1.x; w32[5] = t1.y; w32[6] = t1.z; w32[7] = t1.w;
+#pragma unroll
+        for (int v = 0; v < NW / 4; ++v) {
+          const float4 t0 = *reinterpret_cast<const float4*>(wrow_t + k + v * 4);
+          w32[v * 4 + 0] = t0.x; w32[v * 4 + 1] = t0.y; w32[v * 4 + 2] = t0.z; w32[v * 4 + 3] = t0.w;
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w32[j] = (wn_ok_t && (k + j) < kend) ? wrow_t[k + j] : 0.0f;
+        for (int j = 0; j < NW; ++j) w32[j] = (wn_ok_t && (k + j) < kend) ? wrow_t[k + j] : 0.0f;
       }
     } else {
       if (kFast || (wn_ok_t && a.wvec && k + VK <= kend)) {
@@ -210,6 +213,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
       // current W fragment -> private copy before the prefetch overwrites the registers
       float wc32[NT][kF32 ? 8 : 1];
       bf16x8 wc16[NT][kF32 ? 1 : 2];
+      bf16x8 wcl[NT][kWS ? 2 : 1];         // W_F32S: the weights' lo plane (w - bf16(w))
       if (on) {
         store_x(xs[p], buf);
 #pragma unroll
@@ -217,6 +221,16 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
           if constexpr (kF32) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) wc32[t][j] = wf32[p][t][j];
+          } else if constexpr (kWS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float w = wf32[p][t][h * 8 + j];
+                const __bf16 hi = (__bf16)w;
+                wc16[t][h][j] = hi;
+                wcl[t][h][j] = (__bf16)(w - (float)hi);
+              }
           } else {
             wc16[t][0] = wb16[p][t][0]; wc16[t][1] = wb16[p][t][1];
           }
@@ -262,6 +276,10 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
               for (int t = 0; t < NT; ++t) {
                 acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[t][0], acc[t][rb], 0, 0, 0);
                 acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wc16[t][1], acc[t][rb], 0, 0, 0);
+                if constexpr (kWS) {
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wcl[t][0], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wcl[t][1], acc[t][rb], 0, 0, 0);
+                }
                 acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc16[t][0], acc[t][rb], 0, 0, 0);
                 acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc16[t][1], acc[t][rb], 0, 0, 0);
               }

@@ -91,7 +91,7 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
   DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H;
-  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };     // per-matrix fp32 override
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32S : d->wtype; };     // per-matrix fp32 override
   // (1) positioned, dropped context (fresh mask per step, units.py:205-207)
   RUN(vln_pe_dropout(io->ctx, w->pe, io->pctx, B, L, H, io->seed_pe, io->off_pe, io->p_pe, s));
   // (2) the row blocks that need no computing: xcat = [prev_rep | . | . | h0], hm = [h0 | .]
@@ -142,7 +142,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, C = d->C, H = d->H, M = d->M, XK = 2 * M + 2 * H;
-  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32 : d->wtype; };
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32S : d->wtype; };
   float* q = g->scratch;
   auto take = [&](long k) { float* p = q; q += (k + 63) & ~63L; return p; };
   float *dmg = take((long)B * H), *dc1_t = take((long)B * H), *dww = take((long)B * L), *Z = take((long)B * (L + H)), *dpre = take(B);

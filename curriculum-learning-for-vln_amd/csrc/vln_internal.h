@@ -15,7 +15,12 @@ struct vln_colsum_job;
 namespace vln {
 
 enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
-enum WType { W_F32 = 0, W_BF16 = 1 };
+// W_F32S (round 4): the weights are an fp32 array in memory like W_F32, but the product runs on the bf16 matrix pipe with BOTH
+// operands split hi + lo (x_hi w_hi + x_lo w_hi + x_hi w_lo; the dropped lo*lo term is 2^-16 relative, fp32 accumulate): what the
+// bf16 mode uses for the matrices it streams in fp32 all the same (EnvDropDecoder / MonitorDecoder `fp32_weights`).  Same bytes as
+// W_F32, 3/16 of its matrix-pipe time -- it matters for the tall products (the BN-MLP's 1152 rows), not for the 64-row ones.
+enum WType { W_F32 = 0, W_BF16 = 1, W_F32S = 2 };
+struct f32s_raw { float f; };          // element type tag of W_F32S operands in the kernels' templates
 
 // thread-local last error text (vln_last_error_string)
 void set_error(const char* fmt, ...);

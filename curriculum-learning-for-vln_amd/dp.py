@@ -61,6 +61,39 @@ class BucketReducer:
         self.pending = []
 
 
+class BackwardCut:
+    """Cuts ONE backward pass in two at a set of tensors (the instruction encoder's outputs): the data-parallel iteration starts
+    the all-reduce of the decoder's gradients -- final when the decoder's backward is done -- BEFORE the encoder's backward
+    (BPTT) runs, and a captured iteration must end its first hipGraph segment there (graphs.SegmentedIterationGraph).
+
+        ctx, h, c = cut.at(*encoder(tokens, lengths))      # detached leaves that stand in for the encoder's outputs
+        loss = decoder_rollout(ctx, h, c); loss.backward()   # stops at the leaves: every decoder gradient is final
+        ... start_allreduce(decoder slice) ...
+        cut.resume()                                         # the encoder's backward, fed with the leaves' gradients
+
+    Same arithmetic as one `loss.backward()`: each leaf's gradient is what autograd would have handed to the encoder's node."""
+    carry = ("_vln_lp", "_vln_born")        # attributes the modules hang on their outputs (bf16 stream copy, arena stamp)
+
+    def __init__(self):
+        self.outs, self.leaves = None, None
+
+    def at(self, *tensors):
+        self.outs = tuple(tensors)
+        self.leaves = tuple(t.detach().requires_grad_(True) for t in tensors)
+        for new, old in zip(self.leaves, self.outs):
+            for a in self.carry:
+                if hasattr(old, a):
+                    setattr(new, a, getattr(old, a))
+        return self.leaves
+
+    def resume(self):
+        outs, leaves = self.outs, self.leaves
+        self.outs = self.leaves = None
+        pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None and o.requires_grad]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+
+
 class GradBucket:
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]

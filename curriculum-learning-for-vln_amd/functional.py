@@ -55,6 +55,13 @@ def base_dtype(dtype):
     return dtype[0] if isinstance(dtype, tuple) else dtype
 
 
+def _lin(x, W, kind, dtype, name, bias=None):
+    """x @ shadow(W)^T (+ bias) with matrix `name`'s streaming dtype under `dtype` (see wdtype): an fp32-streamed matrix of the
+    bf16 mode multiplies with split operands (ops.linear_fwd(split=True) = VLN_F32S), like the C-call steps do."""
+    wd = wdtype(dtype, name)
+    return ops.linear_fwd(x, SHADOWS.get(W, kind, wd), bias, split=(wd == torch.float32 and base_dtype(dtype) != torch.float32))
+
+
 # ---- parameter gradients of the fused nodes: returned to autograd (default) or added straight into p.grad ---------------
 _GRAD_IN_PLACE = [False]
 GRAD_IN_PLACE_STATS = [0, 0]            # [gradients added in place, gradients returned to autograd] (diagnostic)
@@ -502,7 +509,9 @@ class BnMlpFn(torch.autograd.Function):
         m = _lib.BnMlp()
         m.R, m.D0, m.nl = x.shape[0], x.shape[1], nl
         m.R1 = seg[0] if seg else 0
-        m.wtype = ops.F32 if dtype == torch.float32 else ops.BF16
+        wdt = wdtype(dtype, "mlp")                  # the Linear layers' streaming dtype (per-matrix fp32 override: functional.wdtype)
+        base = base_dtype(dtype)
+        m.wtype = ops.F32 if base == torch.float32 else (ops.F32S if wdt == torch.float32 else ops.BF16)
         m.training, m.eps, m.momentum = int(training), eps, momentum
         keep = []
 
@@ -512,7 +521,7 @@ class BnMlpFn(torch.autograd.Function):
         affine(m.bn0, tensors[0], tensors[1], bufs[0])
         for i in range(nl):
             W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
-            wn, wt = SHADOWS.get(W, "n", dtype), SHADOWS.get(W, "t", dtype)
+            wn, wt = SHADOWS.get(W, "n", wdt), SHADOWS.get(W, "t", wdt)
             keep += [wn, wt]
             l = m.layer[i]
             l.w, l.w_t, l.w_f32, l.b = wn.data_ptr(), wt.data_ptr(), W.data_ptr(), _p(b)
@@ -591,7 +600,7 @@ class BnMlpFn(torch.autograd.Function):
                 tg, tb = torch.empty_like(gw), torch.empty_like(gb); grads[4 + 4 * i], grads[5 + 4 * i] = tg, tb; ag = False
             gl.g_gamma, gl.g_beta, gl.acc_bn = tg.data_ptr(), tb.data_ptr(), int(ag)
             keepg += [tg, tb]
-        g.precision = ops.wgrad_precision(dtype != torch.float32)
+        g.precision = ops.wgrad_precision(base_dtype(dtype) != torch.float32)
         pj = None
         in_place = all(g.layer[i].acc_w and (tensors[3 + 4 * i] is None or g.layer[i].acc_b) for i in range(ctx.nl))
         if ctx.rw is not None and ROLLOUT_WGRADS.enabled and in_place:
@@ -653,7 +662,7 @@ class BnMlpFn(torch.autograd.Function):
         saved += [x, s0, y]
         for i in range(nl):
             W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
-            z = ops.linear_fwd(y, SHADOWS.get(W, "n", dtype), None if b is None else b.detach())
+            z = _lin(y, W, "n", dtype, "mlp", None if b is None else b.detach())
             last = i == nl - 1
             y, si = bn(z, gw, gb, bufs[1 + i], True, drops[i], rz if last else None)
             saved += [z, si, y]
@@ -678,7 +687,7 @@ class BnMlpFn(torch.autograd.Function):
         R = x.shape[0]
         dev = x.device
         grads = [None] * len(tensors)
-        wb = ops.WgradBatch(dtype != torch.float32, never_plain=True)     # behind a BatchNorm: split operands (csrc/bn_mlp.hip)
+        wb = ops.WgradBatch(base_dtype(dtype) != torch.float32, never_plain=True)     # behind a BatchNorm: split operands (csrc/bn_mlp.hip)
         cb = ops.ColsumBatch()
 
         def bn_bwd(inp, dyy, yy, w, stats, buf, relu, drop, rzp, want_dx, gi):
@@ -718,7 +727,7 @@ class BnMlpFn(torch.autograd.Function):
                 db, accb = _gsink(b)
                 cb.add(dz, db, None, accb)
                 grads[3 + 4 * i] = _gret(db, accb)
-            g = ops.linear_fwd(dz, SHADOWS.get(W, "t", dtype))
+            g = _lin(dz, W, "t", dtype, "mlp")
         # Mt is the same for every product of the call: one grouped launch each for weights and biases
         wb.run(); cb.run()
         dx = bn_bwd(x, g, None, tensors[0], s0, bufs[0], False, (0.0, 0, 0), None, ctx.needs_input_grad[0], 0)
@@ -782,23 +791,23 @@ class MonitorCoreFn(torch.autograd.Function):
         if rc:
             _lib.check(rc, "vln_pe_dropout")
         xcat = ops.empty(B, XK, dtype=f32, device=dev)          # [prev_rep | moves | words | h0]: the LSTM input row
-        tq = ops.linear_fwd(h0, SHADOWS.get(W_tin, "n", wdtype(dtype, "w_tin")))
+        tq = _lin(h0, W_tin, "n", dtype, "w_tin")
         _, word_w = ops.attn_fwd_rows(pctx, tq, ctx_mask, out=xcat[:, 2 * M:2 * M + H])
-        vq = ops.linear_fwd(h0, SHADOWS.get(W_vh, "n", wdtype(dtype, "w_vh")), b_vh.detach())
+        vq = _lin(h0, W_vh, "n", dtype, "w_vh", b_vh.detach())
         _, move_w = ops.attn_fwd_rows(cand_rep, vq, cand_mask, out=xcat[:, M:2 * M])
         xcat[:, :M].copy_(prev_rep)
         xcat[:, 2 * M + H:].copy_(h0)
-        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), False))
+        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), False), split=isinstance(dtype, tuple) and "w_cat" in dtype[1])
         h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off_h1, pd, True)
         tcat = ops.empty(B, 2 * H, dtype=f32, device=dev)        # [words | drop(h1)]
         tcat[:, :H].copy_(xcat[:, 2 * M:2 * M + H])
         tcat[:, H:].copy_(hd)
-        aq = ops.linear_fwd(tcat, SHADOWS.get(W_a, "n", wdtype(dtype, "w_a")), b_a.detach())
+        aq = _lin(tcat, W_a, "n", dtype, "w_a", b_a.detach())
         logit = ops.attn_dot(cand_rep, aq)
         hm = ops.empty(B, H + M, dtype=f32, device=dev)          # [h0 | moves]
         hm[:, :H].copy_(h0)
         hm[:, H:].copy_(xcat[:, M:2 * M])
-        mg = ops.linear_fwd(hm, SHADOWS.get(W_m, "n", wdtype(dtype, "w_m")), b_m.detach())
+        mg = _lin(hm, W_m, "n", dtype, "w_m", b_m.detach())
         mem = ops.empty(B, H, dtype=f32, device=dev)
         prog = ops.empty(B, dtype=f32, device=dev)
         wc = W_c.detach().reshape(-1)
@@ -834,15 +843,15 @@ class MonitorCoreFn(torch.autograd.Function):
                                       _p(dc1_t), _p(dww), _p(Z), _p(dpre), B, L, H, seed, off_mem, pd, st_)
         if rc:
             _lib.check(rc, "vln_monitor_head_bwd")
-        dhm = ops.linear_fwd(dmg, SHADOWS.get(W_m, "t", wdtype(dtype, "w_m")))                          # [B, H+M] -> h0 | moves
+        dhm = _lin(dmg, W_m, "t", dtype, "w_m")                          # [B, H+M] -> h0 | moves
         # action logits (policy.py:108-117): logit = cand_rep . aq
         if dlogit is None:
             dlogit = torch.zeros(B, C, dtype=f32, device=dev)
         daq = ops.rows_wsum(cand_rep, dlogit)
-        dtcat = ops.linear_fwd(daq, SHADOWS.get(W_a, "t", wdtype(dtype, "w_a")))                        # [B, 2H] -> words | drop(h1)
+        dtcat = _lin(daq, W_a, "t", dtype, "w_a")                        # [B, 2H] -> words | drop(h1)
         # LSTM cell
         dg, dc0 = ops.lstm_pointwise_bwd(dh1, dtcat[:, H:].contiguous(), dc1_t, act, tc, c0, seed, off_h1, pd)
-        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), True))          # [B, 2M+2H] -> prev | moves | words | h0
+        dxcat = ops.linear_fwd(dg, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), True), split=isinstance(dtype, tuple) and "w_cat" in dtype[1])          # [B, 2M+2H] -> prev | moves | words | h0
         dmoves = _add_n(E(B, M), [dhm[:, H:], dxcat[:, M:2 * M]])
         dwords = _add_n(E(B, H), [dtcat[:, :H], dxcat[:, 2 * M:2 * M + H]])
         # visual attention over the projected candidates; d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
@@ -852,7 +861,7 @@ class MonitorCoreFn(torch.autograd.Function):
             dcand = torch.empty(B, C, M, dtype=f32, device=dev)
             ops.attn_dctx_deferred([move_w.data_ptr(), dlogit.data_ptr()], [dl_v.data_ptr(), None], [dmoves.data_ptr(), aq.data_ptr()], M,
                                    [vq.data_ptr(), None], M, dcand)
-        dh0_v = ops.linear_fwd(dvq, SHADOWS.get(W_vh, "t", wdtype(dtype, "w_vh")))
+        dh0_v = _lin(dvq, W_vh, "t", dtype, "w_vh")
         # text attention over dropout(ctx + pe): d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's mask
         dtq, dl_t = ops.attn_bwd_rows(pctx, word_w, dwords, dww, want_dl=True)
         dctx = None
@@ -860,7 +869,7 @@ class MonitorCoreFn(torch.autograd.Function):
             dctx = torch.empty(B, L, H, dtype=f32, device=dev)
             ops.attn_dctx_deferred([word_w.data_ptr()], [dl_t.data_ptr()], [dwords.data_ptr()], H, [tq.data_ptr()], H, dctx,
                                    drop=[(seed_pe, off_pe, pp)])
-        dh0_t = ops.linear_fwd(dtq, SHADOWS.get(W_tin, "t", wdtype(dtype, "w_tin")))
+        dh0_t = _lin(dtq, W_tin, "t", dtype, "w_tin")
         dh0 = _add_n(E(B, H), [dhm[:, :H], dxcat[:, 2 * M + H:], dh0_v, dh0_t])
         # parameter gradients: six products over the same B rows -> one grouped launch; biases -> another
         sk = [_gsink(w) for w in (W_tin, W_vh, W_ih, W_hh, W_a, W_m)]

@@ -37,7 +37,7 @@ class IterationGraph:
         self.out = None
         self.replays = 0
 
-    def capture(self, warmup: int = 0):
+    def capture(self, warmup: int = 0, debug_dump: Optional[str] = None):
         """Run `warmup` eager iterations (first-use allocations, weight shadows, step plans), then record one."""
         for _ in range(warmup):
             self.fn()
@@ -47,9 +47,18 @@ class IterationGraph:
         self.clock.restart_sequences()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.out = self.fn()
-        self.clock.uncount()           # the captured tick did not run: the device words still hold the pre-capture values
+        if debug_dump:
+            g.enable_debug_mode()
+        try:
+            with torch.cuda.graph(g):
+                self.out = self.fn()
+        finally:
+            # The captured tick did not run: the device words still hold the pre-capture values.  Also when `fn` RAISED inside the
+            # capture: without this the clock's host mirror would stay one tick ahead of the device words and a
+            # caller that falls back to eager launches on the same clock would draw every dropout offset one iteration off.
+            self.clock.uncount()
+        if debug_dump:
+            g.debug_dump(debug_dump)   # graphviz text of the captured nodes (kernel names, memcpy / memset nodes, edges)
         self.graph = g
         self._check = lib.vln_persistent_check
         return self
@@ -63,5 +72,85 @@ class IterationGraph:
             _lib.check(st, "vln_persistent_check (raised by an earlier replay)")
         self.clock.replayed()          # host mirror of the tick launch inside the graph (+ the launch-sequence wrap guard)
         self.graph.replay()
+        self.replays += 1
+        return self.out
+
+
+class SegmentedIterationGraph:
+    """One training iteration as a SEQUENCE of hipGraphs with host code between them -- the data-parallel form of
+    `IterationGraph` (round 4).
+
+    A data-parallel iteration has two points where the HOST must act (the reference's loop is
+    engine/trainer.py:411-427): the decoder's gradients are final before the encoder's BPTT starts, so their RCCL all-reduce
+    is started there and runs under the BPTT; the rest of the bucket is reduced after the backward, before clip + update.  A
+    single captured graph cannot contain those calls, so round 3's N > 1 path issued all ~170 launches from Python (1.5 ms of
+    host time per iteration against 1.7 ms of GPU time).  Here the iteration is cut AT the exchange points:
+
+        graph A   tick, zero_grad, encoder forward, decoder steps, loss, the decoder's backward + its weight gradients
+        host      start_allreduce(decoder slice)                       (asynchronous, the process group's stream)
+        graph B   the encoder's backward (BPTT, its weight gradients)
+        host      allreduce(rest) + wait
+        graph C   clip + optimizer step
+
+    `segments` is a list of ("graph", fn) / ("host", fn) pairs; the graph segments are captured one after the other INTO ONE
+    memory pool on one stream (tensors made in one segment -- the autograd graph, the loss -- are consumed by the next), the host
+    segments run between them during capture too (so the ranks' collective sequences stay matched) and on every replay.
+    N = 1 and N > 1 replay the same kernels in the same order as the single graph: bit-identical results
+    (tests/test_hip_graphs.py).  Same contract for the iteration as `IterationGraph`: the first graph segment ticks the clock."""
+
+    def __init__(self, segments, clock: DeviceClock):
+        self.segments, self.clock = list(segments), clock
+        self.plan = None           # [("graph", CUDAGraph) | ("host", fn)]
+        self.replays = 0
+        self.out = None
+
+    def capture(self):
+        torch.cuda.synchronize()
+        lib = _lib.load()
+        _lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+        self.clock.restart_sequences()
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        plan = []
+        try:
+            for kind, fn in self.segments:
+                if kind == "graph":
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=stream):
+                        r = fn()
+                    if r is not None:
+                        self.out = r
+                    plan.append(("graph", g))
+                else:
+                    # Host code between two captures: it runs for real (a collective on whatever the buffers hold: the captured
+                    # kernels have not run) -- every rank does the same, so the collective sequences stay matched.  It must be
+                    # ordered after the capture stream's (empty) work like a replay would order it: nothing to wait for here.
+                    fn()
+                    plan.append(("host", fn))
+        finally:
+            self.clock.uncount()       # the captured tick did not run (also when a segment raised: see IterationGraph.capture)
+        self.plan = plan
+        self._check = lib.vln_persistent_check
+        return self
+
+    def run_eager(self):
+        """The same pieces issued as plain launches, in order (warm-up iterations; the CPU / gloo tests of the segment order)."""
+        out = None
+        for _, fn in self.segments:
+            r = fn()
+            out = r if r is not None else out
+        return out
+
+    def replay(self):
+        st = self._check()
+        if st:
+            _lib.check(st, "vln_persistent_check (raised by an earlier replay)")
+        self.clock.replayed()
+        for kind, x in self.plan:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
         self.replays += 1
         return self.out

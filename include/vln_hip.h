@@ -29,6 +29,10 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ERR_HIP 2
 #define VLN_F32 0
 #define VLN_BF16 1
+/* Weight operands only (ABI v13): an fp32 array in memory like VLN_F32, multiplied on the bf16 matrix pipe with both operands
+ * split hi + lo (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; 2^-16 relative) -- what the bf16 mode uses for the matrices
+ * it streams in fp32 all the same (vln_envdrop_weights.f32_mask, vln_monitor_weights.f32_mask, vln_bn_mlp.wtype). */
+#define VLN_F32S 2
 #define VLN_ACT_NONE 0
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2

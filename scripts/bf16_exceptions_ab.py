@@ -24,7 +24,8 @@ def row(tag, fs, prefix="bf16 unrounded: ", **extra):
     names = lambda r: r["what"].replace(prefix, "")
     over = sorted(((names(r), round(r["err"], 5)) for r in recs if r["err"] >= 1e-2 and names(r) not in SMOKE), key=lambda x: -x[1])
     worst = max((r["err"] for r in recs if names(r) not in SMOKE), default=0.0)
-    out = dict(agent=tag, fp32_weights=list(fs), comparisons=len(recs), over_1e2=len(over), worst=round(worst, 5), over=over[:14], **extra)
+    top = sorted(((names(r), round(r["err"], 5)) for r in recs if names(r) not in SMOKE), key=lambda x: -x[1])[:5]
+    out = dict(agent=tag, fp32_weights=list(fs), comparisons=len(recs), over_1e2=len(over), worst=round(worst, 5), over=over[:14], top5=top, **extra)
     print(json.dumps(out), flush=True)
     return out
 
@@ -58,8 +59,8 @@ if "cfg3" in which:
 vln.EnvDropDecoder.default_fp32_weights = default_env
 if "monitor" in which:
     import test_hip_full_size_agents as TA
-    MON_SETS = [(), ("mlp",), ("mlp", "w_cat"), ("mlp", "w_vh", "w_tin"), ("mlp", "w_cat", "w_vh", "w_tin"), ("mlp", "w_cat", "w_vh", "w_tin", "w_a", "w_m"),
-                ("w_cat", "w_vh", "w_tin", "w_a", "w_m")]
+    default_mon = vln.MonitorDecoder.default_fp32_weights
+    MON_SETS = [(), ("mlp",), ("mlp", "w_vh", "w_tin"), ("mlp", "w_cat", "w_vh", "w_tin"), ("mlp", "w_cat", "w_vh", "w_tin", "w_a", "w_m")]
     for fs in MON_SETS:
         vln.MonitorDecoder.default_fp32_weights = frozenset(fs)
         parity.RECORDS.clear()
@@ -71,7 +72,7 @@ if "monitor" in which:
         j = child_ms(code)
         row("self_monitor_cfg2", fs, ms_per_iteration=None if j is None else j["ms_per_iteration"],
             same_weights_worst=round(max(r["err"] for r in same), 5), same_weights_worst_what=max(same, key=lambda r: r["err"])["what"])
-    vln.MonitorDecoder.default_fp32_weights = frozenset()
+    vln.MonitorDecoder.default_fp32_weights = default_mon
     code = ("import sys; sys.path.insert(0,'.'); sys.path.insert(0,'scripts'); import vln_amd as v; import json, bench_agents as b; "
             "b.configure(steps=40, warmup=20, dtype='fp32'); v.functional.set_grad_in_place(True); v.functional.set_rollout_wgrads(True); print(json.dumps(b.run_monitor()))")
-    print(json.dumps(dict(agent="self_monitor_cfg2", dtype="fp32", **(child_ms(code) or {}))), flush=True)
+    print(json.dumps(dict(agent="self_monitor_cfg2", mode="fp32", **(child_ms(code) or {}))), flush=True)

@@ -52,10 +52,13 @@ def check(a, b, tol, what, floor=1e-6):
 # Parameter gradients that are ZERO IN EXACT ARITHMETIC in the parity tests' set-ups: both sides hold rounding noise only, so the
 # error is taken relative to `scale_floor` x the module's largest gradient instead of the tensor's own (vanishing) scale.  They
 # are listed BY NAME (round 4): every other tensor is held to its own scale, so a small but real gradient that is wrong fails.
-#   * a Linear bias directly in front of a train-mode BatchNorm (the batch mean removes any constant): MLPwithBN's Linear layers;
+#   * MLPwithBN (BatchNorm, then Linear -> BatchNorm -> Dropout -> ReLU per hidden layer, units.py:210-242): every Linear bias AND
+#     the first BatchNorm's beta sit directly in front of a train-mode BatchNorm, whose batch mean removes any per-feature
+#     constant -- `mlp.0.bias` (beta of the input BatchNorm), `mlp.1.bias`, `mlp.5.bias` (the Linear layers of the one- and
+#     two-hidden-layer configurations);
 #   * VisualSoftDotAttention.linear_in_v.bias: adds the same constant to every view's logit, softmax is shift-invariant;
 #   * ActionScoring.linear_out.bias: adds the same constant to every candidate's logit under a CE / softmax loss.
-EXACT_ZERO_GRADS = ("proj_navigable_mlp.mlp.1.bias", "visual_attn.linear_in_v.bias", "decode_action.linear_out.bias")
+EXACT_ZERO_GRADS = ("mlp.0.bias", "mlp.1.bias", "mlp.5.bias", "linear_in_v.bias", "decode_action.linear_out.bias")
 
 
 def grad_floor(name, gmax, scale_floor=1e-2, zero_grads=EXACT_ZERO_GRADS):

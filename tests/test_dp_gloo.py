@@ -152,6 +152,69 @@ def test_two_rank_fused_optimizer_bucket_equals_big_batch():
     assert torch.equal(got[0][1], got[1][1])
 
 
+def _worker_segments(rank, world, port, q):
+    """The SEGMENTED iteration of the data-parallel path (graphs.SegmentedIterationGraph, dp.BackwardCut) in its eager form:
+    [forward + the 'decoder' half of the backward] [start_allreduce(decoder group)] [the 'encoder' half] [allreduce] [update]."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import vln_amd as vln
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        enc = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh())
+        dec = torch.nn.Linear(8, 3)
+        X, Y = torch.randn(10, 6), torch.randn(10, 3)
+        opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters())], lr=1e-3, clip_norm=[40.0, 40.0])
+        rows = vln.dp.stride_shard(10, rank, world)
+        cut = vln.dp.BackwardCut()
+        log = []
+
+        def part_a():
+            opt.zero_grad()
+            (h,) = cut.at(enc(X[rows]))
+            loss = ((dec(h) - Y[rows]) ** 2).sum() / 10
+            loss.backward()
+            # the decoder's gradients are final, the encoder's untouched: exactly what the early slice relies on
+            log.append(("A", float(opt.flat_g[:opt._begins[1]].abs().sum()) == 0.0, float(opt.flat_g[opt._begins[1]:].abs().sum()) > 0.0))
+            return loss
+
+        def host1():
+            opt.start_allreduce(1); log.append(("start", len(opt._reducer.pending)))
+
+        def part_b():
+            cut.resume(); log.append(("B", float(opt.flat_g[:opt._begins[1]].abs().sum()) > 0.0))
+
+        def host2():
+            opt.allreduce(); log.append(("finish", len(opt._reducer.pending)))
+
+        def part_c():
+            log.append(("C",))
+
+        seg = vln.SegmentedIterationGraph([("graph", part_a), ("host", host1), ("graph", part_b), ("host", host2), ("graph", part_c)], None)
+        seg.run_eager()
+        q.put((rank, opt.flat_g.clone(), log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(420)
+def test_two_rank_segmented_iteration_order_and_gradients():
+    """the segment order of the one-path data-parallel iteration over a real two-rank world -- the early
+    slice leaves between the two halves of the backward with the decoder's gradients final and the encoder's still zero, the
+    closing all-reduce covers the rest, and the reduced bucket equals the big-batch gradient on both ranks."""
+    got = _run_world(_worker_segments)
+    torch.manual_seed(3)
+    enc = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh())
+    dec = torch.nn.Linear(8, 3)
+    X, Y = torch.randn(10, 6), torch.randn(10, 3)
+    (((dec(enc(X)) - Y) ** 2).sum() / 10).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in list(enc.parameters()) + list(dec.parameters())])
+    for rank, flat, log in got:
+        assert log == [("A", True, True), ("start", 1), ("B", True), ("finish", 0), ("C",)], log
+        assert torch.allclose(flat[:ref.numel()], ref, rtol=1e-5, atol=1e-7), f"rank {rank}: segmented DP gradient != big-batch gradient"
+    assert torch.equal(got[0][1], got[1][1])
+
+
 def _worker_abandon(rank, world, port, q):
     """Rank 1's iteration "raises" at three different points (before its early slice went out, after it, after the whole
     exchange) while rank 0 runs normally: `abandon_iteration` must issue exactly the collectives rank 0 issues -- the ranks

@@ -72,25 +72,21 @@ class _Oracle:
 def _oracles(cdt, sd, leaves, skip, bf16_exceptions):
     if cdt == torch.float32:
         return [_Oracle("fp32", sd, leaves, FP32, False, skip)]
-    # Same-weights oracle, gradients of the BN-MLP (Linear -> BatchNorm -> ReLU): a unit whose pre-activation is within rounding
-    # distance of zero has its ReLU on one side and off on the other (fp32 accumulation order differs between the kernels and
-    # the oracle) and then a WHOLE row term of its gradients differs; plain-bf16 weight-gradient operands add cancelling sums
-    # whose absolute error stays while the value shrinks.  Which elements are hit depends on the dropout draw, so single
-    # elements reach a few 1e-2 of the tensor's maximum (measured 1.5e-2 / 3.0e-2) while every tensor stays below the gradient
-    # tolerance in L2 -- asserted below for each loosened tensor.
-    same_exc = {"grad[proj_navigable_mlp": 6e-2, "grad[": same_bf16_grad_tol()}
+    # Same-weights oracle: the kernels' own arithmetic.  Parameter gradients carry the weight-gradient form's bound (plain bf16
+    # operands by default, split behind a BatchNorm: csrc/bn_mlp.hip).
+    same_exc = {"grad[": same_bf16_grad_tol()}
     return [_Oracle("bf16 same-weights", sd, leaves, SAME_BF16, True, skip, same_exc),
             _Oracle("bf16 unrounded", sd, leaves, BF16, False, skip, bf16_exceptions)]
 
 
-# bf16 vs the UNROUNDED fp64 oracle, Self-Monitor: the BN-MLP ends in a ReLU.  Rounding the 2176 -> 1024 weights moves the
-# pre-activations by ~1e-3 relative, which switches the ReLU of ~1e-3 of the units; each switch changes a gradient term by its
-# full size, so parameter gradients upstream of the ReLU differ by O(sqrt(1e-3)) in L2 whatever the kernel does (the
-# same-weights oracle, where no unit switches, is met at 1e-4).  Recurrent state after two steps: the rounding error of the
-# gate pre-activations (K = 3072 terms) amplified by the candidate softmax.
-MONITOR_BF16_EXC = {"grad[proj_navigable_mlp": 0.6, "grad[visual_attn": 6e-2, "grad[lstm": 3e-2, "grad[": 2e-2, "loss": 0.1,
-                    "h1_": 6e-2, "c1_": 4e-2, "cand_attn": 4e-2, "progress": 3e-2, "dh0": 6e-2, "dc0": 4e-2, "dctx": 2e-2,
-                    "proj_navigable_mlp.mlp.2.running_var": 1e-3}
+# bf16 vs the UNROUNDED fp64 oracle, Self-Monitor.  The BN-MLP ends in a ReLU: rounding its 2176 -> 1024 weights to bf16 moves the
+# pre-activations by ~1e-3 relative, switches the ReLU of ~1e-3 of the units, and each switch changes a gradient term by its full
+# size (0.16 of the gradient's range, round 3); the attention queries sit in front of a softmax and the K = 3072 gate sums feed the
+# recurrent state (h1 / dc0 at 3e-2).  Round 4: MonitorDecoder streams those four matrices in fp32 BY DEFAULT
+# (default_fp32_weights = mlp, w_cat, w_vh, w_tin; VLN_F32S arithmetic) and the default bf16 mode is held to north_star's 1e-2 on
+# every tensor (scripts/bf16_exceptions_ab.py: 0 of 39 comparisons over).  What remains listed: the random-weighted scalar "loss"
+# of this test (a cancelling sum of O(1e4) terms: relative error not meaningful, kept as a smoke value).
+MONITOR_BF16_EXC = {"loss": 0.1}
 FOLLOWER_BF16_EXC = {"loss": 2e-2}
 
 

@@ -16,7 +16,7 @@ def vln():
     return vln_amd
 
 
-def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False):
+def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -30,6 +30,11 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False):
     ag.rollout_gather = ag.gather_branch = branch == "branch"
     ag.ride_gather = branch == "ride"            # the gather as passengers of the encoder's recurrence launch
     ag.use_clock(store)
+    if segmented:                  # the data-parallel form: three graph segments, the gradient exchange issued between them
+        ag.segmented = True
+        if calls is not None:      # stand-ins for the collectives: record WHEN the host segments run
+            ag.opt.start_allreduce = lambda gi: calls.append(("start", gi))
+            ag.opt.allreduce = lambda: calls.append(("finish",))
     out = []
 
     def record(loss):
@@ -68,6 +73,26 @@ def test_iteration_graph_equals_eager(vln, dtype, branch):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the replayed iteration"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segmented_iteration_graph_equals_the_single_graph(vln, dtype):
+    """ONE path for N = 1 and N > 1.  The data-parallel form of the iteration -- graph A (forward, loss,
+    the decoder's backward), host (start the decoder slice's all-reduce), graph B (the encoder's backward), host (reduce the
+    rest, wait), graph C (clip + update); graphs.SegmentedIterationGraph -- replays the same kernels in the same order as the
+    single graph: losses, parameters, RMSprop state and gradient norms are equal bit for bit over four replays with fresh
+    batches and masks, its eager form too, and the host segments run exactly once per iteration, in order, between the graphs."""
+    single, word_s, host_s = _run(vln, dtype, True, "ride")
+    calls = []
+    seg, word_g, host_g = _run(vln, dtype, True, "ride", segmented=True, calls=calls)
+    seg_eager, _, _ = _run(vln, dtype, False, "ride", segmented=True)
+    assert word_s == host_s == word_g == host_g
+    # 2 eager iterations + 1 capture pass + 4 replays, every one of them: start(decoder group) then finish
+    assert calls == [("start", 1), ("finish",)] * 7
+    for i, (a, b, c) in enumerate(zip(single, seg, seg_eager)):
+        for x, y, z, what in zip(a, b, c, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between the single graph and the three segments"
+            assert torch.equal(x, z), f"iteration {i}: {what} differ between the single graph and the eager segments"
 
 
 @pytest.mark.parametrize("graph", [True, False])

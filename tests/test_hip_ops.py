@@ -35,6 +35,21 @@ def test_linear_fwd(vln, M, N, K, wdt):
     check(y, ref, tol, "y")
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2752), (64, 2176, 512), (1152, 1024, 2176), (64, 512, 1024), (4, 48, 40), (7, 1, 64),
+                                   (130, 100, 36)])
+def test_linear_fwd_split_fp32_weights(vln, M, N, K):
+    """VLN_F32S (round 4): fp32 weights multiplied on the bf16 matrix pipe with BOTH operands split hi + lo (three products, the
+    dropped lo * lo term is 2^-16 relative) -- the arithmetic of the bf16 mode's fp32-streamed matrices.  fp32-grade: 1e-4 of the
+    fp64 product like the exact fp32 MFMA path, at the aligned decoder / BN-MLP shapes and at unaligned ones (bounds-checked form)."""
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K + 1)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    ref = torch.tanh(x.double() @ w.double().t() + b.double())
+    y = vln.ops.linear_fwd(x.to(dev()), w.to(dev()), b.to(dev()), vln.ops.ACT_TANH, split=True)
+    check(y, ref, 1e-4, "y (split fp32 weights)")
+    y_bf = vln.ops.linear_fwd(x.to(dev()), w.bfloat16().to(dev()), b.to(dev()), vln.ops.ACT_TANH)
+    assert rel_err(y, ref) < 0.1 * max(rel_err(y_bf, ref), 1e-5) or rel_err(y, ref) < 2e-5     # an order below the bf16-streamed form
+
+
 def test_linear_fwd_strided_x(vln):
     g = torch.Generator().manual_seed(5)
     big = torch.randn(64, 300, generator=g).to(dev())
@@ -452,9 +467,9 @@ def test_split_attention_timeout_has_its_own_sticky_word_and_switches_the_split_
     vln._lib.check(lib.vln_persistent_check(), "clean start")
     B, S, D = 64, 36, 2176
     g = torch.Generator().manual_seed(5)
-    ctx = (torch.randn(B, S, D, generator=g) * 0.3).to(DEV)
-    q = (torch.randn(B, D, generator=g) * 0.1).to(DEV)
-    sync = torch.zeros(int(lib.vln_attn_sync_bytes(B)) // 4 + 1, dtype=torch.int32, device=DEV)
+    ctx = (torch.randn(B, S, D, generator=g) * 0.3).to("cuda:0")
+    q = (torch.randn(B, D, generator=g) * 0.1).to("cuda:0")
+    sync = torch.zeros(int(lib.vln_attn_sync_bytes(B)) // 4 + 1, dtype=torch.int32, device="cuda:0")
     out_split, attn_split = vln.ops.attn_fwd_rows(ctx, q, None, sync=sync)
     assert lib.vln_get_split_attention() == 1
     try:
