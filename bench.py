@@ -149,17 +149,22 @@ def build_store(vln, dev, dtype, n_rows=N_VIEWPOINTS, V=36, IMG=2048, ANG=128, s
 
 class LiveBatch:
     """The small per-batch tensors of the CURRENT episode batch (tokens, lengths, masks, per-step index vectors, targets,
-    angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (one copy
-    per iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA
-    changes every iteration.  The packed batches wait in PINNED HOST memory (`host=True`, the bench's default since round 4: what
-    a trainer's data loader hands over -- base.py:114-178 marshals every batch on the host) and `load(k)` is ONE asynchronous
-    host-to-device copy of batch k's blob into the live blob, stream-ordered in front of the iteration; `host=False` keeps the
-    batches on the device (a device-to-device copy: round 3's form, kept for A/B)."""
+    angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (once per
+    iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA changes
+    every iteration.  Where the packed batches wait (`source`):
+      "pull"    (the bench's default since round 4) in PINNED HOST memory -- what a trainer's data loader hands over; base.py:114-178
+                marshals every batch on the host.  `load(k)` stores batch k's address in a pinned slot (one host store) and the
+                iteration's FIRST launch pulls the blob through PCIe into the live buffers (staging.HostBatchFeed, vln_host_fetch):
+                the agent calls `fetch()` at the top of the iteration, so a captured iteration contains it;
+      "copy"    in pinned host memory, `load(k)` = one hipMemcpyAsync H2D in front of the iteration (A/B: +130 us per iteration in
+                front of a graph replay, profiles/round4_notes.md);
+      "device"  on the device, `load(k)` = one device-to-device copy (round 3's form, A/B)."""
     TOP = ("tokens", "lengths32", "seq_mask")
     STEP = ("rows", "vidx", "crow", "cview", "chead", "celev", "cand_mask", "angle", "target")
 
-    def __init__(self, tapes, host=False):
-        self.host = bool(host)
+    def __init__(self, tapes, source="device"):
+        assert source in ("pull", "copy", "device")
+        self.source = source
         t0 = tapes[0]
         self.layout, off = [], 0
         for name, t in self._items(t0):
@@ -168,6 +173,11 @@ class LiveBatch:
             off = (off + n + 15) & ~15
         self.nbytes = off
         dev = t0["tokens"].device
+        self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+        self.feed = None
+        if source == "pull":
+            import vln_amd
+            self.feed = vln_amd.HostBatchFeed(self.live_blob)
         self.blobs = []
         for tp in tapes:
             blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
@@ -175,10 +185,11 @@ class LiveBatch:
                 if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
                     raise ValueError(f"LiveBatch: tape layouts differ at {name}: {tuple(t.shape)} vs {shape}")
                 blob[o:o + n] = t.contiguous().view(-1).view(torch.uint8)
-            if self.host:
+            if source == "copy":
                 blob = blob.cpu().pin_memory()
+            elif source == "pull":
+                blob = self.feed.register(blob)
             self.blobs.append(blob)
-        self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
         views = {name: self.live_blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.layout}
         self.live = {k: v for k, v in t0.items() if k not in self.TOP + ("steps",)}
         for k in self.TOP:
@@ -193,8 +204,20 @@ class LiveBatch:
                 yield f"{i}.{k}", s[k]
 
     def load(self, k):
-        self.live_blob.copy_(self.blobs[k % len(self.blobs)], non_blocking=True)
+        if self.feed is not None:
+            self.feed.select(self.blobs[k % len(self.blobs)])       # one host store; the iteration's first launch pulls the blob
+        else:
+            self.live_blob.copy_(self.blobs[k % len(self.blobs)], non_blocking=True)
         return self.live
+
+    def fetch(self):
+        """Top of the iteration (eager or inside a capture): the pull of the selected batch, if this LiveBatch pulls."""
+        if self.feed is not None:
+            self.feed.fetch()
+
+    def launched(self):
+        if self.feed is not None:
+            self.feed.launched()
 
 
 class GpuAgent:
@@ -240,6 +263,8 @@ class GpuAgent:
         # the host can start the decoder slice's all-reduce between the two halves -- the data-parallel path (N > 1, --dp-path)
         self.segmented = False
         self._cut = None
+        self.batch_fetch = None         # LiveBatch.fetch / .launched when the batches are pulled from pinned host memory
+        self.batch_launched = None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
         self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
 
@@ -271,7 +296,16 @@ class GpuAgent:
         return self.graph
 
     def replay(self):
-        return self.graph.replay()
+        out = self.graph.replay()
+        if self.batch_launched is not None:
+            self.batch_launched()
+        return out
+
+    def use_live(self, live):
+        """A LiveBatch whose batches are PULLED from pinned host memory: the iteration's first launch is the pull
+        (staging.HostBatchFeed); after every iteration / replay an event bounds how far the host may run ahead."""
+        if live.feed is not None:
+            self.batch_fetch, self.batch_launched = live.fetch, live.launched
 
     def use_arena(self, on: bool):
         self.arena = self.vln.ops.RolloutArena() if on else None
@@ -331,6 +365,12 @@ class GpuAgent:
         return img, cand, dict(already_dropfeat=True)
 
     def iteration(self, tape):
+        out = self._iteration_eager(tape)
+        if self.batch_launched is not None and not torch.cuda.is_current_stream_capturing():
+            self.batch_launched()
+        return out
+
+    def _iteration_eager(self, tape):
         if self.segmented:             # the same five pieces a SegmentedIterationGraph captures / replays, issued eagerly
             out = None
             for _, fn in self.segments(tape):
@@ -377,6 +417,8 @@ class GpuAgent:
 
     def _iteration(self, tape):
         B = tape["B"]
+        if self.batch_fetch is not None:
+            self.batch_fetch()         # one launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull")
         if self.clock is not None:
             self.clock.tick()          # one launch: this iteration's dropout offsets / launch sequence (device words)
         self._probe()
@@ -625,10 +667,11 @@ def main():
                          "inside the step's first launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
-    ap.add_argument("--batch-source", default="host", choices=["host", "device"],
+    ap.add_argument("--batch-source", default="pull", choices=["pull", "copy", "device"],
                     help="where the packed episode batches (tokens, masks, per-step index vectors, targets: ~0.4 MB each) wait: "
-                         "pinned HOST memory, one hipMemcpyAsync H2D per iteration (default: what a data loader hands over), or "
-                         "device memory, one device-to-device copy (round 3's form, A/B)")
+                         "pull = pinned HOST memory, the iteration's first launch pulls the batch through PCIe (default: what a data "
+                         "loader hands over); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
+                         "device memory, one device-to-device copy (round 3's form)")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
                          "exchange issued between them (graphs.SegmentedIterationGraph) on a ONE-rank RCCL group, collectives "
@@ -728,7 +771,9 @@ def main():
             if hd is not None:
                 for s in t["steps"]:
                     del s["img"], s["cand"]
-    live = LiveBatch(tapes, host=args.batch_source == "host") if args.features == "store" else None
+    live = LiveBatch(tapes, source=args.batch_source) if args.features == "store" else None
+    if live is not None:
+        agent.use_live(live)
     if rank == 0:
         print(f"[bench] setup: {store.N}-viewpoint table ({store.table.numel() * store.table.element_size() / 2**30:.2f} GiB {args.dtype}), "
               f"{len(tapes)} tapes, {time.perf_counter() - t_setup:.1f} s", file=sys.stderr, flush=True)
@@ -746,7 +791,7 @@ def main():
             return iterate_eager()
         k = it_no[0]
         it_no[0] = k + 1
-        live.load(k)                  # the new batch into the fixed buffers (one 0.4 MB device copy), then ONE graph launch
+        live.load(k)                  # the new batch: its address into the pinned slot ring (or one copy), then ONE graph launch
         return agent.replay()
 
     def barrier():
@@ -911,6 +956,7 @@ def main():
                          ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
                          ("all_bf16_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
                                                                                     fp32_weights=())),
+                         ("il_host_in_loop", lambda: secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args)),
                          ("decoder_step_fwd_bwd", per_step),
                          ("phases", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, phases=True)),
                          ("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args, graph=use_graph)),
@@ -923,7 +969,9 @@ def main():
                          ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store, dtype="fp32")),
                          ("self_monitor_B128_bf16", lambda: secondary_agents(dev, args, "monitor", store, dtype="bf16")),
                          ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store, dtype="bf16")),
-                         ("speaker_follower_B64_fp32", lambda: secondary_agents(dev, args, "follower", store, dtype="fp32"))):
+                         ("speaker_follower_B64_fp32", lambda: secondary_agents(dev, args, "follower", store, dtype="fp32")),
+                         ("speaker_teacher_forcing_B64", lambda: secondary_agents(dev, args, "speaker", store, dtype="bf16")),
+                         ("speaker_teacher_forcing_B64_fp32", lambda: secondary_agents(dev, args, "speaker", store, dtype="fp32"))):
             t1 = time.perf_counter()
             try:
                 secondary[name] = fn()
@@ -960,7 +1008,9 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
-                       "batch_source": (("pinned host, one H2D copy per iteration" if args.batch_source == "host" else "device, one D2D copy per iteration") if live is not None else "per-step tensors"),
+                       "batch_source": ({"pull": "pinned host memory, pulled by the iteration's first launch (vln_host_fetch)",
+                                         "copy": "pinned host memory, one hipMemcpyAsync H2D per iteration",
+                                         "device": "device memory, one D2D copy per iteration"}[args.batch_source] if live is not None else "per-step tensors"),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
@@ -1019,7 +1069,8 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
         if features == "store":
             st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
             tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
-            live = LiveBatch(tapes)
+            live = LiveBatch(tapes, source=args.batch_source)
+            ag.use_live(live)
             get = live.load
         else:                    # host: pinned host fp32 features (what the reference's ImageFeatures holds); tensor: device tensors
             tapes = []
@@ -1035,7 +1086,7 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
             ag.iteration(get(k))
         torch.cuda.synchronize()
         if phases:
-            return _phase_times(ag, get, steps)
+            return _phase_times(ag, get, steps, len(cpu_tapes[0]["steps"]))
         if graph:
             ag.capture(live.live)
             run = lambda k: (live.load(k), ag.replay())
@@ -1053,7 +1104,115 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
         vln.ops.set_wgrad_precision(prev_w)
 
 
-def _phase_times(ag, get, steps):
+class LiveSteps:
+    """Host-in-the-loop marshalling: like LiveBatch, but the per-STEP inputs (viewpoint rows, view / candidate indices, candidate
+    mask, angle feature of the previous action, teacher action) live in one pinned host blob PER STEP and are copied to that step's
+    fixed device buffers only when the step is about to run -- the shape of the reference's rollout, whose every step marshals the
+    simulator's new observation on the host (agent/base.py:141-178) after the previous action has reached it (envdrop.py:198-204)."""
+
+    def __init__(self, tapes, dev):
+        t0 = tapes[0]
+        T = len(t0["steps"])
+        top = [(k, t0[k]) for k in LiveBatch.TOP]
+        self.top_layout, self.top_bytes = self._layout(top)
+        self.step_layout, self.step_bytes = self._layout([(k, t0["steps"][0][k]) for k in LiveBatch.STEP])
+        self.top_host = [self._pack(self.top_layout, self.top_bytes, [(k, tp[k]) for k in LiveBatch.TOP]) for tp in tapes]
+        self.step_host = [[self._pack(self.step_layout, self.step_bytes, [(k, s[k]) for k in LiveBatch.STEP]) for s in tp["steps"]]
+                          for tp in tapes]
+        self.top_dev = torch.zeros(self.top_bytes, dtype=torch.uint8, device=dev)
+        self.step_dev = [torch.zeros(self.step_bytes, dtype=torch.uint8, device=dev) for _ in range(T)]
+        self.live = {k: v for k, v in t0.items() if k not in LiveBatch.TOP + ("steps",)}
+        self.live.update(self._views(self.top_layout, self.top_dev))
+        self.live["steps"] = [self._views(self.step_layout, b) for b in self.step_dev]
+        # what the fake environment keeps on the host: every step's teacher actions, to be compared with what the agent sent
+        self.host_targets = [[s["target"].cpu().numpy() for s in tp["steps"]] for tp in tapes]
+
+    @staticmethod
+    def _layout(items):
+        out, off = [], 0
+        for name, t in items:
+            n = t.numel() * t.element_size()
+            out.append((name, off, n, t.dtype, tuple(t.shape)))
+            off = (off + n + 15) & ~15
+        return out, off
+
+    @staticmethod
+    def _pack(layout, nbytes, items):
+        blob = torch.zeros(nbytes, dtype=torch.uint8)
+        for (name, o, n, dt, shape), (name2, t) in zip(layout, items):
+            if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
+                raise ValueError(f"LiveSteps: tape layouts differ at {name}")
+            blob[o:o + n] = t.detach().cpu().contiguous().view(-1).view(torch.uint8)
+        return blob.pin_memory()
+
+    @staticmethod
+    def _views(layout, blob):
+        return {name: blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in layout}
+
+    def load_top(self, k):
+        self.top_dev.copy_(self.top_host[k % len(self.top_host)], non_blocking=True)
+        return self.live
+
+    def load_step(self, k, t):
+        self.step_dev[t].copy_(self.step_host[k % len(self.step_host)][t], non_blocking=True)
+        return self.live["steps"][t]
+
+
+def secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args, steps=20, warmup=6):
+    """ms per iteration of the headline workload with THE HOST IN THE LOOP, in the reference's loop shape (envdrop.py:151-220):
+    per decoder step the step's index vectors arrive by a pinned H2D copy (the observation the simulator just produced,
+    base.py:141-178), the step runs (per-step hipGraph, candidate logits formed in the step, CE term per step), the chosen action
+    a_t goes back to the host (`a_t.cpu()`, envdrop.py:198: one D2H + stream synchronisation per step) and a fake environment
+    steps on it (checks the action against its own teacher tape, picks the next observation's blob).  Features stay in the
+    resident table; the iteration is eager launches + per-step graphs: nothing of it can be captured whole."""
+    import numpy as np
+    torch.manual_seed(2020)
+    ag = GpuAgent(vln, dev, dtype, 1, arena=True, rollout_ce=False)
+    ag.clear_grads_in_step = True
+    st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
+    tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
+    ls = LiveSteps(tapes, dev)
+    B = tapes[0]["B"]
+    mismatches = [0]
+
+    def iteration(k):
+        vln.ops.set_arena(ag.arena); ag.arena.begin()
+        try:
+            tape = ls.load_top(k)
+            ag.opt.zero_grad()
+            ctx, h_t, c_t = ag.enc(tape["tokens"], tape["lengths32"])
+            h_tilde = h_t
+            terms = []
+            for t in range(len(tape["steps"])):
+                s = ls.load_step(k, t)                                      # this step's observation: pinned host -> device
+                logits, (h_t, c_t), h_tilde = ag.dec(s["angle"], None, None, h_tilde, h_t, c_t, ctx, tape["seq_mask"],
+                                                     gather=(st, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
+                terms.append(vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
+                a_t = s["target"]                                           # teacher forcing: a_t = target (envdrop.py:183)
+                cpu_a_t = a_t.cpu().numpy()                                 # envdrop.py:198: the action reaches the simulator
+                # fake environment: episodes whose action is -1 have ended (envdrop.py:199-203); it answers with the next blob
+                mismatches[0] += int((cpu_a_t != ls.host_targets[k % len(tapes)][t]).sum())
+            loss = torch.stack(terms).sum() * (ML_WEIGHT / B)
+            loss.backward()
+            ag.opt.step(zero_grads=True)
+            return loss
+        finally:
+            vln.ops.set_arena(None)
+
+    for k in range(4 + warmup):
+        iteration(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        iteration(k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 3), "per_step_host_round_trips": len(tapes[0]["steps"]), "action_mismatches": mismatches[0],
+            "how": "per step: pinned H2D of the step's index vectors, decoder step (per-step hipGraph, logits in the step, CE per step), "
+                   "D2H of a_t + fake-env host step; features from the resident table"}
+
+
+def _phase_times(ag, get, steps, n_dec_steps):
     """GPU time per phase of an eager iteration (per-decoder-step fwd / bwd and the optimizer reported apart): hip
     events recorded on the stream between the phases; the host runs ahead, so the differences are device time."""
     marks = {}
@@ -1065,7 +1224,7 @@ def _phase_times(ag, get, steps):
 
     enc_fwd, dec_call, opt_step, opt_zero = ag.enc.forward, ag.dec.forward, ag.opt.step, ag.opt.zero_grad
     state = {"t": 0}
-    T = len(get(0)["steps"])
+    T = n_dec_steps
 
     def enc_w(*a, **k):
         mark("start")
@@ -1126,7 +1285,8 @@ def secondary_agents(dev, args, which, store, dtype=None):
     gc.collect()
     gc.freeze()                         # the bench's own objects (agent, tapes, store) out of the cyclic collector's way, as in the timed loop
     try:
-        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else (W.run_follower() if which == "follower" else W.run_monitor())
+        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else (W.run_follower() if which == "follower" else
+                                                                    (W.run_speaker() if which == "speaker" else W.run_monitor()))
     finally:
         W.vln.functional.set_rollout_wgrads(False)
         W.vln.functional.set_grad_in_place(False)

@@ -275,6 +275,8 @@ SIGNATURES = {
     "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),
+    "vln_host_device_pointer": (i32, [ptr, C.POINTER(C.c_void_p)]),
+    "vln_host_fetch": (i32, [ptr, i32, ptr, ptr, ptr, i64, ptr]),
     "vln_set_split_attention": (i32, [i32]),
     "vln_get_split_attention": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),

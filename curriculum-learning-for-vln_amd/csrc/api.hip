@@ -333,6 +333,59 @@ extern "C" int vln_tick(const vln_tick_item* items, int n, vln_stream_t s) {
   return VLN_OK;
 }
 
+// ---- the batch hand-over: the GPU PULLS the packed batch out of pinned host memory ------------------------------------------------
+// The reference marshals every batch on the host (agent/base.py:114-178) and copies it with `.to(device)`.  Here the trainer packs the
+// batch's small tensors (tokens, masks, per-step index vectors, targets: ~0.4 MB) into ONE pinned host blob and stores the blob's
+// address in a pinned SLOT word; this kernel -- the first node of the iteration graph -- reads the slot and copies the blob into the
+// fixed device buffers the captured iteration reads.  No copy API call sits between two graph replays (a stream-ordered
+// hipMemcpyAsync in front of the graph cost 130 us per iteration on MI355X: profiles/round4_notes.md), the launch arguments repeat,
+// and the host's share per iteration is one store.
+// The host runs AHEAD of the device (it enqueues many replays), so one slot would be overwritten before the launch that should read
+// it has run: the slots form a RING of `ring` words and the kernel picks slot (*seq % ring), where `seq` is a device word counting
+// the fetches that have run; the last workgroup to finish bumps it (every workgroup has read it by then).
+namespace vln {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void host_fetch_kernel(const unsigned long long* slots, int ring, unsigned long long* seq, unsigned* done,
+                                                         u32x4* dst, long n16) {
+  const unsigned long long n = *seq;
+  const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(slots + (n % (unsigned long long)ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+    dst[i] = __builtin_nontemporal_load(src + i);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {           // every workgroup has read *seq: the next launch sees the next slot
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(seq, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+}  // namespace vln
+extern "C" int vln_host_device_pointer(const void* host, void** dev) {
+  if (!host || !dev) { set_error("vln_host_device_pointer: null pointer"); return VLN_ERR_ARG; }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void*>(host), 0) != hipSuccess || !d) {
+    (void)hipGetLastError();
+    set_error("vln_host_device_pointer: %p is not pinned host memory mapped into the device's address space", host);
+    return VLN_ERR_ARG;
+  }
+  *dev = d;
+  return VLN_OK;
+}
+extern "C" int vln_host_fetch(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, vln_stream_t s) {
+  if (!slots_dev || !seq || !done || !dst || ring < 1 || nbytes <= 0 || (nbytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    set_error("vln_host_fetch: null pointer, empty ring, or size / destination not a multiple of 16 bytes");
+    return VLN_ERR_ARG;
+  }
+  const long n16 = nbytes / 16;
+  int blocks = (int)((n16 + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  VLN_LAUNCH(host_fetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, reinterpret_cast<const unsigned long long*>(slots_dev), ring,
+             reinterpret_cast<unsigned long long*>(seq), reinterpret_cast<unsigned*>(done), static_cast<u32x4*>(dst), n16);
+  VLN_CHECK_LAUNCH("host_fetch");
+  return VLN_OK;
+}
+
 // ---- measurement only: a chain of trivial DEPENDENT launches (what does a kernel boundary cost inside THIS process / graph?) ----
 namespace vln {
 __global__ __launch_bounds__(256) void debug_trivial_kernel(const float4* in, float4* out, int n4, int shift) {

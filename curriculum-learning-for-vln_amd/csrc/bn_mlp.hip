@@ -98,8 +98,12 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     float* z = saved + L.z[i];
     float* si = saved + L.s[i];
     float* yi = saved + L.y[i];
-    // split-K scratch bounded like ops.linear_fwd bounds it: the same K split, hence the same bits, as the operator path
-    RUN(gemm_nt(st, y, in, l.w, m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
+    // split-K scratch bounded like ops.linear_fwd bounds it: the same K split, hence the same bits, as the operator path.
+    // VLN_F32S (fp32-streamed layer of the bf16 mode): the FORWARD product runs on the exact fp32 MFMA -- a ReLU follows (behind the
+    // BatchNorm), and a unit whose pre-activation moves across zero changes a whole gradient term: the 2^-16 of the split product
+    // flipped ~10 of the 1.2 M units at BASELINE config 2 (2.5e-2 of the weight gradient's range, profiles/round4_notes.md), the
+    // exact product flips none.  The backward's products (no ReLU decision in them) keep the split form.
+    RUN(gemm_nt(st, y, in, l.w, m->wtype == W_F32S ? (int)W_F32 : m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
     const bool last = (i == m->nl - 1);
     RUN(bn_fwd_seg(z, l.out, yi, l.out, l.bn.gamma, l.bn.beta, l.bn.run_mean, l.bn.run_var, tr ? l.bn.nbt : nullptr, tr ? si : nullptr,
                    tr ? si + l.out : nullptr, R, R1, 2L * l.out, l.out, m->eps, m->momentum, tr, 1, l.seed, l.offset, l.offset2,

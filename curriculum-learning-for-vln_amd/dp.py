@@ -50,14 +50,21 @@ class BucketReducer:
             self.pending = []
             return
         pos, n = 0, self.flat.numel()
+        late = []
         for lo, hi, _ in sorted(self.pending, key=lambda t: t[0]):
             if lo > pos:
-                dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM, group=group)
+                late.append(dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM, group=group, async_op=True))
             pos = max(pos, hi)
         if pos < n:
-            dist.all_reduce(self.flat[pos:n], op=dist.ReduceOp.SUM, group=group)
-        for _, _, w in self.pending:
-            w.wait()
+            late.append(dist.all_reduce(self.flat[pos:n], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works = [w for _, _, w in self.pending] + late
+        if works and dist.get_backend(group) == "nccl":
+            # RCCL runs every collective of the group on ONE stream, in issue order: waiting for the LAST one joins them all with a
+            # single cross-stream edge (each edge costs tens of microseconds on this stack: profiles/round4_notes.md)
+            works[-1].wait()
+        else:
+            for w in works:
+                w.wait()
         self.pending = []
 
 

@@ -662,7 +662,8 @@ class BnMlpFn(torch.autograd.Function):
         saved += [x, s0, y]
         for i in range(nl):
             W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
-            z = _lin(y, W, "n", dtype, "mlp", None if b is None else b.detach())
+            # forward: exact fp32 for an fp32-streamed layer (a ReLU decision follows: csrc/bn_mlp.hip), split only in the backward
+            z = ops.linear_fwd(y, SHADOWS.get(W, "n", wdtype(dtype, "mlp")), None if b is None else b.detach())
             last = i == nl - 1
             y, si = bn(z, gw, gb, bufs[1 + i], True, drops[i], rz if last else None)
             saved += [z, si, y]

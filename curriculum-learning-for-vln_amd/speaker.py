@@ -33,9 +33,13 @@ class _LSTMSeqFn(torch.autograd.Function):
         Hd = params[1].shape[1]
         dev = x_tm.device
         f32 = dict(dtype=torch.float32, device=dev)
+        dt = owner.compute_dtype                     # bf16: the weights are STREAMED as bf16 shadows, everything else stays fp32
+        wtype = ops.BF16 if dt == torch.bfloat16 else ops.F32
         w_ih = torch.cat([params[4 * d].detach() for d in range(dirs)], 0).contiguous()
         bsum = torch.cat([(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(dirs)], 0).contiguous()
         w_hh = torch.stack([params[4 * d + 1].detach() for d in range(dirs)], 0).contiguous()
+        if dt != torch.float32:
+            w_ih, w_hh = ops.cast_copy(w_ih, dt), ops.cast_copy(w_hh, dt)
         x_tm = x_tm.contiguous()
         xproj = ops.linear_fwd(x_tm, w_ih, bsum)
         hprev = ops.empty(dirs, L, B, Hd, **f32)
@@ -46,10 +50,10 @@ class _LSTMSeqFn(torch.autograd.Function):
         hcat = ops.empty(B, dirs * Hd, **f32)
         ccat = ops.empty(B, dirs * Hd, **f32)
         lens32 = torch.full((B,), L, dtype=torch.int32, device=dev)
-        _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), ops.F32, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
+        _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), wtype, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
                                         *owner._sync_ws(dev, B, Hd, dirs), -1, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
-        ctx.owner, ctx.dims = owner, (B, L, Hd, dirs)
+        ctx.owner, ctx.dims, ctx.dt = owner, (B, L, Hd, dirs), dt
         ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh)
         ctx.set_materialize_grads(False)
         return y, hcat, ccat
@@ -64,17 +68,20 @@ class _LSTMSeqFn(torch.autograd.Function):
         z = lambda t: t.reshape(B, dirs, Hd).transpose(0, 1).contiguous() if t is not None else ops.zeros(dirs, B, Hd, **f32)
         dh_pass, dc_carry = z(dh), z(dc)
         dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
-        w_hh_t = torch.stack([ops.transpose_cast(w_hh[d], torch.float32) for d in range(dirs)], 0).contiguous()
+        dt = ctx.dt
+        wtype = ops.BF16 if dt == torch.bfloat16 else ops.F32
+        w_hh_t = torch.stack([ops.transpose_cast(w_hh[d], dt) for d in range(dirs)], 0).contiguous()
         dyc = dy.contiguous() if dy is not None else None
-        _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), ops.F32, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
+        _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), wtype, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
                                         _p(dh_pass), _p(dc_carry), None, None, B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
                                         -1, _lib.raw_stream()), "vln_lstm_seq_bwd")
         grads = []
+        sb = dt != torch.float32                     # bf16 mode: split-bf16 contractions (fp32 accumulation)
         for d in range(dirs):
             dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
             db = ops.colsum(dg)
-            grads += [ops.linear_wgrad(dg, x_tm), ops.linear_wgrad(dg, hprev[d].view(L * B, Hd)), db, db.clone()]
-        dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, torch.float32)) if ctx.needs_input_grad[1] else None
+            grads += [ops.linear_wgrad(dg, x_tm, split_bf16=sb), ops.linear_wgrad(dg, hprev[d].view(L * B, Hd), split_bf16=sb), db, db.clone()]
+        dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, dt)) if ctx.needs_input_grad[1] else None
         return (None, dx, None, None, None, None) + tuple(grads)
 
 
@@ -86,6 +93,7 @@ class _SeqLSTM(nn.Module):
         # nn.LSTM registers the reference's parameter names and default init; its forward is never called
         self.rnn = nn.LSTM(input_size, hidden_size, 1, batch_first=True, bidirectional=bidirectional)
         self.hidden_size, self.dirs = hidden_size, 2 if bidirectional else 1
+        self.compute_dtype = torch.float32
 
     def _sync_ws(self, dev, B, Hd, dirs):
         need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
@@ -101,9 +109,16 @@ class _SeqLSTM(nn.Module):
             out += [getattr(self.rnn, n + sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         return out
 
-    def forward(self, x, state=None):
-        """x [B, L, I] -> (y [B, L, dirs*H], (h_T, c_T) each [dirs, B, H]) like nn.LSTM(batch_first=True)."""
-        B, L, _ = x.shape
+    def forward(self, x, state=None, time_major=None):
+        """x [B, L, I] -> (y [B, L, dirs*H], (h_T, c_T) each [dirs, B, H]) like nn.LSTM(batch_first=True).
+        time_major=(B, L): `x` is already the [L*B, I] time-major matrix (row t*B + b) the recurrence reads (vln_embed_fwd's layout)."""
+        if time_major is not None:
+            B, L = time_major
+            x_tm_in = x
+            x = None
+        else:
+            B, L, _ = x.shape
+            x_tm_in = None
         H = self.hidden_size
         h0 = c0 = None
         if state is not None:
@@ -114,16 +129,48 @@ class _SeqLSTM(nn.Module):
                 w_ih, w_hh, b_ih, b_hh = self._params()
                 h, c = h0[0], c0[0]
                 ys = []
+                if x is None:
+                    x = x_tm_in.view(L, B, -1).transpose(0, 1)
                 for t in range(L):
-                    h, c = Fh.LSTMCellFn.apply(x[:, t].contiguous(), h, c, w_ih, w_hh, b_ih, b_hh, torch.float32)
+                    h, c = Fh.LSTMCellFn.apply(x[:, t].contiguous(), h, c, w_ih, w_hh, b_ih, b_hh, self.compute_dtype)
                     ys.append(h)
                 return torch.stack(ys, 1), (h.unsqueeze(0), c.unsqueeze(0))
             h0 = h0.detach().to(torch.float32).contiguous()
             c0 = c0.detach().to(torch.float32).contiguous()
-        x_tm = x.transpose(0, 1).reshape(L * B, x.shape[-1])
+        x_tm = x_tm_in if x_tm_in is not None else x.transpose(0, 1).reshape(L * B, x.shape[-1])
         y, hcat, ccat = _LSTMSeqFn.apply(self, x_tm, B, L, h0, c0, *self._params())
         y = y.view(L, B, self.dirs * H).transpose(0, 1)
         return y, (hcat.view(B, self.dirs, H).transpose(0, 1), ccat.view(B, self.dirs, H).transpose(0, 1))
+
+
+class _EmbedFn(torch.autograd.Function):
+    """nn.Embedding(padding_idx) + Dropout (units.py:364-365) on the library's kernels: vln_embed_fwd gathers the rows straight
+    into the TIME-major matrix the sequence LSTM reads (row t*B + b) with the dropout of the site fused (element index in that
+    layout), vln_embed_bwd scatters the gradient rows back (float atomics, like torch's embedding backward on a GPU; the pad row
+    gets none, units.py:352)."""
+
+    @staticmethod
+    def forward(ctx, words, weight, pad, seed, offset, p):
+        lib = _lib.load()
+        words = words.contiguous()
+        B, L = words.shape
+        E = weight.shape[1]
+        out = ops.empty(L * B, E, dtype=torch.float32, device=weight.device)
+        _lib.check(lib.vln_embed_fwd(_p(words), _p(weight.detach()), _p(out), B, L, E, seed, offset, p, None, _lib.raw_stream()),
+                   "vln_embed_fwd")
+        ctx.save_for_backward(words, weight)
+        ctx.cfg = (B, L, E, pad, seed, offset, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        words, weight = ctx.saved_tensors
+        B, L, E, pad, seed, offset, p = ctx.cfg
+        dE = torch.zeros_like(weight)
+        lens32 = torch.full((B,), L, dtype=torch.int32, device=weight.device)
+        _lib.check(_lib.load().vln_embed_bwd(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, -1 if pad is None else pad,
+                                             seed, offset, p, None, _lib.raw_stream()), "vln_embed_bwd")
+        return None, dE, None, None, None, None
 
 
 def _rename_lstm_keys(module: nn.Module, names):
@@ -146,7 +193,8 @@ def _rename_lstm_keys(module: nn.Module, names):
 class SpeakerEncoder(nn.Module, _Seeded):
     """units.py:286-341: LSTM over the path's action features -> attention over each step's 36 views -> post-LSTM."""
 
-    def __init__(self, feature_size, hidden_size, dropout_ratio, bidirectional, angle_feat_size, feat_dropout):
+    def __init__(self, feature_size, hidden_size, dropout_ratio, bidirectional, angle_feat_size, feat_dropout,
+                 compute_dtype=torch.float32):
         super().__init__()
         self.num_directions = 2 if bidirectional else 1
         self.hidden_size = hidden_size
@@ -161,6 +209,13 @@ class SpeakerEncoder(nn.Module, _Seeded):
         self.post_lstm = _SeqLSTM(hidden_size, hidden_size // self.num_directions, bidirectional)
         self._init_seed(0x59EA)
         _rename_lstm_keys(self, ("lstm", "post_lstm"))
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dt):
+        """torch.bfloat16: the weight matrices (both LSTMs, the attention's two projections) are streamed as bf16 shadows; features,
+        activations, recurrent state, softmax and gradients stay fp32."""
+        self.compute_dtype = dt
+        self.lstm.compute_dtype = self.post_lstm.compute_dtype = self.attention_layer.compute_dtype = dt
 
     def forward(self, action_embeds, feature, lengths=None, already_dropfeat=False):
         """action_embeds [B, Lp, F], feature [B, Lp, 36, F] (both mutated in place by the feature dropout like the
@@ -191,7 +246,7 @@ class SpeakerEncoder(nn.Module, _Seeded):
 class SpeakerDecoder(nn.Module, _Seeded):
     """units.py:344-395: word embedding -> LSTM -> attention over the encoded path -> vocabulary logits."""
 
-    def __init__(self, vocab_size, embedding_size, padding_idx, hidden_size, dropout_ratio):
+    def __init__(self, vocab_size, embedding_size, padding_idx, hidden_size, dropout_ratio, compute_dtype=torch.float32):
         super().__init__()
         self.hidden_size = hidden_size
         self.drop_ratio = float(dropout_ratio)
@@ -204,6 +259,13 @@ class SpeakerDecoder(nn.Module, _Seeded):
                                                  nn.Linear(128, 1))
         self._init_seed(0x5DEC)
         _rename_lstm_keys(self, ("lstm",))
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dt):
+        """torch.bfloat16: LSTM, attention and vocabulary-projection weights streamed as bf16 shadows (the embedding rows are
+        gathered in fp32)."""
+        self.compute_dtype = dt
+        self.lstm.compute_dtype = self.attention_layer.compute_dtype = dt
 
     def forward(self, words, ctx, ctx_mask, h0, c0):
         """words [Bw, Lw] int64, ctx [B, Lp, H], ctx_mask [B, Lp] (True = masked), h0/c0 [1, Bw, H]
@@ -213,9 +275,9 @@ class SpeakerDecoder(nn.Module, _Seeded):
         p = self.drop_ratio if self.training else 0.0
         H = self.hidden_size
         Bw, Lw = words.shape
-        emb = torch.nn.functional.embedding(words, self.embedding.weight, self.embedding.padding_idx)
-        emb = Fh.dropout(emb.contiguous(), p, self.training, self.dropout_seed, off + 0)
-        x, (h1, c1) = self.lstm(emb, (h0, c0))
+        # embedding rows + dropout in one launch, written in the time-major layout the recurrence reads (vln_embed_fwd)
+        emb_tm = _EmbedFn.apply(words, self.embedding.weight, self.embedding.padding_idx, self.dropout_seed, off + 0, p)
+        x, (h1, c1) = self.lstm(emb_tm, (h0, c0), time_major=(Bw, Lw))
         x = Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 1)
         n = Bw * Lw
         mult = n // ctx.size(0)
@@ -223,7 +285,7 @@ class SpeakerDecoder(nn.Module, _Seeded):
         mask_e = ctx_mask.unsqueeze(1).expand(-1, mult, -1).contiguous().view(n, -1) if ctx_mask is not None else None
         x, _ = self.attention_layer(x.view(n, H), ctx_e, mask=mask_e)
         x = Fh.dropout(x.view(Bw, Lw, H), p, self.training, self.dropout_seed, off + 2)
-        logit = Fh.linear(x.view(n, H), self.projection.weight, self.projection.bias).view(Bw, Lw, -1)
+        logit = Fh.linear(x.view(n, H), self.projection.weight, self.projection.bias, ops.ACT_NONE, self.compute_dtype).view(Bw, Lw, -1)
         return logit, h1, c1
 
 

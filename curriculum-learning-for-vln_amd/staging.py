@@ -325,3 +325,63 @@ class PinnedStager:
         if slot is not None and slot["free"] is not None:
             slot["free"].record(torch.cuda.current_stream(self.device))
             slot["released"] = True
+
+
+class HostBatchFeed:
+    """The per-batch hand-over with the GPU pulling (round 4): packed batches wait in pinned host memory, the live device buffer is
+    filled by a KERNEL that reads the batch's address from a ring of pinned slot words (`vln_host_fetch`).  `select(blob)` is one
+    host store into the next slot; `fetch()` launches the pull -- as the first launch of a captured iteration its arguments repeat,
+    so a whole-iteration hipGraph replays on a new batch without any copy call between replays (reference: agent/base.py:114-178
+    marshals on the host, `.to(device)` copies).  Exactly one `select` per executed `fetch`, in order.  The host may run ahead of
+    the device by `ring` - 1 batches: `launched()` (call it after the launch / replay that contains the fetch) records an event,
+    and `select` waits for the event of the iteration that last used the slot it is about to overwrite.  A registered blob must
+    stay untouched until the fetch that reads it has run."""
+
+    def __init__(self, live: torch.Tensor, ring: int = 16):
+        if not live.is_cuda or live.dtype != torch.uint8 or live.numel() % 16 or live.data_ptr() % 16:
+            raise ValueError("HostBatchFeed: the live buffer is a 16-byte aligned uint8 device tensor whose size is a multiple of 16")
+        self.live, self.ring = live, int(ring)
+        self.slots = torch.zeros(self.ring, dtype=torch.int64).pin_memory()     # device addresses of the next `ring` blobs
+        self._slots_dev = self._devptr(self.slots)
+        self._state = torch.zeros(4, dtype=torch.int64, device=live.device)     # [0] = seq (fetches run), [1] = done scratch
+        self._addr = {}
+        self._selected = 0                                                      # host mirror: selects made
+        self._events = [None] * self.ring
+
+    @staticmethod
+    def _devptr(t: torch.Tensor) -> int:
+        d = C_.c_void_p()
+        _lib.check(_lib.load().vln_host_device_pointer(t.data_ptr(), C_.byref(d)), "vln_host_device_pointer")
+        return int(d.value)
+
+    def register(self, blob: torch.Tensor) -> torch.Tensor:
+        """-> the blob as a pinned host tensor the device can read (its device address is looked up once)."""
+        if blob.numel() * blob.element_size() != self.live.numel():
+            raise ValueError("HostBatchFeed: blob and live buffer differ in size")
+        b = blob.detach().cpu().contiguous()
+        if not b.is_pinned():
+            b = b.pin_memory()
+        self._addr[b.data_ptr()] = self._devptr(b)
+        return b
+
+    def select(self, blob: torch.Tensor):
+        """The next `fetch()` that runs -- eager or replayed -- pulls this (registered) blob."""
+        i = self._selected % self.ring
+        ev = self._events[i]
+        if ev is not None:                      # the iteration that read this slot `ring` selects ago must have run
+            ev.synchronize()
+            self._events[i] = None
+        self.slots[i] = self._addr[blob.data_ptr()]
+        self._selected += 1
+
+    def launched(self):
+        """Call after issuing the launch / graph replay that contains the fetch of the last `select`."""
+        i = (self._selected - 1) % self.ring
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[i] = ev
+
+    def fetch(self):
+        st = self._state
+        _lib.check(_lib.load().vln_host_fetch(self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(),
+                                              self.live.numel(), _lib.raw_stream()), "vln_host_fetch")

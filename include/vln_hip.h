@@ -49,6 +49,16 @@ const char* vln_last_error_string(void);
 /* Launch chains (one per LSTM time step / per decoder step) are memoised as hipGraphs keyed by their argument
  * block (csrc/graph_cache.h).  vln_set_graphs(0) forces plain launches; results are identical. */
 int vln_set_graphs(int on);
+/* The batch hand-over (reference: agent/base.py:114-178 marshals every batch on the host, `.to(device)` copies it).  The caller
+ * packs a batch's small tensors into ONE pinned host blob (a multiple of 16 bytes, 16-byte aligned) and stores the blob's DEVICE
+ * address (vln_host_device_pointer) into a ring of `ring` pinned 8-byte slots; vln_host_fetch launches a kernel that copies
+ * `nbytes` from the blob named by slot (*seq % ring) to `dst` and then bumps *seq (a zero-initialised DEVICE word; `done` = a
+ * zero-initialised device scratch word).  Inside a captured iteration its arguments repeat: a new batch costs the host one store
+ * into the next slot -- it may run ahead of the device by up to `ring` - 1 batches.  `slots_dev` = the ring's device address.
+ * A blob must not be rewritten, nor its slot reused, before the fetch that reads it has run. */
+int vln_host_device_pointer(const void* host, void** dev);
+int vln_host_fetch(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, vln_stream_t s);
+
 /* Device-resident counters: ONE tiny launch adds inc to every listed word (width 8: uint64, width 4: uint32) -- the dropout
  * clock (`offset_base_dev`) and the recurrence's launch sequence (vln_lstm_sync_seq_offset) of a whole-iteration graph. */
 #define VLN_TICK_MAX 8

@@ -9,7 +9,7 @@
                        at B=64 per GPU, clip 40 + RMSprop over encoder / decoder / critic
 
 Synthetic data of BASELINE.md's shapes, features resident in HBM; prints one JSON line per workload.
-    python scripts/bench_agents.py [monitor|follower|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32] [--T-rl 35]
+    python scripts/bench_agents.py [monitor|follower|speaker|a2c|all] [--steps K] [--warmup W] [--dtype bf16|fp32] [--T-rl 35]
 (bench.py imports run_monitor / run_a2c for the secondary numbers of its JSON line)
 """
 import argparse, json, os, sys, time
@@ -176,6 +176,38 @@ def run_follower(B=64, L=80, T=7, C=8, fused=True):
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
+def run_speaker(B=64, Lp=7, Lw=80, V=36, vocab=992):
+    """The speaker's training iteration (agent/speaker.py:75-87: teacher_forcing -> backward -> clip 40 per module -> two Adam) at
+    the configured size: RNN_DIM 512, bidirectional encoder over paths of up to 7 viewpoints x 36 x 2176 views, WEMB 256, vocabulary
+    992, 80-token instructions, DROPOUT 0.6 / FEAT_DROPOUT 0.3 on."""
+    g = torch.Generator().manual_seed(2020)
+    enc = vln.SpeakerEncoder(F, 512, 0.6, True, 128, 0.3, compute_dtype=dt).to(dev).train()
+    dec = vln.SpeakerDecoder(vocab, 256, 0, 512, 0.6, compute_dtype=dt).to(dev).train()
+    spk = vln.Speaker(enc, dec)
+    opt_e = vln.optim.FusedAdam([list(enc.parameters())], lr=1e-4, clip_norm=40.0)
+    opt_d = vln.optim.FusedAdam([list(dec.parameters())], lr=1e-4, clip_norm=40.0)
+    can = (torch.randn(B, Lp, F, generator=g).abs() * 0.5).to(dev)
+    img = (torch.randn(B, Lp, V, F, generator=g).abs() * 0.5).to(dev)
+    lengths = torch.randint(3, Lp + 1, (B,), generator=g); lengths[0] = Lp
+    wl = torch.randint(8, Lw + 1, (B,), generator=g); wl[0] = Lw
+    insts = torch.zeros(B, Lw, dtype=torch.long)
+    for b in range(B):
+        n = int(wl[b])
+        insts[b, 0] = 3; insts[b, 1:n - 1] = torch.randint(4, vocab, (n - 2,), generator=g); insts[b, n - 1] = 2
+    insts = insts.to(dev)
+
+    def it():
+        opt_e.zero_grad(); opt_d.zero_grad()
+        # the feature dropout works in place (units.py:322,331): a training loop hands over fresh feature tensors every batch
+        loss = spk.teacher_forcing(can.clone(), img.clone(), lengths, insts, train=True)
+        loss.backward()
+        opt_e.step(); opt_d.step()
+
+    ms = timed(it)
+    return dict(workload=f"speaker_teacher_forcing_B{B}_Lp{Lp}_Lw{Lw}_adam", ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
+                dtype=args.dtype)
+
+
 def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
     """EnvDrop IL (teacher-forced rollout, T_il steps) + RL (sampled rollout up to T_rl steps -- the reference caps episodes at
     MAX_EPISODE_LEN = 35, configs/envdrop/envdrop_config.yaml:31 -- A2C with the critic, envdrop.py:186-264) per optimizer step
@@ -288,6 +320,8 @@ def main():
         print(json.dumps(run_follower()), flush=True)
         if not a.fused_only:
             print(json.dumps(run_follower(fused=False)), flush=True)
+    if a.which in ("speaker", "all"):
+        print(json.dumps(run_speaker()), flush=True)
     if a.which in ("a2c", "all"):
         print(json.dumps(run_a2c(T_rl=a.T_rl)), flush=True)
 

@@ -16,15 +16,16 @@ def vln():
     return vln_amd
 
 
-def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None):
+def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device"):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
     store = bench.build_store(vln, dev, dtype, n_rows=300, seed=5)
     tapes = [bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
-    live = bench.LiveBatch(tapes)
+    live = bench.LiveBatch(tapes, source=source)
     torch.manual_seed(78)
     ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
+    ag.use_live(live)
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
     ag.rollout_gather = ag.gather_branch = branch == "branch"
@@ -73,6 +74,20 @@ def test_iteration_graph_equals_eager(vln, dtype, branch):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the replayed iteration"
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_batches_pulled_from_pinned_host_memory_equal_copied_batches(vln, graph):
+    """bench.LiveBatch("pull") / staging.HostBatchFeed / vln_host_fetch: the batches wait in pinned host memory, `load(k)` is one
+    host store into a ring of slot words and the iteration's FIRST launch pulls the batch through PCIe -- also as the first node of
+    the captured iteration.  22 iterations over 5 different batches (the 16-slot ring wraps, the host runs ahead of the device):
+    losses, parameters, optimizer state and gradient norms equal the device-resident batches' bit for bit."""
+    ref, _, _ = _run(vln, torch.bfloat16, graph, "ride", n_more=20)
+    got, _, _ = _run(vln, torch.bfloat16, graph, "ride", n_more=20, source="pull")
+    assert len(ref) == len(got) == 22
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between pulled and device-resident batches"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
