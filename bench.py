@@ -246,6 +246,9 @@ class GpuAgent:
         # rollout at once when losses.RolloutCE evaluates (one GEMM over steps x batch + one dot launch instead of two
         # launches on every step's dependent chain)
         self.dec.defer_logits = bool(rollout_ce)
+        # ... and consecutive steps are chained: a step's last elementwise stage rides in the next step's first launch, forward
+        # and backward (vln_envdrop_step.chain; needs the deferred logits: nothing reads a step's h_tilde but the next step)
+        self.dec.chain_steps = bool(rollout_ce)
         # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
         # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
         self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
@@ -672,6 +675,7 @@ def main():
                          "pull = pinned HOST memory, the iteration's first launch pulls the batch through PCIe (default: what a data "
                          "loader hands over); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
                          "device memory, one device-to-device copy (round 3's form)")
+    ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
                          "exchange issued between them (graphs.SegmentedIterationGraph) on a ONE-rank RCCL group, collectives "
@@ -745,6 +749,8 @@ def main():
     agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
     agent.probe_trivial = int(args.probe_trivial)
     agent.dump_graph = args.dump_graph
+    if args.no_chain:
+        agent.dec.chain_steps = False
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and args.features == "store" and not args.no_arena)
     # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
     # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
@@ -1014,7 +1020,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 
 #include "vln_internal.h"
 #include "graph_cache.h"
@@ -28,6 +29,9 @@ __global__ __launch_bounds__(256) void envdrop_prep_bwd_kernel(PrepBwdArgs p) {
 }
 __global__ __launch_bounds__(256) void tanh_drop_bwd_kernel(TanhDropBwdArgs a) {
   tanh_drop_bwd_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+__global__ __launch_bounds__(256) void envdrop_prep_tanh_bwd_kernel(PrepTanhBwdArgs a) {
+  envdrop_prep_tanh_bwd_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 static inline int nblocks(long n, int cap = 2048) {
@@ -75,6 +79,29 @@ static inline DropSpec site(const vln_envdrop_step* io, int k, float p) {
 }
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 
+// ---- chained steps (vln_envdrop_step.chain) ------------------------------------------------------------------------------------------
+// Two elementwise stages of a step only exist to hand a [B,H] block to the NEXT call on the same stream: the forward's last launch
+// (sum of linear_out's split-K slabs, tanh, dropout -> h_tilde, drop(h_tilde)) feeds the next step's first launch (h_tilde_prev
+// copy + dropout), and the backward's last launch (prep backward -> d h_tilde_prev) feeds the previous step's first backward
+// launch (tanh / dropout backward).  With the chain bits set a step leaves that last stage PENDING (per stream, below) and the
+// next step's first launch does both -- one dependent launch less per step and direction.  A pending stage that the next call
+// does not consume (other pointers, another entry point, the end of the rollout) is issued on its own first: vln_envdrop_flush.
+struct PendFwd { bool on; const float* slabs; int n; long stride; float* ht; float* htd; DropSpec drop; int B, H; };
+struct PendBwd { bool on; PrepBwdArgs pa; };
+struct PendState { PendFwd f; PendBwd b; };
+static std::mutex g_pend_mu;
+static std::unordered_map<hipStream_t, PendState> g_pend;
+static PendState& pend_of(hipStream_t st) { return g_pend[st]; }      // callers hold g_pend_mu
+
+static int issue_pending_fwd(hipStream_t st, const PendFwd& f) {
+  return reduce_epilogue(st, f.slabs, f.n, f.stride, f.H, f.ht, f.H, f.B, f.H, nullptr, ACT_TANH, f.htd, f.H, f.drop);
+}
+static int issue_pending_bwd(hipStream_t st, const PendBwd& b) {
+  VLN_LAUNCH(envdrop_prep_bwd_kernel, dim3(nblocks((long)b.pa.B * (b.pa.AE + b.pa.H))), dim3(256), 0, st, b.pa);
+  VLN_CHECK_LAUNCH("envdrop_prep_bwd");
+  return VLN_OK;
+}
+
 static int check_dims(const vln_envdrop_dims* d) {
   if (!d || d->B <= 0 || d->L <= 0 || d->V <= 0 || d->C <= 0 || d->H <= 0 || d->IMG <= 0 || d->ANG <= 0 || d->AE <= 0) {
     set_error("envdrop: bad dims");
@@ -98,7 +125,8 @@ extern "C" int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d) {
   return ws_layout(*d, nullptr, nullptr);
 }
 
-static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io) {
+static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io,
+                          const PendFwd& use = PendFwd{}) {
   const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop fwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
@@ -115,7 +143,11 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // (1) act embedding, h_tilde_prev copy + dropout            policy.py:224,234
   PrepArgs pa{io->a_prev, w->act_w, w->act_b, io->h_tilde_prev, io->e, io->xcat, XK, io->hq,
               B, d->ANG, AE, F, H, site(io, 0, io->p_drop), site(io, 1, io->p_drop),
-              io->a_stash == io->a_prev ? nullptr : io->a_stash};
+              io->a_stash == io->a_prev ? nullptr : io->a_stash,
+              nullptr, 0, 0, nullptr, nullptr, DropSpec{0, 0, 0.f}};
+  if (use.on) {       // the previous step's linear_out epilogue rides in this step's first launch (chained steps)
+    pa.pend_slabs = use.slabs; pa.pend_n = use.n; pa.pend_stride = use.stride; pa.pend_ht = use.ht; pa.pend_htd = use.htd; pa.pend_drop = use.drop;
+  }
   GatherStepArgs ga{};
   if (io->g_table) {
     // (1)+(2) in ONE launch: the step gathers its own feature rows from the resident table (dropout sites 4 / 5 on the way)
@@ -155,6 +187,12 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
                        ws.dots, B, d->L, H, io->attn_sync, io->attn_sync_bytes));
+  if (io->chain & 1) {        // chained: the slabs stay in ws.s1, the NEXT call's first launch (or vln_envdrop_flush) finishes them
+    int nl = 1;
+    RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, wt(3), 2 * H, nullptr, 0, B, H, 2 * H, nullptr, ACT_NONE, ws.s1, ws.n1, &nl));
+    if (nl != gemm_nt_slabs(B, H, 2 * H, wt(3), ws.n1)) { set_error("envdrop fwd: chained epilogue: slab count mismatch"); return VLN_ERR_ARG; }
+    return VLN_OK;
+  }
   RUN(gemm_nt_fused(st, io->tcat, 2 * H, w->w_tout, wt(3), 2 * H, io->h_tilde, H, B, H, 2 * H, nullptr, ACT_TANH, io->htd, H,
                     site(io, 3, io->p_drop), ws.s1, ws.n1));
   // (6) candidate logits                                        policy.py:243-244,199-206
@@ -165,7 +203,7 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
 }
 
 static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io,
-                          const vln_envdrop_grads* g) {
+                          const vln_envdrop_grads* g, const PendBwd& use = PendBwd{}) {
   const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
   if (io->ws_floats < ws_layout(*d, nullptr, nullptr)) { set_error("envdrop bwd: workspace too small"); return VLN_ERR_ARG; }
   Ws ws; ws_layout(*d, io->ws, &ws);
@@ -199,7 +237,11 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
     RUN(fill_f32(st, ws.s3, (long)B * H, 0.f));
   }
   // h_tilde = tanh(.) with dropout on the way to the logits and the external grad on h_tilde itself
-  {
+  if (use.on) {      // chained: the NEXT step's prep backward (its d h_tilde_prev IS this step's d h_tilde) in the same launch
+    const PrepTanhBwdArgs pt{use.pa, dhtd, dhtd2, io->h_tilde, g->s_dz, site(io, 3, io->p_drop)};
+    VLN_LAUNCH(envdrop_prep_tanh_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pt);
+    VLN_CHECK_LAUNCH("envdrop_prep_tanh_bwd");
+  } else {
     const TanhDropBwdArgs ta{dhtd, dhtd2, g->dh_tilde, io->h_tilde, g->s_dz, B, H, site(io, 3, io->p_drop)};
     VLN_LAUNCH(tanh_drop_bwd_kernel, dim3(nblocks((long)B * H)), dim3(256), 0, st, ta);
     VLN_CHECK_LAUNCH("tanh_drop_bwd");
@@ -233,11 +275,29 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
                        io->attn_sync, io->attn_sync_bytes));
   RUN(gemm_nt(st, g->s_dtv, F, w->w_vin_t, wt(0), F, nullptr, 0, B, H, F, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
   // (1') act embedding + the two uses of h_tilde_prev
+  if (io->chain & 2) {                       // chained: left pending (bwd_pending below names the same arguments)
+    if (n2 != gemm_nt_slabs(B, XK, 4 * H, wt(1), ws.n2) || n3 != gemm_nt_slabs(B, H, F, wt(0), ws.n3)) {
+      set_error("envdrop bwd: chained prep backward: slab count mismatch");
+      return VLN_ERR_ARG;
+    }
+    return VLN_OK;
+  }
   PrepBwdArgs pa{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)};
   VLN_LAUNCH(envdrop_prep_bwd_kernel, dim3(nblocks((long)B * (AE + H))), dim3(256), 0, st, pa);
   VLN_CHECK_LAUNCH("envdrop_prep_bwd");
   return VLN_OK;
+}
+
+// the prep backward a chained step leaves pending: the arguments step_bwd_issue would have launched it with
+static PendBwd bwd_pending(const vln_envdrop_dims* d, const vln_envdrop_weights* w, const vln_envdrop_step* io, const vln_envdrop_grads* g) {
+  const int B = d->B, H = d->H, F = d->IMG + d->ANG, AE = d->AE, XK = AE + F + H;
+  Ws ws; ws_layout(*d, io->ws, &ws);
+  const auto wt = [&](int bit) { return ((w->f32_mask >> bit) & 1) ? (int)W_F32S : d->wtype; };
+  const int n2 = gemm_nt_slabs(B, XK, 4 * H, wt(1), ws.n2), n3 = gemm_nt_slabs(B, H, F, wt(0), ws.n3);
+  const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
+  return PendBwd{true, PrepBwdArgs{dxcat, io->e, SlabVec{ws.s3, H, n3, (long)B * H}, g->s_de, g->dh_tilde_prev, B, AE, F, H,
+                                  site(io, 0, io->p_drop), site(io, 1, io->p_drop)}};
 }
 
 
@@ -250,15 +310,49 @@ namespace {
 struct StepKey {
   vln_envdrop_dims d; vln_envdrop_weights w; vln_envdrop_step io; vln_envdrop_grads g; int bwd;
   int tun[8];          // the launch plan depends on the run-time tunables: a changed tunable never replays an old graph
+  // chained steps: the pending stage of the previous call that this call's first launch carries (all zero: none)
+  const void* pend_p[6]; long pend_v[6];
 };
 }  // namespace
+
+// The stage a chained step left pending on stream `s`, if any, as a launch of its own (end of a rollout's forward / backward,
+// or before anything outside vln_envdrop_step_* reads h_tilde / drop(h_tilde) / d h_tilde_prev / the act-embedding gradient rows).
+extern "C" int vln_envdrop_flush(vln_stream_t s) {
+  hipStream_t st = (hipStream_t)s;
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  auto it = g_pend.find(st);
+  if (it == g_pend.end()) return VLN_OK;
+  PendState& ps = it->second;
+  if (ps.f.on) { ps.f.on = false; RUN(issue_pending_fwd(st, ps.f)); }
+  if (ps.b.on) { ps.b.on = false; RUN(issue_pending_bwd(st, ps.b)); }
+  return VLN_OK;
+}
 
 extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
                                     vln_stream_t s) {
   RUN(check_dims(d));
   if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  if (!io->offset_dev && !io->offset_base_dev) return step_fwd_issue(st, d, w, io);
+  if ((io->chain & 1) && !io->defer_logits) { set_error("vln_envdrop_step_fwd: chain needs defer_logits (nothing may read h_tilde before the next step)"); return VLN_ERR_ARG; }
+  // chained steps: what the previous call left pending on this stream
+  PendFwd use{};
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    PendState& ps = pend_of(st);
+    if (ps.b.on) { ps.b.on = false; RUN(issue_pending_bwd(st, ps.b)); }        // a backward stage left over: not this call's business
+    if (ps.f.on) {
+      ps.f.on = false;
+      if (ps.f.ht == io->h_tilde_prev && ps.f.B == d->B && ps.f.H == d->H) use = ps.f;     // consumed by this step's first launch
+      else RUN(issue_pending_fwd(st, ps.f));
+    }
+    if (io->chain & 1) {
+      Ws ws; ws_layout(*d, io->ws, &ws);
+      const int wt3 = ((w->f32_mask >> 3) & 1) ? (int)W_F32S : d->wtype;
+      ps.f = PendFwd{true, ws.s1, gemm_nt_slabs(d->B, d->H, 2 * d->H, wt3, ws.n1), (long)d->B * d->H, io->h_tilde, io->htd,
+                     site(io, 3, io->p_drop), d->B, d->H};
+    }
+  }
+  if (!io->offset_dev && !io->offset_base_dev) return step_fwd_issue(st, d, w, io, use);
   if (!io->offset_base_dev) {
     VLN_LAUNCH(set_u64_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(io->offset_dev),
                        (unsigned long long)io->offset);
@@ -272,7 +366,13 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   if (!io->offset_base_dev) key.io.offset = 0;      // per-step word: the value is not a launch argument
   memset(&key.g, 0, sizeof(key.g));
   memcpy(key.tun, g_tunable, sizeof(key.tun));
-  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io); });
+  memset(key.pend_p, 0, sizeof(key.pend_p)); memset(key.pend_v, 0, sizeof(key.pend_v));
+  if (use.on) {
+    key.pend_p[0] = use.slabs; key.pend_p[1] = use.ht; key.pend_p[2] = use.htd; key.pend_p[3] = use.drop.step;
+    key.pend_v[0] = use.n; key.pend_v[1] = use.stride; key.pend_v[2] = (long)use.drop.seed; key.pend_v[3] = (long)use.drop.offset;
+    memcpy(&key.pend_v[4], &use.drop.p, sizeof(float));
+  }
+  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_fwd_issue(cs, d, w, io, use); });
 }
 
 extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
@@ -280,7 +380,21 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io || !g) { set_error("vln_envdrop_step_bwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
-  if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g);
+  PendBwd use{};
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    PendState& ps = pend_of(st);
+    if (ps.f.on) { ps.f.on = false; RUN(issue_pending_fwd(st, ps.f)); }        // the rollout's last forward stage (normally flushed by the caller)
+    if (ps.b.on) {
+      ps.b.on = false;
+      // consumed when this step's incoming d h_tilde IS the pending stage's output and this step's first launch reads no
+      // workspace slabs of its own (the rollout-wide logit branch covered its d logits: dhtd_ext without dlogit)
+      if (g->dh_tilde && ps.b.pa.dhtp == g->dh_tilde && ps.b.pa.B == d->B && ps.b.pa.H == d->H && g->dhtd_ext && !g->dlogit) use = ps.b;
+      else RUN(issue_pending_bwd(st, ps.b));
+    }
+    if (io->chain & 2) ps.b = bwd_pending(d, w, io, g);
+  }
+  if (!io->offset_dev && !io->offset_base_dev) return step_bwd_issue(st, d, w, io, g, use);
   static StepKey key;
   static std::mutex mu;
   static GraphCache cache;
@@ -288,5 +402,12 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
   key.d = *d; key.w = *w; key.io = *io; key.g = *g; key.bwd = 1;
   if (!io->offset_base_dev) key.io.offset = 0;
   memcpy(key.tun, g_tunable, sizeof(key.tun));
-  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g); });
+  memset(key.pend_p, 0, sizeof(key.pend_p)); memset(key.pend_v, 0, sizeof(key.pend_v));
+  if (use.on) {
+    const PrepBwdArgs& q = use.pa;
+    key.pend_p[0] = q.dxcat.p; key.pend_p[1] = q.dhq.p; key.pend_p[2] = q.e; key.pend_p[3] = q.s_de; key.pend_p[4] = q.dhtp; key.pend_p[5] = q.d_act.step;
+    key.pend_v[0] = q.dxcat.n; key.pend_v[1] = q.dhq.n; key.pend_v[2] = (long)q.d_act.seed; key.pend_v[3] = (long)q.d_act.offset;
+    key.pend_v[4] = (long)q.d_h.offset; memcpy(&key.pend_v[5], &q.d_act.p, sizeof(float));
+  }
+  return cache.run(st, &key, sizeof(key), [&](hipStream_t cs) { return step_bwd_issue(cs, d, w, io, g, use); });
 }

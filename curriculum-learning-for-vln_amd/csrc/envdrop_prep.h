@@ -11,6 +11,10 @@ struct PrepArgs {
   int B, ANG, AE, F, H;
   DropSpec d_act, d_h;
   float* a_stash;   // nullable: copy of `a` kept for the deferred act_embed weight gradient
+  // Chained steps (round 4, vln_envdrop_step.chain): the PREVIOUS step left the epilogue of its linear_out product pending --
+  // h_tilde = tanh(sum of `pend_n` split-K slabs), drop(h_tilde) (its site 3).  This launch finishes it on the way: the value is
+  // written to pend_ht (= `htp`'s memory, the tensor the previous step returned) and pend_htd (its stash row) and used here.
+  const float* pend_slabs; int pend_n; long pend_stride; float* pend_ht; float* pend_htd; DropSpec pend_drop;
 };
 // e = tanh(a W_a^T + b); xcat[:, :AE] = drop(e); xcat[:, AE+F:] = h_tilde_prev; hq = drop(h_tilde_prev)
 // Work items: B*AE dot products of length ANG, 8 lanes each (a lane group reads 128 contiguous bytes of the weight row
@@ -45,7 +49,28 @@ __device__ __forceinline__ void envdrop_prep_body(const PrepArgs& p, long first,
       const long k4 = i - ne * 8;
       const long k = k4 * 4;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
-      const float4 v = *reinterpret_cast<const float4*>(p.htp + k);
+      float4 v;
+      if (p.pend_slabs) {        // the previous step's reduce + tanh + dropout epilogue (step_bodies.h::reduce_epilogue_body, same sums)
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float* sp = p.pend_slabs + k + c;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          int s = 0;
+          for (; s + 3 < p.pend_n; s += 4) {
+            a0 += sp[(long)s * p.pend_stride]; a1 += sp[(long)(s + 1) * p.pend_stride];
+            a2 += sp[(long)(s + 2) * p.pend_stride]; a3 += sp[(long)(s + 3) * p.pend_stride];
+          }
+          for (; s < p.pend_n; ++s) a0 += sp[(long)s * p.pend_stride];
+          a0 += (a1 + a2) + a3;
+          o[c] = tanhf(a0);
+          p.pend_htd[k + c] = o[c] * dropout_scale1(p.pend_drop.seed, p.pend_drop.off(), (uint32_t)(k + c), p.pend_drop.p);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(p.pend_ht + k) = v;
+      } else {
+        v = *reinterpret_cast<const float4*>(p.htp + k);
+      }
       *reinterpret_cast<float4*>(p.xcat + (long)b * p.ldx + p.AE + p.F + j) = v;
       float m[4] = {1.f, 1.f, 1.f, 1.f};
       if (p.d_h.p > 0.f) dropout_scale4(p.d_h.seed, p.d_h.off(), (uint32_t)k4, p.d_h.p, m);

@@ -56,6 +56,36 @@ static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, i
   return VLN_OK;
 }
 
+// How many K-chunks (= partial slabs) a product is split into: a pure function of its shape, the workspace and the tunables, so a
+// caller that DEFERS the consumption of the slabs (envdrop.hip: the chained steps) can name them without issuing the product.
+static int gemm_nt_split(int nb, int mb, int ksteps, int M, int N, bool have_ws, long ws_floats, bool to_caller, int* steps_per_out) {
+  // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk.  (Measured on MI355X:
+  // many co-resident workgroups with one K-step of prefetch each beat one fat workgroup per CU with all of
+  // its loads in flight: 8.5 vs 12.5 us average per launch in the EnvDrop step, profiles/round1_notes.md.)
+  int nsplit = 1;
+  if (have_ws) {
+    const int target = g_tunable[0];                 // workgroups wanted in flight (default 384)
+    nsplit = target / (nb * mb);
+    if (nsplit > ksteps / 2) nsplit = ksteps / 2;
+    // wide-and-shallow products (N >= 2048 columns, K <= 8 steps: the H->F query projections) already fill 32+
+    // workgroups; splitting them only buys a reduce launch
+    if (g_tunable[1] && nb * mb >= 32 && ksteps <= 8 && !to_caller) nsplit = 1;
+    if (nsplit < 1) nsplit = 1;
+    long per = (long)M * N;
+    if ((long)nsplit * per > ws_floats) nsplit = (int)(ws_floats / per);
+    if (nsplit < 1) nsplit = 1;
+  }
+  int steps_per = (ksteps + nsplit - 1) / nsplit;
+  nsplit = (ksteps + steps_per - 1) / steps_per;
+  if (steps_per_out) *steps_per_out = steps_per;
+  return nsplit;
+}
+// slabs gemm_nt(..., nsplit_out != nullptr) will leave for a [M,K] x [N,K]^T product of weight type `wtype` (64-column tiles)
+int gemm_nt_slabs(int M, int N, int K, int wtype, long ws_floats) {
+  const int BK = (wtype == W_F32) ? 32 : 64;
+  return gemm_nt_split((N + 63) / 64, (M + 63) / 64, (K + BK - 1) / BK, M, N, true, ws_floats, true, nullptr);
+}
+
 // Y = act(X W^T + bias), Y2 = Y * dropout (optional): one launch for narrow outputs, else split-K slabs + reduce
 int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
                   int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats) {
@@ -85,21 +115,8 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   // split K until ~2 workgroups per CU are in flight; keep >= 2 K-steps per chunk.  (Measured on MI355X:
   // many co-resident workgroups with one K-step of prefetch each beat one fat workgroup per CU with all of
   // its loads in flight: 8.5 vs 12.5 us average per launch in the EnvDrop step, profiles/round1_notes.md.)
-  int nsplit = 1;
-  if (ws != nullptr) {
-    const int target = g_tunable[0];                 // workgroups wanted in flight (default 384)
-    nsplit = target / (nb * mb);
-    if (nsplit > ksteps / 2) nsplit = ksteps / 2;
-    // wide-and-shallow products (N >= 2048 columns, K <= 8 steps: the H->F query projections) already fill 32+
-    // workgroups; splitting them only buys a reduce launch
-    if (g_tunable[1] && nb * mb >= 32 && ksteps <= 8 && nsplit_out == nullptr) nsplit = 1;
-    if (nsplit < 1) nsplit = 1;
-    long per = (long)M * N;
-    if ((long)nsplit * per > ws_floats) nsplit = (int)(ws_floats / per);
-    if (nsplit < 1) nsplit = 1;
-  }
-  int steps_per = (ksteps + nsplit - 1) / nsplit;
-  nsplit = (ksteps + steps_per - 1) / steps_per;
+  int steps_per = 1;
+  int nsplit = gemm_nt_split(nb, mb, ksteps, M, N, ws != nullptr, ws_floats, nsplit_out != nullptr, &steps_per);
   GemmNTArgs a;
   a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.kchunk = steps_per * BK;

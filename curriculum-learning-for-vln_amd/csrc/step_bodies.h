@@ -142,6 +142,34 @@ __device__ __forceinline__ void envdrop_prep_bwd_body(const PrepBwdArgs& p, long
   }
 }
 
+// Chained steps (round 4): the prep backward of step t and the tanh / dropout backward of step t-1 -- the FIRST stage of the next
+// step's backward, whose d h_tilde is exactly this stage's dhtp -- as one launch: dhtp is stored AND used in place of `dht_ext`.
+struct PrepTanhBwdArgs { PrepBwdArgs p; SlabVec dhtd; const float* dhtd2; const float* ht; float* dz; DropSpec d; };
+__device__ __forceinline__ void envdrop_prep_tanh_bwd_body(const PrepTanhBwdArgs& a, long first, long stride) {
+  const PrepBwdArgs& p = a.p;
+  const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
+  for (long i = first; i < ne + nh; i += stride) {
+    if (i < ne) {
+      const int b = (int)(i / p.AE), j = (int)(i % p.AE);
+      const float e = p.e[i];
+      const float de = p.dxcat.at(b, j) * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
+      p.s_de[i] = de * (1.f - e * e);
+    } else {
+      const long k = i - ne;
+      const int b = (int)(k / p.H), j = (int)(k % p.H);
+      const float v = p.dxcat.at(b, p.AE + p.F + j) +
+                      p.dhq.at(b, j) * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
+      p.dhtp[k] = v;
+      float gs = a.dhtd.at(b, j);                    // tanh_drop_bwd_body of the next step, with dht_ext = v
+      if (a.dhtd2) gs += a.dhtd2[k];
+      float g = gs * dropout_scale1(a.d.seed, a.d.off(), (uint32_t)k, a.d.p);
+      g += v;
+      const float h = a.ht[k];
+      a.dz[k] = g * (1.f - h * h);
+    }
+  }
+}
+
 // dz = ((dhtd + dhtd2) * mask + dht_ext) * (1 - ht^2)      (dhtd [B,H] may still lie in split-K slabs; dhtd2 nullable:
 // the second consumer of the logits when the rollout-wide logit branch already covered the first)
 struct TanhDropBwdArgs {

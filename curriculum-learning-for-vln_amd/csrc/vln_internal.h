@@ -116,6 +116,7 @@ inline void launch_timed(int kid, double algo_bytes, F kernel, dim3 grid, dim3 b
 // `ws_floats` bounds the split.  If `slabs_out`/`nsplit_out` are given the
 // reduce pass is skipped and the caller's consumer kernel sums the slabs
 // (slab s at ws + s*M*N, dense ld = N).
+int gemm_nt_slabs(int M, int N, int K, int wtype, long ws_floats);   // slabs gemm_nt(..., nsplit_out) leaves for this product (gemm.hip)
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out);
 // (nsplit_out != nullptr  =>  raw partial sums ALWAYS go to ws, even for nsplit == 1; no bias/act applied)

@@ -184,6 +184,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # rollout at once (one GEMM over steps x batch + one multi-step dot launch, logit_branch_forward) when
         # losses.RolloutCE evaluates the loss.  Nothing may read the logits before that (a sampled / greedy rollout does).
         self.defer_logits = False
+        # Opt-in, with defer_logits (TEACHER FORCING ONLY): consecutive steps are CHAINED -- a step leaves the tanh + dropout
+        # epilogue of its last product pending and the next step's first launch finishes it (the same in the backward with the
+        # act-embedding / h_tilde_prev stage): one dependent launch less per step and direction (vln_envdrop_step.chain).  Nothing
+        # but the next step (and the rollout-level logits / loss / weight gradients, which flush) may read a step's h_tilde.
+        self.chain_steps = False
         self.lstm = nn.LSTMCell(action_embed_size + feature_size, hidden_size)
         self.text_attn = _SoftDotParams(hidden_size)
         self.visual_attn = _SoftDotParams(hidden_size, context_dim=feature_size, context_only=True)
@@ -305,6 +310,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         (policy.py:199-206,243-244), formed now: ONE GEMM over (steps x batch) rows of the `htd` stash per contiguous run
         and ONE multi-step dot launch writing into the tensors forward() already returned."""
         lib = _lib.load()
+        if self.chain_steps:          # the last step's pending epilogue (its drop(h_tilde) row is read below)
+            _lib.check(lib.vln_envdrop_flush(_lib.raw_stream()), "vln_envdrop_flush")
         lp = self.compute_dtype != torch.float32
         F = self.feature_size
         B = recs[0].B
@@ -383,6 +390,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
     def _deferred_wgrads(self):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""
         H, F, AE = self.hidden_size, self.feature_size, self.action_embed_size
+        if self.chain_steps:          # the first step's pending prep backward (its act-embedding gradient rows are read below)
+            _lib.check(_lib.load().vln_envdrop_flush(_lib.raw_stream()), "vln_envdrop_flush")
         P = self._gated_params()
         runs = list(self._stash.done_runs())
         self._gate_consumed()
@@ -579,7 +588,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             pkey = (arena.g, arena.i, a_t_prev.data_ptr(), fk, h_tilde_prev.data_ptr(),
                     c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
                     self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
-                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits))
+                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits), bool(self.chain_steps))
         ctx_lp = None
         if lp:                         # once per rollout; BEFORE the step's own buffers so the arena order is the same on
             ctx_lp = entry.lp          # the planned and on the full path
@@ -709,6 +718,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.already_dropfeat = 1
         if self.defer_logits and need_grad:
             io.defer_logits = 1
+            if self.chain_steps:
+                io.chain = 3
         io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
         rec.io, rec.keep = io, keep
         if (pkey is not None and (gather is not None or (img is img_feature and cand is cand_feature)) and a is a_t_prev and htp.is_contiguous()

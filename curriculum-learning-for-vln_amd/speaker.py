@@ -38,6 +38,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         w_ih = torch.cat([params[4 * d].detach() for d in range(dirs)], 0).contiguous()
         bsum = torch.cat([(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(dirs)], 0).contiguous()
         w_hh = torch.stack([params[4 * d + 1].detach() for d in range(dirs)], 0).contiguous()
+        w_ih32, w_hh32 = w_ih, w_hh                  # the fp32 values: the backward builds its transposed shadows from them
         if dt != torch.float32:
             w_ih, w_hh = ops.cast_copy(w_ih, dt), ops.cast_copy(w_hh, dt)
         x_tm = x_tm.contiguous()
@@ -54,7 +55,7 @@ class _LSTMSeqFn(torch.autograd.Function):
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
                                         *owner._sync_ws(dev, B, Hd, dirs), -1, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
         ctx.owner, ctx.dims, ctx.dt = owner, (B, L, Hd, dirs), dt
-        ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh)
+        ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih32, w_hh32)
         ctx.set_materialize_grads(False)
         return y, hcat, ccat
 

@@ -713,6 +713,15 @@ typedef struct vln_envdrop_step {
    * block's columns are split, the partial row dots exchanged once as data-tagged granules), forward and backward.  NULL:
    * one workgroup per episode. */
   void* attn_sync; int64_t attn_sync_bytes;
+  /* ABI v13, CHAINED STEPS (teacher forcing, opt-in; needs defer_logits).  bit 0: forward leaves the last stage of the step -- the
+   * sum of linear_out's split-K slabs, tanh, dropout -> h_tilde, drop(h_tilde) (policy.py:241-243) -- PENDING; the next
+   * vln_envdrop_step_fwd on the same stream whose h_tilde_prev is this step's h_tilde does it inside its own first launch (which
+   * reads exactly that block), anything else gets it issued first (vln_envdrop_flush).  bit 1: backward leaves its last stage --
+   * the act-embedding / h_tilde_prev backward (policy.py:224,234) that produces d h_tilde_prev -- pending for the first launch of
+   * the next vln_envdrop_step_bwd whose d h_tilde is that buffer.  One dependent launch less per step and direction.  The CALLER
+   * promises that nothing outside these two entry points reads h_tilde / htd (forward) or d h_tilde_prev / the `de` stash rows
+   * (backward) before the next step call or a vln_envdrop_flush on that stream. */
+  int chain; int pad3_;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {
@@ -743,6 +752,7 @@ typedef struct vln_envdrop_grads {
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
 int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
+int vln_envdrop_flush(vln_stream_t s);      /* issue what a chained step left pending on this stream (no-op if nothing is) */
 int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io, vln_stream_t s);
 int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
                          vln_envdrop_grads* g, vln_stream_t s);

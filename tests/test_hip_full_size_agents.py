@@ -319,7 +319,8 @@ def _speaker_full(vln, cdt, B=64, Lp=7, V=36, F=2176, ANG=128, H=512, E=256, voc
         check(loss, lo, tol, f"{name}: loss")
         gtol = tol if not same else same_bf16_grad_tol()
         for key, mod, P in (("encoder", enc, Pe), ("decoder", dec, Pd)):
-            refs = {n: P[n].grad for n, _ in mod.named_parameters()}
+            # the holder keeps nn.LSTM's parameters under `<name>.rnn.*`, the state_dict (= the reference's keys) under `<name>.*`
+            refs = {n: P[n.replace(".rnn.", ".")].grad for n, _ in mod.named_parameters()}
             gmax = max(float(r.abs().max()) for r in refs.values() if r is not None)
             for n, prm in mod.named_parameters():
                 if refs[n] is None:                               # baseline_projection: not on the teacher-forcing path
@@ -349,7 +350,7 @@ def test_speaker_infer_batch_full_size(vln, cdt):
     img = torch.randn(B, Lp, V, F, generator=g).abs() * 0.5
     lengths = torch.randint(3, Lp + 1, (B,), generator=g); lengths[0] = Lp
     words = spk.infer_batch(can.to(DEV), img.to(DEV), lengths)
-    ora = R.SpeakerOracle(enc.state_dict(), dec.state_dict(), True)
+    ora = R.SpeakerOracle({k: v.cpu() for k, v in enc.state_dict().items()}, {k: v.cpu() for k, v in dec.state_dict().items()}, True)
     with torch.no_grad():
         ref_words, ref_logits = R.speaker_infer_batch(ora.encode, ora.decode, can, img, lengths.tolist(), H, 8, angle=ANG)
         ctx = enc(can.to(DEV), img.to(DEV), lengths)

@@ -16,7 +16,7 @@ def vln():
     return vln_amd
 
 
-def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device"):
+def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -26,6 +26,7 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmen
     torch.manual_seed(78)
     ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
     ag.use_live(live)
+    ag.dec.chain_steps = chain
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
     ag.rollout_gather = ag.gather_branch = branch == "branch"
@@ -74,6 +75,21 @@ def test_iteration_graph_equals_eager(vln, dtype, branch):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the replayed iteration"
+
+
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chained_decoder_steps_equal_unchained_steps(vln, dtype, graph):
+    """vln_envdrop_step.chain (round 4): a step leaves the tanh + dropout epilogue of its last product pending and the NEXT step's
+    first launch finishes it; in the backward the act-embedding / h_tilde_prev stage of step t rides in the first launch of step
+    t - 1's backward; the rollout-level logits / loss and the weight gradients flush what the last / first step left.  The same
+    arithmetic in the same order: losses, parameters, optimizer state and gradient norms over six iterations with fresh batches
+    and masks equal the unchained steps' bit for bit -- as eager launches with per-step hipGraphs and as one captured iteration."""
+    ref, _, _ = _run(vln, dtype, graph, "ride", chain=False)
+    got, _, _ = _run(vln, dtype, graph, "ride", chain=True)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between chained and unchained decoder steps"
 
 
 @pytest.mark.parametrize("graph", [True, False])
