@@ -342,7 +342,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
     if (ps.b.on) { ps.b.on = false; RUN(issue_pending_bwd(st, ps.b)); }        // a backward stage left over: not this call's business
     if (ps.f.on) {
       ps.f.on = false;
-      if (ps.f.ht == io->h_tilde_prev && ps.f.B == d->B && ps.f.H == d->H) use = ps.f;     // consumed by this step's first launch
+      if (ps.f.ht == io->h_tilde_prev && ps.f.B == d->B && ps.f.H == d->H) { use = ps.f; use.on = true; }     // consumed by this step's first launch
       else RUN(issue_pending_fwd(st, ps.f));
     }
     if (io->chain & 1) {
@@ -389,7 +389,7 @@ extern "C" int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop
       ps.b.on = false;
       // consumed when this step's incoming d h_tilde IS the pending stage's output and this step's first launch reads no
       // workspace slabs of its own (the rollout-wide logit branch covered its d logits: dhtd_ext without dlogit)
-      if (g->dh_tilde && ps.b.pa.dhtp == g->dh_tilde && ps.b.pa.B == d->B && ps.b.pa.H == d->H && g->dhtd_ext && !g->dlogit) use = ps.b;
+      if (g->dh_tilde && ps.b.pa.dhtp == g->dh_tilde && ps.b.pa.B == d->B && ps.b.pa.H == d->H && g->dhtd_ext && !g->dlogit) { use = ps.b; use.on = true; }
       else RUN(issue_pending_bwd(st, ps.b));
     }
     if (io->chain & 2) ps.b = bwd_pending(d, w, io, g);

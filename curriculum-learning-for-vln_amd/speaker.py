@@ -39,10 +39,13 @@ class _LSTMSeqFn(torch.autograd.Function):
         bsum = torch.cat([(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(dirs)], 0).contiguous()
         w_hh = torch.stack([params[4 * d + 1].detach() for d in range(dirs)], 0).contiguous()
         w_ih32, w_hh32 = w_ih, w_hh                  # the fp32 values: the backward builds its transposed shadows from them
+        f32_in = dt != torch.float32 and owner.fp32_input_weights      # W_ih streamed in fp32 all the same (VLN_F32S arithmetic)
         if dt != torch.float32:
-            w_ih, w_hh = ops.cast_copy(w_ih, dt), ops.cast_copy(w_hh, dt)
+            w_hh = ops.cast_copy(w_hh, dt)
+            if not f32_in:
+                w_ih = ops.cast_copy(w_ih, dt)
         x_tm = x_tm.contiguous()
-        xproj = ops.linear_fwd(x_tm, w_ih, bsum)
+        xproj = ops.linear_fwd(x_tm, w_ih, bsum, split=f32_in)
         hprev = ops.empty(dirs, L, B, Hd, **f32)
         cprev = ops.empty(dirs, L, B, Hd, **f32)
         y = ops.empty(L * B, dirs * Hd, **f32)
@@ -54,7 +57,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), wtype, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
                                         *owner._sync_ws(dev, B, Hd, dirs), -1, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
-        ctx.owner, ctx.dims, ctx.dt = owner, (B, L, Hd, dirs), dt
+        ctx.owner, ctx.dims, ctx.dt, ctx.f32_in = owner, (B, L, Hd, dirs), dt, f32_in
         ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih32, w_hh32)
         ctx.set_materialize_grads(False)
         return y, hcat, ccat
@@ -82,7 +85,9 @@ class _LSTMSeqFn(torch.autograd.Function):
             dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
             db = ops.colsum(dg)
             grads += [ops.linear_wgrad(dg, x_tm, split_bf16=sb), ops.linear_wgrad(dg, hprev[d].view(L * B, Hd), split_bf16=sb), db, db.clone()]
-        dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, dt)) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, torch.float32 if ctx.f32_in else dt), split=ctx.f32_in)
         return (None, dx, None, None, None, None) + tuple(grads)
 
 
@@ -95,6 +100,9 @@ class _SeqLSTM(nn.Module):
         self.rnn = nn.LSTM(input_size, hidden_size, 1, batch_first=True, bidirectional=bidirectional)
         self.hidden_size, self.dirs = hidden_size, 2 if bidirectional else 1
         self.compute_dtype = torch.float32
+        # bf16 mode: stream W_ih in fp32 all the same (split-bf16 arithmetic, VLN_F32S).  On for the speaker encoder's FIRST LSTM, whose
+        # 2176-wide input rows sum K = 2176 products per gate: its weight gradient sat at 1.1e-2 of the fp32 reference with bf16 W_ih
+        self.fp32_input_weights = False
 
     def _sync_ws(self, dev, B, Hd, dirs):
         need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
@@ -210,6 +218,7 @@ class SpeakerEncoder(nn.Module, _Seeded):
         self.post_lstm = _SeqLSTM(hidden_size, hidden_size // self.num_directions, bidirectional)
         self._init_seed(0x59EA)
         _rename_lstm_keys(self, ("lstm", "post_lstm"))
+        self.lstm.fp32_input_weights = True
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):

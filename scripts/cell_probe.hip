@@ -1,0 +1,190 @@
+// cell_probe (round 4): the decoder's LSTM cell as ONE launch per direction of time, as north_star words it --
+// "a fused 4-gate LSTM cell": the gate contraction [B, K] x [4H, K]^T (K = AE + F + H = 2752, 4H = 2048, B = 64) and the
+// i, f, g, o pointwise update in the SAME kernel -- against what the product ships: gemm_nt (split-K over workgroups into
+// partial slabs) + lstm_pw (sums the slabs while loading).  Reference: nn.LSTMCell at policy.py:192,237-238.
+//
+// A fused cell needs FINISHED gate sums in the workgroup that applies the nonlinearities, so K cannot be split over workgroups:
+// it is split over the WAVES of one workgroup and reduced through LDS.  Two tilings, both with every (row, unit) of the cell
+// owned by exactly one thread of the epilogue:
+//   A  64 rows x (4 units x 4 gates = 16 columns) per workgroup: 128 workgroups, each streams 16 x 2752 weights (88 KB bf16)
+//      and the WHOLE activation block 64 x 2752 fp32 (704 KB, from L2 after the first toucher of the XCD)
+//   B  32 rows x 16 columns: 256 workgroups, 88 KB of weights + 352 KB of activations each
+// X is split hi + lo in registers exactly like gemm_nt does in LDS (two bf16 MFMAs per product; same arithmetic).
+// The activations are rewritten by another kernel before every launch, as in the real chain.
+//   bash scripts/build_cell_probe.sh && scripts/cell_probe
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "../curriculum-learning-for-vln_amd/csrc/vln_internal.h"
+#include "../include/vln_hip.h"
+using namespace vln;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ROWS = rows per workgroup (64 or 32); 256 threads = 4 waves; wave w contracts K-steps w, w + 4, ... (64 columns of K each)
+template <int ROWS>
+__global__ __launch_bounds__(256) void fused_cell_kernel(const float* __restrict__ X, long ldx, const unsigned short* __restrict__ W, long ldw,
+                                                         const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                         const float* __restrict__ c0, float* __restrict__ h1, float* __restrict__ c1,
+                                                         float* __restrict__ act, float* __restrict__ tanh_c, int B, int H, int K) {
+  constexpr int RB = ROWS / 16;
+  __shared__ float red[4][ROWS][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fi = lane & 15, fq = lane >> 4;
+  const int u0 = blockIdx.x * 4;                   // first of this workgroup's 4 units
+  const int m0 = blockIdx.y * ROWS;
+  // this lane's weight row: column c = gate * 4 + unit_local  ->  weight row gate * H + u0 + unit_local
+  const int gate = fi >> 2, ul = fi & 3;
+  const unsigned short* wrow = W + (long)(gate * H + u0 + ul) * ldw;
+  const float* xrow[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) xrow[r] = X + (long)min(m0 + r * 16 + fi, B - 1) * ldx;
+  f32x4_t acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = K / 64;
+  for (int s = wave; s < nsteps; s += 4) {
+    const int k = s * 64 + fq * 16;                // this lane's 16 consecutive k (two MFMA k-groups of 8)
+    const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(wrow + k), w1 = *reinterpret_cast<const bf16x8_t*>(wrow + k + 8);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      float x[16];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 t = *reinterpret_cast<const float4*>(xrow[r] + k + v * 4);
+        x[v * 4] = t.x; x[v * 4 + 1] = t.y; x[v * 4 + 2] = t.z; x[v * 4 + 3] = t.w;
+      }
+      bf16x8_t h0, h1v, l0, l1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        h0[j] = (__bf16)x[j]; l0[j] = (__bf16)(x[j] - (float)h0[j]);
+        h1v[j] = (__bf16)x[8 + j]; l1[j] = (__bf16)(x[8 + j] - (float)h1v[j]);
+      }
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, w0, acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, w1, acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, w0, acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1v, w1, acc[r], 0, 0, 0);
+    }
+  }
+  // C layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][r * 16 + fq * 4 + e][fi] = acc[r][e];
+  __syncthreads();
+  // epilogue: one thread per (row, unit)
+  for (int t = threadIdx.x; t < ROWS * 4; t += 256) {
+    const int row = t >> 2, u = t & 3;
+    const int b = m0 + row;
+    if (b >= B) continue;
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = q * 4 + u;
+      g[q] = ((red[0][row][c] + red[1][row][c]) + (red[2][row][c] + red[3][row][c])) + b_ih[q * H + u0 + u] + b_hh[q * H + u0 + u];
+    }
+    const float si = 1.f / (1.f + __expf(-g[0])), sf = 1.f / (1.f + __expf(-g[1])), tg = tanhf(g[2]), so = 1.f / (1.f + __expf(-g[3]));
+    const long e = (long)b * H + u0 + u;
+    const float cn = sf * c0[e] + si * tg, tc = tanhf(cn);
+    h1[e] = so * tc; c1[e] = cn; tanh_c[e] = tc;
+    float* a = act + (long)b * 4 * H + u0 + u;
+    a[0] = si; a[H] = sf; a[2 * H] = tg; a[3 * H] = so;
+  }
+}
+
+__global__ void fill_f32_k(float* p, long n, float v) { for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v * 0.01f + (float)(i % 97) * 0.003f - 0.1f; }
+__global__ void fill_w_k(unsigned short* p, long n) { for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { float f = ((float)((i * 2654435761u) % 1000) - 500.f) * 4e-5f; p[i] = (unsigned short)(__float_as_uint(f) >> 16); } }
+
+static float median(std::vector<float>& t) { std::sort(t.begin(), t.end()); return t[t.size() / 2]; }
+
+int main() {
+  const int B = 64, H = 512, K = 2752, N = 4 * H;
+  float *X, *c0, *h1, *c1, *act, *tc, *bi, *bh, *ws, *h1b, *c1b, *actb, *tcb;
+  unsigned short* W;
+  const long wsf = 16L * B * N + 1024;
+  hipMalloc(&X, (long)B * K * 4); hipMalloc(&W, (long)N * K * 2); hipMalloc(&c0, (long)B * H * 4);
+  hipMalloc(&h1, (long)B * H * 4); hipMalloc(&c1, (long)B * H * 4); hipMalloc(&act, (long)B * N * 4); hipMalloc(&tc, (long)B * H * 4);
+  hipMalloc(&h1b, (long)B * H * 4); hipMalloc(&c1b, (long)B * H * 4); hipMalloc(&actb, (long)B * N * 4); hipMalloc(&tcb, (long)B * H * 4);
+  hipMalloc(&bi, N * 4); hipMalloc(&bh, N * 4); hipMalloc(&ws, wsf * 4);
+  hipLaunchKernelGGL(fill_w_k, dim3(1024), dim3(256), 0, 0, W, (long)N * K);
+  hipLaunchKernelGGL(fill_f32_k, dim3(64), dim3(256), 0, 0, c0, (long)B * H, 1.f);
+  hipLaunchKernelGGL(fill_f32_k, dim3(8), dim3(256), 0, 0, bi, (long)N, 2.f);
+  hipLaunchKernelGGL(fill_f32_k, dim3(8), dim3(256), 0, 0, bh, (long)N, 3.f);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char* what, auto&& launch) {
+    std::vector<float> t;
+    for (int r = 0; r < 25; ++r) {
+      hipLaunchKernelGGL(fill_f32_k, dim3(256), dim3(256), 0, 0, X, (long)B * K, 0.5f + r);     // the producer of xcat
+      hipEventRecord(e0, 0);
+      launch();
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f);
+    }
+    const float m = median(t);
+    printf("%-78s median %6.2f us   min %6.2f us\n", what, m, t[0]);
+    return m;
+  };
+  // ... and inside a hipGraph (what the whole-iteration graph pays): 20 x (refill X, the launches) captured, replayed, per repetition,
+  // minus the same graph with the refill only
+  hipStream_t cs; hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  auto graph_us = [&](auto&& launch) {
+    hipGraph_t g; hipGraphExec_t ex;
+    hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    for (int r = 0; r < 20; ++r) { hipLaunchKernelGGL(fill_f32_k, dim3(256), dim3(256), 0, cs, X, (long)B * K, 0.5f + r); launch(cs); }
+    hipStreamEndCapture(cs, &g); hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    std::vector<float> t;
+    for (int i = 0; i < 9; ++i) {
+      hipEventRecord(e0, cs); hipGraphLaunch(ex, cs); hipEventRecord(e1, cs); hipStreamSynchronize(cs);
+      float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms * 1e3f / 20.f);
+    }
+    hipGraphExecDestroy(ex); hipGraphDestroy(g);
+    return median(t);
+  };
+  // the product's two launches: split-K gemm_nt into slabs + the pointwise kernel that sums them while loading
+  int nsplit = 0;
+  timeit("product: gemm_nt (split-K slabs) + lstm_pw (2 launches)", [&] {
+    gemm_nt(0, X, K, W, W_BF16, K, nullptr, 0, B, N, K, nullptr, ACT_NONE, ws, wsf, &nsplit);
+    LstmPwFwd pw{};
+    pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
+    pw.h1 = h1b; pw.ldh1 = H; pw.c1 = c1b; pw.ldc1 = H; pw.act = actb; pw.tanh_c1 = tcb; pw.h1_drop = nullptr; pw.B = B; pw.H = H;
+    lstm_pointwise_fwd(0, pw);
+  });
+  printf("   (gemm_nt split K over %d workgroup rows -> %d workgroups)\n", nsplit, nsplit * (N / 64));
+  timeit("   gemm_nt alone", [&] { gemm_nt(0, X, K, W, W_BF16, K, nullptr, 0, B, N, K, nullptr, ACT_NONE, ws, wsf, &nsplit); });
+  timeit("fused cell A: 64 rows x 16 gate columns per workgroup, 128 workgroups (1 launch)", [&] {
+    hipLaunchKernelGGL(fused_cell_kernel<64>, dim3(H / 4, 1), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
+  });
+  timeit("fused cell B: 32 rows x 16 gate columns per workgroup, 256 workgroups (1 launch)", [&] {
+    hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
+  });
+  {
+    const float base = graph_us([&](hipStream_t) {});
+    auto pw_of = [&]() { LstmPwFwd pw{}; pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
+                         pw.h1 = h1b; pw.ldh1 = H; pw.c1 = c1b; pw.ldc1 = H; pw.act = actb; pw.tanh_c1 = tcb; pw.h1_drop = nullptr; pw.B = B; pw.H = H; return pw; };
+    const float tp = graph_us([&](hipStream_t st) { gemm_nt(st, X, K, W, W_BF16, K, nullptr, 0, B, N, K, nullptr, ACT_NONE, ws, wsf, &nsplit); lstm_pointwise_fwd(st, pw_of()); });
+    const float ta = graph_us([&](hipStream_t st) { hipLaunchKernelGGL(fused_cell_kernel<64>, dim3(H / 4, 1), dim3(256), 0, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K); });
+    const float tb = graph_us([&](hipStream_t st) { hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K); });
+    printf("inside a hipGraph, per repetition, refill-only graph (%.2f us) subtracted:\n  product (gemm_nt + lstm_pw) %6.2f us | fused cell A %6.2f us | fused cell B %6.2f us\n",
+           base, tp - base, ta - base, tb - base);
+  }
+  // same numbers?  one more matched pair on the SAME activations
+  hipLaunchKernelGGL(fill_f32_k, dim3(256), dim3(256), 0, 0, X, (long)B * K, 7.f);
+  gemm_nt(0, X, K, W, W_BF16, K, nullptr, 0, B, N, K, nullptr, ACT_NONE, ws, wsf, &nsplit);
+  {
+    LstmPwFwd pw{};
+    pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
+    pw.h1 = h1b; pw.ldh1 = H; pw.c1 = c1b; pw.ldc1 = H; pw.act = actb; pw.tanh_c1 = tcb; pw.h1_drop = nullptr; pw.B = B; pw.H = H;
+    lstm_pointwise_fwd(0, pw);
+  }
+  hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
+  hipDeviceSynchronize();
+  std::vector<float> a((long)B * H), b((long)B * H);
+  hipMemcpy(a.data(), h1, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), h1b, b.size() * 4, hipMemcpyDeviceToHost);
+  double md = 0, mx = 0;
+  for (size_t i = 0; i < a.size(); ++i) { md = std::max(md, (double)fabsf(a[i] - b[i])); mx = std::max(mx, (double)fabsf(b[i])); }
+  printf("h1: max |fused - product| = %.3e (max |h1| = %.3e)\n", md, mx);
+  return 0;
+}
