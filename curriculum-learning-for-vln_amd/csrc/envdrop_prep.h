@@ -50,20 +50,22 @@ __device__ __forceinline__ void envdrop_prep_body(const PrepArgs& p, long first,
       const long k = k4 * 4;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
       float4 v;
-      if (p.pend_slabs) {        // the previous step's reduce + tanh + dropout epilogue (step_bodies.h::reduce_epilogue_body, same sums)
-        float o[4];
+      if (p.pend_slabs) {        // the previous step's reduce + tanh + dropout epilogue (step_bodies.h::reduce_epilogue_body: the
+        // same per-element sums -- four partial sums over the slabs s mod 4, then (a1 + a2) + a3 -- on 16-byte loads)
+        const float* sp = p.pend_slabs + k;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        auto ld = [&](int s_) { return *reinterpret_cast<const float4*>(sp + (long)s_ * p.pend_stride); };
+        auto add = [](float4& x, const float4& y) { x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; };
+        int s = 0;
+        for (; s + 3 < p.pend_n; s += 4) {
+          const float4 t0 = ld(s), t1 = ld(s + 1), t2 = ld(s + 2), t3 = ld(s + 3);
+          add(a0, t0); add(a1, t1); add(a2, t2); add(a3, t3);
+        }
+        for (; s < p.pend_n; ++s) add(a0, ld(s));
+        float o[4] = {a0.x + ((a1.x + a2.x) + a3.x), a0.y + ((a1.y + a2.y) + a3.y), a0.z + ((a1.z + a2.z) + a3.z), a0.w + ((a1.w + a2.w) + a3.w)};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float* sp = p.pend_slabs + k + c;
-          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          int s = 0;
-          for (; s + 3 < p.pend_n; s += 4) {
-            a0 += sp[(long)s * p.pend_stride]; a1 += sp[(long)(s + 1) * p.pend_stride];
-            a2 += sp[(long)(s + 2) * p.pend_stride]; a3 += sp[(long)(s + 3) * p.pend_stride];
-          }
-          for (; s < p.pend_n; ++s) a0 += sp[(long)s * p.pend_stride];
-          a0 += (a1 + a2) + a3;
-          o[c] = tanhf(a0);
+          o[c] = tanhf(o[c]);
           p.pend_htd[k + c] = o[c] * dropout_scale1(p.pend_drop.seed, p.pend_drop.off(), (uint32_t)(k + c), p.pend_drop.p);
         }
         v = make_float4(o[0], o[1], o[2], o[3]);

@@ -125,19 +125,30 @@ struct PrepBwdArgs {
   int B, AE, F, H;
   DropSpec d_act, d_h;
 };
+// The three element formulas of these stages, with every rounding spelled out (no FMA contraction): the stand-alone kernels and
+// the chained kernel (which does two of the stages in one launch) must produce the same bits.
+__device__ __forceinline__ float prep_bwd_de(float dx, float mask, float e) {           // d act-embedding pre-activation
+  return __fmul_rn(__fmul_rn(dx, mask), __fsub_rn(1.f, __fmul_rn(e, e)));
+}
+__device__ __forceinline__ float prep_bwd_dhtp(float dx_tail, float dhq, float mask) {   // d h_tilde_prev: its two uses
+  return __fadd_rn(dx_tail, __fmul_rn(dhq, mask));
+}
+__device__ __forceinline__ float tanh_drop_dz(float gs, float mask, float dht, bool has_dht, float h) {
+  float g = __fmul_rn(gs, mask);
+  if (has_dht) g = __fadd_rn(g, dht);
+  return __fmul_rn(g, __fsub_rn(1.f, __fmul_rn(h, h)));
+}
+
 __device__ __forceinline__ void envdrop_prep_bwd_body(const PrepBwdArgs& p, long first, long stride) {
   const long ne = (long)p.B * p.AE, nh = (long)p.B * p.H;
   for (long i = first; i < ne + nh; i += stride) {
     if (i < ne) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
-      const float e = p.e[i];
-      const float de = p.dxcat.at(b, j) * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
-      p.s_de[i] = de * (1.f - e * e);
+      p.s_de[i] = prep_bwd_de(p.dxcat.at(b, j), dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p), p.e[i]);
     } else {
       const long k = i - ne;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
-      p.dhtp[k] = p.dxcat.at(b, p.AE + p.F + j) +
-                  p.dhq.at(b, j) * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
+      p.dhtp[k] = prep_bwd_dhtp(p.dxcat.at(b, p.AE + p.F + j), p.dhq.at(b, j), dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p));
     }
   }
 }
@@ -151,21 +162,15 @@ __device__ __forceinline__ void envdrop_prep_tanh_bwd_body(const PrepTanhBwdArgs
   for (long i = first; i < ne + nh; i += stride) {
     if (i < ne) {
       const int b = (int)(i / p.AE), j = (int)(i % p.AE);
-      const float e = p.e[i];
-      const float de = p.dxcat.at(b, j) * dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p);
-      p.s_de[i] = de * (1.f - e * e);
+      p.s_de[i] = prep_bwd_de(p.dxcat.at(b, j), dropout_scale1(p.d_act.seed, p.d_act.off(), (uint32_t)i, p.d_act.p), p.e[i]);
     } else {
       const long k = i - ne;
       const int b = (int)(k / p.H), j = (int)(k % p.H);
-      const float v = p.dxcat.at(b, p.AE + p.F + j) +
-                      p.dhq.at(b, j) * dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p);
+      const float v = prep_bwd_dhtp(p.dxcat.at(b, p.AE + p.F + j), p.dhq.at(b, j), dropout_scale1(p.d_h.seed, p.d_h.off(), (uint32_t)k, p.d_h.p));
       p.dhtp[k] = v;
       float gs = a.dhtd.at(b, j);                    // tanh_drop_bwd_body of the next step, with dht_ext = v
       if (a.dhtd2) gs += a.dhtd2[k];
-      float g = gs * dropout_scale1(a.d.seed, a.d.off(), (uint32_t)k, a.d.p);
-      g += v;
-      const float h = a.ht[k];
-      a.dz[k] = g * (1.f - h * h);
+      a.dz[k] = tanh_drop_dz(gs, dropout_scale1(a.d.seed, a.d.off(), (uint32_t)k, a.d.p), v, true, a.ht[k]);
     }
   }
 }
@@ -180,10 +185,7 @@ __device__ __forceinline__ void tanh_drop_bwd_body(const TanhDropBwdArgs& a, lon
   for (long i = first; i < n; i += stride) {
     float gs = a.dhtd.at(i / a.H, i % a.H);
     if (a.dhtd2) gs += a.dhtd2[i];
-    float g = gs * dropout_scale1(a.d.seed, a.d.off(), (uint32_t)i, a.d.p);
-    if (a.dht_ext) g += a.dht_ext[i];
-    const float h = a.ht[i];
-    a.dz[i] = g * (1.f - h * h);
+    a.dz[i] = tanh_drop_dz(gs, dropout_scale1(a.d.seed, a.d.off(), (uint32_t)i, a.d.p), a.dht_ext ? a.dht_ext[i] : 0.f, a.dht_ext != nullptr, a.ht[i]);
   }
 }
 
