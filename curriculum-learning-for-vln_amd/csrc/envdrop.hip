@@ -345,6 +345,10 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
       if (ps.f.ht == io->h_tilde_prev && ps.f.B == d->B && ps.f.H == d->H) { use = ps.f; use.on = true; }     // consumed by this step's first launch
       else RUN(issue_pending_fwd(st, ps.f));
     }
+    // A step whose h_tilde_prev did NOT come out of a chained step (the head of a rollout: the encoder's state) must finish its own
+    // backward: whoever consumes its d h_tilde_prev is not a chained step (autograd may even COPY that buffer the moment the
+    // step's backward returns -- an AccumulateGrad of a leaf -- long before any flush).
+    if (!use.on) io->chain &= ~2;
     if (io->chain & 1) {
       Ws ws; ws_layout(*d, io->ws, &ws);
       const int wt3 = ((w->f32_mask >> 3) & 1) ? (int)W_F32S : d->wtype;

@@ -125,18 +125,24 @@ struct PrepBwdArgs {
   int B, AE, F, H;
   DropSpec d_act, d_h;
 };
-// The three element formulas of these stages, with every rounding spelled out (no FMA contraction): the stand-alone kernels and
-// the chained kernel (which does two of the stages in one launch) must produce the same bits.
+// The three element formulas of these stages with every rounding spelled out: the stand-alone kernels and the chained kernel (which
+// does two of the stages in one launch) must produce the same bits, and the compiler's FMA contraction (-ffp-contract=fast is the
+// HIP default; __fmul_rn / __fadd_rn are plain operators on AMD) decides differently in different kernels.  Contraction is off
+// inside these helpers and the fused multiply-adds that ARE wanted are written as such.
 __device__ __forceinline__ float prep_bwd_de(float dx, float mask, float e) {           // d act-embedding pre-activation
-  return __fmul_rn(__fmul_rn(dx, mask), __fsub_rn(1.f, __fmul_rn(e, e)));
+#pragma clang fp contract(off)
+  const float t = __builtin_fmaf(-e, e, 1.f);
+  return (dx * mask) * t;
 }
 __device__ __forceinline__ float prep_bwd_dhtp(float dx_tail, float dhq, float mask) {   // d h_tilde_prev: its two uses
-  return __fadd_rn(dx_tail, __fmul_rn(dhq, mask));
+#pragma clang fp contract(off)
+  return __builtin_fmaf(dhq, mask, dx_tail);
 }
 __device__ __forceinline__ float tanh_drop_dz(float gs, float mask, float dht, bool has_dht, float h) {
-  float g = __fmul_rn(gs, mask);
-  if (has_dht) g = __fadd_rn(g, dht);
-  return __fmul_rn(g, __fsub_rn(1.f, __fmul_rn(h, h)));
+#pragma clang fp contract(off)
+  const float g = has_dht ? __builtin_fmaf(gs, mask, dht) : gs * mask;
+  const float t = __builtin_fmaf(-h, h, 1.f);
+  return g * t;
 }
 
 __device__ __forceinline__ void envdrop_prep_bwd_body(const PrepBwdArgs& p, long first, long stride) {

@@ -720,7 +720,8 @@ typedef struct vln_envdrop_step {
    * the act-embedding / h_tilde_prev backward (policy.py:224,234) that produces d h_tilde_prev -- pending for the first launch of
    * the next vln_envdrop_step_bwd whose d h_tilde is that buffer.  One dependent launch less per step and direction.  The CALLER
    * promises that nothing outside these two entry points reads h_tilde / htd (forward) or d h_tilde_prev / the `de` stash rows
-   * (backward) before the next step call or a vln_envdrop_flush on that stream. */
+   * (backward) before the next step call or a vln_envdrop_flush on that stream.  vln_envdrop_step_fwd CLEARS bit 1 in place for a
+   * step that did not consume a pending stage itself (the head of a rollout: what consumes its d h_tilde_prev is not a chained step). */
   int chain; int pad3_;
 } vln_envdrop_step;
 

@@ -307,7 +307,7 @@ def _speaker_full(vln, cdt, B=64, Lp=7, V=36, F=2176, ANG=128, H=512, E=256, voc
     for name, tol, same in variants:
         Pe = {k: v.detach().cpu().double().requires_grad_(True) for k, v in enc.state_dict().items()}
         Pd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()}
-        Pev = bf16_weights(Pe, skip=("lstm.weight_ih_l0", "lstm.weight_ih_l0_reverse")) if same else Pe       # streamed in fp32 (speaker.py)
+        Pev = bf16_weights(Pe, skip=("lstm.weight_ih_l0", "lstm.weight_ih_l0_reverse", "lstm.weight_hh_l0", "lstm.weight_hh_l0_reverse")) if same else Pe   # streamed in fp32 (speaker.py)
         Pdv = bf16_weights(Pd, skip=("embedding.weight",) + tuple(k for k in Pd if k.startswith("baseline_projection"))) if same else Pd
         ctx = O.speaker_encoder(Pev, can_o, img_o, True, drop=edrop)
         z = torch.zeros(1, B, H, dtype=torch.float64)
