@@ -957,7 +957,24 @@ def main():
             b = secondary_envdrop(vln, dev, store, short, dtype, "store", args, graph=use_graph)
             return {"us": round((a - b) / (args.T - 3) * 1e3, 1), "how": f"(ms at T={args.T} - ms at T=3) / {args.T - 3}, same path as the headline"}
 
-        for name, fn in (("eager_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args)),
+        def long_run(n=1000):      # the headline path over a region 50x the driver's: what a 20-step region cannot show (clock ramps, drift)
+            if agent.graph is None:
+                return {"error": "no iteration graph"}
+            gc.collect(); gc.freeze()
+            try:
+                for _ in range(8):
+                    iterate()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    iterate()
+                torch.cuda.synchronize()
+                return {"ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 3), "steps": n}
+            finally:
+                gc.unfreeze()
+
+        for name, fn in (("headline_long_run", long_run),
+                         ("eager_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args)),
                          ("dropin_unchanged_caller_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "tensor", args, dropin=True)),
                          ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
                          ("all_bf16_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
