@@ -268,6 +268,8 @@ class GpuAgent:
         self._cut = None
         self.batch_fetch = None         # LiveBatch.fetch / .launched when the batches are pulled from pinned host memory
         self.batch_launched = None
+        self.batch_feed = None
+        self.use_prologue = True        # pull + tick + shadow refreshes as one launch (runtime.DeviceClock.prologue)
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
         self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
 
@@ -308,7 +310,7 @@ class GpuAgent:
         """A LiveBatch whose batches are PULLED from pinned host memory: the iteration's first launch is the pull
         (staging.HostBatchFeed); after every iteration / replay an event bounds how far the host may run ahead."""
         if live.feed is not None:
-            self.batch_fetch, self.batch_launched = live.fetch, live.launched
+            self.batch_fetch, self.batch_launched, self.batch_feed = live.fetch, live.launched, live.feed
 
     def use_arena(self, on: bool):
         self.arena = self.vln.ops.RolloutArena() if on else None
@@ -420,10 +422,15 @@ class GpuAgent:
 
     def _iteration(self, tape):
         B = tape["B"]
-        if self.batch_fetch is not None:
-            self.batch_fetch()         # one launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull")
-        if self.clock is not None:
-            self.clock.tick()          # one launch: this iteration's dropout offsets / launch sequence (device words)
+        if self.clock is not None and self.use_prologue:
+            # ONE launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull"), the device clock ticks (this
+            # iteration's dropout offsets / launch sequence) and both modules' weight shadows follow the last optimizer step
+            self.clock.prologue(self.batch_feed, (self.enc, self.dec))
+        else:
+            if self.batch_fetch is not None:
+                self.batch_fetch()     # one launch: the pull
+            if self.clock is not None:
+                self.clock.tick()      # one launch: the tick
         self._probe()
         if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
             self.side.wait_stream(torch.cuda.current_stream())
@@ -675,6 +682,7 @@ def main():
                          "pull = pinned HOST memory, the iteration's first launch pulls the batch through PCIe (default: what a data "
                          "loader hands over); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
                          "device memory, one device-to-device copy (round 3's form)")
+    ap.add_argument("--no-prologue", action="store_true", help="(A/B) the batch pull, the clock tick and the shadow refreshes as separate launches")
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
@@ -751,6 +759,8 @@ def main():
     agent.dump_graph = args.dump_graph
     if args.no_chain:
         agent.dec.chain_steps = False
+    if args.no_prologue:
+        agent.use_prologue = False
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and args.features == "store" and not args.no_arena)
     # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
     # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
@@ -1037,7 +1047,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "prologue_launch": bool(agent.use_prologue and use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

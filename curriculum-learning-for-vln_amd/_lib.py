@@ -277,6 +277,7 @@ SIGNATURES = {
     "vln_persistent_check": (i32, []),
     "vln_host_device_pointer": (i32, [ptr, C.POINTER(C.c_void_p)]),
     "vln_host_fetch": (i32, [ptr, i32, ptr, ptr, ptr, i64, ptr]),
+    "vln_prologue": (i32, [ptr, i32, ptr, ptr, ptr, i64, ptr, i32, ptr, i32, ptr]),
     "vln_set_split_attention": (i32, [i32]),
     "vln_get_split_attention": (i32, []),
     "vln_follower_bwd_scratch_floats": (i64, [ptr]),
@@ -296,6 +297,7 @@ SIGNATURES = {
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
 EXPECTED_ABI = 13
+SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None
 try:                                   # resolved once: the two C entry points behind torch.cuda.current_stream()

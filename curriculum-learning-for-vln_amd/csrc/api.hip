@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include "vln_internal.h"
+#include "prologue_bodies.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -309,25 +310,22 @@ extern "C" int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int im
 
 // ---- device-resident counters (runtime.DeviceClock) ----------------------------------------------------------------
 namespace vln {
-struct TickArgs { unsigned long long* w64[VLN_TICK_MAX]; unsigned long long inc64[VLN_TICK_MAX]; unsigned* w32[VLN_TICK_MAX];
-                  unsigned inc32[VLN_TICK_MAX]; int n; };
-__global__ void tick_kernel(TickArgs a) {
-  const int i = threadIdx.x;
-  if (i < a.n) {
-    if (a.w64[i]) *a.w64[i] += a.inc64[i];
-    if (a.w32[i]) *a.w32[i] += a.inc32[i];
+__global__ void tick_kernel(TickArgs a) { tick_body(a, (int)threadIdx.x); }
+int tick_args(const vln_tick_item* items, int n, TickArgs* a) {
+  if (!items || n <= 0 || n > VLN_TICK_MAX) { set_error("vln_tick: 1..%d items", VLN_TICK_MAX); return VLN_ERR_ARG; }
+  *a = TickArgs{};
+  a->n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].word || (items[i].width != 4 && items[i].width != 8)) { set_error("vln_tick: item %d: null word or width not 4 / 8", i); return VLN_ERR_ARG; }
+    if (items[i].width == 8) { a->w64[i] = (unsigned long long*)items[i].word; a->inc64[i] = items[i].inc; }
+    else { a->w32[i] = (unsigned*)items[i].word; a->inc32[i] = (unsigned)items[i].inc; }
   }
+  return VLN_OK;
 }
 }  // namespace vln
 extern "C" int vln_tick(const vln_tick_item* items, int n, vln_stream_t s) {
-  if (!items || n <= 0 || n > VLN_TICK_MAX) { set_error("vln_tick: 1..%d items", VLN_TICK_MAX); return VLN_ERR_ARG; }
-  TickArgs a{};
-  a.n = n;
-  for (int i = 0; i < n; ++i) {
-    if (!items[i].word || (items[i].width != 4 && items[i].width != 8)) { set_error("vln_tick: item %d: null word or width not 4 / 8", i); return VLN_ERR_ARG; }
-    if (items[i].width == 8) { a.w64[i] = (unsigned long long*)items[i].word; a.inc64[i] = items[i].inc; }
-    else { a.w32[i] = (unsigned*)items[i].word; a.inc32[i] = (unsigned)items[i].inc; }
-  }
+  TickArgs a;
+  int r = tick_args(items, n, &a); if (r) return r;
   VLN_LAUNCH(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("tick");
   return VLN_OK;
@@ -340,25 +338,20 @@ extern "C" int vln_tick(const vln_tick_item* items, int n, vln_stream_t s) {
 // fixed device buffers the captured iteration reads.  No copy API call sits between two graph replays (a stream-ordered
 // hipMemcpyAsync in front of the graph cost 130 us per iteration on MI355X: profiles/round4_notes.md), the launch arguments repeat,
 // and the host's share per iteration is one store.
-// The host runs AHEAD of the device (it enqueues many replays), so one slot would be overwritten before the launch that should read
-// it has run: the slots form a RING of `ring` words and the kernel picks slot (*seq % ring), where `seq` is a device word counting
-// the fetches that have run; the last workgroup to finish bumps it (every workgroup has read it by then).
 namespace vln {
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void host_fetch_kernel(const unsigned long long* slots, int ring, unsigned long long* seq, unsigned* done,
-                                                         u32x4* dst, long n16) {
-  const unsigned long long n = *seq;
-  const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(slots + (n % (unsigned long long)ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
-    dst[i] = __builtin_nontemporal_load(src + i);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {           // every workgroup has read *seq: the next launch sees the next slot
-      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(seq, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+__global__ __launch_bounds__(256) void host_fetch_kernel(FetchArgs f) { host_fetch_body(f, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x); }
+int fetch_args(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, FetchArgs* f, int* blocks) {
+  if (!slots_dev || !seq || !done || !dst || ring < 1 || nbytes <= 0 || (nbytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    set_error("vln_host_fetch: null pointer, empty ring, or size / destination not a multiple of 16 bytes");
+    return VLN_ERR_ARG;
   }
+  const long n16 = nbytes / 16;
+  int b = (int)((n16 + 255) / 256);
+  if (b > 512) b = 512;
+  *f = FetchArgs{reinterpret_cast<const unsigned long long*>(slots_dev), ring, reinterpret_cast<unsigned long long*>(seq),
+                 reinterpret_cast<unsigned*>(done), static_cast<u32x4*>(dst), n16};
+  *blocks = b;
+  return VLN_OK;
 }
 }  // namespace vln
 extern "C" int vln_host_device_pointer(const void* host, void** dev) {
@@ -373,15 +366,9 @@ extern "C" int vln_host_device_pointer(const void* host, void** dev) {
   return VLN_OK;
 }
 extern "C" int vln_host_fetch(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, vln_stream_t s) {
-  if (!slots_dev || !seq || !done || !dst || ring < 1 || nbytes <= 0 || (nbytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) {
-    set_error("vln_host_fetch: null pointer, empty ring, or size / destination not a multiple of 16 bytes");
-    return VLN_ERR_ARG;
-  }
-  const long n16 = nbytes / 16;
-  int blocks = (int)((n16 + 255) / 256);
-  if (blocks > 512) blocks = 512;
-  VLN_LAUNCH(host_fetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, reinterpret_cast<const unsigned long long*>(slots_dev), ring,
-             reinterpret_cast<unsigned long long*>(seq), reinterpret_cast<unsigned*>(done), static_cast<u32x4*>(dst), n16);
+  FetchArgs f; int blocks = 0;
+  int r = fetch_args(slots_dev, ring, seq, done, dst, nbytes, &f, &blocks); if (r) return r;
+  VLN_LAUNCH(host_fetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, f);
   VLN_CHECK_LAUNCH("host_fetch");
   return VLN_OK;
 }

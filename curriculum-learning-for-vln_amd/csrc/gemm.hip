@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "vln_internal.h"
+#include "prologue_bodies.h"
 #include "step_bodies.h"
 #include "../../include/vln_hip.h"
 
@@ -1163,35 +1164,73 @@ __device__ __forceinline__ bool shadow_vec_ok(const vln_shadow_job& q) {
   const uintptr_t al = (uintptr_t)q.src | (uintptr_t)q.src2 | (uintptr_t)q.dst | (uintptr_t)q.dst_t;
   return !((q.N | q.K | (int)q.ld_src | (int)q.ld_dst | (int)q.ld_dst_t) & 3) && !(al & 15);
 }
-__global__ __launch_bounds__(256) void shadow_refresh_kernel(ShadowJobs a) {
-  __shared__ float lds[64][65];
+__device__ __forceinline__ void shadow_block(const ShadowJobs& a, int block, float (*lds)[65]) {
   int ji = 0;
-  while (ji + 1 < a.n && (int)blockIdx.x >= a.tile0[ji + 1]) ++ji;
+  while (ji + 1 < a.n && block >= a.tile0[ji + 1]) ++ji;
   const vln_shadow_job& q = a.j[ji];
-  const int tile = (int)blockIdx.x - a.tile0[ji];
+  const int tile = block - a.tile0[ji];
   if (shadow_vec_ok(q)) {
     if (q.out_type == W_BF16) shadow_tile_v4<bf16_raw>(q, tile, lds);
     else shadow_tile_v4<float>(q, tile, lds);
   } else if (q.out_type == W_BF16) shadow_tile<bf16_raw>(q, tile, lds);
   else shadow_tile<float>(q, tile, lds);
 }
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(ShadowJobs a) {
+  __shared__ float lds[64][65];
+  shadow_block(a, (int)blockIdx.x, lds);
+}
+static int shadow_jobs(const vln_shadow_job* jobs, int n, ShadowJobs* a, int* tiles) {
+  a->n = n;
+  int t = 0;
+  for (int i = 0; i < n; ++i) {
+    const vln_shadow_job& q = jobs[i];
+    if (!q.src || q.N <= 0 || q.K <= 0 || (!q.dst && !q.dst_t)) { set_error("shadow_refresh: bad job %d", i); return VLN_ERR_ARG; }
+    a->j[i] = q;
+    a->tile0[i] = t;
+    t += ((q.N + 63) / 64) * ((q.K + 63) / 64);
+  }
+  a->tile0[n] = t;
+  *tiles = t;
+  return VLN_OK;
+}
 int shadow_refresh(hipStream_t st, const vln_shadow_job* jobs, int n) {
   for (int base = 0; base < n; base += VLN_SHADOW_MAX_JOBS) {
-    ShadowJobs a;
-    a.n = (n - base < VLN_SHADOW_MAX_JOBS) ? n - base : VLN_SHADOW_MAX_JOBS;
-    int t = 0;
-    for (int i = 0; i < a.n; ++i) {
-      const vln_shadow_job& q = jobs[base + i];
-      if (!q.src || q.N <= 0 || q.K <= 0 || (!q.dst && !q.dst_t)) { set_error("shadow_refresh: bad job %d", base + i); return VLN_ERR_ARG; }
-      a.j[i] = q;
-      a.tile0[i] = t;
-      t += ((q.N + 63) / 64) * ((q.K + 63) / 64);
-    }
-    a.tile0[a.n] = t;
+    ShadowJobs a; int t = 0;
+    int r = shadow_jobs(jobs + base, (n - base < VLN_SHADOW_MAX_JOBS) ? n - base : VLN_SHADOW_MAX_JOBS, &a, &t); if (r) return r;
     VLN_LAUNCH(shadow_refresh_kernel, dim3(t), dim3(256), 0, st, a);
   }
   VLN_CHECK_LAUNCH("shadow_refresh");
   return VLN_OK;
 }
 
+// ---- the iteration's prologue as ONE launch ------------------------------------------------------------------------------------------
+// Block ranges: [0, nf) pull the batch out of pinned host memory (PCIe-bound, ~39 us alone), [nf, nf + tiles) refresh the weight
+// shadows of the modules whose parameters the previous optimizer step changed (HBM-bound, 21 us as two launches), the last block
+// ticks the device clock.  None of the three depends on another; as separate launches they were 70 us of the iteration's dependent
+// chain (pull 39, tick 4.5, refreshes 5.8 + 15.6 and three boundaries).
+__global__ __launch_bounds__(256) void prologue_kernel(FetchArgs f, int nf, ShadowJobs sj, int tiles, TickArgs tk) {
+  __shared__ float lds[64][65];
+  const int b = (int)blockIdx.x;
+  if (b < nf) { host_fetch_body(f, b, nf, (int)threadIdx.x); return; }
+  if (b < nf + tiles) { shadow_block(sj, b - nf, lds); return; }
+  tick_body(tk, (int)threadIdx.x);
+}
+
 }  // namespace vln
+
+extern "C" int vln_prologue(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes,
+                            const vln_tick_item* ticks, int n_ticks, const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {
+  using namespace vln;
+  if (n_jobs < 0 || n_jobs > VLN_SHADOW_MAX_JOBS || n_ticks < 0) { set_error("vln_prologue: 0..%d shadow jobs, >= 0 tick items", VLN_SHADOW_MAX_JOBS); return VLN_ERR_ARG; }
+  FetchArgs f{}; int nf = 0;
+  if (slots_dev) { int r = fetch_args(slots_dev, ring, seq, done, dst, nbytes, &f, &nf); if (r) return r; }
+  ShadowJobs sj{}; int tiles = 0;
+  if (n_jobs) { int r = shadow_jobs(jobs, n_jobs, &sj, &tiles); if (r) return r; }
+  TickArgs tk{};
+  if (n_ticks) { int r = tick_args(ticks, n_ticks, &tk); if (r) return r; }
+  const int blocks = nf + tiles + (n_ticks ? 1 : 0);
+  if (blocks <= 0) return VLN_OK;
+  VLN_LAUNCH(prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, f, nf, sj, tiles, tk);
+  VLN_CHECK_LAUNCH("prologue");
+  return VLN_OK;
+}

@@ -1,0 +1,41 @@
+// Bodies of the iteration's PROLOGUE (round 4): the pull of the batch out of pinned host memory (vln_host_fetch), the device clock's
+// tick (vln_tick) and the weight-shadow refresh (vln_shadow_refresh) -- three launches at the top of every iteration that do not
+// depend on each other -- also run as block ranges of ONE launch (vln_prologue, gemm.hip).
+#pragma once
+#include "vln_internal.h"
+#include "../../include/vln_hip.h"
+
+namespace vln {
+
+struct TickArgs { unsigned long long* w64[VLN_TICK_MAX]; unsigned long long inc64[VLN_TICK_MAX]; unsigned* w32[VLN_TICK_MAX];
+                  unsigned inc32[VLN_TICK_MAX]; int n; };
+__device__ __forceinline__ void tick_body(const TickArgs& a, int i) {
+  if (i < a.n) {
+    if (a.w64[i]) *a.w64[i] += a.inc64[i];
+    if (a.w32[i]) *a.w32[i] += a.inc32[i];
+  }
+}
+int tick_args(const vln_tick_item* items, int n, TickArgs* a);        // api.hip: validates and fills
+
+// The host runs AHEAD of the device (it enqueues many replays), so one slot would be overwritten before the launch that should read
+// it has run: the slots form a RING of `ring` words and the kernel picks slot (*seq % ring), where `seq` is a device word counting
+// the fetches that have run; the last workgroup to finish bumps it (every workgroup has read it by then).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct FetchArgs { const unsigned long long* slots; int ring; unsigned long long* seq; unsigned* done; u32x4* dst; long n16; };
+__device__ __forceinline__ void host_fetch_body(const FetchArgs& f, int block, int nblocks, int tid) {
+  const unsigned long long n = *f.seq;
+  const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(f.slots + (n % (unsigned long long)f.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  for (long i = (long)block * 256 + tid; i < f.n16; i += (long)nblocks * 256)
+    f.dst[i] = __builtin_nontemporal_load(src + i);
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)nblocks - 1u) {           // every workgroup has read *seq: the next launch sees the next slot
+      __hip_atomic_store(f.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(f.seq, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+int fetch_args(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, FetchArgs* f, int* blocks);
+
+}  // namespace vln

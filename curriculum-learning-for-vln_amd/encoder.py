@@ -337,6 +337,15 @@ class EncoderLSTM(nn.Module):
         sb.add(w, buf("w_e2d", tuple(w.shape)), buf("w_e2d_t", (w.shape[1], w.shape[0])))
         object.__setattr__(self, "_sb_handle", (ck, sb.run()))
 
+    def prefresh(self):
+        """Refresh the weight shadows NOW if a parameter changed since they were built (see GatedModuleMixin.prefresh)."""
+        params = self._params_cached()
+        key = ShadowSet.key_of(params, self.compute_dtype)
+        if self._shadow.stale(key):
+            with torch.no_grad():
+                self._refresh_shadows()
+            self._shadow.commit(key)
+
     def forward(self, inputs: torch.Tensor, lengths, already_sorted: bool = True, ride=None):
         """inputs [B, max_len] int64 on the GPU, lengths [B] (CPU or GPU, any int type).  Rows are processed
         independently with packed-sequence semantics, so `already_sorted` needs no special handling.

@@ -267,20 +267,40 @@ class ShadowBatch:
         self.jobs.append(j)
         self.keep += [src, src2, dst, dst_t]
 
+    # While a collector list is installed (`collect()`), run() / replay() hand their job arrays to it instead of launching: the
+    # caller issues them together with other work in ONE launch (runtime.DeviceClock.prologue -> vln_prologue).
+    _collector = None
+
+    @classmethod
+    def collect(cls):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, cls._collector = cls._collector, []
+            try:
+                yield cls._collector
+            finally:
+                cls._collector = prev
+        return scope()
+
     def run(self):
         """Issues the launch; returns a replayable handle (the job array is valid as long as the sources and destinations
         keep their addresses: `ShadowBatch.replay(handle)` refreshes again without rebuilding the jobs)."""
         if not self.jobs:
             return None
         arr = (_lib.ShadowJob * len(self.jobs))(*self.jobs)
-        _lib.check(_lib.load().vln_shadow_refresh(arr, len(self.jobs), _stream()), "vln_shadow_refresh")
         handle = (arr, len(self.jobs), self.keep)
         self.jobs, self.keep = [], []
+        ShadowBatch.replay(handle)
         return handle
 
     @staticmethod
     def replay(handle):
         arr, n, _keep = handle
+        if ShadowBatch._collector is not None:
+            ShadowBatch._collector.append(handle)
+            return
         _lib.check(_lib.load().vln_shadow_refresh(arr, n, _stream()), "vln_shadow_refresh")
 
 

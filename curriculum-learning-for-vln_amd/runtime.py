@@ -124,6 +124,28 @@ class DeviceClock:
         items, n = self._tick_items()
         _lib.check(_lib.load().vln_tick(items, n, _lib.raw_stream()), "vln_tick")
 
+    def prologue(self, feed=None, modules=()):
+        """tick() + (optional) the pull of the selected batch (staging.HostBatchFeed) + the weight-shadow refresh of `modules`
+        (whatever the last optimizer step staled) as ONE launch (`vln_prologue`): the three do not depend on each other and sat as
+        four launches at the top of every iteration's dependent chain.  The modules' own forward then finds its shadows current."""
+        from . import _lib, ops
+        self._maintain()
+        with ops.ShadowBatch.collect() as handles:
+            for m in modules:
+                m.prefresh()
+        items, n = self._tick_items()
+        njobs = sum(h[1] for h in handles)
+        lib = _lib.load()
+        if njobs > _lib.SHADOW_MAX_JOBS:          # more jobs than one argument block holds: the refreshes keep their own launches
+            for h in handles:
+                _lib.check(lib.vln_shadow_refresh(h[0], h[1], _lib.raw_stream()), "vln_shadow_refresh")
+            handles, njobs = [], 0
+        jobs = None
+        if njobs:
+            jobs = (_lib.ShadowJob * njobs)(*[h[0][i] for h in handles for i in range(h[1])])
+        f = feed.fetch_args() if feed is not None else (None, 0, None, None, None, 0)
+        _lib.check(lib.vln_prologue(*f, items, n, jobs, njobs, _lib.raw_stream()), "vln_prologue")
+
     def uncount(self):
         """Undo the host side of one tick(): a tick that was CAPTURED did not run, the device words are unchanged."""
         self.host -= self.STRIDE
@@ -404,6 +426,17 @@ class GatedModuleMixin:
             self._open_versions = [p._version for p in params]
             self._rebase_offsets(params[0].device)
         return self._gate_outs
+
+    def prefresh(self):
+        """Refresh the weight shadows NOW if a parameter changed since they were built (what the first forward after an optimizer
+        step would do): lets the caller issue the refresh where it likes -- e.g. inside the iteration's prologue launch."""
+        params = self._gated_params()
+        key = ShadowSet.key_of(params, self.compute_dtype)
+        if self._shadow.stale(key):
+            with torch.no_grad():
+                self._refresh_shadows()
+            self._shadow.commit(key)
+            self._gate_outs = None
 
     def _gate_consumed(self):
         # called from _deferred_wgrads once the dW GEMMs are issued: the next forward opens a new gate

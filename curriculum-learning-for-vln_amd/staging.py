@@ -381,6 +381,11 @@ class HostBatchFeed:
         ev.record()
         self._events[i] = ev
 
+    def fetch_args(self):
+        """The pull as arguments of `vln_prologue` (runtime.DeviceClock.prologue issues it together with the tick and the refreshes)."""
+        st = self._state
+        return (self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(), self.live.numel())
+
     def fetch(self):
         st = self._state
         _lib.check(_lib.load().vln_host_fetch(self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(),

@@ -150,6 +150,12 @@ typedef struct vln_shadow_job {
   int N, K, out_type, pad_;
 } vln_shadow_job;
 int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
+/* The three launches at the top of a training iteration -- vln_host_fetch (skipped when slots_dev is NULL), vln_tick (n_ticks items)
+ * and vln_shadow_refresh (n_jobs <= VLN_SHADOW_MAX_JOBS jobs: the weight shadows of every module whose parameters the last optimizer
+ * step changed) -- as ONE launch: none depends on another (the pull is PCIe-bound, the refresh HBM-bound).  Same results as the
+ * three calls. */
+int vln_prologue(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes,
+                 const vln_tick_item* ticks, int n_ticks, const vln_shadow_job* jobs, int n_jobs, vln_stream_t s);
 
 /* out_t[b,:] = sum_s w_t[b,s] ctx_t[b,s,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, w_t [B,S_t], out_t rows of
  * leading dimension ldo): the d(query) of the candidate logits of a whole rollout (policy.py:199-206 backward). */

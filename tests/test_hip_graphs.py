@@ -16,7 +16,8 @@ def vln():
     return vln_amd
 
 
-def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True):
+def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True,
+         prologue=True):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -27,6 +28,7 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmen
     ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
     ag.use_live(live)
     ag.dec.chain_steps = chain
+    ag.use_prologue = prologue
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
     ag.rollout_gather = ag.gather_branch = branch == "branch"
@@ -90,6 +92,20 @@ def test_chained_decoder_steps_equal_unchained_steps(vln, dtype, graph):
     for i, (a, b) in enumerate(zip(ref, got)):
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between chained and unchained decoder steps"
+
+
+@pytest.mark.parametrize("source", ["device", "pull"])
+@pytest.mark.parametrize("graph", [True, False])
+def test_prologue_launch_equals_separate_launches(vln, graph, source):
+    """runtime.DeviceClock.prologue / vln_prologue: the batch pull, the device clock's tick and both modules' weight-shadow refresh
+    as ONE launch at the top of the iteration (block ranges of one kernel) against the same work as separate launches -- the
+    shadows follow every optimizer step, the offsets every tick, the batches the slot ring: bit-identical over six iterations."""
+    ref, w0, h0 = _run(vln, torch.bfloat16, graph, "ride", source=source, prologue=False)
+    got, w1, h1 = _run(vln, torch.bfloat16, graph, "ride", source=source, prologue=True)
+    assert w0 == w1 == h0 == h1
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between the prologue launch and separate launches"
 
 
 @pytest.mark.parametrize("graph", [True, False])
