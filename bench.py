@@ -683,6 +683,8 @@ def main():
                          "loader hands over); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
                          "device memory, one device-to-device copy (round 3's form)")
     ap.add_argument("--no-prologue", action="store_true", help="(A/B) the batch pull, the clock tick and the shadow refreshes as separate launches")
+    ap.add_argument("--no-ride-wgrads", action="store_true", help="(A/B) the decoder's weight / bias gradients as their own launches in front of "
+                    "the encoder's BPTT instead of passengers of its launch (ops.GradRide); N > 1 and --dp-path never ride")
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
@@ -765,6 +767,8 @@ def main():
     # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
     # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
     agent.segmented = bool(use_graph and (world > 1 or args.dp_path))
+    # one GPU: the decoder's parameter gradients ride in the encoder's BPTT launch (a data-parallel rank wants them final before it)
+    agent.dec.ride_wgrads = bool(world == 1 and not args.dp_path and not args.no_ride_wgrads and args.dtype != "fp32")
     if agent.segmented:
         agent.dec.grads_ready_hook = None                        # the early slice goes out between segments A and B instead
     if use_graph and (args.features != "store" or args.ce != "rollout"):
@@ -1047,7 +1051,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "prologue_launch": bool(agent.use_prologue and use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

@@ -204,6 +204,9 @@ SIGNATURES = {
     "vln_wgrad_grouped": (i32, [ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum_grouped": (i32, [ptr, i32, i32, ptr, i64, ptr]),
+    "vln_wgrad_ride_post": (i32, [ptr, i32, ptr, i32, i32, i32, ptr, i64, ptr]),
+    "vln_wgrad_ride_flush": (i32, [ptr]),
+    "vln_wgrad_ride_stats": (i32, [C.POINTER(i64)]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_attn_dot": (i32, [ptr, i32, ptr, i64, ptr, i32, i32, i32, ptr]),
@@ -296,7 +299,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 13
+EXPECTED_ABI = 14
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

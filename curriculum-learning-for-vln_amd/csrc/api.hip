@@ -34,7 +34,7 @@ const unsigned long long*& drop_base_tls() {
   static thread_local const unsigned long long* base = nullptr;
   return base;
 }
-int g_tunable[8] = {384, 1, 1, 512, 0, 0, 0, 0};
+int g_tunable[12] = {384, 1, 1, 512, 0, 0, 0, 0, 1, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {
@@ -88,7 +88,7 @@ extern "C" int vln_graph_stats(int64_t out[3]) {
   return VLN_OK;
 }
 extern "C" int vln_set_tunable(int id, int value) {
-  if (id < 0 || id >= 8) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
+  if (id < 0 || id >= 12) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
   g_tunable[id] = value;
   return VLN_OK;
 }
@@ -118,7 +118,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 13; }
+extern "C" int vln_abi_version(void) { return 14; }
 extern "C" int64_t vln_struct_size(const char* name) {
   if (!name) return -1;
 #define VLN_SZ(T) if (std::strcmp(name, #T) == 0) return (int64_t)sizeof(T)

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs a) {
   }
 }
 
+#include "wgrad_ride.h"
 #include "encoder_persist.h"
 #include "encoder_persist_g.h"
 
@@ -758,17 +759,40 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
   return VLN_OK;
 }
 
+static int ride_passengers(int nrec);
+static constexpr unsigned kRideLdsClaim = 96u * 1024u;
 template <typename TW>
-static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid) {
+static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid,
+                              const WgradRideArgs* ride) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
-  const dim3 g1(grid.x * grid.y * grid.z);
+  dim3 g1(grid.x * grid.y * grid.z);
+  const int nrec = (int)g1.x;
   const int xm = g_tunable[7] != 1;
+  static const WgradRideArgs no_ride{};
+  unsigned lds_claim = 0;
+  if (ride) {
+    // passengers on the CUs the recurrence leaves idle; the dynamic-LDS claim keeps the launch at ONE workgroup per CU (the
+    // passengers' barrier needs all of them resident, and they must not share a CU with the latency-bound recurrence)
+    // HALF as many passengers as recurrence workgroups by default: their traffic slows the recurrence's hand-offs, and the ride only
+    // has to finish inside the launch (B = 64: 128 passengers 1.680 ms, 96 1.667, 48-80 1.665, 32 1.705 -- the ride outlasts the
+    // BPTT --, own launches 1.698; profiles/round4_notes.md).  tunable[11] >= 8 sets the cap (A/B).
+    int np = ride_passengers(nrec) & ~7;
+    const int cap = g_tunable[11] >= 8 ? (g_tunable[11] & ~7) : (nrec / 2 > 8 ? (nrec / 2) & ~7 : 8);
+    if (np > cap) np = cap;
+    if (np <= 0 || (nrec & 7)) { set_error("persistent lstm bwd: a gradient ride was handed to a launch with no room for passengers"); return VLN_ERR_ARG; }
+    g1.x += (unsigned)np; lds_claim = kRideLdsClaim;
+  }
+  const WgradRideArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_BWD(NT_)                                                                                              \
   {                                                                                                                       \
     static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_>);                                    \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
-    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), 0, st, a, counters, status, sticky, exch, xm);           \
+    if (lds_claim) {                                                                                                      \
+      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<TW, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
+      if (!ok) { (void)hipGetLastError(); set_error("persistent lstm bwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
+    }                                                                                                                     \
+    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), lds_claim, st, a, counters, status, sticky, exch, xm, nrec, rd); \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -828,7 +852,6 @@ static int persist_tag_base(hipStream_t st, void* sync_ws, long gran_off, long g
 // Passenger workgroups a recurrence launch of `nrec` workgroups can carry: the CUs it leaves idle (at most as many as it has
 // workgroups itself), and only on a device whose workgroups may claim kRideLdsClaim bytes of dynamic LDS (the claim keeps the
 // launch at one workgroup per CU).  0 = the gather must be its own launch: the CALLER decides before it commits to passengers.
-static constexpr unsigned kRideLdsClaim = 96u * 1024u;
 static int ride_passengers(int nrec) {
   static const int max_lds = [] {
     int dev = 0, v = 0;
@@ -970,6 +993,62 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
   });
 }
 
+// ---- gradient rides (wgrad_ride.h) ------------------------------------------------------------------------------------
+// vln_wgrad_ride_post leaves a module's grouped weight / bias gradient jobs PENDING on a stream; the next vln_lstm_seq_bwd on
+// that stream carries them as passengers of its persistent launch when it can (counter-protocol kernel, idle CUs, jobs the
+// packed kernels take without a reduce launch) and otherwise issues them as their own launches first; vln_wgrad_ride_flush
+// issues whatever is still pending (no backward recurrence followed).  Either way the gradients are final when the stream
+// reaches the end of that call.
+struct PendingRide {
+  vln_wgrad_job w[kRideWgradJobs]; vln_colsum_job c[kRideColsumJobs];
+  int nw = 0, nc = 0, rows = 0, precision = 0; float* ws = nullptr; long ws_floats = 0;
+};
+static std::mutex g_ride_mu;
+static std::unordered_map<hipStream_t, PendingRide> g_rides;
+static int64_t g_ride_stats[2] = {0, 0};       // rides carried as passengers, rides issued as their own launches
+static bool ride_take(hipStream_t st, PendingRide* out) {
+  std::lock_guard<std::mutex> lock(g_ride_mu);
+  auto it = g_rides.find(st);
+  if (it == g_rides.end()) return false;
+  *out = it->second;
+  g_rides.erase(it);
+  return true;
+}
+static int ride_issue_alone(hipStream_t st, const PendingRide& r) {
+  int rc = wgrad_grouped(st, r.w, r.nw, r.rows, r.precision, r.ws, r.ws_floats);
+  if (rc) return rc;
+  if (r.nc) rc = colsum_grouped(st, r.c, r.nc, r.rows, r.ws, r.ws_floats);
+  { std::lock_guard<std::mutex> lock(g_ride_mu); g_ride_stats[1]++; }
+  return rc;
+}
+extern "C" int vln_wgrad_ride_flush(vln_stream_t s) {
+  PendingRide r;
+  if (!ride_take((hipStream_t)s, &r)) return VLN_OK;
+  return ride_issue_alone((hipStream_t)s, r);
+}
+extern "C" int vln_wgrad_ride_post(const vln_wgrad_job* jobs, int n_jobs, const vln_colsum_job* cjobs, int n_cjobs, int rows, int precision,
+                                   float* ws, int64_t ws_floats, vln_stream_t s) {
+  if (!jobs || n_jobs <= 0 || n_jobs > kRideWgradJobs || n_cjobs < 0 || n_cjobs > kRideColsumJobs || (n_cjobs && !cjobs) || rows <= 0 ||
+      precision < 0 || precision > 2) {
+    set_error("vln_wgrad_ride_post: bad args (at most %d products and %d column sums)", kRideWgradJobs, kRideColsumJobs); return VLN_ERR_ARG;
+  }
+  int rc = vln_wgrad_ride_flush(s);          // one pending ride per stream: an older one goes out now
+  if (rc) return rc;
+  PendingRide r;
+  for (int i = 0; i < n_jobs; ++i) r.w[i] = jobs[i];
+  for (int i = 0; i < n_cjobs; ++i) r.c[i] = cjobs[i];
+  r.nw = n_jobs; r.nc = n_cjobs; r.rows = rows; r.precision = precision; r.ws = ws; r.ws_floats = (long)ws_floats;
+  std::lock_guard<std::mutex> lock(g_ride_mu);
+  g_rides[(hipStream_t)s] = r;
+  return VLN_OK;
+}
+extern "C" int vln_wgrad_ride_stats(int64_t out[2]) {
+  if (!out) { set_error("vln_wgrad_ride_stats: null pointer"); return VLN_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(g_ride_mu);
+  out[0] = g_ride_stats[0]; out[1] = g_ride_stats[1];
+  return VLN_OK;
+}
+
 static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                               const float* act, const float* tanh_c, const float* cprev, float* dgates, float* dh_pass,
                               float* dc_carry, int B, int L, int Hd, int dirs, const float* dh_bm, const float* dc_bm) {
@@ -998,10 +1077,29 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2 || ((dh_init_bm == nullptr) != (dc_init_bm == nullptr))) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
   const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
+  PendingRide pend;
+  bool have_ride = ride_take((hipStream_t)s, &pend);
   if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
+    // a pending gradient ride: passengers of the counter-protocol launch when it has idle CUs and the jobs need no reduce
+    // launch, else its own launches in front of the recurrence
+    WgradRideArgs ride_args{};
+    const WgradRideArgs* riders = nullptr;
+    if (have_ride) {
+      const int nrec = (Hd / 16) * dirs * ((B + 15) / 16);
+      if (!bwd_granules() && g_tunable[10] != 1 && (nrec & 7) == 0 && (ride_passengers(nrec) & ~7) > 0 &&       // tunable[10] = 1: never as passengers (A/B)
+          wgrad_ride_prepare(pend.w, pend.nw, pend.rows, pend.precision, pend.c, pend.nc, pend.ws, pend.ws_floats, &ride_args)) {
+        ride_args.bar = reinterpret_cast<unsigned*>(sync_ws) + kRideBarWord;
+        riders = &ride_args;
+        std::lock_guard<std::mutex> lock(g_ride_mu);
+        g_ride_stats[0]++;
+      } else {
+        r = ride_issue_alone(st, pend); if (r) return r;
+      }
+      have_ride = false;
+    }
     // The counter-protocol backward kernel resets its group counters itself and clears its status word; the header only
     // needs a fill when another kernel left counters behind (the counter-protocol FORWARD of mode 2) or in the flag variant.
     // The self-reset only holds for a header this protocol left behind itself: a first launch on a buffer, or one after a mode
@@ -1028,12 +1126,13 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
         r = (wtype == VLN_BF16) ? launch_persist_g_bwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq)
                                 : launch_persist_g_bwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq);
       else
-        r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid)
-                                : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid);
+        r = (wtype == VLN_BF16) ? launch_persist_bwd<bf16_raw>(st, a, cw + 64, cw + 32, exch, grid, riders)
+                                : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid, riders);
     }
     header_mark(sync_ws, r == VLN_OK && self_cleaning);
     return r;
   }
+  if (have_ride) { int rr = ride_issue_alone((hipStream_t)s, pend); if (rr) return rr; }
   struct { const void* p[11]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_bm, dc_bm},
                                                  {wtype, B, L, Hd, dirs}};
   static GraphCache cache;

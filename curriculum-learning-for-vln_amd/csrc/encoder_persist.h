@@ -37,6 +37,7 @@
 //                     of the line (lane p = producer p) until every word reached it.  ~4 % slower (289 vs 278 us).
 // Epochs count steps from 1; the header is zeroed before every launch.
 constexpr int kSyncHeaderBytes = 8192;    // status word at byte 128, flag lines (32 groups x 128 B) from byte 256
+constexpr int kRideBarWord = 1536;        // ... and (byte 6144) the two words of the gradient ride's passenger barrier (wgrad_ride.h)
 #ifndef VLN_SYNC_FLAGS
 #define VLN_SYNC_FLAGS 0
 #endif
@@ -329,8 +330,14 @@ __host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int d
 }
 
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
-__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map) {
+__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map,
+                                                               int nrec, WgradRideArgs ride) {
   constexpr int HD = NT * 64;
+  if ((int)blockIdx.x >= nrec) {     // passengers (wgrad_ride.h): another module's parameter gradients on the CUs the recurrence leaves idle
+    __shared__ float4 ride_part[64][4];
+    wgrad_ride_passenger(ride, (int)blockIdx.x - nrec, (int)gridDim.x - nrec, status, sticky, ride_part);
+    return;
+  }
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
   constexpr int NSK = 64 / BK;                 // K-steps over this workgroup's 64 gate columns
   constexpr int NJB = HD / 16;                 // producers per dependency group

@@ -26,7 +26,20 @@ namespace vln {
 template <typename TW, int PD, bool kFast, int NT = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kF32)];
-  const VBlock vb{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, smem};
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {
+    // Products with MANY row tiles (the encoder's two M = B * L products): the column tiles of one row tile read the same
+    // [64, K] block of X.  Workgroups are dealt to the 8 XCDs round-robin in launch order, so in grid order those column tiles
+    // sit on different XCDs and each L2 fetches the block for itself (d-embedding product: 175 MB of fabric traffic against
+    // 48 MB algorithmic, profiles/round4_gemm_nt_by_shape.txt).  XCD x takes the contiguous range of tiles [x, x + 1) * T / 8
+    // instead: the sharers of a block run together behind ONE L2.  (The host sets the flag only when T % 8 == 0.)
+    const int L = bx + (int)gridDim.x * (by + (int)gridDim.y * bz), per = (int)(gridDim.x * gridDim.y * gridDim.z) >> 3;
+    const int t = (L & 7) * per + (L >> 3);
+    bx = t % (int)gridDim.x;
+    const int r = t / (int)gridDim.x;
+    by = r % (int)gridDim.y; bz = r / (int)gridDim.y;
+  }
+  const VBlock vb{bx, by, bz, (int)threadIdx.x, smem};
   gemm_nt_body<TW, PD, kFast, NT>(a, vb, true, gemm_nt_nsteps(a, vb.by, GemmCfg<TW>::BK), [] {});
 }
 
@@ -129,6 +142,7 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   if (to_slabs) { a.Y = ws; a.ldy = N; a.slab_stride = (long)M * N; }
   else { a.Y = Y; a.ldy = ldy; a.slab_stride = 0; }
   dim3 grid(nb, nsplit, mb), block(256);
+  a.xcd = (mb >= 8 && nb > 1 && ((long)nb * nsplit * mb) % 8 == 0 && g_tunable[8] != 0) ? 1 : 0;
   {
     // algorithmic bytes: the weight stream once + activations in + result out
     const double bytes = (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N;
@@ -516,165 +530,12 @@ int gemm_tn(hipStream_t st, const float* A, long lda, const float* X, long ldx, 
 //           registers the MFMA reads -- no LDS, no barrier, no conversion; waves run independently with the next
 //           step's 16 loads in flight behind the current step's 48 MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-struct PackJob { const float* src; long ld; int C; long dst; long seg_stride; };       // dst: byte offset of the hi plane in the pack area
-// SEGMENTED rows (rollout-level weight gradients of per-step C calls): row m of an operand lives at
-// src + (m / seg_rows) * seg_stride + (m % seg_rows) * ld -- step t's [seg_rows, C] block sits seg_stride floats after step
-// t-1's (the steps' saved-activation / scratch blocks are slots of one arena).  seg_rows == 0: plain rows, m * ld.
-struct PackJobs {
-  PackJob j[2 * VLN_WGRAD_MAX_JOBS];
-  int blk0[2 * VLN_WGRAD_MAX_JOBS + 1];
-  unsigned char* area; int n, Mt, MS;
-  int lo;                 // 1: hi + lo planes (split-bf16 contraction); 0: hi plane only (plain bf16 operands)
-  int seg_rows;
-};
-__device__ __forceinline__ long pack_plane_bytes(int C, int MS) { return (long)((C + 15) / 16) * MS * 1024; }
-__global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) {
-  int ji = 0;
-  while (ji + 1 < a.n && (int)blockIdx.x >= a.blk0[ji + 1]) ++ji;
-  const PackJob q = a.j[ji];
-  const int blk = (int)blockIdx.x - a.blk0[ji];
-  const int ncb = (q.C + 127) / 128;
-  const int cb = blk % ncb, rb = blk / ncb;                       // 128 columns x 64 rows per workgroup
-  const int half = threadIdx.x >> 7, t = threadIdx.x & 127, cg = t & 31, mq = t >> 5;
-  const int ms = rb * 2 + half;
-  if (ms >= a.MS) return;
-  const int col = cb * 128 + cg * 4;
-  if (col >= ((q.C + 15) & ~15)) return;                          // beyond the last (zero-padded) column tile
-  const bool col_ok = col < q.C;                                  // C % 4 == 0
-  const float* pc = q.src + (col_ok ? col : 0);
-  float4 r[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = ms * 32 + mq * 8 + i;
-    const int mc = min(m, a.Mt - 1);
-    const long roff = a.seg_rows ? (long)(mc / a.seg_rows) * q.seg_stride + (long)(mc % a.seg_rows) * q.ld : (long)mc * q.ld;
-    const float4 v = *reinterpret_cast<const float4*>(pc + roff);
-    const bool ok = col_ok && m < a.Mt;
-    r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-  }
-  unsigned char* hi = a.area + q.dst;
-  unsigned char* lo = hi + pack_plane_bytes(q.C, a.MS);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    bf16x8 h, l;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float v = (c == 0) ? r[i].x : (c == 1) ? r[i].y : (c == 2) ? r[i].z : r[i].w;
-      h[i] = (__bf16)v;
-      l[i] = (__bf16)(v - (float)h[i]);
-    }
-    const int column = col + c;
-    const long off = (((long)(column >> 4) * a.MS + ms) * 64 + (mq * 16 + (column & 15))) * 16;
-    *reinterpret_cast<bf16x8*>(hi + off) = h;
-    if (a.lo) *reinterpret_cast<bf16x8*>(lo + off) = l;
-  }
-}
-
-#ifndef VLN_WGRAD_PACKED_BUFS
-#define VLN_WGRAD_PACKED_BUFS 2
-#endif
-struct PackedJobs {
-  vln_wgrad_job j[VLN_WGRAD_MAX_JOBS];
-  long pa[VLN_WGRAD_MAX_JOBS], px[VLN_WGRAD_MAX_JOBS];   // byte offsets of the packed dy / x operands (hi plane)
-  int tile0[VLN_WGRAD_MAX_JOBS + 1];
-  long slab0[VLN_WGRAD_MAX_JOBS];
-  unsigned char* area; float* ws;
-  int n, Mt, MS, msplit, schunk, ntiles, per_xcd;          // schunk: row steps per split
-};
-// TERMS = 3: D = Ah Xh + Ah Xl + Al Xh (split bf16: fp32-grade products, error 2^-16); TERMS = 1: D = Ah Xh (plain bf16 operands,
-// fp32 accumulation: what mixed-precision training computes; a third of the MFMAs, half the fragment loads)
+#include "wgrad_ride.h"
+using PackJobs = PackJobsT<VLN_WGRAD_MAX_JOBS>;
+using PackedJobs = PackedJobsT<VLN_WGRAD_MAX_JOBS>;
+__global__ __launch_bounds__(256) void wgrad_pack_kernel(PackJobs a) { wgrad_pack_block(a, (int)blockIdx.x); }
 template <int TERMS>
-__global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) {
-  const int lt = ((int)blockIdx.x & 7) * a.per_xcd + ((int)blockIdx.x >> 3);       // XCD-aware tile order
-  if (((int)blockIdx.x >> 3) >= a.per_xcd || lt >= a.ntiles) return;
-  int ji = 0;
-  while (ji + 1 < a.n && lt >= a.tile0[ji + 1]) ++ji;
-  const vln_wgrad_job& q = a.j[ji];
-  const int tile = lt - a.tile0[ji];
-  const int nbk = (q.K + 127) / 128;
-  const int n0 = (tile / nbk) * 128, k0 = (tile % nbk) * 128;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fi = lane & 15, fq = lane >> 4;
-  const int wn = n0 + (wave >> 1) * 64, wk = k0 + (wave & 1) * 64;
-  const int s_beg = (int)blockIdx.y * a.schunk, s_end = min(a.MS, s_beg + a.schunk);
-  const int nct = (q.N + 15) / 16, kct = (q.K + 15) / 16;
-  const unsigned char* Ah = a.area + a.pa[ji];
-  const unsigned char* Al = Ah + pack_plane_bytes(q.N, a.MS);
-  const unsigned char* Xh = a.area + a.px[ji];
-  const unsigned char* Xl = Xh + pack_plane_bytes(q.K, a.MS);
-  long oa[4], ox[4];                       // per-fragment base offsets (column tiles past the edge are clamped: their
-#pragma unroll                             // products land in rows / columns the epilogue does not write)
-  for (int i = 0; i < 4; ++i) {
-    oa[i] = ((long)min(wn / 16 + i, nct - 1) * a.MS * 64 + lane) * 16;
-    ox[i] = ((long)min(wk / 16 + i, kct - 1) * a.MS * 64 + lane) * 16;
-  }
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NB = VLN_WGRAD_PACKED_BUFS;      // 2: next step's fragments load behind this step's MFMAs (256 VGPRs, one
-                                                 // workgroup per CU); 1: half the registers, co-resident workgroups overlap instead
-  bf16x8 ah[NB][4], al[NB][4], xh[NB][4], xl[NB][4];
-  auto load = [&](int buf, int ms) {
-    const long so = (long)ms * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[buf][i] = *reinterpret_cast<const bf16x8*>(Ah + oa[i] + so);
-      xh[buf][i] = *reinterpret_cast<const bf16x8*>(Xh + ox[i] + so);
-      if constexpr (TERMS == 3) {
-        al[buf][i] = *reinterpret_cast<const bf16x8*>(Al + oa[i] + so);
-        xl[buf][i] = *reinterpret_cast<const bf16x8*>(Xl + ox[i] + so);
-      }
-    }
-  };
-  auto mma = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (TERMS == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xl[buf][j], acc[i][j], 0, 0, 0);
-        }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[buf][i], xh[buf][j], acc[i][j], 0, 0, 0);
-      }
-  };
-  if constexpr (NB == 2) {
-    if (s_beg < s_end) load(0, s_beg);
-    for (int ms = s_beg; ms < s_end; ms += 2) {
-      if (ms + 1 < s_end) load(NB - 1, ms + 1);
-      mma(0);
-      if (ms + 1 < s_end) {
-        if (ms + 2 < s_end) load(0, ms + 2);
-        mma(NB - 1);
-      }
-    }
-  } else {
-    for (int ms = s_beg; ms < s_end; ++ms) { load(0, ms); mma(0); }
-  }
-  float* D = q.dw; long ldd = q.ld_dw; int accumulate = q.accumulate;
-  if (a.msplit > 1) { D = a.ws + a.slab0[ji] + (long)blockIdx.y * q.N * q.K; ldd = q.K; accumulate = 0; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float old[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kcol = min(wk + j * 16 + fi, q.K - 1), nrow = min(wn + i * 16 + fq * 4 + r, q.N - 1);
-        old[j][r] = accumulate ? D[(long)nrow * ldd + kcol] : 0.f;
-      }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kcol = wk + j * 16 + fi;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nrow = wn + i * 16 + fq * 4 + r;
-        if (nrow < q.N && kcol < q.K) D[(long)nrow * ldd + kcol] = acc[i][j][r] + old[j][r];
-      }
-    }
-  }
-}
+__global__ __launch_bounds__(256) void wgrad_packed_kernel(PackedJobs a) { wgrad_packed_tile<TERMS>(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // bytes of workspace the packed path wants for these jobs (pack area + row-split slabs)
 static long wgrad_packed_ws_floats(const vln_wgrad_job* jobs, int n, int Mt, int* msplit_out, long* area_floats_out) {
@@ -693,13 +554,16 @@ static long wgrad_packed_ws_floats(const vln_wgrad_job* jobs, int n, int Mt, int
   return area / 4 + (msplit > 1 ? (long)msplit * elems : 0);
 }
 
-static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms,
-                                int seg_rows = 0, const int64_t* dy_seg = nullptr, const int64_t* x_seg = nullptr) {
+// Job tables of the packed form (pack launch + contraction launch) for `n` products over Mt rows; returns false when the
+// workspace does not hold them.  NJ = capacity of the tables (the library-wide one, or a ride's).
+template <int NJ>
+static bool wgrad_packed_tables(const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms, int seg_rows,
+                                const int64_t* dy_seg, const int64_t* x_seg, PackJobsT<NJ>& pk, PackedJobsT<NJ>& g, int* pack_blocks,
+                                double* bytes_out) {
   const int MS = (Mt + 31) / 32;
   int msplit = 1; long area_floats = 0;
   const long need = wgrad_packed_ws_floats(jobs, n, Mt, &msplit, &area_floats);
-  if (need > ws_floats || !aligned16(ws)) return -1;                 // caller falls back to the LDS-staged kernel
-  PackJobs pk; PackedJobs g;
+  if (n > NJ || need > ws_floats || !aligned16(ws)) return false;
   pk.area = reinterpret_cast<unsigned char*>(ws); pk.Mt = Mt; pk.MS = MS; pk.n = 0; pk.lo = terms == 3 ? 1 : 0; pk.seg_rows = seg_rows;
   g.area = pk.area; g.ws = ws + area_floats; g.Mt = Mt; g.MS = MS; g.n = n;
   long off = 0; int blk = 0, t = 0; long slab = 0;
@@ -729,6 +593,17 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
   g.tile0[n] = t; g.ntiles = t; g.per_xcd = (t + 7) / 8;
   g.schunk = (MS + msplit - 1) / msplit;
   g.msplit = (MS + g.schunk - 1) / g.schunk;
+  *pack_blocks = blk;
+  if (bytes_out) *bytes_out = bytes;
+  return true;
+}
+
+static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms,
+                                int seg_rows = 0, const int64_t* dy_seg = nullptr, const int64_t* x_seg = nullptr) {
+  PackJobs pk; PackedJobs g;
+  int blk = 0; double bytes = 0.0;
+  if (!wgrad_packed_tables<VLN_WGRAD_MAX_JOBS>(jobs, n, Mt, ws, ws_floats, terms, seg_rows, dy_seg, x_seg, pk, g, &blk, &bytes))
+    return -1;                                                        // caller falls back to the LDS-staged kernel
   VLN_LAUNCH(wgrad_pack_kernel, dim3(blk), dim3(256), 0, st, pk);
   if (terms == 3) launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<3>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
   else launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<1>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
@@ -952,54 +827,10 @@ int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int c
 // job: out1[c] (and out2[c]: the LSTM's b_ih and b_hh receive the same sum) (+)= sum_r A[r*lda + c] over the SAME
 // `rows` for all jobs.  A workgroup owns 16 columns (4 float4 groups) x 64 row lanes and a row chunk; with one chunk
 // the sums go straight to the outputs, else partials go to ws and one second launch finishes every job.
-struct ColsumJobs {
-  vln_colsum_job j[VLN_COLSUM_MAX_JOBS];
-  int blk0[VLN_COLSUM_MAX_JOBS + 1];
-  int col0[VLN_COLSUM_MAX_JOBS + 1];      // first column of the job in the partial buffer
-  float* ws; int n, rows, rsplit, rchunk, total_cols;
-  int seg_rows; long seg_stride[VLN_COLSUM_MAX_JOBS];      // segmented rows as in PackJobs (seg_rows == 0: plain)
-};
+using ColsumJobs = ColsumJobsT<VLN_COLSUM_MAX_JOBS>;
 __global__ __launch_bounds__(256) void colsum_grouped_kernel(ColsumJobs a) {
   __shared__ float4 part[64][4];
-  int ji = 0;
-  while (ji + 1 < a.n && (int)blockIdx.x >= a.blk0[ji + 1]) ++ji;
-  const vln_colsum_job& q = a.j[ji];
-  const int cb = (int)blockIdx.x - a.blk0[ji];
-  const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c = cb * 16 + cg * 4;
-  const int rbeg = (int)blockIdx.y * a.rchunk, rend = min(a.rows, rbeg + a.rchunk);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  if (c < q.cols) {                                   // cols % 4 == 0
-    const float* p = q.A + c;
-    const long sst = a.seg_stride[ji];
-    auto roff = [&](int r) { return a.seg_rows ? (long)(r / a.seg_rows) * sst + (long)(r % a.seg_rows) * q.lda : (long)r * q.lda; };
-    int r = rbeg + rl;
-    for (; r + 64 < rend; r += 128) {
-      const float4 x = *reinterpret_cast<const float4*>(p + roff(r));
-      const float4 y = *reinterpret_cast<const float4*>(p + roff(r + 64));
-      s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
-      s1.x += y.x; s1.y += y.y; s1.z += y.z; s1.w += y.w;
-    }
-    if (r < rend) {
-      const float4 x = *reinterpret_cast<const float4*>(p + roff(r));
-      s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
-    }
-  }
-  part[rl][cg] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int g = threadIdx.x >> 2, e = threadIdx.x & 3, cc = cb * 16 + threadIdx.x;
-    if (cc < q.cols) {
-      float t = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 64; ++k) t += reinterpret_cast<const float*>(&part[k][g])[e];
-      if (a.rsplit > 1) a.ws[(long)blockIdx.y * a.total_cols + a.col0[ji] + cc] = t;
-      else {
-        if (q.out1) q.out1[cc] = q.accumulate ? q.out1[cc] + t : t;
-        if (q.out2) q.out2[cc] = q.accumulate ? q.out2[cc] + t : t;
-      }
-    }
-  }
+  colsum_grouped_block(a, (int)blockIdx.x, (int)blockIdx.y, part);
 }
 __global__ __launch_bounds__(256) void colsum_grouped_finish_kernel(ColsumJobs a) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.total_cols; i += gridDim.x * blockDim.x) {
@@ -1013,10 +844,10 @@ __global__ __launch_bounds__(256) void colsum_grouped_finish_kernel(ColsumJobs a
     if (q.out2) q.out2[cc] = q.accumulate ? q.out2[cc] + t : t;
   }
 }
-int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows,
-                   const int64_t* seg_stride) {
-  if (n <= 0 || n > VLN_COLSUM_MAX_JOBS || rows <= 0) { set_error("colsum_grouped: bad args (n = %d)", n); return VLN_ERR_ARG; }
-  ColsumJobs a;
+template <int NJ>
+static int colsum_tables(const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows, const int64_t* seg_stride,
+                         ColsumJobsT<NJ>& a, int* blocks) {
+  if (n <= 0 || n > NJ || rows <= 0) { set_error("colsum_grouped: bad args (n = %d)", n); return VLN_ERR_ARG; }
   a.n = n; a.rows = rows; a.ws = ws; a.seg_rows = seg_stride ? seg_rows : 0;
   for (int i = 0; i < n; ++i) a.seg_stride[i] = seg_stride ? (long)seg_stride[i] : 0;
   int blk = 0, col = 0;
@@ -1039,10 +870,46 @@ int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, 
   }
   a.rchunk = ((rows + rsplit - 1) / rsplit + 63) / 64 * 64;
   a.rsplit = (rows + a.rchunk - 1) / a.rchunk;
+  *blocks = blk;
+  return VLN_OK;
+}
+int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows,
+                   const int64_t* seg_stride) {
+  ColsumJobs a;
+  int blk = 0;
+  const int r = colsum_tables<VLN_COLSUM_MAX_JOBS>(jobs, n, rows, ws, ws_floats, seg_rows, seg_stride, a, &blk);
+  if (r) return r;
   VLN_LAUNCH(colsum_grouped_kernel, dim3(blk, a.rsplit), dim3(256), 0, st, a);
-  if (a.rsplit > 1) VLN_LAUNCH(colsum_grouped_finish_kernel, dim3((col + 255) / 256), dim3(256), 0, st, a);
+  if (a.rsplit > 1) VLN_LAUNCH(colsum_grouped_finish_kernel, dim3((a.total_cols + 255) / 256), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("colsum_grouped");
   return VLN_OK;
+}
+
+// A ride (wgrad_ride.h): the same job tables, for the passenger workgroups of the backward recurrence launch.  false = these
+// jobs do not ride (exact-fp32 / unaligned operands, a row split that needs a reduce launch, too many jobs, a small workspace):
+// the caller issues them as their own launches.
+bool wgrad_ride_prepare(const vln_wgrad_job* jobs, int n, int Mt, int precision, const vln_colsum_job* cjobs, int nc, float* ws,
+                        long ws_floats, WgradRideArgs* out) {
+  if (n <= 0 || n > kRideWgradJobs || nc < 0 || nc > kRideColsumJobs || Mt <= 0 || Mt > 1024 || !ws) return false;
+  if (precision != 1 && precision != 2) return false;
+  if (g_tunable[6] == 1 || g_tunable[6] == 2) return false;
+  for (int i = 0; i < n; ++i) {
+    const vln_wgrad_job& q = jobs[i];
+    if (!(q.dy && q.x && q.dw && aligned16(q.dy) && aligned16(q.x) && (q.ld_dy % 4 == 0) && (q.ld_x % 4 == 0) && (q.N % 4 == 0) && (q.K % 4 == 0) &&
+          q.N > 0 && q.K > 0)) return false;
+  }
+  WgradRideArgs& r = *out;
+  r.terms = precision == 2 ? 1 : 3;
+  if (!wgrad_packed_tables<kRideWgradJobs>(jobs, n, Mt, ws, ws_floats, r.terms, 0, nullptr, nullptr, r.pk, r.g, &r.pack_blocks, nullptr)) return false;
+  if (r.g.msplit != 1) return false;
+  r.tiles = r.g.per_xcd * 8;
+  r.cs_blocks = 0; r.cs.n = 0;
+  if (nc > 0) {
+    if (colsum_tables<kRideColsumJobs>(cjobs, nc, Mt, nullptr, 0, 0, nullptr, r.cs, &r.cs_blocks) != VLN_OK) return false;
+    if (r.cs.rsplit != 1) return false;
+  }
+  r.on = 1;
+  return true;
 }
 
 // ---------------------------------------------------------------------------

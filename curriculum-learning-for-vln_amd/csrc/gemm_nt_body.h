@@ -16,6 +16,7 @@ struct GemmNTArgs {
   const float* bias; int act;
   int M, N, K, kchunk;
   int xvec, wvec;
+  int xcd;               // 1: the launch's workgroups take their tiles in XCD-aware order (gemm_nt_kernel; many row tiles)
 };
 
 // PD = register prefetch depth: the loads of K-steps s+1 .. s+PD are in flight while step s is multiplied.  Every

@@ -34,8 +34,11 @@ int check_hip(hipError_t e, const char* what);
 //   [5] gemm_nt: 0 fast form with depth-2 prefetch, 1 same, 2 bounds-checked form, 4 depth-4 prefetch
 //   [6] weight gradients of precision 1: 0 packed grouped form, 1 exact fp32 form, 2 LDS-staged grouped form
 //   [7] 1: persistent LSTM workgroups in dispatch order instead of one XCD per dependency group
-// The EnvDrop step's graph key includes all eight, so a changed tunable never replays a stale graph.
-extern int g_tunable[8];
+//   [8] gemm_nt launches with >= 8 row tiles (the encoder's M = B * L products): 1 XCD-aware tile order (sharers of an X block behind one L2), 0 grid order
+//   [10] 1: a pending gradient ride (vln_wgrad_ride_post) is always issued as its own launches (A/B)
+//   [11] >= 8: at most this many passenger workgroups carry a gradient ride (A/B; default: every idle CU up to the recurrence's own count)
+// The EnvDrop step's graph key includes [0..7] (the step has one row tile: [8] never applies), so a changed tunable never replays a stale graph.
+extern int g_tunable[12];
 
 // ---- device-resident dropout offsets of the struct-driven steps -----------------------------------------------------------------
 // vln_monitor_step / vln_follower_step / vln_bn_mlp carry `offset_base_dev`: while such a call issues its launches, every dropout
@@ -141,6 +144,9 @@ int colsum(hipStream_t st, const float* A, long lda, float* out, int rows, int c
            long ws_floats);
 
 // every bias gradient of a module in one launch (two when the rows are split)
+struct WgradRideArgs;              // wgrad_ride.h: a module's grouped weight / bias gradients as passengers of the backward recurrence launch
+bool wgrad_ride_prepare(const ::vln_wgrad_job* jobs, int n, int Mt, int precision, const ::vln_colsum_job* cjobs, int nc, float* ws,
+                        long ws_floats, WgradRideArgs* out);
 int colsum_grouped(hipStream_t st, const ::vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows = 0,
                    const int64_t* seg_stride = nullptr);
 

@@ -206,6 +206,11 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         self._bplans = {}                # ... and of the step backward
         self.plan_hits = 0
         self.grads_ready_hook = None     # optional callable, see _deferred_wgrads
+        # True (bf16 mode, gradients accumulated in place, one stash run): the rollout's weight / bias gradient launches are
+        # posted as a gradient ride (ops.GradRide, csrc/wgrad_ride.h) and travel as passengers of the encoder's BPTT launch instead
+        # of standing in front of it (57-69 us of the dependent chain at B = 64).  Single-GPU schedules only: a data-parallel
+        # caller wants the decoder's gradients final BEFORE the BPTT (grads_ready_hook).
+        self.ride_wgrads = False
         # Replay each decoder step (forward: 13 launches, backward: 15) as ONE hipGraph.  A graph is keyed by the step's
         # argument block, i.e. by device addresses; it only pays when the caller's tensors come back at the SAME
         # addresses every iteration.  PyTorch's caching allocator does not guarantee that (measured: every step's
@@ -418,6 +423,15 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 side = self._side_stream = torch.cuda.Stream(main.device)
             side.wait_stream(main)
             torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+        if (self.ride_wgrads and side is None and self.grads_ready_hook is None and all(acc0) and len(runs) == 1
+                and self.compute_dtype != torch.float32):
+            # every gradient lands in place and nothing reads it before backward() returns: the launches are POSTED as a gradient
+            # ride -- the encoder's BPTT launch (the next vln_lstm_seq_bwd on this stream) carries them on its idle CUs; the
+            # callback issues them if no recurrence picked them up by the end of the backward pass
+            with ops.GradRide.collect():
+                self._issue_wgrads(runs, acc0, tgt)
+            torch.autograd.Variable._execution_engine.queue_callback(ops.GradRide.flush)
+            return ret
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             self._issue_wgrads(runs, acc0, tgt)
         # Every decoder gradient is now final in its .grad (bucket view): a data-parallel caller starts their all-reduce

@@ -117,7 +117,11 @@ class SegmentedIterationGraph:
             for kind, fn in self.segments:
                 if kind == "graph":
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, stream=stream):
+                    # thread_local: a process group's watchdog thread polls the events of collectives that are still in flight
+                    # (the early slice issued right before this segment) -- under the default "global" mode such a call from
+                    # another thread is an error while ANY stream captures.  Launches from the autograd thread are captured all
+                    # the same: capturing is a property of the stream.
+                    with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
                         r = fn()
                     if r is not None:
                         self.out = r

@@ -304,6 +304,68 @@ class ShadowBatch:
         _lib.check(_lib.load().vln_shadow_refresh(arr, n, _stream()), "vln_shadow_refresh")
 
 
+class GradRide:
+    """Collects the WgradBatch / ColsumBatch launches issued inside `with GradRide.collect():` and, instead of launching them, posts
+    them as ONE gradient ride (`vln_wgrad_ride_post`): the next `vln_lstm_seq_bwd` on the stream carries them as passenger workgroups
+    of its persistent launch (csrc/wgrad_ride.h) or issues them itself; `GradRide.flush()` issues a ride nobody carried.  Batches the
+    ride cannot take (other row counts, more than 8 products / 4 column sums, exact-fp32 precision) launch as usual."""
+    MAX_W, MAX_C = 8, 4
+    _active = None
+    _posted = None
+
+    def __init__(self):
+        self.w, self.c, self.keep, self.rows, self.prec, self.dev = [], [], [], None, None, None
+
+    @classmethod
+    def collect(cls):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, cls._active = cls._active, cls()
+            try:
+                yield cls._active
+            finally:
+                ride, cls._active = cls._active, prev
+            ride.post()
+        return scope()
+
+    def take_w(self, jobs, keep, rows, prec):
+        if prec not in (1, 2) or (self.rows not in (None, rows)) or (self.prec not in (None, prec)) or len(self.w) + len(jobs) > self.MAX_W:
+            return False
+        self.w += jobs; self.keep += keep; self.rows, self.prec, self.dev = rows, prec, keep[0].device
+        return True
+
+    def take_c(self, jobs, keep, rows):
+        if not self.w or self.rows != rows or len(self.c) + len(jobs) > self.MAX_C:       # column sums only ride along with products
+            return False
+        self.c += jobs; self.keep += keep
+        return True
+
+    def post(self):
+        if not self.w:
+            return
+        MS = (self.rows + 31) // 32
+        area = sum(2 * ((j.N + 15) // 16 + (j.K + 15) // 16) * MS * 1024 for j in self.w) // 4
+        ws = workspace(self.dev, max(1 << 22, area))
+        wa = (_lib.WgradJob * len(self.w))(*self.w)
+        ca = (_lib.ColsumJob * len(self.c))(*self.c) if self.c else None
+        _lib.check(_lib.load().vln_wgrad_ride_post(wa, len(self.w), ca, len(self.c), self.rows, self.prec, _p(ws), ws.numel(), _stream()),
+                   "vln_wgrad_ride_post")
+        GradRide._posted = (ws, self.keep)           # alive until the next ride is posted (the carrying launch is long past by then)
+        self.w, self.c, self.keep = [], [], []
+
+    @staticmethod
+    def flush():
+        _lib.check(_lib.load().vln_wgrad_ride_flush(_stream()), "vln_wgrad_ride_flush")
+
+    @staticmethod
+    def stats():
+        out = (C.c_int64 * 2)()
+        _lib.check(_lib.load().vln_wgrad_ride_stats(out), "vln_wgrad_ride_stats")
+        return {"carried": int(out[0]), "issued_alone": int(out[1])}
+
+
 class ColsumBatch:
     """Bias gradients over the SAME rows as one launch (`vln_colsum_grouped`): add(a, out1, out2=None, accumulate)."""
 
@@ -325,6 +387,9 @@ class ColsumBatch:
 
     def run(self):
         lib = _lib.load()
+        if self.jobs and GradRide._active is not None and GradRide._active.take_c(self.jobs, self.keep, self.rows):
+            self.jobs, self.keep, self.rows = [], [], None
+            return
         for i in range(0, len(self.jobs), 12):
             chunk = self.jobs[i:i + 12]
             arr = (_lib.ColsumJob * len(chunk))(*chunk)
@@ -389,6 +454,9 @@ class WgradBatch:
         prec = wgrad_precision(self.split)
         if prec == 2 and self.never_plain:
             prec = 1
+        if GradRide._active is not None and GradRide._active.take_w(self.jobs, self.keep, self.Mt, prec):
+            self.jobs, self.keep, self.Mt = [], [], None
+            return
         _lib.check(_lib.load().vln_wgrad_grouped(arr, len(self.jobs), self.Mt, prec, _p(ws), ws.numel(),
                                                  _stream()), "vln_wgrad_grouped")
         self.jobs, self.keep, self.Mt = [], [], None

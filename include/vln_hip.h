@@ -37,7 +37,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2
 
-int vln_abi_version(void);     /* 13 */
+int vln_abi_version(void);     /* 14 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -66,10 +66,10 @@ typedef struct vln_tick_item { void* word; uint64_t inc; int32_t width; int32_t 
 int vln_tick(const vln_tick_item* items, int n /* 1..VLN_TICK_MAX */, vln_stream_t s);
 /* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] times a chain's capturing was paused (2 x capacity captures without one replay) */
 int vln_graph_stats(int64_t out[3]);
-/* performance / A-B tunables, ids 0..7 (never change results beyond summation order; documented in
+/* performance / A-B tunables, ids 0..11 (never change results beyond summation order; documented in
  * csrc/vln_internal.h): 0 = gemm split-K workgroup target (256), 1 = keep wide shallow fused-epilogue products unsplit,
  * 2/3 = 16-column GEMM on / its largest K, 4 = two-kernel attention, 5 = gemm_nt form, 6 = weight-gradient form,
- * 7 = persistent-LSTM workgroup order */
+ * 7 = persistent-LSTM workgroup order, 8 = XCD-aware tile order of gemm_nt launches with many row tiles (1), 9 = spare, 10 = 1: gradient rides never travel as passengers, 11 = cap on a ride's passenger workgroups */
 int vln_set_tunable(int id, int value);
 /* Measurement only: `launches` dependent launches of a trivial kernel (each reads what the one before wrote, rotated by `shift`
  * float4 elements so the bytes come from another XCD) ping-ponging between a and b [n_floats]: the price of a kernel boundary
@@ -119,6 +119,22 @@ typedef struct vln_colsum_job {
   int cols, accumulate;
 } vln_colsum_job;
 int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* ws, int64_t ws_floats, vln_stream_t s);
+/* Gradient rides (ABI v14): a module's grouped weight / bias gradients as PASSENGER workgroups of the next backward recurrence
+ * launch on the same stream.  The encoder's BPTT (vln_lstm_seq_bwd) keeps half of the chip's CUs busy with latency-bound
+ * hand-offs; the DECODER's parameter gradients depend on nothing it produces.  vln_wgrad_ride_post leaves the jobs (what
+ * vln_wgrad_grouped + vln_colsum_grouped would take: at most 8 products and 4 column sums over the same `rows`, precision as in
+ * vln_wgrad_grouped) pending on stream s; the next vln_lstm_seq_bwd on s carries them when it can -- counter-protocol
+ * persistent kernel, >= 8 idle CUs, bf16-mode precision (1 / 2), operands the packed kernels take without a reduce launch --
+ * and otherwise issues them as their own launches in front of the recurrence; vln_wgrad_ride_flush issues a still-pending ride
+ * (no recurrence followed).  Results are bit-identical to vln_wgrad_grouped + vln_colsum_grouped.  The operands, outputs and
+ * ws must stay valid and unwritten by other work until the stream has passed the carrying (or flushing) call.
+ * vln_wgrad_ride_stats: out[0] rides carried as passengers, out[1] rides issued as their own launches, since load.
+ * Replaces nothing in the reference: it is a schedule of autograd's parameter gradients (trainer.py:421-427). */
+int vln_wgrad_ride_post(const vln_wgrad_job* jobs, int n_jobs, const vln_colsum_job* cjobs /*nullable*/, int n_cjobs, int rows,
+                        int precision, float* ws, int64_t ws_floats, vln_stream_t s);
+int vln_wgrad_ride_flush(vln_stream_t s);
+int vln_wgrad_ride_stats(int64_t out[2]);
+
 /* Parameter gradients of the per-step C calls (vln_monitor_step_bwd, vln_follower_step_bwd, vln_bn_mlp_bwd) once per ROLLOUT
  * (ABI v11).  A per-step call that accumulates into p.grad reads and rewrites every weight gradient of the module per decoder
  * step (Self-Monitor: 22 pack + 22 contraction + 22 bias launches per iteration, 0.7 ms).  With `defer` set in its grads

@@ -17,7 +17,7 @@ def vln():
 
 
 def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True,
-         prologue=True):
+         prologue=True, ride=True):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -29,6 +29,7 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmen
     ag.use_live(live)
     ag.dec.chain_steps = chain
     ag.use_prologue = prologue
+    ag.dec.ride_wgrads = bool(ride and not segmented)    # as bench.py sets it for one GPU (bf16 mode only: the module checks)
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
     ag.rollout_gather = ag.gather_branch = branch == "branch"
@@ -92,6 +93,46 @@ def test_chained_decoder_steps_equal_unchained_steps(vln, dtype, graph):
     for i, (a, b) in enumerate(zip(ref, got)):
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between chained and unchained decoder steps"
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_decoder_gradient_ride_equals_its_own_launches(vln, graph):
+    """ops.GradRide / vln_wgrad_ride_post (round 4): the decoder's rollout-level weight and bias gradients (pack, packed contraction,
+    column sums) travel as passenger workgroups of the encoder's BPTT launch instead of three launches in front of it.  Same blocks,
+    same tiles, same arithmetic: losses, parameters, optimizer state and gradient norms over six iterations equal the stand-alone
+    launches' bit for bit, eager and as one captured iteration -- and the rides were really carried (vln_wgrad_ride_stats)."""
+    before = vln.ops.GradRide.stats()
+    ref, _, _ = _run(vln, torch.bfloat16, graph, "ride", ride=False)
+    mid = vln.ops.GradRide.stats()
+    assert mid == before                                             # nothing was posted with the switch off
+    got, _, _ = _run(vln, torch.bfloat16, graph, "ride", ride=True)
+    after = vln.ops.GradRide.stats()
+    assert after["carried"] - mid["carried"] >= (3 if graph else 6) and after["issued_alone"] == mid["issued_alone"]
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between the gradient ride and its own launches"
+
+
+def test_gradient_ride_without_a_carrier_is_issued_by_the_flush(vln):
+    """A posted ride that no backward recurrence picks up: vln_wgrad_ride_flush (the autograd engine's end-of-backward callback in
+    EnvDropDecoder._deferred_wgrads) issues it as its own launches -- same results as WgradBatch / ColsumBatch run directly."""
+    g = torch.Generator().manual_seed(3)
+    dy, x = torch.randn(96, 256, generator=g).to(DEV), torch.randn(96, 384, generator=g).to(DEV)
+    outs = []
+    for ride in (False, True):
+        dw, db = torch.zeros(256, 384, device=DEV), torch.zeros(256, device=DEV)
+        before = vln.ops.GradRide.stats()
+        with (vln.ops.GradRide.collect() if ride else __import__("contextlib").nullcontext()):
+            wb = vln.ops.WgradBatch(True); wb.add(dy, x, dw, True); wb.run()
+            cb = vln.ops.ColsumBatch(); cb.add(dy, db, None, True); cb.run()
+        if ride:
+            assert float(dw.abs().max()) == 0.0                       # posted, not launched
+            vln.ops.GradRide.flush()
+            assert vln.ops.GradRide.stats()["issued_alone"] == before["issued_alone"] + 1
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0
 
 
 @pytest.mark.parametrize("source", ["device", "pull"])
