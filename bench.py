@@ -1001,7 +1001,10 @@ def main():
                          ("batch128_ms_per_step", lambda: secondary_envdrop(
                              vln, dev, store, [make_tape(128, args.L, args.T, 8, seed=4040 + k, n_rows=store.N) for k in range(4)],
                              dtype, "store", args, graph=use_graph)),
+                         # BASELINE config 3's per-rank iteration as 36 graph segments, the host reading every sampled action between them
+                         # (envdrop.py:196-206); beside it the same iteration with the actions left on the device (round 3's form of the figure)
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store)),
+                         ("il_plus_a2c_T35_actions_on_device", lambda: secondary_agents(dev, args, "a2c", store, read_actions=False)),
                          # BASELINE config 2 does not ask for bf16: the Self-Monitor's figure is the fp32 one; bf16 beside it
                          ("self_monitor_B128", lambda: secondary_agents(dev, args, "monitor", store, dtype="fp32")),
                          ("self_monitor_B128_bf16", lambda: secondary_agents(dev, args, "monitor", store, dtype="bf16")),
@@ -1310,7 +1313,7 @@ def _phase_times(ag, get, steps, n_dec_steps):
                                         "decoder_bwd per step includes 1/T of the rollout loss, the logit branch and the decoder's weight gradients"}
 
 
-def secondary_agents(dev, args, which, store, dtype=None):
+def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import bench_agents as W
     # warm-up: the first iterations of a workload in a process grow the allocator's pools and load its kernels' code objects;
@@ -1322,13 +1325,17 @@ def secondary_agents(dev, args, which, store, dtype=None):
     gc.collect()
     gc.freeze()                         # the bench's own objects (agent, tapes, store) out of the cyclic collector's way, as in the timed loop
     try:
-        r = W.run_a2c(T_rl=35, store=store) if which == "a2c" else (W.run_follower() if which == "follower" else
+        r = W.run_a2c(T_rl=35, store=store, read_actions=read_actions) if which == "a2c" else (W.run_follower() if which == "follower" else
                                                                     (W.run_speaker() if which == "speaker" else W.run_monitor()))
     finally:
         W.vln.functional.set_rollout_wgrads(False)
         W.vln.functional.set_grad_in_place(False)
         gc.unfreeze()
-    return {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"], "dtype": r.get("dtype")}
+    out = {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"], "dtype": r.get("dtype")}
+    for k in ("iteration", "per_step_action_read"):       # a2c: how the iteration was issued, and that the host read every sampled action
+        if k in r:
+            out[k] = r[k]
+    return out
 
 
 if __name__ == "__main__":

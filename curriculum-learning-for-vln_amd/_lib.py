@@ -239,7 +239,7 @@ SIGNATURES = {
     "vln_add_n": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i32, ptr]),
     "vln_monitor_loss_fwd": (i32, [ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, f32, i32, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
     "vln_monitor_loss_bwd": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, f32, i32, ptr, ptr, i32, i32, i64, ptr]),
-    "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr]),
+    "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_categorical_multi_bwd": (i32, [C.POINTER(CatStep), i32, i32, ptr, ptr, ptr]),
     "vln_bn_fwd": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, f32, f32, i32, i32, u64, u64, f32, ptr, ptr, i64, ptr]),

@@ -958,7 +958,9 @@ namespace vln {
 // loads, 9.6 us per launch on a sampled rollout's critical path.)
 __global__ __launch_bounds__(256) void categorical_fwd_kernel(const float* logits, long ld, const unsigned char* mask,
                                                               const long long* action_in, long long* action_out, float* probs,
-                                                              float* logp, float* ent, int B, int C, uint64_t seed, uint64_t offset) {
+                                                              float* logp, float* ent, int B, int C, uint64_t seed, uint64_t offset,
+                                                              const uint64_t* offset_base_dev) {
+  if (offset_base_dev) offset += *offset_base_dev * 8ull;       // device clock (vln_tick): the launch arguments repeat, the draws do not
   const float eps = 1.1920928955078125e-07f;
   const int lane = threadIdx.x & 63;
   for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += gridDim.x * 4) {
@@ -1071,14 +1073,14 @@ extern "C" int vln_categorical_multi_bwd(const vln_cat_step* steps, int T, int B
 
 extern "C" int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mask, const int64_t* action_in,
                                    int64_t* action_out, float* probs, float* logp, float* entropy, int B, int C, uint64_t seed,
-                                   uint64_t offset, void* s) {
+                                   uint64_t offset, const uint64_t* offset_base_dev, void* s) {
   if (!logits || !probs || !logp || !entropy || B <= 0 || C <= 0 || (!action_in && !action_out)) {
     vln::set_error("vln_categorical_fwd: bad args");
     return VLN_ERR_ARG;
   }
   if (C > 64) { vln::set_error("vln_categorical_fwd: at most 64 candidates"); return VLN_ERR_ARG; }
   VLN_LAUNCH(vln::categorical_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, (long)ld, cand_mask,
-                     (const long long*)action_in, (long long*)action_out, probs, logp, entropy, B, C, seed, offset);
+                     (const long long*)action_in, (long long*)action_out, probs, logp, entropy, B, C, seed, offset, offset_base_dev);
   VLN_CHECK_LAUNCH("categorical_fwd");
   return VLN_OK;
 }

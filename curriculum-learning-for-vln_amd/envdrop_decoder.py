@@ -773,33 +773,40 @@ class Critic(nn.Module):
         self._calls = 0
 
     def forward(self, state):
-        self._calls += 1
         ops.check_live(state, "Critic(state)")
         p = self.drop_ratio if self.training else 0.0
         l0, l3 = self.state2value[0], self.state2value[3]
-        return _CriticFn.apply(state, l0.weight, l0.bias, l3.weight, l3.bias, p, self.dropout_seed, self._calls).squeeze()
+        clock = self.__dict__.get("clock")
+        if clock is not None:          # runtime.DeviceClock: the mask's offset is (device word + call index since the tick) * 8
+            r = clock.rel(id(self))
+            self._calls = clock.value(r) * 8         # the offset `ops.dropout_mask` reproduces the mask with (tests)
+            off = (r * 8, clock.ptr)
+        else:
+            self._calls += 1
+            off = (self._calls, None)
+        return _CriticFn.apply(state, l0.weight, l0.bias, l3.weight, l3.bias, p, self.dropout_seed, off).squeeze()
 
 
 class _CriticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w0, b0, w3, b3, p, seed, offset):
+    def forward(ctx, x, w0, b0, w3, b3, p, seed, off):
         x = x.contiguous()
         z = ops.linear_fwd(x, w0.detach(), b0.detach(), ops.ACT_RELU)
-        n = z.numel()
-        m = ops.dropout_mask(n, seed, offset, p, x.device).view_as(z) if p > 0 else None
-        zd = z * m if m is not None else z
+        # the mask is regenerated by the kernels from (seed, offset) in the backward: z * mask and dzd * mask are one launch each
+        zd = ops.scale_dropout(z, seed, off[0], p, off[1]) if p > 0 else z
         v = ops.linear_fwd(zd, w3.detach(), b3.detach())
         ctx.save_for_backward(x, w0, w3, z, zd)
-        ctx.m = m
+        ctx.drop = (seed, off, p)
         return v
 
     @staticmethod
     def backward(ctx, dv):
         x, w0, w3, z, zd = ctx.saved_tensors
+        seed, off, p = ctx.drop
         dv = dv.contiguous()
         dzd = ops.linear_fwd(dv, w3.detach().t().contiguous())            # [B,1] x [H,1]^T
-        if ctx.m is not None:
-            dzd = dzd * ctx.m
+        if p > 0:
+            dzd = ops.scale_dropout(dzd, seed, off[0], p, off[1])
         dz = dzd * (z > 0).to(dzd.dtype)
         dw3 = ops.linear_wgrad(dv, zd)
         db3 = dv.sum(0)

@@ -383,7 +383,7 @@ class _Categorical(torch.autograd.Function):
         act = action.contiguous() if action is not None else ops.empty(B, dtype=torch.int64, device=dev)
         st = _lib.load().vln_categorical_fwd(_p(lg), lg.stride(0), _p(_mask8(cand_mask)), _p(action if action is None else act),
                                              None if action is not None else act.data_ptr(), _p(probs), _p(logp), _p(ent), B, C,
-                                             seed, offset, _lib.raw_stream())
+                                             seed, offset, None, _lib.raw_stream())
         if st:
             _lib.check(st, "vln_categorical_fwd")
         ctx.save_for_backward(probs, act)
@@ -476,8 +476,11 @@ class RolloutSampler:
     steps come from one launch at the root of the backward and -- with an EnvDropDecoder -- go through the decoder's
     rollout-wide logit branch (one multi-step weighted sum, one GEMM) instead of three launches on every step's chain."""
 
-    def __init__(self, seed: int = 0x5A3B1E, capacity: int = _lib.CE_MAX_STEPS):
-        self.seed, self.cap = int(seed), int(capacity)
+    def __init__(self, seed: int = 0x5A3B1E, capacity: int = _lib.CE_MAX_STEPS, clock=None):
+        """clock (runtime.DeviceClock): the draws' Philox offsets are (clock word + call index since the last tick) * 8 instead of a
+        host counter -- the launch arguments repeat from iteration to iteration (whole-iteration / segmented hipGraphs), the draws
+        do not."""
+        self.seed, self.cap, self.clock = int(seed), int(capacity), clock
         self.logits, self.keep = [], []
         self.logp = self.ent = None
 
@@ -492,7 +495,10 @@ class RolloutSampler:
             self.ent = ops.empty(self.cap, B, dtype=torch.float32, device=dev)
         if t >= self.cap or B != self.logp.shape[1]:
             raise ValueError(f"RolloutSampler.step: more than {self.cap} steps, or the batch size changed")
-        if offset is None:
+        base = None
+        if offset is None and self.clock is not None:
+            offset, base = self.clock.rel(("RolloutSampler", self.seed)) * 8, self.clock.ptr
+        elif offset is None:
             _sample_calls[0] += 1
             offset = _sample_calls[0]
         lg = logits.detach()
@@ -502,7 +508,7 @@ class RolloutSampler:
         act = action.contiguous() if action is not None else ops.empty(B, dtype=torch.int64, device=dev)
         st = _lib.load().vln_categorical_fwd(_p(lg), lg.stride(0), _p(_mask8(cand_mask)), _p(action if action is None else act),
                                              None if action is not None else act.data_ptr(), _p(probs), self.logp[t].data_ptr(),
-                                             self.ent[t].data_ptr(), B, C, self.seed, int(offset), _lib.raw_stream())
+                                             self.ent[t].data_ptr(), B, C, self.seed, int(offset), base, _lib.raw_stream())
         if st:
             _lib.check(st, "vln_categorical_fwd")
         self.logits.append(logits); self.keep.append((probs, act))

@@ -612,6 +612,19 @@ def dropout_mask(n: int, seed: int, offset: int, p: float, device) -> torch.Tens
     return out
 
 
+def scale_dropout(x, seed: int, offset: int, p: float, base: Optional[int] = None, out=None):
+    """y = x * (pre-scaled keep mask of (seed, offset)), x [rows, cols] fp32 -- the same mask `dropout_mask(rows * cols, ...)` returns.
+    base: address of a DEVICE word; the Philox offset is then word * 8 + offset (runtime.DeviceClock)."""
+    lib = _lib.load()
+    _req(x, "x")
+    rows, cols = x.shape
+    if out is None:
+        out = empty(rows, cols, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vln_scale_dropout(_p(x), x.stride(0), _p(out), out.stride(0), rows, cols, seed, offset, p, base, _stream()),
+               "vln_scale_dropout")
+    return out
+
+
 def feat_dropout_inplace(x, img: int, angle: int, seed: int, offset: int, p: float, copy_bf16=None):
     lib = _lib.load()
     _req(x, "x", None)

@@ -318,7 +318,7 @@ int vln_monitor_loss_bwd(const float* probs, const int64_t* target, const float*
  * Backward: dlogits from the upstream gradients on logp and entropy (either may be NULL). */
 int vln_categorical_fwd(const float* logits, int64_t ld, const uint8_t* cand_mask /*nullable*/, const int64_t* action_in /*nullable*/,
                         int64_t* action_out /*nullable*/, float* probs, float* logp, float* entropy, int B, int C, uint64_t seed,
-                        uint64_t offset, vln_stream_t s);
+                        uint64_t offset, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd (ABI v14)*/, vln_stream_t s);
 int vln_categorical_bwd(const float* probs, const int64_t* action, const float* dlogp /*nullable*/, const float* dent /*nullable*/,
                         float* dlogits, int B, int C, vln_stream_t s);
 /* The backward of EVERY step of a sampled rollout in one launch (losses.RolloutSampler): dlogp / dent [T,B], row t = step t. */

@@ -208,79 +208,150 @@ def run_speaker(B=64, Lp=7, Lw=80, V=36, vocab=992):
                 dtype=args.dtype)
 
 
-def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None):
+def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actions=True, build_only=False, seed=2020):
     """EnvDrop IL (teacher-forced rollout, T_il steps) + RL (sampled rollout up to T_rl steps -- the reference caps episodes at
     MAX_EPISODE_LEN = 35, configs/envdrop/envdrop_config.yaml:31 -- A2C with the critic, envdrop.py:186-264) per optimizer step
-    (trainer.py:411-427); one RMSprop over encoder / decoder / critic, clip 40 on encoder and decoder only (:425-426)."""
+    (trainer.py:411-427); one RMSprop over encoder / decoder / critic, clip 40 on encoder and decoder only (:425-426).
+
+    read_actions: the reference's loop shape for the sampled rollout (envdrop.py:196-206): after EVERY step the sampled action goes
+    to the host (D2H into pinned memory, stream synchronize) where the simulator would take it -- here a host bookkeeping of the
+    `ended` flags stands in for env.step -- before the next step is issued.
+    graph (default: args.graph): the iteration as graphs.SegmentedIterationGraph -- [graph: prologue, the IL rollout, the RL
+    encoder, RL step 0 + draw + D2H of a_0] [host: wait, read a_0] [graph: RL step 1 ...] ... [graph: last step, critic, A2C loss,
+    the backward of BOTH rollouts, clip + RMSprop]: T_rl + 1 graph launches per iteration instead of ~250 Python-driven calls; the
+    dropout offsets and the draws' Philox offsets come from a runtime.DeviceClock."""
+    graph = args.graph if graph is None else graph
     if store is None:
-        cpu_tape = bench.make_tape(B, L, T_rl, C, 2020)
+        cpu_tape = bench.make_tape(B, L, T_rl, C, seed)
         tape = bench.tape_to(cpu_tape, dev, store_dtype=dt)
     else:
-        tape = bench.tape_to(bench.make_tape(B, L, T_rl, C, 2020, n_rows=store.N), dev, store=store)
+        tape = bench.tape_to(bench.make_tape(B, L, T_rl, C, seed, n_rows=store.N), dev, store=store)
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dt).to(dev).train()
     dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, F, compute_dtype=dt).to(dev).train()
     cri = vln.Critic(512, 0.5).to(dev).train()
     opt = vln.optim.FusedRMSprop([list(enc.parameters()), list(dec.parameters()), list(cri.parameters())], lr=1e-4,
                                  clip_norm=[40.0, 40.0, 0.0])
     store = tape["store"]
-    lp = dt != torch.float32
     g = torch.Generator().manual_seed(7)
     rewards = [torch.randn(B, generator=g).sign().to(dev) for _ in range(T_rl)]
     lens_rl = torch.randint(4, T_rl + 1, (B,), generator=g)
     lens_rl[0] = T_rl
     masks = [(t < lens_rl).to(dev) for t in range(T_rl)]
     ended = (lens_rl < T_rl).to(dev)
+    clock = vln.DeviceClock(dev).attach(enc, dec, cri) if graph else None
+    a_host = torch.zeros(T_rl, B, dtype=torch.int64).pin_memory()
+    host_ended = [0]              # what the stand-in for env.step keeps: episodes that chose STOP so far (read, never fed back)
 
     def gather_of(s):
         return (store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"])
 
-    def rollout(T, sample):
+    st = {}                       # the sampled rollout's running state between two segments
+
+    def il_rollout():
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
         ht = h
-        hidden, logps, ents = [], [], []
-        dec.defer_logits = not sample           # teacher forcing: the logits are only needed by the loss (formed once per rollout)
+        dec.defer_logits = True   # teacher forcing: the logits are only needed by the loss (formed once per rollout)
         ce = vln.losses.RolloutCE()
-        sampler = vln.losses.RolloutSampler() if (sample and not getattr(args, "per_step_sampler", False)) else None
-        for s in tape["steps"][:T]:
-            # the step gathers its own feature rows from the resident table inside its first launch (forward(gather=...))
+        for s in tape["steps"][:T_il]:
             logit, (h, c), ht = dec(s["angle"], None, None, ht, h, c, ctx, tape["seq_mask"], gather=gather_of(s))
-            hidden.append(h)
-            if not sample:
-                ce.add(logit, s["target"], s["cand_mask"])
-            elif sampler is not None:
-                sampler.step(logit, s["cand_mask"])                                 # envdrop.py:186-195 as one launch per step ...
-            else:
-                a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])
-                logps.append(lp_a); ents.append(en_a)
-        if not sample:
-            return ce.sum(scale=0.2 / B)
-        if sampler is not None:
-            logps, ents = sampler.stats()                                           # ... and ONE backward node for all steps
-        sl = tape["steps"][T - 1]
-        _, (last_h, _), _ = dec(sl["angle"], None, None, ht, h, c, ctx, tape["seq_mask"], gather=gather_of(sl))
+            ce.add(logit, s["target"], s["cand_mask"])
+        return ce.sum(scale=0.2 / B)
+
+    def rl_begin():
+        ctx, h, c = enc(tape["tokens"], tape["lengths32"])
+        dec.defer_logits = False
+        st.update(ctx=ctx, h=h, c=c, ht=h, hidden=[], logps=[], ents=[],
+                  sampler=None if getattr(args, "per_step_sampler", False) else vln.losses.RolloutSampler(clock=clock))
+
+    def rl_step(t):
+        s = tape["steps"][t]
+        logit, (h, c), ht = dec(s["angle"], None, None, st["ht"], st["h"], st["c"], st["ctx"], tape["seq_mask"], gather=gather_of(s))
+        st.update(h=h, c=c, ht=ht)
+        st["hidden"].append(h)
+        if st["sampler"] is not None:
+            a = st["sampler"].step(logit, s["cand_mask"])                       # envdrop.py:186-195 as one launch per step ...
+        else:
+            a, lp_a, en_a = vln.losses.sample_action(logit, s["cand_mask"])
+            st["logps"].append(lp_a); st["ents"].append(en_a)
+        if read_actions:
+            a_host[t].copy_(a, non_blocking=True)                               # envdrop.py:198: cpu_a_t = a_t.cpu().numpy()
+
+    def host_step(t):
+        if read_actions:
+            torch.cuda.current_stream().synchronize()
+            host_ended[0] = int((a_host[t] == C - 1).sum())                     # stand-in for env.step(cpu_a_t): the host reads the actions
+
+    def rl_end():
+        if st["sampler"] is not None:
+            logps, ents = st["sampler"].stats()                                 # ... and ONE backward node for all steps
+        else:
+            logps, ents = st["logps"], st["ents"]
+        hidden = st["hidden"]
+        sl = tape["steps"][len(hidden) - 1]
+        _, (last_h, _), _ = dec(sl["angle"], None, None, st["ht"], st["h"], st["c"], st["ctx"], tape["seq_mask"], gather=gather_of(sl))
         with torch.no_grad():
             last_v = cri(last_h).detach()
         # the critic is row-wise: V of all T steps in ONE call over (steps x batch) rows instead of T calls (the reference
         # loops `self.critic(hidden_states[t])`, envdrop.py:246 -- same function of the same rows)
         vals = list(cri(torch.cat(hidden, 0)).view(len(hidden), B).unbind(0))
+        T = len(hidden)
         rl, _ = vln.losses.a2c_loss(logps, ents, vals, rewards[:T], masks[:T], last_v, ended, 0.9, "total")
+        st.clear()
         return rl
 
     arena = vln.ops.RolloutArena()
     dec.step_graphs = True
 
-    def it():
-        vln.ops.set_arena(arena); arena.begin()
-        try:
-            opt.zero_grad()
-            (rollout(T_il, False) + rollout(T_rl, True)).backward()
-            opt.step()
-        finally:
-            vln.ops.set_arena(None)
+    def in_arena(fn, begin=False):
+        def run():
+            vln.ops.set_arena(arena)
+            if begin:
+                arena.begin()
+            try:
+                return fn()
+            finally:
+                vln.ops.set_arena(None)
+        return run
 
-    ms = timed(it)
+    def first():
+        if clock is not None:
+            clock.prologue(modules=(enc, dec))
+        opt.zero_grad()               # no launch after a step(zero_grads=True): the update cleared the buffer while it read it
+        st["il"] = il_rollout()
+        rl_begin()
+        rl_step(0)
+
+    def last():
+        il = st.pop("il")
+        loss = il + rl_end()
+        loss.backward()
+        opt.step(zero_grads=True)
+        return loss
+
+    segs = [("graph", in_arena(first, begin=True)), ("host", lambda: host_step(0))]
+    for t in range(1, T_rl):
+        segs += [("graph", in_arena(lambda t=t: rl_step(t))), ("host", lambda t=t: host_step(t))]
+    segs.append(("graph", in_arena(last)))
+
+    def it():
+        out = None
+        for _, fn in segs:
+            r = fn()
+            out = r if r is not None else out
+        return out
+
+    if build_only:          # tests: (eager iteration, a function that captures and returns the replay, the state to compare)
+        return it, (lambda: vln.SegmentedIterationGraph(segs, clock).capture().replay), dict(opt=opt, enc=enc, dec=dec, cri=cri, a_host=a_host, clock=clock)
+    if graph:
+        for _ in range(3):
+            it()
+        run = vln.SegmentedIterationGraph(segs, clock).capture().replay
+    else:
+        run = it
+    ms = timed(run)
     return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3),
-                plan_hits=dec.plan_hits, arena_misses=arena.misses,
+                iteration=(f"{T_rl + 1} hipGraph segments" if graph else "per-step hipGraphs, Python-driven"),
+                per_step_action_read=bool(read_actions), plan_hits=dec.plan_hits, arena_misses=arena.misses,
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
@@ -295,7 +366,8 @@ def main():
     ap.add_argument("--python-step", action="store_true", help="monitor: the step's launches driven from Python (functional.MonitorCoreFn) "
                                                                "instead of one C call each way")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
-    ap.add_argument("--no-graph", action="store_true", help="monitor / follower: eager launches instead of one hipGraph per iteration")
+    ap.add_argument("--no-graph", action="store_true", help="monitor / follower / a2c: eager launches instead of one hipGraph (a2c: a sequence of graph segments) per iteration")
+    ap.add_argument("--no-action-read", action="store_true", help="a2c: (A/B) the sampled actions never leave the device")
     ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE", help="(A/B) vln_set_tunable(ID, VALUE) before anything runs")
     ap.add_argument("--two-bn-mlp-calls", action="store_true", help="monitor: the BN-MLP called twice per step like the reference (A/B) "
                                                                     "instead of once on both batches (MonitorDecoder.merge_projections)")
@@ -323,7 +395,7 @@ def main():
     if a.which in ("speaker", "all"):
         print(json.dumps(run_speaker()), flush=True)
     if a.which in ("a2c", "all"):
-        print(json.dumps(run_a2c(T_rl=a.T_rl)), flush=True)
+        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=not a.no_action_read)), flush=True)
 
 
 if __name__ == "__main__":

@@ -113,6 +113,45 @@ def test_decoder_gradient_ride_equals_its_own_launches(vln, graph):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the gradient ride and its own launches"
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_il_plus_a2c_iteration_as_graph_segments_equals_eager(vln, dtype):
+    """BASELINE config 3's per-rank iteration (trainer.py:411-427: IL rollout + sampled A2C rollout + critic, one RMSprop) as
+    graphs.SegmentedIterationGraph -- one hipGraph per sampled step with the action read on the host between them, the backward
+    of both rollouts + the update in the last segment (scripts/bench_agents.py::run_a2c) -- against the same pieces issued
+    eagerly: sampled actions (the draws follow the device clock), loss, parameters and RMSprop state bit for bit over 5 iterations."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench, bench_agents as W
+    dev = torch.device(DEV)
+    W.configure(steps=1, warmup=0, dtype=dtype, device=dev, graph=True)
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(91)
+        store = bench.build_store(vln, dev, W.dt, n_rows=300, seed=5)
+        torch.manual_seed(92)
+        it, capture, state = W.run_a2c(B=16, L=24, T_il=3, T_rl=5, C=6, store=store, graph=True, build_only=True, seed=600)
+        state["enc"].deterministic_embedding_grad = True
+        rec = []
+
+        def snap(loss):
+            torch.cuda.synchronize()
+            rec.append((loss.detach().clone(), state["opt"].flat_p.clone(), state["opt"].sq.clone(), state["a_host"].clone()))
+
+        for _ in range(2):
+            snap(it())
+        run = capture() if use_graph else it
+        for _ in range(3):
+            snap(run())
+        outs.append(rec)
+        vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    acts = [o[3] for o in outs[0]]
+    assert any(not torch.equal(acts[0], a) for a in acts[1:])            # fresh draws every iteration
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.isfinite(a[0]).all()
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "sampled actions")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the segment-replayed IL + A2C iteration"
+
+
 def test_gradient_ride_without_a_carrier_is_issued_by_the_flush(vln):
     """A posted ride that no backward recurrence picks up: vln_wgrad_ride_flush (the autograd engine's end-of-backward callback in
     EnvDropDecoder._deferred_wgrads) issues it as its own launches -- same results as WgradBatch / ColsumBatch run directly."""
