@@ -393,7 +393,12 @@ class MonitorDecoder(nn.Module, _Seeded):
         return Fh.AttnDotFn.apply(cands_rep, query)
 
     def progress_monitor(self, h_0, c_1, weighted_cands, ctx_attn, site=None):
-        """tanh(W_c [ctx_attn ; drop(sigmoid(W_m [h_0 ; weighted_cands]) * tanh(c_1))])      (policy.py:119-130)"""
+        """tanh(W_c [ctx_attn ; drop(sigmoid(W_m [h_0 ; weighted_cands]) * tanh(c_1))])      (policy.py:119-130)
+
+        This is the OPERATOR-BY-OPERATOR form of the head (`c_step = False`, the A/B / test reference of the one-call step): its gate
+        product and the final Linear are library launches, `sigmoid(gate) * tanh(c_1)` and the two concatenations are torch
+        elementwise ops on purpose -- autograd differentiates them, which is what `tests/test_hip_agents.py::test_monitor_fused_step_equals_operator_path` holds the
+        fused `monitor_head_fwd/bwd` kernels of the default path (csrc/monitor.hip) against."""
         site = self._next() if site is None else site
         gate = Fh.linear(torch.cat((h_0, weighted_cands), 1), self.monitor_linear.weight, self.monitor_linear.bias,
                          ops.ACT_NONE, self._wd("w_m"))

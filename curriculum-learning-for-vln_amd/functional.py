@@ -95,14 +95,16 @@ class RolloutWgrads:
         self.groups = {}
         self._queued = False
         self.stats = [0, 0]          # [steps deferred, segmented launches issued]
+        self.stale_dropped = 0       # queued flushes dropped because the backward pass that queued them raised
 
     class _Group:
-        __slots__ = ("fwd", "fwd_n", "bwd", "bwd_n", "nf", "pending")
+        __slots__ = ("fwd", "fwd_n", "bwd", "bwd_n", "nf", "pending", "out")
 
         def __init__(self):
             self.fwd = self.bwd = None
             self.fwd_n = self.bwd_n = 0
             self.nf, self.pending = 0, []
+            self.out = 0             # forward steps whose backward has not deferred its jobs yet (their slots are live)
 
     def active(self, ctx):
         # (inside Function.forward grad mode is off: whether a backward can follow is what needs_input_grad says)
@@ -111,7 +113,7 @@ class RolloutWgrads:
     def reset(self):
         """Forget half-finished rollouts (forwards whose backward never ran)."""
         for g in self.groups.values():
-            g.nf, g.pending = 0, []
+            g.nf, g.pending, g.out = 0, [], 0
         self._queued = False
 
     @staticmethod
@@ -126,10 +128,19 @@ class RolloutWgrads:
 
     def saved(self, key, floats, dev):
         """forward: (this step's saved-activation block, its slot)."""
+        if self._queued:
+            # A flush is still queued while a NEW forward step runs: the backward pass that queued it raised (the engine drops its
+            # callbacks then) -- its deferred jobs are stale, and `_queued` would keep every later backward from queueing a flush.
+            # Drop them; the failed iteration's gradients are lost with the exception the caller already saw.
+            for g in self.groups.values():
+                g.pending = []
+            self._queued = False
+            self.stale_dropped += 1
         g = self.groups.get(key)
         if g is None:
             g = self.groups[key] = RolloutWgrads._Group()
         slot = g.nf
+        g.out += 1
         if slot >= 4096:
             raise _lib.VlnError("RolloutWgrads: 4096 forward steps without a backward pass; call functional.ROLLOUT_WGRADS.reset()")
         g.nf += 1
@@ -142,7 +153,9 @@ class RolloutWgrads:
         return t
 
     def defer(self, key, slot, jobs, keep):
-        self.groups[key].pending.append((slot, jobs, keep))
+        g = self.groups[key]
+        g.pending.append((slot, jobs, keep))
+        g.out = max(0, g.out - 1)
         self.stats[0] += 1
         if not self._queued:
             self._queued = True
@@ -154,7 +167,9 @@ class RolloutWgrads:
         lib = _lib.load()
         st = _lib.raw_stream()
         for g in self.groups.values():
-            pend, g.pending, g.nf = sorted(g.pending, key=lambda t: t[0]), [], 0
+            pend, g.pending = sorted(g.pending, key=lambda t: t[0]), []
+            if g.out == 0:           # slots restart only when no other rollout's forward steps still wait for their backward
+                g.nf = 0
             i = 0
             while i < len(pend):
                 base = pend[i][1]

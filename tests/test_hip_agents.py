@@ -548,7 +548,13 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             F_.ROLLOUT_WGRADS.stats[:] = [0, 0]
             dec = make(); dec.load_state_dict(sd); dec.to(DEV).train()
             per_rollout = []
-            for rollout in range(2):
+            n_roll = 3 if deferred else 2
+            for rollout in range(n_roll):
+                if rollout == 2:
+                    # as a backward pass that RAISED leaves it: the engine dropped the queued flush, `_queued` stayed set.
+                    # The next forward step must notice, drop the stale jobs and let this rollout's backward queue its own flush.
+                    F_.ROLLOUT_WGRADS._queued = True
+                    stale0 = F_.ROLLOUT_WGRADS.stale_dropped
                 dec._calls = 0                                  # the same dropout masks in both rollouts and both modes
                 for m_ in dec.modules():
                     if hasattr(m_, "_calls"):
@@ -575,7 +581,8 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             res.append(per_rollout)
             if deferred:
                 groups = 3 if agent == "monitor" else 1          # the step + the BN-MLP's two calls per step (B and B*C rows)
-                assert F_.ROLLOUT_WGRADS.stats == [2 * T * groups, 2 * groups], F_.ROLLOUT_WGRADS.stats
+                assert F_.ROLLOUT_WGRADS.stats == [3 * T * groups, 3 * groups], F_.ROLLOUT_WGRADS.stats
+                assert F_.ROLLOUT_WGRADS.stale_dropped == stale0 + 1
             else:
                 assert F_.ROLLOUT_WGRADS.stats == [0, 0]
     finally:
@@ -592,6 +599,7 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             assert torch.equal(x, y), f"rollout {rollout} input grad {i}"
     for n in res[1][0][1]:                                      # the second rollout reproduces the first (slots reused correctly)
         assert torch.equal(res[1][0][1][n], res[1][1][1][n]), n
+        assert torch.equal(res[1][0][1][n], res[1][2][1][n]), f"{n}: after a stale queued flush"
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
