@@ -103,7 +103,8 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     // BatchNorm), and a unit whose pre-activation moves across zero changes a whole gradient term: the 2^-16 of the split product
     // flipped ~10 of the 1.2 M units at BASELINE config 2 (2.5e-2 of the weight gradient's range, profiles/round4_notes.md), the
     // exact product flips none.  The backward's products (no ReLU decision in them) keep the split form.
-    RUN(gemm_nt(st, y, in, l.w, m->wtype == W_F32S ? (int)W_F32 : m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
+    // a ReLU decision follows this product: an fp32-streamed layer multiplies in the fp32-GRADE six-product form (W_F32X), not the 2^-16 one
+    RUN(gemm_nt(st, y, in, l.w, m->wtype == W_F32S ? (int)W_F32X : m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
     const bool last = (i == m->nl - 1);
     RUN(bn_fwd_seg(z, l.out, yi, l.out, l.bn.gamma, l.bn.beta, l.bn.run_mean, l.bn.run_var, tr ? l.bn.nbt : nullptr, tr ? si : nullptr,
                    tr ? si + l.out : nullptr, R, R1, 2L * l.out, l.out, m->eps, m->momentum, tr, 1, l.seed, l.offset, l.offset2,

@@ -25,7 +25,7 @@ namespace vln {
 
 template <typename TW, int PD, bool kFast, int NT = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kF32)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kPlanes)];
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (a.xcd) {
     // Products with MANY row tiles (the encoder's two M = B * L products): the column tiles of one row tile read the same
@@ -49,8 +49,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // narrow outputs: 16-column workgroups with the K split inside the workgroup (no slabs, no reduce launch)
 // tunable[3] = largest K it takes (every workgroup streams the WHOLE X once: long contractions belong to the split-K path)
-static bool n16_applies(int M, int N, int K, int wtype) {     // (W_F32S operands take the 64-column kernel)
-  return wtype != W_F32S && g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
+static bool n16_applies(int M, int N, int K, int wtype) {     // (W_F32S / W_F32X operands take the 64-column kernel)
+  return wtype != W_F32S && wtype != W_F32X && g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
 }
 
 static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
@@ -152,13 +152,16 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
     // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
     const bool deep = g_tunable[5] == 4 && steps_per > 2;
 #define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
-    if (wtype != W_F32 && wtype != W_BF16 && wtype != W_F32S) { set_error("gemm_nt: unknown weight type %d", wtype); return VLN_ERR_ARG; }
-    if (wide && fast && wtype != W_F32S) {
+    if (wtype != W_F32 && wtype != W_BF16 && wtype != W_F32S && wtype != W_F32X) { set_error("gemm_nt: unknown weight type %d", wtype); return VLN_ERR_ARG; }
+    if (wide && fast && wtype != W_F32S && wtype != W_F32X) {
       if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<bf16_raw, 2, true, 2>, grid, block, 0, st, a);
       else launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<float, 2, true, 2>, grid, block, 0, st, a);
     } else if (wtype == W_F32S) {
       if (fast) VLN_NT_LAUNCH(f32s_raw, 2, true);
       else VLN_NT_LAUNCH(f32s_raw, 1, false);
+    } else if (wtype == W_F32X) {
+      if (fast) VLN_NT_LAUNCH(f32x_raw, 2, true);
+      else VLN_NT_LAUNCH(f32x_raw, 1, false);
     } else if (wtype == W_BF16) {
       if (fast) { if (deep) VLN_NT_LAUNCH(bf16_raw, 4, true); else VLN_NT_LAUNCH(bf16_raw, 2, true); }
       else VLN_NT_LAUNCH(bf16_raw, 1, false);

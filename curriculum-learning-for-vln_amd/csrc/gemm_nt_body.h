@@ -3,9 +3,14 @@
 
 // kF32: exact fp32 MFMA on fp32 weights.  kWS: fp32 weights in memory, split into hi + lo bf16 planes in registers (W_F32S).
 template <typename TW> struct GemmCfg;
-template <> struct GemmCfg<float> { static constexpr int BK = 32, VK = 8; static constexpr bool kF32 = true, kWS = false; };
-template <> struct GemmCfg<bf16_raw> { static constexpr int BK = 64, VK = 16; static constexpr bool kF32 = false, kWS = false; };
-template <> struct GemmCfg<f32s_raw> { static constexpr int BK = 64, VK = 16; static constexpr bool kF32 = false, kWS = true; };
+template <> struct GemmCfg<float> { static constexpr int BK = 32, VK = 8, kPlanes = 1; static constexpr bool kF32 = true, kWS = false, kX6 = false; };
+template <> struct GemmCfg<bf16_raw> { static constexpr int BK = 64, VK = 16, kPlanes = 2; static constexpr bool kF32 = false, kWS = false, kX6 = false; };
+template <> struct GemmCfg<f32s_raw> { static constexpr int BK = 64, VK = 16, kPlanes = 2; static constexpr bool kF32 = false, kWS = true, kX6 = false; };
+// W_F32X: fp32 operands as THREE bf16 pieces each (x = hi + mid + lo, 24 bits), six products (every pair whose weight is above
+// 2^-24 of the full product): fp32-grade results -- the truncation is below the fp32 accumulation's own rounding -- at 6/16 of
+// the exact fp32 MFMA's time.  For products in FRONT of a ReLU (the BN-MLP's forward Linear): the three-product W_F32S form's 2^-16
+// flips ~10 of 1.2 M units per call against the exact product, this form none beyond what exact fp32 itself flips against fp64.
+template <> struct GemmCfg<f32x_raw> { static constexpr int BK = 64, VK = 16, kPlanes = 3; static constexpr bool kF32 = false, kWS = true, kX6 = true; };
 
 constexpr int kLdsRow = 144;  // 128 B of data + 16 B pad per staged X row
 
@@ -32,7 +37,7 @@ struct GemmNTArgs {
 // Virtual block of a launch (`nbar` = the K-step count the workgroup's barriers walk through).
 struct VBlock { int bx, by, bz; int tid; unsigned char* smem; };
 
-constexpr int gemm_nt_smem_bytes(bool f32) { return 2 * (f32 ? 1 : 2) * 64 * kLdsRow; }
+constexpr int gemm_nt_smem_bytes(int planes) { return 2 * planes * 64 * kLdsRow; }
 
 __device__ __forceinline__ int gemm_nt_nsteps(const GemmNTArgs& a, int by, int BK) {
   const int kbeg = by * a.kchunk;
@@ -45,11 +50,11 @@ __device__ __forceinline__ int gemm_nt_nsteps(const GemmNTArgs& a, int by, int B
 template <typename TW, int PD, bool kFast, int NT, typename Pre>
 __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& vb, bool active, int nbar, Pre pre) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
-  constexpr bool kF32 = GemmCfg<TW>::kF32, kWS = GemmCfg<TW>::kWS;
+  constexpr bool kF32 = GemmCfg<TW>::kF32, kWS = GemmCfg<TW>::kWS, kX6 = GemmCfg<TW>::kX6;
   typedef typename std::conditional<kWS, float, TW>::type TM;       // the weights' element type IN MEMORY
   // bf16 path: the fp32 activations are split x = hi + lo (two bf16 planes) so only the STREAMED operand is
-  // quantised; the second MFMA pair is free in these weight-bandwidth-bound shapes.
-  constexpr int kPlanes = kF32 ? 1 : 2;
+  // quantised; the second MFMA pair is free in these weight-bandwidth-bound shapes.  (kX6: three planes, hi / mid / lo.)
+  constexpr int kPlanes = GemmCfg<TW>::kPlanes;
   typedef unsigned char (*SmemT)[kPlanes][64 * kLdsRow];
   SmemT smem = reinterpret_cast<SmemT>(vb.smem);
 
@@ -123,14 +128,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
               make_float4(x[i * 4], x[i * 4 + 1], x[i * 4 + 2], x[i * 4 + 3]);
         } else {
           typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          bf16x4 h, l;
+          bf16x4 h, l, m3;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             h[j] = (__bf16)x[i * 4 + j];
-            l[j] = (__bf16)(x[i * 4 + j] - (float)h[j]);
+            const float r1 = x[i * 4 + j] - (float)h[j];
+            l[j] = (__bf16)r1;
+            if constexpr (kX6) m3[j] = (__bf16)(r1 - (float)l[j]);
           }
           *reinterpret_cast<bf16x4*>(&smem[buf][0][xr_i[i] * kLdsRow + xpiece * 8]) = h;
-          *reinterpret_cast<bf16x4*>(&smem[buf][kPlanes - 1][xr_i[i] * kLdsRow + xpiece * 8]) = l;
+          *reinterpret_cast<bf16x4*>(&smem[buf][1][xr_i[i] * kLdsRow + xpiece * 8]) = l;         // (two planes: kPlanes - 1 == 1)
+          if constexpr (kX6) *reinterpret_cast<bf16x4*>(&smem[buf][2][xr_i[i] * kLdsRow + xpiece * 8]) = m3;
         }
       }
       return;
@@ -140,19 +148,26 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
       *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
       *reinterpret_cast<float4*>(dst + 16) = make_float4(x[4], x[5], x[6], x[7]);
     } else {
-      bf16x8 h0, h1, l0, l1;
+      bf16x8 h0, h1, l0, l1, t0, t1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         h0[j] = (__bf16)x[j];
         h1[j] = (__bf16)x[8 + j];
-        l0[j] = (__bf16)(x[j] - (float)h0[j]);
-        l1[j] = (__bf16)(x[8 + j] - (float)h1[j]);
+        const float r0 = x[j] - (float)h0[j], r1 = x[8 + j] - (float)h1[j];
+        l0[j] = (__bf16)r0;
+        l1[j] = (__bf16)r1;
+        if constexpr (kX6) { t0[j] = (__bf16)(r0 - (float)l0[j]); t1[j] = (__bf16)(r1 - (float)l1[j]); }
       }
       *reinterpret_cast<bf16x8*>(dst) = h0;
       *reinterpret_cast<bf16x8*>(dst + 16) = h1;
-      unsigned char* dlo = &smem[buf][kPlanes - 1][srow * kLdsRow + sseg * 32];
+      unsigned char* dlo = &smem[buf][1][srow * kLdsRow + sseg * 32];
       *reinterpret_cast<bf16x8*>(dlo) = l0;
       *reinterpret_cast<bf16x8*>(dlo + 16) = l1;
+      if constexpr (kX6) {
+        unsigned char* d3 = &smem[buf][2][srow * kLdsRow + sseg * 32];
+        *reinterpret_cast<bf16x8*>(d3) = t0;
+        *reinterpret_cast<bf16x8*>(d3 + 16) = t1;
+      }
     }
   };
   auto load_w = [&](float (&w32)[kF32 ? 8 : (kWS ? 16 : 1)], bf16x8 (&w16)[(kF32 || kWS) ? 1 : 2], int kb, int t) {
@@ -215,6 +230,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
       float wc32[NT][kF32 ? 8 : 1];
       bf16x8 wc16[NT][kF32 ? 1 : 2];
       bf16x8 wcl[NT][kWS ? 2 : 1];         // W_F32S: the weights' lo plane (w - bf16(w))
+      bf16x8 wc3[NT][kX6 ? 2 : 1];         // W_F32X: the third piece (w - hi - lo)
       if (on) {
         store_x(xs[p], buf);
 #pragma unroll
@@ -230,7 +246,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
                 const float w = wf32[p][t][h * 8 + j];
                 const __bf16 hi = (__bf16)w;
                 wc16[t][h][j] = hi;
-                wcl[t][h][j] = (__bf16)(w - (float)hi);
+                const float r1 = w - (float)hi;
+                wcl[t][h][j] = (__bf16)r1;
+                if constexpr (kX6) wc3[t][h][j] = (__bf16)(r1 - (float)wcl[t][h][j]);
               }
           } else {
             wc16[t][0] = wb16[p][t][0]; wc16[t][1] = wb16[p][t][1];
@@ -270,9 +288,23 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
             } else {
               bf16x8 a0 = *reinterpret_cast<const bf16x8*>(src);
               bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 16);
-              const unsigned char* slo = &smem[buf][kPlanes - 1][(rb * 16 + fi) * kLdsRow + fq * 32];
+              const unsigned char* slo = &smem[buf][1][(rb * 16 + fi) * kLdsRow + fq * 32];
               bf16x8 b0 = *reinterpret_cast<const bf16x8*>(slo);
               bf16x8 b1 = *reinterpret_cast<const bf16x8*>(slo + 16);
+              if constexpr (kX6) {         // the smallest terms first: x3 w1, x1 w3, x2 w2; then the three of the W_F32S form
+                const unsigned char* s3 = &smem[buf][2][(rb * 16 + fi) * kLdsRow + fq * 32];
+                const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(s3);
+                const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(s3 + 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, wc16[t][0], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, wc16[t][1], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wc3[t][0], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wc3[t][1], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wcl[t][0], acc[t][rb], 0, 0, 0);
+                  acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, wcl[t][1], acc[t][rb], 0, 0, 0);
+                }
+              }
 #pragma unroll
               for (int t = 0; t < NT; ++t) {
                 acc[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, wc16[t][0], acc[t][rb], 0, 0, 0);

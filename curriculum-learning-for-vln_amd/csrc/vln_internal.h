@@ -19,7 +19,8 @@ enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
 // operands split hi + lo (x_hi w_hi + x_lo w_hi + x_hi w_lo; the dropped lo*lo term is 2^-16 relative, fp32 accumulate): what the
 // bf16 mode uses for the matrices it streams in fp32 all the same (EnvDropDecoder / MonitorDecoder `fp32_weights`).  Same bytes as
 // W_F32, 3/16 of its matrix-pipe time -- it matters for the tall products (the BN-MLP's 1152 rows), not for the 64-row ones.
-enum WType { W_F32 = 0, W_BF16 = 1, W_F32S = 2 };
+enum WType { W_F32 = 0, W_BF16 = 1, W_F32S = 2, W_F32X = 3 };
+struct f32x_raw { float f; };          // W_F32X: fp32 in memory, three bf16 pieces per operand, six products (gemm_nt_body.h)
 struct f32s_raw { float f; };          // element type tag of W_F32S operands in the kernels' templates
 
 // thread-local last error text (vln_last_error_string)

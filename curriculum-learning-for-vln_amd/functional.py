@@ -677,8 +677,11 @@ class BnMlpFn(torch.autograd.Function):
         saved += [x, s0, y]
         for i in range(nl):
             W, b, gw, gb = tensors[2 + 4 * i: 6 + 4 * i]
-            # forward: exact fp32 for an fp32-streamed layer (a ReLU decision follows: csrc/bn_mlp.hip), split only in the backward
-            z = ops.linear_fwd(y, SHADOWS.get(W, "n", wdtype(dtype, "mlp")), None if b is None else b.detach())
+            # forward of an fp32-streamed layer in bf16 mode: the fp32-GRADE six-product form (a ReLU decision follows: csrc/bn_mlp.hip),
+            # the three-product split only in the backward
+            wd_ = wdtype(dtype, "mlp")
+            z = ops.linear_fwd(y, SHADOWS.get(W, "n", wd_), None if b is None else b.detach(),
+                               split="x6" if (wd_ == torch.float32 and base_dtype(dtype) != torch.float32) else False)
             last = i == nl - 1
             y, si = bn(z, gw, gb, bufs[1 + i], True, drops[i], rz if last else None)
             saved += [z, si, y]

@@ -13,6 +13,7 @@ from . import _lib
 
 F32, BF16 = 0, 1
 F32S = 2      # weight operands: fp32 in memory, split-bf16 arithmetic (include/vln_hip.h VLN_F32S)
+F32X = 3      # ... three bf16 pieces per operand, six products: fp32-grade (VLN_F32X)
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 
 
@@ -182,7 +183,8 @@ def workspace(device, floats: int) -> torch.Tensor:
 def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None, split=False):
     """y = act(x @ w.T + bias); x [M,K] fp32 (row stride free), w [N,K] fp32|bf16.  split (fp32 `w` only): the product on the bf16
     matrix pipe with both operands split hi + lo (VLN_F32S) instead of the exact fp32 MFMA -- the bf16 mode's fp32-streamed
-    matrices (functional.wdtype)."""
+    matrices (functional.wdtype).  split="x6": three bf16 pieces per operand, six products (VLN_F32X): fp32-grade, for products in
+    front of a ReLU."""
     lib = _lib.load()
     _req(x, "x"); _req(w, "w", None)
     M, K = x.shape
@@ -191,7 +193,7 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None, split=False):
     if out is None:
         out = empty(M, N, dtype=torch.float32, device=x.device)
     ws = workspace(x.device, min(16 * M * N, 1 << 24))
-    wt = F32S if (split and w.dtype == torch.float32) else _dt(w)
+    wt = (F32X if split == "x6" else F32S) if (split and w.dtype == torch.float32) else _dt(w)
     _lib.check(lib.vln_linear_fwd(_p(x), x.stride(0), _p(w), wt, w.stride(0), _p(out), out.stride(0), M, N, K,
                                   _p(bias), act, _p(ws), ws.numel(), _stream()), "vln_linear_fwd")
     return out

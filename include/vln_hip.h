@@ -33,6 +33,10 @@ typedef void* vln_stream_t; /* hipStream_t */
  * split hi + lo (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; 2^-16 relative) -- what the bf16 mode uses for the matrices
  * it streams in fp32 all the same (vln_envdrop_weights.f32_mask, vln_monitor_weights.f32_mask, vln_bn_mlp.wtype). */
 #define VLN_F32S 2
+/* Weight operands only (ABI v14): fp32 in memory, both operands as THREE bf16 pieces, six products (every pair above 2^-24 of the
+ * full product): fp32-grade results at 6/16 of the exact fp32 MFMA's time.  vln_bn_mlp_fwd uses it for the forward Linear of a
+ * VLN_F32S layer (a ReLU decision follows the product); vln_linear_fwd takes it like any weight type. */
+#define VLN_F32X 3
 #define VLN_ACT_NONE 0
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2

@@ -7,7 +7,7 @@ cp $SRC/pmc/round4_pmc.json $P/round4_pmc.json
 cp $SRC/pmc/gemm_nt_by_shape.txt $P/round4_gemm_nt_by_shape.txt
 cp $SRC/pmc/stats.txt $P/round4_kernel_stats.txt
 cp $SRC/bench_full.json $P/round4_bench_bf16.json
-cp $SRC/timeline.txt $P/round4_timeline.txt
+[ -s $SRC/timeline.txt ] && cp $SRC/timeline.txt $P/round4_timeline.txt
 rm -rf $P/round4_pmc_d; mkdir -p $P/round4_pmc_d
 cp $SRC/pmc/kernel_stats.csv $P/round4_pmc_d/
 for d in FETCH_SIZE WRITE_SIZE TCC MFMA; do

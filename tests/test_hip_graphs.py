@@ -17,12 +17,13 @@ def vln():
 
 
 def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True,
-         prologue=True, ride=True):
+         prologue=True, ride=True, shape=(16, 24, 4, 6)):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
     store = bench.build_store(vln, dev, dtype, n_rows=300, seed=5)
-    tapes = [bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
+    B_, L_, T_, C_ = shape
+    tapes = [bench.tape_to(bench.make_tape(B_, L_, T_, C_, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
     live = bench.LiveBatch(tapes, source=source)
     torch.manual_seed(78)
     ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
@@ -150,6 +151,19 @@ def test_il_plus_a2c_iteration_as_graph_segments_equals_eager(vln, dtype):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "sampled actions")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the segment-replayed IL + A2C iteration"
+
+
+def test_decoder_gradient_ride_at_baseline_size(vln):
+    """The same equality at BASELINE config 1's per-GPU size (B 64, L 80, T 7): 128 recurrence workgroups + 64 passengers in the BPTT
+    launch (the passengers-only barrier over 64 workgroups on 8 XCDs), 448-row contractions -- as one captured iteration."""
+    ref, _, _ = _run(vln, torch.bfloat16, True, "ride", n_eager=2, n_more=3, ride=False, shape=(64, 80, 7, 8))
+    mid = vln.ops.GradRide.stats()
+    got, _, _ = _run(vln, torch.bfloat16, True, "ride", n_eager=2, n_more=3, ride=True, shape=(64, 80, 7, 8))
+    after = vln.ops.GradRide.stats()
+    assert after["carried"] > mid["carried"] and after["issued_alone"] == mid["issued_alone"]
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ between the gradient ride and its own launches"
 
 
 def test_gradient_ride_without_a_carrier_is_issued_by_the_flush(vln):

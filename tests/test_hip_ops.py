@@ -48,6 +48,13 @@ def test_linear_fwd_split_fp32_weights(vln, M, N, K):
     check(y, ref, 1e-4, "y (split fp32 weights)")
     y_bf = vln.ops.linear_fwd(x.to(dev()), w.bfloat16().to(dev()), b.to(dev()), vln.ops.ACT_TANH)
     assert rel_err(y, ref) < 0.1 * max(rel_err(y_bf, ref), 1e-5) or rel_err(y, ref) < 2e-5     # an order below the bf16-streamed form
+    # VLN_F32X: three bf16 pieces per operand, six products -- as close to the fp64 product as the exact fp32 MFMA is (its own
+    # accumulation rounding is what remains), an order below the three-product form
+    y6 = vln.ops.linear_fwd(x.to(dev()), w.to(dev()), b.to(dev()), vln.ops.ACT_TANH, split="x6")
+    y32 = vln.ops.linear_fwd(x.to(dev()), w.to(dev()), b.to(dev()), vln.ops.ACT_TANH)
+    check(y6, ref, 1e-5, "y (six-product fp32-grade form)")
+    check(y32, ref, 1e-5, "y (exact fp32 MFMA)")
+    assert rel_err(y6, ref) < 4 * max(rel_err(y32, ref), 5e-7), (rel_err(y6, ref), rel_err(y32, ref))
 
 
 def test_linear_fwd_strided_x(vln):
