@@ -208,7 +208,7 @@ def run_speaker(B=64, Lp=7, Lw=80, V=36, vocab=992):
                 dtype=args.dtype)
 
 
-def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actions=True, build_only=False, seed=2020):
+def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actions=True, build_only=False, seed=2020, chain_il=True):
     """EnvDrop IL (teacher-forced rollout, T_il steps) + RL (sampled rollout up to T_rl steps -- the reference caps episodes at
     MAX_EPISODE_LEN = 35, configs/envdrop/envdrop_config.yaml:31 -- A2C with the critic, envdrop.py:186-264) per optimizer step
     (trainer.py:411-427); one RMSprop over encoder / decoder / critic, clip 40 on encoder and decoder only (:425-426).
@@ -251,6 +251,7 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
         ht = h
         dec.defer_logits = True   # teacher forcing: the logits are only needed by the loss (formed once per rollout)
+        dec.chain_steps = chain_il   # ... and nothing reads a step's h_tilde but the next step: consecutive steps share launches
         ce = vln.losses.RolloutCE()
         for s in tape["steps"][:T_il]:
             logit, (h, c), ht = dec(s["angle"], None, None, ht, h, c, ctx, tape["seq_mask"], gather=gather_of(s))
@@ -260,6 +261,7 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
     def rl_begin():
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
         dec.defer_logits = False
+        dec.chain_steps = False      # the sampled rollout reads every step's logits
         st.update(ctx=ctx, h=h, c=c, ht=h, hidden=[], logps=[], ents=[],
                   sampler=None if getattr(args, "per_step_sampler", False) else vln.losses.RolloutSampler(clock=clock))
 
@@ -368,6 +370,7 @@ def main():
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower / a2c: eager launches instead of one hipGraph (a2c: a sequence of graph segments) per iteration")
     ap.add_argument("--no-action-read", action="store_true", help="a2c: (A/B) the sampled actions never leave the device")
+    ap.add_argument("--no-chain-il", action="store_true", help="a2c: (A/B) the teacher-forced rollout's steps not chained")
     ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE", help="(A/B) vln_set_tunable(ID, VALUE) before anything runs")
     ap.add_argument("--two-bn-mlp-calls", action="store_true", help="monitor: the BN-MLP called twice per step like the reference (A/B) "
                                                                     "instead of once on both batches (MonitorDecoder.merge_projections)")
@@ -395,7 +398,7 @@ def main():
     if a.which in ("speaker", "all"):
         print(json.dumps(run_speaker()), flush=True)
     if a.which in ("a2c", "all"):
-        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=not a.no_action_read)), flush=True)
+        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=not a.no_action_read, chain_il=not a.no_chain_il)), flush=True)
 
 
 if __name__ == "__main__":
