@@ -161,14 +161,21 @@ class LiveBatch:
       "device"  on the device, `load(k)` = one device-to-device copy (round 3's form, A/B)."""
     TOP = ("tokens", "lengths32", "seq_mask")
     STEP = ("rows", "vidx", "crow", "cview", "chead", "celev", "cand_mask", "angle", "target")
+    # Blob order: what the ENCODER and the feature gather need first (tokens, lengths, every step's index vectors: 118 KB at B 64 / T 7),
+    # then what only the decoder reads (sequence mask, every step's candidate mask, angle features, targets: 242 KB).  `split` is where
+    # the second part starts: with the gather riding in the encoder's recurrence launch that part is pulled by a passenger workgroup of
+    # the same launch (HostBatchFeed.split_at / RolloutRide.carry_batch_tail) and the iteration's first launch pulls the head only.
+    HEAD_TOP, HEAD_STEP = ("tokens", "lengths32"), ("rows", "vidx", "crow", "cview", "chead", "celev")
 
     def __init__(self, tapes, source="device"):
         assert source in ("pull", "copy", "device")
         self.source = source
         t0 = tapes[0]
-        self.layout, off = [], 0
+        self.layout, off, self.split = [], 0, 0
         for name, t in self._items(t0):
             n = t.numel() * t.element_size()
+            if name == "seq_mask":
+                self.split = off                   # first byte of the decoder-only part
             self.layout.append((name, off, n, t.dtype, tuple(t.shape)))
             off = (off + n + 15) & ~15
         self.nbytes = off
@@ -197,11 +204,18 @@ class LiveBatch:
         self.live["steps"] = [{k: views[f"{i}.{k}"] for k in self.STEP} for i in range(len(t0["steps"]))]
 
     def _items(self, tp):
-        for k in self.TOP:
+        for k in self.HEAD_TOP:
             yield k, tp[k]
         for i, s in enumerate(tp["steps"]):
-            for k in self.STEP:
+            for k in self.HEAD_STEP:
                 yield f"{i}.{k}", s[k]
+        for k in self.TOP:
+            if k not in self.HEAD_TOP:
+                yield k, tp[k]
+        for i, s in enumerate(tp["steps"]):
+            for k in self.STEP:
+                if k not in self.HEAD_STEP:
+                    yield f"{i}.{k}", s[k]
 
     def load(self, k):
         if self.feed is not None:
@@ -270,6 +284,8 @@ class GpuAgent:
         self.batch_launched = None
         self.batch_feed = None
         self.use_prologue = True        # pull + tick + shadow refreshes as one launch (runtime.DeviceClock.prologue)
+        self.split_pull = True          # the decoder-only part of a pulled batch crosses PCIe under the encoder's recurrence (ride_gather only)
+        self._live_split, self._live_tape = 0, None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
         self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
 
@@ -311,6 +327,7 @@ class GpuAgent:
         (staging.HostBatchFeed); after every iteration / replay an event bounds how far the host may run ahead."""
         if live.feed is not None:
             self.batch_fetch, self.batch_launched, self.batch_feed = live.fetch, live.launched, live.feed
+            self._live_split, self._live_tape = live.split, live.live
 
     def use_arena(self, on: bool):
         self.arena = self.vln.ops.RolloutArena() if on else None
@@ -422,6 +439,12 @@ class GpuAgent:
 
     def _iteration(self, tape):
         B = tape["B"]
+        # the decoder-only part of a pulled batch crosses PCIe under the encoder's recurrence (one passenger workgroup of that launch)
+        # when the rollout's gather rides there too; decided BEFORE the head fetch of this iteration is issued
+        carry_tail = bool(self.batch_feed is not None and self.split_pull and self._live_split and tape is self._live_tape and
+                          self.ride_gather and tape.get("store") is not None)
+        if self.batch_feed is not None:
+            self.batch_feed.split_at(self._live_split if carry_tail else 0)
         if self.clock is not None and self.use_prologue:
             # ONE launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull"), the device clock ticks (this
             # iteration's dropout offsets / launch sequence) and both modules' weight shadows follow the last optimizer step
@@ -462,6 +485,8 @@ class GpuAgent:
             ride = tape["store"].rollout_ride([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
                                               pf, want_bf16=lp, want_f32=not lp)
             pre = ride.outputs
+            if carry_tail:
+                ride.carry_batch_tail(self.batch_feed)
         elif self.rollout_gather and self.gather_branch and tape.get("store") is not None:
             # the gather reads only the resident table + index vectors: as a branch of the captured graph it runs beside the
             # instruction encoder (whose 0.2 ms recurrence keeps half of the CUs idle) and joins before the first decoder step
@@ -685,6 +710,8 @@ def main():
     ap.add_argument("--no-prologue", action="store_true", help="(A/B) the batch pull, the clock tick and the shadow refreshes as separate launches")
     ap.add_argument("--no-ride-wgrads", action="store_true", help="(A/B) the decoder's weight / bias gradients as their own launches in front of "
                     "the encoder's BPTT instead of passengers of its launch (ops.GradRide); N > 1 and --dp-path never ride")
+    ap.add_argument("--no-split-pull", action="store_true", help="(A/B) the iteration's first launch pulls the WHOLE batch blob instead of leaving the "
+                    "decoder-only part to a passenger workgroup of the encoder's recurrence launch")
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
@@ -763,6 +790,8 @@ def main():
         agent.dec.chain_steps = False
     if args.no_prologue:
         agent.use_prologue = False
+    if args.no_split_pull:
+        agent.split_pull = False
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and args.features == "store" and not args.no_arena)
     # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
     # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
@@ -1054,7 +1083,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

@@ -39,7 +39,8 @@ class GatherRolloutStep(C.Structure):
 
 class GatherRide(C.Structure):         # vln_gather_ride
     _fields_ = ([("table", ptr), ("angle_table", ptr), ("steps", ptr)] + [(n, i32) for n in ("ttype", "T", "B", "V", "C", "IMG", "ANG", "pad_")]
-                + [("seed", u64), ("p_feat", f32), ("padf_", f32), ("offset_base_dev", ptr)])
+                + [("seed", u64), ("p_feat", f32), ("padf_", f32), ("offset_base_dev", ptr)]
+                + [("fetch_slots", ptr), ("fetch_seq", ptr), ("fetch_dst", ptr), ("fetch_offset", i64), ("fetch_bytes", i64), ("fetch_ring", i32), ("pad2_", i32)])
 
 
 class CatStep(C.Structure):

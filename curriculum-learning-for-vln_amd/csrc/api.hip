@@ -353,6 +353,25 @@ int fetch_args(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* don
   *blocks = b;
   return VLN_OK;
 }
+__global__ __launch_bounds__(256) void host_fetch_part_kernel(FetchPart f) { host_fetch_part_body(f, (int)threadIdx.x); }
+int fetch_part_args(const ::vln_gather_ride& r, FetchPart* f) {
+  *f = FetchPart{};
+  if (!r.fetch_slots) return VLN_OK;
+  if (!r.fetch_seq || !r.fetch_dst || r.fetch_ring < 1 || r.fetch_bytes <= 0 || (r.fetch_bytes & 15) || (r.fetch_offset & 15) || r.fetch_offset < 0 ||
+      (reinterpret_cast<uintptr_t>(r.fetch_dst) & 15)) {
+    set_error("vln_gather_ride: the batch-tail fetch needs a ring, a sequence word and 16-byte multiples for offset / size / destination");
+    return VLN_ERR_ARG;
+  }
+  *f = FetchPart{reinterpret_cast<const unsigned long long*>(r.fetch_slots), reinterpret_cast<const unsigned long long*>(r.fetch_seq),
+                 static_cast<u32x4*>(r.fetch_dst), (long)(r.fetch_offset / 16), (long)(r.fetch_bytes / 16), r.fetch_ring, 1};
+  return VLN_OK;
+}
+int launch_fetch_part(hipStream_t st, const FetchPart& f) {
+  if (!f.on) return VLN_OK;
+  VLN_LAUNCH(host_fetch_part_kernel, dim3(1), dim3(256), 0, st, f);
+  VLN_CHECK_LAUNCH("host_fetch_part");
+  return VLN_OK;
+}
 }  // namespace vln
 extern "C" int vln_host_device_pointer(const void* host, void** dev) {
   if (!host || !dev) { set_error("vln_host_device_pointer: null pointer"); return VLN_ERR_ARG; }

@@ -17,6 +17,7 @@
 #include "vln_internal.h"
 #include "graph_cache.h"
 #include "gather_ride.h"
+#include "prologue_bodies.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -866,7 +867,7 @@ static int ride_passengers(int nrec) {
 
 template <typename TW>
 static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
-                                const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride) {
+                                const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride, const FetchPart& fetch) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   dim3 g1(grid.x * grid.y * grid.z);
@@ -891,7 +892,8 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
       static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd); \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd, \
+               (ride ? fetch : FetchPart{}));                                                                                 \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -956,6 +958,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     // the ride: as passengers of the granule-protocol launch when it fits one argument block, else its own launch(es) first
     GatherRolloutArgs ride_args{};
     const GatherRolloutArgs* riders = nullptr;
+    FetchPart fetch{};
+    if (ride) { r = fetch_part_args(*ride, &fetch); if (r) return r; }
     if (ride) {
       // passengers need idle CUs (B = 128 with two directions of 256 units fills all 256) and the 96 KB dynamic-LDS claim
       if (fwd_granules() && ride->T <= kGatherMaxSteps && g_tunable[6] != 3 &&       // tunable[6] = 3: never as passengers (A/B)
@@ -964,6 +968,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
         riders = &ride_args;
       } else {
         r = gather_ride_launch(st, *ride); if (r) return r;
+        r = launch_fetch_part(st, fetch); if (r) return r;          // the batch tail as its own one-block launch
       }
     }
     const unsigned* seq_dev = device_seq >= 0 ? reinterpret_cast<const unsigned*>(static_cast<char*>(sync_ws) + sync_off_seq(B, Hd, dirs)) : nullptr;
@@ -974,8 +979,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     {
       ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
       if (fwd_granules())
-        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders)
-                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders);
+        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch)
+                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch);
       else
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
@@ -983,7 +988,12 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     if (!fwd_granules()) header_mark(sync_ws, false);       // the counter-protocol forward leaves its counters behind
     return r;
   }
-  if (ride) { int rr = gather_ride_launch((hipStream_t)s, *ride); if (rr) return rr; }
+  if (ride) {
+    int rr = gather_ride_launch((hipStream_t)s, *ride); if (rr) return rr;
+    FetchPart fetch{};
+    rr = fetch_part_args(*ride, &fetch); if (rr) return rr;
+    rr = launch_fetch_part((hipStream_t)s, fetch); if (rr) return rr;
+  }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[12]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, h0, c0},
                                                  {wtype, B, L, Hd, dirs}};

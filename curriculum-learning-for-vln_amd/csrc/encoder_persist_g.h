@@ -70,14 +70,19 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 template <typename TW, int NS>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
-                                                                 int nrec, GatherRolloutArgs ride) {
+                                                                 int nrec, GatherRolloutArgs ride, FetchPart fetch) {
   // PASSENGERS: workgroups past the recurrence's own `nrec` gather the rollout's feature rows (gather_body.h) on the compute
   // units the recurrence leaves idle -- independent work (it reads the resident table and index vectors only), nothing waits
   // for it inside this launch, and the launch claims a whole CU's LDS per workgroup so that a passenger never shares a CU with
   // a recurrence workgroup (whose hand-off latency is what a co-resident streaming wave would cost, MI355X_MICROARCH.md
   // "handoff-1to1").  Rows are dealt with the passengers' stride: any number of resident passengers finishes the job.
   if ((int)blockIdx.x >= nrec) {
-    gather_ride_passenger(ride, (int)blockIdx.x - nrec, (int)gridDim.x - nrec, (int)threadIdx.x);
+    int p = (int)blockIdx.x - nrec, np = (int)gridDim.x - nrec;
+    if (fetch.on) {      // the LAST passenger pulls the tail of the batch blob out of pinned host memory (PCIe-bound, ~25 us) instead of gathering
+      if (p == np - 1) { host_fetch_part_body(fetch, (int)threadIdx.x); return; }
+      np -= 1;
+    }
+    gather_ride_passenger(ride, p, np, (int)threadIdx.x);
     return;
   }
   // launch sequence in DEVICE memory (whole-iteration graphs: the launch arguments must repeat): the word is bumped by a

@@ -36,6 +36,25 @@ __device__ __forceinline__ void host_fetch_body(const FetchArgs& f, int block, i
     }
   }
 }
+// The TAIL of the current batch's blob, pulled later in the same iteration by one workgroup (a passenger of the forward recurrence
+// launch, or its own one-block launch): the slot is the one the iteration's head fetch used, i.e. (*seq - 1) % ring.
+struct FetchPart { const unsigned long long* slots; const unsigned long long* seq; u32x4* dst; long off16, n16; int ring; int on; };
+__device__ __forceinline__ void host_fetch_part_body(const FetchPart& f, int tid) {
+  const unsigned long long n = *f.seq - 1ull;
+  const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(f.slots + (n % (unsigned long long)f.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) + f.off16;
+  long i = tid;
+  for (; i + 7 * 256 < f.n16; i += 8 * 256) {           // eight PCIe reads in flight per thread
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(src + i + k * 256);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f.dst[i + k * 256] = v[k];
+  }
+  for (; i < f.n16; i += 256) f.dst[i] = __builtin_nontemporal_load(src + i);
+}
+int fetch_part_args(const ::vln_gather_ride& r, FetchPart* f);        // api.hip: validates and fills (on = 0 when the ride carries none)
+int launch_fetch_part(hipStream_t st, const FetchPart& f);            // api.hip: the same body as a one-block launch
+
 int fetch_args(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, FetchArgs* f, int* blocks);
 
 }  // namespace vln

@@ -271,6 +271,16 @@ class RolloutRide:
     def __init__(self, struct, outputs, keep):
         self.struct, self.outputs, self._keep = struct, outputs, keep
 
+    def carry_batch_tail(self, feed: "HostBatchFeed"):
+        """The carrier launch also pulls the TAIL of the current batch blob (`feed.split_at(offset)`: what only the decoder reads) out
+        of pinned host memory with one passenger workgroup -- PCIe traffic under the recurrence instead of in front of it."""
+        t = feed.tail_args()
+        if t is not None:
+            r = self.struct
+            r.fetch_slots, r.fetch_ring, r.fetch_seq, r.fetch_dst, r.fetch_offset, r.fetch_bytes = t
+            self._keep = (self._keep, feed)
+        return self
+
 
 class PinnedStager:
     """Ring of pinned host buffers + a copy stream.  `put(name->array)` returns device tensors that are ordered
@@ -347,6 +357,24 @@ class HostBatchFeed:
         self._addr = {}
         self._selected = 0                                                      # host mirror: selects made
         self._events = [None] * self.ring
+        self.head = live.numel()        # bytes the fetch itself pulls; the rest (split_at) rides in a later launch of the iteration
+
+    def split_at(self, offset: int):
+        """The fetch pulls bytes [0, offset) only; [offset, end) -- the part nothing reads before the decoder -- is pulled by whoever
+        takes `tail_args()` later in the SAME iteration (RolloutRide.carry_batch_tail: a passenger workgroup of the encoder's recurrence
+        launch).  offset: a multiple of 16; 0 or the blob size = no split."""
+        offset = int(offset)
+        if offset % 16 or not (0 <= offset <= self.live.numel()):
+            raise ValueError("HostBatchFeed.split_at: a multiple of 16 bytes inside the blob")
+        self.head = offset if 0 < offset < self.live.numel() else self.live.numel()
+        return self
+
+    def tail_args(self):
+        """(slots, ring, seq word, destination, offset, bytes) of the part the fetch leaves behind, or None."""
+        n = self.live.numel()
+        if self.head >= n:
+            return None
+        return (self._slots_dev, self.ring, self._state.data_ptr(), self.live.data_ptr() + self.head, self.head, n - self.head)
 
     @staticmethod
     def _devptr(t: torch.Tensor) -> int:
@@ -384,9 +412,9 @@ class HostBatchFeed:
     def fetch_args(self):
         """The pull as arguments of `vln_prologue` (runtime.DeviceClock.prologue issues it together with the tick and the refreshes)."""
         st = self._state
-        return (self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(), self.live.numel())
+        return (self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(), self.head)
 
     def fetch(self):
         st = self._state
         _lib.check(_lib.load().vln_host_fetch(self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(),
-                                              self.live.numel(), _lib.raw_stream()), "vln_host_fetch")
+                                              self.head, _lib.raw_stream()), "vln_host_fetch")

@@ -540,6 +540,11 @@ typedef struct vln_gather_ride {
   int32_t ttype, T, B, V, C, IMG, ANG, pad_;
   uint64_t seed; float p_feat; float padf_;
   const uint64_t* offset_base_dev;     /* nullable, see vln_embed_fwd */
+  /* optional (ABI v14; fetch_slots NULL = none): bytes [fetch_offset, fetch_offset + fetch_bytes) of the batch blob that the LAST
+   * vln_host_fetch / vln_prologue on this ring pulled the head of -- slot (*fetch_seq - 1) % fetch_ring -- copied to fetch_dst by ONE
+   * passenger workgroup: the part of a packed batch that only the decoder reads (angle features, masks, targets) crosses PCIe under
+   * the recurrence instead of in front of it.  Multiples of 16 bytes; without room for passengers it is its own small launch. */
+  const uint64_t* fetch_slots; const uint64_t* fetch_seq; void* fetch_dst; int64_t fetch_offset, fetch_bytes; int32_t fetch_ring, pad2_;
 } vln_gather_ride;
 /* Index range checks (ABI v10).  A caller that registers its table's extent -- N viewpoint rows, and the number of view
  * indices the angle table holds (36) -- gets every gather of that table (all entry points below, the in-step gather of
