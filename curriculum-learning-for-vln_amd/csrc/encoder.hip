@@ -231,6 +231,9 @@ struct RecBwdArgs {
   // kernels read their initial dh / dc from these instead of dh_pass / dc_carry (which are then pure scratch): the caller's
   // two transposing copies (two launches of ~5 us in front of the recurrence) disappear.
   const float* dh_bm; const float* dc_bm;
+  // optional (persistent counter-protocol kernel): [dirs][ceil(B / 16)][4 * Hd] partial column sums of dgates -- the LSTM's bias
+  // gradients summed over each workgroup's 16 rows and all L steps by the threads that form the values (vln_lstm_seq_bwd)
+  float* bias_part;
 };
 __global__ __launch_bounds__(256) void state_bm_to_db_kernel(const float* dh_bm, const float* dc_bm, float* dh, float* dc, int B, int dirs, int Hd) {
   const long n = (long)B * dirs * Hd;
@@ -1059,10 +1062,32 @@ extern "C" int vln_wgrad_ride_stats(int64_t out[2]) {
   return VLN_OK;
 }
 
+// Fallback producer of vln_lstm_seq_bwd's `bias_partials` for the recurrence forms that do not accumulate them themselves (granule
+// protocol, per-step launches): the same [dirs][ceil(B / 16)][4 * Hd] layout from the finished dgates.
+__global__ __launch_bounds__(256) void bias_part_from_dgates_kernel(const float* dgates, float* part, int B, int L, int Hd, int dirs) {
+  const int nbb = (B + 15) / 16, G4 = 4 * Hd;
+  const int d = (int)blockIdx.x / nbb, bb = (int)blockIdx.x % nbb;
+  const int c = (int)blockIdx.y * 256 + (int)threadIdx.x;
+  if (c >= G4) return;
+  float t = 0.f;
+  for (int s = 0; s < L; ++s)
+    for (int r = 0; r < 16; ++r) {
+      const int b = bb * 16 + r;
+      if (b < B) t += dgates[((long)s * B + b) * (dirs * G4) + (long)d * G4 + c];
+    }
+  part[((long)d * nbb + bb) * G4 + c] = t;
+}
+static int bias_part_fallback(hipStream_t st, const float* dgates, float* part, int B, int L, int Hd, int dirs) {
+  if (!part) return VLN_OK;
+  VLN_LAUNCH(bias_part_from_dgates_kernel, dim3(dirs * ((B + 15) / 16), (4 * Hd + 255) / 256), dim3(256), 0, st, dgates, part, B, L, Hd, dirs);
+  VLN_CHECK_LAUNCH("bias_part_from_dgates");
+  return VLN_OK;
+}
+
 static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                               const float* act, const float* tanh_c, const float* cprev, float* dgates, float* dh_pass,
                               float* dc_carry, int B, int L, int Hd, int dirs, const float* dh_bm, const float* dc_bm) {
-  RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0, nullptr, nullptr};
+  RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 0, nullptr, nullptr, nullptr};
   if (dh_bm) {          // per-step launches keep their running state in dh_pass / dc_carry: bring the initial values into that layout
     long nb = ((long)B * dirs * Hd + 255) / 256;
     VLN_LAUNCH(state_bm_to_db_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, st, dh_bm, dc_bm, dh_pass, dc_carry, B, dirs, Hd);
@@ -1083,7 +1108,7 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
                                 float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
-                                int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s) {
+                                int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials, vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2 || ((dh_init_bm == nullptr) != (dc_init_bm == nullptr))) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
   const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
@@ -1119,7 +1144,8 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
       r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
       if (r) return r;
     }
-    RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1, dh_bm, dc_bm};
+    RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1, dh_bm, dc_bm,
+                 bwd_granules() ? nullptr : bias_partials};
     dim3 grid(Hd / 16, dirs, (B + 15) / 16);
     unsigned* cw = (unsigned*)sync_ws;
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
@@ -1140,13 +1166,16 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
                                 : launch_persist_bwd<float>(st, a, cw + 64, cw + 32, exch, grid, riders);
     }
     header_mark(sync_ws, r == VLN_OK && self_cleaning);
+    if (r == VLN_OK && bwd_granules()) r = bias_part_fallback(st, dgates, bias_partials, B, L, Hd, dirs);
     return r;
   }
   if (have_ride) { int rr = ride_issue_alone((hipStream_t)s, pend); if (rr) return rr; }
   struct { const void* p[11]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_bm, dc_bm},
                                                  {wtype, B, L, Hd, dirs}};
   static GraphCache cache;
-  return cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
+  int rc = cache.run((hipStream_t)s, &key, sizeof(key), [&](hipStream_t st) {
     return lstm_seq_bwd_issue(st, dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, dh_bm, dc_bm);
   });
+  if (rc == VLN_OK) rc = bias_part_fallback((hipStream_t)s, dgates, bias_partials, B, L, Hd, dirs);
+  return rc;
 }

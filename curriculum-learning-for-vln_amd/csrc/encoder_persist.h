@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   }
   __syncthreads();
 
+  float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;    // this (row, unit)'s dgates summed over the steps: the bias gradients' partial sums
   for (int step = L - 1; step >= 0; --step) {
     const int k = L - 1 - step;                // steps already processed
     const int t = (d == 0) ? step : (L - 1 - step);
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
       float* dg = a.dgates + row * G + (long)d * 4 * HD + j;
       dg[0] = g0; dg[HD] = g1; dg[2 * HD] = g2; dg[3 * HD] = g3;
     }
+    bs0 += g0; bs1 += g1; bs2 += g2; bs3 += g3;     // (zeros at padded steps and rows, like the stored dgates)
     if (step == 0) break;                      // nobody consumes a partial dh of the last processed step
     float* tr = &tile[bl * LDT + jl];
     tr[0] = g0; tr[16] = g1; tr[32] = g2; tr[48] = g3;
@@ -468,6 +470,20 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     VLN_STAMP(4);
     group_arrive(cnt, jb, (unsigned)k + 1u);
     VLN_STAMP(5);
+  }
+  if (a.bias_part) {
+    // the 16 rows' sums through the (now free) dgates tile, added in row order: [d][batch block][gate * HD + unit]
+    __syncthreads();
+    float* tr = &tile[bl * LDT + jl];
+    tr[0] = bs0; tr[16] = bs1; tr[32] = bs2; tr[48] = bs3;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += tile[r * LDT + threadIdx.x];
+      const int gate = threadIdx.x >> 4, u = threadIdx.x & 15;
+      a.bias_part[((long)(d * ix.nbb + ix.bb) * 4 + gate) * HD + j0 + u] = t;
+    }
   }
 #if !VLN_SYNC_FLAGS
   // Leave the group's counter as the launch found it (zero): every workgroup of the group has passed its LAST wait on it by

@@ -159,9 +159,14 @@ class _EncoderFn(torch.autograd.Function):
                 dc_carry = ops.zeros(dirs, B, Hd, **f32)
                 init = (None, None)
             dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
+            # the bias gradients' partial sums (one row per block of 16 episodes) come out of the recurrence itself: its threads
+            # hold every dgates value they store; the column sum below then reads [B / 16, 4 Hd] instead of [L * B, 4 Hd]
+            nbb = (B + 15) // 16
+            bias_part = ops.empty(dirs, nbb, 4 * Hd, **f32)
             _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
                                             _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs,
-                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq + 1 if offset.seq >= 0 else -1, _stream()),
+                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq + 1 if offset.seq >= 0 else -1, _p(bias_part),
+                                            _stream()),
                        "vln_lstm_seq_bwd")
             cbt = ops.ColsumBatch()       # ... and its bias gradients
             wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode
@@ -189,11 +194,12 @@ class _EncoderFn(torch.autograd.Function):
                     else:
                         grads[name] = torch.empty_like(p)
                         outs.append((grads[name], False))
+                bp = bias_part[d]                                             # [B / 16, 4 Hd]: this direction's partial sums
                 if len(outs) == 2 and outs[0][1] == outs[1][1]:
-                    cbt.add(dg, outs[0][0], outs[1][0], outs[0][1])           # one pass over dgates, two destinations
+                    cbt.add(bp, outs[0][0], outs[1][0], outs[0][1])           # one pass over the partials, two destinations
                 else:
                     for o, acc in outs:
-                        cbt.add(dg, o, None, acc)
+                        cbt.add(bp, o, None, acc)
             wb.run()
             cbt.run()
             need_dx = (k > 0) or mod.embedding.weight.requires_grad

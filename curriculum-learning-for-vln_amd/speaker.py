@@ -78,7 +78,7 @@ class _LSTMSeqFn(torch.autograd.Function):
         dyc = dy.contiguous() if dy is not None else None
         _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), wtype, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
                                         _p(dh_pass), _p(dc_carry), None, None, B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
-                                        -1, _lib.raw_stream()), "vln_lstm_seq_bwd")
+                                        -1, None, _lib.raw_stream()), "vln_lstm_seq_bwd")
         grads = []
         sb = dt != torch.float32                     # bf16 mode: split-bf16 contractions (fp32 accumulation)
         for d in range(dirs):

@@ -644,7 +644,12 @@ int vln_get_split_attention(void);
 int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act,
                      const float* tanh_c, const float* cprev, float* dgates, float* dh_pass, float* dc_carry,
                      const float* dh_init_bm /*nullable*/, const float* dc_init_bm /*nullable*/, int B, int L,
-                     int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, vln_stream_t s);
+                     int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq,
+                     float* bias_partials /* nullable out (ABI v14): [dirs][ceil(B / 16)][4 * Hd] = dgates' columns of each direction summed
+                     over the L steps and the 16 rows of a batch block -- the LSTM's bias gradients (b_ih and b_hh receive the same sum,
+                     policy: autograd of nn.LSTM) are the sum over the batch blocks, a [ceil(B / 16), 4 * Hd] column sum instead of a pass
+                     over the [L * B, 4 * Hd] dgates; the persistent kernel's own threads accumulate them, other forms add one launch */,
+                     vln_stream_t s);
 
 /* ---- EnvDropDecoder.forward as one call (policy.py:208-246) and its backward ---------------------- */
 
