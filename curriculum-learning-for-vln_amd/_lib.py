@@ -205,6 +205,7 @@ SIGNATURES = {
     "vln_wgrad_grouped": (i32, [ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum": (i32, [ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_colsum_grouped": (i32, [ptr, i32, i32, ptr, i64, ptr]),
+    "vln_linear_fwd_slabs": (i32, [ptr, i64, ptr, i32, i64, i32, i32, i32, ptr, i64, C.POINTER(i32), ptr]),
     "vln_wgrad_ride_post": (i32, [ptr, i32, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_wgrad_ride_flush": (i32, [ptr]),
     "vln_wgrad_ride_stats": (i32, [C.POINTER(i64)]),

@@ -155,6 +155,13 @@ extern "C" int64_t vln_struct_size(const char* name) {
 }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
+extern "C" int vln_linear_fwd_slabs(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, int M, int N, int K, float* ws,
+                                    int64_t ws_floats, int* n_slabs, vln_stream_t s) {
+  if (!X || !W || !ws || !n_slabs || M <= 0 || N <= 0 || K <= 0 || ws_floats < (int64_t)M * N) {
+    set_error("vln_linear_fwd_slabs: null pointer, bad dims, or a workspace below one [M, N] slab"); return VLN_ERR_ARG;
+  }
+  return gemm_nt((hipStream_t)s, X, ldx, W, wtype, ldw, nullptr, 0, M, N, K, nullptr, ACT_NONE, ws, ws_floats, n_slabs);
+}
 extern "C" int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y,
                               int64_t ldy, int M, int N, int K, const float* bias, int act, float* ws,
                               int64_t ws_floats, vln_stream_t s) {

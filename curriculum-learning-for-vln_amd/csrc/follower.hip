@@ -61,10 +61,12 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   if (io->p_drop > 0.f)      // dropout over cat(a_prev, pano) (policy.py:49-51), in place
     RUN(scale_dropout(st, io->xcat, XK, io->xcat, XK, B, A + F, tls_drop(io->seed, io->off, io->p_drop)));
   // (2) LSTM cell; drop(h1) lands in its tcat block
-  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
+  int gate_slabs = 1;
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, &gate_slabs));
   {
     LstmPwFwd a{};
-    a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
+    a.gates = io->ws; a.nsplit = gate_slabs; a.slab_stride = (long)B * 4 * H; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
     a.c0 = io->c0; a.ldc0 = H; a.h1 = io->h1; a.ldh1 = H; a.c1 = io->c1; a.ldc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = tls_drop(io->seed, io->off + 1, io->p_drop); a.B = B; a.H = H;
     RUN(lstm_pointwise_fwd(st, a));

@@ -110,10 +110,12 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
   RUN(gemm_nt(st, io->h0, H, w->w_vh, wt(1), H, io->vq, M, B, M, H, w->b_vh, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(attn_fwd_rows(st, io->cand_rep, W_F32, io->vq, M, io->cand_mask, io->move_w, io->xcat + M, XK, io->dots, B, C, M));
   // (5) LSTM cell on [prev_rep | moves | words | h0]; drop(h1) lands in its tcat block
-  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt(2), XK, io->gates, 4 * H, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
+  int gate_slabs = 1;
+  RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt(2), XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, &gate_slabs));
   {
     LstmPwFwd a{};
-    a.gates = io->gates; a.nsplit = 1; a.slab_stride = 0; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
+    a.gates = io->ws; a.nsplit = gate_slabs; a.slab_stride = (long)B * 4 * H; a.bias_a = w->b_ih; a.bias_b = w->b_hh;
     a.c0 = io->c0; a.ldc0 = H; a.h1 = io->h1; a.ldh1 = H; a.c1 = io->c1; a.ldc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.h1_drop = io->tcat + H; a.ldh1d = 2 * H; a.drop = tls_drop(io->seed, io->off_h1, io->p_drop); a.B = B; a.H = H;
     RUN(lstm_pointwise_fwd(st, a));

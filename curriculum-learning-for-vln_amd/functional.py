@@ -816,8 +816,9 @@ class MonitorCoreFn(torch.autograd.Function):
         _, move_w = ops.attn_fwd_rows(cand_rep, vq, cand_mask, out=xcat[:, M:2 * M])
         xcat[:, :M].copy_(prev_rep)
         xcat[:, 2 * M + H:].copy_(h0)
-        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), False), split=isinstance(dtype, tuple) and "w_cat" in dtype[1])
-        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off_h1, pd, True)
+        # the gate product's split-K slabs go straight to the pointwise launch (as in the one-call step, csrc/monitor.hip)
+        gates = ops.linear_fwd_slabs(xcat, _fused_lstm_weight(W_ih, W_hh, wdtype(dtype, "w_cat"), False), split=isinstance(dtype, tuple) and "w_cat" in dtype[1])
+        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates, b_ih.detach(), b_hh.detach(), c0, seed, off_h1, pd, True)
         tcat = ops.empty(B, 2 * H, dtype=f32, device=dev)        # [words | drop(h1)]
         tcat[:, :H].copy_(xcat[:, 2 * M:2 * M + H])
         tcat[:, H:].copy_(hd)
@@ -953,8 +954,8 @@ class FollowerCoreFn(torch.autograd.Function):
             if st:
                 _lib.check(st, "vln_scale_dropout")
         # (2) LSTM cell
-        gates = ops.linear_fwd(xcat, _fused_lstm_weight(W_ih, W_hh, dtype, False))
-        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates.view(1, B, 4 * H), b_ih.detach(), b_hh.detach(), c0, seed, off + 1, pd, True)
+        gates = ops.linear_fwd_slabs(xcat, _fused_lstm_weight(W_ih, W_hh, dtype, False))       # slabs -> the pointwise launch (csrc/follower.hip)
+        h1, c1, act, tc, hd = ops.lstm_pointwise_fwd(gates, b_ih.detach(), b_hh.detach(), c0, seed, off + 1, pd, True)
         # (3) text attention + tanh(W_out [wc ; drop(h1)])
         tq2 = ops.linear_fwd(hd, SHADOWS.get(W_tin, "n", dtype))
         tcat = E(B, 2 * H)

@@ -199,6 +199,23 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None, split=False):
     return out
 
 
+def linear_fwd_slabs(x, w, split=False, ws_floats: Optional[int] = None):
+    """x @ w.T left as its split-K partial slabs: a [n, M, N] view of the shared workspace (valid until the next op that uses the
+    workspace) whose sum over n, in order, is the product -- hand it to a consumer that adds the partials while loading
+    (`lstm_pointwise_fwd`): the form the one-call decoder steps use between the LSTM's gate product and its pointwise stage."""
+    lib = _lib.load()
+    _req(x, "x"); _req(w, "w", None)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    ws = workspace(x.device, ws_floats if ws_floats is not None else min(16 * M * N, 1 << 24))
+    wt = (F32X if split == "x6" else F32S) if (split and w.dtype == torch.float32) else _dt(w)
+    n = C.c_int32(0)
+    _lib.check(lib.vln_linear_fwd_slabs(_p(x), x.stride(0), _p(w), wt, w.stride(0), M, N, K, _p(ws), ws.numel(), C.byref(n), _stream()),
+               "vln_linear_fwd_slabs")
+    return ws[:n.value * M * N].view(n.value, M, N)
+
+
 def linear_wgrad(dy, x, out=None, accumulate=False, split_bf16=False):
     """dW[N,K] (+)= dy[Mt,N].T @ x[Mt,K].  split_bf16: both operands as bf16 hi + lo planes on the bf16 MFMA (three
     products, fp32 accumulation) instead of the exact fp32 MFMA -- the bf16 compute mode's weight gradients."""

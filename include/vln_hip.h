@@ -92,6 +92,11 @@ int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* to
  * units.py:69,106,120,144,146,181-184 and policy.py:115,124,189,204.  ws: split-K scratch (may be NULL). */
 int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y, int64_t ldy,
                    int M, int N, int K, const float* bias, int act, float* ws, int64_t ws_floats, vln_stream_t s);
+/* The same product left as its split-K partial slabs (ABI v14): slabs [*n_slabs][M,N] in ws, Y = their sum in slab order -- for a
+ * consumer that adds the partials while it loads them (vln_lstm_pointwise_fwd's `nsplit`), so that no reduce launch sits between the
+ * two.  ws_floats >= M * N; more lets the contraction split over more workgroups. */
+int vln_linear_fwd_slabs(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, int M, int N, int K, float* ws,
+                         int64_t ws_floats, int* n_slabs, vln_stream_t s);
 /* weight gradient: D[N,K] (+)= A[Mt,N]^T X[Mt,K] (autograd of the same Linear layers, batched over steps) */
 int vln_linear_wgrad(const float* A, int64_t lda, const float* X, int64_t ldx, float* D, int64_t ldd, int Mt,
                      int N, int K, int accumulate, float* ws, int64_t ws_floats, vln_stream_t s);
