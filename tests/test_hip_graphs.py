@@ -166,6 +166,22 @@ def test_decoder_gradient_ride_at_baseline_size(vln):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the gradient ride and its own launches"
 
 
+def test_rides_fall_back_to_their_own_launches_when_the_recurrence_fills_the_chip(vln):
+    """B = 128 with a bidirectional 256-unit encoder: 256 recurrence workgroups = every CU of an MI355X, no room for passengers.  The
+    rollout gather, the tail of the pulled batch (`launch_fetch_part`) and the decoder's gradient ride (`ride_issue_alone`) must then
+    run as their own launches with the same results: pulled batches + rides against device-resident batches without the gradient ride."""
+    ref, _, _ = _run(vln, torch.bfloat16, False, "ride", n_eager=2, n_more=2, source="device", ride=False, shape=(128, 24, 4, 6))
+    before = vln.ops.GradRide.stats()
+    got, _, _ = _run(vln, torch.bfloat16, False, "ride", n_eager=2, n_more=2, source="pull", ride=True, shape=(128, 24, 4, 6))
+    after = vln.ops.GradRide.stats()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus <= 256:
+        assert after["issued_alone"] - before["issued_alone"] == 4 and after["carried"] == before["carried"]
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):
+            assert torch.equal(x, y), f"iteration {i}: {what} differ"
+
+
 def test_gradient_ride_without_a_carrier_is_issued_by_the_flush(vln):
     """A posted ride that no backward recurrence picks up: vln_wgrad_ride_flush (the autograd engine's end-of-backward callback in
     EnvDropDecoder._deferred_wgrads) issues it as its own launches -- same results as WgradBatch / ColsumBatch run directly."""
