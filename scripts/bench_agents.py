@@ -215,7 +215,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
 
     read_actions: the reference's loop shape for the sampled rollout (envdrop.py:196-206): after EVERY step the sampled action goes
     to the host (D2H into pinned memory, stream synchronize) where the simulator would take it -- here a host bookkeeping of the
-    `ended` flags stands in for env.step -- before the next step is issued.
+    `ended` flags stands in for env.step -- before the next step is issued.  "poll" (graph form): the host spins on the pinned words
+    (armed with -1 before the replay) instead of synchronising the stream: the wake-up of a synchronisation costs ~17 us per step.
     graph (default: args.graph): the iteration as graphs.SegmentedIterationGraph -- [graph: prologue, the IL rollout, the RL
     encoder, RL step 0 + draw + D2H of a_0] [host: wait, read a_0] [graph: RL step 1 ...] ... [graph: last step, critic, A2C loss,
     the backward of BOTH rollouts, clip + RMSprop]: T_rl + 1 graph launches per iteration instead of ~250 Python-driven calls; the
@@ -240,6 +241,8 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
     ended = (lens_rl < T_rl).to(dev)
     clock = vln.DeviceClock(dev).attach(enc, dec, cri) if graph else None
     a_host = torch.zeros(T_rl, B, dtype=torch.int64).pin_memory()
+    a_np = a_host.numpy()         # the same pinned memory, for the polling form of the action read
+    poll = read_actions == "poll"
     host_ended = [0]              # what the stand-in for env.step keeps: episodes that chose STOP so far (read, never fed back)
 
     def gather_of(s):
@@ -279,7 +282,14 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
             a_host[t].copy_(a, non_blocking=True)                               # envdrop.py:198: cpu_a_t = a_t.cpu().numpy()
 
     def host_step(t):
-        if read_actions:
+        if poll and not torch.cuda.is_current_stream_capturing() and polling[0]:
+            # the D2H copy of a_t is the segment's last node: the host spins on the pinned words (armed with -1 before the launch)
+            # instead of paying a stream synchronisation's wake-up; sampled actions are >= 0
+            row = a_np[t]
+            while (row < 0).any():
+                pass
+            host_ended[0] = int((row == C - 1).sum())
+        elif read_actions:
             torch.cuda.current_stream().synchronize()
             host_ended[0] = int((a_host[t] == C - 1).sum())                     # stand-in for env.step(cpu_a_t): the host reads the actions
 
@@ -342,18 +352,31 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
             out = r if r is not None else out
         return out
 
+    polling = [False]
+
+    def captured():
+        sg = vln.SegmentedIterationGraph(segs, clock).capture()
+        if not poll:
+            return sg.replay
+        polling[0] = True
+
+        def run():
+            a_np[:] = -1              # arm the pinned words (every replayed segment's copy overwrites its row)
+            return sg.replay()
+        return run
+
     if build_only:          # tests: (eager iteration, a function that captures and returns the replay, the state to compare)
-        return it, (lambda: vln.SegmentedIterationGraph(segs, clock).capture().replay), dict(opt=opt, enc=enc, dec=dec, cri=cri, a_host=a_host, clock=clock)
+        return it, captured, dict(opt=opt, enc=enc, dec=dec, cri=cri, a_host=a_host, clock=clock)
     if graph:
         for _ in range(3):
             it()
-        run = vln.SegmentedIterationGraph(segs, clock).capture().replay
+        run = captured()
     else:
         run = it
     ms = timed(run)
     return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3),
                 iteration=(f"{T_rl + 1} hipGraph segments" if graph else "per-step hipGraphs, Python-driven"),
-                per_step_action_read=bool(read_actions), plan_hits=dec.plan_hits, arena_misses=arena.misses,
+                per_step_action_read=("host spins on the pinned action words" if (poll and graph) else bool(read_actions)), plan_hits=dec.plan_hits, arena_misses=arena.misses,
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
@@ -370,6 +393,7 @@ def main():
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower / a2c: eager launches instead of one hipGraph (a2c: a sequence of graph segments) per iteration")
     ap.add_argument("--no-action-read", action="store_true", help="a2c: (A/B) the sampled actions never leave the device")
+    ap.add_argument("--poll-actions", action="store_true", help="a2c: the host spins on the pinned action words instead of synchronising the stream after every step")
     ap.add_argument("--no-chain-il", action="store_true", help="a2c: (A/B) the teacher-forced rollout's steps not chained")
     ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE", help="(A/B) vln_set_tunable(ID, VALUE) before anything runs")
     ap.add_argument("--two-bn-mlp-calls", action="store_true", help="monitor: the BN-MLP called twice per step like the reference (A/B) "
@@ -398,7 +422,7 @@ def main():
     if a.which in ("speaker", "all"):
         print(json.dumps(run_speaker()), flush=True)
     if a.which in ("a2c", "all"):
-        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=not a.no_action_read, chain_il=not a.no_chain_il)), flush=True)
+        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=("poll" if a.poll_actions else not a.no_action_read), chain_il=not a.no_chain_il)), flush=True)
 
 
 if __name__ == "__main__":
