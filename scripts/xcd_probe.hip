@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(unsigned* counter, int rou
       dummy = 1;
     }
     __syncthreads();
-    if (mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (mode == 0 || mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // mode 2: acquire only (L1 + L2 invalidate), no write-back
   }
   if (dummy == 12345) scratch[0] = 1.f;
 }
@@ -95,13 +95,13 @@ int main() {
     for (int workers : {32, 64, 128}) {
       if (!xcd_only && workers == 64) continue;
       const int grid = xcd_only ? workers * 8 : workers;
-      for (int mode = 0; mode < 2; ++mode) {
+      for (int mode = 0; mode < 3; ++mode) {
         auto run = [&](int rounds) {
           return timed([&] { CK(hipMemsetAsync(counter, 0, 4)); hipLaunchKernelGGL(barrier_kernel, dim3(grid), dim3(256), 0, 0, counter, rounds, xcd_only, workers, scratch, mode); }, 20);
         };
         const float t0 = run(0), t1 = run(100);
         printf("  %s  %4d workgroups, %s: %6.2f us per barrier\n", xcd_only ? "ONE XCD " : "all XCDs", workers,
-               mode == 0 ? "agent-scope release / acquire fences" : "no fences (drained stores only)      ", (t1 - t0) * 1e3 / 100);
+               mode == 0 ? "agent-scope release / acquire fences" : mode == 1 ? "no fences (drained stores only)      " : "drained stores + acquire fence only ", (t1 - t0) * 1e3 / 100);
       }
     }
   return 0;
