@@ -34,6 +34,28 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ s
   if (acc == 0x12345u) sink[0] = acc;
 }
 
+// the same stream with `sc1` (agent-scope, past the L1) 16-byte buffer loads: how a consumer would read producer-written data inside
+// one launch without an invalidate
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int DEPTH>
+__global__ __launch_bounds__(256) void stream_sc1_kernel(const uint4* __restrict__ src, long n16, int xcd_only, int workers, unsigned* sink) {
+  int w = blockIdx.x;
+  if (xcd_only) { if (w & 7) return; w >>= 3; }
+  const long per = (n16 + workers - 1) / workers;
+  const long beg = (long)w * per, end = min(n16, beg + per);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(src), 0, (unsigned)(n16 * 16), 0x00020000);
+  unsigned acc = 0;
+  long i = beg + threadIdx.x;
+  for (; i + (DEPTH - 1) * 256 < end; i += DEPTH * 256) {
+    u32x4_t v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((i + k * 256) * 16), 0, 16);
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) acc += v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+  }
+  if (acc == 0x12345u) sink[0] = acc;
+}
+
 // `rounds` barriers among the `workers` participating workgroups; round r waits for the counter to reach (r + 1) * workers
 __global__ __launch_bounds__(256) void barrier_kernel(unsigned* counter, int rounds, int xcd_only, int workers, float* scratch, int mode) {
   int w = blockIdx.x;
@@ -87,6 +109,16 @@ int main() {
       const int grid = xcd_only ? workers * 8 : workers;
       float t4 = timed([&] { hipLaunchKernelGGL(stream_kernel<4>, dim3(grid), dim3(256), 0, 0, buf, n16, xcd_only, workers, sink); }, 20);
       float t8 = timed([&] { hipLaunchKernelGGL(stream_kernel<8>, dim3(grid), dim3(256), 0, 0, buf, n16, xcd_only, workers, sink); }, 20);
+      printf("  %s  %4d workgroups (%d per CU): depth 4 %7.2f us = %5.2f TB/s | depth 8 %7.2f us = %5.2f TB/s\n", xcd_only ? "ONE XCD " : "all XCDs", workers,
+             per_cu, t4 * 1e3, bytes / (t4 * 1e-3) / 1e12, t8 * 1e3, bytes / (t8 * 1e-3) / 1e12);
+    }
+  printf("the same stream with sc1 (L1-bypassing) 16-byte loads:\n");
+  for (int xcd_only = 1; xcd_only >= 0; --xcd_only)
+    for (int per_cu : {1, 4}) {
+      const int workers = (xcd_only ? 32 : 256) * per_cu;
+      const int grid = xcd_only ? workers * 8 : workers;
+      float t4 = timed([&] { hipLaunchKernelGGL(stream_sc1_kernel<4>, dim3(grid), dim3(256), 0, 0, buf, n16, xcd_only, workers, sink); }, 20);
+      float t8 = timed([&] { hipLaunchKernelGGL(stream_sc1_kernel<8>, dim3(grid), dim3(256), 0, 0, buf, n16, xcd_only, workers, sink); }, 20);
       printf("  %s  %4d workgroups (%d per CU): depth 4 %7.2f us = %5.2f TB/s | depth 8 %7.2f us = %5.2f TB/s\n", xcd_only ? "ONE XCD " : "all XCDs", workers,
              per_cu, t4 * 1e3, bytes / (t4 * 1e-3) / 1e12, t8 * 1e3, bytes / (t8 * 1e-3) / 1e12);
     }
