@@ -25,8 +25,9 @@ struct FetchArgs { const unsigned long long* slots; int ring; unsigned long long
 __device__ __forceinline__ void host_fetch_body(const FetchArgs& f, int block, int nblocks, int tid) {
   const unsigned long long n = *f.seq;
   const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(f.slots + (n % (unsigned long long)f.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-  for (long i = (long)block * 256 + tid; i < f.n16; i += (long)nblocks * 256)
-    f.dst[i] = __builtin_nontemporal_load(src + i);
+  if (src)                                       // (a slot the host never selected holds 0: nothing to pull, the sequence still advances)
+    for (long i = (long)block * 256 + tid; i < f.n16; i += (long)nblocks * 256)
+      f.dst[i] = __builtin_nontemporal_load(src + i);
   __syncthreads();
   if (tid == 0) {
     const unsigned t = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -40,8 +41,12 @@ __device__ __forceinline__ void host_fetch_body(const FetchArgs& f, int block, i
 // launch, or its own one-block launch): the slot is the one the iteration's head fetch used, i.e. (*seq - 1) % ring.
 struct FetchPart { const unsigned long long* slots; const unsigned long long* seq; u32x4* dst; long off16, n16; int ring; int on; };
 __device__ __forceinline__ void host_fetch_part_body(const FetchPart& f, int tid) {
-  const unsigned long long n = *f.seq - 1ull;
-  const u32x4* src = reinterpret_cast<const u32x4*>(__hip_atomic_load(f.slots + (n % (unsigned long long)f.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) + f.off16;
+  const unsigned long long done = *f.seq;
+  if (done == 0ull) return;                    // no head fetch has run on this ring yet: there is no current batch to take the tail of
+  const unsigned long long n = done - 1ull;
+  const u32x4* base = reinterpret_cast<const u32x4*>(__hip_atomic_load(f.slots + (n % (unsigned long long)f.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  if (!base) return;                           // an empty slot (never selected)
+  const u32x4* src = base + f.off16;
   long i = tid;
   for (; i + 7 * 256 < f.n16; i += 8 * 256) {           // eight PCIe reads in flight per thread
     u32x4 v[8];
