@@ -19,7 +19,58 @@
 #include <vector>
 #include "../curriculum-learning-for-vln_amd/csrc/vln_internal.h"
 #include "../include/vln_hip.h"
+#include <type_traits>
+#include "../curriculum-learning-for-vln_amd/csrc/step_bodies.h"
+namespace vln {
+#include "../curriculum-learning-for-vln_amd/csrc/gemm_nt_body.h"
+}
 using namespace vln;
+
+// SHARDED cell (round 4, the measured basis of DESIGN section 10's episode-sharded persistent decoder): ONE launch of 8 groups x
+// `wpg` workgroups; group g = blockIdx % 8 sits on XCD g and owns the episodes [g * B / 8, (g + 1) * B / 8): its workgroups walk ALL
+// tiles of the gate product for those rows (gemm_nt_body, the product's own K split and slab layout), meet at a barrier among the
+// group's workgroups only -- drained stores + a relaxed agent-scope counter, NO fences (one XCD = one L2) -- and apply the
+// pointwise stage to the group's rows (lstm_pw_fwd_body reading the slabs).  Same arithmetic per row as the two launches.
+__global__ __launch_bounds__(256) void sharded_cell_kernel(GemmNTArgs ga, int gx, int gy, LstmPwFwd pw, unsigned* bar, int rpg, int wpg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(2)];
+  __shared__ float sg[4][64];
+  const int group = blockIdx.x & 7, local = blockIdx.x >> 3, tid = threadIdx.x;
+  const int r0 = group * rpg;
+  GemmNTArgs a = ga;
+  a.X += (long)r0 * a.ldx; a.Y += (long)r0 * a.ldy; a.M = rpg;
+  const int nvb = gx * gy, iters = (nvb + wpg - 1) / wpg;
+  for (int it = 0; it < iters; ++it) {
+    const int v = local + it * wpg;
+    const bool active = v < nvb;
+    const int vc = active ? v : nvb - 1;
+    const VBlock vb{vc % gx, vc / gx, 0, tid, smem};
+    gemm_nt_body<bf16_raw, 2, true, 1>(a, vb, active, gemm_nt_nsteps(a, vb.by, 64), [] {});
+    __syncthreads();
+  }
+  // the group's barrier (single use per launch; the last workgroup through leaves both words zero)
+  unsigned* cnt = bar + group * 64;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)wpg) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) break;
+    }
+    const unsigned through = __hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (through + 1u == (unsigned)wpg) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  LstmPwFwd p = pw;
+  const long ro = (long)r0;
+  p.gates += ro * 4 * p.H; p.c0 += ro * p.ldc0; p.h1 += ro * p.ldh1; p.c1 += ro * p.ldc1; p.act += ro * 4 * p.H; p.tanh_c1 += ro * p.H; p.B = rpg;
+  const int groups64 = (rpg * p.H + 63) / 64;
+  lstm_pw_fwd_body(p, local, wpg, (groups64 + wpg - 1) / wpg, tid, sg);
+}
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -160,6 +211,25 @@ int main() {
   timeit("fused cell B: 32 rows x 16 gate columns per workgroup, 256 workgroups (1 launch)", [&] {
     hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
   });
+  // the sharded cell: the product's split (kchunk, slab count) taken from gemm_nt itself
+  unsigned* bar; hipMalloc(&bar, 8 * 64 * 4); hipMemset(bar, 0, 8 * 64 * 4);
+  const int steps_per = (K / 64 + nsplit - 1) / nsplit;
+  GemmNTArgs sga{}; sga.X = X; sga.ldx = K; sga.W = W; sga.ldw = K; sga.Y = ws; sga.ldy = N; sga.slab_stride = (long)B * N; sga.bias = nullptr; sga.act = ACT_NONE;
+  sga.M = B; sga.N = N; sga.K = K; sga.kchunk = steps_per * 64; sga.xvec = 1; sga.wvec = 1; sga.xcd = 0;
+  auto spw = [&]() { LstmPwFwd pw{}; pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
+                     pw.h1 = h1; pw.ldh1 = H; pw.c1 = c1; pw.ldc1 = H; pw.act = act; pw.tanh_c1 = tc; pw.h1_drop = nullptr; pw.B = B; pw.H = H; return pw; };
+  for (int wpg : {32, 64})
+    timeit(wpg == 32 ? "SHARDED cell: 8 XCD groups x 32 workgroups, 8 episodes each (1 launch, group barrier)" :
+                       "SHARDED cell: 8 XCD groups x 64 workgroups, 8 episodes each (1 launch, group barrier)", [&] {
+      hipLaunchKernelGGL(sharded_cell_kernel, dim3(8 * wpg), dim3(256), 0, 0, sga, N / 64, nsplit, spw(), bar, B / 8, wpg);
+    });
+  {
+    const float base = graph_us([&](hipStream_t) {});
+    for (int wpg : {32, 64}) {
+      const float tsh = graph_us([&](hipStream_t st) { hipLaunchKernelGGL(sharded_cell_kernel, dim3(8 * wpg), dim3(256), 0, st, sga, N / 64, nsplit, spw(), bar, B / 8, wpg); });
+      printf("inside a hipGraph: sharded cell, %d workgroups per XCD group: %6.2f us\n", wpg, tsh - base);
+    }
+  }
   {
     const float base = graph_us([&](hipStream_t) {});
     auto pw_of = [&]() { LstmPwFwd pw{}; pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
@@ -178,6 +248,15 @@ int main() {
     pw.gates = ws; pw.nsplit = nsplit; pw.slab_stride = (long)B * N; pw.bias_a = bi; pw.bias_b = bh; pw.c0 = c0; pw.ldc0 = H;
     pw.h1 = h1b; pw.ldh1 = H; pw.c1 = c1b; pw.ldc1 = H; pw.act = actb; pw.tanh_c1 = tcb; pw.h1_drop = nullptr; pw.B = B; pw.H = H;
     lstm_pointwise_fwd(0, pw);
+  }
+  hipLaunchKernelGGL(sharded_cell_kernel, dim3(8 * 32), dim3(256), 0, 0, sga, N / 64, nsplit, spw(), bar, B / 8, 32);
+  hipDeviceSynchronize();
+  {
+    std::vector<float> a((long)B * H), b((long)B * H);
+    hipMemcpy(a.data(), h1, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), h1b, b.size() * 4, hipMemcpyDeviceToHost);
+    double md = 0;
+    for (size_t i = 0; i < a.size(); ++i) md = std::max(md, (double)fabsf(a[i] - b[i]));
+    printf("h1: max |sharded - product| = %.3e (0 = bit-identical)\n", md);
   }
   hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
   hipDeviceSynchronize();
