@@ -145,6 +145,143 @@ __global__ __launch_bounds__(256) void fused_cell_kernel(const float* __restrict
   }
 }
 
+// SHARDED cell, streaming body (what an episode-sharded decoder's GEMM stage has to look like): group g = blockIdx % 8 (one XCD) owns
+// R = B / 8 episodes.  Its activation rows [R, K] are split hi + lo into two bf16 LDS planes ONCE (88 KB at K = 2752: one workgroup per
+// CU); every wave then owns 16 gate columns x a K range and STREAMS its 16 weight rows with kDepth x 64 k of loads in flight per
+// lane -- no LDS staging per K-step, no barrier in the loop.  K is split over `ksplit` waves of the SAME workgroup (partials meet in
+// LDS), so the pre-activations leave the workgroup finished: no slabs.  Then the group's fence-free barrier and the pointwise stage.
+constexpr int kSkDepth = 6;
+__global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* __restrict__ X, long ldx, const unsigned short* __restrict__ W, long ldw,
+                                                                  const float* b_ih, const float* b_hh, const float* c0, float* h1, float* c1, float* act,
+                                                                  float* tanh_c, float* pre /*[KH][B, 4H] scratch*/, unsigned* bar, int B, int H, int K, int wpg,
+                                                                  int NG /*groups: 8 or 4 (XCDs used)*/, int KH /*K parts, each on wpg / KH workgroups*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  const int R = B / NG;                                  // rows of the group (<= 16)
+  const int group = blockIdx.x & 7, tid = threadIdx.x;
+  if (group >= NG) return;
+  const int kh = (int)(blockIdx.x >> 3) % KH, local = (int)(blockIdx.x >> 3) / KH;      // K part, workgroup index inside the part
+  const int wph = wpg / KH;                                                               // workgroups per K part
+  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fq = lane >> 4;
+  const int r0 = group * R;
+  const int ksteps_all = K / 64;
+  const int hs0 = (int)((long)ksteps_all * kh / KH), hs1 = (int)((long)ksteps_all * (kh + 1) / KH);      // this part's K-steps
+  const int Kp = (hs1 - hs0) * 64, kof = hs0 * 64;
+  const int LDP = Kp + 8;                                // plane row stride in bf16 (16-byte pad)
+  __bf16* ph = reinterpret_cast<__bf16*>(dyn);
+  __bf16* pl = ph + (long)R * LDP;
+  float* red = reinterpret_cast<float*>(pl + (long)R * LDP);          // [8 waves][16 rows][17]
+  // (1) activations -> LDS planes
+  {
+    const long total4 = (long)R * (Kp / 4);
+    constexpr int kU = 12;                                // float4 loads in flight per thread (R = 16, Kp = 1408: 11 per thread)
+    for (long e0 = tid; e0 < total4; e0 += 512L * kU) {
+      float4 v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const long e = min(e0 + 512L * u, total4 - 1);
+        const int r = (int)(e / (Kp / 4)), k4 = (int)(e % (Kp / 4)) * 4;
+        v[u] = *reinterpret_cast<const float4*>(X + (long)(r0 + r) * ldx + kof + k4);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const long e = e0 + 512L * u;
+        if (e < total4) {
+          const int r = (int)(e / (Kp / 4)), k4 = (int)(e % (Kp / 4)) * 4;
+          const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          bf16x4_t h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { h[j] = (__bf16)x[j]; l[j] = (__bf16)(x[j] - (float)h[j]); }
+          *reinterpret_cast<bf16x4_t*>(ph + (long)r * LDP + k4) = h;
+          *reinterpret_cast<bf16x4_t*>(pl + (long)r * LDP + k4) = l;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // (2) every wave: column tile ct (16 gate columns), K part kp of ksplit
+  const int N = 4 * H, ntiles = N / 16;
+  const int waves_g = wph * 8;                           // waves of this K part
+  const int ksplit = max(1, waves_g / ntiles);           // waves per column tile (all in ONE workgroup: ksplit divides 8)
+  const int gw = local * 8 + wave;                       // wave index in the part
+  // (the groups read the SAME weights: each starts at another column tile so that the XCDs do not walk the same lines -- the same
+  // memory channels -- in lockstep)
+  const int ct0 = gw / ksplit, kp = gw % ksplit;
+  const int ct = ct0 < ntiles ? (ct0 + group * (ntiles / 8)) % ntiles : ct0;
+  const int ksteps = hs1 - hs0;                          // 64 k per step (two MFMA k-blocks), relative to the part's first
+  const int sbeg = (int)((long)ksteps * kp / ksplit), send = (int)((long)ksteps * (kp + 1) / ksplit);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (ct < ntiles) {
+    const unsigned short* wrow = W + (long)(ct * 16 + fi) * ldw + kof + fq * 16;      // 32 contiguous bytes per lane and step: whole 128-byte lines per row
+    bf16x8_t wq[kSkDepth][2];
+    auto ldw_ = [&](int buf, int s) {
+      wq[buf][0] = *reinterpret_cast<const bf16x8_t*>(wrow + (long)s * 64);
+      wq[buf][1] = *reinterpret_cast<const bf16x8_t*>(wrow + (long)s * 64 + 8);
+    };
+    // every load is UNCONDITIONAL (clamped step index): a branch around a load closes the loads in flight with vmcnt(0)
+#pragma unroll
+    for (int d = 0; d < kSkDepth; ++d) ldw_(d, min(sbeg + d, send - 1));
+    const bool row_ok = fi < R;
+    const __bf16* xh = ph + (long)(row_ok ? fi : 0) * LDP + fq * 16;
+    const __bf16* xl = pl + (long)(row_ok ? fi : 0) * LDP + fq * 16;
+    for (int s0 = sbeg; s0 < send; s0 += kSkDepth) {
+#pragma unroll
+      for (int d = 0; d < kSkDepth; ++d) {
+        const int s = s0 + d;
+        {
+          const bf16x8_t w0 = wq[d][0], w1 = wq[d][1];
+          ldw_(d, min(s + kSkDepth, send - 1));
+          const int sx = min(s, send - 1);
+          bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xh + (long)sx * 64), a1 = *reinterpret_cast<const bf16x8_t*>(xh + (long)sx * 64 + 8);
+          bf16x8_t l0 = *reinterpret_cast<const bf16x8_t*>(xl + (long)sx * 64), l1 = *reinterpret_cast<const bf16x8_t*>(xl + (long)sx * 64 + 8);
+          if (!row_ok || s >= send) { a0 = bf16x8_t{}; a1 = bf16x8_t{}; l0 = bf16x8_t{}; l1 = bf16x8_t{}; }      // (steps past the end multiply zeros)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partials of the ksplit waves of a tile meet in LDS (they are consecutive waves of this workgroup)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + fq * 4 + r) * 17 + fi] = acc[r];
+  __syncthreads();
+  if (kp == 0 && ct < ntiles) {
+    for (int e = lane; e < R * 16; e += 64) {
+      const int r = e >> 4, c = e & 15;
+      float v = 0.f;
+      for (int q = 0; q < ksplit; ++q) v += red[((wave + q) * 16 + r) * 17 + c];
+      pre[(long)kh * B * N + (long)(r0 + r) * N + ct * 16 + c] = v;
+    }
+  }
+  // (3) the group's barrier
+  unsigned* cnt = bar + group * 64;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)wpg) { __builtin_amdgcn_s_sleep(2); if (++spins > (1u << 24)) break; }
+    const unsigned through = __hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (through + 1u == (unsigned)wpg) { __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+  __syncthreads();
+  // (4) pointwise on the group's rows (pre-activations written by the group's other workgroups: same L2, not in this CU's L1)
+  for (int e = (int)(blockIdx.x >> 3) * 512 + tid; e < R * H; e += wpg * 512) {
+    const int r = r0 + e / H, j = e % H;
+    const float* g = pre + (long)r * N + j;
+    float gi = b_ih[j] + b_hh[j], gf = b_ih[H + j] + b_hh[H + j], gg = b_ih[2 * H + j] + b_hh[2 * H + j], go = b_ih[3 * H + j] + b_hh[3 * H + j];
+    for (int q = 0; q < KH; ++q) { const float* gq = g + (long)q * B * N; gi += gq[0]; gf += gq[H]; gg += gq[2 * H]; go += gq[3 * H]; }
+    const float si = 1.f / (1.f + __expf(-gi)), sf = 1.f / (1.f + __expf(-gf)), tg = tanhf(gg), so = 1.f / (1.f + __expf(-go));
+    const long o = (long)r * H + j;
+    const float cn = sf * c0[o] + si * tg, tcv = tanhf(cn);
+    h1[o] = so * tcv; c1[o] = cn; tanh_c[o] = tcv;
+    float* a = act + (long)r * N + j;
+    a[0] = si; a[H] = sf; a[2 * H] = tg; a[3 * H] = so;
+  }
+}
+
 __global__ void fill_f32_k(float* p, long n, float v) { for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v * 0.01f + (float)(i % 97) * 0.003f - 0.1f; }
 __global__ void fill_w_k(unsigned short* p, long n) { for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { float f = ((float)((i * 2654435761u) % 1000) - 500.f) * 4e-5f; p[i] = (unsigned short)(__float_as_uint(f) >> 16); } }
 
@@ -223,6 +360,24 @@ int main() {
                        "SHARDED cell: 8 XCD groups x 64 workgroups, 8 episodes each (1 launch, group barrier)", [&] {
       hipLaunchKernelGGL(sharded_cell_kernel, dim3(8 * wpg), dim3(256), 0, 0, sga, N / 64, nsplit, spw(), bar, B / 8, wpg);
     });
+  // the streaming form: one 512-thread workgroup per CU (88 KB of LDS planes), 32 per XCD group
+  float* pre; hipMalloc(&pre, 2L * B * N * 4);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(sharded_stream_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+  int sNG = 8, sKH = 1;
+  auto stream_launch = [&](hipStream_t st) {
+    const int R_ = B / sNG, Kp = ((K / 64 + sKH - 1) / sKH) * 64;
+    const size_t sk_lds = (size_t)2 * R_ * (Kp + 8) * 2 + 8 * 16 * 17 * 4;
+    hipLaunchKernelGGL(sharded_stream_cell_kernel, dim3(8 * 32), dim3(512), sk_lds, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, pre, bar, B, H, K, 32, sNG, sKH);
+  };
+  for (int v = 0; v < 3; ++v) {
+    sNG = v == 0 ? 8 : 4; sKH = v == 0 ? 1 : 2;
+    if (v == 2) { sNG = 8; sKH = 2; }
+    char what[160]; snprintf(what, sizeof what, "SHARDED cell, streaming body: %d XCD groups x 32 workgroups x 8 waves, %d episodes each, K in %d part(s)", sNG, B / sNG, sKH);
+    timeit(what, [&] { stream_launch(0); });
+    const float base = graph_us([&](hipStream_t) {});
+    printf("   inside a hipGraph: %6.2f us\n", graph_us([&](hipStream_t st) { stream_launch(st); }) - base);
+  }
+  sNG = 4; sKH = 2;
   {
     const float base = graph_us([&](hipStream_t) {});
     for (int wpg : {32, 64}) {
@@ -257,6 +412,15 @@ int main() {
     double md = 0;
     for (size_t i = 0; i < a.size(); ++i) md = std::max(md, (double)fabsf(a[i] - b[i]));
     printf("h1: max |sharded - product| = %.3e (0 = bit-identical)\n", md);
+  }
+  stream_launch(0);
+  hipDeviceSynchronize();
+  {
+    std::vector<float> a((long)B * H), b((long)B * H);
+    hipMemcpy(a.data(), h1, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), h1b, b.size() * 4, hipMemcpyDeviceToHost);
+    double md = 0;
+    for (size_t i = 0; i < a.size(); ++i) md = std::max(md, (double)fabsf(a[i] - b[i]));
+    printf("h1: max |sharded streaming - product| = %.3e\n", md);
   }
   hipLaunchKernelGGL(fused_cell_kernel<32>, dim3(H / 4, 2), dim3(256), 0, 0, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, B, H, K);
   hipDeviceSynchronize();

@@ -34,6 +34,26 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ s
   if (acc == 0x12345u) sink[0] = acc;
 }
 
+// NG XCDs each stream the WHOLE buffer (an episode-sharded decoder: every group reads all of the weights), 32 * per_cu workers per XCD
+template <int DEPTH>
+__global__ __launch_bounds__(256) void stream_replicated_kernel(const uint4* __restrict__ src, long n16, int ng, int workers, unsigned* sink) {
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+  if (xcd >= ng) return;
+  const long per = (n16 + workers - 1) / workers;
+  const long beg = (long)w * per, end = min(n16, beg + per);
+  unsigned acc = 0;
+  long i = beg + threadIdx.x;
+  for (; i + (DEPTH - 1) * 256 < end; i += DEPTH * 256) {
+    uint4 v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) v[k] = src[i + k * 256];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) acc += v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+  }
+  for (; i < end; i += 256) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc == 0x12345u) sink[0] = acc;
+}
+
 // the same stream with `sc1` (agent-scope, past the L1) 16-byte buffer loads: how a consumer would read producer-written data inside
 // one launch without an invalidate
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -112,6 +132,12 @@ int main() {
       printf("  %s  %4d workgroups (%d per CU): depth 4 %7.2f us = %5.2f TB/s | depth 8 %7.2f us = %5.2f TB/s\n", xcd_only ? "ONE XCD " : "all XCDs", workers,
              per_cu, t4 * 1e3, bytes / (t4 * 1e-3) / 1e12, t8 * 1e3, bytes / (t8 * 1e-3) / 1e12);
     }
+  printf("NG XCDs EACH stream the whole %.1f MB (128 workgroups per XCD, depth 8):\n", bytes / 1e6);
+  for (int ng : {1, 2, 4, 8}) {
+    const int workers = 128;
+    float t = timed([&] { hipLaunchKernelGGL(stream_replicated_kernel<8>, dim3(workers * 8), dim3(256), 0, 0, buf, n16, ng, workers, sink); }, 20);
+    printf("  %d XCD(s): %7.2f us = %5.2f TB/s aggregate, %5.2f TB/s per XCD\n", ng, t * 1e3, ng * bytes / (t * 1e-3) / 1e12, bytes / (t * 1e-3) / 1e12);
+  }
   printf("the same stream with sc1 (L1-bypassing) 16-byte loads:\n");
   for (int xcd_only = 1; xcd_only >= 0; --xcd_only)
     for (int per_cu : {1, 4}) {
