@@ -154,7 +154,8 @@ constexpr int kSkDepth = 6;
 __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* __restrict__ X, long ldx, const unsigned short* __restrict__ W, long ldw,
                                                                   const float* b_ih, const float* b_hh, const float* c0, float* h1, float* c1, float* act,
                                                                   float* tanh_c, float* pre /*[KH][B, 4H] scratch*/, unsigned* bar, int B, int H, int K, int wpg,
-                                                                  int NG /*groups: 8 or 4 (XCDs used)*/, int KH /*K parts, each on wpg / KH workgroups*/) {
+                                                                  int NG /*groups: 8 or 4 (XCDs used)*/, int KH /*K parts, each on wpg / KH workgroups*/,
+                                                                  int xmode /*0: the rows staged into LDS planes first; 1: X fragments straight from L2, split per step*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int R = B / NG;                                  // rows of the group (<= 16)
   const int group = blockIdx.x & 7, tid = threadIdx.x;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
   __bf16* pl = ph + (long)R * LDP;
   float* red = reinterpret_cast<float*>(pl + (long)R * LDP);          // [8 waves][16 rows][17]
   // (1) activations -> LDS planes
-  {
+  if (xmode == 0) {
     const long total4 = (long)R * (Kp / 4);
     constexpr int kU = 12;                                // float4 loads in flight per thread (R = 16, Kp = 1408: 11 per thread)
     for (long e0 = tid; e0 < total4; e0 += 512L * kU) {
@@ -222,6 +223,41 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
 #pragma unroll
     for (int d = 0; d < kSkDepth; ++d) ldw_(d, min(sbeg + d, send - 1));
     const bool row_ok = fi < R;
+    if (xmode == 1) {
+      // X fragments from global memory (the group's rows are L2-resident), prefetched like the weights, split hi + lo in registers
+      const float* xrow = X + (long)(r0 + (row_ok ? fi : 0)) * ldx + kof + fq * 16;
+      float4 xq[kSkDepth][4];
+      auto ldx_ = [&](int buf, int s) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xq[buf][v] = *reinterpret_cast<const float4*>(xrow + (long)s * 64 + v * 4);
+      };
+#pragma unroll
+      for (int d = 0; d < kSkDepth; ++d) ldx_(d, min(sbeg + d, send - 1));
+      for (int s0 = sbeg; s0 < send; s0 += kSkDepth) {
+#pragma unroll
+        for (int d = 0; d < kSkDepth; ++d) {
+          const int s = s0 + d;
+          const bf16x8_t w0 = wq[d][0], w1 = wq[d][1];
+          float x[16];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) { x[v * 4] = xq[d][v].x; x[v * 4 + 1] = xq[d][v].y; x[v * 4 + 2] = xq[d][v].z; x[v * 4 + 3] = xq[d][v].w; }
+          ldw_(d, min(s + kSkDepth, send - 1));
+          ldx_(d, min(s + kSkDepth, send - 1));
+          bf16x8_t a0, a1, l0, l1;
+          const bool on = row_ok && s < send;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float u0 = on ? x[j] : 0.f, u1 = on ? x[8 + j] : 0.f;
+            a0[j] = (__bf16)u0; l0[j] = (__bf16)(u0 - (float)a0[j]);
+            a1[j] = (__bf16)u1; l1[j] = (__bf16)(u1 - (float)a1[j]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc, 0, 0, 0);
+        }
+      }
+    } else {
     const __bf16* xh = ph + (long)(row_ok ? fi : 0) * LDP + fq * 16;
     const __bf16* xl = pl + (long)(row_ok ? fi : 0) * LDP + fq * 16;
     for (int s0 = sbeg; s0 < send; s0 += kSkDepth) {
@@ -241,6 +277,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1, acc, 0, 0, 0);
         }
       }
+    }
     }
   }
   // partials of the ksplit waves of a tile meet in LDS (they are consecutive waves of this workgroup)
@@ -363,21 +400,22 @@ int main() {
   // the streaming form: one 512-thread workgroup per CU (88 KB of LDS planes), 32 per XCD group
   float* pre; hipMalloc(&pre, 2L * B * N * 4);
   hipFuncSetAttribute(reinterpret_cast<const void*>(sharded_stream_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-  int sNG = 8, sKH = 1;
+  int sNG = 8, sKH = 1, sXM = 0;
   auto stream_launch = [&](hipStream_t st) {
     const int R_ = B / sNG, Kp = ((K / 64 + sKH - 1) / sKH) * 64;
     const size_t sk_lds = (size_t)2 * R_ * (Kp + 8) * 2 + 8 * 16 * 17 * 4;
-    hipLaunchKernelGGL(sharded_stream_cell_kernel, dim3(8 * 32), dim3(512), sk_lds, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, pre, bar, B, H, K, 32, sNG, sKH);
+    hipLaunchKernelGGL(sharded_stream_cell_kernel, dim3(8 * 32), dim3(512), sk_lds, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, pre, bar, B, H, K, 32, sNG, sKH, sXM);
   };
-  for (int v = 0; v < 3; ++v) {
-    sNG = v == 0 ? 8 : 4; sKH = v == 0 ? 1 : 2;
+  for (int v = 0; v < 4; ++v) {
+    sNG = (v == 0 || v == 3) ? 8 : 4; sKH = (v == 0 || v == 3) ? 1 : 2; sXM = v >= 3 ? 1 : 0;
     if (v == 2) { sNG = 8; sKH = 2; }
-    char what[160]; snprintf(what, sizeof what, "SHARDED cell, streaming body: %d XCD groups x 32 workgroups x 8 waves, %d episodes each, K in %d part(s)", sNG, B / sNG, sKH);
+    char what[200]; snprintf(what, sizeof what, "SHARDED cell, streaming body: %d XCD groups x 32 workgroups x 8 waves, %d episodes each, K in %d part(s), X %s", sNG, B / sNG, sKH,
+                             sXM ? "from L2 per step" : "staged in LDS");
     timeit(what, [&] { stream_launch(0); });
     const float base = graph_us([&](hipStream_t) {});
     printf("   inside a hipGraph: %6.2f us\n", graph_us([&](hipStream_t st) { stream_launch(st); }) - base);
   }
-  sNG = 4; sKH = 2;
+  sNG = 8; sKH = 1; sXM = 0;
   {
     const float base = graph_us([&](hipStream_t) {});
     for (int wpg : {32, 64}) {
