@@ -57,6 +57,22 @@ def test_linear_fwd_split_fp32_weights(vln, M, N, K):
     assert rel_err(y6, ref) < 4 * max(rel_err(y32, ref), 5e-7), (rel_err(y6, ref), rel_err(y32, ref))
 
 
+@pytest.mark.parametrize("M,N,K,wdt", [(64, 2048, 2752, torch.bfloat16), (128, 2048, 3072, torch.float32), (8, 512, 512, torch.bfloat16)])
+def test_linear_fwd_slabs_sum_to_the_product(vln, M, N, K, wdt):
+    """ops.linear_fwd_slabs / vln_linear_fwd_slabs: the product left as its split-K partial slabs (what the one-call decoder steps hand
+    to the LSTM's pointwise launch): their sum in slab order IS what linear_fwd returns (the reduce launch adds them in that order)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev()); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(wdt).to(dev())
+    slabs = vln.ops.linear_fwd_slabs(x, w)
+    assert slabs.dim() == 3 and tuple(slabs.shape[1:]) == (M, N) and slabs.shape[0] >= 1
+    acc = slabs[0].clone()
+    for s_ in range(1, slabs.shape[0]):
+        acc = acc + slabs[s_]
+    y = vln.ops.linear_fwd(x, w)
+    check(acc, y.double(), 1e-6, "sum of the slabs vs linear_fwd")
+    check(acc, x.double() @ w.double().t(), 1e-4 if wdt == torch.float32 else 1e-2, "sum of the slabs vs the fp64 product")
+
+
 def test_linear_fwd_strided_x(vln):
     g = torch.Generator().manual_seed(5)
     big = torch.randn(64, 300, generator=g).to(dev())
