@@ -155,7 +155,10 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
                                                                   const float* b_ih, const float* b_hh, const float* c0, float* h1, float* c1, float* act,
                                                                   float* tanh_c, float* pre /*[KH][B, 4H] scratch*/, unsigned* bar, int B, int H, int K, int wpg,
                                                                   int NG /*groups: 8 or 4 (XCDs used)*/, int KH /*K parts, each on wpg / KH workgroups*/,
-                                                                  int xmode /*0: the rows staged into LDS planes first; 1: X fragments straight from L2, split per step*/) {
+                                                                  int xmode /*0: the rows staged into LDS planes first; 1: X fragments straight from L2, split per step*/,
+                                                                  long long* stamps /*nullable: wall_clock64 at the phase ends of group 0's first workgroup*/) {
+#define SK_STAMP(i) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = wall_clock64(); } while (0)
+  SK_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int R = B / NG;                                  // rows of the group (<= 16)
   const int group = blockIdx.x & 7, tid = threadIdx.x;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
     }
   }
   __syncthreads();
+  SK_STAMP(1);
   // (2) every wave: column tile ct (16 gate columns), K part kp of ksplit
   const int N = 4 * H, ntiles = N / 16;
   const int waves_g = wph * 8;                           // waves of this K part
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
     }
     }
   }
+  SK_STAMP(2);
   // partials of the ksplit waves of a tile meet in LDS (they are consecutive waves of this workgroup)
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[(wave * 16 + fq * 4 + r) * 17 + fi] = acc[r];
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
       pre[(long)kh * B * N + (long)(r0 + r) * N + ct * 16 + c] = v;
     }
   }
+  SK_STAMP(3);
   // (3) the group's barrier
   unsigned* cnt = bar + group * 64;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
     if (through + 1u == (unsigned)wpg) { __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
   __syncthreads();
+  SK_STAMP(4);
   // (4) pointwise on the group's rows (pre-activations written by the group's other workgroups: same L2, not in this CU's L1)
   for (int e = (int)(blockIdx.x >> 3) * 512 + tid; e < R * H; e += wpg * 512) {
     const int r = r0 + e / H, j = e % H;
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(512) void sharded_stream_cell_kernel(const float* _
     float* a = act + (long)r * N + j;
     a[0] = si; a[H] = sf; a[2 * H] = tg; a[3 * H] = so;
   }
+  SK_STAMP(5);
 }
 
 __global__ void fill_f32_k(float* p, long n, float v) { for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v * 0.01f + (float)(i % 97) * 0.003f - 0.1f; }
@@ -401,10 +409,11 @@ int main() {
   float* pre; hipMalloc(&pre, 2L * B * N * 4);
   hipFuncSetAttribute(reinterpret_cast<const void*>(sharded_stream_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   int sNG = 8, sKH = 1, sXM = 0;
+  long long* sStamps = nullptr;
   auto stream_launch = [&](hipStream_t st) {
     const int R_ = B / sNG, Kp = ((K / 64 + sKH - 1) / sKH) * 64;
     const size_t sk_lds = (size_t)2 * R_ * (Kp + 8) * 2 + 8 * 16 * 17 * 4;
-    hipLaunchKernelGGL(sharded_stream_cell_kernel, dim3(8 * 32), dim3(512), sk_lds, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, pre, bar, B, H, K, 32, sNG, sKH, sXM);
+    hipLaunchKernelGGL(sharded_stream_cell_kernel, dim3(8 * 32), dim3(512), sk_lds, st, X, (long)K, W, (long)K, bi, bh, c0, h1, c1, act, tc, pre, bar, B, H, K, 32, sNG, sKH, sXM, sStamps);
   };
   for (int v = 0; v < 4; ++v) {
     sNG = (v == 0 || v == 3) ? 8 : 4; sKH = (v == 0 || v == 3) ? 1 : 2; sXM = v >= 3 ? 1 : 0;
@@ -416,6 +425,16 @@ int main() {
     printf("   inside a hipGraph: %6.2f us\n", graph_us([&](hipStream_t st) { stream_launch(st); }) - base);
   }
   sNG = 8; sKH = 1; sXM = 0;
+  {   // where the time goes inside one launch (group 0's first workgroup; wall_clock64 ticks at 100 MHz)
+    long long* st; hipMalloc(&st, 8 * 8); hipMemset(st, 0, 64);
+    sStamps = st;
+    for (int i = 0; i < 3; ++i) { hipLaunchKernelGGL(fill_f32_k, dim3(256), dim3(256), 0, 0, X, (long)B * K, 1.5f + i); stream_launch(0); }
+    hipDeviceSynchronize();
+    long long h[6]; hipMemcpy(h, st, 48, hipMemcpyDeviceToHost);
+    printf("   phases of the streaming sharded cell (us): staging %.2f | weight stream + MFMA %.2f | cross-wave reduction %.2f | drain + barrier %.2f | pointwise %.2f | total %.2f\n",
+           (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01, (h[5] - h[0]) * 0.01);
+    sStamps = nullptr;
+  }
   {
     const float base = graph_us([&](hipStream_t) {});
     for (int wpg : {32, 64}) {
