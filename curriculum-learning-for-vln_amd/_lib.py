@@ -67,7 +67,7 @@ class EnvDropStep(C.Structure):
                    ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr), ("defer_logits", i32),
                    ("pad_", i32)]
                 + [(n, ptr) for n in ("g_table", "g_angle_table", "g_rows", "g_vidx", "g_crows", "g_cviews", "g_chead", "g_celev")]
-                + [("g_ttype", i32), ("pad2_", i32), ("attn_sync", ptr), ("attn_sync_bytes", i64), ("chain", i32), ("pad3_", i32)])
+                + [("g_ttype", i32), ("pad2_", i32), ("attn_sync", ptr), ("attn_sync_bytes", i64), ("chain", i32), ("pad3_", i32), ("kctx", ptr)])
 
 
 class TickItem(C.Structure):          # vln_tick_item
@@ -293,6 +293,7 @@ SIGNATURES = {
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
     "vln_attn_sync_bytes": (i64, [i32]),
+    "vln_attn_textk_ok": (i32, [i32, i32, i32, i32, ptr, i64]),
     "vln_envdrop_flush": (i32, [ptr]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),
@@ -301,7 +302,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 14
+EXPECTED_ABI = 15
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

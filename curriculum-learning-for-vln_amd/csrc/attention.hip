@@ -417,6 +417,7 @@ int attn_bwd(hipStream_t st, const void* ctx, int ctype, const float* attn, cons
 
 #include "attention_fused.h"
 #include "attention_split.h"
+#include "attention_textk.h"
 
 // dots + softmax + weighted sum in one launch when a register-resident configuration fits, else the two-kernel path
 // (`dots_scratch` [B,S] is only touched by the fallback).
@@ -481,8 +482,9 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
     a.vec_ok = ((ldg & 3) == 0 && (ldq & 3) == 0) ? 1 : 0;
     for (int t = 0; t < a.T; ++t) {
       a.alpha[t] = alpha[t0 + t]; a.dl[t] = dl[t0 + t]; a.g[t] = g[t0 + t]; a.q[t] = q[t0 + t];
-      if (!a.alpha[t] || !a.g[t] || (!a.dl[t]) != (!a.q[t])) { set_error("attn_dctx_deferred: null step pointer"); return VLN_ERR_ARG; }
-      if (!aligned16(a.g[t]) || (a.q[t] && !aligned16(a.q[t]))) a.vec_ok = 0;
+      // a step carries an (alpha, g) pair, a (dl, q) pair or both
+      if ((!a.alpha[t]) != (!a.g[t]) || (!a.dl[t]) != (!a.q[t]) || (!a.alpha[t] && !a.dl[t])) { set_error("attn_dctx_deferred: null step pointer"); return VLN_ERR_ARG; }
+      if ((a.g[t] && !aligned16(a.g[t])) || (a.q[t] && !aligned16(a.q[t]))) a.vec_ok = 0;
       a.drop_seed[t] = drop_seed ? drop_seed[t0 + t] : 0; a.drop_off[t] = drop_off ? drop_off[t0 + t] : 0;
       a.drop_p[t] = drop_p ? drop_p[t0 + t] : 0.f;
     }
@@ -498,3 +500,6 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
 }  // namespace vln
 
 extern "C" int64_t vln_attn_sync_bytes(int B) { return B > 0 ? vln::attn_split_sync_bytes(B) : -1; }
+extern "C" int vln_attn_textk_ok(int ctype, int B, int S, int D, const void* sync, int64_t sync_bytes) {
+  return vln::attn_textk_ok(ctype, B, S, D, sync, (long)sync_bytes) ? 1 : 0;
+}

@@ -28,6 +28,54 @@ struct AttnSplitSync {
 };
 __host__ __device__ inline long attn_split_sync_bytes(int B) { return (long)B * 64 + (long)B * kSplitNS * (kSplitSMax / 2) * 16; }
 
+// The exchange of a row's partial dots between its kSplitNS workgroups (512 threads each; S <= kSplitSMax).  In: sdots[s] = this
+// part's partial dot of row s (written, visible after the caller's __syncthreads).  Out: sdots[s] = part 0 + 1 + 2 + 3 in that order
+// (identical bits in all four workgroups), visible to every thread on return.
+__device__ __forceinline__ void attn_split_exchange(const AttnSplitSync& sy, int b, int part, int B, int S, unsigned tag, float* sdots,
+                                                    float (*spart)[kSplitSMax], int* s_abort) {
+  const int lane = threadIdx.x & 63;
+  // publish this part's partials: thread i < ceil(S / 2) stores {dot[2i], tag, dot[2i + 1], tag}, one 16-byte write-through store
+  const int nh = (S + 1) >> 1;
+  __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(sy.gran, 0, (unsigned)((long)B * kSplitNS * (kSplitSMax / 2) * 16), 0x00020000);
+  const unsigned rbase = (unsigned)(b * kSplitNS) * (unsigned)(kSplitSMax / 2) * 16u;
+  if ((int)threadIdx.x < nh) {
+    const int s0 = 2 * threadIdx.x;
+    const float v0 = sdots[s0], v1 = (s0 + 1 < S) ? sdots[s0 + 1] : 0.f;
+    const u32x4_t o = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(o, xres, rbase + (unsigned)(part * (kSplitSMax / 2) + (int)threadIdx.x) * 16u, 0, 16);   // sc1
+  }
+  // sweep all four parts' partials (thread -> part q = tid / 64, pair i = tid % 64; S <= 128) until the tags match
+  float p0 = 0.f, p1 = 0.f;
+  {
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const bool mine = q < kSplitNS && i < nh;
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+      if (mine) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xres, rbase + (unsigned)(q * (kSplitSMax / 2) + i) * 16u, 0, 16);
+        ok = (v.y == tag) && (v.w == tag);
+        p0 = __uint_as_float(v.x); p1 = __uint_as_float(v.z);
+      }
+      if (__all(ok) || *(volatile int*)s_abort) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSplitSpinLimit) {               // a sibling workgroup is not resident / died: report, then drain
+        if (lane == 0) { __hip_atomic_fetch_add(sy.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); *s_abort = 1; }
+        break;
+      }
+    }
+  }
+  __syncthreads();                                   // sdots has been read by the publishers: reuse it for the exchange
+  {
+    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+    if (q < kSplitNS && i < nh) { spart[q][2 * i] = p0; spart[q][2 * i + 1] = p1; }
+  }
+  __syncthreads();
+  if (part == 0 && threadIdx.x == 0) VLN_AGENT_STORE(sy.seq + b, tag);     // every part has read seq[b] (its granules carry the tag)
+  for (int s = threadIdx.x; s < S; s += 8 * 64) sdots[s] = ((spart[0][s] + spart[1][s]) + spart[2][s]) + spart[3][s];
+  __syncthreads();
+}
+
 // Geometry: 8 waves; one wave instruction covers RPI = 64 / LPR rows x (LPR lanes x V elements) columns; lane (rsub = lane /
 // LPR, cl = lane % LPR) owns segments cl, cl + LPR, ... (SLP of them) of rows (wave + i * 8) * RPI + rsub, i < RWI.
 template <typename TC, int LPR, int SLP, int RWI, bool kBwd>
@@ -39,6 +87,7 @@ __global__ __launch_bounds__(512) void attn_split_kernel(AttnFusedArgs a, AttnSp
   __shared__ __attribute__((aligned(16))) float red[NW / 2][DPP];
   __shared__ float sdots[kSplitSMax];
   __shared__ int s_abort;
+  __shared__ float spart[kSplitNS][kSplitSMax];
   // workgroup -> (batch row, part): the four parts of a row get block ids that are equal mod 8 = one XCD under round-robin
   // placement (a speed matter only)
   const int blk = blockIdx.x;
@@ -117,47 +166,8 @@ __global__ __launch_bounds__(512) void attn_split_kernel(AttnFusedArgs a, AttnSp
   }
   __syncthreads();
 
-  // (3) publish this part's partials: thread i < ceil(S / 2) stores {dot[2i], tag, dot[2i + 1], tag}, one 16-byte write-through store
-  const int nh = (S + 1) >> 1;
-  __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(sy.gran, 0, (unsigned)((long)B * kSplitNS * (kSplitSMax / 2) * 16), 0x00020000);
-  const unsigned rbase = (unsigned)(b * kSplitNS) * (unsigned)(kSplitSMax / 2) * 16u;
-  if ((int)threadIdx.x < nh) {
-    const int s0 = 2 * threadIdx.x;
-    const float v0 = sdots[s0], v1 = (s0 + 1 < S) ? sdots[s0 + 1] : 0.f;
-    const u32x4_t o = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-    __builtin_amdgcn_raw_buffer_store_b128(o, xres, rbase + (unsigned)(part * (kSplitSMax / 2) + (int)threadIdx.x) * 16u, 0, 16);   // sc1
-  }
-  // (4) sweep all four parts' partials (thread -> part q = tid / 64, pair i = tid % 64; S <= 128) until the tags match
-  float p0 = 0.f, p1 = 0.f;
-  {
-    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
-    const bool mine = q < kSplitNS && i < nh;
-    unsigned spins = 0;
-    for (;;) {
-      bool ok = true;
-      if (mine) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xres, rbase + (unsigned)(q * (kSplitSMax / 2) + i) * 16u, 0, 16);
-        ok = (v.y == tag) && (v.w == tag);
-        p0 = __uint_as_float(v.x); p1 = __uint_as_float(v.z);
-      }
-      if (__all(ok) || s_abort) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSplitSpinLimit) {               // a sibling workgroup is not resident / died: report, then drain
-        if (lane == 0) { __hip_atomic_fetch_add(sy.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); s_abort = 1; }
-        break;
-      }
-    }
-  }
-  __syncthreads();                                   // sdots has been read by the publishers: reuse it for the exchange
-  __shared__ float spart[kSplitNS][kSplitSMax];
-  {
-    const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
-    if (q < kSplitNS && i < nh) { spart[q][2 * i] = p0; spart[q][2 * i + 1] = p1; }
-  }
-  __syncthreads();
-  if (part == 0 && threadIdx.x == 0) VLN_AGENT_STORE(sy.seq + b, tag);     // every part has read seq[b] (its granules carry the tag)
-  for (int s = threadIdx.x; s < S; s += NW * 64) sdots[s] = ((spart[0][s] + spart[1][s]) + spart[2][s]) + spart[3][s];
-  __syncthreads();
+  // (3) + (4) exchange the partial row dots of the four parts; sdots[s] = their sum in part order
+  attn_split_exchange(sy, b, part, B, S, tag, sdots, spart, &s_abort);
 
   // (5) row weights: every wave derives all of them (S <= 128: two per lane)
   float w0, w1;

@@ -182,11 +182,18 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   pw.bias_a = w->b_ih; pw.bias_b = w->b_hh; pw.c0 = io->c0; pw.ldc0 = H;
   pw.h1 = io->h1; pw.ldh1 = H; pw.c1 = io->c1; pw.ldc1 = H; pw.act = io->gate_act; pw.tanh_c1 = io->tanh_c1;
   pw.h1_drop = io->tcat + H; pw.ldh1d = 2 * H; pw.drop = site(io, 2, io->p_drop); pw.B = B; pw.H = H;
-  RUN(lstm_pointwise_fwd(st, pw));
-  // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
-  RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
-  RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
-                       ws.dots, B, d->L, H, io->attn_sync, io->attn_sync_bytes));
+  if (io->kctx) {
+    // (4b)+(5) in ONE launch: the cell's pointwise stage and the text attention on the projected context K = ctx W_in
+    // (logits = K . drop(h1): no per-step query product; attention_textk.h)
+    RUN(attn_textk_fwd(st, ctx, d->ctype, io->kctx, io->ctx_mask, io->alpha_t, io->tcat, 2 * H, pw, B, d->L, H, io->attn_sync,
+                       io->attn_sync_bytes));
+  } else {
+    RUN(lstm_pointwise_fwd(st, pw));
+    // (5) text attention (full SoftDot)                           policy.py:240-241, units.py:106-121
+    RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3));
+    RUN(attn_fwd_rows_sv(st, ctx, d->ctype, SlabVec{ws.s3, H, n3, (long)B * H}, io->tt, H, io->ctx_mask, io->alpha_t, io->tcat, 2 * H,
+                         ws.dots, B, d->L, H, io->attn_sync, io->attn_sync_bytes));
+  }
   if (io->chain & 1) {        // chained: the slabs stay in ws.s1, the NEXT call's first launch (or vln_envdrop_flush) finishes them
     int nl = 1;
     RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, wt(3), 2 * H, nullptr, 0, B, H, 2 * H, nullptr, ACT_NONE, ws.s1, ws.n1, &nl));
@@ -252,22 +259,31 @@ static int step_bwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // The context gradient is either accumulated in place per step (g->dctx: T read-modify-write sweeps over [B,L,H]) or
   // deferred: this step only leaves d logits (g->s_dl) and d weighted ctx (g->s_dtcat[:, :H]) behind and the caller
   // forms dctx once per rollout with vln_attn_dctx_deferred.
-  if (g->dctx) {
-    RUN(reduce_epilogue(st, ws.s4, n4, (long)B * 2 * H, 2 * H, ws.dtcat, 2 * H, B, 2 * H, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f}));
-    RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
-    RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
-  } else {
-      RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H,
-                         io->attn_sync, io->attn_sync_bytes));
-  }
-  RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
-  // (4') LSTM cell
+  // (4') the LSTM cell's pointwise backward: its arguments (the K-mode text attention runs it inside its own launch)
   LstmPwBwd pb{};
-  pb.dh1_a = g->dh1; pb.ld_a = H; pb.dh1_b = dtcat.shifted(H); pb.dh1_b2 = SlabVec{ws.s3, H, n3b, (long)B * H};
+  pb.dh1_a = g->dh1; pb.ld_a = H;
   pb.drop = site(io, 2, io->p_drop); pb.dc1 = g->dc1; pb.lddc1 = H;
   pb.act = io->gate_act; pb.tanh_c1 = io->tanh_c1; pb.c0 = io->c0; pb.ldc0 = H;
   pb.dgates = g->s_dgates; pb.lddg = 4 * H; pb.dc0 = g->dc0; pb.lddc0 = H; pb.B = B; pb.H = H;
-  RUN(lstm_pointwise_bwd(st, pb));
+  if (io->kctx) {
+    if (g->dctx) { set_error("envdrop bwd: the projected-context step (kctx) needs the deferred context gradient (dctx == NULL)"); return VLN_ERR_ARG; }
+    // (5')+(4') in ONE launch: softmax backward, dq = sum dl ctx (the dY rows of d W_in), d drop(h1) = sum dl K + linear_out's
+    // share, the cell's pointwise backward
+    RUN(attn_textk_bwd(st, ctx, d->ctype, io->kctx, io->alpha_t, dtcat, g->s_dtcat, 2 * H, g->s_dtt, H, g->s_dl, pb, B, d->L, H,
+                       io->attn_sync, io->attn_sync_bytes));
+  } else {
+    if (g->dctx) {
+      RUN(reduce_epilogue(st, ws.s4, n4, (long)B * 2 * H, 2 * H, ws.dtcat, 2 * H, B, 2 * H, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f}));
+      RUN(attn_dot(st, ctx, d->ctype, ws.dtcat, 2 * H, ws.dots, B, d->L, H));
+      RUN(attn_bwd(st, ctx, d->ctype, io->alpha_t, ws.dots, nullptr, ws.dtcat, 2 * H, io->tt, H, g->s_dtt, H, g->dctx, g->s_dl, B, d->L, H));
+    } else {
+      RUN(attn_bwd_rows_sv(st, ctx, d->ctype, io->alpha_t, dtcat, g->s_dtcat, 2 * H, nullptr, g->s_dtt, H, g->s_dl, ws.dots, B, d->L, H,
+                           io->attn_sync, io->attn_sync_bytes));
+    }
+    RUN(gemm_nt(st, g->s_dtt, H, w->w_tin_t, wt(2), H, nullptr, 0, B, H, H, nullptr, ACT_NONE, ws.s3, ws.n3, &n3b));
+    pb.dh1_b = dtcat.shifted(H); pb.dh1_b2 = SlabVec{ws.s3, H, n3b, (long)B * H};
+    RUN(lstm_pointwise_bwd(st, pb));
+  }
   RUN(gemm_nt(st, g->s_dgates, 4 * H, w->w_cat_t, wt(1), 4 * H, nullptr, 0, B, XK, 4 * H, nullptr, ACT_NONE, ws.s2, ws.n2, &n2));
   const SlabVec dxcat{ws.s2, XK, n2, (long)B * XK};
   // (3') visual attention: features carry no gradient, only the query does

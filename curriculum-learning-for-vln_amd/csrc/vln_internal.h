@@ -187,6 +187,15 @@ int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, fl
 int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* attn, SlabVec dwc, float* dwc_out, long lddo,
                      const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D,
                      void* sync = nullptr, long sync_bytes = 0);
+// The EnvDrop step's text attention on the PROJECTED context K = ctx W_in with the LSTM cell's pointwise stage in the same launch
+// (attention_textk.h; four workgroups per row only: attn_textk_ok says whether the shape / device / exchange buffer allow it)
+struct LstmPwFwd; struct LstmPwBwd;
+bool attn_textk_ok(int ctype, int B, int S, int D, const void* sync, long sync_bytes);
+int attn_textk_fwd(hipStream_t st, const void* ctx, int ctype, const float* kctx, const uint8_t* mask, float* alpha, float* out,
+                   long ldo, const LstmPwFwd& pw, int B, int S, int D, void* sync, long sync_bytes);
+int attn_textk_bwd(hipStream_t st, const void* ctx, int ctype, const float* kctx, const float* alpha, SlabVec dwc, float* dwc_out,
+                   long lddo, float* dq, long lddq, float* dl_out, const LstmPwBwd& pb, int B, int S, int D, void* sync,
+                   long sync_bytes);
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,

@@ -33,9 +33,9 @@ class _SoftDotParams(nn.Module):
 
 class _StepPlan:
     """What a decoder step needs again when the same argument block comes back (see EnvDropDecoder.forward)."""
-    __slots__ = ("io", "dims", "nws", "keep", "i0", "n_alloc", "xcat_ptr", "ctx_lp_ptr", "mask_ptr", "first_ptr")
+    __slots__ = ("io", "dims", "nws", "keep", "i0", "n_alloc", "xcat_ptr", "ctx_lp_ptr", "mask_ptr", "first_ptr", "kctx_ptr")
 
-    def __init__(self, io, dims, nws, keep, i0, n_alloc, xcat_ptr, ctx_lp_ptr, mask_ptr, first_ptr, gathered=False):
+    def __init__(self, io, dims, nws, keep, i0, n_alloc, xcat_ptr, ctx_lp_ptr, mask_ptr, first_ptr, gathered=False, kctx_ptr=0):
         self.io = _lib.EnvDropStep.from_buffer_copy(io)
         own = ("logit", "h1", "c1", "h_tilde", "flat", "img_lp", "cand_lp")      # the module's buffers only: the caller's
         if gathered:                                                              # tensors are taken afresh every call
@@ -43,6 +43,7 @@ class _StepPlan:
         self.dims, self.nws, self.i0, self.n_alloc = dims, nws, i0, n_alloc
         self.keep = {k: keep[k] for k in own if k in keep}
         self.xcat_ptr, self.ctx_lp_ptr, self.mask_ptr, self.first_ptr = xcat_ptr, ctx_lp_ptr, mask_ptr, first_ptr
+        self.kctx_ptr = kctx_ptr
 
 
 class _StepRec:
@@ -93,7 +94,7 @@ class _EnvDropStepFn(torch.autograd.Function):
                 dhtp, dc0, t = bp[4], bp[5], bp[6]
                 if want_ctx:
                     io0 = rec.io
-                    rec.entry.terms.append((io0.alpha_t, g.s_dl, g.s_dtcat, io0.tt, t, rec.keep["flat"]))
+                    rec.entry.terms.append((io0.alpha_t, g.s_dl, g.s_dtcat, io0.tcat + 4 * H if io0.kctx else io0.tt, t, rec.keep["flat"]))
                     rec.entry.shape = (B, rec.L, H)
                 io = rec.io
                 io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
@@ -136,7 +137,8 @@ class _EnvDropStepFn(torch.autograd.Function):
             q = t.data_ptr()
             g.s_dl, g.s_dtcat = q, q + 4 * n_dl
             io0 = rec.io
-            rec.entry.terms.append((io0.alpha_t, q, q + 4 * n_dl, io0.tt, t, rec.keep["flat"]))
+            # (the q operand of the deferred dctx: the step's query -- or, on the projected context, its drop(h_1) rows)
+            rec.entry.terms.append((io0.alpha_t, q, q + 4 * n_dl, io0.tcat + 4 * H if io0.kctx else io0.tt, t, rec.keep["flat"]))
             rec.entry.shape = (B, L, H)
         g.s_dtc, g.s_dz, g.s_dtt = s.ptr("dtc"), s.ptr("dz"), s.ptr("dtt")
         g.s_dgates, g.s_dtv, g.s_de = s.ptr("dgates"), s.ptr("dtv"), s.ptr("de")
@@ -222,6 +224,13 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # B * 4 <= the device's CU count (the library checks; larger batches take the one-workgroup kernels).
         self.split_attention = True
         self._attn_sync = None
+        # The text attention on the PROJECTED context (round 5): K = ctx W_in is formed once per rollout (one product over the
+        # B * L context rows) and every step scores K . drop(h_1) -- units.py:106-109 re-associated -- so the per-step query
+        # product W_in drop(h_1) and its transpose in the backward leave the step, and the LSTM cell's pointwise stage runs inside
+        # the text-attention launch (vln_envdrop_step.kctx, csrc/attention_textk.h): two dependent launches less per step and
+        # direction.  Taken when the four-workgroup attention covers the shape (vln_attn_textk_ok), else the step runs as before.
+        self.project_context = True
+        self.last_projected = False
         # bf16 compute: weight matrices that are streamed in fp32 all the same (names: w_vin, w_cat, w_tin, w_tout, w_c).  Set it
         # before the first forward (the shadows are rebuilt when a parameter changes).
         self.fp32_weights = frozenset(type(self).default_fp32_weights)
@@ -232,6 +241,33 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             n = int(_lib.load().vln_attn_sync_bytes(B))
             w = self._attn_sync = (torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev), B)
         return w[0]
+
+    def _ctx_k(self, entry, ctx, lp):
+        """The rollout's projected context K = ctx W_in ([B,L,H] fp32), formed on first use; False when the folded text attention
+        does not cover this shape / device (the steps then project their queries themselves)."""
+        k = entry.kctx
+        if k is not None:
+            return k
+        B, L, H = ctx.shape
+        k = False
+        if self.project_context and self.split_attention and H == self.hidden_size:
+            sy = self._attn_sync_buf(ctx.device, B)
+            if _lib.load().vln_attn_textk_ok(ops.BF16 if lp else ops.F32, B, L, H, sy.data_ptr(), sy.numel() * 4):
+                src = ctx.detach()
+                if not src.is_contiguous():
+                    src = src.contiguous()
+                w_t = self._shadow.t["w_tin_t"]                  # W_in^T [H(query), H(ctx)]: K = ctx @ W_in
+                k = ops.linear_fwd(src.view(B * L, H), w_t, split=lp).view(B, L, H)
+                entry.k_w, entry.k_split = self._shadow.t["w_tin"], lp
+        entry.kctx = k
+        self.last_projected = k is not False          # (tests: which copy of ctx the latest rollout's logits were taken on)
+        return k
+
+    def scores_on_projected_context(self, ctx) -> bool:
+        """Whether the rollout on `ctx` (after its first step) takes its text-attention logits on K = ctx W_in formed from the
+        fp32 context (True) or on the streamed copy of ctx (False) -- what a bit-level restatement of the bf16 mode has to know."""
+        e = self._ctx_entries.get(id(ctx))
+        return bool(e is not None and e.ref() is ctx and e.kctx is not None and e.kctx is not False)
 
     # ---- gating hooks ----------------------------------------------------------------------------------
     def _gated_params(self) -> List[torch.Tensor]:
@@ -477,6 +513,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         ctx_lp = entry.lp
         if lp:
             ok = ctx_lp is not None and ctx_lp.data_ptr() == plan.ctx_lp_ptr
+        kctx = entry.kctx
+        ok = ok and (kctx.data_ptr() if (kctx is not None and kctx is not False) else 0) == plan.kctx_ptr
         m8 = None
         if ok and ctx_mask is not None:
             m8 = entry.mask8 if entry.mask_src is ctx_mask else None
@@ -510,6 +548,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             keep["ctx_lp"] = ctx_lp
             if img_lp is not None:
                 keep["img_lp"], keep["cand_lp"] = img_lp, cand_lp
+        if plan.kctx_ptr:
+            keep["kctx"] = kctx
         if m8 is not None:
             keep["mask"] = m8
         rec = _StepRec()
@@ -602,12 +642,15 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             pkey = (arena.g, arena.i, a_t_prev.data_ptr(), fk, h_tilde_prev.data_ptr(),
                     c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
                     self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
-                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits), bool(self.chain_steps))
+                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits), bool(self.chain_steps), bool(self.project_context))
         ctx_lp = None
         if lp:                         # once per rollout; BEFORE the step's own buffers so the arena order is the same on
             ctx_lp = entry.lp          # the planned and on the full path
             if ctx_lp is None:
                 ctx_lp = self._ctx_lp(entry, ctx, dt)
+        kctx = entry.kctx              # the projected context, likewise once per rollout
+        if kctx is None:
+            kctx = self._ctx_k(entry, ctx, lp)
         if pkey is not None:
             plan = self._plans.get(pkey)
             if plan is not None:
@@ -711,6 +754,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             sy = self._attn_sync_buf(dev, B)
             io.attn_sync, io.attn_sync_bytes = sy.data_ptr(), sy.numel() * 4
         io.h_tilde_prev, io.c0, io.ctx = htp.data_ptr(), c0.data_ptr(), ctxc.data_ptr()
+        if kctx is not False:
+            io.kctx = kctx.data_ptr()
+            keep["kctx"] = kctx
         if ctx_mask is not None:
             m8 = entry.mask8 if entry.mask_src is ctx_mask else None
             if m8 is None:
@@ -743,7 +789,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             first = img if (gather is not None and not lp) else logit          # the first buffer the step took from the arena
             self._plans[pkey] = _StepPlan(io, d, nws, keep, arena_i0, arena.i - arena_i0,
                                           slot.ptr("xcat") if need_grad else 0, keep["ctx_lp"].data_ptr() if lp else 0,
-                                          io.ctx_mask, first.data_ptr(), gathered=gather is not None)
+                                          io.ctx_mask, first.data_ptr(), gathered=gather is not None, kctx_ptr=io.kctx or 0)
 
         if need_grad:
             logit, h1, c1, h_tilde = _EnvDropStepFn.apply(self, rec, h_tilde_prev, c_0, ctx_in, gated)
@@ -771,6 +817,9 @@ class Critic(nn.Module):
                                          nn.Linear(hidden_size, 1))
         self.dropout_seed = 0xC417
         self._calls = 0
+        # Tests only: a list that receives every call's hidden pre-activations' SIGNS (bool [rows, H], ReLU on / off) -- the
+        # decisions a restatement has to share to be compared beyond them (a ReLU is a discontinuity, like a dropout mask)
+        self.relu_record = None
 
     def forward(self, state):
         ops.check_live(state, "Critic(state)")
@@ -784,14 +833,16 @@ class Critic(nn.Module):
         else:
             self._calls += 1
             off = (self._calls, None)
-        return _CriticFn.apply(state, l0.weight, l0.bias, l3.weight, l3.bias, p, self.dropout_seed, off).squeeze()
+        return _CriticFn.apply(state, l0.weight, l0.bias, l3.weight, l3.bias, p, self.dropout_seed, off, self.relu_record).squeeze()
 
 
 class _CriticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w0, b0, w3, b3, p, seed, off):
+    def forward(ctx, x, w0, b0, w3, b3, p, seed, off, record=None):
         x = x.contiguous()
         z = ops.linear_fwd(x, w0.detach(), b0.detach(), ops.ACT_RELU)
+        if record is not None:
+            record.append(z > 0)
         # the mask is regenerated by the kernels from (seed, offset) in the backward: z * mask and dzd * mask are one launch each
         zd = ops.scale_dropout(z, seed, off[0], p, off[1]) if p > 0 else z
         v = ops.linear_fwd(zd, w3.detach(), b3.detach())
@@ -813,4 +864,4 @@ class _CriticFn(torch.autograd.Function):
         dx = ops.linear_fwd(dz, ops.transpose_cast(w0.detach()))
         dw0 = ops.linear_wgrad(dz, x)
         db0 = ops.colsum(dz)
-        return dx, dw0, db0, dw3, db3, None, None, None
+        return dx, dw0, db0, dw3, db3, None, None, None, None

@@ -308,7 +308,7 @@ class WeightGate(torch.autograd.Function):
 class CtxEntry:
     """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
     low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
-    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "__weakref__")
+    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "kctx", "k_w", "k_split", "__weakref__")
 
     def __init__(self, t):
         self.ref = weakref.ref(t)
@@ -319,6 +319,11 @@ class CtxEntry:
         self.lp = None
         self.gated = None
         self.mask_src = self.mask8 = None     # the caller's ctx_mask and its uint8 form (converted once per rollout)
+        # projected context K = ctx W_in of the rollout (EnvDropDecoder.project_context): None = not decided yet, False = not used,
+        # else the [B,L,H] fp32 tensor; k_w = text_attn.linear_in's streamed shadow [H,H], k_split = multiply it in the split form
+        self.kctx = None
+        self.k_w = None
+        self.k_split = False
 
 
 class CtxGate(torch.autograd.Function):
@@ -341,10 +346,22 @@ class CtxGate(torch.autograd.Function):
                 terms, e.terms = e.terms, []
                 B, L, H = e.shape
                 acc = d is not None
-                if d is None:
+                kmode = e.kctx is not None and e.kctx is not False
+                if d is None and not kmode:
                     d = ops.empty(B, L, H, dtype=torch.float32, device=terms[0][4].device)
-                ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
-                                       [t[3] for t in terms], H, d, accumulate=acc)
+                if kmode:
+                    # projected context (vln_envdrop_step.kctx): the steps' queries never existed.  dctx = sum_t alpha_t g_t +
+                    # (sum_t dl_t hd_t) W_in^T with hd_t = drop(h_1) of step t (t[3]: the tcat stash rows, columns [H, 2H))
+                    none = [None] * len(terms)
+                    dk = ops.empty(B, L, H, dtype=torch.float32, device=terms[0][4].device)
+                    ops.attn_dctx_deferred(none, [t[1] for t in terms], none, 2 * H, [t[3] for t in terms], 2 * H, dk)
+                    d2 = ops.linear_fwd(dk.view(B * L, H), e.k_w, split=e.k_split).view(B, L, H)
+                    if acc:
+                        d2 += d
+                    d = ops.attn_dctx_deferred([t[0] for t in terms], none, [t[2] for t in terms], 2 * H, none, 2 * H, d2, accumulate=True)
+                else:
+                    ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
+                                           [t[3] for t in terms], H, d, accumulate=acc)
         if g is not None:
             d = g if d is None else d + g
         return None, d

@@ -764,6 +764,17 @@ typedef struct vln_envdrop_step {
    * (backward) before the next step call or a vln_envdrop_flush on that stream.  vln_envdrop_step_fwd CLEARS bit 1 in place for a
    * step that did not consume a pending stage itself (the head of a rollout: what consumes its d h_tilde_prev is not a chained step). */
   int chain; int pad3_;
+  /* ABI v15, optional (nullable): K = ctx W_in, [B,L,H] fp32 -- the instruction context projected ONCE per rollout through
+   * text_attn.linear_in (units.py:106-109: ctx . (W_in h) = (ctx W_in) . h; the caller forms it with one vln_linear_fwd over the
+   * B * L rows of ctx against w_tin_t).  With it the step's text attention scores K . drop(h_1) directly: the per-step query
+   * product W_in drop(h_1) and, in the backward, its transpose leave the step, and the LSTM cell's pointwise stage (forward) /
+   * pointwise backward run inside the text-attention launch (csrc/attention_textk.h) -- two dependent launches less per step and
+   * direction.  Needs attn_sync and a shape vln_attn_textk_ok accepts (else the call fails), and in the backward the DEFERRED
+   * context gradient (vln_envdrop_grads.dctx == NULL): `tt` is NOT written, the caller forms
+   *   dctx = sum_t alpha_t g_t + (sum_t dl_t hd_t) W_in^T,   hd_t = tcat[:, H:] of step t
+   * with vln_attn_dctx_deferred (dl / q = hd pairs -> [B,L,H]), one vln_linear_fwd against w_tin and a second
+   * vln_attn_dctx_deferred (alpha / g pairs, accumulate).  d W_in still comes from the s_dtt rows. */
+  const float* kctx;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {
@@ -794,6 +805,9 @@ typedef struct vln_envdrop_grads {
 
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
 int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
+/* 1 when the folded text attention of vln_envdrop_step.kctx covers (ctype, B episodes, S tokens, D = H) on the current device with
+ * this exchange buffer (four workgroups per episode co-resident, S <= 96, D <= 512, D % 32 == 0, the path not switched off) */
+int vln_attn_textk_ok(int ctype, int B, int S, int D, const void* sync, int64_t sync_bytes);
 int vln_envdrop_flush(vln_stream_t s);      /* issue what a chained step left pending on this stream (no-op if nothing is) */
 int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io, vln_stream_t s);
 int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,

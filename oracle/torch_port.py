@@ -137,10 +137,12 @@ def masked_softmax(logits: Tensor, mask: Optional[Tensor]) -> Tensor:
 
 
 def softdot_attention(h: Tensor, ctx: Tensor, mask: Optional[Tensor], w_in: Tensor,
-                      w_out: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
-    """`w_out is None` == context_only.  Returns (h_tilde or weighted ctx, attn)."""
+                      w_out: Optional[Tensor], score_ctx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """`w_out is None` == context_only.  Returns (h_tilde or weighted ctx, attn).
+    `score_ctx` (default: ctx, the reference) = the copy of the context the LOGITS are taken on when a build under test stores it
+    apart from the copy its weighted sum streams (a rounding detail of that build: bf16 stream copy vs fp32 projected copy)."""
     target = h @ w_in.t()                                     # units.py:106
-    logits = torch.einsum("bsd,bd->bs", ctx, target)          # units.py:109
+    logits = torch.einsum("bsd,bd->bs", ctx if score_ctx is None else score_ctx, target)          # units.py:109
     attn = masked_softmax(logits, mask)
     wc = torch.einsum("bs,bsd->bd", attn, ctx)                # units.py:117
     if w_out is None:
@@ -176,7 +178,8 @@ def action_scoring(P: Params, prefix: str, cands: Tensor, h_tilde: Tensor) -> Te
 # A5  AttnDecoderLSTM.forward (policy.py:37-60) -- Speaker-Follower step
 # ---------------------------------------------------------------------------
 def follower_step(P: Params, img: Tensor, a_prev: Tensor, cands: Tensor, h0: Tensor, c0: Tensor,
-                  ctx: Tensor, ctx_mask: Optional[Tensor], *, drop: Optional[Dict[str, Tensor]] = None):
+                  ctx: Tensor, ctx_mask: Optional[Tensor], *, drop: Optional[Dict[str, Tensor]] = None,
+                 score_ctx: Optional[Tensor] = None):
     drop = drop or {}
     wv, alpha_v = visual_softdot_attention(
         h0, img, None, P["visual_attn.linear_in_h.weight"], P["visual_attn.linear_in_h.bias"],
@@ -185,7 +188,7 @@ def follower_step(P: Params, img: Tensor, a_prev: Tensor, cands: Tensor, h0: Ten
     h1, c1 = lstm_cell(x, h0, c0, P["lstm.weight_ih"], P["lstm.weight_hh"], P["lstm.bias_ih"], P["lstm.bias_hh"])
     h1d = _mul(h1, drop.get("h1"))
     h_tilde, alpha_c = softdot_attention(h1d, ctx, ctx_mask, P["text_attn.linear_in.weight"],
-                                         P["text_attn.linear_out.weight"])
+                                         P["text_attn.linear_out.weight"], score_ctx=score_ctx)
     logit = action_scoring(P, "decode_action.", cands, h_tilde)
     return logit, (h1, c1), (alpha_c, alpha_v)
 
@@ -194,7 +197,8 @@ def follower_step(P: Params, img: Tensor, a_prev: Tensor, cands: Tensor, h0: Ten
 # A6  EnvDropDecoder.forward (policy.py:208-246)
 # ---------------------------------------------------------------------------
 def envdrop_step(P: Params, a_prev: Tensor, img: Tensor, cand: Tensor, h_tilde_prev: Tensor, c0: Tensor,
-                 ctx: Tensor, ctx_mask: Optional[Tensor], *, drop: Optional[Dict[str, Tensor]] = None):
+                 ctx: Tensor, ctx_mask: Optional[Tensor], *, drop: Optional[Dict[str, Tensor]] = None,
+                 score_ctx: Optional[Tensor] = None):
     """`img`/`cand` are the features AFTER feature dropout (policy.py:226-231
     overwrites the caller's tensors; apply `feature_dropout` first).  h_0 is
     unused by the reference (policy.py:238) and is not an argument here.
@@ -210,7 +214,7 @@ def envdrop_step(P: Params, a_prev: Tensor, img: Tensor, cand: Tensor, h_tilde_p
                        P["lstm.bias_ih"], P["lstm.bias_hh"])
     h1d = _mul(h1, drop.get("h1"))
     h_tilde, alpha_c = softdot_attention(h1d, ctx, ctx_mask, P["text_attn.linear_in.weight"],
-                                         P["text_attn.linear_out.weight"])
+                                         P["text_attn.linear_out.weight"], score_ctx=score_ctx)
     htd = _mul(h_tilde, drop.get("htilde"))
     tgt = htd @ P["cand_attn.weight"].t()                     # policy.py:204
     logit = torch.einsum("bcf,bf->bc", cand, tgt)             # policy.py:205
@@ -227,8 +231,16 @@ def feature_dropout(x: Tensor, keep_scaled: Tensor, angle: int) -> Tensor:
 # ---------------------------------------------------------------------------
 # A8  Critic (policy.py:249-267)
 # ---------------------------------------------------------------------------
-def critic(P: Params, state: Tensor, drop: Optional[Tensor] = None, prefix: str = "") -> Tensor:
-    z = torch.relu(state @ P[prefix + "state2value.0.weight"].t() + P[prefix + "state2value.0.bias"])
+def critic(P: Params, state: Tensor, drop: Optional[Tensor] = None, prefix: str = "", relu_on: Optional[Tensor] = None,
+           pre_out: Optional[list] = None) -> Tensor:
+    """`relu_on` (bool, default None = the reference's ReLU): the on / off decision of every hidden unit given from outside -- a
+    ReLU is a discontinuity, and a build whose input differs in the last bits decides differently for pre-activations near
+    zero; with the decisions shared (like a dropout mask) everything else can be compared.  `pre_out`: receives the
+    pre-activations (so a test can bound WHERE the decisions differ)."""
+    pre = state @ P[prefix + "state2value.0.weight"].t() + P[prefix + "state2value.0.bias"]
+    if pre_out is not None:
+        pre_out.append(pre.detach())
+    z = torch.relu(pre) if relu_on is None else pre * relu_on.to(pre.dtype)
     z = _mul(z, drop)
     return (z @ P[prefix + "state2value.3.weight"].t() + P[prefix + "state2value.3.bias"]).squeeze(1)
 

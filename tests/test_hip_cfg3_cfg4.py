@@ -29,9 +29,15 @@ ML_WEIGHT, GAMMA = 0.2, 0.9          # configs/envdrop/envdrop_config.yaml:45,42
 # bf16 vs the UNROUNDED fp64 oracle (north_star's 1e-2): met by both losses, the log-probs / entropies / values of all 35
 # steps and every encoder / decoder gradient (measured 2e-3 .. 7e-3, gpurun_out/parity_report.json).  The one exception is the
 # critic's hidden layer: its input h_1 differs by ~5e-3 from the oracle's (the rounding of the streamed weights), which flips
-# the ReLU of the units whose pre-activation is near zero -- each flip changes a gradient term by its full size (measured
-# 6e-2 max-abs, 3e-2 in L2; the same-weights oracle, where nothing flips, is met at 6e-3).
-CFG3_BF16_EXC = {"grad[cri.state2value.0": 0.12}
+# the ReLU of the units whose pre-activation is near zero -- each flip changes a gradient term by its full size (rounds 3-4
+# measured 6e-2 max-abs, 3e-2 in L2 with the oracle deciding for itself).
+CFG3_BF16_EXC = {}
+# Round 5: the critic's ReLU decisions are SHARED with the oracle in the bf16 comparisons (Critic.relu_record -> O.critic(relu_on=)),
+# like the dropout masks and the sampled actions: with them every critic gradient meets the bound of its variant.  What is asserted
+# about the decisions themselves: they differ from the oracle's own ReLU for less than CRITIC_RELU_FLIPS[0] of the (row, unit)
+# pairs, and only where the oracle's pre-activation is within CRITIC_RELU_FLIPS[1] of the mean |pre-activation| of zero.
+# (Rounds 3-4 compared with the oracle's own decisions and carried the flipped units as a 0.12 exception on the hidden layer.)
+CRITIC_RELU_FLIPS = (2e-3, 0.03)       # measured: 6.4e-4 of the units, 1.1e-2 of the mean (unrounded oracle); one unit of 1.2 M (same weights)
 # bf16 on the SAME rounded weights: activations enter the MFMAs as hi + lo bf16 planes (2^-17 relative, against 2^-24 in fp32
 # mode), and 35 recurrent steps compound that: the entropies of the last steps reach 1.2e-4 (single steps: <= 5e-5)
 CFG3_SAME_EXC = {"entropy": 3e-4, "logp": 3e-4, "values": 3e-4}
@@ -135,8 +141,11 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
         bl = torch.dot(w.to(ml.dtype), ml + rl)                              # curriculum.py:296
         return bl / w.sum().to(ml.dtype) if normalised else bl               # curriculum.py:301
 
+    cri.relu_record = []             # the ReLU decisions of the critic's two calls (bootstrap value, all steps' values)
     il = gpu_rollout(T_il, False)
     rlr = gpu_rollout(T_rl, True)
+    relu_on = [m.cpu() for m in cri.relu_record]
+    cri.relu_record = None
     loss = batch_loss(il["ml"], rlr["rl"], None if weight is None else weight.to(dev))
     loss.backward()
     torch.cuda.synchronize()
@@ -151,6 +160,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     seq_mask = cpu_tape["seq_mask"]
     lengths = cpu_tape["lengths"].tolist()
     p, pf = 0.5, 0.3
+    flips = []
     for name, tol, same, exc in variants:
         P = {k: {n: v.detach().cpu().double().requires_grad_(True) for n, v in d.items()} for k, d in sd.items()}
         Pe = bf16_weights(P["enc"], skip=("embedding.weight",)) if same else P["enc"]       # embedding rows are gathered in fp32
@@ -165,6 +175,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
                                          emb_mask=_mask(vln, B * L * E, enc.dropout_seed, oe * 8 + 0, p, (B, L, E)),
                                          ctx_mask_drop=_mask(vln, B * L * H, enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
             cxs = bf16_round_st(cx) if same else cx              # the text attention streams a bf16 copy of the context
+            sc = cx if (same and dec.last_projected) else None    # ... and scores on K = ctx W_in formed from the fp32 context (round 5)
             ht = h
             hidden, logps, ents, ml = [], [], [], 0.0
 
@@ -179,7 +190,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
                     img, cand = img.float().bfloat16().double(), cand.float().bfloat16().double()
                 drop = {"act": m(0, B * AE, p, (B, AE)), "hprev": m(1, B * H, p, (B, H)), "h1": m(2, B * H, p, (B, H)),
                         "htilde": m(3, B * H, p, (B, H))}
-                lo, (h1, c1), ht1, _ = O.envdrop_step(Pd, s["angle"].double(), img, cand, ht, c, cxs, seq_mask, drop=drop)
+                lo, (h1, c1), ht1, _ = O.envdrop_step(Pd, s["angle"].double(), img, cand, ht, c, cxs, seq_mask, drop=drop, score_ctx=sc)
                 return lo, h1, c1, ht1
 
             for t, s in enumerate(cpu_tape["steps"][:T]):
@@ -194,11 +205,22 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
             if not sample:
                 return dict(ml=ml * ML_WEIGHT / B)
             _, last_h, _, _ = step(cpu_tape["steps"][T], ht, c)
+            # bf16: the critic's ReLU DECISIONS are the kernels' (CRITIC_RELU above); fp32: the reference's own ReLU
+            on = relu_on if lp else (None, None)
+            pre = []
             oc = next(it["cri"])
             with torch.no_grad():
-                last_v = O.critic(Pc, last_h, _mask(vln, B * H, cri.dropout_seed, oc, p, (B, H)))
+                last_v = O.critic(Pc, last_h, _mask(vln, B * H, cri.dropout_seed, oc, p, (B, H)), relu_on=on[0], pre_out=pre)
             oc = next(it["cri"])
-            vals = O.critic(Pc, torch.cat(hidden, 0), _mask(vln, T * B * H, cri.dropout_seed, oc, p, (T * B, H))).view(T, B)
+            vals = O.critic(Pc, torch.cat(hidden, 0), _mask(vln, T * B * H, cri.dropout_seed, oc, p, (T * B, H)), relu_on=on[1],
+                            pre_out=pre).view(T, B)
+            if lp:       # where the decisions differ from the oracle's own: few units, all with a pre-activation next to zero
+                for z, m in zip(pre, relu_on):
+                    flip = (z > 0) != m
+                    frac, worst = float(flip.double().mean()), float(z[flip].abs().max()) if bool(flip.any()) else 0.0
+                    scale = float(z.abs().mean())
+                    flips.append((name, frac, worst / scale))
+                    assert frac < CRITIC_RELU_FLIPS[0] and worst < CRITIC_RELU_FLIPS[1] * scale, (name, frac, worst, scale)
             rl, total = O.a2c_loss(logps, ents, list(vals.unbind(0)), [r.double() for r in rewards], masks, last_v, ended, GAMMA,
                                    "total", per_sample=weight is not None)
             return dict(rl=rl, total=total, logp=torch.stack(logps), ent=torch.stack(ents), vals=vals)
@@ -222,6 +244,8 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
                 r = refs[n] if refs[n] is not None else torch.zeros_like(P[key][n])
                 got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
                 check(got, r, t(f"grad[{key}.{n}]"), f"{name}: grad[{key}.{n}]", floor=grad_floor(n, gmax))
+    for name, frac, worst in flips:
+        print(f"critic ReLU decisions that differ from the oracle's own ({name}): {frac:.2e} of the units, |pre-activation| <= {worst:.2e} of the mean")
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])

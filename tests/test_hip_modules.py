@@ -197,12 +197,22 @@ def _tol_for(exc, tol, what):
     return tol
 
 
-def _variants(compute_dtype, exc):
+# Round 5, projected context (EnvDropDecoder.project_context): the text logits are taken on K = ctx W_in formed from the FP32 context,
+# while the step's backward forms dq = sum_l dl[l] ctx[l] -- the dY rows of d text_attn.linear_in -- on the bf16 STREAM copy it
+# holds for the d alpha dots.  A restatement that scores on the fp32 context (score_ctx) therefore sees that one gradient with
+# ctx's 2^-9 rounding in it: measured 2.4e-3 (inside the default weight-gradient form's own 8e-3; it only shows in the "split" form).
+PROJECTED_DW_IN = 4e-3
+
+
+def _variants(compute_dtype, exc, projected=False):
     """[(name, tolerance, same-weights?, exceptions)]: fp32 = one oracle at 1e-4; bf16 = the oracle on the bf16-rounded
     weights the kernels stream at SAME_BF16, and the oracle on the unrounded masters at north_star's 1e-2 (tests/parity.py)."""
     if compute_dtype == torch.float32:
         return [("fp32", FP32, False, None)]
-    return [("bf16 same-weights", SAME_BF16, True, {"grad[": same_bf16_grad_tol()}), ("bf16 unrounded", BF16, False, exc)]
+    same_exc = {"grad[": same_bf16_grad_tol()}
+    if projected:
+        same_exc = {"grad[text_attn.linear_in.weight]": max(same_bf16_grad_tol(), PROJECTED_DW_IN), **same_exc}
+    return [("bf16 same-weights", SAME_BF16, True, same_exc), ("bf16 unrounded", BF16, False, exc)]
 
 
 def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=None, bf16_exc=None):
@@ -227,7 +237,7 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=None, b
     ht = torch.tanh(torch.randn(B, H, generator=g)); c = torch.randn(B, H, generator=g) * 0.5
     ctx_d = ctx.to(DEV).requires_grad_(True); ht_d = ht.to(DEV).requires_grad_(True); c_d = c.to(DEV).requires_grad_(True)
     V_ = []
-    for name, tol, same, exc in _variants(compute_dtype, {} if bf16_exc is None else bf16_exc):
+    for name, tol, same, exc in _variants(compute_dtype, {} if bf16_exc is None else bf16_exc, projected=dec.project_context and dec.split_attention):
         V_.append(dict(name=name, tol=tol, same=same, exc=exc, loss=0.,
                        P={k: v.detach().cpu().double().requires_grad_(True) for k, v in dec.state_dict().items()},
                        ctx=ctx.double().requires_grad_(True), ht=ht.double().requires_grad_(True), c=c.double().requires_grad_(True)))
@@ -260,7 +270,9 @@ def _full_size_envdrop(vln, compute_dtype, T=3, train=True, fp32_weights=None, b
             ho, co = v["state"]
             Pv = bf16_weights(v["P"], skip=skip_round) if v["same"] else v["P"]   # the 128 -> 64 embedding (and fp32_weights) run in fp32
             cx = bf16_round_st(v["ctx"]) if v["same"] else v["ctx"]          # the text attention streams a bf16 copy of ctx
-            lo, (h1o, co), ho, _ = O.envdrop_step(Pv, a.double(), img_o, cand_o, ho, co, cx, ctx_mask, drop=drop)
+            # ... and scores on K = ctx W_in formed from the FP32 context when the module projects the context (round 5)
+            sc = v["ctx"] if (v["same"] and dec.scores_on_projected_context(ctx_d)) else None
+            lo, (h1o, co), ho, _ = O.envdrop_step(Pv, a.double(), img_o, cand_o, ho, co, cx, ctx_mask, drop=drop, score_ctx=sc)
             v["state"] = (ho, co)
             for got, ref, what in ((logit, lo, f"logit{t}"), (h1, h1o, f"h1_{t}"), (hd, ho, f"h_tilde{t}")):
                 check(got, ref, _tol_for(v["exc"], v["tol"], what), f"{v['name']}: {what}")
