@@ -713,6 +713,8 @@ def main():
     ap.add_argument("--no-split-pull", action="store_true", help="(A/B) the iteration's first launch pulls the WHOLE batch blob instead of leaving the "
                     "decoder-only part to a passenger workgroup of the encoder's recurrence launch")
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
+    ap.add_argument("--no-project-context", action="store_true", help="(A/B) the decoder projects its text-attention query every step "
+                    "(round 4's step: 8 dependent launches per direction) instead of scoring on K = ctx W_in formed once per rollout")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
                          "exchange issued between them (graphs.SegmentedIterationGraph) on a ONE-rank RCCL group, collectives "
@@ -788,6 +790,8 @@ def main():
     agent.dump_graph = args.dump_graph
     if args.no_chain:
         agent.dec.chain_steps = False
+    if args.no_project_context:
+        agent.dec.project_context = False
     if args.no_prologue:
         agent.use_prologue = False
     if args.no_split_pull:
@@ -1084,7 +1088,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "projected_context": bool(agent.dec.last_projected), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

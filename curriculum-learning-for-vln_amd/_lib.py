@@ -219,7 +219,7 @@ SIGNATURES = {
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
     "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_attn_bwd_rows": (i32, [ptr, i32, ptr, ptr, i64, ptr, ptr, i64, ptr, ptr, i32, i32, i32, ptr, i64, ptr]),
-    "vln_attn_dctx_deferred": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr]),
+    "vln_attn_dctx_deferred": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr, ptr]),
     "vln_lstm_pointwise_fwd": (i32, [ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32, i32, i32, ptr]),
     "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_dropout_mask": (i32, [ptr, i64, u64, u64, f32, ptr]),
@@ -294,6 +294,10 @@ SIGNATURES = {
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
     "vln_attn_sync_bytes": (i64, [i32]),
     "vln_attn_textk_ok": (i32, [i32, i32, i32, i32, ptr, i64]),
+    "vln_attn_textk_fwd": (i32, [ptr, i32, ptr, ptr, ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32,
+                                 i32, i32, i32, ptr, i64, ptr]),
+    "vln_attn_textk_bwd": (i32, [ptr, i32, ptr, ptr, ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32,
+                                 i32, i32, i32, ptr, i64, ptr]),
     "vln_envdrop_flush": (i32, [ptr]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),

@@ -267,9 +267,9 @@ extern "C" int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, 
 }
 extern "C" int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                                       const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,
-                                      int accumulate, vln_stream_t s) {
+                                      int accumulate, float* dk, vln_stream_t s) {
   if (!alpha || !dl || !g || !q || !dctx) { set_error("vln_attn_dctx_deferred: null pointer"); return VLN_ERR_ARG; }
-  return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate);
+  return attn_dctx_deferred((hipStream_t)s, alpha, dl, g, ldg, q, ldq, T, dctx, B, S, D, accumulate, nullptr, nullptr, nullptr, dk);
 }
 extern "C" int vln_attn_dctx_deferred_drop(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                                            const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D,
@@ -299,6 +299,28 @@ extern "C" int vln_lstm_pointwise_bwd(const float* dh1, const float* dh1_drop, c
   a.drop = DropSpec{seed, offset, p}; a.dc1 = dc1; a.lddc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
   a.c0 = c0; a.ldc0 = H; a.dgates = dgates; a.lddg = 4 * H; a.dc0 = dc0; a.lddc0 = H; a.B = B; a.H = H;
   return lstm_pointwise_bwd((hipStream_t)s, a);
+}
+extern "C" int vln_attn_textk_fwd(const void* ctx, int ctype, const float* kctx, const uint8_t* mask, const float* gates, int nsplit,
+                                  int64_t slab_stride, const float* b_ih, const float* b_hh, const float* c0, float* h1, float* c1,
+                                  float* act, float* tanh_c1, float* tcat, float* alpha, uint64_t seed, uint64_t offset, float p,
+                                  int B, int S, int H, void* sync, int64_t sync_bytes, vln_stream_t s) {
+  if (!ctx || !kctx || !gates || !c0 || !h1 || !c1 || !tcat || !alpha || B <= 0 || S <= 0 || H <= 0) { set_error("vln_attn_textk_fwd: bad args"); return VLN_ERR_ARG; }
+  LstmPwFwd a{};
+  a.gates = gates; a.nsplit = nsplit; a.slab_stride = slab_stride; a.bias_a = b_ih; a.bias_b = b_hh;
+  a.c0 = c0; a.ldc0 = H; a.h1 = h1; a.ldh1 = H; a.c1 = c1; a.ldc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
+  a.h1_drop = tcat + H; a.ldh1d = 2 * H; a.drop = DropSpec{seed, offset, p}; a.B = B; a.H = H;
+  return attn_textk_fwd((hipStream_t)s, ctx, ctype, kctx, mask, alpha, tcat, 2 * H, a, B, S, H, sync, (long)sync_bytes);
+}
+extern "C" int vln_attn_textk_bwd(const void* ctx, int ctype, const float* kctx, const float* alpha, const float* dtcat, int nsplit,
+                                  int64_t slab_stride, float* dwc_out, float* dq, float* dl, const float* dh1, const float* dc1,
+                                  const float* act, const float* tanh_c1, const float* c0, float* dgates, float* dc0, uint64_t seed,
+                                  uint64_t offset, float p, int B, int S, int H, void* sync, int64_t sync_bytes, vln_stream_t s) {
+  if (!ctx || !kctx || !alpha || !dtcat || nsplit < 1 || !dq || B <= 0 || S <= 0 || H <= 0) { set_error("vln_attn_textk_bwd: bad args"); return VLN_ERR_ARG; }
+  LstmPwBwd a{};
+  a.dh1_a = dh1; a.ld_a = H; a.drop = DropSpec{seed, offset, p}; a.dc1 = dc1; a.lddc1 = H; a.act = act; a.tanh_c1 = tanh_c1;
+  a.c0 = c0; a.ldc0 = H; a.dgates = dgates; a.lddg = 4 * H; a.dc0 = dc0; a.lddc0 = H; a.B = B; a.H = H;
+  return attn_textk_bwd((hipStream_t)s, ctx, ctype, kctx, alpha, SlabVec{dtcat, 2L * H, nsplit, (long)slab_stride}, dwc_out, 2 * H, dq, H,
+                        dl, a, B, S, H, sync, (long)sync_bytes);
 }
 extern "C" int vln_dropout_mask(float* out, int64_t n, uint64_t seed, uint64_t offset, float p, vln_stream_t s) {
   if (!out || n < 0) { set_error("vln_dropout_mask: bad args"); return VLN_ERR_ARG; }

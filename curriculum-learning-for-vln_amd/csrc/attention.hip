@@ -468,8 +468,8 @@ int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* at
 
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,
-                       const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p) {
-  if (T <= 0 || B <= 0 || S <= 0 || D <= 0 || (D & 3) || !aligned16(dctx)) {
+                       const uint64_t* drop_seed, const uint64_t* drop_off, const float* drop_p, float* dk) {
+  if (T <= 0 || B <= 0 || S <= 0 || D <= 0 || (D & 3) || !aligned16(dctx) || (dk && (!aligned16(dk) || drop_p))) {
     set_error("attn_dctx_deferred: bad args (T=%d B=%d S=%d D=%d)", T, B, S, D);
     return VLN_ERR_ARG;
   }
@@ -489,7 +489,7 @@ int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* c
       a.drop_p[t] = drop_p ? drop_p[t0 + t] : 0.f;
     }
     a.drop_base = drop_base_tls();
-    a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0;
+    a.ldg = ldg; a.ldq = ldq; a.dctx = dctx; a.dk = dk; a.S = S; a.D = D; a.accumulate = (accumulate || t0 > 0) ? 1 : 0; a.dk_accumulate = t0 > 0 ? 1 : 0;
     const unsigned lds = (unsigned)(2 * a.T * (D + 16) * sizeof(float));
     VLN_LAUNCH(attn_dctx_deferred_kernel, dim3(B, (S + 15) / 16), dim3(256), lds, st, a);
     VLN_CHECK_LAUNCH("attn_dctx_deferred");

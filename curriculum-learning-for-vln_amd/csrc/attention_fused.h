@@ -257,7 +257,8 @@ struct DctxArgs {
   const float* q[kDctxMaxSteps];       // [B,*] row stride ldq
   long ldg, ldq;
   float* dctx;                         // [B,S,D]
-  int T, S, D, accumulate, vec_ok;
+  float* dk;                           // nullable [B,S,D]: the (dl, q) half goes HERE (overwritten) instead of into dctx
+  int T, S, D, accumulate, dk_accumulate, vec_ok;
   // optional: step t's contribution passed through a dropout mask of the attended tensor (the Self-Monitor agent attends
   // dropout(ctx + pe) with a fresh mask every step: units.py:188-207); p == 0: none.  Mask index = flat [B,S,D] index.
   unsigned long long drop_seed[kDctxMaxSteps], drop_off[kDctxMaxSteps]; float drop_p[kDctxMaxSteps];
@@ -298,7 +299,19 @@ __global__ __launch_bounds__(256) void attn_dctx_deferred_kernel(DctxArgs a) {
   for (int t = 0; t < T; ++t) any_drop |= a.drop_p[t] > 0.f;
   for (int c = c0; c < D / 4; c += 16) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!any_drop) {
+    if (a.dk) {                               // two outputs: sum_t alpha_t g_t -> dctx, sum_t dl_t q_t -> dk
+      float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int v = 0; v < T; ++v) {
+        const float w = swt[v * 16 + r], w2 = swt[(T + v) * 16 + r];
+        const float4 x = *reinterpret_cast<const float4*>(&sv[(long)v * D + c * 4]);
+        const float4 x2 = *reinterpret_cast<const float4*>(&sv[(long)(T + v) * D + c * 4]);
+        acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+        acc2.x += w2 * x2.x; acc2.y += w2 * x2.y; acc2.z += w2 * x2.z; acc2.w += w2 * x2.w;
+      }
+      float4* o2 = reinterpret_cast<float4*>(a.dk + ((long)b * S + s) * D + c * 4);
+      if (a.dk_accumulate) { const float4 p = *o2; acc2.x += p.x; acc2.y += p.y; acc2.z += p.z; acc2.w += p.w; }
+      *o2 = acc2;
+    } else if (!any_drop) {
       for (int v = 0; v < 2 * T; ++v) {
         const float w = swt[v * 16 + r];
         const float4 x = *reinterpret_cast<const float4*>(&sv[(long)v * D + c * 4]);

@@ -164,26 +164,52 @@ __global__ __launch_bounds__(512) void attn_textk_fwd_kernel(TextKArgs a, AttnSp
   const int c0 = part * DP;
   if (threadIdx.x == 0) s_abort = 0;
 
-  // (1) both slices in flight: K (the dots) first, the context (the weighted sum) behind it
+  // (1) every load of the launch in flight at once, in the order the results are needed (the memory counter retires in issue
+  // order): the gate product's slabs (the previous launch's output: the longest latency) and the cell's other operands first,
+  // then K (the dots), then the context slice (the weighted sum), the mask last.
+  // The LSTM cell's pointwise stage of units [c0, c0 + DP) of row b (policy.py:237-240; gate order i,f,g,o): thread -> (unit
+  // group g of 4, gate q, slab residue r) sums slabs r, r + 4, r + 8, ... of its gate, 16-byte loads.
+  const LstmPwFwd& p = a.pw;
+  const int g = threadIdx.x & 31, q = (threadIdx.x >> 5) & 3, r = threadIdx.x >> 7;
+  const bool gon = 4 * g < DP;
+  const float* gp = p.gates + (long)b * 4 * H + (long)q * H + c0 + 4 * g;
+  float4 t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int sl = r + 4 * k;
+    t[k] = (gon && sl < p.nsplit) ? *reinterpret_cast<const float4*>(gp + (long)sl * p.slab_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int j = threadIdx.x;
+  float cprev = 0.f, bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < DP) {
+    cprev = p.c0[(long)b * p.ldc0 + c0 + j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p.bias_a) bias[k] += p.bias_a[k * H + c0 + j];
+      if (p.bias_b) bias[k] += p.bias_b[k * H + c0 + j];
+    }
+  }
   KS ks; CtxS cs;
   ks.load(a.kctx + (long)b * S * D + c0, S, D, DP / 4);
   cs.load(reinterpret_cast<const TC*>(a.ctx) + (long)b * S * D + c0, S, D, DP / VC);
   const unsigned tag = VLN_AGENT_LOAD(sy.seq + b) + 1u;
+  bool m0 = false, m1 = false;
+  if (a.mask) {
+    if (lane < S) m0 = a.mask[(long)b * S + lane] != 0;
+    if (lane + 64 < S) m1 = a.mask[(long)b * S + lane + 64] != 0;
+  }
 
-  // (2) the LSTM cell's pointwise stage of units [c0, c0 + DP) of row b (policy.py:237-240; gate order i,f,g,o).  Thread ->
-  // (unit group g of 4, gate q, slab residue r): sums slabs r, r + 4, r + 8, ... of its gate, 16-byte loads.
+  // (2) the cell
   {
-    const LstmPwFwd& p = a.pw;
-    const int g = threadIdx.x & 31, q = (threadIdx.x >> 5) & 3, r = threadIdx.x >> 7;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * g < DP) {
-      const float* gp = p.gates + (long)b * 4 * H + (long)q * H + c0 + 4 * g;
-      for (int s0 = r; s0 < p.nsplit; s0 += 16) {          // four partials in flight per round (one round up to 16 slabs)
-        float4 t[4];
+    float4 v;
+    v.x = (t[0].x + t[1].x) + (t[2].x + t[3].x); v.y = (t[0].y + t[1].y) + (t[2].y + t[3].y);
+    v.z = (t[0].z + t[1].z) + (t[2].z + t[3].z); v.w = (t[0].w + t[1].w) + (t[2].w + t[3].w);
+    if (gon) {
+      for (int s0 = r + 16; s0 < p.nsplit; s0 += 16) {       // more than 16 slabs (small shapes only): further rounds of four
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int s = s0 + 4 * k;
-          t[k] = (s < p.nsplit) ? *reinterpret_cast<const float4*>(gp + (long)s * p.slab_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int sl = s0 + 4 * k;
+          t[k] = (sl < p.nsplit) ? *reinterpret_cast<const float4*>(gp + (long)sl * p.slab_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         v.x += (t[0].x + t[1].x) + (t[2].x + t[3].x); v.y += (t[0].y + t[1].y) + (t[2].y + t[3].y);
         v.z += (t[0].z + t[1].z) + (t[2].z + t[3].z); v.w += (t[0].w + t[1].w) + (t[2].w + t[3].w);
@@ -191,20 +217,14 @@ __global__ __launch_bounds__(512) void attn_textk_fwd_kernel(TextKArgs a, AttnSp
     }
     *reinterpret_cast<float4*>(&sg[r][q][4 * g]) = v;
     __syncthreads();
-    const int j = threadIdx.x;
     if (j < kTextKCols) {
       float hd = 0.f;
       if (j < DP) {
         const int u = c0 + j;
         float pre[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float bias = 0.f;
-          if (p.bias_a) bias += p.bias_a[k * H + u];
-          if (p.bias_b) bias += p.bias_b[k * H + u];
-          pre[k] = ((sg[0][k][j] + sg[1][k][j]) + (sg[2][k][j] + sg[3][k][j])) + bias;
-        }
-        const LstmCellPw c = lstm_cell_pw(pre[0], pre[1], pre[2], pre[3], p.c0[(long)b * p.ldc0 + u]);
+        for (int k = 0; k < 4; ++k) pre[k] = ((sg[0][k][j] + sg[1][k][j]) + (sg[2][k][j] + sg[3][k][j])) + bias[k];
+        const LstmCellPw c = lstm_cell_pw(pre[0], pre[1], pre[2], pre[3], cprev);
         const long e = (long)b * H + u;
         p.h1[(long)b * p.ldh1 + u] = c.hn;
         p.c1[(long)b * p.ldc1 + u] = c.cn;
@@ -232,8 +252,8 @@ __global__ __launch_bounds__(512) void attn_textk_fwd_kernel(TextKArgs a, AttnSp
     const int s0 = lane, s1 = lane + 64;
     const long ro = (long)b * S;
     float v0 = -INFINITY, v1 = -INFINITY;
-    if (s0 < S && !(a.mask && a.mask[ro + s0])) v0 = sdots[s0];
-    if (s1 < S && !(a.mask && a.mask[ro + s1])) v1 = sdots[s1];
+    if (s0 < S && !m0) v0 = sdots[s0];
+    if (s1 < S && !m1) v1 = sdots[s1];
     const float mx = wave_max(fmaxf(v0, v1));
     const float e0 = (s0 < S) ? __expf(v0 - mx) : 0.f, e1 = (s1 < S) ? __expf(v1 - mx) : 0.f;
     const float inv = 1.0f / wave_sum(e0 + e1);
@@ -275,12 +295,9 @@ __global__ __launch_bounds__(512) void attn_textk_bwd_kernel(TextKArgs a, AttnSp
   const int c0 = part * DP;
   if (threadIdx.x == 0) s_abort = 0;
 
-  // (1) the context slice (the dots and dq) first, K (d drop(h1)) behind it
-  CtxS cs; KS ks;
-  cs.load(reinterpret_cast<const TC*>(a.ctx) + (long)b * S * D + c0, S, D, DP / VC);
-  ks.load(a.kctx + (long)b * S * D + c0, S, D, DP / 4);
-  const unsigned tag = VLN_AGENT_LOAD(sy.seq + b) + 1u;
-  // d(weighted ctx) and linear_out's share of d drop(h1) for this part's columns, summed from the split-K slabs while staged
+  // (1) every load in flight at once, in the order the results are needed: d(weighted ctx) and linear_out's share of d drop(h1)
+  // for this part's columns (the previous launch's split-K slabs, summed while staged) first, then the context slice (the dots
+  // and dq), then K (d drop(h1)), then alpha and the operands of the cell's pointwise backward
   if (threadIdx.x < 2 * (kTextKCols / 4)) {
     const int half = threadIdx.x / (kTextKCols / 4), i = (threadIdx.x % (kTextKCols / 4)) * 4;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -289,6 +306,25 @@ __global__ __launch_bounds__(512) void attn_textk_bwd_kernel(TextKArgs a, AttnSp
       if (half == 0 && a.dwc_out) *reinterpret_cast<float4*>(a.dwc_out + (long)b * a.lddo + c0 + i) = t;
     }
     *reinterpret_cast<float4*>(half ? &sdh[i] : &sq[i]) = t;
+  }
+  CtxS cs; KS ks;
+  cs.load(reinterpret_cast<const TC*>(a.ctx) + (long)b * S * D + c0, S, D, DP / VC);
+  ks.load(a.kctx + (long)b * S * D + c0, S, D, DP / 4);
+  const unsigned tag = VLN_AGENT_LOAD(sy.seq + b) + 1u;
+  float a0 = 0.f, a1 = 0.f;
+  if (lane < S) a0 = a.alpha[(long)b * S + lane];
+  if (lane + 64 < S) a1 = a.alpha[(long)b * S + lane + 64];
+  const LstmPwBwd& p = a.pb;
+  const int j = threadIdx.x;
+  float e_dh = 0.f, e_si = 0.f, e_sf = 0.f, e_tg = 0.f, e_so = 0.f, e_tc = 0.f, e_c0 = 0.f, e_dc = 0.f;
+  if (j < DP) {
+    const int u = c0 + j;
+    if (p.dh1_a) e_dh = p.dh1_a[(long)b * p.ld_a + u];
+    const float* act = p.act + (long)b * 4 * H + u;
+    e_si = act[0]; e_sf = act[H]; e_tg = act[2 * H]; e_so = act[3 * H];
+    e_tc = p.tanh_c1[(long)b * H + u];
+    e_c0 = p.c0[(long)b * p.ldc0 + u];
+    if (p.dc1) e_dc = p.dc1[(long)b * p.lddc1 + u];
   }
   __syncthreads();
 
@@ -302,9 +338,9 @@ __global__ __launch_bounds__(512) void attn_textk_bwd_kernel(TextKArgs a, AttnSp
   {
     const int s0 = lane, s1 = lane + 64;
     const long ro = (long)b * S;
-    float a0 = 0.f, a1 = 0.f, g0 = 0.f, g1 = 0.f;
-    if (s0 < S) { a0 = a.alpha[ro + s0]; g0 = sdots[s0]; }
-    if (s1 < S) { a1 = a.alpha[ro + s1]; g1 = sdots[s1]; }
+    float g0 = 0.f, g1 = 0.f;
+    if (s0 < S) g0 = sdots[s0];
+    if (s1 < S) g1 = sdots[s1];
     const float tot = wave_sum(a0 * g0 + a1 * g1);
     w0 = a0 * (g0 - tot); w1 = a1 * (g1 - tot);
     if (part == 0 && wave == 0 && a.wout) {
@@ -338,24 +374,17 @@ __global__ __launch_bounds__(512) void attn_textk_bwd_kernel(TextKArgs a, AttnSp
   __syncthreads();
 
   // (5) the cell's pointwise backward on units [c0, c0 + DP) (lstm_pw_bwd_body's formulas)
-  const int j = threadIdx.x;
   if (j < DP) {
-    const LstmPwBwd& p = a.pb;
     const int u = c0 + j;
     const long e = (long)b * H + u;
-    float dh = p.dh1_a ? p.dh1_a[(long)b * p.ld_a + u] : 0.f;
-    dh += sdh[j] * dropout_scale1(p.drop.seed, p.drop.off(), (uint32_t)e, p.drop.p);
-    const float* act = p.act + (long)b * 4 * H + u;
-    const float si = act[0], sf = act[H], tg = act[2 * H], so = act[3 * H];
-    const float tc = p.tanh_c1[e];
-    const float cprev = p.c0[(long)b * p.ldc0 + u];
-    const float dc = (p.dc1 ? p.dc1[(long)b * p.lddc1 + u] : 0.f) + dh * so * (1.f - tc * tc);
+    const float dh = e_dh + sdh[j] * dropout_scale1(p.drop.seed, p.drop.off(), (uint32_t)e, p.drop.p);
+    const float dc = e_dc + dh * e_so * (1.f - e_tc * e_tc);
     float* dg = p.dgates + (long)b * p.lddg + u;
-    dg[0] = dc * tg * si * (1.f - si);
-    dg[H] = dc * cprev * sf * (1.f - sf);
-    dg[2 * H] = dc * si * (1.f - tg * tg);
-    dg[3 * H] = dh * tc * so * (1.f - so);
-    p.dc0[(long)b * p.lddc0 + u] = dc * sf;
+    dg[0] = dc * e_tg * e_si * (1.f - e_si);
+    dg[H] = dc * e_c0 * e_sf * (1.f - e_sf);
+    dg[2 * H] = dc * e_si * (1.f - e_tg * e_tg);
+    dg[3 * H] = dh * e_tc * e_so * (1.f - e_so);
+    p.dc0[(long)b * p.lddc0 + u] = dc * e_sf;
   }
 }
 

@@ -104,7 +104,7 @@ int gemm_nt_slabs(int M, int N, int K, int wtype, long ws_floats) {
 int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
                   int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_fused: bad dims"); return VLN_ERR_ARG; }
-  if (n16_applies(M, N, K, wtype)) return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, Y2, ldy2, drop);
+  if (!(act & ACT_ACCUM) && n16_applies(M, N, K, wtype)) return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, Y2, ldy2, drop);
   int nsplit = 1;
   int r = gemm_nt(st, X, ldx, W, wtype, ldw, nullptr, 0, M, N, K, nullptr, ACT_NONE, ws, ws_floats, &nsplit);
   if (r != VLN_OK) return r;
@@ -114,7 +114,7 @@ int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int w
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }
-  if (nsplit_out == nullptr && n16_applies(M, N, K, wtype))
+  if (nsplit_out == nullptr && !(act & ACT_ACCUM) && n16_applies(M, N, K, wtype))
     return launch_n16(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, act, nullptr, 0, DropSpec{0, 0, 0.f});
   const int BK = (wtype == W_F32) ? 32 : 64;
   // 128-column tiles for the wide AND deep products consumed from slabs (LSTM gates, d xcat: N, K >= 2048): measured

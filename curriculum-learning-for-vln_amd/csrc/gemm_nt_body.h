@@ -339,8 +339,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const VBlock& 
         if (row < a.M) {
           float v = acc[t][rb][r] + bv;
           if (fused) {
-            if (a.act == ACT_TANH) v = tanhf(v);
-            else if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+            if ((a.act & 3) == ACT_TANH) v = tanhf(v);
+            else if ((a.act & 3) == ACT_RELU) v = fmaxf(v, 0.0f);
+            if (a.act & ACT_ACCUM) v += y[(long)row * a.ldy + wn[t]];
           }
           y[(long)row * a.ldy + wn[t]] = v;
         }

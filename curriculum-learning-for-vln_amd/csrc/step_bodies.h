@@ -111,8 +111,9 @@ __device__ __forceinline__ void reduce_epilogue_body(const ReduceEpiArgs& a, lon
     }
     for (; s < nsplit; ++s) v += sp[(long)s * a.slab_stride];
     v += (v1 + v2) + v3;
-    if (a.act == ACT_TANH) v = tanhf(v);
-    else if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+    if ((a.act & 3) == ACT_TANH) v = tanhf(v);
+    else if ((a.act & 3) == ACT_RELU) v = fmaxf(v, 0.0f);
+    if (a.act & ACT_ACCUM) v += a.out[(long)r * a.ldo + c];
     a.out[(long)r * a.ldo + c] = v;
     if (a.out2) a.out2[(long)r * a.ldo2 + c] = v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)e, a.drop.p);
   }

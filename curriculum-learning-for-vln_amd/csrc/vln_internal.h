@@ -14,7 +14,8 @@ struct vln_colsum_job;
 
 namespace vln {
 
-enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
+// ACT_ACCUM (a flag on top of the activation): the finished result is ADDED to what the output holds (Y += act(X W^T + bias))
+enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_ACCUM = 8 };
 // W_F32S (round 4): the weights are an fp32 array in memory like W_F32, but the product runs on the bf16 matrix pipe with BOTH
 // operands split hi + lo (x_hi w_hi + x_lo w_hi + x_hi w_lo; the dropped lo*lo term is 2^-16 relative, fp32 accumulate): what the
 // bf16 mode uses for the matrices it streams in fp32 all the same (EnvDropDecoder / MonitorDecoder `fp32_weights`).  Same bytes as
@@ -199,7 +200,8 @@ int attn_textk_bwd(hipStream_t st, const void* ctx, int ctype, const float* kctx
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,
-                       const uint64_t* drop_seed = nullptr, const uint64_t* drop_off = nullptr, const float* drop_p = nullptr);
+                       const uint64_t* drop_seed = nullptr, const uint64_t* drop_off = nullptr, const float* drop_p = nullptr,
+                       float* dk = nullptr);      // dk: the (dl, q) half written to its own [B,S,D] tensor instead of into dctx
 // dvec[b,:] = sum_c w[b,c] ctx[b,c,:]  (plain weighted sum, no softmax)
 int rows_wsum(hipStream_t st, const void* ctx, int ctype, const float* w, float* out, long ldo, int B, int S,
               int D);

@@ -15,6 +15,7 @@ F32, BF16 = 0, 1
 F32S = 2      # weight operands: fp32 in memory, split-bf16 arithmetic (include/vln_hip.h VLN_F32S)
 F32X = 3      # ... three bf16 pieces per operand, six products: fp32-grade (VLN_F32X)
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+ACT_ACCUM = 8          # flag: out += act(x @ w.T + bias)  (VLN_ACT_ACCUM)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -564,19 +565,21 @@ def attn_bwd_rows(ctx, attn, dwc, dattn_ext=None, want_dl=False, out=None, sync=
     return dvec, dl
 
 
-def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accumulate=False, drop=None):
+def attn_dctx_deferred(alpha_ptrs, dl_ptrs, g_ptrs, ldg, q_ptrs, ldq, out, accumulate=False, drop=None, dk=None):
     """out[b,s,:] (+)= sum_t (alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]) [* mask_t]; the four lists hold T device
     addresses ((dl_t, q_t) may both be None: a pure outer product); drop = [(seed, offset, p)] per step multiplies step
-    t's term by that dropout mask over the flat [B,S,D] index (the attended tensor's own per-step dropout)."""
+    t's term by that dropout mask over the flat [B,S,D] index (the attended tensor's own per-step dropout).
+    dk ([B,S,D], no drop): the (dl, q) half lands there instead of in `out` (the projected-context form, runtime.CtxGate)."""
     lib = _lib.load()
     T = len(alpha_ptrs)
     B, S, D = out.shape
     assert out.is_contiguous() and len(dl_ptrs) == T and len(g_ptrs) == T and len(q_ptrs) == T
     arr = (C.c_void_p * (4 * T))(*alpha_ptrs, *dl_ptrs, *g_ptrs, *q_ptrs)
     base = C.addressof(arr)
-    if drop is None and None not in dl_ptrs:
+    if drop is None and (dk is not None or None not in dl_ptrs):
+        assert dk is None or (dk.is_contiguous() and dk.shape == out.shape)
         _lib.check(lib.vln_attn_dctx_deferred(base, base + 8 * T, base + 16 * T, ldg, base + 24 * T, ldq, T, _p(out), B, S, D,
-                                              1 if accumulate else 0, _stream()), "vln_attn_dctx_deferred")
+                                              1 if accumulate else 0, _p(dk), _stream()), "vln_attn_dctx_deferred")
         return out
     drop = drop or [(0, 0, 0.0)] * T
     seeds = (C.c_uint64 * T)(*[d[0] for d in drop]); offs = (C.c_uint64 * T)(*[d[1] for d in drop])
@@ -675,3 +678,34 @@ def lstm_pointwise_bwd(dh1, dh1_drop, dc1, act, tanh_c1, c0, seed=0, offset=0, p
     _lib.check(lib.vln_lstm_pointwise_bwd(_p(dh1), _p(dh1_drop), _p(dc1), seed, offset, p, _p(act), _p(tanh_c1),
                                           _p(c0), _p(dg), _p(dc0), B, H, _stream()), "vln_lstm_pointwise_bwd")
     return dg, dc0
+
+
+def attn_textk_fwd(ctx, kctx, mask, gates, b_ih, b_hh, c0, sync, seed=0, offset=0, p=0.0):
+    """The projected-context text attention with the LSTM cell's pointwise stage in the same launch (vln_attn_textk_fwd):
+    gates [n,B,4H] slabs, ctx [B,S,H] fp32|bf16, kctx [B,S,H] fp32 -> (h1, c1, act, tanh_c1, tcat [B,2H], alpha [B,S])."""
+    lib = _lib.load()
+    B, S, H = ctx.shape
+    n = gates.shape[0]
+    dev = ctx.device
+    h1, c1 = empty(B, H, device=dev), empty(B, H, device=dev)
+    act, tc = empty(B, 4 * H, device=dev), empty(B, H, device=dev)
+    tcat, alpha = empty(B, 2 * H, device=dev), empty(B, S, device=dev)
+    _lib.check(lib.vln_attn_textk_fwd(_p(ctx), _dt(ctx), _p(kctx), _p(mask), _p(gates), n, gates.stride(0), _p(b_ih), _p(b_hh), _p(c0),
+                                      _p(h1), _p(c1), _p(act), _p(tc), _p(tcat), _p(alpha), seed, offset, p, B, S, H, _p(sync),
+                                      sync.numel() * sync.element_size(), _stream()), "vln_attn_textk_fwd")
+    return h1, c1, act, tc, tcat, alpha
+
+
+def attn_textk_bwd(ctx, kctx, alpha, dtcat, dh1, dc1, act, tanh_c1, c0, sync, seed=0, offset=0, p=0.0):
+    """Backward of attn_textk_fwd (vln_attn_textk_bwd): dtcat [n,B,2H] slabs -> (dq [B,H], dl [B,S], dwc [B,2H] (cols [0,H)),
+    dgates [B,4H], dc0 [B,H])."""
+    lib = _lib.load()
+    B, S, H = ctx.shape
+    n = dtcat.shape[0]
+    dev = ctx.device
+    dq, dl, dwc = empty(B, H, device=dev), empty(B, S, device=dev), zeros(B, 2 * H, device=dev)
+    dg, dc0 = empty(B, 4 * H, device=dev), empty(B, H, device=dev)
+    _lib.check(lib.vln_attn_textk_bwd(_p(ctx), _dt(ctx), _p(kctx), _p(alpha), _p(dtcat), n, dtcat.stride(0), _p(dwc), _p(dq), _p(dl),
+                                      _p(dh1), _p(dc1), _p(act), _p(tanh_c1), _p(c0), _p(dg), _p(dc0), seed, offset, p, B, S, H,
+                                      _p(sync), sync.numel() * sync.element_size(), _stream()), "vln_attn_textk_bwd")
+    return dq, dl, dwc, dg, dc0

@@ -352,13 +352,14 @@ class CtxGate(torch.autograd.Function):
                 if kmode:
                     # projected context (vln_envdrop_step.kctx): the steps' queries never existed.  dctx = sum_t alpha_t g_t +
                     # (sum_t dl_t hd_t) W_in^T with hd_t = drop(h_1) of step t (t[3]: the tcat stash rows, columns [H, 2H))
-                    none = [None] * len(terms)
-                    dk = ops.empty(B, L, H, dtype=torch.float32, device=terms[0][4].device)
-                    ops.attn_dctx_deferred(none, [t[1] for t in terms], none, 2 * H, [t[3] for t in terms], 2 * H, dk)
-                    d2 = ops.linear_fwd(dk.view(B * L, H), e.k_w, split=e.k_split).view(B, L, H)
-                    if acc:
-                        d2 += d
-                    d = ops.attn_dctx_deferred([t[0] for t in terms], none, [t[2] for t in terms], 2 * H, none, 2 * H, d2, accumulate=True)
+                    # -- ONE pass over the steps' vectors writes both sums, ONE product adds the second through W_in^T
+                    dev = terms[0][4].device
+                    dk = ops.empty(B, L, H, dtype=torch.float32, device=dev)
+                    if d is None:
+                        d = ops.empty(B, L, H, dtype=torch.float32, device=dev)
+                    ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
+                                           [t[3] for t in terms], 2 * H, d, accumulate=acc, dk=dk)
+                    ops.linear_fwd(dk.view(B * L, H), e.k_w, act=ops.ACT_ACCUM, out=d.view(B * L, H), split=e.k_split)
                 else:
                     ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
                                            [t[3] for t in terms], H, d, accumulate=acc)

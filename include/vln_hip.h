@@ -40,6 +40,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_NONE 0
 #define VLN_ACT_TANH 1
 #define VLN_ACT_RELU 2
+#define VLN_ACT_ACCUM 8   /* flag, OR-ed onto an activation: the finished result is ADDED to the output (vln_linear_fwd: Y += ...) */
 
 int vln_abi_version(void);     /* 14 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
@@ -222,10 +223,13 @@ int vln_attn_bwd_rows(const void* ctx, int ctype, const float* attn, const float
                       float* dots_scratch /*nullable*/, int B, int S, int D, void* sync /*nullable*/, int64_t sync_bytes,
                       vln_stream_t s);
 /* dctx[b,s,:] (+)= sum_t alpha[t][b,s] * g[t][b,:] + dl[t][b,s] * q[t][b,:]  -- the context gradient of a whole rollout
- * (T decoder steps) in one pass; alpha/dl/g/q are HOST arrays of T device pointers. */
+ * (T decoder steps) in one pass; alpha/dl/g/q are HOST arrays of T device pointers; a step may carry only its (alpha, g) or
+ * only its (dl, q) pair (the other two NULL).  dk (nullable, ABI v15): the (dl, q) half is written to THIS [B,S,D] tensor
+ * instead of into dctx -- with vln_envdrop_step.kctx the q operands are the steps' drop(h_1) rows and
+ * dctx = sum_t alpha_t g_t + dk W_in^T (one vln_linear_fwd with VLN_ACT_ACCUM onto dctx). */
 int vln_attn_dctx_deferred(const float* const* alpha, const float* const* dl, const float* const* g, int64_t ldg,
                            const float* const* q, int64_t ldq, int T, float* dctx, int B, int S, int D, int accumulate,
-                           vln_stream_t s);
+                           float* dk, vln_stream_t s);
 /* Same, with step t's contribution multiplied by the dropout mask (drop_seed[t], drop_off[t], drop_p[t]; mask index = flat
  * [B,S,D] index) the attended tensor went through in that step, and with (dl[t], q[t]) allowed to be NULL together
  * (a pure outer-product term).  HOST arrays of T entries.  The Self-Monitor agent's context and candidate gradients. */
@@ -803,6 +807,24 @@ typedef struct vln_envdrop_grads {
   const float* dhtd_ext;
 } vln_envdrop_grads;
 
+/* The two launches vln_envdrop_step.kctx puts into the step, callable on their own (csrc/attention_textk.h; reference
+ * policy.py:237-241 + units.py:106-117).  Forward: the LSTM cell's pointwise stage on the gate pre-activations `gates`
+ * ([nsplit][B,4H] split-K slabs, slab s at gates + s * slab_stride; order i,f,g,o; + b_ih + b_hh, nullable) -> h1, c1 [B,H],
+ * act [B,4H] / tanh_c1 [B,H] (saved, nullable), tcat[:, H:2H) = dropout(h1) (Philox (seed, offset), p); then
+ * alpha [B,S] = softmax(mask(kctx . dropout(h1))) and tcat[:, 0:H) = sum_s alpha ctx (tcat [B,2H]).  ctx [B,S,H] of `ctype`
+ * (VLN_F32 / VLN_BF16), kctx [B,S,H] fp32 = ctx W_in.  Backward: dtcat = d tcat ([nsplit][B,2H] slabs) -> d alpha = ctx . d wc,
+ * dl (d logits, [B,S], nullable), dq [B,H] = sum_s dl ctx (the dY rows of d W_in), dwc_out (nullable, [B,2H] rows: columns
+ * [0,H) receive the summed d wc), and the cell's pointwise backward with d drop(h1) = dtcat[:, H:] + sum_s dl kctx:
+ * dgates [B,4H], dc0 [B,H] (dh1 / dc1: external gradients on h1 / c1, nullable).  `sync` as vln_envdrop_step.attn_sync; the call
+ * fails unless vln_attn_textk_ok(ctype, B, S, H, sync, sync_bytes). */
+int vln_attn_textk_fwd(const void* ctx, int ctype, const float* kctx, const uint8_t* mask, const float* gates, int nsplit,
+                       int64_t slab_stride, const float* b_ih, const float* b_hh, const float* c0, float* h1, float* c1, float* act,
+                       float* tanh_c1, float* tcat, float* alpha, uint64_t seed, uint64_t offset, float p, int B, int S, int H,
+                       void* sync, int64_t sync_bytes, vln_stream_t s);
+int vln_attn_textk_bwd(const void* ctx, int ctype, const float* kctx, const float* alpha, const float* dtcat, int nsplit,
+                       int64_t slab_stride, float* dwc_out, float* dq, float* dl, const float* dh1, const float* dc1,
+                       const float* act, const float* tanh_c1, const float* c0, float* dgates, float* dc0, uint64_t seed,
+                       uint64_t offset, float p, int B, int S, int H, void* sync, int64_t sync_bytes, vln_stream_t s);
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
 int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
 /* 1 when the folded text attention of vln_envdrop_step.kctx covers (ctype, B episodes, S tokens, D = H) on the current device with

@@ -511,3 +511,93 @@ def test_split_attention_timeout_has_its_own_sticky_word_and_switches_the_split_
         lib.vln_set_split_attention(1)
     out2, _ = vln.ops.attn_fwd_rows(ctx, q, None, sync=sync)
     assert torch.equal(out2, out_split)
+
+
+@pytest.mark.parametrize("B,S,H,n", [(64, 80, 512, 8), (9, 13, 64, 1), (17, 96, 96, 5), (64, 33, 32, 19), (3, 1, 512, 2)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_text_attention_on_projected_context_with_the_cell_in_the_launch(vln, B, S, H, n, cdt):
+    """csrc/attention_textk.h (vln_attn_textk_fwd / _bwd): the LSTM cell's pointwise stage from split-K gate slabs + the text
+    attention scored on K = ctx W_in, one launch each way, against fp64 torch math of policy.py:237-241 / units.py:106-117 with
+    the kernels' dropout mask: h1, c1, the attention weights, [weighted ctx | drop(h1)], and in the backward d logits, dq (the
+    dY rows of d W_in), d(weighted ctx) written back, d gates and d c0 -- ragged masks, B not a multiple of 8, parts narrower
+    than a slice (H / 4 = 8 .. 128 columns), 1 .. 19 slabs, three launches in a row on ONE exchange buffer."""
+    g = torch.Generator().manual_seed(B * 7 + S * 3 + H + n)
+    p, seed = 0.5, 0xABCD
+    tol = 1e-4 if cdt == torch.float32 else 1e-2
+    sync = vln.ops.attn_sync_buffer(B, dev())
+    assert vln._lib.load().vln_attn_textk_ok(vln.ops._dt(torch.empty(0, dtype=cdt)), B, S, H, sync.data_ptr(), sync.numel() * 4) == 1
+    for it in range(3):
+        ctx = (torch.randn(B, S, H, generator=g) * 0.5).to(cdt)
+        w_in = torch.randn(H, H, generator=g) / H ** 0.5
+        kctx = (ctx.double() @ w_in.double()).float()                              # K = ctx W_in  (t = W_in h; logits = ctx . t)
+        mask = torch.zeros(B, S, dtype=torch.bool)
+        for b in range(B):
+            mask[b, max(1, S - (b % S)):] = True
+        gates = torch.randn(n, B, 4 * H, generator=g) / n ** 0.5
+        b_ih, b_hh = torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1
+        c0 = torch.randn(B, H, generator=g) * 0.5
+        off = 11 + it
+        md = vln.ops.dropout_mask(B * H, seed, off, p, dev()).cpu().double().view(B, H)
+        # fp64 reference
+        pre = (gates.double().sum(0) + b_ih.double() + b_hh.double()).requires_grad_(True)
+        c0r = c0.double().requires_grad_(True)
+        i_, f_, g_, o_ = pre.split(H, 1)
+        c1r = torch.sigmoid(f_) * c0r + torch.sigmoid(i_) * torch.tanh(g_)
+        h1r = torch.sigmoid(o_) * torch.tanh(c1r)
+        hd = h1r * md
+        logits = torch.einsum("bsd,bd->bs", kctx.double(), hd).masked_fill(mask, -float("inf"))
+        attn = torch.softmax(logits, 1)
+        attn.retain_grad(); logits.retain_grad()
+        wc = torch.einsum("bs,bsd->bd", attn, ctx.double())
+        tcat_r = torch.cat((wc, hd), 1)
+        h1_, c1_, act, tc, tcat, alpha = vln.ops.attn_textk_fwd(ctx.to(dev()), kctx.to(dev()), mask.to(dev()).view(torch.uint8), gates.to(dev()),
+                                                                b_ih.to(dev()), b_hh.to(dev()), c0.to(dev()), sync, seed, off, p)
+        check(h1_, h1r.detach(), 1e-5, "h1"); check(c1_, c1r.detach(), 1e-5, "c1")
+        check(alpha, attn.detach(), tol, "alpha"); check(tcat, tcat_r.detach(), tol, "tcat")
+        assert (alpha * mask.to(dev())).abs().max().item() == 0.0
+        # backward: a random d tcat (in m slabs) + external gradients on h1 and c1
+        m = 1 + (it + n) % 4
+        dtcat = torch.randn(m, B, 2 * H, generator=g) / m ** 0.5
+        dh1, dc1 = torch.randn(B, H, generator=g) * 0.3, torch.randn(B, H, generator=g) * 0.3
+        loss = (tcat_r * dtcat.double().sum(0)).sum() + (h1r * dh1.double()).sum() + (c1r * dc1.double()).sum()
+        dpre, dc0r = torch.autograd.grad(loss, (pre, c0r), retain_graph=True)
+        dlr, = torch.autograd.grad(loss, logits, retain_graph=True)
+        dq, dl, dwc, dg, dc0 = vln.ops.attn_textk_bwd(ctx.to(dev()), kctx.to(dev()), alpha, dtcat.to(dev()), dh1.to(dev()), dc1.to(dev()),
+                                                      act, tc, c0.to(dev()), sync, seed, off, p)
+        dlr = torch.nan_to_num(dlr)                                                    # masked positions: exactly zero
+        check(dl, dlr, tol, "dl"); check(dq, torch.einsum("bs,bsd->bd", dlr, ctx.double()), tol, "dq")
+        check(dwc[:, :H], dtcat.double().sum(0)[:, :H], 1e-5, "dwc written back")
+        check(dg, dpre, tol, "dgates"); check(dc0, dc0r, tol, "dc0")
+    torch.cuda.synchronize()
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    assert int(sync[0].item()) == 6
+
+
+def test_linear_fwd_accumulates_onto_its_output(vln):
+    """VLN_ACT_ACCUM: Y += X W^T on the fused tall form (M = 5120: dctx += dK W_in^T of the projected context), on the split-K +
+    reduce form (M = 64) and on a narrow output, plain and split-fp32 weights."""
+    g = torch.Generator().manual_seed(77)
+    for M, N, K in ((5120, 512, 512), (64, 512, 2048), (130, 12, 36)):
+        x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; y0 = torch.randn(M, N, generator=g)
+        ref = y0.double() + x.double() @ w.double().t()
+        for split in (False, True):
+            y = y0.clone().to(dev())
+            vln.ops.linear_fwd(x.to(dev()), w.to(dev()), act=vln.ops.ACT_ACCUM, out=y, split=split)
+            check(y, ref, 1e-4, f"y ({M},{N},{K}) split={split}")
+
+
+def test_attention_dctx_deferred_second_output(vln):
+    """`dk`: the (dl, q) half of the rollout's context gradient in its own tensor (the projected-context form), over more steps
+    than one launch stages, with and without accumulation into dctx."""
+    B, S, D, T = 8, 20, 512, 35
+    g = torch.Generator().manual_seed(10)
+    al = torch.rand(T, B, S, generator=g).to(dev()); dl = torch.randn(T, B, S, generator=g).to(dev())
+    gw = torch.randn(T, B, 2 * D, generator=g).to(dev()); q = torch.randn(T, B, 2 * D, generator=g).to(dev())
+    ref_a = torch.einsum("tbs,tbd->bsd", al.double(), gw[:, :, :D].double())
+    ref_k = torch.einsum("tbs,tbd->bsd", dl.double(), q[:, :, D:].double())
+    for acc in (False, True):
+        out = torch.full((B, S, D), 0.5, device=dev()); dk = torch.full((B, S, D), 7.0, device=dev())
+        vln.ops.attn_dctx_deferred([al[t].data_ptr() for t in range(T)], [dl[t].data_ptr() for t in range(T)],
+                                   [gw[t].data_ptr() for t in range(T)], 2 * D, [q[t].data_ptr() + 4 * D for t in range(T)], 2 * D, out,
+                                   accumulate=acc, dk=dk)
+        check(out, ref_a + (0.5 if acc else 0.0), 1e-5, "dctx half"); check(dk, ref_k, 1e-5, "dk half")
