@@ -21,8 +21,9 @@ def dev():
 from parity import check, rel_err
 
 
+# (the last three: TALL products, M = B * L rows -- the encoder's input projection, the projected context K = ctx W_in; ragged M and N)
 @pytest.mark.parametrize("M,N,K", [(64, 2048, 2752), (64, 2176, 512), (64, 512, 1024), (4, 48, 40), (7, 1, 64),
-                                   (130, 100, 36), (64, 512, 2176), (256, 64, 128)])
+                                   (130, 100, 36), (64, 512, 2176), (256, 64, 128), (5120, 2048, 256), (5000, 512, 512), (1100, 96, 256)])
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 def test_linear_fwd(vln, M, N, K, wdt):
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
@@ -36,7 +37,7 @@ def test_linear_fwd(vln, M, N, K, wdt):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 2048, 2752), (64, 2176, 512), (1152, 1024, 2176), (64, 512, 1024), (4, 48, 40), (7, 1, 64),
-                                   (130, 100, 36)])
+                                   (130, 100, 36), (5120, 512, 512), (5000, 2048, 256), (1100, 96, 512)])
 def test_linear_fwd_split_fp32_weights(vln, M, N, K):
     """VLN_F32S (round 4): fp32 weights multiplied on the bf16 matrix pipe with BOTH operands split hi + lo (three products, the
     dropped lo * lo term is 2^-16 relative) -- the arithmetic of the bf16 mode's fp32-streamed matrices.  fp32-grade: 1e-4 of the
