@@ -208,6 +208,7 @@ SIGNATURES = {
     "vln_linear_fwd_slabs": (i32, [ptr, i64, ptr, i32, i64, i32, i32, i32, ptr, i64, C.POINTER(i32), ptr]),
     "vln_wgrad_ride_post": (i32, [ptr, i32, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_wgrad_ride_flush": (i32, [ptr]),
+    "vln_wgrad_ride_drop": (i32, [ptr]),
     "vln_wgrad_ride_stats": (i32, [C.POINTER(i64)]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
@@ -299,6 +300,7 @@ SIGNATURES = {
     "vln_attn_textk_bwd": (i32, [ptr, i32, ptr, ptr, ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32,
                                  i32, i32, i32, ptr, i64, ptr]),
     "vln_envdrop_flush": (i32, [ptr]),
+    "vln_envdrop_drop_pending": (i32, [ptr]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
     "vln_envdrop_step_bwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep),
                                    C.POINTER(EnvDropGrads), ptr]),

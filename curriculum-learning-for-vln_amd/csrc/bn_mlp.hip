@@ -99,10 +99,11 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     float* si = saved + L.s[i];
     float* yi = saved + L.y[i];
     // split-K scratch bounded like ops.linear_fwd bounds it: the same K split, hence the same bits, as the operator path.
-    // VLN_F32S (fp32-streamed layer of the bf16 mode): the FORWARD product runs on the exact fp32 MFMA -- a ReLU follows (behind the
-    // BatchNorm), and a unit whose pre-activation moves across zero changes a whole gradient term: the 2^-16 of the split product
-    // flipped ~10 of the 1.2 M units at BASELINE config 2 (2.5e-2 of the weight gradient's range, profiles/round4_notes.md), the
-    // exact product flips none.  The backward's products (no ReLU decision in them) keep the split form.
+    // VLN_F32S (fp32-streamed layer of the bf16 mode): the FORWARD product runs in the fp32-GRADE six-product form (W_F32X) -- a
+    // ReLU follows (behind the BatchNorm), and a unit whose pre-activation moves across zero changes a whole gradient term: the
+    // 2^-16 of the three-product form flipped ~10 of the 1.2 M units at BASELINE config 2 (2.5e-2 of the weight gradient's range,
+    // profiles/round4_notes.md), the six-product form none beyond what exact fp32 itself flips against fp64 (the exact fp32 MFMA
+    // cost 92 us per call at M = 1152).  The backward's products (no ReLU decision in them) keep the three-product form.
     // a ReLU decision follows this product: an fp32-streamed layer multiplies in the fp32-GRADE six-product form (W_F32X), not the 2^-16 one
     RUN(gemm_nt(st, y, in, l.w, m->wtype == W_F32S ? (int)W_F32X : m->wtype, in, z, l.out, R, l.out, in, l.b, ACT_NONE, ws, lin_ws(ws_floats, R, l.out), nullptr));
     const bool last = (i == m->nl - 1);

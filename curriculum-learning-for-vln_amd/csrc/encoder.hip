@@ -1039,6 +1039,12 @@ extern "C" int vln_wgrad_ride_flush(vln_stream_t s) {
   if (!ride_take((hipStream_t)s, &r)) return VLN_OK;
   return ride_issue_alone((hipStream_t)s, r);
 }
+// Forget a pending ride WITHOUT issuing it (its iteration was abandoned: a backward pass that raised never reached the carrying
+// launch or the flush, and the jobs' operands belong to a dead rollout).  Returns 1 if one was pending.
+extern "C" int vln_wgrad_ride_drop(vln_stream_t s) {
+  PendingRide r;
+  return ride_take((hipStream_t)s, &r) ? 1 : 0;
+}
 extern "C" int vln_wgrad_ride_post(const vln_wgrad_job* jobs, int n_jobs, const vln_colsum_job* cjobs, int n_cjobs, int rows, int precision,
                                    float* ws, int64_t ws_floats, vln_stream_t s) {
   if (!jobs || n_jobs <= 0 || n_jobs > kRideWgradJobs || n_cjobs < 0 || n_cjobs > kRideColsumJobs || (n_cjobs && !cjobs) || rows <= 0 ||

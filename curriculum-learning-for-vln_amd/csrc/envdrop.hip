@@ -344,6 +344,17 @@ extern "C" int vln_envdrop_flush(vln_stream_t s) {
   return VLN_OK;
 }
 
+// Forget what a chained step left pending on stream `s` WITHOUT issuing it: the rollout it belongs to was abandoned (an iteration
+// that raised), its buffers may be gone.  Returns the number of stages dropped (0, 1 or 2).
+extern "C" int vln_envdrop_drop_pending(vln_stream_t s) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  auto it = g_pend.find((hipStream_t)s);
+  if (it == g_pend.end()) return 0;
+  const int n = (it->second.f.on ? 1 : 0) + (it->second.b.on ? 1 : 0);
+  it->second.f.on = false; it->second.b.on = false;
+  return n;
+}
+
 extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
                                     vln_stream_t s) {
   RUN(check_dims(d));

@@ -63,6 +63,7 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   // (2) LSTM cell; drop(h1) lands in its tcat block
   // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
   int gate_slabs = 1;
+  if (!io->ws || io->ws_floats < (int64_t)B * 4 * H) { set_error("vln_follower_step_fwd: the gate product's slabs need a workspace of >= B * 4H floats"); return VLN_ERR_ARG; }
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt, XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, &gate_slabs));
   {
     LstmPwFwd a{};

@@ -122,7 +122,8 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
   // instead of 8) -- the X re-reads hit L2 and are not what bounds these launches.  Opt-in only: tunable[1] bit 1.
   const bool fast_ok = aligned16(X) && (ldx % 4 == 0) && aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0) && (K % BK == 0) &&
                        g_tunable[5] != 2;
-  const bool wide = nsplit_out != nullptr && N >= 2048 && K >= 2048 && M <= 64 && fast_ok && (g_tunable[1] & 2);
+  const bool wide = nsplit_out != nullptr && N >= 2048 && K >= 2048 && M <= 64 && fast_ok && (g_tunable[1] & 2) &&
+                    (wtype == W_F32 || wtype == W_BF16);       // (the split-fp32 forms have 64-column tiles only)
   const int TNW = wide ? 128 : 64;
   const int nb = (N + TNW - 1) / TNW, mb = (M + 63) / 64;
   const int ksteps = (K + BK - 1) / BK;

@@ -112,6 +112,7 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
   // (5) LSTM cell on [prev_rep | moves | words | h0]; drop(h1) lands in its tcat block
   // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
   int gate_slabs = 1;
+  if (!io->ws || io->ws_floats < (int64_t)B * 4 * H) { set_error("vln_monitor_step_fwd: the gate product's slabs need a workspace of >= B * 4H floats"); return VLN_ERR_ARG; }
   RUN(gemm_nt(st, io->xcat, XK, w->w_cat, wt(2), XK, nullptr, 0, B, 4 * H, XK, nullptr, ACT_NONE, io->ws, io->ws_floats, &gate_slabs));
   {
     LstmPwFwd a{};

@@ -63,6 +63,10 @@ class _EnvDropStepFn(torch.autograd.Function):
         st = _lib.load().vln_envdrop_step_fwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(rec.io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_envdrop_step_fwd")
+        if rec.io.chain & 1:
+            # the step left its last stage PENDING in the library: what that stage writes (h_tilde, the htd stash row) stays
+            # alive until the next chained step or flush has replaced this reference, whatever happens to the rollout
+            object.__setattr__(mod, "_pend_keep", rec.keep)
         ctx.mod, ctx.rec = mod, rec
         ctx.set_materialize_grads(False)
         k = rec.keep
@@ -97,13 +101,15 @@ class _EnvDropStepFn(torch.autograd.Function):
                     rec.entry.terms.append((io0.alpha_t, g.s_dl, g.s_dtcat, io0.tcat + 4 * H if io0.kctx else io0.tt, t, rec.keep["flat"]))
                     rec.entry.shape = (B, rec.L, H)
                 io = rec.io
-                io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
+                io.ws = mod._step_ws(dev, io.ws_floats, io.chain != 0)
                 st = _lib.load().vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(io), C.byref(g), _lib.raw_stream())
                 if st:
                     _lib.check(st, "vln_envdrop_step_bwd")
                 s.done = True
                 rec.dhtd_keep = None
                 ctx.rec = None
+                if io.chain & 2:
+                    object.__setattr__(mod, "_pend_keep_b", (dhtp, rec.keep))      # what the pending backward stage writes / reads
                 return None, None, dhtp, dc0, None, None
         arena_i0 = arena.i if arena is not None else 0
         g = _lib.EnvDropGrads()
@@ -148,13 +154,15 @@ class _EnvDropStepFn(torch.autograd.Function):
                 mod._bplans.clear()
             mod._bplans[bkey] = (_lib.EnvDropGrads.from_buffer_copy(g), arena_i0, arena.i - arena_i0, dhtp.data_ptr(), dhtp, dc0, t)
         io = rec.io
-        io.ws = ops.workspace(dev, io.ws_floats).data_ptr()
+        io.ws = mod._step_ws(dev, io.ws_floats, io.chain != 0)
         st = _lib.load().vln_envdrop_step_bwd(C.byref(rec.dims), C.byref(mod._wstruct), C.byref(io), C.byref(g), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_envdrop_step_bwd")
         s.done = True
         rec.dhtd_keep = None
         ctx.rec = None
+        if io.chain & 2:
+            object.__setattr__(mod, "_pend_keep_b", (dhtp, rec.keep))
         return None, None, dhtp, dc0, None, None
 
 
@@ -241,6 +249,30 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             n = int(_lib.load().vln_attn_sync_bytes(B))
             w = self._attn_sync = (torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev), B)
         return w[0]
+
+    def _gate_opened(self):
+        # A gate opens when the previous rollouts' weight gradients have been issued (they flush what was pending) -- or when an
+        # iteration was ABANDONED (a forward or backward pass that raised): a chained step's pending stage or a posted gradient
+        # ride of that iteration would otherwise be issued by the next call, on buffers of a dead rollout.
+        if self.chain_steps or self.ride_wgrads:
+            lib = _lib.load()
+            lib.vln_envdrop_drop_pending(_lib.raw_stream())
+            if self.ride_wgrads:
+                lib.vln_wgrad_ride_drop(_lib.raw_stream())
+
+    def _step_ws(self, dev, floats, chained):
+        """The step's split-K scratch.  Chained steps leave slabs PENDING in it between two step calls, so they get a buffer of
+        their own: the shared per-stream `ops.workspace` is also the scratch of every other product, weight-gradient batch and
+        gradient ride issued in between (and is reallocated when a bigger request comes)."""
+        if not chained:
+            return ops.workspace(dev, floats).data_ptr()
+        w = self.__dict__.get("_chain_ws")
+        if w is None or w.device != dev or w.numel() < floats:
+            if w is not None:          # growing: nothing may still be pending in the old buffer
+                _lib.check(_lib.load().vln_envdrop_flush(_lib.raw_stream()), "vln_envdrop_flush")
+            w = torch.empty(int(floats), dtype=torch.float32, device=dev)
+            object.__setattr__(self, "_chain_ws", w)
+        return w.data_ptr()
 
     def _ctx_k(self, entry, ctx, lp):
         """The rollout's projected context K = ctx W_in ([B,L,H] fp32), formed on first use; False when the folded text attention
@@ -537,7 +569,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         if io.offset_base_dev:
             io.offset -= self._base_value
             io.offset_base_dev = self._base_ptr
-        io.ws = ops.workspace(a_t_prev.device, plan.nws).data_ptr()
+        io.ws = self._step_ws(a_t_prev.device, plan.nws, io.chain != 0)
         keep = dict(plan.keep)
         keep["a"], keep["ctx"] = a_t_prev, ctx
         if gather is None:
@@ -780,7 +812,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.defer_logits = 1
             if self.chain_steps:
                 io.chain = 3
-        io.ws, io.ws_floats = ops.workspace(dev, nws).data_ptr(), nws
+        io.ws, io.ws_floats = self._step_ws(dev, nws, io.chain != 0), nws
         rec.io, rec.keep = io, keep
         if (pkey is not None and (gather is not None or (img is img_feature and cand is cand_feature)) and a is a_t_prev and htp.is_contiguous()
                 and h_tilde_prev.is_contiguous() and c_0.is_contiguous() and ctx.is_contiguous()):

@@ -49,6 +49,7 @@ class IterationGraph:
         g = torch.cuda.CUDAGraph()
         if debug_dump:
             g.enable_debug_mode()
+        epoch0 = self.clock.epoch
         try:
             with torch.cuda.graph(g):
                 self.out = self.fn()
@@ -56,7 +57,9 @@ class IterationGraph:
             # The captured tick did not run: the device words still hold the pre-capture values.  Also when `fn` RAISED inside the
             # capture: without this the clock's host mirror would stay one tick ahead of the device words and a
             # caller that falls back to eager launches on the same clock would draw every dropout offset one iteration off.
-            self.clock.uncount()
+            # Only a tick that WAS counted is taken back (`fn` may raise before it issues its tick / prologue).
+            while self.clock.epoch > epoch0:
+                self.clock.uncount()
         if debug_dump:
             g.debug_dump(debug_dump)   # graphviz text of the captured nodes (kernel names, memcpy / memset nodes, edges)
         self.graph = g
@@ -113,6 +116,7 @@ class SegmentedIterationGraph:
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
         plan = []
+        epoch0 = self.clock.epoch
         try:
             for kind, fn in self.segments:
                 if kind == "graph":
@@ -133,7 +137,8 @@ class SegmentedIterationGraph:
                     fn()
                     plan.append(("host", fn))
         finally:
-            self.clock.uncount()       # the captured tick did not run (also when a segment raised: see IterationGraph.capture)
+            while self.clock.epoch > epoch0:       # the captured tick did not run (also when a segment raised: see IterationGraph.capture)
+                self.clock.uncount()
         self.plan = plan
         self._check = lib.vln_persistent_check
         return self

@@ -440,6 +440,7 @@ class GatedModuleMixin:
             else:
                 self._stash.reset()
             self._ctx_entries = {}
+            self._gate_opened()
             self._gate_outs = WeightGate.apply(weakref.ref(self), *params)
             self._open_versions = [p._version for p in params]
             self._rebase_offsets(params[0].device)
@@ -455,6 +456,9 @@ class GatedModuleMixin:
                 self._refresh_shadows()
             self._shadow.commit(key)
             self._gate_outs = None
+
+    def _gate_opened(self):
+        """A new rollout recording begins (hook): whatever an earlier, abandoned one left pending in the library is stale."""
 
     def _gate_consumed(self):
         # called from _deferred_wgrads once the dW GEMMs are issued: the next forward opens a new gate

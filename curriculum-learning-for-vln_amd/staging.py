@@ -345,7 +345,11 @@ class HostBatchFeed:
     marshals on the host, `.to(device)` copies).  Exactly one `select` per executed `fetch`, in order.  The host may run ahead of
     the device by `ring` - 1 batches: `launched()` (call it after the launch / replay that contains the fetch) records an event,
     and `select` waits for the event of the iteration that last used the slot it is about to overwrite.  A registered blob must
-    stay untouched until the fetch that reads it has run."""
+    stay untouched until the fetch that reads it has run.
+    The protocol is CHECKED on the host (round 5): the device picks its slot by a count of the fetches that have run, the host
+    writes the slot of its count of selects, and nothing else ties the two -- so a fetch issued without a select before it (an
+    eager warm-up iteration of a capture, a retry after an exception), or a second select before the first one's fetch was issued,
+    raises here instead of silently pulling a stale or empty slot from then on.  `resync()` realigns the two counts."""
 
     def __init__(self, live: torch.Tensor, ring: int = 16):
         if not live.is_cuda or live.dtype != torch.uint8 or live.numel() % 16 or live.data_ptr() % 16:
@@ -356,6 +360,7 @@ class HostBatchFeed:
         self._state = torch.zeros(4, dtype=torch.int64, device=live.device)     # [0] = seq (fetches run), [1] = done scratch
         self._addr = {}
         self._selected = 0                                                      # host mirror: selects made
+        self._issued = 0                                                        # fetch executions issued (eager launches + replays)
         self._events = [None] * self.ring
         self.head = live.numel()        # bytes the fetch itself pulls; the rest (split_at) rides in a later launch of the iteration
 
@@ -394,6 +399,9 @@ class HostBatchFeed:
 
     def select(self, blob: torch.Tensor):
         """The next `fetch()` that runs -- eager or replayed -- pulls this (registered) blob."""
+        if self._selected != self._issued:
+            raise _lib.VlnError("HostBatchFeed.select: the fetch of the previous select has not been issued (one select per executed "
+                                "fetch; after a failed iteration call resync())")
         i = self._selected % self.ring
         ev = self._events[i]
         if ev is not None:                      # the iteration that read this slot `ring` selects ago must have run
@@ -404,17 +412,39 @@ class HostBatchFeed:
 
     def launched(self):
         """Call after issuing the launch / graph replay that contains the fetch of the last `select`."""
+        if self._issued == self._selected - 1:          # a replayed graph ran the fetch (an eager fetch counted itself)
+            self._issued = self._selected
+        elif self._issued != self._selected or self._selected == 0:
+            raise _lib.VlnError("HostBatchFeed.launched: a fetch ran without a select before it -- it pulled a stale slot (resync())")
         i = (self._selected - 1) % self.ring
         ev = torch.cuda.Event()
         ev.record()
         self._events[i] = ev
 
+    def _count(self):
+        """An eager fetch is being issued (a captured one runs at replay time: `launched()` counts it then)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._selected != self._issued + 1:
+            raise _lib.VlnError("HostBatchFeed: a fetch is being issued without a select before it (it would pull a stale slot and "
+                                "every later fetch the wrong batch): select() the batch first")
+        self._issued += 1
+
+    def resync(self):
+        """After an iteration that raised: forget selects whose fetch never ran and point the device's count at the host's."""
+        torch.cuda.current_stream(self.live.device).synchronize()
+        self._selected = self._issued
+        self._state[0] = self._issued
+        self._events = [None] * self.ring
+
     def fetch_args(self):
         """The pull as arguments of `vln_prologue` (runtime.DeviceClock.prologue issues it together with the tick and the refreshes)."""
+        self._count()
         st = self._state
         return (self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(), self.head)
 
     def fetch(self):
+        self._count()
         st = self._state
         _lib.check(_lib.load().vln_host_fetch(self._slots_dev, self.ring, st.data_ptr(), st.data_ptr() + 8, self.live.data_ptr(),
                                               self.head, _lib.raw_stream()), "vln_host_fetch")

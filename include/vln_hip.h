@@ -143,6 +143,7 @@ int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* 
 int vln_wgrad_ride_post(const vln_wgrad_job* jobs, int n_jobs, const vln_colsum_job* cjobs /*nullable*/, int n_cjobs, int rows,
                         int precision, float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_wgrad_ride_flush(vln_stream_t s);
+int vln_wgrad_ride_drop(vln_stream_t s);     /* forget a pending ride without issuing it (its iteration was abandoned); 1 if one was pending */
 int vln_wgrad_ride_stats(int64_t out[2]);
 
 /* Parameter gradients of the per-step C calls (vln_monitor_step_bwd, vln_follower_step_bwd, vln_bn_mlp_bwd) once per ROLLOUT
@@ -386,7 +387,7 @@ typedef struct vln_monitor_step {
   float *logit /*[B,C]*/, *prog /*[B]*/, *h1, *c1 /*[B,H]*/, *word_w /*[B,L]*/, *move_w /*[B,C]*/;      /* outputs */
   float *pctx /*[B,L,H]*/, *tq /*[B,H]*/, *vq /*[B,M]*/, *xcat /*[B,2M+2H]*/, *tcat /*[B,2H]*/, *aq /*[B,M]*/, *hm /*[B,H+M]*/,
         *mg /*[B,H]*/, *mem /*[B,H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/;                 /* saved for the backward */
-  float *gates /*[B,4H]*/, *dots /*[B,max(L,C)]*/;                                          /* scratch of the call */
+  float *gates /*[B,4H]: unused since ABI v14 -- the gate product stays as split-K slabs in ws (>= B * 4H floats)*/, *dots /*[B,max(L,C)]*/;   /* scratch of the call */
   float* ws; int64_t ws_floats;                                                             /* split-K / grouped-launch scratch */
   uint64_t seed_pe, off_pe; float p_pe;              /* dropout on the positioned context (units.py:207) */
   uint64_t seed, off_h1, off_mem; float p_drop;      /* dropout on h_1 (policy.py:160) and on the monitor memory (:128) */
@@ -429,7 +430,7 @@ typedef struct vln_follower_step {
   float *logit /*[B,C]*/, *h1, *c1 /*[B,H]*/, *word_w /*[B,L]*/, *view_w /*[B,V]*/;                         /* outputs */
   float *tq /*[B,D]*/, *keys /*[B*V,D]*/, *vlog /*[B,V]*/, *xcat /*[B,A+F+H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/, *tq2 /*[B,H]*/,
         *tcat /*[B,2H]*/, *grounded /*[B,H]*/, *target /*[B,D]*/, *q /*[B,D]*/, *context /*[B*C,D]*/;      /* saved for the backward */
-  float *gates /*[B,4H]*/, *dots /*[B,max(L,V,C)]*/;                                          /* scratch of the call */
+  float *gates /*[B,4H]: unused since ABI v14 -- the gate product stays as split-K slabs in ws (>= B * 4H floats)*/, *dots /*[B,max(L,V,C)]*/;   /* scratch of the call */
   float* ws; int64_t ws_floats;
   uint64_t seed, off; float p_drop;                  /* dropout sites `off` (LSTM input row, policy.py:49) and `off + 1` (h_1, :54) */
   const uint64_t* offset_base_dev;                   /* nullable: offsets relative to a device word (see vln_embed_fwd) */
@@ -831,6 +832,11 @@ int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for
  * this exchange buffer (four workgroups per episode co-resident, S <= 96, D <= 512, D % 32 == 0, the path not switched off) */
 int vln_attn_textk_ok(int ctype, int B, int S, int D, const void* sync, int64_t sync_bytes);
 int vln_envdrop_flush(vln_stream_t s);      /* issue what a chained step left pending on this stream (no-op if nothing is) */
+/* Forget the pending stages of stream s WITHOUT issuing them (their rollout was abandoned: an iteration that raised); returns how
+ * many were dropped.  A pending stage reads the split-K slabs its step left in vln_envdrop_step.ws: the caller keeps that buffer
+ * untouched -- and alive -- until the next step call, vln_envdrop_flush or this call (EnvDropDecoder gives chained steps a
+ * workspace of their own for that reason). */
+int vln_envdrop_drop_pending(vln_stream_t s);
 int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io, vln_stream_t s);
 int vln_envdrop_step_bwd(const vln_envdrop_dims* d, const vln_envdrop_weights* w, vln_envdrop_step* io,
                          vln_envdrop_grads* g, vln_stream_t s);

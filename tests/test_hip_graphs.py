@@ -458,3 +458,67 @@ def test_bench_survives_a_failed_graph_capture():
     assert "could not be captured" in out.stderr
     rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["config"]["iteration_graph"] is False and rep["ms_per_step"] > 0
+
+
+def test_host_batch_feed_refuses_a_fetch_without_a_select_and_two_selects_in_a_row(vln):
+    """the device picks its slot by a count of the fetches that ran, the host writes the slot of its count of
+    selects; nothing else ties the two.  The protocol is checked on the host: a fetch issued with no select before it (the eager
+    warm-up of a capture, a retry after an exception) and a second select before the first one's fetch was issued RAISE instead of
+    pulling stale or empty slots from then on; `resync()` realigns the counts and the pulls are right again."""
+    dev = torch.device(DEV)
+    live = torch.zeros(64, dtype=torch.uint8, device=dev)
+    feed = vln.HostBatchFeed(live, ring=4)
+    blobs = [feed.register(torch.full((64,), k + 1, dtype=torch.uint8)) for k in range(6)]
+    with pytest.raises(vln._lib.VlnError, match="without a select"):
+        feed.fetch()
+    feed.select(blobs[0]); feed.fetch(); feed.launched()
+    torch.cuda.synchronize()
+    assert int(live[0]) == 1
+    feed.select(blobs[1])
+    with pytest.raises(vln._lib.VlnError, match="has not been issued"):
+        feed.select(blobs[2])
+    feed.resync()                                   # the select of blob 1 never ran: forgotten, device and host counts equal again
+    for k in (3, 4, 5, 2, 1):                       # (more than the ring holds)
+        feed.select(blobs[k]); feed.fetch(); feed.launched()
+        torch.cuda.synchronize()
+        assert int(live[0]) == k + 1 and int(live[63]) == k + 1
+    with pytest.raises(vln._lib.VlnError, match="without a select"):
+        feed.fetch()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chained_steps_survive_other_work_on_the_shared_workspace(vln, dtype):
+    """a chained decoder step leaves split-K slabs PENDING between two step calls.  They live in a workspace of
+    the decoder's own now: products, weight-gradient batches or rides issued on the shared per-stream workspace between two steps
+    (here: a product big enough to overwrite -- and to REALLOCATE -- `ops.workspace`) leave the rollout bit-identical."""
+    dev = torch.device(DEV)
+    B, L, V, C, H, IMG, ANG, AE, T = 16, 24, 36, 6, 64, 96, 32, 16, 4
+    F = IMG + ANG
+
+    def rollout(disturb):
+        torch.manual_seed(5)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=dtype).to(dev).train()
+        dec.defer_logits = dec.chain_steps = True
+        g = torch.Generator().manual_seed(6)
+        ctx = (torch.randn(B, L, H, generator=g) * 0.5).to(dev).requires_grad_(True)
+        ht = torch.tanh(torch.randn(B, H, generator=g)).to(dev).requires_grad_(True); c = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+        mask = (torch.arange(L)[None, :] >= torch.randint(4, L + 1, (B, 1), generator=g)).to(dev)
+        ce = vln.losses.RolloutCE()
+        h = ht
+        big = torch.randn(4096, 1024, device=dev); w = torch.randn(1024, 1024, device=dev)
+        for t in range(T):
+            img = (torch.randn(B, V, F, generator=g).abs() * 0.5).to(dev); cand = (torch.randn(B, C, F, generator=g).abs() * 0.5).to(dev)
+            logit, (h, c), ht = dec(torch.sin(torch.randn(B, ANG, generator=g)).to(dev), img, cand, ht, h, c, ctx, mask)
+            ce.add(logit, torch.randint(0, C, (B,), generator=g).to(dev), torch.zeros(B, C, dtype=torch.bool, device=dev))
+            if disturb:                # scribbles over (and, the first time, reallocates) the shared workspace between two steps
+                vln.ops.linear_fwd_slabs(big, w, ws_floats=(1 << 22) + (t + 1) * (1 << 20))
+        loss = ce.sum(scale=0.1)
+        if disturb:
+            hook = ctx.register_hook(lambda g_: (vln.ops.linear_fwd_slabs(big, w), g_)[1])
+        loss.backward()
+        torch.cuda.synchronize()
+        return [loss.detach().clone(), ctx.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+
+    ref, got = rollout(False), rollout(True)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f"tensor {i} differs after other work used the shared workspace between chained steps"
