@@ -1036,7 +1036,8 @@ def main():
                              dtype, "store", args, graph=use_graph)),
                          # BASELINE config 3's per-rank iteration as 36 graph segments, the host reading every sampled action between them
                          # (envdrop.py:196-206); beside it the same iteration with the actions left on the device (round 3's form of the figure)
-                         ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store, read_actions="poll")),
+                         ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store, read_actions="handshake")),
+                         ("il_plus_a2c_T35_graph_per_step", lambda: secondary_agents(dev, args, "a2c", store, read_actions="poll")),
                          ("il_plus_a2c_T35_stream_sync_per_step", lambda: secondary_agents(dev, args, "a2c", store)),
                          ("il_plus_a2c_T35_actions_on_device", lambda: secondary_agents(dev, args, "a2c", store, read_actions=False)),
                          # BASELINE config 2 does not ask for bf16: the Self-Monitor's figure is the fp32 one; bf16 beside it

@@ -11,7 +11,7 @@ from .encoder import EncoderLSTM  # noqa: F401
 from .envdrop_decoder import EnvDropDecoder, Critic  # noqa: F401
 from . import functional, staging, losses, optim, metrics, graphs  # noqa: F401
 from .runtime import DeviceClock  # noqa: F401
-from .graphs import IterationGraph, SegmentedIterationGraph  # noqa: F401
+from .graphs import IterationGraph, SegmentedIterationGraph, HandshakeIterationGraph  # noqa: F401
 from .staging import DeviceFeatureStore, PinnedStager, HostBatchFeed  # noqa: F401
 from .speaker import SpeakerEncoder, SpeakerDecoder, Speaker, back_translate, env_drop_mask  # noqa: F401
 from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401

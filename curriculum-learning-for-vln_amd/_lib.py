@@ -67,7 +67,9 @@ class EnvDropStep(C.Structure):
                    ("ws", ptr), ("ws_floats", i64), ("offset_dev", ptr), ("offset_base_dev", ptr), ("defer_logits", i32),
                    ("pad_", i32)]
                 + [(n, ptr) for n in ("g_table", "g_angle_table", "g_rows", "g_vidx", "g_crows", "g_cviews", "g_chead", "g_celev")]
-                + [("g_ttype", i32), ("pad2_", i32), ("attn_sync", ptr), ("attn_sync_bytes", i64), ("chain", i32), ("pad3_", i32), ("kctx", ptr)])
+                + [("g_ttype", i32), ("pad2_", i32), ("attn_sync", ptr), ("attn_sync_bytes", i64), ("chain", i32), ("pad3_", i32), ("kctx", ptr)]
+                + [(n, ptr) for n in ("s_cand_mask", "s_action_in", "s_action_out", "s_action_host", "s_probs", "s_logp", "s_ent")]
+                + [("s_seed", u64), ("s_offset", u64), ("s_offset_base_dev", ptr)])
 
 
 class TickItem(C.Structure):          # vln_tick_item
@@ -299,6 +301,7 @@ SIGNATURES = {
                                  i32, i32, i32, ptr, i64, ptr]),
     "vln_attn_textk_bwd": (i32, [ptr, i32, ptr, ptr, ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32,
                                  i32, i32, i32, ptr, i64, ptr]),
+    "vln_host_wait": (i32, [ptr, ptr, i64, ptr]),
     "vln_envdrop_flush": (i32, [ptr]),
     "vln_envdrop_drop_pending": (i32, [ptr]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),

@@ -413,6 +413,34 @@ extern "C" int vln_host_device_pointer(const void* host, void** dev) {
   *dev = d;
   return VLN_OK;
 }
+// ---- the device WAITS for the host inside a launch sequence (round 5) -------------------------------------------------------------------
+// A rollout whose next step needs the HOST (envdrop.py:196-206: the simulator takes the sampled action and answers with the next
+// observation) used to be one graph launch per step: launch latency and the wake-up of the stream stand between two steps.  Here the
+// whole iteration is ONE graph and the host's turn is a one-wave kernel between two steps that spins on a word of pinned host memory
+// until it holds the value of a device word (`want`: the device clock's word of THIS iteration, so the flag of an earlier iteration
+// never matches).  The host polls the action words the previous step stored to pinned memory, does its work, writes the next step's
+// inputs and then the flag.  Bounded: a host that never answers raises the sticky word instead of hanging the queue.
+namespace vln {
+__global__ void host_wait_kernel(const unsigned long long* flag, const unsigned long long* want, unsigned* sticky, unsigned long long limit) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long w = *want;
+  for (unsigned long long i = 0;; ++i) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == w) break;
+    if (i > limit) { if (sticky) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);      // what the host wrote before the flag is visible to the launches behind this one
+}
+}  // namespace vln
+extern "C" int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, vln_stream_t s) {
+  if (!flag_dev || !want_dev) { set_error("vln_host_wait: null pointer"); return VLN_ERR_ARG; }
+  unsigned* sticky = sticky_dev_word();
+  VLN_LAUNCH(host_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, reinterpret_cast<const unsigned long long*>(flag_dev),
+             reinterpret_cast<const unsigned long long*>(want_dev), sticky ? sticky + 3 : nullptr,
+             (unsigned long long)(spin_limit > 0 ? spin_limit : (1ll << 26)));
+  VLN_CHECK_LAUNCH("host_wait");
+  return VLN_OK;
+}
 extern "C" int vln_host_fetch(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, vln_stream_t s) {
   FetchArgs f; int blocks = 0;
   int r = fetch_args(slots_dev, ring, seq, done, dst, nbytes, &f, &blocks); if (r) return r;

@@ -308,6 +308,105 @@ int attn_dot_multi(hipStream_t st, const vln_dot_step* steps, int T, int ctype, 
 }
 
 // ---------------------------------------------------------------------------
+// The candidate logits of one step AND the sampled-action branch on them in one launch (policy.py:199-206 + envdrop.py:173,
+// 186-195): logits[b,c] = cand[b,c,:] . q[b,:]; probs = softmax(mask(logits)); a ~ Categorical(probs) (the kernels' Philox
+// stream, or a given action); log pi(a), the entropy (torch.distributions' clamp).  One workgroup per episode: the four waves
+// split the candidate rows (16-byte loads, wave-shuffle reduction), wave 0 then does categorical_fwd_kernel's row (pointwise.hip:
+// same arithmetic).  The action also goes straight to a host-mapped word when the caller gives one: the host that steps the
+// simulator polls it -- no copy launch behind the draw.  A sampled rollout had three launches here (dot, draw, D2H copy).
+// ---------------------------------------------------------------------------
+struct CandSample {
+  const void* cand; SlabVec q; float* logits;
+  const unsigned char* mask; const long long* action_in; long long* action_out; long long* action_host;
+  float* probs; float* logp; float* ent;
+  uint64_t seed, offset; const unsigned long long* offset_base_dev;
+  int B, C, D, vec_ok;
+};
+template <typename TC>
+__global__ __launch_bounds__(256) void cand_sample_kernel(CandSample a) {
+  constexpr int V = Elt<TC>::kVec;
+  __shared__ float sdot[64];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C, D = a.D;
+  const TC* base = reinterpret_cast<const TC*>(a.cand) + (long)b * C * D;
+  for (int c = wave; c < C; c += 4) {
+    const TC* row = base + (long)c * D;
+    float acc = 0.f;
+    if (a.vec_ok) {
+      for (int d = lane * V; d < D; d += 64 * V) {
+        float x[V];
+        Elt<TC>::ld16(row + d, x);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const float4 t = a.q.at4(b, d + j);
+          acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
+        }
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(row + d) * a.q.at(b, d);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sdot[c] = acc;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  uint64_t offset = a.offset;
+  if (a.offset_base_dev) offset += *a.offset_base_dev * 8ull;
+  const float eps = 1.1920928955078125e-07f;
+  const bool in = lane < C;
+  const float raw = in ? sdot[lane] : 0.f;
+  if (in) a.logits[(long)b * C + lane] = raw;
+  const bool masked = in && a.mask && a.mask[(long)b * C + lane];
+  const float l = (in && !masked) ? raw : -INFINITY;
+  const float mx = wave_max(l);
+  const float e = (in && !masked) ? __expf(l - mx) : 0.f;
+  const float inv = 1.f / wave_sum(e);
+  const float pc = e * inv;
+  long av;
+  if (a.action_in) av = a.action_in[b];
+  else {
+    const Philox4 r = philox4x32_10(a.seed, offset, (uint32_t)b);
+    const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+    float cum = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(cum, o, 64);
+      if (lane >= o) cum += t;
+    }
+    const unsigned long long hit = __ballot(in && u < cum), live = __ballot(in && pc > 0.f);
+    av = hit ? (long)(__ffsll((long long)hit) - 1) : (live ? (long)(63 - __clzll((long long)live)) : 0);
+  }
+  const float lc = __logf(fminf(fmaxf(pc, eps), 1.f - eps));
+  const float H = -wave_sum(in ? pc * lc : 0.f);
+  const float la = (av >= 0 && av < C) ? __shfl(lc, (int)av, 64) : 0.f;
+  if (in) a.probs[(long)b * C + lane] = pc;
+  if (lane == 0) {
+    if (a.action_out) a.action_out[b] = av;
+    if (a.action_host) __hip_atomic_store(a.action_host + b, (long long)av, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.logp[b] = la;
+    a.ent[b] = H;
+  }
+}
+int cand_logits_sample(hipStream_t st, const void* cand, int ctype, SlabVec q, float* logits, const uint8_t* mask, const int64_t* action_in,
+                       int64_t* action_out, int64_t* action_host, float* probs, float* logp, float* ent, uint64_t seed, uint64_t offset,
+                       const uint64_t* offset_base_dev, int B, int C, int D) {
+  if (!cand || !q.p || !logits || !probs || !logp || !ent || B <= 0 || C <= 0 || C > 64 || D <= 0 || (!action_in && !action_out)) {
+    set_error("cand_logits_sample: bad args (at most 64 candidates)");
+    return VLN_ERR_ARG;
+  }
+  const int V = (ctype == W_BF16) ? 8 : 4;
+  CandSample a{cand, q, logits, mask, (const long long*)action_in, (long long*)action_out, (long long*)action_host, probs, logp, ent, seed, offset,
+               reinterpret_cast<const unsigned long long*>(offset_base_dev), B, C, D,
+               (aligned16(cand) && aligned16(q.p) && (D % V == 0) && (q.ld % 4 == 0) && (q.stride % 4 == 0)) ? 1 : 0};
+  const double bytes = (double)B * C * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 12.0 * B * C;
+  if (ctype == W_BF16) launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<bf16_raw>, dim3(B), dim3(256), 0, st, a);
+  else launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<float>, dim3(B), dim3(256), 0, st, a);
+  VLN_CHECK_LAUNCH("cand_logits_sample");
+  return VLN_OK;
+}
+
+// ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
 template <typename TC>

@@ -720,6 +720,12 @@ extern "C" int vln_persistent_check(void) {
                 "attention is now off for this process (one workgroup per batch row)", n, d);
       return VLN_ERR_HIP;
     }
+    if (__atomic_load_n(&h[d * 16 + 3], __ATOMIC_RELAXED)) {
+      const unsigned n = __atomic_exchange_n(&h[d * 16 + 3], 0u, __ATOMIC_RELAXED);
+      set_error("%u wait(s) for the host timed out on device %d in an EARLIER launch (vln_host_wait: the host never wrote the flag "
+                "of its turn); the steps behind it ran on whatever their inputs held: that iteration's numbers are invalid", n, d);
+      return VLN_ERR_HIP;
+    }
   }
   return VLN_OK;
 }

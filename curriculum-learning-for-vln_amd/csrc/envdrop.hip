@@ -205,6 +205,10 @@ static int step_fwd_issue(hipStream_t st, const vln_envdrop_dims* d, const vln_e
   // (6) candidate logits                                        policy.py:243-244,199-206
   if (io->defer_logits) return VLN_OK;      // formed for the whole rollout at once by the caller (vln_attn_dot_multi)
   RUN(gemm_nt(st, io->htd, H, w->w_c, wt(4), H, nullptr, 0, B, F, H, nullptr, ACT_NONE, ws.s1, ws.n1, &n1));
+  if (io->s_probs)        // the sampled-action branch rides on the logits' launch (mask, softmax, draw, log-prob, entropy, action to the host)
+    return cand_logits_sample(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, io->s_cand_mask, io->s_action_in,
+                              io->s_action_out, io->s_action_host, io->s_probs, io->s_logp, io->s_ent, io->s_seed, io->s_offset,
+                              io->s_offset_base_dev, B, d->C, F);
   RUN(attn_dot_sv(st, cand, d->ctype, SlabVec{ws.s1, F, n1, (long)B * F}, io->logit, B, d->C, F));
   return VLN_OK;
 }
@@ -360,6 +364,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
   RUN(check_dims(d));
   if (!w || !io) { set_error("vln_envdrop_step_fwd: null pointer"); return VLN_ERR_ARG; }
   hipStream_t st = (hipStream_t)s;
+  if (io->s_probs && io->defer_logits) { set_error("vln_envdrop_step_fwd: the in-step sampler needs the step's logits (defer_logits = 0)"); return VLN_ERR_ARG; }
   if ((io->chain & 1) && !io->defer_logits) { set_error("vln_envdrop_step_fwd: chain needs defer_logits (nothing may read h_tilde before the next step)"); return VLN_ERR_ARG; }
   // chained steps: what the previous call left pending on this stream
   PendFwd use{};
@@ -375,7 +380,7 @@ extern "C" int vln_envdrop_step_fwd(const vln_envdrop_dims* d, const vln_envdrop
     // A step whose h_tilde_prev did NOT come out of a chained step (the head of a rollout: the encoder's state) must finish its own
     // backward: whoever consumes its d h_tilde_prev is not a chained step (autograd may even COPY that buffer the moment the
     // step's backward returns -- an AccumulateGrad of a leaf -- long before any flush).
-    if (!use.on) io->chain &= ~2;
+    if (!use.on && (io->chain & 1)) io->chain &= ~2;      // (chain == 2: the caller named the steps that follow another one)
     if (io->chain & 1) {
       Ws ws; ws_layout(*d, io->ws, &ws);
       const int wt3 = ((w->f32_mask >> 3) & 1) ? (int)W_F32S : d->wtype;

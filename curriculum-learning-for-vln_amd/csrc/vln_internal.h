@@ -197,6 +197,11 @@ int attn_textk_fwd(hipStream_t st, const void* ctx, int ctype, const float* kctx
 int attn_textk_bwd(hipStream_t st, const void* ctx, int ctype, const float* kctx, const float* alpha, SlabVec dwc, float* dwc_out,
                    long lddo, float* dq, long lddq, float* dl_out, const LstmPwBwd& pb, int B, int S, int D, void* sync,
                    long sync_bytes);
+// candidate logits of a step + the sampled-action branch on them (mask, softmax, draw / given action, log-prob, entropy; the
+// action also to a host-mapped word) in ONE launch: envdrop.hip's step (6) when the caller attached a sampler
+int cand_logits_sample(hipStream_t st, const void* cand, int ctype, SlabVec q, float* logits, const uint8_t* mask, const int64_t* action_in,
+                       int64_t* action_out, int64_t* action_host, float* probs, float* logp, float* ent, uint64_t seed, uint64_t offset,
+                       const uint64_t* offset_base_dev, int B, int C, int D);
 // dctx[b,s,:] (+)= sum_t alpha_t[b,s] g_t[b,:] + dl_t[b,s] q_t[b,:]   (host arrays of T device pointers)
 int attn_dctx_deferred(hipStream_t st, const float* const* alpha, const float* const* dl, const float* const* g, long ldg,
                        const float* const* q, long ldq, int T, float* dctx, int B, int S, int D, int accumulate,

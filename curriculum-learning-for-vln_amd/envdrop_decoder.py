@@ -239,6 +239,12 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # direction.  Taken when the four-workgroup attention covers the shape (vln_attn_textk_ok), else the step runs as before.
         self.project_context = True
         self.last_projected = False
+        # Opt-in for SAMPLED rollouts (whose forward cannot be chained: every step's logits are read): the BACKWARD of consecutive
+        # steps is chained like `chain_steps` chains it -- step t's act-embedding / h_tilde_prev stage rides in the first launch of
+        # step t - 1's backward (vln_envdrop_step.chain == 2) -- for every step whose h_tilde_prev IS the previous call's h_tilde.
+        # The caller promises that nothing but the next step consumes a step's h_tilde (its logits and h_1 / c_1 are free).
+        self.chain_backward = False
+        self._last_ht = None
         # bf16 compute: weight matrices that are streamed in fp32 all the same (names: w_vin, w_cat, w_tin, w_tout, w_c).  Set it
         # before the first forward (the shadows are rebuilt when a parameter changes).
         self.fp32_weights = frozenset(type(self).default_fp32_weights)
@@ -254,7 +260,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # A gate opens when the previous rollouts' weight gradients have been issued (they flush what was pending) -- or when an
         # iteration was ABANDONED (a forward or backward pass that raised): a chained step's pending stage or a posted gradient
         # ride of that iteration would otherwise be issued by the next call, on buffers of a dead rollout.
-        if self.chain_steps or self.ride_wgrads:
+        if self.chain_steps or self.chain_backward or self.ride_wgrads:
             lib = _lib.load()
             lib.vln_envdrop_drop_pending(_lib.raw_stream())
             if self.ride_wgrads:
@@ -463,8 +469,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
     def _deferred_wgrads(self):
         """dW for every gated parameter from the stash: one contraction over (steps x batch) per weight."""
         H, F, AE = self.hidden_size, self.feature_size, self.action_embed_size
-        if self.chain_steps:          # the first step's pending prep backward (its act-embedding gradient rows are read below)
-            _lib.check(_lib.load().vln_envdrop_flush(_lib.raw_stream()), "vln_envdrop_flush")
+        # the first step's pending prep backward (its act-embedding gradient rows are read below): chained steps, chain_backward
+        _lib.check(_lib.load().vln_envdrop_flush(_lib.raw_stream()), "vln_envdrop_flush")
         P = self._gated_params()
         runs = list(self._stash.done_runs())
         self._gate_consumed()
@@ -534,7 +540,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             cb.run()
 
     def _forward_planned(self, plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
-                         h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather=None):
+                         h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather=None, smp=None, sbind=None):
         """The fast path of forward(): returns None (and leaves no trace) when anything the plan relies on moved."""
         if not arena.reserve(plan.i0, plan.n_alloc, plan.first_ptr):
             return None
@@ -584,6 +590,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             keep["kctx"] = kctx
         if m8 is not None:
             keep["mask"] = m8
+        if sbind is not None:
+            self._fill_sampler(io, smp, sbind, keep)
         rec = _StepRec()
         rec.B, rec.L, rec.C, rec.H = B, ctx.shape[1], plan.dims.C, H
         rec.ctx_owner, rec.entry, rec.dims, rec.slot, rec.io, rec.keep = ctx, entry, plan.dims, slot, io, keep
@@ -602,7 +610,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
 
     # ---- forward -----------------------------------------------------------------------------------------
     def forward(self, a_t_prev, img_feature, cand_feature, h_tilde_prev, h_0, c_0, ctx, ctx_mask=None,
-                already_dropfeat=False, img_lp=None, cand_lp=None, gather=None):
+                already_dropfeat=False, img_lp=None, cand_lp=None, gather=None, sampler=None):
         """Same contract as policy.py:208-246 (h_0 is unused there too).  img_feature / cand_feature are
         overwritten in place by the feature dropout, like the reference.  Extension (optional): `img_lp` / `cand_lp`
         = bf16 copies of the two feature tensors already produced by `DeviceFeatureStore.gather_*` (together with
@@ -611,7 +619,13 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         `img_feature = cand_feature = None`: the step reads its features from the HBM-resident table of a
         staging.DeviceFeatureStore itself (index vectors as for `store.gather_step`), applies the feature dropout of
         policy.py:226-231 on the way (its own Philox sites, exactly as on caller-given tensors) and does so in the SAME launch as
-        its act-embedding / state prep -- one dependent launch less per step than `store.gather_step` + forward."""
+        its act-embedding / state prep -- one dependent launch less per step than `store.gather_step` + forward.
+        Extension (optional): `sampler=(losses.RolloutSampler, cand_mask, action | None, action_host_address | 0)`: the sampled-action
+        branch of envdrop.py:173,186-195 on this step's logits runs INSIDE the step's last launch (candidate dots + mask + softmax +
+        draw + log-prob + entropy; vln_envdrop_step.s_*) and the step is recorded in the sampler as `sampler.step(logit, cand_mask,
+        action)` would record it; the drawn action is `sampler.keep[-1][1]` and -- with `action_host_address`, the device-visible
+        address of B int64 words of PINNED host memory -- also lands there without a copy launch (the host polls it)."""
+        self._sampler_arg = sampler
         if gather is not None:
             if img_feature is not None or cand_feature is not None or already_dropfeat:
                 raise TypeError("EnvDropDecoder: with gather=(store, ...) pass img_feature=None, cand_feature=None")
@@ -658,6 +672,16 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         ctx_in, entry = self._gated_ctx(ctx, need_grad)
         dt = self.compute_dtype
         lp = dt != torch.float32
+        # the in-step sampler's buffers come first (the same place in the arena's order on the planned and on the full path)
+        smp, self._sampler_arg = self.__dict__.get("_sampler_arg"), None
+        sbind = None
+        if smp is not None:
+            if self.defer_logits:
+                raise ValueError("EnvDropDecoder: sampler= needs the step's logits (defer_logits = False)")
+            sbind = smp[0].bind(B, Cn, dev, smp[2])
+        # backward-only chaining (chain_backward): this step follows the previous call's step
+        follows = bool(self.chain_backward and need_grad and not self.defer_logits and self._last_ht is not None
+                       and self._last_ht() is h_tilde_prev)
 
         # Step plans (arena mode): with address-stable buffers, the n-th step of an iteration sees the argument block of
         # the n-th step two iterations earlier.  The filled C struct, the output tensors and the saved-activation
@@ -674,7 +698,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             pkey = (arena.g, arena.i, a_t_prev.data_ptr(), fk, h_tilde_prev.data_ptr(),
                     c_0.data_ptr(), ctx.data_ptr(), 0 if ctx_mask is None else ctx_mask.data_ptr(), B, V, F, Cn, L, need_grad,
                     self.training, bool(already_dropfeat), 0 if img_lp is None else img_lp.data_ptr(),
-                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits), bool(self.chain_steps), bool(self.project_context))
+                    0 if cand_lp is None else cand_lp.data_ptr(), dt, bool(self.defer_logits), bool(self.chain_steps), bool(self.project_context), follows,
+                    None if smp is None else (0 if smp[1] is None else smp[1].data_ptr(), int(smp[3] or 0), smp[2] is not None))
         ctx_lp = None
         if lp:                         # once per rollout; BEFORE the step's own buffers so the arena order is the same on
             ctx_lp = entry.lp          # the planned and on the full path
@@ -687,9 +712,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             plan = self._plans.get(pkey)
             if plan is not None:
                 out = self._forward_planned(plan, arena, entry, need_grad, gated, ctx_in, a_t_prev, img_feature, cand_feature,
-                                            h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather)
+                                            h_tilde_prev, c_0, ctx, ctx_mask, img_lp, cand_lp, gather, smp, sbind)
                 if out is not None:
-                    return out
+                    return self._step_done(out, smp)
         arena_i0 = arena.i if arena is not None else 0
 
         rec = _StepRec()
@@ -812,6 +837,10 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
             io.defer_logits = 1
             if self.chain_steps:
                 io.chain = 3
+        elif follows:
+            io.chain = 2
+        if sbind is not None:
+            self._fill_sampler(io, smp, sbind, keep)
         io.ws, io.ws_floats = self._step_ws(dev, nws, io.chain != 0), nws
         rec.io, rec.keep = io, keep
         if (pkey is not None and (gather is not None or (img is img_feature and cand is cand_feature)) and a is a_t_prev and htp.is_contiguous()
@@ -835,7 +864,29 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 img_feature.copy_(img)
             if cand is not cand_feature:
                 cand_feature.copy_(cand)
-        return logit, (h1, c1), h_tilde
+        return self._step_done((logit, (h1, c1), h_tilde), smp)
+
+    @staticmethod
+    def _fill_sampler(io, smp, sbind, keep):
+        probs, act, logp_p, ent_p, seed, off, base = sbind
+        cm = smp[1]
+        if cm is not None:
+            cm = cm.view(torch.uint8) if (cm.dtype == torch.bool and cm.is_contiguous()) else cm.to(torch.uint8).contiguous()
+            keep["s_mask"] = cm
+        io.s_cand_mask = _tp(cm)
+        io.s_action_in = act.data_ptr() if smp[2] is not None else None
+        io.s_action_out = None if smp[2] is not None else act.data_ptr()
+        io.s_action_host = int(smp[3] or 0) or None
+        io.s_probs, io.s_logp, io.s_ent = probs.data_ptr(), logp_p, ent_p
+        io.s_seed, io.s_offset, io.s_offset_base_dev = seed, off, base
+        keep["s_probs"], keep["s_act"] = probs, act
+
+    def _step_done(self, out, smp):
+        """Bookkeeping after a step was issued: the in-step sampler records it; the step's h_tilde is remembered (chain_backward)."""
+        if smp is not None:
+            smp[0].commit(out[0])
+        self._last_ht = weakref.ref(out[2]) if self.chain_backward else None
+        return out
 
 
 class Critic(nn.Module):

@@ -163,3 +163,72 @@ class SegmentedIterationGraph:
                 x()
         self.replays += 1
         return self.out
+
+
+
+class HandshakeIterationGraph:
+    """One training iteration whose rollout needs the HOST between steps, as ONE hipGraph (round 5).
+
+    `SegmentedIterationGraph` replays one graph per step and runs the host's turn (read the sampled action, step the simulator:
+    envdrop.py:196-206) between two graph launches: ~40 us of launch latency and stream wake-up per step stand between the
+    steps' kernels (36 segments, 1.4 ms of a 7.7 ms IL + A2C iteration).  Here the `("graph", fn)` segments are captured back to
+    back into ONE graph and every `("host", fn)` segment becomes a one-wave launch that WAITS for the host (`vln_host_wait`: spins
+    on a pinned flag word until it holds this iteration's device-clock value).  `replay()` launches the graph once and then plays
+    the host's part: for each host segment in order, `fn()` (it polls what the step before it stored to pinned memory -- the
+    sampled actions --, does the host's work and leaves the next step's inputs in place), then the flag is written and the device
+    goes on.  Same kernels in the same order as the segmented form: bit-identical results.  The host segments are NOT run
+    while capturing (there is nothing to read yet)."""
+
+    def __init__(self, segments, clock: DeviceClock, spin_limit: int = 0):
+        self.segments, self.clock, self.spin_limit = list(segments), clock, int(spin_limit)
+        n = sum(1 for k, _ in self.segments if k == "host")
+        self.flags = torch.zeros(max(n, 1), dtype=torch.int64).pin_memory()
+        import ctypes as C_
+        d = C_.c_void_p()
+        _lib.check(_lib.load().vln_host_device_pointer(self.flags.data_ptr(), C_.byref(d)), "vln_host_device_pointer")
+        self._flags_dev = int(d.value)
+        self._flags_np = self.flags.numpy()
+        self.graph = None
+        self.host_fns = []
+        self.replays = 0
+        self.out = None
+
+    def capture(self):
+        torch.cuda.synchronize()
+        lib = _lib.load()
+        _lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+        self.clock.restart_sequences()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        epoch0 = self.clock.epoch
+        host_fns = []
+        try:
+            with torch.cuda.graph(g):
+                for kind, fn in self.segments:
+                    if kind == "graph":
+                        r = fn()
+                        if r is not None:
+                            self.out = r
+                    else:
+                        _lib.check(lib.vln_host_wait(self._flags_dev + 8 * len(host_fns), self.clock.ptr, self.spin_limit, _lib.raw_stream()),
+                                   "vln_host_wait")
+                        host_fns.append(fn)
+        finally:
+            while self.clock.epoch > epoch0:
+                self.clock.uncount()
+        self.graph, self.host_fns = g, host_fns
+        self._check = lib.vln_persistent_check
+        return self
+
+    def replay(self):
+        st = self._check()
+        if st:
+            _lib.check(st, "vln_persistent_check (raised by an earlier replay)")
+        self.clock.replayed()
+        want = self.clock.host                # what the device clock's word holds once this replay's tick has run
+        self.graph.replay()
+        for i, fn in enumerate(self.host_fns):
+            fn()
+            self._flags_np[i] = want          # the device's wait for host turn i ends here
+        self.replays += 1
+        return self.out

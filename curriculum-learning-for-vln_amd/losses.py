@@ -514,6 +514,33 @@ class RolloutSampler:
         self.logits.append(logits); self.keep.append((probs, act))
         return act
 
+    def bind(self, B: int, C: int, dev, action: Optional[torch.Tensor] = None, offset: Optional[int] = None):
+        """The arguments of step t's draw for a caller that issues it INSIDE its own launch (EnvDropDecoder.forward(sampler=...):
+        candidate dots + mask + softmax + draw in one launch, vln_envdrop_step.s_*): -> (probs [B,C], action [B] int64, logp row
+        address, entropy row address, seed, offset, device offset base | None).  `commit(logits)` then records the step."""
+        t = len(self.logits)
+        if self.logp is None:
+            self.logp = ops.empty(self.cap, B, dtype=torch.float32, device=dev)
+            self.ent = ops.empty(self.cap, B, dtype=torch.float32, device=dev)
+        if t >= self.cap or B != self.logp.shape[1]:
+            raise ValueError(f"RolloutSampler: more than {self.cap} steps, or the batch size changed")
+        base = None
+        if offset is None and self.clock is not None:
+            offset, base = self.clock.rel(("RolloutSampler", self.seed)) * 8, self.clock.ptr
+        elif offset is None:
+            _sample_calls[0] += 1
+            offset = _sample_calls[0]
+        probs = ops.empty(B, C, dtype=torch.float32, device=dev)
+        act = action.contiguous() if action is not None else ops.empty(B, dtype=torch.int64, device=dev)
+        self._bound = (probs, act)
+        return probs, act, self.logp[t].data_ptr(), self.ent[t].data_ptr(), self.seed, int(offset), base
+
+    def commit(self, logits: torch.Tensor) -> torch.Tensor:
+        probs, act = self._bound
+        self._bound = None
+        self.logits.append(logits); self.keep.append((probs, act))
+        return act
+
     def stats(self):
         """(log_prob [T,B], entropy [T,B]) of the recorded steps, differentiable w.r.t. every step's logits."""
         T = len(self.logits)

@@ -767,7 +767,10 @@ typedef struct vln_envdrop_step {
    * the next vln_envdrop_step_bwd whose d h_tilde is that buffer.  One dependent launch less per step and direction.  The CALLER
    * promises that nothing outside these two entry points reads h_tilde / htd (forward) or d h_tilde_prev / the `de` stash rows
    * (backward) before the next step call or a vln_envdrop_flush on that stream.  vln_envdrop_step_fwd CLEARS bit 1 in place for a
-   * step that did not consume a pending stage itself (the head of a rollout: what consumes its d h_tilde_prev is not a chained step). */
+   * step that did not consume a pending stage itself (the head of a rollout: what consumes its d h_tilde_prev is not a chained step).
+   * chain == 2 (bit 1 alone, ABI v15: sampled rollouts, whose forward cannot be chained -- every step's logits are read): the
+   * caller decides which steps follow another one (h_tilde_prev IS the previous step's h_tilde and nothing else consumes it) and
+   * sets the bit for exactly those; the library leaves it as given. */
   int chain; int pad3_;
   /* ABI v15, optional (nullable): K = ctx W_in, [B,L,H] fp32 -- the instruction context projected ONCE per rollout through
    * text_attn.linear_in (units.py:106-109: ctx . (W_in h) = (ctx W_in) . h; the caller forms it with one vln_linear_fwd over the
@@ -780,6 +783,17 @@ typedef struct vln_envdrop_step {
    * with vln_attn_dctx_deferred (dl / q = hd pairs -> [B,L,H]), one vln_linear_fwd against w_tin and a second
    * vln_attn_dctx_deferred (alpha / g pairs, accumulate).  d W_in still comes from the s_dtt rows. */
   const float* kctx;
+  /* ABI v15, optional (s_probs nullable): the SAMPLED-ACTION branch of envdrop.py:173,186-195 on this step's logits inside the
+   * step's last launch (candidate dots + mask + softmax + draw + log-prob + entropy: what vln_attn_dot + vln_categorical_fwd + a
+   * device-to-host copy of the action did as three launches).  s_cand_mask [B,C] 1 = not a candidate (nullable); s_action_in
+   * [B] a given action (nullable: the kernel draws with Philox (s_seed, s_offset [+ *s_offset_base_dev * 8]), row b's word);
+   * s_action_out [B] int64 device (nullable when s_action_in is given); s_action_host [B] int64 in HOST-MAPPED pinned memory
+   * (device-visible address, nullable): the action lands there with a system-scope store -- the host that steps the simulator
+   * (envdrop.py:196-206) polls it; s_probs [B,C], s_logp [B], s_ent [B] outputs.  `logit` still receives the raw logits.
+   * Not with defer_logits. */
+  const uint8_t* s_cand_mask; const int64_t* s_action_in; int64_t* s_action_out; int64_t* s_action_host;
+  float* s_probs; float* s_logp; float* s_ent;
+  uint64_t s_seed, s_offset; const uint64_t* s_offset_base_dev;
 } vln_envdrop_step;
 
 typedef struct vln_envdrop_grads {
@@ -826,6 +840,13 @@ int vln_attn_textk_bwd(const void* ctx, int ctype, const float* kctx, const floa
                        int64_t slab_stride, float* dwc_out, float* dq, float* dl, const float* dh1, const float* dc1,
                        const float* act, const float* tanh_c1, const float* c0, float* dgates, float* dc0, uint64_t seed,
                        uint64_t offset, float p, int B, int S, int H, void* sync, int64_t sync_bytes, vln_stream_t s);
+/* The device waits for the HOST between two launches of a sequence (ABI v15): a one-wave launch that spins until the 8-byte word
+ * at flag_dev (pinned host memory, device-visible address: vln_host_device_pointer) equals the device word *want_dev, then
+ * lets the stream go on.  For rollouts whose next step needs the host (the simulator step of envdrop.py:196-206) inside ONE
+ * captured iteration: `want` = the device clock's word (it changes every iteration, so an old flag never matches).  spin_limit
+ * (<= 0: ~2^26 polls, seconds) bounds the wait: on a timeout word 3 of the sticky error words is raised (vln_persistent_check)
+ * and the stream goes on. */
+int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, vln_stream_t s);
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
 int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
 /* 1 when the folded text attention of vln_envdrop_step.kctx covers (ctype, B episodes, S tokens, D = H) on the current device with

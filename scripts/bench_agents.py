@@ -242,7 +242,12 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
     clock = vln.DeviceClock(dev).attach(enc, dec, cri) if graph else None
     a_host = torch.zeros(T_rl, B, dtype=torch.int64).pin_memory()
     a_np = a_host.numpy()         # the same pinned memory, for the polling form of the action read
-    poll = read_actions == "poll"
+    import ctypes as C_
+    _d = C_.c_void_p()
+    vln._lib.check(vln._lib.load().vln_host_device_pointer(a_host.data_ptr(), C_.byref(_d)), "vln_host_device_pointer")
+    a_host_dev = int(_d.value)    # the device-visible address of the pinned action words (the step's draw stores there itself)
+    in_step = not getattr(args, "separate_sampler", False) and not getattr(args, "per_step_sampler", False)
+    poll = read_actions in ("poll", "handshake")
     host_ended = [0]              # what the stand-in for env.step keeps: episodes that chose STOP so far (read, never fed back)
 
     def gather_of(s):
@@ -265,11 +270,19 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
         ctx, h, c = enc(tape["tokens"], tape["lengths32"])
         dec.defer_logits = False
         dec.chain_steps = False      # the sampled rollout reads every step's logits
+        dec.chain_backward = not getattr(args, "no_chain_backward", False)     # ... but nothing except the next step consumes its h_tilde
         st.update(ctx=ctx, h=h, c=c, ht=h, hidden=[], logps=[], ents=[],
                   sampler=None if getattr(args, "per_step_sampler", False) else vln.losses.RolloutSampler(clock=clock))
 
     def rl_step(t):
         s = tape["steps"][t]
+        if in_step and st["sampler"] is not None:
+            # mask + softmax + draw + log-prob + entropy inside the step's logits launch; the action goes to the pinned words itself
+            logit, (h, c), ht = dec(s["angle"], None, None, st["ht"], st["h"], st["c"], st["ctx"], tape["seq_mask"], gather=gather_of(s),
+                                    sampler=(st["sampler"], s["cand_mask"], None, (a_host_dev + 8 * B * t) if read_actions else 0))
+            st.update(h=h, c=c, ht=ht)
+            st["hidden"].append(h)
+            return
         logit, (h, c), ht = dec(s["angle"], None, None, st["ht"], st["h"], st["c"], st["ctx"], tape["seq_mask"], gather=gather_of(s))
         st.update(h=h, c=c, ht=ht)
         st["hidden"].append(h)
@@ -355,6 +368,16 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
     polling = [False]
 
     def captured():
+        if read_actions == "handshake":
+            # ONE graph for the iteration: the host's turns are waits INSIDE it (graphs.HandshakeIterationGraph); the host polls the
+            # pinned action words of step t, does its turn and releases step t + 1
+            hg = vln.HandshakeIterationGraph(segs, clock).capture()
+            polling[0] = True
+
+            def run_h():
+                a_np[:] = -1
+                return hg.replay()
+            return run_h
         sg = vln.SegmentedIterationGraph(segs, clock).capture()
         if not poll:
             return sg.replay
@@ -375,7 +398,7 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
         run = it
     ms = timed(run)
     return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3),
-                iteration=(f"{T_rl + 1} hipGraph segments" if graph else "per-step hipGraphs, Python-driven"),
+                iteration=(("ONE hipGraph, the host's turns are waits inside it" if read_actions == "handshake" else f"{T_rl + 1} hipGraph segments") if graph else "per-step hipGraphs, Python-driven"),
                 per_step_action_read=("host spins on the pinned action words" if (poll and graph) else bool(read_actions)), plan_hits=dec.plan_hits, arena_misses=arena.misses,
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
@@ -390,9 +413,12 @@ def main():
     ap.add_argument("--arena", action="store_true", help="monitor / follower: per-iteration buffers from ops.RolloutArena")
     ap.add_argument("--python-step", action="store_true", help="monitor: the step's launches driven from Python (functional.MonitorCoreFn) "
                                                                "instead of one C call each way")
+    ap.add_argument("--separate-sampler", action="store_true", help="a2c: (A/B) candidate dots, draw and the action's D2H copy as three launches instead of inside the step's last launch")
+    ap.add_argument("--no-chain-backward", action="store_true", help="a2c: (A/B) the sampled rollout's step backwards not chained")
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower / a2c: eager launches instead of one hipGraph (a2c: a sequence of graph segments) per iteration")
     ap.add_argument("--no-action-read", action="store_true", help="a2c: (A/B) the sampled actions never leave the device")
+    ap.add_argument("--handshake", action="store_true", help="a2c: the iteration as ONE hipGraph whose per-step host turns are waits inside it (graphs.HandshakeIterationGraph); the host polls every action and releases the next step")
     ap.add_argument("--poll-actions", action="store_true", help="a2c: the host spins on the pinned action words instead of synchronising the stream after every step")
     ap.add_argument("--no-chain-il", action="store_true", help="a2c: (A/B) the teacher-forced rollout's steps not chained")
     ap.add_argument("--tunable", action="append", default=[], metavar="ID=VALUE", help="(A/B) vln_set_tunable(ID, VALUE) before anything runs")
@@ -422,7 +448,7 @@ def main():
     if a.which in ("speaker", "all"):
         print(json.dumps(run_speaker()), flush=True)
     if a.which in ("a2c", "all"):
-        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=("poll" if a.poll_actions else not a.no_action_read), chain_il=not a.no_chain_il)), flush=True)
+        print(json.dumps(run_a2c(T_rl=a.T_rl, read_actions=("handshake" if a.handshake else "poll" if a.poll_actions else not a.no_action_read), chain_il=not a.no_chain_il)), flush=True)
 
 
 if __name__ == "__main__":

@@ -114,7 +114,7 @@ def test_decoder_gradient_ride_equals_its_own_launches(vln, graph):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the gradient ride and its own launches"
 
 
-@pytest.mark.parametrize("dtype,read", [("fp32", True), ("bf16", True), ("bf16", "poll")])
+@pytest.mark.parametrize("dtype,read", [("fp32", True), ("bf16", True), ("bf16", "poll"), ("bf16", "handshake"), ("fp32", "handshake")])
 def test_il_plus_a2c_iteration_as_graph_segments_equals_eager(vln, dtype, read):
     """BASELINE config 3's per-rank iteration (trainer.py:411-427: IL rollout + sampled A2C rollout + critic, one RMSprop) as
     graphs.SegmentedIterationGraph -- one hipGraph per sampled step with the action read on the host between them, the backward
@@ -130,7 +130,8 @@ def test_il_plus_a2c_iteration_as_graph_segments_equals_eager(vln, dtype, read):
         torch.manual_seed(91)
         store = bench.build_store(vln, dev, W.dt, n_rows=300, seed=5)
         torch.manual_seed(92)
-        # (read = "poll": the replayed segments' host steps spin on the pinned action words instead of synchronising the stream)
+        # (read = "poll": the replayed segments' host steps spin on the pinned action words instead of synchronising the stream;
+        #  read = "handshake": ONE graph, every host turn a vln_host_wait inside it -- graphs.HandshakeIterationGraph)
         it, capture, state = W.run_a2c(B=16, L=24, T_il=3, T_rl=5, C=6, store=store, graph=True, build_only=True, seed=600, read_actions=read)
         state["enc"].deterministic_embedding_grad = True
         rec = []

@@ -1002,3 +1002,66 @@ def test_envdrop_full_size_bf16_split_weight_gradients(vln):
     same-weights bound of the outputs (1e-4)."""
     assert same_bf16_grad_tol() == SAME_BF16
     _full_size_envdrop(vln, torch.bfloat16)
+
+
+@pytest.mark.parametrize("given_actions", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_in_step_sampler_and_chained_backward_equal_the_separate_launches(vln, dtype, given_actions):
+    """Round 5, sampled rollouts (envdrop.py:173,186-206): `forward(sampler=...)` runs mask + softmax + draw + log-prob + entropy
+    inside the step's logits launch and stores the action into host-mapped pinned words itself (vln_envdrop_step.s_*), and
+    `chain_backward` lets step t's act-embedding / h_tilde_prev backward stage ride in step t - 1's first backward launch
+    (chain == 2).  Same arithmetic in the same order as `RolloutSampler.step` + a D2H copy and the unchained backward: logits,
+    actions (device AND host words), log-probs, entropies, the loss and every gradient are equal bit for bit."""
+    import ctypes as C_
+    dev = torch.device(DEV)
+    B, L, V, C, H, IMG, ANG, AE, T = 16, 20, 36, 7, 64, 96, 32, 16, 5
+    F = IMG + ANG
+
+    def rollout(in_step):
+        torch.manual_seed(11)
+        dec = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=dtype).to(dev).train()
+        dec.chain_backward = in_step
+        g = torch.Generator().manual_seed(12)
+        ctx = (torch.randn(B, L, H, generator=g) * 0.5).to(dev).requires_grad_(True)
+        ht = torch.tanh(torch.randn(B, H, generator=g)).to(dev).requires_grad_(True); c = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+        mask = (torch.arange(L)[None, :] >= torch.randint(4, L + 1, (B, 1), generator=g)).to(dev)
+        a_host = torch.full((T, B), -1, dtype=torch.int64).pin_memory()
+        d = C_.c_void_p()
+        vln._lib.check(vln._lib.load().vln_host_device_pointer(a_host.data_ptr(), C_.byref(d)), "vln_host_device_pointer")
+        sampler = vln.losses.RolloutSampler(seed=77)
+        h, hidden, logits, acts = ht, [], [], []
+        for t in range(T):
+            img = (torch.randn(B, V, F, generator=g).abs() * 0.5).to(dev); cand = (torch.randn(B, C, F, generator=g).abs() * 0.5).to(dev)
+            ncand = torch.randint(2, C + 1, (B,), generator=g)
+            cmask = (torch.arange(C)[None, :] >= ncand[:, None]).to(dev)
+            given = (torch.rand(B, generator=g) * ncand.float()).long().to(dev) if given_actions else None
+            a_in = torch.sin(torch.randn(B, ANG, generator=g)).to(dev)
+            if in_step:
+                logit, (h, c), ht = dec(a_in, img, cand, ht, h, c, ctx, mask, sampler=(sampler, cmask, given, int(d.value) + 8 * B * t))
+                a = sampler.keep[-1][1]
+            else:
+                logit, (h, c), ht = dec(a_in, img, cand, ht, h, c, ctx, mask)
+                a = sampler.step(logit, cmask, action=given, offset=None)
+                a_host[t].copy_(a, non_blocking=True)
+            hidden.append(h); logits.append(logit.detach().clone()); acts.append(a.clone())
+        logp, ent = sampler.stats()
+        w = torch.randn(T, B, generator=g).to(dev)
+        loss = (logp * w).sum() - 0.01 * ent.sum() + sum(x.sum() for x in hidden) * 0.01 + ht.sum() * 0.1
+        loss.backward()
+        torch.cuda.synchronize()
+        return dict(logits=logits, acts=acts, host=a_host.clone(), logp=logp.detach().clone(), ent=ent.detach().clone(), loss=loss.detach().clone(),
+                    grads=[ctx.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
+
+    # the draws take their Philox offsets from a global call counter: both rollouts start from the same value
+    start = vln.losses._sample_calls[0]
+    ref = rollout(False)
+    vln.losses._sample_calls[0] = start
+    got = rollout(True)
+    for t in range(T):
+        assert torch.equal(ref["logits"][t], got["logits"][t]), f"step {t}: logits"
+        assert torch.equal(ref["acts"][t], got["acts"][t]), f"step {t}: actions"
+    assert torch.equal(ref["host"], got["host"]) and int(got["host"].min()) >= 0            # every word was written by the step's own launch
+    for k in ("logp", "ent", "loss"):
+        assert torch.equal(ref[k], got[k]), k
+    for i, (a, b) in enumerate(zip(ref["grads"], got["grads"])):
+        assert torch.equal(a, b), f"gradient {i} differs between the in-step sampler / chained backward and the separate launches"
