@@ -313,7 +313,8 @@ class GpuAgent:
         if self.segmented:
             self.graph = self.vln.SegmentedIterationGraph(self.segments(tape), self.clock).capture()
             return self.graph
-        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture(debug_dump=getattr(self, "dump_graph", None))
+        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture(
+            debug_dump=getattr(self, "dump_graph", None), capture_error_mode=getattr(self, "capture_error_mode", "global"))
         return self.graph
 
     def replay(self):
@@ -715,6 +716,8 @@ def main():
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
     ap.add_argument("--no-project-context", action="store_true", help="(A/B) the decoder projects its text-attention query every step "
                     "(round 4's step: 8 dependent launches per direction) instead of scoring on K = ctx W_in formed once per rollout")
+    ap.add_argument("--dp-segments", action="store_true", help="with --dp-path / N > 1: (A/B, round 4's form) the iteration as three graph segments with "
+                    "host-issued collectives between them instead of ONE graph with the process group's collectives captured inside")
     ap.add_argument("--dp-path", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the iteration -- three hipGraph segments with the gradient "
                          "exchange issued between them (graphs.SegmentedIterationGraph) on a ONE-rank RCCL group, collectives "
@@ -748,6 +751,8 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if world > 1 or args.dp_path:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's version banner goes to STDOUT: rank 0 owes the driver one JSON line there
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -799,7 +804,11 @@ def main():
     use_graph = args.iteration_graph == "on" or (args.iteration_graph == "auto" and args.features == "store" and not args.no_arena)
     # N > 1 (and --dp-path): the iteration as three graph segments with the gradient exchange issued between them -- the same
     # kernels in the same order as the single graph of N = 1 (graphs.SegmentedIterationGraph)
-    agent.segmented = bool(use_graph and (world > 1 or args.dp_path))
+    args.dp_capture = not args.dp_segments
+    agent.segmented = bool(use_graph and (world > 1 or args.dp_path) and not args.dp_capture)
+    if args.dp_capture and (world > 1 or args.dp_path):
+        agent.dec.grads_ready_hook = lambda: agent.opt.start_allreduce(1)      # (N = 1 rehearsal: the hook GpuAgent sets for world > 1)
+        agent.capture_error_mode = "thread_local"
     # one GPU: the decoder's parameter gradients ride in the encoder's BPTT launch (a data-parallel rank wants them final before it)
     agent.dec.ride_wgrads = bool(world == 1 and not args.dp_path and not args.no_ride_wgrads and args.dtype != "fp32")
     if agent.segmented:
@@ -1088,7 +1097,7 @@ def main():
                                          "device": "device memory, one D2D copy per iteration"}[args.batch_source] if live is not None else "per-step tensors"),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
-                       "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else True) if use_graph else False,
+                       "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else ("one graph, gradient exchange captured inside" if (args.dp_capture and (world > 1 or args.dp_path)) else True)) if use_graph else False,
                        "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "projected_context": bool(agent.dec.last_projected), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},

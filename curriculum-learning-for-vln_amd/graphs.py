@@ -37,8 +37,10 @@ class IterationGraph:
         self.out = None
         self.replays = 0
 
-    def capture(self, warmup: int = 0, debug_dump: Optional[str] = None):
-        """Run `warmup` eager iterations (first-use allocations, weight shadows, step plans), then record one."""
+    def capture(self, warmup: int = 0, debug_dump: Optional[str] = None, capture_error_mode: str = "global"):
+        """Run `warmup` eager iterations (first-use allocations, weight shadows, step plans), then record one.
+        capture_error_mode="thread_local": for iterations that contain collectives of a process group -- its watchdog thread polls
+        events while the capture is open (see SegmentedIterationGraph.capture)."""
         for _ in range(warmup):
             self.fn()
         torch.cuda.synchronize()
@@ -51,7 +53,7 @@ class IterationGraph:
             g.enable_debug_mode()
         epoch0 = self.clock.epoch
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=capture_error_mode):
                 self.out = self.fn()
         finally:
             # The captured tick did not run: the device words still hold the pre-capture values.  Also when `fn` RAISED inside the

@@ -50,6 +50,79 @@ print("RCCL-PATH-OK")
 '''
 
 
+CHILD_GRAPH = r'''
+import os, sys
+sys.path.insert(0, os.environ["VLN_ROOT"])
+import torch, torch.distributed as dist
+import vln_amd as vln, bench
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+vln.dp._dp_active = lambda group=None: True          # a one-rank group: run the collectives anyway
+dtype = torch.bfloat16
+
+def run(form):
+    torch.manual_seed(77)
+    store = bench.build_store(vln, dev, dtype, n_rows=300, seed=5)
+    tapes = [bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
+    live = bench.LiveBatch(tapes, source="pull")
+    torch.manual_seed(78)
+    ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
+    ag.use_live(live)
+    ag.clear_grads_in_step = True
+    ag.enc.deterministic_embedding_grad = True
+    ag.ride_gather = True
+    ag.dec.ride_wgrads = False                       # a data-parallel rank wants the decoder's gradients final before the BPTT
+    ag.use_clock(store)
+    if form == "segments":
+        ag.segmented = True
+    elif form == "captured":                          # ONE graph, the process group's collectives are nodes of it
+        ag.dec.grads_ready_hook = lambda: ag.opt.start_allreduce(1)
+        ag.capture_error_mode = "thread_local"
+    out = []
+    def rec(loss):
+        torch.cuda.synchronize()
+        out.append((loss.detach().clone(), ag.opt.flat_p.clone(), ag.opt.sq.clone()))
+    for k in range(2):
+        rec(ag.iteration(live.load(k)))
+    ag.capture(live.live)
+    for k in range(2, 6):
+        live.load(k)
+        rec(ag.replay())
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    return out
+
+single = run("single")
+for form in ("segments", "captured"):
+    got = run(form)
+    for i, (a, b) in enumerate(zip(single, got)):
+        for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state")):
+            assert torch.equal(x, y), f"{form}: iteration {i}: {what} differ from the single graph"
+dist.destroy_process_group()
+print("RCCL-GRAPH-OK")
+'''
+
+
+def _run_child(code):
+    for attempt in range(2):            # the rendezvous port is picked by bind-and-close: one retry if it was taken meanwhile
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VLN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        if r.returncode == 0 or "address already in use" not in r.stderr.lower():
+            break
+    return r
+
+
+def test_gradient_exchange_captured_inside_the_iteration_graph():
+    """Round 5 (VERDICT r4 item 4): the N > 1 iteration as ONE hipGraph -- the flat bucket's early decoder slice and the rest go
+    through `torch.distributed.all_reduce` on a one-rank RCCL group INSIDE the capture (the collectives become nodes of the graph,
+    the early slice on the process group's stream beside the encoder's BPTT) -- against round 4's three graph segments with
+    host-issued collectives and against the plain single graph: losses, parameters and RMSprop state over six iterations (two
+    eager, four replays) bit for bit."""
+    r = _run_child(CHILD_GRAPH)
+    assert r.returncode == 0 and "RCCL-GRAPH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_collective_path_on_a_one_rank_rccl_group():
     for attempt in range(2):            # the rendezvous port is picked by bind-and-close: one retry if it was taken meanwhile
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
