@@ -93,6 +93,40 @@ def test_headline_iteration_vs_oracle(vln, dtype):
     opt = torch.optim.RMSprop(params, lr=bench.LR)               # trainer.py:380-381: torch defaults (alpha 0.99, eps 1e-8)
     p, pf = 0.5, 0.3
     tol = FP32 if not lp else BF16
+    def oracle_iteration(Pm, k, round_features):
+        tape = cpu_tapes[k % len(cpu_tapes)]
+        host = hosts[k]
+        oe = host + 1
+        cx, h, c = O.encoder_forward(Pm["enc"], tape["tokens"], tape["lengths"].tolist(), num_layers=1, bidirectional=True,
+                                     emb_mask=_mask(vln, B * L * E, ag.enc.dropout_seed, oe * 8 + 0, p, (B, L, E)),
+                                     ctx_mask_drop=_mask(vln, B * L * H, ag.enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
+        ht, ml = h, 0.0
+        for t, s in enumerate(tape["steps"]):
+            f = bench.materialize_step(s, table, ANG)
+            Ct = s["cand_mask"].shape[1]
+            img = O.feature_dropout(f["img"].double(), _mask(vln, B * V * IMG, store.seed, host * 8 + 2 * t + 1, pf, (B, V, IMG)), ANG)
+            cand = O.feature_dropout(f["cand"].double(), _mask(vln, B * Ct * IMG, store.seed, host * 8 + 2 * t + 2, pf, (B, Ct, IMG)), ANG)
+            if round_features:
+                img, cand = img.float().bfloat16().double(), cand.float().bfloat16().double()
+            od = host + t + 1
+            m = lambda site, n, shape: _mask(vln, n, ag.dec.dropout_seed, od * 8 + site, p, shape)
+            drop = {"act": m(0, B * AE, (B, AE)), "hprev": m(1, B * H, (B, H)), "h1": m(2, B * H, (B, H)), "htilde": m(3, B * H, (B, H))}
+            lo, (h, c), ht, _ = O.envdrop_step(Pm["dec"], s["angle"].double(), img, cand, ht, c, cx, tape["seq_mask"], drop=drop)
+            ml = ml + O.masked_cross_entropy(lo.masked_fill(s["cand_mask"], -float("inf")), s["target"], None, "sum")
+        return ml * bench.ML_WEIGHT / B
+
+    if lp:
+        # RECORDED, not asserted: iteration 0 against the oracle on the UN-rounded fp32 feature rows (the store's
+        # table holds bf16 rows here, so only the feature DROPOUT's 1 / (1 - p) scaling is un-rounded: the table itself is the data)
+        P32 = {k: {n: v.clone().requires_grad_(True) for n, v in d.items()} for k, d in sd0.items()}
+        l32 = oracle_iteration(P32, 0, False)
+        l32.backward()
+        check(torch.tensor(losses[0]), l32.detach(), 1.0, "fp32 feature rows (recorded): loss of iteration 0")
+        for key in ("enc", "dec"):
+            gmax = max(float(q.grad.abs().max()) for q in P32[key].values() if q.grad is not None)
+            for n, g in grads0[key].items():
+                r = P32[key][n].grad if P32[key][n].grad is not None else torch.zeros_like(P32[key][n])
+                check(g, r, 1.0, f"fp32 feature rows (recorded): iteration 0: grad[{key}.{n}]", floor=grad_floor(n, gmax))
     for k in range(n_eager + n_replay):
         tape = cpu_tapes[k % len(cpu_tapes)]
         host = hosts[k]
