@@ -297,9 +297,22 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
                 w_t = self._shadow.t["w_tin_t"]                  # W_in^T [H(query), H(ctx)]: K = ctx @ W_in
                 k = ops.linear_fwd(src.view(B * L, H), w_t, split=lp).view(B, L, H)
                 entry.k_w, entry.k_split = self._shadow.t["w_tin"], lp
+                entry.k_hd = self._hd_view
         entry.kctx = k
         self.last_projected = k is not False          # (tests: which copy of ctx the latest rollout's logits were taken on)
         return k
+
+    def _hd_view(self, address: int, rows: int):
+        """[rows, H] view (row stride 2H) of the `tcat` stash whose first element lies at `address` (a step's drop(h_1) block), or
+        None when those rows are not inside one chunk of the stash."""
+        H = self.hidden_size
+        for ch in (self._stash.chunks if self._stash is not None else ()):
+            t = ch.bufs["tcat"]
+            off = address - t.data_ptr()
+            if 0 <= off and off + ((rows - 1) * 2 * H + H) * 4 <= t.numel() * 4 and off % 4 == 0:
+                e0 = off // 4
+                return t.view(-1).as_strided((rows, H), (2 * H, 1), e0)
+        return None
 
     def scores_on_projected_context(self, ctx) -> bool:
         """Whether the rollout on `ctx` (after its first step) takes its text-attention logits on K = ctx W_in formed from the

@@ -308,7 +308,7 @@ class WeightGate(torch.autograd.Function):
 class CtxEntry:
     """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
     low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
-    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "kctx", "k_w", "k_split", "__weakref__")
+    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "kctx", "k_w", "k_split", "k_hd", "__weakref__")
 
     def __init__(self, t):
         self.ref = weakref.ref(t)
@@ -324,6 +324,7 @@ class CtxEntry:
         self.kctx = None
         self.k_w = None
         self.k_split = False
+        self.k_hd = None        # callable (address, rows) -> [rows, H] strided view of the module's drop(h_1) stash rows
 
 
 class CtxGate(torch.autograd.Function):
@@ -352,14 +353,28 @@ class CtxGate(torch.autograd.Function):
                 if kmode:
                     # projected context (vln_envdrop_step.kctx): the steps' queries never existed.  dctx = sum_t alpha_t g_t +
                     # (sum_t dl_t hd_t) W_in^T with hd_t = drop(h_1) of step t (t[3]: the tcat stash rows, columns [H, 2H))
-                    # -- ONE pass over the steps' vectors writes both sums, ONE product adds the second through W_in^T
                     dev = terms[0][4].device
-                    dk = ops.empty(B, L, H, dtype=torch.float32, device=dev)
                     if d is None:
                         d = ops.empty(B, L, H, dtype=torch.float32, device=dev)
-                    ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
-                                           [t[3] for t in terms], 2 * H, d, accumulate=acc, dk=dk)
-                    ops.linear_fwd(dk.view(B * L, H), e.k_w, act=ops.ACT_ACCUM, out=d.view(B * L, H), split=e.k_split)
+                    T = len(terms)
+                    row = B * 2 * H * 4
+                    x = None
+                    if e.k_hd is not None and all(terms[i][3] == terms[0][3] - i * row for i in range(T)):
+                        x = e.k_hd(terms[-1][3], T * B)                              # [T * B, H] view (row stride 2H) of the stash
+                    if x is not None:
+                        # the steps' hd rows are consecutive row blocks of the stash (the backward visits them last step first):
+                        # (sum_t dl_t hd_t) W_in^T = sum_t dl_t (W_in hd_t) -- the steps' QUERIES, formed now for all steps by ONE
+                        # product over (steps x batch) rows, then the one-launch form of the context gradient (no dK tensor)
+                        q = ops.linear_fwd(x, e.k_w, split=e.k_split)                # W_in hd_t, step T-1-i at rows [i * B, (i + 1) * B)
+                        qp = [q.data_ptr() + (T - 1 - i) * B * H * 4 for i in range(T)]
+                        ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H, qp, H, d,
+                                               accumulate=acc)
+                    else:
+                        # -- ONE pass over the steps' vectors writes both sums, ONE product adds the second through W_in^T
+                        dk = ops.empty(B, L, H, dtype=torch.float32, device=dev)
+                        ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
+                                               [t[3] for t in terms], 2 * H, d, accumulate=acc, dk=dk)
+                        ops.linear_fwd(dk.view(B * L, H), e.k_w, act=ops.ACT_ACCUM, out=d.view(B * L, H), split=e.k_split)
                 else:
                     ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
                                            [t[3] for t in terms], H, d, accumulate=acc)
