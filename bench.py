@@ -1119,18 +1119,18 @@ def csrc_sha():
 
 def pmc_figures(kernel, dtype):
     """(HBM-side bytes per launch, MFMA issue-slot utilisation, note) of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/round4_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
+    (profiles/round5_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
     same command).  The file carries the hash of the kernel sources it was taken on: a mismatch means the numbers describe
     OTHER code, and they are refused (null) rather than quoted stale."""
-    f = os.path.join(ROOT, "profiles", "round4_pmc.json")
+    f = os.path.join(ROOT, "profiles", "round5_pmc.json")
     if not os.path.exists(f):
         return None, None, "no PMC passes committed for this round yet"
     d = json.load(open(f))
     if d.get("csrc_sha") != csrc_sha():
-        return None, None, f"profiles/round4_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
+        return None, None, f"profiles/round5_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
     t = d.get("traffic", {}).get(dtype, {}).get(kernel)
     m = d.get("mfma_util", {}).get(dtype, {}).get(kernel)
-    return (t["bytes_per_launch"] if t else None), m, f"profiles/round4_pmc.json, kernel sources {d['csrc_sha']}"
+    return (t["bytes_per_launch"] if t else None), m, f"profiles/round5_pmc.json, kernel sources {d['csrc_sha']}"
 
 
 def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,

@@ -244,7 +244,8 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # step t - 1's backward (vln_envdrop_step.chain == 2) -- for every step whose h_tilde_prev IS the previous call's h_tilde.
         # The caller promises that nothing but the next step consumes a step's h_tilde (its logits and h_1 / c_1 are free).
         self.chain_backward = False
-        self._last_ht = None
+        self.__dict__["_last_ht"] = None
+        self.__dict__["_sampler_arg"] = None
         # bf16 compute: weight matrices that are streamed in fp32 all the same (names: w_vin, w_cat, w_tin, w_tout, w_c).  Set it
         # before the first forward (the shadows are rebuilt when a parameter changes).
         self.fp32_weights = frozenset(type(self).default_fp32_weights)
@@ -638,7 +639,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         draw + log-prob + entropy; vln_envdrop_step.s_*) and the step is recorded in the sampler as `sampler.step(logit, cand_mask,
         action)` would record it; the drawn action is `sampler.keep[-1][1]` and -- with `action_host_address`, the device-visible
         address of B int64 words of PINNED host memory -- also lands there without a copy launch (the host polls it)."""
-        self._sampler_arg = sampler
+        self.__dict__["_sampler_arg"] = sampler          # (plain dict stores: nn.Module.__setattr__ costs microseconds per step)
         if gather is not None:
             if img_feature is not None or cand_feature is not None or already_dropfeat:
                 raise TypeError("EnvDropDecoder: with gather=(store, ...) pass img_feature=None, cand_feature=None")
@@ -686,7 +687,9 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         dt = self.compute_dtype
         lp = dt != torch.float32
         # the in-step sampler's buffers come first (the same place in the arena's order on the planned and on the full path)
-        smp, self._sampler_arg = self.__dict__.get("_sampler_arg"), None
+        smp = self.__dict__.get("_sampler_arg")
+        if smp is not None:
+            self.__dict__["_sampler_arg"] = None
         sbind = None
         if smp is not None:
             if self.defer_logits:
@@ -898,7 +901,10 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         """Bookkeeping after a step was issued: the in-step sampler records it; the step's h_tilde is remembered (chain_backward)."""
         if smp is not None:
             smp[0].commit(out[0])
-        self._last_ht = weakref.ref(out[2]) if self.chain_backward else None
+        if self.chain_backward:
+            self.__dict__["_last_ht"] = weakref.ref(out[2])
+        elif self._last_ht is not None:
+            self.__dict__["_last_ht"] = None
         return out
 
 

@@ -3,7 +3,7 @@
 [gfx950 wide-read correction] + WRITE_SIZE x 1 KiB, MI355X_MICROARCH.md HBM section), L2 hit rate (TCC_HIT_sum / (TCC_HIT_sum +
 TCC_MISS_sum)), against the ALGORITHMIC bytes of the product (weights once + X + the split-K slabs it writes) and its duration.
 
-    python scripts/pmc_by_shape.py <FETCH_SIZE dir> <WRITE_SIZE dir> <TCC dir> > profiles/round4_gemm_nt_by_shape.txt
+    python scripts/pmc_by_shape.py <FETCH_SIZE dir> <WRITE_SIZE dir> <TCC dir> > profiles/round5_gemm_nt_by_shape.txt
 
 A launch is identified by (weight type of the kernel template, grid size in threads); the EnvDrop headline's shapes are named below
 (B = 64, H = 512, F = 2176, AE = 64, L = 80).  Shapes with the same workgroup count and weight type share a row."""
@@ -20,6 +20,8 @@ SHAPES = {
     (32 * 80): [("encoder input projection: E -> 4Hd*2, M = L*B", 5120, 2048, 256)],
     (34 * 7): [("rollout logits query: H -> F, M = T*B", 448, 2176, 512)],
     (8 * 6 * 7): [("rollout logit branch backward: F -> H, M = T*B", 448, 512, 2176)],
+    (8 * 80): [("projected context K = ctx W_in: H -> H, M = L*B (round 5)", 5120, 512, 512)],
+    (8 * 7): [("the rollout's text queries W_in hd_t for the context gradient: H -> H, M = T*B (round 5)", 448, 512, 512)],
 }
 
 
