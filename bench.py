@@ -1363,6 +1363,7 @@ def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
     # warm-up: the first iterations of a workload in a process grow the allocator's pools and load its kernels' code objects;
     # with 8 of them the Self-Monitor number read 5.7 ms against 5.05 ms for a second run in the same process
     W.configure(steps=20, warmup=30, dtype=dtype or args.dtype, arena=False, device=dev)
+    W.args.roofline = bool(which == "a2c" and read_actions == "handshake")     # the cfg3 entry carries its own roofline block
     W.vln.functional.set_grad_in_place(True)
     W.vln.functional.set_rollout_wgrads(which in ("monitor", "follower"))     # parameter gradients once per rollout (functional.RolloutWgrads)
     import gc
@@ -1376,7 +1377,7 @@ def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
         W.vln.functional.set_grad_in_place(False)
         gc.unfreeze()
     out = {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"], "dtype": r.get("dtype")}
-    for k in ("iteration", "per_step_action_read"):       # a2c: how the iteration was issued, and that the host read every sampled action
+    for k in ("iteration", "per_step_action_read", "roofline"):       # a2c: how the iteration was issued, that the host read every sampled action, its dominant kernel
         if k in r:
             out[k] = r[k]
     return out

@@ -397,7 +397,34 @@ def run_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actio
     else:
         run = it
     ms = timed(run)
-    return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3),
+    roof = None
+    if getattr(args, "roofline", False):
+        # the dominant kernel of THIS workload against the HBM roofline: per-kernel hip-event timers ride on plain launches, so five
+        # iterations are issued eagerly (no iteration graph, no per-step graphs while the timers are on)
+        lib = vln._lib.load()
+        nk = 0
+        while lib.vln_prof_kernel_name(nk):
+            nk += 1
+        for k in range(nk):
+            lib.vln_prof_enable(k, 1)
+        bench.read_prof(lib, nk)
+        torch.cuda.synchronize()
+        n_it = 5
+        for _ in range(n_it):
+            it()
+        torch.cuda.synchronize()
+        rows = sorted(bench.read_prof(lib, nk), key=lambda r: -r["ms"])
+        for k in range(nk):
+            lib.vln_prof_enable(k, 0)
+        if rows:
+            top = rows[0]
+            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=top["kernel"], achieved=round(ach, 1), peak=bench.HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / bench.HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(top["ms"] * 1e3 / top["launches"], 2),
+                        algo_bytes_per_launch=round(top["bytes"] / top["launches"]),
+                        kernels=[dict(kernel=r["kernel"], launches_per_iteration=r["launches"] / n_it, us_per_iteration=round(r["ms"] * 1e3 / n_it, 1),
+                                      GBps=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in rows[:6]])
+    return dict(workload=f"envdrop_il_T{T_il}_plus_a2c_T{T_rl}_B{B}_L{L}_rmsprop_arena", ms_per_iteration=round(ms, 3), roofline=roof,
                 iteration=(("ONE hipGraph, the host's turns are waits inside it" if read_actions == "handshake" else f"{T_rl + 1} hipGraph segments") if graph else "per-step hipGraphs, Python-driven"),
                 per_step_action_read=("host spins on the pinned action words" if (poll and graph) else bool(read_actions)), plan_hits=dec.plan_hits, arena_misses=arena.misses,
                 iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
@@ -418,6 +445,7 @@ def main():
     ap.add_argument("--per-step-sampler", action="store_true", help="a2c: losses.sample_action per step (A/B) instead of losses.RolloutSampler")
     ap.add_argument("--no-graph", action="store_true", help="monitor / follower / a2c: eager launches instead of one hipGraph (a2c: a sequence of graph segments) per iteration")
     ap.add_argument("--no-action-read", action="store_true", help="a2c: (A/B) the sampled actions never leave the device")
+    ap.add_argument("--roofline", action="store_true", help="a2c: also time the workload's kernels with hip events (five eager iterations) and report its dominant kernel against the HBM roofline")
     ap.add_argument("--handshake", action="store_true", help="a2c: the iteration as ONE hipGraph whose per-step host turns are waits inside it (graphs.HandshakeIterationGraph); the host polls every action and releases the next step")
     ap.add_argument("--poll-actions", action="store_true", help="a2c: the host spins on the pinned action words instead of synchronising the stream after every step")
     ap.add_argument("--no-chain-il", action="store_true", help="a2c: (A/B) the teacher-forced rollout's steps not chained")
@@ -432,6 +460,7 @@ def main():
     configure(a.steps, a.warmup, a.dtype, a.arena, graph=not a.no_graph)
     args.python_step = a.python_step
     args.per_step_sampler = a.per_step_sampler
+    args.separate_sampler, args.no_chain_backward, args.roofline = a.separate_sampler, a.no_chain_backward, a.roofline
     args.two_bn_mlp_calls = a.two_bn_mlp_calls
     for tv in a.tunable:
         tid, val = tv.split("=")
