@@ -83,7 +83,7 @@ class ShadowJob(C.Structure):
 
 class WgradJob(C.Structure):
     _fields_ = [("dy", ptr), ("x", ptr), ("dw", ptr), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
-                ("N", i32), ("K", i32), ("accumulate", i32), ("pad_", i32)]
+                ("N", i32), ("K", i32), ("accumulate", i32), ("rows", i32)]
 
 
 class ColsumJob(C.Structure):
@@ -211,6 +211,7 @@ SIGNATURES = {
     "vln_wgrad_ride_post": (i32, [ptr, i32, ptr, i32, i32, i32, ptr, i64, ptr]),
     "vln_wgrad_ride_flush": (i32, [ptr]),
     "vln_wgrad_ride_drop": (i32, [ptr]),
+    "vln_wgrad_ride_add": (i32, [ptr, i32, i32, ptr]),
     "vln_wgrad_ride_stats": (i32, [C.POINTER(i64)]),
     "vln_transpose_cast": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),
     "vln_cast_copy": (i32, [ptr, i64, ptr, i32, i64, i32, i32, ptr]),

@@ -1045,6 +1045,20 @@ extern "C" int vln_wgrad_ride_flush(vln_stream_t s) {
   if (!ride_take((hipStream_t)s, &r)) return VLN_OK;
   return ride_issue_alone((hipStream_t)s, r);
 }
+extern "C" int vln_wgrad_ride_add(const vln_wgrad_job* job, int rows, int precision, vln_stream_t s) {
+  if (!job || rows <= 0 || !job->dy || !job->x || !job->dw) return 0;
+  std::lock_guard<std::mutex> lock(g_ride_mu);
+  auto it = g_rides.find((hipStream_t)s);
+  if (it == g_rides.end()) return 0;
+  PendingRide& r = it->second;
+  if (r.precision != precision || r.nw >= kRideWgradJobs || rows > r.rows) return 0;
+  vln_wgrad_job q = *job;
+  q.rows = rows < r.rows ? rows : 0;
+  r.w[r.nw] = q;
+  if (wgrad_grouped_ws_floats(r.w, r.nw + 1, r.rows) > r.ws_floats) return 0;      // the pack area would not hold its operands
+  r.nw++;
+  return 1;
+}
 // Forget a pending ride WITHOUT issuing it (its iteration was abandoned: a backward pass that raised never reached the carrying
 // launch or the flush, and the jobs' operands belong to a dead rollout).  Returns 1 if one was pending.
 extern "C" int vln_wgrad_ride_drop(vln_stream_t s) {

@@ -573,11 +573,11 @@ static bool wgrad_packed_tables(const vln_wgrad_job* jobs, int n, int Mt, float*
   long off = 0; int blk = 0, t = 0; long slab = 0;
   double bytes = 0.0;
   const int rblocks = (MS + 1) / 2;
-  auto add_pack = [&](const float* src, long ld, int C, long seg) -> long {
+  auto add_pack = [&](const float* src, long ld, int C, long seg, int rows) -> long {
     for (int i = 0; i < pk.n; ++i)                                    // an operand shared by two products is packed once
-      if (pk.j[i].src == src && pk.j[i].ld == ld && pk.j[i].C == C && pk.j[i].seg_stride == seg) return pk.j[i].dst;
+      if (pk.j[i].src == src && pk.j[i].ld == ld && pk.j[i].C == C && pk.j[i].seg_stride == seg && pk.j[i].rows == rows) return pk.j[i].dst;
     PackJob& q = pk.j[pk.n];
-    q.src = src; q.ld = ld; q.C = C; q.dst = off; q.seg_stride = seg;
+    q.src = src; q.ld = ld; q.C = C; q.dst = off; q.seg_stride = seg; q.rows = rows;
     pk.blk0[pk.n] = blk;
     blk += ((C + 127) / 128) * rblocks;
     off += 2L * ((C + 15) / 16) * MS * 1024;
@@ -586,8 +586,9 @@ static bool wgrad_packed_tables(const vln_wgrad_job* jobs, int n, int Mt, float*
   };
   for (int i = 0; i < n; ++i) {
     g.j[i] = jobs[i];
-    g.pa[i] = add_pack(jobs[i].dy, jobs[i].ld_dy, jobs[i].N, dy_seg ? (long)dy_seg[i] : 0);
-    g.px[i] = add_pack(jobs[i].x, jobs[i].ld_x, jobs[i].K, x_seg ? (long)x_seg[i] : 0);
+    const int jr = (jobs[i].rows > 0 && jobs[i].rows < Mt) ? jobs[i].rows : Mt;     // a product over fewer rows: the rest packs as zeros
+    g.pa[i] = add_pack(jobs[i].dy, jobs[i].ld_dy, jobs[i].N, dy_seg ? (long)dy_seg[i] : 0, jr);
+    g.px[i] = add_pack(jobs[i].x, jobs[i].ld_x, jobs[i].K, x_seg ? (long)x_seg[i] : 0, jr);
     g.tile0[i] = t;
     t += ((jobs[i].N + 127) / 128) * ((jobs[i].K + 127) / 128);
     g.slab0[i] = slab; slab += (long)msplit * jobs[i].N * jobs[i].K;
@@ -658,6 +659,30 @@ int64_t wgrad_grouped_ws_floats(const vln_wgrad_job* jobs, int n, int Mt) { retu
 
 int wgrad_grouped(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, int precision, float* ws, long ws_floats) {
   if (n <= 0 || Mt <= 0) { set_error("wgrad_grouped: bad args"); return VLN_ERR_ARG; }
+  {
+    // products over their OWN row counts (a ride nobody carried): the jobs over the call's rows stay one grouped call -- the same
+    // launches as without the odd ones -- and each odd one is a call of its own
+    int odd = 0;
+    for (int i = 0; i < n; ++i) odd += (jobs[i].rows > 0 && jobs[i].rows != Mt) ? 1 : 0;
+    if (odd) {
+      if (n > VLN_WGRAD_MAX_JOBS) { set_error("wgrad_grouped: too many jobs"); return VLN_ERR_ARG; }
+      vln_wgrad_job same[VLN_WGRAD_MAX_JOBS];
+      int ns = 0;
+      for (int i = 0; i < n; ++i) {
+        vln_wgrad_job q = jobs[i];
+        const int r = q.rows;
+        q.rows = 0;
+        if (r > 0 && r != Mt) {
+          if (r > Mt) { set_error("wgrad_grouped: job %d has more rows than the call", i); return VLN_ERR_ARG; }
+          const int rc = wgrad_grouped(st, &q, 1, r, precision, ws, ws_floats);
+          if (rc != VLN_OK) return rc;
+        } else {
+          same[ns++] = q;
+        }
+      }
+      return ns ? wgrad_grouped(st, same, ns, Mt, precision, ws, ws_floats) : VLN_OK;
+    }
+  }
   // precision 2 = plain bf16 operands on the packed grouped kernel; where that kernel cannot be used it degrades to the
   // (more accurate) split form
   const int terms = precision == 2 ? 1 : 3;

@@ -5,7 +5,7 @@
 // maxima, a ride travels by value inside another kernel's argument block and uses small ones.
 #pragma once
 
-struct PackJob { const float* src; long ld; int C; long dst; long seg_stride; };       // dst: byte offset of the hi plane in the pack area
+struct PackJob { const float* src; long ld; int C; long dst; long seg_stride; int rows; };   // dst: byte offset of the hi plane in the pack area; rows: the operand's own row count (<= Mt; rows past it pack as zeros)
 // SEGMENTED rows (rollout-level weight gradients of per-step C calls): row m of an operand lives at
 // src + (m / seg_rows) * seg_stride + (m % seg_rows) * ld -- step t's [seg_rows, C] block sits seg_stride floats after step
 // t-1's (the steps' saved-activation / scratch blocks are slots of one arena).  seg_rows == 0: plain rows, m * ld.
@@ -37,10 +37,10 @@ __device__ __forceinline__ void wgrad_pack_block(const PJ& a, int vbx) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = ms * 32 + mq * 8 + i;
-    const int mc = min(m, a.Mt - 1);
+    const int mc = min(m, q.rows - 1);
     const long roff = a.seg_rows ? (long)(mc / a.seg_rows) * q.seg_stride + (long)(mc % a.seg_rows) * q.ld : (long)mc * q.ld;
     const float4 v = *reinterpret_cast<const float4*>(pc + roff);
-    const bool ok = col_ok && m < a.Mt;
+    const bool ok = col_ok && m < q.rows;
     r[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
   unsigned char* hi = a.area + q.dst;

@@ -135,7 +135,23 @@ class _EncoderFn(torch.autograd.Function):
         # decoder_init = tanh(enc2dec(h_t))                                       units.py:69
         if ddec is not None:
             dpre = ops.ew(ops.EW_TANH_GRAD, ddec if ddec.stride(-1) == 1 else ddec.contiguous(), dec_init)      # one launch
-            put("enc2dec.weight", ops.linear_wgrad, dpre, hcat)
+            # d enc2dec.weight: in bf16 mode on the packed grouped kernel (the arithmetic of every other weight gradient) -- and, when a
+            # gradient ride is pending on this stream (the decoder's, posted before the encoder's backward began), as one more product
+            # of that ride: the backward recurrence launch below carries it instead of a 13 us launch in front of it
+            pw = pmap["enc2dec.weight"]
+            if pw.requires_grad:
+                gw = pw.grad
+                inplace = gw is not None and gw.is_contiguous() and gw.dtype == torch.float32
+                if not (sb and inplace and ops.GradRide.try_add(dpre, hcat, gw, sb)):
+                    if sb:
+                        tgt = gw if inplace else torch.empty_like(pw)
+                        wb0 = ops.WgradBatch(sb)
+                        wb0.add(dpre, hcat, tgt, inplace)
+                        wb0.run()
+                        if not inplace:
+                            grads["enc2dec.weight"] = tgt
+                    else:
+                        put("enc2dec.weight", ops.linear_wgrad, dpre, hcat)
             put("enc2dec.bias", ops.colsum, dpre)
             dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])
         else:

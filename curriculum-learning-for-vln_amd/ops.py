@@ -376,6 +376,23 @@ class GradRide:
         self.w, self.c, self.keep = [], [], []
 
     @staticmethod
+    def try_add(dy, x, out, split_bf16=True) -> bool:
+        """One more product out += dy.T @ x, over FEWER rows than the pending ride's, joins the ride posted on this stream
+        (vln_wgrad_ride_add): the encoder head's weight gradient (64 rows) beside the decoder's (steps x batch rows) -- carried by
+        the same backward recurrence launch instead of standing in front of it.  False: nothing pending / no room / another
+        precision -- the caller launches the product itself."""
+        if GradRide._posted is None:
+            return False
+        _req(dy, "dy"); _req(x, "x"); _req(out, "out")
+        Mt, N = dy.shape
+        K = x.shape[1]
+        job = _lib.WgradJob(dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.stride(0), x.stride(0), out.stride(0), N, K, 1, 0)
+        ok = bool(_lib.load().vln_wgrad_ride_add(C.byref(job), Mt, wgrad_precision(split_bf16), _stream()))
+        if ok:
+            GradRide._posted = (GradRide._posted[0], GradRide._posted[1] + [dy, x, out])
+        return ok
+
+    @staticmethod
     def flush():
         _lib.check(_lib.load().vln_wgrad_ride_flush(_stream()), "vln_wgrad_ride_flush")
 

@@ -114,7 +114,9 @@ int vln_linear_wgrad_p(const float* A, int64_t lda, const float* X, int64_t ldx,
 typedef struct vln_wgrad_job {
   const float* dy; const float* x; float* dw;
   int64_t ld_dy, ld_x, ld_dw;
-  int N, K, accumulate, pad_;
+  int N, K, accumulate;
+  int rows;      /* 0: the call's Mt rows.  > 0 (ABI v15, gradient rides only: vln_wgrad_ride_add): this product contracts over its
+                  * FIRST `rows` rows and its operands have no more than that (rows past them count as zeros) */
 } vln_wgrad_job;
 int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precision, float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
@@ -143,6 +145,11 @@ int vln_colsum_grouped(const vln_colsum_job* jobs, int n_jobs, int rows, float* 
 int vln_wgrad_ride_post(const vln_wgrad_job* jobs, int n_jobs, const vln_colsum_job* cjobs /*nullable*/, int n_cjobs, int rows,
                         int precision, float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_wgrad_ride_flush(vln_stream_t s);
+/* Append ONE more product, over its own `rows` <= the pending ride's rows, to the ride pending on stream s (ABI v15): the
+ * instruction encoder's head (`enc2dec`: 64 rows against the decoder's steps x batch) joins the decoder's ride instead of standing
+ * as its own launch in front of the BPTT.  Returns 1 when it was appended (same precision, a free slot, the pack area holds it),
+ * 0 when not -- the caller then forms the gradient itself. */
+int vln_wgrad_ride_add(const vln_wgrad_job* job, int rows, int precision, vln_stream_t s);
 int vln_wgrad_ride_drop(vln_stream_t s);     /* forget a pending ride without issuing it (its iteration was abandoned); 1 if one was pending */
 int vln_wgrad_ride_stats(int64_t out[2]);
 
