@@ -28,6 +28,11 @@ DEV = "cuda:0"
 TRAJ = {torch.float32: dict(l2=2e-4, p99=2e-4, max=4e-3), torch.bfloat16: dict(l2=0.12, p99=0.08)}
 
 
+# the Self-Monitor's small-shape trajectory under Adam (first step = lr * sign(g) for every element): ~3x the measured values
+# (round 5 measured: fp32 L2 1.7e-5, 99th percentile 5.6e-6, max 7.1e-5; bf16 L2 2.2e-2, 99th percentile 7.2e-3, max 0.14)
+MON_TRAJ = {torch.float32: dict(l2=1e-4, p99=5e-5), torch.bfloat16: dict(l2=6e-2, p99=2.5e-2)}
+
+
 @pytest.fixture(scope="module")
 def vln():
     import vln_amd
@@ -194,3 +199,183 @@ def test_headline_iteration_vs_oracle(vln, dtype):
     assert p99 < bound["p99"], f"parameter change, significant-gradient elements: 99th percentile {p99:.3e}"
     if "max" in bound:
         assert worst_sig < bound["max"], f"parameter change, significant-gradient elements: max {worst_sig:.3e} ({worst_name})"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_self_monitor_captured_iteration_vs_oracle_with_adam(vln, dtype):
+    """The same one-hop check for the Self-Monitor agent: one training iteration -- uni-directional encoder,
+    T co-grounding decoder steps (BN-MLP with train-mode statistics, one C call per step each way), the fused step loss of
+    monitor.py:146-165 with the progress target formed on the device, backward with rollout-level parameter gradients, fused Adam
+    whose step count lives in a device word -- captured as ONE hipGraph and replayed over different batches, against the oracle
+    (`O.encoder_forward`, `O.monitor_step`, `O.monitor_mixed_loss`) + `torch.optim.Adam(lr=1e-3)` from the same initial
+    parameters with the kernels' Philox masks: the loss of every iteration (2 eager + 3 replays), every gradient of the first,
+    the BatchNorm running statistics and the parameter change after the 5 updates.  Small shapes (B 16, L 24, T 3): the oracle
+    of the full-size agent is covered per step in test_hip_full_size_agents.py."""
+    from oracle import torch_port as O
+    dev = torch.device(DEV)
+    B, L, T, C, F, H, M, E, V = 16, 24, 3, 6, 192, 64, 32, 32, 60
+    lp = dtype != torch.float32
+    F_ = vln.functional
+    torch.manual_seed(41)
+    g = torch.Generator().manual_seed(42)
+    enc = vln.EncoderLSTM(V, E, H, 0, 0.5, False, 1, compute_dtype=dtype).to(dev).train()
+    dec = vln.MonitorDecoder(H, 0.5, L, (M,), F, F, compute_dtype=dtype).to(dev).train()
+    opt = vln.optim.FusedAdam([list(enc.parameters()) + list(dec.parameters())], lr=1e-3)
+    clock = vln.DeviceClock(dev).attach(enc, dec)
+    opt.use_clock(clock)
+    mlp_drop = [m for m in dec.proj_navigable_mlp.mlp if isinstance(m, torch.nn.Dropout)][0]
+    batches = []
+    for k in range(3):
+        tokens = torch.randint(4, V, (B, L), generator=g)
+        lens = torch.sort(torch.randint(4, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+        for i, n in enumerate(lens.tolist()):
+            tokens[i, n:] = 0
+        steps = []
+        for t in range(T):
+            ncand = torch.randint(2, C + 1, (B,), generator=g)
+            cmask = torch.arange(C)[None, :] >= ncand[:, None]
+            steps.append(dict(cand=torch.randn(B, C, F, generator=g).abs() * 0.5 * (~cmask)[..., None], cmask=cmask,
+                              target=(torch.rand(B, generator=g) * ncand.float()).long(),
+                              start=torch.rand(B, generator=g) * 15 + 4, cur=torch.rand(B, generator=g) * 10 + 0.2,
+                              ended=torch.rand(B, generator=g) < 0.1 * t))
+        batches.append(dict(tokens=tokens, lens=lens, steps=steps))
+    todev = lambda b: dict(tokens=b["tokens"].to(dev), lens=b["lens"].to(dev, torch.int32),
+                           steps=[{k: v.to(dev) for k, v in s.items()} for s in b["steps"]])
+    live = todev(batches[0])
+
+    def load(k):
+        b = todev(batches[k % len(batches)])
+        live["tokens"].copy_(b["tokens"]); live["lens"].copy_(b["lens"])
+        for ls, bs in zip(live["steps"], b["steps"]):
+            for kk in ls:
+                ls[kk].copy_(bs[kk])
+
+    # The first step's previous-action rows: NOT the reference's all-zero rows (monitor.py:108) -- a train-mode BatchNorm over identical
+    # rows has variance 0, its output is rounding noise of (z - mean) times 1 / sqrt(eps), and the ReLU behind it passes or blocks a
+    # unit by the SIGN of that noise: ill-conditioned in any arithmetic (fp32 and fp64 disagree on it, as two fp32 implementations would)
+    a0_cpu = torch.randn(B, F, generator=g).abs() * 0.5
+    a0 = a0_cpu.to(dev)
+
+    def it():
+        clock.tick()
+        opt.zero_grad()
+        ctx, h, c = enc(live["tokens"], live["lens"])
+        seq_mask = live["tokens"] == 0
+        a_prev, loss = a0, 0.0
+        for t, s in enumerate(live["steps"]):
+            (logit, prog), (h, c), _ = dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
+            lt, _ = vln.losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, 0.5)
+            loss = loss + lt
+            a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
+        loss.backward()
+        opt.step()
+        return loss
+
+    sd0 = {"enc": {k: v.detach().cpu().double().clone() for k, v in enc.state_dict().items()},
+           "dec": {k: v.detach().cpu().double().clone() for k, v in dec.state_dict().items()}}
+    n_eager, n_replay = 2, 3
+    losses, hosts, grads0 = [], [], None
+    try:
+        F_.set_grad_in_place(True); F_.set_rollout_wgrads(True)
+        for k in range(n_eager):
+            load(k)
+            loss = it()
+            torch.cuda.synchronize()
+            losses.append(float(loss)); hosts.append(clock.host)
+            if k == 0:
+                grads0 = {key: {n: p.grad.detach().cpu().double().clone() for n, p in mod.named_parameters()}
+                          for key, mod in (("enc", enc), ("dec", dec))}
+        graph = vln.IterationGraph(it, clock).capture()
+        for k in range(n_eager, n_eager + n_replay):
+            load(k)
+            loss = graph.replay()
+            torch.cuda.synchronize()
+            losses.append(float(loss)); hosts.append(clock.host)
+    finally:
+        F_.set_rollout_wgrads(False); F_.set_grad_in_place(False)
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+    final = {"enc": {k: v.detach().cpu().double() for k, v in enc.state_dict().items()},
+             "dec": {k: v.detach().cpu().double() for k, v in dec.state_dict().items()}}
+
+    # ---- the oracle ------------------------------------------------------------------------------------------------------------------
+    P = {k: {n: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running" not in n and "num_batches" not in n and n != "position.pe") else v.clone())
+             for n, v in d.items()} for k, d in sd0.items()}
+    params = [p for d in P.values() for p in d.values() if p.requires_grad]
+    opt_o = torch.optim.Adam(params, lr=1e-3)
+    tol = FP32 if not lp else BF16
+    run_keys = ("proj_navigable_mlp.mlp.0.running_mean", "proj_navigable_mlp.mlp.0.running_var",
+                "proj_navigable_mlp.mlp.2.running_mean", "proj_navigable_mlp.mlp.2.running_var")
+    sig = None
+    for k in range(n_eager + n_replay):
+        b = batches[k % len(batches)]
+        host = hosts[k]
+        opt_o.zero_grad()
+        m = lambda n, seed, off, pp, shape: _mask(vln, n, seed, off, pp, shape)
+        oe = host + 1                                  # encoder: (word + call) * 8 + site
+        ctx, h, c = O.encoder_forward(P["enc"], b["tokens"], b["lens"].tolist(), num_layers=1, bidirectional=False,
+                                      emb_mask=m(B * L * E, enc.dropout_seed, oe * 8 + 0, 0.5, (B, L, E)),
+                                      ctx_mask_drop=m(B * L * H, enc.dropout_seed, oe * 8 + 1, 0.5, (B, L, H)))
+        seq_mask = b["tokens"] == 0
+        a_prev, loss_o = a0_cpu.double(), 0.0
+        Pd = dict(P["dec"])
+        for t, s in enumerate(b["steps"]):
+            # decoder-side modules: word * 8 + (call index since the tick) * 16 + site
+            site = host * 8 + (t + 1) * 16
+            drop = {"mlp_prev": m(B * M, mlp_drop.dropout_seed, host * 8 + (2 * t + 1) * 16, 0.5, (B, M)),
+                    "mlp_cands": m(B * C * M, mlp_drop.dropout_seed, host * 8 + (2 * t + 2) * 16, 0.5, (B * C, M)),
+                    "pe": m(B * L * H, dec.position.dropout_seed, site, dec.position.p, (B, L, H)),
+                    "h1": m(B * H, dec.dropout_seed, site, 0.5, (B, H)), "pm": m(B * H, dec.dropout_seed, site + 1, 0.5, (B, H))}
+            (lo, po), (h, c), _, stats = O.monitor_step(Pd, a_prev, s["cand"].double(), h, c, ctx, seq_mask, s["cmask"], training=True, drop=drop)
+            for j, kk in ((0, "rm0"), (0, "rv0"), (2, "rm1"), (2, "rv1")):
+                Pd[f"proj_navigable_mlp.mlp.{j}.running_{'mean' if kk[1] == 'm' else 'var'}"] = stats[kk].detach()
+            start, cur = s["start"].double(), s["cur"].double()
+            tgt = (start - cur) / start                                                           # monitor.py:154-156
+            tgt = torch.where(cur <= 3.0, torch.ones_like(tgt), tgt)
+            tgt = torch.where(s["ended"], po.detach(), tgt)
+            loss_o = loss_o + O.monitor_mixed_loss(lo, s["target"], s["cmask"], po, tgt, t, 0.5)
+            a_prev = s["cand"][torch.arange(B), s["target"]].double()
+        for kk in run_keys:
+            P["dec"][kk] = Pd[kk]
+        loss_o.backward()
+        check(torch.tensor(losses[k]), loss_o.detach(), tol, f"self-monitor: loss of iteration {k} ({'eager' if k < n_eager else 'replay'})")
+        if k == 0:
+            for key in ("enc", "dec"):
+                gs = [q.grad for q in P[key].values() if q.requires_grad and q.grad is not None]
+                gmax = max(float(x.abs().max()) for x in gs)
+                for n, gg in grads0[key].items():
+                    r = P[key][n].grad if P[key][n].grad is not None else torch.zeros_like(P[key][n])
+                    check(gg, r, tol, f"self-monitor: iteration 0: grad[{key}.{n}]", floor=grad_floor(n, gmax))
+            sig = {key: {n: (q.grad.abs() >= 1e-2 * q.grad.abs().max()) for n, q in P[key].items() if q.requires_grad and q.grad is not None}
+                   for key in P}
+        opt_o.step()
+    # Parameters whose gradient is ZERO in exact arithmetic (a bias / beta in front of a train-mode BatchNorm: parity.EXACT_ZERO_GRADS)
+    # receive rounding noise as gradient, and Adam turns noise above its eps (1e-8; fp32 noise of these sums is ~1e-6, fp64's 1e-15)
+    # into full-size steps of random sign: mlp.0.bias / mlp.1.bias random-walk by lr per iteration in ANY fp32 implementation, with no
+    # effect on the outputs.  They are left out of the trajectory, and so is the second BatchNorm's running MEAN (= the batch mean of
+    # W y + b1: it follows b1's walk); its running variance and the first BatchNorm's statistics do not see them.
+    import parity
+    walkers = tuple(z for z in parity.EXACT_ZERO_GRADS)
+    assert int(final["dec"]["proj_navigable_mlp.mlp.0.num_batches_tracked"]) == 2 * T * (n_eager + n_replay)      # two updates per step
+    for kk in run_keys:
+        if kk.endswith("mlp.2.running_mean"):
+            continue
+        check(final["dec"][kk], P["dec"][kk], 1e-4 if not lp else 1e-2, f"self-monitor: {kk} after {n_eager + n_replay} iterations")
+    num = den = 0.0
+    errs, per = [], []
+    for key in ("enc", "dec"):
+        for n, q in P[key].items():
+            if not q.requires_grad or any(n == z or n.endswith("." + z) for z in walkers):
+                continue
+            d_ref, d_got = q.detach() - sd0[key][n], final[key][n] - sd0[key][n]
+            num += float(((d_got - d_ref) ** 2).sum()); den += float((d_ref ** 2).sum())
+            per.append((float(((d_got - d_ref) ** 2).sum()), float((d_ref ** 2).sum()), f"{key}.{n}"))
+            if n in sig[key] and bool(sig[key][n].any()):
+                errs.append(((d_got - d_ref)[sig[key][n]].abs() / d_ref.abs().max().clamp_min(1e-30)).flatten())
+    l2 = (num / max(den, 1e-300)) ** 0.5
+    errs = torch.cat(errs).sort().values
+    p99 = float(errs[int(0.99 * (errs.numel() - 1))])
+    print(f"self-monitor trajectory after {n_eager + n_replay} Adam updates ({dtype}): L2 error of the parameter change {l2:.2e}; 99th percentile over "
+          f"{errs.numel()} elements with a significant first gradient {p99:.2e}, max {float(errs[-1]):.2e}")
+    check(torch.tensor(l2), torch.tensor(0.0), 1.0, f"self-monitor trajectory L2 (recorded: {l2:.3e})", floor=1.0)
+    bound = MON_TRAJ[dtype]
+    assert l2 < bound["l2"] and p99 < bound["p99"], (l2, p99)
