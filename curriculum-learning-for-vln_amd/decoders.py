@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from . import functional as Fh
-from .monitor_step import FollowerStepFn, MonitorStepFn
+from .monitor_step import FollowerStepFn, MonitorStepFn, gated_ctx
 
 
 def _need_gpu(t, who):
@@ -137,6 +137,8 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
             core = FollowerStepFn if self.c_step else Fh.FollowerCoreFn      # one C call per direction / Python-driven launches
             if self._drop_base() is not None and not self.c_step:
                 raise _lib.VlnError("AttnDecoderLSTM: a DeviceClock needs the C-call step (c_step=True)")
+            if self.c_step:          # the rollout's context gradient accumulates in ONE buffer (monitor_step.gated_ctx)
+                ctx = gated_ctx(ctx)[0]
             logit, h_new, c_new, word_w, view_w = core.apply(
                 (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ()), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
@@ -434,6 +436,8 @@ class MonitorDecoder(nn.Module, _Seeded):
                 cfg = cfg + (self._drop_base(),)
             head = self.critic[0]
             core = MonitorStepFn if self.c_step else Fh.MonitorCoreFn       # one C call per direction / Python-driven launches
+            if self.c_step:          # the rollout's context gradient accumulates in ONE buffer (monitor_step.gated_ctx)
+                ctx = gated_ctx(ctx)[0]
             logit, progress, h_new, c_new, word_w, move_w = core.apply(
                 cfg, pos.pe[0, :ctx.shape[1]], ctx_mask, candidate_mask, prev_rep, cand_rep, h_0, c_0, ctx,
                 self.text_attn.linear_in.weight, self.visual_attn.linear_in_h.weight, self.visual_attn.linear_in_h.bias,

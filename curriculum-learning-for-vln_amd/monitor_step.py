@@ -17,6 +17,50 @@ from .functional import ROLLOUT_WGRADS, SHADOWS, _fused_lstm_weight, _gret, _gsi
 
 _p = ops._p
 
+# ---- the rollout's context gradient in ONE buffer (round 5) ----------------------------------------------------------------------
+# Every decoder step of a rollout attends the SAME encoder context, so autograd received T [B,L,H] gradients per rollout (21 MB each
+# at B 128 / L 80 / H 512) and summed them with T - 1 element-wise adds.  With the context passed through `gated_ctx` the steps'
+# backward calls accumulate into one buffer in place (the C steps' `dctx_accumulate`), hand autograd None, and the identity node
+# `runtime.CtxGate` -- whose backward runs once every step that consumed its output has run -- returns the buffer.
+_CTX_ENTRIES = {}
+
+
+def gated_ctx(ctx_t):
+    """-> (the tensor to hand to the step node, its runtime.CtxEntry or None when no gradient is wanted)."""
+    from .runtime import CtxEntry, CtxGate
+    if not (torch.is_grad_enabled() and ctx_t.requires_grad):
+        return ctx_t, None
+    k = id(ctx_t)
+    e = _CTX_ENTRIES.get(k)
+    if e is None or e.ref() is not ctx_t:
+        if len(_CTX_ENTRIES) > 16:
+            for kk in [kk for kk, x in _CTX_ENTRIES.items() if x.ref() is None]:
+                del _CTX_ENTRIES[kk]
+        e = _CTX_ENTRIES[k] = CtxEntry(ctx_t)
+    if e.gated is None:
+        e.gated = CtxGate.apply(e, ctx_t)
+        e.dctx = None
+        import weakref
+        e.gated._vln_ctx_entry = weakref.ref(e)          # how the step nodes find the rollout's accumulator
+        for a in ("_vln_lp", "_vln_born"):               # attributes the encoder hangs on its output (bf16 stream copy, arena stamp)
+            if hasattr(ctx_t, a):
+                setattr(e.gated, a, getattr(ctx_t, a))
+    return e.gated, e
+
+
+def _dctx_target(ctx, entry_ref, want, B, L, H, dev):
+    """(buffer the step's backward writes, accumulate flag, what the node returns to autograd for the context)."""
+    if not want:
+        return None, 0, None
+    e = entry_ref() if entry_ref is not None else None
+    if e is None:
+        t = torch.empty(B, L, H, dtype=torch.float32, device=dev)
+        return t, 0, t
+    first = e.dctx is None
+    if first:
+        e.dctx = ops.empty(B, L, H, dtype=torch.float32, device=dev)
+    return e.dctx, 0 if first else 1, None
+
 
 def _m8(mask):
     if mask.dtype == torch.bool and mask.is_contiguous():
@@ -34,6 +78,7 @@ class MonitorStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, pe, ctx_mask, cand_mask, prev_rep, cand_rep, h0, c0, ctxt, *params):
+        ctx_arg = ctxt
         training, dtype, p_pe, (seed_pe, off_pe), p_drop, seed, off_h1, off_mem = cfg[:8]
         W_tin, W_vh, b_vh, W_ih, W_hh, b_ih, b_hh, W_a, b_a, W_m, b_m, W_c, b_c = params
         lib = _lib.load()
@@ -104,6 +149,7 @@ class MonitorStepFn(torch.autograd.Function):
         if st:
             _lib.check(st, "vln_monitor_step_fwd")
         ctx.cfg = cfg
+        ctx.dentry = getattr(ctx_arg, "_vln_ctx_entry", None)          # weakref to the rollout's CtxEntry (gated_ctx), or None
         # the backward reads c1, prog and the two attention maps: their memory is kept alive HERE, and the caller gets fresh
         # aliases -- the returned objects carry this node as grad_fn, holding THEM on ctx would be a reference cycle
         ctx.pack = (d, w, io, hold, (m_ctx, m_cand), (prog, c1, word_w, move_w))
@@ -129,8 +175,9 @@ class MonitorStepFn(torch.autograd.Function):
         dprev = ops.empty(B, M, dtype=f32, device=dev)
         dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
         dcand = torch.empty(B, Cn, M, dtype=f32, device=dev) if ctx.needs_input_grad[5] else None
-        dctx = torch.empty(B, L, H, dtype=f32, device=dev) if ctx.needs_input_grad[8] else None
-        g.dprev_rep, g.dcand_rep, g.dh0, g.dc0, g.dctx = dprev.data_ptr(), _p(dcand), dh0.data_ptr(), dc0.data_ptr(), _p(dctx)
+        dctx_buf, dctx_acc, dctx = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[8], B, L, H, dev)
+        g.dprev_rep, g.dcand_rep, g.dh0, g.dc0, g.dctx = dprev.data_ptr(), _p(dcand), dh0.data_ptr(), dc0.data_ptr(), _p(dctx_buf)
+        g.dctx_accumulate = dctx_acc
         sinks = [_gsink(p) for p in params]
         names = ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")
         for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
@@ -165,6 +212,7 @@ class FollowerStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, ctx_mask, img, a_prev, cands, h0, c0, ctxt, *params):
+        ctx_arg = ctxt
         training, dtype, p_drop, seed, off = cfg[:5]
         W_h, b_h, W_v, b_v, W_ih, W_hh, b_ih, b_hh, W_tin, W_tout, W_act, b_act, W_hid, b_hid, w_out, b_out = params
         lib = _lib.load()
@@ -228,6 +276,7 @@ class FollowerStepFn(torch.autograd.Function):
         if st:
             _lib.check(st, "vln_follower_step_fwd")
         ctx.cfg = cfg
+        ctx.dentry = getattr(ctx_arg, "_vln_ctx_entry", None)
         # the backward reads both attention maps: memory kept alive here, fresh aliases returned (no ctx <-> output cycle)
         ctx.pack = (d, w, io, hold, m_ctx, (word_w, view_w))
         ctx.save_for_backward(flat, img, cands, a_prev, h0, c0, ctxt, *params)
@@ -250,8 +299,9 @@ class FollowerStepFn(torch.autograd.Function):
         g.dlogit, g.dh1, g.dc1, g.dww_ext, g.dvw_ext = (_p(t) for t in ups)
         da = ops.empty(B, A, dtype=f32, device=dev) if ctx.needs_input_grad[3] else None
         dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
-        dctx = torch.empty(B, L, H, dtype=f32, device=dev) if ctx.needs_input_grad[7] else None
-        g.da_prev, g.dh0, g.dc0, g.dctx = _p(da), dh0.data_ptr(), dc0.data_ptr(), _p(dctx)
+        dctx_buf, dctx_acc, dctx = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[7], B, L, H, dev)
+        g.da_prev, g.dh0, g.dc0, g.dctx = _p(da), dh0.data_ptr(), dc0.data_ptr(), _p(dctx_buf)
+        g.dctx_accumulate = dctx_acc
         sinks = [_gsink(p) for p in params]
         names = ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact", "g_whid", "g_bhid",
                  "g_wout", "g_bout")
