@@ -165,7 +165,8 @@ class BnMlpLayer(C.Structure):
 
 class BnMlp(C.Structure):
     _fields_ = [("R", i32), ("D0", i32), ("nl", i32), ("wtype", i32), ("training", i32), ("R1", i32), ("eps", f32), ("momentum", f32),
-                ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr), ("offset_base_dev", ptr)]
+                ("bn0", BnAffine), ("layer", BnMlpLayer * BN_MLP_MAX_LAYERS), ("row_zero", ptr), ("offset_base_dev", ptr),
+                ("x2", ptr), ("ldx2", i64)]
 
 
 class BnMlpGradLayer(C.Structure):
@@ -293,6 +294,7 @@ SIGNATURES = {
     "vln_follower_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
+    "vln_monitor_ws_floats": (i64, [ptr]),
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),
@@ -312,7 +314,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 15
+EXPECTED_ABI = 16
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

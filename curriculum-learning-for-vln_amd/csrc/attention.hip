@@ -16,12 +16,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---------------------------------------------------------------------------
 template <typename TC>
 __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec vec, float* dots,
-                                                       long rows, int S, int D, int vec_ok) {
+                                                       long rows, int S, int D, int vec_ok, float* vec_out, long ldvo) {
   constexpr int V = Elt<TC>::kVec;   // elements per 16-byte access
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const int b = (int)(r / S);
     const TC* c = ctx + r * (long)D;
+    const bool wb = vec_out && (r - (long)b * S) == 0;     // the row's first wave writes the summed vector back (nullable)
     float acc = 0.f;
     if (vec_ok) {
       for (int d = lane * V; d < D; d += 64 * V) {
@@ -30,11 +31,16 @@ __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec ve
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           const float4 t = vec.at4(b, d + j);
+          if (wb) *reinterpret_cast<float4*>(vec_out + (long)b * ldvo + d + j) = t;
           acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
         }
       }
     } else {
-      for (int d = lane; d < D; d += 64) acc += Elt<TC>::ld(c + d) * vec.at(b, d);
+      for (int d = lane; d < D; d += 64) {
+        const float t = vec.at(b, d);
+        if (wb) vec_out[(long)b * ldvo + d] = t;
+        acc += Elt<TC>::ld(c + d) * t;
+      }
     }
     acc = wave_sum(acc);
     if (lane == 0) dots[r] = acc;
@@ -45,19 +51,20 @@ int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long 
              int D) {
   return attn_dot_sv(st, ctx, ctype, plain_vec(vec, ldv), dots, B, S, D);
 }
-int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D) {
+int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D, float* vec_out, long ldvo) {
   if (B <= 0 || S <= 0 || D <= 0) { set_error("attn_dot: bad dims"); return VLN_ERR_ARG; }
   const long ldv = vec.ld;
   long rows = (long)B * S;
   int blocks = (int)((rows + 3) / 4);
   if (blocks > 8192) blocks = 8192;
   const int V = (ctype == W_BF16) ? 8 : 4;
-  int vec_ok = aligned16(ctx) && aligned16(vec.p) && (D % V == 0) && (ldv % 4 == 0) && (vec.stride % 4 == 0);
+  int vec_ok = aligned16(ctx) && aligned16(vec.p) && (D % V == 0) && (ldv % 4 == 0) && (vec.stride % 4 == 0) && aligned16(vec.bias) &&
+               (!vec_out || (aligned16(vec_out) && (ldvo % 4 == 0)));
   const double bytes = (double)rows * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 4.0 * rows;
   if (ctype == W_BF16)
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, dots, rows, S, D, vec_ok, vec_out, ldvo);
   else
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, dots, rows, S, D, vec_ok);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, dots, rows, S, D, vec_ok, vec_out, ldvo);
   VLN_CHECK_LAUNCH("attn_dot");
   return VLN_OK;
 }
@@ -533,7 +540,7 @@ int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, fl
   if (attn_fused_try(st, ctype, a, B, false)) { VLN_CHECK_LAUNCH("attn_fused_fwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_fwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
   if (vec_out) {                        // the caller wants the finished vector: sum the slabs into it first
-    int r0 = reduce_epilogue(st, vec.p, vec.n, vec.stride, vec.ld, vec_out, ldvo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
+    int r0 = reduce_epilogue(st, vec.p, vec.n, vec.stride, vec.ld, vec_out, ldvo, B, D, vec.bias, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
     if (r0 != VLN_OK) return r0;
     vec = plain_vec(vec_out, ldvo);
   }
@@ -556,7 +563,7 @@ int attn_bwd_rows_sv(hipStream_t st, const void* ctx, int ctype, const float* at
   if (attn_fused_try(st, ctype, a, B, true)) { VLN_CHECK_LAUNCH("attn_fused_bwd"); return VLN_OK; }
   if (!dots_scratch) { set_error("attn_bwd_rows: shape needs the two-kernel path and no scratch was given"); return VLN_ERR_ARG; }
   if (dwc_out) {
-    int r0 = reduce_epilogue(st, dwc.p, dwc.n, dwc.stride, dwc.ld, dwc_out, lddo, B, D, nullptr, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
+    int r0 = reduce_epilogue(st, dwc.p, dwc.n, dwc.stride, dwc.ld, dwc_out, lddo, B, D, dwc.bias, ACT_NONE, nullptr, 0, DropSpec{0, 0, 0.f});
     if (r0 != VLN_OK) return r0;
     dwc = plain_vec(dwc_out, lddo);
   }

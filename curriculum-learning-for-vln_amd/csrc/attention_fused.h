@@ -220,7 +220,7 @@ static bool attn_fused_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
   if (g_tunable[4]) return false;                               // tunable[4] = 1 forces the two-kernel path (A/B, tests)
   const int V = (ctype == W_BF16) ? 8 : 4;
   const int S = a.S, D = a.D;
-  if (D % V != 0 || !aligned16(a.ctx) || !aligned16(a.vec.p) || !aligned16(a.out) || (a.vec.ld & 3) || (a.vec.stride & 3) ||
+  if (D % V != 0 || !aligned16(a.ctx) || !aligned16(a.vec.p) || !aligned16(a.out) || (a.vec.ld & 3) || (a.vec.stride & 3) || !aligned16(a.vec.bias) ||
       (a.ldo & 3) || (D & 3) || (a.vec_out && (!aligned16(a.vec_out) || (a.ldvo & 3)))) return false;
   const int nseg = D / V;
   const int sl = (nseg + 63) / 64, rw = (S + kFusedWaves - 1) / kFusedWaves;

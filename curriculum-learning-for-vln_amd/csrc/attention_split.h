@@ -268,7 +268,7 @@ static bool attn_split_try(hipStream_t st, int ctype, const AttnFusedArgs& a, in
   const int V = (ctype == W_BF16) ? 8 : 4;
   const int S = a.S, D = a.D;
   if (S > kSplitSMax || D % (V * kSplitNS) != 0 || B * kSplitNS > cus || sync_bytes < attn_split_sync_bytes(B) || !aligned16(sync) ||
-      !aligned16(a.ctx) || !aligned16(a.vec.p) || !aligned16(a.out) || (a.vec.ld & 3) || (a.vec.stride & 3) || (a.ldo & 3) ||
+      !aligned16(a.ctx) || !aligned16(a.vec.p) || !aligned16(a.out) || (a.vec.ld & 3) || (a.vec.stride & 3) || !aligned16(a.vec.bias) || (a.ldo & 3) ||
       (((long)D / kSplitNS) & 3) || (a.vec_out && (!aligned16(a.vec_out) || (a.ldvo & 3)))) return false;
   unsigned* sticky = sticky_dev_word();
   if (!sticky) return false;

@@ -20,6 +20,7 @@ int check_mlp(const vln_bn_mlp* m) {
   if (!m || m->R <= 0 || m->D0 <= 0 || m->nl <= 0 || m->nl > VLN_BN_MLP_MAX_LAYERS || (m->D0 & 3) || m->R1 < 0 || m->R1 >= m->R) { set_error("bn_mlp: bad dims"); return VLN_ERR_ARG; }
   for (int i = 0; i < m->nl; ++i)
     if (m->layer[i].out <= 0 || (m->layer[i].out & 3) || !m->layer[i].w || !m->layer[i].w_t) { set_error("bn_mlp: bad layer %d", i); return VLN_ERR_ARG; }
+  if (m->x2 && m->R1 <= 0) { set_error("bn_mlp: x2 (the second batch's own array) needs R1 > 0"); return VLN_ERR_ARG; }
   return VLN_OK;
 }
 
@@ -91,7 +92,7 @@ extern "C" int vln_bn_mlp_fwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
   const int R1 = m->R1;
   RUN(bn_fwd_seg(x, ldx, y, m->D0, m->bn0.gamma, m->bn0.beta, m->bn0.run_mean, m->bn0.run_var, tr ? m->bn0.nbt : nullptr,
                  tr ? st0 : nullptr, tr ? st0 + m->D0 : nullptr, R, R1, 2L * m->D0, m->D0, m->eps, m->momentum, tr, 0, 0, 0, 0, 0.f, nullptr,
-                 ws, ws_floats, s));
+                 ws, ws_floats, s, m->x2, m->ldx2));
   int in = m->D0;
   for (int i = 0; i < m->nl; ++i) {
     const vln_bn_mlp_layer& l = m->layer[i];
@@ -122,6 +123,7 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     set_error("vln_bn_mlp_bwd: null pointer or scratch too small");
     return VLN_ERR_ARG;
   }
+  if (m->x2 && dx) { set_error("vln_bn_mlp_bwd: an input gradient of the two-array form is not provided (pass the batches as one array)"); return VLN_ERR_ARG; }
   DropBaseScope drop_scope(m->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const SavedLayout L = saved_layout(m);
@@ -167,6 +169,7 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
   }
   const float* s0 = saved + L.s0;
   RUN(bn_bwd_seg(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
-                 g->g_gamma0, g->g_beta0, R, m->R1, 2L * m->D0, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s));
+                 g->g_gamma0, g->g_beta0, R, m->R1, 2L * m->D0, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s,
+                 m->x2, m->ldx2));
   return VLN_OK;
 }

@@ -160,6 +160,7 @@ __host__ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint64_t
 // product can be split over all 256 CUs without a reduce launch in the dependent chain (n == 1: a plain matrix).
 struct SlabVec {
   const float* p; long ld; int n; long stride;
+  const float* bias = nullptr;     // nullable: a per-column vector added to the sum (a Linear's bias that no reduce launch applied)
   // Partials are fetched four at a time (independent loads in flight, no branch between them) and added in slab order.
   __device__ __forceinline__ float at(long r, long c) const {
     const float* q = p + r * ld + c;
@@ -170,6 +171,7 @@ struct SlabVec {
       v += t0; v += t1; v += t2; v += t3;
     }
     for (; s < n; ++s) v += q[(long)s * stride];
+    if (bias) v += bias[c];
     return v;
   }
   __device__ __forceinline__ float4 at4(long r, long c) const {      // 16-byte aligned column group
@@ -183,9 +185,10 @@ struct SlabVec {
       add(v, t0); add(v, t1); add(v, t2); add(v, t3);
     }
     for (; s < n; ++s) add(v, ld4(s));
+    if (bias) add(v, *reinterpret_cast<const float4*>(bias + c));
     return v;
   }
-  __host__ __device__ SlabVec shifted(long cols) const { return SlabVec{p + cols, ld, n, stride}; }
+  __host__ __device__ SlabVec shifted(long cols) const { return SlabVec{p + cols, ld, n, stride, bias ? bias + cols : nullptr}; }
 };
 static inline SlabVec plain_vec(const float* p, long ld) { return SlabVec{p, ld, 1, 0}; }
 

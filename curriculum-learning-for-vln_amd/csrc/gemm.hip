@@ -100,6 +100,34 @@ int gemm_nt_slabs(int M, int N, int K, int wtype, long ws_floats) {
   return gemm_nt_split((N + 63) / 64, (M + 63) / 64, (K + BK - 1) / BK, M, N, true, ws_floats, true, nullptr);
 }
 
+// slabs the PLAIN call gemm_nt(..., nsplit_out = nullptr) would reduce with its own launch (1: it finishes in the product's launch)
+int gemm_nt_plain_slabs(int M, int N, int K, int wtype, long ws_floats) {
+  if (n16_applies(M, N, K, wtype)) return 1;
+  const int BK = (wtype == W_F32) ? 32 : 64;
+  return gemm_nt_split((N + 63) / 64, (M + 63) / 64, (K + BK - 1) / BK, M, N, true, ws_floats, false, nullptr);
+}
+// A product whose CONSUMER sums the split-K slabs (SlabVec, bias included): when the plain call would need a reduce launch the
+// slabs are left in the caller's bump-allocated area (several products' slabs live at once) -- same split, same bits as the plain
+// call + reduce_epilogue; otherwise the plain call writes Y and *out is that matrix.
+int gemm_nt_to_consumer(hipStream_t st, SlabArea& ar, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
+                        int M, int N, int K, const float* bias, SlabVec* out) {
+  if (!out || !ar.base) { set_error("gemm_nt_to_consumer: null pointer"); return VLN_ERR_ARG; }
+  const long per = (long)M * N;
+  if (g_tunable[9] || ar.left < per || gemm_nt_plain_slabs(M, N, K, wtype, ar.left) <= 1) {      // tunable[9] = 1: always the plain call (A/B)
+    if (!Y) { set_error("gemm_nt_to_consumer: the product is not split and no output matrix was given"); return VLN_ERR_ARG; }
+    const int r = gemm_nt(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, ACT_NONE, ar.base, ar.left, nullptr);
+    *out = plain_vec(Y, ldy);
+    return r;
+  }
+  int n = 1;
+  const int r = gemm_nt(st, X, ldx, W, wtype, ldw, nullptr, 0, M, N, K, nullptr, ACT_NONE, ar.base, ar.left, &n);
+  if (r != VLN_OK) return r;
+  *out = SlabVec{ar.base, (long)N, n, per, bias};
+  const long used = ((long)n * per + 63) & ~63L;
+  ar.base += used; ar.left -= used;
+  return VLN_OK;
+}
+
 // Y = act(X W^T + bias), Y2 = Y * dropout (optional): one launch for narrow outputs, else split-K slabs + reduce
 int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
                   int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop, float* ws, long ws_floats) {

@@ -82,6 +82,24 @@ extern "C" int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d) {
   return n;
 }
 
+// floats of the step's workspace (vln_monitor_step.ws): the backward keeps the slabs of its five skinny products live at once
+// (gemm_nt_to_consumer); a smaller workspace still works -- a product that does not fit is reduced by its own launch.
+extern "C" int64_t vln_monitor_ws_floats(const vln_monitor_dims* d) {
+  if (check_monitor_dims(d) != VLN_OK) return -1;
+  const int B = d->B, H = d->H, M = d->M, XK = 2 * M + 2 * H;
+  const int nk[5][2] = {{H + M, H}, {2 * H, M}, {XK, 4 * H}, {H, M}, {H, H}};
+  long n = 0;
+  for (int i = 0; i < 5; ++i) {
+    int most = 1;
+    for (int wt : {(int)W_F32, (int)W_BF16, (int)W_F32S}) {
+      const int k = gemm_nt_plain_slabs(B, nk[i][0], nk[i][1], wt, 1L << 40);
+      if (k > most) most = k;
+    }
+    n += ((long)most * B * nk[i][0] + 63) & ~63L;
+  }
+  return n < (1L << 22) ? (1L << 22) : n;
+}
+
 extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w, vln_monitor_step* io, vln_stream_t s) {
   RUN(check_monitor_dims(d));
   if (!w || !io || !io->prev_rep || !io->cand_rep || !io->h0 || !io->c0 || !io->ctx || !io->ctx_mask || !io->cand_mask || !io->ws) {
@@ -103,12 +121,21 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     j.src[2] = io->h0; j.lds[2] = H; j.dst[2] = io->hm; j.ldd[2] = H + M; j.cols[2] = H;
     RUN(copy_blocks(st, j));
   }
+  // The products of the step go to consumers that sum the split-K slabs themselves (gemm_nt_to_consumer: no reduce launch between
+  // a product and its reader; the reader writes the summed vector back where the backward wants it).
+  SlabArea ar{io->ws, (long)io->ws_floats};
+  const auto area_reset = [&]() { ar = SlabArea{io->ws, (long)io->ws_floats}; };
+  SlabVec sv;
   // (3) text attention over the positioned context, weighted context straight into its xcat block
-  RUN(gemm_nt(st, io->h0, H, w->w_tin, wt(0), H, io->tq, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_fwd_rows(st, io->pctx, W_F32, io->tq, H, io->ctx_mask, io->word_w, io->xcat + 2 * M, XK, io->dots, B, L, H));
+  RUN(gemm_nt_to_consumer(st, ar, io->h0, H, w->w_tin, wt(0), H, io->tq, H, B, H, H, nullptr, &sv));
+  RUN(attn_fwd_rows_sv(st, io->pctx, W_F32, sv, sv.p != io->tq ? io->tq : nullptr, H, io->ctx_mask, io->word_w, io->xcat + 2 * M, XK,
+                       io->dots, B, L, H));
+  area_reset();
   // (4) attention over the projected candidates (padded slots masked)
-  RUN(gemm_nt(st, io->h0, H, w->w_vh, wt(1), H, io->vq, M, B, M, H, w->b_vh, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_fwd_rows(st, io->cand_rep, W_F32, io->vq, M, io->cand_mask, io->move_w, io->xcat + M, XK, io->dots, B, C, M));
+  RUN(gemm_nt_to_consumer(st, ar, io->h0, H, w->w_vh, wt(1), H, io->vq, M, B, M, H, w->b_vh, &sv));
+  RUN(attn_fwd_rows_sv(st, io->cand_rep, W_F32, sv, sv.p != io->vq ? io->vq : nullptr, M, io->cand_mask, io->move_w, io->xcat + M, XK, io->dots,
+                       B, C, M));
+  area_reset();
   // (5) LSTM cell on [prev_rep | moves | words | h0]; drop(h1) lands in its tcat block
   // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
   int gate_slabs = 1;
@@ -129,11 +156,16 @@ extern "C" int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor
     RUN(copy_blocks(st, j));
   }
   // (6) action logits
-  RUN(gemm_nt(st, io->tcat, 2 * H, w->w_a, wt(3), 2 * H, io->aq, M, B, M, 2 * H, w->b_a, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_dot(st, io->cand_rep, W_F32, io->aq, M, io->logit, B, C, M));
+  area_reset();
+  RUN(gemm_nt_to_consumer(st, ar, io->tcat, 2 * H, w->w_a, wt(3), 2 * H, io->aq, M, B, M, 2 * H, w->b_a, &sv));
+  RUN(attn_dot_sv(st, io->cand_rep, W_F32, sv, io->logit, B, C, M, sv.p != io->aq ? io->aq : nullptr, M));
   // (7) progress monitor
-  RUN(gemm_nt(st, io->hm, H + M, w->w_m, wt(4), H + M, io->mg, H, B, H, H + M, w->b_m, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(vln_monitor_head_fwd(io->mg, io->c1, io->word_w, w->w_c, w->b_c, io->mem, io->prog, B, L, H, io->seed, io->off_mem, io->p_drop, s));
+  area_reset();
+  RUN(gemm_nt_to_consumer(st, ar, io->hm, H + M, w->w_m, wt(4), H + M, io->mg, H, B, H, H + M, w->b_m, &sv));
+  if (sv.p != io->mg)
+    RUN(monitor_head_fwd_sv(st, sv, io->mg, io->c1, io->word_w, w->w_c, w->b_c, io->mem, io->prog, B, L, H, io->seed, io->off_mem, io->p_drop));
+  else
+    RUN(vln_monitor_head_fwd(io->mg, io->c1, io->word_w, w->w_c, w->b_c, io->mem, io->prog, B, L, H, io->seed, io->off_mem, io->p_drop, s));
   return VLN_OK;
 }
 
@@ -156,25 +188,29 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   // progress head (policy.py:126-130)
   RUN(vln_monitor_head_bwd(io->mg, io->c1, io->word_w, w->w_c, io->mem, io->prog, g->dprog, g->dc1, g->dww_ext, dmg, dc1_t, dww, Z,
                            dpre, B, L, H, io->seed, io->off_mem, io->p_drop, s));
-  RUN(gemm_nt(st, dmg, H, w->w_m_t, wt(4), H, dhm, H + M, B, H + M, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> h0 | moves
+  // The five skinny products of the backward stay in split-K slabs inside the workspace (bump-allocated: all five are live until
+  // the last sum) and their readers -- the cell's pointwise backward and the two add_n launches -- sum the slabs themselves.
+  SlabArea ar{io->ws, (long)io->ws_floats};
+  SlabVec s_dhm, s_dtcat, s_dxcat, s_dh0v, s_dh0t;
+  RUN(gemm_nt_to_consumer(st, ar, dmg, H, w->w_m_t, wt(4), H, dhm, H + M, B, H + M, H, nullptr, &s_dhm));   // -> h0 | moves
   // action logits (policy.py:108-117): logit = cand_rep . aq
   const float* dlogit = g->dlogit;
   if (!dlogit) { RUN(fill_f32(st, zlogit, (long)B * C, 0.f)); dlogit = zlogit; }
   RUN(rows_wsum(st, io->cand_rep, W_F32, dlogit, daq, M, B, C, M));
-  RUN(gemm_nt(st, daq, M, w->w_a_t, wt(3), M, dtcat, 2 * H, B, 2 * H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));  // -> words | drop(h1)
+  RUN(gemm_nt_to_consumer(st, ar, daq, M, w->w_a_t, wt(3), M, dtcat, 2 * H, B, 2 * H, M, nullptr, &s_dtcat));  // -> words | drop(h1)
   // LSTM cell
   {
     LstmPwBwd a{};
-    a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dtcat + H, 2 * H); a.dh1_b2 = plain_vec(nullptr, 0);
+    a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = s_dtcat.shifted(H); a.dh1_b2 = plain_vec(nullptr, 0);
     a.drop = tls_drop(io->seed, io->off_h1, io->p_drop); a.dc1 = dc1_t; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));
   }
-  RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt(2), 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> prev | moves | words | h0
+  RUN(gemm_nt_to_consumer(st, ar, dg, 4 * H, w->w_cat_t, wt(2), 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, &s_dxcat));   // -> prev | moves | words | h0
   {   // d moves and d words: two sums of the same producers, one launch
-    const AddNJob aj[2] = {{dmoves, M, B, M, 2, {dhm + H, dxcat + M, nullptr, nullptr}, {H + M, XK, 0, 0}},
-                           {dwords, H, B, H, 2, {dtcat, dxcat + 2 * M, nullptr, nullptr}, {2 * H, XK, 0, 0}}};
-    RUN(add_n_multi(st, aj, 2));
+    const AddNSvJob aj[2] = {{dmoves, M, B, M, 2, {s_dhm.shifted(H), s_dxcat.shifted(M), SlabVec{}, SlabVec{}}},
+                             {dwords, H, B, H, 2, {s_dtcat, s_dxcat.shifted(2 * M), SlabVec{}, SlabVec{}}}};
+    RUN(add_n_sv_multi(st, aj, 2));
   }
   // candidates: d cand_rep = move_w (x) dmoves + dl_v (x) vq + dlogit (x) aq
   RUN(attn_bwd_rows(st, io->cand_rep, W_F32, io->move_w, dmoves, M, g->dmw_ext, dvq, M, dl_v, io->dots, B, C, M));
@@ -185,7 +221,7 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     const float* qq[2] = {io->vq, nullptr};
     RUN(attn_dctx_deferred(st, al, dl, gg, M, qq, M, 2, g->dcand_rep, B, C, M, 0));
   }
-  RUN(gemm_nt(st, dvq, M, w->w_vh_t, wt(1), M, dh0_v, H, B, H, M, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt_to_consumer(st, ar, dvq, M, w->w_vh_t, wt(1), M, dh0_v, H, B, H, M, nullptr, &s_dh0v));
   // words: d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's pe-dropout mask
   RUN(attn_bwd_rows(st, io->pctx, W_F32, io->word_w, dwords, H, dww, dtq, H, dl_t, io->dots, B, L, H));
   if (g->dctx) {
@@ -197,11 +233,11 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
     const float dp[1] = {io->p_pe};
     RUN(attn_dctx_deferred(st, al, dl, gg, H, qq, H, 1, g->dctx, B, L, H, g->dctx_accumulate, ds, dof, dp));
   }
-  RUN(gemm_nt(st, dtq, H, w->w_tin_t, wt(0), H, dh0_t, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  RUN(gemm_nt_to_consumer(st, ar, dtq, H, w->w_tin_t, wt(0), H, dh0_t, H, B, H, H, nullptr, &s_dh0t));
   {   // d h0 (four contributions) and d prev_rep (a column block of d xcat), one launch
-    const AddNJob aj[2] = {{g->dh0, H, B, H, 4, {dhm, dxcat + 2 * M + H, dh0_v, dh0_t}, {H + M, XK, H, H}},
-                           {g->dprev_rep, M, B, M, 1, {dxcat, nullptr, nullptr, nullptr}, {XK, 0, 0, 0}}};
-    RUN(add_n_multi(st, aj, 2));
+    const AddNSvJob aj[2] = {{g->dh0, H, B, H, 4, {s_dhm, s_dxcat.shifted(2 * M + H), s_dh0v, s_dh0t}},
+                             {g->dprev_rep, M, B, M, 1, {s_dxcat, SlabVec{}, SlabVec{}, SlabVec{}}}};
+    RUN(add_n_sv_multi(st, aj, 2));
   }
   // parameter gradients: six products over the same B rows -> one grouped launch; biases and the head -> another
   {

@@ -542,6 +542,7 @@ struct BnArgs {
   // (exactly what a second call would do), keeps its saved statistics `stat2` floats after segment 0's, and the running
   // statistics take both updates in order (num_batches_tracked += 2).  R1 == 0: one segment.
   int R1; long stat2; DropSpec drop2;
+  const float* x2; long ldx2;       // nullable (two segments): segment 1's rows are x2 + (r - R1) * ldx2 -- the two batches read in place
 };
 // chunk -> (segment, first row, rows in the chunk, rows of the segment, the segment's first chunk and chunk count)
 struct BnSegChunk { int seg, r0, n, seg_rows, seg_r0, first, count; };
@@ -638,6 +639,7 @@ struct BnBwdArgs {
   int R, D; float eps; int training, relu, accumulate;
   DropSpec drop; const unsigned char* row_zero;     // as in the forward
   int R1; long stat2; DropSpec drop2;               // two segments, as in the forward (row-chunked form only)
+  const float* x2; long ldx2;                       // as in the forward
 };
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
   __shared__ float4 part[64][4];
@@ -731,6 +733,10 @@ __device__ __forceinline__ BnSegChunk bn_chunk(int ch, int R, int R1) {
 }
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+// row r of the input: segment 1 may live in its own array (BnArgs.x2)
+__device__ __forceinline__ const float* bn_xrow(const float* x, long ldx, const float* x2, long ldx2, const BnSegChunk& sc, int r) {
+  return (sc.seg && x2) ? x2 + (long)(r - sc.seg_r0) * ldx2 : x + (long)r * ldx;
+}
 
 __global__ __launch_bounds__(256) void bn_fwd_stats_kernel(BnArgs a, BnChunkWs w) {
   __shared__ float4 part[64][4];
@@ -744,8 +750,8 @@ __global__ __launch_bounds__(256) void bn_fwd_stats_kernel(BnArgs a, BnChunkWs w
   const int ra = r0 + rl, rb = r0 + 64 + rl;
   const bool oka = c_ok && rl < n, okb = c_ok && 64 + rl < n;
   const float4 z = f4(0.f);
-  const float4 ta = oka ? *reinterpret_cast<const float4*>(a.x + (long)ra * a.ldx + cc) : z;
-  const float4 tb = okb ? *reinterpret_cast<const float4*>(a.x + (long)rb * a.ldx + cc) : z;
+  const float4 ta = oka ? *reinterpret_cast<const float4*>(bn_xrow(a.x, a.ldx, a.x2, a.ldx2, sc, ra) + cc) : z;
+  const float4 tb = okb ? *reinterpret_cast<const float4*>(bn_xrow(a.x, a.ldx, a.x2, a.ldx2, sc, rb) + cc) : z;
   float4 s = make_float4(ta.x + tb.x, ta.y + tb.y, ta.z + tb.z, ta.w + tb.w);
   s = bn_strip_sum(s, part, rl, cg);
   const float inv = 1.f / (float)n;
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(BnArgs a, BnChunkWs w
     const int r = r0 + k * 64 + rl;
     if (k * 64 + rl >= sc.n) continue;
     const int rs = r - sc.seg_r0;                     // row within its segment: what a call on the segment alone would index
-    const float4 t = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + c);
+    const float4 t = *reinterpret_cast<const float4*>(bn_xrow(a.x, a.ldx, a.x2, a.ldx2, sc, r) + c);
     float4 o = make_float4((t.x - mean.x) * rstd.x * g.x + bt.x, (t.y - mean.y) * rstd.y * g.y + bt.y,
                            (t.z - mean.z) * rstd.z * g.z + bt.z, (t.w - mean.w) * rstd.w * g.w + bt.w);
     if (dsp.p > 0.f) {
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(BnBwdArgs a, BnChunkW
         d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f; d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
       }
       dv[k] = d;
-      const float4 xv = *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + cc);
+      const float4 xv = *reinterpret_cast<const float4*>(bn_xrow(a.x, a.ldx, a.x2, a.ldx2, sc, r) + cc);
       xh[k] = make_float4((xv.x - mean.x) * rstd.x, (xv.y - mean.y) * rstd.y, (xv.z - mean.z) * rstd.z, (xv.w - mean.w) * rstd.w);
     }
   }
@@ -1120,6 +1126,7 @@ struct MonHeadArgs {
   // backward
   const float* dprog; const float* dc1_ext; const float* dww_ext;      // [B], [B,H] nullable, [B,L] nullable
   float* dmg; float* dc1; float* dww; float* Z; float* dpre;           // [B,H], [B,H], [B,L], [B,L+H] (rows dpre*[word_w|mem]), [B]
+  SlabVec mgs; float* mg_out;      // forward, mgs.p != null: the gate product still in split-K slabs (+ bias); summed here and written to mg_out
 };
 __global__ __launch_bounds__(256) void monitor_head_fwd_kernel(MonHeadArgs a) {
   __shared__ float part[4];
@@ -1127,7 +1134,10 @@ __global__ __launch_bounds__(256) void monitor_head_fwd_kernel(MonHeadArgs a) {
   float acc = 0.f;
   for (int j = threadIdx.x; j < H; j += 256) {
     const long i = (long)b * H + j;
-    const float m = sigmoidf_(a.mg[i]) * tanhf(a.c1[i]) * dropout_scale1(a.dr.seed, a.dr.off(), (uint32_t)i, a.dr.p);
+    float gate;
+    if (a.mgs.p) { gate = a.mgs.at(b, j); a.mg_out[i] = gate; }
+    else gate = a.mg[i];
+    const float m = sigmoidf_(gate) * tanhf(a.c1[i]) * dropout_scale1(a.dr.seed, a.dr.off(), (uint32_t)i, a.dr.p);
     a.mem[i] = m;
     acc += a.wc[L + j] * m;
   }
@@ -1171,6 +1181,31 @@ __global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a) { add_n_body(a);
 // up to 4 independent sums in ONE launch (blockIdx.y = the job; a one-source job is a strided copy): same bits as 4 launches
 struct AddNMulti { AddNArgs j[4]; };
 __global__ __launch_bounds__(256) void add_n_multi_kernel(AddNMulti m) { add_n_body(m.j[blockIdx.y]); }
+// The same sums with sources that still lie in split-K slabs (SlabVec): each source's slabs are added in slab order first, then the
+// sources in their order -- the bits of "reduce each product, then add_n" without the reduce launches.
+struct AddNSvArgs { SlabVec src[4]; int n; float* out; long ldo; int rows, cols, vec; };
+struct AddNSvMulti { AddNSvArgs j[4]; };
+__global__ __launch_bounds__(256) void add_n_sv_multi_kernel(AddNSvMulti m) {
+  const AddNSvArgs& a = m.j[blockIdx.y];
+  if (a.vec) {
+    const int c4 = a.cols >> 2;
+    const long total = (long)a.rows * c4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+      const long r = e / c4, c = (e % c4) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < a.n; ++i) { const float4 t = a.src[i].at4(r, c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = v;
+    }
+    return;
+  }
+  const long total = (long)a.rows * a.cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / a.cols, c = e % a.cols;
+    float v = 0.f;
+    for (int i = 0; i < a.n; ++i) v += a.src[i].at(r, c);
+    a.out[r * a.ldo + c] = v;
+  }
+}
 }  // namespace vln
 int vln::add_n_multi(hipStream_t st, const AddNJob* jobs, int n) {
   if (!jobs || n < 1 || n > 4) { set_error("add_n_multi: 1..4 jobs"); return VLN_ERR_ARG; }
@@ -1192,6 +1227,32 @@ int vln::add_n_multi(hipStream_t st, const AddNJob* jobs, int n) {
   return VLN_OK;
 }
 
+int vln::add_n_sv_multi(hipStream_t st, const AddNSvJob* jobs, int n) {
+  if (!jobs || n < 1 || n > 4) { set_error("add_n_sv_multi: 1..4 jobs"); return VLN_ERR_ARG; }
+  AddNSvMulti m{};
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const AddNSvJob& q = jobs[i];
+    if (!q.out || q.rows <= 0 || q.cols <= 0 || q.n < 1 || q.n > 4) { set_error("add_n_sv_multi: bad job %d", i); return VLN_ERR_ARG; }
+    AddNSvArgs& a = m.j[i];
+    bool vec = (q.cols & 3) == 0 && (q.ldo & 3) == 0 && al16p(q.out);
+    for (int k = 0; k < q.n; ++k) {
+      const SlabVec& v = q.src[k];
+      if (!v.p || v.n < 1) { set_error("add_n_sv_multi: null source"); return VLN_ERR_ARG; }
+      vec = vec && al16p(v.p) && (v.ld & 3) == 0 && (v.stride & 3) == 0 && al16p(v.bias);
+      a.src[k] = v;
+    }
+    a.n = q.n; a.out = q.out; a.ldo = q.ldo; a.rows = q.rows; a.cols = q.cols; a.vec = vec ? 1 : 0;
+    const long t = (long)q.rows * (vec ? q.cols / 4 : q.cols);
+    if (t > most) most = t;
+  }
+  int blocks = (int)((most + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  VLN_LAUNCH(add_n_sv_multi_kernel, dim3(blocks, n), dim3(256), 0, st, m);
+  VLN_CHECK_LAUNCH("add_n_sv_multi");
+  return VLN_OK;
+}
+
 extern "C" int vln_pe_dropout(const float* ctx, const float* pe, float* out, int B, int L, int H, uint64_t seed, uint64_t offset,
                               float p, void* s) {
   if (!ctx || !pe || !out || B <= 0 || L <= 0 || H <= 0 || (H & 3)) { vln::set_error("vln_pe_dropout: bad args (H %% 4 == 0)"); return VLN_ERR_ARG; }
@@ -1209,6 +1270,16 @@ extern "C" int vln_monitor_head_fwd(const float* mg, const float* c1, const floa
   a.mg = mg; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.bc = bc; a.mem = mem; a.prog = prog; a.B = B; a.L = L; a.H = H;
   a.dr = vln::tls_drop(seed, offset, p);
   VLN_LAUNCH(vln::monitor_head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("monitor_head_fwd");
+  return VLN_OK;
+}
+int vln::monitor_head_fwd_sv(hipStream_t st, SlabVec mg, float* mg_out, const float* c1, const float* word_w, const float* wc, const float* bc,
+                             float* mem, float* prog, int B, int L, int H, uint64_t seed, uint64_t offset, float p) {
+  if (!mg.p || !mg_out || !c1 || !word_w || !wc || !bc || !mem || !prog || B <= 0) { set_error("monitor_head_fwd_sv: bad args"); return VLN_ERR_ARG; }
+  MonHeadArgs a{};
+  a.mgs = mg; a.mg_out = mg_out; a.c1 = c1; a.word_w = word_w; a.wc = wc; a.bc = bc; a.mem = mem; a.prog = prog; a.B = B; a.L = L; a.H = H;
+  a.dr = tls_drop(seed, offset, p);
+  VLN_LAUNCH(monitor_head_fwd_kernel, dim3(B), dim3(256), 0, st, a);
   VLN_CHECK_LAUNCH("monitor_head_fwd");
   return VLN_OK;
 }
@@ -1330,10 +1401,12 @@ extern "C" int vln_bn_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, co
 int vln::bn_fwd_seg(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, int R, int R1, int64_t stat2, int D,
                     float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, uint64_t offset2, float p_drop,
-                    const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
+                    const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s, const float* x2, int64_t ldx2) {
   if (R1 < 0 || R1 >= R) { set_error("bn_fwd: bad segment split"); return VLN_ERR_ARG; }
+  if (x2 && (R1 <= 0 || (ldx2 & 3) || !al16p(x2))) { set_error("bn_fwd: a second input array needs two segments and 16-byte aligned rows"); return VLN_ERR_ARG; }
   BnArgs a{x, (long)ldx, y, (long)ldy, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_rstd,
-           R, D, eps, momentum, training, relu, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop)};
+           R, D, eps, momentum, training, relu, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop),
+           x2, (long)ldx2};
   const int nchunk = bn_nchunk(R, R1);
   if (R1 > 0 && !(ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D)) { set_error("bn_fwd: the two-segment form needs its workspace"); return VLN_ERR_ARG; }
   if ((R1 > 0 || R >= 512) && ((!training) || (ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D))) {     // tall input: row-chunked form
@@ -1364,10 +1437,12 @@ extern "C" int vln_bn_bwd(const float* x, int64_t ldx, const float* dy, int64_t 
 int vln::bn_bwd_seg(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
                     const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int R1,
                     int64_t stat2, int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, uint64_t offset2,
-                    float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s) {
+                    float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s, const float* x2, int64_t ldx2) {
   if (R1 < 0 || R1 >= R) { set_error("bn_bwd: bad segment split"); return VLN_ERR_ARG; }
+  if (x2 && (R1 <= 0 || (ldx2 & 3) || !al16p(x2))) { set_error("bn_bwd: a second input array needs two segments and 16-byte aligned rows"); return VLN_ERR_ARG; }
   BnBwdArgs a{x, (long)ldx, dy, (long)lddy, y, (long)ldy, gamma, mean, rstd_or_var, dx, (long)lddx, dgamma, dbeta, R, D, eps,
-              training, relu, accumulate, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop)};
+              training, relu, accumulate, tls_drop(seed, offset, p_drop), row_zero, R1, (long)stat2, tls_drop(seed, offset2, p_drop),
+              x2, (long)ldx2};
   const int nchunk = bn_nchunk(R, R1);
   if (R1 > 0 && !(ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D)) { set_error("bn_bwd: the two-segment form needs its workspace"); return VLN_ERR_ARG; }
   if ((R1 > 0 || R >= 512) && ws && al16p(ws) && ws_floats >= (int64_t)nchunk * 2 * D) {       // tall input: row-chunked form

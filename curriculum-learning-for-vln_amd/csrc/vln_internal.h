@@ -37,6 +37,7 @@ int check_hip(hipError_t e, const char* what);
 //   [6] weight gradients of precision 1: 0 packed grouped form, 1 exact fp32 form, 2 LDS-staged grouped form
 //   [7] 1: persistent LSTM workgroups in dispatch order instead of one XCD per dependency group
 //   [8] gemm_nt launches with >= 8 row tiles (the encoder's M = B * L products): 1 XCD-aware tile order (sharers of an X block behind one L2), 0 grid order
+//   [9] 1: products handed to slab-summing consumers (gemm_nt_to_consumer: the Self-Monitor / Follower steps) take the plain call + reduce launch instead (A/B, same bits)
 //   [10] 1: a pending gradient ride (vln_wgrad_ride_post) is always issued as its own launches (A/B)
 //   [11] >= 8: at most this many passenger workgroups carry a gradient ride (A/B; default: every idle CU up to the recurrence's own count)
 // The EnvDrop step's graph key includes [0..7] (the step has one row tile: [8] never applies), so a changed tunable never replays a stale graph.
@@ -79,17 +80,24 @@ bool prof_slot(int kid, double algo_bytes, hipEvent_t* a, hipEvent_t* b);
 int bn_fwd_seg(const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma, const float* beta, float* running_mean,
                float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_rstd, int R, int R1, int64_t stat2, int D,
                float eps, float momentum, int training, int relu, uint64_t seed, uint64_t offset, uint64_t offset2, float p_drop,
-               const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s);
+               const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s, const float* x2 = nullptr, int64_t ldx2 = 0);
 int bn_bwd_seg(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* gamma,
                const float* mean, const float* rstd_or_var, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int R1,
                int64_t stat2, int D, float eps, int training, int relu, int accumulate, uint64_t seed, uint64_t offset, uint64_t offset2,
-               float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s);
+               float p_drop, const uint8_t* row_zero, float* ws, int64_t ws_floats, void* s, const float* x2 = nullptr, int64_t ldx2 = 0);
+// (x2, ldx2: nullable -- the SECOND segment's rows read from their own array, row r of the segment at x2 + r * ldx2)
 // up to four row-wise elementwise forms (the ops of vln_ew) in one launch (pointwise.hip)
 struct EwJob { int op; const float* a; long lda; const float* b; long ldb; int nb; float* y; long ldy; int rows, cols; };
 int ew_multi(hipStream_t st, const EwJob* jobs, int n);
 // up to four independent `out = sum of <= 4 strided matrices` in one launch (pointwise.hip)
 struct AddNJob { float* out; long ldo; int rows, cols, n; const float* src[4]; long ld[4]; };
 int add_n_multi(hipStream_t st, const AddNJob* jobs, int n);
+// the same with sources still in split-K slabs (each source's slabs summed in slab order, then the sources in order)
+struct AddNSvJob { float* out; long ldo; int rows, cols, n; SlabVec src[4]; };
+int add_n_sv_multi(hipStream_t st, const AddNSvJob* jobs, int n);
+// vln_monitor_head_fwd with the gate product W_m [h0 ; moves] still in split-K slabs (+ bias); the sum is written to mg_out
+int monitor_head_fwd_sv(hipStream_t st, SlabVec mg, float* mg_out, const float* c1, const float* word_w, const float* wc, const float* bc,
+                        float* mem, float* prog, int B, int L, int H, uint64_t seed, uint64_t offset, float p);
 struct GatherCheck;
 GatherCheck gather_check(const void* table);   // features.hip: the registered extent of a feature table (vln_feature_table_extent)
 extern int g_split_attn_enabled;  // encoder.hip: 0 after a four-workgroup attention exchange timed out (vln_persistent_check)
@@ -125,6 +133,12 @@ int gemm_nt_slabs(int M, int N, int K, int wtype, long ws_floats);   // slabs ge
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out);
 // (nsplit_out != nullptr  =>  raw partial sums ALWAYS go to ws, even for nsplit == 1; no bias/act applied)
+
+// a product handed to a slab-summing consumer (gemm.hip): `ar` = what is left of the step's workspace
+struct SlabArea { float* base; long left; };
+int gemm_nt_plain_slabs(int M, int N, int K, int wtype, long ws_floats);
+int gemm_nt_to_consumer(hipStream_t st, SlabArea& ar, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
+                        int M, int N, int K, const float* bias, SlabVec* out);
 
 // Y = act(X W^T + bias) and optionally Y2 = Y * dropout mask, finished output in the fewest launches
 int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M,
@@ -180,7 +194,8 @@ int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, 
 int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
                   const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
 // same, with the vector operand still in split-K slabs (SlabVec) and an optional write-back of the summed vector
-int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D);
+int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D, float* vec_out = nullptr,
+                long ldvo = 0);      // vec_out (nullable): the summed vector (+ its bias) written back, [B, D]
 // `sync` / `sync_bytes` (nullable): the caller's zero-initialised exchange buffer of attn_split_sync_floats(B) floats; with it
 // (and B * 4 <= the device's CU count) a row's block is split over FOUR workgroups (attention_split.h)
 int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,

@@ -522,8 +522,11 @@ class BnMlpFn(torch.autograd.Function):
         seg = cfg[5] if len(cfg) > 5 else None          # (R1, [segment 1's dropout offset per layer]): two batches in one call
         nl = (len(tensors) - 2) // 4
         m = _lib.BnMlp()
-        m.R, m.D0, m.nl = x.shape[0], x.shape[1], nl
+        x2 = seg[2] if (seg and len(seg) > 2) else None         # the second batch in its own array (read in place)
+        m.R, m.D0, m.nl = x.shape[0] + (0 if x2 is None else x2.shape[0]), x.shape[1], nl
         m.R1 = seg[0] if seg else 0
+        if x2 is not None:
+            m.x2, m.ldx2 = x2.data_ptr(), x2.stride(0)
         wdt = wdtype(dtype, "mlp")                  # the Linear layers' streaming dtype (per-matrix fp32 override: functional.wdtype)
         base = base_dtype(dtype)
         m.wtype = ops.F32 if base == torch.float32 else (ops.F32S if wdt == torch.float32 else ops.BF16)
@@ -556,7 +559,7 @@ class BnMlpFn(torch.autograd.Function):
         dev = x.device
         ctx.rw = None
         if ROLLOUT_WGRADS.active(ctx) and cfg[0]:
-            key = ("bn_mlp", x.shape[0], id(tensors[2]))
+            key = ("bn_mlp", m.R, id(tensors[2]))
             saved, slot = ROLLOUT_WGRADS.saved(key, lib.vln_bn_mlp_saved_floats(m), dev)
             ctx.rw = (key, slot)
         else:
@@ -571,7 +574,7 @@ class BnMlpFn(torch.autograd.Function):
         ctx.cfg, ctx.bufs, ctx.nl, ctx.rz, ctx.c_call = cfg, bufs, nl, rz, True
         ctx.save_for_backward(x, saved, *tensors)
         # the output is the last block of `saved` (which the backward reads): the caller gets an alias, the ctx keeps the base
-        out = saved[off:off + x.shape[0] * out_dim].view(x.shape[0], out_dim).detach()
+        out = saved[off:off + m.R * out_dim].view(m.R, out_dim).detach()
         if m.R1 > 0:                                   # two batches: one output (and one incoming gradient) per segment
             return out[:m.R1], out[m.R1:]
         return out
@@ -589,7 +592,11 @@ class BnMlpFn(torch.autograd.Function):
             od = m.layer[m.nl - 1].out
             g1 = dys[0] if dys[0] is not None else torch.zeros(m.R1, od, dtype=torch.float32, device=dev)
             g2 = dys[1] if dys[1] is not None else torch.zeros(m.R - m.R1, od, dtype=torch.float32, device=dev)
-            dy = torch.cat([g1.reshape(m.R1, od), g2.reshape(m.R - m.R1, od)], 0)
+            if g1.is_contiguous() and g2.is_contiguous() and g1.data_ptr() + 4 * m.R1 * od == g2.data_ptr() and \
+                    g1.untyped_storage().data_ptr() == g2.untyped_storage().data_ptr():
+                dy = torch.as_strided(g1, (m.R, od), (od, 1))      # the two gradients already ARE the rows of one array (monitor_step)
+            else:
+                dy = torch.cat([g1.reshape(m.R1, od), g2.reshape(m.R - m.R1, od)], 0)
         else:
             dy = dys[0].contiguous()
         g = _lib.BnMlpGrads()
@@ -763,8 +770,10 @@ def set_bn_mlp_c_call(on: bool):
 
 def bn_mlp(x, row_zero, training, eps, momentum, dtype, drops, bufs, tensors, seg=None):
     """seg = (R1, [dropout offset of segment 1 per layer]): rows [0, R1) and [R1, R) are two independent batches (vln_bn_mlp.R1);
-    `row_zero` then covers segment 1's rows and the result is a pair (one output per segment)."""
-    cfg = (bool(training), float(eps), float(momentum), dtype, tuple(drops)) + (((int(seg[0]), tuple(seg[1])),) if seg else ())
+    `row_zero` then covers segment 1's rows and the result is a pair (one output per segment).  seg = (R1, offsets, x2): `x` holds
+    segment 0's R1 rows only and segment 1 is the contiguous-row matrix `x2`, read where it is (no concatenated copy; neither may
+    require a gradient)."""
+    cfg = (bool(training), float(eps), float(momentum), dtype, tuple(drops)) + (((int(seg[0]), tuple(seg[1])) + tuple(seg[2:3]),) if seg else ())
     return BnMlpFn.apply(x, row_zero, cfg, tuple(bufs), *tensors)
 
 

@@ -140,7 +140,7 @@ class MonitorStepFn(torch.autograd.Function):
         io.ctx_mask, io.cand_mask = m_ctx.data_ptr(), m_cand.data_ptr()
         io.logit, io.prog, io.h1, io.c1 = logit.data_ptr(), prog.data_ptr(), h1.data_ptr(), c1.data_ptr()
         io.word_w, io.move_w = word_w.data_ptr(), move_w.data_ptr()
-        ws = ops.workspace(dev, 1 << 22)
+        ws = ops.workspace(dev, int(lib.vln_monitor_ws_floats(C.byref(d))))       # room for the slabs the consumers sum themselves
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         io.seed_pe, io.off_pe, io.p_pe = seed_pe, off_pe, (p_pe if training else 0.0)
         io.seed, io.off_h1, io.off_mem, io.p_drop = seed, off_h1, off_mem, (p_drop if training else 0.0)
@@ -172,9 +172,14 @@ class MonitorStepFn(torch.autograd.Function):
         ups = [cz(t) for t in (dlogit, dprog, dh1, dc1, dww_ext, dmw_ext)]
         g = _lib.MonitorGrads()
         g.dlogit, g.dprog, g.dh1, g.dc1, g.dww_ext, g.dmw_ext = (_p(t) for t in ups)
-        dprev = ops.empty(B, M, dtype=f32, device=dev)
+        # d prev_rep and d cand_rep as the rows of ONE array: the two-batch BN-MLP in front of the step takes them as its single
+        # [B + B*C, M] incoming gradient without a concatenating copy (functional.BnMlpFn._backward_c)
+        if ctx.needs_input_grad[5]:
+            both = ops.empty(B * (Cn + 1), M, dtype=f32, device=dev)
+            dprev, dcand = both[:B], both[B:].view(B, Cn, M)
+        else:
+            dprev, dcand = ops.empty(B, M, dtype=f32, device=dev), None
         dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
-        dcand = torch.empty(B, Cn, M, dtype=f32, device=dev) if ctx.needs_input_grad[5] else None
         dctx_buf, dctx_acc, dctx = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[8], B, L, H, dev)
         g.dprev_rep, g.dcand_rep, g.dh0, g.dc0, g.dctx = dprev.data_ptr(), _p(dcand), dh0.data_ptr(), dc0.data_ptr(), _p(dctx_buf)
         g.dctx_accumulate = dctx_acc
@@ -193,7 +198,7 @@ class MonitorStepFn(torch.autograd.Function):
         else:
             scratch = ops.empty(ns, dtype=f32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), ns
-        ws = ops.workspace(dev, 1 << 22)             # (the forward's pointer may belong to another stream's workspace)
+        ws = ops.workspace(dev, int(lib.vln_monitor_ws_floats(C.byref(d))))    # (the forward's pointer may belong to another stream's workspace)
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         st = lib.vln_monitor_step_bwd(C.byref(d), C.byref(w), C.byref(io), C.byref(g), _lib.raw_stream())
         if st:

@@ -413,6 +413,10 @@ typedef struct vln_monitor_grads {
   vln_param_jobs* defer;                             /* nullable (ABI v11): see vln_param_jobs; b_c keeps its own one-column launch */
 } vln_monitor_grads;
 int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d);
+/* ABI v16: floats of vln_monitor_step.ws with which every skinny product of the step reaches its consumer as split-K slabs (the
+ * consumers sum them: no reduce launches; the backward keeps five products' slabs live at once).  A smaller workspace computes the
+ * same numbers with a reduce launch for the products that do not fit. */
+int64_t vln_monitor_ws_floats(const vln_monitor_dims* d);
 int vln_monitor_step_fwd(const vln_monitor_dims* d, const vln_monitor_weights* w, vln_monitor_step* io, vln_stream_t s);
 int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor_weights* w, const vln_monitor_step* io,
                          const vln_monitor_grads* g, vln_stream_t s);
@@ -505,6 +509,9 @@ typedef struct vln_bn_mlp {
   vln_bn_mlp_layer layer[VLN_BN_MLP_MAX_LAYERS];
   const uint8_t* row_zero;
   const uint64_t* offset_base_dev;                   /* nullable: the layers' dropout offsets relative to a device word (see vln_embed_fwd) */
+  const float* x2; int64_t ldx2;                     /* ABI v16, nullable (R1 > 0 only): the SECOND batch's rows live in their own array -- row r of
+                                                      * the batch at x2 + r * ldx2 -- and `x` holds the first batch's R1 rows: the previous action and
+                                                      * the candidates (policy.py:146-149) are read where they are, no concatenated copy.  No dx then. */
 } vln_bn_mlp;
 typedef struct vln_bn_mlp_grad_layer { float* g_w; float* g_b; float* g_gamma; float* g_beta; int32_t acc_w, acc_b, acc_bn, pad_; } vln_bn_mlp_grad_layer;
 typedef struct vln_bn_mlp_grads {
