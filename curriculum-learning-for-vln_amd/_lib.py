@@ -120,11 +120,17 @@ class MonitorStep(C.Structure):
                    ("off_mem", u64), ("p_drop", f32), ("offset_base_dev", ptr)])
 
 
+class DctxTerm(C.Structure):
+    _fields_ = [("alpha", ptr), ("dl", ptr), ("g", ptr), ("q", ptr), ("ldg", i64), ("ldq", i64), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("p", f32), ("pad_", f32)]
+
+
 class MonitorGrads(C.Structure):
     _fields_ = ([(n, ptr) for n in ("dlogit", "dprog", "dh1", "dc1", "dww_ext", "dmw_ext", "dprev_rep", "dcand_rep", "dh0", "dc0", "dctx")]
                 + [("dctx_accumulate", i32)]
                 + [(n, ptr) for n in ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")]
-                + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))])
+                + [("acc", i32 * 13), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs)),
+                   ("dctx_term", C.POINTER(DctxTerm))])
 
 
 class FollowerDims(C.Structure):
@@ -148,7 +154,8 @@ class FollowerGrads(C.Structure):
                 + [("dctx_accumulate", i32)]
                 + [(n, ptr) for n in ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact",
                                       "g_whid", "g_bhid", "g_wout", "g_bout")]
-                + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))])
+                + [("acc", i32 * 16), ("precision", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs)),
+                   ("dctx_term", C.POINTER(DctxTerm))])
 
 
 BN_MLP_MAX_LAYERS = 4                 # VLN_BN_MLP_MAX_LAYERS
@@ -186,7 +193,7 @@ STRUCT_MIRRORS = {
     "vln_follower_dims": FollowerDims, "vln_follower_weights": FollowerWeights, "vln_follower_step": FollowerStep,
     "vln_follower_grads": FollowerGrads, "vln_bn_affine": BnAffine, "vln_bn_mlp_layer": BnMlpLayer, "vln_bn_mlp": BnMlp,
     "vln_bn_mlp_grad_layer": BnMlpGradLayer, "vln_bn_mlp_grads": BnMlpGrads, "vln_gather_rollout_step": GatherRolloutStep,
-    "vln_gather_ride": GatherRide, "vln_envdrop_dims": EnvDropDims, "vln_envdrop_weights": EnvDropWeights, "vln_envdrop_step": EnvDropStep,
+    "vln_gather_ride": GatherRide, "vln_envdrop_dims": EnvDropDims, "vln_envdrop_weights": EnvDropWeights, "vln_envdrop_step": EnvDropStep, "vln_dctx_term": DctxTerm,
     "vln_envdrop_grads": EnvDropGrads,
 }
 

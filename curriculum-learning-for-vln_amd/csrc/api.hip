@@ -150,6 +150,7 @@ extern "C" int64_t vln_struct_size(const char* name) {
   VLN_SZ(vln_envdrop_weights);
   VLN_SZ(vln_envdrop_step);
   VLN_SZ(vln_envdrop_grads);
+  VLN_SZ(vln_dctx_term);
 #undef VLN_SZ
   return -1;
 }

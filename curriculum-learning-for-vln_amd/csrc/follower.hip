@@ -117,7 +117,9 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   RUN(vln_ew(2, dgr, H, io->grounded, H, 0, dz, H, B, H, s));
   RUN(gemm_nt(st, dz, H, w->w_tout_t, wt, H, dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> wc | drop(h1)
   RUN(attn_bwd_rows(st, io->ctx, W_F32, io->word_w, dtcat, 2 * H, g->dww_ext, dtq2, H, dl_t, io->dots, B, L, H));
-  if (g->dctx) {
+  if (g->dctx_term) {
+    *g->dctx_term = vln_dctx_term{io->word_w, dl_t, dtcat, io->tq2, 2L * H, H, 0, 0, 0.f, 0.f};
+  } else if (g->dctx) {
     const float* al[1] = {io->word_w};
     const float* dl[1] = {dl_t};
     const float* gg[1] = {dtcat};

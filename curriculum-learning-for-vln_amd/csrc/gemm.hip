@@ -106,14 +106,16 @@ int gemm_nt_plain_slabs(int M, int N, int K, int wtype, long ws_floats) {
   const int BK = (wtype == W_F32) ? 32 : 64;
   return gemm_nt_split((N + 63) / 64, (M + 63) / 64, (K + BK - 1) / BK, M, N, true, ws_floats, false, nullptr);
 }
-// A product whose CONSUMER sums the split-K slabs (SlabVec, bias included): when the plain call would need a reduce launch the
-// slabs are left in the caller's bump-allocated area (several products' slabs live at once) -- same split, same bits as the plain
-// call + reduce_epilogue; otherwise the plain call writes Y and *out is that matrix.
+// A product whose CONSUMER sums the split-K slabs (SlabVec, bias included): the slabs are left in the caller's bump-allocated area
+// (several products' slabs live at once).  The K split is the one of products handed to a caller (gemm_nt_slabs): where the plain
+// call splits too it is the same split -- the bits of the plain call + reduce_epilogue -- and the wide-and-shallow products the
+// plain call leaves un-split (a reduce launch would cost more than the split buys) ARE split here, the summing being free.  A
+// product the narrow-output kernel takes, or that does not fit the area, goes through the plain call into Y (*out = that matrix).
 int gemm_nt_to_consumer(hipStream_t st, SlabArea& ar, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
                         int M, int N, int K, const float* bias, SlabVec* out) {
   if (!out || !ar.base) { set_error("gemm_nt_to_consumer: null pointer"); return VLN_ERR_ARG; }
   const long per = (long)M * N;
-  if (g_tunable[9] || ar.left < per || gemm_nt_plain_slabs(M, N, K, wtype, ar.left) <= 1) {      // tunable[9] = 1: always the plain call (A/B)
+  if (g_tunable[9] || ar.left < per || n16_applies(M, N, K, wtype) || gemm_nt_slabs(M, N, K, wtype, ar.left) <= 1) {      // tunable[9] = 1: always the plain call (A/B)
     if (!Y) { set_error("gemm_nt_to_consumer: the product is not split and no output matrix was given"); return VLN_ERR_ARG; }
     const int r = gemm_nt(st, X, ldx, W, wtype, ldw, Y, ldy, M, N, K, bias, ACT_NONE, ar.base, ar.left, nullptr);
     *out = plain_vec(Y, ldy);

@@ -92,7 +92,7 @@ extern "C" int64_t vln_monitor_ws_floats(const vln_monitor_dims* d) {
   for (int i = 0; i < 5; ++i) {
     int most = 1;
     for (int wt : {(int)W_F32, (int)W_BF16, (int)W_F32S}) {
-      const int k = gemm_nt_plain_slabs(B, nk[i][0], nk[i][1], wt, 1L << 40);
+      const int k = gemm_nt_slabs(B, nk[i][0], nk[i][1], wt, 1L << 40);
       if (k > most) most = k;
     }
     n += ((long)most * B * nk[i][0] + 63) & ~63L;
@@ -224,7 +224,9 @@ extern "C" int vln_monitor_step_bwd(const vln_monitor_dims* d, const vln_monitor
   RUN(gemm_nt_to_consumer(st, ar, dvq, M, w->w_vh_t, wt(1), M, dh0_v, H, B, H, M, nullptr, &s_dh0v));
   // words: d ctx = (word_w (x) dwords + dl_t (x) tq) * this step's pe-dropout mask
   RUN(attn_bwd_rows(st, io->pctx, W_F32, io->word_w, dwords, H, dww, dtq, H, dl_t, io->dots, B, L, H));
-  if (g->dctx) {
+  if (g->dctx_term) {
+    *g->dctx_term = vln_dctx_term{io->word_w, dl_t, dwords, io->tq, H, H, io->seed_pe, io->off_pe, io->p_pe, 0.f};
+  } else if (g->dctx) {
     const float* al[1] = {io->word_w};
     const float* dl[1] = {dl_t};
     const float* gg[1] = {dwords};

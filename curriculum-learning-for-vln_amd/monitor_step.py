@@ -48,18 +48,35 @@ def gated_ctx(ctx_t):
     return e.gated, e
 
 
+DEFER_DCTX = [True]        # A/B: False = every step adds its own term to the rollout's buffer (one launch per step)
+
+
 def _dctx_target(ctx, entry_ref, want, B, L, H, dev):
-    """(buffer the step's backward writes, accumulate flag, what the node returns to autograd for the context)."""
+    """-> (buffer the step's backward writes or None, accumulate flag, what the node returns to autograd for the context, the
+    rollout's CtxEntry when the step's term is only REPORTED (vln_dctx_term) and formed once per rollout by runtime.CtxGate)."""
     if not want:
-        return None, 0, None
+        return None, 0, None, None
     e = entry_ref() if entry_ref is not None else None
     if e is None:
         t = torch.empty(B, L, H, dtype=torch.float32, device=dev)
-        return t, 0, t
+        return t, 0, t, None
+    if DEFER_DCTX[0] and (e.kctx is None or e.kctx is False):
+        return None, 0, None, e
     first = e.dctx is None
     if first:
         e.dctx = ops.empty(B, L, H, dtype=torch.float32, device=dev)
-    return e.dctx, 0 if first else 1, None
+    return e.dctx, 0 if first else 1, None, None
+
+
+def _report_term(e, term, shape, drop, keep):
+    """One step's (alpha, dl, g, q) addresses onto the rollout's list (runtime.CtxGate forms them in one launch)."""
+    if e.tdesc is None:
+        e.tdesc = [int(term.ldg), int(term.ldq), []]
+    elif e.tdesc[0] != term.ldg or e.tdesc[1] != term.ldq:
+        raise _lib.VlnError("deferred context gradient: the steps of one rollout disagree on their layouts")
+    e.shape = shape
+    e.tdesc[2].append(drop)
+    e.terms.append((term.alpha, term.dl, term.g, term.q, keep[0], keep))
 
 
 def _m8(mask):
@@ -180,9 +197,13 @@ class MonitorStepFn(torch.autograd.Function):
         else:
             dprev, dcand = ops.empty(B, M, dtype=f32, device=dev), None
         dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
-        dctx_buf, dctx_acc, dctx = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[8], B, L, H, dev)
+        dctx_buf, dctx_acc, dctx, dentry = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[8], B, L, H, dev)
         g.dprev_rep, g.dcand_rep, g.dh0, g.dc0, g.dctx = dprev.data_ptr(), _p(dcand), dh0.data_ptr(), dc0.data_ptr(), _p(dctx_buf)
         g.dctx_accumulate = dctx_acc
+        term = None
+        if dentry is not None:
+            term = _lib.DctxTerm()
+            g.dctx_term = C.pointer(term)
         sinks = [_gsink(p) for p in params]
         names = ("g_tin", "g_vh", "g_bvh", "g_ih", "g_hh", "g_bih", "g_bhh", "g_a", "g_ba", "g_m", "g_bm", "g_wc", "g_bc")
         for i, (n, (t, acc)) in enumerate(zip(names, sinks)):
@@ -205,6 +226,10 @@ class MonitorStepFn(torch.autograd.Function):
             _lib.check(st, "vln_monitor_step_bwd")
         if pj is not None:
             ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (flat, scratch, hold, [t for t, _ in sinks]))
+        if term is not None:
+            cfg = ctx.cfg
+            drop = (int(term.seed), int(term.offset), float(term.p)) + ((cfg[8],) if len(cfg) > 8 and cfg[8] is not None else ())
+            _report_term(dentry, term, (B, L, H), drop if term.p > 0 else None, (scratch, flat, outs))
         ctx.pack = None
         return (None, None, None, None, dprev, dcand, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)
 
@@ -304,9 +329,13 @@ class FollowerStepFn(torch.autograd.Function):
         g.dlogit, g.dh1, g.dc1, g.dww_ext, g.dvw_ext = (_p(t) for t in ups)
         da = ops.empty(B, A, dtype=f32, device=dev) if ctx.needs_input_grad[3] else None
         dh0 = ops.empty(B, H, dtype=f32, device=dev); dc0 = ops.empty(B, H, dtype=f32, device=dev)
-        dctx_buf, dctx_acc, dctx = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[7], B, L, H, dev)
+        dctx_buf, dctx_acc, dctx, dentry = _dctx_target(ctx, ctx.dentry, ctx.needs_input_grad[7], B, L, H, dev)
         g.da_prev, g.dh0, g.dc0, g.dctx = _p(da), dh0.data_ptr(), dc0.data_ptr(), _p(dctx_buf)
         g.dctx_accumulate = dctx_acc
+        term = None
+        if dentry is not None:
+            term = _lib.DctxTerm()
+            g.dctx_term = C.pointer(term)
         sinks = [_gsink(p) for p in params]
         names = ("g_wh", "g_bh", "g_wv", "g_bv", "g_ih", "g_hh", "g_bih", "g_bhh", "g_tin", "g_tout", "g_wact", "g_bact", "g_whid", "g_bhid",
                  "g_wout", "g_bout")
@@ -330,5 +359,7 @@ class FollowerStepFn(torch.autograd.Function):
             _lib.check(st, "vln_follower_step_bwd")
         if pj is not None:
             ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (flat, scratch, hold, [t for t, _ in sinks]))
+        if term is not None:
+            _report_term(dentry, term, (B, L, H), None, (scratch, flat, _alive))
         ctx.pack = None
         return (None, None, None, da, None, dh0, dc0, dctx) + tuple(_gret(t, acc) for t, acc in sinks)

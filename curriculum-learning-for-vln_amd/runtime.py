@@ -308,7 +308,7 @@ class WeightGate(torch.autograd.Function):
 class CtxEntry:
     """Per-context bookkeeping (one per rollout): the gated alias, the in-place dctx accumulator and the
     low-precision copy.  Autograd nodes only hold it weakly so no tensor<->node cycle can form."""
-    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "kctx", "k_w", "k_split", "k_hd", "__weakref__")
+    __slots__ = ("ref", "dctx", "lp", "gated", "mask_src", "mask8", "terms", "shape", "kctx", "k_w", "k_split", "k_hd", "tdesc", "__weakref__")
 
     def __init__(self, t):
         self.ref = weakref.ref(t)
@@ -325,6 +325,8 @@ class CtxEntry:
         self.k_w = None
         self.k_split = False
         self.k_hd = None        # callable (address, rows) -> [rows, H] strided view of the module's drop(h_1) stash rows
+        # terms of another layout than the EnvDrop step's (monitor_step): [ldg, ldq, [per-term (seed, offset, p[, base]) or None]]
+        self.tdesc = None
 
 
 class CtxGate(torch.autograd.Function):
@@ -375,6 +377,12 @@ class CtxGate(torch.autograd.Function):
                         ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
                                                [t[3] for t in terms], 2 * H, d, accumulate=acc, dk=dk)
                         ops.linear_fwd(dk.view(B * L, H), e.k_w, act=ops.ACT_ACCUM, out=d.view(B * L, H), split=e.k_split)
+                elif e.tdesc is not None:
+                    ldg, ldq, drops = e.tdesc
+                    e.tdesc = None
+                    ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], ldg,
+                                           [t[3] for t in terms], ldq, d, accumulate=acc,
+                                           drop=[x if x is not None else (0, 0, 0.0) for x in drops] if any(x is not None for x in drops) else None)
                 else:
                     ops.attn_dctx_deferred([t[0] for t in terms], [t[1] for t in terms], [t[2] for t in terms], 2 * H,
                                            [t[3] for t in terms], H, d, accumulate=acc)

@@ -400,6 +400,10 @@ typedef struct vln_monitor_step {
   uint64_t seed, off_h1, off_mem; float p_drop;      /* dropout on h_1 (policy.py:160) and on the monitor memory (:128) */
   const uint64_t* offset_base_dev;                   /* nullable: every site's offset is (*offset_base_dev) * 8 + its field (see vln_embed_fwd) */
 } vln_monitor_step;
+/* One decoder step's share of the rollout's context gradient (ABI v16), reported instead of launched:
+ *   dctx[b,s,:] += (alpha[b,s] g[b,:] + dl[b,s] q[b,:]) * dropout mask(seed, offset, p over the flat [B,S,D] index; p = 0: none)
+ * The caller keeps the four arrays alive and forms every step's term with ONE vln_attn_dctx_deferred(_drop) launch per rollout. */
+typedef struct vln_dctx_term { const float *alpha, *dl, *g, *q; int64_t ldg, ldq; uint64_t seed, offset; float p, pad_; } vln_dctx_term;
 typedef struct vln_monitor_grads {
   const float *dlogit, *dprog, *dh1, *dc1, *dww_ext, *dmw_ext;        /* upstream gradients, each nullable */
   float *dprev_rep /*[B,M]*/, *dcand_rep /*[B,C,M], nullable*/, *dh0, *dc0 /*[B,H]*/, *dctx /*[B,L,H], nullable*/;
@@ -411,6 +415,8 @@ typedef struct vln_monitor_grads {
   int precision;                                     /* weight gradients: 0 exact fp32 MFMA, 1 split-bf16 (three bf16 MFMAs) */
   float* scratch; int64_t scratch_floats;            /* >= vln_monitor_bwd_scratch_floats(dims) */
   vln_param_jobs* defer;                             /* nullable (ABI v11): see vln_param_jobs; b_c keeps its own one-column launch */
+  vln_dctx_term* dctx_term;                          /* nullable (ABI v16, out): the step's context-gradient term is REPORTED here and not
+                                                      * launched (dctx is then ignored); its arrays live in `scratch` and the step's saved block */
 } vln_monitor_grads;
 int64_t vln_monitor_bwd_scratch_floats(const vln_monitor_dims* d);
 /* ABI v16: floats of vln_monitor_step.ws with which every skinny product of the step reaches its consumer as split-K slabs (the
@@ -457,6 +463,7 @@ typedef struct vln_follower_grads {
   int precision;
   float* scratch; int64_t scratch_floats;            /* >= vln_follower_bwd_scratch_floats(dims) */
   vln_param_jobs* defer;                             /* nullable (ABI v11): see vln_param_jobs; b_out keeps its own one-column launch */
+  vln_dctx_term* dctx_term;                          /* nullable (ABI v16, out): as in vln_monitor_grads */
 } vln_follower_grads;
 int64_t vln_follower_bwd_scratch_floats(const vln_follower_dims* d);
 int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follower_weights* w, vln_follower_step* io, vln_stream_t s);
