@@ -14,11 +14,15 @@ namespace vln {
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------
+// vmul (nullable, [D]): the vector is multiplied column-wise by it before the dots (and before the write-back) -- ActionScoring's
+// q = target (.) w_out (units.py:181-183); add0 (nullable, [1]): a scalar added to every dot (its b_out)
 template <typename TC>
 __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec vec, float* dots,
-                                                       long rows, int S, int D, int vec_ok, float* vec_out, long ldvo) {
+                                                       long rows, int S, int D, int vec_ok, float* vec_out, long ldvo,
+                                                       const float* vmul, const float* add0) {
   constexpr int V = Elt<TC>::kVec;   // elements per 16-byte access
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float addv = add0 ? add0[0] : 0.f;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
     const int b = (int)(r / S);
     const TC* c = ctx + r * (long)D;
@@ -30,20 +34,22 @@ __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec ve
         Elt<TC>::ld16(c + d, x);
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
-          const float4 t = vec.at4(b, d + j);
+          float4 t = vec.at4(b, d + j);
+          if (vmul) { const float4 m = *reinterpret_cast<const float4*>(vmul + d + j); t.x *= m.x; t.y *= m.y; t.z *= m.z; t.w *= m.w; }
           if (wb) *reinterpret_cast<float4*>(vec_out + (long)b * ldvo + d + j) = t;
           acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
         }
       }
     } else {
       for (int d = lane; d < D; d += 64) {
-        const float t = vec.at(b, d);
+        float t = vec.at(b, d);
+        if (vmul) t *= vmul[d];
         if (wb) vec_out[(long)b * ldvo + d] = t;
         acc += Elt<TC>::ld(c + d) * t;
       }
     }
     acc = wave_sum(acc);
-    if (lane == 0) dots[r] = acc;
+    if (lane == 0) dots[r] = acc + addv;
   }
 }
 
@@ -51,7 +57,8 @@ int attn_dot(hipStream_t st, const void* ctx, int ctype, const float* vec, long 
              int D) {
   return attn_dot_sv(st, ctx, ctype, plain_vec(vec, ldv), dots, B, S, D);
 }
-int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D, float* vec_out, long ldvo) {
+int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D, float* vec_out, long ldvo,
+                const float* vmul, const float* add0) {
   if (B <= 0 || S <= 0 || D <= 0) { set_error("attn_dot: bad dims"); return VLN_ERR_ARG; }
   const long ldv = vec.ld;
   long rows = (long)B * S;
@@ -59,12 +66,14 @@ int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* 
   if (blocks > 8192) blocks = 8192;
   const int V = (ctype == W_BF16) ? 8 : 4;
   int vec_ok = aligned16(ctx) && aligned16(vec.p) && (D % V == 0) && (ldv % 4 == 0) && (vec.stride % 4 == 0) && aligned16(vec.bias) &&
-               (!vec_out || (aligned16(vec_out) && (ldvo % 4 == 0)));
+               (!vec_out || (aligned16(vec_out) && (ldvo % 4 == 0))) && aligned16(vmul);
   const double bytes = (double)rows * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 4.0 * rows;
   if (ctype == W_BF16)
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, dots, rows, S, D, vec_ok, vec_out, ldvo);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<bf16_raw>, dim3(blocks), dim3(256), 0, st, (const bf16_raw*)ctx, vec, dots, rows, S, D, vec_ok,
+                 vec_out, ldvo, vmul, add0);
   else
-    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, dots, rows, S, D, vec_ok, vec_out, ldvo);
+    launch_timed(K_ATTN_DOT, bytes, attn_dot_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ctx, vec, dots, rows, S, D, vec_ok, vec_out,
+                 ldvo, vmul, add0);
   VLN_CHECK_LAUNCH("attn_dot");
   return VLN_OK;
 }

@@ -78,10 +78,9 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, wt, 2 * H, io->grounded, H, B, H, 2 * H, nullptr, ACT_TANH, io->ws, io->ws_floats, nullptr));
   // (4) candidate scores: logit = context . (target (.) w_out) + b_out
   RUN(gemm_nt(st, io->grounded, H, w->w_hid, wt, H, io->target, D, B, D, H, w->b_hid, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(vln_ew(0, io->target, D, w->w_out, 0, 0, io->q, D, B, D, s));
   RUN(gemm_nt(st, io->cands, A, w->w_act, wt, A, io->context, D, B * C, D, A, w->b_act, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_dot(st, io->context, W_F32, io->q, D, io->logit, B, C, D));
-  RUN(vln_ew(1, io->logit, C, w->b_out, 0, 0, io->logit, C, B, C, s));
+  // q = target (.) w_out and the + b_out inside the dot launch (they were a launch each); q written back for the backward
+  RUN(attn_dot_sv(st, io->context, W_F32, plain_vec(io->target, D), io->logit, B, C, D, io->q, D, w->w_out, w->b_out));
   return VLN_OK;
 }
 
@@ -127,11 +126,11 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     RUN(attn_dctx_deferred(st, al, dl, gg, 2 * H, qq, H, 1, g->dctx, B, L, H, g->dctx_accumulate));
   }
   RUN(gemm_nt(st, dtq2, H, w->w_tin_t, wt, H, t1, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(vln_add_n(dhd, H, B, H, dtcat + H, 2 * H, t1, H, nullptr, 0, nullptr, 0, 0, s));
-  // (2) LSTM cell
+  // (2) LSTM cell; d drop(h1) = dtcat[:, H:] + t1, added by the pointwise launch (it was a launch of its own)
+  (void)dhd;
   {
     LstmPwBwd a{};
-    a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dhd, H); a.dh1_b2 = plain_vec(nullptr, 0);
+    a.dh1_a = g->dh1; a.ld_a = H; a.dh1_b = plain_vec(dtcat + H, 2 * H); a.dh1_b2 = plain_vec(t1, H);
     a.drop = tls_drop(io->seed, io->off + 1, io->p_drop); a.dc1 = g->dc1; a.lddc1 = H; a.act = io->act; a.tanh_c1 = io->tanh_c1;
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));

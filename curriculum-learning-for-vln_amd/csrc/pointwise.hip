@@ -284,26 +284,45 @@ __device__ __forceinline__ float ce_row_regs(const CeArgs& a, int b) {
   if (a.loss) a.loss[b] = l;
   return l;
 }
-__global__ __launch_bounds__(256) void masked_ce_fwd_sum_kernel(CeArgs a, float* loss_sum) {
+// mean != 0 (nn.CrossEntropyLoss's default reduction, follower.py:62): loss_sum[0] = sum / #rows with a target, loss_sum[1] = 1 / that
+// count (what the backward scales by) -- the count is formed in the same launch (0 rows: 0/0 = nan, as torch)
+__global__ __launch_bounds__(256) void masked_ce_fwd_sum_kernel(CeArgs a, float* loss_sum, int mean) {
   __shared__ float part[4];
-  float acc = 0.f;
-  for (int b = threadIdx.x; b < a.B; b += 256) acc += (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+  __shared__ float cnt[4];
+  float acc = 0.f, n = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    acc += (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+    if (mean && a.target[b] != a.ignore_index) n += 1.f;
+  }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if (mean) n = wave_sum(n);
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; cnt[threadIdx.x >> 6] = n; }
   __syncthreads();
-  if (threadIdx.x == 0) loss_sum[0] = (part[0] + part[1]) + (part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    const float total = (part[0] + part[1]) + (part[2] + part[3]);
+    if (mean) {
+      const float c = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+      loss_sum[0] = total / c;
+      loss_sum[1] = 1.f / c;
+    } else {
+      loss_sum[0] = total;
+    }
+  }
 }
 
 // dlogits[b,c] = dloss[b] * (p - onehot(target))   (0 for ignored rows; p = 0 at masked slots)
 // dloss_stride 0: one scalar upstream gradient for every row (the backward of the fused sum)
+// scale (nullable): one device scalar multiplied into every row's gradient (the 1 / count of the mean reduction)
 __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* probs, const long long* target, const float* dloss,
                                                             long dloss_stride, float* dlogits, int B, int C,
-                                                            long ignore_index) {
+                                                            long ignore_index, const float* scale) {
   const long total = (long)B * C;
+  const float sc = scale ? scale[0] : 1.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int b = (int)(e / C), c = (int)(e % C);
     const long t = target[b];
-    dlogits[e] = (t == ignore_index) ? 0.f : dloss[b * dloss_stride] * (probs[e] - (c == t ? 1.f : 0.f));
+    const float up = scale ? dloss[b * dloss_stride] * sc : dloss[b * dloss_stride];
+    dlogits[e] = (t == ignore_index) ? 0.f : up * (probs[e] - (c == t ? 1.f : 0.f));
   }
 }
 
@@ -1463,7 +1482,7 @@ extern "C" int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* targe
   if (!logits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_fwd: bad args"); return VLN_ERR_ARG; }
   vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, loss, probs, (const long long*)action, logp, entropy,
                 B, C, (long)ignore_index, write_mask};
-  if (loss_sum) VLN_LAUNCH(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, loss_sum);
+  if (loss_sum) VLN_LAUNCH(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, loss_sum, 0);
   else VLN_LAUNCH(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
   VLN_CHECK_LAUNCH("masked_ce_fwd");
   return VLN_OK;
@@ -1475,8 +1494,29 @@ extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, cons
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   VLN_LAUNCH(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target,
-                     dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index);
+                     dloss, (long)dloss_stride, dlogits, B, C, (long)ignore_index, (const float*)nullptr);
   VLN_CHECK_LAUNCH("masked_ce_bwd");
+  return VLN_OK;
+}
+// reduction = "mean" in the same launch: mean_out[0] = mean over the rows with a target, mean_out[1] = 1 / their count
+extern "C" int vln_masked_ce_mean_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, float* mean_out,
+                                      float* probs, int B, int C, int64_t ignore_index, void* s) {
+  if (!logits || !target || !mean_out || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_mean_fwd: bad args"); return VLN_ERR_ARG; }
+  vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, nullptr, probs, nullptr, nullptr, nullptr, B, C, (long)ignore_index, 0};
+  VLN_LAUNCH(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, mean_out, 1);
+  VLN_CHECK_LAUNCH("masked_ce_mean_fwd");
+  return VLN_OK;
+}
+// d logits of the mean: dloss[0] * inv_count[0] * (p - onehot)
+extern "C" int vln_masked_ce_mean_bwd(const float* probs, const int64_t* target, const float* dloss, const float* inv_count, float* dlogits,
+                                      int B, int C, int64_t ignore_index, void* s) {
+  if (!probs || !target || !dloss || !inv_count || !dlogits || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_mean_bwd: bad args"); return VLN_ERR_ARG; }
+  long total = (long)B * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  VLN_LAUNCH(vln::masked_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, probs, (const long long*)target, dloss, 0L, dlogits, B, C,
+             (long)ignore_index, inv_count);
+  VLN_CHECK_LAUNCH("masked_ce_mean_bwd");
   return VLN_OK;
 }
 

@@ -194,8 +194,10 @@ int attn_fwd_rows(hipStream_t st, const void* ctx, int ctype, const float* vec, 
 int attn_bwd_rows(hipStream_t st, const void* ctx, int ctype, const float* attn, const float* dwc, long lddwc,
                   const float* dattn_ext, float* dvec, long lddvec, float* dl_out, float* dots_scratch, int B, int S, int D);
 // same, with the vector operand still in split-K slabs (SlabVec) and an optional write-back of the summed vector
+// vec_out (nullable): the summed vector (+ its bias, x vmul) written back, [B, D]; vmul (nullable, [D]): column-wise multiplier of
+// the vector; add0 (nullable, [1]): a scalar added to every dot
 int attn_dot_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* dots, int B, int S, int D, float* vec_out = nullptr,
-                long ldvo = 0);      // vec_out (nullable): the summed vector (+ its bias) written back, [B, D]
+                long ldvo = 0, const float* vmul = nullptr, const float* add0 = nullptr);
 // `sync` / `sync_bytes` (nullable): the caller's zero-initialised exchange buffer of attn_split_sync_floats(B) floats; with it
 // (and B * 4 <= the device's CU count) a row's block is split over FOUR workgroups (attention_split.h)
 int attn_fwd_rows_sv(hipStream_t st, const void* ctx, int ctype, SlabVec vec, float* vec_out, long ldvo, const uint8_t* mask,

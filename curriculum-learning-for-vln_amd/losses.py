@@ -81,6 +81,41 @@ class _MaskedCE(torch.autograd.Function):
         return dl, None, None, None, None
 
 
+class _MaskedCEMean(torch.autograd.Function):
+    """reduction="mean": the count of rows with a target and the division inside the loss launch (five torch launches per call
+    before: ne, sum, cast, div and the div's backward)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, cand_mask, ignore_index):
+        B, C = logits.shape
+        dev = logits.device
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        probs = ops.empty(B, C, dtype=torch.float32, device=dev)
+        out = ops.empty(2, dtype=torch.float32, device=dev)           # [mean, 1 / count]
+        tgt = target if target.is_contiguous() else target.contiguous()
+        st = _lib.load().vln_masked_ce_mean_fwd(lg.data_ptr(), lg.stride(0), tgt.data_ptr(), _p(_mask8(cand_mask)), out.data_ptr(),
+                                                probs.data_ptr(), B, C, ignore_index, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_masked_ce_mean_fwd")
+        ctx.save_for_backward(probs, tgt, out)
+        ctx.ignore_index = ignore_index
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        probs, tgt, out = ctx.saved_tensors
+        B, C = probs.shape
+        dl = ops.empty_like(probs)
+        dloss = dloss.contiguous()
+        st = _lib.load().vln_masked_ce_mean_bwd(probs.data_ptr(), tgt.data_ptr(), dloss.data_ptr(), out.data_ptr() + 4, dl.data_ptr(), B, C,
+                                                ctx.ignore_index, _lib.raw_stream())
+        if st:
+            _lib.check(st, "vln_masked_ce_mean_bwd")
+        return dl, None, None, None
+
+
 def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: Optional[torch.Tensor] = None,
                          reduction: str = "none", ignore_index: int = -1) -> torch.Tensor:
     """== `CrossEntropyLoss(ignore_index, reduction)(logits.masked_fill(cand_mask, -inf), target)`.
@@ -89,10 +124,9 @@ def masked_cross_entropy(logits: torch.Tensor, target: torch.Tensor, cand_mask: 
     _not_deferred(logits, "masked_cross_entropy")
     if reduction == "none":
         return _MaskedCE.apply(logits, target, cand_mask, ignore_index, False)
-    total = _MaskedCE.apply(logits, target, cand_mask, ignore_index, True)
     if reduction == "sum":
-        return total
-    return total / (target != ignore_index).sum().to(total.dtype)
+        return _MaskedCE.apply(logits, target, cand_mask, ignore_index, True)
+    return _MaskedCEMean.apply(logits, target, cand_mask, ignore_index)
 
 
 class _MonitorLoss(torch.autograd.Function):

@@ -297,6 +297,12 @@ int vln_masked_ce_fwd(float* logits, int64_t ld, const int64_t* target /*nullabl
 /* dloss_stride: 1 = one upstream gradient per row, 0 = one scalar for all rows (backward of the fused sum) */
 int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dloss, int64_t dloss_stride, float* dlogits,
                       int B, int C, int64_t ignore_index, vln_stream_t s);
+/* ABI v16: reduction = "mean" (nn.CrossEntropyLoss(ignore_index)'s default, follower.py:62) in the same launch: mean_out[0] = the
+ * mean over the rows with a target, mean_out[1] = 1 / their count (0 rows: nan, as torch); the backward multiplies it in. */
+int vln_masked_ce_mean_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask /*nullable*/, float* mean_out /*[2]*/,
+                           float* probs /*[B,C]*/, int B, int C, int64_t ignore_index, vln_stream_t s);
+int vln_masked_ce_mean_bwd(const float* probs, const int64_t* target, const float* dloss /*[1]*/, const float* inv_count /*mean_out + 1*/,
+                           float* dlogits, int B, int C, int64_t ignore_index, vln_stream_t s);
 
 /* The IL loss of a WHOLE rollout, ml_loss = sum_t CrossEntropy(mask(logits_t), target_t) (envdrop.py:173-179 summed over
  * the steps), in one launch after the last decoder step, and all the d logits_t in one launch at the start of backward:
