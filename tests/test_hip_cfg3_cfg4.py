@@ -79,8 +79,10 @@ def _rl_tape(B, T, ncands, g):
     return acts, masks, rewards, lens <= T
 
 
-def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False, only=None):
-    """mode 'sum' = cfg3, 'self_pace' = cfg4.  `only`: run just the bf16 oracle of that name."""
+def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False, only=None, captured=False):
+    """mode 'sum' = cfg3, 'self_pace' = cfg4.  `only`: run just the bf16 oracle of that name.  captured: the iteration (both
+    rollouts, the critic, the losses, the backward) runs as ONE replayed hipGraph on a device clock (graphs.IterationGraph) -- what
+    is compared with the oracle is then the REPLAY's output, one hop away, with the masks of the clock's offsets."""
     import bench
     from oracle import torch_port as O
     H, E, AE, ANG, IMG, V = 512, 256, 64, 128, 2048, 36
@@ -98,6 +100,9 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     acts, masks, rewards, ended = _rl_tape(B, T_rl, ncands, g)
     weight = (torch.rand(B, generator=g) * 0.99 + 0.01) if mode == "self_pace" else None      # uniform [0.01, 1]
     lp = cdt != torch.float32
+    acts_d, rewards_d, masks_d, ended_d = [a.to(dev) for a in acts], [r.to(dev) for r in rewards], [m.to(dev) for m in masks], ended.to(dev)
+    weight_d = None if weight is None else weight.to(dev)
+    clock = vln.DeviceClock(dev).attach(enc, dec, cri) if captured else None
 
     # ---- the HIP path, recording the Philox offsets every module used ------------------------------------------------
     offs = {"enc": [], "dec": [], "cri": []}
@@ -116,7 +121,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
                                     gather=(store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
             hidden.append(h)
             if sample:
-                sampler.step(logit, s["cand_mask"], action=acts[t].to(dev))
+                sampler.step(logit, s["cand_mask"], action=acts_d[t])
             else:
                 ce.add(logit, s["target"], s["cand_mask"])
         if not sample:
@@ -131,8 +136,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
             last_v = cri(last_h).detach()
         offs["cri"].append(cri._calls + 1)
         vals = cri(torch.cat(hidden, 0)).view(T, B)
-        rl, total = vln.losses.a2c_loss(logps, ents, vals, [r.to(dev) for r in rewards], [m.to(dev) for m in masks], last_v,
-                                        ended.to(dev), GAMMA, "total", per_sample=weight is not None)
+        rl, total = vln.losses.a2c_loss(logps, ents, vals, rewards_d, masks_d, last_v, ended_d, GAMMA, "total", per_sample=weight is not None)
         return dict(rl=rl, total=total, logp=logps, ent=ents, vals=vals)
 
     def batch_loss(ml, rl, w):
@@ -141,14 +145,34 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
         bl = torch.dot(w.to(ml.dtype), ml + rl)                              # curriculum.py:296
         return bl / w.sum().to(ml.dtype) if normalised else bl               # curriculum.py:301
 
-    cri.relu_record = []             # the ReLU decisions of the critic's two calls (bootstrap value, all steps' values)
-    il = gpu_rollout(T_il, False)
-    rlr = gpu_rollout(T_rl, True)
-    relu_on = [m.cpu() for m in cri.relu_record]
-    cri.relu_record = None
-    loss = batch_loss(il["ml"], rlr["rl"], None if weight is None else weight.to(dev))
-    loss.backward()
-    torch.cuda.synchronize()
+    def hip_iteration():
+        if clock is not None:
+            clock.tick()
+        for mod in (enc, dec, cri):
+            for prm in mod.parameters():
+                prm.grad = None
+        cri.relu_record = []         # the ReLU decisions of the critic's two calls (bootstrap value, all steps' values)
+        il = gpu_rollout(T_il, False)
+        rlr = gpu_rollout(T_rl, True)
+        relu = list(cri.relu_record)
+        cri.relu_record = None
+        loss = batch_loss(il["ml"], rlr["rl"], weight_d)
+        loss.backward()
+        return il, rlr, relu, loss
+
+    if captured:
+        graph = vln.IterationGraph(hip_iteration, clock).capture(warmup=2)
+        graph.replay()                                   # (a first replay; the second one below is what is compared)
+        il, rlr, relu, loss = graph.replay()
+        torch.cuda.synchronize()
+        vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+        host = clock.host            # call r of a module since the tick draws with the host-counter value host + r (runtime.DeviceClock)
+        assert host == clock.STRIDE * 4    # two eager warm-up iterations + two replays
+        offs = {"enc": [host + 1, host + 2], "dec": [host + 1 + i for i in range(T_il + T_rl + 1)], "cri": [(host + 1) * 8, (host + 2) * 8]}
+    else:
+        il, rlr, relu, loss = hip_iteration()
+        torch.cuda.synchronize()
+    relu_on = [m.cpu() for m in relu]
 
     # ---- the oracle(s) ---------------------------------------------------------------------------------------------------
     variants = [("fp32", FP32, False, None)] if not lp else \
@@ -251,6 +275,13 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_cfg3_il_plus_a2c_full_size(vln, cdt):
     _iteration(vln, cdt, "sum")
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_cfg3_captured_iteration_vs_oracle(vln, cdt):
+    """the cfg3 iteration as ONE replayed hipGraph (device clock, no host code between the 50 decoder steps)
+    against the oracle one hop away -- every loss, log-prob, entropy, value and gradient of the second replay."""
+    _iteration(vln, cdt, "sum", captured=True, only=None if cdt == torch.float32 else "bf16 unrounded")
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
