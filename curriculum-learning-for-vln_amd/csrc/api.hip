@@ -34,7 +34,7 @@ const unsigned long long*& drop_base_tls() {
   static thread_local const unsigned long long* base = nullptr;
   return base;
 }
-int g_tunable[12] = {384, 1, 1, 512, 0, 0, 0, 0, 1, 0, 0, 0};
+int g_tunable[16] = {384, 1, 1, 512, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
 // ---- per-kernel event timers -------------------------------------------------------------------------
 unsigned g_prof_mask = 0;
 namespace {
@@ -88,7 +88,7 @@ extern "C" int vln_graph_stats(int64_t out[3]) {
   return VLN_OK;
 }
 extern "C" int vln_set_tunable(int id, int value) {
-  if (id < 0 || id >= 12) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
+  if (id < 0 || id >= 16) { set_error("vln_set_tunable: bad id"); return VLN_ERR_ARG; }
   g_tunable[id] = value;
   return VLN_OK;
 }

@@ -22,6 +22,7 @@
 namespace vln {
 
 #include "gemm_nt_body.h"
+#include "gemm_rows.h"
 
 template <typename TW, int PD, bool kFast, int NT = 1>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
@@ -141,6 +142,44 @@ int gemm_nt_fused(hipStream_t st, const float* X, long ldx, const void* W, int w
   return reduce_epilogue(st, ws, nsplit, (long)M * N, N, Y, ldy, M, N, bias, act, Y2, ldy2, drop);
 }
 
+// one instantiation of gemm_rows_kernel (LDS above 64 KB needs the attribute, set once)
+template <typename TW, int NRB>
+static int launch_rows_t(hipStream_t st, int tiles, const GemmNTArgs& a, RowTiling rt, double bytes) {
+  constexpr int smem = gemm_rows_smem_bytes<TW, NRB>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<TW, NRB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr_set = true;
+  }
+  launch_timed(K_GEMM_NT, bytes, gemm_rows_kernel<TW, NRB>, dim3(tiles), dim3(256), (unsigned)smem, st, a, rt);
+  VLN_CHECK_LAUNCH("gemm_rows");
+  return VLN_OK;
+}
+// -1: no instantiation for this (weight type, tile height) -- the caller falls back to gemm_nt's tiles
+static int launch_rows(hipStream_t st, int wtype, int rb_max, int tiles, const GemmNTArgs& a, RowTiling rt, double bytes) {
+#define VLN_ROWS(TW)                                                   \
+  do {                                                                 \
+    switch (rb_max) {                                                  \
+      case 3: return launch_rows_t<TW, 3>(st, tiles, a, rt, bytes);    \
+      case 4: return launch_rows_t<TW, 4>(st, tiles, a, rt, bytes);    \
+      case 5: return launch_rows_t<TW, 5>(st, tiles, a, rt, bytes);    \
+      case 6: return launch_rows_t<TW, 6>(st, tiles, a, rt, bytes);    \
+      case 7: return launch_rows_t<TW, 7>(st, tiles, a, rt, bytes);    \
+      case 8: return launch_rows_t<TW, 8>(st, tiles, a, rt, bytes);    \
+      default: return -1;                                              \
+    }                                                                  \
+  } while (0)
+  if (wtype == W_F32) VLN_ROWS(float);
+  if (wtype == W_F32S) VLN_ROWS(f32s_raw);
+  if (wtype == W_F32X) VLN_ROWS(f32x_raw);
+#undef VLN_ROWS
+  return -1;
+}
+
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }
@@ -182,6 +221,17 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
     // Depth 4 was measured slower than depth 2 on every decoder shape (scripts/gemm_probe.hip: LSTM gates 13.0 vs 11.7 us;
     // the M = 5120 encoder projection 52 vs 37 us: 224 VGPRs halve the workgroups per CU): opt-in only, tunable[5] = 4.
     const bool deep = g_tunable[5] == 4 && steps_per > 2;
+    // tall activations whose 64-row tiles do not fill whole rounds of the CUs: 16-row-block tiling (gemm_rows.h), same bits
+    // (not for bf16-streamed weights: two bf16 MFMAs per fragment pair leave nothing to pipeline -- measured 43 vs 42 us and 40 vs 38 us)
+    if (!to_slabs && fast && M >= 256 && wtype != W_BF16 && g_tunable[12] == 0) {
+      RowTiling rt; int tiles = 0, rbm = 0;
+      if (gemm_rows_plan(M, N, device_cus(), &rt, &tiles, &rbm)) {
+        a.xcd = (tiles % 8 == 0 && nb > 1 && g_tunable[8] != 0) ? 1 : 0;
+        const int r = launch_rows(st, wtype, rbm, tiles, a, rt, bytes);
+        if (r != -1) return r;
+        a.xcd = (mb >= 8 && nb > 1 && ((long)nb * nsplit * mb) % 8 == 0 && g_tunable[8] != 0) ? 1 : 0;
+      }
+    }
 #define VLN_NT_LAUNCH(TW, PDv, FASTv) launch_timed(K_GEMM_NT, bytes, gemm_nt_kernel<TW, PDv, FASTv>, grid, block, 0, st, a)
     if (wtype != W_F32 && wtype != W_BF16 && wtype != W_F32S && wtype != W_F32X) { set_error("gemm_nt: unknown weight type %d", wtype); return VLN_ERR_ARG; }
     if (wide && fast && wtype != W_F32S && wtype != W_F32X) {

@@ -71,7 +71,7 @@ typedef struct vln_tick_item { void* word; uint64_t inc; int32_t width; int32_t 
 int vln_tick(const vln_tick_item* items, int n /* 1..VLN_TICK_MAX */, vln_stream_t s);
 /* hipGraph memoisation counters since load: out[0] replays, out[1] captures (= misses), out[2] times a chain's capturing was paused (2 x capacity captures without one replay) */
 int vln_graph_stats(int64_t out[3]);
-/* performance / A-B tunables, ids 0..11 (never change results beyond summation order; documented in
+/* performance / A-B tunables, ids 0..15 (never change results beyond summation order; documented in
  * csrc/vln_internal.h): 0 = gemm split-K workgroup target (256), 1 = keep wide shallow fused-epilogue products unsplit,
  * 2/3 = 16-column GEMM on / its largest K, 4 = two-kernel attention, 5 = gemm_nt form, 6 = weight-gradient form,
  * 7 = persistent-LSTM workgroup order, 8 = XCD-aware tile order of gemm_nt launches with many row tiles (1), 9 = spare, 10 = 1: gradient rides never travel as passengers, 11 = cap on a ride's passenger workgroups */

@@ -58,6 +58,31 @@ def test_linear_fwd_split_fp32_weights(vln, M, N, K):
     assert rel_err(y6, ref) < 4 * max(rel_err(y32, ref), 5e-7), (rel_err(y6, ref), rel_err(y32, ref))
 
 
+@pytest.mark.parametrize("M,N,K", [(1152, 1024, 2176), (1152, 2176, 1024), (5120, 256, 2048), (1100, 1000, 512), (300, 192, 128), (8064, 64, 64)])
+def test_tall_products_row_block_tiling_is_bit_identical(vln, M, N, K):
+    """gemm_rows.h (round 5): tall activations are tiled in 16-row blocks so that the workgroups fill whole rounds of the CUs
+    (the BN-MLP's [1152, 2176] x [1024, 2176]^T: 256 workgroups of 80 / 64 rows instead of 288 of 64).  Same operand paths and the
+    same MFMA sequence per output element as gemm_nt's 64-row tiles: bit-identical results in all four weight forms, with bias,
+    activation and the accumulate flag, at aligned and ragged M / N."""
+    lib = vln._lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev()); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev()); b = torch.randn(N, generator=g).to(dev())
+    y0 = torch.randn(M, N, generator=g).to(dev())
+    for wt, split in ((w, False), (w.bfloat16(), False), (w, True), (w, "x6")):
+        outs = []
+        for keep64 in (1, 0):
+            vln._lib.check(lib.vln_set_tunable(12, keep64), "vln_set_tunable")
+            try:
+                y = vln.ops.linear_fwd(x, wt, b, vln.ops.ACT_TANH, split=split)
+                ya = vln.ops.linear_fwd(x, wt, b, vln.ops.ACT_ACCUM, out=y0.clone(), split=split)
+            finally:
+                vln._lib.check(lib.vln_set_tunable(12, 0), "vln_set_tunable")
+            outs.append((y, ya))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (M, N, K, wt.dtype, split)
+    ref = torch.tanh(x.double() @ w.double().t() + b.double())
+    check(vln.ops.linear_fwd(x, w, b, vln.ops.ACT_TANH), ref, 1e-4, "y (row-block tiling)")
+
+
 @pytest.mark.parametrize("M,N,K,wdt", [(64, 2048, 2752, torch.bfloat16), (128, 2048, 3072, torch.float32), (8, 512, 512, torch.bfloat16)])
 def test_linear_fwd_slabs_sum_to_the_product(vln, M, N, K, wdt):
     """ops.linear_fwd_slabs / vln_linear_fwd_slabs: the product left as its split-K partial slabs (what the one-call decoder steps hand
