@@ -57,9 +57,14 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   RUN(gemm_nt(st, io->img, F, w->w_v, wt, F, io->keys, D, B * V, D, F, w->b_v, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(attn_dot(st, io->keys, W_F32, io->tq, D, io->vlog, B, V, D));
   RUN(attn_softmax_wsum(st, io->img, W_F32, io->vlog, nullptr, io->view_w, io->xcat + A, XK, B, V, F));
-  RUN(copy_blocks2(st, B, io->a_prev, A, io->xcat, XK, A, io->h0, H, io->xcat + A + F, XK, H));
-  if (io->p_drop > 0.f)      // dropout over cat(a_prev, pano) (policy.py:49-51), in place
-    RUN(scale_dropout(st, io->xcat, XK, io->xcat, XK, B, A + F, tls_drop(io->seed, io->off, io->p_drop)));
+  {   // xcat = [drop(a_prev) | drop(pano), in place | h0]: the dropout over cat(a_prev, pano) (policy.py:49-51) in the launch that
+      // copies the two blocks (they were a launch each)
+    const DropSpec dr = tls_drop(io->seed, io->off, io->p_drop);
+    AddNSvJob aj[3] = {{io->xcat, XK, B, A, 1, {plain_vec(io->a_prev, A), SlabVec{}, SlabVec{}, SlabVec{}}, dr, A + F, 0},
+                       {io->xcat + A, XK, B, F, 1, {plain_vec(io->xcat + A, XK), SlabVec{}, SlabVec{}, SlabVec{}}, dr, A + F, A},
+                       {io->xcat + A + F, XK, B, H, 1, {plain_vec(io->h0, H), SlabVec{}, SlabVec{}, SlabVec{}}}};
+    RUN(add_n_sv_multi(st, aj, 3));
+  }
   // (2) LSTM cell; drop(h1) lands in its tcat block
   // the product's K-chunks stay split-K slabs in the workspace: the pointwise launch sums them while it loads (no reduce launch)
   int gate_slabs = 1;
@@ -135,9 +140,17 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     a.c0 = io->c0; a.ldc0 = H; a.dgates = dg; a.lddg = 4 * H; a.dc0 = g->dc0; a.lddc0 = H; a.B = B; a.H = H;
     RUN(lstm_pointwise_bwd(st, a));
   }
-  RUN(gemm_nt(st, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> a_prev | pano | h0
-  if (io->p_drop > 0.f)
-    RUN(scale_dropout(st, dxcat, XK, dxcat, XK, B, A + F, tls_drop(io->seed, io->off, io->p_drop)));
+  {   // d xcat -> a_prev | pano | h0: the product's split-K slabs are summed AND the input dropout's mask applied by one launch
+      // (they were a reduce launch and a dropout launch)
+    SlabArea ar{io->ws, (long)io->ws_floats};
+    SlabVec s_dxcat;
+    RUN(gemm_nt_to_consumer(st, ar, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, &s_dxcat));
+    if (s_dxcat.p != dxcat || io->p_drop > 0.f) {
+      AddNSvJob aj[2] = {{dxcat, XK, B, A + F, 1, {s_dxcat, SlabVec{}, SlabVec{}, SlabVec{}}, tls_drop(io->seed, io->off, io->p_drop), A + F, 0},
+                         {dxcat + A + F, XK, B, H, 1, {s_dxcat.shifted(A + F), SlabVec{}, SlabVec{}, SlabVec{}}}};
+      RUN(add_n_sv_multi(st, aj, s_dxcat.p != dxcat ? 2 : 1));
+    }
+  }
   // (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq); rv = sum_v dl_v img_v comes out of the same pass
   RUN(attn_dot(st, io->img, W_F32, dxcat + A, XK, dalpha, B, V, F));
   RUN(attn_bwd(st, io->img, W_F32, io->view_w, dalpha, g->dvw_ext, nullptr, 0, nullptr, 0, rv, F, nullptr, dl_v, B, V, F));

@@ -1202,7 +1202,9 @@ struct AddNMulti { AddNArgs j[4]; };
 __global__ __launch_bounds__(256) void add_n_multi_kernel(AddNMulti m) { add_n_body(m.j[blockIdx.y]); }
 // The same sums with sources that still lie in split-K slabs (SlabVec): each source's slabs are added in slab order first, then the
 // sources in their order -- the bits of "reduce each product, then add_n" without the reduce launches.
-struct AddNSvArgs { SlabVec src[4]; int n; float* out; long ldo; int rows, cols, vec; };
+// drop (p > 0): the sum is multiplied by a dropout mask whose element index is r * drop_cols + drop_col0 + c -- a column block of
+// a wider dropped row (the Follower's drop([a_prev | pano]), policy.py:49-51)
+struct AddNSvArgs { SlabVec src[4]; int n; float* out; long ldo; int rows, cols, vec; DropSpec drop; int drop_cols, drop_col0; };
 struct AddNSvMulti { AddNSvArgs j[4]; };
 __global__ __launch_bounds__(256) void add_n_sv_multi_kernel(AddNSvMulti m) {
   const AddNSvArgs& a = m.j[blockIdx.y];
@@ -1213,6 +1215,11 @@ __global__ __launch_bounds__(256) void add_n_sv_multi_kernel(AddNSvMulti m) {
       const long r = e / c4, c = (e % c4) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = 0; i < a.n; ++i) { const float4 t = a.src[i].at4(r, c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (a.drop.p > 0.f) {
+        float m[4];
+        dropout_scale4(a.drop.seed, a.drop.off(), (uint32_t)((r * a.drop_cols + a.drop_col0 + c) >> 2), a.drop.p, m);
+        v.x *= m[0]; v.y *= m[1]; v.z *= m[2]; v.w *= m[3];
+      }
       *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = v;
     }
     return;
@@ -1222,6 +1229,7 @@ __global__ __launch_bounds__(256) void add_n_sv_multi_kernel(AddNSvMulti m) {
     const long r = e / a.cols, c = e % a.cols;
     float v = 0.f;
     for (int i = 0; i < a.n; ++i) v += a.src[i].at(r, c);
+    if (a.drop.p > 0.f) v *= dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)(r * a.drop_cols + a.drop_col0 + c), a.drop.p);
     a.out[r * a.ldo + c] = v;
   }
 }
@@ -1261,7 +1269,9 @@ int vln::add_n_sv_multi(hipStream_t st, const AddNSvJob* jobs, int n) {
       vec = vec && al16p(v.p) && (v.ld & 3) == 0 && (v.stride & 3) == 0 && al16p(v.bias);
       a.src[k] = v;
     }
+    if (q.drop.p > 0.f && ((q.drop_cols & 3) || (q.drop_col0 & 3))) vec = false;
     a.n = q.n; a.out = q.out; a.ldo = q.ldo; a.rows = q.rows; a.cols = q.cols; a.vec = vec ? 1 : 0;
+    a.drop = q.drop; a.drop_cols = q.drop_cols; a.drop_col0 = q.drop_col0;
     const long t = (long)q.rows * (vec ? q.cols / 4 : q.cols);
     if (t > most) most = t;
   }

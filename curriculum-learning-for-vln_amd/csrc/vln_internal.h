@@ -94,7 +94,8 @@ int ew_multi(hipStream_t st, const EwJob* jobs, int n);
 struct AddNJob { float* out; long ldo; int rows, cols, n; const float* src[4]; long ld[4]; };
 int add_n_multi(hipStream_t st, const AddNJob* jobs, int n);
 // the same with sources still in split-K slabs (each source's slabs summed in slab order, then the sources in order)
-struct AddNSvJob { float* out; long ldo; int rows, cols, n; SlabVec src[4]; };
+// drop (p > 0): the sum times a dropout mask indexed r * drop_cols + drop_col0 + c (a column block of a wider dropped row)
+struct AddNSvJob { float* out; long ldo; int rows, cols, n; SlabVec src[4]; DropSpec drop = DropSpec{0, 0, 0.f}; int drop_cols = 0, drop_col0 = 0; };
 int add_n_sv_multi(hipStream_t st, const AddNSvJob* jobs, int n);
 // vln_monitor_head_fwd with the gate product W_m [h0 ; moves] still in split-K slabs (+ bias); the sum is written to mg_out
 int monitor_head_fwd_sv(hipStream_t st, SlabVec mg, float* mg_out, const float* c1, const float* word_w, const float* wc, const float* bc,
