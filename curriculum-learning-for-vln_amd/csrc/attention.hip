@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void attn_dot_kernel(const TC* ctx, SlabVec ve
           float4 t = vec.at4(b, d + j);
           if (vmul) { const float4 m = *reinterpret_cast<const float4*>(vmul + d + j); t.x *= m.x; t.y *= m.y; t.z *= m.z; t.w *= m.w; }
           if (wb) *reinterpret_cast<float4*>(vec_out + (long)b * ldvo + d + j) = t;
-          acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
+          acc += dot4(&x[j], t);
         }
       }
     } else {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_dot_multi_kernel(DotMulti m, int vec
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           const float4 w = *reinterpret_cast<const float4*>(v + d + j);
-          acc += x[j] * w.x + x[j + 1] * w.y + x[j + 2] * w.z + x[j + 3] * w.w;
+          acc += dot4(&x[j], w);
         }
       }
     } else {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void cand_sample_kernel(CandSample a) {
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           const float4 t = a.q.at4(b, d + j);
-          acc += x[j] * t.x + x[j + 1] * t.y + x[j + 2] * t.z + x[j + 3] * t.w;
+          acc += dot4(&x[j], t);
         }
       }
     } else {

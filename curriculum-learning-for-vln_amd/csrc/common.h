@@ -192,6 +192,11 @@ struct SlabVec {
 };
 static inline SlabVec plain_vec(const float* p, long ld) { return SlabVec{p, ld, 1, 0}; }
 
+// x[0..3] . t in ONE fixed association.  The candidate-logit kernels (attn_dot_kernel, attn_dot_multi_kernel, cand_sample_kernel) must
+// agree bit for bit (per-step, rollout-wide and in-step forms of the same logits): left to the compiler, the contraction of
+// `a * b + c * d + ...` into fused multiply-adds may differ from one kernel to the next.
+__device__ __forceinline__ float dot4(const float* x, const float4& t) { return fmaf(x[3], t.w, fmaf(x[2], t.z, fmaf(x[1], t.y, x[0] * t.x))); }
+
 struct DropSpec {      // one dropout site; p == 0 disables it
   uint64_t seed;
   uint64_t offset;     // Philox offset of the site -- or, when `step` is set, the site index k of offset = *step * 8 + k

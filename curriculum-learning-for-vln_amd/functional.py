@@ -572,6 +572,10 @@ class BnMlpFn(torch.autograd.Function):
         off = lib.vln_bn_mlp_out_offset(m)
         out_dim = m.layer[nl - 1].out
         ctx.cfg, ctx.bufs, ctx.nl, ctx.rz, ctx.c_call = cfg, bufs, nl, rz, True
+        # the second batch is read in place again by the backward (BatchNorm's d gamma): it rides in `cfg`, not among the saved
+        # tensors, so its version is checked by hand -- what autograd does for a saved tensor that was modified in place
+        seg = cfg[5] if len(cfg) > 5 else None
+        ctx.x2_version = seg[2]._version if (seg and len(seg) > 2) else None
         ctx.save_for_backward(x, saved, *tensors)
         # the output is the last block of `saved` (which the backward reads): the caller gets an alias, the ctx keeps the base
         out = saved[off:off + m.R * out_dim].view(m.R, out_dim).detach()
@@ -586,6 +590,10 @@ class BnMlpFn(torch.autograd.Function):
         tensors = list(ctx.saved_tensors[2:])
         cfg = ctx.cfg
         dtype = cfg[3]
+        if ctx.x2_version is not None and cfg[5][2]._version != ctx.x2_version:
+            raise RuntimeError("MLPwithBN.forward_pair: the second batch (read in place, not copied) was modified in place between "
+                               "the forward and the backward; keep it unchanged until the backward has run, or set "
+                               "`inputs_in_place = False` on the module (one concatenated copy per call)")
         m, keep = BnMlpFn._c_desc(x, ctx.rz, cfg, ctx.bufs, tensors)
         dev = x.device
         if m.R1 > 0:                                   # the two segments' gradients -> the rows of one [R, out] operand (one launch)

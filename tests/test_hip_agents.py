@@ -623,8 +623,9 @@ def test_bn_mlp_two_batches_in_one_call_equal_two_calls(vln, cdt, shape):
     make = lambda: MLPwithBN(F, dims, use_bn=True, dropout=0.3, relu=True)
     sd = {k: v.clone() for k, v in make().state_dict().items()}
     res = {}
-    for mode in ("two", "pair"):
+    for mode in ("two", "pair", "pair_cat"):
         mlp = make(); mlp.load_state_dict(sd); mlp.to(DEV)
+        mlp.inputs_in_place = mode != "pair_cat"                  # round 5: both batches read where they are (vln_bn_mlp.x2) / concatenated first
         n_set = 0
         for m_ in mlp.modules():
             if hasattr(m_, "compute_dtype"):
@@ -656,6 +657,20 @@ def test_bn_mlp_two_batches_in_one_call_equal_two_calls(vln, cdt, shape):
         gscale = max([v.abs().max().item() for v in b[3].values()] + [1e-30])
         for n in b[3]:
             check(a[3][n], b[3][n], 5e-5, f"call {i} grad[{n}]", floor=grad_floor(n, gscale))
+    # the in-place form reads the same numbers through two pointers: bit-identical to the concatenated copy
+    for i, (a, b) in enumerate(zip(res["pair"], res["pair_cat"])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), f"call {i}: outputs differ between the in-place and the concatenated input"
+        for n in b[2]:
+            assert torch.equal(a[2][n], b[2][n]), f"call {i}: buffer {n}"
+        for n in b[3]:
+            assert torch.equal(a[3][n], b[3][n]), f"call {i}: grad[{n}]"
+    # ... and, like a tensor autograd saved, the second batch must not change between the forward and the backward
+    mlp = make(); mlp.load_state_dict(sd); mlp.to(DEV).train()
+    x2m = x2.clone()
+    y1, y2 = mlp.forward_pair(x1, x2m, row_zero2=rz)
+    x2m.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ((y1 * r1).sum() + (y2 * r2).sum()).backward()
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
