@@ -21,6 +21,7 @@ SHAPES = {
     (34 * 7): [("rollout logits query: H -> F, M = T*B", 448, 2176, 512)],
     (8 * 6 * 7): [("rollout logit branch backward: F -> H, M = T*B", 448, 512, 2176)],
     (8 * 80): [("projected context K = ctx W_in: H -> H, M = L*B (round 5)", 5120, 512, 512)],
+    (8 * 64): [("projected context K = ctx W_in on 80-row tiles (gemm_rows.h, round 5): H -> H, M = L*B", 5120, 512, 512)],
     (8 * 7): [("the rollout's text queries W_in hd_t for the context gradient: H -> H, M = T*B (round 5)", 448, 512, 512)],
 }
 
@@ -30,7 +31,7 @@ def rows(d, counters):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if "gemm_nt_kernel" not in n:
+            if "gemm_nt_kernel" not in n and "gemm_rows_kernel" not in n:
                 continue
             wt = "f32s" if "f32s_raw" in n else ("bf16" if "unsigned short" in n else "f32")
             key = (wt, int(r["Grid_Size"]) // int(r["Workgroup_Size"]))

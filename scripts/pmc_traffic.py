@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "gemm_tn_x3_kernel": "gemm_tn",
+NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_rows_kernel": "gemm_nt", "gemm_tn_kernel": "gemm_tn", "gemm_tn_x3_kernel": "gemm_tn",
          "wgrad_packed_kernel": "gemm_tn", "wgrad_grouped_x3_kernel": "gemm_tn", "attn_dot_kernel": "attn_dot",
          "attn_wsum_kernel": "attn_wsum", "attn_bwd_kernel": "attn_bwd", "lstm_persist_fwd_kernel": "lstm_rec_fwd", "lstm_persist_g_fwd_kernel": "lstm_rec_fwd", "lstm_persist_g_bwd_kernel": "lstm_rec_bwd",
          "gather_step_prep_kernel": "gather_step",
