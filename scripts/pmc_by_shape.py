@@ -22,6 +22,7 @@ SHAPES = {
     (8 * 6 * 7): [("rollout logit branch backward: F -> H, M = T*B", 448, 512, 2176)],
     (8 * 80): [("projected context K = ctx W_in: H -> H, M = L*B (round 5)", 5120, 512, 512)],
     (8 * 64): [("projected context K = ctx W_in on 80-row tiles (gemm_rows.h, round 5): H -> H, M = L*B", 5120, 512, 512)],
+    (8 * 10): [("the rollout's text queries W_in hd_t on 48-row tiles (gemm_rows.h): H -> H, M = T*B (round 5)", 448, 512, 512)],
     (8 * 7): [("the rollout's text queries W_in hd_t for the context gradient: H -> H, M = T*B (round 5)", 448, 512, 512)],
 }
 
