@@ -304,6 +304,7 @@ SIGNATURES = {
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
     "vln_monitor_ws_floats": (i64, [ptr]),
+    "vln_gemm_rows_tiling": (i32, [i32, i32, i32, ptr, ptr, ptr]),
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_envdrop_ws_floats": (i64, [C.POINTER(EnvDropDims)]),

@@ -156,6 +156,13 @@ extern "C" int64_t vln_struct_size(const char* name) {
 }
 extern "C" const char* vln_last_error_string(void) { return get_error(); }
 
+// The row tiling a tall product Y[M,N] = X W^T takes (csrc/gemm_rows.h) on a device of `cus` compute units: host arithmetic only
+// (no device call).  Returns 1 and (n_big, rb_big, tiles) -- row tiles [0, n_big) of rb_big 16-row blocks, the others of
+// rb_big - 1, tiles = row tiles x ceil(N / 64) workgroups -- or 0 when the product keeps the 64-row tiles.
+extern "C" int vln_gemm_rows_tiling(int M, int N, int cus, int* n_big, int* rb_big, int* tiles) {
+  return gemm_rows_tiling(M, N, cus, n_big, rb_big, tiles);
+}
+
 extern "C" int vln_linear_fwd_slabs(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, int M, int N, int K, float* ws,
                                     int64_t ws_floats, int* n_slabs, vln_stream_t s) {
   if (!X || !W || !ws || !n_slabs || M <= 0 || N <= 0 || K <= 0 || ws_floats < (int64_t)M * N) {

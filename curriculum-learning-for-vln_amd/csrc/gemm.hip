@@ -180,6 +180,17 @@ static int launch_rows(hipStream_t st, int wtype, int rb_max, int tiles, const G
   return -1;
 }
 
+// host-only view of gemm_rows_plan for the tests: 1 and the tiling when a tall [M, K] x [N, K]^T product would take the row-block
+// tiling on a device of `cus` compute units, 0 when it keeps gemm_nt's 64-row tiles
+int gemm_rows_tiling(int M, int N, int cus, int* n_big, int* rb_big, int* tiles) {
+  RowTiling rt{0, 0}; int t = 0, rbm = 0;
+  if (M < 256 || !gemm_rows_plan(M, N, cus, &rt, &t, &rbm)) return 0;
+  if (n_big) *n_big = rt.n_big;
+  if (rb_big) *rb_big = rt.rb_big;
+  if (tiles) *tiles = t;
+  return 1;
+}
+
 int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
             int M, int N, int K, const float* bias, int act, float* ws, long ws_floats, int* nsplit_out) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: bad dims %d %d %d", M, N, K); return VLN_ERR_ARG; }

@@ -236,9 +236,10 @@ static bool gemm_rows_plan(int M, int N, int cus, RowTiling* rt, int* tiles, int
   for (int R = 1; R <= mbk; ++R) {
     const int rb = (mbk + R - 1) / R;
     if (rb > 8 || rb < 3) continue;
-    if ((long)(R - 1) * rb >= mbk) continue;                   // fewer tiles of this height already cover the rows
     const long cost = (((long)R * nb + cus - 1) / cus) * rb;
-    if (best < 0 || cost < best) { best = cost; best_r = R; best_rb = rb; }     // (ascending R: the first of equal costs has the tallest tiles)
+    // ties go to the tallest tile (ascending R: the first seen), and among tilings of that height to the one with the MOST tiles
+    // (fewer of them are tall; every CU of the round has one)
+    if (best < 0 || cost < best || (cost == best && rb == best_rb)) { best = cost; best_r = R; best_rb = rb; }
   }
   if (best < 0 || best >= old_cost) return false;
   // best_r tiles: n_big of best_rb blocks, the rest best_rb - 1, covering exactly mbk blocks

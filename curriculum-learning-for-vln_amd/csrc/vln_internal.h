@@ -139,6 +139,7 @@ int gemm_nt(hipStream_t st, const float* X, long ldx, const void* W, int wtype, 
 // a product handed to a slab-summing consumer (gemm.hip): `ar` = what is left of the step's workspace
 struct SlabArea { float* base; long left; };
 int gemm_nt_plain_slabs(int M, int N, int K, int wtype, long ws_floats);
+int gemm_rows_tiling(int M, int N, int cus, int* n_big, int* rb_big, int* tiles);   // gemm_rows.h's plan (host arithmetic only)
 int gemm_nt_to_consumer(hipStream_t st, SlabArea& ar, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
                         int M, int N, int K, const float* bias, SlabVec* out);
 

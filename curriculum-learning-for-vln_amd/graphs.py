@@ -26,8 +26,28 @@ from typing import Callable, Optional
 
 import torch
 
+import contextlib
+import gc
+
 from . import _lib
 from .runtime import DeviceClock
+
+
+@contextlib.contextmanager
+def _no_gc_while_capturing():
+    """Python's cyclic collector must not run inside a stream capture: it may destroy objects left over from EARLIER work (an old
+    CUDAGraph, tensors with cross-stream uses, autograd nodes kept alive by a traceback) whose destructors issue device calls that
+    are illegal while a stream captures -- an exception in a destructor aborts the process (seen once in the round-5 test suite:
+    `Fatal Python error: Aborted` with the interpreter "Garbage-collecting" inside an autograd node's apply during a capture).
+    Collect first, keep the collector off for the capture, restore its state after."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class IterationGraph:
@@ -53,7 +73,7 @@ class IterationGraph:
             g.enable_debug_mode()
         epoch0 = self.clock.epoch
         try:
-            with torch.cuda.graph(g, capture_error_mode=capture_error_mode):
+            with _no_gc_while_capturing(), torch.cuda.graph(g, capture_error_mode=capture_error_mode):
                 self.out = self.fn()
         finally:
             # The captured tick did not run: the device words still hold the pre-capture values.  Also when `fn` RAISED inside the
@@ -127,7 +147,7 @@ class SegmentedIterationGraph:
                     # (the early slice issued right before this segment) -- under the default "global" mode such a call from
                     # another thread is an error while ANY stream captures.  Launches from the autograd thread are captured all
                     # the same: capturing is a property of the stream.
-                    with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
+                    with _no_gc_while_capturing(), torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
                         r = fn()
                     if r is not None:
                         self.out = r
@@ -205,7 +225,7 @@ class HandshakeIterationGraph:
         epoch0 = self.clock.epoch
         host_fns = []
         try:
-            with torch.cuda.graph(g):
+            with _no_gc_while_capturing(), torch.cuda.graph(g):
                 for kind, fn in self.segments:
                     if kind == "graph":
                         r = fn()

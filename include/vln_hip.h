@@ -93,6 +93,11 @@ int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* to
  * units.py:69,106,120,144,146,181-184 and policy.py:115,124,189,204.  ws: split-K scratch (may be NULL). */
 int vln_linear_fwd(const float* X, int64_t ldx, const void* W, int wtype, int64_t ldw, float* Y, int64_t ldy,
                    int M, int N, int K, const float* bias, int act, float* ws, int64_t ws_floats, vln_stream_t s);
+/* ABI v16, host arithmetic only (no device call): the row tiling a tall product (M >= 256 rows, fp32 / split-fp32 weights, not
+ * split over K) takes on a device of `cus` compute units -- csrc/gemm_rows.h: row tiles [0, n_big) of rb_big 16-row blocks, the
+ * others of rb_big - 1, `tiles` = row tiles x ceil(N / 64) workgroups chosen to fill whole rounds of the CUs.  Returns 1 and the
+ * tiling, or 0 when the product keeps the 64 x 64 tiles.  The results do not depend on the tiling (bit-identical). */
+int vln_gemm_rows_tiling(int M, int N, int cus, int* n_big, int* rb_big, int* tiles);
 /* The same product left as its split-K partial slabs (ABI v14): slabs [*n_slabs][M,N] in ws, Y = their sum in slab order -- for a
  * consumer that adds the partials while it loads them (vln_lstm_pointwise_fwd's `nsplit`), so that no reduce launch sits between the
  * two.  ws_floats >= M * N; more lets the contraction split over more workgroups. */

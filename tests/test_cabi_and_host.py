@@ -224,3 +224,36 @@ def test_every_public_struct_has_a_size_checked_mirror():
         L.STRUCT_MIRRORS["vln_monitor_grads"] = good
         L._lib = None
         L.load()
+
+
+def test_row_block_tiling_of_tall_products_covers_every_row_once(vln):
+    """csrc/gemm_rows.h's plan (host arithmetic, `vln_gemm_rows_tiling`): for every tall shape the row tiles -- n_big of rb_big
+    16-row blocks, the rest of rb_big - 1 -- cover exactly ceil(M / 16) blocks, no tile is empty or taller than the 8 blocks the
+    kernels are instantiated for, the workgroup count is (row tiles) x ceil(N / 64), and the tiling is only taken when it needs
+    fewer block-rounds over the CUs than 64-row tiles would.  A wrong tiling would skip or repeat rows silently."""
+    import ctypes as C
+    lib = vln._lib.load()
+    n_big, rb_big, tiles = C.c_int(), C.c_int(), C.c_int()
+    taken = 0
+    for cus in (256, 304, 64):
+        for N in (64, 96, 256, 512, 1000, 1024, 2176):
+            nb = (N + 63) // 64
+            for M in list(range(256, 1400, 7)) + [1152, 2304, 4096, 5000, 5120, 8064, 65536]:
+                ok = lib.vln_gemm_rows_tiling(M, N, cus, C.byref(n_big), C.byref(rb_big), C.byref(tiles))
+                if not ok:
+                    continue
+                taken += 1
+                mbk = (M + 15) // 16
+                rb, nbig = rb_big.value, n_big.value
+                assert 2 <= rb <= 8 and tiles.value % nb == 0, (M, N, cus)
+                R = tiles.value // nb
+                assert 1 <= nbig <= R, (M, N, cus, nbig, R)
+                assert nbig * rb + (R - nbig) * (rb - 1) == mbk, (M, N, cus, nbig, rb, R)
+                assert rb > 1 or nbig == R                                      # no tile of zero blocks
+                rounds = lambda t: (t + cus - 1) // cus
+                assert rounds(tiles.value) * rb < rounds(((M + 63) // 64) * nb) * 4, (M, N, cus)
+    assert taken > 100
+    # the BN-MLP forward at BASELINE config 2 (B 128, C 8): 256 workgroups of 80 / 64 rows
+    assert lib.vln_gemm_rows_tiling(1152, 1024, 256, C.byref(n_big), C.byref(rb_big), C.byref(tiles)) == 1
+    assert (n_big.value, rb_big.value, tiles.value) == (8, 5, 256)
+    assert lib.vln_gemm_rows_tiling(128, 1024, 256, C.byref(n_big), C.byref(rb_big), C.byref(tiles)) == 0      # skinny: gemm_nt's own tiles
