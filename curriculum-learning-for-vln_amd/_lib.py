@@ -182,7 +182,7 @@ class BnMlpGradLayer(C.Structure):
 
 class BnMlpGrads(C.Structure):
     _fields_ = [("g_gamma0", ptr), ("g_beta0", ptr), ("acc0", i32), ("pad0_", i32), ("layer", BnMlpGradLayer * BN_MLP_MAX_LAYERS),
-                ("precision", i32), ("pad_", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))]
+                ("precision", i32), ("bn0_from_wgrad", i32), ("scratch", ptr), ("scratch_floats", i64), ("defer", C.POINTER(ParamJobs))]
 
 
 # C struct name -> ctypes mirror: load() compares sizeof on both sides (vln_struct_size)
@@ -304,6 +304,7 @@ SIGNATURES = {
     "vln_follower_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),
     "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
     "vln_monitor_ws_floats": (i64, [ptr]),
+    "vln_bn0_grads_from_wgrad": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_gemm_rows_tiling": (i32, [i32, i32, i32, ptr, ptr, ptr]),
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),
     "vln_monitor_step_bwd": (i32, [ptr, ptr, ptr, ptr, ptr]),

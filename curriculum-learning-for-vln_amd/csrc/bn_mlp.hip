@@ -131,6 +131,10 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
   float* sc = g->scratch;
   long so = 0;
   auto take = [&](long n) { float* p = sc + so; so += r64(n); return p; };
+  // the input BatchNorm's d gamma / d beta from the first layer's weight gradient (vln_bn0_grads_from_wgrad): nothing below the
+  // first layer's BatchNorm backward is formed here
+  const bool skip0 = g->bn0_from_wgrad != 0;
+  if (skip0 && (dx || !tr || !g->defer)) { set_error("vln_bn_mlp_bwd: bn0_from_wgrad needs training mode, no input gradient and deferred parameter jobs"); return VLN_ERR_ARG; }
   vln_wgrad_job wj[VLN_BN_MLP_MAX_LAYERS];
   vln_colsum_job cj[VLN_BN_MLP_MAX_LAYERS];
   int nw = 0, nc = 0;
@@ -150,6 +154,7 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
                    l.offset2, tr ? l.p_drop : 0.f, last ? m->row_zero : nullptr, ws, ws_floats, s));
     if (g->layer[i].g_w) wj[nw++] = vln_wgrad_job{dz, yprev, g->layer[i].g_w, l.out, in, in, l.out, in, g->layer[i].acc_w, 0};
     if (g->layer[i].g_b && l.b) cj[nc++] = vln_colsum_job{dz, g->layer[i].g_b, nullptr, l.out, l.out, g->layer[i].acc_b};
+    if (skip0 && i == 0) break;
     float* gi = take((long)R * in);
     RUN(gemm_nt(st, dz, l.out, l.w_t, m->wtype, l.out, gi, in, R, in, l.out, nullptr, ACT_NONE, ws, lin_ws(ws_floats, R, in), nullptr));
     gcur = gi; ldg = in;
@@ -167,9 +172,67 @@ extern "C" int vln_bn_mlp_bwd(const vln_bn_mlp* m, const float* x, int64_t ldx, 
     if (nw) RUN(wgrad_grouped(st, wj, nw, R, prec, ws, ws_floats));
     if (nc) RUN(colsum_grouped(st, cj, nc, R, ws, ws_floats));
   }
+  if (skip0) return VLN_OK;
   const float* s0 = saved + L.s0;
   RUN(bn_bwd_seg(x, ldx, gcur, ldg, nullptr, 0, m->bn0.gamma, tr ? s0 : m->bn0.run_mean, tr ? s0 + m->D0 : m->bn0.run_var, dx, lddx,
                  g->g_gamma0, g->g_beta0, R, m->R1, 2L * m->D0, m->D0, m->eps, tr, 0, g->acc0, 0, 0, 0, 0.f, nullptr, ws, ws_floats, s,
                  m->x2, m->ldx2));
+  return VLN_OK;
+}
+
+
+// ---- the input BatchNorm's parameter gradients from the first layer's weight gradient (include/vln_hip.h) ------------------------------
+namespace vln {
+struct Bn0FromW {
+  const float* dW; const float* db; const float* W; long ldw; const float* gamma; const float* beta;
+  float* gW; float* gb; float* gg; float* gbeta; float* part; int N, K, nch, per, acc_w, acc_b, acc_bn; unsigned* sticky;
+};
+// grid (ceil(K / 256), nch): thread = column k, workgroup row = a chunk of `per` rows n; partial sums -> part[chunk][2][K]
+__global__ __launch_bounds__(256) void bn0_from_wgrad_part_kernel(Bn0FromW a) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  const int n0 = blockIdx.y * a.per, n1 = min(a.N, n0 + a.per);
+  const float g = a.gamma[k], bt = a.beta[k];
+  const bool bad = g == 0.f;
+  if (bad && blockIdx.y == 0 && a.sticky) atomicAdd(a.sticky + 4, 1u);
+  const float inv = bad ? 0.f : 1.f / g;
+  float sg = 0.f, sb = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float d = a.dW[(long)n * a.K + k], w = a.W[(long)n * a.ldw + k], s = a.db[n];
+    sg += (d - bt * s) * inv * w;
+    sb += s * w;
+    float* o = a.gW + (long)n * a.K + k;
+    *o = a.acc_w ? *o + d : d;
+  }
+  a.part[((long)blockIdx.y * 2 + 0) * a.K + k] = sg;
+  a.part[((long)blockIdx.y * 2 + 1) * a.K + k] = sb;
+}
+// the chunks' partials in chunk order -> d gamma / d beta; the layer's bias gradient handed on
+__global__ __launch_bounds__(256) void bn0_from_wgrad_finish_kernel(Bn0FromW a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.K) {
+    float sg = 0.f, sb = 0.f;
+    for (int c = 0; c < a.nch; ++c) { sg += a.part[((long)c * 2 + 0) * a.K + i]; sb += a.part[((long)c * 2 + 1) * a.K + i]; }
+    if (a.gg) a.gg[i] = a.acc_bn ? a.gg[i] + sg : sg;
+    if (a.gbeta) a.gbeta[i] = a.acc_bn ? a.gbeta[i] + sb : sb;
+  }
+  if (i < a.N && a.gb) a.gb[i] = a.acc_b ? a.gb[i] + a.db[i] : a.db[i];
+}
+}  // namespace vln
+
+extern "C" int vln_bn0_grads_from_wgrad(const float* dW, const float* db, const float* W, int64_t ldw, const float* gamma, const float* beta,
+                                        float* gW, float* gb, float* g_gamma, float* g_beta, int N, int K, int acc_w, int acc_b, int acc_bn,
+                                        float* ws, int64_t ws_floats, vln_stream_t s) {
+  if (!dW || !db || !W || !gamma || !beta || !gW || !ws || N <= 0 || K <= 0 || ldw < K) { set_error("vln_bn0_grads_from_wgrad: bad args"); return VLN_ERR_ARG; }
+  int nch = 32;
+  if (nch > N) nch = N;
+  if ((int64_t)nch * 2 * K > ws_floats) { set_error("vln_bn0_grads_from_wgrad: workspace below %d * 2 * K floats", nch); return VLN_ERR_ARG; }
+  Bn0FromW a{dW, db, W, (long)ldw, gamma, beta, gW, gb, g_gamma, g_beta, ws, N, K, nch, (N + nch - 1) / nch, acc_w, acc_b, acc_bn, sticky_dev_word()};
+  a.nch = (N + a.per - 1) / a.per;
+  hipStream_t st = (hipStream_t)s;
+  VLN_LAUNCH(bn0_from_wgrad_part_kernel, dim3((K + 255) / 256, a.nch), dim3(256), 0, st, a);
+  const int most = K > N ? K : N;
+  VLN_LAUNCH(bn0_from_wgrad_finish_kernel, dim3((most + 255) / 256), dim3(256), 0, st, a);
+  VLN_CHECK_LAUNCH("bn0_grads_from_wgrad");
   return VLN_OK;
 }

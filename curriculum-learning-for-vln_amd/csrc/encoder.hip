@@ -726,6 +726,13 @@ extern "C" int vln_persistent_check(void) {
                 "of its turn); the steps behind it ran on whatever their inputs held: that iteration's numbers are invalid", n, d);
       return VLN_ERR_HIP;
     }
+    if (__atomic_load_n(&h[d * 16 + 4], __ATOMIC_RELAXED)) {
+      const unsigned n = __atomic_exchange_n(&h[d * 16 + 4], 0u, __ATOMIC_RELAXED);
+      set_error("%u weight(s) of an input BatchNorm were exactly 0 on device %d in an EARLIER launch (vln_bn0_grads_from_wgrad divides the "
+                "first layer's weight gradient by them): their d gamma was left 0; form the gradients by the direct path instead "
+                "(functional.set_bn0_grads_from_wgrad(False))", n, d);
+      return VLN_ERR_ARG;
+    }
   }
   return VLN_OK;
 }

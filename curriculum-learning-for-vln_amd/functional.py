@@ -189,6 +189,16 @@ class RolloutWgrads:
                 if stride is None:
                     stride = tuple(tuple(0 for _ in u) for u in p0)
                 dev = pend[i][2][0].device
+                # BnMlpFn's input BatchNorm from the first layer's weight gradient: that layer's dW / db of THIS run of steps go to
+                # temporaries (not yet into the accumulated gradients), vln_bn0_grads_from_wgrad hands them on
+                meta = next((k["bn0"] for k in pend[i][2] if isinstance(k, dict) and "bn0" in k), None)
+                if meta is not None:
+                    N_, K_ = meta["W"].shape
+                    tmpW = ops.empty(N_, K_, dtype=torch.float32, device=dev); tmpb = ops.empty(N_, dtype=torch.float32, device=dev)
+                    jw = next(k for k in range(nw) if base.w[k].dw == meta["gW"].data_ptr())
+                    jc = next(k for k in range(nc) if base.c[k].out1 == meta["gb"].data_ptr())
+                    base.w[jw].dw, base.w[jw].accumulate = tmpW.data_ptr(), 0
+                    base.c[jc].out1, base.c[jc].accumulate = tmpb.data_ptr(), 0
                 if nw:
                     dy_s = (_lib.i64 * nw)(*[v // 4 for v in stride[0]]); x_s = (_lib.i64 * nw)(*[v // 4 for v in stride[1]])
                     need = max(int(lib.vln_wgrad_grouped_ws_floats(base.w, nw, base.rows * n_seg)), 1 << 22)
@@ -200,11 +210,25 @@ class RolloutWgrads:
                     ws = ops.workspace(dev, 1 << 22)
                     _lib.check(lib.vln_colsum_grouped_seg(base.c, c_s, nc, base.rows, n_seg, ws.data_ptr(), ws.numel(), st),
                                "vln_colsum_grouped_seg")
+                if meta is not None:
+                    ws = ops.workspace(dev, 1 << 22)
+                    _lib.check(lib.vln_bn0_grads_from_wgrad(tmpW.data_ptr(), tmpb.data_ptr(), meta["W"].data_ptr(), meta["W"].stride(0),
+                                                            meta["gamma"].data_ptr(), meta["beta"].data_ptr(), meta["gW"].data_ptr(),
+                                                            meta["gb"].data_ptr(), meta["gg"].data_ptr(), meta["gbeta"].data_ptr(), N_, K_,
+                                                            1, 1, 1, ws.data_ptr(), ws.numel(), st), "vln_bn0_grads_from_wgrad")
                 self.stats[1] += 1
                 i = j
 
 
 ROLLOUT_WGRADS = RolloutWgrads()
+_BN0_FROM_WGRAD = [True]
+
+
+def set_bn0_grads_from_wgrad(on: bool):
+    """BnMlpFn with rollout-level parameter gradients and an input that carries no gradient: the INPUT BatchNorm's d gamma / d beta
+    from the first Linear layer's weight gradient (vln_bn0_grads_from_wgrad: no dz W product, no BatchNorm backward over the input
+    rows) -- the default -- or by the direct path (False; A/B, and the way out when a BatchNorm weight is exactly 0)."""
+    _BN0_FROM_WGRAD[0] = bool(on)
 
 
 def set_rollout_wgrads(on: bool):
@@ -633,10 +657,19 @@ class BnMlpFn(torch.autograd.Function):
         g.precision = ops.wgrad_precision(base_dtype(dtype) != torch.float32)
         pj = None
         in_place = all(g.layer[i].acc_w and (tensors[3 + 4 * i] is None or g.layer[i].acc_b) for i in range(ctx.nl))
+        bn0_meta = None
         if ctx.rw is not None and ROLLOUT_WGRADS.enabled and in_place:
             scratch = ROLLOUT_WGRADS.scratch(ctx.rw[0], ctx.rw[1], lib.vln_bn_mlp_bwd_scratch_floats(m), dev)
             pj = _lib.ParamJobs()
             g.defer = C.pointer(pj)
+            W0, b0_ = tensors[2], tensors[3]
+            if _BN0_FROM_WGRAD[0] and not ctx.needs_input_grad[0] and cfg[0] and a0 and b0_ is not None and W0.is_contiguous() and \
+                    W0.dtype == torch.float32:
+                # the input carries no gradient: its BatchNorm's d gamma / d beta come from the first layer's rollout-level weight
+                # gradient (RolloutWgrads.flush -> vln_bn0_grads_from_wgrad); this call skips dz W and the BatchNorm backward
+                g.bn0_from_wgrad = 1
+                bn0_meta = {"bn0": dict(W=W0.detach(), gamma=tensors[0].detach(), beta=tensors[1].detach(), gW=keepg[2], gb=keepg[3],
+                                        gg=g0, gbeta=b0)}
         else:
             scratch = ops.empty(lib.vln_bn_mlp_bwd_scratch_floats(m), dtype=torch.float32, device=dev)
         g.scratch, g.scratch_floats = scratch.data_ptr(), scratch.numel()
@@ -647,7 +680,7 @@ class BnMlpFn(torch.autograd.Function):
         if rc:
             _lib.check(rc, "vln_bn_mlp_bwd")
         if pj is not None:
-            ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (saved, scratch, keep, keepg))
+            ROLLOUT_WGRADS.defer(ctx.rw[0], ctx.rw[1], pj, (saved, scratch, keep, keepg) + ((bn0_meta,) if bn0_meta else ()))
         return (dx, None, None, None) + tuple(grads)
 
     @staticmethod

@@ -535,10 +535,26 @@ typedef struct vln_bn_mlp_grad_layer { float* g_w; float* g_b; float* g_gamma; f
 typedef struct vln_bn_mlp_grads {
   float* g_gamma0; float* g_beta0; int32_t acc0, pad0_;
   vln_bn_mlp_grad_layer layer[VLN_BN_MLP_MAX_LAYERS];
-  int32_t precision, pad_;          /* weight gradients: 0 fp32, 1 split bf16, 2 plain bf16 (vln_wgrad_grouped) */
+  int32_t precision;                /* weight gradients: 0 fp32, 1 split bf16, 2 plain bf16 (vln_wgrad_grouped) */
+  int32_t bn0_from_wgrad;           /* ABI v16.  1 (training, dx == NULL, `defer` set): the input BatchNorm's d gamma / d beta are NOT formed
+                                     * here -- the call skips the product dz W of the first layer and the BatchNorm backward over the
+                                     * [R, D0] input that would only feed them; the caller derives them from the first layer's own weight
+                                     * gradient with vln_bn0_grads_from_wgrad (below) */
   float* scratch; int64_t scratch_floats;     /* vln_bn_mlp_bwd_scratch_floats */
   vln_param_jobs* defer;                      /* nullable (ABI v11): the Linear weight / bias gradients as jobs, see vln_param_jobs */
 } vln_bn_mlp_grads;
+/* The INPUT BatchNorm's parameter gradients of a BN-MLP whose input carries no gradient (the Self-Monitor projects raw features,
+ * policy.py:146-149), from the first Linear layer's weight gradient instead of a pass over the rows (ABI v16).  With y0 = gamma * xhat + beta
+ * the layer's input, dW[n,k] = sum_r dz[r,n] y0[r,k] = gamma_k A[n,k] + beta_k db[n] where A = dz^T xhat and db = sum_r dz[r,:], so
+ *   d gamma_k = sum_r (dz W)[r,k] xhat[r,k] = sum_n A[n,k] W[n,k] = sum_n (dW[n,k] - beta_k db[n]) / gamma_k * W[n,k]
+ *   d beta_k  = sum_r (dz W)[r,k]           = sum_n db[n] W[n,k]
+ * -- the [R, K] product dz W and the BatchNorm backward over the [R, K] input are never formed (at BASELINE config 2: 5.1 GFLOP and two
+ * passes over 10 MB per decoder step).  dW [N,K] / db [N] hold THIS rollout's sums (not yet added to the accumulated gradients); the call
+ * also adds them to gW / gb (acc_w / acc_b = 0: stores them).  g_gamma / g_beta: acc_bn = 1 adds.  ws: >= 64 * K floats.  A gamma_k of
+ * exactly 0 has no quotient: the launch raises the sticky status word 4 (vln_persistent_check) and leaves d gamma_k = 0. */
+int vln_bn0_grads_from_wgrad(const float* dW, const float* db, const float* W /*fp32 master [N,K]*/, int64_t ldw, const float* gamma,
+                             const float* beta, float* gW, float* gb, float* g_gamma, float* g_beta, int N, int K, int acc_w, int acc_b,
+                             int acc_bn, float* ws, int64_t ws_floats, vln_stream_t s);
 int64_t vln_bn_mlp_saved_floats(const vln_bn_mlp* m);
 int64_t vln_bn_mlp_out_offset(const vln_bn_mlp* m);
 int64_t vln_bn_mlp_ws_floats(const vln_bn_mlp* m);            /* forward and backward workspace (split-K slabs, chunked-BN partials) */

@@ -594,7 +594,12 @@ def test_rollout_level_parameter_gradients_equal_per_step(vln, agent, cdt):
             assert torch.equal(x, y), f"rollout {rollout} output {i}"
         gscale = max(v.abs().max().item() for v in b[1].values())
         for n in b[1]:
-            check(a[1][n], b[1][n], 2e-5, f"grad[{n}]", floor=grad_floor(n, gscale))
+            # The input BatchNorm's bias (mlp.0.bias) has a gradient of zero in exact arithmetic: both sides hold rounding noise, and
+            # since round 5 not the same noise -- the rollout-level path forms it as sum_n db[n] W[n,k] from the first layer's bias
+            # gradient and the fp32 weights (vln_bn0_grads_from_wgrad), the per-step path as the column sums of dz W, whose bf16-mode
+            # product carries 2^-16 per term.  Judged on 1e-2 of the module's largest gradient like every exact zero.
+            tol_n = 5e-4 if n.endswith("mlp.0.bias") else 2e-5
+            check(a[1][n], b[1][n], tol_n, f"grad[{n}]", floor=grad_floor(n, gscale))
         for i, (x, y) in enumerate(zip(a[2], b[2])):
             assert torch.equal(x, y), f"rollout {rollout} input grad {i}"
     for n in res[1][0][1]:                                      # the second rollout reproduces the first (slots reused correctly)
