@@ -142,13 +142,17 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   }
   {   // d xcat -> a_prev | pano | h0: the product's split-K slabs are summed AND the input dropout's mask applied by one launch
       // (they were a reduce launch and a dropout launch)
+    // The previous action's block of d xcat (columns [0, A): 2176 of 4608) is wanted only when a_prev carries a gradient -- it is a
+    // feature row in the reference's agents -- so the product starts at column c0 = A then (rows c0.. of the transposed weight).
     SlabArea ar{io->ws, (long)io->ws_floats};
     SlabVec s_dxcat;
-    RUN(gemm_nt_to_consumer(st, ar, dg, 4 * H, w->w_cat_t, wt, 4 * H, dxcat, XK, B, XK, 4 * H, nullptr, &s_dxcat));
-    if (s_dxcat.p != dxcat || io->p_drop > 0.f) {
-      AddNSvJob aj[2] = {{dxcat, XK, B, A + F, 1, {s_dxcat, SlabVec{}, SlabVec{}, SlabVec{}}, tls_drop(io->seed, io->off, io->p_drop), A + F, 0},
-                         {dxcat + A + F, XK, B, H, 1, {s_dxcat.shifted(A + F), SlabVec{}, SlabVec{}, SlabVec{}}}};
-      RUN(add_n_sv_multi(st, aj, s_dxcat.p != dxcat ? 2 : 1));
+    const int c0 = g->da_prev ? 0 : A;
+    const char* wct = static_cast<const char*>(w->w_cat_t) + (size_t)c0 * 4 * H * (wt == W_BF16 ? 2 : 4);
+    RUN(gemm_nt_to_consumer(st, ar, dg, 4 * H, wct, wt, 4 * H, dxcat + c0, XK, B, XK - c0, 4 * H, nullptr, &s_dxcat));
+    if (s_dxcat.p != dxcat + c0 || io->p_drop > 0.f) {
+      AddNSvJob aj[2] = {{dxcat + c0, XK, B, A + F - c0, 1, {s_dxcat, SlabVec{}, SlabVec{}, SlabVec{}}, tls_drop(io->seed, io->off, io->p_drop), A + F, c0},
+                         {dxcat + A + F, XK, B, H, 1, {s_dxcat.shifted(A + F - c0), SlabVec{}, SlabVec{}, SlabVec{}}}};
+      RUN(add_n_sv_multi(st, aj, s_dxcat.p != dxcat + c0 ? 2 : 1));
     }
   }
   // (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq); rv = sum_v dl_v img_v comes out of the same pass
