@@ -192,6 +192,9 @@ class RolloutWgrads:
                 # BnMlpFn's input BatchNorm from the first layer's weight gradient: that layer's dW / db of THIS run of steps go to
                 # temporaries (not yet into the accumulated gradients), vln_bn0_grads_from_wgrad hands them on
                 meta = next((k["bn0"] for k in pend[i][2] if isinstance(k, dict) and "bn0" in k), None)
+                with_meta = sum(1 for q in pend[i:j] if any(isinstance(k, dict) and "bn0" in k for k in q[2]))
+                if with_meta not in (0, n_seg):
+                    raise _lib.VlnError("RolloutWgrads: set_bn0_grads_from_wgrad changed between the steps of one rollout")
                 if meta is not None:
                     N_, K_ = meta["W"].shape
                     tmpW = ops.empty(N_, K_, dtype=torch.float32, device=dev); tmpb = ops.empty(N_, dtype=torch.float32, device=dev)
