@@ -247,6 +247,22 @@ def colsum(a, out=None, accumulate=False):
     return out
 
 
+def bn0_grads_from_wgrad(dW, db, W, gamma, beta, gW, gb, g_gamma, g_beta, accumulate=True):
+    """The input BatchNorm's d gamma / d beta of a BN-MLP from its first Linear layer's weight / bias gradient of ONE rollout
+    (include/vln_hip.h, vln_bn0_grads_from_wgrad): d gamma_k = sum_n (dW[n,k] - beta_k db[n]) / gamma_k W[n,k], d beta_k =
+    sum_n db[n] W[n,k]; dW / db are handed on into gW / gb.  accumulate: the four targets are added to (else stored)."""
+    lib = _lib.load()
+    N, K = W.shape
+    for t, what in ((dW, "dW"), (W, "W"), (gW, "gW")):
+        assert t.shape == (N, K) and t.dtype == torch.float32 and t.stride(1) == 1, what
+    assert dW.is_contiguous() and gW.is_contiguous()
+    ws = workspace(W.device, 64 * K)
+    acc = 1 if accumulate else 0
+    _lib.check(lib.vln_bn0_grads_from_wgrad(dW.data_ptr(), db.data_ptr(), W.data_ptr(), W.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                            gW.data_ptr(), _p(gb), _p(g_gamma), _p(g_beta), N, K, acc, acc, acc, ws.data_ptr(), ws.numel(),
+                                            _stream()), "vln_bn0_grads_from_wgrad")
+
+
 def transpose_cast(w, dtype=torch.float32, out=None):
     lib = _lib.load()
     _req(w, "w")

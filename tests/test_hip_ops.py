@@ -627,3 +627,43 @@ def test_attention_dctx_deferred_second_output(vln):
                                    [gw[t].data_ptr() for t in range(T)], 2 * D, [q[t].data_ptr() + 4 * D for t in range(T)], 2 * D, out,
                                    accumulate=acc, dk=dk)
         check(out, ref_a + (0.5 if acc else 0.0), 1e-5, "dctx half"); check(dk, ref_k, 1e-5, "dk half")
+
+
+@pytest.mark.parametrize("N,K", [(1024, 2176), (96, 300), (33, 64)])
+def test_input_batchnorm_gradients_from_the_first_layers_weight_gradient(vln, N, K):
+    """vln_bn0_grads_from_wgrad (round 5): with y0 = gamma * xhat + beta the first Linear layer's input and x itself carrying no
+    gradient, d gamma / d beta of the input BatchNorm follow from that layer's dW = dz^T y0 and db = sum_r dz -- against the direct
+    definition d gamma_k = sum_r (dz W)[r,k] xhat[r,k], d beta_k = sum_r (dz W)[r,k] in fp64, on a random batch; the layer's own
+    dW / db are handed on into the accumulated gradients; a gamma of exactly 0 is reported, not divided by."""
+    g = torch.Generator().manual_seed(N + K)
+    R = 200
+    xhat = torch.randn(R, K, generator=g).double()
+    gamma = (torch.rand(K, generator=g) + 0.5).double() * torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0).double()
+    beta = torch.randn(K, generator=g).double() * 0.3
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).double()
+    dz = torch.randn(R, N, generator=g).double()
+    y0 = xhat * gamma + beta
+    dW, db = dz.t() @ y0, dz.sum(0)
+    gfull = dz @ W
+    ref_gg, ref_gb = (gfull * xhat).sum(0), gfull.sum(0)
+    f = lambda t: t.float().to(dev())
+    gW0, gb0, gg0, gbeta0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g), torch.randn(K, generator=g), torch.randn(K, generator=g)
+    gW, gb, gg, gbeta = f(gW0.double()), f(gb0.double()), f(gg0.double()), f(gbeta0.double())
+    vln.ops.bn0_grads_from_wgrad(f(dW), f(db), f(W), f(gamma), f(beta), gW, gb, gg, gbeta, accumulate=True)
+    check(gg - f(gg0.double()), ref_gg, 2e-5, "d gamma of the input BatchNorm")
+    check(gbeta - f(gbeta0.double()), ref_gb, 2e-5, "d beta of the input BatchNorm")
+    check(gW, gW0.double() + dW, 1e-6, "the layer's weight gradient handed on")
+    check(gb, gb0.double() + db, 1e-6, "the layer's bias gradient handed on")
+    gg2, gbeta2 = torch.empty(K, device=dev()), torch.empty(K, device=dev())
+    vln.ops.bn0_grads_from_wgrad(f(dW), f(db), f(W), f(gamma), f(beta), torch.empty(N, K, device=dev()), torch.empty(N, device=dev()), gg2, gbeta2,
+                                 accumulate=False)
+    check(gg2, ref_gg, 2e-5, "d gamma (stored)")
+    # a BatchNorm weight of exactly 0: no quotient -- the launch says so through the sticky status line and leaves that d gamma 0
+    lib = vln._lib.load()
+    assert lib.vln_persistent_check() == 0
+    gz = f(gamma).clone(); gz[3] = 0.0
+    vln.ops.bn0_grads_from_wgrad(f(dW), f(db), f(W), gz, f(beta), torch.empty(N, K, device=dev()), torch.empty(N, device=dev()), gg2, gbeta2, accumulate=False)
+    torch.cuda.synchronize()
+    assert float(gg2[3]) == 0.0 and torch.isfinite(gg2).all()
+    assert lib.vln_persistent_check() != 0 and b"set_bn0_grads_from_wgrad" in lib.vln_last_error_string()
+    assert lib.vln_persistent_check() == 0
