@@ -20,8 +20,10 @@ _p = ops._p
 # ---- the rollout's context gradient in ONE buffer (round 5) ----------------------------------------------------------------------
 # Every decoder step of a rollout attends the SAME encoder context, so autograd received T [B,L,H] gradients per rollout (21 MB each
 # at B 128 / L 80 / H 512) and summed them with T - 1 element-wise adds.  With the context passed through `gated_ctx` the steps'
-# backward calls accumulate into one buffer in place (the C steps' `dctx_accumulate`), hand autograd None, and the identity node
-# `runtime.CtxGate` -- whose backward runs once every step that consumed its output has run -- returns the buffer.
+# backward calls hand autograd None and only REPORT their term (`vln_dctx_term`: the addresses of alpha, dl, g, q and the step's
+# pe-dropout site); the identity node `runtime.CtxGate` -- whose backward runs once every step that consumed its output has run --
+# forms all T terms with ONE launch and returns the buffer.  (`DEFER_DCTX[0] = False`: the steps add their terms to the rollout's
+# buffer in place, one launch each -- the C steps' `dctx_accumulate`.)
 _CTX_ENTRIES = {}
 
 
