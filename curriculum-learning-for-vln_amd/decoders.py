@@ -139,6 +139,13 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
                 raise _lib.VlnError("AttnDecoderLSTM: a DeviceClock needs the C-call step (c_step=True)")
             if self.c_step:          # the rollout's context gradient accumulates in ONE buffer (monitor_step.gated_ctx)
                 ctx = gated_ctx(ctx)[0]
+                # every weight shadow the step streams, refreshed (when an optimizer step staled it) by ONE launch
+                dt_ = self.compute_dtype
+                Fh.SHADOWS.ensure([(va.linear_in_h.weight, "n", dt_), (va.linear_in_h.weight, "t", dt_), (va.linear_in_v.weight, "n", dt_),
+                                   (self.text_attn.linear_in.weight, "n", dt_), (self.text_attn.linear_in.weight, "t", dt_),
+                                   (self.text_attn.linear_out.weight, "n", dt_), (self.text_attn.linear_out.weight, "t", dt_),
+                                   (ds.linear_act.weight, "n", dt_), (ds.linear_hid.weight, "n", dt_), (ds.linear_hid.weight, "t", dt_)],
+                                  [(self.lstm.weight_ih, self.lstm.weight_hh, dt_, False), (self.lstm.weight_ih, self.lstm.weight_hh, dt_, True)])
             logit, h_new, c_new, word_w, view_w = core.apply(
                 (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ()), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
@@ -394,6 +401,23 @@ class MonitorDecoder(nn.Module, _Seeded):
             return self.compute_dtype
         return (self.compute_dtype, self.fp32_weights)
 
+    def _prefresh_shadows(self):
+        """Every weight shadow a step streams (the BN-MLP's Linear layers, the step's five matrices + the [W_ih | W_hh] pair, each in
+        its own streaming dtype), refreshed -- when an optimizer step staled it -- by ONE launch at the top of the rollout's first
+        forward (Fh.SHADOWS.ensure) instead of a cast / transpose launch per matrix."""
+        nd = self._node_dtype()
+        wants = []
+        for m in self.proj_navigable_mlp.mlp:
+            if isinstance(m, _HipLinear):
+                wd = Fh.wdtype(m.compute_dtype, "mlp")
+                wants += [(m.weight, "n", wd), (m.weight, "t", wd)]
+        for name, W in (("w_tin", self.text_attn.linear_in.weight), ("w_vh", self.visual_attn.linear_in_h.weight),
+                        ("w_a", self.action_linear.weight), ("w_m", self.monitor_linear.weight)):
+            wd = Fh.wdtype(nd, name)
+            wants += [(W, "n", wd), (W, "t", wd)]
+        wc = Fh.wdtype(nd, "w_cat")
+        Fh.SHADOWS.ensure(wants, [(self.lstm.weight_ih, self.lstm.weight_hh, wc, False), (self.lstm.weight_ih, self.lstm.weight_hh, wc, True)])
+
     def policy_net(self, weighted_ctx, hidden, cands_rep):
         """logit[b,c] = cands_rep[b,c,:] . W_a [weighted_ctx ; hidden]      (policy.py:108-117)"""
         query = Fh.linear(torch.cat((weighted_ctx, hidden), 1), self.action_linear.weight, self.action_linear.bias,
@@ -418,6 +442,8 @@ class MonitorDecoder(nn.Module, _Seeded):
         _need_gpu(a_t_prev, "MonitorDecoder")
         site = self._next()
         B, C, _ = a_t_cands.shape
+        if self.fused_step and self.c_step:
+            self._prefresh_shadows()
         # BN-MLP twice (previous action rows, then all B*C candidate rows incl. padded ones): two sets of batch
         # statistics and two running-stat updates per step, as in the reference
         if self.merge_projections:

@@ -39,6 +39,60 @@ class _ShadowCache:
         return t
 
 
+    def ensure(self, wants, fused=()):
+        """Refresh every STALE shadow of `wants` = [(parameter, kind "n" | "t", dtype)] and of `fused` = [(w_ih, w_hh, dtype,
+        transposed)] (the [w_ih | w_hh] matrices of _fused_lstm_weight) in ONE launch (`vln_shadow_refresh`) instead of one
+        transpose / cast launch (and one torch.cat) each: a decoder's forward names all the shadows its steps will stream (round 5:
+        8-14 launches per iteration at the top of the Self-Monitor / Follower rollouts).  The later `get` / `_fused_lstm_weight`
+        calls then hit.  Same bytes as the single launches (the same cast / transpose of the same source)."""
+        batch = ops.ShadowBatch()
+        for w, kind, dtype in wants:
+            key = (id(w), kind, dtype)
+            ver = (w._version, w.data_ptr())
+            hit = self._d.get(key)
+            if hit is not None and hit[0] == ver and hit[2]() is w:
+                continue
+            src = w.detach()
+            if kind != "t" and dtype == torch.float32:
+                t = src.contiguous()
+            elif not src.is_contiguous() or src.dim() != 2 or src.dtype != torch.float32:
+                continue                                    # (left to get(): shapes the grouped launch does not take)
+            else:
+                N, K = src.shape
+                t = torch.empty((K, N) if kind == "t" else (N, K), dtype=dtype, device=src.device)
+                batch.add(src, dst=None if kind == "t" else t, dst_t=t if kind == "t" else None)
+            if len(self._d) > 256:
+                self._d.clear()
+            self._d[key] = (ver, t, weakref.ref(w))
+        for w_ih, w_hh, dtype, transposed in fused:
+            key = (id(w_ih), id(w_hh), dtype, transposed)
+            ver = (w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr())
+            hit = _fused_cache.get(key)
+            if hit is not None and hit[0] == ver and hit[2]() is w_ih and hit[3]() is w_hh:
+                continue
+            a, b = w_ih.detach(), w_hh.detach()
+            if not (a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 and b.dtype == torch.float32):
+                continue
+            N, Kx, Kh = a.shape[0], a.shape[1], b.shape[1]
+            if transposed:
+                t = torch.empty(Kx + Kh, N, dtype=dtype, device=a.device)
+                batch.add(a, dst_t=t[:Kx]); batch.add(b, dst_t=t[Kx:])
+            else:
+                t = torch.empty(N, Kx + Kh, dtype=dtype, device=a.device)
+                batch.add(a, dst=t[:, :Kx]); batch.add(b, dst=t[:, Kx:])
+            if len(_fused_cache) > 64:
+                _fused_cache.clear()
+            _fused_cache[key] = (ver, t, weakref.ref(w_ih), weakref.ref(w_hh))
+        if len(batch.jobs) > _lib.SHADOW_MAX_JOBS:
+            jobs, keep = batch.jobs, batch.keep
+            for i in range(0, len(jobs), _lib.SHADOW_MAX_JOBS):
+                part = ops.ShadowBatch()
+                part.jobs, part.keep = jobs[i:i + _lib.SHADOW_MAX_JOBS], keep
+                part.run()
+        else:
+            batch.run()
+
+
 SHADOWS = _ShadowCache()
 
 
