@@ -139,7 +139,7 @@ class FollowerDims(C.Structure):
 
 class FollowerWeights(C.Structure):
     _fields_ = [(n, ptr) for n in ("w_h", "w_h_t", "b_h", "w_v", "b_v", "w_cat", "w_cat_t", "b_ih", "b_hh", "w_tin", "w_tin_t", "w_tout",
-                                   "w_tout_t", "w_act", "b_act", "w_hid", "w_hid_t", "b_hid", "w_out", "b_out")]
+                                   "w_tout_t", "w_act", "b_act", "w_hid", "w_hid_t", "b_hid", "w_out", "b_out", "w_v_t")]
 
 
 class FollowerStep(C.Structure):

@@ -2,7 +2,8 @@
 // call each: the launch sequence of functional.FollowerCoreFn (17 forward / ~30 backward launches) issued by the library instead
 // of one ctypes call per launch from Python.
 //
-//   forward   alpha_v, pano = VisualSoftDot(h0, img): keys = W_v img + b_v, query = W_h h0 + b_h, pano = sum_v alpha_v img_v
+//   forward   alpha_v, pano = VisualSoftDot(h0, img): logits_v = img_v . (W_v^T (W_h h0 + b_h)) [= (W_v img_v + b_v) . query up to a
+//             per-episode constant], pano = sum_v alpha_v img_v
 //             x = drop([a_prev | pano]);  h1, c1 = LSTMCell(x, (h0, c0))                       policy.py:46-52
 //             grounded, alpha_c = SoftDot(drop(h1), ctx, ctx_mask)                             policy.py:54-55
 //             logit = w_out . ((W_act cands + b_act) (.) (W_hid grounded + b_hid)) + b_out     units.py:175-184
@@ -45,18 +46,23 @@ extern "C" int64_t vln_follower_bwd_scratch_floats(const vln_follower_dims* d) {
 
 extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follower_weights* w, vln_follower_step* io, vln_stream_t s) {
   RUN(check_follower_dims(d));
-  if (!w || !io || !io->img || !io->a_prev || !io->cands || !io->h0 || !io->c0 || !io->ctx || !io->ws) {
+  if (!w || !io || !io->img || !io->a_prev || !io->cands || !io->h0 || !io->c0 || !io->ctx || !io->ws || !w->w_v_t || !io->keys) {
     set_error("vln_follower_step_fwd: null pointer");
     return VLN_ERR_ARG;
   }
   DropBaseScope drop_scope(io->offset_base_dev);
   hipStream_t st = (hipStream_t)s;
   const int B = d->B, L = d->L, V = d->V, C = d->C, H = d->H, F = d->F, A = d->A, D = d->D, XK = A + F + H, wt = d->wtype;
-  // (1) panorama attention: keys = W_v img + b_v, query = W_h h0 + b_h, weighted sum over the UN-projected views
+  // (1) panorama attention (units.py:144-159): logits_v = (W_v img_v + b_v) . tq with tq = W_h h0 + b_h.  Taken as img_v . (W_v^T tq):
+  // b_v . tq is one constant per episode under the softmax, and the product over the B * V view rows ([2304, 2176] x [256, 2176]^T
+  // per step at BASELINE config 0's model) becomes a B-row one -- the keys are never formed.  Weighted sum over the UN-projected views.
   RUN(gemm_nt(st, io->h0, H, w->w_h, wt, H, io->tq, D, B, D, H, w->b_h, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(gemm_nt(st, io->img, F, w->w_v, wt, F, io->keys, D, B * V, D, F, w->b_v, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_dot(st, io->keys, W_F32, io->tq, D, io->vlog, B, V, D));
-  RUN(attn_softmax_wsum(st, io->img, W_F32, io->vlog, nullptr, io->view_w, io->xcat + A, XK, B, V, F));
+  {
+    SlabArea ar{io->ws, (long)io->ws_floats};
+    SlabVec vq;
+    RUN(gemm_nt_to_consumer(st, ar, io->tq, D, w->w_v_t, wt, D, io->keys, F, B, F, D, nullptr, &vq));
+    RUN(attn_fwd_rows_sv(st, io->img, W_F32, vq, nullptr, 0, nullptr, io->view_w, io->xcat + A, XK, io->dots, B, V, F));
+  }
   {   // xcat = [drop(a_prev) | drop(pano), in place | h0]: the dropout over cat(a_prev, pano) (policy.py:49-51) in the launch that
       // copies the two blocks (they were a launch each)
     const DropSpec dr = tls_drop(io->seed, io->off, io->p_drop);
@@ -158,14 +164,17 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   // (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq); rv = sum_v dl_v img_v comes out of the same pass
   RUN(attn_dot(st, io->img, W_F32, dxcat + A, XK, dalpha, B, V, F));
   RUN(attn_bwd(st, io->img, W_F32, io->view_w, dalpha, g->dvw_ext, nullptr, 0, nullptr, 0, rv, F, nullptr, dl_v, B, V, F));
-  RUN(rows_wsum(st, io->keys, W_F32, dl_v, dtq, D, B, V, D));
-  RUN(vln_ew(3, io->tq, D, dl_v, V, V, tqs, D, B, D, s));                           // colsum -> d b_v (analytically 0: softmax rows)
+  // logits_v = img_v . (W_v^T tq): d(W_v^T tq) = sum_v dl_v img_v = rv, so d tq = rv W_v^T (a B-row product) and d W_v = tq^T rv
+  // (below); d b_v is exactly 0 (b_v . tq shifts every view's logit of an episode alike)
+  (void)tqs;
+  RUN(gemm_nt(st, rv, F, w->w_v, wt, F, dtq, D, B, D, F, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   RUN(gemm_nt(st, dtq, D, w->w_h_t, wt, D, t2, H, B, H, D, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
   {   // d h0 and (optionally) d a_prev, one launch
     const AddNJob aj[2] = {{g->dh0, H, B, H, 2, {dxcat + A + F, t2, nullptr, nullptr}, {XK, H, 0, 0}},
                            {g->da_prev, A, B, A, 1, {dxcat, nullptr, nullptr, nullptr}, {XK, 0, 0, 0}}};
     RUN(add_n_multi(st, aj, g->da_prev ? 2 : 1));
   }
+  if (g->g_bv && !g->acc[3]) RUN(fill_f32(st, g->g_bv, D, 0.f));      // d b_v = 0 exactly (see the panorama attention above)
   // parameter gradients: eight products over the same B rows -> one grouped launch; the biases and the head -> another
   {
     vln_wgrad_job jobs[8];
@@ -191,7 +200,6 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
       if (o1) jobs[n++] = vln_colsum_job{Am, o1, o2, lda, cols, acc};
     };
     add(dtq, D, g->g_bh, nullptr, D, g->acc[1]);
-    add(tqs, D, g->g_bv, nullptr, D, g->acc[3]);
     add(qs, D, g->g_bact, nullptr, D, g->acc[11]);
     add(dtarget, D, g->g_bhid, nullptr, D, g->acc[13]);
     add(Zo, D, g->g_wout, nullptr, D, g->acc[14]);

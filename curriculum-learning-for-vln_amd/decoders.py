@@ -142,6 +142,7 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
                 # every weight shadow the step streams, refreshed (when an optimizer step staled it) by ONE launch
                 dt_ = self.compute_dtype
                 Fh.SHADOWS.ensure([(va.linear_in_h.weight, "n", dt_), (va.linear_in_h.weight, "t", dt_), (va.linear_in_v.weight, "n", dt_),
+                                   (va.linear_in_v.weight, "t", dt_),
                                    (self.text_attn.linear_in.weight, "n", dt_), (self.text_attn.linear_in.weight, "t", dt_),
                                    (self.text_attn.linear_out.weight, "n", dt_), (self.text_attn.linear_out.weight, "t", dt_),
                                    (ds.linear_act.weight, "n", dt_), (ds.linear_hid.weight, "n", dt_), (ds.linear_hid.weight, "t", dt_)],

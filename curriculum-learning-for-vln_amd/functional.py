@@ -1047,10 +1047,11 @@ class FollowerCoreFn(torch.autograd.Function):
         dev = h0.device
         pd = p_drop if training else 0.0
         E = lambda *sh: ops.empty(*sh, dtype=f32, device=dev)
-        # (1) panorama attention: keys = W_v img + b_v, query = W_h h0 + b_h, weighted sum over the UN-projected views
+        # (1) panorama attention: logits_v = (W_v img_v + b_v) . tq, tq = W_h h0 + b_h, taken as img_v . (W_v^T tq) -- b_v . tq is one
+        # constant per episode under the softmax, the [B * V, D] keys are never formed (csrc/follower.hip); weighted sum over the views
         tq = ops.linear_fwd(h0, SHADOWS.get(W_h, "n", dtype), b_h.detach())
-        keys = ops.linear_fwd(img.view(B * V, F), SHADOWS.get(W_v, "n", dtype), b_v.detach())
-        vlog = ops.attn_dot(keys.view(B, V, D), tq)
+        keys = ops.linear_fwd(tq, SHADOWS.get(W_v, "t", dtype))  # [B, F]: the projected query (the saved slot keeps its old name)
+        vlog = ops.attn_dot(img, keys)
         xcat = E(B, A + F + H)                                   # [a_prev | pano | h0]: the LSTM input row
         _, view_w = ops.attn_softmax_wsum(img, vlog, None, out=xcat[:, A:A + F])
         xcat[:, :A].copy_(a_prev)
@@ -1129,9 +1130,9 @@ class FollowerCoreFn(torch.autograd.Function):
         dpano = dxcat[:, A:A + F]
         dalpha = ops.attn_dot(img, dpano)
         _, dl_v = ops.attn_bwd(img, view_w, dalpha, dvw_ext, None, None, None, want_dl=True)
-        dtq = ops.rows_wsum(keys.view(B, V, D), dl_v)
-        rv = ops.rows_wsum(img, dl_v)                                            # [B, F]: sum_v dl_v img_v -> d W_v = tq^T rv
-        tqs = ops.ew(ops.EW_MUL_ROWSUM, tq, dl_v, nb=V)                          # colsum -> d b_v (analytically 0: softmax rows)
+        rv = ops.rows_wsum(img, dl_v)                                            # [B, F]: sum_v dl_v img_v = d(W_v^T tq) -> d W_v = tq^T rv
+        dtq = ops.linear_fwd(rv, SHADOWS.get(W_v, "n", dtype))                   # d tq = rv W_v^T
+        tqs = torch.zeros(B, D, dtype=f32, device=dev)                           # d b_v is exactly 0 (b_v . tq shifts an episode's logits alike)
         dh0 = _add_n(E(B, H), [dxcat[:, A + F:], ops.linear_fwd(dtq, SHADOWS.get(W_h, "t", dtype))])
         # parameter gradients: eight products over the same B rows -> one grouped launch; the biases -> another
         sk = [_gsink(w) for w in (W_h, W_v, W_ih, W_hh, W_tin, W_tout, W_act, W_hid)]

@@ -267,7 +267,7 @@ class FollowerStepFn(torch.autograd.Function):
             return t.data_ptr()
 
         w.w_h, w.w_h_t, w.b_h = sh(W_h, "n"), sh(W_h, "t"), b_h.data_ptr()
-        w.w_v, w.b_v = sh(W_v, "n"), b_v.data_ptr()
+        w.w_v, w.w_v_t, w.b_v = sh(W_v, "n"), sh(W_v, "t"), b_v.data_ptr()
         wc_n, wc_t = _fused_lstm_weight(W_ih, W_hh, dtype, False), _fused_lstm_weight(W_ih, W_hh, dtype, True)
         wo = w_out.detach().reshape(-1)
         hold += [wc_n, wc_t, wo]
@@ -280,7 +280,8 @@ class FollowerStepFn(torch.autograd.Function):
         logit = ops.empty(B, Cn, dtype=f32, device=dev)
         h1 = ops.empty(B, H, dtype=f32, device=dev); c1 = ops.empty(B, H, dtype=f32, device=dev)
         word_w = ops.empty(B, L, dtype=f32, device=dev); view_w = ops.empty(B, V, dtype=f32, device=dev)
-        sizes = (("tq", B * D), ("keys", B * V * D), ("vlog", B * V), ("xcat", B * XK), ("act", B * 4 * H), ("tanh_c1", B * H),
+        # ("keys": the projected query W_v^T tq [B, F] since ABI 16 -- the [B * V, D] keys are never formed)
+        sizes = (("tq", B * D), ("keys", B * F), ("vlog", 0), ("xcat", B * XK), ("act", B * 4 * H), ("tanh_c1", B * H),
                  ("tq2", B * H), ("tcat", B * 2 * H), ("grounded", B * H), ("target", B * D), ("q", B * D), ("context", B * Cn * D),
                  ("gates", B * 4 * H), ("dots", B * max(L, V, Cn)))
         ctx.rw = None

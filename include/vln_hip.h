@@ -451,12 +451,15 @@ typedef struct vln_follower_weights {
   const void* w_act; const float* b_act;             /* decode_action.linear_act          [D, A], [D]       */
   const void *w_hid, *w_hid_t; const float* b_hid;   /* decode_action.linear_hid          [D, H], [D]       */
   const float *w_out, *b_out;                        /* decode_action.linear_out, fp32    [D], [1]          */
+  const void* w_v_t;                                 /* ABI v16: linear_in_v.weight transposed [F, D]: the view logits are img . (W_v^T tq) --
+                                                      * the [B*V, D] keys W_v img + b_v are never formed (b_v . tq is one constant per episode
+                                                      * under the softmax: d b_v is exactly 0) */
 } vln_follower_weights;
 typedef struct vln_follower_step {
   const float *img /*[B,V,F]*/, *a_prev /*[B,A]*/, *cands /*[B,C,A]*/, *h0, *c0 /*[B,H]*/, *ctx /*[B,L,H]*/;
   const uint8_t* ctx_mask;                           /* [B,L], 1 = masked; nullable */
   float *logit /*[B,C]*/, *h1, *c1 /*[B,H]*/, *word_w /*[B,L]*/, *view_w /*[B,V]*/;                         /* outputs */
-  float *tq /*[B,D]*/, *keys /*[B*V,D]*/, *vlog /*[B,V]*/, *xcat /*[B,A+F+H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/, *tq2 /*[B,H]*/,
+  float *tq /*[B,D]*/, *keys /*[B,F] since ABI v16: the projected query W_v^T tq (was the [B*V,D] keys)*/, *vlog /*[B,V]: unused since ABI v16*/, *xcat /*[B,A+F+H]*/, *act /*[B,4H]*/, *tanh_c1 /*[B,H]*/, *tq2 /*[B,H]*/,
         *tcat /*[B,2H]*/, *grounded /*[B,H]*/, *target /*[B,D]*/, *q /*[B,D]*/, *context /*[B*C,D]*/;      /* saved for the backward */
   float *gates /*[B,4H]: unused since ABI v14 -- the gate product stays as split-K slabs in ws (>= B * 4H floats)*/, *dots /*[B,max(L,V,C)]*/;   /* scratch of the call */
   float* ws; int64_t ws_floats;

@@ -279,7 +279,9 @@ def test_follower_c_call_step_equals_python_driven_node(vln, cdt):
         total.backward()
         res.append((outs + [hh, cc], {n: p.grad.clone() for n, p in dec.named_parameters()}, [ctx.grad, h.grad, c.grad]))
     for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
-        assert torch.equal(a, b), f"output {i}"
+        # (bit for bit until round 5; the C call now hands its projected query to the attention as split-K slabs, the Python-driven
+        #  node as one matrix: the same products in another summation order)
+        check(a, b, 2e-5, f"output {i}")
     gscale = max(v.abs().max().item() for v in res[1][1].values())
     for n in res[0][1]:
         check(res[0][1][n], res[1][1][n], 2e-5, f"grad[{n}]", floor=grad_floor(n, gscale))
