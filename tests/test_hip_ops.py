@@ -667,3 +667,37 @@ def test_input_batchnorm_gradients_from_the_first_layers_weight_gradient(vln, N,
     assert float(gg2[3]) == 0.0 and torch.isfinite(gg2).all()
     assert lib.vln_persistent_check() != 0 and b"set_bn0_grads_from_wgrad" in lib.vln_last_error_string()
     assert lib.vln_persistent_check() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_shadow_refresh_of_named_weights_equals_the_single_launches(vln, dtype):
+    """functional._ShadowCache.ensure (round 5): a decoder names the weight shadows its steps will stream and the stale ones are
+    cast / transposed by ONE `vln_shadow_refresh` launch -- the [W_ih | W_hh] pair without a concatenated copy.  Same bytes as the
+    per-matrix launches of `get` / `_fused_lstm_weight`; afterwards those calls hit the cache (the very same tensors), and an
+    in-place update of a parameter stales exactly its shadows."""
+    F_ = vln.functional
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *sh: torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev()))
+    W1, W2, Wih, Whh = mk(96, 200), mk(64, 64), mk(256, 132), mk(256, 64)
+    ref_cache, cache = F_._ShadowCache(), F_._ShadowCache()
+    wants = [(W1, "n", dtype), (W1, "t", dtype), (W2, "t", dtype)]
+    refs = [ref_cache.get(w, k, d).clone() for w, k, d in wants]
+    F_._fused_cache.clear()
+    ref_f = [F_._fused_lstm_weight(Wih, Whh, dtype, tr).clone() for tr in (False, True)]
+    F_._fused_cache.clear()
+    cache.ensure(wants, [(Wih, Whh, dtype, False), (Wih, Whh, dtype, True)])
+    got = [cache.get(w, k, d) for w, k, d in wants]
+    for a, b, (w, k, d) in zip(got, refs, wants):
+        assert a.dtype == (dtype if not (k == "n" and dtype == torch.float32) else torch.float32) and torch.equal(a, b), (k, d)
+    got_f = [F_._fused_lstm_weight(Wih, Whh, dtype, tr) for tr in (False, True)]
+    for a, b in zip(got_f, ref_f):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # hits: the same objects, no new tensors
+    assert all(cache.get(w, k, d) is t for (w, k, d), t in zip(wants, got))
+    assert all(F_._fused_lstm_weight(Wih, Whh, dtype, tr) is t for tr, t in zip((False, True), got_f))
+    with torch.no_grad():
+        W1.mul_(2.0)
+    cache.ensure(wants, [])
+    assert torch.equal(cache.get(W1, "t", dtype).float(), (W1.detach().t().contiguous().to(dtype)).float())
+    assert cache.get(W2, "t", dtype) is got[2]                       # untouched parameter: still the old shadow
+    F_._fused_cache.clear()
