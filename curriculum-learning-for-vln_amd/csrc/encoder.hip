@@ -785,7 +785,9 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
   dim3 g1(grid.x * grid.y * grid.z);
   const int nrec = (int)g1.x;
-  const int xm = g_tunable[7] != 1;
+  // bit 0: one XCD per dependency group; bit 1: the hand-off stores may stay in that XCD's L2 once the group has verified that it
+  // does run on one XCD (encoder_persist.h; tunable[14] = 1: always write-through, A/B)
+  const int xm = (g_tunable[7] != 1 ? 1 : 0) | (g_tunable[14] != 1 ? 2 : 0);
   static const WgradRideArgs no_ride{};
   unsigned lds_claim = 0;
   if (ride) {

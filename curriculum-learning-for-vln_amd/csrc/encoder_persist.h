@@ -16,6 +16,7 @@
 // timeout sets the status word and lets the kernel drain (wrong numbers, never a hang).
 #pragma once
 
+
 // A/B switch for scripts/lstm_probe.hip.  1 = the forward's bookkeeping stores are issued AFTER the arrival.  Measured
 // on MI355X (same box, interleaved): 572 us vs 515 us per 80-step launch -- LATE IS SLOWER: the poll's
 // `s_waitcnt vmcnt(0)` then also waits for those seven stores.  Default 0.
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1);      // (bit 1 of xcd_map: the XCD-local hand-off may be used, see below)
   const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
@@ -396,6 +397,23 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     s_abort = 0;
     if (blockIdx.x == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status word (a timeout sets it long after this store)
   }
+  // XCD-LOCAL HAND-OFF (round 5).  The partial products are exchanged through memory: an `sc1` (write-through) store leaves the
+  // writer's L2, and a reader on the SAME XCD then fetches the line at the cross-XCD rate (MI355X_MICROARCH.md, stores of each
+  // flavour).  A plain store keeps the line in the XCD's L2, where a same-XCD reader's L1-bypassing load finds it: 2.28 -> 1.90 us
+  // per step (scripts/lstm_probe).  That is only CORRECT when every workgroup of the dependency group runs on one XCD (the L2s are
+  // not coherent with each other) -- which the block -> role mapping aims at but HIP does not promise.  So it is verified per
+  // launch: every workgroup ORs its XCC_ID bit into a word of the group's flag line BEFORE its first arrival; after its first
+  // wait a workgroup reads the word -- every member's bit is in by then -- and only if exactly one bit is set do the stores from
+  // the second processed step on go plain.  Step one and any group that spans XCDs keep the write-through stores.  The word is
+  // reset with the counters by the last workgroup through.
+  bool xcd_local = false;
+#if !VLN_SYNC_FLAGS
+  if (threadIdx.x == 0 && (xcd_map & 2)) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    (void)__hip_atomic_fetch_or(cnt + 8, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // returns: performed before the arrival below
+  }
+#endif
   __syncthreads();
 
   float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;    // this (row, unit)'s dgates summed over the steps: the bias gradients' partial sums
@@ -416,6 +434,12 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     float dh = dh_pass;
     if (k > 0) {
       group_wait(cnt, NJB, (unsigned)k, status, sticky, &s_abort);
+#if !VLN_SYNC_FLAGS
+      if (k == 1 && (xcd_map & 2)) {           // every member's XCC_ID bit is in (each ORed it before its first arrival)
+        const unsigned m = VLN_AGENT_LOAD(cnt + 8);
+        xcd_local = m != 0u && (m & (m - 1u)) == 0u;
+      }
+#endif
       VLN_STAMP(1);
       const unsigned rbase = (unsigned)(((grp + ((k - 1) & 1)) * NJB * HD + j0) * 16 * 4) + (unsigned)lane * 16u;
       float4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -464,7 +488,8 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
         mfma_frags<TW, NSK>(af, w[i], acc);
         const int n = (wave * NT + i) * 16 + fi;
         u32x4_t o = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, xres, wbase + (unsigned)((n * 16 + fq * 4) * 4), 0, 16);   // sc1
+        if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(o, xres, wbase + (unsigned)((n * 16 + fq * 4) * 4), 0, 0);     // stays in this XCD's L2
+        else __builtin_amdgcn_raw_buffer_store_b128(o, xres, wbase + (unsigned)((n * 16 + fq * 4) * 4), 0, 16);              // sc1
       }
     }
     VLN_STAMP(4);
@@ -496,6 +521,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     const unsigned through = __hip_atomic_fetch_add(cnt + 24, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (through + 1u == (unsigned)NJB) {
       __hip_atomic_store(cnt, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 8, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // the XCC_ID mask of the XCD-local hand-off
       __hip_atomic_store(cnt + 24, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -21,6 +21,10 @@
 // Spins are bounded; a timeout sets the status words (encoder.hip: vln_persistent_check) and lets the kernel drain.
 // Summation orders equal the counter-protocol kernels': results are bit-identical to theirs.
 #pragma once
+#ifndef VLN_GRAN_ST_AUX
+#define VLN_GRAN_ST_AUX 16      // cache policy of the forward hand-off's granule stores: 16 = sc1 (write-through; probe builds may override)
+#endif
+
 
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       if ((jl & 1) == 0) {
         const unsigned tg_ = tag_base + (unsigned)step + 1u;
         const u32x4_t o = {__float_as_uint(hs), tg_, __float_as_uint(hnb), tg_};
-        __builtin_amdgcn_raw_buffer_store_b128(o, xres, gbase + (unsigned)(step & 1) * (16u * HD * 8u) + (unsigned)(bl * HD + j) * 8u, 0, 16);   // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(o, xres, gbase + (unsigned)(step & 1) * (16u * HD * 8u) + (unsigned)(bl * HD + j) * 8u, 0, VLN_GRAN_ST_AUX);   // sc1
       }
       if (live) a.hprev[(((long)d * L + tn) * B + b) * HD + j] = hs;     // history for BPTT / the weight gradients: plain
     } else if (live) {

@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 4; ++rep) {
     hipMemset(d_dh, 0, dirs * B * Hd * 4); hipMemset(d_dc, 0, dirs * B * Hd * 4);
     hipEventRecord(e0, 0);
-    int r = vln_lstm_seq_bwd(d_dy, d_wt, wtype, d_len, d_act, d_tc, d_cp, d_dg, d_dh, d_dc, nullptr, nullptr, B, L, Hd, dirs, d_sync, sync_bytes, -1, nullptr);
+    int r = vln_lstm_seq_bwd(d_dy, d_wt, wtype, d_len, d_act, d_tc, d_cp, d_dg, d_dh, d_dc, nullptr, nullptr, B, L, Hd, dirs, d_sync, sync_bytes, -1, nullptr, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (r) { printf("bwd failed: %s\n", vln_last_error_string()); return 1; }

@@ -388,6 +388,45 @@ def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
             check(a, b, 2e-5, n)         # dgates) and the embedding scatter-add uses float atomics
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_hand_off(vln, dtype):
+    """Round 5: when every workgroup of a dependency group of the backward recurrence verified (XCC_ID bits ORed into the group's
+    flag line before the first arrival) that the group runs on ONE XCD, its partial-product stores stay in that XCD's L2 instead
+    of being written through -- the same numbers by a faster route.  Three runs of the same backward: the default (one XCD per
+    group -> plain stores), always write-through (tunable 14 = 1), and groups dealt ACROSS the XCDs in dispatch order (tunable
+    7 = 1: the check finds several XCC_IDs and the stores stay write-through): bit-identical gradients, clean status words, twice
+    in a row (the mask word is reset with the counters by the last workgroup through)."""
+    lib = vln._lib.load()
+    B, L, E, H, vocab = 64, 80, 256, 512, 992
+    g = torch.Generator().manual_seed(31)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=dtype).to(DEV).train()
+    enc.deterministic_embedding_grad = True
+    lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    r = torch.randn(B, L, H, generator=g).to(DEV)
+    outs = []
+    try:
+        for t14, t7 in ((0, 0), (1, 0), (0, 1), (0, 0)):
+            vln._lib.check(lib.vln_set_tunable(14, t14), "vln_set_tunable"); vln._lib.check(lib.vln_set_tunable(7, t7), "vln_set_tunable")
+            for rep in range(2):
+                enc._calls = 0
+                enc.zero_grad(set_to_none=True)
+                ctx, h, c = enc(tokens.to(DEV), lens)
+                ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
+                torch.cuda.synchronize()
+                assert enc.persistent_status() == 0
+                outs.append([p.grad.detach().clone() for p in enc.parameters()])
+    finally:
+        lib.vln_set_tunable(14, 0); lib.vln_set_tunable(7, 0)
+    vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+    names = [n for n, _ in enc.named_parameters()]
+    for k, o in enumerate(outs[1:]):
+        for n, a, b in zip(names, outs[0], o):
+            assert torch.equal(a, b), f"run {k + 1}: grad[{n}] differs from the first run's"
+
+
 def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
     """the counter-protocol backward leaves its group counters zero itself and skips the fill launch -- which
     only holds for a header it left behind.  (a) a caller-supplied workspace whose header was never zeroed, (b) a header the
