@@ -736,6 +736,19 @@ extern "C" int vln_persistent_check(void) {
   }
   return VLN_OK;
 }
+// Test hook: the cumulative tallies of the backward recurrence's hand-off decisions kept in a sync workspace's header (synchronous
+// device-to-host copy): dependency groups whose launches verified one XCD (stores kept in its L2) / found several (write-through).
+extern "C" int vln_lstm_handoff_stats(const void* sync_ws, uint32_t* xcd_local, uint32_t* spanning) {
+  if (!sync_ws || !xcd_local || !spanning) { set_error("vln_lstm_handoff_stats: null pointer"); return VLN_ERR_ARG; }
+  uint32_t w[2] = {0, 0};
+  if (hipMemcpy(w, static_cast<const char*>(sync_ws) + (32 + 8) * 4, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("vln_lstm_handoff_stats: copy failed");
+    return VLN_ERR_HIP;
+  }
+  *xcd_local = w[0]; *spanning = w[1];
+  return VLN_OK;
+}
 extern "C" int vln_set_split_attention(int on) { g_split_attn_enabled = on ? 1 : 0; return VLN_OK; }
 extern "C" int vln_get_split_attention(void) { return g_split_attn_enabled; }
 

@@ -438,6 +438,8 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
       if (k == 1 && (xcd_map & 2)) {           // every member's XCC_ID bit is in (each ORed it before its first arrival)
         const unsigned m = VLN_AGENT_LOAD(cnt + 8);
         xcd_local = m != 0u && (m & (m - 1u)) == 0u;
+        // cumulative tallies for the tests (vln_lstm_handoff_stats): groups that went XCD-local / that span XCDs, status line words 8, 9
+        if (threadIdx.x == 0 && jb == 0) __hip_atomic_fetch_add(status + (xcd_local ? 8 : 9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #endif
       VLN_STAMP(1);

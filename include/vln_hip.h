@@ -696,6 +696,10 @@ int vln_debug_raise_sticky(int word);
 /* The four-workgroups-per-row attention (units.py:77-160 on csrc/attention_split.h) spins (bounded) on its three sibling
  * workgroups.  A timeout is counted in its OWN sticky word: vln_persistent_check reports it once as VLN_ERR_HIP and clears
  * this switch, after which every attention runs on one workgroup per row.  1 = allowed (default), 0 = off. */
+/* Test hook (ABI v16): cumulative tallies, kept in a recurrence sync workspace's header, of the backward recurrence's per-launch
+ * hand-off decisions -- dependency groups that verified they run on ONE XCD (their partial products stay in that XCD's L2) and groups
+ * that span XCDs (write-through stores).  Synchronous. */
+int vln_lstm_handoff_stats(const void* sync_ws, uint32_t* xcd_local, uint32_t* spanning);
 int vln_set_split_attention(int on);
 int vln_get_split_attention(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]

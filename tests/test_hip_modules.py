@@ -406,7 +406,14 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
     for i, n in enumerate(lens.tolist()):
         tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
     r = torch.randn(B, L, H, generator=g).to(DEV)
-    outs = []
+    import ctypes as C
+    outs, tallies = [], []
+
+    def tally():
+        a, b = C.c_uint32(), C.c_uint32()
+        ws = enc._sync_ws(torch.device(DEV), B, H // 2, 2)
+        vln._lib.check(lib.vln_lstm_handoff_stats(ws[0], C.byref(a), C.byref(b)), "vln_lstm_handoff_stats")
+        return a.value, b.value
     try:
         for t14, t7 in ((0, 0), (1, 0), (0, 1), (0, 0)):
             vln._lib.check(lib.vln_set_tunable(14, t14), "vln_set_tunable"); vln._lib.check(lib.vln_set_tunable(7, t7), "vln_set_tunable")
@@ -414,10 +421,13 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
                 enc._calls = 0
                 enc.zero_grad(set_to_none=True)
                 ctx, h, c = enc(tokens.to(DEV), lens)
+                before = tally()
                 ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
                 torch.cuda.synchronize()
+                after = tally()
                 assert enc.persistent_status() == 0
                 outs.append([p.grad.detach().clone() for p in enc.parameters()])
+                tallies.append((t14, t7, after[0] - before[0], after[1] - before[1]))
     finally:
         lib.vln_set_tunable(14, 0); lib.vln_set_tunable(7, 0)
     vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
@@ -425,6 +435,14 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
     for k, o in enumerate(outs[1:]):
         for n, a, b in zip(names, outs[0], o):
             assert torch.equal(a, b), f"run {k + 1}: grad[{n}] differs from the first run's"
+    # what the launches decided (vln_lstm_handoff_stats): 2 directions x 4 row blocks = 8 dependency groups per backward
+    for t14, t7, loc, span in tallies:
+        if t14:
+            assert (loc, span) == (0, 0), tallies                   # switch off: no check, write-through
+        elif t7:
+            assert loc + span == 8 and span > 0, tallies            # groups dealt across the XCDs: found out, write-through
+        else:
+            assert (loc, span) == (8, 0), tallies                   # one XCD per group: verified, stores kept in its L2
 
 
 def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
