@@ -417,19 +417,33 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __syncthreads();
 
   float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;    // this (row, unit)'s dgates summed over the steps: the bias gradients' partial sums
+  // The step's saved operands (gate activations, tanh(c), c_{t-1}, the upstream gradient: produced before this launch, plain loads)
+  // do not depend on the recurrence, and their ~0.4 us of load latency sat at the top of EVERY workgroup's step, i.e. on the ring's
+  // critical path (scripts/lstm_probe "loop-around").  Step s - 1's are requested in the middle of step s (after the hand-off's
+  // loads, before the pointwise arithmetic) and have landed when the loop comes around.
+  struct StepOps { float dyv, si, sf, tg, so, tc, cp; };
+  auto load_ops = [&](int step_) {
+    // UNCONDITIONAL loads (rows past the batch clamp to row 0, padded steps read what the forward stored there): a per-thread
+    // branch around them would make the compiler close it with s_waitcnt vmcnt(0) and expose their latency right here; what a
+    // padded step / row loaded is never used (`valid` below)
+    StepOps o;
+    const int t_ = (d == 0) ? step_ : (L - 1 - step_);
+    const int b_ = live ? b : 0;
+    const long row_ = (long)t_ * B + b_;
+    o.dyv = a.dy ? a.dy[row_ * Y + d * HD + j] : 0.f;
+    const float* ac = a.act + row_ * G + (long)d * 4 * HD + j;
+    o.si = ac[0]; o.sf = ac[HD]; o.tg = ac[2 * HD]; o.so = ac[3 * HD];
+    o.tc = a.tanh_c[row_ * Y + d * HD + j];
+    o.cp = a.cprev[(((long)d * L + t_) * B + b_) * HD + j];
+    return o;
+  };
+  StepOps nxt = load_ops(L - 1);
   for (int step = L - 1; step >= 0; --step) {
     const int k = L - 1 - step;                // steps already processed
     const int t = (d == 0) ? step : (L - 1 - step);
     const long row = (long)t * B + (live ? b : 0);
     const bool valid = live && (t < len);
-    float dyv = 0.f, si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, cp = 0.f;
-    if (valid) {   // plain loads: produced by the forward pass / upstream gradient before this launch
-      if (a.dy) dyv = a.dy[row * Y + d * HD + j];
-      const float* ac = a.act + row * G + (long)d * 4 * HD + j;
-      si = ac[0]; sf = ac[HD]; tg = ac[2 * HD]; so = ac[3 * HD];
-      tc = a.tanh_c[row * Y + d * HD + j];
-      cp = a.cprev[(((long)d * L + t) * B + b) * HD + j];
-    }
+    const float dyv = nxt.dyv, si = nxt.si, sf = nxt.sf, tg = nxt.tg, so = nxt.so, tc = nxt.tc, cp = nxt.cp;
     VLN_STAMP(0);
     float dh = dh_pass;
     if (k > 0) {
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
       dh += (red[0][q][e] + red[1][q][e]) + (red[2][q][e] + red[3][q][e]);
     }
     VLN_STAMP(2);
+    if (step > 0) nxt = load_ops(step - 1);          // the next step's operands: in flight under the rest of this step
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
     if (valid) {
       dh += dyv;
@@ -478,7 +493,9 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     if (step == 0) break;                      // nobody consumes a partial dh of the last processed step
     float* tr = &tile[bl * LDT + jl];
     tr[0] = g0; tr[16] = g1; tr[32] = g2; tr[48] = g3;
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also drain the vector-memory counter, i.e. wait right here for the next step's
+    // operand loads requested above (and for the dgates stores, which nobody in this launch reads)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     VLN_STAMP(3);
     {
       AFrag<TW, NSK> af;
