@@ -152,7 +152,10 @@ class LiveBatch:
     angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (once per
     iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA changes
     every iteration.  Where the packed batches wait (`source`):
-      "pull"    (the bench's default since round 4) in PINNED HOST memory -- what a trainer's data loader hands over; base.py:114-178
+      "push"    (round 5, A/B) in PINNED HOST memory; `load(k)` sends batch k (and k + 1) ahead: one asynchronous H2D copy on
+                a copy stream into a device-resident ring slot (staging.HostBatchFeed(prefetch=True)), under the previous iteration's
+                compute; the iteration's first launch moves it from the slot into the live buffers (same kernel as "pull", reading HBM);
+      "pull"    (round 4) in PINNED HOST memory -- what a trainer's data loader hands over; base.py:114-178
                 marshals every batch on the host.  `load(k)` stores batch k's address in a pinned slot (one host store) and the
                 iteration's FIRST launch pulls the blob through PCIe into the live buffers (staging.HostBatchFeed, vln_host_fetch):
                 the agent calls `fetch()` at the top of the iteration, so a captured iteration contains it;
@@ -168,8 +171,9 @@ class LiveBatch:
     HEAD_TOP, HEAD_STEP = ("tokens", "lengths32"), ("rows", "vidx", "crow", "cview", "chead", "celev")
 
     def __init__(self, tapes, source="device"):
-        assert source in ("pull", "copy", "device")
+        assert source in ("push", "pull", "copy", "device")
         self.source = source
+        self.send_ahead = True
         t0 = tapes[0]
         self.layout, off, self.split = [], 0, 0
         for name, t in self._items(t0):
@@ -182,9 +186,9 @@ class LiveBatch:
         dev = t0["tokens"].device
         self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
         self.feed = None
-        if source == "pull":
+        if source in ("pull", "push"):
             import vln_amd
-            self.feed = vln_amd.HostBatchFeed(self.live_blob)
+            self.feed = vln_amd.HostBatchFeed(self.live_blob, prefetch=source == "push")
         self.blobs = []
         for tp in tapes:
             blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
@@ -194,7 +198,7 @@ class LiveBatch:
                 blob[o:o + n] = t.contiguous().view(-1).view(torch.uint8)
             if source == "copy":
                 blob = blob.cpu().pin_memory()
-            elif source == "pull":
+            elif source in ("pull", "push"):
                 blob = self.feed.register(blob)
             self.blobs.append(blob)
         views = {name: self.live_blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.layout}
@@ -220,6 +224,8 @@ class LiveBatch:
     def load(self, k):
         if self.feed is not None:
             self.feed.select(self.blobs[k % len(self.blobs)])       # one host store; the iteration's first launch pulls the blob
+            if self.source == "push" and self.send_ahead:           # the loop visits the batches in order: batch k + 1 starts travelling now
+                self.feed.send_ahead(self.blobs[(k + 1) % len(self.blobs)])
         else:
             self.live_blob.copy_(self.blobs[k % len(self.blobs)], non_blocking=True)
         return self.live
@@ -288,6 +294,7 @@ class GpuAgent:
         self._live_split, self._live_tape = 0, None
         self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
         self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
+        self.ride_shadows = False       # ... which then also refresh the decoder's weight shadows, out of the prologue launch (--ride-shadows: measured neutral)
 
     def _probe(self):
         n = getattr(self, "probe_trivial", 0)
@@ -438,6 +445,11 @@ class GpuAgent:
         return [("graph", in_arena(part_a, begin=True)), ("host", lambda: self.opt.start_allreduce(1)),
                 ("graph", in_arena(part_b)), ("host", lambda: self.opt.allreduce()), ("graph", in_arena(part_c))]
 
+    def _shadows_ride(self, tape):
+        """The decoder's weight shadows are refreshed by the gather ride's passengers (staging.RolloutRide.carry_shadows) instead of
+        the prologue launch: whenever there is a ride and a prologue to take them out of."""
+        return bool(self.ride_shadows and self.ride_gather and tape.get("store") is not None and self.clock is not None and self.use_prologue)
+
     def _iteration(self, tape):
         B = tape["B"]
         # the decoder-only part of a pulled batch crosses PCIe under the encoder's recurrence (one passenger workgroup of that launch)
@@ -449,7 +461,8 @@ class GpuAgent:
         if self.clock is not None and self.use_prologue:
             # ONE launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull"), the device clock ticks (this
             # iteration's dropout offsets / launch sequence) and both modules' weight shadows follow the last optimizer step
-            self.clock.prologue(self.batch_feed, (self.enc, self.dec))
+            # (the decoder's shadows ride in the encoder's recurrence launch instead when the gather does: carry_shadows below)
+            self.clock.prologue(self.batch_feed, (self.enc,) if self._shadows_ride(tape) else (self.enc, self.dec))
         else:
             if self.batch_fetch is not None:
                 self.batch_fetch()     # one launch: the pull
@@ -488,6 +501,8 @@ class GpuAgent:
             pre = ride.outputs
             if carry_tail:
                 ride.carry_batch_tail(self.batch_feed)
+            if self._shadows_ride(tape):
+                ride.carry_shadows((self.dec,))
         elif self.rollout_gather and self.gather_branch and tape.get("store") is not None:
             # the gather reads only the resident table + index vectors: as a branch of the captured graph it runs beside the
             # instruction encoder (whose 0.2 ms recurrence keeps half of the CUs idle) and joins before the first decoder step
@@ -693,6 +708,11 @@ def main():
                     help="store features, teacher forcing: the rollout's feature gather as PASSENGER workgroups of the encoder's "
                          "persistent recurrence launch (the 128 CUs that launch leaves idle at B = 64); the decoder steps then "
                          "start with their prep launch only.  auto = on (profiles/round3_notes.md: 1.661 vs 1.687 ms)")
+    ap.add_argument("--ride-shadows", action="store_true",
+                    help="(A/B) the decoder's weight shadows are refreshed by the gather ride's passengers under the encoder's recurrence "
+                         "(staging.RolloutRide.carry_shadows) instead of the prologue launch: the prologue is bound by its PCIe pull, not "
+                         "by the refresh, so this only pays together with --batch-source push -- and measured the same "
+                         "(profiles/round5_notes.md section 11)")
     ap.add_argument("--gather-branch", action="store_true",
                     help="with --rollout-gather and the iteration graph: the rollout-wide gather as a captured BRANCH beside the encoder")
     ap.add_argument("--rollout-gather", action="store_true",
@@ -703,10 +723,12 @@ def main():
                          "inside the step's first launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' only to smoke-test "
                                                       "the N>1 code path on a single-GPU box")
-    ap.add_argument("--batch-source", default="pull", choices=["pull", "copy", "device"],
+    ap.add_argument("--batch-source", default="pull", choices=["push", "pull", "copy", "device"],
                     help="where the packed episode batches (tokens, masks, per-step index vectors, targets: ~0.4 MB each) wait: "
-                         "pull = pinned HOST memory, the iteration's first launch pulls the batch through PCIe (default: what a data "
-                         "loader hands over); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
+                         "push = pinned HOST memory (what a data loader hands over), sent ahead by an asynchronous H2D copy on a copy "
+                         "stream into a device ring slot under the previous iteration, the iteration's first launch moves it into the "
+                         "live buffers; pull = pinned host memory, the iteration's first launch pulls the batch through PCIe itself "
+                         "(round 4); copy = pinned host memory, one hipMemcpyAsync H2D in front of the iteration; device = "
                          "device memory, one device-to-device copy (round 3's form)")
     ap.add_argument("--no-prologue", action="store_true", help="(A/B) the batch pull, the clock tick and the shadow refreshes as separate launches")
     ap.add_argument("--no-ride-wgrads", action="store_true", help="(A/B) the decoder's weight / bias gradients as their own launches in front of "
@@ -791,6 +813,7 @@ def main():
     agent.rollout_gather = bool(args.rollout_gather)
     agent.gather_branch = bool(args.gather_branch)
     agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
+    agent.ride_shadows = bool(args.ride_shadows)
     agent.probe_trivial = int(args.probe_trivial)
     agent.dump_graph = args.dump_graph
     if args.no_chain:
@@ -1092,13 +1115,14 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"envdrop_il_fwd_bwd_clip_rmsprop_B{args.batch}_L{args.L}_T{args.T}", "features": args.features,
                        "feature_table": f"{store.N}x36x2048 {args.dtype} resident in HBM", "episode_batches_rotated": len(tapes),
-                       "batch_source": ({"pull": "pinned host memory, pulled by the iteration's first launch (vln_host_fetch)",
+                       "batch_source": ({"push": "pinned host memory, sent one iteration ahead by an async H2D copy on a copy stream into a device ring slot; the iteration's first launch moves it into the live buffers (HostBatchFeed prefetch)",
+                                         "pull": "pinned host memory, pulled by the iteration's first launch (vln_host_fetch)",
                                          "copy": "pinned host memory, one hipMemcpyAsync H2D per iteration",
                                          "device": "device memory, one D2D copy per iteration"}[args.batch_source] if live is not None else "per-step tensors"),
                        "global_batch": args.batch * world, "seq_len": args.L, "decoder_steps": args.T,
                        "parallelism": f"dp{world}", "world_size": world,
                        "iteration_graph": ("3 segments + host-issued gradient exchange" if agent.segmented else ("one graph, gradient exchange captured inside" if (args.dp_capture and (world > 1 or args.dp_path)) else True)) if use_graph else False,
-                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "projected_context": bool(agent.dec.last_projected), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
+                       "decoder_fp32_weights": sorted(agent.dec.fp32_weights), "chained_steps": bool(agent.dec.chain_steps), "projected_context": bool(agent.dec.last_projected), "decoder_wgrad_ride": (vln.ops.GradRide.stats() if agent.dec.ride_wgrads else False), "prologue_launch": bool(agent.use_prologue and use_graph), "batch_tail_under_recurrence": bool(agent.split_pull and agent.batch_feed is not None and agent.ride_gather), "decoder_shadows_under_recurrence": bool(agent.ride_shadows and agent.ride_gather and agent.use_prologue and use_graph), "gather": "recurrence passengers" if agent.ride_gather else ("rollout launch" if agent.rollout_gather else "per step"),
                        "wgrad": vln.ops.get_wgrad_precision(),
                        "backend": (args.backend + ("=rccl" if args.backend == "nccl" else "")) if (world > 1 or args.dp_path) else None},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))

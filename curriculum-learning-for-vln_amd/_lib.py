@@ -40,7 +40,8 @@ class GatherRolloutStep(C.Structure):
 class GatherRide(C.Structure):         # vln_gather_ride
     _fields_ = ([("table", ptr), ("angle_table", ptr), ("steps", ptr)] + [(n, i32) for n in ("ttype", "T", "B", "V", "C", "IMG", "ANG", "pad_")]
                 + [("seed", u64), ("p_feat", f32), ("padf_", f32), ("offset_base_dev", ptr)]
-                + [("fetch_slots", ptr), ("fetch_seq", ptr), ("fetch_dst", ptr), ("fetch_offset", i64), ("fetch_bytes", i64), ("fetch_ring", i32), ("pad2_", i32)])
+                + [("fetch_slots", ptr), ("fetch_seq", ptr), ("fetch_dst", ptr), ("fetch_offset", i64), ("fetch_bytes", i64), ("fetch_ring", i32), ("pad2_", i32)]
+                + [("shadow_jobs", ptr), ("n_shadow_jobs", i32), ("pad3_", i32)])
 
 
 class CatStep(C.Structure):
@@ -326,7 +327,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 16
+EXPECTED_ABI = 17
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

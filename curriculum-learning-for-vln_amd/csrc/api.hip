@@ -118,7 +118,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 16; }
+extern "C" int vln_abi_version(void) { return 17; }
 extern "C" int64_t vln_struct_size(const char* name) {
   if (!name) return -1;
 #define VLN_SZ(T) if (std::strcmp(name, #T) == 0) return (int64_t)sizeof(T)

@@ -18,6 +18,7 @@
 #include "graph_cache.h"
 #include "gather_ride.h"
 #include "prologue_bodies.h"
+#include "shadow_bodies.h"
 #include "../../include/vln_hip.h"
 
 namespace vln {
@@ -790,6 +791,11 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
 }
 
 static int ride_passengers(int nrec);
+// the shadow jobs a gather ride carries, as their own launch (no passengers to carry them)
+static int ride_shadows_launch(hipStream_t st, const ::vln_gather_ride& r) {
+  if (r.n_shadow_jobs < 0 || (r.n_shadow_jobs > 0 && !r.shadow_jobs)) { set_error("gather ride: bad shadow jobs"); return VLN_ERR_ARG; }
+  return r.n_shadow_jobs > 0 ? shadow_refresh(st, r.shadow_jobs, r.n_shadow_jobs) : VLN_OK;
+}
 static constexpr unsigned kRideLdsClaim = 96u * 1024u;
 template <typename TW>
 static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* counters, unsigned* status, float* exch, dim3 grid,
@@ -898,9 +904,11 @@ static int ride_passengers(int nrec) {
 
 template <typename TW>
 static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* status, unsigned char* exch, unsigned tag_base, dim3 grid,
-                                const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride, const FetchPart& fetch) {
+                                const unsigned* seq_dev, unsigned seq_rel, const GatherRolloutArgs* ride, const FetchPart& fetch, const RideShadows& shadows) {
   unsigned* sticky = sticky_dev_word();
   if (!sticky) { set_error("persistent lstm: no host-mapped status word"); return VLN_ERR_HIP; }
+  static_assert(sizeof(RecFwdArgs) + sizeof(GatherRolloutArgs) + sizeof(FetchPart) + sizeof(RideShadows) + 96 <= 4096,
+                "the forward recurrence launch's arguments must fit the 4 KB a launch may pass");
   dim3 g1(grid.x * grid.y * grid.z);
   const int nrec = (int)g1.x;
   const int xm = g_tunable[7] != 1;
@@ -924,7 +932,7 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
     VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd, \
-               (ride ? fetch : FetchPart{}));                                                                                 \
+               (ride ? fetch : FetchPart{}), (ride ? shadows : RideShadows{}));                                                   \
   }                                                                                                                       \
   break
   switch (a.Hd / BK) {
@@ -990,6 +998,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     GatherRolloutArgs ride_args{};
     const GatherRolloutArgs* riders = nullptr;
     FetchPart fetch{};
+    RideShadows shadows{};
     if (ride) { r = fetch_part_args(*ride, &fetch); if (r) return r; }
     if (ride) {
       // passengers need idle CUs (B = 128 with two directions of 256 units fills all 256) and the 96 KB dynamic-LDS claim
@@ -997,9 +1006,16 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
           ride_passengers((int)(grid.x * grid.y * grid.z)) > 0) {
         r = gather_ride_args(*ride, 0, &ride_args); if (r) return r;
         riders = &ride_args;
+        // the shadows the ride carries: the passengers' when one argument block holds the jobs, else their own launch first
+        if (ride->n_shadow_jobs > 0 && ride->n_shadow_jobs <= kRideShadowJobs) {
+          r = shadow_jobs(ride->shadow_jobs, ride->n_shadow_jobs, &shadows.jobs, &shadows.tiles); if (r) return r;
+        } else {
+          r = ride_shadows_launch(st, *ride); if (r) return r;
+        }
       } else {
         r = gather_ride_launch(st, *ride); if (r) return r;
         r = launch_fetch_part(st, fetch); if (r) return r;          // the batch tail as its own one-block launch
+        r = ride_shadows_launch(st, *ride); if (r) return r;        // and the shadows as theirs
       }
     }
     const unsigned* seq_dev = device_seq >= 0 ? reinterpret_cast<const unsigned*>(static_cast<char*>(sync_ws) + sync_off_seq(B, Hd, dirs)) : nullptr;
@@ -1010,8 +1026,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     {
       ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
       if (fwd_granules())
-        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch)
-                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch);
+        r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch, shadows)
+                                : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch, shadows);
       else
         r = (wtype == VLN_BF16) ? launch_persist_fwd<bf16_raw>(st, a, cw + 64, cw + 32, grid)
                                 : launch_persist_fwd<float>(st, a, cw + 64, cw + 32, grid);
@@ -1024,6 +1040,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     FetchPart fetch{};
     rr = fetch_part_args(*ride, &fetch); if (rr) return rr;
     rr = launch_fetch_part((hipStream_t)s, fetch); if (rr) return rr;
+    rr = ride_shadows_launch((hipStream_t)s, *ride); if (rr) return rr;
   }
   // the L-launch chain is a pure function of this argument block -> memoised as a hipGraph (graph_cache.h)
   struct { const void* p[12]; int v[5]; } key = {{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, h0, c0},

@@ -74,7 +74,7 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 template <typename TW, int NS>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
-                                                                 int nrec, GatherRolloutArgs ride, FetchPart fetch) {
+                                                                 int nrec, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
   // PASSENGERS: workgroups past the recurrence's own `nrec` gather the rollout's feature rows (gather_body.h) on the compute
   // units the recurrence leaves idle -- independent work (it reads the resident table and index vectors only), nothing waits
   // for it inside this launch, and the launch claims a whole CU's LDS per workgroup so that a passenger never shares a CU with
@@ -87,6 +87,16 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       np -= 1;
     }
     gather_ride_passenger(ride, p, np, (int)threadIdx.x);
+    // then the weight shadows the ride carries (shadow_bodies.h), tiles dealt like the rows; the tile buffer is the launch's
+    // dynamic LDS claim (unused otherwise: it only keeps the launch at one workgroup per CU)
+    if (shadows.tiles > 0) {
+      extern __shared__ __attribute__((aligned(16))) unsigned char ride_lds[];
+      float (*lds)[65] = reinterpret_cast<float (*)[65]>(ride_lds);
+      for (int b = p; b < shadows.tiles; b += np) {
+        shadow_block<true>(shadows.jobs, b, lds);
+        __syncthreads();                       // the tile buffer is written again by the next tile
+      }
+    }
     return;
   }
   // launch sequence in DEVICE memory (whole-iteration graphs: the launch arguments must repeat): the word is bumped by a

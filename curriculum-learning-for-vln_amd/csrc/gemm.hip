@@ -16,6 +16,7 @@
 
 #include "vln_internal.h"
 #include "prologue_bodies.h"
+#include "shadow_bodies.h"
 #include "step_bodies.h"
 #include "../../include/vln_hip.h"
 
@@ -1083,102 +1084,11 @@ int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type,
   return VLN_OK;
 }
 
-// ---- all shadows of a module in ONE launch ------------------------------------------------------------------------
-// job = one fp32 matrix [N,K] (optionally the sum of two: b_ih + b_hh) -> its compute-dtype copy and/or its transposed
-// copy.  64x64 tiles; a workgroup finds its job from the prefix sums of the jobs' tile counts.
-struct ShadowJobs {
-  vln_shadow_job j[VLN_SHADOW_MAX_JOBS];
-  int tile0[VLN_SHADOW_MAX_JOBS + 1];
-  int n;
-};
-template <typename TO>
-__device__ __forceinline__ void shadow_tile(const vln_shadow_job& q, int tile, float (*lds)[65]) {
-  const int tk = (q.K + 63) / 64;
-  const int n0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int n = n0 + r, k = k0 + tx;
-    float v = 0.f;
-    if (n < q.N && k < q.K) {
-      v = q.src[(long)n * q.ld_src + k];
-      if (q.src2) v += q.src2[(long)n * q.ld_src + k];
-      if (q.dst) Elt<TO>::st(reinterpret_cast<TO*>(q.dst) + (long)n * q.ld_dst + k, v);
-    }
-    lds[r][tx] = v;
-  }
-  if (!q.dst_t) return;
-  __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int k = k0 + r, n = n0 + tx;
-    if (k < q.K && n < q.N) Elt<TO>::st(reinterpret_cast<TO*>(q.dst_t) + (long)k * q.ld_dst_t + n, lds[tx][r]);
-  }
-}
-// Same tile with 16-byte loads and 8/16-byte stores (N, K and every leading dimension multiples of 4, 16-byte aligned
-// bases): a thread owns 4 consecutive k of a row on the way in and 4 consecutive n of a transposed row on the way out.  The
-// scalar form above moved 4 bytes in and 2 bytes out per lane and instruction (43 us for the 40 MB of EnvDrop weights).
-template <typename TO>
-__device__ __forceinline__ void shadow_tile_v4(const vln_shadow_job& q, int tile, float (*lds)[65]) {
-  const int tk = (q.K + 63) / 64;
-  const int n0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
-  const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 16 * i, n = n0 + r, k = k0 + c4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < q.N && k < q.K) {
-      Elt<float>::ld4(q.src + (long)n * q.ld_src + k, v);
-      if (q.src2) {
-        float w[4];
-        Elt<float>::ld4(q.src2 + (long)n * q.ld_src + k, w);
-        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
-      }
-      if (q.dst) Elt<TO>::st4(reinterpret_cast<TO*>(q.dst) + (long)n * q.ld_dst + k, v);
-    }
-    lds[r][c4] = v[0]; lds[r][c4 + 1] = v[1]; lds[r][c4 + 2] = v[2]; lds[r][c4 + 3] = v[3];
-  }
-  if (!q.dst_t) return;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 16 * i, k = k0 + r, n = n0 + c4;
-    if (k < q.K && n < q.N) {
-      const float v[4] = {lds[c4][r], lds[c4 + 1][r], lds[c4 + 2][r], lds[c4 + 3][r]};
-      Elt<TO>::st4(reinterpret_cast<TO*>(q.dst_t) + (long)k * q.ld_dst_t + n, v);
-    }
-  }
-}
-__device__ __forceinline__ bool shadow_vec_ok(const vln_shadow_job& q) {
-  const uintptr_t al = (uintptr_t)q.src | (uintptr_t)q.src2 | (uintptr_t)q.dst | (uintptr_t)q.dst_t;
-  return !((q.N | q.K | (int)q.ld_src | (int)q.ld_dst | (int)q.ld_dst_t) & 3) && !(al & 15);
-}
-__device__ __forceinline__ void shadow_block(const ShadowJobs& a, int block, float (*lds)[65]) {
-  int ji = 0;
-  while (ji + 1 < a.n && block >= a.tile0[ji + 1]) ++ji;
-  const vln_shadow_job& q = a.j[ji];
-  const int tile = block - a.tile0[ji];
-  if (shadow_vec_ok(q)) {
-    if (q.out_type == W_BF16) shadow_tile_v4<bf16_raw>(q, tile, lds);
-    else shadow_tile_v4<float>(q, tile, lds);
-  } else if (q.out_type == W_BF16) shadow_tile<bf16_raw>(q, tile, lds);
-  else shadow_tile<float>(q, tile, lds);
-}
+// ---- all shadows of a module in ONE launch (shadow_bodies.h) --------------------------------------------------------
+using ShadowJobs = ShadowJobsT<VLN_SHADOW_MAX_JOBS>;
 __global__ __launch_bounds__(256) void shadow_refresh_kernel(ShadowJobs a) {
   __shared__ float lds[64][65];
-  shadow_block(a, (int)blockIdx.x, lds);
-}
-static int shadow_jobs(const vln_shadow_job* jobs, int n, ShadowJobs* a, int* tiles) {
-  a->n = n;
-  int t = 0;
-  for (int i = 0; i < n; ++i) {
-    const vln_shadow_job& q = jobs[i];
-    if (!q.src || q.N <= 0 || q.K <= 0 || (!q.dst && !q.dst_t)) { set_error("shadow_refresh: bad job %d", i); return VLN_ERR_ARG; }
-    a->j[i] = q;
-    a->tile0[i] = t;
-    t += ((q.N + 63) / 64) * ((q.K + 63) / 64);
-  }
-  a->tile0[n] = t;
-  *tiles = t;
-  return VLN_OK;
+  shadow_block<false>(a, (int)blockIdx.x, lds);
 }
 int shadow_refresh(hipStream_t st, const vln_shadow_job* jobs, int n) {
   for (int base = 0; base < n; base += VLN_SHADOW_MAX_JOBS) {
@@ -1199,7 +1109,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(FetchArgs f, int nf, Shad
   __shared__ float lds[64][65];
   const int b = (int)blockIdx.x;
   if (b < nf) { host_fetch_body(f, b, nf, (int)threadIdx.x); return; }
-  if (b < nf + tiles) { shadow_block(sj, b - nf, lds); return; }
+  if (b < nf + tiles) { shadow_block<false>(sj, b - nf, lds); return; }
   tick_body(tk, (int)threadIdx.x);
 }
 

@@ -281,6 +281,26 @@ class RolloutRide:
             self._keep = (self._keep, feed)
         return self
 
+    def carry_shadows(self, modules):
+        """The carrier launch also refreshes the weight shadows of `modules` (whatever the last optimizer step staled, as
+        `DeviceClock.prologue(modules=...)` would): modules the carrier does NOT read itself -- the decoder, first used after the
+        instruction encoder.  The passengers do it once their rows are gathered, so those bytes leave the iteration's dependent
+        chain (the prologue launch was bound by them).  The modules' own forward then finds its shadows current."""
+        with ops.ShadowBatch.collect() as handles:
+            for m in modules:
+                m.prefresh()
+        return self.carry_shadow_jobs([h[0][i] for h in handles for i in range(h[1])], handles)
+
+    def carry_shadow_jobs(self, jobs, keep=None):
+        """`carry_shadows` for explicit jobs (a sequence of _lib.ShadowJob, e.g. ops.ShadowBatch().jobs): same results as
+        vln_shadow_refresh on them."""
+        n = len(jobs)
+        if n:
+            arr = (_lib.ShadowJob * n)(*jobs)
+            self.struct.shadow_jobs, self.struct.n_shadow_jobs = C_.addressof(arr), n
+            self._keep = (self._keep, arr, keep)
+        return self
+
 
 class PinnedStager:
     """Ring of pinned host buffers + a copy stream.  `put(name->array)` returns device tensors that are ordered
@@ -349,9 +369,14 @@ class HostBatchFeed:
     The protocol is CHECKED on the host (round 5): the device picks its slot by a count of the fetches that have run, the host
     writes the slot of its count of selects, and nothing else ties the two -- so a fetch issued without a select before it (an
     eager warm-up iteration of a capture, a retry after an exception), or a second select before the first one's fetch was issued,
-    raises here instead of silently pulling a stale or empty slot from then on.  `resync()` realigns the two counts."""
+    raises here instead of silently pulling a stale or empty slot from then on.  `resync()` realigns the two counts.
+    prefetch=True (round 5): `select(blob)` also SENDS the blob ahead -- one asynchronous H2D copy on a copy stream into a ring of
+    device-resident staging slots, ordered before whatever the current stream launches next -- and the slot word holds the staging
+    slot's address: the fetch kernel then moves the batch HBM -> HBM.  The host runs ahead of the device, so the copy crosses PCIe
+    under the PREVIOUS iteration's compute instead of inside the iteration's first launch (a GPU pulling 118 KB over PCIe is bound
+    by its outstanding read requests: 27 us of the dependent chain at B = 64, profiles/round5_notes.md)."""
 
-    def __init__(self, live: torch.Tensor, ring: int = 16):
+    def __init__(self, live: torch.Tensor, ring: int = 16, prefetch: bool = False):
         if not live.is_cuda or live.dtype != torch.uint8 or live.numel() % 16 or live.data_ptr() % 16:
             raise ValueError("HostBatchFeed: the live buffer is a 16-byte aligned uint8 device tensor whose size is a multiple of 16")
         self.live, self.ring = live, int(ring)
@@ -363,6 +388,12 @@ class HostBatchFeed:
         self._issued = 0                                                        # fetch executions issued (eager launches + replays)
         self._events = [None] * self.ring
         self.head = live.numel()        # bytes the fetch itself pulls; the rest (split_at) rides in a later launch of the iteration
+        self.prefetch = bool(prefetch)
+        if self.prefetch:
+            self._stage = torch.empty(self.ring, live.numel(), dtype=torch.uint8, device=live.device)
+            self._copy_stream = torch.cuda.Stream(live.device)
+            self._sent = [torch.cuda.Event() for _ in range(self.ring)]
+            self._ahead = None                  # (select index, blob address) send_ahead() has already sent
 
     def split_at(self, offset: int):
         """The fetch pulls bytes [0, offset) only; [offset, end) -- the part nothing reads before the decoder -- is pulled by whoever
@@ -407,8 +438,37 @@ class HostBatchFeed:
         if ev is not None:                      # the iteration that read this slot `ring` selects ago must have run
             ev.synchronize()
             self._events[i] = None
-        self.slots[i] = self._addr[blob.data_ptr()]
+        if self.prefetch:
+            # the blob travels on the copy stream -- now, unless send_ahead() already sent it to this slot -- and what the current
+            # stream launches next (the iteration with the fetch) waits for it
+            if blob.data_ptr() not in self._addr:
+                raise KeyError("HostBatchFeed.select: the blob was not registered")
+            if self._ahead != (self._selected, blob.data_ptr()):
+                self._send(i, blob)
+            self._ahead = None
+            torch.cuda.current_stream(self.live.device).wait_event(self._sent[i])
+            self.slots[i] = self._stage[i].data_ptr()
+        else:
+            self.slots[i] = self._addr[blob.data_ptr()]
         self._selected += 1
+
+    def _send(self, i, blob):
+        with torch.cuda.stream(self._copy_stream):
+            self._stage[i].copy_(blob.view(torch.uint8).view(-1), non_blocking=True)
+            self._sent[i].record(self._copy_stream)
+
+    def send_ahead(self, blob: torch.Tensor):
+        """prefetch only: start the copy of the blob the NEXT select() will pick (call it right after a select: the copy then has
+        a whole iteration to cross PCIe in).  A select() of a different blob simply sends that one."""
+        if not self.prefetch:
+            return
+        i = self._selected % self.ring
+        ev = self._events[i]
+        if ev is not None:                      # the iteration that read this staging slot `ring` selects ago must have run
+            ev.synchronize()
+            self._events[i] = None
+        self._send(i, blob)
+        self._ahead = (self._selected, blob.data_ptr())
 
     def launched(self):
         """Call after issuing the launch / graph replay that contains the fetch of the last `select`."""
@@ -436,6 +496,8 @@ class HostBatchFeed:
         self._selected = self._issued
         self._state[0] = self._issued
         self._events = [None] * self.ring
+        if self.prefetch:
+            self._ahead = None
 
     def fetch_args(self):
         """The pull as arguments of `vln_prologue` (runtime.DeviceClock.prologue issues it together with the tick and the refreshes)."""

@@ -42,7 +42,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_RELU 2
 #define VLN_ACT_ACCUM 8   /* flag, OR-ed onto an activation: the finished result is ADDED to the output (vln_linear_fwd: Y += ...) */
 
-int vln_abi_version(void);     /* 14 */
+int vln_abi_version(void);     /* 17 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -606,6 +606,11 @@ typedef struct vln_gather_ride {
    * passenger workgroup: the part of a packed batch that only the decoder reads (angle features, masks, targets) crosses PCIe under
    * the recurrence instead of in front of it.  Multiples of 16 bytes; without room for passengers it is its own small launch. */
   const uint64_t* fetch_slots; const uint64_t* fetch_seq; void* fetch_dst; int64_t fetch_offset, fetch_bytes; int32_t fetch_ring, pad2_;
+  /* optional (ABI v17; NULL / 0 = none): weight-shadow jobs (vln_shadow_refresh's, HOST array) of modules the carrier launch does
+   * not read itself -- the decoder's, whose first use comes after the instruction encoder -- refreshed by the passengers once their
+   * rows are gathered: 69 of the 79 MB the iteration's prologue launch moved at B = 64 leave the dependent chain.  Same results as
+   * vln_shadow_refresh(shadow_jobs, n_shadow_jobs); more than 8 jobs, or no room for passengers: that call is issued instead. */
+  const vln_shadow_job* shadow_jobs; int32_t n_shadow_jobs, pad3_;
 } vln_gather_ride;
 /* Index range checks (ABI v10).  A caller that registers its table's extent -- N viewpoint rows, and the number of view
  * indices the angle table holds (36) -- gets every gather of that table (all entry points below, the in-step gather of

@@ -17,7 +17,7 @@ def vln():
 
 
 def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmented=False, calls=None, source="device", chain=True,
-         prologue=True, ride=True, shape=(16, 24, 4, 6)):
+         prologue=True, ride=True, shape=(16, 24, 4, 6), ride_shadows=False):
     import bench
     dev = torch.device(DEV)
     torch.manual_seed(77)
@@ -30,6 +30,7 @@ def _run(vln, dtype, graph, branch, n_eager=2, n_more=4, near_wrap=False, segmen
     ag.use_live(live)
     ag.dec.chain_steps = chain
     ag.use_prologue = prologue
+    ag.ride_shadows = ride_shadows                       # the decoder's weight shadows refreshed by the gather ride's passengers
     ag.dec.ride_wgrads = bool(ride and not segmented)    # as bench.py sets it for one GPU (bf16 mode only: the module checks)
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True           # float atomics would differ between two runs of the SAME path
@@ -220,14 +221,18 @@ def test_prologue_launch_equals_separate_launches(vln, graph, source):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the prologue launch and separate launches"
 
 
+@pytest.mark.parametrize("source", ["pull", "push"])
 @pytest.mark.parametrize("graph", [True, False])
-def test_batches_pulled_from_pinned_host_memory_equal_copied_batches(vln, graph):
+def test_batches_pulled_from_pinned_host_memory_equal_copied_batches(vln, graph, source):
     """bench.LiveBatch("pull") / staging.HostBatchFeed / vln_host_fetch: the batches wait in pinned host memory, `load(k)` is one
     host store into a ring of slot words and the iteration's FIRST launch pulls the batch through PCIe -- also as the first node of
     the captured iteration.  22 iterations over 5 different batches (the 16-slot ring wraps, the host runs ahead of the device):
-    losses, parameters, optimizer state and gradient norms equal the device-resident batches' bit for bit."""
+    losses, parameters, optimizer state and gradient norms equal the device-resident batches' bit for bit.
+    source "push" (round 5): the same batches SENT ahead -- an asynchronous H2D copy on a copy stream into a device ring slot, one
+    select early (HostBatchFeed(prefetch=True).send_ahead), the first launch then moves the batch HBM -> HBM -- and, in that run, the
+    decoder's weight shadows refreshed by the gather ride's passengers instead of the prologue launch (RolloutRide.carry_shadows)."""
     ref, _, _ = _run(vln, torch.bfloat16, graph, "ride", n_more=20)
-    got, _, _ = _run(vln, torch.bfloat16, graph, "ride", n_more=20, source="pull")
+    got, _, _ = _run(vln, torch.bfloat16, graph, "ride", n_more=20, source=source, ride_shadows=source == "push")
     assert len(ref) == len(got) == 22
     for i, (a, b) in enumerate(zip(ref, got)):
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state", "gradient norms")):

@@ -440,7 +440,9 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
     precisions at once (the plain 8-rows-per-pass passenger loop); 13 steps (more than one argument block holds: the ride runs
     as its own launch in front of the recurrence); the per-step recurrence (no persistent launch to ride in: the same); B = 128
     (two directions x 16 unit slices x 8 row blocks = 256 workgroups fill every CU of an MI355X, no passenger fits:
-    the library must notice BEFORE it commits to passengers and issue the gather as its own launch -- round 3 dropped it)."""
+    the library must notice BEFORE it commits to passengers and issue the gather as its own launch -- round 3 dropped it).
+    Every variant also hands the ride four weight-shadow jobs (vln_gather_ride::shadow_jobs): refreshed by the passengers, or by
+    their own launch where there are none, bit for bit what vln_shadow_refresh writes."""
     import bench
     dev_ = torch.device(DEV)
     lib = vln._lib.load()
@@ -462,12 +464,30 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
         ctx0, h0, c0 = enc(tape["tokens"], tape["lengths32"])
         store._calls = 0; enc._calls = 0
         ride = store.rollout_ride(steps, 0.3, **want)
+        # ... and the ride carries weight-shadow jobs (ABI v17): an aligned matrix with both copies, a ragged one (scalar tile
+        # path), a transposed-only fp32 copy and a two-source bias sum == vln_shadow_refresh on the same jobs
+        gs = torch.Generator().manual_seed(5)
+        srcs = [torch.randn(n, k, generator=gs).to(dev_) for n, k in ((192, 320), (70, 45), (128, 64), (1, 1024), (1, 1024))]
+        def shadow_batch():
+            sb = vln.ops.ShadowBatch()
+            outs = [torch.full((192, 320), 7.0, dtype=torch.bfloat16, device=dev_), torch.full((320, 192), 7.0, dtype=torch.bfloat16, device=dev_),
+                    torch.full((70, 45), 7.0, dtype=torch.bfloat16, device=dev_), torch.full((45, 70), 7.0, dtype=torch.bfloat16, device=dev_),
+                    torch.full((64, 128), 7.0, device=dev_), torch.full((1, 1024), 7.0, device=dev_)]
+            sb.add(srcs[0], outs[0], outs[1]); sb.add(srcs[1], outs[2], outs[3]); sb.add(srcs[2], None, outs[4])
+            sb.add(srcs[3], outs[5], None, src2=srcs[4])
+            return sb, outs
+        sb_ref, shadows_ref = shadow_batch()
+        sb_ref.run()
+        sb_ride, shadows_ride = shadow_batch()
+        ride.carry_shadow_jobs(sb_ride.jobs, sb_ride.keep)
         ctx1, h1, c1 = enc(tape["tokens"], tape["lengths32"], ride=ride)
         torch.cuda.synchronize()
     finally:
         lib.vln_set_persistent(1)
     vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
     assert torch.equal(ctx0, ctx1) and torch.equal(h0, h1) and torch.equal(c0, c1)
+    for x, y in zip(shadows_ref, shadows_ride):
+        assert torch.equal(x, y) and not bool((y.float() == 7.0).all())
     assert len(ride.outputs) == T
     for (a_img, a_cand), (b_img, b_cand) in zip(ref, ride.outputs):
         for x, y in list(zip(a_img, b_img)) + list(zip(a_cand, b_cand)):
