@@ -791,6 +791,11 @@ static int launch_persist_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* cou
 }
 
 static int ride_passengers(int nrec);
+// Recurrence workgroups on XCDs 0-3, passengers on XCDs 4-7 (persist_role, encoder_persist.h): when the recurrence's workgroups come
+// in fours and fit half of the device's compute units -- ride_passengers() then allows as many passengers as the other half holds.
+static bool ride_partitioned(int nrec) {
+  return g_tunable[15] != 1 && nrec > 0 && (nrec & 3) == 0 && 2 * nrec <= device_cus();
+}
 // the shadow jobs a gather ride carries, as their own launch (no passengers to carry them)
 static int ride_shadows_launch(hipStream_t st, const ::vln_gather_ride& r) {
   if (r.n_shadow_jobs < 0 || (r.n_shadow_jobs > 0 && !r.shadow_jobs)) { set_error("gather ride: bad shadow jobs"); return VLN_ERR_ARG; }
@@ -806,20 +811,24 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
   const int nrec = (int)g1.x;
   // bit 0: one XCD per dependency group; bit 1: the hand-off stores may stay in that XCD's L2 once the group has verified that it
   // does run on one XCD (encoder_persist.h; tunable[14] = 1: always write-through, A/B)
-  const int xm = (g_tunable[7] != 1 ? 1 : 0) | (g_tunable[14] != 1 ? 2 : 0);
+  int xm = (g_tunable[7] != 1 ? 1 : 0) | (g_tunable[14] != 1 ? 2 : 0);
   static const WgradRideArgs no_ride{};
   unsigned lds_claim = 0;
+  int np = 0;
   if (ride) {
     // passengers on the CUs the recurrence leaves idle; the dynamic-LDS claim keeps the launch at ONE workgroup per CU (the
     // passengers' barrier needs all of them resident, and they must not share a CU with the latency-bound recurrence)
     // HALF as many passengers as recurrence workgroups by default: their traffic slows the recurrence's hand-offs, and the ride only
     // has to finish inside the launch (B = 64: 128 passengers 1.680 ms, 96 1.667, 48-80 1.665, 32 1.705 -- the ride outlasts the
     // BPTT --, own launches 1.698; profiles/round4_notes.md).  tunable[11] >= 8 sets the cap (A/B).
-    int np = ride_passengers(nrec) & ~7;
+    np = ride_passengers(nrec) & ~7;
     const int cap = g_tunable[11] >= 8 ? (g_tunable[11] & ~7) : (nrec / 2 > 8 ? (nrec / 2) & ~7 : 8);
     if (np > cap) np = cap;
     if (np <= 0 || (nrec & 7)) { set_error("persistent lstm bwd: a gradient ride was handed to a launch with no room for passengers"); return VLN_ERR_ARG; }
-    g1.x += (unsigned)np; lds_claim = kRideLdsClaim;
+    // the two kinds of workgroup on disjoint XCDs when the recurrence fits four of them (persist_role; tunable[15] = 1: interleaved, A/B)
+    if (ride_partitioned(nrec)) { xm |= 4; g1.x = 2u * (unsigned)nrec; }
+    else g1.x += (unsigned)np;
+    lds_claim = kRideLdsClaim;
   }
   const WgradRideArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_BWD(NT_)                                                                                              \
@@ -830,7 +839,7 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
       static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<TW, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm bwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), lds_claim, st, a, counters, status, sticky, exch, xm, nrec, rd); \
+    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), lds_claim, st, a, counters, status, sticky, exch, xm, nrec, np, rd); \
   }                                                                                                                       \
   break
   switch (a.Hd / 64) {
@@ -911,16 +920,20 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
                 "the forward recurrence launch's arguments must fit the 4 KB a launch may pass");
   dim3 g1(grid.x * grid.y * grid.z);
   const int nrec = (int)g1.x;
-  const int xm = g_tunable[7] != 1;
+  int xm = g_tunable[7] != 1;
   constexpr int BK = RecCfg<TW>::BK;
   static const GatherRolloutArgs no_ride{};
   unsigned lds_claim = 0;
+  int np = 0;
   if (ride) {
     // passengers on the CUs the recurrence leaves idle (at most as many as it has workgroups); 96 KB of dynamic LDS on top of
     // the kernel's own ~20 KB: ONE workgroup per compute unit, so the two kinds never share a CU
-    const int np = ride_passengers(nrec);
+    np = ride_passengers(nrec);
     if (np <= 0) { set_error("persistent lstm fwd: a gather ride was handed to a launch with no room for passengers (caller must check ride_passengers)"); return VLN_ERR_ARG; }
-    g1.x += (unsigned)np; lds_claim = kRideLdsClaim;
+    // the two kinds of workgroup on disjoint XCDs when the recurrence fits four of them (persist_role; tunable[15] = 1: interleaved, A/B)
+    if (ride_partitioned(nrec)) { xm |= 4; g1.x = 2u * (unsigned)nrec; }
+    else g1.x += (unsigned)np;
+    lds_claim = kRideLdsClaim;
   }
   const GatherRolloutArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_GF(NS_)                                                                                               \
@@ -931,7 +944,7 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
       static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, rd, \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, np, rd, \
                (ride ? fetch : FetchPart{}), (ride ? shadows : RideShadows{}));                                                   \
   }                                                                                                                       \
   break

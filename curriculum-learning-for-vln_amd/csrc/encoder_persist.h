@@ -48,11 +48,33 @@ constexpr int kRideBarWord = 1536;        // ... and (byte 6144) the two words o
 // loads then meet the producer's write-through stores in that XCD's L2 instead of crossing the fabric.  Placement is a
 // speed matter only -- the protocol (sc1 stores, counters, sc1 loads) does not assume it.
 struct PersistIdx { int jb, d, bb, nbb; };
-__device__ __forceinline__ PersistIdx persist_index(int njb, int dirs, int nbb, int xcd_map) {
-  const int id = (int)blockIdx.x, ngrp = dirs * nbb;
+// id: the workgroup's index among the recurrence's workgroups (blockIdx.x, or PersistRole::rid of a launch with passengers)
+__device__ __forceinline__ PersistIdx persist_index(int njb, int dirs, int nbb, int xcd_map, int id) {
+  const int ngrp = dirs * nbb;
   int g, jb;
   if (xcd_map) { g = id % ngrp; jb = id / ngrp; } else { jb = id % njb; g = id / njb; }
   return PersistIdx{jb, g % dirs, g / dirs, nbb};
+}
+
+// Who a workgroup of a launch WITH PASSENGERS is.  Plain form: the first `nrec` workgroups are the recurrence, the rest passengers --
+// workgroups go to the 8 XCDs round-robin, so every XCD's L2 serves both kinds, and the passengers' streaming traffic slows the
+// recurrence's hand-offs through that L2 (B = 64: the BPTT launch 166 us without passengers, 190 us with 64, 200 us with 96).
+// PARTITIONED form (bit 2 of xcd_map; round 5): of every 8 consecutive workgroups the first 4 -- XCDs 0-3 -- are recurrence
+// workgroups, the last 4 -- XCDs 4-7 -- passengers (the first `np` of them work, the others leave at once): the two kinds share no
+// L2.  Recurrence workgroup r sits on XCD r % 4, so with persist_index's group = r % (dirs * row blocks) a dependency group still
+// has ONE XCD whenever the group count is a multiple of 4 (two groups per XCD at B = 64: 32 workgroups, the XCD's 32 CUs).
+// Placement is a speed matter only, as above.
+struct PersistRole { int rid, pid; };     // rid >= 0: recurrence workgroup rid; else pid >= 0: passenger pid; else: nothing to do
+__device__ __forceinline__ PersistRole persist_role(int xcd_map, int nrec, int np) {
+  const int id = (int)blockIdx.x;
+  if (xcd_map & 4) {
+    const int xr = id & 7, ch = id >> 3;
+    if (xr < 4) return PersistRole{ch * 4 + xr < nrec ? ch * 4 + xr : -1, -1};
+    const int p = ch * 4 + (xr - 4);
+    return PersistRole{-1, p < np ? p : -1};
+  }
+  if (id < nrec) return PersistRole{id, -1};
+  return PersistRole{-1, id - nrec < np ? id - nrec : -1};
 }
 
 __device__ __forceinline__ void group_wait(unsigned* flags, int njb, unsigned epoch, unsigned* status, unsigned* sticky, int* s_abort) {
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(256) void lstm_persist_fwd_kernel(RecFwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map, (int)blockIdx.x);
   const int j0 = ix.jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int njb = HD / 16;
@@ -332,11 +354,12 @@ __host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int d
 
 template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
 __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map,
-                                                               int nrec, WgradRideArgs ride) {
+                                                               int nrec, int np, WgradRideArgs ride) {
   constexpr int HD = NT * 64;
-  if ((int)blockIdx.x >= nrec) {     // passengers (wgrad_ride.h): another module's parameter gradients on the CUs the recurrence leaves idle
+  const PersistRole role = persist_role(xcd_map, nrec, np);
+  if (role.rid < 0) {                // passengers (wgrad_ride.h): another module's parameter gradients on the CUs the recurrence leaves idle
     __shared__ float4 ride_part[64][4];
-    wgrad_ride_passenger(ride, (int)blockIdx.x - nrec, (int)gridDim.x - nrec, status, sticky, ride_part);
+    if (role.pid >= 0) wgrad_ride_passenger(ride, role.pid, np, status, sticky, ride_part);
     return;
   }
   constexpr int BK = RecCfg<TW>::BK, VK = RecCfg<TW>::VK;
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1);      // (bit 1 of xcd_map: the XCD-local hand-off may be used, see below)
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1, role.rid);      // (bit 1 of xcd_map: the XCD-local hand-off may be used, see below)
   const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) {
     s_abort = 0;
-    if (blockIdx.x == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status word (a timeout sets it long after this store)
+    if (role.rid == 0) VLN_AGENT_STORE(status, 0u);       // this launch's status word (a timeout sets it long after this store)
   }
   // XCD-LOCAL HAND-OFF (round 5).  The partial products are exchanged through memory: an `sc1` (write-through) store leaves the
   // writer's L2, and a reader on the SAME XCD then fetches the line at the cross-XCD rate (MI355X_MICROARCH.md, stores of each

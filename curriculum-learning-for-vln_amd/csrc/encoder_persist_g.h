@@ -74,14 +74,16 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 template <typename TW, int NS>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
-                                                                 int nrec, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
+                                                                 int nrec, int np_, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
   // PASSENGERS: workgroups past the recurrence's own `nrec` gather the rollout's feature rows (gather_body.h) on the compute
   // units the recurrence leaves idle -- independent work (it reads the resident table and index vectors only), nothing waits
   // for it inside this launch, and the launch claims a whole CU's LDS per workgroup so that a passenger never shares a CU with
   // a recurrence workgroup (whose hand-off latency is what a co-resident streaming wave would cost, MI355X_MICROARCH.md
   // "handoff-1to1").  Rows are dealt with the passengers' stride: any number of resident passengers finishes the job.
-  if ((int)blockIdx.x >= nrec) {
-    int p = (int)blockIdx.x - nrec, np = (int)gridDim.x - nrec;
+  const PersistRole role = persist_role(xcd_map, nrec, np_);
+  if (role.rid < 0) {
+    int p = role.pid, np = np_;
+    if (p < 0) return;
     if (fetch.on) {      // the LAST passenger pulls the tail of the batch blob out of pinned host memory (PCIe-bound, ~25 us) instead of gathering
       if (p == np - 1) { host_fetch_part_body(fetch, (int)threadIdx.x); return; }
       np -= 1;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1, role.rid);
   const int j0 = ix.jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
   if (threadIdx.x == 0) {
     s_abort = 0;
-    if (blockIdx.x == 0) VLN_AGENT_STORE(status, 0u);   // this launch's status (a timeout is >= 1 s away): no fill launch in front
+    if (role.rid == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status (a timeout is >= 1 s away): no fill launch in front
   }
   __syncthreads();
 
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_bwd_kernel(RecBwdArgs a, u
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map);
+  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map, (int)blockIdx.x);
   const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;

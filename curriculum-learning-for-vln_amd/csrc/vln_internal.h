@@ -41,6 +41,8 @@ int check_hip(hipError_t e, const char* what);
 //   [10] 1: a pending gradient ride (vln_wgrad_ride_post) is always issued as its own launches (A/B)
 //   [12] 1: tall products keep gemm_nt's 64-row tiles instead of the 16-row-block tiling of gemm_rows.h (A/B, same bits)
 //   [14] 1: the backward recurrence's hand-off stores are always write-through (sc1), also when its group verified that it runs on one XCD (A/B)
+//   [15] 1: a recurrence launch with passengers interleaves the two kinds of workgroup over all 8 XCDs (round 4) instead of keeping the
+//        recurrence on XCDs 0-3 and the passengers on XCDs 4-7 (persist_role, encoder_persist.h) (A/B)
 //   [11] >= 8: at most this many passenger workgroups carry a gradient ride (A/B; default: every idle CU up to the recurrence's own count)
 // The EnvDrop step's graph key includes [0..7] (the step has one row tile: [8] never applies), so a changed tunable never replays a stale graph.
 extern int g_tunable[16];
