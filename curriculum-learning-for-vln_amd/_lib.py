@@ -306,6 +306,7 @@ SIGNATURES = {
     "vln_monitor_bwd_scratch_floats": (i64, [ptr]),
     "vln_monitor_ws_floats": (i64, [ptr]),
     "vln_lstm_handoff_stats": (i32, [ptr, ptr, ptr]),
+    "vln_lstm_fwd_handoff_stats": (i32, [ptr, ptr, ptr]),
     "vln_bn0_grads_from_wgrad": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, ptr, i64, ptr]),
     "vln_gemm_rows_tiling": (i32, [i32, i32, i32, ptr, ptr, ptr]),
     "vln_monitor_step_fwd": (i32, [ptr, ptr, ptr, ptr]),

@@ -750,6 +750,17 @@ extern "C" int vln_lstm_handoff_stats(const void* sync_ws, uint32_t* xcd_local, 
   *xcd_local = w[0]; *spanning = w[1];
   return VLN_OK;
 }
+extern "C" int vln_lstm_fwd_handoff_stats(const void* sync_ws, uint32_t* xcd_local, uint32_t* spanning) {
+  if (!sync_ws || !xcd_local || !spanning) { set_error("vln_lstm_fwd_handoff_stats: null pointer"); return VLN_ERR_ARG; }
+  uint32_t w[2] = {0, 0};
+  if (hipMemcpy(w, static_cast<const char*>(sync_ws) + (32 + 10) * 4, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("vln_lstm_fwd_handoff_stats: copy failed");
+    return VLN_ERR_HIP;
+  }
+  *xcd_local = w[0]; *spanning = w[1];
+  return VLN_OK;
+}
 extern "C" int vln_set_split_attention(int on) { g_split_attn_enabled = on ? 1 : 0; return VLN_OK; }
 extern "C" int vln_get_split_attention(void) { return g_split_attn_enabled; }
 
@@ -920,7 +931,9 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
                 "the forward recurrence launch's arguments must fit the 4 KB a launch may pass");
   dim3 g1(grid.x * grid.y * grid.z);
   const int nrec = (int)g1.x;
-  int xm = g_tunable[7] != 1;
+  // bit 0: one XCD per dependency group; bit 1: the granule stores may stay in that XCD's L2 once the group has verified that it runs
+  // on one XCD (encoder_persist_g.h; tunable[14] = 1: always write-through, A/B)
+  int xm = (g_tunable[7] != 1 ? 1 : 0) | (g_tunable[14] != 1 ? 2 : 0);
   constexpr int BK = RecCfg<TW>::BK;
   static const GatherRolloutArgs no_ride{};
   unsigned lds_claim = 0;

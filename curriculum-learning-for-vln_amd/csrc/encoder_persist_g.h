@@ -139,9 +139,23 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(exch, 0, (unsigned)persist_g_fwd_bytes(B, HD, a.dirs), 0x00020000);
   const unsigned gbase = (unsigned)(d * ix.nbb + ix.bb) * grp_bytes;
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
+  // XCD-LOCAL HAND-OFF (round 5, as in the backward recurrence: encoder_persist.h).  A granule stored write-through (`sc1`) leaves
+  // the writer's L2, and the group's readers on the SAME XCD fetch it at the cross-XCD rate; a plain store keeps it in that L2.
+  // Correct only when the whole dependency group runs on one XCD, so it is verified per launch: every workgroup ORs its XCC_ID bit
+  // into word 12 of the group's flag line before its first publish (the barrier below drains the atomic); the sweep of step 1 has
+  // seen every member's first granule, hence every member's bit -- exactly one bit set switches the later publishes to plain
+  // stores.  The last workgroup of the group through the end of the kernel resets the two words (word 28 counts them).
+  // Bit 1 of xcd_map (tunable[14] = 1 clears it: always write-through, A/B).
+  unsigned* const gw = status + 32 + (unsigned)(d * ix.nbb + ix.bb) * 32u;
+  bool xcd_local = false;
   if (threadIdx.x == 0) {
     s_abort = 0;
     if (role.rid == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status (a timeout is >= 1 s away): no fill launch in front
+    if (xcd_map & 2) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      (void)__hip_atomic_fetch_or(gw + 12, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
 
@@ -176,6 +190,11 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
         }
       }
       VLN_STAMP(1);
+      if (step == 1 && (xcd_map & 2)) {            // every member's XCC_ID bit is in: each ORed it before the granules just seen
+        const unsigned m = VLN_AGENT_LOAD(gw + 12);
+        xcd_local = m != 0u && (m & (m - 1u)) == 0u && s_abort == 0;
+        if (threadIdx.x == 0 && ix.jb == 0) __hip_atomic_fetch_add(status + (xcd_local ? 10 : 11), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
         const int unit = threadIdx.x + u * 256;                 // pair index within the tile: row r, units 2*c2, 2*c2 + 1
@@ -232,7 +251,9 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       if ((jl & 1) == 0) {
         const unsigned tg_ = tag_base + (unsigned)step + 1u;
         const u32x4_t o = {__float_as_uint(hs), tg_, __float_as_uint(hnb), tg_};
-        __builtin_amdgcn_raw_buffer_store_b128(o, xres, gbase + (unsigned)(step & 1) * (16u * HD * 8u) + (unsigned)(bl * HD + j) * 8u, 0, VLN_GRAN_ST_AUX);   // sc1
+        const unsigned po = gbase + (unsigned)(step & 1) * (16u * HD * 8u) + (unsigned)(bl * HD + j) * 8u;
+        if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(o, xres, po, 0, 0);       // stays in this XCD's L2
+        else __builtin_amdgcn_raw_buffer_store_b128(o, xres, po, 0, VLN_GRAN_ST_AUX);   // sc1
       }
       if (live) a.hprev[(((long)d * L + tn) * B + b) * HD + j] = hs;     // history for BPTT / the weight gradients: plain
     } else if (live) {
@@ -249,6 +270,13 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       if (step == 0 && !a.init) a.hprev[(sbase + b) * HD + j] = 0.f;
     }
     VLN_STAMP(5);
+  }
+  if (threadIdx.x == 0 && (xcd_map & 2)) {       // the last workgroup of the group through leaves the two words as it found them (zero)
+    const unsigned through = __hip_atomic_fetch_add(gw + 28, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (through + 1u == (unsigned)(HD / 16)) {
+      __hip_atomic_store(gw + 12, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gw + 28, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -705,6 +705,8 @@ int vln_debug_raise_sticky(int word);
  * hand-off decisions -- dependency groups that verified they run on ONE XCD (their partial products stay in that XCD's L2) and groups
  * that span XCDs (write-through stores).  Synchronous. */
 int vln_lstm_handoff_stats(const void* sync_ws, uint32_t* xcd_local, uint32_t* spanning);
+/* (ABI v17) the same tallies for the FORWARD recurrence's granule hand-off (csrc/encoder_persist_g.h) */
+int vln_lstm_fwd_handoff_stats(const void* sync_ws, uint32_t* xcd_local, uint32_t* spanning);
 int vln_set_split_attention(int on);
 int vln_get_split_attention(void);
 /* dy_tm grad of y_tm (nullable); w_hh_t [dirs][Hd,4Hd]; dgates [L*B, dirs*4Hd] out; dh_pass/dc_carry [dirs][B][Hd]

@@ -409,18 +409,25 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
     import ctypes as C
     outs, tallies = [], []
 
-    def tally():
+    def tally(fwd=False):
         a, b = C.c_uint32(), C.c_uint32()
         ws = enc._sync_ws(torch.device(DEV), B, H // 2, 2)
-        vln._lib.check(lib.vln_lstm_handoff_stats(ws[0], C.byref(a), C.byref(b)), "vln_lstm_handoff_stats")
+        f = lib.vln_lstm_fwd_handoff_stats if fwd else lib.vln_lstm_handoff_stats
+        vln._lib.check(f(ws[0], C.byref(a), C.byref(b)), "vln_lstm_handoff_stats")
         return a.value, b.value
+    fouts, ftallies = [], []
     try:
         for t14, t7 in ((0, 0), (1, 0), (0, 1), (0, 0)):
             vln._lib.check(lib.vln_set_tunable(14, t14), "vln_set_tunable"); vln._lib.check(lib.vln_set_tunable(7, t7), "vln_set_tunable")
             for rep in range(2):
                 enc._calls = 0
                 enc.zero_grad(set_to_none=True)
+                fbefore = tally(True)
                 ctx, h, c = enc(tokens.to(DEV), lens)
+                torch.cuda.synchronize()
+                fafter = tally(True)
+                fouts.append((ctx.detach().clone(), h.detach().clone(), c.detach().clone()))
+                ftallies.append((t14, t7, fafter[0] - fbefore[0], fafter[1] - fbefore[1]))
                 before = tally()
                 ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
                 torch.cuda.synchronize()
@@ -435,6 +442,17 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
     for k, o in enumerate(outs[1:]):
         for n, a, b in zip(names, outs[0], o):
             assert torch.equal(a, b), f"run {k + 1}: grad[{n}] differs from the first run's"
+    # the FORWARD recurrence's granule hand-off takes the same decision the same way (round 5): same outputs bit for bit
+    for k, o in enumerate(fouts[1:]):
+        for a, b in zip(fouts[0], o):
+            assert torch.equal(a, b), f"run {k + 1}: the forward's outputs differ from the first run's"
+    for t14, t7, loc, span in ftallies:
+        if t14:
+            assert (loc, span) == (0, 0), ftallies
+        elif t7:
+            assert loc + span == 8 and span > 0, ftallies
+        else:
+            assert (loc, span) == (8, 0), ftallies
     # what the launches decided (vln_lstm_handoff_stats): 2 directions x 4 row blocks = 8 dependency groups per backward
     for t14, t7, loc, span in tallies:
         if t14:

@@ -475,6 +475,10 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
                     torch.full((64, 128), 7.0, device=dev_), torch.full((1, 1024), 7.0, device=dev_)]
             sb.add(srcs[0], outs[0], outs[1]); sb.add(srcs[1], outs[2], outs[3]); sb.add(srcs[2], None, outs[4])
             sb.add(srcs[3], outs[5], None, src2=srcs[4])
+            if variant == "both_outputs":          # nine jobs: more than one argument block of the carrier holds -> their own launch
+                for _ in range(5):
+                    outs.append(torch.full((64, 128), 7.0, device=dev_))
+                    sb.add(srcs[2], None, outs[-1])
             return sb, outs
         sb_ref, shadows_ref = shadow_batch()
         sb_ref.run()
