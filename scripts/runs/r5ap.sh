@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, GPU call ap: recurrence launch durations, XCD-partitioned vs interleaved roles (kernel traces)
+# round 5, GPU call ap: recurrence launch durations in the headline (kernel trace)
 OUT=gpurun_out/r5ap; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
-for F in "--tunable 15=1" "" "--tunable 11=96" "--tunable 11=128"; do
+for F in "" "--no-ride-wgrads --ride-gather off"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$i -o trace -- python3 bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-secondary --no-roofline $F > $OUT/bench_$i.json 2> $OUT/bench_$i.err
   python3 scripts/rocpd_stats.py $(ls $OUT/trace_$i/*results.db | head -1) --iters 72 > $OUT/stats_$i.txt 2>&1
