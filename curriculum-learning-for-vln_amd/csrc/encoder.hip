@@ -831,7 +831,8 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
     // passengers' barrier needs all of them resident, and they must not share a CU with the latency-bound recurrence)
     // HALF as many passengers as recurrence workgroups by default: their traffic slows the recurrence's hand-offs, and the ride only
     // has to finish inside the launch (B = 64: 128 passengers 1.680 ms, 96 1.667, 48-80 1.665, 32 1.705 -- the ride outlasts the
-    // BPTT --, own launches 1.698; profiles/round4_notes.md).  tunable[11] >= 8 sets the cap (A/B).
+    // BPTT --, own launches 1.698; profiles/round4_notes.md).  tunable[11] >= 8 sets the cap (A/B).  (Round 5, partitioned form below:
+    // 64, 96 or 128 passengers cost the BPTT the same 184 us -- the cap no longer matters there.)
     np = ride_passengers(nrec) & ~7;
     const int cap = g_tunable[11] >= 8 ? (g_tunable[11] & ~7) : (nrec / 2 > 8 ? (nrec / 2) & ~7 : 8);
     if (np > cap) np = cap;

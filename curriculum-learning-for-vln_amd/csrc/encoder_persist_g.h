@@ -75,8 +75,8 @@ template <typename TW, int NS>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
                                                                  int nrec, int np_, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
-  // PASSENGERS: workgroups past the recurrence's own `nrec` gather the rollout's feature rows (gather_body.h) on the compute
-  // units the recurrence leaves idle -- independent work (it reads the resident table and index vectors only), nothing waits
+  // PASSENGERS: the workgroups that are not the recurrence's own `nrec` (persist_role, encoder_persist.h: past them, or -- partitioned
+  // form -- the ones on XCDs 4-7) gather the rollout's feature rows (gather_body.h) on the compute units the recurrence leaves idle -- independent work (it reads the resident table and index vectors only), nothing waits
   // for it inside this launch, and the launch claims a whole CU's LDS per workgroup so that a passenger never shares a CU with
   // a recurrence workgroup (whose hand-off latency is what a co-resident streaming wave would cost, MI355X_MICROARCH.md
   // "handoff-1to1").  Rows are dealt with the passengers' stride: any number of resident passengers finishes the job.

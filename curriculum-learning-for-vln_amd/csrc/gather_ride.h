@@ -3,12 +3,14 @@
 // A passenger compute unit holds ONE 256-thread workgroup (the launch claims a CU's LDS per workgroup so that passengers never
 // share a CU with a recurrence workgroup), i.e. one wave per SIMD: nothing hides a wave's memory latency or its Philox
 // arithmetic but the wave itself.  Measured with the plain per-row loop: 287 us for the 7 x 2944 rows of the headline
-// rollout, longer than the 179 us recurrence it rides in (profiles/round3_notes.md); this loop: 150 us alone.  It is a three-stage
-// software pipeline over groups of 8 output rows, every memory operation unconditional (clamped addresses, idempotent
-// duplicate stores for the rows past the end of a step) so that the wait counts the compiler places stay exact:
-//   A(i+2): the rows' table indices (wave-uniform scalar loads) and the angle item's index / heading;
-//   B(i+1): the 8 rows' 16-byte loads per thread + the angle item's load;
-//   C(i)  : Philox scale, pack, store.
+// rollout, longer than the 179 us recurrence it rides in (profiles/round3_notes.md); round 3's pipeline 175 us alone; this loop
+// 95 us (round 5, profiles/round5_notes.md section 11).  It is a software pipeline over groups of 8 output rows, every memory
+// operation unconditional (clamped addresses, idempotent duplicate stores for the rows past the end of a step) so that the
+// wait counts the compiler places stay exact -- there is no vmcnt(0) in the loop:
+//   A1(i+2): lanes 0-7 load the 8 rows' table indices, one vector load per index array, + the dropout offset words;
+//   A2(i+1): the same arithmetic for the 8 rows at once, v_readlane into the wave-uniform RideIdx (+ the angle item's);
+//   B(i+1) : the 8 rows' 16-byte non-temporal loads per thread + the angle item's load;
+//   C(i)   : Philox scale, pack, non-temporal store.
 // Same outputs, same Philox indexing as gather_step_rows (tests/test_hip_staging.py compares them bit for bit).
 // Requires IMG == 2048 (one 8-element chunk per thread per row), ANG == 128 (one float4 per lane of a half-wave per row) and
 // exactly one output precision (GatherRolloutArgs::pipe: 1 = bf16 outputs, 2 = fp32 outputs); else the plain loop runs.
