@@ -733,6 +733,8 @@ def main():
     ap.add_argument("--no-prologue", action="store_true", help="(A/B) the batch pull, the clock tick and the shadow refreshes as separate launches")
     ap.add_argument("--no-ride-wgrads", action="store_true", help="(A/B) the decoder's weight / bias gradients as their own launches in front of "
                     "the encoder's BPTT instead of passengers of its launch (ops.GradRide); N > 1 and --dp-path never ride")
+    ap.add_argument("--no-dx-post", action="store_true", help="(A/B) the encoder backward's d x product as its own launch behind the weight "
+                    "gradients instead of extra workgroups of their pack launch (EncoderLSTM.dx_with_wgrads, vln_linear_fwd_post)")
     ap.add_argument("--no-split-pull", action="store_true", help="(A/B) the iteration's first launch pulls the WHOLE batch blob instead of leaving the "
                     "decoder-only part to a passenger workgroup of the encoder's recurrence launch")
     ap.add_argument("--no-chain", action="store_true", help="(A/B) decoder steps not chained: every step issues its own last stage")
@@ -814,6 +816,7 @@ def main():
     agent.gather_branch = bool(args.gather_branch)
     agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
     agent.ride_shadows = bool(args.ride_shadows)
+    agent.enc.dx_with_wgrads = not args.no_dx_post
     agent.probe_trivial = int(args.probe_trivial)
     agent.dump_graph = args.dump_graph
     if args.no_chain:

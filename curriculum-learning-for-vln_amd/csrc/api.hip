@@ -504,6 +504,12 @@ extern "C" int vln_debug_trivial_chain(float* a, float* b, int n_floats, int lau
   return VLN_OK;
 }
 
+extern "C" int vln_linear_fwd_post(const float* x, int64_t ldx, const void* w, int wtype, int64_t ldw, float* y, int64_t ldy, int M, int N, int K) {
+  return linear_fwd_post(x, (long)ldx, w, wtype, (long)ldw, y, (long)ldy, M, N, K);
+}
+extern "C" int vln_linear_fwd_post_flush(float* ws, int64_t ws_floats, vln_stream_t s) {
+  return linear_fwd_post_flush((hipStream_t)s, ws, (long)ws_floats);
+}
 extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {
   if (!jobs || n_jobs <= 0) { set_error("vln_shadow_refresh: bad args"); return VLN_ERR_ARG; }
   return shadow_refresh((hipStream_t)s, jobs, n_jobs);

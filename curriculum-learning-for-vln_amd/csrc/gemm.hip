@@ -695,12 +695,64 @@ static bool wgrad_packed_tables(const vln_wgrad_job* jobs, int n, int Mt, float*
   return true;
 }
 
+// ---- a POSTED product (vln_linear_fwd_post): Y = X W^T that the NEXT packed weight-gradient call issues as extra workgroups of its
+// pack launch.  The encoder backward's d x = dgates W_ih (M = L * B rows, 320 tiles of 32 K-steps: 36 us, bound by its first-touch
+// latencies and by 1.25 tiles per CU) and the pack of the same dgates for the layer's weight gradients (HBM-bound, 21 us) do not depend
+// on each other: in one launch the pack's blocks fill the slots the product's tiles leave.  Same tiles, same kernel body as the
+// stand-alone call: bit-identical.  A post that no packed call takes is issued on its own by vln_linear_fwd_post_flush.
+struct PostedProduct { bool on = false; const float* X; long ldx; const void* W; int wtype; long ldw; float* Y; long ldy; int M, N, K; };
+static thread_local PostedProduct g_posted;
+
+template <typename TW>
+__global__ __launch_bounds__(256) void wgrad_pack_gemm_kernel(PackJobs pk, GemmNTArgs a, int gx, int gz) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kPlanes)];
+  const int ng = gx * gz;
+  if ((int)blockIdx.x >= ng) { wgrad_pack_block(pk, (int)blockIdx.x - ng); return; }
+  int t = (int)blockIdx.x;
+  if (a.xcd) t = (t & 7) * (ng >> 3) + (t >> 3);          // gemm_nt_kernel's XCD-aware tile order (ng % 8 == 0)
+  const VBlock vb{t % gx, 0, t / gx, (int)threadIdx.x, smem};
+  gemm_nt_body<TW, 2, true, 1>(a, vb, true, gemm_nt_nsteps(a, 0, GemmCfg<TW>::BK), [] {});
+}
+// the posted product as gemm_nt's un-split fast launch would run it: its argument block and tile grid; false: not that form
+static bool posted_args(const PostedProduct& p, GemmNTArgs* a, int* gx, int* gz) {
+  if (p.wtype != W_BF16 && p.wtype != W_F32) return false;
+  const int BK = (p.wtype == W_F32) ? 32 : 64;
+  const bool fast = aligned16(p.X) && (p.ldx % 4 == 0) && aligned16(p.W) && (p.ldw % (p.wtype == W_BF16 ? 8 : 4) == 0) && (p.K % BK == 0) &&
+                    g_tunable[5] != 2 && g_tunable[5] != 4;
+  if (!fast || n16_applies(p.M, p.N, p.K, p.wtype) || gemm_nt_plain_slabs(p.M, p.N, p.K, p.wtype, 1L << 40) != 1) return false;
+  const int nb = (p.N + 63) / 64, mb = (p.M + 63) / 64;
+  a->X = p.X; a->ldx = p.ldx; a->W = p.W; a->ldw = p.ldw; a->Y = p.Y; a->ldy = p.ldy; a->slab_stride = 0;
+  a->bias = nullptr; a->act = ACT_NONE; a->M = p.M; a->N = p.N; a->K = p.K; a->kchunk = ((p.K + BK - 1) / BK) * BK;
+  a->xvec = 1; a->wvec = 1;
+  a->xcd = (mb >= 8 && nb > 1 && ((long)nb * mb) % 8 == 0 && g_tunable[8] != 0) ? 1 : 0;
+  *gx = nb; *gz = mb;
+  return true;
+}
+int linear_fwd_post(const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M, int N, int K) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) { set_error("vln_linear_fwd_post: bad args"); return VLN_ERR_ARG; }
+  if (g_posted.on) { set_error("vln_linear_fwd_post: a posted product is still pending (vln_linear_fwd_post_flush)"); return VLN_ERR_ARG; }
+  g_posted = PostedProduct{true, X, ldx, W, wtype, ldw, Y, ldy, M, N, K};
+  return VLN_OK;
+}
+int linear_fwd_post_flush(hipStream_t st, float* ws, long ws_floats) {
+  if (!g_posted.on) return VLN_OK;
+  const PostedProduct p = g_posted;
+  g_posted.on = false;
+  return gemm_nt(st, p.X, p.ldx, p.W, p.wtype, p.ldw, p.Y, p.ldy, p.M, p.N, p.K, nullptr, ACT_NONE, ws, ws_floats, nullptr);
+}
+
 static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms,
                                 int seg_rows = 0, const int64_t* dy_seg = nullptr, const int64_t* x_seg = nullptr) {
   PackJobs pk; PackedJobs g;
   int blk = 0; double bytes = 0.0;
   if (!wgrad_packed_tables<VLN_WGRAD_MAX_JOBS>(jobs, n, Mt, ws, ws_floats, terms, seg_rows, dy_seg, x_seg, pk, g, &blk, &bytes))
     return -1;                                                        // caller falls back to the LDS-staged kernel
+  GemmNTArgs pa; int gx = 0, gz = 0;
+  if (g_posted.on && posted_args(g_posted, &pa, &gx, &gz)) {          // the posted product's tiles first, the pack blocks behind them
+    if (g_posted.wtype == W_BF16) VLN_LAUNCH(wgrad_pack_gemm_kernel<bf16_raw>, dim3(gx * gz + blk), dim3(256), 0, st, pk, pa, gx, gz);
+    else VLN_LAUNCH(wgrad_pack_gemm_kernel<float>, dim3(gx * gz + blk), dim3(256), 0, st, pk, pa, gx, gz);
+    g_posted.on = false;
+  } else
   VLN_LAUNCH(wgrad_pack_kernel, dim3(blk), dim3(256), 0, st, pk);
   if (terms == 3) launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<3>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);
   else launch_timed(K_GEMM_TN, bytes, wgrad_packed_kernel<1>, dim3(g.per_xcd * 8, g.msplit), dim3(256), 0, st, g);

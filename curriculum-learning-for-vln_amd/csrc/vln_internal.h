@@ -179,6 +179,8 @@ int reduce_epilogue(hipStream_t st, const float* slabs, int nsplit, long slab_st
 // Wt[K,N] = W[N,K]^T (fp32 or bf16 out);  Wc = cast(W)
 int transpose_cast(hipStream_t st, const float* W, long ldw, void* Wt, int out_type, long ldt, int N, int K);
 int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type, long ldo, int rows, int cols);
+int linear_fwd_post(const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M, int N, int K);   // gemm.hip
+int linear_fwd_post_flush(hipStream_t st, float* ws, long ws_floats);
 int shadow_refresh(hipStream_t st, const ::vln_shadow_job* jobs, int n);   // all shadows of a module in one launch
 
 // ---- attention.hip --------------------------------------------------------

@@ -200,6 +200,24 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, out=None, split=False):
     return out
 
 
+def linear_fwd_post(x, w, out):
+    """POST out = x @ w.T (no bias, no activation; `w` fp32 or bf16 as stored) for the NEXT `WgradBatch.run()` of this thread to issue as
+    extra workgroups of its pack launch (`vln_linear_fwd_post`): the encoder backward's d x beside the pack of the same dgates.  Call
+    `linear_fwd_post_flush()` after that run: it issues a post nobody took.  Same bits as `linear_fwd`."""
+    _req(x, "x"); _req(w, "w", None); _req(out, "out")
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and tuple(out.shape) == (M, N)
+    _lib.check(_lib.load().vln_linear_fwd_post(_p(x), x.stride(0), _p(w), _dt(w), w.stride(0), _p(out), out.stride(0), M, N, K),
+               "vln_linear_fwd_post")
+    return out
+
+
+def linear_fwd_post_flush(device, M=0, N=0):
+    ws = workspace(device, max(1 << 22, min(16 * M * N, 1 << 24)))
+    _lib.check(_lib.load().vln_linear_fwd_post_flush(_p(ws), ws.numel(), _stream()), "vln_linear_fwd_post_flush")
+
+
 def linear_fwd_slabs(x, w, split=False, ws_floats: Optional[int] = None):
     """x @ w.T left as its split-K partial slabs: a [n, M, N] view of the shared workspace (valid until the next op that uses the
     workspace) whose sum over n, in order, is the product -- hand it to a consumer that adds the partials while loading

@@ -124,6 +124,13 @@ typedef struct vln_wgrad_job {
                   * FIRST `rows` rows and its operands have no more than that (rows past them count as zeros) */
 } vln_wgrad_job;
 int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precision, float* ws, int64_t ws_floats, vln_stream_t s);
+/* (ABI v17) POST a plain product y[M,N] = x[M,K] w[N,K]^T (vln_linear_fwd without bias / activation; w_type VLN_F32 or VLN_BF16) for the
+ * NEXT vln_wgrad_grouped call of this thread to issue as extra workgroups of its pack launch -- the encoder backward's d x = dgates W_ih
+ * beside the pack of the same dgates (model.py:9-66 backward).  Same tiles and arithmetic as vln_linear_fwd: bit-identical.  ALWAYS
+ * follow the wgrad call with vln_linear_fwd_post_flush, which issues a post nobody took (another weight-gradient form, a split
+ * product) as its own launch; a second post while one is pending is an error. */
+int vln_linear_fwd_post(const float* x, int64_t ldx, const void* w, int w_type, int64_t ldw, float* y, int64_t ldy, int M, int N, int K);
+int vln_linear_fwd_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */

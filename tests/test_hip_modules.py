@@ -463,6 +463,44 @@ def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_han
             assert (loc, span) == (8, 0), tallies                   # one XCD per group: verified, stores kept in its L2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_dx_posted_into_the_weight_gradients_pack_launch_is_bit_identical(vln, dtype):
+    """ops.linear_fwd_post / vln_linear_fwd_post (round 5): the encoder backward's d x = dgates W_ih rides as extra workgroups of the
+    weight gradients' pack launch (same tiles, same kernel body as the stand-alone product).  Every parameter gradient -- the
+    embedding's, which is what d x feeds -- equals the separate launches' bit for bit; in fp32 mode the weight gradients take the exact
+    form, nobody takes the post and the flush issues it alone: the same again.  A second post while one is pending is refused."""
+    B, L, E, H, vocab = 64, 80, 256, 512, 992
+    g = torch.Generator().manual_seed(7)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=dtype).to(DEV).train()
+    enc.deterministic_embedding_grad = True
+    lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    r = torch.randn(B, L, H, generator=g).to(DEV)
+    outs = []
+    for post in (True, False, True):
+        enc.dx_with_wgrads = post
+        enc._calls = 0
+        enc.zero_grad(set_to_none=True)
+        ctx, h, c = enc(tokens.to(DEV), lens)
+        ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
+        torch.cuda.synchronize()
+        outs.append([p.grad.detach().clone() for p in enc.parameters()])
+    names = [n for n, _ in enc.named_parameters()]
+    for o in outs[1:]:
+        for n, a, b in zip(names, outs[0], o):
+            assert torch.equal(a, b), f"grad[{n}] differs between the posted and the stand-alone d x product"
+    assert float(outs[0][names.index("embedding.weight")].abs().sum()) > 0
+    x = torch.randn(128, 64, device=DEV); w = torch.randn(32, 64, device=DEV); y = torch.empty(128, 32, device=DEV)
+    vln.ops.linear_fwd_post(x, w, y)
+    with pytest.raises(vln.VlnError, match="pending"):
+        vln.ops.linear_fwd_post(x, w, y)
+    vln.ops.linear_fwd_post_flush(torch.device(DEV), 128, 32)
+    assert torch.equal(y, vln.ops.linear_fwd(x, w))
+    vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
+
+
 def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
     """the counter-protocol backward leaves its group counters zero itself and skips the fill launch -- which
     only holds for a header it left behind.  (a) a caller-supplied workspace whose header was never zeroed, (b) a header the
