@@ -307,6 +307,8 @@ SIGNATURES = {
     "vln_monitor_ws_floats": (i64, [ptr]),
     "vln_linear_fwd_post": (i32, [ptr, i64, ptr, i32, i64, ptr, i64, i32, i32, i32]),
     "vln_linear_fwd_post_flush": (i32, [ptr, i64, ptr]),
+    "vln_colsum_post": (i32, [ptr, i32, i32]),
+    "vln_colsum_post_flush": (i32, [ptr, i64, ptr]),
     "vln_lstm_handoff_stats": (i32, [ptr, ptr, ptr]),
     "vln_lstm_fwd_handoff_stats": (i32, [ptr, ptr, ptr]),
     "vln_bn0_grads_from_wgrad": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, ptr, i64, ptr]),

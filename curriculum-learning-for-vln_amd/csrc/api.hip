@@ -510,6 +510,8 @@ extern "C" int vln_linear_fwd_post(const float* x, int64_t ldx, const void* w, i
 extern "C" int vln_linear_fwd_post_flush(float* ws, int64_t ws_floats, vln_stream_t s) {
   return linear_fwd_post_flush((hipStream_t)s, ws, (long)ws_floats);
 }
+extern "C" int vln_colsum_post(const vln_colsum_job* jobs, int n_jobs, int rows) { return colsum_post(jobs, n_jobs, rows); }
+extern "C" int vln_colsum_post_flush(float* ws, int64_t ws_floats, vln_stream_t s) { return colsum_post_flush((hipStream_t)s, ws, (long)ws_floats); }
 extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {
   if (!jobs || n_jobs <= 0) { set_error("vln_shadow_refresh: bad args"); return VLN_ERR_ARG; }
   return shadow_refresh((hipStream_t)s, jobs, n_jobs);

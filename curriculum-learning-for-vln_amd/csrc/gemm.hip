@@ -702,12 +702,21 @@ static bool wgrad_packed_tables(const vln_wgrad_job* jobs, int n, int Mt, float*
 // stand-alone call: bit-identical.  A post that no packed call takes is issued on its own by vln_linear_fwd_post_flush.
 struct PostedProduct { bool on = false; const float* X; long ldx; const void* W; int wtype; long ldw; float* Y; long ldy; int M, N, K; };
 static thread_local PostedProduct g_posted;
+// ... and POSTED column sums (vln_colsum_post: the layer's bias gradients, sums over the BPTT's per-row-block partials): they depend on
+// nothing the weight gradients produce either and ride in the same launch, behind the product's tiles
+using ColsumJobs = ColsumJobsT<VLN_COLSUM_MAX_JOBS>;                  // (defined with the column-sum launches below)
+template <int NJ>
+static int colsum_tables(const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows, const int64_t* seg_stride,
+                         ColsumJobsT<NJ>& a, int* blocks);
+struct PostedColsums { bool on = false; vln_colsum_job j[VLN_COLSUM_MAX_JOBS]; int n, rows; };
+static thread_local PostedColsums g_posted_cs;
 
 template <typename TW>
-__global__ __launch_bounds__(256) void wgrad_pack_gemm_kernel(PackJobs pk, GemmNTArgs a, int gx, int gz) {
+__global__ __launch_bounds__(256) void wgrad_pack_gemm_kernel(PackJobs pk, GemmNTArgs a, int gx, int gz, ColsumJobs cs, int cs_blocks) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[gemm_nt_smem_bytes(GemmCfg<TW>::kPlanes)];
   const int ng = gx * gz;
-  if ((int)blockIdx.x >= ng) { wgrad_pack_block(pk, (int)blockIdx.x - ng); return; }
+  if ((int)blockIdx.x >= ng + cs_blocks) { wgrad_pack_block(pk, (int)blockIdx.x - ng - cs_blocks); return; }
+  if ((int)blockIdx.x >= ng) { colsum_grouped_block(cs, (int)blockIdx.x - ng, 0, reinterpret_cast<float4 (*)[4]>(smem)); return; }
   int t = (int)blockIdx.x;
   if (a.xcd) t = (t & 7) * (ng >> 3) + (t >> 3);          // gemm_nt_kernel's XCD-aware tile order (ng % 8 == 0)
   const VBlock vb{t % gx, 0, t / gx, (int)threadIdx.x, smem};
@@ -740,6 +749,19 @@ int linear_fwd_post_flush(hipStream_t st, float* ws, long ws_floats) {
   g_posted.on = false;
   return gemm_nt(st, p.X, p.ldx, p.W, p.wtype, p.ldw, p.Y, p.ldy, p.M, p.N, p.K, nullptr, ACT_NONE, ws, ws_floats, nullptr);
 }
+int colsum_grouped(hipStream_t st, const vln_colsum_job* jobs, int n, int rows, float* ws, long ws_floats, int seg_rows, const int64_t* seg_stride);
+int colsum_post(const vln_colsum_job* jobs, int n, int rows) {
+  if (!jobs || n <= 0 || n > VLN_COLSUM_MAX_JOBS || rows <= 0) { set_error("vln_colsum_post: 1..%d jobs over > 0 rows", VLN_COLSUM_MAX_JOBS); return VLN_ERR_ARG; }
+  if (g_posted_cs.on) { set_error("vln_colsum_post: posted column sums are still pending (vln_colsum_post_flush)"); return VLN_ERR_ARG; }
+  g_posted_cs.on = true; g_posted_cs.n = n; g_posted_cs.rows = rows;
+  for (int i = 0; i < n; ++i) g_posted_cs.j[i] = jobs[i];
+  return VLN_OK;
+}
+int colsum_post_flush(hipStream_t st, float* ws, long ws_floats) {
+  if (!g_posted_cs.on) return VLN_OK;
+  g_posted_cs.on = false;
+  return colsum_grouped(st, g_posted_cs.j, g_posted_cs.n, g_posted_cs.rows, ws, ws_floats, 0, nullptr);
+}
 
 static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n, int Mt, float* ws, long ws_floats, int terms,
                                 int seg_rows = 0, const int64_t* dy_seg = nullptr, const int64_t* x_seg = nullptr) {
@@ -749,8 +771,12 @@ static int wgrad_grouped_packed(hipStream_t st, const vln_wgrad_job* jobs, int n
     return -1;                                                        // caller falls back to the LDS-staged kernel
   GemmNTArgs pa; int gx = 0, gz = 0;
   if (g_posted.on && posted_args(g_posted, &pa, &gx, &gz)) {          // the posted product's tiles first, the pack blocks behind them
-    if (g_posted.wtype == W_BF16) VLN_LAUNCH(wgrad_pack_gemm_kernel<bf16_raw>, dim3(gx * gz + blk), dim3(256), 0, st, pk, pa, gx, gz);
-    else VLN_LAUNCH(wgrad_pack_gemm_kernel<float>, dim3(gx * gz + blk), dim3(256), 0, st, pk, pa, gx, gz);
+    ColsumJobs cs{}; int csb = 0;                                     // ... and the posted column sums between them (one pass each)
+    if (g_posted_cs.on && colsum_tables<VLN_COLSUM_MAX_JOBS>(g_posted_cs.j, g_posted_cs.n, g_posted_cs.rows, nullptr, 0, 0, nullptr, cs, &csb) == VLN_OK &&
+        cs.rsplit == 1) g_posted_cs.on = false;
+    else csb = 0;
+    if (g_posted.wtype == W_BF16) VLN_LAUNCH(wgrad_pack_gemm_kernel<bf16_raw>, dim3(gx * gz + csb + blk), dim3(256), 0, st, pk, pa, gx, gz, cs, csb);
+    else VLN_LAUNCH(wgrad_pack_gemm_kernel<float>, dim3(gx * gz + csb + blk), dim3(256), 0, st, pk, pa, gx, gz, cs, csb);
     g_posted.on = false;
   } else
   VLN_LAUNCH(wgrad_pack_kernel, dim3(blk), dim3(256), 0, st, pk);

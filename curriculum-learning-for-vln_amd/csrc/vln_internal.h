@@ -181,6 +181,8 @@ int transpose_cast(hipStream_t st, const float* W, long ldw, void* Wt, int out_t
 int cast_copy(hipStream_t st, const float* W, long ldw, void* out, int out_type, long ldo, int rows, int cols);
 int linear_fwd_post(const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy, int M, int N, int K);   // gemm.hip
 int linear_fwd_post_flush(hipStream_t st, float* ws, long ws_floats);
+int colsum_post(const ::vln_colsum_job* jobs, int n, int rows);
+int colsum_post_flush(hipStream_t st, float* ws, long ws_floats);
 int shadow_refresh(hipStream_t st, const ::vln_shadow_job* jobs, int n);   // all shadows of a module in one launch
 
 // ---- attention.hip --------------------------------------------------------

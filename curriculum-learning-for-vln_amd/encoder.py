@@ -223,10 +223,14 @@ class _EncoderFn(torch.autograd.Function):
             if need_dx and mod.dx_with_wgrads and wb.jobs:
                 w_t = sh[f"w_ih_t{k}"]
                 dx = ops.linear_fwd_post(dgates, w_t, ops.empty(L * B, w_t.shape[0], **f32))
+            cs_posted = dx is not None and cbt.post()                   # the bias gradients' column sums: the same launch
             wb.run()
             if dx is not None:
                 ops.linear_fwd_post_flush(dev, L * B, dx.shape[1])      # (issues it alone if the batch took another form)
-            cbt.run()
+            if cs_posted:
+                cbt.flush()
+            else:
+                cbt.run()
             if need_dx:
                 if dx is None:
                     dx = ops.linear_fwd(dgates, sh[f"w_ih_t{k}"])

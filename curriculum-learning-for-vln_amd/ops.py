@@ -456,6 +456,21 @@ class ColsumBatch:
         self.jobs.append(_lib.ColsumJob(a.data_ptr(), _p(out1), _p(out2), a.stride(0), cols, int(accumulate)))
         self.keep += [a, out1, out2]
 
+    def post(self) -> bool:
+        """POST the jobs (at most 12) for the next `WgradBatch.run()` that carries a posted product (`linear_fwd_post`) to issue in the
+        same launch; call `flush()` after that run.  False: not posted (a gradient ride is collecting, too many jobs): call run()."""
+        if not self.jobs or len(self.jobs) > 12 or GradRide._active is not None:
+            return False
+        arr = (_lib.ColsumJob * len(self.jobs))(*self.jobs)
+        _lib.check(_lib.load().vln_colsum_post(arr, len(self.jobs), self.rows), "vln_colsum_post")
+        return True
+
+    def flush(self):
+        """After the run that could have taken the post: issues the sums as their own launch if it did not."""
+        ws = workspace(self.keep[0].device, 1 << 22)
+        _lib.check(_lib.load().vln_colsum_post_flush(_p(ws), ws.numel(), _stream()), "vln_colsum_post_flush")
+        self.jobs, self.keep, self.rows = [], [], None
+
     def run(self):
         lib = _lib.load()
         if self.jobs and GradRide._active is not None and GradRide._active.take_c(self.jobs, self.keep, self.rows):

@@ -131,6 +131,10 @@ int vln_wgrad_grouped(const vln_wgrad_job* jobs, int n_jobs, int Mt, int precisi
  * product) as its own launch; a second post while one is pending is an error. */
 int vln_linear_fwd_post(const float* x, int64_t ldx, const void* w, int w_type, int64_t ldw, float* y, int64_t ldy, int M, int N, int K);
 int vln_linear_fwd_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
+/* the same for grouped column sums (vln_colsum_grouped's jobs over `rows` rows: the layer's bias gradients): they ride in the launch
+ * that carries a posted product; vln_colsum_post_flush issues what nobody took */
+int vln_colsum_post(const vln_colsum_job* jobs, int n_jobs, int rows);
+int vln_colsum_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);
 /* weight shadows (transposed and/or bf16 copies), refreshed once per optimizer step */
