@@ -20,7 +20,7 @@ NAMES = {"gemm_nt_kernel": "gemm_nt", "gemm_nt_n16_kernel": "gemm_nt", "gemm_row
          "gather_step_prep_kernel": "gather_step",
          "lstm_persist_bwd_kernel": "lstm_rec_bwd", "lstm_rec_fwd_kernel": "lstm_rec_fwd", "lstm_rec_bwd_kernel": "lstm_rec_bwd",
          "feat_dropout_kernel": "feat_dropout", "lstm_pw_fwd_kernel": "lstm_pointwise", "reduce_epilogue_kernel": "reduce_epilogue",
-         "wgrad_pack_kernel": "wgrad_pack", "gather_step_kernel": "gather_step"}
+         "wgrad_pack_kernel": "wgrad_pack", "wgrad_pack_gemm_kernel": "wgrad_pack", "gather_step_kernel": "gather_step"}
 
 
 def kernel_key(name):
