@@ -817,6 +817,7 @@ def main():
     agent.ride_gather = args.features == "store" and args.ride_gather != "off" and not args.rollout_gather
     agent.ride_shadows = bool(args.ride_shadows)
     agent.enc.dx_with_wgrads = not args.no_dx_post
+    agent.enc.layout_with_bridge = not args.no_dx_post
     agent.probe_trivial = int(args.probe_trivial)
     agent.dump_graph = args.dump_graph
     if args.no_chain:

@@ -17,6 +17,7 @@
 #include "vln_internal.h"
 #include "prologue_bodies.h"
 #include "shadow_bodies.h"
+#include "layout_bodies.h"
 #include "step_bodies.h"
 #include "../../include/vln_hip.h"
 
@@ -55,6 +56,8 @@ static bool n16_applies(int M, int N, int K, int wtype) {     // (W_F32S / W_F32
   return wtype != W_F32S && wtype != W_F32X && g_tunable[2] && N <= 1024 && M <= 256 && K >= 64 && (g_tunable[3] <= 0 || K <= g_tunable[3]);
 }
 
+struct PostedLayout { bool on = false; LayoutArgs a; };
+static thread_local PostedLayout g_posted_layout;
 static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, int wtype, long ldw, float* Y, long ldy,
                       int M, int N, int K, const float* bias, int act, float* Y2, long ldy2, DropSpec drop) {
   const int BK = (wtype == W_BF16) ? 64 : 32;
@@ -66,9 +69,40 @@ static int launch_n16(hipStream_t st, const float* X, long ldx, const void* W, i
   a.wvec = aligned16(W) && (ldw % (wtype == W_BF16 ? 8 : 4) == 0);
   dim3 grid((N + 15) / 16, 1, (M + 63) / 64), block(256);
   const double bytes = (double)N * K * (wtype == W_BF16 ? 2 : 4) + 4.0 * M * K + 4.0 * M * N;
+  if (g_posted_layout.on) {                          // a posted layout change rides behind the product's tiles
+    const LayoutArgs lay = g_posted_layout.a;
+    g_posted_layout.on = false;
+    const int gx = (int)grid.x, gz = (int)grid.z;
+    if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_layout_kernel<bf16_raw>, dim3(gx * gz + lay.blocks), block, 0, st, a, gx, gz, lay);
+    else launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_layout_kernel<float>, dim3(gx * gz + lay.blocks), block, 0, st, a, gx, gz, lay);
+    VLN_CHECK_LAUNCH("gemm_nt_n16 + layout");
+    return VLN_OK;
+  }
   if (wtype == W_BF16) launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_kernel<bf16_raw>, grid, block, 0, st, a);
   else launch_timed(K_GEMM_NT, bytes, gemm_nt_n16_kernel<float>, grid, block, 0, st, a);
   VLN_CHECK_LAUNCH("gemm_nt_n16");
+  return VLN_OK;
+}
+__global__ __launch_bounds__(256) void layout_posted_kernel(LayoutArgs lay) {
+  if (lay.kind == 0) tm_to_bm_body(lay.src, lay.dst, lay.dst_lp, lay.B, lay.L, lay.W, lay.dr, lay.vec, (long)blockIdx.x, (long)gridDim.x);
+  else bm_to_tm_body(lay.src, lay.dst, lay.B, lay.L, lay.W, lay.dr, lay.vec, (long)blockIdx.x, (long)gridDim.x);
+}
+int layout_post(int kind, const float* src, float* dst, void* dst_lp, int B, int L, int W, DropSpec dr) {
+  if ((kind != 0 && kind != 1) || !src || !dst || B <= 0 || L <= 0 || W <= 0 || (kind == 1 && dst_lp)) { set_error("vln_layout_post: bad args"); return VLN_ERR_ARG; }
+  if (g_posted_layout.on) { set_error("vln_layout_post: a posted layout change is still pending (vln_layout_post_flush)"); return VLN_ERR_ARG; }
+  int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dst_lp)) & 15) == 0;
+  if (vec && W % 8 == 0) vec = 2;
+  const long n = (long)B * L * W / (vec == 2 ? 8 : vec ? 4 : 1);
+  long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  g_posted_layout.on = true;
+  g_posted_layout.a = LayoutArgs{kind, src, dst, static_cast<bf16_raw*>(dst_lp), B, L, W, dr, vec, (int)blocks};
+  return VLN_OK;
+}
+int layout_post_flush(hipStream_t st) {
+  if (!g_posted_layout.on) return VLN_OK;
+  g_posted_layout.on = false;
+  VLN_LAUNCH(layout_posted_kernel, dim3((unsigned)g_posted_layout.a.blocks), dim3(256), 0, st, g_posted_layout.a);
+  VLN_CHECK_LAUNCH("layout (posted)");
   return VLN_OK;
 }
 

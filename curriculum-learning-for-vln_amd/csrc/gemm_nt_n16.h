@@ -16,14 +16,14 @@ struct GemmN16Args {
   int xvec, wvec;
 };
 
+// the tile of column block bx, row block bz; red: 4 x 64 x 17 floats of LDS
 template <typename TW>
-__global__ __launch_bounds__(256) void gemm_nt_n16_kernel(GemmN16Args a) {
+__device__ __forceinline__ void gemm_nt_n16_body(const GemmN16Args& a, int bx, int bz, float (*red)[64][17]) {
   constexpr int BK = GemmCfg<TW>::BK, VK = GemmCfg<TW>::VK;
   constexpr bool kF32 = (sizeof(TW) == 4);
-  __shared__ float red[4][64][17];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.z * 64;
+  const int n0 = bx * 16, m0 = bz * 64;
   const int wn = n0 + fi;
   const bool wn_ok = wn < a.N;
   const TW* wrow = reinterpret_cast<const TW*>(a.W) + (long)(wn_ok ? wn : 0) * a.ldw;
@@ -118,4 +118,24 @@ __global__ __launch_bounds__(256) void gemm_nt_n16_kernel(GemmN16Args a) {
       if (a.Y2) a.Y2[(long)row * a.ldy2 + col] = v * dropout_scale1(a.drop.seed, a.drop.off(), (uint32_t)((long)row * a.N + col), a.drop.p);
     }
   }
+}
+
+template <typename TW>
+__global__ __launch_bounds__(256) void gemm_nt_n16_kernel(GemmN16Args a) {
+  __shared__ float red[4][64][17];
+  gemm_nt_n16_body<TW>(a, (int)blockIdx.x, (int)blockIdx.z, red);
+}
+
+// A POSTED layout change (vln_layout_post: the encoder's [L,B,W] <-> [B,L,W] copies with their dropout, layout_bodies.h) as extra
+// workgroups of a narrow product's launch: the product's few tiles (32 workgroups for an H x H one) are a chain of latencies, the copy
+// is HBM-bound, and in the encoder's forward and backward the two do not depend on each other.
+struct LayoutArgs { int kind; const float* src; float* dst; bf16_raw* dst_lp; int B, L, W; DropSpec dr; int vec; int blocks; };   // kind 0: tm -> bm, 1: bm -> tm
+template <typename TW>
+__global__ __launch_bounds__(256) void gemm_nt_n16_layout_kernel(GemmN16Args a, int gx, int gz, LayoutArgs lay) {
+  __shared__ float red[4][64][17];
+  const int ng = gx * gz;
+  if ((int)blockIdx.x < ng) { gemm_nt_n16_body<TW>(a, (int)blockIdx.x % gx, (int)blockIdx.x / gx, red); return; }
+  const long vb = (long)blockIdx.x - ng;
+  if (lay.kind == 0) tm_to_bm_body(lay.src, lay.dst, lay.dst_lp, lay.B, lay.L, lay.W, lay.dr, lay.vec, vb, (long)lay.blocks);
+  else bm_to_tm_body(lay.src, lay.dst, lay.B, lay.L, lay.W, lay.dr, lay.vec, vb, (long)lay.blocks);
 }

@@ -85,10 +85,18 @@ class _EncoderFn(torch.autograd.Function):
         ctx_out = ops.empty(B, L, H, **f32)
         # bf16 mode: the stream copy of the context the decoders' attention reads comes out of the same pass
         ctx_lp = ops.empty(B, L, H, dtype=torch.bfloat16, device=dev) if wtype == ops.BF16 else None
-        _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset.site(1), p_drop, offset.base, _stream()),
-                   "vln_tm_to_bm")
+        if mod.layout_with_bridge:
+            # the context's layout change (HBM-bound) and the bridge product tanh(enc2dec(h_t)) (32 workgroups of latencies) do not
+            # depend on each other: the copy is POSTED and rides in the product's launch (vln_layout_post)
+            _lib.check(lib.vln_layout_post(0, _p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset.site(1), p_drop, offset.base),
+                       "vln_layout_post")
+        else:
+            _lib.check(lib.vln_tm_to_bm(_p(y), _p(ctx_out), _p(ctx_lp), B, L, H, seed, offset.site(1), p_drop, offset.base, _stream()),
+                       "vln_tm_to_bm")
         mod._last_ctx_lp = ctx_lp
         dec_init = ops.linear_fwd(hcat, sh["w_e2d"], mod.enc2dec.bias.detach(), ops.ACT_TANH)
+        if mod.layout_with_bridge:
+            _lib.check(lib.vln_layout_post_flush(_stream()), "vln_layout_post_flush")      # (its own launch if the product took another kernel)
         # dec_init is an OUTPUT: keeping the returned object on ctx would close a reference cycle through its grad_fn
         # (tensor -> node -> ctx -> tensor) that only the cyclic GC can free -- ~85 MB of activations per iteration
         ctx.mod, ctx.saved, ctx.misc = mod, saved, (tokens, lens32, p_drop, offset, hcat, dec_init.detach(), wtype)
@@ -153,12 +161,22 @@ class _EncoderFn(torch.autograd.Function):
                     else:
                         put("enc2dec.weight", ops.linear_wgrad, dpre, hcat)
             put("enc2dec.bias", ops.colsum, dpre)
+            # the context gradient's layout change rides in the launch of d h_t = dpre W_e2d (as the forward's does)
+            dy_posted = None
+            if dctx is not None and mod.layout_with_bridge:
+                dy_posted = ops.empty(L * B, H, **f32)
+                dctx = dctx.contiguous()
+                _lib.check(lib.vln_layout_post(1, _p(dctx), _p(dy_posted), None, B, L, H, seed, offset.site(1), p_drop, offset.base),
+                           "vln_layout_post")
             dhcat = ops.linear_fwd(dpre, sh["w_e2d_t"])
+            if dy_posted is not None:
+                _lib.check(lib.vln_layout_post_flush(_stream()), "vln_layout_post_flush")
         else:
             dhcat = ops.zeros(B, H, **f32)
+            dy_posted = None
         dccat = dct.contiguous() if dct is not None else ops.zeros(B, H, **f32)
-        dy = None
-        if dctx is not None:
+        dy = dy_posted
+        if dctx is not None and dy is None:
             dy = ops.empty(L * B, H, **f32)
             dctx = dctx.contiguous()
             _lib.check(lib.vln_bm_to_tm(_p(dctx), _p(dy), B, L, H, seed, offset.site(1), p_drop, offset.base, _stream()),
@@ -288,6 +306,8 @@ class EncoderLSTM(nn.Module):
         self.deterministic_embedding_grad = False
         # True: the backward's d x product is issued inside the weight gradients' pack launch (ops.linear_fwd_post)
         self.dx_with_wgrads = True
+        # True: the context's layout changes ride in the launches of the encoder -> decoder bridge's products (vln_layout_post)
+        self.layout_with_bridge = True
         self._calls = 0
         self._shadow = ShadowSet()
         self._param_names = [n for n, _ in self.named_parameters()]

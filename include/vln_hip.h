@@ -134,6 +134,12 @@ int vln_linear_fwd_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
 /* the same for grouped column sums (vln_colsum_grouped's jobs over `rows` rows: the layer's bias gradients): they ride in the launch
  * that carries a posted product; vln_colsum_post_flush issues what nobody took */
 int vln_colsum_post(const vln_colsum_job* jobs, int n_jobs, int rows);
+/* POST a layout change -- kind 0 = vln_tm_to_bm's arguments ([L,B,W] -> [B,L,W] (+ bf16 copy) with dropout), kind 1 = vln_bm_to_tm's -- for
+ * the NEXT narrow product of this thread (a vln_linear_fwd / vln_linear_fused that takes the 16-column kernel: N <= 1024, M <= 64 ...) to
+ * issue as extra workgroups of its launch; vln_layout_post_flush issues a post nobody took.  Same results as the stand-alone calls. */
+int vln_layout_post(int kind, const float* src, float* dst, void* dst_bf16 /* kind 0 only, nullable */, int B, int L, int W, uint64_t seed,
+                    uint64_t offset, float p, const uint64_t* offset_base_dev);
+int vln_layout_post_flush(vln_stream_t s);
 int vln_colsum_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);

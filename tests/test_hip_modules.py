@@ -478,12 +478,14 @@ def test_encoder_dx_posted_into_the_weight_gradients_pack_launch_is_bit_identica
     for i, n in enumerate(lens.tolist()):
         tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
     r = torch.randn(B, L, H, generator=g).to(DEV)
-    outs = []
+    outs, fwds = [], []
     for post in (True, False, True):
         enc.dx_with_wgrads = post
+        enc.layout_with_bridge = post          # ... and the context's two layout changes in the bridge products' launches (vln_layout_post)
         enc._calls = 0
         enc.zero_grad(set_to_none=True)
         ctx, h, c = enc(tokens.to(DEV), lens)
+        fwds.append((ctx.detach().clone(), h.detach().clone(), c.detach().clone()))
         ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
         torch.cuda.synchronize()
         outs.append([p.grad.detach().clone() for p in enc.parameters()])
@@ -491,6 +493,9 @@ def test_encoder_dx_posted_into_the_weight_gradients_pack_launch_is_bit_identica
     for o in outs[1:]:
         for n, a, b in zip(names, outs[0], o):
             assert torch.equal(a, b), f"grad[{n}] differs between the posted and the stand-alone d x product"
+    for f in fwds[1:]:
+        for a, b in zip(fwds[0], f):
+            assert torch.equal(a, b), "the forward's outputs differ between the posted and the stand-alone layout change"
     assert float(outs[0][names.index("embedding.weight")].abs().sum()) > 0
     x = torch.randn(128, 64, device=DEV); w = torch.randn(32, 64, device=DEV); y = torch.empty(128, 32, device=DEV)
     vln.ops.linear_fwd_post(x, w, y)
