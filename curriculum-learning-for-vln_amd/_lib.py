@@ -309,6 +309,7 @@ SIGNATURES = {
     "vln_linear_fwd_post_flush": (i32, [ptr, i64, ptr]),
     "vln_layout_post": (i32, [i32, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_layout_post_flush": (i32, [ptr]),
+    "vln_posted_drop": (i32, []),
     "vln_colsum_post": (i32, [ptr, i32, i32]),
     "vln_colsum_post_flush": (i32, [ptr, i64, ptr]),
     "vln_lstm_handoff_stats": (i32, [ptr, ptr, ptr]),

@@ -515,6 +515,7 @@ extern "C" int vln_layout_post(int kind, const float* src, float* dst, void* dst
   return layout_post(kind, src, dst, dst_bf16, B, L, W, drop_spec(seed, offset, p, offset_base_dev));
 }
 extern "C" int vln_layout_post_flush(vln_stream_t s) { return layout_post_flush((hipStream_t)s); }
+extern "C" int vln_posted_drop(void) { return posted_drop(); }
 extern "C" int vln_colsum_post(const vln_colsum_job* jobs, int n_jobs, int rows) { return colsum_post(jobs, n_jobs, rows); }
 extern "C" int vln_colsum_post_flush(float* ws, int64_t ws_floats, vln_stream_t s) { return colsum_post_flush((hipStream_t)s, ws, (long)ws_floats); }
 extern "C" int vln_shadow_refresh(const vln_shadow_job* jobs, int n_jobs, vln_stream_t s) {

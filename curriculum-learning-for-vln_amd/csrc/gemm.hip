@@ -791,6 +791,12 @@ int colsum_post(const vln_colsum_job* jobs, int n, int rows) {
   for (int i = 0; i < n; ++i) g_posted_cs.j[i] = jobs[i];
   return VLN_OK;
 }
+// what an aborted caller left posted (it raised between its post and its flush): forgotten, its buffers may be gone
+int posted_drop() {
+  const int n = (g_posted.on ? 1 : 0) + (g_posted_cs.on ? 1 : 0) + (g_posted_layout.on ? 1 : 0);
+  g_posted.on = false; g_posted_cs.on = false; g_posted_layout.on = false;
+  return n;
+}
 int colsum_post_flush(hipStream_t st, float* ws, long ws_floats) {
   if (!g_posted_cs.on) return VLN_OK;
   g_posted_cs.on = false;

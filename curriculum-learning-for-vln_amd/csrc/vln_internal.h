@@ -184,6 +184,7 @@ int linear_fwd_post_flush(hipStream_t st, float* ws, long ws_floats);
 int colsum_post(const ::vln_colsum_job* jobs, int n, int rows);
 int layout_post(int kind, const float* src, float* dst, void* dst_lp, int B, int L, int W, DropSpec dr);     // gemm.hip (kind 0: tm -> bm, 1: bm -> tm)
 int layout_post_flush(hipStream_t st);
+int posted_drop();
 int colsum_post_flush(hipStream_t st, float* ws, long ws_floats);
 int shadow_refresh(hipStream_t st, const ::vln_shadow_job* jobs, int n);   // all shadows of a module in one launch
 

@@ -44,6 +44,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, tokens, lens32, p_drop, offset, *params):
         lib = _lib.load()
+        lib.vln_posted_drop()          # (see backward)
         ride, mod._ride = mod.__dict__.get("_ride"), None
         sh = mod._shadow.t
         B, L = tokens.shape
@@ -106,6 +107,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dctx, ddec, dct):
         lib = _lib.load()
+        lib.vln_posted_drop()          # whatever an aborted earlier call left posted (between its post and its flush) is forgotten
         mod = ctx.mod
         sh = mod._shadow.t
         tokens, lens32, p_drop, offset, hcat, dec_init, wtype = ctx.misc

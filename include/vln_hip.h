@@ -140,6 +140,9 @@ int vln_colsum_post(const vln_colsum_job* jobs, int n_jobs, int rows);
 int vln_layout_post(int kind, const float* src, float* dst, void* dst_bf16 /* kind 0 only, nullable */, int B, int L, int W, uint64_t seed,
                     uint64_t offset, float p, const uint64_t* offset_base_dev);
 int vln_layout_post_flush(vln_stream_t s);
+/* Forget every post of this thread that was neither taken nor flushed (a caller that raised between its post and its flush; its buffers
+ * may be gone); returns how many.  The drop-in modules call it at the top of the calls that post. */
+int vln_posted_drop(void);
 int vln_colsum_post_flush(float* ws, int64_t ws_floats, vln_stream_t s);
 int vln_colsum(const float* A, int64_t lda, float* out, int rows, int cols, int accumulate, float* ws,
                int64_t ws_floats, vln_stream_t s);

@@ -503,6 +503,13 @@ def test_encoder_dx_posted_into_the_weight_gradients_pack_launch_is_bit_identica
         vln.ops.linear_fwd_post(x, w, y)
     vln.ops.linear_fwd_post_flush(torch.device(DEV), 128, 32)
     assert torch.equal(y, vln.ops.linear_fwd(x, w))
+    # a caller that raised between its post and its flush: the next call that posts forgets what it left (vln_posted_drop)
+    y2 = torch.full((128, 32), 3.0, device=DEV)
+    vln.ops.linear_fwd_post(x, w, y2)
+    assert vln._lib.load().vln_posted_drop() == 1 and vln._lib.load().vln_posted_drop() == 0
+    vln.ops.linear_fwd_post_flush(torch.device(DEV), 128, 32)          # nothing pending: no launch
+    torch.cuda.synchronize()
+    assert bool((y2 == 3.0).all())
     vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
 
 
