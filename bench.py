@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- EnvDrop agent training steps/sec on MI355X (BASELINE.json metric, config 1).
 
-One "step" = one agent training iteration of the reference's EnvDrop IL path
-(trainer.py:411-427 with feedback="teacher"): instruction encoder forward, T teacher-forced decoder steps
-with the in-place candidate mask + cross-entropy (envdrop.py:151-179), `ml_loss * ML_WEIGHT / B`, full
-backward, gradient all-reduce (N > 1), clip-norm 40 on encoder and decoder, RMSprop step.  Batch 64 episodes
-per GPU, 36 x (2048+128) view features, <= 80 instruction tokens, synthetic data, dropout ON.
+One "step" = one agent training iteration of the reference's EnvDrop IL path (trainer.py:411-427 with feedback="teacher"):
+`vln_amd.trainers.EnvDropILIteration` -- instruction encoder forward, T teacher-forced decoder steps with the in-place candidate
+mask + cross-entropy (envdrop.py:151-179), `ml_loss * ML_WEIGHT / B`, full backward, gradient all-reduce (N > 1), clip-norm 40 on
+encoder and decoder, RMSprop step.  This file holds NO training logic: it builds the synthetic workload (vln_amd.synthetic,
+BASELINE.md section 3), drives the package's iteration objects, times them and prints the line.  Batch 64 episodes per GPU,
+36 x (2048+128) view features, <= 80 instruction tokens, dropout ON.
 Inputs are resident in HBM before the timed region: the FULL-size ResNet table (10,567 viewpoints x 36 x 2048, 1.56 GB in
 bf16) and 8 different episode batches (tokens, viewpoint / candidate indices, targets) that the timed loop rotates through,
 so every iteration gathers rows it has not touched for 8 iterations from a table six times the Infinity Cache.
@@ -25,542 +26,23 @@ agent at B=128 -- driver-timed side numbers, never `value`.
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
 import time
 
 import torch
-import torch.nn.functional as Fn
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ML_WEIGHT = 0.2            # configs/envdrop/envdrop_config.yaml:45
-CLIP = 40.0                # trainer.py:425-426
-LR = 1e-4                  # envdrop_config.yaml:19
+import vln_amd as vln                                                    # noqa: E402  (no GPU call at import: the library loads lazily)
+from vln_amd.batches import LiveBatch, LiveSteps                         # noqa: E402,F401
+from vln_amd.synthetic import (N_TAPES, N_VIEWPOINTS, build_store, make_tape, materialize_step, tape_to)  # noqa: E402,F401
+from vln_amd.trainers import (CLIP, HBM_PEAK_GBS, LR, ML_WEIGHT, EnvDropILIteration, EnvDropHostLoopIteration,  # noqa: E402,F401
+                              read_kernel_timers, time_iterations)
 
-
-N_VIEWPOINTS = 10567      # panoramas in the R2R ResNet-152 feature TSV (ImageFeatures.read_in, utils/misc.py:253-279)
-N_TAPES = 8               # distinct episode batches rotated through the timed loop
-
-
-def make_tape(B, L, T, C_max, seed, vocab=992, V=36, IMG=2048, ANG=128, n_rows=None):
-    """Synthetic episode batch (BASELINE.md §3 / SURVEY.md §8d), CPU tensors.  Features are defined the way the
-    reference's environment builds them (common_env.py:272,287-291,307-308): a per-viewpoint ResNet table
-    [viewpoints, 36 views, 2048] (post-ReLU, non-negative), the agent's viewIndex selecting the static angle
-    table, and each candidate = (view of the current panorama, its relative heading/elevation).
-    n_rows=None: the tape brings its own compact table (T*B viewpoints) and the explicit img/cand tensors of every step
-    (tensor path, CPU baseline, tests).  n_rows=N: INDEX-ONLY tape over a resident table of N viewpoints (the bench's
-    DeviceFeatureStore): every step visits B random viewpoints, one row of every step has all C_max candidate slots in use
-    so the padded candidate width is the same for every tape."""
-    g = torch.Generator().manual_seed(seed)
-    lens = torch.sort(torch.randint(8, L + 1, (B,), generator=g), descending=True).values
-    lens[0] = L
-    tokens = torch.zeros(B, L, dtype=torch.long)
-    for i, n in enumerate(lens.tolist()):
-        tokens[i, 0] = 3                                        # <BOS>
-        tokens[i, 1:n - 1] = torch.randint(4, vocab, (n - 2,), generator=g)
-        tokens[i, n - 1] = 2                                    # <EOS>
-    seq_mask = tokens == 0
-    table = None if n_rows is not None else torch.randn(T * B, V, IMG, generator=g).abs() * 0.5
-    T_i = torch.randint(min(4, T), T + 1, (B,), generator=g)
-    T_i[0] = T
-    steps = []
-    for t in range(T):
-        rows = torch.arange(B) + t * B if n_rows is None else torch.randint(0, n_rows, (B,), generator=g)
-        vidx = torch.randint(0, V, (B,), generator=g).int()
-        ncand = torch.randint(3, C_max + 1, (B,), generator=g)      # candidates incl. the STOP slot
-        if n_rows is not None:
-            ncand[int(torch.randint(0, B, (1,), generator=g))] = C_max
-        Ct = int(ncand.max())
-        cmask = torch.arange(Ct)[None, :] >= ncand[:, None]
-        real = torch.arange(Ct)[None, :] < (ncand - 1)[:, None]     # STOP slot + padding are all-zero rows
-        crow = torch.where(real, rows[:, None].expand(B, Ct), torch.full((B, Ct), -1))
-        cview = torch.randint(0, V, (B, Ct), generator=g).int()
-        chead = (torch.rand(B, Ct, generator=g) - 0.5) * 6.0
-        celev = (torch.rand(B, Ct, generator=g) - 0.5) * 1.04
-        ended = t >= T_i
-        tgt = torch.where(t == T_i - 1, ncand - 1, (torch.rand(B, generator=g) * (ncand - 1).float()).long())
-        tgt = torch.where(ended, torch.full_like(tgt, -1), tgt)
-        ah = torch.rand(B, generator=g) * 6.283 - 3.1415
-        st = dict(cand_mask=cmask, angle=angle_feat(ah, torch.zeros(B), ANG), target=tgt, rows=rows,
-                  vidx=vidx, crow=crow, cview=cview, chead=chead, celev=celev)
-        if table is not None:
-            st.update(materialize_step(st, table, ANG))
-        steps.append(st)
-    return dict(tokens=tokens, lengths=lens, seq_mask=seq_mask, steps=steps, table=table, B=B, L=L, T=T, IMG=IMG, ANG=ANG)
-
-
-def angle_feat(h, e, ANG=128):                                  # utils/misc.py:285-293
-    return torch.stack([h.sin(), h.cos(), e.sin(), e.cos()], -1).repeat_interleave(ANG // 4, dim=-1)
-
-
-def materialize_step(st, table, ANG=128):
-    """The explicit img [B,36,F] / cand [B,C,F] tensors of a step from the ResNet table (any device), built the way the
-    reference's marshalling does (agent/base.py:141-157): what the tensor / host feature modes and the CPU baseline consume."""
-    import vln_amd
-    dev = table.device
-    V = table.shape[1]
-    loc_table = vln_amd.staging.loc_embedding_table(ANG, V).to(dev)            # [V, V, ANG], misc.py:296-317
-    rows, crow = st["rows"].to(dev), st["crow"].to(dev)
-    real = (crow >= 0)
-    img = torch.cat((table[rows].float(), loc_table[st["vidx"].to(dev).long()]), -1)
-    cand = torch.cat((table[crow.clamp_min(0), st["cview"].to(dev).long()].float(),
-                      angle_feat(st["chead"].to(dev), st["celev"].to(dev), ANG)), -1) * real[..., None]
-    return dict(img=img, cand=cand)
-
-
-def tape_to(tape, dev, store_dtype=None, host_dtype=None, store=None):
-    """Device copy.  With `store_dtype` the tape's own ResNet table becomes a resident DeviceFeatureStore (or `store` = an
-    existing one, for index-only tapes) and the per-step img/cand tensors are NOT uploaded (a step only needs its index
-    vectors).  With `host_dtype` the per-step img/cand tensors stay on the HOST, pinned, in that dtype (fp32 = what the
-    reference's ImageFeatures holds, utils/misc.py:253-279; bf16 = converted once at load time): every step then pays its
-    H2D copy (PCIe-inclusive mode, never the headline value)."""
-    skip = ("steps", "table")
-    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tape.items() if k not in skip}
-    out["lengths32"] = tape["lengths"].to(dev, torch.int32)
-    drop = ("img", "cand") if (store_dtype is not None or host_dtype is not None or store is not None) else ()
-    out["steps"] = [{k: v.to(dev) for k, v in s.items() if k not in drop} for s in tape["steps"]]
-    if host_dtype is not None:
-        for so, si in zip(out["steps"], tape["steps"]):
-            so["img_host"] = si["img"].to("cpu", host_dtype).contiguous().pin_memory()
-            so["cand_host"] = si["cand"].to("cpu", host_dtype).contiguous().pin_memory()
-    if store is not None:
-        out["store"] = store
-    elif store_dtype is not None:
-        import vln_amd
-        out["store"] = vln_amd.DeviceFeatureStore(tape["table"], device=dev, dtype=store_dtype, angle_size=tape["ANG"])
-    return out
-
-
-def build_store(vln, dev, dtype, n_rows=N_VIEWPOINTS, V=36, IMG=2048, ANG=128, seed=2020):
-    """The full-size resident feature table: n_rows x 36 x 2048 (1.56 GB in bf16, 3.1 GB in fp32 -- the reference keeps 2.9 GB
-    of fp32 on the host), generated on the device chunk by chunk.  Post-ReLU statistics: |N(0,1)| * 0.5."""
-    g = torch.Generator(device=dev).manual_seed(seed)
-    table = torch.empty(n_rows, V, IMG, dtype=dtype, device=dev)
-    for r0 in range(0, n_rows, 512):
-        r1 = min(n_rows, r0 + 512)
-        table[r0:r1] = (torch.randn(r1 - r0, V, IMG, generator=g, device=dev).abs_() * 0.5).to(dtype)
-    return vln.DeviceFeatureStore(table, device=dev, dtype=dtype, angle_size=ANG)
-
-
-class LiveBatch:
-    """The small per-batch tensors of the CURRENT episode batch (tokens, lengths, masks, per-step index vectors, targets,
-    angle inputs: ~0.4 MB) at FIXED device addresses.  A trainer marshals every new batch into the same buffers (once per
-    iteration), so the modules' step plans and hipGraphs -- keyed by device addresses -- keep replaying while the DATA changes
-    every iteration.  Where the packed batches wait (`source`):
-      "push"    (round 5, A/B) in PINNED HOST memory; `load(k)` sends batch k (and k + 1) ahead: one asynchronous H2D copy on
-                a copy stream into a device-resident ring slot (staging.HostBatchFeed(prefetch=True)), under the previous iteration's
-                compute; the iteration's first launch moves it from the slot into the live buffers (same kernel as "pull", reading HBM);
-      "pull"    (round 4) in PINNED HOST memory -- what a trainer's data loader hands over; base.py:114-178
-                marshals every batch on the host.  `load(k)` stores batch k's address in a pinned slot (one host store) and the
-                iteration's FIRST launch pulls the blob through PCIe into the live buffers (staging.HostBatchFeed, vln_host_fetch):
-                the agent calls `fetch()` at the top of the iteration, so a captured iteration contains it;
-      "copy"    in pinned host memory, `load(k)` = one hipMemcpyAsync H2D in front of the iteration (A/B: +130 us per iteration in
-                front of a graph replay, profiles/round4_notes.md);
-      "device"  on the device, `load(k)` = one device-to-device copy (round 3's form, A/B)."""
-    TOP = ("tokens", "lengths32", "seq_mask")
-    STEP = ("rows", "vidx", "crow", "cview", "chead", "celev", "cand_mask", "angle", "target")
-    # Blob order: what the ENCODER and the feature gather need first (tokens, lengths, every step's index vectors: 118 KB at B 64 / T 7),
-    # then what only the decoder reads (sequence mask, every step's candidate mask, angle features, targets: 242 KB).  `split` is where
-    # the second part starts: with the gather riding in the encoder's recurrence launch that part is pulled by a passenger workgroup of
-    # the same launch (HostBatchFeed.split_at / RolloutRide.carry_batch_tail) and the iteration's first launch pulls the head only.
-    HEAD_TOP, HEAD_STEP = ("tokens", "lengths32"), ("rows", "vidx", "crow", "cview", "chead", "celev")
-
-    def __init__(self, tapes, source="device"):
-        assert source in ("push", "pull", "copy", "device")
-        self.source = source
-        self.send_ahead = True
-        t0 = tapes[0]
-        self.layout, off, self.split = [], 0, 0
-        for name, t in self._items(t0):
-            n = t.numel() * t.element_size()
-            if name == "seq_mask":
-                self.split = off                   # first byte of the decoder-only part
-            self.layout.append((name, off, n, t.dtype, tuple(t.shape)))
-            off = (off + n + 15) & ~15
-        self.nbytes = off
-        dev = t0["tokens"].device
-        self.live_blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
-        self.feed = None
-        if source in ("pull", "push"):
-            import vln_amd
-            self.feed = vln_amd.HostBatchFeed(self.live_blob, prefetch=source == "push")
-        self.blobs = []
-        for tp in tapes:
-            blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
-            for (name, o, n, dt, shape), (name2, t) in zip(self.layout, self._items(tp)):
-                if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
-                    raise ValueError(f"LiveBatch: tape layouts differ at {name}: {tuple(t.shape)} vs {shape}")
-                blob[o:o + n] = t.contiguous().view(-1).view(torch.uint8)
-            if source == "copy":
-                blob = blob.cpu().pin_memory()
-            elif source in ("pull", "push"):
-                blob = self.feed.register(blob)
-            self.blobs.append(blob)
-        views = {name: self.live_blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.layout}
-        self.live = {k: v for k, v in t0.items() if k not in self.TOP + ("steps",)}
-        for k in self.TOP:
-            self.live[k] = views[k]
-        self.live["steps"] = [{k: views[f"{i}.{k}"] for k in self.STEP} for i in range(len(t0["steps"]))]
-
-    def _items(self, tp):
-        for k in self.HEAD_TOP:
-            yield k, tp[k]
-        for i, s in enumerate(tp["steps"]):
-            for k in self.HEAD_STEP:
-                yield f"{i}.{k}", s[k]
-        for k in self.TOP:
-            if k not in self.HEAD_TOP:
-                yield k, tp[k]
-        for i, s in enumerate(tp["steps"]):
-            for k in self.STEP:
-                if k not in self.HEAD_STEP:
-                    yield f"{i}.{k}", s[k]
-
-    def load(self, k):
-        if self.feed is not None:
-            self.feed.select(self.blobs[k % len(self.blobs)])       # one host store; the iteration's first launch pulls the blob
-            if self.source == "push" and self.send_ahead:           # the loop visits the batches in order: batch k + 1 starts travelling now
-                self.feed.send_ahead(self.blobs[(k + 1) % len(self.blobs)])
-        else:
-            self.live_blob.copy_(self.blobs[k % len(self.blobs)], non_blocking=True)
-        return self.live
-
-    def fetch(self):
-        """Top of the iteration (eager or inside a capture): the pull of the selected batch, if this LiveBatch pulls."""
-        if self.feed is not None:
-            self.feed.fetch()
-
-    def launched(self):
-        if self.feed is not None:
-            self.feed.launched()
-
-
-class GpuAgent:
-    """The caller side of the drop-in modules: the reference's rollout/optimizer sequence for IL."""
-
-    def __init__(self, vln, dev, dtype, world, arena=False, rollout_ce=True, side_gather=False, fused_gather=True):
-        self.vln, self.world, self.dtype = vln, world, dtype
-        # (A/B option, off by default: measured slower) the step's feature gather reads only the resident table + index
-        # vectors, so it can be issued on a side stream beside the encoder / the previous step's kernels
-        self.side = torch.cuda.Stream(device=dev) if side_gather else None
-        self.copy_stream, self._copy_fenced, self._host_drop = None, False, 0
-        self._branch_stream = None
-        self._gen_done, self._iter_no, self.prefetch_under_backward = [None, None], 0, True
-        self._one = None
-        # store-fed steps: the decoder gathers its own rows from the resident table inside its first launch (forward(gather=...))
-        # instead of a separate store.gather_step launch in front of every step
-        self.fused_gather = bool(fused_gather) and not side_gather
-        # teacher forcing: every step's rows are known up front -> ONE gather launch per rollout (store.gather_rollout), A/B option
-        self.rollout_gather = False
-        self.clear_grads_in_step = False
-        self.rollout_ce = rollout_ce
-        self.enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev)
-        self.dec = vln.EnvDropDecoder(512, 0.5, 0.3, 64, 128, 2176, compute_dtype=dtype).to(dev)
-        self.enc.train(); self.dec.train()
-        # teacher forcing: nothing reads the logits before the loss, so the decoder leaves them to be formed for the whole
-        # rollout at once when losses.RolloutCE evaluates (one GEMM over steps x batch + one dot launch instead of two
-        # launches on every step's dependent chain)
-        self.dec.defer_logits = bool(rollout_ce)
-        # ... and consecutive steps are chained: a step's last elementwise stage rides in the next step's first launch, forward
-        # and backward (vln_envdrop_step.chain; needs the deferred logits: nothing reads a step's h_tilde but the next step)
-        self.dec.chain_steps = bool(rollout_ce)
-        # trainer.py:380-381,423-427: RMSprop(lr) + clip_grad_norm(40) per module -- fused over flat buffers; the flat
-        # gradient buffer doubles as the RCCL all-reduce bucket (optim.FusedRMSprop)
-        self.opt = vln.optim.FusedRMSprop([list(self.enc.parameters()), list(self.dec.parameters())], lr=LR, clip_norm=CLIP)
-        if world > 1:   # the decoder's 34.7 MB of gradients are final before the encoder's BPTT starts: reduce them under it
-            self.dec.grads_ready_hook = lambda: self.opt.start_allreduce(1)
-        # A training loop allocates the same sequence of buffers every iteration: with the arena they come back at the
-        # same device addresses, so each decoder step (13 forward / 15 backward launches) replays as one hipGraph.
-        self.arena = None
-        self.use_arena(arena)
-        # runtime.DeviceClock: dropout offsets and the recurrence's launch sequence come from device words that one tick
-        # launch bumps per iteration -> the iteration's launch arguments repeat and it can be captured whole (graphs.IterationGraph)
-        self.clock = None
-        self.graph = None
-        # Segmented form of the iteration (graphs.SegmentedIterationGraph): the backward is cut at the encoder's outputs so that
-        # the host can start the decoder slice's all-reduce between the two halves -- the data-parallel path (N > 1, --dp-path)
-        self.segmented = False
-        self._cut = None
-        self.batch_fetch = None         # LiveBatch.fetch / .launched when the batches are pulled from pinned host memory
-        self.batch_launched = None
-        self.batch_feed = None
-        self.use_prologue = True        # pull + tick + shadow refreshes as one launch (runtime.DeviceClock.prologue)
-        self.split_pull = True          # the decoder-only part of a pulled batch crosses PCIe under the encoder's recurrence (ride_gather only)
-        self._live_split, self._live_tape = 0, None
-        self.gather_branch = False      # graph mode A/B: the rollout-wide gather as a captured branch beside the encoder
-        self.ride_gather = False        # the rollout-wide gather as passenger workgroups of the encoder's recurrence launch
-        self.ride_shadows = False       # ... which then also refresh the decoder's weight shadows, out of the prologue launch (--ride-shadows: measured neutral)
-
-    def _probe(self):
-        n = getattr(self, "probe_trivial", 0)
-        if n:
-            if getattr(self, "_probe_buf", None) is None:
-                self._probe_buf = torch.zeros(2, 64 * 512, device=next(self.enc.parameters()).device)
-            lib = self.vln._lib.load()
-            self.vln._lib.check(lib.vln_debug_trivial_chain(self._probe_buf[0].data_ptr(), self._probe_buf[1].data_ptr(), 64 * 512, n, 256,
-                                                            self.vln._lib.raw_stream()), "vln_debug_trivial_chain")
-
-    def use_clock(self, store=None):
-        self.clock = self.vln.DeviceClock(next(self.enc.parameters()).device)
-        self.clock.attach(self.enc, self.dec)
-        if store is not None:
-            self.clock.attach(store)
-        return self.clock
-
-    def capture(self, tape):
-        """Record one iteration over `tape` (buffers at fixed addresses: LiveBatch.live) as ONE hipGraph; `replay()` then runs
-        an iteration on whatever those buffers hold."""
-        if self.clock is None:
-            raise RuntimeError("GpuAgent.capture: use_clock() first (a captured iteration reads its dropout offsets from device words)")
-        if self.segmented:
-            self.graph = self.vln.SegmentedIterationGraph(self.segments(tape), self.clock).capture()
-            return self.graph
-        self.graph = self.vln.IterationGraph(lambda: self.iteration(tape), self.clock).capture(
-            debug_dump=getattr(self, "dump_graph", None), capture_error_mode=getattr(self, "capture_error_mode", "global"))
-        return self.graph
-
-    def replay(self):
-        out = self.graph.replay()
-        if self.batch_launched is not None:
-            self.batch_launched()
-        return out
-
-    def use_live(self, live):
-        """A LiveBatch whose batches are PULLED from pinned host memory: the iteration's first launch is the pull
-        (staging.HostBatchFeed); after every iteration / replay an event bounds how far the host may run ahead."""
-        if live.feed is not None:
-            self.batch_fetch, self.batch_launched, self.batch_feed = live.fetch, live.launched, live.feed
-            self._live_split, self._live_tape = live.split, live.live
-
-    def use_arena(self, on: bool):
-        self.arena = self.vln.ops.RolloutArena() if on else None
-        self.dec.step_graphs = bool(on)
-
-    def step_features(self, tape, s):
-        """Per-step marshalling (agent/base.py:141-157 + the EnvDrop feature dropout, policy.py:226-231).
-        store path: ONE gather pass per tensor from the HBM-resident table (indices in, dropped features + bf16 stream
-        copy out); tensor path: fresh copies of pre-built feature tensors, the decoder applies the dropout in place."""
-        store = tape.get("store")
-        if "img_host" in s:
-            return self.stage_from_host(s)
-        if store is None:
-            return s["img"].clone(), s["cand"].clone(), {}
-        if self.fused_gather:
-            return None, None, dict(gather=(store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
-        lp = self.dtype != torch.float32
-        pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-        # bf16 decoder: only the bf16 rows exist (nothing on this path reads fp32 features)
-        (img, img_lp), (cand, cand_lp), _ = store.gather_step(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"],
-                                                              pf, want_bf16=lp, want_f32=not lp, stream=self.side)
-        kw = dict(already_dropfeat=True)
-        return (img_lp, cand_lp, kw) if lp else (img, cand, kw)
-
-    def stage_from_host(self, s):
-        """Host-resident (pinned) features: hipMemcpyAsync on a copy stream into per-step device buffers, the compute stream
-        waits for the step's copy only -- the copies of later steps run under the encoder / earlier steps (north star:
-        'pinned and hipMemcpyAsync-streamed to HBM overlapped').  bf16 host features get the feature dropout here (the
-        decoder only takes non-fp32 features that are already dropped)."""
-        ops = self.vln.ops
-        if self.copy_stream is None:
-            self.copy_stream = torch.cuda.Stream()
-            self.copy_events = {}
-        main = torch.cuda.current_stream()
-        if ops.current_arena() is None or not self._copy_fenced:   # buffers may still be in use by earlier work on `main`
-            self.copy_stream.wait_stream(main)
-            self._copy_fenced = True
-        ih, ch = s["img_host"], s["cand_host"]
-        img = ops.empty(ih.shape, dtype=ih.dtype, device=main.device)
-        cand = ops.empty(ch.shape, dtype=ch.dtype, device=main.device)
-        with torch.cuda.stream(self.copy_stream):
-            img.copy_(ih, non_blocking=True)
-            cand.copy_(ch, non_blocking=True)
-        ev = self.copy_events.get(id(s))
-        if ev is None:
-            ev = self.copy_events[id(s)] = torch.cuda.Event()
-        ev.record(self.copy_stream)
-        main.wait_event(ev)
-        if ih.dtype == torch.float32:
-            return img, cand, {}                                   # the decoder drops in place + writes its bf16 stream copies
-        pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-        if pf > 0:
-            F, ANG = self.dec.feature_size, self.dec.angle_feat_size
-            self._host_drop += 2
-            ops.feat_dropout_inplace(img, F - ANG, ANG, 0x51A6E, self._host_drop, pf)
-            ops.feat_dropout_inplace(cand, F - ANG, ANG, 0x51A6E, self._host_drop + 1, pf)
-        return img, cand, dict(already_dropfeat=True)
-
-    def iteration(self, tape):
-        out = self._iteration_eager(tape)
-        if self.batch_launched is not None and not torch.cuda.is_current_stream_capturing():
-            self.batch_launched()
-        return out
-
-    def _iteration_eager(self, tape):
-        if self.segmented:             # the same five pieces a SegmentedIterationGraph captures / replays, issued eagerly
-            out = None
-            for _, fn in self.segments(tape):
-                r = fn()
-                out = r if r is not None else out
-            return out
-        self._copy_fenced = False
-        self.vln.ops.set_arena(self.arena)
-        if self.arena is not None:
-            self.arena.begin()
-        try:
-            return self._iteration(tape)
-        finally:
-            self.vln.ops.set_arena(None)
-
-    def segments(self, tape):
-        """The iteration cut at its two exchange points (trainer.py:421-427 with the gradient all-reduce in it):
-        [graph A: forward, loss, the decoder's backward] [host: start the decoder slice's all-reduce] [graph B: the encoder's
-        backward] [host: reduce the rest, wait] [graph C: clip + update]."""
-        def in_arena(fn, begin=False):
-            def run():
-                self.vln.ops.set_arena(self.arena)
-                if begin and self.arena is not None:
-                    self.arena.begin()
-                try:
-                    return fn()
-                finally:
-                    self.vln.ops.set_arena(None)
-            return run
-
-        def part_a():
-            self._copy_fenced = False
-            return self._iteration(tape)
-
-        def part_b():
-            self._cut.resume()
-
-        def part_c():
-            self.opt.step(zero_grads=self.clear_grads_in_step)
-            self._iter_no += 1
-
-        return [("graph", in_arena(part_a, begin=True)), ("host", lambda: self.opt.start_allreduce(1)),
-                ("graph", in_arena(part_b)), ("host", lambda: self.opt.allreduce()), ("graph", in_arena(part_c))]
-
-    def _shadows_ride(self, tape):
-        """The decoder's weight shadows are refreshed by the gather ride's passengers (staging.RolloutRide.carry_shadows) instead of
-        the prologue launch: whenever there is a ride and a prologue to take them out of."""
-        return bool(self.ride_shadows and self.ride_gather and tape.get("store") is not None and self.clock is not None and self.use_prologue)
-
-    def _iteration(self, tape):
-        B = tape["B"]
-        # the decoder-only part of a pulled batch crosses PCIe under the encoder's recurrence (one passenger workgroup of that launch)
-        # when the rollout's gather rides there too; decided BEFORE the head fetch of this iteration is issued
-        carry_tail = bool(self.batch_feed is not None and self.split_pull and self._live_split and tape is self._live_tape and
-                          self.ride_gather and tape.get("store") is not None)
-        if self.batch_feed is not None:
-            self.batch_feed.split_at(self._live_split if carry_tail else 0)
-        if self.clock is not None and self.use_prologue:
-            # ONE launch: the GPU pulls the selected batch out of pinned host memory (LiveBatch "pull"), the device clock ticks (this
-            # iteration's dropout offsets / launch sequence) and both modules' weight shadows follow the last optimizer step
-            # (the decoder's shadows ride in the encoder's recurrence launch instead when the gather does: carry_shadows below)
-            self.clock.prologue(self.batch_feed, (self.enc,) if self._shadows_ride(tape) else (self.enc, self.dec))
-        else:
-            if self.batch_fetch is not None:
-                self.batch_fetch()     # one launch: the pull
-            if self.clock is not None:
-                self.clock.tick()      # one launch: the tick
-        self._probe()
-        if self.side is not None:      # once per iteration: the side stream's gathers write buffers last read two iterations ago
-            self.side.wait_stream(torch.cuda.current_stream())
-        if self.copy_stream is not None and self.arena is not None:
-            # Fence for the H2D copy stream (host features).  The arena alternates between two buffer generations, so this
-            # iteration's staging buffers were last read TWO iterations ago: the copies only wait for the end of that
-            # iteration and run under the previous iteration's backward (the link is busy for the whole iteration instead
-            # of the forward only: 'streamed to HBM overlapped with backward', north star / base.py:141-157).
-            ev = self._gen_done[self._iter_no & 1]
-            if ev is not None and self.prefetch_under_backward:
-                self.copy_stream.wait_event(ev)
-            else:
-                self.copy_stream.wait_stream(torch.cuda.current_stream())
-            self._copy_fenced = True
-        self.opt.zero_grad()
-        pre, branch = None, None
-
-        def gather_all():
-            lp = self.dtype != torch.float32
-            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-            return tape["store"].gather_rollout([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
-                                                pf, want_bf16=lp, want_f32=not lp)
-
-        ride = None
-        if self.ride_gather and tape.get("store") is not None:
-            # the rollout's gather rides in the encoder's persistent recurrence launch (passenger workgroups on its idle CUs)
-            lp = self.dtype != torch.float32
-            pf = self.dec.feat_drop_ratio if self.dec.training else 0.0
-            ride = tape["store"].rollout_ride([(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]],
-                                              pf, want_bf16=lp, want_f32=not lp)
-            pre = ride.outputs
-            if carry_tail:
-                ride.carry_batch_tail(self.batch_feed)
-            if self._shadows_ride(tape):
-                ride.carry_shadows((self.dec,))
-        elif self.rollout_gather and self.gather_branch and tape.get("store") is not None:
-            # the gather reads only the resident table + index vectors: as a branch of the captured graph it runs beside the
-            # instruction encoder (whose 0.2 ms recurrence keeps half of the CUs idle) and joins before the first decoder step
-            main = torch.cuda.current_stream()
-            if self._branch_stream is None:
-                self._branch_stream = torch.cuda.Stream()
-            branch = self._branch_stream
-            branch.wait_stream(main)
-            with torch.cuda.stream(branch):
-                pre = gather_all()
-        ctx, h_t, c_t = self.enc(tape["tokens"], tape["lengths32"], ride=ride) if ride is not None else self.enc(tape["tokens"], tape["lengths32"])
-        if self.segmented:
-            # the decoder's backward ends at these leaves; the encoder's backward starts from their .grad (segments(): part_b)
-            self._cut = self.vln.dp.BackwardCut()
-            ctx, h_t, c_t = self._cut.at(ctx, h_t, c_t)
-        h_tilde = h_t
-        terms = []
-        ce = self.vln.losses.RolloutCE() if self.rollout_ce else None
-        if branch is not None:
-            torch.cuda.current_stream().wait_stream(branch)
-        elif pre is None and self.rollout_gather and tape.get("store") is not None:
-            pre = gather_all()
-        for t, s in enumerate(tape["steps"]):
-            if pre is not None:
-                (im, im_lp), (cd, cd_lp) = pre[t]
-                img, cand, kw = (im_lp, cd_lp, dict(already_dropfeat=True)) if im_lp is not None else (im, cd, dict(already_dropfeat=True))
-            else:
-                img, cand, kw = self.step_features(tape, s)
-            logits, (h_t, c_t), h_tilde = self.dec(s["angle"], img, cand, h_tilde, h_t, c_t, ctx, tape["seq_mask"], **kw)
-            # envdrop.py:173-179: masked_fill_(-inf) + CrossEntropyLoss(ignore_index=-1, reduction="none").sum() (SURVEY §8 row
-            # A9): recorded per step, evaluated for the whole rollout in ONE launch (losses.RolloutCE) -- or, --ce per-step,
-            # one fused launch per step
-            if ce is not None:
-                ce.add(logits, s["target"], s["cand_mask"])
-            else:
-                terms.append(self.vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
-        w = ML_WEIGHT / (B * self.world)                         # envdrop.py:268; global batch normalisation under DP
-        if ce is not None:
-            loss = ce.sum(scale=w)                               # ml_loss summed over the steps (envdrop.py:179), scaled in the launch
-        else:
-            loss = torch.stack(terms).sum() * w
-        if self._one is None or self._one.device != loss.device:
-            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-        self._probe()
-        loss.backward(self._one)                                 # the root gradient is a constant: no ones_like fill per iteration
-        if self.segmented:
-            return loss
-        self.opt.allreduce()
-        # bench: the update clears the gradients it consumed (the next zero_grad() is free); tests keep them to look at
-        self.opt.step(zero_grads=self.clear_grads_in_step)
-        if self.copy_stream is not None and self.arena is not None:
-            g = self._iter_no & 1
-            if self._gen_done[g] is None:
-                self._gen_done[g] = torch.cuda.Event()
-            self._gen_done[g].record()                          # this generation's buffers are free again from here
-        self._iter_no += 1
-        return loss
-
+PMC_FILE = "round6_pmc.json"       # profiles/<this>: the committed rocprofv3 --pmc passes (hash-checked against csrc/)
 
 def cpu_baseline(tape, P_enc, P_dec):
     """The CPU oracle driven identically (dropout sampled with bernoulli_ like nn.Dropout).  Returns run(warm, iters, budget_s)
@@ -625,16 +107,6 @@ def usable_cores() -> int:
         except (OSError, ValueError, IndexError):
             pass
     return max(1, n)
-
-
-def read_prof(lib, nk):
-    rows = []
-    for k in range(nk):
-        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
-        lib.vln_prof_read(k, C.byref(n), C.byref(ms), C.byref(by))
-        if n.value:
-            rows.append(dict(kernel=lib.vln_prof_kernel_name(k).decode(), launches=n.value, ms=ms.value, bytes=by.value))
-    return rows
 
 
 def launch_ranks(n: int) -> int:
@@ -788,7 +260,6 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    import vln_amd as vln
     lib = vln._lib.load()                                        # fails loudly if the HIP extension is missing
     if args.dp_path:
         if world != 1:
@@ -808,7 +279,7 @@ def main():
     if args.features == "host-bf16" and dtype != torch.bfloat16:
         raise SystemExit("--features host-bf16 needs --dtype bf16")
     torch.manual_seed(2020)
-    agent = GpuAgent(vln, dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
+    agent = EnvDropILIteration(dev, dtype, world, arena=not args.no_arena, rollout_ce=args.ce == "rollout",
                      side_gather=args.gather_stream == "side" and args.features == "store", fused_gather=not args.separate_gather)
     agent.clear_grads_in_step = True
     agent.prefetch_under_backward = not args.no_backward_prefetch
@@ -834,7 +305,7 @@ def main():
     args.dp_capture = not args.dp_segments
     agent.segmented = bool(use_graph and (world > 1 or args.dp_path) and not args.dp_capture)
     if args.dp_capture and (world > 1 or args.dp_path):
-        agent.dec.grads_ready_hook = lambda: agent.opt.start_allreduce(1)      # (N = 1 rehearsal: the hook GpuAgent sets for world > 1)
+        agent.dec.grads_ready_hook = lambda: agent.opt.start_allreduce(1)      # (N = 1 rehearsal: the hook EnvDropILIteration sets for world > 1)
         agent.capture_error_mode = "thread_local"
     # one GPU: the decoder's parameter gradients ride in the encoder's BPTT launch (a data-parallel rank wants them final before it)
     agent.dec.ride_wgrads = bool(world == 1 and not args.dp_path and not args.no_ride_wgrads and args.dtype != "fp32")
@@ -846,7 +317,7 @@ def main():
     # timed loop rotates through N_TAPES different episode batches (new tokens, new viewpoints every iteration): the gather
     # reads rows that were last touched 8 iterations ago out of a table six times the Infinity Cache, i.e. from HBM.
     t_setup = time.perf_counter()
-    store = build_store(vln, dev, dtype, args.viewpoints)
+    store = build_store(dev, dtype, args.viewpoints)
     cpu_tapes = [make_tape(args.batch, args.L, args.T, 8, seed=2020 + 97 * rank + k, n_rows=store.N) for k in range(args.tapes)]
     if args.features == "store":
         tapes = [tape_to(t, dev, store=store) for t in cpu_tapes]
@@ -998,12 +469,12 @@ def main():
         if rank == 0:
             for k in range(nk):
                 lib.vln_prof_enable(k, 1)
-            read_prof(lib, nk)
+            read_kernel_timers(lib)
         torch.cuda.synchronize()
         for _ in range(args.steps):
             iterate_eager()           # per-kernel event pairs ride on plain launches (a captured graph has none)
         torch.cuda.synchronize()
-        rows = read_prof(lib, nk) if rank == 0 else []
+        rows = read_kernel_timers(lib) if rank == 0 else []
         if rank == 0:
             for k in range(nk):
                 lib.vln_prof_enable(k, 0)
@@ -1062,7 +533,8 @@ def main():
                          ("split_wgrad_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph, wgrad="split")),
                          ("all_bf16_weights_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, graph=use_graph,
                                                                                     fp32_weights=())),
-                         ("il_host_in_loop", lambda: secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args)),
+                         ("il_host_in_loop", lambda: secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args, handshake=True)),
+                         ("il_host_in_loop_stream_sync_per_step", lambda: secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args)),
                          ("decoder_step_fwd_bwd", per_step),
                          ("phases", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, dtype, "store", args, phases=True)),
                          ("fp32_ms_per_step", lambda: secondary_envdrop(vln, dev, store, cpu_tapes, torch.float32, "store", args, graph=use_graph)),
@@ -1147,18 +619,18 @@ def csrc_sha():
 
 def pmc_figures(kernel, dtype):
     """(HBM-side bytes per launch, MFMA issue-slot utilisation, note) of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/round5_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
+    (profiles/round6_pmc.json, written by scripts/pmc_stamp.py from separate FETCH_SIZE / WRITE_SIZE / MFMA_BUSY runs of this
     same command).  The file carries the hash of the kernel sources it was taken on: a mismatch means the numbers describe
     OTHER code, and they are refused (null) rather than quoted stale."""
-    f = os.path.join(ROOT, "profiles", "round5_pmc.json")
+    f = os.path.join(ROOT, "profiles", "round6_pmc.json")
     if not os.path.exists(f):
         return None, None, "no PMC passes committed for this round yet"
     d = json.load(open(f))
     if d.get("csrc_sha") != csrc_sha():
-        return None, None, f"profiles/round5_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
+        return None, None, f"profiles/round6_pmc.json was taken on kernel sources {d.get('csrc_sha')}, this is {csrc_sha()}: refused"
     t = d.get("traffic", {}).get(dtype, {}).get(kernel)
     m = d.get("mfma_util", {}).get(dtype, {}).get(kernel)
-    return (t["bytes_per_launch"] if t else None), m, f"profiles/round5_pmc.json, kernel sources {d['csrc_sha']}"
+    return (t["bytes_per_launch"] if t else None), m, f"profiles/round6_pmc.json, kernel sources {d['csrc_sha']}"
 
 
 def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=20, warmup=6, graph=False, dropin=False,
@@ -1173,7 +645,7 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
     if wgrad is not None:
         vln.ops.set_wgrad_precision(wgrad)
     try:
-        ag = GpuAgent(vln, dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
+        ag = EnvDropILIteration(dev, dtype, 1, arena=not dropin, rollout_ce=not dropin)
         ag.clear_grads_in_step = True
         ag.ride_gather = features == "store" and args.ride_gather != "off" and not args.rollout_gather
         if fp32_weights is not None:       # None: the module's default (the two attention query projections in fp32)
@@ -1216,112 +688,33 @@ def secondary_envdrop(vln, dev, store, cpu_tapes, dtype, features, args, steps=2
         vln.ops.set_wgrad_precision(prev_w)
 
 
-class LiveSteps:
-    """Host-in-the-loop marshalling: like LiveBatch, but the per-STEP inputs (viewpoint rows, view / candidate indices, candidate
-    mask, angle feature of the previous action, teacher action) live in one pinned host blob PER STEP and are copied to that step's
-    fixed device buffers only when the step is about to run -- the shape of the reference's rollout, whose every step marshals the
-    simulator's new observation on the host (agent/base.py:141-178) after the previous action has reached it (envdrop.py:198-204)."""
-
-    def __init__(self, tapes, dev):
-        t0 = tapes[0]
-        T = len(t0["steps"])
-        top = [(k, t0[k]) for k in LiveBatch.TOP]
-        self.top_layout, self.top_bytes = self._layout(top)
-        self.step_layout, self.step_bytes = self._layout([(k, t0["steps"][0][k]) for k in LiveBatch.STEP])
-        self.top_host = [self._pack(self.top_layout, self.top_bytes, [(k, tp[k]) for k in LiveBatch.TOP]) for tp in tapes]
-        self.step_host = [[self._pack(self.step_layout, self.step_bytes, [(k, s[k]) for k in LiveBatch.STEP]) for s in tp["steps"]]
-                          for tp in tapes]
-        self.top_dev = torch.zeros(self.top_bytes, dtype=torch.uint8, device=dev)
-        self.step_dev = [torch.zeros(self.step_bytes, dtype=torch.uint8, device=dev) for _ in range(T)]
-        self.live = {k: v for k, v in t0.items() if k not in LiveBatch.TOP + ("steps",)}
-        self.live.update(self._views(self.top_layout, self.top_dev))
-        self.live["steps"] = [self._views(self.step_layout, b) for b in self.step_dev]
-        # what the fake environment keeps on the host: every step's teacher actions, to be compared with what the agent sent
-        self.host_targets = [[s["target"].cpu().numpy() for s in tp["steps"]] for tp in tapes]
-
-    @staticmethod
-    def _layout(items):
-        out, off = [], 0
-        for name, t in items:
-            n = t.numel() * t.element_size()
-            out.append((name, off, n, t.dtype, tuple(t.shape)))
-            off = (off + n + 15) & ~15
-        return out, off
-
-    @staticmethod
-    def _pack(layout, nbytes, items):
-        blob = torch.zeros(nbytes, dtype=torch.uint8)
-        for (name, o, n, dt, shape), (name2, t) in zip(layout, items):
-            if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
-                raise ValueError(f"LiveSteps: tape layouts differ at {name}")
-            blob[o:o + n] = t.detach().cpu().contiguous().view(-1).view(torch.uint8)
-        return blob.pin_memory()
-
-    @staticmethod
-    def _views(layout, blob):
-        return {name: blob[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in layout}
-
-    def load_top(self, k):
-        self.top_dev.copy_(self.top_host[k % len(self.top_host)], non_blocking=True)
-        return self.live
-
-    def load_step(self, k, t):
-        self.step_dev[t].copy_(self.step_host[k % len(self.step_host)][t], non_blocking=True)
-        return self.live["steps"][t]
-
-
-def secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args, steps=20, warmup=6):
-    """ms per iteration of the headline workload with THE HOST IN THE LOOP, in the reference's loop shape (envdrop.py:151-220):
-    per decoder step the step's index vectors arrive by a pinned H2D copy (the observation the simulator just produced,
-    base.py:141-178), the step runs (per-step hipGraph, candidate logits formed in the step, CE term per step), the chosen action
-    a_t goes back to the host (`a_t.cpu()`, envdrop.py:198: one D2H + stream synchronisation per step) and a fake environment
-    steps on it (checks the action against its own teacher tape, picks the next observation's blob).  Features stay in the
-    resident table; the iteration is eager launches + per-step graphs: nothing of it can be captured whole."""
-    import numpy as np
+def secondary_host_in_loop(vln, dev, store, cpu_tapes, dtype, args, steps=20, warmup=6, handshake=False):
+    """ms per iteration of the headline workload with THE HOST IN THE LOOP (trainers.EnvDropHostLoopIteration; reference loop shape
+    envdrop.py:151-220): per decoder step the step's index vectors come from the host (the observation the simulator just produced),
+    the action a_t goes back to it and a fake environment steps on it.  handshake=False: eager launches + per-step graphs, one pinned
+    H2D copy and one D2H + stream synchronisation per step; True: ONE hipGraph whose host turns are waits inside it."""
     torch.manual_seed(2020)
-    ag = GpuAgent(vln, dev, dtype, 1, arena=True, rollout_ce=False)
-    ag.clear_grads_in_step = True
     st = store if store.table.dtype == dtype else vln.DeviceFeatureStore(store.table.to(dtype), device=dev, dtype=dtype)
     tapes = [tape_to(t, dev, store=st) for t in cpu_tapes]
     ls = LiveSteps(tapes, dev)
-    B = tapes[0]["B"]
-    mismatches = [0]
+    it = EnvDropHostLoopIteration(dev, dtype, ls, st)
+    for k in range(4):
+        it.iteration(k)
+    if handshake:
+        it.capture(warmup=0)
+        run = it.replay
+    else:
+        run = it.iteration
+    k0 = [0]
 
-    def iteration(k):
-        vln.ops.set_arena(ag.arena); ag.arena.begin()
-        try:
-            tape = ls.load_top(k)
-            ag.opt.zero_grad()
-            ctx, h_t, c_t = ag.enc(tape["tokens"], tape["lengths32"])
-            h_tilde = h_t
-            terms = []
-            for t in range(len(tape["steps"])):
-                s = ls.load_step(k, t)                                      # this step's observation: pinned host -> device
-                logits, (h_t, c_t), h_tilde = ag.dec(s["angle"], None, None, h_tilde, h_t, c_t, ctx, tape["seq_mask"],
-                                                     gather=(st, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]))
-                terms.append(vln.losses.masked_cross_entropy(logits, s["target"], s["cand_mask"], "sum"))
-                a_t = s["target"]                                           # teacher forcing: a_t = target (envdrop.py:183)
-                cpu_a_t = a_t.cpu().numpy()                                 # envdrop.py:198: the action reaches the simulator
-                # fake environment: episodes whose action is -1 have ended (envdrop.py:199-203); it answers with the next blob
-                mismatches[0] += int((cpu_a_t != ls.host_targets[k % len(tapes)][t]).sum())
-            loss = torch.stack(terms).sum() * (ML_WEIGHT / B)
-            loss.backward()
-            ag.opt.step(zero_grads=True)
-            return loss
-        finally:
-            vln.ops.set_arena(None)
-
-    for k in range(4 + warmup):
-        iteration(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        iteration(k)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"ms_per_step": round(ms, 3), "per_step_host_round_trips": len(tapes[0]["steps"]), "action_mismatches": mismatches[0],
-            "how": "per step: pinned H2D of the step's index vectors, decoder step (per-step hipGraph, logits in the step, CE per step), "
-                   "D2H of a_t + fake-env host step; features from the resident table"}
+    def one():
+        run(k0[0]); k0[0] += 1
+    ms = time_iterations(one, steps, warmup)
+    return {"ms_per_step": round(ms, 3), "per_step_host_round_trips": len(tapes[0]["steps"]), "action_mismatches": it.mismatches,
+            "how": ("ONE hipGraph: per step an in-graph wait that also pulls the step's index vectors from pinned memory (vln_host_wait_fetch), "
+                    "decoder step (logits + CE in the step), a_t stored to pinned words the host polls + fake-env host step" if handshake else
+                    "per step: pinned H2D of the step's index vectors, decoder step (per-step hipGraph, logits in the step, CE per step), "
+                    "D2H of a_t + fake-env host step") + "; features from the resident table"}
 
 
 def _phase_times(ag, get, steps, n_dec_steps):
@@ -1386,14 +779,13 @@ def _phase_times(ag, get, steps, n_dec_steps):
 
 
 def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
+    """The other BASELINE workloads (scripts/bench_agents.py builds their synthetic batches; the iterations are vln_amd.trainers')."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import bench_agents as W
     # warm-up: the first iterations of a workload in a process grow the allocator's pools and load its kernels' code objects;
     # with 8 of them the Self-Monitor number read 5.7 ms against 5.05 ms for a second run in the same process
     W.configure(steps=20, warmup=30, dtype=dtype or args.dtype, arena=False, device=dev)
     W.args.roofline = bool(which == "a2c" and read_actions == "handshake")     # the cfg3 entry carries its own roofline block
-    W.vln.functional.set_grad_in_place(True)
-    W.vln.functional.set_rollout_wgrads(which in ("monitor", "follower"))     # parameter gradients once per rollout (functional.RolloutWgrads)
     import gc
     gc.collect()
     gc.freeze()                         # the bench's own objects (agent, tapes, store) out of the cyclic collector's way, as in the timed loop
@@ -1401,8 +793,6 @@ def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
         r = W.run_a2c(T_rl=35, store=store, read_actions=read_actions) if which == "a2c" else (W.run_follower() if which == "follower" else
                                                                     (W.run_speaker() if which == "speaker" else W.run_monitor()))
     finally:
-        W.vln.functional.set_rollout_wgrads(False)
-        W.vln.functional.set_grad_in_place(False)
         gc.unfreeze()
     out = {"workload": r["workload"], "ms_per_iteration": r["ms_per_iteration"], "dtype": r.get("dtype")}
     for k in ("iteration", "per_step_action_read", "roofline"):       # a2c: how the iteration was issued, that the host read every sampled action, its dominant kernel

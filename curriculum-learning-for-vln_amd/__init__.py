@@ -14,10 +14,15 @@ from .runtime import DeviceClock  # noqa: F401
 from .graphs import IterationGraph, SegmentedIterationGraph, HandshakeIterationGraph  # noqa: F401
 from .staging import DeviceFeatureStore, PinnedStager, HostBatchFeed  # noqa: F401
 from .speaker import SpeakerEncoder, SpeakerDecoder, Speaker, back_translate, env_drop_mask  # noqa: F401
+from . import synthetic, batches, trainers  # noqa: F401
+from .batches import LiveBatch, LiveSteps  # noqa: F401
+from .trainers import (EnvDropILIteration, EnvDropA2CIteration, SelfMonitorIteration, FollowerIteration,  # noqa: F401
+                       SpeakerIteration)
 from .decoders import (SoftDotAttention, VisualSoftDotAttention, ActionScoring, PositionalEncoding, MLPwithBN,  # noqa: F401
                        AttnDecoderLSTM, MonitorDecoder)
 
 __all__ = ["_lib", "ops", "runtime", "dp", "functional", "VlnError", "LIB_PATH", "EncoderLSTM", "EnvDropDecoder",
            "Critic", "SoftDotAttention", "VisualSoftDotAttention", "ActionScoring", "PositionalEncoding", "MLPwithBN",
            "AttnDecoderLSTM", "MonitorDecoder", "SpeakerEncoder", "SpeakerDecoder", "Speaker", "back_translate",
-           "env_drop_mask"]
+           "env_drop_mask", "synthetic", "batches", "trainers", "LiveBatch", "LiveSteps", "EnvDropILIteration",
+           "EnvDropA2CIteration", "SelfMonitorIteration", "FollowerIteration", "SpeakerIteration"]

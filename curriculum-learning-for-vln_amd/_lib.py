@@ -325,7 +325,9 @@ SIGNATURES = {
                                  i32, i32, i32, ptr, i64, ptr]),
     "vln_attn_textk_bwd": (i32, [ptr, i32, ptr, ptr, ptr, i32, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, u64, u64, f32,
                                  i32, i32, i32, ptr, i64, ptr]),
-    "vln_host_wait": (i32, [ptr, ptr, i64, ptr]),
+    "vln_host_wait": (i32, [ptr, ptr, i64, ptr, ptr]),
+    "vln_host_wait_fetch": (i32, [ptr, ptr, i64, ptr, ptr, i64, ptr, ptr]),
+    "vln_store_to_host": (i32, [ptr, ptr, i64, ptr]),
     "vln_envdrop_flush": (i32, [ptr]),
     "vln_envdrop_drop_pending": (i32, [ptr]),
     "vln_envdrop_step_fwd": (i32, [C.POINTER(EnvDropDims), C.POINTER(EnvDropWeights), C.POINTER(EnvDropStep), ptr]),
@@ -335,7 +337,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 17
+EXPECTED_ABI = 18
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

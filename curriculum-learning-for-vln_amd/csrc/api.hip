@@ -118,7 +118,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 17; }
+extern "C" int vln_abi_version(void) { return 18; }
 extern "C" int64_t vln_struct_size(const char* name) {
   if (!name) return -1;
 #define VLN_SZ(T) if (std::strcmp(name, #T) == 0) return (int64_t)sizeof(T)
@@ -429,24 +429,88 @@ extern "C" int vln_host_device_pointer(const void* host, void** dev) {
 // never matches).  The host polls the action words the previous step stored to pinned memory, does its work, writes the next step's
 // inputs and then the flag.  Bounded: a host that never answers raises the sticky word instead of hanging the queue.
 namespace vln {
-__global__ void host_wait_kernel(const unsigned long long* flag, const unsigned long long* want, unsigned* sticky, unsigned long long limit) {
-  if (threadIdx.x != 0) return;
+// limit > 0: a number of polls; limit < 0: -limit ticks of the 100 MHz constant clock (s_memrealtime: a wall-clock bound that does not
+// depend on how fast this wave polls).  A flag equal to VLN_HOST_WAIT_POISON means the host has given the iteration up (an exception in
+// its turn): the wait ends at once, the sticky word is raised so that the next vln_persistent_check reports the iteration as invalid.
+__device__ __forceinline__ void host_wait_spin(const unsigned long long* flag, const unsigned long long* want, unsigned* sticky, long long limit) {
   const unsigned long long w = *want;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  bool bad = false;
   for (unsigned long long i = 0;; ++i) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == w) break;
-    if (i > limit) { if (sticky) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    const unsigned long long f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (f == w) break;
+    if (f == VLN_HOST_WAIT_POISON) { bad = true; break; }
+    if (limit > 0 ? (long long)i > limit : (long long)(__builtin_amdgcn_s_memrealtime() - t0) > -limit) { bad = true; break; }
     __builtin_amdgcn_s_sleep(2);
   }
+  if (bad && sticky) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __atomic_thread_fence(__ATOMIC_ACQUIRE);      // what the host wrote before the flag is visible to the launches behind this one
 }
+// `ack` (nullable, pinned host memory): once the wait is over -- and, in the fetching form, the host's bytes have been read -- the
+// launch stores *want there: the host may start the SAME turn of the NEXT iteration (rewrite that turn's mailbox and flag) only after
+// it has seen this iteration's value, so a host that runs ahead of the device cannot overwrite a flag the device has yet to see.
+__global__ void host_wait_kernel(const unsigned long long* flag, const unsigned long long* want, unsigned* sticky, long long limit,
+                                 unsigned long long* ack) {
+  if (threadIdx.x != 0) return;
+  host_wait_spin(flag, want, sticky, limit);
+  if (ack) __hip_atomic_store(ack, *want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and the same wait followed, in the SAME launch, by the pull of what the host left for the next step (the observation's packed
+// index vectors, a few KB in pinned host memory): one workgroup, the flag first, then 16-byte reads through PCIe.
+__global__ __launch_bounds__(256) void host_wait_fetch_kernel(const unsigned long long* flag, const unsigned long long* want, unsigned* sticky,
+                                                              long long limit, const u32x4* src, u32x4* dst, long n16, unsigned long long* ack) {
+  if (threadIdx.x == 0) host_wait_spin(flag, want, sticky, limit);
+  __syncthreads();
+  for (long i = threadIdx.x; i < n16; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+  __syncthreads();                              // every read of the mailbox has returned (a load's data is needed for its store)
+  if (ack && threadIdx.x == 0) __hip_atomic_store(ack, *want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static long long host_wait_limit(int64_t spin_limit) {
+  if (spin_limit > 0) return (long long)spin_limit;                                   // polls
+  const long long us = spin_limit < 0 ? -(long long)spin_limit : (long long)VLN_HOST_WAIT_DEFAULT_US;
+  return -(us * 100ll);                                                                // 100 MHz ticks
+}
 }  // namespace vln
-extern "C" int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, vln_stream_t s) {
+extern "C" int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, uint64_t* ack_dev, vln_stream_t s) {
   if (!flag_dev || !want_dev) { set_error("vln_host_wait: null pointer"); return VLN_ERR_ARG; }
   unsigned* sticky = sticky_dev_word();
   VLN_LAUNCH(host_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, reinterpret_cast<const unsigned long long*>(flag_dev),
-             reinterpret_cast<const unsigned long long*>(want_dev), sticky ? sticky + 3 : nullptr,
-             (unsigned long long)(spin_limit > 0 ? spin_limit : (1ll << 26)));
+             reinterpret_cast<const unsigned long long*>(want_dev), sticky ? sticky + 3 : nullptr, host_wait_limit(spin_limit),
+             reinterpret_cast<unsigned long long*>(ack_dev));
   VLN_CHECK_LAUNCH("host_wait");
+  return VLN_OK;
+}
+extern "C" int vln_host_wait_fetch(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, const void* src_dev, void* dst,
+                                   int64_t nbytes, uint64_t* ack_dev, vln_stream_t s) {
+  if (!flag_dev || !want_dev || !src_dev || !dst || nbytes <= 0 || (nbytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15) ||
+      (reinterpret_cast<uintptr_t>(src_dev) & 15)) {
+    set_error("vln_host_wait_fetch: null pointer, or size / source / destination not a multiple of 16 bytes");
+    return VLN_ERR_ARG;
+  }
+  unsigned* sticky = sticky_dev_word();
+  VLN_LAUNCH(host_wait_fetch_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, reinterpret_cast<const unsigned long long*>(flag_dev),
+             reinterpret_cast<const unsigned long long*>(want_dev), sticky ? sticky + 3 : nullptr, host_wait_limit(spin_limit),
+             static_cast<const u32x4*>(src_dev), static_cast<u32x4*>(dst), (long)(nbytes / 16), reinterpret_cast<unsigned long long*>(ack_dev));
+  VLN_CHECK_LAUNCH("host_wait_fetch");
+  return VLN_OK;
+}
+// What a step hands BACK to the host without a copy call: `nbytes` (multiple of 8) from device memory to pinned host memory
+// (device-visible address), stored by one workgroup with system-scope stores -- the teacher-forced rollout's chosen actions
+// (envdrop.py:198 `a_t.cpu()`), which the host polls while the captured iteration goes on (the sampled rollout's draw stores its
+// actions itself: cand_sample_kernel).
+namespace vln {
+__global__ __launch_bounds__(256) void store_to_host_kernel(const unsigned long long* src, unsigned long long* dst, long n8) {
+  for (long i = threadIdx.x; i < n8; i += 256) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace vln
+extern "C" int vln_store_to_host(const void* src, void* dst_dev, int64_t nbytes, vln_stream_t s) {
+  if (!src || !dst_dev || nbytes <= 0 || (nbytes & 7) || (reinterpret_cast<uintptr_t>(src) & 7) || (reinterpret_cast<uintptr_t>(dst_dev) & 7)) {
+    set_error("vln_store_to_host: null pointer, or size / addresses not multiples of 8 bytes");
+    return VLN_ERR_ARG;
+  }
+  VLN_LAUNCH(store_to_host_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, static_cast<const unsigned long long*>(src),
+             static_cast<unsigned long long*>(dst_dev), (long)(nbytes / 8));
+  VLN_CHECK_LAUNCH("store_to_host");
   return VLN_OK;
 }
 extern "C" int vln_host_fetch(const uint64_t* slots_dev, int ring, uint64_t* seq, uint32_t* done, void* dst, int64_t nbytes, vln_stream_t s) {

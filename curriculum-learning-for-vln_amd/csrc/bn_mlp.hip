@@ -194,7 +194,11 @@ __global__ __launch_bounds__(256) void bn0_from_wgrad_part_kernel(Bn0FromW a) {
   const int n0 = blockIdx.y * a.per, n1 = min(a.N, n0 + a.per);
   const float g = a.gamma[k], bt = a.beta[k];
   const bool bad = g == 0.f;
-  if (bad && blockIdx.y == 0 && a.sticky) atomicAdd(a.sticky + 4, 1u);
+  // |gamma_k| far below |beta_k|: (dW - beta db) cancels to ~|gamma| / |beta| of its terms and the quotient amplifies dW's rounding
+  // by |beta| / |gamma|.  Above VLN_BN0_MAX_AMPLIFICATION the result is still written but the launch REPORTS it
+  // (sticky word 4) instead of handing on a silently degraded d gamma: the caller switches to the direct path.
+  const bool ill = !bad && fabsf(g) * VLN_BN0_MAX_AMPLIFICATION < fabsf(bt);
+  if ((bad || ill) && blockIdx.y == 0 && a.sticky) atomicAdd(a.sticky + 4, 1u);
   const float inv = bad ? 0.f : 1.f / g;
   float sg = 0.f, sb = 0.f;
   for (int n = n0; n < n1; ++n) {

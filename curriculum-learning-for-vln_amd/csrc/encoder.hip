@@ -618,6 +618,9 @@ extern "C" int vln_debug_raise_sticky(int word) {      // test hook: what a time
   return VLN_OK;
 }
 extern "C" int vln_persistent_check(void) {
+  // (the status line is created here if no launch has needed it yet: every graph capture starts with this call, and the pinned
+  //  allocation must not happen INSIDE a capture -- a first vln_host_wait in a fresh process would invalidate it)
+  if (!g_sticky_host) (void)sticky_dev_word();
   unsigned* h = g_sticky_host;
   if (!h) return VLN_OK;
   for (int d = 0; d < 16; ++d) {
@@ -652,9 +655,10 @@ extern "C" int vln_persistent_check(void) {
     }
     if (__atomic_load_n(&h[d * 16 + 4], __ATOMIC_RELAXED)) {
       const unsigned n = __atomic_exchange_n(&h[d * 16 + 4], 0u, __ATOMIC_RELAXED);
-      set_error("%u weight(s) of an input BatchNorm were exactly 0 on device %d in an EARLIER launch (vln_bn0_grads_from_wgrad divides the "
-                "first layer's weight gradient by them): their d gamma was left 0; form the gradients by the direct path instead "
-                "(functional.set_bn0_grads_from_wgrad(False))", n, d);
+      set_error("%u weight(s) of an input BatchNorm were exactly 0, or below 1/%d of their bias in magnitude, on device %d in an EARLIER "
+                "launch (vln_bn0_grads_from_wgrad divides the first layer's weight gradient by them: a zero weight's d gamma was left 0, a "
+                "tiny one's carries the weight gradient's rounding amplified by |beta| / |gamma|); form the gradients by the direct path "
+                "instead (functional.set_bn0_grads_from_wgrad(False))", n, VLN_BN0_MAX_AMPLIFICATION, d);
       return VLN_ERR_ARG;
     }
   }

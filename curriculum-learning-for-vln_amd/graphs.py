@@ -140,7 +140,8 @@ class SegmentedIterationGraph:
         plan = []
         epoch0 = self.clock.epoch
         try:
-            for kind, fn in self.segments:
+            for sg in self.segments:
+                kind, fn = sg[0], sg[1]
                 if kind == "graph":
                     g = torch.cuda.CUDAGraph()
                     # thread_local: a process group's watchdog thread polls the events of collectives that are still in flight
@@ -168,8 +169,8 @@ class SegmentedIterationGraph:
     def run_eager(self):
         """The same pieces issued as plain launches, in order (warm-up iterations; the CPU / gloo tests of the segment order)."""
         out = None
-        for _, fn in self.segments:
-            r = fn()
+        for sg in self.segments:
+            r = sg[1]()
             out = r if r is not None else out
         return out
 
@@ -201,19 +202,29 @@ class HandshakeIterationGraph:
     goes on.  Same kernels in the same order as the segmented form: bit-identical results.  The host segments are NOT run
     while capturing (there is nothing to read yet)."""
 
+    POISON = 0xFFFFFFFFFFFFFFFF        # VLN_HOST_WAIT_POISON: "the host has given this iteration up"
+
     def __init__(self, segments, clock: DeviceClock, spin_limit: int = 0):
+        """segments: ("graph", fn) | ("host", fn) | ("host", fn, (src, dst)) -- the third form's wait also PULLS `src` (a pinned host
+        uint8 tensor the host turn fills: the next step's packed observation) into the device tensor `dst` in the same launch
+        (vln_host_wait_fetch).  spin_limit: vln_host_wait's bound (0 = 2 s of wall clock, > 0 polls, < 0 microseconds)."""
         self.segments, self.clock, self.spin_limit = list(segments), clock, int(spin_limit)
-        n = sum(1 for k, _ in self.segments if k == "host")
+        n = sum(1 for sg in self.segments if sg[0] == "host")
         self.flags = torch.zeros(max(n, 1), dtype=torch.int64).pin_memory()
-        import ctypes as C_
-        d = C_.c_void_p()
-        _lib.check(_lib.load().vln_host_device_pointer(self.flags.data_ptr(), C_.byref(d)), "vln_host_device_pointer")
-        self._flags_dev = int(d.value)
-        self._flags_np = self.flags.numpy()
+        self._flags_dev = _device_pointer(self.flags)
+        self._flags_np = self.flags.numpy().view("uint64")
+        # one acknowledgement word per host turn: the wait of turn i stores the iteration's clock value once it is over (and its mailbox
+        # read); the host starts turn i of the NEXT replay only after it has seen the previous replay's value there
+        self.acks = torch.zeros(max(n, 1), dtype=torch.int64).pin_memory()
+        self._acks_dev = _device_pointer(self.acks)
+        self._acks_np = self.acks.numpy().view("uint64")
+        self._prev_want = None
+        self.ack_deadline_s = 10.0
         self.graph = None
         self.host_fns = []
         self.replays = 0
         self.out = None
+        self.poisoned = 0
 
     def capture(self):
         torch.cuda.synchronize()
@@ -226,21 +237,30 @@ class HandshakeIterationGraph:
         host_fns = []
         try:
             with _no_gc_while_capturing(), torch.cuda.graph(g):
-                for kind, fn in self.segments:
+                for sg in self.segments:
+                    kind, fn = sg[0], sg[1]
                     if kind == "graph":
                         r = fn()
                         if r is not None:
                             self.out = r
+                        continue
+                    flag, ack = self._flags_dev + 8 * len(host_fns), self._acks_dev + 8 * len(host_fns)
+                    if len(sg) > 2 and sg[2] is not None:
+                        src, dst = sg[2]
+                        _lib.check(lib.vln_host_wait_fetch(flag, self.clock.ptr, self.spin_limit, _device_pointer(src), dst.data_ptr(),
+                                                           src.numel() * src.element_size(), ack, _lib.raw_stream()), "vln_host_wait_fetch")
                     else:
-                        _lib.check(lib.vln_host_wait(self._flags_dev + 8 * len(host_fns), self.clock.ptr, self.spin_limit, _lib.raw_stream()),
-                                   "vln_host_wait")
-                        host_fns.append(fn)
+                        _lib.check(lib.vln_host_wait(flag, self.clock.ptr, self.spin_limit, ack, _lib.raw_stream()), "vln_host_wait")
+                    host_fns.append(fn)
         finally:
             while self.clock.epoch > epoch0:
                 self.clock.uncount()
         self.graph, self.host_fns = g, host_fns
         self._check = lib.vln_persistent_check
         return self
+
+    def _await_ack(self, i, prev):
+        _await_ack_impl(self._acks_np, i, prev, self.ack_deadline_s, self._check)
 
     def replay(self):
         st = self._check()
@@ -249,8 +269,43 @@ class HandshakeIterationGraph:
         self.clock.replayed()
         want = self.clock.host                # what the device clock's word holds once this replay's tick has run
         self.graph.replay()
-        for i, fn in enumerate(self.host_fns):
-            fn()
-            self._flags_np[i] = want          # the device's wait for host turn i ends here
+        i, prev = 0, self._prev_want
+        try:
+            for i, fn in enumerate(self.host_fns):
+                if prev is not None and self._acks_np[i] != prev:
+                    self._await_ack(i, prev)  # the host is a whole iteration ahead: turn i of the PREVIOUS replay is not over yet
+                fn()
+                self._flags_np[i] = want      # the device's wait for host turn i ends here
+            i = len(self.host_fns)
+            self._prev_want = want
+        finally:
+            if i < len(self.host_fns):
+                # A host turn raised (simulator error, KeyboardInterrupt, a poll deadline): the device must not sit in the remaining
+                # waits until their bound.  Every flag not yet released gets the POISON value: each wait ends at once and raises the
+                # sticky word, so the NEXT library entry (vln_persistent_check at the top of the next replay, the optimizer step) reports
+                # this iteration as invalid -- its update ran on stale inputs; the caller restores its last good state.
+                self._flags_np[i:len(self.host_fns)] = self.POISON
+                self.poisoned += 1
+                self._prev_want = None        # (the abandoned waits acknowledge nothing: the next replay starts from a drained queue)
+                torch.cuda.current_stream().synchronize()
         self.replays += 1
         return self.out
+
+
+def _await_ack_impl(acks, i, prev, deadline_s, check):
+    import time
+    t0 = time.perf_counter()
+    while acks[i] != prev:
+        if time.perf_counter() - t0 > deadline_s:
+            st = check()
+            if st:
+                _lib.check(st, "vln_persistent_check (while the host waited for the previous iteration's turn to end)")
+            raise TimeoutError(f"HandshakeIterationGraph: host turn {i} of the previous replay was not acknowledged within {deadline_s} s")
+
+
+def _device_pointer(pinned: torch.Tensor) -> int:
+    """The device-visible address of a pinned host tensor (vln_host_device_pointer)."""
+    import ctypes as C_
+    d = C_.c_void_p()
+    _lib.check(_lib.load().vln_host_device_pointer(pinned.data_ptr(), C_.byref(d)), "vln_host_device_pointer")
+    return int(d.value)

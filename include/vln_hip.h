@@ -42,7 +42,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_RELU 2
 #define VLN_ACT_ACCUM 8   /* flag, OR-ed onto an activation: the finished result is ADDED to the output (vln_linear_fwd: Y += ...) */
 
-int vln_abi_version(void);     /* 17 */
+int vln_abi_version(void);     /* 18 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -574,7 +574,11 @@ typedef struct vln_bn_mlp_grads {
  * -- the [R, K] product dz W and the BatchNorm backward over the [R, K] input are never formed (at BASELINE config 2: 5.1 GFLOP and two
  * passes over 10 MB per decoder step).  dW [N,K] / db [N] hold THIS rollout's sums (not yet added to the accumulated gradients); the call
  * also adds them to gW / gb (acc_w / acc_b = 0: stores them).  g_gamma / g_beta: acc_bn = 1 adds.  ws: >= 64 * K floats.  A gamma_k of
- * exactly 0 has no quotient: the launch raises the sticky status word 4 (vln_persistent_check) and leaves d gamma_k = 0. */
+ * exactly 0 has no quotient: the launch raises the sticky status word 4 (vln_persistent_check) and leaves d gamma_k = 0.  A gamma_k with
+ * |gamma_k| * VLN_BN0_MAX_AMPLIFICATION < |beta_k| (ABI v18) is ill-conditioned -- (dW - beta db) cancels and the quotient amplifies dW's
+ * rounding by |beta| / |gamma| --: d gamma_k is still written, and the same sticky word reports it, so a degraded gradient is never
+ * handed on silently (the caller takes the direct path: vln_bn_mlp_bwd without skip). */
+#define VLN_BN0_MAX_AMPLIFICATION 64   /* split-bf16 dW (2^-16) x 64 = 1e-3, a tenth of the bf16 bound; fp32 dW x 64 = 4e-6 */
 int vln_bn0_grads_from_wgrad(const float* dW, const float* db, const float* W /*fp32 master [N,K]*/, int64_t ldw, const float* gamma,
                              const float* beta, float* gW, float* gb, float* g_gamma, float* g_beta, int N, int K, int acc_w, int acc_b,
                              int acc_bn, float* ws, int64_t ws_floats, vln_stream_t s);
@@ -925,10 +929,24 @@ int vln_attn_textk_bwd(const void* ctx, int ctype, const float* kctx, const floa
 /* The device waits for the HOST between two launches of a sequence (ABI v15): a one-wave launch that spins until the 8-byte word
  * at flag_dev (pinned host memory, device-visible address: vln_host_device_pointer) equals the device word *want_dev, then
  * lets the stream go on.  For rollouts whose next step needs the host (the simulator step of envdrop.py:196-206) inside ONE
- * captured iteration: `want` = the device clock's word (it changes every iteration, so an old flag never matches).  spin_limit
- * (<= 0: ~2^26 polls, seconds) bounds the wait: on a timeout word 3 of the sticky error words is raised (vln_persistent_check)
- * and the stream goes on. */
-int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, vln_stream_t s);
+ * captured iteration: `want` = the device clock's word (it changes every iteration, so an old flag never matches).  The wait is
+ * bounded (ABI v18): spin_limit > 0 = that many polls; 0 = VLN_HOST_WAIT_DEFAULT_US of wall clock (the 100 MHz constant clock);
+ * < 0 = -spin_limit microseconds.  On a timeout -- or when the host stores VLN_HOST_WAIT_POISON into the flag: it has given the
+ * iteration up, e.g. an exception in its turn -- word 3 of the sticky error words is raised (vln_persistent_check reports the
+ * iteration as invalid) and the stream goes on.  vln_host_wait_fetch (ABI v18): the same wait and then, in the same launch, a copy
+ * of nbytes (multiple of 16) from src_dev (pinned host memory, device-visible address) to dst -- what the host left for the next
+ * step (agent/base.py:141-178: the observation's index vectors) crosses PCIe without a launch of its own.  ack_dev (nullable;
+ * pinned host memory, device-visible address): when the wait is over and the bytes are read, *want_dev is stored there -- a host that
+ * runs AHEAD of the device (the next iteration's graph is already launched) must see this iteration's value in the word of turn i
+ * before it rewrites turn i's mailbox and flag for the next iteration (graphs.HandshakeIterationGraph does). */
+#define VLN_HOST_WAIT_POISON 0xFFFFFFFFFFFFFFFFull
+#define VLN_HOST_WAIT_DEFAULT_US 2000000
+int vln_host_wait(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, uint64_t* ack_dev, vln_stream_t s);
+/* ... and what a step hands BACK (ABI v18): nbytes (multiple of 8) from device memory to pinned host memory (device-visible
+ * address) by one workgroup's system-scope stores -- the chosen actions of envdrop.py:198 (`a_t.cpu()`), polled by the host. */
+int vln_store_to_host(const void* src, void* dst_dev, int64_t nbytes, vln_stream_t s);
+int vln_host_wait_fetch(const uint64_t* flag_dev, const uint64_t* want_dev, int64_t spin_limit, const void* src_dev, void* dst,
+                        int64_t nbytes, uint64_t* ack_dev, vln_stream_t s);
 int64_t vln_envdrop_ws_floats(const vln_envdrop_dims* d);
 int64_t vln_attn_sync_bytes(int B);   /* bytes of vln_envdrop_step.attn_sync for B episodes */
 /* 1 when the folded text attention of vln_envdrop_step.kctx covers (ctype, B episodes, S tokens, D = H) on the current device with

@@ -12,9 +12,9 @@ import vln_amd as vln
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
-cpu_tape = bench.make_tape(64, 80, 7, 8, 2020)
-tape_t = bench.tape_to(cpu_tape, dev)
-tape_s = bench.tape_to(cpu_tape, dev, store_dtype=dtype)
+cpu_tape = vln.synthetic.make_tape(64, 80, 7, 8, 2020)
+tape_t = vln.synthetic.tape_to(cpu_tape, dev)
+tape_s = vln.synthetic.tape_to(cpu_tape, dev, store_dtype=dtype)
 lib = vln._lib.load()
 
 # variant -> {tunable id: value} on top of the defaults (vln_set_tunable; see csrc/vln_internal.h)
@@ -32,7 +32,7 @@ VARIANTS = {
     "per_step_logits_and_loss_branch": {},
 }
 torch.manual_seed(0)
-agent = bench.GpuAgent(vln, dev, dtype, 1)
+agent = vln.trainers.EnvDropILIteration(dev, dtype, 1)
 
 
 def configure(cfg, name=""):

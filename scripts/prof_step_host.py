@@ -5,8 +5,8 @@ sys.path.insert(0, '.')
 import torch, bench
 import vln_amd as vln
 dev = torch.device('cuda:0')
-agent = bench.GpuAgent(vln, dev, torch.bfloat16, 1, arena=True)
-tape = bench.tape_to(bench.make_tape(64, 80, 7, 8, 2020), dev, store_dtype=torch.bfloat16)
+agent = vln.trainers.EnvDropILIteration(dev, torch.bfloat16, 1, arena=True)
+tape = vln.synthetic.tape_to(vln.synthetic.make_tape(64, 80, 7, 8, 2020), dev, store_dtype=torch.bfloat16)
 for _ in range(5): agent.iteration(tape)
 torch.cuda.synchronize()
 pr = cProfile.Profile()

@@ -29,8 +29,8 @@ def main():
         i, v = tv.split("=")
         vln._lib.check(vln._lib.load().vln_set_tunable(int(i), int(v)), "vln_set_tunable")
     dtype = torch.bfloat16
-    store = bench.build_store(vln, dev, dtype, 10567)
-    tapes = [bench.tape_to(bench.make_tape(64, 80, 7, 8, seed=2020 + k, n_rows=store.N), dev, store=store) for k in range(8)]
+    store = vln.synthetic.build_store(dev, dtype, 10567)
+    tapes = [vln.synthetic.tape_to(vln.synthetic.make_tape(64, 80, 7, 8, seed=2020 + k, n_rows=store.N), dev, store=store) for k in range(8)]
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev).train()
 
     def run(label, use_ride, L):

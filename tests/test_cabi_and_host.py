@@ -149,7 +149,8 @@ def test_shadow_key_tracks_optimizer_steps(vln):
 
 def test_synthetic_tape_follows_the_obs_contract():
     import bench
-    t = bench.make_tape(8, 20, 5, 6, seed=1)
+    import vln_amd as vln
+    t = vln.synthetic.make_tape(8, 20, 5, 6, seed=1)
     assert t["tokens"].shape == (8, 20) and t["lengths"][0] == 20
     assert (t["lengths"][:-1] >= t["lengths"][1:]).all()             # sorted descending (common_env.py:204-205)
     assert ((t["tokens"] == 0) == t["seq_mask"]).all()

@@ -57,6 +57,9 @@ def vln():
     return vln_amd
 
 
+OWN_RELU = "bf16 unrounded, the oracle's own critic ReLU (recorded)"
+
+
 def _mask(vln, n, seed, offset, p, shape):
     return vln.ops.dropout_mask(n, seed, offset, p, DEV).cpu().double().view(shape)
 
@@ -83,7 +86,6 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     """mode 'sum' = cfg3, 'self_pace' = cfg4.  `only`: run just the bf16 oracle of that name.  captured: the iteration (both
     rollouts, the critic, the losses, the backward) runs as ONE replayed hipGraph on a device clock (graphs.IterationGraph) -- what
     is compared with the oracle is then the REPLAY's output, one hop away, with the masks of the clock's offsets."""
-    import bench
     from oracle import torch_port as O
     H, E, AE, ANG, IMG, V = 512, 256, 64, 128, 2048, 36
     dev = torch.device(DEV)
@@ -94,8 +96,8 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     cri = vln.Critic(H, 0.5).to(dev).train()
     table = (torch.randn(N, V, IMG, generator=g).abs() * 0.5).to(cdt)
     store = vln.DeviceFeatureStore(table, device=dev, dtype=cdt, angle_size=ANG)
-    cpu_tape = bench.make_tape(B, L, T_rl + 1, 8, seed=3031, n_rows=N)
-    tape = bench.tape_to(cpu_tape, dev, store=store)
+    cpu_tape = vln.synthetic.make_tape(B, L, T_rl + 1, 8, seed=3031, n_rows=N)
+    tape = vln.synthetic.tape_to(cpu_tape, dev, store=store)
     ncands = [(~s["cand_mask"]).sum(1) for s in cpu_tape["steps"]]
     acts, masks, rewards, ended = _rl_tape(B, T_rl, ncands, g)
     weight = (torch.rand(B, generator=g) * 0.99 + 0.01) if mode == "self_pace" else None      # uniform [0.01, 1]
@@ -177,7 +179,11 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     # ---- the oracle(s) ---------------------------------------------------------------------------------------------------
     variants = [("fp32", FP32, False, None)] if not lp else \
         [("bf16 same-weights", SAME_BF16, True, dict(CFG3_SAME_EXC, **{"grad[": same_bf16_grad_tol()})),
-         ("bf16 unrounded", BF16, False, CFG3_BF16_EXC)]
+         ("bf16 unrounded", BF16, False, CFG3_BF16_EXC),
+         # RECORDED, not asserted: the same comparison against the oracle's OWN ReLU decisions in the critic -- the
+         # reference's exact function -- so that a regression of that number (round 4: 3.5e-2 / 4.9e-2 on the critic's first layer) stays
+         # visible next to the shared-decision assertion above; every check of this variant runs with tol = 1.0
+         (OWN_RELU, 1.0, False, None)]
     if only is not None:
         variants = [v for v in variants if v[0] == only]
     sd = {"enc": enc.state_dict(), "dec": dec.state_dict(), "cri": cri.state_dict()}
@@ -206,7 +212,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
             def step(s, ht, c):
                 od = next(it["dec"])
                 m = lambda site, n, pp, shape: _mask(vln, n, dec.dropout_seed, od * 8 + site, pp, shape)
-                f = bench.materialize_step(s, table.float(), ANG)
+                f = vln.synthetic.materialize_step(s, table.float(), ANG)
                 Ct = s["cand_mask"].shape[1]
                 img = O.feature_dropout(f["img"].double(), m(4, B * V * IMG, pf, (B, V, IMG)), ANG)
                 cand = O.feature_dropout(f["cand"].double(), m(5, B * Ct * IMG, pf, (B, Ct, IMG)), ANG)
@@ -230,7 +236,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
                 return dict(ml=ml * ML_WEIGHT / B)
             _, last_h, _, _ = step(cpu_tape["steps"][T], ht, c)
             # bf16: the critic's ReLU DECISIONS are the kernels' (CRITIC_RELU above); fp32: the reference's own ReLU
-            on = relu_on if lp else (None, None)
+            on = relu_on if (lp and name != OWN_RELU) else (None, None)
             pre = []
             oc = next(it["cri"])
             with torch.no_grad():
@@ -238,7 +244,7 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
             oc = next(it["cri"])
             vals = O.critic(Pc, torch.cat(hidden, 0), _mask(vln, T * B * H, cri.dropout_seed, oc, p, (T * B, H)), relu_on=on[1],
                             pre_out=pre).view(T, B)
-            if lp:       # where the decisions differ from the oracle's own: few units, all with a pre-activation next to zero
+            if lp and name != OWN_RELU:       # where the decisions differ from the oracle's own: few units, all with a pre-activation next to zero
                 for z, m in zip(pre, relu_on):
                     flip = (z > 0) != m
                     frac, worst = float(flip.double().mean()), float(z[flip].abs().max()) if bool(flip.any()) else 0.0

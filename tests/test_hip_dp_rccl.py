@@ -63,11 +63,11 @@ dtype = torch.bfloat16
 
 def run(form):
     torch.manual_seed(77)
-    store = bench.build_store(vln, dev, dtype, n_rows=300, seed=5)
-    tapes = [bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
-    live = bench.LiveBatch(tapes, source="pull")
+    store = vln.synthetic.build_store(dev, dtype, n_rows=300, seed=5)
+    tapes = [vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 4, 6, seed=500 + k, n_rows=store.N), dev, store=store) for k in range(5)]
+    live = vln.LiveBatch(tapes, source="pull")
     torch.manual_seed(78)
-    ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)
+    ag = vln.trainers.EnvDropILIteration(dev, dtype, 1, arena=True)
     ag.use_live(live)
     ag.clear_grads_in_step = True
     ag.enc.deterministic_embedding_grad = True

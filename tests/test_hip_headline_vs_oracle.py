@@ -1,4 +1,4 @@
-"""GPU: the artefact `bench.py` TIMES -- `bench.GpuAgent`'s captured iteration: one hipGraph holding the prologue launch (batch
+"""GPU: the artefact `bench.py` TIMES -- `trainers.EnvDropILIteration`'s captured iteration: one hipGraph holding the prologue launch (batch
 pull from pinned host memory + device-clock tick + weight-shadow refresh), the encoder with the rollout's feature gather and
 the batch tail as passengers of its recurrence launch, seven chained decoder steps on the projected context, the rollout-wide
 logits and cross-entropy, the backward with the decoder's weight gradients riding in the BPTT launch, per-module clip and
@@ -46,7 +46,6 @@ def _mask(vln, n, seed, offset, p, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_headline_iteration_vs_oracle(vln, dtype):
-    import bench
     from oracle import torch_port as O
     dev = torch.device(DEV)
     B, L, T, C = 64, 80, 7, 8
@@ -54,12 +53,12 @@ def test_headline_iteration_vs_oracle(vln, dtype):
     n_eager, n_replay = 2, 5
     lp = dtype != torch.float32
     torch.manual_seed(2020)
-    store = bench.build_store(vln, dev, dtype, n_rows=512, seed=5)
-    cpu_tapes = [bench.make_tape(B, L, T, C, seed=700 + k, n_rows=store.N) for k in range(4)]
-    tapes = [bench.tape_to(t, dev, store=store) for t in cpu_tapes]
-    live = bench.LiveBatch(tapes, source="pull")
+    store = vln.synthetic.build_store(dev, dtype, n_rows=512, seed=5)
+    cpu_tapes = [vln.synthetic.make_tape(B, L, T, C, seed=700 + k, n_rows=store.N) for k in range(4)]
+    tapes = [vln.synthetic.tape_to(t, dev, store=store) for t in cpu_tapes]
+    live = vln.LiveBatch(tapes, source="pull")
     torch.manual_seed(2021)
-    ag = bench.GpuAgent(vln, dev, dtype, 1, arena=True)          # defaults: rollout CE, deferred logits, chained steps
+    ag = vln.trainers.EnvDropILIteration(dev, dtype, 1, arena=True)          # defaults: rollout CE, deferred logits, chained steps
     ag.use_live(live)
     ag.ride_gather = True                                        # as bench.py main() sets them for --features store on one GPU
     ag.dec.ride_wgrads = lp
@@ -95,7 +94,7 @@ def test_headline_iteration_vs_oracle(vln, dtype):
     # ---- the oracle: the same K iterations from the same initial parameters ---------------------------------------------------------
     P = {k: {n: v.clone().requires_grad_(True) for n, v in d.items()} for k, d in sd0.items()}
     params = [p for d in P.values() for p in d.values()]
-    opt = torch.optim.RMSprop(params, lr=bench.LR)               # trainer.py:380-381: torch defaults (alpha 0.99, eps 1e-8)
+    opt = torch.optim.RMSprop(params, lr=vln.trainers.LR)               # trainer.py:380-381: torch defaults (alpha 0.99, eps 1e-8)
     p, pf = 0.5, 0.3
     tol = FP32 if not lp else BF16
     def oracle_iteration(Pm, k, round_features):
@@ -107,7 +106,7 @@ def test_headline_iteration_vs_oracle(vln, dtype):
                                      ctx_mask_drop=_mask(vln, B * L * H, ag.enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
         ht, ml = h, 0.0
         for t, s in enumerate(tape["steps"]):
-            f = bench.materialize_step(s, table, ANG)
+            f = vln.synthetic.materialize_step(s, table, ANG)
             Ct = s["cand_mask"].shape[1]
             img = O.feature_dropout(f["img"].double(), _mask(vln, B * V * IMG, store.seed, host * 8 + 2 * t + 1, pf, (B, V, IMG)), ANG)
             cand = O.feature_dropout(f["cand"].double(), _mask(vln, B * Ct * IMG, store.seed, host * 8 + 2 * t + 2, pf, (B, Ct, IMG)), ANG)
@@ -118,7 +117,7 @@ def test_headline_iteration_vs_oracle(vln, dtype):
             drop = {"act": m(0, B * AE, (B, AE)), "hprev": m(1, B * H, (B, H)), "h1": m(2, B * H, (B, H)), "htilde": m(3, B * H, (B, H))}
             lo, (h, c), ht, _ = O.envdrop_step(Pm["dec"], s["angle"].double(), img, cand, ht, c, cx, tape["seq_mask"], drop=drop)
             ml = ml + O.masked_cross_entropy(lo.masked_fill(s["cand_mask"], -float("inf")), s["target"], None, "sum")
-        return ml * bench.ML_WEIGHT / B
+        return ml * vln.trainers.ML_WEIGHT / B
 
     if lp:
         # RECORDED, not asserted: iteration 0 against the oracle on the UN-rounded fp32 feature rows (the store's
@@ -143,7 +142,7 @@ def test_headline_iteration_vs_oracle(vln, dtype):
                                      ctx_mask_drop=_mask(vln, B * L * H, ag.enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
         ht, ml = h, 0.0
         for t, s in enumerate(tape["steps"]):
-            f = bench.materialize_step(s, table, ANG)
+            f = vln.synthetic.materialize_step(s, table, ANG)
             Ct = s["cand_mask"].shape[1]
             # the rollout's gather rode in the recurrence launch: the store's Philox stream, offsets word * 8 + (2 t + 1 | 2 t + 2)
             img = O.feature_dropout(f["img"].double(), _mask(vln, B * V * IMG, store.seed, host * 8 + 2 * t + 1, pf, (B, V, IMG)), ANG)
@@ -156,7 +155,7 @@ def test_headline_iteration_vs_oracle(vln, dtype):
             lo, (h, c), ht, _ = O.envdrop_step(P["dec"], s["angle"].double(), img, cand, ht, c, cx, tape["seq_mask"], drop=drop)
             lo = lo.masked_fill(s["cand_mask"], -float("inf"))                                     # envdrop.py:173
             ml = ml + O.masked_cross_entropy(lo, s["target"], None, "sum")                         # envdrop.py:178-179
-        oloss = ml * bench.ML_WEIGHT / B                                                           # envdrop.py:268
+        oloss = ml * vln.trainers.ML_WEIGHT / B                                                           # envdrop.py:268
         oloss.backward()
         check(torch.tensor(losses[k]), oloss.detach(), tol, f"loss of iteration {k} ({'eager' if k < n_eager else 'replay'})")
         if k == 0:
@@ -167,8 +166,8 @@ def test_headline_iteration_vs_oracle(vln, dtype):
                     check(g, r, tol, f"iteration 0: grad[{key}.{n}]", floor=grad_floor(n, gmax))
             sig = {key: {n: (q.grad.abs() >= 1e-2 * q.grad.abs().max()) if q.grad is not None else None for n, q in P[key].items()}
                    for key in P}
-        torch.nn.utils.clip_grad_norm_(list(P["enc"].values()), bench.CLIP)                        # trainer.py:425-426
-        torch.nn.utils.clip_grad_norm_(list(P["dec"].values()), bench.CLIP)
+        torch.nn.utils.clip_grad_norm_(list(P["enc"].values()), vln.trainers.CLIP)                        # trainer.py:425-426
+        torch.nn.utils.clip_grad_norm_(list(P["dec"].values()), vln.trainers.CLIP)
         opt.step()
 
     # ---- the trajectory: parameters after K updates, as the change from the start -----------------------------------------------------
@@ -239,44 +238,25 @@ def test_self_monitor_captured_iteration_vs_oracle_with_adam(vln, dtype):
                               start=torch.rand(B, generator=g) * 15 + 4, cur=torch.rand(B, generator=g) * 10 + 0.2,
                               ended=torch.rand(B, generator=g) < 0.1 * t))
         batches.append(dict(tokens=tokens, lens=lens, steps=steps))
-    todev = lambda b: dict(tokens=b["tokens"].to(dev), lens=b["lens"].to(dev, torch.int32),
+    todev = lambda b: dict(tokens=b["tokens"].to(dev), lens32=b["lens"].to(dev, torch.int32),
                            steps=[{k: v.to(dev) for k, v in s.items()} for s in b["steps"]])
-    live = todev(batches[0])
-
-    def load(k):
-        b = todev(batches[k % len(batches)])
-        live["tokens"].copy_(b["tokens"]); live["lens"].copy_(b["lens"])
-        for ls, bs in zip(live["steps"], b["steps"]):
-            for kk in ls:
-                ls[kk].copy_(bs[kk])
 
     # The first step's previous-action rows: NOT the reference's all-zero rows (monitor.py:108) -- a train-mode BatchNorm over identical
     # rows has variance 0, its output is rounding noise of (z - mean) times 1 / sqrt(eps), and the ReLU behind it passes or blocks a
-    # unit by the SIGN of that noise: ill-conditioned in any arithmetic (fp32 and fp64 disagree on it, as two fp32 implementations would)
+    # unit by the SIGN of that noise: ill-conditioned in any arithmetic (fp32 and fp64 disagree on it, as two fp32 implementations would).
+    # (The reference's zero rows: test_hip_full_size_agents.py::test_monitor_step_with_the_reference_zero_first_action.)
     a0_cpu = torch.randn(B, F, generator=g).abs() * 0.5
-    a0 = a0_cpu.to(dev)
-
-    def it():
-        clock.tick()
-        opt.zero_grad()
-        ctx, h, c = enc(live["tokens"], live["lens"])
-        seq_mask = live["tokens"] == 0
-        a_prev, loss = a0, 0.0
-        for t, s in enumerate(live["steps"]):
-            (logit, prog), (h, c), _ = dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
-            lt, _ = vln.losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, 0.5)
-            loss = loss + lt
-            a_prev = s["cand"][torch.arange(B, device=dev), s["target"]].detach()
-        loss.backward()
-        opt.step()
-        return loss
+    # the artefact under test: the package's iteration object (what scripts/bench_agents.py times at BASELINE config 2's size)
+    ag = vln.trainers.SelfMonitorIteration(dev, dtype, enc=enc, dec=dec, opt=opt, lam=0.5, graph=False, a_prev0=a0_cpu.to(dev))
+    ag.clock = clock
+    load = lambda k: ag.load(todev(batches[k % len(batches)]))
+    it = ag.iteration
 
     sd0 = {"enc": {k: v.detach().cpu().double().clone() for k, v in enc.state_dict().items()},
            "dec": {k: v.detach().cpu().double().clone() for k, v in dec.state_dict().items()}}
     n_eager, n_replay = 2, 3
     losses, hosts, grads0 = [], [], None
     try:
-        F_.set_grad_in_place(True); F_.set_rollout_wgrads(True)
         for k in range(n_eager):
             load(k)
             loss = it()
@@ -285,14 +265,14 @@ def test_self_monitor_captured_iteration_vs_oracle_with_adam(vln, dtype):
             if k == 0:
                 grads0 = {key: {n: p.grad.detach().cpu().double().clone() for n, p in mod.named_parameters()}
                           for key, mod in (("enc", enc), ("dec", dec))}
-        graph = vln.IterationGraph(it, clock).capture()
+        ag.capture(warmup=0)
         for k in range(n_eager, n_eager + n_replay):
             load(k)
-            loss = graph.replay()
+            loss = ag.replay()
             torch.cuda.synchronize()
             losses.append(float(loss)); hosts.append(clock.host)
     finally:
-        F_.set_rollout_wgrads(False); F_.set_grad_in_place(False)
+        assert not F_.ROLLOUT_WGRADS.enabled              # the iteration object restores the module-level switches
     vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
     final = {"enc": {k: v.detach().cpu().double() for k, v in enc.state_dict().items()},
              "dec": {k: v.detach().cpu().double() for k, v in dec.state_dict().items()}}

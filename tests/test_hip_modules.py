@@ -563,17 +563,16 @@ def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
 
 
 def test_training_iteration_side_stream_overlap_is_transparent(vln):
-    """bench.GpuAgent.iteration with the deferred weight-gradient GEMMs on a side stream (gradients accumulate into the
+    """trainers.EnvDropILIteration.iteration with the deferred weight-gradient GEMMs on a side stream (gradients accumulate into the
     flat bucket views) must give exactly the gradients of the serial configuration; store- and tensor-fed features
     must give the same loss when dropout is off."""
-    import bench
     dev_ = torch.device(DEV)
-    cpu_tape = bench.make_tape(16, 24, 3, 6, seed=4)
-    tape = bench.tape_to(cpu_tape, dev_)
+    cpu_tape = vln.synthetic.make_tape(16, 24, 3, 6, seed=4)
+    tape = vln.synthetic.tape_to(cpu_tape, dev_)
     res = []
     for overlap in (True, False):
         torch.manual_seed(11)
-        ag = bench.GpuAgent(vln, dev_, torch.float32, 1)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.float32, 1)
         ag.dec.overlap_wgrads = overlap
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
@@ -585,11 +584,11 @@ def test_training_iteration_side_stream_overlap_is_transparent(vln):
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
     # feature store (indices -> gather) vs pre-built tensors: same episode data, dropout off -> same loss
-    store_tape = bench.tape_to(cpu_tape, dev_, store_dtype=torch.float32)
+    store_tape = vln.synthetic.tape_to(cpu_tape, dev_, store_dtype=torch.float32)
     losses = []
     for tp in (tape, store_tape):
         torch.manual_seed(11)
-        ag = bench.GpuAgent(vln, dev_, torch.float32, 1)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.float32, 1)
         ag.enc.eval(); ag.dec.eval(); ag.opt.lr = 0.0
         losses.append(ag.iteration(tp).detach().clone())
     check(losses[0], losses[1], 1e-6, "store vs tensor loss")
@@ -600,13 +599,12 @@ def test_step_graphs_with_device_side_dropout_offset_are_transparent(vln):
     replayed as a hipGraph (vln_envdrop_step.offset_dev).  Dropout ON: loss and every gradient must be bit-identical to
     the plain-launch path, over two iterations (second one exercises re-capture or replay)."""
     import ctypes
-    import bench
     dev_ = torch.device(DEV)
-    tape = bench.tape_to(bench.make_tape(16, 24, 3, 6, seed=5), dev_)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 3, 6, seed=5), dev_)
     res = []
     for graphs in (True, False):
         torch.manual_seed(13)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1)
         ag.dec.step_graphs = graphs
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
@@ -632,15 +630,14 @@ def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
     decoder step replays its hipGraph; losses and gradients equal the torch.empty / plain-launch configuration bit for
     bit (dropout on), and the arena must not be left active after an iteration."""
     import ctypes
-    import bench
     dev_ = torch.device(DEV)
-    tape = bench.tape_to(bench.make_tape(16, 24, 3, 6, seed=6), dev_, store_dtype=torch.bfloat16)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 3, 6, seed=6), dev_, store_dtype=torch.bfloat16)
     lib = vln._lib.load()
     st0, st1 = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
     res = []
     for arena in (True, False):
         torch.manual_seed(17)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=arena)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=arena)
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True    # no float atomics anywhere: every gradient must match bit for bit
         tape["store"]._calls = 0                      # the store's feature-dropout stream restarts too
@@ -674,17 +671,16 @@ def test_missing_library_fails_loudly(vln, monkeypatch):
 
 
 def test_side_stream_gather_and_rollout_ce_are_transparent(vln):
-    """bench.GpuAgent's two scheduling choices -- the per-step feature gather on a side stream and the IL loss of the whole
+    """trainers.EnvDropILIteration's two scheduling choices -- the per-step feature gather on a side stream and the IL loss of the whole
     rollout in one launch (losses.RolloutCE) -- change WHEN work is issued, not what is computed: gradients of every
     parameter equal the in-line / per-step configuration bit for bit over four arena iterations (dropout on); the loss
     value differs only by the summation order of the per-step terms."""
-    import bench
     dev_ = torch.device(DEV)
-    tape = bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=8), dev_, store_dtype=torch.bfloat16)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 4, 6, seed=8), dev_, store_dtype=torch.bfloat16)
     res = []
     for side, rce in ((True, True), (False, False), (True, False), (False, True)):
         torch.manual_seed(19)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side, fused_gather=False)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=True, rollout_ce=rce, side_gather=side, fused_gather=False)
         ag.dec.batch_logit_backward = False           # (the batched logit branch sums in another order: its own test below)
         ag.dec.defer_logits = False
         ag.enc._calls = 0; ag.dec._step_counter = 0
@@ -708,14 +704,13 @@ def test_host_feature_staging_matches_resident_tensors(vln):
     """bench.py --features host / host-bf16: per-step features in pinned host memory, copied on a copy stream into per-step
     device buffers; dropout off -> the same loss and gradients as the device-resident tensors (fp32 host: bit for bit; bf16
     host: the features are rounded once at load time, so to bf16 tolerance), over three arena iterations (buffer reuse)."""
-    import bench
     dev_ = torch.device(DEV)
-    cpu_tape = bench.make_tape(16, 24, 3, 6, seed=9)
+    cpu_tape = vln.synthetic.make_tape(16, 24, 3, 6, seed=9)
     res = {}
     for mode, hd in (("tensor", None), ("host", torch.float32), ("host-bf16", torch.bfloat16)):
-        tape = bench.tape_to(cpu_tape, dev_, host_dtype=hd)
+        tape = vln.synthetic.tape_to(cpu_tape, dev_, host_dtype=hd)
         torch.manual_seed(23)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=True)
         ag.enc.eval(); ag.dec.eval(); ag.opt.lr = 0.0
         ag.enc.deterministic_embedding_grad = True
         for _ in range(3):
@@ -733,14 +728,13 @@ def test_host_feature_copies_under_the_previous_backward(vln):
     reader of its buffer generation) and so run under the previous iteration's backward.  Three different episode batches
     rotating, six iterations back to back with no host sync in between, dropout ON: every iteration's loss and the final
     gradients equal the forward-only overlap (copies wait for the previous iteration's end) bit for bit."""
-    import bench
     dev_ = torch.device(DEV)
-    cpu_tapes = [bench.make_tape(16, 24, 3, 6, seed=90 + k) for k in range(3)]
+    cpu_tapes = [vln.synthetic.make_tape(16, 24, 3, 6, seed=90 + k) for k in range(3)]
     res = []
     for prefetch in (True, False):
-        tapes = [bench.tape_to(t, dev_, host_dtype=torch.float32) for t in cpu_tapes]
+        tapes = [vln.synthetic.tape_to(t, dev_, host_dtype=torch.float32) for t in cpu_tapes]
         torch.manual_seed(29)
-        ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=True)
         ag.prefetch_under_backward = prefetch
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True
@@ -762,13 +756,12 @@ def test_batched_logit_branch_backward_equals_per_step(vln, dtype):
     backward, and `defer_logits` (the forward's candidate logits for the whole rollout at once) against the per-step logits:
     loss and every gradient to summation-order rounding; over four arena iterations with dropout
     on (plans and graph replays included), steps with different candidate counts."""
-    import bench
     dev_ = torch.device(DEV)
-    tape = bench.tape_to(bench.make_tape(16, 24, 4, 6, seed=10), dev_, store_dtype=dtype)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 4, 6, seed=10), dev_, store_dtype=dtype)
     res = []
     for batched in (True, False):
         torch.manual_seed(29)
-        ag = bench.GpuAgent(vln, dev_, dtype, 1, arena=True)
+        ag = vln.trainers.EnvDropILIteration(dev_, dtype, 1, arena=True)
         ag.dec.batch_logit_backward = batched
         ag.dec.defer_logits = batched                 # ... and the forward's logits for the whole rollout at once
         ag.enc._calls = 0; ag.dec._step_counter = 0
@@ -1036,12 +1029,11 @@ def test_long_rollouts_replay_their_step_graphs(vln):
     used to switch itself off for good after 24 misses in a row -- i.e. inside the first two (all-miss by construction)
     arena generations -- before the first possible hit.  Iterations 3.. must replay every step, forward and backward."""
     import ctypes
-    import bench
     dev_ = torch.device(DEV)
     T = 20
-    tape = bench.tape_to(bench.make_tape(8, 12, T, 5, seed=12), dev_, store_dtype=torch.bfloat16)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(8, 12, T, 5, seed=12), dev_, store_dtype=torch.bfloat16)
     lib = vln._lib.load()
-    ag = bench.GpuAgent(vln, dev_, torch.bfloat16, 1, arena=True)
+    ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=True)
     st = [(ctypes.c_int64 * 3)() for _ in range(3)]
     lib.vln_graph_stats(st[0])
     for _ in range(2):
@@ -1094,17 +1086,16 @@ def test_step_gathers_its_own_features_like_caller_given_tensors(vln, dtype):
     and applies the feature dropout with its own Philox sites -- the very masks it uses on caller-given tensors.  Against the
     tensor path (explicit img / cand tensors, dropped in place) on the same episode data: loss and every gradient bit for
     bit, dropout ON, over four arena iterations (plans + graph replays)."""
-    import bench
     dev_ = torch.device(DEV)
-    cpu_tape = bench.make_tape(16, 24, 4, 6, seed=31)
+    cpu_tape = vln.synthetic.make_tape(16, 24, 4, 6, seed=31)
     cpu_tape["table"] = cpu_tape["table"].bfloat16().float()          # values both table dtypes hold exactly
     for s_ in cpu_tape["steps"]:
-        s_.update(bench.materialize_step(s_, cpu_tape["table"]))
+        s_.update(vln.synthetic.materialize_step(s_, cpu_tape["table"]))
     res = []
     for gathered in (True, False):
-        tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype) if gathered else bench.tape_to(cpu_tape, dev_)
+        tape = vln.synthetic.tape_to(cpu_tape, dev_, store_dtype=dtype) if gathered else vln.synthetic.tape_to(cpu_tape, dev_)
         torch.manual_seed(37)
-        ag = bench.GpuAgent(vln, dev_, dtype, 1, arena=True, fused_gather=gathered)
+        ag = vln.trainers.EnvDropILIteration(dev_, dtype, 1, arena=True, fused_gather=gathered)
         ag.enc._calls = 0; ag.dec._step_counter = 0
         ag.enc.deterministic_embedding_grad = True
         ag.opt.lr = 0.0

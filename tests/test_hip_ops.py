@@ -669,6 +669,53 @@ def test_input_batchnorm_gradients_from_the_first_layers_weight_gradient(vln, N,
     assert lib.vln_persistent_check() == 0
 
 
+def test_input_batchnorm_gradient_shortcut_reports_ill_conditioned_weights(vln):
+    """d gamma_k = sum_n (dW[n,k] - beta_k db[n]) / gamma_k W[n,k] cancels catastrophically when |gamma_k| << |beta_k|,
+    and the quotient amplifies the weight gradient's rounding by |beta| / |gamma|.  (a) |gamma| = |beta| / 32 -- inside the bound
+    VLN_BN0_MAX_AMPLIFICATION = 64 --: from an fp32 dW (the fp32 mode) the shortcut's d gamma meets 1e-4 of the tensor's scale
+    (measured 2e-6); from a dW carrying the rounding of the split-bf16 form (what the bf16 mode forms a BN-MLP's deferred weight
+    gradients in: hi + lo planes, three MFMAs, ~2^-16) it meets 1e-3, a tenth of the bf16 bound (2e-4); nothing is reported.  The
+    same dW from PLAIN bf16 operands (what precision 2 would be -- the library never uses it behind a BatchNorm, csrc/bn_mlp.hip)
+    misses by orders of magnitude: recorded.  (b) |gamma| < |beta| / 64: the launch reports it through the sticky status line
+    instead of handing the degraded d gamma on silently."""
+    g = torch.Generator().manual_seed(77)
+    N, K, R = 256, 192, 200
+    xhat = torch.randn(R, K, generator=g).double()
+    beta = (torch.rand(K, generator=g) + 0.5).double()                                          # O(1)
+    gamma = beta / 32 * torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0).double()      # |gamma| = |beta| / 32
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).double()
+    dz = torch.randn(R, N, generator=g).double()
+    y0 = xhat * gamma + beta
+    dW, db = dz.t() @ y0, dz.sum(0)
+    gfull = dz @ W
+    ref_gg = (gfull * xhat).sum(0)
+    f = lambda t: t.float().to(dev())
+    lib = vln._lib.load()
+    assert lib.vln_persistent_check() == 0
+    # dW as the split-bf16 wgrad forms it: both operands as hi + lo bf16 planes, the lo x lo product dropped, fp32 accumulate
+    hi = lambda t: t.float().bfloat16().float()
+    dzf, y0f = dz.float(), y0.float()
+    dzh, y0h = hi(dzf), hi(y0f)
+    dzl, y0l = hi(dzf - dzh), hi(y0f - y0h)
+    dW_split = (dzh.t().double() @ y0h.double() + dzh.t().double() @ y0l.double() + dzl.t().double() @ y0h.double()).float()
+    for name, dW_in, tol in (("an fp32 dW (fp32 mode)", dW.float(), 1e-4),
+                             ("a split-bf16 dW (bf16 mode behind a BatchNorm)", dW_split, 1e-3),
+                             ("a plain-bf16 dW (never used behind a BatchNorm; recorded)", (dzh.t().double() @ y0h.double()).float(), 1e9)):
+        gg, gbeta = torch.empty(K, device=dev()), torch.empty(K, device=dev())
+        vln.ops.bn0_grads_from_wgrad(dW_in.to(dev()), f(db), f(W), f(gamma), f(beta), torch.empty(N, K, device=dev()), torch.empty(N, device=dev()),
+                                     gg, gbeta, accumulate=False)
+        torch.cuda.synchronize()
+        check(gg, ref_gg, tol, f"d gamma at |gamma| = |beta| / 32 from {name}")
+    assert lib.vln_persistent_check() == 0                          # amplification 32 < 64: inside the bound, nothing reported
+    gs = f(gamma).clone(); gs[5] = float(beta[5]) / 4096.0           # one weight 4096x below its bias
+    gg, gbeta = torch.empty(K, device=dev()), torch.empty(K, device=dev())
+    vln.ops.bn0_grads_from_wgrad(f(dW), f(db), f(W), gs, f(beta), torch.empty(N, K, device=dev()), torch.empty(N, device=dev()), gg, gbeta, accumulate=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(gg).all()
+    assert lib.vln_persistent_check() != 0 and b"set_bn0_grads_from_wgrad" in lib.vln_last_error_string()
+    assert lib.vln_persistent_check() == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_grouped_shadow_refresh_of_named_weights_equals_the_single_launches(vln, dtype):
     """functional._ShadowCache.ensure (round 5): a decoder names the weight shadows its steps will stream and the stale ones are

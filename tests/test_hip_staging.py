@@ -376,10 +376,9 @@ def test_fused_step_can_clear_the_gradients_it_consumed(vln):
 def test_rollout_gather_equals_per_step_gathers(vln, dtype):
     """DeviceFeatureStore.gather_rollout: every step of a teacher-forced rollout gathered in ONE launch == gather_step called
     for the steps in order (same Philox offsets): bit for bit, feature dropout on, both output precisions."""
-    import bench
     dev_ = torch.device(DEV)
-    cpu_tape = bench.make_tape(16, 24, 14, 6, seed=77)          # 14 steps: more than one chunk of the launch's argument block
-    tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
+    cpu_tape = vln.synthetic.make_tape(16, 24, 14, 6, seed=77)          # 14 steps: more than one chunk of the launch's argument block
+    tape = vln.synthetic.tape_to(cpu_tape, dev_, store_dtype=dtype)
     lp = dtype != torch.float32
     res = []
     for rollout in (True, False):
@@ -443,14 +442,13 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
     the library must notice BEFORE it commits to passengers and issue the gather as its own launch -- round 3 dropped it).
     Every variant also hands the ride four weight-shadow jobs (vln_gather_ride::shadow_jobs): refreshed by the passengers, or by
     their own launch where there are none, bit for bit what vln_shadow_refresh writes."""
-    import bench
     dev_ = torch.device(DEV)
     lib = vln._lib.load()
     torch.manual_seed(11)
     T = 13 if variant == "thirteen_steps" else 7
-    cpu_tape = bench.make_tape(128 if variant == "batch128_no_idle_cus" else 64, 80, T, 8, seed=77)
+    cpu_tape = vln.synthetic.make_tape(128 if variant == "batch128_no_idle_cus" else 64, 80, T, 8, seed=77)
     cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
-    tape = bench.tape_to(cpu_tape, dev_, store_dtype=dtype)
+    tape = vln.synthetic.tape_to(cpu_tape, dev_, store_dtype=dtype)
     store = tape["store"]
     enc = vln.EncoderLSTM(992, 256, 512, 0, 0.5, True, 1, compute_dtype=dtype).to(dev_).train()
     steps = [(s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"]) for s in tape["steps"]]
