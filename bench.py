@@ -542,6 +542,10 @@ def main():
                          ("batch128_ms_per_step", lambda: secondary_envdrop(
                              vln, dev, store, [make_tape(128, args.L, args.T, 8, seed=4040 + k, n_rows=store.N) for k in range(4)],
                              dtype, "store", args, graph=use_graph)),
+                         # 256 episodes per GPU: the persistent recurrence in two passes (round 6; B > 128 used to fall back to 2 x 80 launches)
+                         ("batch256_ms_per_step", lambda: secondary_envdrop(
+                             vln, dev, store, [make_tape(256, args.L, args.T, 8, seed=4140 + k, n_rows=store.N) for k in range(4)],
+                             dtype, "store", args, graph=use_graph)),
                          # BASELINE config 3's per-rank iteration as 36 graph segments, the host reading every sampled action between them
                          # (envdrop.py:196-206); beside it the same iteration with the actions left on the device (round 3's form of the figure)
                          ("il_plus_a2c_T35", lambda: secondary_agents(dev, args, "a2c", store, read_actions="handshake")),

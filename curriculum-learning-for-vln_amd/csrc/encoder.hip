@@ -161,6 +161,7 @@ struct RecFwdArgs {
   float* ccat;            // [B, dirs*Hd] final c
   int B, L, Hd, dirs, step, vec;
   int init;               // 1: the first time slot of hprev/cprev holds a caller-given initial state (else zeros)
+  int nbb_per;            // persistent granule kernel: row blocks per PASS (0 = all of them in one pass), see persist_passes()
 };
 
 template <typename TW>
@@ -236,6 +237,7 @@ struct RecBwdArgs {
   // optional (persistent counter-protocol kernel): [dirs][ceil(B / 16)][4 * Hd] partial column sums of dgates -- the LSTM's bias
   // gradients summed over each workgroup's 16 rows and all L steps by the threads that form the values (vln_lstm_seq_bwd)
   float* bias_part;
+  int nbb_per;            // persistent counter-protocol kernel: row blocks per PASS (0 = all in one pass), see persist_passes()
 };
 __global__ __launch_bounds__(256) void state_bm_to_db_kernel(const float* dh_bm, const float* dc_bm, float* dh, float* dc, int B, int dirs, int Hd) {
   const long n = (long)B * dirs * Hd;
@@ -691,12 +693,26 @@ extern "C" int vln_lstm_fwd_handoff_stats(const void* sync_ws, uint32_t* xcd_loc
 extern "C" int vln_set_split_attention(int on) { g_split_attn_enabled = on ? 1 : 0; return VLN_OK; }
 extern "C" int vln_get_split_attention(void) { return g_split_attn_enabled; }
 
-static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws) {
+// A batch whose one-workgroup-per-(slice, direction, 16 rows) grid exceeds the device (B > 128 with two directions of 256 units on 256
+// CUs) runs the SAME persistent launch in PASSES (round 6): the grid holds `nbb_per` row blocks per direction, and a workgroup that has
+// finished the L steps of row block bb starts over on row block bb + nbb_per -- the rows of a batch never interact, every dependency
+// group (direction, row block) keeps its own flag line and exchange region, the resident W_hh fragments are loaded once.  Returns the
+// row blocks per pass (= all of them when the batch fits), 0 when even one row block per direction does not fit.  Only the default
+// protocol pair takes passes (granules forward, counters backward): `passes_ok`.
+static int persist_passes(int B, int Hd, int dirs, bool passes_ok) {
+  const int nbb = (B + 15) / 16, cus = device_cus();
+  if (cus <= 0) return 0;
+  const int fit = cus / ((Hd / 16) * dirs);          // row blocks per direction that are co-resident
+  if (fit <= 0) return 0;
+  if (nbb <= fit) return nbb;
+  if (!passes_ok || g_tunable[13] == 7) return 0;     // (tunable[13] = 7: never in passes -- the per-step chain instead, A/B)
+  const int passes = (nbb + fit - 1) / fit;
+  return (nbb + passes - 1) / passes;                 // balanced: B = 192 -> 2 x 6 row blocks, not 8 + 4
+}
+static bool persist_ok(int B, int L, int Hd, int dirs, const void* sync_ws, bool passes_ok = false) {
   if (!g_persist_enabled || !sync_ws) return false;
   if (Hd != 128 && Hd != 256 && Hd != 512) return false;
-  const long wgs = (long)(Hd / 16) * dirs * ((B + 15) / 16);
-  const int cus = device_cus();
-  if (cus <= 0 || wgs > cus || dirs * ((B + 15) / 16) > 32) return false;   // every workgroup must be co-resident
+  if (persist_passes(B, Hd, dirs, passes_ok) <= 0 || dirs * ((B + 15) / 16) > 32) return false;   // every workgroup of a pass co-resident; 32 flag lines
   if ((long)L * B * dirs * 4 * Hd * 4 >= (1L << 32)) return false;       // 32-bit buffer offsets
   if ((fwd_granules() || bwd_granules()) && L > 255) return false;      // granule tags hold the step in 8 bits
   return true;
@@ -932,7 +948,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
                                 int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s) {
   if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
-  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
+  if (persist_ok(B, L, Hd, dirs, sync_ws, fwd_granules()) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
@@ -942,8 +958,9 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     }
     const int init = (h0 || c0) ? 1 : 0;
     if (init) { r = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs); if (r) return r; }
-    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init};
-    dim3 grid(Hd / 16, dirs, (B + 15) / 16);
+    const int nbbp = persist_passes(B, Hd, dirs, fwd_granules());       // row blocks per pass (persist_ok: > 0)
+    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init, nbbp < (B + 15) / 16 ? nbbp : 0};
+    dim3 grid(Hd / 16, dirs, nbbp);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
     unsigned tag_base = 0;
@@ -1133,7 +1150,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
   const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
   PendingRide pend;
   bool have_ride = ride_take((hipStream_t)s, &pend);
-  if (persist_ok(B, L, Hd, dirs, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
+  if (persist_ok(B, L, Hd, dirs, sync_ws, !bwd_granules()) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh_t) &&
       al16(sync_ws)) {
     hipStream_t st = (hipStream_t)s;
     int r = vln_persistent_check(); if (r) return r;
@@ -1142,7 +1159,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     WgradRideArgs ride_args{};
     const WgradRideArgs* riders = nullptr;
     if (have_ride) {
-      const int nrec = (Hd / 16) * dirs * ((B + 15) / 16);
+      const int nrec = (Hd / 16) * dirs * persist_passes(B, Hd, dirs, !bwd_granules());
       if (!bwd_granules() && g_tunable[10] != 1 && (nrec & 7) == 0 && (ride_passengers(nrec) & ~7) > 0 &&       // tunable[10] = 1: never as passengers (A/B)
           wgrad_ride_prepare(pend.w, pend.nw, pend.rows, pend.precision, pend.c, pend.nc, pend.ws, pend.ws_floats, &ride_args)) {
         ride_args.bar = reinterpret_cast<unsigned*>(sync_ws) + kRideBarWord;
@@ -1163,9 +1180,10 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
       r = fill_f32(st, (float*)sync_ws, kSyncHeaderBytes / 4, 0.f);
       if (r) return r;
     }
+    const int nbbp = persist_passes(B, Hd, dirs, !bwd_granules());
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1, dh_bm, dc_bm,
-                 bwd_granules() ? nullptr : bias_partials};
-    dim3 grid(Hd / 16, dirs, (B + 15) / 16);
+                 bwd_granules() ? nullptr : bias_partials, nbbp < (B + 15) / 16 ? nbbp : 0};
+    dim3 grid(Hd / 16, dirs, nbbp);
     unsigned* cw = (unsigned*)sync_ws;
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
     unsigned tag_base = 0;

@@ -371,11 +371,13 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1, role.rid);      // (bit 1 of xcd_map: the XCD-local hand-off may be used, see below)
-  const int jb = ix.jb, j0 = jb * 16, d = ix.d, b0 = ix.bb * 16;
+  // PASSES (round 6, encoder.hip: persist_passes): as in the forward kernel -- `nbb_pass` row blocks per direction in the grid, a
+  // workgroup runs the L steps of row blocks bb, bb + nbb_pass, ... one after the other with the same resident W_hh slice.
+  const int nbb_all = (a.B + 15) / 16, nbb_pass = a.nbb_per > 0 ? a.nbb_per : nbb_all;
+  const PersistIdx ix0 = persist_index(HD / 16, a.dirs, nbb_pass, xcd_map & 1, role.rid);      // (bit 1 of xcd_map: the XCD-local hand-off may be used, see below)
+  const int jb = ix0.jb, j0 = jb * 16, d = ix0.d;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
-  unsigned* cnt = counters + (d * ix.nbb + ix.bb) * 32;      // this group's flag line
 
   // resident slice of W_hh: rows = this workgroup's 64 gate columns, all HD input units; read from the transposed
   // shadow [unit n][4*HD] where each gate's 16 columns are contiguous
@@ -399,7 +401,14 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   }
 
   const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
-  const int b = b0 + bl, j = j0 + jl;
+  const int j = j0 + jl;
+  for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
+  const bool first_pass = bb == ix0.bb;
+  if (!first_pass) __syncthreads();            // the dgates tile / reduction buffer of the previous pass are free
+  const PersistIdx ix{jb, d, bb, nbb_all};
+  const int b0 = bb * 16;
+  unsigned* cnt = counters + (d * ix.nbb + ix.bb) * 32;      // this group's flag line
+  const int b = b0 + bl;
   const bool live = b < B;
   const int len = live ? a.lengths[b] : 0;
   const long ci = ((long)d * B + (live ? b : 0)) * HD + j;
@@ -416,8 +425,8 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       exch, 0, (unsigned)(persist_bwd_exchange_floats(B, HD, a.dirs) * 4), 0x00020000);
   __builtin_amdgcn_s_setprio(3);   // latency-critical chain: win issue arbitration against co-resident streaming work
-  if (threadIdx.x == 0) {
-    s_abort = 0;
+  if (threadIdx.x == 0 && first_pass) {
+    s_abort = 0;                                          // (a timeout of an earlier pass keeps later passes from spinning again)
     if (role.rid == 0) VLN_AGENT_STORE(status, 0u);       // this launch's status word (a timeout sets it long after this store)
   }
   // XCD-LOCAL HAND-OFF (round 5).  The partial products are exchanged through memory: an `sc1` (write-through) store leaves the
@@ -568,4 +577,5 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
     }
   }
 #endif
+  }   // next pass
 }

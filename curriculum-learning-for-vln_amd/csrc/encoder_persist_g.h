@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   __shared__ int s_abort;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const PersistIdx ix = persist_index(HD / 16, a.dirs, (a.B + 15) / 16, xcd_map & 1, role.rid);
-  const int j0 = ix.jb * 16, d = ix.d, b0 = ix.bb * 16;
+  // PASSES (round 6, encoder.hip: persist_passes): the grid holds `nbb_pass` row blocks per direction; a workgroup that has finished
+  // the L steps of row block bb starts over on row block bb + nbb_pass.  Rows never interact, every (direction, row block) group has
+  // its own exchange region and flag line, and the resident W_hh fragments are loaded once.
+  const int nbb_all = (a.B + 15) / 16, nbb_pass = a.nbb_per > 0 ? a.nbb_per : nbb_all;
+  const PersistIdx ix0 = persist_index(HD / 16, a.dirs, nbb_pass, xcd_map & 1, role.rid);
+  const int j0 = ix0.jb * 16, d = ix0.d;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
 
@@ -127,7 +131,13 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
 
   const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
-  const int b = b0 + bl, j = j0 + jl;
+  const int j = j0 + jl;
+  for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
+  const bool first_pass = bb == ix0.bb;
+  if (!first_pass) __syncthreads();            // the tile / gate buffers of the previous pass are free
+  const PersistIdx ix{ix0.jb, d, bb, nbb_all};
+  const int b0 = bb * 16;
+  const int b = b0 + bl;
   const bool live = b < B;
   const int len = live ? a.lengths[b] : 0;
   float hreg = 0.f, creg = 0.f;
@@ -149,8 +159,10 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   unsigned* const gw = status + 32 + (unsigned)(d * ix.nbb + ix.bb) * 32u;
   bool xcd_local = false;
   if (threadIdx.x == 0) {
-    s_abort = 0;
-    if (role.rid == 0) VLN_AGENT_STORE(status, 0u);     // this launch's status (a timeout is >= 1 s away): no fill launch in front
+    if (first_pass) {
+      s_abort = 0;                                      // (a timeout of an earlier pass keeps later passes from spinning again)
+      if (role.rid == 0) VLN_AGENT_STORE(status, 0u);   // this launch's status (a timeout is >= 1 s away): no fill launch in front
+    }
     if (xcd_map & 2) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       __hip_atomic_store(gw + 28, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  }   // next pass
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -359,6 +359,20 @@ class EncoderLSTM(nn.Module):
         w = getattr(self, "_sync_buf", None)
         return 0 if w is None else int(w[32].item())
 
+    def ran_persistent(self) -> bool:
+        """True when persistent recurrence launches have run on this module's scratch buffer: their dependency groups tally how they
+        handed off (vln_lstm_fwd_handoff_stats / vln_lstm_handoff_stats; a per-step launch chain leaves the tallies at zero)."""
+        w = getattr(self, "_sync_buf", None)
+        if w is None:
+            return False
+        lib = _lib.load()
+        n = 0
+        for f in (lib.vln_lstm_fwd_handoff_stats, lib.vln_lstm_handoff_stats):
+            a, b = C.c_uint32(), C.c_uint32()
+            _lib.check(f(w.data_ptr(), C.byref(a), C.byref(b)), "vln_lstm_handoff_stats")
+            n += a.value + b.value
+        return n > 0
+
     def _refresh_shadows(self):
         """Per layer: w_ih [dirs*4Hd, I] (+ transpose), bsum = b_ih + b_hh [dirs*4Hd], w_hh [dirs][4Hd,Hd] (+ per-direction
         transposes), and enc2dec -- all written by ONE launch (ops.ShadowBatch), straight into their stacked layouts."""

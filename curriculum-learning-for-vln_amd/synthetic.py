@@ -111,3 +111,115 @@ def build_store(dev, dtype, n_rows=N_VIEWPOINTS, V=36, IMG=2048, ANG=128, seed=2
         r1 = min(n_rows, r0 + 512)
         table[r0:r1] = (torch.randn(r1 - r0, V, IMG, generator=g, device=dev).abs_() * 0.5).to(dtype)
     return DeviceFeatureStore(table, device=dev, dtype=dtype, angle_size=ANG)
+
+
+class GoalGridWorld:
+    """A LEARNABLE stand-in for R2R (there is no Matterport simulator or R2R data on the box): a G x G torus of viewpoints, four
+    neighbours each (headings 0, pi/2, pi, 3 pi/2; edges `edge_m` metres long), a fixed ResNet-like panorama per viewpoint.  Goal
+    viewpoints (x % 3 == 0 and y % 3 == 0) carry a visual landmark in every view; an episode starts 1-3 moves away from a goal in a
+    straight line, its instruction names the direction (one of four direction words repeated, BOS / EOS around them) and the teacher
+    is the shortest path: that direction until the landmark is in view, then STOP.  An agent that learns (direction word -> the
+    candidate with that heading; landmark -> STOP) reaches success rate 1; a random policy about 0.1.
+
+    Used by the learnability tests (loss curve of the HIP path against the oracle, greedy success rate via metrics.py) -- the
+    stand-in for north_star's SR / SPL clause, which needs the real simulator.  Observations follow the reference's environment:
+    candidates = (a view of the CURRENT panorama, relative heading / elevation), the last real slot is STOP (all-zero row,
+    agent/base.py:152-153); ended episodes stay where they are and carry target -1 (envdrop.py:199-203)."""
+
+    HEADINGS = (0.0, 1.5707963, 3.1415927, 4.712389)      # N, E, S, W
+    MOVES = ((0, 1), (1, 0), (0, -1), (-1, 0))
+    VIEW_OF = (12, 15, 18, 21)                             # the horizontal views that look along the four headings
+    DIR_TOKENS = (4, 5, 6, 7)
+
+    def __init__(self, G=9, IMG=2048, ANG=128, V=36, seed=0, edge_m=4.0, landmark=2.0):
+        assert G % 3 == 0
+        self.G, self.IMG, self.ANG, self.V, self.edge_m = G, IMG, ANG, V, edge_m
+        g = torch.Generator().manual_seed(seed)
+        self.N = G * G
+        table = torch.randn(self.N, V, IMG, generator=g).abs() * 0.5
+        self.goal = torch.tensor([(n // G) % 3 == 0 and (n % G) % 3 == 0 for n in range(self.N)])
+        table[self.goal, :, :64] += landmark               # the landmark: a bump in the first 64 channels of every view
+        self.table = table
+        # candidate order per viewpoint: a fixed permutation of the four directions (the agent cannot learn "slot 0 = north")
+        self.perm = torch.stack([torch.randperm(4, generator=g) for _ in range(self.N)])       # [N, 4]: slot -> direction
+
+    def node(self, x, y):
+        return (x % self.G) * self.G + (y % self.G)
+
+    def neighbour(self, n, d):
+        x, y = n // self.G, n % self.G
+        dx, dy = self.MOVES[d]
+        return self.node(x + dx, y + dy)
+
+    def edges(self):
+        return [(f"v{n}", f"v{self.neighbour(n, d)}", self.edge_m) for n in range(self.N) for d in range(2)]
+
+    def episodes(self, B, seed, L=12):
+        """B episodes: (start node, direction, moves to the goal), instruction tokens sorted by length (descending, like
+        common_env.py:204-205)."""
+        g = torch.Generator().manual_seed(seed)
+        eps = []
+        goals = [n for n in range(self.N) if bool(self.goal[n])]
+        for _ in range(B):
+            goal = goals[int(torch.randint(0, len(goals), (1,), generator=g))]
+            d = int(torch.randint(0, 4, (1,), generator=g))
+            n_moves = int(torch.randint(1, 3, (1,), generator=g))           # 1 or 2: the next goal along a line is 3 away
+            start = goal
+            for _ in range(n_moves):
+                start = self.neighbour(start, (d + 2) % 4)
+            length = int(torch.randint(4, L + 1, (1,), generator=g))
+            eps.append(dict(start=start, goal=goal, d=d, n=n_moves, length=length))
+        eps.sort(key=lambda e: -e["length"])
+        eps[0]["length"] = L
+        tokens = torch.zeros(B, L, dtype=torch.long)
+        for i, e in enumerate(eps):
+            n = e["length"]
+            tokens[i, 0] = 3
+            tokens[i, 1:n - 1] = self.DIR_TOKENS[e["d"]]
+            tokens[i, n - 1] = 2
+        return eps, tokens, torch.tensor([e["length"] for e in eps])
+
+    def observe(self, nodes):
+        """Index vectors of one step for the episodes standing at `nodes` [B] (what agent/base.py:141-157 marshals): 5 candidate
+        slots = the four neighbours in the viewpoint's own order + STOP (zero row, crow = -1)."""
+        B = len(nodes)
+        nodes = torch.as_tensor(nodes, dtype=torch.long)
+        dirs = self.perm[nodes]                                              # [B, 4]
+        crow = torch.cat((nodes[:, None].expand(B, 4), torch.full((B, 1), -1, dtype=torch.long)), 1)
+        cview = torch.cat((torch.tensor(self.VIEW_OF)[dirs], torch.zeros(B, 1, dtype=torch.long)), 1).int()
+        chead = torch.cat((torch.tensor(self.HEADINGS)[dirs], torch.zeros(B, 1)), 1)
+        return dict(rows=nodes.clone(), vidx=torch.full((B,), 12, dtype=torch.int32), crow=crow, cview=cview, chead=chead,
+                    celev=torch.zeros(B, 5), cand_mask=torch.zeros(B, 5, dtype=torch.bool),
+                    angle=angle_feat(torch.zeros(B), torch.zeros(B), self.ANG))
+
+    def teacher(self, nodes, eps):
+        """Shortest-path action per episode: the slot of its direction, or STOP (slot 4) at the goal."""
+        out = []
+        for n, e in zip(torch.as_tensor(nodes).tolist(), eps):
+            out.append(4 if n == e["goal"] else int((self.perm[n] == e["d"]).nonzero()[0]))
+        return torch.tensor(out)
+
+    def step(self, nodes, actions, ended):
+        """env.step: every running episode moves to the chosen neighbour; STOP (slot 4) or -1 ends / keeps it."""
+        nxt, end = [], []
+        for n, a, e in zip(torch.as_tensor(nodes).tolist(), torch.as_tensor(actions).tolist(), torch.as_tensor(ended).tolist()):
+            if e or a < 0 or a == 4:
+                nxt.append(n); end.append(True)
+            else:
+                nxt.append(self.neighbour(n, int(self.perm[n, a]))); end.append(False)
+        return torch.tensor(nxt), torch.tensor(end)
+
+    def tape(self, B, seed, L=12, T=3):
+        """A teacher-forced episode batch in make_tape()'s format (index-only: the table is this world's), T steps."""
+        eps, tokens, lens = self.episodes(B, seed, L)
+        nodes = torch.tensor([e["start"] for e in eps])
+        ended = torch.zeros(B, dtype=torch.bool)
+        steps = []
+        for _ in range(T):
+            st = self.observe(nodes)
+            tgt = self.teacher(nodes, eps)
+            st["target"] = torch.where(ended, torch.full_like(tgt, -1), tgt)
+            steps.append(st)
+            nodes, ended = self.step(nodes, st["target"], ended)
+        return dict(tokens=tokens, lengths=lens, seq_mask=tokens == 0, steps=steps, table=None, B=B, L=L, T=T, IMG=self.IMG,
+                    ANG=self.ANG, episodes=eps)

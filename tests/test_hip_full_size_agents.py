@@ -64,7 +64,8 @@ class _Oracle:
             check(g, r, self.t(f"grad[{n}]"), f"{self.name}: grad[{n}]", floor=grad_floor(n, gmax))
             # a loosened max-abs bound keeps its L2 bound (gradients that vanish in exact arithmetic -- a bias in front of a
             # train-mode BatchNorm -- are rounding noise on both sides: no relative L2)
-            if self.same and self.t(f"grad[{n}]") > same_bf16_grad_tol() and float(r.abs().max()) > 1e-2 * gmax:
+            # (a tolerance >= 1e8 marks a tensor that is RECORDED only -- ill-conditioned in any arithmetic -- : no L2 bound either)
+            if self.same and same_bf16_grad_tol() < self.t(f"grad[{n}]") < 1e8 and float(r.abs().max()) > 1e-2 * gmax:
                 import parity
                 assert parity.RECORD_ONLY or parity.rel_l2(g, r) < same_bf16_grad_tol(), f"{self.name}: grad[{n}] L2 error {parity.rel_l2(g, r):.2e}"
 
@@ -93,7 +94,7 @@ MONITOR_BF16_EXC = {"loss": 0.1}
 FOLLOWER_BF16_EXC = {"loss": 2e-2}
 
 
-def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176, T=2, fused=True, merged=False):
+def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176, T=2, fused=True, merged=False, zero_first=False):
     from oracle import torch_port as O
     g = torch.Generator().manual_seed(2021)
     torch.manual_seed(2021)
@@ -110,6 +111,16 @@ def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176,
     hd, cd = h_d, c_d
     state = [(o.leaves[1], o.leaves[2]) for o in ors]
     a_prev = torch.randn(B, F, generator=g).abs() * 0.5
+    if zero_first:
+        # the reference's first step: `a_t_prev = zeros` (monitor.py:108).  B identical rows through a train-mode BatchNorm: the second
+        # BatchNorm sees z - mean(z) = rounding noise, scales it by 1 / sqrt(eps) = 316 and the ReLU behind it passes or blocks a unit
+        # by the SIGN of that noise.  The projected rows themselves stay ~1e-5 (nothing downstream notices), but the ReLU's decisions
+        # gate a gradient that the same 1 / sqrt(eps) amplifies on its way back: the BN-MLP's parameter gradients are ill-conditioned
+        # in ANY arithmetic (the reference's own fp32 run and an fp64 run of it disagree on them).  Those six tensors are recorded with
+        # tol = 1e9; everything else -- logits, progress, states, attention weights, every other gradient -- is asserted as usual.
+        a_prev = torch.zeros(B, F)
+        for o in ors:
+            o.exc = dict({"grad[proj_navigable_mlp": 1e9}, **o.exc)
     loss_d = 0.0
     mlp_drop = [m for m in dec.proj_navigable_mlp.mlp if isinstance(m, torch.nn.Dropout)][0]
     for t in range(T):
@@ -165,6 +176,14 @@ def _monitor_full(vln, cdt, train=True, B=128, L=80, H=512, M=1024, C=8, F=2176,
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_monitor_cfg2_full_size_dropout_on(vln, cdt, merged):
     _monitor_full(vln, cdt, train=True, merged=merged)
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_monitor_step_with_the_reference_zero_first_action(vln, cdt):
+    """the Self-Monitor's FIRST step as the reference runs it -- all-zero previous-action rows (monitor.py:108) -- at
+    BASELINE config 2's size, fp32 and bf16, followed by a second step on real rows.  What is ill-conditioned (the BN-MLP's six
+    parameter gradients, see _monitor_full) is recorded; the rest is held to 1e-4 / 1e-2."""
+    _monitor_full(vln, cdt, train=True, merged=True, zero_first=True)
 
 
 @pytest.mark.parametrize("merged", [False, True], ids=["two_bn_mlp_calls", "merged_projections"])

@@ -353,13 +353,16 @@ def _encoder_full(vln, compute_dtype):
             check(prm.grad, P[n].grad, _tol_for(exc, tol, f"grad[{n}]"), f"{name}: grad[{n}]", floor=grad_floor(n, gmax))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype,B", [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 144), (torch.float32, 192), (torch.bfloat16, 256)])
 @pytest.mark.usefixtures("split_wgrads")
-def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
+def test_persistent_recurrence_equals_per_step_launches(vln, dtype, B):
     """The single-launch persistent bi-LSTM (in-kernel cross-workgroup hand-off) must reproduce the per-step
-    launch chain bit for bit, forward and backward, and report a clean status word."""
+    launch chain bit for bit, forward and backward, and report a clean status word.  B > 128 (round 6): the
+    one-workgroup-per-(slice, direction, 16 rows) grid no longer fits the 256 CUs, and the launch runs in PASSES -- 144 rows = 9 row
+    blocks -> 2 passes of 5 (the last pass one block short), 192 -> 2 x 6, 256 -> 2 x 8 -- instead of falling back to 2 x L per-step
+    launches (encoder.hip: persist_passes)."""
     lib = vln._lib.load()
-    B, L, E, H, vocab = 64, 80, 256, 512, 992
+    L, E, H, vocab = 80, 256, 512, 992
     g = torch.Generator().manual_seed(3)
     enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=dtype).to(DEV).train()
     lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
@@ -377,6 +380,8 @@ def test_persistent_recurrence_equals_per_step_launches(vln, dtype):
         torch.cuda.synchronize()
         if persistent:
             assert enc.persistent_status() == 0
+            if B > 128:       # the persistent path WAS taken: its launch ran in passes (a per-step chain leaves no hand-off tallies)
+                assert enc.ran_persistent(), "B > 128 fell back to the per-step launch chain"
         outs.append([ctx.detach().clone(), h.detach().clone(), c.detach().clone()] +
                     [p.grad.detach().clone() for p in enc.parameters()])
     lib.vln_set_persistent(1)
