@@ -607,6 +607,26 @@ class SpeakerIteration:
         return loss
 
 
+class _SplitRows(torch.autograd.Function):
+    """x [2B, ...] -> (x[:B], x[B:]) as views; backward = ONE concatenation of the two halves' gradients (autograd's own slice nodes
+    would each fill a full-size zero tensor, copy their half in and add the two: five launches over 2 x the bytes)."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B, ctx.shape = B, x.shape
+        ctx.set_materialize_grads(False)
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None, None
+        B = ctx.B
+        z = lambda g, n: g if g is not None else torch.zeros((n,) + tuple(ctx.shape[1:]), dtype=(g1 if g1 is not None else g2).dtype,
+                                                             device=(g1 if g1 is not None else g2).device)
+        return torch.cat((z(g1, B), z(g2, ctx.shape[0] - B)), 0), None
+
+
 class EnvDropA2CIteration:
     """BASELINE config 3's per-rank iteration -- the reference's DEFAULT EnvDrop iteration (engine/trainer.py:411-427): a
     teacher-forced IL rollout (T_il steps) and a SAMPLED rollout of up to T_rl steps (the reference caps episodes at
@@ -629,7 +649,7 @@ class EnvDropA2CIteration:
 
     def __init__(self, dev, dtype, tape, *, T_il=7, rewards=None, masks=None, ended=None, graph=True, read_actions=True, host_turn=None,
                  enc=None, dec=None, critic=None, sampler_in_step=True, per_step_sampler=False, chain_il=True, chain_backward=True,
-                 lr=LR, clip_norm=CLIP, ml_weight=ML_WEIGHT, gamma=0.9, normalize="total", stop_action=None, reward_seed=7):
+                 lr=LR, clip_norm=CLIP, ml_weight=ML_WEIGHT, gamma=0.9, normalize="total", stop_action=None, reward_seed=7, merge_encoders=True):
         self.dev, self.dtype, self.tape, self.T_il, self.T_rl = dev, dtype, tape, T_il, len(tape["steps"])
         self.read_actions, self.ml_weight, self.gamma, self.normalize = read_actions, ml_weight, gamma, normalize
         B, T_rl = tape["B"], self.T_rl
@@ -656,6 +676,12 @@ class EnvDropA2CIteration:
         self._a_host_dev = int(d.value)         # the device-visible address of the pinned action words (the step's draw stores there itself)
         self.in_step = bool(sampler_in_step) and not per_step_sampler
         self.per_step_sampler, self.chain_il, self.chain_backward = per_step_sampler, chain_il, chain_backward
+        # The two rollouts of an iteration encode the SAME instructions (trainer.py:413-416: the sampled rollout restarts the batch) with
+        # independent dropout masks: ONE encoder call over 2B rows -- rows [0, B) feed the teacher-forced rollout, rows [B, 2B) the
+        # sampled one, each row with its own Philox positions -- instead of two calls (round 6: the recurrence is bound by its L
+        # dependent steps, not by its rows; B > 128 runs it in passes).  merge_encoders=False: the two calls (A/B).
+        self.merge_encoders = merge_encoders
+        self._tokens2 = self._lens2 = None
         self.poll = read_actions in ("poll", "handshake")
         self.stop_action = (tape["steps"][0]["cand_mask"].shape[1] - 1) if stop_action is None else stop_action
         self.host_ended = 0                     # what the stand-in for env.step keeps: episodes that chose STOP so far (read, never fed back)
@@ -675,9 +701,35 @@ class EnvDropA2CIteration:
     def _gather_of(self, s):
         return (self.store, s["rows"], s["vidx"], s["crow"], s["cview"], s["chead"], s["celev"])
 
+    def _encode(self, which):
+        """(ctx, h, c) of rollout `which` (0 = teacher-forced, 1 = sampled): two encoder calls, or the halves of one call over 2B rows."""
+        tape = self.tape
+        if not self.merge_encoders:
+            return self.enc(tape["tokens"], tape["lengths32"])
+        if which == 0:
+            B = self.B
+            if self._tokens2 is None:
+                self._tokens2 = torch.empty((2 * B,) + tuple(tape["tokens"].shape[1:]), dtype=tape["tokens"].dtype, device=self.dev)
+                self._lens2 = torch.empty(2 * B, dtype=tape["lengths32"].dtype, device=self.dev)
+            torch.cat((tape["tokens"], tape["tokens"]), 0, out=self._tokens2)       # (the live batch's buffers may have new contents)
+            torch.cat((tape["lengths32"], tape["lengths32"]), 0, out=self._lens2)
+            ctx2, h2, c2 = self.enc(self._tokens2, self._lens2)
+            lp = getattr(ctx2, "_vln_lp", None)
+            halves = []
+            parts = [_SplitRows.apply(t, B) for t in (ctx2, h2, c2)]
+            for k in range(2):
+                cx, hh, cc = parts[0][k], parts[1][k], parts[2][k]
+                if lp is not None:
+                    cx._vln_lp = lp[:B] if k == 0 else lp[B:]
+                ops.stamp(cx, hh, cc)
+                halves.append((cx, hh, cc))
+            self._st["enc_rl"] = halves[1]
+            return halves[0]
+        return self._st.pop("enc_rl")
+
     def _il_rollout(self):
         tape, dec = self.tape, self.dec
-        ctx, h, c = self.enc(tape["tokens"], tape["lengths32"])
+        ctx, h, c = self._encode(0)
         ht = h
         dec.defer_logits = True            # teacher forcing: the logits are only needed by the loss (formed once per rollout)
         dec.chain_steps = self.chain_il    # ... and nothing reads a step's h_tilde but the next step: consecutive steps share launches
@@ -689,7 +741,7 @@ class EnvDropA2CIteration:
 
     def _rl_begin(self):
         tape, dec = self.tape, self.dec
-        ctx, h, c = self.enc(tape["tokens"], tape["lengths32"])
+        ctx, h, c = self._encode(1)
         dec.defer_logits = False
         dec.chain_steps = False               # the sampled rollout reads every step's logits
         dec.chain_backward = self.chain_backward     # ... but nothing except the next step consumes its h_tilde

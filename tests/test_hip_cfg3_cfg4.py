@@ -82,7 +82,7 @@ def _rl_tape(B, T, ncands, g):
     return acts, masks, rewards, lens <= T
 
 
-def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False, only=None, captured=False):
+def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=False, only=None, captured=False, merged=False):
     """mode 'sum' = cfg3, 'self_pace' = cfg4.  `only`: run just the bf16 oracle of that name.  captured: the iteration (both
     rollouts, the critic, the losses, the backward) runs as ONE replayed hipGraph on a device clock (graphs.IterationGraph) -- what
     is compared with the oracle is then the REPLAY's output, one hop away, with the masks of the clock's offsets."""
@@ -109,9 +109,28 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
     # ---- the HIP path, recording the Philox offsets every module used ------------------------------------------------
     offs = {"enc": [], "dec": [], "cri": []}
 
+    both = {}
+
+    def gpu_encode(sample):
+        """merged (round 6, trainers.EnvDropA2CIteration.merge_encoders): ONE encoder call over 2B rows -- the same instructions twice --
+        whose halves feed the two rollouts, instead of two calls."""
+        if not merged:
+            offs["enc"].append(enc._calls + 1)
+            return enc(tape["tokens"], tape["lengths32"])
+        if not sample:
+            offs["enc"].append(enc._calls + 1)
+            ctx2, h2, c2 = enc(torch.cat((tape["tokens"], tape["tokens"]), 0), torch.cat((tape["lengths32"], tape["lengths32"]), 0))
+            lp = getattr(ctx2, "_vln_lp", None)
+            parts = [vln.trainers._SplitRows.apply(t, B) for t in (ctx2, h2, c2)]
+            for k in range(2):
+                if lp is not None:
+                    parts[0][k]._vln_lp = lp[:B] if k == 0 else lp[B:]
+            both["rl"] = tuple(p_[1] for p_ in parts)
+            return tuple(p_[0] for p_ in parts)
+        return both.pop("rl")
+
     def gpu_rollout(T, sample):
-        offs["enc"].append(enc._calls + 1)
-        ctx, h, c = enc(tape["tokens"], tape["lengths32"])
+        ctx, h, c = gpu_encode(sample)
         ht = h
         hidden = []
         dec.defer_logits = not sample
@@ -170,7 +189,8 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
         vln._lib.check(vln._lib.load().vln_persistent_check(), "vln_persistent_check")
         host = clock.host            # call r of a module since the tick draws with the host-counter value host + r (runtime.DeviceClock)
         assert host == clock.STRIDE * 4    # two eager warm-up iterations + two replays
-        offs = {"enc": [host + 1, host + 2], "dec": [host + 1 + i for i in range(T_il + T_rl + 1)], "cri": [(host + 1) * 8, (host + 2) * 8]}
+        offs = {"enc": [host + 1] if merged else [host + 1, host + 2], "dec": [host + 1 + i for i in range(T_il + T_rl + 1)],
+                "cri": [(host + 1) * 8, (host + 2) * 8]}
     else:
         il, rlr, relu, loss = hip_iteration()
         torch.cuda.synchronize()
@@ -199,11 +219,26 @@ def _iteration(vln, cdt, mode, T_il=7, T_rl=35, B=64, L=80, N=768, normalised=Fa
         Pc = P["cri"]                                                                       # the critic computes in fp32
         it = {k: iter(v) for k, v in offs.items()}
 
-        def ora_rollout(T, sample):
-            oe = next(it["enc"])
-            cx, h, c = O.encoder_forward(Pe, cpu_tape["tokens"], lengths, num_layers=1, bidirectional=True,
+        obo = {}
+
+        def ora_encode(sample):
+            if not merged:
+                oe = next(it["enc"])
+                return O.encoder_forward(Pe, cpu_tape["tokens"], lengths, num_layers=1, bidirectional=True,
                                          emb_mask=_mask(vln, B * L * E, enc.dropout_seed, oe * 8 + 0, p, (B, L, E)),
                                          ctx_mask_drop=_mask(vln, B * L * H, enc.dropout_seed, oe * 8 + 1, p, (B, L, H)))
+            if not sample:       # one call over 2B rows: row r of the call draws the Philox positions of row r
+                oe = next(it["enc"])
+                cx2, h2, c2 = O.encoder_forward(Pe, torch.cat((cpu_tape["tokens"], cpu_tape["tokens"]), 0), lengths + lengths, num_layers=1,
+                                                bidirectional=True,
+                                                emb_mask=_mask(vln, 2 * B * L * E, enc.dropout_seed, oe * 8 + 0, p, (2 * B, L, E)),
+                                                ctx_mask_drop=_mask(vln, 2 * B * L * H, enc.dropout_seed, oe * 8 + 1, p, (2 * B, L, H)))
+                obo["rl"] = (cx2[B:], h2[B:], c2[B:])
+                return cx2[:B], h2[:B], c2[:B]
+            return obo.pop("rl")
+
+        def ora_rollout(T, sample):
+            cx, h, c = ora_encode(sample)
             cxs = bf16_round_st(cx) if same else cx              # the text attention streams a bf16 copy of the context
             sc = cx if (same and dec.last_projected) else None    # ... and scores on K = ctx W_in formed from the fp32 context (round 5)
             ht = h
@@ -295,6 +330,14 @@ def test_cfg4_self_pace_weighted_full_size(vln, cdt):
     # bf16: north_star's comparison (the unrounded oracle); the kernels' own arithmetic is pinned by cfg3's same-weights run --
     # the two configs differ in the loss weighting only
     _iteration(vln, cdt, "self_pace", only=None if cdt == torch.float32 else "bf16 unrounded")
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_cfg3_with_one_encoder_call_for_both_rollouts(vln, cdt):
+    """Round 6: the iteration's two rollouts encode the same instructions (trainer.py:413-416) -- ONE encoder call over 2B rows whose
+    halves feed them (what trainers.EnvDropA2CIteration does by default), against the oracle run the same way: every loss, log-prob,
+    entropy, value and gradient, at BASELINE config 3's per-rank size with a shorter sampled rollout."""
+    _iteration(vln, cdt, "sum", T_rl=12, merged=True, only=None if cdt == torch.float32 else "bf16 unrounded")
 
 
 def test_cfg4_self_pace_weight_normalised_form(vln):
