@@ -86,6 +86,25 @@ class LiveBatch:
                 if k not in self.HEAD_STEP:
                     yield f"{i}.{k}", s[k]
 
+    def put(self, k, tape):
+        """A trainer's NEW batch into blob slot k (same keys, shapes and dtypes as the batches this LiveBatch was built from; CPU
+        tensors or anything `.cpu()` accepts): the marshalling of agent/base.py:114-178 ends here.  Rotate at least two slots: slot k
+        must not be rewritten while an iteration that was `load(k)`-ed is still in flight.  Packing goes through numpy views of the
+        blob (no torch CPU op per field)."""
+        blob = self.blobs[k % len(self.blobs)]
+        if blob.is_cuda:                                   # source "device": stage through a host buffer, one H2D copy
+            host = torch.empty(self.nbytes, dtype=torch.uint8)
+            self._pack(host.numpy(), tape)
+            blob.copy_(host, non_blocking=False)
+            return
+        self._pack(blob.numpy(), tape)
+
+    def _pack(self, dst, tape):
+        for (name, o, n, dt, shape), (name2, t) in zip(self.layout, self._items(tape)):
+            if name != name2 or tuple(t.shape) != shape or t.dtype != dt:
+                raise ValueError(f"LiveBatch.put: the batch's layout differs at {name}: {tuple(t.shape)} {t.dtype} vs {shape} {dt}")
+            dst[o:o + n] = t.detach().cpu().contiguous().view(-1).view(torch.uint8).numpy()
+
     def load(self, k):
         if self.feed is not None:
             self.feed.select(self.blobs[k % len(self.blobs)])       # one host store; the iteration's first launch pulls the blob

@@ -174,6 +174,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
     # alone put d h_tilde / d visual_attn.linear_in at 1.4e-2 of the fp32 reference; with them in fp32 EVERY logit and gradient
     # of BASELINE config 1 is within north_star's 1e-2 (tests/test_hip_modules.py::test_envdrop_full_size_bf16).  `frozenset()`
     # = every matrix bf16 (round 3's default; bench.py secondary `all_bf16_weights_ms_per_step`).
+    default_step_graphs = True       # decoder steps as hipGraphs by default (see __init__)
     default_fp32_weights = frozenset({"w_vin", "w_tin"})
 
     def __init__(self, hidden_size, drop_ratio, feat_drop_ratio, action_embed_size: int = 64,
@@ -221,12 +222,13 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         # of standing in front of it (57-69 us of the dependent chain at B = 64).  Single-GPU schedules only: a data-parallel
         # caller wants the decoder's gradients final BEFORE the BPTT (grads_ready_hook).
         self.ride_wgrads = False
-        # Replay each decoder step (forward: 13 launches, backward: 15) as ONE hipGraph.  A graph is keyed by the step's
-        # argument block, i.e. by device addresses; it only pays when the caller's tensors come back at the SAME
-        # addresses every iteration.  PyTorch's caching allocator does not guarantee that (measured: every step's
-        # block differs between consecutive iterations, 0 replays), so this is off unless the caller allocates from a
-        # fixed arena; results are identical either way.
-        self.step_graphs = False
+        # Replay each decoder step (forward: 9-13 launches, backward: up to 15) as ONE hipGraph.  A graph is keyed by the step's
+        # argument block, i.e. by device addresses; it pays when the caller's tensors come back at the SAME addresses every
+        # iteration: guaranteed under ops.RolloutArena, and in practice also with PyTorch's caching allocator once a training loop
+        # has settled (round 6, the reference's unchanged caller: 458 replays against 46 captures over 36 iterations, host-bound
+        # iteration 2.16 -> 1.95 ms; a chain that never repeats pauses its own capturing: csrc/graph_cache.h).  Results are
+        # identical either way (tests/test_hip_modules.py::test_per_step_graphs_without_an_arena_equal_plain_launches).
+        self.step_graphs = self.default_step_graphs
         # The step's two attentions on FOUR workgroups per episode (csrc/attention_split.h) instead of one: 256 workgroups at
         # B = 64.  Needs a zero-initialised exchange buffer that lives as long as the module (allocated on first use) and
         # B * 4 <= the device's CU count (the library checks; larger batches take the one-workgroup kernels).

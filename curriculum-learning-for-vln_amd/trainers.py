@@ -228,7 +228,7 @@ class EnvDropILIteration:
 
     def use_arena(self, on: bool):
         self.arena = ops.RolloutArena() if on else None
-        self.dec.step_graphs = bool(on)
+        self.dec.step_graphs = True if on else bool(getattr(type(self.dec), "default_step_graphs", False))
 
     def step_features(self, tape, s):
         """Per-step marshalling (agent/base.py:141-157 + the EnvDrop feature dropout, policy.py:226-231).

@@ -662,3 +662,36 @@ def test_host_in_the_loop_iteration_as_one_graph_equals_eager(vln, dtype):
         assert torch.isfinite(a[0]).all()
         for x, y, what in zip(a, b, ("loss", "parameters", "RMSprop state")):
             assert torch.equal(x, y), f"iteration {i}: {what} differ between the eager and the one-graph host-in-the-loop iteration"
+
+
+def test_live_batch_put_repacks_a_new_batch_into_a_pinned_slot(vln):
+    """batches.LiveBatch.put: a trainer's new batch packed into blob slot k and pulled by the captured iteration's first launch gives the
+    iteration the same inputs as a LiveBatch built from that batch (loss of the replay bit for bit)."""
+    dev = torch.device(DEV)
+    dtype = torch.bfloat16
+    torch.manual_seed(77)
+    store = vln.synthetic.build_store(dev, dtype, n_rows=300, seed=5)
+    cpu = [vln.synthetic.make_tape(16, 24, 4, 6, seed=800 + k, n_rows=store.N) for k in range(3)]
+    tapes = [vln.synthetic.tape_to(t, dev, store=store) for t in cpu]
+    outs = []
+    for via_put in (False, True):
+        live = vln.LiveBatch(tapes if not via_put else [tapes[0], tapes[0], tapes[0]], source="pull")
+        torch.manual_seed(78)
+        ag = vln.trainers.EnvDropILIteration(dev, dtype, 1, arena=True)
+        ag.use_live(live); ag.ride_gather = True; ag.clear_grads_in_step = True
+        ag.enc.deterministic_embedding_grad = True
+        ag.use_clock(store)
+        for k in range(2):
+            ag.iteration(live.load(0))
+        ag.capture(live.live)
+        rec = []
+        for k in (1, 2, 1):
+            if via_put:
+                live.put(k, tapes[k])                         # (device tensors: put() brings them to the host itself)
+            live.load(k)
+            loss = ag.replay()
+            torch.cuda.synchronize()
+            rec.append(loss.detach().clone())
+        outs.append(rec)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -668,6 +668,49 @@ def test_rollout_arena_replays_step_graphs_with_identical_results(vln):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_per_step_graphs_without_an_arena_equal_plain_launches(vln, dtype):
+    """Round 6: the reference's UNCHANGED caller (feature tensors handed in every step, per-step masked CE, torch's own allocator, no
+    arena, no iteration graph) gets its decoder steps replayed as hipGraphs too -- `EnvDropDecoder.step_graphs` is on by default; the
+    step's dropout offset then lives in a device word and the C call memoises its launch chain by argument block, which repeats once
+    the caching allocator has settled.  Same losses and gradients as plain launches, bit for bit, over six iterations (dropout on),
+    and the later iterations really replay."""
+    import ctypes
+    dev_ = torch.device(DEV)
+    cpu_tape = vln.synthetic.make_tape(16, 24, 3, 6, seed=16)
+    tape = vln.synthetic.tape_to(cpu_tape, dev_)                   # explicit img / cand tensors per step: the reference's marshalling
+    lib = vln._lib.load()
+    st0, st1 = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
+    res = []
+    for graphs in (False, True):
+        torch.manual_seed(23)
+        ag = vln.trainers.EnvDropILIteration(dev_, dtype, 1, arena=False, rollout_ce=False)
+        assert ag.dec.step_graphs is True                          # the module's default, arena or not
+        ag.dec.step_graphs = graphs
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        ag.opt.lr = 0.0
+        if graphs:
+            lib.vln_graph_stats(st0)
+        out = []
+        for _ in range(14):
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            # (host copies: a device clone kept per iteration would move every later allocation and no argument block could repeat)
+            out.append((loss.detach().cpu(), [p.grad.detach().cpu() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
+            del loss
+        if graphs:
+            lib.vln_graph_stats(st1)
+        res.append(out)
+    print(f"per-step graphs without an arena: {st1[0] - st0[0]} replays, {st1[1] - st0[1]} captures over 14 iterations of 3 steps")
+    assert st1[0] - st0[0] >= 3                                    # the allocator settles: later iterations replay steps
+    for (la, ga), (lb, gb) in zip(res[0], res[1]):
+        assert torch.equal(la, lb)
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+    assert vln.EnvDropDecoder(64, 0.5, 0.3, 16, 32, 128).step_graphs is True      # the module's own default
+
+
 def test_missing_library_fails_loudly(vln, monkeypatch):
     monkeypatch.setattr(vln._lib, "_lib", None)
     monkeypatch.setattr(vln._lib, "LIB_PATH", "/nonexistent/libvln_hip.so")
