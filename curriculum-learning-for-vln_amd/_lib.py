@@ -292,6 +292,9 @@ SIGNATURES = {
     "vln_lstm_sync_granule_range": (i32, [i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr, ptr]),
+    "vln_lstm_inproj_ok": (i32, [i32, i32, i32, i32, i32, ptr, i64]),
+    "vln_lstm_seq_fwd_x": (i32, [ptr, i32, ptr, ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64,
+                                 ptr, ptr]),
     "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),
     "vln_set_persistent": (i32, [i32]),
     "vln_persistent_check": (i32, []),

@@ -390,16 +390,24 @@ __global__ __launch_bounds__(512) void attn_textk_bwd_kernel(TextKArgs a, AttnSp
 
 // Whether the folded text attention covers this shape on this device (the four workgroups of every row co-resident, a part's
 // columns in one slice, the exchange buffer present and the four-workgroup path not switched off by a timeout or a tunable).
-bool attn_textk_ok(int ctype, int B, int S, int D, const void* sync, long sync_bytes) {
-  if (!sync || g_tunable[4] != 0 || !g_split_attn_enabled) return false;
+// CAPABLE: what the kernels need.  OK: capable AND chosen -- the switches (tunable[4], the four-workgroup path turned off by a timeout
+// report) decide which form a NEW rollout takes; a rollout that already runs on the projected context has no per-step query to fall
+// back to, so its launches only ask `capable` and finish the rollout on the kernels it started with (their waits stay bounded)
+// instead of failing its remaining forward steps and its whole backward.
+static bool attn_textk_capable(int ctype, int B, int S, int D, const void* sync, long sync_bytes) {
+  if (!sync) return false;
   if (ctype != W_BF16 && ctype != W_F32) return false;
   if (S <= 0 || S > kTextKSMax || D <= 0 || (D % 32) != 0 || D / kSplitNS > kTextKCols) return false;
   if (B * kSplitNS > device_cus() || sync_bytes < attn_split_sync_bytes(B) || !aligned16(sync)) return false;
   return sticky_dev_word() != nullptr;
 }
+bool attn_textk_ok(int ctype, int B, int S, int D, const void* sync, long sync_bytes) {
+  if (g_tunable[4] != 0 || !g_split_attn_enabled) return false;
+  return attn_textk_capable(ctype, B, S, D, sync, sync_bytes);
+}
 
 static int textk_launch(hipStream_t st, int ctype, const TextKArgs& a, int B, bool bwd, void* sync, long sync_bytes) {
-  if (!attn_textk_ok(ctype, B, a.S, a.D, sync, sync_bytes)) {
+  if (!attn_textk_capable(ctype, B, a.S, a.D, sync, sync_bytes)) {
     set_error("attn_textk: shape / device / exchange buffer not supported (B=%d S=%d D=%d)", B, a.S, a.D);
     return VLN_ERR_ARG;
   }

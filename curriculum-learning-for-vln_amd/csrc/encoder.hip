@@ -162,6 +162,10 @@ struct RecFwdArgs {
   int B, L, Hd, dirs, step, vec;
   int init;               // 1: the first time slot of hprev/cprev holds a caller-given initial state (else zeros)
   int nbb_per;            // persistent granule kernel: row blocks per PASS (0 = all of them in one pass), see persist_passes()
+  // in-kernel input projection (persistent granule kernel, round 6; x == nullptr: the gate inputs come from xproj):
+  const float* x;         // [L*B, kInprojE] time-major embedded inputs
+  const void* w_ih;       // [dirs*4Hd, kInprojE] in the recurrence's weight type
+  const float* bsum;      // [dirs*4Hd] b_ih + b_hh
 };
 
 template <typename TW>
@@ -893,24 +897,30 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
     lds_claim = kRideLdsClaim;
   }
   const GatherRolloutArgs& rd = ride ? *ride : no_ride;
-#define VLN_PERSIST_GF(NS_)                                                                                               \
+#define VLN_PERSIST_GF(NS_, XP_)                                                                                          \
   {                                                                                                                       \
-    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_>);                                  \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_, XP_>);                             \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
     if (lds_claim) {                                                                                                      \
-      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
+      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_, XP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, np, rd, \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_, XP_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, np, rd, \
                (ride ? fetch : FetchPart{}), (ride ? shadows : RideShadows{}));                                                   \
   }                                                                                                                       \
   break
-  switch (a.Hd / BK) {
-    case 2: VLN_PERSIST_GF(2);
-    case 4: VLN_PERSIST_GF(4);
-    case 8: VLN_PERSIST_GF(8);
-    case 16: VLN_PERSIST_GF(16);
-    default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
+  if (a.x) {       // the input projection inside the recurrence (inproj_ok: Hd 256 / 512, kInprojE input features)
+    if (a.Hd == 256) switch (a.Hd / BK) { case 4: VLN_PERSIST_GF(4, true); case 8: VLN_PERSIST_GF(8, true); default: break; }
+    else if (a.Hd == 512) switch (a.Hd / BK) { case 8: VLN_PERSIST_GF(8, true); case 16: VLN_PERSIST_GF(16, true); default: break; }
+    else { set_error("persistent lstm fwd: the in-kernel input projection takes Hd = 256 or 512"); return VLN_ERR_ARG; }
+  } else {
+    switch (a.Hd / BK) {
+      case 2: VLN_PERSIST_GF(2, false);
+      case 4: VLN_PERSIST_GF(4, false);
+      case 8: VLN_PERSIST_GF(8, false);
+      case 16: VLN_PERSIST_GF(16, false);
+      default: set_error("persistent lstm fwd: unsupported Hd"); return VLN_ERR_ARG;
+    }
   }
 #undef VLN_PERSIST_GF
   VLN_CHECK_LAUNCH("lstm_persist_g_fwd");
@@ -942,11 +952,42 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
   return VLN_OK;
 }
 
+// Whether vln_lstm_seq_fwd_x forms the input projection INSIDE the persistent recurrence for this shape on this device (round 6):
+// the granule-protocol forward launch, Hd 256 / 512, E = kInprojE input features.  tunable[13] = 5: never (A/B: the GEMM launch).
+static bool inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws) {
+  return g_tunable[13] != 5 && fwd_granules() && E == kInprojE && (Hd == 256 || Hd == 512) && persist_ok(B, L, Hd, dirs, sync_ws, true);
+}
+extern "C" int vln_lstm_inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws, int64_t sync_ws_bytes) {
+  return (inproj_ok(B, L, Hd, dirs, E, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(sync_ws)) ? 1 : 0;
+}
+static int lstm_seq_fwd_impl(const float* xproj, const float* x, const void* w_ih, const float* bsum, const void* w_hh, int wtype,
+                             const int32_t* lengths, float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat,
+                             int B, int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws, int64_t sync_ws_bytes,
+                             int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s);
 extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int32_t* lengths, float* hprev,
                                 float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat, int B,
                                 int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
                                 int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s) {
-  if (!xproj || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
+  return lstm_seq_fwd_impl(xproj, nullptr, nullptr, nullptr, w_hh, wtype, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs,
+                           h0, c0, sync_ws, sync_ws_bytes, device_seq, ride, s);
+}
+extern "C" int vln_lstm_seq_fwd_x(const float* x, int E, const void* w_ih, const float* bsum, const void* w_hh, int wtype,
+                                  const int32_t* lengths, float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
+                                  float* ccat, int B, int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
+                                  int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s) {
+  if (!x || !w_ih || !bsum || !al16(x) || !al16(w_ih)) { set_error("vln_lstm_seq_fwd_x: null or misaligned x / w_ih / bsum"); return VLN_ERR_ARG; }
+  if (!vln_lstm_inproj_ok(B, L, Hd, dirs, E, sync_ws, sync_ws_bytes)) {
+    set_error("vln_lstm_seq_fwd_x: this shape does not take the in-kernel input projection (ask vln_lstm_inproj_ok; B=%d L=%d Hd=%d E=%d)", B, L, Hd, E);
+    return VLN_ERR_ARG;
+  }
+  return lstm_seq_fwd_impl(nullptr, x, w_ih, bsum, w_hh, wtype, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, h0, c0,
+                           sync_ws, sync_ws_bytes, device_seq, ride, s);
+}
+static int lstm_seq_fwd_impl(const float* xproj, const float* x, const void* w_ih, const float* bsum, const void* w_hh, int wtype,
+                             const int32_t* lengths, float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat, float* ccat,
+                             int B, int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws, int64_t sync_ws_bytes,
+                             int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s) {
+  if ((!xproj && !x) || !w_hh || !lengths || !hprev || !cprev || !y_tm || !act || !tanh_c || !hcat || !ccat || B <= 0 ||
       L <= 0 || Hd <= 0 || dirs < 1 || dirs > 2) { set_error("vln_lstm_seq_fwd: bad args"); return VLN_ERR_ARG; }
   if (persist_ok(B, L, Hd, dirs, sync_ws, fwd_granules()) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(w_hh) && al16(hprev) &&
       al16(sync_ws)) {
@@ -959,7 +1000,8 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     const int init = (h0 || c0) ? 1 : 0;
     if (init) { r = seed_initial_state(st, h0, c0, hprev, cprev, B, L, Hd, dirs); if (r) return r; }
     const int nbbp = persist_passes(B, Hd, dirs, fwd_granules());       // row blocks per pass (persist_ok: > 0)
-    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init, nbbp < (B + 15) / 16 ? nbbp : 0};
+    RecFwdArgs a{xproj, w_hh, lengths, hprev, cprev, y_tm, act, tanh_c, hcat, ccat, B, L, Hd, dirs, 0, 1, init, nbbp < (B + 15) / 16 ? nbbp : 0,
+                 x, w_ih, bsum};
     dim3 grid(Hd / 16, dirs, nbbp);
     unsigned* cw = (unsigned*)sync_ws;
     // algorithmic bytes of the whole sequence: W_hh ONCE (register-resident), per step state/xproj/outputs
@@ -1006,6 +1048,7 @@ extern "C" int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype,
     if (!fwd_granules()) header_mark(sync_ws, false);       // the counter-protocol forward leaves its counters behind
     return r;
   }
+  if (!xproj) { set_error("vln_lstm_seq_fwd_x: the persistent path was refused after vln_lstm_inproj_ok said yes (mode switched?)"); return VLN_ERR_ARG; }
   if (ride) {
     int rr = gather_ride_launch((hipStream_t)s, *ride); if (rr) return rr;
     FetchPart fetch{};

@@ -71,7 +71,14 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 // ---------------------------------------------------------------------------------------------------------
 // forward: NS = Hd / BK.  Exchange layout: [group][parity][row 16][unit HD] granules.
 // ---------------------------------------------------------------------------------------------------------
-template <typename TW, int NS>
+// XP (round 6): the INPUT PROJECTION x_t W_ih^T + (b_ih + b_hh) of the step is formed INSIDE the recurrence (E = kInprojE input features)
+// instead of by a GEMM launch over all L * B rows in front of it: a workgroup's share -- its 16 rows x (4 gates x 16 units) -- does not
+// depend on h, its W_ih rows stay in registers next to the W_hh fragments, the x tile is prefetched one step ahead, and the MFMAs run
+// BEFORE the step's wait for its neighbours' granules (a workgroup idles ~1 us of every 2.1 us step there).  The projection launch
+// (31.8 us at B 64 / L 80) and the 42 MB it wrote and the recurrence re-read leave the iteration.  Same MFMA sequence as gemm_nt's
+// (K-steps in order, lo x w before hi x w, bias added to the finished sum): bit-identical gate pre-activations.
+constexpr int kInprojE = 256;
+template <typename TW, int NS, bool XP>
 __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
                                                                  int nrec, int np_, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
@@ -132,6 +139,22 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
 
   const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
   const int j = j0 + jl;
+  // in-kernel input projection: this wave's 16 gate columns of W_ih (all kInprojE input features) in registers, the x tile in LDS
+  constexpr int NSX = XP ? kInprojE / RecCfg<TW>::BK : 1;
+  constexpr int LDXH = kInprojE + 4, LDXP = kInprojE + 8;
+  constexpr int kXTileBytes = XP ? (kPlanes ? 2 * 16 * LDXP * 2 : 16 * LDXH * 4) : 16;
+  __shared__ __attribute__((aligned(16))) unsigned char xtile_raw[kXTileBytes];
+  __shared__ float sgx[XP ? 4 : 1][16][17];
+  float* const xsh = reinterpret_cast<float*>(xtile_raw);
+  bf16_raw* const xph = reinterpret_cast<bf16_raw*>(xtile_raw);
+  bf16_raw* const xpl = xph + 16 * LDXP;
+  WFrag<TW, NSX> wx;
+  float bx_i = 0.f, bx_f = 0.f, bx_g = 0.f, bx_o = 0.f;
+  if constexpr (XP) {
+    load_wfrag<TW, NSX>(wx, reinterpret_cast<const TW*>(a.w_ih) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * kInprojE, fq);
+    const float* bp = a.bsum + (long)d * 4 * HD + j;
+    bx_i = bp[0]; bx_f = bp[HD]; bx_g = bp[2 * HD]; bx_o = bp[3 * HD];
+  }
   for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
   const bool first_pass = bb == ix0.bb;
   if (!first_pass) __syncthreads();            // the tile / gate buffers of the previous pass are free
@@ -171,27 +194,72 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   }
   __syncthreads();
 
+  // XP: the x tile of a time step = rows (t * B + b0 .. + 15) x kInprojE floats of the embedded (dropped) inputs: thread -> 4 float4
+  // Prefetch distance TWO steps, requested right AFTER a step's wait for the granules has ended: vector-memory loads return in order,
+  // so a tile request still in flight when the wait's sweep is issued would hold the sweep's loads behind its ~1.5 us first-touch
+  // latency (measured: the launch then gains per step what the projection launch saved).
+  float4 xr[XP ? 4 : 1], xr2[XP ? 4 : 1];
+  auto load_xtile = [&](float4 (&dst)[XP ? 4 : 1], int step_) {
+    const int t_ = (d == 0) ? step_ : (L - 1 - step_);
+#pragma unroll
+    for (int u = 0; u < (XP ? 4 : 1); ++u) {
+      const int unit = threadIdx.x + u * 256;
+      const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
+      const int br = min(b0 + r, B - 1);                   // rows past the batch: any valid row (their results are never used)
+      dst[u] = *reinterpret_cast<const float4*>(a.x + ((long)t_ * B + br) * kInprojE + c4 * 4);
+    }
+  };
+  if constexpr (XP) { load_xtile(xr, 0); if (L > 1) load_xtile(xr2, 1); }
   for (int step = 0; step < L; ++step) {
     const int t = (d == 0) ? step : (L - 1 - step);
     const long sbase = ((long)d * L + t) * B;
     const long row = (long)t * B + (live ? b : 0);
     float xi = 0.f, xf = 0.f, xg = 0.f, xo = 0.f;
-    if (live) {   // plain loads: written by the projection GEMM before this launch
-      const float* xp = a.xproj + row * G + (long)d * 4 * HD + j;
-      xi = xp[0]; xf = xp[HD]; xg = xp[2 * HD]; xo = xp[3 * HD];
+    if constexpr (!XP) {
+      if (live) {   // plain loads: written by the projection GEMM before this launch
+        const float* xp = a.xproj + row * G + (long)d * 4 * HD + j;
+        xi = xp[0]; xf = xp[HD]; xg = xp[2 * HD]; xo = xp[3 * HD];
+      }
     }
     VLN_STAMP(0);
+    // sweep this thread's NLD x 2 granules of the group's h tile (time t), published in step - 1.  The FIRST sweep's loads are issued
+    // here and checked below: with XP the step's input projection runs while they are in flight (the hand-off is one load round trip --
+    // a wave that computes first and sweeps afterwards pays the projection in full: measured +0.36 us per step).
+    const unsigned expect = tag_base + (unsigned)step;
+    const unsigned pbase = gbase + (unsigned)((step - 1) & 1) * (16u * HD * 8u);
+    u32x4_t v[NLD];
     if (step > 0) {
-      // sweep this thread's NLD x 2 granules of the group's h tile (time t), published in step - 1
-      const unsigned expect = tag_base + (unsigned)step;
-      const unsigned pbase = gbase + (unsigned)((step - 1) & 1) * (16u * HD * 8u);
-      u32x4_t v[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xres, pbase + (unsigned)(threadIdx.x + u * 256) * 16u, 0, 16);
+    }
+    if constexpr (XP) {
+      // this step's x tile (prefetched) -> LDS, the next step's requested, then the projection's MFMAs: all of it BEFORE the wait for
+      // the neighbours' granules.  (The tile buffers were last read two barriers ago: the previous step's h-tile and gate barriers.)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int unit = threadIdx.x + u * 256;
+        const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
+        if constexpr (kPlanes) {
+          split_store2(xph + r * LDXP + c4 * 4, xpl + r * LDXP + c4 * 4, xr[u].x, xr[u].y);
+          split_store2(xph + r * LDXP + c4 * 4 + 2, xpl + r * LDXP + c4 * 4 + 2, xr[u].z, xr[u].w);
+        } else {
+          *reinterpret_cast<float4*>(&xsh[r * LDXH + c4 * 4]) = xr[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xr[u] = xr2[u];                            // step + 1's tile (requested a step ago)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier: requests in flight stay in flight
+      f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (kPlanes) mfma_resident_planes<NSX>(xph + fi * LDXP, xpl + fi * LDXP, wx, fq, ax);
+      else mfma_resident<TW, NSX>(&xsh[fi * LDXH], wx, fq, ax);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sgx[wave][fq * 4 + r][fi] = ax[r];       // read after the h-tile barrier below
+    }
+    if (step > 0) {
       unsigned spins = 0;
       const bool dead = s_abort != 0;
       for (;;) {
         bool ok = true;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xres, pbase + (unsigned)(threadIdx.x + u * 256) * 16u, 0, 16);
 #pragma unroll
         for (int u = 0; u < NLD; ++u) ok = ok && (v[u].y == expect) && (v[u].w == expect);
         if (__all(ok) || dead) break;
@@ -200,6 +268,8 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
           if (lane == 0) gran_timeout(status, sticky, &s_abort);
           break;
         }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xres, pbase + (unsigned)(threadIdx.x + u * 256) * 16u, 0, 16);
       }
       VLN_STAMP(1);
       if (step == 1 && (xcd_map & 2)) {            // every member's XCC_ID bit is in: each ORed it before the granules just seen
@@ -234,7 +304,9 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       VLN_STAMP(1);
       for (int i = threadIdx.x; i < kTileBytes / 4; i += 256) reinterpret_cast<uint32_t*>(tile_raw)[i] = 0u;
     }
-    __syncthreads();
+    if constexpr (XP) { if (step + 2 < L) load_xtile(xr2, step + 2); }      // behind the sweep: nothing waits for it before the next step's top
+    if constexpr (XP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS-only: a __syncthreads() would drain the request just made)
+    else __syncthreads();
     VLN_STAMP(2);
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -247,6 +319,9 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
     VLN_STAMP(3);
     float si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, yv = 0.f, c_in = creg, hs = 0.f, cs = 0.f;
     if (live) {
+      if constexpr (XP) {      // the projection's finished sums + bias: what the GEMM's epilogue stored into xproj
+        xi = sgx[0][bl][jl] + bx_i; xf = sgx[1][bl][jl] + bx_f; xg = sgx[2][bl][jl] + bx_g; xo = sgx[3][bl][jl] + bx_o;
+      }
       const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf, pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
       const bool valid = t < len;
       const LstmCellPw cw = lstm_cell_pw(pi, pf, pg, po, creg);

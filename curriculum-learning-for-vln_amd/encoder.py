@@ -61,7 +61,13 @@ class _EncoderFn(torch.autograd.Function):
         saved = []
         p_inter = p_drop if nl > 1 else 0.0
         for k in range(nl):
-            xproj = ops.linear_fwd(x, sh[f"w_ih{k}"], sh[f"bsum{k}"])
+            sync_p, sync_n = mod._sync_ws(dev, B, Hd, dirs)
+            w_ih_k = sh[f"w_ih{k}"]
+            # round 6: the input projection inside the persistent recurrence launch where the library takes it (Hd 256 / 512, 256 input
+            # features, the granule-protocol launch): no projection GEMM, no [L*B, dirs*4Hd] intermediate written and re-read
+            inproj = bool(mod.inproj and x.is_contiguous() and w_ih_k.is_contiguous() and
+                          lib.vln_lstm_inproj_ok(B, L, Hd, dirs, x.shape[1], sync_p, sync_n))
+            xproj = None if inproj else ops.linear_fwd(x, w_ih_k, sh[f"bsum{k}"])
             hprev = ops.empty(dirs, L, B, Hd, **f32)
             cprev = ops.empty(dirs, L, B, Hd, **f32)
             y = ops.empty(L * B, dirs * Hd, **f32)
@@ -69,10 +75,15 @@ class _EncoderFn(torch.autograd.Function):
             tanh_c = ops.empty(L * B, dirs * Hd, **f32)
             hcat = ops.empty(B, dirs * Hd, **f32)
             ccat = ops.empty(B, dirs * Hd, **f32)
-            _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
-                                            _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
-                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq,
-                                            C.byref(ride.struct) if (ride is not None and k == nl - 1) else None, _stream()), "vln_lstm_seq_fwd")
+            ride_p = C.byref(ride.struct) if (ride is not None and k == nl - 1) else None
+            if inproj:
+                _lib.check(lib.vln_lstm_seq_fwd_x(_p(x), x.shape[1], _p(w_ih_k), _p(sh[f"bsum{k}"]), _p(sh[f"w_hh{k}"]), wtype, _p(lens32),
+                                                  _p(hprev), _p(cprev), _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
+                                                  sync_p, sync_n, offset.seq, ride_p, _stream()), "vln_lstm_seq_fwd_x")
+            else:
+                _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh[f"w_hh{k}"]), wtype, _p(lens32), _p(hprev), _p(cprev),
+                                                _p(y), _p(act), _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, None, None,
+                                                sync_p, sync_n, offset.seq, ride_p, _stream()), "vln_lstm_seq_fwd")
             saved.append((x, hprev, cprev, act, tanh_c))
             if k < nl - 1:
                 if p_inter > 0:
@@ -310,6 +321,11 @@ class EncoderLSTM(nn.Module):
         self.dx_with_wgrads = True
         # True: the context's layout changes ride in the launches of the encoder -> decoder bridge's products (vln_layout_post)
         self.layout_with_bridge = True
+        # (A/B, off: measured neutral) the input projection formed INSIDE the persistent forward recurrence (vln_lstm_seq_fwd_x): the
+        # projection launch (32 us) and the 84 MB it writes / the recurrence re-reads disappear, bit-identical results -- but the
+        # recurrence launch grows by 0.45 us per time step (172 -> 210 us at L 80): its hand-off wait is a load round trip the wave
+        # itself issues, not idle time the projection's MFMAs could fill (profiles/round6_notes.md)
+        self.inproj = False
         self._calls = 0
         self._shadow = ShadowSet()
         self._param_names = [n for n, _ in self.named_parameters()]

@@ -175,6 +175,7 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
     # of BASELINE config 1 is within north_star's 1e-2 (tests/test_hip_modules.py::test_envdrop_full_size_bf16).  `frozenset()`
     # = every matrix bf16 (round 3's default; bench.py secondary `all_bf16_weights_ms_per_step`).
     default_step_graphs = True       # decoder steps as hipGraphs by default (see __init__)
+    IN_STEP_SAMPLER_MAX_C = 64       # candidates per row the sampled branch takes (cand_logits_sample, vln_categorical_fwd: one wavefront)
     default_fp32_weights = frozenset({"w_vin", "w_tin"})
 
     def __init__(self, hidden_size, drop_ratio, feat_drop_ratio, action_embed_size: int = 64,
@@ -641,6 +642,15 @@ class EnvDropDecoder(nn.Module, GatedModuleMixin):
         draw + log-prob + entropy; vln_envdrop_step.s_*) and the step is recorded in the sampler as `sampler.step(logit, cand_mask,
         action)` would record it; the drawn action is `sampler.keep[-1][1]` and -- with `action_host_address`, the device-visible
         address of B int64 words of PINNED host memory -- also lands there without a copy launch (the host polls it)."""
+        if sampler is not None:
+            cm = sampler[1]
+            Cn_ = cm.shape[1] if cm is not None else (gather[3].shape[1] if gather is not None else cand_feature.shape[1])
+            if Cn_ > self.IN_STEP_SAMPLER_MAX_C:
+                # both forms of the sampled branch (this step's in-launch draw and losses.RolloutSampler.step / vln_categorical_fwd) hold a
+                # row's candidates in one wavefront; R2R's panoramas have at most ~15 navigable candidates.  Say so here, before any launch
+                # of the step has gone out, instead of failing in the step's last launch (ADVICE r5).
+                raise ValueError(f"EnvDropDecoder: the sampled-action branch takes at most {self.IN_STEP_SAMPLER_MAX_C} candidates per row, "
+                                 f"got a batch padded to {Cn_}")
         self.__dict__["_sampler_arg"] = sampler          # (plain dict stores: nn.Module.__setattr__ costs microseconds per step)
         if gather is not None:
             if img_feature is not None or cand_feature is not None or already_dropfeat:

@@ -711,6 +711,17 @@ int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int3
                      const vln_gather_ride* ride /* nullable: a rollout's feature gather done by this call -- as passenger
                      workgroups of the persistent launch when that path is taken (T <= 12), else as its own launch first */,
                      vln_stream_t s);
+/* The same forward recurrence with the INPUT PROJECTION formed inside the persistent launch (ABI v18, round 6): instead of xproj =
+ * x W_ih^T + (b_ih + b_hh) from a GEMM launch over all L * B rows, the call takes x [L*B, E] (time-major, fp32), w_ih [dirs*4Hd, E] in
+ * the recurrence's weight type and bsum [dirs*4Hd]; every recurrence workgroup forms its 16 rows x 64 gate columns per step from
+ * register-resident W_ih rows before it waits for its neighbours' hidden state.  Same MFMA sequence as vln_linear_fwd: bit-identical
+ * results.  Only where vln_lstm_inproj_ok(...) returns 1 (the granule-protocol persistent launch, Hd 256 / 512, E = 256); elsewhere
+ * the caller forms xproj itself and calls vln_lstm_seq_fwd. */
+int vln_lstm_inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws, int64_t sync_ws_bytes);
+int vln_lstm_seq_fwd_x(const float* x, int E, const void* w_ih, const float* bsum, const void* w_hh, int wtype,
+                       const int32_t* lengths, float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
+                       float* ccat, int B, int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
+                       int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = persistent kernels, granule hand-off forward, counter
                                    * hand-off backward; 2 = counter both ways (round 1); 3 = granules both ways; identical results */
 /* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the

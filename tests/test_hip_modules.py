@@ -353,14 +353,17 @@ def _encoder_full(vln, compute_dtype):
             check(prm.grad, P[n].grad, _tol_for(exc, tol, f"grad[{n}]"), f"{name}: grad[{n}]", floor=grad_floor(n, gmax))
 
 
-@pytest.mark.parametrize("dtype,B", [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 144), (torch.float32, 192), (torch.bfloat16, 256)])
+@pytest.mark.parametrize("dtype,B,inproj", [(torch.float32, 64, False), (torch.bfloat16, 64, False), (torch.bfloat16, 144, False),
+                                            (torch.float32, 192, False), (torch.bfloat16, 256, False),
+                                            (torch.bfloat16, 64, True), (torch.float32, 64, True), (torch.bfloat16, 144, True)])
 @pytest.mark.usefixtures("split_wgrads")
-def test_persistent_recurrence_equals_per_step_launches(vln, dtype, B):
+def test_persistent_recurrence_equals_per_step_launches(vln, dtype, B, inproj):
     """The single-launch persistent bi-LSTM (in-kernel cross-workgroup hand-off) must reproduce the per-step
     launch chain bit for bit, forward and backward, and report a clean status word.  B > 128 (round 6): the
     one-workgroup-per-(slice, direction, 16 rows) grid no longer fits the 256 CUs, and the launch runs in PASSES -- 144 rows = 9 row
     blocks -> 2 passes of 5 (the last pass one block short), 192 -> 2 x 6, 256 -> 2 x 8 -- instead of falling back to 2 x L per-step
-    launches (encoder.hip: persist_passes)."""
+    launches (encoder.hip: persist_passes).  inproj (round 6, an A/B option: EncoderLSTM.inproj): the persistent launch forms the input
+    projection x_t W_ih^T + b itself, in gemm_nt's MFMA order -- still bit-identical to the chain that reads the GEMM's output."""
     lib = vln._lib.load()
     L, E, H, vocab = 80, 256, 512, 992
     g = torch.Generator().manual_seed(3)
@@ -371,6 +374,7 @@ def test_persistent_recurrence_equals_per_step_launches(vln, dtype, B):
         tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
     r = torch.randn(B, L, H, generator=g).to(DEV)
     outs = []
+    enc.inproj = inproj
     for persistent in (1, 0):
         lib.vln_set_persistent(persistent)
         enc._calls = 0                                  # same dropout stream for both runs
@@ -709,6 +713,44 @@ def test_per_step_graphs_without_an_arena_equal_plain_launches(vln, dtype):
         for a, b in zip(ga, gb):
             assert torch.equal(a, b)
     assert vln.EnvDropDecoder(64, 0.5, 0.3, 16, 32, 128).step_graphs is True      # the module's own default
+
+
+def test_a_rollout_on_the_projected_context_survives_the_split_attention_being_switched_off(vln):
+    """the projected-context (kctx) form is chosen once per rollout; if the four-workgroup attention is switched off in the
+    middle of it (what a timeout report does: vln_persistent_check -> g_split_attn_enabled = 0), the remaining forward steps and the
+    whole backward still run on the kernels the rollout started with -- they have no per-step query to fall back to -- instead of
+    failing with VLN_ERR_ARG; the NEXT rollout takes the per-step query form.  Loss and gradients agree with the undisturbed run."""
+    dev_ = torch.device(DEV)
+    lib = vln._lib.load()
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 4, 6, seed=26), dev_, store_dtype=torch.bfloat16)
+    res = []
+    for disturb in (False, True):
+        torch.manual_seed(29)
+        ag = vln.trainers.EnvDropILIteration(dev_, torch.bfloat16, 1, arena=True)
+        ag.enc._calls = 0; ag.dec._step_counter = 0
+        ag.enc.deterministic_embedding_grad = True
+        tape["store"]._calls = 0
+        ag.opt.lr = 0.0
+        assert ag.dec.project_context
+        fwd, calls = ag.dec.forward, [0]
+
+        def spy(*a, **k):
+            calls[0] += 1
+            if disturb and calls[0] == 2:              # after the rollout's first step went out in K mode
+                lib.vln_set_split_attention(0)
+            return fwd(*a, **k)
+        ag.dec.forward = spy
+        try:
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            assert ag.dec.last_projected
+        finally:
+            lib.vln_set_split_attention(1)
+        res.append((loss.detach().clone(), [p.grad.detach().clone() for p in list(ag.dec.parameters()) + list(ag.enc.parameters())]))
+    # (the panorama attention DOES have a one-workgroup form and takes it from the switch on: same numbers in another summation order)
+    check(res[1][0], res[0][0], 1e-4, "loss with the split attention switched off mid-rollout")
+    for i, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        check(b, a, 2e-3, f"gradient {i} with the split attention switched off mid-rollout")
 
 
 def test_missing_library_fails_loudly(vln, monkeypatch):
@@ -1178,17 +1220,18 @@ def test_envdrop_full_size_bf16_split_weight_gradients(vln):
     _full_size_envdrop(vln, torch.bfloat16)
 
 
-@pytest.mark.parametrize("given_actions", [False, True])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_in_step_sampler_and_chained_backward_equal_the_separate_launches(vln, dtype, given_actions):
+@pytest.mark.parametrize("dtype,given_actions,C", [(torch.float32, False, 7), (torch.float32, True, 7), (torch.bfloat16, False, 7),
+                                                   (torch.bfloat16, True, 7)])
+def test_in_step_sampler_and_chained_backward_equal_the_separate_launches(vln, dtype, given_actions, C):
     """Round 5, sampled rollouts (envdrop.py:173,186-206): `forward(sampler=...)` runs mask + softmax + draw + log-prob + entropy
     inside the step's logits launch and stores the action into host-mapped pinned words itself (vln_envdrop_step.s_*), and
     `chain_backward` lets step t's act-embedding / h_tilde_prev backward stage ride in step t - 1's first backward launch
     (chain == 2).  Same arithmetic in the same order as `RolloutSampler.step` + a D2H copy and the unchained backward: logits,
-    actions (device AND host words), log-probs, entropies, the loss and every gradient are equal bit for bit."""
+    actions (device AND host words), log-probs, entropies, the loss and every gradient are equal bit for bit.  (More than 64
+    candidates per row -- R2R has at most ~15 -- are refused by `forward(sampler=...)` before any launch: ADVICE r5.)"""
     import ctypes as C_
     dev = torch.device(DEV)
-    B, L, V, C, H, IMG, ANG, AE, T = 16, 20, 36, 7, 64, 96, 32, 16, 5
+    B, L, V, H, IMG, ANG, AE, T = 16, 20, 36, 64, 96, 32, 16, 5
     F = IMG + ANG
 
     def rollout(in_step):
@@ -1226,6 +1269,11 @@ def test_in_step_sampler_and_chained_backward_equal_the_separate_launches(vln, d
         return dict(logits=logits, acts=acts, host=a_host.clone(), logp=logp.detach().clone(), ent=ent.detach().clone(), loss=loss.detach().clone(),
                     grads=[ctx.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
 
+    wide = vln.EnvDropDecoder(H, 0.5, 0.3, AE, ANG, F, compute_dtype=dtype).to(dev).train()
+    with pytest.raises(ValueError, match="at most 64 candidates"):
+        wide(torch.zeros(B, ANG, device=dev), torch.zeros(B, V, F, device=dev), torch.zeros(B, 70, F, device=dev), torch.zeros(B, H, device=dev),
+             torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, L, H, device=dev), None,
+             sampler=(vln.losses.RolloutSampler(seed=1), torch.zeros(B, 70, dtype=torch.bool, device=dev), None, 0))
     # the draws take their Philox offsets from a global call counter: both rollouts start from the same value
     start = vln.losses._sample_calls[0]
     ref = rollout(False)
