@@ -3,7 +3,7 @@
 [gfx950 wide-read correction] + WRITE_SIZE x 1 KiB, MI355X_MICROARCH.md HBM section), L2 hit rate (TCC_HIT_sum / (TCC_HIT_sum +
 TCC_MISS_sum)), against the ALGORITHMIC bytes of the product (weights once + X + the split-K slabs it writes) and its duration.
 
-    python scripts/pmc_by_shape.py <FETCH_SIZE dir> <WRITE_SIZE dir> <TCC dir> > profiles/round5_gemm_nt_by_shape.txt
+    python scripts/pmc_by_shape.py <FETCH_SIZE dir> <WRITE_SIZE dir> <TCC dir> > profiles/round6_gemm_nt_by_shape.txt
 
 A launch is identified by (weight type of the kernel template, grid size in threads); the EnvDrop headline's shapes are named below
 (B = 64, H = 512, F = 2176, AE = 64, L = 80).  Shapes with the same workgroup count and weight type share a row."""
@@ -24,6 +24,8 @@ SHAPES = {
     (8 * 64): [("projected context K = ctx W_in on 80-row tiles (gemm_rows.h, round 5): H -> H, M = L*B", 5120, 512, 512)],
     (8 * 10): [("the rollout's text queries W_in hd_t on 48-row tiles (gemm_rows.h): H -> H, M = T*B (round 5)", 448, 512, 512)],
     (8 * 7): [("the rollout's text queries W_in hd_t for the context gradient: H -> H, M = T*B (round 5)", 448, 512, 512)],
+    104: [("the rollout's text queries W_in hd_t on gemm_rows<3> tiles (vln_gemm_rows_tiling(448, 512) = 104 tiles): H -> H, M = T*B", 448, 512, 512)],
+    (4 * 64): [("d embedding rows on gemm_rows<5> tiles: 4Hd*2 -> E, M = L*B", 5120, 256, 2048)],
 }
 
 
@@ -55,7 +57,10 @@ for key in sorted(set(fetch) | set(write), key=lambda k: (k[1], k[0])):
     nf, nw = max(f[1], 1), max(w[1], 1)
     fb = f[0] / nf * 1024 * 2.0; wb = w[0] / nw * 1024
     dur = fetch[key]["_dur"]; us = dur[0] / max(dur[1], 1)
-    names = SHAPES.get(key[1], [("?", 0, 0, 0)])
+    names = SHAPES.get(key[1])
+    if names is None:          # a launch shape this table does not know: reported as such, never priced against 0 algorithmic bytes
+        print(f"{key[0]:7s} {key[1]:5d} {f[1]:8d} {us:12.2f} {fb / 1e6:9.2f} {wb / 1e6:9.2f} {(fb + wb) / 1e6:10.2f} {'n/a':>8s} {'n/a':>6s} {'':>7s}  (launch shape not in scripts/pmc_by_shape.py::SHAPES)")
+        continue
     ws = 2 if key[0] == "bf16" else 4
     algo = []
     for what, M, N, K in names:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merge the rocprofv3 --pmc passes of `bench.py` into profiles/round5_pmc.json, stamped with the hash of the kernel sources they
+"""Merge the rocprofv3 --pmc passes of `bench.py` into profiles/round6_pmc.json, stamped with the hash of the kernel sources they
 were taken on (bench.py refuses the figures when the sources have changed since):
 
     python scripts/pmc_stamp.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <MFMA pass counter_collection.csv> [dtype]
@@ -24,6 +24,6 @@ util = {}
 for k, v in mf.items():
     util.setdefault(names.get(k, k), v["mfma_util"])
 out = {"csrc_sha": bench.csrc_sha(), "traffic": traffic, "mfma_util": {dtype: util}, "mfma_detail": mf}
-path = os.path.join(ROOT, "profiles", "round5_pmc.json")
+path = os.path.join(ROOT, "profiles", "round6_pmc.json")
 json.dump(out, open(path, "w"), indent=1)
 print(f"wrote {path} for kernel sources {out['csrc_sha']}")

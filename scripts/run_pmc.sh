@@ -13,6 +13,6 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/MFMA -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/mfma.err
 python3 scripts/rocpd_stats.py $(ls $OUT/trace/*results.db | head -1) --iters 112 --shapes gemm_nt attn_fused --csv $OUT/kernel_stats.csv > $OUT/stats.txt
 python3 scripts/pmc_stamp.py $OUT/FETCH_SIZE $OUT/WRITE_SIZE $(ls $OUT/MFMA/*counter_collection.csv $OUT/MFMA/*/*counter_collection.csv 2>/dev/null | head -1) bf16
-cp profiles/round5_pmc.json $OUT/round5_pmc.json
+cp profiles/round6_pmc.json $OUT/round6_pmc.json
 python3 scripts/pmc_by_shape.py $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/TCC > $OUT/gemm_nt_by_shape.txt 2>&1
 head -30 $OUT/stats.txt
