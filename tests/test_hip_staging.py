@@ -430,7 +430,8 @@ def test_rollout_sampler_long_rollout_chunks(vln):
             s.step(steps[0][0].to(DEV))
 
 
-@pytest.mark.parametrize("variant", ["pipelined", "both_outputs", "thirteen_steps", "per_step_recurrence", "batch128_no_idle_cus"])
+@pytest.mark.parametrize("variant", ["pipelined", "both_outputs", "thirteen_steps", "per_step_recurrence", "batch128_no_idle_cus",
+                                     "batch144_two_passes_with_passengers"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, dtype, variant):
     """EncoderLSTM.forward(ride=store.rollout_ride(...)): the rollout's feature rows gathered by PASSENGER workgroups of the
@@ -446,7 +447,8 @@ def test_gather_riding_in_the_recurrence_launch_equals_the_rollout_gather(vln, d
     lib = vln._lib.load()
     torch.manual_seed(11)
     T = 13 if variant == "thirteen_steps" else 7
-    cpu_tape = vln.synthetic.make_tape(128 if variant == "batch128_no_idle_cus" else 64, 80, T, 8, seed=77)
+    # (B = 144, round 6: 9 row blocks -> the recurrence runs in two passes of 5 row blocks, 160 workgroups, and STILL carries passengers)
+    cpu_tape = vln.synthetic.make_tape({"batch128_no_idle_cus": 128, "batch144_two_passes_with_passengers": 144}.get(variant, 64), 80, T, 8, seed=77)
     cpu_tape["table"] = cpu_tape["table"].bfloat16().float()
     tape = vln.synthetic.tape_to(cpu_tape, dev_, store_dtype=dtype)
     store = tape["store"]
