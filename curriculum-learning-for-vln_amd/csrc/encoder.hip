@@ -589,9 +589,9 @@ int vln::device_cus() {
   return cus[dev] > 0 ? cus[dev] : 0;
 }
 template <typename K>
-static bool kernel_fits_one_per_cu(K kernel) {      // the occupancy API's answer for this instantiation, cached by the caller
+static bool kernel_fits_one_per_cu(K kernel, int threads = 256) {      // the occupancy API's answer for this instantiation, cached by the caller
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
   return n >= 1;
 }
 
@@ -899,20 +899,20 @@ static int launch_persist_g_fwd(hipStream_t st, const RecFwdArgs& a, unsigned* s
   const GatherRolloutArgs& rd = ride ? *ride : no_ride;
 #define VLN_PERSIST_GF(NS_, XP_)                                                                                          \
   {                                                                                                                       \
-    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_, XP_>);                             \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_g_fwd_kernel<TW, NS_, XP_>, XP_ ? 512 : 256);            \
     if (!fits) { set_error("persistent lstm fwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
     if (lds_claim) {                                                                                                      \
       static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_g_fwd_kernel<TW, NS_, XP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm fwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_, XP_>), g1, dim3(256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, np, rd, \
+    VLN_LAUNCH((lstm_persist_g_fwd_kernel<TW, NS_, XP_>), g1, dim3(XP_ ? 512 : 256), lds_claim, st, a, status, sticky, exch, tag_base, xm, seq_dev, seq_rel, nrec, np, rd, \
                (ride ? fetch : FetchPart{}), (ride ? shadows : RideShadows{}));                                                   \
   }                                                                                                                       \
   break
   if (a.x) {       // the input projection inside the recurrence (inproj_ok: Hd 256 / 512, kInprojE input features)
-    if (a.Hd == 256) switch (a.Hd / BK) { case 4: VLN_PERSIST_GF(4, true); case 8: VLN_PERSIST_GF(8, true); default: break; }
-    else if (a.Hd == 512) switch (a.Hd / BK) { case 8: VLN_PERSIST_GF(8, true); case 16: VLN_PERSIST_GF(16, true); default: break; }
-    else { set_error("persistent lstm fwd: the in-kernel input projection takes Hd = 256 or 512"); return VLN_ERR_ARG; }
+    // (Hd = 256 only: at 512 the two wave groups' 256-register budget spills -- 29 VGPRs in bf16, 124 in fp32)
+    if (a.Hd != 256) { set_error("persistent lstm fwd: the in-kernel input projection takes Hd = 256"); return VLN_ERR_ARG; }
+    switch (0) { default: VLN_PERSIST_GF(256 / BK, true); }
   } else {
     switch (a.Hd / BK) {
       case 2: VLN_PERSIST_GF(2, false);
@@ -953,9 +953,9 @@ static int launch_persist_g_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* s
 }
 
 // Whether vln_lstm_seq_fwd_x forms the input projection INSIDE the persistent recurrence for this shape on this device (round 6):
-// the granule-protocol forward launch, Hd 256 / 512, E = kInprojE input features.  tunable[13] = 5: never (A/B: the GEMM launch).
+// the granule-protocol forward launch, Hd 256, E = kInprojE input features.  tunable[13] = 5: never (A/B: the GEMM launch).
 static bool inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws) {
-  return g_tunable[13] != 5 && fwd_granules() && E == kInprojE && (Hd == 256 || Hd == 512) && persist_ok(B, L, Hd, dirs, sync_ws, true);
+  return g_tunable[13] != 5 && fwd_granules() && E == kInprojE && Hd == 256 && persist_ok(B, L, Hd, dirs, sync_ws, true);
 }
 extern "C" int vln_lstm_inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws, int64_t sync_ws_bytes) {
   return (inproj_ok(B, L, Hd, dirs, E, sync_ws) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(sync_ws)) ? 1 : 0;

@@ -71,15 +71,29 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 // ---------------------------------------------------------------------------------------------------------
 // forward: NS = Hd / BK.  Exchange layout: [group][parity][row 16][unit HD] granules.
 // ---------------------------------------------------------------------------------------------------------
-// XP (round 6): the INPUT PROJECTION x_t W_ih^T + (b_ih + b_hh) of the step is formed INSIDE the recurrence (E = kInprojE input features)
-// instead of by a GEMM launch over all L * B rows in front of it: a workgroup's share -- its 16 rows x (4 gates x 16 units) -- does not
-// depend on h, its W_ih rows stay in registers next to the W_hh fragments, the x tile is prefetched one step ahead, and the MFMAs run
-// BEFORE the step's wait for its neighbours' granules (a workgroup idles ~1 us of every 2.1 us step there).  The projection launch
-// (31.8 us at B 64 / L 80) and the 42 MB it wrote and the recurrence re-read leave the iteration.  Same MFMA sequence as gemm_nt's
-// (K-steps in order, lo x w before hi x w, bias added to the finished sum): bit-identical gate pre-activations.
+// XP (round 6): the INPUT PROJECTION x_t W_ih^T + (b_ih + b_hh) of every step is formed INSIDE the recurrence launch (E = kInprojE input
+// features) instead of by a GEMM launch over all L * B rows in front of it -- by FOUR EXTRA WAVES per workgroup (threads 256..511, one
+// per SIMD beside a recurrence wave, lowest issue priority): while waves 0-3 run step s (sweep the neighbours' granules, h W_hh^T,
+// pointwise, publish), waves 4-7 form the projection of step s + 1 -- its 16 rows x (4 gates x 16 units), W_ih rows resident in
+// registers, the x tile prefetched two steps ahead through LDS planes of their own -- and leave it in a triple-buffered LDS tile that
+// the pointwise stage reads two workgroup barriers later.  The two groups share the step's two barriers and nothing else.  (The
+// first form of this, the same four waves doing both jobs, was bit-identical and NEUTRAL: the hand-off wait is a load round trip the
+// wave itself issues, not idle time -- profiles/round6_notes.md section 6.)  The projection launch (31.8 us at B 64 / L 80) and the
+// 42 MB it wrote and the recurrence re-read leave the iteration.  Same MFMA sequence as gemm_nt's (K-steps in order, lo x w before
+// hi x w, bias added to the finished sum): bit-identical gate pre-activations.
 constexpr int kInprojE = 256;
+// barrier among the four projection waves only (the workgroup barrier also counts the recurrence waves): an LDS counter
+__device__ __forceinline__ void proj_waves_barrier(unsigned* cnt, unsigned& gen, int lane) {
+  gen += 4u;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's LDS traffic has completed
+  if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen; ) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 22)) break;                               // (a projection wave died: bounded, the results are garbage either way)
+  }
+}
 template <typename TW, int NS, bool XP>
-__global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
+__global__ __launch_bounds__(XP ? 512 : 256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,
                                                                  int nrec, int np_, GatherRolloutArgs ride, FetchPart fetch, RideShadows shadows) {
   // PASSENGERS: the workgroups that are not the recurrence's own `nrec` (persist_role, encoder_persist.h: past them, or -- partitioned
@@ -91,6 +105,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   if (role.rid < 0) {
     int p = role.pid, np = np_;
     if (p < 0) return;
+    if (XP && threadIdx.x >= 256) return;          // the passengers' bodies are written for 256 threads
     if (fetch.on) {      // the LAST passenger pulls the tail of the batch blob out of pinned host memory (PCIe-bound, ~25 us) instead of gathering
       if (p == np - 1) { host_fetch_part_body(fetch, (int)threadIdx.x); return; }
       np -= 1;
@@ -134,27 +149,86 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
 
-  WFrag<TW, NS> w;
-  load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
-
-  const int bl = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int bl = (threadIdx.x & 255) >> 4, jl = threadIdx.x & 15;
   const int j = j0 + jl;
-  // in-kernel input projection: this wave's 16 gate columns of W_ih (all kInprojE input features) in registers, the x tile in LDS
+  // in-kernel input projection (XP): LDS shared by the two wave groups -- the x tile (projection waves only), the finished projection
+  // of three consecutive steps, the projection waves' own barrier counter
   constexpr int NSX = XP ? kInprojE / RecCfg<TW>::BK : 1;
   constexpr int LDXH = kInprojE + 4, LDXP = kInprojE + 8;
   constexpr int kXTileBytes = XP ? (kPlanes ? 2 * 16 * LDXP * 2 : 16 * LDXH * 4) : 16;
   __shared__ __attribute__((aligned(16))) unsigned char xtile_raw[kXTileBytes];
-  __shared__ float sgx[XP ? 4 : 1][16][17];
-  float* const xsh = reinterpret_cast<float*>(xtile_raw);
-  bf16_raw* const xph = reinterpret_cast<bf16_raw*>(xtile_raw);
-  bf16_raw* const xpl = xph + 16 * LDXP;
-  WFrag<TW, NSX> wx;
+  __shared__ float sgx[XP ? 3 : 1][4][16][17];
+  __shared__ unsigned s_pcnt;
   float bx_i = 0.f, bx_f = 0.f, bx_g = 0.f, bx_o = 0.f;
   if constexpr (XP) {
-    load_wfrag<TW, NSX>(wx, reinterpret_cast<const TW*>(a.w_ih) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * kInprojE, fq);
+    if (threadIdx.x >= 256) {
+      // ---- the PROJECTION waves (4-7): wave pw forms gate pw's 16 columns; same barrier sequence as the recurrence waves below ----
+      const int ptid = (int)threadIdx.x - 256, pw = ptid >> 6;
+      float* const xsh = reinterpret_cast<float*>(xtile_raw);
+      bf16_raw* const xph = reinterpret_cast<bf16_raw*>(xtile_raw);
+      bf16_raw* const xpl = xph + 16 * LDXP;
+      WFrag<TW, NSX> wx;
+      load_wfrag<TW, NSX>(wx, reinterpret_cast<const TW*>(a.w_ih) + ((long)d * 4 * HD + (long)pw * HD + j0 + fi) * kInprojE, fq);
+      __builtin_amdgcn_s_setprio(0);             // never ahead of the recurrence wave on the same SIMD
+      unsigned pgen = 0;
+      for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
+        const bool first_pass = bb == ix0.bb;
+        if (!first_pass) __syncthreads();
+        const int b0 = bb * 16;
+        if (ptid == 0 && first_pass) s_pcnt = 0u;
+        __syncthreads();                          // (the recurrence waves' barrier behind their s_abort / XCC_ID set-up)
+        float4 xr[4], xr2[4];
+        auto load_xtile = [&](float4 (&dst)[4], int step_) {
+          const int t_ = (d == 0) ? step_ : (L - 1 - step_);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int unit = ptid + u * 256;
+            const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
+            const int br = min(b0 + r, B - 1);     // rows past the batch: any valid row (their results are never used)
+            dst[u] = *reinterpret_cast<const float4*>(a.x + ((long)t_ * B + br) * kInprojE + c4 * 4);
+          }
+        };
+        auto project = [&](int step_) {           // tile of `step_` (in xr) -> sgx[step_ % 3]; then xr <- xr2, xr2 <- tile step_ + 2
+          proj_waves_barrier(&s_pcnt, pgen, lane);               // every projection wave has finished reading the previous tile
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int unit = ptid + u * 256;
+            const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
+            if constexpr (kPlanes) {
+              split_store2(xph + r * LDXP + c4 * 4, xpl + r * LDXP + c4 * 4, xr[u].x, xr[u].y);
+              split_store2(xph + r * LDXP + c4 * 4 + 2, xpl + r * LDXP + c4 * 4 + 2, xr[u].z, xr[u].w);
+            } else {
+              *reinterpret_cast<float4*>(&xsh[r * LDXH + c4 * 4]) = xr[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xr[u] = xr2[u];
+          if (step_ + 2 < L) load_xtile(xr2, step_ + 2);
+          proj_waves_barrier(&s_pcnt, pgen, lane);               // the tile is complete
+          f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (kPlanes) mfma_resident_planes<NSX>(xph + fi * LDXP, xpl + fi * LDXP, wx, fq, ax);
+          else mfma_resident<TW, NSX>(&xsh[fi * LDXH], wx, fq, ax);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sgx[step_ % 3][pw][fq * 4 + r][fi] = ax[r];
+        };
+        load_xtile(xr, 0);
+        if (L > 1) load_xtile(xr2, 1);
+        project(0);
+        for (int step = 0; step < L; ++step) {
+          if (step + 1 < L) project(step + 1);    // read by the pointwise stage of step + 1, two workgroup barriers from here
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the recurrence waves' h-tile barrier (LDS-only: the prefetch stays in flight)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // ... and their gate barrier
+        }
+      }
+      return;
+    }
     const float* bp = a.bsum + (long)d * 4 * HD + j;
     bx_i = bp[0]; bx_f = bp[HD]; bx_g = bp[2 * HD]; bx_o = bp[3 * HD];
   }
+  // (recurrence waves only from here: threads 0..255)
+  WFrag<TW, NS> w;
+  load_wfrag<TW, NS>(w, reinterpret_cast<const TW*>(a.w_hh) + ((long)d * 4 * HD + (long)wave * HD + j0 + fi) * HD, fq);
+
   for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
   const bool first_pass = bb == ix0.bb;
   if (!first_pass) __syncthreads();            // the tile / gate buffers of the previous pass are free
@@ -194,22 +268,6 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
   }
   __syncthreads();
 
-  // XP: the x tile of a time step = rows (t * B + b0 .. + 15) x kInprojE floats of the embedded (dropped) inputs: thread -> 4 float4
-  // Prefetch distance TWO steps, requested right AFTER a step's wait for the granules has ended: vector-memory loads return in order,
-  // so a tile request still in flight when the wait's sweep is issued would hold the sweep's loads behind its ~1.5 us first-touch
-  // latency (measured: the launch then gains per step what the projection launch saved).
-  float4 xr[XP ? 4 : 1], xr2[XP ? 4 : 1];
-  auto load_xtile = [&](float4 (&dst)[XP ? 4 : 1], int step_) {
-    const int t_ = (d == 0) ? step_ : (L - 1 - step_);
-#pragma unroll
-    for (int u = 0; u < (XP ? 4 : 1); ++u) {
-      const int unit = threadIdx.x + u * 256;
-      const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
-      const int br = min(b0 + r, B - 1);                   // rows past the batch: any valid row (their results are never used)
-      dst[u] = *reinterpret_cast<const float4*>(a.x + ((long)t_ * B + br) * kInprojE + c4 * 4);
-    }
-  };
-  if constexpr (XP) { load_xtile(xr, 0); if (L > 1) load_xtile(xr2, 1); }
   for (int step = 0; step < L; ++step) {
     const int t = (d == 0) ? step : (L - 1 - step);
     const long sbase = ((long)d * L + t) * B;
@@ -222,38 +280,13 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       }
     }
     VLN_STAMP(0);
-    // sweep this thread's NLD x 2 granules of the group's h tile (time t), published in step - 1.  The FIRST sweep's loads are issued
-    // here and checked below: with XP the step's input projection runs while they are in flight (the hand-off is one load round trip --
-    // a wave that computes first and sweeps afterwards pays the projection in full: measured +0.36 us per step).
+    // sweep this thread's NLD x 2 granules of the group's h tile (time t), published in step - 1
     const unsigned expect = tag_base + (unsigned)step;
     const unsigned pbase = gbase + (unsigned)((step - 1) & 1) * (16u * HD * 8u);
     u32x4_t v[NLD];
     if (step > 0) {
 #pragma unroll
       for (int u = 0; u < NLD; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(xres, pbase + (unsigned)(threadIdx.x + u * 256) * 16u, 0, 16);
-    }
-    if constexpr (XP) {
-      // this step's x tile (prefetched) -> LDS, the next step's requested, then the projection's MFMAs: all of it BEFORE the wait for
-      // the neighbours' granules.  (The tile buffers were last read two barriers ago: the previous step's h-tile and gate barriers.)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int unit = threadIdx.x + u * 256;
-        const int r = unit / (kInprojE / 4), c4 = unit % (kInprojE / 4);
-        if constexpr (kPlanes) {
-          split_store2(xph + r * LDXP + c4 * 4, xpl + r * LDXP + c4 * 4, xr[u].x, xr[u].y);
-          split_store2(xph + r * LDXP + c4 * 4 + 2, xpl + r * LDXP + c4 * 4 + 2, xr[u].z, xr[u].w);
-        } else {
-          *reinterpret_cast<float4*>(&xsh[r * LDXH + c4 * 4]) = xr[u];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xr[u] = xr2[u];                            // step + 1's tile (requested a step ago)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier: requests in flight stay in flight
-      f32x4 ax = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (kPlanes) mfma_resident_planes<NSX>(xph + fi * LDXP, xpl + fi * LDXP, wx, fq, ax);
-      else mfma_resident<TW, NSX>(&xsh[fi * LDXH], wx, fq, ax);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sgx[wave][fq * 4 + r][fi] = ax[r];       // read after the h-tile barrier below
     }
     if (step > 0) {
       unsigned spins = 0;
@@ -304,9 +337,7 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
       VLN_STAMP(1);
       for (int i = threadIdx.x; i < kTileBytes / 4; i += 256) reinterpret_cast<uint32_t*>(tile_raw)[i] = 0u;
     }
-    if constexpr (XP) { if (step + 2 < L) load_xtile(xr2, step + 2); }      // behind the sweep: nothing waits for it before the next step's top
-    if constexpr (XP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (LDS-only: a __syncthreads() would drain the request just made)
-    else __syncthreads();
+    __syncthreads();
     VLN_STAMP(2);
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -319,8 +350,9 @@ __global__ __launch_bounds__(256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, u
     VLN_STAMP(3);
     float si = 0.f, sf = 0.f, tg = 0.f, so = 0.f, tc = 0.f, yv = 0.f, c_in = creg, hs = 0.f, cs = 0.f;
     if (live) {
-      if constexpr (XP) {      // the projection's finished sums + bias: what the GEMM's epilogue stored into xproj
-        xi = sgx[0][bl][jl] + bx_i; xf = sgx[1][bl][jl] + bx_f; xg = sgx[2][bl][jl] + bx_g; xo = sgx[3][bl][jl] + bx_o;
+      if constexpr (XP) {      // the projection waves' finished sums + bias: what the GEMM's epilogue stored into xproj
+        const int sx = step % 3;
+        xi = sgx[sx][0][bl][jl] + bx_i; xf = sgx[sx][1][bl][jl] + bx_f; xg = sgx[sx][2][bl][jl] + bx_g; xo = sgx[sx][3][bl][jl] + bx_o;
       }
       const float pi = sg[0][bl][jl] + xi, pf = sg[1][bl][jl] + xf, pg = sg[2][bl][jl] + xg, po = sg[3][bl][jl] + xo;
       const bool valid = t < len;

@@ -321,11 +321,11 @@ class EncoderLSTM(nn.Module):
         self.dx_with_wgrads = True
         # True: the context's layout changes ride in the launches of the encoder -> decoder bridge's products (vln_layout_post)
         self.layout_with_bridge = True
-        # (A/B, off: measured neutral) the input projection formed INSIDE the persistent forward recurrence (vln_lstm_seq_fwd_x): the
-        # projection launch (32 us) and the 84 MB it writes / the recurrence re-reads disappear, bit-identical results -- but the
-        # recurrence launch grows by 0.45 us per time step (172 -> 210 us at L 80): its hand-off wait is a load round trip the wave
-        # itself issues, not idle time the projection's MFMAs could fill (profiles/round6_notes.md)
-        self.inproj = False
+        # The input projection formed INSIDE the persistent forward recurrence launch (vln_lstm_seq_fwd_x, round 6) where the library takes
+        # it (vln_lstm_inproj_ok: Hd 256, 256 input features): four extra waves per recurrence workgroup form step s + 1's projection
+        # while the first four run step s.  The projection launch (32 us) and the 84 MB it writes / the recurrence re-reads disappear:
+        # headline 1.403 -> 1.370 ms; bit-identical to the per-step chain that reads the GEMM's output.  False: the GEMM launch (A/B).
+        self.inproj = True
         self._calls = 0
         self._shadow = ShadowSet()
         self._param_names = [n for n, _ in self.named_parameters()]

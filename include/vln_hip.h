@@ -713,9 +713,10 @@ int vln_lstm_seq_fwd(const float* xproj, const void* w_hh, int wtype, const int3
                      vln_stream_t s);
 /* The same forward recurrence with the INPUT PROJECTION formed inside the persistent launch (ABI v18, round 6): instead of xproj =
  * x W_ih^T + (b_ih + b_hh) from a GEMM launch over all L * B rows, the call takes x [L*B, E] (time-major, fp32), w_ih [dirs*4Hd, E] in
- * the recurrence's weight type and bsum [dirs*4Hd]; every recurrence workgroup forms its 16 rows x 64 gate columns per step from
- * register-resident W_ih rows before it waits for its neighbours' hidden state.  Same MFMA sequence as vln_linear_fwd: bit-identical
- * results.  Only where vln_lstm_inproj_ok(...) returns 1 (the granule-protocol persistent launch, Hd 256 / 512, E = 256); elsewhere
+ * the recurrence's weight type and bsum [dirs*4Hd]; four EXTRA waves of every recurrence workgroup form its 16 rows x 64 gate columns
+ * of step s + 1 from register-resident W_ih rows while the workgroup's first four waves run step s.  Same MFMA sequence as
+ * vln_linear_fwd: bit-identical results.  Only where vln_lstm_inproj_ok(...) returns 1 (the granule-protocol persistent launch,
+ * Hd 256, E = 256); elsewhere
  * the caller forms xproj itself and calls vln_lstm_seq_fwd. */
 int vln_lstm_inproj_ok(int B, int L, int Hd, int dirs, int E, const void* sync_ws, int64_t sync_ws_bytes);
 int vln_lstm_seq_fwd_x(const float* x, int E, const void* w_ih, const float* bsum, const void* w_hh, int wtype,
