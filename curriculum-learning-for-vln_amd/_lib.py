@@ -293,6 +293,11 @@ SIGNATURES = {
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr, ptr]),
     "vln_lstm_seq_bwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr, ptr]),
     "vln_lstm_inproj_ok": (i32, [i32, i32, i32, i32, i32, ptr, i64]),
+    "vln_lstm_wgrad_inlaunch_ok": (i32, [i32, i32, i32, i32, i32, i32, i32, ptr, i64]),
+    "vln_lstm_wgrad_part_floats": (i64, [i32, i32, i32, i32]),
+    "vln_lstm_seq_bwd_w": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr,
+                                 ptr, i32, ptr, ptr, i64, ptr]),
+    "vln_lstm_wgrad_reduce": (i32, [ptr, i32, i32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
     "vln_lstm_seq_fwd_x": (i32, [ptr, i32, ptr, ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64,
                                  ptr, ptr]),
     "vln_tick": (i32, [C.POINTER(TickItem), i32, ptr]),

@@ -242,6 +242,10 @@ struct RecBwdArgs {
   // gradients summed over each workgroup's 16 rows and all L steps by the threads that form the values (vln_lstm_seq_bwd)
   float* bias_part;
   int nbb_per;            // persistent counter-protocol kernel: row blocks per PASS (0 = all in one pass), see persist_passes()
+  // in-launch weight gradients (persistent counter-protocol kernel, round 6; wg_part == nullptr: none):
+  const float* x;         // [L*B, kWgE] the layer's inputs (time-major)
+  const float* hprev;     // [dirs][L][B][Hd] the state fed into the cell at time t
+  float* wg_part;         // [dirs][row blocks per pass][4Hd][Hd + kWgE] the workgroups' partial sums
 };
 __global__ __launch_bounds__(256) void state_bm_to_db_kernel(const float* dh_bm, const float* dc_bm, float* dh, float* dc, int B, int dirs, int Hd) {
   const long n = (long)B * dirs * Hd;
@@ -790,22 +794,31 @@ static int launch_persist_bwd(hipStream_t st, const RecBwdArgs& a, unsigned* cou
     lds_claim = kRideLdsClaim;
   }
   const WgradRideArgs& rd = ride ? *ride : no_ride;
-#define VLN_PERSIST_BWD(NT_)                                                                                              \
+#define VLN_PERSIST_BWD(NT_, WG_)                                                                                         \
   {                                                                                                                       \
-    static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_>);                                    \
+    static const bool fits = kernel_fits_one_per_cu(lstm_persist_bwd_kernel<TW, NT_, WG_>, WG_ ? 512 : 256);              \
     if (!fits) { set_error("persistent lstm bwd: the kernel does not fit one workgroup per CU on this device"); return VLN_ERR_HIP; } \
     if (lds_claim) {                                                                                                      \
-      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<TW, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
+      static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<TW, NT_, WG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRideLdsClaim) == hipSuccess; \
       if (!ok) { (void)hipGetLastError(); set_error("persistent lstm bwd: the dynamic-LDS claim of the passenger launch was refused"); return VLN_ERR_HIP; } \
     }                                                                                                                     \
-    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_>), g1, dim3(256), lds_claim, st, a, counters, status, sticky, exch, xm, nrec, np, rd); \
+    VLN_LAUNCH((lstm_persist_bwd_kernel<TW, NT_, WG_>), g1, dim3(WG_ ? 512 : 256), lds_claim, st, a, counters, status, sticky, exch, xm, nrec, np, rd); \
   }                                                                                                                       \
   break
-  switch (a.Hd / 64) {
-    case 2: VLN_PERSIST_BWD(2);
-    case 4: VLN_PERSIST_BWD(4);
-    case 8: VLN_PERSIST_BWD(8);
-    default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
+  if (a.wg_part) {      // the layer's own weight gradients inside the launch (wgrad_inlaunch_ok: Hd 256, bf16 weights)
+    if constexpr (sizeof(TW) == 2) {
+      if (a.Hd != 256) { set_error("persistent lstm bwd: the in-launch weight gradients take Hd = 256"); return VLN_ERR_ARG; }
+      switch (0) { default: VLN_PERSIST_BWD(4, true); }
+    } else {
+      set_error("persistent lstm bwd: the in-launch weight gradients are the bf16 mode's"); return VLN_ERR_ARG;
+    }
+  } else {
+    switch (a.Hd / 64) {
+      case 2: VLN_PERSIST_BWD(2, false);
+      case 4: VLN_PERSIST_BWD(4, false);
+      case 8: VLN_PERSIST_BWD(8, false);
+      default: set_error("persistent lstm bwd: unsupported Hd"); return VLN_ERR_ARG;
+    }
   }
 #undef VLN_PERSIST_BWD
   VLN_CHECK_LAUNCH("lstm_persist_bwd");
@@ -1184,10 +1197,87 @@ static int lstm_seq_bwd_issue(hipStream_t st, const float* dy_tm, const void* w_
   return VLN_OK;
 }
 
+// Whether vln_lstm_seq_bwd_w accumulates the layer's own weight gradients INSIDE the persistent BPTT launch for this shape (round 6):
+// the counter-protocol launch, bf16-streamed weights, Hd = 256, E = kWgE inputs, the plain-bf16 weight-gradient precision (the
+// process default: ops.set_wgrad_precision("bf16")).  tunable[13] = 6: never (A/B: the pack + contraction launches).
+extern "C" int vln_lstm_wgrad_inlaunch_ok(int B, int L, int Hd, int dirs, int E, int wtype, int precision, const void* sync_ws, int64_t sync_ws_bytes) {
+  return (g_tunable[13] != 6 && !bwd_granules() && wtype == VLN_BF16 && precision == 2 && Hd == 256 && E == kWgE &&
+          persist_ok(B, L, Hd, dirs, sync_ws, true) && sync_ws_bytes >= vln_lstm_sync_ws_bytes(B, Hd, dirs) && al16(sync_ws)) ? 1 : 0;
+}
+extern "C" int64_t vln_lstm_wgrad_part_floats(int B, int Hd, int dirs, int E) {
+  const int nbbp = persist_passes(B, Hd, dirs, true);
+  return nbbp <= 0 ? 0 : (int64_t)dirs * nbbp * 4 * Hd * (Hd + E);
+}
+namespace vln {
+// partial sums of the in-launch weight gradients -> the gradients: out_hh[d] [4Hd, Hd] (+)= sum_pb part[d][pb][:, :Hd], out_ih[d]
+// [4Hd, E] (+)= sum_pb part[d][pb][:, Hd:], the row blocks' partials added in order
+struct WgReduce { const float* part; float* out_hh[2]; float* out_ih[2]; int acc_hh[2], acc_ih[2]; int nparts, Hd, E, dirs; };
+__global__ __launch_bounds__(256) void lstm_wgrad_reduce_kernel(WgReduce a) {
+  const int W = a.Hd + a.E, W4 = W / 4;
+  const long n4 = (long)a.dirs * 4 * a.Hd * W4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % W4);
+    const long rr = i / W4;
+    const int row = (int)(rr % (4 * a.Hd)), d = (int)(rr / (4 * a.Hd));
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < a.nparts; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(a.part + (((long)d * a.nparts + p) * 4 * a.Hd + row) * W + c4 * 4);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int c = c4 * 4;
+    float* o; int acc;
+    if (c < a.Hd) { o = a.out_hh[d] ? a.out_hh[d] + (long)row * a.Hd + c : nullptr; acc = a.acc_hh[d]; }
+    else { o = a.out_ih[d] ? a.out_ih[d] + (long)row * a.E + (c - a.Hd) : nullptr; acc = a.acc_ih[d]; }
+    if (!o) continue;
+    if (acc) { const float4 g = *reinterpret_cast<const float4*>(o); sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w; }
+    *reinterpret_cast<float4*>(o) = sum;
+  }
+}
+}  // namespace vln
+extern "C" int vln_lstm_wgrad_reduce(const float* part, int B, int Hd, int dirs, int E, float* const* out_hh, float* const* out_ih,
+                                     const int* acc_hh, const int* acc_ih, vln_stream_t s) {
+  if (!part || !out_hh || !out_ih || !acc_hh || !acc_ih || dirs < 1 || dirs > 2 || (Hd & 3) || (E & 3)) { set_error("vln_lstm_wgrad_reduce: bad args"); return VLN_ERR_ARG; }
+  WgReduce a{};
+  a.part = part; a.nparts = persist_passes(B, Hd, dirs, true); a.Hd = Hd; a.E = E; a.dirs = dirs;
+  if (a.nparts <= 0) { set_error("vln_lstm_wgrad_reduce: this batch takes no persistent launch"); return VLN_ERR_ARG; }
+  for (int d = 0; d < dirs; ++d) {
+    a.out_hh[d] = out_hh[d]; a.out_ih[d] = out_ih[d]; a.acc_hh[d] = acc_hh[d]; a.acc_ih[d] = acc_ih[d];
+    if ((out_hh[d] && !al16(out_hh[d])) || (out_ih[d] && !al16(out_ih[d]))) { set_error("vln_lstm_wgrad_reduce: gradients must be 16-byte aligned"); return VLN_ERR_ARG; }
+  }
+  VLN_LAUNCH(lstm_wgrad_reduce_kernel, dim3(512), dim3(256), 0, (hipStream_t)s, a);
+  VLN_CHECK_LAUNCH("lstm_wgrad_reduce");
+  return VLN_OK;
+}
+static int lstm_seq_bwd_impl(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                             const float* act, const float* tanh_c, const float* cprev, float* dgates,
+                             float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
+                             int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials,
+                             const float* wg_x, const float* wg_hprev, float* wg_part, vln_stream_t s);
 extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
                                 const float* act, const float* tanh_c, const float* cprev, float* dgates,
                                 float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
                                 int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials, vln_stream_t s) {
+  return lstm_seq_bwd_impl(dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_init_bm, dc_init_bm, B, L, Hd, dirs,
+                           sync_ws, sync_ws_bytes, device_seq, bias_partials, nullptr, nullptr, nullptr, s);
+}
+extern "C" int vln_lstm_seq_bwd_w(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                                  const float* act, const float* tanh_c, const float* cprev, float* dgates,
+                                  float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
+                                  int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials,
+                                  const float* x, int E, const float* hprev, float* wg_part, int64_t wg_part_floats, vln_stream_t s) {
+  if (!x || !hprev || !wg_part || !al16(x) || !al16(hprev) || !al16(wg_part)) { set_error("vln_lstm_seq_bwd_w: null or misaligned x / hprev / wg_part"); return VLN_ERR_ARG; }
+  if (!vln_lstm_wgrad_inlaunch_ok(B, L, Hd, dirs, E, wtype, 2, sync_ws, sync_ws_bytes) || wg_part_floats < vln_lstm_wgrad_part_floats(B, Hd, dirs, E)) {
+    set_error("vln_lstm_seq_bwd_w: this shape does not take the in-launch weight gradients (ask vln_lstm_wgrad_inlaunch_ok), or wg_part is too small");
+    return VLN_ERR_ARG;
+  }
+  return lstm_seq_bwd_impl(dy_tm, w_hh_t, wtype, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_init_bm, dc_init_bm, B, L, Hd, dirs,
+                           sync_ws, sync_ws_bytes, device_seq, bias_partials, x, hprev, wg_part, s);
+}
+static int lstm_seq_bwd_impl(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths,
+                             const float* act, const float* tanh_c, const float* cprev, float* dgates,
+                             float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm, int B, int L,
+                             int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials,
+                             const float* wg_x, const float* wg_hprev, float* wg_part, vln_stream_t s) {
   if (!w_hh_t || !lengths || !act || !tanh_c || !cprev || !dgates || !dh_pass || !dc_carry || B <= 0 || L <= 0 ||
       Hd <= 0 || dirs < 1 || dirs > 2 || ((dh_init_bm == nullptr) != (dc_init_bm == nullptr))) { set_error("vln_lstm_seq_bwd: bad args"); return VLN_ERR_ARG; }
   const float* dh_bm = dh_init_bm; const float* dc_bm = dc_init_bm;
@@ -1225,7 +1315,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     }
     const int nbbp = persist_passes(B, Hd, dirs, !bwd_granules());
     RecBwdArgs a{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, B, L, Hd, dirs, 0, 1, 1, dh_bm, dc_bm,
-                 bwd_granules() ? nullptr : bias_partials, nbbp < (B + 15) / 16 ? nbbp : 0};
+                 bwd_granules() ? nullptr : bias_partials, nbbp < (B + 15) / 16 ? nbbp : 0, wg_x, wg_hprev, wg_part};
     dim3 grid(Hd / 16, dirs, nbbp);
     unsigned* cw = (unsigned*)sync_ws;
     float* exch = reinterpret_cast<float*>(static_cast<char*>(sync_ws) + kSyncHeaderBytes);
@@ -1250,6 +1340,7 @@ extern "C" int vln_lstm_seq_bwd(const float* dy_tm, const void* w_hh_t, int wtyp
     return r;
   }
   if (have_ride) { int rr = ride_issue_alone((hipStream_t)s, pend); if (rr) return rr; }
+  if (wg_part) { set_error("vln_lstm_seq_bwd_w: the persistent path was refused after vln_lstm_wgrad_inlaunch_ok said yes (mode switched?)"); return VLN_ERR_ARG; }
   struct { const void* p[11]; int v[5]; } key = {{dy_tm, w_hh_t, lengths, act, tanh_c, cprev, dgates, dh_pass, dc_carry, dh_bm, dc_bm},
                                                  {wtype, B, L, Hd, dirs}};
   static GraphCache cache;

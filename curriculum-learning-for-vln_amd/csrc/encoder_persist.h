@@ -352,13 +352,38 @@ __host__ __device__ inline long persist_bwd_exchange_floats(int B, int Hd, int d
   return (long)dirs * ((B + 15) / 16) * 2 * (Hd / 16) * Hd * 16;
 }
 
-template <typename TW, int NT>   // NT = Hd / 64: output tiles (16 units each) per wave
-__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map,
+// barrier among the four EXTRA waves of a recurrence workgroup only (the forward's projection waves, the backward's weight-gradient waves;
+// the workgroup barrier also counts the recurrence waves): an LDS counter
+__device__ __forceinline__ void proj_waves_barrier(unsigned* cnt, unsigned& gen, int lane) {
+  gen += 4u;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's LDS traffic has completed
+  if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen; ) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 22)) break;                               // (a projection wave died: bounded, the results are garbage either way)
+  }
+}
+// WG (round 6; an A/B option that measured SLOWER and is off by default): the layer's OWN weight gradients d W_hh = sum_t dgates_t^T
+// h_{t-1}, d W_ih = sum_t dgates_t^T x_t accumulated INSIDE the BPTT launch by FOUR EXTRA WAVES per workgroup (threads 256..511; the
+// forward's projection waves are the same idea): a workgroup holds the step's dgates tile [16 rows x 64 gate columns] in LDS anyway; the
+// extra waves contract it against the step's h_{t-1} and x_t rows (16 x kWgE each, staged through LDS tiles of their own) on
+// v_mfma_f32_16x16x16_bf16 -- plain bf16 operands, fp32 accumulation in 128 registers per lane: the arithmetic of the packed
+// contraction in its default precision (results within 5e-7 of it).  At the end every workgroup stores its [64, Hd + kWgE] partial;
+// vln_lstm_wgrad_reduce adds the row blocks' partials in order.  It removes the encoder's pack (44 us) and contraction (28 us)
+// launches -- and makes the BPTT launch 192 -> 392 us: every workgroup must pull 32 KB of h / x rows per step from HBM through its
+// compute unit's vector-memory pipeline, which returns loads in order and keeps ~8 KB in flight; the recurrence waves' own hand-off
+// loads queue behind them wherever in the step they are requested (behind the arrival barrier +1.7 us per step, two steps deep +3.5,
+// behind the reduction barrier +1.7; without the rows' loads the iteration reads 1.346 ms against 1.361).  The forward's projection
+// waves do not have the problem: their 16 KB per step were written a few microseconds earlier and hit in L2.  profiles/round6_notes.md.
+constexpr int kWgE = 256;
+template <typename TW, int NT, bool WG>   // NT = Hd / 64: output tiles (16 units each) per wave
+__global__ __launch_bounds__(WG ? 512 : 256) void lstm_persist_bwd_kernel(RecBwdArgs a, unsigned* counters, unsigned* status, unsigned* sticky, float* exch, int xcd_map,
                                                                int nrec, int np, WgradRideArgs ride) {
   constexpr int HD = NT * 64;
   const PersistRole role = persist_role(xcd_map, nrec, np);
   if (role.rid < 0) {                // passengers (wgrad_ride.h): another module's parameter gradients on the CUs the recurrence leaves idle
     __shared__ float4 ride_part[64][4];
+    if (WG && threadIdx.x >= 256) return;      // (the passengers' bodies are written for 256 threads)
     if (role.pid >= 0) wgrad_ride_passenger(ride, role.pid, np, status, sticky, ride_part);
     return;
   }
@@ -378,6 +403,108 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
   const int jb = ix0.jb, j0 = jb * 16, d = ix0.d;
   const int B = a.B, L = a.L;
   const int G = a.dirs * 4 * HD, Y = a.dirs * HD;
+  // ---- the WEIGHT-GRADIENT waves (4-7) ---------------------------------------------------------------------------------------------
+  constexpr int LDW = kWgE + 4;
+  __shared__ __attribute__((aligned(16))) float wg_h[WG ? 16 * (HD + 4) : 4];      // h_{t-1} rows of the step (fp32, row-major)
+  __shared__ __attribute__((aligned(16))) float wg_x[WG ? 16 * LDW : 4];           // x_t rows of the step
+  __shared__ unsigned s_wcnt;
+  if constexpr (WG) {
+    if (threadIdx.x >= 256) {
+      static_assert(!WG || HD == 256, "the in-launch weight gradients are instantiated for Hd = 256");
+      constexpr int LDHW = HD + 4;
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const int wtid = (int)threadIdx.x - 256, ww = wtid >> 6;          // wave ww: input-unit tiles ww * 4 .. ww * 4 + 3 of both matrices
+      __builtin_amdgcn_s_setprio(0);
+      f32x4 acc_h[4][4], acc_x[4][4];                                     // [gate m-tile][n-tile of this wave]
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc_h[m][n] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_x[m][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      unsigned wgen = 0;
+      for (int bb = ix0.bb; bb < nbb_all; bb += nbb_pass) {
+        const bool first_pass = bb == ix0.bb;
+        if (!first_pass) __syncthreads();
+        const int b0 = bb * 16;
+        if (wtid == 0 && first_pass) s_wcnt = 0u;
+        __syncthreads();                            // (the recurrence waves' barrier behind their s_abort / XCC_ID set-up)
+        // the step's h_{t-1} / x_t rows (thread -> 4 float4 of each), requested a step ahead -- and WHEN matters more than how far
+        // ahead: a compute unit's vector-memory pipeline returns loads in order, so these 32 KB must not be in it while the
+        // recurrence waves poll their group's counter and fetch the partial sums (requested behind the arrival barrier they cost
+        // 1.7 us per step, two steps deep 3.5 us); they are requested right behind the recurrence waves' reduction barrier, when
+        // those waves have their exchange data and go on to arithmetic and stores
+        float4 hr[4], xr[4], hr2[4], xr2[4];
+        auto load_rows = [&](float4 (&hd)[4], float4 (&xd)[4], int step_) {
+          const int t_ = (d == 0) ? step_ : (L - 1 - step_);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int unit = wtid + u * 256;
+            const int r = unit / 64, c4 = unit % 64;                       // HD / 4 = kWgE / 4 = 64 float4 per row
+            const int br = min(b0 + r, B - 1);                            // rows past the batch: a valid row (their dgates are zero)
+            hd[u] = *reinterpret_cast<const float4*>(a.hprev + (((long)d * L + t_) * B + br) * HD + c4 * 4);
+            xd[u] = *reinterpret_cast<const float4*>(a.x + ((long)t_ * B + br) * kWgE + c4 * 4);
+          }
+        };
+        load_rows(hr, xr, L - 1);
+        for (int step = L - 1; step >= 0; --step) {
+          const int k = L - 1 - step;
+          if (k > 0) {                              // the recurrence waves' group_wait barrier and their reduction barrier
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+          if (step > 0) load_rows(hr2, xr2, step - 1);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the step's dgates tile is complete
+          // A fragments: A[m = gate column][k = row] = tile[row][column]: lane (m = lane & 15, rows (lane >> 4) * 4 .. + 3)
+          bf16x4_t af[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af[m][r] = (__bf16)tile[(fq * 4 + r) * LDT + m * 16 + fi];
+          if (step > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the recurrence waves' arrival barrier (their last step has none)
+          // this step's rows -> the LDS tiles of these waves, the next step's requested
+          proj_waves_barrier(&s_wcnt, wgen, lane);                           // every wave has finished reading the previous tiles
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int unit = wtid + u * 256;
+            const int r = unit / 64, c4 = unit % 64;
+            *reinterpret_cast<float4*>(&wg_h[r * LDHW + c4 * 4]) = hr[u];
+            *reinterpret_cast<float4*>(&wg_x[r * LDW + c4 * 4]) = xr[u];
+          }
+          proj_waves_barrier(&s_wcnt, wgen, lane);                           // the tiles are complete
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int col = (ww * 4 + n) * 16 + fi;                          // B[k = row][n = input unit]: rows (lane >> 4) * 4 .. + 3
+            bf16x4_t bh, bx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bh[r] = (__bf16)wg_h[(fq * 4 + r) * LDHW + col]; bx[r] = (__bf16)wg_x[(fq * 4 + r) * LDW + col]; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              acc_h[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[m], bh, acc_h[m][n], 0, 0, 0);
+              acc_x[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[m], bx, acc_x[m][n], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { hr[u] = hr2[u]; xr[u] = xr2[u]; }     // the next step's rows (requested above)
+        }
+        if (a.bias_part) {                          // the recurrence waves' two barriers around the bias sums
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      // the workgroup's partial: [d][first row block][gate * HD + j0 + m][HD + kWgE]; C layout: column n = lane & 15, rows (lane >> 4) * 4 + r
+      float* pp = a.wg_part + ((long)(d * nbb_pass + ix0.bb) * 4 * HD) * (HD + kWgE);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* row = pp + ((long)m * HD + j0 + fq * 4 + r) * (HD + kWgE);
+            row[(ww * 4 + n) * 16 + fi] = acc_h[m][n][r];
+            row[HD + (ww * 4 + n) * 16 + fi] = acc_x[m][n][r];
+          }
+      return;
+    }
+  }
 
   // resident slice of W_hh: rows = this workgroup's 64 gate columns, all HD input units; read from the transposed
   // shadow [unit n][4*HD] where each gate's 16 columns are contiguous
@@ -522,12 +649,13 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(RecBwdArgs a, uns
       dg[0] = g0; dg[HD] = g1; dg[2 * HD] = g2; dg[3 * HD] = g3;
     }
     bs0 += g0; bs1 += g1; bs2 += g2; bs3 += g3;     // (zeros at padded steps and rows, like the stored dgates)
-    if (step == 0) break;                      // nobody consumes a partial dh of the last processed step
+    if (step == 0 && !WG) break;               // nobody consumes a partial dh of the last processed step
     float* tr = &tile[bl * LDT + jl];
     tr[0] = g0; tr[16] = g1; tr[32] = g2; tr[48] = g3;
     // LDS-only barrier: __syncthreads() would also drain the vector-memory counter, i.e. wait right here for the next step's
     // operand loads requested above (and for the dgates stores, which nobody in this launch reads)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (step == 0) break;                      // (WG: the weight-gradient waves read the last step's tile too)
     VLN_STAMP(3);
     {
       AFrag<TW, NSK> af;

@@ -82,16 +82,6 @@ __device__ __forceinline__ void gran_timeout(unsigned* status, unsigned* sticky,
 // 42 MB it wrote and the recurrence re-read leave the iteration.  Same MFMA sequence as gemm_nt's (K-steps in order, lo x w before
 // hi x w, bias added to the finished sum): bit-identical gate pre-activations.
 constexpr int kInprojE = 256;
-// barrier among the four projection waves only (the workgroup barrier also counts the recurrence waves): an LDS counter
-__device__ __forceinline__ void proj_waves_barrier(unsigned* cnt, unsigned& gen, int lane) {
-  gen += 4u;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's LDS traffic has completed
-  if (lane == 0) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen; ) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 22)) break;                               // (a projection wave died: bounded, the results are garbage either way)
-  }
-}
 template <typename TW, int NS, bool XP>
 __global__ __launch_bounds__(XP ? 512 : 256) void lstm_persist_g_fwd_kernel(RecFwdArgs a, unsigned* status, unsigned* sticky, unsigned char* exch,
                                                                  unsigned tag_base, int xcd_map, const unsigned* seq_dev, unsigned seq_rel,

@@ -210,17 +210,43 @@ class _EncoderFn(torch.autograd.Function):
             # hold every dgates value they store; the column sum below then reads [B / 16, 4 Hd] instead of [L * B, 4 Hd]
             nbb = (B + 15) // 16
             bias_part = ops.empty(dirs, nbb, 4 * Hd, **f32)
-            _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
-                                            _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs,
-                                            *mod._sync_ws(dev, B, Hd, dirs), offset.seq + 1 if offset.seq >= 0 else -1, _p(bias_part),
-                                            _stream()),
-                       "vln_lstm_seq_bwd")
+            sync_p, sync_n = mod._sync_ws(dev, B, Hd, dirs)
+            seq_b = offset.seq + 1 if offset.seq >= 0 else -1
+            # round 6: the layer's own weight gradients accumulated INSIDE the persistent BPTT launch (four extra waves per workgroup)
+            # where the library takes it: no pack launch, no contraction launch over the L * B rows
+            E_in = x.shape[1]
+            inl = bool(mod.wgrad_inlaunch and sb and x.is_contiguous() and ops.wgrad_precision(True) == 2 and
+                       all(pmap[f"lstm.weight_{w_}_l{k}" + sf_].requires_grad for w_ in ("hh", "ih") for sf_ in [""] + (["_reverse"] if dirs == 2 else [])) and
+                       lib.vln_lstm_wgrad_inlaunch_ok(B, L, Hd, dirs, E_in, wtype, 2, sync_p, sync_n))
+            if inl:
+                part = ops.empty(int(lib.vln_lstm_wgrad_part_floats(B, Hd, dirs, E_in)), **f32)
+                _lib.check(lib.vln_lstm_seq_bwd_w(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
+                                                  _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs, sync_p, sync_n, seq_b,
+                                                  _p(bias_part), _p(x), E_in, _p(hprev), _p(part), part.numel(), _stream()), "vln_lstm_seq_bwd_w")
+                o_hh, o_ih = (C.c_void_p * 2)(), (C.c_void_p * 2)()
+                a_hh, a_ih = (C.c_int * 2)(), (C.c_int * 2)()
+                for d in range(dirs):
+                    sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
+                    for name, outs_, accs_ in (("lstm.weight_hh" + sfx, o_hh, a_hh), ("lstm.weight_ih" + sfx, o_ih, a_ih)):
+                        p = pmap[name]
+                        g = p.grad
+                        if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+                            outs_[d], accs_[d] = g.data_ptr(), 1
+                        else:
+                            grads[name] = torch.empty_like(p)
+                            outs_[d], accs_[d] = grads[name].data_ptr(), 0
+                _lib.check(lib.vln_lstm_wgrad_reduce(_p(part), B, Hd, dirs, E_in, o_hh, o_ih, a_hh, a_ih, _stream()), "vln_lstm_wgrad_reduce")
+            else:
+                _lib.check(lib.vln_lstm_seq_bwd(_p(dy), _p(sh[f"w_hh_t{k}"]), wtype, _p(lens32), _p(act), _p(tanh_c),
+                                                _p(cprev), _p(dgates), _p(dh_pass), _p(dc_carry), _p(init[0]), _p(init[1]), B, L, Hd, dirs,
+                                                sync_p, sync_n, seq_b, _p(bias_part), _stream()),
+                           "vln_lstm_seq_bwd")
             cbt = ops.ColsumBatch()       # ... and its bias gradients
             wb = ops.WgradBatch(sb)       # the layer's weight gradients (all over the same L*B rows): one launch in bf16 mode
             for d in range(dirs):
                 sfx = f"_l{k}" + ("_reverse" if d == 1 else "")
                 dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
-                for name, xop in (("lstm.weight_hh" + sfx, hprev[d].view(L * B, Hd)), ("lstm.weight_ih" + sfx, x)):
+                for name, xop in (() if inl else (("lstm.weight_hh" + sfx, hprev[d].view(L * B, Hd)), ("lstm.weight_ih" + sfx, x))):
                     p = pmap[name]
                     if not p.requires_grad:
                         continue
@@ -321,6 +347,11 @@ class EncoderLSTM(nn.Module):
         self.dx_with_wgrads = True
         # True: the context's layout changes ride in the launches of the encoder -> decoder bridge's products (vln_layout_post)
         self.layout_with_bridge = True
+        # (A/B, off: measured SLOWER, 1.68 vs 1.36 ms) the layer's own weight gradients accumulated INSIDE the persistent BPTT launch
+        # by four extra waves per workgroup (vln_lstm_seq_bwd_w; bf16 mode, Hd 256, 256 inputs): same products as the pack +
+        # contraction launches (within 5e-7), but the 32 KB of h / x rows every workgroup must pull per step block the recurrence
+        # waves' hand-off loads in the compute unit's in-order vector-memory pipeline (csrc/encoder_persist.h, notes section 8)
+        self.wgrad_inlaunch = False
         # The input projection formed INSIDE the persistent forward recurrence launch (vln_lstm_seq_fwd_x, round 6) where the library takes
         # it (vln_lstm_inproj_ok: Hd 256, 256 input features): four extra waves per recurrence workgroup form step s + 1's projection
         # while the first four run step s.  The projection launch (32 us) and the 84 MB it writes / the recurrence re-reads disappear:

@@ -723,6 +723,21 @@ int vln_lstm_seq_fwd_x(const float* x, int E, const void* w_ih, const float* bsu
                        const int32_t* lengths, float* hprev, float* cprev, float* y_tm, float* act, float* tanh_c, float* hcat,
                        float* ccat, int B, int L, int Hd, int dirs, const float* h0, const float* c0, void* sync_ws,
                        int64_t sync_ws_bytes, int64_t device_seq, const vln_gather_ride* ride, vln_stream_t s);
+/* The backward recurrence with the layer's OWN weight gradients accumulated inside the persistent launch (ABI v18, round 6): four extra
+ * waves per recurrence workgroup contract the step's dgates tile against the step's h_{t-1} and x_t rows (plain bf16 operands, fp32
+ * accumulation: the packed contraction's default precision) and leave per-workgroup partial sums in wg_part
+ * (vln_lstm_wgrad_part_floats); vln_lstm_wgrad_reduce then adds the row blocks' partials in order into out_hh[d] [4Hd, Hd] and
+ * out_ih[d] [4Hd, E] (acc_*[d] = 1: added to what is there; a NULL output is skipped).  d W_hh = sum_t dgates_t^T h_{t-1},
+ * d W_ih = sum_t dgates_t^T x_t as vln_wgrad_grouped forms them over the same rows, in another summation order.  Only where
+ * vln_lstm_wgrad_inlaunch_ok(...) returns 1 (the counter-protocol persistent launch, bf16 weights, Hd 256, E 256, precision 2). */
+int vln_lstm_wgrad_inlaunch_ok(int B, int L, int Hd, int dirs, int E, int wtype, int precision, const void* sync_ws, int64_t sync_ws_bytes);
+int64_t vln_lstm_wgrad_part_floats(int B, int Hd, int dirs, int E);
+int vln_lstm_seq_bwd_w(const float* dy_tm, const void* w_hh_t, int wtype, const int32_t* lengths, const float* act, const float* tanh_c,
+                       const float* cprev, float* dgates, float* dh_pass, float* dc_carry, const float* dh_init_bm, const float* dc_init_bm,
+                       int B, int L, int Hd, int dirs, void* sync_ws, int64_t sync_ws_bytes, int64_t device_seq, float* bias_partials,
+                       const float* x, int E, const float* hprev, float* wg_part, int64_t wg_part_floats, vln_stream_t s);
+int vln_lstm_wgrad_reduce(const float* part, int B, int Hd, int dirs, int E, float* const* out_hh, float* const* out_ih,
+                          const int* acc_hh, const int* acc_ih, vln_stream_t s);
 int vln_set_persistent(int on);   /* 0 = per-step launch chain; 1 (default) = persistent kernels, granule hand-off forward, counter
                                    * hand-off backward; 2 = counter both ways (round 1); 3 = granules both ways; identical results */
 /* The persistent recurrence spins (bounded) on its neighbour workgroups; the host only launches it when the grid fits the

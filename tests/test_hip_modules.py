@@ -397,6 +397,48 @@ def test_persistent_recurrence_equals_per_step_launches(vln, dtype, B, inproj):
             check(a, b, 2e-5, n)         # dgates) and the embedding scatter-add uses float atomics
 
 
+@pytest.mark.parametrize("B", [64, 50, 144])
+def test_encoder_weight_gradients_inside_the_bptt_launch_equal_the_packed_contraction(vln, B):
+    """Round 6 (an A/B option, off by default: it measured slower -- EncoderLSTM.wgrad_inlaunch): in bf16 mode the bi-LSTM's own weight
+    gradients d W_hh = sum_t dgates_t^T h_{t-1}, d W_ih = sum_t dgates_t^T x_t can be
+    accumulated INSIDE the persistent BPTT launch by four extra waves per workgroup (vln_lstm_seq_bwd_w + vln_lstm_wgrad_reduce)
+    instead of by the pack + contraction launches over the L * B rows (vln_wgrad_grouped, precision 2): the same bf16 x bf16
+    products with fp32 accumulation in another summation order -- every other output of the backward bit for bit, the four weight
+    gradients within 2e-5 of each other (relative to the tensor's maximum).  B = 50: a ragged last row block; B = 144: two passes
+    (the partials are summed over a workgroup's row blocks in registers).  Gradients ACCUMULATE into existing .grad buffers like the
+    packed form (second backward)."""
+    lib = vln._lib.load()
+    L, E, H, vocab = 80, 256, 512, 992
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(31)
+    enc = vln.EncoderLSTM(vocab, E, H, 0, 0.5, True, 1, compute_dtype=torch.bfloat16).to(DEV).train()
+    lens = torch.sort(torch.randint(1, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    tokens = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, :n] = torch.randint(4, vocab, (n,), generator=g)
+    r = torch.randn(B, L, H, generator=g).to(DEV)
+    assert vln.ops.get_wgrad_precision() == "bf16"
+    outs = []
+    for inl in (False, True):
+        enc.wgrad_inlaunch = inl
+        enc._calls = 0
+        enc.zero_grad(set_to_none=True)
+        for rep in range(2):                            # the second backward accumulates into the first one's .grad tensors
+            ctx, h, c = enc(tokens.to(DEV), lens)
+            ((ctx * r).sum() + h.sum() + (c * c).sum()).backward()
+        torch.cuda.synchronize()
+        assert enc.persistent_status() == 0
+        outs.append({n: p.grad.detach().clone() for n, p in enc.named_parameters()})
+    vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+    for n in outs[0]:
+        a, b = outs[0][n], outs[1][n]
+        if n.startswith("lstm.weight"):
+            check(b, a, 2e-5, f"in-launch {n} (B = {B})")
+            assert not torch.equal(a, torch.zeros_like(a))
+        elif n != "embedding.weight":                   # (the embedding scatter-add uses float atomics)
+            assert torch.equal(a, b), n
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_backward_recurrence_hand_off_in_the_xcd_l2_equals_the_write_through_hand_off(vln, dtype):
     """Round 5: when every workgroup of a dependency group of the backward recurrence verified (XCC_ID bits ORed into the group's
