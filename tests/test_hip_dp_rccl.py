@@ -110,6 +110,11 @@ def _run_child(code):
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
         if r.returncode == 0 or "address already in use" not in r.stderr.lower():
             break
+    if r.returncode != 0:               # keep the child's whole output where the caller of the suite can read it (pytest's repr truncates)
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "dp_rccl_child_failure.txt"), "a") as f:
+            f.write(f"==== return code {r.returncode}\n---- stdout\n{r.stdout}\n---- stderr\n{r.stderr}\n")
     return r
 
 
