@@ -1050,7 +1050,11 @@ static int lstm_seq_fwd_impl(const float* xproj, const float* x, const void* w_i
       if (r) return r;
     }
     {
-      ProfScope prof(st, K_LSTM_REC_FWD, (double)dirs * (4.0 * Hd * Hd * (wtype == VLN_BF16 ? 2 : 4) + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
+      // algorithmic bytes: the resident weights once, per (step, row, unit) the gate inputs (xproj, 4 floats -- or, with the projection
+      // inside the launch, the row's E inputs once per direction and W_ih once) + activations / states / outputs written (10 floats)
+      const double wb = wtype == VLN_BF16 ? 2 : 4;
+      ProfScope prof(st, K_LSTM_REC_FWD, x ? (double)dirs * (4.0 * Hd * (Hd + kInprojE) * wb + (double)L * 4.0 * B * (kInprojE + Hd * 10.0))
+                                           : (double)dirs * (4.0 * Hd * Hd * wb + (double)L * 4.0 * B * Hd * (4 + 4 + 1 + 4 + 1)));
       if (fwd_granules())
         r = (wtype == VLN_BF16) ? launch_persist_g_fwd<bf16_raw>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch, shadows)
                                 : launch_persist_g_fwd<float>(st, a, cw + 32, gex, tag_base, grid, seq_dev, (unsigned)device_seq, riders, fetch, shadows);
