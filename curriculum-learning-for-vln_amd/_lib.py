@@ -237,7 +237,7 @@ SIGNATURES = {
     "vln_lstm_pointwise_bwd": (i32, [ptr, ptr, ptr, u64, u64, f32, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_dropout_mask": (i32, [ptr, i64, u64, u64, f32, ptr]),
     "vln_scale_dropout": (i32, [ptr, i64, ptr, i64, i32, i32, u64, u64, f32, ptr, ptr]),
-    "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr]),
+    "vln_feat_dropout_inplace": (i32, [ptr, i32, i64, i32, i32, u64, u64, f32, ptr, ptr, ptr]),
     "vln_rmsprop_partial_floats": (i64, [ptr, i32]),
     "vln_rmsprop_clip_step": (i32, [ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, ptr, f32, ptr]),
     "vln_adam_clip_step": (i32, [ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, f32, f32, f32, f32, i64, ptr, ptr, f32, ptr]),
@@ -288,6 +288,7 @@ SIGNATURES = {
     "vln_graph_stats": (i32, [C.POINTER(C.c_int64)]),
     "vln_shadow_refresh": (i32, [ptr, i32, ptr]),
     "vln_lstm_sync_ws_bytes": (i64, [i32, i32, i32]),
+    "vln_lstm_sync_ws_forget": (i32, [ptr]),
     "vln_lstm_sync_seq_offset": (i64, [i32, i32, i32]),
     "vln_lstm_sync_granule_range": (i32, [i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
     "vln_lstm_seq_fwd": (i32, [ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i64, i64, ptr, ptr]),
@@ -345,7 +346,7 @@ SIGNATURES = {
 
 # The ABI this binding was written against (csrc/api.hip::vln_abi_version).  Entry points change their argument lists
 # between versions under the SAME names, so a stale libvln_hip.so must be refused, not called with shifted arguments.
-EXPECTED_ABI = 18
+EXPECTED_ABI = 19
 SHADOW_MAX_JOBS = 24          # include/vln_hip.h VLN_SHADOW_MAX_JOBS
 
 _lib = None

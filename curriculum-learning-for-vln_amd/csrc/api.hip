@@ -118,7 +118,7 @@ extern "C" int vln_prof_read(int kernel_id, int64_t* launches, double* total_ms,
   return VLN_OK;
 }
 
-extern "C" int vln_abi_version(void) { return 18; }
+extern "C" int vln_abi_version(void) { return 19; }
 extern "C" int64_t vln_struct_size(const char* name) {
   if (!name) return -1;
 #define VLN_SZ(T) if (std::strcmp(name, #T) == 0) return (int64_t)sizeof(T)
@@ -340,9 +340,9 @@ extern "C" int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t 
   return scale_dropout((hipStream_t)s, x, ldx, y, ldy, rows, cols, drop_spec(seed, offset, p, offset_base_dev));
 }
 extern "C" int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed,
-                                        uint64_t offset, float p, void* copy_bf16, vln_stream_t s) {
+                                        uint64_t offset, float p, void* copy_bf16, const uint64_t* offset_base_dev, vln_stream_t s) {
   if (!x) { set_error("vln_feat_dropout_inplace: null pointer"); return VLN_ERR_ARG; }
-  return feat_dropout_inplace((hipStream_t)s, x, xtype, rows, img, angle, DropSpec{seed, offset, p}, copy_bf16);
+  return feat_dropout_inplace((hipStream_t)s, x, xtype, rows, img, angle, drop_spec(seed, offset, p, offset_base_dev), copy_bf16);
 }
 
 // ---- device-resident counters (runtime.DeviceClock) ----------------------------------------------------------------

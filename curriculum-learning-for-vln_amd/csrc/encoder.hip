@@ -569,6 +569,11 @@ static void header_mark(const void* ws, bool clean) {
   std::lock_guard<std::mutex> lock(g_hdr_mu);
   g_hdr_clean[ws] = clean;
 }
+extern "C" int vln_lstm_sync_ws_forget(const void* sync_ws) {
+  std::lock_guard<std::mutex> lock(g_hdr_mu);
+  g_hdr_clean.erase(sync_ws);       // (the allocator may hand an old buffer's address to a new one: what is known about it is void)
+  return VLN_OK;
+}
 extern "C" int vln_set_persistent(int on) {
   g_persist_enabled = (on >= 0 && on <= 3) ? on : 1;
   std::lock_guard<std::mutex> lock(g_hdr_mu);

@@ -390,6 +390,10 @@ class EncoderLSTM(nn.Module):
         clock = self.__dict__.get("clock")
         mode = (None if clock is None else id(clock), B, Hd, dirs)
         if self.__dict__.get("_sync_mode") != mode:
+            if self.__dict__.get("_sync_mode") is None:
+                # a buffer this module has not used before: whatever the library remembers about its ADDRESS belongs to memory the
+                # allocator has handed out again (the header gets its fill in front of the next counter-protocol launch)
+                _lib.check(lib.vln_lstm_sync_ws_forget(w.data_ptr()), "vln_lstm_sync_ws_forget")
             # The exchange's tags count launches: by the library on the host, or from the clock's device word.  When the
             # counting changes hands (or the layout changes) old tags mean nothing: clear the exchange once.
             go, gb = _lib.i64(), _lib.i64()

@@ -502,20 +502,21 @@ def _fused_lstm_weight(w_ih, w_hh, dtype, transposed):
 
 
 class DropoutFn(torch.autograd.Function):
-    """nn.Dropout with the kernels' Philox stream (seed, offset): mask regenerated in backward."""
+    """nn.Dropout with the kernels' Philox stream (seed, offset): mask regenerated in backward.  base: the device word the kernels
+    add (x 8) to `offset` (runtime.DeviceClock: the launch arguments then repeat from iteration to iteration), or None."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, offset):
-        ctx.cfg = (p, seed, offset)
-        return _scale_dropout(x, p, seed, offset)
+    def forward(ctx, x, p, seed, offset, base=None):
+        ctx.cfg = (p, seed, offset, base)
+        return _scale_dropout(x, p, seed, offset, base)
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed, offset = ctx.cfg
-        return _scale_dropout(dy, p, seed, offset), None, None, None
+        p, seed, offset, base = ctx.cfg
+        return _scale_dropout(dy, p, seed, offset, base), None, None, None, None
 
 
-def _scale_dropout(x, p, seed, offset):
+def _scale_dropout(x, p, seed, offset, base=None):
     """y = x * mask(seed, offset) in ONE launch (vln_scale_dropout); the mask is a function of the flat element index."""
     xc = x.contiguous()
     if xc.dtype != torch.float32:
@@ -523,16 +524,16 @@ def _scale_dropout(x, p, seed, offset):
     y = ops.empty(xc.shape, dtype=torch.float32, device=xc.device)
     cols = xc.shape[-1] if xc.dim() > 0 else 1
     rows = xc.numel() // max(cols, 1)
-    st = _lib.load().vln_scale_dropout(_p(xc), cols, _p(y), cols, rows, cols, seed, offset, p, None, _lib.raw_stream())
+    st = _lib.load().vln_scale_dropout(_p(xc), cols, _p(y), cols, rows, cols, seed, offset, p, base, _lib.raw_stream())
     if st:
         _lib.check(st, "vln_scale_dropout")
     return y
 
 
-def dropout(x, p: float, training: bool, seed: int, offset: int):
+def dropout(x, p: float, training: bool, seed: int, offset: int, base=None):
     if not training or p <= 0.0:
         return x
-    return DropoutFn.apply(x, p, seed, offset)
+    return DropoutFn.apply(x, p, seed, offset, base)
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -484,7 +484,7 @@ class ColsumBatch:
         self.jobs, self.keep, self.rows = [], [], None
 
 
-# Weight gradients in bf16 compute mode (fp32 compute mode always uses the exact fp32 MFMA):
+# Weight gradients in bf16 compute mode:
 #   "bf16"  (default) plain bf16 operands, fp32 accumulation -- ONE MFMA per product, what mixed-precision training computes;
 #           gradients within 2-5e-3 of the fp64 result on the same weights (measured, tests/parity.py SAME_BF16_GRAD), inside
 #           north_star's 1e-2 bound for bf16;
@@ -504,8 +504,27 @@ def get_wgrad_precision() -> str:
     return "split" if _WGRAD_BF16[0] == 1 else "bf16"
 
 
+# ... and in fp32 compute mode (round 6):
+#   "split" (default) the same hi + lo planes, three bf16 MFMAs per product, as ONE packed contraction per rollout: every fp32
+#           parity test holds 1e-4 with it (worst weight gradient 1.6e-5 of the oracle's, profiles/round6_notes.md section 10);
+#           Self-Monitor B 128 5.25 -> 4.40 ms, EnvDrop fp32 2.12 -> 1.93 ms;
+#   "exact" the fp32 MFMA (v_mfma_f32_16x16x4_f32: 1/16 of the bf16 MFMA rate), one launch per product and step -- rounds 1-5.
+_WGRAD_F32 = [0 if __import__('os').environ.get('VLN_WGRAD_FP32') == 'exact' else 1]    # VLN_WGRAD_FP32=exact: process-wide default
+
+
+def set_wgrad_precision_fp32(mode: str):
+    """"split" (default) or "exact": the form of the weight-gradient contractions in fp32 compute mode (see above)."""
+    if mode not in ("split", "exact"):
+        raise ValueError("fp32 wgrad precision: 'split' or 'exact'")
+    _WGRAD_F32[0] = 1 if mode == "split" else 0
+
+
+def get_wgrad_precision_fp32() -> str:
+    return "split" if _WGRAD_F32[0] == 1 else "exact"
+
+
 def wgrad_precision(lp: bool) -> int:
-    return _WGRAD_BF16[0] if lp else 0
+    return _WGRAD_BF16[0] if lp else _WGRAD_F32[0]
 
 
 class WgradBatch:
@@ -713,12 +732,13 @@ def scale_dropout(x, seed: int, offset: int, p: float, base: Optional[int] = Non
     return out
 
 
-def feat_dropout_inplace(x, img: int, angle: int, seed: int, offset: int, p: float, copy_bf16=None):
+def feat_dropout_inplace(x, img: int, angle: int, seed: int, offset: int, p: float, copy_bf16=None, base=None):
+    """base: device word the kernel adds (x 8) to `offset` (runtime.DeviceClock), or None (an absolute host offset)."""
     lib = _lib.load()
     _req(x, "x", None)
     assert x.is_contiguous() and x.shape[-1] == img + angle
     rows = x.numel() // (img + angle)
-    _lib.check(lib.vln_feat_dropout_inplace(_p(x), _dt(x), rows, img, angle, seed, offset, p, _p(copy_bf16),
+    _lib.check(lib.vln_feat_dropout_inplace(_p(x), _dt(x), rows, img, angle, seed, offset, p, _p(copy_bf16), base,
                                             _stream()), "vln_feat_dropout_inplace")
     return x
 

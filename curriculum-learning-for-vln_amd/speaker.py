@@ -27,25 +27,20 @@ class _LSTMSeqFn(torch.autograd.Function):
     params = (w_ih, w_hh, b_ih, b_hh) per direction.  Returns y_tm [L*B, dirs*Hd], h_T, c_T [B, dirs*Hd]."""
 
     @staticmethod
-    def forward(ctx, owner, x_tm, B, L, h0, c0, *params):
+    def forward(ctx, owner, x_tm, B, L, h0, c0, seq, *params):
+        """seq: -1 = the library counts this buffer's launches on the host; >= 0 = the launch's index into the device-resident launch
+        sequence of a runtime.DeviceClock (forward `seq`, backward `seq + 1`)."""
         lib = _lib.load()
         dirs = len(params) // 4
         Hd = params[1].shape[1]
         dev = x_tm.device
         f32 = dict(dtype=torch.float32, device=dev)
         dt = owner.compute_dtype                     # bf16: the weights are STREAMED as bf16 shadows, everything else stays fp32
-        wtype = ops.BF16 if dt == torch.bfloat16 else ops.F32
-        w_ih = torch.cat([params[4 * d].detach() for d in range(dirs)], 0).contiguous()
-        bsum = torch.cat([(params[4 * d + 2] + params[4 * d + 3]).detach() for d in range(dirs)], 0).contiguous()
-        w_hh = torch.stack([params[4 * d + 1].detach() for d in range(dirs)], 0).contiguous()
-        w_ih32, w_hh32 = w_ih, w_hh                  # the fp32 values: the backward builds its transposed shadows from them
         f32_in = dt != torch.float32 and owner.fp32_input_weights      # this layer's weights streamed in fp32 all the same
-        if f32_in:
-            wtype = ops.F32                          # (W_ih: VLN_F32S arithmetic; W_hh: the recurrence's fp32 form)
-        elif dt != torch.float32:
-            w_ih, w_hh = ops.cast_copy(w_ih, dt), ops.cast_copy(w_hh, dt)
+        wtype = ops.BF16 if (dt == torch.bfloat16 and not f32_in) else ops.F32     # (f32_in: W_ih in VLN_F32S arithmetic, W_hh in the recurrence's fp32 form)
+        sh = owner._shadows(params)                  # stacked copies in the streamed dtype (+ transposes), one launch per optimizer step
         x_tm = x_tm.contiguous()
-        xproj = ops.linear_fwd(x_tm, w_ih, bsum, split=f32_in)
+        xproj = ops.linear_fwd(x_tm, sh["w_ih"], sh["bsum"], split=f32_in)
         hprev = ops.empty(dirs, L, B, Hd, **f32)
         cprev = ops.empty(dirs, L, B, Hd, **f32)
         y = ops.empty(L * B, dirs * Hd, **f32)
@@ -53,42 +48,51 @@ class _LSTMSeqFn(torch.autograd.Function):
         tanh_c = ops.empty(L * B, dirs * Hd, **f32)
         hcat = ops.empty(B, dirs * Hd, **f32)
         ccat = ops.empty(B, dirs * Hd, **f32)
-        lens32 = torch.full((B,), L, dtype=torch.int32, device=dev)
-        _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(w_hh), wtype, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
+        lens32 = owner._full_lengths(B, L, dev)
+        _lib.check(lib.vln_lstm_seq_fwd(_p(xproj), _p(sh["w_hh"]), wtype, _p(lens32), _p(hprev), _p(cprev), _p(y), _p(act),
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
-                                        *owner._sync_ws(dev, B, Hd, dirs), -1, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
-        ctx.owner, ctx.dims, ctx.dt, ctx.f32_in = owner, (B, L, Hd, dirs), dt, f32_in
-        ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32, w_ih32, w_hh32)
+                                        *owner._sync_ws(dev, B, Hd, dirs), seq, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
+        ctx.owner, ctx.dims, ctx.dt, ctx.f32_in, ctx.seq, ctx.wtype, ctx.sh = owner, (B, L, Hd, dirs), dt, f32_in, seq, wtype, sh
+        ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32)
         ctx.set_materialize_grads(False)
         return y, hcat, ccat
 
     @staticmethod
     def backward(ctx, dy, dh, dc):
         lib = _lib.load()
-        x_tm, hprev, cprev, act, tanh_c, lens32, w_ih, w_hh = ctx.saved_tensors
+        x_tm, hprev, cprev, act, tanh_c, lens32 = ctx.saved_tensors
         B, L, Hd, dirs = ctx.dims
+        sh = ctx.sh                                  # the forward's shadows: the weights have not changed in between
         dev = x_tm.device
         f32 = dict(dtype=torch.float32, device=dev)
         z = lambda t: t.reshape(B, dirs, Hd).transpose(0, 1).contiguous() if t is not None else ops.zeros(dirs, B, Hd, **f32)
         dh_pass, dc_carry = z(dh), z(dc)
         dgates = ops.empty(L * B, dirs * 4 * Hd, **f32)
-        dt = ctx.dt
-        wtype = ops.BF16 if (dt == torch.bfloat16 and not ctx.f32_in) else ops.F32
-        w_hh_t = torch.stack([ops.transpose_cast(w_hh[d], torch.float32 if ctx.f32_in else dt) for d in range(dirs)], 0).contiguous()
         dyc = dy.contiguous() if dy is not None else None
-        _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(w_hh_t), wtype, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
+        _lib.check(lib.vln_lstm_seq_bwd(_p(dyc), _p(sh["w_hh_t"]), ctx.wtype, _p(lens32), _p(act), _p(tanh_c), _p(cprev), _p(dgates),
                                         _p(dh_pass), _p(dc_carry), None, None, B, L, Hd, dirs, *ctx.owner._sync_ws(dev, B, Hd, dirs),
-                                        -1, None, _lib.raw_stream()), "vln_lstm_seq_bwd")
+                                        ctx.seq + 1 if ctx.seq >= 0 else -1, None, _lib.raw_stream()), "vln_lstm_seq_bwd")
+        # the layer's weight gradients (all over the same L * B rows) as ONE grouped contraction, its bias gradients as one grouped
+        # column sum (they were a product + a slab reduction per matrix and two launches per bias pair); split hi + lo planes in bf16
+        # mode, as before (never the plain-bf16 form: the 2176-wide input rows, see fp32_input_weights)
+        wb = ops.WgradBatch(ctx.dt != torch.float32, never_plain=True)
+        cb = ops.ColsumBatch()
         grads = []
-        sb = dt != torch.float32                     # bf16 mode: split-bf16 contractions (fp32 accumulation)
+        I = x_tm.shape[1]
         for d in range(dirs):
             dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
-            db = ops.colsum(dg)
-            grads += [ops.linear_wgrad(dg, x_tm, split_bf16=sb), ops.linear_wgrad(dg, hprev[d].view(L * B, Hd), split_bf16=sb), db, db.clone()]
+            g_ih, g_hh = ops.empty(4 * Hd, I, **f32), ops.empty(4 * Hd, Hd, **f32)
+            b1, b2 = ops.empty(4 * Hd, **f32), ops.empty(4 * Hd, **f32)
+            wb.add(dg, x_tm, g_ih, False)
+            wb.add(dg, hprev[d].view(L * B, Hd), g_hh, False)
+            cb.add(dg, b1, b2, False)
+            grads += [g_ih, g_hh, b1, b2]
+        wb.run()
+        cb.run()
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = ops.linear_fwd(dgates, ops.transpose_cast(w_ih, torch.float32 if ctx.f32_in else dt), split=ctx.f32_in)
-        return (None, dx, None, None, None, None) + tuple(grads)
+            dx = ops.linear_fwd(dgates, sh["w_ih_t"], split=ctx.f32_in)
+        return (None, dx, None, None, None, None, None) + tuple(grads)
 
 
 class _SeqLSTM(nn.Module):
@@ -106,12 +110,79 @@ class _SeqLSTM(nn.Module):
         self.fp32_input_weights = False
 
     def _sync_ws(self, dev, B, Hd, dirs):
-        need = int(_lib.load().vln_lstm_sync_ws_bytes(B, Hd, dirs))
+        import ctypes as C
+        lib = _lib.load()
+        need = int(lib.vln_lstm_sync_ws_bytes(B, Hd, dirs))
         w = self.__dict__.get("_sync_buf")
         if w is None or w.device != dev or w.numel() * 4 < need:
             w = torch.zeros((need + 3) // 4, dtype=torch.int32, device=dev)
             object.__setattr__(self, "_sync_buf", w)
+            object.__setattr__(self, "_sync_mode", None)
+            _lib.check(lib.vln_lstm_sync_ws_forget(w.data_ptr()), "vln_lstm_sync_ws_forget")    # (a reused address: see encoder.py)
+        clock = self.__dict__.get("clock")
+        mode = (None if clock is None else id(clock), B, Hd, dirs)
+        if self.__dict__.get("_sync_mode") != mode:      # the launch counting changes hands / the layout changes: as in EncoderLSTM._sync_ws
+            go, gb = _lib.i64(), _lib.i64()
+            _lib.check(lib.vln_lstm_sync_granule_range(B, Hd, dirs, C.byref(go), C.byref(gb)), "vln_lstm_sync_granule_range")
+            if self.__dict__.get("_sync_mode") is not None or clock is not None:
+                w[go.value // 4:(go.value + gb.value) // 4].zero_()
+            if clock is not None:
+                clock.register_sequence(w, int(lib.vln_lstm_sync_seq_offset(B, Hd, dirs)), go.value, gb.value)
+            object.__setattr__(self, "_sync_mode", mode)
         return w.data_ptr(), w.numel() * 4
+
+    def _shadows(self, params):
+        """w_ih [dirs*4Hd, I] (+ transpose), w_hh [dirs][4Hd, Hd] (+ per-direction transposes) in the streamed dtype and bsum = b_ih + b_hh,
+        rebuilt by ONE launch (ops.ShadowBatch) when a parameter has changed since -- every call cast, concatenated and transposed
+        them anew (about twenty launches per layer and iteration)."""
+        from .runtime import ShadowSet
+        dt = torch.float32 if (self.compute_dtype == torch.float32 or self.fp32_input_weights) else self.compute_dtype
+        ss = self.__dict__.get("_shadow")
+        if ss is None:
+            ss = ShadowSet()
+            object.__setattr__(self, "_shadow", ss)
+        key = ShadowSet.key_of(params, dt)
+        if not ss.stale(key):
+            return ss.t
+        t, dirs = ss.t, len(params) // 4
+        H4, I = params[0].shape
+        Hd = params[1].shape[1]
+        dev = params[0].device
+        ck = (dt, tuple(p.data_ptr() for p in params))
+        c = self.__dict__.get("_sb_handle")
+        with torch.no_grad():
+            if c is not None and c[0] == ck:
+                ops.ShadowBatch.replay(c[1])
+            else:
+                def buf(name, shape, dtype=dt):
+                    x = t.get(name)
+                    if x is None or x.dtype != dtype or x.device != dev or tuple(x.shape) != tuple(shape):
+                        x = t[name] = torch.empty(shape, dtype=dtype, device=dev)
+                    return x
+                w_ih, w_ih_t = buf("w_ih", (dirs * H4, I)), buf("w_ih_t", (I, dirs * H4))
+                w_hh, w_hh_t = buf("w_hh", (dirs, H4, Hd)), buf("w_hh_t", (dirs, Hd, H4))
+                bsum = buf("bsum", (dirs * H4,), torch.float32)
+                sb = ops.ShadowBatch()
+                for d in range(dirs):
+                    r0, r1 = d * H4, (d + 1) * H4
+                    sb.add(params[4 * d].detach(), w_ih[r0:r1], w_ih_t[:, r0:r1])
+                    sb.add(params[4 * d + 1].detach(), w_hh[d], w_hh_t[d])
+                    sb.add(params[4 * d + 2].detach().view(1, -1), bsum[r0:r1].view(1, -1), None, src2=params[4 * d + 3].detach().view(1, -1))
+                object.__setattr__(self, "_sb_handle", (ck, sb.run()))
+        ss.commit(key)
+        return t
+
+    def _full_lengths(self, B, L, dev):
+        c = self.__dict__.get("_lens")
+        if c is None or c[0] != (B, L, dev):
+            c = ((B, L, dev), torch.full((B,), L, dtype=torch.int32, device=dev))
+            object.__setattr__(self, "_lens", c)
+        return c[1]
+
+    def _seq(self):
+        """This call's index into the clock's launch sequence (forward; the backward takes the next one), -1 without a clock."""
+        clock = self.__dict__.get("clock")
+        return -1 if clock is None else 2 * (clock.rel(("seq", id(self)), 31) - 1)
 
     def _params(self):
         out = []
@@ -148,7 +219,7 @@ class _SeqLSTM(nn.Module):
             h0 = h0.detach().to(torch.float32).contiguous()
             c0 = c0.detach().to(torch.float32).contiguous()
         x_tm = x_tm_in if x_tm_in is not None else x.transpose(0, 1).reshape(L * B, x.shape[-1])
-        y, hcat, ccat = _LSTMSeqFn.apply(self, x_tm, B, L, h0, c0, *self._params())
+        y, hcat, ccat = _LSTMSeqFn.apply(self, x_tm, B, L, h0, c0, self._seq(), *self._params())
         y = y.view(L, B, self.dirs * H).transpose(0, 1)
         return y, (hcat.view(B, self.dirs, H).transpose(0, 1), ccat.view(B, self.dirs, H).transpose(0, 1))
 
@@ -160,27 +231,32 @@ class _EmbedFn(torch.autograd.Function):
     gets none, units.py:352)."""
 
     @staticmethod
-    def forward(ctx, words, weight, pad, seed, offset, p):
+    def forward(ctx, words, weight, pad, seed, offset, p, base=None, det=False):
         lib = _lib.load()
+        ctx.det = det
         words = words.contiguous()
         B, L = words.shape
         E = weight.shape[1]
         out = ops.empty(L * B, E, dtype=torch.float32, device=weight.device)
-        _lib.check(lib.vln_embed_fwd(_p(words), _p(weight.detach()), _p(out), B, L, E, seed, offset, p, None, _lib.raw_stream()),
+        _lib.check(lib.vln_embed_fwd(_p(words), _p(weight.detach()), _p(out), B, L, E, seed, offset, p, base, _lib.raw_stream()),
                    "vln_embed_fwd")
         ctx.save_for_backward(words, weight)
-        ctx.cfg = (B, L, E, pad, seed, offset, p)
+        ctx.cfg = (B, L, E, pad, seed, offset, p, base)
         return out
 
     @staticmethod
     def backward(ctx, dx):
         words, weight = ctx.saved_tensors
-        B, L, E, pad, seed, offset, p = ctx.cfg
+        B, L, E, pad, seed, offset, p, base = ctx.cfg
         dE = torch.zeros_like(weight)
         lens32 = torch.full((B,), L, dtype=torch.int32, device=weight.device)
-        _lib.check(_lib.load().vln_embed_bwd(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, -1 if pad is None else pad,
-                                             seed, offset, p, None, _lib.raw_stream()), "vln_embed_bwd")
-        return None, dE, None, None, None, None
+        if ctx.det and E <= 1024:           # fixed summation order, no float atomics (SpeakerDecoder.deterministic_embedding_grad)
+            _lib.check(_lib.load().vln_embed_bwd_det(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, weight.shape[0],
+                                                     -1 if pad is None else pad, seed, offset, p, base, _lib.raw_stream()), "vln_embed_bwd_det")
+        else:
+            _lib.check(_lib.load().vln_embed_bwd(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, -1 if pad is None else pad,
+                                                 seed, offset, p, base, _lib.raw_stream()), "vln_embed_bwd")
+        return None, dE, None, None, None, None, None, None
 
 
 def _rename_lstm_keys(module: nn.Module, names):
@@ -232,26 +308,26 @@ class SpeakerEncoder(nn.Module, _Seeded):
         """action_embeds [B, Lp, F], feature [B, Lp, 36, F] (both mutated in place by the feature dropout like the
         reference, units.py:322,331) -> context [B, Lp, hidden]."""
         _need_gpu(action_embeds, "SpeakerEncoder")
-        off = self._next()
+        off, base = self._next(), self._drop_base()
         p, pf = (self.drop_ratio, self.feat_drop_ratio) if self.training else (0.0, 0.0)
         F, ANG = self.feature_size, self.angle_feat_size
         B, Lp, _ = action_embeds.shape
         x = action_embeds
         if not already_dropfeat and pf > 0:
             xc = x if x.is_contiguous() else x.contiguous()
-            ops.feat_dropout_inplace(xc, F - ANG, ANG, self.dropout_seed, off + 0, pf)
+            ops.feat_dropout_inplace(xc, F - ANG, ANG, self.dropout_seed, off + 0, pf, base=base)
             if xc is not x:
                 x.copy_(xc)
             fc = feature if feature.is_contiguous() else feature.contiguous()
-            ops.feat_dropout_inplace(fc, F - ANG, ANG, self.dropout_seed, off + 1, pf)
+            ops.feat_dropout_inplace(fc, F - ANG, ANG, self.dropout_seed, off + 1, pf, base=base)
             if fc is not feature:
                 feature.copy_(fc)
         ctx, _ = self.lstm(x)
-        ctx = Fh.dropout(ctx.contiguous(), p, self.training, self.dropout_seed, off + 2)
+        ctx = Fh.dropout(ctx.contiguous(), p, self.training, self.dropout_seed, off + 2, base)
         x, _ = self.attention_layer(ctx.view(B * Lp, self.hidden_size), feature.reshape(B * Lp, -1, F))
-        x = Fh.dropout(x.view(B, Lp, -1), p, self.training, self.dropout_seed, off + 3)
+        x = Fh.dropout(x.view(B, Lp, -1), p, self.training, self.dropout_seed, off + 3, base)
         x, _ = self.post_lstm(x)
-        return Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 4)
+        return Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 4, base)
 
 
 class SpeakerDecoder(nn.Module, _Seeded):
@@ -269,6 +345,7 @@ class SpeakerDecoder(nn.Module, _Seeded):
         self.baseline_projection = nn.Sequential(nn.Linear(hidden_size, 128), nn.ReLU(), nn.Dropout(dropout_ratio),
                                                  nn.Linear(128, 1))
         self._init_seed(0x5DEC)
+        self.deterministic_embedding_grad = False      # True: the embedding gradient in a fixed summation order (no float atomics)
         _rename_lstm_keys(self, ("lstm",))
         self.set_compute_dtype(compute_dtype)
 
@@ -282,20 +359,21 @@ class SpeakerDecoder(nn.Module, _Seeded):
         """words [Bw, Lw] int64, ctx [B, Lp, H], ctx_mask [B, Lp] (True = masked), h0/c0 [1, Bw, H]
         -> (logit [Bw, Lw, vocab], h1, c1).  Bw may be a multiple of B (beam search), units.py:375-376."""
         _need_gpu(ctx, "SpeakerDecoder")
-        off = self._next()
+        off, base = self._next(), self._drop_base()
         p = self.drop_ratio if self.training else 0.0
         H = self.hidden_size
         Bw, Lw = words.shape
         # embedding rows + dropout in one launch, written in the time-major layout the recurrence reads (vln_embed_fwd)
-        emb_tm = _EmbedFn.apply(words, self.embedding.weight, self.embedding.padding_idx, self.dropout_seed, off + 0, p)
+        emb_tm = _EmbedFn.apply(words, self.embedding.weight, self.embedding.padding_idx, self.dropout_seed, off + 0, p, base,
+                                self.deterministic_embedding_grad)
         x, (h1, c1) = self.lstm(emb_tm, (h0, c0), time_major=(Bw, Lw))
-        x = Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 1)
+        x = Fh.dropout(x.contiguous(), p, self.training, self.dropout_seed, off + 1, base)
         n = Bw * Lw
         mult = n // ctx.size(0)
         ctx_e = ctx.unsqueeze(1).expand(-1, mult, -1, -1).contiguous().view(n, -1, H)
         mask_e = ctx_mask.unsqueeze(1).expand(-1, mult, -1).contiguous().view(n, -1) if ctx_mask is not None else None
         x, _ = self.attention_layer(x.view(n, H), ctx_e, mask=mask_e)
-        x = Fh.dropout(x.view(Bw, Lw, H), p, self.training, self.dropout_seed, off + 2)
+        x = Fh.dropout(x.view(Bw, Lw, H), p, self.training, self.dropout_seed, off + 2, base)
         logit = Fh.linear(x.view(n, H), self.projection.weight, self.projection.bias, ops.ACT_NONE, self.compute_dtype).view(Bw, Lw, -1)
         return logit, h1, c1
 
@@ -338,17 +416,18 @@ class Speaker:
     def _zero_state(self, B, dev):
         return (torch.zeros(1, B, self.rnn_dim, device=dev), torch.zeros(1, B, self.rnn_dim, device=dev))
 
-    def teacher_forcing(self, can_feats, img_feats, lengths, insts, train: bool = True, for_listener: bool = False):
+    def teacher_forcing(self, can_feats, img_feats, lengths, insts, train: bool = True, for_listener: bool = False, ctx_mask=None):
         """speaker.py:235-290.  insts [B, Lw] int64 (<BOS> w1 .. <EOS> <PAD>..).  train -> mean CE over the non-pad
         targets; for_listener -> the un-reduced [B, Lw-1] losses (beam-search scoring); eval -> (loss, word_accu,
-        sent_accu)."""
+        sent_accu).  ctx_mask: `length2mask(lengths)` already on the device (a captured iteration cannot copy it there)."""
         from . import losses
         self._mode(train)
         dev = can_feats.device
         B = can_feats.shape[0]
         ctx = self.encoder(can_feats, img_feats, lengths)
         h_t, c_t = self._zero_state(B, dev)
-        ctx_mask = length2mask(lengths, dev, ctx.shape[1])
+        if ctx_mask is None:
+            ctx_mask = length2mask(lengths, dev, ctx.shape[1])
         logits, _, _ = self.decoder(insts, ctx, ctx_mask, h_t, c_t)                   # [B, Lw, vocab]
         Lw, V = logits.shape[1], logits.shape[2]
         flat = logits[:, :-1].reshape(B * (Lw - 1), V)                                # -1 for aligning (speaker.py:270)

@@ -582,26 +582,64 @@ class FollowerIteration(_GraphedIteration):
         return loss
 
 
-class SpeakerIteration:
+class SpeakerIteration(_GraphedIteration):
     """The speaker's training iteration (agent/speaker.py:75-87: teacher_forcing -> backward -> clip 40 per module -> two Adam) at
     the configured size: RNN_DIM 512, bidirectional encoder over paths of up to 7 viewpoints x 36 x 2176 views, WEMB 256,
     vocabulary 992, 80-token instructions, DROPOUT 0.6 / FEAT_DROPOUT 0.3.
 
-    batch: `can` [B, Lp, F] (the taken views), `img` [B, Lp, 36, F], `lengths` [B] (CPU), `insts` [B, Lw]."""
+    batch: `can` [B, Lp, F] (the taken views), `img` [B, Lp, 36, F], `lengths` [B] (CPU), `insts` [B, Lw].
+    graph=True (round 6): dropout offsets and the three recurrences' launch sequences come from a runtime.DeviceClock, the batch
+    lives at fixed addresses (`load`: also the path mask, which the eager form builds on the host every iteration), and
+    `capture()` / `replay()` run the iteration as ONE hipGraph."""
+
+    rollout_wgrads = False
 
     def __init__(self, dev, dtype, *, enc=None, dec=None, vocab=992, wemb=256, rnn=512, feature_size=2176, angle_size=128,
-                 drop=0.6, feat_drop=0.3, lr=1e-4, clip_norm=CLIP):
+                 drop=0.6, feat_drop=0.3, lr=1e-4, clip_norm=CLIP, graph=False):
         self.dev, self.dtype = dev, dtype
         self.enc = enc if enc is not None else SpeakerEncoder(feature_size, rnn, drop, True, angle_size, feat_drop, compute_dtype=dtype).to(dev).train()
         self.dec = dec if dec is not None else SpeakerDecoder(vocab, wemb, 0, rnn, drop, compute_dtype=dtype).to(dev).train()
         self.speaker = Speaker(self.enc, self.dec)
         self.opt_e = optim.FusedAdam([list(self.enc.parameters())], lr=lr, clip_norm=clip_norm)
         self.opt_d = optim.FusedAdam([list(self.dec.parameters())], lr=lr, clip_norm=clip_norm)
+        if self._make_clock(dev, graph, self.enc, self.dec) is not None:
+            self.opt_e.use_clock(self.clock); self.opt_d.use_clock(self.clock)
 
-    def iteration(self, batch):
+    def load(self, batch):
+        """The batch at fixed addresses + the path mask of `lengths` on the device (speaker.length2mask)."""
+        from .speaker import length2mask
+        mask = length2mask(batch["lengths"], self.dev, batch["can"].shape[1])
+        if self.live is None:
+            self.live = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            self.live["ctx_mask"] = mask
+            return self.live
+        for k in ("can", "img", "insts"):
+            self.live[k].copy_(batch[k], non_blocking=True)
+        self.live["lengths"] = batch["lengths"]
+        self.live["ctx_mask"].copy_(mask, non_blocking=True)
+        return self.live
+
+    def iteration(self, batch=None):
+        if batch is not None and batch is not self.live:
+            if self.clock is None and self.live is None:          # the eager form of rounds 1-5: no copy of the batch, no clock
+                return self._eager(batch)
+            self.load(batch)
+        return self._iteration()
+
+    def _eager(self, b):
         self.opt_e.zero_grad(); self.opt_d.zero_grad()
         # the feature dropout works in place (units.py:322,331): a training loop hands over fresh feature tensors every batch
-        loss = self.speaker.teacher_forcing(batch["can"].clone(), batch["img"].clone(), batch["lengths"], batch["insts"], train=True)
+        loss = self.speaker.teacher_forcing(b["can"].clone(), b["img"].clone(), b["lengths"], b["insts"], train=True)
+        loss.backward()
+        self.opt_e.step(); self.opt_d.step()
+        return loss
+
+    def _iteration(self):
+        b = self.live
+        if self.clock is not None:
+            self.clock.tick()
+        self.opt_e.zero_grad(); self.opt_d.zero_grad()
+        loss = self.speaker.teacher_forcing(b["can"].clone(), b["img"].clone(), b["lengths"], b["insts"], train=True, ctx_mask=b["ctx_mask"])
         loss.backward()
         self.opt_e.step(); self.opt_d.step()
         return loss

@@ -42,7 +42,7 @@ typedef void* vln_stream_t; /* hipStream_t */
 #define VLN_ACT_RELU 2
 #define VLN_ACT_ACCUM 8   /* flag, OR-ed onto an activation: the finished result is ADDED to the output (vln_linear_fwd: Y += ...) */
 
-int vln_abi_version(void);     /* 18 */
+int vln_abi_version(void);     /* 19 */
 /* sizeof(struct vln_<name>) as THIS library was compiled, -1 for an unknown name: a binding checks its struct mirrors against
  * it when it loads the library (a mirror that is one field short makes the kernels read wild pointers). */
 int64_t vln_struct_size(const char* name);
@@ -288,7 +288,7 @@ int vln_scale_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int ro
                       uint64_t offset, float p, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/, vln_stream_t s);
 /* EnvDropDecoder feature dropout, in place on x[..., :img] (policy.py:226-231); optional bf16 copy of x */
 int vln_feat_dropout_inplace(void* x, int xtype, int64_t rows, int img, int angle, uint64_t seed, uint64_t offset,
-                             float p, void* copy_bf16, vln_stream_t s);
+                             float p, void* copy_bf16, const uint64_t* offset_base_dev /*nullable, see vln_embed_fwd*/, vln_stream_t s);
 
 /* ---- optimizer step over flat buffers (engine/trainer.py:380-381,423-427): per-group clip_grad_norm (max_norms: HOST array
  * of ngroups norms, torch semantics, 0 = that group is not clipped -- the reference clips encoder and decoder at 40 and leaves
@@ -693,8 +693,12 @@ int vln_bm_to_tm(const float* bm, float* tm, int B, int L, int W, uint64_t seed,
  * INITIAL CONTENTS: the caller zero-fills sync_ws once, when it allocates it.  The granule exchange (data-tagged values) reads
  * stale tags as "not yet written" only if they are older launches' or zero; the arrival counters of the header are zeroed by
  * the library in front of the first counter-protocol launch on a buffer and whenever another protocol (vln_set_persistent)
- * or the counter-protocol forward touched it since -- afterwards the backward kernel leaves them zero itself. */
+ * or the counter-protocol forward touched it since -- afterwards the backward kernel leaves them zero itself.
+ * The library remembers that by the buffer's ADDRESS: memory that was freed and handed out again at an address the library has
+ * seen, or a header the caller wrote to, must be announced with vln_lstm_sync_ws_forget() before the next launch on it (the
+ * header then gets its fill again); EncoderLSTM does so for every buffer it has not used before. */
 int64_t vln_lstm_sync_ws_bytes(int B, int Hd, int dirs);
+int vln_lstm_sync_ws_forget(const void* sync_ws);
 /* The granule hand-off tags every exchanged value with a per-buffer LAUNCH SEQUENCE.  device_seq < 0: the library counts the
  * launches of a sync_ws on the host (and clears the exchange when the 24-bit count wraps).  device_seq >= 0: the sequence is
  * the 32-bit device word at byte vln_lstm_sync_seq_offset() of sync_ws PLUS device_seq, read by the kernel -- the launch

@@ -144,11 +144,16 @@ def speaker_batch(B=64, Lp=7, Lw=80, V=36, vocab=992, seed=2020):
 
 def run_speaker(B=64, Lp=7, Lw=80, V=36, vocab=992):
     """The speaker's training iteration (agent/speaker.py:75-87) at the configured size: trainers.SpeakerIteration."""
-    it = trainers.SpeakerIteration(dev, dt, vocab=vocab)
+    it = trainers.SpeakerIteration(dev, dt, vocab=vocab, graph=args.graph)
     batch = speaker_batch(B, Lp, Lw, V, vocab)
-    ms = timed(lambda: it.iteration(batch))
-    return dict(workload=f"speaker_teacher_forcing_B{B}_Lp{Lp}_Lw{Lw}_adam", ms_per_iteration=round(ms, 3), iterations_per_s=round(1e3 / ms, 2),
-                dtype=args.dtype)
+    if args.graph:
+        it.load(batch)
+        it.capture()
+        ms = timed(it.replay)
+    else:
+        ms = timed(lambda: it.iteration(batch))
+    return dict(workload=f"speaker_teacher_forcing_B{B}_Lp{Lp}_Lw{Lw}_adam" + ("_graph" if args.graph else ""), ms_per_iteration=round(ms, 3),
+                iterations_per_s=round(1e3 / ms, 2), dtype=args.dtype)
 
 
 def build_a2c(B=64, L=80, T_il=7, T_rl=10, C=8, store=None, graph=None, read_actions=True, seed=2020, chain_il=True):

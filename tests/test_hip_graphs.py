@@ -398,6 +398,50 @@ def test_other_agents_iteration_graph_equals_eager(vln, kind, rollout_wgrads):
             assert torch.equal(x, y), f"iteration {i}: parameters differ"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_speaker_iteration_as_one_graph_equals_eager(vln, dtype):
+    """Round 6: the speaker's teacher-forcing iteration (three sequence LSTMs, two attentions, vocabulary CE, clip, two Adam) on
+    device-clock dropout offsets and launch sequences, captured whole (trainers.SpeakerIteration.capture) and replayed over
+    changing batches: losses and parameters equal the eager iterations on the same clock bit for bit."""
+    dev = torch.device(DEV)
+    B, Lp, Lw, V, F, vocab = 8, 4, 12, 36, 96, 50
+
+    def batch(k):
+        g = torch.Generator().manual_seed(100 + k)
+        lengths = torch.randint(2, Lp + 1, (B,), generator=g); lengths[0] = Lp
+        wl = torch.randint(4, Lw + 1, (B,), generator=g); wl[0] = Lw
+        insts = torch.zeros(B, Lw, dtype=torch.long)
+        for b in range(B):
+            n = int(wl[b])
+            insts[b, 0] = 3; insts[b, 1:n - 1] = torch.randint(4, vocab, (n - 2,), generator=g); insts[b, n - 1] = 2
+        return dict(can=(torch.randn(B, Lp, F, generator=g).abs() * 0.5).to(dev), img=(torch.randn(B, Lp, V, F, generator=g).abs() * 0.5).to(dev),
+                    lengths=lengths, insts=insts.to(dev))
+
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(23)
+        it = vln.trainers.SpeakerIteration(dev, dtype, vocab=vocab, wemb=32, rnn=64, feature_size=F, angle_size=32, lr=1e-3, graph=True)
+        it.dec.deterministic_embedding_grad = True
+        out = []
+        it.load(batch(0))
+        if graph:
+            it.capture(warmup=3)
+        else:
+            for _ in range(3):
+                it.iteration()
+        for k in range(1, 5):
+            it.load(batch(k))
+            loss = it.replay() if graph else it.iteration()
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), it.opt_e.flat_p.clone(), it.opt_d.flat_p.clone()))
+        runs.append(out)
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], b[0]), f"iteration {i}: loss {float(a[0])} vs {float(b[0])}"
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), f"iteration {i}: parameters differ"
+    assert not torch.equal(runs[0][0][0], runs[0][1][0])          # (the batches do change)
+
+
 @pytest.mark.parametrize("graph", ["on", "off"])
 def test_bench_falls_back_to_per_step_launches_after_a_timeout(graph):
     """the sticky timeout raises VlnError from the next library entry, which bench.py did not catch -- the

@@ -590,6 +590,12 @@ def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
         assert enc.persistent_status() == 0
         return [p.grad.detach().clone() for p in enc.parameters()]
 
+    names = [n for n, _ in enc.named_parameters()]
+
+    def same(tag, got):
+        bad = [(n, float((a - b).abs().max())) for n, a, b in zip(names, ref, got) if not torch.equal(a, b)]
+        assert not bad, f"{tag}: gradients differ from the clean-workspace run: {bad}"
+
     ref = run()
     # (a) a fresh, larger workspace the library has never seen, header full of garbage (granule area zero as documented)
     need = int(lib.vln_lstm_sync_ws_bytes(B, H // 2, 2))
@@ -597,8 +603,7 @@ def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
     w[:2048] = 0x01010101
     w[32] = 0
     enc._sync_buf, enc._sync_mode = w, None
-    for a, b in zip(ref, run()):
-        assert torch.equal(a, b)
+    same("dirty header", run())
     # (b) mode 2 (counter forward + counter backward): a forward WITHOUT its backward leaves counters behind, then mode 1
     try:
         lib.vln_set_persistent(2)
@@ -607,10 +612,39 @@ def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
         torch.cuda.synchronize()
     finally:
         lib.vln_set_persistent(1)
-    for a, b in zip(ref, run()):
-        assert torch.equal(a, b)
-    for a, b in zip(ref, run()):                   # and the header it left itself needs no fill
-        assert torch.equal(a, b)
+    same("a foreign forward's counters", run())
+    same("its own header", run())                  # and the header it left itself needs no fill
+
+
+def test_fp32_weight_gradients_split_planes_against_the_exact_fp32_mfma(vln):
+    """Round 6: fp32 compute mode forms its weight gradients on the bf16 MFMA with both operands split hi + lo (three products, one
+    packed contraction per rollout) by default; `ops.set_wgrad_precision_fp32("exact")` keeps the fp32 MFMA of rounds 1-5.  The two
+    forms of every parameter gradient of an EnvDrop IL iteration agree to 5e-5 of the tensor's max (the oracle tests hold 1e-4
+    with the default)."""
+    from parity import check
+    dev_ = torch.device(DEV)
+    tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 3, 6, seed=4), dev_)
+    assert vln.ops.get_wgrad_precision_fp32() == "split"
+    res = {}
+    try:
+        for mode in ("split", "exact"):
+            vln.ops.set_wgrad_precision_fp32(mode)
+            torch.manual_seed(11)
+            ag = vln.trainers.EnvDropILIteration(dev_, torch.float32, 1)
+            ag.enc._calls = 0; ag.dec._step_counter = 0
+            ag.enc.deterministic_embedding_grad = True
+            ag.opt.lr = 0.0
+            loss = ag.iteration(tape)
+            torch.cuda.synchronize()
+            res[mode] = (loss.detach().clone(), {n: p.grad.detach().clone() for m in (ag.enc, ag.dec) for n, p in m.named_parameters()})
+    finally:
+        vln.ops.set_wgrad_precision_fp32("split")
+    assert torch.equal(res["split"][0], res["exact"][0])          # the forward does not depend on it
+    differ = 0
+    for n, g in res["exact"][1].items():
+        check(res["split"][1][n], g, 5e-5, f"grad[{n}] split planes vs exact fp32 MFMA")
+        differ += int(not torch.equal(res["split"][1][n], g))
+    assert differ > 0                                            # (the switch does select another kernel)
 
 
 def test_training_iteration_side_stream_overlap_is_transparent(vln):
