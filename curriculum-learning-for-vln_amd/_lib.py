@@ -244,7 +244,7 @@ SIGNATURES = {
     "vln_sgd_clip_step": (i32, [ptr, ptr, ptr, i32, ptr, ptr, f32, ptr, f32, ptr]),
     "vln_masked_ce_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i64, i32, ptr]),
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
-    "vln_masked_ce_mean_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
+    "vln_masked_ce_mean_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, i32, i32, i64, ptr, ptr]),
     "vln_masked_ce_mean_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
     "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, ptr, i32, ptr]),
     "vln_masked_ce_multi_bwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, i64, ptr]),

@@ -310,6 +310,28 @@ __global__ __launch_bounds__(256) void masked_ce_fwd_sum_kernel(CeArgs a, float*
   }
 }
 
+// the mean of LARGE problems (the speaker's 5120 x 992 word logits): masked_ce_fwd_kernel has left the per-row losses in `rows` (a
+// wave per row over the whole chip); one workgroup sums them and counts the rows with a target, in a fixed order
+__global__ __launch_bounds__(256) void masked_ce_mean_finish_kernel(const float* rows, const long long* target, int B, long ignore_index,
+                                                                    float* loss_sum) {
+  __shared__ float part[4];
+  __shared__ float cnt[4];
+  float acc = 0.f, n = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    acc += rows[b];
+    if (target[b] != ignore_index) n += 1.f;
+  }
+  acc = wave_sum(acc);
+  n = wave_sum(n);
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; cnt[threadIdx.x >> 6] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float c = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+    loss_sum[0] = ((part[0] + part[1]) + (part[2] + part[3])) / c;
+    loss_sum[1] = 1.f / c;
+  }
+}
+
 // dlogits[b,c] = dloss[b] * (p - onehot(target))   (0 for ignored rows; p = 0 at masked slots)
 // dloss_stride 0: one scalar upstream gradient for every row (the backward of the fused sum)
 // scale (nullable): one device scalar multiplied into every row's gradient (the 1 / count of the mean reduction)
@@ -1510,9 +1532,15 @@ extern "C" int vln_masked_ce_bwd(const float* probs, const int64_t* target, cons
 }
 // reduction = "mean" in the same launch: mean_out[0] = mean over the rows with a target, mean_out[1] = 1 / their count
 extern "C" int vln_masked_ce_mean_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask, float* mean_out,
-                                      float* probs, int B, int C, int64_t ignore_index, void* s) {
+                                      float* probs, int B, int C, int64_t ignore_index, float* rows_scratch, void* s) {
   if (!logits || !target || !mean_out || B <= 0 || C <= 0) { vln::set_error("vln_masked_ce_mean_fwd: bad args"); return VLN_ERR_ARG; }
   vln::CeArgs a{logits, (long)ld, (const long long*)target, cand_mask, nullptr, probs, nullptr, nullptr, nullptr, B, C, (long)ignore_index, 0};
+  if (rows_scratch && (long)B * C > VLN_CE_MEAN_ONE_LAUNCH_MAX) {     // one workgroup would walk B rows of C logits serially
+    a.loss = rows_scratch;
+    VLN_LAUNCH(vln::masked_ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, a);
+    VLN_LAUNCH(vln::masked_ce_mean_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)rows_scratch, (const long long*)target, B,
+               (long)ignore_index, mean_out);
+  } else
   VLN_LAUNCH(vln::masked_ce_fwd_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, mean_out, 1);
   VLN_CHECK_LAUNCH("masked_ce_mean_fwd");
   return VLN_OK;

@@ -331,7 +331,7 @@ class LinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         y = ops.linear_fwd(x2, SHADOWS.get(weight, "n", dtype), None if bias is None else bias.detach(), act)
         ctx.save_for_backward(x2, weight, y if act != ops.ACT_NONE else None)
-        ctx.act, ctx.dtype, ctx.has_bias, ctx.xshape = act, dtype, bias is not None, x.shape
+        ctx.act, ctx.dtype, ctx.has_bias, ctx.xshape, ctx.bias = act, dtype, bias is not None, x.shape, bias
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -345,10 +345,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_fwd(dy2, SHADOWS.get(weight, "t", ctx.dtype)).view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy2, x2)
+        if ctx.needs_input_grad[1]:           # (set_grad_in_place: added into weight.grad by the launch, autograd gets None)
+            g, acc = _gsink(weight)
+            dw = _gret(ops.linear_wgrad(dy2, x2, out=g, accumulate=acc), acc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)
+            g, acc = _gsink(ctx.bias)
+            db = _gret(ops.colsum(dy2, out=g, accumulate=acc), acc)
         return dx, dw, db, None, None
 
 

@@ -95,8 +95,9 @@ class _MaskedCEMean(torch.autograd.Function):
         probs = ops.empty(B, C, dtype=torch.float32, device=dev)
         out = ops.empty(2, dtype=torch.float32, device=dev)           # [mean, 1 / count]
         tgt = target if target.is_contiguous() else target.contiguous()
+        rows = ops.empty(B, dtype=torch.float32, device=dev) if B * C > 16384 else None      # (VLN_CE_MEAN_ONE_LAUNCH_MAX: see the header)
         st = _lib.load().vln_masked_ce_mean_fwd(lg.data_ptr(), lg.stride(0), tgt.data_ptr(), _p(_mask8(cand_mask)), out.data_ptr(),
-                                                probs.data_ptr(), B, C, ignore_index, _lib.raw_stream())
+                                                probs.data_ptr(), B, C, ignore_index, _p(rows), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_masked_ce_mean_fwd")
         ctx.save_for_backward(probs, tgt, out)

@@ -237,7 +237,9 @@ def linear_fwd_slabs(x, w, split=False, ws_floats: Optional[int] = None):
 
 def linear_wgrad(dy, x, out=None, accumulate=False, split_bf16=False):
     """dW[N,K] (+)= dy[Mt,N].T @ x[Mt,K].  split_bf16: both operands as bf16 hi + lo planes on the bf16 MFMA (three
-    products, fp32 accumulation) instead of the exact fp32 MFMA -- the bf16 compute mode's weight gradients."""
+    products, fp32 accumulation) instead of the exact fp32 MFMA -- the bf16 compute mode's weight gradients, and (round 6) the
+    fp32 compute mode's too unless `set_wgrad_precision_fp32("exact")`: the flag is then taken as set."""
+    split_bf16 = bool(split_bf16) or _WGRAD_F32[0] == 1
     lib = _lib.load()
     _req(dy, "dy"); _req(x, "x")
     Mt, N = dy.shape

@@ -53,6 +53,7 @@ class _LSTMSeqFn(torch.autograd.Function):
                                         _p(tanh_c), _p(hcat), _p(ccat), B, L, Hd, dirs, _p(h0), _p(c0),
                                         *owner._sync_ws(dev, B, Hd, dirs), seq, None, _lib.raw_stream()), "vln_lstm_seq_fwd")
         ctx.owner, ctx.dims, ctx.dt, ctx.f32_in, ctx.seq, ctx.wtype, ctx.sh = owner, (B, L, Hd, dirs), dt, f32_in, seq, wtype, sh
+        ctx.params = params
         ctx.save_for_backward(x_tm, hprev, cprev, act, tanh_c, lens32)
         ctx.set_materialize_grads(False)
         return y, hcat, ccat
@@ -81,12 +82,15 @@ class _LSTMSeqFn(torch.autograd.Function):
         I = x_tm.shape[1]
         for d in range(dirs):
             dg = dgates[:, d * 4 * Hd:(d + 1) * 4 * Hd]
-            g_ih, g_hh = ops.empty(4 * Hd, I, **f32), ops.empty(4 * Hd, Hd, **f32)
-            b1, b2 = ops.empty(4 * Hd, **f32), ops.empty(4 * Hd, **f32)
-            wb.add(dg, x_tm, g_ih, False)
-            wb.add(dg, hprev[d].view(L * B, Hd), g_hh, False)
-            cb.add(dg, b1, b2, False)
-            grads += [g_ih, g_hh, b1, b2]
+            # (functional.set_grad_in_place: the launches add into the parameters' .grad, autograd gets None)
+            (g_ih, a_ih), (g_hh, a_hh), (b1, a1), (b2, a2) = (Fh._gsink(p) for p in ctx.params[4 * d:4 * d + 4])
+            wb.add(dg, x_tm, g_ih, a_ih)
+            wb.add(dg, hprev[d].view(L * B, Hd), g_hh, a_hh)
+            if a1 == a2:
+                cb.add(dg, b1, b2, a1)
+            else:
+                cb.add(dg, b1, None, a1); cb.add(dg, b2, None, a2)
+            grads += [Fh._gret(g_ih, a_ih), Fh._gret(g_hh, a_hh), Fh._gret(b1, a1), Fh._gret(b2, a2)]
         wb.run()
         cb.run()
         dx = None
@@ -248,7 +252,9 @@ class _EmbedFn(torch.autograd.Function):
     def backward(ctx, dx):
         words, weight = ctx.saved_tensors
         B, L, E, pad, seed, offset, p, base = ctx.cfg
-        dE = torch.zeros_like(weight)
+        dE, acc = Fh._gsink(weight)               # (both kernels ADD into dE)
+        if not acc:
+            dE.zero_()
         lens32 = torch.full((B,), L, dtype=torch.int32, device=weight.device)
         if ctx.det and E <= 1024:           # fixed summation order, no float atomics (SpeakerDecoder.deterministic_embedding_grad)
             _lib.check(_lib.load().vln_embed_bwd_det(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, weight.shape[0],
@@ -256,7 +262,7 @@ class _EmbedFn(torch.autograd.Function):
         else:
             _lib.check(_lib.load().vln_embed_bwd(_p(words), _p(lens32), _p(dx.contiguous()), _p(dE), B, L, E, -1 if pad is None else pad,
                                                  seed, offset, p, base, _lib.raw_stream()), "vln_embed_bwd")
-        return None, dE, None, None, None, None, None, None
+        return None, Fh._gret(dE, acc), None, None, None, None, None, None
 
 
 def _rename_lstm_keys(module: nn.Module, names):
@@ -430,15 +436,17 @@ class Speaker:
             ctx_mask = length2mask(lengths, dev, ctx.shape[1])
         logits, _, _ = self.decoder(insts, ctx, ctx_mask, h_t, c_t)                   # [B, Lw, vocab]
         Lw, V = logits.shape[1], logits.shape[2]
-        flat = logits[:, :-1].reshape(B * (Lw - 1), V)                                # -1 for aligning (speaker.py:270)
-        tgt = insts[:, 1:].reshape(-1)                                                # "1:" ignores <BOS> (speaker.py:271)
-        per_word = losses.masked_cross_entropy(flat, tgt, None, "none", ignore_index=self.pad)
+        # "-1 for aligning" / "1: ignores <BOS>" (speaker.py:270-271) WITHOUT the copy of logits[:, :-1]: every position is scored, the
+        # last one against <PAD> -- ignored by the loss, zero gradient, exactly what the slice's backward would have filled in
+        flat = logits.reshape(B * Lw, V)
+        tgt = torch.cat((insts[:, 1:], insts.new_full((B, 1), self.pad)), 1).reshape(-1)
+        if train and not for_listener:             # mean over the non-pad targets inside the launch (speaker.py:272-273)
+            return losses.masked_cross_entropy(flat, tgt, None, "mean", ignore_index=self.pad)
+        per_word = losses.masked_cross_entropy(flat, tgt, None, "none", ignore_index=self.pad).view(B, Lw)[:, :-1]
         if for_listener:
-            return per_word.view(B, Lw - 1)
-        n_words = (tgt != self.pad).sum()
+            return per_word
+        n_words = (insts[:, 1:] != self.pad).sum()
         loss = per_word.sum() / n_words.to(per_word.dtype)
-        if train:
-            return loss
         predict = logits.detach().argmax(dim=2)                                       # [B, Lw]
         gt_mask = insts != self.pad
         correct = (predict[:, :-1] == insts[:, 1:]) & gt_mask[:, 1:]

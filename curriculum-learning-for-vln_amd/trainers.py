@@ -622,9 +622,11 @@ class SpeakerIteration(_GraphedIteration):
     def iteration(self, batch=None):
         if batch is not None and batch is not self.live:
             if self.clock is None and self.live is None:          # the eager form of rounds 1-5: no copy of the batch, no clock
-                return self._eager(batch)
+                with rollout_wgrads(False):
+                    return self._eager(batch)
             self.load(batch)
-        return self._iteration()
+        with rollout_wgrads(False):                               # (parameter gradients added into .grad by the launches themselves)
+            return self._iteration()
 
     def _eager(self, b):
         self.opt_e.zero_grad(); self.opt_d.zero_grad()

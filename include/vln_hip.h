@@ -324,8 +324,11 @@ int vln_masked_ce_bwd(const float* probs, const int64_t* target, const float* dl
                       int B, int C, int64_t ignore_index, vln_stream_t s);
 /* ABI v16: reduction = "mean" (nn.CrossEntropyLoss(ignore_index)'s default, follower.py:62) in the same launch: mean_out[0] = the
  * mean over the rows with a target, mean_out[1] = 1 / their count (0 rows: nan, as torch); the backward multiplies it in. */
+#define VLN_CE_MEAN_ONE_LAUNCH_MAX 16384     /* B * C up to which the mean is formed by ONE workgroup in one launch (the decoders' B x <= 16 logits) */
+/* rows_scratch (nullable, [B] floats): larger problems (the speaker's [B * Lw, vocab] word logits) take a wave per row over the whole
+ * chip + a finishing launch when it is given; without it they run on the one workgroup all the same (slow, correct). */
 int vln_masked_ce_mean_fwd(float* logits, int64_t ld, const int64_t* target, const uint8_t* cand_mask /*nullable*/, float* mean_out /*[2]*/,
-                           float* probs /*[B,C]*/, int B, int C, int64_t ignore_index, vln_stream_t s);
+                           float* probs /*[B,C]*/, int B, int C, int64_t ignore_index, float* rows_scratch, vln_stream_t s);
 int vln_masked_ce_mean_bwd(const float* probs, const int64_t* target, const float* dloss /*[1]*/, const float* inv_count /*mean_out + 1*/,
                            float* dlogits, int B, int C, int64_t ignore_index, vln_stream_t s);
 
