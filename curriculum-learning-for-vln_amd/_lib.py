@@ -147,7 +147,8 @@ class FollowerStep(C.Structure):
     _fields_ = ([(n, ptr) for n in ("img", "a_prev", "cands", "h0", "c0", "ctx", "ctx_mask", "logit", "h1", "c1", "word_w", "view_w",
                                     "tq", "keys", "vlog", "xcat", "act", "tanh_c1", "tq2", "tcat", "grounded", "target", "q", "context",
                                     "gates", "dots", "ws")]
-                + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32), ("offset_base_dev", ptr)])
+                + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32), ("offset_base_dev", ptr), ("attn_sync", ptr),
+                   ("attn_sync_bytes", i64)])
 
 
 class FollowerGrads(C.Structure):
@@ -246,8 +247,8 @@ SIGNATURES = {
     "vln_masked_ce_bwd": (i32, [ptr, ptr, ptr, i64, ptr, i32, i32, i64, ptr]),
     "vln_masked_ce_mean_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, i32, i32, i64, ptr, ptr]),
     "vln_masked_ce_mean_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
-    "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, ptr, i32, ptr]),
-    "vln_masked_ce_multi_bwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, i64, ptr]),
+    "vln_masked_ce_multi_fwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, ptr, i32, ptr, ptr]),
+    "vln_masked_ce_multi_bwd": (i32, [C.POINTER(CeStep), i32, i32, i64, f32, ptr, i64, ptr, ptr]),
     "vln_attn_dctx_deferred_drop": (i32, [ptr, ptr, ptr, i64, ptr, i64, i32, ptr, i32, i32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
     "vln_pe_dropout": (i32, [ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),
     "vln_monitor_head_fwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, u64, u64, f32, ptr]),

@@ -61,7 +61,8 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
     SlabArea ar{io->ws, (long)io->ws_floats};
     SlabVec vq;
     RUN(gemm_nt_to_consumer(st, ar, io->tq, D, w->w_v_t, wt, D, io->keys, F, B, F, D, nullptr, &vq));
-    RUN(attn_fwd_rows_sv(st, io->img, W_F32, vq, nullptr, 0, nullptr, io->view_w, io->xcat + A, XK, io->dots, B, V, F));
+    RUN(attn_fwd_rows_sv(st, io->img, W_F32, vq, nullptr, 0, nullptr, io->view_w, io->xcat + A, XK, io->dots, B, V, F, io->attn_sync,
+                         io->attn_sync_bytes));
   }
   {   // xcat = [drop(a_prev) | drop(pano), in place | h0]: the dropout over cat(a_prev, pano) (policy.py:49-51) in the launch that
       // copies the two blocks (they were a launch each)
@@ -85,7 +86,8 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   }
   // (3) text attention + tanh(W_out [wc ; drop(h1)])
   RUN(gemm_nt(st, io->tcat + H, 2 * H, w->w_tin, wt, H, io->tq2, H, B, H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(attn_fwd_rows(st, io->ctx, W_F32, io->tq2, H, io->ctx_mask, io->word_w, io->tcat, 2 * H, io->dots, B, L, H));
+  RUN(attn_fwd_rows_sv(st, io->ctx, W_F32, plain_vec(io->tq2, H), nullptr, 0, io->ctx_mask, io->word_w, io->tcat, 2 * H, io->dots, B, L, H,
+                       io->attn_sync, io->attn_sync_bytes));
   RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, wt, 2 * H, io->grounded, H, B, H, 2 * H, nullptr, ACT_TANH, io->ws, io->ws_floats, nullptr));
   // (4) candidate scores: logit = context . (target (.) w_out) + b_out
   RUN(gemm_nt(st, io->grounded, H, w->w_hid, wt, H, io->target, D, B, D, H, w->b_hid, ACT_NONE, io->ws, io->ws_floats, nullptr));
@@ -126,7 +128,8 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
   // (3) grounded = tanh(W_out tcat)
   RUN(vln_ew(2, dgr, H, io->grounded, H, 0, dz, H, B, H, s));
   RUN(gemm_nt(st, dz, H, w->w_tout_t, wt, H, dtcat, 2 * H, B, 2 * H, H, nullptr, ACT_NONE, io->ws, io->ws_floats, nullptr));   // -> wc | drop(h1)
-  RUN(attn_bwd_rows(st, io->ctx, W_F32, io->word_w, dtcat, 2 * H, g->dww_ext, dtq2, H, dl_t, io->dots, B, L, H));
+  RUN(attn_bwd_rows_sv(st, io->ctx, W_F32, io->word_w, plain_vec(dtcat, 2 * H), nullptr, 0, g->dww_ext, dtq2, H, dl_t, io->dots, B, L, H,
+                       io->attn_sync, io->attn_sync_bytes));
   if (g->dctx_term) {
     *g->dctx_term = vln_dctx_term{io->word_w, dl_t, dtcat, io->tq2, 2L * H, H, 0, 0, 0.f, 0.f};
   } else if (g->dctx) {
@@ -162,8 +165,11 @@ extern "C" int vln_follower_step_bwd(const vln_follower_dims* d, const vln_follo
     }
   }
   // (1) panorama attention: pano = sum_v alpha_v img_v, alpha = softmax(keys . tq); rv = sum_v dl_v img_v comes out of the same pass
-  RUN(attn_dot(st, io->img, W_F32, dxcat + A, XK, dalpha, B, V, F));
-  RUN(attn_bwd(st, io->img, W_F32, io->view_w, dalpha, g->dvw_ext, nullptr, 0, nullptr, 0, rv, F, nullptr, dl_v, B, V, F));
+  // (round 6: the dots and the softmax backward in ONE launch, on four workgroups per episode when the exchange buffer is given; the
+  // two-launch pair of rounds 1-5 when the shape fits neither one-launch form)
+  (void)dalpha;
+  RUN(attn_bwd_rows_sv(st, io->img, W_F32, io->view_w, plain_vec(dxcat + A, XK), nullptr, 0, g->dvw_ext, rv, F, dl_v, io->dots, B, V, F,
+                       io->attn_sync, io->attn_sync_bytes));
   // logits_v = img_v . (W_v^T tq): d(W_v^T tq) = sum_v dl_v img_v = rv, so d tq = rv W_v^T (a B-row product) and d W_v = tq^T rv
   // (below); d b_v is exactly 0 (b_v . tq shifts every view's logit of an episode alike)
   (void)tqs;

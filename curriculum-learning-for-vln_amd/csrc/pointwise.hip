@@ -429,6 +429,39 @@ struct CeMultiArgs {
   float* probs[VLN_CE_MAX_STEPS]; float* dlogits[VLN_CE_MAX_STEPS]; int C[VLN_CE_MAX_STEPS]; int ld[VLN_CE_MAX_STEPS];
   int T, B; long ignore_index;
 };
+// Mean PER STEP (nn.CrossEntropyLoss(ignore_index)'s default reduction applied to every step's batch, then summed over the steps:
+// follower.py:62,123-139): loss = scale * sum_t (sum_b CE_tb / n_t), n_t = step t's rows with a target; inv_counts[t] = 1 / n_t is left
+// for the backward.  One workgroup; the row losses go through LDS, thread t sums step t's rows in episode order (fixed order).
+constexpr int kCeMeanRowsMax = 8192;
+__global__ __launch_bounds__(256) void masked_ce_multi_mean_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale, float* inv_counts) {
+  __shared__ float rowloss[kCeMeanRowsMax];
+  __shared__ float stepmean[VLN_CE_MAX_STEPS];
+  const int rows = m.T * m.B;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int t = r / m.B, b = r - t * m.B;
+    CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
+             m.ignore_index, 0};
+    rowloss[r] = (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m.T) {
+    const int t = threadIdx.x;
+    float acc = 0.f, n = 0.f;
+    for (int b = 0; b < m.B; ++b) {
+      acc += rowloss[t * m.B + b];
+      if (m.target[t][b] != m.ignore_index) n += 1.f;
+    }
+    stepmean[t] = acc / n;                       // (no row with a target: 0 / 0 = nan, as torch)
+    inv_counts[t] = 1.f / n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int t = 0; t < m.T; ++t) v += stepmean[t];
+    v *= scale;
+    loss_sum[0] = accumulate ? loss_sum[0] + v : v;
+  }
+}
 __global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale) {
   __shared__ float part[4];
   float acc = 0.f;
@@ -470,16 +503,18 @@ __global__ __launch_bounds__(256) void masked_ce_multi_rows_kernel(CeMultiArgs m
   }
 }
 // dloss_stride 0: one upstream scalar (the summed form); 1: one per episode (the per-episode form)
-__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss, int dloss_stride, float scale) {
+__global__ __launch_bounds__(256) void masked_ce_multi_bwd_kernel(CeMultiArgs m, const float* dloss, int dloss_stride, float scale,
+                                                                  const float* inv_counts) {
   const int t = blockIdx.x;
   const int C = m.C[t];
   const float* probs = m.probs[t];
   const long long* target = m.target[t];
   float* dl = m.dlogits[t];
+  const float sc = inv_counts ? scale * inv_counts[t] : scale;          // (the mean per step: 1 / n_t, left by the forward)
   for (int e = threadIdx.x; e < m.B * C; e += 256) {
     const int b = e / C, c = e - b * C;
     const long tg = target[b];
-    dl[e] = (tg == m.ignore_index) ? 0.f : dloss[b * dloss_stride] * scale * (probs[e] - (c == tg ? 1.f : 0.f));
+    dl[e] = (tg == m.ignore_index) ? 0.f : dloss[b * dloss_stride] * sc * (probs[e] - (c == tg ? 1.f : 0.f));
   }
 }
 }  // namespace vln
@@ -1605,11 +1640,15 @@ static int ce_multi_fill(vln::CeMultiArgs& m, const vln_ce_step* steps, int T, i
   return VLN_OK;
 }
 extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, float* loss_sum,
-                                       float* loss_rows, int accumulate, void* s) {
+                                       float* loss_rows, int accumulate, float* inv_counts, void* s) {
   vln::CeMultiArgs m{};
   if (!loss_sum == !loss_rows) { vln::set_error("vln_masked_ce_multi_fwd: exactly one of loss_sum / loss_rows"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, false, "vln_masked_ce_multi_fwd: bad args");
   if (rc) return rc;
+  if (inv_counts) {
+    if (!loss_sum || (long)T * B > vln::kCeMeanRowsMax) { vln::set_error("vln_masked_ce_multi_fwd: the mean per step needs loss_sum and T * B <= %d", vln::kCeMeanRowsMax); return VLN_ERR_ARG; }
+    VLN_LAUNCH(vln::masked_ce_multi_mean_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale, inv_counts);
+  } else
   if (loss_sum)
     VLN_LAUNCH(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
   else
@@ -1619,12 +1658,12 @@ extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, i
   return VLN_OK;
 }
 extern "C" int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
-                                       int64_t dloss_stride, void* s) {
+                                       int64_t dloss_stride, const float* inv_counts, void* s) {
   vln::CeMultiArgs m{};
   if (!dloss || (dloss_stride != 0 && dloss_stride != 1)) { vln::set_error("vln_masked_ce_multi_bwd: bad args"); return VLN_ERR_ARG; }
   const int rc = ce_multi_fill(m, steps, T, B, ignore_index, true, "vln_masked_ce_multi_bwd: bad args");
   if (rc) return rc;
-  VLN_LAUNCH(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, (int)dloss_stride, scale);
+  VLN_LAUNCH(vln::masked_ce_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m, dloss, (int)dloss_stride, scale, inv_counts);
   VLN_CHECK_LAUNCH("masked_ce_multi_bwd");
   return VLN_OK;
 }

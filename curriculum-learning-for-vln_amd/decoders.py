@@ -120,12 +120,21 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
         self._init_seed(0xF0110)
         self.fused_step = True            # False: every operator its own autograd node (A/B, and the reference for the fused node)
         self.c_step = True                # the fused node as ONE C call each way (csrc/follower.hip); False: launches driven from Python
+        self.split_attention = True       # the C-call step's two attentions on four workgroups per episode (B * 4 <= the device's CUs)
+        self._attn_sync = None
         self.set_compute_dtype(compute_dtype)
 
     def set_compute_dtype(self, dt):
         self.compute_dtype = dt
         for m in (self.text_attn, self.visual_attn, self.decode_action):
             m.compute_dtype = dt
+
+    def _attn_sync_buf(self, dev, B):
+        w = self._attn_sync
+        if w is None or w[0].device != dev or w[1] < B:
+            n = int(_lib.load().vln_attn_sync_bytes(B))
+            w = self._attn_sync = (torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev), B)
+        return w[0]
 
     def forward(self, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx, ctx_mask=None):
         _need_gpu(img_feature, "AttnDecoderLSTM")
@@ -147,8 +156,11 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
                                    (self.text_attn.linear_out.weight, "n", dt_), (self.text_attn.linear_out.weight, "t", dt_),
                                    (ds.linear_act.weight, "n", dt_), (ds.linear_hid.weight, "n", dt_), (ds.linear_hid.weight, "t", dt_)],
                                   [(self.lstm.weight_ih, self.lstm.weight_hh, dt_, False), (self.lstm.weight_ih, self.lstm.weight_hh, dt_, True)])
+            cfg = (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ())
+            if self.c_step and self.split_attention:      # the exchange buffer of the four-workgroups-per-episode attentions (round 6)
+                cfg = cfg[:5] + (self._drop_base(), self._attn_sync_buf(img_feature.device, img_feature.shape[0]))
             logit, h_new, c_new, word_w, view_w = core.apply(
-                (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ()), ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
+                cfg, ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,
                 self.lstm.weight_ih, self.lstm.weight_hh, self.lstm.bias_ih, self.lstm.bias_hh,
                 self.text_attn.linear_in.weight, self.text_attn.linear_out.weight,

@@ -202,7 +202,8 @@ def monitor_mixed_loss(logits: torch.Tensor, target: torch.Tensor, cand_mask: Op
 class _RolloutCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *logits):
-        targets, masks, ignore_index, scale, per_sample = meta
+        targets, masks, ignore_index, scale, per_sample = meta[:5]
+        step_mean = len(meta) > 5 and bool(meta[5])
         T, B = len(logits), logits[0].shape[0]
         dev = logits[0].device
         lib = _lib.load()
@@ -223,14 +224,16 @@ class _RolloutCE(torch.autograd.Function):
             m8 = _mask8(mk)
             keep.append((lg, tg, m8, probs))
             steps.append(_lib.CeStep(lg.data_ptr(), lg.stride(0), tg.data_ptr(), _p(m8), probs.data_ptr(), None, C_))
+        inv = ops.empty(T, dtype=torch.float32, device=dev) if step_mean else None       # 1 / (rows with a target) per step
         for i in range(0, T, _lib.CE_MAX_STEPS):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
             st = lib.vln_masked_ce_multi_fwd(arr, len(chunk), B, ignore_index, scale, None if per_sample else out.data_ptr(),
-                                             out.data_ptr() if per_sample else None, 1 if i else 0, _lib.raw_stream())
+                                             out.data_ptr() if per_sample else None, 1 if i else 0,
+                                             None if inv is None else inv.data_ptr() + 4 * i, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_fwd")
-        ctx.keep, ctx.ignore_index, ctx.scale, ctx.per_sample = keep, ignore_index, scale, per_sample
+        ctx.keep, ctx.ignore_index, ctx.scale, ctx.per_sample, ctx.inv = keep, ignore_index, scale, per_sample, inv
         ctx.recs = recs                                                   # their logit branch of the backward can be batched too
         return out
 
@@ -252,6 +255,8 @@ class _RolloutCE(torch.autograd.Function):
         # the step backward ADDS to the branch's result (envdrop.hip) -- nothing is dropped or counted twice.
         if batched and any(r.dhtd_ext for r in recs):
             batched = False
+        if batched and ctx.inv is not None:
+            batched = False                     # (the decoder's rollout-wide branch forms sum-reduction d logits only)
         if batched and not ctx.per_sample:
             # every consumer of these d logits is the decoder's rollout-wide logit branch: it forms them on the fly from the
             # saved probabilities (no d logits tensors, no launch of its own here)
@@ -268,7 +273,7 @@ class _RolloutCE(torch.autograd.Function):
             chunk = steps[i:i + _lib.CE_MAX_STEPS]
             arr = (_lib.CeStep * len(chunk))(*chunk)
             st = lib.vln_masked_ce_multi_bwd(arr, len(chunk), B, ctx.ignore_index, ctx.scale, dloss.data_ptr(), 1 if ctx.per_sample else 0,
-                                             _lib.raw_stream())
+                                             None if ctx.inv is None else ctx.inv.data_ptr() + 4 * i, _lib.raw_stream())
             if st:
                 _lib.check(st, "vln_masked_ce_multi_bwd")
         ctx.keep = None
@@ -311,8 +316,16 @@ class RolloutCE:
             raise ValueError("RolloutCE.per_sample: no steps recorded")
         return self._run(scale, True)
 
-    def _run(self, scale, per_sample):
-        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index, float(scale), bool(per_sample)), *self.logits)
+    def mean_per_step(self, scale: float = 1.0) -> torch.Tensor:
+        """sum_t CrossEntropyLoss(ignore_index)(logits_t, target_t) with the criterion's DEFAULT (mean) reduction on every step's batch --
+        the Speaker-Follower agent's loss (follower.py:62,123-139) -- in the same single launch each way."""
+        if not self.logits:
+            raise ValueError("RolloutCE.mean_per_step: no steps recorded")
+        return self._run(scale, False, True)
+
+    def _run(self, scale, per_sample, step_mean=False):
+        out = _RolloutCE.apply((tuple(self.targets), tuple(self.masks), self.ignore_index, float(scale), bool(per_sample), bool(step_mean)),
+                               *self.logits)
         self.logits, self.targets, self.masks = [], [], []
         return out
 

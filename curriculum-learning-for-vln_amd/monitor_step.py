@@ -305,6 +305,10 @@ class FollowerStepFn(torch.autograd.Function):
         io.ws, io.ws_floats = ws.data_ptr(), ws.numel()
         io.seed, io.off, io.p_drop = seed, off, (p_drop if training else 0.0)
         io.offset_base_dev = cfg[5] if len(cfg) > 5 else None
+        sync = cfg[6] if len(cfg) > 6 else None
+        if sync is not None:
+            io.attn_sync, io.attn_sync_bytes = sync.data_ptr(), sync.numel() * 4
+            hold.append(sync)
         st = lib.vln_follower_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_follower_step_fwd")

@@ -551,8 +551,8 @@ class FollowerIteration(_GraphedIteration):
     batch: `tokens`, `lens32`, `steps` = per step `img` [B, 36, F], `cand` [B, C, F], `cmask`, `target`."""
 
     def __init__(self, dev, dtype, *, enc=None, dec=None, vocab=992, embed=300, hidden=256, feature_size=2176, drop=0.5, lr=1e-4,
-                 graph=True, rollout_wgrads=True, fused=True):
-        self.dev, self.dtype, self.rollout_wgrads = dev, dtype, rollout_wgrads
+                 graph=True, rollout_wgrads=True, fused=True, rollout_ce=True):
+        self.dev, self.dtype, self.rollout_wgrads, self.rollout_ce = dev, dtype, rollout_wgrads, rollout_ce
         self.enc = enc if enc is not None else EncoderLSTM(vocab, embed, hidden, 0, drop, True, 2, compute_dtype=dtype).to(dev).train()
         self.dec = dec if dec is not None else AttnDecoderLSTM(hidden, drop, feature_size, feature_size, compute_dtype=dtype).to(dev).train()
         self.dec.fused_step = fused
@@ -573,10 +573,16 @@ class FollowerIteration(_GraphedIteration):
         if self._a0 is None:
             self._a0, self._arange = torch.zeros(B, F, device=self.dev), torch.arange(B, device=self.dev)
         a_prev, loss = self._a0, 0.0                                             # follower.py:101: zeros
+        ce = losses.RolloutCE() if self.rollout_ce else None                     # every step's mean CE in ONE launch each way (round 6)
         for s in b["steps"]:
             logit, (h, c), _ = self.dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask)
-            loss = loss + losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
+            if ce is not None:
+                ce.add(logit, s["target"], s["cmask"])
+            else:
+                loss = loss + losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
             a_prev = s["cand"][self._arange, s["target"]].detach()              # follower.py:164
+        if ce is not None:
+            loss = ce.mean_per_step()
         loss.backward()
         self.opt_e.step(); self.opt_d.step()
         return loss

@@ -347,10 +347,15 @@ int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, int64_t igno
                             float* loss_sum /*[1]: total over steps and episodes*/,
                             float* loss_rows /*[B]: per episode (reduction="none" summed over the steps, what SELF-PACE weighs,
                                                curriculum.py:296); exactly one of the two*/,
-                            int accumulate, vln_stream_t s);
-/* dloss_stride 0: one upstream scalar; 1: one per episode */
+                            int accumulate,
+                            float* inv_counts /*nullable (ABI v19) [T]: the MEAN PER STEP (nn.CrossEntropyLoss(ignore_index)'s default reduction on
+                                                every step's batch, summed over the steps: follower.py:62,123-139) -- loss_sum = scale *
+                                                sum_t (sum_b CE_tb / n_t); inv_counts[t] = 1 / n_t is written for the backward; loss_sum only,
+                                                T * B <= 8192*/,
+                            vln_stream_t s);
+/* dloss_stride 0: one upstream scalar; 1: one per episode; inv_counts (nullable): what the forward of the mean per step left */
 int vln_masked_ce_multi_bwd(const vln_ce_step* steps, int T, int B, int64_t ignore_index, float scale, const float* dloss,
-                            int64_t dloss_stride, vln_stream_t s);
+                            int64_t dloss_stride, const float* inv_counts, vln_stream_t s);
 
 /* The Self-Monitor agent's step loss (monitor.py:146-165) in one launch each way, no host round trip: action CE on the masked
  * logits, the progress target from the distances (monitor.py:155-157: (start_dist - cur_dist) / start_dist, 1 where
@@ -488,6 +493,8 @@ typedef struct vln_follower_step {
   float* ws; int64_t ws_floats;
   uint64_t seed, off; float p_drop;                  /* dropout sites `off` (LSTM input row, policy.py:49) and `off + 1` (h_1, :54) */
   const uint64_t* offset_base_dev;                   /* nullable: offsets relative to a device word (see vln_embed_fwd) */
+  void* attn_sync; int64_t attn_sync_bytes;          /* nullable (ABI v19): vln_attn_sync_bytes(B) of zero-initialised scratch: the two attentions
+                                                      * of the step run on FOUR workgroups per episode (attention_split.h), forward and backward */
 } vln_follower_step;
 typedef struct vln_follower_grads {
   const float *dlogit, *dh1, *dc1, *dww_ext, *dvw_ext;                /* upstream gradients, each nullable */

@@ -127,6 +127,34 @@ def test_linear_wgrad(vln, Mt, N, K):
     check(o3b, 2 * ref, 5e-5, "o3b")
 
 
+def test_rollout_ce_mean_per_step_equals_the_per_step_criterion(vln):
+    """losses.RolloutCE.mean_per_step (round 6): sum_t CrossEntropyLoss(ignore_index)(masked logits_t, target_t) with the default mean
+    reduction on every step's batch (follower.py:62,123-139) in ONE launch each way == torch's criterion step by step, value and
+    d logits; steps differ in their candidate count and in their number of ignored rows."""
+    g = torch.Generator().manual_seed(77)
+    B, T = 64, 7
+    ce = vln.losses.RolloutCE(ignore_index=-100)
+    ref, lgs, rlgs = 0.0, [], []
+    for t in range(T):
+        C_ = 4 + 3 * t                                         # 4 .. 22: both row forms of the kernel
+        ncand = torch.randint(2, C_ + 1, (B,), generator=g)
+        mask = torch.arange(C_)[None, :] >= ncand[:, None]
+        tgt = (torch.rand(B, generator=g) * ncand.float()).long()
+        tgt[torch.rand(B, generator=g) < 0.1 * t] = -100       # ended episodes
+        lg = torch.randn(B, C_, generator=g)
+        r = lg.clone().double().requires_grad_(True)
+        ref = ref + torch.nn.functional.cross_entropy(r.masked_fill(mask, float("-inf")), tgt, ignore_index=-100)
+        x = lg.to(dev()).requires_grad_(True)
+        ce.add(x, tgt.to(dev()), mask.to(dev()))
+        lgs.append(x); rlgs.append(r)
+    loss = ce.mean_per_step(0.5)
+    (ref * 0.5).backward()
+    loss.backward()
+    check(loss, ref.detach() * 0.5, 1e-6, "loss")
+    for t in range(T):
+        check(lgs[t].grad, rlgs[t].grad, 1e-5, f"d logits step {t}")
+
+
 @pytest.mark.parametrize("split", [False, True, "bf16"])
 def test_wgrad_grouped(vln, split):
     """All weight gradients of a module from one call (one launch in the bf16 forms): the decoder's seven
