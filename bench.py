@@ -558,7 +558,8 @@ def main():
                          ("speaker_follower_B64", lambda: secondary_agents(dev, args, "follower", store, dtype="bf16")),
                          ("speaker_follower_B64_fp32", lambda: secondary_agents(dev, args, "follower", store, dtype="fp32")),
                          ("speaker_teacher_forcing_B64", lambda: secondary_agents(dev, args, "speaker", store, dtype="bf16")),
-                         ("speaker_teacher_forcing_B64_fp32", lambda: secondary_agents(dev, args, "speaker", store, dtype="fp32"))):
+                         ("speaker_teacher_forcing_B64_fp32", lambda: secondary_agents(dev, args, "speaker", store, dtype="fp32")),
+                         ("speaker_teacher_forcing_B64_eager_launches", lambda: secondary_agents(dev, args, "speaker", store, dtype="bf16", graph=False))):
             t1 = time.perf_counter()
             try:
                 secondary[name] = fn()
@@ -782,13 +783,13 @@ def _phase_times(ag, get, steps, n_dec_steps):
                                         "decoder_bwd per step includes 1/T of the rollout loss, the logit branch and the decoder's weight gradients"}
 
 
-def secondary_agents(dev, args, which, store, dtype=None, read_actions=True):
+def secondary_agents(dev, args, which, store, dtype=None, read_actions=True, graph=True):
     """The other BASELINE workloads (scripts/bench_agents.py builds their synthetic batches; the iterations are vln_amd.trainers')."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import bench_agents as W
     # warm-up: the first iterations of a workload in a process grow the allocator's pools and load its kernels' code objects;
     # with 8 of them the Self-Monitor number read 5.7 ms against 5.05 ms for a second run in the same process
-    W.configure(steps=20, warmup=30, dtype=dtype or args.dtype, arena=False, device=dev)
+    W.configure(steps=20, warmup=30, dtype=dtype or args.dtype, arena=False, device=dev, graph=graph)
     W.args.roofline = bool(which == "a2c" and read_actions == "handshake")     # the cfg3 entry carries its own roofline block
     import gc
     gc.collect()

@@ -338,24 +338,44 @@ struct CandSample {
   uint64_t seed, offset; const unsigned long long* offset_base_dev;
   int B, C, D, vec_ok;
 };
+// 16 waves per workgroup (round 6): up to 16 candidate rows in flight at once, the query summed from its split-K slabs ONCE into
+// LDS (every row's dot re-read the slabs: C x nsplit loads of the same values on the step's dependent chain).  Same per-lane
+// accumulation order as the four-wave form: identical logits.
+constexpr int kCandWaves = 16;
+constexpr int kCandQMax = 4096;             // query columns the LDS copy holds (wider: the slabs are read in place)
 template <typename TC>
-__global__ __launch_bounds__(256) void cand_sample_kernel(CandSample a) {
+__global__ __launch_bounds__(kCandWaves * 64) void cand_sample_kernel(CandSample a) {
   constexpr int V = Elt<TC>::kVec;
   __shared__ float sdot[64];
+  __shared__ __attribute__((aligned(16))) float sq[kCandQMax];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C, D = a.D;
   const TC* base = reinterpret_cast<const TC*>(a.cand) + (long)b * C * D;
-  for (int c = wave; c < C; c += 4) {
+  const bool staged = a.vec_ok && D <= kCandQMax;
+  // the rows' first loads go out before the query is staged
+  float x0[V];
+  const bool own = wave < C && a.vec_ok && lane * V < D;
+  if (own) Elt<TC>::ld16(base + (long)wave * D + lane * V, x0);
+  if (staged) {
+    for (int d = threadIdx.x * 4; d < D; d += kCandWaves * 64 * 4) *reinterpret_cast<float4*>(&sq[d]) = a.q.at4(b, d);
+    __syncthreads();
+  }
+  for (int c = wave; c < C; c += kCandWaves) {
     const TC* row = base + (long)c * D;
     float acc = 0.f;
     if (a.vec_ok) {
       for (int d = lane * V; d < D; d += 64 * V) {
         float x[V];
-        Elt<TC>::ld16(row + d, x);
+        if (c == wave && d == lane * V) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) x[j] = x0[j];
+        } else {
+          Elt<TC>::ld16(row + d, x);
+        }
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
-          const float4 t = a.q.at4(b, d + j);
+          const float4 t = staged ? *reinterpret_cast<const float4*>(&sq[d + j]) : a.q.at4(b, d + j);
           acc += dot4(&x[j], t);
         }
       }
@@ -416,8 +436,8 @@ int cand_logits_sample(hipStream_t st, const void* cand, int ctype, SlabVec q, f
                reinterpret_cast<const unsigned long long*>(offset_base_dev), B, C, D,
                (aligned16(cand) && aligned16(q.p) && (D % V == 0) && (q.ld % 4 == 0) && (q.stride % 4 == 0)) ? 1 : 0};
   const double bytes = (double)B * C * D * (ctype == W_BF16 ? 2 : 4) + 4.0 * B * D + 12.0 * B * C;
-  if (ctype == W_BF16) launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<bf16_raw>, dim3(B), dim3(256), 0, st, a);
-  else launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<float>, dim3(B), dim3(256), 0, st, a);
+  if (ctype == W_BF16) launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<bf16_raw>, dim3(B), dim3(kCandWaves * 64), 0, st, a);
+  else launch_timed(K_ATTN_DOT, bytes, cand_sample_kernel<float>, dim3(B), dim3(kCandWaves * 64), 0, st, a);
   VLN_CHECK_LAUNCH("cand_logits_sample");
   return VLN_OK;
 }
