@@ -604,6 +604,13 @@ def test_counter_backward_on_a_dirty_or_foreign_sync_workspace(vln):
     w[32] = 0
     enc._sync_buf, enc._sync_mode = w, None
     same("dirty header", run())
+    # (a') round 6: the SAME address with a header the caller has written to -- what torch's allocator produces when it hands a freed
+    # buffer's address to a new one (seen once in the full suite: the library remembered the address as clean, skipped the fill and the
+    # BPTT ran on garbage counters).  The module announces a buffer it has not used before with vln_lstm_sync_ws_forget.
+    w[:2048] = 0x01010101
+    w[32] = 0
+    enc._sync_mode = None
+    same("the same address, dirtied by the caller", run())
     # (b) mode 2 (counter forward + counter backward): a forward WITHOUT its backward leaves counters behind, then mode 1
     try:
         lib.vln_set_persistent(2)
