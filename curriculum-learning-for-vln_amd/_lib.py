@@ -55,6 +55,14 @@ class CeStep(C.Structure):           # vln_ce_step
 CE_MAX_STEPS = 40                     # VLN_CE_MAX_STEPS
 
 
+class MonitorLossStep(C.Structure):  # vln_monitor_loss_step
+    _fields_ = [("logits", ptr), ("ld", i64), ("target", ptr), ("cand_mask", ptr), ("probs", ptr), ("progress", ptr), ("ldp", i64),
+                ("start_dist", ptr), ("cur_dist", ptr), ("ended", ptr), ("prog_target", ptr), ("dlogits", ptr), ("dprogress", ptr), ("C", i32)]
+
+
+MONITOR_LOSS_MAX_STEPS = 16           # VLN_MONITOR_LOSS_MAX_STEPS
+
+
 class EnvDropWeights(C.Structure):
     _fields_ = [(n, ptr) for n in ("act_w", "act_b", "w_vin", "w_vin_t", "w_cat", "w_cat_t", "b_ih", "b_hh",
                                    "w_tin", "w_tin_t", "w_tout", "w_tout_t", "w_c", "w_c_t")] + [("f32_mask", i32), ("pad_", i32)]
@@ -191,6 +199,7 @@ class BnMlpGrads(C.Structure):
 STRUCT_MIRRORS = {
     "vln_tick_item": TickItem, "vln_wgrad_job": WgradJob, "vln_colsum_job": ColsumJob, "vln_param_jobs": ParamJobs,
     "vln_shadow_job": ShadowJob, "vln_wsum_step": WsumStep, "vln_dot_step": DotStep, "vln_ce_step": CeStep, "vln_cat_step": CatStep,
+    "vln_monitor_loss_step": MonitorLossStep,
     "vln_monitor_dims": MonitorDims, "vln_monitor_weights": MonitorWeights, "vln_monitor_step": MonitorStep, "vln_monitor_grads": MonitorGrads,
     "vln_follower_dims": FollowerDims, "vln_follower_weights": FollowerWeights, "vln_follower_step": FollowerStep,
     "vln_follower_grads": FollowerGrads, "vln_bn_affine": BnAffine, "vln_bn_mlp_layer": BnMlpLayer, "vln_bn_mlp": BnMlp,
@@ -257,6 +266,8 @@ SIGNATURES = {
     "vln_add_n": (i32, [ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i32, ptr]),
     "vln_monitor_loss_fwd": (i32, [ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, i32, f32, i32, ptr, ptr, ptr, ptr, i32, i32, i64, ptr]),
     "vln_monitor_loss_bwd": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, f32, i32, ptr, ptr, i32, i32, i64, ptr]),
+    "vln_monitor_loss_multi_fwd": (i32, [C.POINTER(MonitorLossStep), i32, i32, i32, f32, i64, ptr, ptr, i32, ptr]),
+    "vln_monitor_loss_multi_bwd": (i32, [C.POINTER(MonitorLossStep), i32, i32, i32, f32, i64, ptr, ptr, ptr]),
     "vln_categorical_fwd": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, u64, u64, ptr, ptr]),
     "vln_categorical_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
     "vln_categorical_multi_bwd": (i32, [C.POINTER(CatStep), i32, i32, ptr, ptr, ptr]),

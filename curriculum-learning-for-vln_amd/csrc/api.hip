@@ -130,6 +130,7 @@ extern "C" int64_t vln_struct_size(const char* name) {
   VLN_SZ(vln_wsum_step);
   VLN_SZ(vln_dot_step);
   VLN_SZ(vln_ce_step);
+  VLN_SZ(vln_monitor_loss_step);
   VLN_SZ(vln_cat_step);
   VLN_SZ(vln_monitor_dims);
   VLN_SZ(vln_monitor_weights);

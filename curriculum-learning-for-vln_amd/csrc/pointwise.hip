@@ -419,6 +419,77 @@ __global__ __launch_bounds__(256) void monitor_loss_bwd_kernel(MonLossBwdArgs m)
   }
 }
 
+// The Self-Monitor loss of a WHOLE ROLLOUT, sum_t cur_loss_t (monitor.py:146-165,196), in one launch each way (round 6): nothing on
+// the rollout's dependent chain reads a step's loss, so the T launches (and the T of the backward, and the T - 1 additions of the
+// running total) only lengthened the stream.  One workgroup; thread per (step, episode) row, same per-row arithmetic as
+// monitor_loss_fwd_kernel; the row terms go through LDS and thread t sums step t in episode order.
+constexpr int kMonMultiMaxT = 16;
+constexpr int kMonMultiRowsMax = 4096;
+struct MonMultiArgs {
+  float* logits[kMonMultiMaxT]; const long long* target[kMonMultiMaxT]; const unsigned char* mask[kMonMultiMaxT]; float* probs[kMonMultiMaxT];
+  const float* progress[kMonMultiMaxT]; const float* start_dist[kMonMultiMaxT]; const float* cur_dist[kMonMultiMaxT];
+  const unsigned char* ended[kMonMultiMaxT]; float* prog_target[kMonMultiMaxT]; float* dlogits[kMonMultiMaxT]; float* dprogress[kMonMultiMaxT];
+  int C[kMonMultiMaxT], ld[kMonMultiMaxT], ldp[kMonMultiMaxT];
+  int T, B, t0; long ignore_index; float lam;
+  float* out; float* stats;               // [1] (+= when accumulate), [T][2] = {mean progress MSE, rows with a target} per step
+  int accumulate;
+  const float* dloss;                     // backward: [1]
+};
+__global__ __launch_bounds__(256) void monitor_loss_multi_fwd_kernel(MonMultiArgs m) {
+  __shared__ float rce[kMonMultiRowsMax], rsq[kMonMultiRowsMax];
+  __shared__ float steploss[kMonMultiMaxT];
+  const int rows = m.T * m.B;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int t = r / m.B, b = r - t * m.B;
+    CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t], m.ignore_index, 0};
+    rce[r] = (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+    const float p = m.progress[t][(long)b * m.ldp[t]];
+    const float sd = m.start_dist[t][b], cd = m.cur_dist[t][b];
+    float pt = (sd - cd) / sd;
+    if (cd <= 3.0f) pt = 1.0f;
+    if (m.ended[t][b]) pt = p;
+    m.prog_target[t][b] = pt;
+    rsq[r] = (p - pt) * (p - pt);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m.T) {
+    const int t = threadIdx.x;
+    float ce = 0.f, sq = 0.f, n = 0.f;
+    for (int b = 0; b < m.B; ++b) {
+      ce += rce[t * m.B + b]; sq += rsq[t * m.B + b];
+      n += (m.target[t][b] != m.ignore_index) ? 1.f : 0.f;
+    }
+    const float mse = sq / (float)m.B, cem = ce / n;          // (no row with a target: 0 / 0 = nan, as torch)
+    m.stats[2 * t] = mse; m.stats[2 * t + 1] = n;
+    steploss[t] = (m.t0 + t == 0) ? cem : m.lam * mse + (1.f - m.lam) * cem;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int t = 0; t < m.T; ++t) v += steploss[t];
+    m.out[0] = m.accumulate ? m.out[0] + v : v;
+  }
+}
+__global__ __launch_bounds__(256) void monitor_loss_multi_bwd_kernel(MonMultiArgs m) {
+  const int t = blockIdx.x;
+  const int C = m.C[t];
+  const long total = (long)m.B * C;
+  const bool first = (m.t0 + t == 0);
+  const float up = m.dloss[0];
+  const float wce = (first ? 1.f : 1.f - m.lam) / m.stats[2 * t + 1];
+  const float wsq = (first ? 0.f : m.lam * 2.f) / (float)m.B;
+  for (long e = threadIdx.x; e < total + m.B; e += 256) {
+    if (e < total) {
+      const int b = (int)(e / C), c = (int)(e % C);
+      const long tg = m.target[t][b];
+      m.dlogits[t][e] = (tg == m.ignore_index) ? 0.f : up * wce * (m.probs[t][e] - (c == tg ? 1.f : 0.f));
+    } else {
+      const int b = (int)(e - total);
+      m.dprogress[t][b] = up * wsq * (m.progress[t][(long)b * m.ldp[t]] - m.prog_target[t][b]);
+    }
+  }
+}
+
 // The IL loss of a whole rollout, ml_loss = sum_t CE_t (envdrop.py:178-179), in ONE launch after the last decoder step
 // instead of one per step: nothing on the rollout's dependent chain needs the loss, so the T small launches (and the T
 // backward ones) only lengthen it.  One workgroup; thread per (step, episode) row; rows of <= 16 candidates in registers.
@@ -1625,6 +1696,45 @@ extern "C" int vln_monitor_loss_bwd(const float* probs, const int64_t* target, c
   if (blocks > 1024) blocks = 1024;
   VLN_LAUNCH(vln::monitor_loss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, m);
   VLN_CHECK_LAUNCH("monitor_loss_bwd");
+  return VLN_OK;
+}
+
+static int mon_multi_fill(vln::MonMultiArgs& m, const vln_monitor_loss_step* steps, int T, int B, int t0, float lam, int64_t ignore_index,
+                          float* stats, bool bwd, const char* who) {
+  if (!steps || T <= 0 || T > VLN_MONITOR_LOSS_MAX_STEPS || B <= 0 || (long)T * B > vln::kMonMultiRowsMax || t0 < 0 || !stats) { vln::set_error(who); return VLN_ERR_ARG; }
+  m.T = T; m.B = B; m.t0 = t0; m.lam = lam; m.ignore_index = (long)ignore_index; m.stats = stats;
+  for (int t = 0; t < T; ++t) {
+    const vln_monitor_loss_step& q = steps[t];
+    if (!q.logits || !q.target || !q.probs || !q.progress || !q.start_dist || !q.cur_dist || !q.ended || !q.prog_target || q.C <= 0 || q.ld < q.C ||
+        (bwd && (!q.dlogits || !q.dprogress))) { vln::set_error(who); return VLN_ERR_ARG; }
+    m.logits[t] = q.logits; m.target[t] = (const long long*)q.target; m.mask[t] = q.cand_mask; m.probs[t] = q.probs;
+    m.progress[t] = q.progress; m.start_dist[t] = q.start_dist; m.cur_dist[t] = q.cur_dist; m.ended[t] = q.ended;
+    m.prog_target[t] = q.prog_target; m.dlogits[t] = q.dlogits; m.dprogress[t] = q.dprogress;
+    m.C[t] = q.C; m.ld[t] = (int)q.ld; m.ldp[t] = (int)q.ldp;
+  }
+  return VLN_OK;
+}
+extern "C" int vln_monitor_loss_multi_fwd(const vln_monitor_loss_step* steps, int T, int B, int t0, float lam, int64_t ignore_index, float* out,
+                                          float* stats, int accumulate, void* s) {
+  static_assert(VLN_MONITOR_LOSS_MAX_STEPS == vln::kMonMultiMaxT, "header / kernel step capacity");
+  vln::MonMultiArgs m{};
+  if (!out) { vln::set_error("vln_monitor_loss_multi_fwd: bad args"); return VLN_ERR_ARG; }
+  const int rc = mon_multi_fill(m, steps, T, B, t0, lam, ignore_index, stats, false, "vln_monitor_loss_multi_fwd: bad args");
+  if (rc) return rc;
+  m.out = out; m.accumulate = accumulate;
+  VLN_LAUNCH(vln::monitor_loss_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("monitor_loss_multi_fwd");
+  return VLN_OK;
+}
+extern "C" int vln_monitor_loss_multi_bwd(const vln_monitor_loss_step* steps, int T, int B, int t0, float lam, int64_t ignore_index,
+                                          const float* stats, const float* dloss, void* s) {
+  vln::MonMultiArgs m{};
+  if (!dloss) { vln::set_error("vln_monitor_loss_multi_bwd: bad args"); return VLN_ERR_ARG; }
+  const int rc = mon_multi_fill(m, steps, T, B, t0, lam, ignore_index, const_cast<float*>(stats), true, "vln_monitor_loss_multi_bwd: bad args");
+  if (rc) return rc;
+  m.dloss = dloss;
+  VLN_LAUNCH(vln::monitor_loss_multi_bwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("monitor_loss_multi_bwd");
   return VLN_OK;
 }
 

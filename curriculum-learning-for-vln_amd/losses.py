@@ -199,6 +199,100 @@ def monitor_mixed_loss(logits: torch.Tensor, target: torch.Tensor, cand_mask: Op
     return loss, stats[0]
 
 
+class _RolloutMonitorLoss(torch.autograd.Function):
+    """sum_t monitor_mixed_loss(step t) in one launch each way (vln_monitor_loss_multi_fwd / _bwd); inputs: logits_0 .. logits_{T-1},
+    progress_0 .. progress_{T-1}."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        targets, masks, starts, curs, endeds, lam, ignore_index = meta
+        T = len(targets)
+        logits, progs = tensors[:T], tensors[T:]
+        B = logits[0].shape[0]
+        dev = logits[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        out = ops.empty((), **f32)
+        stats = ops.empty(T, 2, **f32)
+        keep, steps = [], []
+        for lg, pr, tg, mk, sd, cd, en in zip(logits, progs, targets, masks, starts, curs, endeds):
+            lg = lg.detach()
+            if not lg.is_contiguous():
+                lg = lg.contiguous()
+            pr = pr.detach().reshape(B)
+            if not pr.is_contiguous():
+                pr = pr.contiguous()
+            C_ = lg.shape[1]
+            probs, pt = ops.empty(B, C_, **f32), ops.empty(B, **f32)
+            tg = tg if tg.is_contiguous() else tg.contiguous()
+            m8, e8 = _mask8(mk), _mask8(en)
+            keep.append((lg, pr, tg, m8, sd, cd, e8, probs, pt))
+            steps.append(_lib.MonitorLossStep(lg.data_ptr(), lg.stride(0), tg.data_ptr(), _p(m8), probs.data_ptr(), pr.data_ptr(), 1,
+                                              sd.data_ptr(), cd.data_ptr(), e8.data_ptr(), pt.data_ptr(), None, None, C_))
+        n = _lib.MONITOR_LOSS_MAX_STEPS
+        for i in range(0, T, n):
+            chunk = steps[i:i + n]
+            arr = (_lib.MonitorLossStep * len(chunk))(*chunk)
+            st = lib.vln_monitor_loss_multi_fwd(arr, len(chunk), B, i, lam, ignore_index, out.data_ptr(), stats.data_ptr() + 8 * i, 1 if i else 0,
+                                                _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_monitor_loss_multi_fwd")
+        ctx.keep, ctx.stats, ctx.cfg = keep, stats, (lam, ignore_index, [p.shape for p in progs])
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        keep, stats = ctx.keep, ctx.stats
+        lam, ignore_index, pshapes = ctx.cfg
+        T, B = len(keep), keep[0][0].shape[0]
+        lib = _lib.load()
+        dloss = dloss.contiguous()
+        steps, dls, dps = [], [], []
+        for lg, pr, tg, m8, sd, cd, e8, probs, pt in keep:
+            dl, dp = ops.empty_like(probs), ops.empty(B, dtype=torch.float32, device=probs.device)
+            dls.append(dl); dps.append(dp)
+            steps.append(_lib.MonitorLossStep(lg.data_ptr(), lg.stride(0), tg.data_ptr(), _p(m8), probs.data_ptr(), pr.data_ptr(), 1,
+                                              sd.data_ptr(), cd.data_ptr(), e8.data_ptr(), pt.data_ptr(), dl.data_ptr(), dp.data_ptr(), probs.shape[1]))
+        n = _lib.MONITOR_LOSS_MAX_STEPS
+        for i in range(0, T, n):
+            chunk = steps[i:i + n]
+            arr = (_lib.MonitorLossStep * len(chunk))(*chunk)
+            st = lib.vln_monitor_loss_multi_bwd(arr, len(chunk), B, i, lam, ignore_index, stats.data_ptr() + 8 * i, dloss.data_ptr(), _lib.raw_stream())
+            if st:
+                _lib.check(st, "vln_monitor_loss_multi_bwd")
+        ctx.keep = None
+        return (None, *dls, *[dp.view(sh) for dp, sh in zip(dps, pshapes)])
+
+
+class RolloutMonitorLoss:
+    """The Self-Monitor agent's loss of a whole rollout, `sum_t cur_loss_t` (monitor.py:146-165,196: CE at t = 0, then lam * MSE(progress)
+    + (1 - lam) * CE, both with their default mean reductions), evaluated ONCE after the last decoder step: `add(...)` per step only
+    records the operands (in step order, from t = 0), `sum()` is one launch forward and one backward for all steps.  Same numbers as
+    summing `monitor_mixed_loss` over the steps.  `progress_mse` (after `sum()`): the [T] mean progress MSEs the agent logs."""
+
+    def __init__(self, lam: float, ignore_index: int = -1):
+        self.lam, self.ignore_index = float(lam), ignore_index
+        self.rows = []
+        self.progress_mse = None
+
+    def add(self, logits, target, cand_mask, progress, start_dist, cur_dist, ended):
+        if logits.dim() != 2 or (self.rows and logits.shape[0] != self.rows[0][0].shape[0]):
+            raise ValueError("RolloutMonitorLoss.add: logits must be [B, C] with the same B every step")
+        _not_deferred(logits, "RolloutMonitorLoss.add")
+        self.rows.append((logits, progress, target, cand_mask, start_dist, cur_dist, ended))
+
+    def sum(self) -> torch.Tensor:
+        if not self.rows:
+            raise ValueError("RolloutMonitorLoss.sum: no steps recorded")
+        cols = list(zip(*self.rows))
+        out, stats = _RolloutMonitorLoss.apply((tuple(cols[2]), tuple(cols[3]), tuple(cols[4]), tuple(cols[5]), tuple(cols[6]), self.lam, self.ignore_index),
+                                               *cols[0], *cols[1])
+        self.progress_mse = stats[:, 0]
+        self.rows = []
+        return out
+
+
 class _RolloutCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *logits):

@@ -505,8 +505,8 @@ class SelfMonitorIteration(_GraphedIteration):
     `a_prev0`: the first step's previous-action rows (default: the reference's zeros, monitor.py:108)."""
 
     def __init__(self, dev, dtype, *, enc=None, dec=None, opt=None, vocab=992, embed=256, hidden=512, max_len=80, mlp=(1024,),
-                 feature_size=2176, drop=0.5, lr=1e-4, lam=0.5, graph=True, rollout_wgrads=True, a_prev0=None):
-        self.dev, self.dtype, self.lam, self.rollout_wgrads = dev, dtype, lam, rollout_wgrads
+                 feature_size=2176, drop=0.5, lr=1e-4, lam=0.5, graph=True, rollout_wgrads=True, a_prev0=None, rollout_loss=True):
+        self.dev, self.dtype, self.lam, self.rollout_wgrads, self.rollout_loss = dev, dtype, lam, rollout_wgrads, rollout_loss
         # MLP_HIDDEN (1024,): configs/monitor/selfmonitor_config.yaml:45
         self.enc = enc if enc is not None else EncoderLSTM(vocab, embed, hidden, 0, drop, False, 1, compute_dtype=dtype).to(dev).train()
         self.dec = dec if dec is not None else MonitorDecoder(hidden, drop, max_len, tuple(mlp), feature_size, feature_size, compute_dtype=dtype).to(dev).train()
@@ -527,12 +527,18 @@ class SelfMonitorIteration(_GraphedIteration):
             self.a_prev0 = torch.zeros(B, self.dec.feature_size if hasattr(self.dec, "feature_size") else b["steps"][0]["cand"].shape[-1], device=self.dev)
         a_prev, loss = self.a_prev0, 0.0
         rows = self._rows(B)
+        rl = losses.RolloutMonitorLoss(self.lam) if self.rollout_loss else None      # every step's loss in ONE launch each way (round 6)
         for t, s in enumerate(b["steps"]):
             (logit, prog), (h, c), _ = self.dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
-            # monitor.py:146-165 in one launch each way (CE + progress target + MSE + the lambda mix)
-            loss_t, _ = losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, self.lam)
-            loss = loss + loss_t
+            if rl is not None:
+                rl.add(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"])
+            else:
+                # monitor.py:146-165 in one launch each way (CE + progress target + MSE + the lambda mix)
+                loss_t, _ = losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, self.lam)
+                loss = loss + loss_t
             a_prev = s["cand"][rows, s["target"]].detach()                      # monitor.py:191
+        if rl is not None:
+            loss = rl.sum()
         loss.backward()
         self.opt.step()
         return loss

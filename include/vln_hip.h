@@ -371,6 +371,20 @@ int vln_monitor_loss_bwd(const float* probs, const int64_t* target, const float*
                          const float* stats, const float* dloss, int64_t dloss_stride /*0: one scalar, 1: per episode*/, int t,
                          float lam, int per_sample, float* dlogits /*[B,C]*/, float* dprogress /*[B]*/, int B, int C,
                          int64_t ignore_index, vln_stream_t s);
+/* ABI v19: the same loss for a WHOLE ROLLOUT, sum over the steps t0 .. t0 + T - 1 of cur_loss_t (the non-curriculum means), in one
+ * launch each way: out [1] (+= when accumulate), stats [T][2] = per step {mean progress MSE, rows with a target} (read again by the
+ * backward); T <= VLN_MONITOR_LOSS_MAX_STEPS per call (t0 = the first step's index: only step 0 is the plain CE), T * B <= 4096. */
+#define VLN_MONITOR_LOSS_MAX_STEPS 16
+typedef struct vln_monitor_loss_step {
+  float* logits; int64_t ld; const int64_t* target; const uint8_t* cand_mask /*nullable*/; float* probs /*[B,C] out*/;
+  const float* progress; int64_t ldp; const float* start_dist; const float* cur_dist; const uint8_t* ended;
+  float* prog_target /*[B] out*/; float* dlogits /*[B,C] bwd*/; float* dprogress /*[B] bwd*/;
+  int C;
+} vln_monitor_loss_step;
+int vln_monitor_loss_multi_fwd(const vln_monitor_loss_step* steps, int T, int B, int t0, float lam, int64_t ignore_index, float* out,
+                               float* stats, int accumulate, vln_stream_t s);
+int vln_monitor_loss_multi_bwd(const vln_monitor_loss_step* steps, int T, int B, int t0, float lam, int64_t ignore_index,
+                               const float* stats, const float* dloss /*[1]*/, vln_stream_t s);
 
 /* The sampled-action branch of a rollout step (envdrop.py:186-195) as one launch: probs = softmax(logits masked with
  * -inf where cand_mask), action ~ Categorical(probs) unless action_in is given (then action_out may be NULL), logp =

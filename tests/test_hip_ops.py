@@ -127,6 +127,41 @@ def test_linear_wgrad(vln, Mt, N, K):
     check(o3b, 2 * ref, 5e-5, "o3b")
 
 
+def test_rollout_monitor_loss_equals_the_sum_of_the_step_losses(vln):
+    """losses.RolloutMonitorLoss (round 6): the Self-Monitor agent's loss of a whole rollout in ONE launch each way == the sum of
+    `monitor_mixed_loss` over the steps (itself held to the reference's sequence by test_fused_monitor_step_loss_*): value, d logits,
+    d progress, the logged progress MSEs; the steps differ in candidate count, ignored rows and ended episodes."""
+    g = torch.Generator().manual_seed(78)
+    B, T, lam = 128, 7, 0.5
+    rl = vln.losses.RolloutMonitorLoss(lam, ignore_index=-100)
+    ref, xs, ps, rxs, rps, mses = 0.0, [], [], [], [], []
+    for t in range(T):
+        C_ = 5 + 2 * t                                          # 5 .. 17: both row forms of the kernel
+        ncand = torch.randint(2, C_ + 1, (B,), generator=g)
+        mask = (torch.arange(C_)[None, :] >= ncand[:, None]).to(dev())
+        tgt = (torch.rand(B, generator=g) * ncand.float()).long()
+        tgt[torch.rand(B, generator=g) < 0.08 * t] = -100
+        tgt = tgt.to(dev())
+        start = (torch.rand(B, generator=g) * 15 + 4).to(dev()); cur = (torch.rand(B, generator=g) * 10 + 0.2).to(dev())
+        ended = (torch.rand(B, generator=g) < 0.1 * t).to(dev())
+        lg, pr = torch.randn(B, C_, generator=g), torch.rand(B, 1, generator=g)
+        x, p = lg.to(dev()).requires_grad_(True), pr.to(dev()).requires_grad_(True)
+        rx, rp = lg.to(dev()).requires_grad_(True), pr.to(dev()).requires_grad_(True)
+        l_t, mse_t = vln.losses.monitor_mixed_loss(rx, tgt, mask, rp, start, cur, ended, t, lam, ignore_index=-100)
+        ref = ref + l_t
+        mses.append(mse_t)
+        rl.add(x, tgt, mask, p, start, cur, ended)
+        xs.append(x); ps.append(p); rxs.append(rx); rps.append(rp)
+    loss = rl.sum()
+    ref.backward()
+    loss.backward()
+    check(loss, ref.detach(), 1e-6, "loss")
+    check(rl.progress_mse[1:], torch.stack(mses)[1:], 1e-6, "progress MSE per step")
+    for t in range(T):
+        check(xs[t].grad, rxs[t].grad, 1e-6, f"d logits step {t}")
+        check(ps[t].grad, rps[t].grad, 1e-6, f"d progress step {t}", floor=1e-12)
+
+
 def test_rollout_ce_mean_per_step_equals_the_per_step_criterion(vln):
     """losses.RolloutCE.mean_per_step (round 6): sum_t CrossEntropyLoss(ignore_index)(masked logits_t, target_t) with the default mean
     reduction on every step's batch (follower.py:62,123-139) in ONE launch each way == torch's criterion step by step, value and
