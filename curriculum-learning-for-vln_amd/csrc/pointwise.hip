@@ -435,11 +435,11 @@ struct MonMultiArgs {
   int accumulate;
   const float* dloss;                     // backward: [1]
 };
-__global__ __launch_bounds__(256) void monitor_loss_multi_fwd_kernel(MonMultiArgs m) {
+__global__ __launch_bounds__(1024) void monitor_loss_multi_fwd_kernel(MonMultiArgs m) {
   __shared__ float rce[kMonMultiRowsMax], rsq[kMonMultiRowsMax];
   __shared__ float steploss[kMonMultiMaxT];
   const int rows = m.T * m.B;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {       // (1024 threads: a row each at B 128 / T 7 -- 25 us with 256, the rows in turn)
     const int t = r / m.B, b = r - t * m.B;
     CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t], m.ignore_index, 0};
     rce[r] = (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
@@ -504,11 +504,11 @@ struct CeMultiArgs {
 // follower.py:62,123-139): loss = scale * sum_t (sum_b CE_tb / n_t), n_t = step t's rows with a target; inv_counts[t] = 1 / n_t is left
 // for the backward.  One workgroup; the row losses go through LDS, thread t sums step t's rows in episode order (fixed order).
 constexpr int kCeMeanRowsMax = 8192;
-__global__ __launch_bounds__(256) void masked_ce_multi_mean_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale, float* inv_counts) {
+__global__ __launch_bounds__(1024) void masked_ce_multi_mean_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale, float* inv_counts) {
   __shared__ float rowloss[kCeMeanRowsMax];
   __shared__ float stepmean[VLN_CE_MAX_STEPS];
   const int rows = m.T * m.B;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {
     const int t = r / m.B, b = r - t * m.B;
     CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
              m.ignore_index, 0};
@@ -1722,7 +1722,7 @@ extern "C" int vln_monitor_loss_multi_fwd(const vln_monitor_loss_step* steps, in
   const int rc = mon_multi_fill(m, steps, T, B, t0, lam, ignore_index, stats, false, "vln_monitor_loss_multi_fwd: bad args");
   if (rc) return rc;
   m.out = out; m.accumulate = accumulate;
-  VLN_LAUNCH(vln::monitor_loss_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m);
+  VLN_LAUNCH(vln::monitor_loss_multi_fwd_kernel, dim3(1), dim3((long)T * B > 512 ? 1024 : ((long)T * B > 256 ? 512 : 256)), 0, (hipStream_t)s, m);
   VLN_CHECK_LAUNCH("monitor_loss_multi_fwd");
   return VLN_OK;
 }
@@ -1757,7 +1757,8 @@ extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, i
   if (rc) return rc;
   if (inv_counts) {
     if (!loss_sum || (long)T * B > vln::kCeMeanRowsMax) { vln::set_error("vln_masked_ce_multi_fwd: the mean per step needs loss_sum and T * B <= %d", vln::kCeMeanRowsMax); return VLN_ERR_ARG; }
-    VLN_LAUNCH(vln::masked_ce_multi_mean_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale, inv_counts);
+    VLN_LAUNCH(vln::masked_ce_multi_mean_fwd_kernel, dim3(1), dim3((long)T * B > 512 ? 1024 : ((long)T * B > 256 ? 512 : 256)), 0, (hipStream_t)s, m,
+               loss_sum, accumulate, scale, inv_counts);
   } else
   if (loss_sum)
     VLN_LAUNCH(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
