@@ -437,7 +437,8 @@ struct MonMultiArgs {
 };
 __global__ __launch_bounds__(1024) void monitor_loss_multi_fwd_kernel(MonMultiArgs m) {
   __shared__ float rce[kMonMultiRowsMax], rsq[kMonMultiRowsMax];
-  __shared__ float steploss[kMonMultiMaxT];
+  __shared__ unsigned char rhas[kMonMultiRowsMax];        // the row has a target (the per-step sums below read LDS only: a global load
+  __shared__ float steploss[kMonMultiMaxT];               // per row in that serial loop cost 25 us at T 7 x B 128)
   const int rows = m.T * m.B;
   for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {       // (1024 threads: a row each at B 128 / T 7 -- 25 us with 256, the rows in turn)
     const int t = r / m.B, b = r - t * m.B;
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(1024) void monitor_loss_multi_fwd_kernel(MonMultiAr
     if (m.ended[t][b]) pt = p;
     m.prog_target[t][b] = pt;
     rsq[r] = (p - pt) * (p - pt);
+    rhas[r] = (m.target[t][b] != m.ignore_index) ? 1 : 0;
   }
   __syncthreads();
   if ((int)threadIdx.x < m.T) {
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(1024) void monitor_loss_multi_fwd_kernel(MonMultiAr
     float ce = 0.f, sq = 0.f, n = 0.f;
     for (int b = 0; b < m.B; ++b) {
       ce += rce[t * m.B + b]; sq += rsq[t * m.B + b];
-      n += (m.target[t][b] != m.ignore_index) ? 1.f : 0.f;
+      n += rhas[t * m.B + b] ? 1.f : 0.f;
     }
     const float mse = sq / (float)m.B, cem = ce / n;          // (no row with a target: 0 / 0 = nan, as torch)
     m.stats[2 * t] = mse; m.stats[2 * t + 1] = n;
@@ -506,6 +508,7 @@ struct CeMultiArgs {
 constexpr int kCeMeanRowsMax = 8192;
 __global__ __launch_bounds__(1024) void masked_ce_multi_mean_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale, float* inv_counts) {
   __shared__ float rowloss[kCeMeanRowsMax];
+  __shared__ unsigned char rowhas[kCeMeanRowsMax];        // the row has a target (the serial sums below read LDS only)
   __shared__ float stepmean[VLN_CE_MAX_STEPS];
   const int rows = m.T * m.B;
   for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(1024) void masked_ce_multi_mean_fwd_kernel(CeMultiA
     CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
              m.ignore_index, 0};
     rowloss[r] = (a.C <= 16) ? ce_row_regs(a, b) : ce_row_serial(a, b);
+    rowhas[r] = (m.target[t][b] != m.ignore_index) ? 1 : 0;
   }
   __syncthreads();
   if ((int)threadIdx.x < m.T) {
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(1024) void masked_ce_multi_mean_fwd_kernel(CeMultiA
     float acc = 0.f, n = 0.f;
     for (int b = 0; b < m.B; ++b) {
       acc += rowloss[t * m.B + b];
-      if (m.target[t][b] != m.ignore_index) n += 1.f;
+      if (rowhas[t * m.B + b]) n += 1.f;
     }
     stepmean[t] = acc / n;                       // (no row with a target: 0 / 0 = nan, as torch)
     inv_counts[t] = 1.f / n;
@@ -533,11 +537,13 @@ __global__ __launch_bounds__(1024) void masked_ce_multi_mean_fwd_kernel(CeMultiA
     loss_sum[0] = accumulate ? loss_sum[0] + v : v;
   }
 }
-__global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale) {
-  __shared__ float part[4];
+// (256 or 512 threads -- blockDim.x: at the headline's 7 x 64 rows every thread of 512 takes ONE row, its loads are not queued
+// behind another row's; the total is summed in a fixed order either way: rows strided by the block per thread, waves, wave pairs)
+__global__ __launch_bounds__(512) void masked_ce_multi_fwd_kernel(CeMultiArgs m, float* loss_sum, int accumulate, float scale) {
+  __shared__ float part[8];
   float acc = 0.f;
   const int rows = m.T * m.B;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {
     const int t = r / m.B, b = r - t * m.B;
     CeArgs a{m.logits[t], (long)m.ld[t], m.target[t], m.mask[t], nullptr, m.probs[t], nullptr, nullptr, nullptr, m.B, m.C[t],
              m.ignore_index, 0};
@@ -547,7 +553,9 @@ __global__ __launch_bounds__(256) void masked_ce_multi_fwd_kernel(CeMultiArgs m,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float v = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+    float v = (part[0] + part[1]) + (part[2] + part[3]);
+    if (blockDim.x > 256) v += (part[4] + part[5]) + (part[6] + part[7]);
+    v *= scale;
     loss_sum[0] = accumulate ? loss_sum[0] + v : v;
   }
 }
@@ -1761,7 +1769,7 @@ extern "C" int vln_masked_ce_multi_fwd(const vln_ce_step* steps, int T, int B, i
                loss_sum, accumulate, scale, inv_counts);
   } else
   if (loss_sum)
-    VLN_LAUNCH(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
+    VLN_LAUNCH(vln::masked_ce_multi_fwd_kernel, dim3(1), dim3((long)T * B > 256 ? 512 : 256), 0, (hipStream_t)s, m, loss_sum, accumulate, scale);
   else
     VLN_LAUNCH(vln::masked_ce_multi_rows_kernel, dim3((B + 63) / 64), dim3(256), 0, (hipStream_t)s, m, loss_rows, accumulate,
                        scale);
