@@ -28,6 +28,10 @@ class DotStep(C.Structure):          # vln_dot_step
     _fields_ = [("ctx", ptr), ("vec", ptr), ("dots", ptr), ("S", i32)]
 
 
+class SelectStep(C.Structure):       # vln_select_step
+    _fields_ = [("src", ptr), ("index", ptr), ("out", ptr), ("C", i32)]
+
+
 class WsumStep(C.Structure):         # vln_wsum_step
     _fields_ = [("ctx", ptr), ("w", ptr), ("out", ptr), ("S", i32), ("probs", ptr), ("target", ptr)]
 
@@ -198,7 +202,7 @@ class BnMlpGrads(C.Structure):
 # C struct name -> ctypes mirror: load() compares sizeof on both sides (vln_struct_size)
 STRUCT_MIRRORS = {
     "vln_tick_item": TickItem, "vln_wgrad_job": WgradJob, "vln_colsum_job": ColsumJob, "vln_param_jobs": ParamJobs,
-    "vln_shadow_job": ShadowJob, "vln_wsum_step": WsumStep, "vln_dot_step": DotStep, "vln_ce_step": CeStep, "vln_cat_step": CatStep,
+    "vln_shadow_job": ShadowJob, "vln_wsum_step": WsumStep, "vln_dot_step": DotStep, "vln_ce_step": CeStep, "vln_cat_step": CatStep, "vln_select_step": SelectStep,
     "vln_monitor_loss_step": MonitorLossStep,
     "vln_monitor_dims": MonitorDims, "vln_monitor_weights": MonitorWeights, "vln_monitor_step": MonitorStep, "vln_monitor_grads": MonitorGrads,
     "vln_follower_dims": FollowerDims, "vln_follower_weights": FollowerWeights, "vln_follower_step": FollowerStep,
@@ -238,6 +242,7 @@ SIGNATURES = {
     "vln_attn_softmax_wsum": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_dot_multi": (i32, [C.POINTER(DotStep), i32, i32, i32, i32, i64, ptr]),
     "vln_rows_wsum_multi": (i32, [C.POINTER(WsumStep), i32, i32, i32, i32, i64, f32, ptr, i64, ptr]),
+    "vln_select_rows_multi": (i32, [C.POINTER(SelectStep), i32, i32, i32, ptr]),
     "vln_rows_wsum": (i32, [ptr, i32, ptr, ptr, i64, i32, i32, i32, ptr]),
     "vln_attn_bwd": (i32, [ptr, i32, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, ptr]),
     "vln_attn_fwd_rows": (i32, [ptr, i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i32, i32, i32, ptr, i64, ptr]),

@@ -130,6 +130,7 @@ extern "C" int64_t vln_struct_size(const char* name) {
   VLN_SZ(vln_wsum_step);
   VLN_SZ(vln_dot_step);
   VLN_SZ(vln_ce_step);
+  VLN_SZ(vln_select_step);
   VLN_SZ(vln_monitor_loss_step);
   VLN_SZ(vln_cat_step);
   VLN_SZ(vln_monitor_dims);
@@ -248,6 +249,36 @@ extern "C" int vln_rows_wsum(const void* ctx, int ctype, const float* w, float* 
 }
 extern "C" int vln_attn_dot_multi(const vln_dot_step* steps, int T, int ctype, int B, int D, int64_t ldv, vln_stream_t s) {
   return attn_dot_multi((hipStream_t)s, steps, T, ctype, B, D, (long)ldv);
+}
+namespace vln {
+struct SelectMulti { const float* src[VLN_CE_MAX_STEPS]; const long long* index[VLN_CE_MAX_STEPS]; float* out[VLN_CE_MAX_STEPS]; int C[VLN_CE_MAX_STEPS]; int T, B, F; unsigned* bad; };
+__global__ __launch_bounds__(256) void select_rows_multi_kernel(SelectMulti m) {
+  const int t = (int)blockIdx.x / m.B, b = (int)blockIdx.x % m.B;
+  long i = m.index[t][b];
+  if (i < 0) i += m.C[t];
+  const bool ok = i >= 0 && i < m.C[t];
+  if (!ok && threadIdx.x == 0 && m.bad) __hip_atomic_fetch_add(m.bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float4* src = reinterpret_cast<const float4*>(m.src[t] + ((long)b * m.C[t] + (ok ? i : 0)) * m.F);
+  float4* dst = reinterpret_cast<float4*>(m.out[t] + (long)b * m.F);
+  for (int c = threadIdx.x; c < m.F / 4; c += 256) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace vln
+extern "C" int vln_select_rows_multi(const vln_select_step* steps, int T, int B, int F, vln_stream_t s) {
+  if (!steps || T <= 0 || T > VLN_CE_MAX_STEPS || B <= 0 || F <= 0 || (F & 3)) { set_error("vln_select_rows_multi: bad dims (F %% 4 == 0, T <= %d)", VLN_CE_MAX_STEPS); return VLN_ERR_ARG; }
+  SelectMulti m{};
+  m.T = T; m.B = B; m.F = F;
+  unsigned* w = sticky_dev_word();
+  m.bad = w ? w + 1 : nullptr;
+  for (int t = 0; t < T; ++t) {
+    if (!steps[t].src || !steps[t].index || !steps[t].out || steps[t].C <= 0 || ((uintptr_t)steps[t].src & 15) || ((uintptr_t)steps[t].out & 15)) {
+      set_error("vln_select_rows_multi: bad step %d", t);
+      return VLN_ERR_ARG;
+    }
+    m.src[t] = steps[t].src; m.index[t] = (const long long*)steps[t].index; m.out[t] = steps[t].out; m.C[t] = steps[t].C;
+  }
+  VLN_LAUNCH(select_rows_multi_kernel, dim3(T * B), dim3(256), 0, (hipStream_t)s, m);
+  VLN_CHECK_LAUNCH("select_rows_multi");
+  return VLN_OK;
 }
 extern "C" int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, float ce_scale,
                                    const float* ce_dloss, int64_t ignore_index, vln_stream_t s) {

@@ -650,8 +650,8 @@ extern "C" int vln_persistent_check(void) {
     if (__atomic_load_n(&h[d * 16 + 1], __ATOMIC_RELAXED)) {
       const unsigned n = __atomic_exchange_n(&h[d * 16 + 1], 0u, __ATOMIC_RELAXED);
       set_error("%u feature-gather index(es) were out of range of the registered table on device %d in an EARLIER launch "
-                "(viewpoint row, view index or candidate view): those rows were gathered as zeros; that iteration's numbers "
-                "are invalid", n, d);
+                "(viewpoint row, view index or candidate view; or a row index of vln_select_rows_multi): those rows were gathered "
+                "as zeros; that iteration's numbers are invalid", n, d);
       return VLN_ERR_ARG;
     }
     if (__atomic_load_n(&h[d * 16 + 2], __ATOMIC_RELAXED)) {

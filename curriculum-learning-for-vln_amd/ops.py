@@ -569,6 +569,29 @@ class WgradBatch:
         self.jobs, self.keep, self.Mt = [], [], None
 
 
+def select_rows_multi(srcs, indices):
+    """[src_t[arange(B), index_t] for t] in ONE launch (`vln_select_rows_multi`): the previous-action rows of a teacher-forced rollout
+    (`a_t_prev = a_t_cand[arange, a_t]`, monitor.py:191 / follower.py:164) -- every step's row is known when the rollout starts.
+    srcs: [B, C_t, F] fp32 contiguous; indices: [B] int64.  Returns views of one [T, B, F] buffer (no gradient)."""
+    lib = _lib.load()
+    T = len(srcs)
+    B, _, F = srcs[0].shape
+    out = empty(T, B, F, dtype=torch.float32, device=srcs[0].device)
+    res = []
+    for i in range(0, T, _lib.CE_MAX_STEPS):
+        steps = []
+        for t in range(i, min(T, i + _lib.CE_MAX_STEPS)):
+            x, ix = srcs[t].detach(), indices[t]
+            _req(x, "src")
+            assert x.is_contiguous() and x.shape[0] == B and x.shape[2] == F and ix.dtype == torch.int64 and ix.is_contiguous()
+            steps.append(_lib.SelectStep(x.data_ptr(), ix.data_ptr(), out[t].data_ptr(), x.shape[1]))
+        arr = (_lib.SelectStep * len(steps))(*steps)
+        _lib.check(lib.vln_select_rows_multi(arr, len(steps), B, F, _stream()), "vln_select_rows_multi")
+    for t in range(T):
+        res.append(out[t])
+    return res
+
+
 def attn_dot(ctx, vec):
     """dots[b,s] = ctx[b,s,:] . vec[b,:]"""
     lib = _lib.load()

@@ -528,6 +528,8 @@ class SelfMonitorIteration(_GraphedIteration):
         a_prev, loss = self.a_prev0, 0.0
         rows = self._rows(B)
         rl = losses.RolloutMonitorLoss(self.lam) if self.rollout_loss else None      # every step's loss in ONE launch each way (round 6)
+        # teacher forcing: every step's previous-action row is a function of the batch -- one launch up front instead of one per step
+        nxt = ops.select_rows_multi([s["cand"] for s in b["steps"][:-1]], [s["target"] for s in b["steps"][:-1]]) if (self.rollout_loss and len(b["steps"]) > 1) else None
         for t, s in enumerate(b["steps"]):
             (logit, prog), (h, c), _ = self.dec(None, a_prev, s["cand"], h, c, ctx, seq_mask, s["cmask"])
             if rl is not None:
@@ -536,7 +538,10 @@ class SelfMonitorIteration(_GraphedIteration):
                 # monitor.py:146-165 in one launch each way (CE + progress target + MSE + the lambda mix)
                 loss_t, _ = losses.monitor_mixed_loss(logit, s["target"], s["cmask"], prog, s["start"], s["cur"], s["ended"], t, self.lam)
                 loss = loss + loss_t
-            a_prev = s["cand"][rows, s["target"]].detach()                      # monitor.py:191
+            if nxt is None:
+                a_prev = s["cand"][rows, s["target"]].detach()                  # monitor.py:191
+            elif t < len(nxt):
+                a_prev = nxt[t]
         if rl is not None:
             loss = rl.sum()
         loss.backward()
@@ -580,13 +585,18 @@ class FollowerIteration(_GraphedIteration):
             self._a0, self._arange = torch.zeros(B, F, device=self.dev), torch.arange(B, device=self.dev)
         a_prev, loss = self._a0, 0.0                                             # follower.py:101: zeros
         ce = losses.RolloutCE() if self.rollout_ce else None                     # every step's mean CE in ONE launch each way (round 6)
-        for s in b["steps"]:
+        # ... and every step's previous-action row (a function of the batch under teacher forcing) in one launch up front
+        nxt = ops.select_rows_multi([s["cand"] for s in b["steps"][:-1]], [s["target"] for s in b["steps"][:-1]]) if (self.rollout_ce and len(b["steps"]) > 1) else None
+        for t, s in enumerate(b["steps"]):
             logit, (h, c), _ = self.dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask)
             if ce is not None:
                 ce.add(logit, s["target"], s["cmask"])
             else:
                 loss = loss + losses.masked_cross_entropy(logit, s["target"], s["cmask"], "mean")
-            a_prev = s["cand"][self._arange, s["target"]].detach()              # follower.py:164
+            if nxt is None:
+                a_prev = s["cand"][self._arange, s["target"]].detach()          # follower.py:164
+            elif t < len(nxt):
+                a_prev = nxt[t]
         if ce is not None:
             loss = ce.mean_per_step()
         loss.backward()

@@ -228,6 +228,14 @@ typedef struct vln_wsum_step {
 int vln_rows_wsum_multi(const vln_wsum_step* steps, int T, int ctype, int B, int D, int64_t ldo, float ce_scale,
                         const float* ce_dloss, int64_t ignore_index, vln_stream_t s);
 
+/* ABI v19: out_t[b,:] = src_t[b, index_t[b], :] for T steps in ONE launch -- the previous-action rows of a TEACHER-FORCED rollout
+ * (a_t_prev = a_t_cand[arange, a_t], monitor.py:191 / follower.py:164: with teacher forcing a_t is the batch's target, every step's
+ * row is known when the rollout starts; the loop issued one indexing launch per step on its dependent chain).  src_t [B, C_t, F]
+ * contiguous fp32, index_t [B] int64 (a negative index counts from the end, as torch's; an index outside [-C_t, C_t) yields a zero
+ * row and raises sticky word 1 of vln_persistent_check), out_t [B, F] dense; F % 4 == 0, T <= VLN_CE_MAX_STEPS. */
+typedef struct vln_select_step { const float* src; const int64_t* index; float* out; int C; } vln_select_step;
+int vln_select_rows_multi(const vln_select_step* steps, int T, int B, int F, vln_stream_t s);
+
 /* dots_t[b,s] = ctx_t[b,s,:] . vec_t[b,:] for T steps in one launch (ctx_t [B,S_t,D] contiguous, vec_t rows of leading
  * dimension ldv, dots_t [B,S_t] dense): the candidate logits of a whole teacher-forced rollout (policy.py:199-206), whose
  * queries W_c drop(h_tilde_t) come from ONE GEMM over (steps x batch) rows -- see vln_envdrop_step.defer_logits. */

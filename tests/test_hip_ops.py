@@ -127,6 +127,28 @@ def test_linear_wgrad(vln, Mt, N, K):
     check(o3b, 2 * ref, 5e-5, "o3b")
 
 
+def test_select_rows_multi_equals_torch_indexing(vln):
+    """ops.select_rows_multi (round 6): [src_t[arange(B), index_t]] for all steps in one launch == torch's advanced indexing, negative
+    indices counting from the end; an index out of range gives a zero row and raises the library's sticky gather word."""
+    g = torch.Generator().manual_seed(79)
+    B, F = 37, 2176
+    srcs = [torch.randn(B, C_, F, generator=g).to(dev()) for C_ in (3, 8, 16, 1)]
+    idx = [torch.randint(-C_, C_, (B,), generator=g).to(dev()) for C_ in (3, 8, 16, 1)]
+    outs = vln.ops.select_rows_multi(srcs, idx)
+    ar = torch.arange(B, device=dev())
+    for t, (x, i, o) in enumerate(zip(srcs, idx, outs)):
+        assert torch.equal(o, x[ar, i]), f"step {t}"
+    lib = vln._lib.load()
+    vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+    bad = idx[1].clone(); bad[5] = 8
+    o = vln.ops.select_rows_multi([srcs[1]], [bad])[0]
+    torch.cuda.synchronize()
+    assert float(o[5].abs().max()) == 0.0 and torch.equal(o[4], srcs[1][4, bad[4]])
+    with pytest.raises(vln._lib.VlnError):
+        vln._lib.check(lib.vln_persistent_check(), "vln_persistent_check")
+    lib.vln_persistent_check()                              # (reading the sticky words clears them)
+
+
 def test_rollout_monitor_loss_equals_the_sum_of_the_step_losses(vln):
     """losses.RolloutMonitorLoss (round 6): the Self-Monitor agent's loss of a whole rollout in ONE launch each way == the sum of
     `monitor_mixed_loss` over the steps (itself held to the reference's sequence by test_fused_monitor_step_loss_*): value, d logits,
