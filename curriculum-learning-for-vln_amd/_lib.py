@@ -160,7 +160,7 @@ class FollowerStep(C.Structure):
                                     "tq", "keys", "vlog", "xcat", "act", "tanh_c1", "tq2", "tcat", "grounded", "target", "q", "context",
                                     "gates", "dots", "ws")]
                 + [("ws_floats", i64), ("seed", u64), ("off", u64), ("p_drop", f32), ("offset_base_dev", ptr), ("attn_sync", ptr),
-                   ("attn_sync_bytes", i64)])
+                   ("attn_sync_bytes", i64), ("context_ready", i32)])
 
 
 class FollowerGrads(C.Structure):

@@ -91,7 +91,8 @@ extern "C" int vln_follower_step_fwd(const vln_follower_dims* d, const vln_follo
   RUN(gemm_nt(st, io->tcat, 2 * H, w->w_tout, wt, 2 * H, io->grounded, H, B, H, 2 * H, nullptr, ACT_TANH, io->ws, io->ws_floats, nullptr));
   // (4) candidate scores: logit = context . (target (.) w_out) + b_out
   RUN(gemm_nt(st, io->grounded, H, w->w_hid, wt, H, io->target, D, B, D, H, w->b_hid, ACT_NONE, io->ws, io->ws_floats, nullptr));
-  RUN(gemm_nt(st, io->cands, A, w->w_act, wt, A, io->context, D, B * C, D, A, w->b_act, ACT_NONE, io->ws, io->ws_floats, nullptr));
+  if (!io->context_ready)     // (formed for the whole rollout up front by the caller when it is teacher-forced: vln_follower_step.context_ready)
+    RUN(gemm_nt(st, io->cands, A, w->w_act, wt, A, io->context, D, B * C, D, A, w->b_act, ACT_NONE, io->ws, io->ws_floats, nullptr));
   // q = target (.) w_out and the + b_out inside the dot launch (they were a launch each); q written back for the backward
   RUN(attn_dot_sv(st, io->context, W_F32, plain_vec(io->target, D), io->logit, B, C, D, io->q, D, w->w_out, w->b_out));
   return VLN_OK;

@@ -136,7 +136,20 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
             w = self._attn_sync = (torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev), B)
         return w[0]
 
-    def forward(self, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx, ctx_mask=None):
+    def project_candidates(self, cands_all):
+        """ActionScoring's candidate projection `linear_act(a_t_cands)` (units.py:175) for SEVERAL steps in one product: cands_all
+        [T, B, C, A] contiguous (the steps' candidate tensors as slices of one buffer) -> [T] matrices [B * C, D] to hand to
+        `forward(..., cand_context=...)`.  The projection depends on the batch only, so a teacher-forced rollout (the candidates of
+        every step are known when it starts) forms it once, off the steps' dependent chain; its weight gradient is formed by the
+        steps' backward as before (it never needed the projection's own backward).  No autograd through the returned matrices."""
+        T, B, C_, A = cands_all.shape
+        ds = self.decode_action
+        with torch.no_grad():
+            w = Fh.SHADOWS.get(ds.linear_act.weight, "n", self.compute_dtype)
+            y = ops.linear_fwd(cands_all.view(T * B * C_, A), w, ds.linear_act.bias.detach())
+        return list(y.view(T, B * C_, -1).unbind(0))
+
+    def forward(self, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx, ctx_mask=None, cand_context=None):
         _need_gpu(img_feature, "AttnDecoderLSTM")
         site = self._next()
         p, tr, seed = self.drop_ratio, self.training, self.dropout_seed
@@ -157,8 +170,12 @@ class AttnDecoderLSTM(nn.Module, _Seeded):
                                    (ds.linear_act.weight, "n", dt_), (ds.linear_hid.weight, "n", dt_), (ds.linear_hid.weight, "t", dt_)],
                                   [(self.lstm.weight_ih, self.lstm.weight_hh, dt_, False), (self.lstm.weight_ih, self.lstm.weight_hh, dt_, True)])
             cfg = (tr, self.compute_dtype, p, seed, site) + ((self._drop_base(),) if self._drop_base() is not None else ())
-            if self.c_step and self.split_attention:      # the exchange buffer of the four-workgroups-per-episode attentions (round 6)
-                cfg = cfg[:5] + (self._drop_base(), self._attn_sync_buf(img_feature.device, img_feature.shape[0]))
+            if self.c_step and (self.split_attention or cand_context is not None):
+                # the exchange buffer of the four-workgroups-per-episode attentions; the candidates' projection formed up front (round 6)
+                cfg = cfg[:5] + (self._drop_base(), self._attn_sync_buf(img_feature.device, img_feature.shape[0]) if self.split_attention else None,
+                                 cand_context)
+            elif cand_context is not None:
+                raise _lib.VlnError("AttnDecoderLSTM: cand_context needs the C-call step (c_step=True)")
             logit, h_new, c_new, word_w, view_w = core.apply(
                 cfg, ctx_mask, img_feature, a_t_prev, a_t_cands, h_0, c_0, ctx,
                 va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias,

@@ -309,6 +309,12 @@ class FollowerStepFn(torch.autograd.Function):
         if sync is not None:
             io.attn_sync, io.attn_sync_bytes = sync.data_ptr(), sync.numel() * 4
             hold.append(sync)
+        pre = cfg[7] if len(cfg) > 7 else None           # W_act cands + b_act formed up front (AttnDecoderLSTM.project_candidates)
+        if pre is not None:
+            if tuple(pre.shape) != (B * Cn, D) or not pre.is_contiguous() or pre.dtype != f32:
+                raise _lib.VlnError(f"FollowerStepFn: the projected candidates must be a contiguous fp32 [{B * Cn}, {D}] matrix")
+            io.context, io.context_ready = pre.data_ptr(), 1
+            hold.append(pre)
         st = lib.vln_follower_step_fwd(C.byref(d), C.byref(w), C.byref(io), _lib.raw_stream())
         if st:
             _lib.check(st, "vln_follower_step_fwd")

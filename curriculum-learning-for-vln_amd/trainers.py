@@ -564,6 +564,7 @@ class FollowerIteration(_GraphedIteration):
     def __init__(self, dev, dtype, *, enc=None, dec=None, vocab=992, embed=300, hidden=256, feature_size=2176, drop=0.5, lr=1e-4,
                  graph=True, rollout_wgrads=True, fused=True, rollout_ce=True):
         self.dev, self.dtype, self.rollout_wgrads, self.rollout_ce = dev, dtype, rollout_wgrads, rollout_ce
+        self.hoist_batch_only_work = rollout_ce        # previous-action rows and candidate projections of all steps up front (teacher forcing)
         self.enc = enc if enc is not None else EncoderLSTM(vocab, embed, hidden, 0, drop, True, 2, compute_dtype=dtype).to(dev).train()
         self.dec = dec if dec is not None else AttnDecoderLSTM(hidden, drop, feature_size, feature_size, compute_dtype=dtype).to(dev).train()
         self.dec.fused_step = fused
@@ -572,6 +573,20 @@ class FollowerIteration(_GraphedIteration):
         if self._make_clock(dev, graph and fused and getattr(self.dec, "c_step", True), self.enc, self.dec) is not None:
             self.opt_e.use_clock(self.clock); self.opt_d.use_clock(self.clock)
         self._a0 = None
+
+    def load(self, batch):
+        """As _GraphedIteration.load; the steps' candidate tensors become slices of ONE [T, B, C, F] buffer (`cand_all`) when they
+        share a shape, so that one product can project them all (AttnDecoderLSTM.project_candidates)."""
+        first = self.live is None
+        live = super().load(batch)
+        if first:
+            cs = [s["cand"] for s in live["steps"]]
+            if all(c.shape == cs[0].shape and c.dtype == torch.float32 for c in cs):
+                allc = torch.stack(cs, 0).contiguous()
+                for t, s in enumerate(live["steps"]):
+                    s["cand"] = allc[t]
+                live["cand_all"] = allc
+        return live
 
     def _iteration(self):
         b = self.live
@@ -586,9 +601,12 @@ class FollowerIteration(_GraphedIteration):
         a_prev, loss = self._a0, 0.0                                             # follower.py:101: zeros
         ce = losses.RolloutCE() if self.rollout_ce else None                     # every step's mean CE in ONE launch each way (round 6)
         # ... and every step's previous-action row (a function of the batch under teacher forcing) in one launch up front
-        nxt = ops.select_rows_multi([s["cand"] for s in b["steps"][:-1]], [s["target"] for s in b["steps"][:-1]]) if (self.rollout_ce and len(b["steps"]) > 1) else None
+        nxt = ops.select_rows_multi([s["cand"] for s in b["steps"][:-1]], [s["target"] for s in b["steps"][:-1]]) if (self.hoist_batch_only_work and len(b["steps"]) > 1) else None
+        # ... and the candidates' projection of ALL steps in one product (it depends on the batch only; `load` keeps the steps' candidate
+        # tensors as slices of one buffer)
+        pre = self.dec.project_candidates(b["cand_all"]) if (self.hoist_batch_only_work and "cand_all" in b and getattr(self.dec, "c_step", False) and self.dec.fused_step) else None
         for t, s in enumerate(b["steps"]):
-            logit, (h, c), _ = self.dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask)
+            logit, (h, c), _ = self.dec(s["img"], a_prev, s["cand"], h, c, ctx, seq_mask, cand_context=None if pre is None else pre[t])
             if ce is not None:
                 ce.add(logit, s["target"], s["cmask"])
             else:

@@ -517,6 +517,8 @@ typedef struct vln_follower_step {
   const uint64_t* offset_base_dev;                   /* nullable: offsets relative to a device word (see vln_embed_fwd) */
   void* attn_sync; int64_t attn_sync_bytes;          /* nullable (ABI v19): vln_attn_sync_bytes(B) of zero-initialised scratch: the two attentions
                                                       * of the step run on FOUR workgroups per episode (attention_split.h), forward and backward */
+  int context_ready;                                 /* 1 (ABI v19): `context` = W_act cands + b_act was formed by the caller -- for all steps of a
+                                                      * teacher-forced rollout at once (it depends on the batch only) -- and is only read here */
 } vln_follower_step;
 typedef struct vln_follower_grads {
   const float *dlogit, *dh1, *dc1, *dww_ext, *dvw_ext;                /* upstream gradients, each nullable */

@@ -736,3 +736,46 @@ def test_monitor_merged_projections_equal_two_bn_mlp_calls(vln, cdt):
                 assert torch.equal(got[3][n], ref[3][n]), n
             elif ref[3][n].is_floating_point():
                 check(got[3][n], ref[3][n], 2e-5, f"variant {k} buffer {n}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_follower_iteration_with_batch_only_work_hoisted_equals_the_per_step_form(vln, dtype):
+    """Round 6 (trainers.FollowerIteration): under teacher forcing the previous-action rows and the candidates' projection
+    `linear_act(a_t_cands)` of every step depend on the batch only; one launch each up front (`ops.select_rows_multi`,
+    `AttnDecoderLSTM.project_candidates` + `vln_follower_step.context_ready`) and the rollout's mean CE as one launch each way
+    (`RolloutCE.mean_per_step`) give the losses and gradients of the per-step form (another K split in the projection, another
+    summation order in the loss: 2e-5 of each tensor's range)."""
+    from parity import check
+    dev_ = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, L, T, C, F = 16, 12, 4, 6, 96
+    tokens = torch.randint(4, 60, (B, L), generator=g)
+    lens = torch.sort(torch.randint(4, L + 1, (B,), generator=g), descending=True).values; lens[0] = L
+    for i, n in enumerate(lens.tolist()):
+        tokens[i, n:] = 0
+    steps = []
+    for t in range(T):
+        ncand = torch.randint(2, C + 1, (B,), generator=g)
+        cmask = torch.arange(C)[None, :] >= ncand[:, None]
+        steps.append(dict(img=(torch.randn(B, 36, F, generator=g).abs() * 0.5).to(dev_), cmask=cmask.to(dev_),
+                          cand=(torch.randn(B, C, F, generator=g).abs() * 0.5 * (~cmask)[..., None]).to(dev_),
+                          target=(torch.rand(B, generator=g) * ncand.float()).long().to(dev_)))
+    batch = dict(tokens=tokens.to(dev_), lens32=lens.to(dev_, torch.int32), steps=steps)
+    res = []
+    for hoist in (False, True):
+        torch.manual_seed(3)
+        it = vln.trainers.FollowerIteration(dev_, dtype, vocab=60, embed=32, hidden=64, feature_size=F, lr=1e-3, graph=False, rollout_ce=hoist)
+        it.enc.deterministic_embedding_grad = True
+        it.opt_e.lr = it.opt_d.lr = 0.0          # keep the weights: Adam's g / sqrt(v) turns last-bit gradient noise into +-lr steps
+        it.load(batch)
+        assert ("cand_all" in it.live) and it.hoist_batch_only_work == hoist
+        losses_ = [it.iteration().detach().clone() for _ in range(3)]        # (three different dropout draws)
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses_), it.opt_e.flat_g.clone(), it.opt_d.flat_g.clone()))
+    # bf16 mode forms its weight gradients from operands rounded to bf16: a 1e-7 change of an activation flips roundings of 2^-9,
+    # i.e. 1e-4 .. 1e-3 of a gradient tensor's range between two equally valid runs (the mode's bound against the oracle is 1e-2)
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+    check(res[1][0], res[0][0], 2e-5, "losses of three iterations")
+    check(res[1][1], res[0][1], tol, "encoder gradients of the third iteration")
+    check(res[1][2], res[0][2], tol, "decoder gradients of the third iteration")
