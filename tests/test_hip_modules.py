@@ -5,6 +5,8 @@
       Philox masks the kernels used.
 Tolerances (north_star): fp32 1e-4, bf16 1e-2 for outputs AND gradients (max-abs error relative to the tensor's
 max, tests/parity.py); the achieved errors are printed at the end of the run."""
+import os
+
 import pytest
 import torch
 
@@ -631,7 +633,8 @@ def test_fp32_weight_gradients_split_planes_against_the_exact_fp32_mfma(vln):
     from parity import check
     dev_ = torch.device(DEV)
     tape = vln.synthetic.tape_to(vln.synthetic.make_tape(16, 24, 3, 6, seed=4), dev_)
-    assert vln.ops.get_wgrad_precision_fp32() == "split"
+    default = "exact" if os.environ.get("VLN_WGRAD_FP32") == "exact" else "split"       # (the process-wide override keeps rounds 1-5's form)
+    assert vln.ops.get_wgrad_precision_fp32() == default
     res = {}
     try:
         for mode in ("split", "exact"):
@@ -645,7 +648,7 @@ def test_fp32_weight_gradients_split_planes_against_the_exact_fp32_mfma(vln):
             torch.cuda.synchronize()
             res[mode] = (loss.detach().clone(), {n: p.grad.detach().clone() for m in (ag.enc, ag.dec) for n, p in m.named_parameters()})
     finally:
-        vln.ops.set_wgrad_precision_fp32("split")
+        vln.ops.set_wgrad_precision_fp32(default)
     assert torch.equal(res["split"][0], res["exact"][0])          # the forward does not depend on it
     differ = 0
     for n, g in res["exact"][1].items():
